@@ -1,0 +1,81 @@
+"""CPU: the numpy restatement of the Kirchhoff integral (oracle/kirchhoff_np.py)
+against golden vectors produced by the imported reference
+(oracle/gen_fixtures_p2.py -> tests/golden/g4_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import kirchhoff_np as kn
+
+CASES = ['g4_slit_2000x32', 'g4_slit_4000x48', 'g4_toroid_3000x24']
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _inputs(g):
+    good = g['s_state'] == 1
+    n = [g['n'][i][good] for i in range(3)]
+    return (g['px'], g['py'], g['pz'], g['s_x'][good], g['s_y'][good],
+            g['s_z'][good], n, g['nl'][good], g['s_E'][good], g['s_Es'][good],
+            g['s_Ep'][good])
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_raw_integrals_match_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    raw = kn.kirchhoff_conv(*_inputs(g))
+    for mine, ref in zip(raw, g['raw']):
+        scale = np.abs(ref).max()
+        # same expressions, same order: only the row chunking differs
+        assert np.abs(mine - ref).max() <= 1e-13 * scale
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_post_processing_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    npix = len(g['px'])
+    acc = {k: np.zeros(npix, dtype=complex)
+           for k in ('EsAcc', 'EpAcc', 'aEacc', 'bEacc', 'cEacc')}
+    res = kn.diffract_post(
+        acc, list(g['raw']), str(g['kind']) == 'oe', float(g['w_dS']),
+        float(g['s_area']), float(g['w_beamReflSumJ']),
+        float(g['w_beamReflSumJnl']), int(g['w_beamReflRays']),
+        int(g['w_diffract_repeats']))
+    if str(g['kind']) == 'oe':
+        # for an OE the reference then rotates the coherency matrix / amplitudes
+        # into the global frame (OE.local_to_global, waves.py:763-771 and
+        # 783-786): only the rotation invariants stay comparable here; the full
+        # chain is checked against xrt_amd's own diffract (tests/test_gpu_*).
+        ref = g['w_Jss'] + g['w_Jpp']
+        assert np.allclose(res['Jss'] + res['Jpp'], ref, rtol=1e-12,
+                           atol=1e-12 * ref.max())
+        ref = np.abs(g['w_Es'])**2 + np.abs(g['w_Ep'])**2
+        mine = np.abs(res['Es'])**2 + np.abs(res['Ep'])**2
+        assert np.allclose(mine, ref, rtol=1e-12, atol=1e-12 * ref.max())
+        return
+    for key in ('Jss', 'Jpp'):
+        ref = g['w_' + key]
+        assert np.allclose(res[key], ref, rtol=1e-12, atol=1e-12 * ref.max())
+    for key in ('Es', 'Ep', 'Jsp'):
+        ref = g['w_' + key]
+        assert np.abs(res[key] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300)
+
+
+def test_cl_convention_mapping_cancels_in_post(golden_dir):
+    """the OpenCL sign/(1+i) convention changes Es, Ep by a global
+    pi phase but not Jss, Jpp, a, b, c."""
+    g = _load(golden_dir, 'g4_slit_2000x32')
+    npix = len(g['px'])
+    args = (False, float(g['w_dS']), float(g['s_area']),
+            float(g['w_beamReflSumJ']), float(g['w_beamReflSumJnl']),
+            int(g['w_beamReflRays']), 1)
+    zero = lambda: {k: np.zeros(npix, dtype=complex)  # noqa: E731
+                    for k in ('EsAcc', 'EpAcc', 'aEacc', 'bEacc', 'cEacc')}
+    r0 = kn.diffract_post(zero(), list(g['raw']), *args)
+    r1 = kn.diffract_post(zero(), list(kn.to_cl_convention(*g['raw'])), *args)
+    for key in ('Jss', 'Jpp', 'a', 'b', 'c'):
+        assert np.allclose(r0[key], r1[key], rtol=1e-10, atol=1e-12 * np.abs(r0[key]).max())
+    assert np.allclose(r0['Es'], -r1['Es'], rtol=1e-12)

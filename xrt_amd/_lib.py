@@ -1,0 +1,94 @@
+"""ctypes binding of libxrt_hip.so (C ABI in include/xrt_hip.h).
+
+There is NO CPU fallback: if the HIP library cannot be loaded, or a call fails,
+an exception is raised. (The numpy restatements under ``oracle/`` are test
+infrastructure and are never imported from this package.)
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libxrt_hip.so')
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_size_p = ctypes.POINTER(ctypes.c_size_t)
+vp = ctypes.c_void_p
+i64 = ctypes.c_int64
+
+# name -> (restype, argtypes); mirrors include/xrt_hip.h one to one
+SIGNATURES = {
+    'xrt_hip_version': (ctypes.c_int, []),
+    'xrt_hip_device_count': (ctypes.c_int, []),
+    'xrt_hip_last_error': (ctypes.c_char_p, []),
+    'xrt_hip_kirchhoff_plan': (ctypes.c_int, [
+        i64, i64, ctypes.c_int, ctypes.c_int, c_size_p, c_int_p, c_int_p]),
+    'xrt_hip_kirchhoff_f64_dev': (ctypes.c_int, [
+        i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+        ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_int,
+        ctypes.c_int, vp, c_float_p]),
+    'xrt_hip_kirchhoff_f64': (ctypes.c_int, [
+        ctypes.c_int, c_int_p, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp,
+        ctypes.c_int, vp, vp, vp, vp, vp, c_float_p]),
+    'xrt_hip_debug_sqrt_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
+    'xrt_hip_debug_sincos_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
+}
+
+
+class XrtHipError(RuntimeError):
+    pass
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load(build_if_missing=True):
+    """Returns the loaded CDLL with typed signatures; raises XrtHipError if the
+    library is missing and cannot be built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            if not build_if_missing:
+                raise XrtHipError('%s not built' % LIB_PATH)
+            try:
+                from .csrc.build import build
+                build()
+            except Exception as e:  # noqa: BLE001
+                raise XrtHipError(
+                    'libxrt_hip.so is missing and could not be built with '
+                    'hipcc (%s); there is no CPU fallback' % (e,))
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise XrtHipError('cannot load %s: %s' % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().xrt_hip_last_error().decode('utf-8', 'replace')
+        raise XrtHipError('%s failed (%d): %s' % (what or 'xrt_hip call', rc, msg))
+
+
+def device_count():
+    n = load().xrt_hip_device_count()
+    return max(n, 0)
+
+
+def require_gpu():
+    lib = load()
+    n = lib.xrt_hip_device_count()
+    if n <= 0:
+        raise XrtHipError('no MI355X/ROCm device visible: %s (there is no CPU '
+                          'fallback)' % lib.xrt_hip_last_error().decode())
+    return n

@@ -1,0 +1,118 @@
+"""XRT_HIP — the drop-in for xrt's ``XRT_CL`` accelerator object
+(xrt/backends/raycing/myopencl.py:86-97, 414-583) on MI355X.
+
+``xrt.backends.raycing.waves`` only needs an object with ``run_parallel``,
+``cl_precisionF``, ``cl_precisionC``, ``set_cl`` and a non-None
+``lastTargetOpenCL`` (waves.py:493-498, 698-705, 855-894); assign an instance
+to ``waves.waveCL`` and ``diffract`` runs its Kirchhoff integral on the GPU:
+
+    import xrt.backends.raycing.waves as rw
+    from xrt_amd.backends.raycing.myhip import XRT_HIP
+    rw.waveCL = XRT_HIP()
+
+Like the OpenCL kernel it replaces (cl/diffract.cl:143-148) the returned
+integrals use the -i/4pi sign and the (1+i) direction factor by default
+(``convention='opencl'``); ``convention='numpy'`` returns what
+``_diffraction_integral_conv`` returns. Both give identical post-`diffract`
+intensities and directions.
+"""
+import ctypes
+
+import numpy as np
+
+from ... import _lib
+
+
+class XRT_HIP(object):
+    kernels = ('integrate_kirchhoff',)
+
+    def __init__(self, filename=None, targetOpenCL='auto',
+                 precisionOpenCL='float64', convention='opencl', devices=None):
+        self.cl_filename = filename
+        self.cl_precisionF = np.float64
+        self.cl_precisionC = np.complex128
+        self.cl_is_blocking = True
+        self.convention = convention
+        self.lastTargetOpenCL = None
+        self.lastPrecisionOpenCL = None
+        self.lastKernelMs = None
+        self.devices = devices
+        self.set_cl(targetOpenCL, precisionOpenCL)
+
+    def set_cl(self, targetOpenCL='auto', precisionOpenCL='float64'):
+        """targetOpenCL: 'auto' / 'GPU' / 'all' = every visible GPU; an int or a
+        sequence of ints = those device ordinals. fp32 is not offered: the
+        Kirchhoff phase k*r ~ 4e11 rad needs fp64."""
+        if precisionOpenCL not in ('auto', 'float64', np.float64):
+            raise ValueError('XRT_HIP computes in float64 only')
+        n = _lib.require_gpu()
+        if self.devices is not None:
+            devs = list(self.devices)
+        elif isinstance(targetOpenCL, (int, np.integer)):
+            devs = [int(targetOpenCL)]
+        elif isinstance(targetOpenCL, (list, tuple)) and len(targetOpenCL) and \
+                all(isinstance(d, (int, np.integer)) for d in targetOpenCL):
+            devs = [int(d) for d in targetOpenCL]
+        elif targetOpenCL is None:
+            raise ValueError('targetOpenCL=None disables the accelerator; '
+                             'do not install XRT_HIP then')
+        else:
+            devs = list(range(n))
+        for d in devs:
+            if not 0 <= d < n:
+                raise ValueError('GPU ordinal %d out of range (%d visible)' % (d, n))
+        self.device_ids = devs
+        self.lastTargetOpenCL = targetOpenCL
+        self.lastPrecisionOpenCL = precisionOpenCL
+
+    def run_parallel(self, kernelName='', scalarArgs=None, slicedROArgs=None,
+                     nonSlicedROArgs=None, slicedRWArgs=None,
+                     nonSlicedRWArgs=None, dimension=0, complexity=0,
+                     signal=None):
+        if kernelName != 'integrate_kirchhoff':
+            raise NotImplementedError(
+                "XRT_HIP implements 'integrate_kirchhoff' only, not %r"
+                % (kernelName,))
+        return self._integrate_kirchhoff(scalarArgs, slicedROArgs,
+                                         nonSlicedROArgs, slicedRWArgs,
+                                         int(dimension))
+
+    def _integrate_kirchhoff(self, scalarArgs, slicedRO, nonSlicedRO, slicedRW,
+                             dimension):
+        lib = _lib.load()
+        ns = int(scalarArgs[0])
+
+        def f64(a, n, name):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.size != n:
+                raise ValueError('%s: %d elements, expected %d' % (name, a.size, n))
+            return a
+
+        px, py, pz = (f64(a, dimension, 'mesh') for a in slicedRO)
+        nl = f64(nonSlicedRO[0], ns, 'nl')
+        Es = np.ascontiguousarray(nonSlicedRO[1], dtype=np.complex128)
+        Ep = np.ascontiguousarray(nonSlicedRO[2], dtype=np.complex128)
+        k = f64(nonSlicedRO[3], ns, 'k')
+        # (4, ns) order='F'  ==  ns x [x, y, z, 0] in memory (waves.py:872-879)
+        pos = np.asfortranarray(nonSlicedRO[4], dtype=np.float64)
+        nrm = np.asfortranarray(nonSlicedRO[5], dtype=np.float64)
+        if pos.shape != (4, ns) or nrm.shape != (4, ns):
+            raise ValueError('coordinate / normal arrays must be (4, %d)' % ns)
+        outs = []
+        for a in slicedRW:
+            if not (isinstance(a, np.ndarray) and a.dtype == np.complex128 and
+                    a.flags.c_contiguous and a.size == dimension):
+                raise ValueError('RW arrays must be contiguous complex128[%d]'
+                                 % dimension)
+            outs.append(a)
+        devs = (ctypes.c_int * len(self.device_ids))(*self.device_ids)
+        ms = ctypes.c_float(0.)
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+        rc = lib.xrt_hip_kirchhoff_f64(
+            len(self.device_ids), devs, dimension, ptr(px), ptr(py), ptr(pz), ns,
+            ptr(nl), ptr(Es), ptr(Ep), ptr(k), ptr(pos), ptr(nrm),
+            0 if self.convention == 'numpy' else 1,
+            *[ptr(a) for a in outs], ctypes.byref(ms))
+        _lib.check(rc, 'xrt_hip_kirchhoff_f64')
+        self.lastKernelMs = ms.value
+        return tuple(outs)

@@ -1,0 +1,241 @@
+// C ABI of libxrt_hip.so (see include/xrt_hip.h for the contract).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "../../include/xrt_hip.h"
+#include "kirchhoff.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess)                                                      \
+      return fail(XRT_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr,             \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                  \
+  } while (0)
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+  template <class T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int xrt_hip_version(void) { return 100; }
+
+const char* xrt_hip_last_error(void) { return g_err; }
+
+int xrt_hip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(XRT_HIP_ERR_NODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  return n;
+}
+
+int xrt_hip_kirchhoff_plan(int64_t np, int64_t ns, int nsplit_req, int ppt_req,
+                           size_t* workspace_bytes, int* nsplit, int* ppt) {
+  if (np < 0 || ns < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  xrt::KirchhoffPlan pl = xrt::kirchhoff_plan(np, ns, nsplit_req, ppt_req);
+  if (workspace_bytes) *workspace_bytes = pl.workspace_bytes();
+  if (nsplit) *nsplit = pl.nsplit;
+  if (ppt) *ppt = pl.ppt;
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_kirchhoff_f64_dev(
+    int64_t np, const double* px, const double* py, const double* pz, int64_t ns,
+    const double* sx, const double* sy, const double* sz, const double* nx,
+    const double* ny, const double* nz, const double* nl, const double* k,
+    const double* Es_ri, const double* Ep_ri, int convention, double* S_ri,
+    double* P_ri, double* A_ri, double* B_ri, double* C_ri, void* workspace,
+    size_t workspace_bytes, int nsplit_req, int ppt_req, void* stream,
+    float* kernel_ms) {
+  if (np < 0 || ns < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (convention != 0 && convention != 1)
+    return fail(XRT_HIP_ERR_ARG, "convention must be 0 (numpy) or 1 (OpenCL)");
+  if (np > 0 && (!px || !py || !pz || !S_ri || !P_ri || !A_ri || !B_ri || !C_ri))
+    return fail(XRT_HIP_ERR_ARG, "NULL receiving-point / output pointer");
+  if (ns > 0 && (!sx || !sy || !sz || !nx || !ny || !nz || !nl || !k || !Es_ri || !Ep_ri))
+    return fail(XRT_HIP_ERR_ARG, "NULL sample pointer");
+  xrt::KirchhoffPlan pl = xrt::kirchhoff_plan(np, ns, nsplit_req, ppt_req);
+  if (!workspace || workspace_bytes < pl.workspace_bytes())
+    return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes,
+                pl.workspace_bytes());
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (kernel_ms) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+  }
+  hipError_t e = xrt::kirchhoff_launch(pl, np, px, py, pz, ns, sx, sy, sz, 1, nx, ny, nz,
+                                       1, nl, k, Es_ri, Ep_ri, convention, S_ri, P_ri,
+                                       A_ri, B_ri, C_ri, workspace, st, e0, e1);
+  if (e != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return fail(XRT_HIP_ERR_HIP, "kirchhoff launch: %s", hipGetErrorString(e));
+  }
+  if (kernel_ms) {
+    *kernel_ms = 0.f;
+    if (np > 0) {
+      HIP_TRY(hipEventSynchronize(e1));
+      HIP_TRY(hipEventElapsedTime(kernel_ms, e0, e1));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_kirchhoff_f64(int ndev, const int* dev_ids, int64_t np, const double* px,
+                          const double* py, const double* pz, int64_t ns,
+                          const double* cos_gamma, const double* Es_ri,
+                          const double* Ep_ri, const double* k, const double* pos_xyzw,
+                          const double* nrm_xyzw, int convention, double* S_ri,
+                          double* P_ri, double* A_ri, double* B_ri, double* C_ri,
+                          float* kernel_ms) {
+  if (ndev < 1 || !dev_ids) return fail(XRT_HIP_ERR_ARG, "need >=1 device id");
+  if (np < 0 || ns < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (convention != 0 && convention != 1)
+    return fail(XRT_HIP_ERR_ARG, "convention must be 0 (numpy) or 1 (OpenCL)");
+  if (np > 0 && (!px || !py || !pz || !S_ri || !P_ri || !A_ri || !B_ri || !C_ri))
+    return fail(XRT_HIP_ERR_ARG, "NULL receiving-point / output pointer");
+  if (ns > 0 && (!cos_gamma || !Es_ri || !Ep_ri || !k || !pos_xyzw || !nrm_xyzw))
+    return fail(XRT_HIP_ERR_ARG, "NULL sample pointer");
+  int prev_dev = 0;
+  HIP_TRY(hipGetDevice(&prev_dev));
+
+  struct Slice {
+    int dev;
+    int64_t p0, n;
+    DevBuf px, py, pz, nl, es, ep, k, pos, nrm, out[5], ws;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    xrt::KirchhoffPlan pl;
+  };
+  std::vector<Slice> sl(ndev);
+  int rc = XRT_HIP_OK;
+  double* outs[5] = {S_ri, P_ri, A_ri, B_ri, C_ri};
+
+  auto run = [&]() -> int {
+    for (int d = 0; d < ndev; ++d) {
+      Slice& s = sl[d];
+      s.dev = dev_ids[d];
+      s.p0 = np * d / ndev;
+      s.n = np * (d + 1) / ndev - s.p0;
+      HIP_TRY(hipSetDevice(s.dev));
+      HIP_TRY(hipStreamCreate(&s.st));
+      HIP_TRY(hipEventCreate(&s.e0));
+      HIP_TRY(hipEventCreate(&s.e1));
+      s.pl = xrt::kirchhoff_plan(s.n, ns, 0, 0);
+      const size_t pb = (size_t)s.n * sizeof(double), sb = (size_t)ns * sizeof(double);
+      HIP_TRY(s.px.alloc(pb));
+      HIP_TRY(s.py.alloc(pb));
+      HIP_TRY(s.pz.alloc(pb));
+      HIP_TRY(s.nl.alloc(sb));
+      HIP_TRY(s.k.alloc(sb));
+      HIP_TRY(s.es.alloc(2 * sb));
+      HIP_TRY(s.ep.alloc(2 * sb));
+      HIP_TRY(s.pos.alloc(4 * sb));
+      HIP_TRY(s.nrm.alloc(4 * sb));
+      HIP_TRY(s.ws.alloc(s.pl.workspace_bytes()));
+      for (int c = 0; c < 5; ++c) HIP_TRY(s.out[c].alloc(2 * pb));
+      if (s.n > 0) {
+        HIP_TRY(hipMemcpyAsync(s.px.p, px + s.p0, pb, hipMemcpyHostToDevice, s.st));
+        HIP_TRY(hipMemcpyAsync(s.py.p, py + s.p0, pb, hipMemcpyHostToDevice, s.st));
+        HIP_TRY(hipMemcpyAsync(s.pz.p, pz + s.p0, pb, hipMemcpyHostToDevice, s.st));
+      }
+      if (ns > 0) {
+        HIP_TRY(hipMemcpyAsync(s.nl.p, cos_gamma, sb, hipMemcpyHostToDevice, s.st));
+        HIP_TRY(hipMemcpyAsync(s.k.p, k, sb, hipMemcpyHostToDevice, s.st));
+        HIP_TRY(hipMemcpyAsync(s.es.p, Es_ri, 2 * sb, hipMemcpyHostToDevice, s.st));
+        HIP_TRY(hipMemcpyAsync(s.ep.p, Ep_ri, 2 * sb, hipMemcpyHostToDevice, s.st));
+        HIP_TRY(hipMemcpyAsync(s.pos.p, pos_xyzw, 4 * sb, hipMemcpyHostToDevice, s.st));
+        HIP_TRY(hipMemcpyAsync(s.nrm.p, nrm_xyzw, 4 * sb, hipMemcpyHostToDevice, s.st));
+      }
+      const double* pos = s.pos.as<double>();
+      const double* nrm = s.nrm.as<double>();
+      hipError_t e = xrt::kirchhoff_launch(
+          s.pl, s.n, s.px.as<double>(), s.py.as<double>(), s.pz.as<double>(), ns, pos,
+          pos + 1, pos + 2, 4, nrm, nrm + 1, nrm + 2, 4, s.nl.as<double>(),
+          s.k.as<double>(), s.es.as<double>(), s.ep.as<double>(), convention,
+          s.out[0].as<double>(), s.out[1].as<double>(), s.out[2].as<double>(),
+          s.out[3].as<double>(), s.out[4].as<double>(), s.ws.p, s.st, s.e0, s.e1);
+      if (e != hipSuccess)
+        return fail(XRT_HIP_ERR_HIP, "kirchhoff launch on device %d: %s", s.dev,
+                    hipGetErrorString(e));
+      if (s.n > 0)
+        for (int c = 0; c < 5; ++c)
+          HIP_TRY(hipMemcpyAsync(outs[c] + 2 * s.p0, s.out[c].p, 2 * pb,
+                                 hipMemcpyDeviceToHost, s.st));
+    }
+    float worst = 0.f;
+    for (int d = 0; d < ndev; ++d) {
+      Slice& s = sl[d];
+      HIP_TRY(hipSetDevice(s.dev));
+      HIP_TRY(hipStreamSynchronize(s.st));
+      if (s.n > 0) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s.e0, s.e1));
+        if (ms > worst) worst = ms;
+      }
+    }
+    if (kernel_ms) *kernel_ms = worst;
+    return XRT_HIP_OK;
+  };
+  rc = run();
+  for (int d = 0; d < ndev; ++d) {
+    Slice& s = sl[d];
+    if (s.st || s.e0 || s.e1) (void)hipSetDevice(s.dev);
+    if (s.st) {
+      (void)hipStreamSynchronize(s.st);
+      (void)hipStreamDestroy(s.st);
+    }
+    if (s.e0) (void)hipEventDestroy(s.e0);
+    if (s.e1) (void)hipEventDestroy(s.e1);
+  }
+  // DevBuf destructors free on whatever device is current; hipFree works across devices
+  (void)hipSetDevice(prev_dev);
+  return rc;
+}
+
+int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,
+                               void* stream) {
+  if (n <= 0) return XRT_HIP_OK;
+  HIP_TRY(xrt::debug_sqrt_launch(n, x, r, rinv, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_debug_sincos_f64_dev(int64_t n, const double* phi, double* sn, double* cs,
+                                 void* stream) {
+  if (n <= 0) return XRT_HIP_OK;
+  HIP_TRY(xrt::debug_sincos_launch(n, phi, sn, cs, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+}  // extern "C"

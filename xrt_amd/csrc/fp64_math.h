@@ -1,0 +1,81 @@
+// fp64 building blocks for the gfx950 kernels.
+//
+// This translation unit is compiled with -ffp-contract=off: every a*b+c below
+// is two roundings unless it is spelled fma(). The reference (numpy) never
+// fuses, so the values that decide ray states / the Kirchhoff phase must be
+// computed with the very same sequence of IEEE operations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace xrt {
+
+__device__ __forceinline__ double fma_(double a, double b, double c) {
+  return __builtin_fma(a, b, c);
+}
+
+// Correctly rounded sqrt(x) for normal positive x (no scaling / special cases:
+// callers guarantee 2^-700 < x < 2^700) that ALSO hands back 1/sqrt(x) to ~1 ulp
+// for free. Same Goldschmidt iteration LLVM emits for f64 sqrt on AMDGPU
+// (SIISelLowering lowerFSQRTF64) minus its denormal scaling; h1 of that
+// iteration converges to 0.5/sqrt(x), which the plain builtin throws away.
+__device__ __forceinline__ double sqrt_rn_rinv(double x, double& rinv) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  double r0 = fma_(-h, g, 0.5);
+  g = fma_(g, r0, g);
+  h = fma_(h, r0, h);
+  double d0 = fma_(-g, g, x);
+  g = fma_(d0, h, g);
+  double d1 = fma_(-g, g, x);
+  g = fma_(d1, h, g);
+  rinv = h + h;
+  return g;
+}
+
+// sin/cos of a LARGE positive-or-negative phase phi [rad] (|phi| < 2^50),
+// accurate to ~2e-16 absolute. The Kirchhoff phase k*r is ~4e11 rad, so ocml's
+// generic sincos would take its Payne-Hanek path every call; here the
+// reduction is two fma against a double-double 2/pi:
+//   t = phi*(2/pi) in quarter turns, n = rint(t) via the 1.5*2^52 trick (its
+//   low mantissa bits give the quadrant), u = phi*(2/pi) - n exactly (fma),
+// then minimax polynomials in w = u^2 for sin(pi/2 u) and cos(pi/2 u), |u|<=1/2.
+__device__ __forceinline__ void sincos_phase(double phi, double& sn, double& cs) {
+  const double TWO_OVER_PI_HI = 0x1.45f306dc9c883p-1;
+  const double TWO_OVER_PI_LO = -0x1.6b01ec5417056p-55;
+  const double MAGIC = 0x1.8p52;
+  double t = phi * TWO_OVER_PI_HI;
+  double m = t + MAGIC;
+  double n = m - MAGIC;
+  unsigned q = (unsigned)__double2loint(m);
+  double u = fma_(phi, TWO_OVER_PI_HI, -n);
+  u = fma_(phi, TWO_OVER_PI_LO, u);
+  double w = u * u;
+  double ps = 0x1.e3f38399551bfp-25;
+  ps = fma_(ps, w, -0x1.e30071afc3e59p-19);
+  ps = fma_(ps, w, 0x1.50782fda12d96p-13);
+  ps = fma_(ps, w, -0x1.32d2cce2e5b19p-8);
+  ps = fma_(ps, w, 0x1.466bc677587f8p-4);
+  ps = fma_(ps, w, -0x1.4abbce625be41p-1);
+  ps = fma_(ps, w, 0x1.921fb54442d18p+0);
+  double s = ps * u;
+  double pc = 0x1.f3dbcea61b1a4p-22;
+  pc = fma_(pc, w, -0x1.a6c9c1be9eb49p-16);
+  pc = fma_(pc, w, 0x1.e1f4fb60281f6p-11);
+  pc = fma_(pc, w, -0x1.55d3c7dbfd139p-6);
+  pc = fma_(pc, w, 0x1.03c1f081b0780p-2);
+  pc = fma_(pc, w, -0x1.3bd3cc9be458bp+0);
+  double c = fma_(pc, w, 1.0);
+  // quadrant: 0:(c,s) 1:(-s,c) 2:(-c,-s) 3:(s,-c)
+  double cc = (q & 1u) ? s : c;
+  double ss = (q & 1u) ? c : s;
+  // sign bit flips through the high dword only
+  unsigned long long cb = __double_as_longlong(cc);
+  unsigned long long sb = __double_as_longlong(ss);
+  cb ^= (unsigned long long)(((q + 1u) >> 1) & 1u) << 63;
+  sb ^= (unsigned long long)((q >> 1) & 1u) << 63;
+  cs = __longlong_as_double(cb);
+  sn = __longlong_as_double(sb);
+}
+
+}  // namespace xrt

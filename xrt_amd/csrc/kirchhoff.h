@@ -1,0 +1,39 @@
+// Internal (C++) interface between kirchhoff.hip and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define KIRCHHOFF_BLOCK 256
+#define KIRCHHOFF_REC_DOUBLES 16
+
+namespace xrt {
+
+struct KirchhoffPlan {
+  int ppt;               // receiving points per lane (1 or 2)
+  int nsplit;            // sample splits (grid = tiles * nsplit)
+  int64_t tiles;         // pixel tiles of KIRCHHOFF_BLOCK*ppt
+  int64_t np_pad;        // row pitch of the partial-sum workspace
+  size_t rec_bytes;      // packed sample records
+  size_t partial_bytes;  // nsplit * 10 * np_pad doubles
+  size_t workspace_bytes() const { return ((rec_bytes + 255) / 256) * 256 + partial_bytes; }
+};
+
+KirchhoffPlan kirchhoff_plan(int64_t np, int64_t ns, int nsplit_req, int ppt_req);
+
+hipError_t kirchhoff_launch(const KirchhoffPlan& pl, int64_t np, const double* px,
+                            const double* py, const double* pz, int64_t ns,
+                            const double* sx, const double* sy, const double* sz,
+                            int pstride, const double* nx, const double* ny,
+                            const double* nz, int nstride, const double* nl,
+                            const double* k, const double* Es,
+                            const double* Ep, int convention, double* S, double* P,
+                            double* A, double* B, double* C, void* workspace,
+                            hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1);
+
+hipError_t debug_sqrt_launch(int64_t n, const double* x, double* r, double* ri,
+                             hipStream_t stream);
+hipError_t debug_sincos_launch(int64_t n, const double* phi, double* sn, double* cs,
+                               hipStream_t stream);
+
+}  // namespace xrt

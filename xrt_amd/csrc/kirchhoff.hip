@@ -1,0 +1,313 @@
+// Fresnel-Kirchhoff diffraction integral for gfx950 (MI355X), fp64.
+//
+// Replaces xrt's numpy `_diffraction_integral_conv` (waves.py:834-851) and the
+// OpenCL kernel `integrate_kirchhoff` (cl/diffract.cl:80-151): for every
+// receiving point p and every source sample s
+//     d = p - s, r = |d|, g = (k/r)(d.n/r + nl) e^{ikr}
+//     S += g Es, P += g Ep, (A,B,C) += (k/r) g k(Es+Ep) d
+// followed by the constant prefactors of either convention.
+//
+// Design (streaming form, VALU fp64):
+//   * one lane = PPT receiving points, 10 fp64 accumulators each, kept in VGPRs;
+//   * samples are pre-packed into 128-byte records (pack kernel below) and the
+//     inner loop indexes them with a wave-uniform index, so they arrive through
+//     the scalar cache into SGPRs (s_load_dwordx16): no LDS traffic, no VGPRs,
+//     and VALU takes them as its one scalar operand;
+//   * the grid is (pixel tiles) x (sample splits); split = blockIdx % nsplit so
+//     that, with the observed block -> XCD round robin, each XCD's L2 streams
+//     its own slice of the sample records; partial sums go to a workspace and a
+//     tiny finalize kernel adds them in fixed order (deterministic, no atomics);
+//   * r and k*r use exactly numpy's operation order with no FMA contraction
+//     (k*r ~ 4e11 rad: one ulp is 6e-5 rad), sqrt is correctly rounded and also
+//     yields 1/r; sincos uses a 2-fma double-double reduction (fp64_math.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fp64_math.h"
+#include "kirchhoff.h"
+
+namespace xrt {
+
+// ---------------------------------------------------------------------------
+// pack: sample arrays -> 16-double records. Positions / normals are read with
+// an element stride so that both the SoA layout (stride 1) and the reference's
+// OpenCL marshalling ns x [x,y,z,0] (stride 4, waves.py:872-879) feed it.
+//   [0..2] x,y,z  [3] nl  [4..6] n  [7] k  [8,9] Es  [10,11] Ep
+//   [12,13] k*(Es+Ep)  [14,15] 0
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kirchhoff_pack(
+    int64_t ns, const double* __restrict__ sx, const double* __restrict__ sy,
+    const double* __restrict__ sz, int pstride, const double* __restrict__ nx,
+    const double* __restrict__ ny, const double* __restrict__ nz, int nstride,
+    const double* __restrict__ nl, const double* __restrict__ k,
+    const double2* __restrict__ Es, const double2* __restrict__ Ep,
+    double* __restrict__ rec) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ns) return;
+  double2 es = Es[i], ep = Ep[i];
+  double kk = k[i];
+  double2* o = reinterpret_cast<double2*>(rec + i * KIRCHHOFF_REC_DOUBLES);
+  const int64_t ip = i * pstride, in = i * nstride;
+  o[0] = make_double2(sx[ip], sy[ip]);
+  o[1] = make_double2(sz[ip], nl[i]);
+  o[2] = make_double2(nx[in], ny[in]);
+  o[3] = make_double2(nz[in], kk);
+  o[4] = es;
+  o[5] = ep;
+  // numpy: k**2/(4pi) * (Es+Ep) * U / r ; the sum Es+Ep is formed first there too
+  o[6] = make_double2(kk * (es.x + ep.x), kk * (es.y + ep.y));
+  o[7] = make_double2(0.0, 0.0);
+}
+
+// ---------------------------------------------------------------------------
+// main streaming kernel
+// ---------------------------------------------------------------------------
+struct Acc {
+  double sr, si, pr, pi, ar, ai, br, bi, cr, ci;
+};
+
+__device__ __forceinline__ void pair_update(
+    double px, double py, double pz, const double* __restrict__ r, Acc& a) {
+  const double sx = r[0], sy = r[1], sz = r[2], nl = r[3];
+  const double nx = r[4], ny = r[5], nz = r[6], k = r[7];
+  const double esr = r[8], esi = r[9], epr = r[10], epi = r[11];
+  const double qr = r[12], qi = r[13];
+  // --- bit-exact part (numpy order, no contraction) ---
+  const double dx = px - sx;
+  const double dy = py - sy;
+  const double dz = pz - sz;
+  const double s2 = (dx * dx + dy * dy) + dz * dz;
+  double rinv;
+  const double rr = sqrt_rn_rinv(s2, rinv);
+  const double phase = k * rr;
+  // --- the rest only needs ~1e-16 relative accuracy ---
+  double dn = dx * nx;
+  dn = fma_(dy, ny, dn);
+  dn = fma_(dz, nz, dn);
+  const double kip = k * rinv;
+  const double cr = kip * fma_(dn, rinv, nl);
+  double sn, cs;
+  sincos_phase(phase, sn, cs);
+  const double gr = cr * cs;
+  const double gi = cr * sn;
+  a.sr = fma_(gr, esr, a.sr);
+  a.sr = fma_(-gi, esi, a.sr);
+  a.si = fma_(gr, esi, a.si);
+  a.si = fma_(gi, esr, a.si);
+  a.pr = fma_(gr, epr, a.pr);
+  a.pr = fma_(-gi, epi, a.pr);
+  a.pi = fma_(gr, epi, a.pi);
+  a.pi = fma_(gi, epr, a.pi);
+  const double hr0 = kip * gr;
+  const double hi0 = kip * gi;
+  double hr = hr0 * qr;
+  hr = fma_(-hi0, qi, hr);
+  double hi = hr0 * qi;
+  hi = fma_(hi0, qr, hi);
+  a.ar = fma_(hr, dx, a.ar);
+  a.ai = fma_(hi, dx, a.ai);
+  a.br = fma_(hr, dy, a.br);
+  a.bi = fma_(hi, dy, a.bi);
+  a.cr = fma_(hr, dz, a.cr);
+  a.ci = fma_(hi, dz, a.ci);
+}
+
+template <int PPT>
+__global__ __launch_bounds__(KIRCHHOFF_BLOCK) void kirchhoff_stream(
+    int64_t np, const double* __restrict__ px, const double* __restrict__ py,
+    const double* __restrict__ pz, int64_t ns, const double* __restrict__ rec,
+    int nsplit, int64_t np_pad, double* __restrict__ partial) {
+  const int split = blockIdx.x % nsplit;
+  const int64_t tile = blockIdx.x / nsplit;
+  const int64_t base = tile * (int64_t)(KIRCHHOFF_BLOCK * PPT) + threadIdx.x;
+  const int64_t s0 = ns * split / nsplit;
+  const int64_t s1 = ns * (split + 1) / nsplit;
+
+  double x[PPT], y[PPT], z[PPT];
+  Acc acc[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    int64_t p = base + (int64_t)j * KIRCHHOFF_BLOCK;
+    // out-of-range lanes re-use the last pixel (their result is not stored)
+    int64_t pc = p < np ? p : np - 1;
+    x[j] = px[pc];
+    y[j] = py[pc];
+    z[j] = pz[pc];
+    acc[j] = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  for (int64_t s = s0; s < s1; ++s) {
+    const double* r = rec + s * KIRCHHOFF_REC_DOUBLES;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) pair_update(x[j], y[j], z[j], r, acc[j]);
+  }
+  double* out = partial + (int64_t)split * 10 * np_pad;
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    int64_t p = base + (int64_t)j * KIRCHHOFF_BLOCK;
+    if (p < np) {
+      out[0 * np_pad + p] = acc[j].sr;
+      out[1 * np_pad + p] = acc[j].si;
+      out[2 * np_pad + p] = acc[j].pr;
+      out[3 * np_pad + p] = acc[j].pi;
+      out[4 * np_pad + p] = acc[j].ar;
+      out[5 * np_pad + p] = acc[j].ai;
+      out[6 * np_pad + p] = acc[j].br;
+      out[7 * np_pad + p] = acc[j].bi;
+      out[8 * np_pad + p] = acc[j].cr;
+      out[9 * np_pad + p] = acc[j].ci;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// finalize: add the split partials in fixed order, apply the prefactors.
+//   convention 0 (numpy, waves.py:844,847): S,P *= i/(4pi); A,B,C *= i/(4pi)^2
+//   convention 1 (OpenCL, diffract.cl:143-148): S,P *= -i/(4pi);
+//                                              A,B,C *= (1+i)/(4pi)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kirchhoff_finalize(
+    int64_t np, int nsplit, int64_t np_pad, const double* __restrict__ partial,
+    int convention, double2* __restrict__ S, double2* __restrict__ P,
+    double2* __restrict__ A, double2* __restrict__ B, double2* __restrict__ C) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= np) return;
+  double v[10];
+#pragma unroll
+  for (int c = 0; c < 10; ++c) v[c] = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    const double* in = partial + (int64_t)s * 10 * np_pad;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) v[c] += in[c * np_pad + p];
+  }
+  const double inv4pi = 0.07957747154594767;  // 1/(4 pi)
+  double2 o[5];
+  if (convention == 0) {
+    const double f2 = inv4pi * inv4pi;
+    o[0] = make_double2(-v[1] * inv4pi, v[0] * inv4pi);
+    o[1] = make_double2(-v[3] * inv4pi, v[2] * inv4pi);
+    o[2] = make_double2(-v[5] * f2, v[4] * f2);
+    o[3] = make_double2(-v[7] * f2, v[6] * f2);
+    o[4] = make_double2(-v[9] * f2, v[8] * f2);
+  } else {
+    o[0] = make_double2(v[1] * inv4pi, -v[0] * inv4pi);
+    o[1] = make_double2(v[3] * inv4pi, -v[2] * inv4pi);
+    o[2] = make_double2((v[4] - v[5]) * inv4pi, (v[4] + v[5]) * inv4pi);
+    o[3] = make_double2((v[6] - v[7]) * inv4pi, (v[6] + v[7]) * inv4pi);
+    o[4] = make_double2((v[8] - v[9]) * inv4pi, (v[8] + v[9]) * inv4pi);
+  }
+  S[p] = o[0];
+  P[p] = o[1];
+  A[p] = o[2];
+  B[p] = o[3];
+  C[p] = o[4];
+}
+
+// ---------------------------------------------------------------------------
+// debug kernels for the building blocks (tests/test_gpu_math.py)
+// ---------------------------------------------------------------------------
+__global__ void debug_sqrt_kernel(int64_t n, const double* __restrict__ x,
+                                  double* __restrict__ r, double* __restrict__ ri) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double rinv;
+  r[i] = sqrt_rn_rinv(x[i], rinv);
+  ri[i] = rinv;
+}
+
+__global__ void debug_sincos_kernel(int64_t n, const double* __restrict__ phi,
+                                    double* __restrict__ sn, double* __restrict__ cs) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s, c;
+  sincos_phase(phi[i], s, c);
+  sn[i] = s;
+  cs[i] = c;
+}
+
+}  // namespace xrt
+
+// ---------------------------------------------------------------------------
+// launch plan + launchers (called from capi.hip)
+// ---------------------------------------------------------------------------
+namespace xrt {
+
+KirchhoffPlan kirchhoff_plan(int64_t np, int64_t ns, int nsplit_req, int ppt_req) {
+  KirchhoffPlan pl;
+  pl.ppt = (ppt_req == 1 || ppt_req == 2) ? ppt_req : 1;
+  int64_t per_block = (int64_t)KIRCHHOFF_BLOCK * pl.ppt;
+  pl.tiles = (np + per_block - 1) / per_block;
+  if (pl.tiles < 1) pl.tiles = 1;
+  int nsplit = nsplit_req;
+  if (nsplit <= 0) {
+    // want >= ~4 blocks per CU (1024 blocks); splits come in multiples of 8 so
+    // that split == XCD under the round-robin block placement
+    nsplit = 1;
+    const int64_t want_blocks = 1024;
+    if (pl.tiles < want_blocks) {
+      int64_t need = (want_blocks + pl.tiles - 1) / pl.tiles;
+      nsplit = (int)(((need + 7) / 8) * 8);
+      if (nsplit > 256) nsplit = 256;
+    }
+  }
+  // never split finer than 64 samples per split
+  while (nsplit > 1 && ns / nsplit < 64) nsplit /= 2;
+  if (nsplit < 1) nsplit = 1;
+  pl.nsplit = nsplit;
+  pl.np_pad = ((np + 31) / 32) * 32;
+  pl.rec_bytes = (size_t)ns * KIRCHHOFF_REC_DOUBLES * sizeof(double);
+  pl.partial_bytes = (size_t)nsplit * 10 * pl.np_pad * sizeof(double);
+  return pl;
+}
+
+hipError_t kirchhoff_launch(const KirchhoffPlan& pl, int64_t np, const double* px,
+                            const double* py, const double* pz, int64_t ns,
+                            const double* sx, const double* sy, const double* sz,
+                            int pstride, const double* nx, const double* ny,
+                            const double* nz, int nstride, const double* nl,
+                            const double* k, const double* Es,
+                            const double* Ep, int convention, double* S, double* P,
+                            double* A, double* B, double* C, void* workspace,
+                            hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+  double* rec = reinterpret_cast<double*>(workspace);
+  double* partial =
+      reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) +
+                                ((pl.rec_bytes + 255) / 256) * 256);
+  if (ns > 0) {
+    hipLaunchKernelGGL(kirchhoff_pack, dim3((unsigned)((ns + 255) / 256)), dim3(256),
+                       0, stream, ns, sx, sy, sz, pstride, nx, ny, nz, nstride, nl, k,
+                       reinterpret_cast<const double2*>(Es),
+                       reinterpret_cast<const double2*>(Ep), rec);
+  }
+  if (np > 0) {
+    dim3 grid((unsigned)(pl.tiles * pl.nsplit));
+    if (ev0) (void)hipEventRecord(ev0, stream);
+    if (pl.ppt == 2)
+      hipLaunchKernelGGL(kirchhoff_stream<2>, grid, dim3(KIRCHHOFF_BLOCK), 0, stream,
+                         np, px, py, pz, ns, rec, pl.nsplit, pl.np_pad, partial);
+    else
+      hipLaunchKernelGGL(kirchhoff_stream<1>, grid, dim3(KIRCHHOFF_BLOCK), 0, stream,
+                         np, px, py, pz, ns, rec, pl.nsplit, pl.np_pad, partial);
+    if (ev1) (void)hipEventRecord(ev1, stream);
+    hipLaunchKernelGGL(kirchhoff_finalize, dim3((unsigned)((np + 255) / 256)),
+                       dim3(256), 0, stream, np, pl.nsplit, pl.np_pad, partial,
+                       convention, reinterpret_cast<double2*>(S),
+                       reinterpret_cast<double2*>(P), reinterpret_cast<double2*>(A),
+                       reinterpret_cast<double2*>(B), reinterpret_cast<double2*>(C));
+  }
+  return hipGetLastError();
+}
+
+hipError_t debug_sqrt_launch(int64_t n, const double* x, double* r, double* ri,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(debug_sqrt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
+                     0, stream, n, x, r, ri);
+  return hipGetLastError();
+}
+
+hipError_t debug_sincos_launch(int64_t n, const double* phi, double* sn, double* cs,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(debug_sincos_kernel, dim3((unsigned)((n + 255) / 256)),
+                     dim3(256), 0, stream, n, phi, sn, cs);
+  return hipGetLastError();
+}
+
+}  // namespace xrt

@@ -1,0 +1,113 @@
+"""Typed Python wrappers over the device-pointer entry points of libxrt_hip.so.
+
+torch is used only as the owner of device memory and streams: tensors are
+passed to the C ABI as raw pointers (``data_ptr()``) together with torch's
+current HIP stream.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_workspaces = {}
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f64(t, n=None, name='array'):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError('%s must be a CUDA/HIP tensor' % name)
+    if t.dtype != torch.float64:
+        raise TypeError('%s must be float64, got %s' % (name, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+    if n is not None and t.numel() != n:
+        raise ValueError('%s has %d elements, expected %d' % (name, t.numel(), n))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _c128(t, n, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError('%s must be a CUDA/HIP tensor' % name)
+    if t.dtype != torch.complex128:
+        raise TypeError('%s must be complex128, got %s' % (name, t.dtype))
+    if not t.is_contiguous() or t.numel() != n:
+        raise ValueError('%s must be contiguous with %d elements' % (name, n))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def workspace(device, nbytes, tag='default'):
+    """Grow-only per-device scratch buffer owned by torch's allocator."""
+    key = (device.index if device.index is not None else
+           torch.cuda.current_device(), tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def kirchhoff_plan(npix, ns, nsplit=0, ppt=0):
+    lib = _lib.load()
+    wsb = ctypes.c_size_t(0)
+    ns_out = ctypes.c_int(0)
+    ppt_out = ctypes.c_int(0)
+    _lib.check(lib.xrt_hip_kirchhoff_plan(
+        npix, ns, nsplit, ppt, ctypes.byref(wsb), ctypes.byref(ns_out),
+        ctypes.byref(ppt_out)), 'xrt_hip_kirchhoff_plan')
+    return wsb.value, ns_out.value, ppt_out.value
+
+
+def kirchhoff(px, py, pz, sx, sy, sz, nx, ny, nz, nl, k, Es, Ep, convention=0,
+              nsplit=0, ppt=0, out=None, timing=False):
+    """Fresnel-Kirchhoff integral on device-resident arrays.
+
+    Returns (S, P, A, B, C) complex128 tensors [npix] = the (Es, Ep, aE, bE, cE)
+    of xrt's _diffraction_integral_conv (convention 0) or of its OpenCL kernel
+    (convention 1); with ``timing=True`` also the main kernel's milliseconds
+    (the call then synchronises)."""
+    lib = _lib.load()
+    npix = px.numel()
+    ns = sx.numel()
+    dev = px.device
+    if out is None:
+        out = tuple(torch.empty(npix, dtype=torch.complex128, device=dev)
+                    for _ in range(5))
+    wsb, _, _ = kirchhoff_plan(npix, ns, nsplit, ppt)
+    ws = workspace(dev, wsb, 'kirchhoff')
+    ms = ctypes.c_float(0.)
+    with torch.cuda.device(dev):
+        rc = lib.xrt_hip_kirchhoff_f64_dev(
+            npix, _f64(px, npix, 'px'), _f64(py, npix, 'py'), _f64(pz, npix, 'pz'),
+            ns, _f64(sx, ns, 'sx'), _f64(sy, ns, 'sy'), _f64(sz, ns, 'sz'),
+            _f64(nx, ns, 'nx'), _f64(ny, ns, 'ny'), _f64(nz, ns, 'nz'),
+            _f64(nl, ns, 'nl'), _f64(k, ns, 'k'), _c128(Es, ns, 'Es'),
+            _c128(Ep, ns, 'Ep'), int(convention),
+            *[_c128(o, npix, 'out') for o in out],
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), int(nsplit), int(ppt),
+            _stream_ptr(), ctypes.byref(ms) if timing else None)
+    _lib.check(rc, 'xrt_hip_kirchhoff_f64_dev')
+    if timing:
+        return out + (ms.value,)
+    return out
+
+
+def debug_sqrt(x):
+    lib = _lib.load()
+    r = torch.empty_like(x)
+    ri = torch.empty_like(x)
+    _lib.check(lib.xrt_hip_debug_sqrt_f64_dev(
+        x.numel(), _f64(x), _f64(r), _f64(ri), _stream_ptr()), 'debug_sqrt')
+    return r, ri
+
+
+def debug_sincos(phi):
+    lib = _lib.load()
+    s = torch.empty_like(phi)
+    c = torch.empty_like(phi)
+    _lib.check(lib.xrt_hip_debug_sincos_f64_dev(
+        phi.numel(), _f64(phi), _f64(s), _f64(c), _stream_ptr()), 'debug_sincos')
+    return s, c
