@@ -1,0 +1,751 @@
+"""TEST INFRASTRUCTURE ONLY — numpy restatement of xrt's ray-surface hot path
+(the P1 oracle): frame transforms, bracketing, the bracketed secant / Brent
+root solve, state classification, direction update, coherency-matrix rotation,
+Fresnel and Bragg amplitudes.
+
+Same arithmetic, same operation order as the reference so that hit states come
+out bit-identical; the code is organised differently (plain functions over a
+small Beam record and parameter dictionaries). Reference anchors, relative to
+xrt/backends/raycing/:
+
+* rotate_*/rotate_beam          <- _rotate.py:5-57
+* global_to_virgin_local etc.   <- beamline.py:230-287
+* bracket                       <- oes/base.py:1231-1295 (_set_t, _bracketing)
+* find_dz / find_intersection   <- oes/base.py:801-885
+* secant / brent                <- oes/base.py:933-959 / 961-1048
+* rays_good                     <- oes/base.py:1094-1163
+* flat / toroid surface         <- oes/base.py:675-742, oes/__init__.py:398-411
+* reflect_local                 <- oes/reflect.py:551-1139
+* oe_reflect                    <- oes/reflect.py:18-163
+* dcm_double_reflect            <- oes/dcm.py:248-354
+* rotate_coherency_matrix       <- sources/beams.py:448-479
+* material / crystal amplitudes <- see oracle/materials_np.py
+
+Parity pinned: tests/golden/g2_*.npz, g3_*.npz (oracle/gen_fixtures_p1.py).
+Supported subset: rectangular / round OEs, flat and toroidal surfaces, no
+figure error, no gratings / multilayers / mosaicity (SURVEY 2.1 OOS rows).
+"""
+import copy
+
+import numpy as np
+
+from . import materials_np as mat
+from .consts import CH, CHBAR
+
+zEps = 1e-12            # raycing/__init__.py:86
+maxIteration = 100      # :88
+dt = 1e-5               # :90 bracket margin [mm]
+maxHalfSizeOfOE = 1000.  # :92
+maxDepthOfOE = 100.      # :94
+
+F64 = ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp')
+
+
+class Beam(object):
+    """SoA ray record (sources/beams.py:153-182)."""
+
+    def __init__(self, n=0, with_amplitudes=False):
+        for f in F64:
+            setattr(self, f, np.zeros(n))
+        self.b[:] = 1.
+        self.Jss[:] = 1.
+        self.Jsp = np.zeros(n, dtype=complex)
+        self.state = np.zeros(n, dtype=np.int32)
+        if with_amplitudes:
+            self.Es = np.zeros(n, dtype=complex)
+            self.Ep = np.zeros(n, dtype=complex)
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def fields(self):
+        names = list(F64) + ['Jsp', 'state']
+        if hasattr(self, 'Es'):
+            names += ['Es', 'Ep']
+        return names
+
+    @staticmethod
+    def from_dict(d, prefix=''):
+        n = len(d[prefix + 'x'])
+        b = Beam(n, with_amplitudes=(prefix + 'Es') in d)
+        for f in b.fields():
+            setattr(b, f, np.array(d[prefix + f]))
+        if (prefix + 'theta') in d:
+            b.theta = np.array(d[prefix + 'theta'])
+        return b
+
+
+# --------------------------------------------------------------------------
+# plane rotations (_rotate.py:5-20)
+# --------------------------------------------------------------------------
+def rotate_x(y, z, cosangle, sinangle):
+    return cosangle*y - sinangle*z, sinangle*y + cosangle*z
+
+
+def rotate_y(x, z, cosangle, sinangle):
+    return cosangle*x + sinangle*z, -sinangle*x + cosangle*z
+
+
+def rotate_z(x, y, cosangle, sinangle):
+    return cosangle*x - sinangle*y, sinangle*x + cosangle*y
+
+
+def rotation_steps(rotationSequence, pitch, roll, yaw):
+    """The list of (axis, cos, sin) that rotate_beam applies
+    (_rotate.py:30-57): axes in the order of the sequence string (reversed for
+    a leading '-'), zero angles skipped, cos/sin of the scalar angle."""
+    angles = {'z': yaw, 'y': roll, 'x': pitch}
+    if rotationSequence[0] == '-':
+        seq = rotationSequence[6] + rotationSequence[4] + rotationSequence[2]
+    else:
+        seq = rotationSequence[1] + rotationSequence[3] + rotationSequence[5]
+    steps = []
+    for s in seq:
+        angle = angles[s]
+        if angle != 0:
+            steps.append((s, np.cos(angle), np.sin(angle)))
+    return steps
+
+
+def apply_steps(steps, b, idx, xyz=True, abc=True):
+    for s, cA, sA in steps:
+        if s == 'z':
+            if xyz:
+                b.x[idx], b.y[idx] = rotate_z(b.x[idx], b.y[idx], cA, sA)
+            if abc:
+                b.a[idx], b.b[idx] = rotate_z(b.a[idx], b.b[idx], cA, sA)
+        elif s == 'y':
+            if xyz:
+                b.x[idx], b.z[idx] = rotate_y(b.x[idx], b.z[idx], cA, sA)
+            if abc:
+                b.a[idx], b.c[idx] = rotate_y(b.a[idx], b.c[idx], cA, sA)
+        else:
+            if xyz:
+                b.y[idx], b.z[idx] = rotate_x(b.y[idx], b.z[idx], cA, sA)
+            if abc:
+                b.b[idx], b.c[idx] = rotate_x(b.b[idx], b.c[idx], cA, sA)
+
+
+def rotate_beam(b, idx, rotationSequence='RzRyRx', pitch=0, roll=0, yaw=0):
+    apply_steps(rotation_steps(rotationSequence, pitch, roll, yaw), b, idx)
+
+
+# --------------------------------------------------------------------------
+# global <-> virgin local (beamline.py:230-287)
+# --------------------------------------------------------------------------
+def global_to_virgin_local(azimuth_sc, beam, lo, center, part):
+    a0, b0 = azimuth_sc           # (sinAzimuth, cosAzimuth)
+    lo.x[part] = beam.x[part] - center[0]
+    lo.y[part] = beam.y[part] - center[1]
+    lo.z[part] = beam.z[part] - center[2]
+    if a0 == 0:
+        lo.a[part] = beam.a[part]
+        lo.b[part] = beam.b[part]
+    else:
+        lo.x[part], lo.y[part] = rotate_z(lo.x[part], lo.y[part], b0, a0)
+        lo.a[part], lo.b[part] = rotate_z(beam.a[part], beam.b[part], b0, a0)
+    lo.c[part] = beam.c[part]
+
+
+def virgin_local_to_global(azimuth_sc, vlb, center, part):
+    a0, b0 = azimuth_sc
+    if a0 != 0:
+        vlb.a[part], vlb.b[part] = rotate_z(vlb.a[part], vlb.b[part], b0, -a0)
+        vlb.x[part], vlb.y[part] = rotate_z(vlb.x[part], vlb.y[part], b0, -a0)
+    if center is not None:
+        vlb.x[part] += center[0]
+        vlb.y[part] += center[1]
+        vlb.z[part] += center[2]
+
+
+def copy_beam(to, fr, idx, includeState=False, includeJspEsp=True):
+    """sources/beams.py:409-445 (array fields only)."""
+    for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E'):
+        getattr(to, f)[idx] = getattr(fr, f)[idx]
+    if includeState:
+        to.state[idx] = fr.state[idx]
+    if includeJspEsp:
+        for f in ('Jss', 'Jpp', 'Jsp'):
+            getattr(to, f)[idx] = getattr(fr, f)[idx]
+        if hasattr(fr, 'Es') and hasattr(to, 'Es'):
+            to.Es[idx] = fr.Es[idx]
+            to.Ep[idx] = fr.Ep[idx]
+
+
+def rotate_coherency_matrix(b, idx, roll):
+    """sources/beams.py:448-479."""
+    c = np.cos(roll)
+    s = np.sin(roll)
+    c2 = c**2
+    s2 = s**2
+    cs = c * s
+    JssN = b.Jss[idx]*c2 + b.Jpp[idx]*s2 + 2*b.Jsp[idx].real*cs
+    JppN = b.Jss[idx]*s2 + b.Jpp[idx]*c2 - 2*b.Jsp[idx].real*cs
+    JspN = (b.Jpp[idx]-b.Jss[idx])*cs + b.Jsp[idx].real*(c2-s2) + \
+        b.Jsp[idx].imag*1j
+    return JssN, JppN, JspN
+
+
+# --------------------------------------------------------------------------
+# surfaces
+# --------------------------------------------------------------------------
+def local_z(surf, x, y):
+    if surf['kind'] == 'flat':                    # oes/base.py:675-679
+        return np.zeros_like(y)
+    if surf['kind'] == 'toroid':                  # oes/__init__.py:398-401
+        R, r = surf['R'], surf['r']
+        rx = 1 - (np.asarray(x)/r)**2
+        rx[rx < 0] = 0.
+        return y**2/2.0/R + r*(1 - rx**0.5)
+    raise ValueError(surf['kind'])
+
+
+def local_n(surf, x, y):
+    """3-list, or 6-list [n_H(3), n_surface(3)] for an asymmetric cut."""
+    if surf['kind'] == 'flat':                    # oes/base.py:719-742
+        a = 0.
+        b = 0.
+        c = 1.
+        alpha = surf.get('alpha')
+        if alpha:
+            bAlpha, cAlpha = rotate_x(b, c, np.cos(alpha), -np.sin(alpha))
+            res = [a, bAlpha, cAlpha, a, b, c]
+        else:
+            res = [a, b, c]
+        if surf.get('flip_n_y') and alpha:        # DCM.local_n2, dcm.py:234-238
+            res[1] *= -1
+        return res
+    if surf['kind'] == 'toroid':                  # oes/__init__.py:403-411
+        R, r = surf['R'], surf['r']
+        rx = 1 - (np.asarray(x)/r)**2
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ax = np.where(rx < 0, 0, rx**(-0.5))
+        a = -x / r * ax
+        b = -y / R
+        c = 1.
+        norm = (a**2 + b**2 + 1)**0.5
+        return [a/norm, b/norm, c/norm]
+    raise ValueError(surf['kind'])
+
+
+# --------------------------------------------------------------------------
+# bracketing + root solve
+# --------------------------------------------------------------------------
+def _set_t(xyz, abc, surfPhys=None, defSize=maxHalfSizeOfOE):
+    if surfPhys is None:
+        limMin = -defSize
+        limMax = defSize
+    else:
+        limMin = surfPhys[0] if surfPhys[0] > -np.inf else -defSize
+        limMax = surfPhys[1] if surfPhys[1] < np.inf else defSize
+    if abc[0] > 0:                                # first ray decides, base.py:1239
+        tMin = (limMin-xyz)/abc - dt
+        tMax = (limMax-xyz)/abc + dt
+    else:
+        tMin = (limMax-xyz)/abc - dt
+        tMax = (limMin-xyz)/abc + dt
+    return tMin, tMax
+
+
+def bracket(oe, x, y, z, a, b, c, is2ndXtal, mainPart, info=None):
+    sfx = '2' if is2ndXtal else ''
+    surfPhysX = oe['surfPhysX' + sfx]
+    surfPhysY = oe['surfPhysY' + sfx]
+    try:
+        maxa = np.max(abs(a[mainPart]))
+        maxb = np.max(abs(b[mainPart]))
+        maxc = np.max(abs(c[mainPart]))
+    except ValueError:
+        maxa, maxb, maxc = 0, 1, 0
+    maxMax = max(maxa, maxb, maxc)
+    if maxMax == maxa:
+        axis = 0
+        tMin, tMax = _set_t(x, a, surfPhysX)
+    elif maxMax == maxb:
+        axis = 1
+        tMin, tMax = _set_t(y, b, surfPhysY)
+    else:
+        axis = 2
+        tMin, tMax = _set_t(z, c, defSize=maxDepthOfOE)
+    tMin[tMin < -1e6*zEps] = -1e6*zEps            # base.py:1275
+    if info is not None:
+        info['axis'] = axis
+    return tMin, tMax
+
+
+def find_dz(surf, t, x0, y0, z0, a, b, c, invertNormal):
+    x = x0 + a*t
+    y = y0 + b*t
+    z = z0 + c*t
+    s = local_z(surf, x, y)
+    ind = np.isnan(s)
+    if ind.sum() > 0:
+        s[ind] = 0
+    dz = (z - s) * 1 * invertNormal               # diffSign = 1 (base.py:841)
+    return dz, x, y, z
+
+
+def find_intersection(surf, t1, t2, x, y, z, a, b, c, invertNormal, info=None):
+    dz1, x1, y1, z1 = find_dz(surf, t1, x, y, z, a, b, c, invertNormal)
+    dz2, x2, y2, z2 = find_dz(surf, t2, x, y, z, a, b, c, invertNormal)
+    tMin = t1.min()
+    tMax = t2.max()
+    ind1 = dz1 <= 0
+    ind2 = dz2 >= 0
+    dz2[ind1 | ind2] = 0
+    t2[ind1] = t1[ind1]
+    x2[ind1] = x1[ind1]
+    y2[ind1] = y1[ind1]
+    z2[ind1] = z1[ind1]
+    ind = ~(ind1 | ind2)
+    use_brent = bool(abs(dz2).max() > abs(dz1).max()*20)
+    solver = brent if use_brent else secant
+    t2, x2, y2, z2, numit = solver(
+        surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
+        x2, y2, z2, ind)
+    if info is not None:
+        info.update(brent=use_brent, numit=numit, tMinGlobal=tMin,
+                    tMaxGlobal=tMax)
+    return t2, x2, y2, z2, ind1
+
+
+def secant(surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
+           x2, y2, z2, ind):
+    """base.py:933-959."""
+    numit = 2
+    while (ind.sum() > 0) and (numit < maxIteration):
+        t = t1[ind]
+        dz = dz1[ind]
+        t1[ind] = t2[ind]
+        dz1[ind] = dz2[ind]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            t2[ind] = t - (t1[ind]-t) * dz / (dz1[ind]-dz)
+        where = np.where(ind)[0]
+        t2[where[t2[ind] < tMin]] = tMin
+        t2[where[t2[ind] > tMax]] = tMax
+        dz2[ind], x2[ind], y2[ind], z2[ind] = find_dz(
+            surf, t2[ind], x[ind], y[ind], z[ind], a[ind], b[ind], c[ind],
+            invertNormal)
+        swap = np.sign(dz2[ind]) == np.sign(dz1[ind])
+        t1[where[swap]] = t[swap]
+        dz1[where[swap]] = dz[swap]
+        ind = ind & (abs(dz2) > zEps)
+        numit += 1
+    return t2, x2, y2, z2, numit
+
+
+def brent(surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
+          x2, y2, z2, ind):
+    """base.py:961-1048."""
+    where = np.where(ind)[0]
+    swap = abs(dz1[ind]) < abs(dz2[ind])
+    if swap.sum() > 0:
+        w = where[swap]
+        t1[w], t2[w] = t2[w], t1[w]
+        dz1[w], dz2[w] = dz2[w], dz1[w]
+    t3 = np.copy(t1)
+    dz3 = np.copy(dz1)
+    t4 = np.zeros_like(t1)
+    mflag = np.ones_like(t1, dtype='bool')
+    numit = 2
+    ind = ind & (abs(dz2) > zEps)
+    while (ind.sum() > 0) and (numit < maxIteration):
+        xa, xb, xc, xd = t1[ind], t2[ind], t3[ind], t4[ind]
+        fa, fb, fc = dz1[ind], dz2[ind], dz3[ind]
+        mf = mflag[ind]
+        xs = np.empty_like(xa)
+        inq = (fa != fc) & (fb != fc)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            if inq.sum() > 0:
+                xai, xbi, xci = xa[inq], xb[inq], xc[inq]
+                fai, fbi, fci = fa[inq], fb[inq], fc[inq]
+                xs[inq] = \
+                    xai * fbi * fci / (fai-fbi) / (fai-fci) + \
+                    fai * xbi * fci / (fbi-fai) / (fbi-fci) + \
+                    fai * fbi * xci / (fci-fai) / (fci-fbi)
+            inx = ~inq
+            if inx.sum() > 0:
+                xai, xbi = xa[inx], xb[inx]
+                fai, fbi = fa[inx], fb[inx]
+                xs[inx] = xbi - fbi * (xbi-xai) / (fbi-fai)
+        cond1 = ((xs < (3*xa + xb) / 4.) & (xs < xb) |
+                 (xs > (3*xa + xb) / 4.) & (xs > xb))
+        cond2 = mf & (abs(xs - xb) >= (abs(xb - xc) / 2.))
+        cond3 = (~mf) & (abs(xs - xb) >= (abs(xc - xd) / 2.))
+        cond4 = mf & (abs(xb - xc) < zEps)
+        cond5 = (~mf) & (abs(xc - xd) < zEps)
+        conds = cond1 | cond2 | cond3 | cond4 | cond5
+        xs[conds] = (xa[conds] + xb[conds]) / 2.
+        mf = conds
+        fs, x2[ind], y2[ind], z2[ind] = find_dz(
+            surf, xs, x[ind], y[ind], z[ind], a[ind], b[ind], c[ind],
+            invertNormal)
+        xd[:] = xc[:]
+        xc[:] = xb[:]
+        fc[:] = fb[:]
+        fafsNeg = ((fa < 0) & (fs > 0)) | ((fa > 0) & (fs < 0))
+        xb[fafsNeg] = xs[fafsNeg]
+        fb[fafsNeg] = fs[fafsNeg]
+        fafsPos = ~fafsNeg
+        xa[fafsPos] = xs[fafsPos]
+        fa[fafsPos] = fs[fafsPos]
+        swap = abs(fa) < abs(fb)
+        xa[swap], xb[swap] = xb[swap], xa[swap]
+        fa[swap], fb[swap] = fb[swap], fa[swap]
+        t1[ind], t2[ind], t3[ind], t4[ind] = xa, xb, xc, xd
+        dz1[ind], dz2[ind], dz3[ind] = fa, fb, fc
+        mflag[ind] = mf
+        ind = ind & (abs(dz2) > zEps)
+        numit += 1
+    return t2, x2, y2, z2, numit
+
+
+def rays_good(oe, x, y, is2ndXtal=False):
+    """base.py:1094-1163 for shape 'rect' / 'round'."""
+    sfx = '2' if is2ndXtal else ''
+    surfPhysX, surfPhysY = oe['surfPhysX' + sfx], oe['surfPhysY' + sfx]
+    surfOptX, surfOptY = oe.get('surfOptX' + sfx), oe.get('surfOptY' + sfx)
+    lostNum = oe['lostNum']
+    locState = np.ones(x.size, dtype=np.int32)
+    shape = oe.get('shape', 'rect')
+    if shape.startswith('re'):
+        if surfOptX is not None:
+            locState[((surfPhysX[0] <= x) & (x < surfOptX[0])) |
+                     ((surfOptX[1] <= x) & (x < surfPhysX[1]))] = 2
+        if surfOptY is not None:
+            locState[((surfPhysY[0] <= y) & (y < surfOptY[0])) |
+                     ((surfOptY[1] <= y) & (y < surfPhysY[1]))] = 2
+        ovE = str(oe.get('overEdge', 'yMax')).lower()
+        outside = (x < surfPhysX[0]) | (x > surfPhysX[1]) |\
+            (y < surfPhysY[0]) | (y > surfPhysY[1])
+        over = np.zeros_like(outside)
+        if 'xmin' in ovE:
+            over |= x < surfPhysX[0]
+        if 'xmax' in ovE:
+            over |= x > surfPhysX[1]
+        if 'ymin' in ovE:
+            over |= y < surfPhysY[0]
+        if 'ymax' in ovE:
+            over |= y > surfPhysY[1]
+        locState[outside] = lostNum
+        locState[over] = 3
+    elif shape.startswith('ro'):
+        centerX = (surfPhysX[0]+surfPhysX[1]) * 0.5
+        if np.isnan(centerX):
+            centerX = 0
+        radiusX = (surfPhysX[1]-surfPhysX[0]) * 0.5
+        if surfPhysY is not None:
+            centerY = (surfPhysY[0]+surfPhysY[1]) * 0.5
+            radiusY = (surfPhysY[1]-surfPhysY[0]) * 0.5
+        else:
+            centerY = 0.
+            radiusY = radiusX
+        if np.isnan(centerY):
+            centerY = 0
+        if not np.isinf(radiusX):
+            locState[((x-centerX)/radiusX)**2 +
+                     ((y-centerY)/radiusY)**2 > 1] = lostNum
+    else:
+        raise ValueError('unsupported shape')
+    return locState
+
+
+# --------------------------------------------------------------------------
+# crystal-as-grating deflection (reflect.py:451-469, 568-612)
+# --------------------------------------------------------------------------
+def grating_deflection(a, b, c, E, g, oeNormal, beamInDotNormal, order, sig):
+    beamInDotG = a*g[0] + b*g[1] + c*g[2]
+    G2 = g[0]**2 + g[1]**2 + g[2]**2
+    orderLambda = order * CH / E * 1e-7
+    u = beamInDotNormal**2 - 2*beamInDotG*orderLambda - G2*orderLambda**2
+    gs = np.sign(beamInDotNormal) if sig is None else sig
+    dn = beamInDotNormal + gs*np.sqrt(abs(u))
+    a_out = a - oeNormal[-3]*dn + g[0]*orderLambda
+    b_out = b - oeNormal[-2]*dn + g[1]*orderLambda
+    c_out = c - oeNormal[-1]*dn + g[2]*orderLambda
+    norm = (a_out**2 + b_out**2 + c_out**2)**0.5
+    return a_out/norm, b_out/norm, c_out/norm
+
+
+def asymmetric_reflection_grating(matSur, a, b, c, E, oeNormal,
+                                  beamInDotSurfaceNormal, beamInDotNormal):
+    normalDotSurfNormal = oeNormal[0]*oeNormal[-3] +\
+        oeNormal[1]*oeNormal[-2] + oeNormal[2]*oeNormal[-1]
+    bdn = beamInDotNormal.sum() / len(beamInDotNormal)
+    sgbdn = 1 if bdn < 0 else -1
+    wH = 0
+    crystd = matSur['d']
+    wHd = (1 + wH) / (crystd * 1e-7)
+    gNormalCryst = np.asarray((
+        (oeNormal[0]-normalDotSurfNormal*oeNormal[-3]) * wHd,
+        (oeNormal[1]-normalDotSurfNormal*oeNormal[-2]) * wHd,
+        (oeNormal[2]-normalDotSurfNormal*oeNormal[-1]) * wHd),
+        order='F') * sgbdn
+    sg = 1 if matSur['geom'].startswith('Laue') else -1
+    return grating_deflection(a, b, c, E, gNormalCryst, oeNormal,
+                              beamInDotSurfaceNormal, 1, sg)
+
+
+# --------------------------------------------------------------------------
+# the per-surface pipeline (reflect.py:551-1139)
+# --------------------------------------------------------------------------
+def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
+                  dz=None, surf=None, fromVacuum=True, material=None,
+                  is2ndXtal=False, noIntersectionSearch=False, info=None):
+    if surf is None:
+        surf = oe['surface']
+    rotSeq = oe.get('rotationSequence', 'RzRyRx')
+    extra = [oe.get(k, 0) for k in ('extraPitch', 'extraRoll', 'extraYaw')]
+    extraSeq = oe.get('extraRotationSequence', 'RzRyRx')
+    extraAnglesSign = 1.
+    if is2ndXtal:
+        rotate_beam(lb, good, roll=-np.pi)
+        extraAnglesSign = -1.
+    rotate_beam(lb, good, rotSeq, pitch=-pitch, roll=-roll, yaw=-yaw)
+    if extra[0] or extra[1] or extra[2]:
+        rotate_beam(lb, good, extraSeq, pitch=-extraAnglesSign*extra[0],
+                    roll=-extra[1], yaw=-extraAnglesSign*extra[2])
+    if dx:
+        lb.x[good] -= dx
+    if dy:
+        lb.y[good] -= dy
+    if dz:
+        lb.z[good] -= dz
+
+    if 'invertNormal' in oe:
+        invertNormal = oe['invertNormal']
+    else:
+        invertNormal = 1 if fromVacuum else -1
+
+    mainPart = lb.state[good] == 1
+    tMin = np.zeros_like(lb.x)
+    tMax = np.zeros_like(lb.x)
+    tMin[good], tMax[good] = bracket(
+        oe, lb.x[good], lb.y[good], lb.z[good], lb.a[good], lb.b[good],
+        lb.c[good], is2ndXtal, mainPart, info)
+    if info is not None:
+        info['tMin'] = tMin.copy()
+        info['tMax0'] = tMax.copy()
+
+    _lost = None
+    if noIntersectionSearch:
+        tMax[good] = 0.
+    else:
+        res = find_intersection(
+            surf, tMin[good], tMax[good], lb.x[good], lb.y[good], lb.z[good],
+            lb.a[good], lb.b[good], lb.c[good], invertNormal, info)
+        tMax[good], lb.x[good], lb.y[good], lb.z[good] = res[:4]
+        _lost = res[4]
+
+    lb.state[good] = rays_good(oe, lb.x[good], lb.y[good], is2ndXtal)
+    if _lost is not None:
+        lb.state[np.where(good)[0][_lost]] = oe['lostNum']
+
+    goodN = (lb.state == 1)
+    goodNsum = goodN.sum()
+    if goodNsum > 0:
+        lb.path[goodN] += tMax[goodN]
+        toWhere = 0
+        matSur = material
+        kind = None
+        if material is not None:
+            kind = matSur['kind']
+            if kind in ('plate', 'lens'):
+                toWhere = 1
+            elif kind == 'crystal':
+                if matSur['geom'].endswith('transmitted'):
+                    toWhere = 2
+            elif kind not in ('mirror', 'thin mirror'):
+                raise ValueError('unsupported material kind ' + kind)
+
+        oeNormal = list(local_n(surf, lb.x[goodN], lb.y[goodN]))
+        isAsymmetric = len(oeNormal) == 6
+        oeNormal = np.asarray(
+            [np.broadcast_to(np.asarray(v, dtype=float), lb.x[goodN].shape)
+             for v in oeNormal], order='F')
+        beamInDotNormal = lb.a[goodN]*oeNormal[0] +\
+            lb.b[goodN]*oeNormal[1] + lb.c[goodN]*oeNormal[2]
+        lb.theta = np.zeros_like(lb.x)
+        beamInDotNormal[beamInDotNormal < -1] = -1
+        beamInDotNormal[beamInDotNormal > 1] = 1
+        lb.theta[goodN] = np.arccos(beamInDotNormal) - np.pi/2
+        if isAsymmetric:
+            beamInDotSurfaceNormal = lb.a[goodN]*oeNormal[-3] +\
+                lb.b[goodN]*oeNormal[-2] + lb.c[goodN]*oeNormal[-1]
+        else:
+            beamInDotSurfaceNormal = beamInDotNormal
+
+        if toWhere in (0, 2):
+            if kind == 'crystal' and toWhere == 0:
+                a_out, b_out, c_out = asymmetric_reflection_grating(
+                    matSur, lb.a[goodN], lb.b[goodN], lb.c[goodN], lb.E[goodN],
+                    oeNormal, beamInDotSurfaceNormal, beamInDotNormal)
+            else:
+                a_out = lb.a[goodN] - oeNormal[0]*2*beamInDotNormal
+                b_out = lb.b[goodN] - oeNormal[1]*2*beamInDotNormal
+                c_out = lb.c[goodN] - oeNormal[2]*2*beamInDotNormal
+            if toWhere == 0:
+                lb.a[goodN] = a_out
+                lb.b[goodN] = b_out
+                lb.c[goodN] = c_out
+        elif toWhere == 1:                        # reflect.py:894-919
+            refractive_index = mat.refractive_index(matSur, lb.E[goodN]).real
+            if fromVacuum:
+                n1overn2 = 1. / refractive_index
+            else:
+                n1overn2 = refractive_index
+            signN = np.sign(-beamInDotNormal)
+            n1overn2cosTheta1 = -n1overn2 * beamInDotNormal
+            cosTheta2 = signN * \
+                np.sqrt(1 - n1overn2**2 + n1overn2cosTheta1**2)
+            dn = (n1overn2cosTheta1 - cosTheta2)
+            lb.a[goodN] = lb.a[goodN] * n1overn2 + oeNormal[0]*dn
+            lb.b[goodN] = lb.b[goodN] * n1overn2 + oeNormal[1]*dn
+            lb.c[goodN] = lb.c[goodN] * n1overn2 + oeNormal[2]*dn
+
+        rollAngle = roll + np.arctan2(oeNormal[-3], oeNormal[-1])
+        localJ = rotate_coherency_matrix(lb, goodN, -rollAngle)
+        if hasattr(lb, 'Es'):
+            cosY, sinY = np.cos(rollAngle), np.sin(rollAngle)
+            lb.Es[goodN], lb.Ep[goodN] = rotate_y(
+                lb.Es[goodN], lb.Ep[goodN], cosY, -sinY)
+
+        if material is not None:
+            if kind == 'crystal':
+                beamOutDotSurfaceNormal = a_out*oeNormal[-3] + \
+                    b_out*oeNormal[-2] + c_out*oeNormal[-1]
+                refl = mat.crystal_amplitude(
+                    matSur, lb.E[goodN], beamInDotSurfaceNormal,
+                    beamOutDotSurfaceNormal, beamInDotNormal)
+            else:
+                refl = mat.material_amplitude(
+                    matSur, lb.E[goodN], beamInDotNormal, fromVacuum)
+        else:
+            refl = 1., 1.
+        ras, rap = refl[0], refl[1]
+        if isinstance(ras, np.ndarray):
+            ras[np.isnan(ras)] = 0.
+            rap[np.isnan(rap)] = 0.
+
+        lb.Jss[goodN] = (localJ[0] * ras * np.conjugate(ras)).real
+        lb.Jpp[goodN] = (localJ[1] * rap * np.conjugate(rap)).real
+        lb.Jsp[goodN] = localJ[2] * ras * np.conjugate(rap)
+        if hasattr(lb, 'Es'):
+            lb.Es[goodN] *= ras
+            lb.Ep[goodN] *= rap
+
+        if (not fromVacuum) and material is not None and kind != 'crystal':
+            att = np.exp(-refl[2] * tMax[goodN] * 0.1)
+            lb.Jss[goodN] *= att
+            lb.Jpp[goodN] *= att
+            lb.Jsp[goodN] *= att
+            if hasattr(lb, 'Es'):
+                mPh = att**0.5 * np.exp(0.1j * refl[3] * tMax[goodN])
+                lb.Es[goodN] *= mPh
+                lb.Ep[goodN] *= mPh
+        else:
+            if hasattr(lb, 'Es'):
+                mPh = np.exp(1e7j * lb.E[goodN]/CHBAR * tMax[goodN])
+                lb.Es[goodN] *= mPh
+                lb.Ep[goodN] *= mPh
+
+        vlb.Jss[goodN], vlb.Jpp[goodN], vlb.Jsp[goodN] =\
+            rotate_coherency_matrix(lb, goodN, rollAngle)
+        if hasattr(lb, 'Es'):
+            vlb.Es[goodN], vlb.Ep[goodN] = rotate_y(
+                lb.Es[goodN], lb.Ep[goodN], cosY, sinY)
+
+    if vlb is not lb:
+        copy_beam(vlb, lb, good, includeState=True, includeJspEsp=False)
+    if dx:
+        vlb.x[good] += dx
+    if dy:
+        vlb.y[good] += dy
+    if dz:
+        vlb.z[good] += dz
+    if extra[0] or extra[1] or extra[2]:
+        rotate_beam(vlb, good, '-' + extraSeq, pitch=extraAnglesSign*extra[0],
+                    roll=extra[1], yaw=extraAnglesSign*extra[2])
+    rotate_beam(vlb, good, '-' + rotSeq, pitch=pitch, roll=roll, yaw=yaw)
+    if is2ndXtal:
+        rotate_beam(vlb, good, roll=np.pi)
+    if info is not None:
+        info['tMax'] = tMax
+
+
+def oe_reflect(oe, beam, noIntersectionSearch=False, createdByDiffract=False,
+               info=None):
+    """OE.reflect (reflect.py:18-163) -> (gb, lb)."""
+    gb = beam.copy()
+    lb = beam.copy()
+    good = beam.state > 0
+    if good.sum() == 0:
+        return gb, lb
+    pitch = oe['pitch']
+    global_to_virgin_local(oe['azimuth_sc'], beam, lb, oe['center'], good)
+    reflect_local(oe, good, lb, gb, pitch, oe['roll'] + oe['positionRoll'],
+                  oe['yaw'], oe.get('dx', 0),
+                  noIntersectionSearch=noIntersectionSearch,
+                  material=oe.get('material'), info=info)
+    if createdByDiffract:
+        goodAfter = gb.state == 1
+    else:
+        goodAfter = (gb.state == 1) | (gb.state == 2)
+    if goodAfter.sum() > 0:
+        virgin_local_to_global(oe['azimuth_sc'], gb, oe['center'], goodAfter)
+    notGood = ~goodAfter
+    if notGood.sum() > 0:
+        copy_beam(gb, beam, notGood)
+    return gb, lb
+
+
+def dcm_double_reflect(oe, beam, fromVacuum1=True, fromVacuum2=True,
+                       is_plate=False, info=None):
+    """DCM.double_reflect (dcm.py:248-354) -> (gb2, lo1, lo2)."""
+    gb = beam.copy()
+    lo1 = beam.copy()
+    good1 = beam.state > 0
+    if good1.sum() == 0:
+        return gb, lo1, lo1
+    global_to_virgin_local(oe['azimuth_sc'], beam, lo1, oe['center'], good1)
+    i1 = {} if info is not None else None
+    reflect_local(
+        oe, good1, lo1, gb, oe['pitch'] + oe['bragg'],
+        oe['roll'] + oe['positionRoll'] + oe['cryst1roll'], oe['yaw'],
+        oe.get('dx', 0), surf=oe['surface'], fromVacuum=fromVacuum1,
+        material=oe.get('material'), info=i1)
+    goodAfter1 = (gb.state == 1) | (gb.state == 2)
+    notGood = ~goodAfter1
+    if notGood.sum() > 0:
+        copy_beam(gb, beam, notGood)
+    gb2 = gb.copy()
+    lo2 = gb2.copy()
+    good2 = goodAfter1
+    if (~good2).sum() > 0:
+        lo2.state[~good2] = 0
+        lo2.x[~good2] = 0.
+        lo2.y[~good2] = 0.
+        lo2.z[~good2] = 0.
+    if is_plate:
+        gb2.state[~good2] = oe['lostNum']
+    if good2.sum() == 0:
+        return gb2, lo1, lo2
+    i2 = {} if info is not None else None
+    reflect_local(
+        oe, good2, lo2, gb2,
+        -oe['pitch'] - oe['bragg'] + oe['cryst2pitch'] + oe['cryst2finePitch'],
+        oe['roll'] + oe['cryst2roll'] + oe['positionRoll'], -oe['yaw'],
+        -oe.get('dx', 0), oe['cryst2longTransl'], -oe['cryst2perpTransl'],
+        surf=oe['surface2'], fromVacuum=fromVacuum2,
+        material=oe.get('material2'), is2ndXtal=True, info=i2)
+    goodAfter2 = (gb2.state == 1) | (gb2.state == 2)
+    virgin_local_to_global(oe['azimuth_sc'], gb2, oe['center'], goodAfter2)
+    notGood = ~goodAfter2
+    if is_plate:
+        gb2.state[notGood] = oe['lostNum']
+    if notGood.sum() > 0:
+        copy_beam(gb2, beam, notGood)
+    if info is not None:
+        info['crystal1'] = i1
+        info['crystal2'] = i2
+    return gb2, lo1, lo2

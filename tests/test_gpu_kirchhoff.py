@@ -63,7 +63,7 @@ def test_sqrt_is_correctly_rounded_and_rinv_accurate():
     r = r.cpu().numpy()
     ri = ri.cpu().numpy()
     assert np.array_equal(r, np.sqrt(x))           # IEEE: numpy sqrt is correctly rounded
-    assert np.abs(ri * np.sqrt(x) - 1).max() < 5e-16
+    assert np.abs(ri * np.sqrt(x) - 1).max() < 1e-14   # one Goldschmidt step on v_rsq_f64
 
 
 def test_sincos_of_large_phases():
