@@ -1,0 +1,65 @@
+"""TEST INFRASTRUCTURE ONLY — turns the committed golden files
+(tests/golden/g2_*.npz, g3_dcm_*.npz) back into oracle parameter dictionaries and
+Beam records. The configurations mirror oracle/gen_fixtures_p1.py."""
+import os
+
+import numpy as np
+
+from . import materials_np as mn
+from . import reflect_np as rn
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                      'tests', 'golden')
+
+
+def tables():
+    return np.load(os.path.join(GOLDEN, 'g6_element_tables.npz'))
+
+
+def _unflatten(g):
+    p = {}
+    for key in g.files:
+        if not key.startswith('oe_'):
+            continue
+        v = g[key]
+        name = key[3:]
+        if v.dtype.kind in 'US':
+            p[name] = str(v)
+        elif v.ndim == 0:
+            p[name] = None if np.isnan(v) else float(v)
+        else:
+            p[name] = [float(t) for t in v]
+    p['azimuth_sc'] = tuple(p['azimuth_sc'])
+    p['lostNum'] = int(p['lostNum'])
+    return p
+
+
+def load_case(name):
+    """-> (params, beam_in, golden npz)."""
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    tb = tables()
+    p = _unflatten(g)
+    if name == 'g2_toroid_pt':
+        p['surface'] = dict(kind='toroid', R=float(g['surf_R']), r=float(g['surf_r']))
+        p['material'] = mn.make_material([mn.load_element(tb, 'Pt')], None,
+                                         'mirror', float(g['mat_rho']))
+    elif name == 'g2_flat_general':
+        p['surface'] = dict(kind='flat')
+        p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,
+                                         'thin mirror', float(g['mat_rho']),
+                                         float(g['mat_t']))
+    elif name == 'g2_toroid_brent':
+        p['surface'] = dict(kind='toroid', R=float(g['surf_R']), r=float(g['surf_r']))
+        p['material'] = None
+    elif name.startswith('g3_dcm'):
+        alpha = float(g['alpha'])
+        p['surface'] = dict(kind='flat', alpha=alpha)
+        p['surface2'] = dict(kind='flat', alpha=alpha, flip_n_y=True)
+        si = mn.load_element(tb, 'Si')
+        for key in ('material', 'material2'):
+            p[key] = mn.make_crystal(si, (1, 1, 1), float(g['cr_d']), 'diamond',
+                                     'Bragg reflected', None, 1., float(g['cr_V']))
+            assert p[key]['chiToF'] == float(g['cr_chiToF'])
+    else:
+        raise KeyError(name)
+    return p, rn.Beam.from_dict(g, 'in_'), g

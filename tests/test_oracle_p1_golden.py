@@ -1,0 +1,115 @@
+"""CPU: the numpy restatement of the ray-surface hot path (oracle/reflect_np.py,
+oracle/materials_np.py) against golden vectors produced by the imported
+reference (oracle/gen_fixtures_p1.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fixture_io, materials_np as mn, reflect_np as rn
+
+BEAM_TOL = 1e-13
+
+
+def check_beam(mine, g, prefix):
+    for f in mine.fields():
+        if prefix + f not in g.files:
+            continue
+        m = getattr(mine, f)
+        r = g[prefix + f]
+        if f == 'state':
+            assert np.array_equal(m, r), f
+        else:
+            scale = max(np.abs(r).max(), 1e-300)
+            assert np.abs(m - r).max() <= BEAM_TOL * scale, (prefix, f)
+
+
+@pytest.mark.parametrize('name', ['g2_toroid_pt', 'g2_flat_general',
+                                  'g2_toroid_brent'])
+def test_oe_reflect_matches_reference(name):
+    p, beam, g = fixture_io.load_case(name)
+    info = {}
+    gb, lb = rn.oe_reflect(p, beam, info=info)
+    check_beam(gb, g, 'gb_')
+    check_beam(lb, g, 'lb_')
+    assert np.allclose(lb.theta, g['lb_theta'], rtol=0, atol=1e-15)
+    assert bool(g['brent']) == info['brent']
+    assert int(g['numit']) == info['numit']
+    assert int(g['axis']) == info['axis']
+    good = g['in_state'] > 0
+    assert np.array_equal(info['tMin'][good], g['tMin'][good])
+    assert np.array_equal(info['tMax'][good], g['tMax'][good])
+
+
+@pytest.mark.parametrize('name', ['g3_dcm_si111', 'g3_dcm_si111_asym'])
+def test_dcm_double_reflect_matches_reference(name):
+    p, beam, g = fixture_io.load_case(name)
+    gb2, lo1, lo2 = rn.dcm_double_reflect(p, beam)
+    check_beam(gb2, g, 'gb_')
+    check_beam(lo1, g, 'lo1_')
+    check_beam(lo2, g, 'lo2_')
+
+
+def test_edge_rays_are_present_in_toroid_fixture():
+    """The fixture must exercise lost / over / out / untouched rays."""
+    _, _, g = fixture_io.load_case('g2_toroid_pt')
+    st = set(np.unique(g['lb_state']).tolist())
+    assert {1, 3, -1, 0} <= st
+    assert g['gb_state'][7] == -1 and g['gb_x'][7] == g['in_x'][7]
+
+
+def test_material_grid(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g5_material_grid.npz'))
+    tb = fixture_io.tables()
+    el = lambda s: mn.load_element(tb, s)  # noqa: E731
+    mats = dict(
+        Pt=mn.make_material([el('Pt')], None, 'mirror', 21.45),
+        Rh=mn.make_material([el('Rh')], None, 'mirror', 12.41),
+        Si=mn.make_material([el('Si')], None, 'mirror', 2.33),
+        SiO2=mn.make_material([el('Si'), el('O')], [1, 2], 'mirror', 2.2),
+        PtThin=mn.make_material([el('Pt')], None, 'thin mirror', 21.45, 30e-6),
+        SiPlate=mn.make_material([el('Si')], None, 'plate', 2.33))
+    for name, m in mats.items():
+        assert np.allclose(mn.refractive_index(m, g['Egrid']), g[name + '_n'],
+                           rtol=1e-15, atol=0)
+        for d, fv in (('in', True), ('out', False)):
+            key = '%s_%s' % (name, d)
+            if key + '_rs' not in g.files:
+                continue
+            res = mn.material_amplitude(m, g['E'].copy(), g[key + '_bdn'].copy(), fv)
+            for i, lab in enumerate(('rs', 'rp', 'mu', 'nk')):
+                assert np.allclose(res[i], g[key + '_' + lab], rtol=1e-14, atol=0)
+
+
+def test_rocking_curves(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g3_rocking_curves.npz'))
+    si = mn.load_element(fixture_io.tables(), 'Si')
+    keys = sorted(k[:-3] for k in g.files if k.endswith('_in'))
+    assert len(keys) == 2 * 3 * (1 + 4 * 2)
+    for key in keys:
+        hkl = tuple(int(c) for c in key[2:5])
+        geom = 'Bragg' if 'Bragg' in key else 'Laue'
+        geom += ' transmitted' if 'transmitted' in key else ' reflected'
+        d, V, chiToF, t = g[key + '_par']
+        cr = mn.make_crystal(si, hkl, d, 'diamond', geom,
+                             None if np.isnan(t) else t, 1., V)
+        E, g0, gh, hns = g[key + '_in']
+        S, P = mn.crystal_amplitude(cr, E.copy(), g0.copy(), gh.copy(), hns.copy())
+        for mine, ref in ((S, g[key + '_S']), (P, g[key + '_P'])):
+            fin = np.isfinite(ref)
+            assert np.array_equal(fin, np.isfinite(mine))
+            assert np.abs(mine[fin] - ref[fin]).max() <= 1e-12 * np.abs(ref[fin]).max()
+
+
+def test_thick_bragg_peak_reflectivity_is_physical(golden_dir):
+    """Loose known-answer pin (the reference's XOP curves pin |R|^2 only at
+    percent level, tests/raycing/test_materials.py:239-349): Si(111) at 9 keV,
+    symmetric thick Bragg: peak |R_s|^2 ~ 0.95, Darwin width ~ 25-35 urad."""
+    g = np.load(os.path.join(golden_dir, 'g3_rocking_curves.npz'))
+    S = g['Si111_Braggreflected_thick_+0_S']
+    E, g0, gh, hns = g['Si111_Braggreflected_thick_+0_in']
+    R = np.abs(S)**2
+    assert 0.9 < R.max() < 1.0
+    theta = -np.arcsin(hns)
+    width = np.ptp(theta[R > 0.5 * R.max()])
+    assert 20e-6 < width < 40e-6
