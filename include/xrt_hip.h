@@ -92,6 +92,157 @@ XRT_HIP_API int xrt_hip_kirchhoff_f64(
     const double* nrm_xyzw, int convention, double* S_ri, double* P_ri,
     double* A_ri, double* B_ri, double* C_ri, float* kernel_ms);
 
+
+/* ---- P1: ray-surface intersection + reflect / refract amplitudes ---------
+ * One call = one pass of OE._reflect_local (oes/reflect.py:551-1139) over a
+ * device-resident beam, including the global<->local transforms that
+ * OE.reflect (reflect.py:104-134) and DCM.double_reflect (dcm.py:270-335) wrap
+ * around it. All angles arrive as host-computed cos/sin (the reference also
+ * takes np.cos/np.sin of the scalar angle, _rotate.py:48-50).               */
+
+/* SoA ray record, sources/beams.py:153-182. Jsp, Es, Ep: interleaved (re,im).
+ * Es/Ep may both be NULL (beam without field amplitudes). */
+typedef struct xrt_hip_beam {
+  int64_t n;
+  double *x, *y, *z, *a, *b, *c, *path, *E, *Jss, *Jpp, *Jsp_ri;
+  int32_t* state;
+  double *Es_ri, *Ep_ri;
+} xrt_hip_beam;
+
+#define XRT_HIP_MAX_ROT 8
+/* Sequence of plane rotations as rotate_beam applies them (_rotate.py:23-57):
+ * axis 0 = x (pitch), 1 = y (roll), 2 = z (yaw); zero angles are left out. */
+typedef struct xrt_hip_rotation {
+  int32_t n;
+  int32_t axis[XRT_HIP_MAX_ROT];
+  double cosa[XRT_HIP_MAX_ROT];
+  double sina[XRT_HIP_MAX_ROT];
+} xrt_hip_rotation;
+
+#define XRT_HIP_SURF_FLAT 0
+#define XRT_HIP_SURF_TOROID 1
+#define XRT_HIP_SHAPE_RECT 0
+#define XRT_HIP_SHAPE_ROUND 1
+#define XRT_HIP_OVER_XMIN 1
+#define XRT_HIP_OVER_XMAX 2
+#define XRT_HIP_OVER_YMIN 4
+#define XRT_HIP_OVER_YMAX 8
+
+typedef struct xrt_hip_pass {
+  /* entering rays: 0 = state>0 (reflect.py:110), 1 = state in {1,2} (dcm.py:297) */
+  int32_t good_mode;
+  /* input frame: 1 = global (translate by -center, Rz by the beamline azimuth,
+   * beamline.py:230-252), 0 = already virgin local (2nd crystal of a DCM) */
+  int32_t in_is_global;
+  double center[3];
+  double sin_az, cos_az;
+  xrt_hip_rotation to_local;   /* reflect.py:617-629 */
+  xrt_hip_rotation to_virgin;  /* reflect.py:1122-1132 */
+  double shift[3];             /* dx, dy, dz subtracted in the local frame (:630-635) */
+  int32_t invert_normal;       /* +1 / -1 (:638-641) */
+  int32_t no_intersection_search;
+  /* surface */
+  int32_t surf_kind;
+  double surf_p[8];            /* toroid: R, r */
+  double n_const[6];           /* flat: [nH(3), n_surface(3)] (base.py:719-742) */
+  int32_t asymmetric;          /* 1: n_const holds two different normals */
+  /* limits, base.py:1094-1163 */
+  int32_t shape;
+  double phys_x[2], phys_y[2];
+  int32_t has_opt_x, has_opt_y;
+  double opt_x[2], opt_y[2];
+  int32_t over_mask;
+  int32_t lost_num;
+  double roll;                 /* roll (+positionRoll...) used for the coherency
+                                  rotation angle roll+atan2(nx,nz) (:948) */
+  /* output frame of the "global" beam */
+  int32_t out_to_global;       /* 1: virgin local -> global for rays ending in
+                                  state {1,2} (reflect.py:124-130) */
+  int32_t only_state1_out;     /* 1: only state 1 (beam createdByDiffract, :121-122) */
+  int32_t zero_local_not_entering; /* 1: dcm.py:298-303 (lo2 of rays that missed) */
+} xrt_hip_pass;
+
+#define XRT_HIP_MAT_NONE 0
+#define XRT_HIP_MAT_MIRROR 1
+#define XRT_HIP_MAT_THIN_MIRROR 2
+#define XRT_HIP_MAT_PLATE 3
+#define XRT_HIP_MAT_CRYSTAL 4
+#define XRT_HIP_MAX_ELEM 4
+
+typedef struct xrt_hip_material {
+  int32_t kind;
+  int32_t from_vacuum;
+  /* elements: Z, stoichiometric quantity, device pointers to the tabulated
+   * E, f1, f2 (element.py:252-263) */
+  int32_t nelem;
+  int32_t Z[XRT_HIP_MAX_ELEM];
+  int32_t tab_n[XRT_HIP_MAX_ELEM];
+  double quantity[XRT_HIP_MAX_ELEM];
+  const double* tab_E[XRT_HIP_MAX_ELEM];
+  const double* tab_f1[XRT_HIP_MAX_ELEM];
+  const double* tab_f2[XRT_HIP_MAX_ELEM];
+  double f0_hkl;               /* crystals: f0(sin(theta)/lambda = 1/2d) of element 0
+                                  (element.py:203-207), a per-crystal constant */
+  double d2f_re, d2f_im;       /* crystals: 1 + exp(i pi/2 (h+k+l)), crystals_basic.py:77 */
+  double rho, mass, t;         /* g/cm3, g/mol, thickness [mm] (thin mirror) */
+  /* crystal (crystal.py:150-226, crystals_basic.py) */
+  int32_t structure;           /* 0 fcc, 1 diamond */
+  int32_t hkl[3];
+  int32_t geom_bragg;          /* 1 Bragg, 0 Laue */
+  int32_t geom_transmitted;    /* 1 transmitted, 0 reflected */
+  int32_t thick;               /* 1: t is None (semi-infinite Bragg) */
+  double d, chi_to_f, fact_dw, t_crystal;
+} xrt_hip_material;
+
+/* Scratch needed by xrt_hip_reflect_pass_f64_dev for n rays. */
+XRT_HIP_API size_t xrt_hip_reflect_workspace_bytes(int64_t n);
+
+/* sizeof() of the structs above, to let a binding verify its layout:
+ * which = 0 beam, 1 rotation, 2 pass, 3 material, 4 screen. */
+XRT_HIP_API int xrt_hip_sizeof(int which);
+
+/* in: incoming beam. out_local: "lb" of the reference (true local frame).
+ * out_virgin: "gb"/"vlb" (virgin local or global, see xrt_hip_pass).
+ * restore: beam whose x..E,J are copied into out_virgin for rays that did not
+ * end in state {1,2} (reflect.py:131-134; dcm.py:330-335 passes the ORIGINAL
+ * beam here on the 2nd crystal); usually == in. theta (optional): lb.theta[n]
+ * (reflect.py:793-796). info_host (optional, 16 doubles, forces a sync):
+ * [0] bracketing axis, [1] first-ray sign, [2] brent?, [3] t1.min, [4] t2.max,
+ * [5] max|dz1|, [6] max|dz2|, [7] entering rays, [8] rays ending in state 1,
+ * [9] sum(beamInDotNormal over state 1). Asynchronous on `stream` otherwise. */
+XRT_HIP_API int xrt_hip_reflect_pass_f64_dev(
+    const xrt_hip_pass* pass, const xrt_hip_material* material,
+    const xrt_hip_beam* in, const xrt_hip_beam* restore, xrt_hip_beam* out_local,
+    xrt_hip_beam* out_virgin, double* theta, void* workspace,
+    size_t workspace_bytes, void* stream, double* info_host, float* kernel_ms);
+
+/* Stand-alone amplitude evaluation on device arrays (what the reference exposes
+ * as Material.get_amplitude(E, beamInDotNormal, fromVacuum) -> rs, rp, mu, n'k
+ * (materials/material.py:415-493) and Crystal.get_amplitude(E, beamInDotNormal,
+ * beamOutDotNormal, beamInDotHNormal) -> curveS, curveP (crystal.py:492-645)).
+ * rs/rp, S/P: complex interleaved [2n]; mu, nk: [n] (may be NULL). */
+XRT_HIP_API int xrt_hip_material_amplitude_f64_dev(
+    const xrt_hip_material* material, int64_t n, const double* E, const double* bdn,
+    double* rs_ri, double* rp_ri, double* mu, double* nk, void* stream);
+XRT_HIP_API int xrt_hip_crystal_amplitude_f64_dev(
+    const xrt_hip_material* material, int64_t n, const double* E, const double* gamma0,
+    const double* gammah, const double* hns, double* S_ri, double* P_ri, void* stream);
+
+/* ---- Screen.expose (screens.py:226-302) on a device-resident beam ---------
+ * ex, ey, ez: the screen's local axes in the global frame (beamline.py:288-316);
+ * lost_num = -ordinal-2000 (screens.py:77). */
+typedef struct xrt_hip_screen {
+  double center[3];
+  double ex[3], ey[3], ez[3];
+  double compress_x, compress_z; /* 0 = none */
+  int32_t lost_num;
+  int32_t only_positive_path;
+} xrt_hip_screen;
+
+XRT_HIP_API int xrt_hip_screen_expose_f64_dev(const xrt_hip_screen* screen,
+                                              const xrt_hip_beam* in, xrt_hip_beam* out,
+                                              void* stream);
+
 /* ---- building-block checks (used by the GPU tests only) ---------------- */
 XRT_HIP_API int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,
                                void* stream);

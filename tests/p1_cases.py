@@ -1,0 +1,148 @@
+"""Test helper: builds xrt_amd (product) optical elements and beams for the
+golden P1 configurations (mirrors oracle/gen_fixtures_p1.py and
+oracle/fixture_io.py, which build the reference / oracle versions)."""
+import os
+
+import numpy as np
+
+import xrt_amd.backends.raycing as raycing
+import xrt_amd.backends.raycing.materials as rm
+import xrt_amd.backends.raycing.oes as roe
+import xrt_amd.backends.raycing.sources as rs
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def product_beam(src, prefix='in_'):
+    """Beam from a golden npz (or any mapping of arrays)."""
+    n = len(src[prefix + 'x'])
+    b = rs.Beam(nrays=n, withAmplitudes=(prefix + 'Es') in src)
+    for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp',
+              'state'):
+        setattr(b, f, np.array(src[prefix + f]))
+    if (prefix + 'Es') in src:
+        b.Es = np.array(src[prefix + 'Es'])
+        b.Ep = np.array(src[prefix + 'Ep'])
+    return b
+
+
+def beam_from_oracle(ob):
+    b = rs.Beam(nrays=len(ob.x), withAmplitudes=hasattr(ob, 'Es'))
+    for f in ob.fields():
+        setattr(b, f, np.array(getattr(ob, f)))
+    return b
+
+
+def _pad_ordinal(bl, lostNum):
+    """The element's ordinal decides the 'lost' state value."""
+    class _Dummy(object):
+        pass
+    while len(bl.oes) < -int(lostNum) - 1:
+        bl.oes.append(_Dummy())
+
+
+def _az(g):
+    s, c = [float(v) for v in g['oe_azimuth_sc']]
+    return float(np.arctan2(s, c))
+
+
+def _opt(g, key):
+    v = g[key]
+    return None if v.ndim == 0 else [float(t) for t in v]
+
+
+def product_oe(name, g):
+    """-> the xrt_amd optical element for golden case *name*."""
+    bl = raycing.BeamLine(azimuth=_az(g))
+    # use the exact sin/cos the fixture was generated with
+    bl.sinAzimuth, bl.cosAzimuth = [float(v) for v in g['oe_azimuth_sc']]
+    _pad_ordinal(bl, g['oe_lostNum'])
+    common = dict(
+        center=[float(v) for v in g['oe_center']], pitch=float(g['oe_pitch']),
+        roll=float(g['oe_roll']), yaw=float(g['oe_yaw']),
+        positionRoll=float(g['oe_positionRoll']),
+        rotationSequence=str(g['oe_rotationSequence']),
+        extraPitch=float(g['oe_extraPitch']), extraRoll=float(g['oe_extraRoll']),
+        extraYaw=float(g['oe_extraYaw']),
+        extraRotationSequence=str(g['oe_extraRotationSequence']),
+        limPhysX=_opt(g, 'oe_surfPhysX'), limPhysY=_opt(g, 'oe_surfPhysY'),
+        limOptX=_opt(g, 'oe_surfOptX'), limOptY=_opt(g, 'oe_surfOptY'),
+        shape=str(g['oe_shape']), overEdge=str(g['oe_overEdge']))
+    if name == 'g2_toroid_pt':
+        m = rm.Material('Pt', rho=float(g['mat_rho']), kind='mirror')
+        oe = roe.ToroidMirror(bl, 'tm', R=float(g['surf_R']), r=float(g['surf_r']),
+                              material=m, **common)
+    elif name == 'g2_flat_general':
+        m = rm.Material('Rh', rho=float(g['mat_rho']), kind='thin mirror',
+                        t=float(g['mat_t']))
+        oe = roe.OE(bl, 'fm', material=m, **common)
+    elif name == 'g2_toroid_brent':
+        oe = roe.ToroidMirror(bl, 'tm2', R=float(g['surf_R']), r=float(g['surf_r']),
+                              material=None, **common)
+    elif name.startswith('g3_dcm'):
+        alpha = float(g['alpha'])
+        si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+        si2 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+        assert si1.d == float(g['cr_d']) and si1.chiToF == float(g['cr_chiToF'])
+        oe = roe.DCM(
+            bl, 'dcm', bragg=float(g['oe_bragg']), material=si1, material2=si2,
+            cryst1roll=float(g['oe_cryst1roll']), cryst2roll=float(g['oe_cryst2roll']),
+            cryst2pitch=float(g['oe_cryst2pitch']),
+            cryst2finePitch=float(g['oe_cryst2finePitch']),
+            cryst2perpTransl=float(g['oe_cryst2perpTransl']),
+            cryst2longTransl=float(g['oe_cryst2longTransl']),
+            limPhysX2=_opt(g, 'oe_surfPhysX2'), limPhysY2=_opt(g, 'oe_surfPhysY2'),
+            limOptX2=_opt(g, 'oe_surfOptX2'), limOptY2=_opt(g, 'oe_surfOptY2'),
+            alpha=alpha if alpha else None, **common)
+    else:
+        raise KeyError(name)
+    assert oe.lostNum == int(g['oe_lostNum'])
+    return oe
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def cfg2_toroid(bl=None):
+    """BASELINE cfg2: toroid mirror + Pt, SURVEY 8d."""
+    bl = bl or raycing.BeamLine()
+    p, q, pitch = 20000., 10000., 4e-3
+    m = rm.Material('Pt', rho=21.45, kind='mirror')
+    return roe.ToroidMirror(bl, 'tm', center=[0, p, 0], pitch=pitch, R=(p, q),
+                            r=(p, q), material=m, limPhysX=[-10, 10],
+                            limPhysY=[-300, 300])
+
+
+def cfg3_dcm(bl=None):
+    """BASELINE cfg3: Si(111) double-crystal monochromator, SURVEY 8d."""
+    bl = bl or raycing.BeamLine()
+    si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    si2 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    thB = float(si1.get_Bragg_angle(9000.) - si1.get_dtheta(9000.))
+    return roe.DCM(bl, 'dcm', center=[0, 20000., 0], bragg=thB, material=si1,
+                   material2=si2, cryst2perpTransl=10., limPhysX=[-10, 10],
+                   limPhysY=[-50, 50], limPhysX2=[-10, 10], limPhysY2=[-50, 150])
+
+
+def synthetic_rays(n, seed, sa=2e-4, sc=2e-5, E=(8990., 9010.), amplitudes=False):
+    """SURVEY 8d cfg2/cfg3 ray generator (numpy default_rng on the host)."""
+    rng = np.random.default_rng(seed)
+    b = rs.Beam(nrays=n, withAmplitudes=amplitudes)
+    b.x = rng.normal(0, 0.1, n)
+    b.z = rng.normal(0, 0.1, n)
+    b.y = np.zeros(n)
+    a = rng.normal(0, sa, n)
+    c = rng.normal(0, sc, n)
+    b.a = a
+    b.c = c
+    b.b = np.sqrt(1 - a**2 - c**2)
+    b.E = rng.uniform(E[0], E[1], n)
+    b.state = np.ones(n, dtype=np.int32)
+    b.Jss = np.ones(n)
+    b.Jpp = np.zeros(n)
+    b.Jsp = np.zeros(n, dtype=complex)
+    if amplitudes:
+        b.Es = np.ones(n, dtype=complex)
+        b.Ep = np.zeros(n, dtype=complex)
+    return b

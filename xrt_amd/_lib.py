@@ -32,6 +32,16 @@ SIGNATURES = {
     'xrt_hip_kirchhoff_f64': (ctypes.c_int, [
         ctypes.c_int, c_int_p, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp,
         ctypes.c_int, vp, vp, vp, vp, vp, c_float_p]),
+    'xrt_hip_reflect_workspace_bytes': (ctypes.c_size_t, [i64]),
+    'xrt_hip_sizeof': (ctypes.c_int, [ctypes.c_int]),
+    'xrt_hip_reflect_pass_f64_dev': (ctypes.c_int, [
+        vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, c_double_p,
+        c_float_p]),
+    'xrt_hip_material_amplitude_f64_dev': (ctypes.c_int, [
+        vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+    'xrt_hip_crystal_amplitude_f64_dev': (ctypes.c_int, [
+        vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+    'xrt_hip_screen_expose_f64_dev': (ctypes.c_int, [vp, vp, vp, vp]),
     'xrt_hip_debug_sqrt_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
     'xrt_hip_debug_sincos_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
 }
@@ -70,6 +80,12 @@ def load(build_if_missing=True):
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        from . import _structs
+        for which, st in enumerate(_structs.STRUCTS):
+            if lib.xrt_hip_sizeof(which) != ctypes.sizeof(st):
+                raise XrtHipError(
+                    'struct layout mismatch for %s: C %d B, ctypes %d B'
+                    % (st.__name__, lib.xrt_hip_sizeof(which), ctypes.sizeof(st)))
         _lib = lib
         return lib
 

@@ -1,0 +1,102 @@
+"""ctypes mirrors of the C structs in include/xrt_hip.h (layout checked against
+xrt_hip_sizeof at load time in hipcalls)."""
+import ctypes
+
+MAX_ROT = 8
+MAX_ELEM = 4
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+
+SURF_FLAT, SURF_TOROID = 0, 1
+SHAPE_RECT, SHAPE_ROUND = 0, 1
+OVER_XMIN, OVER_XMAX, OVER_YMIN, OVER_YMAX = 1, 2, 4, 8
+MAT_NONE, MAT_MIRROR, MAT_THIN_MIRROR, MAT_PLATE, MAT_CRYSTAL = 0, 1, 2, 3, 4
+
+
+class Beam(ctypes.Structure):
+    _fields_ = [('n', ctypes.c_int64)] + \
+        [(f, ctypes.c_void_p) for f in
+         ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp_ri',
+          'state', 'Es_ri', 'Ep_ri')]
+
+
+class Rotation(ctypes.Structure):
+    _fields_ = [('n', ctypes.c_int32),
+                ('axis', ctypes.c_int32 * MAX_ROT),
+                ('cosa', ctypes.c_double * MAX_ROT),
+                ('sina', ctypes.c_double * MAX_ROT)]
+
+
+class Pass(ctypes.Structure):
+    _fields_ = [
+        ('good_mode', ctypes.c_int32),
+        ('in_is_global', ctypes.c_int32),
+        ('center', ctypes.c_double * 3),
+        ('sin_az', ctypes.c_double),
+        ('cos_az', ctypes.c_double),
+        ('to_local', Rotation),
+        ('to_virgin', Rotation),
+        ('shift', ctypes.c_double * 3),
+        ('invert_normal', ctypes.c_int32),
+        ('no_intersection_search', ctypes.c_int32),
+        ('surf_kind', ctypes.c_int32),
+        ('surf_p', ctypes.c_double * 8),
+        ('n_const', ctypes.c_double * 6),
+        ('asymmetric', ctypes.c_int32),
+        ('shape', ctypes.c_int32),
+        ('phys_x', ctypes.c_double * 2),
+        ('phys_y', ctypes.c_double * 2),
+        ('has_opt_x', ctypes.c_int32),
+        ('has_opt_y', ctypes.c_int32),
+        ('opt_x', ctypes.c_double * 2),
+        ('opt_y', ctypes.c_double * 2),
+        ('over_mask', ctypes.c_int32),
+        ('lost_num', ctypes.c_int32),
+        ('roll', ctypes.c_double),
+        ('out_to_global', ctypes.c_int32),
+        ('only_state1_out', ctypes.c_int32),
+        ('zero_local_not_entering', ctypes.c_int32),
+    ]
+
+
+class Material(ctypes.Structure):
+    _fields_ = [
+        ('kind', ctypes.c_int32),
+        ('from_vacuum', ctypes.c_int32),
+        ('nelem', ctypes.c_int32),
+        ('Z', ctypes.c_int32 * MAX_ELEM),
+        ('tab_n', ctypes.c_int32 * MAX_ELEM),
+        ('quantity', ctypes.c_double * MAX_ELEM),
+        ('tab_E', ctypes.c_void_p * MAX_ELEM),
+        ('tab_f1', ctypes.c_void_p * MAX_ELEM),
+        ('tab_f2', ctypes.c_void_p * MAX_ELEM),
+        ('f0_hkl', ctypes.c_double),
+        ('d2f_re', ctypes.c_double),
+        ('d2f_im', ctypes.c_double),
+        ('rho', ctypes.c_double),
+        ('mass', ctypes.c_double),
+        ('t', ctypes.c_double),
+        ('structure', ctypes.c_int32),
+        ('hkl', ctypes.c_int32 * 3),
+        ('geom_bragg', ctypes.c_int32),
+        ('geom_transmitted', ctypes.c_int32),
+        ('thick', ctypes.c_int32),
+        ('d', ctypes.c_double),
+        ('chi_to_f', ctypes.c_double),
+        ('fact_dw', ctypes.c_double),
+        ('t_crystal', ctypes.c_double),
+    ]
+
+
+class Screen(ctypes.Structure):
+    _fields_ = [('center', ctypes.c_double * 3),
+                ('ex', ctypes.c_double * 3),
+                ('ey', ctypes.c_double * 3),
+                ('ez', ctypes.c_double * 3),
+                ('compress_x', ctypes.c_double),
+                ('compress_z', ctypes.c_double),
+                ('lost_num', ctypes.c_int32),
+                ('only_positive_path', ctypes.c_int32)]
+
+
+STRUCTS = (Beam, Rotation, Pass, Material, Screen)

@@ -1,0 +1,97 @@
+"""``RectangularAperture`` as a diffracting / receiving element of the wave
+path — host-side mirror of xrt/backends/raycing/apertures.py:29-499 restricted to
+what ``waves.diffract`` needs (blade geometry, local frame, ``prepare_wave``)."""
+import numpy as np
+
+from .. import raycing
+from . import sources as rs
+
+_BLADE_ORDER = ('left', 'right', 'bottom', 'top')
+
+
+class RectangularAperture(object):
+    def __init__(self, bl=None, name='', center=[0, 0, 0],
+                 kind=('left', 'right', 'bottom', 'top'),
+                 opening=(-10, 10, -10, 10), x='auto', z='auto', alarmLevel=None,
+                 blades=None, **kwargs):
+        self.bl = bl
+        if bl is not None:
+            if self not in bl.slits:
+                bl.slits.append(self)
+                self.ordinalNum = len(bl.slits)
+                self.lostNum = -self.ordinalNum - 1000     # apertures.py:80
+        else:
+            self.ordinalNum = 1
+            self.lostNum = -1001
+        self.name = name or 'Aperture{0}'.format(self.ordinalNum)
+        self.uuid = kwargs.get('uuid', raycing.new_uuid())
+        if bl is not None:
+            bl.oesDict[self.uuid] = [self, 1]
+        self.center = center
+        self.limOptX = [-raycing.maxHalfSizeOfOE, raycing.maxHalfSizeOfOE]
+        self.limOptY = [-raycing.maxHalfSizeOfOE, raycing.maxHalfSizeOfOE]
+        if blades is None:
+            kinds = [kind] if isinstance(kind, str) else list(kind)
+            opens = list(opening) if raycing.is_sequence(opening) else [opening]
+            blades = {k: v for k, v in zip(kinds, opens) if v is not None}
+        self.blades = {k: blades[k] for k in _BLADE_ORDER if k in blades}
+        for akind, d in self.blades.items():
+            td = float(d)
+            if akind.startswith('l'):
+                self.limOptX[0] = td
+            elif akind.startswith('r'):
+                self.limOptX[1] = td
+            elif akind.startswith('b'):
+                self.limOptY[0] = td
+            elif akind.startswith('t'):
+                self.limOptY[1] = td
+        self.isBeamStop = False
+        self.alarmLevel = alarmLevel
+        if isinstance(x, str):
+            x = None
+        if isinstance(z, str):
+            z = None
+        self.xyz = raycing.xyz_from_xz(self, x, z)
+        self.x, self.y, self.z = self.xyz
+
+    @property
+    def kind(self):
+        return list(self.blades.keys())
+
+    @property
+    def opening(self):
+        return list(self.blades.values())
+
+    def local_to_global(self, glo, **kwargs):
+        """apertures.py:436-457 on host arrays."""
+        x, y, z = glo.x, glo.y, glo.z
+        xglo = self.center[0] + x*self.x[0] + y*self.y[0] + z*self.z[0]
+        yglo = self.center[1] + x*self.x[1] + y*self.y[1] + z*self.z[1]
+        zglo = self.center[2] + x*self.x[2] + y*self.y[2] + z*self.z[2]
+        glo.x, glo.y, glo.z = xglo, yglo, zglo
+        a, b, c = glo.a, glo.b, glo.c
+        aglo = a*self.x[0] + b*self.y[0] + c*self.z[0]
+        bglo = a*self.x[1] + b*self.y[1] + c*self.z[1]
+        cglo = a*self.x[2] + b*self.y[2] + c*self.z[2]
+        glo.a, glo.b, glo.c = aglo, bglo, cglo
+
+    def prepare_wave(self, prevOE, nrays, rw=None):
+        """*nrays* samples uniformly random over the slit area
+        (apertures.py:467-499); uses the global np.random state like xrt."""
+        if rw is None:
+            from . import waves as rw
+        nrays = int(nrays)
+        wave = rs.Beam(nrays=nrays, forceState=1, withAmplitudes=True)
+        xy = np.random.rand(nrays, 2)
+        dX = self.limOptX[1] - self.limOptX[0]
+        dZ = self.limOptY[1] - self.limOptY[0]
+        wave.x[:] = xy[:, 0] * dX + self.limOptX[0]
+        wave.z[:] = xy[:, 1] * dZ + self.limOptY[0]
+        wave.area = dX * dZ
+        wave.dS = wave.area / nrays
+        wave.toOE = self
+        wave.parentId = self.uuid
+        glo = rs.Beam(copyFrom=wave)
+        self.local_to_global(glo)
+        rw.prepare_wave(prevOE, wave, glo.x, glo.y, glo.z)
+        return wave

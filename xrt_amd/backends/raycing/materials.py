@@ -1,0 +1,365 @@
+"""Materials on the accelerated path — host-side mirror of
+xrt/backends/raycing/materials/{element,material,crystal,crystals_basic}.py.
+
+The objects carry the parameters (tables, density, lattice constants ...); the
+amplitudes themselves — Fresnel rs/rp/ts/tp (material.py:415-493) and the
+Belyakov-Dmitrienko Bragg/Laue amplitudes (crystal.py:492-645) — are evaluated
+per ray inside the HIP kernels. ``get_amplitude`` / ``get_refractive_index``
+keep xrt's signatures and run the same device functions on arrays.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from ... import _lib, _structs
+from .physconsts import AVOGADRO, CH, CHBAR, PI, PI2, R0
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__)))), 'data', 'elements.npz')
+_tables = None
+
+elementsList = (
+    'none', 'H', 'He', 'Li', 'Be', 'B', 'C', 'N', 'O', 'F', 'Ne', 'Na', 'Mg',
+    'Al', 'Si', 'P', 'S', 'Cl', 'Ar', 'K', 'Ca', 'Sc', 'Ti', 'V', 'Cr', 'Mn',
+    'Fe', 'Co', 'Ni', 'Cu', 'Zn', 'Ga', 'Ge', 'As', 'Se', 'Br', 'Kr', 'Rb',
+    'Sr', 'Y', 'Zr', 'Nb', 'Mo', 'Tc', 'Ru', 'Rh', 'Pd', 'Ag', 'Cd', 'In',
+    'Sn', 'Sb', 'Te', 'I', 'Xe', 'Cs', 'Ba', 'La', 'Ce', 'Pr', 'Nd', 'Pm',
+    'Sm', 'Eu', 'Gd', 'Tb', 'Dy', 'Ho', 'Er', 'Tm', 'Yb', 'Lu', 'Hf', 'Ta',
+    'W', 'Re', 'Os', 'Ir', 'Pt', 'Au', 'Hg', 'Tl', 'Pb', 'Bi', 'Po', 'At',
+    'Rn', 'Fr', 'Ra', 'Ac', 'Th', 'Pa', 'U')
+
+
+def _load_tables():
+    global _tables
+    if _tables is None:
+        _tables = np.load(_DATA)
+    return _tables
+
+
+class Element(object):
+    """Chemical element with f0 coefficients and tabulated f1, f2
+    (element.py:76-263; table 'Chantler total' shipped in xrt_amd/data)."""
+
+    def __init__(self, elem=None, table='Chantler total'):
+        if isinstance(elem, str):
+            self.name = elem
+            self.Z = elementsList.index(elem)
+        elif isinstance(elem, (int, np.integer)):
+            self.name = elementsList[int(elem)]
+            self.Z = int(elem)
+        else:
+            raise NameError('Wrong chemical element')
+        if table != 'Chantler total':
+            raise ValueError("only the 'Chantler total' table is shipped")
+        self.table = table
+        tb = _load_tables()
+        if self.name + '_E' not in tb.files:
+            raise ValueError('no tabulated data for ' + self.name)
+        self.f0coeffs = [float(v) for v in tb[self.name + '_f0']]
+        self.mass = float(tb[self.name + '_mass'])
+        self.E = np.array(tb[self.name + '_E'], dtype=np.float64)
+        self.f1 = np.array(tb[self.name + '_f1'], dtype=np.float64)
+        self.f2 = np.array(tb[self.name + '_f2'], dtype=np.float64)
+        self._dev = {}
+
+    def get_f0(self, qOver4pi=0):
+        """Waasmaier-Kirfel f0 (element.py:203-207); a per-crystal constant on
+        this path, evaluated once on the host."""
+        return self.f0coeffs[5] + sum(
+            a * np.exp(-b * qOver4pi**2)
+            for a, b in zip(self.f0coeffs[:5], self.f0coeffs[6:]))
+
+    def device_tables(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = tuple(
+                torch.from_numpy(a).to(device) for a in (self.E, self.f1, self.f2))
+        return self._dev[key]
+
+
+_KINDS = {'mirror': _structs.MAT_MIRROR, 'thin mirror': _structs.MAT_THIN_MIRROR,
+          'plate': _structs.MAT_PLATE, 'lens': _structs.MAT_PLATE,
+          'crystal': _structs.MAT_CRYSTAL}
+
+
+def _dev_f64(a, device):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=device)
+
+
+class Material(object):
+    """Amorphous material given by its chemical formula and density
+    (material.py:23-157)."""
+
+    def __init__(self, elements=None, quantities=None, kind='auto', rho=0, t=None,
+                 table='Chantler total', name='', **kwargs):
+        if isinstance(elements, str):
+            elements = elements,
+        self.table = table
+        self.elements = [e if isinstance(e, Element) else Element(e, table)
+                         for e in (elements or ())]
+        if quantities is None:
+            self.quantities = [1. for _ in self.elements]
+        elif not isinstance(quantities, (list, tuple)):
+            self.quantities = [quantities]
+        else:
+            self.quantities = list(quantities)
+        if len(self.elements) > _structs.MAX_ELEM:
+            raise ValueError('at most %d elements per material' % _structs.MAX_ELEM)
+        self.kind = kind
+        self.rho = rho
+        self.t = t
+        self.geom = ''
+        self.mass = 0.
+        for elem, xi in zip(self.elements, self.quantities):
+            self.mass += xi * elem.mass
+        self.name = name or ''.join(e.name for e in self.elements)
+        self.uuid = kwargs.get('uuid')
+
+    # ---- struct for the kernels ---------------------------------------------
+    def _fill_elements(self, s, device):
+        keep = []
+        s.nelem = len(self.elements)
+        for i, (e, xi) in enumerate(zip(self.elements, self.quantities)):
+            tE, t1, t2 = e.device_tables(device)
+            keep += [tE, t1, t2]
+            s.Z[i] = e.Z
+            s.tab_n[i] = tE.numel()
+            s.quantity[i] = float(xi)
+            s.tab_E[i] = tE.data_ptr()
+            s.tab_f1[i] = t1.data_ptr()
+            s.tab_f2[i] = t2.data_ptr()
+        return keep
+
+    def to_struct(self, fromVacuum=True, device=None):
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        kind = 'mirror' if self.kind == 'auto' else self.kind
+        if kind not in _KINDS:
+            raise NotImplementedError('material kind %r is not on the GPU path' % kind)
+        s = _structs.Material()
+        s.kind = _KINDS[kind]
+        s.from_vacuum = 1 if fromVacuum else 0
+        s._keep = self._fill_elements(s, device)
+        s.rho = float(self.rho)
+        s.mass = float(self.mass)
+        s.t = float(self.t) if self.t is not None else 0.
+        if kind == 'thin mirror' and self.t is None:
+            raise ValueError('thin mirror needs a thickness t')
+        return s
+
+    # ---- xrt API, evaluated by the device functions ---------------------------
+    def get_amplitude(self, E, beamInDotNormal, fromVacuum=True):
+        """(rs, rp, mu [1/cm], Re(n) k [1/cm]) per ray, material.py:415-493."""
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        E = np.atleast_1d(np.asarray(E, dtype=np.float64))
+        bdn = np.broadcast_to(np.asarray(beamInDotNormal, dtype=np.float64),
+                              E.shape)
+        n = E.size
+        s = self.to_struct(fromVacuum, dev)
+        dE, db = _dev_f64(E, dev), _dev_f64(bdn, dev)
+        rs = torch.empty(n, dtype=torch.complex128, device=dev)
+        rp = torch.empty(n, dtype=torch.complex128, device=dev)
+        mu = torch.empty(n, dtype=torch.float64, device=dev)
+        nk = torch.empty(n, dtype=torch.float64, device=dev)
+        _lib.check(lib.xrt_hip_material_amplitude_f64_dev(
+            ctypes.byref(s), n, dE.data_ptr(), db.data_ptr(), rs.data_ptr(),
+            rp.data_ptr(), mu.data_ptr(), nk.data_ptr(),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            'xrt_hip_material_amplitude_f64_dev')
+        return (rs.cpu().numpy(), rp.cpu().numpy(), mu.cpu().numpy(),
+                nk.cpu().numpy())
+
+    def get_refractive_index(self, E):
+        """n(E) from (mu, Re(n) k) of the device function (material.py:348-378):
+        n = nk*CHBAR/(E*1e8) + i*mu*CHBAR/(E*2e8); sign of Im(n) as tabulated
+        (f2 > 0 -> Im(n) < 0)."""
+        E = np.atleast_1d(np.asarray(E, dtype=np.float64))
+        saved = self.kind
+        try:
+            if saved not in ('mirror', 'thin mirror', 'plate', 'lens'):
+                self.kind = 'mirror'
+            _, _, mu, nk = self.get_amplitude(E, -np.ones_like(E) * 0.5)
+        finally:
+            self.kind = saved
+        return nk * CHBAR / (E * 1e8) - 1j * mu * CHBAR / (E * 2e8)
+
+    def get_absorption_coefficient(self, E):
+        E = np.atleast_1d(np.asarray(E, dtype=np.float64))
+        return self.get_amplitude(E, -np.ones_like(E) * 0.5)[2]
+
+
+def parse_hkl(hkl):
+    return tuple(int(i) for i in hkl)
+
+
+class Crystal(Material):
+    """Perfect crystal (crystal.py:30-226): hkl, d spacing, unit-cell volume,
+    geometry 'Bragg|Laue reflected|transmitted', thickness t [mm] or None."""
+
+    structure = 0      # 0: fcc-like structure factor; 1: diamond
+
+    def __init__(self, hkl=(1, 1, 1), d=0, V=None, elements='Si', quantities=None,
+                 rho=0, t=None, factDW=1., geom='Bragg reflected',
+                 table='Chantler total', name='', **kwargs):
+        super(Crystal, self).__init__(elements, quantities, rho=rho, table=table,
+                                      name=name, **kwargs)
+        self.hkl = parse_hkl(hkl) if len(hkl) else (1, 1, 1)
+        self.sqrthkl2 = (sum(i**2 for i in self.hkl))**0.5
+        self.d = d
+        self.V = V if V is not None else (d * self.sqrthkl2)**3
+        self.chiToF = -R0 / PI / self.V          # crystal.py:201
+        self.chiToFd2 = abs(self.chiToF) * d**2
+        if len(geom) < 6:
+            geom = geom.strip() + ' reflected'
+        self.geom = geom
+        self.factDW = factDW
+        self.kind = 'crystal'
+        self.t = t
+        self.mosaicity = 0
+        self.useTT = False
+        self.volumetricDiffraction = False
+
+    def get_Bragg_angle(self, E, order=1):
+        a = order * CH / (2*self.d*np.asarray(E, dtype=float))
+        a = np.clip(a, -1 + 1e-16, 1 - 1e-16)
+        return np.arcsin(a)
+
+    def get_structure_factor_f0(self):
+        return self.elements[0].get_f0(0.5 / self.d)
+
+    def to_struct(self, fromVacuum=True, device=None):
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if self.mosaicity or self.useTT or self.volumetricDiffraction:
+            raise NotImplementedError('mosaic / bent (TT) / volumetric crystals '
+                                      'are outside the accelerated path')
+        if self.geom.endswith('Fresnel'):
+            raise NotImplementedError("'Fresnel' crystal geometry is not on the GPU path")
+        s = _structs.Material()
+        s.kind = _structs.MAT_CRYSTAL
+        s.from_vacuum = 1 if fromVacuum else 0
+        s._keep = self._fill_elements(s, device)
+        s.rho = float(self.rho)
+        s.mass = float(self.mass)
+        s.t = 0.
+        s.structure = int(self.structure)
+        for i in range(3):
+            s.hkl[i] = int(self.hkl[i])
+        s.geom_bragg = 1 if self.geom.startswith('Bragg') else 0
+        s.geom_transmitted = 1 if self.geom.endswith('transmitted') else 0
+        s.thick = 1 if self.t is None else 0
+        s.t_crystal = 0. if self.t is None else float(self.t)
+        s.d = float(self.d)
+        s.chi_to_f = float(self.chiToF)
+        s.fact_dw = float(self.factDW)
+        s.f0_hkl = float(self.get_structure_factor_f0())
+        d2f = 1 + np.exp(0.5j * PI * sum(self.hkl))   # crystals_basic.py:77
+        s.d2f_re = float(d2f.real)
+        s.d2f_im = float(d2f.imag)
+        return s
+
+    def get_amplitude(self, E, beamInDotNormal, beamOutDotNormal=None,
+                      beamInDotHNormal=None, xd=None, yd=None):
+        """(curveS, curveP) complex amplitudes per ray, crystal.py:492-645."""
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        E = np.atleast_1d(np.asarray(E, dtype=np.float64))
+        g0 = np.broadcast_to(np.asarray(beamInDotNormal, dtype=np.float64), E.shape)
+        gh = -g0 if beamOutDotNormal is None else np.broadcast_to(
+            np.asarray(beamOutDotNormal, dtype=np.float64), E.shape)
+        hn = g0 if beamInDotHNormal is None else np.broadcast_to(
+            np.asarray(beamInDotHNormal, dtype=np.float64), E.shape)
+        n = E.size
+        s = self.to_struct(True, dev)
+        S = torch.empty(n, dtype=torch.complex128, device=dev)
+        P = torch.empty(n, dtype=torch.complex128, device=dev)
+        args = [_dev_f64(a, dev) for a in (E, g0, gh, hn)]
+        _lib.check(lib.xrt_hip_crystal_amplitude_f64_dev(
+            ctypes.byref(s), n, *[a.data_ptr() for a in args], S.data_ptr(),
+            P.data_ptr(),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            'xrt_hip_crystal_amplitude_f64_dev')
+        return S.cpu().numpy(), P.cpu().numpy()
+
+    def get_dtheta_symmetric_Bragg(self, E):
+        """chi0 / sin(2 theta_B), crystal.py:1125-1139 (host scalar helper used
+        for alignment; needs only F0 = 8 or 4 (Z + f1 + i f2) at E)."""
+        E = np.atleast_1d(np.asarray(E, dtype=float))
+        e = self.elements[0]
+        f1 = np.interp(E, e.E, e.f1)
+        F0re = 4 * (e.Z + f1) * self.factDW * (2 if self.structure == 1 else 1)
+        chi0 = F0re * self.chiToF * (CH / E)**2
+        return chi0 / np.sin(2*self.get_Bragg_angle(E))
+
+    def get_dtheta(self, E, alpha=None):
+        """Refraction correction of the Bragg angle for an asymmetric cut,
+        crystal.py:1141-1171 (Authier eq. 8.3); alignment helper."""
+        if alpha is None:
+            alpha = 0
+        thetaB = self.get_Bragg_angle(E)
+        pm = -1 if self.geom.startswith('Bragg') else 1
+        gamma0 = np.sin(thetaB + alpha)
+        gammah = pm * np.sin(thetaB - alpha)
+        symm_dt = self.get_dtheta_symmetric_Bragg(E)
+        osqg0 = np.sqrt(1. - gamma0**2)
+        dtheta0 = (pm*gamma0 - pm*np.sqrt(gamma0**2 +
+                   pm*(gamma0 - gammah) * osqg0 * symm_dt)) / osqg0
+        return -dtheta0
+
+
+class CrystalFcc(Crystal):
+    structure = 0
+
+
+class CrystalDiamond(CrystalFcc):
+    structure = 1
+
+    def __init__(self, *args, **kwargs):
+        a = kwargs.pop('a', None)
+        if a is not None:
+            hkl = kwargs.get('hkl', args[0] if args else (1, 1, 1))
+            kwargs['d'] = a / (sum(i**2 for i in hkl))**0.5
+        kwargs.setdefault('name', 'Diamond')
+        super(CrystalDiamond, self).__init__(*args, **kwargs)
+        self.a = self.d * self.sqrthkl2
+
+
+class CrystalSi(CrystalDiamond):
+    """Silicon with the temperature-dependent lattice parameter of
+    crystals_basic.py:83-142 (Swenson's thermal expansion)."""
+
+    def __init__(self, *args, **kwargs):
+        self.a0 = 5.430710
+        self.tK = kwargs.pop('tK', 297.15)
+        hkl = kwargs.get('hkl', args[0] if args else (1, 1, 1))
+        kwargs.pop('a', None)
+        sqrthkl2 = (sum(i**2 for i in hkl))**0.5
+        kwargs['d'] = self.get_a() / sqrthkl2
+        kwargs['elements'] = 'Si'
+        kwargs['hkl'] = hkl
+        kwargs.setdefault('name', 'Si')
+        super(CrystalSi, self).__init__(*args[1:], **kwargs)
+
+    @staticmethod
+    def dl_l(t):
+        if t >= 0.0 and t < 30.0:
+            return -2.154537e-004
+        elif t >= 30.0 and t < 130.0:
+            return -2.303956e-014 * t**4 + 7.834799e-011 * t**3 - \
+                1.724143e-008 * t**2 + 8.396104e-007 * t - 2.276144e-004
+        elif t >= 130.0 and t < 293.0:
+            return -1.223001e-011 * t**3 + 1.532991e-008 * t**2 - \
+                3.263667e-006 * t - 5.217231e-005
+        elif t >= 293.0 and t <= 1000.0:
+            return -1.161022e-012 * t**3 + 3.311476e-009 * t**2 + \
+                1.124129e-006 * t - 5.844535e-004
+        else:
+            return 1.0e+100
+
+    def get_a(self):
+        return self.a0 * (self.dl_l(self.tK) - self.dl_l(273.15 + 19.9) + 1)

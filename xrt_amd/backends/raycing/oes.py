@@ -1,0 +1,466 @@
+"""Optical elements on the accelerated path — host-side mirror of
+xrt/backends/raycing/oes (OE: oes/base.py:61-330 + oes/reflect.py:18-163,
+ToroidMirror: oes/__init__.py:321-411, DCM: oes/dcm.py:12-354).
+
+The objects hold geometry and material; ``reflect`` / ``double_reflect`` build
+the parameter block of one ``_reflect_local`` pass (include/xrt_hip.h
+``xrt_hip_pass``) and launch the fused HIP kernels on device-resident beams.
+Same call signatures and return values (beamGlobal, beamLocal[, beamLocal2])
+as the reference. Outside the accelerated subset (figure error, gratings,
+parametric surfaces, mosaic/bent crystals, polygon shapes) a
+NotImplementedError is raised — there is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import raycing
+from ... import _lib, _structs, hipcalls
+from . import sources as rs
+
+
+def _limits(lim, default_half=raycing.maxHalfSizeOfOE):
+    if lim is None:
+        return None
+    return [float(lim[0]), float(lim[1])]
+
+
+class OE(object):
+    """Generic flat optical element (mirror, crystal, plate surface)."""
+
+    surf_kind = _structs.SURF_FLAT
+
+    def __init__(self, bl=None, name='', center=[0, 0, 0], pitch=0, roll=0, yaw=0,
+                 positionRoll=0, rotationSequence='RzRyRx', extraPitch=0,
+                 extraRoll=0, extraYaw=0, extraRotationSequence='RzRyRx',
+                 alarmLevel=None, surface=None, material=None, figureError=None,
+                 alpha=None,
+                 limPhysX=[-raycing.maxHalfSizeOfOE, raycing.maxHalfSizeOfOE],
+                 limOptX=None,
+                 limPhysY=[-raycing.maxHalfSizeOfOE, raycing.maxHalfSizeOfOE],
+                 limOptY=None, isParametric=False, shape='rect',
+                 gratingDensity=None, order=None, **kwargs):
+        if figureError is not None or isParametric or gratingDensity is not None:
+            raise NotImplementedError('figure error / parametric / grating OEs are '
+                                      'outside the accelerated path')
+        if not isinstance(shape, str):
+            raise NotImplementedError('polygon-shaped OEs are outside the '
+                                      'accelerated path')
+        self.bl = bl
+        if bl is not None:
+            if self not in bl.oes:
+                bl.oes.append(self)
+                self.ordinalNum = len(bl.oes)
+                self.lostNum = -self.ordinalNum
+        else:
+            self.ordinalNum = 1
+            self.lostNum = -1
+        self.name = name or '{0}{1}'.format(type(self).__name__, self.ordinalNum)
+        self.uuid = kwargs.get('uuid', raycing.new_uuid())
+        if bl is not None:
+            bl.oesDict[self.uuid] = [self, 1]
+        self.center = center
+        self.pitch = pitch
+        self.roll = roll
+        self.yaw = yaw
+        self.rotationSequence = rotationSequence
+        self.positionRoll = positionRoll
+        self.extraPitch = extraPitch
+        self.extraRoll = extraRoll
+        self.extraYaw = extraYaw
+        self.extraRotationSequence = extraRotationSequence
+        self.alarmLevel = alarmLevel
+        self.isParametric = False
+        self.shape = shape
+        self.overEdge = kwargs.get('overEdge', 'yMax')
+        self.surface = surface
+        self.material = material
+        self.alpha = alpha
+        self.curSurface = 0
+        self.dx = 0
+        self.limOptX = limOptX
+        self.limOptY = limOptY
+        self.limPhysX = limPhysX
+        self.limPhysY = limPhysY
+        self.order = order
+        self.footprint = []
+
+    # -- asymmetric cut ----------------------------------------------------
+    @property
+    def alpha(self):
+        return self._alpha
+
+    @alpha.setter
+    def alpha(self, alpha):
+        self._alpha = alpha
+        if alpha is not None:
+            self.cosalpha = float(np.cos(alpha))
+            self.sinalpha = float(np.sin(alpha))
+
+    # -- surface: flat (oes/base.py:675-742) ----------------------------------
+    def local_z(self, x, y):
+        return np.zeros_like(y)
+
+    def local_n(self, x, y):
+        a, b, c = 0., 0., 1.
+        if self.alpha:
+            bAlpha, cAlpha = raycing.rotate_x(b, c, self.cosalpha, -self.sinalpha)
+            return [a, bAlpha, cAlpha, a, b, c]
+        return [a, b, c]
+
+    def _surface_params(self, p, second=False):
+        p.surf_kind = _structs.SURF_FLAT
+        n = list(self.local_n2(0., 0.) if second else self.local_n(0., 0.))
+        if len(n) == 3:
+            n = n + n
+            p.asymmetric = 0
+        else:
+            p.asymmetric = 1
+        for i in range(6):
+            p.n_const[i] = float(n[i])
+
+    def local_n2(self, x, y):
+        return self.local_n(x, y)
+
+    # -- Coddington radii (oes/base.py:649-673) -------------------------------
+    def get_Rmer_from_Coddington(self, p, q, pitch=None):
+        if pitch is None:
+            pitch = self.pitch
+        return 2 * p * q / (p+q) / np.sin(abs(pitch))
+
+    def get_rsag_from_Coddington(self, p, q, pitch=None):
+        if pitch is None:
+            pitch = self.pitch
+        return 2 * p * q / (p+q) * np.sin(abs(pitch))
+
+    # -- the parameter block of one _reflect_local pass ------------------------
+    def _limits_for(self, second):
+        sfx = '2' if second else ''
+        return (getattr(self, 'limPhysX' + sfx), getattr(self, 'limPhysY' + sfx),
+                getattr(self, 'limOptX' + sfx, None),
+                getattr(self, 'limOptY' + sfx, None))
+
+    def _make_pass(self, pitch, roll, yaw, dx=0, dy=0, dz=0, fromVacuum=True,
+                   is2ndXtal=False, noIntersectionSearch=False, in_is_global=True,
+                   good_mode=0, out_to_global=True, only_state1_out=False,
+                   zero_local_not_entering=False):
+        p = _structs.Pass()
+        p.good_mode = good_mode
+        p.in_is_global = 1 if in_is_global else 0
+        for i in range(3):
+            p.center[i] = float(self.center[i])
+        p.sin_az = self.bl.sinAzimuth if self.bl is not None else 0.
+        p.cos_az = self.bl.cosAzimuth if self.bl is not None else 1.
+        # rotate the world around the element, reflect.py:617-629 ...
+        to_local = []
+        extraSign = 1.
+        if is2ndXtal:
+            to_local += raycing.rotation_steps(roll=-np.pi)
+            extraSign = -1.
+        to_local += raycing.rotation_steps(self.rotationSequence, pitch=-pitch,
+                                           roll=-roll, yaw=-yaw)
+        if self.extraPitch or self.extraRoll or self.extraYaw:
+            to_local += raycing.rotation_steps(
+                self.extraRotationSequence, pitch=-extraSign*self.extraPitch,
+                roll=-self.extraRoll, yaw=-extraSign*self.extraYaw)
+        # ... and back, reflect.py:1122-1132
+        to_virgin = []
+        if self.extraPitch or self.extraRoll or self.extraYaw:
+            to_virgin += raycing.rotation_steps(
+                '-' + self.extraRotationSequence, pitch=extraSign*self.extraPitch,
+                roll=self.extraRoll, yaw=extraSign*self.extraYaw)
+        to_virgin += raycing.rotation_steps('-' + self.rotationSequence,
+                                            pitch=pitch, roll=roll, yaw=yaw)
+        if is2ndXtal:
+            to_virgin += raycing.rotation_steps(roll=np.pi)
+        for rot, steps in ((p.to_local, to_local), (p.to_virgin, to_virgin)):
+            if len(steps) > _structs.MAX_ROT:
+                raise ValueError('too many rotation steps')
+            rot.n = len(steps)
+            for i, (ax, c, s) in enumerate(steps):
+                rot.axis[i] = ax
+                rot.cosa[i] = c
+                rot.sina[i] = s
+        p.shift[0] = float(dx or 0.)
+        p.shift[1] = float(dy or 0.)
+        p.shift[2] = float(dz or 0.)
+        if hasattr(self, 'invertNormal'):
+            p.invert_normal = int(self.invertNormal)
+        else:
+            p.invert_normal = 1 if fromVacuum else -1
+        p.no_intersection_search = 1 if noIntersectionSearch else 0
+        self._surface_params(p, is2ndXtal)
+        physX, physY, optX, optY = self._limits_for(is2ndXtal)
+        if self.shape.startswith('re'):
+            p.shape = _structs.SHAPE_RECT
+        elif self.shape.startswith('ro'):
+            p.shape = _structs.SHAPE_ROUND
+        else:
+            raise NotImplementedError('shape %r' % (self.shape,))
+        p.phys_x[0], p.phys_x[1] = float(physX[0]), float(physX[1])
+        p.phys_y[0], p.phys_y[1] = float(physY[0]), float(physY[1])
+        p.has_opt_x = 0 if optX is None else 1
+        p.has_opt_y = 0 if optY is None else 1
+        if optX is not None:
+            p.opt_x[0], p.opt_x[1] = float(optX[0]), float(optX[1])
+        if optY is not None:
+            p.opt_y[0], p.opt_y[1] = float(optY[0]), float(optY[1])
+        ovE = str(getattr(self, 'overEdge', 'yMax')).lower()
+        mask = 0
+        if 'xmin' in ovE:
+            mask |= _structs.OVER_XMIN
+        if 'xmax' in ovE:
+            mask |= _structs.OVER_XMAX
+        if 'ymin' in ovE:
+            mask |= _structs.OVER_YMIN
+        if 'ymax' in ovE:
+            mask |= _structs.OVER_YMAX
+        p.over_mask = mask
+        p.lost_num = int(self.lostNum)
+        p.roll = float(roll)
+        p.out_to_global = 1 if out_to_global else 0
+        p.only_state1_out = 1 if only_state1_out else 0
+        p.zero_local_not_entering = 1 if zero_local_not_entering else 0
+        return p
+
+    @staticmethod
+    def _material_struct(material, fromVacuum, device):
+        if material is None:
+            s = _structs.Material()
+            s.kind = _structs.MAT_NONE
+            s.from_vacuum = 1 if fromVacuum else 0
+            s._keep = []
+            return s
+        if raycing.is_sequence(material):
+            raise NotImplementedError('per-surface material lists')
+        return material.to_struct(fromVacuum, device)
+
+    def _run_pass(self, p, material, fromVacuum, beam_in, restore, want_info=False,
+                  timing=False):
+        """-> (lb, vlb) new device-resident beams (+ info dict)."""
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        ms = self._material_struct(material, fromVacuum, dev)
+        s_in = beam_in.to_struct(dev)
+        s_re = s_in if restore is beam_in else restore.to_struct(dev)
+        lb = rs.Beam.empty_like_on_device(beam_in, dev)
+        vb = rs.Beam.empty_like_on_device(beam_in, dev)
+        s_lb, s_vb = lb.to_struct(dev), vb.to_struct(dev)
+        n = beam_in.nrays
+        theta = torch.zeros(n, dtype=torch.float64, device=dev)
+        wsb = lib.xrt_hip_reflect_workspace_bytes(n)
+        ws = hipcalls.workspace(dev, wsb, 'reflect')
+        info = (ctypes.c_double * 16)() if want_info else None
+        ms_out = ctypes.c_float(0.) if timing else None
+        rc = lib.xrt_hip_reflect_pass_f64_dev(
+            ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in),
+            ctypes.byref(s_re), ctypes.byref(s_lb), ctypes.byref(s_vb),
+            ctypes.c_void_p(theta.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+            ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+            info, ctypes.byref(ms_out) if timing else None)
+        _lib.check(rc, 'xrt_hip_reflect_pass_f64_dev')
+        lb.theta = theta
+        for b in (lb, vb):
+            for k in rs._SCALAR_ATTRS:
+                if k in beam_in.__dict__:
+                    object.__setattr__(b, k, beam_in.__dict__[k])
+            if 'area' in beam_in.__dict__:      # copy_beam, beams.py:431-432
+                object.__setattr__(b, 'area', beam_in.__dict__['area'])
+            b.parentId = self.uuid
+        res_info = None
+        if want_info:
+            v = list(info)
+            res_info = dict(axis=int(v[0]), positive=bool(v[1]), brent=bool(v[2]),
+                            tMinGlobal=v[3], tMaxGlobal=v[4], maxdz1=v[5],
+                            maxdz2=v[6], n_enter=int(v[7]))
+        if timing:
+            res_info = res_info or {}
+            res_info['kernel_ms'] = ms_out.value
+        return lb, vb, res_info
+
+    # -- local -> global for a beam on the surface (oes/base.py:1165-1229) ------
+    def local_to_global(self, lb, returnBeam=False, is2ndXtal=False, **kwargs):
+        """Host-side (wave post-processing glue): *lb* in the true local frame
+        -> global frame, coherency matrix and amplitudes included."""
+        dx, dy, dz = 0, 0, 0
+        extraAnglesSign = 1.
+        if hasattr(self, 'cryst2pitch'):
+            if is2ndXtal:
+                pitch = -self.pitch - self.bragg + self.cryst2pitch +\
+                    self.cryst2finePitch
+                roll = self.roll + self.cryst2roll + self.positionRoll
+                yaw = -self.yaw
+                dx = -self.dx
+                dy = self.cryst2longTransl
+                dz = -self.cryst2perpTransl
+                extraAnglesSign = -1.
+            else:
+                pitch = self.pitch + self.bragg
+                roll = self.roll + self.positionRoll + self.cryst1roll
+                yaw = self.yaw
+                dx = self.dx
+        else:
+            pitch = self.pitch
+            roll = self.roll + self.positionRoll
+            yaw = self.yaw
+        if dx:
+            lb.x += dx
+        if dy:
+            lb.y += dy
+        if dz:
+            lb.z += dz
+        if self.extraPitch or self.extraRoll or self.extraYaw:
+            raycing.rotate_beam(
+                lb, rotationSequence='-'+self.extraRotationSequence,
+                pitch=extraAnglesSign*self.extraPitch, roll=self.extraRoll,
+                yaw=extraAnglesSign*self.extraYaw)
+        raycing.rotate_beam(lb, rotationSequence='-'+self.rotationSequence,
+                            pitch=pitch, roll=roll, yaw=yaw)
+        if hasattr(self, 'cryst2pitch') and is2ndXtal:
+            raycing.rotate_beam(lb, roll=np.pi)
+        oeNormal = list(self.local_n(lb.x, lb.y))
+        roll = self.roll + self.positionRoll +\
+            np.arctan2(oeNormal[-3], oeNormal[-1])
+        lb.Jss[:], lb.Jpp[:], lb.Jsp[:] =\
+            rs.rotate_coherency_matrix(lb, slice(None), roll)
+        if hasattr(lb, 'Es'):
+            cosY, sinY = np.cos(roll), np.sin(roll)
+            lb.Es[:], lb.Ep[:] = raycing.rotate_y(lb.Es, lb.Ep, cosY, sinY)
+        if returnBeam:
+            retGlo = rs.Beam(copyFrom=lb)
+            raycing.virgin_local_to_global(self.bl, retGlo, self.center)
+            return retGlo
+        raycing.virgin_local_to_global(self.bl, lb, self.center)
+
+    # -- OE.reflect, oes/reflect.py:18-163 ----------------------------------
+    def reflect(self, beam=None, needLocal=True, noIntersectionSearch=False,
+                returnLocalAbsorbed=None, _info=None):
+        pitch = self.pitch
+        if hasattr(self, 'bragg'):
+            pitch = pitch + self.bragg
+        p = self._make_pass(
+            pitch, self.roll + self.positionRoll, self.yaw, self.dx,
+            noIntersectionSearch=noIntersectionSearch,
+            only_state1_out=hasattr(beam, 'createdByDiffract'))
+        lb, gb, info = self._run_pass(p, self.material, True, beam, beam,
+                                      want_info=_info is not None)
+        if _info is not None:
+            _info.update(info)
+        return gb, lb
+
+
+class ToroidMirror(OE):
+    """Toroidal mirror: z = y^2/(2R) + r - sqrt(r^2 - x^2)
+    (oes/__init__.py:321-411). R and r may be (p, q) tuples for the Coddington
+    equations."""
+
+    def __init__(self, *args, **kwargs):
+        R = kwargs.pop('R', 5.0e6)
+        r = kwargs.pop('r', 50.)
+        OE.__init__(self, *args, **kwargs)
+        self.R = R
+        self.r = r
+
+    @property
+    def R(self):
+        return self._RVal
+
+    @R.setter
+    def R(self, R):
+        if isinstance(R, (list, tuple)):
+            self._RVal = self.get_Rmer_from_Coddington(*R)
+        elif R in [0, None]:
+            self._RVal = 1e100
+        else:
+            self._RVal = R
+
+    @property
+    def r(self):
+        return self._rVal
+
+    @r.setter
+    def r(self, r):
+        if isinstance(r, (list, tuple)):
+            self._rVal = self.get_rsag_from_Coddington(*r)
+        elif r in [0, None]:
+            self._rVal = 1e100
+        else:
+            self._rVal = r
+
+    def local_z(self, x, y):
+        rx = 1 - (np.asarray(x)/self.r)**2
+        rx[rx < 0] = 0.
+        return y**2/2.0/self.R + self.r*(1 - rx**0.5)
+
+    def local_n(self, x, y):
+        rx = 1 - (np.asarray(x)/self.r)**2
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ax = np.where(rx < 0, 0, rx**(-0.5))
+        a = -x / self.r * ax
+        b = -y / self.R
+        c = 1.
+        norm = (a**2 + b**2 + 1)**0.5
+        return [a/norm, b/norm, c/norm]
+
+    def _surface_params(self, p, second=False):
+        p.surf_kind = _structs.SURF_TOROID
+        p.surf_p[0] = float(self.R)
+        p.surf_p[1] = float(self.r)
+        p.asymmetric = 0
+        for i, v in enumerate((0., 0., 1., 0., 0., 1.)):
+            p.n_const[i] = v
+
+
+SimpleVFM = ToroidMirror
+
+
+class DCM(OE):
+    """Double-crystal monochromator with flat crystals (oes/dcm.py)."""
+
+    def __init__(self, *args, **kwargs):
+        self.bragg = kwargs.pop('bragg', 0)
+        self.cryst1roll = kwargs.pop('cryst1roll', 0)
+        self.cryst2roll = kwargs.pop('cryst2roll', 0)
+        self.cryst2pitch = kwargs.pop('cryst2pitch', 0)
+        self.cryst2finePitch = kwargs.pop('cryst2finePitch', 0)
+        self.cryst2perpTransl = kwargs.pop('cryst2perpTransl', 0)
+        self.cryst2longTransl = kwargs.pop('cryst2longTransl', 0)
+        self.limPhysX2 = kwargs.pop(
+            'limPhysX2', [-raycing.maxHalfSizeOfOE, raycing.maxHalfSizeOfOE])
+        self.limPhysY2 = kwargs.pop(
+            'limPhysY2', [-raycing.maxHalfSizeOfOE, raycing.maxHalfSizeOfOE])
+        self.limOptX2 = kwargs.pop('limOptX2', None)
+        self.limOptY2 = kwargs.pop('limOptY2', None)
+        self.material2 = kwargs.pop('material2', None)
+        fixedOffset = kwargs.pop('fixedOffset', None)
+        OE.__init__(self, *args, **kwargs)
+        if fixedOffset not in [0, None]:
+            self.cryst2perpTransl = fixedOffset/2./np.cos(self.bragg)
+
+    def local_n1(self, x, y):
+        return self.local_n(x, y)
+
+    def local_n2(self, x, y):
+        res = list(self.local_n1(x, y))
+        if self.alpha:
+            res[1] *= -1
+        return res
+
+    def double_reflect(self, beam=None, needLocal=True, fromVacuum1=True,
+                       fromVacuum2=True, returnLocalAbsorbed=None):
+        """-> (beamGlobal, beamLocal1, beamLocal2), dcm.py:248-354."""
+        p1 = self._make_pass(
+            self.pitch + self.bragg,
+            self.roll + self.positionRoll + self.cryst1roll, self.yaw, self.dx,
+            fromVacuum=fromVacuum1, out_to_global=False)
+        lo1, gb, _ = self._run_pass(p1, self.material, fromVacuum1, beam, beam)
+        p2 = self._make_pass(
+            -self.pitch - self.bragg + self.cryst2pitch + self.cryst2finePitch,
+            self.roll + self.cryst2roll + self.positionRoll, -self.yaw,
+            -self.dx, self.cryst2longTransl, -self.cryst2perpTransl,
+            fromVacuum=fromVacuum2, is2ndXtal=True, in_is_global=False,
+            good_mode=1, out_to_global=True, zero_local_not_entering=True)
+        lo2, gb2, _ = self._run_pass(p2, self.material2, fromVacuum2, gb, beam)
+        return gb2, lo1, lo2

@@ -7,6 +7,8 @@
 
 #include "../../include/xrt_hip.h"
 #include "kirchhoff.h"
+#include "reflect.h"
+#include "screen.h"
 
 namespace {
 
@@ -222,6 +224,162 @@ int xrt_hip_kirchhoff_f64(int ndev, const int* dev_ids, int64_t np, const double
   // DevBuf destructors free on whatever device is current; hipFree works across devices
   (void)hipSetDevice(prev_dev);
   return rc;
+}
+
+
+size_t xrt_hip_reflect_workspace_bytes(int64_t n) {
+  return xrt::reflect_workspace_bytes(n < 0 ? 0 : n);
+}
+
+int xrt_hip_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(xrt_hip_beam);
+    case 1: return (int)sizeof(xrt_hip_rotation);
+    case 2: return (int)sizeof(xrt_hip_pass);
+    case 3: return (int)sizeof(xrt_hip_material);
+    case 4: return (int)sizeof(xrt_hip_screen);
+    default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
+  }
+}
+
+static int check_beam(const xrt_hip_beam* b, const char* name, int64_t n, bool need_amp) {
+  if (!b) return fail(XRT_HIP_ERR_ARG, "%s: NULL beam", name);
+  if (b->n != n) return fail(XRT_HIP_ERR_ARG, "%s: %lld rays, expected %lld", name,
+                             (long long)b->n, (long long)n);
+  if (n > 0 && (!b->x || !b->y || !b->z || !b->a || !b->b || !b->c || !b->path || !b->E ||
+                !b->Jss || !b->Jpp || !b->Jsp_ri || !b->state))
+    return fail(XRT_HIP_ERR_ARG, "%s: NULL field pointer", name);
+  if (n > 0 && need_amp && (!b->Es_ri || !b->Ep_ri))
+    return fail(XRT_HIP_ERR_ARG, "%s: Es/Ep missing although the input beam has them", name);
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_material* material,
+                                 const xrt_hip_beam* in, const xrt_hip_beam* restore,
+                                 xrt_hip_beam* out_local, xrt_hip_beam* out_virgin,
+                                 double* theta, void* workspace, size_t workspace_bytes,
+                                 void* stream, double* info_host, float* kernel_ms) {
+  if (!pass || !material) return fail(XRT_HIP_ERR_ARG, "NULL pass / material");
+  if (!in) return fail(XRT_HIP_ERR_ARG, "NULL input beam");
+  const int64_t n = in->n;
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative ray count");
+  const bool amp = in->Es_ri != nullptr || in->Ep_ri != nullptr;
+  int rc;
+  if ((rc = check_beam(in, "in", n, amp))) return rc;
+  if ((rc = check_beam(restore, "restore", n, amp))) return rc;
+  if ((rc = check_beam(out_local, "out_local", n, amp))) return rc;
+  if ((rc = check_beam(out_virgin, "out_virgin", n, amp))) return rc;
+  if (pass->to_local.n < 0 || pass->to_local.n > XRT_HIP_MAX_ROT || pass->to_virgin.n < 0 ||
+      pass->to_virgin.n > XRT_HIP_MAX_ROT)
+    return fail(XRT_HIP_ERR_ARG, "rotation sequence longer than %d", XRT_HIP_MAX_ROT);
+  if (pass->surf_kind != XRT_HIP_SURF_FLAT && pass->surf_kind != XRT_HIP_SURF_TOROID)
+    return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
+  if (pass->invert_normal != 1 && pass->invert_normal != -1)
+    return fail(XRT_HIP_ERR_ARG, "invert_normal must be +1 or -1");
+  if (material->kind < XRT_HIP_MAT_NONE || material->kind > XRT_HIP_MAT_CRYSTAL)
+    return fail(XRT_HIP_ERR_ARG, "unknown material kind %d", material->kind);
+  if (material->kind != XRT_HIP_MAT_NONE) {
+    if (material->nelem < 1 || material->nelem > XRT_HIP_MAX_ELEM)
+      return fail(XRT_HIP_ERR_ARG, "material needs 1..%d elements", XRT_HIP_MAX_ELEM);
+    for (int e = 0; e < material->nelem; ++e)
+      if (!material->tab_E[e] || !material->tab_f1[e] || !material->tab_f2[e] ||
+          material->tab_n[e] < 2)
+        return fail(XRT_HIP_ERR_ARG, "element %d: missing f1/f2 table", e);
+  }
+  if (n == 0) return XRT_HIP_OK;
+  if (!workspace || workspace_bytes < xrt::reflect_workspace_bytes(n))
+    return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes,
+                xrt::reflect_workspace_bytes(n));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (kernel_ms) {
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+  }
+  hipError_t e = xrt::reflect_pass_launch(*pass, *material, *in, *restore, *out_local,
+                                          *out_virgin, theta, workspace, st, e0, e1);
+  if (e != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return fail(XRT_HIP_ERR_HIP, "reflect launch: %s", hipGetErrorString(e));
+  }
+  if (kernel_ms) {
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(kernel_ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  if (info_host) {
+    xrt::GStat g;
+    HIP_TRY(hipMemcpyAsync(&g, workspace, sizeof(g), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int j = 0; j < 16; ++j) info_host[j] = 0.;
+    info_host[0] = g.axis;
+    info_host[1] = g.positive;
+    info_host[2] = (g.maxdz2 > g.maxdz1 * 20.) ? 1. : 0.;
+    info_host[3] = g.t1min;
+    info_host[4] = g.t2max;
+    info_host[5] = g.maxdz1;
+    info_host[6] = g.maxdz2;
+    info_host[7] = (double)g.n_enter;
+    info_host[8] = (double)g.n_good1;
+    info_host[9] = g.sum_bdn;
+  }
+  return XRT_HIP_OK;
+}
+
+static int check_material_tables(const xrt_hip_material* m) {
+  if (!m) return fail(XRT_HIP_ERR_ARG, "NULL material");
+  if (m->nelem < 1 || m->nelem > XRT_HIP_MAX_ELEM)
+    return fail(XRT_HIP_ERR_ARG, "material needs 1..%d elements", XRT_HIP_MAX_ELEM);
+  for (int e = 0; e < m->nelem; ++e)
+    if (!m->tab_E[e] || !m->tab_f1[e] || !m->tab_f2[e] || m->tab_n[e] < 2)
+      return fail(XRT_HIP_ERR_ARG, "element %d: missing f1/f2 table", e);
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_material_amplitude_f64_dev(const xrt_hip_material* material, int64_t n,
+                                       const double* E, const double* bdn, double* rs_ri,
+                                       double* rp_ri, double* mu, double* nk, void* stream) {
+  int rc = check_material_tables(material);
+  if (rc) return rc;
+  if (material->kind < XRT_HIP_MAT_MIRROR || material->kind > XRT_HIP_MAT_PLATE)
+    return fail(XRT_HIP_ERR_ARG, "material kind %d has no Fresnel amplitude", material->kind);
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (n == 0) return XRT_HIP_OK;
+  if (!E || !bdn || !rs_ri || !rp_ri) return fail(XRT_HIP_ERR_ARG, "NULL array");
+  HIP_TRY(xrt::material_amplitude_launch(*material, n, E, bdn, rs_ri, rp_ri, mu, nk,
+                                         reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_crystal_amplitude_f64_dev(const xrt_hip_material* material, int64_t n,
+                                      const double* E, const double* gamma0,
+                                      const double* gammah, const double* hns, double* S_ri,
+                                      double* P_ri, void* stream) {
+  int rc = check_material_tables(material);
+  if (rc) return rc;
+  if (material->kind != XRT_HIP_MAT_CRYSTAL)
+    return fail(XRT_HIP_ERR_ARG, "material is not a crystal");
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (n == 0) return XRT_HIP_OK;
+  if (!E || !gamma0 || !gammah || !hns || !S_ri || !P_ri)
+    return fail(XRT_HIP_ERR_ARG, "NULL array");
+  HIP_TRY(xrt::crystal_amplitude_launch(*material, n, E, gamma0, gammah, hns, S_ri, P_ri,
+                                        reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_screen_expose_f64_dev(const xrt_hip_screen* screen, const xrt_hip_beam* in,
+                                  xrt_hip_beam* out, void* stream) {
+  if (!screen || !in) return fail(XRT_HIP_ERR_ARG, "NULL screen / beam");
+  const int64_t n = in->n;
+  const bool amp = in->Es_ri != nullptr || in->Ep_ri != nullptr;
+  int rc;
+  if ((rc = check_beam(in, "in", n, amp))) return rc;
+  if ((rc = check_beam(out, "out", n, amp))) return rc;
+  HIP_TRY(xrt::screen_expose_launch(*screen, *in, *out, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
 }
 
 int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,

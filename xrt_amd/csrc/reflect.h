@@ -1,0 +1,39 @@
+// Internal (C++) interface between reflect.hip and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/xrt_hip.h"
+
+#define REFLECT_BLOCK 256
+
+namespace xrt {
+
+// batch-global decisions of one pass, kept in device memory (workspace head)
+struct GStat {
+  double maxa, maxb, maxc;           // max |a|,|b|,|c| over entering rays with state 1
+  unsigned long long first_good;     // index of the first entering ray
+  unsigned long long n_enter, n_main;
+  int axis, positive;                // bracketing axis; sign of the first ray's component
+  double t1min, t2max, maxdz1, maxdz2;
+  unsigned long long n_good1;        // rays that ended in state 1
+  double sum_bdn;                    // sum of beamInDotNormal over them
+};
+
+size_t reflect_workspace_bytes(int64_t n);
+
+hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
+                               const xrt_hip_beam& in, const xrt_hip_beam& restore,
+                               const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
+                               void* workspace, hipStream_t st, hipEvent_t ev0,
+                               hipEvent_t ev1);
+
+hipError_t material_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
+                                     const double* bdn, double* rs, double* rp, double* mu,
+                                     double* nk, hipStream_t st);
+hipError_t crystal_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
+                                    const double* g0, const double* gh, const double* hns,
+                                    double* S, double* P, hipStream_t st);
+
+}  // namespace xrt

@@ -1,0 +1,1278 @@
+// Ray-surface intersection + reflect / refract with Fresnel / Bragg amplitudes
+// for gfx950 (MI355X), fp64. One "pass" = OE._reflect_local of the reference
+// (oes/reflect.py:551-1139) with the frame transforms of OE.reflect /
+// DCM.double_reflect fused in.
+//
+// The reference takes four batch-global decisions that every ray depends on:
+//   (1) the bracketing axis = argmax of max|a|, max|b|, max|c| over the rays
+//       with state 1 (oes/base.py:1257-1270);
+//   (2) the bracket formula = sign of that direction component of the FIRST
+//       entering ray (base.py:1239);
+//   (3) t1.min(), t2.max() clamps and the Brent-vs-secant choice
+//       max|dz2| > 20 max|dz1| (base.py:861-878);
+//   (4) for crystals, the sign of mean(beamInDotNormal) over the rays that hit
+//       (reflect.py:573-574).
+// They stay on the device: tiny reduction kernels write them into a GStat
+// record in the workspace, the next kernel reads them. Kernel sequence:
+//   init -> K1 stats_dir -> decide_axis -> K2 stats_bracket ->
+//   K3 fused solve+finish            (mirror / plate / no material), or
+//   K3a solve -> K3b finish          (crystal: needs decision (4) in between).
+// One lane = one ray; ray fields are SoA so every load/store is coalesced
+// (8 B/lane, 512 B per wave instruction). All arithmetic that decides the ray
+// state follows numpy's operation order with no FMA contraction
+// (-ffp-contract=off), IEEE division and correctly rounded sqrt.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/xrt_hip.h"
+#include "fp64_math.h"
+#include "reflect.h"
+
+namespace xrt {
+
+// constants, restated from xrt/backends/raycing/physconsts.py (same FP expressions)
+__device__ constexpr double kPI = 3.1415926535897932384626433832795;
+__device__ constexpr double kPI2 = 6.283185307179586476925286766559;
+__device__ constexpr double kCH = 6.626069573e-27 * 2.99792458e10 / 1.602176565e-12 * 1e8;
+__device__ constexpr double kCHBAR = kCH / kPI2;
+__device__ constexpr double kR0 = 2.817940285e-5;
+__device__ constexpr double kAVOGADRO = 6.02214199e23;
+__device__ constexpr double kZEps = 1e-12;        // raycing/__init__.py:86
+__device__ constexpr int kMaxIteration = 100;     // :88
+__device__ constexpr double kDt = 1e-5;           // :90
+__device__ constexpr double kMaxHalfSize = 1000.; // :92
+__device__ constexpr double kMaxDepth = 100.;     // :94
+
+// ---------------------------------------------------------------------------
+// complex helpers (numpy's algorithms where the choice is visible at 1e-16)
+// ---------------------------------------------------------------------------
+struct cplx {
+  double re, im;
+};
+__device__ __forceinline__ cplx C(double r, double i) { return cplx{r, i}; }
+__device__ __forceinline__ cplx operator+(cplx a, cplx b) { return C(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cplx operator-(cplx a, cplx b) { return C(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cplx operator-(cplx a) { return C(-a.re, -a.im); }
+__device__ __forceinline__ cplx operator*(cplx a, cplx b) {
+  return C(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+__device__ __forceinline__ cplx operator*(cplx a, double s) { return C(a.re * s, a.im * s); }
+__device__ __forceinline__ cplx operator*(double s, cplx a) { return C(a.re * s, a.im * s); }
+// numpy divides complex by real through its complex loop (Smith): x * (1/s)
+__device__ __forceinline__ cplx operator/(cplx a, double s) {
+  const double scl = 1.0 / s;
+  return C(a.re * scl, a.im * scl);
+}
+__device__ __forceinline__ cplx conj(cplx a) { return C(a.re, -a.im); }
+__device__ __forceinline__ double cabs_(cplx a) { return hypot(a.re, a.im); }
+__device__ __forceinline__ bool cisnan(cplx a) { return isnan(a.re) || isnan(a.im); }
+// Smith's algorithm, as numpy's complex division loop
+__device__ __forceinline__ cplx operator/(cplx a, cplx b) {
+  if (fabs(b.re) >= fabs(b.im)) {
+    if (b.re == 0. && b.im == 0.) return C(a.re / fabs(b.re), a.im / fabs(b.im));
+    const double rat = b.im / b.re;
+    const double scl = 1.0 / (b.re + b.im * rat);
+    return C((a.re + a.im * rat) * scl, (a.im - a.re * rat) * scl);
+  }
+  const double rat = b.re / b.im;
+  const double scl = 1.0 / (b.im + b.re * rat);
+  return C((a.re * rat + a.im) * scl, (a.im * rat - a.re) * scl);
+}
+__device__ __forceinline__ cplx csqrt_(cplx z) {  // principal root (C99 csqrt)
+  if (z.re == 0. && z.im == 0.) return C(0., z.im);
+  const double m = hypot(z.re, z.im);
+  if (z.re >= 0.) {
+    const double t = sqrt((z.re + m) * 0.5);
+    return C(t, z.im / (2. * t));
+  }
+  const double t = sqrt((-z.re + m) * 0.5);
+  return C(fabs(z.im) / (2. * t), copysign(t, z.im));
+}
+__device__ __forceinline__ cplx cexp_(cplx z) {
+  double s, c;
+  sincos(z.im, &s, &c);
+  const double e = exp(z.re);
+  return C(e * c, e * s);
+}
+__device__ __forceinline__ cplx ccos_(cplx z) {
+  double s, c;
+  sincos(z.re, &s, &c);
+  return C(c * cosh(z.im), -s * sinh(z.im));
+}
+__device__ __forceinline__ cplx csin_(cplx z) {
+  double s, c;
+  sincos(z.re, &s, &c);
+  return C(s * cosh(z.im), c * sinh(z.im));
+}
+__device__ __forceinline__ cplx ctan_(cplx z) {
+  double s2, c2;
+  sincos(2. * z.re, &s2, &c2);
+  if (fabs(z.im) > 20.) {  // cosh(2y) dwarfs cos(2x): tan -> +-i
+    const double e = exp(-2. * fabs(z.im));
+    return C(2. * s2 * e, copysign(1., z.im));
+  }
+  const double den = c2 + cosh(2. * z.im);
+  return C(s2 / den, sinh(2. * z.im) / den);
+}
+
+// ---------------------------------------------------------------------------
+// geometry helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void rotate3(const xrt_hip_rotation& R, double& x, double& y,
+                                        double& z) {
+  for (int i = 0; i < R.n; ++i) {
+    const double c = R.cosa[i], s = R.sina[i];
+    const int ax = R.axis[i];
+    if (ax == 2) {  // rotate_z, _rotate.py:17-20
+      const double xn = c * x - s * y, yn = s * x + c * y;
+      x = xn;
+      y = yn;
+    } else if (ax == 1) {  // rotate_y, :11-14
+      const double xn = c * x + s * z, zn = -s * x + c * z;
+      x = xn;
+      z = zn;
+    } else {  // rotate_x, :5-8
+      const double yn = c * y - s * z, zn = s * y + c * z;
+      y = yn;
+      z = zn;
+    }
+  }
+}
+
+__device__ __forceinline__ bool entering(const xrt_hip_pass& P, int st) {
+  return P.good_mode == 0 ? (st > 0) : (st == 1 || st == 2);
+}
+
+// direction of ray i in the true local frame (beamline.py:243-252, reflect.py:617-629)
+__device__ __forceinline__ void local_dir(const xrt_hip_pass& P, double& a, double& b,
+                                          double& c) {
+  if (P.in_is_global && P.sin_az != 0.) {
+    const double an = P.cos_az * a - P.sin_az * b, bn = P.sin_az * a + P.cos_az * b;
+    a = an;
+    b = bn;
+  }
+  rotate3(P.to_local, a, b, c);
+}
+
+__device__ __forceinline__ void local_pos(const xrt_hip_pass& P, double& x, double& y,
+                                          double& z) {
+  if (P.in_is_global) {
+    x = x - P.center[0];
+    y = y - P.center[1];
+    z = z - P.center[2];
+    if (P.sin_az != 0.) {
+      const double xn = P.cos_az * x - P.sin_az * y, yn = P.sin_az * x + P.cos_az * y;
+      x = xn;
+      y = yn;
+    }
+  }
+  rotate3(P.to_local, x, y, z);
+  x -= P.shift[0];
+  y -= P.shift[1];
+  z -= P.shift[2];
+}
+
+// surface height, oes/base.py:675-679 (flat), oes/__init__.py:398-401 (toroid)
+__device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double y) {
+  if (P.surf_kind == XRT_HIP_SURF_TOROID) {
+    const double R = P.surf_p[0], r = P.surf_p[1];
+    const double q = x / r;
+    double rx = 1. - q * q;
+    if (rx < 0.) rx = 0.;
+    const double yy = y * y;
+    return yy / 2.0 / R + r * (1. - sqrt(rx));
+  }
+  return 0.;
+}
+
+// find_dz, oes/base.py:801-846
+__device__ __forceinline__ double find_dz(const xrt_hip_pass& P, double t, double x0,
+                                          double y0, double z0, double a, double b,
+                                          double c, double& x, double& y, double& z) {
+  x = x0 + a * t;
+  y = y0 + b * t;
+  z = z0 + c * t;
+  double s = surf_z(P, x, y);
+  if (isnan(s)) s = 0.;
+  return (z - s) * (double)P.invert_normal;
+}
+
+// _set_t + clamp, oes/base.py:1231-1245, 1275
+__device__ __forceinline__ void bracket(const xrt_hip_pass& P, int axis, int positive,
+                                        double x, double y, double z, double a, double b,
+                                        double c, double& tMin, double& tMax) {
+  double limMin, limMax, xyz, abc;
+  if (axis == 0) {
+    limMin = P.phys_x[0] > -INFINITY ? P.phys_x[0] : -kMaxHalfSize;
+    limMax = P.phys_x[1] < INFINITY ? P.phys_x[1] : kMaxHalfSize;
+    xyz = x;
+    abc = a;
+  } else if (axis == 1) {
+    limMin = P.phys_y[0] > -INFINITY ? P.phys_y[0] : -kMaxHalfSize;
+    limMax = P.phys_y[1] < INFINITY ? P.phys_y[1] : kMaxHalfSize;
+    xyz = y;
+    abc = b;
+  } else {
+    limMin = -kMaxDepth;
+    limMax = kMaxDepth;
+    xyz = z;
+    abc = c;
+  }
+  if (positive) {
+    tMin = (limMin - xyz) / abc - kDt;
+    tMax = (limMax - xyz) / abc + kDt;
+  } else {
+    tMin = (limMax - xyz) / abc - kDt;
+    tMax = (limMin - xyz) / abc + kDt;
+  }
+  if (tMin < -1e6 * kZEps) tMin = -1e6 * kZEps;
+}
+
+__device__ __forceinline__ int sgn(double v) { return (v > 0.) - (v < 0.); }
+
+// ---------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------
+template <class T, class F>
+__device__ __forceinline__ T block_reduce(T v, F f, T* lds) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = f(v, __shfl_xor(v, off));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  T r = lds[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = f(r, lds[w]);
+  return r;
+}
+
+__device__ __forceinline__ void atomic_min_double(double* p, double v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  unsigned long long old = *q;
+  while (v < __longlong_as_double((long long)old)) {
+    const unsigned long long prev = atomicCAS(q, old, (unsigned long long)__double_as_longlong(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+__device__ __forceinline__ void atomic_max_double(double* p, double v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  unsigned long long old = *q;
+  while (v > __longlong_as_double((long long)old)) {
+    const unsigned long long prev = atomicCAS(q, old, (unsigned long long)__double_as_longlong(v));
+    if (prev == old) break;
+    old = prev;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K0 / K1 / decide / K2
+// ---------------------------------------------------------------------------
+__global__ void reflect_init(GStat* g) {
+  g->maxa = 0.;
+  g->maxb = 0.;
+  g->maxc = 0.;
+  g->first_good = ~0ull;
+  g->n_enter = 0;
+  g->n_main = 0;
+  g->axis = 1;
+  g->positive = 1;
+  g->t1min = INFINITY;
+  g->t2max = -INFINITY;
+  g->maxdz1 = 0.;
+  g->maxdz2 = 0.;
+  g->n_good1 = 0;
+  g->sum_bdn = 0.;
+}
+
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass P,
+                                                                   xrt_hip_beam in,
+                                                                   GStat* g) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double ma = 0., mb = 0., mc = 0.;
+  unsigned long long first = ~0ull, nent = 0, nmain = 0;
+  if (i < in.n) {
+    const int st = in.state[i];
+    if (entering(P, st)) {
+      first = (unsigned long long)i;
+      nent = 1;
+      if (st == 1) {  // mainPartForBracketing, reflect.py:644
+        double a = in.a[i], b = in.b[i], c = in.c[i];
+        local_dir(P, a, b, c);
+        ma = fabs(a);
+        mb = fabs(b);
+        mc = fabs(c);
+        nmain = 1;
+      }
+    }
+  }
+  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
+  auto fminu = [](unsigned long long u, unsigned long long v) { return u < v ? u : v; };
+  auto faddu = [](unsigned long long u, unsigned long long v) { return u + v; };
+  ma = block_reduce(ma, fmaxd, lds_d);
+  mb = block_reduce(mb, fmaxd, lds_d);
+  mc = block_reduce(mc, fmaxd, lds_d);
+  first = block_reduce(first, fminu, lds_u);
+  nent = block_reduce(nent, faddu, lds_u);
+  nmain = block_reduce(nmain, faddu, lds_u);
+  if (threadIdx.x == 0 && nent) {
+    // non-negative doubles order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxa),
+              (unsigned long long)__double_as_longlong(ma));
+    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxb),
+              (unsigned long long)__double_as_longlong(mb));
+    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxc),
+              (unsigned long long)__double_as_longlong(mc));
+    atomicMin(&g->first_good, first);
+    atomicAdd(&g->n_enter, nent);
+    atomicAdd(&g->n_main, nmain);
+  }
+}
+
+__global__ void reflect_decide_axis(xrt_hip_pass P, xrt_hip_beam in, GStat* g) {
+  if (g->n_enter == 0) return;
+  double maxa = g->maxa, maxb = g->maxb, maxc = g->maxc;
+  if (g->n_main == 0) {  // np.max of an empty selection -> (0, 1, 0), base.py:1261-1262
+    maxa = 0.;
+    maxb = 1.;
+    maxc = 0.;
+  }
+  const double mm = fmax(fmax(maxa, maxb), maxc);
+  int axis = 2;
+  if (mm == maxa)
+    axis = 0;
+  else if (mm == maxb)
+    axis = 1;
+  const int64_t i0 = (int64_t)g->first_good;
+  double a = in.a[i0], b = in.b[i0], c = in.c[i0];
+  local_dir(P, a, b, c);
+  const double comp = axis == 0 ? a : (axis == 1 ? b : c);
+  g->axis = axis;
+  g->positive = comp > 0. ? 1 : 0;
+}
+
+struct LocalRay {
+  double x, y, z, a, b, c;
+};
+
+__device__ __forceinline__ LocalRay load_local(const xrt_hip_pass& P, const xrt_hip_beam& in,
+                                               int64_t i) {
+  LocalRay r;
+  r.x = in.x[i];
+  r.y = in.y[i];
+  r.z = in.z[i];
+  r.a = in.a[i];
+  r.b = in.b[i];
+  r.c = in.c[i];
+  local_pos(P, r.x, r.y, r.z);
+  local_dir(P, r.a, r.b, r.c);
+  return r;
+}
+
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(xrt_hip_pass P,
+                                                                       xrt_hip_beam in,
+                                                                       GStat* g) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
+  int have = 0;
+  if (i < in.n && entering(P, in.state[i])) {
+    const LocalRay r = load_local(P, in, i);
+    double t1, t2, x, y, z;
+    bracket(P, g->axis, g->positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
+    const double dz1 = find_dz(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
+    double dz2 = find_dz(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
+    if (dz1 <= 0. || dz2 >= 0.) dz2 = 0.;  // base.py:863-865
+    t1m = t1;
+    t2m = t2;
+    d1m = fabs(dz1);
+    d2m = fabs(dz2);
+    have = 1;
+  }
+  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
+  auto fmind = [](double u, double v) { return u < v ? u : v; };
+  t1m = block_reduce(t1m, fmind, lds_d);
+  t2m = block_reduce(t2m, fmaxd, lds_d);
+  d1m = block_reduce(d1m, fmaxd, lds_d);
+  d2m = block_reduce(d2m, fmaxd, lds_d);
+  have = __syncthreads_or(have);
+  if (threadIdx.x == 0 && have) {
+    atomic_min_double(&g->t1min, t1m);
+    atomic_max_double(&g->t2max, t2m);
+    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxdz1),
+              (unsigned long long)__double_as_longlong(d1m));
+    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxdz2),
+              (unsigned long long)__double_as_longlong(d2m));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// root solve, oes/base.py:848-1048, one ray
+// ---------------------------------------------------------------------------
+struct Hit {
+  double t, x, y, z;
+  int lost;  // ind1 of the reference: dz1 <= 0
+};
+
+__device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
+                                         const LocalRay& r) {
+  Hit h;
+  if (P.no_intersection_search) {  // reflect.py:676-682
+    h.t = 0.;
+    h.x = r.x;
+    h.y = r.y;
+    h.z = r.z;
+    h.lost = 0;
+    return h;
+  }
+  double t1, t2;
+  bracket(P, g.axis, g.positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
+  double x1, y1, z1, x2, y2, z2;
+  double dz1 = find_dz(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x1, y1, z1);
+  double dz2 = find_dz(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
+  const bool ind1 = dz1 <= 0.;
+  const bool ind2 = dz2 >= 0.;
+  h.lost = ind1 ? 1 : 0;
+  if (ind1) {
+    h.t = t1;
+    h.x = x1;
+    h.y = y1;
+    h.z = z1;
+    return h;
+  }
+  if (ind2) {
+    h.t = t2;
+    h.x = x2;
+    h.y = y2;
+    h.z = z2;
+    return h;
+  }
+  const double tMinG = g.t1min, tMaxG = g.t2max;
+  const bool use_brent = g.maxdz2 > g.maxdz1 * 20.;
+  int numit = 2;
+  if (!use_brent) {
+    // bracket-keeping secant, base.py:933-959. The first step is taken
+    // unconditionally (the reference filters on |dz2| only after it).
+    bool active = true;
+    while (active && numit < kMaxIteration) {
+      const double t = t1, dz = dz1;
+      t1 = t2;
+      dz1 = dz2;
+      t2 = t - (t1 - t) * dz / (dz1 - dz);
+      if (t2 < tMinG) t2 = tMinG;
+      if (t2 > tMaxG) t2 = tMaxG;
+      dz2 = find_dz(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
+      if (!isnan(dz2) && !isnan(dz1) && sgn(dz2) == sgn(dz1)) {
+        t1 = t;
+        dz1 = dz;
+      }
+      active = fabs(dz2) > kZEps;
+      ++numit;
+    }
+  } else {
+    // Brent, base.py:961-1048
+    if (fabs(dz1) < fabs(dz2)) {
+      double tmp = t1;
+      t1 = t2;
+      t2 = tmp;
+      tmp = dz1;
+      dz1 = dz2;
+      dz2 = tmp;
+    }
+    double t3 = t1, dz3 = dz1, t4 = 0.;
+    bool mflag = true;
+    bool active = fabs(dz2) > kZEps;
+    while (active && numit < kMaxIteration) {
+      double xa = t1, xb = t2, xc = t3, xd = t4;
+      double fa = dz1, fb = dz2, fc = dz3;
+      double xs;
+      if (fa != fc && fb != fc) {
+        xs = xa * fb * fc / (fa - fb) / (fa - fc) + fa * xb * fc / (fb - fa) / (fb - fc) +
+             fa * fb * xc / (fc - fa) / (fc - fb);
+      } else {
+        xs = xb - fb * (xb - xa) / (fb - fa);
+      }
+      const double q = (3. * xa + xb) / 4.;
+      const bool cond1 = ((xs < q) && (xs < xb)) || ((xs > q) && (xs > xb));
+      const bool cond2 = mflag && (fabs(xs - xb) >= (fabs(xb - xc) / 2.));
+      const bool cond3 = (!mflag) && (fabs(xs - xb) >= (fabs(xc - xd) / 2.));
+      const bool cond4 = mflag && (fabs(xb - xc) < kZEps);
+      const bool cond5 = (!mflag) && (fabs(xc - xd) < kZEps);
+      const bool conds = cond1 || cond2 || cond3 || cond4 || cond5;
+      if (conds) xs = (xa + xb) / 2.;
+      mflag = conds;
+      const double fs = find_dz(P, xs, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
+      xd = xc;
+      xc = xb;
+      fc = fb;
+      const bool neg = ((fa < 0.) && (fs > 0.)) || ((fa > 0.) && (fs < 0.));
+      if (neg) {
+        xb = xs;
+        fb = fs;
+      } else {
+        xa = xs;
+        fa = fs;
+      }
+      if (fabs(fa) < fabs(fb)) {
+        double tmp = xa;
+        xa = xb;
+        xb = tmp;
+        tmp = fa;
+        fa = fb;
+        fb = tmp;
+      }
+      t1 = xa;
+      t2 = xb;
+      t3 = xc;
+      t4 = xd;
+      dz1 = fa;
+      dz2 = fb;
+      dz3 = fc;
+      active = fabs(dz2) > kZEps;
+      ++numit;
+    }
+  }
+  h.t = t2;
+  h.x = x2;
+  h.y = y2;
+  h.z = z2;
+  return h;
+}
+
+// rays_good, oes/base.py:1094-1163
+__device__ __forceinline__ int rays_good(const xrt_hip_pass& P, double x, double y) {
+  int st = 1;
+  if (P.shape == XRT_HIP_SHAPE_RECT) {
+    if (P.has_opt_x &&
+        (((P.phys_x[0] <= x) && (x < P.opt_x[0])) || ((P.opt_x[1] <= x) && (x < P.phys_x[1]))))
+      st = 2;
+    if (P.has_opt_y &&
+        (((P.phys_y[0] <= y) && (y < P.opt_y[0])) || ((P.opt_y[1] <= y) && (y < P.phys_y[1]))))
+      st = 2;
+    const bool outside =
+        (x < P.phys_x[0]) || (x > P.phys_x[1]) || (y < P.phys_y[0]) || (y > P.phys_y[1]);
+    bool over = false;
+    if (P.over_mask & XRT_HIP_OVER_XMIN) over |= x < P.phys_x[0];
+    if (P.over_mask & XRT_HIP_OVER_XMAX) over |= x > P.phys_x[1];
+    if (P.over_mask & XRT_HIP_OVER_YMIN) over |= y < P.phys_y[0];
+    if (P.over_mask & XRT_HIP_OVER_YMAX) over |= y > P.phys_y[1];
+    if (outside) st = P.lost_num;
+    if (over) st = 3;
+  } else {
+    double cx = (P.phys_x[0] + P.phys_x[1]) * 0.5;
+    if (isnan(cx)) cx = 0.;
+    const double rx = (P.phys_x[1] - P.phys_x[0]) * 0.5;
+    double cy = (P.phys_y[0] + P.phys_y[1]) * 0.5;
+    const double ry = (P.phys_y[1] - P.phys_y[0]) * 0.5;
+    if (isnan(cy)) cy = 0.;
+    if (!isinf(rx)) {
+      const double u = (x - cx) / rx, v = (y - cy) / ry;
+      if (u * u + v * v > 1.) st = P.lost_num;
+    }
+  }
+  return st;
+}
+
+// ---------------------------------------------------------------------------
+// amplitudes
+// ---------------------------------------------------------------------------
+// np.interp on the element table (element.py:252-263): upper_bound - 1, then
+// slope*(x - xp[j]) + fp[j]
+__device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, double E) {
+  const double* __restrict__ tE = M.tab_E[e];
+  const int n = M.tab_n[e];
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (E >= tE[mid])
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  int j = lo - 1;
+  if (j < 0) j = 0;
+  double f1, f2;
+  if (j >= n - 1) {
+    f1 = M.tab_f1[e][n - 1];
+    f2 = M.tab_f2[e][n - 1];
+  } else if (tE[j] == E) {
+    f1 = M.tab_f1[e][j];
+    f2 = M.tab_f2[e][j];
+  } else {
+    const double dx = tE[j + 1] - tE[j];
+    const double s1 = (M.tab_f1[e][j + 1] - M.tab_f1[e][j]) / dx;
+    const double s2 = (M.tab_f2[e][j + 1] - M.tab_f2[e][j]) / dx;
+    f1 = s1 * (E - tE[j]) + M.tab_f1[e][j];
+    f2 = s2 * (E - tE[j]) + M.tab_f2[e][j];
+  }
+  return C(f1, f2);
+}
+
+// material.py:348-378
+__device__ __forceinline__ cplx refractive_index(const xrt_hip_material& M, double E) {
+  cplx xf = C(0., 0.);
+  for (int e = 0; e < M.nelem; ++e) {
+    cplx f = interp_f1f2(M, e, E);
+    f.re += (double)M.Z[e];
+    xf = xf + f * M.quantity[e];
+  }
+  const double w = kCH / E;
+  const double pre = 1e-24 * kAVOGADRO * kR0 / kPI2 * (w * w) * M.rho;
+  const cplx v = (xf * pre) / M.mass;
+  return C(1. - v.re, -v.im);
+}
+
+struct Ampl {
+  cplx rs, rp;
+  double mu, nk;
+};
+
+// Fresnel, material.py:415-493
+__device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, double E,
+                                                   double bdn) {
+  Ampl A;
+  const cplx n = refractive_index(M, E);
+  const cplx one = C(1., 0.);
+  const cplx n1 = M.from_vacuum ? one : n;
+  const cplx n2 = M.from_vacuum ? n : one;
+  const double cosAlpha = fabs(bdn);
+  double sinAlpha2 = 1. - bdn * bdn;
+  if (sinAlpha2 < 0.) sinAlpha2 = 0.;
+  const cplx n1cosAlpha = n1 * cosAlpha;
+  const cplx rat = n1 / n2;
+  const cplx cosBeta = csqrt_(one - (rat * rat) * sinAlpha2);
+  const cplx n2cosBeta = n2 * cosBeta;
+  if (M.kind == XRT_HIP_MAT_MIRROR || M.kind == XRT_HIP_MAT_THIN_MIRROR) {
+    A.rs = (n1cosAlpha - n2cosBeta) / (n1cosAlpha + n2cosBeta);
+    A.rp = (n2 * cosAlpha - n1 * cosBeta) / (n2 * cosAlpha + n1 * cosBeta);
+    if (M.kind == XRT_HIP_MAT_THIN_MIRROR) {
+      // p2 = exp(2j E/CHBAR n2cosBeta t 1e7)
+      const double f = 2. * E * (1.0 / kCHBAR);
+      const cplx arg = ((C(0., f) * n2cosBeta) * M.t) * 1e7;
+      const cplx p2 = cexp_(arg);
+      A.rs = A.rs * ((one - p2) / (one - (A.rs * A.rs) * p2));
+      A.rp = A.rp * ((one - p2) / (one - (A.rp * A.rp) * p2));
+    }
+  } else {  // plate
+    const double tf = sqrt((n2cosBeta * conj(n1)).re / cosAlpha) / cabs_(n1);
+    A.rs = ((2. * n1cosAlpha) / (n1cosAlpha + n2cosBeta)) * tf;
+    A.rp = ((2. * n1cosAlpha) / (n2 * cosAlpha + n1 * cosBeta)) * tf;
+  }
+  A.mu = fabs(n.im) * E / kCHBAR * 2e8;
+  A.nk = n.re * E / kCHBAR * 1e8;
+  return A;
+}
+
+// Bragg / Laue dynamical-diffraction amplitudes, crystal.py:492-645
+__device__ __forceinline__ cplx crystal_one_pol(const xrt_hip_material& M, double polFactor,
+                                                cplx alpha, cplx chih, cplx chih_, cplx chi0,
+                                                double b, double k02, double k0s,
+                                                double kHs) {
+  const cplx delta = csqrt_(alpha * alpha + ((chih * (polFactor * polFactor)) * chih_) / b);
+  const double sqb = sqrt(fabs(b));
+  if (M.thick) {
+    const cplx num = chih * polFactor;
+    cplx ra = num / (alpha + delta);
+    cplx ad = alpha - delta;
+    if (ad.re == 0. && ad.im == 0.) ad = C(1e-100, 0.);
+    const cplx rb = num / ad;
+    if (cisnan(ra)) ra = rb;
+    if (cabs_(rb) < cabs_(ra)) ra = rb;
+    return ra / sqb;
+  }
+  const double t = M.t_crystal * 1e7;
+  const cplx l = ((delta * t) * k02) / 2. / kHs;
+  const cplx I = C(0., 1.);
+  cplx ra;
+  // exp(1j k02 t (chi0 - alpha b) / 2 / k0s)
+  const cplx ph = cexp_(((I * (k02 * t)) * (chi0 - alpha * b)) / 2. / k0s);
+  if (M.geom_bragg) {
+    if (M.geom_transmitted)
+      ra = (C(1., 0.) / (ccos_(l) - ((I * alpha) * csin_(l)) / delta)) * ph;
+    else
+      ra = (chih * polFactor) / (alpha + (I * delta) / ctan_(l));
+  } else {
+    if (M.geom_transmitted)
+      ra = (ccos_(l) + ((I * alpha) * csin_(l)) / delta) * ph;
+    else
+      ra = (((chih * polFactor) * csin_(l)) / delta) * ph;
+  }
+  if (!M.geom_transmitted) ra = ra / sqb;
+  return ra;
+}
+
+__device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, double E,
+                                                  double bdsn, double bosn, double bdhn) {
+  Ampl A;
+  const double waveLength = kCH / E;
+  const double k = kPI2 / waveLength;
+  const double k0s = -bdsn * k;
+  double kHs = -bosn * k;
+  const double HH = kPI2 / M.d;
+  const double k0H = fabs(bdhn) * HH * k;
+  const double k02 = k * k;
+  const double H2 = HH * HH;
+  double b;
+  if (kHs == 0.) {
+    kHs = 1.;
+    b = -1.;
+  } else {
+    b = k0s / kHs;
+  }
+  // structure factors, crystals_basic.py:22-31, 76-80; chi, crystal.py:297-306
+  const cplx anom = interp_f1f2(M, 0, E);
+  cplx F0 = (C((double)M.Z[0], 0.) + anom) * 4. * M.fact_dw;
+  const int residue = (abs(M.hkl[0]) % 2) + (abs(M.hkl[1]) % 2) + (abs(M.hkl[2]) % 2);
+  cplx Fh = C(0., 0.), Fh_ = C(0., 0.);
+  if (residue == 0 || residue == 3) Fh = (C(M.f0_hkl, 0.) + anom) * 4. * M.fact_dw;
+  Fh_ = Fh;
+  if (M.structure == 1) {
+    const cplx d2f = C(M.d2f_re, M.d2f_im);
+    F0 = F0 * 2.;
+    Fh_ = Fh * conj(d2f);
+    Fh = Fh * d2f;
+  }
+  const double c2l = M.chi_to_f * (waveLength * waveLength);
+  const cplx chi0 = conj(F0) * c2l, chih = conj(Fh) * c2l, chih_ = conj(Fh_) * c2l;
+  // Bragg angle, crystal.py:1105-1120
+  double sb = kCH / (2. * M.d * E);
+  if (sb > 1.) sb = 1. - 1e-16;
+  if (sb < -1.) sb = -1. + 1e-16;
+  const double thetaB = asin(sb);
+  const cplx alpha = C((H2 / 2. - k0H) / k02, 0.) + (chi0 / 2.) * (1. / b - 1.);
+  A.rs = crystal_one_pol(M, 1., alpha, chih, chih_, chi0, b, k02, k0s, kHs);
+  A.rp = crystal_one_pol(M, cos(2. * thetaB), alpha, chih, chih_, chi0, b, k02, k0s, kHs);
+  A.mu = 0.;
+  A.nk = 0.;
+  return A;
+}
+
+// ---------------------------------------------------------------------------
+// per-ray record and the "finish" half of _reflect_local (reflect.py:715-1110)
+// ---------------------------------------------------------------------------
+struct RayIn {
+  double path, E, Jss, Jpp, Jsr, Jsi, Esr, Esi, Epr, Epi;
+};
+
+__device__ __forceinline__ void rot_coherency(double roll, double& Jss, double& Jpp,
+                                              double& Jsr, double Jsi) {
+  // sources/beams.py:448-479 (imaginary part of Jsp is unchanged)
+  double s, c;
+  sincos(roll, &s, &c);
+  const double c2 = c * c, s2 = s * s, cs = c * s;
+  const double ss = Jss * c2 + Jpp * s2 + 2. * Jsr * cs;
+  const double pp = Jss * s2 + Jpp * c2 - 2. * Jsr * cs;
+  const double sr = (Jpp - Jss) * cs + Jsr * (c2 - s2);
+  Jss = ss;
+  Jpp = pp;
+  Jsr = sr;
+  (void)Jsi;
+}
+
+struct Finished {
+  double a, b, c;           // outgoing direction, local
+  double theta;
+  RayIn lo;                 // local beam fields (path, J, E-fields)
+  double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;  // rotated back for vlb
+};
+
+__device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
+                                               const xrt_hip_material& M, const GStat& g,
+                                               const LocalRay& r, const Hit& h, RayIn q,
+                                               bool has_amp) {
+  Finished F;
+  q.path += h.t;
+  // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
+  double n[6];
+  if (P.surf_kind == XRT_HIP_SURF_TOROID) {  // oes/__init__.py:403-411
+    const double R = P.surf_p[0], rr = P.surf_p[1];
+    const double qx = h.x / rr;
+    const double rx = 1. - qx * qx;
+    const double ax = rx < 0. ? 0. : 1. / sqrt(rx);
+    const double na = -h.x / rr * ax;
+    const double nb = -h.y / R;
+    const double norm = sqrt(na * na + nb * nb + 1.);
+    n[0] = n[3] = na / norm;
+    n[1] = n[4] = nb / norm;
+    n[2] = n[5] = 1. / norm;
+  } else {
+    for (int j = 0; j < 6; ++j) n[j] = P.n_const[j];
+  }
+  double bdn = r.a * n[0] + r.b * n[1] + r.c * n[2];
+  if (bdn < -1.) bdn = -1.;
+  if (bdn > 1.) bdn = 1.;
+  F.theta = acos(bdn) - kPI / 2.;
+  const double bdsn = P.asymmetric ? (r.a * n[3] + r.b * n[4] + r.c * n[5]) : bdn;
+
+  int toWhere = 0;  // reflect.py:723-752
+  if (M.kind == XRT_HIP_MAT_PLATE)
+    toWhere = 1;
+  else if (M.kind == XRT_HIP_MAT_CRYSTAL && M.geom_transmitted)
+    toWhere = 2;
+
+  double ao = r.a, bo = r.b, co = r.c;  // a_out of the reference
+  F.a = r.a;
+  F.b = r.b;
+  F.c = r.c;
+  if (toWhere == 0 || toWhere == 2) {
+    if (M.kind == XRT_HIP_MAT_CRYSTAL && toWhere == 0) {
+      // crystal as a grating, reflect.py:568-612 + 451-469
+      const double ndsn = n[0] * n[3] + n[1] * n[4] + n[2] * n[5];
+      const double bdnMean = g.sum_bdn / (double)g.n_good1;
+      const double sgbdn = bdnMean < 0. ? 1. : -1.;
+      const double wHd = 1. / (M.d * 1e-7);
+      const double g0 = (n[0] - ndsn * n[3]) * wHd * sgbdn;
+      const double g1 = (n[1] - ndsn * n[4]) * wHd * sgbdn;
+      const double g2 = (n[2] - ndsn * n[5]) * wHd * sgbdn;
+      const double sig = M.geom_bragg ? -1. : 1.;
+      const double bdg = r.a * g0 + r.b * g1 + r.c * g2;
+      const double G2 = g0 * g0 + g1 * g1 + g2 * g2;
+      const double ol = 1. * kCH / q.E * 1e-7;
+      const double u = bdsn * bdsn - 2. * bdg * ol - G2 * (ol * ol);
+      const double dn = bdsn + sig * sqrt(fabs(u));
+      ao = r.a - n[3] * dn + g0 * ol;
+      bo = r.b - n[4] * dn + g1 * ol;
+      co = r.c - n[5] * dn + g2 * ol;
+      const double nm = sqrt(ao * ao + bo * bo + co * co);
+      ao /= nm;
+      bo /= nm;
+      co /= nm;
+    } else {  // specular, reflect.py:875-877
+      ao = r.a - n[0] * 2. * bdn;
+      bo = r.b - n[1] * 2. * bdn;
+      co = r.c - n[2] * 2. * bdn;
+    }
+    if (toWhere == 0) {
+      F.a = ao;
+      F.b = bo;
+      F.c = co;
+    }
+  } else {  // refraction, reflect.py:894-919
+    const double nre = refractive_index(M, q.E).re;
+    const double n1overn2 = M.from_vacuum ? 1. / nre : nre;
+    const double signN = (double)sgn(-bdn);
+    const double n1c = -n1overn2 * bdn;
+    const double cosTheta2 = signN * sqrt(1. - n1overn2 * n1overn2 + n1c * n1c);
+    const double dn = n1c - cosTheta2;
+    F.a = r.a * n1overn2 + n[0] * dn;
+    F.b = r.b * n1overn2 + n[1] * dn;
+    F.c = r.c * n1overn2 + n[2] * dn;
+  }
+
+  // coherency matrix into the local s/p frame, reflect.py:948-953
+  const double rollAngle = P.roll + atan2(n[3], n[5]);
+  double Jss = q.Jss, Jpp = q.Jpp, Jsr = q.Jsr, Jsi = q.Jsi;
+  rot_coherency(-rollAngle, Jss, Jpp, Jsr, Jsi);
+  double sinY = 0., cosY = 1.;
+  cplx Es = C(q.Esr, q.Esi), Ep = C(q.Epr, q.Epi);
+  if (has_amp) {
+    sincos(rollAngle, &sinY, &cosY);
+    const cplx e1 = Es * cosY + Ep * (-sinY);
+    const cplx e2 = Es * sinY + Ep * cosY;
+    Es = e1;
+    Ep = e2;
+  }
+  // amplitudes, reflect.py:955-1035
+  Ampl A;
+  A.rs = C(1., 0.);
+  A.rp = C(1., 0.);
+  A.mu = 0.;
+  A.nk = 0.;
+  if (M.kind == XRT_HIP_MAT_CRYSTAL) {
+    const double bosn = ao * n[3] + bo * n[4] + co * n[5];
+    A = crystal_amplitude(M, q.E, bdsn, bosn, bdn);
+  } else if (M.kind != XRT_HIP_MAT_NONE) {
+    A = material_amplitude(M, q.E, bdn);
+  }
+  if (cisnan(A.rs)) A.rs = C(0., 0.);
+  if (cisnan(A.rp)) A.rp = C(0., 0.);
+  // J' and E', reflect.py:1038-1064
+  const double as2 = A.rs.re * A.rs.re + A.rs.im * A.rs.im;
+  const double ap2 = A.rp.re * A.rp.re + A.rp.im * A.rp.im;
+  Jss = Jss * as2;
+  Jpp = Jpp * ap2;
+  const cplx jsp = (C(Jsr, Jsi) * A.rs) * conj(A.rp);
+  Jsr = jsp.re;
+  Jsi = jsp.im;
+  if (has_amp) {
+    Es = Es * A.rs;
+    Ep = Ep * A.rp;
+  }
+  if (!M.from_vacuum && M.kind != XRT_HIP_MAT_NONE && M.kind != XRT_HIP_MAT_CRYSTAL) {
+    const double att = exp(-A.mu * h.t * 0.1);
+    Jss *= att;
+    Jpp *= att;
+    Jsr *= att;
+    Jsi *= att;
+    if (has_amp) {
+      double s, c;
+      sincos(0.1 * A.nk * h.t, &s, &c);
+      const double sq = sqrt(att);
+      const cplx mPh = C(sq * c, sq * s);
+      Es = Es * mPh;
+      Ep = Ep * mPh;
+    }
+  } else if (has_amp) {
+    // exp(1e7j E/CHBAR t): numpy divides the complex 1e7j*E by CHBAR with
+    // Smith's algorithm = multiply by 1.0/CHBAR; the phase is ~1e12 rad, so
+    // the rounding sequence must be the same
+    const double ph = ((1e7 * q.E) * (1.0 / kCHBAR)) * h.t;
+    double s, c;
+    sincos_phase(ph, s, c);
+    const cplx mPh = C(c, s);
+    Es = Es * mPh;
+    Ep = Ep * mPh;
+  }
+  q.Jss = Jss;
+  q.Jpp = Jpp;
+  q.Jsr = Jsr;
+  q.Jsi = Jsi;
+  q.Esr = Es.re;
+  q.Esi = Es.im;
+  q.Epr = Ep.re;
+  q.Epi = Ep.im;
+  F.lo = q;
+  // rotate back for the virgin-local beam, reflect.py:1106-1110
+  F.vJss = Jss;
+  F.vJpp = Jpp;
+  F.vJsr = Jsr;
+  F.vJsi = Jsi;
+  rot_coherency(rollAngle, F.vJss, F.vJpp, F.vJsr, F.vJsi);
+  if (has_amp) {
+    const cplx e1 = Es * cosY + Ep * sinY;
+    const cplx e2 = Es * (-sinY) + Ep * cosY;
+    F.vEsr = e1.re;
+    F.vEsi = e1.im;
+    F.vEpr = e2.re;
+    F.vEpi = e2.im;
+  } else {
+    F.vEsr = F.vEsi = F.vEpr = F.vEpi = 0.;
+  }
+  return F;
+}
+
+// ---------------------------------------------------------------------------
+// stores
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void store_ray(const xrt_hip_beam& o, int64_t i, double x, double y,
+                                          double z, double a, double b, double c, double path,
+                                          double E, double Jss, double Jpp, double Jsr,
+                                          double Jsi, int st, double Esr, double Esi,
+                                          double Epr, double Epi, bool has_amp) {
+  o.x[i] = x;
+  o.y[i] = y;
+  o.z[i] = z;
+  o.a[i] = a;
+  o.b[i] = b;
+  o.c[i] = c;
+  o.path[i] = path;
+  o.E[i] = E;
+  o.Jss[i] = Jss;
+  o.Jpp[i] = Jpp;
+  reinterpret_cast<double2*>(o.Jsp_ri)[i] = make_double2(Jsr, Jsi);
+  o.state[i] = st;
+  if (has_amp) {
+    reinterpret_cast<double2*>(o.Es_ri)[i] = make_double2(Esr, Esi);
+    reinterpret_cast<double2*>(o.Ep_ri)[i] = make_double2(Epr, Epi);
+  }
+}
+
+__device__ __forceinline__ void copy_ray(const xrt_hip_beam& o, const xrt_hip_beam& s,
+                                         int64_t i, int st, bool has_amp, bool zero_xyz) {
+  double2 js = reinterpret_cast<const double2*>(s.Jsp_ri)[i];
+  double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+  if (has_amp) {
+    es = reinterpret_cast<const double2*>(s.Es_ri)[i];
+    ep = reinterpret_cast<const double2*>(s.Ep_ri)[i];
+  }
+  store_ray(o, i, zero_xyz ? 0. : s.x[i], zero_xyz ? 0. : s.y[i], zero_xyz ? 0. : s.z[i],
+            s.a[i], s.b[i], s.c[i], s.path[i], s.E[i], s.Jss[i], s.Jpp[i], js.x, js.y, st,
+            es.x, es.y, ep.x, ep.y, has_amp);
+}
+
+// everything after the solve for one entering ray: state, finish, both stores
+__device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hip_material& M,
+                                             const GStat& g, const xrt_hip_beam& in,
+                                             const xrt_hip_beam& restore,
+                                             const xrt_hip_beam& lb, const xrt_hip_beam& vb,
+                                             double* theta, int64_t i, const LocalRay& r,
+                                             const Hit& h, int st, bool has_amp) {
+  RayIn q;
+  q.path = in.path[i];
+  q.E = in.E[i];
+  q.Jss = in.Jss[i];
+  q.Jpp = in.Jpp[i];
+  const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
+  q.Jsr = js.x;
+  q.Jsi = js.y;
+  q.Esr = q.Esi = q.Epr = q.Epi = 0.;
+  if (has_amp) {
+    const double2 es = reinterpret_cast<const double2*>(in.Es_ri)[i];
+    const double2 ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
+    q.Esr = es.x;
+    q.Esi = es.y;
+    q.Epr = ep.x;
+    q.Epi = ep.y;
+  }
+  double la = r.a, lbb = r.b, lc = r.c, th = 0.;
+  RayIn lo = q;
+  double vJss = q.Jss, vJpp = q.Jpp, vJsr = q.Jsr, vJsi = q.Jsi;
+  double vEsr = q.Esr, vEsi = q.Esi, vEpr = q.Epr, vEpi = q.Epi;
+  if (st == 1) {
+    const Finished F = finish_ray(P, M, g, r, h, q, has_amp);
+    la = F.a;
+    lbb = F.b;
+    lc = F.c;
+    th = F.theta;
+    lo = F.lo;
+    vJss = F.vJss;
+    vJpp = F.vJpp;
+    vJsr = F.vJsr;
+    vJsi = F.vJsi;
+    vEsr = F.vEsr;
+    vEsi = F.vEsi;
+    vEpr = F.vEpr;
+    vEpi = F.vEpi;
+  }
+  if (theta) theta[i] = th;
+  store_ray(lb, i, h.x, h.y, h.z, la, lbb, lc, lo.path, lo.E, lo.Jss, lo.Jpp, lo.Jsr, lo.Jsi,
+            st, lo.Esr, lo.Esi, lo.Epr, lo.Epi, has_amp);
+  const bool keep = P.only_state1_out ? (st == 1) : (st == 1 || st == 2);
+  if (!keep) {  // reflect.py:131-134: everything but the state comes from `restore`
+    copy_ray(vb, restore, i, st, has_amp, false);
+    return;
+  }
+  // back to the virgin local frame, reflect.py:1115-1132
+  double x = h.x + P.shift[0], y = h.y + P.shift[1], z = h.z + P.shift[2];
+  rotate3(P.to_virgin, x, y, z);
+  rotate3(P.to_virgin, la, lbb, lc);
+  if (P.out_to_global) {  // beamline.py:267-287
+    if (P.sin_az != 0.) {
+      const double an = P.cos_az * la - (-P.sin_az) * lbb, bn = (-P.sin_az) * la + P.cos_az * lbb;
+      la = an;
+      lbb = bn;
+      const double xn = P.cos_az * x - (-P.sin_az) * y, yn = (-P.sin_az) * x + P.cos_az * y;
+      x = xn;
+      y = yn;
+    }
+    x += P.center[0];
+    y += P.center[1];
+    z += P.center[2];
+  }
+  store_ray(vb, i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, st, vEsr, vEsi,
+            vEpr, vEpi, has_amp);
+}
+
+__device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hip_beam& in,
+                                             const xrt_hip_beam& restore,
+                                             const xrt_hip_beam& lb, const xrt_hip_beam& vb,
+                                             double* theta, int64_t i, int st, bool has_amp) {
+  // not entering: both outputs are copies (reflect.py:104-108); dcm.py:298-303
+  // zeroes the local record of rays that never reached the 2nd crystal
+  if (P.zero_local_not_entering)
+    copy_ray(lb, in, i, 0, has_amp, true);
+  else
+    copy_ray(lb, in, i, st, has_amp, false);
+  copy_ray(vb, restore, i, st, has_amp, false);
+  if (theta) theta[i] = 0.;
+}
+
+// ---------------------------------------------------------------------------
+// K3 kernels
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_fused(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
+    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* gp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in.n) return;
+  const bool has_amp = in.Es_ri != nullptr;
+  const int st0 = in.state[i];
+  if (!entering(P, st0)) {
+    pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
+    return;
+  }
+  const GStat g = *gp;
+  const LocalRay r = load_local(P, in, i);
+  const Hit h = solve_ray(P, g, r);
+  int st = rays_good(P, h.x, h.y);
+  if (h.lost) st = P.lost_num;
+  complete_ray(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
+}
+
+// crystal path, first half: solve + state; stores t, local hit point and state,
+// accumulates sum(beamInDotNormal) over the rays that hit (reflect.py:573)
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
+    xrt_hip_pass P, xrt_hip_beam in, double* ht, double* hx, double* hy, double* hz,
+    int32_t* hst, GStat* gp) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double bdn = 0.;
+  unsigned long long cnt = 0;
+  if (i < in.n && entering(P, in.state[i])) {
+    const GStat g = *gp;
+    const LocalRay r = load_local(P, in, i);
+    const Hit h = solve_ray(P, g, r);
+    int st = rays_good(P, h.x, h.y);
+    if (h.lost) st = P.lost_num;
+    ht[i] = h.t;
+    hx[i] = h.x;
+    hy[i] = h.y;
+    hz[i] = h.z;
+    hst[i] = st;
+    if (st == 1) {
+      double n0 = P.n_const[0], n1 = P.n_const[1], n2 = P.n_const[2];
+      if (P.surf_kind == XRT_HIP_SURF_TOROID) {
+        const double R = P.surf_p[0], rr = P.surf_p[1];
+        const double qx = h.x / rr;
+        const double rx = 1. - qx * qx;
+        const double ax = rx < 0. ? 0. : 1. / sqrt(rx);
+        const double na = -h.x / rr * ax, nb = -h.y / R;
+        const double norm = sqrt(na * na + nb * nb + 1.);
+        n0 = na / norm;
+        n1 = nb / norm;
+        n2 = 1. / norm;
+      }
+      bdn = r.a * n0 + r.b * n1 + r.c * n2;
+      if (bdn < -1.) bdn = -1.;
+      if (bdn > 1.) bdn = 1.;
+      cnt = 1;
+    }
+  }
+  auto faddd = [](double u, double v) { return u + v; };
+  auto faddu = [](unsigned long long u, unsigned long long v) { return u + v; };
+  bdn = block_reduce(bdn, faddd, lds_d);
+  cnt = block_reduce(cnt, faddu, lds_u);
+  if (threadIdx.x == 0 && cnt) {
+    atomicAdd(&gp->sum_bdn, bdn);
+    atomicAdd(&gp->n_good1, cnt);
+  }
+}
+
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_finish(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
+    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const double* ht, const double* hx,
+    const double* hy, const double* hz, const int32_t* hst, const GStat* gp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in.n) return;
+  const bool has_amp = in.Es_ri != nullptr;
+  const int st0 = in.state[i];
+  if (!entering(P, st0)) {
+    pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
+    return;
+  }
+  const GStat g = *gp;
+  LocalRay r;
+  r.x = 0.;
+  r.y = 0.;
+  r.z = 0.;
+  r.a = in.a[i];
+  r.b = in.b[i];
+  r.c = in.c[i];
+  local_dir(P, r.a, r.b, r.c);
+  Hit h;
+  h.t = ht[i];
+  h.x = hx[i];
+  h.y = hy[i];
+  h.z = hz[i];
+  h.lost = 0;
+  complete_ray(P, M, g, in, restore, lb, vb, theta, i, r, h, hst[i], has_amp);
+}
+
+
+// ---------------------------------------------------------------------------
+// stand-alone amplitude kernels (Material.get_amplitude / Crystal.get_amplitude)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(REFLECT_BLOCK) void material_amplitude_kernel(
+    xrt_hip_material M, int64_t n, const double* __restrict__ E,
+    const double* __restrict__ bdn, double2* __restrict__ rs, double2* __restrict__ rp,
+    double* __restrict__ mu, double* __restrict__ nk) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Ampl A = material_amplitude(M, E[i], bdn[i]);
+  rs[i] = make_double2(A.rs.re, A.rs.im);
+  rp[i] = make_double2(A.rp.re, A.rp.im);
+  if (mu) mu[i] = A.mu;
+  if (nk) nk[i] = A.nk;
+}
+
+__global__ __launch_bounds__(REFLECT_BLOCK) void crystal_amplitude_kernel(
+    xrt_hip_material M, int64_t n, const double* __restrict__ E,
+    const double* __restrict__ g0, const double* __restrict__ gh,
+    const double* __restrict__ hns, double2* __restrict__ S, double2* __restrict__ P) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Ampl A = crystal_amplitude(M, E[i], g0[i], gh[i], hns[i]);
+  S[i] = make_double2(A.rs.re, A.rs.im);
+  P[i] = make_double2(A.rp.re, A.rp.im);
+}
+
+hipError_t material_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
+                                     const double* bdn, double* rs, double* rp, double* mu,
+                                     double* nk, hipStream_t st) {
+  hipLaunchKernelGGL(material_amplitude_kernel,
+                     dim3((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)),
+                     dim3(REFLECT_BLOCK), 0, st, M, n, E, bdn, reinterpret_cast<double2*>(rs),
+                     reinterpret_cast<double2*>(rp), mu, nk);
+  return hipGetLastError();
+}
+
+hipError_t crystal_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
+                                    const double* g0, const double* gh, const double* hns,
+                                    double* S, double* P, hipStream_t st) {
+  hipLaunchKernelGGL(crystal_amplitude_kernel,
+                     dim3((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)),
+                     dim3(REFLECT_BLOCK), 0, st, M, n, E, g0, gh, hns,
+                     reinterpret_cast<double2*>(S), reinterpret_cast<double2*>(P));
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// host-side launcher
+// ---------------------------------------------------------------------------
+size_t reflect_workspace_bytes(int64_t n) {
+  // GStat (256 B) + t, x, y, z (4 x 8n) + state (4n), each 256-aligned
+  const size_t a = ((size_t)n * 8 + 255) / 256 * 256;
+  const size_t s = ((size_t)n * 4 + 255) / 256 * 256;
+  return 256 + 4 * a + s;
+}
+
+hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
+                               const xrt_hip_beam& in, const xrt_hip_beam& restore,
+                               const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
+                               void* workspace, hipStream_t st, hipEvent_t ev0,
+                               hipEvent_t ev1) {
+  GStat* g = reinterpret_cast<GStat*>(workspace);
+  const int64_t n = in.n;
+  if (n <= 0) return hipSuccess;
+  const size_t a = ((size_t)n * 8 + 255) / 256 * 256;
+  char* base = reinterpret_cast<char*>(workspace) + 256;
+  double* ht = reinterpret_cast<double*>(base);
+  double* hx = reinterpret_cast<double*>(base + a);
+  double* hy = reinterpret_cast<double*>(base + 2 * a);
+  double* hz = reinterpret_cast<double*>(base + 3 * a);
+  int32_t* hst = reinterpret_cast<int32_t*>(base + 4 * a);
+  const dim3 grid((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)), block(REFLECT_BLOCK);
+  if (ev0) (void)hipEventRecord(ev0, st);
+  hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g);
+  if (!P.no_intersection_search) {
+    hipLaunchKernelGGL(reflect_stats_dir, grid, block, 0, st, P, in, g);
+    hipLaunchKernelGGL(reflect_decide_axis, dim3(1), dim3(1), 0, st, P, in, g);
+    hipLaunchKernelGGL(reflect_stats_bracket, grid, block, 0, st, P, in, g);
+  }
+  const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  if (need_mean) {
+    hipLaunchKernelGGL(reflect_solve, grid, block, 0, st, P, in, ht, hx, hy, hz, hst, g);
+    hipLaunchKernelGGL(reflect_finish, grid, block, 0, st, P, M, in, restore, lb, vb, theta,
+                       ht, hx, hy, hz, hst, g);
+  } else {
+    hipLaunchKernelGGL(reflect_fused, grid, block, 0, st, P, M, in, restore, lb, vb, theta, g);
+  }
+  if (ev1) (void)hipEventRecord(ev1, st);
+  return hipGetLastError();
+}
+
+}  // namespace xrt

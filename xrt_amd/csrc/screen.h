@@ -1,0 +1,7 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/xrt_hip.h"
+namespace xrt {
+hipError_t screen_expose_launch(const xrt_hip_screen& S, const xrt_hip_beam& in,
+                                const xrt_hip_beam& out, hipStream_t st);
+}
