@@ -1,0 +1,308 @@
+#!/usr/bin/env python
+"""Benchmark of the accelerated hot path (BASELINE.json metric):
+
+  primary    ray-surface intersections/s   cfg2: 1e7 rays -> ToroidMirror(Pt),
+                                           one OE.reflect per step (P1)
+  kirchhoff  sample*pixel pairs/s          cfg4: 1e6 samples -> 512x512 screen
+                                           (cfg5 4e6 x 2048^2 on 8 GPUs / request)
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU. P1 does not shard (geometric tracing stays single-GPU,
+SURVEY 8e): N ranks run N independent replicas (weak scaling). The Kirchhoff
+integral shards over output-pixel tiles (strong scaling) with one RCCL
+all_gather of the five complex result arrays.
+
+Rank 0 prints ONE JSON line. ``value`` is whole-job throughput with all inputs
+resident in HBM. ``roofline`` times the dominant kernel with HIP events on the
+launch stream; ``cpu_baseline`` times the numpy oracle (test infrastructure) on
+a bounded sample of the same workload on the host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip table (spec)
+FP64_PEAK = 78.6e12        # flop/s vector = matrix fp64 (256 CU x 4 SIMD x 16 lanes
+#                            x 2 flop x 2.4 GHz)
+BYTES_PER_INTERSECTION = 308   # SURVEY 8d / BASELINE.md: 100 B in + 2 x 100 B out + 8 B theta
+FLOP_PER_PAIR = 57             # SURVEY 8d / BASELINE.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--rays', type=float, default=1e7)
+    ap.add_argument('--kirchhoff-config', type=int, default=0,
+                    help='4 or 5; 0 = 4, plus 5 when --gpus 8')
+    ap.add_argument('--kirchhoff-steps', type=int, default=0)
+    ap.add_argument('--skip-kirchhoff', action='store_true')
+    ap.add_argument('--skip-cpu-baseline', action='store_true')
+    ap.add_argument('--with-dcm', action='store_true',
+                    help='also time cfg3 (DCM Si111, 2 intersections per ray)')
+    return ap.parse_args()
+
+
+def setup_dist(args):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs one process per GPU: launch with '
+                             'python -m torch.distributed.run --nproc-per-node %d'
+                             % (args.gpus, args.gpus))
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    return world, rank, local, dist
+
+
+def barrier(dist):
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(dist, seconds):
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ----------------------------------------------------------------------------
+# P1
+# ----------------------------------------------------------------------------
+def bench_reflect(args, world, rank, dist, dcm=False):
+    from xrt_amd import workloads as pc
+    n = int(args.rays)
+    seed = (43 if dcm else 42) + 1000 * rank          # replicas: own rays per rank
+    if dcm:
+        oe = pc.cfg3_dcm()
+        beam = pc.synthetic_rays(n, seed, sa=1e-4, E=(8995., 9005.))
+        op = oe.double_reflect
+        surfaces = 2
+    else:
+        oe = pc.cfg2_toroid()
+        beam = pc.synthetic_rays(n, seed)
+        op = oe.reflect
+        surfaces = 1
+    for f in beam.array_fields():                      # inputs resident in HBM
+        beam.dev(f)
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        op(beam)
+    barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = op(beam)
+    barrier(dist)
+    dt = max_over_ranks(dist, time.perf_counter() - t0)
+    n_enter = int((beam.peek('state') > 0).sum())
+    value = world * n_enter * surfaces * args.steps / dt
+    # dominant kernel, HIP events on the launch stream
+    kms, pms = [], []
+    if not dcm:
+        p = oe._make_pass(oe.pitch, oe.roll + oe.positionRoll, oe.yaw, oe.dx)
+        for _ in range(max(3, min(args.steps, 10))):
+            _, _, info = oe._run_pass(p, oe.material, True, beam, beam, timing=True)
+            kms.append(info['kernel_ms'])
+            pms.append(info['pass_ms'])
+    st = out[0].peek('state')
+    res = dict(value=value, ms_per_step=dt / args.steps * 1e3, rays=n,
+               n_enter=n_enter, surfaces=surfaces,
+               good_fraction=float((st == 1).mean()))
+    if kms:
+        k = float(np.mean(kms)) * 1e-3
+        res['kernel_ms'] = k * 1e3
+        res['pass_ms'] = float(np.mean(pms))
+        res['roofline'] = dict(
+            bound='hbm', kernel='reflect_fused',
+            achieved=BYTES_PER_INTERSECTION * n_enter / k / 1e9,
+            peak=HBM_PEAK / 1e9, unit='GB/s',
+            frac=BYTES_PER_INTERSECTION * n_enter / k / HBM_PEAK,
+            traffic=load_traffic('reflect_fused'))
+    return res
+
+
+def cpu_baseline_reflect(nrays=1_000_000):
+    """numpy oracle of the same cfg2 workload on the host, bounded sample."""
+    from xrt_amd import workloads as pc
+    from oracle.adapters import oracle_params, to_oracle_beam
+    from oracle import reflect_np as rn
+    oe = pc.cfg2_toroid()
+    beam = to_oracle_beam(pc.synthetic_rays(nrays, 42))
+    params = oracle_params(oe)
+    t0 = time.perf_counter()
+    rn.oe_reflect(params, beam)
+    dt = time.perf_counter() - t0
+    return dict(value=nrays / dt, unit='intersections/s', cores=1, kind='port',
+                sample='%d rays of cfg2 through oracle/reflect_np.py (numpy, 1 '
+                       'thread), %.1f s' % (nrays, dt))
+
+
+# ----------------------------------------------------------------------------
+# P2
+# ----------------------------------------------------------------------------
+def kirchhoff_inputs(cfg, device):
+    """SURVEY 8d cfg4 / cfg5 (xrt_amd.workloads.kirchhoff_case), samples
+    uploaded to HBM."""
+    from xrt_amd import workloads
+    h = workloads.kirchhoff_case(cfg)
+    ns = h['ns']
+    up = lambda a, dt=np.float64: torch.from_numpy(  # noqa: E731
+        np.ascontiguousarray(a, dtype=dt)).to(device)
+    samples = dict(sx=up(h['sx']), sy=up(h['sy']), sz=up(h['sz']),
+                   nx=up(np.zeros(ns)), ny=up(np.ones(ns)), nz=up(np.zeros(ns)),
+                   nl=up(h['nl']), k=up(h['k']), Es=up(h['Es'], np.complex128),
+                   Ep=up(h['Ep'], np.complex128))
+    return samples, (h['px'], h['py'], h['pz']), h, ns, h['side']
+
+
+def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
+    from xrt_amd import hipcalls
+    dev = torch.device('cuda', torch.cuda.current_device())
+    s, (px, py, pz), host, ns, side = kirchhoff_inputs(cfg, dev)
+    npix = px.size
+    p0, p1 = npix * rank // world, npix * (rank + 1) // world   # pixel tile
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a[p0:p1])).to(dev)  # noqa: E731
+    tx, ty, tz = up(px), up(py), up(pz)
+    out = tuple(torch.empty(p1 - p0, dtype=torch.complex128, device=dev)
+                for _ in range(5))
+    gathered = None
+    if dist is not None:
+        assert npix % world == 0
+        gathered = [torch.empty(npix, dtype=torch.complex128, device=dev)
+                    for _ in range(5)]
+
+    def step(timing=False):
+        r = hipcalls.kirchhoff(tx, ty, tz, s['sx'], s['sy'], s['sz'], s['nx'],
+                               s['ny'], s['nz'], s['nl'], s['k'], s['Es'], s['Ep'],
+                               convention=0, out=out, timing=timing)
+        if dist is not None:        # assemble the full field on every rank (RCCL)
+            for g, o in zip(gathered, out):
+                dist.all_gather_into_tensor(g, o)
+        return r
+    for _ in range(warmup):
+        step()
+    barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier(dist)
+    dt = max_over_ranks(dist, time.perf_counter() - t0)
+    pairs = float(ns) * float(npix)
+    kms = [step(timing=True)[5] for _ in range(2)]
+    k = float(np.mean(kms)) * 1e-3
+    my_pairs = float(ns) * float(p1 - p0)
+    res = dict(
+        metric='Kirchhoff sample*pixel pairs/s', value=pairs * steps / dt,
+        unit='pairs/s', n_gpus=world, steps=steps, warmup=warmup,
+        ms_per_step=dt / steps * 1e3, scaling='strong', dtype='f64',
+        config=dict(workload='cfg%d: %d samples -> %dx%d screen, fp64, pixel-tiled'
+                             % (cfg, ns, side, side), samples=ns, pixels=npix,
+                    parallelism='pixel tiles x%d + all_gather' % world),
+        kernel_ms=k * 1e3,
+        roofline=dict(bound='mfma', kernel='kirchhoff_stream',
+                      note='fp64 VALU kernel; MI355X vector fp64 peak = matrix '
+                           'fp64 peak = 78.6 TFLOP/s; 57 flop per pair '
+                           '(sqrt, div, sin, cos counted as 1)',
+                      achieved=FLOP_PER_PAIR * my_pairs / k / 1e12,
+                      peak=FP64_PEAK / 1e12, unit='TFLOP/s',
+                      frac=FLOP_PER_PAIR * my_pairs / k / FP64_PEAK,
+                      traffic=load_traffic('kirchhoff_stream')))
+    return res, host
+
+
+def cpu_baseline_kirchhoff(host, npix=32):
+    from oracle import kirchhoff_np as kn
+    idx = np.linspace(0, host['px'].size - 1, npix).astype(int)
+    t0 = time.perf_counter()
+    kn.kirchhoff_conv(host['px'][idx], host['py'][idx], host['pz'][idx],
+                      host['sx'], host['sy'], host['sz'], [0, 1, 0], host['nl'],
+                      host['E'], host['Es'], host['Ep'])
+    dt = time.perf_counter() - t0
+    ns = host['sx'].size
+    return dict(value=npix * ns / dt, unit='pairs/s', cores=1, kind='port',
+                sample='%d pixels x %d samples of cfg4 through '
+                       'oracle/kirchhoff_np.py (numpy, 1 thread), %.1f s; the '
+                       'integral is linear in pixels' % (npix, ns, dt))
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch from the committed PMC summary (profiles/), or None."""
+    path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get('hbm_bytes_per_launch')
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def main():
+    args = parse()
+    from xrt_amd import _lib
+    _lib.require_gpu()                    # no CPU fallback: fail loudly
+    world, rank, local, dist = setup_dist(args)
+    main_res = bench_reflect(args, world, rank, dist)
+    line = dict(
+        metric='ray-surface intersections/sec/GPU; Kirchhoff sample*pixel '
+               'pairs/sec at 1/2/4/8 GPUs (see "kirchhoff")',
+        value=main_res['value'], unit='intersections/s', n_gpus=world,
+        steps=args.steps, warmup=args.warmup,
+        ms_per_step=main_res['ms_per_step'], higher_is_better=True,
+        scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+        config=dict(
+            workload='cfg2: %d rays/GPU -> ToroidMirror(Pt, p=20 m, q=10 m, '
+                     '4 mrad), one OE.reflect per step' % int(args.rays),
+            rays_per_gpu=int(args.rays), entering=main_res['n_enter'],
+            good_fraction=main_res['good_fraction'],
+            parallelism='replicas x%d (P1 does not shard, SURVEY 8e)' % world),
+        per_gpu=main_res['value'] / world, pass_ms=main_res.get('pass_ms'),
+        kernel_ms=main_res.get('kernel_ms'), roofline=main_res.get('roofline'))
+    if args.with_dcm:
+        d = bench_reflect(args, world, rank, dist, dcm=True)
+        line['dcm'] = dict(metric='ray-surface intersections/s (cfg3 DCM Si111)',
+                           value=d['value'], ms_per_step=d['ms_per_step'],
+                           good_fraction=d['good_fraction'])
+    host = None
+    if not args.skip_kirchhoff:
+        cfgs = [args.kirchhoff_config] if args.kirchhoff_config else \
+            ([4, 5] if world == 8 else [4])
+        for cfg in cfgs:
+            ks = args.kirchhoff_steps or (max(1, min(args.steps, 3)) if cfg == 4 else 1)
+            kw = 1 if cfg == 4 else 0
+            kres, h = bench_kirchhoff(cfg, ks, kw, world, rank, dist)
+            if cfg == 4 or host is None:
+                host = h
+            line['kirchhoff' if 'kirchhoff' not in line else 'kirchhoff_cfg%d' % cfg] = kres
+    if world == 1 and rank == 0 and not args.skip_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline_reflect()
+        line['cpu_baseline']['host_cpus'] = os.cpu_count()
+        if host is not None and 'kirchhoff' in line:
+            line['kirchhoff']['cpu_baseline'] = cpu_baseline_kirchhoff(host)
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,51 @@
+"""TEST INFRASTRUCTURE ONLY — converts xrt_amd (product) objects into the
+oracle's parameter dictionaries / Beam records, so that tests and bench.py's
+cpu_baseline leg can run the numpy restatement on the very same configuration."""
+import numpy as np
+
+from . import fixture_io, materials_np as mn, reflect_np as rn
+
+
+def oracle_params(oe):
+    """xrt_amd OE -> the oracle's parameter dictionary."""
+    p = dict(
+        center=[float(c) for c in oe.center],
+        azimuth_sc=(oe.bl.sinAzimuth, oe.bl.cosAzimuth), pitch=oe.pitch,
+        roll=oe.roll, yaw=oe.yaw, positionRoll=oe.positionRoll,
+        rotationSequence=oe.rotationSequence, extraPitch=oe.extraPitch,
+        extraRoll=oe.extraRoll, extraYaw=oe.extraYaw,
+        extraRotationSequence=oe.extraRotationSequence, dx=oe.dx, shape=oe.shape,
+        overEdge=oe.overEdge, lostNum=oe.lostNum, surfPhysX=list(oe.limPhysX),
+        surfPhysY=list(oe.limPhysY), surfOptX=oe.limOptX, surfOptY=oe.limOptY)
+    tb = fixture_io.tables()
+    if hasattr(oe, 'R'):
+        p['surface'] = dict(kind='toroid', R=oe.R, r=oe.r)
+    else:
+        p['surface'] = dict(kind='flat', alpha=oe.alpha)
+
+    def mat(m):
+        if m is None:
+            return None
+        if m.kind == 'crystal':
+            return mn.make_crystal(mn.load_element(tb, m.elements[0].name), m.hkl,
+                                   m.d, 'diamond', m.geom, m.t, m.factDW, m.V)
+        return mn.make_material([mn.load_element(tb, e.name) for e in m.elements],
+                                list(m.quantities), m.kind, m.rho, m.t)
+    p['material'] = mat(oe.material)
+    if hasattr(oe, 'cryst2pitch'):
+        p.update(bragg=oe.bragg, cryst1roll=oe.cryst1roll, cryst2roll=oe.cryst2roll,
+                 cryst2pitch=oe.cryst2pitch, cryst2finePitch=oe.cryst2finePitch,
+                 cryst2perpTransl=oe.cryst2perpTransl,
+                 cryst2longTransl=oe.cryst2longTransl,
+                 surfPhysX2=list(oe.limPhysX2), surfPhysY2=list(oe.limPhysY2),
+                 surfOptX2=oe.limOptX2, surfOptY2=oe.limOptY2,
+                 surface2=dict(kind='flat', alpha=oe.alpha, flip_n_y=True),
+                 material2=mat(oe.material2))
+    return p
+
+
+def to_oracle_beam(b):
+    o = rn.Beam(len(b), with_amplitudes=b.has_amplitudes())
+    for f in o.fields():
+        setattr(o, f, np.array(b.peek(f)))
+    return o

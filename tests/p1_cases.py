@@ -104,45 +104,4 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'))
 
 
-def cfg2_toroid(bl=None):
-    """BASELINE cfg2: toroid mirror + Pt, SURVEY 8d."""
-    bl = bl or raycing.BeamLine()
-    p, q, pitch = 20000., 10000., 4e-3
-    m = rm.Material('Pt', rho=21.45, kind='mirror')
-    return roe.ToroidMirror(bl, 'tm', center=[0, p, 0], pitch=pitch, R=(p, q),
-                            r=(p, q), material=m, limPhysX=[-10, 10],
-                            limPhysY=[-300, 300])
-
-
-def cfg3_dcm(bl=None):
-    """BASELINE cfg3: Si(111) double-crystal monochromator, SURVEY 8d."""
-    bl = bl or raycing.BeamLine()
-    si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
-    si2 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
-    thB = float(si1.get_Bragg_angle(9000.) - si1.get_dtheta(9000.))
-    return roe.DCM(bl, 'dcm', center=[0, 20000., 0], bragg=thB, material=si1,
-                   material2=si2, cryst2perpTransl=10., limPhysX=[-10, 10],
-                   limPhysY=[-50, 50], limPhysX2=[-10, 10], limPhysY2=[-50, 150])
-
-
-def synthetic_rays(n, seed, sa=2e-4, sc=2e-5, E=(8990., 9010.), amplitudes=False):
-    """SURVEY 8d cfg2/cfg3 ray generator (numpy default_rng on the host)."""
-    rng = np.random.default_rng(seed)
-    b = rs.Beam(nrays=n, withAmplitudes=amplitudes)
-    b.x = rng.normal(0, 0.1, n)
-    b.z = rng.normal(0, 0.1, n)
-    b.y = np.zeros(n)
-    a = rng.normal(0, sa, n)
-    c = rng.normal(0, sc, n)
-    b.a = a
-    b.c = c
-    b.b = np.sqrt(1 - a**2 - c**2)
-    b.E = rng.uniform(E[0], E[1], n)
-    b.state = np.ones(n, dtype=np.int32)
-    b.Jss = np.ones(n)
-    b.Jpp = np.zeros(n)
-    b.Jsp = np.zeros(n, dtype=complex)
-    if amplitudes:
-        b.Es = np.ones(n, dtype=complex)
-        b.Ep = np.zeros(n, dtype=complex)
-    return b
+from xrt_amd.workloads import cfg2_toroid, cfg3_dcm, synthetic_rays  # noqa: E402,F401

@@ -253,13 +253,13 @@ class OE(object):
         wsb = lib.xrt_hip_reflect_workspace_bytes(n)
         ws = hipcalls.workspace(dev, wsb, 'reflect')
         info = (ctypes.c_double * 16)() if want_info else None
-        ms_out = ctypes.c_float(0.) if timing else None
+        ms_out = (ctypes.c_float * 2)() if timing else None
         rc = lib.xrt_hip_reflect_pass_f64_dev(
             ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in),
             ctypes.byref(s_re), ctypes.byref(s_lb), ctypes.byref(s_vb),
             ctypes.c_void_p(theta.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
             ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
-            info, ctypes.byref(ms_out) if timing else None)
+            info, ms_out)
         _lib.check(rc, 'xrt_hip_reflect_pass_f64_dev')
         lb.theta = theta
         for b in (lb, vb):
@@ -277,7 +277,8 @@ class OE(object):
                             maxdz2=v[6], n_enter=int(v[7]))
         if timing:
             res_info = res_info or {}
-            res_info['kernel_ms'] = ms_out.value
+            res_info['pass_ms'] = ms_out[0]
+            res_info['kernel_ms'] = ms_out[1]
         return lb, vb, res_info
 
     # -- local -> global for a beam on the surface (oes/base.py:1165-1229) ------

@@ -291,23 +291,25 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
     return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes,
                 xrt::reflect_workspace_bytes(n));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;
   if (kernel_ms) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventCreate(&k0));
+    HIP_TRY(hipEventCreate(&k1));
   }
   hipError_t e = xrt::reflect_pass_launch(*pass, *material, *in, *restore, *out_local,
-                                          *out_virgin, theta, workspace, st, e0, e1);
+                                          *out_virgin, theta, workspace, st, e0, e1, k0, k1);
   if (e != hipSuccess) {
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
+    for (hipEvent_t ev : {e0, e1, k0, k1})
+      if (ev) (void)hipEventDestroy(ev);
     return fail(XRT_HIP_ERR_HIP, "reflect launch: %s", hipGetErrorString(e));
   }
   if (kernel_ms) {
     HIP_TRY(hipEventSynchronize(e1));
-    HIP_TRY(hipEventElapsedTime(kernel_ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIP_TRY(hipEventElapsedTime(&kernel_ms[0], e0, e1));
+    HIP_TRY(hipEventElapsedTime(&kernel_ms[1], k0, k1));
+    for (hipEvent_t ev : {e0, e1, k0, k1}) (void)hipEventDestroy(ev);
   }
   if (info_host) {
     xrt::GStat g;

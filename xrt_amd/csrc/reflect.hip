@@ -1244,7 +1244,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                const xrt_hip_beam& in, const xrt_hip_beam& restore,
                                const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
                                void* workspace, hipStream_t st, hipEvent_t ev0,
-                               hipEvent_t ev1) {
+                               hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1) {
   GStat* g = reinterpret_cast<GStat*>(workspace);
   const int64_t n = in.n;
   if (n <= 0) return hipSuccess;
@@ -1266,10 +1266,14 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
   if (need_mean) {
     hipLaunchKernelGGL(reflect_solve, grid, block, 0, st, P, in, ht, hx, hy, hz, hst, g);
+    if (evk0) (void)hipEventRecord(evk0, st);
     hipLaunchKernelGGL(reflect_finish, grid, block, 0, st, P, M, in, restore, lb, vb, theta,
                        ht, hx, hy, hz, hst, g);
+    if (evk1) (void)hipEventRecord(evk1, st);
   } else {
+    if (evk0) (void)hipEventRecord(evk0, st);
     hipLaunchKernelGGL(reflect_fused, grid, block, 0, st, P, M, in, restore, lb, vb, theta, g);
+    if (evk1) (void)hipEventRecord(evk1, st);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   return hipGetLastError();
