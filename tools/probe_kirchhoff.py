@@ -3,28 +3,24 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, '.')
-from xrt_amd import hipcalls  # noqa: E402
+from xrt_amd import hipcalls, workloads  # noqa: E402
 
 
 def main():
-    npix = int(float(sys.argv[1])) if len(sys.argv) > 1 else 512 * 512
-    ns = int(float(sys.argv[2])) if len(sys.argv) > 2 else 200_000
-    g = torch.Generator(device='cuda').manual_seed(7)
-    r = lambda n, lo, hi: (torch.rand(n, generator=g, device='cuda', dtype=torch.float64) * (hi - lo) + lo)  # noqa: E731
-    px, pz = r(npix, -.5, .5), r(npix, -.5, .5)
-    py = torch.full((npix,), 10000., device='cuda', dtype=torch.float64)
-    sx, sz, sy = r(ns, -.1, .1), r(ns, -.1, .1), torch.zeros(ns, device='cuda', dtype=torch.float64)
-    nx = torch.zeros_like(sx); ny = torch.ones_like(sx); nz = torch.zeros_like(sx)
-    nl = r(ns, .99, 1.)
-    k = torch.full((ns,), 7900. / 1973.2697177417986 * 1e7, device='cuda', dtype=torch.float64)
-    Es = torch.complex(r(ns, -1, 1), r(ns, -1, 1))
-    Ep = torch.complex(r(ns, -1, 1), r(ns, -1, 1))
+    cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    h = workloads.kirchhoff_case(cfg) if cfg in (4, 5) else workloads.kirchhoff_custom(200000, 512)
+    dev = torch.device('cuda', 0)
+    up = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
+    ns = h['ns']
+    args = [up(h['px']), up(h['py']), up(h['pz']), up(h['sx']), up(h['sy']), up(h['sz']),
+            up(np.zeros(ns)), up(np.ones(ns)), up(np.zeros(ns)), up(h['nl']), up(h['k']),
+            up(h['Es'], np.complex128), up(h['Ep'], np.complex128)]
+    npix = h['px'].size
     for ppt in (1, 2):
-        for nsplit in (0, 1, 2, 4, 8, 16):
+        for nsplit in (1, 2, 4, 8, 16, 32):
             best = 1e30
-            for it in range(3):
-                *_, ms = hipcalls.kirchhoff(px, py, pz, sx, sy, sz, nx, ny, nz, nl, k, Es, Ep,
-                                            nsplit=nsplit, ppt=ppt, timing=True)
+            for it in range(2):
+                *_, ms = hipcalls.kirchhoff(*args, nsplit=nsplit, ppt=ppt, timing=True)
                 best = min(best, ms)
             pairs = npix * ns / (best * 1e-3)
             print('ppt=%d nsplit=%2d  %8.2f ms  %.3e pairs/s  %.1f%% of 78.6 TF (57 flop/pair)'

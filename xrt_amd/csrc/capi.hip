@@ -78,6 +78,7 @@ int xrt_hip_kirchhoff_f64_dev(
     size_t workspace_bytes, int nsplit_req, int ppt_req, void* stream,
     float* kernel_ms) {
   if (np < 0 || ns < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (ns > 2147483647LL) return fail(XRT_HIP_ERR_ARG, "more than 2^31-1 samples");
   if (convention != 0 && convention != 1)
     return fail(XRT_HIP_ERR_ARG, "convention must be 0 (numpy) or 1 (OpenCL)");
   if (np > 0 && (!px || !py || !pz || !S_ri || !P_ri || !A_ri || !B_ri || !C_ri))
@@ -123,6 +124,7 @@ int xrt_hip_kirchhoff_f64(int ndev, const int* dev_ids, int64_t np, const double
                           float* kernel_ms) {
   if (ndev < 1 || !dev_ids) return fail(XRT_HIP_ERR_ARG, "need >=1 device id");
   if (np < 0 || ns < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (ns > 2147483647LL) return fail(XRT_HIP_ERR_ARG, "more than 2^31-1 samples");
   if (convention != 0 && convention != 1)
     return fail(XRT_HIP_ERR_ARG, "convention must be 0 (numpy) or 1 (OpenCL)");
   if (np > 0 && (!px || !py || !pz || !S_ri || !P_ri || !A_ri || !B_ri || !C_ri))

@@ -33,6 +33,23 @@ __device__ __forceinline__ double sqrt_rn_rinv(double x, double& rinv) {
   return g;
 }
 
+// Same, but returns h = 1/(2 sqrt(x)) as it falls out of the iteration (callers
+// fold the factor 2 into a per-sample constant).
+__device__ __forceinline__ double sqrt_rn_halfinv(double x, double& hinv) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  double r0 = fma_(-h, g, 0.5);
+  g = fma_(g, r0, g);
+  h = fma_(h, r0, h);
+  double d0 = fma_(-g, g, x);
+  g = fma_(d0, h, g);
+  double d1 = fma_(-g, g, x);
+  g = fma_(d1, h, g);
+  hinv = h;
+  return g;
+}
+
 // sin/cos of a LARGE positive-or-negative phase phi [rad] (|phi| < 2^50),
 // accurate to ~2e-16 absolute. The Kirchhoff phase k*r is ~4e11 rad, so ocml's
 // generic sincos would take its Payne-Hanek path every call; here the

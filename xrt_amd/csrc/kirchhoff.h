@@ -6,15 +6,18 @@
 
 #define KIRCHHOFF_BLOCK 256
 #define KIRCHHOFF_REC_DOUBLES 16
+#define KIRCHHOFF_FLAG_EP 1u
+#define KIRCHHOFF_FLAG_NXZ 2u
 
 namespace xrt {
 
 struct KirchhoffPlan {
   int ppt;               // receiving points per lane (1 or 2)
   int nsplit;            // sample splits (grid = tiles * nsplit)
+  int chunk;             // samples per split
   int64_t tiles;         // pixel tiles of KIRCHHOFF_BLOCK*ppt
   int64_t np_pad;        // row pitch of the partial-sum workspace
-  size_t rec_bytes;      // packed sample records
+  size_t rec_bytes;      // flags (256 B) + packed sample records
   size_t partial_bytes;  // nsplit * 10 * np_pad doubles
   size_t workspace_bytes() const { return ((rec_bytes + 255) / 256) * 256 + partial_bytes; }
 };

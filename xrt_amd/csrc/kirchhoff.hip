@@ -31,8 +31,13 @@ namespace xrt {
 // pack: sample arrays -> 16-double records. Positions / normals are read with
 // an element stride so that both the SoA layout (stride 1) and the reference's
 // OpenCL marshalling ns x [x,y,z,0] (stride 4, waves.py:872-879) feed it.
-//   [0..2] x,y,z  [3] nl  [4..6] n  [7] k  [8,9] Es  [10,11] Ep
-//   [12,13] k*(Es+Ep)  [14,15] 0
+//   [0..2] x,y,z  [3] nl  [4..6] 2n  [7] k  [8,9] Es  [10,11] Ep
+//   [12,13] k*(Es+Ep)  [14] 2k  [15] k*k
+// (1/r comes out of the sqrt iteration as h = 1/(2r): the factor 2 is folded
+// into 2n and 2k here, once per sample instead of once per pair.)
+// The kernel also classifies the sample set so that the main kernel can take a
+// shorter instruction stream when it is safe: flags bit 0 = some Ep != 0,
+// bit 1 = some normal has an x or z component.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kirchhoff_pack(
     int64_t ns, const double* __restrict__ sx, const double* __restrict__ sy,
@@ -40,22 +45,29 @@ __global__ __launch_bounds__(256) void kirchhoff_pack(
     const double* __restrict__ ny, const double* __restrict__ nz, int nstride,
     const double* __restrict__ nl, const double* __restrict__ k,
     const double2* __restrict__ Es, const double2* __restrict__ Ep,
-    double* __restrict__ rec) {
+    double* __restrict__ rec, unsigned* __restrict__ flags) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ns) return;
-  double2 es = Es[i], ep = Ep[i];
-  double kk = k[i];
-  double2* o = reinterpret_cast<double2*>(rec + i * KIRCHHOFF_REC_DOUBLES);
-  const int64_t ip = i * pstride, in = i * nstride;
-  o[0] = make_double2(sx[ip], sy[ip]);
-  o[1] = make_double2(sz[ip], nl[i]);
-  o[2] = make_double2(nx[in], ny[in]);
-  o[3] = make_double2(nz[in], kk);
-  o[4] = es;
-  o[5] = ep;
-  // numpy: k**2/(4pi) * (Es+Ep) * U / r ; the sum Es+Ep is formed first there too
-  o[6] = make_double2(kk * (es.x + ep.x), kk * (es.y + ep.y));
-  o[7] = make_double2(0.0, 0.0);
+  unsigned f = 0;
+  if (i < ns) {
+    double2 es = Es[i], ep = Ep[i];
+    double kk = k[i];
+    double2* o = reinterpret_cast<double2*>(rec + i * KIRCHHOFF_REC_DOUBLES);
+    const int64_t ip = i * pstride, in = i * nstride;
+    const double vx = nx[in], vy = ny[in], vz = nz[in];
+    o[0] = make_double2(sx[ip], sy[ip]);
+    o[1] = make_double2(sz[ip], nl[i]);
+    o[2] = make_double2(2. * vx, 2. * vy);
+    o[3] = make_double2(2. * vz, kk);
+    o[4] = es;
+    o[5] = ep;
+    // numpy: k**2/(4pi) * (Es+Ep) * U / r ; the sum Es+Ep is formed first there too
+    o[6] = make_double2(kk * (es.x + ep.x), kk * (es.y + ep.y));
+    o[7] = make_double2(2. * kk, kk * kk);
+    if (ep.x != 0. || ep.y != 0.) f |= KIRCHHOFF_FLAG_EP;
+    if (vx != 0. || vz != 0.) f |= KIRCHHOFF_FLAG_NXZ;
+  }
+  f = __builtin_amdgcn_readfirstlane(__reduce_or_sync(~0ull, f));
+  if ((threadIdx.x & 63) == 0 && f) atomicOr(flags, f);
 }
 
 // ---------------------------------------------------------------------------
@@ -65,44 +77,70 @@ struct Acc {
   double sr, si, pr, pi, ar, ai, br, bi, cr, ci;
 };
 
-__device__ __forceinline__ void pair_update(
-    double px, double py, double pz, const double* __restrict__ r, Acc& a) {
+// HAS_P: the p-polarised source field is present. GEN_N: normals are general
+// (otherwise every normal is (0, ny, 0), the aperture / screen / source case of
+// waves.py:687-689 — d.n collapses to dy*ny).
+template <bool HAS_P, bool GEN_N>
+__device__ __forceinline__ void pair_update(double px, double py, double pz,
+                                            const double* __restrict__ r, Acc& a) {
   const double sx = r[0], sy = r[1], sz = r[2], nl = r[3];
-  const double nx = r[4], ny = r[5], nz = r[6], k = r[7];
+  const double n2x = r[4], n2y = r[5], n2z = r[6], k = r[7];
   const double esr = r[8], esi = r[9], epr = r[10], epi = r[11];
-  const double qr = r[12], qi = r[13];
+  const double qr = r[12], qi = r[13], k2 = r[14], kk = r[15];
   // --- bit-exact part (numpy order, no contraction) ---
   const double dx = px - sx;
   const double dy = py - sy;
   const double dz = pz - sz;
   const double s2 = (dx * dx + dy * dy) + dz * dz;
-  double rinv;
-  const double rr = sqrt_rn_rinv(s2, rinv);
+  double h;  // 1/(2r)
+  const double rr = sqrt_rn_halfinv(s2, h);
   const double phase = k * rr;
   // --- the rest only needs ~1e-16 relative accuracy ---
-  double dn = dx * nx;
-  dn = fma_(dy, ny, dn);
-  dn = fma_(dz, nz, dn);
-  const double kip = k * rinv;
-  const double cr = kip * fma_(dn, rinv, nl);
+  double dn2;
+  if (GEN_N) {
+    dn2 = dx * n2x;
+    dn2 = fma_(dy, n2y, dn2);
+    dn2 = fma_(dz, n2z, dn2);
+  } else {
+    dn2 = dy * n2y;
+  }
+  const double kip = k2 * h;                    // k/r
+  const double cr = kip * fma_(dn2, h, nl);     // (k/r)(d.n/r + nl)
   double sn, cs;
   sincos_phase(phase, sn, cs);
   const double gr = cr * cs;
   const double gi = cr * sn;
-  a.sr = fma_(gr, esr, a.sr);
-  a.sr = fma_(-gi, esi, a.sr);
-  a.si = fma_(gr, esi, a.si);
-  a.si = fma_(gi, esr, a.si);
-  a.pr = fma_(gr, epr, a.pr);
-  a.pr = fma_(-gi, epi, a.pr);
-  a.pi = fma_(gr, epi, a.pi);
-  a.pi = fma_(gi, epr, a.pi);
-  const double hr0 = kip * gr;
-  const double hi0 = kip * gi;
-  double hr = hr0 * qr;
-  hr = fma_(-hi0, qi, hr);
-  double hi = hr0 * qi;
-  hi = fma_(hi0, qr, hi);
+  double hr, hi;
+  if (HAS_P) {
+    a.sr = fma_(gr, esr, a.sr);
+    a.sr = fma_(-gi, esi, a.sr);
+    a.si = fma_(gr, esi, a.si);
+    a.si = fma_(gi, esr, a.si);
+    a.pr = fma_(gr, epr, a.pr);
+    a.pr = fma_(-gi, epi, a.pr);
+    a.pi = fma_(gr, epi, a.pi);
+    a.pi = fma_(gi, epr, a.pi);
+    const double hr0 = kip * gr;
+    const double hi0 = kip * gi;
+    hr = hr0 * qr;
+    hr = fma_(-hi0, qi, hr);
+    hi = hr0 * qi;
+    hi = fma_(hi0, qr, hi);
+  } else {
+    // Ep == 0: k(Es+Ep) = k Es, so g*Es is shared by S and by the direction term
+    double wr = gr * esr;
+    wr = fma_(-gi, esi, wr);
+    double wi = gr * esi;
+    wi = fma_(gi, esr, wi);
+    a.sr += wr;
+    a.si += wi;
+    const double kkip = kip * k;
+    hr = kkip * wr;
+    hi = kkip * wi;
+    (void)qr;
+    (void)qi;
+  }
+  (void)kk;
   a.ar = fma_(hr, dx, a.ar);
   a.ai = fma_(hi, dx, a.ai);
   a.br = fma_(hr, dy, a.br);
@@ -111,16 +149,28 @@ __device__ __forceinline__ void pair_update(
   a.ci = fma_(hi, dz, a.ci);
 }
 
+template <int PPT, bool HAS_P, bool GEN_N>
+__device__ __forceinline__ void stream_loop(const double (&x)[PPT], const double (&y)[PPT],
+                                            const double (&z)[PPT], Acc (&acc)[PPT],
+                                            const double* __restrict__ rec, int s0, int s1) {
+  for (int s = s0; s < s1; ++s) {
+    const double* r = rec + (int64_t)s * KIRCHHOFF_REC_DOUBLES;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) pair_update<HAS_P, GEN_N>(x[j], y[j], z[j], r, acc[j]);
+  }
+}
+
 template <int PPT>
 __global__ __launch_bounds__(KIRCHHOFF_BLOCK) void kirchhoff_stream(
     int64_t np, const double* __restrict__ px, const double* __restrict__ py,
-    const double* __restrict__ pz, int64_t ns, const double* __restrict__ rec,
-    int nsplit, int64_t np_pad, double* __restrict__ partial) {
+    const double* __restrict__ pz, int ns, const double* __restrict__ rec,
+    const unsigned* __restrict__ flags, int nsplit, int chunk, int64_t np_pad,
+    double* __restrict__ partial) {
   const int split = blockIdx.x % nsplit;
   const int64_t tile = blockIdx.x / nsplit;
   const int64_t base = tile * (int64_t)(KIRCHHOFF_BLOCK * PPT) + threadIdx.x;
-  const int64_t s0 = ns * split / nsplit;
-  const int64_t s1 = ns * (split + 1) / nsplit;
+  const int s0 = split * chunk;
+  const int s1 = min(ns, s0 + chunk);
 
   double x[PPT], y[PPT], z[PPT];
   Acc acc[PPT];
@@ -134,11 +184,15 @@ __global__ __launch_bounds__(KIRCHHOFF_BLOCK) void kirchhoff_stream(
     z[j] = pz[pc];
     acc[j] = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   }
-  for (int64_t s = s0; s < s1; ++s) {
-    const double* r = rec + s * KIRCHHOFF_REC_DOUBLES;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) pair_update(x[j], y[j], z[j], r, acc[j]);
-  }
+  const unsigned f = __builtin_amdgcn_readfirstlane(*flags);   // wave-uniform dispatch
+  if (f == 0)
+    stream_loop<PPT, false, false>(x, y, z, acc, rec, s0, s1);
+  else if (f == KIRCHHOFF_FLAG_EP)
+    stream_loop<PPT, true, false>(x, y, z, acc, rec, s0, s1);
+  else if (f == KIRCHHOFF_FLAG_NXZ)
+    stream_loop<PPT, false, true>(x, y, z, acc, rec, s0, s1);
+  else
+    stream_loop<PPT, true, true>(x, y, z, acc, rec, s0, s1);
   double* out = partial + (int64_t)split * 10 * np_pad;
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
@@ -238,10 +292,11 @@ KirchhoffPlan kirchhoff_plan(int64_t np, int64_t ns, int nsplit_req, int ppt_req
   if (pl.tiles < 1) pl.tiles = 1;
   int nsplit = nsplit_req;
   if (nsplit <= 0) {
-    // want >= ~4 blocks per CU (1024 blocks); splits come in multiples of 8 so
-    // that split == XCD under the round-robin block placement
+    // The kernel is VALU-bound and VGPR-limited to ~7 blocks per CU; many more
+    // blocks than that (64 per CU) keep the tail short. Splits come in multiples
+    // of 8 so that split == XCD under the round-robin block placement.
     nsplit = 1;
-    const int64_t want_blocks = 1024;
+    const int64_t want_blocks = 16384;
     if (pl.tiles < want_blocks) {
       int64_t need = (want_blocks + pl.tiles - 1) / pl.tiles;
       nsplit = (int)(((need + 7) / 8) * 8);
@@ -253,7 +308,10 @@ KirchhoffPlan kirchhoff_plan(int64_t np, int64_t ns, int nsplit_req, int ppt_req
   if (nsplit < 1) nsplit = 1;
   pl.nsplit = nsplit;
   pl.np_pad = ((np + 31) / 32) * 32;
-  pl.rec_bytes = (size_t)ns * KIRCHHOFF_REC_DOUBLES * sizeof(double);
+  pl.chunk = (int)((ns + nsplit - 1) / nsplit);
+  if (pl.chunk < 1) pl.chunk = 1;
+  // 256 B in front of the records hold the sample-set flags
+  pl.rec_bytes = 256 + (size_t)ns * KIRCHHOFF_REC_DOUBLES * sizeof(double);
   pl.partial_bytes = (size_t)nsplit * 10 * pl.np_pad * sizeof(double);
   return pl;
 }
@@ -267,25 +325,30 @@ hipError_t kirchhoff_launch(const KirchhoffPlan& pl, int64_t np, const double* p
                             const double* Ep, int convention, double* S, double* P,
                             double* A, double* B, double* C, void* workspace,
                             hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-  double* rec = reinterpret_cast<double*>(workspace);
+  unsigned* flags = reinterpret_cast<unsigned*>(workspace);
+  double* rec = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 256);
   double* partial =
       reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) +
                                 ((pl.rec_bytes + 255) / 256) * 256);
+  hipError_t me = hipMemsetAsync(flags, 0, 256, stream);
+  if (me != hipSuccess) return me;
   if (ns > 0) {
     hipLaunchKernelGGL(kirchhoff_pack, dim3((unsigned)((ns + 255) / 256)), dim3(256),
                        0, stream, ns, sx, sy, sz, pstride, nx, ny, nz, nstride, nl, k,
                        reinterpret_cast<const double2*>(Es),
-                       reinterpret_cast<const double2*>(Ep), rec);
+                       reinterpret_cast<const double2*>(Ep), rec, flags);
   }
   if (np > 0) {
     dim3 grid((unsigned)(pl.tiles * pl.nsplit));
     if (ev0) (void)hipEventRecord(ev0, stream);
     if (pl.ppt == 2)
       hipLaunchKernelGGL(kirchhoff_stream<2>, grid, dim3(KIRCHHOFF_BLOCK), 0, stream,
-                         np, px, py, pz, ns, rec, pl.nsplit, pl.np_pad, partial);
+                         np, px, py, pz, (int)ns, rec, flags, pl.nsplit, pl.chunk, pl.np_pad,
+                         partial);
     else
       hipLaunchKernelGGL(kirchhoff_stream<1>, grid, dim3(KIRCHHOFF_BLOCK), 0, stream,
-                         np, px, py, pz, ns, rec, pl.nsplit, pl.np_pad, partial);
+                         np, px, py, pz, (int)ns, rec, flags, pl.nsplit, pl.chunk, pl.np_pad,
+                         partial);
     if (ev1) (void)hipEventRecord(ev1, stream);
     hipLaunchKernelGGL(kirchhoff_finalize, dim3((unsigned)((np + 255) / 256)),
                        dim3(256), 0, stream, np, pl.nsplit, pl.np_pad, partial,

@@ -289,23 +289,25 @@ __global__ void reflect_init(GStat* g) {
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass P,
                                                                    xrt_hip_beam in,
                                                                    GStat* g) {
+  // grid-stride over the rays with a capped grid: one set of atomics per block,
+  // and all blocks hit the same few words, so the block count is what it costs
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double ma = 0., mb = 0., mc = 0.;
   unsigned long long first = ~0ull, nent = 0, nmain = 0;
-  if (i < in.n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
     const int st = in.state[i];
     if (entering(P, st)) {
-      first = (unsigned long long)i;
-      nent = 1;
+      if ((unsigned long long)i < first) first = (unsigned long long)i;
+      ++nent;
       if (st == 1) {  // mainPartForBracketing, reflect.py:644
         double a = in.a[i], b = in.b[i], c = in.c[i];
         local_dir(P, a, b, c);
-        ma = fabs(a);
-        mb = fabs(b);
-        mc = fabs(c);
-        nmain = 1;
+        ma = fmax(ma, fabs(a));
+        mb = fmax(mb, fabs(b));
+        mc = fmax(mc, fabs(c));
+        ++nmain;
       }
     }
   }
@@ -376,20 +378,22 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(xrt_hip_p
                                                                        xrt_hip_beam in,
                                                                        GStat* g) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
   int have = 0;
-  if (i < in.n && entering(P, in.state[i])) {
+  const int axis = g->axis, positive = g->positive;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
+    if (!entering(P, in.state[i])) continue;
     const LocalRay r = load_local(P, in, i);
     double t1, t2, x, y, z;
-    bracket(P, g->axis, g->positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
+    bracket(P, axis, positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
     const double dz1 = find_dz(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
     double dz2 = find_dz(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
     if (dz1 <= 0. || dz2 >= 0.) dz2 = 0.;  // base.py:863-865
-    t1m = t1;
-    t2m = t2;
-    d1m = fabs(dz1);
-    d2m = fabs(dz2);
+    t1m = t1 < t1m ? t1 : t1m;
+    t2m = t2 > t2m ? t2 : t2m;
+    d1m = fmax(d1m, fabs(dz1));
+    d2m = fmax(d2m, fabs(dz2));
     have = 1;
   }
   auto fmaxd = [](double u, double v) { return u > v ? u : v; };
@@ -1109,11 +1113,12 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
     int32_t* hst, GStat* gp) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double bdn = 0.;
+  double bdn_sum = 0.;
   unsigned long long cnt = 0;
-  if (i < in.n && entering(P, in.state[i])) {
-    const GStat g = *gp;
+  const GStat g = *gp;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
+    if (!entering(P, in.state[i])) continue;
     const LocalRay r = load_local(P, in, i);
     const Hit h = solve_ray(P, g, r);
     int st = rays_good(P, h.x, h.y);
@@ -1136,18 +1141,19 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
         n1 = nb / norm;
         n2 = 1. / norm;
       }
-      bdn = r.a * n0 + r.b * n1 + r.c * n2;
+      double bdn = r.a * n0 + r.b * n1 + r.c * n2;
       if (bdn < -1.) bdn = -1.;
       if (bdn > 1.) bdn = 1.;
-      cnt = 1;
+      bdn_sum += bdn;
+      ++cnt;
     }
   }
   auto faddd = [](double u, double v) { return u + v; };
   auto faddu = [](unsigned long long u, unsigned long long v) { return u + v; };
-  bdn = block_reduce(bdn, faddd, lds_d);
+  bdn_sum = block_reduce(bdn_sum, faddd, lds_d);
   cnt = block_reduce(cnt, faddu, lds_u);
   if (threadIdx.x == 0 && cnt) {
-    atomicAdd(&gp->sum_bdn, bdn);
+    atomicAdd(&gp->sum_bdn, bdn_sum);
     atomicAdd(&gp->n_good1, cnt);
   }
 }
@@ -1258,14 +1264,17 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const dim3 grid((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)), block(REFLECT_BLOCK);
   if (ev0) (void)hipEventRecord(ev0, st);
   hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g);
+  // reductions: capped grid (4 blocks per CU), grid-stride inside
+  const dim3 rgrid(grid.x < 1024u ? grid.x : 1024u);
   if (!P.no_intersection_search) {
-    hipLaunchKernelGGL(reflect_stats_dir, grid, block, 0, st, P, in, g);
+    hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, g);
     hipLaunchKernelGGL(reflect_decide_axis, dim3(1), dim3(1), 0, st, P, in, g);
-    hipLaunchKernelGGL(reflect_stats_bracket, grid, block, 0, st, P, in, g);
+    hipLaunchKernelGGL(reflect_stats_bracket, rgrid, block, 0, st, P, in, g);
   }
   const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
   if (need_mean) {
-    hipLaunchKernelGGL(reflect_solve, grid, block, 0, st, P, in, ht, hx, hy, hz, hst, g);
+    const dim3 sgrid(grid.x < 4096u ? grid.x : 4096u);
+    hipLaunchKernelGGL(reflect_solve, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst, g);
     if (evk0) (void)hipEventRecord(evk0, st);
     hipLaunchKernelGGL(reflect_finish, grid, block, 0, st, P, M, in, restore, lb, vb, theta,
                        ht, hx, hy, hz, hst, g);
