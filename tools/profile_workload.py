@@ -1,0 +1,43 @@
+"""Workload to run under rocprofv3 (kernel trace or one --pmc counter at a time):
+  * Screen.expose on 1e7 rays   - pure streaming, exactly 100 B read + 100 B
+                                  written per ray with the same 8 B/lane SoA
+                                  accesses as the reflect kernels: the
+                                  CALIBRATION kernel for FETCH_SIZE / WRITE_SIZE
+  * OE.reflect cfg2, 1e7 rays   - P1
+  * DCM.double_reflect cfg3     - P1, crystal path
+  * Kirchhoff cfg4 (1 launch)   - P2
+"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+from xrt_amd import hipcalls, workloads  # noqa: E402
+import xrt_amd.backends.raycing as raycing  # noqa: E402
+import xrt_amd.backends.raycing.screens as rsc  # noqa: E402
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+reps = 3
+oe = workloads.cfg2_toroid()
+beam = workloads.synthetic_rays(n, 42)
+for f in beam.array_fields():
+    beam.dev(f)
+scr = rsc.Screen(raycing.BeamLine(), 'scr', [0, 30000., 0])
+for _ in range(reps):
+    scr.expose(beam)
+for _ in range(reps):
+    oe.reflect(beam)
+dcm = workloads.cfg3_dcm()
+b3 = workloads.synthetic_rays(n, 43, sa=1e-4, E=(8995., 9005.))
+for _ in range(reps):
+    dcm.double_reflect(b3)
+torch.cuda.synchronize()
+if '--no-kirchhoff' not in sys.argv:
+    h = workloads.kirchhoff_case(4)
+    dev = torch.device('cuda', 0)
+    up = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
+    ns = h['ns']
+    hipcalls.kirchhoff(up(h['px']), up(h['py']), up(h['pz']), up(h['sx']), up(h['sy']), up(h['sz']),
+                       up(np.zeros(ns)), up(np.ones(ns)), up(np.zeros(ns)), up(h['nl']), up(h['k']),
+                       up(h['Es'], np.complex128), up(h['Ep'], np.complex128))
+torch.cuda.synchronize()
+print('done')

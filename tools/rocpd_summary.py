@@ -1,0 +1,96 @@
+"""Turns rocprofv3's rocpd sqlite outputs into the committed summaries under
+profiles/:
+
+  python tools/rocpd_summary.py ROUND trace.db [fetch.db write.db [nrays]]
+
+  profiles/rROUND_kernel_stats.csv   per-kernel calls / total / average (ns)
+  profiles/hbm_traffic.json          per-launch HBM bytes of our kernels from
+                                     FETCH_SIZE / WRITE_SIZE (KB), corrected by
+                                     the ratio measured on the streaming
+                                     calibration kernel (screen_expose: exactly
+                                     100 B read + 100 B written per ray), as
+                                     MI355X_MICROARCH.md (HBM) prescribes.
+"""
+import csv
+import json
+import os
+import sqlite3
+import sys
+
+OURS = ('reflect_fused', 'reflect_solve', 'reflect_finish', 'reflect_stats_dir',
+        'reflect_stats_bracket', 'screen_expose_kernel', 'kirchhoff_stream',
+        'kirchhoff_pack', 'kirchhoff_finalize')
+
+
+def short(name):
+    for k in OURS:
+        if k in name:
+            return k
+    return name.split('(')[0][-60:]
+
+
+def kernel_stats(db):
+    c = sqlite3.connect(db)
+    rows = c.execute('select name, count(*), sum(duration), avg(duration), '
+                     'min(duration), max(duration) from kernels group by name '
+                     'order by sum(duration) desc').fetchall()
+    return [(short(r[0]),) + tuple(r[1:]) for r in rows]
+
+
+def counter_per_launch(db, counter):
+    c = sqlite3.connect(db)
+    rows = c.execute('select kernel_name, avg(value), count(*) from '
+                     'counters_collection where counter_name=? group by '
+                     'kernel_name', (counter,)).fetchall()
+    return {short(r[0]): (r[1], r[2]) for r in rows}
+
+
+def main():
+    rnd, trace = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, 'profiles')
+    os.makedirs(out, exist_ok=True)
+    stats = kernel_stats(trace)
+    path = os.path.join(out, 'r%s_kernel_stats.csv' % rnd)
+    with open(path, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns'])
+        for r in stats:
+            w.writerow([r[0], r[1], int(r[2]), round(r[3], 1), r[4], r[5]])
+    print('wrote', path)
+    for r in stats[:12]:
+        print('  %-28s calls %4d  avg %12.1f us' % (r[0], r[1], r[3] / 1e3))
+    if len(sys.argv) >= 5:
+        nrays = float(sys.argv[5]) if len(sys.argv) > 5 else 1e7
+        fetch = counter_per_launch(sys.argv[3], 'FETCH_SIZE')
+        write = counter_per_launch(sys.argv[4], 'WRITE_SIZE')
+        cal_r = 100. * nrays / (fetch['screen_expose_kernel'][0] * 1024.)
+        cal_w = 100. * nrays / (write['screen_expose_kernel'][0] * 1024.)
+        res = {'_calibration': {
+            'kernel': 'screen_expose_kernel', 'rays': nrays,
+            'known_read_bytes': 100. * nrays, 'known_write_bytes': 100. * nrays,
+            'FETCH_SIZE_KB': fetch['screen_expose_kernel'][0],
+            'WRITE_SIZE_KB': write['screen_expose_kernel'][0],
+            'read_correction': cal_r, 'write_correction': cal_w,
+            'note': 'bytes = counter_KB * 1024 * correction; correction = known '
+                    'bytes / counted bytes on a pure streaming kernel with the '
+                    'same 8 B/lane SoA access pattern'}}
+        for k in OURS:
+            if k in fetch and k in write:
+                rb = fetch[k][0] * 1024. * cal_r
+                wb = write[k][0] * 1024. * cal_w
+                res[k] = dict(FETCH_SIZE_KB=fetch[k][0], WRITE_SIZE_KB=write[k][0],
+                              launches=fetch[k][1], read_bytes=rb, write_bytes=wb,
+                              hbm_bytes_per_launch=rb + wb)
+        path = os.path.join(out, 'hbm_traffic.json')
+        with open(path, 'w') as f:
+            json.dump(res, f, indent=1)
+        print('wrote', path)
+        for k, v in res.items():
+            if not k.startswith('_'):
+                print('  %-24s read %.3e B  write %.3e B' % (k, v['read_bytes'], v['write_bytes']))
+        print('  calibration read x%.3f write x%.3f' % (cal_r, cal_w))
+
+
+if __name__ == '__main__':
+    main()

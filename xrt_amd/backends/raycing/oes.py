@@ -249,7 +249,7 @@ class OE(object):
         vb = rs.Beam.empty_like_on_device(beam_in, dev)
         s_lb, s_vb = lb.to_struct(dev), vb.to_struct(dev)
         n = beam_in.nrays
-        theta = torch.zeros(n, dtype=torch.float64, device=dev)
+        theta = torch.empty(n, dtype=torch.float64, device=dev)   # every element is written
         wsb = lib.xrt_hip_reflect_workspace_bytes(n)
         ws = hipcalls.workspace(dev, wsb, 'reflect')
         info = (ctypes.c_double * 16)() if want_info else None
