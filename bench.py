@@ -177,28 +177,23 @@ def kirchhoff_inputs(cfg, device):
 
 
 def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
-    from xrt_amd import hipcalls
+    from xrt_amd import hipcalls, multigpu
     dev = torch.device('cuda', torch.cuda.current_device())
     s, (px, py, pz), host, ns, side = kirchhoff_inputs(cfg, dev)
     npix = px.size
-    p0, p1 = npix * rank // world, npix * (rank + 1) // world   # pixel tile
+    p0, p1 = multigpu.tile_range(npix, rank, world)             # pixel tile
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a[p0:p1])).to(dev)  # noqa: E731
     tx, ty, tz = up(px), up(py), up(pz)
     out = tuple(torch.empty(p1 - p0, dtype=torch.complex128, device=dev)
                 for _ in range(5))
-    gathered = None
-    if dist is not None:
-        assert npix % world == 0
-        gathered = [torch.empty(npix, dtype=torch.complex128, device=dev)
-                    for _ in range(5)]
 
     def step(timing=False):
         r = hipcalls.kirchhoff(tx, ty, tz, s['sx'], s['sy'], s['sz'], s['nx'],
                                s['ny'], s['nz'], s['nl'], s['k'], s['Es'], s['Ep'],
                                convention=0, out=out, timing=timing)
         if dist is not None:        # assemble the full field on every rank (RCCL)
-            for g, o in zip(gathered, out):
-                dist.all_gather_into_tensor(g, o)
+            for o in out:
+                multigpu.all_gather_tiles(o, npix, dist, rank, world)
         return r
     for _ in range(warmup):
         step()

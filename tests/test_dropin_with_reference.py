@@ -1,0 +1,94 @@
+"""CPU, build container only (skipped where /root/reference is absent): the
+XRT_HIP drop-in is installed as ``waves.waveCL`` of the REAL reference and the
+reference's own ``diffract`` is run through it. The C call is replaced by the
+numpy oracle here (no GPU in this environment), so the test pins everything on
+the Python side of the boundary: the marshalling contract of
+_diffraction_integral_CL (waves.py:854-896), in-place + returned outputs, and
+that the OpenCL sign convention gives the same intensities / directions as the
+reference's numpy path."""
+import numpy as np
+import pytest
+
+from oracle import _refenv, kirchhoff_np as kn
+from oracle.consts import CHBAR
+
+pytestmark = pytest.mark.skipif(not _refenv.available(),
+                                reason='reference tree not present')
+
+
+def _make_fake(convention):
+    from xrt_amd.backends.raycing.myhip import XRT_HIP
+
+    class OracleBackedHIP(XRT_HIP):
+        def set_cl(self, targetOpenCL='auto', precisionOpenCL='float64'):
+            self.device_ids = [0]
+            self.lastTargetOpenCL = targetOpenCL
+            self.lastPrecisionOpenCL = precisionOpenCL
+
+        def _call_lib(self, npix, px, py, pz, ns, nl, Es, Ep, k, pos, nrm, conv,
+                      outs):
+            assert pos.flags.f_contiguous and pos.shape == (4, ns)
+            E = k * CHBAR / 1e7
+            raw = kn.kirchhoff_conv(px, py, pz, pos[0], pos[1], pos[2],
+                                    [nrm[0], nrm[1], nrm[2]], nl, E, Es, Ep)
+            if conv == 1:
+                raw = kn.to_cl_convention(*raw)
+            for o, r in zip(outs, raw):
+                o[:] = r
+    return OracleBackedHIP(convention=convention)
+
+
+def _scene(rw, seed):
+    import xrt.backends.raycing as raycing
+    import xrt.backends.raycing.sources as rs
+    import xrt.backends.raycing.screens as rsc
+    import xrt.backends.raycing.apertures as ra
+    np.random.seed(seed)
+    bl = raycing.BeamLine()
+    src = rs.GeometricSource(bl, 'src', nrays=500, dx=0.01, dz=0.01, dxprime=1e-6,
+                             dzprime=1e-6, distE='lines', energies=(7900.,),
+                             polarization='h')
+    slit = ra.RectangularAperture(bl, 'slit', [0, 44000., 0],
+                                  ('left', 'right', 'bottom', 'top'),
+                                  [-0.1, 0.1, -0.1, 0.1])
+    scr = rsc.Screen(bl, 'scr', [0, 54000., 0])
+    mesh = np.linspace(-0.5, 0.5, 12)
+    wscr = scr.prepare_wave(slit, mesh, mesh)
+    wslit = slit.prepare_wave(src, 500)
+    # a deterministic field on the slit (what source.shine(wave=...) would fill)
+    k = 7900. / CHBAR * 1e7
+    rho2 = wslit.x**2 + wslit.z**2
+    wslit.Es[:] = np.exp(1j * k * rho2 / (2 * 44000.))
+    wslit.Ep[:] = 0.3 * wslit.Es
+    wslit.Jss[:] = np.abs(wslit.Es)**2
+    wslit.Jpp[:] = np.abs(wslit.Ep)**2
+    wslit.E[:] = 7900.
+    wslit.a[:] = wslit.x / 44000.
+    wslit.c[:] = wslit.z / 44000.
+    wslit.b[:] = np.sqrt(1 - wslit.a**2 - wslit.c**2)
+    return wslit, wscr
+
+
+@pytest.mark.parametrize('convention', ['opencl', 'numpy'])
+def test_reference_diffract_runs_through_the_dropin(convention):
+    _refenv.activate()
+    import xrt.backends.raycing.waves as rw
+    saved = rw.waveCL
+    try:
+        rw.waveCL = None
+        wslit, wscr = _scene(rw, 3)
+        rw.diffract(wslit, wscr)                     # the reference's numpy path
+        ref = {f: np.array(getattr(wscr, f)) for f in
+               ('Es', 'Ep', 'Jss', 'Jpp', 'Jsp', 'a', 'b', 'c')}
+        rw.waveCL = _make_fake(convention)
+        wslit, wscr = _scene(rw, 3)
+        rw.diffract(wslit, wscr)                     # the reference + XRT_HIP
+        for f in ('Jss', 'Jpp', 'Jsp', 'a', 'b', 'c'):
+            r = ref[f]
+            assert np.abs(getattr(wscr, f) - r).max() <= 1e-10 * np.abs(r).max(), f
+        sign = -1. if convention == 'opencl' else 1.
+        for f in ('Es', 'Ep'):
+            r = ref[f]
+            assert np.abs(getattr(wscr, f) - sign * r).max() <= 1e-10 * np.abs(r).max(), f
+    finally:
+        rw.waveCL = saved

@@ -79,7 +79,6 @@ class XRT_HIP(object):
 
     def _integrate_kirchhoff(self, scalarArgs, slicedRO, nonSlicedRO, slicedRW,
                              dimension):
-        lib = _lib.load()
         ns = int(scalarArgs[0])
 
         def f64(a, n, name):
@@ -105,14 +104,20 @@ class XRT_HIP(object):
                 raise ValueError('RW arrays must be contiguous complex128[%d]'
                                  % dimension)
             outs.append(a)
+        self._call_lib(dimension, px, py, pz, ns, nl, Es, Ep, k, pos, nrm,
+                       0 if self.convention == 'numpy' else 1, outs)
+        return tuple(outs)
+
+    def _call_lib(self, npix, px, py, pz, ns, nl, Es, Ep, k, pos, nrm, convention,
+                  outs):
+        """The one place that crosses the C ABI (xrt_hip_kirchhoff_f64)."""
+        lib = _lib.load()
         devs = (ctypes.c_int * len(self.device_ids))(*self.device_ids)
         ms = ctypes.c_float(0.)
         ptr = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
         rc = lib.xrt_hip_kirchhoff_f64(
-            len(self.device_ids), devs, dimension, ptr(px), ptr(py), ptr(pz), ns,
-            ptr(nl), ptr(Es), ptr(Ep), ptr(k), ptr(pos), ptr(nrm),
-            0 if self.convention == 'numpy' else 1,
+            len(self.device_ids), devs, npix, ptr(px), ptr(py), ptr(pz), ns,
+            ptr(nl), ptr(Es), ptr(Ep), ptr(k), ptr(pos), ptr(nrm), convention,
             *[ptr(a) for a in outs], ctypes.byref(ms))
         _lib.check(rc, 'xrt_hip_kirchhoff_f64')
         self.lastKernelMs = ms.value
-        return tuple(outs)
