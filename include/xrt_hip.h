@@ -155,11 +155,14 @@ typedef struct xrt_hip_pass {
   int32_t lost_num;
   double roll;                 /* roll (+positionRoll...) used for the coherency
                                   rotation angle roll+atan2(nx,nz) (:948) */
+  double cos_roll, sin_roll;   /* host np.cos / np.sin of it */
   /* output frame of the "global" beam */
   int32_t out_to_global;       /* 1: virgin local -> global for rays ending in
                                   state {1,2} (reflect.py:124-130) */
   int32_t only_state1_out;     /* 1: only state 1 (beam createdByDiffract, :121-122) */
   int32_t zero_local_not_entering; /* 1: dcm.py:298-303 (lo2 of rays that missed) */
+  int32_t force_lost_out;      /* 1: rays of out_virgin that do not end in state {1,2}
+                                  get state lost_num (Plate, dcm.py:304-305, 331-332) */
 } xrt_hip_pass;
 
 #define XRT_HIP_MAT_NONE 0

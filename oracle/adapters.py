@@ -40,6 +40,7 @@ def oracle_params(oe):
                  surfPhysX2=list(oe.limPhysX2), surfPhysY2=list(oe.limPhysY2),
                  surfOptX2=oe.limOptX2, surfOptY2=oe.limOptY2,
                  surface2=dict(kind='flat', alpha=oe.alpha, flip_n_y=True),
+                 is_plate=hasattr(oe, 't'),
                  material2=mat(oe.material2))
     return p
 

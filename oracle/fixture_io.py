@@ -51,6 +51,14 @@ def load_case(name):
     elif name == 'g2_toroid_brent':
         p['surface'] = dict(kind='toroid', R=float(g['surf_R']), r=float(g['surf_r']))
         p['material'] = None
+    elif name == 'g2_plate_be':
+        p['surface'] = dict(kind='flat')
+        p['surface2'] = dict(kind='flat')
+        be = dict(name='Be', Z=int(g['Be_Z']), mass=float(g['Be_mass']),
+                  f0coeffs=np.array(g['Be_f0']), E=np.array(g['Be_E']),
+                  f1=np.array(g['Be_f1']), f2=np.array(g['Be_f2']))
+        p['material'] = mn.make_material([be], None, 'plate', float(g['mat_rho']))
+        p['material2'] = p['material']
     elif name.startswith('g3_dcm'):
         alpha = float(g['alpha'])
         p['surface'] = dict(kind='flat', alpha=alpha)

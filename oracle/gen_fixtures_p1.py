@@ -405,6 +405,43 @@ def main():
                    cr_chiToF=np.array(si1.chiToF))
         save(tag, **out)
 
+    # ---------------- G2d: Plate.double_refract (Be window) ---------------
+    bl = raycing.BeamLine()
+    mBe = rm.Material('Be', rho=1.848, kind='plate')
+    plate = roe.Plate(bl, 'win', center=[0, 5000., 0], pitch=np.pi/2 - 0.05,
+                      material=mBe, t=0.5, limPhysX=[-3, 4], limPhysY=[-2, 2])
+    beam = make_rays(rs, n, 46, sx=1.0, sz=0.6, sa=3e-4, sc=3e-4,
+                     E=(5000., 15000.), amplitudes=True, pol='mixed')
+    gbp, lp1, lp2 = plate.double_refract(beam)
+    par = oe_params(plate, dict(kind='flat'))
+    par['surface2'] = dict(kind='flat')
+    tbBe = dict(tables)
+    eBe = rm.Element('Be', table='Chantler total')
+    for key, val in (('Z', eBe.Z), ('mass', eBe.mass), ('f0', eBe.f0coeffs),
+                     ('E', eBe.E), ('f1', eBe.f1), ('f2', eBe.f2)):
+        tbBe['Be_' + key] = np.array(val, dtype=float)
+    par['material'] = material_dict(tbBe, mBe)
+    par['material2'] = par['material']
+    m2, m1l, m2l = rn.dcm_double_reflect(par, to_oracle_beam(beam),
+                                         fromVacuum1=True, fromVacuum2=False,
+                                         is_plate=True)
+    assert_beams('g2_plate:gb2', m2, gbp)
+    assert_beams('g2_plate:lo1', m1l, lp1)
+    assert_beams('g2_plate:lo2', m2l, lp2)
+    st, cnt = np.unique(gbp.state, return_counts=True)
+    print('g2_plate_be states', dict(zip(st.tolist(), cnt.tolist())), 'mean T',
+          (gbp.Jss + gbp.Jpp)[gbp.state == 1].mean())
+    out = {}
+    out.update(beam_dict('in_', beam))
+    out.update(beam_dict('gb_', gbp))
+    out.update(beam_dict('lo1_', lp1))
+    out.update(beam_dict('lo2_', lp2))
+    out.update(flat_params(par))
+    out.update(plate_t=np.array(0.5), mat_rho=np.array(1.848))
+    for key in ('Z', 'mass', 'f0', 'E', 'f1', 'f2'):
+        out['Be_' + key] = tbBe['Be_' + key]
+    save('g2_plate_be', **out)
+
     # ---------------- G1: GeometricSource -> Screen -----------------------
     np.random.seed(0)
     bl = raycing.BeamLine(azimuth=0.05)

@@ -79,6 +79,9 @@ def product_oe(name, g):
     elif name == 'g2_toroid_brent':
         oe = roe.ToroidMirror(bl, 'tm2', R=float(g['surf_R']), r=float(g['surf_r']),
                               material=None, **common)
+    elif name == 'g2_plate_be':
+        m = rm.Material('Be', rho=float(g['mat_rho']), kind='plate')
+        oe = roe.Plate(bl, 'win', material=m, t=float(g['plate_t']), **common)
     elif name.startswith('g3_dcm'):
         alpha = float(g['alpha'])
         si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)

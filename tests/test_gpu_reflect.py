@@ -71,6 +71,17 @@ def test_dcm_double_reflect_matches_reference_golden(name):
     compare(lo2, g, lambda f: g['lo2_' + f])
 
 
+def test_plate_double_refract_matches_reference_golden():
+    """Refraction branch, transmission amplitudes, absorption exp(-mu t) and the
+    in-material phase exp(0.1j n'k t) (reflect.py:894-919, 1048-1059)."""
+    g = pc.load('g2_plate_be')
+    plate = pc.product_oe('g2_plate_be', g)
+    gb2, lo1, lo2 = plate.double_refract(pc.product_beam(g))
+    compare(gb2, g, lambda f: g['gb_' + f])
+    compare(lo1, g, lambda f: g['lo1_' + f])
+    compare(lo2, g, lambda f: g['lo2_' + f])
+
+
 # ---- amplitude functions ----------------------------------------------------------
 def test_material_amplitudes_match_reference_grid(golden_dir):
     import os

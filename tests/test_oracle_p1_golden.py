@@ -50,6 +50,17 @@ def test_dcm_double_reflect_matches_reference(name):
     check_beam(lo2, g, 'lo2_')
 
 
+def test_plate_double_refract_matches_reference():
+    p, beam, g = fixture_io.load_case('g2_plate_be')
+    gb2, lo1, lo2 = rn.dcm_double_reflect(p, beam, fromVacuum1=True,
+                                          fromVacuum2=False, is_plate=True)
+    check_beam(gb2, g, 'gb_')
+    check_beam(lo1, g, 'lo1_')
+    check_beam(lo2, g, 'lo2_')
+    T = (gb2.Jss + gb2.Jpp)[gb2.state == 1]
+    assert 0.5 < T.mean() < 1.0 and T.max() <= 1.0      # an absorbing Be window
+
+
 def test_edge_rays_are_present_in_toroid_fixture():
     """The fixture must exercise lost / over / out / untouched rays."""
     _, _, g = fixture_io.load_case('g2_toroid_pt')

@@ -53,9 +53,12 @@ class Pass(ctypes.Structure):
         ('over_mask', ctypes.c_int32),
         ('lost_num', ctypes.c_int32),
         ('roll', ctypes.c_double),
+        ('cos_roll', ctypes.c_double),
+        ('sin_roll', ctypes.c_double),
         ('out_to_global', ctypes.c_int32),
         ('only_state1_out', ctypes.c_int32),
         ('zero_local_not_entering', ctypes.c_int32),
+        ('force_lost_out', ctypes.c_int32),
     ]
 
 

@@ -144,7 +144,7 @@ class OE(object):
     def _make_pass(self, pitch, roll, yaw, dx=0, dy=0, dz=0, fromVacuum=True,
                    is2ndXtal=False, noIntersectionSearch=False, in_is_global=True,
                    good_mode=0, out_to_global=True, only_state1_out=False,
-                   zero_local_not_entering=False):
+                   zero_local_not_entering=False, force_lost_out=False):
         p = _structs.Pass()
         p.good_mode = good_mode
         p.in_is_global = 1 if in_is_global else 0
@@ -219,9 +219,12 @@ class OE(object):
         p.over_mask = mask
         p.lost_num = int(self.lostNum)
         p.roll = float(roll)
+        p.cos_roll = float(np.cos(roll))
+        p.sin_roll = float(np.sin(roll))
         p.out_to_global = 1 if out_to_global else 0
         p.only_state1_out = 1 if only_state1_out else 0
         p.zero_local_not_entering = 1 if zero_local_not_entering else 0
+        p.force_lost_out = 1 if force_lost_out else 0
         return p
 
     @staticmethod
@@ -462,6 +465,39 @@ class DCM(OE):
             self.roll + self.cryst2roll + self.positionRoll, -self.yaw,
             -self.dx, self.cryst2longTransl, -self.cryst2perpTransl,
             fromVacuum=fromVacuum2, is2ndXtal=True, in_is_global=False,
-            good_mode=1, out_to_global=True, zero_local_not_entering=True)
+            good_mode=1, out_to_global=True, zero_local_not_entering=True,
+            force_lost_out=hasattr(self, 't'))
         lo2, gb2, _ = self._run_pass(p2, self.material2, fromVacuum2, gb, beam)
         return gb2, lo1, lo2
+
+
+class Plate(DCM):
+    """A body with two flat surfaces (window, filter): the 2nd 'crystal' of the
+    DCM skeleton is the back face at -t (oes/refractive.py:11-235)."""
+
+    def __init__(self, *args, **kwargs):
+        t = kwargs.pop('t', 0)
+        wedgeAngle = kwargs.pop('wedgeAngle', 0)
+        kwargs.setdefault('overEdge', '')
+        DCM.__init__(self, *args, **kwargs)
+        self.t = t
+        self.wedgeAngle = wedgeAngle
+        self.cryst2perpTransl = -t
+        self.cryst2pitch = wedgeAngle
+        # As constructed, the reference's Plate ends up with the back-face limits
+        # EQUAL to the front-face ones: its __init__ mirrors x only `if
+        # isinstance(self.limPhysX, (list, tuple))`, but the property returns a
+        # Limits array, so the else branch runs (refractive.py:37-46). Reproduced,
+        # not "fixed" (golden case g2_plate_be has asymmetric x limits).
+        self.limPhysX2 = list(self.limPhysX)
+        self.limPhysY2 = list(self.limPhysY)
+        self.limOptX2 = self.limOptX
+        self.limOptY2 = self.limOptY
+        self.material2 = self.material
+        if self.material is not None and self.material.kind == 'auto':
+            self.material.kind = 'plate'
+
+    def double_refract(self, beam=None, needLocal=True, returnLocalAbsorbed=None):
+        """-> (beamGlobal, beamLocal1, beamLocal2), refractive.py:171-235."""
+        return self.double_reflect(beam=beam, needLocal=needLocal,
+                                   fromVacuum1=True, fromVacuum2=False)

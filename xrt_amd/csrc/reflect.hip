@@ -60,34 +60,48 @@ __device__ __forceinline__ cplx operator*(cplx a, cplx b) {
 __device__ __forceinline__ cplx operator*(cplx a, double s) { return C(a.re * s, a.im * s); }
 __device__ __forceinline__ cplx operator*(double s, cplx a) { return C(a.re * s, a.im * s); }
 // numpy divides complex by real through its complex loop (Smith): x * (1/s)
+__device__ __forceinline__ double frcp(double x);
 __device__ __forceinline__ cplx operator/(cplx a, double s) {
-  const double scl = 1.0 / s;
+  const double scl = frcp(s);
   return C(a.re * scl, a.im * scl);
 }
 __device__ __forceinline__ cplx conj(cplx a) { return C(a.re, -a.im); }
-__device__ __forceinline__ double cabs_(cplx a) { return hypot(a.re, a.im); }
+// The amplitude half of the pipeline only needs ~1e-16 relative accuracy (it is
+// compared at 1e-10, bar 1e-5), not IEEE-exact quotients: reciprocal by
+// v_rcp_f64 + two Newton steps (<= 1 ulp) instead of the 14-instruction IEEE
+// division, and an unscaled hypot (magnitudes are O(1e-10..1e3) here).
+__device__ __forceinline__ double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma_(fma_(-x, r, 1.0), r, r);
+  r = fma_(fma_(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fhypot(double a, double b) {
+  return __builtin_sqrt(fma_(a, a, b * b));
+}
+__device__ __forceinline__ double cabs_(cplx a) { return fhypot(a.re, a.im); }
 __device__ __forceinline__ bool cisnan(cplx a) { return isnan(a.re) || isnan(a.im); }
 // Smith's algorithm, as numpy's complex division loop
 __device__ __forceinline__ cplx operator/(cplx a, cplx b) {
   if (fabs(b.re) >= fabs(b.im)) {
     if (b.re == 0. && b.im == 0.) return C(a.re / fabs(b.re), a.im / fabs(b.im));
-    const double rat = b.im / b.re;
-    const double scl = 1.0 / (b.re + b.im * rat);
+    const double rat = b.im * frcp(b.re);
+    const double scl = frcp(b.re + b.im * rat);
     return C((a.re + a.im * rat) * scl, (a.im - a.re * rat) * scl);
   }
-  const double rat = b.re / b.im;
-  const double scl = 1.0 / (b.im + b.re * rat);
+  const double rat = b.re * frcp(b.im);
+  const double scl = frcp(b.im + b.re * rat);
   return C((a.re * rat + a.im) * scl, (a.im * rat - a.re) * scl);
 }
 __device__ __forceinline__ cplx csqrt_(cplx z) {  // principal root (C99 csqrt)
   if (z.re == 0. && z.im == 0.) return C(0., z.im);
-  const double m = hypot(z.re, z.im);
+  const double m = fhypot(z.re, z.im);
   if (z.re >= 0.) {
     const double t = sqrt((z.re + m) * 0.5);
-    return C(t, z.im / (2. * t));
+    return C(t, z.im * frcp(2. * t));
   }
   const double t = sqrt((-z.re + m) * 0.5);
-  return C(fabs(z.im) / (2. * t), copysign(t, z.im));
+  return C(fabs(z.im) * frcp(2. * t), copysign(t, z.im));
 }
 __device__ __forceinline__ cplx cexp_(cplx z) {
   double s, c;
@@ -665,7 +679,7 @@ __device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, do
     A.rs = ((2. * n1cosAlpha) / (n1cosAlpha + n2cosBeta)) * tf;
     A.rp = ((2. * n1cosAlpha) / (n2 * cosAlpha + n1 * cosBeta)) * tf;
   }
-  A.mu = fabs(n.im) * E / kCHBAR * 2e8;
+  A.mu = fabs(n.im) * E / kCHBAR * 2e8;   // exact division kept: mu, nk are compared bitwise
   A.nk = n.re * E / kCHBAR * 1e8;
   return A;
 }
@@ -711,11 +725,11 @@ __device__ __forceinline__ cplx crystal_one_pol(const xrt_hip_material& M, doubl
 __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, double E,
                                                   double bdsn, double bosn, double bdhn) {
   Ampl A;
-  const double waveLength = kCH / E;
-  const double k = kPI2 / waveLength;
+  const double waveLength = kCH * frcp(E);
+  const double k = kPI2 * frcp(waveLength);
   const double k0s = -bdsn * k;
   double kHs = -bosn * k;
-  const double HH = kPI2 / M.d;
+  const double HH = kPI2 * frcp(M.d);
   const double k0H = fabs(bdhn) * HH * k;
   const double k02 = k * k;
   const double H2 = HH * HH;
@@ -724,7 +738,7 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
     kHs = 1.;
     b = -1.;
   } else {
-    b = k0s / kHs;
+    b = k0s * frcp(kHs);
   }
   // structure factors, crystals_basic.py:22-31, 76-80; chi, crystal.py:297-306
   const cplx anom = interp_f1f2(M, 0, E);
@@ -742,11 +756,11 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
   const double c2l = M.chi_to_f * (waveLength * waveLength);
   const cplx chi0 = conj(F0) * c2l, chih = conj(Fh) * c2l, chih_ = conj(Fh_) * c2l;
   // Bragg angle, crystal.py:1105-1120
-  double sb = kCH / (2. * M.d * E);
+  double sb = kCH * frcp(2. * M.d * E);
   if (sb > 1.) sb = 1. - 1e-16;
   if (sb < -1.) sb = -1. + 1e-16;
   const double thetaB = asin(sb);
-  const cplx alpha = C((H2 / 2. - k0H) / k02, 0.) + (chi0 / 2.) * (1. / b - 1.);
+  const cplx alpha = C((H2 * 0.5 - k0H) * frcp(k02), 0.) + (chi0 * 0.5) * (frcp(b) - 1.);
   A.rs = crystal_one_pol(M, 1., alpha, chih, chih_, chi0, b, k02, k0s, kHs);
   A.rp = crystal_one_pol(M, cos(2. * thetaB), alpha, chih, chih_, chi0, b, k02, k0s, kHs);
   A.mu = 0.;
@@ -761,11 +775,10 @@ struct RayIn {
   double path, E, Jss, Jpp, Jsr, Jsi, Esr, Esi, Epr, Epi;
 };
 
-__device__ __forceinline__ void rot_coherency(double roll, double& Jss, double& Jpp,
+__device__ __forceinline__ void rot_coherency(double c, double s, double& Jss, double& Jpp,
                                               double& Jsr, double Jsi) {
-  // sources/beams.py:448-479 (imaginary part of Jsp is unchanged)
-  double s, c;
-  sincos(roll, &s, &c);
+  // sources/beams.py:448-479 with c = cos(roll), s = sin(roll) (imaginary part of
+  // Jsp is unchanged)
   const double c2 = c * c, s2 = s * s, cs = c * s;
   const double ss = Jss * c2 + Jpp * s2 + 2. * Jsr * cs;
   const double pp = Jss * s2 + Jpp * c2 - 2. * Jsr * cs;
@@ -793,15 +806,15 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   double n[6];
   if (P.surf_kind == XRT_HIP_SURF_TOROID) {  // oes/__init__.py:403-411
     const double R = P.surf_p[0], rr = P.surf_p[1];
-    const double qx = h.x / rr;
+    const double qx = h.x * frcp(rr);
     const double rx = 1. - qx * qx;
-    const double ax = rx < 0. ? 0. : 1. / sqrt(rx);
-    const double na = -h.x / rr * ax;
-    const double nb = -h.y / R;
-    const double norm = sqrt(na * na + nb * nb + 1.);
-    n[0] = n[3] = na / norm;
-    n[1] = n[4] = nb / norm;
-    n[2] = n[5] = 1. / norm;
+    const double ax = rx < 0. ? 0. : frcp(sqrt(rx));
+    const double na = -qx * ax;
+    const double nb = -h.y * frcp(R);
+    const double inorm = frcp(sqrt(na * na + nb * nb + 1.));
+    n[0] = n[3] = na * inorm;
+    n[1] = n[4] = nb * inorm;
+    n[2] = n[5] = inorm;
   } else {
     for (int j = 0; j < 6; ++j) n[j] = P.n_const[j];
   }
@@ -841,7 +854,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       bo = r.b - n[4] * dn + g1 * ol;
       co = r.c - n[5] * dn + g2 * ol;
       const double nm = sqrt(ao * ao + bo * bo + co * co);
-      ao /= nm;
+      ao /= nm;   // directions are compared at 1e-12: exact quotients here
       bo /= nm;
       co /= nm;
     } else {  // specular, reflect.py:875-877
@@ -866,14 +879,23 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     F.c = r.c * n1overn2 + n[2] * dn;
   }
 
-  // coherency matrix into the local s/p frame, reflect.py:948-953
-  const double rollAngle = P.roll + atan2(n[3], n[5]);
+  // coherency matrix into the local s/p frame, reflect.py:948-953:
+  // rollAngle = roll + atan2(n_x, n_z); only its cos and sin are ever used, so
+  // they come from the angle-addition formulas with cos/sin(atan2) = (n_z, n_x)/hyp
+  double cosY = P.cos_roll, sinY = P.sin_roll;
+  if (n[3] != 0.) {
+    const double ih = frcp(fhypot(n[3], n[5]));
+    const double cphi = n[5] * ih, sphi = n[3] * ih;
+    cosY = P.cos_roll * cphi - P.sin_roll * sphi;
+    sinY = P.sin_roll * cphi + P.cos_roll * sphi;
+  } else if (n[5] < 0.) {  // atan2(0, negative) = pi
+    cosY = -P.cos_roll;
+    sinY = -P.sin_roll;
+  }
   double Jss = q.Jss, Jpp = q.Jpp, Jsr = q.Jsr, Jsi = q.Jsi;
-  rot_coherency(-rollAngle, Jss, Jpp, Jsr, Jsi);
-  double sinY = 0., cosY = 1.;
+  rot_coherency(cosY, -sinY, Jss, Jpp, Jsr, Jsi);
   cplx Es = C(q.Esr, q.Esi), Ep = C(q.Epr, q.Epi);
   if (has_amp) {
-    sincos(rollAngle, &sinY, &cosY);
     const cplx e1 = Es * cosY + Ep * (-sinY);
     const cplx e2 = Es * sinY + Ep * cosY;
     Es = e1;
@@ -944,7 +966,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   F.vJpp = Jpp;
   F.vJsr = Jsr;
   F.vJsi = Jsi;
-  rot_coherency(rollAngle, F.vJss, F.vJpp, F.vJsr, F.vJsi);
+  rot_coherency(cosY, sinY, F.vJss, F.vJpp, F.vJsr, F.vJsi);
   if (has_amp) {
     const cplx e1 = Es * cosY + Ep * sinY;
     const cplx e2 = Es * (-sinY) + Ep * cosY;
@@ -1046,7 +1068,7 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
             st, lo.Esr, lo.Esi, lo.Epr, lo.Epi, has_amp);
   const bool keep = P.only_state1_out ? (st == 1) : (st == 1 || st == 2);
   if (!keep) {  // reflect.py:131-134: everything but the state comes from `restore`
-    copy_ray(vb, restore, i, st, has_amp, false);
+    copy_ray(vb, restore, i, P.force_lost_out ? P.lost_num : st, has_amp, false);
     return;
   }
   // back to the virgin local frame, reflect.py:1115-1132
@@ -1080,7 +1102,7 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
     copy_ray(lb, in, i, 0, has_amp, true);
   else
     copy_ray(lb, in, i, st, has_amp, false);
-  copy_ray(vb, restore, i, st, has_amp, false);
+  copy_ray(vb, restore, i, P.force_lost_out ? P.lost_num : st, has_amp, false);
   if (theta) theta[i] = 0.;
 }
 
@@ -1132,14 +1154,14 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
       double n0 = P.n_const[0], n1 = P.n_const[1], n2 = P.n_const[2];
       if (P.surf_kind == XRT_HIP_SURF_TOROID) {
         const double R = P.surf_p[0], rr = P.surf_p[1];
-        const double qx = h.x / rr;
+        const double qx = h.x * frcp(rr);
         const double rx = 1. - qx * qx;
-        const double ax = rx < 0. ? 0. : 1. / sqrt(rx);
-        const double na = -h.x / rr * ax, nb = -h.y / R;
-        const double norm = sqrt(na * na + nb * nb + 1.);
-        n0 = na / norm;
-        n1 = nb / norm;
-        n2 = 1. / norm;
+        const double ax = rx < 0. ? 0. : frcp(sqrt(rx));
+        const double na = -qx * ax, nb = -h.y * frcp(R);
+        const double inorm = frcp(sqrt(na * na + nb * nb + 1.));
+        n0 = na * inorm;
+        n1 = nb * inorm;
+        n2 = inorm;
       }
       double bdn = r.a * n0 + r.b * n1 + r.c * n2;
       if (bdn < -1.) bdn = -1.;
