@@ -1109,7 +1109,7 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
 // ---------------------------------------------------------------------------
 // K3 kernels
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_fused(
+__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* gp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
   }
 }
 
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_finish(
+__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_finish(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const double* ht, const double* hx,
     const double* hy, const double* hz, const int32_t* hst, const GStat* gp) {
