@@ -201,7 +201,7 @@ typedef struct xrt_hip_material {
 XRT_HIP_API size_t xrt_hip_reflect_workspace_bytes(int64_t n);
 
 /* sizeof() of the structs above, to let a binding verify its layout:
- * which = 0 beam, 1 rotation, 2 pass, 3 material, 4 screen. */
+ * which = 0 beam, 1 rotation, 2 pass, 3 material, 4 screen, 5 aperture. */
 XRT_HIP_API int xrt_hip_sizeof(int which);
 
 /* in: incoming beam. out_local: "lb" of the reference (true local frame).
@@ -248,6 +248,27 @@ typedef struct xrt_hip_screen {
 XRT_HIP_API int xrt_hip_screen_expose_f64_dev(const xrt_hip_screen* screen,
                                               const xrt_hip_beam* in, xrt_hip_beam* out,
                                               void* stream);
+
+/* ---- RectangularAperture.propagate (apertures.py:334-413) -----------------
+ * Rays with state > 0 are taken to the aperture plane (local y = 0); those
+ * outside the blades (inside, for a beam stop) get state lost_num = -ordinal-1000
+ * IN THE INCOMING BEAM TOO (the reference mutates beam.state, :373). blade_mask:
+ * bit 0 left, 1 right, 2 bottom, 3 top (which blades exist). out_global may be
+ * NULL (needNewGlobal=False). */
+typedef struct xrt_hip_aperture {
+  double center[3];
+  double ex[3], ey[3], ez[3];
+  double sin_az, cos_az;       /* for the optional global output, beamline.py:267-287 */
+  double blade[4];             /* left, right, bottom, top */
+  int32_t blade_mask;
+  int32_t is_beam_stop;
+  int32_t lost_num;
+} xrt_hip_aperture;
+
+XRT_HIP_API int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* aperture,
+                                                   xrt_hip_beam* beam_inout,
+                                                   xrt_hip_beam* out_local,
+                                                   xrt_hip_beam* out_global, void* stream);
 
 /* ---- building-block checks (used by the GPU tests only) ---------------- */
 XRT_HIP_API int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,

@@ -1,0 +1,92 @@
+"""TEST INFRASTRUCTURE ONLY — numpy restatement of the two streaming elements
+either side of the ray-surface path:
+
+* screen_expose       <- xrt/backends/raycing/screens.py:226-302 with
+                         global_to_virgin_local(xyz basis) beamline.py:253-264
+* aperture_propagate  <- xrt/backends/raycing/apertures.py:334-413
+
+Pinned by tests/golden/g1_source_screen.npz and g7_aperture.npz
+(oracle/gen_fixtures_p1.py)."""
+import numpy as np
+
+from .consts import CHBAR
+from .reflect_np import rotate_z
+
+
+def _to_basis(beam, lo, basis, center, part):
+    lx, ly, lz = basis
+    lo.x[part] = beam.x[part] - center[0]
+    lo.y[part] = beam.y[part] - center[1]
+    lo.z[part] = beam.z[part] - center[2]
+    xyz = lo.x[part], lo.y[part], lo.z[part]
+    lo.x[part], lo.y[part], lo.z[part] = (
+        sum(c*b for c, b in zip(lx, xyz)), sum(c*b for c, b in zip(ly, xyz)),
+        sum(c*b for c, b in zip(lz, xyz)))
+    abc = beam.a[part], beam.b[part], beam.c[part]
+    lo.a[part], lo.b[part], lo.c[part] = (
+        sum(c*b for c, b in zip(lx, abc)), sum(c*b for c, b in zip(ly, abc)),
+        sum(c*b for c, b in zip(lz, abc)))
+
+
+def screen_expose(beam, basis, center, lostNum, onlyPositivePath=False):
+    blo = beam.copy()
+    part = np.ones(beam.x.shape, dtype=bool)
+    _to_basis(beam, blo, basis, center, part)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        path = -blo.y / blo.b
+    condBad = np.isnan(path) | np.isinf(path)
+    if onlyPositivePath:
+        condBad = condBad | (path < 0)
+    path[condBad] = 0.
+    blo.state[condBad] = lostNum
+    blo.path += path
+    blo.x[:] += blo.a * path
+    blo.z[:] += blo.c * path
+    blo.y[:] = 0.
+    if hasattr(blo, 'Es'):
+        propPhase = np.exp(1e7j * (blo.E/CHBAR) * path)
+        blo.Es *= propPhase
+        blo.Ep *= propPhase
+    return blo
+
+
+def aperture_propagate(beam, basis, center, blades, lostNum, azimuth_sc=(0., 1.),
+                       isBeamStop=False, needNewGlobal=False):
+    """Mutates beam.state like the reference. blades: dict left/right/bottom/top."""
+    good = beam.state > 0
+    lo = beam.copy()
+    _to_basis(beam, lo, basis, center, good)
+    path = -lo.y[good] / lo.b[good]
+    lo.x[good] += lo.a[good] * path
+    lo.z[good] += lo.c[good] * path
+    lo.path[good] += path
+    badIndices = np.zeros(len(beam.x), dtype=bool)
+    for akind, d in blades.items():
+        if akind.startswith('l'):
+            badIndices[good] = badIndices[good] | (lo.x[good] < d)
+        elif akind.startswith('r'):
+            badIndices[good] = badIndices[good] | (lo.x[good] > d)
+        elif akind.startswith('b'):
+            badIndices[good] = badIndices[good] | (lo.z[good] < d)
+        elif akind.startswith('t'):
+            badIndices[good] = badIndices[good] | (lo.z[good] > d)
+    if isBeamStop:
+        badIndices[good] = np.invert(badIndices[good])
+    beam.state[badIndices] = lostNum
+    lo.state[:] = beam.state
+    lo.y[good] = 0.
+    if hasattr(lo, 'Es'):
+        propPhase = np.exp(1e7j * (lo.E[good]/CHBAR) * path)
+        lo.Es[good] *= propPhase
+        lo.Ep[good] *= propPhase
+    if not needNewGlobal:
+        return lo
+    glo = lo.copy()
+    a0, b0 = azimuth_sc
+    if a0 != 0:
+        glo.a[good], glo.b[good] = rotate_z(glo.a[good], glo.b[good], b0, -a0)
+        glo.x[good], glo.y[good] = rotate_z(glo.x[good], glo.y[good], b0, -a0)
+    glo.x[good] += center[0]
+    glo.y[good] += center[1]
+    glo.z[good] += center[2]
+    return glo, lo

@@ -24,6 +24,7 @@ import numpy as np
 from . import _refenv
 from . import materials_np as mn
 from . import reflect_np as rn
+from . import elements_np as en
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                    'tests', 'golden')
@@ -461,6 +462,47 @@ def main():
                scr_z=np.array(scr.z, dtype=float), azimuth=np.array(0.05),
                scr_lostNum=np.array(scr.lostNum))
     save('g1_source_screen', **out)
+    mine = en.screen_expose(to_oracle_beam(b0), (scr.x, scr.y, scr.z), scr.center,
+                            scr.lostNum)
+    assert_beams('g1:screen', mine, lo)
+
+    # ---------------- G7: RectangularAperture.propagate -------------------
+    import xrt.backends.raycing.apertures as ra
+    bl = raycing.BeamLine(azimuth=-0.02)
+    slit = ra.RectangularAperture(
+        bl, 'slit', center=[np.sin(-0.02)*8000., np.cos(-0.02)*8000., 0.2],
+        kind=('left', 'right', 'bottom', 'top'), opening=[-0.8, 1.1, -0.3, 0.25])
+    dummy = ra.RectangularAperture(bl, 'pad', [0, 1, 0], ('left',), [0])  # ordinal 2
+    assert slit.lostNum == -1001
+    beam = make_rays(rs, n, 47, sx=0.4, sz=0.15, sa=1e-4, sc=3e-5,
+                     E=(7000., 9000.), amplitudes=True, pol='mixed')
+    xx, yy, aa, bb = beam.x.copy(), beam.y.copy(), beam.a.copy(), beam.b.copy()
+    beam.x[:], beam.y[:] = raycing.rotate_z(xx, yy, bl.cosAzimuth, -bl.sinAzimuth)
+    beam.a[:], beam.b[:] = raycing.rotate_z(aa, bb, bl.cosAzimuth, -bl.sinAzimuth)
+    beam.state[3] = 2
+    beam.state[4] = 3
+    beam.state[5] = -7
+    beam.state[6] = 0
+    b_in = rs.Beam(copyFrom=beam)
+    glo, lo = slit.propagate(beam, needNewGlobal=True)
+    ob = to_oracle_beam(b_in)
+    mglo, mlo = en.aperture_propagate(
+        ob, slit.xyz, slit.center, dict(slit.blades), slit.lostNum,
+        (bl.sinAzimuth, bl.cosAzimuth), needNewGlobal=True)
+    assert_beams('g7:lo', mlo, lo)
+    assert_beams('g7:glo', mglo, glo)
+    assert np.array_equal(ob.state, beam.state)
+    st, cnt = np.unique(lo.state, return_counts=True)
+    print('g7_aperture states', dict(zip(st.tolist(), cnt.tolist())))
+    out = {}
+    out.update(beam_dict('in_', b_in))
+    out.update(beam_dict('lo_', lo))
+    out.update(beam_dict('glo_', glo))
+    out.update(in_state_after=np.array(beam.state), azimuth=np.array(-0.02),
+               center=np.array(slit.center, dtype=float),
+               opening=np.array([-0.8, 1.1, -0.3, 0.25]),
+               lostNum=np.array(slit.lostNum))
+    save('g7_aperture', **out)
 
 
 if __name__ == '__main__':

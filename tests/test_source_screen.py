@@ -95,3 +95,93 @@ def test_screen_expose_with_amplitudes_and_bad_rays():
     ph = np.exp(1e7j * (b.peek('E') / CHBAR) * np.where(ok, path, 0.))
     assert np.abs(lo.Es - b.peek('Es') * ph)[ok].max() < 1e-12
     assert np.abs(lo.path[ok] - path[ok]).max() < 1e-9 and not lo.y.any()
+
+
+# ---- G7: RectangularAperture.propagate ---------------------------------------------
+def _oracle_beam(g, prefix):
+    from oracle import reflect_np as rn
+    return rn.Beam.from_dict(g, prefix)
+
+
+def test_oracle_screen_and_aperture_match_reference(golden_dir):
+    """CPU: oracle/elements_np.py against the golden vectors."""
+    from oracle import elements_np as en
+    g = _g1(golden_dir)
+    lo = en.screen_expose(_oracle_beam(g, 'in_'), (g['scr_x'], g['scr_y'], g['scr_z']),
+                          g['scr_center'], int(g['scr_lostNum']))
+    assert np.array_equal(lo.state, g['lo_state'])
+    for f in FIELDS:
+        assert np.array_equal(getattr(lo, f), g['lo_' + f]), f
+    g = np.load(os.path.join(golden_dir, 'g7_aperture.npz'))
+    b = _oracle_beam(g, 'in_')
+    az = float(g['azimuth'])
+    basis = ([np.cos(az), -np.sin(az), 0.], [np.sin(az), np.cos(az), 0.], [0., 0., 1.])
+    blades = dict(zip(('left', 'right', 'bottom', 'top'), g['opening']))
+    glo, lo = en.aperture_propagate(b, basis, g['center'], blades, int(g['lostNum']),
+                                    (np.sin(az), np.cos(az)), needNewGlobal=True)
+    assert np.array_equal(b.state, g['in_state_after'])
+    for ob, pre in ((lo, 'lo_'), (glo, 'glo_')):
+        assert np.array_equal(ob.state, g[pre + 'state'])
+        for f in FIELDS + ('Es', 'Ep'):
+            r = g[pre + f]
+            assert np.abs(getattr(ob, f) - r).max() <= 1e-13 * max(np.abs(r).max(), 1e-300), f
+
+
+@pytest.mark.gpu
+def test_aperture_propagate_matches_reference(golden_dir):
+    import xrt_amd.backends.raycing.apertures as ra
+    g = np.load(os.path.join(golden_dir, 'g7_aperture.npz'))
+    bl = raycing.BeamLine(azimuth=float(g['azimuth']))
+    slit = ra.RectangularAperture(bl, 'slit', center=[float(v) for v in g['center']],
+                                  kind=('left', 'right', 'bottom', 'top'),
+                                  opening=[float(v) for v in g['opening']])
+    assert slit.lostNum == int(g['lostNum'])
+    b = rs.Beam(nrays=len(g['in_x']), withAmplitudes=True)
+    for f in FIELDS + ('state', 'Es', 'Ep'):
+        setattr(b, f, g['in_' + f])
+    glo, lo = slit.propagate(b, needNewGlobal=True)
+    assert np.array_equal(b.state, g['in_state_after'])     # incoming beam marked too
+    for ob, pre in ((lo, 'lo_'), (glo, 'glo_')):
+        assert np.array_equal(ob.state, g[pre + 'state'])
+        for f in FIELDS + ('Es', 'Ep'):
+            r = g[pre + f]
+            assert np.abs(getattr(ob, f) - r).max() <= 1e-13 * max(np.abs(r).max(), 1e-300), f
+    lo2 = slit.propagate(b)                                  # needNewGlobal=False
+    assert np.array_equal(lo2.state, lo.state)
+
+
+@pytest.mark.gpu
+def test_resident_chain_source_slit_mirror_screen_matches_oracle():
+    """A run_process-style chain that never leaves HBM between elements:
+    GeometricSource -> RectangularAperture -> ToroidMirror(Pt) -> Screen, against
+    the same chain through the numpy oracle."""
+    import xrt_amd.backends.raycing.apertures as ra
+    from xrt_amd import workloads
+    from oracle import elements_np as en, reflect_np as rn
+    from oracle.adapters import oracle_params, to_oracle_beam
+    np.random.seed(5)
+    bl = raycing.BeamLine()
+    src = rs.GeometricSource(bl, 'src', nrays=50000, dx=0.1, dz=0.1, dxprime=2e-4,
+                             dzprime=2e-5, distE='flat', energies=(8990., 9010.))
+    slit = ra.RectangularAperture(bl, 'slit', [0, 10000., 0],
+                                  ('left', 'right', 'bottom', 'top'),
+                                  [-2.5, 2.5, -0.25, 0.3])
+    m1 = workloads.cfg2_toroid(bl)
+    scr = rsc.Screen(bl, 'scr', [0, 30000., 10000. * np.tan(8e-3)])
+    b0 = src.shine()
+    ob0 = to_oracle_beam(b0)
+    slit.propagate(b0)
+    gb, lb = m1.reflect(b0)
+    img = scr.expose(gb)
+    basis = ([1., 0., 0.], [0., 1., 0.], [0., 0., 1.])
+    en.aperture_propagate(ob0, basis, slit.center, dict(slit.blades), slit.lostNum)
+    ogb, olb = rn.oe_reflect(oracle_params(m1), ob0)
+    oimg = en.screen_expose(ogb, basis, scr.center, scr.lostNum)
+    assert np.array_equal(img.state, oimg.state)
+    st = set(np.unique(img.state).tolist())
+    assert 1 in st and slit.lostNum in st
+    for f in ('x', 'z', 'a', 'b', 'c', 'path'):
+        r = getattr(oimg, f)
+        assert np.abs(getattr(img, f) - r).max() <= 1e-12 * np.abs(r).max(), f
+    good = oimg.state == 1
+    assert np.abs(img.Jss - oimg.Jss)[good].max() <= 1e-10 * oimg.Jss.max()

@@ -42,6 +42,7 @@ SIGNATURES = {
     'xrt_hip_crystal_amplitude_f64_dev': (ctypes.c_int, [
         vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_screen_expose_f64_dev': (ctypes.c_int, [vp, vp, vp, vp]),
+    'xrt_hip_aperture_propagate_f64_dev': (ctypes.c_int, [vp, vp, vp, vp, vp]),
     'xrt_hip_debug_sqrt_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
     'xrt_hip_debug_sincos_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
 }

@@ -102,4 +102,17 @@ class Screen(ctypes.Structure):
                 ('only_positive_path', ctypes.c_int32)]
 
 
-STRUCTS = (Beam, Rotation, Pass, Material, Screen)
+class Aperture(ctypes.Structure):
+    _fields_ = [('center', ctypes.c_double * 3),
+                ('ex', ctypes.c_double * 3),
+                ('ey', ctypes.c_double * 3),
+                ('ez', ctypes.c_double * 3),
+                ('sin_az', ctypes.c_double),
+                ('cos_az', ctypes.c_double),
+                ('blade', ctypes.c_double * 4),
+                ('blade_mask', ctypes.c_int32),
+                ('is_beam_stop', ctypes.c_int32),
+                ('lost_num', ctypes.c_int32)]
+
+
+STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture)

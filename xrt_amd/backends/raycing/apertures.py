@@ -1,9 +1,14 @@
-"""``RectangularAperture`` as a diffracting / receiving element of the wave
-path — host-side mirror of xrt/backends/raycing/apertures.py:29-499 restricted to
-what ``waves.diffract`` needs (blade geometry, local frame, ``prepare_wave``)."""
+"""``RectangularAperture`` — host-side mirror of
+xrt/backends/raycing/apertures.py:29-499: blade geometry, local frame,
+``propagate`` (streaming HIP kernel on device-resident beams) and
+``prepare_wave`` for the wave path."""
+import ctypes
+
 import numpy as np
+import torch
 
 from .. import raycing
+from ... import _lib, _structs
 from . import sources as rs
 
 _BLADE_ORDER = ('left', 'right', 'bottom', 'top')
@@ -74,6 +79,51 @@ class RectangularAperture(object):
         bglo = a*self.x[1] + b*self.y[1] + c*self.z[1]
         cglo = a*self.x[2] + b*self.y[2] + c*self.z[2]
         glo.a, glo.b, glo.c = aglo, bglo, cglo
+
+    def propagate(self, beam=None, needNewGlobal=False):
+        """Rays stopped by the blades get state ``lostNum`` — in *beam* itself
+        too, as in the reference (apertures.py:334-413). Returns the beam in the
+        aperture's local frame (and the new global beam if *needNewGlobal*)."""
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        a = _structs.Aperture()
+        for i in range(3):
+            a.center[i] = float(self.center[i])
+            a.ex[i] = float(self.x[i])
+            a.ey[i] = float(self.y[i])
+            a.ez[i] = float(self.z[i])
+        a.sin_az = self.bl.sinAzimuth if self.bl is not None else 0.
+        a.cos_az = self.bl.cosAzimuth if self.bl is not None else 1.
+        mask = 0
+        for bit, key in enumerate(_BLADE_ORDER):
+            if key in self.blades:
+                mask |= 1 << bit
+                a.blade[bit] = float(self.blades[key])
+        a.blade_mask = mask
+        a.is_beam_stop = 1 if self.isBeamStop else 0
+        a.lost_num = int(self.lostNum)
+        s_in = beam.to_struct(dev)
+        lo = rs.Beam.empty_like_on_device(beam, dev)
+        s_lo = lo.to_struct(dev)
+        glo = s_glo = None
+        if needNewGlobal:
+            glo = rs.Beam.empty_like_on_device(beam, dev)
+            s_glo = glo.to_struct(dev)
+        _lib.check(lib.xrt_hip_aperture_propagate_f64_dev(
+            ctypes.byref(a), ctypes.byref(s_in), ctypes.byref(s_lo),
+            ctypes.byref(s_glo) if s_glo is not None else None,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            'xrt_hip_aperture_propagate_f64_dev')
+        beam._h.pop('state', None)       # the kernel updated beam.state in HBM
+        for b in (lo, glo):
+            if b is not None:
+                for k in rs._SCALAR_ATTRS:
+                    if k in beam.__dict__:
+                        object.__setattr__(b, k, beam.__dict__[k])
+        if needNewGlobal:
+            return glo, lo
+        return lo
 
     def prepare_wave(self, prevOE, nrays, rw=None):
         """*nrays* samples uniformly random over the slit area

@@ -240,6 +240,7 @@ int xrt_hip_sizeof(int which) {
     case 2: return (int)sizeof(xrt_hip_pass);
     case 3: return (int)sizeof(xrt_hip_material);
     case 4: return (int)sizeof(xrt_hip_screen);
+    case 5: return (int)sizeof(xrt_hip_aperture);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -383,6 +384,24 @@ int xrt_hip_screen_expose_f64_dev(const xrt_hip_screen* screen, const xrt_hip_be
   if ((rc = check_beam(in, "in", n, amp))) return rc;
   if ((rc = check_beam(out, "out", n, amp))) return rc;
   HIP_TRY(xrt::screen_expose_launch(*screen, *in, *out, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* aperture,
+                                       xrt_hip_beam* beam_inout, xrt_hip_beam* out_local,
+                                       xrt_hip_beam* out_global, void* stream) {
+  if (!aperture || !beam_inout) return fail(XRT_HIP_ERR_ARG, "NULL aperture / beam");
+  const int64_t n = beam_inout->n;
+  const bool amp = beam_inout->Es_ri != nullptr || beam_inout->Ep_ri != nullptr;
+  int rc;
+  if ((rc = check_beam(beam_inout, "beam", n, amp))) return rc;
+  if ((rc = check_beam(out_local, "out_local", n, amp))) return rc;
+  xrt_hip_beam none;
+  memset(&none, 0, sizeof(none));
+  if (out_global && (rc = check_beam(out_global, "out_global", n, amp))) return rc;
+  HIP_TRY(xrt::aperture_propagate_launch(*aperture, *beam_inout, *out_local,
+                                         out_global ? *out_global : none,
+                                         reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
 }
 

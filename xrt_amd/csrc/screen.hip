@@ -78,4 +78,120 @@ hipError_t screen_expose_launch(const xrt_hip_screen& S, const xrt_hip_beam& in,
   return hipGetLastError();
 }
 
+
+// RectangularAperture.propagate, apertures.py:334-413. Same streaming shape as
+// screen_expose; additionally writes the new state back into the incoming beam.
+__global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_aperture A,
+                                                                xrt_hip_beam in,
+                                                                xrt_hip_beam lo,
+                                                                xrt_hip_beam glo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in.n) return;
+  const bool has_amp = in.Es_ri != nullptr;
+  const bool want_glo = glo.x != nullptr;
+  int st = in.state[i];
+  double x = in.x[i], y = in.y[i], z = in.z[i];
+  double a = in.a[i], b = in.b[i], c = in.c[i];
+  double path = in.path[i];
+  const double E = in.E[i];
+  double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+  if (has_amp) {
+    es = reinterpret_cast<const double2*>(in.Es_ri)[i];
+    ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
+  }
+  const bool good = st > 0;
+  if (good) {
+    const double gx = x - A.center[0], gy = y - A.center[1], gz = z - A.center[2];
+    const double ga = a, gb = b, gc = c;
+    x = (A.ex[0] * gx + A.ex[1] * gy) + A.ex[2] * gz;
+    y = (A.ey[0] * gx + A.ey[1] * gy) + A.ey[2] * gz;
+    z = (A.ez[0] * gx + A.ez[1] * gy) + A.ez[2] * gz;
+    a = (A.ex[0] * ga + A.ex[1] * gb) + A.ex[2] * gc;
+    b = (A.ey[0] * ga + A.ey[1] * gb) + A.ey[2] * gc;
+    c = (A.ez[0] * ga + A.ez[1] * gb) + A.ez[2] * gc;
+    const double dpath = -y / b;
+    x = x + a * dpath;
+    z = z + c * dpath;
+    path = path + dpath;
+    bool bad = false;
+    if (A.blade_mask & 1) bad = bad || (x < A.blade[0]);
+    if (A.blade_mask & 2) bad = bad || (x > A.blade[1]);
+    if (A.blade_mask & 4) bad = bad || (z < A.blade[2]);
+    if (A.blade_mask & 8) bad = bad || (z > A.blade[3]);
+    if (A.is_beam_stop) bad = !bad;
+    if (bad) {
+      st = A.lost_num;
+      in.state[i] = st;   // the reference marks the incoming beam as well
+    }
+    y = 0.;
+    if (has_amp) {  // exp(1e7j (E/CHBAR) path), apertures.py:379-382
+      const double kCH = 6.626069573e-27 * 2.99792458e10 / 1.602176565e-12 * 1e8;
+      const double kCHBAR = kCH / 6.283185307179586476925286766559;
+      const double ph = (1e7 * (E / kCHBAR)) * dpath;
+      double s, co;
+      sincos_phase(ph, s, co);
+      es = make_double2(es.x * co - es.y * s, es.x * s + es.y * co);
+      ep = make_double2(ep.x * co - ep.y * s, ep.x * s + ep.y * co);
+    }
+  }
+  const double Jss = in.Jss[i], Jpp = in.Jpp[i];
+  const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
+  lo.x[i] = x;
+  lo.y[i] = y;
+  lo.z[i] = z;
+  lo.a[i] = a;
+  lo.b[i] = b;
+  lo.c[i] = c;
+  lo.path[i] = path;
+  lo.E[i] = E;
+  lo.Jss[i] = Jss;
+  lo.Jpp[i] = Jpp;
+  reinterpret_cast<double2*>(lo.Jsp_ri)[i] = js;
+  lo.state[i] = st;
+  if (has_amp) {
+    reinterpret_cast<double2*>(lo.Es_ri)[i] = es;
+    reinterpret_cast<double2*>(lo.Ep_ri)[i] = ep;
+  }
+  if (want_glo) {
+    if (good) {  // virgin_local_to_global(bl, glo, center, good)
+      if (A.sin_az != 0.) {
+        const double an = A.cos_az * a - (-A.sin_az) * b, bn = (-A.sin_az) * a + A.cos_az * b;
+        a = an;
+        b = bn;
+        const double xn = A.cos_az * x - (-A.sin_az) * y, yn = (-A.sin_az) * x + A.cos_az * y;
+        x = xn;
+        y = yn;
+      }
+      x += A.center[0];
+      y += A.center[1];
+      z += A.center[2];
+    }
+    glo.x[i] = x;
+    glo.y[i] = y;
+    glo.z[i] = z;
+    glo.a[i] = a;
+    glo.b[i] = b;
+    glo.c[i] = c;
+    glo.path[i] = path;
+    glo.E[i] = E;
+    glo.Jss[i] = Jss;
+    glo.Jpp[i] = Jpp;
+    reinterpret_cast<double2*>(glo.Jsp_ri)[i] = js;
+    glo.state[i] = st;
+    if (has_amp) {
+      reinterpret_cast<double2*>(glo.Es_ri)[i] = es;
+      reinterpret_cast<double2*>(glo.Ep_ri)[i] = ep;
+    }
+  }
+}
+
+hipError_t aperture_propagate_launch(const xrt_hip_aperture& A, const xrt_hip_beam& in,
+                                     const xrt_hip_beam& lo, const xrt_hip_beam& glo,
+                                     hipStream_t st) {
+  if (in.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(aperture_propagate_kernel, dim3((unsigned)((in.n + 255) / 256)), dim3(256),
+                     0, st, A, in, lo, glo);
+  return hipGetLastError();
+}
+
 }  // namespace xrt
