@@ -270,6 +270,26 @@ XRT_HIP_API int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* apert
                                                    xrt_hip_beam* out_local,
                                                    xrt_hip_beam* out_global, void* stream);
 
+/* ---- weighted 2-D histogram of a device-resident beam ---------------------
+ * The reduce step of every run_ray_tracing iteration: raycing.get_output
+ * (raycing/__init__.py:170-300) selects rays by state and forms the intensity,
+ * multipro.do_hist2d (xrt/multipro.py:111-177) bins it with
+ * np.histogram2d(y, x, bins, range, weights). Binning follows numpy: edges =
+ * linspace(lo, hi, bins+1), right-open bins, last bin right-closed.
+ * x, y: device arrays [n] (any beam field or derived quantity), multiplied by
+ * x_factor / y_factor. ray_flags: bit0 state==1, bit1 ==2, bit2 ==3, bit3 <0
+ * (lost), bit4 >0 (rayFlag 4). flux_kind: 0 total (Jss+Jpp), 1 s, 2 p,
+ * 3 +/-45 (2 Re Jsp), 4 left-right (2 Im Jsp), 5 power ((Jss+Jpp) E e0).
+ * hist: bins_y * bins_x doubles, row-major [iy][ix], ACCUMULATED into (zero it
+ * first for a fresh histogram). counters (optional, 8 doubles, accumulated):
+ * [0] selected rays, [1] sum of weights of all selected, [2] of those inside the
+ * range, [3] alive (state>0), [4] good, [5] out, [6] over, [7] dead. */
+XRT_HIP_API int xrt_hip_hist2d_f64_dev(
+    const xrt_hip_beam* beam, const double* x, const double* y, double x_factor,
+    double y_factor, int ray_flags, int flux_kind, double source_weight,
+    int bins_x, double x_lo, double x_hi, int bins_y, double y_lo, double y_hi,
+    double* hist, double* counters, void* stream);
+
 /* ---- building-block checks (used by the GPU tests only) ---------------- */
 XRT_HIP_API int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,
                                void* stream);

@@ -1,0 +1,92 @@
+"""GPU: the run_ray_tracing plug-in surface with on-device histogramming against
+np.histogram2d on the host (numpy IS the reference's histogram code,
+xrt/multipro.py:165-166)."""
+import numpy as np
+import pytest
+
+import xrt_amd.backends.raycing as raycing
+import xrt_amd.backends.raycing.run as rr
+import xrt_amd.backends.raycing.screens as rsc
+import xrt_amd.backends.raycing.sources as rs
+from xrt_amd import plotter as xrtp, runner as xrtr, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def build():
+    bl = raycing.BeamLine()
+    bl.src = rs.GeometricSource(bl, 'src', nrays=40000, dx=0.1, dz=0.1, dxprime=2e-4,
+                                dzprime=2e-5, distE='flat', energies=(8990., 9010.))
+    bl.m1 = workloads.cfg2_toroid(bl)
+    bl.scr = rsc.Screen(bl, 'scr', [0, 30000., 10000. * np.tan(8e-3)])
+    return bl
+
+
+def test_run_ray_tracing_accumulates_histograms():
+    bl = build()
+    kept = []
+
+    def run_process(beamLine):
+        b0 = beamLine.src.shine()
+        gb, lb = beamLine.m1.reflect(b0)
+        img = beamLine.scr.expose(gb)
+        kept.append((lb, img))
+        return {'beamSource': b0, 'beamM1local': lb, 'beamScreen': img}
+    rr.run_process = run_process
+    np.random.seed(11)
+    plots = [
+        xrtp.XYCPlot('beamM1local', (1,), xrtp.XYCAxis('x', 'mm', limits=[-1, 1], bins=64),
+                     xrtp.XYCAxis('y', 'mm', limits=[-300, 300], bins=48)),
+        xrtp.XYCPlot('beamScreen', (1, 3), xrtp.XYCAxis('x', u'µm', limits=[-400, 400],
+                                                        bins=100),
+                     xrtp.XYCAxis("z'", u'µrad', bins=32), fluxKind='s'),
+    ]
+    xrtr.run_ray_tracing(plots, repeats=3, beamLine=bl)
+    assert len(kept) == 3 and plots[0].iteration == 3
+    # plot 0 against numpy on the host copies
+    ref = np.zeros((48, 64))
+    nsel = 0
+    inten = 0.
+    for lb, img in kept:
+        sel = lb.state == 1
+        w = (lb.Jss + lb.Jpp)[sel]
+        h, _, _ = np.histogram2d(lb.y[sel], lb.x[sel], bins=[48, 64],
+                                 range=[[-300, 300], [-1, 1]], weights=w)
+        ref += h
+        nsel += sel.sum()
+        inten += w.sum()
+    assert plots[0].nRaysSelected == nsel and plots[0].nRaysAll == 3 * 40000
+    assert abs(plots[0].intensity - inten) <= 1e-10 * inten
+    assert np.abs(plots[0].total2D - ref).max() <= 1e-10 * ref.max()
+    assert np.allclose(plots[0].total1D_x, ref.sum(axis=0), rtol=1e-9, atol=1e-9)
+    # plot 1: unit factors, derived axis z' = c/b, auto limits, two ray flags, Jss
+    ylim = plots[1].yaxis.limits
+    ref = np.zeros((32, 100))
+    for lb, img in kept:
+        sel = (img.state == 1) | (img.state == 3)
+        h, _, _ = np.histogram2d((img.c / img.b)[sel] * 1e6, img.x[sel] * 1e3,
+                                 bins=[32, 100], range=[ylim, [-400, 400]],
+                                 weights=img.Jss[sel])
+        ref += h
+    assert np.abs(plots[1].total2D - ref).max() <= 1e-10 * ref.max()
+    assert plots[1].nRaysGood + plots[1].nRaysOver + plots[1].nRaysOut + \
+        plots[1].nRaysDead == plots[1].nRaysAll
+
+
+def test_rays_on_bin_edges_follow_numpy():
+    """Edge semantics of np.histogram2d: right-open bins, last bin closed."""
+    import ctypes
+    import torch
+    from xrt_amd import _lib
+    n = 11
+    b = rs.Beam(nrays=n)
+    b.x = np.linspace(-1, 1, n)            # exactly on the edges of 10 bins
+    b.z = np.array([-1., 1., 0., 0.2, -0.2, 0.6, 1.0000001, -1.0000001, 0.999999, 0., 0.4])
+    b.state = np.ones(n, dtype=np.int32)
+    plot = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis('x', 'mm', limits=[-1, 1], bins=10),
+                        xrtp.XYCAxis('z', 'mm', limits=[-1, 1], bins=5))
+    xrtr.accumulate_plot(plot, {'b': b})
+    ref, _, _ = np.histogram2d(b.z, b.x, bins=[5, 10], range=[[-1, 1], [-1, 1]],
+                               weights=b.Jss + b.Jpp)
+    assert np.array_equal(plot.total2D, ref)
+    assert plot.intensityInRange == ref.sum() and plot.intensity == n

@@ -43,6 +43,10 @@ SIGNATURES = {
         vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_screen_expose_f64_dev': (ctypes.c_int, [vp, vp, vp, vp]),
     'xrt_hip_aperture_propagate_f64_dev': (ctypes.c_int, [vp, vp, vp, vp, vp]),
+    'xrt_hip_hist2d_f64_dev': (ctypes.c_int, [
+        vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+        ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+        ctypes.c_int, ctypes.c_double, ctypes.c_double, vp, vp, vp]),
     'xrt_hip_debug_sqrt_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
     'xrt_hip_debug_sincos_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
 }

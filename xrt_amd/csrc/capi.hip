@@ -9,6 +9,7 @@
 #include "kirchhoff.h"
 #include "reflect.h"
 #include "screen.h"
+#include "hist.h"
 
 namespace {
 
@@ -402,6 +403,24 @@ int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* aperture,
   HIP_TRY(xrt::aperture_propagate_launch(*aperture, *beam_inout, *out_local,
                                          out_global ? *out_global : none,
                                          reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_hist2d_f64_dev(const xrt_hip_beam* beam, const double* x, const double* y,
+                           double x_factor, double y_factor, int ray_flags, int flux_kind,
+                           double source_weight, int bins_x, double x_lo, double x_hi,
+                           int bins_y, double y_lo, double y_hi, double* hist,
+                           double* counters, void* stream) {
+  if (!beam) return fail(XRT_HIP_ERR_ARG, "NULL beam");
+  int rc;
+  if ((rc = check_beam(beam, "beam", beam->n, false))) return rc;
+  if (bins_x < 1 || bins_y < 1) return fail(XRT_HIP_ERR_ARG, "bins must be >= 1");
+  if (!(x_hi > x_lo) || !(y_hi > y_lo)) return fail(XRT_HIP_ERR_ARG, "empty histogram range");
+  if (flux_kind < 0 || flux_kind > 5) return fail(XRT_HIP_ERR_ARG, "unknown flux kind");
+  if (beam->n > 0 && (!x || !y || !hist)) return fail(XRT_HIP_ERR_ARG, "NULL array");
+  HIP_TRY(xrt::hist2d_launch(*beam, x, y, x_factor, y_factor, ray_flags, flux_kind,
+                             source_weight, bins_x, x_lo, x_hi, bins_y, y_lo, y_hi, hist,
+                             counters, reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
 }
 

@@ -1,0 +1,9 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/xrt_hip.h"
+namespace xrt {
+hipError_t hist2d_launch(const xrt_hip_beam& beam, const double* x, const double* y, double xf,
+                         double yf, int ray_flags, int flux_kind, double srcw, int bx,
+                         double xlo, double xhi, int by, double ylo, double yhi, double* hist,
+                         double* counters, hipStream_t st);
+}

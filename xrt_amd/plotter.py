@@ -1,0 +1,99 @@
+"""Minimal, matplotlib-free mirror of the part of ``xrt.plotter`` that the job
+runner needs: ``XYCAxis`` / ``XYCPlot`` as accumulators of the 2-D histogram,
+its 1-D projections and the ray counters (xrt/plotter.py:227-330, 684-900;
+xrt/multipro.py:53-177). Drawing, colour (hue) histograms, KDE and persistence
+are out of scope (plotter OOS)."""
+import numpy as np
+
+_UNIT_FACTORS = {'mm': 1., 'm': 1e-3, 'um': 1e3, u'µm': 1e3, 'nm': 1e6,
+                 'rad': 1., 'mrad': 1e3, 'urad': 1e6, u'µrad': 1e6, 'eV': 1.,
+                 'keV': 1e-3, '': 1.}
+_FLUX = {'total': 0, 's': 1, 'p': 2, '+/-45': 3, 'left-right': 4, 'power': 5}
+
+
+class XYCAxis(object):
+    def __init__(self, label='', unit='mm', factor=None, data='auto', limits=None,
+                 offset=0, bins=128, ppb=2, density='histogram', **kwargs):
+        self.label = label
+        self.unit = unit
+        self.factor = _UNIT_FACTORS.get(unit, 1.) if factor is None else factor
+        self.data = data
+        self.limits = limits
+        self.offset = offset
+        self.bins = int(bins)
+        self.ppb = ppb
+        self.density = density
+
+    def field(self):
+        """Which beam quantity this axis shows (label convention of xrt:
+        x, y, z, x', z', energy, path)."""
+        lab = self.label.strip('$').replace(' ', '').lower()
+        return {'x': 'x', 'y': 'y', 'z': 'z', "x'": 'xprime', "z'": 'zprime',
+                'energy': 'E', 'e': 'E', 'path': 'path'}.get(lab, lab)
+
+
+class XYCPlot(object):
+    def __init__(self, beam=None, rayFlag=(1,), xaxis=None, yaxis=None, caxis=None,
+                 aspect='equal', title='', fluxKind='total', beamState=None,
+                 **kwargs):
+        self.beam = beam
+        self.rayFlag = tuple(rayFlag)
+        self.xaxis = xaxis if xaxis is not None else XYCAxis('x', 'mm')
+        self.yaxis = yaxis if yaxis is not None else XYCAxis('z', 'mm')
+        self.caxis = caxis
+        self.title = title or str(beam)
+        if not any(fluxKind.startswith(k) for k in _FLUX):
+            raise NotImplementedError('fluxKind %r' % fluxKind)
+        self.fluxKind = fluxKind
+        self.beamState = beamState
+        self.reset_bins2D()
+
+    def reset_bins2D(self):
+        self.total2D = np.zeros((self.yaxis.bins, self.xaxis.bins))
+        self.nRaysAll = 0
+        self.nRaysSelected = 0
+        self.nRaysAlive = 0
+        self.nRaysGood = 0
+        self.nRaysOut = 0
+        self.nRaysOver = 0
+        self.nRaysDead = 0
+        self.intensity = 0.          # sum of weights of the selected rays
+        self.intensityInRange = 0.   # ... of those inside the plot limits
+        self.iteration = 0
+
+    @property
+    def flux_kind_code(self):
+        for k, v in _FLUX.items():
+            if self.fluxKind.startswith(k):
+                return v
+        return 0
+
+    @property
+    def ray_flag_mask(self):
+        m = 0
+        for f in self.rayFlag:
+            if f == 1:
+                m |= 1
+            elif f == 2:
+                m |= 2
+            elif f == 3:
+                m |= 4
+            elif f == 4:
+                m |= 16
+            elif f < 0:
+                m |= 8
+        return m
+
+    @property
+    def total1D_x(self):
+        return self.total2D.sum(axis=0)
+
+    @property
+    def total1D_y(self):
+        return self.total2D.sum(axis=1)
+
+    def edges(self):
+        return (np.linspace(self.xaxis.limits[0], self.xaxis.limits[1],
+                            self.xaxis.bins + 1),
+                np.linspace(self.yaxis.limits[0], self.yaxis.limits[1],
+                            self.yaxis.bins + 1))
