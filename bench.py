@@ -142,7 +142,7 @@ def bench_reflect(args, world, rank, dist, dcm=False):
     return res
 
 
-def cpu_baseline_reflect(nrays=1_000_000):
+def cpu_baseline_reflect(nrays=10_000_000):
     """numpy oracle of the same cfg2 workload on the host, bounded sample."""
     from xrt_amd import workloads as pc
     from oracle.adapters import oracle_params, to_oracle_beam
@@ -226,7 +226,7 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
     return res, host
 
 
-def cpu_baseline_kirchhoff(host, npix=32):
+def cpu_baseline_kirchhoff(host, npix=256):
     from oracle import kirchhoff_np as kn
     idx = np.linspace(0, host['px'].size - 1, npix).astype(int)
     t0 = time.perf_counter()

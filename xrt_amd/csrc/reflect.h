@@ -7,6 +7,8 @@
 #include "../../include/xrt_hip.h"
 
 #define REFLECT_BLOCK 256
+#define REFLECT_MAX_PART 8192u                    /* partial records (blocks) per reduction */
+#define REFLECT_PART_BYTES (REFLECT_MAX_PART * 64) /* 8 doubles each */
 
 namespace xrt {
 

@@ -302,9 +302,9 @@ __global__ void reflect_init(GStat* g) {
 
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass P,
                                                                    xrt_hip_beam in,
-                                                                   GStat* g) {
-  // grid-stride over the rays with a capped grid: one set of atomics per block,
-  // and all blocks hit the same few words, so the block count is what it costs
+                                                                   double* __restrict__ part) {
+  // two-level reduction: every block writes one 64-byte partial record, a
+  // one-block kernel folds them (no same-address atomics, deterministic)
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
   double ma = 0., mb = 0., mc = 0.;
@@ -334,24 +334,52 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass 
   first = block_reduce(first, fminu, lds_u);
   nent = block_reduce(nent, faddu, lds_u);
   nmain = block_reduce(nmain, faddu, lds_u);
-  if (threadIdx.x == 0 && nent) {
-    // non-negative doubles order like their bit patterns
-    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxa),
-              (unsigned long long)__double_as_longlong(ma));
-    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxb),
-              (unsigned long long)__double_as_longlong(mb));
-    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxc),
-              (unsigned long long)__double_as_longlong(mc));
-    atomicMin(&g->first_good, first);
-    atomicAdd(&g->n_enter, nent);
-    atomicAdd(&g->n_main, nmain);
+  if (threadIdx.x == 0) {
+    double* o = part + (int64_t)blockIdx.x * 8;
+    o[0] = ma;
+    o[1] = mb;
+    o[2] = mc;
+    o[3] = __longlong_as_double((long long)first);
+    o[4] = (double)nent;
+    o[5] = (double)nmain;
   }
 }
 
-__global__ void reflect_decide_axis(xrt_hip_pass P, xrt_hip_beam in, GStat* g) {
-  if (g->n_enter == 0) return;
-  double maxa = g->maxa, maxb = g->maxb, maxc = g->maxc;
-  if (g->n_main == 0) {  // np.max of an empty selection -> (0, 1, 0), base.py:1261-1262
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
+    xrt_hip_pass P, xrt_hip_beam in, const double* __restrict__ part, int nblocks, GStat* g) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
+  double ma = 0., mb = 0., mc = 0., nent = 0., nmain = 0.;
+  unsigned long long first = ~0ull;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    const double* o = part + (int64_t)b * 8;
+    ma = fmax(ma, o[0]);
+    mb = fmax(mb, o[1]);
+    mc = fmax(mc, o[2]);
+    const unsigned long long f = (unsigned long long)__double_as_longlong(o[3]);
+    first = f < first ? f : first;
+    nent += o[4];
+    nmain += o[5];
+  }
+  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
+  auto fminu = [](unsigned long long u, unsigned long long v) { return u < v ? u : v; };
+  auto faddd = [](double u, double v) { return u + v; };
+  ma = block_reduce(ma, fmaxd, lds_d);
+  mb = block_reduce(mb, fmaxd, lds_d);
+  mc = block_reduce(mc, fmaxd, lds_d);
+  first = block_reduce(first, fminu, lds_u);
+  nent = block_reduce(nent, faddd, lds_d);
+  nmain = block_reduce(nmain, faddd, lds_d);
+  if (threadIdx.x != 0) return;
+  g->maxa = ma;
+  g->maxb = mb;
+  g->maxc = mc;
+  g->first_good = first;
+  g->n_enter = (unsigned long long)nent;
+  g->n_main = (unsigned long long)nmain;
+  if (nent == 0.) return;
+  double maxa = ma, maxb = mb, maxc = mc;
+  if (nmain == 0.) {  // np.max of an empty selection -> (0, 1, 0), base.py:1261-1262
     maxa = 0.;
     maxb = 1.;
     maxc = 0.;
@@ -362,7 +390,7 @@ __global__ void reflect_decide_axis(xrt_hip_pass P, xrt_hip_beam in, GStat* g) {
     axis = 0;
   else if (mm == maxb)
     axis = 1;
-  const int64_t i0 = (int64_t)g->first_good;
+  const int64_t i0 = (int64_t)first;
   double a = in.a[i0], b = in.b[i0], c = in.c[i0];
   local_dir(P, a, b, c);
   const double comp = axis == 0 ? a : (axis == 1 ? b : c);
@@ -388,12 +416,10 @@ __device__ __forceinline__ LocalRay load_local(const xrt_hip_pass& P, const xrt_
   return r;
 }
 
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(xrt_hip_pass P,
-                                                                       xrt_hip_beam in,
-                                                                       GStat* g) {
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
+    xrt_hip_pass P, xrt_hip_beam in, const GStat* __restrict__ g, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
-  int have = 0;
   const int axis = g->axis, positive = g->positive;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
@@ -408,7 +434,6 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(xrt_hip_p
     t2m = t2 > t2m ? t2 : t2m;
     d1m = fmax(d1m, fabs(dz1));
     d2m = fmax(d2m, fabs(dz2));
-    have = 1;
   }
   auto fmaxd = [](double u, double v) { return u > v ? u : v; };
   auto fmind = [](double u, double v) { return u < v ? u : v; };
@@ -416,14 +441,55 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(xrt_hip_p
   t2m = block_reduce(t2m, fmaxd, lds_d);
   d1m = block_reduce(d1m, fmaxd, lds_d);
   d2m = block_reduce(d2m, fmaxd, lds_d);
-  have = __syncthreads_or(have);
-  if (threadIdx.x == 0 && have) {
-    atomic_min_double(&g->t1min, t1m);
-    atomic_max_double(&g->t2max, t2m);
-    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxdz1),
-              (unsigned long long)__double_as_longlong(d1m));
-    atomicMax(reinterpret_cast<unsigned long long*>(&g->maxdz2),
-              (unsigned long long)__double_as_longlong(d2m));
+  if (threadIdx.x == 0) {
+    double* o = part + (int64_t)blockIdx.x * 8;
+    o[0] = t1m;
+    o[1] = t2m;
+    o[2] = d1m;
+    o[3] = d2m;
+  }
+}
+
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bracket(
+    const double* __restrict__ part, int nblocks, GStat* g) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    const double* o = part + (int64_t)b * 8;
+    t1m = o[0] < t1m ? o[0] : t1m;
+    t2m = o[1] > t2m ? o[1] : t2m;
+    d1m = fmax(d1m, o[2]);
+    d2m = fmax(d2m, o[3]);
+  }
+  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
+  auto fmind = [](double u, double v) { return u < v ? u : v; };
+  t1m = block_reduce(t1m, fmind, lds_d);
+  t2m = block_reduce(t2m, fmaxd, lds_d);
+  d1m = block_reduce(d1m, fmaxd, lds_d);
+  d2m = block_reduce(d2m, fmaxd, lds_d);
+  if (threadIdx.x == 0) {
+    g->t1min = t1m;
+    g->t2max = t2m;
+    g->maxdz1 = d1m;
+    g->maxdz2 = d2m;
+  }
+}
+
+// sum(beamInDotNormal) and count over the rays that hit (crystal path)
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bdn(
+    const double* __restrict__ part, int nblocks, GStat* g) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  double sum = 0., cnt = 0.;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    sum += part[(int64_t)b * 8];
+    cnt += part[(int64_t)b * 8 + 1];
+  }
+  auto faddd = [](double u, double v) { return u + v; };
+  sum = block_reduce(sum, faddd, lds_d);
+  cnt = block_reduce(cnt, faddd, lds_d);
+  if (threadIdx.x == 0) {
+    g->sum_bdn = sum;
+    g->n_good1 = (unsigned long long)cnt;
   }
 }
 
@@ -1132,7 +1198,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused(
 // accumulates sum(beamInDotNormal) over the rays that hit (reflect.py:573)
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
     xrt_hip_pass P, xrt_hip_beam in, double* ht, double* hx, double* hy, double* hz,
-    int32_t* hst, GStat* gp) {
+    int32_t* hst, const GStat* gp, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
   double bdn_sum = 0.;
@@ -1174,9 +1240,9 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
   auto faddu = [](unsigned long long u, unsigned long long v) { return u + v; };
   bdn_sum = block_reduce(bdn_sum, faddd, lds_d);
   cnt = block_reduce(cnt, faddu, lds_u);
-  if (threadIdx.x == 0 && cnt) {
-    atomicAdd(&gp->sum_bdn, bdn_sum);
-    atomicAdd(&gp->n_good1, cnt);
+  if (threadIdx.x == 0) {
+    part[(int64_t)blockIdx.x * 8] = bdn_sum;
+    part[(int64_t)blockIdx.x * 8 + 1] = (double)cnt;
   }
 }
 
@@ -1262,10 +1328,10 @@ hipError_t crystal_amplitude_launch(const xrt_hip_material& M, int64_t n, const 
 // host-side launcher
 // ---------------------------------------------------------------------------
 size_t reflect_workspace_bytes(int64_t n) {
-  // GStat (256 B) + t, x, y, z (4 x 8n) + state (4n), each 256-aligned
+  // GStat (256 B) + per-block partials + t, x, y, z (4 x 8n) + state (4n)
   const size_t a = ((size_t)n * 8 + 255) / 256 * 256;
   const size_t s = ((size_t)n * 4 + 255) / 256 * 256;
-  return 256 + 4 * a + s;
+  return 256 + REFLECT_PART_BYTES + 4 * a + s;
 }
 
 hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
@@ -1277,7 +1343,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const int64_t n = in.n;
   if (n <= 0) return hipSuccess;
   const size_t a = ((size_t)n * 8 + 255) / 256 * 256;
-  char* base = reinterpret_cast<char*>(workspace) + 256;
+  double* part = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 256);
+  char* base = reinterpret_cast<char*>(workspace) + 256 + REFLECT_PART_BYTES;
   double* ht = reinterpret_cast<double*>(base);
   double* hx = reinterpret_cast<double*>(base + a);
   double* hy = reinterpret_cast<double*>(base + 2 * a);
@@ -1286,17 +1353,22 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const dim3 grid((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)), block(REFLECT_BLOCK);
   if (ev0) (void)hipEventRecord(ev0, st);
   hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g);
-  // reductions: capped grid (4 blocks per CU), grid-stride inside
-  const dim3 rgrid(grid.x < 1024u ? grid.x : 1024u);
+  // reductions: ~4 rays per lane, one partial record per block, folded by a
+  // one-block kernel
+  unsigned rblocks = (unsigned)((n + 4 * REFLECT_BLOCK - 1) / (4 * REFLECT_BLOCK));
+  if (rblocks > REFLECT_MAX_PART) rblocks = REFLECT_MAX_PART;
+  const dim3 rgrid(rblocks);
   if (!P.no_intersection_search) {
-    hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, g);
-    hipLaunchKernelGGL(reflect_decide_axis, dim3(1), dim3(1), 0, st, P, in, g);
-    hipLaunchKernelGGL(reflect_stats_bracket, rgrid, block, 0, st, P, in, g);
+    hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, part);
+    hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, in, part, (int)rblocks, g);
+    hipLaunchKernelGGL(reflect_stats_bracket, rgrid, block, 0, st, P, in, g, part);
+    hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
   }
   const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
   if (need_mean) {
-    const dim3 sgrid(grid.x < 4096u ? grid.x : 4096u);
-    hipLaunchKernelGGL(reflect_solve, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst, g);
+    const dim3 sgrid(grid.x < REFLECT_MAX_PART ? grid.x : REFLECT_MAX_PART);
+    hipLaunchKernelGGL(reflect_solve, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst, g, part);
+    hipLaunchKernelGGL(reflect_reduce_bdn, dim3(1), block, 0, st, part, (int)sgrid.x, g);
     if (evk0) (void)hipEventRecord(evk0, st);
     hipLaunchKernelGGL(reflect_finish, grid, block, 0, st, P, M, in, restore, lb, vb, theta,
                        ht, hx, hy, hz, hst, g);
