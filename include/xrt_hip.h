@@ -143,7 +143,8 @@ typedef struct xrt_hip_pass {
   int32_t no_intersection_search;
   /* surface */
   int32_t surf_kind;
-  double surf_p[8];            /* toroid: R, r */
+  double surf_p[8];            /* toroid: R, r, RN(1/R), RN(1/r), flag: 1 = the two
+                                  reciprocals may be used (constant-divisor division) */
   double n_const[6];           /* flat: [nH(3), n_surface(3)] (base.py:719-742) */
   int32_t asymmetric;          /* 1: n_const holds two different normals */
   /* limits, base.py:1094-1163 */
@@ -293,6 +294,9 @@ XRT_HIP_API int xrt_hip_hist2d_f64_dev(
 /* ---- building-block checks (used by the GPU tests only) ---------------- */
 XRT_HIP_API int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,
                                void* stream);
+/* q[i] = a[i] / b through the constant-divisor sequence of the reflect kernels */
+XRT_HIP_API int xrt_hip_debug_divconst_f64_dev(int64_t n, const double* a, double b, double* q,
+                                   void* stream);
 XRT_HIP_API int xrt_hip_debug_sincos_f64_dev(int64_t n, const double* phi, double* sn, double* cs,
                                  void* stream);
 

@@ -412,6 +412,12 @@ class ToroidMirror(OE):
         p.surf_kind = _structs.SURF_TOROID
         p.surf_p[0] = float(self.R)
         p.surf_p[1] = float(self.r)
+        # correctly rounded reciprocals for the constant-divisor division of the
+        # kernel; only for ordinary radii (R = 1e100 / inf mean 'flat')
+        ok = all(np.isfinite(v) and 1e-100 < abs(v) < 1e100 for v in (self.R, self.r))
+        p.surf_p[2] = 1.0 / float(self.R) if ok else 0.
+        p.surf_p[3] = 1.0 / float(self.r) if ok else 0.
+        p.surf_p[4] = 1.0 if ok else 0.
         p.asymmetric = 0
         for i, v in enumerate((0., 0., 1., 0., 0., 1.)):
             p.n_const[i] = v

@@ -431,6 +431,13 @@ int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* ri
   return XRT_HIP_OK;
 }
 
+int xrt_hip_debug_divconst_f64_dev(int64_t n, const double* a, double b, double* q,
+                                   void* stream) {
+  if (n <= 0) return XRT_HIP_OK;
+  HIP_TRY(xrt::debug_divconst_launch(n, a, b, 1.0 / b, q, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
 int xrt_hip_debug_sincos_f64_dev(int64_t n, const double* phi, double* sn, double* cs,
                                  void* stream) {
   if (n <= 0) return XRT_HIP_OK;

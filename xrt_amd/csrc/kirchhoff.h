@@ -36,6 +36,8 @@ hipError_t kirchhoff_launch(const KirchhoffPlan& pl, int64_t np, const double* p
 
 hipError_t debug_sqrt_launch(int64_t n, const double* x, double* r, double* ri,
                              hipStream_t stream);
+hipError_t debug_divconst_launch(int64_t n, const double* a, double b, double y, double* q,
+                                 hipStream_t stream);
 hipError_t debug_sincos_launch(int64_t n, const double* phi, double* sn, double* cs,
                                hipStream_t stream);
 

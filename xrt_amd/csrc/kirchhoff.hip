@@ -267,6 +267,15 @@ __global__ void debug_sqrt_kernel(int64_t n, const double* __restrict__ x,
   ri[i] = rinv;
 }
 
+__global__ void debug_divconst_kernel(int64_t n, const double* __restrict__ a, double b,
+                                      double y, double* __restrict__ q) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double q0 = a[i] * y;
+  const double r = fma_(-q0, b, a[i]);
+  q[i] = fma_(r, y, q0);
+}
+
 __global__ void debug_sincos_kernel(int64_t n, const double* __restrict__ phi,
                                     double* __restrict__ sn, double* __restrict__ cs) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -363,6 +372,13 @@ hipError_t debug_sqrt_launch(int64_t n, const double* x, double* r, double* ri,
                              hipStream_t stream) {
   hipLaunchKernelGGL(debug_sqrt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256),
                      0, stream, n, x, r, ri);
+  return hipGetLastError();
+}
+
+hipError_t debug_divconst_launch(int64_t n, const double* a, double b, double y, double* q,
+                                 hipStream_t stream) {
+  hipLaunchKernelGGL(debug_divconst_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     stream, n, a, b, y, q);
   return hipGetLastError();
 }
 

@@ -111,3 +111,11 @@ def debug_sincos(phi):
     _lib.check(lib.xrt_hip_debug_sincos_f64_dev(
         phi.numel(), _f64(phi), _f64(s), _f64(c), _stream_ptr()), 'debug_sincos')
     return s, c
+
+
+def debug_divconst(a, b):
+    lib = _lib.load()
+    q = torch.empty_like(a)
+    _lib.check(lib.xrt_hip_debug_divconst_f64_dev(
+        a.numel(), _f64(a), float(b), _f64(q), _stream_ptr()), 'debug_divconst')
+    return q
