@@ -21,6 +21,10 @@ struct GStat {
   double t1min, t2max, maxdz1, maxdz2;
   unsigned long long n_good1;        // rays that ended in state 1
   double sum_bdn;                    // sum of beamInDotNormal over them
+  double emin, emax;                 // energy range of the entering rays
+  int tab_lo[XRT_HIP_MAX_ELEM];      // per element: upper_bound(E table, emin) ...
+  int tab_hi[XRT_HIP_MAX_ELEM];      // ... and upper_bound(E table, emax): the f1/f2
+                                     // binary search of every ray stays inside
 };
 
 size_t reflect_workspace_bytes(int64_t n);

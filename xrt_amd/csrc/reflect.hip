@@ -322,6 +322,12 @@ __global__ void reflect_init(GStat* g) {
   g->maxdz2 = 0.;
   g->n_good1 = 0;
   g->sum_bdn = 0.;
+  g->emin = -INFINITY;
+  g->emax = INFINITY;
+  for (int e = 0; e < XRT_HIP_MAX_ELEM; ++e) {
+    g->tab_lo[e] = 0;
+    g->tab_hi[e] = 0x7fffffff;
+  }
 }
 
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass P,
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass 
   // one-block kernel folds them (no same-address atomics, deterministic)
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  double ma = 0., mb = 0., mc = 0.;
+  double ma = 0., mb = 0., mc = 0., emin = INFINITY, emax = -INFINITY;
   unsigned long long first = ~0ull, nent = 0, nmain = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
@@ -339,6 +345,9 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass 
     if (entering(P, st)) {
       if ((unsigned long long)i < first) first = (unsigned long long)i;
       ++nent;
+      const double E = in.E[i];
+      emin = E < emin ? E : emin;
+      emax = E > emax ? E : emax;
       if (st == 1) {  // mainPartForBracketing, reflect.py:644
         double a = in.a[i], b = in.b[i], c = in.c[i];
         local_dir(P, a, b, c);
@@ -358,6 +367,9 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass 
   first = block_reduce(first, fminu, lds_u);
   nent = block_reduce(nent, faddu, lds_u);
   nmain = block_reduce(nmain, faddu, lds_u);
+  auto fmind = [](double u, double v) { return u < v ? u : v; };
+  emin = block_reduce(emin, fmind, lds_d);
+  emax = block_reduce(emax, fmaxd, lds_d);
   if (threadIdx.x == 0) {
     double* o = part + (int64_t)blockIdx.x * 8;
     o[0] = ma;
@@ -366,14 +378,17 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass 
     o[3] = __longlong_as_double((long long)first);
     o[4] = (double)nent;
     o[5] = (double)nmain;
+    o[6] = emin;
+    o[7] = emax;
   }
 }
 
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
-    xrt_hip_pass P, xrt_hip_beam in, const double* __restrict__ part, int nblocks, GStat* g) {
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, const double* __restrict__ part,
+    int nblocks, GStat* g) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  double ma = 0., mb = 0., mc = 0., nent = 0., nmain = 0.;
+  double ma = 0., mb = 0., mc = 0., nent = 0., nmain = 0., emin = INFINITY, emax = -INFINITY;
   unsigned long long first = ~0ull;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     const double* o = part + (int64_t)b * 8;
@@ -384,10 +399,15 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
     first = f < first ? f : first;
     nent += o[4];
     nmain += o[5];
+    emin = o[6] < emin ? o[6] : emin;
+    emax = o[7] > emax ? o[7] : emax;
   }
   auto fmaxd = [](double u, double v) { return u > v ? u : v; };
+  auto fmind = [](double u, double v) { return u < v ? u : v; };
   auto fminu = [](unsigned long long u, unsigned long long v) { return u < v ? u : v; };
   auto faddd = [](double u, double v) { return u + v; };
+  emin = block_reduce(emin, fmind, lds_d);
+  emax = block_reduce(emax, fmaxd, lds_d);
   ma = block_reduce(ma, fmaxd, lds_d);
   mb = block_reduce(mb, fmaxd, lds_d);
   mc = block_reduce(mc, fmaxd, lds_d);
@@ -402,6 +422,27 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
   g->n_enter = (unsigned long long)nent;
   g->n_main = (unsigned long long)nmain;
   if (nent == 0.) return;
+  // f1/f2 table window of this batch: upper_bound(E table, emin / emax)
+  g->emin = emin;
+  g->emax = emax;
+  if (M.kind != XRT_HIP_MAT_NONE && emin <= emax) {
+    for (int e = 0; e < M.nelem; ++e) {
+      const double* tE = M.tab_E[e];
+      const int n = M.tab_n[e];
+      int lo = 0, hi = n;
+      while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (emin >= tE[mid]) lo = mid + 1; else hi = mid;
+      }
+      g->tab_lo[e] = lo;
+      hi = n;
+      while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (emax >= tE[mid]) lo = mid + 1; else hi = mid;
+      }
+      g->tab_hi[e] = lo;
+    }
+  }
   double maxa = ma, maxb = mb, maxc = mc;
   if (nmain == 0.) {  // np.max of an empty selection -> (0, 1, 0), base.py:1261-1262
     maxa = 0.;
@@ -689,10 +730,32 @@ __device__ __forceinline__ int rays_good(const xrt_hip_pass& P, double x, double
 // ---------------------------------------------------------------------------
 // np.interp on the element table (element.py:252-263): upper_bound - 1, then
 // slope*(x - xp[j]) + fp[j]
-__device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, double E) {
+struct TabWin {
+  int lo[XRT_HIP_MAX_ELEM], hi[XRT_HIP_MAX_ELEM];
+};
+__device__ __forceinline__ TabWin full_window() {
+  TabWin w;
+  for (int e = 0; e < XRT_HIP_MAX_ELEM; ++e) {
+    w.lo[e] = 0;
+    w.hi[e] = 0x7fffffff;
+  }
+  return w;
+}
+__device__ __forceinline__ TabWin window_of(const GStat& g) {
+  TabWin w;
+  for (int e = 0; e < XRT_HIP_MAX_ELEM; ++e) {
+    w.lo[e] = g.tab_lo[e];
+    w.hi[e] = g.tab_hi[e];
+  }
+  return w;
+}
+
+__device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, double E,
+                                            const TabWin& w) {
   const double* __restrict__ tE = M.tab_E[e];
   const int n = M.tab_n[e];
-  int lo = 0, hi = n;
+  // the batch's energy range confines upper_bound(E) to [w.lo, w.hi]
+  int lo = w.lo[e], hi = w.hi[e] < n ? w.hi[e] : n;
   while (lo < hi) {
     const int mid = lo + ((hi - lo) >> 1);
     if (E >= tE[mid])
@@ -720,15 +783,16 @@ __device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, do
 }
 
 // material.py:348-378
-__device__ __forceinline__ cplx refractive_index(const xrt_hip_material& M, double E) {
+__device__ __forceinline__ cplx refractive_index(const xrt_hip_material& M, double E,
+                                                 const TabWin& w) {
   cplx xf = C(0., 0.);
   for (int e = 0; e < M.nelem; ++e) {
-    cplx f = interp_f1f2(M, e, E);
+    cplx f = interp_f1f2(M, e, E, w);
     f.re += (double)M.Z[e];
     xf = xf + f * M.quantity[e];
   }
-  const double w = kCH / E;
-  const double pre = 1e-24 * kAVOGADRO * kR0 / kPI2 * (w * w) * M.rho;
+  const double wl = kCH / E;
+  const double pre = 1e-24 * kAVOGADRO * kR0 / kPI2 * (wl * wl) * M.rho;
   const cplx v = (xf * pre) / M.mass;
   return C(1. - v.re, -v.im);
 }
@@ -740,9 +804,9 @@ struct Ampl {
 
 // Fresnel, material.py:415-493
 __device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, double E,
-                                                   double bdn) {
+                                                   double bdn, const TabWin& w) {
   Ampl A;
-  const cplx n = refractive_index(M, E);
+  const cplx n = refractive_index(M, E, w);
   const cplx one = C(1., 0.);
   const cplx n1 = M.from_vacuum ? one : n;
   const cplx n2 = M.from_vacuum ? n : one;
@@ -813,7 +877,8 @@ __device__ __forceinline__ cplx crystal_one_pol(const xrt_hip_material& M, doubl
 }
 
 __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, double E,
-                                                  double bdsn, double bosn, double bdhn) {
+                                                  double bdsn, double bosn, double bdhn,
+                                                  const TabWin& w) {
   Ampl A;
   const double waveLength = kCH * frcp(E);
   const double k = kPI2 * frcp(waveLength);
@@ -831,7 +896,7 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
     b = k0s * frcp(kHs);
   }
   // structure factors, crystals_basic.py:22-31, 76-80; chi, crystal.py:297-306
-  const cplx anom = interp_f1f2(M, 0, E);
+  const cplx anom = interp_f1f2(M, 0, E, w);
   cplx F0 = (C((double)M.Z[0], 0.) + anom) * 4. * M.fact_dw;
   const int residue = (abs(M.hkl[0]) % 2) + (abs(M.hkl[1]) % 2) + (abs(M.hkl[2]) % 2);
   cplx Fh = C(0., 0.), Fh_ = C(0., 0.);
@@ -958,7 +1023,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       F.c = co;
     }
   } else {  // refraction, reflect.py:894-919
-    const double nre = refractive_index(M, q.E).re;
+    const double nre = refractive_index(M, q.E, window_of(g)).re;
     const double n1overn2 = M.from_vacuum ? 1. / nre : nre;
     const double signN = (double)sgn(-bdn);
     const double n1c = -n1overn2 * bdn;
@@ -999,9 +1064,9 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   A.nk = 0.;
   if (M.kind == XRT_HIP_MAT_CRYSTAL) {
     const double bosn = ao * n[3] + bo * n[4] + co * n[5];
-    A = crystal_amplitude(M, q.E, bdsn, bosn, bdn);
+    A = crystal_amplitude(M, q.E, bdsn, bosn, bdn, window_of(g));
   } else if (M.kind != XRT_HIP_MAT_NONE) {
-    A = material_amplitude(M, q.E, bdn);
+    A = material_amplitude(M, q.E, bdn, window_of(g));
   }
   if (cisnan(A.rs)) A.rs = C(0., 0.);
   if (cisnan(A.rp)) A.rp = C(0., 0.);
@@ -1310,7 +1375,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void material_amplitude_kernel(
     double* __restrict__ mu, double* __restrict__ nk) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Ampl A = material_amplitude(M, E[i], bdn[i]);
+  const Ampl A = material_amplitude(M, E[i], bdn[i], full_window());
   rs[i] = make_double2(A.rs.re, A.rs.im);
   rp[i] = make_double2(A.rp.re, A.rp.im);
   if (mu) mu[i] = A.mu;
@@ -1323,7 +1388,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void crystal_amplitude_kernel(
     const double* __restrict__ hns, double2* __restrict__ S, double2* __restrict__ P) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Ampl A = crystal_amplitude(M, E[i], g0[i], gh[i], hns[i]);
+  const Ampl A = crystal_amplitude(M, E[i], g0[i], gh[i], hns[i], full_window());
   S[i] = make_double2(A.rs.re, A.rs.im);
   P[i] = make_double2(A.rp.re, A.rp.im);
 }
@@ -1384,7 +1449,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const dim3 rgrid(rblocks);
   if (!P.no_intersection_search) {
     hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, part);
-    hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, in, part, (int)rblocks, g);
+    hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, M, in, part, (int)rblocks, g);
     hipLaunchKernelGGL(reflect_stats_bracket, rgrid, block, 0, st, P, in, g, part);
     hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
   }
