@@ -107,12 +107,16 @@ def bench_reflect(args, world, rank, dist, dcm=False):
     for f in beam.array_fields():                      # inputs resident in HBM
         beam.dev(f)
     torch.cuda.synchronize()
+    out = None
+    kw = {} if dcm else {'out': None}
     for _ in range(args.warmup):
-        op(beam)
+        out = op(beam, **kw)
+        if not dcm:
+            kw['out'] = out          # steady state: outputs overwritten in place
     barrier(dist)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = op(beam)
+        out = op(beam, **kw)
     barrier(dist)
     dt = max_over_ranks(dist, time.perf_counter() - t0)
     n_enter = int((beam.peek('state') > 0).sum())

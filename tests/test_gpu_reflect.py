@@ -228,3 +228,20 @@ def test_full_size_cfg2_properties():
     for f in ('Jss', 'Jpp'):
         r = getattr(ogb, f)
         assert np.abs(gb.peek(f)[idx] - r).max() <= AMP_TOL * scale
+
+
+def test_reflect_out_reuse_overwrites_in_place():
+    """`out=` (extension used by bench.py): the second call writes into the first
+    call's arrays and gives the same result."""
+    oe = pc.cfg2_toroid()
+    b1 = pc.synthetic_rays(5000, seed=1)
+    b2 = pc.synthetic_rays(5000, seed=2)
+    gb, lb = oe.reflect(b1)
+    ref_gb2, ref_lb2 = oe.reflect(b2)
+    ptr = gb.dev('x').data_ptr()
+    gb2, lb2 = oe.reflect(b2, out=(gb, lb))
+    assert gb2 is gb and lb2 is lb and gb.dev('x').data_ptr() == ptr
+    for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'Jss', 'Jpp', 'state'):
+        assert np.array_equal(gb2.peek(f), ref_gb2.peek(f)), f
+        assert np.array_equal(lb2.peek(f), ref_lb2.peek(f)), f
+    assert np.array_equal(lb2.peek('theta'), ref_lb2.peek('theta'))

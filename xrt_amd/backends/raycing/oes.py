@@ -240,19 +240,27 @@ class OE(object):
         return material.to_struct(fromVacuum, device)
 
     def _run_pass(self, p, material, fromVacuum, beam_in, restore, want_info=False,
-                  timing=False):
-        """-> (lb, vlb) new device-resident beams (+ info dict)."""
+                  timing=False, out=None):
+        """-> (lb, vlb) device-resident beams (+ info dict). *out*: an (lb, vlb)
+        pair from an earlier call on a beam of the same size to be overwritten
+        instead of allocating new arrays."""
         _lib.require_gpu()
         lib = _lib.load()
         dev = torch.device('cuda', torch.cuda.current_device())
         ms = self._material_struct(material, fromVacuum, dev)
         s_in = beam_in.to_struct(dev)
         s_re = s_in if restore is beam_in else restore.to_struct(dev)
-        lb = rs.Beam.empty_like_on_device(beam_in, dev)
-        vb = rs.Beam.empty_like_on_device(beam_in, dev)
-        s_lb, s_vb = lb.to_struct(dev), vb.to_struct(dev)
         n = beam_in.nrays
-        theta = torch.empty(n, dtype=torch.float64, device=dev)   # every element is written
+        if out is not None and out[0].nrays == n and out[1].nrays == n and \
+                out[0].has_amplitudes() == beam_in.has_amplitudes() and \
+                not out[0]._h_dirty() and not out[1]._h_dirty() and 'theta' in out[0]._d:
+            lb, vb = out
+            theta = lb._d['theta']
+        else:
+            lb = rs.Beam.empty_like_on_device(beam_in, dev)
+            vb = rs.Beam.empty_like_on_device(beam_in, dev)
+            theta = torch.empty(n, dtype=torch.float64, device=dev)   # fully written
+        s_lb, s_vb = lb.to_struct(dev), vb.to_struct(dev)
         wsb = lib.xrt_hip_reflect_workspace_bytes(n)
         ws = hipcalls.workspace(dev, wsb, 'reflect')
         info = (ctypes.c_double * 16)() if want_info else None
@@ -264,7 +272,9 @@ class OE(object):
             ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
             info, ms_out)
         _lib.check(rc, 'xrt_hip_reflect_pass_f64_dev')
-        lb.theta = theta
+        if 'theta' not in lb._d or lb._d['theta'] is not theta:
+            lb._h.pop('theta', None)
+            lb._d['theta'] = theta
         for b in (lb, vb):
             for k in rs._SCALAR_ATTRS:
                 if k in beam_in.__dict__:
@@ -340,7 +350,9 @@ class OE(object):
 
     # -- OE.reflect, oes/reflect.py:18-163 ----------------------------------
     def reflect(self, beam=None, needLocal=True, noIntersectionSearch=False,
-                returnLocalAbsorbed=None, _info=None):
+                returnLocalAbsorbed=None, _info=None, out=None):
+        """-> (beamGlobal, beamLocal). *out* (extension): the pair returned by an
+        earlier call, to be overwritten in place (no new HBM allocations)."""
         pitch = self.pitch
         if hasattr(self, 'bragg'):
             pitch = pitch + self.bragg
@@ -348,8 +360,9 @@ class OE(object):
             pitch, self.roll + self.positionRoll, self.yaw, self.dx,
             noIntersectionSearch=noIntersectionSearch,
             only_state1_out=hasattr(beam, 'createdByDiffract'))
-        lb, gb, info = self._run_pass(p, self.material, True, beam, beam,
-                                      want_info=_info is not None)
+        lb, gb, info = self._run_pass(
+            p, self.material, True, beam, beam, want_info=_info is not None,
+            out=None if out is None else (out[1], out[0]))
         if _info is not None:
             _info.update(info)
         return gb, lb

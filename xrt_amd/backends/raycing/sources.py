@@ -102,6 +102,7 @@ class Beam(object):
 
     def __setattr__(self, name, value):
         if name in _ARRAY_FIELDS:
+            self.__dict__.pop('_struct', None)
             self._d.pop(name, None)
             if isinstance(value, torch.Tensor):
                 if value.is_cuda:
@@ -178,7 +179,10 @@ class Beam(object):
 
     def to_struct(self, device=None):
         """ctypes xrt_hip_beam with device pointers (keeps the tensors alive
-        through the returned struct's ``_keep``)."""
+        through the returned struct's ``_keep``). Cached until a field changes."""
+        cached = self.__dict__.get('_struct')
+        if cached is not None and not self._h_dirty():
+            return cached
         s = _structs.Beam()
         keep = []
         s.n = self.nrays
@@ -198,7 +202,15 @@ class Beam(object):
             s.Es_ri = None
             s.Ep_ri = None
         s._keep = keep
+        object.__setattr__(self, '_struct', s)
         return s
+
+    def _h_dirty(self):
+        """True if some array field has no device copy (host access drops it)."""
+        need = ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp', 'state')
+        if any(n not in self._d for n in need):
+            return True
+        return self.has_amplitudes() and ('Es' not in self._d or 'Ep' not in self._d)
 
 
 def copy_beam(beamTo, beamFrom, indarr, includeState=False, includeJspEsp=True):
