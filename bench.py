@@ -287,7 +287,7 @@ def main():
             ([4, 5] if world == 8 else [4])
         for cfg in cfgs:
             ks = args.kirchhoff_steps or (max(1, min(args.steps, 3)) if cfg == 4 else 1)
-            kw = 1 if cfg == 4 else 0
+            kw = 1
             kres, h = bench_kirchhoff(cfg, ks, kw, world, rank, dist)
             if cfg == 4 or host is None:
                 host = h

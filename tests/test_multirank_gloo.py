@@ -25,7 +25,9 @@ def _free_port():
 def _worker(rank, world, port, npix_side, ns, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=60))
     try:
         h = workloads.kirchhoff_custom(ns, npix_side, seed=11)
         n = h['px'].size
@@ -41,20 +43,27 @@ def _worker(rank, world, port, npix_side, ns, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(180)
 @pytest.mark.parametrize('npix_side', [8, 7])     # 64 pixels (even) / 49 (uneven tiles)
 def test_two_rank_pixel_tiling_matches_single_rank(npix_side):
     world, ns = 2, 300
     ctx = mp.get_context('spawn')
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, npix_side, ns, q))
              for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get()
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        got = q.get(timeout=120)     # raises queue.Empty if a rank died
+        for p in procs:
+            p.join(60)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    finally:
+        for p in procs:          # never leave a rank blocked in a collective
+            if p.is_alive():
+                p.terminate()
+                p.join(5)
     h = workloads.kirchhoff_custom(ns, npix_side, seed=11)
     ref = kn.kirchhoff_conv(h['px'], h['py'], h['pz'], h['sx'], h['sy'], h['sz'],
                             h['n'], h['nl'], h['E'], h['Es'], h['Ep'])

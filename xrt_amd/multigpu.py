@@ -18,22 +18,32 @@ def tile_range(n, rank, world):
     return n * rank // world, n * (rank + 1) // world
 
 
-def all_gather_tiles(local, n_total, dist, rank, world):
-    """Assembles the full array from the ranks' tiles (uneven tiles are padded to
-    the largest one for the collective and trimmed afterwards)."""
+def all_gather_tiles(local, n_total, dist, rank, world, width=1):
+    """Assembles the full array from the ranks' tiles. *local* holds this rank's
+    tile (``width`` scalars per item); uneven tiles are padded to the largest one
+    for the collective and trimmed afterwards. Complex tiles travel as their
+    interleaved (re, im) doubles (RCCL has no complex dtypes)."""
     if dist is None or world == 1:
         return local
-    sizes = [tile_range(n_total, r, world) for r in range(world)]
-    maxn = max(p1 - p0 for p0, p1 in sizes)
-    if all(p1 - p0 == maxn for p0, p1 in sizes):
-        out = torch.empty(n_total, dtype=local.dtype, device=local.device)
+    if local.is_complex():
+        real = torch.view_as_real(local.contiguous()).reshape(-1)
+        out = all_gather_tiles(real, n_total, dist, rank, world, width=2 * width)
+        return torch.view_as_complex(out.reshape(-1, 2))
+    sizes = [(p1 - p0) * width
+             for p0, p1 in (tile_range(n_total, r, world) for r in range(world))]
+    if local.numel() != sizes[rank]:
+        raise ValueError('rank %d holds %d values, its tile has %d'
+                         % (rank, local.numel(), sizes[rank]))
+    maxn = max(sizes)
+    if all(sz == maxn for sz in sizes):
+        out = torch.empty(n_total * width, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous())
         return out
     pad = torch.zeros(maxn, dtype=local.dtype, device=local.device)
     pad[:local.numel()] = local
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
-    return torch.cat([b[:p1 - p0] for b, (p0, p1) in zip(bufs, sizes)])
+    return torch.cat([b[:sz] for b, sz in zip(bufs, sizes)])
 
 
 def kirchhoff_tiled(px, py, pz, samples, dist, rank, world, convention=0):
