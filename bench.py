@@ -49,6 +49,9 @@ def parse():
     ap.add_argument('--kirchhoff-steps', type=int, default=0)
     ap.add_argument('--skip-kirchhoff', action='store_true')
     ap.add_argument('--skip-cpu-baseline', action='store_true')
+    ap.add_argument('--with-softi-shapes', action='store_true',
+                    help='also time the two Kirchhoff shapes of the reference\'s '
+                         'published speed test (2e5 x 2e5 and 2e5 x 64^2)')
     ap.add_argument('--with-dcm', action='store_true',
                     help='also time cfg3 (DCM Si111, 2 intersections per ray)')
     return ap.parse_args()
@@ -230,6 +233,42 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
     return res, host
 
 
+def bench_softi_shapes():
+    """The reference's only published P2 numbers are whole-script times of
+    tests/speed/3_Softi_CXIw2D_speed.py: 7 diffract calls of <= 2e5 x 2e5 pairs
+    and 3 of <= 2e5 x 4096 (derived A100 rate
+    ~1.6e10 pairs/s incl. everything else the script does). This times our
+    kernel on synthetic data of those two shapes."""
+    from xrt_amd import hipcalls, workloads
+    dev = torch.device('cuda', torch.cuda.current_device())
+    up = lambda a, dt=np.float64: torch.from_numpy(  # noqa: E731
+        np.ascontiguousarray(a, dtype=dt)).to(dev)
+    res = {}
+    for tag, ns, side in (('2e5x2e5', 200_000, 447), ('2e5x64x64', 200_000, 64)):
+        h = workloads.kirchhoff_custom(ns, side)
+        args = [up(h['px']), up(h['py']), up(h['pz']), up(h['sx']), up(h['sy']),
+                up(h['sz']), up(np.zeros(ns)), up(np.ones(ns)), up(np.zeros(ns)),
+                up(h['nl']), up(h['k']), up(h['Es'], np.complex128),
+                up(h['Ep'], np.complex128)]
+        hipcalls.kirchhoff(*args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            hipcalls.kirchhoff(*args)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        pairs = float(ns) * h['px'].size
+        res[tag] = dict(samples=ns, pixels=int(h['px'].size), ms=dt * 1e3,
+                        pairs_per_s=pairs / dt)
+    total = 7 * res['2e5x2e5']['ms'] + 3 * res['2e5x64x64']['ms']
+    res['ten_calls_ms'] = total
+    res['note'] = ('7 x (2e5 x 2e5) + 3 x (2e5 x 4096) Kirchhoff calls, kernel + '
+                   'pack + finalize, inputs resident; the reference publishes '
+                   '17.5 s (1 x A100) for the whole script that contains them')
+    return res
+
+
 def cpu_baseline_kirchhoff(host, npix=256):
     from oracle import kirchhoff_np as kn
     idx = np.linspace(0, host['px'].size - 1, npix).astype(int)
@@ -292,6 +331,8 @@ def main():
             if cfg == 4 or host is None:
                 host = h
             line['kirchhoff' if 'kirchhoff' not in line else 'kirchhoff_cfg%d' % cfg] = kres
+    if args.with_softi_shapes and world == 1:
+        line['softi_shapes'] = bench_softi_shapes()
     if world == 1 and rank == 0 and not args.skip_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline_reflect()
         line['cpu_baseline']['host_cpus'] = os.cpu_count()

@@ -121,6 +121,7 @@ typedef struct xrt_hip_rotation {
 
 #define XRT_HIP_SURF_FLAT 0
 #define XRT_HIP_SURF_TOROID 1
+#define XRT_HIP_SURF_BENTFLAT 2   /* z = (y^2 - y0^2)/2/R, oes/__init__.py:240-303 */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_OVER_XMIN 1
@@ -144,7 +145,8 @@ typedef struct xrt_hip_pass {
   /* surface */
   int32_t surf_kind;
   double surf_p[8];            /* toroid: R, r, RN(1/R), RN(1/r), flag: 1 = the two
-                                  reciprocals may be used (constant-divisor division) */
+                                  reciprocals may be used (constant-divisor division);
+                                  bent-flat: R, limPhysY[0]^2, RN(1/R), -, flag */
   double n_const[6];           /* flat: [nH(3), n_surface(3)] (base.py:719-742) */
   int32_t asymmetric;          /* 1: n_const holds two different normals */
   /* limits, base.py:1094-1163 */

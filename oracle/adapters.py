@@ -18,8 +18,10 @@ def oracle_params(oe):
         overEdge=oe.overEdge, lostNum=oe.lostNum, surfPhysX=list(oe.limPhysX),
         surfPhysY=list(oe.limPhysY), surfOptX=oe.limOptX, surfOptY=oe.limOptY)
     tb = fixture_io.tables()
-    if hasattr(oe, 'R'):
+    if hasattr(oe, 'R') and hasattr(oe, 'r'):
         p['surface'] = dict(kind='toroid', R=oe.R, r=oe.r)
+    elif hasattr(oe, 'R'):
+        p['surface'] = dict(kind='bentflat', R=oe.R, y0=oe.limPhysY[0])
     else:
         p['surface'] = dict(kind='flat', alpha=oe.alpha)
 

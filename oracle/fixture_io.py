@@ -51,6 +51,10 @@ def load_case(name):
     elif name == 'g2_toroid_brent':
         p['surface'] = dict(kind='toroid', R=float(g['surf_R']), r=float(g['surf_r']))
         p['material'] = None
+    elif name == 'g2_bentflat_rh':
+        p['surface'] = dict(kind='bentflat', R=float(g['surf_R']), y0=p['surfPhysY'][0])
+        p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,
+                                         'mirror', float(g['mat_rho']))
     elif name == 'g2_plate_be':
         p['surface'] = dict(kind='flat')
         p['surface2'] = dict(kind='flat')

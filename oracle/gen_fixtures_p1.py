@@ -406,6 +406,19 @@ def main():
                    cr_chiToF=np.array(si1.chiToF))
         save(tag, **out)
 
+    # ---------------- G2e: BentFlatMirror (VCM) + Rh ----------------------
+    bl = raycing.BeamLine()
+    mRhM = rm.Material('Rh', rho=12.41, kind='mirror')
+    vcm = roe.BentFlatMirror(
+        bl, 'vcm', center=[0, 15000., 0], pitch=2.5e-3, R=(15000., 1e9),
+        material=mRhM, limPhysX=[-15, 15], limPhysY=[-400, 400])
+    beam = make_rays(rs, n, 48, sx=0.5, sz=0.2, sa=3e-4, sc=2e-5,
+                     E=(6000., 14000.), amplitudes=True, pol='mixed')
+    par = oe_params(vcm, dict(kind='bentflat', R=vcm.R, y0=vcm.limPhysY[0]))
+    par['material'] = material_dict(tables, mRhM)
+    run_reflect('g2_bentflat_rh', rs, vcm, par, beam, surf_R=np.array(vcm.R),
+                mat_rho=np.array(12.41))
+
     # ---------------- G2d: Plate.double_refract (Be window) ---------------
     bl = raycing.BeamLine()
     mBe = rm.Material('Be', rho=1.848, kind='plate')

@@ -197,6 +197,8 @@ def local_z(surf, x, y):
         rx = 1 - (np.asarray(x)/r)**2
         rx[rx < 0] = 0.
         return y**2/2.0/R + r*(1 - rx**0.5)
+    if surf['kind'] == 'bentflat':                # oes/__init__.py:289-293
+        return (y**2 - surf['y0']**2) / 2.0 / surf['R']
     raise ValueError(surf['kind'])
 
 
@@ -224,6 +226,12 @@ def local_n(surf, x, y):
         b = -y / R
         c = 1.
         norm = (a**2 + b**2 + 1)**0.5
+        return [a/norm, b/norm, c/norm]
+    if surf['kind'] == 'bentflat':                # oes/__init__.py:295-303
+        a = 0.
+        b = -y / surf['R']
+        c = 1.
+        norm = (b**2 + 1)**0.5
         return [a/norm, b/norm, c/norm]
     raise ValueError(surf['kind'])
 

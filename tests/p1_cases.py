@@ -79,6 +79,9 @@ def product_oe(name, g):
     elif name == 'g2_toroid_brent':
         oe = roe.ToroidMirror(bl, 'tm2', R=float(g['surf_R']), r=float(g['surf_r']),
                               material=None, **common)
+    elif name == 'g2_bentflat_rh':
+        m = rm.Material('Rh', rho=float(g['mat_rho']), kind='mirror')
+        oe = roe.BentFlatMirror(bl, 'vcm', R=float(g['surf_R']), material=m, **common)
     elif name == 'g2_plate_be':
         m = rm.Material('Be', rho=float(g['mat_rho']), kind='plate')
         oe = roe.Plate(bl, 'win', material=m, t=float(g['plate_t']), **common)

@@ -44,7 +44,7 @@ from oracle.adapters import oracle_params, to_oracle_beam  # noqa: E402
 
 # ---- golden vectors from the reference ----------------------------------------
 @pytest.mark.parametrize('name', ['g2_toroid_pt', 'g2_flat_general',
-                                  'g2_toroid_brent'])
+                                  'g2_toroid_brent', 'g2_bentflat_rh'])
 def test_oe_reflect_matches_reference_golden(name):
     g = pc.load(name)
     oe = pc.product_oe(name, g)

@@ -25,7 +25,7 @@ def check_beam(mine, g, prefix):
 
 
 @pytest.mark.parametrize('name', ['g2_toroid_pt', 'g2_flat_general',
-                                  'g2_toroid_brent'])
+                                  'g2_toroid_brent', 'g2_bentflat_rh'])
 def test_oe_reflect_matches_reference(name):
     p, beam, g = fixture_io.load_case(name)
     info = {}

@@ -439,6 +439,53 @@ class ToroidMirror(OE):
 SimpleVFM = ToroidMirror
 
 
+class BentFlatMirror(OE):
+    """Meridionally bent parabolic cylinder with fixed ends:
+    z = (y^2 - limPhysY[0]^2) / (2R) (oes/__init__.py:240-303)."""
+
+    def __init__(self, *args, **kwargs):
+        R = kwargs.pop('R', 5.0e6)
+        OE.__init__(self, *args, **kwargs)
+        self.R = R
+
+    @property
+    def R(self):
+        return self._RVal
+
+    @R.setter
+    def R(self, R):
+        if isinstance(R, (list, tuple)):
+            self._RVal = self.get_Rmer_from_Coddington(*R)
+        elif R is None:
+            self._RVal = 1e100
+        else:
+            self._RVal = R
+
+    def local_z(self, x, y):
+        return (y**2 - self.limPhysY[0]**2) / 2.0 / self.R
+
+    def local_n(self, x, y):
+        a = 0.
+        b = -y / self.R
+        c = 1.
+        norm = (b**2 + 1)**0.5
+        return [a/norm, b/norm, c/norm]
+
+    def _surface_params(self, p, second=False):
+        p.surf_kind = _structs.SURF_BENTFLAT
+        ok = bool(np.isfinite(self.R)) and 1e-100 < abs(self.R) < 1e100
+        p.surf_p[0] = float(self.R)
+        p.surf_p[1] = float(self.limPhysY[0]**2)
+        p.surf_p[2] = 1.0 / float(self.R) if ok else 0.
+        p.surf_p[4] = 1.0 if ok else 0.
+        p.asymmetric = 0
+        for i, v in enumerate((0., 0., 1., 0., 0., 1.)):
+            p.n_const[i] = v
+
+
+SimpleVCM = BentFlatMirror
+
+
 class DCM(OE):
     """Double-crystal monochromator with flat crystals (oes/dcm.py)."""
 

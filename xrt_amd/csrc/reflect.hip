@@ -221,6 +221,10 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
     if (rx < 0.) rx = 0.;
     return h + r * (1. - sqrt_unit(rx));
   }
+  if (P.surf_kind == XRT_HIP_SURF_BENTFLAT) {  // (y**2 - limPhysY[0]**2) / 2.0 / R
+    const double num = (y * y - P.surf_p[1]) * 0.5;
+    return P.surf_p[4] != 0. ? div_const(num, P.surf_p[0], P.surf_p[2]) : num / P.surf_p[0];
+  }
   return 0.;
 }
 
@@ -970,6 +974,12 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     n[0] = n[3] = na * inorm;
     n[1] = n[4] = nb * inorm;
     n[2] = n[5] = inorm;
+  } else if (P.surf_kind == XRT_HIP_SURF_BENTFLAT) {  // oes/__init__.py:296-303
+    const double nb = -h.y * frcp(P.surf_p[0]);
+    const double inorm = frcp(sqrt(nb * nb + 1.));
+    n[0] = n[3] = 0.;
+    n[1] = n[4] = nb * inorm;
+    n[2] = n[5] = inorm;
   } else {
     for (int j = 0; j < 6; ++j) n[j] = P.n_const[j];
   }
@@ -1315,6 +1325,12 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
         const double na = -qx * ax, nb = -h.y * frcp(R);
         const double inorm = frcp(sqrt(na * na + nb * nb + 1.));
         n0 = na * inorm;
+        n1 = nb * inorm;
+        n2 = inorm;
+      } else if (P.surf_kind == XRT_HIP_SURF_BENTFLAT) {
+        const double nb = -h.y * frcp(P.surf_p[0]);
+        const double inorm = frcp(sqrt(nb * nb + 1.));
+        n0 = 0.;
         n1 = nb * inorm;
         n2 = inorm;
       }
