@@ -105,3 +105,29 @@ def test_convex_hull_area_matches_qhull_value(golden_dir):
     g = np.load(os.path.join(golden_dir, 'g4_toroid_3000x24.npz'))
     area = rw.convex_hull_area(g['s_x'], g['s_y'])
     assert abs(area - float(g['s_area'])) <= 1e-12 * float(g['s_area'])
+
+
+def test_sequential_wave_chain_matches_reference(golden_dir):
+    """N4: slit field --diffract--> ToroidMirror.propagate_wave (random samples on
+    the mirror, reflect with noIntersectionSearch, createdByDiffract) --diffract-->
+    screen, against the same chain run by the reference (G8). Same np.random seeds
+    give the same samples."""
+    from oracle.gen_fixtures_wave_chain import build, slit_field
+    g = np.load(os.path.join(golden_dir, 'g8_wave_chain.npz'))
+    bl = build(raycing, ra, roe, rm, rsc, rs)
+    np.random.seed(21)
+    wslit = bl.slit.prepare_wave(bl.src, 1500)
+    slit_field(wslit)
+    for f in ('x', 'z', 'Es', 'Ep', 'a', 'b', 'c'):
+        assert np.array_equal(getattr(wslit, f), g['s_' + f]), f
+    np.random.seed(22)
+    glo, lo = bl.m1.propagate_wave(wave=wslit, nrays=1200)
+    assert np.array_equal(lo.state, g['m_state'])
+    check(lo, g, 'm_', [('x', 'y', 'z'), ('a', 'b', 'c'), ('Es', 'Ep'),
+                        ('Jss', 'Jpp', 'Jsp')])
+    check(glo, g, 'mg_', [('x', 'y', 'z'), ('a', 'b', 'c'), ('Es', 'Ep'),
+                          ('Jss', 'Jpp', 'Jsp')])
+    wscr = bl.scr.prepare_wave(bl.m1, g['xmesh'], g['zmesh'])
+    rw.diffract(lo, wscr)
+    assert abs(lo.area - float(g['m_area'])) <= 1e-10 * float(g['m_area'])
+    check(wscr, g, 'w_', [('Es', 'Ep'), ('Jss', 'Jpp', 'Jsp'), ('a', 'b', 'c')])

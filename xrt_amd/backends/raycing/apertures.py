@@ -67,7 +67,8 @@ class RectangularAperture(object):
     def opening(self):
         return list(self.blades.values())
 
-    def local_to_global(self, glo, **kwargs):
+    def local_to_global(self, glo, returnBeam=False, **kwargs):
+        kwargs['returnBeam'] = returnBeam
         """apertures.py:436-457 on host arrays."""
         x, y, z = glo.x, glo.y, glo.z
         xglo = self.center[0] + x*self.x[0] + y*self.y[0] + z*self.z[0]

@@ -279,8 +279,6 @@ class OE(object):
             for k in rs._SCALAR_ATTRS:
                 if k in beam_in.__dict__:
                     object.__setattr__(b, k, beam_in.__dict__[k])
-            if 'area' in beam_in.__dict__:      # copy_beam, beams.py:431-432
-                object.__setattr__(b, 'area', beam_in.__dict__['area'])
             b.parentId = self.uuid
         res_info = None
         if want_info:
@@ -347,6 +345,125 @@ class OE(object):
             raycing.virgin_local_to_global(self.bl, retGlo, self.center)
             return retGlo
         raycing.virgin_local_to_global(self.bl, lb, self.center)
+
+    # -- wave propagation through the element (oes/reflect.py:266-449) ---------
+    def prepare_wave(self, prevOE, nrays, shape='auto', area='auto', rw=None):
+        """Wave samples on this surface that will receive the field diffracted
+        by *prevOE*: random over the physical limits (int *nrays*), a uniform mesh
+        ((nx, ny)) or given positions ((x array, y array)). Uses the global
+        np.random state like the reference."""
+        if rw is None:
+            from . import waves as rw
+        if isinstance(nrays, (int, float)):
+            nsamples = int(nrays)
+        elif isinstance(nrays, (list, tuple)):
+            if isinstance(nrays[0], (int, float)):
+                nsamples = nrays[0] * nrays[1]
+            elif isinstance(nrays[0], np.ndarray) and isinstance(nrays[1], np.ndarray):
+                nsamples = len(nrays[0]) * len(nrays[1])
+            else:
+                raise ValueError('wrong type of `nrays`!')
+        else:
+            raise ValueError('wrong type of `nrays`!')
+        lb = rs.Beam(nrays=nsamples, forceState=1, withAmplitudes=True)
+        lb.parentId = prevOE.uuid
+        if shape == 'auto':
+            shape = self.shape
+        if isinstance(nrays, (int, float)):
+            xy = np.random.rand(nsamples, 2)
+            if shape.startswith('ro'):
+                dR = (self.limPhysX[1] - self.limPhysX[0]) / 2
+                r = xy[:, 0]**0.5 * dR
+                phi = xy[:, 1] * 2*np.pi
+                x = r * np.cos(phi)
+                y = r * np.sin(phi)
+                if area == 'auto':
+                    area = np.pi * dR**2
+            elif shape.startswith('re'):
+                dX = self.limPhysX[1] - self.limPhysX[0]
+                dY = self.limPhysY[1] - self.limPhysY[0]
+                x = xy[:, 0] * dX + self.limPhysX[0]
+                y = xy[:, 1] * dY + self.limPhysY[0]
+                if area == 'auto':
+                    area = dX * dY
+            else:
+                raise ValueError('unknown shape!')
+        else:
+            if shape.startswith('ro'):
+                raise ValueError('must be rectangular')
+            if isinstance(nrays[0], (int, float)):
+                xx = np.linspace(*self.limPhysX, nrays[0])
+                yy = np.linspace(*self.limPhysY, nrays[1])
+            else:
+                xx, yy = nrays
+            X, Y = np.meshgrid(xx, yy)
+            x = X.ravel()
+            y = Y.ravel()
+            if area == 'auto':
+                area = (self.limPhysX[1] - self.limPhysX[0]) * \
+                    (self.limPhysY[1] - self.limPhysY[0])
+        lb.x[:] = x
+        lb.y[:] = y
+        lb.z[:] = self.local_z(x, y)
+        self.local_to_global(lb)
+        if hasattr(prevOE, 'rotationSequence'):   # the previous element is an OE
+            cx = (prevOE.limPhysX[1] + prevOE.limPhysX[0])*0.5
+            cy = (prevOE.limPhysY[1] + prevOE.limPhysY[0])*0.5
+            cz = prevOE.local_z(np.atleast_1d(float(cx)), np.atleast_1d(float(cy)))
+            lbc = rs.Beam(nrays=1)
+            lbc.x[:] = cx
+            lbc.y[:] = cy
+            lbc.z[:] = cz
+            prevOE.local_to_global(lbc)
+            prevCenter = [lbc.x[0], lbc.y[0], lbc.z[0]]
+        else:
+            prevCenter = prevOE.center
+        lb.a[:] = lb.x - prevCenter[0]
+        lb.b[:] = lb.y - prevCenter[1]
+        lb.c[:] = lb.z - prevCenter[2]
+        norm = (lb.a**2 + lb.b**2 + lb.c**2)**0.5
+        lb.a /= norm
+        lb.b /= norm
+        lb.c /= norm
+        lb.x[:] = prevCenter[0]
+        lb.y[:] = prevCenter[1]
+        lb.z[:] = prevCenter[2]
+        lbn = rs.Beam(nrays=1)
+        lbn.b[:] = 0.
+        lbn.c[:] = 1.
+        self.local_to_global(lbn)
+        a = lbn.x - prevCenter[0]
+        b = lbn.y - prevCenter[1]
+        c = lbn.z - prevCenter[2]
+        norm = (a**2 + b**2 + c**2)**0.5
+        areaNormalFact = abs(float(((a*lbn.a[0] + b*lbn.b[0] + c*lbn.c[0]) / norm)[0]))
+        waveGlobal, waveLocal = self.reflect(lb)        # HIP kernels
+        good = (waveLocal.state == 1) | (waveLocal.state == 2)
+        waveGlobal.filter_by_index(good)
+        waveLocal.filter_by_index(good)
+        area *= good.sum() / float(len(good))
+        waveLocal.area = area
+        waveLocal.areaNormal = area * areaNormalFact
+        waveLocal.dS = area / float(len(good))
+        waveLocal.toOE = self
+        waveLocal.parentId = self.uuid
+        rw.prepare_wave(prevOE, waveLocal, waveGlobal.x, waveGlobal.y, waveGlobal.z)
+        return waveLocal
+
+    def propagate_wave(self, wave=None, beam=None, nrays='auto'):
+        """Kirchhoff-propagates *wave* (the local field on the previous element)
+        onto this surface and reflects it: -> (beamGlobal, beamLocal) usable for
+        further ray or wave propagation (oes/reflect.py:405-449)."""
+        from . import waves as rw
+        waveSize = len(wave.x) if nrays == 'auto' else int(nrays)
+        prevOE = self.bl.oesDict[wave.parentId][0]
+        if hasattr(prevOE, 'shine'):
+            raise NotImplementedError('wave propagation directly from a source')
+        waveOnSelf = self.prepare_wave(prevOE, waveSize, rw=rw)
+        beamToSelf = rw.diffract(wave, waveOnSelf)
+        retGlo, retLoc = self.reflect(beamToSelf, noIntersectionSearch=True)
+        retLoc.parentId = self.uuid
+        return retGlo, retLoc
 
     # -- OE.reflect, oes/reflect.py:18-163 ----------------------------------
     def reflect(self, beam=None, needLocal=True, noIntersectionSearch=False,

@@ -121,6 +121,11 @@ class Beam(object):
         else:
             object.__delattr__(self, name)
 
+    def filter_by_index(self, indarr):
+        """Keeps the rays selected by *indarr* (sources/beams.py:296-318)."""
+        for name in self.array_fields():
+            setattr(self, name, getattr(self, name)[indarr])
+
     def array_fields(self):
         return [n for n in (_F64 + _C128 + _OPT_F64 + ('state',))
                 if n in self._h or n in self._d]
