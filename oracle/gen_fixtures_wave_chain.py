@@ -2,7 +2,7 @@
 sequential wave-propagation chain
 
     field on a rectangular slit --diffract--> ToroidMirror(Pt).propagate_wave
-    (prepare_wave: random samples on the mirror, reflect with
+    (= prepare_wave: random samples on the mirror; diffract; reflect with
     noIntersectionSearch) --diffract--> 20x20 screen
 
 Stored: the slit field, the np.random seed, the mirror-local wave after
@@ -64,8 +64,17 @@ def main():
     slit_field(wslit)
     out = {'s_' + f: np.array(getattr(wslit, f)) for f in F}
     out['s_area'] = np.float64(wslit.area)
+    # The explicit three-call sequence the reference's own wave examples and
+    # speed test use (tests/speed/3_Softi_CXIw2D_speed.py:369-407). NOT
+    # OE.propagate_wave: that method first passes `wave` through
+    # prevOE.local_to_global(wave, returnBeam=True) for auto-alignment
+    # (oes/reflect.py:434-438), which transforms `wave` IN PLACE, so the
+    # integral that follows sees the samples in the wrong frame.
     np.random.seed(22)
-    glo, lo = bl.m1.propagate_wave(wave=wslit, nrays=1200)
+    wm = bl.m1.prepare_wave(bl.slit, 1200)
+    beamToM1 = rw.diffract(wslit, wm)
+    glo, lo = bl.m1.reflect(beamToM1, noIntersectionSearch=True)
+    lo.parentId = bl.m1.uuid
     out.update({'m_' + f: np.array(getattr(lo, f)) for f in F})
     out.update({'mg_' + f: np.array(getattr(glo, f)) for f in F})
     xm = np.linspace(-0.15, 0.15, 20)

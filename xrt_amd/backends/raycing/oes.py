@@ -453,7 +453,12 @@ class OE(object):
     def propagate_wave(self, wave=None, beam=None, nrays='auto'):
         """Kirchhoff-propagates *wave* (the local field on the previous element)
         onto this surface and reflects it: -> (beamGlobal, beamLocal) usable for
-        further ray or wave propagation (oes/reflect.py:405-449)."""
+        further ray or wave propagation (oes/reflect.py:405-449). This is the
+        explicit sequence prepare_wave -> diffract -> reflect(noIntersectionSearch)
+        that the reference's wave examples spell out; the reference's own
+        propagate_wave additionally transforms *wave* in place while
+        auto-aligning (reflect.py:434-438), a side effect that is not reproduced
+        (golden case G8 is generated with the explicit sequence)."""
         from . import waves as rw
         waveSize = len(wave.x) if nrays == 'auto' else int(nrays)
         prevOE = self.bl.oesDict[wave.parentId][0]
