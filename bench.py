@@ -145,7 +145,7 @@ def bench_reflect(args, world, rank, dist, dcm=False):
             achieved=BYTES_PER_INTERSECTION * n_enter / k / 1e9,
             peak=HBM_PEAK / 1e9, unit='GB/s',
             frac=BYTES_PER_INTERSECTION * n_enter / k / HBM_PEAK,
-            traffic=load_traffic('reflect_fused'))
+            traffic=load_traffic('reflect_fused') if n == 10_000_000 else None)
     return res
 
 
@@ -229,7 +229,8 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
                       achieved=FLOP_PER_PAIR * my_pairs / k / 1e12,
                       peak=FP64_PEAK / 1e12, unit='TFLOP/s',
                       frac=FLOP_PER_PAIR * my_pairs / k / FP64_PEAK,
-                      traffic=load_traffic('kirchhoff_stream')))
+                      traffic=load_traffic('kirchhoff_stream')
+                      if cfg == 4 and world == 1 else None))
     return res, host
 
 
