@@ -1,0 +1,149 @@
+"""CPU: host-side logic of xrt_amd that needs no GPU — rotation bookkeeping, the
+parameter block of a reflect pass, wave meshes, hull area, Beam container,
+plot descriptors."""
+import os
+
+import numpy as np
+import pytest
+
+import xrt_amd.backends.raycing as raycing
+import xrt_amd.backends.raycing.apertures as ra
+import xrt_amd.backends.raycing.materials as rm
+import xrt_amd.backends.raycing.oes as roe
+import xrt_amd.backends.raycing.screens as rsc
+import xrt_amd.backends.raycing.sources as rs
+import xrt_amd.backends.raycing.waves as rw
+from oracle import reflect_np as rn
+from xrt_amd import _structs, plotter as xrtp
+
+
+def test_rotation_steps_match_oracle_for_all_sequences():
+    rng = np.random.default_rng(0)
+    axis_name = {0: 'x', 1: 'y', 2: 'z'}
+    for seq in ('RzRyRx', 'RxRyRz', 'RyRzRx', '-RzRyRx', '-RxRzRy'):
+        for _ in range(20):
+            ang = rng.normal(0, 0.5, 3) * (rng.random(3) > 0.3)     # some exact zeros
+            mine = raycing.rotation_steps(seq, *ang)
+            ref = rn.rotation_steps(seq, *ang)
+            assert [(axis_name[a], c, s) for a, c, s in mine] == \
+                [(a, float(c), float(s)) for a, c, s in ref]
+
+
+def _apply(rot, v):
+    x, y, z = v
+    for i in range(rot.n):
+        c, s, ax = rot.cosa[i], rot.sina[i], rot.axis[i]
+        if ax == 2:
+            x, y = c*x - s*y, s*x + c*y
+        elif ax == 1:
+            x, z = c*x + s*z, -s*x + c*z
+        else:
+            y, z = c*y - s*z, s*y + c*z
+    return np.array([x, y, z])
+
+
+def test_pass_block_of_a_general_element():
+    bl = raycing.BeamLine(azimuth=0.3)
+    oe = roe.OE(bl, 'm', center=[1, 2, 3], pitch=3e-3, roll=2e-3, yaw=-1e-3,
+                positionRoll=np.pi/2, extraPitch=1e-4, extraYaw=2e-4,
+                limPhysX=[-8, 8], limPhysY=[-200, 150], limOptX=[-5, 5],
+                overEdge='xMin yMax', shape='rect')
+    p = oe._make_pass(oe.pitch, oe.roll + oe.positionRoll, oe.yaw, oe.dx)
+    assert p.to_local.n == 5 and p.to_virgin.n == 5     # 3 main + 2 extra, zero roll skipped
+    v = np.array([0.3, -1.2, 0.7])
+    back = _apply(p.to_virgin, _apply(p.to_local, v))
+    assert np.abs(back - v).max() < 1e-15               # to_virgin undoes to_local
+    assert (p.sin_az, p.cos_az) == (bl.sinAzimuth, bl.cosAzimuth)
+    assert p.over_mask == _structs.OVER_XMIN | _structs.OVER_YMAX
+    assert p.has_opt_x == 1 and p.has_opt_y == 0 and p.lost_num == -1
+    assert list(p.n_const) == [0, 0, 1, 0, 0, 1] and p.asymmetric == 0
+    assert p.invert_normal == 1 and p.good_mode == 0 and p.out_to_global == 1
+    # second crystal of a DCM: roll -pi first, flipped signs, asymmetric normals
+    si = rm.CrystalSi(hkl=(1, 1, 1))
+    dcm = roe.DCM(bl, 'dcm', bragg=0.22, material=si, material2=si,
+                  cryst2perpTransl=10., alpha=0.05)
+    p2 = dcm._make_pass(-dcm.pitch - dcm.bragg, dcm.roll, -dcm.yaw, -dcm.dx,
+                        dcm.cryst2longTransl, -dcm.cryst2perpTransl, is2ndXtal=True,
+                        in_is_global=False, good_mode=1)
+    assert p2.to_local.axis[0] == 1 and p2.to_local.cosa[0] == np.cos(-np.pi)
+    assert p2.shift[2] == -10. and p2.asymmetric == 1 and p2.in_is_global == 0
+    n1, n2 = dcm.local_n1(0., 0.), dcm.local_n2(0., 0.)
+    assert n2[1] == -n1[1] and list(p2.n_const) == [float(t) for t in n2]
+    assert dcm.lostNum == -2
+
+
+def test_toroid_radii_from_coddington_and_reciprocals():
+    bl = raycing.BeamLine()
+    tm = roe.ToroidMirror(bl, 'tm', pitch=4e-3, R=(20000., 10000.), r=(20000., 10000.))
+    assert tm.R == 2*20000.*10000./30000./np.sin(4e-3)
+    assert tm.r == 2*20000.*10000./30000.*np.sin(4e-3)
+    p = tm._make_pass(tm.pitch, 0., 0.)
+    assert p.surf_kind == _structs.SURF_TOROID and p.surf_p[4] == 1.
+    assert p.surf_p[2] == 1.0 / tm.R and p.surf_p[3] == 1.0 / tm.r
+    flat = roe.ToroidMirror(bl, 'flat', R=None, r=None)    # R = r = 1e100: no reciprocals
+    assert flat._make_pass(0., 0., 0.).surf_p[4] == 0.
+
+
+@pytest.mark.parametrize('name', ['g4_slit_2000x32', 'g4_slit_4000x48'])
+def test_screen_prepare_wave_matches_reference(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    bl = raycing.BeamLine()
+    slit = ra.RectangularAperture(bl, 'slit', [float(v) for v in g['slit_center']],
+                                  ('left', 'right', 'bottom', 'top'),
+                                  [-0.1, 0.1, -0.1, 0.1])
+    scr = rsc.Screen(bl, 'scr', [float(v) for v in g['screen_center']])
+    w = scr.prepare_wave(slit, g['xmesh'], g['zmesh'])
+    assert np.array_equal(w.xDiffr, g['px']) and np.array_equal(w.yDiffr, g['py'])
+    assert np.array_equal(w.zDiffr, g['pz']) and w.dS == float(g['w_dS'])
+    assert w.fromOE is slit and w.toOE is scr and not w.EsAcc.any()
+
+
+def test_convex_hull_area_against_scipy():
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(3)
+    for n in (3, 10, 1000):
+        pts = rng.normal(size=(n, 2)) * [2.0, 300.0]
+        assert abs(rw.convex_hull_area(pts[:, 0], pts[:, 1]) -
+                   ConvexHull(pts).volume) <= 1e-10 * ConvexHull(pts).volume
+    with pytest.raises(ValueError):
+        rw.convex_hull_area(np.zeros(5), np.zeros(5))
+
+
+def test_beam_container():
+    b = rs.Beam(nrays=5, withAmplitudes=True)
+    assert len(b) == 5 and b.b.tolist() == [1.] * 5 and b.Jss.sum() == 5
+    assert b.state.dtype == np.int32 and b.Jsp.dtype == np.complex128
+    b.x[:] = np.arange(5.)
+    b.state[:] = [1, 2, 3, -1, 0]
+    c = rs.Beam(copyFrom=b)
+    c.x[0] = 99.
+    assert b.x[0] == 0. and c.x[1] == 1. and hasattr(c, 'Es')
+    c.filter_by_index(c.state > 0)
+    assert len(c) == 3 and c.state.tolist() == [1, 2, 3] and len(c.Es) == 3
+    assert not hasattr(rs.Beam(nrays=2), 'Es')
+    with pytest.raises(AttributeError):
+        rs.Beam(nrays=2).nonexistent
+    assert rs.Beam(nrays=3, forceState=1).state.tolist() == [1, 1, 1]
+
+
+def test_plot_descriptors():
+    p = xrtp.XYCPlot('beam', (1, 3, -1), xrtp.XYCAxis("x'", u'µrad', bins=16),
+                     xrtp.XYCAxis('energy', 'keV'), fluxKind='power')
+    assert p.ray_flag_mask == 1 | 4 | 8 and p.flux_kind_code == 5
+    assert p.xaxis.field() == 'xprime' and p.xaxis.factor == 1e6
+    assert p.yaxis.field() == 'E' and p.yaxis.factor == 1e-3
+    assert p.total2D.shape == (128, 16)
+    with pytest.raises(NotImplementedError):
+        xrtp.XYCPlot('b', fluxKind='EsPCA')
+
+
+def test_out_of_scope_requests_fail_loudly():
+    bl = raycing.BeamLine()
+    with pytest.raises(NotImplementedError):
+        roe.OE(bl, 'g', gratingDensity=['y', 300., 1.])
+    with pytest.raises(NotImplementedError):
+        roe.OE(bl, 'p', isParametric=True)
+    with pytest.raises(NotImplementedError):
+        roe.OE(bl, 'poly', shape=[(0, 0), (1, 0), (0, 1)])
+    with pytest.raises(ValueError):
+        rm.Element('Si', table='Henke')

@@ -63,9 +63,10 @@ class XYCPlot(object):
 
     @property
     def flux_kind_code(self):
-        for k, v in _FLUX.items():
+        # same precedence as raycing.get_output: 'power' before 'p'
+        for k in ('power', 's', 'p', '+/-45', 'left-right', 'total'):
             if self.fluxKind.startswith(k):
-                return v
+                return _FLUX[k]
         return 0
 
     @property
