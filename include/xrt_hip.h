@@ -293,6 +293,50 @@ XRT_HIP_API int xrt_hip_hist2d_f64_dev(
     int bins_x, double x_lo, double x_hi, int bins_y, double y_lo, double y_hi,
     double* hist, double* counters, void* stream);
 
+/* ---- undulator field integral -------------------------
+ * Replaces run_parallel('undulator' | 'undulator_taper' | 'undulator_nf', ...)
+ * as issued by Undulator._build_I_map_CL (sources/synchr.py:2110-2176; kernels
+ * cl/undulator.cl:54-300): per ray, the sum over the quadrature nodes of one
+ * period (far field) or of all `nper` periods (taper / near field). Arithmetic
+ * follows the reference's numpy path Undulator._sp_sum (synchr.py:1930-2038),
+ * including its two quirks (tapered phase uses sintg for the Kx term; the
+ * near-field carrier is sin/cos(R0z) without w/wu) — see DESIGN.md.
+ * Arguments as marshalled at synchr.py:2132-2160:
+ *   scalarArgs  -> alpha_s (= _taperVal / E2WC, mode 1) | r0z (= R0*2pi/L0,
+ *                  mode 2), Kx, Ky, jend, nper (= Np, modes 1 and 2)
+ *   slicedRO    -> gamma, wu, w, ww1, ddphi (theta), ddpsi  [nrays]
+ *   nonSlicedRO -> tg, ag, sintg, costg, sintgph, costgph   [jend]
+ *   slicedRW    -> Is, Ip: complex128 [nrays] (interleaved re,im), overwritten */
+enum { XRT_HIP_UND_FAR = 0, XRT_HIP_UND_TAPER = 1, XRT_HIP_UND_NF = 2 };
+
+typedef struct xrt_hip_undulator {
+  int32_t mode;
+  int32_t nper;
+  double Kx, Ky;
+  double alpha_s;
+  double r0z;
+  int64_t jend;
+  const double *tg, *ag, *sintg, *costg, *sintgph, *costgph;
+} xrt_hip_undulator;
+
+/* bytes of device scratch the _dev entry point needs for `jend` nodes */
+XRT_HIP_API size_t xrt_hip_undulator_workspace_bytes(int64_t jend);
+
+/* all pointers (also those inside `u`) are device pointers; asynchronous on
+ * `stream` unless kernel_ms is given (then it synchronises and returns the
+ * duration of the summation kernel, HIP events on that stream) */
+XRT_HIP_API int xrt_hip_undulator_f64_dev(
+    const xrt_hip_undulator* u, int64_t nrays, const double* gamma, const double* wu,
+    const double* w, const double* ww1, const double* ddphi, const double* ddpsi,
+    double* Is_ri, double* Ip_ri, void* workspace, size_t workspace_bytes, void* stream,
+    float* kernel_ms);
+
+/* host pointers everywhere (what XRT_CL.run_parallel is handed); blocking */
+XRT_HIP_API int xrt_hip_undulator_f64(
+    int device, const xrt_hip_undulator* u, int64_t nrays, const double* gamma,
+    const double* wu, const double* w, const double* ww1, const double* ddphi,
+    const double* ddpsi, double* Is_ri, double* Ip_ri, float* kernel_ms);
+
 /* ---- building-block checks (used by the GPU tests only) ---------------- */
 XRT_HIP_API int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,
                                void* stream);

@@ -1,0 +1,186 @@
+"""TEST INFRASTRUCTURE ONLY (never imported by the product path).
+
+CPU restatement (numpy, fp64) of the reference's undulator field integral — the
+per-ray sum over the quadrature nodes of one undulator period (far field) or of
+all Np periods (tapered / near field):
+
+    Undulator._sp_sum            xrt/backends/raycing/sources/synchr.py:1930-2038
+    Undulator._build_I_map_conv  synchr.py:2050-2108 (pre-factors wu, ww1, ab and
+                                 the Amp2Flux scaling around the sum)
+    Undulator._build_integration_grid  synchr.py:1789-1801 (node tables)
+
+The reference's OpenCL kernels `undulator`, `undulator_taper`, `undulator_nf`
+(cl/undulator.cl:54-300) evaluate the same integrals; they differ from the numpy
+path in three documented places: the far-field kernel divides
+betaP.z by beta.z (relative 2e-8), the near-field kernel uses r.y = -Kx sin/γ
+and sin(w/wu * R0z) where `_sp_sum` has +Kx sin/γ and sin(R0z). This file (and
+the HIP kernel it checks) follows the numpy path `_sp_sum`, operation by
+operation, because that is the path the reference can run here.
+
+Pinned against fixtures made by calling the reference's own `_sp_sum` and
+`_build_I_map_conv` (oracle/gen_fixtures_undulator.py → tests/golden/g9_*.npz).
+"""
+import numpy as np
+
+from .consts import PI, PI2
+
+E2WC = 5067.7309392068091       # synchr.py / sybase.py module constant [1/(eV mm)]
+FINE_STR = 1 / 137.03599976
+SIE0 = 1.602176565e-19
+
+MODE_FAR, MODE_TAPER, MODE_NF = 0, 1, 2
+
+
+def clenshaw_curtis(n):
+    """n-point Clenshaw–Curtis rule on [-1, 1] (the reference's default
+    quadrature, sybase.py:1106-1140 via FFT; here the classical closed form
+    w_k = c_k/N · [1 − Σ_j b_j/(4j²−1) · cos(2jkπ/N)], N = n−1), equal to the
+    reference's weights to rounding."""
+    N = n - 1
+    k = np.arange(n)
+    x = -np.cos(np.pi * k / N)
+    j = np.arange(1, N // 2 + 1)
+    b = np.where(2 * j == N, 1., 2.)
+    c = np.where((k == 0) | (k == N), 1., 2.)
+    s = (b / (4. * j * j - 1.) *
+         np.cos(2. * np.pi * np.outer(k, j) / N)).sum(axis=1)
+    return x, c / N * (1. - s)
+
+
+def node_tables(quadm, g_intervals, phase, use_gauleg=False):
+    """Node/weight tables of synchr.py:1789-1801: `g_intervals` equal panels of
+    one undulator period [-π, π], `quadm` nodes in each."""
+    if use_gauleg:
+        tg_n, ag_n = np.polynomial.legendre.leggauss(quadm)
+    else:
+        tg_n, ag_n = clenshaw_curtis(quadm)
+    dstep = 2 * PI / float(g_intervals)
+    dI = np.arange(-PI + 0.5 * dstep, PI, dstep)
+    tg = (dI[:, None] + 0.5 * dstep * tg_n).ravel()
+    ag = (dI[:, None] * 0 + ag_n).ravel()
+    return dict(tg=tg, ag=ag, sintg=np.sin(tg), costg=np.cos(tg),
+                sintgph=np.sin(tg + phase), costgph=np.cos(tg + phase),
+                dstep=dstep)
+
+
+def sp_sum(mode, Kx, Ky, Np, tab, ww1, w, wu, gamma, ddphi, ddpsi,
+           taper_val=None, r0z=None):
+    """Is, Ip = wu/γ · Σ_nodes ag · e^{iφ} · [n × ((n−β) × β')]_{x,y} / (1−n·β)²
+
+    synchr.py:1930-2038. `tab` = node_tables(); per-ray arrays ww1, w, wu,
+    gamma, ddphi, ddpsi. mode TAPER needs taper_val (= Undulator._taperVal),
+    mode NF needs r0z (= R0·2π/L0, synchr.py:2077)."""
+    tg, ag = tab['tg'], tab['ag']
+    sintg, costg = tab['sintg'], tab['costg']
+    sintgph, costgph = tab['sintgph'], tab['costgph']
+    taperC = 1
+    alphaS = 0
+    sin2x = 2. * sintg * costg
+    sin2xph = 2. * sintgph * costgph
+    revg = 1. / gamma
+    revg2 = revg**2
+    betam = 1. - (1. + 0.5 * Kx**2 + 0.5 * Ky**2) * 0.5 * revg2
+    wwu = w / wu
+    Bs = np.zeros(len(w), dtype=np.complex128)
+    Bp = np.zeros(len(w), dtype=np.complex128)
+    dirx = ddphi
+    diry = ddpsi
+    dirz = 1. - 0.5 * (ddphi**2 + ddpsi**2)
+    nper = Np if mode != MODE_FAR else 1
+    if mode == MODE_NF:
+        R0 = np.array((np.tan(ddphi), np.tan(ddpsi), np.ones_like(ddpsi)))
+        R0 *= r0z
+        sinr0z = np.sin(R0[-1])     # sic: no w/wu here (synchr.py:1950)
+        cosr0z = np.cos(R0[-1])
+    for ip in range(nper):
+        for i in range(len(tg)):
+            if mode == MODE_TAPER:
+                zloc = -(nper - 1) * np.pi + ip * PI2 + tg[i]
+                alphaS = taper_val / E2WC
+                taperC = 1. - alphaS * zloc / wu
+                ucos = ww1 * zloc + wwu * revg * (
+                    -Ky * dirx * (sintg[i] + alphaS / wu *
+                                  (1 - costg[i] - zloc * sintg[i])) +
+                    Kx * diry * sintg[i] + 0.125 * revg *
+                    (Kx**2 * sin2xph[i] + Ky**2 * (
+                        sin2x[i] - 2 * alphaS / wu *
+                        (zloc**2 + costg[i]**2 + zloc * sin2x[i]))))
+                eucos = np.cos(ucos) + 1j * np.sin(ucos)
+            elif mode == MODE_NF:
+                zterm = 0.5 * (Ky**2 * sin2x[i] + Kx**2 * sin2xph[i]) * revg
+                zloc = -(nper - 1) * np.pi + ip * PI2 + tg[i]
+                rx = Ky * sintg[i] * revg
+                ry = Kx * sintgph[i] * revg
+                rz = betam * zloc - 0.25 * zterm * revg
+                drx, dry, drz = R0[0] - rx, R0[1] - ry, R0[2] - rz
+                dist = np.sqrt(drx * drx + dry * dry + drz * drz)
+                drs = 0.5 * (drx**2 + dry**2) / drz
+                a1 = wwu * zloc * (1. - betam)
+                a2 = wwu * (drs + 0.25 * zterm * revg)
+                sinzloc, coszloc = np.sin(a1), np.cos(a1)
+                sindrs, cosdrs = np.sin(a2), np.cos(a2)
+                ex = (-sinr0z * sinzloc * cosdrs - sinr0z * coszloc * sindrs -
+                      cosr0z * sinzloc * sindrs + cosr0z * coszloc * cosdrs)
+                ey = (-sinr0z * sinzloc * sindrs + sinr0z * coszloc * cosdrs +
+                      cosr0z * sinzloc * cosdrs + cosr0z * coszloc * sindrs)
+                eucos = ex + 1j * ey
+                dirx, diry, dirz = drx / dist, dry / dist, drz / dist
+            else:
+                ucos = ww1 * tg[i] + wwu * revg * (
+                    -Ky * ddphi * sintg[i] + Kx * ddpsi * sintgph[i] +
+                    0.125 * revg * (Ky**2 * sin2x[i] + Kx**2 * sin2xph[i]))
+                eucos = np.cos(ucos) + 1j * np.sin(ucos)
+            betax = taperC * Ky * revg * costg[i]
+            betay = -Kx * revg * costgph[i]
+            betaz = 1. - 0.5 * (revg2 + betax * betax + betay * betay)
+            betaPx = -Ky * (alphaS * costg[i] + taperC * sintg[i])
+            betaPy = Kx * sintgph[i]
+            betaPz = 0.5 * revg * (
+                Ky**2 * taperC * (alphaS * costg[i]**2 + taperC * sin2x[i]) +
+                Kx**2 * sin2xph[i])
+            rkrel = 1. / (1. - dirx * betax - diry * betay - dirz * betaz)
+            eucos = eucos * (ag[i] * rkrel**2)
+            bnx, bny, bnz = dirx - betax, diry - betay, dirz - betaz
+            nbp = dirx * betaPx + diry * betaPy + dirz * betaPz
+            nbn = dirx * bnx + diry * bny + dirz * bnz
+            Bs += eucos * (bnx * nbp - betaPx * nbn)
+            Bp += eucos * (bny * nbp - betaPy * nbn)
+    return wu * revg * Bs, wu * revg * Bp
+
+
+def prefactors(Kx, Ky, Np, L0, gamma, w, ddtheta, ddpsi, single_period):
+    """wu, ww1, ab of synchr.py:2060-2068. `single_period` = far-field case
+    (the Np periods enter through the analytic sin(πNp·ww1)/sin(π·ww1))."""
+    gamma = gamma * np.ones(len(w))
+    gamma2 = gamma**2
+    wu = PI / L0 / gamma2 * np.ones_like(w) * \
+        (2 * gamma2 - 1 - 0.5 * Kx**2 - 0.5 * Ky**2) / E2WC
+    ww1 = w * ((1. + 0.5 * Kx**2 + 0.5 * Ky**2) +
+               gamma2 * (ddtheta**2 + ddpsi**2)) / (2. * gamma2 * wu)
+    if single_period:
+        ab = 1. / PI2 / wu * np.sin(PI * Np * ww1) / np.sin(PI * ww1)
+    else:
+        ab = 1. / PI2 / wu
+    return gamma, wu, ww1, ab
+
+
+def intensity_map(mode, Kx, Ky, Np, L0, gamma0, eI, dist_e_bw, tab, w, ddtheta,
+                  ddpsi, taper_val=None, R0=None, harmonic=None):
+    """(I, Es, Ep) of Undulator._build_I_map_conv (synchr.py:2050-2108) for
+    eEspread = 0."""
+    gamma, wu, ww1, ab = prefactors(Kx, Ky, Np, L0, gamma0, w, ddtheta, ddpsi,
+                                    mode == MODE_FAR)
+    r0z = None if R0 is None else R0 * np.pi * 2 / L0
+    Is, Ip = sp_sum(mode, Kx, Ky, Np, tab, ww1, w, wu, gamma, ddtheta, ddpsi,
+                    taper_val, r0z)
+    bw = 0.001 if dist_e_bw else 1. / w
+    amp2flux = FINE_STR * bw * eI / SIE0
+    if harmonic is not None:
+        for a in (Is, Ip):
+            a[ww1 > harmonic + 0.5] = 0
+            a[ww1 < harmonic - 0.5] = 0
+    dstep = tab['dstep']
+    field = np.abs(Is)**2 + np.abs(Ip)**2
+    return (amp2flux * ab**2 * 0.25 * dstep**2 * field,
+            np.sqrt(amp2flux) * ab * Is * 0.5 * dstep,
+            np.sqrt(amp2flux) * ab * Ip * 0.5 * dstep)

@@ -92,3 +92,67 @@ def test_reference_diffract_runs_through_the_dropin(convention):
             assert np.abs(getattr(wscr, f) - sign * r).max() <= 1e-10 * np.abs(r).max(), f
     finally:
         rw.waveCL = saved
+
+
+def _make_fake_undulator_backend():
+    from xrt_amd.backends.raycing.myhip import XRT_HIP
+    from oracle import undulator_np as un
+
+    class OracleBackedHIP(XRT_HIP):
+        calls = 0
+
+        def set_cl(self, targetOpenCL='auto', precisionOpenCL='float64'):
+            self.device_ids = [0]
+            self.lastTargetOpenCL = targetOpenCL
+            self.lastPrecisionOpenCL = precisionOpenCL
+
+        def _call_lib_undulator(self, u, n, rays, outs):
+            import ctypes
+            type(self).calls += 1
+
+            def tab(p):
+                return np.ctypeslib.as_array(
+                    ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), (u.jend,))
+            t = dict(tg=tab(u.tg), ag=tab(u.ag), sintg=tab(u.sintg), costg=tab(u.costg),
+                     sintgph=tab(u.sintgph), costgph=tab(u.costgph))
+            gamma, wu, w, ww1, th, ps = rays
+            taper = u.alpha_s * un.E2WC if u.mode == 1 else None
+            Is, Ip = un.sp_sum(u.mode, u.Kx, u.Ky, u.nper, t, ww1, w, wu, gamma, th, ps,
+                               taper, u.r0z)
+            outs[0][:] = Is
+            outs[1][:] = Ip
+    return OracleBackedHIP()
+
+
+@pytest.mark.parametrize('kw', [
+    dict(n=30, K=0.9),
+    dict(n=12, K=1.1, taper=(0.4, 10.)),
+    dict(n=12, K=1.1, R0=25000.),
+], ids=['far', 'taper', 'nf'])
+def test_reference_undulator_runs_through_the_dropin(kw):
+    """The reference's Undulator.build_I_map takes its OpenCL branch
+    (_build_I_map_CL, synchr.py:2110-2176) with XRT_HIP attached, and the result
+    equals its numpy branch: pins the run_parallel marshalling of the three
+    undulator kernels (scalar order, alphaS = taper/E2WC, nper)."""
+    _refenv.activate()
+    import xrt.backends.raycing as raycing
+    import xrt.backends.raycing.sources as rs
+    raycing._VERBOSITY_ = 0
+    bl = raycing.BeamLine()
+    u = rs.Undulator(bl, 'u', nrays=500, eE=3.0, eI=0.5, eEspread=0, eEpsilonX=0.263,
+                     eEpsilonZ=0.008, betaX=9., betaZ=2., period=18.5, eMin=2500,
+                     eMax=3200, xPrimeMax=0.03, zPrimeMax=0.03, targetOpenCL=None,
+                     distE='BW', gNodes=12, gIntervals=2, **kw)
+    if u.needReset:
+        u.reset()
+    rng = np.random.RandomState(5)
+    w = rng.uniform(2500, 3200, 64)
+    th = rng.uniform(-3e-5, 3e-5, 64)
+    ps = rng.uniform(-3e-5, 3e-5, 64)
+    ref = u.build_I_map(w, th, ps)                    # numpy branch (cl_ctx is None)
+    fake = _make_fake_undulator_backend()
+    fake.attach_to_source(u)
+    got = u.build_I_map(w, th, ps)                    # OpenCL branch -> XRT_HIP
+    assert type(fake).calls == 1
+    for a, b in zip(got, ref):
+        assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(b)

@@ -115,4 +115,20 @@ class Aperture(ctypes.Structure):
                 ('lost_num', ctypes.c_int32)]
 
 
-STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture)
+class Undulator(ctypes.Structure):
+    _fields_ = [('mode', ctypes.c_int32),
+                ('nper', ctypes.c_int32),
+                ('Kx', ctypes.c_double),
+                ('Ky', ctypes.c_double),
+                ('alpha_s', ctypes.c_double),
+                ('r0z', ctypes.c_double),
+                ('jend', ctypes.c_int64),
+                ('tg', ctypes.c_void_p),
+                ('ag', ctypes.c_void_p),
+                ('sintg', ctypes.c_void_p),
+                ('costg', ctypes.c_void_p),
+                ('sintgph', ctypes.c_void_p),
+                ('costgph', ctypes.c_void_p)]
+
+
+STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator)

@@ -24,7 +24,8 @@ from ... import _lib
 
 
 class XRT_HIP(object):
-    kernels = ('integrate_kirchhoff',)
+    kernels = ('integrate_kirchhoff', 'undulator', 'undulator_taper',
+               'undulator_nf')
 
     def __init__(self, filename=None, targetOpenCL='auto',
                  precisionOpenCL='float64', convention='opencl', devices=None):
@@ -69,10 +70,13 @@ class XRT_HIP(object):
                      nonSlicedROArgs=None, slicedRWArgs=None,
                      nonSlicedRWArgs=None, dimension=0, complexity=0,
                      signal=None):
+        if kernelName in ('undulator', 'undulator_taper', 'undulator_nf'):
+            return self._undulator(kernelName, scalarArgs, slicedROArgs,
+                                   nonSlicedROArgs, slicedRWArgs,
+                                   int(dimension))
         if kernelName != 'integrate_kirchhoff':
             raise NotImplementedError(
-                "XRT_HIP implements 'integrate_kirchhoff' only, not %r"
-                % (kernelName,))
+                "XRT_HIP implements %s, not %r" % (self.kernels, kernelName))
         return self._integrate_kirchhoff(scalarArgs, slicedROArgs,
                                          nonSlicedROArgs, slicedRWArgs,
                                          int(dimension))
@@ -107,6 +111,68 @@ class XRT_HIP(object):
         self._call_lib(dimension, px, py, pz, ns, nl, Es, Ep, k, pos, nrm,
                        0 if self.convention == 'numpy' else 1, outs)
         return tuple(outs)
+
+    # E2WC of sources/synchr.py (module constant): _taperVal / E2WC = alphaS
+    E2WC = 5067.7309392068091
+
+    def attach_to_source(self, source):
+        """Makes a reference ``Undulator`` built with ``targetOpenCL=None`` use
+        this object for its field sums: sets what ``IntegratedSource._set_cl``
+        (sources/sybase.py:1087-1104) would have set for an XRT_CL."""
+        source.ucl = self
+        source.cl_precisionF = self.cl_precisionF
+        source.cl_precisionC = self.cl_precisionC
+        source.cl_ctx = self            # only tested against None
+        source.cl_is_blocking = True
+        return source
+
+    def _undulator(self, kernelName, scalarArgs, slicedRO, nonSlicedRO, slicedRW,
+                   dimension):
+        """Argument order of Undulator._build_I_map_CL (synchr.py:2132-2160)."""
+        from ..._structs import Undulator
+        mode = {'undulator': 0, 'undulator_taper': 1, 'undulator_nf': 2}[kernelName]
+        if len(scalarArgs) != (4 if mode == 0 else 5):
+            raise ValueError('%s takes %d scalar arguments'
+                             % (kernelName, 4 if mode == 0 else 5))
+        if len(slicedRO) != 6 or len(nonSlicedRO) != 6 or len(slicedRW) != 2:
+            raise ValueError('%s: 6 sliced RO, 6 non-sliced RO and 2 RW arrays '
+                             'expected' % kernelName)
+        jend = int(scalarArgs[3])
+        rays = [np.ascontiguousarray(a, dtype=np.float64) for a in slicedRO]
+        tabs = [np.ascontiguousarray(a, dtype=np.float64) for a in nonSlicedRO]
+        for a in rays:
+            if a.size != dimension:
+                raise ValueError('ray arrays must have %d elements' % dimension)
+        for a in tabs:
+            if a.size != jend:
+                raise ValueError('node tables must have jend=%d elements' % jend)
+        for a in slicedRW:
+            if not (isinstance(a, np.ndarray) and a.dtype == np.complex128 and
+                    a.flags.c_contiguous and a.size == dimension):
+                raise ValueError('RW arrays must be contiguous complex128[%d]'
+                                 % dimension)
+        u = Undulator()
+        u.mode = mode
+        u.nper = int(scalarArgs[4]) if mode else 1
+        u.Kx, u.Ky = float(scalarArgs[1]), float(scalarArgs[2])
+        u.alpha_s = float(scalarArgs[0]) / self.E2WC if mode == 1 else 0.
+        u.r0z = float(scalarArgs[0]) if mode == 2 else 0.
+        u.jend = jend
+        for name, t in zip(('tg', 'ag', 'sintg', 'costg', 'sintgph', 'costgph'),
+                           tabs):
+            setattr(u, name, t.ctypes.data)
+        self._call_lib_undulator(u, dimension, rays, slicedRW)
+        return tuple(slicedRW)
+
+    def _call_lib_undulator(self, u, n, rays, outs):
+        lib = _lib.load()
+        ms = ctypes.c_float(0.)
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+        rc = lib.xrt_hip_undulator_f64(
+            self.device_ids[0], ctypes.byref(u), n, *[ptr(a) for a in rays],
+            ptr(outs[0]), ptr(outs[1]), ctypes.byref(ms))
+        _lib.check(rc, 'xrt_hip_undulator_f64')
+        self.lastKernelMs = ms.value
 
     def _call_lib(self, npix, px, py, pz, ns, nl, Es, Ep, k, pos, nrm, convention,
                   outs):

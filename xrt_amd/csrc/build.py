@@ -11,8 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libxrt_hip.so')
-SOURCES = ['kirchhoff.hip', 'reflect.hip', 'screen.hip', 'hist.hip', 'capi.hip']
-HEADERS = ['fp64_math.h', 'kirchhoff.h', 'reflect.h', 'screen.h', 'hist.h',
+SOURCES = ['kirchhoff.hip', 'reflect.hip', 'screen.hip', 'hist.hip', 'undulator.hip',
+           'capi.hip']
+HEADERS = ['fp64_math.h', 'kirchhoff.h', 'reflect.h', 'screen.h', 'hist.h', 'undulator.h',
            os.path.join('..', '..', 'include', 'xrt_hip.h')]
 # -ffp-contract=off: fused multiply-add only where the source says fma();
 # the reference (numpy) never fuses and ray states / the Kirchhoff phase

@@ -10,6 +10,7 @@
 #include "reflect.h"
 #include "screen.h"
 #include "hist.h"
+#include "undulator.h"
 
 namespace {
 
@@ -242,6 +243,7 @@ int xrt_hip_sizeof(int which) {
     case 3: return (int)sizeof(xrt_hip_material);
     case 4: return (int)sizeof(xrt_hip_screen);
     case 5: return (int)sizeof(xrt_hip_aperture);
+    case 6: return (int)sizeof(xrt_hip_undulator);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -422,6 +424,113 @@ int xrt_hip_hist2d_f64_dev(const xrt_hip_beam* beam, const double* x, const doub
                              source_weight, bins_x, x_lo, x_hi, bins_y, y_lo, y_hi, hist,
                              counters, reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
+}
+
+static int check_undulator(const xrt_hip_undulator* u, int64_t nrays) {
+  if (!u) return fail(XRT_HIP_ERR_ARG, "NULL undulator description");
+  if (u->mode < XRT_HIP_UND_FAR || u->mode > XRT_HIP_UND_NF)
+    return fail(XRT_HIP_ERR_ARG, "unknown undulator mode %d", u->mode);
+  if (u->jend < 0 || nrays < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (u->mode != XRT_HIP_UND_FAR && u->nper < 1)
+    return fail(XRT_HIP_ERR_ARG, "nper must be >= 1 for the taper / near-field sums");
+  if (u->jend > 0 && (!u->tg || !u->ag || !u->sintg || !u->costg || !u->sintgph || !u->costgph))
+    return fail(XRT_HIP_ERR_ARG, "NULL node table");
+  return XRT_HIP_OK;
+}
+
+size_t xrt_hip_undulator_workspace_bytes(int64_t jend) {
+  return (size_t)(jend < 1 ? 1 : jend) * xrt::UND_NODE_DOUBLES * sizeof(double);
+}
+
+int xrt_hip_undulator_f64_dev(const xrt_hip_undulator* u, int64_t nrays, const double* gamma,
+                              const double* wu, const double* w, const double* ww1,
+                              const double* ddphi, const double* ddpsi, double* Is_ri,
+                              double* Ip_ri, void* workspace, size_t workspace_bytes,
+                              void* stream, float* kernel_ms) {
+  int rc;
+  if ((rc = check_undulator(u, nrays))) return rc;
+  if (nrays > 0 && (!gamma || !wu || !w || !ww1 || !ddphi || !ddpsi || !Is_ri || !Ip_ri))
+    return fail(XRT_HIP_ERR_ARG, "NULL ray array");
+  if (!workspace || workspace_bytes < xrt_hip_undulator_workspace_bytes(u->jend))
+    return fail(XRT_HIP_ERR_ARG, "workspace too small: %zu < %zu", workspace_bytes,
+                xrt_hip_undulator_workspace_bytes(u->jend));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  HIP_TRY(xrt::undulator_pack_launch(*u, workspace, st));
+  if (!kernel_ms) {
+    HIP_TRY(xrt::undulator_sum_launch(*u, nrays, gamma, wu, w, ww1, ddphi, ddpsi, Is_ri, Ip_ri,
+                                      workspace, st));
+    return XRT_HIP_OK;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipError_t e = hipEventRecord(e0, st);
+  if (e == hipSuccess)
+    e = xrt::undulator_sum_launch(*u, nrays, gamma, wu, w, ww1, ddphi, ddpsi, Is_ri, Ip_ri,
+                                  workspace, st);
+  if (e == hipSuccess) e = hipEventRecord(e1, st);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  if (e == hipSuccess) e = hipEventElapsedTime(kernel_ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HIP_TRY(e);
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_undulator_f64(int device, const xrt_hip_undulator* u, int64_t nrays,
+                          const double* gamma, const double* wu, const double* w,
+                          const double* ww1, const double* ddphi, const double* ddpsi,
+                          double* Is_ri, double* Ip_ri, float* kernel_ms) {
+  int rc;
+  if ((rc = check_undulator(u, nrays))) return rc;
+  if (nrays == 0) return XRT_HIP_OK;
+  if (!gamma || !wu || !w || !ww1 || !ddphi || !ddpsi || !Is_ri || !Ip_ri)
+    return fail(XRT_HIP_ERR_ARG, "NULL ray array");
+  int prev = 0;
+  HIP_TRY(hipGetDevice(&prev));
+  HIP_TRY(hipSetDevice(device));
+  int result = XRT_HIP_OK;
+  {
+    const size_t rb = (size_t)nrays * sizeof(double), nb = (size_t)u->jend * sizeof(double);
+    DevBuf ray[6], tab[6], out[2], ws;
+    const double* hray[6] = {gamma, wu, w, ww1, ddphi, ddpsi};
+    const double* htab[6] = {u->tg, u->ag, u->sintg, u->costg, u->sintgph, u->costgph};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) {
+      e = ray[i].alloc(rb);
+      if (e == hipSuccess) e = hipMemcpy(ray[i].p, hray[i], rb, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = tab[i].alloc(nb);
+      if (e == hipSuccess && nb) e = hipMemcpy(tab[i].p, htab[i], nb, hipMemcpyHostToDevice);
+    }
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = out[i].alloc(2 * rb);
+    const size_t wb = xrt_hip_undulator_workspace_bytes(u->jend);
+    if (e == hipSuccess) e = ws.alloc(wb);
+    if (e != hipSuccess) {
+      result = fail(XRT_HIP_ERR_HIP, "undulator staging failed: %s", hipGetErrorString(e));
+    } else {
+      xrt_hip_undulator d = *u;
+      d.tg = tab[0].as<double>();
+      d.ag = tab[1].as<double>();
+      d.sintg = tab[2].as<double>();
+      d.costg = tab[3].as<double>();
+      d.sintgph = tab[4].as<double>();
+      d.costgph = tab[5].as<double>();
+      float ms = 0.f;
+      result = xrt_hip_undulator_f64_dev(
+          &d, nrays, ray[0].as<double>(), ray[1].as<double>(), ray[2].as<double>(),
+          ray[3].as<double>(), ray[4].as<double>(), ray[5].as<double>(), out[0].as<double>(),
+          out[1].as<double>(), ws.p, wb, nullptr, &ms);
+      if (kernel_ms) *kernel_ms = ms;
+      if (result == XRT_HIP_OK) {
+        e = hipMemcpy(Is_ri, out[0].p, 2 * rb, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(Ip_ri, out[1].p, 2 * rb, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+          result = fail(XRT_HIP_ERR_HIP, "undulator copy-back failed: %s", hipGetErrorString(e));
+      }
+    }
+  }
+  (void)hipSetDevice(prev);
+  return result;
 }
 
 int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,

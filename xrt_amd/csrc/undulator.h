@@ -1,0 +1,14 @@
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/xrt_hip.h"
+namespace xrt {
+using UndulatorArgs = xrt_hip_undulator;
+enum { UND_FAR = XRT_HIP_UND_FAR, UND_TAPER = XRT_HIP_UND_TAPER, UND_NF = XRT_HIP_UND_NF };
+constexpr int UND_NODE_DOUBLES = 16;
+// workspace: jend * UND_NODE_DOUBLES doubles (packed node records)
+hipError_t undulator_pack_launch(const UndulatorArgs& a, void* workspace, hipStream_t st);
+hipError_t undulator_sum_launch(const UndulatorArgs& a, int64_t n, const double* gamma,
+                                const double* wu, const double* w, const double* ww1,
+                                const double* ddphi, const double* ddpsi, double* Is_ri,
+                                double* Ip_ri, const void* workspace, hipStream_t st);
+}

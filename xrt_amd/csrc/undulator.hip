@@ -1,0 +1,220 @@
+// Undulator field integral for gfx950.
+//
+// What the reference computes (xrt/backends/raycing/sources/synchr.py:1930-2038,
+// Undulator._sp_sum; OpenCL twins cl/undulator.cl:54-300): for every ray
+// (photon energy w, observation angles ddphi/ddpsi, electron gamma) the sum over
+// the quadrature nodes of one undulator period (far field) or over all Np
+// periods (tapered gap / near field) of
+//     ag · e^{iφ} · [ n × ((n − β) × β') ]_{x,y} / (1 − n·β)²
+// One ray per lane; the node tables are the same for all rays, so a small pack
+// kernel turns them into 16-double records that the main loop reads through
+// the scalar unit (wave-uniform address → s_load), leaving the vector ALU the
+// fp64 arithmetic only. The arithmetic follows the numpy path operation by
+// operation (this library is built with -ffp-contract=off), because
+// krel = 1 − n·β cancels eight digits and every rounding upstream of it shows.
+#include "undulator.h"
+
+#include "fp64_math.h"
+
+namespace xrt {
+
+namespace {
+
+constexpr double PI_ = 3.1415926535897932384626433832795;
+constexpr double PI2_ = 6.283185307179586476925286766559;
+
+// record layout (doubles)
+enum { N_TG, N_AG, N_S, N_C, N_SPH, N_CPH, N_S2X, N_S2XPH, N_SUM2, N_BPX, N_BPY, N_C2,
+       N_KX2S2XPH, N_PAD0, N_PAD1, N_PAD2, N_REC };
+static_assert(N_REC == UND_NODE_DOUBLES, "node record size");
+
+__global__ void und_pack(UndulatorArgs a, double* __restrict__ rec) {
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= a.jend) return;
+  double s = a.sintg[j], c = a.costg[j], sp = a.sintgph[j], cp = a.costgph[j];
+  double kx2 = a.Kx * a.Kx, ky2 = a.Ky * a.Ky;
+  double s2x = (2. * s) * c;
+  double s2xph = (2. * sp) * cp;
+  double* r = rec + j * N_REC;
+  r[N_TG] = a.tg[j];
+  r[N_AG] = a.ag[j];
+  r[N_S] = s;
+  r[N_C] = c;
+  r[N_SPH] = sp;
+  r[N_CPH] = cp;
+  r[N_S2X] = s2x;
+  r[N_S2XPH] = s2xph;
+  r[N_SUM2] = ky2 * s2x + kx2 * s2xph;   // Ky²·sin2x + Kx²·sin2xph (synchr.py:2003, :2017)
+  r[N_BPX] = (-a.Ky) * s;                 // betaPx for taperC = 1, alphaS = 0
+  r[N_BPY] = a.Kx * sp;
+  r[N_C2] = c * c;
+  r[N_KX2S2XPH] = kx2 * s2xph;
+  r[N_PAD0] = r[N_PAD1] = r[N_PAD2] = 0.;
+}
+
+// a / b, correctly rounded, for a divisor whose correctly rounded reciprocal y
+// is already known (same construction as reflect.hip's div_const)
+__device__ __forceinline__ double div_known(double a, double b, double y) {
+  double q = a * y;
+  double r = fma_(-q, b, a);
+  return fma_(r, y, q);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
+        const double* __restrict__ gamma, const double* __restrict__ wu_,
+        const double* __restrict__ w_, const double* __restrict__ ww1_,
+        const double* __restrict__ ddphi, const double* __restrict__ ddpsi,
+        double2* __restrict__ Is, double2* __restrict__ Ip) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double Kx = a.Kx, Ky = a.Ky;
+  const double kx2 = Kx * Kx, ky2 = Ky * Ky;
+  const double g = gamma[i], wu = wu_[i], w = w_[i], ww1 = ww1_[i];
+  const double phi = ddphi[i], psi = ddpsi[i];
+  const double revg = 1. / g;
+  const double revg2 = revg * revg;
+  const double wwu = w / wu;
+  const double wwug = wwu * revg;
+  const double e8 = 0.125 * revg;
+  const double h2 = 0.5 * revg;
+  const double kyg = Ky * revg;
+  const double nkxg = (-Kx) * revg;
+  double dirx = phi, diry = psi;
+  double dirz = 1. - 0.5 * (phi * phi + psi * psi);
+  const double nky_dx = (-Ky) * dirx;
+  const double kx_dy = Kx * diry;
+
+  // mode-specific per-ray constants
+  double aw = 0., aw2 = 0., rwu = 0.;            // taper
+  double betam = 0., omb = 0., r0x = 0., r0y = 0., r0zv = 0., sr0 = 0., cr0 = 0.;
+  if (MODE == UND_TAPER) {
+    rwu = 1. / wu;
+    aw = a.alpha_s / wu;
+    aw2 = (2 * a.alpha_s) / wu;
+  }
+  if (MODE == UND_NF) {
+    betam = 1. - (((1. + 0.5 * kx2) + 0.5 * ky2) * 0.5) * revg2;
+    omb = 1. - betam;
+    r0x = tan(phi) * a.r0z;
+    r0y = tan(psi) * a.r0z;
+    r0zv = a.r0z;
+    sincos_phase(r0zv, sr0, cr0);   // sic: no w/wu factor (synchr.py:1950-1951)
+  }
+
+  double bsr = 0., bsi = 0., bpr = 0., bpi = 0.;
+  const int nper = (MODE == UND_FAR) ? 1 : a.nper;
+  for (int ip = 0; ip < nper; ++ip) {
+    const double z0 = (double)(-(nper - 1)) * PI_ + (double)ip * PI2_;
+    const double* __restrict__ r = rec;
+    for (int64_t j = 0; j < a.jend; ++j, r += N_REC) {
+      const double tg = r[N_TG], ag = r[N_AG], s = r[N_S], c = r[N_C];
+      const double sp = r[N_SPH], cp = r[N_CPH];
+      double er, ei, betax, bPx, bPz;
+      const double bPy = r[N_BPY];
+      if (MODE == UND_FAR) {
+        double A = (nky_dx * s + kx_dy * sp) + e8 * r[N_SUM2];
+        double ucos = ww1 * tg + wwug * A;
+        sincos_phase(ucos, ei, er);
+        betax = kyg * c;
+        bPx = r[N_BPX];
+        bPz = h2 * r[N_SUM2];
+      } else if (MODE == UND_TAPER) {
+        const double zloc = z0 + tg;
+        const double s2x = r[N_S2X];
+        double taperC = 1. - div_known(a.alpha_s * zloc, wu, rwu);
+        double u1 = (1 - c) - zloc * s;                       // wave-uniform
+        double u2 = (zloc * zloc + r[N_C2]) + zloc * s2x;     // wave-uniform
+        double T1 = nky_dx * (s + aw * u1);
+        double T2 = kx_dy * s;                                // sic: sintg, not sintgph
+        double T3 = e8 * (r[N_KX2S2XPH] + ky2 * (s2x - aw2 * u2));
+        double ucos = ww1 * zloc + wwug * ((T1 + T2) + T3);
+        sincos_phase(ucos, ei, er);
+        betax = ((taperC * Ky) * revg) * c;
+        bPx = (-Ky) * (a.alpha_s * c + taperC * s);
+        bPz = h2 * ((ky2 * taperC) * (a.alpha_s * r[N_C2] + taperC * s2x) + r[N_KX2S2XPH]);
+      } else {
+        const double zloc = z0 + tg;
+        double zterm = (0.5 * r[N_SUM2]) * revg;
+        double q4 = (0.25 * zterm) * revg;
+        double rx = (Ky * s) * revg;
+        double ry = (Kx * sp) * revg;
+        double rz = betam * zloc - q4;
+        double drx = r0x - rx, dry = r0y - ry, drz = r0zv - rz;
+        double dxy = drx * drx + dry * dry;
+        double dist = __builtin_sqrt(dxy + drz * drz);
+        double drs = (0.5 * dxy) / drz;
+        double sz, cz, sd, cd;
+        sincos_phase((wwu * zloc) * omb, sz, cz);
+        sincos_phase(wwu * (drs + q4), sd, cd);
+        er = ((((-sr0) * sz) * cd - (sr0 * cz) * sd) - (cr0 * sz) * sd) + (cr0 * cz) * cd;
+        ei = ((((-sr0) * sz) * sd + (sr0 * cz) * cd) + (cr0 * sz) * cd) + (cr0 * cz) * sd;
+        dirx = drx / dist;
+        diry = dry / dist;
+        dirz = drz / dist;
+        betax = kyg * c;
+        bPx = r[N_BPX];
+        bPz = h2 * r[N_SUM2];
+      }
+      const double betay = nkxg * cp;
+      const double betaz = 1. - 0.5 * ((revg2 + betax * betax) + betay * betay);
+      const double krel = ((1. - dirx * betax) - diry * betay) - dirz * betaz;
+      const double rkrel = 1. / krel;
+      const double fac = ag * (rkrel * rkrel);
+      er = er * fac;
+      ei = ei * fac;
+      const double bnx = dirx - betax, bny = diry - betay, bnz = dirz - betaz;
+      const double nbp = (dirx * bPx + diry * bPy) + dirz * bPz;
+      const double nbn = (dirx * bnx + diry * bny) + dirz * bnz;
+      const double ts = bnx * nbp - bPx * nbn;
+      const double tp = bny * nbp - bPy * nbn;
+      bsr += er * ts;
+      bsi += ei * ts;
+      bpr += er * tp;
+      bpi += ei * tp;
+    }
+  }
+  const double f = wu * revg;
+  Is[i] = make_double2(f * bsr, f * bsi);
+  Ip[i] = make_double2(f * bpr, f * bpi);
+}
+
+}  // namespace
+
+hipError_t undulator_pack_launch(const UndulatorArgs& a, void* workspace, hipStream_t st) {
+  if (a.jend <= 0) return hipSuccess;
+  int pb = (int)((a.jend + 127) / 128);
+  hipLaunchKernelGGL(und_pack, dim3(pb), dim3(128), 0, st, a, reinterpret_cast<double*>(workspace));
+  return hipGetLastError();
+}
+
+hipError_t undulator_sum_launch(const UndulatorArgs& a, int64_t n, const double* gamma,
+                                const double* wu, const double* w, const double* ww1,
+                                const double* ddphi, const double* ddpsi, double* Is_ri,
+                                double* Ip_ri, const void* workspace, hipStream_t st) {
+  const double* rec = reinterpret_cast<const double*>(workspace);
+  if (n <= 0) return hipSuccess;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  double2* is = reinterpret_cast<double2*>(Is_ri);
+  double2* ip = reinterpret_cast<double2*>(Ip_ri);
+  switch (a.mode) {
+    case UND_FAR:
+      hipLaunchKernelGGL(und_sum<UND_FAR>, grid, block, 0, st, a, rec, n, gamma, wu, w, ww1,
+                         ddphi, ddpsi, is, ip);
+      break;
+    case UND_TAPER:
+      hipLaunchKernelGGL(und_sum<UND_TAPER>, grid, block, 0, st, a, rec, n, gamma, wu, w, ww1,
+                         ddphi, ddpsi, is, ip);
+      break;
+    case UND_NF:
+      hipLaunchKernelGGL(und_sum<UND_NF>, grid, block, 0, st, a, rec, n, gamma, wu, w, ww1,
+                         ddphi, ddpsi, is, ip);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace xrt

@@ -119,3 +119,44 @@ def debug_divconst(a, b):
     _lib.check(lib.xrt_hip_debug_divconst_f64_dev(
         a.numel(), _f64(a), float(b), _f64(q), _stream_ptr()), 'debug_divconst')
     return q
+
+
+UND_FAR, UND_TAPER, UND_NF = 0, 1, 2
+
+
+def undulator(mode, Kx, Ky, tables, gamma, wu, w, ww1, ddphi, ddpsi, nper=1,
+              alpha_s=0., r0z=0., Is=None, Ip=None, timing=False):
+    """Undulator field sums on device tensors (xrt_hip_undulator_f64_dev).
+
+    tables = (tg, ag, sintg, costg, sintgph, costgph) float64 CUDA tensors of
+    equal length; the six ray arrays float64 CUDA tensors of equal length.
+    Returns (Is, Ip) complex128 tensors (and the kernel ms when timing)."""
+    from ._structs import Undulator
+    lib = _lib.load()
+    n = gamma.numel()
+    jend = tables[0].numel()
+    dev = gamma.device
+    if Is is None:
+        Is = torch.empty(n, dtype=torch.complex128, device=dev)
+    if Ip is None:
+        Ip = torch.empty(n, dtype=torch.complex128, device=dev)
+    u = Undulator()
+    u.mode, u.nper = int(mode), int(nper)
+    u.Kx, u.Ky = float(Kx), float(Ky)
+    u.alpha_s, u.r0z = float(alpha_s), float(r0z)
+    u.jend = jend
+    for name, t in zip(('tg', 'ag', 'sintg', 'costg', 'sintgph', 'costgph'),
+                       tables):
+        setattr(u, name, _f64(t, jend, name).value)
+    wsb = lib.xrt_hip_undulator_workspace_bytes(jend)
+    ws = workspace(dev, wsb, 'undulator')
+    ms = ctypes.c_float(0.)
+    with torch.cuda.device(dev):
+        rc = lib.xrt_hip_undulator_f64_dev(
+            ctypes.byref(u), n, _f64(gamma, n, 'gamma'), _f64(wu, n, 'wu'),
+            _f64(w, n, 'w'), _f64(ww1, n, 'ww1'), _f64(ddphi, n, 'ddphi'),
+            _f64(ddpsi, n, 'ddpsi'), _c128(Is, n, 'Is'), _c128(Ip, n, 'Ip'),
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(),
+            ctypes.byref(ms) if timing else None)
+    _lib.check(rc, 'xrt_hip_undulator_f64_dev')
+    return (Is, Ip, ms.value) if timing else (Is, Ip)
