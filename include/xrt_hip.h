@@ -337,6 +337,29 @@ XRT_HIP_API int xrt_hip_undulator_f64(
     const double* wu, const double* w, const double* ww1, const double* ddphi,
     const double* ddpsi, double* Is_ri, double* Ip_ri, float* kernel_ms);
 
+/* The whole Undulator._build_I_map_conv (synchr.py:2050-2108) in one launch:
+ * pre-factors wu, ww1, ab from (w, theta, psi, gamma), the node sum above, the
+ * optional harmonic window (synchr.py:2094-2098) and the Amp2Flux scaling.
+ * gamma: per-ray array (energy spread, synchr.py:2054-2059) or NULL = gamma0.
+ * Outputs: I [n] (flux density), Es, Ep complex128 [n]. u->r0z must be
+ * R0*2*pi/L0 for mode 2, u->alpha_s = _taperVal/E2WC for mode 1. */
+typedef struct xrt_hip_undulator_map {
+  double L0;          /* period [mm] */
+  double Np;          /* number of periods (enters sin(pi Np ww1)/sin(pi ww1)) */
+  double gamma0;
+  double eI;          /* ring current [A] */
+  double dstep;       /* 2 pi / gIntervals */
+  double harmonic;
+  int32_t has_harmonic;
+  int32_t dist_bw;    /* 1: distE == 'BW' (bwFact = 0.001), 0: 1/w */
+} xrt_hip_undulator_map;
+
+XRT_HIP_API int xrt_hip_undulator_imap_f64_dev(
+    const xrt_hip_undulator* u, const xrt_hip_undulator_map* m, int64_t nrays,
+    const double* w, const double* theta, const double* psi, const double* gamma,
+    double* I, double* Es_ri, double* Ep_ri, void* workspace, size_t workspace_bytes,
+    void* stream);
+
 /* ---- building-block checks (used by the GPU tests only) ---------------- */
 XRT_HIP_API int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,
                                void* stream);

@@ -51,6 +51,8 @@ SIGNATURES = {
     'xrt_hip_undulator_f64_dev': (ctypes.c_int, [
         vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp,
         c_float_p]),
+    'xrt_hip_undulator_imap_f64_dev': (ctypes.c_int, [
+        vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
     'xrt_hip_undulator_f64': (ctypes.c_int, [
         ctypes.c_int, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, c_float_p]),
     'xrt_hip_debug_sqrt_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),

@@ -131,4 +131,16 @@ class Undulator(ctypes.Structure):
                 ('costgph', ctypes.c_void_p)]
 
 
-STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator)
+class UndulatorMap(ctypes.Structure):
+    _fields_ = [('L0', ctypes.c_double),
+                ('Np', ctypes.c_double),
+                ('gamma0', ctypes.c_double),
+                ('eI', ctypes.c_double),
+                ('dstep', ctypes.c_double),
+                ('harmonic', ctypes.c_double),
+                ('has_harmonic', ctypes.c_int32),
+                ('dist_bw', ctypes.c_int32)]
+
+
+STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
+           UndulatorMap)

@@ -150,5 +150,26 @@ class BeamLine(object):
         self.cosAzimuth = float(np.cos(value))
 
 
+_ANGLE_UNITS = (('mrad', 1e-3), ('urad', 1e-6), ('nrad', 1e-9), ('rad', 1.),
+                ('deg', np.pi / 180.))
+
+
+def auto_units_angle(angle, defaultFactor=1.):
+    """Angle given as a number (times *defaultFactor*) or as a string with a
+    unit suffix: '2mrad', '10 urad', '0.5deg' (reference: _flow_utils.py:74-103)."""
+    if isinstance(angle, str):
+        text = angle.strip()
+        if 'auto' in text:
+            return angle
+        for unit, factor in _ANGLE_UNITS:
+            if unit in text:
+                value = float(text[:text.index(unit[0])].strip())
+                return np.radians(value) if unit == 'deg' else value * factor
+        return float(text) * defaultFactor
+    if angle is None or isinstance(angle, (list, tuple)):
+        return angle
+    return angle * defaultFactor
+
+
 def new_uuid():
     return str(uuid.uuid4())

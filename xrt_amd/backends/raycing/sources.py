@@ -457,3 +457,5 @@ class GeometricSource(object):
             raycing.virgin_local_to_global(self.bl, bo, self.center)
         bo.parentId = self.uuid
         return bo
+
+from .undulator import Undulator  # noqa: E402,F401  (needs Beam from this module)

@@ -1,0 +1,719 @@
+"""``Undulator`` — host-side mirror of the reference's analytic undulator source
+(xrt/backends/raycing/sources/synchr.py:1349-2260 on top of
+sources/sybase.py:29-560, 933-1810) for the cases its three OpenCL kernels
+cover: far field, tapered gap, near field (``R0``).
+
+What runs where: the sampling logic (numpy RNG in the reference's call order,
+rejection, electron-beam convolution, coherency matrix) is host code exactly as
+in the reference; the field integral ``build_I_map`` — the only expensive
+step — is ONE HIP kernel launch (``xrt_hip_undulator_imap_f64_dev``: pre-factors,
+node sum, scaling). There is no numpy implementation of the integral here: without
+the GPU library ``build_I_map`` raises.
+
+Not mirrored (raise NotImplementedError / absent): custom magnetic field
+(``SourceFromField``), ``multi_electron_stack``, ``intensities_on_mesh``,
+``power_vs_K``, ``tuning_curves``, the Qt flow hooks.
+"""
+import numpy as np
+import torch
+from scipy import special
+
+from .. import raycing
+from ... import hipcalls
+from .physconsts import (PI, PI2, C, EV2ERG, CHeVcm, CHBAR, M0, K2B, E2WC, SIE0,
+                         SQ2, SQPI)
+from .sources import Beam
+
+UND_FAR, UND_TAPER, UND_NF = 0, 1, 2
+
+
+def clenshaw_curtis(n):
+    """n-point Clenshaw–Curtis nodes and weights on [-1, 1] (the reference's
+    default rule, sybase.py:1106-1140): w_k = c_k/N · Σ_j g_j cos(2πjk/N),
+    g_0 = 1, g_j = −b_j/(4j²−1), evaluated with one length-N FFT."""
+    N = n - 1
+    x = -np.cos(np.pi * np.arange(n) / N)
+    if n == 2:
+        return x, np.array([1.0, 1.0])
+    half = N // 2
+    j = np.arange(1, half + 1)
+    g = -2. / (4. * j * j - 1.)
+    G = np.zeros(N)
+    G[0] = 1.
+    if N % 2 == 0:
+        g[-1] *= 0.5            # b_{N/2} = 1
+        G[j[:-1]] += 0.5 * g[:-1]
+        G[N - j[:-1]] += 0.5 * g[:-1]
+        G[half] += g[-1]
+    else:
+        G[j] += 0.5 * g
+        G[N - j] += 0.5 * g
+    S = np.fft.fft(G).real
+    S = np.append(S, S[0])
+    c = np.full(n, 2.)
+    c[0] = c[-1] = 1.
+    return x, c / N * S
+
+
+class Undulator(object):
+    def __init__(self, bl=None, name='GenericSource', center=(0, 0, 0),
+                 nrays=raycing.nrays, eE=6.0, eI=0.1, eEspread=0., eSigmaX=None,
+                 eSigmaZ=None, eEpsilonX=1., eEpsilonZ=0.01, betaX=9., betaZ=2.,
+                 eMin=9000, eMax=9100, distE='eV', xPrimeMax=0.01, zPrimeMax=0.01,
+                 R0=None, uniformRayDensity=False, filamentBeam=False, pitch=0,
+                 yaw=0, period=50, n=50, K=1, Kx=0, Ky=0, B0x=0, B0y=0, phaseDeg=0,
+                 taper=None, targetE=None, xPrimeMaxAutoReduce=True,
+                 zPrimeMaxAutoReduce=True, gp=1e-6, gIntervals=2, gNodes=None,
+                 targetOpenCL='auto', precisionOpenCL='auto', device=None, **kwargs):
+        """Arguments as the reference's ``Undulator`` (synchr.py:1362-1435,
+        sybase.py:34-190, 940-1030); *targetOpenCL*/*precisionOpenCL* are
+        accepted and ignored (the integral always runs in fp64 on the GPU);
+        *device*: torch device for the kernel (default: current)."""
+        if kwargs:
+            raise NotImplementedError('unsupported Undulator arguments: %s'
+                                      % sorted(kwargs))
+        self.bl = bl
+        if bl is not None and self not in bl.sources:
+            bl.sources.append(self)
+            self.ordinalNum = len(bl.sources)
+        self.name = name
+        self.uuid = raycing.new_uuid()
+        self.center = center
+        self.pitch = raycing.auto_units_angle(pitch)
+        self.yaw = raycing.auto_units_angle(yaw)
+        self.nrays = np.int64(nrays)
+        self.R0 = R0
+        self.distE = distE
+        self.uniformRayDensity = uniformRayDensity
+        self.filamentBeam = filamentBeam
+        self.eE = float(eE)
+        self.gamma = self.eE * 1e9 * EV2ERG / (M0 * C**2)       # sybase.py:154
+        self.gamma2 = self.gamma**2
+        self.eEspread = eEspread
+        self.eI = float(eI)
+        self.eMin = float(eMin)
+        self.eMax = float(eMax)
+        self._set_electron_beam(eSigmaX, eSigmaZ, eEpsilonX, eEpsilonZ, betaX, betaZ)
+        self._xPrimeMin, self._xPrimeMax = self._angular_range(xPrimeMax)
+        self._zPrimeMin, self._zPrimeMax = self._angular_range(zPrimeMax)
+        self.gp = gp
+        self.gIntervals = int(gIntervals)
+        if gNodes is None:
+            self.needConvergence = True
+            self.quadm = 0
+        else:
+            self.needConvergence = False
+            self.quadm = int(gNodes)
+        self.maxIntegrationNodes = int(6e5)
+        self.convergenceSearchFlag = False
+        self._useGauLeg = False
+        self.device = device
+
+        self.L0 = period
+        self.Np = n
+        self._set_taper(taper)
+        self.phaseDeg = phaseDeg
+        self.phase = np.radians(phaseDeg)
+        self.targetE = None
+        if targetE is not None:
+            self._set_targetE(targetE)
+        if self.targetE is None:
+            if Kx == 0 and Ky == 0:
+                if abs(K) > 0:
+                    self.Kx, self.Ky = 0., float(K)
+                elif B0x == 0 and B0y == 0:
+                    raise ValueError("Please define either K or B0!")
+                else:
+                    self.Ky = float(B0y) * self.L0 / K2B
+                    self.Kx = float(B0x) * self.L0 / K2B
+            else:
+                self.Kx, self.Ky = float(Kx), float(Ky)
+        self.xPrimeMaxAutoReduce = xPrimeMaxAutoReduce
+        self.zPrimeMaxAutoReduce = zPrimeMaxAutoReduce
+        if self.R0 is not None:
+            self.xPrimeMaxAutoReduce = True
+            self.zPrimeMaxAutoReduce = True
+        self.report_E1()
+        self.needReset = True
+
+    # ---- parameter bookkeeping (host, mirrors the property setters) ---------
+    def _set_electron_beam(self, eSigmaX, eSigmaZ, epsX, epsZ, betaX, betaZ):
+        """dx, dz [mm], dxprime, dzprime [rad] from emittance [nm rad] and beta
+        [m] or explicit sizes [um] (sybase.py:160-175, 219-348)."""
+        out = []
+        for sig, eps, beta in ((eSigmaX, epsX, betaX), (eSigmaZ, epsZ, betaZ)):
+            eps = None if eps is None else eps * 1e-6
+            if sig is not None:
+                d = sig * 1e-3
+            elif eps is not None and beta is not None:
+                d = np.sqrt(eps * (beta * 1e3))
+            else:
+                d = 0
+            dp = (eps / d if d > 0 else 0) if eps is not None else 0
+            out += [d, dp]
+        self.dx, self.dxprime, self.dz, self.dzprime = out
+
+    @staticmethod
+    def _angular_range(v):
+        """mrad input -> (min, max) in rad (sybase.py:393-409)."""
+        if isinstance(v, (tuple, list)):
+            lim = [raycing.auto_units_angle(v[0], defaultFactor=1e-3),
+                   raycing.auto_units_angle(v[-1], defaultFactor=1e-3)]
+            return min(lim), max(lim)
+        if isinstance(v, str):
+            m = abs(raycing.auto_units_angle(v))
+            return -m, m
+        m = abs(v) * 1e-3
+        return -m, m
+
+    def _set_taper(self, taper):
+        """synchr.py:1566-1594."""
+        self.taper = taper
+        if taper is None:
+            self._taperVal = None
+        elif np.ndim(taper) == 0:
+            self._taperVal = float(taper)
+        else:
+            t = np.asarray(taper, dtype=float).ravel()
+            if len(t) == 1:
+                dgap, gap = 0., t[0]
+            elif len(t) == 2:
+                dgap, gap = t
+            else:
+                raise ValueError('taper must be (dgap, gap)')
+            self.gap = gap
+            self._taperVal = None if dgap == 0 else dgap / self.Np / self.L0 / gap
+
+    def _set_targetE(self, targetE):
+        """(energy, harmonic[, isElliptical]) -> Kx, Ky (synchr.py:1499-1560)."""
+        energy, harmonic = float(targetE[0]), float(targetE[1])
+        Ky = np.sqrt(harmonic * 8 * PI * self.gamma2 / self.L0 / energy / E2WC - 2)
+        Kx = 0
+        if np.isnan(Ky):
+            raise ValueError('Cannot calculate K, try to increase the undulator '
+                             'harmonic number')
+        if len(targetE) > 2 and targetE[2]:
+            if isinstance(targetE[2], float):
+                Kx = Ky * np.cos(targetE[2])
+                Ky = Ky * np.sin(targetE[2])
+            else:
+                Kx = Ky = Ky / 2**0.5
+        self.targetE = targetE
+        self.Kx, self.Ky = Kx, Ky
+
+    @property
+    def K(self):
+        return self.Ky
+
+    @property
+    def B0x(self):
+        return K2B * self.Kx / self.L0
+
+    @property
+    def B0y(self):
+        return K2B * self.Ky / self.L0
+
+    def report_E1(self):
+        """First-harmonic energy (synchr.py:1658-1674)."""
+        wu = PI / self.L0 / self.gamma2 * \
+            (2*self.gamma2 - 1. - 0.5*self.Kx**2 - 0.5*self.Ky**2) / E2WC
+        self.E1 = 2*wu*self.gamma2 / (1 + 0.5*self.Kx**2 + 0.5*self.Ky**2)
+        return self.E1
+
+    def _prime_max_mrad(self, lo, hi, reduce_by):
+        """What the reference's xPrimeMax / zPrimeMax *getters* return
+        (sybase.py:369-392, 410-434): mrad, reduced to K/gamma if asked."""
+        if reduce_by is not None:
+            tmp = reduce_by / self.gamma
+            if abs(hi) > abs(tmp):
+                hi_new = tmp
+            else:
+                hi_new = hi
+            if abs(lo) > abs(tmp):
+                lo = np.sign(lo) * tmp
+            hi = hi_new
+        if abs(lo) == abs(hi):
+            return hi * 1e3
+        return [lo * 1e3, hi * 1e3]
+
+    def _reset_limits(self):
+        """sybase.py:479-515. (The reference's z auto-reduction tests for an
+        attribute `_gamma` that never exists, sybase.py:417, so only the
+        horizontal range is ever reduced; same here.)"""
+        kx = (self.Ky if abs(self.Ky) > 0 else 2.) if self.xPrimeMaxAutoReduce \
+            else None
+        xp = self._prime_max_mrad(self._xPrimeMin, self._xPrimeMax, kx)
+        zp = self._prime_max_mrad(self._zPrimeMin, self._zPrimeMax, None)
+        lims = []
+        for raw, v in ((self._xPrimeMax, xp), (self._zPrimeMax, zp)):
+            if not raw:
+                lims.append((-1e-3, 1e-3))
+            elif isinstance(v, (tuple, list)):
+                lims.append((v[0] * 1e-3, v[-1] * 1e-3))
+            else:
+                lims.append((-v * 1e-3, v * 1e-3))
+        (xpMin, xpMax), (zpMin, zpMax) = lims
+        self.Theta_min = float(xpMin - self.dxprime)
+        self.Theta_max = float(xpMax + self.dxprime)
+        self.Psi_min = float(zpMin - self.dzprime)
+        self.Psi_max = float(zpMax + self.dzprime)
+        self.E_min = float(min(self.eMin, self.eMax))
+        self.E_max = float(max(self.eMin, self.eMax))
+
+    # ---- integration grid ----------------------------------------------------
+    def _build_integration_grid(self):
+        """Node tables of one period, uploaded once per grid
+        (synchr.py:1787-1801)."""
+        rule = np.polynomial.legendre.leggauss if self._useGauLeg else \
+            clenshaw_curtis
+        tg_n, ag_n = rule(self.quadm)
+        dstep = 2 * PI / float(self.gIntervals)
+        dI = np.arange(-PI + 0.5 * dstep, PI, dstep)
+        self.tg = (dI[:, None] + 0.5 * dstep * tg_n).ravel()
+        self.ag = (dI[:, None] * 0 + ag_n).ravel()
+        self.sintg = np.sin(self.tg)
+        self.costg = np.cos(self.tg)
+        self.sintgph = np.sin(self.tg + self.phase)
+        self.costgph = np.cos(self.tg + self.phase)
+        self.dstep = dstep
+        self._tables = None          # uploaded on first use
+
+    def _device_tables(self):
+        if self._tables is None:
+            dev = self._device()
+            self._tables = [torch.from_numpy(np.ascontiguousarray(t)).to(dev)
+                            for t in (self.tg, self.ag, self.sintg, self.costg,
+                                      self.sintgph, self.costgph)]
+        return self._tables
+
+    def _device(self):
+        if self.device is not None:
+            return torch.device(self.device)
+        from ... import _lib
+        _lib.require_gpu()
+        return torch.device('cuda', torch.cuda.current_device())
+
+    def _get_mad(self):
+        """Median spread of the on-edge intensity over 5 neighbouring grid
+        sizes (sybase.py:1245-1285)."""
+        keep = self.quadm
+        k = self.quadm - 2
+        sE = self.E_max * np.ones(1)
+        sT = self.Theta_max * np.ones(1)
+        sP = self.Psi_max * np.ones(1)
+        vals, dvals = [], []
+        old = None
+        for m in range(5):
+            k += 1
+            self.quadm = k
+            self._build_integration_grid()
+            new = self.build_I_map(sE, sT, sP)[0]
+            if m > 0:
+                vals.append(new)
+                dvals.append(np.abs(new - old) / new)
+            old = new
+        v = np.abs(np.array(vals))
+        mad = np.median(np.abs(v - np.median(v)))
+        dimad = np.median(dvals)
+        self.quadm = keep
+        return mad, dimad
+
+    def _find_convergence_mixed(self):
+        """Doubling then bisection on the number of nodes until the on-edge
+        intensity is stable to *gp* (sybase.py:1190-1243)."""
+        m = 3
+        while m < 10000:
+            m += 1
+            self.quadm = int(2**m)
+            mad, dimad = self._get_mad()
+            if (dimad < self.gp) or (mad < self.gp):
+                break
+            if self.quadm > self.maxIntegrationNodes:
+                break
+        lo, hi = int(2**(m - 1)), self.quadm
+        for _ in range(int(np.log2((hi - lo) / 20.))):
+            self.quadm = int(0.5 * (hi + lo))
+            mad, dimad = self._get_mad()
+            if (dimad < self.gp) or (mad < self.gp):
+                hi = self.quadm
+            else:
+                lo = self.quadm
+        self.quadm = hi
+
+    def _reset_integration_grid(self):
+        """sybase.py:1452-1467."""
+        if self.needConvergence:
+            self.quadm = 0
+            spread = self.eEspread
+            self.eEspread = 0
+            self.convergenceSearchFlag = True
+            self._find_convergence_mixed()
+            self.convergenceSearchFlag = False
+            self.eEspread = spread
+        self._build_integration_grid()
+
+    def reset(self):
+        """sybase.py:521-547."""
+        self.needReset = False
+        self._reset_limits()
+        self._reset_integration_grid()
+        if self.filamentBeam and not hasattr(self, 'dimExy'):
+            rMax = self.nrays
+            rE = np.random.uniform(self.E_min, self.E_max, rMax)
+            rTheta = np.random.uniform(self.Theta_min, self.Theta_max, rMax)
+            rPsi = np.random.uniform(self.Psi_min, self.Psi_max, rMax)
+            spread = self.eEspread
+            self.eEspread = 0
+            DistI = self.build_I_map(rE, rTheta, rPsi)[0]
+            self.Imax = np.max(DistI) * 1.2
+            self.nrepmax = np.floor(rMax / len(np.where(
+                self.Imax * np.random.rand(rMax) < DistI)[0]))
+            self.eEspread = spread
+        else:
+            self.Imax = 0.
+        self.xzE = (self.E_max - self.E_min) *\
+            (self.Theta_max - self.Theta_min) *\
+            (self.Psi_max - self.Psi_min)
+        self.fluxConst = self.Imax * self.xzE
+
+    # ---- the field integral: one HIP launch ---------------------------------
+    @property
+    def mode(self):
+        return UND_TAPER if self._taperVal is not None else \
+            UND_NF if self.R0 is not None else UND_FAR
+
+    def build_I_map_device(self, w, ddtheta, ddpsi, harmonic=None, gamma=None):
+        """(I, Es, Ep) as device tensors for device (or host) arrays of photon
+        energy [eV] and observation angles [rad]; *gamma*: optional per-ray
+        electron gamma (energy spread)."""
+        if not hasattr(self, '_tables') and self.needReset:
+            self.reset()
+        tables = self._device_tables()
+        dev = tables[0].device
+
+        def up(a):
+            if isinstance(a, torch.Tensor):
+                return a.to(dev, torch.float64).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+
+        mode = self.mode
+        return hipcalls.undulator_imap(
+            mode, self.Kx, self.Ky, tables, up(w), up(ddtheta), up(ddpsi),
+            self.L0, self.Np, self.gamma, self.eI, self.dstep, self.distE == 'BW',
+            gamma=None if gamma is None else up(gamma), harmonic=harmonic,
+            alpha_s=self._taperVal / E2WC if mode == UND_TAPER else 0.,
+            r0z=self.R0 * np.pi * 2 / self.L0 if mode == UND_NF else 0.)
+
+    def build_I_map(self, w, ddtheta, ddpsi, harmonic=None, dg=None):
+        """Host-array form with the reference's return values
+        (synchr.py:2035-2108): (I, Es, Ep) numpy arrays, or the bare
+        |field|·dstep/2 during the convergence search."""
+        w = np.atleast_1d(np.asarray(w, dtype=float))
+        n = len(w)
+        th = np.atleast_1d(np.asarray(ddtheta, dtype=float)) * np.ones(n)
+        ps = np.atleast_1d(np.asarray(ddpsi, dtype=float)) * np.ones(n)
+        gamma = None
+        if self.eEspread > 0:
+            g = self.gamma
+            if dg is not None:
+                g = g + dg
+            else:
+                sz = 1 if self.filamentBeam else n
+                g = g + g * self.eEspread * np.random.normal(size=sz)
+            gamma = g * np.ones(n)
+        if self.convergenceSearchFlag:
+            return self._bare_field(w, th, ps, gamma)
+        I, Es, Ep = self.build_I_map_device(w, th, ps, harmonic, gamma)
+        return I.cpu().numpy(), Es.cpu().numpy(), Ep.cpu().numpy()
+
+    def _bare_field(self, w, th, ps, gamma):
+        """|Is|,|Ip| -> sqrt(|Is|²+|Ip|²)·dstep/2 (synchr.py:2103-2104), from the
+        raw device sums."""
+        g = self.gamma * np.ones(len(w)) if gamma is None else gamma
+        g2 = g**2
+        wu = PI / self.L0 / g2 * np.ones_like(w) * \
+            (2*g2 - 1 - 0.5*self.Kx**2 - 0.5*self.Ky**2) / E2WC
+        ww1 = w * ((1. + 0.5*self.Kx**2 + 0.5*self.Ky**2) +
+                   g2 * (th**2 + ps**2)) / (2. * g2 * wu)
+        tables = self._device_tables()
+        dev = tables[0].device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        mode = self.mode
+        Is, Ip = hipcalls.undulator(
+            mode, self.Kx, self.Ky, tables, up(g), up(wu), up(w), up(ww1),
+            up(th), up(ps), nper=self.Np if mode else 1,
+            alpha_s=self._taperVal / E2WC if mode == UND_TAPER else 0.,
+            r0z=self.R0 * np.pi * 2 / self.L0 if mode == UND_NF else 0.)
+        f = np.abs(Is.cpu().numpy())**2 + np.abs(Ip.cpu().numpy())**2
+        return np.abs(np.sqrt(f) * 0.5 * self.dstep)
+
+    # ---- photon source size (synchr.py:2200-2260, sybase.py:664-674) --------
+    def get_sigma_r02(self, E):
+        return 2 * CHeVcm/E*10 * self.L0*self.Np / PI2**2
+
+    def get_sigmaP_r02(self, E):
+        return CHeVcm/E*10 / (2 * self.L0*self.Np)
+
+    @staticmethod
+    def tanaka_kitamura_Qa2(x, eps=1e-6):
+        ret = np.ones_like(x, dtype=float)
+        xarr = np.array(x)
+        y = SQ2 * xarr[xarr > eps]
+        y2 = y**2
+        ret[x > eps] = y2 / (np.exp(-y2) + SQPI*y*special.erf(y) - 1)
+        return ret
+
+    def _harmonic_of(self, E, onlyOddHarmonics):
+        harmonic = np.floor_divide(E, self.E1)
+        if onlyOddHarmonics:
+            harmonic += harmonic % 2 - 1
+        return harmonic
+
+    def get_sigma_r2(self, E, onlyOddHarmonics=True, with0eSpread=False):
+        s = self.get_sigma_r02(E)
+        if self.eEspread == 0 or with0eSpread:
+            return s
+        norm = PI2 * self._harmonic_of(E, onlyOddHarmonics) * self.Np * self.eEspread
+        return s * self.tanaka_kitamura_Qa2(norm/4.)**(2/3.)
+
+    def get_sigmaP_r2(self, E, onlyOddHarmonics=True, with0eSpread=False):
+        s = self.get_sigmaP_r02(E)
+        if self.eEspread == 0 or with0eSpread:
+            return s
+        norm = PI2 * self._harmonic_of(E, onlyOddHarmonics) * self.Np * self.eEspread
+        return s * self.tanaka_kitamura_Qa2(norm)
+
+    def get_SIGMA(self, E, onlyOddHarmonics=True, with0eSpread=False):
+        s = self.get_sigma_r2(E, onlyOddHarmonics, with0eSpread)
+        return (self.dx**2 + s)**0.5, (self.dz**2 + s)**0.5
+
+    def get_SIGMAP(self, E, onlyOddHarmonics=True, with0eSpread=False):
+        s = self.get_sigmaP_r2(E, onlyOddHarmonics, with0eSpread)
+        return (self.dxprime**2 + s)**0.5, (self.dzprime**2 + s)**0.5
+
+    # ---- shine ----------------------------------------------------------------
+    def shine(self, toGlobal=True, withAmplitudes=True, fixedEnergy=False,
+              wave=None, accuBeam=None):
+        """The source beam (rays sampled by rejection on the intensity map) or,
+        with *wave* (a beam from ``prepare_wave``), the undulator field on the
+        wave's points. Same numpy RNG call order as sybase.py:1470-1810."""
+        if self.needReset:
+            self.reset()
+        if self.bl is not None:
+            try:
+                self.bl._alignE = float(self.bl.alignE)
+            except (ValueError, AttributeError, TypeError):
+                self.bl._alignE = 0.5 * (self.eMin + self.eMax)
+        if wave is not None:
+            if not hasattr(wave, 'rDiffr'):
+                raise ValueError("If you want to use a `wave`, run a "
+                                 "`prepare_wave` before shine!")
+            self.uniformRayDensity = True
+            mcRays = len(wave.a)
+        else:
+            mcRays = self.nrays
+        if self.uniformRayDensity:
+            withAmplitudes = True
+        parts = []
+        length = 0
+        seeded = np.int64(0)
+        seededI = 0.
+        dgamma = None
+        if self.filamentBeam:
+            if accuBeam is None:
+                rsE = np.random.random_sample() * \
+                    float(self.E_max - self.E_min) + self.E_min
+                rX = self.dx * np.random.standard_normal()
+                rZ = self.dz * np.random.standard_normal()
+                dtheta = self.dxprime * np.random.standard_normal()
+                dpsi = self.dzprime * np.random.standard_normal()
+                if self.eEspread > 0:
+                    dgamma = self.gamma * self.eEspread * \
+                        np.random.standard_normal()
+            else:
+                rsE = accuBeam.E[0]
+                rX, rZ = accuBeam.filamentDX, accuBeam.filamentDZ
+                dtheta, dpsi = accuBeam.filamentDtheta, accuBeam.filamentDpsi
+                dgamma = accuBeam.filamentDgamma
+                seeded, seededI = accuBeam.seeded, accuBeam.seededI
+        if fixedEnergy:
+            rsE = fixedEnergy
+        nrep = 0
+        while True:
+            seeded += mcRays
+            if self.filamentBeam or fixedEnergy:
+                rE = rsE * np.ones(mcRays)
+            else:
+                rE = np.random.rand(mcRays) * float(self.E_max - self.E_min) + \
+                    self.E_min
+            if wave is not None:
+                self.xzE = (self.E_max - self.E_min)
+                if self.filamentBeam:
+                    shiftX, shiftZ = rX, rZ
+                else:
+                    shiftX = np.random.normal(0, self.dx, mcRays) \
+                        if self.dx > 0 else 0
+                    shiftZ = np.random.normal(0, self.dz, mcRays) \
+                        if self.dz > 0 else 0
+                x = wave.xDiffr + shiftX
+                y = wave.yDiffr
+                z = wave.zDiffr + shiftZ
+                rDiffr = np.sqrt((x**2 + y**2 + z**2))
+                rTheta = x / rDiffr
+                rPsi = z / rDiffr
+                if self.filamentBeam:
+                    rTheta += dtheta
+                    rPsi += dpsi
+                else:
+                    if self.dxprime > 0:
+                        rTheta += np.random.normal(0, self.dxprime, mcRays)
+                    if self.dzprime > 0:
+                        rPsi += np.random.normal(0, self.dzprime, mcRays)
+            else:
+                rTheta = np.random.rand(mcRays) * \
+                    (self.Theta_max - self.Theta_min) + self.Theta_min
+                rPsi = np.random.rand(mcRays) * \
+                    (self.Psi_max - self.Psi_min) + self.Psi_min
+
+            Intensity, mJs, mJp = self.build_I_map(rE, rTheta, rPsi, dg=dgamma)
+
+            if self.uniformRayDensity:
+                seededI += mcRays * self.xzE
+                sourceWeight = self.xzE
+            else:
+                seededI += Intensity.sum() * self.xzE
+                sourceWeight = seededI / seeded
+            tmp_max = np.max(Intensity)
+            if tmp_max > self.Imax:
+                self.Imax = tmp_max
+                self.fluxConst = self.Imax * self.xzE
+            if self.uniformRayDensity:
+                I_pass = slice(None)
+                npassed = mcRays
+            else:
+                rndg = np.random.rand(mcRays)
+                I_pass = np.where(self.Imax * rndg < Intensity)[0]
+                npassed = len(I_pass)
+            if npassed == 0:
+                continue
+
+            bot = wave if wave is not None else \
+                Beam(npassed, withAmplitudes=withAmplitudes)
+            bot.state[:] = 1
+            bot.E[:] = rE[I_pass]
+            if self.filamentBeam:
+                dxR, dzR = rX, rZ
+            else:
+                bot.sourceSIGMAx, bot.sourceSIGMAz = self.get_SIGMA(
+                    bot.E, onlyOddHarmonics=False)
+                dxR = np.random.normal(0, bot.sourceSIGMAx, npassed)
+                dzR = np.random.normal(0, bot.sourceSIGMAz, npassed)
+
+            if wave is not None:
+                wave.rDiffr = np.sqrt(
+                    ((wave.xDiffr - dxR)**2 + wave.yDiffr**2 +
+                     (wave.zDiffr - dzR)**2))
+                wave.path[:] = 0
+                wave.a[:] = (wave.xDiffr - dxR) / wave.rDiffr
+                wave.b[:] = wave.yDiffr / wave.rDiffr
+                wave.c[:] = (wave.zDiffr - dzR) / wave.rDiffr
+            else:
+                bot.x[:] = dxR
+                bot.z[:] = dzR
+                bot.a[:] = rTheta[I_pass]
+                bot.c[:] = rPsi[I_pass]
+                if self.filamentBeam:
+                    bot.a[:] += dtheta
+                    bot.c[:] += dpsi
+                else:
+                    if self.dxprime > 0:
+                        bot.a[:] += np.random.normal(0, self.dxprime, npassed)
+                    if self.dzprime > 0:
+                        bot.c[:] += np.random.normal(0, self.dzprime, npassed)
+
+            mJs = mJs[I_pass]
+            mJp = mJp[I_pass]
+            if wave is not None:
+                area = wave.areaNormal if hasattr(wave, 'areaNormal') else \
+                    wave.area
+                norm = area**0.5 / wave.rDiffr
+                mJs *= norm
+                mJp *= norm
+            mJs2 = (mJs * np.conj(mJs)).real
+            mJp2 = (mJp * np.conj(mJp)).real
+            sSP = 1. if self.uniformRayDensity else mJs2 + mJp2
+            with np.errstate(invalid='ignore', divide='ignore'):
+                bot.Jsp[:] = np.where(sSP, mJs * np.conj(mJp) / sSP, 0)
+                bot.Jss[:] = np.where(sSP, mJs2 / sSP, 0)
+                bot.Jpp[:] = np.where(sSP, mJp2 / sSP, 0)
+                if withAmplitudes:
+                    if self.uniformRayDensity:
+                        bot.Es[:] = mJs
+                        bot.Ep[:] = mJp
+                    else:
+                        bot.Es[:] = mJs / mJs2**0.5
+                        bot.Ep[:] = mJp / mJp2**0.5
+            parts.append(bot)
+            length += npassed
+            if self.filamentBeam:
+                nrep += 1
+                more = nrep < self.nrepmax
+            else:
+                more = length < self.nrays
+            if self.uniformRayDensity:
+                more = False
+            if not more:
+                break
+
+        bo = parts[0] if len(parts) == 1 else _concatenate(parts, withAmplitudes)
+        bo.accepted = length * self.fluxConst
+        bo.acceptedE = bo.E.sum() * self.fluxConst * SIE0
+        bo.seeded = seeded
+        bo.seededI = seededI
+        nnorm = self.nrays if wave is None else len(wave.a)
+        bo.sourceWeight = sourceWeight / nnorm
+        if length > self.nrays and not self.filamentBeam and wave is None:
+            bo.filter_by_index(slice(0, int(self.nrays)))
+        if self.filamentBeam:
+            bo.filamentDtheta, bo.filamentDpsi = dtheta, dpsi
+            bo.filamentDX, bo.filamentDZ = rX, rZ
+            bo.filamentDgamma = dgamma
+        norm = (bo.a**2 + bo.b**2 + bo.c**2)**0.5
+        bo.a /= norm
+        bo.b /= norm
+        bo.c /= norm
+        if self.pitch or self.yaw:
+            raycing.rotate_beam(bo, pitch=self.pitch, yaw=self.yaw)
+        bor = Beam(copyFrom=bo)
+        if wave is not None:
+            bor.x[:] = dxR
+            bor.y[:] = 0.
+            bor.z[:] = dzR
+            if self.R0 is None:
+                bor.path[:] = 0.
+                mPh = np.exp(1e7j * wave.E/CHBAR * wave.rDiffr)
+                wave.Es *= mPh
+                wave.Ep *= mPh
+        bor.parentId = self.uuid
+        if toGlobal:
+            raycing.virgin_local_to_global(self.bl, bor, self.center)
+        return bor
+
+
+def _concatenate(parts, withAmplitudes):
+    """All batches of one shine() in one Beam (the reference's
+    Beam.concatenate, beams.py:230-252, does not carry Es/Ep along; here they
+    are kept consistent with the other fields)."""
+    n = sum(len(p.x) for p in parts)
+    bo = Beam(n, withAmplitudes=withAmplitudes)
+    fields = ['state', 'x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp']
+    if withAmplitudes:
+        fields += ['Es', 'Ep']
+    for f in fields:
+        setattr(bo, f, np.concatenate([getattr(p, f) for p in parts]))
+    last = parts[-1]
+    for k in ('sourceSIGMAx', 'sourceSIGMAz'):
+        if k in parts[0].__dict__:
+            object.__setattr__(bo, k, parts[0].__dict__[k])
+    del last
+    return bo

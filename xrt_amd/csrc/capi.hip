@@ -244,6 +244,7 @@ int xrt_hip_sizeof(int which) {
     case 4: return (int)sizeof(xrt_hip_screen);
     case 5: return (int)sizeof(xrt_hip_aperture);
     case 6: return (int)sizeof(xrt_hip_undulator);
+    case 7: return (int)sizeof(xrt_hip_undulator_map);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -474,6 +475,28 @@ int xrt_hip_undulator_f64_dev(const xrt_hip_undulator* u, int64_t nrays, const d
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   HIP_TRY(e);
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_undulator_imap_f64_dev(const xrt_hip_undulator* u, const xrt_hip_undulator_map* m,
+                                   int64_t nrays, const double* w, const double* theta,
+                                   const double* psi, const double* gamma, double* I,
+                                   double* Es_ri, double* Ep_ri, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  int rc;
+  if ((rc = check_undulator(u, nrays))) return rc;
+  if (!m) return fail(XRT_HIP_ERR_ARG, "NULL map description");
+  if (!(m->L0 > 0) || !(m->gamma0 > 1) || !(m->dstep > 0))
+    return fail(XRT_HIP_ERR_ARG, "undulator map: L0, gamma0 and dstep must be positive");
+  if (nrays > 0 && (!w || !theta || !psi || !I || !Es_ri || !Ep_ri))
+    return fail(XRT_HIP_ERR_ARG, "NULL ray array");
+  if (!workspace || workspace_bytes < xrt_hip_undulator_workspace_bytes(u->jend))
+    return fail(XRT_HIP_ERR_ARG, "workspace too small: %zu < %zu", workspace_bytes,
+                xrt_hip_undulator_workspace_bytes(u->jend));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  HIP_TRY(xrt::undulator_pack_launch(*u, workspace, st));
+  HIP_TRY(xrt::undulator_imap_launch(*u, *m, nrays, w, theta, psi, gamma, I, Es_ri, Ep_ri,
+                                     workspace, st));
   return XRT_HIP_OK;
 }
 

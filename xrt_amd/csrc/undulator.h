@@ -3,6 +3,7 @@
 #include "../../include/xrt_hip.h"
 namespace xrt {
 using UndulatorArgs = xrt_hip_undulator;
+using UndulatorMap = xrt_hip_undulator_map;
 enum { UND_FAR = XRT_HIP_UND_FAR, UND_TAPER = XRT_HIP_UND_TAPER, UND_NF = XRT_HIP_UND_NF };
 constexpr int UND_NODE_DOUBLES = 16;
 // workspace: jend * UND_NODE_DOUBLES doubles (packed node records)
@@ -11,4 +12,8 @@ hipError_t undulator_sum_launch(const UndulatorArgs& a, int64_t n, const double*
                                 const double* wu, const double* w, const double* ww1,
                                 const double* ddphi, const double* ddpsi, double* Is_ri,
                                 double* Ip_ri, const void* workspace, hipStream_t st);
+hipError_t undulator_imap_launch(const UndulatorArgs& a, const UndulatorMap& m, int64_t n,
+                                 const double* w, const double* theta, const double* psi,
+                                 const double* gamma, double* I, double* Es_ri, double* Ep_ri,
+                                 const void* workspace, hipStream_t st);
 }

@@ -22,6 +22,9 @@ namespace {
 
 constexpr double PI_ = 3.1415926535897932384626433832795;
 constexpr double PI2_ = 6.283185307179586476925286766559;
+constexpr double E2WC_ = 5067.7309392068091;          // synchr.py module constant
+constexpr double FINE_STR_ = 1 / 137.03599976;       // physconsts.py
+constexpr double SIE0_ = 1.602176565e-19;
 
 // record layout (doubles)
 enum { N_TG, N_AG, N_S, N_C, N_SPH, N_CPH, N_S2X, N_S2XPH, N_SUM2, N_BPX, N_BPY, N_C2,
@@ -60,19 +63,13 @@ __device__ __forceinline__ double div_known(double a, double b, double y) {
   return fma_(r, y, q);
 }
 
+// The per-ray sum; returns wu/γ·Σ (synchr.py:2038).
 template <int MODE>
-__global__ void __launch_bounds__(256)
-und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
-        const double* __restrict__ gamma, const double* __restrict__ wu_,
-        const double* __restrict__ w_, const double* __restrict__ ww1_,
-        const double* __restrict__ ddphi, const double* __restrict__ ddpsi,
-        double2* __restrict__ Is, double2* __restrict__ Ip) {
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __restrict__ rec,
+                                        double g, double wu, double w, double ww1, double phi,
+                                        double psi, double2& out_s, double2& out_p) {
   const double Kx = a.Kx, Ky = a.Ky;
   const double kx2 = Kx * Kx, ky2 = Ky * Ky;
-  const double g = gamma[i], wu = wu_[i], w = w_[i], ww1 = ww1_[i];
-  const double phi = ddphi[i], psi = ddpsi[i];
   const double revg = 1. / g;
   const double revg2 = revg * revg;
   const double wwu = w / wu;
@@ -176,8 +173,64 @@ und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
     }
   }
   const double f = wu * revg;
-  Is[i] = make_double2(f * bsr, f * bsi);
-  Ip[i] = make_double2(f * bpr, f * bpi);
+  out_s = make_double2(f * bsr, f * bsi);
+  out_p = make_double2(f * bpr, f * bpi);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
+        const double* __restrict__ gamma, const double* __restrict__ wu,
+        const double* __restrict__ w, const double* __restrict__ ww1,
+        const double* __restrict__ ddphi, const double* __restrict__ ddpsi,
+        double2* __restrict__ Is, double2* __restrict__ Ip) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double2 s, p;
+  und_ray<MODE>(a, rec, gamma[i], wu[i], w[i], ww1[i], ddphi[i], ddpsi[i], s, p);
+  Is[i] = s;
+  Ip[i] = p;
+}
+
+// Whole Undulator._build_I_map_conv (synchr.py:2050-2108) in one kernel: the
+// pre-factors wu, ww1, ab from (w, theta, psi, gamma), the sum, the harmonic
+// window and the Amp2Flux scaling. numpy's operation order throughout.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+und_imap(UndulatorArgs a, UndulatorMap m, const double* __restrict__ rec, int64_t n,
+         const double* __restrict__ w_, const double* __restrict__ theta,
+         const double* __restrict__ psi_, const double* __restrict__ gamma_,
+         double* __restrict__ I, double2* __restrict__ Es, double2* __restrict__ Ep) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double w = w_[i], th = theta[i], ps = psi_[i];
+  const double g = gamma_ ? gamma_[i] : m.gamma0;
+  const double kx2 = a.Kx * a.Kx, ky2 = a.Ky * a.Ky;
+  const double g2 = g * g;
+  const double wu = ((((PI_ / m.L0) / g2) * 1.0) * (((2 * g2 - 1) - 0.5 * kx2) - 0.5 * ky2)) / E2WC_;
+  const double ww1 = (w * (((1. + 0.5 * kx2) + 0.5 * ky2) + g2 * (th * th + ps * ps))) /
+                     ((2. * g2) * wu);
+  double ab = (1. / PI2_) / wu;
+  if (MODE == UND_FAR) {
+    double s1, c1, s2, c2;
+    sincos_phase((PI_ * m.Np) * ww1, s1, c1);
+    sincos_phase(PI_ * ww1, s2, c2);
+    ab = (ab * s1) / s2;
+  }
+  double2 s, p;
+  und_ray<MODE>(a, rec, g, wu, w, ww1, th, ps, s, p);
+  if (m.has_harmonic && (ww1 > m.harmonic + 0.5 || ww1 < m.harmonic - 0.5)) {
+    s = make_double2(0., 0.);
+    p = make_double2(0., 0.);
+  }
+  const double bw = m.dist_bw ? 0.001 : 1. / w;
+  const double a2f = ((FINE_STR_ * bw) * m.eI) / SIE0_;
+  const double as = hypot(s.x, s.y), ap = hypot(p.x, p.y);
+  const double field = as * as + ap * ap;
+  I[i] = (((a2f * (ab * ab)) * 0.25) * (m.dstep * m.dstep)) * field;
+  const double f = __builtin_sqrt(a2f) * ab;
+  Es[i] = make_double2(((f * s.x) * 0.5) * m.dstep, ((f * s.y) * 0.5) * m.dstep);
+  Ep[i] = make_double2(((f * p.x) * 0.5) * m.dstep, ((f * p.y) * 0.5) * m.dstep);
 }
 
 }  // namespace
@@ -210,6 +263,34 @@ hipError_t undulator_sum_launch(const UndulatorArgs& a, int64_t n, const double*
     case UND_NF:
       hipLaunchKernelGGL(und_sum<UND_NF>, grid, block, 0, st, a, rec, n, gamma, wu, w, ww1,
                          ddphi, ddpsi, is, ip);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t undulator_imap_launch(const UndulatorArgs& a, const UndulatorMap& m, int64_t n,
+                                 const double* w, const double* theta, const double* psi,
+                                 const double* gamma, double* I, double* Es_ri, double* Ep_ri,
+                                 const void* workspace, hipStream_t st) {
+  const double* rec = reinterpret_cast<const double*>(workspace);
+  if (n <= 0) return hipSuccess;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  double2* es = reinterpret_cast<double2*>(Es_ri);
+  double2* ep = reinterpret_cast<double2*>(Ep_ri);
+  switch (a.mode) {
+    case UND_FAR:
+      hipLaunchKernelGGL(und_imap<UND_FAR>, grid, block, 0, st, a, m, rec, n, w, theta, psi,
+                         gamma, I, es, ep);
+      break;
+    case UND_TAPER:
+      hipLaunchKernelGGL(und_imap<UND_TAPER>, grid, block, 0, st, a, m, rec, n, w, theta, psi,
+                         gamma, I, es, ep);
+      break;
+    case UND_NF:
+      hipLaunchKernelGGL(und_imap<UND_NF>, grid, block, 0, st, a, m, rec, n, w, theta, psi,
+                         gamma, I, es, ep);
       break;
     default:
       return hipErrorInvalidValue;

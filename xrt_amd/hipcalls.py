@@ -160,3 +160,48 @@ def undulator(mode, Kx, Ky, tables, gamma, wu, w, ww1, ddphi, ddpsi, nper=1,
             ctypes.byref(ms) if timing else None)
     _lib.check(rc, 'xrt_hip_undulator_f64_dev')
     return (Is, Ip, ms.value) if timing else (Is, Ip)
+
+
+def _undulator_struct(mode, Kx, Ky, tables, nper, alpha_s, r0z):
+    from ._structs import Undulator
+    u = Undulator()
+    jend = tables[0].numel()
+    u.mode, u.nper = int(mode), int(nper)
+    u.Kx, u.Ky = float(Kx), float(Ky)
+    u.alpha_s, u.r0z = float(alpha_s), float(r0z)
+    u.jend = jend
+    for name, t in zip(('tg', 'ag', 'sintg', 'costg', 'sintgph', 'costgph'),
+                       tables):
+        setattr(u, name, _f64(t, jend, name).value)
+    return u
+
+
+def undulator_imap(mode, Kx, Ky, tables, w, theta, psi, L0, Np, gamma0, eI, dstep,
+                   dist_bw, gamma=None, harmonic=None, alpha_s=0., r0z=0.):
+    """Whole ``Undulator.build_I_map`` in one launch
+    (xrt_hip_undulator_imap_f64_dev): returns device tensors (I, Es, Ep)."""
+    from ._structs import UndulatorMap
+    lib = _lib.load()
+    n = w.numel()
+    dev = w.device
+    u = _undulator_struct(mode, Kx, Ky, tables, int(Np) if mode else 1, alpha_s, r0z)
+    m = UndulatorMap()
+    m.L0, m.Np, m.gamma0, m.eI, m.dstep = (float(L0), float(Np), float(gamma0),
+                                            float(eI), float(dstep))
+    m.has_harmonic = 0 if harmonic is None else 1
+    m.harmonic = 0. if harmonic is None else float(harmonic)
+    m.dist_bw = 1 if dist_bw else 0
+    I = torch.empty(n, dtype=torch.float64, device=dev)
+    Es = torch.empty(n, dtype=torch.complex128, device=dev)
+    Ep = torch.empty(n, dtype=torch.complex128, device=dev)
+    wsb = lib.xrt_hip_undulator_workspace_bytes(u.jend)
+    ws = workspace(dev, wsb, 'undulator')
+    with torch.cuda.device(dev):
+        rc = lib.xrt_hip_undulator_imap_f64_dev(
+            ctypes.byref(u), ctypes.byref(m), n, _f64(w, n, 'w'),
+            _f64(theta, n, 'theta'), _f64(psi, n, 'psi'),
+            None if gamma is None else _f64(gamma, n, 'gamma'), _f64(I, n, 'I'),
+            _c128(Es, n, 'Es'), _c128(Ep, n, 'Ep'),
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr())
+    _lib.check(rc, 'xrt_hip_undulator_imap_f64_dev')
+    return I, Es, Ep
