@@ -48,6 +48,7 @@ def parse():
                     help='4 or 5; 0 = 4, plus 5 when --gpus 8')
     ap.add_argument('--kirchhoff-steps', type=int, default=0)
     ap.add_argument('--skip-kirchhoff', action='store_true')
+    ap.add_argument('--skip-undulator', action='store_true')
     ap.add_argument('--skip-cpu-baseline', action='store_true')
     ap.add_argument('--with-softi-shapes', action='store_true',
                     help='also time the two Kirchhoff shapes of the reference\'s '
@@ -270,6 +271,60 @@ def bench_softi_shapes():
     return res
 
 
+def bench_undulator(with_cpu=True):
+    """N3: the fused far-field map (Undulator.build_I_map) on 2^20 rays x 48
+    nodes of a planar undulator, inputs resident; CPU leg = the numpy oracle of
+    the reference's _sp_sum on a bounded sample."""
+    from xrt_amd import hipcalls
+    dev = torch.device('cuda', torch.cuda.current_device())
+    rng = np.random.RandomState(5)
+    n, Kx, Ky, Np, L0, gamma0 = 1 << 20, 0., 0.52, 108, 18.5, 5870.853297866972
+    quadm, gi = 24, 2
+    dstep = 2 * np.pi / gi
+    from xrt_amd.backends.raycing.undulator import clenshaw_curtis
+    xk, wk = clenshaw_curtis(quadm)
+    dI = np.arange(-np.pi + 0.5 * dstep, np.pi, dstep)
+    tg = (dI[:, None] + 0.5 * dstep * xk).ravel()
+    ag = (dI[:, None] * 0 + wk).ravel()
+    tabs_h = (tg, ag, np.sin(tg), np.cos(tg), np.sin(tg), np.cos(tg))
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    tabs = [up(t) for t in tabs_h]
+    w = rng.uniform(3900., 4250., n)
+    th = rng.uniform(-3e-5, 3e-5, n)
+    ps = rng.uniform(-3e-5, 3e-5, n)
+    dw, dth, dps = up(w), up(th), up(ps)
+    call = lambda: hipcalls.undulator_imap(  # noqa: E731
+        0, Kx, Ky, tabs, dw, dth, dps, L0, Np, gamma0, 0.5, dstep, True)
+    call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nodes = len(tg)
+    res = dict(metric='undulator field map, ray-nodes/s (far field, fused '
+                      'build_I_map)', rays=n, nodes=nodes, ms=ms,
+               value=n * nodes / ms * 1e3, unit='ray-nodes/s', dtype='f64')
+    if with_cpu:
+        from oracle import undulator_np as un
+        m = 100_000
+        tab = dict(zip(('tg', 'ag', 'sintg', 'costg', 'sintgph', 'costgph'), tabs_h),
+                   dstep=dstep)
+        t0 = time.perf_counter()
+        un.intensity_map(0, Kx, Ky, Np, L0, gamma0, 0.5, True, tab, w[:m], th[:m],
+                         ps[:m])
+        dt = time.perf_counter() - t0
+        res['cpu_baseline'] = dict(
+            value=m * nodes / dt, unit='ray-nodes/s', cores=1, kind='port',
+            sample='%d rays x %d nodes through oracle/undulator_np.py (numpy '
+                   'restatement of the reference\'s _sp_sum), %.1f s' % (m, nodes, dt))
+    return res
+
+
 def cpu_baseline_kirchhoff(host, npix=256):
     from oracle import kirchhoff_np as kn
     idx = np.linspace(0, host['px'].size - 1, npix).astype(int)
@@ -332,6 +387,8 @@ def main():
             if cfg == 4 or host is None:
                 host = h
             line['kirchhoff' if 'kirchhoff' not in line else 'kirchhoff_cfg%d' % cfg] = kres
+    if world == 1 and not args.skip_undulator:
+        line['undulator'] = bench_undulator(not args.skip_cpu_baseline)
     if args.with_softi_shapes and world == 1:
         line['softi_shapes'] = bench_softi_shapes()
     if world == 1 and rank == 0 and not args.skip_cpu_baseline:
