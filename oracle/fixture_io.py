@@ -55,6 +55,20 @@ def load_case(name):
         p['surface'] = dict(kind='bentflat', R=float(g['surf_R']), y0=p['surfPhysY'][0])
         p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,
                                          'mirror', float(g['mat_rho']))
+    elif name == 'g2_blazed_au':
+        p['surface'] = rn.make_blazed(float(g['surf_blaze']), float(g['surf_rho']),
+                                      float(g['surf_antiblaze']))
+        p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
+                                         'mirror', float(g['mat_rho']))
+    elif name.startswith('g2_ellipse'):
+        p['surface'] = dict(
+            kind='ellipse_param', isClosed=False,
+            isCylindrical=bool(float(g['surf_isCylindrical'])),
+            **{k: float(g['surf_' + k]) for k in
+               ('p', 'q', 'cosGamma', 'sinGamma', 'y0', 'z0', 'ellipseA',
+                'ellipseB')})
+        p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
+                                         'mirror', float(g['mat_rho']))
     elif name == 'g2_plate_be':
         p['surface'] = dict(kind='flat')
         p['surface2'] = dict(kind='flat')

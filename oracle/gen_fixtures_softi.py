@@ -1,0 +1,136 @@
+"""TEST INFRASTRUCTURE ONLY — regenerates by RUNNING THE REFERENCE (imported
+from /root/reference, build container only) the golden vectors of the surface
+kinds the SoftiMAX wave benchmark needs (SURVEY 8f row N4,
+tests/speed/3_Softi_CXIw2D_speed.py:176-246):
+
+  g2_blazed_au.npz      BlazedGrating (gratings.py:316-535) in ray mode: the ad
+                        hoc first-facet intersection, facet normals, Au mirror
+                        amplitudes, positionRoll = pi as mounted in the PGM
+  g2_ellipse_cyl.npz    EllipticalMirrorParam(isCylindrical=True) (the KB pair
+                        M4/M5): parametric bracketed root solve in (s, phi, r)
+  g2_ellipse_full.npz   same, ellipsoid of revolution (isCylindrical=False)
+  g2_ellipse_cyl_nis.npz  reflect(noIntersectionSearch=True) on points that
+                        already lie on the surface (what follows a diffract)
+
+While generating, oracle/reflect_np.py is asserted against the reference.
+
+Run:  python -m oracle.gen_fixtures_softi
+"""
+import numpy as np
+
+from . import _refenv
+from . import reflect_np as rn
+from .gen_fixtures_p1 import (oe_params, make_rays, run_reflect, material_dict,
+                              to_oracle_beam, assert_beams, beam_dict,
+                              flat_params, save)
+from .fixture_io import tables as load_tables
+
+SURF_KEYS_BLAZED = ('blaze', 'antiblaze', 'rho0')
+SURF_KEYS_ELL = ('p', 'q', 'cosGamma', 'sinGamma', 'y0', 'z0', 'ellipseA',
+                 'ellipseB')
+
+
+def ellipse_surface(oe):
+    d = dict(kind='ellipse_param', isCylindrical=bool(oe.isCylindrical),
+             isClosed=bool(oe.isClosed))
+    for k in SURF_KEYS_ELL:
+        d[k] = float(getattr(oe, k))
+    return d
+
+
+def main():
+    _refenv.activate()
+    import xrt.backends.raycing as raycing
+    import xrt.backends.raycing.sources as rs
+    import xrt.backends.raycing.oes as roe
+    import xrt.backends.raycing.materials as rm
+    raycing._VERBOSITY_ = 0
+    tables = load_tables()
+    mAu = rm.Material('Au', rho=19.32, kind='mirror')
+    n = 2048
+
+    # ---------------- blazed grating as in the SoftiMAX PGM ---------------
+    bl = raycing.BeamLine()
+    blaze, rho = np.radians(0.6), 300.
+    beta = -np.radians(86.5)
+    pg = roe.BlazedGrating(
+        bl, 'pg', center=[0, 2000., 20.], pitch=-(beta + np.pi/2),
+        positionRoll=np.pi, material=mAu, blaze=blaze, rho=rho,
+        limPhysX=(-2, 2), limPhysY=(-40, 40), alarmLevel=None)
+    # a fan that arrives from below (the grating looks down) at ~alpha
+    beam = make_rays(rs, n, 61, sx=1.0, sz=0.9, sa=3e-5, sc=2e-5,
+                     E=(275., 285.), amplitudes=True, pol='mixed')
+    inc = np.radians(2.0)                 # elevation of the incoming fan
+    beam.y[:] = 2000. - 1500.*np.cos(inc)
+    beam.z[:] += 20. - 1500.*np.sin(inc)
+    cc = beam.c + np.sin(inc)
+    beam.c[:] = cc
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.state[5] = 2
+    beam.state[6] = -2
+    surf = rn.make_blazed(blaze, rho)
+    for k in ('sinBlaze', 'cosBlaze', 'tanBlaze', 'sinAntiblaze', 'cosAntiblaze',
+              'tanAntiblaze', 'rho_1'):
+        assert surf[k] == getattr(pg, k), k
+    par = oe_params(pg, surf)
+    par['material'] = material_dict(tables, mAu)
+    run_reflect('g2_blazed_au', rs, pg, par, beam, mat_rho=np.array(19.32),
+                surf_blaze=np.array(blaze), surf_antiblaze=np.array(pg.antiblaze),
+                surf_rho=np.array(rho))
+
+    # ---------------- elliptical mirrors (parametric) ---------------------
+    pitch = np.radians(1)
+    for tag, cyl, kw in (('g2_ellipse_cyl', True, dict(positionRoll=np.pi/2)),
+                         ('g2_ellipse_full', False, dict())):
+        bl = raycing.BeamLine()
+        m = roe.EllipticalMirrorParam(
+            bl, 'm4', center=[0, 43000., 0], material=mAu, pitch=pitch,
+            isCylindrical=cyl, p=43000., q=5000., limPhysX=(-0.5, 0.5),
+            limPhysY=(-70., 70.), alarmLevel=None, **kw)
+        beam = make_rays(rs, n, 62 if cyl else 63, sx=0.02, sz=0.02, sa=1.2e-5,
+                         sc=1.2e-5, E=(275., 285.), amplitudes=True, pol='mixed')
+        beam.x[0] = 3.        # misses
+        beam.state[1] = 2
+        beam.state[2] = -1
+        surf = ellipse_surface(m)
+        absPitch = abs(np.arcsin(np.sin(pitch)))
+        mine = rn.make_ellipse_param(43000., 5000., absPitch, cyl)
+        for k in SURF_KEYS_ELL:
+            assert abs(mine[k] - surf[k]) <= 1e-15 * max(1., abs(surf[k])), k
+        par = oe_params(m, surf)
+        par['material'] = material_dict(tables, mAu)
+        extra = {'surf_' + k: np.array(surf[k]) for k in SURF_KEYS_ELL}
+        extra['surf_isCylindrical'] = np.array(float(cyl))
+        run_reflect(tag, rs, m, par, beam, mat_rho=np.array(19.32), **extra)
+
+        if cyl:
+            # noIntersectionSearch: start from the local beam of the ray pass
+            # (points on the surface), expressed in the global frame again
+            gb, lb = m.reflect(beam)
+            onsurf = rs.Beam(copyFrom=lb)
+            good = lb.state == 1
+            onsurf.filter_by_index(good)
+            m.local_to_global(onsurf)
+            # local_to_global rotated the amplitudes as well; fine: it is just
+            # another input beam lying on the surface
+            onsurf.a[:], onsurf.b[:], onsurf.c[:] = 0., 1., 0.
+            inb = rs.Beam(copyFrom=onsurf)
+            gb2, lb2 = m.reflect(rs.Beam(copyFrom=inb), noIntersectionSearch=True)
+            mg, ml = rn.oe_reflect(par, to_oracle_beam(inb),
+                                   noIntersectionSearch=True)
+            assert_beams(tag + '_nis:gb', mg, gb2)
+            assert_beams(tag + '_nis:lb', ml, lb2)
+            out = {}
+            out.update(beam_dict('in_', inb))
+            out.update(beam_dict('gb_', gb2))
+            out.update(beam_dict('lb_', lb2))
+            out.update(flat_params(par))
+            out.update(extra)
+            out['mat_rho'] = np.array(19.32)
+            save(tag + '_nis', **out)
+            st, cnt = np.unique(lb2.state, return_counts=True)
+            print(tag + '_nis', 'states', dict(zip(st.tolist(), cnt.tolist())))
+
+
+if __name__ == '__main__':
+    main()

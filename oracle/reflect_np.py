@@ -21,9 +21,17 @@ xrt/backends/raycing/:
 * rotate_coherency_matrix       <- sources/beams.py:448-479
 * material / crystal amplitudes <- see oracle/materials_np.py
 
-Parity pinned: tests/golden/g2_*.npz, g3_*.npz (oracle/gen_fixtures_p1.py).
-Supported subset: rectangular / round OEs, flat and toroidal surfaces, no
-figure error, no gratings / multilayers / mosaicity (SURVEY 2.1 OOS rows).
+* blazed grating surface        <- oes/gratings.py:461-522 (local_pre/z/n and the
+                                   ad hoc first-facet find_intersection)
+* elliptical mirror (parametric)<- oes/parametric.py:117-157, 213-249; the
+                                   parametric branches of find_dz (base.py:822-841)
+                                   and _reflect_local (reflect.py:676-703, 1066-1071)
+
+Parity pinned: tests/golden/g2_*.npz, g3_*.npz (oracle/gen_fixtures_p1.py,
+oracle/gen_fixtures_softi.py).
+Supported subset: rectangular / round OEs; flat, toroidal, bent-flat, blazed
+(constant line density) and elliptical-parametric surfaces; no figure error, no
+grating-equation materials / multilayers / mosaicity (SURVEY 2.1 OOS rows).
 """
 import copy
 
@@ -199,7 +207,68 @@ def local_z(surf, x, y):
         return y**2/2.0/R + r*(1 - rx**0.5)
     if surf['kind'] == 'bentflat':                # oes/__init__.py:289-293
         return (y**2 - surf['y0']**2) / 2.0 / surf['R']
+    if surf['kind'] == 'blazed':                  # oes/gratings.py:475-480
+        y0, y1, yC, yL = blazed_pre(surf, y)
+        return np.where(yL > yC, -(y1-y) * surf['tanBlaze'],
+                        -yL * surf['tanAntiblaze'])
     raise ValueError(surf['kind'])
+
+
+def blazed_pre(surf, y):
+    """Facet bookkeeping of a constant-density blazed grating
+    (gratings.py:461-473): groove start/end, apex position, offset in groove."""
+    rho_1 = surf['rho_1']
+    y0 = (y // rho_1) * rho_1
+    y1 = y0 + rho_1
+    yL = y % rho_1
+    yC = (y1-y0) / (1 + surf['tanAntiblaze']/surf['tanBlaze'])
+    return y0, y1, yC, yL
+
+
+def make_blazed(blaze, rho, antiblaze=np.pi*0.4999):
+    """Surface dictionary as BlazedGrating.reset derives it (gratings.py:416-440)."""
+    return dict(kind='blazed', blaze=blaze, antiblaze=antiblaze, rho0=rho,
+                rho_1=1. / rho, sinBlaze=np.sin(blaze), cosBlaze=np.cos(blaze),
+                tanBlaze=np.tan(blaze), sinAntiblaze=np.sin(antiblaze),
+                cosAntiblaze=np.cos(antiblaze), tanAntiblaze=np.tan(antiblaze))
+
+
+def make_ellipse_param(p, q, abs_pitch, isCylindrical=False, isClosed=False):
+    """EllipticalMirrorParam._reset_pq (parametric.py:143-157) for a mirror whose
+    p arm lies along the global y axis: *abs_pitch* = |asin(axis . normal)|."""
+    gamma = np.arctan2((p - q) * np.sin(abs_pitch), (p + q) * np.cos(abs_pitch))
+    return dict(kind='ellipse_param', p=p, q=q, cosGamma=np.cos(gamma),
+                sinGamma=np.sin(gamma), y0=(q - p)/2. * np.cos(abs_pitch),
+                z0=(q + p)/2. * np.sin(abs_pitch), ellipseA=(q + p)/2.,
+                ellipseB=np.sqrt(q * p) * np.sin(abs_pitch),
+                isCylindrical=bool(isCylindrical), isClosed=bool(isClosed))
+
+
+def is_param(surf):
+    return surf['kind'] == 'ellipse_param'
+
+
+def xyz_to_param(surf, x, y, z):                  # parametric.py:213-216
+    yNew, zNew = rotate_x(y - surf['y0'], z - surf['z0'], surf['cosGamma'],
+                          surf['sinGamma'])
+    return yNew, np.arctan2(x, zNew), np.sqrt(x**2 + zNew**2)
+
+
+def param_to_xyz(surf, s, phi, r):                # parametric.py:218-223
+    x = r * np.sin(phi)
+    y = s
+    z = r * np.cos(phi)
+    yNew, zNew = rotate_x(y, z, surf['cosGamma'], -surf['sinGamma'])
+    return x, yNew + surf['y0'], zNew + surf['z0']
+
+
+def local_r(surf, s, phi):                        # parametric.py:225-231
+    r = surf['ellipseB'] * np.sqrt(abs(1 - s**2 / surf['ellipseA']**2))
+    if surf['isCylindrical']:
+        r /= abs(np.cos(phi))
+    if surf['isClosed']:
+        return r
+    return np.where(abs(phi) > np.pi/2, r, np.ones_like(phi)*1e20)
 
 
 def local_n(surf, x, y):
@@ -233,6 +302,26 @@ def local_n(surf, x, y):
         c = 1.
         norm = (b**2 + 1)**0.5
         return [a/norm, b/norm, c/norm]
+    if surf['kind'] == 'blazed':                  # gratings.py:482-490
+        y0, y1, yC, yL = blazed_pre(surf, y)
+        return [np.zeros_like(x),
+                np.where(yL > yC, -surf['sinBlaze'], surf['sinAntiblaze']),
+                np.where(yL > yC, surf['cosBlaze'], surf['cosAntiblaze'])]
+    if surf['kind'] == 'ellipse_param':           # parametric.py:233-247, (s, phi)
+        s, phi = x, y
+        A2s2 = np.array(surf['ellipseA']**2 - s**2)
+        A2s2[A2s2 <= 0] = 1e22
+        nr = -surf['ellipseB'] / surf['ellipseA'] * s / np.sqrt(A2s2)
+        norm = np.sqrt(nr**2 + 1)
+        b = nr / norm
+        if surf['isCylindrical']:
+            a = np.zeros_like(phi)
+            c = 1. / norm
+        else:
+            a = -np.sin(phi) / norm
+            c = -np.cos(phi) / norm
+        bNew, cNew = rotate_x(b, c, surf['cosGamma'], -surf['sinGamma'])
+        return [a, bNew, cNew]
     raise ValueError(surf['kind'])
 
 
@@ -285,15 +374,53 @@ def find_dz(surf, t, x0, y0, z0, a, b, c, invertNormal):
     x = x0 + a*t
     y = y0 + b*t
     z = z0 + c*t
-    s = local_z(surf, x, y)
+    if is_param(surf):                            # base.py:822-841, diffSign = -1
+        x, y, z = xyz_to_param(surf, x, y, z)     # s, phi, r
+        s = local_r(surf, x, y)
+        diffSign = -1
+    else:
+        s = local_z(surf, x, y)
+        diffSign = 1
     ind = np.isnan(s)
     if ind.sum() > 0:
         s[ind] = 0
-    dz = (z - s) * 1 * invertNormal               # diffSign = 1 (base.py:841)
+    dz = (z - s) * diffSign * invertNormal
     return dz, x, y, z
 
 
+def blazed_find_intersection(surf, x, y, z, a, b, c):
+    """First illuminated facet of the saw-tooth, closed form
+    (gratings.py:492-522, constant line density)."""
+    b_c = b / c
+    n = np.floor((y - b_c*z) / surf['rho_1'])
+    y0 = surf['rho_1'] * n
+    y1 = y0 + surf['rho_1']
+    if surf['antiblaze'] == np.pi/2:
+        zabl = (y0-y) / b_c + z
+    else:
+        zabl = -surf['tanAntiblaze'] * (y - b_c*z - y0) /\
+            (1 + surf['tanAntiblaze']*b_c)
+    if surf['blaze'] == np.pi/2:
+        zbl = (y1-y) / b_c + z
+    else:
+        zbl = surf['tanBlaze'] * (y - b_c*z - y1) / (1 - surf['tanBlaze']*b_c)
+    if ((zabl > 0) & (zbl > 0)).any():
+        raise ValueError('blazed grating: ray above both facets')
+    zabl[zabl > 0] = zbl[zabl > 0] - 1
+    zbl[zbl > 0] = zabl[zbl > 0] - 1
+    z2 = zbl
+    y2 = b_c * (z2 - z) + y
+    t2 = (y2 - y) / b
+    x2 = x + t2 * a
+    return t2, x2, y2, z2
+
+
 def find_intersection(surf, t1, t2, x, y, z, a, b, c, invertNormal, info=None):
+    if surf['kind'] == 'blazed':
+        if info is not None:
+            info.update(brent=False, numit=0, tMinGlobal=np.nan,
+                        tMaxGlobal=np.nan)
+        return blazed_find_intersection(surf, x, y, z, a, b, c) + (None,)
     dz1, x1, y1, z1 = find_dz(surf, t1, x, y, z, a, b, c, invertNormal)
     dz2, x2, y2, z2 = find_dz(surf, t2, x, y, z, a, b, c, invertNormal)
     tMin = t1.min()
@@ -538,6 +665,9 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
     _lost = None
     if noIntersectionSearch:
         tMax[good] = 0.
+        if is_param(surf):                        # reflect.py:679-682
+            lb.x[good], lb.y[good], lb.z[good] = xyz_to_param(
+                surf, lb.x[good], lb.y[good], lb.z[good])
     else:
         res = find_intersection(
             surf, tMin[good], tMax[good], lb.x[good], lb.y[good], lb.z[good],
@@ -545,7 +675,11 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
         tMax[good], lb.x[good], lb.y[good], lb.z[good] = res[:4]
         _lost = res[4]
 
-    lb.state[good] = rays_good(oe, lb.x[good], lb.y[good], is2ndXtal)
+    if is_param(surf):                            # reflect.py:701-704
+        tX, tY, _ = param_to_xyz(surf, lb.x[good], lb.y[good], lb.z[good])
+    else:
+        tX, tY = lb.x[good], lb.y[good]
+    lb.state[good] = rays_good(oe, tX, tY, is2ndXtal)
     if _lost is not None:
         lb.state[np.where(good)[0][_lost]] = oe['lostNum']
 
@@ -662,6 +796,10 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
         if hasattr(lb, 'Es'):
             vlb.Es[goodN], vlb.Ep[goodN] = rotate_y(
                 lb.Es[goodN], lb.Ep[goodN], cosY, sinY)
+
+    if is_param(surf):                            # reflect.py:1066-1071
+        lb.x[good], lb.y[good], lb.z[good] = param_to_xyz(
+            surf, lb.x[good], lb.y[good], lb.z[good])
 
     if vlb is not lb:
         copy_beam(vlb, lb, good, includeState=True, includeJspEsp=False)

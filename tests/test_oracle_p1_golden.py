@@ -25,7 +25,9 @@ def check_beam(mine, g, prefix):
 
 
 @pytest.mark.parametrize('name', ['g2_toroid_pt', 'g2_flat_general',
-                                  'g2_toroid_brent', 'g2_bentflat_rh'])
+                                  'g2_toroid_brent', 'g2_bentflat_rh',
+                                  'g2_blazed_au', 'g2_ellipse_cyl',
+                                  'g2_ellipse_full'])
 def test_oe_reflect_matches_reference(name):
     p, beam, g = fixture_io.load_case(name)
     info = {}
@@ -39,6 +41,17 @@ def test_oe_reflect_matches_reference(name):
     good = g['in_state'] > 0
     assert np.array_equal(info['tMin'][good], g['tMin'][good])
     assert np.array_equal(info['tMax'][good], g['tMax'][good])
+
+
+def test_parametric_mirror_without_intersection_search():
+    """reflect(noIntersectionSearch=True) on an elliptical (parametric) mirror:
+    the points are converted to (s, phi, r) and back (reflect.py:679-682,
+    1066-1071)."""
+    p, beam, g = fixture_io.load_case('g2_ellipse_cyl_nis')
+    gb, lb = rn.oe_reflect(p, beam, noIntersectionSearch=True)
+    check_beam(gb, g, 'gb_')
+    check_beam(lb, g, 'lb_')
+    assert (lb.state == 1).all()
 
 
 @pytest.mark.parametrize('name', ['g3_dcm_si111', 'g3_dcm_si111_asym'])
