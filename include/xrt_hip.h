@@ -122,6 +122,10 @@ typedef struct xrt_hip_rotation {
 #define XRT_HIP_SURF_FLAT 0
 #define XRT_HIP_SURF_TOROID 1
 #define XRT_HIP_SURF_BENTFLAT 2   /* z = (y^2 - y0^2)/2/R, oes/__init__.py:240-303 */
+#define XRT_HIP_SURF_BLAZED 3     /* saw-tooth grating, constant line density,
+                                     oes/gratings.py:316-535 (own first-facet intersection) */
+#define XRT_HIP_SURF_ELLIPSE_PARAM 4  /* EllipticalMirrorParam, oes/parametric.py:9-249:
+                                     parametric (s, phi, r) root solve, base.py:822-841 */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_OVER_XMIN 1
@@ -144,9 +148,14 @@ typedef struct xrt_hip_pass {
   int32_t no_intersection_search;
   /* surface */
   int32_t surf_kind;
-  double surf_p[8];            /* toroid: R, r, RN(1/R), RN(1/r), flag: 1 = the two
+  double surf_p[12];           /* toroid: R, r, RN(1/R), RN(1/r), flag: 1 = the two
                                   reciprocals may be used (constant-divisor division);
-                                  bent-flat: R, limPhysY[0]^2, RN(1/R), -, flag */
+                                  bent-flat: R, limPhysY[0]^2, RN(1/R), -, flag;
+                                  blazed: rho_1 (= 1/rho), tanBlaze, tanAntiblaze, sinBlaze,
+                                  cosBlaze, sinAntiblaze, cosAntiblaze, 1+tanAntiblaze/tanBlaze,
+                                  blaze==pi/2, antiblaze==pi/2;
+                                  ellipse: y0, z0, cosGamma, sinGamma, ellipseA, ellipseB,
+                                  isCylindrical, isClosed (parametric.py:143-157) */
   double n_const[6];           /* flat: [nH(3), n_surface(3)] (base.py:719-742) */
   int32_t asymmetric;          /* 1: n_const holds two different normals */
   /* limits, base.py:1094-1163 */

@@ -82,6 +82,19 @@ def product_oe(name, g):
     elif name == 'g2_bentflat_rh':
         m = rm.Material('Rh', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.BentFlatMirror(bl, 'vcm', R=float(g['surf_R']), material=m, **common)
+    elif name == 'g2_blazed_au':
+        m = rm.Material('Au', rho=float(g['mat_rho']), kind='mirror')
+        oe = roe.BlazedGrating(bl, 'pg', material=m, blaze=float(g['surf_blaze']),
+                               antiblaze=float(g['surf_antiblaze']),
+                               rho=float(g['surf_rho']), **common)
+    elif name.startswith('g2_ellipse'):
+        m = rm.Material('Au', rho=float(g['mat_rho']), kind='mirror')
+        oe = roe.EllipticalMirrorParam(
+            bl, 'm4', material=m, p=float(g['surf_p']), q=float(g['surf_q']),
+            isCylindrical=bool(float(g['surf_isCylindrical'])), **common)
+        for k in ('cosGamma', 'sinGamma', 'y0', 'z0', 'ellipseA', 'ellipseB'):
+            assert abs(getattr(oe, k) - float(g['surf_' + k])) <= \
+                1e-15 * max(1., abs(float(g['surf_' + k]))), k
     elif name == 'g2_plate_be':
         m = rm.Material('Be', rho=float(g['mat_rho']), kind='plate')
         oe = roe.Plate(bl, 'win', material=m, t=float(g['plate_t']), **common)

@@ -61,6 +61,46 @@ def test_oe_reflect_matches_reference_golden(name):
     assert info['tMaxGlobal'] == g['tMax0'][good].max()
 
 
+@pytest.mark.parametrize('name', ['g2_blazed_au', 'g2_ellipse_cyl',
+                                  'g2_ellipse_full'])
+def test_softimax_surface_kinds_match_reference_golden(name):
+    """Blazed grating (closed-form first-facet intersection) and elliptical
+    parametric mirrors (root solve in (s, phi, r)). Positions come back through
+    sin/cos/atan2 of phi ~ pi in both implementations: 4e-12 of the aperture.
+
+    The parametric solve evaluates atan2/cos (libm on the host, ocml on the
+    device: both < 1 ulp, not identical), so the converged path length agrees to
+    a few ulp (checked: 8 ulp) instead of bit for bit; the propagation phase
+    k*t ~ 6e10 rad turns one ulp of t into ~1e-5 rad. |Es|, |Ep| and the
+    coherency matrix do not see that phase and are held to 1e-10."""
+    g = pc.load(name)
+    oe = pc.product_oe(name, g)
+    info = {}
+    gb, lb = oe.reflect(pc.product_beam(g), _info=info)
+    parametric = name != 'g2_blazed_au'
+    amp_tol = 1e-4 if parametric else AMP_TOL
+    compare(gb, g, lambda f: g['gb_' + f], geo_tol=4e-12, amp_tol=amp_tol)
+    compare(lb, g, lambda f: g['lb_' + f], geo_tol=4e-12, amp_tol=amp_tol)
+    hit = g['lb_state'] == 1
+    assert np.abs(lb.path - g['lb_path'])[hit].max() <= \
+        8 * np.spacing(np.abs(g['lb_path'][hit]).max())
+    for f in ('Es', 'Ep'):
+        assert np.abs(np.abs(getattr(lb, f)) - np.abs(g['lb_' + f])).max() <= \
+            AMP_TOL * np.abs(g['lb_Es']).max()
+    assert np.abs(lb.theta - g['lb_theta']).max() < 1e-13
+    if name != 'g2_blazed_au':
+        assert info['axis'] == int(g['axis'])
+        assert info['brent'] == bool(g['brent'])
+
+
+def test_parametric_mirror_without_intersection_search_golden():
+    g = pc.load('g2_ellipse_cyl_nis')
+    oe = pc.product_oe('g2_ellipse_cyl_nis', g)
+    gb, lb = oe.reflect(pc.product_beam(g), noIntersectionSearch=True)
+    compare(gb, g, lambda f: g['gb_' + f], geo_tol=4e-12)
+    compare(lb, g, lambda f: g['lb_' + f], geo_tol=4e-12)
+
+
 @pytest.mark.parametrize('name', ['g3_dcm_si111', 'g3_dcm_si111_asym'])
 def test_dcm_double_reflect_matches_reference_golden(name):
     g = pc.load(name)

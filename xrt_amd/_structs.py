@@ -7,7 +7,7 @@ MAX_ELEM = 4
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
-SURF_FLAT, SURF_TOROID, SURF_BENTFLAT = 0, 1, 2
+SURF_FLAT, SURF_TOROID, SURF_BENTFLAT, SURF_BLAZED, SURF_ELLIPSE_PARAM = 0, 1, 2, 3, 4
 SHAPE_RECT, SHAPE_ROUND = 0, 1
 OVER_XMIN, OVER_XMAX, OVER_YMIN, OVER_YMAX = 1, 2, 4, 8
 MAT_NONE, MAT_MIRROR, MAT_THIN_MIRROR, MAT_PLATE, MAT_CRYSTAL = 0, 1, 2, 3, 4
@@ -40,7 +40,7 @@ class Pass(ctypes.Structure):
         ('invert_normal', ctypes.c_int32),
         ('no_intersection_search', ctypes.c_int32),
         ('surf_kind', ctypes.c_int32),
-        ('surf_p', ctypes.c_double * 8),
+        ('surf_p', ctypes.c_double * 12),
         ('n_const', ctypes.c_double * 6),
         ('asymmetric', ctypes.c_int32),
         ('shape', ctypes.c_int32),

@@ -123,6 +123,15 @@ class OE(object):
     def local_n2(self, x, y):
         return self.local_n(x, y)
 
+    def _surface_height(self, x, y):
+        """z of the surface above (x, y), also for parametric surfaces
+        (reflect.py:336-341)."""
+        if self.isParametric:
+            s, phi, r = self.xyz_to_param(x, y, 0)
+            r = self.local_r(s, phi)
+            return self.param_to_xyz(s, phi, r)[2]
+        return self.local_z(x, y)
+
     # -- Coddington radii (oes/base.py:649-673) -------------------------------
     def get_Rmer_from_Coddington(self, p, q, pitch=None):
         if pitch is None:
@@ -332,7 +341,11 @@ class OE(object):
                             pitch=pitch, roll=roll, yaw=yaw)
         if hasattr(self, 'cryst2pitch') and is2ndXtal:
             raycing.rotate_beam(lb, roll=np.pi)
-        oeNormal = list(self.local_n(lb.x, lb.y))
+        if self.isParametric:                  # base.py:1210-1214
+            s, phi, r = self.xyz_to_param(lb.x, lb.y, lb.z)
+            oeNormal = list(self.local_n(s, phi))
+        else:
+            oeNormal = list(self.local_n(lb.x, lb.y))
         roll = self.roll + self.positionRoll +\
             np.arctan2(oeNormal[-3], oeNormal[-1])
         lb.Jss[:], lb.Jpp[:], lb.Jsp[:] =\
@@ -404,12 +417,13 @@ class OE(object):
                     (self.limPhysY[1] - self.limPhysY[0])
         lb.x[:] = x
         lb.y[:] = y
-        lb.z[:] = self.local_z(x, y)
+        lb.z[:] = self._surface_height(x, y)
         self.local_to_global(lb)
         if hasattr(prevOE, 'rotationSequence'):   # the previous element is an OE
             cx = (prevOE.limPhysX[1] + prevOE.limPhysX[0])*0.5
             cy = (prevOE.limPhysY[1] + prevOE.limPhysY[0])*0.5
-            cz = prevOE.local_z(np.atleast_1d(float(cx)), np.atleast_1d(float(cy)))
+            cz = prevOE._surface_height(np.atleast_1d(float(cx)),
+                                        np.atleast_1d(float(cy)))
             lbc = rs.Beam(nrays=1)
             lbc.x[:] = cx
             lbc.y[:] = cy
@@ -559,6 +573,184 @@ class ToroidMirror(OE):
 
 
 SimpleVFM = ToroidMirror
+
+
+class BlazedGrating(OE):
+    """Saw-tooth grating of constant line density for WAVE propagation: the
+    diffraction comes from the surface itself through the Kirchhoff integral,
+    the material is a mirror (oes/gratings.py:316-535). Facet geometry, the
+    first-facet intersection and the facet normals run in the reflect kernels
+    (surface kind XRT_HIP_SURF_BLAZED)."""
+
+    def __init__(self, *args, **kwargs):
+        self.blaze = raycing.auto_units_angle(kwargs.pop('blaze'))
+        self.antiblaze = raycing.auto_units_angle(
+            kwargs.pop('antiblaze', np.pi*0.4999))
+        self.rho0 = kwargs.pop('rho', 1)
+        if kwargs.get('gratingDensity') is not None:
+            raise NotImplementedError('variable line density')
+        OE.__init__(self, *args, **kwargs)
+        self.gratingDensity = None
+        self.reset()
+
+    def reset(self):
+        self.rho_1 = 1. / self.rho0
+        self.sinBlaze, self.cosBlaze, self.tanBlaze = \
+            np.sin(self.blaze), np.cos(self.blaze), np.tan(self.blaze)
+        self.sinAntiblaze, self.cosAntiblaze, self.tanAntiblaze = \
+            np.sin(self.antiblaze), np.cos(self.antiblaze), np.tan(self.antiblaze)
+
+    def local_pre(self, x, y):
+        y0 = (y // self.rho_1) * self.rho_1
+        y1 = y0 + self.rho_1
+        yL = y % self.rho_1
+        yC = (y1-y0) / (1 + self.tanAntiblaze/self.tanBlaze)
+        return 0, y0, y1, yC, yL
+
+    def local_z(self, x, y):
+        y0ind, y0, y1, yC, yL = self.local_pre(x, y)
+        return np.where(yL > yC, -(y1-y) * self.tanBlaze, -yL * self.tanAntiblaze)
+
+    def local_n(self, x, y):
+        y0ind, y0, y1, yC, yL = self.local_pre(x, y)
+        return [np.zeros_like(x),
+                np.where(yL > yC, -self.sinBlaze, self.sinAntiblaze),
+                np.where(yL > yC, self.cosBlaze, self.cosAntiblaze)]
+
+    def get_grating_area_fraction(self):
+        """Illuminated fraction of the groove length (gratings.py:524-535)."""
+        tanPitch = np.tan(abs(self.pitch))
+        y1 = self.rho_1 * self.tanBlaze / (self.tanBlaze + tanPitch)
+        z1 = -y1 * tanPitch
+        y2 = self.rho_1
+        z2 = 0
+        d = ((y2-y1)**2 + (z2-z1)**2)**0.5
+        return d * self.rho0
+
+    def _surface_params(self, p, second=False):
+        p.surf_kind = _structs.SURF_BLAZED
+        vals = (self.rho_1, self.tanBlaze, self.tanAntiblaze, self.sinBlaze,
+                self.cosBlaze, self.sinAntiblaze, self.cosAntiblaze,
+                1 + self.tanAntiblaze/self.tanBlaze,
+                1. if self.blaze == np.pi/2 else 0.,
+                1. if self.antiblaze == np.pi/2 else 0.)
+        for i, v in enumerate(vals):
+            p.surf_p[i] = float(v)
+        p.asymmetric = 0
+        for i, v in enumerate((0., 0., 1., 0., 0., 1.)):
+            p.n_const[i] = v
+
+
+class EllipticalMirrorParam(OE):
+    """Elliptical mirror (ellipsoid of revolution, or elliptical cylinder with
+    *isCylindrical*) in the parametric coordinates (s, phi, r) of
+    oes/parametric.py:9-249: s along the major axis, r the distance from it.
+    The root solve runs on r - local_r(s, phi) in the reflect kernels (surface
+    kind XRT_HIP_SURF_ELLIPSE_PARAM). *f1*/*f2*/*pAxis* are not mirrored: give
+    *p* and *q* (the p arm along the global y axis)."""
+
+    def __init__(self, *args, **kwargs):
+        for k in ('f1', 'f2', 'pAxis'):
+            if kwargs.pop(k, None) is not None:
+                raise NotImplementedError('EllipticalMirrorParam(%s=...)' % k)
+        p = kwargs.pop('p', 1000)
+        q = kwargs.pop('q', 1000)
+        self.isCylindrical = kwargs.pop('isCylindrical', False)
+        self.isClosed = kwargs.pop('isClosed', False)
+        OE.__init__(self, *args, **kwargs)
+        self.isParametric = True
+        self._p, self._q = p, q
+        self._reset_pq()
+
+    # every quantity that enters the ellipse is a property so that a later
+    # `oe.pitch = ...` re-derives it, like the reference's setters do
+    def _get(name):
+        return property(lambda self: getattr(self, '_' + name),
+                        lambda self, v: (setattr(self, '_' + name, v),
+                                         self._reset_pq())[0])
+    p = _get('p')
+    q = _get('q')
+    pitch = _get('pitchVal')
+    roll = _get('rollVal')
+    yaw = _get('yawVal')
+    positionRoll = _get('positionRollVal')
+    del _get
+
+    def _reset_pq(self):
+        """parametric.py:117-157."""
+        need = ('_p', '_q', '_pitchVal', '_rollVal', '_yawVal', '_positionRollVal',
+                'rotationSequence')
+        if not all(hasattr(self, v) for v in need) or self.bl is None:
+            return
+        lbn = rs.Beam(nrays=1)
+        lbn.a[:], lbn.b[:], lbn.c[:] = 0, 0, 1
+        raycing.rotate_beam(lbn, rotationSequence='-'+self.rotationSequence,
+                            pitch=self.pitch, roll=self.roll+self.positionRoll,
+                            yaw=self.yaw, skip_xyz=True)
+        raycing.virgin_local_to_global(self.bl, lbn, self.center, skip_xyz=True)
+        normal = lbn.a[0], lbn.b[0], lbn.c[0]
+        axis = [0, 1, 0]
+        norm = sum([a**2 for a in axis])**0.5
+        sintheta = sum([a*n for a, n in zip(axis, normal)]) / norm
+        absPitch = abs(np.arcsin(sintheta))
+        if self.p and self.q:
+            gamma = np.arctan2((self.p - self.q) * np.sin(absPitch),
+                               (self.p + self.q) * np.cos(absPitch))
+            self.cosGamma = np.cos(gamma)
+            self.sinGamma = np.sin(gamma)
+            self.y0 = (self.q - self.p)/2. * np.cos(absPitch)
+            self.z0 = (self.q + self.p)/2. * np.sin(absPitch)
+            self.ellipseA = (self.q + self.p)/2.
+            self.ellipseB = np.sqrt(self.q * self.p) * np.sin(absPitch)
+
+    def xyz_to_param(self, x, y, z):
+        yNew, zNew = raycing.rotate_x(y - self.y0, z - self.z0, self.cosGamma,
+                                      self.sinGamma)
+        return yNew, np.arctan2(x, zNew), np.sqrt(x**2 + zNew**2)
+
+    def param_to_xyz(self, s, phi, r):
+        x = r * np.sin(phi)
+        y = s
+        z = r * np.cos(phi)
+        yNew, zNew = raycing.rotate_x(y, z, self.cosGamma, -self.sinGamma)
+        return x, yNew + self.y0, zNew + self.z0
+
+    def local_r(self, s, phi):
+        r = self.ellipseB * np.sqrt(abs(1 - s**2 / self.ellipseA**2))
+        if self.isCylindrical:
+            r /= abs(np.cos(phi))
+        if self.isClosed:
+            return r
+        return np.where(abs(phi) > np.pi/2, r, np.ones_like(phi)*1e20)
+
+    def local_n(self, s, phi):
+        A2s2 = np.array(self.ellipseA**2 - s**2)
+        A2s2[A2s2 <= 0] = 1e22
+        nr = -self.ellipseB / self.ellipseA * s / np.sqrt(A2s2)
+        norm = np.sqrt(nr**2 + 1)
+        b = nr / norm
+        if self.isCylindrical:
+            a = np.zeros_like(phi)
+            c = 1. / norm
+        else:
+            a = -np.sin(phi) / norm
+            c = -np.cos(phi) / norm
+        bNew, cNew = raycing.rotate_x(b, c, self.cosGamma, -self.sinGamma)
+        return [a, bNew, cNew]
+
+    def _surface_params(self, p, second=False):
+        p.surf_kind = _structs.SURF_ELLIPSE_PARAM
+        vals = (self.y0, self.z0, self.cosGamma, self.sinGamma, self.ellipseA,
+                self.ellipseB, 1. if self.isCylindrical else 0.,
+                1. if self.isClosed else 0.)
+        for i, v in enumerate(vals):
+            p.surf_p[i] = float(v)
+        p.asymmetric = 0
+        for i, v in enumerate((0., 0., 1., 0., 0., 1.)):
+            p.n_const[i] = v
+
+
+EllipticalMirror = EllipticalMirrorParam
 
 
 class BentFlatMirror(OE):

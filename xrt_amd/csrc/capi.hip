@@ -279,8 +279,10 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
   if (pass->to_local.n < 0 || pass->to_local.n > XRT_HIP_MAX_ROT || pass->to_virgin.n < 0 ||
       pass->to_virgin.n > XRT_HIP_MAX_ROT)
     return fail(XRT_HIP_ERR_ARG, "rotation sequence longer than %d", XRT_HIP_MAX_ROT);
-  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_BENTFLAT)
+  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_ELLIPSE_PARAM)
     return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
+  if (pass->surf_kind >= XRT_HIP_SURF_BLAZED && material->kind == XRT_HIP_MAT_CRYSTAL)
+    return fail(XRT_HIP_ERR_ARG, "crystals on blazed / parametric surfaces are not supported");
   if (pass->invert_normal != 1 && pass->invert_normal != -1)
     return fail(XRT_HIP_ERR_ARG, "invert_normal must be +1 or -1");
   if (material->kind < XRT_HIP_MAT_NONE || material->kind > XRT_HIP_MAT_CRYSTAL)

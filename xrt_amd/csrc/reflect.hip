@@ -204,6 +204,78 @@ __device__ __forceinline__ double sqrt_unit(double x) {
   return x == 0. ? 0. : sqrt_rn_rinv(x, dummy);
 }
 
+// numpy's floor_divide / remainder for doubles (npy_divmod): the facet
+// bookkeeping of the blazed grating is written with `//` and `%`
+__device__ __forceinline__ void np_divmod(double a, double b, double& fdiv, double& mod) {
+  mod = fmod(a, b);
+  double div = (a - mod) / b;
+  if (mod != 0.) {
+    if ((b < 0.) != (mod < 0.)) {
+      mod += b;
+      div -= 1.0;
+    }
+  } else {
+    mod = copysign(0., b);
+  }
+  if (div != 0.) {
+    fdiv = floor(div);
+    if (div - fdiv > 0.5) fdiv += 1.0;
+  } else {
+    fdiv = copysign(0., a / b);
+  }
+}
+
+// blazed grating, gratings.py:461-490: is (x, y) on the blaze facet (the one
+// facing the source) of its groove?
+__device__ __forceinline__ bool blazed_front(const xrt_hip_pass& P, double y, double& y1,
+                                             double& yL) {
+  const double rho_1 = P.surf_p[0];
+  double fdiv;
+  np_divmod(y, rho_1, fdiv, yL);
+  const double y0 = fdiv * rho_1;
+  y1 = y0 + rho_1;
+  const double yC = (y1 - y0) / P.surf_p[7];
+  return yL > yC;
+}
+
+__device__ __forceinline__ bool surf_is_param(const xrt_hip_pass& P) {
+  return P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM;
+}
+
+// EllipticalMirrorParam, parametric.py:213-231. rotate_x(y, z, c, s) =
+// (c y - s z, s y + c z) (_rotate.py:5-6)
+__device__ __forceinline__ void ell_xyz_to_param(const xrt_hip_pass& P, double x, double y,
+                                                 double z, double& s, double& phi, double& r) {
+  const double yy = y - P.surf_p[0], zz = z - P.surf_p[1];
+  const double cg = P.surf_p[2], sg = P.surf_p[3];
+  const double yN = cg * yy - sg * zz;
+  const double zN = sg * yy + cg * zz;
+  s = yN;
+  phi = atan2(x, zN);
+  r = sqrt(x * x + zN * zN);
+}
+
+__device__ __forceinline__ void ell_param_to_xyz(const xrt_hip_pass& P, double s, double phi,
+                                                 double r, double& x, double& y, double& z) {
+  double sn, cs;
+  sincos(phi, &sn, &cs);
+  x = r * sn;
+  const double zz = r * cs;
+  const double cg = P.surf_p[2], msg = -P.surf_p[3];
+  const double yN = cg * s - msg * zz;
+  const double zN = msg * s + cg * zz;
+  y = yN + P.surf_p[0];
+  z = zN + P.surf_p[1];
+}
+
+__device__ __forceinline__ double ell_local_r(const xrt_hip_pass& P, double s, double phi) {
+  const double A = P.surf_p[4], B = P.surf_p[5];
+  double r = B * sqrt(fabs(1. - (s * s) / (A * A)));
+  if (P.surf_p[6] != 0.) r /= fabs(cos(phi));
+  if (P.surf_p[7] != 0.) return r;
+  return fabs(phi) > kPI / 2. ? r : 1e20;
+}
+
 // surface height, oes/base.py:675-679 (flat), oes/__init__.py:398-401 (toroid)
 __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double y) {
   if (P.surf_kind == XRT_HIP_SURF_TOROID) {
@@ -225,6 +297,10 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
     const double num = (y * y - P.surf_p[1]) * 0.5;
     return P.surf_p[4] != 0. ? div_const(num, P.surf_p[0], P.surf_p[2]) : num / P.surf_p[0];
   }
+  if (P.surf_kind == XRT_HIP_SURF_BLAZED) {  // gratings.py:475-480
+    double y1, yL;
+    return blazed_front(P, y, y1, yL) ? -(y1 - y) * P.surf_p[1] : -yL * P.surf_p[2];
+  }
   return 0.;
 }
 
@@ -235,6 +311,16 @@ __device__ __forceinline__ double find_dz(const xrt_hip_pass& P, double t, doubl
   x = x0 + a * t;
   y = y0 + b * t;
   z = z0 + c * t;
+  if (surf_is_param(P)) {  // base.py:822-841: (x, y, z) become (s, phi, r), diffSign = -1
+    double sp, phi, rr;
+    ell_xyz_to_param(P, x, y, z, sp, phi, rr);
+    x = sp;
+    y = phi;
+    z = rr;
+    double s = ell_local_r(P, sp, phi);
+    if (isnan(s)) s = 0.;
+    return (z - s) * -1. * (double)P.invert_normal;
+  }
   double s = surf_z(P, x, y);
   if (isnan(s)) s = 0.;
   return (z - s) * (double)P.invert_normal;
@@ -566,9 +652,25 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bdn(
 // root solve, oes/base.py:848-1048, one ray
 // ---------------------------------------------------------------------------
 struct Hit {
-  double t, x, y, z;
+  double t, x, y, z;     // local Cartesian hit point
+  double px, py;         // what local_n takes: (x, y), or (s, phi) on a parametric surface
   int lost;  // ind1 of the reference: dz1 <= 0
 };
+
+// end of the solve: on a parametric surface the solver worked in (s, phi, r); the
+// reference keeps those for local_n and converts back for everything else
+// (reflect.py:701-704, 1066-1071)
+__device__ __forceinline__ void hit_done(const xrt_hip_pass& P, Hit& h) {
+  h.px = h.x;
+  h.py = h.y;
+  if (surf_is_param(P)) {
+    double x, y, z;
+    ell_param_to_xyz(P, h.x, h.y, h.z, x, y, z);
+    h.x = x;
+    h.y = y;
+    h.z = z;
+  }
+}
 
 __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
                                          const LocalRay& r) {
@@ -579,6 +681,32 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.y = r.y;
     h.z = r.z;
     h.lost = 0;
+    if (surf_is_param(P)) ell_xyz_to_param(P, r.x, r.y, r.z, h.x, h.y, h.z);
+    hit_done(P, h);
+    return h;
+  }
+  if (P.surf_kind == XRT_HIP_SURF_BLAZED) {
+    // first illuminated facet in closed form, gratings.py:492-522 (the bracket
+    // is not used). A ray above both facets makes the reference raise; here it
+    // is marked lost.
+    const double rho_1 = P.surf_p[0], tanB = P.surf_p[1], tanAB = P.surf_p[2];
+    const double b_c = r.b / r.c;
+    const double v = r.y - b_c * r.z;
+    const double n = floor(v / rho_1);
+    const double y0 = rho_1 * n;
+    const double y1 = y0 + rho_1;
+    double zabl = P.surf_p[9] != 0. ? (y0 - r.y) / b_c + r.z
+                                    : ((-tanAB) * (v - y0)) / (1. + tanAB * b_c);
+    double zbl = P.surf_p[8] != 0. ? (y1 - r.y) / b_c + r.z
+                                   : (tanB * (v - y1)) / (1. - tanB * b_c);
+    h.lost = (zabl > 0. && zbl > 0.) ? 1 : 0;
+    if (zabl > 0.) zabl = zbl - 1.;
+    if (zbl > 0.) zbl = zabl - 1.;
+    h.z = zbl;
+    h.y = b_c * (h.z - r.z) + r.y;
+    h.t = (h.y - r.y) / r.b;
+    h.x = r.x + h.t * r.a;
+    hit_done(P, h);
     return h;
   }
   double t1, t2;
@@ -594,6 +722,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.x = x1;
     h.y = y1;
     h.z = z1;
+    hit_done(P, h);
     return h;
   }
   if (ind2) {
@@ -601,6 +730,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.x = x2;
     h.y = y2;
     h.z = z2;
+    hit_done(P, h);
     return h;
   }
   const double tMinG = g.t1min, tMaxG = g.t2max;
@@ -692,6 +822,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
   h.x = x2;
   h.y = y2;
   h.z = z2;
+  hit_done(P, h);
   return h;
 }
 
@@ -980,6 +1111,34 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     n[0] = n[3] = 0.;
     n[1] = n[4] = nb * inorm;
     n[2] = n[5] = inorm;
+  } else if (P.surf_kind == XRT_HIP_SURF_BLAZED) {  // gratings.py:482-490
+    double y1, yL;
+    const bool front = blazed_front(P, h.py, y1, yL);
+    n[0] = n[3] = 0.;
+    n[1] = n[4] = front ? -P.surf_p[3] : P.surf_p[5];
+    n[2] = n[5] = front ? P.surf_p[4] : P.surf_p[6];
+  } else if (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM) {  // parametric.py:233-247
+    const double A = P.surf_p[4], B = P.surf_p[5];
+    const double sp = h.px, phi = h.py;
+    double A2s2 = A * A - sp * sp;
+    if (A2s2 <= 0.) A2s2 = 1e22;
+    const double nr = (((-B) / A) * sp) / sqrt(A2s2);
+    const double norm = sqrt(nr * nr + 1.);
+    const double nb = nr / norm;
+    double na, nc;
+    if (P.surf_p[6] != 0.) {
+      na = 0.;
+      nc = 1. / norm;
+    } else {
+      double sn, cs;
+      sincos(phi, &sn, &cs);
+      na = -sn / norm;
+      nc = -cs / norm;
+    }
+    const double cg = P.surf_p[2], msg = -P.surf_p[3];
+    n[0] = n[3] = na;
+    n[1] = n[4] = cg * nb - msg * nc;
+    n[2] = n[5] = msg * nb + cg * nc;
   } else {
     for (int j = 0; j < 6; ++j) n[j] = P.n_const[j];
   }
@@ -1377,6 +1536,8 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_finish(
   h.x = hx[i];
   h.y = hy[i];
   h.z = hz[i];
+  h.px = h.x;   // crystals are only combined with non-parametric surfaces (capi check)
+  h.py = h.y;
   h.lost = 0;
   complete_ray(P, M, g, in, restore, lb, vb, theta, i, r, h, hst[i], has_amp);
 }
@@ -1466,8 +1627,10 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   if (!P.no_intersection_search) {
     hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, part);
     hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, M, in, part, (int)rblocks, g);
-    hipLaunchKernelGGL(reflect_stats_bracket, rgrid, block, 0, st, P, in, g, part);
-    hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
+    if (P.surf_kind != XRT_HIP_SURF_BLAZED) {  // its intersection is closed-form: no clamps
+      hipLaunchKernelGGL(reflect_stats_bracket, rgrid, block, 0, st, P, in, g, part);
+      hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
+    }
   }
   const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
   if (need_mean) {

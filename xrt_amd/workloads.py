@@ -25,7 +25,7 @@ def cfg3_dcm(bl=None):
     bl = bl or raycing.BeamLine()
     si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
     si2 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
-    thB = float(si1.get_Bragg_angle(9000.) - si1.get_dtheta(9000.))
+    thB = float(np.ravel(si1.get_Bragg_angle(9000.) - si1.get_dtheta(9000.))[0])
     return roe.DCM(bl, 'dcm', center=[0, 20000., 0], bragg=thB, material=si1,
                    material2=si2, cryst2perpTransl=10., limPhysX=[-10, 10],
                    limPhysY=[-50, 50], limPhysX2=[-10, 10], limPhysY2=[-50, 150])
