@@ -18,7 +18,15 @@ def oracle_params(oe):
         overEdge=oe.overEdge, lostNum=oe.lostNum, surfPhysX=list(oe.limPhysX),
         surfPhysY=list(oe.limPhysY), surfOptX=oe.limOptX, surfOptY=oe.limOptY)
     tb = fixture_io.tables()
-    if hasattr(oe, 'R') and hasattr(oe, 'r'):
+    if hasattr(oe, 'ellipseA'):
+        p['surface'] = dict(
+            kind='ellipse_param', isCylindrical=bool(oe.isCylindrical),
+            isClosed=bool(oe.isClosed), p=oe.p, q=oe.q, cosGamma=oe.cosGamma,
+            sinGamma=oe.sinGamma, y0=oe.y0, z0=oe.z0, ellipseA=oe.ellipseA,
+            ellipseB=oe.ellipseB)
+    elif hasattr(oe, 'tanBlaze'):
+        p['surface'] = rn.make_blazed(oe.blaze, oe.rho0, oe.antiblaze)
+    elif hasattr(oe, 'R') and hasattr(oe, 'r'):
         p['surface'] = dict(kind='toroid', R=oe.R, r=oe.r)
     elif hasattr(oe, 'R'):
         p['surface'] = dict(kind='bentflat', R=oe.R, y0=oe.limPhysY[0])
@@ -32,8 +40,12 @@ def oracle_params(oe):
             return mn.make_crystal(mn.load_element(tb, m.elements[0].name), m.hkl,
                                    m.d, 'diamond', m.geom, m.t, m.factDW, m.V)
         return mn.make_material([mn.load_element(tb, e.name) for e in m.elements],
-                                list(m.quantities), m.kind, m.rho, m.t)
-    p['material'] = mat(oe.material)
+                                list(m.quantities),
+                                'mirror' if m.kind == 'auto' else m.kind, m.rho, m.t)
+    material = oe.material
+    if isinstance(material, (list, tuple)):
+        material = material[0]
+    p['material'] = mat(material)
     if hasattr(oe, 'cryst2pitch'):
         p.update(bragg=oe.bragg, cryst1roll=oe.cryst1roll, cryst2roll=oe.cryst2roll,
                  cryst2pitch=oe.cryst2pitch, cryst2finePitch=oe.cryst2finePitch,

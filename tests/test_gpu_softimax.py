@@ -1,0 +1,84 @@
+"""GPU: the reference's published wave benchmark (SoftiMAX, BASELINE.md section
+1) on this package's classes against what the reference produced with its numpy
+kernels for the same seed (golden G11, oracle/gen_fixtures_softi_chain.py):
+undulator field (N3 kernel) -> ten Kirchhoff integrals (P2 kernel) interleaved
+with reflect(noIntersectionSearch=True) on toroid / plane / blazed-grating /
+elliptical mirrors (P1 kernels), wave samples placed by prepare_wave (a
+ray-mode reflect on each element).
+
+Same random samples (host RNG in the reference's call order) -> same positions;
+fields are compared stage by stage, norm-wise.
+
+Expected and asserted: up to the exit slit (five integrals, toroid / plane /
+grating surfaces, all arithmetic reproduced operation by operation) 1e-12. The
+wave samples on the elliptical mirrors M4/M5 come out of a root solve in
+(s, phi, r) that evaluates atan2/cos/sin (libm in the reference, ocml on the
+device: both < 1 ulp, not identical), so their positions agree to ~1e-12 mm
+only, and with k = 1.4e6 rad/mm every later field carries a phase noise of
+~1e-7 rad: 1e-6 asserted there (north_star: 1e-5)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def product_modules():
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.sources as rs
+    import xrt_amd.backends.raycing.apertures as ra
+    import xrt_amd.backends.raycing.oes as roe
+    import xrt_amd.backends.raycing.materials as rm
+    import xrt_amd.backends.raycing.screens as rsc
+    import xrt_amd.backends.raycing.waves as rw
+    return types.SimpleNamespace(raycing=raycing, rs=rs, ra=ra, roe=roe, rm=rm,
+                                 rsc=rsc, rw=rw)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+def test_softimax_wave_chain_matches_reference(golden_dir):
+    from xrt_amd.workloads import SoftiMAX
+    g = np.load(os.path.join(golden_dir, 'g11_softimax_chain.npz'))
+    np.random.seed(int(g['seed']))
+    scene = SoftiMAX(product_modules(), nrays=int(g['nrays']),
+                     source_kwargs=dict(gNodes=int(g['gNodes'])))
+    assert np.array_equal([scene.bl.source.Kx, scene.bl.source.Ky], g['Kxy'])
+    assert scene.bl.pg.areaFraction == float(g['pg_areaFraction'])
+    assert np.array_equal(np.array(scene.screenCenters), g['screenCenters'])
+    report = []
+
+    def check(name, beam):
+        ref = lambda f: g['%s_%s' % (name, f)]  # noqa: E731
+        assert len(beam.x) == len(ref('x')), name
+        assert np.array_equal(beam.state, ref('state')), name
+        pos = max(np.abs(getattr(beam, f) - ref(f)).max() /
+                  max(np.abs(ref(f)).max(), 1e-300) for f in 'xyz')
+        geo = (pos, max(np.abs(getattr(beam, f) - ref(f)).max() for f in 'abc'))
+        amp = max(rel(getattr(beam, f), ref(f)) for f in ('Es', 'Ep')
+                  if np.abs(ref(f)).max() > 0)
+        flux = rel(beam.Jss + beam.Jpp, ref('Jss') + ref('Jpp'))
+        report.append((name, geo, amp, flux))
+        for k in ('area', 'dS', 'areaNormal'):
+            key = '%s_%s' % (name, k)
+            if key in g.files and name != 'beamPGlocal':
+                assert abs(getattr(beam, k) - float(g[key])) <= \
+                    1e-12 * abs(float(g[key])), key
+
+    out = scene.run(check)
+    assert list(out) == [str(s) for s in g['stages']]
+    for name, geo, amp, flux in report:
+        print('%-14s positions %.1e  directions %.1e rad  amplitudes %.1e  flux %.1e'
+              % (name, geo[0], geo[1], amp, flux))
+    exact = True
+    for name, geo, amp, flux in report:
+        if name == 'beamM4local':
+            exact = False
+        assert geo[0] <= (1e-13 if exact else 1e-10), (name, geo)
+        assert geo[1] <= (1e-12 if exact else 1e-6), (name, geo)
+        assert amp <= (1e-12 if exact else 1e-6), (name, amp)
+        assert flux <= (1e-12 if exact else 1e-6), (name, flux)

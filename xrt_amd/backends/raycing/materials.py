@@ -16,6 +16,9 @@ import torch
 from ... import _lib, _structs
 from .physconsts import AVOGADRO, CH, CHBAR, PI, PI2, R0
 
+ch = CH        # names user scripts use (materials/__init__.py:97-98)
+chbar = CHBAR
+
 _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
     os.path.abspath(__file__)))), 'data', 'elements.npz')
 _tables = None

@@ -244,8 +244,10 @@ class OE(object):
             s.from_vacuum = 1 if fromVacuum else 0
             s._keep = []
             return s
-        if raycing.is_sequence(material):
-            raise NotImplementedError('per-surface material lists')
+        if raycing.is_sequence(material):     # reflect.py:725-728, one stripe only
+            if len(material) != 1:
+                raise NotImplementedError('multi-stripe material lists')
+            material = material[0]
         return material.to_struct(fromVacuum, device)
 
     def _run_pass(self, p, material, fromVacuum, beam_in, restore, want_info=False,

@@ -176,7 +176,11 @@ def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
 
     if hasattr(oe, 'rotationSequence'):  # OE
         local_n = oe.local_n2 if hasattr(oe, 'cryst2pitch') else oe.local_n
-        n = local_n(oeLocal.x, oeLocal.y)[-3:]
+        if oe.isParametric:                 # waves.py:680-682
+            sp, phi, _ = oe.xyz_to_param(oeLocal.x, oeLocal.y, oeLocal.z)
+            n = local_n(sp, phi)
+        else:
+            n = local_n(oeLocal.x, oeLocal.y)[-3:]
         nl = (oeLocal.a*np.asarray([n[-3]]) + oeLocal.b*np.asarray([n[-2]]) +
               oeLocal.c*np.asarray([n[-1]])).flatten()
     else:
@@ -259,7 +263,11 @@ def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
         a0, b0 = toOE.bl.sinAzimuth, toOE.bl.cosAzimuth
         wave.a[:], wave.b[:] = raycing.rotate_z(wave.a, wave.b, b0, a0)
         if hasattr(toOE, 'rotationSequence'):  # the receiver is an OE
-            oeNormal = list(toOE.local_n(wave.x, wave.y))
+            if toOE.isParametric:          # waves.py:791-793
+                sp, phi, _ = toOE.xyz_to_param(wave.x, wave.y, wave.z)
+                oeNormal = list(toOE.local_n(sp, phi))
+            else:
+                oeNormal = list(toOE.local_n(wave.x, wave.y))
             rollAngle = toOE.roll + toOE.positionRoll +\
                 np.arctan2(oeNormal[-3], oeNormal[-1])
             wave.Jss[:], wave.Jpp[:], wave.Jsp[:] = \

@@ -79,3 +79,184 @@ def kirchhoff_custom(ns, side, seed=7):
     py = np.full(px.shape, 10000.)
     return dict(ns=ns, side=side, px=px, py=py, pz=pz, sx=sx, sy=sy, sz=sz,
                 n=[0, 1, 0], nl=nl, E=E, k=k, Es=Es, Ep=Ep)
+
+
+# ---------------------------------------------------------------------------
+# The reference's published wave benchmark (reference
+# script tests/speed/3_Softi_CXIw2D_speed.py): SoftiMAX beamline at 280 eV,
+# undulator -> front-end slit -> M1 (toroid) -> M2 (plane) -> blazed grating ->
+# M3 (toroid) -> exit slit -> M4, M5 (elliptical cylinders, KB) -> 3 screens of
+# 64 x 64 pixels around the focus; nrays = 2e5 samples per wave, i.e. seven
+# 2e5 x 2e5 and three 2e5 x 4096 Kirchhoff integrals.
+#
+# `mods` is any namespace with raycing / rs / ra / roe / rm / rsc / rw modules of
+# xrt's layout: this package's (bench, GPU tests) or the reference's (fixture
+# generation in the build container) - the same scene description serves both.
+# ---------------------------------------------------------------------------
+class SoftiMAX(object):
+    E0 = 280.
+    dE = 0.5
+    harmonic = 1
+    acceptanceHor = 2.2e-4
+    acceptanceVer = 4.2e-4
+    pFE = 19250.
+    pM1 = 24000.
+    pPG = 2000.
+    pM3 = 2800.
+    qM3sag = 12000.
+    dM4ES = 2200.
+    dM45 = 3200.
+    pExp = 1800.
+    pitch = np.radians(1)
+    cff = 1.6
+    fixedExit = 20.
+    rho = 300.
+    blaze = np.radians(0.6)
+    ESdX = 2.
+    ESdZ = 0.1
+    dFocus = (-50., 0., 50.)
+    screenBins = 64
+    screenExtent = 50e-3   # mm (half size)
+
+    def __init__(self, mods, nrays=200000, source_kwargs=None):
+        self.m = mods
+        self.nrays = nrays
+        self.bl = self._build(source_kwargs or {})
+        self._align()
+
+    def _build(self, source_kwargs):
+        m, c = self.m, self
+        rm = m.rm
+        mAu = rm.Material('Au', rho=19.32)
+        bl = m.raycing.BeamLine(azimuth=-2*c.pitch, height=0)
+        bl.source = m.rs.Undulator(
+            bl, 'Softi53', nrays=self.nrays, eE=3.0, eI=0.5, eEspread=0.,
+            eEpsilonX=0., eEpsilonZ=0., betaX=9., betaZ=2., period=48., n=77,
+            targetE=(c.E0, c.harmonic), eMin=c.E0-c.dE, eMax=c.E0+c.dE,
+            xPrimeMax=c.acceptanceHor/2*1e3, zPrimeMax=c.acceptanceVer/2*1e3,
+            xPrimeMaxAutoReduce=False, zPrimeMaxAutoReduce=False,
+            uniformRayDensity=True, filamentBeam=True, **source_kwargs)
+        opening = [-c.acceptanceHor*c.pFE/2, c.acceptanceHor*c.pFE/2,
+                   -c.acceptanceVer*c.pFE/2, c.acceptanceVer*c.pFE/2]
+        bl.slitFE = m.ra.RectangularAperture(
+            bl, 'FE slit', kind=['left', 'right', 'bottom', 'top'], opening=opening)
+        bl.m1 = m.roe.ToroidMirror(
+            bl, 'M1', surface=('Au',), material=(mAu,), limPhysX=(-5, 5),
+            limPhysY=(-150, 150), positionRoll=np.pi/2, R=1e22, alarmLevel=0.1)
+        bl.m2 = m.roe.OE(
+            bl, 'M2', surface=('Au',), material=(mAu,), limPhysX=(-5, 5),
+            limPhysY=(-225, 225), alarmLevel=0.1)
+        bl.pg = m.roe.BlazedGrating(
+            bl, 'BlazedGrating', material=rm.Material('Au', rho=19.32),
+            blaze=c.blaze, rho=c.rho, positionRoll=np.pi, limPhysX=(-2, 2),
+            limPhysY=(-40, 40), alarmLevel=0.1)
+        bl.pg.order = 1
+        bl.m3 = m.roe.ToroidMirror(
+            bl, 'M3', surface=('Au',), material=(mAu,), positionRoll=-np.pi/2,
+            limPhysX=(-10., 10.), limPhysY=(-100., 100.), alarmLevel=0.1)
+        bl.exitSlit = m.ra.RectangularAperture(
+            bl, 'ExitSlit', opening=[-c.ESdX/2, c.ESdX/2, -c.ESdZ/2, c.ESdZ/2])
+        bl.m4 = m.roe.EllipticalMirrorParam(
+            bl, 'M4', surface=('Au',), material=(mAu,), positionRoll=np.pi/2,
+            pitch=c.pitch, isCylindrical=True, p=43000., q=c.dM45+c.pExp,
+            limPhysX=(-0.5, 0.5), limPhysY=(-70., 70.), alarmLevel=0.2)
+        bl.m5 = m.roe.EllipticalMirrorParam(
+            bl, 'M5', surface=('Au',), material=(mAu,), yaw=-2*c.pitch,
+            pitch=c.pitch, isCylindrical=True, p=c.dM4ES+c.dM45, q=c.pExp,
+            limPhysX=(-0.5, 0.5), limPhysY=(-40., 40.), alarmLevel=0.2)
+        bl.fsmExp = m.rsc.Screen(bl, 'FSM-Exp')
+        return bl
+
+    def _grating_angles(self, E, order):
+        c = self
+        order = abs(order) if c.cff > 1 else -abs(order)
+        f1 = c.cff**2 + 1
+        f2 = c.cff**2 - 1
+        ml_d = order * c.rho * self.m.rm.ch / E * 1e-7
+        cosAlpha = np.sqrt(-ml_d**2 * f1 + 2*abs(ml_d) *
+                           np.sqrt(f2**2 + c.cff**2 * ml_d**2)) / abs(f2)
+        cosBeta = c.cff * cosAlpha
+        return np.arccos(cosAlpha), -np.arccos(cosBeta)
+
+    def _align(self):
+        bl, c = self.bl, self
+        pitch = c.pitch
+        bl.source.center = c.pM1 * np.sin(2*pitch), -c.pM1 * np.cos(2*pitch), 0
+        bl.slitFE.center = (c.pM1-c.pFE) * np.sin(2*pitch), \
+            -(c.pM1-c.pFE) * np.cos(2*pitch), 0
+        bl.m1.center = 0, 0, 0
+        bl.m1.pitch = pitch
+        bl.m1.r = 2. * c.pM1 * np.sin(pitch)
+        alpha, beta = self._grating_angles(c.E0, bl.pg.order)
+        includedAngle = alpha - beta
+        t = -c.fixedExit / np.tan(includedAngle)
+        bl.m2.pitch = (np.pi - includedAngle) / 2.
+        bl.m2.center = 0, c.pPG - t, 0
+        bl.m2.yaw = -2 * bl.m1.pitch
+        bl.pg.pitch = -(beta + np.pi/2)
+        bl.pg.center = 0, c.pPG, c.fixedExit
+        bl.pg.yaw = -2 * bl.m1.pitch
+        bl.pg.areaFraction = bl.pg.get_grating_area_fraction()
+        bl.m3.center = [0, c.pPG + c.pM3, c.fixedExit]
+        bl.m3.pitch = -pitch
+        bl.m3.r = 2. * np.sin(pitch) * c.qM3sag
+        bl.m3.R = 1e22
+        bl.exitSlit.center = -c.qM3sag * np.sin(2*pitch), \
+            bl.m3.center[1] + c.qM3sag * np.cos(2*pitch), c.fixedExit
+        bl.m4.center = -(c.qM3sag+c.dM4ES) * np.sin(2*pitch), \
+            bl.m3.center[1] + (c.qM3sag+c.dM4ES) * np.cos(2*pitch), c.fixedExit
+        bl.m5.center = bl.m4.center[0], bl.m4.center[1] + c.dM45, c.fixedExit
+        self.screenCenters = []
+        for d in c.dFocus:
+            p = c.pExp + d
+            self.screenCenters.append(
+                [bl.m4.center[0] + (c.dM45+p) * np.sin(pitch-pitch),
+                 bl.m4.center[1] + (c.dM45+p) * np.cos(pitch-pitch),
+                 bl.m4.center[2] + p * np.tan(2*pitch)])
+        edges = np.linspace(-c.screenExtent*1e3, c.screenExtent*1e3, c.screenBins+1)
+        self.screenX = (edges[:-1] + edges[1:]) * 0.5 / 1e3
+        self.screenZ = self.screenX.copy()
+
+    def run(self, on_stage=None):
+        """One pass of the reference's run_process_wave; returns the dictionary
+        of beams. *on_stage(name, beam)* is called after every stage."""
+        bl, rw, nrays = self.bl, self.m.rw, self.nrays
+        out = {}
+
+        def done(name, beam):
+            out[name] = beam
+            if on_stage is not None:
+                on_stage(name, beam)
+
+        waveOnSamples = []
+        for center in self.screenCenters:
+            bl.fsmExp.center = center
+            waveOnSamples.append(
+                bl.fsmExp.prepare_wave(bl.m5, self.screenX, self.screenZ))
+        waveOnSlit = bl.slitFE.prepare_wave(bl.source, nrays)
+        done('beamSource', bl.source.shine(wave=waveOnSlit, fixedEnergy=self.E0))
+        done('beamFSM0', waveOnSlit)
+        prev, prevWave = bl.slitFE, waveOnSlit
+        for name, oe in (('M1', bl.m1), ('M2', bl.m2), ('PG', bl.pg), ('M3', bl.m3)):
+            wave = oe.prepare_wave(prev, nrays)
+            beamTo = rw.diffract(prevWave, wave)
+            glo, loc = oe.reflect(beamTo, noIntersectionSearch=True)
+            if oe is bl.pg:
+                loc.area = 0
+                loc.areaFraction = bl.pg.areaFraction
+            done('beam%slocal' % name, loc)
+            prev, prevWave = oe, loc
+        waveOnExitSlit = bl.exitSlit.prepare_wave(bl.m3, nrays)
+        rw.diffract(prevWave, waveOnExitSlit)
+        done('beamExitSlit', waveOnExitSlit)
+        prev, prevWave = bl.exitSlit, waveOnExitSlit
+        for name, oe in (('M4', bl.m4), ('M5', bl.m5)):
+            wave = oe.prepare_wave(prev, nrays)
+            beamTo = rw.diffract(prevWave, wave)
+            glo, loc = oe.reflect(beamTo, noIntersectionSearch=True)
+            done('beam%slocal' % name, loc)
+            prev, prevWave = oe, loc
+        for ic, wave in enumerate(waveOnSamples):
+            rw.diffract(prevWave, wave)
+            done('beamFSMExp%02d' % ic, wave)
+        return out
