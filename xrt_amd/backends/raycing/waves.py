@@ -95,6 +95,24 @@ def qualify_sampling(wave, E, goodlen):
 def convex_hull_area(px, py):
     """Area of the convex hull of 2-D points (Andrew's monotone chain); the
     reference takes it from scipy.spatial.ConvexHull (waves.py:661-668)."""
+    px = np.asarray(px, dtype=float)
+    py = np.asarray(py, dtype=float)
+    if len(px) > 64:
+        # Akl-Toussaint pre-filter: points strictly inside the octagon of the
+        # extreme points in 8 directions cannot be hull vertices
+        ext = []
+        for key in (px, px + py, py, py - px, -px, -px - py, -py, px - py):
+            i = int(np.argmax(key))
+            if not ext or (px[i], py[i]) != ext[-1]:
+                ext.append((px[i], py[i]))
+        if len(ext) > 1 and ext[0] == ext[-1]:
+            ext.pop()
+        if len(ext) >= 3:
+            inside = np.ones(len(px), dtype=bool)
+            for (x1, y1), (x2, y2) in zip(ext, ext[1:] + ext[:1]):
+                inside &= (x2-x1)*(py-y1) - (y2-y1)*(px-x1) > 0
+            keep = ~inside
+            px, py = px[keep], py[keep]
     pts = np.unique(np.column_stack((px, py)), axis=0)
     if len(pts) < 3:
         raise ValueError('cannot normalize this way!')

@@ -238,8 +238,16 @@ __device__ __forceinline__ bool blazed_front(const xrt_hip_pass& P, double y, do
   return yL > yC;
 }
 
+// F = surface family, a compile-time switch: 0 = flat / toroid / bent-flat (the
+// bulk ray-tracing kernels stay free of the code below), 1 = blazed grating and
+// parametric ellipse (fmod / atan2 / sincos in the solve)
+template <int F>
 __device__ __forceinline__ bool surf_is_param(const xrt_hip_pass& P) {
-  return P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM;
+  return F == 1 && P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM;
+}
+template <int F>
+__device__ __forceinline__ bool surf_is_blazed(const xrt_hip_pass& P) {
+  return F == 1 && P.surf_kind == XRT_HIP_SURF_BLAZED;
 }
 
 // EllipticalMirrorParam, parametric.py:213-231. rotate_x(y, z, c, s) =
@@ -277,6 +285,7 @@ __device__ __forceinline__ double ell_local_r(const xrt_hip_pass& P, double s, d
 }
 
 // surface height, oes/base.py:675-679 (flat), oes/__init__.py:398-401 (toroid)
+template <int F>
 __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double y) {
   if (P.surf_kind == XRT_HIP_SURF_TOROID) {
     const double R = P.surf_p[0], r = P.surf_p[1];
@@ -297,7 +306,7 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
     const double num = (y * y - P.surf_p[1]) * 0.5;
     return P.surf_p[4] != 0. ? div_const(num, P.surf_p[0], P.surf_p[2]) : num / P.surf_p[0];
   }
-  if (P.surf_kind == XRT_HIP_SURF_BLAZED) {  // gratings.py:475-480
+  if (surf_is_blazed<F>(P)) {  // gratings.py:475-480
     double y1, yL;
     return blazed_front(P, y, y1, yL) ? -(y1 - y) * P.surf_p[1] : -yL * P.surf_p[2];
   }
@@ -305,13 +314,14 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
 }
 
 // find_dz, oes/base.py:801-846
+template <int F>
 __device__ __forceinline__ double find_dz(const xrt_hip_pass& P, double t, double x0,
                                           double y0, double z0, double a, double b,
                                           double c, double& x, double& y, double& z) {
   x = x0 + a * t;
   y = y0 + b * t;
   z = z0 + c * t;
-  if (surf_is_param(P)) {  // base.py:822-841: (x, y, z) become (s, phi, r), diffSign = -1
+  if (surf_is_param<F>(P)) {  // base.py:822-841: (x, y, z) become (s, phi, r), diffSign = -1
     double sp, phi, rr;
     ell_xyz_to_param(P, x, y, z, sp, phi, rr);
     x = sp;
@@ -321,7 +331,7 @@ __device__ __forceinline__ double find_dz(const xrt_hip_pass& P, double t, doubl
     if (isnan(s)) s = 0.;
     return (z - s) * -1. * (double)P.invert_normal;
   }
-  double s = surf_z(P, x, y);
+  double s = surf_z<F>(P, x, y);
   if (isnan(s)) s = 0.;
   return (z - s) * (double)P.invert_normal;
 }
@@ -571,6 +581,7 @@ __device__ __forceinline__ LocalRay load_local(const xrt_hip_pass& P, const xrt_
   return r;
 }
 
+template <int F>
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
     xrt_hip_pass P, xrt_hip_beam in, const GStat* __restrict__ g, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
@@ -582,8 +593,8 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
     const LocalRay r = load_local(P, in, i);
     double t1, t2, x, y, z;
     bracket(P, axis, positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
-    const double dz1 = find_dz(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
-    double dz2 = find_dz(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
+    const double dz1 = find_dz<F>(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
+    double dz2 = find_dz<F>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
     if (dz1 <= 0. || dz2 >= 0.) dz2 = 0.;  // base.py:863-865
     t1m = t1 < t1m ? t1 : t1m;
     t2m = t2 > t2m ? t2 : t2m;
@@ -660,10 +671,11 @@ struct Hit {
 // end of the solve: on a parametric surface the solver worked in (s, phi, r); the
 // reference keeps those for local_n and converts back for everything else
 // (reflect.py:701-704, 1066-1071)
+template <int F>
 __device__ __forceinline__ void hit_done(const xrt_hip_pass& P, Hit& h) {
   h.px = h.x;
   h.py = h.y;
-  if (surf_is_param(P)) {
+  if (surf_is_param<F>(P)) {
     double x, y, z;
     ell_param_to_xyz(P, h.x, h.y, h.z, x, y, z);
     h.x = x;
@@ -672,6 +684,7 @@ __device__ __forceinline__ void hit_done(const xrt_hip_pass& P, Hit& h) {
   }
 }
 
+template <int F>
 __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
                                          const LocalRay& r) {
   Hit h;
@@ -681,11 +694,11 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.y = r.y;
     h.z = r.z;
     h.lost = 0;
-    if (surf_is_param(P)) ell_xyz_to_param(P, r.x, r.y, r.z, h.x, h.y, h.z);
-    hit_done(P, h);
+    if (surf_is_param<F>(P)) ell_xyz_to_param(P, r.x, r.y, r.z, h.x, h.y, h.z);
+    hit_done<F>(P, h);
     return h;
   }
-  if (P.surf_kind == XRT_HIP_SURF_BLAZED) {
+  if (surf_is_blazed<F>(P)) {
     // first illuminated facet in closed form, gratings.py:492-522 (the bracket
     // is not used). A ray above both facets makes the reference raise; here it
     // is marked lost.
@@ -706,14 +719,14 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.y = b_c * (h.z - r.z) + r.y;
     h.t = (h.y - r.y) / r.b;
     h.x = r.x + h.t * r.a;
-    hit_done(P, h);
+    hit_done<F>(P, h);
     return h;
   }
   double t1, t2;
   bracket(P, g.axis, g.positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
   double x1, y1, z1, x2, y2, z2;
-  double dz1 = find_dz(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x1, y1, z1);
-  double dz2 = find_dz(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
+  double dz1 = find_dz<F>(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x1, y1, z1);
+  double dz2 = find_dz<F>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
   const bool ind1 = dz1 <= 0.;
   const bool ind2 = dz2 >= 0.;
   h.lost = ind1 ? 1 : 0;
@@ -722,7 +735,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.x = x1;
     h.y = y1;
     h.z = z1;
-    hit_done(P, h);
+    hit_done<F>(P, h);
     return h;
   }
   if (ind2) {
@@ -730,7 +743,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.x = x2;
     h.y = y2;
     h.z = z2;
-    hit_done(P, h);
+    hit_done<F>(P, h);
     return h;
   }
   const double tMinG = g.t1min, tMaxG = g.t2max;
@@ -747,7 +760,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
       t2 = t - (t1 - t) * dz / (dz1 - dz);
       if (t2 < tMinG) t2 = tMinG;
       if (t2 > tMaxG) t2 = tMaxG;
-      dz2 = find_dz(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
+      dz2 = find_dz<F>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
       if (!isnan(dz2) && !isnan(dz1) && sgn(dz2) == sgn(dz1)) {
         t1 = t;
         dz1 = dz;
@@ -787,7 +800,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
       const bool conds = cond1 || cond2 || cond3 || cond4 || cond5;
       if (conds) xs = (xa + xb) / 2.;
       mflag = conds;
-      const double fs = find_dz(P, xs, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
+      const double fs = find_dz<F>(P, xs, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
       xd = xc;
       xc = xb;
       fc = fb;
@@ -822,7 +835,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
   h.x = x2;
   h.y = y2;
   h.z = z2;
-  hit_done(P, h);
+  hit_done<F>(P, h);
   return h;
 }
 
@@ -1086,11 +1099,12 @@ struct Finished {
   double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;  // rotated back for vlb
 };
 
+template <int F>
 __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
                                                const xrt_hip_material& M, const GStat& g,
                                                const LocalRay& r, const Hit& h, RayIn q,
                                                bool has_amp) {
-  Finished F;
+  Finished out;
   q.path += h.t;
   // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
   double n[6];
@@ -1111,13 +1125,13 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     n[0] = n[3] = 0.;
     n[1] = n[4] = nb * inorm;
     n[2] = n[5] = inorm;
-  } else if (P.surf_kind == XRT_HIP_SURF_BLAZED) {  // gratings.py:482-490
+  } else if (surf_is_blazed<F>(P)) {  // gratings.py:482-490
     double y1, yL;
     const bool front = blazed_front(P, h.py, y1, yL);
     n[0] = n[3] = 0.;
     n[1] = n[4] = front ? -P.surf_p[3] : P.surf_p[5];
     n[2] = n[5] = front ? P.surf_p[4] : P.surf_p[6];
-  } else if (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM) {  // parametric.py:233-247
+  } else if (surf_is_param<F>(P)) {  // parametric.py:233-247
     const double A = P.surf_p[4], B = P.surf_p[5];
     const double sp = h.px, phi = h.py;
     double A2s2 = A * A - sp * sp;
@@ -1145,7 +1159,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   double bdn = r.a * n[0] + r.b * n[1] + r.c * n[2];
   if (bdn < -1.) bdn = -1.;
   if (bdn > 1.) bdn = 1.;
-  F.theta = acos(bdn) - kPI / 2.;
+  out.theta = acos(bdn) - kPI / 2.;
   const double bdsn = P.asymmetric ? (r.a * n[3] + r.b * n[4] + r.c * n[5]) : bdn;
 
   int toWhere = 0;  // reflect.py:723-752
@@ -1155,9 +1169,9 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     toWhere = 2;
 
   double ao = r.a, bo = r.b, co = r.c;  // a_out of the reference
-  F.a = r.a;
-  F.b = r.b;
-  F.c = r.c;
+  out.a = r.a;
+  out.b = r.b;
+  out.c = r.c;
   if (toWhere == 0 || toWhere == 2) {
     if (M.kind == XRT_HIP_MAT_CRYSTAL && toWhere == 0) {
       // crystal as a grating, reflect.py:568-612 + 451-469
@@ -1187,9 +1201,9 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       co = r.c - n[2] * 2. * bdn;
     }
     if (toWhere == 0) {
-      F.a = ao;
-      F.b = bo;
-      F.c = co;
+      out.a = ao;
+      out.b = bo;
+      out.c = co;
     }
   } else {  // refraction, reflect.py:894-919
     const double nre = refractive_index(M, q.E, window_of(g)).re;
@@ -1198,9 +1212,9 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     const double n1c = -n1overn2 * bdn;
     const double cosTheta2 = signN * sqrt(1. - n1overn2 * n1overn2 + n1c * n1c);
     const double dn = n1c - cosTheta2;
-    F.a = r.a * n1overn2 + n[0] * dn;
-    F.b = r.b * n1overn2 + n[1] * dn;
-    F.c = r.c * n1overn2 + n[2] * dn;
+    out.a = r.a * n1overn2 + n[0] * dn;
+    out.b = r.b * n1overn2 + n[1] * dn;
+    out.c = r.c * n1overn2 + n[2] * dn;
   }
 
   // coherency matrix into the local s/p frame, reflect.py:948-953:
@@ -1284,24 +1298,24 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   q.Esi = Es.im;
   q.Epr = Ep.re;
   q.Epi = Ep.im;
-  F.lo = q;
+  out.lo = q;
   // rotate back for the virgin-local beam, reflect.py:1106-1110
-  F.vJss = Jss;
-  F.vJpp = Jpp;
-  F.vJsr = Jsr;
-  F.vJsi = Jsi;
-  rot_coherency(cosY, sinY, F.vJss, F.vJpp, F.vJsr, F.vJsi);
+  out.vJss = Jss;
+  out.vJpp = Jpp;
+  out.vJsr = Jsr;
+  out.vJsi = Jsi;
+  rot_coherency(cosY, sinY, out.vJss, out.vJpp, out.vJsr, out.vJsi);
   if (has_amp) {
     const cplx e1 = Es * cosY + Ep * sinY;
     const cplx e2 = Es * (-sinY) + Ep * cosY;
-    F.vEsr = e1.re;
-    F.vEsi = e1.im;
-    F.vEpr = e2.re;
-    F.vEpi = e2.im;
+    out.vEsr = e1.re;
+    out.vEsi = e1.im;
+    out.vEpr = e2.re;
+    out.vEpi = e2.im;
   } else {
-    F.vEsr = F.vEsi = F.vEpr = F.vEpi = 0.;
+    out.vEsr = out.vEsi = out.vEpr = out.vEpi = 0.;
   }
-  return F;
+  return out;
 }
 
 // ---------------------------------------------------------------------------
@@ -1344,6 +1358,7 @@ __device__ __forceinline__ void copy_ray(const xrt_hip_beam& o, const xrt_hip_be
 }
 
 // everything after the solve for one entering ray: state, finish, both stores
+template <int F>
 __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hip_material& M,
                                              const GStat& g, const xrt_hip_beam& in,
                                              const xrt_hip_beam& restore,
@@ -1372,20 +1387,20 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
   double vJss = q.Jss, vJpp = q.Jpp, vJsr = q.Jsr, vJsi = q.Jsi;
   double vEsr = q.Esr, vEsi = q.Esi, vEpr = q.Epr, vEpi = q.Epi;
   if (st == 1) {
-    const Finished F = finish_ray(P, M, g, r, h, q, has_amp);
-    la = F.a;
-    lbb = F.b;
-    lc = F.c;
-    th = F.theta;
-    lo = F.lo;
-    vJss = F.vJss;
-    vJpp = F.vJpp;
-    vJsr = F.vJsr;
-    vJsi = F.vJsi;
-    vEsr = F.vEsr;
-    vEsi = F.vEsi;
-    vEpr = F.vEpr;
-    vEpi = F.vEpi;
+    const Finished fin = finish_ray<F>(P, M, g, r, h, q, has_amp);
+    la = fin.a;
+    lbb = fin.b;
+    lc = fin.c;
+    th = fin.theta;
+    lo = fin.lo;
+    vJss = fin.vJss;
+    vJpp = fin.vJpp;
+    vJsr = fin.vJsr;
+    vJsi = fin.vJsi;
+    vEsr = fin.vEsr;
+    vEsi = fin.vEsi;
+    vEpr = fin.vEpr;
+    vEpi = fin.vEpi;
   }
   if (theta) theta[i] = th;
   store_ray(lb, i, h.x, h.y, h.z, la, lbb, lc, lo.path, lo.E, lo.Jss, lo.Jpp, lo.Jsr, lo.Jsi,
@@ -1433,6 +1448,7 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
 // ---------------------------------------------------------------------------
 // K3 kernels
 // ---------------------------------------------------------------------------
+template <int F>
 __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* gp) {
@@ -1446,10 +1462,10 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused(
   }
   const GStat g = *gp;
   const LocalRay r = load_local(P, in, i);
-  const Hit h = solve_ray(P, g, r);
+  const Hit h = solve_ray<F>(P, g, r);
   int st = rays_good(P, h.x, h.y);
   if (h.lost) st = P.lost_num;
-  complete_ray(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
+  complete_ray<F>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
 }
 
 // crystal path, first half: solve + state; stores t, local hit point and state,
@@ -1466,7 +1482,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
     if (!entering(P, in.state[i])) continue;
     const LocalRay r = load_local(P, in, i);
-    const Hit h = solve_ray(P, g, r);
+    const Hit h = solve_ray<0>(P, g, r);
     int st = rays_good(P, h.x, h.y);
     if (h.lost) st = P.lost_num;
     ht[i] = h.t;
@@ -1539,7 +1555,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_finish(
   h.px = h.x;   // crystals are only combined with non-parametric surfaces (capi check)
   h.py = h.y;
   h.lost = 0;
-  complete_ray(P, M, g, in, restore, lb, vb, theta, i, r, h, hst[i], has_amp);
+  complete_ray<0>(P, M, g, in, restore, lb, vb, theta, i, r, h, hst[i], has_amp);
 }
 
 
@@ -1627,8 +1643,11 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   if (!P.no_intersection_search) {
     hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, part);
     hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, M, in, part, (int)rblocks, g);
-    if (P.surf_kind != XRT_HIP_SURF_BLAZED) {  // its intersection is closed-form: no clamps
-      hipLaunchKernelGGL(reflect_stats_bracket, rgrid, block, 0, st, P, in, g, part);
+    if (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM) {
+      hipLaunchKernelGGL(reflect_stats_bracket<1>, rgrid, block, 0, st, P, in, g, part);
+      hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
+    } else if (P.surf_kind != XRT_HIP_SURF_BLAZED) {  // blazed: closed form, no clamps
+      hipLaunchKernelGGL(reflect_stats_bracket<0>, rgrid, block, 0, st, P, in, g, part);
       hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
     }
   }
@@ -1643,7 +1662,12 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     if (evk1) (void)hipEventRecord(evk1, st);
   } else {
     if (evk0) (void)hipEventRecord(evk0, st);
-    hipLaunchKernelGGL(reflect_fused, grid, block, 0, st, P, M, in, restore, lb, vb, theta, g);
+    if (P.surf_kind >= XRT_HIP_SURF_BLAZED)
+      hipLaunchKernelGGL(reflect_fused<1>, grid, block, 0, st, P, M, in, restore, lb, vb, theta,
+                         g);
+    else
+      hipLaunchKernelGGL(reflect_fused<0>, grid, block, 0, st, P, M, in, restore, lb, vb, theta,
+                         g);
     if (evk1) (void)hipEventRecord(evk1, st);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
