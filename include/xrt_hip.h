@@ -175,6 +175,18 @@ typedef struct xrt_hip_pass {
   int32_t zero_local_not_entering; /* 1: dcm.py:298-303 (lo2 of rays that missed) */
   int32_t force_lost_out;      /* 1: rays of out_virgin that do not end in state {1,2}
                                   get state lost_num (Plate, dcm.py:304-305, 331-332) */
+  /* grating equation instead of specular reflection (material kind 'grating',
+   * reflect.py:840-861 with _grating_deflection :451-469, sign -1). The groove
+   * vector OE.local_g (base.py:688-717): grating_axis -1 = the constant g_const;
+   * 0 / 1 = line density polynomial along x / y:
+   * N = g_rho0 * sum_i (i+1) g_coef[i] coord^i, g = N e_axis. */
+  int32_t grating;
+  int32_t grating_axis;
+  int32_t grating_order;
+  int32_t g_ncoef;
+  double g_rho0;
+  double g_coef[8];
+  double g_const[3];
 } xrt_hip_pass;
 
 #define XRT_HIP_MAT_NONE 0

@@ -55,6 +55,16 @@ def load_case(name):
         p['surface'] = dict(kind='bentflat', R=float(g['surf_R']), y0=p['surfPhysY'][0])
         p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,
                                          'mirror', float(g['mat_rho']))
+    elif name.startswith('g2_grating'):
+        p['surface'] = dict(kind='flat')
+        p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
+                                         'grating', float(g['mat_rho']))
+        p['order'] = int(g['order'])
+        if 'gd_axis' in g.files:
+            p['gratingDensity'] = [str(g['gd_axis'])] + \
+                [float(v) for v in g['gd_coeffs']]
+        else:
+            p['gVector'] = tuple(float(v) for v in g['g_vector'])
     elif name == 'g2_blazed_au':
         p['surface'] = rn.make_blazed(float(g['surf_blaze']), float(g['surf_rho']),
                                       float(g['surf_antiblaze']))

@@ -102,7 +102,8 @@ def flat_params(p):
     """Flatten the parameter dict into npz-storable scalars/arrays."""
     out = {}
     for k, v in p.items():
-        if k in ('surface', 'surface2', 'material', 'material2'):
+        if k in ('surface', 'surface2', 'material', 'material2', 'gratingDensity',
+                 'gVector', 'order'):
             continue
         if v is None:
             out['oe_' + k] = np.array(np.nan)

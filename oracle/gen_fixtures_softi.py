@@ -11,6 +11,11 @@ tests/speed/3_Softi_CXIw2D_speed.py:176-246):
   g2_ellipse_full.npz   same, ellipsoid of revolution (isCylindrical=False)
   g2_ellipse_cyl_nis.npz  reflect(noIntersectionSearch=True) on points that
                         already lie on the surface (what follows a diffract)
+  g2_grating_vls.npz    plane grating with the grating EQUATION (material
+                        kind='grating', reflect.py:840-861, 451-469): VLS line
+                        density polynomial along y, order -1, as a PGM grating
+  g2_grating_const.npz  a subclass with a constant local_g (the SoftiMAX
+                        example's `Grating`), order +1, lines along x
 
 While generating, oracle/reflect_np.py is asserted against the reference.
 
@@ -77,6 +82,42 @@ def main():
     run_reflect('g2_blazed_au', rs, pg, par, beam, mat_rho=np.array(19.32),
                 surf_blaze=np.array(blaze), surf_antiblaze=np.array(pg.antiblaze),
                 surf_rho=np.array(rho))
+
+    # ---------------- grating equation (ray mode) -------------------------
+    mAuG = rm.Material('Au', rho=19.32, kind='grating')
+    for tag, kw, order in (
+            ('g2_grating_vls',
+             dict(gratingDensity=['y', 300., 1., 2.4e-4, -3.1e-8]), -1),
+            ('g2_grating_const', dict(), 1)):
+        bl = raycing.BeamLine()
+        if kw:
+            cls = roe.OE
+        else:
+            class XGrating(roe.OE):
+                def local_g(self, x, y, rho=120.):
+                    return rho, 0, 0          # grooves along y: sagittal mount
+            cls = XGrating
+        gr = cls(bl, 'gr', center=[0, 2000., 0.], pitch=np.radians(2.2),
+                 material=mAuG, order=order, limPhysX=(-3, 3), limPhysY=(-45, 45),
+                 alarmLevel=None, **kw)
+        beam = make_rays(rs, n, 64 if kw else 65, sx=1.0, sz=0.9, sa=3e-5,
+                         sc=2e-5, E=(270., 290.), amplitudes=True, pol='mixed')
+        beam.state[3] = 3
+        beam.state[4] = -4
+        par = oe_params(gr, dict(kind='flat'))
+        par['material'] = material_dict(tables, mAuG)
+        par['order'] = order
+        if kw:
+            par['gratingDensity'] = kw['gratingDensity']
+        else:
+            par['gVector'] = (120., 0, 0)
+        extra = dict(mat_rho=np.array(19.32), order=np.array(order))
+        if kw:
+            extra['gd_axis'] = np.array(kw['gratingDensity'][0])
+            extra['gd_coeffs'] = np.array(kw['gratingDensity'][1:], dtype=float)
+        else:
+            extra['g_vector'] = np.array([120., 0., 0.])
+        run_reflect(tag, rs, gr, par, beam, **extra)
 
     # ---------------- elliptical mirrors (parametric) ---------------------
     pitch = np.radians(1)

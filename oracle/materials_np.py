@@ -84,7 +84,7 @@ def material_amplitude(m, E, beamInDotNormal, fromVacuum=True):
     n1cosAlpha = n1 * cosAlpha
     cosBeta = np.sqrt(1 - (n1/n2)**2*sinAlpha2)
     n2cosBeta = n2 * cosBeta
-    if kind in ('mirror', 'thin mirror'):
+    if kind in ('mirror', 'thin mirror', 'grating'):   # material.py:476
         rs = (n1cosAlpha - n2cosBeta) / (n1cosAlpha + n2cosBeta)
         rp = (n2*cosAlpha - n1*cosBeta) / (n2*cosAlpha + n1*cosBeta)
         if kind == 'thin mirror':

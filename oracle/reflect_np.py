@@ -586,8 +586,24 @@ def rays_good(oe, x, y, is2ndXtal=False):
 
 
 # --------------------------------------------------------------------------
-# crystal-as-grating deflection (reflect.py:451-469, 568-612)
+# grating deflection (reflect.py:451-469); crystal-as-grating (:568-612)
 # --------------------------------------------------------------------------
+def local_g(oe, x, y):
+    """Reciprocal groove vector [1/mm] of OE.local_g (base.py:688-717):
+    polynomial line density ['x'|'y', rho0, p0, p1, ...] or a constant vector."""
+    rhoList = oe.get('gratingDensity')
+    if rhoList is not None:
+        coord = x if rhoList[0] == 'x' else y
+        poly = 0.
+        for ic, coeff in enumerate(rhoList[2:]):
+            poly += (ic+1) * coeff * coord**ic
+        N = rhoList[1] * poly
+        if rhoList[0] == 'x':
+            return N, np.zeros_like(N), np.zeros_like(N)
+        return np.zeros_like(N), N, np.zeros_like(N)
+    return oe.get('gVector', (0, -100., 0))
+
+
 def grating_deflection(a, b, c, E, g, oeNormal, beamInDotNormal, order, sig):
     beamInDotG = a*g[0] + b*g[1] + c*g[2]
     G2 = g[0]**2 + g[1]**2 + g[2]**2
@@ -697,6 +713,8 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
             elif kind == 'crystal':
                 if matSur['geom'].endswith('transmitted'):
                     toWhere = 2
+            elif kind == 'grating':               # reflect.py:743-744
+                toWhere = 3
             elif kind not in ('mirror', 'thin mirror'):
                 raise ValueError('unsupported material kind ' + kind)
 
@@ -717,7 +735,14 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
         else:
             beamInDotSurfaceNormal = beamInDotNormal
 
-        if toWhere in (0, 2):
+        if toWhere == 3:                          # reflect.py:840-861
+            if is_param(surf):
+                raise ValueError('gratings on parametric surfaces not restated')
+            g = local_g(oe, lb.x[goodN], lb.y[goodN])
+            lb.a[goodN], lb.b[goodN], lb.c[goodN] = grating_deflection(
+                lb.a[goodN], lb.b[goodN], lb.c[goodN], lb.E[goodN], g, oeNormal,
+                beamInDotSurfaceNormal, oe.get('order', 1), -1)
+        elif toWhere in (0, 2):
             if kind == 'crystal' and toWhere == 0:
                 a_out, b_out, c_out = asymmetric_reflection_grating(
                     matSur, lb.a[goodN], lb.b[goodN], lb.c[goodN], lb.E[goodN],

@@ -82,6 +82,19 @@ def product_oe(name, g):
     elif name == 'g2_bentflat_rh':
         m = rm.Material('Rh', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.BentFlatMirror(bl, 'vcm', R=float(g['surf_R']), material=m, **common)
+    elif name.startswith('g2_grating'):
+        m = rm.Material('Au', rho=float(g['mat_rho']), kind='grating')
+        if 'gd_axis' in g.files:
+            oe = roe.OE(bl, 'gr', material=m, order=int(g['order']),
+                        gratingDensity=[str(g['gd_axis'])] +
+                        [float(v) for v in g['gd_coeffs']], **common)
+        else:
+            gv = [float(v) for v in g['g_vector']]
+
+            class ConstGrating(roe.OE):
+                def local_g(self, x, y, rho=None):
+                    return gv[0], gv[1], gv[2]
+            oe = ConstGrating(bl, 'gr', material=m, order=int(g['order']), **common)
     elif name == 'g2_blazed_au':
         m = rm.Material('Au', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.BlazedGrating(bl, 'pg', material=m, blaze=float(g['surf_blaze']),

@@ -137,12 +137,38 @@ def test_plot_descriptors():
         xrtp.XYCPlot('b', fluxKind='EsPCA')
 
 
+def test_grating_block_of_the_pass():
+    """gratingDensity / constant local_g -> xrt_hip_pass grating fields."""
+    bl = raycing.BeamLine()
+    m = rm.Material('Au', rho=19.3, kind='grating')
+    g = roe.OE(bl, 'g', material=m, gratingDensity=['y', 300., 1., 2e-4], order=-1)
+    p = g._make_pass(g.pitch, g.roll, g.yaw)
+    assert (p.grating, p.grating_axis, p.grating_order, p.g_ncoef) == (1, 1, -1, 2)
+    assert (p.g_rho0, p.g_coef[0], p.g_coef[1]) == (300., 1., 2e-4)
+    gx, gy, gz = g.local_g(np.array([0., 1.]), np.array([0., 10.]))
+    assert np.array_equal(gy, 300. * (1. + 2 * 2e-4 * np.array([0., 10.])))
+
+    class C(roe.OE):
+        def local_g(self, x, y, rho=None):
+            return 0, -250., 0
+    c = C(bl, 'c', material=m)
+    p = c._make_pass(0., 0., 0.)
+    assert (p.grating, p.grating_axis, p.grating_order) == (1, -1, 1)
+    assert list(p.g_const) == [0., -250., 0.]
+    mirror = roe.OE(bl, 'm', material=rm.Material('Au', rho=19.3, kind='mirror'))
+    assert mirror._make_pass(0., 0., 0.).grating == 0
+
+
 def test_out_of_scope_requests_fail_loudly():
     bl = raycing.BeamLine()
     with pytest.raises(NotImplementedError):
-        roe.OE(bl, 'g', gratingDensity=['y', 300., 1.])
+        roe.OE(bl, 'g', gratingDensity=['y', 300., 1.], order=(1, 2))
     with pytest.raises(NotImplementedError):
         roe.OE(bl, 'p', isParametric=True)
+    with pytest.raises(NotImplementedError):
+        roe.BlazedGrating(bl, 'b', blaze=0.01, rho=300., gratingDensity=['y', 300., 1.])
+    with pytest.raises(NotImplementedError):
+        roe.EllipticalMirrorParam(bl, 'e', p=1000., q=100., f1=[0, 0, 0])
     with pytest.raises(NotImplementedError):
         roe.OE(bl, 'poly', shape=[(0, 0), (1, 0), (0, 1)])
     with pytest.raises(ValueError):

@@ -59,6 +59,13 @@ class Pass(ctypes.Structure):
         ('only_state1_out', ctypes.c_int32),
         ('zero_local_not_entering', ctypes.c_int32),
         ('force_lost_out', ctypes.c_int32),
+        ('grating', ctypes.c_int32),
+        ('grating_axis', ctypes.c_int32),
+        ('grating_order', ctypes.c_int32),
+        ('g_ncoef', ctypes.c_int32),
+        ('g_rho0', ctypes.c_double),
+        ('g_coef', ctypes.c_double * 8),
+        ('g_const', ctypes.c_double * 3),
     ]
 
 

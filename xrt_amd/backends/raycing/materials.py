@@ -84,7 +84,10 @@ class Element(object):
 
 _KINDS = {'mirror': _structs.MAT_MIRROR, 'thin mirror': _structs.MAT_THIN_MIRROR,
           'plate': _structs.MAT_PLATE, 'lens': _structs.MAT_PLATE,
-          'crystal': _structs.MAT_CRYSTAL}
+          'crystal': _structs.MAT_CRYSTAL,
+          # a 'grating' reflects like a mirror (material.py:476); the grating
+          # equation itself is a property of the element (xrt_hip_pass.grating)
+          'grating': _structs.MAT_MIRROR}
 
 
 def _dev_f64(a, device):

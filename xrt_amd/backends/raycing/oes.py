@@ -41,9 +41,9 @@ class OE(object):
                  limPhysY=[-raycing.maxHalfSizeOfOE, raycing.maxHalfSizeOfOE],
                  limOptY=None, isParametric=False, shape='rect',
                  gratingDensity=None, order=None, **kwargs):
-        if figureError is not None or isParametric or gratingDensity is not None:
-            raise NotImplementedError('figure error / parametric / grating OEs are '
-                                      'outside the accelerated path')
+        if figureError is not None or isParametric:
+            raise NotImplementedError('figure error / user-defined parametric OEs '
+                                      'are outside the accelerated path')
         if not isinstance(shape, str):
             raise NotImplementedError('polygon-shaped OEs are outside the '
                                       'accelerated path')
@@ -83,7 +83,11 @@ class OE(object):
         self.limOptY = limOptY
         self.limPhysX = limPhysX
         self.limPhysY = limPhysY
-        self.order = order
+        if order is not None and not isinstance(order, (int, np.integer)):
+            raise NotImplementedError('a sequence of diffraction orders (random '
+                                      'order per ray)')
+        self.order = 1 if order is None else int(order)      # base.py:507-509
+        self.gratingDensity = gratingDensity
         self.footprint = []
 
     # -- asymmetric cut ----------------------------------------------------
@@ -122,6 +126,66 @@ class OE(object):
 
     def local_n2(self, x, y):
         return self.local_n(x, y)
+
+    # -- gratings by the grating equation (base.py:688-717, reflect.py:840-861) --
+    def local_g(self, x, y, rho=-100.):
+        """Reciprocal groove vector [1/mm] at (x, y): the *gratingDensity*
+        polynomial ['x'|'y', rho0, p0, p1, ...] or (0, rho, 0). Subclasses may
+        override it with a CONSTANT vector (evaluated on the host once)."""
+        rhoList = self.gratingDensity
+        if rhoList is not None:
+            coord = x if rhoList[0] == 'x' else y
+            poly = 0.
+            for ic, coeff in enumerate(rhoList[2:]):
+                poly += (ic+1) * coeff * coord**ic
+            N = rhoList[1] * poly
+            if rhoList[0] == 'x':
+                return N, np.zeros_like(N), np.zeros_like(N)
+            return np.zeros_like(N), N, np.zeros_like(N)
+        return 0, rho, 0
+
+    def _is_grating(self):
+        material = self.material
+        if raycing.is_sequence(material):
+            material = material[0] if len(material) == 1 else None
+        if material is None:
+            return False
+        kind = getattr(material, 'kind', None)
+        if kind == 'auto' and self.gratingDensity is not None:   # base.py:1088-1092
+            return True
+        return kind == 'grating'
+
+    def _grating_params(self, p, second=False):
+        p.grating = 0
+        if second or not self._is_grating():
+            return
+        if self.isParametric:
+            raise NotImplementedError('grating equation on a parametric surface')
+        p.grating = 1
+        p.grating_order = int(self.order)
+        rhoList = self.gratingDensity
+        overridden = type(self).local_g is not OE.local_g
+        if rhoList is not None and not overridden:
+            coefs = [float(c) for c in rhoList[2:]]
+            if len(coefs) > 8 or rhoList[0] not in ('x', 'y'):
+                raise NotImplementedError('gratingDensity %r' % (rhoList,))
+            p.grating_axis = 0 if rhoList[0] == 'x' else 1
+            p.g_rho0 = float(rhoList[1])
+            p.g_ncoef = len(coefs)
+            for i, c in enumerate(coefs):
+                p.g_coef[i] = c
+        else:
+            xs = np.array([-0.7, 0., 0.3, 1.1])
+            ys = np.array([0.9, 0., -1.3, 0.2])
+            g = [np.broadcast_to(np.asarray(v, dtype=float), xs.shape)
+                 for v in self.local_g(xs, ys)]
+            if any(np.ptp(v) != 0 for v in g):
+                raise NotImplementedError(
+                    'a user-defined position-dependent local_g: express it as '
+                    'gratingDensity')
+            p.grating_axis = -1
+            for i in range(3):
+                p.g_const[i] = float(g[i][0])
 
     def _surface_height(self, x, y):
         """z of the surface above (x, y), also for parametric surfaces
@@ -233,6 +297,7 @@ class OE(object):
         p.out_to_global = 1 if out_to_global else 0
         p.only_state1_out = 1 if only_state1_out else 0
         p.zero_local_not_entering = 1 if zero_local_not_entering else 0
+        self._grating_params(p, is2ndXtal)
         p.force_lost_out = 1 if force_lost_out else 0
         return p
 

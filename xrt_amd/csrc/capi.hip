@@ -283,6 +283,11 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
     return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
   if (pass->surf_kind >= XRT_HIP_SURF_BLAZED && material->kind == XRT_HIP_MAT_CRYSTAL)
     return fail(XRT_HIP_ERR_ARG, "crystals on blazed / parametric surfaces are not supported");
+  if (pass->grating && (pass->grating_axis < -1 || pass->grating_axis > 1 ||
+                        pass->g_ncoef < 0 || pass->g_ncoef > 8))
+    return fail(XRT_HIP_ERR_ARG, "bad grating description");
+  if (pass->grating && material->kind == XRT_HIP_MAT_CRYSTAL)
+    return fail(XRT_HIP_ERR_ARG, "grating equation on a crystal material");
   if (pass->invert_normal != 1 && pass->invert_normal != -1)
     return fail(XRT_HIP_ERR_ARG, "invert_normal must be +1 or -1");
   if (material->kind < XRT_HIP_MAT_NONE || material->kind > XRT_HIP_MAT_CRYSTAL)

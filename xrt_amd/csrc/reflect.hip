@@ -1195,6 +1195,35 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       ao /= nm;   // directions are compared at 1e-12: exact quotients here
       bo /= nm;
       co /= nm;
+    } else if (P.grating) {
+      // grating equation, reflect.py:840-861 + 451-469 (sign -1); the groove
+      // vector of OE.local_g (base.py:688-717)
+      double g0 = P.g_const[0], g1 = P.g_const[1], g2 = P.g_const[2];
+      if (P.grating_axis >= 0) {
+        const double coord = P.grating_axis == 0 ? h.x : h.y;
+        double poly = 0.;
+        for (int ic = 0; ic < P.g_ncoef; ++ic) {
+          const double pw = ic == 0 ? 1. : ic == 1 ? coord : ic == 2 ? coord * coord
+                                                                    : pow(coord, (double)ic);
+          poly += ((double)(ic + 1) * P.g_coef[ic]) * pw;
+        }
+        const double N = P.g_rho0 * poly;
+        g0 = P.grating_axis == 0 ? N : 0.;
+        g1 = P.grating_axis == 0 ? 0. : N;
+        g2 = 0.;
+      }
+      const double bdg = r.a * g0 + r.b * g1 + r.c * g2;
+      const double G2 = g0 * g0 + g1 * g1 + g2 * g2;
+      const double ol = (double)P.grating_order * kCH / q.E * 1e-7;
+      const double u = bdsn * bdsn - 2. * bdg * ol - G2 * (ol * ol);
+      const double dn = bdsn + -1. * sqrt(fabs(u));
+      ao = r.a - n[3] * dn + g0 * ol;
+      bo = r.b - n[4] * dn + g1 * ol;
+      co = r.c - n[5] * dn + g2 * ol;
+      const double nm = sqrt(ao * ao + bo * bo + co * co);
+      ao /= nm;
+      bo /= nm;
+      co /= nm;
     } else {  // specular, reflect.py:875-877
       ao = r.a - n[0] * 2. * bdn;
       bo = r.b - n[1] * 2. * bdn;
