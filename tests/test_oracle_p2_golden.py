@@ -79,3 +79,16 @@ def test_cl_convention_mapping_cancels_in_post(golden_dir):
     for key in ('Jss', 'Jpp', 'a', 'b', 'c'):
         assert np.allclose(r0[key], r1[key], rtol=1e-10, atol=1e-12 * np.abs(r0[key]).max())
     assert np.allclose(r0['Es'], -r1['Es'], rtol=1e-12)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_c_openmp_restatement_matches_reference(golden_dir, name):
+    """oracle/kirchhoff_c.c (all-core CPU baseline of bench.py) against the
+    reference's raw integrals; sequential instead of pairwise summation."""
+    from oracle import kirchhoff_c as kc
+    from oracle.consts import CHBAR
+    g = _load(golden_dir, name)
+    px, py, pz, sx, sy, sz, n, nl, E, Es, Ep = _inputs(g)
+    raw = kc.kirchhoff(px, py, pz, sx, sy, sz, n, nl, E / CHBAR * 1e7, Es, Ep)
+    for mine, ref in zip(raw, g['raw']):
+        assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max()
