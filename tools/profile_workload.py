@@ -39,5 +39,22 @@ if '--no-kirchhoff' not in sys.argv:
     hipcalls.kirchhoff(up(h['px']), up(h['py']), up(h['pz']), up(h['sx']), up(h['sy']), up(h['sz']),
                        up(np.zeros(ns)), up(np.ones(ns)), up(np.zeros(ns)), up(h['nl']), up(h['k']),
                        up(h['Es'], np.complex128), up(h['Ep'], np.complex128))
+# undulator field map (N3): 2^20 rays x 48 nodes, far field
+from xrt_amd.backends.raycing.undulator import clenshaw_curtis  # noqa: E402
+rng = np.random.RandomState(5)
+nr = 1 << 20
+xk, wk = clenshaw_curtis(24)
+dstep = np.pi
+dI = np.arange(-np.pi + 0.5 * dstep, np.pi, dstep)
+tg = (dI[:, None] + 0.5 * dstep * xk).ravel()
+ag = (dI[:, None] * 0 + wk).ravel()
+dev = torch.device('cuda', 0)
+upd = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+tabs = [upd(t) for t in (tg, ag, np.sin(tg), np.cos(tg), np.sin(tg), np.cos(tg))]
+w, th, ps = (upd(rng.uniform(3900., 4250., nr)), upd(rng.uniform(-3e-5, 3e-5, nr)),
+             upd(rng.uniform(-3e-5, 3e-5, nr)))
+for _ in range(reps):
+    hipcalls.undulator_imap(0, 0., 0.52, tabs, w, th, ps, 18.5, 108, 5870.853297866972,
+                            0.5, dstep, True)
 torch.cuda.synchronize()
 print('done')

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace of the default bench.py
+# and the two HBM counter passes on tools/profile_workload.py; summaries go to
+# profiles/ (copied back through gpurun_out/).
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh 01'
+set -u
+RND=${1:-01}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/prof_r$RND
+rm -rf $O && mkdir -p $O
+rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python bench.py > $O/bench_under_rocprof.json 2> $O/trace.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch -- python tools/profile_workload.py > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write -- python tools/profile_workload.py > $O/write.log 2>&1
+T=$(find $O/trace -name '*.db' | head -1); F=$(find $O/fetch -name '*.db' | head -1); W=$(find $O/write -name '*.db' | head -1)
+echo "dbs: $T $F $W"
+python tools/rocpd_summary.py $RND "$T" "$F" "$W" 1e7
+mkdir -p $O/summaries && cp profiles/r${RND}_kernel_stats.csv profiles/hbm_traffic.json $O/summaries/
+tail -c 600 $O/bench_under_rocprof.json | head -c 600; echo
+find $O -name '*.db' -size +40M -delete

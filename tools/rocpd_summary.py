@@ -19,7 +19,9 @@ import sys
 
 OURS = ('reflect_fused', 'reflect_solve', 'reflect_finish', 'reflect_stats_dir',
         'reflect_stats_bracket', 'screen_expose_kernel', 'kirchhoff_stream',
-        'kirchhoff_pack', 'kirchhoff_finalize')
+        'kirchhoff_pack', 'kirchhoff_finalize', 'und_imap', 'und_sum', 'und_pack',
+        'aperture_propagate_kernel', 'hist2d_kernel', 'reflect_decide_axis',
+        'reflect_reduce_bracket', 'reflect_reduce_bdn', 'reflect_init')
 
 
 def short(name):
@@ -29,12 +31,25 @@ def short(name):
     return name.split('(')[0][-60:]
 
 
+def variant(name):
+    """short name + the template argument, e.g. reflect_fused<0>"""
+    k = short(name)
+    i = name.find(k)
+    if i >= 0 and name[i + len(k):i + len(k) + 1] == '<':
+        j = name.find('>', i)
+        k += name[i + len(k):j + 1]
+    return k
+
+
 def kernel_stats(db):
+    """One row per (kernel, launch size): the same kernel is launched on 1e7-ray
+    beams by the primary bench and on 2e5-sample waves by the SoftiMAX chain;
+    an average over both would match neither."""
     c = sqlite3.connect(db)
-    rows = c.execute('select name, count(*), sum(duration), avg(duration), '
-                     'min(duration), max(duration) from kernels group by name '
+    rows = c.execute('select name, grid_x, count(*), sum(duration), avg(duration), '
+                     'min(duration), max(duration) from kernels group by name, grid_x '
                      'order by sum(duration) desc').fetchall()
-    return [(short(r[0]),) + tuple(r[1:]) for r in rows]
+    return [(variant(r[0]),) + tuple(r[1:]) for r in rows]
 
 
 def counter_per_launch(db, counter):
@@ -54,12 +69,13 @@ def main():
     path = os.path.join(out, 'r%s_kernel_stats.csv' % rnd)
     with open(path, 'w', newline='') as f:
         w = csv.writer(f)
-        w.writerow(['kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns'])
+        w.writerow(['kernel', 'grid_threads', 'calls', 'total_ns', 'avg_ns', 'min_ns',
+                    'max_ns'])
         for r in stats:
-            w.writerow([r[0], r[1], int(r[2]), round(r[3], 1), r[4], r[5]])
+            w.writerow([r[0], r[1], r[2], int(r[3]), round(r[4], 1), r[5], r[6]])
     print('wrote', path)
-    for r in stats[:12]:
-        print('  %-28s calls %4d  avg %12.1f us' % (r[0], r[1], r[3] / 1e3))
+    for r in stats[:14]:
+        print('  %-28s grid %9d calls %4d  avg %12.1f us' % (r[0], r[1], r[2], r[4] / 1e3))
     if len(sys.argv) >= 5:
         nrays = float(sys.argv[5]) if len(sys.argv) > 5 else 1e7
         fetch = counter_per_launch(sys.argv[3], 'FETCH_SIZE')

@@ -7,6 +7,10 @@
 #include "../../include/xrt_hip.h"
 
 #define REFLECT_BLOCK 256
+// waves per SIMD the fused kernel is compiled for (register budget 512/N VGPRs)
+#ifndef REFLECT_FUSED_WAVES
+#define REFLECT_FUSED_WAVES 4
+#endif
 #define REFLECT_MAX_PART 8192u                    /* partial records (blocks) per reduction */
 #define REFLECT_PART_BYTES (REFLECT_MAX_PART * 64) /* 8 doubles each */
 

@@ -1099,10 +1099,32 @@ struct Finished {
   double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;  // rotated back for vlb
 };
 
+// The coherency matrix and the field amplitudes of the incoming ray (8 doubles)
+// are loaded only after the geometry and the Fresnel / Bragg amplitudes are done:
+// keeping them live across that code was what spilled to scratch.
+__device__ __forceinline__ void load_fields(const xrt_hip_beam& in, int64_t i, bool has_amp,
+                                            RayIn& q) {
+  q.Jss = in.Jss[i];
+  q.Jpp = in.Jpp[i];
+  const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
+  q.Jsr = js.x;
+  q.Jsi = js.y;
+  q.Esr = q.Esi = q.Epr = q.Epi = 0.;
+  if (has_amp) {
+    const double2 es = reinterpret_cast<const double2*>(in.Es_ri)[i];
+    const double2 ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
+    q.Esr = es.x;
+    q.Esi = es.y;
+    q.Epr = ep.x;
+    q.Epi = ep.y;
+  }
+}
+
 template <int F>
 __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
                                                const xrt_hip_material& M, const GStat& g,
                                                const LocalRay& r, const Hit& h, RayIn q,
+                                               const xrt_hip_beam& in, int64_t i,
                                                bool has_amp) {
   Finished out;
   q.path += h.t;
@@ -1202,10 +1224,13 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       if (P.grating_axis >= 0) {
         const double coord = P.grating_axis == 0 ? h.x : h.y;
         double poly = 0.;
+        // coord**ic: exact for ic <= 2 like numpy's; for higher powers numpy
+        // calls pow() (one rounding), here repeated products (ic-1 roundings,
+        // <= 3 ulp on terms that are ~1e-6 of the line density)
+        double pw = 1.;
         for (int ic = 0; ic < P.g_ncoef; ++ic) {
-          const double pw = ic == 0 ? 1. : ic == 1 ? coord : ic == 2 ? coord * coord
-                                                                    : pow(coord, (double)ic);
           poly += ((double)(ic + 1) * P.g_coef[ic]) * pw;
+          pw *= coord;
         }
         const double N = P.g_rho0 * poly;
         g0 = P.grating_axis == 0 ? N : 0.;
@@ -1259,15 +1284,6 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     cosY = -P.cos_roll;
     sinY = -P.sin_roll;
   }
-  double Jss = q.Jss, Jpp = q.Jpp, Jsr = q.Jsr, Jsi = q.Jsi;
-  rot_coherency(cosY, -sinY, Jss, Jpp, Jsr, Jsi);
-  cplx Es = C(q.Esr, q.Esi), Ep = C(q.Epr, q.Epi);
-  if (has_amp) {
-    const cplx e1 = Es * cosY + Ep * (-sinY);
-    const cplx e2 = Es * sinY + Ep * cosY;
-    Es = e1;
-    Ep = e2;
-  }
   // amplitudes, reflect.py:955-1035
   Ampl A;
   A.rs = C(1., 0.);
@@ -1282,6 +1298,17 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   }
   if (cisnan(A.rs)) A.rs = C(0., 0.);
   if (cisnan(A.rp)) A.rp = C(0., 0.);
+  // now the fields of the incoming ray, rotated into the local s/p frame
+  load_fields(in, i, has_amp, q);
+  double Jss = q.Jss, Jpp = q.Jpp, Jsr = q.Jsr, Jsi = q.Jsi;
+  rot_coherency(cosY, -sinY, Jss, Jpp, Jsr, Jsi);
+  cplx Es = C(q.Esr, q.Esi), Ep = C(q.Epr, q.Epi);
+  if (has_amp) {
+    const cplx e1 = Es * cosY + Ep * (-sinY);
+    const cplx e2 = Es * sinY + Ep * cosY;
+    Es = e1;
+    Ep = e2;
+  }
   // J' and E', reflect.py:1038-1064
   const double as2 = A.rs.re * A.rs.re + A.rs.im * A.rs.im;
   const double ap2 = A.rp.re * A.rp.re + A.rp.im * A.rp.im;
@@ -1397,26 +1424,11 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
   RayIn q;
   q.path = in.path[i];
   q.E = in.E[i];
-  q.Jss = in.Jss[i];
-  q.Jpp = in.Jpp[i];
-  const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
-  q.Jsr = js.x;
-  q.Jsi = js.y;
-  q.Esr = q.Esi = q.Epr = q.Epi = 0.;
-  if (has_amp) {
-    const double2 es = reinterpret_cast<const double2*>(in.Es_ri)[i];
-    const double2 ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
-    q.Esr = es.x;
-    q.Esi = es.y;
-    q.Epr = ep.x;
-    q.Epi = ep.y;
-  }
   double la = r.a, lbb = r.b, lc = r.c, th = 0.;
-  RayIn lo = q;
-  double vJss = q.Jss, vJpp = q.Jpp, vJsr = q.Jsr, vJsi = q.Jsi;
-  double vEsr = q.Esr, vEsi = q.Esi, vEpr = q.Epr, vEpi = q.Epi;
+  RayIn lo;
+  double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;
   if (st == 1) {
-    const Finished fin = finish_ray<F>(P, M, g, r, h, q, has_amp);
+    const Finished fin = finish_ray<F>(P, M, g, r, h, q, in, i, has_amp);
     la = fin.a;
     lbb = fin.b;
     lc = fin.c;
@@ -1430,6 +1442,17 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
     vEsi = fin.vEsi;
     vEpr = fin.vEpr;
     vEpi = fin.vEpi;
+  } else {
+    load_fields(in, i, has_amp, q);
+    lo = q;
+    vJss = q.Jss;
+    vJpp = q.Jpp;
+    vJsr = q.Jsr;
+    vJsi = q.Jsi;
+    vEsr = q.Esr;
+    vEsi = q.Esi;
+    vEpr = q.Epr;
+    vEpi = q.Epi;
   }
   if (theta) theta[i] = th;
   store_ray(lb, i, h.x, h.y, h.z, la, lbb, lc, lo.path, lo.E, lo.Jss, lo.Jpp, lo.Jsr, lo.Jsi,
@@ -1478,7 +1501,7 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
 // K3 kernels
 // ---------------------------------------------------------------------------
 template <int F>
-__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused(
+__global__ __launch_bounds__(REFLECT_BLOCK, REFLECT_FUSED_WAVES) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* gp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
