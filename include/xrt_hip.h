@@ -314,6 +314,29 @@ XRT_HIP_API int xrt_hip_hist2d_f64_dev(
     int bins_x, double x_lo, double x_hi, int bins_y, double y_lo, double y_hi,
     double* hist, double* counters, void* stream);
 
+/* ---- all histograms of one XYCPlot in one pass ----------------------------
+ * multipro.py:316-361: cData01 = clip((c - c_lim0) colorFactor/(c_lim1 - c_lim0));
+ * RGB = hsv_to_rgb(cData01, colorSaturation, flux); then np.histogram on x, y, c
+ * (weights flux and R, G, B) and np.histogram2d(y, x) (weights intensity and
+ * R, G, B). flux = intensity for the supported flux kinds.
+ * c: device array of the colour datum (e.g. beam.E). Outputs are ACCUMULATED:
+ * hist2d [by][bx], hist2d_rgb [by][bx][3] (may be NULL), hist_x [bx][4] =
+ * (flux, R, G, B) per bin, hist_y [by][4], hist_c [bc][4] (each may be NULL).
+ * counters as in xrt_hip_hist2d_f64_dev. */
+typedef struct xrt_hip_plot {
+  double x_factor, y_factor, c_factor;
+  double source_weight;
+  double x_lim[2], y_lim[2], c_lim[2];
+  double color_factor, color_saturation;
+  int32_t bins_x, bins_y, bins_c;
+  int32_t ray_flags, flux_kind;
+} xrt_hip_plot;
+
+XRT_HIP_API int xrt_hip_plot_hist_f64_dev(
+    const xrt_hip_beam* beam, const double* x, const double* y, const double* c,
+    const xrt_hip_plot* plot, double* hist2d, double* hist2d_rgb, double* hist_x,
+    double* hist_y, double* hist_c, double* counters, void* stream);
+
 /* ---- undulator field integral -------------------------
  * Replaces run_parallel('undulator' | 'undulator_taper' | 'undulator_nf', ...)
  * as issued by Undulator._build_I_map_CL (sources/synchr.py:2110-2176; kernels

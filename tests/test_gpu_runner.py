@@ -90,3 +90,59 @@ def test_rays_on_bin_edges_follow_numpy():
                                weights=b.Jss + b.Jpp)
     assert np.array_equal(plot.total2D, ref)
     assert plot.intensityInRange == ref.sum() and plot.intensity == n
+
+
+def test_colour_and_1d_histograms_match_numpy_and_matplotlib():
+    """The complete per-plot reduce of multipro.py:316-361: hue from the colour
+    axis (energy), hsv_to_rgb with value = flux, three 1-D histograms with
+    flux / R / G / B weights, 2-D intensity and RGB histograms."""
+    import matplotlib.colors as mc
+    bl = build()
+    kept = []
+
+    def run_process(beamLine):
+        b0 = beamLine.src.shine()
+        gb, lb = beamLine.m1.reflect(b0)
+        kept.append(lb)
+        return {'beamM1local': lb}
+    rr.run_process = run_process
+    np.random.seed(12)
+    plot = xrtp.XYCPlot(
+        'beamM1local', (1, 3), xrtp.XYCAxis('x', 'mm', limits=[-0.8, 0.8], bins=40),
+        xrtp.XYCAxis('y', 'mm', limits=[-250, 250], bins=36),
+        caxis=xrtp.XYCAxis('energy', 'eV', limits=[8992., 9008.], bins=50),
+        fluxKind='total')
+    xrtr.run_ray_tracing([plot], repeats=2, beamLine=bl)
+    ref2 = np.zeros((36, 40))
+    ref2rgb = np.zeros((36, 40, 3))
+    r1 = {k: np.zeros((n, 4)) for k, n in (('x', 40), ('y', 36), ('c', 50))}
+    for lb in kept:
+        sel = (lb.state == 1) | (lb.state == 3)
+        x, y, c = lb.x[sel], lb.y[sel], lb.E[sel]
+        flux = (lb.Jss + lb.Jpp)[sel]
+        c01 = ((c - 8992.) * plot.colorFactor / (9008. - 8992.)).reshape(-1, 1)
+        c01[c01 < 0] = 0.
+        c01[c01 > 1] = 1.
+        hsv = np.dstack((c01, np.ones_like(c01) * plot.colorSaturation,
+                         flux.reshape(-1, 1)))
+        rgb = mc.hsv_to_rgb(hsv).reshape(-1, 3)
+        ref2 += np.histogram2d(y, x, bins=[36, 40], range=[[-250, 250], [-0.8, 0.8]],
+                               weights=flux)[0]
+        for k in range(3):
+            ref2rgb[:, :, k] += np.histogram2d(
+                y, x, bins=[36, 40], range=[[-250, 250], [-0.8, 0.8]],
+                weights=rgb[:, k])[0]
+        for key, v, n, lim in (('x', x, 40, (-0.8, 0.8)), ('y', y, 36, (-250, 250)),
+                               ('c', c, 50, (8992., 9008.))):
+            r1[key][:, 0] += np.histogram(v, bins=n, range=lim, weights=flux)[0]
+            for k in range(3):
+                r1[key][:, 1 + k] += np.histogram(v, bins=n, range=lim,
+                                                  weights=rgb[:, k])[0]
+    tol = 1e-10
+    assert np.abs(plot.total2D - ref2).max() <= tol * ref2.max()
+    assert np.abs(plot.total2D_RGB - ref2rgb).max() <= tol * ref2rgb.max()
+    for key, axis in (('x', plot.xaxis), ('y', plot.yaxis), ('c', plot.caxis)):
+        assert np.abs(axis.total1D4 - r1[key]).max() <= tol * r1[key].max(), key
+    # the 1-D histograms see rays that fall outside the other axis' range
+    assert plot.total1D_x.sum() > plot.total2D.sum() * (1 + 1e-6)
+    assert np.array_equal(plot.total1D_c, plot.caxis.total1D4[:, 0])

@@ -47,6 +47,8 @@ SIGNATURES = {
         vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
         ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double,
         ctypes.c_int, ctypes.c_double, ctypes.c_double, vp, vp, vp]),
+    'xrt_hip_plot_hist_f64_dev': (ctypes.c_int, [
+        vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_undulator_workspace_bytes': (ctypes.c_size_t, [i64]),
     'xrt_hip_undulator_f64_dev': (ctypes.c_int, [
         vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp,

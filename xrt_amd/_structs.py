@@ -149,5 +149,22 @@ class UndulatorMap(ctypes.Structure):
                 ('dist_bw', ctypes.c_int32)]
 
 
+class Plot(ctypes.Structure):
+    _fields_ = [('x_factor', ctypes.c_double),
+                ('y_factor', ctypes.c_double),
+                ('c_factor', ctypes.c_double),
+                ('source_weight', ctypes.c_double),
+                ('x_lim', ctypes.c_double * 2),
+                ('y_lim', ctypes.c_double * 2),
+                ('c_lim', ctypes.c_double * 2),
+                ('color_factor', ctypes.c_double),
+                ('color_saturation', ctypes.c_double),
+                ('bins_x', ctypes.c_int32),
+                ('bins_y', ctypes.c_int32),
+                ('bins_c', ctypes.c_int32),
+                ('ray_flags', ctypes.c_int32),
+                ('flux_kind', ctypes.c_int32)]
+
+
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
-           UndulatorMap)
+           UndulatorMap, Plot)

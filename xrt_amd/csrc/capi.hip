@@ -245,6 +245,7 @@ int xrt_hip_sizeof(int which) {
     case 5: return (int)sizeof(xrt_hip_aperture);
     case 6: return (int)sizeof(xrt_hip_undulator);
     case 7: return (int)sizeof(xrt_hip_undulator_map);
+    case 8: return (int)sizeof(xrt_hip_plot);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -431,6 +432,25 @@ int xrt_hip_hist2d_f64_dev(const xrt_hip_beam* beam, const double* x, const doub
   HIP_TRY(xrt::hist2d_launch(*beam, x, y, x_factor, y_factor, ray_flags, flux_kind,
                              source_weight, bins_x, x_lo, x_hi, bins_y, y_lo, y_hi, hist,
                              counters, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_plot_hist_f64_dev(const xrt_hip_beam* beam, const double* x, const double* y,
+                              const double* c, const xrt_hip_plot* plot, double* hist2d,
+                              double* hist2d_rgb, double* hist_x, double* hist_y,
+                              double* hist_c, double* counters, void* stream) {
+  if (!beam || !plot) return fail(XRT_HIP_ERR_ARG, "NULL beam / plot");
+  int rc;
+  if ((rc = check_beam(beam, "beam", beam->n, false))) return rc;
+  if (plot->bins_x < 1 || plot->bins_y < 1 || (hist_c && plot->bins_c < 1))
+    return fail(XRT_HIP_ERR_ARG, "bins must be >= 1");
+  if (!(plot->x_lim[1] > plot->x_lim[0]) || !(plot->y_lim[1] > plot->y_lim[0]) ||
+      !(plot->c_lim[1] > plot->c_lim[0]))
+    return fail(XRT_HIP_ERR_ARG, "empty histogram range");
+  if (plot->flux_kind < 0 || plot->flux_kind > 5) return fail(XRT_HIP_ERR_ARG, "unknown flux kind");
+  if (beam->n > 0 && (!x || !y || !c || !hist2d)) return fail(XRT_HIP_ERR_ARG, "NULL array");
+  HIP_TRY(xrt::plot_hist_launch(*beam, x, y, c, *plot, hist2d, hist2d_rgb, hist_x, hist_y,
+                                hist_c, counters, reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
 }
 

@@ -35,12 +35,19 @@ class XYCAxis(object):
 class XYCPlot(object):
     def __init__(self, beam=None, rayFlag=(1,), xaxis=None, yaxis=None, caxis=None,
                  aspect='equal', title='', fluxKind='total', beamState=None,
-                 **kwargs):
+                 ePos=1, colorFactor=0.85, colorSaturation=0.85, **kwargs):
         self.beam = beam
         self.rayFlag = tuple(rayFlag)
         self.xaxis = xaxis if xaxis is not None else XYCAxis('x', 'mm')
         self.yaxis = yaxis if yaxis is not None else XYCAxis('z', 'mm')
-        self.caxis = caxis
+        # colour axis (xrt/plotter.py: caxis='category' colours by ray state and
+        # is not mirrored): default = energy in eV
+        if caxis == 'category':
+            raise NotImplementedError("caxis='category'")
+        self.caxis = caxis if caxis is not None else XYCAxis('energy', 'eV', bins=128)
+        self.ePos = ePos
+        self.colorFactor = colorFactor          # xrt/plotter.py defaults
+        self.colorSaturation = colorSaturation
         self.title = title or str(beam)
         if not any(fluxKind.startswith(k) for k in _FLUX):
             raise NotImplementedError('fluxKind %r' % fluxKind)
@@ -50,6 +57,12 @@ class XYCPlot(object):
 
     def reset_bins2D(self):
         self.total2D = np.zeros((self.yaxis.bins, self.xaxis.bins))
+        self.total2D_RGB = np.zeros((self.yaxis.bins, self.xaxis.bins, 3))
+        # 1-D histograms, accumulated like xrt/plotter.py's *axis.total1D* and
+        # *total1D_RGB*: column 0 = flux weights, columns 1..3 = R, G, B
+        self.xaxis.total1D4 = np.zeros((self.xaxis.bins, 4))
+        self.yaxis.total1D4 = np.zeros((self.yaxis.bins, 4))
+        self.caxis.total1D4 = np.zeros((self.caxis.bins, 4))
         self.nRaysAll = 0
         self.nRaysSelected = 0
         self.nRaysAlive = 0
@@ -87,11 +100,17 @@ class XYCPlot(object):
 
     @property
     def total1D_x(self):
-        return self.total2D.sum(axis=0)
+        """1-D histogram of x over ALL selected rays (np.histogram on x alone,
+        multipro.py:338): not the marginal of the 2-D histogram."""
+        return self.xaxis.total1D4[:, 0]
 
     @property
     def total1D_y(self):
-        return self.total2D.sum(axis=1)
+        return self.yaxis.total1D4[:, 0]
+
+    @property
+    def total1D_c(self):
+        return self.caxis.total1D4[:, 0]
 
     def edges(self):
         return (np.linspace(self.xaxis.limits[0], self.xaxis.limits[1],

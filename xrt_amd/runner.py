@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, _structs
 from .backends.raycing import run as rr
 
 
@@ -39,9 +39,20 @@ def accumulate_plot(plot, beams):
             if hi <= lo:
                 lo, hi = lo - 0.5, hi + 0.5
             axis.limits = [lo, hi]
-    hist = torch.zeros((plot.yaxis.bins, plot.xaxis.bins), dtype=torch.float64,
-                       device=dev)
-    counters = torch.zeros(8, dtype=torch.float64, device=dev)
+    cax = plot.caxis
+    cdat = _axis_tensor(beam, cax.field(), dev).contiguous()
+    if cax.limits is None:
+        sel = beam.dev('state', dev) == 1
+        v = cdat[sel] * cax.factor if bool(sel.any()) else cdat * cax.factor
+        lo, hi = float(v.min()), float(v.max())
+        if hi <= lo:
+            lo, hi = lo - 0.5, hi + 0.5
+        cax.limits = [lo, hi]
+    nx, ny, nc = plot.xaxis.bins, plot.yaxis.bins, cax.bins
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)  # noqa: E731
+    hist, hist_rgb = z(ny, nx), z(ny, nx, 3)
+    hx, hy, hc = z(nx, 4), z(ny, 4), z(nc, 4)
+    counters = z(8)
     srcw = beam.nrays * beam.sourceWeight if hasattr(beam, 'sourceWeight') else 1.
     state_beam = beam if plot.beamState is None else beams[plot.beamState]
     s = beam.to_struct(dev)
@@ -49,15 +60,27 @@ def accumulate_plot(plot, beams):
         keep = state_beam.dev('state', dev)
         s.state = keep.data_ptr()
         s._keep.append(keep)
-    _lib.check(lib.xrt_hip_hist2d_f64_dev(
-        ctypes.byref(s), ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(y.data_ptr()),
-        float(plot.xaxis.factor), float(plot.yaxis.factor), plot.ray_flag_mask,
-        plot.flux_kind_code, float(srcw), plot.xaxis.bins,
-        float(plot.xaxis.limits[0]), float(plot.xaxis.limits[1]), plot.yaxis.bins,
-        float(plot.yaxis.limits[0]), float(plot.yaxis.limits[1]),
-        ctypes.c_void_p(hist.data_ptr()), ctypes.c_void_p(counters.data_ptr()),
+    P = _structs.Plot()
+    P.x_factor, P.y_factor, P.c_factor = (float(plot.xaxis.factor),
+                                          float(plot.yaxis.factor), float(cax.factor))
+    P.source_weight = float(srcw)
+    for lim, axis in ((P.x_lim, plot.xaxis), (P.y_lim, plot.yaxis), (P.c_lim, cax)):
+        lim[0], lim[1] = float(axis.limits[0]), float(axis.limits[1])
+    P.color_factor = float(plot.colorFactor)
+    P.color_saturation = float(plot.colorSaturation)
+    P.bins_x, P.bins_y, P.bins_c = nx, ny, nc
+    P.ray_flags, P.flux_kind = plot.ray_flag_mask, plot.flux_kind_code
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(lib.xrt_hip_plot_hist_f64_dev(
+        ctypes.byref(s), ptr(x), ptr(y), ptr(cdat), ctypes.byref(P), ptr(hist),
+        ptr(hist_rgb), ptr(hx), ptr(hy), ptr(hc) if plot.ePos else None, ptr(counters),
         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-        'xrt_hip_hist2d_f64_dev')
+        'xrt_hip_plot_hist_f64_dev')
+    plot.total2D_RGB += hist_rgb.cpu().numpy()
+    plot.xaxis.total1D4 += hx.cpu().numpy()
+    plot.yaxis.total1D4 += hy.cpu().numpy()
+    if plot.ePos:
+        cax.total1D4 += hc.cpu().numpy()
     c = counters.cpu().numpy()
     plot.total2D += hist.cpu().numpy()
     plot.nRaysAll += beam.nrays
