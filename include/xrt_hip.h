@@ -404,6 +404,38 @@ XRT_HIP_API int xrt_hip_undulator_imap_f64_dev(
     double* I, double* Es_ri, double* Ep_ri, void* workspace, size_t workspace_bytes,
     void* stream);
 
+/* ---- field sums of a source with a tabulated magnetic field ----------------
+ * Replaces run_parallel('custom_field' | 'custom_field_filament', ...) of
+ * SourceFromField._build_I_map_custom_field_CL (sources/synchr.py:1157-1272;
+ * kernels cl/undulator.cl:822-1103); arithmetic of the numpy path
+ * SourceFromField._sp_sum (synchr.py:888-973). Node tables on the integration
+ * grid (built by the caller's trajectory integration): tg, ag, Bx, By, Bz, betax,
+ * betay, trajx, trajy, trajz [jend]. Per ray: emcg (= SIE0/SIM0/C/10/gamma),
+ * gamma, w, ddphi, ddpsi. betam = betazav[-1]; near_field: screen at R0 [mm].
+ * Outputs Is, Ip complex128 [nrays]. Workspace as for the undulator sums. */
+typedef struct xrt_hip_custom_field {
+  int32_t filament;
+  int32_t near_field;
+  double betam;
+  double R0;
+  double wc;        /* filament only: if > 0, the carrier w E2WC / betam given by the caller
+                       (what the OpenCL kernel receives, synchr.py:1206); 0: derived
+                       from w, gamma, betam as _sp_sum does */
+  int64_t jend;
+  const double *tg, *ag, *Bx, *By, *Bz, *betax, *betay, *trajx, *trajy, *trajz;
+} xrt_hip_custom_field;
+
+XRT_HIP_API int xrt_hip_custom_field_f64_dev(
+    const xrt_hip_custom_field* f, int64_t nrays, const double* emcg, const double* gamma,
+    const double* w, const double* ddphi, const double* ddpsi, double* Is_ri, double* Ip_ri,
+    void* workspace, size_t workspace_bytes, void* stream, float* kernel_ms);
+
+/* host pointers everywhere; blocking */
+XRT_HIP_API int xrt_hip_custom_field_f64(
+    int device, const xrt_hip_custom_field* f, int64_t nrays, const double* emcg,
+    const double* gamma, const double* w, const double* ddphi, const double* ddpsi,
+    double* Is_ri, double* Ip_ri, float* kernel_ms);
+
 /* ---- building-block checks (used by the GPU tests only) ---------------- */
 XRT_HIP_API int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,
                                void* stream);

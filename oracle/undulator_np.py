@@ -184,3 +184,82 @@ def intensity_map(mode, Kx, Ky, Np, L0, gamma0, eI, dist_e_bw, tab, w, ddtheta,
     return (amp2flux * ab**2 * 0.25 * dstep**2 * field,
             np.sqrt(amp2flux) * ab * Is * 0.5 * dstep,
             np.sqrt(amp2flux) * ab * Ip * 0.5 * dstep)
+
+
+# --------------------------------------------------------------------------
+# custom (tabulated) magnetic field: SourceFromField._sp_sum, synchr.py:888-973
+# (OpenCL twins `custom_field`, `custom_field_filament`, cl/undulator.cl:822-1103)
+# --------------------------------------------------------------------------
+EMC = 0.5866791802416487        # physconsts.py:24
+
+
+def custom_sp_sum(filament, tab, emcg, w, gamma, ddphi, ddpsi, betam, R0=None):
+    """Is, Ip of SourceFromField._sp_sum. `tab`: dict of the node tables tg, ag,
+    Bx, By, Bz, betax, betay, trajx, trajy, trajz on the integration grid;
+    per-ray arrays emcg, w, gamma, ddphi, ddpsi; betam = betazav[-1]; R0: None
+    or the scalar screen distance [mm] (near field).
+
+    Reproduces the reference as written, including its choice of the carrier
+    wc, whose two branches are swapped relative to the vectorised `_sp`
+    (synchr.py:901-902 vs :813-816)."""
+    tg, ag = tab['tg'], tab['ag']
+    Bx, By, Bz = tab['Bx'], tab['By'], tab['Bz']
+    Bs = np.zeros(len(w), dtype=np.complex128)
+    Bp = np.zeros(len(w), dtype=np.complex128)
+    gamma_ = gamma[0] if filament else gamma
+    dirx = ddphi
+    diry = ddpsi
+    dirz = np.sqrt(1. - ddphi**2 - ddpsi**2)
+    revgamma2 = 1. / gamma_**2
+    wc = w * E2WC / (1. + (betam*EMC**2 - 0.5)*revgamma2) if filament else \
+        w * E2WC / betam
+    if R0 is not None:
+        R0v = np.array((np.tan(ddphi), np.tan(ddpsi), np.ones_like(ddpsi)))
+        R0v *= R0
+        sinr0z, cosr0z = np.sin(wc*R0v[2, :]), np.cos(wc*R0v[2, :])
+    for i in range(len(tg)):
+        if filament:
+            betax_, betay_ = tab['betax'][i], tab['betay'][i]
+            trajx_, trajy_, trajz_ = tab['trajx'][i], tab['trajy'][i], tab['trajz'][i]
+        else:
+            betax_ = emcg*tab['betax'][i]
+            betay_ = emcg*tab['betay'][i]
+            trajx_ = emcg*tab['trajx'][i]
+            trajy_ = emcg*tab['trajy'][i]
+            trajz_ = tg[i]*(1.-0.5*revgamma2) + EMC**2*revgamma2*tab['trajz'][i]
+        if R0 is not None:
+            drx, dry, drz = R0v[0] - trajx_, R0v[1] - trajy_, R0v[2] - trajz_
+            dist = np.sqrt(drx*drx + dry*dry + drz*drz)
+            rdrz = 1./drz
+            drs = (drx**2+dry**2)*rdrz
+            LRS = 0.5*drs - 0.125*drs**2*rdrz + 0.0625*drs**3*rdrz**2
+            a1 = wc * (tg[i] - trajz_)
+            a2 = wc * LRS
+            sinzloc, coszloc = np.sin(a1), np.cos(a1)
+            sindrs, cosdrs = np.sin(a2), np.cos(a2)
+            ex = (-sinr0z*sinzloc*cosdrs - sinr0z*coszloc*sindrs -
+                  cosr0z*sinzloc*sindrs + cosr0z*coszloc*cosdrs)
+            ey = (-sinr0z*sinzloc*sindrs + sinr0z*coszloc*cosdrs +
+                  cosr0z*sinzloc*cosdrs + cosr0z*coszloc*sindrs)
+            dirx, diry, dirz = drx/dist, dry/dist, drz/dist
+        else:
+            phz = wc*(tg[i] - dirz*trajz_)
+            phxy = wc*(dirx*trajx_ + diry*trajy_)
+            sinphz, cosphz = np.sin(phz), np.cos(phz)
+            sinphxy, cosphxy = np.sin(phxy), np.cos(phxy)
+            ex = sinphz*cosphxy - cosphz*sinphxy
+            ey = cosphz*cosphxy + sinphz*sinphxy
+        eucos = ex + 1j*ey
+        smTerm = revgamma2 + betax_**2 + betay_**2
+        betaz = 1. - 0.5*smTerm - 0.125*smTerm**2 - 0.0625*smTerm**3
+        betaPx = betay_*Bz[i] - betaz*By[i]
+        betaPy = -betax_*Bz[i] + betaz*Bx[i]
+        betaPz = betax_*By[i] - betay_*Bx[i]
+        rkrel = 1./(1. - dirx*betax_ - diry*betay_ - dirz*betaz)
+        eucos = eucos * (ag[i] * rkrel**2)
+        bnx, bny, bnz = dirx - betax_, diry - betay_, dirz - betaz
+        nbp = dirx*betaPx + diry*betaPy + dirz*betaPz
+        nbn = dirx*bnx + diry*bny + dirz*bnz
+        Bs += eucos*(bnx*nbp - betaPx*nbn)
+        Bp += eucos*(bny*nbp - betaPy*nbn)
+    return Bs*emcg, Bp*emcg

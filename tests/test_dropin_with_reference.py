@@ -156,3 +156,64 @@ def test_reference_undulator_runs_through_the_dropin(kw):
     assert type(fake).calls == 1
     for a, b in zip(got, ref):
         assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(b)
+
+
+def test_reference_source_from_field_runs_through_the_dropin():
+    """SourceFromField.build_I_map takes its OpenCL branch
+    (_build_I_map_custom_field_CL, synchr.py:1157-1272) with XRT_HIP attached:
+    pins the 'custom_field' marshalling (scalar order, 10 node tables, emcg
+    rebuilt from gamma)."""
+    _refenv.activate()
+    import ctypes
+    import xrt.backends.raycing as raycing
+    import xrt.backends.raycing.sources as rs
+    from xrt_amd.backends.raycing.myhip import XRT_HIP
+    from oracle import undulator_np as un
+    raycing._VERBOSITY_ = 0
+
+    class OracleBackedHIP(XRT_HIP):
+        calls = 0
+
+        def set_cl(self, targetOpenCL='auto', precisionOpenCL='float64'):
+            self.device_ids = [0]
+            self.lastTargetOpenCL = targetOpenCL
+            self.lastPrecisionOpenCL = precisionOpenCL
+
+        def _call_lib_custom_field(self, f, n, rays, outs):
+            type(self).calls += 1
+
+            def tab(p):
+                return np.ctypeslib.as_array(
+                    ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), (f.jend,))
+            t = {k: tab(getattr(f, k)) for k in ('tg', 'ag', 'Bx', 'By', 'Bz', 'betax',
+                                                 'betay', 'trajx', 'trajy', 'trajz')}
+            emcg, gamma, w, th, ps = rays
+            assert not f.filament and f.wc == 0.
+            Is, Ip = un.custom_sp_sum(False, t, emcg, w, gamma, th, ps, f.betam,
+                                      f.R0 if f.near_field else None)
+            outs[0][:] = Is
+            outs[1][:] = Ip
+
+    L0, Np = 30., 6
+    z = np.linspace(-L0*Np/2-40, L0*Np/2+40, 1500)
+    env = 0.5*(np.tanh((z + L0*Np/2)/8.) - np.tanh((z - L0*Np/2)/8.))
+    field = np.vstack((z, 0.6*np.sin(2*np.pi*z/L0)*env)).T
+    bl = raycing.BeamLine()
+    s = rs.SourceFromField(
+        bl, 'sff', nrays=500, eE=3.0, eI=0.5, eEspread=0, eEpsilonX=0.263,
+        eEpsilonZ=0.008, betaX=9., betaZ=2., eMin=1500, eMax=1700, xPrimeMax=0.1,
+        zPrimeMax=0.1, targetOpenCL=None, distE='BW', customField=field, gNodes=20,
+        gIntervals=12, R0=15000.)
+    if s.needReset:
+        s.reset()
+    rng = np.random.RandomState(5)
+    w = rng.uniform(1500, 1700, 64)
+    th = rng.uniform(-1e-4, 1e-4, 64)
+    ps = rng.uniform(-1e-4, 1e-4, 64)
+    ref = s.build_I_map(w, th, ps)
+    fake = OracleBackedHIP()
+    fake.attach_to_source(s)
+    got = s.build_I_map(w, th, ps)
+    assert type(fake).calls == 1
+    for a, b in zip(got, ref):
+        assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b)

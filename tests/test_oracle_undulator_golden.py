@@ -67,3 +67,16 @@ def test_planar_on_axis_has_no_vertical_field(golden_dir):
     on_axis = (g['ddphi'] == 0) & (g['ddpsi'] == 0)
     assert on_axis.sum() >= 2
     assert np.all(np.abs(g['Ip'][on_axis]) <= 1e-12 * np.abs(g['Is'][on_axis]))
+
+
+@pytest.mark.parametrize('tag', ['far', 'filament', 'nf'])
+def test_custom_field_sums_match_reference(golden_dir, tag):
+    """SourceFromField._sp_sum (tabulated field) restated in
+    undulator_np.custom_sp_sum."""
+    g = np.load(os.path.join(golden_dir, 'g12_custom_field_%s.npz' % tag))
+    tab = {k: g[k] for k in ('tg', 'ag', 'Bx', 'By', 'Bz', 'betax', 'betay', 'trajx',
+                             'trajy', 'trajz')}
+    Is, Ip = un.custom_sp_sum(bool(g['filament']), tab, g['emcg'], g['w'], g['gamma'],
+                              g['ddphi'], g['ddpsi'], float(g['betam']),
+                              nan_to_none(g['R0']))
+    assert rel(Is, g['Is']) < 1e-13 and rel(Ip, g['Ip']) < 1e-13

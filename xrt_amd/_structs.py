@@ -166,5 +166,16 @@ class Plot(ctypes.Structure):
                 ('flux_kind', ctypes.c_int32)]
 
 
+class CustomField(ctypes.Structure):
+    _fields_ = [('filament', ctypes.c_int32),
+                ('near_field', ctypes.c_int32),
+                ('betam', ctypes.c_double),
+                ('R0', ctypes.c_double),
+                ('wc', ctypes.c_double),
+                ('jend', ctypes.c_int64)] + \
+        [(k, ctypes.c_void_p) for k in ('tg', 'ag', 'Bx', 'By', 'Bz', 'betax',
+                                        'betay', 'trajx', 'trajy', 'trajz')]
+
+
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
-           UndulatorMap, Plot)
+           UndulatorMap, Plot, CustomField)

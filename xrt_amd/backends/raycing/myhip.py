@@ -25,7 +25,7 @@ from ... import _lib
 
 class XRT_HIP(object):
     kernels = ('integrate_kirchhoff', 'undulator', 'undulator_taper',
-               'undulator_nf')
+               'undulator_nf', 'custom_field', 'custom_field_filament')
 
     def __init__(self, filename=None, targetOpenCL='auto',
                  precisionOpenCL='float64', convention='opencl', devices=None):
@@ -74,6 +74,9 @@ class XRT_HIP(object):
             return self._undulator(kernelName, scalarArgs, slicedROArgs,
                                    nonSlicedROArgs, slicedRWArgs,
                                    int(dimension))
+        if kernelName in ('custom_field', 'custom_field_filament'):
+            return self._custom_field(kernelName, scalarArgs, slicedROArgs,
+                                      nonSlicedROArgs, slicedRWArgs, int(dimension))
         if kernelName != 'integrate_kirchhoff':
             raise NotImplementedError(
                 "XRT_HIP implements %s, not %r" % (self.kernels, kernelName))
@@ -124,6 +127,13 @@ class XRT_HIP(object):
         source.cl_precisionC = self.cl_precisionC
         source.cl_ctx = self            # only tested against None
         source.cl_is_blocking = True
+        if hasattr(source, '_build_trajectory_conv'):
+            # SourceFromField integrates the electron trajectory once per reset in
+            # a ONE-work-item OpenCL kernel ('get_trajectory', dimension=1,
+            # synchr.py:1010-1035): a sequential O(N) job with nothing to
+            # parallelise. It stays on the reference's own numpy routine; the
+            # per-ray field sums ('custom_field') run on the GPU.
+            source.build_trajectory = source._build_trajectory_conv
         return source
 
     def _undulator(self, kernelName, scalarArgs, slicedRO, nonSlicedRO, slicedRW,
@@ -163,6 +173,69 @@ class XRT_HIP(object):
             setattr(u, name, t.ctypes.data)
         self._call_lib_undulator(u, dimension, rays, slicedRW)
         return tuple(slicedRW)
+
+    # SIE0 / SIM0 / C / 10 of synchr.py:1309 (emcg = that / gamma)
+    EMC_NUM = 1.602176565e-19 / 9.109383701528e-31 / 2.99792458e10 / 10.
+
+    def _custom_field(self, kernelName, scalarArgs, slicedRO, nonSlicedRO, slicedRW,
+                      dimension):
+        """Argument order of SourceFromField._build_I_map_custom_field_CL
+        (synchr.py:1196-1256)."""
+        from ..._structs import CustomField
+        fil = kernelName.endswith('filament')
+        if len(nonSlicedRO) != 10 or len(slicedRW) != 2:
+            raise ValueError('%s: 10 node tables and 2 RW arrays expected' % kernelName)
+        jend = int(scalarArgs[0])
+        tabs = [np.ascontiguousarray(a, dtype=np.float64) for a in nonSlicedRO]
+        for a in tabs:
+            if a.size != jend:
+                raise ValueError('node tables must have jend=%d elements' % jend)
+        f = CustomField()
+        f.filament = 1 if fil else 0
+        f.jend = jend
+        ones = np.ones(dimension)
+        if fil:
+            # scalars: jend, emcg0, 1/gamma0^2, R0, wc (= w0 E2WC / betam)
+            theta, psi = (np.ascontiguousarray(a, dtype=np.float64) for a in slicedRO)
+            emcg = float(scalarArgs[1]) * ones
+            gamma = ones / np.sqrt(float(scalarArgs[2]))
+            R0 = float(scalarArgs[3])
+            f.wc = float(scalarArgs[4])
+            f.betam = 1.
+            w = ones            # unused: the carrier is given
+        else:
+            # scalars: jend, betam, R0
+            gamma, w, theta, psi = (np.ascontiguousarray(a, dtype=np.float64)
+                                    for a in slicedRO)
+            emcg = self.EMC_NUM / gamma
+            f.betam = float(scalarArgs[1])
+            R0 = scalarArgs[2]
+            R0 = 0. if R0 is None else float(R0)
+            f.wc = 0.
+        f.near_field = 1 if R0 > 0 else 0
+        f.R0 = R0
+        for name, t in zip(('tg', 'ag', 'Bx', 'By', 'Bz', 'betax', 'betay', 'trajx',
+                            'trajy', 'trajz'), tabs):
+            setattr(f, name, t.ctypes.data)
+        for a in slicedRW:
+            if not (isinstance(a, np.ndarray) and a.dtype == np.complex128 and
+                    a.flags.c_contiguous and a.size == dimension):
+                raise ValueError('RW arrays must be contiguous complex128[%d]'
+                                 % dimension)
+        self._call_lib_custom_field(f, dimension, [emcg, gamma, w, theta, psi],
+                                    slicedRW)
+        return tuple(slicedRW)
+
+    def _call_lib_custom_field(self, f, n, rays, outs):
+        lib = _lib.load()
+        ms = ctypes.c_float(0.)
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+        rays = [np.ascontiguousarray(a, dtype=np.float64) for a in rays]
+        rc = lib.xrt_hip_custom_field_f64(
+            self.device_ids[0], ctypes.byref(f), n, *[ptr(a) for a in rays],
+            ptr(outs[0]), ptr(outs[1]), ctypes.byref(ms))
+        _lib.check(rc, 'xrt_hip_custom_field_f64')
+        self.lastKernelMs = ms.value
 
     def _call_lib_undulator(self, u, n, rays, outs):
         lib = _lib.load()

@@ -246,6 +246,7 @@ int xrt_hip_sizeof(int which) {
     case 6: return (int)sizeof(xrt_hip_undulator);
     case 7: return (int)sizeof(xrt_hip_undulator_map);
     case 8: return (int)sizeof(xrt_hip_plot);
+    case 9: return (int)sizeof(xrt_hip_custom_field);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -576,6 +577,105 @@ int xrt_hip_undulator_f64(int device, const xrt_hip_undulator* u, int64_t nrays,
         if (e == hipSuccess) e = hipMemcpy(Ip_ri, out[1].p, 2 * rb, hipMemcpyDeviceToHost);
         if (e != hipSuccess)
           result = fail(XRT_HIP_ERR_HIP, "undulator copy-back failed: %s", hipGetErrorString(e));
+      }
+    }
+  }
+  (void)hipSetDevice(prev);
+  return result;
+}
+
+static int check_custom(const xrt_hip_custom_field* f, int64_t nrays) {
+  if (!f) return fail(XRT_HIP_ERR_ARG, "NULL custom-field description");
+  if (f->jend < 0 || nrays < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (f->jend > 0 && (!f->tg || !f->ag || !f->Bx || !f->By || !f->Bz || !f->betax ||
+                      !f->betay || !f->trajx || !f->trajy || !f->trajz))
+    return fail(XRT_HIP_ERR_ARG, "NULL node table");
+  if (f->near_field && !(f->R0 > 0)) return fail(XRT_HIP_ERR_ARG, "near field needs R0 > 0");
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_custom_field_f64_dev(const xrt_hip_custom_field* f, int64_t nrays,
+                                 const double* emcg, const double* gamma, const double* w,
+                                 const double* ddphi, const double* ddpsi, double* Is_ri,
+                                 double* Ip_ri, void* workspace, size_t workspace_bytes,
+                                 void* stream, float* kernel_ms) {
+  int rc;
+  if ((rc = check_custom(f, nrays))) return rc;
+  if (nrays > 0 && (!emcg || !gamma || !w || !ddphi || !ddpsi || !Is_ri || !Ip_ri))
+    return fail(XRT_HIP_ERR_ARG, "NULL ray array");
+  if (!workspace || workspace_bytes < xrt_hip_undulator_workspace_bytes(f->jend))
+    return fail(XRT_HIP_ERR_ARG, "workspace too small: %zu < %zu", workspace_bytes,
+                xrt_hip_undulator_workspace_bytes(f->jend));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!kernel_ms) {
+    HIP_TRY(xrt::custom_field_launch(*f, nrays, emcg, gamma, w, ddphi, ddpsi, Is_ri, Ip_ri,
+                                     workspace, st, nullptr, nullptr));
+    return XRT_HIP_OK;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipError_t e = xrt::custom_field_launch(*f, nrays, emcg, gamma, w, ddphi, ddpsi, Is_ri,
+                                          Ip_ri, workspace, st, e0, e1);
+  *kernel_ms = 0.f;
+  if (e == hipSuccess && nrays > 0) e = hipEventSynchronize(e1);
+  if (e == hipSuccess && nrays > 0) e = hipEventElapsedTime(kernel_ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HIP_TRY(e);
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_custom_field_f64(int device, const xrt_hip_custom_field* f, int64_t nrays,
+                             const double* emcg, const double* gamma, const double* w,
+                             const double* ddphi, const double* ddpsi, double* Is_ri,
+                             double* Ip_ri, float* kernel_ms) {
+  int rc;
+  if ((rc = check_custom(f, nrays))) return rc;
+  if (nrays == 0) return XRT_HIP_OK;
+  if (!emcg || !gamma || !w || !ddphi || !ddpsi || !Is_ri || !Ip_ri)
+    return fail(XRT_HIP_ERR_ARG, "NULL ray array");
+  int prev = 0;
+  HIP_TRY(hipGetDevice(&prev));
+  HIP_TRY(hipSetDevice(device));
+  int result = XRT_HIP_OK;
+  {
+    const size_t rb = (size_t)nrays * sizeof(double), nb = (size_t)f->jend * sizeof(double);
+    DevBuf ray[5], tab[10], out[2], ws;
+    const double* hray[5] = {emcg, gamma, w, ddphi, ddpsi};
+    const double* htab[10] = {f->tg, f->ag, f->Bx, f->By, f->Bz, f->betax, f->betay,
+                              f->trajx, f->trajy, f->trajz};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 5 && e == hipSuccess; ++i) {
+      e = ray[i].alloc(rb);
+      if (e == hipSuccess) e = hipMemcpy(ray[i].p, hray[i], rb, hipMemcpyHostToDevice);
+    }
+    for (int i = 0; i < 10 && e == hipSuccess; ++i) {
+      e = tab[i].alloc(nb);
+      if (e == hipSuccess && nb) e = hipMemcpy(tab[i].p, htab[i], nb, hipMemcpyHostToDevice);
+    }
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = out[i].alloc(2 * rb);
+    const size_t wb = xrt_hip_undulator_workspace_bytes(f->jend);
+    if (e == hipSuccess) e = ws.alloc(wb);
+    if (e != hipSuccess) {
+      result = fail(XRT_HIP_ERR_HIP, "custom-field staging failed: %s", hipGetErrorString(e));
+    } else {
+      xrt_hip_custom_field d = *f;
+      const double** dst[10] = {&d.tg, &d.ag, &d.Bx, &d.By, &d.Bz, &d.betax, &d.betay,
+                                &d.trajx, &d.trajy, &d.trajz};
+      for (int i = 0; i < 10; ++i) *dst[i] = tab[i].as<double>();
+      float ms = 0.f;
+      result = xrt_hip_custom_field_f64_dev(
+          &d, nrays, ray[0].as<double>(), ray[1].as<double>(), ray[2].as<double>(),
+          ray[3].as<double>(), ray[4].as<double>(), out[0].as<double>(), out[1].as<double>(),
+          ws.p, wb, nullptr, &ms);
+      if (kernel_ms) *kernel_ms = ms;
+      if (result == XRT_HIP_OK) {
+        e = hipMemcpy(Is_ri, out[0].p, 2 * rb, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(Ip_ri, out[1].p, 2 * rb, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+          result = fail(XRT_HIP_ERR_HIP, "custom-field copy-back failed: %s",
+                        hipGetErrorString(e));
       }
     }
   }

@@ -16,4 +16,10 @@ hipError_t undulator_imap_launch(const UndulatorArgs& a, const UndulatorMap& m, 
                                  const double* w, const double* theta, const double* psi,
                                  const double* gamma, double* I, double* Es_ri, double* Ep_ri,
                                  const void* workspace, hipStream_t st);
+// workspace: jend * UND_NODE_DOUBLES doubles as well
+hipError_t custom_field_launch(const xrt_hip_custom_field& a, int64_t n, const double* emcg,
+                               const double* gamma, const double* w, const double* ddphi,
+                               const double* ddpsi, double* Is_ri, double* Ip_ri,
+                               void* workspace, hipStream_t st, hipEvent_t e0,
+                               hipEvent_t e1);
 }

@@ -235,6 +235,160 @@ und_imap(UndulatorArgs a, UndulatorMap m, const double* __restrict__ rec, int64_
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// Custom (tabulated) magnetic field: SourceFromField._sp_sum, synchr.py:888-973;
+// OpenCL twins custom_field / custom_field_filament (cl/undulator.cl:822-1103).
+// Node record: tg, ag, Bx, By, Bz, betax, betay, trajx, trajy, trajz.
+// ---------------------------------------------------------------------------
+namespace {
+enum { C_TG, C_AG, C_BX, C_BY, C_BZ, C_BETAX, C_BETAY, C_TRAJX, C_TRAJY, C_TRAJZ, C_REC = 16 };
+constexpr double EMC_ = 0.5866791802416487;   // physconsts.py:24
+
+__global__ void cust_pack(xrt_hip_custom_field a, double* __restrict__ rec) {
+  int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= a.jend) return;
+  double* r = rec + j * C_REC;
+  r[C_TG] = a.tg[j];
+  r[C_AG] = a.ag[j];
+  r[C_BX] = a.Bx[j];
+  r[C_BY] = a.By[j];
+  r[C_BZ] = a.Bz[j];
+  r[C_BETAX] = a.betax[j];
+  r[C_BETAY] = a.betay[j];
+  r[C_TRAJX] = a.trajx[j];
+  r[C_TRAJY] = a.trajy[j];
+  r[C_TRAJZ] = a.trajz[j];
+  for (int k = C_TRAJZ + 1; k < C_REC; ++k) r[k] = 0.;
+}
+
+template <bool FIL, bool NF>
+__global__ void __launch_bounds__(256)
+cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
+         const double* __restrict__ emcg_, const double* __restrict__ gamma,
+         const double* __restrict__ w_, const double* __restrict__ ddphi,
+         const double* __restrict__ ddpsi, double2* __restrict__ Is,
+         double2* __restrict__ Ip) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double emcg = emcg_[i], w = w_[i], phi = ddphi[i], psi = ddpsi[i];
+  const double g = FIL ? gamma[0] : gamma[i];
+  double dirx = phi, diry = psi;
+  double dirz = __builtin_sqrt((1. - phi * phi) - psi * psi);
+  const double revg2 = 1. / (g * g);
+  const double emc2 = EMC_ * EMC_;
+  // sic: the two carrier formulas are swapped w.r.t. the vectorised _sp
+  const double wc = FIL ? (a.wc > 0. ? a.wc
+                                     : (w * E2WC_) / (1. + (a.betam * emc2 - 0.5) * revg2))
+                        : (w * E2WC_) / a.betam;
+  const double zfac = 1. - 0.5 * revg2;     // non-filament trajz_
+  const double tfac = emc2 * revg2;
+  double r0x = 0., r0y = 0., r0z = 0., sr0 = 0., cr0 = 0.;
+  if (NF) {
+    r0x = tan(phi) * a.R0;
+    r0y = tan(psi) * a.R0;
+    r0z = a.R0;
+    sincos_phase(wc * r0z, sr0, cr0);
+  }
+  double bsr = 0., bsi = 0., bpr = 0., bpi = 0.;
+  const double* __restrict__ r = rec;
+  for (int64_t j = 0; j < a.jend; ++j, r += C_REC) {
+    const double tg = r[C_TG], ag = r[C_AG];
+    double bx, by, tx, ty, tz;
+    if (FIL) {
+      bx = r[C_BETAX];
+      by = r[C_BETAY];
+      tx = r[C_TRAJX];
+      ty = r[C_TRAJY];
+      tz = r[C_TRAJZ];
+    } else {
+      bx = emcg * r[C_BETAX];
+      by = emcg * r[C_BETAY];
+      tx = emcg * r[C_TRAJX];
+      ty = emcg * r[C_TRAJY];
+      tz = tg * zfac + tfac * r[C_TRAJZ];
+    }
+    double er, ei;
+    if (NF) {
+      const double drx = r0x - tx, dry = r0y - ty, drz = r0z - tz;
+      const double dxy = drx * drx + dry * dry;
+      const double dist = __builtin_sqrt(dxy + drz * drz);
+      const double rdrz = 1. / drz;
+      const double drs = dxy * rdrz;
+      const double LRS = (0.5 * drs - (0.125 * (drs * drs)) * rdrz) +
+                         (0.0625 * pow(drs, 3.)) * (rdrz * rdrz);
+      double sz, cz, sd, cd;
+      sincos_phase(wc * (tg - tz), sz, cz);
+      sincos_phase(wc * LRS, sd, cd);
+      er = ((((-sr0) * sz) * cd - (sr0 * cz) * sd) - (cr0 * sz) * sd) + (cr0 * cz) * cd;
+      ei = ((((-sr0) * sz) * sd + (sr0 * cz) * cd) + (cr0 * sz) * cd) + (cr0 * cz) * sd;
+      dirx = drx / dist;
+      diry = dry / dist;
+      dirz = drz / dist;
+    } else {
+      double s1, c1, s2, c2;
+      sincos_phase(wc * (tg - dirz * tz), s1, c1);
+      sincos_phase(wc * (dirx * tx + diry * ty), s2, c2);
+      er = s1 * c2 - c1 * s2;
+      ei = c1 * c2 + s1 * s2;
+    }
+    const double sm = (revg2 + bx * bx) + by * by;
+    const double bz = ((1. - 0.5 * sm) - 0.125 * (sm * sm)) - 0.0625 * pow(sm, 3.);
+    const double Bx = r[C_BX], By = r[C_BY], Bz = r[C_BZ];
+    const double bPx = by * Bz - bz * By;
+    const double bPy = (-bx) * Bz + bz * Bx;
+    const double bPz = bx * By - by * Bx;
+    const double krel = ((1. - dirx * bx) - diry * by) - dirz * bz;
+    const double rkrel = 1. / krel;
+    const double fac = ag * (rkrel * rkrel);
+    er *= fac;
+    ei *= fac;
+    const double bnx = dirx - bx, bny = diry - by, bnz = dirz - bz;
+    const double nbp = (dirx * bPx + diry * bPy) + dirz * bPz;
+    const double nbn = (dirx * bnx + diry * bny) + dirz * bnz;
+    const double ts = bnx * nbp - bPx * nbn;
+    const double tp = bny * nbp - bPy * nbn;
+    bsr += er * ts;
+    bsi += ei * ts;
+    bpr += er * tp;
+    bpi += ei * tp;
+  }
+  Is[i] = make_double2(bsr * emcg, bsi * emcg);
+  Ip[i] = make_double2(bpr * emcg, bpi * emcg);
+}
+}  // namespace
+
+hipError_t custom_field_launch(const xrt_hip_custom_field& a, int64_t n, const double* emcg,
+                               const double* gamma, const double* w, const double* ddphi,
+                               const double* ddpsi, double* Is_ri, double* Ip_ri,
+                               void* workspace, hipStream_t st, hipEvent_t e0,
+                               hipEvent_t e1) {
+  double* rec = reinterpret_cast<double*>(workspace);
+  if (a.jend > 0) {
+    hipLaunchKernelGGL(cust_pack, dim3((unsigned)((a.jend + 127) / 128)), dim3(128), 0, st, a,
+                       rec);
+  }
+  if (n <= 0) return hipGetLastError();
+  if (e0) (void)hipEventRecord(e0, st);
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  double2* is = reinterpret_cast<double2*>(Is_ri);
+  double2* ip = reinterpret_cast<double2*>(Ip_ri);
+  const bool nf = a.near_field != 0, fil = a.filament != 0;
+#define XRT_CUST(FIL, NF)                                                                   \
+  hipLaunchKernelGGL((cust_sum<FIL, NF>), grid, block, 0, st, a, rec, n, emcg, gamma, w, \
+                     ddphi, ddpsi, is, ip)
+  if (fil && nf)
+    XRT_CUST(true, true);
+  else if (fil)
+    XRT_CUST(true, false);
+  else if (nf)
+    XRT_CUST(false, true);
+  else
+    XRT_CUST(false, false);
+#undef XRT_CUST
+  if (e1) (void)hipEventRecord(e1, st);
+  return hipGetLastError();
+}
+
 hipError_t undulator_pack_launch(const UndulatorArgs& a, void* workspace, hipStream_t st) {
   if (a.jend <= 0) return hipSuccess;
   int pb = (int)((a.jend + 127) / 128);

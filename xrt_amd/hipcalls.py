@@ -205,3 +205,43 @@ def undulator_imap(mode, Kx, Ky, tables, w, theta, psi, L0, Np, gamma0, eI, dste
             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr())
     _lib.check(rc, 'xrt_hip_undulator_imap_f64_dev')
     return I, Es, Ep
+
+
+CUSTOM_TABLES = ('tg', 'ag', 'Bx', 'By', 'Bz', 'betax', 'betay', 'trajx', 'trajy',
+                 'trajz')
+
+
+def custom_field(tables, emcg, gamma, w, ddphi, ddpsi, betam, filament=False, R0=None,
+                 wc=0., timing=False):
+    """Field sums of a tabulated-field source on device tensors
+    (xrt_hip_custom_field_f64_dev). tables: dict or sequence of the ten node
+    tables in CUSTOM_TABLES order. Returns (Is, Ip[, kernel ms])."""
+    from ._structs import CustomField
+    lib = _lib.load()
+    if isinstance(tables, dict):
+        tables = [tables[k] for k in CUSTOM_TABLES]
+    n = w.numel()
+    jend = tables[0].numel()
+    dev = w.device
+    f = CustomField()
+    f.filament = 1 if filament else 0
+    f.near_field = 0 if R0 is None else 1
+    f.betam = float(betam)
+    f.R0 = 0. if R0 is None else float(R0)
+    f.wc = float(wc)
+    f.jend = jend
+    for name, t in zip(CUSTOM_TABLES, tables):
+        setattr(f, name, _f64(t, jend, name).value)
+    Is = torch.empty(n, dtype=torch.complex128, device=dev)
+    Ip = torch.empty(n, dtype=torch.complex128, device=dev)
+    wsb = lib.xrt_hip_undulator_workspace_bytes(jend)
+    ws = workspace(dev, wsb, 'undulator')
+    ms = ctypes.c_float(0.)
+    with torch.cuda.device(dev):
+        rc = lib.xrt_hip_custom_field_f64_dev(
+            ctypes.byref(f), n, _f64(emcg, n, 'emcg'), _f64(gamma, n, 'gamma'),
+            _f64(w, n, 'w'), _f64(ddphi, n, 'ddphi'), _f64(ddpsi, n, 'ddpsi'),
+            _c128(Is, n, 'Is'), _c128(Ip, n, 'Ip'), ctypes.c_void_p(ws.data_ptr()),
+            ws.numel(), _stream_ptr(), ctypes.byref(ms) if timing else None)
+    _lib.check(rc, 'xrt_hip_custom_field_f64_dev')
+    return (Is, Ip, ms.value) if timing else (Is, Ip)
