@@ -146,3 +146,22 @@ def test_colour_and_1d_histograms_match_numpy_and_matplotlib():
     # the 1-D histograms see rays that fall outside the other axis' range
     assert plot.total1D_x.sum() > plot.total2D.sum() * (1 + 1e-6)
     assert np.array_equal(plot.total1D_c, plot.caxis.total1D4[:, 0])
+
+
+def test_plot_histograms_of_an_empty_selection():
+    """No ray matches the ray flag: all histograms stay zero, counters count."""
+    bl = build()
+
+    def run_process(beamLine):
+        b0 = beamLine.src.shine()
+        b0.state[:] = -1
+        return {'beam': b0}
+    rr.run_process = run_process
+    np.random.seed(2)
+    plot = xrtp.XYCPlot('beam', (1,), xrtp.XYCAxis('x', 'mm', limits=[-1, 1], bins=8),
+                        xrtp.XYCAxis('z', 'mm', limits=[-1, 1], bins=8),
+                        caxis=xrtp.XYCAxis('energy', 'eV', limits=[8990., 9010.], bins=8))
+    xrtr.run_ray_tracing([plot], repeats=1, beamLine=bl)
+    assert plot.nRaysSelected == 0 and plot.nRaysDead == 40000
+    assert not plot.total2D.any() and not plot.total2D_RGB.any()
+    assert not plot.xaxis.total1D4.any() and not plot.caxis.total1D4.any()

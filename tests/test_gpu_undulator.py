@@ -196,3 +196,17 @@ def test_custom_field_dropin_marshalling(golden_dir):
         [g['gamma'], g['w'], g['ddphi'], g['ddpsi']], [g[k] for k in CTABS], rw, None, n)
     assert out[0] is rw[0]
     assert rel(rw[0], g['Is']) < 1e-10 and rel(rw[1], g['Ip']) < 1e-10
+
+
+def test_custom_field_empty_and_bad_arguments():
+    from xrt_amd import hipcalls, _lib
+    e = torch.empty(0, dtype=torch.float64, device='cuda')
+    one = torch.ones(4, dtype=torch.float64, device='cuda')
+    tabs = [one.clone() for _ in CTABS]
+    Is, Ip = hipcalls.custom_field(tabs, e, e, e, e, e, 1.0)
+    assert Is.numel() == 0
+    Is, Ip = hipcalls.custom_field([e] * 10, one, one * 5000, one, one * 0, one * 0, 1.0)
+    torch.cuda.synchronize()
+    assert torch.all(Is == 0) and torch.all(Ip == 0)
+    with pytest.raises(_lib.XrtHipError):
+        hipcalls.custom_field(tabs, one, one, one, one, one, 1.0, R0=-5.)
