@@ -668,9 +668,10 @@ class BlazedGrating(OE):
             np.sin(self.antiblaze), np.cos(self.antiblaze), np.tan(self.antiblaze)
 
     def local_pre(self, x, y):
-        y0 = (y // self.rho_1) * self.rho_1
+        # np.divmod = the same npy_divmod as `//` and `%`, in one pass
+        q, yL = np.divmod(y, self.rho_1)
+        y0 = q * self.rho_1
         y1 = y0 + self.rho_1
-        yL = y % self.rho_1
         yC = (y1-y0) / (1 + self.tanAntiblaze/self.tanBlaze)
         return 0, y0, y1, yC, yL
 
