@@ -492,11 +492,109 @@ class Undulator(object):
         return (self.dxprime**2 + s)**0.5, (self.dzprime**2 + s)**0.5
 
     # ---- shine ----------------------------------------------------------------
+    # The numpy RNG is the only shared state with the reference: for one seed the
+    # same rays must come out. The order of draws (documented per helper) is the
+    # contract; it follows sybase.py:1470-1810.
+    def _draw_filament(self, accuBeam):
+        """One electron of the beam: (E, x, z, x', z', dgamma, seeded, seededI).
+        Draws: 1 uniform, 4 normals (+1 normal with energy spread)."""
+        if accuBeam is not None:
+            return dict(E=accuBeam.E[0], x=accuBeam.filamentDX, z=accuBeam.filamentDZ,
+                        xp=accuBeam.filamentDtheta, zp=accuBeam.filamentDpsi,
+                        dgamma=accuBeam.filamentDgamma, seeded=accuBeam.seeded,
+                        seededI=accuBeam.seededI)
+        el = dict(seeded=np.int64(0), seededI=0., dgamma=None)
+        el['E'] = np.random.random_sample() * float(self.E_max - self.E_min) + \
+            self.E_min
+        el['x'] = self.dx * np.random.standard_normal()
+        el['z'] = self.dz * np.random.standard_normal()
+        el['xp'] = self.dxprime * np.random.standard_normal()
+        el['zp'] = self.dzprime * np.random.standard_normal()
+        if self.eEspread > 0:
+            el['dgamma'] = self.gamma * self.eEspread * np.random.standard_normal()
+        return el
+
+    def _draw_observation(self, n, el, fixedEnergy, wave):
+        """Photon energies and observation angles of one batch. Draws: energies
+        (unless filament / fixed energy); for a wave the electron offsets and
+        divergences (4 normal arrays, each only if its sigma > 0); for rays the
+        two uniform angle arrays."""
+        if el is not None or fixedEnergy:
+            E = (fixedEnergy if fixedEnergy else el['E']) * np.ones(n)
+        else:
+            E = np.random.rand(n) * float(self.E_max - self.E_min) + self.E_min
+        if wave is None:
+            theta = np.random.rand(n) * (self.Theta_max - self.Theta_min) + \
+                self.Theta_min
+            psi = np.random.rand(n) * (self.Psi_max - self.Psi_min) + self.Psi_min
+            return E, theta, psi
+        self.xzE = (self.E_max - self.E_min)
+        if el is not None:
+            sx, sz = el['x'], el['z']
+        else:
+            sx = np.random.normal(0, self.dx, n) if self.dx > 0 else 0
+            sz = np.random.normal(0, self.dz, n) if self.dz > 0 else 0
+        x = wave.xDiffr + sx
+        y = wave.yDiffr
+        z = wave.zDiffr + sz
+        r = np.sqrt((x**2 + y**2 + z**2))
+        theta = x / r
+        psi = z / r
+        if el is not None:
+            theta += el['xp']
+            psi += el['zp']
+        else:
+            if self.dxprime > 0:
+                theta += np.random.normal(0, self.dxprime, n)
+            if self.dzprime > 0:
+                psi += np.random.normal(0, self.dzprime, n)
+        return E, theta, psi
+
+    def _accept(self, intensity, n):
+        """Rejection sampling against the running maximum (1 uniform array); a
+        slice for uniform ray density."""
+        top = np.max(intensity)
+        if top > self.Imax:
+            self.Imax = top
+            self.fluxConst = self.Imax * self.xzE
+        if self.uniformRayDensity:
+            return slice(None), n
+        keep = np.where(self.Imax * np.random.rand(n) < intensity)[0]
+        return keep, len(keep)
+
+    def _source_points(self, bot, npassed, el):
+        """Emission points: the electron position or the photon source size
+        convolved with the electron beam (2 normal arrays)."""
+        if el is not None:
+            return el['x'], el['z']
+        bot.sourceSIGMAx, bot.sourceSIGMAz = self.get_SIGMA(
+            bot.E, onlyOddHarmonics=False)
+        return (np.random.normal(0, bot.sourceSIGMAx, npassed),
+                np.random.normal(0, bot.sourceSIGMAz, npassed))
+
+    def _set_polarisation(self, bot, fs, fp, withAmplitudes):
+        """Coherency matrix (normalised per ray unless uniform ray density) and
+        amplitudes from the two field components."""
+        s2 = (fs * np.conj(fs)).real
+        p2 = (fp * np.conj(fp)).real
+        tot = 1. if self.uniformRayDensity else s2 + p2
+        with np.errstate(invalid='ignore', divide='ignore'):
+            bot.Jsp[:] = np.where(tot, fs * np.conj(fp) / tot, 0)
+            bot.Jss[:] = np.where(tot, s2 / tot, 0)
+            bot.Jpp[:] = np.where(tot, p2 / tot, 0)
+            if withAmplitudes:
+                if self.uniformRayDensity:
+                    bot.Es[:] = fs
+                    bot.Ep[:] = fp
+                else:
+                    bot.Es[:] = fs / s2**0.5
+                    bot.Ep[:] = fp / p2**0.5
+
     def shine(self, toGlobal=True, withAmplitudes=True, fixedEnergy=False,
               wave=None, accuBeam=None):
         """The source beam (rays sampled by rejection on the intensity map) or,
         with *wave* (a beam from ``prepare_wave``), the undulator field on the
-        wave's points. Same numpy RNG call order as sybase.py:1470-1810."""
+        wave's points (reference: sybase.py:1470-1810)."""
         if self.needReset:
             self.reset()
         if self.bl is not None:
@@ -509,160 +607,67 @@ class Undulator(object):
                 raise ValueError("If you want to use a `wave`, run a "
                                  "`prepare_wave` before shine!")
             self.uniformRayDensity = True
-            mcRays = len(wave.a)
-        else:
-            mcRays = self.nrays
+        batch = len(wave.a) if wave is not None else self.nrays
         if self.uniformRayDensity:
             withAmplitudes = True
-        parts = []
-        length = 0
-        seeded = np.int64(0)
-        seededI = 0.
-        dgamma = None
-        if self.filamentBeam:
-            if accuBeam is None:
-                rsE = np.random.random_sample() * \
-                    float(self.E_max - self.E_min) + self.E_min
-                rX = self.dx * np.random.standard_normal()
-                rZ = self.dz * np.random.standard_normal()
-                dtheta = self.dxprime * np.random.standard_normal()
-                dpsi = self.dzprime * np.random.standard_normal()
-                if self.eEspread > 0:
-                    dgamma = self.gamma * self.eEspread * \
-                        np.random.standard_normal()
-            else:
-                rsE = accuBeam.E[0]
-                rX, rZ = accuBeam.filamentDX, accuBeam.filamentDZ
-                dtheta, dpsi = accuBeam.filamentDtheta, accuBeam.filamentDpsi
-                dgamma = accuBeam.filamentDgamma
-                seeded, seededI = accuBeam.seeded, accuBeam.seededI
-        if fixedEnergy:
-            rsE = fixedEnergy
-        nrep = 0
+        el = self._draw_filament(accuBeam) if self.filamentBeam else None
+        seeded = el['seeded'] if el is not None else np.int64(0)
+        seededI = el['seededI'] if el is not None else 0.
+        parts, length, nrep = [], 0, 0
         while True:
-            seeded += mcRays
-            if self.filamentBeam or fixedEnergy:
-                rE = rsE * np.ones(mcRays)
-            else:
-                rE = np.random.rand(mcRays) * float(self.E_max - self.E_min) + \
-                    self.E_min
-            if wave is not None:
-                self.xzE = (self.E_max - self.E_min)
-                if self.filamentBeam:
-                    shiftX, shiftZ = rX, rZ
-                else:
-                    shiftX = np.random.normal(0, self.dx, mcRays) \
-                        if self.dx > 0 else 0
-                    shiftZ = np.random.normal(0, self.dz, mcRays) \
-                        if self.dz > 0 else 0
-                x = wave.xDiffr + shiftX
-                y = wave.yDiffr
-                z = wave.zDiffr + shiftZ
-                rDiffr = np.sqrt((x**2 + y**2 + z**2))
-                rTheta = x / rDiffr
-                rPsi = z / rDiffr
-                if self.filamentBeam:
-                    rTheta += dtheta
-                    rPsi += dpsi
-                else:
-                    if self.dxprime > 0:
-                        rTheta += np.random.normal(0, self.dxprime, mcRays)
-                    if self.dzprime > 0:
-                        rPsi += np.random.normal(0, self.dzprime, mcRays)
-            else:
-                rTheta = np.random.rand(mcRays) * \
-                    (self.Theta_max - self.Theta_min) + self.Theta_min
-                rPsi = np.random.rand(mcRays) * \
-                    (self.Psi_max - self.Psi_min) + self.Psi_min
-
-            Intensity, mJs, mJp = self.build_I_map(rE, rTheta, rPsi, dg=dgamma)
-
+            seeded += batch
+            E, theta, psi = self._draw_observation(batch, el, fixedEnergy, wave)
+            intensity, fs, fp = self.build_I_map(
+                E, theta, psi, dg=None if el is None else el['dgamma'])
             if self.uniformRayDensity:
-                seededI += mcRays * self.xzE
+                seededI += batch * self.xzE
                 sourceWeight = self.xzE
             else:
-                seededI += Intensity.sum() * self.xzE
+                seededI += intensity.sum() * self.xzE
                 sourceWeight = seededI / seeded
-            tmp_max = np.max(Intensity)
-            if tmp_max > self.Imax:
-                self.Imax = tmp_max
-                self.fluxConst = self.Imax * self.xzE
-            if self.uniformRayDensity:
-                I_pass = slice(None)
-                npassed = mcRays
-            else:
-                rndg = np.random.rand(mcRays)
-                I_pass = np.where(self.Imax * rndg < Intensity)[0]
-                npassed = len(I_pass)
+            keep, npassed = self._accept(intensity, batch)
             if npassed == 0:
                 continue
-
             bot = wave if wave is not None else \
                 Beam(npassed, withAmplitudes=withAmplitudes)
             bot.state[:] = 1
-            bot.E[:] = rE[I_pass]
-            if self.filamentBeam:
-                dxR, dzR = rX, rZ
-            else:
-                bot.sourceSIGMAx, bot.sourceSIGMAz = self.get_SIGMA(
-                    bot.E, onlyOddHarmonics=False)
-                dxR = np.random.normal(0, bot.sourceSIGMAx, npassed)
-                dzR = np.random.normal(0, bot.sourceSIGMAz, npassed)
-
+            bot.E[:] = E[keep]
+            px, pz = self._source_points(bot, npassed, el)
+            fs, fp = fs[keep], fp[keep]
             if wave is not None:
-                wave.rDiffr = np.sqrt(
-                    ((wave.xDiffr - dxR)**2 + wave.yDiffr**2 +
-                     (wave.zDiffr - dzR)**2))
+                wave.rDiffr = np.sqrt(((wave.xDiffr - px)**2 + wave.yDiffr**2 +
+                                       (wave.zDiffr - pz)**2))
                 wave.path[:] = 0
-                wave.a[:] = (wave.xDiffr - dxR) / wave.rDiffr
+                wave.a[:] = (wave.xDiffr - px) / wave.rDiffr
                 wave.b[:] = wave.yDiffr / wave.rDiffr
-                wave.c[:] = (wave.zDiffr - dzR) / wave.rDiffr
+                wave.c[:] = (wave.zDiffr - pz) / wave.rDiffr
+                area = wave.areaNormal if hasattr(wave, 'areaNormal') else wave.area
+                spread = area**0.5 / wave.rDiffr     # field per sample area
+                fs *= spread
+                fp *= spread
             else:
-                bot.x[:] = dxR
-                bot.z[:] = dzR
-                bot.a[:] = rTheta[I_pass]
-                bot.c[:] = rPsi[I_pass]
-                if self.filamentBeam:
-                    bot.a[:] += dtheta
-                    bot.c[:] += dpsi
-                else:
+                bot.x[:] = px
+                bot.z[:] = pz
+                bot.a[:] = theta[keep]
+                bot.c[:] = psi[keep]
+                if el is not None:
+                    bot.a[:] += el['xp']
+                    bot.c[:] += el['zp']
+                else:                       # electron divergence: 2 normal arrays
                     if self.dxprime > 0:
                         bot.a[:] += np.random.normal(0, self.dxprime, npassed)
                     if self.dzprime > 0:
                         bot.c[:] += np.random.normal(0, self.dzprime, npassed)
-
-            mJs = mJs[I_pass]
-            mJp = mJp[I_pass]
-            if wave is not None:
-                area = wave.areaNormal if hasattr(wave, 'areaNormal') else \
-                    wave.area
-                norm = area**0.5 / wave.rDiffr
-                mJs *= norm
-                mJp *= norm
-            mJs2 = (mJs * np.conj(mJs)).real
-            mJp2 = (mJp * np.conj(mJp)).real
-            sSP = 1. if self.uniformRayDensity else mJs2 + mJp2
-            with np.errstate(invalid='ignore', divide='ignore'):
-                bot.Jsp[:] = np.where(sSP, mJs * np.conj(mJp) / sSP, 0)
-                bot.Jss[:] = np.where(sSP, mJs2 / sSP, 0)
-                bot.Jpp[:] = np.where(sSP, mJp2 / sSP, 0)
-                if withAmplitudes:
-                    if self.uniformRayDensity:
-                        bot.Es[:] = mJs
-                        bot.Ep[:] = mJp
-                    else:
-                        bot.Es[:] = mJs / mJs2**0.5
-                        bot.Ep[:] = mJp / mJp2**0.5
+            self._set_polarisation(bot, fs, fp, withAmplitudes)
             parts.append(bot)
             length += npassed
+            if self.uniformRayDensity:
+                break
             if self.filamentBeam:
                 nrep += 1
-                more = nrep < self.nrepmax
-            else:
-                more = length < self.nrays
-            if self.uniformRayDensity:
-                more = False
-            if not more:
+                if nrep >= self.nrepmax:
+                    break
+            elif length >= self.nrays:
                 break
 
         bo = parts[0] if len(parts) == 1 else _concatenate(parts, withAmplitudes)
@@ -670,34 +675,33 @@ class Undulator(object):
         bo.acceptedE = bo.E.sum() * self.fluxConst * SIE0
         bo.seeded = seeded
         bo.seededI = seededI
-        nnorm = self.nrays if wave is None else len(wave.a)
-        bo.sourceWeight = sourceWeight / nnorm
+        bo.sourceWeight = sourceWeight / (self.nrays if wave is None else len(wave.a))
         if length > self.nrays and not self.filamentBeam and wave is None:
             bo.filter_by_index(slice(0, int(self.nrays)))
-        if self.filamentBeam:
-            bo.filamentDtheta, bo.filamentDpsi = dtheta, dpsi
-            bo.filamentDX, bo.filamentDZ = rX, rZ
-            bo.filamentDgamma = dgamma
+        if el is not None:
+            bo.filamentDtheta, bo.filamentDpsi = el['xp'], el['zp']
+            bo.filamentDX, bo.filamentDZ = el['x'], el['z']
+            bo.filamentDgamma = el['dgamma']
         norm = (bo.a**2 + bo.b**2 + bo.c**2)**0.5
         bo.a /= norm
         bo.b /= norm
         bo.c /= norm
         if self.pitch or self.yaw:
             raycing.rotate_beam(bo, pitch=self.pitch, yaw=self.yaw)
-        bor = Beam(copyFrom=bo)
+        out = Beam(copyFrom=bo)
         if wave is not None:
-            bor.x[:] = dxR
-            bor.y[:] = 0.
-            bor.z[:] = dzR
-            if self.R0 is None:
-                bor.path[:] = 0.
-                mPh = np.exp(1e7j * wave.E/CHBAR * wave.rDiffr)
-                wave.Es *= mPh
-                wave.Ep *= mPh
-        bor.parentId = self.uuid
+            out.x[:] = px
+            out.y[:] = 0.
+            out.z[:] = pz
+            if self.R0 is None:     # far field: carry the spherical-wave phase
+                out.path[:] = 0.
+                phase = np.exp(1e7j * wave.E/CHBAR * wave.rDiffr)
+                wave.Es *= phase
+                wave.Ep *= phase
+        out.parentId = self.uuid
         if toGlobal:
-            raycing.virgin_local_to_global(self.bl, bor, self.center)
-        return bor
+            raycing.virgin_local_to_global(self.bl, out, self.center)
+        return out
 
 
 def _concatenate(parts, withAmplitudes):
