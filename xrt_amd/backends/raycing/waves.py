@@ -21,58 +21,59 @@ _DEBUG = 0
 lastKernelMs = None
 
 
-def prepare_wave(fromOE, wave, xglo, yglo, zglo):
-    """Receiving points *xglo, yglo, zglo* expressed in the local frame of the
-    diffracting element *fromOE*; zeroed accumulators (waves.py:505-584)."""
-    if not hasattr(wave, 'Es'):
-        nrays = len(wave.x)
-        wave.Es = np.zeros(nrays, dtype=complex)
-        wave.Ep = np.zeros(nrays, dtype=complex)
-    else:
-        wave.Es[:] = 0
-        wave.Ep[:] = 0
-    wave.EsAcc = np.zeros_like(wave.Es)
-    wave.EpAcc = np.zeros_like(wave.Es)
-    wave.aEacc = np.zeros_like(wave.Es)
-    wave.bEacc = np.zeros_like(wave.Es)
-    wave.cEacc = np.zeros_like(wave.Es)
-    wave.Jss[:] = 0
-    wave.Jpp[:] = 0
-    wave.Jsp[:] = 0
-    x, y, z = np.array(xglo, dtype=float), np.array(yglo, dtype=float), \
-        np.array(zglo, dtype=float)
-    x -= fromOE.center[0]
-    y -= fromOE.center[1]
-    z -= fromOE.center[2]
-    a0, b0 = fromOE.bl.sinAzimuth, fromOE.bl.cosAzimuth
-    x[:], y[:] = raycing.rotate_z(x, y, b0, a0)
-    if hasattr(fromOE, 'rotationSequence'):  # OE
-        dt = 0
-        extraAnglesSign = 1.
-        if hasattr(fromOE, 'local_n2') and hasattr(fromOE, 'cryst2pitch'):
+_ACCUMULATORS = ('EsAcc', 'EpAcc', 'aEacc', 'bEacc', 'cEacc')
+
+
+def _into_frame_of(element, xglo, yglo, zglo):
+    """Global points -> the local frame of *element*: shift to its centre, undo
+    the beamline azimuth and, for an optical element, its own rotations
+    (waves.py:529-560)."""
+    px = np.array(xglo, dtype=float) - element.center[0]
+    py = np.array(yglo, dtype=float) - element.center[1]
+    pz = np.array(zglo, dtype=float) - element.center[2]
+    bl = element.bl
+    px[:], py[:] = raycing.rotate_z(px, py, bl.cosAzimuth, bl.sinAzimuth)
+    if hasattr(element, 'rotationSequence'):
+        if hasattr(element, 'local_n2') and hasattr(element, 'cryst2pitch'):
             raise NotImplementedError('wave propagation from a DCM/plate 2nd '
                                       'surface')
-        raycing.rotate_xyz(
-            x, y, z, rotationSequence=fromOE.rotationSequence,
-            pitch=-fromOE.pitch, roll=-(fromOE.roll+fromOE.positionRoll),
-            yaw=-fromOE.yaw)
-        if fromOE.extraPitch or fromOE.extraRoll or fromOE.extraYaw:
-            raycing.rotate_xyz(
-                x, y, z, rotationSequence=fromOE.extraRotationSequence,
-                pitch=-extraAnglesSign*fromOE.extraPitch,
-                roll=-fromOE.extraRoll, yaw=-extraAnglesSign*fromOE.extraYaw)
-        if dt:
-            z += dt
-    wave.xDiffr = x
-    wave.yDiffr = y
-    wave.zDiffr = z
-    wave.rDiffr = (wave.xDiffr**2 + wave.yDiffr**2 + wave.zDiffr**2)**0.5
-    wave.a[:] = wave.xDiffr / wave.rDiffr
-    wave.b[:] = wave.yDiffr / wave.rDiffr
-    wave.c[:] = wave.zDiffr / wave.rDiffr
+        raycing.rotate_xyz(px, py, pz, rotationSequence=element.rotationSequence,
+                           pitch=-element.pitch,
+                           roll=-(element.roll + element.positionRoll),
+                           yaw=-element.yaw)
+        if element.extraPitch or element.extraRoll or element.extraYaw:
+            raycing.rotate_xyz(px, py, pz,
+                               rotationSequence=element.extraRotationSequence,
+                               pitch=-element.extraPitch, roll=-element.extraRoll,
+                               yaw=-element.extraYaw)
+    return px, py, pz
+
+
+def prepare_wave(fromOE, wave, xglo, yglo, zglo):
+    """Binds the receiving samples *wave* (global positions *xglo, yglo, zglo*)
+    to the diffracting element *fromOE*: their coordinates in its local frame
+    (``xDiffr`` ...), unit directions from its centre, and empty field
+    accumulators (reference: waves.py:505-584)."""
+    nsamples = len(wave.x)
+    if hasattr(wave, 'Es'):
+        wave.Es[:] = 0
+        wave.Ep[:] = 0
+    else:
+        wave.Es = np.zeros(nsamples, dtype=complex)
+        wave.Ep = np.zeros(nsamples, dtype=complex)
+    for name in _ACCUMULATORS:
+        setattr(wave, name, np.zeros(nsamples, dtype=complex))
+    for component in (wave.Jss, wave.Jpp, wave.Jsp):
+        component[:] = 0
+    px, py, pz = _into_frame_of(fromOE, xglo, yglo, zglo)
+    dist = (px**2 + py**2 + pz**2)**0.5
+    wave.xDiffr, wave.yDiffr, wave.zDiffr, wave.rDiffr = px, py, pz, dist
+    wave.a[:] = px / dist
+    wave.b[:] = py / dist
+    wave.c[:] = pz / dist
     wave.path[:] = 0.
     wave.fromOE = fromOE
-    wave.beamReflRays = np.int64(0)
+    wave.beamReflRays = np.int64(0)       # running sums over repeated diffract()
     wave.beamReflSumJ = 0.
     wave.beamReflSumJnl = 0.
     wave.diffract_repeats = np.int64(0)
@@ -158,160 +159,176 @@ def _kirchhoff_on_gpu(oeLocal, n, nl, wave, good):
     return [o.cpu().numpy() for o in out[:5]]
 
 
-def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
-             precisionOpenCL=raycing.precisionOpenCL):
-    """Diffracted field on the points of *wave* from the field *oeLocal* on the
-    diffracting surface ``wave.fromOE`` (waves.py:606-831). Returns the global
-    beam; *wave* accumulates over repeated calls."""
-    oe = wave.fromOE
-    t0 = time.time()
-    good = oeLocal.state == 1
-    goodlen = good.sum()
-    if goodlen < 1e2:
-        print("Not enough good rays at {0}: {1} of {2}".format(
-            oe.name, goodlen, len(oeLocal.x)))
-        return rs.Beam(goodlen)
-    if len(wave.xDiffr) == 0:
-        print("No wave samples on {0}".format(oe.name))
-        return rs.Beam(goodlen)
-
-    shouldCalculateArea = False
-    if not hasattr(oeLocal, 'area'):
-        shouldCalculateArea = True
-    elif oeLocal.area is None or (oeLocal.area <= 0):
-        shouldCalculateArea = True
-    if shouldCalculateArea:
-        if hasattr(oe, 'rotationSequence'):
-            secondDim = oeLocal.y
-        elif hasattr(oe, 'propagate') or hasattr(oe, 'prepare_wave') or \
-                hasattr(oe, 'shine'):
-            secondDim = oeLocal.z
-        else:
-            raise ValueError('Unknown diffracting element!')
-        oeLocal.area = convex_hull_area(oeLocal.x[good], secondDim[good])
-        if hasattr(oeLocal, 'areaFraction'):
-            oeLocal.area *= oeLocal.areaFraction
-
-    if hasattr(oe, 'rotationSequence'):  # OE
-        local_n = oe.local_n2 if hasattr(oe, 'cryst2pitch') else oe.local_n
-        if oe.isParametric:                 # waves.py:680-682
-            sp, phi, _ = oe.xyz_to_param(oeLocal.x, oeLocal.y, oeLocal.z)
-            n = local_n(sp, phi)
-        else:
-            n = local_n(oeLocal.x, oeLocal.y)[-3:]
-        nl = (oeLocal.a*np.asarray([n[-3]]) + oeLocal.b*np.asarray([n[-2]]) +
-              oeLocal.c*np.asarray([n[-1]])).flatten()
+def _illuminated_area(oe, field, lit):
+    """Footprint of the lit samples on the diffracting element, for the flux
+    normalisation: given by whoever made *field*, else the convex hull in the
+    element's surface coordinates (waves.py:642-670)."""
+    area = getattr(field, 'area', None)
+    if area is not None and area > 0:
+        return area
+    if hasattr(oe, 'rotationSequence'):
+        along = field.y                      # an optical element: (x, y)
+    elif hasattr(oe, 'propagate') or hasattr(oe, 'prepare_wave') or \
+            hasattr(oe, 'shine'):
+        along = field.z                      # aperture / screen / source: (x, z)
     else:
-        n = [0, 1, 0]
-        nl = oeLocal.a*n[0] + oeLocal.b*n[1] + oeLocal.c*n[2]
+        raise ValueError('Unknown diffracting element!')
+    area = convex_hull_area(field.x[lit], along[lit])
+    if hasattr(field, 'areaFraction'):
+        area *= field.areaFraction
+    return area
 
-    wave.diffract_repeats += 1
-    wave.beamReflRays += goodlen
-    wave.beamReflSumJ += (oeLocal.Jss[good] + oeLocal.Jpp[good]).sum()
-    wave.beamReflSumJnl += abs(((oeLocal.Jss[good] + oeLocal.Jpp[good]) *
-                               nl[good]).sum())
 
-    Es, Ep, aE, bE, cE = _kirchhoff_on_gpu(oeLocal, n, nl, wave, good)
+def _surface_normals(oe, field):
+    """Normal of the diffracting surface at every sample and the cosine between
+    it and the incoming direction (waves.py:674-689)."""
+    if not hasattr(oe, 'rotationSequence'):
+        normal = [0, 1, 0]
+        return normal, field.a*normal[0] + field.b*normal[1] + field.c*normal[2]
+    normal_at = oe.local_n2 if hasattr(oe, 'cryst2pitch') else oe.local_n
+    if oe.isParametric:
+        sp, phi, _ = oe.xyz_to_param(field.x, field.y, field.z)
+        normal = normal_at(sp, phi)
+    else:
+        normal = normal_at(field.x, field.y)[-3:]
+    cosine = (field.a*np.asarray([normal[-3]]) + field.b*np.asarray([normal[-2]]) +
+              field.c*np.asarray([normal[-1]])).flatten()
+    return normal, cosine
 
-    wave.EsAcc += Es
-    wave.EpAcc += Ep
-    wave.aEacc += aE
-    wave.bEacc += bE
-    wave.cEacc += cE
-    wave.E[:] = oeLocal.E[0]
+
+def _fields_and_directions(oe, wave, energy):
+    """From the accumulated integrals: amplitudes, coherency matrix and the
+    propagation direction (the direction integrals share one arbitrary phase,
+    removed with the dominant component; waves.py:707-733)."""
+    wave.E[:] = energy
     wave.Es[:] = wave.EsAcc
     wave.Ep[:] = wave.EpAcc
     wave.Jss[:] = (wave.Es * np.conj(wave.Es)).real
     wave.Jpp[:] = (wave.Ep * np.conj(wave.Ep)).real
     wave.Jsp[:] = wave.Es * np.conj(wave.Ep)
+    carrier = wave.bEacc
+    if hasattr(oe, 'rotationSequence') and abs(wave.cEacc[0]) > abs(wave.bEacc[0]):
+        carrier = wave.cEacc
+    unphase = np.exp(-1j * np.angle(carrier))
+    wave.a[:] = (wave.aEacc * unphase).real
+    wave.b[:] = (wave.bEacc * unphase).real
+    wave.c[:] = (wave.cEacc * unphase).real
+    length = (wave.a**2 + wave.b**2 + wave.c**2)**0.5
+    length[length == 0] = 1.
+    wave.a /= length
+    wave.b /= length
+    wave.c /= length
 
-    if hasattr(oe, 'rotationSequence'):  # OE: waves.py:719-722
-        toRealComp = wave.cEacc if abs(wave.cEacc[0]) > abs(wave.bEacc[0]) \
-            else wave.bEacc
-        toReal = np.exp(-1j * np.angle(toRealComp))
-    else:
-        toReal = np.exp(-1j * np.angle(wave.bEacc))
-    wave.a[:] = (wave.aEacc * toReal).real
-    wave.b[:] = (wave.bEacc * toReal).real
-    wave.c[:] = (wave.cEacc * toReal).real
-    norm = (wave.a**2 + wave.b**2 + wave.c**2)**0.5
-    norm[norm == 0] = 1.
-    wave.a /= norm
-    wave.b /= norm
-    wave.c /= norm
 
-    norm = wave.dS * oeLocal.area * wave.beamReflSumJ
-    de = wave.beamReflRays * wave.beamReflSumJnl * wave.diffract_repeats
-    if de > 0:
-        norm /= de
-    else:
-        norm = 0
-    wave.Jss *= norm
-    wave.Jpp *= norm
-    wave.Jsp *= norm
-    wave.Es *= norm**0.5
-    wave.Ep *= norm**0.5
-    if hasattr(oeLocal, 'accepted'):
-        wave.accepted = oeLocal.accepted
-        wave.acceptedE = oeLocal.acceptedE
-        wave.seeded = oeLocal.seeded
-        wave.seededI = oeLocal.seededI * len(wave.x) / len(oeLocal.x)
+def _scale_to_flux(wave, area):
+    """Monte-Carlo weight of the integral: receiving cell x illuminated area x
+    incoming flux over (samples x obliquity-weighted flux x repeats),
+    waves.py:735-749."""
+    scale = wave.dS * area * wave.beamReflSumJ
+    denom = wave.beamReflRays * wave.beamReflSumJnl * wave.diffract_repeats
+    scale = scale / denom if denom > 0 else 0
+    wave.Jss *= scale
+    wave.Jpp *= scale
+    wave.Jsp *= scale
+    wave.Es *= scale**0.5
+    wave.Ep *= scale**0.5
 
+
+def _as_global_beam(oe, wave):
+    """Copy of *wave* positioned at the receiving points in the global frame
+    (waves.py:756-770)."""
     glo = rs.Beam(copyFrom=wave)
     glo.parentId = oe.uuid
     glo.x[:] = wave.xDiffr
     glo.y[:] = wave.yDiffr
     glo.z[:] = wave.zDiffr
     if hasattr(oe, 'local_to_global'):
-        if hasattr(oe, 'expose'):  # a Screen
-            glo.x[:], glo.y[:], glo.z[:] = \
-                oe.local_to_global(glo.x, glo.y, glo.z)
+        if hasattr(oe, 'expose'):            # a screen transforms bare arrays
+            glo.x[:], glo.y[:], glo.z[:] = oe.local_to_global(glo.x, glo.y, glo.z)
         else:
             oe.local_to_global(glo)
+    return glo
 
-    if hasattr(wave, 'toOE'):          # waves.py:773-824
-        if hasattr(oe, 'rotationSequence'):
-            rollAngle = oe.roll + oe.positionRoll
-            cosY, sinY = np.cos(rollAngle), np.sin(rollAngle)
-            Es[:], Ep[:] = raycing.rotate_y(Es, Ep, cosY, sinY)
-        toOE = wave.toOE
-        wave.a[:], wave.b[:], wave.c[:] = glo.a, glo.b, glo.c
-        wave.Jss[:], wave.Jpp[:], wave.Jsp[:] = glo.Jss, glo.Jpp, glo.Jsp
-        wave.Es[:], wave.Ep[:] = glo.Es, glo.Ep
-        a0, b0 = toOE.bl.sinAzimuth, toOE.bl.cosAzimuth
-        wave.a[:], wave.b[:] = raycing.rotate_z(wave.a, wave.b, b0, a0)
-        if hasattr(toOE, 'rotationSequence'):  # the receiver is an OE
-            if toOE.isParametric:          # waves.py:791-793
-                sp, phi, _ = toOE.xyz_to_param(wave.x, wave.y, wave.z)
-                oeNormal = list(toOE.local_n(sp, phi))
-            else:
-                oeNormal = list(toOE.local_n(wave.x, wave.y))
-            rollAngle = toOE.roll + toOE.positionRoll +\
-                np.arctan2(oeNormal[-3], oeNormal[-1])
-            wave.Jss[:], wave.Jpp[:], wave.Jsp[:] = \
-                rs.rotate_coherency_matrix(wave, slice(None), -rollAngle)
-            cosY, sinY = np.cos(rollAngle), np.sin(rollAngle)
-            wave.Es[:], wave.Ep[:] = raycing.rotate_y(
-                wave.Es, wave.Ep, cosY, -sinY)
-            raycing.rotate_xyz(
-                wave.a, wave.b, wave.c, rotationSequence=toOE.rotationSequence,
-                pitch=-toOE.pitch, roll=-toOE.roll-toOE.positionRoll,
-                yaw=-toOE.yaw)
-            if toOE.extraPitch or toOE.extraRoll or toOE.extraYaw:
-                raycing.rotate_xyz(
-                    wave.a, wave.b, wave.c,
-                    rotationSequence=toOE.extraRotationSequence,
-                    pitch=-toOE.extraPitch, roll=-toOE.extraRoll,
-                    yaw=-toOE.extraYaw)
-            norm = -wave.a*oeNormal[-3] - wave.b*oeNormal[-2] -\
-                wave.c*oeNormal[-1]
-            norm = np.abs(norm)
-            for b in (wave, glo):
-                b.Jss *= norm
-                b.Jpp *= norm
-                b.Jsp *= norm
-                b.Es *= norm**0.5
-                b.Ep *= norm**0.5
+
+def _into_receiver_frame(wave, glo):
+    """The receiving samples live on an element (``wave.toOE``): directions,
+    coherency matrix and amplitudes go from the global frame into its local
+    s/p frame, and the flux is projected on its surface (waves.py:773-824)."""
+    receiver = wave.toOE
+    wave.a[:], wave.b[:], wave.c[:] = glo.a, glo.b, glo.c
+    wave.Jss[:], wave.Jpp[:], wave.Jsp[:] = glo.Jss, glo.Jpp, glo.Jsp
+    wave.Es[:], wave.Ep[:] = glo.Es, glo.Ep
+    bl = receiver.bl
+    wave.a[:], wave.b[:] = raycing.rotate_z(wave.a, wave.b, bl.cosAzimuth,
+                                            bl.sinAzimuth)
+    if not hasattr(receiver, 'rotationSequence'):
+        return
+    if receiver.isParametric:
+        sp, phi, _ = receiver.xyz_to_param(wave.x, wave.y, wave.z)
+        normal = list(receiver.local_n(sp, phi))
+    else:
+        normal = list(receiver.local_n(wave.x, wave.y))
+    turn = receiver.roll + receiver.positionRoll + np.arctan2(normal[-3], normal[-1])
+    wave.Jss[:], wave.Jpp[:], wave.Jsp[:] = \
+        rs.rotate_coherency_matrix(wave, slice(None), -turn)
+    wave.Es[:], wave.Ep[:] = raycing.rotate_y(wave.Es, wave.Ep, np.cos(turn),
+                                              -np.sin(turn))
+    raycing.rotate_xyz(wave.a, wave.b, wave.c,
+                       rotationSequence=receiver.rotationSequence,
+                       pitch=-receiver.pitch,
+                       roll=-receiver.roll-receiver.positionRoll, yaw=-receiver.yaw)
+    if receiver.extraPitch or receiver.extraRoll or receiver.extraYaw:
+        raycing.rotate_xyz(wave.a, wave.b, wave.c,
+                           rotationSequence=receiver.extraRotationSequence,
+                           pitch=-receiver.extraPitch, roll=-receiver.extraRoll,
+                           yaw=-receiver.extraYaw)
+    obliquity = np.abs(-wave.a*normal[-3] - wave.b*normal[-2] - wave.c*normal[-1])
+    for beam in (wave, glo):
+        beam.Jss *= obliquity
+        beam.Jpp *= obliquity
+        beam.Jsp *= obliquity
+        beam.Es *= obliquity**0.5
+        beam.Ep *= obliquity**0.5
+
+
+def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
+             precisionOpenCL=raycing.precisionOpenCL):
+    """Field diffracted from the samples *oeLocal* on ``wave.fromOE`` onto the
+    points of *wave*, by the Fresnel-Kirchhoff integral on the GPU. *wave* is
+    updated (it accumulates over repeated calls); returns the same field as a
+    beam in the global frame. Interface of the reference's ``waves.diffract``
+    (waves.py:606-831)."""
+    oe = wave.fromOE
+    t0 = time.time()
+    lit = oeLocal.state == 1
+    nlit = lit.sum()
+    if nlit < 1e2:
+        print("Not enough good rays at {0}: {1} of {2}".format(
+            oe.name, nlit, len(oeLocal.x)))
+        return rs.Beam(nlit)
+    if len(wave.xDiffr) == 0:
+        print("No wave samples on {0}".format(oe.name))
+        return rs.Beam(nlit)
+    oeLocal.area = _illuminated_area(oe, oeLocal, lit)
+    normal, cosine = _surface_normals(oe, oeLocal)
+    flux = oeLocal.Jss[lit] + oeLocal.Jpp[lit]
+    wave.diffract_repeats += 1
+    wave.beamReflRays += nlit
+    wave.beamReflSumJ += flux.sum()
+    wave.beamReflSumJnl += abs((flux * cosine[lit]).sum())
+    integrals = _kirchhoff_on_gpu(oeLocal, normal, cosine, wave, lit)
+    for name, part in zip(_ACCUMULATORS, integrals):
+        getattr(wave, name).__iadd__(part)
+    _fields_and_directions(oe, wave, oeLocal.E[0])
+    _scale_to_flux(wave, oeLocal.area)
+    if hasattr(oeLocal, 'accepted'):         # source bookkeeping for absolute flux
+        wave.accepted = oeLocal.accepted
+        wave.acceptedE = oeLocal.acceptedE
+        wave.seeded = oeLocal.seeded
+        wave.seededI = oeLocal.seededI * len(wave.x) / len(oeLocal.x)
+    glo = _as_global_beam(oe, wave)
+    if hasattr(wave, 'toOE'):
+        _into_receiver_frame(wave, glo)
     if _DEBUG > 10:
         print("diffract on {0} completed in {1:.4f} s".format(
             oe.name, time.time()-t0))
