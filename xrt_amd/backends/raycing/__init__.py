@@ -171,5 +171,19 @@ def auto_units_angle(angle, defaultFactor=1.):
     return angle * defaultFactor
 
 
+def along_basis(basis, u, v, w, origin=None):
+    """u*ex + v*ey + w*ez (+ origin) for the three basis vectors of a screen or
+    an aperture, in the reference's summation order (component by component:
+    ((o + u ex) + v ey) + w ez)."""
+    ex, ey, ez = basis
+    out = []
+    for k in range(3):
+        if origin is None:
+            out.append(u*ex[k] + v*ey[k] + w*ez[k])
+        else:
+            out.append(origin[k] + u*ex[k] + v*ey[k] + w*ez[k])
+    return out
+
+
 def new_uuid():
     return str(uuid.uuid4())

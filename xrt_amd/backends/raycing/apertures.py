@@ -68,18 +68,12 @@ class RectangularAperture(object):
         return list(self.blades.values())
 
     def local_to_global(self, glo, returnBeam=False, **kwargs):
-        kwargs['returnBeam'] = returnBeam
-        """apertures.py:436-457 on host arrays."""
-        x, y, z = glo.x, glo.y, glo.z
-        xglo = self.center[0] + x*self.x[0] + y*self.y[0] + z*self.z[0]
-        yglo = self.center[1] + x*self.x[1] + y*self.y[1] + z*self.z[1]
-        zglo = self.center[2] + x*self.x[2] + y*self.y[2] + z*self.z[2]
-        glo.x, glo.y, glo.z = xglo, yglo, zglo
-        a, b, c = glo.a, glo.b, glo.c
-        aglo = a*self.x[0] + b*self.y[0] + c*self.z[0]
-        bglo = a*self.x[1] + b*self.y[1] + c*self.z[1]
-        cglo = a*self.x[2] + b*self.y[2] + c*self.z[2]
-        glo.a, glo.b, glo.c = aglo, bglo, cglo
+        """Beam in the aperture's frame -> global frame, in place
+        (reference: apertures.py:436-457)."""
+        basis = (self.x, self.y, self.z)
+        glo.x, glo.y, glo.z = raycing.along_basis(basis, glo.x, glo.y, glo.z,
+                                                  self.center)
+        glo.a, glo.b, glo.c = raycing.along_basis(basis, glo.a, glo.b, glo.c)
 
     def propagate(self, beam=None, needNewGlobal=False):
         """Rays stopped by the blades get state ``lostNum`` — in *beam* itself
@@ -133,12 +127,12 @@ class RectangularAperture(object):
             from . import waves as rw
         nrays = int(nrays)
         wave = rs.Beam(nrays=nrays, forceState=1, withAmplitudes=True)
-        xy = np.random.rand(nrays, 2)
-        dX = self.limOptX[1] - self.limOptX[0]
-        dZ = self.limOptY[1] - self.limOptY[0]
-        wave.x[:] = xy[:, 0] * dX + self.limOptX[0]
-        wave.z[:] = xy[:, 1] * dZ + self.limOptY[0]
-        wave.area = dX * dZ
+        uv = np.random.rand(nrays, 2)             # one (nrays, 2) draw, like xrt
+        width = self.limOptX[1] - self.limOptX[0]
+        height = self.limOptY[1] - self.limOptY[0]
+        wave.x[:] = uv[:, 0] * width + self.limOptX[0]
+        wave.z[:] = uv[:, 1] * height + self.limOptY[0]
+        wave.area = width * height
         wave.dS = wave.area / nrays
         wave.toOE = self
         wave.parentId = self.uuid

@@ -41,10 +41,8 @@ class Screen(object):
         self.x, self.y, self.z = raycing.xyz_from_xz(self, x, z)
 
     def local_to_global(self, x=0, y=0, z=0, **kwargs):
-        xglo = self.center[0] + x*self.x[0] + y*self.y[0] + z*self.z[0]
-        yglo = self.center[1] + x*self.x[1] + y*self.y[1] + z*self.z[1]
-        zglo = self.center[2] + x*self.x[2] + y*self.y[2] + z*self.z[2]
-        return xglo, yglo, zglo
+        return tuple(raycing.along_basis((self.x, self.y, self.z), x, y, z,
+                                         self.center))
 
     def expose(self, beam=None, onlyPositivePath=False):
         """*beam* in the global frame -> the image in the screen's local frame
