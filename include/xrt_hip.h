@@ -124,8 +124,9 @@ typedef struct xrt_hip_rotation {
 #define XRT_HIP_SURF_BENTFLAT 2   /* z = (y^2 - y0^2)/2/R, oes/__init__.py:240-303 */
 #define XRT_HIP_SURF_BLAZED 3     /* saw-tooth grating, constant line density,
                                      oes/gratings.py:316-535 (own first-facet intersection) */
-#define XRT_HIP_SURF_ELLIPSE_PARAM 4  /* EllipticalMirrorParam, oes/parametric.py:9-249:
-                                     parametric (s, phi, r) root solve, base.py:822-841 */
+#define XRT_HIP_SURF_ELLIPSE_PARAM 4  /* Elliptical / Parabolical / HyperbolicMirrorParam,
+                                     oes/parametric.py:9-716: parametric (s, phi, r) root
+                                     solve, base.py:822-841; surf_p[8] selects the conic */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_OVER_XMIN 1
@@ -154,8 +155,11 @@ typedef struct xrt_hip_pass {
                                   blazed: rho_1 (= 1/rho), tanBlaze, tanAntiblaze, sinBlaze,
                                   cosBlaze, sinAntiblaze, cosAntiblaze, 1+tanAntiblaze/tanBlaze,
                                   blaze==pi/2, antiblaze==pi/2;
-                                  ellipse: y0, z0, cosGamma, sinGamma, ellipseA, ellipseB,
-                                  isCylindrical, isClosed (parametric.py:143-157) */
+                                  conic of revolution (XRT_HIP_SURF_ELLIPSE_PARAM): y0, z0,
+                                  cosGamma, sinGamma, A, B, isCylindrical, isClosed, conic
+                                  (0 ellipse: A, B = ellipseA, ellipseB, parametric.py:143-157;
+                                  1 parabola: A = parabParam, :411-425; 2 hyperbola: A, B =
+                                  hyperbolaA, hyperbolaB, :611-622) */
   double n_const[6];           /* flat: [nH(3), n_surface(3)] (base.py:719-742) */
   int32_t asymmetric;          /* 1: n_const holds two different normals */
   /* limits, base.py:1094-1163 */

@@ -17,8 +17,20 @@ def oracle_params(oe):
         extraRotationSequence=oe.extraRotationSequence, dx=oe.dx, shape=oe.shape,
         overEdge=oe.overEdge, lostNum=oe.lostNum, surfPhysX=list(oe.limPhysX),
         surfPhysY=list(oe.limPhysY), surfOptX=oe.limOptX, surfOptY=oe.limOptY)
+    if hasattr(oe, 'invertNormal'):
+        p['invertNormal'] = int(oe.invertNormal)
     tb = fixture_io.tables()
-    if hasattr(oe, 'ellipseA'):
+    if hasattr(oe, 'parabParam'):
+        p['surface'] = dict(
+            kind='parabola_param', isCylindrical=bool(oe.isCylindrical),
+            isClosed=bool(oe.isClosed), cosGamma=oe.cosGamma, sinGamma=oe.sinGamma,
+            y0=oe.y0, z0=oe.z0, parabParam=oe.parabParam)
+    elif hasattr(oe, 'hyperbolaA'):
+        p['surface'] = dict(
+            kind='hyperbola_param', isCylindrical=bool(oe.isCylindrical),
+            isClosed=bool(oe.isClosed), cosGamma=oe.cosGamma, sinGamma=oe.sinGamma,
+            y0=oe.y0, z0=oe.z0, hyperbolaA=oe.hyperbolaA, hyperbolaB=oe.hyperbolaB)
+    elif hasattr(oe, 'ellipseA'):
         p['surface'] = dict(
             kind='ellipse_param', isCylindrical=bool(oe.isCylindrical),
             isClosed=bool(oe.isClosed), p=oe.p, q=oe.q, cosGamma=oe.cosGamma,

@@ -31,6 +31,8 @@ def _unflatten(g):
             p[name] = [float(t) for t in v]
     p['azimuth_sc'] = tuple(p['azimuth_sc'])
     p['lostNum'] = int(p['lostNum'])
+    if 'invertNormal' in p:
+        p['invertNormal'] = int(p['invertNormal'])
     return p
 
 
@@ -68,6 +70,15 @@ def load_case(name):
     elif name == 'g2_blazed_au':
         p['surface'] = rn.make_blazed(float(g['surf_blaze']), float(g['surf_rho']),
                                       float(g['surf_antiblaze']))
+        p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
+                                         'mirror', float(g['mat_rho']))
+    elif name.startswith('g2_parabola') or name == 'g2_hyperbola':
+        keys = ('cosGamma', 'sinGamma', 'y0', 'z0') + (
+            ('parabParam',) if 'parabola' in name else ('hyperbolaA', 'hyperbolaB'))
+        p['surface'] = dict(
+            kind='parabola_param' if 'parabola' in name else 'hyperbola_param',
+            isClosed=False, isCylindrical=bool(float(g['surf_isCylindrical'])),
+            **{k: float(g['surf_' + k]) for k in keys})
         p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
                                          'mirror', float(g['mat_rho']))
     elif name.startswith('g2_ellipse'):

@@ -86,6 +86,8 @@ def oe_params(oe, surface):
         surfOptX=None if oe.surfOptX is None else list(oe.surfOptX),
         surfOptY=None if oe.surfOptY is None else list(oe.surfOptY),
         surface=surface)
+    if hasattr(oe, 'invertNormal'):          # e.g. HyperbolicMirrorParam
+        p['invertNormal'] = int(oe.invertNormal)
     if hasattr(oe, 'cryst2pitch'):
         p.update(
             bragg=oe.bragg, cryst1roll=oe.cryst1roll, cryst2roll=oe.cryst2roll,

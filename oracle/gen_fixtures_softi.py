@@ -11,6 +11,11 @@ tests/speed/3_Softi_CXIw2D_speed.py:176-246):
   g2_ellipse_full.npz   same, ellipsoid of revolution (isCylindrical=False)
   g2_ellipse_cyl_nis.npz  reflect(noIntersectionSearch=True) on points that
                         already lie on the surface (what follows a diffract)
+  g2_parabola_q.npz / g2_parabola_p_cyl.npz / g2_hyperbola.npz
+                        ParabolicalMirrorParam (focusing paraboloid; collimating
+                        parabolic cylinder) and HyperbolicMirrorParam
+                        (parametric.py:252-716): the other two conics of the
+                        same parametric family
   g2_grating_vls.npz    plane grating with the grating EQUATION (material
                         kind='grating', reflect.py:840-861, 451-469): VLS line
                         density polynomial along y, order -1, as a PGM grating
@@ -173,5 +178,59 @@ def main():
             print(tag + '_nis', 'states', dict(zip(st.tolist(), cnt.tolist())))
 
 
+def conics(raycing, rs, roe, rm, tables):
+    mAu = rm.Material('Au', rho=19.32, kind='mirror')
+    n = 2048
+    pitch = np.radians(1.2)
+    cases = (
+        ('g2_parabola_q', roe.ParabolicalMirrorParam,
+         dict(p=None, q=8000.), 71, rn.make_parabola_param),
+        ('g2_parabola_p_cyl', roe.ParabolicalMirrorParam,
+         dict(p=30000., isCylindrical=True, positionRoll=np.pi/2), 72,
+         rn.make_parabola_param),
+        ('g2_hyperbola', roe.HyperbolicMirrorParam, dict(p=30000., q=6000.), 73,
+         rn.make_hyperbola_param))
+    for tag, cls, kw, seed, maker in cases:
+        bl = raycing.BeamLine()
+        m = cls(bl, 'm', center=[0, 30000., 0], material=mAu, pitch=pitch,
+                limPhysX=(-1.5, 1.5), limPhysY=(-90., 90.), alarmLevel=None, **kw)
+        beam = make_rays(rs, n, seed, sx=0.05, sz=0.05, sa=1.5e-5, sc=1.5e-5,
+                         E=(7000., 9000.), amplitudes=True, pol='mixed')
+        beam.x[0] = 5.
+        beam.state[1] = 3
+        beam.state[2] = -2
+        keys = ('cosGamma', 'sinGamma', 'y0', 'z0') + (
+            ('parabParam',) if 'parabola' in tag else ('hyperbolaA', 'hyperbolaB'))
+        surf = dict(kind='parabola_param' if 'parabola' in tag else 'hyperbola_param',
+                    isCylindrical=bool(m.isCylindrical), isClosed=bool(m.isClosed))
+        for k in keys:
+            surf[k] = float(getattr(m, k))
+        mine = maker(kw.get('p'), kw.get('q'), abs(np.arcsin(np.sin(pitch))),
+                     bool(m.isCylindrical))
+        for k in keys:
+            assert abs(mine[k] - surf[k]) <= 1e-15 * max(1., abs(surf[k])), (tag, k)
+        par = oe_params(m, surf)
+        par['material'] = material_dict(tables, mAu)
+        extra = {'surf_' + k: np.array(surf[k]) for k in keys}
+        extra['surf_isCylindrical'] = np.array(float(m.isCylindrical))
+        extra['surf_p'] = np.array(np.nan if kw.get('p') is None else kw['p'])
+        extra['surf_q'] = np.array(np.nan if kw.get('q') is None else kw['q'])
+        run_reflect(tag, rs, m, par, beam, mat_rho=np.array(19.32), **extra)
+
+
+def main_conics():
+    _refenv.activate()
+    import xrt.backends.raycing as raycing
+    import xrt.backends.raycing.sources as rs
+    import xrt.backends.raycing.oes as roe
+    import xrt.backends.raycing.materials as rm
+    raycing._VERBOSITY_ = 0
+    conics(raycing, rs, roe, rm, load_tables())
+
+
 if __name__ == '__main__':
+    import sys
+    if 'conics' in sys.argv:
+        main_conics()
+        sys.exit(0)
     main()

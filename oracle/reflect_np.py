@@ -244,8 +244,37 @@ def make_ellipse_param(p, q, abs_pitch, isCylindrical=False, isClosed=False):
                 isCylindrical=bool(isCylindrical), isClosed=bool(isClosed))
 
 
+PARAM_KINDS = ('ellipse_param', 'parabola_param', 'hyperbola_param')
+
+
+def make_parabola_param(p, q, abs_pitch, isCylindrical=False, isClosed=False):
+    """ParabolicalMirrorParam._reset_pq (parametric.py:411-425): exactly one of
+    p (collimating) / q (focusing) is given."""
+    if p is None:
+        y0, z0 = q * np.cos(abs_pitch), q * np.sin(abs_pitch)
+        parabParam = -q * np.sin(abs_pitch)**2
+        gamma = abs_pitch
+    else:
+        y0, z0 = -p * np.cos(abs_pitch), p * np.sin(abs_pitch)
+        parabParam = p * np.sin(abs_pitch)**2
+        gamma = -abs_pitch
+    return dict(kind='parabola_param', cosGamma=np.cos(gamma), sinGamma=np.sin(gamma),
+                y0=y0, z0=z0, parabParam=parabParam,
+                isCylindrical=bool(isCylindrical), isClosed=bool(isClosed))
+
+
+def make_hyperbola_param(p, q, abs_pitch, isCylindrical=False, isClosed=False):
+    """HyperbolicMirrorParam._reset_pq (parametric.py:611-622)."""
+    gamma = np.arctan2((p + q) * np.sin(abs_pitch), (p - q) * np.cos(abs_pitch))
+    return dict(kind='hyperbola_param', cosGamma=np.cos(gamma),
+                sinGamma=np.sin(gamma), y0=-(p + q)/2. * np.cos(abs_pitch),
+                z0=(p - q)/2. * np.sin(abs_pitch), hyperbolaA=abs(p - q)/2.,
+                hyperbolaB=np.sqrt(p*q) * np.sin(abs_pitch),
+                isCylindrical=bool(isCylindrical), isClosed=bool(isClosed))
+
+
 def is_param(surf):
-    return surf['kind'] == 'ellipse_param'
+    return surf['kind'] in PARAM_KINDS
 
 
 def xyz_to_param(surf, x, y, z):                  # parametric.py:213-216
@@ -262,12 +291,21 @@ def param_to_xyz(surf, s, phi, r):                # parametric.py:218-223
     return x, yNew + surf['y0'], zNew + surf['z0']
 
 
-def local_r(surf, s, phi):                        # parametric.py:225-231
-    r = surf['ellipseB'] * np.sqrt(abs(1 - s**2 / surf['ellipseA']**2))
+def local_r(surf, s, phi):        # parametric.py:225-231, 450-458, 690-696
+    if surf['kind'] == 'parabola_param':
+        r2 = surf['parabParam']*s + surf['parabParam']**2
+        r2[r2 < 0] = 0
+        r = 2 * r2**0.5
+    elif surf['kind'] == 'hyperbola_param':
+        r = surf['hyperbolaB'] * np.sqrt(abs(s**2/surf['hyperbolaA']**2 - 1))
+    else:
+        r = surf['ellipseB'] * np.sqrt(abs(1 - s**2 / surf['ellipseA']**2))
     if surf['isCylindrical']:
         r /= abs(np.cos(phi))
     if surf['isClosed']:
         return r
+    if surf['kind'] == 'hyperbola_param':           # the branch facing +z
+        return np.where(abs(phi) < np.pi/2, r, np.ones_like(phi)*1e20)
     return np.where(abs(phi) > np.pi/2, r, np.ones_like(phi)*1e20)
 
 
@@ -307,19 +345,32 @@ def local_n(surf, x, y):
         return [np.zeros_like(x),
                 np.where(yL > yC, -surf['sinBlaze'], surf['sinAntiblaze']),
                 np.where(yL > yC, surf['cosBlaze'], surf['cosAntiblaze'])]
-    if surf['kind'] == 'ellipse_param':           # parametric.py:233-247, (s, phi)
+    if surf['kind'] in PARAM_KINDS:   # parametric.py:233-247, 460-472, 698-713
         s, phi = x, y
-        A2s2 = np.array(surf['ellipseA']**2 - s**2)
-        A2s2[A2s2 <= 0] = 1e22
-        nr = -surf['ellipseB'] / surf['ellipseA'] * s / np.sqrt(A2s2)
+        sign = -1.
+        if surf['kind'] == 'parabola_param':
+            nr = surf['parabParam'] / \
+                (surf['parabParam']*s + surf['parabParam']**2)**0.5
+        elif surf['kind'] == 'hyperbola_param':
+            A2s2 = np.array(s**2 - surf['hyperbolaA']**2)
+            A2s2[A2s2 <= 0] = 1e22
+            nr = -surf['hyperbolaB'] / surf['hyperbolaA'] * s / np.sqrt(A2s2)
+            sign = 1.
+        else:
+            A2s2 = np.array(surf['ellipseA']**2 - s**2)
+            A2s2[A2s2 <= 0] = 1e22
+            nr = -surf['ellipseB'] / surf['ellipseA'] * s / np.sqrt(A2s2)
         norm = np.sqrt(nr**2 + 1)
         b = nr / norm
         if surf['isCylindrical']:
             a = np.zeros_like(phi)
             c = 1. / norm
-        else:
+        elif sign < 0:
             a = -np.sin(phi) / norm
             c = -np.cos(phi) / norm
+        else:
+            a = np.sin(phi) / norm
+            c = np.cos(phi) / norm
         bNew, cNew = rotate_x(b, c, surf['cosGamma'], -surf['sinGamma'])
         return [a, bNew, cNew]
     raise ValueError(surf['kind'])

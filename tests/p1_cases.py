@@ -100,6 +100,19 @@ def product_oe(name, g):
         oe = roe.BlazedGrating(bl, 'pg', material=m, blaze=float(g['surf_blaze']),
                                antiblaze=float(g['surf_antiblaze']),
                                rho=float(g['surf_rho']), **common)
+    elif name.startswith('g2_parabola') or name == 'g2_hyperbola':
+        m = rm.Material('Au', rho=float(g['mat_rho']), kind='mirror')
+        pq = {k: (None if np.isnan(float(g['surf_' + k])) else float(g['surf_' + k]))
+              for k in ('p', 'q')}
+        cls = roe.ParabolicalMirrorParam if 'parabola' in name else \
+            roe.HyperbolicMirrorParam
+        oe = cls(bl, 'm', material=m, isCylindrical=bool(float(g['surf_isCylindrical'])),
+                 **pq, **common)
+        keys = ('cosGamma', 'sinGamma', 'y0', 'z0') + (
+            ('parabParam',) if 'parabola' in name else ('hyperbolaA', 'hyperbolaB'))
+        for k in keys:
+            assert abs(getattr(oe, k) - float(g['surf_' + k])) <= \
+                1e-15 * max(1., abs(float(g['surf_' + k]))), k
     elif name.startswith('g2_ellipse'):
         m = rm.Material('Au', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.EllipticalMirrorParam(

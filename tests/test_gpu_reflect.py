@@ -62,7 +62,8 @@ def test_oe_reflect_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize('name', ['g2_blazed_au', 'g2_ellipse_cyl',
-                                  'g2_ellipse_full'])
+                                  'g2_ellipse_full', 'g2_parabola_q',
+                                  'g2_parabola_p_cyl', 'g2_hyperbola'])
 def test_softimax_surface_kinds_match_reference_golden(name):
     """Blazed grating (closed-form first-facet intersection) and elliptical
     parametric mirrors (root solve in (s, phi, r)). Positions come back through

@@ -810,7 +810,7 @@ class EllipticalMirrorParam(OE):
         p.surf_kind = _structs.SURF_ELLIPSE_PARAM
         vals = (self.y0, self.z0, self.cosGamma, self.sinGamma, self.ellipseA,
                 self.ellipseB, 1. if self.isCylindrical else 0.,
-                1. if self.isClosed else 0.)
+                1. if self.isClosed else 0., 0.)
         for i, v in enumerate(vals):
             p.surf_p[i] = float(v)
         p.asymmetric = 0
@@ -819,6 +819,158 @@ class EllipticalMirrorParam(OE):
 
 
 EllipticalMirror = EllipticalMirrorParam
+
+
+class _ConicMirrorParam(EllipticalMirrorParam):
+    """Shared parts of the other two conics of revolution: same parametric
+    frame (s along the axis, r from it), own generatrix."""
+    conic = None
+
+    def _conic_ab(self):
+        raise NotImplementedError
+
+    def _abs_pitch(self):
+        lbn = rs.Beam(nrays=1)
+        lbn.a[:], lbn.b[:], lbn.c[:] = 0, 0, 1
+        raycing.rotate_beam(lbn, rotationSequence='-'+self.rotationSequence,
+                            pitch=self.pitch, roll=self.roll+self.positionRoll,
+                            yaw=self.yaw, skip_xyz=True)
+        raycing.virgin_local_to_global(self.bl, lbn, self.center, skip_xyz=True)
+        axis = [0, 1, 0]
+        norm = sum([a**2 for a in axis])**0.5
+        sintheta = sum([a*n for a, n in
+                        zip(axis, (lbn.a[0], lbn.b[0], lbn.c[0]))]) / norm
+        return abs(np.arcsin(sintheta))
+
+    def _ready(self):
+        need = ('_p', '_q', '_pitchVal', '_rollVal', '_yawVal', '_positionRollVal',
+                'rotationSequence')
+        return all(hasattr(self, v) for v in need) and self.bl is not None
+
+    def _surface_params(self, p, second=False):
+        p.surf_kind = _structs.SURF_ELLIPSE_PARAM
+        A, B = self._conic_ab()
+        vals = (self.y0, self.z0, self.cosGamma, self.sinGamma, A, B,
+                1. if self.isCylindrical else 0., 1. if self.isClosed else 0.,
+                float(self.conic))
+        for i, v in enumerate(vals):
+            p.surf_p[i] = float(v)
+        p.asymmetric = 0
+        for i, v in enumerate((0., 0., 1., 0., 0., 1.)):
+            p.n_const[i] = v
+
+
+class ParabolicalMirrorParam(_ConicMirrorParam):
+    """Paraboloid (or parabolic cylinder): collimates a source at distance *p*
+    or focuses a parallel beam at *q* — exactly one of them is given
+    (oes/parametric.py:252-474)."""
+    conic = 1
+
+    def __init__(self, *args, **kwargs):
+        if kwargs.pop('parabolaAxis', None) is not None:
+            raise NotImplementedError('ParabolicalMirrorParam(parabolaAxis=...)')
+        kwargs.setdefault('p', 10000)
+        kwargs.setdefault('q', None)
+        EllipticalMirrorParam.__init__(self, *args, **kwargs)
+
+    def _reset_pq(self):
+        if not self._ready():
+            return
+        if (self.p is None) == (self.q is None):
+            raise ValueError('One and only one of p or q must be None!')
+        absPitch = self._abs_pitch()
+        if self.p is None:
+            self.y0 = self.q * np.cos(absPitch)
+            self.z0 = self.q * np.sin(absPitch)
+            self.parabParam = -self.q * np.sin(absPitch)**2
+            gamma = absPitch
+        else:
+            self.y0 = -self.p * np.cos(absPitch)
+            self.z0 = self.p * np.sin(absPitch)
+            self.parabParam = self.p * np.sin(absPitch)**2
+            gamma = -absPitch
+        self.cosGamma = np.cos(gamma)
+        self.sinGamma = np.sin(gamma)
+
+    def _conic_ab(self):
+        return self.parabParam, 0.
+
+    def local_r(self, s, phi):
+        r2 = self.parabParam*s + self.parabParam**2
+        r2[r2 < 0] = 0
+        r = 2 * r2**0.5
+        if self.isCylindrical:
+            r /= abs(np.cos(phi))
+        if self.isClosed:
+            return r
+        return np.where(abs(phi) > np.pi/2, r, np.ones_like(phi)*1e20)
+
+    def local_n(self, s, phi):
+        nr = self.parabParam / (self.parabParam*s + self.parabParam**2)**0.5
+        return self._normal_from_slope(nr, phi, -1.)
+
+    def _normal_from_slope(self, nr, phi, sign):
+        norm = np.sqrt(nr**2 + 1)
+        b = nr / norm
+        if self.isCylindrical:
+            a = np.zeros_like(phi)
+            c = 1. / norm
+        elif sign < 0:
+            a = -np.sin(phi) / norm
+            c = -np.cos(phi) / norm
+        else:
+            a = np.sin(phi) / norm
+            c = np.cos(phi) / norm
+        bNew, cNew = raycing.rotate_x(b, c, self.cosGamma, -self.sinGamma)
+        return [a, bNew, cNew]
+
+
+ParabolicMirror = ParabolicalMirrorParam
+
+
+class HyperbolicMirrorParam(_ConicMirrorParam):
+    """Hyperboloid (or hyperbolic cylinder) between the foci at *p* and *q*; the
+    OUTER surface reflects (``invertNormal = -1``), oes/parametric.py:477-716."""
+    conic = 2
+    _normal_from_slope = ParabolicalMirrorParam._normal_from_slope
+
+    def __init__(self, *args, **kwargs):
+        EllipticalMirrorParam.__init__(self, *args, **kwargs)
+        self.invertNormal = -1
+
+    def _reset_pq(self):
+        if not self._ready():
+            return
+        absPitch = self._abs_pitch()
+        if self.p and self.q:
+            gamma = np.arctan2((self.p + self.q) * np.sin(absPitch),
+                               (self.p - self.q) * np.cos(absPitch))
+            self.cosGamma = np.cos(gamma)
+            self.sinGamma = np.sin(gamma)
+            self.y0 = -(self.p + self.q)/2. * np.cos(absPitch)
+            self.z0 = (self.p - self.q)/2. * np.sin(absPitch)
+            self.hyperbolaA = abs(self.p - self.q)/2.
+            self.hyperbolaB = np.sqrt(self.p*self.q) * np.sin(absPitch)
+
+    def _conic_ab(self):
+        return self.hyperbolaA, self.hyperbolaB
+
+    def local_r(self, s, phi):
+        r = self.hyperbolaB * np.sqrt(abs(s**2/self.hyperbolaA**2 - 1))
+        if self.isCylindrical:
+            r /= abs(np.cos(phi))
+        if self.isClosed:
+            return r
+        return np.where(abs(phi) < np.pi/2, r, np.ones_like(phi)*1e20)
+
+    def local_n(self, s, phi):
+        A2s2 = np.array(s**2 - self.hyperbolaA**2)
+        A2s2[A2s2 <= 0] = 1e22
+        nr = -self.hyperbolaB / self.hyperbolaA * s / np.sqrt(A2s2)
+        return self._normal_from_slope(nr, phi, 1.)
+
+
+HyperbolicMirror = HyperbolicMirrorParam
 
 
 class BentFlatMirror(OE):

@@ -278,9 +278,20 @@ __device__ __forceinline__ void ell_param_to_xyz(const xrt_hip_pass& P, double s
 
 __device__ __forceinline__ double ell_local_r(const xrt_hip_pass& P, double s, double phi) {
   const double A = P.surf_p[4], B = P.surf_p[5];
-  double r = B * sqrt(fabs(1. - (s * s) / (A * A)));
+  const int conic = (int)P.surf_p[8];
+  double r;
+  if (conic == 1) {  // parabola, parametric.py:450-453: A = parabParam
+    double r2 = A * s + A * A;
+    if (r2 < 0.) r2 = 0.;
+    r = 2. * sqrt(r2);
+  } else if (conic == 2) {  // hyperbola, :690-691
+    r = B * sqrt(fabs((s * s) / (A * A) - 1.));
+  } else {
+    r = B * sqrt(fabs(1. - (s * s) / (A * A)));
+  }
   if (P.surf_p[6] != 0.) r /= fabs(cos(phi));
   if (P.surf_p[7] != 0.) return r;
+  if (conic == 2) return fabs(phi) < kPI / 2. ? r : 1e20;
   return fabs(phi) > kPI / 2. ? r : 1e20;
 }
 
@@ -1153,12 +1164,23 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     n[0] = n[3] = 0.;
     n[1] = n[4] = front ? -P.surf_p[3] : P.surf_p[5];
     n[2] = n[5] = front ? P.surf_p[4] : P.surf_p[6];
-  } else if (surf_is_param<F>(P)) {  // parametric.py:233-247
+  } else if (surf_is_param<F>(P)) {  // parametric.py:233-247, 460-472, 698-713
     const double A = P.surf_p[4], B = P.surf_p[5];
+    const int conic = (int)P.surf_p[8];
     const double sp = h.px, phi = h.py;
-    double A2s2 = A * A - sp * sp;
-    if (A2s2 <= 0.) A2s2 = 1e22;
-    const double nr = (((-B) / A) * sp) / sqrt(A2s2);
+    double nr, sg = -1.;
+    if (conic == 1) {
+      nr = A / sqrt(A * sp + A * A);
+    } else if (conic == 2) {
+      double A2s2 = sp * sp - A * A;
+      if (A2s2 <= 0.) A2s2 = 1e22;
+      nr = (((-B) / A) * sp) / sqrt(A2s2);
+      sg = 1.;
+    } else {
+      double A2s2 = A * A - sp * sp;
+      if (A2s2 <= 0.) A2s2 = 1e22;
+      nr = (((-B) / A) * sp) / sqrt(A2s2);
+    }
     const double norm = sqrt(nr * nr + 1.);
     const double nb = nr / norm;
     double na, nc;
@@ -1168,8 +1190,8 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     } else {
       double sn, cs;
       sincos(phi, &sn, &cs);
-      na = -sn / norm;
-      nc = -cs / norm;
+      na = (sg * sn) / norm;
+      nc = (sg * cs) / norm;
     }
     const double cg = P.surf_p[2], msg = -P.surf_p[3];
     n[0] = n[3] = na;
