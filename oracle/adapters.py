@@ -53,7 +53,15 @@ def oracle_params(oe):
                                    m.d, 'diamond', m.geom, m.t, m.factDW, m.V)
         return mn.make_material([mn.load_element(tb, e.name) for e in m.elements],
                                 list(m.quantities),
-                                'mirror' if m.kind == 'auto' else m.kind, m.rho, m.t)
+                                ('grating' if 'order' in p else 'mirror')
+                                if m.kind == 'auto' else m.kind, m.rho, m.t)
+    if hasattr(oe, '_is_grating') and oe._is_grating():
+        p['order'] = int(oe.order)
+        if oe.gratingDensity is not None and type(oe).local_g is type(oe).__mro__[-2].local_g:
+            p['gratingDensity'] = list(oe.gratingDensity)
+        else:
+            g = oe.local_g(np.zeros(1), np.zeros(1))
+            p['gVector'] = tuple(float(np.ravel(v)[0]) for v in g)
     material = oe.material
     if isinstance(material, (list, tuple)):
         material = material[0]
