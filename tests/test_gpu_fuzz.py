@@ -155,3 +155,66 @@ def test_random_elements_match_oracle(kind, seed):
                 (tag, f)
     hit = olb.state == 1
     assert hit.sum() > 100, 'the fan should mostly hit (%d)' % hit.sum()
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_dcm_matches_oracle(seed):
+    """Double-crystal monochromators: random Bragg energy, (hkl), asymmetric cut,
+    second-crystal translations and fine pitch, azimuth; the fan carries states
+    that miss either crystal."""
+    rng = np.random.default_rng(5000 + seed)
+    bl = raycing.BeamLine(azimuth=float(rng.choice([0., 0.15])))
+    hkl = [(1, 1, 1), (3, 1, 1), (3, 3, 3)][int(rng.integers(0, 3))]
+    E0 = float(rng.uniform(9500. if hkl == (3, 3, 3) else 7000., 16000.))
+    si1 = rm.CrystalSi(hkl=hkl, tK=297.15)
+    si2 = rm.CrystalSi(hkl=hkl, tK=297.15)
+    alpha = float(rng.choice([0., 0., np.radians(2.), np.radians(-3.)]))
+    thB = float(np.ravel(si1.get_Bragg_angle(E0))[0])
+    if alpha:
+        thB -= float(np.ravel(si1.get_dtheta(E0, alpha))[0])
+    perp = float(rng.uniform(5., 25.))
+    dcm = roe.DCM(
+        bl, 'dcm', center=[20000. * bl.sinAzimuth, 20000. * bl.cosAzimuth, 0.],
+        bragg=thB, pitch=alpha, material=si1,
+        material2=si2, alpha=alpha if alpha else None, cryst2perpTransl=perp,
+        cryst2longTransl=float(perp / np.tan(thB) * rng.uniform(0.8, 1.2)),
+        cryst2finePitch=float(rng.normal(0, 2e-6)),
+        limPhysX=[-10, 10], limPhysY=[-40, 40], limPhysX2=[-10, 10],
+        limPhysY2=[-80, 80])
+    n = 3000
+    beam = rs.Beam(nrays=n, withAmplitudes=bool(rng.random() < 0.5))
+    beam.x[:] = rng.normal(0, 2.5, n)
+    beam.z[:] = rng.normal(0, 0.6, n)
+    beam.a[:] = rng.normal(0, 1e-4, n)
+    beam.c[:] = rng.normal(0, 2e-5, n)
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    if bl.azimuth:
+        for u, v in (('x', 'y'), ('a', 'b')):
+            p, q = getattr(beam, u).copy(), getattr(beam, v).copy()
+            pu, qv = raycing.rotate_z(p, q, bl.cosAzimuth, -bl.sinAzimuth)
+            getattr(beam, u)[:] = pu
+            getattr(beam, v)[:] = qv
+    beam.E[:] = rng.uniform(E0 - 3., E0 + 3., n)
+    ang = rng.uniform(0, np.pi, n)
+    es, ep = np.cos(ang), np.sin(ang) * np.exp(1j * rng.uniform(-np.pi, np.pi, n))
+    beam.Jss[:], beam.Jpp[:], beam.Jsp[:] = es * es, (ep * np.conj(ep)).real, \
+        es * np.conj(ep)
+    if hasattr(beam, 'Es'):
+        beam.Es[:], beam.Ep[:] = es, ep
+    st = np.ones(n, dtype=np.int32)
+    st[rng.random(n) < 0.03] = 2
+    st[rng.random(n) < 0.02] = -1
+    beam.state[:] = st
+    o2, o1l, o2l = rn.dcm_double_reflect(oracle_params(dcm), to_oracle_beam(beam))
+    gb2, lo1, lo2 = dcm.double_reflect(beam)
+    for mine, ref, tag in ((gb2, o2, 'global'), (lo1, o1l, 'xtal1'), (lo2, o2l, 'xtal2')):
+        assert np.array_equal(mine.state, ref.state), (tag, seed)
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):
+            r = getattr(ref, f)
+            assert np.abs(getattr(mine, f) - r).max() <= \
+                1e-12 * max(np.abs(r).max(), 1e-300), (tag, f)
+        scale = max(np.abs(ref.Jss).max(), np.abs(ref.Jpp).max(), 1e-300)
+        for f in ('Jss', 'Jpp', 'Jsp'):
+            assert np.abs(getattr(mine, f) - getattr(ref, f)).max() <= 1e-9 * scale, \
+                (tag, f)
+    assert (o2.state == 1).sum() > 200, (hkl, E0, thB)
