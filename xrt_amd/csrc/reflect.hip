@@ -238,16 +238,39 @@ __device__ __forceinline__ bool blazed_front(const xrt_hip_pass& P, double y, do
   return yL > yC;
 }
 
+// ---------------------------------------------------------------------------
+// Compile-time specialisation. K = Spec<F, SK, MK, PLAIN>:
+//   F      surface family (0 = flat / toroid / bent-flat, 1 = + blazed / conics)
+//   SK, MK surface kind / material kind fixed at compile time, or -1 = read from
+//          the pass / material records at run time
+//   PLAIN  no grating equation, no asymmetric cut, intersection search on
+// The generic kernel carries every branch (13 k instructions, 128 VGPRs); with the
+// kinds known the common cases shrink to a quarter of that and ~90 VGPRs
+// (measured on cfg2: fused kernel 0.84 -> 0.77 ms).
+// ---------------------------------------------------------------------------
+template <int F_, int SK_, int MK_, bool PLAIN_>
+struct Spec {
+  static constexpr int F = F_, SK = SK_, MK = MK_;
+  static constexpr bool PLAIN = PLAIN_;
+};
+using Generic0 = Spec<0, -1, -1, false>;
+using Generic1 = Spec<1, -1, -1, false>;
+#define PSURF(P) (K::SK >= 0 ? K::SK : (P).surf_kind)
+#define MKIND(M) (K::MK >= 0 ? K::MK : (M).kind)
+#define PGRATING(P) (K::PLAIN ? 0 : (P).grating)
+#define PASYM(P) (K::PLAIN ? 0 : (P).asymmetric)
+#define PNIS(P) (K::PLAIN ? 0 : (P).no_intersection_search)
+
 // F = surface family, a compile-time switch: 0 = flat / toroid / bent-flat (the
 // bulk ray-tracing kernels stay free of the code below), 1 = blazed grating and
 // parametric ellipse (fmod / atan2 / sincos in the solve)
-template <int F>
+template <class K>
 __device__ __forceinline__ bool surf_is_param(const xrt_hip_pass& P) {
-  return F == 1 && P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM;
+  return K::F == 1 && PSURF(P) == XRT_HIP_SURF_ELLIPSE_PARAM;
 }
-template <int F>
+template <class K>
 __device__ __forceinline__ bool surf_is_blazed(const xrt_hip_pass& P) {
-  return F == 1 && P.surf_kind == XRT_HIP_SURF_BLAZED;
+  return K::F == 1 && PSURF(P) == XRT_HIP_SURF_BLAZED;
 }
 
 // EllipticalMirrorParam, parametric.py:213-231. rotate_x(y, z, c, s) =
@@ -296,9 +319,9 @@ __device__ __forceinline__ double ell_local_r(const xrt_hip_pass& P, double s, d
 }
 
 // surface height, oes/base.py:675-679 (flat), oes/__init__.py:398-401 (toroid)
-template <int F>
+template <class K>
 __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double y) {
-  if (P.surf_kind == XRT_HIP_SURF_TOROID) {
+  if (PSURF(P) == XRT_HIP_SURF_TOROID) {
     const double R = P.surf_p[0], r = P.surf_p[1];
     double q, h;
     const double yy = y * y;
@@ -313,11 +336,11 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
     if (rx < 0.) rx = 0.;
     return h + r * (1. - sqrt_unit(rx));
   }
-  if (P.surf_kind == XRT_HIP_SURF_BENTFLAT) {  // (y**2 - limPhysY[0]**2) / 2.0 / R
+  if (PSURF(P) == XRT_HIP_SURF_BENTFLAT) {  // (y**2 - limPhysY[0]**2) / 2.0 / R
     const double num = (y * y - P.surf_p[1]) * 0.5;
     return P.surf_p[4] != 0. ? div_const(num, P.surf_p[0], P.surf_p[2]) : num / P.surf_p[0];
   }
-  if (surf_is_blazed<F>(P)) {  // gratings.py:475-480
+  if (surf_is_blazed<K>(P)) {  // gratings.py:475-480
     double y1, yL;
     return blazed_front(P, y, y1, yL) ? -(y1 - y) * P.surf_p[1] : -yL * P.surf_p[2];
   }
@@ -325,14 +348,14 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
 }
 
 // find_dz, oes/base.py:801-846
-template <int F>
+template <class K>
 __device__ __forceinline__ double find_dz(const xrt_hip_pass& P, double t, double x0,
                                           double y0, double z0, double a, double b,
                                           double c, double& x, double& y, double& z) {
   x = x0 + a * t;
   y = y0 + b * t;
   z = z0 + c * t;
-  if (surf_is_param<F>(P)) {  // base.py:822-841: (x, y, z) become (s, phi, r), diffSign = -1
+  if (surf_is_param<K>(P)) {  // base.py:822-841: (x, y, z) become (s, phi, r), diffSign = -1
     double sp, phi, rr;
     ell_xyz_to_param(P, x, y, z, sp, phi, rr);
     x = sp;
@@ -342,7 +365,7 @@ __device__ __forceinline__ double find_dz(const xrt_hip_pass& P, double t, doubl
     if (isnan(s)) s = 0.;
     return (z - s) * -1. * (double)P.invert_normal;
   }
-  double s = surf_z<F>(P, x, y);
+  double s = surf_z<K>(P, x, y);
   if (isnan(s)) s = 0.;
   return (z - s) * (double)P.invert_normal;
 }
@@ -592,7 +615,7 @@ __device__ __forceinline__ LocalRay load_local(const xrt_hip_pass& P, const xrt_
   return r;
 }
 
-template <int F>
+template <class K>
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
     xrt_hip_pass P, xrt_hip_beam in, const GStat* __restrict__ g, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
@@ -604,8 +627,8 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
     const LocalRay r = load_local(P, in, i);
     double t1, t2, x, y, z;
     bracket(P, axis, positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
-    const double dz1 = find_dz<F>(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
-    double dz2 = find_dz<F>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
+    const double dz1 = find_dz<K>(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
+    double dz2 = find_dz<K>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
     if (dz1 <= 0. || dz2 >= 0.) dz2 = 0.;  // base.py:863-865
     t1m = t1 < t1m ? t1 : t1m;
     t2m = t2 > t2m ? t2 : t2m;
@@ -682,11 +705,11 @@ struct Hit {
 // end of the solve: on a parametric surface the solver worked in (s, phi, r); the
 // reference keeps those for local_n and converts back for everything else
 // (reflect.py:701-704, 1066-1071)
-template <int F>
+template <class K>
 __device__ __forceinline__ void hit_done(const xrt_hip_pass& P, Hit& h) {
   h.px = h.x;
   h.py = h.y;
-  if (surf_is_param<F>(P)) {
+  if (surf_is_param<K>(P)) {
     double x, y, z;
     ell_param_to_xyz(P, h.x, h.y, h.z, x, y, z);
     h.x = x;
@@ -695,21 +718,21 @@ __device__ __forceinline__ void hit_done(const xrt_hip_pass& P, Hit& h) {
   }
 }
 
-template <int F>
+template <class K>
 __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
                                          const LocalRay& r) {
   Hit h;
-  if (P.no_intersection_search) {  // reflect.py:676-682
+  if (PNIS(P)) {  // reflect.py:676-682
     h.t = 0.;
     h.x = r.x;
     h.y = r.y;
     h.z = r.z;
     h.lost = 0;
-    if (surf_is_param<F>(P)) ell_xyz_to_param(P, r.x, r.y, r.z, h.x, h.y, h.z);
-    hit_done<F>(P, h);
+    if (surf_is_param<K>(P)) ell_xyz_to_param(P, r.x, r.y, r.z, h.x, h.y, h.z);
+    hit_done<K>(P, h);
     return h;
   }
-  if (surf_is_blazed<F>(P)) {
+  if (surf_is_blazed<K>(P)) {
     // first illuminated facet in closed form, gratings.py:492-522 (the bracket
     // is not used). A ray above both facets makes the reference raise; here it
     // is marked lost.
@@ -730,14 +753,14 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.y = b_c * (h.z - r.z) + r.y;
     h.t = (h.y - r.y) / r.b;
     h.x = r.x + h.t * r.a;
-    hit_done<F>(P, h);
+    hit_done<K>(P, h);
     return h;
   }
   double t1, t2;
   bracket(P, g.axis, g.positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
   double x1, y1, z1, x2, y2, z2;
-  double dz1 = find_dz<F>(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x1, y1, z1);
-  double dz2 = find_dz<F>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
+  double dz1 = find_dz<K>(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x1, y1, z1);
+  double dz2 = find_dz<K>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
   const bool ind1 = dz1 <= 0.;
   const bool ind2 = dz2 >= 0.;
   h.lost = ind1 ? 1 : 0;
@@ -746,7 +769,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.x = x1;
     h.y = y1;
     h.z = z1;
-    hit_done<F>(P, h);
+    hit_done<K>(P, h);
     return h;
   }
   if (ind2) {
@@ -754,7 +777,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     h.x = x2;
     h.y = y2;
     h.z = z2;
-    hit_done<F>(P, h);
+    hit_done<K>(P, h);
     return h;
   }
   const double tMinG = g.t1min, tMaxG = g.t2max;
@@ -771,7 +794,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
       t2 = t - (t1 - t) * dz / (dz1 - dz);
       if (t2 < tMinG) t2 = tMinG;
       if (t2 > tMaxG) t2 = tMaxG;
-      dz2 = find_dz<F>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
+      dz2 = find_dz<K>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
       if (!isnan(dz2) && !isnan(dz1) && sgn(dz2) == sgn(dz1)) {
         t1 = t;
         dz1 = dz;
@@ -811,7 +834,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
       const bool conds = cond1 || cond2 || cond3 || cond4 || cond5;
       if (conds) xs = (xa + xb) / 2.;
       mflag = conds;
-      const double fs = find_dz<F>(P, xs, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
+      const double fs = find_dz<K>(P, xs, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
       xd = xc;
       xc = xb;
       fc = fb;
@@ -846,7 +869,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
   h.x = x2;
   h.y = y2;
   h.z = z2;
-  hit_done<F>(P, h);
+  hit_done<K>(P, h);
   return h;
 }
 
@@ -962,8 +985,8 @@ struct Ampl {
 };
 
 // Fresnel, material.py:415-493
-__device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, double E,
-                                                   double bdn, const TabWin& w) {
+__device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, int kind,
+                                                   double E, double bdn, const TabWin& w) {
   Ampl A;
   const cplx n = refractive_index(M, E, w);
   const cplx one = C(1., 0.);
@@ -976,10 +999,10 @@ __device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, do
   const cplx rat = n1 / n2;
   const cplx cosBeta = csqrt_(one - (rat * rat) * sinAlpha2);
   const cplx n2cosBeta = n2 * cosBeta;
-  if (M.kind == XRT_HIP_MAT_MIRROR || M.kind == XRT_HIP_MAT_THIN_MIRROR) {
+  if (kind == XRT_HIP_MAT_MIRROR || kind == XRT_HIP_MAT_THIN_MIRROR) {
     A.rs = (n1cosAlpha - n2cosBeta) / (n1cosAlpha + n2cosBeta);
     A.rp = (n2 * cosAlpha - n1 * cosBeta) / (n2 * cosAlpha + n1 * cosBeta);
-    if (M.kind == XRT_HIP_MAT_THIN_MIRROR) {
+    if (kind == XRT_HIP_MAT_THIN_MIRROR) {
       // p2 = exp(2j E/CHBAR n2cosBeta t 1e7)
       const double f = 2. * E * (1.0 / kCHBAR);
       const cplx arg = ((C(0., f) * n2cosBeta) * M.t) * 1e7;
@@ -1131,7 +1154,7 @@ __device__ __forceinline__ void load_fields(const xrt_hip_beam& in, int64_t i, b
   }
 }
 
-template <int F>
+template <class K>
 __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
                                                const xrt_hip_material& M, const GStat& g,
                                                const LocalRay& r, const Hit& h, RayIn q,
@@ -1141,7 +1164,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   q.path += h.t;
   // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
   double n[6];
-  if (P.surf_kind == XRT_HIP_SURF_TOROID) {  // oes/__init__.py:403-411
+  if (PSURF(P) == XRT_HIP_SURF_TOROID) {  // oes/__init__.py:403-411
     const double R = P.surf_p[0], rr = P.surf_p[1];
     const double qx = h.x * frcp(rr);
     const double rx = 1. - qx * qx;
@@ -1152,19 +1175,19 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     n[0] = n[3] = na * inorm;
     n[1] = n[4] = nb * inorm;
     n[2] = n[5] = inorm;
-  } else if (P.surf_kind == XRT_HIP_SURF_BENTFLAT) {  // oes/__init__.py:296-303
+  } else if (PSURF(P) == XRT_HIP_SURF_BENTFLAT) {  // oes/__init__.py:296-303
     const double nb = -h.y * frcp(P.surf_p[0]);
     const double inorm = frcp(sqrt(nb * nb + 1.));
     n[0] = n[3] = 0.;
     n[1] = n[4] = nb * inorm;
     n[2] = n[5] = inorm;
-  } else if (surf_is_blazed<F>(P)) {  // gratings.py:482-490
+  } else if (surf_is_blazed<K>(P)) {  // gratings.py:482-490
     double y1, yL;
     const bool front = blazed_front(P, h.py, y1, yL);
     n[0] = n[3] = 0.;
     n[1] = n[4] = front ? -P.surf_p[3] : P.surf_p[5];
     n[2] = n[5] = front ? P.surf_p[4] : P.surf_p[6];
-  } else if (surf_is_param<F>(P)) {  // parametric.py:233-247, 460-472, 698-713
+  } else if (surf_is_param<K>(P)) {  // parametric.py:233-247, 460-472, 698-713
     const double A = P.surf_p[4], B = P.surf_p[5];
     const int conic = (int)P.surf_p[8];
     const double sp = h.px, phi = h.py;
@@ -1204,12 +1227,12 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   if (bdn < -1.) bdn = -1.;
   if (bdn > 1.) bdn = 1.;
   out.theta = acos(bdn) - kPI / 2.;
-  const double bdsn = P.asymmetric ? (r.a * n[3] + r.b * n[4] + r.c * n[5]) : bdn;
+  const double bdsn = PASYM(P) ? (r.a * n[3] + r.b * n[4] + r.c * n[5]) : bdn;
 
   int toWhere = 0;  // reflect.py:723-752
-  if (M.kind == XRT_HIP_MAT_PLATE)
+  if (MKIND(M) == XRT_HIP_MAT_PLATE)
     toWhere = 1;
-  else if (M.kind == XRT_HIP_MAT_CRYSTAL && M.geom_transmitted)
+  else if (MKIND(M) == XRT_HIP_MAT_CRYSTAL && M.geom_transmitted)
     toWhere = 2;
 
   double ao = r.a, bo = r.b, co = r.c;  // a_out of the reference
@@ -1217,7 +1240,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   out.b = r.b;
   out.c = r.c;
   if (toWhere == 0 || toWhere == 2) {
-    if (M.kind == XRT_HIP_MAT_CRYSTAL && toWhere == 0) {
+    if (MKIND(M) == XRT_HIP_MAT_CRYSTAL && toWhere == 0) {
       // crystal as a grating, reflect.py:568-612 + 451-469
       const double ndsn = n[0] * n[3] + n[1] * n[4] + n[2] * n[5];
       const double bdnMean = g.sum_bdn / (double)g.n_good1;
@@ -1239,7 +1262,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       ao /= nm;   // directions are compared at 1e-12: exact quotients here
       bo /= nm;
       co /= nm;
-    } else if (P.grating) {
+    } else if (PGRATING(P)) {
       // grating equation, reflect.py:840-861 + 451-469 (sign -1); the groove
       // vector of OE.local_g (base.py:688-717)
       double g0 = P.g_const[0], g1 = P.g_const[1], g2 = P.g_const[2];
@@ -1312,11 +1335,11 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   A.rp = C(1., 0.);
   A.mu = 0.;
   A.nk = 0.;
-  if (M.kind == XRT_HIP_MAT_CRYSTAL) {
+  if (MKIND(M) == XRT_HIP_MAT_CRYSTAL) {
     const double bosn = ao * n[3] + bo * n[4] + co * n[5];
     A = crystal_amplitude(M, q.E, bdsn, bosn, bdn, window_of(g));
-  } else if (M.kind != XRT_HIP_MAT_NONE) {
-    A = material_amplitude(M, q.E, bdn, window_of(g));
+  } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
+    A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g));
   }
   if (cisnan(A.rs)) A.rs = C(0., 0.);
   if (cisnan(A.rp)) A.rp = C(0., 0.);
@@ -1343,7 +1366,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     Es = Es * A.rs;
     Ep = Ep * A.rp;
   }
-  if (!M.from_vacuum && M.kind != XRT_HIP_MAT_NONE && M.kind != XRT_HIP_MAT_CRYSTAL) {
+  if (!M.from_vacuum && MKIND(M) != XRT_HIP_MAT_NONE && MKIND(M) != XRT_HIP_MAT_CRYSTAL) {
     const double att = exp(-A.mu * h.t * 0.1);
     Jss *= att;
     Jpp *= att;
@@ -1436,7 +1459,7 @@ __device__ __forceinline__ void copy_ray(const xrt_hip_beam& o, const xrt_hip_be
 }
 
 // everything after the solve for one entering ray: state, finish, both stores
-template <int F>
+template <class K>
 __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hip_material& M,
                                              const GStat& g, const xrt_hip_beam& in,
                                              const xrt_hip_beam& restore,
@@ -1450,7 +1473,7 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
   RayIn lo;
   double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;
   if (st == 1) {
-    const Finished fin = finish_ray<F>(P, M, g, r, h, q, in, i, has_amp);
+    const Finished fin = finish_ray<K>(P, M, g, r, h, q, in, i, has_amp);
     la = fin.a;
     lbb = fin.b;
     lc = fin.c;
@@ -1522,7 +1545,7 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
 // ---------------------------------------------------------------------------
 // K3 kernels
 // ---------------------------------------------------------------------------
-template <int F>
+template <class K>
 __global__ __launch_bounds__(REFLECT_BLOCK, REFLECT_FUSED_WAVES) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* gp) {
@@ -1536,14 +1559,15 @@ __global__ __launch_bounds__(REFLECT_BLOCK, REFLECT_FUSED_WAVES) void reflect_fu
   }
   const GStat g = *gp;
   const LocalRay r = load_local(P, in, i);
-  const Hit h = solve_ray<F>(P, g, r);
+  const Hit h = solve_ray<K>(P, g, r);
   int st = rays_good(P, h.x, h.y);
   if (h.lost) st = P.lost_num;
-  complete_ray<F>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
+  complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
 }
 
 // crystal path, first half: solve + state; stores t, local hit point and state,
 // accumulates sum(beamInDotNormal) over the rays that hit (reflect.py:573)
+template <class K>
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
     xrt_hip_pass P, xrt_hip_beam in, double* ht, double* hx, double* hy, double* hz,
     int32_t* hst, const GStat* gp, double* __restrict__ part) {
@@ -1556,7 +1580,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
     if (!entering(P, in.state[i])) continue;
     const LocalRay r = load_local(P, in, i);
-    const Hit h = solve_ray<0>(P, g, r);
+    const Hit h = solve_ray<K>(P, g, r);
     int st = rays_good(P, h.x, h.y);
     if (h.lost) st = P.lost_num;
     ht[i] = h.t;
@@ -1566,7 +1590,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
     hst[i] = st;
     if (st == 1) {
       double n0 = P.n_const[0], n1 = P.n_const[1], n2 = P.n_const[2];
-      if (P.surf_kind == XRT_HIP_SURF_TOROID) {
+      if (PSURF(P) == XRT_HIP_SURF_TOROID) {
         const double R = P.surf_p[0], rr = P.surf_p[1];
         const double qx = h.x * frcp(rr);
         const double rx = 1. - qx * qx;
@@ -1576,7 +1600,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
         n0 = na * inorm;
         n1 = nb * inorm;
         n2 = inorm;
-      } else if (P.surf_kind == XRT_HIP_SURF_BENTFLAT) {
+      } else if (PSURF(P) == XRT_HIP_SURF_BENTFLAT) {
         const double nb = -h.y * frcp(P.surf_p[0]);
         const double inorm = frcp(sqrt(nb * nb + 1.));
         n0 = 0.;
@@ -1600,6 +1624,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
   }
 }
 
+template <class K>
 __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_finish(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const double* ht, const double* hx,
@@ -1629,7 +1654,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_finish(
   h.px = h.x;   // crystals are only combined with non-parametric surfaces (capi check)
   h.py = h.y;
   h.lost = 0;
-  complete_ray<0>(P, M, g, in, restore, lb, vb, theta, i, r, h, hst[i], has_amp);
+  complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, hst[i], has_amp);
 }
 
 
@@ -1642,7 +1667,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void material_amplitude_kernel(
     double* __restrict__ mu, double* __restrict__ nk) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Ampl A = material_amplitude(M, E[i], bdn[i], full_window());
+  const Ampl A = material_amplitude(M, M.kind, E[i], bdn[i], full_window());
   rs[i] = make_double2(A.rs.re, A.rs.im);
   rp[i] = make_double2(A.rp.re, A.rp.im);
   if (mu) mu[i] = A.mu;
@@ -1720,31 +1745,68 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   if (!P.no_intersection_search) {
     hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, part);
     hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, M, in, part, (int)rblocks, g);
-    if (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM) {
-      hipLaunchKernelGGL(reflect_stats_bracket<1>, rgrid, block, 0, st, P, in, g, part);
-      hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
-    } else if (P.surf_kind != XRT_HIP_SURF_BLAZED) {  // blazed: closed form, no clamps
-      hipLaunchKernelGGL(reflect_stats_bracket<0>, rgrid, block, 0, st, P, in, g, part);
+    using ToroidAny = Spec<0, XRT_HIP_SURF_TOROID, -1, false>;
+    using FlatAny = Spec<0, XRT_HIP_SURF_FLAT, -1, false>;
+    if (P.surf_kind != XRT_HIP_SURF_BLAZED) {  // blazed: closed form, no clamps
+      switch (P.surf_kind) {
+        case XRT_HIP_SURF_ELLIPSE_PARAM:
+          hipLaunchKernelGGL(reflect_stats_bracket<Generic1>, rgrid, block, 0, st, P, in, g, part);
+          break;
+        case XRT_HIP_SURF_TOROID:
+          hipLaunchKernelGGL(reflect_stats_bracket<ToroidAny>, rgrid, block, 0, st, P, in, g, part);
+          break;
+        case XRT_HIP_SURF_FLAT:
+          hipLaunchKernelGGL(reflect_stats_bracket<FlatAny>, rgrid, block, 0, st, P, in, g, part);
+          break;
+        default:
+          hipLaunchKernelGGL(reflect_stats_bracket<Generic0>, rgrid, block, 0, st, P, in, g, part);
+      }
       hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
     }
   }
   const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
   if (need_mean) {
     const dim3 sgrid(grid.x < REFLECT_MAX_PART ? grid.x : REFLECT_MAX_PART);
-    hipLaunchKernelGGL(reflect_solve, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst, g, part);
+    // Bragg-reflecting crystals sit on flat surfaces in practice (DCM): that case is
+    // compiled with the kinds fixed
+    const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
+    using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
+    using AnyXtal = Spec<0, -1, XRT_HIP_MAT_CRYSTAL, false>;
+    if (flat_xtal)
+      hipLaunchKernelGGL(reflect_solve<FlatXtal>, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst,
+                         g, part);
+    else
+      hipLaunchKernelGGL(reflect_solve<AnyXtal>, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst,
+                         g, part);
     hipLaunchKernelGGL(reflect_reduce_bdn, dim3(1), block, 0, st, part, (int)sgrid.x, g);
     if (evk0) (void)hipEventRecord(evk0, st);
-    hipLaunchKernelGGL(reflect_finish, grid, block, 0, st, P, M, in, restore, lb, vb, theta,
-                       ht, hx, hy, hz, hst, g);
+    if (flat_xtal)
+      hipLaunchKernelGGL(reflect_finish<FlatXtal>, grid, block, 0, st, P, M, in, restore, lb, vb,
+                         theta, ht, hx, hy, hz, hst, g);
+    else
+      hipLaunchKernelGGL(reflect_finish<AnyXtal>, grid, block, 0, st, P, M, in, restore, lb, vb,
+                         theta, ht, hx, hy, hz, hst, g);
     if (evk1) (void)hipEventRecord(evk1, st);
   } else {
     if (evk0) (void)hipEventRecord(evk0, st);
-    if (P.surf_kind >= XRT_HIP_SURF_BLAZED)
-      hipLaunchKernelGGL(reflect_fused<1>, grid, block, 0, st, P, M, in, restore, lb, vb, theta,
-                         g);
-    else
-      hipLaunchKernelGGL(reflect_fused<0>, grid, block, 0, st, P, M, in, restore, lb, vb, theta,
-                         g);
+#define XRT_FUSED(SPEC) \
+  hipLaunchKernelGGL((reflect_fused<SPEC>), grid, block, 0, st, P, M, in, restore, lb, vb, theta, g)
+    const bool plain = !P.grating && !P.asymmetric && !P.no_intersection_search;
+    using ToroidMirror = Spec<0, XRT_HIP_SURF_TOROID, XRT_HIP_MAT_MIRROR, true>;
+    using FlatMirror = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_MIRROR, true>;
+    using BentMirror = Spec<0, XRT_HIP_SURF_BENTFLAT, XRT_HIP_MAT_MIRROR, true>;
+    if (P.surf_kind >= XRT_HIP_SURF_BLAZED) {
+      XRT_FUSED(Generic1);
+    } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_TOROID) {
+      XRT_FUSED(ToroidMirror);
+    } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_FLAT) {
+      XRT_FUSED(FlatMirror);
+    } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_BENTFLAT) {
+      XRT_FUSED(BentMirror);
+    } else {
+      XRT_FUSED(Generic0);
+    }
+#undef XRT_FUSED
     if (evk1) (void)hipEventRecord(evk1, st);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
