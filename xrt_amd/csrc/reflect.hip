@@ -1154,6 +1154,13 @@ __device__ __forceinline__ void load_fields(const xrt_hip_beam& in, int64_t i, b
   }
 }
 
+// kernels compiled for fixed kinds need ~90 VGPRs: they can afford to have the 8
+// doubles of the coherency matrix / amplitudes in flight during the whole finish
+template <class K>
+__device__ __forceinline__ constexpr bool early_fields() {
+  return K::PLAIN && K::MK >= 0 && K::SK >= 0;
+}
+
 template <class K>
 __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
                                                const xrt_hip_material& M, const GStat& g,
@@ -1343,8 +1350,9 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   }
   if (cisnan(A.rs)) A.rs = C(0., 0.);
   if (cisnan(A.rp)) A.rp = C(0., 0.);
-  // now the fields of the incoming ray, rotated into the local s/p frame
-  load_fields(in, i, has_amp, q);
+  // now the fields of the incoming ray, rotated into the local s/p frame (the lean
+  // specialised kernels have registers to spare and issued these loads up front)
+  if (!early_fields<K>()) load_fields(in, i, has_amp, q);
   double Jss = q.Jss, Jpp = q.Jpp, Jsr = q.Jsr, Jsi = q.Jsi;
   rot_coherency(cosY, -sinY, Jss, Jpp, Jsr, Jsi);
   cplx Es = C(q.Esr, q.Esi), Ep = C(q.Epr, q.Epi);
@@ -1469,6 +1477,7 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
   RayIn q;
   q.path = in.path[i];
   q.E = in.E[i];
+  if (early_fields<K>()) load_fields(in, i, has_amp, q);
   double la = r.a, lbb = r.b, lc = r.c, th = 0.;
   RayIn lo;
   double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;
@@ -1488,7 +1497,7 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
     vEpr = fin.vEpr;
     vEpi = fin.vEpi;
   } else {
-    load_fields(in, i, has_amp, q);
+    if (!early_fields<K>()) load_fields(in, i, has_amp, q);
     lo = q;
     vJss = q.Jss;
     vJpp = q.Jpp;
