@@ -248,10 +248,15 @@ __device__ __forceinline__ bool blazed_front(const xrt_hip_pass& P, double y, do
 // kinds known the common cases shrink to a quarter of that and ~90 VGPRs
 // (measured on cfg2: fused kernel 0.84 -> 0.77 ms).
 // ---------------------------------------------------------------------------
+#ifndef XRT_LEAN_WAVES
+#define XRT_LEAN_WAVES 4
+#endif
 template <int F_, int SK_, int MK_, bool PLAIN_>
 struct Spec {
   static constexpr int F = F_, SK = SK_, MK = MK_;
   static constexpr bool PLAIN = PLAIN_;
+  // waves per SIMD the fused kernel is compiled for
+  static constexpr int WAVES = (PLAIN_ && SK_ >= 0 && MK_ >= 0) ? XRT_LEAN_WAVES : REFLECT_FUSED_WAVES;
 };
 using Generic0 = Spec<0, -1, -1, false>;
 using Generic1 = Spec<1, -1, -1, false>;
@@ -1555,7 +1560,7 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
 // K3 kernels
 // ---------------------------------------------------------------------------
 template <class K>
-__global__ __launch_bounds__(REFLECT_BLOCK, REFLECT_FUSED_WAVES) void reflect_fused(
+__global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* gp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
