@@ -480,15 +480,17 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass 
   unsigned long long first = ~0ull, nent = 0, nmain = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
+    // all five loads are issued before the state is looked at: one memory round
+    // trip per iteration instead of up to three dependent ones
     const int st = in.state[i];
+    const double E = in.E[i];
+    double a = in.a[i], b = in.b[i], c = in.c[i];
     if (entering(P, st)) {
       if ((unsigned long long)i < first) first = (unsigned long long)i;
       ++nent;
-      const double E = in.E[i];
       emin = E < emin ? E : emin;
       emax = E > emax ? E : emax;
       if (st == 1) {  // mainPartForBracketing, reflect.py:644
-        double a = in.a[i], b = in.b[i], c = in.c[i];
         local_dir(P, a, b, c);
         ma = fmax(ma, fabs(a));
         mb = fmax(mb, fabs(b));
@@ -628,8 +630,9 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
   const int axis = g->axis, positive = g->positive;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
-    if (!entering(P, in.state[i])) continue;
-    const LocalRay r = load_local(P, in, i);
+    const int st = in.state[i];
+    const LocalRay r = load_local(P, in, i);   // loads issued together with the state
+    if (!entering(P, st)) continue;
     double t1, t2, x, y, z;
     bracket(P, axis, positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
     const double dz1 = find_dz<K>(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
