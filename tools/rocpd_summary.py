@@ -32,12 +32,17 @@ def short(name):
 
 
 def variant(name):
-    """short name + the template argument, e.g. reflect_fused<0>"""
+    """short name + its template arguments, e.g. reflect_fused<xrt::Spec<0, 1, 1, true>>"""
     k = short(name)
     i = name.find(k)
-    if i >= 0 and name[i + len(k):i + len(k) + 1] == '<':
-        j = name.find('>', i)
-        k += name[i + len(k):j + 1]
+    j = i + len(k)
+    if i >= 0 and name[j:j + 1] == '<':
+        depth = 0
+        for e in range(j, len(name)):
+            depth += name[e] == '<'
+            depth -= name[e] == '>'
+            if depth == 0:
+                return k + name[j:e + 1]
     return k
 
 
