@@ -12,7 +12,8 @@
 #define REFLECT_FUSED_WAVES 4
 #endif
 #define REFLECT_MAX_PART 8192u                    /* partial records (blocks) per reduction */
-#define REFLECT_PART_BYTES (REFLECT_MAX_PART * 64) /* 8 doubles each */
+#define REFLECT_PART_DOUBLES 16                   /* widest partial record (stats_dir_y) */
+#define REFLECT_PART_BYTES (REFLECT_MAX_PART * REFLECT_PART_DOUBLES * 8)
 
 namespace xrt {
 
@@ -23,6 +24,7 @@ struct GStat {
   unsigned long long n_enter, n_main;
   int axis, positive;                // bracketing axis; sign of the first ray's component
   double t1min, t2max, maxdz1, maxdz2;
+  int bracket_valid;                 // the bracket statistics above are already final
   unsigned long long n_good1;        // rays that ended in state 1
   double sum_bdn;                    // sum of beamInDotNormal over them
   double emin, emax;                 // energy range of the entering rays

@@ -459,6 +459,7 @@ __global__ void reflect_init(GStat* g) {
   g->t2max = -INFINITY;
   g->maxdz1 = 0.;
   g->maxdz2 = 0.;
+  g->bracket_valid = 0;
   g->n_good1 = 0;
   g->sum_bdn = 0.;
   g->emin = -INFINITY;
@@ -524,15 +525,27 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass 
   }
 }
 
+// stride = doubles per partial record: 8 (reflect_stats_dir) or 16
+// (reflect_stats_dir_y, which also carries the bracket statistics of the y axis
+// for both signs: [8..11] positive, [12..15] negative)
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, const double* __restrict__ part,
-    int nblocks, GStat* g) {
+    int nblocks, int stride, GStat* g) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
   double ma = 0., mb = 0., mc = 0., nent = 0., nmain = 0., emin = INFINITY, emax = -INFINITY;
   unsigned long long first = ~0ull;
+  double yb[8] = {INFINITY, -INFINITY, 0., 0., INFINITY, -INFINITY, 0., 0.};
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    const double* o = part + (int64_t)b * 8;
+    const double* o = part + (int64_t)b * stride;
+    if (stride == 16) {
+      for (int v = 0; v < 2; ++v) {
+        yb[4 * v] = o[8 + 4 * v] < yb[4 * v] ? o[8 + 4 * v] : yb[4 * v];
+        yb[4 * v + 1] = o[9 + 4 * v] > yb[4 * v + 1] ? o[9 + 4 * v] : yb[4 * v + 1];
+        yb[4 * v + 2] = fmax(yb[4 * v + 2], o[10 + 4 * v]);
+        yb[4 * v + 3] = fmax(yb[4 * v + 3], o[11 + 4 * v]);
+      }
+    }
     ma = fmax(ma, o[0]);
     mb = fmax(mb, o[1]);
     mc = fmax(mc, o[2]);
@@ -555,6 +568,14 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
   first = block_reduce(first, fminu, lds_u);
   nent = block_reduce(nent, faddd, lds_d);
   nmain = block_reduce(nmain, faddd, lds_d);
+  if (stride == 16) {
+    for (int v = 0; v < 2; ++v) {
+      yb[4 * v] = block_reduce(yb[4 * v], fmind, lds_d);
+      yb[4 * v + 1] = block_reduce(yb[4 * v + 1], fmaxd, lds_d);
+      yb[4 * v + 2] = block_reduce(yb[4 * v + 2], fmaxd, lds_d);
+      yb[4 * v + 3] = block_reduce(yb[4 * v + 3], fmaxd, lds_d);
+    }
+  }
   if (threadIdx.x != 0) return;
   g->maxa = ma;
   g->maxb = mb;
@@ -602,6 +623,14 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
   const double comp = axis == 0 ? a : (axis == 1 ? b : c);
   g->axis = axis;
   g->positive = comp > 0. ? 1 : 0;
+  if (stride == 16 && axis == 1) {  // the usual case: the brackets are known already
+    const int v = comp > 0. ? 0 : 1;
+    g->t1min = yb[4 * v];
+    g->t2max = yb[4 * v + 1];
+    g->maxdz1 = yb[4 * v + 2];
+    g->maxdz2 = yb[4 * v + 3];
+    g->bracket_valid = 1;
+  }
 }
 
 struct LocalRay {
@@ -626,6 +655,7 @@ template <class K>
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
     xrt_hip_pass P, xrt_hip_beam in, const GStat* __restrict__ g, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
+  if (g->bracket_valid) return;  // decided from the first pass (wave-uniform)
   double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
   const int axis = g->axis, positive = g->positive;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -658,9 +688,91 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
   }
 }
 
+// First statistics pass that also anticipates the second one. The bracketing axis
+// is y whenever max|b| is the largest direction cosine - always, for a beam that
+// travels along the beamline. The brackets of that axis are evaluated here for
+// both signs of the first ray's b (the reference's _set_t takes either formula for
+// the whole batch); if the decision comes out as "y", reflect_stats_bracket finds
+// bracket_valid set and returns at once. One pass over the beam saved.
+template <class K>
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir_y(
+    xrt_hip_pass P, xrt_hip_beam in, double* __restrict__ part) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
+  double ma = 0., mb = 0., mc = 0., emin = INFINITY, emax = -INFINITY;
+  unsigned long long first = ~0ull, nent = 0, nmain = 0;
+  double t1m[2] = {INFINITY, INFINITY}, t2m[2] = {-INFINITY, -INFINITY};
+  double d1m[2] = {0., 0.}, d2m[2] = {0., 0.};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
+    const int st = in.state[i];
+    const double E = in.E[i];
+    const LocalRay r = load_local(P, in, i);
+    if (!entering(P, st)) continue;
+    if ((unsigned long long)i < first) first = (unsigned long long)i;
+    ++nent;
+    emin = E < emin ? E : emin;
+    emax = E > emax ? E : emax;
+    if (st == 1) {  // mainPartForBracketing, reflect.py:644
+      ma = fmax(ma, fabs(r.a));
+      mb = fmax(mb, fabs(r.b));
+      mc = fmax(mc, fabs(r.c));
+      ++nmain;
+    }
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      double t1, t2, x, y, z;
+      bracket(P, 1, v == 0 ? 1 : 0, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
+      const double dz1 = find_dz<K>(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
+      double dz2 = find_dz<K>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
+      if (dz1 <= 0. || dz2 >= 0.) dz2 = 0.;  // base.py:863-865
+      t1m[v] = t1 < t1m[v] ? t1 : t1m[v];
+      t2m[v] = t2 > t2m[v] ? t2 : t2m[v];
+      d1m[v] = fmax(d1m[v], fabs(dz1));
+      d2m[v] = fmax(d2m[v], fabs(dz2));
+    }
+  }
+  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
+  auto fmind = [](double u, double v) { return u < v ? u : v; };
+  auto fminu = [](unsigned long long u, unsigned long long v) { return u < v ? u : v; };
+  auto faddu = [](unsigned long long u, unsigned long long v) { return u + v; };
+  ma = block_reduce(ma, fmaxd, lds_d);
+  mb = block_reduce(mb, fmaxd, lds_d);
+  mc = block_reduce(mc, fmaxd, lds_d);
+  first = block_reduce(first, fminu, lds_u);
+  nent = block_reduce(nent, faddu, lds_u);
+  nmain = block_reduce(nmain, faddu, lds_u);
+  emin = block_reduce(emin, fmind, lds_d);
+  emax = block_reduce(emax, fmaxd, lds_d);
+  for (int v = 0; v < 2; ++v) {
+    t1m[v] = block_reduce(t1m[v], fmind, lds_d);
+    t2m[v] = block_reduce(t2m[v], fmaxd, lds_d);
+    d1m[v] = block_reduce(d1m[v], fmaxd, lds_d);
+    d2m[v] = block_reduce(d2m[v], fmaxd, lds_d);
+  }
+  if (threadIdx.x == 0) {
+    double* o = part + (int64_t)blockIdx.x * 16;
+    o[0] = ma;
+    o[1] = mb;
+    o[2] = mc;
+    o[3] = __longlong_as_double((long long)first);
+    o[4] = (double)nent;
+    o[5] = (double)nmain;
+    o[6] = emin;
+    o[7] = emax;
+    for (int v = 0; v < 2; ++v) {
+      o[8 + 4 * v] = t1m[v];
+      o[9 + 4 * v] = t2m[v];
+      o[10 + 4 * v] = d1m[v];
+      o[11 + 4 * v] = d2m[v];
+    }
+  }
+}
+
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bracket(
     const double* __restrict__ part, int nblocks, GStat* g) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
+  if (g->bracket_valid) return;
   double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     const double* o = part + (int64_t)b * 8;
@@ -1760,10 +1872,28 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   if (rblocks > REFLECT_MAX_PART) rblocks = REFLECT_MAX_PART;
   const dim3 rgrid(rblocks);
   if (!P.no_intersection_search) {
-    hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, part);
-    hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, M, in, part, (int)rblocks, g);
     using ToroidAny = Spec<0, XRT_HIP_SURF_TOROID, -1, false>;
     using FlatAny = Spec<0, XRT_HIP_SURF_FLAT, -1, false>;
+    int pstride = 16;
+    switch (P.surf_kind) {
+      case XRT_HIP_SURF_BLAZED:   // closed-form intersection: no brackets at all
+        pstride = 8;
+        hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, part);
+        break;
+      case XRT_HIP_SURF_ELLIPSE_PARAM:
+        hipLaunchKernelGGL(reflect_stats_dir_y<Generic1>, rgrid, block, 0, st, P, in, part);
+        break;
+      case XRT_HIP_SURF_TOROID:
+        hipLaunchKernelGGL(reflect_stats_dir_y<ToroidAny>, rgrid, block, 0, st, P, in, part);
+        break;
+      case XRT_HIP_SURF_FLAT:
+        hipLaunchKernelGGL(reflect_stats_dir_y<FlatAny>, rgrid, block, 0, st, P, in, part);
+        break;
+      default:
+        hipLaunchKernelGGL(reflect_stats_dir_y<Generic0>, rgrid, block, 0, st, P, in, part);
+    }
+    hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, M, in, part, (int)rblocks,
+                       pstride, g);
     if (P.surf_kind != XRT_HIP_SURF_BLAZED) {  // blazed: closed form, no clamps
       switch (P.surf_kind) {
         case XRT_HIP_SURF_ELLIPSE_PARAM:
