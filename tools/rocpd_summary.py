@@ -17,7 +17,8 @@ import os
 import sqlite3
 import sys
 
-OURS = ('reflect_fused', 'reflect_solve', 'reflect_finish', 'reflect_stats_dir',
+OURS = ('reflect_fused', 'reflect_solve', 'reflect_finish', 'reflect_stats_dir_y',
+        'reflect_stats_dir',
         'reflect_stats_bracket', 'screen_expose_kernel', 'kirchhoff_stream',
         'kirchhoff_pack', 'kirchhoff_finalize', 'und_imap', 'und_sum', 'und_pack',
         'aperture_propagate_kernel', 'hist2d_kernel', 'reflect_decide_axis',
