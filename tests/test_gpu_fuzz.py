@@ -188,6 +188,8 @@ def test_random_dcm_matches_oracle(seed):
     beam.a[:] = rng.normal(0, 1e-4, n)
     beam.c[:] = rng.normal(0, 2e-5, n)
     beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.y[:] = 9900.                       # a fan converging on the crystal
+    beam.z[:] += -beam.c / beam.b * 100.
     if bl.azimuth:
         for u, v in (('x', 'y'), ('a', 'b')):
             p, q = getattr(beam, u).copy(), getattr(beam, v).copy()
@@ -218,3 +220,50 @@ def test_random_dcm_matches_oracle(seed):
             assert np.abs(getattr(mine, f) - getattr(ref, f)).max() <= 1e-9 * scale, \
                 (tag, f)
     assert (o2.state == 1).sum() > 200, (hkl, E0, thB)
+
+
+@pytest.mark.parametrize('alpha_deg,expect_mixed', [(3., True), (-3., False),
+                                                    (8., False), (0., False)])
+def test_crystal_batch_sign_optimistic_pass_and_redo(alpha_deg, expect_mixed):
+    """A Bragg crystal deflects with a batch-global sign (mean beamInDotNormal,
+    reflect.py:573-574). The kernel first assumes all rays agree; an asymmetric cut
+    hit at grazing angles on both sides of the cut angle makes a MIXED batch, which
+    must trigger the exact two-pass redo. Both outcomes against the oracle."""
+    rng = np.random.default_rng(77)
+    bl = raycing.BeamLine()
+    si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    alpha = np.radians(alpha_deg)
+    oe = roe.OE(bl, 'xtal', center=[0., 10000., 0.], pitch=np.radians(3.5), material=si,
+                alpha=alpha if alpha else None, limPhysX=[-20, 20], limPhysY=[-300, 300])
+    n = 4000
+    beam = rs.Beam(nrays=n, withAmplitudes=True)
+    beam.x[:] = rng.normal(0, 1., n)
+    beam.z[:] = rng.normal(0, 0.5, n)
+    beam.a[:] = rng.normal(0, 1e-4, n)
+    beam.c[:] = rng.uniform(-np.radians(2.5), np.radians(2.0), n)   # grazing 1..5.5 deg
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.y[:] = 9900.                       # a fan converging on the crystal
+    beam.z[:] += -beam.c / beam.b * 100.
+    beam.E[:] = rng.uniform(8990., 9010., n)
+    ang = rng.uniform(0, np.pi, n)
+    es, ep = np.cos(ang), np.sin(ang) * np.exp(1j * rng.uniform(-np.pi, np.pi, n))
+    beam.Jss[:], beam.Jpp[:], beam.Jsp[:] = es * es, (ep * np.conj(ep)).real, \
+        es * np.conj(ep)
+    beam.Es[:], beam.Ep[:] = es, ep
+    beam.state[:] = 1
+    ogb, olb = rn.oe_reflect(oracle_params(oe), to_oracle_beam(beam))
+    # what the batch looks like
+    theta = olb.theta[olb.state == 1]
+    mixed = bool((theta > 0).any() and (theta < 0).any())
+    assert mixed == expect_mixed
+    gb, lb = oe.reflect(beam)
+    for mine, ref, tag in ((lb, olb, 'local'), (gb, ogb, 'global')):
+        assert np.array_equal(mine.state, ref.state), tag
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):
+            r = getattr(ref, f)
+            assert np.abs(getattr(mine, f) - r).max() <= \
+                1e-12 * max(np.abs(r).max(), 1e-300), (tag, f)
+        scale = max(np.abs(ref.Jss).max(), np.abs(ref.Jpp).max(), 1e-300)
+        for f in ('Jss', 'Jpp', 'Jsp'):
+            assert np.abs(getattr(mine, f) - getattr(ref, f)).max() <= 1e-9 * scale, \
+                (tag, f)

@@ -460,6 +460,7 @@ __global__ void reflect_init(GStat* g) {
   g->maxdz1 = 0.;
   g->maxdz2 = 0.;
   g->bracket_valid = 0;
+  g->redo_crystal = 0;
   g->n_good1 = 0;
   g->sum_bdn = 0.;
   g->emin = -INFINITY;
@@ -799,6 +800,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bracket(
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bdn(
     const double* __restrict__ part, int nblocks, GStat* g) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
+  if (!g->redo_crystal) return;
   double sum = 0., cnt = 0.;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     sum += part[(int64_t)b * 8];
@@ -1248,7 +1250,7 @@ __device__ __forceinline__ void rot_coherency(double c, double s, double& Jss, d
 
 struct Finished {
   double a, b, c;           // outgoing direction, local
-  double theta;
+  double theta, bdn;        // grazing angle; beamInDotNormal (clamped to [-1, 1])
   RayIn lo;                 // local beam fields (path, J, E-fields)
   double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;  // rotated back for vlb
 };
@@ -1286,7 +1288,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
                                                const xrt_hip_material& M, const GStat& g,
                                                const LocalRay& r, const Hit& h, RayIn q,
                                                const xrt_hip_beam& in, int64_t i,
-                                               bool has_amp) {
+                                               bool has_amp, int own_sign = 0) {
   Finished out;
   q.path += h.t;
   // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
@@ -1354,6 +1356,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   if (bdn < -1.) bdn = -1.;
   if (bdn > 1.) bdn = 1.;
   out.theta = acos(bdn) - kPI / 2.;
+  out.bdn = bdn;
   const double bdsn = PASYM(P) ? (r.a * n[3] + r.b * n[4] + r.c * n[5]) : bdn;
 
   int toWhere = 0;  // reflect.py:723-752
@@ -1370,7 +1373,10 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     if (MKIND(M) == XRT_HIP_MAT_CRYSTAL && toWhere == 0) {
       // crystal as a grating, reflect.py:568-612 + 451-469
       const double ndsn = n[0] * n[3] + n[1] * n[4] + n[2] * n[5];
-      const double bdnMean = g.sum_bdn / (double)g.n_good1;
+      // sign of the batch mean of beamInDotNormal (reflect.py:573-574). In the
+      // optimistic single pass (own_sign) every ray uses its own sign: identical
+      // whenever all rays of the batch agree, which reflect_reduce_sign verifies.
+      const double bdnMean = own_sign ? bdn : g.sum_bdn / (double)g.n_good1;
       const double sgbdn = bdnMean < 0. ? 1. : -1.;
       const double wHd = 1. / (M.d * 1e-7);
       const double g0 = (n[0] - ndsn * n[3]) * wHd * sgbdn;
@@ -1593,7 +1599,8 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
                                              const xrt_hip_beam& restore,
                                              const xrt_hip_beam& lb, const xrt_hip_beam& vb,
                                              double* theta, int64_t i, const LocalRay& r,
-                                             const Hit& h, int st, bool has_amp) {
+                                             const Hit& h, int st, bool has_amp,
+                                             int own_sign = 0, double* bdn_out = nullptr) {
   RayIn q;
   q.path = in.path[i];
   q.E = in.E[i];
@@ -1602,7 +1609,8 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
   RayIn lo;
   double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;
   if (st == 1) {
-    const Finished fin = finish_ray<K>(P, M, g, r, h, q, in, i, has_amp);
+    const Finished fin = finish_ray<K>(P, M, g, r, h, q, in, i, has_amp, own_sign);
+    if (bdn_out) *bdn_out = fin.bdn;
     la = fin.a;
     lbb = fin.b;
     lc = fin.c;
@@ -1694,6 +1702,82 @@ __global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
   complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
 }
 
+// ---------------------------------------------------------------------------
+// Bragg-reflecting crystals in ONE pass. The reference needs a batch-global sign
+// (of the mean beamInDotNormal) before it can deflect a single ray, which is why
+// the crystal path was solve -> reduce -> finish. For a real beam every ray has
+// the same sign, and then each ray's own sign IS the batch sign: this kernel
+// assumes so, and records how many rays fell on either side. reflect_reduce_sign
+// sets redo_crystal only if the batch was mixed; the exact two-pass sequence that
+// follows in the stream returns at once otherwise.
+// ---------------------------------------------------------------------------
+template <class K>
+__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_xtal(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
+    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* gp,
+    double* __restrict__ part4) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double sum = 0., cnt = 0., nneg = 0., npos = 0.;
+  if (i < in.n) {
+    const bool has_amp = in.Es_ri != nullptr;
+    const int st0 = in.state[i];
+    if (!entering(P, st0)) {
+      pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
+    } else {
+      const GStat g = *gp;
+      const LocalRay r = load_local(P, in, i);
+      const Hit h = solve_ray<K>(P, g, r);
+      int st = rays_good(P, h.x, h.y);
+      if (h.lost) st = P.lost_num;
+      double bdn = 0.;
+      complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 1, &bdn);
+      if (st == 1) {
+        sum = bdn;
+        cnt = 1.;
+        if (bdn < 0.)
+          nneg = 1.;
+        else
+          npos = 1.;
+      }
+    }
+  }
+  auto faddd = [](double u, double v) { return u + v; };
+  sum = block_reduce(sum, faddd, lds_d);
+  cnt = block_reduce(cnt, faddd, lds_d);
+  nneg = block_reduce(nneg, faddd, lds_d);
+  npos = block_reduce(npos, faddd, lds_d);
+  if (threadIdx.x == 0) {
+    double* o = part4 + (int64_t)blockIdx.x * 4;
+    o[0] = sum;
+    o[1] = cnt;
+    o[2] = nneg;
+    o[3] = npos;
+  }
+}
+
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_sign(
+    const double* __restrict__ part4, int64_t nblocks, GStat* g) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  double sum = 0., cnt = 0., nneg = 0., npos = 0.;
+  for (int64_t b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    sum += part4[b * 4];
+    cnt += part4[b * 4 + 1];
+    nneg += part4[b * 4 + 2];
+    npos += part4[b * 4 + 3];
+  }
+  auto faddd = [](double u, double v) { return u + v; };
+  sum = block_reduce(sum, faddd, lds_d);
+  cnt = block_reduce(cnt, faddd, lds_d);
+  nneg = block_reduce(nneg, faddd, lds_d);
+  npos = block_reduce(npos, faddd, lds_d);
+  if (threadIdx.x == 0) {
+    g->sum_bdn = sum;   // (block-wise order; only its sign is ever used)
+    g->n_good1 = (unsigned long long)cnt;
+    g->redo_crystal = (nneg > 0. && npos > 0.) ? 1 : 0;
+  }
+}
+
 // crystal path, first half: solve + state; stores t, local hit point and state,
 // accumulates sum(beamInDotNormal) over the rays that hit (reflect.py:573)
 template <class K>
@@ -1702,6 +1786,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
     int32_t* hst, const GStat* gp, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
+  if (!gp->redo_crystal) return;   // the optimistic single pass was exact
   double bdn_sum = 0.;
   unsigned long long cnt = 0;
   const GStat g = *gp;
@@ -1759,7 +1844,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_finish(
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const double* ht, const double* hx,
     const double* hy, const double* hz, const int32_t* hst, const GStat* gp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= in.n) return;
+  if (i >= in.n || !gp->redo_crystal) return;
   const bool has_amp = in.Es_ri != nullptr;
   const int st0 = in.state[i];
   if (!entering(P, st0)) {
@@ -1919,6 +2004,17 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
     using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
     using AnyXtal = Spec<0, -1, XRT_HIP_MAT_CRYSTAL, false>;
+    // optimistic single pass + verification; `ht` doubles as its partial-record buffer
+    if (evk0) (void)hipEventRecord(evk0, st);
+    if (flat_xtal)
+      hipLaunchKernelGGL(reflect_fused_xtal<FlatXtal>, grid, block, 0, st, P, M, in, restore, lb,
+                         vb, theta, g, ht);
+    else
+      hipLaunchKernelGGL(reflect_fused_xtal<AnyXtal>, grid, block, 0, st, P, M, in, restore, lb,
+                         vb, theta, g, ht);
+    if (evk1) (void)hipEventRecord(evk1, st);
+    hipLaunchKernelGGL(reflect_reduce_sign, dim3(1), block, 0, st, ht, (int64_t)grid.x, g);
+    // exact two-pass sequence, a no-op unless the batch had both signs
     if (flat_xtal)
       hipLaunchKernelGGL(reflect_solve<FlatXtal>, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst,
                          g, part);
@@ -1926,14 +2022,12 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       hipLaunchKernelGGL(reflect_solve<AnyXtal>, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst,
                          g, part);
     hipLaunchKernelGGL(reflect_reduce_bdn, dim3(1), block, 0, st, part, (int)sgrid.x, g);
-    if (evk0) (void)hipEventRecord(evk0, st);
     if (flat_xtal)
       hipLaunchKernelGGL(reflect_finish<FlatXtal>, grid, block, 0, st, P, M, in, restore, lb, vb,
                          theta, ht, hx, hy, hz, hst, g);
     else
       hipLaunchKernelGGL(reflect_finish<AnyXtal>, grid, block, 0, st, P, M, in, restore, lb, vb,
                          theta, ht, hx, hy, hz, hst, g);
-    if (evk1) (void)hipEventRecord(evk1, st);
   } else {
     if (evk0) (void)hipEventRecord(evk0, st);
 #define XRT_FUSED(SPEC) \
