@@ -239,10 +239,12 @@ XRT_HIP_API int xrt_hip_sizeof(int which);
  * beam here on the 2nd crystal); usually == in. theta (optional): lb.theta[n]
  * (reflect.py:793-796). info_host (optional, 16 doubles, forces a sync):
  * [0] bracketing axis, [1] first-ray sign, [2] brent?, [3] t1.min, [4] t2.max,
- * [5] max|dz1|, [6] max|dz2|, [7] entering rays, [8] rays ending in state 1,
- * [9] sum(beamInDotNormal over state 1). kernel_ms (optional, 2 floats, forces a
- * sync): [0] whole pass, [1] the dominant kernel (fused solve+finish, or the
- * finish kernel on the crystal path), HIP events on `stream`. Asynchronous on
+ * [5] max|dz1|, [6] max|dz2|, [7] entering rays, [8] rays ending in state 1 and
+ * [9] sum(beamInDotNormal over them) -- crystals only, and only when the batch
+ * had both signs of beamInDotNormal (the exact two-pass redo ran), [10]/[11] the
+ * batch held negative / non-negative beamInDotNormal (crystals). kernel_ms
+ * (optional, 2 floats, forces a sync): [0] whole pass, [1] the dominant kernel
+ * (fused solve+finish), HIP events on `stream`. Asynchronous on
  * `stream` otherwise. */
 XRT_HIP_API int xrt_hip_reflect_pass_f64_dev(
     const xrt_hip_pass* pass, const xrt_hip_material* material,

@@ -256,7 +256,9 @@ def test_crystal_batch_sign_optimistic_pass_and_redo(alpha_deg, expect_mixed):
     theta = olb.theta[olb.state == 1]
     mixed = bool((theta > 0).any() and (theta < 0).any())
     assert mixed == expect_mixed
-    gb, lb = oe.reflect(beam)
+    info = {}
+    gb, lb = oe.reflect(beam, _info=info)
+    assert info['mixed_sign'] == expect_mixed     # ... and the redo ran iff mixed
     for mine, ref, tag in ((lb, olb, 'local'), (gb, ogb, 'global')):
         assert np.array_equal(mine.state, ref.state), tag
         for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):

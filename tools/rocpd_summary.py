@@ -17,7 +17,7 @@ import os
 import sqlite3
 import sys
 
-OURS = ('reflect_fused', 'reflect_solve', 'reflect_finish', 'reflect_stats_dir_y',
+OURS = ('reflect_fused_xtal', 'reflect_reduce_sign', 'reflect_fused', 'reflect_solve', 'reflect_finish', 'reflect_stats_dir_y',
         'reflect_stats_dir',
         'reflect_stats_bracket', 'screen_expose_kernel', 'kirchhoff_stream',
         'kirchhoff_pack', 'kirchhoff_finalize', 'und_imap', 'und_sum', 'und_pack',

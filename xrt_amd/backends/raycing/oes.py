@@ -361,7 +361,8 @@ class OE(object):
             v = list(info)
             res_info = dict(axis=int(v[0]), positive=bool(v[1]), brent=bool(v[2]),
                             tMinGlobal=v[3], tMaxGlobal=v[4], maxdz1=v[5],
-                            maxdz2=v[6], n_enter=int(v[7]))
+                            maxdz2=v[6], n_enter=int(v[7]),
+                            mixed_sign=bool(v[10] and v[11]))
         if timing:
             res_info = res_info or {}
             res_info['pass_ms'] = ms_out[0]

@@ -342,6 +342,8 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
     info_host[7] = (double)g.n_enter;
     info_host[8] = (double)g.n_good1;
     info_host[9] = g.sum_bdn;
+    info_host[10] = g.any_neg;
+    info_host[11] = g.any_pos;
   }
   return XRT_HIP_OK;
 }

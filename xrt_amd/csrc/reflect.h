@@ -25,7 +25,8 @@ struct GStat {
   int axis, positive;                // bracketing axis; sign of the first ray's component
   double t1min, t2max, maxdz1, maxdz2;
   int bracket_valid;                 // the bracket statistics above are already final
-  int redo_crystal;                  // 1: in.n mixed signs -> the optimistic crystal pass is redone
+  int any_neg, any_pos;              // optimistic crystal pass saw beamInDotNormal <0 / >=0;
+                                     // both set -> mixed batch, the exact two passes redo it
   unsigned long long n_good1;        // rays that ended in state 1
   double sum_bdn;                    // sum of beamInDotNormal over them
   double emin, emax;                 // energy range of the entering rays

@@ -460,7 +460,8 @@ __global__ void reflect_init(GStat* g) {
   g->maxdz1 = 0.;
   g->maxdz2 = 0.;
   g->bracket_valid = 0;
-  g->redo_crystal = 0;
+  g->any_neg = 0;
+  g->any_pos = 0;
   g->n_good1 = 0;
   g->sum_bdn = 0.;
   g->emin = -INFINITY;
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bracket(
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bdn(
     const double* __restrict__ part, int nblocks, GStat* g) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
-  if (!g->redo_crystal) return;
+  if (!(g->any_neg && g->any_pos)) return;
   double sum = 0., cnt = 0.;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     sum += part[(int64_t)b * 8];
@@ -1707,18 +1708,16 @@ __global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
 // (of the mean beamInDotNormal) before it can deflect a single ray, which is why
 // the crystal path was solve -> reduce -> finish. For a real beam every ray has
 // the same sign, and then each ray's own sign IS the batch sign: this kernel
-// assumes so, and records how many rays fell on either side. reflect_reduce_sign
-// sets redo_crystal only if the batch was mixed; the exact two-pass sequence that
-// follows in the stream returns at once otherwise.
+// assumes so, and raises GStat::any_neg / any_pos for the sides it saw. The exact
+// two-pass sequence that follows in the stream returns at once unless both are up.
 // ---------------------------------------------------------------------------
 template <class K>
 __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_xtal(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
-    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* gp,
-    double* __restrict__ part4) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
+    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
+    int* __restrict__ any_neg_pos) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double sum = 0., cnt = 0., nneg = 0., npos = 0.;
+  int neg = 0, pos = 0;
   if (i < in.n) {
     const bool has_amp = in.Es_ri != nullptr;
     const int st0 = in.state[i];
@@ -1732,49 +1731,16 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_xtal(
       if (h.lost) st = P.lost_num;
       double bdn = 0.;
       complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 1, &bdn);
-      if (st == 1) {
-        sum = bdn;
-        cnt = 1.;
-        if (bdn < 0.)
-          nneg = 1.;
-        else
-          npos = 1.;
-      }
+      neg = st == 1 && bdn < 0.;
+      pos = st == 1 && !(bdn < 0.);
     }
   }
-  auto faddd = [](double u, double v) { return u + v; };
-  sum = block_reduce(sum, faddd, lds_d);
-  cnt = block_reduce(cnt, faddd, lds_d);
-  nneg = block_reduce(nneg, faddd, lds_d);
-  npos = block_reduce(npos, faddd, lds_d);
+  // same-value racing stores; any_neg/any_pos are read only by the kernels that follow
+  neg = __syncthreads_or(neg);
+  pos = __syncthreads_or(pos);
   if (threadIdx.x == 0) {
-    double* o = part4 + (int64_t)blockIdx.x * 4;
-    o[0] = sum;
-    o[1] = cnt;
-    o[2] = nneg;
-    o[3] = npos;
-  }
-}
-
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_sign(
-    const double* __restrict__ part4, int64_t nblocks, GStat* g) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  double sum = 0., cnt = 0., nneg = 0., npos = 0.;
-  for (int64_t b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    sum += part4[b * 4];
-    cnt += part4[b * 4 + 1];
-    nneg += part4[b * 4 + 2];
-    npos += part4[b * 4 + 3];
-  }
-  auto faddd = [](double u, double v) { return u + v; };
-  sum = block_reduce(sum, faddd, lds_d);
-  cnt = block_reduce(cnt, faddd, lds_d);
-  nneg = block_reduce(nneg, faddd, lds_d);
-  npos = block_reduce(npos, faddd, lds_d);
-  if (threadIdx.x == 0) {
-    g->sum_bdn = sum;   // (block-wise order; only its sign is ever used)
-    g->n_good1 = (unsigned long long)cnt;
-    g->redo_crystal = (nneg > 0. && npos > 0.) ? 1 : 0;
+    if (neg) any_neg_pos[0] = 1;
+    if (pos) any_neg_pos[1] = 1;
   }
 }
 
@@ -1786,7 +1752,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
     int32_t* hst, const GStat* gp, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  if (!gp->redo_crystal) return;   // the optimistic single pass was exact
+  if (!(gp->any_neg && gp->any_pos)) return;   // the optimistic single pass was exact
   double bdn_sum = 0.;
   unsigned long long cnt = 0;
   const GStat g = *gp;
@@ -1844,7 +1810,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_finish(
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const double* ht, const double* hx,
     const double* hy, const double* hz, const int32_t* hst, const GStat* gp) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= in.n || !gp->redo_crystal) return;
+  if (i >= in.n || !(gp->any_neg && gp->any_pos)) return;
   const bool has_amp = in.Es_ri != nullptr;
   const int st0 = in.state[i];
   if (!entering(P, st0)) {
@@ -2004,16 +1970,15 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
     using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
     using AnyXtal = Spec<0, -1, XRT_HIP_MAT_CRYSTAL, false>;
-    // optimistic single pass + verification; `ht` doubles as its partial-record buffer
+    // optimistic single pass; it raises any_neg / any_pos
     if (evk0) (void)hipEventRecord(evk0, st);
     if (flat_xtal)
       hipLaunchKernelGGL(reflect_fused_xtal<FlatXtal>, grid, block, 0, st, P, M, in, restore, lb,
-                         vb, theta, g, ht);
+                         vb, theta, g, &g->any_neg);
     else
       hipLaunchKernelGGL(reflect_fused_xtal<AnyXtal>, grid, block, 0, st, P, M, in, restore, lb,
-                         vb, theta, g, ht);
+                         vb, theta, g, &g->any_neg);
     if (evk1) (void)hipEventRecord(evk1, st);
-    hipLaunchKernelGGL(reflect_reduce_sign, dim3(1), block, 0, st, ht, (int64_t)grid.x, g);
     // exact two-pass sequence, a no-op unless the batch had both signs
     if (flat_xtal)
       hipLaunchKernelGGL(reflect_solve<FlatXtal>, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst,
