@@ -450,6 +450,9 @@ XRT_HIP_API int xrt_hip_debug_divconst_f64_dev(int64_t n, const double* a, doubl
                                    void* stream);
 XRT_HIP_API int xrt_hip_debug_sincos_f64_dev(int64_t n, const double* phi, double* sn, double* cs,
                                  void* stream);
+/* the LDS-table form the Kirchhoff kernel uses when |k r| < 2^42 */
+XRT_HIP_API int xrt_hip_debug_sincos_tab_f64_dev(int64_t n, const double* phi, double* sn,
+                                     double* cs, void* stream);
 
 #ifdef __cplusplus
 }

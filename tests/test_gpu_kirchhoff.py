@@ -66,19 +66,27 @@ def test_sqrt_is_correctly_rounded_and_rinv_accurate():
     assert np.abs(ri * np.sqrt(x) - 1).max() < 1e-14   # one Goldschmidt step on v_rsq_f64
 
 
-def test_sincos_of_large_phases():
+@pytest.mark.parametrize('table', [False, True])
+def test_sincos_of_large_phases(table):
+    """Both sincos forms of the Kirchhoff kernel: the general one (|phi| < 2^50) and
+    the LDS-table one it takes when the whole launch has |k r| < 2^42."""
     from xrt_amd import hipcalls
     rng = np.random.default_rng(2)
+    top = 4e12 if table else 1e14
     phi = np.concatenate([rng.uniform(0, 1e12, 2_000_000),
+                          rng.uniform(-top, top, 500_000),
                           rng.uniform(-1e6, 1e6, 500_000),
                           rng.uniform(-10, 10, 500_000),
+                          np.arange(-4096, 4097) * (np.pi / 1024),   # table nodes
+                          (np.arange(-4096, 4097) + 0.5) * (np.pi / 1024),
                           np.arange(-64, 65) * (np.pi / 4)])
-    s, c = hipcalls.debug_sincos(dev(phi))
+    s, c = hipcalls.debug_sincos(dev(phi), table=table)
     s = s.cpu().numpy()
     c = c.cpu().numpy()
     # glibc sin/cos are < 1 ulp with exact argument reduction
-    assert np.abs(s - np.sin(phi)).max() < 4e-16
-    assert np.abs(c - np.cos(phi)).max() < 4e-16
+    tol = 6e-16 if table else 5e-16
+    assert np.abs(s - np.sin(phi)).max() < tol
+    assert np.abs(c - np.cos(phi)).max() < tol
 
 
 # ---- golden vectors from the reference --------------------------------------

@@ -1,31 +1,26 @@
-"""Quick on-GPU timing sweep of the Kirchhoff kernel (development aid)."""
+"""Kirchhoff kernel time over (ppt, nsplit) on the cfg4 shape: PYTHONPATH=. python tools/probe_kirchhoff.py"""
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
-from xrt_amd import hipcalls, workloads  # noqa: E402
+from xrt_amd import hipcalls
 
-
-def main():
-    cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    h = workloads.kirchhoff_case(cfg) if cfg in (4, 5) else workloads.kirchhoff_custom(200000, 512)
-    dev = torch.device('cuda', 0)
-    up = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
-    ns = h['ns']
-    args = [up(h['px']), up(h['py']), up(h['pz']), up(h['sx']), up(h['sy']), up(h['sz']),
-            up(np.zeros(ns)), up(np.ones(ns)), up(np.zeros(ns)), up(h['nl']), up(h['k']),
-            up(h['Es'], np.complex128), up(h['Ep'], np.complex128)]
-    npix = h['px'].size
-    for ppt in (1, 2):
-        for nsplit in (1, 2, 4, 8, 16, 32):
-            best = 1e30
-            for it in range(2):
-                *_, ms = hipcalls.kirchhoff(*args, nsplit=nsplit, ppt=ppt, timing=True)
-                best = min(best, ms)
-            pairs = npix * ns / (best * 1e-3)
-            print('ppt=%d nsplit=%2d  %8.2f ms  %.3e pairs/s  %.1f%% of 78.6 TF (57 flop/pair)'
-                  % (ppt, nsplit, best, pairs, pairs * 57 / 78.6e12 * 100), flush=True)
-
-
-if __name__ == '__main__':
-    main()
+ns, side = 1_000_000, 512
+rng = np.random.default_rng(7)
+dev = lambda a: torch.as_tensor(a, device='cuda')
+sx = dev(rng.uniform(-0.1, 0.1, ns)); sy = dev(np.zeros(ns)); sz = dev(rng.uniform(-0.1, 0.1, ns))
+k = dev(np.full(ns, 7900 / 1973.269804593025 * 1e1 * 1e0 * 1e3))
+nl = dev(np.ones(ns)); nx = dev(np.zeros(ns)); ny = dev(np.ones(ns)); nz = dev(np.zeros(ns))
+Es = dev(rng.normal(size=ns) + 1j * rng.normal(size=ns)); Ep = dev(np.zeros(ns, complex))
+g = np.linspace(-0.5, 0.5, side)
+X, Z = np.meshgrid(g, g)
+px = dev(X.ravel().copy()); pz = dev(Z.ravel().copy()); py = dev(np.full(side * side, 1e4))
+cases = [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else \
+    [(a, b) for a in (1, 2) for b in (0, 8, 32, 64)]
+for ppt, nsplit in cases:
+    if True:
+        best = 1e9
+        for _ in range(3):
+            out = hipcalls.kirchhoff(px, py, pz, sx, sy, sz, nx, ny, nz, nl, k, Es, Ep,
+                                     nsplit=nsplit, ppt=ppt, timing=True)
+            best = min(best, out[-1])
+        print('ppt %d nsplit %2d  %.1f ms  %.3e pairs/s' % (ppt, nsplit, best, ns * side * side / best * 1e3))

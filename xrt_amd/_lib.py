@@ -64,6 +64,7 @@ SIGNATURES = {
     'xrt_hip_debug_sqrt_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
     'xrt_hip_debug_divconst_f64_dev': (ctypes.c_int, [i64, vp, ctypes.c_double, vp, vp]),
     'xrt_hip_debug_sincos_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
+    'xrt_hip_debug_sincos_tab_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
 }
 
 

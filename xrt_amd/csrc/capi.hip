@@ -702,7 +702,14 @@ int xrt_hip_debug_divconst_f64_dev(int64_t n, const double* a, double b, double*
 int xrt_hip_debug_sincos_f64_dev(int64_t n, const double* phi, double* sn, double* cs,
                                  void* stream) {
   if (n <= 0) return XRT_HIP_OK;
-  HIP_TRY(xrt::debug_sincos_launch(n, phi, sn, cs, reinterpret_cast<hipStream_t>(stream)));
+  HIP_TRY(xrt::debug_sincos_launch(n, phi, sn, cs, 0, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_debug_sincos_tab_f64_dev(int64_t n, const double* phi, double* sn, double* cs,
+                                     void* stream) {
+  if (n <= 0) return XRT_HIP_OK;
+  HIP_TRY(xrt::debug_sincos_launch(n, phi, sn, cs, 1, reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
 }
 

@@ -50,23 +50,10 @@ __device__ __forceinline__ double sqrt_rn_halfinv(double x, double& hinv) {
   return g;
 }
 
-// sin/cos of a LARGE positive-or-negative phase phi [rad] (|phi| < 2^50),
-// accurate to ~2e-16 absolute. The Kirchhoff phase k*r is ~4e11 rad, so ocml's
-// generic sincos would take its Payne-Hanek path every call; here the
-// reduction is two fma against a double-double 2/pi:
-//   t = phi*(2/pi) in quarter turns, n = rint(t) via the 1.5*2^52 trick (its
-//   low mantissa bits give the quadrant), u = phi*(2/pi) - n exactly (fma),
-// then minimax polynomials in w = u^2 for sin(pi/2 u) and cos(pi/2 u), |u|<=1/2.
-__device__ __forceinline__ void sincos_phase(double phi, double& sn, double& cs) {
-  const double TWO_OVER_PI_HI = 0x1.45f306dc9c883p-1;
-  const double TWO_OVER_PI_LO = -0x1.6b01ec5417056p-55;
-  const double MAGIC = 0x1.8p52;
-  double t = phi * TWO_OVER_PI_HI;
-  double m = t + MAGIC;
-  double n = m - MAGIC;
-  unsigned q = (unsigned)__double2loint(m);
-  double u = fma_(phi, TWO_OVER_PI_HI, -n);
-  u = fma_(phi, TWO_OVER_PI_LO, u);
+// sin/cos of (q + u) quarter turns, |u| <= 1/2: minimax polynomials in w = u^2 for
+// sin(pi/2 u) and cos(pi/2 u), then the quadrant q (mod 4) swaps / negates.
+__device__ __forceinline__ void sincos_quarter_turns(double u, unsigned q, double& sn,
+                                                     double& cs) {
   double w = u * u;
   double ps = 0x1.e3f38399551bfp-25;
   ps = fma_(ps, w, -0x1.e30071afc3e59p-19);
@@ -93,6 +80,74 @@ __device__ __forceinline__ void sincos_phase(double phi, double& sn, double& cs)
   sb ^= (unsigned long long)((q >> 1) & 1u) << 63;
   cs = __longlong_as_double(cb);
   sn = __longlong_as_double(sb);
+}
+
+// sin/cos of a LARGE positive-or-negative phase phi [rad] (|phi| < 2^50),
+// accurate to ~2e-16 absolute. The Kirchhoff phase k*r is ~4e11 rad, so ocml's
+// generic sincos would take its Payne-Hanek path every call; here the
+// reduction is two fma against a double-double 2/pi:
+//   t = phi*(2/pi) in quarter turns, n = rint(t) via the 1.5*2^52 trick (its
+//   low mantissa bits give the quadrant), u = phi*(2/pi) - n exactly (fma),
+// then minimax polynomials in w = u^2 for sin(pi/2 u) and cos(pi/2 u), |u|<=1/2.
+__device__ __forceinline__ void sincos_phase(double phi, double& sn, double& cs) {
+  const double TWO_OVER_PI_HI = 0x1.45f306dc9c883p-1;
+  const double TWO_OVER_PI_LO = -0x1.6b01ec5417056p-55;
+  const double MAGIC = 0x1.8p52;
+  double t = phi * TWO_OVER_PI_HI;
+  double m = t + MAGIC;
+  double n = m - MAGIC;
+  unsigned q = (unsigned)__double2loint(m);
+  double u = fma_(phi, TWO_OVER_PI_HI, -n);
+  u = fma_(phi, TWO_OVER_PI_LO, u);
+  sincos_quarter_turns(u, q, sn, cs);
+}
+
+// ---------------------------------------------------------------------------
+// Table-driven variant for the Kirchhoff inner loop, |phi| < 2^42. The circle is
+// cut into SINCOS_TAB_N steps of delta = 2 pi / N; (cos, sin) of every step sit in
+// LDS (filled by the block with the routine above: each entry correctly rounded to
+// < 1 ulp), the remainder |theta| <= delta/2 = 1.53e-3 rad needs only
+//   sin theta = theta (1 - theta^2/6)           (next term 7e-17)
+//   cos theta = 1 - theta^2/2 + theta^4/24       (next term 2e-20)
+// and one complex product joins them: 15 VALU slots instead of 31, no quadrant
+// selects. Absolute accuracy ~4e-16. The reduction is the same two-fma form with
+// N/(2 pi) as a double-double.
+// ---------------------------------------------------------------------------
+#define SINCOS_TAB_N 2048
+
+__device__ __forceinline__ void sincos_tab_fill(double2* tab) {
+  for (int j = threadIdx.x; j < SINCOS_TAB_N; j += blockDim.x) {
+    const double qt = (double)j * (4.0 / SINCOS_TAB_N);   // quarter turns, exact
+    const double n = __builtin_rint(qt);
+    double s, c;
+    sincos_quarter_turns(qt - n, (unsigned)(int)n, s, c);
+    tab[j] = make_double2(c, s);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void sincos_tab(double phi, const double2* tab, double& sn,
+                                           double& cs) {
+  constexpr double STEPS_PER_RAD_HI = 0x1.45f306dc9c883p-1 * (SINCOS_TAB_N / 4);
+  constexpr double STEPS_PER_RAD_LO = -0x1.6b01ec5417056p-55 * (SINCOS_TAB_N / 4);
+  constexpr double DELTA = 0x1.921fb54442d18p+1 * (2.0 / SINCOS_TAB_N);
+  constexpr double S0 = DELTA, S1 = -(DELTA * DELTA * DELTA) / 6.0;
+  constexpr double C1 = -(DELTA * DELTA) / 2.0, C2 = (DELTA * DELTA) * (DELTA * DELTA) / 24.0;
+  const double MAGIC = 0x1.8p52;
+  // one rounding instead of numpy-style two: n may differ from rint(t) on exact
+  // ties only, which merely lets |u| reach 1/2 + 2^-53
+  const double m = fma_(phi, STEPS_PER_RAD_HI, MAGIC);
+  const double n = m - MAGIC;
+  const double2 T = tab[(unsigned)__double2loint(m) & (SINCOS_TAB_N - 1)];
+  double u = fma_(phi, STEPS_PER_RAD_HI, -n);
+  u = fma_(phi, STEPS_PER_RAD_LO, u);
+  const double w = u * u;
+  const double s = fma_(S1, w, S0) * u;
+  const double c = fma_(fma_(C2, w, C1), w, 1.0);
+  cs = T.x * c;
+  cs = fma_(-T.y, s, cs);
+  sn = T.y * c;
+  sn = fma_(T.x, s, sn);
 }
 
 }  // namespace xrt

@@ -6,6 +6,9 @@
 
 #define KIRCHHOFF_BLOCK 256
 #define KIRCHHOFF_REC_DOUBLES 16
+#ifndef KIRCHHOFF_WAVES
+#define KIRCHHOFF_WAVES 4   /* waves per SIMD the stream kernel is register-budgeted for */
+#endif
 #define KIRCHHOFF_FLAG_EP 1u
 #define KIRCHHOFF_FLAG_NXZ 2u
 
@@ -39,6 +42,6 @@ hipError_t debug_sqrt_launch(int64_t n, const double* x, double* r, double* ri,
 hipError_t debug_divconst_launch(int64_t n, const double* a, double b, double y, double* q,
                                  hipStream_t stream);
 hipError_t debug_sincos_launch(int64_t n, const double* phi, double* sn, double* cs,
-                               hipStream_t stream);
+                               int table, hipStream_t stream);
 
 }  // namespace xrt

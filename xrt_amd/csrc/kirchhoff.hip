@@ -19,7 +19,8 @@
 //     tiny finalize kernel adds them in fixed order (deterministic, no atomics);
 //   * r and k*r use exactly numpy's operation order with no FMA contraction
 //     (k*r ~ 4e11 rad: one ulp is 6e-5 rad), sqrt is correctly rounded and also
-//     yields 1/r; sincos uses a 2-fma double-double reduction (fp64_math.h).
+//     yields 1/r; sincos uses a 2-fma double-double reduction onto a 2048-step
+//     (cos, sin) table in LDS plus a 2-term remainder (fp64_math.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fp64_math.h"
@@ -31,14 +32,24 @@ namespace xrt {
 // pack: sample arrays -> 16-double records. Positions / normals are read with
 // an element stride so that both the SoA layout (stride 1) and the reference's
 // OpenCL marshalling ns x [x,y,z,0] (stride 4, waves.py:872-879) feed it.
-//   [0..2] x,y,z  [3] nl  [4..6] 2n  [7] k  [8,9] Es  [10,11] Ep
-//   [12,13] k*(Es+Ep)  [14] 2k  [15] k*k
+//   [0..2] x,y,z  [3] nl  [4] 2ny  [5] k  [6,7] Es  |  [8] 2k  [9] 2nx  [10] 2nz
+//   [11,12] Ep  [13,14] k*(Es+Ep)  [15] k*k
+// (the first 72 bytes are all the Ep == 0, planar-normal case reads)
 // (1/r comes out of the sqrt iteration as h = 1/(2r): the factor 2 is folded
 // into 2n and 2k here, once per sample instead of once per pair.)
 // The kernel also classifies the sample set so that the main kernel can take a
 // shorter instruction stream when it is safe: flags bit 0 = some Ep != 0,
 // bit 1 = some normal has an x or z component.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void kirchhoff_pack(
     int64_t ns, const double* __restrict__ sx, const double* __restrict__ sy,
     const double* __restrict__ sz, int pstride, const double* __restrict__ nx,
@@ -48,6 +59,7 @@ __global__ __launch_bounds__(256) void kirchhoff_pack(
     double* __restrict__ rec, unsigned* __restrict__ flags) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned f = 0;
+  unsigned long long kabs = 0, sabs = 0;
   if (i < ns) {
     double2 es = Es[i], ep = Ep[i];
     double kk = k[i];
@@ -56,18 +68,30 @@ __global__ __launch_bounds__(256) void kirchhoff_pack(
     const double vx = nx[in], vy = ny[in], vz = nz[in];
     o[0] = make_double2(sx[ip], sy[ip]);
     o[1] = make_double2(sz[ip], nl[i]);
-    o[2] = make_double2(2. * vx, 2. * vy);
-    o[3] = make_double2(2. * vz, kk);
-    o[4] = es;
-    o[5] = ep;
+    o[2] = make_double2(2. * vy, kk);
+    o[3] = es;
+    o[4] = make_double2(2. * kk, 2. * vx);
+    o[5] = make_double2(2. * vz, ep.x);
     // numpy: k**2/(4pi) * (Es+Ep) * U / r ; the sum Es+Ep is formed first there too
-    o[6] = make_double2(kk * (es.x + ep.x), kk * (es.y + ep.y));
-    o[7] = make_double2(2. * kk, kk * kk);
+    o[6] = make_double2(ep.y, kk * (es.x + ep.x));
+    o[7] = make_double2(kk * (es.y + ep.y), kk * kk);
     if (ep.x != 0. || ep.y != 0.) f |= KIRCHHOFF_FLAG_EP;
     if (vx != 0. || vz != 0.) f |= KIRCHHOFF_FLAG_NXZ;
+    // ingredients of the bound |k r| <= kmax (|p|_1 + |s|_1) the main kernel checks
+    // before it trusts the table-driven sincos (non-negative doubles order like
+    // their bit patterns)
+    kabs = __double_as_longlong(fabs(kk));
+    sabs = __double_as_longlong(fabs(sx[ip]) + fabs(sy[ip]) + fabs(sz[ip]));
   }
   f = __builtin_amdgcn_readfirstlane(__reduce_or_sync(~0ull, f));
-  if ((threadIdx.x & 63) == 0 && f) atomicOr(flags, f);
+  kabs = wave_max_u64(kabs);
+  sabs = wave_max_u64(sabs);
+  if ((threadIdx.x & 63) == 0) {
+    if (f) atomicOr(flags, f);
+    unsigned long long* bound = reinterpret_cast<unsigned long long*>(flags) + 1;
+    atomicMax(bound, kabs);
+    atomicMax(bound + 1, sabs);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -80,36 +104,57 @@ struct Acc {
 // HAS_P: the p-polarised source field is present. GEN_N: normals are general
 // (otherwise every normal is (0, ny, 0), the aperture / screen / source case of
 // waves.py:687-689 — d.n collapses to dy*ny).
-template <bool HAS_P, bool GEN_N>
-__device__ __forceinline__ void pair_update(double px, double py, double pz,
-                                            const double* __restrict__ r, Acc& a) {
+// TAB: sincos through the LDS table (|k r| < 2^42 is guaranteed by the caller).
+//
+// The update of one (receiving point, sample) pair comes in two halves so that the
+// loop can put its scalar prefetch between them (see stream_loop): pair_head ends
+// with the first use of the LDS table entry, pair_tail is pure accumulation.
+struct Mid {
+  double dx, dy, dz, gr, gi, kip;
+};
+
+template <bool GEN_N, bool TAB>
+__device__ __forceinline__ Mid pair_head(double px, double py, double pz,
+                                         const double (&r)[KIRCHHOFF_REC_DOUBLES],
+                                         const double2* tab) {
   const double sx = r[0], sy = r[1], sz = r[2], nl = r[3];
-  const double n2x = r[4], n2y = r[5], n2z = r[6], k = r[7];
-  const double esr = r[8], esi = r[9], epr = r[10], epi = r[11];
-  const double qr = r[12], qi = r[13], k2 = r[14], kk = r[15];
+  const double n2y = r[4], k = r[5], k2 = r[8], n2x = r[9], n2z = r[10];
+  Mid m;
   // --- bit-exact part (numpy order, no contraction) ---
-  const double dx = px - sx;
-  const double dy = py - sy;
-  const double dz = pz - sz;
-  const double s2 = (dx * dx + dy * dy) + dz * dz;
+  m.dx = px - sx;
+  m.dy = py - sy;
+  m.dz = pz - sz;
+  const double s2 = (m.dx * m.dx + m.dy * m.dy) + m.dz * m.dz;
   double h;  // 1/(2r)
   const double rr = sqrt_rn_halfinv(s2, h);
   const double phase = k * rr;
   // --- the rest only needs ~1e-16 relative accuracy ---
   double dn2;
   if (GEN_N) {
-    dn2 = dx * n2x;
-    dn2 = fma_(dy, n2y, dn2);
-    dn2 = fma_(dz, n2z, dn2);
+    dn2 = m.dx * n2x;
+    dn2 = fma_(m.dy, n2y, dn2);
+    dn2 = fma_(m.dz, n2z, dn2);
   } else {
-    dn2 = dy * n2y;
+    dn2 = m.dy * n2y;
   }
-  const double kip = k2 * h;                    // k/r
-  const double cr = kip * fma_(dn2, h, nl);     // (k/r)(d.n/r + nl)
+  m.kip = k2 * h;                                 // k/r
+  const double cr = m.kip * fma_(dn2, h, nl);     // (k/r)(d.n/r + nl)
   double sn, cs;
-  sincos_phase(phase, sn, cs);
-  const double gr = cr * cs;
-  const double gi = cr * sn;
+  if (TAB)
+    sincos_tab(phase, tab, sn, cs);
+  else
+    sincos_phase(phase, sn, cs);
+  m.gr = cr * cs;
+  m.gi = cr * sn;
+  return m;
+}
+
+template <bool HAS_P>
+__device__ __forceinline__ void pair_tail(const Mid& m,
+                                          const double (&r)[KIRCHHOFF_REC_DOUBLES], Acc& a) {
+  const double k = r[5], esr = r[6], esi = r[7];
+  const double epr = r[11], epi = r[12], qr = r[13], qi = r[14];
+  const double gr = m.gr, gi = m.gi;
   double hr, hi;
   if (HAS_P) {
     a.sr = fma_(gr, esr, a.sr);
@@ -120,8 +165,8 @@ __device__ __forceinline__ void pair_update(double px, double py, double pz,
     a.pr = fma_(-gi, epi, a.pr);
     a.pi = fma_(gr, epi, a.pi);
     a.pi = fma_(gi, epr, a.pi);
-    const double hr0 = kip * gr;
-    const double hi0 = kip * gi;
+    const double hr0 = m.kip * gr;
+    const double hi0 = m.kip * gi;
     hr = hr0 * qr;
     hr = fma_(-hi0, qi, hr);
     hi = hr0 * qi;
@@ -134,34 +179,160 @@ __device__ __forceinline__ void pair_update(double px, double py, double pz,
     wi = fma_(gi, esr, wi);
     a.sr += wr;
     a.si += wi;
-    const double kkip = kip * k;
+    const double kkip = m.kip * k;
     hr = kkip * wr;
     hi = kkip * wi;
-    (void)qr;
-    (void)qi;
   }
-  (void)kk;
-  a.ar = fma_(hr, dx, a.ar);
-  a.ai = fma_(hi, dx, a.ai);
-  a.br = fma_(hr, dy, a.br);
-  a.bi = fma_(hi, dy, a.bi);
-  a.cr = fma_(hr, dz, a.cr);
-  a.ci = fma_(hi, dz, a.ci);
+  a.ar = fma_(hr, m.dx, a.ar);
+  a.ai = fma_(hi, m.dx, a.ai);
+  a.br = fma_(hr, m.dy, a.br);
+  a.bi = fma_(hi, m.dy, a.bi);
+  a.cr = fma_(hr, m.dz, a.cr);
+  a.ci = fma_(hi, m.dz, a.ci);
 }
 
-template <int PPT, bool HAS_P, bool GEN_N>
+// One packed sample record in SGPRs. The record index is wave-uniform, so the
+// record comes through the scalar cache (s_load) and VALU takes its fields as
+// scalar operands: no VGPRs, no LDS traffic for it. The loads are inline asm
+// because the compiler otherwise sinks them to their first use and waits on the
+// spot. gfx950 counts SMEM and LDS returns on ONE counter (lgkmcnt) and SMEM
+// returns out of order, so every wait for an LDS read is an lgkmcnt(0) that also
+// drains any scalar prefetch in flight. The loop therefore issues the prefetch
+// right AFTER the last LDS wait of an iteration (sched_barrier pins that place)
+// and, where SGPRs allow (three register sets), two records ahead: the request
+// then has a whole iteration before the next LDS wait catches it.
+// The compiler does not count these loads in its own s_waitcnt bookkeeping; extra
+// outstanding SMEM only makes its waits stricter, and settle() -- tied to the
+// destination registers -- is the wait that guards their use.
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool FULL>
+struct SRec;
+
+template <>
+struct SRec<false> {   // 72 bytes: Ep == 0 and every normal is (0, ny, 0)
+  u32x16 lo;
+  u32x2 hi;
+  __device__ __forceinline__ void issue(const double* p) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40"
+                 : "=&s"(lo), "=&s"(hi)
+                 : "s"(p)
+                 : "memory");
+  }
+  __device__ __forceinline__ void settle() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi));
+  }
+  __device__ __forceinline__ void unpack(double (&r)[KIRCHHOFF_REC_DOUBLES]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = __hiloint2double((int)lo[2 * i + 1], (int)lo[2 * i]);
+    r[8] = __hiloint2double((int)hi[1], (int)hi[0]);
+#pragma unroll
+    for (int i = 9; i < KIRCHHOFF_REC_DOUBLES; ++i) r[i] = 0.;
+  }
+};
+
+template <>
+struct SRec<true> {    // the whole 128-byte record
+  u32x16 lo, hi;
+  __device__ __forceinline__ void issue(const double* p) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40"
+                 : "=&s"(lo), "=&s"(hi)
+                 : "s"(p)
+                 : "memory");
+  }
+  __device__ __forceinline__ void settle() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi));
+  }
+  __device__ __forceinline__ void unpack(double (&r)[KIRCHHOFF_REC_DOUBLES]) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      r[i] = __hiloint2double((int)lo[2 * i + 1], (int)lo[2 * i]);
+      r[8 + i] = __hiloint2double((int)hi[2 * i + 1], (int)hi[2 * i]);
+    }
+  }
+};
+
+// work on the record in `cur`; between the two halves settle `landed` (if any) and
+// request the record at `pnext` into `fetch`
+template <int PPT, bool HAS_P, bool GEN_N, bool TAB, class R>
+__device__ __forceinline__ void stream_step(const double (&x)[PPT], const double (&y)[PPT],
+                                            const double (&z)[PPT], Acc (&acc)[PPT],
+                                            const double2* tab, const R& cur, R* landed,
+                                            R& fetch, const double* pnext) {
+  double r[KIRCHHOFF_REC_DOUBLES];
+  cur.unpack(r);
+  Mid m[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) m[j] = pair_head<GEN_N, TAB>(x[j], y[j], z[j], r, tab);
+  __builtin_amdgcn_sched_barrier(0);
+  if (landed) landed->settle();
+  fetch.issue(pnext);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) pair_tail<HAS_P>(m[j], r, acc[j]);
+}
+
+template <int PPT, bool HAS_P, bool GEN_N, bool TAB>
 __device__ __forceinline__ void stream_loop(const double (&x)[PPT], const double (&y)[PPT],
                                             const double (&z)[PPT], Acc (&acc)[PPT],
-                                            const double* __restrict__ rec, int s0, int s1) {
-  for (int s = s0; s < s1; ++s) {
-    const double* r = rec + (int64_t)s * KIRCHHOFF_REC_DOUBLES;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) pair_update<HAS_P, GEN_N>(x[j], y[j], z[j], r, acc[j]);
+                                            const double* __restrict__ rec,
+                                            const double2* tab, int s0, int s1) {
+  if (s0 >= s1) return;
+  constexpr bool FULL = HAS_P || GEN_N;
+  typedef SRec<FULL> R;
+  const double* p = rec + (int64_t)s0 * KIRCHHOFF_REC_DOUBLES;
+  // requests past the last record re-read the last one (never used): uniform loop.
+  // `left` counts the records not yet worked on, the current one included.
+#define KIRCHHOFF_AHEAD(q, n) ((q) + (left > (n) ? (n) : left - 1) * KIRCHHOFF_REC_DOUBLES)
+  int left = s1 - s0;
+  if (FULL) {
+    // two register sets (2 x 32 SGPRs): request s+1 mid-iteration, settle at its end
+    R A, B;
+    A.issue(p);
+    A.settle();
+    for (;;) {
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, A, nullptr, B,
+                                             KIRCHHOFF_AHEAD(p, 1));
+      B.settle();
+      if (--left == 0) break;
+      p += KIRCHHOFF_REC_DOUBLES;
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, B, nullptr, A,
+                                             KIRCHHOFF_AHEAD(p, 1));
+      A.settle();
+      if (--left == 0) break;
+      p += KIRCHHOFF_REC_DOUBLES;
+    }
+  } else {
+    // three register sets (3 x 18 SGPRs): request s+2 mid-iteration s; it is settled
+    // mid-iteration s+1, right after that iteration's LDS wait has drained it anyway
+    R A, B, C;
+    A.issue(p);
+    B.issue(KIRCHHOFF_AHEAD(p, 1));
+    A.settle();   // lgkmcnt(0): B has landed as well
+    for (;;) {
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, A, &B, C,
+                                             KIRCHHOFF_AHEAD(p, 2));
+      if (--left == 0) break;
+      p += KIRCHHOFF_REC_DOUBLES;
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, B, &C, A,
+                                             KIRCHHOFF_AHEAD(p, 2));
+      if (--left == 0) break;
+      p += KIRCHHOFF_REC_DOUBLES;
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, C, &A, B,
+                                             KIRCHHOFF_AHEAD(p, 2));
+      if (--left == 0) break;
+      p += KIRCHHOFF_REC_DOUBLES;
+    }
+    // drain the request still in flight before any of the three sets is reused
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+s"(A.lo), "+s"(A.hi), "+s"(B.lo), "+s"(B.hi), "+s"(C.lo), "+s"(C.hi));
   }
+#undef KIRCHHOFF_AHEAD
 }
 
 template <int PPT>
-__global__ __launch_bounds__(KIRCHHOFF_BLOCK) void kirchhoff_stream(
+__global__ __launch_bounds__(KIRCHHOFF_BLOCK, KIRCHHOFF_WAVES) void kirchhoff_stream(
     int64_t np, const double* __restrict__ px, const double* __restrict__ py,
     const double* __restrict__ pz, int ns, const double* __restrict__ rec,
     const unsigned* __restrict__ flags, int nsplit, int chunk, int64_t np_pad,
@@ -172,8 +343,12 @@ __global__ __launch_bounds__(KIRCHHOFF_BLOCK) void kirchhoff_stream(
   const int s0 = split * chunk;
   const int s1 = min(ns, s0 + chunk);
 
+  __shared__ double2 tab[SINCOS_TAB_N];
+  sincos_tab_fill(tab);
+
   double x[PPT], y[PPT], z[PPT];
   Acc acc[PPT];
+  double pabs = 0.;
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     int64_t p = base + (int64_t)j * KIRCHHOFF_BLOCK;
@@ -182,17 +357,27 @@ __global__ __launch_bounds__(KIRCHHOFF_BLOCK) void kirchhoff_stream(
     x[j] = px[pc];
     y[j] = py[pc];
     z[j] = pz[pc];
+    pabs = fmax(pabs, fabs(x[j]) + fabs(y[j]) + fabs(z[j]));
     acc[j] = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   }
   const unsigned f = __builtin_amdgcn_readfirstlane(*flags);   // wave-uniform dispatch
-  if (f == 0)
-    stream_loop<PPT, false, false>(x, y, z, acc, rec, s0, s1);
+  // |k r| <= kmax (|p|_1 + |s|_1): below 2^42 the table-driven sincos is exact
+  // enough (fp64_math.h); harder X-rays over longer distances take the general one
+  const unsigned long long* bound = reinterpret_cast<const unsigned long long*>(flags) + 1;
+  const double kmax = __longlong_as_double(bound[0]);
+  const double smax = __longlong_as_double(bound[1]);
+  const bool small_phase =
+      wave_max_u64(__double_as_longlong(kmax * (pabs + smax))) < __double_as_longlong(0x1p42);
+  if (!small_phase)
+    stream_loop<PPT, true, true, false>(x, y, z, acc, rec, tab, s0, s1);
+  else if (f == 0)
+    stream_loop<PPT, false, false, true>(x, y, z, acc, rec, tab, s0, s1);
   else if (f == KIRCHHOFF_FLAG_EP)
-    stream_loop<PPT, true, false>(x, y, z, acc, rec, s0, s1);
+    stream_loop<PPT, true, false, true>(x, y, z, acc, rec, tab, s0, s1);
   else if (f == KIRCHHOFF_FLAG_NXZ)
-    stream_loop<PPT, false, true>(x, y, z, acc, rec, s0, s1);
+    stream_loop<PPT, false, true, true>(x, y, z, acc, rec, tab, s0, s1);
   else
-    stream_loop<PPT, true, true>(x, y, z, acc, rec, s0, s1);
+    stream_loop<PPT, true, true, true>(x, y, z, acc, rec, tab, s0, s1);
   double* out = partial + (int64_t)split * 10 * np_pad;
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
@@ -282,6 +467,19 @@ __global__ void debug_sincos_kernel(int64_t n, const double* __restrict__ phi,
   if (i >= n) return;
   double s, c;
   sincos_phase(phi[i], s, c);
+  sn[i] = s;
+  cs[i] = c;
+}
+
+__global__ __launch_bounds__(256) void debug_sincos_tab_kernel(
+    int64_t n, const double* __restrict__ phi, double* __restrict__ sn,
+    double* __restrict__ cs) {
+  __shared__ double2 tab[SINCOS_TAB_N];
+  sincos_tab_fill(tab);
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s, c;
+  sincos_tab(phi[i], tab, s, c);
   sn[i] = s;
   cs[i] = c;
 }
@@ -383,9 +581,13 @@ hipError_t debug_divconst_launch(int64_t n, const double* a, double b, double y,
 }
 
 hipError_t debug_sincos_launch(int64_t n, const double* phi, double* sn, double* cs,
-                               hipStream_t stream) {
-  hipLaunchKernelGGL(debug_sincos_kernel, dim3((unsigned)((n + 255) / 256)),
-                     dim3(256), 0, stream, n, phi, sn, cs);
+                               int table, hipStream_t stream) {
+  if (table)
+    hipLaunchKernelGGL(debug_sincos_tab_kernel, dim3((unsigned)((n + 255) / 256)),
+                       dim3(256), 0, stream, n, phi, sn, cs);
+  else
+    hipLaunchKernelGGL(debug_sincos_kernel, dim3((unsigned)((n + 255) / 256)),
+                       dim3(256), 0, stream, n, phi, sn, cs);
   return hipGetLastError();
 }
 

@@ -104,12 +104,12 @@ def debug_sqrt(x):
     return r, ri
 
 
-def debug_sincos(phi):
+def debug_sincos(phi, table=False):
     lib = _lib.load()
     s = torch.empty_like(phi)
     c = torch.empty_like(phi)
-    _lib.check(lib.xrt_hip_debug_sincos_f64_dev(
-        phi.numel(), _f64(phi), _f64(s), _f64(c), _stream_ptr()), 'debug_sincos')
+    fn = lib.xrt_hip_debug_sincos_tab_f64_dev if table else lib.xrt_hip_debug_sincos_f64_dev
+    _lib.check(fn(phi.numel(), _f64(phi), _f64(s), _f64(c), _stream_ptr()), 'debug_sincos')
     return s, c
 
 
