@@ -32,11 +32,12 @@ namespace xrt {
 // pack: sample arrays -> 16-double records. Positions / normals are read with
 // an element stride so that both the SoA layout (stride 1) and the reference's
 // OpenCL marshalling ns x [x,y,z,0] (stride 4, waves.py:872-879) feed it.
-//   [0..2] x,y,z  [3] nl  [4] 2ny  [5] k  [6,7] Es  |  [8] 2k  [9] 2nx  [10] 2nz
-//   [11,12] Ep  [13,14] k*(Es+Ep)  [15] k*k
+//   [0..2] x,y,z  [3] 2k nl  [4] 4k ny  [5] k  [6,7] Es  |  [8] 2k^2  [9] 4k nx
+//   [10] 4k nz  [11,12] Ep  [13,14] k*(Es+Ep)  [15] 2k
 // (the first 72 bytes are all the Ep == 0, planar-normal case reads)
-// (1/r comes out of the sqrt iteration as h = 1/(2r): the factor 2 is folded
-// into 2n and 2k here, once per sample instead of once per pair.)
+// (1/r comes out of the sqrt iteration as h = 1/(2r): the factors 2 and the k of
+// (k/r)(d.n/r + nl) = h (4k n.d h + 2k nl) are folded in here, once per sample
+// instead of once per pair.)
 // The kernel also classifies the sample set so that the main kernel can take a
 // shorter instruction stream when it is safe: flags bit 0 = some Ep != 0,
 // bit 1 = some normal has an x or z component.
@@ -66,15 +67,16 @@ __global__ __launch_bounds__(256) void kirchhoff_pack(
     double2* o = reinterpret_cast<double2*>(rec + i * KIRCHHOFF_REC_DOUBLES);
     const int64_t ip = i * pstride, in = i * nstride;
     const double vx = nx[in], vy = ny[in], vz = nz[in];
+    const double k2 = 2. * kk;
     o[0] = make_double2(sx[ip], sy[ip]);
-    o[1] = make_double2(sz[ip], nl[i]);
-    o[2] = make_double2(2. * vy, kk);
+    o[1] = make_double2(sz[ip], k2 * nl[i]);
+    o[2] = make_double2(k2 * (2. * vy), kk);
     o[3] = es;
-    o[4] = make_double2(2. * kk, 2. * vx);
-    o[5] = make_double2(2. * vz, ep.x);
+    o[4] = make_double2(k2 * kk, k2 * (2. * vx));
+    o[5] = make_double2(k2 * (2. * vz), ep.x);
     // numpy: k**2/(4pi) * (Es+Ep) * U / r ; the sum Es+Ep is formed first there too
     o[6] = make_double2(ep.y, kk * (es.x + ep.x));
-    o[7] = make_double2(kk * (es.y + ep.y), kk * kk);
+    o[7] = make_double2(kk * (es.y + ep.y), k2);
     if (ep.x != 0. || ep.y != 0.) f |= KIRCHHOFF_FLAG_EP;
     if (vx != 0. || vz != 0.) f |= KIRCHHOFF_FLAG_NXZ;
     // ingredients of the bound |k r| <= kmax (|p|_1 + |s|_1) the main kernel checks
@@ -110,35 +112,34 @@ struct Acc {
 // loop can put its scalar prefetch between them (see stream_loop): pair_head ends
 // with the first use of the LDS table entry, pair_tail is pure accumulation.
 struct Mid {
-  double dx, dy, dz, gr, gi, kip;
+  double dx, dy, dz, gr, gi, h;
 };
 
 template <bool GEN_N, bool TAB>
 __device__ __forceinline__ Mid pair_head(double px, double py, double pz,
                                          const double (&r)[KIRCHHOFF_REC_DOUBLES],
                                          const double2* tab) {
-  const double sx = r[0], sy = r[1], sz = r[2], nl = r[3];
-  const double n2y = r[4], k = r[5], k2 = r[8], n2x = r[9], n2z = r[10];
+  const double sx = r[0], sy = r[1], sz = r[2], knl = r[3];
+  const double kny = r[4], k = r[5], knx = r[9], knz = r[10];
   Mid m;
   // --- bit-exact part (numpy order, no contraction) ---
   m.dx = px - sx;
   m.dy = py - sy;
   m.dz = pz - sz;
   const double s2 = (m.dx * m.dx + m.dy * m.dy) + m.dz * m.dz;
-  double h;  // 1/(2r)
-  const double rr = sqrt_rn_halfinv(s2, h);
+  // h = 1/(2r)
+  const double rr = sqrt_rn_halfinv(s2, m.h);
   const double phase = k * rr;
   // --- the rest only needs ~1e-16 relative accuracy ---
-  double dn2;
+  double dn;
   if (GEN_N) {
-    dn2 = m.dx * n2x;
-    dn2 = fma_(m.dy, n2y, dn2);
-    dn2 = fma_(m.dz, n2z, dn2);
+    dn = m.dx * knx;
+    dn = fma_(m.dy, kny, dn);
+    dn = fma_(m.dz, knz, dn);
   } else {
-    dn2 = m.dy * n2y;
+    dn = m.dy * kny;
   }
-  m.kip = k2 * h;                                 // k/r
-  const double cr = m.kip * fma_(dn2, h, nl);     // (k/r)(d.n/r + nl)
+  const double cr = m.h * fma_(dn, m.h, knl);     // (k/r)(d.n/r + nl)
   double sn, cs;
   if (TAB)
     sincos_tab(phase, tab, sn, cs);
@@ -152,8 +153,8 @@ __device__ __forceinline__ Mid pair_head(double px, double py, double pz,
 template <bool HAS_P>
 __device__ __forceinline__ void pair_tail(const Mid& m,
                                           const double (&r)[KIRCHHOFF_REC_DOUBLES], Acc& a) {
-  const double k = r[5], esr = r[6], esi = r[7];
-  const double epr = r[11], epi = r[12], qr = r[13], qi = r[14];
+  const double esr = r[6], esi = r[7], k2k = r[8];
+  const double epr = r[11], epi = r[12], qr = r[13], qi = r[14], k2 = r[15];
   const double gr = m.gr, gi = m.gi;
   double hr, hi;
   if (HAS_P) {
@@ -165,8 +166,9 @@ __device__ __forceinline__ void pair_tail(const Mid& m,
     a.pr = fma_(-gi, epi, a.pr);
     a.pi = fma_(gr, epi, a.pi);
     a.pi = fma_(gi, epr, a.pi);
-    const double hr0 = m.kip * gr;
-    const double hi0 = m.kip * gi;
+    const double kip = k2 * m.h;                  // k/r
+    const double hr0 = kip * gr;
+    const double hi0 = kip * gi;
     hr = hr0 * qr;
     hr = fma_(-hi0, qi, hr);
     hi = hr0 * qi;
@@ -179,7 +181,7 @@ __device__ __forceinline__ void pair_tail(const Mid& m,
     wi = fma_(gi, esr, wi);
     a.sr += wr;
     a.si += wi;
-    const double kkip = m.kip * k;
+    const double kkip = k2k * m.h;                // k^2/r
     hr = kkip * wr;
     hi = kkip * wi;
   }
