@@ -706,6 +706,15 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir_y(
   double t1m[2] = {INFINITY, INFINITY}, t2m[2] = {-INFINITY, -INFINITY};
   double d1m[2] = {0., 0.}, d2m[2] = {0., 0.};
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // Which of the two formulas applies is the sign of the FIRST entering ray's b. If
+  // ray 0 enters it is that ray, and only its variant is worth evaluating.
+  int only = -1;
+  if (in.n > 0 && entering(P, in.state[0])) {
+    double a0 = in.a[0], b0 = in.b[0], c0 = in.c[0];
+    local_dir(P, a0, b0, c0);
+    only = b0 > 0. ? 0 : 1;
+  }
+  only = __builtin_amdgcn_readfirstlane(only);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
     const int st = in.state[i];
     const double E = in.E[i];
@@ -723,6 +732,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir_y(
     }
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
+      if (only >= 0 && only != v) continue;   // wave-uniform
       double t1, t2, x, y, z;
       bracket(P, 1, v == 0 ? 1 : 0, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
       const double dz1 = find_dz<K>(P, t1, r.x, r.y, r.z, r.a, r.b, r.c, x, y, z);
