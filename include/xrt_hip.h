@@ -237,14 +237,21 @@ XRT_HIP_API int xrt_hip_sizeof(int which);
  * restore: beam whose x..E,J are copied into out_virgin for rays that did not
  * end in state {1,2} (reflect.py:131-134; dcm.py:330-335 passes the ORIGINAL
  * beam here on the 2nd crystal); usually == in. theta (optional): lb.theta[n]
- * (reflect.py:793-796). info_host (optional, 16 doubles, forces a sync):
+ * (reflect.py:793-796). By default the pass first runs on the batch-global decisions
+ * a beam along the beamline always produces (axis y, ray 0's sign, secant, clamp
+ * inactive), every ray verifying them, and repeats itself through the exact
+ * statistics only if one was contradicted -- same bits either way; a request for
+ * info_host, outputs that alias the inputs, or XRT_HIP_REFLECT_EXACT=1 in the
+ * environment take the exact sequence directly.
+ * info_host (optional, 16 doubles, forces a sync):
  * [0] bracketing axis, [1] first-ray sign, [2] brent?, [3] t1.min, [4] t2.max,
  * [5] max|dz1|, [6] max|dz2|, [7] entering rays, [8] rays ending in state 1 and
  * [9] sum(beamInDotNormal over them) -- crystals only, and only when the batch
  * had both signs of beamInDotNormal (the exact two-pass redo ran), [10]/[11] the
  * batch held negative / non-negative beamInDotNormal (crystals). kernel_ms
- * (optional, 2 floats, forces a sync): [0] whole pass, [1] the dominant kernel
- * (fused solve+finish), HIP events on `stream`. Asynchronous on
+ * (optional, 3 floats, forces a sync): [0] whole pass, [1] the dominant kernel
+ * (fused solve+finish), HIP events on `stream`; [2] 1 if the exact sequence did
+ * the work (forced, or the single pass was contradicted), else 0. Asynchronous on
  * `stream` otherwise. */
 XRT_HIP_API int xrt_hip_reflect_pass_f64_dev(
     const xrt_hip_pass* pass, const xrt_hip_material* material,

@@ -269,3 +269,96 @@ def test_crystal_batch_sign_optimistic_pass_and_redo(alpha_deg, expect_mixed):
         for f in ('Jss', 'Jpp', 'Jsp'):
             assert np.abs(getattr(mine, f) - getattr(ref, f)).max() <= 1e-9 * scale, \
                 (tag, f)
+
+
+# ---- the optimistic single pass against the exact sequence -----------------------
+def _beam_for(rng, n, spread_c=2e-5, y0=0.):
+    beam = rs.Beam(nrays=n, withAmplitudes=True)
+    beam.x[:] = rng.normal(0, 0.1, n)
+    beam.z[:] = rng.normal(0, 0.1, n)
+    beam.y[:] = y0
+    beam.a[:] = rng.normal(0, 2e-4, n)
+    beam.c[:] = rng.normal(0, spread_c, n)
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.E[:] = rng.uniform(8990., 9010., n)
+    beam.state[:] = 1
+    return beam
+
+
+def _same_bits(b1, b2):
+    for f in ('state', 'x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp',
+              'Es', 'Ep'):
+        if f in ('Es', 'Ep') and not hasattr(b1, 'Es'):
+            continue
+        v1, v2 = getattr(b1, f), getattr(b2, f)
+        assert np.array_equal(v1, v2, equal_nan=True), f
+
+
+def _toroid(bl):
+    p, q, th = 20000., 10000., 4e-3
+    return roe.ToroidMirror(bl, 'tm', center=[0, p, 0], pitch=th,
+                            R=2*p*q/((p+q)*np.sin(th)), r=2*p*q*np.sin(th)/(p+q),
+                            limPhysX=[-10, 10], limPhysY=[-300, 300],
+                            material=rm.Material('Pt', rho=21.45))
+
+
+@pytest.mark.parametrize('case', ['plain', 'ray0_lost', 'sideways', 'backwards_first',
+                                  'steep'])
+def test_single_pass_equals_exact_sequence(case, monkeypatch):
+    """reflect first runs on the batch-global decisions every ordinary beam produces and
+    falls back to the exact statistics when a ray contradicts them. Whatever the
+    route, the bits are those of the exact sequence (XRT_HIP_REFLECT_EXACT=1)."""
+    rng = np.random.default_rng(5)
+    bl = raycing.BeamLine()
+    oe = _toroid(bl)
+    beam = _beam_for(rng, 5000)
+    expect_exact = True
+    if case == 'plain':
+        expect_exact = False
+    elif case == 'ray0_lost':            # the first entering ray is not ray 0
+        beam.state[0] = -1
+        beam.b[1] *= -1                   # ... and it flies backwards
+    elif case == 'sideways':             # one state-1 ray whose largest cosine is a
+        beam.a[7], beam.b[7], beam.c[7] = 0.8, 0.6, 0.
+    elif case == 'backwards_first':      # ray 0 picks the other bracket formula: still one pass
+        beam.b[0] *= -1
+        expect_exact = False
+    elif case == 'steep':                # bracket-end |dz| ratios that ask for Brent
+        beam.c[:] = rng.normal(0, 3e-2, len(beam.c))
+        beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+        expect_exact = None
+    t = {}
+    g1, l1 = oe.reflect(rs.Beam(copyFrom=beam), _timing=t)
+    if expect_exact is not None:
+        assert t['exact_sequence'] == expect_exact
+    monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
+    t2 = {}
+    g2, l2 = oe.reflect(rs.Beam(copyFrom=beam), _timing=t2)
+    assert t2['exact_sequence']
+    _same_bits(g1, g2)
+    _same_bits(l1, l2)
+    info = {}
+    g3, l3 = oe.reflect(rs.Beam(copyFrom=beam), _info=info)    # statistics -> exact as well
+    _same_bits(g1, g3)
+    if case == 'steep':
+        print('steep: brent', info['brent'], 'single pass kept', not t['exact_sequence'])
+
+
+def test_single_pass_equals_exact_sequence_over_random_elements(monkeypatch):
+    n_single = n_searching = 0
+    for k, kind in enumerate(KINDS * 3):
+        rng = np.random.default_rng(7000 + k)
+        oe, pitch = make_element(kind, rng)
+        beam = aimed_beam(oe, pitch, rng)
+        monkeypatch.delenv('XRT_HIP_REFLECT_EXACT', raising=False)
+        t = {}
+        g1, l1 = oe.reflect(rs.Beam(copyFrom=beam), _timing=t)
+        if kind != 'blazed':                 # (closed-form intersection: nothing assumed)
+            n_searching += 1
+            n_single += not t['exact_sequence']
+        monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
+        g2, l2 = oe.reflect(rs.Beam(copyFrom=beam))
+        _same_bits(g1, g2)
+        _same_bits(l1, l2)
+    print('single pass kept for %d of %d' % (n_single, n_searching))
+    assert n_single >= n_searching // 2     # the single pass is the rule, not the exception

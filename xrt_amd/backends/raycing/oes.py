@@ -340,7 +340,7 @@ class OE(object):
         wsb = lib.xrt_hip_reflect_workspace_bytes(n)
         ws = hipcalls.workspace(dev, wsb, 'reflect')
         info = (ctypes.c_double * 16)() if want_info else None
-        ms_out = (ctypes.c_float * 2)() if timing else None
+        ms_out = (ctypes.c_float * 3)() if timing else None
         rc = lib.xrt_hip_reflect_pass_f64_dev(
             ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in),
             ctypes.byref(s_re), ctypes.byref(s_lb), ctypes.byref(s_vb),
@@ -367,6 +367,7 @@ class OE(object):
             res_info = res_info or {}
             res_info['pass_ms'] = ms_out[0]
             res_info['kernel_ms'] = ms_out[1]
+            res_info['exact_sequence'] = bool(ms_out[2])
         return lb, vb, res_info
 
     # -- local -> global for a beam on the surface (oes/base.py:1165-1229) ------
@@ -554,9 +555,12 @@ class OE(object):
 
     # -- OE.reflect, oes/reflect.py:18-163 ----------------------------------
     def reflect(self, beam=None, needLocal=True, noIntersectionSearch=False,
-                returnLocalAbsorbed=None, _info=None, out=None):
+                returnLocalAbsorbed=None, _info=None, out=None, _timing=None):
         """-> (beamGlobal, beamLocal). *out* (extension): the pair returned by an
-        earlier call, to be overwritten in place (no new HBM allocations)."""
+        earlier call, to be overwritten in place (no new HBM allocations).
+        *_info* (dict) receives the batch statistics (this takes the exact kernel
+        sequence); *_timing* (dict) the pass / kernel milliseconds and whether the
+        exact sequence had to run."""
         pitch = self.pitch
         if hasattr(self, 'bragg'):
             pitch = pitch + self.bragg
@@ -566,9 +570,12 @@ class OE(object):
             only_state1_out=hasattr(beam, 'createdByDiffract'))
         lb, gb, info = self._run_pass(
             p, self.material, True, beam, beam, want_info=_info is not None,
-            out=None if out is None else (out[1], out[0]))
+            timing=_timing is not None, out=None if out is None else (out[1], out[0]))
         if _info is not None:
-            _info.update(info)
+            _info.update({k: v for k, v in info.items() if k not in
+                          ('pass_ms', 'kernel_ms', 'exact_sequence')})
+        if _timing is not None:
+            _timing.update({k: info[k] for k in ('pass_ms', 'kernel_ms', 'exact_sequence')})
         return gb, lb
 
 

@@ -25,6 +25,8 @@ struct GStat {
   int axis, positive;                // bracketing axis; sign of the first ray's component
   double t1min, t2max, maxdz1, maxdz2;
   int bracket_valid;                 // the bracket statistics above are already final
+  int optimistic;                    // the single-pass geometry assumptions were set up
+  int redo;                          // 1: the exact statistics + fused sequence must run
   int any_neg, any_pos;              // optimistic crystal pass saw beamInDotNormal <0 / >=0;
                                      // both set -> mixed batch, the exact two passes redo it
   unsigned long long n_good1;        // rays that ended in state 1
@@ -35,13 +37,28 @@ struct GStat {
                                      // binary search of every ray stays inside
 };
 
+// What the optimistic fused pass reports back. Same-address atomics from 150 000
+// waves serialise at the memory side (3 ms for 1e7 rays, measured), so the reports
+// are spread over REFLECT_OPT_SLOTS cache lines (slot = block % slots; fire-and-forget
+// unsigned max on the bit patterns of non-negative doubles) and a one-block kernel
+// folds the slots. They live at the head of the partial-record area, which is idle
+// while the fused kernel runs.
+#define REFLECT_OPT_SLOTS 256
+struct OptStat {
+  unsigned long long maxdz1, maxdz2;   // max |dz| at the bracket ends (bit patterns)
+  int viol;                            // a ray contradicted an assumption
+  int pad[27];
+};
+static_assert(sizeof(OptStat) == 128, "one slot per 128-byte line");
+
 size_t reflect_workspace_bytes(int64_t n);
 
 hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                const xrt_hip_beam& in, const xrt_hip_beam& restore,
                                const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
                                void* workspace, hipStream_t st, hipEvent_t ev0,
-                               hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1);
+                               hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1,
+                               bool force_exact);
 
 hipError_t material_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
                                      const double* bdn, double* rs, double* rp, double* mu,

@@ -22,6 +22,7 @@
 // state follows numpy's operation order with no FMA contraction
 // (-ffp-contract=off), IEEE division and correctly rounded sqrt.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include <stdint.h>
 
@@ -446,7 +447,9 @@ __device__ __forceinline__ void atomic_max_double(double* p, double v) {
 // ---------------------------------------------------------------------------
 // K0 / K1 / decide / K2
 // ---------------------------------------------------------------------------
-__global__ void reflect_init(GStat* g) {
+__global__ void reflect_init(GStat* g, int redo) {
+  g->optimistic = 0;
+  g->redo = redo;
   g->maxa = 0.;
   g->maxb = 0.;
   g->maxc = 0.;
@@ -527,6 +530,31 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass 
   }
 }
 
+// f1/f2 table window of a batch: upper_bound(E table, emin / emax) per element
+__device__ __forceinline__ void table_windows(const xrt_hip_material& M, double emin,
+                                              double emax, GStat* g) {
+  g->emin = emin;
+  g->emax = emax;
+  if (M.kind != XRT_HIP_MAT_NONE && emin <= emax) {
+    for (int e = 0; e < M.nelem; ++e) {
+      const double* tE = M.tab_E[e];
+      const int n = M.tab_n[e];
+      int lo = 0, hi = n;
+      while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (emin >= tE[mid]) lo = mid + 1; else hi = mid;
+      }
+      g->tab_lo[e] = lo;
+      hi = n;
+      while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (emax >= tE[mid]) lo = mid + 1; else hi = mid;
+      }
+      g->tab_hi[e] = lo;
+    }
+  }
+}
+
 // stride = doubles per partial record: 8 (reflect_stats_dir) or 16
 // (reflect_stats_dir_y, which also carries the bracket statistics of the y axis
 // for both signs: [8..11] positive, [12..15] negative)
@@ -535,6 +563,9 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
     int nblocks, int stride, GStat* g) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
+  if (!g->redo) return;   // the optimistic single pass stands
+  g->any_neg = 0;         // (a crystal's sign flags are re-raised by the exact pass)
+  g->any_pos = 0;
   double ma = 0., mb = 0., mc = 0., nent = 0., nmain = 0., emin = INFINITY, emax = -INFINITY;
   unsigned long long first = ~0ull;
   double yb[8] = {INFINITY, -INFINITY, 0., 0., INFINITY, -INFINITY, 0., 0.};
@@ -586,27 +617,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
   g->n_enter = (unsigned long long)nent;
   g->n_main = (unsigned long long)nmain;
   if (nent == 0.) return;
-  // f1/f2 table window of this batch: upper_bound(E table, emin / emax)
-  g->emin = emin;
-  g->emax = emax;
-  if (M.kind != XRT_HIP_MAT_NONE && emin <= emax) {
-    for (int e = 0; e < M.nelem; ++e) {
-      const double* tE = M.tab_E[e];
-      const int n = M.tab_n[e];
-      int lo = 0, hi = n;
-      while (lo < hi) {
-        const int mid = lo + ((hi - lo) >> 1);
-        if (emin >= tE[mid]) lo = mid + 1; else hi = mid;
-      }
-      g->tab_lo[e] = lo;
-      hi = n;
-      while (lo < hi) {
-        const int mid = lo + ((hi - lo) >> 1);
-        if (emax >= tE[mid]) lo = mid + 1; else hi = mid;
-      }
-      g->tab_hi[e] = lo;
-    }
-  }
+  table_windows(M, emin, emax, g);
   double maxa = ma, maxb = mb, maxc = mc;
   if (nmain == 0.) {  // np.max of an empty selection -> (0, 1, 0), base.py:1261-1262
     maxa = 0.;
@@ -635,6 +646,129 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
   }
 }
 
+// ---------------------------------------------------------------------------
+// The optimistic single pass. The reference takes four decisions from the whole
+// batch before it moves a single ray: the bracketing axis (largest direction
+// cosine), which of two bracket formulas (sign of the FIRST ray's component), the
+// clamp range of the iterates ([min t1, max t2]) and secant-or-Brent (max |dz| at
+// the bracket ends). For a beam that travels along the beamline they come out the
+// same every time: axis y, the sign of ray 0, a clamp that never bites (a
+// bracket-keeping secant iterate stays inside its own bracket, which lies inside
+// the global range) and secant. So the fused kernel is first run ON those
+// assumptions, after a light pass over (state, E) only -- the energy range keeps
+// the f1/f2 binary searches short -- and every ray checks them for itself:
+//   * a state-1 ray with |b| <= |a| or |b| <= |c| (axis might not be y),
+//   * an iterate outside its own bracket (the clamp might have acted),
+//   * ray 0 not entering (the first entering ray is somebody else),
+// raise `viol`; the bracket-end |dz| maxima are collected on the way. A one-thread
+// kernel then decides: if anything was contradicted, or the maxima ask for Brent,
+// `redo` goes up and the exact sequence (statistics, decisions, fused kernel again)
+// that follows in the stream does the pass properly; otherwise those kernels return
+// at once. Results are bit-identical to the exact sequence either way.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_light_stats(
+    xrt_hip_pass P, xrt_hip_beam in, double* __restrict__ part) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  double emin = INFINITY, emax = -INFINITY, nent = 0.;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x * 2 + threadIdx.x; i < in.n; i += stride) {
+    const int64_t j = i + blockDim.x;
+    const bool two = j < in.n;
+    const int st0 = in.state[i];
+    const double E0 = in.E[i];
+    const int st1 = two ? in.state[j] : 0;
+    const double E1 = two ? in.E[j] : 0.;
+    if (entering(P, st0)) {
+      nent += 1.;
+      emin = E0 < emin ? E0 : emin;
+      emax = E0 > emax ? E0 : emax;
+    }
+    if (two && entering(P, st1)) {
+      nent += 1.;
+      emin = E1 < emin ? E1 : emin;
+      emax = E1 > emax ? E1 : emax;
+    }
+  }
+  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
+  auto fmind = [](double u, double v) { return u < v ? u : v; };
+  auto faddd = [](double u, double v) { return u + v; };
+  emin = block_reduce(emin, fmind, lds_d);
+  emax = block_reduce(emax, fmaxd, lds_d);
+  nent = block_reduce(nent, faddd, lds_d);
+  if (threadIdx.x == 0) {
+    double* o = part + (int64_t)blockIdx.x * 4;
+    o[0] = emin;
+    o[1] = emax;
+    o[2] = nent;
+  }
+}
+
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, double* part, int nblocks, GStat* g) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  double emin = INFINITY, emax = -INFINITY, nent = 0.;
+  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+    const double* o = part + (int64_t)b * 4;
+    emin = o[0] < emin ? o[0] : emin;
+    emax = o[1] > emax ? o[1] : emax;
+    nent += o[2];
+  }
+  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
+  auto fmind = [](double u, double v) { return u < v ? u : v; };
+  auto faddd = [](double u, double v) { return u + v; };
+  emin = block_reduce(emin, fmind, lds_d);
+  emax = block_reduce(emax, fmaxd, lds_d);
+  nent = block_reduce(nent, faddd, lds_d);
+  // the partial records are folded: their area now holds the report slots
+  OptStat* slots = reinterpret_cast<OptStat*>(part);
+  for (int k = threadIdx.x; k < REFLECT_OPT_SLOTS; k += blockDim.x) {
+    slots[k].maxdz1 = 0;
+    slots[k].maxdz2 = 0;
+    slots[k].viol = 0;
+  }
+  if (threadIdx.x != 0) return;
+  g->n_enter = (unsigned long long)nent;
+  if (nent == 0. || !entering(P, in.state[0])) {
+    g->redo = 1;    // nothing assumed: the exact sequence handles it (and empty batches)
+    return;
+  }
+  table_windows(M, emin, emax, g);
+  double a0 = in.a[0], b0 = in.b[0], c0 = in.c[0];
+  local_dir(P, a0, b0, c0);
+  g->first_good = 0;
+  g->axis = 1;
+  g->positive = b0 > 0. ? 1 : 0;
+  g->t1min = -INFINITY;    // no clamp: escapes are reported instead
+  g->t2max = INFINITY;
+  g->maxdz1 = 1.;          // secant
+  g->maxdz2 = 0.;
+  g->optimistic = 1;
+}
+
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_check_opt(GStat* g,
+                                                                   const OptStat* slots) {
+  __shared__ double lds_d[REFLECT_BLOCK / 64];
+  if (!g->optimistic) return;     // redo is up already
+  double m1 = 0., m2 = 0., viol = 0.;
+  for (int k = threadIdx.x; k < REFLECT_OPT_SLOTS; k += blockDim.x) {
+    m1 = fmax(m1, __longlong_as_double((long long)slots[k].maxdz1));
+    m2 = fmax(m2, __longlong_as_double((long long)slots[k].maxdz2));
+    viol = fmax(viol, (double)slots[k].viol);
+  }
+  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
+  m1 = block_reduce(m1, fmaxd, lds_d);
+  m2 = block_reduce(m2, fmaxd, lds_d);
+  viol = block_reduce(viol, fmaxd, lds_d);
+  if (threadIdx.x != 0) return;
+  const bool brent = m2 > m1 * 20.;
+  if (viol != 0. || brent) {
+    g->redo = 1;
+    return;
+  }
+  g->maxdz1 = m1;                 // (diagnostics; the clamp range stays open)
+  g->maxdz2 = m2;
+}
+
 struct LocalRay {
   double x, y, z, a, b, c;
 };
@@ -657,7 +791,7 @@ template <class K>
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
     xrt_hip_pass P, xrt_hip_beam in, const GStat* __restrict__ g, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
-  if (g->bracket_valid) return;  // decided from the first pass (wave-uniform)
+  if (!g->redo || g->bracket_valid) return;  // nothing to redo / decided from the first pass
   double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
   const int axis = g->axis, positive = g->positive;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -698,9 +832,10 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
 // bracket_valid set and returns at once. One pass over the beam saved.
 template <class K>
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir_y(
-    xrt_hip_pass P, xrt_hip_beam in, double* __restrict__ part) {
+    xrt_hip_pass P, xrt_hip_beam in, const GStat* __restrict__ g, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
+  if (!g->redo) return;   // the optimistic single pass stands
   double ma = 0., mb = 0., mc = 0., emin = INFINITY, emax = -INFINITY;
   unsigned long long first = ~0ull, nent = 0, nmain = 0;
   double t1m[2] = {INFINITY, INFINITY}, t2m[2] = {-INFINITY, -INFINITY};
@@ -784,7 +919,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir_y(
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bracket(
     const double* __restrict__ part, int nblocks, GStat* g) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
-  if (g->bracket_valid) return;
+  if (!g->redo || g->bracket_valid) return;
   double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     const double* o = part + (int64_t)b * 8;
@@ -851,9 +986,15 @@ __device__ __forceinline__ void hit_done(const xrt_hip_pass& P, Hit& h) {
   }
 }
 
-template <class K>
+// what a ray of the optimistic pass reports (see reflect_light_stats)
+struct SolveAux {
+  double adz1 = 0., adz2 = 0.;   // |dz| at the bracket ends, as find_intersection maximises them
+  int escaped = 0;               // an iterate left the ray's own bracket
+};
+
+template <class K, bool OPT = false>
 __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
-                                         const LocalRay& r) {
+                                         const LocalRay& r, SolveAux* aux = nullptr) {
   Hit h;
   if (PNIS(P)) {  // reflect.py:676-682
     h.t = 0.;
@@ -896,6 +1037,11 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
   double dz2 = find_dz<K>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
   const bool ind1 = dz1 <= 0.;
   const bool ind2 = dz2 >= 0.;
+  if (OPT) {
+    aux->adz1 = fabs(dz1);
+    aux->adz2 = (ind1 || ind2) ? 0. : fabs(dz2);   // base.py:863-865
+  }
+  const double t1own = t1, t2own = t2;
   h.lost = ind1 ? 1 : 0;
   if (ind1) {
     h.t = t1;
@@ -925,6 +1071,7 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
       t1 = t2;
       dz1 = dz2;
       t2 = t - (t1 - t) * dz / (dz1 - dz);
+      if (OPT) aux->escaped |= (t2 < t1own) || (t2 > t2own);
       if (t2 < tMinG) t2 = tMinG;
       if (t2 > tMaxG) t2 = tMaxG;
       dz2 = find_dz<K>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
@@ -1693,24 +1840,65 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
 // ---------------------------------------------------------------------------
 // K3 kernels
 // ---------------------------------------------------------------------------
-template <class K>
+// mode: 0 = optimistic single pass (runs if g.optimistic; reports to OptStat),
+//       1 = the exact redo (runs if g.redo), 2 = unconditional (no statistics needed)
+__device__ __forceinline__ bool fused_skips(const GStat* gp, int mode) {
+  return (mode == 0 && !gp->optimistic) || (mode == 1 && !gp->redo);
+}
+
+// wave-level fold of the optimistic pass's reports into this block's slot
+__device__ __forceinline__ void report_opt(OptStat* slots, const SolveAux& aux, int viol) {
+  double m1 = aux.adz1, m2 = aux.adz2;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m1 = fmax(m1, __shfl_xor(m1, off));
+    m2 = fmax(m2, __shfl_xor(m2, off));
+  }
+  const bool any = __any(viol | aux.escaped);
+  if ((threadIdx.x & 63) == 0) {
+    OptStat* o = slots + (blockIdx.x % REFLECT_OPT_SLOTS);
+    // results unused: no-return atomics, the wave does not wait for them
+    if (m1 > 0.) (void)atomicMax(&o->maxdz1, (unsigned long long)__double_as_longlong(m1));
+    if (m2 > 0.) (void)atomicMax(&o->maxdz2, (unsigned long long)__double_as_longlong(m2));
+    if (any) o->viol = 1;
+  }
+}
+
+template <class K, int mode>
 __global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
-    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* gp) {
+    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
+    OptStat* __restrict__ opt) {
+  if (fused_skips(gp, mode)) return;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= in.n) return;
   const bool has_amp = in.Es_ri != nullptr;
-  const int st0 = in.state[i];
-  if (!entering(P, st0)) {
-    pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
-    return;
-  }
+  const int st0 = i < in.n ? in.state[i] : 0;
+  const bool active = i < in.n && entering(P, st0);
+  if (i < in.n && !active) pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
   const GStat g = *gp;
-  const LocalRay r = load_local(P, in, i);
-  const Hit h = solve_ray<K>(P, g, r);
-  int st = rays_good(P, h.x, h.y);
-  if (h.lost) st = P.lost_num;
-  complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
+  LocalRay r;
+  Hit h;
+  if (mode == 0) {
+    // solve, then report while the wave is convergent and before the amplitude code
+    // needs the registers
+    SolveAux aux;
+    int viol = 0;
+    if (active) {
+      r = load_local(P, in, i);
+      h = solve_ray<K, true>(P, g, r, &aux);
+      // the axis is y only if max|b| beats max|a| and max|c| over the state-1 rays
+      viol = st0 == 1 && !(fabs(r.b) > fabs(r.a) && fabs(r.b) > fabs(r.c));
+    }
+    report_opt(opt, aux, viol);
+  } else if (active) {
+    r = load_local(P, in, i);
+    h = solve_ray<K>(P, g, r);
+  }
+  if (active) {
+    int st = rays_good(P, h.x, h.y);
+    if (h.lost) st = P.lost_num;
+    complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1721,29 +1909,41 @@ __global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
 // assumes so, and raises GStat::any_neg / any_pos for the sides it saw. The exact
 // two-pass sequence that follows in the stream returns at once unless both are up.
 // ---------------------------------------------------------------------------
-template <class K>
+template <class K, int mode>
 __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_xtal(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
-    int* __restrict__ any_neg_pos) {
+    int* __restrict__ any_neg_pos, OptStat* __restrict__ opt) {
+  if (fused_skips(gp, mode)) return;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int neg = 0, pos = 0;
-  if (i < in.n) {
-    const bool has_amp = in.Es_ri != nullptr;
-    const int st0 = in.state[i];
-    if (!entering(P, st0)) {
-      pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
-    } else {
-      const GStat g = *gp;
-      const LocalRay r = load_local(P, in, i);
-      const Hit h = solve_ray<K>(P, g, r);
-      int st = rays_good(P, h.x, h.y);
-      if (h.lost) st = P.lost_num;
-      double bdn = 0.;
-      complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 1, &bdn);
-      neg = st == 1 && bdn < 0.;
-      pos = st == 1 && !(bdn < 0.);
+  const bool has_amp = in.Es_ri != nullptr;
+  const int st0 = i < in.n ? in.state[i] : 0;
+  const bool active = i < in.n && entering(P, st0);
+  if (i < in.n && !active) pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
+  const GStat g = *gp;
+  LocalRay r;
+  Hit h;
+  if (mode == 0) {
+    SolveAux aux;
+    int viol = 0;
+    if (active) {
+      r = load_local(P, in, i);
+      h = solve_ray<K, true>(P, g, r, &aux);
+      viol = st0 == 1 && !(fabs(r.b) > fabs(r.a) && fabs(r.b) > fabs(r.c));
     }
+    report_opt(opt, aux, viol);
+  } else if (active) {
+    r = load_local(P, in, i);
+    h = solve_ray<K>(P, g, r);
+  }
+  if (active) {
+    int st = rays_good(P, h.x, h.y);
+    if (h.lost) st = P.lost_num;
+    double bdn = 0.;
+    complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 1, &bdn);
+    neg = st == 1 && bdn < 0.;
+    pos = st == 1 && !(bdn < 0.);
   }
   // same-value racing stores; any_neg/any_pos are read only by the kernels that follow
   neg = __syncthreads_or(neg);
@@ -1905,16 +2105,24 @@ size_t reflect_workspace_bytes(int64_t n) {
   return 256 + REFLECT_PART_BYTES + 4 * a + s;
 }
 
+static bool beams_overlap(const xrt_hip_beam& a, const xrt_hip_beam& b) {
+  return a.x == b.x || a.a == b.a || a.state == b.state || a.Jss == b.Jss || a.E == b.E;
+}
+
 hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                const xrt_hip_beam& in, const xrt_hip_beam& restore,
                                const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
                                void* workspace, hipStream_t st, hipEvent_t ev0,
-                               hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1) {
+                               hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1,
+                               bool force_exact) {
+  static_assert(sizeof(GStat) <= 256, "workspace head slot");
+  static_assert(REFLECT_OPT_SLOTS * sizeof(OptStat) <= REFLECT_PART_BYTES, "report slots");
   GStat* g = reinterpret_cast<GStat*>(workspace);
   const int64_t n = in.n;
   if (n <= 0) return hipSuccess;
   const size_t a = ((size_t)n * 8 + 255) / 256 * 256;
   double* part = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 256);
+  OptStat* opt = reinterpret_cast<OptStat*>(part);
   char* base = reinterpret_cast<char*>(workspace) + 256 + REFLECT_PART_BYTES;
   double* ht = reinterpret_cast<double*>(base);
   double* hx = reinterpret_cast<double*>(base + a);
@@ -1922,8 +2130,53 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   double* hz = reinterpret_cast<double*>(base + 3 * a);
   int32_t* hst = reinterpret_cast<int32_t*>(base + 4 * a);
   const dim3 grid((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)), block(REFLECT_BLOCK);
+  // The optimistic single pass (see reflect_light_stats) needs the input intact for a
+  // possible redo, and surfaces that bracket at all.
+  const bool searches = !P.no_intersection_search && P.surf_kind != XRT_HIP_SURF_BLAZED;
+  const bool optimistic = searches && !force_exact && !beams_overlap(in, lb) &&
+                          !beams_overlap(in, vb) && !beams_overlap(restore, lb) &&
+                          !beams_overlap(restore, vb);
+  const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
+  using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
+  using AnyXtal = Spec<0, -1, XRT_HIP_MAT_CRYSTAL, false>;
+  using ToroidMirror = Spec<0, XRT_HIP_SURF_TOROID, XRT_HIP_MAT_MIRROR, true>;
+  using FlatMirror = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_MIRROR, true>;
+  using BentMirror = Spec<0, XRT_HIP_SURF_BENTFLAT, XRT_HIP_MAT_MIRROR, true>;
+  // the solve + finish kernel of this (surface, material) in the given mode
+  auto launch_fused = [&](auto mode_tag) {
+    constexpr int mode = decltype(mode_tag)::value;
+    if (need_mean) {
+      // Bragg-reflecting crystals sit on flat surfaces in practice (DCM): that case is
+      // compiled with the kinds fixed. Each ray takes its own sign of beamInDotNormal
+      // and raises any_neg / any_pos (see reflect_fused_xtal).
+      if (flat_xtal)
+        hipLaunchKernelGGL((reflect_fused_xtal<FlatXtal, mode>), grid, block, 0, st, P, M, in,
+                           restore, lb, vb, theta, g, &g->any_neg, opt);
+      else
+        hipLaunchKernelGGL((reflect_fused_xtal<AnyXtal, mode>), grid, block, 0, st, P, M, in,
+                           restore, lb, vb, theta, g, &g->any_neg, opt);
+      return;
+    }
+#define XRT_FUSED(SPEC)                                                                    \
+  hipLaunchKernelGGL((reflect_fused<SPEC, mode>), grid, block, 0, st, P, M, in, restore, lb, \
+                     vb, theta, g, opt)
+    const bool plain = !P.grating && !P.asymmetric && !P.no_intersection_search;
+    if (P.surf_kind >= XRT_HIP_SURF_BLAZED) {
+      XRT_FUSED(Generic1);
+    } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_TOROID) {
+      XRT_FUSED(ToroidMirror);
+    } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_FLAT) {
+      XRT_FUSED(FlatMirror);
+    } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_BENTFLAT) {
+      XRT_FUSED(BentMirror);
+    } else {
+      XRT_FUSED(Generic0);
+    }
+#undef XRT_FUSED
+  };
   if (ev0) (void)hipEventRecord(ev0, st);
-  hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g);
+  hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g, optimistic ? 0 : 1);
   // reductions: one partial record per block, folded by a one-block kernel
   // (measured on 1e7 rays: 32 rays per lane / ~1200 blocks beat 4 rays per lane by 3 %
   // of the pass - fewer partial records to fold; small batches keep >= 1024 blocks)
@@ -1932,6 +2185,16 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   if (rblocks < 1024u) rblocks = full < 1024u ? full : 1024u;
   if (rblocks > REFLECT_MAX_PART) rblocks = REFLECT_MAX_PART;
   const dim3 rgrid(rblocks);
+  if (optimistic) {
+    hipLaunchKernelGGL(reflect_light_stats, rgrid, block, 0, st, P, in, part);
+    hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, (int)rblocks,
+                       g);
+    if (evk0) (void)hipEventRecord(evk0, st);
+    launch_fused(std::integral_constant<int, 0>());
+    if (evk1) (void)hipEventRecord(evk1, st);
+    hipLaunchKernelGGL(reflect_check_opt, dim3(1), block, 0, st, g, opt);
+  }
+  // the exact sequence: every kernel of it returns at once unless g->redo is up
   if (!P.no_intersection_search) {
     using ToroidAny = Spec<0, XRT_HIP_SURF_TOROID, -1, false>;
     using FlatAny = Spec<0, XRT_HIP_SURF_FLAT, -1, false>;
@@ -1942,16 +2205,16 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
         hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, part);
         break;
       case XRT_HIP_SURF_ELLIPSE_PARAM:
-        hipLaunchKernelGGL(reflect_stats_dir_y<Generic1>, rgrid, block, 0, st, P, in, part);
+        hipLaunchKernelGGL(reflect_stats_dir_y<Generic1>, rgrid, block, 0, st, P, in, g, part);
         break;
       case XRT_HIP_SURF_TOROID:
-        hipLaunchKernelGGL(reflect_stats_dir_y<ToroidAny>, rgrid, block, 0, st, P, in, part);
+        hipLaunchKernelGGL(reflect_stats_dir_y<ToroidAny>, rgrid, block, 0, st, P, in, g, part);
         break;
       case XRT_HIP_SURF_FLAT:
-        hipLaunchKernelGGL(reflect_stats_dir_y<FlatAny>, rgrid, block, 0, st, P, in, part);
+        hipLaunchKernelGGL(reflect_stats_dir_y<FlatAny>, rgrid, block, 0, st, P, in, g, part);
         break;
       default:
-        hipLaunchKernelGGL(reflect_stats_dir_y<Generic0>, rgrid, block, 0, st, P, in, part);
+        hipLaunchKernelGGL(reflect_stats_dir_y<Generic0>, rgrid, block, 0, st, P, in, g, part);
     }
     hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, M, in, part, (int)rblocks,
                        pstride, g);
@@ -1972,24 +2235,15 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
     }
   }
-  const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  if (!optimistic && evk0) (void)hipEventRecord(evk0, st);
+  if (P.no_intersection_search)
+    launch_fused(std::integral_constant<int, 2>());
+  else
+    launch_fused(std::integral_constant<int, 1>());
+  if (!optimistic && evk1) (void)hipEventRecord(evk1, st);
   if (need_mean) {
+    // exact two-pass sign sequence, a no-op unless the batch had both signs
     const dim3 sgrid(grid.x < REFLECT_MAX_PART ? grid.x : REFLECT_MAX_PART);
-    // Bragg-reflecting crystals sit on flat surfaces in practice (DCM): that case is
-    // compiled with the kinds fixed
-    const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
-    using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
-    using AnyXtal = Spec<0, -1, XRT_HIP_MAT_CRYSTAL, false>;
-    // optimistic single pass; it raises any_neg / any_pos
-    if (evk0) (void)hipEventRecord(evk0, st);
-    if (flat_xtal)
-      hipLaunchKernelGGL(reflect_fused_xtal<FlatXtal>, grid, block, 0, st, P, M, in, restore, lb,
-                         vb, theta, g, &g->any_neg);
-    else
-      hipLaunchKernelGGL(reflect_fused_xtal<AnyXtal>, grid, block, 0, st, P, M, in, restore, lb,
-                         vb, theta, g, &g->any_neg);
-    if (evk1) (void)hipEventRecord(evk1, st);
-    // exact two-pass sequence, a no-op unless the batch had both signs
     if (flat_xtal)
       hipLaunchKernelGGL(reflect_solve<FlatXtal>, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst,
                          g, part);
@@ -2003,27 +2257,6 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     else
       hipLaunchKernelGGL(reflect_finish<AnyXtal>, grid, block, 0, st, P, M, in, restore, lb, vb,
                          theta, ht, hx, hy, hz, hst, g);
-  } else {
-    if (evk0) (void)hipEventRecord(evk0, st);
-#define XRT_FUSED(SPEC) \
-  hipLaunchKernelGGL((reflect_fused<SPEC>), grid, block, 0, st, P, M, in, restore, lb, vb, theta, g)
-    const bool plain = !P.grating && !P.asymmetric && !P.no_intersection_search;
-    using ToroidMirror = Spec<0, XRT_HIP_SURF_TOROID, XRT_HIP_MAT_MIRROR, true>;
-    using FlatMirror = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_MIRROR, true>;
-    using BentMirror = Spec<0, XRT_HIP_SURF_BENTFLAT, XRT_HIP_MAT_MIRROR, true>;
-    if (P.surf_kind >= XRT_HIP_SURF_BLAZED) {
-      XRT_FUSED(Generic1);
-    } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_TOROID) {
-      XRT_FUSED(ToroidMirror);
-    } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_FLAT) {
-      XRT_FUSED(FlatMirror);
-    } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_BENTFLAT) {
-      XRT_FUSED(BentMirror);
-    } else {
-      XRT_FUSED(Generic0);
-    }
-#undef XRT_FUSED
-    if (evk1) (void)hipEventRecord(evk1, st);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   return hipGetLastError();
