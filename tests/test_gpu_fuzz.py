@@ -303,7 +303,7 @@ def _toroid(bl):
 
 
 @pytest.mark.parametrize('case', ['plain', 'ray0_lost', 'sideways', 'backwards_first',
-                                  'steep'])
+                                  'steep', 'normal_incidence'])
 def test_single_pass_equals_exact_sequence(case, monkeypatch):
     """reflect first runs on the batch-global decisions every ordinary beam produces and
     falls back to the exact statistics when a ray contradicts them. Whatever the
@@ -327,10 +327,17 @@ def test_single_pass_equals_exact_sequence(case, monkeypatch):
         beam.c[:] = rng.normal(0, 3e-2, len(beam.c))
         beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
         expect_exact = None
+    elif case == 'normal_incidence':     # the beam runs along local -z: axis z, one pass
+        oe = roe.OE(bl, 'ml', center=[0, 20000., 0], pitch=np.pi/2,
+                    limPhysX=[-5, 5], limPhysY=[-5, 5],
+                    material=rm.Material('Pt', rho=21.45))
+        expect_exact = False
     t = {}
     g1, l1 = oe.reflect(rs.Beam(copyFrom=beam), _timing=t)
     if expect_exact is not None:
         assert t['exact_sequence'] == expect_exact
+    if case == 'normal_incidence':
+        assert (l1.state == 1).sum() > 3000
     monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
     t2 = {}
     g2, l2 = oe.reflect(rs.Beam(copyFrom=beam), _timing=t2)

@@ -655,9 +655,11 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
 // same every time: axis y, the sign of ray 0, a clamp that never bites (a
 // bracket-keeping secant iterate stays inside its own bracket, which lies inside
 // the global range) and secant. So the fused kernel is first run ON those
-// assumptions, after a light pass over (state, E) only -- the energy range keeps
+// assumptions (more precisely: on ray 0's largest direction cosine as the axis, so
+// that normal-incidence elements take the single pass as well), after a light pass
+// over (state, E) only -- the energy range keeps
 // the f1/f2 binary searches short -- and every ray checks them for itself:
-//   * a state-1 ray with |b| <= |a| or |b| <= |c| (axis might not be y),
+//   * a state-1 ray whose own largest cosine is another one (the axis might differ),
 //   * an iterate outside its own bracket (the clamp might have acted),
 //   * ray 0 not entering (the first entering ray is somebody else),
 // raise `viol`; the bracket-end |dz| maxima are collected on the way. A one-thread
@@ -733,11 +735,16 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
     return;
   }
   table_windows(M, emin, emax, g);
+  // axis: ray 0's largest direction cosine (y along a beamline, z at normal incidence);
+  // every state-1 ray then checks that the same cosine strictly dominates its own
   double a0 = in.a[0], b0 = in.b[0], c0 = in.c[0];
   local_dir(P, a0, b0, c0);
+  const double m0 = fmax(fmax(fabs(a0), fabs(b0)), fabs(c0));
+  const int axis = m0 == fabs(a0) ? 0 : (m0 == fabs(b0) ? 1 : 2);
+  const double comp0 = axis == 0 ? a0 : (axis == 1 ? b0 : c0);
   g->first_good = 0;
-  g->axis = 1;
-  g->positive = b0 > 0. ? 1 : 0;
+  g->axis = axis;
+  g->positive = comp0 > 0. ? 1 : 0;
   g->t1min = -INFINITY;    // no clamp: escapes are reported instead
   g->t2max = INFINITY;
   g->maxdz1 = 1.;          // secant
@@ -1846,6 +1853,12 @@ __device__ __forceinline__ bool fused_skips(const GStat* gp, int mode) {
   return (mode == 0 && !gp->optimistic) || (mode == 1 && !gp->redo);
 }
 
+// |direction cosine| along `axis` strictly larger than the other two
+__device__ __forceinline__ bool dominates(int axis, const LocalRay& r) {
+  const double fa = fabs(r.a), fb = fabs(r.b), fc = fabs(r.c);
+  return axis == 0 ? (fa > fb && fa > fc) : (axis == 1 ? (fb > fa && fb > fc) : (fc > fa && fc > fb));
+}
+
 // wave-level fold of the optimistic pass's reports into this block's slot
 __device__ __forceinline__ void report_opt(OptStat* slots, const SolveAux& aux, int viol) {
   double m1 = aux.adz1, m2 = aux.adz2;
@@ -1864,18 +1877,17 @@ __device__ __forceinline__ void report_opt(OptStat* slots, const SolveAux& aux, 
   }
 }
 
-template <class K, int mode>
-__global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
-    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
-    OptStat* __restrict__ opt) {
-  if (fused_skips(gp, mode)) return;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// one ray of the fused solve + finish; own_sign / neg / pos serve the crystal variant
+template <class K, int mode, bool XTAL>
+__device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_material& M,
+                                          const xrt_hip_beam& in, const xrt_hip_beam& restore,
+                                          const xrt_hip_beam& lb, const xrt_hip_beam& vb,
+                                          double* theta, const GStat& g, OptStat* opt,
+                                          int64_t i, int& neg, int& pos) {
   const bool has_amp = in.Es_ri != nullptr;
   const int st0 = i < in.n ? in.state[i] : 0;
   const bool active = i < in.n && entering(P, st0);
   if (i < in.n && !active) pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
-  const GStat g = *gp;
   LocalRay r;
   Hit h;
   if (mode == 0) {
@@ -1886,8 +1898,8 @@ __global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
     if (active) {
       r = load_local(P, in, i);
       h = solve_ray<K, true>(P, g, r, &aux);
-      // the axis is y only if max|b| beats max|a| and max|c| over the state-1 rays
-      viol = st0 == 1 && !(fabs(r.b) > fabs(r.a) && fabs(r.b) > fabs(r.c));
+      // the axis stands only if its max beats the other two maxima over the state-1 rays
+      viol = st0 == 1 && !dominates(g.axis, r);
     }
     report_opt(opt, aux, viol);
   } else if (active) {
@@ -1897,8 +1909,29 @@ __global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
   if (active) {
     int st = rays_good(P, h.x, h.y);
     if (h.lost) st = P.lost_num;
-    complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
+    if (XTAL) {
+      double bdn = 0.;
+      complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 1, &bdn);
+      neg |= st == 1 && bdn < 0.;
+      pos |= st == 1 && !(bdn < 0.);
+    } else {
+      complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
+    }
   }
+}
+
+template <class K, int mode>
+__global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
+    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
+    OptStat* __restrict__ opt) {
+  if (fused_skips(gp, mode)) return;
+  const GStat g = *gp;
+  int neg = 0, pos = 0;
+  // (one ray per lane also in the redo: a strided loop here makes the compiler hoist the
+  // frame constants into VGPRs and spill -- 300 B of scratch, measured)
+  fused_ray<K, mode, false>(P, M, in, restore, lb, vb, theta, g, opt,
+                            (int64_t)blockIdx.x * blockDim.x + threadIdx.x, neg, pos);
 }
 
 // ---------------------------------------------------------------------------
@@ -1915,36 +1948,10 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_xtal(
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     int* __restrict__ any_neg_pos, OptStat* __restrict__ opt) {
   if (fused_skips(gp, mode)) return;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int neg = 0, pos = 0;
-  const bool has_amp = in.Es_ri != nullptr;
-  const int st0 = i < in.n ? in.state[i] : 0;
-  const bool active = i < in.n && entering(P, st0);
-  if (i < in.n && !active) pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
   const GStat g = *gp;
-  LocalRay r;
-  Hit h;
-  if (mode == 0) {
-    SolveAux aux;
-    int viol = 0;
-    if (active) {
-      r = load_local(P, in, i);
-      h = solve_ray<K, true>(P, g, r, &aux);
-      viol = st0 == 1 && !(fabs(r.b) > fabs(r.a) && fabs(r.b) > fabs(r.c));
-    }
-    report_opt(opt, aux, viol);
-  } else if (active) {
-    r = load_local(P, in, i);
-    h = solve_ray<K>(P, g, r);
-  }
-  if (active) {
-    int st = rays_good(P, h.x, h.y);
-    if (h.lost) st = P.lost_num;
-    double bdn = 0.;
-    complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 1, &bdn);
-    neg = st == 1 && bdn < 0.;
-    pos = st == 1 && !(bdn < 0.);
-  }
+  int neg = 0, pos = 0;
+  fused_ray<K, mode, true>(P, M, in, restore, lb, vb, theta, g, opt,
+                           (int64_t)blockIdx.x * blockDim.x + threadIdx.x, neg, pos);
   // same-value racing stores; any_neg/any_pos are read only by the kernels that follow
   neg = __syncthreads_or(neg);
   pos = __syncthreads_or(pos);
