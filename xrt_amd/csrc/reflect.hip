@@ -447,7 +447,7 @@ __device__ __forceinline__ void atomic_max_double(double* p, double v) {
 // ---------------------------------------------------------------------------
 // K0 / K1 / decide / K2
 // ---------------------------------------------------------------------------
-__global__ void reflect_init(GStat* g, int redo) {
+__device__ __forceinline__ void gstat_reset(GStat* g, int redo) {
   g->optimistic = 0;
   g->redo = redo;
   g->maxa = 0.;
@@ -474,6 +474,8 @@ __global__ void reflect_init(GStat* g, int redo) {
     g->tab_hi[e] = 0x7fffffff;
   }
 }
+
+__global__ void reflect_init(GStat* g, int redo) { gstat_reset(g, redo); }
 
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass P,
                                                                    xrt_hip_beam in,
@@ -672,23 +674,26 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_light_stats(
     xrt_hip_pass P, xrt_hip_beam in, double* __restrict__ part) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
   double emin = INFINITY, emax = -INFINITY, nent = 0.;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x * 2 + threadIdx.x; i < in.n; i += stride) {
-    const int64_t j = i + blockDim.x;
-    const bool two = j < in.n;
-    const int st0 = in.state[i];
-    const double E0 = in.E[i];
-    const int st1 = two ? in.state[j] : 0;
-    const double E1 = two ? in.E[j] : 0.;
-    if (entering(P, st0)) {
-      nent += 1.;
-      emin = E0 < emin ? E0 : emin;
-      emax = E0 > emax ? E0 : emax;
+  constexpr int U = 8;   // rays per lane and trip, all 16 loads in flight together
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x * U + threadIdx.x; i < in.n; i += stride) {
+    int st[U];
+    double E[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t j = i + (int64_t)u * blockDim.x;
+      const bool ok = j < in.n;
+      st[u] = ok ? in.state[j] : 0;
+      E[u] = ok ? in.E[j] : 0.;
+      if (!ok) st[u] = P.good_mode == 0 ? 0 : -1;   // not entering in either mode
     }
-    if (two && entering(P, st1)) {
-      nent += 1.;
-      emin = E1 < emin ? E1 : emin;
-      emax = E1 > emax ? E1 : emax;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (entering(P, st[u])) {
+        nent += 1.;
+        emin = E[u] < emin ? E[u] : emin;
+        emax = E[u] > emax ? E[u] : emax;
+      }
     }
   }
   auto fmaxd = [](double u, double v) { return u > v ? u : v; };
@@ -729,6 +734,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
     slots[k].viol = 0;
   }
   if (threadIdx.x != 0) return;
+  gstat_reset(g, 0);     // (this kernel opens the pass: no separate init launch)
   g->n_enter = (unsigned long long)nent;
   if (nent == 0. || !entering(P, in.state[0])) {
     g->redo = 1;    // nothing assumed: the exact sequence handles it (and empty batches)
@@ -2183,7 +2189,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
 #undef XRT_FUSED
   };
   if (ev0) (void)hipEventRecord(ev0, st);
-  hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g, optimistic ? 0 : 1);
+  if (!optimistic) hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g, 1);
   // reductions: one partial record per block, folded by a one-block kernel
   // (measured on 1e7 rays: 32 rays per lane / ~1200 blocks beat 4 rays per lane by 3 %
   // of the pass - fewer partial records to fold; small batches keep >= 1024 blocks)
@@ -2193,8 +2199,10 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   if (rblocks > REFLECT_MAX_PART) rblocks = REFLECT_MAX_PART;
   const dim3 rgrid(rblocks);
   if (optimistic) {
-    hipLaunchKernelGGL(reflect_light_stats, rgrid, block, 0, st, P, in, part);
-    hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, (int)rblocks,
+    unsigned lblocks = (unsigned)((n + 8 * REFLECT_BLOCK - 1) / (8 * REFLECT_BLOCK));
+    if (lblocks > REFLECT_MAX_PART) lblocks = REFLECT_MAX_PART;
+    hipLaunchKernelGGL(reflect_light_stats, dim3(lblocks), block, 0, st, P, in, part);
+    hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, (int)lblocks,
                        g);
     if (evk0) (void)hipEventRecord(evk0, st);
     launch_fused(std::integral_constant<int, 0>());
