@@ -17,7 +17,8 @@ import os
 import sqlite3
 import sys
 
-OURS = ('reflect_fused_xtal', 'reflect_reduce_sign', 'reflect_fused', 'reflect_solve', 'reflect_finish', 'reflect_stats_dir_y',
+OURS = ('reflect_fused_xtal', 'reflect_light_stats', 'reflect_decide_opt', 'reflect_check_opt',
+        'reflect_fused', 'reflect_solve', 'reflect_finish', 'reflect_stats_dir_y',
         'reflect_stats_dir',
         'reflect_stats_bracket', 'screen_expose_kernel', 'kirchhoff_stream',
         'kirchhoff_pack', 'kirchhoff_finalize', 'und_imap', 'und_sum', 'und_pack',
@@ -59,11 +60,20 @@ def kernel_stats(db):
 
 
 def counter_per_launch(db, counter):
+    """{short kernel name: (average per launch, launches, variant)}. A kernel that
+    exists in several instantiations (reflect_fused<Spec, mode>: the optimistic pass,
+    the redo that usually returns at once, ...) is represented by the instantiation
+    with the largest average - the one that did the work."""
     c = sqlite3.connect(db)
     rows = c.execute('select kernel_name, avg(value), count(*) from '
                      'counters_collection where counter_name=? group by '
                      'kernel_name', (counter,)).fetchall()
-    return {short(r[0]): (r[1], r[2]) for r in rows}
+    out = {}
+    for name, avg, cnt in rows:
+        k = short(name)
+        if k not in out or avg > out[k][0]:
+            out[k] = (avg, cnt, variant(name))
+    return out
 
 
 def main():
@@ -101,7 +111,8 @@ def main():
             if k in fetch and k in write:
                 rb = fetch[k][0] * 1024. * cal_r
                 wb = write[k][0] * 1024. * cal_w
-                res[k] = dict(FETCH_SIZE_KB=fetch[k][0], WRITE_SIZE_KB=write[k][0],
+                res[k] = dict(variant=fetch[k][2], FETCH_SIZE_KB=fetch[k][0],
+                              WRITE_SIZE_KB=write[k][0],
                               launches=fetch[k][1], read_bytes=rb, write_bytes=wb,
                               hbm_bytes_per_launch=rb + wb)
         path = os.path.join(out, 'hbm_traffic.json')
