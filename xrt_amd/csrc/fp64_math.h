@@ -150,4 +150,14 @@ __device__ __forceinline__ void sincos_tab(double phi, const double2* tab, doubl
   sn = fma_(T.x, s, sn);
 }
 
+// table form where its bound holds, the general polynomial form otherwise (the
+// branch is taken per lane; a wave whose lanes all qualify skips the slow side)
+__device__ __forceinline__ void sincos_any(double phi, const double2* tab, double& sn,
+                                           double& cs) {
+  if (__builtin_fabs(phi) < 0x1p42)
+    sincos_tab(phi, tab, sn, cs);
+  else
+    sincos_phase(phi, sn, cs);
+}
+
 }  // namespace xrt

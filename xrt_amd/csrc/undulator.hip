@@ -66,8 +66,9 @@ __device__ __forceinline__ double div_known(double a, double b, double y) {
 // The per-ray sum; returns wu/γ·Σ (synchr.py:2038).
 template <int MODE>
 __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __restrict__ rec,
-                                        double g, double wu, double w, double ww1, double phi,
-                                        double psi, double2& out_s, double2& out_p) {
+                                        const double2* tab, double g, double wu, double w,
+                                        double ww1, double phi, double psi, double2& out_s,
+                                        double2& out_p) {
   const double Kx = a.Kx, Ky = a.Ky;
   const double kx2 = Kx * Kx, ky2 = Ky * Ky;
   const double revg = 1. / g;
@@ -113,7 +114,7 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
       if (MODE == UND_FAR) {
         double A = (nky_dx * s + kx_dy * sp) + e8 * r[N_SUM2];
         double ucos = ww1 * tg + wwug * A;
-        sincos_phase(ucos, ei, er);
+        sincos_any(ucos, tab, ei, er);
         betax = kyg * c;
         bPx = r[N_BPX];
         bPz = h2 * r[N_SUM2];
@@ -127,7 +128,7 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
         double T2 = kx_dy * s;                                // sic: sintg, not sintgph
         double T3 = e8 * (r[N_KX2S2XPH] + ky2 * (s2x - aw2 * u2));
         double ucos = ww1 * zloc + wwug * ((T1 + T2) + T3);
-        sincos_phase(ucos, ei, er);
+        sincos_any(ucos, tab, ei, er);
         betax = ((taperC * Ky) * revg) * c;
         bPx = (-Ky) * (a.alpha_s * c + taperC * s);
         bPz = h2 * ((ky2 * taperC) * (a.alpha_s * r[N_C2] + taperC * s2x) + r[N_KX2S2XPH]);
@@ -143,8 +144,8 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
         double dist = __builtin_sqrt(dxy + drz * drz);
         double drs = (0.5 * dxy) / drz;
         double sz, cz, sd, cd;
-        sincos_phase((wwu * zloc) * omb, sz, cz);
-        sincos_phase(wwu * (drs + q4), sd, cd);
+        sincos_any((wwu * zloc) * omb, tab, sz, cz);
+        sincos_any(wwu * (drs + q4), tab, sd, cd);
         er = ((((-sr0) * sz) * cd - (sr0 * cz) * sd) - (cr0 * sz) * sd) + (cr0 * cz) * cd;
         ei = ((((-sr0) * sz) * sd + (sr0 * cz) * cd) + (cr0 * sz) * cd) + (cr0 * cz) * sd;
         dirx = drx / dist;
@@ -184,10 +185,13 @@ und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
         const double* __restrict__ w, const double* __restrict__ ww1,
         const double* __restrict__ ddphi, const double* __restrict__ ddpsi,
         double2* __restrict__ Is, double2* __restrict__ Ip) {
+  // (cos, sin) of 2048 steps per turn for the in-loop sincos, fp64_math.h
+  __shared__ double2 tab[SINCOS_TAB_N];
+  sincos_tab_fill(tab);
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   double2 s, p;
-  und_ray<MODE>(a, rec, gamma[i], wu[i], w[i], ww1[i], ddphi[i], ddpsi[i], s, p);
+  und_ray<MODE>(a, rec, tab, gamma[i], wu[i], w[i], ww1[i], ddphi[i], ddpsi[i], s, p);
   Is[i] = s;
   Ip[i] = p;
 }
@@ -201,6 +205,8 @@ und_imap(UndulatorArgs a, UndulatorMap m, const double* __restrict__ rec, int64_
          const double* __restrict__ w_, const double* __restrict__ theta,
          const double* __restrict__ psi_, const double* __restrict__ gamma_,
          double* __restrict__ I, double2* __restrict__ Es, double2* __restrict__ Ep) {
+  __shared__ double2 tab[SINCOS_TAB_N];
+  sincos_tab_fill(tab);
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double w = w_[i], th = theta[i], ps = psi_[i];
@@ -218,7 +224,7 @@ und_imap(UndulatorArgs a, UndulatorMap m, const double* __restrict__ rec, int64_
     ab = (ab * s1) / s2;
   }
   double2 s, p;
-  und_ray<MODE>(a, rec, g, wu, w, ww1, th, ps, s, p);
+  und_ray<MODE>(a, rec, tab, g, wu, w, ww1, th, ps, s, p);
   if (m.has_harmonic && (ww1 > m.harmonic + 0.5 || ww1 < m.harmonic - 0.5)) {
     s = make_double2(0., 0.);
     p = make_double2(0., 0.);
@@ -268,6 +274,8 @@ cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
          const double* __restrict__ w_, const double* __restrict__ ddphi,
          const double* __restrict__ ddpsi, double2* __restrict__ Is,
          double2* __restrict__ Ip) {
+  __shared__ double2 tab[SINCOS_TAB_N];
+  sincos_tab_fill(tab);
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double emcg = emcg_[i], w = w_[i], phi = ddphi[i], psi = ddpsi[i];
@@ -317,8 +325,8 @@ cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
       const double LRS = (0.5 * drs - (0.125 * (drs * drs)) * rdrz) +
                          (0.0625 * pow(drs, 3.)) * (rdrz * rdrz);
       double sz, cz, sd, cd;
-      sincos_phase(wc * (tg - tz), sz, cz);
-      sincos_phase(wc * LRS, sd, cd);
+      sincos_any(wc * (tg - tz), tab, sz, cz);
+      sincos_any(wc * LRS, tab, sd, cd);
       er = ((((-sr0) * sz) * cd - (sr0 * cz) * sd) - (cr0 * sz) * sd) + (cr0 * cz) * cd;
       ei = ((((-sr0) * sz) * sd + (sr0 * cz) * cd) + (cr0 * sz) * cd) + (cr0 * cz) * sd;
       dirx = drx / dist;
@@ -326,8 +334,8 @@ cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
       dirz = drz / dist;
     } else {
       double s1, c1, s2, c2;
-      sincos_phase(wc * (tg - dirz * tz), s1, c1);
-      sincos_phase(wc * (dirx * tx + diry * ty), s2, c2);
+      sincos_any(wc * (tg - dirz * tz), tab, s1, c1);
+      sincos_any(wc * (dirx * tx + diry * ty), tab, s2, c2);
       er = s1 * c2 - c1 * s2;
       ei = c1 * c2 + s1 * s2;
     }
