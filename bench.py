@@ -55,7 +55,9 @@ def parse():
                     help='also time the two Kirchhoff shapes of the reference\'s '
                          'published speed test (2e5 x 2e5 and 2e5 x 64^2)')
     ap.add_argument('--with-dcm', action='store_true',
-                    help='also time cfg3 (DCM Si111, 2 intersections per ray)')
+                    help='(default on one GPU) also time cfg3 (DCM Si111, 2 intersections '
+                         'per ray)')
+    ap.add_argument('--skip-dcm', action='store_true')
     return ap.parse_args()
 
 
@@ -450,7 +452,7 @@ def main():
             parallelism='replicas x%d (P1 does not shard, SURVEY 8e)' % world),
         per_gpu=main_res['value'] / world, pass_ms=main_res.get('pass_ms'),
         kernel_ms=main_res.get('kernel_ms'), roofline=main_res.get('roofline'))
-    if args.with_dcm:
+    if args.with_dcm or (world == 1 and not args.skip_dcm):
         d = bench_reflect(args, world, rank, dist, dcm=True)
         line['dcm'] = dict(metric='ray-surface intersections/s (cfg3 DCM Si111)',
                            value=d['value'], ms_per_step=d['ms_per_step'],

@@ -557,6 +557,41 @@ __device__ __forceinline__ void table_windows(const xrt_hip_material& M, double 
   }
 }
 
+// the same by the whole block: upper_bound(x) in a sorted table = number of entries <= x,
+// counted in parallel (a one-thread binary search is 20 dependent memory round trips)
+__device__ __forceinline__ void table_windows_block(const xrt_hip_material& M, double emin,
+                                                    double emax, GStat* g,
+                                                    unsigned long long* lds_u) {
+  if (M.kind == XRT_HIP_MAT_NONE || !(emin <= emax)) {
+    if (threadIdx.x == 0) {
+      g->emin = emin;
+      g->emax = emax;
+    }
+    return;
+  }
+  auto faddu = [](unsigned long long u, unsigned long long v) { return u + v; };
+  for (int e = 0; e < M.nelem; ++e) {
+    const double* tE = M.tab_E[e];
+    const int n = M.tab_n[e];
+    unsigned long long lo = 0, hi = 0;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const double v = tE[j];
+      lo += v <= emin;
+      hi += v <= emax;
+    }
+    lo = block_reduce(lo, faddu, lds_u);
+    hi = block_reduce(hi, faddu, lds_u);
+    if (threadIdx.x == 0) {
+      g->tab_lo[e] = (int)lo;
+      g->tab_hi[e] = (int)hi;
+    }
+  }
+  if (threadIdx.x == 0) {
+    g->emin = emin;
+    g->emax = emax;
+  }
+}
+
 // stride = doubles per partial record: 8 (reflect_stats_dir) or 16
 // (reflect_stats_dir_y, which also carries the bracket statistics of the y axis
 // for both signs: [8..11] positive, [12..15] negative)
@@ -713,6 +748,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_light_stats(
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, double* part, int nblocks, GStat* g) {
   __shared__ double lds_d[REFLECT_BLOCK / 64];
+  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
   double emin = INFINITY, emax = -INFINITY, nent = 0.;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     const double* o = part + (int64_t)b * 4;
@@ -733,14 +769,19 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
     slots[k].maxdz2 = 0;
     slots[k].viol = 0;
   }
-  if (threadIdx.x != 0) return;
-  gstat_reset(g, 0);     // (this kernel opens the pass: no separate init launch)
-  g->n_enter = (unsigned long long)nent;
-  if (nent == 0. || !entering(P, in.state[0])) {
-    g->redo = 1;    // nothing assumed: the exact sequence handles it (and empty batches)
+  // (this kernel opens the pass: no separate init launch)
+  if (threadIdx.x == 0) {
+    gstat_reset(g, 0);
+    g->n_enter = (unsigned long long)nent;
+  }
+  const bool assume = nent != 0. && entering(P, in.state[0]);
+  if (!assume) {
+    if (threadIdx.x == 0) g->redo = 1;   // nothing assumed: the exact sequence handles it
     return;
   }
-  table_windows(M, emin, emax, g);
+  __syncthreads();                        // the reset precedes the window stores
+  table_windows_block(M, emin, emax, g, lds_u);
+  if (threadIdx.x != 0) return;
   // axis: ray 0's largest direction cosine (y along a beamline, z at normal incidence);
   // every state-1 ray then checks that the same cosine strictly dominates its own
   double a0 = in.a[0], b0 = in.b[0], c0 = in.c[0];
