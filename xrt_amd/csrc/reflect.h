@@ -35,6 +35,8 @@ struct GStat {
   int tab_lo[XRT_HIP_MAX_ELEM];      // per element: upper_bound(E table, emin) ...
   int tab_hi[XRT_HIP_MAX_ELEM];      // ... and upper_bound(E table, emax): the f1/f2
                                      // binary search of every ray stays inside
+  double win_lo, win_hi;             // energies the windows (of all elements) are valid
+                                     // for: [win_lo, win_hi); -inf, +inf = the whole batch
 };
 
 // What the optimistic fused pass reports back. Same-address atomics from 150 000

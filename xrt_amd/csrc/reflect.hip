@@ -473,6 +473,8 @@ __device__ __forceinline__ void gstat_reset(GStat* g, int redo) {
     g->tab_lo[e] = 0;
     g->tab_hi[e] = 0x7fffffff;
   }
+  g->win_lo = -INFINITY;
+  g->win_hi = INFINITY;
 }
 
 __global__ void reflect_init(GStat* g, int redo) { gstat_reset(g, redo); }
@@ -693,9 +695,8 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
 // bracket-keeping secant iterate stays inside its own bracket, which lies inside
 // the global range) and secant. So the fused kernel is first run ON those
 // assumptions (more precisely: on ray 0's largest direction cosine as the axis, so
-// that normal-incidence elements take the single pass as well), after a light pass
-// over (state, E) only -- the energy range keeps
-// the f1/f2 binary searches short -- and every ray checks them for itself:
+// that normal-incidence elements take the single pass as well) and every ray checks
+// them for itself:
 //   * a state-1 ray whose own largest cosine is another one (the axis might differ),
 //   * an iterate outside its own bracket (the clamp might have acted),
 //   * ray 0 not entering (the first entering ray is somebody else),
@@ -705,64 +706,10 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
 // that follows in the stream does the pass properly; otherwise those kernels return
 // at once. Results are bit-identical to the exact sequence either way.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_light_stats(
-    xrt_hip_pass P, xrt_hip_beam in, double* __restrict__ part) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  double emin = INFINITY, emax = -INFINITY, nent = 0.;
-  constexpr int U = 8;   // rays per lane and trip, all 16 loads in flight together
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x * U + threadIdx.x; i < in.n; i += stride) {
-    int st[U];
-    double E[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t j = i + (int64_t)u * blockDim.x;
-      const bool ok = j < in.n;
-      st[u] = ok ? in.state[j] : 0;
-      E[u] = ok ? in.E[j] : 0.;
-      if (!ok) st[u] = P.good_mode == 0 ? 0 : -1;   // not entering in either mode
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (entering(P, st[u])) {
-        nent += 1.;
-        emin = E[u] < emin ? E[u] : emin;
-        emax = E[u] > emax ? E[u] : emax;
-      }
-    }
-  }
-  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
-  auto fmind = [](double u, double v) { return u < v ? u : v; };
-  auto faddd = [](double u, double v) { return u + v; };
-  emin = block_reduce(emin, fmind, lds_d);
-  emax = block_reduce(emax, fmaxd, lds_d);
-  nent = block_reduce(nent, faddd, lds_d);
-  if (threadIdx.x == 0) {
-    double* o = part + (int64_t)blockIdx.x * 4;
-    o[0] = emin;
-    o[1] = emax;
-    o[2] = nent;
-  }
-}
-
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, double* part, int nblocks, GStat* g) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, double* part, GStat* g) {
   __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  double emin = INFINITY, emax = -INFINITY, nent = 0.;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    const double* o = part + (int64_t)b * 4;
-    emin = o[0] < emin ? o[0] : emin;
-    emax = o[1] > emax ? o[1] : emax;
-    nent += o[2];
-  }
-  auto fmaxd = [](double u, double v) { return u > v ? u : v; };
-  auto fmind = [](double u, double v) { return u < v ? u : v; };
-  auto faddd = [](double u, double v) { return u + v; };
-  emin = block_reduce(emin, fmind, lds_d);
-  emax = block_reduce(emax, fmaxd, lds_d);
-  nent = block_reduce(nent, faddd, lds_d);
-  // the partial records are folded: their area now holds the report slots
+  // the (idle) partial-record area holds the report slots of the fused kernel
   OptStat* slots = reinterpret_cast<OptStat*>(part);
   for (int k = threadIdx.x; k < REFLECT_OPT_SLOTS; k += blockDim.x) {
     slots[k].maxdz1 = 0;
@@ -770,18 +717,29 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
     slots[k].viol = 0;
   }
   // (this kernel opens the pass: no separate init launch)
-  if (threadIdx.x == 0) {
-    gstat_reset(g, 0);
-    g->n_enter = (unsigned long long)nent;
-  }
-  const bool assume = nent != 0. && entering(P, in.state[0]);
-  if (!assume) {
+  if (threadIdx.x == 0) gstat_reset(g, 0);
+  if (!entering(P, in.state[0])) {
     if (threadIdx.x == 0) g->redo = 1;   // nothing assumed: the exact sequence handles it
     return;
   }
   __syncthreads();                        // the reset precedes the window stores
-  table_windows_block(M, emin, emax, g, lds_u);
+  // f1/f2 window: the table interval of ray 0's energy and its two neighbours; rays
+  // outside it search the whole table (interp_f1f2)
+  const double E0 = in.E[0];
+  table_windows_block(M, E0, E0, g, lds_u);
   if (threadIdx.x != 0) return;
+  double wlo = -INFINITY, whi = INFINITY;
+  for (int e = 0; e < M.nelem && M.kind != XRT_HIP_MAT_NONE; ++e) {
+    const int n = M.tab_n[e];
+    const int lo = g->tab_lo[e] > 0 ? g->tab_lo[e] - 1 : 0;
+    const int hi = g->tab_hi[e] + 1 < n ? g->tab_hi[e] + 1 : n;
+    g->tab_lo[e] = lo;
+    g->tab_hi[e] = hi;
+    if (lo > 0) wlo = fmax(wlo, M.tab_E[e][lo - 1]);
+    if (hi < n) whi = fmin(whi, M.tab_E[e][hi]);
+  }
+  g->win_lo = wlo;     // one energy interval in which every element's window holds
+  g->win_hi = whi;
   // axis: ray 0's largest direction cosine (y along a beamline, z at normal incidence);
   // every state-1 ray then checks that the same cosine strictly dominates its own
   double a0 = in.a[0], b0 = in.b[0], c0 = in.c[0];
@@ -1040,7 +998,7 @@ __device__ __forceinline__ void hit_done(const xrt_hip_pass& P, Hit& h) {
   }
 }
 
-// what a ray of the optimistic pass reports (see reflect_light_stats)
+// what a ray of the optimistic pass reports (see reflect_decide_opt)
 struct SolveAux {
   double adz1 = 0., adz2 = 0.;   // |dz| at the bracket ends, as find_intersection maximises them
   int escaped = 0;               // an iterate left the ray's own bracket
@@ -1248,6 +1206,7 @@ __device__ __forceinline__ int rays_good(const xrt_hip_pass& P, double x, double
 // slope*(x - xp[j]) + fp[j]
 struct TabWin {
   int lo[XRT_HIP_MAX_ELEM], hi[XRT_HIP_MAX_ELEM];
+  double elo, ehi;   // energies it is valid for
 };
 __device__ __forceinline__ TabWin full_window() {
   TabWin w;
@@ -1255,6 +1214,8 @@ __device__ __forceinline__ TabWin full_window() {
     w.lo[e] = 0;
     w.hi[e] = 0x7fffffff;
   }
+  w.elo = -INFINITY;
+  w.ehi = INFINITY;
   return w;
 }
 __device__ __forceinline__ TabWin window_of(const GStat& g) {
@@ -1263,6 +1224,8 @@ __device__ __forceinline__ TabWin window_of(const GStat& g) {
     w.lo[e] = g.tab_lo[e];
     w.hi[e] = g.tab_hi[e];
   }
+  w.elo = g.win_lo;
+  w.ehi = g.win_hi;
   return w;
 }
 
@@ -1270,8 +1233,16 @@ __device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, do
                                             const TabWin& w) {
   const double* __restrict__ tE = M.tab_E[e];
   const int n = M.tab_n[e];
-  // the batch's energy range confines upper_bound(E) to [w.lo, w.hi]
+  // upper_bound(E) lies in [w.lo, w.hi] for tE[w.lo - 1] <= E < tE[w.hi] (all elements:
+  // for E in [w.elo, w.ehi)).
+  // The exact sequence hands over the window of the batch's energy range (valid for
+  // every ray); the optimistic pass a window around ray 0's energy, which a ray of a
+  // different energy simply does not use.
   int lo = w.lo[e], hi = w.hi[e] < n ? w.hi[e] : n;
+  if (!(E >= w.elo && E < w.ehi)) {
+    lo = 0;
+    hi = n;
+  }
   while (lo < hi) {
     const int mid = lo + ((hi - lo) >> 1);
     if (E >= tE[mid])
@@ -2184,7 +2155,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   double* hz = reinterpret_cast<double*>(base + 3 * a);
   int32_t* hst = reinterpret_cast<int32_t*>(base + 4 * a);
   const dim3 grid((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)), block(REFLECT_BLOCK);
-  // The optimistic single pass (see reflect_light_stats) needs the input intact for a
+  // The optimistic single pass (see reflect_decide_opt) needs the input intact for a
   // possible redo, and surfaces that bracket at all.
   const bool searches = !P.no_intersection_search && P.surf_kind != XRT_HIP_SURF_BLAZED;
   const bool optimistic = searches && !force_exact && !beams_overlap(in, lb) &&
@@ -2240,11 +2211,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   if (rblocks > REFLECT_MAX_PART) rblocks = REFLECT_MAX_PART;
   const dim3 rgrid(rblocks);
   if (optimistic) {
-    unsigned lblocks = (unsigned)((n + 8 * REFLECT_BLOCK - 1) / (8 * REFLECT_BLOCK));
-    if (lblocks > REFLECT_MAX_PART) lblocks = REFLECT_MAX_PART;
-    hipLaunchKernelGGL(reflect_light_stats, dim3(lblocks), block, 0, st, P, in, part);
-    hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, (int)lblocks,
-                       g);
+    hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, g);
     if (evk0) (void)hipEventRecord(evk0, st);
     launch_fused(std::integral_constant<int, 0>());
     if (evk1) (void)hipEventRecord(evk1, st);
