@@ -224,3 +224,26 @@ def test_full_size_additivity_and_linearity():
     ref = kn.kirchhoff_conv(*sub)
     for f, r in zip(full, ref):
         assert np.abs(f[idx] - r).max() <= TOL * np.abs(f).max()
+
+
+@pytest.mark.parametrize('scale,ppt', [(1., 1), (30., 2), (2000., 1)])
+def test_phase_magnitudes_across_the_table_bound(scale, ppt):
+    """|k r| < 2^42 goes through the LDS-table sincos, larger phases (hard X-rays over
+    long distances) through the general one; the switch is per wave from
+    max k (|p|_1 + max |s|_1). scale 1: 4e11 rad (table); 30: 1.2e13 (general);
+    2000: 8e14, where one ulp of k r is already 0.1 rad - the reference rounds k r
+    the same way, so the results still agree."""
+    px, py, pz, sx, sy, sz, nrm, nl, E, Es, Ep = random_case(300, 400, seed=11)
+    case = (px, py * scale, pz, sx, sy, sz, nrm, nl, E, Es, Ep)
+    ref = kn.kirchhoff_conv(*case)
+    mine = run_hip(*case, ppt=ppt)
+    assert_close(mine, ref, tol=1e-9)
+
+
+def test_mixed_waves_on_both_sides_of_the_table_bound():
+    """pixels near and far in one launch: some waves take the table, others not"""
+    px, py, pz, sx, sy, sz, nrm, nl, E, Es, Ep = random_case(1024, 300, seed=12)
+    py = py.copy()
+    py[512:] *= 40.
+    case = (px, py, pz, sx, sy, sz, nrm, nl, E, Es, Ep)
+    assert_close(run_hip(*case), kn.kirchhoff_conv(*case), tol=1e-9)
