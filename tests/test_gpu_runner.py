@@ -92,10 +92,14 @@ def test_rays_on_bin_edges_follow_numpy():
     assert plot.intensityInRange == ref.sum() and plot.intensity == n
 
 
-def test_colour_and_1d_histograms_match_numpy_and_matplotlib():
+@pytest.mark.parametrize('bx,by,bc', [(40, 36, 50), (128, 128, 128), (100, 90, 2000),
+                                      (300, 200, 64)])
+def test_colour_and_1d_histograms_match_numpy_and_matplotlib(bx, by, bc):
     """The complete per-plot reduce of multipro.py:316-361: hue from the colour
     axis (energy), hsv_to_rgb with value = flux, three 1-D histograms with
-    flux / R / G / B weights, 2-D intensity and RGB histograms."""
+    flux / R / G / B weights, 2-D intensity and RGB histograms. Bin counts: all four
+    2-D planes in one LDS pass; one plane per pass (128 x 128 = 128 KB); 1-D cells
+    beyond the LDS budget; a 2-D plane beyond it (both through the global-atomic form)."""
     import matplotlib.colors as mc
     bl = build()
     kept = []
@@ -108,14 +112,14 @@ def test_colour_and_1d_histograms_match_numpy_and_matplotlib():
     rr.run_process = run_process
     np.random.seed(12)
     plot = xrtp.XYCPlot(
-        'beamM1local', (1, 3), xrtp.XYCAxis('x', 'mm', limits=[-0.8, 0.8], bins=40),
-        xrtp.XYCAxis('y', 'mm', limits=[-250, 250], bins=36),
-        caxis=xrtp.XYCAxis('energy', 'eV', limits=[8992., 9008.], bins=50),
+        'beamM1local', (1, 3), xrtp.XYCAxis('x', 'mm', limits=[-0.8, 0.8], bins=bx),
+        xrtp.XYCAxis('y', 'mm', limits=[-250, 250], bins=by),
+        caxis=xrtp.XYCAxis('energy', 'eV', limits=[8992., 9008.], bins=bc),
         fluxKind='total')
     xrtr.run_ray_tracing([plot], repeats=2, beamLine=bl)
-    ref2 = np.zeros((36, 40))
-    ref2rgb = np.zeros((36, 40, 3))
-    r1 = {k: np.zeros((n, 4)) for k, n in (('x', 40), ('y', 36), ('c', 50))}
+    ref2 = np.zeros((by, bx))
+    ref2rgb = np.zeros((by, bx, 3))
+    r1 = {k: np.zeros((n, 4)) for k, n in (('x', bx), ('y', by), ('c', bc))}
     for lb in kept:
         sel = (lb.state == 1) | (lb.state == 3)
         x, y, c = lb.x[sel], lb.y[sel], lb.E[sel]
@@ -126,14 +130,14 @@ def test_colour_and_1d_histograms_match_numpy_and_matplotlib():
         hsv = np.dstack((c01, np.ones_like(c01) * plot.colorSaturation,
                          flux.reshape(-1, 1)))
         rgb = mc.hsv_to_rgb(hsv).reshape(-1, 3)
-        ref2 += np.histogram2d(y, x, bins=[36, 40], range=[[-250, 250], [-0.8, 0.8]],
+        ref2 += np.histogram2d(y, x, bins=[by, bx], range=[[-250, 250], [-0.8, 0.8]],
                                weights=flux)[0]
         for k in range(3):
             ref2rgb[:, :, k] += np.histogram2d(
-                y, x, bins=[36, 40], range=[[-250, 250], [-0.8, 0.8]],
+                y, x, bins=[by, bx], range=[[-250, 250], [-0.8, 0.8]],
                 weights=rgb[:, k])[0]
-        for key, v, n, lim in (('x', x, 40, (-0.8, 0.8)), ('y', y, 36, (-250, 250)),
-                               ('c', c, 50, (8992., 9008.))):
+        for key, v, n, lim in (('x', x, bx, (-0.8, 0.8)), ('y', y, by, (-250, 250)),
+                               ('c', c, bc, (8992., 9008.))):
             r1[key][:, 0] += np.histogram(v, bins=n, range=lim, weights=flux)[0]
             for k in range(3):
                 r1[key][:, 1 + k] += np.histogram(v, bins=n, range=lim,

@@ -1,0 +1,22 @@
+"""Time of the per-plot histogram reduce (N2) on 1e7 rays: PYTHONPATH=. python tools/probe_hist.py"""
+import time
+import torch
+from xrt_amd import workloads, plotter as xrtp, runner
+
+n = 10_000_000
+oe = workloads.cfg2_toroid()
+beam = workloads.synthetic_rays(n, 42)
+for f in beam.array_fields():
+    beam.dev(f)
+gb, lb = oe.reflect(beam)
+for name, b, xa, ya in (('footprint', lb, 'x', 'y'), ('global xz', gb, 'x', 'z')):
+    plot = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis(xa, 'mm', bins=128), xrtp.XYCAxis(ya, 'mm', bins=128),
+                        caxis=xrtp.XYCAxis('energy', 'eV', bins=128))
+    runner.accumulate_plot(plot, {'b': b})          # sets the limits
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        runner.accumulate_plot(plot, {'b': b})
+    torch.cuda.synchronize()
+    print('%-10s %.2f ms per accumulate_plot (host glue included), selected %d' % (
+        name, (time.perf_counter() - t0) / 5 * 1e3, plot.nRaysSelected))

@@ -115,89 +115,216 @@ __device__ __forceinline__ void hsv_to_rgb(double h, double s, double v, double&
   if (s == 0.) r = g = b = v;
 }
 
+// what one ray contributes to the histograms of a plot
+struct PlotRay {
+  int sel;             // selected by ray_flags
+  int ix, iy, ic;      // bins (-1: outside the axis range)
+  double w, rgb[3];
+};
+
+__device__ __forceinline__ void count_state(int st, double (&c)[8]) {
+  if (st > 0) c[3] += 1.;
+  if (st == 1) c[4] += 1.;
+  if (st == 2) c[5] += 1.;
+  if (st == 3) c[6] += 1.;
+  if (st < 0) c[7] += 1.;
+}
+
+__device__ __forceinline__ PlotRay plot_ray(const xrt_hip_beam& beam, const double* x,
+                                            const double* y, const double* cd,
+                                            const xrt_hip_plot& P, int64_t i, int st,
+                                            bool want_c) {
+  PlotRay r;
+  r.ix = r.iy = r.ic = -1;
+  r.w = 0.;
+  r.rgb[0] = r.rgb[1] = r.rgb[2] = 0.;
+  bool sel = false;
+  if ((P.ray_flags & 1) && st == 1) sel = true;
+  if ((P.ray_flags & 2) && st == 2) sel = true;
+  if ((P.ray_flags & 4) && st == 3) sel = true;
+  if ((P.ray_flags & 8) && st < 0) sel = true;
+  if ((P.ray_flags & 16) && st > 0) sel = true;
+  r.sel = sel;
+  if (!sel) return r;
+  double w;
+  if (P.flux_kind == 1)
+    w = beam.Jss[i];
+  else if (P.flux_kind == 2)
+    w = beam.Jpp[i];
+  else if (P.flux_kind == 3)
+    w = 2. * beam.Jsp_ri[2 * i];
+  else if (P.flux_kind == 4)
+    w = 2. * beam.Jsp_ri[2 * i + 1];
+  else if (P.flux_kind == 5)
+    w = (beam.Jss[i] + beam.Jpp[i]) * beam.E[i] * 1.602176565e-19;
+  else
+    w = beam.Jss[i] + beam.Jpp[i];
+  w *= P.source_weight;
+  r.w = w;
+  const double cv = cd[i] * P.c_factor;
+  double h01 = ((cv - P.c_lim[0]) * P.color_factor) / (P.c_lim[1] - P.c_lim[0]);
+  if (h01 < 0.) h01 = 0.;
+  if (h01 > 1.) h01 = 1.;
+  hsv_to_rgb(h01, P.color_saturation, w, r.rgb[0], r.rgb[1], r.rgb[2]);
+  r.ix = find_bin(x[i] * P.x_factor, P.x_lim[0], P.x_lim[1], P.bins_x);
+  r.iy = find_bin(y[i] * P.y_factor, P.y_lim[0], P.y_lim[1], P.bins_y);
+  if (want_c) r.ic = find_bin(cv, P.c_lim[0], P.c_lim[1], P.bins_c);
+  return r;
+}
+
+__device__ __forceinline__ void flush_counters(double (&c)[8], double* counters,
+                                               double (*lds)[16]) {
+  const int nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double v = c[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) lds[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double v = 0.;
+    for (int w = 0; w < nw; ++w) v += lds[threadIdx.x][w];
+    if (v != 0.) atomicAdd(&counters[threadIdx.x], v);
+  }
+}
+
+// General form: one fp64 global atomic per ray and histogram cell. `parts` selects
+// the 2-D histograms (1) and/or the 1-D histograms with the counters (2): it serves
+// whatever does not fit the LDS-privatised kernels below.
 __global__ __launch_bounds__(256) void plot_hist_kernel(
     xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
     const double* __restrict__ cd, xrt_hip_plot P, double* __restrict__ h2,
     double* __restrict__ h2rgb, double* __restrict__ hx, double* __restrict__ hy,
-    double* __restrict__ hc, double* __restrict__ counters) {
-  __shared__ double lds[8][4];
+    double* __restrict__ hc, double* __restrict__ counters, int parts) {
+  __shared__ double lds[8][16];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (i < beam.n) {
     const int st = beam.state[i];
-    if (st > 0) c[3] = 1.;
-    if (st == 1) c[4] = 1.;
-    if (st == 2) c[5] = 1.;
-    if (st == 3) c[6] = 1.;
-    if (st < 0) c[7] = 1.;
-    bool sel = false;
-    if ((P.ray_flags & 1) && st == 1) sel = true;
-    if ((P.ray_flags & 2) && st == 2) sel = true;
-    if ((P.ray_flags & 4) && st == 3) sel = true;
-    if ((P.ray_flags & 8) && st < 0) sel = true;
-    if ((P.ray_flags & 16) && st > 0) sel = true;
-    if (sel) {
-      double w;
-      if (P.flux_kind == 1)
-        w = beam.Jss[i];
-      else if (P.flux_kind == 2)
-        w = beam.Jpp[i];
-      else if (P.flux_kind == 3)
-        w = 2. * beam.Jsp_ri[2 * i];
-      else if (P.flux_kind == 4)
-        w = 2. * beam.Jsp_ri[2 * i + 1];
-      else if (P.flux_kind == 5)
-        w = (beam.Jss[i] + beam.Jpp[i]) * beam.E[i] * 1.602176565e-19;
-      else
-        w = beam.Jss[i] + beam.Jpp[i];
-      w *= P.source_weight;
+    count_state(st, c);
+    const PlotRay r = plot_ray(beam, x, y, cd, P, i, st, hc != nullptr);
+    if (r.sel) {
       c[0] = 1.;
-      c[1] = w;
-      const double cv = cd[i] * P.c_factor;
-      double h01 = ((cv - P.c_lim[0]) * P.color_factor) / (P.c_lim[1] - P.c_lim[0]);
-      if (h01 < 0.) h01 = 0.;
-      if (h01 > 1.) h01 = 1.;
-      double rgb[3];
-      hsv_to_rgb(h01, P.color_saturation, w, rgb[0], rgb[1], rgb[2]);
-      const int ix = find_bin(x[i] * P.x_factor, P.x_lim[0], P.x_lim[1], P.bins_x);
-      const int iy = find_bin(y[i] * P.y_factor, P.y_lim[0], P.y_lim[1], P.bins_y);
-      if (ix >= 0 && iy >= 0) {
-        c[2] = w;
-        const int64_t b = (int64_t)iy * P.bins_x + ix;
-        atomicAdd(&h2[b], w);
-        if (h2rgb)
-          for (int k = 0; k < 3; ++k) atomicAdd(&h2rgb[3 * b + k], rgb[k]);
+      c[1] = r.w;
+      if (r.ix >= 0 && r.iy >= 0) {
+        c[2] = r.w;
+        if (parts & 1) {
+          const int64_t b = (int64_t)r.iy * P.bins_x + r.ix;
+          atomicAdd(&h2[b], r.w);
+          if (h2rgb)
+            for (int k = 0; k < 3; ++k) atomicAdd(&h2rgb[3 * b + k], r.rgb[k]);
+        }
       }
-      if (hx && ix >= 0) {
-        atomicAdd(&hx[4 * ix], w);
-        for (int k = 0; k < 3; ++k) atomicAdd(&hx[4 * ix + 1 + k], rgb[k]);
-      }
-      if (hy && iy >= 0) {
-        atomicAdd(&hy[4 * iy], w);
-        for (int k = 0; k < 3; ++k) atomicAdd(&hy[4 * iy + 1 + k], rgb[k]);
-      }
-      if (hc) {
-        const int ic = find_bin(cv, P.c_lim[0], P.c_lim[1], P.bins_c);
-        if (ic >= 0) {
-          atomicAdd(&hc[4 * ic], w);
-          for (int k = 0; k < 3; ++k) atomicAdd(&hc[4 * ic + 1 + k], rgb[k]);
+      if (parts & 2) {
+        if (hx && r.ix >= 0) {
+          atomicAdd(&hx[4 * r.ix], r.w);
+          for (int k = 0; k < 3; ++k) atomicAdd(&hx[4 * r.ix + 1 + k], r.rgb[k]);
+        }
+        if (hy && r.iy >= 0) {
+          atomicAdd(&hy[4 * r.iy], r.w);
+          for (int k = 0; k < 3; ++k) atomicAdd(&hy[4 * r.iy + 1 + k], r.rgb[k]);
+        }
+        if (hc && r.ic >= 0) {
+          atomicAdd(&hc[4 * r.ic], r.w);
+          for (int k = 0; k < 3; ++k) atomicAdd(&hc[4 * r.ic + 1 + k], r.rgb[k]);
         }
       }
     }
   }
-  if (counters) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      double v = c[k];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if ((threadIdx.x & 63) == 0) lds[k][threadIdx.x >> 6] = v;
+  if (counters && (parts & 2)) flush_counters(c, counters, lds);
+}
+
+// ---------------------------------------------------------------------------
+// LDS-privatised forms. With global atomics only, 1e7 rays issue 1.6e8 fp64 atomics,
+// most of them onto the few hundred cells of the 1-D histograms: 27 ms measured, 35x
+// the reflect pass that produced the beam. Here every block keeps its own copy of
+// the cells in LDS (ds_add_f64), strides over the beam and adds its non-zero cells to
+// the global arrays once.
+//   plot_hist1d_lds: the three 1-D histograms (4 values per bin) + the counters;
+//   plot_hist2d_lds: `nch` of the four 2-D channels (flux, R, G, B) from `ch0` on, one
+//     [by][bx] plane each in up to 128 KB of LDS, one block per CU, 1024 lanes; a
+//     128 x 128 plot takes four passes over (x, y, c, state, J): 1.8 GB, not atomics.
+// ---------------------------------------------------------------------------
+#define HIST_LDS_BUDGET (128 * 1024)
+
+__global__ __launch_bounds__(256) void plot_hist1d_lds(
+    xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
+    const double* __restrict__ cd, xrt_hip_plot P, double* __restrict__ hx,
+    double* __restrict__ hy, double* __restrict__ hc, double* __restrict__ counters) {
+  extern __shared__ double cells[];     // [bx*4 | by*4 | bc*4]
+  __shared__ double lds[8][16];
+  const int nx = hx ? 4 * P.bins_x : 0, ny = hy ? 4 * P.bins_y : 0;
+  const int nc = hc ? 4 * P.bins_c : 0;
+  double* lx = cells;
+  double* ly = cells + nx;
+  double* lc = ly + ny;
+  for (int k = threadIdx.x; k < nx + ny + nc; k += blockDim.x) cells[k] = 0.;
+  __syncthreads();
+  double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < beam.n; i += stride) {
+    const int st = beam.state[i];
+    count_state(st, c);
+    const PlotRay r = plot_ray(beam, x, y, cd, P, i, st, hc != nullptr);
+    if (!r.sel) continue;
+    c[0] += 1.;
+    c[1] += r.w;
+    if (r.ix >= 0 && r.iy >= 0) c[2] += r.w;
+    if (hx && r.ix >= 0) {
+      atomicAdd(&lx[4 * r.ix], r.w);
+      for (int k = 0; k < 3; ++k) atomicAdd(&lx[4 * r.ix + 1 + k], r.rgb[k]);
     }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-      const double v = lds[threadIdx.x][0] + lds[threadIdx.x][1] + lds[threadIdx.x][2] +
-                       lds[threadIdx.x][3];
-      if (v != 0.) atomicAdd(&counters[threadIdx.x], v);
+    if (hy && r.iy >= 0) {
+      atomicAdd(&ly[4 * r.iy], r.w);
+      for (int k = 0; k < 3; ++k) atomicAdd(&ly[4 * r.iy + 1 + k], r.rgb[k]);
+    }
+    if (hc && r.ic >= 0) {
+      atomicAdd(&lc[4 * r.ic], r.w);
+      for (int k = 0; k < 3; ++k) atomicAdd(&lc[4 * r.ic + 1 + k], r.rgb[k]);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nx; k += blockDim.x)
+    if (lx[k] != 0.) atomicAdd(&hx[k], lx[k]);
+  for (int k = threadIdx.x; k < ny; k += blockDim.x)
+    if (ly[k] != 0.) atomicAdd(&hy[k], ly[k]);
+  for (int k = threadIdx.x; k < nc; k += blockDim.x)
+    if (lc[k] != 0.) atomicAdd(&hc[k], lc[k]);
+  if (counters) flush_counters(c, counters, lds);
+}
+
+__global__ __launch_bounds__(1024) void plot_hist2d_lds(
+    xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
+    const double* __restrict__ cd, xrt_hip_plot P, double* __restrict__ h2,
+    double* __restrict__ h2rgb, int ch0, int nch) {
+  extern __shared__ double cells[];     // [nch][by][bx]
+  const int plane = P.bins_x * P.bins_y;
+  for (int k = threadIdx.x; k < nch * plane; k += blockDim.x) cells[k] = 0.;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < beam.n; i += stride) {
+    const int st = beam.state[i];
+    const PlotRay r = plot_ray(beam, x, y, cd, P, i, st, false);
+    if (!r.sel || r.ix < 0 || r.iy < 0) continue;
+    const int b = r.iy * P.bins_x + r.ix;
+    for (int k = 0; k < nch; ++k) {
+      const int ch = ch0 + k;
+      const double v = ch == 0 ? r.w : r.rgb[ch - 1];
+      if (v != 0.) atomicAdd(&cells[k * plane + b], v);
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < nch; ++k) {
+    const int ch = ch0 + k;
+    for (int b = threadIdx.x; b < plane; b += blockDim.x) {
+      const double v = cells[k * plane + b];
+      if (v == 0.) continue;
+      if (ch == 0)
+        atomicAdd(&h2[b], v);
+      else
+        atomicAdd(&h2rgb[3 * (int64_t)b + ch - 1], v);
     }
   }
 }
@@ -207,8 +334,45 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
                             double* hx, double* hy, double* hc, double* counters,
                             hipStream_t st) {
   if (beam.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(plot_hist_kernel, dim3((unsigned)((beam.n + 255) / 256)), dim3(256), 0, st,
-                     beam, x, y, c, P, h2, h2rgb, hx, hy, hc, counters);
+  const dim3 full((unsigned)((beam.n + 255) / 256));
+  int general = 0;   // parts left to the global-atomics kernel
+  // 1-D histograms + counters
+  const size_t b1 = sizeof(double) * 4 *
+                    ((hx ? P.bins_x : 0) + (hy ? P.bins_y : 0) + (hc ? P.bins_c : 0));
+  if (b1 <= 48 * 1024) {
+    unsigned blocks = full.x < 2048u ? full.x : 2048u;
+    hipLaunchKernelGGL(plot_hist1d_lds, dim3(blocks), dim3(256), b1, st, beam, x, y, c, P, hx, hy,
+                       hc, counters);
+  } else {
+    general |= 2;
+  }
+  // 2-D histograms: as many of the (flux, R, G, B) planes per pass as fit the LDS
+  const size_t plane = sizeof(double) * (size_t)P.bins_x * (size_t)P.bins_y;
+  const int nchan = h2rgb ? 4 : 1;
+  if (plane > 0 && plane <= HIST_LDS_BUDGET) {
+    // (per device; cheap enough to repeat on every call)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plot_hist2d_lds),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       HIST_LDS_BUDGET);
+    if (e != hipSuccess) return e;
+    int per_pass = (int)(HIST_LDS_BUDGET / plane);
+    if (per_pass > nchan) per_pass = nchan;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    unsigned blocks = (unsigned)((beam.n + 1023) / 1024);
+    if (blocks > (unsigned)cus) blocks = (unsigned)cus;   // one 128-KB block per CU
+    for (int ch0 = 0; ch0 < nchan; ch0 += per_pass) {
+      const int nch = ch0 + per_pass <= nchan ? per_pass : nchan - ch0;
+      hipLaunchKernelGGL(plot_hist2d_lds, dim3(blocks), dim3(1024), nch * plane, st, beam, x, y,
+                         c, P, h2, h2rgb, ch0, nch);
+    }
+  } else if (plane > 0) {
+    general |= 1;
+  }
+  if (general)
+    hipLaunchKernelGGL(plot_hist_kernel, full, dim3(256), 0, st, beam, x, y, c, P, h2, h2rgb, hx,
+                       hy, hc, counters, general);
   return hipGetLastError();
 }
 
@@ -217,6 +381,30 @@ hipError_t hist2d_launch(const xrt_hip_beam& beam, const double* x, const double
                          double xlo, double xhi, int by, double ylo, double yhi, double* hist,
                          double* counters, hipStream_t st) {
   if (beam.n <= 0) return hipSuccess;
+  const size_t plane = sizeof(double) * (size_t)bx * (size_t)by;
+  if (plane > 0 && plane <= HIST_LDS_BUDGET) {
+    // the flux plane of a plot without colour axis: same LDS-privatised kernels
+    xrt_hip_plot P;
+    P.x_factor = xf;
+    P.y_factor = yf;
+    P.c_factor = 0.;
+    P.source_weight = srcw;
+    P.x_lim[0] = xlo;
+    P.x_lim[1] = xhi;
+    P.y_lim[0] = ylo;
+    P.y_lim[1] = yhi;
+    P.c_lim[0] = 0.;
+    P.c_lim[1] = 1.;
+    P.color_factor = 0.;
+    P.color_saturation = 0.;
+    P.bins_x = bx;
+    P.bins_y = by;
+    P.bins_c = 1;
+    P.ray_flags = ray_flags;
+    P.flux_kind = flux_kind;
+    return plot_hist_launch(beam, x, y, x, P, hist, nullptr, nullptr, nullptr, nullptr, counters,
+                            st);
+  }
   hipLaunchKernelGGL(hist2d_kernel, dim3((unsigned)((beam.n + 255) / 256)), dim3(256), 0, st,
                      beam, x, y, xf, yf, ray_flags, flux_kind, srcw, bx, xlo, xhi, by, ylo, yhi,
                      hist, counters);
