@@ -158,7 +158,7 @@ def test_random_elements_match_oracle(kind, seed):
 
 
 @pytest.mark.parametrize('seed', range(8))
-def test_random_dcm_matches_oracle(seed):
+def test_random_dcm_matches_oracle(seed, monkeypatch):
     """Double-crystal monochromators: random Bragg energy, (hkl), asymmetric cut,
     second-crystal translations and fine pitch, azimuth; the fan carries states
     that miss either crystal."""
@@ -220,6 +220,10 @@ def test_random_dcm_matches_oracle(seed):
             assert np.abs(getattr(mine, f) - getattr(ref, f)).max() <= 1e-9 * scale, \
                 (tag, f)
     assert (o2.state == 1).sum() > 200, (hkl, E0, thB)
+    # the exact kernel sequence (both passes) gives the same bits as the single passes
+    monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
+    for mine, exact in zip((gb2, lo1, lo2), dcm.double_reflect(beam)):
+        _same_bits(mine, exact)
 
 
 @pytest.mark.parametrize('alpha_deg,expect_mixed', [(3., True), (-3., False),
