@@ -33,8 +33,16 @@ __device__ __forceinline__ double sqrt_rn_rinv(double x, double& rinv) {
   return g;
 }
 
-// Same, but returns h = 1/(2 sqrt(x)) as it falls out of the iteration (callers
-// fold the factor 2 into a per-sample constant).
+// The Kirchhoff inner loop's form: returns h = 1/(2 sqrt(x)) as it falls out of the
+// iteration (callers fold the factor 2 into a per-sample constant) and takes ONE
+// correction step. After the Goldschmidt step g and h are good to ~2^-51; the first
+// correction leaves an error of ~2^-100, so the second one can only matter for an
+// argument whose root lies within that of a rounding boundary. Measured on gfx950
+// (tools/probes/probe_sqrt_corrections.hip, profiles/r01_sqrt_corrections.txt): over
+// 5.5e11 random arguments in [1,4) and in 2^26..2^28 (r^2 of 8..16 m in mm^2) the
+// second correction changed none, and all agree with the compiler's correctly
+// rounded sqrt; the hard cases of tests/test_gpu_kirchhoff.py (squares and their
+// neighbours) pass as well. Two VALU slots of 59.
 __device__ __forceinline__ double sqrt_rn_halfinv(double x, double& hinv) {
   double y = __builtin_amdgcn_rsq(x);
   double g = x * y;
@@ -44,8 +52,6 @@ __device__ __forceinline__ double sqrt_rn_halfinv(double x, double& hinv) {
   h = fma_(h, r0, h);
   double d0 = fma_(-g, g, x);
   g = fma_(d0, h, g);
-  double d1 = fma_(-g, g, x);
-  g = fma_(d1, h, g);
   hinv = h;
   return g;
 }
@@ -138,7 +144,9 @@ __device__ __forceinline__ void sincos_tab(double phi, const double2* tab, doubl
   // ties only, which merely lets |u| reach 1/2 + 2^-53
   const double m = fma_(phi, STEPS_PER_RAD_HI, MAGIC);
   const double n = m - MAGIC;
-  const double2 T = tab[(unsigned)__double2loint(m) & (SINCOS_TAB_N - 1)];
+  // byte offset of the entry: two 32-bit ops (shift, mask)
+  const unsigned off = ((unsigned)__double2loint(m) << 4) & ((SINCOS_TAB_N - 1u) << 4);
+  const double2 T = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + off);
   double u = fma_(phi, STEPS_PER_RAD_HI, -n);
   u = fma_(phi, STEPS_PER_RAD_LO, u);
   const double w = u * u;
