@@ -132,26 +132,45 @@ __device__ __forceinline__ void sincos_tab_fill(double2* tab) {
   __syncthreads();
 }
 
-__device__ __forceinline__ void sincos_tab(double phi, const double2* tab, double& sn,
-                                           double& cs) {
+// Two of the polynomial constants, parked in VGPRs. A VOP3 instruction reads at most
+// one SGPR / literal: fma(S1, w, S0) and fma(C2, w, C1) need one of their constants in
+// a VGPR, and the compiler re-materialises those with a v_mov in every loop iteration
+// unless they are opaque to it. One instance per kernel, made before the loop.
+struct SinCosTabRegs {
+  double s0, c1;
+  __device__ __forceinline__ SinCosTabRegs() {
+    constexpr double DELTA = 0x1.921fb54442d18p+1 * (2.0 / SINCOS_TAB_N);
+    const double S0 = DELTA, C1 = -(DELTA * DELTA) / 2.0;
+    asm volatile("v_mov_b64 %0, %1" : "=v"(s0) : "s"(S0));
+    asm volatile("v_mov_b64 %0, %1" : "=v"(c1) : "s"(C1));
+  }
+};
+
+__device__ __forceinline__ void sincos_tab(double phi, const double2* tab,
+                                           const SinCosTabRegs& k, double& sn, double& cs) {
   constexpr double STEPS_PER_RAD_HI = 0x1.45f306dc9c883p-1 * (SINCOS_TAB_N / 4);
   constexpr double STEPS_PER_RAD_LO = -0x1.6b01ec5417056p-55 * (SINCOS_TAB_N / 4);
   constexpr double DELTA = 0x1.921fb54442d18p+1 * (2.0 / SINCOS_TAB_N);
-  constexpr double S0 = DELTA, S1 = -(DELTA * DELTA * DELTA) / 6.0;
-  constexpr double C1 = -(DELTA * DELTA) / 2.0, C2 = (DELTA * DELTA) * (DELTA * DELTA) / 24.0;
+  constexpr double S1 = -(DELTA * DELTA * DELTA) / 6.0;
+  constexpr double C2 = (DELTA * DELTA) * (DELTA * DELTA) / 24.0;
   const double MAGIC = 0x1.8p52;
   // one rounding instead of numpy-style two: n may differ from rint(t) on exact
   // ties only, which merely lets |u| reach 1/2 + 2^-53
   const double m = fma_(phi, STEPS_PER_RAD_HI, MAGIC);
   const double n = m - MAGIC;
   // byte offset of the entry: two 32-bit ops (shift, mask)
-  const unsigned off = ((unsigned)__double2loint(m) << 4) & ((SINCOS_TAB_N - 1u) << 4);
+  // (asm: left to itself the compiler SLP-packs the shifts of two pairs into five ops)
+  unsigned off;
+  asm("v_lshlrev_b32 %0, 4, %1\n\tv_and_b32 %0, 0x7ff0, %0"
+      : "=v"(off)
+      : "v"((unsigned)__double2loint(m)));
+  static_assert(SINCOS_TAB_N == 2048, "mask 0x7ff0 = (N - 1) << 4");
   const double2 T = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + off);
   double u = fma_(phi, STEPS_PER_RAD_HI, -n);
   u = fma_(phi, STEPS_PER_RAD_LO, u);
   const double w = u * u;
-  const double s = fma_(S1, w, S0) * u;
-  const double c = fma_(fma_(C2, w, C1), w, 1.0);
+  const double s = fma_(S1, w, k.s0) * u;
+  const double c = fma_(fma_(C2, w, k.c1), w, 1.0);
   cs = T.x * c;
   cs = fma_(-T.y, s, cs);
   sn = T.y * c;
@@ -160,10 +179,10 @@ __device__ __forceinline__ void sincos_tab(double phi, const double2* tab, doubl
 
 // table form where its bound holds, the general polynomial form otherwise (the
 // branch is taken per lane; a wave whose lanes all qualify skips the slow side)
-__device__ __forceinline__ void sincos_any(double phi, const double2* tab, double& sn,
-                                           double& cs) {
+__device__ __forceinline__ void sincos_any(double phi, const double2* tab,
+                                           const SinCosTabRegs& k, double& sn, double& cs) {
   if (__builtin_fabs(phi) < 0x1p42)
-    sincos_tab(phi, tab, sn, cs);
+    sincos_tab(phi, tab, k, sn, cs);
   else
     sincos_phase(phi, sn, cs);
 }

@@ -118,7 +118,7 @@ struct Mid {
 template <bool GEN_N, bool TAB>
 __device__ __forceinline__ Mid pair_head(double px, double py, double pz,
                                          const double (&r)[KIRCHHOFF_REC_DOUBLES],
-                                         const double2* tab) {
+                                         const double2* tab, const SinCosTabRegs& kreg) {
   const double sx = r[0], sy = r[1], sz = r[2], knl = r[3];
   const double kny = r[4], k = r[5], knx = r[9], knz = r[10];
   Mid m;
@@ -142,7 +142,7 @@ __device__ __forceinline__ Mid pair_head(double px, double py, double pz,
   const double cr = m.h * fma_(dn, m.h, knl);     // (k/r)(d.n/r + nl)
   double sn, cs;
   if (TAB)
-    sincos_tab(phase, tab, sn, cs);
+    sincos_tab(phase, tab, kreg, sn, cs);
   else
     sincos_phase(phase, sn, cs);
   m.gr = cr * cs;
@@ -260,13 +260,14 @@ struct SRec<true> {    // the whole 128-byte record
 template <int PPT, bool HAS_P, bool GEN_N, bool TAB, class R>
 __device__ __forceinline__ void stream_step(const double (&x)[PPT], const double (&y)[PPT],
                                             const double (&z)[PPT], Acc (&acc)[PPT],
-                                            const double2* tab, const R& cur, R* landed,
-                                            R& fetch, const double* pnext) {
+                                            const double2* tab, const SinCosTabRegs& kreg,
+                                            const R& cur, R* landed, R& fetch,
+                                            const double* pnext) {
   double r[KIRCHHOFF_REC_DOUBLES];
   cur.unpack(r);
   Mid m[PPT];
 #pragma unroll
-  for (int j = 0; j < PPT; ++j) m[j] = pair_head<GEN_N, TAB>(x[j], y[j], z[j], r, tab);
+  for (int j = 0; j < PPT; ++j) m[j] = pair_head<GEN_N, TAB>(x[j], y[j], z[j], r, tab, kreg);
   __builtin_amdgcn_sched_barrier(0);
   if (landed) landed->settle();
   fetch.issue(pnext);
@@ -281,6 +282,7 @@ __device__ __forceinline__ void stream_loop(const double (&x)[PPT], const double
                                             const double* __restrict__ rec,
                                             const double2* tab, int s0, int s1) {
   if (s0 >= s1) return;
+  const SinCosTabRegs kreg;
   constexpr bool FULL = HAS_P || GEN_N;
   typedef SRec<FULL> R;
   const double* p = rec + (int64_t)s0 * KIRCHHOFF_REC_DOUBLES;
@@ -294,12 +296,12 @@ __device__ __forceinline__ void stream_loop(const double (&x)[PPT], const double
     A.issue(p);
     A.settle();
     for (;;) {
-      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, A, nullptr, B,
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, kreg, A, nullptr, B,
                                              KIRCHHOFF_AHEAD(p, 1));
       B.settle();
       if (--left == 0) break;
       p += KIRCHHOFF_REC_DOUBLES;
-      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, B, nullptr, A,
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, kreg, B, nullptr, A,
                                              KIRCHHOFF_AHEAD(p, 1));
       A.settle();
       if (--left == 0) break;
@@ -313,15 +315,15 @@ __device__ __forceinline__ void stream_loop(const double (&x)[PPT], const double
     B.issue(KIRCHHOFF_AHEAD(p, 1));
     A.settle();   // lgkmcnt(0): B has landed as well
     for (;;) {
-      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, A, &B, C,
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, kreg, A, &B, C,
                                              KIRCHHOFF_AHEAD(p, 2));
       if (--left == 0) break;
       p += KIRCHHOFF_REC_DOUBLES;
-      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, B, &C, A,
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, kreg, B, &C, A,
                                              KIRCHHOFF_AHEAD(p, 2));
       if (--left == 0) break;
       p += KIRCHHOFF_REC_DOUBLES;
-      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, C, &A, B,
+      stream_step<PPT, HAS_P, GEN_N, TAB, R>(x, y, z, acc, tab, kreg, C, &A, B,
                                              KIRCHHOFF_AHEAD(p, 2));
       if (--left == 0) break;
       p += KIRCHHOFF_REC_DOUBLES;
@@ -485,7 +487,8 @@ __global__ __launch_bounds__(256) void debug_sincos_tab_kernel(
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double s, c;
-  sincos_tab(phi[i], tab, s, c);
+  const SinCosTabRegs kreg;
+  sincos_tab(phi[i], tab, kreg, s, c);
   sn[i] = s;
   cs[i] = c;
 }

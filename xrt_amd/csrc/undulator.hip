@@ -69,6 +69,7 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
                                         const double2* tab, double g, double wu, double w,
                                         double ww1, double phi, double psi, double2& out_s,
                                         double2& out_p) {
+  const SinCosTabRegs kreg;
   const double Kx = a.Kx, Ky = a.Ky;
   const double kx2 = Kx * Kx, ky2 = Ky * Ky;
   const double revg = 1. / g;
@@ -114,7 +115,7 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
       if (MODE == UND_FAR) {
         double A = (nky_dx * s + kx_dy * sp) + e8 * r[N_SUM2];
         double ucos = ww1 * tg + wwug * A;
-        sincos_any(ucos, tab, ei, er);
+        sincos_any(ucos, tab, kreg, ei, er);
         betax = kyg * c;
         bPx = r[N_BPX];
         bPz = h2 * r[N_SUM2];
@@ -128,7 +129,7 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
         double T2 = kx_dy * s;                                // sic: sintg, not sintgph
         double T3 = e8 * (r[N_KX2S2XPH] + ky2 * (s2x - aw2 * u2));
         double ucos = ww1 * zloc + wwug * ((T1 + T2) + T3);
-        sincos_any(ucos, tab, ei, er);
+        sincos_any(ucos, tab, kreg, ei, er);
         betax = ((taperC * Ky) * revg) * c;
         bPx = (-Ky) * (a.alpha_s * c + taperC * s);
         bPz = h2 * ((ky2 * taperC) * (a.alpha_s * r[N_C2] + taperC * s2x) + r[N_KX2S2XPH]);
@@ -144,8 +145,8 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
         double dist = __builtin_sqrt(dxy + drz * drz);
         double drs = (0.5 * dxy) / drz;
         double sz, cz, sd, cd;
-        sincos_any((wwu * zloc) * omb, tab, sz, cz);
-        sincos_any(wwu * (drs + q4), tab, sd, cd);
+        sincos_any((wwu * zloc) * omb, tab, kreg, sz, cz);
+        sincos_any(wwu * (drs + q4), tab, kreg, sd, cd);
         er = ((((-sr0) * sz) * cd - (sr0 * cz) * sd) - (cr0 * sz) * sd) + (cr0 * cz) * cd;
         ei = ((((-sr0) * sz) * sd + (sr0 * cz) * cd) + (cr0 * sz) * cd) + (cr0 * cz) * sd;
         dirx = drx / dist;
@@ -278,6 +279,7 @@ cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
   sincos_tab_fill(tab);
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const SinCosTabRegs kreg;
   const double emcg = emcg_[i], w = w_[i], phi = ddphi[i], psi = ddpsi[i];
   const double g = FIL ? gamma[0] : gamma[i];
   double dirx = phi, diry = psi;
@@ -325,8 +327,8 @@ cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
       const double LRS = (0.5 * drs - (0.125 * (drs * drs)) * rdrz) +
                          (0.0625 * pow(drs, 3.)) * (rdrz * rdrz);
       double sz, cz, sd, cd;
-      sincos_any(wc * (tg - tz), tab, sz, cz);
-      sincos_any(wc * LRS, tab, sd, cd);
+      sincos_any(wc * (tg - tz), tab, kreg, sz, cz);
+      sincos_any(wc * LRS, tab, kreg, sd, cd);
       er = ((((-sr0) * sz) * cd - (sr0 * cz) * sd) - (cr0 * sz) * sd) + (cr0 * cz) * cd;
       ei = ((((-sr0) * sz) * sd + (sr0 * cz) * cd) + (cr0 * sz) * cd) + (cr0 * cz) * sd;
       dirx = drx / dist;
@@ -334,8 +336,8 @@ cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
       dirz = drz / dist;
     } else {
       double s1, c1, s2, c2;
-      sincos_any(wc * (tg - dirz * tz), tab, s1, c1);
-      sincos_any(wc * (dirx * tx + diry * ty), tab, s2, c2);
+      sincos_any(wc * (tg - dirz * tz), tab, kreg, s1, c1);
+      sincos_any(wc * (dirx * tx + diry * ty), tab, kreg, s2, c2);
       er = s1 * c2 - c1 * s2;
       ei = c1 * c2 + s1 * s2;
     }
