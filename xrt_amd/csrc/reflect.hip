@@ -1558,7 +1558,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       const double ndsn = n[0] * n[3] + n[1] * n[4] + n[2] * n[5];
       // sign of the batch mean of beamInDotNormal (reflect.py:573-574). In the
       // optimistic single pass (own_sign) every ray uses its own sign: identical
-      // whenever all rays of the batch agree, which reflect_reduce_sign verifies.
+      // whenever all rays of the batch agree, which the any_neg / any_pos flags verify.
       const double bdnMean = own_sign ? bdn : g.sum_bdn / (double)g.n_good1;
       const double sgbdn = bdnMean < 0. ? 1. : -1.;
       const double wHd = 1. / (M.d * 1e-7);
