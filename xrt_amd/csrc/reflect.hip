@@ -1938,8 +1938,12 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   }
 }
 
+// The redo (mode 1) runs in 1024-lane blocks: in the usual case that it has nothing to
+// do, 9 800 blocks are dispatched and return in 4 us instead of 39 000 in 15 us.
+#define REFLECT_REDO_BLOCK 1024
 template <class K, int mode>
-__global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
+__global__ __launch_bounds__(mode == 1 ? REFLECT_REDO_BLOCK : REFLECT_BLOCK,
+                             mode == 1 ? 1 : K::WAVES) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     OptStat* __restrict__ opt) {
@@ -1961,7 +1965,8 @@ __global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
 // two-pass sequence that follows in the stream returns at once unless both are up.
 // ---------------------------------------------------------------------------
 template <class K, int mode>
-__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_xtal(
+__global__ __launch_bounds__(mode == 1 ? REFLECT_REDO_BLOCK : REFLECT_BLOCK,
+                             mode == 1 ? 1 : 4) void reflect_fused_xtal(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     int* __restrict__ any_neg_pos, OptStat* __restrict__ opt) {
@@ -2040,7 +2045,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
 }
 
 template <class K>
-__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_finish(
+__global__ __launch_bounds__(REFLECT_REDO_BLOCK, 1) void reflect_finish(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const double* ht, const double* hx,
     const double* hy, const double* hz, const int32_t* hst, const GStat* gp) {
@@ -2169,8 +2174,12 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   using FlatMirror = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_MIRROR, true>;
   using BentMirror = Spec<0, XRT_HIP_SURF_BENTFLAT, XRT_HIP_MAT_MIRROR, true>;
   // the solve + finish kernel of this (surface, material) in the given mode
+  const dim3 redo_block(REFLECT_REDO_BLOCK);
+  const dim3 redo_grid((unsigned)((n + REFLECT_REDO_BLOCK - 1) / REFLECT_REDO_BLOCK));
   auto launch_fused = [&](auto mode_tag) {
     constexpr int mode = decltype(mode_tag)::value;
+    const dim3 grid = mode == 1 ? redo_grid : dim3((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK));
+    const dim3 block = mode == 1 ? redo_block : dim3(REFLECT_BLOCK);
     if (need_mean) {
       // Bragg-reflecting crystals sit on flat surfaces in practice (DCM): that case is
       // compiled with the kinds fixed. Each ray takes its own sign of beamInDotNormal
@@ -2275,11 +2284,11 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                          g, part);
     hipLaunchKernelGGL(reflect_reduce_bdn, dim3(1), block, 0, st, part, (int)sgrid.x, g);
     if (flat_xtal)
-      hipLaunchKernelGGL(reflect_finish<FlatXtal>, grid, block, 0, st, P, M, in, restore, lb, vb,
-                         theta, ht, hx, hy, hz, hst, g);
+      hipLaunchKernelGGL(reflect_finish<FlatXtal>, redo_grid, redo_block, 0, st, P, M, in,
+                         restore, lb, vb, theta, ht, hx, hy, hz, hst, g);
     else
-      hipLaunchKernelGGL(reflect_finish<AnyXtal>, grid, block, 0, st, P, M, in, restore, lb, vb,
-                         theta, ht, hx, hy, hz, hst, g);
+      hipLaunchKernelGGL(reflect_finish<AnyXtal>, redo_grid, redo_block, 0, st, P, M, in,
+                         restore, lb, vb, theta, ht, hx, hy, hz, hst, g);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   return hipGetLastError();
