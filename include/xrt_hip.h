@@ -449,6 +449,19 @@ XRT_HIP_API int xrt_hip_custom_field_f64(
     const double* gamma, const double* w, const double* ddphi, const double* ddpsi,
     double* Is_ri, double* Ip_ri, float* kernel_ms);
 
+/* ---- timing without a host sync ------------------------------------------
+ * xrt_hip_reflect_time_next_pass arms the NEXT xrt_hip_reflect_pass_f64_dev call of
+ * this thread: it records pass_begin / pass_end around the whole pass and
+ * kernel_begin / kernel_end around its dominant kernel (the fused solve+finish) on
+ * the pass's stream and returns without waiting -- for measuring launch durations
+ * inside a pipelined loop (bench.py). Events come from xrt_hip_event_create;
+ * xrt_hip_event_elapsed_ms waits for `end`. Any of the four may be NULL. */
+XRT_HIP_API int xrt_hip_event_create(void** event);
+XRT_HIP_API int xrt_hip_event_destroy(void* event);
+XRT_HIP_API int xrt_hip_event_elapsed_ms(void* begin, void* end, float* ms);
+XRT_HIP_API int xrt_hip_reflect_time_next_pass(void* pass_begin, void* pass_end,
+                                   void* kernel_begin, void* kernel_end);
+
 /* ---- building-block checks (used by the GPU tests only) ---------------- */
 XRT_HIP_API int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,
                                void* stream);

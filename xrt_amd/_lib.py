@@ -65,6 +65,10 @@ SIGNATURES = {
     'xrt_hip_debug_divconst_f64_dev': (ctypes.c_int, [i64, vp, ctypes.c_double, vp, vp]),
     'xrt_hip_debug_sincos_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
     'xrt_hip_debug_sincos_tab_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
+    'xrt_hip_event_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    'xrt_hip_event_destroy': (ctypes.c_int, [vp]),
+    'xrt_hip_event_elapsed_ms': (ctypes.c_int, [vp, vp, ctypes.POINTER(ctypes.c_float)]),
+    'xrt_hip_reflect_time_next_pass': (ctypes.c_int, [vp, vp, vp, vp]),
 }
 
 

@@ -16,6 +16,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local hipEvent_t g_next_pass_events[4] = {nullptr, nullptr, nullptr, nullptr};
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -309,6 +310,13 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
                 xrt::reflect_workspace_bytes(n));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;
+  if (!kernel_ms) {   // armed by xrt_hip_reflect_time_next_pass: record, do not wait
+    e0 = g_next_pass_events[0];
+    e1 = g_next_pass_events[1];
+    k0 = g_next_pass_events[2];
+    k1 = g_next_pass_events[3];
+    for (hipEvent_t& ev : g_next_pass_events) ev = nullptr;
+  }
   if (kernel_ms) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -323,8 +331,9 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
                                           *out_virgin, theta, workspace, st, e0, e1, k0, k1,
                                           force_exact);
   if (e != hipSuccess) {
-    for (hipEvent_t ev : {e0, e1, k0, k1})
-      if (ev) (void)hipEventDestroy(ev);
+    if (kernel_ms)
+      for (hipEvent_t ev : {e0, e1, k0, k1})
+        if (ev) (void)hipEventDestroy(ev);
     return fail(XRT_HIP_ERR_HIP, "reflect launch: %s", hipGetErrorString(e));
   }
   if (kernel_ms) {
@@ -719,6 +728,36 @@ int xrt_hip_debug_sincos_tab_f64_dev(int64_t n, const double* phi, double* sn, d
                                      void* stream) {
   if (n <= 0) return XRT_HIP_OK;
   HIP_TRY(xrt::debug_sincos_launch(n, phi, sn, cs, 1, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_event_create(void** event) {
+  if (!event) return fail(XRT_HIP_ERR_ARG, "NULL event slot");
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreate(&ev));
+  *event = ev;
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_event_destroy(void* event) {
+  if (event) HIP_TRY(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_event_elapsed_ms(void* begin, void* end, float* ms) {
+  if (!begin || !end || !ms) return fail(XRT_HIP_ERR_ARG, "NULL event / result");
+  HIP_TRY(hipEventSynchronize(reinterpret_cast<hipEvent_t>(end)));
+  HIP_TRY(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(begin),
+                              reinterpret_cast<hipEvent_t>(end)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_reflect_time_next_pass(void* pass_begin, void* pass_end, void* kernel_begin,
+                                   void* kernel_end) {
+  g_next_pass_events[0] = reinterpret_cast<hipEvent_t>(pass_begin);
+  g_next_pass_events[1] = reinterpret_cast<hipEvent_t>(pass_end);
+  g_next_pass_events[2] = reinterpret_cast<hipEvent_t>(kernel_begin);
+  g_next_pass_events[3] = reinterpret_cast<hipEvent_t>(kernel_end);
   return XRT_HIP_OK;
 }
 
