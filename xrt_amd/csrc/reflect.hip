@@ -258,6 +258,14 @@ struct Spec {
   static constexpr bool PLAIN = PLAIN_;
   // waves per SIMD the fused kernel is compiled for
   static constexpr int WAVES = (PLAIN_ && SK_ >= 0 && MK_ >= 0) ? XRT_LEAN_WAVES : REFLECT_FUSED_WAVES;
+  // crystal known to be thick (crystal.py:571-584): the thin-crystal forms with their
+  // complex exp / cos / sin / tan are not compiled in
+  static constexpr bool XTHICK = false;
+};
+// a thick (semi-infinite) crystal: what a DCM is made of
+template <int SK_>
+struct ThickXtal : Spec<0, SK_, XRT_HIP_MAT_CRYSTAL, false> {
+  static constexpr bool XTHICK = true;
 };
 using Generic0 = Spec<0, -1, -1, false>;
 using Generic1 = Spec<1, -1, -1, false>;
@@ -1326,13 +1334,14 @@ __device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, in
 }
 
 // Bragg / Laue dynamical-diffraction amplitudes, crystal.py:492-645
+template <bool THICK = false>
 __device__ __forceinline__ cplx crystal_one_pol(const xrt_hip_material& M, double polFactor,
                                                 cplx alpha, cplx chih, cplx chih_, cplx chi0,
                                                 double b, double k02, double k0s,
                                                 double kHs) {
   const cplx delta = csqrt_(alpha * alpha + ((chih * (polFactor * polFactor)) * chih_) / b);
   const double sqb = sqrt(fabs(b));
-  if (M.thick) {
+  if (THICK || M.thick) {
     const cplx num = chih * polFactor;
     cplx ra = num / (alpha + delta);
     cplx ad = alpha - delta;
@@ -1363,6 +1372,7 @@ __device__ __forceinline__ cplx crystal_one_pol(const xrt_hip_material& M, doubl
   return ra;
 }
 
+template <bool THICK = false>
 __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, double E,
                                                   double bdsn, double bosn, double bdhn,
                                                   const TabWin& w) {
@@ -1403,8 +1413,9 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
   if (sb < -1.) sb = -1. + 1e-16;
   const double thetaB = asin(sb);
   const cplx alpha = C((H2 * 0.5 - k0H) * frcp(k02), 0.) + (chi0 * 0.5) * (frcp(b) - 1.);
-  A.rs = crystal_one_pol(M, 1., alpha, chih, chih_, chi0, b, k02, k0s, kHs);
-  A.rp = crystal_one_pol(M, cos(2. * thetaB), alpha, chih, chih_, chi0, b, k02, k0s, kHs);
+  A.rs = crystal_one_pol<THICK>(M, 1., alpha, chih, chih_, chi0, b, k02, k0s, kHs);
+  A.rp = crystal_one_pol<THICK>(M, cos(2. * thetaB), alpha, chih, chih_, chi0, b, k02, k0s,
+                               kHs);
   A.mu = 0.;
   A.nk = 0.;
   return A;
@@ -1653,7 +1664,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   A.nk = 0.;
   if (MKIND(M) == XRT_HIP_MAT_CRYSTAL) {
     const double bosn = ao * n[3] + bo * n[4] + co * n[5];
-    A = crystal_amplitude(M, q.E, bdsn, bosn, bdn, window_of(g));
+    A = crystal_amplitude<K::XTHICK>(M, q.E, bdsn, bosn, bdn, window_of(g));
   } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
     A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g));
   }
@@ -2184,12 +2195,18 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       // Bragg-reflecting crystals sit on flat surfaces in practice (DCM): that case is
       // compiled with the kinds fixed. Each ray takes its own sign of beamInDotNormal
       // and raises any_neg / any_pos (see reflect_fused_xtal).
-      if (flat_xtal)
-        hipLaunchKernelGGL((reflect_fused_xtal<FlatXtal, mode>), grid, block, 0, st, P, M, in,
-                           restore, lb, vb, theta, g, &g->any_neg, opt);
+#define XRT_XTAL(SPEC)                                                                       \
+  hipLaunchKernelGGL((reflect_fused_xtal<SPEC, mode>), grid, block, 0, st, P, M, in, restore, \
+                     lb, vb, theta, g, &g->any_neg, opt)
+      if (M.thick && flat_xtal)
+        XRT_XTAL(ThickXtal<XRT_HIP_SURF_FLAT>);
+      else if (M.thick)
+        XRT_XTAL(ThickXtal<-1>);
+      else if (flat_xtal)
+        XRT_XTAL(FlatXtal);
       else
-        hipLaunchKernelGGL((reflect_fused_xtal<AnyXtal, mode>), grid, block, 0, st, P, M, in,
-                           restore, lb, vb, theta, g, &g->any_neg, opt);
+        XRT_XTAL(AnyXtal);
+#undef XRT_XTAL
       return;
     }
 #define XRT_FUSED(SPEC)                                                                    \
