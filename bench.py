@@ -189,9 +189,41 @@ def cpu_baseline_reflect(nrays=10_000_000):
     t0 = time.perf_counter()
     rn.oe_reflect(params, beam)
     dt = time.perf_counter() - t0
-    return dict(value=nrays / dt, unit='intersections/s', cores=1, kind='port',
-                sample='%d rays of cfg2 through oracle/reflect_np.py (numpy, 1 '
-                       'thread), %.1f s' % (nrays, dt))
+    res = dict(value=nrays / dt, unit='intersections/s', cores=1, kind='port',
+               sample='%d rays of cfg2 through oracle/reflect_np.py (numpy, 1 '
+                      'thread), %.1f s' % (nrays, dt))
+    # the same on all host cores: numpy itself is single-threaded here, so one process
+    # per core, each on its own slice of the beam ("on all host cores")
+    try:
+        import multiprocessing as mp
+        workers = max(1, min((os.cpu_count() or 2) // 2, 128))
+        per = 500_000
+        ctx = mp.get_context('fork')
+        global _CPU_PARAMS
+        _CPU_PARAMS = params      # inherited by the forked workers (no file access there)
+        t0 = time.perf_counter()
+        with ctx.Pool(workers) as pool:
+            pool.map(_cpu_reflect_slice, [(per, 100 + k) for k in range(workers)])
+        dt = time.perf_counter() - t0
+        res['all_cores'] = dict(
+            value=workers * per / dt, unit='intersections/s', cores=workers, kind='port',
+            sample='%d processes x %d rays of cfg2 through oracle/reflect_np.py, %.1f s '
+                   'including process start-up and ray generation' % (workers, per, dt))
+    except Exception as e:          # a baseline must never take the bench line down
+        res['all_cores'] = dict(error=repr(e))
+    return res
+
+
+_CPU_PARAMS = None
+
+
+def _cpu_reflect_slice(job):
+    per, seed = job
+    from xrt_amd import workloads as pc
+    from oracle.adapters import to_oracle_beam
+    from oracle import reflect_np as rn
+    rn.oe_reflect(_CPU_PARAMS, to_oracle_beam(pc.synthetic_rays(per, seed)))
+    return per
 
 
 # ----------------------------------------------------------------------------
