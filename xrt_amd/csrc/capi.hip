@@ -315,8 +315,8 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
     e1 = g_next_pass_events[1];
     k0 = g_next_pass_events[2];
     k1 = g_next_pass_events[3];
-    for (hipEvent_t& ev : g_next_pass_events) ev = nullptr;
   }
+  for (hipEvent_t& ev : g_next_pass_events) ev = nullptr;   // one call only, either way
   if (kernel_ms) {
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
