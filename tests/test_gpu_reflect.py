@@ -319,3 +319,27 @@ def test_reflect_out_reuse_overwrites_in_place():
         assert np.array_equal(gb2.peek(f), ref_gb2.peek(f)), f
         assert np.array_equal(lb2.peek(f), ref_lb2.peek(f)), f
     assert np.array_equal(lb2.peek('theta'), ref_lb2.peek('theta'))
+
+
+def test_pass_timing_events_without_host_sync():
+    """xrt_hip_reflect_time_next_pass: the library records caller-owned events around
+    the next pass and its dominant kernel and returns without waiting (bench.py reads
+    them after its timed region); they apply to one call only."""
+    import ctypes
+    from xrt_amd import _lib, workloads
+    lib = _lib.load()
+    oe = workloads.cfg2_toroid()
+    beam = workloads.synthetic_rays(200_000, 42)
+    quad = [ctypes.c_void_p() for _ in range(4)]
+    for e in quad:
+        _lib.check(lib.xrt_hip_event_create(ctypes.byref(e)), 'create')
+    oe.reflect(beam)                                   # nothing armed: nothing recorded
+    _lib.check(lib.xrt_hip_reflect_time_next_pass(*quad), 'arm')
+    gb, lb = oe.reflect(beam)
+    ms_pass, ms_kernel = ctypes.c_float(-1.), ctypes.c_float(-1.)
+    _lib.check(lib.xrt_hip_event_elapsed_ms(quad[0], quad[1], ctypes.byref(ms_pass)), 'ms')
+    _lib.check(lib.xrt_hip_event_elapsed_ms(quad[2], quad[3], ctypes.byref(ms_kernel)), 'ms')
+    assert 0. < ms_kernel.value <= ms_pass.value < 50.
+    for e in quad:
+        lib.xrt_hip_event_destroy(e)
+    assert (lb.state == 1).mean() > 0.9
