@@ -373,3 +373,67 @@ def test_single_pass_equals_exact_sequence_over_random_elements(monkeypatch):
         _same_bits(l1, l2)
     print('single pass kept for %d of %d' % (n_single, n_searching))
     assert n_single >= n_searching // 2     # the single pass is the rule, not the exception
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_plate_matches_oracle(seed, monkeypatch):
+    """Plate.double_refract (refractive.py:171-235): windows / filters at normal and
+    tilted incidence, random material, thickness, wedge; refraction in and out,
+    transmission amplitudes, absorption and the in-material phase. At normal incidence
+    the bracketing axis is z: the single pass takes its axis from ray 0."""
+    rng = np.random.default_rng(9000 + seed)
+    bl = raycing.BeamLine(azimuth=float(rng.choice([0., -0.1])))
+    # (elements of the oracle's committed table set, tests/golden/g6_element_tables.npz)
+    mat = [rm.Material('Si', rho=2.33, kind='plate'),
+           rm.Material(('Si', 'O'), quantities=(1, 2), rho=2.2, kind='plate')][seed % 2]
+    pitch = float(np.pi / 2 if seed % 3 != 1 else rng.uniform(0.3, 1.2))
+    plate = roe.Plate(
+        bl, 'w', center=[20000. * bl.sinAzimuth, 20000. * bl.cosAzimuth, 0.], pitch=pitch,
+        material=mat, t=float(rng.uniform(0.02, 0.3)),
+        wedgeAngle=float(rng.choice([0., 0., 2e-3])),
+        limPhysX=[-float(rng.uniform(3, 6)), float(rng.uniform(3, 6))],
+        limPhysY=[-float(rng.uniform(3, 6)), float(rng.uniform(3, 6))])
+    n = 3000
+    beam = rs.Beam(nrays=n, withAmplitudes=bool(seed % 3 == 0))
+    beam.x[:] = rng.normal(0, 1.5, n)
+    beam.z[:] = rng.normal(0, 1.5, n)
+    beam.a[:] = rng.normal(0, 1e-4, n)
+    beam.c[:] = rng.normal(0, 1e-4, n)
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    if bl.azimuth:
+        for u, v in (('x', 'y'), ('a', 'b')):
+            p, q = getattr(beam, u).copy(), getattr(beam, v).copy()
+            pu, qv = raycing.rotate_z(p, q, bl.cosAzimuth, -bl.sinAzimuth)
+            getattr(beam, u)[:] = pu
+            getattr(beam, v)[:] = qv
+    beam.E[:] = rng.uniform(7000., 20000., n)
+    ang = rng.uniform(0, np.pi, n)
+    es, ep = np.cos(ang), np.sin(ang) * np.exp(1j * rng.uniform(-np.pi, np.pi, n))
+    beam.Jss[:], beam.Jpp[:], beam.Jsp[:] = es * es, (ep * np.conj(ep)).real, \
+        es * np.conj(ep)
+    if hasattr(beam, 'Es'):
+        beam.Es[:], beam.Ep[:] = es, ep
+    st = np.ones(n, dtype=np.int32)
+    st[rng.random(n) < 0.03] = -1
+    beam.state[:] = st
+    o2, o1l, o2l = rn.dcm_double_reflect(oracle_params(plate), to_oracle_beam(beam),
+                                         fromVacuum1=True, fromVacuum2=False)
+    gb2, lo1, lo2 = plate.double_refract(beam)
+    for mine, ref, tag in ((gb2, o2, 'global'), (lo1, o1l, 'front'), (lo2, o2l, 'back')):
+        assert np.array_equal(mine.state, ref.state), (tag, seed)
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):
+            r = getattr(ref, f)
+            assert np.abs(getattr(mine, f) - r).max() <= \
+                1e-12 * max(np.abs(r).max(), 1e-300), (tag, f)
+        scale = max(np.abs(ref.Jss).max(), np.abs(ref.Jpp).max(), 1e-300)
+        for f in ('Jss', 'Jpp', 'Jsp'):
+            assert np.abs(getattr(mine, f) - getattr(ref, f)).max() <= 1e-9 * scale, \
+                (tag, f)
+        if hasattr(beam, 'Es'):
+            sc = max(np.abs(ref.Es).max(), np.abs(ref.Ep).max(), 1e-300)
+            for f in ('Es', 'Ep'):
+                assert np.abs(getattr(mine, f) - getattr(ref, f)).max() <= 2e-6 * sc, (tag, f)
+    assert (o2.state == 1).sum() > 500
+    monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
+    for mine, exact in zip((gb2, lo1, lo2), plate.double_refract(beam)):
+        _same_bits(mine, exact)
