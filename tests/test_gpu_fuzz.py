@@ -437,3 +437,54 @@ def test_random_plate_matches_oracle(seed, monkeypatch):
     monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
     for mine, exact in zip((gb2, lo1, lo2), plate.double_refract(beam)):
         _same_bits(mine, exact)
+
+
+@pytest.mark.parametrize('geom', ['Bragg reflected', 'Bragg transmitted'])
+@pytest.mark.parametrize('t_mm', [0.007, 0.1])
+def test_thin_crystal_pass_matches_oracle(geom, t_mm, monkeypatch):
+    """A crystal of finite thickness on a flat element: the thin-crystal amplitude forms
+    (complex cot / cos / sin of the Pendelloesung phase, crystal.py:598-616) inside the
+    reflect pass -- the generic crystal kernels; DCM-grade thick crystals run on a
+    specialised instantiation without them."""
+    rng = np.random.default_rng(4242)
+    bl = raycing.BeamLine()
+    si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15, t=t_mm, geom=geom)
+    E0 = 9000.
+    thB = float(np.ravel(si.get_Bragg_angle(E0))[0])
+    oe = roe.OE(bl, 'xtal', center=[0., 10000., 0.], pitch=thB, material=si,
+                limPhysX=[-20, 20], limPhysY=[-60, 60])
+    n = 4000
+    beam = rs.Beam(nrays=n, withAmplitudes=True)
+    beam.x[:] = rng.normal(0, 1., n)
+    beam.z[:] = rng.normal(0, 0.3, n)
+    beam.a[:] = rng.normal(0, 1e-4, n)
+    beam.c[:] = rng.normal(0, 3e-5, n)          # across the rocking curve
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.y[:] = 9900.
+    beam.z[:] += -beam.c / beam.b * 100.
+    beam.E[:] = rng.uniform(E0 - 2., E0 + 2., n)
+    ang = rng.uniform(0, np.pi, n)
+    es, ep = np.cos(ang), np.sin(ang) * np.exp(1j * rng.uniform(-np.pi, np.pi, n))
+    beam.Jss[:], beam.Jpp[:], beam.Jsp[:] = es * es, (ep * np.conj(ep)).real, \
+        es * np.conj(ep)
+    beam.Es[:], beam.Ep[:] = es, ep
+    beam.state[:] = 1
+    ogb, olb = rn.oe_reflect(oracle_params(oe), to_oracle_beam(beam))
+    gb, lb = oe.reflect(beam)
+    for mine, ref, tag in ((lb, olb, 'local'), (gb, ogb, 'global')):
+        assert np.array_equal(mine.state, ref.state), tag
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):
+            r = getattr(ref, f)
+            assert np.abs(getattr(mine, f) - r).max() <= \
+                1e-12 * max(np.abs(r).max(), 1e-300), (tag, f)
+        scale = max(np.abs(ref.Jss).max(), np.abs(ref.Jpp).max(), 1e-300)
+        for f in ('Jss', 'Jpp', 'Jsp'):
+            assert np.abs(getattr(mine, f) - getattr(ref, f)).max() <= 1e-9 * scale, \
+                (tag, f)
+    assert (olb.state == 1).sum() > 3000
+    # something was actually diffracted / transmitted
+    assert 1e-3 < (olb.Jss + olb.Jpp)[olb.state == 1].mean() < 1.
+    monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
+    g2, l2 = oe.reflect(beam)
+    _same_bits(gb, g2)
+    _same_bits(lb, l2)
