@@ -495,8 +495,12 @@ def main():
     world, rank, local, dist = setup_dist(args)
     main_res = bench_reflect(args, world, rank, dist)
     line = dict(
-        metric='ray-surface intersections/sec/GPU; Kirchhoff sample*pixel '
-               'pairs/sec at 1/2/4/8 GPUs (see "kirchhoff")',
+        # BASELINE.json's metric, verbatim; `value` is its first quantity, the second one
+        # is the "kirchhoff" object of the same line
+        metric='ray-surface intersections/sec/GPU; Kirchhoff sample\u00b7pixel '
+               'pairs/sec at 1/2/4/8 GPUs',
+        metric_note='value = ray-surface intersections/s over all GPUs (cfg2); the Kirchhoff '
+                    'pairs/s of the same run are in "kirchhoff"',
         value=main_res['value'], unit='intersections/s', n_gpus=world,
         steps=args.steps, warmup=args.warmup,
         ms_per_step=main_res['ms_per_step'], higher_is_better=True,
