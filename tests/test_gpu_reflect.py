@@ -343,3 +343,31 @@ def test_pass_timing_events_without_host_sync():
     for e in quad:
         lib.xrt_hip_event_destroy(e)
     assert (lb.state == 1).mean() > 0.9
+
+
+def test_large_batch_slices_match_oracle():
+    """3e7 rays (3 GB per beam) in one pass: 64-bit indexing, grid sizes and the
+    report-slot fold at scale; three slices against the oracle (ray 0, on which the
+    batch decisions hinge, kept in front of each slice)."""
+    from xrt_amd import workloads
+    import xrt_amd.backends.raycing.sources as rs
+    n, m = 30_000_000, 20000
+    beam = workloads.synthetic_rays(n, 7)
+    oe = workloads.cfg2_toroid()
+    t = {}
+    gb, lb = oe.reflect(beam, _timing=t)
+    assert not t['exact_sequence']
+    fields = ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp', 'state')
+    for lo in (0, n // 2, n - m):
+        sub = rs.Beam(nrays=m)
+        for f in fields:
+            getattr(sub, f)[:] = beam.peek(f)[lo:lo + m]
+            if lo:
+                getattr(sub, f)[0] = beam.peek(f)[0]
+        ogb, olb = rn.oe_reflect(oracle_params(oe), to_oracle_beam(sub))
+        s, o = slice(lo + (1 if lo else 0), lo + m), slice(1 if lo else 0, m)
+        assert np.array_equal(lb.peek('state')[s], olb.state[o])
+        assert np.array_equal(gb.peek('state')[s], ogb.state[o])
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):
+            r = getattr(ogb, f)[o]
+            assert np.abs(gb.peek(f)[s] - r).max() <= 1e-12 * max(np.abs(r).max(), 1e-300), f
