@@ -3,7 +3,7 @@ GPU box (tabulated E/f1/f2 'Chantler total', Waasmaier-Kirfel f0 coefficients,
 atomic masses, Z = 1..92) through the reference's own Element API and writes
 xrt_amd/data/elements.npz. Data only; no reference code is copied.
 
-    python tools/extract_element_data.py
+    python -m oracle.gen_element_data
 """
 import os
 import sys
