@@ -57,8 +57,12 @@ XRT_HIP_API const char* xrt_hip_last_error(void);   /* thread-local, never NULL 
 #define XRT_HIP_KIRCHHOFF_NUMPY 0
 #define XRT_HIP_KIRCHHOFF_OPENCL 1
 
-/* Launch plan. nsplit_req<=0 / ppt_req<=0 = choose automatically.
- * Outputs may be NULL. */
+/* Launch plan. nsplit_req<=0 / ppt_req<=0 = choose automatically. ppt_req: receiving
+ * points per lane (1, 2 or 4), optionally OR-ed with XRT_HIP_KIRCHHOFF_NO_FAST /
+ * _NO_SHARE, which keep the kernel off its specialised loops (tests compare every
+ * loop with the oracle that way). Outputs may be NULL. */
+#define XRT_HIP_KIRCHHOFF_NO_FAST 0x100   /* no planar / paraxial specialisation */
+#define XRT_HIP_KIRCHHOFF_NO_SHARE 0x200  /* no sharing of a receiving-mesh column */
 XRT_HIP_API int xrt_hip_kirchhoff_plan(int64_t np, int64_t ns, int nsplit_req, int ppt_req,
                            size_t* workspace_bytes, int* nsplit, int* ppt);
 
@@ -78,6 +82,14 @@ XRT_HIP_API int xrt_hip_kirchhoff_f64_dev(
     double* S_ri, double* P_ri, double* A_ri, double* B_ri, double* C_ri,
     void* workspace, size_t workspace_bytes, int nsplit_req, int ppt_req,
     void* stream, float* kernel_ms);
+
+/* What the last launch on `workspace` found and did (synchronises `stream`):
+ * flags: bit 0 some Ep != 0, bit 1 some normal off the y axis, bit 2 more than one
+ * wavenumber, bit 3 receiving points not on one plane y = const; variants: bit v =
+ * loop variant v of kirchhoff.hip ran (KV_* there); row: receiving-mesh row length
+ * found (0: none). Any output may be NULL. */
+XRT_HIP_API int xrt_hip_kirchhoff_report(const void* workspace, void* stream,
+                                         unsigned* flags, unsigned* variants, int64_t* row);
 
 /* Host form with exactly the reference's OpenCL marshalling
  * (waves.py:860-894): pos_xyzw / nrm_xyzw are ns*4 doubles = ns x [x,y,z,0]
@@ -465,6 +477,10 @@ XRT_HIP_API int xrt_hip_reflect_time_next_pass(void* pass_begin, void* pass_end,
 /* ---- building-block checks (used by the GPU tests only) ---------------- */
 XRT_HIP_API int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* rinv,
                                void* stream);
+/* the Kirchhoff loop's root from a caller-supplied seed ~ 1/sqrt(x); hinv = 1/(2 sqrt x) */
+XRT_HIP_API int xrt_hip_debug_sqrt_seeded_f64_dev(int64_t n, const double* x,
+                                                  const double* seed, double* r,
+                                                  double* hinv, void* stream);
 /* q[i] = a[i] / b through the constant-divisor sequence of the reflect kernels */
 XRT_HIP_API int xrt_hip_debug_divconst_f64_dev(int64_t n, const double* a, double b, double* q,
                                    void* stream);

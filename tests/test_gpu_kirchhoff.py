@@ -66,6 +66,22 @@ def test_sqrt_is_correctly_rounded_and_rinv_accurate():
     assert np.abs(ri * np.sqrt(x) - 1).max() < 1e-14   # one Goldschmidt step on v_rsq_f64
 
 
+def test_seeded_sqrt_is_correctly_rounded_at_the_seed_error_limit():
+    """The fast-geometry loop seeds the root with 1/|dy| instead of v_rsq_f64; it is
+    used while the seed is within 2^-27 of 1/sqrt(x) (kirchhoff_fast). Checked here at
+    twice that error, both signs, on r^2 of the Kirchhoff geometry and on hard cases."""
+    from xrt_amd import hipcalls
+    rng = np.random.default_rng(21)
+    sq = np.arange(3000, 203000, dtype=float)**2
+    x = np.concatenate([rng.uniform(1e7, 2e8, 4_000_000), rng.uniform(1., 4., 2_000_000),
+                        np.nextafter(sq, 0), sq, np.nextafter(sq, np.inf)])
+    for err in (2.**-26, -2.**-26, 2.**-30, 0.):
+        seed = (1. + err * rng.uniform(0.5, 1., x.size)) / np.sqrt(x)
+        r, h = hipcalls.debug_sqrt_seeded(dev(x), dev(seed))
+        assert np.array_equal(r.cpu().numpy(), np.sqrt(x)), err
+        assert np.abs(2. * h.cpu().numpy() * np.sqrt(x) - 1).max() < 1e-14
+
+
 @pytest.mark.parametrize('table', [False, True])
 def test_sincos_of_large_phases(table):
     """Both sincos forms of the Kirchhoff kernel: the general one (|phi| < 2^50) and
@@ -91,7 +107,7 @@ def test_sincos_of_large_phases(table):
 
 # ---- golden vectors from the reference --------------------------------------
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('ppt', [1, 2])
+@pytest.mark.parametrize('ppt', [1, 2, 4])
 def test_matches_reference_golden(golden_dir, name, ppt):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     mine = run_hip(*golden_inputs(g), ppt=ppt)
@@ -105,22 +121,102 @@ def test_opencl_convention(golden_dir):
 
 
 # ---- seeded random inputs vs the oracle, ragged shapes and splits ----------
-def random_case(npix, ns, seed, ep_zero=False):
+def random_case(npix, ns, seed, ep_zero=False, plane=False, axis_y=False, one_k=False,
+                mesh=0, dist=10000.):
+    """plane: receiving points on y = const; axis_y: every normal (0, ny, 0);
+    one_k: one photon energy; mesh: row length of an x-fastest receiving mesh."""
     rng = np.random.default_rng(seed)
-    px = rng.uniform(-0.5, 0.5, npix)
-    pz = rng.uniform(-0.5, 0.5, npix)
-    py = 10000. + rng.uniform(-1, 1, npix)
+    if mesh:
+        rows = -(-npix // mesh)
+        gx, gz = np.meshgrid(np.sort(rng.uniform(-0.5, 0.5, mesh)),
+                             np.sort(rng.uniform(-0.5, 0.5, rows)))
+        px, pz = gx.ravel()[:npix].copy(), gz.ravel()[:npix].copy()
+    else:
+        px = rng.uniform(-0.5, 0.5, npix)
+        pz = rng.uniform(-0.5, 0.5, npix)
+    py = np.full(npix, dist) if plane else dist + rng.uniform(-1, 1, npix)
     sx = rng.uniform(-0.1, 0.1, ns)
     sz = rng.uniform(-0.1, 0.1, ns)
     sy = rng.uniform(-0.01, 0.01, ns)
     nrm = rng.normal(size=(3, ns)) * 0.01 + np.array([[0.], [1.], [0.]])
     nrm /= np.sqrt((nrm**2).sum(axis=0))
+    if axis_y:
+        nrm[0] = nrm[2] = 0.
     nl = rng.uniform(0.9, 1.0, ns)
-    E = rng.uniform(7899.5, 7900.5, ns)
+    E = np.full(ns, 7900.) if one_k else rng.uniform(7899.5, 7900.5, ns)
     Es = rng.normal(size=ns) + 1j * rng.normal(size=ns)
     Ep = np.zeros(ns, dtype=complex) if ep_zero else \
         0.3 * (rng.normal(size=ns) + 1j * rng.normal(size=ns))
     return px, py, pz, sx, sy, sz, list(nrm), nl, E, Es, Ep
+
+
+# ---- every loop of kirchhoff_stream against the oracle ----------------------
+# name -> (random_case options, run options, variant that must have run)
+NO_FAST, NO_SHARE = 0x100, 0x200
+LOOPS = {
+    'gen_s_y': (dict(ep_zero=True, axis_y=True), 0),
+    'gen_s_n': (dict(ep_zero=True), 0),
+    'gen_sp_y': (dict(axis_y=True), 0),
+    'gen_sp_n': (dict(), 0),
+    'gen_s_notab': (dict(ep_zero=True, dist=3e5), 0),
+    'gen_sp_notab': (dict(dist=3e5), 0),
+    'fast_s': (dict(ep_zero=True, axis_y=True, plane=True), 0),
+    'fast_s_unik': (dict(ep_zero=True, axis_y=True, plane=True, one_k=True), 0),
+    'fast_sp': (dict(axis_y=True, plane=True), 0),
+    'fast_s_share': (dict(ep_zero=True, axis_y=True, plane=True, mesh=96), 0),
+    'fast_s_share_unik': (dict(ep_zero=True, axis_y=True, plane=True, one_k=True,
+                               mesh=96), 0),
+    'fast_sp_share': (dict(axis_y=True, plane=True, mesh=96), 0),
+    'fast_s_notab': (dict(ep_zero=True, axis_y=True, plane=True, dist=3e5), 0),
+    'fast_s_notab_unik': (dict(ep_zero=True, axis_y=True, plane=True, one_k=True,
+                               dist=3e5), 0),
+    'fast_sp_notab': (dict(axis_y=True, plane=True, dist=3e5), 0),
+    # the same planar inputs kept off the specialised loops
+    'gen_s_y/no_fast': (dict(ep_zero=True, axis_y=True, plane=True, one_k=True,
+                             mesh=96), NO_FAST),
+    'gen_sp_y/no_fast': (dict(axis_y=True, plane=True, mesh=96), NO_FAST),
+    'fast_s_unik/no_share': (dict(ep_zero=True, axis_y=True, plane=True, one_k=True,
+                                  mesh=96), NO_SHARE),
+}
+
+
+@pytest.mark.parametrize('ppt', [1, 2, 4])
+@pytest.mark.parametrize('loop', sorted(LOOPS))
+def test_every_loop_variant_matches_oracle(loop, ppt):
+    from xrt_amd import hipcalls
+    opts, knobs = LOOPS[loop]
+    want = loop.split('/')[0]
+    if ppt == 1 and 'share' in want:
+        want = want.replace('_share', '')        # one point per lane has nothing to share
+    case = random_case(96 * 37 + 5, 700, seed=31 + ppt, **opts)
+    ref = kn.kirchhoff_conv(*case)
+    mine = run_hip(*case, ppt=ppt | knobs, nsplit=8)
+    rep = hipcalls.kirchhoff_report()
+    assert rep['variants'] == {want}, rep
+    assert_close(mine, ref)
+
+
+def test_planar_but_wide_angle_keeps_the_general_loop():
+    """receiving plane 2 mm from the samples: 1/|dy| is no seed for the root"""
+    from xrt_amd import hipcalls
+    case = random_case(3000, 500, seed=41, ep_zero=True, axis_y=True, plane=True,
+                       mesh=100, dist=2.)
+    mine = run_hip(*case, ppt=2)
+    assert hipcalls.kirchhoff_report()['variants'] == {'gen_s_y'}
+    assert_close(mine, kn.kirchhoff_conv(*case))
+
+
+def test_mesh_with_broken_rows_falls_back_per_wave():
+    """px repeats with period 96 except in one row: the waves holding that row take the
+    unshared loop, the result is the same"""
+    from xrt_amd import hipcalls
+    case = list(random_case(96 * 40, 600, seed=42, ep_zero=True, axis_y=True, plane=True,
+                            one_k=True, mesh=96))
+    case[0] = case[0].copy()
+    case[0][96 * 7 + 13] += 1e-3
+    mine = run_hip(*case, ppt=2)
+    assert hipcalls.kirchhoff_report()['variants'] == {'fast_s_share_unik', 'fast_s_unik'}
+    assert_close(mine, kn.kirchhoff_conv(*case))
 
 
 @pytest.mark.parametrize('npix,ns,nsplit,ppt', [
@@ -224,6 +320,61 @@ def test_full_size_additivity_and_linearity():
     ref = kn.kirchhoff_conv(*sub)
     for f, r in zip(full, ref):
         assert np.abs(f[idx] - r).max() <= TOL * np.abs(f).max()
+
+
+def _on_device(h):
+    n = [np.broadcast_to(np.asarray(c, dtype=float), h['sx'].shape) for c in h['n']]
+    return [dev(h[f]) for f in ('px', 'py', 'pz', 'sx', 'sy', 'sz')] + \
+        [dev(c) for c in n] + [dev(h['nl']), dev(h['k']),
+                               dev(h['Es'], torch.complex128), dev(h['Ep'], torch.complex128)]
+
+
+def _oracle_on_pixels(h, idx):
+    return kn.kirchhoff_conv(h['px'][idx], h['py'][idx], h['pz'][idx], h['sx'], h['sy'],
+                             h['sz'], h['n'], h['nl'], h['E'], h['Es'], h['Ep'])
+
+
+@pytest.mark.parametrize('ppt', [0, 1, 2, 4])
+def test_cfg4_workload_itself_against_the_oracle(ppt):
+    """The very inputs bench.py times (workloads.kirchhoff_case(4): 1e6 samples,
+    512 x 512 mesh, Ep = 0, one energy, planar): 64 receiving points of the full-size
+    launch against the oracle, and the loop the launch took."""
+    from xrt_amd import hipcalls, workloads
+    h = workloads.kirchhoff_case(4)
+    out = hipcalls.kirchhoff(*_on_device(h), ppt=ppt)
+    torch.cuda.synchronize()
+    rep = hipcalls.kirchhoff_report()
+    assert rep['row'] == 512
+    assert rep['variants'] == ({'fast_s_unik'} if ppt == 1 else {'fast_s_share_unik'}), rep
+    idx = np.random.default_rng(4).choice(h['px'].size, 64, replace=False)
+    ref = _oracle_on_pixels(h, idx)
+    for o, r in zip(out, ref):
+        o = o.cpu().numpy()
+        assert np.abs(o[idx] - r).max() <= TOL * max(np.abs(o).max(), 1e-300)
+
+
+@pytest.mark.timeout(900)
+def test_cfg5_on_one_gpu():
+    """cfg5 (4e6 samples x 2048 x 2048) on one GPU: additive over two halves of the
+    sample set, 64 receiving points against the oracle."""
+    from xrt_amd import hipcalls, workloads
+    h = workloads.kirchhoff_case(5)
+    d = _on_device(h)
+    full = [o.clone() for o in hipcalls.kirchhoff(*d)]
+    assert hipcalls.kirchhoff_report()['variants'] == {'fast_s_share_unik'}
+    ns = h['ns']
+    parts = []
+    for sl in (slice(0, ns // 2), slice(ns // 2, ns)):
+        part = hipcalls.kirchhoff(*(d[:3] + [a[sl].contiguous() for a in d[3:]]))
+        parts.append([o.clone() for o in part])
+    for f, a, b in zip(full, *parts):
+        scale = float(f.abs().max())
+        assert float((f - (a + b)).abs().max()) <= 1e-11 * max(scale, 1e-300)
+    idx = np.random.default_rng(5).choice(h['px'].size, 64, replace=False)
+    ref = _oracle_on_pixels(h, idx)
+    for f, r in zip(full, ref):
+        f = f.cpu().numpy()
+        assert np.abs(f[idx] - r).max() <= TOL * max(np.abs(f).max(), 1e-300)
 
 
 @pytest.mark.parametrize('scale,ppt', [(1., 1), (30., 2), (2000., 1)])

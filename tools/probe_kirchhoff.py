@@ -15,7 +15,7 @@ g = np.linspace(-0.5, 0.5, side)
 X, Z = np.meshgrid(g, g)
 px = dev(X.ravel().copy()); pz = dev(Z.ravel().copy()); py = dev(np.full(side * side, 1e4))
 cases = [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else \
-    [(a, b) for a in (1, 2) for b in (0, 8, 32, 64)]
+    [(a, b) for a in (1, 2, 4, 2 | 0x200, 2 | 0x100) for b in (0, 8, 32, 64)]
 for ppt, nsplit in cases:
     if True:
         best = 1e9
@@ -23,4 +23,4 @@ for ppt, nsplit in cases:
             out = hipcalls.kirchhoff(px, py, pz, sx, sy, sz, nx, ny, nz, nl, k, Es, Ep,
                                      nsplit=nsplit, ppt=ppt, timing=True)
             best = min(best, out[-1])
-        print('ppt %d nsplit %2d  %.1f ms  %.3e pairs/s' % (ppt, nsplit, best, ns * side * side / best * 1e3))
+        print('ppt %#x nsplit %2d  %.1f ms  %.3e pairs/s' % (ppt, nsplit, best, ns * side * side / best * 1e3))

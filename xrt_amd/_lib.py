@@ -61,7 +61,11 @@ SIGNATURES = {
         vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, c_float_p]),
     'xrt_hip_custom_field_f64': (ctypes.c_int, [
         ctypes.c_int, vp, i64, vp, vp, vp, vp, vp, vp, vp, c_float_p]),
+    'xrt_hip_kirchhoff_report': (ctypes.c_int, [
+        vp, vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint),
+        ctypes.POINTER(ctypes.c_int64)]),
     'xrt_hip_debug_sqrt_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
+    'xrt_hip_debug_sqrt_seeded_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp, vp]),
     'xrt_hip_debug_divconst_f64_dev': (ctypes.c_int, [i64, vp, ctypes.c_double, vp, vp]),
     'xrt_hip_debug_sincos_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
     'xrt_hip_debug_sincos_tab_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),

@@ -710,6 +710,27 @@ int xrt_hip_debug_sqrt_f64_dev(int64_t n, const double* x, double* r, double* ri
   return XRT_HIP_OK;
 }
 
+int xrt_hip_debug_sqrt_seeded_f64_dev(int64_t n, const double* x, const double* seed,
+                                      double* r, double* hinv, void* stream) {
+  if (n <= 0) return XRT_HIP_OK;
+  HIP_TRY(xrt::debug_sqrt_seeded_launch(n, x, seed, r, hinv,
+                                        reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_kirchhoff_report(const void* workspace, void* stream, unsigned* flags,
+                             unsigned* variants, int64_t* row) {
+  if (!workspace) return fail(XRT_HIP_ERR_ARG, "NULL workspace");
+  xrt::KirchhoffInfo info;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(&info, workspace, sizeof(info), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (flags) *flags = info.flags;
+  if (variants) *variants = info.variants;
+  if (row) *row = info.not_row ? (int64_t)~info.not_row : 0;
+  return XRT_HIP_OK;
+}
+
 int xrt_hip_debug_divconst_f64_dev(int64_t n, const double* a, double b, double* q,
                                    void* stream) {
   if (n <= 0) return XRT_HIP_OK;

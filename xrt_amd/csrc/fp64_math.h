@@ -56,6 +56,28 @@ __device__ __forceinline__ double sqrt_rn_halfinv(double x, double& hinv) {
   return g;
 }
 
+// The same iteration from a caller-supplied seed y = (1 + e)/sqrt(x), h0 = y/2, instead
+// of v_rsq_f64 (a quarter-rate instruction: 16 cycles per wave, as much as four fma).
+// The Goldschmidt step leaves g, h with a relative error of 1.5 e^2, the correction
+// 2.25 e^4: for |e| <= 2^-26 that is 2^-103, the same as after the hardware seed, so
+// the result is the correctly rounded root under the same argument as above
+// (tests/test_gpu_math.py compares it with np.sqrt at the seed-error limit). The
+// Kirchhoff loop uses it when every distance of a launch is within 2^-27 (relative) of
+// a per-sample constant: receiving points on a plane y = const facing the samples
+// (paraxial geometry, the rule on a beamline), seed = 1/|y - sy| from the pack kernel,
+// held in SGPRs. Six VALU slots, no transcendental.
+__device__ __forceinline__ double sqrt_rn_seeded(double x, double y, double h0,
+                                                 double& hinv) {
+  double g = x * y;
+  double r0 = fma_(-h0, g, 0.5);
+  double h = fma_(h0, r0, h0);
+  g = fma_(g, r0, g);
+  double d0 = fma_(-g, g, x);
+  g = fma_(d0, h, g);
+  hinv = h;
+  return g;
+}
+
 // sin/cos of (q + u) quarter turns, |u| <= 1/2: minimax polynomials in w = u^2 for
 // sin(pi/2 u) and cos(pi/2 u), then the quadrant q (mod 4) swaps / negates.
 __device__ __forceinline__ void sincos_quarter_turns(double u, unsigned q, double& sn,

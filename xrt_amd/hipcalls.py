@@ -61,6 +61,30 @@ def kirchhoff_plan(npix, ns, nsplit=0, ppt=0):
     return wsb.value, ns_out.value, ppt_out.value
 
 
+KIRCHHOFF_NO_FAST = 0x100     # XRT_HIP_KIRCHHOFF_NO_FAST
+KIRCHHOFF_NO_SHARE = 0x200    # XRT_HIP_KIRCHHOFF_NO_SHARE
+# loop variants of csrc/kirchhoff.hip (KV_*), as reported by kirchhoff_report()
+KIRCHHOFF_VARIANTS = (
+    'gen_s_y', 'gen_s_n', 'gen_sp_y', 'gen_sp_n', 'gen_s_notab', 'gen_sp_notab',
+    'fast_s', 'fast_s_unik', 'fast_sp', 'fast_s_share', 'fast_s_share_unik',
+    'fast_sp_share', 'fast_s_notab', 'fast_s_notab_unik', 'fast_sp_notab')
+
+
+def kirchhoff_report(device=None):
+    """What the last kirchhoff() call on this device found and ran: dict with the
+    classification flags, the set of loop-variant names, the mesh row length."""
+    lib = _lib.load()
+    dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    ws = workspace(dev, 256, 'kirchhoff')
+    f, v, row = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.xrt_hip_kirchhoff_report(
+            ctypes.c_void_p(ws.data_ptr()), _stream_ptr(), ctypes.byref(f),
+            ctypes.byref(v), ctypes.byref(row)), 'xrt_hip_kirchhoff_report')
+    names = {n for i, n in enumerate(KIRCHHOFF_VARIANTS) if (v.value >> i) & 1}
+    return dict(flags=f.value, variants=names, row=row.value)
+
+
 def kirchhoff(px, py, pz, sx, sy, sz, nx, ny, nz, nl, k, Es, Ep, convention=0,
               nsplit=0, ppt=0, out=None, timing=False):
     """Fresnel-Kirchhoff integral on device-resident arrays.
@@ -102,6 +126,16 @@ def debug_sqrt(x):
     _lib.check(lib.xrt_hip_debug_sqrt_f64_dev(
         x.numel(), _f64(x), _f64(r), _f64(ri), _stream_ptr()), 'debug_sqrt')
     return r, ri
+
+
+def debug_sqrt_seeded(x, seed):
+    lib = _lib.load()
+    r = torch.empty_like(x)
+    h = torch.empty_like(x)
+    _lib.check(lib.xrt_hip_debug_sqrt_seeded_f64_dev(
+        x.numel(), _f64(x), _f64(seed, x.numel()), _f64(r), _f64(h), _stream_ptr()),
+        'debug_sqrt_seeded')
+    return r, h
 
 
 def debug_sincos(phi, table=False):
