@@ -9,7 +9,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU. P1 does not shard (geometric tracing stays single-GPU,
+One process per GPU: started without a torch.distributed environment and with
+--gpus N > 1, the script launches itself under torch.distributed.run (N ranks on
+127.0.0.1) and relays rank 0's line -- the reference also splits the devices inside
+one call (myopencl.py:455-533). P1 does not shard (geometric tracing stays single-GPU,
 SURVEY 8e): N ranks run N independent replicas (weak scaling). The Kirchhoff
 integral shards over output-pixel tiles (strong scaling) with one RCCL
 all_gather of the five complex result arrays.
@@ -59,7 +62,44 @@ def parse():
                     help='(default on one GPU) also time cfg3 (DCM Si111, 2 intersections '
                          'per ray)')
     ap.add_argument('--skip-dcm', action='store_true')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='no GPU work: the ranks only rendezvous (gloo) and rank 0 prints '
+                         'the line skeleton -- checks the launch path on a CPU box')
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N without a torch.distributed environment: become the launcher."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        'HSA_ENABLE_IPC_MODE_LEGACY', '0'), OMP_NUM_THREADS=os.environ.get(
+        'OMP_NUM_THREADS', '8'))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args):
+    import datetime
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=120))
+        t = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(t)                       # every rank is there
+        assert int(t.item()) == world
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(dict(dry_run=True, n_gpus=world, steps=args.steps,
+                              warmup=args.warmup)))
 
 
 def setup_dist(args):
@@ -67,10 +107,6 @@ def setup_dist(args):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs one process per GPU: launch with '
-                             'python -m torch.distributed.run --nproc-per-node %d'
-                             % (args.gpus, args.gpus))
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     torch.cuda.set_device(local)
     dist = None
@@ -174,7 +210,8 @@ def bench_reflect(args, world, rank, dist, dcm=False):
             achieved=BYTES_PER_INTERSECTION * n_enter / k / 1e9,
             peak=HBM_PEAK / 1e9, unit='GB/s',
             frac=BYTES_PER_INTERSECTION * n_enter / k / HBM_PEAK,
-            traffic=load_traffic('reflect_fused') if n == 10_000_000 else None)
+            traffic=load_traffic('reflect_fused') if n == 10_000_000 else None,
+            traffic_source=TRAFFIC_SOURCE)
     return res
 
 
@@ -283,15 +320,20 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
                              % (cfg, ns, side, side), samples=ns, pixels=npix,
                     parallelism='pixel tiles x%d + all_gather' % world),
         kernel_ms=k * 1e3,
-        roofline=dict(bound='mfma', kernel='kirchhoff_stream',
-                      note='fp64 VALU kernel; MI355X vector fp64 peak = matrix '
-                           'fp64 peak = 78.6 TFLOP/s; 57 flop per pair '
-                           '(sqrt, div, sin, cos counted as 1)',
+        roofline=dict(bound='valu_fp64', kernel='kirchhoff_stream',
+                      note='fp64 VALU kernel (no MFMA: profiles/r01_mfma_f64_probe.txt); '
+                           'MI355X vector fp64 peak = matrix fp64 peak = 78.6 TFLOP/s '
+                           'at 2.4 GHz; 57 flop per pair (sqrt, div, sin, cos counted '
+                           'as 1)',
                       achieved=FLOP_PER_PAIR * my_pairs / k / 1e12,
                       peak=FP64_PEAK / 1e12, unit='TFLOP/s',
                       frac=FLOP_PER_PAIR * my_pairs / k / FP64_PEAK,
                       traffic=load_traffic('kirchhoff_stream')
-                      if cfg == 4 and world == 1 else None))
+                      if cfg == 4 and world == 1 else None,
+                      traffic_source=TRAFFIC_SOURCE,
+                      traffic_note='the packed sample records re-streamed through the '
+                                   'scalar cache by every block; unique bytes are ~0.15 GB '
+                                   '(compute-bound kernel, HBM at <1 % of peak)'))
     return res, host
 
 
@@ -478,6 +520,10 @@ def cpu_baseline_kirchhoff(host, npix=256):
     return res
 
 
+TRAFFIC_SOURCE = ('profiles/hbm_traffic.json: PMC passes of tools/refresh_profiles.sh on the '
+                  'same command, committed -- static, not collected in this run')
+
+
 def load_traffic(kernel):
     """HBM bytes per launch from the committed PMC summary (profiles/), or None."""
     path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
@@ -490,6 +536,10 @@ def load_traffic(kernel):
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
+    if args.dry_run:
+        return dry_run(args)
     from xrt_amd import _lib
     _lib.require_gpu()                    # no CPU fallback: fail loudly
     world, rank, local, dist = setup_dist(args)
@@ -515,9 +565,19 @@ def main():
         kernel_ms=main_res.get('kernel_ms'), roofline=main_res.get('roofline'))
     if args.with_dcm or (world == 1 and not args.skip_dcm):
         d = bench_reflect(args, world, rank, dist, dcm=True)
+        dcm_bytes = 416 * d['n_enter']       # 100 B in, 3 x 100 B + 2 x 8 B out
+        dcm_s = d['ms_per_step'] * 1e-3
         line['dcm'] = dict(metric='ray-surface intersections/s (cfg3 DCM Si111)',
                            value=d['value'], ms_per_step=d['ms_per_step'],
-                           good_fraction=d['good_fraction'])
+                           good_fraction=d['good_fraction'],
+                           roofline=dict(
+                               bound='hbm', kernel='DCM.double_reflect (whole pass: both '
+                                                   'crystals, host clock over the steps)',
+                               achieved=dcm_bytes / dcm_s / 1e9, peak=HBM_PEAK / 1e9,
+                               unit='GB/s', frac=dcm_bytes / dcm_s / HBM_PEAK,
+                               note='208 B per intersection (416 B per ray)',
+                               traffic=load_traffic('dcm_double_reflect'),
+                               traffic_source=TRAFFIC_SOURCE))
     host = None
     if not args.skip_kirchhoff:
         cfgs = [args.kirchhoff_config] if args.kirchhoff_config else \

@@ -77,3 +77,25 @@ def test_tile_ranges_cover_everything():
             edges = [multigpu.tile_range(n, r, world) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+
+
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver types it (no torch.distributed
+    environment): the script re-launches itself under torch.distributed.run with one
+    rank per GPU and rank 0 prints ONE JSON line. --dry-run stops after the rendezvous
+    (gloo), so this runs without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2',
+                        '--steps', '2', '--warmup', '1', '--dry-run'],
+                       capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1
