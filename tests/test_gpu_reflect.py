@@ -304,6 +304,48 @@ def test_full_size_cfg2_properties():
         assert np.abs(gb.peek(f)[idx] - r).max() <= AMP_TOL * scale
 
 
+def test_full_size_cfg3_properties():
+    """cfg3 at BASELINE size: 1e7 rays through both crystals of the Si(111) DCM. Hit
+    points on the crystal planes, unit directions, reflectivities <= 1, the second
+    crystal sees exactly the rays the first one kept, and a 100k-ray subset equals
+    the oracle (states bit for bit)."""
+    n = 10_000_000
+    dcm = pc.cfg3_dcm()
+    beam = pc.synthetic_rays(n, seed=43, sa=1e-4, E=(8995., 9005.))
+    gb2, lo1, lo2 = dcm.double_reflect(beam)
+    s1, s2, sg = lo1.peek('state'), lo2.peek('state'), gb2.peek('state')
+    hit1 = s1 == 1
+    assert hit1.mean() > 0.9
+    assert np.abs(lo1.peek('z')[hit1]).max() < 2e-12               # flat crystals: z = 0
+    entered2 = (s1 == 1) | (s1 == 2)
+    assert np.array_equal(s2 != 0, entered2)        # dcm.py:298-303: others are zeroed
+    hit2 = s2 == 1
+    assert np.abs(lo2.peek('z')[hit2]).max() < 2e-12
+    assert np.array_equal(sg[hit2], s2[hit2])
+    a, b, c = (gb2.peek(f)[hit2] for f in 'abc')
+    assert np.abs(a*a + b*b + c*c - 1).max() < 1e-14
+    J0 = (beam.peek('Jss') + beam.peek('Jpp'))[hit2]
+    J1 = (lo1.peek('Jss') + lo1.peek('Jpp'))[hit2]
+    J2 = (gb2.peek('Jss') + gb2.peek('Jpp'))[hit2]
+    assert (J1 <= J0 * (1 + 1e-12)).all() and (J2 <= J1 * (1 + 1e-12)).all() and J2.min() >= 0
+    # fixed-exit geometry: the beam leaves parallel to how it came (two equal crystals)
+    assert np.abs(gb2.peek('c')[hit2] - beam.peek('c')[hit2]).max() < 1e-9
+    idx = np.sort(np.random.default_rng(1).choice(n, 100_000, replace=False))
+    sub = rn.Beam(len(idx))
+    for f in sub.fields():
+        setattr(sub, f, beam.peek(f)[idx].copy())
+    o2, o1l, o2l = rn.dcm_double_reflect(oracle_params(dcm), sub)
+    for mine, ref in ((gb2, o2), (lo1, o1l), (lo2, o2l)):
+        assert np.array_equal(mine.peek('state')[idx], ref.state)
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):
+            r = getattr(ref, f)
+            assert np.abs(mine.peek(f)[idx] - r).max() <= GEO_TOL * max(np.abs(r).max(), 1e-300), f
+        scale = (ref.Jss + ref.Jpp).max()
+        for f in ('Jss', 'Jpp', 'Jsp'):
+            r = getattr(ref, f)
+            assert np.abs(mine.peek(f)[idx] - r).max() <= AMP_TOL * scale, f
+
+
 def test_reflect_out_reuse_overwrites_in_place():
     """`out=` (extension used by bench.py): the second call writes into the first
     call's arrays and gives the same result."""

@@ -169,3 +169,40 @@ def test_plot_histograms_of_an_empty_selection():
     assert plot.nRaysSelected == 0 and plot.nRaysDead == 40000
     assert not plot.total2D.any() and not plot.total2D_RGB.any()
     assert not plot.xaxis.total1D4.any() and not plot.caxis.total1D4.any()
+
+
+def test_two_plots_of_one_beam_with_and_without_beam_state():
+    """A plot whose states come from ANOTHER beam (beamState) must not leave that
+    state array behind in the beam's cached struct: the next plot of the same beam,
+    and any later GPU op on it, read the beam's own states again."""
+    bl = build()
+    kept = []
+
+    def run_process(beamLine):
+        b0 = beamLine.src.shine()
+        gb, lb = beamLine.m1.reflect(b0)
+        img = beamLine.scr.expose(gb)
+        lb.state[::7] = 3                 # make the two beams' selections differ
+        kept.append((lb, img))
+        return {'beamSource': b0, 'beamM1local': lb, 'beamScreen': img}
+    rr.run_process = run_process
+    np.random.seed(12)
+    ax = lambda: (xrtp.XYCAxis('x', 'mm', limits=[-2, 2], bins=40),   # noqa: E731
+                  xrtp.XYCAxis('z', 'mm', limits=[-2, 2], bins=40))
+    plots = [xrtp.XYCPlot('beamScreen', (1,), *ax(), beamState='beamM1local'),
+             xrtp.XYCPlot('beamScreen', (1,), *ax()),
+             xrtp.XYCPlot('beamScreen', (1,), *ax(), beamState='beamM1local')]
+    xrtr.run_ray_tracing(plots, repeats=2, beamLine=bl)
+    ref_own = np.zeros((40, 40))
+    ref_m1 = np.zeros((40, 40))
+    for lb, img in kept:
+        for ref, st in ((ref_own, img.state), (ref_m1, lb.state)):
+            sel = st == 1
+            h, _, _ = np.histogram2d(img.z[sel], img.x[sel], bins=[40, 40],
+                                     range=[[-2, 2], [-2, 2]],
+                                     weights=(img.Jss + img.Jpp)[sel])
+            ref += h
+    assert (ref_own != ref_m1).any()
+    assert np.abs(plots[1].total2D - ref_own).max() <= 1e-10 * ref_own.max()
+    assert np.abs(plots[0].total2D - ref_m1).max() <= 1e-10 * ref_m1.max()
+    assert np.abs(plots[2].total2D - ref_m1).max() <= 1e-10 * ref_m1.max()

@@ -95,7 +95,10 @@ class Beam(object):
             h = object.__getattribute__(self, '_h')
             d = object.__getattribute__(self, '_d')
             if name in d:
+                # the host copy becomes the master (it may be edited in place): the
+                # device tensor and any struct pointing at it are dropped
                 h[name] = d.pop(name).cpu().numpy()
+                self.__dict__.pop('_struct', None)
             if name in h:
                 return h[name]
         raise AttributeError(name)
@@ -155,6 +158,7 @@ class Beam(object):
         h = np.ascontiguousarray(self._h[name], dtype=_np_dtype(name))
         t = torch.from_numpy(h).to(device)
         self._d[name] = t
+        self.__dict__.pop('_struct', None)      # a new tensor: cached pointers are stale
         # the host copy stays valid until a kernel overwrites the tensor; the
         # operators below always write into NEW beams, never into their input
         return t

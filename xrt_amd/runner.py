@@ -56,10 +56,14 @@ def accumulate_plot(plot, beams):
     srcw = beam.nrays * beam.sourceWeight if hasattr(beam, 'sourceWeight') else 1.
     state_beam = beam if plot.beamState is None else beams[plot.beamState]
     s = beam.to_struct(dev)
+    keep = None
     if state_beam is not beam:
+        # the struct is the beam's cached one: the other beam's state goes into a
+        # private copy of it, alive for this call only
+        cached, s = s, _structs.Beam()
+        ctypes.memmove(ctypes.byref(s), ctypes.byref(cached), ctypes.sizeof(s))
         keep = state_beam.dev('state', dev)
         s.state = keep.data_ptr()
-        s._keep.append(keep)
     P = _structs.Plot()
     P.x_factor, P.y_factor, P.c_factor = (float(plot.xaxis.factor),
                                           float(plot.yaxis.factor), float(cax.factor))
@@ -76,7 +80,8 @@ def accumulate_plot(plot, beams):
         ptr(hist_rgb), ptr(hx), ptr(hy), ptr(hc) if plot.ePos else None, ptr(counters),
         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
         'xrt_hip_plot_hist_f64_dev')
-    plot.total2D_RGB += hist_rgb.cpu().numpy()
+    plot.total2D_RGB += hist_rgb.cpu().numpy()      # (a sync: `keep` outlives the kernel)
+    del keep
     plot.xaxis.total1D4 += hx.cpu().numpy()
     plot.yaxis.total1D4 += hy.cpu().numpy()
     if plot.ePos:
