@@ -252,7 +252,8 @@ XRT_HIP_API int xrt_hip_sizeof(int which);
  * (reflect.py:793-796). By default the pass first runs on the batch-global decisions
  * a beam along the beamline always produces (axis y, ray 0's sign, secant, clamp
  * inactive), every ray verifying them, and repeats itself through the exact
- * statistics only if one was contradicted -- same bits either way; a request for
+ * statistics (one more launch, reflect_exact, which otherwise returns at once) only
+ * if one was contradicted -- same bits either way; a request for
  * info_host, outputs that alias the inputs, or XRT_HIP_REFLECT_EXACT=1 in the
  * environment take the exact sequence directly.
  * info_host (optional, 16 doubles, forces a sync):
@@ -270,6 +271,28 @@ XRT_HIP_API int xrt_hip_reflect_pass_f64_dev(
     const xrt_hip_beam* in, const xrt_hip_beam* restore, xrt_hip_beam* out_local,
     xrt_hip_beam* out_virgin, double* theta, void* workspace,
     size_t workspace_bytes, void* stream, double* info_host, float* kernel_ms);
+
+/* DCM.double_reflect (oes/dcm.py:248-354) as ONE pass over the beam: both crystals
+ * per ray, the beam between them never goes to memory (416 B of HBM traffic per ray
+ * instead of 716). pass1 / pass2 are what two xrt_hip_reflect_pass_f64_dev calls
+ * would take (pass1.out_to_global = 0; pass2.in_is_global = 0, good_mode 1,
+ * out_to_global = 1, zero_local_not_entering = 1); `in` is also the beam that rays
+ * lost on the way are restored from (dcm.py:330-335). Flat Bragg-reflecting crystals
+ * of one thickness class only: xrt_hip_double_reflect_fusable tells (1 / 0), other
+ * pairs take two pass calls. Outputs must not share arrays with `in`. The batch
+ * decisions are assumed as in the single pass -- the second crystal's from the head
+ * ray mirrored at the first -- and verified per ray; contradicted, both passes are
+ * redone exactly inside the same call. kernel_ms as above. */
+XRT_HIP_API int xrt_hip_double_reflect_fusable(const xrt_hip_pass* pass1,
+                                               const xrt_hip_material* material1,
+                                               const xrt_hip_pass* pass2,
+                                               const xrt_hip_material* material2);
+XRT_HIP_API int xrt_hip_double_reflect_f64_dev(
+    const xrt_hip_pass* pass1, const xrt_hip_material* material1,
+    const xrt_hip_pass* pass2, const xrt_hip_material* material2, const xrt_hip_beam* in,
+    xrt_hip_beam* out_local1, xrt_hip_beam* out_local2, xrt_hip_beam* out_global,
+    double* theta1, double* theta2, void* workspace, size_t workspace_bytes, void* stream,
+    float* kernel_ms);
 
 /* Stand-alone amplitude evaluation on device arrays (what the reference exposes
  * as Material.get_amplitude(E, beamInDotNormal, fromVacuum) -> rs, rp, mu, n'k

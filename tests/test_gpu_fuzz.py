@@ -306,8 +306,8 @@ def _toroid(bl):
                             material=rm.Material('Pt', rho=21.45))
 
 
-@pytest.mark.parametrize('case', ['plain', 'ray0_lost', 'sideways', 'backwards_first',
-                                  'steep', 'normal_incidence'])
+@pytest.mark.parametrize('case', ['plain', 'ray0_lost', 'head_lost', 'sideways',
+                                  'backwards_first', 'steep', 'normal_incidence'])
 def test_single_pass_equals_exact_sequence(case, monkeypatch):
     """reflect first runs on the batch-global decisions every ordinary beam produces and
     falls back to the exact statistics when a ray contradicts them. Whatever the
@@ -319,9 +319,12 @@ def test_single_pass_equals_exact_sequence(case, monkeypatch):
     expect_exact = True
     if case == 'plain':
         expect_exact = False
-    elif case == 'ray0_lost':            # the first entering ray is not ray 0
-        beam.state[0] = -1
+    elif case == 'ray0_lost':            # the first entering ray is not ray 0: found in the
+        beam.state[0] = -1               # head of the beam, still one pass
         beam.b[1] *= -1                   # ... and it flies backwards
+        expect_exact = False
+    elif case == 'head_lost':            # no entering ray among the first 1024
+        beam.state[:1500] = -1
     elif case == 'sideways':             # one state-1 ray whose largest cosine is a
         beam.a[7], beam.b[7], beam.c[7] = 0.8, 0.6, 0.
     elif case == 'backwards_first':      # ray 0 picks the other bracket formula: still one pass
@@ -488,3 +491,97 @@ def test_thin_crystal_pass_matches_oracle(geom, t_mm, monkeypatch):
     g2, l2 = oe.reflect(beam)
     _same_bits(gb, g2)
     _same_bits(lb, l2)
+
+
+# ---- DCM.double_reflect: one fused pass vs two passes vs the exact sequence ---------
+def _dcm_and_beam(seed, n=6000, alpha=0.):
+    rng = np.random.default_rng(9000 + seed)
+    bl = raycing.BeamLine()
+    si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    si2 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    E0 = 9000.
+    thB = float(np.ravel(si1.get_Bragg_angle(E0))[0])
+    if alpha:
+        thB -= float(np.ravel(si1.get_dtheta(E0, alpha))[0])
+    dcm = roe.DCM(bl, 'dcm', center=[0, 20000., 0], bragg=thB, pitch=alpha, material=si1,
+                  material2=si2, alpha=alpha if alpha else None, cryst2perpTransl=10.,
+                  limPhysX=[-10, 10], limPhysY=[-50, 50], limPhysX2=[-10, 10],
+                  limPhysY2=[-50, 150])
+    beam = rs.Beam(nrays=n, withAmplitudes=bool(seed % 2))
+    beam.x[:] = rng.normal(0, 3., n)
+    beam.z[:] = rng.normal(0, 3., n)            # part of the fan misses the first crystal
+    beam.a[:] = rng.normal(0, 1e-4, n)
+    beam.c[:] = rng.normal(0, 2e-5, n)
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.y[:] = 0.
+    beam.E[:] = rng.uniform(E0 - 3., E0 + 3., n)
+    beam.Jss[:] = rng.uniform(0.2, 1., n)
+    beam.Jpp[:] = rng.uniform(0., 0.5, n)
+    beam.Jsp[:] = 0.1 * (rng.normal(size=n) + 1j * rng.normal(size=n))
+    if hasattr(beam, 'Es'):
+        beam.Es[:] = rng.normal(size=n) + 1j * rng.normal(size=n)
+        beam.Ep[:] = rng.normal(size=n) + 1j * rng.normal(size=n)
+    st = np.ones(n, dtype=np.int32)
+    st[rng.random(n) < 0.03] = 2
+    st[rng.random(n) < 0.02] = -3
+    beam.state[:] = st
+    return dcm, beam
+
+
+@pytest.mark.parametrize('case', ['plain', 'ray0_lost', 'head_lost', 'sideways',
+                                  'second_crystal_contradicted', 'asymmetric'])
+def test_fused_dcm_equals_two_passes_and_exact_sequence(case, monkeypatch):
+    """DCM.double_reflect runs both crystals in one kernel on assumed batch decisions
+    (the second crystal's guessed from the head ray mirrored at the first). Whatever
+    the route -- fused, two separate passes, the exact sequence -- the bits are the same,
+    and they are the oracle's."""
+    dcm, beam = _dcm_and_beam({'plain': 0, 'asymmetric': 3}.get(case, 1),
+                              alpha=np.radians(2.) if case == 'asymmetric' else 0.)
+    expect_exact = False
+    if case == 'ray0_lost':
+        beam.state[0] = -1
+    elif case == 'head_lost':
+        beam.state[:1200] = -2
+        expect_exact = True
+    elif case == 'sideways':                 # a state-1 ray that travels across the crystal
+        beam.a[11], beam.b[11], beam.c[11] = 0.8, 0.6, 0.
+        expect_exact = True
+    elif case == 'second_crystal_contradicted':
+        # a ray the first crystal sends on at a steep angle: it reaches the second
+        # crystal's plane with another dominant direction cosine than the guessed one
+        beam.c[5] = 0.45
+        beam.b[5] = np.sqrt(1 - beam.a[5]**2 - beam.c[5]**2)
+        expect_exact = None
+    elif case == 'asymmetric':
+        expect_exact = None
+    monkeypatch.delenv('XRT_HIP_REFLECT_EXACT', raising=False)
+    monkeypatch.delenv('XRT_HIP_DCM_TWO_PASSES', raising=False)
+    t = {}
+    fused = dcm.double_reflect(rs.Beam(copyFrom=beam), _timing=t)
+    assert 'kernel_ms' in t                  # the one-kernel route ran
+    if expect_exact is not None:
+        assert t['exact_sequence'] == expect_exact, t
+    o2, o1l, o2l = rn.dcm_double_reflect(oracle_params(dcm), to_oracle_beam(beam))
+    for mine, ref, tag in zip(fused, (o2, o1l, o2l), ('global', 'xtal1', 'xtal2')):
+        assert np.array_equal(mine.state, ref.state), (tag, case)
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):
+            r = getattr(ref, f)
+            assert np.abs(getattr(mine, f) - r).max() <= \
+                1e-12 * max(np.abs(r).max(), 1e-300), (tag, f)
+        scale = max(np.abs(ref.Jss).max(), np.abs(ref.Jpp).max(), 1e-300)
+        for f in ('Jss', 'Jpp', 'Jsp'):
+            assert np.abs(getattr(mine, f) - getattr(ref, f)).max() <= 1e-9 * scale, (tag, f)
+    assert np.array_equal(fused[1].theta, fused[1].theta)
+    monkeypatch.setenv('XRT_HIP_DCM_TWO_PASSES', '1')
+    two = dcm.double_reflect(rs.Beam(copyFrom=beam))
+    for a, b in zip(fused, two):
+        _same_bits(a, b)
+    assert np.array_equal(fused[1].theta, two[1].theta)
+    assert np.array_equal(fused[2].theta, two[2].theta)
+    monkeypatch.delenv('XRT_HIP_DCM_TWO_PASSES')
+    monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
+    t2 = {}
+    exact = dcm.double_reflect(rs.Beam(copyFrom=beam), _timing=t2)
+    assert t2['exact_sequence']
+    for a, b in zip(fused, exact):
+        _same_bits(a, b)

@@ -37,6 +37,9 @@ SIGNATURES = {
     'xrt_hip_reflect_pass_f64_dev': (ctypes.c_int, [
         vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, c_double_p,
         c_float_p]),
+    'xrt_hip_double_reflect_fusable': (ctypes.c_int, [vp, vp, vp, vp]),
+    'xrt_hip_double_reflect_f64_dev': (ctypes.c_int, [
+        vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, c_float_p]),
     'xrt_hip_material_amplitude_f64_dev': (ctypes.c_int, [
         vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_crystal_amplitude_f64_dev': (ctypes.c_int, [

@@ -11,6 +11,7 @@ parametric surfaces, mosaic/bent crystals, polygon shapes) a
 NotImplementedError is raised — there is no CPU fallback.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -1061,13 +1062,12 @@ class DCM(OE):
         return res
 
     def double_reflect(self, beam=None, needLocal=True, fromVacuum1=True,
-                       fromVacuum2=True, returnLocalAbsorbed=None):
+                       fromVacuum2=True, returnLocalAbsorbed=None, _timing=None):
         """-> (beamGlobal, beamLocal1, beamLocal2), dcm.py:248-354."""
         p1 = self._make_pass(
             self.pitch + self.bragg,
             self.roll + self.positionRoll + self.cryst1roll, self.yaw, self.dx,
             fromVacuum=fromVacuum1, out_to_global=False)
-        lo1, gb, _ = self._run_pass(p1, self.material, fromVacuum1, beam, beam)
         p2 = self._make_pass(
             -self.pitch - self.bragg + self.cryst2pitch + self.cryst2finePitch,
             self.roll + self.cryst2roll + self.positionRoll, -self.yaw,
@@ -1075,7 +1075,51 @@ class DCM(OE):
             fromVacuum=fromVacuum2, is2ndXtal=True, in_is_global=False,
             good_mode=1, out_to_global=True, zero_local_not_entering=True,
             force_lost_out=hasattr(self, 't'))
+        # (XRT_HIP_DCM_TWO_PASSES=1: the two separate passes, for comparison)
+        if os.environ.get('XRT_HIP_DCM_TWO_PASSES', '') != '1':
+            fused = self._run_double(p1, p2, fromVacuum1, fromVacuum2, beam, _timing)
+            if fused is not None:
+                return fused
+        lo1, gb, _ = self._run_pass(p1, self.material, fromVacuum1, beam, beam)
         lo2, gb2, _ = self._run_pass(p2, self.material2, fromVacuum2, gb, beam)
+        return gb2, lo1, lo2
+
+    def _run_double(self, p1, p2, fromVacuum1, fromVacuum2, beam, timing=None):
+        """Both crystals in one pass over the beam (xrt_hip_double_reflect_f64_dev) when
+        the pair qualifies (flat Bragg crystals), else None. -> (gb2, lo1, lo2)"""
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        m1 = self._material_struct(self.material, fromVacuum1, dev)
+        m2 = self._material_struct(self.material2, fromVacuum2, dev)
+        if not lib.xrt_hip_double_reflect_fusable(ctypes.byref(p1), ctypes.byref(m1),
+                                                  ctypes.byref(p2), ctypes.byref(m2)):
+            return None
+        n = beam.nrays
+        s_in = beam.to_struct(dev)
+        outs = [rs.Beam.empty_like_on_device(beam, dev) for _ in range(3)]
+        lo1, lo2, gb2 = outs
+        th1 = torch.empty(n, dtype=torch.float64, device=dev)
+        th2 = torch.empty(n, dtype=torch.float64, device=dev)
+        ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(n), 'reflect')
+        ms = (ctypes.c_float * 3)() if timing is not None else None
+        rc = lib.xrt_hip_double_reflect_f64_dev(
+            ctypes.byref(p1), ctypes.byref(m1), ctypes.byref(p2), ctypes.byref(m2),
+            ctypes.byref(s_in), ctypes.byref(lo1.to_struct(dev)),
+            ctypes.byref(lo2.to_struct(dev)), ctypes.byref(gb2.to_struct(dev)),
+            ctypes.c_void_p(th1.data_ptr()), ctypes.c_void_p(th2.data_ptr()),
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ms)
+        _lib.check(rc, 'xrt_hip_double_reflect_f64_dev')
+        if timing is not None:
+            timing.update(pass_ms=ms[0], kernel_ms=ms[1], exact_sequence=bool(ms[2]))
+        lo1._d['theta'] = th1
+        lo2._d['theta'] = th2
+        for b in outs:
+            for k in rs._SCALAR_ATTRS:
+                if k in beam.__dict__:
+                    object.__setattr__(b, k, beam.__dict__[k])
+            b.parentId = self.uuid
         return gb2, lo1, lo2
 
 

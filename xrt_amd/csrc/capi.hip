@@ -265,21 +265,8 @@ static int check_beam(const xrt_hip_beam* b, const char* name, int64_t n, bool n
   return XRT_HIP_OK;
 }
 
-int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_material* material,
-                                 const xrt_hip_beam* in, const xrt_hip_beam* restore,
-                                 xrt_hip_beam* out_local, xrt_hip_beam* out_virgin,
-                                 double* theta, void* workspace, size_t workspace_bytes,
-                                 void* stream, double* info_host, float* kernel_ms) {
+static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material) {
   if (!pass || !material) return fail(XRT_HIP_ERR_ARG, "NULL pass / material");
-  if (!in) return fail(XRT_HIP_ERR_ARG, "NULL input beam");
-  const int64_t n = in->n;
-  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative ray count");
-  const bool amp = in->Es_ri != nullptr || in->Ep_ri != nullptr;
-  int rc;
-  if ((rc = check_beam(in, "in", n, amp))) return rc;
-  if ((rc = check_beam(restore, "restore", n, amp))) return rc;
-  if ((rc = check_beam(out_local, "out_local", n, amp))) return rc;
-  if ((rc = check_beam(out_virgin, "out_virgin", n, amp))) return rc;
   if (pass->to_local.n < 0 || pass->to_local.n > XRT_HIP_MAX_ROT || pass->to_virgin.n < 0 ||
       pass->to_virgin.n > XRT_HIP_MAX_ROT)
     return fail(XRT_HIP_ERR_ARG, "rotation sequence longer than %d", XRT_HIP_MAX_ROT);
@@ -304,24 +291,71 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
           material->tab_n[e] < 2)
         return fail(XRT_HIP_ERR_ARG, "element %d: missing f1/f2 table", e);
   }
+  return XRT_HIP_OK;
+}
+
+// the events armed by xrt_hip_reflect_time_next_pass belong to the NEXT pass call,
+// whatever becomes of it: taken out of the thread-local slots before anything can fail
+struct ArmedEvents {
+  hipEvent_t e[4];
+  ArmedEvents() {
+    for (int k = 0; k < 4; ++k) {
+      e[k] = g_next_pass_events[k];
+      g_next_pass_events[k] = nullptr;
+    }
+  }
+};
+
+// events of a kernel_ms request: created together, destroyed on every way out
+struct OwnEvents {
+  hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipError_t create() {
+    for (hipEvent_t& ev : e) {
+      hipError_t rc = hipEventCreate(&ev);
+      if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+  }
+  ~OwnEvents() {
+    for (hipEvent_t ev : e)
+      if (ev) (void)hipEventDestroy(ev);
+  }
+};
+
+int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_material* material,
+                                 const xrt_hip_beam* in, const xrt_hip_beam* restore,
+                                 xrt_hip_beam* out_local, xrt_hip_beam* out_virgin,
+                                 double* theta, void* workspace, size_t workspace_bytes,
+                                 void* stream, double* info_host, float* kernel_ms) {
+  const ArmedEvents armed;
+  int rc;
+  if ((rc = check_pass(pass, material))) return rc;
+  if (!in) return fail(XRT_HIP_ERR_ARG, "NULL input beam");
+  const int64_t n = in->n;
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative ray count");
+  const bool amp = in->Es_ri != nullptr || in->Ep_ri != nullptr;
+  if ((rc = check_beam(in, "in", n, amp))) return rc;
+  if ((rc = check_beam(restore, "restore", n, amp))) return rc;
+  if ((rc = check_beam(out_local, "out_local", n, amp))) return rc;
+  if ((rc = check_beam(out_virgin, "out_virgin", n, amp))) return rc;
   if (n == 0) return XRT_HIP_OK;
   if (!workspace || workspace_bytes < xrt::reflect_workspace_bytes(n))
     return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes,
                 xrt::reflect_workspace_bytes(n));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;
-  if (!kernel_ms) {   // armed by xrt_hip_reflect_time_next_pass: record, do not wait
-    e0 = g_next_pass_events[0];
-    e1 = g_next_pass_events[1];
-    k0 = g_next_pass_events[2];
-    k1 = g_next_pass_events[3];
-  }
-  for (hipEvent_t& ev : g_next_pass_events) ev = nullptr;   // one call only, either way
+  OwnEvents own;
   if (kernel_ms) {
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventCreate(&k0));
-    HIP_TRY(hipEventCreate(&k1));
+    HIP_TRY(own.create());
+    e0 = own.e[0];
+    e1 = own.e[1];
+    k0 = own.e[2];
+    k1 = own.e[3];
+  } else {            // armed by xrt_hip_reflect_time_next_pass: record, do not wait
+    e0 = armed.e[0];
+    e1 = armed.e[1];
+    k0 = armed.e[2];
+    k1 = armed.e[3];
   }
   // info_host wants the batch statistics, which only the exact sequence collects;
   // XRT_HIP_REFLECT_EXACT=1 switches the optimistic single pass off altogether
@@ -330,20 +364,15 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
   hipError_t e = xrt::reflect_pass_launch(*pass, *material, *in, *restore, *out_local,
                                           *out_virgin, theta, workspace, st, e0, e1, k0, k1,
                                           force_exact);
-  if (e != hipSuccess) {
-    if (kernel_ms)
-      for (hipEvent_t ev : {e0, e1, k0, k1})
-        if (ev) (void)hipEventDestroy(ev);
-    return fail(XRT_HIP_ERR_HIP, "reflect launch: %s", hipGetErrorString(e));
-  }
+  if (e != hipSuccess) return fail(XRT_HIP_ERR_HIP, "reflect launch: %s", hipGetErrorString(e));
   if (kernel_ms) {
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipEventElapsedTime(&kernel_ms[0], e0, e1));
     HIP_TRY(hipEventElapsedTime(&kernel_ms[1], k0, k1));
-    for (hipEvent_t ev : {e0, e1, k0, k1}) (void)hipEventDestroy(ev);
     xrt::GStat g;
     HIP_TRY(hipMemcpy(&g, workspace, sizeof(g), hipMemcpyDeviceToHost));
     kernel_ms[2] = g.redo ? 1.f : 0.f;
+    if (g.hang) return fail(XRT_HIP_ERR_HIP, "reflect: a grid barrier of the exact sequence timed out");
   }
   if (info_host) {
     xrt::GStat g;
@@ -362,6 +391,79 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
     info_host[9] = g.sum_bdn;
     info_host[10] = g.any_neg;
     info_host[11] = g.any_pos;
+    if (g.hang) return fail(XRT_HIP_ERR_HIP, "reflect: a grid barrier of the exact sequence timed out");
+  }
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_double_reflect_fusable(const xrt_hip_pass* pass1, const xrt_hip_material* material1,
+                                   const xrt_hip_pass* pass2,
+                                   const xrt_hip_material* material2) {
+  if (!pass1 || !material1 || !pass2 || !material2) return 0;
+  return xrt::reflect_dcm_fusable(*pass1, *material1, *pass2, *material2) ? 1 : 0;
+}
+
+int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_material* material1,
+                                   const xrt_hip_pass* pass2, const xrt_hip_material* material2,
+                                   const xrt_hip_beam* in, xrt_hip_beam* out_local1,
+                                   xrt_hip_beam* out_local2, xrt_hip_beam* out_global,
+                                   double* theta1, double* theta2, void* workspace,
+                                   size_t workspace_bytes, void* stream, float* kernel_ms) {
+  const ArmedEvents armed;
+  int rc;
+  if ((rc = check_pass(pass1, material1))) return rc;
+  if ((rc = check_pass(pass2, material2))) return rc;
+  if (!xrt::reflect_dcm_fusable(*pass1, *material1, *pass2, *material2))
+    return fail(XRT_HIP_ERR_ARG, "double_reflect: this pair of passes needs two "
+                                 "xrt_hip_reflect_pass_f64_dev calls (flat Bragg crystals only)");
+  if (!in) return fail(XRT_HIP_ERR_ARG, "NULL input beam");
+  const int64_t n = in->n;
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative ray count");
+  const bool amp = in->Es_ri != nullptr || in->Ep_ri != nullptr;
+  if ((rc = check_beam(in, "in", n, amp))) return rc;
+  if ((rc = check_beam(out_local1, "out_local1", n, amp))) return rc;
+  if ((rc = check_beam(out_local2, "out_local2", n, amp))) return rc;
+  if ((rc = check_beam(out_global, "out_global", n, amp))) return rc;
+  if (n == 0) return XRT_HIP_OK;
+  if (!workspace || workspace_bytes < xrt::reflect_workspace_bytes(n))
+    return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes,
+                xrt::reflect_workspace_bytes(n));
+  for (const xrt_hip_beam* o : {out_local1, out_local2, out_global})
+    if (o->x == in->x || o->state == in->state)
+      return fail(XRT_HIP_ERR_ARG, "double_reflect: outputs must not share arrays with the input");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;
+  OwnEvents own;
+  if (kernel_ms) {
+    HIP_TRY(own.create());
+    e0 = own.e[0];
+    e1 = own.e[1];
+    k0 = own.e[2];
+    k1 = own.e[3];
+  } else {
+    e0 = armed.e[0];
+    e1 = armed.e[1];
+    k0 = armed.e[2];
+    k1 = armed.e[3];
+  }
+  const char* ex = getenv("XRT_HIP_REFLECT_EXACT");
+  const bool force_exact = ex && ex[0] == '1';
+  hipError_t e = xrt::reflect_dcm_launch(*pass1, *material1, *pass2, *material2, *in,
+                                         *out_local1, *out_local2, *out_global, theta1, theta2,
+                                         workspace, st, e0, e1, k0, k1, force_exact);
+  if (e != hipSuccess)
+    return fail(XRT_HIP_ERR_HIP, "double_reflect launch: %s", hipGetErrorString(e));
+  if (kernel_ms) {
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(&kernel_ms[0], e0, e1));
+    HIP_TRY(hipEventElapsedTime(&kernel_ms[1], k0, k1));
+    xrt::GStat g[2];
+    HIP_TRY(hipMemcpy(&g[0], workspace, sizeof(xrt::GStat), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&g[1], reinterpret_cast<char*>(workspace) + 256 + REFLECT_PART_BYTES,
+                      sizeof(xrt::GStat), hipMemcpyDeviceToHost));
+    kernel_ms[2] = (g[0].redo || g[1].redo) ? 1.f : 0.f;
+    if (g[0].hang || g[1].hang)
+      return fail(XRT_HIP_ERR_HIP, "double_reflect: a grid barrier of the exact sequence timed out");
   }
   return XRT_HIP_OK;
 }

@@ -7,6 +7,7 @@
 #include "../../include/xrt_hip.h"
 
 #define REFLECT_BLOCK 256
+#define REFLECT_MAX_WAVES 16                      /* waves of the largest block (1024 lanes) */
 // waves per SIMD the fused kernel is compiled for (register budget 512/N VGPRs)
 #ifndef REFLECT_FUSED_WAVES
 #define REFLECT_FUSED_WAVES 4
@@ -37,6 +38,8 @@ struct GStat {
                                      // binary search of every ray stays inside
   double win_lo, win_hi;             // energies the windows (of all elements) are valid
                                      // for: [win_lo, win_hi); -inf, +inf = the whole batch
+  unsigned bar;                      // arrival counter of reflect_exact's grid barrier
+  int hang;                          // a grid barrier gave up waiting (never expected)
 };
 
 // What the optimistic fused pass reports back. Same-address atomics from 150 000
@@ -61,6 +64,19 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                void* workspace, hipStream_t st, hipEvent_t ev0,
                                hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1,
                                bool force_exact);
+
+// DCM.double_reflect in one kernel: both crystals per ray, the beam between them stays
+// in registers. lo1 / lo2: local beams of the two crystals, gb2: global beam after the
+// second one (also the scratch of the exact two-pass redo).
+bool reflect_dcm_fusable(const xrt_hip_pass& P1, const xrt_hip_material& M1,
+                         const xrt_hip_pass& P2, const xrt_hip_material& M2);
+hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1,
+                              const xrt_hip_pass& P2, const xrt_hip_material& M2,
+                              const xrt_hip_beam& in, const xrt_hip_beam& lo1,
+                              const xrt_hip_beam& lo2, const xrt_hip_beam& gb2,
+                              double* theta1, double* theta2, void* workspace,
+                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                              hipEvent_t evk0, hipEvent_t evk1, bool force_exact);
 
 hipError_t material_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
                                      const double* bdn, double* rs, double* rp, double* mu,

@@ -452,8 +452,19 @@ __device__ __forceinline__ void atomic_max_double(double* p, double v) {
   }
 }
 
+// Loads that another workgroup of the SAME launch may have written (reflect_exact's
+// phases): agent scope = served by L2, past this CU's vector L1 and the scalar cache,
+// neither of which another CU's stores ever refresh.
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(
+      reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+      __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // ---------------------------------------------------------------------------
-// K0 / K1 / decide / K2
+// K0 / K1 / decide / K2. The statistics passes and their folds are device functions:
+// they run as phases of reflect_exact (one launch, grid barriers in between); blockIdx /
+// gridDim are that kernel's.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void gstat_reset(GStat* g, int redo) {
   g->optimistic = 0;
@@ -485,15 +496,12 @@ __device__ __forceinline__ void gstat_reset(GStat* g, int redo) {
   g->win_hi = INFINITY;
 }
 
-__global__ void reflect_init(GStat* g, int redo) { gstat_reset(g, redo); }
-
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir(xrt_hip_pass P,
-                                                                   xrt_hip_beam in,
-                                                                   double* __restrict__ part) {
+__device__ __forceinline__ void stats_dir_body(const xrt_hip_pass& P, const xrt_hip_beam& in,
+                                               double* __restrict__ part) {
   // two-level reduction: every block writes one 64-byte partial record, a
   // one-block kernel folds them (no same-address atomics, deterministic)
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
   double ma = 0., mb = 0., mc = 0., emin = INFINITY, emax = -INFINITY;
   unsigned long long first = ~0ull, nent = 0, nmain = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -605,14 +613,19 @@ __device__ __forceinline__ void table_windows_block(const xrt_hip_material& M, d
 // stride = doubles per partial record: 8 (reflect_stats_dir) or 16
 // (reflect_stats_dir_y, which also carries the bracket statistics of the y axis
 // for both signs: [8..11] positive, [12..15] negative)
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, const double* __restrict__ part,
-    int nblocks, int stride, GStat* g) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  if (!g->redo) return;   // the optimistic single pass stands
-  g->any_neg = 0;         // (a crystal's sign flags are re-raised by the exact pass)
-  g->any_pos = 0;
+__device__ __forceinline__ void decide_axis_body(const xrt_hip_pass& P,
+                                                 const xrt_hip_material& M,
+                                                 const xrt_hip_beam& in, const double* part,
+                                                 int nblocks, int stride, GStat* g) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
+  if (threadIdx.x == 0) {
+    g->any_neg = 0;       // (a crystal's sign flags are re-raised by the exact pass)
+    g->any_pos = 0;
+    g->bracket_valid = 0;
+    g->win_lo = -INFINITY;   // the windows below hold for the whole batch
+    g->win_hi = INFINITY;
+  }
   double ma = 0., mb = 0., mc = 0., nent = 0., nmain = 0., emin = INFINITY, emax = -INFINITY;
   unsigned long long first = ~0ull;
   double yb[8] = {INFINITY, -INFINITY, 0., 0., INFINITY, -INFINITY, 0., 0.};
@@ -620,21 +633,23 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
     const double* o = part + (int64_t)b * stride;
     if (stride == 16) {
       for (int v = 0; v < 2; ++v) {
-        yb[4 * v] = o[8 + 4 * v] < yb[4 * v] ? o[8 + 4 * v] : yb[4 * v];
-        yb[4 * v + 1] = o[9 + 4 * v] > yb[4 * v + 1] ? o[9 + 4 * v] : yb[4 * v + 1];
-        yb[4 * v + 2] = fmax(yb[4 * v + 2], o[10 + 4 * v]);
-        yb[4 * v + 3] = fmax(yb[4 * v + 3], o[11 + 4 * v]);
+        const double q0 = ld_agent(o + 8 + 4 * v), q1 = ld_agent(o + 9 + 4 * v);
+        yb[4 * v] = q0 < yb[4 * v] ? q0 : yb[4 * v];
+        yb[4 * v + 1] = q1 > yb[4 * v + 1] ? q1 : yb[4 * v + 1];
+        yb[4 * v + 2] = fmax(yb[4 * v + 2], ld_agent(o + 10 + 4 * v));
+        yb[4 * v + 3] = fmax(yb[4 * v + 3], ld_agent(o + 11 + 4 * v));
       }
     }
-    ma = fmax(ma, o[0]);
-    mb = fmax(mb, o[1]);
-    mc = fmax(mc, o[2]);
-    const unsigned long long f = (unsigned long long)__double_as_longlong(o[3]);
+    ma = fmax(ma, ld_agent(o));
+    mb = fmax(mb, ld_agent(o + 1));
+    mc = fmax(mc, ld_agent(o + 2));
+    const unsigned long long f = (unsigned long long)__double_as_longlong(ld_agent(o + 3));
     first = f < first ? f : first;
-    nent += o[4];
-    nmain += o[5];
-    emin = o[6] < emin ? o[6] : emin;
-    emax = o[7] > emax ? o[7] : emax;
+    nent += ld_agent(o + 4);
+    nmain += ld_agent(o + 5);
+    const double e0 = ld_agent(o + 6), e1 = ld_agent(o + 7);
+    emin = e0 < emin ? e0 : emin;
+    emax = e1 > emax ? e1 : emax;
   }
   auto fmaxd = [](double u, double v) { return u > v ? u : v; };
   auto fmind = [](double u, double v) { return u < v ? u : v; };
@@ -714,28 +729,50 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_axis(
 // that follows in the stream does the pass properly; otherwise those kernels return
 // at once. Results are bit-identical to the exact sequence either way.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, double* part, GStat* g) {
-  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  // the (idle) partial-record area holds the report slots of the fused kernel
-  OptStat* slots = reinterpret_cast<OptStat*>(part);
+// rays looked at for the first entering ray and the first entering ray with state 1
+#define REFLECT_SCAN 1024
+
+// what the optimistic pass assumes, from the head of the beam (one block of
+// REFLECT_BLOCK lanes). Returns false (and raises g->redo) when no ray of the head
+// enters: the exact sequence then does the pass.
+__device__ __forceinline__ bool decide_opt_body(const xrt_hip_pass& P, const xrt_hip_material& M,
+                                                const xrt_hip_beam& in, OptStat* slots,
+                                                GStat* g, unsigned long long* lds_u) {
   for (int k = threadIdx.x; k < REFLECT_OPT_SLOTS; k += blockDim.x) {
     slots[k].maxdz1 = 0;
     slots[k].maxdz2 = 0;
     slots[k].viol = 0;
   }
-  // (this kernel opens the pass: no separate init launch)
-  if (threadIdx.x == 0) gstat_reset(g, 0);
-  if (!entering(P, in.state[0])) {
+  // (this opens the pass: no separate init launch)
+  if (threadIdx.x == 0) {
+    gstat_reset(g, 0);
+    g->bar = 0;
+    g->hang = 0;
+  }
+  // the first entering ray decides the bracket formula (base.py:1268-1283), the state-1
+  // rays the axis (base.py:1257-1263): the first of each kind within the head
+  unsigned long long i0 = ~0ull, i1 = ~0ull;
+  const int64_t nscan = in.n < REFLECT_SCAN ? in.n : REFLECT_SCAN;
+  for (int64_t i = threadIdx.x; i < nscan; i += blockDim.x) {
+    const int st = in.state[i];
+    if (entering(P, st)) {
+      if ((unsigned long long)i < i0) i0 = (unsigned long long)i;
+      if (st == 1 && (unsigned long long)i < i1) i1 = (unsigned long long)i;
+    }
+  }
+  auto fminu = [](unsigned long long u, unsigned long long v) { return u < v ? u : v; };
+  i0 = block_reduce(i0, fminu, lds_u);
+  i1 = block_reduce(i1, fminu, lds_u);
+  if (i0 == ~0ull) {
     if (threadIdx.x == 0) g->redo = 1;   // nothing assumed: the exact sequence handles it
-    return;
+    return false;
   }
   __syncthreads();                        // the reset precedes the window stores
-  // f1/f2 window: the table interval of ray 0's energy and its two neighbours; rays
+  // f1/f2 window: the table interval of that ray's energy and its two neighbours; rays
   // outside it search the whole table (interp_f1f2)
-  const double E0 = in.E[0];
+  const double E0 = in.E[i0];
   table_windows_block(M, E0, E0, g, lds_u);
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x != 0) return true;
   double wlo = -INFINITY, whi = INFINITY;
   for (int e = 0; e < M.nelem && M.kind != XRT_HIP_MAT_NONE; ++e) {
     const int n = M.tab_n[e];
@@ -748,14 +785,22 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
   }
   g->win_lo = wlo;     // one energy interval in which every element's window holds
   g->win_hi = whi;
-  // axis: ray 0's largest direction cosine (y along a beamline, z at normal incidence);
-  // every state-1 ray then checks that the same cosine strictly dominates its own
-  double a0 = in.a[0], b0 = in.b[0], c0 = in.c[0];
+  // axis: the largest direction cosine of the first state-1 ray (y along a beamline, z at
+  // normal incidence); every state-1 ray then checks that the same cosine strictly
+  // dominates its own. No state-1 ray in the head: y, which is also what the reference
+  // falls back to when the batch has none at all (base.py:1261-1262) -- any state-1 ray
+  // further down still has to agree.
+  int axis = 1;
+  if (i1 != ~0ull) {
+    double a1 = in.a[i1], b1 = in.b[i1], c1 = in.c[i1];
+    local_dir(P, a1, b1, c1);
+    const double m1 = fmax(fmax(fabs(a1), fabs(b1)), fabs(c1));
+    axis = m1 == fabs(a1) ? 0 : (m1 == fabs(b1) ? 1 : 2);
+  }
+  double a0 = in.a[i0], b0 = in.b[i0], c0 = in.c[i0];
   local_dir(P, a0, b0, c0);
-  const double m0 = fmax(fmax(fabs(a0), fabs(b0)), fabs(c0));
-  const int axis = m0 == fabs(a0) ? 0 : (m0 == fabs(b0) ? 1 : 2);
   const double comp0 = axis == 0 ? a0 : (axis == 1 ? b0 : c0);
-  g->first_good = 0;
+  g->first_good = i0;
   g->axis = axis;
   g->positive = comp0 > 0. ? 1 : 0;
   g->t1min = -INFINITY;    // no clamp: escapes are reported instead
@@ -763,30 +808,35 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
   g->maxdz1 = 1.;          // secant
   g->maxdz2 = 0.;
   g->optimistic = 1;
+  return true;
 }
 
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_check_opt(GStat* g,
-                                                                   const OptStat* slots) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  if (!g->optimistic) return;     // redo is up already
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, double* part, GStat* g) {
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
+  // the (idle) partial-record area holds the report slots of the fused kernel
+  decide_opt_body(P, M, in, reinterpret_cast<OptStat*>(part), g, lds_u);
+}
+
+// What the optimistic pass reported, folded by every block that needs the verdict
+// (reflect_exact's gate; 256 slots): true = an assumption was contradicted or the
+// bracket-end |dz| maxima ask for Brent, the pass has to be redone exactly.
+__device__ __forceinline__ bool fold_opt(const OptStat* slots, double* lds_d, double& m1o,
+                                         double& m2o) {
   double m1 = 0., m2 = 0., viol = 0.;
   for (int k = threadIdx.x; k < REFLECT_OPT_SLOTS; k += blockDim.x) {
-    m1 = fmax(m1, __longlong_as_double((long long)slots[k].maxdz1));
-    m2 = fmax(m2, __longlong_as_double((long long)slots[k].maxdz2));
-    viol = fmax(viol, (double)slots[k].viol);
+    m1 = fmax(m1, ld_agent(reinterpret_cast<const double*>(&slots[k].maxdz1)));
+    m2 = fmax(m2, ld_agent(reinterpret_cast<const double*>(&slots[k].maxdz2)));
+    viol = fmax(viol, (double)__hip_atomic_load(&slots[k].viol, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT));
   }
   auto fmaxd = [](double u, double v) { return u > v ? u : v; };
   m1 = block_reduce(m1, fmaxd, lds_d);
   m2 = block_reduce(m2, fmaxd, lds_d);
   viol = block_reduce(viol, fmaxd, lds_d);
-  if (threadIdx.x != 0) return;
-  const bool brent = m2 > m1 * 20.;
-  if (viol != 0. || brent) {
-    g->redo = 1;
-    return;
-  }
-  g->maxdz1 = m1;                 // (diagnostics; the clamp range stays open)
-  g->maxdz2 = m2;
+  m1o = m1;
+  m2o = m2;
+  return viol != 0. || m2 > m1 * 20.;
 }
 
 struct LocalRay {
@@ -808,12 +858,11 @@ __device__ __forceinline__ LocalRay load_local(const xrt_hip_pass& P, const xrt_
 }
 
 template <class K>
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
-    xrt_hip_pass P, xrt_hip_beam in, const GStat* __restrict__ g, double* __restrict__ part) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  if (!g->redo || g->bracket_valid) return;  // nothing to redo / decided from the first pass
+__device__ __forceinline__ void stats_bracket_body(const xrt_hip_pass& P,
+                                                   const xrt_hip_beam& in, int axis,
+                                                   int positive, double* __restrict__ part) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
   double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
-  const int axis = g->axis, positive = g->positive;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
     const int st = in.state[i];
@@ -851,11 +900,10 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_bracket(
 // the whole batch); if the decision comes out as "y", reflect_stats_bracket finds
 // bracket_valid set and returns at once. One pass over the beam saved.
 template <class K>
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir_y(
-    xrt_hip_pass P, xrt_hip_beam in, const GStat* __restrict__ g, double* __restrict__ part) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  if (!g->redo) return;   // the optimistic single pass stands
+__device__ __forceinline__ void stats_dir_y_body(const xrt_hip_pass& P, const xrt_hip_beam& in,
+                                                 double* __restrict__ part) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
   double ma = 0., mb = 0., mc = 0., emin = INFINITY, emax = -INFINITY;
   unsigned long long first = ~0ull, nent = 0, nmain = 0;
   double t1m[2] = {INFINITY, INFINITY}, t2m[2] = {-INFINITY, -INFINITY};
@@ -936,17 +984,16 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_stats_dir_y(
   }
 }
 
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bracket(
-    const double* __restrict__ part, int nblocks, GStat* g) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  if (!g->redo || g->bracket_valid) return;
+__device__ __forceinline__ void reduce_bracket_body(const double* part, int nblocks, GStat* g) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
   double t1m = INFINITY, t2m = -INFINITY, d1m = 0., d2m = 0.;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
     const double* o = part + (int64_t)b * 8;
-    t1m = o[0] < t1m ? o[0] : t1m;
-    t2m = o[1] > t2m ? o[1] : t2m;
-    d1m = fmax(d1m, o[2]);
-    d2m = fmax(d2m, o[3]);
+    const double q0 = ld_agent(o), q1 = ld_agent(o + 1);
+    t1m = q0 < t1m ? q0 : t1m;
+    t2m = q1 > t2m ? q1 : t2m;
+    d1m = fmax(d1m, ld_agent(o + 2));
+    d2m = fmax(d2m, ld_agent(o + 3));
   }
   auto fmaxd = [](double u, double v) { return u > v ? u : v; };
   auto fmind = [](double u, double v) { return u < v ? u : v; };
@@ -963,14 +1010,12 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bracket(
 }
 
 // sum(beamInDotNormal) and count over the rays that hit (crystal path)
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_reduce_bdn(
-    const double* __restrict__ part, int nblocks, GStat* g) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  if (!(g->any_neg && g->any_pos)) return;
+__device__ __forceinline__ void reduce_bdn_body(const double* part, int nblocks, GStat* g) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
   double sum = 0., cnt = 0.;
   for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    sum += part[(int64_t)b * 8];
-    cnt += part[(int64_t)b * 8 + 1];
+    sum += ld_agent(part + (int64_t)b * 8);
+    cnt += ld_agent(part + (int64_t)b * 8 + 1);
   }
   auto faddd = [](double u, double v) { return u + v; };
   sum = block_reduce(sum, faddd, lds_d);
@@ -1428,6 +1473,12 @@ struct RayIn {
   double path, E, Jss, Jpp, Jsr, Jsi, Esr, Esi, Epr, Epi;
 };
 
+struct Rec {   // one whole ray in registers (the beam between the crystals of a DCM)
+  double x, y, z, a, b, c;
+  RayIn f;
+  int st;
+};
+
 __device__ __forceinline__ void rot_coherency(double c, double s, double& Jss, double& Jpp,
                                               double& Jsr, double Jsi) {
   // sources/beams.py:448-479 with c = cos(roll), s = sin(roll) (imaginary part of
@@ -1477,7 +1528,8 @@ __device__ __forceinline__ constexpr bool early_fields() {
   return K::PLAIN && K::MK >= 0 && K::SK >= 0;
 }
 
-template <class K>
+// QREADY: q already holds the ray's fields (they came in registers, not from `in`)
+template <class K, bool QREADY = false>
 __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
                                                const xrt_hip_material& M, const GStat& g,
                                                const LocalRay& r, const Hit& h, RayIn q,
@@ -1672,7 +1724,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   if (cisnan(A.rp)) A.rp = C(0., 0.);
   // now the fields of the incoming ray, rotated into the local s/p frame (the lean
   // specialised kernels have registers to spare and issued these loads up front)
-  if (!early_fields<K>()) load_fields(in, i, has_amp, q);
+  if (!QREADY && !early_fields<K>()) load_fields(in, i, has_amp, q);
   double Jss = q.Jss, Jpp = q.Jpp, Jsr = q.Jsr, Jsi = q.Jsi;
   rot_coherency(cosY, -sinY, Jss, Jpp, Jsr, Jsi);
   cplx Es = C(q.Esr, q.Esi), Ep = C(q.Epr, q.Epi);
@@ -1786,24 +1838,35 @@ __device__ __forceinline__ void copy_ray(const xrt_hip_beam& o, const xrt_hip_be
             es.x, es.y, ep.x, ep.y, has_amp);
 }
 
-// everything after the solve for one entering ray: state, finish, both stores
-template <class K>
-__device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hip_material& M,
-                                             const GStat& g, const xrt_hip_beam& in,
-                                             const xrt_hip_beam& restore,
-                                             const xrt_hip_beam& lb, const xrt_hip_beam& vb,
-                                             double* theta, int64_t i, const LocalRay& r,
-                                             const Hit& h, int st, bool has_amp,
-                                             int own_sign = 0, double* bdn_out = nullptr) {
+// everything after the solve for one entering ray: state, finish, both stores.
+// QREADY: the ray's fields come in qin instead of from `in`. VREC: the outgoing
+// ("virgin") record is handed back in registers instead of being stored, with `kept` =
+// the ray ended in state 1 or 2 (otherwise the caller restores it).
+struct Completed {
+  bool kept;
+  Rec v;
+};
+template <class K, bool QREADY = false, bool VREC = false>
+__device__ __forceinline__ Completed complete_ray(
+    const xrt_hip_pass& P, const xrt_hip_material& M, const GStat& g, const xrt_hip_beam& in,
+    const xrt_hip_beam& restore, const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
+    int64_t i, const LocalRay& r, const Hit& h, int st, bool has_amp, int own_sign = 0,
+    double* bdn_out = nullptr, RayIn qin = RayIn()) {
+  Completed res;
+  res.kept = false;
   RayIn q;
-  q.path = in.path[i];
-  q.E = in.E[i];
-  if (early_fields<K>()) load_fields(in, i, has_amp, q);
+  if (QREADY) {
+    q = qin;
+  } else {
+    q.path = in.path[i];
+    q.E = in.E[i];
+    if (early_fields<K>()) load_fields(in, i, has_amp, q);
+  }
   double la = r.a, lbb = r.b, lc = r.c, th = 0.;
   RayIn lo;
   double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;
   if (st == 1) {
-    const Finished fin = finish_ray<K>(P, M, g, r, h, q, in, i, has_amp, own_sign);
+    const Finished fin = finish_ray<K, QREADY>(P, M, g, r, h, q, in, i, has_amp, own_sign);
     if (bdn_out) *bdn_out = fin.bdn;
     la = fin.a;
     lbb = fin.b;
@@ -1819,7 +1882,7 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
     vEpr = fin.vEpr;
     vEpi = fin.vEpi;
   } else {
-    if (!early_fields<K>()) load_fields(in, i, has_amp, q);
+    if (!QREADY && !early_fields<K>()) load_fields(in, i, has_amp, q);
     lo = q;
     vJss = q.Jss;
     vJpp = q.Jpp;
@@ -1835,9 +1898,10 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
             st, lo.Esr, lo.Esi, lo.Epr, lo.Epi, has_amp);
   const bool keep = P.only_state1_out ? (st == 1) : (st == 1 || st == 2);
   if (!keep) {  // reflect.py:131-134: everything but the state comes from `restore`
-    copy_ray(vb, restore, i, P.force_lost_out ? P.lost_num : st, has_amp, false);
-    return;
+    if (!VREC) copy_ray(vb, restore, i, P.force_lost_out ? P.lost_num : st, has_amp, false);
+    return res;
   }
+  res.kept = true;
   // back to the virgin local frame, reflect.py:1115-1132
   double x = h.x + P.shift[0], y = h.y + P.shift[1], z = h.z + P.shift[2];
   rotate3(P.to_virgin, x, y, z);
@@ -1855,8 +1919,29 @@ __device__ __forceinline__ void complete_ray(const xrt_hip_pass& P, const xrt_hi
     y += P.center[1];
     z += P.center[2];
   }
+  if (VREC) {
+    res.v.x = x;
+    res.v.y = y;
+    res.v.z = z;
+    res.v.a = la;
+    res.v.b = lbb;
+    res.v.c = lc;
+    res.v.f.path = lo.path;
+    res.v.f.E = lo.E;
+    res.v.f.Jss = vJss;
+    res.v.f.Jpp = vJpp;
+    res.v.f.Jsr = vJsr;
+    res.v.f.Jsi = vJsi;
+    res.v.f.Esr = vEsr;
+    res.v.f.Esi = vEsi;
+    res.v.f.Epr = vEpr;
+    res.v.f.Epi = vEpi;
+    res.v.st = st;
+    return res;
+  }
   store_ray(vb, i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, st, vEsr, vEsi,
             vEpr, vEpi, has_amp);
+  return res;
 }
 
 __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hip_beam& in,
@@ -1877,9 +1962,10 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
 // K3 kernels
 // ---------------------------------------------------------------------------
 // mode: 0 = optimistic single pass (runs if g.optimistic; reports to OptStat),
-//       1 = the exact redo (runs if g.redo), 2 = unconditional (no statistics needed)
+//       1 = exact (a phase of reflect_exact: the statistics in g are the batch's own),
+//       2 = unconditional (no statistics needed)
 __device__ __forceinline__ bool fused_skips(const GStat* gp, int mode) {
-  return (mode == 0 && !gp->optimistic) || (mode == 1 && !gp->redo);
+  return mode == 0 && !gp->optimistic;
 }
 
 // |direction cosine| along `axis` strictly larger than the other two
@@ -1891,6 +1977,9 @@ __device__ __forceinline__ bool dominates(int axis, const LocalRay& r) {
 // wave-level fold of the optimistic pass's reports into this block's slot
 __device__ __forceinline__ void report_opt(OptStat* slots, const SolveAux& aux, int viol) {
   double m1 = aux.adz1, m2 = aux.adz2;
+  // np.max hands a NaN on to the secant-or-Brent comparison, fmax would drop it: let
+  // the exact sequence decide
+  viol |= isnan(m1) || isnan(m2);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     m1 = fmax(m1, __shfl_xor(m1, off));
@@ -1949,20 +2038,14 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   }
 }
 
-// The redo (mode 1) runs in 1024-lane blocks: in the usual case that it has nothing to
-// do, 9 800 blocks are dispatched and return in 4 us instead of 39 000 in 15 us.
-#define REFLECT_REDO_BLOCK 1024
 template <class K, int mode>
-__global__ __launch_bounds__(mode == 1 ? REFLECT_REDO_BLOCK : REFLECT_BLOCK,
-                             mode == 1 ? 1 : K::WAVES) void reflect_fused(
+__global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     OptStat* __restrict__ opt) {
   if (fused_skips(gp, mode)) return;
   const GStat g = *gp;
   int neg = 0, pos = 0;
-  // (one ray per lane also in the redo: a strided loop here makes the compiler hoist the
-  // frame constants into VGPRs and spill -- 300 B of scratch, measured)
   fused_ray<K, mode, false>(P, M, in, restore, lb, vb, theta, g, opt,
                             (int64_t)blockIdx.x * blockDim.x + threadIdx.x, neg, pos);
 }
@@ -1972,12 +2055,11 @@ __global__ __launch_bounds__(mode == 1 ? REFLECT_REDO_BLOCK : REFLECT_BLOCK,
 // (of the mean beamInDotNormal) before it can deflect a single ray, which is why
 // the crystal path was solve -> reduce -> finish. For a real beam every ray has
 // the same sign, and then each ray's own sign IS the batch sign: this kernel
-// assumes so, and raises GStat::any_neg / any_pos for the sides it saw. The exact
-// two-pass sequence that follows in the stream returns at once unless both are up.
+// assumes so, and raises GStat::any_neg / any_pos for the sides it saw. Only if both
+// are up does reflect_exact run the two-pass tail.
 // ---------------------------------------------------------------------------
 template <class K, int mode>
-__global__ __launch_bounds__(mode == 1 ? REFLECT_REDO_BLOCK : REFLECT_BLOCK,
-                             mode == 1 ? 1 : 4) void reflect_fused_xtal(
+__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_xtal(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     int* __restrict__ any_neg_pos, OptStat* __restrict__ opt) {
@@ -1998,15 +2080,14 @@ __global__ __launch_bounds__(mode == 1 ? REFLECT_REDO_BLOCK : REFLECT_BLOCK,
 // crystal path, first half: solve + state; stores t, local hit point and state,
 // accumulates sum(beamInDotNormal) over the rays that hit (reflect.py:573)
 template <class K>
-__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
-    xrt_hip_pass P, xrt_hip_beam in, double* ht, double* hx, double* hy, double* hz,
-    int32_t* hst, const GStat* gp, double* __restrict__ part) {
-  __shared__ double lds_d[REFLECT_BLOCK / 64];
-  __shared__ unsigned long long lds_u[REFLECT_BLOCK / 64];
-  if (!(gp->any_neg && gp->any_pos)) return;   // the optimistic single pass was exact
+__device__ __forceinline__ void solve_body(const xrt_hip_pass& P, const xrt_hip_beam& in,
+                                           double* ht, double* hx, double* hy, double* hz,
+                                           int32_t* hst, const GStat& g,
+                                           double* __restrict__ part) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
   double bdn_sum = 0.;
   unsigned long long cnt = 0;
-  const GStat g = *gp;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
     if (!entering(P, in.state[i])) continue;
@@ -2055,39 +2136,461 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_solve(
   }
 }
 
+// second half: every ray is read completely before its outputs are written, so the
+// outputs may share arrays with `in`
 template <class K>
-__global__ __launch_bounds__(REFLECT_REDO_BLOCK, 1) void reflect_finish(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
-    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const double* ht, const double* hx,
-    const double* hy, const double* hz, const int32_t* hst, const GStat* gp) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= in.n || !(gp->any_neg && gp->any_pos)) return;
+__device__ __forceinline__ void finish_body(const xrt_hip_pass& P, const xrt_hip_material& M,
+                                            const xrt_hip_beam& in,
+                                            const xrt_hip_beam& restore,
+                                            const xrt_hip_beam& lb, const xrt_hip_beam& vb,
+                                            double* theta, const double* ht, const double* hx,
+                                            const double* hy, const double* hz,
+                                            const int32_t* hst, const GStat& g) {
   const bool has_amp = in.Es_ri != nullptr;
-  const int st0 = in.state[i];
-  if (!entering(P, st0)) {
-    pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
-    return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
+    const int st0 = in.state[i];
+    if (!entering(P, st0)) {
+      pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
+      continue;
+    }
+    LocalRay r;
+    r.x = 0.;
+    r.y = 0.;
+    r.z = 0.;
+    r.a = in.a[i];
+    r.b = in.b[i];
+    r.c = in.c[i];
+    local_dir(P, r.a, r.b, r.c);
+    Hit h;
+    h.t = ht[i];
+    h.x = hx[i];
+    h.y = hy[i];
+    h.z = hz[i];
+    h.px = h.x;   // crystals are only combined with non-parametric surfaces (capi check)
+    h.py = h.y;
+    h.lost = 0;
+    complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, hst[i], has_amp);
   }
-  const GStat g = *gp;
-  LocalRay r;
-  r.x = 0.;
-  r.y = 0.;
-  r.z = 0.;
-  r.a = in.a[i];
-  r.b = in.b[i];
-  r.c = in.c[i];
-  local_dir(P, r.a, r.b, r.c);
-  Hit h;
-  h.t = ht[i];
-  h.x = hx[i];
-  h.y = hy[i];
-  h.z = hz[i];
-  h.px = h.x;   // crystals are only combined with non-parametric surfaces (capi check)
-  h.py = h.y;
-  h.lost = 0;
-  complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, hst[i], has_amp);
 }
 
+// ---------------------------------------------------------------------------
+// reflect_exact: the exact sequence of one pass in ONE launch. It follows the
+// optimistic kernel in the stream and first folds that kernel's reports: in the usual
+// case that nothing was contradicted (and a crystal batch had one sign) every block
+// returns -- one 4-us launch instead of the nine small ones the sequence used to be.
+// Otherwise its blocks, all resident (<= one 256-lane block per CU), walk through the
+// phases statistics -> decisions -> [bracket statistics -> fold] -> solve + finish ->
+// [crystals with both signs: solve -> mean -> finish], separated by grid barriers.
+// The phases are the batch-global decisions of the reference (base.py:1231-1295,
+// :848-885; reflect.py:573-574). Performance matters little here; the arithmetic per
+// ray is the same code as in the optimistic kernels, so both routes give the same bits.
+// ---------------------------------------------------------------------------
+struct PassAux {   // (the pass, material and beam records travel as kernel arguments of
+                   // their own: inside one struct they end up copied to scratch memory)
+  double* theta;
+  GStat* g;
+  double* part;                   // partial records (one per block) / report slots
+  double *ht, *hx, *hy, *hz;      // crystal tail: hit records between solve and finish
+  int32_t* hst;
+  int aliased;                    // an output shares arrays with an input
+};
+
+// Barrier over all blocks of the launch (Guideline 16's counter form): every wave's
+// stores done -> block sync -> one lane releases at agent scope, arrives, polls with
+// relaxed agent loads, acquires -> block sync. The counter only grows (zeroed by the
+// kernel that opens the pass); `phase` counts the barriers passed. A poll that never
+// ends would take the box down with it: it gives up after ~4 s and flags the pass.
+__device__ __forceinline__ void grid_barrier(GStat* g, unsigned& phase) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ++phase;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    (void)__hip_atomic_fetch_add(&g->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = phase * gridDim.x;
+    unsigned spins = 0;
+    while (__hip_atomic_load(&g->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(32);
+      if (++spins > (1u << 22)) {
+        g->hang = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+// the decisions as another block of this launch wrote them (field by field: a struct
+// copied through a word pointer stays in scratch memory)
+__device__ __forceinline__ int ld_agent_i(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent_u(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ GStat load_gstat(const GStat* g) {
+  GStat r;
+  r.maxa = ld_agent(&g->maxa);
+  r.maxb = ld_agent(&g->maxb);
+  r.maxc = ld_agent(&g->maxc);
+  r.first_good = ld_agent_u(&g->first_good);
+  r.n_enter = ld_agent_u(&g->n_enter);
+  r.n_main = ld_agent_u(&g->n_main);
+  r.axis = ld_agent_i(&g->axis);
+  r.positive = ld_agent_i(&g->positive);
+  r.t1min = ld_agent(&g->t1min);
+  r.t2max = ld_agent(&g->t2max);
+  r.maxdz1 = ld_agent(&g->maxdz1);
+  r.maxdz2 = ld_agent(&g->maxdz2);
+  r.bracket_valid = ld_agent_i(&g->bracket_valid);
+  r.optimistic = ld_agent_i(&g->optimistic);
+  r.redo = ld_agent_i(&g->redo);
+  r.any_neg = ld_agent_i(&g->any_neg);
+  r.any_pos = ld_agent_i(&g->any_pos);
+  r.n_good1 = ld_agent_u(&g->n_good1);
+  r.sum_bdn = ld_agent(&g->sum_bdn);
+  r.emin = ld_agent(&g->emin);
+  r.emax = ld_agent(&g->emax);
+#pragma unroll
+  for (int e = 0; e < XRT_HIP_MAX_ELEM; ++e) {
+    r.tab_lo[e] = ld_agent_i(&g->tab_lo[e]);
+    r.tab_hi[e] = ld_agent_i(&g->tab_hi[e]);
+  }
+  r.win_lo = ld_agent(&g->win_lo);
+  r.win_hi = ld_agent(&g->win_hi);
+  r.bar = 0;
+  r.hang = 0;
+  return r;
+}
+
+// full: statistics -> decisions -> solve + finish (+ crystal tail if the batch has both
+// signs); otherwise the crystal tail alone, on the decisions already in g
+template <class K>
+__device__ __forceinline__ void exact_pass(const xrt_hip_pass& P, const xrt_hip_material& M,
+                                           const xrt_hip_beam& in, const xrt_hip_beam& restore,
+                                           const xrt_hip_beam& lb, const xrt_hip_beam& vb,
+                                           const PassAux& A, bool full, unsigned& phase) {
+  GStat* g = A.g;
+  const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  const bool blazed = P.surf_kind == XRT_HIP_SURF_BLAZED;
+  bool tail = !full;
+  if (full) {
+    if (!P.no_intersection_search) {
+      // reductions: one partial record per block, folded by block 0
+      if (blazed)   // closed-form intersection: no brackets at all
+        stats_dir_body(P, in, A.part);
+      else
+        stats_dir_y_body<K>(P, in, A.part);
+      grid_barrier(g, phase);
+      if (blockIdx.x == 0)
+        decide_axis_body(P, M, in, A.part, (int)gridDim.x, blazed ? 8 : 16, g);
+      grid_barrier(g, phase);
+      if (!blazed) {
+        const GStat gl = load_gstat(g);
+        if (!gl.bracket_valid && gl.n_enter > 0) {   // the axis is not y: second pass
+          stats_bracket_body<K>(P, in, gl.axis, gl.positive, A.part);
+          grid_barrier(g, phase);
+          if (blockIdx.x == 0) reduce_bracket_body(A.part, (int)gridDim.x, g);
+          grid_barrier(g, phase);
+        }
+      }
+    }
+    if (need_mean && A.aliased) {
+      // the own-sign kernel would overwrite the rays the tail has to read again
+      tail = true;
+    } else {
+      const GStat gl = load_gstat(g);
+      int neg = 0, pos = 0;
+      const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+      for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < in.n; base += stride) {
+        if (need_mean)
+          fused_ray<K, 1, true>(P, M, in, restore, lb, vb, A.theta, gl, nullptr,
+                                base + threadIdx.x, neg, pos);
+        else
+          fused_ray<K, 1, false>(P, M, in, restore, lb, vb, A.theta, gl, nullptr,
+                                 base + threadIdx.x, neg, pos);
+      }
+      if (need_mean) {
+        neg = __syncthreads_or(neg);
+        pos = __syncthreads_or(pos);
+        if (threadIdx.x == 0) {
+          if (neg) (void)atomicOr(&g->any_neg, 1);
+          if (pos) (void)atomicOr(&g->any_pos, 1);
+        }
+        grid_barrier(g, phase);
+        const GStat g2 = load_gstat(g);
+        tail = g2.any_neg && g2.any_pos;
+      }
+    }
+  }
+  if (need_mean && tail) {
+    // exact two-pass sign sequence: the mean of beamInDotNormal over the rays that hit
+    GStat gl = load_gstat(g);
+    solve_body<K>(P, in, A.ht, A.hx, A.hy, A.hz, A.hst, gl, A.part);
+    grid_barrier(g, phase);
+    if (blockIdx.x == 0) reduce_bdn_body(A.part, (int)gridDim.x, g);
+    grid_barrier(g, phase);
+    gl = load_gstat(g);
+    finish_body<K>(P, M, in, restore, lb, vb, A.theta, A.ht, A.hx, A.hy, A.hz, A.hst,
+                   gl);
+  }
+}
+
+#define REFLECT_EXACT_BLOCK 256
+// verdict on the optimistic kernel that ran before (every block folds the 256 report
+// slots itself); block 0 leaves it in g for the host's diagnostics
+__device__ __forceinline__ bool exact_gate(GStat* g, const OptStat* slots, double* lds_d) {
+  bool full;
+  if (g->optimistic) {
+    double m1, m2;
+    full = fold_opt(slots, lds_d, m1, m2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      g->redo = full ? 1 : 0;
+      if (!full) {
+        g->maxdz1 = m1;   // (diagnostics; the clamp range stays open)
+        g->maxdz2 = m2;
+      }
+    }
+  } else {
+    full = g->redo != 0;
+  }
+  return full;
+}
+
+template <class K>
+__global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_exact(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore, xrt_hip_beam lb,
+    xrt_hip_beam vb, PassAux A) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  const bool mixed = need_mean && A.g->any_neg && A.g->any_pos;
+  const bool full = exact_gate(A.g, reinterpret_cast<const OptStat*>(A.part), lds_d);
+  if (!full && !mixed) return;
+  unsigned phase = 0;
+  exact_pass<K>(P, M, in, restore, lb, vb, A, full, phase);
+}
+
+// ---------------------------------------------------------------------------
+// DCM.double_reflect (dcm.py:248-354) in one kernel: both crystals per ray, the
+// virgin-local beam between them (100 B/ray written by the first pass and read back by
+// the second when they are separate launches) stays in registers. Flat crystals.
+// The second crystal's batch decisions cannot come from its first entering ray (that ray
+// exists only after the first crystal): they are GUESSED from the head ray's direction
+// mirrored at the first crystal, and every ray entering the second crystal checks that
+// its own direction cosine along the guessed axis dominates (if it has state 1) and has
+// the guessed sign -- then the first of them has it too, which is all the reference
+// looks at. A contradiction on either crystal, Brent, or a crystal batch with both
+// signs makes dcm_exact redo both passes exactly.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_rec(Rec& q, const xrt_hip_beam& s, int64_t i,
+                                         bool has_amp) {
+  q.x = s.x[i];
+  q.y = s.y[i];
+  q.z = s.z[i];
+  q.a = s.a[i];
+  q.b = s.b[i];
+  q.c = s.c[i];
+  q.f.path = s.path[i];
+  q.f.E = s.E[i];
+  load_fields(s, i, has_amp, q.f);
+  q.st = s.state[i];
+}
+
+__device__ __forceinline__ void store_rec(const xrt_hip_beam& o, int64_t i, const Rec& q,
+                                          int st, bool has_amp, bool zero_xyz) {
+  store_ray(o, i, zero_xyz ? 0. : q.x, zero_xyz ? 0. : q.y, zero_xyz ? 0. : q.z, q.a, q.b,
+            q.c, q.f.path, q.f.E, q.f.Jss, q.f.Jpp, q.f.Jsr, q.f.Jsi, st, q.f.Esr, q.f.Esi,
+            q.f.Epr, q.f.Epi, has_amp);
+}
+
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_dcm(
+    xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2,
+    xrt_hip_beam in, double* part1, double* part2, GStat* g1, GStat* g2) {
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
+  OptStat* slots2 = reinterpret_cast<OptStat*>(part2);
+  for (int k = threadIdx.x; k < REFLECT_OPT_SLOTS; k += blockDim.x) {
+    slots2[k].maxdz1 = 0;
+    slots2[k].maxdz2 = 0;
+    slots2[k].viol = 0;
+  }
+  if (threadIdx.x == 0) {
+    gstat_reset(g2, 0);
+    g2->bar = 0;
+    g2->hang = 0;
+  }
+  const bool ok = decide_opt_body(P1, M1, in, reinterpret_cast<OptStat*>(part1), g1, lds_u);
+  if (!ok) return;     // g1->redo is up: dcm_exact does both passes
+  __syncthreads();
+  const int64_t i0 = (int64_t)g1->first_good;
+  const double E0 = in.E[i0];
+  table_windows_block(M2, E0, E0, g2, lds_u);
+  if (threadIdx.x != 0) return;
+  double wlo = -INFINITY, whi = INFINITY;
+  for (int e = 0; e < M2.nelem && M2.kind != XRT_HIP_MAT_NONE; ++e) {
+    const int n = M2.tab_n[e];
+    const int lo = g2->tab_lo[e] > 0 ? g2->tab_lo[e] - 1 : 0;
+    const int hi = g2->tab_hi[e] + 1 < n ? g2->tab_hi[e] + 1 : n;
+    g2->tab_lo[e] = lo;
+    g2->tab_hi[e] = hi;
+    if (lo > 0) wlo = fmax(wlo, M2.tab_E[e][lo - 1]);
+    if (hi < n) whi = fmin(whi, M2.tab_E[e][hi]);
+  }
+  g2->win_lo = wlo;
+  g2->win_hi = whi;
+  // the head ray mirrored at the first crystal's surface, seen from the second crystal
+  double a = in.a[i0], b = in.b[i0], c = in.c[i0];
+  local_dir(P1, a, b, c);
+  const double dn = a * P1.n_const[3] + b * P1.n_const[4] + c * P1.n_const[5];
+  a -= 2. * dn * P1.n_const[3];
+  b -= 2. * dn * P1.n_const[4];
+  c -= 2. * dn * P1.n_const[5];
+  rotate3(P1.to_virgin, a, b, c);
+  local_dir(P2, a, b, c);
+  const double m = fmax(fmax(fabs(a), fabs(b)), fabs(c));
+  const int axis = m == fabs(a) ? 0 : (m == fabs(b) ? 1 : 2);
+  const double comp = axis == 0 ? a : (axis == 1 ? b : c);
+  g2->first_good = (unsigned long long)i0;
+  g2->axis = axis;
+  g2->positive = comp > 0. ? 1 : 0;
+  g2->t1min = -INFINITY;
+  g2->t2max = INFINITY;
+  g2->maxdz1 = 1.;
+  g2->maxdz2 = 0.;
+  g2->optimistic = 1;
+}
+
+template <class K>
+__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_dcm(
+    xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2,
+    xrt_hip_beam in, xrt_hip_beam lo1, xrt_hip_beam lo2, xrt_hip_beam gb2, double* theta1,
+    double* theta2, const GStat* __restrict__ g1p, const GStat* __restrict__ g2p,
+    int* __restrict__ flags1, int* __restrict__ flags2, OptStat* __restrict__ opt1,
+    OptStat* __restrict__ opt2) {
+  if (!g1p->optimistic) return;      // nothing could be assumed: dcm_exact does the work
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool has_amp = in.Es_ri != nullptr;
+  const bool live = i < in.n;
+  int neg1 = 0, pos1 = 0, neg2 = 0, pos2 = 0;
+  Rec v = {};         // the beam between the crystals (virgin local frame), this ray
+  // ---- first crystal ----
+  {
+    const GStat g = *g1p;
+    const int st0 = live ? in.state[i] : 0;
+    const LocalRay r = load_local(P1, in, live ? i : 0);
+    const bool active = live && entering(P1, st0);
+    SolveAux aux;
+    int viol = 0;
+    Hit h;
+    if (active) {
+      h = solve_ray<K, true>(P1, g, r, &aux);
+      viol = st0 == 1 && !dominates(g.axis, r);
+    }
+    report_opt(opt1, aux, viol);
+    bool kept = false;
+    if (active) {
+      int st = rays_good(P1, h.x, h.y);
+      if (h.lost) st = P1.lost_num;
+      double bdn = 0.;
+      const Completed c1 = complete_ray<K, false, true>(P1, M1, g, in, in, lo1, lo1, theta1, i, r,
+                                                        h, st, has_amp, 1, &bdn);
+      kept = c1.kept;
+      neg1 |= st == 1 && bdn < 0.;
+      pos1 |= st == 1 && !(bdn < 0.);
+      if (kept) {
+        v = c1.v;
+      } else {       // reflect.py:131-134: everything but the state comes from the input
+        load_rec(v, in, i, has_amp);
+        v.st = P1.force_lost_out ? P1.lost_num : st;
+      }
+    } else if (live) {
+      load_rec(v, in, i, has_amp);
+      store_rec(lo1, i, v, P1.zero_local_not_entering ? 0 : st0, has_amp,
+                P1.zero_local_not_entering != 0);
+      if (theta1) theta1[i] = 0.;
+      v.st = P1.force_lost_out ? P1.lost_num : st0;
+    }
+  }
+  // ---- second crystal ----
+  {
+    const GStat g = *g2p;
+    LocalRay r;
+    r.x = v.x;
+    r.y = v.y;
+    r.z = v.z;
+    r.a = v.a;
+    r.b = v.b;
+    r.c = v.c;
+    const bool active = live && entering(P2, v.st);
+    SolveAux aux;
+    int viol = 0;
+    Hit h;
+    if (active) {
+      local_pos(P2, r.x, r.y, r.z);
+      local_dir(P2, r.a, r.b, r.c);
+      h = solve_ray<K, true>(P2, g, r, &aux);
+      const double comp = g.axis == 0 ? r.a : (g.axis == 1 ? r.b : r.c);
+      viol = (v.st == 1 && !dominates(g.axis, r)) || ((comp > 0. ? 1 : 0) != g.positive);
+    }
+    report_opt(opt2, aux, viol);
+    if (active) {
+      int st = rays_good(P2, h.x, h.y);
+      if (h.lost) st = P2.lost_num;
+      double bdn = 0.;
+      complete_ray<K, true>(P2, M2, g, in, in, lo2, gb2, theta2, i, r, h, st, has_amp, 1, &bdn,
+                            v.f);
+      neg2 |= st == 1 && bdn < 0.;
+      pos2 |= st == 1 && !(bdn < 0.);
+    } else if (live) {
+      // dcm.py:298-303 zeroes the local record of rays that never reached the crystal;
+      // the global beam gets the ORIGINAL ray back (dcm.py:330-335)
+      store_rec(lo2, i, v, P2.zero_local_not_entering ? 0 : v.st, has_amp,
+                P2.zero_local_not_entering != 0);
+      if (theta2) theta2[i] = 0.;
+      copy_ray(gb2, in, i, P2.force_lost_out ? P2.lost_num : v.st, has_amp, false);
+    }
+  }
+  neg1 = __syncthreads_or(neg1);
+  pos1 = __syncthreads_or(pos1);
+  neg2 = __syncthreads_or(neg2);
+  pos2 = __syncthreads_or(pos2);
+  if (threadIdx.x == 0) {
+    if (neg1) flags1[0] = 1;
+    if (pos1) flags1[1] = 1;
+    if (neg2) flags2[0] = 1;
+    if (pos2) flags2[1] = 1;
+  }
+}
+
+template <class K>
+__global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_dcm_exact(
+    xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2, xrt_hip_beam in,
+    xrt_hip_beam lo1, xrt_hip_beam lo2, xrt_hip_beam gb2, PassAux A1, PassAux A2) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  GStat *g1 = A1.g, *g2 = A2.g;
+  const bool mixed = (g1->any_neg && g1->any_pos) || (g2->any_neg && g2->any_pos);
+  const bool forced = !g1->optimistic;
+  bool full = forced;
+  if (!forced) {
+    const bool f1 = exact_gate(g1, reinterpret_cast<const OptStat*>(A1.part), lds_d);
+    const bool f2 = exact_gate(g2, reinterpret_cast<const OptStat*>(A2.part), lds_d);
+    full = f1 || f2;
+  }
+  if (!full && !mixed) return;
+  // anything off (rare): both passes as separate exact passes, the beam between them in
+  // gb2's arrays (the second pass reads every ray before it overwrites it)
+  unsigned phase1 = 0, phase2 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g1->redo = 1;
+    g2->redo = 1;
+    g2->any_neg = g2->any_pos = 0;
+  }
+  exact_pass<K>(P1, M1, in, in, lo1, gb2, A1, true, phase1);
+  grid_barrier(g1, phase1);
+  exact_pass<K>(P2, M2, gb2, in, lo2, gb2, A2, true, phase2);
+}
 
 // ---------------------------------------------------------------------------
 // stand-alone amplitude kernels (Material.get_amplitude / Crystal.get_amplitude)
@@ -2140,14 +2643,70 @@ hipError_t crystal_amplitude_launch(const xrt_hip_material& M, int64_t n, const 
 // host-side launcher
 // ---------------------------------------------------------------------------
 size_t reflect_workspace_bytes(int64_t n) {
-  // GStat (256 B) + per-block partials + t, x, y, z (4 x 8n) + state (4n)
+  // two passes' worth (DCM) of GStat (256 B) + per-block partials, then t, x, y, z
+  // (4 x 8n) + state (4n) of the crystal tail
   const size_t a = ((size_t)n * 8 + 255) / 256 * 256;
   const size_t s = ((size_t)n * 4 + 255) / 256 * 256;
-  return 256 + REFLECT_PART_BYTES + 4 * a + s;
+  return 2 * (256 + REFLECT_PART_BYTES) + 4 * a + s;
 }
 
+// any array of one beam is an array of the other
 static bool beams_overlap(const xrt_hip_beam& a, const xrt_hip_beam& b) {
-  return a.x == b.x || a.a == b.a || a.state == b.state || a.Jss == b.Jss || a.E == b.E;
+  const void* pa[] = {a.x, a.y, a.z, a.a, a.b, a.c, a.path, a.E, a.Jss, a.Jpp, a.Jsp_ri,
+                      a.state, a.Es_ri, a.Ep_ri};
+  const void* pb[] = {b.x, b.y, b.z, b.a, b.b, b.c, b.path, b.E, b.Jss, b.Jpp, b.Jsp_ri,
+                      b.state, b.Es_ri, b.Ep_ri};
+  for (const void* u : pa)
+    for (const void* v : pb)
+      if (u && u == v) return true;
+  return false;
+}
+
+__global__ void reflect_init(GStat* g, int redo) {
+  gstat_reset(g, redo);
+  g->bar = 0;
+  g->hang = 0;
+}
+
+// blocks of reflect_exact: all of them resident at once (one 256-lane block per CU:
+// 1 wave per SIMD, up to 512 VGPRs -- the generic code of every phase without spilling)
+static unsigned exact_blocks(int64_t n) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 64;
+  }
+  int64_t b = (n + REFLECT_EXACT_BLOCK - 1) / REFLECT_EXACT_BLOCK;
+  if (b > cus) b = cus;
+  if (b > (int64_t)REFLECT_MAX_PART) b = REFLECT_MAX_PART;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+struct WsLayout {
+  GStat *g1, *g2;
+  double *part1, *part2;
+  double *ht, *hx, *hy, *hz;
+  int32_t* hst;
+};
+
+static WsLayout ws_layout(void* workspace, int64_t n) {
+  const size_t a = ((size_t)n * 8 + 255) / 256 * 256;
+  char* w = reinterpret_cast<char*>(workspace);
+  WsLayout L;
+  L.g1 = reinterpret_cast<GStat*>(w);
+  L.part1 = reinterpret_cast<double*>(w + 256);
+  L.g2 = reinterpret_cast<GStat*>(w + 256 + REFLECT_PART_BYTES);
+  L.part2 = reinterpret_cast<double*>(w + 2 * 256 + REFLECT_PART_BYTES);
+  char* base = w + 2 * (256 + REFLECT_PART_BYTES);
+  L.ht = reinterpret_cast<double*>(base);
+  L.hx = reinterpret_cast<double*>(base + a);
+  L.hy = reinterpret_cast<double*>(base + 2 * a);
+  L.hz = reinterpret_cast<double*>(base + 3 * a);
+  L.hst = reinterpret_cast<int32_t*>(base + 4 * a);
+  return L;
 }
 
 hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
@@ -2158,25 +2717,20 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                bool force_exact) {
   static_assert(sizeof(GStat) <= 256, "workspace head slot");
   static_assert(REFLECT_OPT_SLOTS * sizeof(OptStat) <= REFLECT_PART_BYTES, "report slots");
-  GStat* g = reinterpret_cast<GStat*>(workspace);
   const int64_t n = in.n;
   if (n <= 0) return hipSuccess;
-  const size_t a = ((size_t)n * 8 + 255) / 256 * 256;
-  double* part = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + 256);
+  const WsLayout L = ws_layout(workspace, n);
+  GStat* g = L.g1;
+  double* part = L.part1;
   OptStat* opt = reinterpret_cast<OptStat*>(part);
-  char* base = reinterpret_cast<char*>(workspace) + 256 + REFLECT_PART_BYTES;
-  double* ht = reinterpret_cast<double*>(base);
-  double* hx = reinterpret_cast<double*>(base + a);
-  double* hy = reinterpret_cast<double*>(base + 2 * a);
-  double* hz = reinterpret_cast<double*>(base + 3 * a);
-  int32_t* hst = reinterpret_cast<int32_t*>(base + 4 * a);
   const dim3 grid((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)), block(REFLECT_BLOCK);
-  // The optimistic single pass (see reflect_decide_opt) needs the input intact for a
+  // The optimistic single pass (see decide_opt_body) needs the input intact for a
   // possible redo, and surfaces that bracket at all.
-  const bool searches = !P.no_intersection_search && P.surf_kind != XRT_HIP_SURF_BLAZED;
-  const bool optimistic = searches && !force_exact && !beams_overlap(in, lb) &&
-                          !beams_overlap(in, vb) && !beams_overlap(restore, lb) &&
-                          !beams_overlap(restore, vb);
+  const bool aliased = beams_overlap(in, lb) || beams_overlap(in, vb) ||
+                       beams_overlap(restore, lb) || beams_overlap(restore, vb);
+  const bool nis = P.no_intersection_search != 0;
+  const bool searches = !nis && P.surf_kind != XRT_HIP_SURF_BLAZED;
+  const bool optimistic = searches && !force_exact && !aliased;
   const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
   const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
   using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
@@ -2184,13 +2738,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   using ToroidMirror = Spec<0, XRT_HIP_SURF_TOROID, XRT_HIP_MAT_MIRROR, true>;
   using FlatMirror = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_MIRROR, true>;
   using BentMirror = Spec<0, XRT_HIP_SURF_BENTFLAT, XRT_HIP_MAT_MIRROR, true>;
-  // the solve + finish kernel of this (surface, material) in the given mode
-  const dim3 redo_block(REFLECT_REDO_BLOCK);
-  const dim3 redo_grid((unsigned)((n + REFLECT_REDO_BLOCK - 1) / REFLECT_REDO_BLOCK));
+  // the solve + finish kernel of this (surface, material): mode 0 (optimistic) or 2
   auto launch_fused = [&](auto mode_tag) {
     constexpr int mode = decltype(mode_tag)::value;
-    const dim3 grid = mode == 1 ? redo_grid : dim3((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK));
-    const dim3 block = mode == 1 ? redo_block : dim3(REFLECT_BLOCK);
     if (need_mean) {
       // Bragg-reflecting crystals sit on flat surfaces in practice (DCM): that case is
       // compiled with the kinds fixed. Each ray takes its own sign of beamInDotNormal
@@ -2226,87 +2776,123 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     }
 #undef XRT_FUSED
   };
+  PassAux A;
+  A.theta = theta;
+  A.g = g;
+  A.part = part;
+  A.ht = L.ht;
+  A.hx = L.hx;
+  A.hy = L.hy;
+  A.hz = L.hz;
+  A.hst = L.hst;
+  A.aliased = aliased ? 1 : 0;
+  const dim3 xgrid(exact_blocks(n)), xblock(REFLECT_EXACT_BLOCK);
+  auto launch_exact = [&]() {
+    if (P.surf_kind >= XRT_HIP_SURF_BLAZED)
+      hipLaunchKernelGGL(reflect_exact<Generic1>, xgrid, xblock, 0, st, P, M, in, restore, lb,
+                         vb, A);
+    else
+      hipLaunchKernelGGL(reflect_exact<Generic0>, xgrid, xblock, 0, st, P, M, in, restore, lb,
+                         vb, A);
+  };
   if (ev0) (void)hipEventRecord(ev0, st);
-  if (!optimistic) hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g, 1);
-  // reductions: one partial record per block, folded by a one-block kernel
-  // (measured on 1e7 rays: 32 rays per lane / ~1200 blocks beat 4 rays per lane by 3 %
-  // of the pass - fewer partial records to fold; small batches keep >= 1024 blocks)
-  const unsigned full = (unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK);
-  unsigned rblocks = (unsigned)((n + 32 * REFLECT_BLOCK - 1) / (32 * REFLECT_BLOCK));
-  if (rblocks < 1024u) rblocks = full < 1024u ? full : 1024u;
-  if (rblocks > REFLECT_MAX_PART) rblocks = REFLECT_MAX_PART;
-  const dim3 rgrid(rblocks);
   if (optimistic) {
+    // assumptions from the head of the beam -> the pass on them, every ray checking ->
+    // reflect_exact: folds the reports, returns at once unless one was contradicted
     hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, g);
     if (evk0) (void)hipEventRecord(evk0, st);
     launch_fused(std::integral_constant<int, 0>());
     if (evk1) (void)hipEventRecord(evk1, st);
-    hipLaunchKernelGGL(reflect_check_opt, dim3(1), block, 0, st, g, opt);
-  }
-  // the exact sequence: every kernel of it returns at once unless g->redo is up
-  if (!P.no_intersection_search) {
-    using ToroidAny = Spec<0, XRT_HIP_SURF_TOROID, -1, false>;
-    using FlatAny = Spec<0, XRT_HIP_SURF_FLAT, -1, false>;
-    int pstride = 16;
-    switch (P.surf_kind) {
-      case XRT_HIP_SURF_BLAZED:   // closed-form intersection: no brackets at all
-        pstride = 8;
-        hipLaunchKernelGGL(reflect_stats_dir, rgrid, block, 0, st, P, in, part);
-        break;
-      case XRT_HIP_SURF_ELLIPSE_PARAM:
-        hipLaunchKernelGGL(reflect_stats_dir_y<Generic1>, rgrid, block, 0, st, P, in, g, part);
-        break;
-      case XRT_HIP_SURF_TOROID:
-        hipLaunchKernelGGL(reflect_stats_dir_y<ToroidAny>, rgrid, block, 0, st, P, in, g, part);
-        break;
-      case XRT_HIP_SURF_FLAT:
-        hipLaunchKernelGGL(reflect_stats_dir_y<FlatAny>, rgrid, block, 0, st, P, in, g, part);
-        break;
-      default:
-        hipLaunchKernelGGL(reflect_stats_dir_y<Generic0>, rgrid, block, 0, st, P, in, g, part);
+    launch_exact();
+  } else if (nis) {
+    // no intersection search: no batch statistics; only a crystal batch with both signs
+    // of beamInDotNormal needs the tail
+    const bool tail_only = need_mean && aliased;   // the tail reads every ray before writing
+    hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g, tail_only ? 1 : 0);
+    if (evk0) (void)hipEventRecord(evk0, st);
+    if (tail_only) {
+      launch_exact();
+    } else {
+      launch_fused(std::integral_constant<int, 2>());
+      if (need_mean) launch_exact();
     }
-    hipLaunchKernelGGL(reflect_decide_axis, dim3(1), block, 0, st, P, M, in, part, (int)rblocks,
-                       pstride, g);
-    if (P.surf_kind != XRT_HIP_SURF_BLAZED) {  // blazed: closed form, no clamps
-      switch (P.surf_kind) {
-        case XRT_HIP_SURF_ELLIPSE_PARAM:
-          hipLaunchKernelGGL(reflect_stats_bracket<Generic1>, rgrid, block, 0, st, P, in, g, part);
-          break;
-        case XRT_HIP_SURF_TOROID:
-          hipLaunchKernelGGL(reflect_stats_bracket<ToroidAny>, rgrid, block, 0, st, P, in, g, part);
-          break;
-        case XRT_HIP_SURF_FLAT:
-          hipLaunchKernelGGL(reflect_stats_bracket<FlatAny>, rgrid, block, 0, st, P, in, g, part);
-          break;
-        default:
-          hipLaunchKernelGGL(reflect_stats_bracket<Generic0>, rgrid, block, 0, st, P, in, g, part);
-      }
-      hipLaunchKernelGGL(reflect_reduce_bracket, dim3(1), block, 0, st, part, (int)rblocks, g);
-    }
+    if (evk1) (void)hipEventRecord(evk1, st);
+  } else {
+    hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, g, 1);
+    if (evk0) (void)hipEventRecord(evk0, st);
+    launch_exact();
+    if (evk1) (void)hipEventRecord(evk1, st);
   }
-  if (!optimistic && evk0) (void)hipEventRecord(evk0, st);
-  if (P.no_intersection_search)
-    launch_fused(std::integral_constant<int, 2>());
-  else
-    launch_fused(std::integral_constant<int, 1>());
-  if (!optimistic && evk1) (void)hipEventRecord(evk1, st);
-  if (need_mean) {
-    // exact two-pass sign sequence, a no-op unless the batch had both signs
-    const dim3 sgrid(grid.x < REFLECT_MAX_PART ? grid.x : REFLECT_MAX_PART);
-    if (flat_xtal)
-      hipLaunchKernelGGL(reflect_solve<FlatXtal>, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst,
-                         g, part);
+  if (ev1) (void)hipEventRecord(ev1, st);
+  return hipGetLastError();
+}
+
+// both crystals flat, both Bragg-reflecting (the reference's DCM), the same thickness
+// class (one kernel instantiation serves both), beam enters in the global frame and
+// leaves in it
+bool reflect_dcm_fusable(const xrt_hip_pass& P1, const xrt_hip_material& M1,
+                         const xrt_hip_pass& P2, const xrt_hip_material& M2) {
+  auto bragg = [](const xrt_hip_material& M) {
+    return M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  };
+  auto flat = [](const xrt_hip_pass& P) {
+    return P.surf_kind == XRT_HIP_SURF_FLAT && !P.no_intersection_search && !P.grating;
+  };
+  return bragg(M1) && bragg(M2) && flat(P1) && flat(P2) && (M1.thick != 0) == (M2.thick != 0) &&
+         !P1.out_to_global && !P2.in_is_global && !P1.only_state1_out && !P2.only_state1_out;
+}
+
+hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1,
+                              const xrt_hip_pass& P2, const xrt_hip_material& M2,
+                              const xrt_hip_beam& in, const xrt_hip_beam& lo1,
+                              const xrt_hip_beam& lo2, const xrt_hip_beam& gb2,
+                              double* theta1, double* theta2, void* workspace,
+                              hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
+                              hipEvent_t evk0, hipEvent_t evk1, bool force_exact) {
+  const int64_t n = in.n;
+  if (n <= 0) return hipSuccess;
+  const WsLayout L = ws_layout(workspace, n);
+  using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
+  const dim3 grid((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)), block(REFLECT_BLOCK);
+  // (redo: the beam between the crystals lives in gb2's arrays)
+  PassAux a1, a2;
+  a1.theta = theta1;
+  a1.g = L.g1;
+  a1.part = L.part1;
+  a1.ht = L.ht;
+  a1.hx = L.hx;
+  a1.hy = L.hy;
+  a1.hz = L.hz;
+  a1.hst = L.hst;
+  a1.aliased = 0;
+  a2 = a1;
+  a2.theta = theta2;
+  a2.g = L.g2;
+  a2.part = L.part2;
+  a2.aliased = 1;
+  if (ev0) (void)hipEventRecord(ev0, st);
+  if (force_exact) {
+    hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, L.g1, 1);
+    hipLaunchKernelGGL(reflect_init, dim3(1), dim3(1), 0, st, L.g2, 1);
+    if (evk0) (void)hipEventRecord(evk0, st);
+  } else {
+    hipLaunchKernelGGL(reflect_decide_dcm, dim3(1), block, 0, st, P1, M1, P2, M2, in, L.part1,
+                       L.part2, L.g1, L.g2);
+    if (evk0) (void)hipEventRecord(evk0, st);
+#define XRT_DCM(SPEC)                                                                       \
+  hipLaunchKernelGGL(reflect_fused_dcm<SPEC>, grid, block, 0, st, P1, M1, P2, M2, in, lo1, \
+                     lo2, gb2, theta1, theta2, L.g1, L.g2, &L.g1->any_neg, &L.g2->any_neg, \
+                     reinterpret_cast<OptStat*>(L.part1), reinterpret_cast<OptStat*>(L.part2))
+    if (M1.thick)
+      XRT_DCM(ThickXtal<XRT_HIP_SURF_FLAT>);
     else
-      hipLaunchKernelGGL(reflect_solve<AnyXtal>, sgrid, block, 0, st, P, in, ht, hx, hy, hz, hst,
-                         g, part);
-    hipLaunchKernelGGL(reflect_reduce_bdn, dim3(1), block, 0, st, part, (int)sgrid.x, g);
-    if (flat_xtal)
-      hipLaunchKernelGGL(reflect_finish<FlatXtal>, redo_grid, redo_block, 0, st, P, M, in,
-                         restore, lb, vb, theta, ht, hx, hy, hz, hst, g);
-    else
-      hipLaunchKernelGGL(reflect_finish<AnyXtal>, redo_grid, redo_block, 0, st, P, M, in,
-                         restore, lb, vb, theta, ht, hx, hy, hz, hst, g);
+      XRT_DCM(FlatXtal);
+#undef XRT_DCM
+    if (evk1) (void)hipEventRecord(evk1, st);
   }
+  hipLaunchKernelGGL(reflect_dcm_exact<Generic0>, dim3(exact_blocks(n)),
+                     dim3(REFLECT_EXACT_BLOCK), 0, st, P1, M1, P2, M2, in, lo1, lo2, gb2, a1, a2);
+  if (force_exact && evk1) (void)hipEventRecord(evk1, st);
   if (ev1) (void)hipEventRecord(ev1, st);
   return hipGetLastError();
 }
