@@ -294,6 +294,30 @@ XRT_HIP_API int xrt_hip_double_reflect_f64_dev(
     double* theta1, double* theta2, void* workspace, size_t workspace_bytes, void* stream,
     float* kernel_ms);
 
+/* The surface functions of an element on device arrays -- what the reference's OE
+ * classes expose as local_z / local_n / local_r / xyz_to_param / param_to_xyz
+ * (oes/base.py:675-742, oes/__init__.py:398-411, oes/parametric.py:213-247), evaluated
+ * by the code the ray kernels use. Only the surface part of `pass` is read.
+ *   what 0: (u, v) = (x, y) -> z           1: (u, v) = (x, y) | (s, phi) -> n[0..5]
+ *        2: (u, v) = (s, phi) -> r         3: (u, v, w) = (x, y, z) -> (s, phi, r)
+ *        4: (u, v, w) = (s, phi, r) -> (x, y, z)
+ * out: k-th output of point i at out[k * n + i] (1, 6, 1, 3, 3 outputs). */
+#define XRT_HIP_SURF_EVAL_Z 0
+#define XRT_HIP_SURF_EVAL_N 1
+#define XRT_HIP_SURF_EVAL_R 2
+#define XRT_HIP_SURF_EVAL_TO_PARAM 3
+#define XRT_HIP_SURF_EVAL_FROM_PARAM 4
+XRT_HIP_API int xrt_hip_surface_eval_f64_dev(const xrt_hip_pass* pass, int what, int64_t n,
+                                             const double* u, const double* v,
+                                             const double* w, double* out, void* stream);
+
+/* OE.local_to_global (oes/base.py:1165-1229) on a device-resident beam, IN PLACE: true
+ * local frame -> global frame (pass: shift, to_virgin, sin_az / cos_az, center,
+ * out_to_global), coherency matrix and amplitudes turned by roll + atan2(n_x, n_z)
+ * (pass: cos_roll, sin_roll and the surface). Every ray, whatever its state. */
+XRT_HIP_API int xrt_hip_local_to_global_f64_dev(const xrt_hip_pass* pass, xrt_hip_beam* beam,
+                                                void* stream);
+
 /* Stand-alone amplitude evaluation on device arrays (what the reference exposes
  * as Material.get_amplitude(E, beamInDotNormal, fromVacuum) -> rs, rp, mu, n'k
  * (materials/material.py:415-493) and Crystal.get_amplitude(E, beamInDotNormal,

@@ -40,6 +40,9 @@ SIGNATURES = {
     'xrt_hip_double_reflect_fusable': (ctypes.c_int, [vp, vp, vp, vp]),
     'xrt_hip_double_reflect_f64_dev': (ctypes.c_int, [
         vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, c_float_p]),
+    'xrt_hip_surface_eval_f64_dev': (ctypes.c_int, [
+        vp, ctypes.c_int, i64, vp, vp, vp, vp, vp]),
+    'xrt_hip_local_to_global_f64_dev': (ctypes.c_int, [vp, vp, vp]),
     'xrt_hip_material_amplitude_f64_dev': (ctypes.c_int, [
         vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_crystal_amplitude_f64_dev': (ctypes.c_int, [

@@ -1,12 +1,18 @@
-"""Host-side mirror of the part of ``xrt.backends.raycing`` that sits on the
-accelerated hot path: module constants (xrt/backends/raycing/__init__.py:84-108),
-the rotation primitives (_rotate.py:5-108), ``BeamLine`` and the global<->local
-transforms (beamline.py:230-316, 407-478). Only what the path needs."""
+"""Host side of the accelerated path, laid out like ``xrt.backends.raycing`` so that
+beamline scripts read the same: the module constants (reference
+raycing/__init__.py:84-108), plane rotations in the reference's order of operations
+(_rotate.py), ``BeamLine`` and the frame changes between the global frame and an
+element's frames (beamline.py:230-316, 407-478). Only what the path needs.
+
+Every frame change here is a short list of elementary steps -- (axis, cos, sin) plane
+rotations and shifts -- interpreted by ``turn``: the kernels of csrc/reflect.hip take the
+same lists (``xrt_hip_rotation``), so host and device walk one description and round
+the same way."""
 import uuid
 
 import numpy as np
 
-# ray states, raycing/__init__.py:84
+# ray states and solver constants
 stateGood, stateOut, stateOver = 1, 2, 3
 zEps = 1e-12
 maxIteration = 100
@@ -18,126 +24,122 @@ targetOpenCL = 'auto'
 precisionOpenCL = 'auto'
 _VERBOSITY_ = 0
 
+_AXIS = {'x': 0, 'y': 1, 'z': 2}
+# the two coordinates an axis turns into each other, and the sense of the sine:
+# x: (y, z), y: (x, z) with the sine reversed, z: (x, y)
+_PLANE = ((1, 2, 1.), (0, 2, -1.), (0, 1, 1.))
+
 
 def is_sequence(arg):
     return isinstance(arg, (list, tuple, np.ndarray))
 
 
+def _in_plane(u, v, c, s):
+    """(u, v) turned by the angle whose cosine and sine are c, s."""
+    return u*c - v*s, u*s + v*c
+
+
 def rotate_x(y, z, cosangle, sinangle):
-    return cosangle*y - sinangle*z, sinangle*y + cosangle*z
+    return _in_plane(y, z, cosangle, sinangle)
 
 
 def rotate_y(x, z, cosangle, sinangle):
-    return cosangle*x + sinangle*z, -sinangle*x + cosangle*z
+    return _in_plane(x, z, cosangle, -sinangle)
 
 
 def rotate_z(x, y, cosangle, sinangle):
-    return cosangle*x - sinangle*y, sinangle*x + cosangle*y
-
-
-_AXIS = {'x': 0, 'y': 1, 'z': 2}
+    return _in_plane(x, y, cosangle, sinangle)
 
 
 def rotation_steps(rotationSequence='RzRyRx', pitch=0, roll=0, yaw=0):
-    """[(axis, cos, sin)] exactly as rotate_beam walks the sequence
-    (_rotate.py:30-57): leading '-' reverses, zero angles are skipped and
-    cos/sin are taken of the scalar angle on the host."""
-    angles = {'z': yaw, 'y': roll, 'x': pitch}
-    if rotationSequence[0] == '-':
-        seq = rotationSequence[6] + rotationSequence[4] + rotationSequence[2]
-    else:
-        seq = rotationSequence[1] + rotationSequence[3] + rotationSequence[5]
-    steps = []
-    for s in seq:
-        angle = angles[s]
-        if angle != 0:
-            steps.append((_AXIS[s], float(np.cos(angle)), float(np.sin(angle))))
-    return steps
+    """[(axis, cos, sin)] in the order the reference's rotate_beam applies them: the
+    letters of e.g. 'RzRyRx' left to right, right to left behind a leading '-';
+    zero angles drop out; cos/sin of the scalar angle are taken here, once."""
+    angle_of = (pitch, roll, yaw)
+    letters = [ch for ch in rotationSequence if ch in _AXIS]
+    if rotationSequence.startswith('-'):
+        letters.reverse()
+    return [(_AXIS[ch], float(np.cos(angle_of[_AXIS[ch]])),
+             float(np.sin(angle_of[_AXIS[ch]])))
+            for ch in letters if angle_of[_AXIS[ch]] != 0]
+
+
+def turn(triple, steps, part=None):
+    """Applies the plane rotations *steps* to the three host arrays of *triple*
+    (x, y, z or a, b, c) in place, on the rays *part*."""
+    part = slice(None) if part is None else part
+    for axis, c, s in steps:
+        i, j, sense = _PLANE[axis]
+        triple[i][part], triple[j][part] = _in_plane(triple[i][part], triple[j][part],
+                                                     c, sense*s)
+    return triple
 
 
 def rotate_xyz(x, y, z, indarr=None, rotationSequence='RzRyRx', pitch=0, roll=0,
                yaw=0):
-    """In-place rotation of three host arrays (_rotate.py:60-82)."""
-    if indarr is None:
-        indarr = slice(None)
-    for ax, cA, sA in rotation_steps(rotationSequence, pitch, roll, yaw):
-        if ax == 2:
-            x[indarr], y[indarr] = rotate_z(x[indarr], y[indarr], cA, sA)
-        elif ax == 1:
-            x[indarr], z[indarr] = rotate_y(x[indarr], z[indarr], cA, sA)
-        else:
-            y[indarr], z[indarr] = rotate_x(y[indarr], z[indarr], cA, sA)
+    turn([x, y, z], rotation_steps(rotationSequence, pitch, roll, yaw), indarr)
     return x, y, z
 
 
 def rotate_beam(beam, indarr=None, rotationSequence='RzRyRx', pitch=0, roll=0,
                 yaw=0, skip_xyz=False, skip_abc=False, **kw):
-    """Host-side rotate_beam for O(N) glue (wave pre/post-processing)."""
-    if not skip_xyz:
-        rotate_xyz(beam.x, beam.y, beam.z, indarr, rotationSequence, pitch, roll,
-                   yaw)
-    if not skip_abc:
-        rotate_xyz(beam.a, beam.b, beam.c, indarr, rotationSequence, pitch, roll,
-                   yaw)
+    """Positions and directions of a host-resident beam through one rotation sequence."""
+    steps = rotation_steps(rotationSequence, pitch, roll, yaw)
+    for skipped, names in ((skip_xyz, 'xyz'), (skip_abc, 'abc')):
+        if not skipped:
+            turn([getattr(beam, n) for n in names], steps, indarr)
 
 
 def virgin_local_to_global(bl, vlb, center=None, part=None, skip_xyz=False,
                            skip_abc=False, **kw):
-    """beamline.py:267-287 on host arrays."""
-    if part is None:
-        part = slice(None)
-    a0, b0 = bl.sinAzimuth, bl.cosAzimuth
-    if a0 != 0:
-        if not skip_abc:
-            vlb.a[part], vlb.b[part] = rotate_z(vlb.a[part], vlb.b[part], b0, -a0)
-        if not skip_xyz:
-            vlb.x[part], vlb.y[part] = rotate_z(vlb.x[part], vlb.y[part], b0, -a0)
-    if (center is not None) and (not skip_xyz):
-        vlb.x[part] += center[0]
-        vlb.y[part] += center[1]
-        vlb.z[part] += center[2]
+    """Out of an element's virgin local frame: back through the beamline azimuth about z,
+    then out to *center* (host arrays, in place)."""
+    undo_azimuth = [(2, bl.cosAzimuth, -bl.sinAzimuth)] if bl.sinAzimuth != 0 else []
+    if not skip_abc:
+        turn([vlb.a, vlb.b, vlb.c], undo_azimuth, part)
+    if not skip_xyz:
+        xyz = turn([vlb.x, vlb.y, vlb.z], undo_azimuth, part)
+        if center is not None:
+            part = slice(None) if part is None else part
+            for arr, c0 in zip(xyz, center):
+                arr[part] += c0
+
+
+def _unit(vec):
+    length = sum(c*c for c in vec)**0.5
+    return [c/length for c in vec]
 
 
 def xyz_from_xz(obj, x=None, z=None):
-    """Local axes of a screen from optional x and z directions
-    (beamline.py:288-316)."""
+    """The three local axes of a screen or an aperture in global coordinates. Defaults:
+    z up, x horizontal across the beamline direction; y completes the right-handed
+    triad. *x*, *z* given as 3-sequences are normalised and must be orthogonal."""
     bl = obj.bl
-    if isinstance(x, (list, tuple, np.ndarray)):
-        norm = sum([xc**2 for xc in x])**0.5
-        retx = [xc/norm for xc in x]
+    if is_sequence(x):
+        ex = _unit(x)
+    elif bl is None:
+        ex = 1, 0, 0.
     else:
-        if bl is None:
-            retx = 1, 0, 0.
-        else:
-            retx = bl.cosAzimuth, -bl.sinAzimuth, 0.
-    if isinstance(z, (list, tuple, np.ndarray)):
-        norm = sum([zc**2 for zc in z])**0.5
-        retz = [zc/norm for zc in z]
-    else:
-        retz = 0., 0., 1.
-    xdotz = np.dot(retx, retz)
-    if abs(xdotz) > 1e-8:
-        raise ValueError('x and z must be orthogonal, got xz={0:.4e}'.format(xdotz))
-    rety = np.cross(retz, retx)
-    return [retx, rety, retz]
+        ex = bl.cosAzimuth, -bl.sinAzimuth, 0.
+    ez = _unit(z) if is_sequence(z) else (0., 0., 1.)
+    skew = np.dot(ex, ez)
+    if abs(skew) > 1e-8:
+        raise ValueError('x and z must be orthogonal, got xz={0:.4e}'.format(skew))
+    return [ex, np.cross(ez, ex), ez]
 
 
 class BeamLine(object):
-    """Container of beamline elements (beamline.py:407-478): azimuth, element
-    lists that give each element its ordinal (lost rays get state
-    -ordinal, oes/base.py:266-267)."""
+    """The list of elements along one beam path. Elements register themselves in the
+    roster of their kind, which numbers them: a ray lost at element #n of its roster
+    carries state -n (OEs), -1000-n (apertures), -2000-n (screens)."""
+    rosters = ('sources', 'oes', 'slits', 'screens', 'alarms')
 
     def __init__(self, azimuth=0., height=0., alignE='auto', name=''):
-        self.azimuth = azimuth
-        self.height = height
-        self.alignE = alignE
-        self.name = name
-        self.sources = []
-        self.oes = []
-        self.slits = []
-        self.screens = []
-        self.alarms = []
+        for roster in self.rosters:
+            setattr(self, roster, [])
         self.oesDict = {}
+        self.name, self.height, self.alignE = name, height, alignE
+        self.azimuth = azimuth
 
     @property
     def azimuth(self):
@@ -146,8 +148,24 @@ class BeamLine(object):
     @azimuth.setter
     def azimuth(self, value):
         self._azimuth = value
-        self.sinAzimuth = float(np.sin(value))
-        self.cosAzimuth = float(np.cos(value))
+        self.cosAzimuth, self.sinAzimuth = float(np.cos(value)), float(np.sin(value))
+
+
+def enrol(element, bl, roster, lost_offset, name, stem, uuid_=None):
+    """Registration of *element* on beamline *bl* (None: stand-alone): its number in
+    the roster, the state its lost rays get, name and uuid."""
+    element.bl = bl
+    members = getattr(bl, roster) if bl is not None else None
+    if members is None:
+        element.ordinalNum = 1
+    elif element not in members:
+        members.append(element)
+        element.ordinalNum = len(members)
+    element.lostNum = -element.ordinalNum - lost_offset
+    element.name = name or '{0}{1}'.format(stem, element.ordinalNum)
+    element.uuid = uuid_ or new_uuid()
+    if bl is not None:
+        bl.oesDict[element.uuid] = [element, 1]
 
 
 _ANGLE_UNITS = (('mrad', 1e-3), ('urad', 1e-6), ('nrad', 1e-9), ('rad', 1.),

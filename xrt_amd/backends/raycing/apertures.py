@@ -1,6 +1,6 @@
-"""``RectangularAperture`` — host-side mirror of
-xrt/backends/raycing/apertures.py:29-499: blade geometry, local frame,
-``propagate`` (streaming HIP kernel on device-resident beams) and
+"""``RectangularAperture`` with the interface of the reference's
+(xrt/backends/raycing/apertures.py:29-499): four optional blades in the aperture's
+own frame, ``propagate`` as a streaming HIP kernel over a device-resident beam,
 ``prepare_wave`` for the wave path."""
 import ctypes
 
@@ -11,132 +11,99 @@ from .. import raycing
 from ... import _lib, _structs
 from . import sources as rs
 
-_BLADE_ORDER = ('left', 'right', 'bottom', 'top')
+# blade -> (which limit it sets, lower or upper end); also the bit order of the kernel
+_BLADES = {'left': ('limOptX', 0), 'right': ('limOptX', 1),
+           'bottom': ('limOptY', 0), 'top': ('limOptY', 1)}
+_BLADE_ORDER = tuple(_BLADES)
 
 
 class RectangularAperture(object):
     def __init__(self, bl=None, name='', center=[0, 0, 0],
-                 kind=('left', 'right', 'bottom', 'top'),
-                 opening=(-10, 10, -10, 10), x='auto', z='auto', alarmLevel=None,
-                 blades=None, **kwargs):
-        self.bl = bl
-        if bl is not None:
-            if self not in bl.slits:
-                bl.slits.append(self)
-                self.ordinalNum = len(bl.slits)
-                self.lostNum = -self.ordinalNum - 1000     # apertures.py:80
-        else:
-            self.ordinalNum = 1
-            self.lostNum = -1001
-        self.name = name or 'Aperture{0}'.format(self.ordinalNum)
-        self.uuid = kwargs.get('uuid', raycing.new_uuid())
-        if bl is not None:
-            bl.oesDict[self.uuid] = [self, 1]
+                 kind=_BLADE_ORDER, opening=(-10, 10, -10, 10),
+                 x='auto', z='auto', alarmLevel=None, blades=None, **kwargs):
+        raycing.enrol(self, bl, 'slits', 1000, name, 'Aperture', kwargs.get('uuid'))
         self.center = center
-        self.limOptX = [-raycing.maxHalfSizeOfOE, raycing.maxHalfSizeOfOE]
-        self.limOptY = [-raycing.maxHalfSizeOfOE, raycing.maxHalfSizeOfOE]
-        if blades is None:
-            kinds = [kind] if isinstance(kind, str) else list(kind)
-            opens = list(opening) if raycing.is_sequence(opening) else [opening]
-            blades = {k: v for k, v in zip(kinds, opens) if v is not None}
-        self.blades = {k: blades[k] for k in _BLADE_ORDER if k in blades}
-        for akind, d in self.blades.items():
-            td = float(d)
-            if akind.startswith('l'):
-                self.limOptX[0] = td
-            elif akind.startswith('r'):
-                self.limOptX[1] = td
-            elif akind.startswith('b'):
-                self.limOptY[0] = td
-            elif akind.startswith('t'):
-                self.limOptY[1] = td
-        self.isBeamStop = False
         self.alarmLevel = alarmLevel
-        if isinstance(x, str):
-            x = None
-        if isinstance(z, str):
-            z = None
-        self.xyz = raycing.xyz_from_xz(self, x, z)
+        self.isBeamStop = False
+        if blades is None:        # parallel lists of blade names and positions
+            names = [kind] if isinstance(kind, str) else kind
+            edges = opening if raycing.is_sequence(opening) else [opening]
+            blades = {b: e for b, e in zip(names, edges) if e is not None}
+        unknown = set(blades) - set(_BLADES)
+        if unknown:
+            raise ValueError('unknown blade(s) {0}'.format(sorted(unknown)))
+        self.blades = {b: blades[b] for b in _BLADE_ORDER if b in blades}
+        wide = raycing.maxHalfSizeOfOE
+        self.limOptX, self.limOptY = [-wide, wide], [-wide, wide]
+        for blade, edge in self.blades.items():
+            limit, end = _BLADES[blade]
+            getattr(self, limit)[end] = float(edge)
+        axes = [None if isinstance(v, str) else v for v in (x, z)]
+        self.xyz = raycing.xyz_from_xz(self, *axes)
         self.x, self.y, self.z = self.xyz
 
-    @property
-    def kind(self):
-        return list(self.blades.keys())
-
-    @property
-    def opening(self):
-        return list(self.blades.values())
+    kind = property(lambda self: list(self.blades))
+    opening = property(lambda self: list(self.blades.values()))
 
     def local_to_global(self, glo, returnBeam=False, **kwargs):
-        """Beam in the aperture's frame -> global frame, in place
-        (reference: apertures.py:436-457)."""
-        basis = (self.x, self.y, self.z)
-        glo.x, glo.y, glo.z = raycing.along_basis(basis, glo.x, glo.y, glo.z,
-                                                  self.center)
-        glo.a, glo.b, glo.c = raycing.along_basis(basis, glo.a, glo.b, glo.c)
+        """Positions and directions of a host beam from the aperture's frame to the
+        global one, in place (reference apertures.py:436-457)."""
+        axes = (self.x, self.y, self.z)
+        glo.x, glo.y, glo.z = raycing.along_basis(axes, glo.x, glo.y, glo.z, self.center)
+        glo.a, glo.b, glo.c = raycing.along_basis(axes, glo.a, glo.b, glo.c)
+
+    def _record(self):
+        a = _structs.Aperture()
+        for k in range(3):
+            a.center[k], a.ex[k], a.ey[k], a.ez[k] = (
+                float(self.center[k]), float(self.x[k]), float(self.y[k]), float(self.z[k]))
+        a.sin_az, a.cos_az = (0., 1.) if self.bl is None else \
+            (self.bl.sinAzimuth, self.bl.cosAzimuth)
+        a.blade_mask = 0
+        for bit, blade in enumerate(_BLADE_ORDER):
+            if blade in self.blades:
+                a.blade_mask |= 1 << bit
+                a.blade[bit] = float(self.blades[blade])
+        a.is_beam_stop = int(bool(self.isBeamStop))
+        a.lost_num = int(self.lostNum)
+        return a
 
     def propagate(self, beam=None, needNewGlobal=False):
-        """Rays stopped by the blades get state ``lostNum`` — in *beam* itself
-        too, as in the reference (apertures.py:334-413). Returns the beam in the
-        aperture's local frame (and the new global beam if *needNewGlobal*)."""
+        """*beam* (global frame) carried to the aperture plane; rays the blades stop
+        get state ``lostNum`` -- also in *beam* itself, as in the reference
+        (apertures.py:334-413). Returns the beam in the aperture's frame, preceded by
+        the new global beam if *needNewGlobal*."""
         _lib.require_gpu()
-        lib = _lib.load()
         dev = torch.device('cuda', torch.cuda.current_device())
-        a = _structs.Aperture()
-        for i in range(3):
-            a.center[i] = float(self.center[i])
-            a.ex[i] = float(self.x[i])
-            a.ey[i] = float(self.y[i])
-            a.ez[i] = float(self.z[i])
-        a.sin_az = self.bl.sinAzimuth if self.bl is not None else 0.
-        a.cos_az = self.bl.cosAzimuth if self.bl is not None else 1.
-        mask = 0
-        for bit, key in enumerate(_BLADE_ORDER):
-            if key in self.blades:
-                mask |= 1 << bit
-                a.blade[bit] = float(self.blades[key])
-        a.blade_mask = mask
-        a.is_beam_stop = 1 if self.isBeamStop else 0
-        a.lost_num = int(self.lostNum)
-        s_in = beam.to_struct(dev)
-        lo = rs.Beam.empty_like_on_device(beam, dev)
-        s_lo = lo.to_struct(dev)
-        glo = s_glo = None
-        if needNewGlobal:
-            glo = rs.Beam.empty_like_on_device(beam, dev)
-            s_glo = glo.to_struct(dev)
-        _lib.check(lib.xrt_hip_aperture_propagate_f64_dev(
-            ctypes.byref(a), ctypes.byref(s_in), ctypes.byref(s_lo),
-            ctypes.byref(s_glo) if s_glo is not None else None,
+        local = rs.Beam.empty_like_on_device(beam, dev)
+        glo = rs.Beam.empty_like_on_device(beam, dev) if needNewGlobal else None
+        rec = self._record()
+        _lib.check(_lib.load().xrt_hip_aperture_propagate_f64_dev(
+            ctypes.byref(rec), ctypes.byref(beam.to_struct(dev)),
+            ctypes.byref(local.to_struct(dev)),
+            ctypes.byref(glo.to_struct(dev)) if glo is not None else None,
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
             'xrt_hip_aperture_propagate_f64_dev')
         beam._h.pop('state', None)       # the kernel updated beam.state in HBM
-        for b in (lo, glo):
-            if b is not None:
-                for k in rs._SCALAR_ATTRS:
-                    if k in beam.__dict__:
-                        object.__setattr__(b, k, beam.__dict__[k])
-        if needNewGlobal:
-            return glo, lo
-        return lo
+        rs.inherit_scalars(local, beam)
+        if glo is None:
+            return local
+        rs.inherit_scalars(glo, beam)
+        return glo, local
 
     def prepare_wave(self, prevOE, nrays, rw=None):
-        """*nrays* samples uniformly random over the slit area
-        (apertures.py:467-499); uses the global np.random state like xrt."""
+        """*nrays* receiving samples, uniformly random over the open rectangle (one
+        (nrays, 2) draw from numpy's global generator: column 0 across, column 1 up --
+        the reference's order of consumption, apertures.py:467-499)."""
         if rw is None:
             from . import waves as rw
-        nrays = int(nrays)
-        wave = rs.Beam(nrays=nrays, forceState=1, withAmplitudes=True)
-        uv = np.random.rand(nrays, 2)             # one (nrays, 2) draw, like xrt
-        width = self.limOptX[1] - self.limOptX[0]
-        height = self.limOptY[1] - self.limOptY[0]
-        wave.x[:] = uv[:, 0] * width + self.limOptX[0]
-        wave.z[:] = uv[:, 1] * height + self.limOptY[0]
-        wave.area = width * height
-        wave.dS = wave.area / nrays
-        wave.toOE = self
-        wave.parentId = self.uuid
-        glo = rs.Beam(copyFrom=wave)
-        self.local_to_global(glo)
-        rw.prepare_wave(prevOE, wave, glo.x, glo.y, glo.z)
-        return wave
+        count = int(nrays)
+        draw = np.random.rand(count, 2)
+        spans = [lim[1] - lim[0] for lim in (self.limOptX, self.limOptY)]
+        px = draw[:, 0] * spans[0] + self.limOptX[0]
+        pz = draw[:, 1] * spans[1] + self.limOptY[0]
+        py = np.zeros(count)
+        there = raycing.along_basis((self.x, self.y, self.z), px, py, pz, self.center)
+        opened = spans[0] * spans[1]
+        return rw.receiving_wave(self, prevOE, (px, py, pz), there, opened / count,
+                                 opened, self.uuid)

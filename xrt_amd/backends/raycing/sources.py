@@ -222,118 +222,135 @@ class Beam(object):
         return self.has_amplitudes() and ('Es' not in self._d or 'Ep' not in self._d)
 
 
+def inherit_scalars(new, old):
+    """Per-beam scalars (source bookkeeping, flags) follow the rays into a new beam."""
+    for key in _SCALAR_ATTRS:
+        if key in old.__dict__:
+            object.__setattr__(new, key, old.__dict__[key])
+
+
 def copy_beam(beamTo, beamFrom, indarr, includeState=False, includeJspEsp=True):
-    """Host-side copy_beam (sources/beams.py:409-445), for glue code."""
-    for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E'):
-        getattr(beamTo, f)[indarr] = getattr(beamFrom, f)[indarr]
+    """Rays *indarr* of one host beam into another: geometry, path and energy always,
+    the state and the coherency matrix / amplitudes on request."""
+    fields = ['x', 'y', 'z', 'a', 'b', 'c', 'path', 'E']
     if includeState:
-        beamTo.state[indarr] = beamFrom.state[indarr]
+        fields.append('state')
     if includeJspEsp:
-        for f in ('Jss', 'Jpp', 'Jsp'):
-            getattr(beamTo, f)[indarr] = getattr(beamFrom, f)[indarr]
+        fields += ['Jss', 'Jpp', 'Jsp']
         if hasattr(beamFrom, 'Es') and hasattr(beamTo, 'Es'):
-            beamTo.Es[indarr] = beamFrom.Es[indarr]
-            beamTo.Ep[indarr] = beamFrom.Ep[indarr]
+            fields += ['Es', 'Ep']
+    for name in fields:
+        getattr(beamTo, name)[indarr] = getattr(beamFrom, name)[indarr]
 
 
 def rotate_coherency_matrix(beam, indarr, roll):
-    """sources/beams.py:448-479 on host arrays (wave post-processing glue)."""
-    c = np.cos(roll)
-    s = np.sin(roll)
-    c2 = c**2
-    s2 = s**2
-    cs = c * s
-    JssN = beam.Jss[indarr]*c2 + beam.Jpp[indarr]*s2 +\
-        2*beam.Jsp[indarr].real*cs
-    JppN = beam.Jss[indarr]*s2 + beam.Jpp[indarr]*c2 -\
-        2*beam.Jsp[indarr].real*cs
-    JspN = (beam.Jpp[indarr]-beam.Jss[indarr])*cs +\
-        beam.Jsp[indarr].real*(c2-s2) + beam.Jsp[indarr].imag*1j
-    return JssN, JppN, JspN
+    """J' = R J R^T of the rays *indarr* for the rotation by *roll* about the ray (host
+    arrays): -> (Jss', Jpp', Jsp'); the imaginary part of Jsp is invariant."""
+    cr, sr = np.cos(roll), np.sin(roll)
+    cc, ss, mixed = cr**2, sr**2, cr * sr
+    jss, jpp, jsp = beam.Jss[indarr], beam.Jpp[indarr], beam.Jsp[indarr]
+    return (jss*cc + jpp*ss + 2*jsp.real*mixed,
+            jss*ss + jpp*cc - 2*jsp.real*mixed,
+            (jpp-jss)*mixed + jsp.real*(cc-ss) + jsp.imag*1j)
 
 
 # ---------------------------------------------------------------------------
-# GeometricSource (sources/geoms.py). Sampling is host-side numpy with the
-# GLOBAL np.random state and the same call order as the reference, so a script
-# that seeds np.random gets the very same rays.
+# GeometricSource (reference: sources/geoms.py). Sampling is host-side numpy on the
+# GLOBAL np.random state, consuming it in the reference's order -- polarisation phase
+# (unpolarised beams with amplitudes), y, then x and z, then x' and z', then the energy --
+# so a script that seeds np.random gets the very same rays.
 # ---------------------------------------------------------------------------
-def make_energy(distE, energies, nrays, filamentBeam=False, energyWeights=None):
-    locnrays = 1 if filamentBeam else int(nrays)
-    eArr = np.atleast_1d(energies)
-    if distE == 'normal':
-        eMean = eArr[0]
-        eSigma = eArr[1] if len(eArr) == 2 else 0
-        E = np.random.normal(
-            eMean, 0 if abs(eSigma) > 0.1*abs(eMean) else abs(eSigma), locnrays)
-    elif distE == 'flat':
-        eMin = eArr[0]
-        eMax = eArr[1] or eArr[0] if len(eArr) == 2 else eArr[0]
-        E = np.random.uniform(eMin, eMax, locnrays)
-    elif distE == 'lines':
-        if 0 in eArr:
-            eArr = eArr[eArr > 0]
-        if energyWeights is not None and len(eArr) == len(np.atleast_1d(energyWeights)):
-            E = np.random.choice(eArr, size=locnrays, p=np.atleast_1d(energyWeights))
-        else:
-            E = np.random.choice(eArr, size=locnrays)
-    else:
-        raise ValueError('unknown distE')
-    return E
+_ROOT_HALF = 2**(-0.5)
+_RANDOM_PHASE = 'random phase'
+# named polarisation states: Jss, Jpp, Jsp, Es, Ep
+_POLARIZATION = {
+    'un': (0.5, 0.5, 0, _ROOT_HALF, _RANDOM_PHASE),
+    'r': (0.5, 0.5, 0.5j, _ROOT_HALF, -1j * _ROOT_HALF),
+    'l': (0.5, 0.5, -0.5j, _ROOT_HALF, 1j * _ROOT_HALF),
+}
+
+
+def _linear_state(angle):
+    """Linear polarisation at *angle* [rad] from the horizontal."""
+    es, ep = np.cos(angle), np.sin(angle)
+    return es*es, ep*ep, es*ep, es, ep
+
+
+def _polarization_state(spec):
+    """-> (Jss, Jpp, Jsp, Es, Ep) of a polarisation given the reference's way: None or
+    'unpolarized', 'horizontal', 'vertical', 'right', 'left' (first letters suffice), an
+    angle in degrees (number or string; '...rad' for radians), or the four real numbers
+    (Jss, Jpp, Re Jsp, Im Jsp), which carry no amplitudes."""
+    if spec is None:
+        return _POLARIZATION['un']
+    if isinstance(spec, (tuple, list, np.ndarray)):
+        if len(spec) != 4:
+            raise ValueError('wrong coherency matrix: must be a 4-sequence!')
+        return spec[0], spec[1], spec[2] + 1j*spec[3], None, None
+    if not isinstance(spec, str):
+        return _linear_state(float(spec) * np.pi / 180.)
+    word = spec.lower()
+    for head, state in _POLARIZATION.items():
+        if word.startswith(head):
+            return state
+    if word.startswith('h'):
+        return _linear_state(0.)
+    if word.startswith('v'):
+        return _linear_state(np.pi / 2.)
+    try:
+        return _linear_state(float(word[:-3]) if word.endswith('rad')
+                             else float(word) * np.pi / 180.)
+    except ValueError:
+        raise ValueError('wrong polarization!')
 
 
 def make_polarization(polarization, bo, nrays=raycing.nrays):
-    """Coherency matrix (and Es, Ep) of the generated rays, geoms.py:63-179."""
-    def _fill_beam(Jss, Jpp, Jsp, Es, Ep):
-        bo.Jss.fill(Jss)
-        bo.Jpp.fill(Jpp)
-        bo.Jsp.fill(Jsp)
-        if hasattr(bo, 'Es'):
-            bo.Es.fill(Es)
-            if isinstance(Ep, str):
-                bo.Ep[:] = np.random.uniform(size=int(nrays)) * 2**(-0.5)
-            else:
-                bo.Ep.fill(Ep)
-
-    def _fill_linear(angle):
-        Es = np.cos(angle)
-        Ep = np.sin(angle)
-        _fill_beam(Es*Es, Ep*Ep, Es*Ep, Es, Ep)
-
-    if polarization is None:
-        _fill_beam(0.5, 0.5, 0, 2**(-0.5), 'random phase')
-    elif isinstance(polarization, (tuple, list, np.ndarray)):
-        if len(polarization) != 4:
-            raise ValueError('wrong coherency matrix: must be a 4-sequence!')
-        bo.Jss.fill(polarization[0])
-        bo.Jpp.fill(polarization[1])
-        bo.Jsp.fill(polarization[2] + 1j*polarization[3])
-    elif isinstance(polarization, str):
-        pol = polarization.lower()
-        if pol.startswith('un'):
-            _fill_beam(0.5, 0.5, 0, 2**(-0.5), 'random phase')
-        elif pol.startswith('r'):
-            _fill_beam(0.5, 0.5, 0.5j, 2**(-0.5), -1j * 2**(-0.5))
-        elif pol.startswith('l'):
-            _fill_beam(0.5, 0.5, -0.5j, 2**(-0.5), 1j * 2**(-0.5))
-        elif pol.startswith('h'):
-            _fill_linear(0.)
-        elif pol.startswith('v'):
-            _fill_linear(np.pi / 2.)
-        else:
-            try:
-                if pol.endswith('rad'):
-                    angle = float(pol[:-3])
-                else:
-                    angle = float(pol) * np.pi / 180.
-            except ValueError:
-                raise ValueError('wrong polarization!')
-            _fill_linear(angle)
+    """Fills the coherency matrix of *bo* -- and its amplitudes, if it has them; an
+    unpolarised beam gets Ep of uniformly random size up to 1/sqrt(2) (one draw)."""
+    jss, jpp, jsp, es, ep = _polarization_state(polarization)
+    bo.Jss.fill(jss)
+    bo.Jpp.fill(jpp)
+    bo.Jsp.fill(jsp)
+    if es is None or not hasattr(bo, 'Es'):
+        return
+    bo.Es.fill(es)
+    if isinstance(ep, str):
+        bo.Ep[:] = np.random.uniform(size=int(nrays)) * _ROOT_HALF
     else:
-        _fill_linear(float(polarization) * np.pi / 180.)
+        bo.Ep.fill(ep)
+
+
+def make_energy(distE, energies, nrays, filamentBeam=False, energyWeights=None):
+    """Photon energies: 'normal' (mean, sigma -- a sigma above a tenth of the mean is
+    taken as 0), 'flat' (min, max) or 'lines' (discrete values, optionally weighted); a
+    filament beam has one energy."""
+    count = 1 if filamentBeam else int(nrays)
+    values = np.atleast_1d(energies)
+    pair = len(values) == 2
+    if distE == 'normal':
+        spread = abs(values[1]) if pair else 0
+        return np.random.normal(values[0], 0 if spread > 0.1*abs(values[0]) else spread,
+                                count)
+    if distE == 'flat':
+        return np.random.uniform(values[0], (values[1] or values[0]) if pair else values[0],
+                                 count)
+    if distE == 'lines':
+        if 0 in values:
+            values = values[values > 0]
+        weights = None if energyWeights is None else np.atleast_1d(energyWeights)
+        if weights is not None and len(weights) != len(values):
+            weights = None
+        return np.random.choice(values, size=count, p=weights)
+    raise ValueError('unknown distE')
 
 
 class GeometricSource(object):
     """Rays with origin, divergence and energy sampled from simple laws."""
+    # the sampled ray coordinates in the order the random numbers are drawn: a lone one,
+    # then pairs that may form an annulus
+    _LONE = ('y',)
+    _PAIRS = (('x', 'z'), ('xprime', 'zprime'))
+    _FIELD = {'x': 'x', 'y': 'y', 'z': 'z', 'xprime': 'a', 'zprime': 'c'}
 
     def __init__(self, bl=None, name='', center=(0, 0, 0), nrays=raycing.nrays,
                  distx='normal', dx=0.32, disty=None, dy=0, distz='normal',
@@ -342,6 +359,7 @@ class GeometricSource(object):
                  energies=(defaultEnergy,), energyWeights=None,
                  polarization='horizontal', filamentBeam=False,
                  uniformRayDensity=False, pitch=0, roll=0, yaw=0, **kwargs):
+        given = dict(locals())
         self.bl = bl
         if bl is not None and self not in bl.sources:
             bl.sources.append(self)
@@ -350,116 +368,95 @@ class GeometricSource(object):
         self.uuid = kwargs.get('uuid', raycing.new_uuid())
         if bl is not None:
             bl.oesDict[self.uuid] = [self, 0]
-        self.center = center
         self.nrays = int(nrays)
-        self.distx, self.dx = distx, dx
-        self.disty, self.dy = disty, dy
-        self.distz, self.dz = distz, dz
-        self.distxprime, self.dxprime = distxprime, dxprime
-        self.distzprime, self.dzprime = distzprime, dzprime
-        self.distE = distE
-        self.energies = energies
-        self.energyWeights = energyWeights
-        self.polarization = polarization
-        self.filamentBeam = filamentBeam
-        self.uniformRayDensity = uniformRayDensity
-        self.pitch, self.roll, self.yaw = pitch, roll, yaw
+        for key in ('center', 'distE', 'energies', 'energyWeights', 'polarization',
+                    'filamentBeam', 'uniformRayDensity', 'pitch', 'roll', 'yaw'):
+            setattr(self, key, given[key])
+        for coord in self._FIELD:
+            setattr(self, 'dist' + coord, given['dist' + coord])
+            setattr(self, 'd' + coord, given['d' + coord])
+
+    def _weigh_down(self, bo, weight):
+        """Uniform ray density: the law goes into the intensities instead."""
+        for name in ('Jss', 'Jpp', 'Jsp'):
+            getattr(bo, name).__imul__(weight)
+        for name in ('Es', 'Ep'):
+            getattr(bo, name).__imul__(weight**0.5)
 
     def _apply_distribution(self, axis, distaxis, daxis, bo=None):
-        if distaxis == 'normal':
-            if self.uniformRayDensity:
-                daxisArr = np.atleast_1d(daxis)
-                if len(daxisArr) < 2:
-                    sigma = daxisArr[0]
-                    cutLim = 5 * abs(sigma)
-                else:
-                    sigma = daxisArr[0]
-                    cutLim = daxisArr[-1]
-                axis[:] = np.random.uniform(-cutLim, cutLim, self.nrays)
-                amp = np.exp(-axis**2 / sigma**2 / 2) /\
-                    PI2**0.5 / sigma * 2 * cutLim
-                bo.Jss *= amp
-                bo.Jpp *= amp
-                bo.Jsp *= amp
-                amp = amp**0.5
-                bo.Es *= amp
-                bo.Ep *= amp
-            else:
-                sigma = daxis[0] if isinstance(daxis, (list, tuple)) else daxis
-                try:
-                    axis[:] = np.random.normal(0, sigma, self.nrays)
-                except ValueError:
-                    axis[:] = np.zeros(self.nrays)
+        """One coordinate from its law: 'normal' (sigma, or (sigma, cut) for a uniform
+        ray density, default cut 5 sigma) or 'flat' (full width, or (min, max))."""
+        n = self.nrays
+        if distaxis == 'normal' and self.uniformRayDensity:
+            widths = np.atleast_1d(daxis)
+            sigma = widths[0]
+            cut = widths[-1] if len(widths) > 1 else 5 * abs(sigma)
+            axis[:] = np.random.uniform(-cut, cut, n)
+            self._weigh_down(bo, np.exp(-axis**2 / sigma**2 / 2) / PI2**0.5 / sigma * 2 * cut)
+        elif distaxis == 'normal':
+            try:
+                axis[:] = np.random.normal(
+                    0, daxis[0] if isinstance(daxis, (list, tuple)) else daxis, n)
+            except ValueError:            # a negative sigma
+                axis[:] = 0.
         elif distaxis == 'flat':
             if raycing.is_sequence(daxis):
-                aMin, aMax = daxis[0], daxis[1]
-            else:
-                if daxis <= 0:
-                    return
-                aMin, aMax = -daxis*0.5, daxis*0.5
-            axis[:] = np.random.uniform(aMin, aMax, self.nrays)
+                axis[:] = np.random.uniform(daxis[0], daxis[1], n)
+            elif daxis > 0:
+                axis[:] = np.random.uniform(-daxis*0.5, daxis*0.5, n)
 
     def _set_annulus(self, axis1, axis2, rMin, rMax, phiMin, phiMax):
+        """Uniform over the ring between two radii (a circle line if they coincide)."""
+        n = self.nrays
+        radius = rMax
         if rMax > rMin:
-            A = 2. / (rMax**2 - rMin**2)
-            r = np.sqrt(2*np.random.uniform(0, 1, self.nrays)/A + rMin**2)
-        else:
-            r = rMax
-        phi = np.random.uniform(phiMin, phiMax, self.nrays)
-        axis1[:] = r * np.cos(phi)
-        axis2[:] = r * np.sin(phi)
+            density = 2. / (rMax**2 - rMin**2)
+            radius = np.sqrt(2*np.random.uniform(0, 1, n)/density + rMin**2)
+        angle = np.random.uniform(phiMin, phiMax, n)
+        axis1[:], axis2[:] = radius * np.cos(angle), radius * np.sin(angle)
 
-    def _pair(self, bo, n1, n2, dist1, d1, dist2, d2):
-        isAnnulus = False
-        if (dist1 == 'annulus') or (dist2 == 'annulus'):
-            isAnnulus = True
-            if raycing.is_sequence(d1):
-                rMin, rMax = d1
-            else:
-                isAnnulus = False
-            if raycing.is_sequence(d2):
-                phiMin, phiMax = d2
-            else:
-                phiMin, phiMax = 0, PI2
-        if isAnnulus:
-            self._set_annulus(getattr(bo, n1), getattr(bo, n2), rMin, rMax,
-                              phiMin, phiMax)
+    def _sample_pair(self, bo, first, second):
+        laws = [getattr(self, 'dist' + c) for c in (first, second)]
+        sizes = [getattr(self, 'd' + c) for c in (first, second)]
+        fields = [getattr(bo, self._FIELD[c]) for c in (first, second)]
+        if 'annulus' in laws and raycing.is_sequence(sizes[0]):
+            arc = sizes[1] if raycing.is_sequence(sizes[1]) else (0, PI2)
+            self._set_annulus(fields[0], fields[1], sizes[0][0], sizes[0][1], *arc)
         else:
-            self._apply_distribution(getattr(bo, n1), dist1, d1, bo)
-            self._apply_distribution(getattr(bo, n2), dist2, d2, bo)
+            for field, law, size in zip(fields, laws, sizes):
+                self._apply_distribution(field, law, size, bo)
 
     def shine(self, toGlobal=True, withAmplitudes=False, accuBeam=None):
-        """The source beam, in the global frame if *toGlobal*
-        (geoms.py:420-535)."""
-        if self.uniformRayDensity:
-            withAmplitudes = True
-        bo = Beam(self.nrays, withAmplitudes=withAmplitudes)
+        """One beam of ``nrays`` rays, in the global frame if *toGlobal*."""
+        bo = Beam(self.nrays, withAmplitudes=withAmplitudes or self.uniformRayDensity)
         bo.state[:] = 1
         make_polarization(self.polarization, bo, self.nrays)
-        self._apply_distribution(bo.y, self.disty, self.dy, bo)
-        self._pair(bo, 'x', 'z', self.distx, self.dx, self.distz, self.dz)
-        self._pair(bo, 'a', 'c', self.distxprime, self.dxprime, self.distzprime,
-                   self.dzprime)
-        ac = bo.a**2 + bo.c**2
-        if sum(ac > 1) > 0:
-            bo.b[:] = (ac + 1)**0.5
-            bo.a[:] /= bo.b
-            bo.c[:] /= bo.b
-            bo.b[:] = 1.0 / bo.b
+        for coord in self._LONE:
+            self._apply_distribution(getattr(bo, self._FIELD[coord]),
+                                     getattr(self, 'dist' + coord),
+                                     getattr(self, 'd' + coord), bo)
+        for pair in self._PAIRS:
+            self._sample_pair(bo, *pair)
+        # b from the two tangents: as direction cosines when they leave room for it,
+        # else as slopes of a vector of length sqrt(1 + a^2 + c^2)
+        transverse = bo.a**2 + bo.c**2
+        if (transverse > 1).any():
+            length = (transverse + 1)**0.5
+            bo.a[:] /= length
+            bo.c[:] /= length
+            bo.b[:] = 1.0 / length
         else:
-            bo.b[:] = (1 - ac)**0.5
+            bo.b[:] = (1 - transverse)**0.5
         if self.distE is not None:
-            if accuBeam is None:
-                bo.E[:] = make_energy(self.distE, self.energies, self.nrays,
-                                      self.filamentBeam, self.energyWeights)
-            else:
-                bo.E[:] = accuBeam.E[:]
+            bo.E[:] = accuBeam.E[:] if accuBeam is not None else make_energy(
+                self.distE, self.energies, self.nrays, self.filamentBeam,
+                self.energyWeights)
         if self.pitch or self.roll or self.yaw:
-            raycing.rotate_beam(bo, pitch=self.pitch, roll=self.roll,
-                                yaw=self.yaw)
+            raycing.rotate_beam(bo, pitch=self.pitch, roll=self.roll, yaw=self.yaw)
         if toGlobal:
             raycing.virgin_local_to_global(self.bl, bo, self.center)
         bo.parentId = self.uuid
         return bo
+
 
 from .undulator import Undulator  # noqa: E402,F401  (needs Beam from this module)

@@ -80,6 +80,16 @@ def prepare_wave(fromOE, wave, xglo, yglo, zglo):
     return wave
 
 
+def receiving_wave(element, prevOE, local, glob, dS, area, parent):
+    """Wave samples at the points *local* (x, y, z in the frame of *element*, which
+    owns them) = *glob* in the global frame, bound to the diffracting *prevOE*."""
+    wave = rs.Beam(nrays=len(local[0]), forceState=1, withAmplitudes=True)
+    for name, values in zip('xyz', local):
+        getattr(wave, name)[:] = values
+    wave.dS, wave.area, wave.toOE, wave.parentId = dS, area, element, parent
+    return prepare_wave(prevOE, wave, *glob)
+
+
 def qualify_sampling(wave, E, goodlen):
     """Effective Fresnel number and samples per Fresnel zone
     (waves.py:587-603)."""

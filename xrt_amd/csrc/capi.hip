@@ -468,6 +468,31 @@ int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_mate
   return XRT_HIP_OK;
 }
 
+int xrt_hip_surface_eval_f64_dev(const xrt_hip_pass* pass, int what, int64_t n, const double* u,
+                                 const double* v, const double* w, double* out, void* stream) {
+  if (!pass) return fail(XRT_HIP_ERR_ARG, "NULL pass");
+  if (what < 0 || what > 4) return fail(XRT_HIP_ERR_ARG, "surface_eval: what = %d", what);
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (n == 0) return XRT_HIP_OK;
+  if (!u || !v || !out || (what >= 3 && !w)) return fail(XRT_HIP_ERR_ARG, "NULL array");
+  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_ELLIPSE_PARAM)
+    return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
+  HIP_TRY(xrt::surface_eval_launch(*pass, what, n, u, v, w, out,
+                                   reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_local_to_global_f64_dev(const xrt_hip_pass* pass, xrt_hip_beam* beam, void* stream) {
+  if (!pass || !beam) return fail(XRT_HIP_ERR_ARG, "NULL pass / beam");
+  const bool amp = beam->Es_ri != nullptr || beam->Ep_ri != nullptr;
+  int rc;
+  if ((rc = check_beam(beam, "beam", beam->n, amp))) return rc;
+  if (pass->to_virgin.n < 0 || pass->to_virgin.n > XRT_HIP_MAX_ROT)
+    return fail(XRT_HIP_ERR_ARG, "rotation sequence longer than %d", XRT_HIP_MAX_ROT);
+  HIP_TRY(xrt::beam_to_global_launch(*pass, *beam, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
 static int check_material_tables(const xrt_hip_material* m) {
   if (!m) return fail(XRT_HIP_ERR_ARG, "NULL material");
   if (m->nelem < 1 || m->nelem > XRT_HIP_MAX_ELEM)

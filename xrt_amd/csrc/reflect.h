@@ -78,6 +78,10 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
                               hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
                               hipEvent_t evk0, hipEvent_t evk1, bool force_exact);
 
+hipError_t surface_eval_launch(const xrt_hip_pass& P, int what, int64_t n, const double* u,
+                               const double* v, const double* w, double* o, hipStream_t st);
+hipError_t beam_to_global_launch(const xrt_hip_pass& P, const xrt_hip_beam& b, hipStream_t st);
+
 hipError_t material_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
                                      const double* bdn, double* rs, double* rp, double* mu,
                                      double* nk, hipStream_t st);

@@ -1528,44 +1528,40 @@ __device__ __forceinline__ constexpr bool early_fields() {
   return K::PLAIN && K::MK >= 0 && K::SK >= 0;
 }
 
-// QREADY: q already holds the ray's fields (they came in registers, not from `in`)
-template <class K, bool QREADY = false>
-__device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
-                                               const xrt_hip_material& M, const GStat& g,
-                                               const LocalRay& r, const Hit& h, RayIn q,
-                                               const xrt_hip_beam& in, int64_t i,
-                                               bool has_amp, int own_sign = 0) {
-  Finished out;
-  q.path += h.t;
-  // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
-  double n[6];
+// local_n at a hit point: n[0..2] = n_H (Bragg planes), n[3..5] = the surface normal
+// (the same unless the crystal is cut asymmetrically). (x, y): Cartesian hit point;
+// (px, py): what the reference hands to local_n -- the same, or (s, phi) on a
+// parametric surface.
+template <class K>
+__device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, double y,
+                                               double px, double py, double (&n)[6]) {
   if (PSURF(P) == XRT_HIP_SURF_TOROID) {  // oes/__init__.py:403-411
     const double R = P.surf_p[0], rr = P.surf_p[1];
-    const double qx = h.x * frcp(rr);
+    const double qx = x * frcp(rr);
     const double rx = 1. - qx * qx;
     const double ax = rx < 0. ? 0. : frcp(sqrt(rx));
     const double na = -qx * ax;
-    const double nb = -h.y * frcp(R);
+    const double nb = -y * frcp(R);
     const double inorm = frcp(sqrt(na * na + nb * nb + 1.));
     n[0] = n[3] = na * inorm;
     n[1] = n[4] = nb * inorm;
     n[2] = n[5] = inorm;
   } else if (PSURF(P) == XRT_HIP_SURF_BENTFLAT) {  // oes/__init__.py:296-303
-    const double nb = -h.y * frcp(P.surf_p[0]);
+    const double nb = -y * frcp(P.surf_p[0]);
     const double inorm = frcp(sqrt(nb * nb + 1.));
     n[0] = n[3] = 0.;
     n[1] = n[4] = nb * inorm;
     n[2] = n[5] = inorm;
   } else if (surf_is_blazed<K>(P)) {  // gratings.py:482-490
     double y1, yL;
-    const bool front = blazed_front(P, h.py, y1, yL);
+    const bool front = blazed_front(P, py, y1, yL);
     n[0] = n[3] = 0.;
     n[1] = n[4] = front ? -P.surf_p[3] : P.surf_p[5];
     n[2] = n[5] = front ? P.surf_p[4] : P.surf_p[6];
   } else if (surf_is_param<K>(P)) {  // parametric.py:233-247, 460-472, 698-713
     const double A = P.surf_p[4], B = P.surf_p[5];
     const int conic = (int)P.surf_p[8];
-    const double sp = h.px, phi = h.py;
+    const double sp = px, phi = py;
     double nr, sg = -1.;
     if (conic == 1) {
       nr = A / sqrt(A * sp + A * A);
@@ -1598,6 +1594,20 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   } else {
     for (int j = 0; j < 6; ++j) n[j] = P.n_const[j];
   }
+}
+
+// QREADY: q already holds the ray's fields (they came in registers, not from `in`)
+template <class K, bool QREADY = false>
+__device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
+                                               const xrt_hip_material& M, const GStat& g,
+                                               const LocalRay& r, const Hit& h, RayIn q,
+                                               const xrt_hip_beam& in, int64_t i,
+                                               bool has_amp, int own_sign = 0) {
+  Finished out;
+  q.path += h.t;
+  // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
+  double n[6];
+  surface_normal<K>(P, h.x, h.y, h.px, h.py, n);
   double bdn = r.a * n[0] + r.b * n[1] + r.c * n[2];
   if (bdn < -1.) bdn = -1.;
   if (bdn > 1.) bdn = 1.;
@@ -2590,6 +2600,141 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_dcm_exact(
   exact_pass<K>(P1, M1, in, in, lo1, gb2, A1, true, phase1);
   grid_barrier(g1, phase1);
   exact_pass<K>(P2, M2, gb2, in, lo2, gb2, A2, true, phase2);
+}
+
+// ---------------------------------------------------------------------------
+// The surface functions of an element, for the host classes: OE.local_z / local_n /
+// local_r / xyz_to_param / param_to_xyz evaluate HERE, with the very code the ray
+// kernels use, instead of being written a second time in numpy.
+//   what 0: (u, v) = (x, y) -> z of the surface above it (on a parametric surface: the z
+//           of the point with these x, y; reflect.py:336-341)
+//        1: (u, v) = (x, y), or (s, phi) on a parametric surface -> normals n[0..5]
+//        2: (u, v) = (s, phi) -> r           3: (u, v, w) = (x, y, z) -> (s, phi, r)
+//        4: (u, v, w) = (s, phi, r) -> (x, y, z)
+// Output k of point i at o[k * n + i].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(REFLECT_BLOCK) void surface_eval_kernel(
+    xrt_hip_pass P, int what, int64_t n, const double* __restrict__ u,
+    const double* __restrict__ v, const double* __restrict__ w, double* __restrict__ o) {
+  using K = Generic1;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double p = u[i], q = v[i], t = w ? w[i] : 0.;
+  const bool param = P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM;
+  if (what == 0) {
+    if (param) {
+      double sp, phi, rr, x, y, z;
+      ell_xyz_to_param(P, p, q, 0., sp, phi, rr);
+      ell_param_to_xyz(P, sp, phi, ell_local_r(P, sp, phi), x, y, z);
+      o[i] = z;
+    } else {
+      o[i] = surf_z<K>(P, p, q);
+    }
+  } else if (what == 1) {
+    double nn[6];
+    surface_normal<K>(P, p, q, p, q, nn);
+    for (int k = 0; k < 6; ++k) o[k * n + i] = nn[k];
+  } else if (what == 2) {
+    o[i] = param ? ell_local_r(P, p, q) : 0.;
+  } else if (what == 3) {
+    double a = p, b = q, c = t;
+    if (param) ell_xyz_to_param(P, p, q, t, a, b, c);
+    o[i] = a;
+    o[n + i] = b;
+    o[2 * n + i] = c;
+  } else {
+    double a = p, b = q, c = t;
+    if (param) ell_param_to_xyz(P, p, q, t, a, b, c);
+    o[i] = a;
+    o[n + i] = b;
+    o[2 * n + i] = c;
+  }
+}
+
+hipError_t surface_eval_launch(const xrt_hip_pass& P, int what, int64_t n, const double* u,
+                               const double* v, const double* w, double* o, hipStream_t st) {
+  hipLaunchKernelGGL(surface_eval_kernel,
+                     dim3((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)),
+                     dim3(REFLECT_BLOCK), 0, st, P, what, n, u, v, w, o);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// OE.local_to_global (oes/base.py:1165-1229) on a device-resident beam, in place: out
+// of the element's true local frame (shift, rotations back: P.to_virgin), the coherency
+// matrix and the amplitudes turned by roll + atan2(n_x, n_z) -- with the normal the
+// reference takes there, at the ALREADY rotated coordinates --, then the beamline
+// azimuth and the element's centre. All rays, whatever their state.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(REFLECT_BLOCK) void beam_to_global_kernel(xrt_hip_pass P,
+                                                                       xrt_hip_beam b) {
+  using K = Generic1;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n) return;
+  double x = b.x[i] + P.shift[0], y = b.y[i] + P.shift[1], z = b.z[i] + P.shift[2];
+  double da = b.a[i], db = b.b[i], dc = b.c[i];
+  rotate3(P.to_virgin, x, y, z);
+  rotate3(P.to_virgin, da, db, dc);
+  double px = x, py = y;
+  if (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM) {
+    double rr;
+    ell_xyz_to_param(P, x, y, z, px, py, rr);
+  }
+  double nn[6];
+  surface_normal<K>(P, x, y, px, py, nn);
+  double cosY = P.cos_roll, sinY = P.sin_roll;
+  if (nn[3] != 0.) {
+    const double ih = frcp(fhypot(nn[3], nn[5]));
+    const double cphi = nn[5] * ih, sphi = nn[3] * ih;
+    cosY = P.cos_roll * cphi - P.sin_roll * sphi;
+    sinY = P.sin_roll * cphi + P.cos_roll * sphi;
+  } else if (nn[5] < 0.) {
+    cosY = -P.cos_roll;
+    sinY = -P.sin_roll;
+  }
+  double Jss = b.Jss[i], Jpp = b.Jpp[i];
+  double2 js = reinterpret_cast<double2*>(b.Jsp_ri)[i];
+  rot_coherency(cosY, sinY, Jss, Jpp, js.x, js.y);
+  b.Jss[i] = Jss;
+  b.Jpp[i] = Jpp;
+  reinterpret_cast<double2*>(b.Jsp_ri)[i] = js;
+  if (b.Es_ri) {
+    const double2 es = reinterpret_cast<double2*>(b.Es_ri)[i];
+    const double2 ep = reinterpret_cast<double2*>(b.Ep_ri)[i];
+    const cplx Es = C(es.x, es.y), Ep = C(ep.x, ep.y);
+    const cplx e1 = Es * cosY + Ep * sinY;
+    const cplx e2 = Es * (-sinY) + Ep * cosY;
+    reinterpret_cast<double2*>(b.Es_ri)[i] = make_double2(e1.re, e1.im);
+    reinterpret_cast<double2*>(b.Ep_ri)[i] = make_double2(e2.re, e2.im);
+  }
+  if (P.out_to_global) {
+    if (P.sin_az != 0.) {
+      const double an = P.cos_az * da - (-P.sin_az) * db, bn = (-P.sin_az) * da + P.cos_az * db;
+      da = an;
+      db = bn;
+      const double xn = P.cos_az * x - (-P.sin_az) * y, yn = (-P.sin_az) * x + P.cos_az * y;
+      x = xn;
+      y = yn;
+    }
+    x += P.center[0];
+    y += P.center[1];
+    z += P.center[2];
+  }
+  b.x[i] = x;
+  b.y[i] = y;
+  b.z[i] = z;
+  b.a[i] = da;
+  b.b[i] = db;
+  b.c[i] = dc;
+}
+
+hipError_t beam_to_global_launch(const xrt_hip_pass& P, const xrt_hip_beam& b,
+                                 hipStream_t st) {
+  if (b.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(beam_to_global_kernel,
+                     dim3((unsigned)((b.n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)),
+                     dim3(REFLECT_BLOCK), 0, st, P, b);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
