@@ -351,21 +351,27 @@ class CrystalSi(CrystalDiamond):
         kwargs.setdefault('name', 'Si')
         super(CrystalSi, self).__init__(*args[1:], **kwargs)
 
-    @staticmethod
-    def dl_l(t):
-        if t >= 0.0 and t < 30.0:
-            return -2.154537e-004
-        elif t >= 30.0 and t < 130.0:
-            return -2.303956e-014 * t**4 + 7.834799e-011 * t**3 - \
-                1.724143e-008 * t**2 + 8.396104e-007 * t - 2.276144e-004
-        elif t >= 130.0 and t < 293.0:
-            return -1.223001e-011 * t**3 + 1.532991e-008 * t**2 - \
-                3.263667e-006 * t - 5.217231e-005
-        elif t >= 293.0 and t <= 1000.0:
-            return -1.161022e-012 * t**3 + 3.311476e-009 * t**2 + \
-                1.124129e-006 * t - 5.844535e-004
-        else:
-            return 1.0e+100
+    # Swenson's relative thermal expansion of silicon: [t_from, t_to) in K -> coefficients
+    # of t^4 ... t^0 (summed in that order)
+    _EXPANSION = (
+        (0.0, 30.0, (0., 0., 0., 0., -2.154537e-004)),
+        (30.0, 130.0, (-2.303956e-014, 7.834799e-011, -1.724143e-008, 8.396104e-007,
+                       -2.276144e-004)),
+        (130.0, 293.0, (0., -1.223001e-011, 1.532991e-008, -3.263667e-006, -5.217231e-005)),
+        (293.0, 1000.0 + 1e-9, (0., -1.161022e-012, 3.311476e-009, 1.124129e-006,
+                                -5.844535e-004)),
+    )
+
+    @classmethod
+    def dl_l(cls, t):
+        for t_from, t_to, coefs in cls._EXPANSION:
+            if t_from <= t < t_to:
+                terms = [c * t**(4 - k) for k, c in enumerate(coefs) if c != 0.]
+                total = terms[0]
+                for term in terms[1:]:
+                    total = total + term
+                return total
+        return 1.0e+100
 
     def get_a(self):
         return self.a0 * (self.dl_l(self.tK) - self.dl_l(273.15 + 19.9) + 1)

@@ -69,6 +69,7 @@ class Undulator(object):
         sybase.py:34-190, 940-1030); *targetOpenCL*/*precisionOpenCL* are
         accepted and ignored (the integral always runs in fp64 on the GPU);
         *device*: torch device for the kernel (default: current)."""
+        given = dict(locals())
         if kwargs:
             raise NotImplementedError('unsupported Undulator arguments: %s'
                                       % sorted(kwargs))
@@ -76,63 +77,44 @@ class Undulator(object):
         if bl is not None and self not in bl.sources:
             bl.sources.append(self)
             self.ordinalNum = len(bl.sources)
-        self.name = name
         self.uuid = raycing.new_uuid()
-        self.center = center
-        self.pitch = raycing.auto_units_angle(pitch)
-        self.yaw = raycing.auto_units_angle(yaw)
+        for key in ('name', 'center', 'R0', 'distE', 'uniformRayDensity', 'filamentBeam',
+                    'eEspread', 'gp', 'device', 'phaseDeg'):
+            setattr(self, key, given[key])
+        for key in ('eE', 'eI', 'eMin', 'eMax'):
+            setattr(self, key, float(given[key]))
+        self.pitch, self.yaw = (raycing.auto_units_angle(v) for v in (pitch, yaw))
         self.nrays = np.int64(nrays)
-        self.R0 = R0
-        self.distE = distE
-        self.uniformRayDensity = uniformRayDensity
-        self.filamentBeam = filamentBeam
-        self.eE = float(eE)
-        self.gamma = self.eE * 1e9 * EV2ERG / (M0 * C**2)       # sybase.py:154
+        # Lorentz factor of the electrons
+        self.gamma = self.eE * 1e9 * EV2ERG / (M0 * C**2)
         self.gamma2 = self.gamma**2
-        self.eEspread = eEspread
-        self.eI = float(eI)
-        self.eMin = float(eMin)
-        self.eMax = float(eMax)
         self._set_electron_beam(eSigmaX, eSigmaZ, eEpsilonX, eEpsilonZ, betaX, betaZ)
         self._xPrimeMin, self._xPrimeMax = self._angular_range(xPrimeMax)
         self._zPrimeMin, self._zPrimeMax = self._angular_range(zPrimeMax)
-        self.gp = gp
+        # quadrature: a given number of nodes per interval, or searched for at reset()
         self.gIntervals = int(gIntervals)
-        if gNodes is None:
-            self.needConvergence = True
-            self.quadm = 0
-        else:
-            self.needConvergence = False
-            self.quadm = int(gNodes)
+        self.needConvergence = gNodes is None
+        self.quadm = 0 if gNodes is None else int(gNodes)
         self.maxIntegrationNodes = int(6e5)
-        self.convergenceSearchFlag = False
-        self._useGauLeg = False
-        self.device = device
-
-        self.L0 = period
-        self.Np = n
+        self.convergenceSearchFlag = self._useGauLeg = False
+        # the magnet: period [mm], number of periods, gap taper, phase between the fields
+        self.L0, self.Np = period, n
         self._set_taper(taper)
-        self.phaseDeg = phaseDeg
         self.phase = np.radians(phaseDeg)
         self.targetE = None
         if targetE is not None:
-            self._set_targetE(targetE)
-        if self.targetE is None:
-            if Kx == 0 and Ky == 0:
-                if abs(K) > 0:
-                    self.Kx, self.Ky = 0., float(K)
-                elif B0x == 0 and B0y == 0:
-                    raise ValueError("Please define either K or B0!")
-                else:
-                    self.Ky = float(B0y) * self.L0 / K2B
-                    self.Kx = float(B0x) * self.L0 / K2B
-            else:
-                self.Kx, self.Ky = float(Kx), float(Ky)
-        self.xPrimeMaxAutoReduce = xPrimeMaxAutoReduce
-        self.zPrimeMaxAutoReduce = zPrimeMaxAutoReduce
-        if self.R0 is not None:
-            self.xPrimeMaxAutoReduce = True
-            self.zPrimeMaxAutoReduce = True
+            self._set_targetE(targetE)           # K from the wanted harmonic energy
+        elif Kx != 0 or Ky != 0:
+            self.Kx, self.Ky = float(Kx), float(Ky)
+        elif abs(K) > 0:
+            self.Kx, self.Ky = 0., float(K)
+        elif B0x != 0 or B0y != 0:               # peak fields [T]
+            self.Kx, self.Ky = (float(b) * self.L0 / K2B for b in (B0x, B0y))
+        else:
+            raise ValueError("Please define either K or B0!")
+        # a near-field calculation always narrows the angular range to the radiation cone
+        self.xPrimeMaxAutoReduce = xPrimeMaxAutoReduce or R0 is not None
+        self.zPrimeMaxAutoReduce = zPrimeMaxAutoReduce or R0 is not None
         self.report_E1()
         self.needReset = True
 
@@ -353,26 +335,26 @@ class Undulator(object):
         self._build_integration_grid()
 
     def reset(self):
-        """sybase.py:521-547."""
+        """Limits, quadrature grid and -- for a filament beam -- the intensity ceiling of
+        the rejection sampling, estimated from one batch of uniformly drawn (E, theta, psi)
+        without energy spread (three uniform draws, then one rand for the acceptance
+        count: the reference's order, sybase.py:521-547)."""
         self.needReset = False
         self._reset_limits()
         self._reset_integration_grid()
+        self.Imax = 0.
         if self.filamentBeam and not hasattr(self, 'dimExy'):
-            rMax = self.nrays
-            rE = np.random.uniform(self.E_min, self.E_max, rMax)
-            rTheta = np.random.uniform(self.Theta_min, self.Theta_max, rMax)
-            rPsi = np.random.uniform(self.Psi_min, self.Psi_max, rMax)
-            spread = self.eEspread
-            self.eEspread = 0
-            DistI = self.build_I_map(rE, rTheta, rPsi)[0]
-            self.Imax = np.max(DistI) * 1.2
-            self.nrepmax = np.floor(rMax / len(np.where(
-                self.Imax * np.random.rand(rMax) < DistI)[0]))
+            count = self.nrays
+            trial = [np.random.uniform(lo, hi, count) for lo, hi in (
+                (self.E_min, self.E_max), (self.Theta_min, self.Theta_max),
+                (self.Psi_min, self.Psi_max))]
+            spread, self.eEspread = self.eEspread, 0
+            intensity = self.build_I_map(*trial)[0]
             self.eEspread = spread
-        else:
-            self.Imax = 0.
-        self.xzE = (self.E_max - self.E_min) *\
-            (self.Theta_max - self.Theta_min) *\
+            self.Imax = np.max(intensity) * 1.2
+            accepted = np.where(self.Imax * np.random.rand(count) < intensity)[0]
+            self.nrepmax = np.floor(count / len(accepted))
+        self.xzE = (self.E_max - self.E_min) * (self.Theta_max - self.Theta_min) * \
             (self.Psi_max - self.Psi_min)
         self.fluxConst = self.Imax * self.xzE
 
