@@ -215,52 +215,41 @@ def bench_reflect(args, world, rank, dist, dcm=False):
     return res
 
 
-def cpu_baseline_reflect(nrays=10_000_000):
-    """numpy oracle of the same cfg2 workload on the host, bounded sample."""
+def cpu_baseline_reflect(nrays=10_000_000, numpy_rays=4_000_000):
+    """The same cfg2 workload on the host: the numpy oracle on one core (bounded sample:
+    the first *numpy_rays* rays) and its C/OpenMP restatement on all cores."""
     from xrt_amd import workloads as pc
     from oracle.adapters import oracle_params, to_oracle_beam
     from oracle import reflect_np as rn
     oe = pc.cfg2_toroid()
     beam = to_oracle_beam(pc.synthetic_rays(nrays, 42))
     params = oracle_params(oe)
+    m = min(nrays, numpy_rays)
+    part = rn.Beam(m)
+    for f in part.fields():
+        setattr(part, f, getattr(beam, f)[:m].copy())
     t0 = time.perf_counter()
-    rn.oe_reflect(params, beam)
+    rn.oe_reflect(params, part)
     dt = time.perf_counter() - t0
-    res = dict(value=nrays / dt, unit='intersections/s', cores=1, kind='port',
+    res = dict(value=m / dt, unit='intersections/s', cores=1, kind='port',
                sample='%d rays of cfg2 through oracle/reflect_np.py (numpy, 1 '
-                      'thread), %.1f s' % (nrays, dt))
-    # the same on all host cores: numpy itself is single-threaded here, so one process
-    # per core, each on its own slice of the beam (SURVEY 8d: "on all host cores")
+                      'thread), %.1f s' % (m, dt))
+    # all host cores: the C/OpenMP restatement of the same pass (oracle/reflect_c.c,
+    # validated against reflect_np and the reference's golden G2 by
+    # tests/test_oracle_reflect_c.py), same 1e7 rays
     try:
-        import multiprocessing as mp
-        workers = max(1, min((os.cpu_count() or 2) // 2, 128))
-        per = 500_000
-        ctx = mp.get_context('fork')
-        global _CPU_PARAMS
-        _CPU_PARAMS = params      # inherited by the forked workers (no file access there)
+        from oracle import reflect_c as rc
+        rc.oe_reflect(params, to_oracle_beam(pc.synthetic_rays(20000, 1)))    # warm up
         t0 = time.perf_counter()
-        with ctx.Pool(workers) as pool:
-            pool.map(_cpu_reflect_slice, [(per, 100 + k) for k in range(workers)])
-        dt = time.perf_counter() - t0
+        rc.oe_reflect(params, beam)
+        dtc = time.perf_counter() - t0
         res['all_cores'] = dict(
-            value=workers * per / dt, unit='intersections/s', cores=workers, kind='port',
-            sample='%d processes x %d rays of cfg2 through oracle/reflect_np.py, %.1f s '
-                   'including process start-up and ray generation' % (workers, per, dt))
+            value=nrays / dtc, unit='intersections/s', cores=rc.max_threads(), kind='port',
+            sample='%d rays of cfg2 through oracle/reflect_c.c (gcc -O2 -fopenmp, %d '
+                   'threads), %.2f s' % (nrays, rc.max_threads(), dtc))
     except Exception as e:          # a baseline must never take the bench line down
         res['all_cores'] = dict(error=repr(e))
     return res
-
-
-_CPU_PARAMS = None
-
-
-def _cpu_reflect_slice(job):
-    per, seed = job
-    from xrt_amd import workloads as pc
-    from oracle.adapters import to_oracle_beam
-    from oracle import reflect_np as rn
-    rn.oe_reflect(_CPU_PARAMS, to_oracle_beam(pc.synthetic_rays(per, seed)))
-    return per
 
 
 # ----------------------------------------------------------------------------
