@@ -141,6 +141,10 @@ typedef struct xrt_hip_rotation {
                                      solve, base.py:822-841; surf_p[8] selects the conic */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
+#define XRT_HIP_SHAPE_POLYGON 2   /* optical surface outlined by a polygon in the local (x, y)
+                                     plane, oes/base.py:1156-1160: matplotlib's
+                                     Path.contains_points decides (crossing number with its
+                                     edge rules); outside below phys_y[0] = lost, else over */
 #define XRT_HIP_OVER_XMIN 1
 #define XRT_HIP_OVER_XMAX 2
 #define XRT_HIP_OVER_YMIN 4
@@ -203,6 +207,10 @@ typedef struct xrt_hip_pass {
   double g_rho0;
   double g_coef[8];
   double g_const[3];
+  /* XRT_HIP_SHAPE_POLYGON: poly_n vertices, DEVICE array of 2 * poly_n doubles (x0, y0,
+   * x1, y1, ...), implicitly closed */
+  int32_t poly_n;
+  const double* poly_xy;
 } xrt_hip_pass;
 
 #define XRT_HIP_MAT_NONE 0
@@ -301,12 +309,14 @@ XRT_HIP_API int xrt_hip_double_reflect_f64_dev(
  *   what 0: (u, v) = (x, y) -> z           1: (u, v) = (x, y) | (s, phi) -> n[0..5]
  *        2: (u, v) = (s, phi) -> r         3: (u, v, w) = (x, y, z) -> (s, phi, r)
  *        4: (u, v, w) = (s, phi, r) -> (x, y, z)
- * out: k-th output of point i at out[k * n + i] (1, 6, 1, 3, 3 outputs). */
+ *        5: (u, v) = (x, y) -> the state rays_good gives a hit there (as a double)
+ * out: k-th output of point i at out[k * n + i] (1, 6, 1, 3, 3, 1 outputs). */
 #define XRT_HIP_SURF_EVAL_Z 0
 #define XRT_HIP_SURF_EVAL_N 1
 #define XRT_HIP_SURF_EVAL_R 2
 #define XRT_HIP_SURF_EVAL_TO_PARAM 3
 #define XRT_HIP_SURF_EVAL_FROM_PARAM 4
+#define XRT_HIP_SURF_EVAL_STATE 5
 XRT_HIP_API int xrt_hip_surface_eval_f64_dev(const xrt_hip_pass* pass, int what, int64_t n,
                                              const double* u, const double* v,
                                              const double* w, double* out, void* stream);

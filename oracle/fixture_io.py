@@ -41,7 +41,12 @@ def load_case(name):
     g = np.load(os.path.join(GOLDEN, name + '.npz'))
     tb = tables()
     p = _unflatten(g)
-    if name == 'g2_toroid_pt':
+    if name == 'g2_polygon':
+        p['surface'] = dict(kind='flat')
+        p['shape'] = [list(v) for v in g['polygon']]
+        p['material'] = mn.make_material([mn.load_element(tb, 'Pt')], None,
+                                         'mirror', float(g['mat_rho']))
+    elif name == 'g2_toroid_pt':
         p['surface'] = dict(kind='toroid', R=float(g['surf_R']), r=float(g['surf_r']))
         p['material'] = mn.make_material([mn.load_element(tb, 'Pt')], None,
                                          'mirror', float(g['mat_rho']))

@@ -586,6 +586,30 @@ def brent(surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
     return t2, x2, y2, z2, numit
 
 
+def points_in_polygon(vertices, x, y):
+    """matplotlib.path.Path(vertices).contains_points(zip(x, y)) with radius 0 -- what
+    the reference's polygon-shaped elements call (base.py:1157-1158). matplotlib's
+    crossing-number test (src/_path.h, point_in_path_impl): every edge v0 -> v1 of the
+    implicitly closed polygon whose ends lie on different sides of the horizontal through
+    the point toggles `inside` if
+        ((y1 - ty) * (x0 - x1) >= (x1 - tx) * (y0 - y1)) == (y1 >= ty).
+    Pinned against matplotlib itself by the golden file g2_polygon (edge and vertex points
+    included)."""
+    v = np.asarray(vertices, dtype=float)
+    x = np.asarray(x, dtype=float)
+    y = np.asarray(y, dtype=float)
+    inside = np.zeros(x.shape, dtype=bool)
+    if len(v) < 3:
+        return inside
+    for k in range(len(v)):
+        x0, y0 = v[k]
+        x1, y1 = v[(k + 1) % len(v)]
+        above0, above1 = y0 >= y, y1 >= y
+        crosses = ((y1 - y) * (x0 - x1) >= (x1 - x) * (y0 - y1)) == above1
+        inside ^= (above0 != above1) & crosses
+    return inside & np.isfinite(x) & np.isfinite(y)
+
+
 def rays_good(oe, x, y, is2ndXtal=False):
     """base.py:1094-1163 for shape 'rect' / 'round'."""
     sfx = '2' if is2ndXtal else ''
@@ -594,6 +618,12 @@ def rays_good(oe, x, y, is2ndXtal=False):
     lostNum = oe['lostNum']
     locState = np.ones(x.size, dtype=np.int32)
     shape = oe.get('shape', 'rect')
+    if isinstance(shape, (list, tuple, np.ndarray)):     # base.py:1156-1160
+        inside = points_in_polygon(shape, x, y)
+        locState[:] = inside
+        locState[(locState == 0) & (y < surfPhysY[0])] = lostNum
+        locState[locState == 0] = 3
+        return locState
     if shape.startswith('re'):
         if surfOptX is not None:
             locState[((surfPhysX[0] <= x) & (x < surfOptX[0])) |

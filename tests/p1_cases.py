@@ -68,7 +68,11 @@ def product_oe(name, g):
         limPhysX=_opt(g, 'oe_surfPhysX'), limPhysY=_opt(g, 'oe_surfPhysY'),
         limOptX=_opt(g, 'oe_surfOptX'), limOptY=_opt(g, 'oe_surfOptY'),
         shape=str(g['oe_shape']), overEdge=str(g['oe_overEdge']))
-    if name == 'g2_toroid_pt':
+    if name == 'g2_polygon':
+        common['shape'] = [tuple(v) for v in g['polygon']]
+        m = rm.Material('Pt', rho=float(g['mat_rho']), kind='mirror')
+        oe = roe.OE(bl, 'poly', material=m, **common)
+    elif name == 'g2_toroid_pt':
         m = rm.Material('Pt', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.ToroidMirror(bl, 'tm', R=float(g['surf_R']), r=float(g['surf_r']),
                               material=m, **common)

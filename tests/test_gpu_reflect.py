@@ -44,7 +44,7 @@ from oracle.adapters import oracle_params, to_oracle_beam  # noqa: E402
 
 # ---- golden vectors from the reference ----------------------------------------
 @pytest.mark.parametrize('name', ['g2_toroid_pt', 'g2_flat_general',
-                                  'g2_toroid_brent', 'g2_bentflat_rh'])
+                                  'g2_toroid_brent', 'g2_bentflat_rh', 'g2_polygon'])
 def test_oe_reflect_matches_reference_golden(name):
     g = pc.load(name)
     oe = pc.product_oe(name, g)
@@ -59,6 +59,17 @@ def test_oe_reflect_matches_reference_golden(name):
     good = g['in_state'] > 0
     assert info['tMinGlobal'] == g['tMin'][good].min()
     assert info['tMaxGlobal'] == g['tMax0'][good].max()
+
+
+def test_polygon_outline_states_equal_matplotlibs():
+    """rays_good of a polygon-shaped element (oes/base.py:1156-1160) on hand-made points:
+    vertices, edge midpoints, points level with vertices, integer grid points -- the
+    states the REFERENCE (matplotlib's Path.contains_points) gave, bit for bit."""
+    g = pc.load('g2_polygon')
+    oe = pc.product_oe('g2_polygon', g)
+    mine = oe.rays_good(g['pip_x'], g['pip_y'])
+    assert np.array_equal(mine, g['pip_state'])
+    assert set(np.unique(mine)) == {1, 3, int(g['oe_lostNum'])}
 
 
 @pytest.mark.parametrize('name', ['g2_blazed_au', 'g2_ellipse_cyl',

@@ -169,7 +169,9 @@ def test_out_of_scope_requests_fail_loudly():
         roe.BlazedGrating(bl, 'b', blaze=0.01, rho=300., gratingDensity=['y', 300., 1.])
     with pytest.raises(NotImplementedError):
         roe.EllipticalMirrorParam(bl, 'e', p=1000., q=100., f1=[0, 0, 0])
-    with pytest.raises(NotImplementedError):
-        roe.OE(bl, 'poly', shape=[(0, 0), (1, 0), (0, 1)])
+    poly = roe.OE(bl, 'poly', shape=[(0, 0), (1, 0), (0, 1)])      # polygons are in
+    assert poly.shape == [(0, 0), (1, 0), (0, 1)]
+    with pytest.raises(ValueError):
+        roe.OE(bl, 'odd', shape=3.5)
     with pytest.raises(ValueError):
         rm.Element('Si', table='Henke')

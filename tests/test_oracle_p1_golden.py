@@ -29,7 +29,7 @@ def check_beam(mine, g, prefix):
                                   'g2_blazed_au', 'g2_ellipse_cyl',
                                   'g2_ellipse_full', 'g2_grating_vls',
                                   'g2_grating_const', 'g2_parabola_q',
-                                  'g2_parabola_p_cyl', 'g2_hyperbola'])
+                                  'g2_parabola_p_cyl', 'g2_hyperbola', 'g2_polygon'])
 def test_oe_reflect_matches_reference(name):
     p, beam, g = fixture_io.load_case(name)
     info = {}
@@ -43,6 +43,13 @@ def test_oe_reflect_matches_reference(name):
     good = g['in_state'] > 0
     assert np.array_equal(info['tMin'][good], g['tMin'][good])
     assert np.array_equal(info['tMax'][good], g['tMax'][good])
+
+
+def test_polygon_outline_states_are_the_references():
+    """The oracle's point-in-polygon is matplotlib's: the reference's rays_good on
+    vertices, edge points and points level with vertices (golden file)."""
+    p, _, g = fixture_io.load_case('g2_polygon')
+    assert np.array_equal(rn.rays_good(p, g['pip_x'], g['pip_y']), g['pip_state'])
 
 
 def test_parametric_mirror_without_intersection_search():

@@ -31,7 +31,7 @@ from . import sources as rs
 _WIDE = raycing.maxHalfSizeOfOE
 _OVER_EDGE = (('xmin', _structs.OVER_XMIN), ('xmax', _structs.OVER_XMAX),
               ('ymin', _structs.OVER_YMIN), ('ymax', _structs.OVER_YMAX))
-_SURF_Z, _SURF_N, _SURF_R, _SURF_TO_PARAM, _SURF_FROM_PARAM = range(5)
+_SURF_Z, _SURF_N, _SURF_R, _SURF_TO_PARAM, _SURF_FROM_PARAM, _SURF_STATE = range(6)
 _BEAM_FIELDS = ('x', 'y', 'z', 'a', 'b', 'c', 'Jss', 'Jpp', 'Jsp', 'Es', 'Ep')
 
 
@@ -82,9 +82,8 @@ class OE(object):
         if figureError is not None or isParametric:
             raise NotImplementedError('figure error / user-defined parametric OEs '
                                       'are outside the accelerated path')
-        if not isinstance(shape, str):
-            raise NotImplementedError('polygon-shaped OEs are outside the '
-                                      'accelerated path')
+        if not isinstance(shape, str) and not raycing.is_sequence(shape):
+            raise ValueError('Unknown shape of OE {0}!'.format(name))
         if order is not None and not isinstance(order, (int, np.integer)):
             raise NotImplementedError('a sequence of diffraction orders (random '
                                       'order per ray)')
@@ -149,18 +148,28 @@ class OE(object):
                for c in ((u, v) if w is None else (u, v, w))]
         count = pts[0].size
         dev = _device()
-        nout = (1, 6, 1, 3, 3)[what]
+        nout = (1, 6, 1, 3, 3, 1)[what]
         ins = [torch.from_numpy(c.copy()).to(dev) for c in pts]
         out = torch.empty(nout * max(count, 1), dtype=torch.float64, device=dev)
-        p = _structs.Pass()
-        p.invert_normal = 1
-        self._surface_params(p)
+        if what == _SURF_STATE:
+            p = self._make_pass(*self._own_angles()[:4])
+        else:
+            p = _structs.Pass()
+            p.invert_normal = 1
+            self._surface_params(p)
         _lib.check(_lib.load().xrt_hip_surface_eval_f64_dev(
             ctypes.byref(p), what, count, *[ctypes.c_void_p(t.data_ptr()) for t in ins],
             *([None] if w is None else []), ctypes.c_void_p(out.data_ptr()), _stream()),
             'xrt_hip_surface_eval_f64_dev')
         res = out.cpu().numpy()[:nout * count].reshape(nout, count)
         return [r.reshape(shape) for r in res]
+
+    def rays_good(self, x, y, z=None, is2ndXtal=False):
+        """State of a ray that hits the surface at local (x, y): 1 good, 2 out, 3 over,
+        ``lostNum`` absorbed (reference oes/base.py:1094-1163) -- evaluated on the GPU."""
+        if is2ndXtal:
+            raise NotImplementedError('rays_good of a second crystal')
+        return self._eval_surface(_SURF_STATE, x, y)[0].astype(np.int32)
 
     def _surface_height(self, x, y):
         """z of the surface above (x, y) -- on a parametric surface the point of the
@@ -278,9 +287,18 @@ class OE(object):
                 target = getattr(p, 'opt_' + axis)
                 target[0], target[1] = float(optical[0]), float(optical[1])
         shapes = {'re': _structs.SHAPE_RECT, 'ro': _structs.SHAPE_ROUND}
-        if self.shape[:2] not in shapes:
+        if not isinstance(self.shape, str):
+            # outline of the optical surface as (x, y) vertices: kept in HBM for the kernels
+            outline = np.ascontiguousarray(self.shape, dtype=np.float64).reshape(-1, 2)
+            cached = getattr(self, '_outline', None)
+            if cached is None or not np.array_equal(cached[0], outline):
+                self._outline = cached = (outline, torch.from_numpy(outline.copy()).to(_device()))
+            p.shape, p.poly_n, p.poly_xy = _structs.SHAPE_POLYGON, len(outline), \
+                cached[1].data_ptr()
+        elif self.shape[:2] in shapes:
+            p.shape = shapes[self.shape[:2]]
+        else:
             raise NotImplementedError('shape %r' % (self.shape,))
-        p.shape = shapes[self.shape[:2]]
         edges = str(getattr(self, 'overEdge', 'yMax')).lower()
         p.over_mask = sum(bit for word, bit in _OVER_EDGE if word in edges)
         p.lost_num = int(self.lostNum)

@@ -281,6 +281,10 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
     return fail(XRT_HIP_ERR_ARG, "grating equation on a crystal material");
   if (pass->invert_normal != 1 && pass->invert_normal != -1)
     return fail(XRT_HIP_ERR_ARG, "invert_normal must be +1 or -1");
+  if (pass->shape < XRT_HIP_SHAPE_RECT || pass->shape > XRT_HIP_SHAPE_POLYGON)
+    return fail(XRT_HIP_ERR_ARG, "unknown shape %d", pass->shape);
+  if (pass->shape == XRT_HIP_SHAPE_POLYGON && (pass->poly_n < 0 || (pass->poly_n > 0 && !pass->poly_xy)))
+    return fail(XRT_HIP_ERR_ARG, "polygon shape without vertices");
   if (material->kind < XRT_HIP_MAT_NONE || material->kind > XRT_HIP_MAT_CRYSTAL)
     return fail(XRT_HIP_ERR_ARG, "unknown material kind %d", material->kind);
   if (material->kind != XRT_HIP_MAT_NONE) {
@@ -471,10 +475,13 @@ int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_mate
 int xrt_hip_surface_eval_f64_dev(const xrt_hip_pass* pass, int what, int64_t n, const double* u,
                                  const double* v, const double* w, double* out, void* stream) {
   if (!pass) return fail(XRT_HIP_ERR_ARG, "NULL pass");
-  if (what < 0 || what > 4) return fail(XRT_HIP_ERR_ARG, "surface_eval: what = %d", what);
+  if (what < 0 || what > 5) return fail(XRT_HIP_ERR_ARG, "surface_eval: what = %d", what);
+  if (what == 5 && pass->shape == XRT_HIP_SHAPE_POLYGON && (pass->poly_n < 0 || !pass->poly_xy))
+    return fail(XRT_HIP_ERR_ARG, "polygon shape without vertices");
   if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
   if (n == 0) return XRT_HIP_OK;
-  if (!u || !v || !out || (what >= 3 && !w)) return fail(XRT_HIP_ERR_ARG, "NULL array");
+  if (!u || !v || !out || ((what == 3 || what == 4) && !w))
+    return fail(XRT_HIP_ERR_ARG, "NULL array");
   if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_ELLIPSE_PARAM)
     return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
   HIP_TRY(xrt::surface_eval_launch(*pass, what, n, u, v, w, out,

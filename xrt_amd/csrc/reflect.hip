@@ -1221,6 +1221,27 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
 // rays_good, oes/base.py:1094-1163
 __device__ __forceinline__ int rays_good(const xrt_hip_pass& P, double x, double y) {
   int st = 1;
+  if (P.shape == XRT_HIP_SHAPE_POLYGON) {
+    // matplotlib's Path.contains_points (src/_path.h, point_in_path_impl, radius 0): an
+    // edge v0 -> v1 of the closed outline whose ends lie on different sides of the
+    // horizontal through the point toggles `inside` when the crossing is to its right,
+    // with matplotlib's tie rules on both comparisons
+    bool inside = false;
+    const double* v = P.poly_xy;
+    double x0 = v[2 * (P.poly_n - 1)], y0 = v[2 * (P.poly_n - 1) + 1];
+    for (int k = 0; k < P.poly_n; ++k) {
+      const double x1 = v[2 * k], y1 = v[2 * k + 1];
+      const bool up0 = y0 >= y, up1 = y1 >= y;
+      if (up0 != up1 && (((y1 - y) * (x0 - x1) >= (x1 - x) * (y0 - y1)) == up1)) inside = !inside;
+      x0 = x1;
+      y0 = y1;
+    }
+    if (!(isfinite(x) && isfinite(y))) inside = false;
+    if (P.poly_n < 3) inside = false;
+    // base.py:1158-1160
+    if (inside) return 1;
+    return y < P.phys_y[0] ? P.lost_num : 3;
+  }
   if (P.shape == XRT_HIP_SHAPE_RECT) {
     if (P.has_opt_x &&
         (((P.phys_x[0] <= x) && (x < P.opt_x[0])) || ((P.opt_x[1] <= x) && (x < P.phys_x[1]))))
@@ -2611,6 +2632,7 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_dcm_exact(
 //        1: (u, v) = (x, y), or (s, phi) on a parametric surface -> normals n[0..5]
 //        2: (u, v) = (s, phi) -> r           3: (u, v, w) = (x, y, z) -> (s, phi, r)
 //        4: (u, v, w) = (s, phi, r) -> (x, y, z)
+//        5: (u, v) = (x, y) -> the state rays_good gives a hit there
 // Output k of point i at o[k * n + i].
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(REFLECT_BLOCK) void surface_eval_kernel(
@@ -2634,6 +2656,8 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void surface_eval_kernel(
     double nn[6];
     surface_normal<K>(P, p, q, p, q, nn);
     for (int k = 0; k < 6; ++k) o[k * n + i] = nn[k];
+  } else if (what == 5) {
+    o[i] = (double)rays_good(P, p, q);
   } else if (what == 2) {
     o[i] = param ? ell_local_r(P, p, q) : 0.;
   } else if (what == 3) {
