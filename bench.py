@@ -171,17 +171,20 @@ def bench_reflect(args, world, rank, dist, dcm=False):
     # (xrt_hip_reflect_time_next_pass) and read after the region
     from xrt_amd import _lib
     lib = _lib.load()
-    events = []
+    # (every 4th step carries events: four event records per pass are not free on the
+    # stream -- up to ~40 us of gaps per pass were seen -- and a sample is all the roofline
+    # figure needs)
+    events = {}
     if not dcm:
-        for _ in range(args.steps):
+        for k in range(0, args.steps, 4):
             quad = [ctypes.c_void_p() for _ in range(4)]
             for e in quad:
                 _lib.check(lib.xrt_hip_event_create(ctypes.byref(e)), 'event_create')
-            events.append(quad)
+            events[k] = quad
     barrier(dist)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        if events:
+        if k in events:
             lib.xrt_hip_reflect_time_next_pass(*events[k])
         out = op(beam, **kw)
     barrier(dist)
@@ -189,7 +192,7 @@ def bench_reflect(args, world, rank, dist, dcm=False):
     n_enter = int((beam.peek('state') > 0).sum())
     value = world * n_enter * surfaces * args.steps / dt
     kms, pms = [], []
-    for quad in events:
+    for quad in events.values():
         ms = ctypes.c_float(0.)
         _lib.check(lib.xrt_hip_event_elapsed_ms(quad[0], quad[1], ctypes.byref(ms)), 'elapsed')
         pms.append(ms.value)

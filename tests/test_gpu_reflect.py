@@ -10,6 +10,7 @@ import torch
 
 import p1_cases as pc
 from oracle import fixture_io, materials_np as mn, reflect_np as rn
+from oracle.consts import CHBAR
 
 pytestmark = pytest.mark.gpu
 GEO_TOL = 1e-12
@@ -90,10 +91,23 @@ def test_softimax_surface_kinds_match_reference_golden(name):
     info = {}
     gb, lb = oe.reflect(pc.product_beam(g), _info=info)
     parametric = name != 'g2_blazed_au'
-    amp_tol = 1e-4 if parametric else AMP_TOL
+    hit = g['lb_state'] == 1
+    # what the field amplitudes differ by, and what a few ulp of path length explain
+    k = g['lb_E'][hit] / CHBAR * 1e7
+    dt = np.abs(lb.path - g['lb_path'])[hit]
+    phase_noise = float((k * dt).max())
+    field_err = max(float(np.abs(getattr(lb, f) - g['lb_' + f]).max()) for f in ('Es', 'Ep')) \
+        / float(np.abs(g['lb_Es']).max())
+    print('%s: |dE|/|E| = %.2e, k*|dt| = %.2e rad (%.1f ulp of path)' % (
+        name, field_err, phase_noise,
+        dt.max() / np.spacing(np.abs(g['lb_path'][hit]).max())))
+    # the complex amplitudes agree to the propagation-phase noise of the path length
+    # (k*dt, each side < 1 ulp in atan2 / cos of the parametric solve), and to 1e-10
+    # where no parametric surface is involved
+    amp_tol = max(2. * phase_noise, AMP_TOL) if parametric else AMP_TOL
+    assert phase_noise < 1e-3 and field_err < 5e-5
     compare(gb, g, lambda f: g['gb_' + f], geo_tol=4e-12, amp_tol=amp_tol)
     compare(lb, g, lambda f: g['lb_' + f], geo_tol=4e-12, amp_tol=amp_tol)
-    hit = g['lb_state'] == 1
     assert np.abs(lb.path - g['lb_path'])[hit].max() <= \
         8 * np.spacing(np.abs(g['lb_path'][hit]).max())
     for f in ('Es', 'Ep'):

@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libxrt_hip.so')
+# (XRT_HIP_LIBRARY: another build of the same library, for A/B measurements)
+LIB_PATH = os.environ.get('XRT_HIP_LIBRARY') or os.path.join(_HERE, 'libxrt_hip.so')
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int_p = ctypes.POINTER(ctypes.c_int)

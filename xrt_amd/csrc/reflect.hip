@@ -1364,10 +1364,14 @@ struct Ampl {
 };
 
 // Fresnel, material.py:415-493
+// npre: the refractive index at E, if the caller looked it up already (the fused
+// kernels do so BEFORE the root solve: the table search is two dependent trips to L2,
+// which then overlap with the solve instead of standing between it and the amplitudes)
 __device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, int kind,
-                                                   double E, double bdn, const TabWin& w) {
+                                                   double E, double bdn, const TabWin& w,
+                                                   const cplx* npre = nullptr) {
   Ampl A;
-  const cplx n = refractive_index(M, E, w);
+  const cplx n = npre ? *npre : refractive_index(M, E, w);
   const cplx one = C(1., 0.);
   const cplx n1 = M.from_vacuum ? one : n;
   const cplx n2 = M.from_vacuum ? n : one;
@@ -1623,7 +1627,8 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
                                                const xrt_hip_material& M, const GStat& g,
                                                const LocalRay& r, const Hit& h, RayIn q,
                                                const xrt_hip_beam& in, int64_t i,
-                                               bool has_amp, int own_sign = 0) {
+                                               bool has_amp, int own_sign = 0,
+                                               const cplx* npre = nullptr) {
   Finished out;
   q.path += h.t;
   // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
@@ -1749,7 +1754,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     const double bosn = ao * n[3] + bo * n[4] + co * n[5];
     A = crystal_amplitude<K::XTHICK>(M, q.E, bdsn, bosn, bdn, window_of(g));
   } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
-    A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g));
+    A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g), npre);
   }
   if (cisnan(A.rs)) A.rs = C(0., 0.);
   if (cisnan(A.rp)) A.rp = C(0., 0.);
@@ -1882,7 +1887,7 @@ __device__ __forceinline__ Completed complete_ray(
     const xrt_hip_pass& P, const xrt_hip_material& M, const GStat& g, const xrt_hip_beam& in,
     const xrt_hip_beam& restore, const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
     int64_t i, const LocalRay& r, const Hit& h, int st, bool has_amp, int own_sign = 0,
-    double* bdn_out = nullptr, RayIn qin = RayIn()) {
+    double* bdn_out = nullptr, RayIn qin = RayIn(), const cplx* npre = nullptr) {
   Completed res;
   res.kept = false;
   RayIn q;
@@ -1897,7 +1902,7 @@ __device__ __forceinline__ Completed complete_ray(
   RayIn lo;
   double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;
   if (st == 1) {
-    const Finished fin = finish_ray<K, QREADY>(P, M, g, r, h, q, in, i, has_amp, own_sign);
+    const Finished fin = finish_ray<K, QREADY>(P, M, g, r, h, q, in, i, has_amp, own_sign, npre);
     if (bdn_out) *bdn_out = fin.bdn;
     la = fin.a;
     lbb = fin.b;
@@ -2039,6 +2044,26 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   const int st0 = i < in.n ? in.state[i] : 0;
   LocalRay r = load_local(P, in, i < in.n ? i : 0);
   const bool active = i < in.n && entering(P, st0);
+  // Fresnel coatings: the refractive index now, so that its table look-up (dependent
+  // loads) is in flight during the root solve
+#ifdef XRT_NO_NPRE
+  constexpr bool NPRE = false;
+#else
+  constexpr bool NPRE = K::PLAIN && K::MK == XRT_HIP_MAT_MIRROR;
+#endif
+  cplx npre = C(1., 0.);
+  if (NPRE && active) npre = refractive_index(M, in.E[i], window_of(g));
+#ifndef XRT_LATE_FIELDS
+  // the lean kernels have the registers to request the WHOLE input record before the
+  // solve: one trip to HBM per ray instead of two (measured on cfg2: 0.71 -> 0.68 ms, at
+  // four waves per SIMD instead of five)
+  RayIn qpre = RayIn();
+  if (early_fields<K>() && active) {
+    qpre.path = in.path[i];
+    qpre.E = in.E[i];
+    load_fields(in, i, has_amp, qpre);
+  }
+#endif
   if (i < in.n && !active) pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
   Hit h;
   if (mode == 0) {
@@ -2064,7 +2089,14 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
       neg |= st == 1 && bdn < 0.;
       pos |= st == 1 && !(bdn < 0.);
     } else {
-      complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp);
+#ifndef XRT_LATE_FIELDS
+      if (early_fields<K>())
+        complete_ray<K, true>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 0,
+                              nullptr, qpre, NPRE ? &npre : nullptr);
+      else
+#endif
+      complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 0, nullptr,
+                      RayIn(), NPRE ? &npre : nullptr);
     }
   }
 }
