@@ -80,29 +80,27 @@ __device__ __forceinline__ double frcp(double x) {
 __device__ __forceinline__ double fhypot(double a, double b) {
   return __builtin_sqrt(fma_(a, a, b * b));
 }
+__device__ __forceinline__ double cnorm2(double re, double im) { return fma_(re, re, im * im); }
 __device__ __forceinline__ double cabs_(cplx a) { return fhypot(a.re, a.im); }
 __device__ __forceinline__ bool cisnan(cplx a) { return isnan(a.re) || isnan(a.im); }
-// Smith's algorithm, as numpy's complex division loop
+// a / b = a conj(b) / |b|^2: one reciprocal and no branch. (numpy's loop is Smith's
+// algorithm, two divisions; the operands of this pipeline are far from over- or
+// underflowing when squared, and ~1e-16 relative is all that is compared.) b = 0 gives
+// inf / NaN components like numpy's.
 __device__ __forceinline__ cplx operator/(cplx a, cplx b) {
-  if (fabs(b.re) >= fabs(b.im)) {
-    if (b.re == 0. && b.im == 0.) return C(a.re / fabs(b.re), a.im / fabs(b.im));
-    const double rat = b.im * frcp(b.re);
-    const double scl = frcp(b.re + b.im * rat);
-    return C((a.re + a.im * rat) * scl, (a.im - a.re * rat) * scl);
-  }
-  const double rat = b.re * frcp(b.im);
-  const double scl = frcp(b.im + b.re * rat);
-  return C((a.re * rat + a.im) * scl, (a.im * rat - a.re) * scl);
+  const double scl = frcp(cnorm2(b.re, b.im));
+  return C(fma_(a.re, b.re, a.im * b.im) * scl, fma_(a.im, b.re, -(a.re * b.im)) * scl);
 }
-__device__ __forceinline__ cplx csqrt_(cplx z) {  // principal root (C99 csqrt)
+// principal root (C99 csqrt); both square roots through the unscaled Goldschmidt
+// sequence of fp64_math.h, whose second result 1/sqrt replaces the division by 2t
+__device__ __forceinline__ cplx csqrt_(cplx z) {
   if (z.re == 0. && z.im == 0.) return C(0., z.im);
-  const double m = fhypot(z.re, z.im);
-  if (z.re >= 0.) {
-    const double t = sqrt((z.re + m) * 0.5);
-    return C(t, z.im * frcp(2. * t));
-  }
-  const double t = sqrt((-z.re + m) * 0.5);
-  return C(fabs(z.im) * frcp(2. * t), copysign(t, z.im));
+  double unused, it;
+  const double m = sqrt_rn_rinv(cnorm2(z.re, z.im), unused);
+  const double t = sqrt_rn_rinv((fabs(z.re) + m) * 0.5, it);   // it = 1/t
+  const double other = fabs(z.im) * (0.5 * it);
+  if (z.re >= 0.) return C(t, copysign(other, z.im));
+  return C(other, copysign(t, z.im));
 }
 __device__ __forceinline__ cplx cexp_(cplx z) {
   double s, c;
@@ -1364,7 +1362,8 @@ struct Ampl {
 };
 
 // Fresnel, material.py:415-493
-// npre: the refractive index at E, if the caller looked it up already (the fused
+// npre: the refractive index at E (for a crystal: f1 + i f2 of its element), if the
+// caller looked it up already (the fused
 // kernels do so BEFORE the root solve: the table search is two dependent trips to L2,
 // which then overlap with the solve instead of standing between it and the amplitudes)
 __device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, int kind,
@@ -1418,7 +1417,8 @@ __device__ __forceinline__ cplx crystal_one_pol(const xrt_hip_material& M, doubl
     if (ad.re == 0. && ad.im == 0.) ad = C(1e-100, 0.);
     const cplx rb = num / ad;
     if (cisnan(ra)) ra = rb;
-    if (cabs_(rb) < cabs_(ra)) ra = rb;
+    // the root of smaller modulus (crystal.py:577-583), compared through |.|^2
+    if (cnorm2(rb.re, rb.im) < cnorm2(ra.re, ra.im)) ra = rb;
     return ra / sqb;
   }
   const double t = M.t_crystal * 1e7;
@@ -1442,10 +1442,11 @@ __device__ __forceinline__ cplx crystal_one_pol(const xrt_hip_material& M, doubl
   return ra;
 }
 
+// apre: f1 + i f2 of the crystal's element at E, if the caller looked it up already
 template <bool THICK = false>
 __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, double E,
                                                   double bdsn, double bosn, double bdhn,
-                                                  const TabWin& w) {
+                                                  const TabWin& w, const cplx* apre = nullptr) {
   Ampl A;
   const double waveLength = kCH * frcp(E);
   const double k = kPI2 * frcp(waveLength);
@@ -1463,7 +1464,7 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
     b = k0s * frcp(kHs);
   }
   // structure factors, crystals_basic.py:22-31, 76-80; chi, crystal.py:297-306
-  const cplx anom = interp_f1f2(M, 0, E, w);
+  const cplx anom = apre ? *apre : interp_f1f2(M, 0, E, w);
   cplx F0 = (C((double)M.Z[0], 0.) + anom) * 4. * M.fact_dw;
   const int residue = (abs(M.hkl[0]) % 2) + (abs(M.hkl[1]) % 2) + (abs(M.hkl[2]) % 2);
   cplx Fh = C(0., 0.), Fh_ = C(0., 0.);
@@ -1477,15 +1478,14 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
   }
   const double c2l = M.chi_to_f * (waveLength * waveLength);
   const cplx chi0 = conj(F0) * c2l, chih = conj(Fh) * c2l, chih_ = conj(Fh_) * c2l;
-  // Bragg angle, crystal.py:1105-1120
+  // Bragg angle, crystal.py:1105-1120: only cos(2 thetaB) = 1 - 2 sin^2(thetaB) is used
   double sb = kCH * frcp(2. * M.d * E);
   if (sb > 1.) sb = 1. - 1e-16;
   if (sb < -1.) sb = -1. + 1e-16;
-  const double thetaB = asin(sb);
+  const double cos2thetaB = 1. - 2. * (sb * sb);
   const cplx alpha = C((H2 * 0.5 - k0H) * frcp(k02), 0.) + (chi0 * 0.5) * (frcp(b) - 1.);
   A.rs = crystal_one_pol<THICK>(M, 1., alpha, chih, chih_, chi0, b, k02, k0s, kHs);
-  A.rp = crystal_one_pol<THICK>(M, cos(2. * thetaB), alpha, chih, chih_, chi0, b, k02, k0s,
-                               kHs);
+  A.rp = crystal_one_pol<THICK>(M, cos2thetaB, alpha, chih, chih_, chi0, b, k02, k0s, kHs);
   A.mu = 0.;
   A.nk = 0.;
   return A;
@@ -1752,7 +1752,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   A.nk = 0.;
   if (MKIND(M) == XRT_HIP_MAT_CRYSTAL) {
     const double bosn = ao * n[3] + bo * n[4] + co * n[5];
-    A = crystal_amplitude<K::XTHICK>(M, q.E, bdsn, bosn, bdn, window_of(g));
+    A = crystal_amplitude<K::XTHICK>(M, q.E, bdsn, bosn, bdn, window_of(g), npre);
   } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
     A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g), npre);
   }
@@ -2538,6 +2538,25 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_dcm(
   const bool live = i < in.n;
   int neg1 = 0, pos1 = 0, neg2 = 0, pos2 = 0;
   Rec v = {};         // the beam between the crystals (virgin local frame), this ray
+  // the anomalous scattering factors at this ray's energy, looked up (dependent trips to
+  // L2) before any geometry, once for both crystals if they are cut from one table
+  cplx anom1 = C(0., 0.), anom2 = C(0., 0.);
+#ifdef XRT_DCM_EARLY
+  RayIn q0 = RayIn();
+#endif
+  if (live) {
+    const double E0 = in.E[i];
+    anom1 = interp_f1f2(M1, 0, E0, window_of(*g1p));
+#ifdef XRT_DCM_EARLY
+    q0.E = E0;
+    q0.path = in.path[i];
+    load_fields(in, i, has_amp, q0);
+#endif
+    anom2 = (M2.tab_E[0] == M1.tab_E[0] && M2.tab_f1[0] == M1.tab_f1[0] &&
+             M2.tab_f2[0] == M1.tab_f2[0])
+                ? anom1
+                : interp_f1f2(M2, 0, E0, window_of(*g2p));
+  }
   // ---- first crystal ----
   {
     const GStat g = *g1p;
@@ -2557,8 +2576,14 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_dcm(
       int st = rays_good(P1, h.x, h.y);
       if (h.lost) st = P1.lost_num;
       double bdn = 0.;
+#ifdef XRT_DCM_EARLY
+      const Completed c1 = complete_ray<K, true, true>(P1, M1, g, in, in, lo1, lo1, theta1, i, r,
+                                                       h, st, has_amp, 1, &bdn, q0, &anom1);
+#else
       const Completed c1 = complete_ray<K, false, true>(P1, M1, g, in, in, lo1, lo1, theta1, i, r,
-                                                        h, st, has_amp, 1, &bdn);
+                                                        h, st, has_amp, 1, &bdn, RayIn(),
+                                                        &anom1);
+#endif
       kept = c1.kept;
       neg1 |= st == 1 && bdn < 0.;
       pos1 |= st == 1 && !(bdn < 0.);
@@ -2603,7 +2628,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_dcm(
       if (h.lost) st = P2.lost_num;
       double bdn = 0.;
       complete_ray<K, true>(P2, M2, g, in, in, lo2, gb2, theta2, i, r, h, st, has_amp, 1, &bdn,
-                            v.f);
+                            v.f, &anom2);
       neg2 |= st == 1 && bdn < 0.;
       pos2 |= st == 1 && !(bdn < 0.);
     } else if (live) {
