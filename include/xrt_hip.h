@@ -543,9 +543,13 @@ XRT_HIP_API int xrt_hip_debug_divconst_f64_dev(int64_t n, const double* a, doubl
                                    void* stream);
 XRT_HIP_API int xrt_hip_debug_sincos_f64_dev(int64_t n, const double* phi, double* sn, double* cs,
                                  void* stream);
-/* the LDS-table form the Kirchhoff kernel uses when |k r| < 2^42 */
+/* the LDS-table forms the Kirchhoff kernel uses when |k r| < 2^42: 2048 entries
+ * (4e-16) and, with four receiving points per lane, 4096 entries (1.5e-14; 2.6e-14 at
+ * the largest phases) */
 XRT_HIP_API int xrt_hip_debug_sincos_tab_f64_dev(int64_t n, const double* phi, double* sn,
                                      double* cs, void* stream);
+XRT_HIP_API int xrt_hip_debug_sincos_tab4k_f64_dev(int64_t n, const double* phi, double* sn,
+                                                   double* cs, void* stream);
 
 #ifdef __cplusplus
 }

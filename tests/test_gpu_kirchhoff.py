@@ -82,25 +82,30 @@ def test_seeded_sqrt_is_correctly_rounded_at_the_seed_error_limit():
         assert np.abs(2. * h.cpu().numpy() * np.sqrt(x) - 1).max() < 1e-14
 
 
-@pytest.mark.parametrize('table', [False, True])
+@pytest.mark.parametrize('table', [0, 1, 2])
 def test_sincos_of_large_phases(table):
-    """Both sincos forms of the Kirchhoff kernel: the general one (|phi| < 2^50) and
-    the LDS-table one it takes when the whole launch has |k r| < 2^42."""
+    """The sincos forms of the Kirchhoff kernel: the general one (|phi| < 2^50) and the
+    LDS-table ones it takes when the whole launch has |k r| < 2^42 -- 2048 entries, or
+    4096 (cos of the remainder to second order: 1.5e-14) with four points per lane."""
     from xrt_amd import hipcalls
     rng = np.random.default_rng(2)
-    top = 4e12 if table else 1e14
+    top = {0: 1e14, 1: 4e12, 2: 2e12}[table]      # 2^50, 2^42, 2^41 rad
     phi = np.concatenate([rng.uniform(0, 1e12, 2_000_000),
                           rng.uniform(-top, top, 500_000),
                           rng.uniform(-1e6, 1e6, 500_000),
                           rng.uniform(-10, 10, 500_000),
                           np.arange(-4096, 4097) * (np.pi / 1024),   # table nodes
                           (np.arange(-4096, 4097) + 0.5) * (np.pi / 1024),
+                          np.arange(-8192, 8193) * (np.pi / 2048),    # nodes of the 4096 table
+                          (np.arange(-8192, 8193) + 0.5) * (np.pi / 2048),
                           np.arange(-64, 65) * (np.pi / 4)])
     s, c = hipcalls.debug_sincos(dev(phi), table=table)
     s = s.cpu().numpy()
     c = c.cpu().numpy()
     # glibc sin/cos are < 1 ulp with exact argument reduction
-    tol = 6e-16 if table else 5e-16
+    # (4096 entries, second-order cos: (pi/4096)^4/24 = 1.4e-14 at mid-step, up to 1.8 x
+    # that at the largest phases, where the low word of N/2pi shifts the remainder by 0.08)
+    tol = {0: 5e-16, 1: 6e-16, 2: 2.7e-14}[table]
     assert np.abs(s - np.sin(phi)).max() < tol
     assert np.abs(c - np.cos(phi)).max() < tol
 
@@ -377,7 +382,7 @@ def test_cfg5_on_one_gpu():
         assert np.abs(f[idx] - r).max() <= TOL * max(np.abs(f).max(), 1e-300)
 
 
-@pytest.mark.parametrize('scale,ppt', [(1., 1), (30., 2), (2000., 1)])
+@pytest.mark.parametrize('scale,ppt', [(1., 1), (30., 2), (2000., 1), (6., 4), (3., 4)])
 def test_phase_magnitudes_across_the_table_bound(scale, ppt):
     """|k r| < 2^42 goes through the LDS-table sincos, larger phases (hard X-rays over
     long distances) through the general one; the switch is per wave from

@@ -76,6 +76,7 @@ SIGNATURES = {
     'xrt_hip_debug_divconst_f64_dev': (ctypes.c_int, [i64, vp, ctypes.c_double, vp, vp]),
     'xrt_hip_debug_sincos_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
     'xrt_hip_debug_sincos_tab_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
+    'xrt_hip_debug_sincos_tab4k_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
     'xrt_hip_event_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     'xrt_hip_event_destroy': (ctypes.c_int, [vp]),
     'xrt_hip_event_elapsed_ms': (ctypes.c_int, [vp, vp, ctypes.POINTER(ctypes.c_float)]),

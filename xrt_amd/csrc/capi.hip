@@ -886,6 +886,13 @@ int xrt_hip_debug_sincos_tab_f64_dev(int64_t n, const double* phi, double* sn, d
   return XRT_HIP_OK;
 }
 
+int xrt_hip_debug_sincos_tab4k_f64_dev(int64_t n, const double* phi, double* sn, double* cs,
+                                     void* stream) {
+  if (n <= 0) return XRT_HIP_OK;
+  HIP_TRY(xrt::debug_sincos_launch(n, phi, sn, cs, 2, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
 int xrt_hip_event_create(void** event) {
   if (!event) return fail(XRT_HIP_ERR_ARG, "NULL event slot");
   hipEvent_t ev;

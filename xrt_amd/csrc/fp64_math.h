@@ -143,9 +143,10 @@ __device__ __forceinline__ void sincos_phase(double phi, double& sn, double& cs)
 // ---------------------------------------------------------------------------
 #define SINCOS_TAB_N 2048
 
+template <int N = SINCOS_TAB_N>
 __device__ __forceinline__ void sincos_tab_fill(double2* tab) {
-  for (int j = threadIdx.x; j < SINCOS_TAB_N; j += blockDim.x) {
-    const double qt = (double)j * (4.0 / SINCOS_TAB_N);   // quarter turns, exact
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    const double qt = (double)j * (4.0 / N);   // quarter turns, exact
     const double n = __builtin_rint(qt);
     double s, c;
     sincos_quarter_turns(qt - n, (unsigned)(int)n, s, c);
@@ -158,21 +159,32 @@ __device__ __forceinline__ void sincos_tab_fill(double2* tab) {
 // one SGPR / literal: fma(S1, w, S0) and fma(C2, w, C1) need one of their constants in
 // a VGPR, and the compiler re-materialises those with a v_mov in every loop iteration
 // unless they are opaque to it. One instance per kernel, made before the loop.
+template <int N = SINCOS_TAB_N>
 struct SinCosTabRegs {
   double s0, c1;
   __device__ __forceinline__ SinCosTabRegs() {
-    constexpr double DELTA = 0x1.921fb54442d18p+1 * (2.0 / SINCOS_TAB_N);
+    constexpr double DELTA = 0x1.921fb54442d18p+1 * (2.0 / N);
     const double S0 = DELTA, C1 = -(DELTA * DELTA) / 2.0;
     asm volatile("v_mov_b64 %0, %1" : "=v"(s0) : "s"(S0));
     asm volatile("v_mov_b64 %0, %1" : "=v"(c1) : "s"(C1));
   }
 };
 
+// N = 2048 (32 KB of LDS; |phi| < 2^42): remainder |theta| <= 1.53e-3, cos needs the
+// theta^4 term; absolute accuracy ~4e-16. N = 4096 (|phi| < 2^41) (64 KB; the kernels that run two blocks per CU
+// anyway): |theta| <= 7.7e-4 (8.9e-4 at the largest phases), cos theta = 1 - theta^2/2
+// is good to 1.5e-14 (2.6e-14 there) (the phase
+// itself, k r ~ 4e11 rad, is only known to 6e-5 rad), and the byte offset of the entry
+// is ONE instruction: an SDWA shift whose 16-bit destination keeps exactly the 12 index
+// bits times 16.
+template <int N = SINCOS_TAB_N>
 __device__ __forceinline__ void sincos_tab(double phi, const double2* tab,
-                                           const SinCosTabRegs& k, double& sn, double& cs) {
-  constexpr double STEPS_PER_RAD_HI = 0x1.45f306dc9c883p-1 * (SINCOS_TAB_N / 4);
-  constexpr double STEPS_PER_RAD_LO = -0x1.6b01ec5417056p-55 * (SINCOS_TAB_N / 4);
-  constexpr double DELTA = 0x1.921fb54442d18p+1 * (2.0 / SINCOS_TAB_N);
+                                           const SinCosTabRegs<N>& k, double& sn,
+                                           double& cs) {
+  static_assert(N == 2048 || N == 4096, "table sizes the offset arithmetic knows");
+  constexpr double STEPS_PER_RAD_HI = 0x1.45f306dc9c883p-1 * (N / 4);
+  constexpr double STEPS_PER_RAD_LO = -0x1.6b01ec5417056p-55 * (N / 4);
+  constexpr double DELTA = 0x1.921fb54442d18p+1 * (2.0 / N);
   constexpr double S1 = -(DELTA * DELTA * DELTA) / 6.0;
   constexpr double C2 = (DELTA * DELTA) * (DELTA * DELTA) / 24.0;
   const double MAGIC = 0x1.8p52;
@@ -180,19 +192,24 @@ __device__ __forceinline__ void sincos_tab(double phi, const double2* tab,
   // ties only, which merely lets |u| reach 1/2 + 2^-53
   const double m = fma_(phi, STEPS_PER_RAD_HI, MAGIC);
   const double n = m - MAGIC;
-  // byte offset of the entry: two 32-bit ops (shift, mask)
+  // byte offset of the entry
   // (asm: left to itself the compiler SLP-packs the shifts of two pairs into five ops)
   unsigned off;
-  asm("v_lshlrev_b32 %0, 4, %1\n\tv_and_b32 %0, 0x7ff0, %0"
-      : "=v"(off)
-      : "v"((unsigned)__double2loint(m)));
-  static_assert(SINCOS_TAB_N == 2048, "mask 0x7ff0 = (N - 1) << 4");
+  if (N == 2048)
+    asm("v_lshlrev_b32 %0, 4, %1\n\tv_and_b32 %0, 0x7ff0, %0"
+        : "=v"(off)
+        : "v"((unsigned)__double2loint(m)));
+  else
+    asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD "
+        "src0_sel:DWORD src1_sel:DWORD"
+        : "=v"(off)
+        : "v"((unsigned)__double2loint(m)));
   const double2 T = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + off);
   double u = fma_(phi, STEPS_PER_RAD_HI, -n);
   u = fma_(phi, STEPS_PER_RAD_LO, u);
   const double w = u * u;
   const double s = fma_(S1, w, k.s0) * u;
-  const double c = fma_(fma_(C2, w, k.c1), w, 1.0);
+  const double c = N == 2048 ? fma_(fma_(C2, w, k.c1), w, 1.0) : fma_(k.c1, w, 1.0);
   cs = T.x * c;
   cs = fma_(-T.y, s, cs);
   sn = T.y * c;
@@ -202,7 +219,7 @@ __device__ __forceinline__ void sincos_tab(double phi, const double2* tab,
 // table form where its bound holds, the general polynomial form otherwise (the
 // branch is taken per lane; a wave whose lanes all qualify skips the slow side)
 __device__ __forceinline__ void sincos_any(double phi, const double2* tab,
-                                           const SinCosTabRegs& k, double& sn, double& cs) {
+                                           const SinCosTabRegs<>& k, double& sn, double& cs) {
   if (__builtin_fabs(phi) < 0x1p42)
     sincos_tab(phi, tab, k, sn, cs);
   else

@@ -278,10 +278,11 @@ struct GenKern {
   template <int PPT>
   static __device__ __forceinline__ void pre(const Pts<PPT>&,
                                              const double (&)[KIRCHHOFF_REC_DOUBLES], Shared&) {}
-  template <int PPT>
+  template <int PPT, int TN>
   static __device__ __forceinline__ Mid head(const Pts<PPT>& p, int j, const Shared&,
                                              const double (&r)[KIRCHHOFF_REC_DOUBLES],
-                                             const double2* tab, const SinCosTabRegs& kreg) {
+                                             const double2* tab,
+                                             const SinCosTabRegs<TN>& kreg) {
     const double sx = r[0], sy = r[1], sz = r[2], knl = r[3];
     const double kny = r[4], k = r[5], knx = r[9], knz = r[10];
     Mid m;
@@ -304,7 +305,7 @@ struct GenKern {
     const double cr = m.h * fma_(dn, m.h, knl);   // (k/r)(d.n/r + nl)
     double sn, cs;
     if (TAB)
-      sincos_tab(phase, tab, kreg, sn, cs);
+      sincos_tab<TN>(phase, tab, kreg, sn, cs);
     else
       sincos_phase(phase, sn, cs);
     m.gr = cr * cs;
@@ -340,10 +341,11 @@ struct FastKern {
       s.t = s.dx * s.dx + r[3];
     }
   }
-  template <int PPT>
+  template <int PPT, int TN>
   static __device__ __forceinline__ Mid head(const Pts<PPT>& p, int j, const Shared& s,
                                              const double (&r)[KIRCHHOFF_REC_DOUBLES],
-                                             const double2* tab, const SinCosTabRegs& kreg) {
+                                             const double2* tab,
+                                             const SinCosTabRegs<TN>& kreg) {
     const double sx = r[0], sz = r[1], dy2 = r[3], y0 = r[4], h0 = r[5];
     const double k = r[6], knl = r[7], dn = r[8];
     Mid m;
@@ -365,7 +367,7 @@ struct FastKern {
     const double cr = m.h * fma_(dn, m.h, knl);
     double sn, cs;
     if (TAB)
-      sincos_tab(phase, tab, kreg, sn, cs);
+      sincos_tab<TN>(phase, tab, kreg, sn, cs);
     else
       sincos_phase(phase, sn, cs);
     m.gr = cr * cs;
@@ -467,9 +469,10 @@ struct SRec<32> {   // the whole 128-byte record
 
 // work on the record in `cur`; between the two halves settle `landed` (if any) and
 // request the record at `pnext` into `fetch`
-template <int PPT, class K, class R>
+template <int PPT, int TN, class K, class R>
 __device__ __forceinline__ void stream_step(const Pts<PPT>& pts, Acc (&acc)[PPT],
-                                            const double2* tab, const SinCosTabRegs& kreg,
+                                            const double2* tab,
+                                            const SinCosTabRegs<TN>& kreg,
                                             const R& cur, R* landed, R& fetch,
                                             const double* pnext) {
   double r[KIRCHHOFF_REC_DOUBLES];
@@ -478,7 +481,7 @@ __device__ __forceinline__ void stream_step(const Pts<PPT>& pts, Acc (&acc)[PPT]
   K::template pre<PPT>(pts, r, sh);
   Mid m[PPT];
 #pragma unroll
-  for (int j = 0; j < PPT; ++j) m[j] = K::template head<PPT>(pts, j, sh, r, tab, kreg);
+  for (int j = 0; j < PPT; ++j) m[j] = K::template head<PPT, TN>(pts, j, sh, r, tab, kreg);
   __builtin_amdgcn_sched_barrier(0);
   if (landed) landed->settle();
   fetch.issue(pnext);
@@ -487,12 +490,12 @@ __device__ __forceinline__ void stream_step(const Pts<PPT>& pts, Acc (&acc)[PPT]
   for (int j = 0; j < PPT; ++j) K::tail(m[j], sh, r, acc[j]);
 }
 
-template <int PPT, class K>
+template <int PPT, int TN, class K>
 __device__ __forceinline__ void stream_loop(const Pts<PPT>& pts, Acc (&acc)[PPT],
                                             const double* __restrict__ rec,
                                             const double2* tab, int s0, int s1) {
   if (s0 >= s1) return;
-  const SinCosTabRegs kreg;
+  const SinCosTabRegs<TN> kreg;
   typedef SRec<K::NDW> R;
   const double* p = rec + (int64_t)s0 * KIRCHHOFF_REC_DOUBLES;
   // requests past the last record re-read the last one (never used): uniform loop.
@@ -505,11 +508,11 @@ __device__ __forceinline__ void stream_loop(const Pts<PPT>& pts, Acc (&acc)[PPT]
     A.issue(p);
     A.settle();
     for (;;) {
-      stream_step<PPT, K, R>(pts, acc, tab, kreg, A, nullptr, B, KIRCHHOFF_AHEAD(p, 1));
+      stream_step<PPT, TN, K, R>(pts, acc, tab, kreg, A, nullptr, B, KIRCHHOFF_AHEAD(p, 1));
       B.settle();
       if (--left == 0) break;
       p += KIRCHHOFF_REC_DOUBLES;
-      stream_step<PPT, K, R>(pts, acc, tab, kreg, B, nullptr, A, KIRCHHOFF_AHEAD(p, 1));
+      stream_step<PPT, TN, K, R>(pts, acc, tab, kreg, B, nullptr, A, KIRCHHOFF_AHEAD(p, 1));
       A.settle();
       if (--left == 0) break;
       p += KIRCHHOFF_REC_DOUBLES;
@@ -522,13 +525,13 @@ __device__ __forceinline__ void stream_loop(const Pts<PPT>& pts, Acc (&acc)[PPT]
     B.issue(KIRCHHOFF_AHEAD(p, 1));
     A.settle();   // lgkmcnt(0): B has landed as well
     for (;;) {
-      stream_step<PPT, K, R>(pts, acc, tab, kreg, A, &B, C, KIRCHHOFF_AHEAD(p, 2));
+      stream_step<PPT, TN, K, R>(pts, acc, tab, kreg, A, &B, C, KIRCHHOFF_AHEAD(p, 2));
       if (--left == 0) break;
       p += KIRCHHOFF_REC_DOUBLES;
-      stream_step<PPT, K, R>(pts, acc, tab, kreg, B, &C, A, KIRCHHOFF_AHEAD(p, 2));
+      stream_step<PPT, TN, K, R>(pts, acc, tab, kreg, B, &C, A, KIRCHHOFF_AHEAD(p, 2));
       if (--left == 0) break;
       p += KIRCHHOFF_REC_DOUBLES;
-      stream_step<PPT, K, R>(pts, acc, tab, kreg, C, &A, B, KIRCHHOFF_AHEAD(p, 2));
+      stream_step<PPT, TN, K, R>(pts, acc, tab, kreg, C, &A, B, KIRCHHOFF_AHEAD(p, 2));
       if (--left == 0) break;
       p += KIRCHHOFF_REC_DOUBLES;
     }
@@ -587,8 +590,11 @@ __global__ __launch_bounds__(KIRCHHOFF_BLOCK, PPT > 2 ? 2 : KIRCHHOFF_WAVES) voi
   const int64_t lanes = ((rows + PPT - 1) / PPT) * L;
   if (tile * KIRCHHOFF_BLOCK >= lanes) return;   // the grid is sized for the worst L
 
-  __shared__ double2 tab[SINCOS_TAB_N];
-  sincos_tab_fill(tab);
+  // four points per lane run two blocks per CU (register budget): room for the 64-KB
+  // table, whose remainder needs one term less and whose offset is one instruction
+  constexpr int TN = PPT >= 4 ? 4096 : SINCOS_TAB_N;
+  __shared__ double2 tab[TN];
+  sincos_tab_fill<TN>(tab);
 
   const int64_t n = tile * KIRCHHOFF_BLOCK + threadIdx.x;
   const int64_t grp = n / L;
@@ -616,8 +622,10 @@ __global__ __launch_bounds__(KIRCHHOFF_BLOCK, PPT > 2 ? 2 : KIRCHHOFF_WAVES) voi
   // enough (fp64_math.h); harder X-rays over longer distances take the general one
   const double kmax = __longlong_as_double(info->kmax);
   const double smax = __longlong_as_double(info->s1max);
+  // (the reduction keeps phase * N/2pi + 1.5 * 2^52 at unit spacing: 2^42 rad for the
+  // 2048-entry table, 2^41 for the 4096-entry one)
   const bool small_phase =
-      wave_max_u64(dbits(kmax * (pabs + smax))) < dbits(0x1p42);
+      wave_max_u64(dbits(kmax * (pabs + smax))) < dbits(TN > 2048 ? 0x1p41 : 0x1p42);
   const bool share = PPT > 1 && L != KIRCHHOFF_BLOCK && __all(onex);
   const bool has_p = f & KIRCHHOFF_FLAG_EP;
   const bool gen_n = f & KIRCHHOFF_FLAG_NXZ;
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(KIRCHHOFF_BLOCK, PPT > 2 ? 2 : KIRCHHOFF_WAVES) voi
 #define KIRCHHOFF_RUN(vid, ...)                                   \
   do {                                                            \
     v = (vid);                                                    \
-    stream_loop<PPT, __VA_ARGS__>(pts, acc, rec, tab, s0, s1);    \
+    stream_loop<PPT, TN, __VA_ARGS__>(pts, acc, rec, tab, s0, s1); \
   } while (0)
   if (fast) {
     if (!small_phase) {
@@ -783,16 +791,17 @@ __global__ void debug_sincos_kernel(int64_t n, const double* __restrict__ phi,
   cs[i] = c;
 }
 
+template <int TN>
 __global__ __launch_bounds__(256) void debug_sincos_tab_kernel(
     int64_t n, const double* __restrict__ phi, double* __restrict__ sn,
     double* __restrict__ cs) {
-  __shared__ double2 tab[SINCOS_TAB_N];
-  sincos_tab_fill(tab);
+  __shared__ double2 tab[TN];
+  sincos_tab_fill<TN>(tab);
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double s, c;
-  const SinCosTabRegs kreg;
-  sincos_tab(phi[i], tab, kreg, s, c);
+  const SinCosTabRegs<TN> kreg;
+  sincos_tab<TN>(phi[i], tab, kreg, s, c);
   sn[i] = s;
   cs[i] = c;
 }
@@ -923,9 +932,13 @@ hipError_t debug_divconst_launch(int64_t n, const double* a, double b, double y,
 
 hipError_t debug_sincos_launch(int64_t n, const double* phi, double* sn, double* cs,
                                int table, hipStream_t stream) {
-  if (table)
-    hipLaunchKernelGGL(debug_sincos_tab_kernel, dim3((unsigned)((n + 255) / 256)),
+  if (table == 2)
+    hipLaunchKernelGGL(debug_sincos_tab_kernel<4096>, dim3((unsigned)((n + 255) / 256)),
                        dim3(256), 0, stream, n, phi, sn, cs);
+  else if (table)
+    hipLaunchKernelGGL(debug_sincos_tab_kernel<SINCOS_TAB_N>,
+                       dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, phi, sn,
+                       cs);
   else
     hipLaunchKernelGGL(debug_sincos_kernel, dim3((unsigned)((n + 255) / 256)),
                        dim3(256), 0, stream, n, phi, sn, cs);

@@ -69,7 +69,7 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
                                         const double2* tab, double g, double wu, double w,
                                         double ww1, double phi, double psi, double2& out_s,
                                         double2& out_p) {
-  const SinCosTabRegs kreg;
+  const SinCosTabRegs<> kreg;
   const double Kx = a.Kx, Ky = a.Ky;
   const double kx2 = Kx * Kx, ky2 = Ky * Ky;
   const double revg = 1. / g;
@@ -279,7 +279,7 @@ cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
   sincos_tab_fill(tab);
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const SinCosTabRegs kreg;
+  const SinCosTabRegs<> kreg;
   const double emcg = emcg_[i], w = w_[i], phi = ddphi[i], psi = ddpsi[i];
   const double g = FIL ? gamma[0] : gamma[i];
   double dirx = phi, diry = psi;

@@ -142,7 +142,8 @@ def debug_sincos(phi, table=False):
     lib = _lib.load()
     s = torch.empty_like(phi)
     c = torch.empty_like(phi)
-    fn = lib.xrt_hip_debug_sincos_tab_f64_dev if table else lib.xrt_hip_debug_sincos_f64_dev
+    fn = {0: lib.xrt_hip_debug_sincos_f64_dev, 1: lib.xrt_hip_debug_sincos_tab_f64_dev,
+          2: lib.xrt_hip_debug_sincos_tab4k_f64_dev}[int(table)]
     _lib.check(fn(phi.numel(), _f64(phi), _f64(s), _f64(c), _stream_ptr()), 'debug_sincos')
     return s, c
 
