@@ -563,12 +563,13 @@ def main():
                            value=d['value'], ms_per_step=d['ms_per_step'],
                            good_fraction=d['good_fraction'],
                            roofline=dict(
-                               bound='hbm', kernel='DCM.double_reflect (whole pass: both '
-                                                   'crystals, host clock over the steps)',
+                               bound='hbm', kernel='reflect_fused_dcm + its two small '
+                                                   'launches (whole double_reflect pass, '
+                                                   'host clock over the steps)',
                                achieved=dcm_bytes / dcm_s / 1e9, peak=HBM_PEAK / 1e9,
                                unit='GB/s', frac=dcm_bytes / dcm_s / HBM_PEAK,
                                note='208 B per intersection (416 B per ray)',
-                               traffic=load_traffic('dcm_double_reflect'),
+                               traffic=load_traffic('reflect_fused_dcm'),
                                traffic_source=TRAFFIC_SOURCE))
     host = None
     if not args.skip_kirchhoff:

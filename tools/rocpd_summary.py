@@ -17,13 +17,12 @@ import os
 import sqlite3
 import sys
 
-OURS = ('reflect_fused_xtal', 'reflect_light_stats', 'reflect_decide_opt', 'reflect_check_opt',
-        'reflect_fused', 'reflect_solve', 'reflect_finish', 'reflect_stats_dir_y',
-        'reflect_stats_dir',
-        'reflect_stats_bracket', 'screen_expose_kernel', 'kirchhoff_stream',
-        'kirchhoff_pack', 'kirchhoff_finalize', 'und_imap', 'und_sum', 'und_pack',
-        'aperture_propagate_kernel', 'hist2d_kernel', 'reflect_decide_axis',
-        'reflect_reduce_bracket', 'reflect_reduce_bdn', 'reflect_init')
+OURS = ('reflect_fused_xtal', 'reflect_fused_dcm', 'reflect_dcm_exact', 'reflect_decide_dcm',
+        'reflect_decide_opt', 'reflect_exact', 'reflect_fused', 'reflect_init',
+        'screen_expose_kernel', 'kirchhoff_stream', 'kirchhoff_scan', 'kirchhoff_pack',
+        'kirchhoff_finalize', 'und_imap', 'und_sum', 'und_pack', 'aperture_propagate_kernel',
+        'hist2d_kernel', 'plot_hist1d_lds', 'plot_hist2d_lds', 'surface_eval_kernel',
+        'beam_to_global_kernel')
 
 
 def short(name):

@@ -53,6 +53,20 @@ __device__ __forceinline__ unsigned long long dbits(double v) {
 //     distance of any pair is from |py0 - sy| (kirchhoff_fast below);
 //   * the row length of a receiving mesh: the first p > 0 with px[p] == px[0].
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v,
+                                                           unsigned long long* lds) {
+  v = wave_max_u64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long r = lds[0];
+  for (unsigned w = 1; w < (blockDim.x >> 6); ++w) r = lds[w] > r ? lds[w] : r;
+  return r;
+}
+
+// (a capped grid of striding blocks, one atomic per block and quantity: the atomics all go
+// to the same few addresses, where they serialise -- one per WAVE made this pass take 1 ms
+// on 1e6 samples)
 __global__ __launch_bounds__(256) void kirchhoff_scan(
     int64_t np, const double* __restrict__ px, const double* __restrict__ py,
     const double* __restrict__ pz, int64_t ns, const double* __restrict__ sx,
@@ -60,63 +74,76 @@ __global__ __launch_bounds__(256) void kirchhoff_scan(
     const double* __restrict__ nx, const double* __restrict__ nz, int nstride,
     const double* __restrict__ k, const double2* __restrict__ Ep, int nbp, unsigned opts,
     KirchhoffInfo* __restrict__ info) {
+  __shared__ unsigned long long lds[4];
   unsigned f = 0;
-  const bool lane0 = (threadIdx.x & 63) == 0;
   if ((int)blockIdx.x < nbp) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long xm = 0, zm = 0, nr = 0;
-    if (i < np) {
-      if (py[i] != py[0]) f |= KIRCHHOFF_FLAG_PYVAR;
-      xm = dbits(fabs(px[i]));
-      zm = dbits(fabs(pz[i]));
-      if (i > 0 && px[i] == px[0]) nr = ~(unsigned long long)i;
+    const double y0 = np > 0 ? py[0] : 0., x0 = np > 0 ? px[0] : 0.;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < np;
+         i += (int64_t)nbp * blockDim.x) {
+      if (py[i] != y0) f |= KIRCHHOFF_FLAG_PYVAR;
+      const unsigned long long ax = dbits(fabs(px[i])), az = dbits(fabs(pz[i]));
+      xm = ax > xm ? ax : xm;
+      zm = az > zm ? az : zm;
+      if (i > 0 && px[i] == x0) {
+        const unsigned long long c = ~(unsigned long long)i;
+        nr = c > nr ? c : nr;
+      }
     }
     f = __builtin_amdgcn_readfirstlane(__reduce_or_sync(~0ull, f));
-    xm = wave_max_u64(xm);
-    zm = wave_max_u64(zm);
-    nr = wave_max_u64(nr);
-    if (lane0) {
-      if (f) atomicOr(&info->flags, f);
+    if (f && (threadIdx.x & 63) == 0) atomicOr(&info->flags, f);
+    xm = block_max_u64(xm, lds);
+    zm = block_max_u64(zm, lds);
+    nr = block_max_u64(nr, lds);
+    if (threadIdx.x == 0) {
       atomicMax(&info->pxmax, xm);
       atomicMax(&info->pzmax, zm);
       if (nr) atomicMax(&info->not_row, nr);
-    }
-    if (i == 0) {
-      info->py0 = py[0];
-      info->opts = opts;
+      if (blockIdx.x == 0) {
+        info->py0 = y0;
+        info->opts = opts;
+      }
     }
     return;
   }
-  const int64_t i = (int64_t)((int)blockIdx.x - nbp) * blockDim.x + threadIdx.x;
+  const int nbs = (int)gridDim.x - nbp;
   unsigned long long km = 0, s1 = 0, xm = 0, zm = 0, dm = 0;
-  if (i < ns) {
+  const double y0 = np > 0 ? py[0] : 0., k0 = ns > 0 ? k[0] : 0.;
+  for (int64_t i = (int64_t)((int)blockIdx.x - nbp) * blockDim.x + threadIdx.x; i < ns;
+       i += (int64_t)nbs * blockDim.x) {
     const int64_t ip = i * pstride, in = i * nstride;
     const double2 ep = Ep[i];
     const double kk = k[i], x = sx[ip], y = sy[ip], z = sz[ip];
     if (ep.x != 0. || ep.y != 0.) f |= KIRCHHOFF_FLAG_EP;
     if (nx[in] != 0. || nz[in] != 0.) f |= KIRCHHOFF_FLAG_NXZ;
-    if (kk != k[0]) f |= KIRCHHOFF_FLAG_KVAR;
-    km = dbits(fabs(kk));
-    s1 = dbits(fabs(x) + fabs(y) + fabs(z));
-    xm = dbits(fabs(x));
-    zm = dbits(fabs(z));
+    if (kk != k0) f |= KIRCHHOFF_FLAG_KVAR;
+    unsigned long long t;
+    t = dbits(fabs(kk));
+    km = t > km ? t : km;
+    t = dbits(fabs(x) + fabs(y) + fabs(z));
+    s1 = t > s1 ? t : s1;
+    t = dbits(fabs(x));
+    xm = t > xm ? t : xm;
+    t = dbits(fabs(z));
+    zm = t > zm ? t : zm;
     // 1/0 = inf and NaN both sort above every finite value: no fast geometry then
-    dm = np > 0 ? dbits(fabs(1. / (py[0] - y))) : 0;
-    if (i == 0) info->k0 = kk;
+    t = np > 0 ? dbits(fabs(1. / (y0 - y))) : 0;
+    dm = t > dm ? t : dm;
   }
   f = __builtin_amdgcn_readfirstlane(__reduce_or_sync(~0ull, f));
-  km = wave_max_u64(km);
-  s1 = wave_max_u64(s1);
-  xm = wave_max_u64(xm);
-  zm = wave_max_u64(zm);
-  dm = wave_max_u64(dm);
-  if (lane0) {
-    if (f) atomicOr(&info->flags, f);
+  if (f && (threadIdx.x & 63) == 0) atomicOr(&info->flags, f);
+  km = block_max_u64(km, lds);
+  s1 = block_max_u64(s1, lds);
+  xm = block_max_u64(xm, lds);
+  zm = block_max_u64(zm, lds);
+  dm = block_max_u64(dm, lds);
+  if (threadIdx.x == 0) {
     atomicMax(&info->kmax, km);
     atomicMax(&info->s1max, s1);
     atomicMax(&info->sxmax, xm);
     atomicMax(&info->szmax, zm);
     atomicMax(&info->dyinvmax, dm);
+    if ((int)blockIdx.x == nbp) info->k0 = k0;
   }
 }
 
@@ -875,7 +902,9 @@ hipError_t kirchhoff_launch(const KirchhoffPlan& pl, int64_t np, const double* p
   hipError_t me = hipMemsetAsync(info, 0, sizeof(KirchhoffInfo), stream);
   if (me != hipSuccess) return me;
   if (np > 0 || ns > 0) {
-    const int nbp = (int)((np + 255) / 256), nbs = (int)((ns + 255) / 256);
+    // at most 256 striding blocks per point set
+    const int64_t wp = (np + 255) / 256, wsm = (ns + 255) / 256;
+    const int nbp = (int)(wp < 256 ? wp : 256), nbs = (int)(wsm < 256 ? wsm : 256);
     hipLaunchKernelGGL(kirchhoff_scan, dim3((unsigned)(nbp + nbs)), dim3(256), 0, stream, np,
                        px, py, pz, ns, sx, sy, sz, pstride, nx, nz, nstride, k,
                        reinterpret_cast<const double2*>(Ep), nbp, (unsigned)pl.opts, info);
