@@ -328,6 +328,44 @@ XRT_HIP_API int xrt_hip_surface_eval_f64_dev(const xrt_hip_pass* pass, int what,
 XRT_HIP_API int xrt_hip_local_to_global_f64_dev(const xrt_hip_pass* pass, xrt_hip_beam* beam,
                                                 void* stream);
 
+/* waves.diffract around the Kirchhoff integral (waves.py:606-831), on device arrays.
+ *
+ * diffract_pre: the samples on the diffracting element -> the inputs of
+ * xrt_hip_kirchhoff_f64_dev (positions, normals -- the element's surface normal at each
+ * sample if is_oe, else (0, 1, 0) --, nl = direction . normal, k = E / CHBAR 1e7, Es / Ep
+ * with every sample not in state 1 switched off, waves.py:674-689, :841) and
+ * sums_host[0..2] = sum(Jss + Jpp), sum((Jss + Jpp) nl), count over the lit samples
+ * (:690-696). workspace >= 6144 bytes. Synchronises.
+ *
+ * wave_fields: acc += fresh (the five integrals S, P, A, B, C of this call into the
+ * wave's accumulators), then amplitudes, coherency matrix, direction (phase of the
+ * dominant direction integral removed) and energy of `wave` from the accumulators,
+ * intensities times `scale`, amplitudes times sqrt(scale) (:707-749).
+ *
+ * basis_to_global: beam positions (and directions) out of a frame given by the
+ * origin / axes of an xrt_hip_screen record (screens, apertures), in place.
+ *
+ * wave_receive: the diffracted field `glo` (global frame) into the local frame of the
+ * element the samples `wave` lie on: receiver = its pass record (azimuth, to_local, roll,
+ * surface); is_oe = 0 for screens / apertures (azimuth only); obliquity applied to both
+ * beams (:773-824). */
+XRT_HIP_API int xrt_hip_diffract_pre_f64_dev(
+    const xrt_hip_pass* surface, int is_oe, const xrt_hip_beam* samples, double* sx,
+    double* sy, double* sz, double* nx, double* ny, double* nz, double* nl, double* k,
+    double* Es_ri, double* Ep_ri, void* workspace, size_t workspace_bytes, void* stream,
+    double* sums_host);
+XRT_HIP_API int xrt_hip_wave_fields_f64_dev(int64_t n, double* const* fresh_ri,
+                                            double* const* acc_ri, const double* energy0,
+                                            double scale, int from_oe, xrt_hip_beam* wave,
+                                            void* stream);
+struct xrt_hip_screen;
+XRT_HIP_API int xrt_hip_basis_to_global_f64_dev(const struct xrt_hip_screen* frame,
+                                                xrt_hip_beam* beam, int with_directions,
+                                                void* stream);
+XRT_HIP_API int xrt_hip_wave_receive_f64_dev(const xrt_hip_pass* receiver, int is_oe,
+                                             xrt_hip_beam* wave, xrt_hip_beam* glo,
+                                             void* stream);
+
 /* Stand-alone amplitude evaluation on device arrays (what the reference exposes
  * as Material.get_amplitude(E, beamInDotNormal, fromVacuum) -> rs, rp, mu, n'k
  * (materials/material.py:415-493) and Crystal.get_amplitude(E, beamInDotNormal,

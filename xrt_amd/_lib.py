@@ -44,6 +44,13 @@ SIGNATURES = {
     'xrt_hip_surface_eval_f64_dev': (ctypes.c_int, [
         vp, ctypes.c_int, i64, vp, vp, vp, vp, vp]),
     'xrt_hip_local_to_global_f64_dev': (ctypes.c_int, [vp, vp, vp]),
+    'xrt_hip_diffract_pre_f64_dev': (ctypes.c_int, [
+        vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp,
+        c_double_p]),
+    'xrt_hip_wave_fields_f64_dev': (ctypes.c_int, [
+        i64, vp, vp, vp, ctypes.c_double, ctypes.c_int, vp, vp]),
+    'xrt_hip_basis_to_global_f64_dev': (ctypes.c_int, [vp, vp, ctypes.c_int, vp]),
+    'xrt_hip_wave_receive_f64_dev': (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp]),
     'xrt_hip_material_amplitude_f64_dev': (ctypes.c_int, [
         vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_crystal_amplitude_f64_dev': (ctypes.c_int, [

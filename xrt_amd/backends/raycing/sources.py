@@ -20,11 +20,13 @@ defaultEnergy = 9.0e3
 
 _F64 = ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp')
 _C128 = ('Jsp', 'Es', 'Ep')
-_OPT_F64 = ('theta', 'order')
+_OPT_F64 = ('theta', 'order', 'xDiffr', 'yDiffr', 'zDiffr', 'rDiffr')
+# accumulated Kirchhoff integrals of a receiving wave (waves.diffract)
+_OPT_C128 = ('EsAcc', 'EpAcc', 'aEacc', 'bEacc', 'cEacc')
 _SCALAR_ATTRS = ('sourceSIGMAx', 'sourceSIGMAz', 'filamentDX', 'filamentDZ',
                  'filamentDtheta', 'filamentDpsi', 'filamentDgamma', 'accepted',
                  'acceptedE', 'seeded', 'seededI', 'sourceWeight')
-_ARRAY_FIELDS = set(_F64) | set(_C128) | set(_OPT_F64) | {'state'}
+_ARRAY_FIELDS = set(_F64) | set(_C128) | set(_OPT_F64) | set(_OPT_C128) | {'state'}
 _TORCH_DTYPE = {np.dtype('float64'): torch.float64,
                 np.dtype('complex128'): torch.complex128,
                 np.dtype('int32'): torch.int32}
@@ -33,7 +35,7 @@ _TORCH_DTYPE = {np.dtype('float64'): torch.float64,
 def _np_dtype(name):
     if name == 'state':
         return np.int32
-    if name in _C128:
+    if name in _C128 or name in _OPT_C128:
         return np.complex128
     return np.float64
 
@@ -130,7 +132,7 @@ class Beam(object):
             setattr(self, name, getattr(self, name)[indarr])
 
     def array_fields(self):
-        return [n for n in (_F64 + _C128 + _OPT_F64 + ('state',))
+        return [n for n in (_F64 + _C128 + _OPT_F64 + _OPT_C128 + ('state',))
                 if n in self._h or n in self._d]
 
     @property

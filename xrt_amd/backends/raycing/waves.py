@@ -7,13 +7,14 @@ footprint area, normalisation, phase strip, frame changes) is host glue, like in
 the reference. Sign convention: the numpy path of the reference
 (``_diffraction_integral_conv``, +i k/4pi).
 """
+import ctypes
 import time
 
 import numpy as np
 import torch
 
 from .. import raycing
-from ... import _lib, hipcalls
+from ... import _lib, _structs, hipcalls
 from . import sources as rs
 from .physconsts import CH, CHBAR
 
@@ -103,26 +104,46 @@ def qualify_sampling(wave, E, goodlen):
     return fn, samplesPerZone
 
 
+def _outside_polygon(px, py, corners):
+    """Mask of the points NOT strictly inside the convex polygon *corners* (counter-
+    clockwise): only those can be vertices of the hull."""
+    inside = np.ones(len(px), dtype=bool)
+    for (x1, y1), (x2, y2) in zip(corners, corners[1:] + corners[:1]):
+        inside &= (x2-x1)*(py-y1) - (y2-y1)*(px-x1) > 0
+    return ~inside
+
+
+def _extremes(px, py, keys):
+    """The points that are extreme along the given directions, in the order of the
+    directions, consecutive duplicates dropped."""
+    ext = []
+    for key in keys:
+        i = int(np.argmax(key))
+        if not ext or (px[i], py[i]) != ext[-1]:
+            ext.append((px[i], py[i]))
+    if len(ext) > 1 and ext[0] == ext[-1]:
+        ext.pop()
+    return ext
+
+
 def convex_hull_area(px, py):
-    """Area of the convex hull of 2-D points (Andrew's monotone chain); the
-    reference takes it from scipy.spatial.ConvexHull (waves.py:661-668)."""
+    """Area of the convex hull of 2-D points (Andrew's monotone chain; the reference
+    takes it from scipy.spatial.ConvexHull, waves.py:661-668). Two rounds of the
+    Akl-Toussaint filter come first -- the octagon of the 8 axis / diagonal extremes over
+    all points, then the polygon of the extremes in 64 directions over the survivors --,
+    so that the Python loop of the chain only sees a handful of points."""
     px = np.asarray(px, dtype=float)
     py = np.asarray(py, dtype=float)
     if len(px) > 64:
-        # Akl-Toussaint pre-filter: points strictly inside the octagon of the
-        # extreme points in 8 directions cannot be hull vertices
-        ext = []
-        for key in (px, px + py, py, py - px, -px, -px - py, -py, px - py):
-            i = int(np.argmax(key))
-            if not ext or (px[i], py[i]) != ext[-1]:
-                ext.append((px[i], py[i]))
-        if len(ext) > 1 and ext[0] == ext[-1]:
-            ext.pop()
+        ext = _extremes(px, py, (px, px + py, py, py - px, -px, -px - py, -py, px - py))
         if len(ext) >= 3:
-            inside = np.ones(len(px), dtype=bool)
-            for (x1, y1), (x2, y2) in zip(ext, ext[1:] + ext[:1]):
-                inside &= (x2-x1)*(py-y1) - (y2-y1)*(px-x1) > 0
-            keep = ~inside
+            keep = _outside_polygon(px, py, ext)
+            px, py = px[keep], py[keep]
+    if len(px) > 256:
+        ang = np.arange(64) * (2 * np.pi / 64)
+        ext = _extremes(px, py, [px * c + py * s_ for c, s_ in zip(np.cos(ang), np.sin(ang))])
+        if len(ext) >= 3:
+            keep = _outside_polygon(px, py, ext)
             px, py = px[keep], py[keep]
     pts = np.unique(np.column_stack((px, py)), axis=0)
     if len(pts) < 3:
@@ -147,158 +168,102 @@ def convex_hull_area(px, py):
     return 0.5 * abs(np.sum(x1*y2 - x2*y1))
 
 
-def _kirchhoff_on_gpu(oeLocal, n, nl, wave, good):
-    """(Es, Ep, aE, bE, cE) of waves.py:834-851, computed by the HIP kernel."""
+def _kirchhoff_on_gpu(points, samples):
+    """The five integrals (Es, Ep, aE, bE, cE) of the reference's numpy kernel
+    (waves.py:834-851) for receiving *points* (3 device tensors) and *samples* (the ten
+    device tensors of ``_sample_arrays``), by the HIP kernel -> 5 device tensors."""
     global lastKernelMs
-    _lib.require_gpu()
-    dev = torch.device('cuda', torch.cuda.current_device())
-
-    def up(a, dtype=np.float64):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(dev)
-    shape = oeLocal.x[good].shape
-    n3 = [np.broadcast_to(np.asarray(c, dtype=float), oeLocal.x.shape)[good]
-          if np.ndim(c) else np.full(shape, float(c)) for c in n]
-    k = oeLocal.E[good] / CHBAR * 1e7                      # waves.py:841
-    out = hipcalls.kirchhoff(
-        up(wave.xDiffr), up(wave.yDiffr), up(wave.zDiffr),
-        up(oeLocal.x[good]), up(oeLocal.y[good]), up(oeLocal.z[good]),
-        up(n3[0]), up(n3[1]), up(n3[2]), up(nl[good]), up(k),
-        up(oeLocal.Es[good], np.complex128), up(oeLocal.Ep[good], np.complex128),
-        convention=0, timing=True)
+    out = hipcalls.kirchhoff(*points, *samples, convention=0, timing=True)
     lastKernelMs = out[5]
-    return [o.cpu().numpy() for o in out[:5]]
+    return out[:5]
 
 
-def _illuminated_area(oe, field, lit):
+def _illuminated_area(oe, field):
     """Footprint of the lit samples on the diffracting element, for the flux
     normalisation: given by whoever made *field*, else the convex hull in the
     element's surface coordinates (waves.py:642-670)."""
     area = getattr(field, 'area', None)
     if area is not None and area > 0:
         return area
+    lit = field.peek('state') == 1
     if hasattr(oe, 'rotationSequence'):
-        along = field.y                      # an optical element: (x, y)
+        along = field.peek('y')              # an optical element: (x, y)
     elif hasattr(oe, 'propagate') or hasattr(oe, 'prepare_wave') or \
             hasattr(oe, 'shine'):
-        along = field.z                      # aperture / screen / source: (x, z)
+        along = field.peek('z')              # aperture / screen / source: (x, z)
     else:
         raise ValueError('Unknown diffracting element!')
-    area = convex_hull_area(field.x[lit], along[lit])
+    area = convex_hull_area(field.peek('x')[lit], along[lit])
     if hasattr(field, 'areaFraction'):
         area *= field.areaFraction
     return area
 
 
-def _surface_normals(oe, field):
-    """Normal of the diffracting surface at every sample and the cosine between
-    it and the incoming direction (waves.py:674-689)."""
-    if not hasattr(oe, 'rotationSequence'):
-        normal = [0, 1, 0]
-        return normal, field.a*normal[0] + field.b*normal[1] + field.c*normal[2]
-    normal_at = oe.local_n2 if hasattr(oe, 'cryst2pitch') else oe.local_n
-    if oe.isParametric:
-        sp, phi, _ = oe.xyz_to_param(field.x, field.y, field.z)
-        normal = normal_at(sp, phi)
-    else:
-        normal = normal_at(field.x, field.y)[-3:]
-    cosine = (field.a*np.asarray([normal[-3]]) + field.b*np.asarray([normal[-2]]) +
-              field.c*np.asarray([normal[-1]])).flatten()
-    return normal, cosine
+def _element_pass(element, lib_pass=None):
+    """(pass record, is_oe) that tells the kernels about *element*'s surface and frame."""
+    if hasattr(element, 'rotationSequence'):
+        if hasattr(element, 'cryst2pitch'):
+            raise NotImplementedError('wave propagation from / onto a DCM or plate')
+        return element._make_pass(*element._own_angles()[:4]), 1
+    p = _structs.Pass()
+    p.invert_normal = 1
+    bl = getattr(element, 'bl', None)
+    p.sin_az, p.cos_az = (0., 1.) if bl is None else (bl.sinAzimuth, bl.cosAzimuth)
+    return p, 0
 
 
-def _fields_and_directions(oe, wave, energy):
-    """From the accumulated integrals: amplitudes, coherency matrix and the
-    propagation direction (the direction integrals share one arbitrary phase,
-    removed with the dominant component; waves.py:707-733)."""
-    wave.E[:] = energy
-    wave.Es[:] = wave.EsAcc
-    wave.Ep[:] = wave.EpAcc
-    wave.Jss[:] = (wave.Es * np.conj(wave.Es)).real
-    wave.Jpp[:] = (wave.Ep * np.conj(wave.Ep)).real
-    wave.Jsp[:] = wave.Es * np.conj(wave.Ep)
-    carrier = wave.bEacc
-    if hasattr(oe, 'rotationSequence') and abs(wave.cEacc[0]) > abs(wave.bEacc[0]):
-        carrier = wave.cEacc
-    unphase = np.exp(-1j * np.angle(carrier))
-    wave.a[:] = (wave.aEacc * unphase).real
-    wave.b[:] = (wave.bEacc * unphase).real
-    wave.c[:] = (wave.cEacc * unphase).real
-    length = (wave.a**2 + wave.b**2 + wave.c**2)**0.5
-    length[length == 0] = 1.
-    wave.a /= length
-    wave.b /= length
-    wave.c /= length
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
 
 
-def _scale_to_flux(wave, area):
-    """Monte-Carlo weight of the integral: receiving cell x illuminated area x
-    incoming flux over (samples x obliquity-weighted flux x repeats),
-    waves.py:735-749."""
-    scale = wave.dS * area * wave.beamReflSumJ
-    denom = wave.beamReflRays * wave.beamReflSumJnl * wave.diffract_repeats
-    scale = scale / denom if denom > 0 else 0
-    wave.Jss *= scale
-    wave.Jpp *= scale
-    wave.Jsp *= scale
-    wave.Es *= scale**0.5
-    wave.Ep *= scale**0.5
+def _sample_arrays(oe, field, dev):
+    """Inputs of the integral from the samples on the diffracting element (device):
+    -> (ten tensors sx, sy, sz, nx, ny, nz, nl, k, Es, Ep; flux, |flux . nl|, lit count)."""
+    n = field.nrays
+    f64 = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(8)]
+    c128 = [torch.empty(n, dtype=torch.complex128, device=dev) for _ in range(2)]
+    p, is_oe = _element_pass(oe)
+    ws = hipcalls.workspace(dev, 8192, 'diffract')
+    sums = (ctypes.c_double * 3)()
+    _lib.check(_lib.load().xrt_hip_diffract_pre_f64_dev(
+        ctypes.byref(p), is_oe, ctypes.byref(field.to_struct(dev)), *[_ptr(t) for t in f64],
+        *[_ptr(t) for t in c128], _ptr(ws), ws.numel(),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), sums),
+        'xrt_hip_diffract_pre_f64_dev')
+    return f64 + c128, sums[0], abs(sums[1]), int(sums[2])
 
 
-def _as_global_beam(oe, wave):
-    """Copy of *wave* positioned at the receiving points in the global frame
-    (waves.py:756-770)."""
-    glo = rs.Beam(copyFrom=wave)
+_WAVE_FIELDS = ('a', 'b', 'c', 'E', 'Jss', 'Jpp', 'Jsp', 'Es', 'Ep')
+
+
+def _as_global_beam(oe, wave, dev):
+    """The field on the receiving points as a beam in the global frame (waves.py:756-770):
+    a copy of *wave* positioned at the points (known in the frame of *oe*), taken out of
+    that frame on the GPU."""
+    glo = rs.Beam.empty_like_on_device(wave, dev)
+    for name, source in (('x', 'xDiffr'), ('y', 'yDiffr'), ('z', 'zDiffr'), ('path', 'path'),
+                         ('state', 'state')) + tuple((f, f) for f in _WAVE_FIELDS):
+        glo._d[name].copy_(wave.dev(source, dev))
+    rs.inherit_scalars(glo, wave)
     glo.parentId = oe.uuid
-    glo.x[:] = wave.xDiffr
-    glo.y[:] = wave.yDiffr
-    glo.z[:] = wave.zDiffr
-    if hasattr(oe, 'local_to_global'):
-        if hasattr(oe, 'expose'):            # a screen transforms bare arrays
-            glo.x[:], glo.y[:], glo.z[:] = oe.local_to_global(glo.x, glo.y, glo.z)
-        else:
-            oe.local_to_global(glo)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if hasattr(oe, 'rotationSequence'):
+        oe.local_to_global(glo)
+    elif hasattr(oe, 'local_to_global'):
+        # a screen moves bare points, an aperture whole rays (positions and directions)
+        frame = _structs.Screen()
+        for k in range(3):
+            frame.center[k], frame.ex[k], frame.ey[k], frame.ez[k] = (
+                float(oe.center[k]), float(oe.x[k]), float(oe.y[k]), float(oe.z[k]))
+        _lib.check(_lib.load().xrt_hip_basis_to_global_f64_dev(
+            ctypes.byref(frame), ctypes.byref(glo.to_struct(dev)),
+            0 if hasattr(oe, 'expose') else 1, stream), 'xrt_hip_basis_to_global_f64_dev')
     return glo
 
 
-def _into_receiver_frame(wave, glo):
-    """The receiving samples live on an element (``wave.toOE``): directions,
-    coherency matrix and amplitudes go from the global frame into its local
-    s/p frame, and the flux is projected on its surface (waves.py:773-824)."""
-    receiver = wave.toOE
-    wave.a[:], wave.b[:], wave.c[:] = glo.a, glo.b, glo.c
-    wave.Jss[:], wave.Jpp[:], wave.Jsp[:] = glo.Jss, glo.Jpp, glo.Jsp
-    wave.Es[:], wave.Ep[:] = glo.Es, glo.Ep
-    bl = receiver.bl
-    wave.a[:], wave.b[:] = raycing.rotate_z(wave.a, wave.b, bl.cosAzimuth,
-                                            bl.sinAzimuth)
-    if not hasattr(receiver, 'rotationSequence'):
-        return
-    if receiver.isParametric:
-        sp, phi, _ = receiver.xyz_to_param(wave.x, wave.y, wave.z)
-        normal = list(receiver.local_n(sp, phi))
-    else:
-        normal = list(receiver.local_n(wave.x, wave.y))
-    turn = receiver.roll + receiver.positionRoll + np.arctan2(normal[-3], normal[-1])
-    wave.Jss[:], wave.Jpp[:], wave.Jsp[:] = \
-        rs.rotate_coherency_matrix(wave, slice(None), -turn)
-    wave.Es[:], wave.Ep[:] = raycing.rotate_y(wave.Es, wave.Ep, np.cos(turn),
-                                              -np.sin(turn))
-    raycing.rotate_xyz(wave.a, wave.b, wave.c,
-                       rotationSequence=receiver.rotationSequence,
-                       pitch=-receiver.pitch,
-                       roll=-receiver.roll-receiver.positionRoll, yaw=-receiver.yaw)
-    if receiver.extraPitch or receiver.extraRoll or receiver.extraYaw:
-        raycing.rotate_xyz(wave.a, wave.b, wave.c,
-                           rotationSequence=receiver.extraRotationSequence,
-                           pitch=-receiver.extraPitch, roll=-receiver.extraRoll,
-                           yaw=-receiver.extraYaw)
-    obliquity = np.abs(-wave.a*normal[-3] - wave.b*normal[-2] - wave.c*normal[-1])
-    for beam in (wave, glo):
-        beam.Jss *= obliquity
-        beam.Jpp *= obliquity
-        beam.Jsp *= obliquity
-        beam.Es *= obliquity**0.5
-        beam.Ep *= obliquity**0.5
+def _forget_host(beam, names):
+    for name in names:
+        beam._h.pop(name, None)
 
 
 def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
@@ -307,38 +272,55 @@ def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
     points of *wave*, by the Fresnel-Kirchhoff integral on the GPU. *wave* is
     updated (it accumulates over repeated calls); returns the same field as a
     beam in the global frame. Interface of the reference's ``waves.diffract``
-    (waves.py:606-831)."""
+    (waves.py:606-831); every array stays in HBM between the steps."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     oe = wave.fromOE
     t0 = time.time()
-    lit = oeLocal.state == 1
-    nlit = lit.sum()
+    samples, flux, flux_nl, nlit = _sample_arrays(oe, oeLocal, dev)
     if nlit < 1e2:
         print("Not enough good rays at {0}: {1} of {2}".format(
-            oe.name, nlit, len(oeLocal.x)))
+            oe.name, nlit, oeLocal.nrays))
         return rs.Beam(nlit)
-    if len(wave.xDiffr) == 0:
+    if wave.nrays == 0 or 'xDiffr' not in wave.array_fields():
         print("No wave samples on {0}".format(oe.name))
         return rs.Beam(nlit)
-    oeLocal.area = _illuminated_area(oe, oeLocal, lit)
-    normal, cosine = _surface_normals(oe, oeLocal)
-    flux = oeLocal.Jss[lit] + oeLocal.Jpp[lit]
+    oeLocal.area = _illuminated_area(oe, oeLocal)
     wave.diffract_repeats += 1
     wave.beamReflRays += nlit
-    wave.beamReflSumJ += flux.sum()
-    wave.beamReflSumJnl += abs((flux * cosine[lit]).sum())
-    integrals = _kirchhoff_on_gpu(oeLocal, normal, cosine, wave, lit)
-    for name, part in zip(_ACCUMULATORS, integrals):
-        getattr(wave, name).__iadd__(part)
-    _fields_and_directions(oe, wave, oeLocal.E[0])
-    _scale_to_flux(wave, oeLocal.area)
+    wave.beamReflSumJ += flux
+    wave.beamReflSumJnl += flux_nl
+    points = [wave.dev(name, dev) for name in ('xDiffr', 'yDiffr', 'zDiffr')]
+    fresh = _kirchhoff_on_gpu(points, samples)
+    # Monte-Carlo weight of the integral: receiving cell x illuminated area x incoming flux
+    # over (samples x obliquity-weighted flux x repeats), waves.py:735-749
+    denom = wave.beamReflRays * wave.beamReflSumJnl * wave.diffract_repeats
+    scale = wave.dS * oeLocal.area * wave.beamReflSumJ / denom if denom > 0 else 0
+    acc = [wave.dev(name, dev) for name in _ACCUMULATORS]
+    pointers = ctypes.c_void_p * 5
+    _lib.check(lib.xrt_hip_wave_fields_f64_dev(
+        wave.nrays, pointers(*[t.data_ptr() for t in fresh]),
+        pointers(*[t.data_ptr() for t in acc]), _ptr(oeLocal.dev('E', dev)), float(scale),
+        1 if hasattr(oe, 'rotationSequence') else 0, ctypes.byref(wave.to_struct(dev)),
+        stream), 'xrt_hip_wave_fields_f64_dev')
+    _forget_host(wave, _WAVE_FIELDS + _ACCUMULATORS)
     if hasattr(oeLocal, 'accepted'):         # source bookkeeping for absolute flux
         wave.accepted = oeLocal.accepted
         wave.acceptedE = oeLocal.acceptedE
         wave.seeded = oeLocal.seeded
-        wave.seededI = oeLocal.seededI * len(wave.x) / len(oeLocal.x)
-    glo = _as_global_beam(oe, wave)
+        wave.seededI = oeLocal.seededI * wave.nrays / oeLocal.nrays
+    glo = _as_global_beam(oe, wave, dev)
     if hasattr(wave, 'toOE'):
-        _into_receiver_frame(wave, glo)
+        p, is_oe = _element_pass(wave.toOE)
+        if is_oe:        # the polarisation frame turns by roll + positionRoll
+            turn = wave.toOE.roll + wave.toOE.positionRoll
+            p.cos_roll, p.sin_roll = float(np.cos(turn)), float(np.sin(turn))
+        _lib.check(lib.xrt_hip_wave_receive_f64_dev(
+            ctypes.byref(p), is_oe, ctypes.byref(wave.to_struct(dev)),
+            ctypes.byref(glo.to_struct(dev)), stream), 'xrt_hip_wave_receive_f64_dev')
+        _forget_host(wave, _WAVE_FIELDS)
     if _DEBUG > 10:
         print("diffract on {0} completed in {1:.4f} s".format(
             oe.name, time.time()-t0))

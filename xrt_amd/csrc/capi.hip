@@ -500,6 +500,74 @@ int xrt_hip_local_to_global_f64_dev(const xrt_hip_pass* pass, xrt_hip_beam* beam
   return XRT_HIP_OK;
 }
 
+int xrt_hip_diffract_pre_f64_dev(const xrt_hip_pass* surface, int is_oe,
+                                 const xrt_hip_beam* samples, double* sx, double* sy,
+                                 double* sz, double* nx, double* ny, double* nz, double* nl,
+                                 double* k, double* Es_ri, double* Ep_ri, void* workspace,
+                                 size_t workspace_bytes, void* stream, double* sums_host) {
+  if (!surface || !samples || !sums_host) return fail(XRT_HIP_ERR_ARG, "NULL argument");
+  const int64_t n = samples->n;
+  int rc;
+  if ((rc = check_beam(samples, "samples", n, false))) return rc;
+  sums_host[0] = sums_host[1] = sums_host[2] = 0.;
+  if (n == 0) return XRT_HIP_OK;
+  if (!sx || !sy || !sz || !nx || !ny || !nz || !nl || !k || !Es_ri || !Ep_ri)
+    return fail(XRT_HIP_ERR_ARG, "NULL output array");
+  const size_t need = (size_t)DIFFRACT_PRE_MAX_BLOCKS * 3 * sizeof(double);
+  if (!workspace || workspace_bytes < need)
+    return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes, need);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int nblocks = 0;
+  HIP_TRY(xrt::diffract_pre_launch(*surface, is_oe, *samples, sx, sy, sz, nx, ny, nz, nl, k,
+                                   Es_ri, Ep_ri, reinterpret_cast<double*>(workspace),
+                                   &nblocks, st));
+  double part[DIFFRACT_PRE_MAX_BLOCKS * 3];
+  HIP_TRY(hipMemcpyAsync(part, workspace, (size_t)nblocks * 3 * sizeof(double),
+                         hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int b = 0; b < nblocks; ++b)        // in block order: the same sums every time
+    for (int j = 0; j < 3; ++j) sums_host[j] += part[3 * b + j];
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_wave_fields_f64_dev(int64_t n, double* const* fresh_ri, double* const* acc_ri,
+                                const double* energy0, double scale, int from_oe,
+                                xrt_hip_beam* wave, void* stream) {
+  if (n < 0 || !fresh_ri || !acc_ri || !wave) return fail(XRT_HIP_ERR_ARG, "bad argument");
+  int rc;
+  if ((rc = check_beam(wave, "wave", n, true))) return rc;
+  if (n == 0) return XRT_HIP_OK;
+  for (int j = 0; j < 5; ++j)
+    if (!fresh_ri[j] || !acc_ri[j]) return fail(XRT_HIP_ERR_ARG, "NULL integral array");
+  if (!energy0) return fail(XRT_HIP_ERR_ARG, "NULL energy");
+  HIP_TRY(xrt::wave_fields_launch(n, fresh_ri, acc_ri, energy0, scale, from_oe, *wave,
+                                  reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_basis_to_global_f64_dev(const xrt_hip_screen* frame, xrt_hip_beam* beam,
+                                    int with_directions, void* stream) {
+  if (!frame || !beam) return fail(XRT_HIP_ERR_ARG, "NULL frame / beam");
+  int rc;
+  if ((rc = check_beam(beam, "beam", beam->n, false))) return rc;
+  HIP_TRY(xrt::basis_to_global_launch(*frame, *beam, with_directions,
+                                      reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_wave_receive_f64_dev(const xrt_hip_pass* receiver, int is_oe, xrt_hip_beam* wave,
+                                 xrt_hip_beam* glo, void* stream) {
+  if (!receiver || !wave || !glo) return fail(XRT_HIP_ERR_ARG, "NULL argument");
+  int rc;
+  if ((rc = check_beam(wave, "wave", wave->n, true))) return rc;
+  if ((rc = check_beam(glo, "glo", wave->n, true))) return rc;
+  if (receiver->to_local.n < 0 || receiver->to_local.n > XRT_HIP_MAX_ROT)
+    return fail(XRT_HIP_ERR_ARG, "rotation sequence longer than %d", XRT_HIP_MAX_ROT);
+  HIP_TRY(xrt::wave_receive_launch(*receiver, is_oe, *wave, *glo,
+                                   reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
 static int check_material_tables(const xrt_hip_material* m) {
   if (!m) return fail(XRT_HIP_ERR_ARG, "NULL material");
   if (m->nelem < 1 || m->nelem > XRT_HIP_MAX_ELEM)

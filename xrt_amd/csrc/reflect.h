@@ -82,6 +82,19 @@ hipError_t surface_eval_launch(const xrt_hip_pass& P, int what, int64_t n, const
                                const double* v, const double* w, double* o, hipStream_t st);
 hipError_t beam_to_global_launch(const xrt_hip_pass& P, const xrt_hip_beam& b, hipStream_t st);
 
+#define DIFFRACT_PRE_MAX_BLOCKS 256
+hipError_t diffract_pre_launch(const xrt_hip_pass& P, int is_oe, const xrt_hip_beam& s,
+                               double* sx, double* sy, double* sz, double* nx, double* ny,
+                               double* nz, double* nl, double* k, double* Es, double* Ep,
+                               double* part, int* nblocks, hipStream_t st);
+hipError_t wave_fields_launch(int64_t n, double* const* fresh, double* const* acc,
+                              const double* energy0, double scale, int from_oe,
+                              const xrt_hip_beam& w, hipStream_t st);
+hipError_t basis_to_global_launch(const xrt_hip_screen& F, const xrt_hip_beam& b,
+                                  int with_directions, hipStream_t st);
+hipError_t wave_receive_launch(const xrt_hip_pass& P, int is_oe, const xrt_hip_beam& w,
+                               const xrt_hip_beam& g, hipStream_t st);
+
 hipError_t material_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
                                      const double* bdn, double* rs, double* rp, double* mu,
                                      double* nk, hipStream_t st);

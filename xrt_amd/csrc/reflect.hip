@@ -2819,6 +2819,260 @@ hipError_t beam_to_global_launch(const xrt_hip_pass& P, const xrt_hip_beam& b,
 }
 
 // ---------------------------------------------------------------------------
+// waves.diffract around the Kirchhoff integral (waves.py:606-831), on the device. The
+// O(Ns Np) integral is csrc/kirchhoff.hip; these O(N) kernels keep its inputs and
+// outputs in HBM, so that a chain of diffractions does not bounce every array through
+// the host between its steps.
+// ---------------------------------------------------------------------------
+
+// Before the integral: what the samples on the diffracting element contribute.
+//   normal (the surface's at the sample; (0, 1, 0) for apertures, screens, sources),
+//   nl = direction . normal, k = E / CHBAR 1e7 (waves.py:674-689, :841), and the field
+//   with every sample that is not in state 1 switched off (Es = Ep = 0: it then adds
+//   exact zeros to the sums, which spares compacting the arrays);
+//   per block: sum of Jss + Jpp and of (Jss + Jpp) nl over the lit samples, their count
+//   (part[3 b .. 3 b + 2]; the host adds the blocks up in order).
+__global__ __launch_bounds__(REFLECT_BLOCK) void diffract_pre_kernel(
+    xrt_hip_pass P, int is_oe, xrt_hip_beam s, double* __restrict__ sx,
+    double* __restrict__ sy, double* __restrict__ sz, double* __restrict__ nx,
+    double* __restrict__ ny, double* __restrict__ nz, double* __restrict__ nl,
+    double* __restrict__ k, double2* __restrict__ Es, double2* __restrict__ Ep,
+    double* __restrict__ part) {
+  using K = Generic1;
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  double sumJ = 0., sumJn = 0., cnt = 0.;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.n; i += stride) {
+    const bool lit = s.state[i] == 1;
+    double x = s.x[i], y = s.y[i], z = s.z[i];
+    if (!lit && !(isfinite(x) && isfinite(y) && isfinite(z))) x = y = z = 0.;
+    double n3[3] = {0., 1., 0.};
+    if (is_oe) {
+      double px = x, py = y;
+      if (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM) {
+        double rr;
+        ell_xyz_to_param(P, x, y, z, px, py, rr);
+      }
+      double nn[6];
+      surface_normal<K>(P, x, y, px, py, nn);
+      n3[0] = nn[3];
+      n3[1] = nn[4];
+      n3[2] = nn[5];
+    }
+    const double cosine = s.a[i] * n3[0] + s.b[i] * n3[1] + s.c[i] * n3[2];
+    sx[i] = x;
+    sy[i] = y;
+    sz[i] = z;
+    nx[i] = n3[0];
+    ny[i] = n3[1];
+    nz[i] = n3[2];
+    nl[i] = cosine;
+    k[i] = s.E[i] / kCHBAR * 1e7;
+    double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+    if (lit) {
+      if (s.Es_ri) {
+        es = reinterpret_cast<const double2*>(s.Es_ri)[i];
+        ep = reinterpret_cast<const double2*>(s.Ep_ri)[i];
+      }
+      const double flux = s.Jss[i] + s.Jpp[i];
+      sumJ += flux;
+      sumJn += flux * cosine;
+      cnt += 1.;
+    }
+    Es[i] = es;
+    Ep[i] = ep;
+  }
+  auto faddd = [](double u, double v) { return u + v; };
+  sumJ = block_reduce(sumJ, faddd, lds_d);
+  sumJn = block_reduce(sumJn, faddd, lds_d);
+  cnt = block_reduce(cnt, faddd, lds_d);
+  if (threadIdx.x == 0) {
+    part[3 * blockIdx.x] = sumJ;
+    part[3 * blockIdx.x + 1] = sumJn;
+    part[3 * blockIdx.x + 2] = cnt;
+  }
+}
+
+// After the integral (waves.py:707-749): the new integrals are added to the wave's
+// accumulators, and from those come the amplitudes, the coherency matrix and the
+// propagation direction -- the three direction integrals share one arbitrary phase,
+// removed with the dominant one's (c if the diffracting element is an optical element
+// and |c| > |b| at sample 0, else b) --, everything scaled to flux.
+__global__ __launch_bounds__(REFLECT_BLOCK) void wave_fields_kernel(
+    int64_t n, const double2* __restrict__ nS, const double2* __restrict__ nP,
+    const double2* __restrict__ nA, const double2* __restrict__ nB,
+    const double2* __restrict__ nC, double2* __restrict__ aS, double2* __restrict__ aP,
+    double2* __restrict__ aA, double2* __restrict__ aB, double2* __restrict__ aC,
+    const double* __restrict__ energy0, double scale, int from_oe, xrt_hip_beam w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto add = [](double2 u, double2 v) { return make_double2(u.x + v.x, u.y + v.y); };
+  // (every lane forms sample 0's sums itself: no ordering against the lane that stores them)
+  const double2 b0 = add(aB[0], nB[0]), c0 = add(aC[0], nC[0]);
+  const bool use_c = from_oe && fhypot(c0.x, c0.y) > fhypot(b0.x, b0.y);
+  const double2 S = add(aS[i], nS[i]), Pp = add(aP[i], nP[i]);
+  const double2 A = add(aA[i], nA[i]), B = add(aB[i], nB[i]), Cc = add(aC[i], nC[i]);
+  aS[i] = S;
+  aP[i] = Pp;
+  aA[i] = A;
+  aB[i] = B;
+  aC[i] = Cc;
+  const double2 car = use_c ? Cc : B;
+  const double mag = fhypot(car.x, car.y);
+  const double ur = mag > 0. ? car.x / mag : 1., ui = mag > 0. ? -car.y / mag : 0.;
+  double a = A.x * ur - A.y * ui, b = B.x * ur - B.y * ui, c = Cc.x * ur - Cc.y * ui;
+  double len = sqrt(a * a + b * b + c * c);
+  if (len == 0.) len = 1.;
+  w.a[i] = a / len;
+  w.b[i] = b / len;
+  w.c[i] = c / len;
+  w.E[i] = energy0[0];
+  const double rs = sqrt(scale);
+  w.Jss[i] = (S.x * S.x + S.y * S.y) * scale;
+  w.Jpp[i] = (Pp.x * Pp.x + Pp.y * Pp.y) * scale;
+  reinterpret_cast<double2*>(w.Jsp_ri)[i] =
+      make_double2((S.x * Pp.x + S.y * Pp.y) * scale, (S.y * Pp.x - S.x * Pp.y) * scale);
+  reinterpret_cast<double2*>(w.Es_ri)[i] = make_double2(S.x * rs, S.y * rs);
+  reinterpret_cast<double2*>(w.Ep_ri)[i] = make_double2(Pp.x * rs, Pp.y * rs);
+}
+
+// Positions (and directions) of a beam from a frame given by three basis vectors and an
+// origin (screens, apertures) to the global one, in place.
+__global__ __launch_bounds__(REFLECT_BLOCK) void basis_to_global_kernel(
+    xrt_hip_screen F, xrt_hip_beam b, int with_directions) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b.n) return;
+  const double x = b.x[i], y = b.y[i], z = b.z[i];
+  b.x[i] = F.center[0] + x * F.ex[0] + y * F.ey[0] + z * F.ez[0];
+  b.y[i] = F.center[1] + x * F.ex[1] + y * F.ey[1] + z * F.ez[1];
+  b.z[i] = F.center[2] + x * F.ex[2] + y * F.ey[2] + z * F.ez[2];
+  if (with_directions) {
+    const double a = b.a[i], bb = b.b[i], c = b.c[i];
+    b.a[i] = a * F.ex[0] + bb * F.ey[0] + c * F.ez[0];
+    b.b[i] = a * F.ex[1] + bb * F.ey[1] + c * F.ez[1];
+    b.c[i] = a * F.ex[2] + bb * F.ey[2] + c * F.ez[2];
+  }
+}
+
+// The receiving samples live on an element (waves.py:773-824): the diffracted field,
+// known in the global frame (glo), goes into the element's local s/p frame -- directions
+// through the azimuth and the element's rotations, coherency matrix and amplitudes turned
+// by -(roll + atan2(n_x, n_z)) -- and the flux is projected on the surface (obliquity, also
+// applied to glo). A receiver that is no optical element (screen, aperture) only has the
+// azimuth taken out of the directions.
+__global__ __launch_bounds__(REFLECT_BLOCK) void wave_receive_kernel(xrt_hip_pass P, int is_oe,
+                                                                     xrt_hip_beam w,
+                                                                     xrt_hip_beam g) {
+  using K = Generic1;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w.n) return;
+  double a = g.a[i], b = g.b[i], c = g.c[i];
+  double Jss = g.Jss[i], Jpp = g.Jpp[i];
+  double2 js = reinterpret_cast<const double2*>(g.Jsp_ri)[i];
+  const double2 es0 = reinterpret_cast<const double2*>(g.Es_ri)[i];
+  const double2 ep0 = reinterpret_cast<const double2*>(g.Ep_ri)[i];
+  cplx Es = C(es0.x, es0.y), Ep = C(ep0.x, ep0.y);
+  {
+    const double an = P.cos_az * a - P.sin_az * b, bn = P.sin_az * a + P.cos_az * b;
+    a = an;
+    b = bn;
+  }
+  if (is_oe) {
+    const double x = w.x[i], y = w.y[i], z = w.z[i];
+    double px = x, py = y;
+    if (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM) {
+      double rr;
+      ell_xyz_to_param(P, x, y, z, px, py, rr);
+    }
+    double nn[6];
+    surface_normal<K>(P, x, y, px, py, nn);
+    double cosY = P.cos_roll, sinY = P.sin_roll;
+    if (nn[3] != 0.) {
+      const double ih = frcp(fhypot(nn[3], nn[5]));
+      const double cphi = nn[5] * ih, sphi = nn[3] * ih;
+      cosY = P.cos_roll * cphi - P.sin_roll * sphi;
+      sinY = P.sin_roll * cphi + P.cos_roll * sphi;
+    } else if (nn[5] < 0.) {
+      cosY = -P.cos_roll;
+      sinY = -P.sin_roll;
+    }
+    rot_coherency(cosY, -sinY, Jss, Jpp, js.x, js.y);
+    const cplx e1 = Es * cosY + Ep * (-sinY);
+    const cplx e2 = Es * sinY + Ep * cosY;
+    Es = e1;
+    Ep = e2;
+    rotate3(P.to_local, a, b, c);
+    const double obl = fabs(-a * nn[3] - b * nn[4] - c * nn[5]);
+    const double ro = sqrt(obl);
+    Jss *= obl;
+    Jpp *= obl;
+    js.x *= obl;
+    js.y *= obl;
+    Es = Es * ro;
+    Ep = Ep * ro;
+    g.Jss[i] *= obl;
+    g.Jpp[i] *= obl;
+    double2 gj = reinterpret_cast<double2*>(g.Jsp_ri)[i];
+    reinterpret_cast<double2*>(g.Jsp_ri)[i] = make_double2(gj.x * obl, gj.y * obl);
+    reinterpret_cast<double2*>(g.Es_ri)[i] = make_double2(es0.x * ro, es0.y * ro);
+    reinterpret_cast<double2*>(g.Ep_ri)[i] = make_double2(ep0.x * ro, ep0.y * ro);
+  }
+  w.a[i] = a;
+  w.b[i] = b;
+  w.c[i] = c;
+  w.Jss[i] = Jss;
+  w.Jpp[i] = Jpp;
+  reinterpret_cast<double2*>(w.Jsp_ri)[i] = js;
+  reinterpret_cast<double2*>(w.Es_ri)[i] = make_double2(Es.re, Es.im);
+  reinterpret_cast<double2*>(w.Ep_ri)[i] = make_double2(Ep.re, Ep.im);
+}
+
+#define DIFFRACT_PRE_BLOCKS 256
+hipError_t diffract_pre_launch(const xrt_hip_pass& P, int is_oe, const xrt_hip_beam& s,
+                               double* sx, double* sy, double* sz, double* nx, double* ny,
+                               double* nz, double* nl, double* k, double* Es, double* Ep,
+                               double* part, int* nblocks, hipStream_t st) {
+  int64_t b = (s.n + REFLECT_BLOCK - 1) / REFLECT_BLOCK;
+  if (b > DIFFRACT_PRE_BLOCKS) b = DIFFRACT_PRE_BLOCKS;
+  if (b < 1) b = 1;
+  *nblocks = (int)b;
+  hipLaunchKernelGGL(diffract_pre_kernel, dim3((unsigned)b), dim3(REFLECT_BLOCK), 0, st, P,
+                     is_oe, s, sx, sy, sz, nx, ny, nz, nl, k, reinterpret_cast<double2*>(Es),
+                     reinterpret_cast<double2*>(Ep), part);
+  return hipGetLastError();
+}
+
+hipError_t wave_fields_launch(int64_t n, double* const* fresh, double* const* acc,
+                              const double* energy0, double scale, int from_oe,
+                              const xrt_hip_beam& w, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  auto c2 = [](double* p) { return reinterpret_cast<double2*>(p); };
+  hipLaunchKernelGGL(wave_fields_kernel, dim3((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)),
+                     dim3(REFLECT_BLOCK), 0, st, n, c2(fresh[0]), c2(fresh[1]), c2(fresh[2]),
+                     c2(fresh[3]), c2(fresh[4]), c2(acc[0]), c2(acc[1]), c2(acc[2]), c2(acc[3]),
+                     c2(acc[4]), energy0, scale, from_oe, w);
+  return hipGetLastError();
+}
+
+hipError_t basis_to_global_launch(const xrt_hip_screen& F, const xrt_hip_beam& b,
+                                  int with_directions, hipStream_t st) {
+  if (b.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(basis_to_global_kernel,
+                     dim3((unsigned)((b.n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)),
+                     dim3(REFLECT_BLOCK), 0, st, F, b, with_directions);
+  return hipGetLastError();
+}
+
+hipError_t wave_receive_launch(const xrt_hip_pass& P, int is_oe, const xrt_hip_beam& w,
+                               const xrt_hip_beam& g, hipStream_t st) {
+  if (w.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(wave_receive_kernel,
+                     dim3((unsigned)((w.n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)),
+                     dim3(REFLECT_BLOCK), 0, st, P, is_oe, w, g);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // stand-alone amplitude kernels (Material.get_amplitude / Crystal.get_amplitude)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(REFLECT_BLOCK) void material_amplitude_kernel(
