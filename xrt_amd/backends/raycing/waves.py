@@ -128,12 +128,34 @@ def _extremes(px, py, keys):
 
 def convex_hull_area(px, py):
     """Area of the convex hull of 2-D points (Andrew's monotone chain; the reference
-    takes it from scipy.spatial.ConvexHull, waves.py:661-668). Two rounds of the
-    Akl-Toussaint filter come first -- the octagon of the 8 axis / diagonal extremes over
-    all points, then the polygon of the extremes in 64 directions over the survivors --,
-    so that the Python loop of the chain only sees a handful of points."""
+    takes it from scipy.spatial.ConvexHull, waves.py:661-668). Points that cannot be hull
+    vertices are filtered out first -- a box inside a subsample's octagon, then the
+    Akl-Toussaint octagon of the 8 axis / diagonal extremes, then the polygon of the extremes
+    in 64 directions --, so that the Python loop of the chain only sees a handful of
+    points."""
     px = np.asarray(px, dtype=float)
     py = np.asarray(py, dtype=float)
+    if len(px) > 4096:
+        # round 0: an axis-parallel box inside the octagon of a 1/16 subsample's extremes --
+        # four comparisons per point throw out the bulk before any polygon test
+        qx, qy = px[::16], py[::16]
+        ext = _extremes(qx, qy, (qx, qx + qy, qy, qy - qx, -qx, -qx - qy, -qy, qx - qy))
+        if len(ext) >= 3:
+            cx, cy = np.mean([e[0] for e in ext]), np.mean([e[1] for e in ext])
+            wx = max(abs(e[0] - cx) for e in ext)
+            wy = max(abs(e[1] - cy) for e in ext)
+            t = 1.
+            for _ in range(12):      # shrink until the four corners lie inside the octagon
+                bx = np.array([cx - t*wx, cx + t*wx, cx + t*wx, cx - t*wx])
+                by = np.array([cy - t*wy, cy - t*wy, cy + t*wy, cy + t*wy])
+                if not _outside_polygon(bx, by, ext).any():
+                    break
+                t *= 0.8
+            else:
+                t = 0.
+            if t > 0.:
+                keep = (np.abs(px - cx) >= t*wx) | (np.abs(py - cy) >= t*wy)
+                px, py = px[keep], py[keep]
     if len(px) > 64:
         ext = _extremes(px, py, (px, px + py, py, py - px, -px, -px - py, -py, px - py))
         if len(ext) >= 3:
