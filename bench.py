@@ -403,6 +403,18 @@ def bench_undulator(with_cpu=True):
     res = dict(metric='undulator field map, ray-nodes/s (far field, fused '
                       'build_I_map)', rays=n, nodes=nodes, ms=ms,
                value=n * nodes / ms * 1e3, unit='ray-nodes/s', dtype='f64')
+    # Static count from the gfx950 ISA of und_imap<0>'s node loop: 37 mul +
+    # 23 add + 13 fma = 86 flop in 81 VALU instructions (one of them v_rcp_f64, a
+    # quarter-rate instruction: 84 issue slots); -ffp-contract=off keeps the reference's
+    # roundings, so most slots carry one flop, not two.
+    flop, slots = 86, 84
+    tf = flop * n * nodes / ms * 1e3 / 1e12
+    res['roofline'] = dict(
+        bound='valu_fp64', kernel='und_imap', achieved=tf, peak=78.6, unit='TFLOP/s',
+        frac=tf / 78.6, traffic=None,
+        note='%d flop / %d VALU issue slots per ray-node; issue-slot use = %.2f of the '
+             '3.93e13 lane-slots/s of 256 CUs x 4 SIMDs at 2.4 GHz; 64 B of HBM traffic '
+             'per ray' % (flop, slots, slots * n * nodes / ms * 1e3 / 3.93e13))
     if with_cpu:
         from oracle import undulator_np as un
         m = 100_000

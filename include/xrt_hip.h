@@ -139,6 +139,9 @@ typedef struct xrt_hip_rotation {
 #define XRT_HIP_SURF_ELLIPSE_PARAM 4  /* Elliptical / Parabolical / HyperbolicMirrorParam,
                                      oes/parametric.py:9-716: parametric (s, phi, r) root
                                      solve, base.py:822-841; surf_p[8] selects the conic */
+#define XRT_HIP_SURF_PARABOLOID 5  /* refractive lenses, oes/refractive.py:394-419, 613-617:
+                                     z = (x^2 + y^2) / (4 focus), cut off at zmax; a parabolic
+                                     cylinder takes x = 0 */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_SHAPE_POLYGON 2   /* optical surface outlined by a polygon in the local (x, y)
@@ -175,7 +178,9 @@ typedef struct xrt_hip_pass {
                                   cosGamma, sinGamma, A, B, isCylindrical, isClosed, conic
                                   (0 ellipse: A, B = ellipseA, ellipseB, parametric.py:143-157;
                                   1 parabola: A = parabParam, :411-425; 2 hyperbola: A, B =
-                                  hyperbolaA, hyperbolaB, :611-622) */
+                                  hyperbolaA, hyperbolaB, :611-622);
+                                  paraboloid: 4 focus, 2 focus, zmax, 1 = zmax given,
+                                  1 = parabolic cylinder */
   double n_const[6];           /* flat: [nH(3), n_surface(3)] (base.py:719-742) */
   int32_t asymmetric;          /* 1: n_const holds two different normals */
   /* limits, base.py:1094-1163 */
@@ -211,6 +216,11 @@ typedef struct xrt_hip_pass {
    * x1, y1, ...), implicitly closed */
   int32_t poly_n;
   const double* poly_xy;
+  /* a sequence of diffraction orders, one drawn per hit ray (reflect.py:455-456):
+   * DEVICE array of n int32, the order of ray i at order_ray[i]; NULL = grating_order
+   * for every ray. The draw itself (numpy's generator, over the rays that end in state 1)
+   * stays with the caller, see xrt_amd/backends/raycing/oes.py:OE._with_ray_orders. */
+  const int32_t* order_ray;
 } xrt_hip_pass;
 
 #define XRT_HIP_MAT_NONE 0

@@ -66,7 +66,8 @@ def load_case(name):
         p['surface'] = dict(kind='flat')
         p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
                                          'grating', float(g['mat_rho']))
-        p['order'] = int(g['order'])
+        p['order'] = int(g['order']) if g['order'].ndim == 0 else \
+            tuple(int(o) for o in g['order'])
         if 'gd_axis' in g.files:
             p['gratingDensity'] = [str(g['gd_axis'])] + \
                 [float(v) for v in g['gd_coeffs']]
@@ -103,6 +104,18 @@ def load_case(name):
                   f1=np.array(g['Be_f1']), f2=np.array(g['Be_f2']))
         p['material'] = mn.make_material([be], None, 'plate', float(g['mat_rho']))
         p['material2'] = p['material']
+    elif name.startswith('g2_lens'):
+        zmax = None if np.isnan(g['lens_zmax']) else float(g['lens_zmax'])
+        kind = str(g['lens_class'])
+        p['surface'] = p['surface2'] = dict(kind='paraboloid', focus=float(g['lens_focus']),
+                                            zmax=zmax, cylinder='Cylinder' in kind)
+        be = dict(name='Be', Z=int(g['Be_Z']), mass=float(g['Be_mass']),
+                  f0coeffs=np.array(g['Be_f0']), E=np.array(g['Be_E']),
+                  f1=np.array(g['Be_f1']), f2=np.array(g['Be_f2']))
+        p['material'] = p['material2'] = mn.make_material([be], None, 'lens',
+                                                          float(g['mat_rho']))
+        p.update(nCRL=int(g['lens_nCRL']), zmax=zmax, t=float(g['lens_t']),
+                 double_sided=kind.startswith('Double'))
     elif name.startswith('g3_dcm'):
         alpha = float(g['alpha'])
         p['surface'] = dict(kind='flat', alpha=alpha)

@@ -160,11 +160,20 @@ def run_reflect(tag, rs, oe, params, beam, brent_expected=None, **extra):
         return orig(local_f, t1, t2, *a, **k)
     oe.find_intersection = find_spy
     verb = raycing._VERBOSITY_
+    seed = extra.pop('np_seed', None)
+    if seed is not None:            # elements that draw from numpy's global generator
+        np.random.seed(seed)
     gb, lb = oe.reflect(beam)
     raycing._VERBOSITY_ = verb
     oe.find_intersection = orig
     info = {}
+    if seed is not None:
+        np.random.seed(seed)
+        extra['np_seed'] = np.array(seed)
+        extra['lb_order'] = np.array(lb.order)
     mgb, mlb = rn.oe_reflect(params, to_oracle_beam(beam), info=info)
+    if seed is not None:
+        assert np.array_equal(mlb.order, lb.order)
     assert_beams(tag + ':gb', mgb, gb)
     assert_beams(tag + ':lb', mlb, lb)
     assert np.allclose(mlb.theta, lb.theta, rtol=0, atol=1e-15)

@@ -21,6 +21,8 @@ tests/speed/3_Softi_CXIw2D_speed.py:176-246):
                         density polynomial along y, order -1, as a PGM grating
   g2_grating_const.npz  a subclass with a constant local_g (the SoftiMAX
                         example's `Grating`), order +1, lines along x
+  g2_grating_orders.npz a sequence of orders (1, -1, 2, 0): one per hit ray from
+                        numpy's global generator (reflect.py:455-458), seeded
 
 While generating, oracle/reflect_np.py is asserted against the reference.
 
@@ -93,7 +95,9 @@ def main():
     for tag, kw, order in (
             ('g2_grating_vls',
              dict(gratingDensity=['y', 300., 1., 2.4e-4, -3.1e-8]), -1),
-            ('g2_grating_const', dict(), 1)):
+            ('g2_grating_const', dict(), 1),
+            ('g2_grating_orders', dict(gratingDensity=['y', 300., 1., 2.4e-4]),
+             (1, -1, 2, 0))):
         bl = raycing.BeamLine()
         if kw:
             cls = roe.OE
@@ -105,7 +109,8 @@ def main():
         gr = cls(bl, 'gr', center=[0, 2000., 0.], pitch=np.radians(2.2),
                  material=mAuG, order=order, limPhysX=(-3, 3), limPhysY=(-45, 45),
                  alarmLevel=None, **kw)
-        beam = make_rays(rs, n, 64 if kw else 65, sx=1.0, sz=0.9, sa=3e-5,
+        several = isinstance(order, tuple)      # one order per hit ray, drawn at random
+        beam = make_rays(rs, n, (66 if several else 64) if kw else 65, sx=1.0, sz=0.9, sa=3e-5,
                          sc=2e-5, E=(270., 290.), amplitudes=True, pol='mixed')
         beam.state[3] = 3
         beam.state[4] = -4
@@ -117,6 +122,8 @@ def main():
         else:
             par['gVector'] = (120., 0, 0)
         extra = dict(mat_rho=np.array(19.32), order=np.array(order))
+        if several:
+            extra['np_seed'] = 20260928
         if kw:
             extra['gd_axis'] = np.array(kw['gratingDensity'][0])
             extra['gd_coeffs'] = np.array(kw['gratingDensity'][1:], dtype=float)

@@ -12,7 +12,7 @@ Follows, expression by expression (same operation order, so that ``r`` and
                              (accumulate, phase strip, normalise, flux norm).
 
 Parity pinned: tests/golden/g4_*.npz hold inputs and outputs produced by the
-imported reference (oracle/gen_fixtures.py); tests/test_oracle_golden.py checks
+imported reference (oracle/gen_fixtures_p2.py); tests/test_oracle_p2_golden.py checks
 this module against them.
 """
 import numpy as np

@@ -211,6 +211,13 @@ def local_z(surf, x, y):
         y0, y1, yC, yL = blazed_pre(surf, y)
         return np.where(yL > yC, -(y1-y) * surf['tanBlaze'],
                         -yL * surf['tanAntiblaze'])
+    if surf['kind'] == 'paraboloid':              # oes/refractive.py:394-399, 613-614
+        if surf['cylinder']:
+            x = 0
+        z = (x**2 + y**2) / (4 * surf['focus'])
+        if surf['zmax'] is not None:
+            z[z > surf['zmax']] = surf['zmax']
+        return z
     raise ValueError(surf['kind'])
 
 
@@ -345,6 +352,20 @@ def local_n(surf, x, y):
         return [np.zeros_like(x),
                 np.where(yL > yC, -surf['sinBlaze'], surf['sinAntiblaze']),
                 np.where(yL > yC, surf['cosBlaze'], surf['cosAntiblaze'])]
+    if surf['kind'] == 'paraboloid':              # oes/refractive.py:405-419, 616-617
+        if surf['cylinder']:
+            x = 0
+        a = -x / (2*surf['focus'])  # -dz/dx
+        b = -y / (2*surf['focus'])  # -dz/dy
+        if surf['zmax'] is not None:
+            z = (x**2 + y**2) / (4*surf['focus'])
+            if isinstance(a, np.ndarray):
+                a[z > surf['zmax']] = 0
+            if isinstance(b, np.ndarray):
+                b[z > surf['zmax']] = 0
+        c = np.ones_like(x)
+        norm = (a**2 + b**2 + 1)**0.5
+        return [a/norm, b/norm, c/norm]
     if surf['kind'] in PARAM_KINDS:   # parametric.py:233-247, 460-472, 698-713
         s, phi = x, y
         sign = -1.
@@ -685,10 +706,17 @@ def local_g(oe, x, y):
     return oe.get('gVector', (0, -100., 0))
 
 
-def grating_deflection(a, b, c, E, g, oeNormal, beamInDotNormal, order, sig):
+def grating_deflection(a, b, c, E, g, oeNormal, beamInDotNormal, order, sig,
+                       drawn=None):
+    """reflect.py:451-469. A sequence *order*: one per hit ray from numpy's GLOBAL
+    generator, as the reference draws it (:455-456); the draw goes to drawn[0]."""
     beamInDotG = a*g[0] + b*g[1] + c*g[2]
     G2 = g[0]**2 + g[1]**2 + g[2]**2
-    orderLambda = order * CH / E * 1e-7
+    locOrder = order if isinstance(order, (int, np.integer)) else \
+        np.array(order)[np.random.randint(len(order), size=len(a))]
+    if drawn is not None:
+        drawn.append(locOrder)
+    orderLambda = locOrder * CH / E * 1e-7
     u = beamInDotNormal**2 - 2*beamInDotG*orderLambda - G2*orderLambda**2
     gs = np.sign(beamInDotNormal) if sig is None else sig
     dn = beamInDotNormal + gs*np.sqrt(abs(u))
@@ -820,9 +848,12 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
             if is_param(surf):
                 raise ValueError('gratings on parametric surfaces not restated')
             g = local_g(oe, lb.x[goodN], lb.y[goodN])
+            drawn = []
             lb.a[goodN], lb.b[goodN], lb.c[goodN] = grating_deflection(
                 lb.a[goodN], lb.b[goodN], lb.c[goodN], lb.E[goodN], g, oeNormal,
-                beamInDotSurfaceNormal, oe.get('order', 1), -1)
+                beamInDotSurfaceNormal, oe.get('order', 1), -1, drawn)
+            lb.order = np.zeros(len(lb.a))               # :457-458
+            lb.order[goodN] = drawn[0]
         elif toWhere in (0, 2):
             if kind == 'crystal' and toWhere == 0:
                 a_out, b_out, c_out = asymmetric_reflection_grating(
@@ -1001,3 +1032,51 @@ def dcm_double_reflect(oe, beam, fromVacuum1=True, fromVacuum2=True,
         info['crystal1'] = i1
         info['crystal2'] = i2
     return gb2, lo1, lo2
+
+
+def rotate_point(point, rotationSequence='RzRyRx', pitch=0, roll=0, yaw=0):
+    """_rotate.py:87-108."""
+    angles = {'z': yaw, 'y': roll, 'x': pitch}
+    rotates = {'z': rotate_z, 'y': rotate_y, 'x': rotate_x}
+    ind1 = {'z': 0, 'y': 0, 'x': 1}
+    ind2 = {'z': 1, 'y': 2, 'x': 2}
+    newp = [coord for coord in point]
+    if rotationSequence[0] == '-':
+        seq = rotationSequence[6] + rotationSequence[4] + rotationSequence[2]
+    else:
+        seq = rotationSequence[1] + rotationSequence[3] + rotationSequence[5]
+    for s in seq:
+        angle, rotate = angles[s], rotates[s]
+        if angle != 0:
+            cA = np.cos(angle)
+            sA = np.sin(angle)
+            newp[ind1[s]], newp[ind2[s]] = rotate(
+                newp[ind1[s]], newp[ind2[s]], cA, sA)
+    return newp
+
+
+def lens_multiple_refract(oe, beam):
+    """ParaboloidFlatLens.multiple_refract (oes/refractive.py:457-519): nCRL
+    double_refract passes, the centre of the stack moved by `step` along the rotated
+    local z between them; -> (global beam behind the last lenslet, the two local beams
+    of the FIRST lenslet). oe: the DCM/Plate dictionary + nCRL, zmax, t, double_sided."""
+    if oe['nCRL'] == 1:
+        return dcm_double_reflect(oe, beam, True, False, is_plate=True)
+    oe = dict(oe)
+    oe['center'] = [c for c in oe['center']]
+    beamIn = beam
+    zmax = 5 if oe['zmax'] is None else oe['zmax']
+    step = 2.*zmax + oe['t'] if oe['double_sided'] else zmax + oe['t']
+    for ilens in range(oe['nCRL']):
+        lglobal, tlocal1, tlocal2 = dcm_double_reflect(oe, beamIn, True, False,
+                                                       is_plate=True)
+        if oe['zmax'] is not None:
+            toward = rotate_point([0, 0, 1], oe['rotationSequence'], oe['pitch'],
+                                  oe['roll']+oe['positionRoll'], oe['yaw'])
+            oe['center'][0] -= step * toward[0]
+            oe['center'][1] -= step * toward[1]
+            oe['center'][2] -= step * toward[2]
+        beamIn = lglobal
+        if ilens == 0:
+            llocal1, llocal2 = tlocal1, tlocal2
+    return lglobal, llocal1, llocal2

@@ -89,7 +89,9 @@ def product_oe(name, g):
     elif name.startswith('g2_grating'):
         m = rm.Material('Au', rho=float(g['mat_rho']), kind='grating')
         if 'gd_axis' in g.files:
-            oe = roe.OE(bl, 'gr', material=m, order=int(g['order']),
+            oe = roe.OE(bl, 'gr', material=m,
+                        order=int(g['order']) if g['order'].ndim == 0 else
+                        [int(o) for o in g['order']],
                         gratingDensity=[str(g['gd_axis'])] +
                         [float(v) for v in g['gd_coeffs']], **common)
         else:
@@ -128,6 +130,12 @@ def product_oe(name, g):
     elif name == 'g2_plate_be':
         m = rm.Material('Be', rho=float(g['mat_rho']), kind='plate')
         oe = roe.Plate(bl, 'win', material=m, t=float(g['plate_t']), **common)
+    elif name.startswith('g2_lens'):
+        m = rm.Material('Be', rho=float(g['mat_rho']), kind='lens')
+        zmax = None if np.isnan(g['lens_zmax']) else float(g['lens_zmax'])
+        oe = getattr(roe, str(g['lens_class']))(
+            bl, 'crl', material=m, t=float(g['lens_t']), focus=float(g['lens_focus']),
+            zmax=zmax, nCRL=int(g['lens_nCRL']), **common)
     elif name.startswith('g3_dcm'):
         alpha = float(g['alpha'])
         si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)

@@ -206,3 +206,48 @@ def test_two_plots_of_one_beam_with_and_without_beam_state():
     assert np.abs(plots[1].total2D - ref_own).max() <= 1e-10 * ref_own.max()
     assert np.abs(plots[0].total2D - ref_m1).max() <= 1e-10 * ref_m1.max()
     assert np.abs(plots[2].total2D - ref_m1).max() <= 1e-10 * ref_m1.max()
+
+
+def test_two_threads_on_their_own_streams_equal_the_serial_run():
+    """Thread safety of the host layer (error slot, armed events and the scratch-buffer
+    cache are per thread / per stream): two Python threads trace different beams through
+    their own elements at the same time, each on its own HIP stream; every array equals
+    what the same work gives serially. (np.random is process-global, so the source
+    beams are drawn before the threads start.)"""
+    import threading
+
+    import torch
+
+    def source_beam(seed):
+        np.random.seed(seed)
+        src = rs.GeometricSource(raycing.BeamLine(), 'src', nrays=300000, dx=0.1, dz=0.1,
+                                 dxprime=2e-4, dzprime=2e-5, distE='flat',
+                                 energies=(8990., 9010.))
+        return src.shine()
+
+    def trace(b0, out, key, stream):
+        bl = raycing.BeamLine()
+        m1 = workloads.cfg2_toroid(bl)
+        scr = rsc.Screen(bl, 'scr', [0, 30000., 10000. * np.tan(8e-3)])
+        with torch.cuda.stream(stream):
+            b = rs.Beam(copyFrom=b0)
+            for _ in range(8):
+                gb, lb = m1.reflect(b)
+                img = scr.expose(gb)
+            stream.synchronize()
+            out[key] = {(n, f): np.array(getattr(bm, f)) for n, bm in (('lb', lb), ('img', img))
+                        for f in ('x', 'z', 'state', 'Jss', 'Jsp')}
+
+    beams = {seed: source_beam(seed) for seed in (3, 4)}
+    serial, threaded = {}, {}
+    for seed, b0 in beams.items():
+        trace(b0, serial, seed, torch.cuda.current_stream())
+    ts = [threading.Thread(target=trace, args=(b0, threaded, seed, torch.cuda.Stream()))
+          for seed, b0 in beams.items()]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert set(threaded) == {3, 4}
+    for seed in (3, 4):
+        for key, a in serial[seed].items():
+            assert np.array_equal(a, threaded[seed][key], equal_nan=True), (seed, key)
+    assert not np.array_equal(serial[3][('lb', 'x')], serial[4][('lb', 'x')])

@@ -161,8 +161,8 @@ def test_grating_block_of_the_pass():
 
 def test_out_of_scope_requests_fail_loudly():
     bl = raycing.BeamLine()
-    with pytest.raises(NotImplementedError):
-        roe.OE(bl, 'g', gratingDensity=['y', 300., 1.], order=(1, 2))
+    several = roe.OE(bl, 'g', gratingDensity=['y', 300., 1.], order=(1, 2))   # sequences are in
+    assert several.order == [1, 2]
     with pytest.raises(NotImplementedError):
         roe.OE(bl, 'p', isParametric=True)
     with pytest.raises(NotImplementedError):

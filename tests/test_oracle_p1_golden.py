@@ -45,6 +45,30 @@ def test_oe_reflect_matches_reference(name):
     assert np.array_equal(info['tMax'][good], g['tMax'][good])
 
 
+@pytest.mark.parametrize('name', ['g2_lens_crl3', 'g2_lens_cyl2', 'g2_lens_single'])
+def test_lens_stacks_match_reference(name):
+    """Refractive lenses / CRL stacks (oes/refractive.py:237-663): paraboloid and
+    parabolic-cylinder faces with their flat rim, multiple_refract's walk."""
+    p, beam, g = fixture_io.load_case(name)
+    gb, lo1, lo2 = rn.lens_multiple_refract(p, beam)
+    check_beam(gb, g, 'gb_')
+    check_beam(lo1, g, 'lo1_')
+    check_beam(lo2, g, 'lo2_')
+
+
+def test_random_diffraction_orders_follow_the_references_draw():
+    """order=(1, -1, 2, 0): one order per hit ray from numpy's global generator
+    (reflect.py:455-458); with the reference's seed the oracle draws the same."""
+    p, beam, g = fixture_io.load_case('g2_grating_orders')
+    np.random.seed(int(g['np_seed']))
+    gb, lb = rn.oe_reflect(p, beam)
+    check_beam(gb, g, 'gb_')
+    check_beam(lb, g, 'lb_')
+    assert np.array_equal(lb.order, g['lb_order'])
+    hit = g['lb_state'] == 1
+    assert set(np.unique(lb.order[hit])) == {-1., 0., 1., 2.} and not lb.order[~hit].any()
+
+
 def test_polygon_outline_states_are_the_references():
     """The oracle's point-in-polygon is matplotlib's: the reference's rays_good on
     vertices, edge points and points level with vertices (golden file)."""

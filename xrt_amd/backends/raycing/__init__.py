@@ -81,6 +81,13 @@ def rotate_xyz(x, y, z, indarr=None, rotationSequence='RzRyRx', pitch=0, roll=0,
     return x, y, z
 
 
+def rotate_point(point, rotationSequence='RzRyRx', pitch=0, roll=0, yaw=0):
+    """The 3-sequence *point* through one rotation sequence -> list of three numbers."""
+    held = [np.array([float(c)]) for c in point]
+    turn(held, rotation_steps(rotationSequence, pitch, roll, yaw))
+    return [float(c[0]) for c in held]
+
+
 def rotate_beam(beam, indarr=None, rotationSequence='RzRyRx', pitch=0, roll=0,
                 yaw=0, skip_xyz=False, skip_abc=False, **kw):
     """Positions and directions of a host-resident beam through one rotation sequence."""

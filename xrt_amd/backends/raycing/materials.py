@@ -70,9 +70,9 @@ class Element(object):
     def get_f0(self, qOver4pi=0):
         """Waasmaier-Kirfel f0 (element.py:203-207); a per-crystal constant on
         this path, evaluated once on the host."""
-        return self.f0coeffs[5] + sum(
-            a * np.exp(-b * qOver4pi**2)
-            for a, b in zip(self.f0coeffs[:5], self.f0coeffs[6:]))
+        c = self.f0coeffs
+        gauss = [amp * np.exp(-width * qOver4pi**2) for amp, width in zip(c[:5], c[6:])]
+        return c[5] + sum(gauss)
 
     def device_tables(self, device):
         key = str(device)
@@ -305,17 +305,14 @@ class Crystal(Material):
     def get_dtheta(self, E, alpha=None):
         """Refraction correction of the Bragg angle for an asymmetric cut,
         crystal.py:1141-1171 (Authier eq. 8.3); alignment helper."""
-        if alpha is None:
-            alpha = 0
-        thetaB = self.get_Bragg_angle(E)
-        pm = -1 if self.geom.startswith('Bragg') else 1
-        gamma0 = np.sin(thetaB + alpha)
-        gammah = pm * np.sin(thetaB - alpha)
-        symm_dt = self.get_dtheta_symmetric_Bragg(E)
-        osqg0 = np.sqrt(1. - gamma0**2)
-        dtheta0 = (pm*gamma0 - pm*np.sqrt(gamma0**2 +
-                   pm*(gamma0 - gammah) * osqg0 * symm_dt)) / osqg0
-        return -dtheta0
+        cut = 0 if alpha is None else alpha
+        theta = self.get_Bragg_angle(E)
+        sign = 1 if not self.geom.startswith('Bragg') else -1
+        g_in = np.sin(theta + cut)
+        g_out = sign * np.sin(theta - cut)
+        cos_in = np.sqrt(1. - g_in**2)
+        under = g_in**2 + sign*(g_in - g_out) * cos_in * self.get_dtheta_symmetric_Bragg(E)
+        return -((sign*g_in - sign*np.sqrt(under)) / cos_in)
 
 
 class CrystalFcc(Crystal):

@@ -84,15 +84,18 @@ class OE(object):
                                       'are outside the accelerated path')
         if not isinstance(shape, str) and not raycing.is_sequence(shape):
             raise ValueError('Unknown shape of OE {0}!'.format(name))
-        if order is not None and not isinstance(order, (int, np.integer)):
-            raise NotImplementedError('a sequence of diffraction orders (random '
-                                      'order per ray)')
         raycing.enrol(self, bl, 'oes', 0, name, type(self).__name__, kwargs.get('uuid'))
         self.isParametric = False
         for key in self._PLAIN:
             setattr(self, key, given[key])
         self.overEdge = kwargs.get('overEdge', 'yMax')
-        self.order = int(order) if order is not None else 1
+        # one diffraction order, or a sequence to draw from per hit ray
+        if order is None:
+            self.order = 1
+        elif raycing.is_sequence(order):
+            self.order = [int(o) for o in order]
+        else:
+            self.order = int(order)
         self.curSurface, self.dx, self.footprint = 0, 0, []
 
     # ---- asymmetric cut: the angle between the Bragg planes and the surface -------
@@ -206,7 +209,8 @@ class OE(object):
             return
         if self.isParametric:
             raise NotImplementedError('grating equation on a parametric surface')
-        p.grating, p.grating_order = 1, int(self.order)
+        several = raycing.is_sequence(self.order)
+        p.grating, p.grating_order = 1, int(self.order[0] if several else self.order)
         spec = self.gratingDensity
         if spec is not None and type(self).local_g is OE.local_g:
             coefs = [float(c) for c in spec[2:]]
@@ -529,12 +533,41 @@ class OE(object):
         lb, gb, report = self._run_pass(
             p, self.material, True, beam, beam, want_info=_info is not None,
             timing=_timing is not None, out=None if out is None else (out[1], out[0]))
+        if p.grating and raycing.is_sequence(self.order):
+            lb, gb, report = self._with_ray_orders(p, beam, lb, gb, _info, _timing)
         clock = ('pass_ms', 'kernel_ms', 'exact_sequence')
         if _info is not None:
             _info.update({k: v for k, v in report.items() if k not in clock})
         if _timing is not None:
             _timing.update({k: report[k] for k in clock})
         return gb, lb
+
+
+def _ray_orders(self, p, beam, lb, gb, _info, _timing):
+    """A sequence of diffraction orders: every ray that hits (state 1 in the local beam —
+    which order it takes does not move its hit point) gets one, drawn with numpy's global
+    generator the way the reference draws it (oes/reflect.py:455-458, one randint call of
+    the size of the hit set, in ray order), then the pass is repeated with the draw as a
+    per-ray array. The local beam carries it as *order* like the reference's."""
+    dev = _device()
+    hit = lb.dev('state', dev) == 1
+    count = int(hit.sum())
+    choice = np.asarray(self.order)[np.random.randint(len(self.order), size=count)]
+    per_ray = torch.zeros(beam.nrays, dtype=torch.int32, device=dev)
+    per_ray[hit] = torch.as_tensor(choice.astype(np.int32), device=dev)
+    p.order_ray = per_ray.data_ptr()
+    try:
+        lb, gb, report = self._run_pass(
+            p, self.material, True, beam, beam, want_info=_info is not None,
+            timing=_timing is not None, out=(lb, gb))
+        torch.cuda.current_stream().synchronize()     # per_ray is released below
+    finally:
+        p.order_ray = None
+    lb.order = per_ray.to(torch.float64)
+    return lb, gb, report
+
+
+OE._with_ray_orders = _ray_orders
 
 
 class _Curved(OE):
@@ -890,3 +923,125 @@ class Plate(DCM):
         """-> (beamGlobal, beamLocal1, beamLocal2), refractive.py:171-235."""
         return self.double_reflect(beam=beam, needLocal=needLocal,
                                    fromVacuum1=True, fromVacuum2=False)
+
+
+class ParaboloidFlatLens(Plate):
+    """Refractive lens, or a stack of *nCRL* of them (compound refractive lens): the
+    surface is z = (x^2 + y^2) / (4 focus), cut off at *zmax* (a plate of thickness
+    zmax + t with a paraboloid hole). *focus* is the focal length of the PARABOLA, a
+    shape parameter; either *focus* or *nCRL* may be a pair (focal distance, E) to be
+    derived from the other one and the material (reference oes/refractive.py:237-550).
+    As in the reference, the back surface has the shape of the front one in all four
+    lens classes (its local_z2 returns local_z); they differ in the lenslet spacing of
+    ``multiple_refract`` and in the factor between focus and nCRL."""
+    _double_sided = False
+    _cylinder = False
+
+    def __init__(self, *args, **kwargs):
+        focus, count = kwargs.pop('focus', 1.), kwargs.pop('nCRL', 1)
+        self.zmax = kwargs.pop('zmax', None)
+        kwargs.setdefault('pitch', np.pi/2)
+        Plate.__init__(self, *args, **kwargs)
+        if getattr(self.material, 'kind', None) in ('auto', 'plate'):
+            self.material.kind = 'lens'
+        if raycing.is_sequence(focus) and raycing.is_sequence(count):
+            print("'focus' and 'nCRL' cannot be both automatic")
+            count = 1
+        # the given one first, the derived one after it
+        for name, value in sorted((('focus', focus), ('nCRL', count)),
+                                  key=lambda item: raycing.is_sequence(item[1])):
+            setattr(self, name, value)
+
+    @property
+    def nCRL(self):
+        return self._nCRL
+
+    @nCRL.setter
+    def nCRL(self, value):
+        if raycing.is_sequence(value):
+            exact = self.get_nCRL(*value)
+            self._nCRL = max(int(round(exact)), 1)
+        else:
+            self._nCRL = max(int(round(value)), 1)
+
+    @property
+    def focus(self):
+        return self._focus
+
+    @focus.setter
+    def focus(self, value):
+        self._focus = self.get_focus(*value) if raycing.is_sequence(value) else value
+
+    def _lens_power(self, E):
+        """(1 - Re n) of the material times the number of curved faces per lenslet."""
+        faces = 1. if self._double_sided else 2.
+        index = np.ravel(self.material.get_refractive_index(E))[0]
+        return 1. - float(index.real), faces
+
+    def get_nCRL(self, f, E):
+        decrement, faces = self._lens_power(E)
+        return self.focus / (f*decrement) * faces
+
+    def get_focus(self, f, E):
+        decrement, faces = self._lens_power(E)
+        return (f*decrement) * self.nCRL / faces
+
+    def _surface_params(self, p, second=False):
+        self._curved(p, _structs.SURF_PARABOLOID,
+                     (4 * self.focus, 2 * self.focus,
+                      0. if self.zmax is None else self.zmax,
+                      0. if self.zmax is None else 1., 1. if self._cylinder else 0.))
+
+    def local_z1(self, x, y):
+        return self._eval_surface(_SURF_Z, x, y)[0]
+
+    def local_n1(self, x, y):
+        return self._eval_surface(_SURF_N, x, y)[3:]
+
+    local_z = local_z2 = local_z1
+    local_n = local_n2 = local_n1
+
+    def multiple_refract(self, beam=None, needLocal=True, returnLocalAbsorbed=None):
+        """The beam through all *nCRL* lenslets -> (global beam behind the last one, the
+        two local beams of the FIRST one). Between lenslets the centre walks by one
+        lenslet spacing against the rotated local z (only when *zmax* is given: the
+        reference does not move an unbounded paraboloid); the element is back at its own
+        centre afterwards and *centerShift* holds the last step."""
+        if self.nCRL == 1:
+            self.centerShift = np.zeros(3)
+            return self.double_refract(beam=beam, needLocal=needLocal)
+        depth = 5 if self.zmax is None else self.zmax
+        spacing = (2.*depth if self._double_sided else depth) + self.t
+        axis = [0, -spacing, 0]
+        home = list(self.center)
+        self.center = list(home)
+        try:
+            current, first = beam, None
+            for _ in range(self.nCRL):
+                gb, lo1, lo2 = self.double_refract(beam=current, needLocal=needLocal)
+                if self.zmax is not None:
+                    axis = raycing.rotate_point([0, 0, 1], self.rotationSequence, self.pitch,
+                                                self.roll + self.positionRoll, self.yaw)
+                    for k in range(3):
+                        self.center[k] -= spacing * axis[k]
+                current = gb
+                first = first or (lo1, lo2)
+        finally:
+            self.center = home
+        self.centerShift = spacing * np.array(axis)
+        return (gb,) + first
+
+
+class ParabolicCylinderFlatLens(ParaboloidFlatLens):
+    """Lens(es) focusing in one direction: flat along the local x, parabolic along y."""
+    _cylinder = True
+
+
+class DoubleParaboloidLens(ParaboloidFlatLens):
+    """Lens(es) with two paraboloid faces."""
+    _double_sided = True
+
+
+class DoubleParabolicCylinderLens(ParabolicCylinderFlatLens):
+    """Lens(es) with two parabolic-cylinder faces."""
+    _double_sided = True

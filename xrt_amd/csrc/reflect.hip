@@ -285,6 +285,16 @@ __device__ __forceinline__ bool surf_is_blazed(const xrt_hip_pass& P) {
   return K::F == 1 && PSURF(P) == XRT_HIP_SURF_BLAZED;
 }
 
+template <class K>
+__device__ __forceinline__ bool surf_is_lens(const xrt_hip_pass& P) {
+  return K::F == 1 && PSURF(P) == XRT_HIP_SURF_PARABOLOID;
+}
+// the paraboloid of a refractive lens before its cut-off, refractive.py:396, 411
+__device__ __forceinline__ double lens_parabola(const xrt_hip_pass& P, double& x, double y) {
+  if (P.surf_p[4] != 0.) x = 0.;  // parabolic cylinder: local_z1(0, y), :613-617
+  return (x * x + y * y) / P.surf_p[0];
+}
+
 // EllipticalMirrorParam, parametric.py:213-231. rotate_x(y, z, c, s) =
 // (c y - s z, s y + c z) (_rotate.py:5-6)
 __device__ __forceinline__ void ell_xyz_to_param(const xrt_hip_pass& P, double x, double y,
@@ -355,6 +365,10 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
   if (surf_is_blazed<K>(P)) {  // gratings.py:475-480
     double y1, yL;
     return blazed_front(P, y, y1, yL) ? -(y1 - y) * P.surf_p[1] : -yL * P.surf_p[2];
+  }
+  if (surf_is_lens<K>(P)) {  // refractive.py:394-399
+    const double z = lens_parabola(P, x, y);
+    return P.surf_p[3] != 0. && z > P.surf_p[2] ? P.surf_p[2] : z;
   }
   return 0.;
 }
@@ -1583,6 +1597,15 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     n[0] = n[3] = 0.;
     n[1] = n[4] = front ? -P.surf_p[3] : P.surf_p[5];
     n[2] = n[5] = front ? P.surf_p[4] : P.surf_p[6];
+  } else if (surf_is_lens<K>(P)) {  // refractive.py:405-419
+    const double z = lens_parabola(P, x, y);
+    const bool rim = P.surf_p[3] != 0. && z > P.surf_p[2];
+    const double na = rim || P.surf_p[4] != 0. ? 0. : -x / P.surf_p[1];  // cylinder: -0 / (2 f) of an int 0
+    const double nb = rim ? 0. : -y / P.surf_p[1];
+    const double norm = sqrt(na * na + nb * nb + 1.);
+    n[0] = n[3] = na / norm;
+    n[1] = n[4] = nb / norm;
+    n[2] = n[5] = 1. / norm;
   } else if (surf_is_param<K>(P)) {  // parametric.py:233-247, 460-472, 698-713
     const double A = P.surf_p[4], B = P.surf_p[5];
     const int conic = (int)P.surf_p[8];
@@ -1699,7 +1722,9 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       }
       const double bdg = r.a * g0 + r.b * g1 + r.c * g2;
       const double G2 = g0 * g0 + g1 * g1 + g2 * g2;
-      const double ol = (double)P.grating_order * kCH / q.E * 1e-7;
+      // one order for all rays, or the caller's per-ray draw (reflect.py:455-459)
+      const double ord = P.order_ray ? (double)P.order_ray[i] : (double)P.grating_order;
+      const double ol = ord * kCH / q.E * 1e-7;
       const double u = bdsn * bdsn - 2. * bdg * ol - G2 * (ol * ol);
       const double dn = bdsn + -1. * sqrt(fabs(u));
       ao = r.a - n[3] * dn + g0 * ol;

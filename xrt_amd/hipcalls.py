@@ -5,12 +5,13 @@ passed to the C ABI as raw pointers (``data_ptr()``) together with torch's
 current HIP stream.
 """
 import ctypes
+import threading
 
 import torch
 
 from . import _lib
 
-_workspaces = {}
+_tls = threading.local()
 
 
 def _stream_ptr():
@@ -40,13 +41,16 @@ def _c128(t, n, name):
 
 
 def workspace(device, nbytes, tag='default'):
-    """Grow-only per-device scratch buffer owned by torch's allocator."""
-    key = (device.index if device.index is not None else
-           torch.cuda.current_device(), tag)
-    ws = _workspaces.get(key)
+    """Grow-only scratch buffer owned by torch's allocator, one per (thread, device,
+    HIP stream, tag): kernels of one stream reuse it in stream order; two Python
+    threads, or two streams of one thread, never share one."""
+    cache = _tls.__dict__.setdefault('workspaces', {})
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(index).cuda_stream, tag)
+    ws = cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+        cache[key] = ws
     return ws
 
 
