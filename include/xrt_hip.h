@@ -221,6 +221,15 @@ typedef struct xrt_hip_pass {
    * for every ray. The draw itself (numpy's generator, over the rays that end in state 1)
    * stays with the caller, see xrt_amd/backends/raycing/oes.py:OE._with_ray_orders. */
   const int32_t* order_ray;
+  /* grating == 2: a circular Fresnel zone plate in the local (x, y) plane
+   * (NormalFZP, oes/gratings.py:10-137): zone_r = DEVICE array of the zone_n + 1 zone
+   * radii r_0 = 0 < r_1 < ...; rays in zones of the wrong parity or beyond the last one are
+   * lost, the others are deflected by the local zone density 1 / (r_{i+1} - r_{i-1})
+   * pointing at the axis (sign +1 in the grating equation, reflect.py:857). zone_black =
+   * 1: the central zone is opaque. */
+  int32_t zone_n;
+  int32_t zone_black;
+  const double* zone_r;
 } xrt_hip_pass;
 
 #define XRT_HIP_MAT_NONE 0

@@ -104,6 +104,13 @@ def load_case(name):
                   f1=np.array(g['Be_f1']), f2=np.array(g['Be_f2']))
         p['material'] = mn.make_material([be], None, 'plate', float(g['mat_rho']))
         p['material2'] = p['material']
+    elif name.startswith('g2_fzp'):
+        p['surface'] = dict(kind='flat')
+        p['material'] = dict(kind='FZP')
+        p['order'] = int(g['order']) if g['order'].ndim == 0 else \
+            tuple(int(o) for o in g['order'])
+        p['fzp'] = dict(zones=np.arange(len(g['fzp_rn'])), rn=np.array(g['fzp_rn']),
+                        black=bool(g['fzp_black']))
     elif name.startswith('g2_lens'):
         zmax = None if np.isnan(g['lens_zmax']) else float(g['lens_zmax'])
         kind = str(g['lens_class'])

@@ -70,6 +70,8 @@ def refractive_index(m, E):
 
 def material_amplitude(m, E, beamInDotNormal, fromVacuum=True):
     kind = m['kind']
+    if kind in ('FZP'):                                # material.py:457-459
+        return 1, 1, 0
     n = refractive_index(m, E)
     if fromVacuum:
         n1 = 1.

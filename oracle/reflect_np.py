@@ -690,6 +690,42 @@ def rays_good(oe, x, y, is2ndXtal=False):
 # --------------------------------------------------------------------------
 # grating deflection (reflect.py:451-469); crystal-as-grating (:568-612)
 # --------------------------------------------------------------------------
+def make_fzp(f, E, N, isCentralZoneBlack=True, thinnestZone=None):
+    """NormalFZP.reset, gratings.py:97-116 -> the zone table."""
+    lambdaE = CH / E * 1e-7
+    if thinnestZone is not None:
+        N = lambdaE * f / 4. / thinnestZone**2
+    zones = np.arange(N+1)
+    rn = np.sqrt(zones*f*lambdaE + 0.25*(zones*lambdaE)**2)
+    return dict(zones=zones, rn=rn, black=bool(isCentralZoneBlack))
+
+
+def _table(xp, fp, x):
+    """scipy's interp1d(xp, fp, bounds_error=False, fill_value=0) for a float / int
+    table: np.interp inside the table, 0 outside (scipy/interpolate/_interpolate.py,
+    _call_linear_np + _check_bounds)."""
+    x = np.asarray(x)
+    y = np.interp(x, xp, fp)
+    y[(x < xp[0]) | (x > xp[-1])] = 0
+    return y
+
+
+def fzp_rays_good_gn(oe, x, y):
+    """NormalFZP.rays_good_gn, gratings.py:120-137."""
+    fzp = oe['fzp']
+    rn, zones = fzp['rn'], fzp['zones']
+    locState = rays_good(oe, x, y)
+    r = np.sqrt(x**2 + y**2)
+    i = (_table(rn, zones, r)).astype(int)
+    good = ((i % 2 == int(fzp['black'])) & (r < rn[-1]) & (locState == 1))
+    locState[~good] = oe['lostNum']
+    gz = np.zeros_like(x[good])
+    rho = 1./(_table(zones, rn, i[good]+1) - _table(zones, rn, i[good]-1))
+    gx = -x[good] / r[good] * rho
+    gy = -y[good] / r[good] * rho
+    return locState, (gx, gy, gz)
+
+
 def local_g(oe, x, y):
     """Reciprocal groove vector [1/mm] of OE.local_g (base.py:688-717):
     polynomial line density ['x'|'y', rho0, p0, p1, ...] or a constant vector."""
@@ -804,7 +840,11 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
         tX, tY, _ = param_to_xyz(surf, lb.x[good], lb.y[good], lb.z[good])
     else:
         tX, tY = lb.x[good], lb.y[good]
-    lb.state[good] = rays_good(oe, tX, tY, is2ndXtal)
+    gNormal = None
+    if 'fzp' in oe:                               # reflect.py:706-707
+        lb.state[good], gNormal = fzp_rays_good_gn(oe, tX, tY)
+    else:
+        lb.state[good] = rays_good(oe, tX, tY, is2ndXtal)
     if _lost is not None:
         lb.state[np.where(good)[0][_lost]] = oe['lostNum']
 
@@ -824,6 +864,8 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
                     toWhere = 2
             elif kind == 'grating':               # reflect.py:743-744
                 toWhere = 3
+            elif kind == 'FZP':
+                toWhere = 4
             elif kind not in ('mirror', 'thin mirror'):
                 raise ValueError('unsupported material kind ' + kind)
 
@@ -853,6 +895,14 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
                 lb.a[goodN], lb.b[goodN], lb.c[goodN], lb.E[goodN], g, oeNormal,
                 beamInDotSurfaceNormal, oe.get('order', 1), -1, drawn)
             lb.order = np.zeros(len(lb.a))               # :457-458
+            lb.order[goodN] = drawn[0]
+        elif toWhere == 4:                        # zone plate: reflect.py:840, 857-861
+            drawn = []
+            lb.a[goodN], lb.b[goodN], lb.c[goodN] = grating_deflection(
+                lb.a[goodN], lb.b[goodN], lb.c[goodN], lb.E[goodN],
+                np.asarray(gNormal, order='F'), oeNormal, beamInDotSurfaceNormal,
+                oe.get('order', 1), 1, drawn)
+            lb.order = np.zeros(len(lb.a))
             lb.order[goodN] = drawn[0]
         elif toWhere in (0, 2):
             if kind == 'crystal' and toWhere == 0:

@@ -130,6 +130,18 @@ def product_oe(name, g):
     elif name == 'g2_plate_be':
         m = rm.Material('Be', rho=float(g['mat_rho']), kind='plate')
         oe = roe.Plate(bl, 'win', material=m, t=float(g['plate_t']), **common)
+    elif name.startswith('g2_fzp'):
+        m = rm.Material('Au', rho=19.3, kind='FZP')
+        for key in ('limPhysX', 'limPhysY'):        # the zone plate sets its own outline
+            common.pop(key)
+        kw = dict(thinnestZone=float(g['fzp_thinnestZone'])) if 'fzp_thinnestZone' in g.files \
+            else dict(N=int(g['fzp_N']))
+        oe = roe.NormalFZP(
+            bl, 'fzp', material=m, f=float(g['fzp_f']), E=float(g['fzp_E']),
+            isCentralZoneBlack=bool(g['fzp_black']),
+            order=int(g['order']) if g['order'].ndim == 0 else [int(o) for o in g['order']],
+            **kw, **common)
+        assert np.array_equal(oe.rn, g['fzp_rn'])
     elif name.startswith('g2_lens'):
         m = rm.Material('Be', rho=float(g['mat_rho']), kind='lens')
         zmax = None if np.isnan(g['lens_zmax']) else float(g['lens_zmax'])

@@ -211,6 +211,38 @@ def test_plate_double_refract_matches_reference_golden():
     compare(lo2, g, lambda f: g['lo2_' + f])
 
 
+@pytest.mark.parametrize('name', ['g2_fzp_first', 'g2_fzp_orders'])
+def test_zone_plate_matches_reference_golden(name):
+    """NormalFZP (oes/gratings.py:10-137): rays in opaque zones and beyond the last zone
+    are lost (states bit-exact, incl. a ray exactly on a zone boundary and one on the
+    axis), the others take the grating equation with the local zone density, sign +1;
+    bracketing along z (normal incidence); a sequence of orders is drawn per ray."""
+    g = pc.load(name)
+    fzp = pc.product_oe(name, g)
+    if 'np_seed' in g.files:
+        np.random.seed(int(g['np_seed']))
+    info = {}
+    gb, lb = fzp.reflect(pc.product_beam(g), _info=info)
+    assert info['axis'] == 2
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    hit = g['lb_state'] == 1
+    assert 700 < hit.sum() < 1000                 # about half the zones are open
+    if 'np_seed' in g.files:
+        assert np.array_equal(lb.order, g['lb_order'])
+    else:
+        # first order focuses: the deflection points at the axis and grows with r
+        r = np.hypot(lb.x[hit], lb.y[hit])
+        kick = ((lb.a - g['in_a'])[hit] * lb.x[hit] + (lb.b - 0.)[hit] * lb.y[hit]) / r
+        far = r > 0.5 * r.max()
+        assert (kick[far] < 0).all() and np.corrcoef(r[far], kick[far])[0, 1] < -0.99
+    # the host-side zone function agrees with the kernel on which rays pass
+    state, gn = fzp.rays_good_gn(lb.x, lb.y)
+    entered = g['in_state'] > 0
+    assert np.array_equal(state[entered] == 1, hit[entered])
+    assert len(gn[0]) == (state == 1).sum()
+
+
 @pytest.mark.parametrize('name', ['g2_lens_crl3', 'g2_lens_cyl2', 'g2_lens_single'])
 def test_lens_stacks_match_reference_golden(name):
     """Refractive lenses and CRL stacks (oes/refractive.py:237-663): paraboloid /

@@ -56,6 +56,21 @@ def test_lens_stacks_match_reference(name):
     check_beam(lo2, g, 'lo2_')
 
 
+@pytest.mark.parametrize('name', ['g2_fzp_first', 'g2_fzp_orders'])
+def test_zone_plate_matches_reference(name):
+    """NormalFZP in ray mode (gratings.py:10-137): opaque zones absorb, the others
+    deflect by the local zone density; one order or a seeded draw per ray."""
+    p, beam, g = fixture_io.load_case(name)
+    if 'np_seed' in g.files:
+        np.random.seed(int(g['np_seed']))
+    gb, lb = rn.oe_reflect(p, beam)
+    check_beam(gb, g, 'gb_')
+    check_beam(lb, g, 'lb_')
+    assert int(g['axis']) == 2
+    if 'np_seed' in g.files:
+        assert np.array_equal(lb.order, g['lb_order'])
+
+
 def test_random_diffraction_orders_follow_the_references_draw():
     """order=(1, -1, 2, 0): one order per hit ray from numpy's global generator
     (reflect.py:455-458); with the reference's seed the oracle draws the same."""

@@ -70,6 +70,9 @@ class Pass(ctypes.Structure):
         ('poly_n', ctypes.c_int32),
         ('poly_xy', ctypes.c_void_p),
         ('order_ray', ctypes.c_void_p),
+        ('zone_n', ctypes.c_int32),
+        ('zone_black', ctypes.c_int32),
+        ('zone_r', ctypes.c_void_p),
     ]
 
 

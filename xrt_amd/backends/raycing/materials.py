@@ -87,11 +87,13 @@ _KINDS = {'mirror': _structs.MAT_MIRROR, 'thin mirror': _structs.MAT_THIN_MIRROR
           'crystal': _structs.MAT_CRYSTAL,
           # a 'grating' reflects like a mirror (material.py:476); the grating
           # equation itself is a property of the element (xrt_hip_pass.grating)
-          'grating': _structs.MAT_MIRROR}
+          'grating': _structs.MAT_MIRROR,
+          # the transparent zones of a zone plate pass the ray unchanged (material.py:457-459)
+          'FZP': _structs.MAT_NONE}
 
 
 def _dev_f64(a, device):
-    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=device)
+    return torch.from_numpy(np.array(a, dtype=np.float64, order='C')).to(device)
 
 
 class Material(object):
@@ -158,6 +160,8 @@ class Material(object):
     # ---- xrt API, evaluated by the device functions ---------------------------
     def get_amplitude(self, E, beamInDotNormal, fromVacuum=True):
         """(rs, rp, mu [1/cm], Re(n) k [1/cm]) per ray, material.py:415-493."""
+        if self.kind == 'FZP':
+            return 1, 1, 0
         _lib.require_gpu()
         lib = _lib.load()
         dev = torch.device('cuda', torch.cuda.current_device())
@@ -186,7 +190,7 @@ class Material(object):
         E = np.atleast_1d(np.asarray(E, dtype=np.float64))
         saved = self.kind
         try:
-            if saved not in ('mirror', 'thin mirror', 'plate', 'lens'):
+            if saved not in ('mirror', 'thin mirror', 'plate', 'lens'):   # incl. 'FZP', 'grating'
                 self.kind = 'mirror'
             _, _, mu, nk = self.get_amplitude(E, -np.ones_like(E) * 0.5)
         finally:

@@ -27,6 +27,7 @@ import torch
 from .. import raycing
 from ... import _lib, _structs, hipcalls
 from . import sources as rs
+from .physconsts import CH
 
 _WIDE = raycing.maxHalfSizeOfOE
 _OVER_EDGE = (('xmin', _structs.OVER_XMIN), ('xmax', _structs.OVER_XMAX),
@@ -201,7 +202,7 @@ class OE(object):
         if raycing.is_sequence(material):
             material = material[0] if len(material) == 1 else None
         kind = getattr(material, 'kind', None)
-        return kind == 'grating' or (kind == 'auto' and self.gratingDensity is not None)
+        return kind in ('grating', 'FZP') or (kind == 'auto' and self.gratingDensity is not None)
 
     def _grating_params(self, p, second=False):
         p.grating = 0
@@ -211,6 +212,15 @@ class OE(object):
             raise NotImplementedError('grating equation on a parametric surface')
         several = raycing.is_sequence(self.order)
         p.grating, p.grating_order = 1, int(self.order[0] if several else self.order)
+        if hasattr(self, 'rn'):           # zone plate: the zone radii instead of a groove vector
+            cached = getattr(self, '_zone_table', None)     # kept in HBM for the kernels
+            if cached is None or cached[0] is not self.rn:
+                table = np.ascontiguousarray(self.rn, dtype=np.float64)
+                self._zone_table = cached = (self.rn, torch.from_numpy(table.copy()).to(_device()))
+            p.grating, p.grating_axis = 2, -1
+            p.zone_n, p.zone_black = len(self.rn) - 1, int(bool(self.isCentralZoneBlack))
+            p.zone_r = cached[1].data_ptr()
+            return
         spec = self.gratingDensity
         if spec is not None and type(self).local_g is OE.local_g:
             coefs = [float(c) for c in spec[2:]]
@@ -1045,3 +1055,56 @@ class DoubleParaboloidLens(ParaboloidFlatLens):
 class DoubleParabolicCylinderLens(ParabolicCylinderFlatLens):
     """Lens(es) with two parabolic-cylinder faces."""
     _double_sided = True
+
+
+def _zone_reset(name):
+    """A zone-plate parameter: storing it rebuilds the zone table."""
+    def store(self, value):
+        setattr(self, '_' + name, value)
+        self.reset()
+    return property(lambda self: getattr(self, '_' + name), store)
+
+
+class NormalFZP(OE):
+    """Circular Fresnel zone plate in the local (x, y) plane, the optical axis along the
+    local z (X-Ray Data Booklet 4.4): zones of zero thickness, alternately opaque and
+    transparent; the material must be of kind 'FZP'. *f* [mm] is the focal length at the
+    energy *E* [eV], *N* the number of zones, given or derived from the width of the
+    *thinnestZone* [mm]; *isCentralZoneBlack* False inverts the zones; *order* is one
+    diffraction order or a sequence to draw from (reference oes/gratings.py:10-137)."""
+    f, E, N, thinnestZone = (_zone_reset(k) for k in ('f', 'E', 'N', 'thinnestZone'))
+
+    def __init__(self, *args, **kwargs):
+        self.isCentralZoneBlack = kwargs.pop('isCentralZoneBlack', True)
+        given = {k: kwargs.pop(k, default) for k, default in
+                 (('f', 50), ('E', 1000), ('N', 1000), ('thinnestZone', None))}
+        for key, value in given.items():
+            setattr(self, '_' + key, value)
+        self.reset()
+        kwargs['limPhysX'] = kwargs['limPhysY'] = [-self.rn[-1], self.rn[-1]]
+        OE.__init__(self, *args, **kwargs)
+        if getattr(self.material, 'kind', None) == 'auto':
+            self.material.kind = 'FZP'
+
+    def reset(self):
+        """r_n = sqrt(n f lambda + (n lambda / 2)^2), n = 0..N; the outline follows."""
+        if not all(hasattr(self, '_' + k) for k in ('f', 'E', 'N', 'thinnestZone')):
+            return
+        wavelength = CH / self.E * 1e-7
+        if self.thinnestZone is not None:
+            self._N = wavelength * self.f / 4. / self.thinnestZone**2
+        self.zones = np.arange(self.N + 1)
+        self.rn = np.sqrt(self.zones*self.f*wavelength + 0.25*(self.zones*wavelength)**2)
+        self.limPhysX = self.limPhysY = [-self.rn[-1], self.rn[-1]]
+
+    def rays_good_gn(self, x, y, z=None):
+        """-> (state, (gx, gy, gz) of the rays with state 1): rays in opaque zones or
+        beyond the last zone are lost (the state comes from the kernels' own function)."""
+        state = self.rays_good(x, y)
+        hit = state == 1
+        xs, ys = np.asarray(x, dtype=float)[hit], np.asarray(y, dtype=float)[hit]
+        radius = np.sqrt(xs**2 + ys**2)
+        zone = np.searchsorted(self.rn, radius, side='right') - 1
+        density = 1. / (self.rn[np.minimum(zone + 1, len(self.rn) - 1)] -
+                        np.where(zone >= 1, self.rn[np.maximum(zone - 1, 0)], 0.))
+        return state, (-xs / radius * density, -ys / radius * density, np.zeros_like(xs))

@@ -1230,8 +1230,54 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
   return h;
 }
 
+// The zone of a Fresnel zone plate a point falls into, NormalFZP.rays_good_gn
+// (gratings.py:120-137): i = int(r_to_i(r)) with r_to_i = scipy's interp1d(rn, zones,
+// bounds_error=False, fill_value=0), which for this table is np.interp (its slope form,
+// exact table values at the knots) with 0 outside [rn[0], rn[N]]. -> transparent or not;
+// rho = the local zone density 1 / (i_to_r(i+1) - i_to_r(i-1)), table ends giving 0.
+__device__ __forceinline__ bool fzp_zone(const xrt_hip_pass& P, double x, double y, double& r,
+                                         double& rho) {
+  const double* rn = P.zone_r;
+  const int N = P.zone_n;
+  r = sqrt(x * x + y * y);
+  double zi = 0.;
+  if (r >= rn[0] && r <= rn[N]) {
+    int lo = 0, hi = N;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (r >= rn[mid])
+        lo = mid;
+      else
+        hi = mid;
+    }
+    if (r == rn[N]) {
+      zi = (double)N;
+    } else if (r == rn[lo]) {
+      zi = (double)lo;
+    } else {
+      const double slope = 1. / (rn[lo + 1] - rn[lo]);
+      zi = slope * (r - rn[lo]) + (double)lo;
+    }
+  }
+  const int i = (int)zi;
+  const double above = i + 1 <= N ? rn[i + 1] : 0.;
+  const double below = i - 1 >= 0 ? rn[i - 1] : 0.;
+  rho = 1. / (above - below);
+  return (i % 2 == P.zone_black) && (r < rn[N]);
+}
+
 // rays_good, oes/base.py:1094-1163
+__device__ __forceinline__ int rays_good_outline(const xrt_hip_pass& P, double x, double y);
+template <class K>
 __device__ __forceinline__ int rays_good(const xrt_hip_pass& P, double x, double y) {
+  const int st = rays_good_outline(P, x, y);
+  if (PGRATING(P) == 2) {  // gratings.py:123-129: opaque zones absorb
+    double r, rho;
+    return fzp_zone(P, x, y, r, rho) && st == 1 ? 1 : P.lost_num;
+  }
+  return st;
+}
+__device__ __forceinline__ int rays_good_outline(const xrt_hip_pass& P, double x, double y) {
   int st = 1;
   if (P.shape == XRT_HIP_SHAPE_POLYGON) {
     // matplotlib's Path.contains_points (src/_path.h, point_in_path_impl, radius 0): an
@@ -1704,7 +1750,15 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       // grating equation, reflect.py:840-861 + 451-469 (sign -1); the groove
       // vector of OE.local_g (base.py:688-717)
       double g0 = P.g_const[0], g1 = P.g_const[1], g2 = P.g_const[2];
-      if (P.grating_axis >= 0) {
+      double gsig = -1.;
+      if (P.grating == 2) {  // zone plate: gn of rays_good_gn, sign +1 (reflect.py:857)
+        double rad, rho;
+        fzp_zone(P, h.x, h.y, rad, rho);
+        g0 = -h.x / rad * rho;
+        g1 = -h.y / rad * rho;
+        g2 = 0.;
+        gsig = 1.;
+      } else if (P.grating_axis >= 0) {
         const double coord = P.grating_axis == 0 ? h.x : h.y;
         double poly = 0.;
         // coord**ic: exact for ic <= 2 like numpy's; for higher powers numpy
@@ -1726,7 +1780,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       const double ord = P.order_ray ? (double)P.order_ray[i] : (double)P.grating_order;
       const double ol = ord * kCH / q.E * 1e-7;
       const double u = bdsn * bdsn - 2. * bdg * ol - G2 * (ol * ol);
-      const double dn = bdsn + -1. * sqrt(fabs(u));
+      const double dn = bdsn + gsig * sqrt(fabs(u));
       ao = r.a - n[3] * dn + g0 * ol;
       bo = r.b - n[4] * dn + g1 * ol;
       co = r.c - n[5] * dn + g2 * ol;
@@ -2106,7 +2160,7 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
     h = solve_ray<K>(P, g, r);
   }
   if (active) {
-    int st = rays_good(P, h.x, h.y);
+    int st = rays_good<K>(P, h.x, h.y);
     if (h.lost) st = P.lost_num;
     if (XTAL) {
       double bdn = 0.;
@@ -2181,7 +2235,7 @@ __device__ __forceinline__ void solve_body(const xrt_hip_pass& P, const xrt_hip_
     if (!entering(P, in.state[i])) continue;
     const LocalRay r = load_local(P, in, i);
     const Hit h = solve_ray<K>(P, g, r);
-    int st = rays_good(P, h.x, h.y);
+    int st = rays_good<K>(P, h.x, h.y);
     if (h.lost) st = P.lost_num;
     ht[i] = h.t;
     hx[i] = h.x;
@@ -2598,7 +2652,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_dcm(
     report_opt(opt1, aux, viol);
     bool kept = false;
     if (active) {
-      int st = rays_good(P1, h.x, h.y);
+      int st = rays_good<K>(P1, h.x, h.y);
       if (h.lost) st = P1.lost_num;
       double bdn = 0.;
 #ifdef XRT_DCM_EARLY
@@ -2649,7 +2703,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_dcm(
     }
     report_opt(opt2, aux, viol);
     if (active) {
-      int st = rays_good(P2, h.x, h.y);
+      int st = rays_good<K>(P2, h.x, h.y);
       if (h.lost) st = P2.lost_num;
       double bdn = 0.;
       complete_ray<K, true>(P2, M2, g, in, in, lo2, gb2, theta2, i, r, h, st, has_amp, 1, &bdn,
@@ -2739,7 +2793,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void surface_eval_kernel(
     surface_normal<K>(P, p, q, p, q, nn);
     for (int k = 0; k < 6; ++k) o[k * n + i] = nn[k];
   } else if (what == 5) {
-    o[i] = (double)rays_good(P, p, q);
+    o[i] = (double)rays_good<K>(P, p, q);
   } else if (what == 2) {
     o[i] = param ? ell_local_r(P, p, q) : 0.;
   } else if (what == 3) {
