@@ -654,7 +654,10 @@ class BlazedGrating(_Curved):
         self.antiblaze = raycing.auto_units_angle(kwargs.pop('antiblaze', np.pi*0.4999))
         self.rho0 = kwargs.pop('rho', 1)
         if kwargs.get('gratingDensity') is not None:
-            raise NotImplementedError('variable line density')
+            # the reference cannot run this case either: its rho0 setter and reset() call
+            # each other without end (gratings.py:378-380, 418-420), so there is nothing
+            # to pin a variable-density saw-tooth against
+            raise NotImplementedError('variable line density of a blazed grating')
         OE.__init__(self, *args, **kwargs)
         self.gratingDensity = None
         self.reset()
