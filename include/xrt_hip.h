@@ -575,6 +575,22 @@ XRT_HIP_API int xrt_hip_custom_field_f64(
     const double* gamma, const double* w, const double* ddphi, const double* ddpsi,
     double* Is_ri, double* Ip_ri, float* kernel_ms);
 
+/* Electron trajectory through a tabulated field, SourceFromField._build_trajectory_conv
+ * (sources/synchr.py:1049-1147) = run_parallel('get_trajectory' |
+ * 'get_trajectory_filament', ...) of _build_trajectory_CL (:1011-1047; kernels
+ * cl/undulator.cl:733, 918): Runge-Kutta along the grid wt[n] [mm] with the field [T] on
+ * the half-step grid (Bx, By, Bz [2n - 1]); the mean velocity and mean position are
+ * removed. filament = 0: per unit emcg (pass emcg = 1, gamma unused); 1: in units of c for
+ * the electron `gamma`, emcg = SIE0/SIM0/C/10/gamma. Outputs on the grid: betax, betay,
+ * trajx, trajy, trajz [n]; betam[1] = the mean longitudinal term (betazav[-1]). All
+ * pointers are device pointers. */
+XRT_HIP_API int xrt_hip_trajectory_f64_dev(int filament, int64_t n, const double* wt,
+                                           const double* Bx, const double* By,
+                                           const double* Bz, double gamma, double emcg,
+                                           double* betax, double* betay, double* trajx,
+                                           double* trajy, double* trajz, double* betam,
+                                           void* stream);
+
 /* ---- timing without a host sync ------------------------------------------
  * xrt_hip_reflect_time_next_pass arms the NEXT xrt_hip_reflect_pass_f64_dev call of
  * this thread: it records pass_begin / pass_end around the whole pass and

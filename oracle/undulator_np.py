@@ -263,3 +263,91 @@ def custom_sp_sum(filament, tab, emcg, w, gamma, ddphi, ddpsi, betam, R0=None):
         Bs += eucos*(bnx*nbp - betaPx*nbn)
         Bp += eucos*(bny*nbp - betaPy*nbn)
     return Bs*emcg, Bp*emcg
+
+
+# --------------------------------------------------------------------------
+# electron trajectory in a tabulated field: SourceFromField._build_trajectory_conv,
+# synchr.py:1049-1147 (OpenCL twins get_trajectory[_filament], cl/undulator.cl:733, 918)
+# --------------------------------------------------------------------------
+SIM0, C_LIGHT = 9.109383701528e-31, 2.99792458e10        # physconsts.py:17, 14
+
+
+def trajectory(wtGrid, Bx, By, Bz, gamma=None):
+    """-> (betax, betay, betam_int, trajx, trajy, trajz) ON THE GRID wtGrid (the
+    reference then splines them onto the integration nodes). *gamma* None: the
+    non-filament form (velocities per unit emcg); else the filament electron's gamma.
+    Field arrays on the half-step grid (2 len(wtGrid) - 1 points)."""
+    filamentBeam = gamma is not None
+
+    def f_beta(B, beta):
+        return emcg*np.array((beta[1]*B[2]-B[1], B[0] - beta[0]*B[2]))
+
+    def f_traj(beta):
+        if filamentBeam:
+            smTerm = 1./gamma**2 + beta[0]**2 + beta[1]**2
+            betaz = 1. - 0.5*smTerm - 0.125*smTerm**2 - 0.0625*smTerm**3
+        else:
+            betaz = -0.5*(beta[0]**2 + beta[1]**2)
+        return np.array((beta[0], beta[1], betaz))
+
+    def next_beta_rk(iB, beta):
+        k1beta = rkStep * f_beta([Bx[iB], By[iB], Bz[iB]], beta)
+        k2beta = rkStep * f_beta([Bx[iB+1], By[iB+1], Bz[iB+1]], beta + 0.5*k1beta)
+        k3beta = rkStep * f_beta([Bx[iB+1], By[iB+1], Bz[iB+1]], beta + 0.5*k2beta)
+        k4beta = rkStep * f_beta([Bx[iB+2], By[iB+2], Bz[iB+2]], beta + k3beta)
+        return beta + (k1beta + 2*k2beta + 2*k3beta + k4beta)/6.
+
+    def next_traj_rk(iB, beta, traj):
+        k1beta = rkStep * f_beta([Bx[iB], By[iB], Bz[iB]], beta)
+        k1traj = rkStep * f_traj(beta)
+        k2beta = rkStep * f_beta([Bx[iB+1], By[iB+1], Bz[iB+1]], beta + 0.5*k1beta)
+        k2traj = rkStep * f_traj(beta + 0.5*k1beta)
+        k3beta = rkStep * f_beta([Bx[iB+1], By[iB+1], Bz[iB+1]], beta + 0.5*k2beta)
+        k3traj = rkStep * f_traj(beta + 0.5*k2beta)
+        k4beta = rkStep * f_beta([Bx[iB+2], By[iB+2], Bz[iB+2]], beta + k3beta)
+        k4traj = rkStep * f_traj(beta + k3beta)
+        return (beta + (k1beta + 2*k2beta + 2*k3beta + k4beta)/6.,
+                traj + (k1traj + 2*k2traj + 2*k3traj + k4traj)/6.)
+
+    if filamentBeam:
+        gamma = np.array(gamma)
+    emcg = SIE0 / SIM0 / C_LIGHT / 10. / gamma if filamentBeam else 1.
+    beta_next = np.zeros(2)
+    beta0 = np.zeros(2)
+    betam_int = 0
+    for i in range(len(wtGrid)-1):
+        rkStep = wtGrid[i+1] - wtGrid[i]
+        beta_next = next_beta_rk(2*i, beta_next)
+        beta0 += rkStep * beta_next
+    beta0 /= -(wtGrid[-1] - wtGrid[0])
+    beta_next = np.copy(beta0)
+    traj_next = np.zeros(3)
+    traj0 = np.zeros(3)
+    for i in range(len(wtGrid)-1):
+        rkStep = wtGrid[i+1] - wtGrid[i]
+        beta_next, traj_next = next_traj_rk(2*i, beta_next, traj_next)
+        traj0 += rkStep * traj_next
+        if filamentBeam:
+            betam_int += rkStep * np.sqrt(
+                1. - 1./gamma**2 - beta_next[0]**2 - beta_next[1]**2)
+        else:
+            betam_int += beta_next[0]**2 + beta_next[1]**2
+    traj0 /= -(wtGrid[-1] - wtGrid[0])
+    beta_next = np.copy(beta0)
+    traj_next = np.copy(traj0)
+    if filamentBeam:
+        betam_int /= -(wtGrid[-1] - wtGrid[0])
+    else:
+        betam_int *= -0.5/(len(wtGrid)-1)
+    betax, betay = [beta0[0]], [beta0[1]]
+    trajx, trajy, trajz = [traj0[0]], [traj0[1]], [traj0[2]]
+    for i in range(len(wtGrid)-1):
+        rkStep = wtGrid[i+1] - wtGrid[i]
+        beta_next, traj_next = next_traj_rk(2*i, beta_next, traj_next)
+        betax.append(beta_next[0])
+        betay.append(beta_next[1])
+        trajx.append(traj_next[0])
+        trajy.append(traj_next[1])
+        trajz.append(traj_next[2])
+    return (np.array(betax), np.array(betay), float(betam_int), np.array(trajx),
+            np.array(trajy), np.array(trajz))

@@ -173,11 +173,21 @@ def test_reference_source_from_field_runs_through_the_dropin():
 
     class OracleBackedHIP(XRT_HIP):
         calls = 0
+        trajectories = 0
 
         def set_cl(self, targetOpenCL='auto', precisionOpenCL='float64'):
             self.device_ids = [0]
             self.lastTargetOpenCL = targetOpenCL
             self.lastPrecisionOpenCL = precisionOpenCL
+
+        def _trajectory(self, kernelName, scalarArgs, nonSlicedRO, nonSlicedRW):
+            # 'get_trajectory' as _build_trajectory_CL marshals it (synchr.py:1011-1035)
+            type(self).trajectories += 1
+            assert kernelName == 'get_trajectory' and len(nonSlicedRW) == 6
+            grid, Bx, By, Bz = (np.array(a) for a in nonSlicedRO)
+            assert int(scalarArgs[0]) == len(grid) and len(Bx) == 2 * len(grid) - 1
+            bx, by, bm, tx, ty, tz = un.trajectory(grid, Bx, By, Bz)
+            return bx, by, np.full(len(grid), bm), tx, ty, tz
 
         def _call_lib_custom_field(self, f, n, rays, outs):
             type(self).calls += 1
@@ -214,6 +224,6 @@ def test_reference_source_from_field_runs_through_the_dropin():
     fake = OracleBackedHIP()
     fake.attach_to_source(s)
     got = s.build_I_map(w, th, ps)
-    assert type(fake).calls == 1
+    assert type(fake).calls == 1 and type(fake).trajectories == 1
     for a, b in zip(got, ref):
         assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b)

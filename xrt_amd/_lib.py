@@ -75,6 +75,9 @@ SIGNATURES = {
         vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, c_float_p]),
     'xrt_hip_custom_field_f64': (ctypes.c_int, [
         ctypes.c_int, vp, i64, vp, vp, vp, vp, vp, vp, vp, c_float_p]),
+    'xrt_hip_trajectory_f64_dev': (ctypes.c_int, [
+        ctypes.c_int, i64, vp, vp, vp, vp, ctypes.c_double, ctypes.c_double,
+        vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_kirchhoff_report': (ctypes.c_int, [
         vp, vp, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint),
         ctypes.POINTER(ctypes.c_int64)]),

@@ -25,7 +25,8 @@ from ... import _lib
 
 class XRT_HIP(object):
     kernels = ('integrate_kirchhoff', 'undulator', 'undulator_taper',
-               'undulator_nf', 'custom_field', 'custom_field_filament')
+               'undulator_nf', 'custom_field', 'custom_field_filament',
+               'get_trajectory', 'get_trajectory_filament')
 
     def __init__(self, filename=None, targetOpenCL='auto',
                  precisionOpenCL='float64', convention='opencl', devices=None):
@@ -77,6 +78,8 @@ class XRT_HIP(object):
         if kernelName in ('custom_field', 'custom_field_filament'):
             return self._custom_field(kernelName, scalarArgs, slicedROArgs,
                                       nonSlicedROArgs, slicedRWArgs, int(dimension))
+        if kernelName in ('get_trajectory', 'get_trajectory_filament'):
+            return self._trajectory(kernelName, scalarArgs, nonSlicedROArgs, nonSlicedRWArgs)
         if kernelName != 'integrate_kirchhoff':
             raise NotImplementedError(
                 "XRT_HIP implements %s, not %r" % (self.kernels, kernelName))
@@ -127,14 +130,35 @@ class XRT_HIP(object):
         source.cl_precisionC = self.cl_precisionC
         source.cl_ctx = self            # only tested against None
         source.cl_is_blocking = True
-        if hasattr(source, '_build_trajectory_conv'):
-            # SourceFromField integrates the electron trajectory once per reset in
-            # a ONE-work-item OpenCL kernel ('get_trajectory', dimension=1,
-            # synchr.py:1010-1035): a sequential O(N) job with nothing to
-            # parallelise. It stays on the reference's own numpy routine; the
-            # per-ray field sums ('custom_field') run on the GPU.
-            source.build_trajectory = source._build_trajectory_conv
         return source
+
+    def _trajectory(self, kernelName, scalarArgs, nonSlicedRO, nonSlicedRW):
+        """Argument order of SourceFromField._build_trajectory_CL (synchr.py:1011-1035):
+        scalars [jend(, gamma)], RO [wtGrid, Bx, By, Bz], RW [betax, betay, betazav,
+        trajx, trajy, trajz] on the grid; the caller reads betazav[-1]."""
+        import torch
+        from ... import hipcalls
+        filament = kernelName.endswith('filament')
+        jend = int(scalarArgs[0])
+        grid, Bx, By, Bz = (np.ascontiguousarray(a, dtype=np.float64) for a in nonSlicedRO)
+        if grid.size != jend or any(b.size != 2 * jend - 1 for b in (Bx, By, Bz)):
+            raise ValueError('%s: grid of %d points needs the field on %d points'
+                             % (kernelName, jend, 2 * jend - 1))
+        dev = torch.device('cuda', self.device_ids[0])
+        up = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+        if filament:
+            gamma = float(scalarArgs[1])
+            res = hipcalls.trajectory(up(grid), up(Bx), up(By), up(Bz), gamma=gamma,
+                                      emcg=self.EMC_NUM / gamma)
+        else:
+            res = hipcalls.trajectory(up(grid), up(Bx), up(By), up(Bz))
+        betax, betay, trajx, trajy, trajz = (t.cpu().numpy() for t in res[:5])
+        mean = np.full(jend, float(res[5][0]))
+        outs = (betax, betay, mean, trajx, trajy, trajz)
+        for target, value in zip(nonSlicedRW or (), outs):
+            if isinstance(target, np.ndarray) and target.shape == value.shape:
+                target[...] = value
+        return outs
 
     def _undulator(self, kernelName, scalarArgs, slicedRO, nonSlicedRO, slicedRW,
                    dimension):

@@ -851,6 +851,20 @@ int xrt_hip_custom_field_f64_dev(const xrt_hip_custom_field* f, int64_t nrays,
   return XRT_HIP_OK;
 }
 
+int xrt_hip_trajectory_f64_dev(int filament, int64_t n, const double* wt, const double* Bx,
+                               const double* By, const double* Bz, double gamma, double emcg,
+                               double* betax, double* betay, double* trajx, double* trajy,
+                               double* trajz, double* betam, void* stream) {
+  if (n < 2) return fail(XRT_HIP_ERR_ARG, "a trajectory needs at least 2 grid points, got %lld",
+                         (long long)n);
+  if (!wt || !Bx || !By || !Bz || !betax || !betay || !trajx || !trajy || !trajz || !betam)
+    return fail(XRT_HIP_ERR_ARG, "NULL trajectory array");
+  if (filament && !(gamma > 0)) return fail(XRT_HIP_ERR_ARG, "filament trajectory needs gamma");
+  HIP_TRY(xrt::trajectory_launch(filament, n, wt, Bx, By, Bz, gamma, emcg, betax, betay, trajx,
+                                 trajy, trajz, betam, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
 int xrt_hip_custom_field_f64(int device, const xrt_hip_custom_field* f, int64_t nrays,
                              const double* emcg, const double* gamma, const double* w,
                              const double* ddphi, const double* ddpsi, double* Is_ri,

@@ -22,4 +22,9 @@ hipError_t custom_field_launch(const xrt_hip_custom_field& a, int64_t n, const d
                                const double* ddpsi, double* Is_ri, double* Ip_ri,
                                void* workspace, hipStream_t st, hipEvent_t e0,
                                hipEvent_t e1);
+// n grid points, field on the 2n-1 half-step points; outputs n values each, betam one
+hipError_t trajectory_launch(int filament, int64_t n, const double* wt, const double* Bx,
+                             const double* By, const double* Bz, double gamma, double emcg,
+                             double* betax, double* betay, double* trajx, double* trajy,
+                             double* trajz, double* betam, hipStream_t st);
 }

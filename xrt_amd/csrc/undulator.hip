@@ -462,4 +462,156 @@ hipError_t undulator_imap_launch(const UndulatorArgs& a, const UndulatorMap& m, 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Electron trajectory in a tabulated field: SourceFromField._build_trajectory_conv
+// (sources/synchr.py:1049-1147), the job of the OpenCL one-work-item kernels
+// get_trajectory / get_trajectory_filament (cl/undulator.cl:733, 918). Fourth-order
+// Runge-Kutta along the grid wt[n] with the field on the half-step grid B[2n-1]; three
+// sweeps: (1) velocity from rest -> its mean is removed, (2) velocity + position -> the
+// mean position is removed and the mean longitudinal term is collected, (3) the final
+// tables. A recurrence: ONE lane walks it (a step is ~90 dependent fp64 operations, the
+// grid has thousands of points: milliseconds, where the reference's Python loop takes
+// seconds per call), in the reference's operation order. FIL: filamentBeam (velocities in
+// units of c with the electron's own gamma) / else per unit emcg.
+// ---------------------------------------------------------------------------
+namespace {
+struct Vel {
+  double x, y;
+};
+struct Pos {
+  double x, y, z;
+};
+struct Field {
+  double x, y, z;
+};
+
+__device__ __forceinline__ Vel beta_rate(double emcg, const Field& B, const Vel& b) {
+  return {emcg * (b.y * B.z - B.y), emcg * (B.x - b.x * B.z)};
+}
+
+template <bool FIL>
+__device__ __forceinline__ Pos traj_rate(double gamma, const Vel& b) {
+  double bz;
+  if (FIL) {
+    const double sm = 1. / (gamma * gamma) + b.x * b.x + b.y * b.y;
+    bz = 1. - 0.5 * sm - 0.125 * (sm * sm) - 0.0625 * (sm * sm * sm);
+  } else {
+    bz = -0.5 * (b.x * b.x + b.y * b.y);
+  }
+  return {b.x, b.y, bz};
+}
+
+__device__ __forceinline__ Vel vel_at(const Vel& b, double f, const Vel& k) {
+  return {b.x + f * k.x, b.y + f * k.y};
+}
+
+__device__ __forceinline__ double rk_mix(double k1, double k2, double k3, double k4) {
+  return (k1 + 2. * k2 + 2. * k3 + k4) / 6.;
+}
+
+// one Runge-Kutta step of the velocity (and, WITH_POS, of the position)
+template <bool FIL, bool WITH_POS>
+__device__ __forceinline__ void rk_step(double h, double emcg, double gamma, const Field& B0,
+                                        const Field& B1, const Field& B2, Vel& b, Pos& p) {
+  const Vel r1 = beta_rate(emcg, B0, b);
+  const Vel k1 = {h * r1.x, h * r1.y};
+  const Vel b2 = vel_at(b, 0.5, k1);
+  const Vel r2 = beta_rate(emcg, B1, b2);
+  const Vel k2 = {h * r2.x, h * r2.y};
+  const Vel b3 = vel_at(b, 0.5, k2);
+  const Vel r3 = beta_rate(emcg, B1, b3);
+  const Vel k3 = {h * r3.x, h * r3.y};
+  const Vel b4 = {b.x + k3.x, b.y + k3.y};
+  const Vel r4 = beta_rate(emcg, B2, b4);
+  const Vel k4 = {h * r4.x, h * r4.y};
+  if (WITH_POS) {
+    const Pos t1 = traj_rate<FIL>(gamma, b), t2 = traj_rate<FIL>(gamma, b2);
+    const Pos t3 = traj_rate<FIL>(gamma, b3), t4 = traj_rate<FIL>(gamma, b4);
+    p.x = p.x + rk_mix(h * t1.x, h * t2.x, h * t3.x, h * t4.x);
+    p.y = p.y + rk_mix(h * t1.y, h * t2.y, h * t3.y, h * t4.y);
+    p.z = p.z + rk_mix(h * t1.z, h * t2.z, h * t3.z, h * t4.z);
+  }
+  b.x = b.x + rk_mix(k1.x, k2.x, k3.x, k4.x);
+  b.y = b.y + rk_mix(k1.y, k2.y, k3.y, k4.y);
+}
+
+template <bool FIL>
+__global__ void trajectory_kernel(int64_t n, const double* __restrict__ wt,
+                                  const double* __restrict__ Bx, const double* __restrict__ By,
+                                  const double* __restrict__ Bz, double gamma, double emcg,
+                                  double* __restrict__ betax, double* __restrict__ betay,
+                                  double* __restrict__ trajx, double* __restrict__ trajy,
+                                  double* __restrict__ trajz, double* __restrict__ betam) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const double span = -(wt[n - 1] - wt[0]);
+  auto field = [&](int64_t j) { return Field{Bx[j], By[j], Bz[j]}; };
+  // sweep 1: velocity from rest; beta0 = -(its integral) / length
+  Vel b = {0., 0.}, b0 = {0., 0.};
+  Pos none = {0., 0., 0.};
+  for (int64_t i = 0; i + 1 < n; ++i) {
+    const double h = wt[i + 1] - wt[i];
+    rk_step<FIL, false>(h, emcg, gamma, field(2 * i), field(2 * i + 1), field(2 * i + 2), b,
+                        none);
+    b0.x += h * b.x;
+    b0.y += h * b.y;
+  }
+  b0.x /= span;
+  b0.y /= span;
+  // sweep 2: position from the origin; traj0 likewise, and the mean longitudinal term
+  b = b0;
+  Pos p = {0., 0., 0.}, p0 = {0., 0., 0.};
+  double bm = 0.;
+  for (int64_t i = 0; i + 1 < n; ++i) {
+    const double h = wt[i + 1] - wt[i];
+    rk_step<FIL, true>(h, emcg, gamma, field(2 * i), field(2 * i + 1), field(2 * i + 2), b, p);
+    p0.x += h * p.x;
+    p0.y += h * p.y;
+    p0.z += h * p.z;
+    if (FIL)
+      bm += h * sqrt(1. - 1. / (gamma * gamma) - b.x * b.x - b.y * b.y);
+    else
+      bm += b.x * b.x + b.y * b.y;
+  }
+  p0.x /= span;
+  p0.y /= span;
+  p0.z /= span;
+  if (FIL)
+    bm /= span;
+  else
+    bm *= -0.5 / (double)(n - 1);
+  *betam = bm;
+  // sweep 3: the tables
+  b = b0;
+  p = p0;
+  betax[0] = b.x;
+  betay[0] = b.y;
+  trajx[0] = p.x;
+  trajy[0] = p.y;
+  trajz[0] = p.z;
+  for (int64_t i = 0; i + 1 < n; ++i) {
+    const double h = wt[i + 1] - wt[i];
+    rk_step<FIL, true>(h, emcg, gamma, field(2 * i), field(2 * i + 1), field(2 * i + 2), b, p);
+    betax[i + 1] = b.x;
+    betay[i + 1] = b.y;
+    trajx[i + 1] = p.x;
+    trajy[i + 1] = p.y;
+    trajz[i + 1] = p.z;
+  }
+}
+}  // namespace
+
+hipError_t trajectory_launch(int filament, int64_t n, const double* wt, const double* Bx,
+                             const double* By, const double* Bz, double gamma, double emcg,
+                             double* betax, double* betay, double* trajx, double* trajy,
+                             double* trajz, double* betam, hipStream_t st) {
+  if (n < 2) return hipErrorInvalidValue;
+  if (filament)
+    hipLaunchKernelGGL(trajectory_kernel<true>, dim3(1), dim3(64), 0, st, n, wt, Bx, By, Bz,
+                       gamma, emcg, betax, betay, trajx, trajy, trajz, betam);
+  else
+    hipLaunchKernelGGL(trajectory_kernel<false>, dim3(1), dim3(64), 0, st, n, wt, Bx, By, Bz,
+                       gamma, emcg, betax, betay, trajx, trajy, trajz, betam);
+  return hipGetLastError();
+}
+
 }  // namespace xrt

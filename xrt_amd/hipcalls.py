@@ -250,6 +250,27 @@ CUSTOM_TABLES = ('tg', 'ag', 'Bx', 'By', 'Bz', 'betax', 'betay', 'trajx', 'trajy
                  'trajz')
 
 
+def trajectory(wt, Bx, By, Bz, gamma=None, emcg=1.):
+    """Electron trajectory through a field tabulated on the half-step grid of *wt*
+    (xrt_hip_trajectory_f64_dev) -> (betax, betay, trajx, trajy, trajz, betam) device
+    tensors; *gamma* given = a filament beam's electron (then *emcg* is its
+    e/(m c gamma) factor)."""
+    lib = _lib.load()
+    n = wt.numel()
+    dev = wt.device
+    outs = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(5)]
+    betam = torch.empty(1, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.xrt_hip_trajectory_f64_dev(
+            0 if gamma is None else 1, n, _f64(wt, n, 'wt'),
+            *[_f64(t, 2 * n - 1, name) for t, name in ((Bx, 'Bx'), (By, 'By'), (Bz, 'Bz'))],
+            0. if gamma is None else float(gamma), float(emcg),
+            *[ctypes.c_void_p(t.data_ptr()) for t in outs],
+            ctypes.c_void_p(betam.data_ptr()), _stream_ptr())
+    _lib.check(rc, 'xrt_hip_trajectory_f64_dev')
+    return tuple(outs) + (betam,)
+
+
 def custom_field(tables, emcg, gamma, w, ddphi, ddpsi, betam, filament=False, R0=None,
                  wc=0., timing=False):
     """Field sums of a tabulated-field source on device tensors
