@@ -591,6 +591,28 @@ XRT_HIP_API int xrt_hip_trajectory_f64_dev(int filament, int64_t n, const double
                                            double* trajy, double* trajz, double* betam,
                                            void* stream);
 
+/* Intensity and amplitude map of a bending magnet or a wiggler, BendingMagnet.build_I_map
+ * (sources/synchr.py:185-227; the reference has no accelerator path for it): per ray the
+ * photon energy E [eV] and the observation angles theta, psi [rad] -> flux I and the two
+ * field amplitudes (Es imaginary, Ep real, as the reference's). gamma_ray: per-ray electron
+ * gamma (energy spread) or NULL for the nominal one. */
+typedef struct xrt_hip_bend {
+  double gamma;            /* nominal Lorentz factor */
+  double B;                /* peak field [T] */
+  double K;                /* wiggler: deflection parameter */
+  double poles;            /* 2 Np (bending magnet: Np = 0.5 -> 1) */
+  double eI;               /* ring current [A] */
+  int32_t wiggler;         /* 1: critical energy varies with theta (isMPW) */
+  int32_t per_bandwidth;   /* 1: distE = 'BW' (per 0.1 % bandwidth), 0: per eV */
+} xrt_hip_bend;
+XRT_HIP_API int xrt_hip_bend_imap_f64_dev(const xrt_hip_bend* m, int64_t n, const double* E,
+                                          const double* theta, const double* psi,
+                                          const double* gamma_ray, double* I, double* Es_ri,
+                                          double* Ep_ri, void* stream);
+/* building block (GPU tests): modified Bessel functions K_{1/3}, K_{2/3} */
+XRT_HIP_API int xrt_hip_debug_bessel_k_f64_dev(int64_t n, const double* x, double* k13,
+                                               double* k23, void* stream);
+
 /* ---- timing without a host sync ------------------------------------------
  * xrt_hip_reflect_time_next_pass arms the NEXT xrt_hip_reflect_pass_f64_dev call of
  * this thread: it records pass_begin / pass_end around the whole pass and

@@ -184,5 +184,11 @@ class CustomField(ctypes.Structure):
                                         'betay', 'trajx', 'trajy', 'trajz')]
 
 
+class Bend(ctypes.Structure):
+    _fields_ = [('gamma', ctypes.c_double), ('B', ctypes.c_double), ('K', ctypes.c_double),
+                ('poles', ctypes.c_double), ('eI', ctypes.c_double),
+                ('wiggler', ctypes.c_int32), ('per_bandwidth', ctypes.c_int32)]
+
+
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
-           UndulatorMap, Plot, CustomField)
+           UndulatorMap, Plot, CustomField, Bend)

@@ -463,3 +463,4 @@ class GeometricSource(object):
 
 from .undulator import Undulator  # noqa: E402,F401  (needs Beam from this module)
 from .fieldsource import SourceFromField  # noqa: E402,F401
+from .bendsource import BendingMagnet, Wiggler  # noqa: E402,F401

@@ -249,6 +249,7 @@ int xrt_hip_sizeof(int which) {
     case 7: return (int)sizeof(xrt_hip_undulator_map);
     case 8: return (int)sizeof(xrt_hip_plot);
     case 9: return (int)sizeof(xrt_hip_custom_field);
+    case 10: return (int)sizeof(xrt_hip_bend);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -862,6 +863,26 @@ int xrt_hip_trajectory_f64_dev(int filament, int64_t n, const double* wt, const 
   if (filament && !(gamma > 0)) return fail(XRT_HIP_ERR_ARG, "filament trajectory needs gamma");
   HIP_TRY(xrt::trajectory_launch(filament, n, wt, Bx, By, Bz, gamma, emcg, betax, betay, trajx,
                                  trajy, trajz, betam, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_bend_imap_f64_dev(const xrt_hip_bend* m, int64_t n, const double* E,
+                              const double* theta, const double* psi, const double* gamma_ray,
+                              double* I, double* Es_ri, double* Ep_ri, void* stream) {
+  if (!m) return fail(XRT_HIP_ERR_ARG, "NULL magnet description");
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (n > 0 && (!E || !theta || !psi || !I || !Es_ri || !Ep_ri))
+    return fail(XRT_HIP_ERR_ARG, "NULL ray array");
+  if (m->wiggler && !(m->K != 0.)) return fail(XRT_HIP_ERR_ARG, "a wiggler needs K");
+  HIP_TRY(xrt::bend_imap_launch(*m, n, E, theta, psi, gamma_ray, I, Es_ri, Ep_ri,
+                                reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_debug_bessel_k_f64_dev(int64_t n, const double* x, double* k13, double* k23,
+                                   void* stream) {
+  if (n > 0 && (!x || !k13 || !k23)) return fail(XRT_HIP_ERR_ARG, "NULL array");
+  HIP_TRY(xrt::bessel_k_probe_launch(n, x, k13, k23, reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
 }
 

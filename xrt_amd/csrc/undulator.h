@@ -27,4 +27,9 @@ hipError_t trajectory_launch(int filament, int64_t n, const double* wt, const do
                              const double* By, const double* Bz, double gamma, double emcg,
                              double* betax, double* betay, double* trajx, double* trajy,
                              double* trajz, double* betam, hipStream_t st);
+hipError_t bend_imap_launch(const xrt_hip_bend& m, int64_t n, const double* E,
+                            const double* theta, const double* psi, const double* gamma,
+                            double* I, double* Es_ri, double* Ep_ri, hipStream_t st);
+hipError_t bessel_k_probe_launch(int64_t n, const double* x, double* k13, double* k23,
+                                 hipStream_t st);
 }

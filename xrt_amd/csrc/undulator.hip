@@ -614,4 +614,143 @@ hipError_t trajectory_launch(int filament, int64_t n, const double* wt, const do
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Bending magnet / wiggler: BendingMagnet.build_I_map (sources/synchr.py:185-227), an
+// elementwise map per (E, theta, psi) with the modified Bessel functions K_{1/3}, K_{2/3}
+// (scipy.special.kv in the reference).
+// ---------------------------------------------------------------------------
+namespace {
+constexpr double kPI = 3.1415926535897932384626433832795;
+// K_{1/3}(x) and K_{2/3}(x), x > 0: Temme's series below x = 2, Steed's continued fraction
+// above (the classical pair of methods for fractional order, with mu = -1/3 so that one
+// upward recurrence step gives the order 2/3); 1/Gamma(1 -+ mu) and their two combinations
+// are constants for this mu.
+__device__ __forceinline__ void bessel_k13_k23(double x, double& k13, double& k23) {
+  constexpr double MU = -1. / 3., MU2 = MU * MU;
+  constexpr double GAMPL = 0.7384881116216483129, GAMMI = 1.1198465217221856850;
+  constexpr double GAM1 = -0.5720376151508060581, GAM2 = 0.9291673166719169990;
+  constexpr double EPS = 1e-16;
+  if (!(x > 0.)) {
+    k13 = k23 = x == 0. ? INFINITY : NAN;
+    return;
+  }
+  if (x > 705.) {  // exp(-x) underflows what the prefactors can bring back
+    k13 = k23 = 0.;
+    return;
+  }
+  const double xi = 1. / x, xi2 = 2. * xi;
+  if (x < 2.) {
+    const double x2 = 0.5 * x, pimu = kPI * MU;
+    const double fact = pimu / sin(pimu);
+    double d = -log(x2);
+    double e = MU * d;
+    const double fact2 = fabs(e) < EPS ? 1. : sinh(e) / e;
+    double ff = fact * (GAM1 * cosh(e) + GAM2 * fact2 * d);
+    double sum = ff;
+    e = exp(e);
+    double p = 0.5 * e / GAMPL, q = 0.5 / (e * GAMMI), c = 1.;
+    d = x2 * x2;
+    double sum1 = p;
+    for (int i = 1; i <= 500; ++i) {
+      ff = (i * ff + p + q) / (i * (double)i - MU2);
+      c *= d / i;
+      p /= i - MU;
+      q /= i + MU;
+      const double del = c * ff;
+      sum += del;
+      sum1 += c * (p - i * ff);
+      if (fabs(del) < fabs(sum) * EPS) break;
+    }
+    k13 = sum;
+    k23 = sum1 * xi2;
+    return;
+  }
+  double b = 2. * (1. + x), d = 1. / b, h = d, delh = d, q1 = 0., q2 = 1.;
+  const double a1 = 0.25 - MU2;
+  double q = a1, c = a1, a = -a1, sc = 1. + q * delh;
+  for (int i = 2; i <= 500; ++i) {
+    a -= 2 * (i - 1);
+    c = -a * c / i;
+    const double qnew = (q1 - b * q2) / a;
+    q1 = q2;
+    q2 = qnew;
+    q += c * qnew;
+    b += 2.;
+    d = 1. / (b + a * d);
+    delh = (b * d - 1.) * delh;
+    h += delh;
+    const double dels = q * delh;
+    sc += dels;
+    if (fabs(dels / sc) < EPS) break;
+  }
+  h = a1 * h;
+  k13 = sqrt(kPI / (2. * x)) * exp(-x) / sc;
+  k23 = k13 * (MU + x + 0.5 - h) * xi;
+}
+
+__global__ __launch_bounds__(256) void bend_imap(xrt_hip_bend m, int64_t n,
+                                                 const double* __restrict__ E,
+                                                 const double* __restrict__ theta,
+                                                 const double* __restrict__ psi,
+                                                 const double* __restrict__ gamma_ray,
+                                                 double* __restrict__ I,
+                                                 double2* __restrict__ Es,
+                                                 double2* __restrict__ Ep) {
+  constexpr double SQ3 = 1.7320508075688772935, E2W = 1519267514747457.9195;
+  constexpr double SIE0 = 1.602176565e-19, SIM0 = 9.109383701528e-31;
+  constexpr double FINE_STR = 1 / 137.03599976;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double gamma = gamma_ray ? gamma_ray[i] : m.gamma;
+  const double e = E[i];
+  double w_cr = 1.5 * (gamma * gamma) * m.B * SIE0 / SIM0;
+  if (m.wiggler) {  // the field the electron sees where it points along theta
+    const double arg = theta[i] * gamma / m.K;
+    const double under = 1. - arg * arg;
+    w_cr *= sqrt(under > 0. ? under : 0.);
+  }
+  if (!isfinite(w_cr)) w_cr = 0.;
+  const double gpsi = gamma * psi[i];
+  const double g2p1 = gpsi * gpsi + 1.;
+  const double eta = 0.5 * e * E2W / w_cr * (g2p1 * sqrt(g2p1));
+  const double pref = -0.5 * SQ3 / kPI * gamma * e * E2W / w_cr * g2p1;  // ampSP = i pref
+  double k13, k23;
+  bessel_k13_k23(eta, k13, k23);
+  double as = pref * k23;                        // ampS = i as
+  double ap = -gpsi * pref * k13 / sqrt(g2p1);   // ampP = ap
+  if (!isfinite(as)) as = 0.;
+  if (!isfinite(ap)) ap = 0.;
+  const double flux = FINE_STR * (m.per_bandwidth ? 0.001 : 1. / e) * m.eI / SIE0 * m.poles;
+  const double root = sqrt(flux);
+  I[i] = flux * (as * as + ap * ap);
+  Es[i] = make_double2(0., root * as);
+  Ep[i] = make_double2(root * ap, 0.);
+}
+
+__global__ __launch_bounds__(256) void bessel_k_probe(int64_t n, const double* __restrict__ x,
+                                                      double* __restrict__ k13,
+                                                      double* __restrict__ k23) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) bessel_k13_k23(x[i], k13[i], k23[i]);
+}
+}  // namespace
+
+hipError_t bend_imap_launch(const xrt_hip_bend& m, int64_t n, const double* E,
+                            const double* theta, const double* psi, const double* gamma,
+                            double* I, double* Es_ri, double* Ep_ri, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bend_imap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m, n, E,
+                     theta, psi, gamma, I, reinterpret_cast<double2*>(Es_ri),
+                     reinterpret_cast<double2*>(Ep_ri));
+  return hipGetLastError();
+}
+
+hipError_t bessel_k_probe_launch(int64_t n, const double* x, double* k13, double* k23,
+                                 hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bessel_k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, x,
+                     k13, k23);
+  return hipGetLastError();
+}
+
 }  // namespace xrt

@@ -271,6 +271,40 @@ def trajectory(wt, Bx, By, Bz, gamma=None, emcg=1.):
     return tuple(outs) + (betam,)
 
 
+def bend_imap(E, theta, psi, gamma0, B, eI, poles=1., K=0., wiggler=False, per_bandwidth=True,
+              gamma=None):
+    """Flux and amplitudes of a bending magnet / wiggler per ray
+    (xrt_hip_bend_imap_f64_dev) -> (I, Es, Ep) device tensors."""
+    from ._structs import Bend
+    lib = _lib.load()
+    n = E.numel()
+    dev = E.device
+    m = Bend(float(gamma0), float(B), float(K), float(poles), float(eI),
+             1 if wiggler else 0, 1 if per_bandwidth else 0)
+    I = torch.empty(n, dtype=torch.float64, device=dev)
+    Es = torch.empty(n, dtype=torch.complex128, device=dev)
+    Ep = torch.empty(n, dtype=torch.complex128, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.xrt_hip_bend_imap_f64_dev(
+            ctypes.byref(m), n, _f64(E, n, 'E'), _f64(theta, n, 'theta'), _f64(psi, n, 'psi'),
+            None if gamma is None else _f64(gamma, n, 'gamma'),
+            ctypes.c_void_p(I.data_ptr()), _c128(Es, n, 'Es'), _c128(Ep, n, 'Ep'),
+            _stream_ptr())
+    _lib.check(rc, 'xrt_hip_bend_imap_f64_dev')
+    return I, Es, Ep
+
+
+def debug_bessel_k(x):
+    lib = _lib.load()
+    n = x.numel()
+    k13, k23 = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.xrt_hip_debug_bessel_k_f64_dev(
+            n, _f64(x, n, 'x'), ctypes.c_void_p(k13.data_ptr()),
+            ctypes.c_void_p(k23.data_ptr()), _stream_ptr()), 'xrt_hip_debug_bessel_k_f64_dev')
+    return k13, k23
+
+
 def custom_field(tables, emcg, gamma, w, ddphi, ddpsi, betam, filament=False, R0=None,
                  wc=0., timing=False):
     """Field sums of a tabulated-field source on device tensors
