@@ -251,3 +251,40 @@ def test_two_threads_on_their_own_streams_equal_the_serial_run():
         for key, a in serial[seed].items():
             assert np.array_equal(a, threaded[seed][key], equal_nan=True), (seed, key)
     assert not np.array_equal(serial[3][('lb', 'x')], serial[4][('lb', 'x')])
+
+
+def test_run_ray_tracing_with_worker_threads_sums_the_same_histograms():
+    """threads=3: three run_process calls in flight per step (own streams), the plots'
+    copies summed -- with beams that do not depend on the draw order (the source beam is
+    made once) the result equals the single-threaded run's."""
+    bl = build()
+    np.random.seed(5)
+    fixed = bl.src.shine()
+    calls = []
+
+    def run_process(beamLine):
+        b0 = rs.Beam(copyFrom=fixed)
+        gb, lb = beamLine.m1.reflect(b0)
+        img = beamLine.scr.expose(gb)
+        calls.append(1)
+        return {'beamM1local': lb, 'beamScreen': img}
+    rr.run_process = run_process
+
+    def plots():
+        return [xrtp.XYCPlot('beamM1local', (1,), xrtp.XYCAxis('x', 'mm', bins=64),
+                             xrtp.XYCAxis('y', 'mm', limits=[-300, 300], bins=48)),
+                xrtp.XYCPlot('beamScreen', (1, 3), xrtp.XYCAxis('x', u'µm', limits=[-400, 400],
+                                                                bins=100),
+                             xrtp.XYCAxis("z'", u'µrad', bins=32), fluxKind='s')]
+    one = xrtr.run_ray_tracing(plots(), repeats=7, beamLine=bl)
+    assert len(calls) == 7
+    many = xrtr.run_ray_tracing(plots(), repeats=7, beamLine=bl, threads=3)
+    assert len(calls) == 14
+    for a, b in zip(one, many):
+        assert a.iteration == b.iteration == 7 and a.nRaysAll == b.nRaysAll
+        assert a.xaxis.limits == b.xaxis.limits
+        assert np.abs(a.total2D - b.total2D).max() <= 1e-12 * a.total2D.max()
+        assert np.abs(a.total2D_RGB - b.total2D_RGB).max() <= 1e-12 * a.total2D_RGB.max()
+        assert abs(a.intensity - b.intensity) <= 1e-12 * a.intensity
+        assert a.nRaysGood == b.nRaysGood and a.nRaysSelected == b.nRaysSelected
+        assert np.allclose(a.total1D_x, b.total1D_x, rtol=1e-12, atol=0)

@@ -213,10 +213,12 @@ class OE(object):
         several = raycing.is_sequence(self.order)
         p.grating, p.grating_order = 1, int(self.order[0] if several else self.order)
         if hasattr(self, 'rn'):           # zone plate: the zone radii instead of a groove vector
-            cached = getattr(self, '_zone_table', None)     # kept in HBM for the kernels
+            held = self.__dict__.setdefault('_zone_table', {})     # in HBM, per device
+            cached = held.get(str(_device()))
             if cached is None or cached[0] is not self.rn:
                 table = np.ascontiguousarray(self.rn, dtype=np.float64)
-                self._zone_table = cached = (self.rn, torch.from_numpy(table.copy()).to(_device()))
+                cached = held[str(_device())] = (
+                    self.rn, torch.from_numpy(table.copy()).to(_device()))
             p.grating, p.grating_axis = 2, -1
             p.zone_n, p.zone_black = len(self.rn) - 1, int(bool(self.isCentralZoneBlack))
             p.zone_r = cached[1].data_ptr()
@@ -304,9 +306,11 @@ class OE(object):
         if not isinstance(self.shape, str):
             # outline of the optical surface as (x, y) vertices: kept in HBM for the kernels
             outline = np.ascontiguousarray(self.shape, dtype=np.float64).reshape(-1, 2)
-            cached = getattr(self, '_outline', None)
+            held = self.__dict__.setdefault('_outline', {})        # per device
+            cached = held.get(str(_device()))
             if cached is None or not np.array_equal(cached[0], outline):
-                self._outline = cached = (outline, torch.from_numpy(outline.copy()).to(_device()))
+                cached = held[str(_device())] = (
+                    outline, torch.from_numpy(outline.copy()).to(_device()))
             p.shape, p.poly_n, p.poly_xy = _structs.SHAPE_POLYGON, len(outline), \
                 cached[1].data_ptr()
         elif self.shape[:2] in shapes:

@@ -74,6 +74,29 @@ class XYCPlot(object):
         self.intensityInRange = 0.   # ... of those inside the plot limits
         self.iteration = 0
 
+    _COUNTERS = ('nRaysAll', 'nRaysSelected', 'nRaysAlive', 'nRaysGood', 'nRaysOut',
+                 'nRaysOver', 'nRaysDead', 'intensity', 'intensityInRange', 'iteration')
+
+    def spawn(self):
+        """An empty accumulator with this plot's settings (axes copied, limits as they are
+        now): what a worker of run_ray_tracing fills."""
+        import copy
+        twin = copy.copy(self)
+        twin.xaxis, twin.yaxis, twin.caxis = (copy.copy(a) for a in
+                                              (self.xaxis, self.yaxis, self.caxis))
+        twin.reset_bins2D()
+        return twin
+
+    def absorb(self, other):
+        """Adds a worker's histograms and counters to this plot."""
+        self.total2D += other.total2D
+        self.total2D_RGB += other.total2D_RGB
+        for mine, theirs in ((self.xaxis, other.xaxis), (self.yaxis, other.yaxis),
+                             (self.caxis, other.caxis)):
+            mine.total1D4 += theirs.total1D4
+        for name in self._COUNTERS:
+            setattr(self, name, getattr(self, name) + getattr(other, name))
+
     @property
     def flux_kind_code(self):
         # same precedence as raycing.get_output: 'power' before 'p'

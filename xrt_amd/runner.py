@@ -4,9 +4,15 @@ xrt/multipro.py:235-373) for the accelerated backend: calls the user's
 plot's histogram and ray counters. The histogram reduce runs on the GPU on the
 resident beams (csrc/hist.hip), so only bins cross PCIe.
 
-Threads/processes are not used: one process drives one GPU (the reference warns
-that OpenCL and processes>1 cannot be combined, runner.py:560-564)."""
+*threads* (or *processes*: one process can drive every GPU, so both mean the same here)
+= that many ``run_process`` calls in flight, as the reference starts that many workers per
+step (xrt/runner.py:248-330): each worker is a Python thread with its own HIP stream, on
+the visible GPUs in turn, filling its own copy of the plots; the copies are summed in the
+order of the iterations. While any plot limit is still automatic the first iteration runs
+alone, as in the reference (its ``uniqueFirstRun``). numpy's global generator is shared
+by the workers (as it is by the reference's threads): reproducible runs use 1 thread."""
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -100,6 +106,36 @@ def accumulate_plot(plot, beams):
     plot.iteration += 1
 
 
+def _parallel_iterations(plots, beamLine, count):
+    """*count* iterations at once: one thread each, own stream, GPUs in turn."""
+    ndev = torch.cuda.device_count()
+    results, errors = [None] * count, []
+
+    def work(k):
+        try:
+            with torch.cuda.device(k % ndev):
+                stream = torch.cuda.Stream()
+                with torch.cuda.stream(stream):
+                    mine = [p.spawn() for p in plots]
+                    beams = rr.run_process(beamLine)
+                    for plot in mine:
+                        accumulate_plot(plot, beams)
+                    stream.synchronize()
+            results[k] = mine
+        except BaseException as e:   # noqa: BLE001  (re-raised in the caller's thread)
+            errors.append(e)
+    pool = [threading.Thread(target=work, args=(k,)) for k in range(count)]
+    for t in pool:
+        t.start()
+    for t in pool:
+        t.join()
+    if errors:
+        raise errors[0]
+    for mine in results:
+        for plot, part in zip(plots, mine):
+            plot.absorb(part)
+
+
 def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
                     energyRange=None, backend='raycing', beamLine=None, threads=1,
                     processes=1, generator=None, generatorArgs=[],
@@ -113,11 +149,20 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
     if not isinstance(plots, (list, tuple)):
         plots = [plots]
 
+    workers = max(int(threads), int(processes), 1)
+
     def one_scan():
-        for _ in range(int(repeats)):
-            beams = rr.run_process(beamLine)
-            for plot in plots:
-                accumulate_plot(plot, beams)
+        left = int(repeats)
+        while left > 0:
+            auto = any(a.limits is None for p in plots for a in (p.xaxis, p.yaxis, p.caxis))
+            batch = 1 if (auto or workers == 1) else min(workers, left)
+            if batch == 1:
+                beams = rr.run_process(beamLine)
+                for plot in plots:
+                    accumulate_plot(plot, beams)
+            else:
+                _parallel_iterations(plots, beamLine, batch)
+            left -= batch
 
     if generator is None:
         one_scan()
