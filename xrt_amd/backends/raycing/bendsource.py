@@ -13,7 +13,7 @@ import torch
 
 from .. import raycing
 from ... import hipcalls
-from .physconsts import C, CHeVcm, E0, K2B, M0, PI, PI2, SIE0
+from .physconsts import C, CHeVcm, E0, EV2ERG, K2B, M0, PI, PI2, SIE0
 from .sources import Beam
 from .undulator import Undulator, _concatenate
 
@@ -270,7 +270,33 @@ class Wiggler(BendingMagnet):
         self.X0 = 0.5 * K * self.L0 / self.gamma / PI
         self.xPrimeMaxAutoReduce = True      # to the K / gamma fan
 
-    K = property(lambda self: self._K)
+    @property
+    def K(self):
+        return self._K
+
+    @K.setter
+    def K(self, value):
+        """As the reference's setter (synchr.py:568-576): K, the orbit amplitude and the
+        radius follow; the field B that the critical energy is computed from stays."""
+        self._K = float(value)
+        self.ro = self._bend(self.B)
+        self.X0 = 0.5 * value * self.L0 / self.gamma / PI
+        self.needReset = True
+
+    def power_vs_K(self, energy, theta, psi, Ks):
+        """Total power [W] through the aperture per K of *Ks* (synchr.py:581-609)."""
+        energy = np.asarray(energy)
+        volume = (theta[1] - theta[0]) * (psi[1] - psi[0]) * (energy[1] - energy[0]) \
+            if np.ndim(theta) else 1
+        keep, powers = self.K, []
+        for K in Ks:
+            self.K = K
+            self.reset()
+            flux = self.intensities_on_mesh(energy, theta, psi)[0]
+            flux = flux * 1e3 if self.distE == 'BW' else flux * energy[:, None, None]
+            powers.append(flux.sum() * volume * EV2ERG * 1e-7)
+        self.K = keep
+        return np.array(powers)
     period = property(lambda self: self.L0)
     n = property(lambda self: self.Np)
 

@@ -11,8 +11,9 @@ node sum, scaling). There is no numpy implementation of the integral here: witho
 the GPU library ``build_I_map`` raises.
 
 Not mirrored (raise NotImplementedError / absent): custom magnetic field
-(``SourceFromField``), ``multi_electron_stack``, ``intensities_on_mesh``,
-``power_vs_K``, ``tuning_curves``, the Qt flow hooks.
+(``SourceFromField``: fieldsource.py), the Qt flow hooks. The mesh functions
+(``intensities_on_mesh``, ``multi_electron_stack``, ``tuning_curves``, ``power_vs_K``) are in
+meshes.py.
 """
 import numpy as np
 import torch
@@ -23,6 +24,7 @@ from ... import hipcalls
 from .physconsts import (PI, PI2, C, EV2ERG, CHeVcm, CHBAR, M0, K2B, E2WC, SIE0,
                          SQ2, SQPI)
 from .sources import Beam
+from .meshes import MeshFunctions
 
 UND_FAR, UND_TAPER, UND_NF = 0, 1, 2
 
@@ -55,7 +57,7 @@ def clenshaw_curtis(n):
     return x, c / N * S
 
 
-class Undulator(object):
+class Undulator(MeshFunctions):
     def __init__(self, bl=None, name='GenericSource', center=(0, 0, 0),
                  nrays=raycing.nrays, eE=6.0, eI=0.1, eEspread=0., eSigmaX=None,
                  eSigmaZ=None, eEpsilonX=1., eEpsilonZ=0.01, betaX=9., betaZ=2.,
@@ -64,7 +66,8 @@ class Undulator(object):
                  yaw=0, period=50, n=50, K=1, Kx=0, Ky=0, B0x=0, B0y=0, phaseDeg=0,
                  taper=None, targetE=None, xPrimeMaxAutoReduce=True,
                  zPrimeMaxAutoReduce=True, gp=1e-6, gIntervals=2, gNodes=None,
-                 targetOpenCL='auto', precisionOpenCL='auto', device=None, **kwargs):
+                 targetOpenCL='auto', precisionOpenCL='auto', device=None, eN=51, nx=25,
+                 nz=25, **kwargs):
         """Arguments as the reference's ``Undulator`` (synchr.py:1362-1435,
         sybase.py:34-190, 940-1030); *targetOpenCL*/*precisionOpenCL* are
         accepted and ignored (the integral always runs in fp64 on the GPU);
@@ -83,6 +86,7 @@ class Undulator(object):
             setattr(self, key, given[key])
         for key in ('eE', 'eI', 'eMin', 'eMax'):
             setattr(self, key, float(given[key]))
+        self.eN, self.nx, self.nz = eN, nx, nz         # the default meshes of meshes.py
         self.pitch, self.yaw = (raycing.auto_units_angle(v) for v in (pitch, yaw))
         self.nrays = np.int64(nrays)
         # Lorentz factor of the electrons
@@ -241,6 +245,9 @@ class Undulator(object):
         self.Psi_max = float(zpMax + self.dzprime)
         self.E_min = float(min(self.eMin, self.eMax))
         self.E_max = float(max(self.eMin, self.eMax))
+        self.dE = (self.E_max - self.E_min) / float(self.eN)
+        self.dTheta = (self.Theta_max - self.Theta_min) / float(2*self.nx)
+        self.dPsi = (self.Psi_max - self.Psi_min) / float(2*self.nz)
 
     # ---- integration grid ----------------------------------------------------
     def _build_integration_grid(self):
@@ -405,6 +412,17 @@ class Undulator(object):
             gamma = g * np.ones(n)
         if self.convergenceSearchFlag:
             return self._bare_field(w, th, ps, gamma)
+        if harmonic is not None and np.ndim(harmonic):
+            # a harmonic per ray (mesh functions): one launch per distinct value
+            harmonic = np.asarray(harmonic) * np.ones(n)
+            out = (np.zeros(n), np.zeros(n, dtype=complex), np.zeros(n, dtype=complex))
+            for h in np.unique(harmonic):
+                sel = harmonic == h
+                part = self.build_I_map_device(w[sel], th[sel], ps[sel], float(h),
+                                               None if gamma is None else gamma[sel])
+                for whole, piece in zip(out, part):
+                    whole[sel] = piece.cpu().numpy()
+            return out
         I, Es, Ep = self.build_I_map_device(w, th, ps, harmonic, gamma)
         return I.cpu().numpy(), Es.cpu().numpy(), Ep.cpu().numpy()
 
