@@ -562,6 +562,10 @@ typedef struct xrt_hip_custom_field {
                        from w, gamma, betam as _sp_sum does */
   int64_t jend;
   const double *tg, *ag, *Bx, *By, *Bz, *betax, *betay, *trajx, *trajy, *trajz;
+  int32_t carrier_form; /* 0: the carrier of the summing form _sp_sum (what the reference takes
+                           for more than 10 rays); 1: that of its vectorised form _sp (10 rays
+                           or fewer: the node-number search), synchr.py:813-816 vs :901-902 */
+  int32_t reserved;
 } xrt_hip_custom_field;
 
 XRT_HIP_API int xrt_hip_custom_field_f64_dev(

@@ -109,5 +109,38 @@ def main():
             seed=np.int64(11), reference_seconds=np.float64(seconds), **beam_arrays(beam))
 
 
+def node_search():
+    """g13_nodes: the automatic search for the number of nodes (gNodes=None) -- the number
+    found, and the probe value |field| dstep / 2 of one ray at the edge of the ranges (ten
+    rays or fewer go through the reference's vectorised form _sp -- which, without a filament
+    beam, only runs for ONE ray: its per-ray factor does not broadcast against the nodes)."""
+    _refenv.activate()
+    import xrt.backends.raycing as raycing
+    import xrt.backends.raycing.sources as rs
+    raycing._VERBOSITY_ = 0
+    field = tabulated_field()
+    out = {}
+    for tag, kw in (('plain', {}), ('filament', dict(filamentBeam=True))):
+        cfg = dict(SOURCE, gp=1e-6, gIntervals=6, **kw)
+        cfg.pop('gNodes')
+        s = rs.SourceFromField(raycing.BeamLine(), name='sff', targetOpenCL=None,
+                               customField=field, **cfg)
+        np.random.seed(5)
+        t0 = time.perf_counter()
+        s.reset()
+        seconds = time.perf_counter() - t0
+        s.convergenceSearchFlag = True
+        probe = s.build_I_map(s.E_max * np.ones(1), s.Theta_max * np.ones(1),
+                              s.Psi_max * np.ones(1))
+        s.convergenceSearchFlag = False
+        print('node search', tag, 'quadm', s.quadm, '%.1f s' % seconds, 'probe', probe)
+        out.update({tag + '_quadm': np.int64(s.quadm), tag + '_probe': np.array(probe),
+                    tag + '_seconds': np.float64(seconds)})
+    np.savez_compressed(os.path.join(OUT, 'g13_nodes.npz'), field=field, **out)
+
+
 if __name__ == '__main__':
+    if 'nodes' in os.sys.argv[1:]:
+        node_search()
+        raise SystemExit
     main()

@@ -99,12 +99,30 @@ def test_shine_returns_the_references_rays(golden_dir, tag):
 
 
 def test_requests_outside_the_mirrored_part_fail_loudly(golden_dir):
-    g = np.load(os.path.join(golden_dir, 'g13_sff_rays.npz'))
     with pytest.raises(NotImplementedError):
         rs.SourceFromField(raycing.BeamLine(), 'a', **SOURCE)
-    with pytest.raises(NotImplementedError):
-        rs.SourceFromField(raycing.BeamLine(), 'b', customField=np.array(g['field']),
-                           **dict(SOURCE, gNodes=None))
+
+
+@pytest.mark.parametrize('tag', ['plain', 'filament'])
+def test_automatic_number_of_nodes(golden_dir, tag):
+    """gNodes=None: doubling + bisection until the probe ray's field is stable to *gp*; the
+    probe calls (ten rays or fewer) use the carrier of the reference's vectorised form."""
+    g = np.load(os.path.join(golden_dir, 'g13_nodes.npz'))
+    cfg = dict(SOURCE, gp=1e-6, gIntervals=6, filamentBeam=(tag == 'filament'))
+    cfg.pop('gNodes')
+    src = rs.SourceFromField(raycing.BeamLine(), 'sff', customField=np.array(g['field']), **cfg)
+    np.random.seed(5)
+    t0 = time.perf_counter()
+    src.reset()
+    seconds = time.perf_counter() - t0
+    assert src.quadm == int(g[tag + '_quadm'])
+    src.convergenceSearchFlag = True
+    probe = src.build_I_map(src.E_max * np.ones(1), src.Theta_max * np.ones(1),
+                            src.Psi_max * np.ones(1))
+    src.convergenceSearchFlag = False
+    assert abs(probe[0] - g[tag + '_probe'][0]) <= 1e-10 * g[tag + '_probe'][0]
+    print('node search (%s): %d nodes in %.2f s (the reference: %.1f s)' % (
+        tag, src.quadm, seconds, float(g[tag + '_seconds'])))
 
 
 @pytest.mark.parametrize('tag', ['plain', 'filament'])

@@ -181,7 +181,8 @@ class CustomField(ctypes.Structure):
                 ('wc', ctypes.c_double),
                 ('jend', ctypes.c_int64)] + \
         [(k, ctypes.c_void_p) for k in ('tg', 'ag', 'Bx', 'By', 'Bz', 'betax',
-                                        'betay', 'trajx', 'trajy', 'trajz')]
+                                        'betay', 'trajx', 'trajy', 'trajz')] + \
+        [('carrier_form', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 class Bend(ctypes.Structure):

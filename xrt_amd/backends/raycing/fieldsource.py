@@ -14,10 +14,11 @@ per such pair, not once per batch of rays. Cubic splines (field table -> grids, 
 polarisation are the host code shared with ``Undulator`` (numpy RNG in the reference's
 order, so a seed gives the reference's rays).
 
-Not mirrored: the automatic search for the number of nodes (``gNodes=None``: the reference
-switches to a second formulation of the integrand for its <= 10 probe rays, synchr.py:1327-
-1335, whose carrier frequency differs from the summing form's), the built-in periodic test
-field (``customField=None``), Excel input.
+Calls of ten rays or fewer (the probe rays of the automatic search for the number of
+nodes, ``gNodes=None``) take the carrier frequency of the reference's second, vectorised
+formulation of the integrand, as the reference does (synchr.py:1327-1335; the two differ
+in nothing else). Not mirrored: the built-in periodic test field (``customField=None``),
+Excel input.
 """
 import numpy as np
 import torch
@@ -37,15 +38,12 @@ class SourceFromField(Undulator):
         """*customField*: the field table as an array or the name of a text file (or a
         pair (name, keyword dictionary for ``numpy.loadtxt``)): columns = longitudinal
         coordinate [mm], then B_ver, or B_hor and B_ver, or B_hor, B_ver and B_long [T].
-        The other arguments are the electron-beam, energy-range and angular-range
-        arguments of ``Undulator``; *gNodes* (nodes per integration interval) is needed."""
+        The other arguments are the electron-beam, energy-range, angular-range and
+        quadrature (*gNodes*, *gIntervals*, *gp*) arguments of ``Undulator``."""
         table = kwargs.pop('customField', None)
         if table is None:
             raise NotImplementedError('SourceFromField needs a customField table (the '
                                       "reference's periodic test field is not mirrored)")
-        if kwargs.get('gNodes') is None:
-            raise NotImplementedError('SourceFromField: give gNodes (the automatic node '
-                                      'search is not mirrored)')
         kwargs.update(K=1., xPrimeMaxAutoReduce=False, zPrimeMaxAutoReduce=False)
         Undulator.__init__(self, *args, **kwargs)
         for undulator_only in ('Kx', 'Ky', 'L0', 'Np', 'phase', 'targetE'):
@@ -64,6 +62,7 @@ class SourceFromField(Undulator):
     @customField.setter
     def customField(self, table):
         self._customField = table
+        self._grid_paths = {}
         if isinstance(table, np.ndarray):
             self.customFieldData = table
         else:
@@ -138,8 +137,6 @@ class SourceFromField(Undulator):
         self.dstep = dstep
         self._trajectories = {}
 
-    def _reset_integration_grid(self):
-        self._build_integration_grid()
 
     # ---- trajectory: one kernel, cached ---------------------------------------------------
     def build_trajectory(self, Bx, By, Bz, gamma=None):
@@ -149,13 +146,16 @@ class SourceFromField(Undulator):
 
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
-        if self.filamentBeam:
-            g = float(self.gamma if gamma is None else gamma)
-            out = hipcalls.trajectory(up(self.wtGrid), up(Bx), up(By), up(Bz), gamma=g,
-                                      emcg=SIE0 / SIM0 / C / 10. / g)
-        else:
-            out = hipcalls.trajectory(up(self.wtGrid), up(Bx), up(By), up(Bz))
-        on_grid = [t.cpu().numpy() for t in out]
+        g = float(self.gamma if gamma is None else gamma) if self.filamentBeam else None
+        key = (id(self.customFieldData), g)
+        on_grid = self._grid_paths.get(key)      # the grid does not depend on the nodes
+        if on_grid is None:
+            if g is not None:
+                out = hipcalls.trajectory(up(self.wtGrid), up(Bx), up(By), up(Bz), gamma=g,
+                                          emcg=SIE0 / SIM0 / C / 10. / g)
+            else:
+                out = hipcalls.trajectory(up(self.wtGrid), up(Bx), up(By), up(Bz))
+            on_grid = self._grid_paths[key] = [t.cpu().numpy() for t in out]
         on_nodes = [interp1d(self.wtGrid, a, **_CUBIC)(self.tg) for a in on_grid[:5]]
         return on_nodes[0], on_nodes[1], [float(on_grid[5][0])], on_nodes[2], on_nodes[3], \
             on_nodes[4]
@@ -217,7 +217,8 @@ class SourceFromField(Undulator):
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
         Is, Ip = hipcalls.custom_field(
             tables, up(emcg), up(gamma), up(w), up(theta), up(psi), betam,
-            filament=bool(self.filamentBeam), R0=self.R0 if self.R0 else None)
+            filament=bool(self.filamentBeam), R0=self.R0 if self.R0 else None,
+            carrier_form=0 if n > 10 else 1)
         Is, Ip = Is.cpu().numpy(), Ip.cpu().numpy()
         bandwidth = 0.001 if self.distE == 'BW' else 1./w
         to_flux = FINE_STR * bandwidth * self.eI / SIE0

@@ -287,9 +287,10 @@ cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
   const double revg2 = 1. / (g * g);
   const double emc2 = EMC_ * EMC_;
   // sic: the two carrier formulas are swapped w.r.t. the vectorised _sp
-  const double wc = FIL ? (a.wc > 0. ? a.wc
-                                     : (w * E2WC_) / (1. + (a.betam * emc2 - 0.5) * revg2))
-                        : (w * E2WC_) / a.betam;
+  const double by_mean = (w * E2WC_) / a.betam;
+  const double by_gamma = (w * E2WC_) / (1. + (a.betam * emc2 - 0.5) * revg2);
+  const double wc = a.carrier_form ? (FIL ? by_mean : by_gamma)   // the vectorised _sp
+                                   : (FIL ? (a.wc > 0. ? a.wc : by_gamma) : by_mean);
   const double zfac = 1. - 0.5 * revg2;     // non-filament trajz_
   const double tfac = emc2 * revg2;
   double r0x = 0., r0y = 0., r0z = 0., sr0 = 0., cr0 = 0.;

@@ -306,7 +306,7 @@ def debug_bessel_k(x):
 
 
 def custom_field(tables, emcg, gamma, w, ddphi, ddpsi, betam, filament=False, R0=None,
-                 wc=0., timing=False):
+                 wc=0., timing=False, carrier_form=0):
     """Field sums of a tabulated-field source on device tensors
     (xrt_hip_custom_field_f64_dev). tables: dict or sequence of the ten node
     tables in CUSTOM_TABLES order. Returns (Is, Ip[, kernel ms])."""
@@ -323,6 +323,7 @@ def custom_field(tables, emcg, gamma, w, ddphi, ddpsi, betam, filament=False, R0
     f.betam = float(betam)
     f.R0 = 0. if R0 is None else float(R0)
     f.wc = float(wc)
+    f.carrier_form = int(carrier_form)
     f.jend = jend
     for name, t in zip(CUSTOM_TABLES, tables):
         setattr(f, name, _f64(t, jend, name).value)
