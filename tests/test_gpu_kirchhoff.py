@@ -294,7 +294,7 @@ def test_run_parallel_dropin(devices):
     res = cl2.run_parallel('integrate_kirchhoff', sa, sro, nsro, srw, None, len(case[0]))
     assert_close(res, ref)
     with pytest.raises(NotImplementedError):
-        cl.run_parallel('get_trajectory', [], [], [], [], None, 1)
+        cl.run_parallel('undulator_nf_byparts', [], [], [], [], None, 1)   # no caller in the reference
 
 
 # ---- BASELINE-size properties (the oracle cannot run these sizes) -----------
