@@ -13,7 +13,7 @@ import torch
 
 from .. import raycing
 from ... import hipcalls
-from .physconsts import C, CHeVcm, E0, EV2ERG, K2B, M0, PI, PI2, SIE0
+from .physconsts import C, CHeVcm, E0, EV2ERG, K2B, M0, PI, PI2
 from .sources import Beam
 from .undulator import Undulator, _concatenate
 
@@ -94,7 +94,7 @@ class BendingMagnet(Undulator):
     # ---- sampling -----------------------------------------------------------------------
     def _filament_electron(self, accuBeam):
         """The one electron of a filament beam: energy, emission point, angular offsets.
-        Draws (no accuBeam): E uniform; wiggler: theta0 uniform, pole (random_integers),
+        Draws (no accuBeam): E uniform; wiggler: theta0 uniform, pole (integer),
         x normal, z normal; magnet: z normal, theta0 uniform, radius normal; then the two
         angular offsets."""
         if accuBeam is not None:
@@ -107,7 +107,7 @@ class BendingMagnet(Undulator):
             el['theta0'] = np.random.random_sample() * span + self.Theta_min
             lean = np.clip(el['theta0'] * self.gamma / self.K, -1., 1.)
             along = 0.5 * self.L0 * (np.arccos(lean) / PI) + \
-                0.5 * self.L0 * np.random.random_integers(0, int(2*self.Np - 1))
+                0.5 * self.L0 * np.random.randint(0, int(2*self.Np - 1) + 1)   # = random_integers
             y = along - 0.5*self.L0*self.Np
             if along - 0.25*self.L0 <= 0:
                 y += self.L0*self.Np
@@ -228,24 +228,15 @@ class BendingMagnet(Undulator):
         for name in ('sourceSIGMAx', 'sourceSIGMAz'):
             if hasattr(parts[-1], name) and not hasattr(bo, name):
                 setattr(bo, name, getattr(parts[-1], name))
-        if length >= self.nrays:
-            bo.accepted = length * self.fluxConst
-            bo.acceptedE = bo.E.sum() * self.fluxConst * SIE0
-            bo.seeded = seeded
-            bo.seededI = seededI
-            bo.sourceWeight = sourceWeight / self.nrays
+        if length >= self.nrays:      # (a filament beam may deliver fewer: no flux figures)
+            self._book_flux(bo, length, seeded, seededI, sourceWeight / self.nrays)
         if length > self.nrays and el is None:
             bo.filter_by_index(slice(0, int(self.nrays)))
         if el is not None:
             bo.filamentDtheta, bo.filamentDpsi = el['dtheta'], el['dpsi']
             bo.filamentTheta0 = el['theta0']
-        norm = np.sqrt(bo.a**2 + 1.0 + bo.c**2)
-        bo.a /= norm
-        bo.b /= norm
-        bo.c /= norm
+        self._unit_directions(bo, np.sqrt(bo.a**2 + 1.0 + bo.c**2))    # (a, 1, c) = tangents
         bo.parentId = self.uuid
-        if self.pitch or self.yaw:
-            raycing.rotate_beam(bo, pitch=self.pitch, yaw=self.yaw)
         if toGlobal:
             raycing.virgin_local_to_global(self.bl, bo, self.center)
         return bo

@@ -671,23 +671,15 @@ class Undulator(MeshFunctions):
                 break
 
         bo = parts[0] if len(parts) == 1 else _concatenate(parts, withAmplitudes)
-        bo.accepted = length * self.fluxConst
-        bo.acceptedE = bo.E.sum() * self.fluxConst * SIE0
-        bo.seeded = seeded
-        bo.seededI = seededI
-        bo.sourceWeight = sourceWeight / (self.nrays if wave is None else len(wave.a))
+        self._book_flux(bo, length, seeded, seededI,
+                        sourceWeight / (self.nrays if wave is None else len(wave.a)))
         if length > self.nrays and not self.filamentBeam and wave is None:
             bo.filter_by_index(slice(0, int(self.nrays)))
         if el is not None:
             bo.filamentDtheta, bo.filamentDpsi = el['xp'], el['zp']
             bo.filamentDX, bo.filamentDZ = el['x'], el['z']
             bo.filamentDgamma = el['dgamma']
-        norm = (bo.a**2 + bo.b**2 + bo.c**2)**0.5
-        bo.a /= norm
-        bo.b /= norm
-        bo.c /= norm
-        if self.pitch or self.yaw:
-            raycing.rotate_beam(bo, pitch=self.pitch, yaw=self.yaw)
+        self._unit_directions(bo, (bo.a**2 + bo.b**2 + bo.c**2)**0.5)
         out = Beam(copyFrom=bo)
         if wave is not None:
             out.x[:] = px
@@ -702,6 +694,25 @@ class Undulator(MeshFunctions):
         if toGlobal:
             raycing.virgin_local_to_global(self.bl, out, self.center)
         return out
+
+
+def _book_flux(self, bo, length, seeded, seededI, weight):
+    """What the beam says about the flux it represents (the rays accepted of those seeded)."""
+    bo.accepted, bo.acceptedE = (length * self.fluxConst,
+                                 bo.E.sum() * self.fluxConst * SIE0)
+    bo.seeded, bo.seededI, bo.sourceWeight = seeded, seededI, weight
+
+
+def _unit_directions(self, bo, length):
+    """Direction cosines from the (a, b, c) drawn so far, turned by the source's pitch / yaw."""
+    for comp in (bo.a, bo.b, bo.c):
+        comp /= length
+    if self.pitch or self.yaw:
+        raycing.rotate_beam(bo, pitch=self.pitch, yaw=self.yaw)
+
+
+Undulator._book_flux = _book_flux
+Undulator._unit_directions = _unit_directions
 
 
 def _concatenate(parts, withAmplitudes):
