@@ -123,6 +123,14 @@ def load_case(name):
                                                           float(g['mat_rho']))
         p.update(nCRL=int(g['lens_nCRL']), zmax=zmax, t=float(g['lens_t']),
                  double_sided=kind.startswith('Double'))
+    elif name.startswith('g3_laue_plate'):
+        alpha = float(g['alpha'])
+        p['surface'] = dict(kind='flat', laue=True, alpha=alpha if alpha else None)
+        si = mn.load_element(tb, 'Si')
+        p['material'] = mn.make_crystal(si, (1, 1, 1), float(g['cr_d']), 'diamond',
+                                        str(g['cr_geom']), float(g['cr_t']), 1.,
+                                        float(g['cr_V']))
+        assert p['material']['chiToF'] == float(g['cr_chiToF'])
     elif name.startswith('g3_dcm'):
         alpha = float(g['alpha'])
         p['surface'] = dict(kind='flat', alpha=alpha)

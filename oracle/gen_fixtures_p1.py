@@ -431,6 +431,28 @@ def main():
     run_reflect('g2_bentflat_rh', rs, vcm, par, beam, surf_R=np.array(vcm.R),
                 mat_rho=np.array(12.41))
 
+    # ---------------- G3c: LauePlate (oes/laue.py:11-23) -------------------
+    for tag, alpha, geom in (('g3_laue_plate', None, 'Laue reflected'),
+                             ('g3_laue_plate_asym', np.radians(5.), 'Laue reflected'),
+                             ('g3_laue_plate_transmitted', np.radians(-3.),
+                              'Laue transmitted')):
+        bl = raycing.BeamLine()
+        siL = rm.CrystalSi(hkl=(1, 1, 1), geom=geom, t=0.1)
+        thL = siL.get_Bragg_angle(9000.) - siL.get_dtheta(9000., alpha)
+        lp = roe.LauePlate(bl, 'lp', center=[0, 10000., 0],
+                           pitch=float(thL[0] if np.ndim(thL) else thL) +
+                           (alpha if alpha else 0) + np.pi/2, material=siL, alpha=alpha,
+                           limPhysX=[-5, 5], limPhysY=[-1.2, 1.5])
+        beam = make_rays(rs, n, 71, sx=0.5, sz=0.5, sa=2e-5, sc=2e-5,
+                         E=(8999., 9001.), amplitudes=True, pol='mixed')
+        beam.state[2] = 2
+        beam.state[3] = -3
+        par = oe_params(lp, dict(kind='flat', laue=True, alpha=alpha))
+        par['material'] = crystal_dict(tables, siL)
+        run_reflect(tag, rs, lp, par, beam, alpha=np.array(alpha if alpha else 0.),
+                    cr_d=np.array(siL.d), cr_t=np.array(0.1), cr_geom=np.array(geom),
+                    cr_chiToF=np.array(siL.chiToF), cr_V=np.array(siL.V))
+
     # ---------------- G2d: Plate.double_refract (Be window) ---------------
     bl = raycing.BeamLine()
     mBe = rm.Material('Be', rho=1.848, kind='plate')

@@ -318,6 +318,13 @@ def local_r(surf, s, phi):        # parametric.py:225-231, 450-458, 690-696
 
 def local_n(surf, x, y):
     """3-list, or 6-list [n_H(3), n_surface(3)] for an asymmetric cut."""
+    if surf['kind'] == 'flat' and surf.get('laue'):   # LauePlate.local_n, oes/laue.py:14-20
+        a, b, c = 0, 0, 1
+        if surf.get('alpha'):
+            bB, cB = rotate_x(b, c, -np.sin(surf['alpha']), -np.cos(surf['alpha']))
+        else:
+            bB, cB = c, -b
+        return [a, bB, cB, a, b, c]
     if surf['kind'] == 'flat':                    # oes/base.py:719-742
         a = 0.
         b = 0.

@@ -148,6 +148,11 @@ def product_oe(name, g):
         oe = getattr(roe, str(g['lens_class']))(
             bl, 'crl', material=m, t=float(g['lens_t']), focus=float(g['lens_focus']),
             zmax=zmax, nCRL=int(g['lens_nCRL']), **common)
+    elif name.startswith('g3_laue_plate'):
+        alpha = float(g['alpha'])
+        si = rm.CrystalSi(hkl=(1, 1, 1), geom=str(g['cr_geom']), t=float(g['cr_t']))
+        assert si.d == float(g['cr_d']) and si.chiToF == float(g['cr_chiToF'])
+        oe = roe.LauePlate(bl, 'lp', material=si, alpha=alpha if alpha else None, **common)
     elif name.startswith('g3_dcm'):
         alpha = float(g['alpha'])
         si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)

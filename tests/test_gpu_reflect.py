@@ -200,6 +200,28 @@ def test_dcm_double_reflect_matches_reference_golden(name):
     compare(lo2, g, lambda f: g['lo2_' + f])
 
 
+@pytest.mark.parametrize('name', ['g3_laue_plate', 'g3_laue_plate_asym',
+                                  'g3_laue_plate_transmitted'])
+def test_laue_plate_matches_reference_golden(name):
+    """A flat Laue crystal (oes/laue.py:11-23): diffracting planes standing on the
+    surface, symmetric and with an asymmetry angle; the reflected beam leaves deflected by
+    2 theta_B, the transmitted one straight on; bracketing along z."""
+    g = pc.load(name)
+    oe = pc.product_oe(name, g)
+    info = {}
+    gb, lb = oe.reflect(pc.product_beam(g), _info=info)
+    assert info['axis'] == int(g['axis']) == 2
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    hit = g['lb_state'] == 1
+    n = oe.local_n(0., 0.)
+    assert len(n) == 6 and abs(n[1]**2 + n[2]**2 - 1.) < 1e-15 and n[5] == 1.
+    if name.endswith('transmitted'):
+        assert np.abs(gb.c[hit] - g['in_c'][hit]).max() < 1e-12
+    else:
+        assert gb.c[hit].mean() > 0.4          # sin(2 theta_B) at 9 keV, Si(111)
+
+
 def test_plate_double_refract_matches_reference_golden():
     """Refraction branch, transmission amplitudes, absorption exp(-mu t) and the
     in-material phase exp(0.1j n'k t) (reflect.py:894-919, 1048-1059)."""

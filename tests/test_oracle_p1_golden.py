@@ -29,7 +29,9 @@ def check_beam(mine, g, prefix):
                                   'g2_blazed_au', 'g2_ellipse_cyl',
                                   'g2_ellipse_full', 'g2_grating_vls',
                                   'g2_grating_const', 'g2_parabola_q',
-                                  'g2_parabola_p_cyl', 'g2_hyperbola', 'g2_polygon'])
+                                  'g2_parabola_p_cyl', 'g2_hyperbola', 'g2_polygon',
+                                  'g3_laue_plate', 'g3_laue_plate_asym',
+                                  'g3_laue_plate_transmitted'])
 def test_oe_reflect_matches_reference(name):
     p, beam, g = fixture_io.load_case(name)
     info = {}

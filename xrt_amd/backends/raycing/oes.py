@@ -914,6 +914,23 @@ class DCM(OE):
         return gb2, lo1, lo2
 
 
+class LauePlate(OE):
+    """Flat crystal plate in Laue geometry: the diffracting planes stand on the surface
+    (turned from its normal by 90 deg + *alpha*); the thickness belongs to the material
+    (reference oes/laue.py:11-23)."""
+
+    def _flat_normals(self, second=False):
+        planes = [0., self.cosalpha, -self.sinalpha] if self.alpha else [0., 1., 0.]
+        return planes + [0., 0., 1.]
+
+    def local_n(self, x, y):
+        return self._flat_normals()
+
+    def _surface_params(self, p, second=False):
+        OE._surface_params(self, p, second)
+        p.asymmetric = 1          # the two normals always differ
+
+
 class Plate(DCM):
     """A body with two flat surfaces (window, filter): the 2nd 'crystal' of the
     DCM skeleton is the back face at -t (oes/refractive.py:11-235)."""
