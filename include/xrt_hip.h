@@ -142,6 +142,9 @@ typedef struct xrt_hip_rotation {
 #define XRT_HIP_SURF_PARABOLOID 5  /* refractive lenses, oes/refractive.py:394-419, 613-617:
                                      z = (x^2 + y^2) / (4 focus), cut off at zmax; a parabolic
                                      cylinder takes x = 0 */
+#define XRT_HIP_SURF_CONE 6        /* ConicalMirror, oes/__init__.py:589-636: surf_p = L0,
+                                     0.25 t2t^2, redfocus t2t, -0.5 t2t, sign(t2t), redfocus,
+                                     t2t, 0.5 t2t with t2t = tan(2 theta) */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_SHAPE_POLYGON 2   /* optical surface outlined by a polygon in the local (x, y)

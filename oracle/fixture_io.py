@@ -123,6 +123,10 @@ def load_case(name):
                                                           float(g['mat_rho']))
         p.update(nCRL=int(g['lens_nCRL']), zmax=zmax, t=float(g['lens_t']),
                  double_sided=kind.startswith('Double'))
+    elif name == 'g2_cone_rh':
+        p['surface'] = rn.make_cone(float(g['surf_L0']), float(g['surf_theta']))
+        p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,
+                                         'mirror', float(g['mat_rho']))
     elif name.startswith('g3_laue_plate'):
         alpha = float(g['alpha'])
         p['surface'] = dict(kind='flat', laue=True, alpha=alpha if alpha else None)

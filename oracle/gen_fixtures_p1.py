@@ -431,6 +431,24 @@ def main():
     run_reflect('g2_bentflat_rh', rs, vcm, par, beam, surf_R=np.array(vcm.R),
                 mat_rho=np.array(12.41))
 
+    # ---------------- G2o: ConicalMirror (oes/__init__.py:589-636) ---------
+    bl = raycing.BeamLine()
+    mRhC = rm.Material('Rh', rho=12.41, kind='mirror')
+    cone = roe.ConicalMirror(bl, 'cone', center=[0, 12000., 0], pitch=4e-3, L0=900.,
+                             theta=3e-3, material=mRhC, limPhysX=[-1.5, 1.5],
+                             limPhysY=[-250, 250])
+    beam = make_rays(rs, n, 72, sx=0.4, sz=0.3, sa=5e-5, sc=2e-5,
+                     E=(7000., 12000.), amplitudes=True, pol='mixed')
+    beam.state[1] = 2
+    beam.state[2] = -2
+    surfc = rn.make_cone(cone.L0, cone.theta)
+    for k in ('tt', 't2t', 'redfocus'):
+        assert surfc[k] == getattr(cone, k), k
+    par = oe_params(cone, surfc)
+    par['material'] = material_dict(tables, mRhC)
+    run_reflect('g2_cone_rh', rs, cone, par, beam, surf_L0=np.array(cone.L0),
+                surf_theta=np.array(cone.theta), mat_rho=np.array(12.41))
+
     # ---------------- G3c: LauePlate (oes/laue.py:11-23) -------------------
     for tag, alpha, geom in (('g3_laue_plate', None, 'Laue reflected'),
                              ('g3_laue_plate_asym', np.radians(5.), 'Laue reflected'),

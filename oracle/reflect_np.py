@@ -211,6 +211,11 @@ def local_z(surf, x, y):
         y0, y1, yC, yL = blazed_pre(surf, y)
         return np.where(yL > yC, -(y1-y) * surf['tanBlaze'],
                         -yL * surf['tanAntiblaze'])
+    if surf['kind'] == 'cone':                    # ConicalMirror, oes/__init__.py:623-627
+        t2t, L0, redfocus = surf['t2t'], surf['L0'], surf['redfocus']
+        sqroot = np.sqrt(0.25*t2t**2*(y - L0)**2 - redfocus*t2t*x**2)
+        z = -0.5*t2t*(y-L0)-np.sign(t2t)*sqroot
+        return z
     if surf['kind'] == 'paraboloid':              # oes/refractive.py:394-399, 613-614
         if surf['cylinder']:
             x = 0
@@ -238,6 +243,14 @@ def make_blazed(blaze, rho, antiblaze=np.pi*0.4999):
                 rho_1=1. / rho, sinBlaze=np.sin(blaze), cosBlaze=np.cos(blaze),
                 tanBlaze=np.tan(blaze), sinAntiblaze=np.sin(antiblaze),
                 cosAntiblaze=np.cos(antiblaze), tanAntiblaze=np.tan(antiblaze))
+
+
+def make_cone(L0, theta):
+    """ConicalMirror's derived constants (oes/__init__.py:610-616)."""
+    tt = np.tan(theta)
+    t2t = np.tan(2*theta)
+    return dict(kind='cone', L0=L0, theta=theta, tt=tt, t2t=t2t,
+                redfocus=np.cos(theta)**2 / (1./tt-1./t2t))
 
 
 def make_ellipse_param(p, q, abs_pitch, isCylindrical=False, isClosed=False):
@@ -359,6 +372,14 @@ def local_n(surf, x, y):
         return [np.zeros_like(x),
                 np.where(yL > yC, -surf['sinBlaze'], surf['sinAntiblaze']),
                 np.where(yL > yC, surf['cosBlaze'], surf['cosAntiblaze'])]
+    if surf['kind'] == 'cone':                    # oes/__init__.py:629-636
+        t2t, L0, redfocus = surf['t2t'], surf['L0'], surf['redfocus']
+        sqroot = np.sign(t2t)*np.sqrt(0.25*t2t**2*(y - L0)**2 - redfocus*x*x*t2t)
+        a = -x*redfocus*t2t/sqroot  # -dz/dx
+        b = .5*t2t + 0.25*t2t**2*(y-L0)/sqroot  # -dz/dy
+        c = 1.
+        norm = (a**2 + b**2 + 1.)**0.5
+        return [a/norm, b/norm, c/norm]
     if surf['kind'] == 'paraboloid':              # oes/refractive.py:405-419, 616-617
         if surf['cylinder']:
             x = 0

@@ -148,6 +148,10 @@ def product_oe(name, g):
         oe = getattr(roe, str(g['lens_class']))(
             bl, 'crl', material=m, t=float(g['lens_t']), focus=float(g['lens_focus']),
             zmax=zmax, nCRL=int(g['lens_nCRL']), **common)
+    elif name == 'g2_cone_rh':
+        m = rm.Material('Rh', rho=float(g['mat_rho']), kind='mirror')
+        oe = roe.ConicalMirror(bl, 'cone', L0=float(g['surf_L0']),
+                               theta=float(g['surf_theta']), material=m, **common)
     elif name.startswith('g3_laue_plate'):
         alpha = float(g['alpha'])
         si = rm.CrystalSi(hkl=(1, 1, 1), geom=str(g['cr_geom']), t=float(g['cr_t']))

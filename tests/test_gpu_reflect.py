@@ -200,6 +200,26 @@ def test_dcm_double_reflect_matches_reference_golden(name):
     compare(lo2, g, lambda f: g['lo2_' + f])
 
 
+def test_conical_mirror_matches_reference_golden():
+    """ConicalMirror (oes/__init__.py:589-636): the surface and its normal in the
+    reference's operation order (states bit-exact), the host class's surface functions
+    evaluated by the same device code."""
+    g = pc.load('g2_cone_rh')
+    oe = pc.product_oe('g2_cone_rh', g)
+    info = {}
+    gb, lb = oe.reflect(pc.product_beam(g), _info=info)
+    assert info['axis'] == int(g['axis']) and info['brent'] == bool(g['brent'])
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    x, y = np.array([0., 0.7, -1.2]), np.array([0., 100., -200.])
+    t2t, L0, rf = oe.t2t, oe.L0, oe.redfocus
+    z = -0.5*t2t*(y-L0) - np.sign(t2t)*np.sqrt(0.25*t2t**2*(y - L0)**2 - rf*t2t*x**2)
+    assert np.array_equal(oe.local_z(x, y), z) and z[0] == 0.
+    # sagittal focusing: the horizontal kick is against x
+    hit = g['lb_state'] == 1
+    assert np.corrcoef(lb.x[hit], (gb.a - g['in_a'])[hit])[0, 1] < -0.9
+
+
 @pytest.mark.parametrize('name', ['g3_laue_plate', 'g3_laue_plate_asym',
                                   'g3_laue_plate_transmitted'])
 def test_laue_plate_matches_reference_golden(name):

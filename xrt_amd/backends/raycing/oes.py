@@ -646,6 +646,33 @@ class BentFlatMirror(_Curved):
 SimpleVCM = BentFlatMirror
 
 
+class ConicalMirror(_Curved):
+    """Mirror on the inside of a cone: *L0* = distance from the mirror centre to the
+    vertex measured ALONG THE SURFACE, *theta* = half opening angle (axis to surface)
+    (reference oes/__init__.py:589-636)."""
+
+    def __init__(self, *args, **kwargs):
+        self.L0 = kwargs.pop('L0', 1000.)
+        self.theta = kwargs.pop('theta', np.pi/6.)
+        OE.__init__(self, *args, **kwargs)
+
+    @property
+    def theta(self):
+        return self._theta
+
+    @theta.setter
+    def theta(self, value):
+        self._theta = raycing.auto_units_angle(value)
+        self.tt, self.t2t = np.tan(self._theta), np.tan(2*self._theta)
+        self.redfocus = np.cos(self._theta)**2 / (1./self.tt - 1./self.t2t)
+
+    def _surface_params(self, p, second=False):
+        t2t = self.t2t
+        self._curved(p, _structs.SURF_CONE,
+                     (self.L0, 0.25*t2t**2, self.redfocus*t2t, -0.5*t2t, np.sign(t2t),
+                      self.redfocus, t2t, .5*t2t))
+
+
 class BlazedGrating(_Curved):
     """Saw-tooth grating of constant line density for WAVE propagation: the
     diffraction comes from the surface itself through the Kirchhoff integral,

@@ -289,6 +289,10 @@ template <class K>
 __device__ __forceinline__ bool surf_is_lens(const xrt_hip_pass& P) {
   return K::F == 1 && PSURF(P) == XRT_HIP_SURF_PARABOLOID;
 }
+template <class K>
+__device__ __forceinline__ bool surf_is_cone(const xrt_hip_pass& P) {
+  return K::F == 1 && PSURF(P) == XRT_HIP_SURF_CONE;
+}
 // the paraboloid of a refractive lens before its cut-off, refractive.py:396, 411
 __device__ __forceinline__ double lens_parabola(const xrt_hip_pass& P, double& x, double y) {
   if (P.surf_p[4] != 0.) x = 0.;  // parabolic cylinder: local_z1(0, y), :613-617
@@ -369,6 +373,11 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
   if (surf_is_lens<K>(P)) {  // refractive.py:394-399
     const double z = lens_parabola(P, x, y);
     return P.surf_p[3] != 0. && z > P.surf_p[2] ? P.surf_p[2] : z;
+  }
+  if (surf_is_cone<K>(P)) {  // oes/__init__.py:623-627
+    const double u = y - P.surf_p[0];
+    const double root = sqrt(P.surf_p[1] * (u * u) - P.surf_p[2] * (x * x));
+    return P.surf_p[3] * u - P.surf_p[4] * root;
   }
   return 0.;
 }
@@ -1643,6 +1652,16 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     n[0] = n[3] = 0.;
     n[1] = n[4] = front ? -P.surf_p[3] : P.surf_p[5];
     n[2] = n[5] = front ? P.surf_p[4] : P.surf_p[6];
+  } else if (surf_is_cone<K>(P)) {  // oes/__init__.py:629-636
+    const double u = y - P.surf_p[0];
+    const double root =
+        P.surf_p[4] * sqrt(P.surf_p[1] * (u * u) - ((P.surf_p[5] * x) * x) * P.surf_p[6]);
+    const double na = (((-x) * P.surf_p[5]) * P.surf_p[6]) / root;
+    const double nb = P.surf_p[7] + (P.surf_p[1] * u) / root;
+    const double norm = sqrt(na * na + nb * nb + 1.);
+    n[0] = n[3] = na / norm;
+    n[1] = n[4] = nb / norm;
+    n[2] = n[5] = 1. / norm;
   } else if (surf_is_lens<K>(P)) {  // refractive.py:405-419
     const double z = lens_parabola(P, x, y);
     const bool rim = P.surf_p[3] != 0. && z > P.surf_p[2];
