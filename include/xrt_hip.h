@@ -145,6 +145,9 @@ typedef struct xrt_hip_rotation {
 #define XRT_HIP_SURF_CONE 6        /* ConicalMirror, oes/__init__.py:589-636: surf_p = L0,
                                      0.25 t2t^2, redfocus t2t, -0.5 t2t, sign(t2t), redfocus,
                                      t2t, 0.5 t2t with t2t = tan(2 theta) */
+#define XRT_HIP_SURF_SAGITTAL 7    /* sagittally bent cylinder z = Rs - sqrt(Rs^2 - x^2), the
+                                     second crystal of DCMwithSagittalFocusing
+                                     (oes/__init__.py:639-664): surf_p = Rs, Rs^2 */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_SHAPE_POLYGON 2   /* optical surface outlined by a polygon in the local (x, y)

@@ -138,7 +138,8 @@ def load_case(name):
     elif name.startswith('g3_dcm'):
         alpha = float(g['alpha'])
         p['surface'] = dict(kind='flat', alpha=alpha)
-        p['surface2'] = dict(kind='flat', alpha=alpha, flip_n_y=True)
+        p['surface2'] = dict(kind='sagittal', Rs=float(g['Rs'])) if 'Rs' in g.files else \
+            dict(kind='flat', alpha=alpha, flip_n_y=True)
         si = mn.load_element(tb, 'Si')
         for key in ('material', 'material2'):
             p[key] = mn.make_crystal(si, (1, 1, 1), float(g['cr_d']), 'diamond',

@@ -377,26 +377,32 @@ def main():
                 surf_R=np.array(tm2.R), surf_r=np.array(tm2.r))
 
     # ---------------- G3b: DCM Si(111) (cfg3 geometry) --------------------
-    for tag, alphaDeg in (('g3_dcm_si111', 0.), ('g3_dcm_si111_asym', 3.)):
+    for tag, alphaDeg in (('g3_dcm_si111', 0.), ('g3_dcm_si111_asym', 3.),
+                          ('g3_dcm_sagittal', 0.)):
+        sagittal = tag.endswith('sagittal')     # 2nd crystal bent to Rs (:639-664)
         bl = raycing.BeamLine()
         si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
         si2 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
         E0 = 9000.
         thB = si1.get_Bragg_angle(E0) - si1.get_dtheta(E0, np.radians(alphaDeg))
         kw = dict(alpha=np.radians(alphaDeg)) if alphaDeg else {}
-        dcm = roe.DCM(
+        if sagittal:
+            kw['Rs'] = 2 * 20000. * 10000. / 30000. * np.sin(float(thB))   # 20 m : 10 m
+        dcm = (roe.DCMwithSagittalFocusing if sagittal else roe.DCM)(
             bl, 'dcm', center=[0, 20000., 0], bragg=thB,
             pitch=np.radians(alphaDeg), material=si1,
             material2=si2, cryst2perpTransl=10., limPhysX=[-10, 10],
             limPhysY=[-50, 50], limPhysX2=[-10, 10], limPhysY2=[-50, 150], **kw)
-        beam = make_rays(rs, n, 45, sa=1e-4, sc=2e-5, E=(8995., 9005.),
+        beam = make_rays(rs, n, 73 if sagittal else 45, sx=2.0 if sagittal else 0.1,
+                         sa=1e-4, sc=2e-5, E=(8995., 9005.),
                          amplitudes=(alphaDeg == 0), pol='mixed')
         beam.x[0] = 30.                # misses crystal 1
         beam.z[1] = 8.                 # far above: lost at crystal 1 physical edge
         beam.state[2] = -3
         gb2, lo1, lo2 = dcm.double_reflect(beam)
         par = oe_params(dcm, dict(kind='flat', alpha=dcm.alpha))
-        par['surface2'] = dict(kind='flat', alpha=dcm.alpha, flip_n_y=True)
+        par['surface2'] = dict(kind='sagittal', Rs=dcm.Rs) if sagittal else \
+            dict(kind='flat', alpha=dcm.alpha, flip_n_y=True)
         par['material'] = crystal_dict(tables, si1)
         par['material2'] = crystal_dict(tables, si2)
         info = {}
@@ -416,6 +422,8 @@ def main():
         out.update(alpha=np.array(dcm.alpha if dcm.alpha else 0.),
                    cr_d=np.array(si1.d), cr_V=np.array(si1.V),
                    cr_chiToF=np.array(si1.chiToF))
+        if sagittal:
+            out['Rs'] = np.array(dcm.Rs)
         save(tag, **out)
 
     # ---------------- G2e: BentFlatMirror (VCM) + Rh ----------------------

@@ -211,6 +211,8 @@ def local_z(surf, x, y):
         y0, y1, yC, yL = blazed_pre(surf, y)
         return np.where(yL > yC, -(y1-y) * surf['tanBlaze'],
                         -yL * surf['tanAntiblaze'])
+    if surf['kind'] == 'sagittal':                # DCMwithSagittalFocusing.local_z2, :655-656
+        return surf['Rs'] - np.sqrt(surf['Rs']**2 - x**2)
     if surf['kind'] == 'cone':                    # ConicalMirror, oes/__init__.py:623-627
         t2t, L0, redfocus = surf['t2t'], surf['L0'], surf['redfocus']
         sqroot = np.sqrt(0.25*t2t**2*(y - L0)**2 - redfocus*t2t*x**2)
@@ -372,6 +374,11 @@ def local_n(surf, x, y):
         return [np.zeros_like(x),
                 np.where(yL > yC, -surf['sinBlaze'], surf['sinAntiblaze']),
                 np.where(yL > yC, surf['cosBlaze'], surf['cosAntiblaze'])]
+    if surf['kind'] == 'sagittal':                # oes/__init__.py:658-662
+        a = -x / surf['Rs']  # -dz/dx
+        c = (surf['Rs']**2-x**2)**0.5 / surf['Rs']
+        b = np.zeros_like(y)  # -dz/dy
+        return [a, b, c]
     if surf['kind'] == 'cone':                    # oes/__init__.py:629-636
         t2t, L0, redfocus = surf['t2t'], surf['L0'], surf['redfocus']
         sqroot = np.sign(t2t)*np.sqrt(0.25*t2t**2*(y - L0)**2 - redfocus*x*x*t2t)

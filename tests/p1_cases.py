@@ -162,8 +162,9 @@ def product_oe(name, g):
         si1 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
         si2 = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
         assert si1.d == float(g['cr_d']) and si1.chiToF == float(g['cr_chiToF'])
-        oe = roe.DCM(
-            bl, 'dcm', bragg=float(g['oe_bragg']), material=si1, material2=si2,
+        bent = dict(Rs=float(g['Rs'])) if 'Rs' in g.files else {}
+        oe = (roe.DCMwithSagittalFocusing if bent else roe.DCM)(
+            bl, 'dcm', bragg=float(g['oe_bragg']), material=si1, material2=si2, **bent,
             cryst1roll=float(g['oe_cryst1roll']), cryst2roll=float(g['oe_cryst2roll']),
             cryst2pitch=float(g['oe_cryst2pitch']),
             cryst2finePitch=float(g['oe_cryst2finePitch']),

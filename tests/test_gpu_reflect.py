@@ -190,7 +190,7 @@ def test_parametric_mirror_without_intersection_search_golden():
     compare(lb, g, lambda f: g['lb_' + f], geo_tol=4e-12)
 
 
-@pytest.mark.parametrize('name', ['g3_dcm_si111', 'g3_dcm_si111_asym'])
+@pytest.mark.parametrize('name', ['g3_dcm_si111', 'g3_dcm_si111_asym', 'g3_dcm_sagittal'])
 def test_dcm_double_reflect_matches_reference_golden(name):
     g = pc.load(name)
     dcm = pc.product_oe(name, g)
@@ -198,6 +198,13 @@ def test_dcm_double_reflect_matches_reference_golden(name):
     compare(gb2, g, lambda f: g['gb_' + f])
     compare(lo1, g, lambda f: g['lo1_' + f])
     compare(lo2, g, lambda f: g['lo2_' + f])
+    if name == 'g3_dcm_sagittal':       # the bent second crystal focuses horizontally
+        hit = g['gb_state'] == 1
+        assert np.corrcoef(gb2.x[hit], (gb2.a - g['in_a'])[hit])[0, 1] < -0.99
+        x = np.array([0., 3., -7.])
+        assert np.array_equal(dcm.local_z2(x, 0 * x), dcm.Rs - np.sqrt(dcm.Rs**2 - x**2))
+        n2 = dcm.local_n2(x, 0 * x)
+        assert np.array_equal(n2[0], -x / dcm.Rs) and not n2[1].any()
 
 
 def test_conical_mirror_matches_reference_golden():

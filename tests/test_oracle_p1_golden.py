@@ -104,7 +104,7 @@ def test_parametric_mirror_without_intersection_search():
     assert (lb.state == 1).all()
 
 
-@pytest.mark.parametrize('name', ['g3_dcm_si111', 'g3_dcm_si111_asym'])
+@pytest.mark.parametrize('name', ['g3_dcm_si111', 'g3_dcm_si111_asym', 'g3_dcm_sagittal'])
 def test_dcm_double_reflect_matches_reference(name):
     p, beam, g = fixture_io.load_case(name)
     gb2, lo1, lo2 = rn.dcm_double_reflect(p, beam)

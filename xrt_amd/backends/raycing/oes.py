@@ -941,6 +941,36 @@ class DCM(OE):
         return gb2, lo1, lo2
 
 
+class DCMwithSagittalFocusing(DCM):
+    """Double-crystal monochromator whose second crystal is bent sagittally to the radius
+    *Rs* (a cylinder along the beam), no miscut (reference oes/__init__.py:639-664)."""
+
+    def __init__(self, *args, **kwargs):
+        self.Rs = kwargs.pop('Rs', 1e12)
+        DCM.__init__(self, *args, **kwargs)
+
+    def local_z2(self, x, y):
+        return self._eval_second(_SURF_Z, x, y)[0]
+
+    def local_n2(self, x, y):
+        return self._eval_second(_SURF_N, x, y)[3:]
+
+    def _eval_second(self, what, x, y):
+        keep = self._surface_params
+        self._surface_params = lambda p, second=False: keep(p, True)
+        try:
+            return self._eval_surface(what, x, y)
+        finally:
+            del self._surface_params
+
+    def _surface_params(self, p, second=False):
+        if not second:
+            return DCM._surface_params(self, p, second)
+        if self.alpha:
+            raise NotImplementedError('a miscut on the bent crystal')
+        self._curved(p, _structs.SURF_SAGITTAL, (self.Rs, self.Rs**2))
+
+
 class LauePlate(OE):
     """Flat crystal plate in Laue geometry: the diffracting planes stand on the surface
     (turned from its normal by 90 deg + *alpha*); the thickness belongs to the material

@@ -374,6 +374,8 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
     const double z = lens_parabola(P, x, y);
     return P.surf_p[3] != 0. && z > P.surf_p[2] ? P.surf_p[2] : z;
   }
+  if (PSURF(P) == XRT_HIP_SURF_SAGITTAL)  // oes/__init__.py:655-656 (crystals: family 0 too)
+    return P.surf_p[0] - sqrt(P.surf_p[1] - x * x);
   if (surf_is_cone<K>(P)) {  // oes/__init__.py:623-627
     const double u = y - P.surf_p[0];
     const double root = sqrt(P.surf_p[1] * (u * u) - P.surf_p[2] * (x * x));
@@ -1652,6 +1654,10 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     n[0] = n[3] = 0.;
     n[1] = n[4] = front ? -P.surf_p[3] : P.surf_p[5];
     n[2] = n[5] = front ? P.surf_p[4] : P.surf_p[6];
+  } else if (PSURF(P) == XRT_HIP_SURF_SAGITTAL) {  // oes/__init__.py:658-662
+    n[0] = n[3] = -x / P.surf_p[0];
+    n[1] = n[4] = 0.;
+    n[2] = n[5] = sqrt(P.surf_p[1] - x * x) / P.surf_p[0];
   } else if (surf_is_cone<K>(P)) {  // oes/__init__.py:629-636
     const double u = y - P.surf_p[0];
     const double root =
