@@ -171,6 +171,12 @@ def test_out_of_scope_requests_fail_loudly():
         roe.EllipticalMirrorParam(bl, 'e', p=1000., q=100., f1=[0, 0, 0])
     poly = roe.OE(bl, 'poly', shape=[(0, 0), (1, 0), (0, 1)])      # polygons are in
     assert poly.shape == [(0, 0), (1, 0), (0, 1)]
+    class Bump(roe.OE):                       # a user-defined surface: refused, not flattened
+        def local_z(self, x, y):
+            return 1e-3 * np.exp(-x**2 - y**2)
+    with pytest.raises(NotImplementedError):
+        Bump(bl, 'bump')._make_pass(0., 0., 0.)
+    assert roe.LauePlate(bl, 'lp', alpha=0.1)._make_pass(0., 0., 0.).asymmetric == 1
     with pytest.raises(ValueError):
         roe.OE(bl, 'odd', shape=3.5)
     with pytest.raises(ValueError):

@@ -129,6 +129,15 @@ class OE(object):
         return self.local_n(x, y)
 
     def _surface_params(self, p, second=False):
+        # a subclass that brings its own numpy local_z / local_n (the usual way to define a
+        # surface in an xrt script) cannot be evaluated by the kernels: say so instead of
+        # tracing a flat surface
+        for name in ('local_z', 'local_n'):
+            if getattr(type(self), name) is not getattr(OE, name) and \
+                    type(self)._surface_params is OE._surface_params:
+                raise NotImplementedError(
+                    '%s.%s is user-defined: only the built-in surface kinds run on the GPU'
+                    % (type(self).__name__, name))
         p.surf_kind = _structs.SURF_FLAT
         p.asymmetric = 1 if self.alpha else 0
         for k, value in enumerate(self._flat_normals(second and hasattr(self, 'cryst2pitch'))):
