@@ -13,15 +13,11 @@ import uuid
 import numpy as np
 
 # ray states and solver constants
-stateGood, stateOut, stateOver = 1, 2, 3
-zEps = 1e-12
-maxIteration = 100
-dt = 1e-5
-maxHalfSizeOfOE = 1000.
-maxDepthOfOE = 100.
-nrays = 100000
-targetOpenCL = 'auto'
-precisionOpenCL = 'auto'
+stateGood, stateOut, stateOver = range(1, 4)
+zEps, dt, maxIteration = 1e-12, 1e-5, 100
+maxHalfSizeOfOE, maxDepthOfOE = 1000., 100.      # bracket sizes [mm] without limits
+nrays = 10**5
+targetOpenCL = precisionOpenCL = 'auto'          # accepted by the classes, unused
 _VERBOSITY_ = 0
 
 _AXIS = {'x': 0, 'y': 1, 'z': 2}
@@ -148,14 +144,12 @@ class BeamLine(object):
         self.name, self.height, self.alignE = name, height, alignE
         self.azimuth = azimuth
 
-    @property
-    def azimuth(self):
-        return self._azimuth
+    def _turn_to(self, angle):
+        self._azimuth = angle
+        self.cosAzimuth, self.sinAzimuth = float(np.cos(angle)), float(np.sin(angle))
 
-    @azimuth.setter
-    def azimuth(self, value):
-        self._azimuth = value
-        self.cosAzimuth, self.sinAzimuth = float(np.cos(value)), float(np.sin(value))
+    azimuth = property(lambda self: self._azimuth, _turn_to,
+                       doc='angle of the beam path about the global z, from the y axis')
 
 
 def enrol(element, bl, roster, lost_offset, name, stem, uuid_=None):
@@ -191,9 +185,8 @@ def auto_units_angle(angle, defaultFactor=1.):
                 value = float(text[:text.index(unit[0])].strip())
                 return np.radians(value) if unit == 'deg' else value * factor
         return float(text) * defaultFactor
-    if angle is None or isinstance(angle, (list, tuple)):
-        return angle
-    return angle * defaultFactor
+    plain_number = not (angle is None or isinstance(angle, (list, tuple)))
+    return angle * defaultFactor if plain_number else angle
 
 
 def along_basis(basis, u, v, w, origin=None):

@@ -137,13 +137,7 @@ class BendingMagnet(Undulator):
     def shine(self, toGlobal=True, withAmplitudes=True, fixedEnergy=False, accuBeam=None):
         """The source beam: rejection sampling of (E, theta, psi) on the intensity map,
         batches of 1.2 nrays until nrays are accepted (reference synchr.py:229-508)."""
-        if self.needReset:
-            self.reset()
-        if self.bl is not None:
-            try:
-                self.bl._alignE = float(self.bl.alignE)
-            except (ValueError, AttributeError, TypeError):
-                self.bl._alignE = 0.5 * (self.eMin + self.eMax)
+        self._ready_to_shine()
         if self.uniformRayDensity:
             withAmplitudes = True
         batch = self.nrays if self.uniformRayDensity else np.int64(self.nrays * 1.2)

@@ -23,9 +23,8 @@ class Screen(object):
     def __init__(self, bl=None, name='', center=[0, 0, 0], x='auto', z='auto',
                  compressX=None, compressZ=None, **kwargs):
         raycing.enrol(self, bl, 'screens', 2000, name, 'Screen', kwargs.get('uuid'))
-        self.center = center
+        self.center, self.footprint = center, []
         self.compressX, self.compressZ = compressX, compressZ
-        self.footprint = []
         self.set_orientation(x, z)
 
     def set_orientation(self, x=None, z=None):
@@ -70,12 +69,12 @@ class Screen(object):
         thinned by *condition(x, z)*, in a plane *dy* off the screen's
         (reference screens.py:304-365). The cell size is taken from the first
         intervals of the two axes."""
-        if rw is None:
+        if not rw:
             from . import waves as rw
         gx, gz = (g.ravel() for g in np.meshgrid(dim1, dim2))
         steps = _pitch_of(dim1), _pitch_of(dim2)
         cell = 1. if None in steps else steps[0] * steps[1]
-        if condition is not None:
+        if callable(condition):
             gx, gz = condition(gx, gz)
         gy = np.zeros_like(gx) + dy
         xg, yg, zg = self.local_to_global(x=gx, z=gz)

@@ -76,11 +76,9 @@ class Undulator(MeshFunctions):
         if kwargs:
             raise NotImplementedError('unsupported Undulator arguments: %s'
                                       % sorted(kwargs))
-        self.bl = bl
-        if bl is not None and self not in bl.sources:
-            bl.sources.append(self)
-            self.ordinalNum = len(bl.sources)
-        self.uuid = raycing.new_uuid()
+        raycing.enrol(self, bl, 'sources', 0, name, 'Source')
+        if bl is not None:
+            bl.oesDict[self.uuid][1] = 0          # a source, not an optical element
         for key in ('name', 'center', 'R0', 'distE', 'uniformRayDensity', 'filamentBeam',
                     'eEspread', 'gp', 'device', 'phaseDeg'):
             setattr(self, key, given[key])
@@ -88,10 +86,10 @@ class Undulator(MeshFunctions):
             setattr(self, key, float(given[key]))
         self.eN, self.nx, self.nz = eN, nx, nz         # the default meshes of meshes.py
         self.pitch, self.yaw = (raycing.auto_units_angle(v) for v in (pitch, yaw))
-        self.nrays = np.int64(nrays)
-        # Lorentz factor of the electrons
+        self.nrays = np.int64(int(nrays))
+        # Lorentz factor of the electrons, and its square
         self.gamma = self.eE * 1e9 * EV2ERG / (M0 * C**2)
-        self.gamma2 = self.gamma**2
+        self.gamma2 = self.gamma * self.gamma
         self._set_electron_beam(eSigmaX, eSigmaZ, eEpsilonX, eEpsilonZ, betaX, betaZ)
         self._xPrimeMin, self._xPrimeMax = self._angular_range(xPrimeMax)
         self._zPrimeMin, self._zPrimeMax = self._angular_range(zPrimeMax)
@@ -154,12 +152,10 @@ class Undulator(MeshFunctions):
 
     def _set_taper(self, taper):
         """synchr.py:1566-1594."""
-        self.taper = taper
-        if taper is None:
-            self._taperVal = None
-        elif np.ndim(taper) == 0:
+        self.taper, self._taperVal = taper, None
+        if taper is not None and np.ndim(taper) == 0:
             self._taperVal = float(taper)
-        else:
+        elif taper is not None:
             t = np.asarray(taper, dtype=float).ravel()
             if len(t) == 1:
                 dgap, gap = 0., t[0]
@@ -167,15 +163,15 @@ class Undulator(MeshFunctions):
                 dgap, gap = t
             else:
                 raise ValueError('taper must be (dgap, gap)')
-            self.gap = gap
-            self._taperVal = None if dgap == 0 else dgap / self.Np / self.L0 / gap
+            self.gap, self._taperVal = gap, \
+                (None if dgap == 0 else dgap / self.Np / self.L0 / gap)
 
     def _set_targetE(self, targetE):
         """(energy, harmonic[, isElliptical]) -> Kx, Ky (synchr.py:1499-1560)."""
         energy, harmonic = float(targetE[0]), float(targetE[1])
         Ky = np.sqrt(harmonic * 8 * PI * self.gamma2 / self.L0 / energy / E2WC - 2)
         Kx = 0
-        if np.isnan(Ky):
+        if Ky != Ky:                   # below the harmonic's lowest energy
             raise ValueError('Cannot calculate K, try to increase the undulator '
                              'harmonic number')
         if len(targetE) > 2 and targetE[2]:
@@ -183,9 +179,8 @@ class Undulator(MeshFunctions):
                 Kx = Ky * np.cos(targetE[2])
                 Ky = Ky * np.sin(targetE[2])
             else:
-                Kx = Ky = Ky / 2**0.5
-        self.targetE = targetE
-        self.Kx, self.Ky = Kx, Ky
+                Kx = Ky = Ky / 2**0.5          # helical
+        self.targetE, self.Kx, self.Ky = targetE, Kx, Ky
 
     @property
     def K(self):
@@ -201,9 +196,9 @@ class Undulator(MeshFunctions):
 
     def report_E1(self):
         """First-harmonic energy (synchr.py:1658-1674)."""
-        wu = PI / self.L0 / self.gamma2 * \
-            (2*self.gamma2 - 1. - 0.5*self.Kx**2 - 0.5*self.Ky**2) / E2WC
-        self.E1 = 2*wu*self.gamma2 / (1 + 0.5*self.Kx**2 + 0.5*self.Ky**2)
+        g2, kk = self.gamma2, (0.5*self.Kx**2, 0.5*self.Ky**2)
+        wu = PI / self.L0 / g2 * (2*g2 - 1. - kk[0] - kk[1]) / E2WC
+        self.E1 = 2*wu*g2 / (1 + kk[0] + kk[1])
         return self.E1
 
     def _prime_max_mrad(self, lo, hi, reduce_by):
@@ -243,11 +238,12 @@ class Undulator(MeshFunctions):
         self.Theta_max = float(xpMax + self.dxprime)
         self.Psi_min = float(zpMin - self.dzprime)
         self.Psi_max = float(zpMax + self.dzprime)
-        self.E_min = float(min(self.eMin, self.eMax))
-        self.E_max = float(max(self.eMin, self.eMax))
-        self.dE = (self.E_max - self.E_min) / float(self.eN)
-        self.dTheta = (self.Theta_max - self.Theta_min) / float(2*self.nx)
-        self.dPsi = (self.Psi_max - self.Psi_min) / float(2*self.nz)
+        self.E_min, self.E_max = (float(pick(self.eMin, self.eMax)) for pick in (min, max))
+        # steps of the default meshes (meshes.py): eN energies, 2 nx by 2 nz angles
+        for step, lo, hi, count in (('dE', self.E_min, self.E_max, self.eN),
+                                    ('dTheta', self.Theta_min, self.Theta_max, 2*self.nx),
+                                    ('dPsi', self.Psi_min, self.Psi_max, 2*self.nz)):
+            setattr(self, step, (hi - lo) / float(count))
 
     # ---- integration grid ----------------------------------------------------
     def _build_integration_grid(self):
@@ -256,15 +252,13 @@ class Undulator(MeshFunctions):
         rule = np.polynomial.legendre.leggauss if self._useGauLeg else \
             clenshaw_curtis
         tg_n, ag_n = rule(self.quadm)
-        dstep = 2 * PI / float(self.gIntervals)
-        dI = np.arange(-PI + 0.5 * dstep, PI, dstep)
-        self.tg = (dI[:, None] + 0.5 * dstep * tg_n).ravel()
-        self.ag = (dI[:, None] * 0 + ag_n).ravel()
-        self.sintg = np.sin(self.tg)
-        self.costg = np.cos(self.tg)
-        self.sintgph = np.sin(self.tg + self.phase)
-        self.costgph = np.cos(self.tg + self.phase)
-        self.dstep = dstep
+        self.dstep = dstep = 2 * PI / float(self.gIntervals)
+        mid = np.arange(-PI + 0.5 * dstep, PI, dstep)           # interval centres
+        self.tg = (mid[:, None] + 0.5 * dstep * tg_n).ravel()
+        self.ag = (mid[:, None] * 0 + ag_n).ravel()
+        shifted = self.tg + self.phase                          # the horizontal field's phase
+        self.sintg, self.costg = np.sin(self.tg), np.cos(self.tg)
+        self.sintgph, self.costgph = np.sin(shifted), np.cos(shifted)
         self._tables = None          # uploaded on first use
 
     def _device_tables(self):
@@ -310,35 +304,34 @@ class Undulator(MeshFunctions):
     def _find_convergence_mixed(self):
         """Doubling then bisection on the number of nodes until the on-edge
         intensity is stable to *gp* (sybase.py:1190-1243)."""
-        m = 3
-        while m < 10000:
-            m += 1
-            self.quadm = int(2**m)
-            mad, dimad = self._get_mad()
-            if (dimad < self.gp) or (mad < self.gp):
-                break
-            if self.quadm > self.maxIntegrationNodes:
-                break
-        lo, hi = int(2**(m - 1)), self.quadm
+        def stable(nodes):
+            self.quadm = nodes
+            spread, drift = self._get_mad()
+            return drift < self.gp or spread < self.gp
+        power = 4
+        while not stable(int(2**power)) and self.quadm <= self.maxIntegrationNodes and \
+                power < 10000:
+            power += 1
+        lo, hi = int(2**(power - 1)), self.quadm
         for _ in range(int(np.log2((hi - lo) / 20.))):
-            self.quadm = int(0.5 * (hi + lo))
-            mad, dimad = self._get_mad()
-            if (dimad < self.gp) or (mad < self.gp):
-                hi = self.quadm
+            half = int(0.5 * (hi + lo))
+            if stable(half):
+                hi = half
             else:
-                lo = self.quadm
+                lo = half
         self.quadm = hi
 
     def _reset_integration_grid(self):
         """sybase.py:1452-1467."""
         if self.needConvergence:
-            self.quadm = 0
-            spread = self.eEspread
-            self.eEspread = 0
+            # searched without energy spread, on the bare field of one probe ray
+            spread, self.eEspread, self.quadm = self.eEspread, 0, 0
             self.convergenceSearchFlag = True
-            self._find_convergence_mixed()
-            self.convergenceSearchFlag = False
-            self.eEspread = spread
+            try:
+                self._find_convergence_mixed()
+            finally:
+                self.convergenceSearchFlag = False
+                self.eEspread = spread
         self._build_integration_grid()
 
     def reset(self):
@@ -456,12 +449,14 @@ class Undulator(MeshFunctions):
 
     @staticmethod
     def tanaka_kitamura_Qa2(x, eps=1e-6):
-        ret = np.ones_like(x, dtype=float)
-        xarr = np.array(x)
-        y = SQ2 * xarr[xarr > eps]
+        """Tanaka & Kitamura's energy-spread factor Q_a(x)^2 (1 below *eps*)."""
+        x = np.asarray(x, dtype=float)
+        out = np.ones_like(x)
+        big = x > eps
+        y = SQ2 * x[big]
         y2 = y**2
-        ret[x > eps] = y2 / (np.exp(-y2) + SQPI*y*special.erf(y) - 1)
-        return ret
+        out[big] = y2 / (np.exp(-y2) + SQPI*y*special.erf(y) - 1)
+        return out
 
     def _harmonic_of(self, E, onlyOddHarmonics):
         harmonic = np.floor_divide(E, self.E1)
@@ -595,13 +590,7 @@ class Undulator(MeshFunctions):
         """The source beam (rays sampled by rejection on the intensity map) or,
         with *wave* (a beam from ``prepare_wave``), the undulator field on the
         wave's points (reference: sybase.py:1470-1810)."""
-        if self.needReset:
-            self.reset()
-        if self.bl is not None:
-            try:
-                self.bl._alignE = float(self.bl.alignE)
-            except (ValueError, AttributeError, TypeError):
-                self.bl._alignE = 0.5 * (self.eMin + self.eMax)
+        self._ready_to_shine()
         if wave is not None:
             if not hasattr(wave, 'rDiffr'):
                 raise ValueError("If you want to use a `wave`, run a "
@@ -696,6 +685,17 @@ class Undulator(MeshFunctions):
         return out
 
 
+def _ready_to_shine(self):
+    """Pending reset; the beamline's alignment energy defaults to the middle of the range."""
+    if self.needReset:
+        self.reset()
+    if self.bl is not None:
+        try:
+            self.bl._alignE = float(self.bl.alignE)
+        except (ValueError, AttributeError, TypeError):
+            self.bl._alignE = 0.5 * (self.eMin + self.eMax)
+
+
 def _book_flux(self, bo, length, seeded, seededI, weight):
     """What the beam says about the flux it represents (the rays accepted of those seeded)."""
     bo.accepted, bo.acceptedE = (length * self.fluxConst,
@@ -711,6 +711,7 @@ def _unit_directions(self, bo, length):
         raycing.rotate_beam(bo, pitch=self.pitch, yaw=self.yaw)
 
 
+Undulator._ready_to_shine = _ready_to_shine
 Undulator._book_flux = _book_flux
 Undulator._unit_directions = _unit_directions
 

@@ -14,15 +14,11 @@ _FLUX = {'total': 0, 's': 1, 'p': 2, '+/-45': 3, 'left-right': 4, 'power': 5}
 class XYCAxis(object):
     def __init__(self, label='', unit='mm', factor=None, data='auto', limits=None,
                  offset=0, bins=128, ppb=2, density='histogram', **kwargs):
-        self.label = label
-        self.unit = unit
+        given = dict(locals())
+        for key in ('label', 'unit', 'data', 'limits', 'offset', 'ppb', 'density'):
+            setattr(self, key, given[key])
         self.factor = _UNIT_FACTORS.get(unit, 1.) if factor is None else factor
-        self.data = data
-        self.limits = limits
-        self.offset = offset
         self.bins = int(bins)
-        self.ppb = ppb
-        self.density = density
 
     def field(self):
         """Which beam quantity this axis shows (label convention of xrt:
@@ -36,8 +32,7 @@ class XYCPlot(object):
     def __init__(self, beam=None, rayFlag=(1,), xaxis=None, yaxis=None, caxis=None,
                  aspect='equal', title='', fluxKind='total', beamState=None,
                  ePos=1, colorFactor=0.85, colorSaturation=0.85, **kwargs):
-        self.beam = beam
-        self.rayFlag = tuple(rayFlag)
+        self.beam, self.rayFlag = beam, tuple(rayFlag)
         self.xaxis = xaxis if xaxis is not None else XYCAxis('x', 'mm')
         self.yaxis = yaxis if yaxis is not None else XYCAxis('z', 'mm')
         # colour axis (xrt/plotter.py: caxis='category' colours by ray state and
@@ -45,14 +40,11 @@ class XYCPlot(object):
         if caxis == 'category':
             raise NotImplementedError("caxis='category'")
         self.caxis = caxis if caxis is not None else XYCAxis('energy', 'eV', bins=128)
-        self.ePos = ePos
-        self.colorFactor = colorFactor          # xrt/plotter.py defaults
-        self.colorSaturation = colorSaturation
+        self.ePos, self.colorFactor, self.colorSaturation = ePos, colorFactor, colorSaturation
         self.title = title or str(beam)
         if not any(fluxKind.startswith(k) for k in _FLUX):
             raise NotImplementedError('fluxKind %r' % fluxKind)
-        self.fluxKind = fluxKind
-        self.beamState = beamState
+        self.fluxKind, self.beamState = fluxKind, beamState
         self.reset_bins2D()
 
     def reset_bins2D(self):
