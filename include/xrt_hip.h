@@ -418,7 +418,7 @@ XRT_HIP_API int xrt_hip_screen_expose_f64_dev(const xrt_hip_screen* screen,
                                               const xrt_hip_beam* in, xrt_hip_beam* out,
                                               void* stream);
 
-/* ---- RectangularAperture.propagate (apertures.py:334-413) -----------------
+/* ---- RectangularAperture.propagate / RoundAperture.propagate (apertures.py:334-413, 770-846)
  * Rays with state > 0 are taken to the aperture plane (local y = 0); those
  * outside the blades (inside, for a beam stop) get state lost_num = -ordinal-1000
  * IN THE INCOMING BEAM TOO (the reference mutates beam.state, :373). blade_mask:
@@ -432,6 +432,9 @@ typedef struct xrt_hip_aperture {
   int32_t blade_mask;
   int32_t is_beam_stop;
   int32_t lost_num;
+  int32_t round;               /* 1: RoundAperture (apertures.py:770-846): stopped where
+                                  sqrt(x^2 + z^2) > radius instead of by blades */
+  double radius;
 } xrt_hip_aperture;
 
 XRT_HIP_API int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* aperture,

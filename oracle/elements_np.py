@@ -51,8 +51,9 @@ def screen_expose(beam, basis, center, lostNum, onlyPositivePath=False):
 
 
 def aperture_propagate(beam, basis, center, blades, lostNum, azimuth_sc=(0., 1.),
-                       isBeamStop=False, needNewGlobal=False):
-    """Mutates beam.state like the reference. blades: dict left/right/bottom/top."""
+                       isBeamStop=False, needNewGlobal=False, radius=None):
+    """Mutates beam.state like the reference. blades: dict left/right/bottom/top;
+    *radius*: a RoundAperture instead (apertures.py:770-846)."""
     good = beam.state > 0
     lo = beam.copy()
     _to_basis(beam, lo, basis, center, good)
@@ -61,6 +62,8 @@ def aperture_propagate(beam, basis, center, blades, lostNum, azimuth_sc=(0., 1.)
     lo.z[good] += lo.c[good] * path
     lo.path[good] += path
     badIndices = np.zeros(len(beam.x), dtype=bool)
+    if radius is not None:
+        badIndices[good] = (lo.x[good]**2 + lo.z[good]**2)**0.5 > radius
     for akind, d in blades.items():
         if akind.startswith('l'):
             badIndices[good] = badIndices[good] | (lo.x[good] < d)

@@ -577,6 +577,38 @@ def main():
                lostNum=np.array(slit.lostNum))
     save('g7_aperture', **out)
 
+    # ---------------- G7b: beam stops and round apertures ------------------
+    out = {}
+    for tag, cls, kw in (
+            ('rect_stop', ra.RectangularBeamStop,
+             dict(kind=('left', 'right', 'bottom', 'top'), opening=[-0.3, 0.4, -0.1, 0.12])),
+            ('round', ra.RoundAperture, dict(r=0.45)),
+            ('round_stop', ra.RoundBeamStop, dict(r=0.2))):
+        bl = raycing.BeamLine(azimuth=-0.02)
+        ap = cls(bl, tag, center=[np.sin(-0.02)*8000., np.cos(-0.02)*8000., 0.05], **kw)
+        beam = rs.Beam(copyFrom=b_in)
+        glo, lo = ap.propagate(beam, needNewGlobal=True)
+        ob = to_oracle_beam(b_in)
+        mglo, mlo = en.aperture_propagate(
+            ob, ap.xyz, ap.center, dict(getattr(ap, 'blades', {})) if 'rect' in tag else {},
+            ap.lostNum, (bl.sinAzimuth, bl.cosAzimuth), isBeamStop=ap.isBeamStop,
+            needNewGlobal=True, radius=kw.get('r'))
+        assert_beams('g7b:lo', mlo, lo)
+        assert_beams('g7b:glo', mglo, glo)
+        assert np.array_equal(ob.state, beam.state)
+        st, cnt = np.unique(lo.state, return_counts=True)
+        print('g7b', tag, 'states', dict(zip(st.tolist(), cnt.tolist())))
+        out.update(beam_dict(tag + '_lo_', lo))
+        if tag == 'round':
+            out.update(beam_dict(tag + '_glo_', glo))
+        out[tag + '_in_state_after'] = np.array(beam.state)
+        out[tag + '_center'] = np.array(ap.center, dtype=float)
+        out[tag + '_lostNum'] = np.array(ap.lostNum)
+    out.update(beam_dict('in_', b_in))
+    out.update(azimuth=np.array(-0.02), rect_stop_opening=np.array([-0.3, 0.4, -0.1, 0.12]),
+               round_r=np.array(0.45), round_stop_r=np.array(0.2))
+    save('g7_stops_round', **out)
+
 
 if __name__ == '__main__':
     main()

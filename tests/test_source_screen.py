@@ -150,6 +150,66 @@ def test_aperture_propagate_matches_reference(golden_dir):
     assert np.array_equal(lo2.state, lo.state)
 
 
+_STOPS = (('rect_stop', 'RectangularBeamStop'), ('round', 'RoundAperture'),
+          ('round_stop', 'RoundBeamStop'))
+
+
+def _stop_args(g, tag):
+    if tag == 'rect_stop':
+        return dict(kind=('left', 'right', 'bottom', 'top'),
+                    opening=[float(v) for v in g['rect_stop_opening']])
+    return dict(r=float(g[tag + '_r']))
+
+
+def test_oracle_stops_and_round_apertures_match_reference(golden_dir):
+    """CPU: the oracle's beam-stop and round-aperture branches against the reference's
+    RectangularBeamStop / RoundAperture / RoundBeamStop (golden g7_stops_round)."""
+    from oracle import elements_np as en
+    g = np.load(os.path.join(golden_dir, 'g7_stops_round.npz'))
+    az = float(g['azimuth'])
+    basis = ([np.cos(az), -np.sin(az), 0.], [np.sin(az), np.cos(az), 0.], [0., 0., 1.])
+    for tag, _ in _STOPS:
+        b = _oracle_beam(g, 'in_')
+        kw = _stop_args(g, tag)
+        blades = dict(zip(kw['kind'], kw['opening'])) if 'kind' in kw else {}
+        lo = en.aperture_propagate(b, basis, g[tag + '_center'], blades,
+                                   int(g[tag + '_lostNum']), (np.sin(az), np.cos(az)),
+                                   isBeamStop=tag.endswith('stop'), radius=kw.get('r'))
+        assert np.array_equal(b.state, g[tag + '_in_state_after'])
+        assert np.array_equal(lo.state, g[tag + '_lo_state'])
+        for f in FIELDS + ('Es', 'Ep'):
+            r = g['%s_lo_%s' % (tag, f)]
+            assert np.abs(getattr(lo, f) - r).max() <= 1e-13 * max(np.abs(r).max(), 1e-300), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,cls', _STOPS)
+def test_stops_and_round_apertures_match_reference(golden_dir, tag, cls):
+    import xrt_amd.backends.raycing.apertures as ra
+    g = np.load(os.path.join(golden_dir, 'g7_stops_round.npz'))
+    bl = raycing.BeamLine(azimuth=float(g['azimuth']))
+    ap = getattr(ra, cls)(bl, tag, center=[float(v) for v in g[tag + '_center']],
+                          **_stop_args(g, tag))
+    assert ap.lostNum == int(g[tag + '_lostNum']) and ap.isBeamStop == tag.endswith('stop')
+    b = rs.Beam(nrays=len(g['in_x']), withAmplitudes=True)
+    for f in FIELDS + ('state', 'Es', 'Ep'):
+        setattr(b, f, g['in_' + f])
+    glo, lo = ap.propagate(b, needNewGlobal=True)
+    assert np.array_equal(b.state, g[tag + '_in_state_after'])
+    checks = [(lo, '_lo_')] + ([(glo, '_glo_')] if tag == 'round' else [])
+    for ob, pre in checks:
+        assert np.array_equal(ob.state, g[tag + pre + 'state'])
+        for f in FIELDS + ('Es', 'Ep'):
+            r = g[tag + pre + f]
+            assert np.abs(getattr(ob, f) - r).max() <= 1e-13 * max(np.abs(r).max(), 1e-300), f
+    if tag == 'round':           # the wave samples fill the disc
+        np.random.seed(2)
+        w = ap.prepare_wave(ap, 4000)
+        rr = np.hypot(w.x, w.z)
+        assert rr.max() <= ap.r and abs((rr < ap.r / 2**0.5).mean() - 0.5) < 0.03
+        assert abs(w.dS * 4000 - np.pi * ap.r**2) < 1e-12
+
+
 @pytest.mark.gpu
 def test_resident_chain_source_slit_mirror_screen_matches_oracle():
     """A run_process-style chain that never leaves HBM between elements:

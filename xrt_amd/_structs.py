@@ -126,7 +126,9 @@ class Aperture(ctypes.Structure):
                 ('blade', ctypes.c_double * 4),
                 ('blade_mask', ctypes.c_int32),
                 ('is_beam_stop', ctypes.c_int32),
-                ('lost_num', ctypes.c_int32)]
+                ('lost_num', ctypes.c_int32),
+                ('round', ctypes.c_int32),
+                ('radius', ctypes.c_double)]
 
 
 class Undulator(ctypes.Structure):

@@ -1,7 +1,7 @@
-"""``RectangularAperture`` with the interface of the reference's
-(xrt/backends/raycing/apertures.py:29-499): four optional blades in the aperture's
-own frame, ``propagate`` as a streaming HIP kernel over a device-resident beam,
-``prepare_wave`` for the wave path."""
+"""Apertures with the interface of the reference's (xrt/backends/raycing/apertures.py):
+``RectangularAperture`` (:75-541: four optional blades in the aperture's own frame),
+``RoundAperture`` (:668-914) and their beam stops; ``propagate`` is one streaming HIP kernel
+over a device-resident beam, ``prepare_wave`` serves the wave path."""
 import ctypes
 
 import numpy as np
@@ -66,6 +66,8 @@ class RectangularAperture(object):
                 a.blade[bit] = float(self.blades[blade])
         a.is_beam_stop = int(bool(self.isBeamStop))
         a.lost_num = int(self.lostNum)
+        if hasattr(self, 'r'):
+            a.round, a.radius, a.blade_mask = 1, float(self.r), 0
         return a
 
     def propagate(self, beam=None, needNewGlobal=False):
@@ -107,3 +109,50 @@ class RectangularAperture(object):
         opened = spans[0] * spans[1]
         return rw.receiving_wave(self, prevOE, (px, py, pz), there, opened / count,
                                  opened, self.uuid)
+
+
+class RectangularBeamStop(RectangularAperture):
+    """The blades enclose the solid part: rays inside are stopped, rays outside pass."""
+
+    def __init__(self, *args, **kwargs):
+        RectangularAperture.__init__(self, *args, **kwargs)
+        self.isBeamStop = True
+
+
+class RoundAperture(RectangularAperture):
+    """A pipe or a flange: open within the radius *r* around the centre."""
+
+    def __init__(self, bl=None, name='', center=[0, 0, 0], r=1, x='auto', z='auto',
+                 alarmLevel=None, **kwargs):
+        RectangularAperture.__init__(self, bl, name, center, blades={}, x=x, z=z,
+                                     alarmLevel=alarmLevel, **kwargs)
+        self.r = r
+        self.limOptX, self.limOptY, self.shape = [-r, r], [-r, r], 'round'
+
+    def get_divergence(self, source):
+        """Full angle the aperture subtends at *source*."""
+        gap = np.subtract(self.center, source.center)
+        return self.r * 2 * np.dot(gap, gap) ** -0.5
+
+    def prepare_wave(self, prevOE, nrays, rw=None):
+        """*nrays* receiving samples uniform over the disc: one (nrays, 2) draw, column 0
+        -> radius (its square root), column 1 -> azimuth (apertures.py:848-874)."""
+        if not rw:
+            from . import waves as rw
+        count = int(nrays)
+        draw = np.random.rand(count, 2)
+        radius = draw[:, 0]**0.5 * self.r
+        angle = draw[:, 1] * 2*np.pi
+        px, pz, py = radius * np.cos(angle), radius * np.sin(angle), np.zeros(count)
+        there = raycing.along_basis((self.x, self.y, self.z), px, py, pz, self.center)
+        disc = np.pi * self.r**2
+        return rw.receiving_wave(self, prevOE, (px, py, pz), there, disc / count, disc,
+                                 self.uuid)
+
+
+class RoundBeamStop(RoundAperture):
+    """A disc of radius *r* in the beam: rays inside are stopped."""
+
+    def __init__(self, *args, **kwargs):
+        RoundAperture.__init__(self, *args, **kwargs)
+        self.isBeamStop = True

@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_apertur
     z = z + c * dpath;
     path = path + dpath;
     bool bad = false;
+    if (A.round) bad = sqrt(x * x + z * z) > A.radius;
     if (A.blade_mask & 1) bad = bad || (x < A.blade[0]);
     if (A.blade_mask & 2) bad = bad || (x > A.blade[1]);
     if (A.blade_mask & 4) bad = bad || (z < A.blade[2]);
