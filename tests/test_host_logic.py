@@ -181,3 +181,42 @@ def test_out_of_scope_requests_fail_loudly():
         roe.OE(bl, 'odd', shape=3.5)
     with pytest.raises(ValueError):
         rm.Element('Si', table='Henke')
+
+
+def test_beam_utilities(tmp_path):
+    a = rs.Beam(nrays=4, withAmplitudes=True)
+    b = rs.Beam(nrays=3, withAmplitudes=True)
+    a.x[:] = np.arange(4.)
+    b.x[:] = 10 + np.arange(3.)
+    a.state[:] = [1, 2, 1, -1]
+    b.state[:] = 1
+    a.E[:] = [100., 200., 300., 400.]
+    b.Es[:] = 1j
+    a.sourceWeight, b.sourceWeight = 2., 3.
+    a.concatenate(b)
+    assert len(a) == 7 and a.x.tolist() == [0, 1, 2, 3, 10, 11, 12]
+    assert a.Es[4] == 1j and a.sourceWeight.tolist() == [2.] * 4 + [3.] * 3
+    good = rs.Beam(copyFrom=a)
+    good.filter_good()
+    assert len(good) == 5 and (good.state == 1).all()
+    c = rs.Beam(copyFrom=a)
+    c.Jss[:] = 0.25
+    c.absorb_intensity(a)
+    assert np.allclose(c.Jss, 0.75) and c.displayAsAbsorbedPower
+    a.project_energy_to_band(1000., 2000.)
+    assert a.E.min() == 1000. and a.E.max() == 2000.
+    d = rs.Beam(copyFrom=a)
+    d.x[:] = -1.
+    a.replace_by_index(np.array([0, 6]), d)
+    assert a.x.tolist() == [-1, 1, 2, 3, 10, 11, -1]
+    w = rs.Beam(copyFrom=a)
+    w.Es[:] = 2.
+    w.Ep[:] = 0.
+    a.Es[:] = 1.
+    a.Ep[:] = 1j
+    a.add_wave(w, sign=-1)
+    assert np.allclose(a.Jss, 1.) and np.allclose(a.Jsp, (-1.) * np.conj(1j))
+    path = str(tmp_path / 'beam')
+    a.export_beam(path)
+    back = np.load(path + '.npy', allow_pickle=True).item()
+    assert np.array_equal(back['x'], a.x) and 'Es' in back

@@ -131,6 +131,94 @@ class Beam(object):
         for name in self.array_fields():
             setattr(self, name, getattr(self, name)[indarr])
 
+    def filter_good(self):
+        return self.filter_by_index(self.state == 1)
+
+    def _stored(self, name):
+        """The array as it is held: device tensor or host array (no transfer)."""
+        return self._d[name] if name in self._d else self._h[name]
+
+    def concatenate(self, beam):
+        """Appends the rays of *beam* (several sources feeding one beamline,
+        sources/beams.py:230-294): every array both beams carry, amplitudes included; two
+        different scalar source weights become per-ray weights. Arrays that both beams hold
+        on the GPU are joined there."""
+        mine, theirs = self.nrays, beam.nrays
+        for name in self.array_fields():
+            if name not in beam.array_fields():
+                if name not in _F64 + _C128 + ('state',):
+                    delattr(self, name)
+                continue
+            a, b = self._stored(name), beam._stored(name)
+            if isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor):
+                setattr(self, name, torch.cat((a, b)))
+            else:
+                setattr(self, name, np.concatenate((getattr(self, name), getattr(beam, name))))
+        if hasattr(self, 'sourceWeight') and hasattr(beam, 'sourceWeight'):
+            w0, w1 = self.sourceWeight, beam.sourceWeight
+            if np.ndim(w0) or np.ndim(w1) or w0 != w1:
+                self.sourceWeight = np.concatenate((np.broadcast_to(w0, mine),
+                                                    np.broadcast_to(w1, theirs)))
+        return self
+
+    def replace_by_index(self, indarr, beam):
+        """Rays *indarr* take their arrays from the same rays of *beam*."""
+        for name in self.array_fields():
+            if name in beam.array_fields():
+                getattr(self, name)[indarr] = getattr(beam, name)[indarr]
+        return self
+
+    def absorb_intensity(self, inBeam, sign=1):
+        """The coherency matrix becomes what was lost on the way from *inBeam*."""
+        for name in ('Jss', 'Jpp', 'Jsp'):
+            setattr(self, name, (inBeam._stored(name) - self._stored(name)) * sign
+                    if isinstance(inBeam._stored(name), type(self._stored(name)))
+                    else (getattr(inBeam, name) - getattr(self, name)) * sign)
+        self.displayAsAbsorbedPower = True
+
+    def add_wave(self, wave, sign=1):
+        """Coherent sum with another field on the same points."""
+        self.Es = self.Es + sign*wave.Es
+        self.Ep = self.Ep + sign*wave.Ep
+        self.Jss = (self.Es * self.Es.conjugate()).real
+        self.Jpp = (self.Ep * self.Ep.conjugate()).real
+        self.Jsp = self.Es * self.Ep.conjugate()
+
+    def project_energy_to_band(self, EnewMin, EnewMax):
+        """The energies stretched linearly onto [EnewMin, EnewMax]."""
+        lo, hi = np.min(self.E), np.max(self.E)
+        if lo < hi:
+            self.E = EnewMin + (self.E - lo) / (hi - lo) * (EnewMax - EnewMin)
+
+    def make_uniform_energy_band(self, EnewMin, EnewMax):
+        self.E = np.random.uniform(EnewMin, EnewMax, self.nrays)
+
+    def diffract(self, wave):
+        from . import waves as rw
+        return rw.diffract(self, wave)
+
+    def export_beam(self, fileName, fformat='npy'):
+        """The beam's arrays and scalars as one dictionary in a numpy ('npy'), Matlab
+        ('mat') or pickle file."""
+        record = {name: np.asarray(getattr(self, name)) for name in self.array_fields()}
+        record.update({k: v for k, v in self.__dict__.items()
+                       if not k.startswith('_') and k not in ('fromOE', 'toOE')})
+        for key in ('fromOE', 'toOE'):
+            if key in self.__dict__:
+                record[key] = getattr(self.__dict__[key], 'name', None)
+        kind = str(fformat).lower()
+        if kind in ('npy', 'np', 'numpy'):
+            np.save(fileName if fileName.endswith('npy') else fileName + '.npy', record)
+        elif kind in ('mat', 'matlab'):
+            import scipy.io
+            scipy.io.savemat(fileName if fileName.endswith('mat') else fileName + '.mat',
+                             {k: v for k, v in record.items() if v is not None})
+        else:
+            import pickle
+            with open(fileName if fileName.endswith('pickle') else fileName + '.pickle',
+                      'wb') as f:
+                pickle.dump(record, f, protocol=2)
+
     def array_fields(self):
         return [n for n in (_F64 + _C128 + _OPT_F64 + _OPT_C128 + ('state',))
                 if n in self._h or n in self._d]
