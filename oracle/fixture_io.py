@@ -123,6 +123,22 @@ def load_case(name):
                                                           float(g['mat_rho']))
         p.update(nCRL=int(g['lens_nCRL']), zmax=zmax, t=float(g['lens_t']),
                  double_sided=kind.startswith('Double'))
+    elif name.startswith('g2_capillary'):
+        shape = name.split('_')[-1]
+        if shape == 'parab':
+            q, r0 = float(g['cap_q']), float(g['cap_r0'])
+            focus = -0.5*(q-(q**2+r0**2)**0.5)
+            p['surface'] = dict(kind='parab_capillary', s0=focus + q, focus=focus)
+        else:
+            A, B = float(g['cap_%sA' % shape]), float(g['cap_%sB' % shape])
+            half = 0.5*np.abs(p['surfPhysY'][-1]-p['surfPhysY'][0])
+            wd = float(g['cap_workingDistance'])
+            ctd = (A**2 - B**2)**0.5 - wd - half if shape == 'ellipse' else \
+                (A**2 + B**2)**0.5 + wd + half
+            p['surface'] = {'kind': shape + '_capillary', shape + 'A': A, shape + 'B': B,
+                            'ctd': ctd}
+        p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
+                                         'mirror', float(g['mat_rho']))
     elif name == 'g2_cone_rh':
         p['surface'] = rn.make_cone(float(g['surf_L0']), float(g['surf_theta']))
         p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,

@@ -457,6 +457,33 @@ def main():
     run_reflect('g2_cone_rh', rs, cone, par, beam, surf_L0=np.array(cone.L0),
                 surf_theta=np.array(cone.theta), mat_rho=np.array(12.41))
 
+    # ---------------- G2p: capillaries (oes/parametric.py:717-988) ---------
+    mAuC = rm.Material('Au', rho=19.3, kind='mirror')
+    for tag, cls, kw, spread in (
+            ('g2_capillary_parab', roe.ParaboloidCapillaryMirror, dict(q=500., r0=2.5), 2.0),
+            ('g2_capillary_ellipse', roe.EllipsoidCapillaryMirror,
+             dict(ellipseA=1000., ellipseB=3., workingDistance=100.), 2.0),
+            ('g2_capillary_hyperbola', roe.HyperboloidCapillaryMirror,
+             dict(hyperbolaA=1000., hyperbolaB=3., workingDistance=100.), 1.0)):
+        bl = raycing.BeamLine()
+        cap = cls(bl, 'cap', center=[0, 1000., 0], material=mAuC, limPhysY=[-50, 50], **kw)
+        beam = make_rays(rs, n, 74, sx=spread, sz=spread, sa=2e-5, sc=2e-5,
+                         E=(8999., 9001.), amplitudes=True, pol='mixed')
+        beam.state[1] = 2
+        beam.state[2] = -2
+        if 'parab' in tag:
+            surf = dict(kind='parab_capillary', s0=cap.s0, focus=cap.focus)
+        elif 'ellipse' in tag:
+            surf = dict(kind='ellipse_capillary', ellipseA=cap.ellipseA,
+                        ellipseB=cap.ellipseB, ctd=cap.ctd)
+        else:
+            surf = dict(kind='hyperbola_capillary', hyperbolaA=cap.hyperbolaA,
+                        hyperbolaB=cap.hyperbolaB, ctd=cap.ctd)
+        par = oe_params(cap, surf)
+        par['material'] = material_dict(tables, mAuC)
+        run_reflect(tag, rs, cap, par, beam, mat_rho=np.array(19.3),
+                    **{'cap_' + k: np.array(float(v)) for k, v in kw.items()})
+
     # ---------------- G3c: LauePlate (oes/laue.py:11-23) -------------------
     for tag, alpha, geom in (('g3_laue_plate', None, 'Laue reflected'),
                              ('g3_laue_plate_asym', np.radians(5.), 'Laue reflected'),

@@ -267,6 +267,8 @@ def make_ellipse_param(p, q, abs_pitch, isCylindrical=False, isClosed=False):
 
 
 PARAM_KINDS = ('ellipse_param', 'parabola_param', 'hyperbola_param')
+# surfaces of revolution about the local y axis (capillaries), parametric.py:717-988
+REVOLUTION_KINDS = ('parab_capillary', 'ellipse_capillary', 'hyperbola_capillary')
 
 
 def make_parabola_param(p, q, abs_pitch, isCylindrical=False, isClosed=False):
@@ -296,16 +298,20 @@ def make_hyperbola_param(p, q, abs_pitch, isCylindrical=False, isClosed=False):
 
 
 def is_param(surf):
-    return surf['kind'] in PARAM_KINDS
+    return surf['kind'] in PARAM_KINDS + REVOLUTION_KINDS
 
 
 def xyz_to_param(surf, x, y, z):                  # parametric.py:213-216
+    if surf['kind'] in REVOLUTION_KINDS:          # :726-727
+        return y, np.arctan2(x, z), np.sqrt(x**2 + z**2)
     yNew, zNew = rotate_x(y - surf['y0'], z - surf['z0'], surf['cosGamma'],
                           surf['sinGamma'])
     return yNew, np.arctan2(x, zNew), np.sqrt(x**2 + zNew**2)
 
 
 def param_to_xyz(surf, s, phi, r):                # parametric.py:218-223
+    if surf['kind'] in REVOLUTION_KINDS:          # :729-730
+        return r * np.sin(phi), s, r * np.cos(phi)
     x = r * np.sin(phi)
     y = s
     z = r * np.cos(phi)
@@ -314,6 +320,13 @@ def param_to_xyz(surf, s, phi, r):                # parametric.py:218-223
 
 
 def local_r(surf, s, phi):        # parametric.py:225-231, 450-458, 690-696
+    if surf['kind'] == 'parab_capillary':         # :780-781
+        return 2*np.sqrt((surf['s0']-s)*surf['focus'])
+    if surf['kind'] == 'ellipse_capillary':       # :877-879
+        return surf['ellipseB'] * np.sqrt(abs(1 - (surf['ctd']+s)**2/surf['ellipseA']**2))
+    if surf['kind'] == 'hyperbola_capillary':     # :974-977
+        ss = surf['ctd'] + s
+        return surf['hyperbolaB'] * np.sqrt(abs(ss**2/surf['hyperbolaA']**2 - 1))
     if surf['kind'] == 'parabola_param':
         r2 = surf['parabParam']*s + surf['parabParam']**2
         r2[r2 < 0] = 0
@@ -401,6 +414,28 @@ def local_n(surf, x, y):
         c = np.ones_like(x)
         norm = (a**2 + b**2 + 1)**0.5
         return [a/norm, b/norm, c/norm]
+    if surf['kind'] == 'parab_capillary':         # parametric.py:783-788
+        s, phi = x, y
+        a = -np.sin(phi)
+        b = -np.sqrt(surf['focus']/(surf['s0']-s))
+        c = -np.cos(phi)
+        norm = np.sqrt(a**2 + b**2 + c**2)
+        return [a/norm, b/norm, c/norm]
+    if surf['kind'] == 'ellipse_capillary':       # :881-889
+        s, phi = x, y
+        A2s2 = np.array(surf['ellipseA']**2 - (surf['ctd']+s)**2)
+        A2s2[A2s2 <= 0] = 1e22
+        nr = -surf['ellipseB'] / surf['ellipseA'] * (surf['ctd']+s) / np.sqrt(A2s2)
+        norm = np.sqrt(nr**2 + 1.)
+        return [-np.sin(phi) / norm, nr / norm, -np.cos(phi) / norm]
+    if surf['kind'] == 'hyperbola_capillary':     # :979-988
+        s, phi = x, y
+        ss = surf['ctd'] + s
+        A2s2 = np.array(ss**2 - surf['hyperbolaA']**2)
+        A2s2[A2s2 <= 0] = 1e22
+        nr = -surf['hyperbolaB'] / surf['hyperbolaA'] * ss / np.sqrt(A2s2)
+        norm = np.sqrt(nr**2 + 1)
+        return [np.sin(phi) / norm, nr / norm, np.cos(phi) / norm]
     if surf['kind'] in PARAM_KINDS:   # parametric.py:233-247, 460-472, 698-713
         s, phi = x, y
         sign = -1.

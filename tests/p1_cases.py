@@ -148,6 +148,12 @@ def product_oe(name, g):
         oe = getattr(roe, str(g['lens_class']))(
             bl, 'crl', material=m, t=float(g['lens_t']), focus=float(g['lens_focus']),
             zmax=zmax, nCRL=int(g['lens_nCRL']), **common)
+    elif name.startswith('g2_capillary'):
+        m = rm.Material('Au', rho=float(g['mat_rho']), kind='mirror')
+        cls = {'parab': roe.ParaboloidCapillaryMirror, 'ellipse': roe.EllipsoidCapillaryMirror,
+               'hyperbola': roe.HyperboloidCapillaryMirror}[name.split('_')[-1]]
+        kw = {k[4:]: float(g[k]) for k in g.files if k.startswith('cap_')}
+        oe = cls(bl, 'cap', material=m, **kw, **common)
     elif name == 'g2_cone_rh':
         m = rm.Material('Rh', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.ConicalMirror(bl, 'cone', L0=float(g['surf_L0']),

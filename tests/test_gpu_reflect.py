@@ -75,7 +75,9 @@ def test_polygon_outline_states_equal_matplotlibs():
 
 @pytest.mark.parametrize('name', ['g2_blazed_au', 'g2_ellipse_cyl',
                                   'g2_ellipse_full', 'g2_parabola_q',
-                                  'g2_parabola_p_cyl', 'g2_hyperbola'])
+                                  'g2_parabola_p_cyl', 'g2_hyperbola',
+                                  'g2_capillary_parab', 'g2_capillary_ellipse',
+                                  'g2_capillary_hyperbola'])
 def test_softimax_surface_kinds_match_reference_golden(name):
     """Blazed grating (closed-form first-facet intersection) and elliptical
     parametric mirrors (root solve in (s, phi, r)). Positions come back through

@@ -30,7 +30,8 @@ def check_beam(mine, g, prefix):
                                   'g2_ellipse_full', 'g2_grating_vls',
                                   'g2_grating_const', 'g2_parabola_q',
                                   'g2_parabola_p_cyl', 'g2_hyperbola', 'g2_polygon',
-                                  'g2_cone_rh', 'g3_laue_plate', 'g3_laue_plate_asym',
+                                  'g2_cone_rh', 'g2_capillary_parab', 'g2_capillary_ellipse',
+                                  'g2_capillary_hyperbola', 'g3_laue_plate', 'g3_laue_plate_asym',
                                   'g3_laue_plate_transmitted'])
 def test_oe_reflect_matches_reference(name):
     p, beam, g = fixture_io.load_case(name)

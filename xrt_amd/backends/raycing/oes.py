@@ -877,6 +877,99 @@ class HyperbolicMirrorParam(EllipticalMirrorParam):
 HyperbolicMirror = HyperbolicMirrorParam
 
 
+class SurfaceOfRevolution(EllipticalMirrorParam):
+    """Closed surfaces about the local y axis -- capillaries -- in cylindrical coordinates:
+    s = y along the axis, (phi, r) polar across it (reference oes/parametric.py:717-731).
+    The kernels' conic kind with the axis untilted and the full turn open."""
+    isClosed, isCylindrical = True, False
+    cosGamma, sinGamma, y0, z0 = 1., 0., 0., 0.
+    _ctd = 0.
+
+    def __init__(self, *args, **kwargs):
+        OE.__init__(self, *args, **kwargs)
+        self.isParametric = True
+
+    def _reset_pq(self):         # nothing to re-derive when the element is turned
+        pass
+
+    def _surface_params(self, p, second=False):
+        semi = self._conic_ab()
+        self._curved(p, _structs.SURF_ELLIPSE_PARAM,
+                     (0., 0., 1., 0., semi[0], semi[1], 0., 1., float(self.conic),
+                      float(self._ctd)))
+
+
+class ParaboloidCapillaryMirror(SurfaceOfRevolution):
+    """Paraboloid of revolution focusing at the distance *q* behind its centre, radius
+    *r0* at the centre (yaw = 180 deg collimates) (oes/parametric.py:733-788)."""
+    conic = 3
+
+    def __init__(self, *args, **kwargs):
+        self.q, self.r0 = kwargs.pop('q', 500.), kwargs.pop('r0', 2.5)
+        SurfaceOfRevolution.__init__(self, *args, **kwargs)
+
+    @property
+    def focus(self):
+        return -0.5*(self.q-(self.q**2+self.r0**2)**0.5)
+
+    @property
+    def s0(self):
+        return self.focus + self.q
+
+    def _conic_ab(self):
+        return self.s0, self.focus
+
+
+class EllipsoidCapillaryMirror(SurfaceOfRevolution):
+    """Ellipsoid of revolution, the inside reflecting: semi-axes *ellipseA*, *ellipseB*
+    (not the tube radius), *workingDistance* from the end face to the focus; the centre is
+    the middle of the tube, whose length is limPhysY (oes/parametric.py:791-889)."""
+    conic = 0
+
+    def __init__(self, *args, **kwargs):
+        self.ellipseA = kwargs.pop('ellipseA', 10000)
+        self.ellipseB = kwargs.pop('ellipseB', 2.5)
+        self.workingDistance = kwargs.pop('workingDistance', 17.)
+        SurfaceOfRevolution.__init__(self, *args, **kwargs)
+
+    def _half_length(self):
+        ends = self.limPhysY
+        return 0.5*np.abs(ends[-1]-ends[0])
+
+    @property
+    def ctd(self):
+        """Centre of the tube measured from the centre of the ellipse."""
+        c = (self.ellipseA**2 - self.ellipseB**2)**0.5
+        return c - self.workingDistance - self._half_length()
+
+    _ctd = property(lambda self: self.ctd)
+
+    def _conic_ab(self):
+        return self.ellipseA, self.ellipseB
+
+
+class HyperboloidCapillaryMirror(EllipsoidCapillaryMirror):
+    """Hyperboloid of revolution (mirror lens), the OUTSIDE reflecting: *hyperbolaA*,
+    *hyperbolaB*, *workingDistance* from the virtual focus to the front face
+    (oes/parametric.py:892-988)."""
+    conic = 2
+
+    def __init__(self, *args, **kwargs):
+        self.hyperbolaA = kwargs.pop('hyperbolaA', 10000)
+        self.hyperbolaB = kwargs.pop('hyperbolaB', 2.5)
+        self.workingDistance = kwargs.pop('workingDistance', 17.)
+        self.invertNormal = -1
+        SurfaceOfRevolution.__init__(self, *args, **kwargs)
+
+    @property
+    def ctd(self):
+        c = (self.hyperbolaA**2 + self.hyperbolaB**2)**0.5
+        return c + self.workingDistance + self._half_length()
+
+    def _conic_ab(self):
+        return self.hyperbolaA, self.hyperbolaB
+
+
 class DCM(OE):
     """Double-crystal monochromator with flat crystals (oes/dcm.py): the second
     crystal is described relative to the first -- extra roll / pitch, the translations

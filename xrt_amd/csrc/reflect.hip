@@ -328,8 +328,11 @@ __device__ __forceinline__ void ell_param_to_xyz(const xrt_hip_pass& P, double s
 __device__ __forceinline__ double ell_local_r(const xrt_hip_pass& P, double s, double phi) {
   const double A = P.surf_p[4], B = P.surf_p[5];
   const int conic = (int)P.surf_p[8];
+  s = P.surf_p[9] + s;   // capillaries measure s from their middle (ctd), parametric.py:878, 975
   double r;
-  if (conic == 1) {  // parabola, parametric.py:450-453: A = parabParam
+  if (conic == 3) {  // paraboloid capillary, :780-781: A = s0, B = focus
+    r = 2. * sqrt((A - s) * B);
+  } else if (conic == 1) {  // parabola, parametric.py:450-453: A = parabParam
     double r2 = A * s + A * A;
     if (r2 < 0.) r2 = 0.;
     r = 2. * sqrt(r2);
@@ -1680,8 +1683,18 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
   } else if (surf_is_param<K>(P)) {  // parametric.py:233-247, 460-472, 698-713
     const double A = P.surf_p[4], B = P.surf_p[5];
     const int conic = (int)P.surf_p[8];
-    const double sp = px, phi = py;
+    const double sp = P.surf_p[9] + px, phi = py;
     double nr, sg = -1.;
+    if (conic == 3) {  // paraboloid capillary, parametric.py:783-788 (its own norm)
+      double sn, cs;
+      sincos(phi, &sn, &cs);
+      const double na = -sn, nb = -sqrt(B / (A - sp)), nc = -cs;
+      const double norm = sqrt(na * na + nb * nb + nc * nc);
+      n[0] = n[3] = na / norm;
+      n[1] = n[4] = nb / norm;
+      n[2] = n[5] = nc / norm;
+      return;
+    }
     if (conic == 1) {
       nr = A / sqrt(A * sp + A * A);
     } else if (conic == 2) {
