@@ -566,6 +566,18 @@ def main():
                             scr.lostNum)
     assert_beams('g1:screen', mine, lo)
 
+    # ---------------- G1b: MeshSource / NESWSource -------------------------
+    kwm = dict(center=(1., 2., 3.), minxprime=-2e-4, maxxprime=3e-4, minzprime=-1e-4,
+               maxzprime=1.5e-4, nx=7, nz=5, distE='flat', energies=(8000., 9000.),
+               polarization='+45', totalFlux=1e12)
+    outm = {}
+    for cls in ('MeshSource', 'NESWSource'):
+        np.random.seed(4)
+        bm = getattr(rs, cls)(raycing.BeamLine(azimuth=0.03), name='m', **kwm).shine()
+        outm.update(beam_dict(cls + '_', bm))
+        outm[cls + '_sourceWeight'] = np.array(getattr(bm, 'sourceWeight', np.nan))
+    save('g1_mesh_sources', **outm)
+
     # ---------------- G7: RectangularAperture.propagate -------------------
     import xrt.backends.raycing.apertures as ra
     bl = raycing.BeamLine(azimuth=-0.02)

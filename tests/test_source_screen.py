@@ -150,6 +150,23 @@ def test_aperture_propagate_matches_reference(golden_dir):
     assert np.array_equal(lo2.state, lo.state)
 
 
+def test_mesh_sources_match_reference(golden_dir):
+    """MeshSource / NESWSource (host classes, sources/geoms.py:853-1108): the fan of
+    directions, energies and polarisation bit-identical to the reference's."""
+    g = np.load(os.path.join(golden_dir, 'g1_mesh_sources.npz'))
+    kw = dict(center=(1., 2., 3.), minxprime=-2e-4, maxxprime=3e-4, minzprime=-1e-4,
+              maxzprime=1.5e-4, nx=7, nz=5, distE='flat', energies=(8000., 9000.),
+              polarization='+45', totalFlux=1e12)
+    for cls in ('MeshSource', 'NESWSource'):
+        np.random.seed(4)
+        b = getattr(rs, cls)(raycing.BeamLine(azimuth=0.03), name='m', **kw).shine()
+        assert len(b) == (36 if cls == 'MeshSource' else 4)
+        for f in FIELDS + ('state',):
+            assert np.array_equal(getattr(b, f), g['%s_%s' % (cls, f)]), (cls, f)
+        if cls == 'MeshSource':
+            assert b.sourceWeight == float(g[cls + '_sourceWeight'])
+
+
 _STOPS = (('rect_stop', 'RectangularBeamStop'), ('round', 'RoundAperture'),
           ('round_stop', 'RoundBeamStop'))
 

@@ -549,6 +549,79 @@ class GeometricSource(object):
         return bo
 
 
+class MeshSource(object):
+    """Point source sending a regular fan of rays: *nx* by *nz* directions between the given
+    angular limits (rows from the top), optionally preceded by the central ray; used to
+    find the divergence an element accepts (reference sources/geoms.py:853-1068)."""
+
+    def __init__(self, bl=None, name='', center=(0, 0, 0), minxprime=-1e-4, maxxprime=1e-4,
+                 minzprime=-1e-4, maxzprime=1e-4, nx=11, nz=11, distE='lines',
+                 energies=(defaultEnergy,), energyWeights=None, polarization='horizontal',
+                 withCentralRay=True, autoAppendToBL=False, totalFlux=None, **kwargs):
+        given = dict(locals())
+        self.bl = bl
+        if autoAppendToBL and bl is not None and self not in bl.sources:
+            bl.sources.append(self)
+            self.ordinalNum = len(bl.sources)
+        self.name = name or 'MeshSource'
+        self.uuid = kwargs.get('uuid', raycing.new_uuid())
+        if bl is not None:
+            bl.oesDict[self.uuid] = [self, 0]
+        for key in ('center', 'nx', 'nz', 'distE', 'energies', 'energyWeights', 'polarization',
+                    'withCentralRay', 'totalFlux'):
+            setattr(self, key, given[key])
+        for key in ('minxprime', 'maxxprime', 'minzprime', 'maxzprime'):
+            setattr(self, key, raycing.auto_units_angle(given[key]))
+
+    nrays = property(lambda self: self.nx * self.nz + int(self.withCentralRay))
+
+    def _fan(self, bo, first, a, c):
+        """Tangents (a, c) -> unit directions of the rays from *first* on."""
+        bo.a[first:], bo.c[first:] = a, c
+        length = (bo.a**2 + 1.0 + bo.c**2)**0.5
+        bo.a[:] = bo.a / length
+        bo.c[:] = bo.c / length
+        bo.b[:] = 1.0 / length
+
+    def shine(self, toGlobal=True):
+        bo = Beam(self.nrays)
+        bo.state[:] = 1
+        self.dxprime = (self.maxxprime-self.minxprime) / (self.nx-1)
+        self.dzprime = (self.maxzprime-self.minzprime) / (self.nz-1)
+        across, up = np.meshgrid(np.linspace(self.minxprime, self.maxxprime, self.nx),
+                                 np.linspace(self.minzprime, self.maxzprime, self.nz))
+        self._fan(bo, int(self.withCentralRay), across.flatten(), np.flipud(up).flatten())
+        if self.distE is not None:
+            bo.E[:] = make_energy(self.distE, self.energies, self.nrays,
+                                  energyWeights=self.energyWeights)
+        make_polarization(self.polarization, bo, self.nrays)
+        if np.isscalar(self.totalFlux) and self.totalFlux > 0:      # absolute flux [ph/s]
+            total = (bo.Jss + bo.Jpp).sum()
+            if total > 0:
+                bo.sourceWeight = self.totalFlux / total
+                bo.seeded, bo.seededI, bo.accepted, bo.acceptedE = len(bo.E), 1., 1., 1.
+        if toGlobal:
+            raycing.virgin_local_to_global(self.bl, bo, self.center)
+        bo.parentId = self.uuid
+        return bo
+
+
+class NESWSource(MeshSource):
+    """The four extreme rays of the fan: up, right, down, left, from 50 um above the
+    centre (sources/geoms.py:1071-1108)."""
+    nrays = 4
+
+    def shine(self, toGlobal=True):
+        bo = Beam(4)
+        bo.state[:] = 1
+        self._fan(bo, 0, np.array([0, self.maxxprime, 0, self.minxprime]),
+                  np.array([self.maxzprime, 0, self.minzprime, 0]))
+        bo.z[:] += 0.05
+        if toGlobal:
+            raycing.virgin_local_to_global(self.bl, bo, self.center)
+        return bo
+
+
 from .undulator import Undulator  # noqa: E402,F401  (needs Beam from this module)
 from .fieldsource import SourceFromField  # noqa: E402,F401
 from .bendsource import BendingMagnet, Wiggler  # noqa: E402,F401
