@@ -2219,7 +2219,7 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
 }
 
 template <class K, int mode>
-__global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     OptStat* __restrict__ opt) {
@@ -2239,7 +2239,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK, K::WAVES) void reflect_fused(
 // are up does reflect_exact run the two-pass tail.
 // ---------------------------------------------------------------------------
 template <class K, int mode>
-__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_xtal(
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, 4) void reflect_fused_xtal(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     int* __restrict__ any_neg_pos, OptStat* __restrict__ opt) {
@@ -2643,7 +2643,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_dcm(
 }
 
 template <class K>
-__global__ __launch_bounds__(REFLECT_BLOCK, 4) void reflect_fused_dcm(
+__global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
     xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2,
     xrt_hip_beam in, xrt_hip_beam lo1, xrt_hip_beam lo2, xrt_hip_beam gb2, double* theta1,
     double* theta2, const GStat* __restrict__ g1p, const GStat* __restrict__ g2p,
@@ -3320,7 +3320,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   GStat* g = L.g1;
   double* part = L.part1;
   OptStat* opt = reinterpret_cast<OptStat*>(part);
-  const dim3 grid((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)), block(REFLECT_BLOCK);
+  const dim3 grid((unsigned)((n + REFLECT_FUSED_BLOCK - 1) / REFLECT_FUSED_BLOCK)),
+      block(REFLECT_BLOCK), fblock(REFLECT_FUSED_BLOCK);
   // The optimistic single pass (see decide_opt_body) needs the input intact for a
   // possible redo, and surfaces that bracket at all.
   const bool aliased = beams_overlap(in, lb) || beams_overlap(in, vb) ||
@@ -3343,7 +3344,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       // compiled with the kinds fixed. Each ray takes its own sign of beamInDotNormal
       // and raises any_neg / any_pos (see reflect_fused_xtal).
 #define XRT_XTAL(SPEC)                                                                       \
-  hipLaunchKernelGGL((reflect_fused_xtal<SPEC, mode>), grid, block, 0, st, P, M, in, restore, \
+  hipLaunchKernelGGL((reflect_fused_xtal<SPEC, mode>), grid, fblock, 0, st, P, M, in, restore, \
                      lb, vb, theta, g, &g->any_neg, opt)
       if (M.thick && flat_xtal)
         XRT_XTAL(ThickXtal<XRT_HIP_SURF_FLAT>);
@@ -3357,7 +3358,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       return;
     }
 #define XRT_FUSED(SPEC)                                                                    \
-  hipLaunchKernelGGL((reflect_fused<SPEC, mode>), grid, block, 0, st, P, M, in, restore, lb, \
+  hipLaunchKernelGGL((reflect_fused<SPEC, mode>), grid, fblock, 0, st, P, M, in, restore, lb, \
                      vb, theta, g, opt)
     const bool plain = !P.grating && !P.asymmetric && !P.no_intersection_search;
     if (P.surf_kind >= XRT_HIP_SURF_BLAZED) {
@@ -3450,7 +3451,8 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
   if (n <= 0) return hipSuccess;
   const WsLayout L = ws_layout(workspace, n);
   using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
-  const dim3 grid((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)), block(REFLECT_BLOCK);
+  const dim3 grid((unsigned)((n + REFLECT_DCM_BLOCK - 1) / REFLECT_DCM_BLOCK)),
+      block(REFLECT_BLOCK), fblock(REFLECT_DCM_BLOCK);
   // (redo: the beam between the crystals lives in gb2's arrays)
   PassAux a1, a2;
   a1.theta = theta1;
@@ -3477,7 +3479,7 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
                        L.part2, L.g1, L.g2);
     if (evk0) (void)hipEventRecord(evk0, st);
 #define XRT_DCM(SPEC)                                                                       \
-  hipLaunchKernelGGL(reflect_fused_dcm<SPEC>, grid, block, 0, st, P1, M1, P2, M2, in, lo1, \
+  hipLaunchKernelGGL(reflect_fused_dcm<SPEC>, grid, fblock, 0, st, P1, M1, P2, M2, in, lo1, \
                      lo2, gb2, theta1, theta2, L.g1, L.g2, &L.g1->any_neg, &L.g2->any_neg, \
                      reinterpret_cast<OptStat*>(L.part1), reinterpret_cast<OptStat*>(L.part2))
     if (M1.thick)
