@@ -236,6 +236,13 @@ typedef struct xrt_hip_pass {
   int32_t zone_n;
   int32_t zone_black;
   const double* zone_r;
+  /* grating / zone-plate efficiency per diffraction order in place of the Fresnel
+   * amplitudes (Material.get_grating_efficiency, materials/material.py:391-413, constant
+   * values): eff_n pairs (order, sqrt(efficiency)); an order that is not listed gets 0.
+   * eff_n = 0: the material's own amplitudes. */
+  int32_t eff_n;
+  int32_t eff_order[8];
+  double eff_amp[8];
 } xrt_hip_pass;
 
 #define XRT_HIP_MAT_NONE 0

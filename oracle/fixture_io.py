@@ -68,6 +68,8 @@ def load_case(name):
                                          'grating', float(g['mat_rho']))
         p['order'] = int(g['order']) if g['order'].ndim == 0 else \
             tuple(int(o) for o in g['order'])
+        if 'efficiency' in g.files:
+            p['material']['efficiency'] = [[int(o), float(v)] for o, v in g['efficiency']]
         if 'gd_axis' in g.files:
             p['gratingDensity'] = [str(g['gd_axis'])] + \
                 [float(v) for v in g['gd_coeffs']]

@@ -97,6 +97,8 @@ def main():
              dict(gratingDensity=['y', 300., 1., 2.4e-4, -3.1e-8]), -1),
             ('g2_grating_const', dict(), 1),
             ('g2_grating_orders', dict(gratingDensity=['y', 300., 1., 2.4e-4]),
+             (1, -1, 2, 0)),
+            ('g2_grating_efficiency', dict(gratingDensity=['y', 300., 1., 2.4e-4]),
              (1, -1, 2, 0))):
         bl = raycing.BeamLine()
         if kw:
@@ -106,16 +108,23 @@ def main():
                 def local_g(self, x, y, rho=120.):
                     return rho, 0, 0          # grooves along y: sagittal mount
             cls = XGrating
+        efficiency = [[1, 0.31], [-1, 0.12], [2, 0.045]] if tag.endswith('efficiency') \
+            else None               # order 0 is not listed: those rays get no intensity
+        mG = rm.Material('Au', rho=19.32, kind='grating', efficiency=efficiency) \
+            if efficiency else mAuG
         gr = cls(bl, 'gr', center=[0, 2000., 0.], pitch=np.radians(2.2),
-                 material=mAuG, order=order, limPhysX=(-3, 3), limPhysY=(-45, 45),
+                 material=mG, order=order, limPhysX=(-3, 3), limPhysY=(-45, 45),
                  alarmLevel=None, **kw)
         several = isinstance(order, tuple)      # one order per hit ray, drawn at random
-        beam = make_rays(rs, n, (66 if several else 64) if kw else 65, sx=1.0, sz=0.9, sa=3e-5,
+        beam = make_rays(rs, n, ((68 if tag.endswith('efficiency') else 66) if several
+                                 else 64) if kw else 65, sx=1.0, sz=0.9, sa=3e-5,
                          sc=2e-5, E=(270., 290.), amplitudes=True, pol='mixed')
         beam.state[3] = 3
         beam.state[4] = -4
         par = oe_params(gr, dict(kind='flat'))
-        par['material'] = material_dict(tables, mAuG)
+        par['material'] = material_dict(tables, mG)
+        if efficiency:
+            par['material']['efficiency'] = efficiency
         par['order'] = order
         if kw:
             par['gratingDensity'] = kw['gratingDensity']
@@ -123,7 +132,9 @@ def main():
             par['gVector'] = (120., 0, 0)
         extra = dict(mat_rho=np.array(19.32), order=np.array(order))
         if several:
-            extra['np_seed'] = 20260928
+            extra['np_seed'] = 20260928 + int(bool(efficiency))
+        if efficiency:
+            extra['efficiency'] = np.array(efficiency, dtype=float)
         if kw:
             extra['gd_axis'] = np.array(kw['gratingDensity'][0])
             extra['gd_coeffs'] = np.array(kw['gratingDensity'][1:], dtype=float)

@@ -1016,6 +1016,14 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
                 refl = mat.crystal_amplitude(
                     matSur, lb.E[goodN], beamInDotSurfaceNormal,
                     beamOutDotSurfaceNormal, beamInDotNormal)
+            elif kind in ('grating', 'FZP') and matSur.get('efficiency') is not None:
+                # Material.get_grating_efficiency, material.py:391-413 (constant values)
+                resI = np.zeros(goodN.sum())
+                order = lb.order[goodN]
+                for eff in matSur['efficiency']:
+                    resI[order == eff[0]] = eff[1]
+                resA = resI**0.5
+                refl = resA, resA, 0
             else:
                 refl = mat.material_amplitude(
                     matSur, lb.E[goodN], beamInDotNormal, fromVacuum)

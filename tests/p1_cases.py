@@ -87,7 +87,9 @@ def product_oe(name, g):
         m = rm.Material('Rh', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.BentFlatMirror(bl, 'vcm', R=float(g['surf_R']), material=m, **common)
     elif name.startswith('g2_grating'):
-        m = rm.Material('Au', rho=float(g['mat_rho']), kind='grating')
+        eff = [[int(o), float(v)] for o, v in g['efficiency']] if 'efficiency' in g.files \
+            else None
+        m = rm.Material('Au', rho=float(g['mat_rho']), kind='grating', efficiency=eff)
         if 'gd_axis' in g.files:
             oe = roe.OE(bl, 'gr', material=m,
                         order=int(g['order']) if g['order'].ndim == 0 else

@@ -168,6 +168,26 @@ def test_random_diffraction_orders_match_reference_golden():
     assert np.array_equal(lb2.x, lb.x) and np.array_equal(lb2.state, lb.state)
 
 
+def test_grating_efficiency_per_order_matches_reference_golden():
+    """Material(kind='grating', efficiency=[[order, value], ...]) with a sequence of
+    orders: every ray's intensity is its order's efficiency (material.py:391-413), zero
+    for the order the table does not list."""
+    g = pc.load('g2_grating_efficiency')
+    oe = pc.product_oe('g2_grating_efficiency', g)
+    np.random.seed(int(g['np_seed']))
+    gb, lb = oe.reflect(pc.product_beam(g))
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    assert np.array_equal(lb.order, g['lb_order'])
+    hit = g['lb_state'] == 1
+    table = {int(o): float(v) for o, v in g['efficiency']}
+    flux_in = (g['in_Jss'] + g['in_Jpp'])
+    for order in (1, -1, 2, 0):
+        sel = hit & (g['lb_order'] == order)
+        ratio = (lb.Jss + lb.Jpp)[sel] / flux_in[sel]
+        assert sel.sum() > 300 and np.abs(ratio - table.get(order, 0.)).max() < 1e-12
+
+
 def test_position_dependent_user_local_g_is_refused():
     import xrt_amd.backends.raycing as raycing
     import xrt_amd.backends.raycing.materials as rm

@@ -74,10 +74,13 @@ def test_zone_plate_matches_reference(name):
         assert np.array_equal(lb.order, g['lb_order'])
 
 
-def test_random_diffraction_orders_follow_the_references_draw():
+@pytest.mark.parametrize('name', ['g2_grating_orders', 'g2_grating_efficiency'])
+def test_random_diffraction_orders_follow_the_references_draw(name):
     """order=(1, -1, 2, 0): one order per hit ray from numpy's global generator
-    (reflect.py:455-458); with the reference's seed the oracle draws the same."""
-    p, beam, g = fixture_io.load_case('g2_grating_orders')
+    (reflect.py:455-458); with the reference's seed the oracle draws the same. With a
+    table of efficiencies per order (material.py:391-413) the amplitudes are its square
+    roots, zero for an order the table does not list."""
+    p, beam, g = fixture_io.load_case(name)
     np.random.seed(int(g['np_seed']))
     gb, lb = rn.oe_reflect(p, beam)
     check_beam(gb, g, 'gb_')

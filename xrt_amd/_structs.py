@@ -73,6 +73,9 @@ class Pass(ctypes.Structure):
         ('zone_n', ctypes.c_int32),
         ('zone_black', ctypes.c_int32),
         ('zone_r', ctypes.c_void_p),
+        ('eff_n', ctypes.c_int32),
+        ('eff_order', ctypes.c_int32 * 8),
+        ('eff_amp', ctypes.c_double * 8),
     ]
 
 

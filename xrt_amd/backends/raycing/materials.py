@@ -101,7 +101,8 @@ class Material(object):
     (material.py:23-157)."""
 
     def __init__(self, elements=None, quantities=None, kind='auto', rho=0, t=None,
-                 table='Chantler total', name='', **kwargs):
+                 table='Chantler total', efficiency=None, efficiencyFile=None, name='',
+                 **kwargs):
         if isinstance(elements, str):
             elements = elements,
         self.table = table
@@ -118,6 +119,11 @@ class Material(object):
         self.kind = kind
         self.rho = rho
         self.t = t
+        # gratings / zone plates: [order, efficiency] pairs used in place of the Fresnel
+        # amplitudes (material.py:78-95, 391-413)
+        if efficiencyFile is not None:
+            raise NotImplementedError('efficiency tables from a file')
+        self.efficiency, self.efficiencyFile = efficiency, None
         self.geom = ''
         self.mass = 0.
         for elem, xi in zip(self.elements, self.quantities):

@@ -221,6 +221,14 @@ class OE(object):
             raise NotImplementedError('grating equation on a parametric surface')
         several = raycing.is_sequence(self.order)
         p.grating, p.grating_order = 1, int(self.order[0] if several else self.order)
+        material = self.material[0] if raycing.is_sequence(self.material) else self.material
+        pairs = getattr(material, 'efficiency', None)
+        if pairs is not None:
+            if len(pairs) > 8:
+                raise NotImplementedError('more than 8 efficiency entries')
+            p.eff_n = len(pairs)
+            for k, (order, value) in enumerate(pairs):
+                p.eff_order[k], p.eff_amp[k] = int(order), float(np.float64(value)**0.5)
         if hasattr(self, 'rn'):           # zone plate: the zone radii instead of a groove vector
             held = self.__dict__.setdefault('_zone_table', {})     # in HBM, per device
             cached = held.get(str(_device()))

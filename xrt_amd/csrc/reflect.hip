@@ -1748,6 +1748,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   out.bdn = bdn;
   const double bdsn = PASYM(P) ? (r.a * n[3] + r.b * n[4] + r.c * n[5]) : bdn;
 
+  int took_order = 0;   // the diffraction order this ray takes (gratings, zone plates)
   int toWhere = 0;  // reflect.py:723-752
   if (MKIND(M) == XRT_HIP_MAT_PLATE)
     toWhere = 1;
@@ -1789,6 +1790,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       // vector of OE.local_g (base.py:688-717)
       double g0 = P.g_const[0], g1 = P.g_const[1], g2 = P.g_const[2];
       double gsig = -1.;
+      took_order = P.order_ray ? P.order_ray[i] : P.grating_order;
       if (P.grating == 2) {  // zone plate: gn of rays_good_gn, sign +1 (reflect.py:857)
         double rad, rho;
         fzp_zone(P, h.x, h.y, rad, rho);
@@ -1872,6 +1874,13 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     A = crystal_amplitude<K::XTHICK>(M, q.E, bdsn, bosn, bdn, window_of(g), npre);
   } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
     A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g), npre);
+  }
+  if (PGRATING(P) && P.eff_n > 0) {  // tabulated efficiency of the order, material.py:391-413
+    double amp = 0.;
+    for (int k = 0; k < P.eff_n; ++k)
+      if (P.eff_order[k] == took_order) amp = P.eff_amp[k];
+    A.rs = A.rp = C(amp, 0.);
+    A.mu = A.nk = 0.;
   }
   if (cisnan(A.rs)) A.rs = C(0., 0.);
   if (cisnan(A.rp)) A.rp = C(0., 0.);
