@@ -442,6 +442,18 @@ typedef struct xrt_hip_aperture {
   int32_t round;               /* 1: RoundAperture (apertures.py:770-846): stopped where
                                   sqrt(x^2 + z^2) > radius instead of by blades */
   double radius;
+  /* DoubleSlit (apertures.py:931-1021): an opaque band shade[0] < z < shade[1] between the
+   * bottom and the top blade; its new global beam carries the incoming path twice (:1013) */
+  int32_t has_shade;
+  int32_t glo_adds_path;
+  double shade[2];
+  /* PolygonalAperture (apertures.py:1035-1310): open inside the polygon of poly_n
+   * vertices (DEVICE array x0, z0, x1, z1, ...; matplotlib's Path.contains_points). As in
+   * the reference the test also runs on the rays that do NOT enter (state <= 0), on their
+   * untransformed coordinates, and relabels them in the incoming beam (:1198-1203). */
+  int32_t poly_n;
+  int32_t reserved;
+  const double* poly_xz;
 } xrt_hip_aperture;
 
 XRT_HIP_API int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* aperture,

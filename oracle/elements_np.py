@@ -51,9 +51,11 @@ def screen_expose(beam, basis, center, lostNum, onlyPositivePath=False):
 
 
 def aperture_propagate(beam, basis, center, blades, lostNum, azimuth_sc=(0., 1.),
-                       isBeamStop=False, needNewGlobal=False, radius=None):
+                       isBeamStop=False, needNewGlobal=False, radius=None,
+                       shadeFraction=None, vertices=None):
     """Mutates beam.state like the reference. blades: dict left/right/bottom/top;
-    *radius*: a RoundAperture instead (apertures.py:770-846)."""
+    *radius*: a RoundAperture instead (apertures.py:770-846); *shadeFraction*: a DoubleSlit
+    (:931-1021); *vertices*: a PolygonalAperture (:1183-1225)."""
     good = beam.state > 0
     lo = beam.copy()
     _to_basis(beam, lo, basis, center, good)
@@ -73,10 +75,21 @@ def aperture_propagate(beam, basis, center, blades, lostNum, azimuth_sc=(0., 1.)
             badIndices[good] = badIndices[good] | (lo.z[good] < d)
         elif akind.startswith('t'):
             badIndices[good] = badIndices[good] | (lo.z[good] > d)
+    if shadeFraction is not None:
+        shadeMin = (1 - shadeFraction) * 0.5
+        shadeMax = shadeMin + shadeFraction
+        dsb, dst = blades['bottom'], blades['top']
+        sb = dsb + (dst - dsb) * shadeMin
+        st = dsb + (dst - dsb) * shadeMax
+        badIndices[good] = \
+            badIndices[good] | ((lo.z[good] > sb) & (lo.z[good] < st))
+    if vertices is not None:                      # every ray, entering or not (:1198-1199)
+        from .reflect_np import points_in_polygon
+        badIndices = np.invert(points_in_polygon(vertices, lo.x, lo.z))
     if isBeamStop:
         badIndices[good] = np.invert(badIndices[good])
     beam.state[badIndices] = lostNum
-    lo.state[:] = beam.state
+    lo.state[good] = beam.state[good]
     lo.y[good] = 0.
     if hasattr(lo, 'Es'):
         propPhase = np.exp(1e7j * (lo.E[good]/CHBAR) * path)
@@ -92,4 +105,6 @@ def aperture_propagate(beam, basis, center, blades, lostNum, azimuth_sc=(0., 1.)
     glo.x[good] += center[0]
     glo.y[good] += center[1]
     glo.z[good] += center[2]
+    if shadeFraction is not None:                 # apertures.py:1013
+        glo.path[good] += beam.path[good]
     return glo, lo

@@ -622,30 +622,47 @@ def main():
             ('rect_stop', ra.RectangularBeamStop,
              dict(kind=('left', 'right', 'bottom', 'top'), opening=[-0.3, 0.4, -0.1, 0.12])),
             ('round', ra.RoundAperture, dict(r=0.45)),
-            ('round_stop', ra.RoundBeamStop, dict(r=0.2))):
+            ('round_stop', ra.RoundBeamStop, dict(r=0.2)),
+            ('double', ra.DoubleSlit,
+             dict(kind=('left', 'right', 'bottom', 'top'), opening=[-0.5, 0.6, -0.25, 0.3],
+                  shadeFraction=0.4)),
+            ('polygon', ra.PolygonalAperture,
+             dict(vertices=[(-0.5, -0.2), (0.1, -0.3), (0.6, 0.0), (0.2, 0.3), (-0.3, 0.15)])),
+            ('polygon_stop', ra.PolygonalBeamStop,
+             dict(vertices=[(-0.2, -0.1), (0.2, -0.1), (0.0, 0.2)]))):
         bl = raycing.BeamLine(azimuth=-0.02)
         ap = cls(bl, tag, center=[np.sin(-0.02)*8000., np.cos(-0.02)*8000., 0.05], **kw)
         beam = rs.Beam(copyFrom=b_in)
         glo, lo = ap.propagate(beam, needNewGlobal=True)
         ob = to_oracle_beam(b_in)
         mglo, mlo = en.aperture_propagate(
-            ob, ap.xyz, ap.center, dict(getattr(ap, 'blades', {})) if 'rect' in tag else {},
+            ob, ap.xyz, ap.center,
+            dict(getattr(ap, 'blades', {})) if tag in ('rect_stop', 'double') else {},
             ap.lostNum, (bl.sinAzimuth, bl.cosAzimuth), isBeamStop=ap.isBeamStop,
-            needNewGlobal=True, radius=kw.get('r'))
+            needNewGlobal=True, radius=kw.get('r'), shadeFraction=kw.get('shadeFraction'),
+            vertices=kw.get('vertices'))
         assert_beams('g7b:lo', mlo, lo)
         assert_beams('g7b:glo', mglo, glo)
         assert np.array_equal(ob.state, beam.state)
         st, cnt = np.unique(lo.state, return_counts=True)
         print('g7b', tag, 'states', dict(zip(st.tolist(), cnt.tolist())))
-        out.update(beam_dict(tag + '_lo_', lo))
-        if tag == 'round':
+        # (the full local / global records of a slit are in g7_aperture: here what the
+        # stop shapes decide, plus the complete global beam where it is special)
+        full = beam_dict(tag + '_lo_', lo)
+        out.update({k: v for k, v in full.items()
+                    if k.rsplit('_', 1)[1] in ('state', 'x', 'y', 'z', 'path', 'Es')})
+        if tag in ('round', 'double'):
             out.update(beam_dict(tag + '_glo_', glo))
         out[tag + '_in_state_after'] = np.array(beam.state)
         out[tag + '_center'] = np.array(ap.center, dtype=float)
         out[tag + '_lostNum'] = np.array(ap.lostNum)
     out.update(beam_dict('in_', b_in))
     out.update(azimuth=np.array(-0.02), rect_stop_opening=np.array([-0.3, 0.4, -0.1, 0.12]),
-               round_r=np.array(0.45), round_stop_r=np.array(0.2))
+               round_r=np.array(0.45), round_stop_r=np.array(0.2),
+               double_opening=np.array([-0.5, 0.6, -0.25, 0.3]), double_shade=np.array(0.4),
+               polygon_vertices=np.array([(-0.5, -0.2), (0.1, -0.3), (0.6, 0.0), (0.2, 0.3),
+                                          (-0.3, 0.15)]),
+               polygon_stop_vertices=np.array([(-0.2, -0.1), (0.2, -0.1), (0.0, 0.2)]))
     save('g7_stops_round', **out)
 
 

@@ -168,13 +168,20 @@ def test_mesh_sources_match_reference(golden_dir):
 
 
 _STOPS = (('rect_stop', 'RectangularBeamStop'), ('round', 'RoundAperture'),
-          ('round_stop', 'RoundBeamStop'))
+          ('round_stop', 'RoundBeamStop'), ('double', 'DoubleSlit'),
+          ('polygon', 'PolygonalAperture'), ('polygon_stop', 'PolygonalBeamStop'))
+_LO_FIELDS = ('x', 'y', 'z', 'path', 'Es')
 
 
 def _stop_args(g, tag):
-    if tag == 'rect_stop':
-        return dict(kind=('left', 'right', 'bottom', 'top'),
-                    opening=[float(v) for v in g['rect_stop_opening']])
+    if tag in ('rect_stop', 'double'):
+        kw = dict(kind=('left', 'right', 'bottom', 'top'),
+                  opening=[float(v) for v in g[tag + '_opening']])
+        if tag == 'double':
+            kw['shadeFraction'] = float(g['double_shade'])
+        return kw
+    if tag.startswith('polygon'):
+        return dict(vertices=[tuple(float(c) for c in v) for v in g[tag + '_vertices']])
     return dict(r=float(g[tag + '_r']))
 
 
@@ -191,10 +198,12 @@ def test_oracle_stops_and_round_apertures_match_reference(golden_dir):
         blades = dict(zip(kw['kind'], kw['opening'])) if 'kind' in kw else {}
         lo = en.aperture_propagate(b, basis, g[tag + '_center'], blades,
                                    int(g[tag + '_lostNum']), (np.sin(az), np.cos(az)),
-                                   isBeamStop=tag.endswith('stop'), radius=kw.get('r'))
+                                   isBeamStop=tag.endswith('stop'), radius=kw.get('r'),
+                                   shadeFraction=kw.get('shadeFraction'),
+                                   vertices=kw.get('vertices'))
         assert np.array_equal(b.state, g[tag + '_in_state_after'])
         assert np.array_equal(lo.state, g[tag + '_lo_state'])
-        for f in FIELDS + ('Es', 'Ep'):
+        for f in _LO_FIELDS:
             r = g['%s_lo_%s' % (tag, f)]
             assert np.abs(getattr(lo, f) - r).max() <= 1e-13 * max(np.abs(r).max(), 1e-300), f
 
@@ -213,10 +222,11 @@ def test_stops_and_round_apertures_match_reference(golden_dir, tag, cls):
         setattr(b, f, g['in_' + f])
     glo, lo = ap.propagate(b, needNewGlobal=True)
     assert np.array_equal(b.state, g[tag + '_in_state_after'])
-    checks = [(lo, '_lo_')] + ([(glo, '_glo_')] if tag == 'round' else [])
-    for ob, pre in checks:
+    checks = [(lo, '_lo_', _LO_FIELDS)] + (
+        [(glo, '_glo_', FIELDS + ('Es', 'Ep'))] if tag in ('round', 'double') else [])
+    for ob, pre, fields in checks:
         assert np.array_equal(ob.state, g[tag + pre + 'state'])
-        for f in FIELDS + ('Es', 'Ep'):
+        for f in fields:
             r = g[tag + pre + f]
             assert np.abs(getattr(ob, f) - r).max() <= 1e-13 * max(np.abs(r).max(), 1e-300), f
     if tag == 'round':           # the wave samples fill the disc

@@ -131,7 +131,13 @@ class Aperture(ctypes.Structure):
                 ('is_beam_stop', ctypes.c_int32),
                 ('lost_num', ctypes.c_int32),
                 ('round', ctypes.c_int32),
-                ('radius', ctypes.c_double)]
+                ('radius', ctypes.c_double),
+                ('has_shade', ctypes.c_int32),
+                ('glo_adds_path', ctypes.c_int32),
+                ('shade', ctypes.c_double * 2),
+                ('poly_n', ctypes.c_int32),
+                ('reserved', ctypes.c_int32),
+                ('poly_xz', ctypes.c_void_p)]
 
 
 class Undulator(ctypes.Structure):

@@ -68,6 +68,19 @@ class RectangularAperture(object):
         a.lost_num = int(self.lostNum)
         if hasattr(self, 'r'):
             a.round, a.radius, a.blade_mask = 1, float(self.r), 0
+        if hasattr(self, 'shadeFraction'):      # the band between the two slits
+            low = (1 - self.shadeFraction) * 0.5
+            bottom, top = self.blades['bottom'], self.blades['top']
+            a.has_shade, a.glo_adds_path = 1, 1
+            a.shade[0] = bottom + (top - bottom) * low
+            a.shade[1] = bottom + (top - bottom) * (low + self.shadeFraction)
+        if hasattr(self, 'vertices'):
+            outline = np.ascontiguousarray(self.vertices, dtype=np.float64).reshape(-1, 2)
+            held = self.__dict__.setdefault('_outline', {})
+            dev = torch.device('cuda', torch.cuda.current_device())
+            if str(dev) not in held or not np.array_equal(held[str(dev)][0], outline):
+                held[str(dev)] = (outline, torch.from_numpy(outline.copy()).to(dev))
+            a.poly_n, a.poly_xz, a.blade_mask = len(outline), held[str(dev)][1].data_ptr(), 0
         return a
 
     def propagate(self, beam=None, needNewGlobal=False):
@@ -155,4 +168,51 @@ class RoundBeamStop(RoundAperture):
 
     def __init__(self, *args, **kwargs):
         RoundAperture.__init__(self, *args, **kwargs)
+        self.isBeamStop = True
+
+
+class DoubleSlit(RectangularAperture):
+    """Two slits one above the other: the opening between the bottom and the top blade
+    with its middle *shadeFraction* (0..1) opaque."""
+
+    def __init__(self, *args, **kwargs):
+        self.shadeFraction = kwargs.pop('shadeFraction', 0.5)
+        RectangularAperture.__init__(self, *args, **kwargs)
+        if not {'bottom', 'top'} <= set(self.blades):
+            raise ValueError('a DoubleSlit needs a bottom and a top blade')
+
+
+class DoubleBeamStop(DoubleSlit):
+    """The two slit openings are the solid parts."""
+
+    def __init__(self, *args, **kwargs):
+        DoubleSlit.__init__(self, *args, **kwargs)
+        self.isBeamStop = True
+
+
+class PolygonalAperture(RectangularAperture):
+    """Open inside the polygon of *vertices* [(x0, z0), ...] in the aperture's plane
+    (*opening* is an alias); a point on the outline counts as matplotlib's
+    ``Path.contains_points`` counts it."""
+
+    def __init__(self, bl=None, name='', center=[0, 0, 0], opening=None, x='auto', z='auto',
+                 alarmLevel=None, vertices=((-10, -10), (-10, 10), (10, 10), (10, -10)),
+                 **kwargs):
+        RectangularAperture.__init__(self, bl, name, center, blades={}, x=x, z=z,
+                                     alarmLevel=alarmLevel, **kwargs)
+        self.vertices = [tuple(v) for v in (opening if opening is not None else vertices)]
+        self.shape = 'polygon'
+        corners = np.array(self.vertices, dtype=float)
+        self.limOptX = [corners[:, 0].min(), corners[:, 0].max()]
+        self.limOptY = [corners[:, 1].min(), corners[:, 1].max()]
+
+    def prepare_wave(self, prevOE, nrays, rw=None):
+        raise NotImplementedError('wave samples on a polygonal aperture')
+
+
+class PolygonalBeamStop(PolygonalAperture):
+    """The polygon is the solid part."""
+
+    def __init__(self, *args, **kwargs):
+        PolygonalAperture.__init__(self, *args, **kwargs)
         self.isBeamStop = True

@@ -79,6 +79,23 @@ hipError_t screen_expose_launch(const xrt_hip_screen& S, const xrt_hip_beam& in,
 }
 
 
+// matplotlib's Path.contains_points for a closed polygon (src/_path.h, point_in_path_impl,
+// radius 0), as in reflect.hip's rays_good: an edge whose ends lie on different sides of the
+// horizontal through the point toggles `inside` when the crossing is to its right.
+__device__ __forceinline__ bool inside_polygon(const double* v, int n, double x, double y) {
+  if (n < 3 || !(isfinite(x) && isfinite(y))) return false;
+  bool inside = false;
+  double x0 = v[2 * (n - 1)], y0 = v[2 * (n - 1) + 1];
+  for (int k = 0; k < n; ++k) {
+    const double x1 = v[2 * k], y1 = v[2 * k + 1];
+    const bool up0 = y0 >= y, up1 = y1 >= y;
+    if (up0 != up1 && (((y1 - y) * (x0 - x1) >= (x1 - x) * (y0 - y1)) == up1)) inside = !inside;
+    x0 = x1;
+    y0 = y1;
+  }
+  return inside;
+}
+
 // RectangularAperture.propagate, apertures.py:334-413. Same streaming shape as
 // screen_expose; additionally writes the new state back into the incoming beam.
 __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_aperture A,
@@ -119,6 +136,8 @@ __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_apertur
     if (A.blade_mask & 2) bad = bad || (x > A.blade[1]);
     if (A.blade_mask & 4) bad = bad || (z < A.blade[2]);
     if (A.blade_mask & 8) bad = bad || (z > A.blade[3]);
+    if (A.has_shade) bad = bad || (z > A.shade[0] && z < A.shade[1]);
+    if (A.poly_n > 0) bad = !inside_polygon(A.poly_xz, A.poly_n, x, z);
     if (A.is_beam_stop) bad = !bad;
     if (bad) {
       st = A.lost_num;
@@ -135,6 +154,9 @@ __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_apertur
       ep = make_double2(ep.x * co - ep.y * s, ep.x * s + ep.y * co);
     }
   }
+  if (!good && A.poly_n > 0 && !inside_polygon(A.poly_xz, A.poly_n, x, z))
+    in.state[i] = A.lost_num;   // apertures.py:1198-1203: the incoming beam only
+  const double path_in = in.path[i];
   const double Jss = in.Jss[i], Jpp = in.Jpp[i];
   const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
   lo.x[i] = x;
@@ -166,6 +188,7 @@ __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_apertur
       x += A.center[0];
       y += A.center[1];
       z += A.center[2];
+      if (A.glo_adds_path) path = path + path_in;   // DoubleSlit, apertures.py:1013
     }
     glo.x[i] = x;
     glo.y[i] = y;
