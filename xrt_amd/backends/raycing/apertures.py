@@ -17,6 +17,14 @@ _BLADES = {'left': ('limOptX', 0), 'right': ('limOptX', 1),
 _BLADE_ORDER = tuple(_BLADES)
 
 
+def _stop_of(opening, name, doc):
+    """The beam-stop twin of an aperture class: the nominal opening is the solid part."""
+    def construct(self, *args, **kwargs):
+        opening.__init__(self, *args, **kwargs)
+        self.isBeamStop = True
+    return type(name, (opening,), {'__init__': construct, '__doc__': doc})
+
+
 class RectangularAperture(object):
     def __init__(self, bl=None, name='', center=[0, 0, 0],
                  kind=_BLADE_ORDER, opening=(-10, 10, -10, 10),
@@ -124,12 +132,7 @@ class RectangularAperture(object):
                                  opened, self.uuid)
 
 
-class RectangularBeamStop(RectangularAperture):
-    """The blades enclose the solid part: rays inside are stopped, rays outside pass."""
-
-    def __init__(self, *args, **kwargs):
-        RectangularAperture.__init__(self, *args, **kwargs)
-        self.isBeamStop = True
+RectangularBeamStop = _stop_of(RectangularAperture, "RectangularBeamStop", """The blades enclose the solid part: rays inside are stopped, rays outside pass.""")
 
 
 class RoundAperture(RectangularAperture):
@@ -163,12 +166,7 @@ class RoundAperture(RectangularAperture):
                                  self.uuid)
 
 
-class RoundBeamStop(RoundAperture):
-    """A disc of radius *r* in the beam: rays inside are stopped."""
-
-    def __init__(self, *args, **kwargs):
-        RoundAperture.__init__(self, *args, **kwargs)
-        self.isBeamStop = True
+RoundBeamStop = _stop_of(RoundAperture, "RoundBeamStop", """A disc of radius *r* in the beam: rays inside are stopped.""")
 
 
 class DoubleSlit(RectangularAperture):
@@ -182,12 +180,7 @@ class DoubleSlit(RectangularAperture):
             raise ValueError('a DoubleSlit needs a bottom and a top blade')
 
 
-class DoubleBeamStop(DoubleSlit):
-    """The two slit openings are the solid parts."""
-
-    def __init__(self, *args, **kwargs):
-        DoubleSlit.__init__(self, *args, **kwargs)
-        self.isBeamStop = True
+DoubleBeamStop = _stop_of(DoubleSlit, "DoubleBeamStop", """The two slit openings are the solid parts.""")
 
 
 class PolygonalAperture(RectangularAperture):
@@ -210,9 +203,4 @@ class PolygonalAperture(RectangularAperture):
         raise NotImplementedError('wave samples on a polygonal aperture')
 
 
-class PolygonalBeamStop(PolygonalAperture):
-    """The polygon is the solid part."""
-
-    def __init__(self, *args, **kwargs):
-        PolygonalAperture.__init__(self, *args, **kwargs)
-        self.isBeamStop = True
+PolygonalBeamStop = _stop_of(PolygonalAperture, "PolygonalBeamStop", """The polygon is the solid part.""")

@@ -434,6 +434,19 @@ def make_energy(distE, energies, nrays, filamentBeam=False, energyWeights=None):
     raise ValueError('unknown distE')
 
 
+def _enrol_source(source, bl, name, uuid_=None, listed=True):
+    """A source on its beamline: numbered in ``bl.sources`` (if *listed*) and findable by
+    its uuid."""
+    source.bl, source.name = bl, name
+    source.uuid = uuid_ or raycing.new_uuid()
+    if bl is None:
+        return
+    if listed and source not in bl.sources:
+        bl.sources.append(source)
+        source.ordinalNum = len(bl.sources)
+    bl.oesDict[source.uuid] = [source, 0]
+
+
 class GeometricSource(object):
     """Rays with origin, divergence and energy sampled from simple laws."""
     # the sampled ray coordinates in the order the random numbers are drawn: a lone one,
@@ -450,14 +463,7 @@ class GeometricSource(object):
                  polarization='horizontal', filamentBeam=False,
                  uniformRayDensity=False, pitch=0, roll=0, yaw=0, **kwargs):
         given = dict(locals())
-        self.bl = bl
-        if bl is not None and self not in bl.sources:
-            bl.sources.append(self)
-            self.ordinalNum = len(bl.sources)
-        self.name = name or 'GeometricSource'
-        self.uuid = kwargs.get('uuid', raycing.new_uuid())
-        if bl is not None:
-            bl.oesDict[self.uuid] = [self, 0]
+        _enrol_source(self, bl, name or 'GeometricSource', kwargs.get('uuid'))
         self.nrays = int(nrays)
         for key in ('center', 'distE', 'energies', 'energyWeights', 'polarization',
                     'filamentBeam', 'uniformRayDensity', 'pitch', 'roll', 'yaw'):
@@ -559,14 +565,7 @@ class MeshSource(object):
                  energies=(defaultEnergy,), energyWeights=None, polarization='horizontal',
                  withCentralRay=True, autoAppendToBL=False, totalFlux=None, **kwargs):
         given = dict(locals())
-        self.bl = bl
-        if autoAppendToBL and bl is not None and self not in bl.sources:
-            bl.sources.append(self)
-            self.ordinalNum = len(bl.sources)
-        self.name = name or 'MeshSource'
-        self.uuid = kwargs.get('uuid', raycing.new_uuid())
-        if bl is not None:
-            bl.oesDict[self.uuid] = [self, 0]
+        _enrol_source(self, bl, name or 'MeshSource', kwargs.get('uuid'), autoAppendToBL)
         for key in ('center', 'nx', 'nz', 'distE', 'energies', 'energyWeights', 'polarization',
                     'withCentralRay', 'totalFlux'):
             setattr(self, key, given[key])
