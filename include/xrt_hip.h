@@ -250,7 +250,13 @@ typedef struct xrt_hip_pass {
 #define XRT_HIP_MAT_THIN_MIRROR 2
 #define XRT_HIP_MAT_PLATE 3
 #define XRT_HIP_MAT_CRYSTAL 4
+#define XRT_HIP_MAT_MULTILAYER 5 /* Multilayer / GradedMultilayer / Coated: xrt_hip_material.layers */
 #define XRT_HIP_MAX_ELEM 4
+#define XRT_HIP_BUCKETS 1280
+#define XRT_HIP_BUCKET_SHIFT 46
+#define XRT_HIP_BUCKET_KEY0 (0x3FF << 6) /* the bits of 1.0 >> XRT_HIP_BUCKET_SHIFT */
+
+struct xrt_hip_multilayer;
 
 typedef struct xrt_hip_material {
   int32_t kind;
@@ -264,6 +270,12 @@ typedef struct xrt_hip_material {
   const double* tab_E[XRT_HIP_MAX_ELEM];
   const double* tab_f1[XRT_HIP_MAX_ELEM];
   const double* tab_f2[XRT_HIP_MAX_ELEM];
+  /* optional (NULL: plain binary search) -- a coarse index of tab_E that brings the
+   * search down to a step or two: tab_bucket[e][k], k = 0..XRT_HIP_BUCKETS, = number of
+   * table energies <= the k-th bucket edge; the edges are the doubles whose top 18 bits
+   * are XRT_HIP_BUCKET_KEY0 + k and whose other bits are 0 (64 edges per octave from
+   * 1 eV to 2^20 eV). */
+  const int32_t* tab_bucket[XRT_HIP_MAX_ELEM];
   double f0_hkl;               /* crystals: f0(sin(theta)/lambda = 1/2d) of element 0
                                   (element.py:203-207), a per-crystal constant */
   double d2f_re, d2f_im;       /* crystals: 1 + exp(i pi/2 (h+k+l)), crystals_basic.py:77 */
@@ -275,13 +287,39 @@ typedef struct xrt_hip_material {
   int32_t geom_transmitted;    /* 1 transmitted, 0 reflected */
   int32_t thick;               /* 1: t is None (semi-infinite Bragg) */
   double d, chi_to_f, fact_dw, t_crystal;
+  /* kind == XRT_HIP_MAT_MULTILAYER: the stack, a record in DEVICE memory. Of the fields
+   * above the pass reads geom_bragg -- 1: kind 'multilayer', deflects like a Bragg crystal
+   * of spacing d, the period (reflect.py:865-872), amplitude at the cosine to the surface
+   * normal; 0: Coated (kind 'mirror'), mirror direction, amplitude at the cosine to the
+   * local normal --, d and geom_transmitted. */
+  const struct xrt_hip_multilayer* layers;
 } xrt_hip_material;
+
+/* Multilayer / GradedMultilayer / Coated (materials/multilayer.py): npairs periods of a
+ * top and a bottom layer on a substrate, Parratt's recursion with Nevot-Croce roughness
+ * factors (multilayer.py:257-566). Of the three xrt_hip_material records only the element
+ * tables, rho and mass are read; nelem == 0 stands for vacuum (n = 1: a missing layer or
+ * substrate). Thicknesses in Angstrom. */
+typedef struct xrt_hip_multilayer {
+  xrt_hip_material top, bottom, substrate;
+  int32_t npairs;
+  int32_t transmitted;      /* geom 'transmitted': the stack + substrate of subst_thickness */
+  int32_t uniform;          /* every period has dti[0], dbi[0]: the two phase factors are
+                               evaluated once per ray */
+  const double* dti;        /* [npairs] top-layer thickness per period, vacuum side first */
+  const double* dbi;        /* [npairs] bottom-layer thickness */
+  double id2;               /* idThickness^2 (interdiffusion / roughness, rms) */
+  double bs_rough2;         /* bottom layer - substrate: id2, or substRoughness^2 without a
+                               top layer (multilayer.py:353) */
+  double subst_thickness;   /* transmitted only; may be INFINITY */
+} xrt_hip_multilayer;
 
 /* Scratch needed by xrt_hip_reflect_pass_f64_dev for n rays. */
 XRT_HIP_API size_t xrt_hip_reflect_workspace_bytes(int64_t n);
 
 /* sizeof() of the structs above, to let a binding verify its layout:
- * which = 0 beam, 1 rotation, 2 pass, 3 material, 4 screen, 5 aperture. */
+ * which = 0 beam, 1 rotation, 2 pass, 3 material, 4 screen, 5 aperture, 6 undulator,
+ * 7 undulator_map, 8 plot, 9 custom_field, 10 bend, 11 multilayer. */
 XRT_HIP_API int xrt_hip_sizeof(int which);
 
 /* in: incoming beam. out_local: "lb" of the reference (true local frame).
@@ -409,6 +447,13 @@ XRT_HIP_API int xrt_hip_material_amplitude_f64_dev(
 XRT_HIP_API int xrt_hip_crystal_amplitude_f64_dev(
     const xrt_hip_material* material, int64_t n, const double* E, const double* gamma0,
     const double* gammah, const double* hns, double* S_ri, double* P_ri, void* stream);
+/* Multilayer.get_amplitude(E, beamInDotNormal) -> (ri_s, ri_p) or, transmitted, (ti_s,
+ * ti_p) (materials/multilayer.py:257-566; the reference's OpenCL twins are
+ * get_amplitude_graded_multilayer{,_tran}, cl/materials.cl). material->kind must be
+ * XRT_HIP_MAT_MULTILAYER. */
+XRT_HIP_API int xrt_hip_multilayer_amplitude_f64_dev(
+    const xrt_hip_material* material, int64_t n, const double* E, const double* bdn,
+    double* rs_ri, double* rp_ri, void* stream);
 
 /* ---- Screen.expose (screens.py:226-302) on a device-resident beam ---------
  * ex, ey, ez: the screen's local axes in the global frame (beamline.py:288-316);

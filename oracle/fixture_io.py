@@ -89,6 +89,11 @@ def load_case(name):
             **{k: float(g['surf_' + k]) for k in keys})
         p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
                                          'mirror', float(g['mat_rho']))
+    elif name in ('g2_multilayer_flat', 'g2_multilayer_tran', 'g2_coated_toroid'):
+        from . import gen_fixtures_multilayer as gm
+        p['surface'] = dict(kind='toroid', R=float(g['surf_R']), r=float(g['surf_r'])) \
+            if 'surf_R' in g.files else dict(kind='flat')
+        p['material'] = gm.oracle_stack(gm.all_tables(), str(g['stack']))
     elif name.startswith('g2_ellipse'):
         p['surface'] = dict(
             kind='ellipse_param', isClosed=False,
@@ -96,8 +101,12 @@ def load_case(name):
             **{k: float(g['surf_' + k]) for k in
                ('p', 'q', 'cosGamma', 'sinGamma', 'y0', 'z0', 'ellipseA',
                 'ellipseB')})
-        p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
-                                         'mirror', float(g['mat_rho']))
+        if 'stack' in g.files:
+            from . import gen_fixtures_multilayer as gm
+            p['material'] = gm.oracle_stack(gm.all_tables(), str(g['stack']))
+        else:
+            p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
+                                             'mirror', float(g['mat_rho']))
     elif name == 'g2_plate_be':
         p['surface'] = dict(kind='flat')
         p['surface2'] = dict(kind='flat')

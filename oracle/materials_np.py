@@ -14,6 +14,8 @@ Reference anchors, relative to xrt/backends/raycing/materials/:
 * crystal_amplitude  <- crystal.py:492-645 (Belyakov-Dmitrienko), :297-306
                         (get_F_chi), :1105-1120 (Bragg angle)
 * si_lattice_a       <- crystals_basic.py:99-142 (Swenson thermal expansion)
+* make_multilayer / multilayer_amplitude <- multilayer.py:167-191 (depth grading),
+                        :257-566 (Parratt recursion, Nevot-Croce factors; Coated :577-625)
 """
 import numpy as np
 
@@ -101,6 +103,109 @@ def material_amplitude(m, E, beamInDotNormal, fromVacuum=True):
     else:
         raise ValueError('Unknown kind of material')
     return (rs, rp, abs(n.imag) * E / CHBAR * 2e8, n.real * E / CHBAR * 1e8)
+
+
+# --------------------------------------------------------------------------
+# multilayers and coated mirrors
+# --------------------------------------------------------------------------
+def _graded(high, low, nPairs, power):                 # multilayer.py:167-191
+    if low:
+        layers = np.arange(1, nPairs+1)
+        qRoot = (high/low)**(1./power)
+        qB = (nPairs-qRoot) / (qRoot-1.)
+        qA = high * (qB+1)**power
+        return qA * (qB+layers)**(-power)
+    return np.ones(nPairs) * float(high)
+
+
+def make_multilayer(tLayer=None, tThickness=0., bLayer=None, bThickness=0., nPairs=0,
+                    substrate=None, tThicknessLow=0., bThicknessLow=0., idThickness=0.,
+                    power=2., substRoughness=0., substThickness=np.inf, geom='reflected',
+                    kind='multilayer'):
+    """Layers are material dicts (make_material) or None = vacuum. kind 'mirror' is the
+    reference's Coated (one period, no top layer)."""
+    return dict(kind=kind, layered=True, tLayer=tLayer, bLayer=bLayer, substrate=substrate,
+                nPairs=int(nPairs), dti=_graded(float(tThickness), float(tThicknessLow),
+                                                int(nPairs), power),
+                dbi=_graded(float(bThickness), float(bThicknessLow), int(nPairs), power),
+                idThickness=idThickness, substRoughness=float(substRoughness),
+                substThickness=substThickness, geom=geom,
+                d=float(tThickness + bThickness))
+
+
+def make_coated(coating, cThickness, substrate, surfaceRoughness=0., substRoughness=0.):
+    return make_multilayer(bLayer=coating, bThickness=cThickness, idThickness=surfaceRoughness,
+                           nPairs=1, substrate=substrate, substRoughness=substRoughness,
+                           kind='mirror')
+
+
+def multilayer_amplitude(ml, E, beamInDotNormal):
+    k = E / CHBAR
+    nt = refractive_index(ml['tLayer'], E).conjugate() if ml['tLayer'] else 1.
+    nb = refractive_index(ml['bLayer'], E).conjugate() if ml['bLayer'] else 1.
+    ns = refractive_index(ml['substrate'], E).conjugate() if ml['substrate'] else 1.
+    tran = 'tran' in ml['geom']
+    Q = 2 * k * abs(beamInDotNormal)
+    Q2 = Q**2
+    k28 = 8 * k**2
+    Qt = (Q2 + (nt-1)*k28)**0.5
+    Qb = (Q2 + (nb-1)*k28)**0.5
+    Qs = (Q2 + (ns-1)*k28)**0.5
+    id2 = ml['idThickness']**2
+
+    def interface(Qa, na, Qb_, nb_, rough):
+        """(r_s, r_p, t_s, t_p) from medium a into medium b."""
+        A, B = Qa/na*nb_, Qb_/nb_*na
+        return (np.complex128((Qa-Qb_) / (Qa+Qb_) * rough),
+                np.complex128((A-B) / (A+B) * rough),
+                np.complex128(2*Qa / (Qa+Qb_) * rough),
+                np.complex128(2*A / (A+B) * rough))
+    vt = interface(Q, 1., Qt, nt, np.exp(-0.5 * Q * Qt * id2))
+    roughtb = np.exp(-0.5 * Qt * Qb * id2)
+    tb = interface(Qt, nt, Qb, nb, roughtb)
+    bt = interface(Qb, nb, Qt, nt, roughtb)
+    rmsbs = id2 if ml['tLayer'] else ml['substRoughness']**2
+    roughbs = np.exp(-0.5 * Qb * Qs * rmsbs)
+    bs = interface(Qb, nb, Qs, ns, roughbs)
+    sv = interface(Qs, ns, Q, 1., roughbs)
+    nPairs = ml['nPairs']
+    if tran:
+        rj_s, rj_p, tj_s, tj_p = sv
+        extraLayer = 1
+    else:
+        rj_s, rj_p = bs[0], bs[1]
+        tj_s = tj_p = 0.
+        extraLayer = 0
+    for i in reversed(range(2*nPairs+extraLayer)):
+        if i % 2 == 0:
+            if i == 0:
+                f = vt
+                iQT = Qt * ml['dti'][0]
+            elif i == 2*nPairs:
+                f = bs
+                iQT = Qs * ml['substThickness']
+            else:
+                f = bt
+                iQT = Qt * ml['dti'][i//2]
+        else:
+            f = tb
+            iQT = Qb * ml['dbi'][i//2]
+        p1i = np.complex128(np.exp(0.5j*iQT))
+        p2i = p1i**2
+        rj2i_s = rj_s * p2i
+        rj2i_p = rj_p * p2i
+        ri_s = (f[0] + rj2i_s) / (1 + f[0]*rj2i_s)
+        ri_p = (f[1] + rj2i_p) / (1 + f[1]*rj2i_p)
+        if tran:
+            tj_s = f[2] * tj_s * p1i / (1 + f[0]*rj2i_s)
+            tj_p = f[3] * tj_p * p1i / (1 + f[1]*rj2i_p)
+        rj_s, rj_p = ri_s, ri_p
+    if tran:
+        return tj_s, tj_p
+    nn = nt[0] if isinstance(nt, np.ndarray) else nt
+    if (nn - 1) > 0:
+        return rj_s.conjugate(), rj_p.conjugate()
+    return rj_s, rj_p
 
 
 # --------------------------------------------------------------------------

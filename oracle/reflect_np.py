@@ -929,7 +929,7 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
             kind = matSur['kind']
             if kind in ('plate', 'lens'):
                 toWhere = 1
-            elif kind == 'crystal':
+            elif kind in ('crystal', 'multilayer'):       # reflect.py:734-741
                 if matSur['geom'].endswith('transmitted'):
                     toWhere = 2
             elif kind == 'grating':               # reflect.py:743-744
@@ -975,7 +975,7 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
             lb.order = np.zeros(len(lb.a))
             lb.order[goodN] = drawn[0]
         elif toWhere in (0, 2):
-            if kind == 'crystal' and toWhere == 0:
+            if kind in ('crystal', 'multilayer') and toWhere == 0:   # reflect.py:865-872
                 a_out, b_out, c_out = asymmetric_reflection_grating(
                     matSur, lb.a[goodN], lb.b[goodN], lb.c[goodN], lb.E[goodN],
                     oeNormal, beamInDotSurfaceNormal, beamInDotNormal)
@@ -1016,6 +1016,11 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
                 refl = mat.crystal_amplitude(
                     matSur, lb.E[goodN], beamInDotSurfaceNormal,
                     beamOutDotSurfaceNormal, beamInDotNormal)
+            elif kind == 'multilayer':                # reflect.py:999-1003
+                refl = mat.multilayer_amplitude(
+                    matSur, lb.E[goodN], beamInDotSurfaceNormal)
+            elif matSur.get('layered'):               # Coated, kind 'mirror': :1031-1032
+                refl = mat.multilayer_amplitude(matSur, lb.E[goodN], beamInDotNormal)
             elif kind in ('grating', 'FZP') and matSur.get('efficiency') is not None:
                 # Material.get_grating_efficiency, material.py:391-413 (constant values)
                 resI = np.zeros(goodN.sum())
@@ -1041,7 +1046,8 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
             lb.Es[goodN] *= ras
             lb.Ep[goodN] *= rap
 
-        if (not fromVacuum) and material is not None and kind != 'crystal':
+        if (not fromVacuum) and material is not None and \
+                kind not in ('crystal', 'multilayer'):
             att = np.exp(-refl[2] * tMax[goodN] * 0.1)
             lb.Jss[goodN] *= att
             lb.Jpp[goodN] *= att

@@ -51,6 +51,18 @@ def _opt(g, key):
     return None if v.ndim == 0 else [float(t) for t in v]
 
 
+def product_stack(name):
+    """The xrt_amd Multilayer / Coated of the stack *name* of
+    oracle/gen_fixtures_multilayer.py."""
+    from oracle.gen_fixtures_multilayer import COMPOUNDS, STACKS
+    kw = dict(STACKS[name])
+    for key in ('tLayer', 'bLayer', 'substrate', 'coating'):
+        if kw.get(key) is not None:
+            els, q, rho = COMPOUNDS[kw[key]]
+            kw[key] = rm.Material(els, quantities=q, rho=rho)
+    return (rm.Coated if 'coating' in kw else rm.Multilayer)(**kw)
+
+
 def product_oe(name, g):
     """-> the xrt_amd optical element for golden case *name*."""
     bl = raycing.BeamLine(azimuth=_az(g))
@@ -121,8 +133,16 @@ def product_oe(name, g):
         for k in keys:
             assert abs(getattr(oe, k) - float(g['surf_' + k])) <= \
                 1e-15 * max(1., abs(float(g['surf_' + k]))), k
+    elif name in ('g2_multilayer_flat', 'g2_multilayer_tran', 'g2_coated_toroid'):
+        m = product_stack(str(g['stack']))
+        if 'surf_R' in g.files:
+            oe = roe.ToroidMirror(bl, 'tm', R=float(g['surf_R']), r=float(g['surf_r']),
+                                  material=m, **common)
+        else:
+            oe = roe.OE(bl, 'ml', material=m, **common)
     elif name.startswith('g2_ellipse'):
-        m = rm.Material('Au', rho=float(g['mat_rho']), kind='mirror')
+        m = product_stack(str(g['stack'])) if 'stack' in g.files else \
+            rm.Material('Au', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.EllipticalMirrorParam(
             bl, 'm4', material=m, p=float(g['surf_p']), q=float(g['surf_q']),
             isCylindrical=bool(float(g['surf_isCylindrical'])), **common)

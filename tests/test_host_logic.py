@@ -220,3 +220,32 @@ def test_beam_utilities(tmp_path):
     a.export_beam(path)
     back = np.load(path + '.npy', allow_pickle=True).item()
     assert np.array_equal(back['x'], a.x) and 'Es' in back
+
+
+def test_multilayer_thickness_profiles_and_angles():
+    """Multilayer host side (materials/multilayer.py:167-240): depth grading by the power
+    law through the two end thicknesses, re-laid when a parameter changes; Bragg angle of
+    the period; Coated = one period without a top layer, kind 'mirror'."""
+    import xrt_amd.backends.raycing.materials as rm
+    from oracle import materials_np as mn
+    si, w = rm.Material('Si', rho=2.33), rm.Material('W', rho=19.3)
+    ml = rm.GradedMultilayer(w, 28., si, 41., 30, si, tThicknessLow=20., bThicknessLow=30.,
+                             power=2.)
+    ref = mn.make_multilayer(tThickness=28., bThickness=41., nPairs=30, tThicknessLow=20.,
+                             bThicknessLow=30., power=2.)
+    assert np.array_equal(ml.dti, ref['dti']) and np.array_equal(ml.dbi, ref['dbi'])
+    assert ml.dti[0] == 28. and abs(ml.dti[-1] - 20.) < 1e-12 and ml.d == 69.
+    ml.nPairs = 12
+    assert len(ml.dti) == len(ml.dbi) == 12 and abs(ml.dbi[-1] - 30.) < 1e-12
+    ml.tThicknessLow = 0.
+    assert np.array_equal(ml.dti, np.full(12, 28.))
+    assert ml.get_t_thickness(None, None, 3) == 28.
+    E = np.array([8000., 12000.])
+    assert np.allclose(np.sin(ml.get_Bragg_angle(E)), 12398.419297617678 / (2 * 69. * E))
+    assert ml.get_sin_Bragg_angle(10.) == 1 - 1e-16
+    c = rm.Coated(coating=w, cThickness=250., substrate=si, surfaceRoughness=3.,
+                  substRoughness=4.)
+    assert c.kind == 'mirror' and c.nPairs == 1 and c.tLayer is None and c.coating is w
+    assert c.cThickness == 250. and c.dbi[0] == 250. and c.dti[0] == 0.
+    c.cThickness = 300.
+    assert c.dbi[0] == 300. and c.surfaceRoughness == 3.

@@ -32,7 +32,9 @@ def check_beam(mine, g, prefix):
                                   'g2_parabola_p_cyl', 'g2_hyperbola', 'g2_polygon',
                                   'g2_cone_rh', 'g2_capillary_parab', 'g2_capillary_ellipse',
                                   'g2_capillary_hyperbola', 'g3_laue_plate', 'g3_laue_plate_asym',
-                                  'g3_laue_plate_transmitted'])
+                                  'g3_laue_plate_transmitted', 'g2_multilayer_flat',
+                                  'g2_ellipse_multilayer', 'g2_multilayer_tran',
+                                  'g2_coated_toroid'])
 def test_oe_reflect_matches_reference(name):
     p, beam, g = fixture_io.load_case(name)
     info = {}
@@ -191,3 +193,18 @@ def test_thick_bragg_peak_reflectivity_is_physical(golden_dir):
     theta = -np.arcsin(hns)
     width = np.ptp(theta[R > 0.5 * R.max()])
     assert 20e-6 < width < 40e-6
+
+
+def test_multilayer_amplitudes_match_reference():
+    """Multilayer / Coated .get_amplitude (materials/multilayer.py:257-566): Parratt's
+    recursion on periodic, depth-graded, transmitted, vacuum-spaced and single-coating
+    stacks."""
+    from oracle import gen_fixtures_multilayer as gm
+    from oracle import materials_np as mn
+    g = np.load(os.path.join(fixture_io.GOLDEN, 'g5_multilayer_amplitudes.npz'))
+    tb = gm.all_tables()
+    for name in gm.STACKS:
+        s, p = mn.multilayer_amplitude(gm.oracle_stack(tb, name), g[name + '_E'],
+                                       g[name + '_bdn'])
+        for mine, ref in ((s, g[name + '_s']), (p, g[name + '_p'])):
+            assert np.abs(mine - ref).max() <= 1e-13 * np.abs(ref).max(), name

@@ -53,6 +53,7 @@ SIGNATURES = {
     'xrt_hip_wave_receive_f64_dev': (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp]),
     'xrt_hip_material_amplitude_f64_dev': (ctypes.c_int, [
         vp, i64, vp, vp, vp, vp, vp, vp, vp]),
+    'xrt_hip_multilayer_amplitude_f64_dev': (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp]),
     'xrt_hip_crystal_amplitude_f64_dev': (ctypes.c_int, [
         vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_screen_expose_f64_dev': (ctypes.c_int, [vp, vp, vp, vp]),

@@ -3,6 +3,7 @@ xrt_hip_sizeof at load time in hipcalls)."""
 import ctypes
 
 MAX_ROT = 8
+BUCKETS, BUCKET_SHIFT, BUCKET_KEY0 = 1280, 46, 0x3FF << 6
 MAX_ELEM = 4
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
@@ -11,7 +12,7 @@ SURF_FLAT, SURF_TOROID, SURF_BENTFLAT, SURF_BLAZED, SURF_ELLIPSE_PARAM = 0, 1, 2
 SURF_PARABOLOID, SURF_CONE, SURF_SAGITTAL = 5, 6, 7
 SHAPE_RECT, SHAPE_ROUND, SHAPE_POLYGON = 0, 1, 2
 OVER_XMIN, OVER_XMAX, OVER_YMIN, OVER_YMAX = 1, 2, 4, 8
-MAT_NONE, MAT_MIRROR, MAT_THIN_MIRROR, MAT_PLATE, MAT_CRYSTAL = 0, 1, 2, 3, 4
+MAT_NONE, MAT_MIRROR, MAT_THIN_MIRROR, MAT_PLATE, MAT_CRYSTAL, MAT_MULTILAYER = 0, 1, 2, 3, 4, 5
 
 
 class Beam(ctypes.Structure):
@@ -90,6 +91,7 @@ class Material(ctypes.Structure):
         ('tab_E', ctypes.c_void_p * MAX_ELEM),
         ('tab_f1', ctypes.c_void_p * MAX_ELEM),
         ('tab_f2', ctypes.c_void_p * MAX_ELEM),
+        ('tab_bucket', ctypes.c_void_p * MAX_ELEM),
         ('f0_hkl', ctypes.c_double),
         ('d2f_re', ctypes.c_double),
         ('d2f_im', ctypes.c_double),
@@ -105,6 +107,23 @@ class Material(ctypes.Structure):
         ('chi_to_f', ctypes.c_double),
         ('fact_dw', ctypes.c_double),
         ('t_crystal', ctypes.c_double),
+        ('layers', ctypes.c_void_p),
+    ]
+
+
+class Multilayer(ctypes.Structure):
+    _fields_ = [
+        ('top', Material),
+        ('bottom', Material),
+        ('substrate', Material),
+        ('npairs', ctypes.c_int32),
+        ('transmitted', ctypes.c_int32),
+        ('uniform', ctypes.c_int32),
+        ('dti', ctypes.c_void_p),
+        ('dbi', ctypes.c_void_p),
+        ('id2', ctypes.c_double),
+        ('bs_rough2', ctypes.c_double),
+        ('subst_thickness', ctypes.c_double),
     ]
 
 
@@ -203,4 +222,4 @@ class Bend(ctypes.Structure):
 
 
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
-           UndulatorMap, Plot, CustomField, Bend)
+           UndulatorMap, Plot, CustomField, Bend, Multilayer)

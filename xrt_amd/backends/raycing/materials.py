@@ -75,10 +75,14 @@ class Element(object):
         return c[5] + sum(gauss)
 
     def device_tables(self, device):
+        """E, f1, f2 and the coarse index of E (xrt_hip.h: tab_bucket) on *device*."""
         key = str(device)
         if key not in self._dev:
+            edges = ((np.arange(_structs.BUCKETS + 1, dtype=np.int64) + _structs.BUCKET_KEY0)
+                     << _structs.BUCKET_SHIFT).view(np.float64)
+            coarse = np.searchsorted(self.E, edges, side='right').astype(np.int32)
             self._dev[key] = tuple(
-                torch.from_numpy(a).to(device) for a in (self.E, self.f1, self.f2))
+                torch.from_numpy(a).to(device) for a in (self.E, self.f1, self.f2, coarse))
         return self._dev[key]
 
 
@@ -136,8 +140,9 @@ class Material(object):
         keep = []
         s.nelem = len(self.elements)
         for i, (e, xi) in enumerate(zip(self.elements, self.quantities)):
-            tE, t1, t2 = e.device_tables(device)
-            keep += [tE, t1, t2]
+            tE, t1, t2, coarse = e.device_tables(device)
+            keep += [tE, t1, t2, coarse]
+            s.tab_bucket[i] = coarse.data_ptr()
             s.Z[i] = e.Z
             s.tab_n[i] = tE.numel()
             s.quantity[i] = float(xi)
@@ -206,6 +211,200 @@ class Material(object):
     def get_absorption_coefficient(self, E):
         E = np.atleast_1d(np.asarray(E, dtype=np.float64))
         return self.get_amplitude(E, -np.ones_like(E) * 0.5)[2]
+
+
+def _depth_profile(at_top, at_substrate, periods, power):
+    """Thickness of one layer kind in every period, vacuum side first: constant, or the
+    power law d_n = A / (B + n)**power through the two end values
+    (multilayer.py:167-191)."""
+    if not at_substrate:
+        return np.full(periods, float(at_top))
+    ratio = (at_top / at_substrate) ** (1. / power)
+    shift = (periods - ratio) / (ratio - 1.)
+    scale = at_top * (shift + 1.) ** power
+    return scale * (shift + np.arange(1, periods + 1)) ** (-power)
+
+
+class Multilayer(object):
+    """Periodic or depth-graded multilayer on a substrate (materials/multilayer.py:10-566):
+    *nPairs* periods of *tLayer* (towards vacuum, *tThickness* [A]) over *bLayer*
+    (*bThickness*), thicknesses running to *tThicknessLow* / *bThicknessLow* at the
+    substrate by a power law when those are given; *idThickness*: rms interdiffusion /
+    roughness of every interface; *geom* 'reflected' or 'transmitted' (then through a
+    substrate of *substThickness*).
+
+    The reflectivity (Parratt's recursion with Nevot-Croce factors) is evaluated per ray
+    inside the reflect kernels, and by ``get_amplitude`` on arrays through the same device
+    function. Laterally graded thicknesses -- the reference's way is to override
+    ``get_t_thickness`` / ``get_b_thickness`` in Python -- are not on the GPU path."""
+
+    def __init__(self, tLayer=None, tThickness=0., bLayer=None, bThickness=0., nPairs=0,
+                 substrate=None, tThicknessLow=0., bThicknessLow=0., idThickness=0., power=2.,
+                 substRoughness=0., substThickness=np.inf, name='', geom='reflected', **kwargs):
+        self.tLayer, self.bLayer, self.substrate = tLayer, bLayer, substrate
+        self._profile = dict(nPairs=int(nPairs), power=power, tThickness=float(tThickness),
+                             bThickness=float(bThickness), tThicknessLow=float(tThicknessLow),
+                             bThicknessLow=float(bThicknessLow))
+        self.kind = 'multilayer'
+        self.geom = geom or 'reflected'
+        self.idThickness = idThickness
+        self.substRoughness = float(substRoughness)
+        self.substThickness = substThickness
+        self.name = name
+        self.uuid = kwargs.get('uuid')
+        self._layout()
+
+    # the six numbers the thickness profile depends on; changing one lays it out again
+    def _layout(self):
+        q = self._profile
+        self.dti = _depth_profile(q['tThickness'], q['tThicknessLow'], q['nPairs'], q['power'])
+        self.dbi = _depth_profile(q['bThickness'], q['bThicknessLow'], q['nPairs'], q['power'])
+        self._records = {}
+
+    def __getattr__(self, name):
+        q = self.__dict__.get('_profile')
+        if q is not None and name in q:
+            return q[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        q = self.__dict__.get('_profile')
+        if q is not None and name in q:
+            q[name] = int(value) if name == 'nPairs' else float(value)
+            self._layout()
+        else:
+            object.__setattr__(self, name, value)
+            if name in ('tLayer', 'bLayer', 'substrate', 'idThickness', 'substRoughness',
+                        'substThickness', 'geom') and '_records' in self.__dict__:
+                self._records = {}
+
+    @property
+    def d(self):
+        return float(self.tThickness + self.bThickness)
+
+    # ---- alignment helpers (host scalars) ---------------------------------------------
+    def get_sin_Bragg_angle(self, E, order=1):
+        s = order * CH / (2 * self.d * np.asarray(E, dtype=float))
+        return np.clip(s, -1 + 1e-16, 1 - 1e-16)
+
+    def get_Bragg_angle(self, E, order=1):
+        return np.arcsin(self.get_sin_Bragg_angle(E, order))
+
+    def get_dtheta_symmetric_Bragg(self, E, order=1):
+        """Bragg angle minus the angle of the refraction-corrected Bragg law with the
+        period average of delta (multilayer.py:222-240)."""
+        def decrement(layer, thickness):
+            return 0. if layer is None else \
+                (layer.get_refractive_index(E).real - 1) * thickness
+        mean = abs(decrement(self.tLayer, self.tThickness) +
+                   decrement(self.bLayer, self.bThickness)) / self.d
+        corrected = ((order * CH / np.asarray(E, dtype=float))**2 +
+                     self.d**2 * 8 * mean)**0.5 / (2 * self.d)
+        return self.get_Bragg_angle(E, order) - np.arcsin(corrected)
+
+    def get_dtheta(self, E, order=1):
+        return self.get_dtheta_symmetric_Bragg(E, order=order)
+
+    def get_t_thickness(self, x, y, iPair):
+        return self.dti[iPair]
+
+    def get_b_thickness(self, x, y, iPair):
+        return self.dbi[iPair]
+
+    # ---- the record the kernels read ----------------------------------------------------
+    def _layer_struct(self, layer, device, keep):
+        s = _structs.Material()
+        if layer is not None:
+            keep += layer._fill_elements(s, device)
+            s.rho, s.mass = float(layer.rho), float(layer.mass)
+        return s
+
+    def to_struct(self, fromVacuum=True, device=None):
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        cls = type(self)
+        if cls.get_t_thickness is not Multilayer.get_t_thickness or \
+                cls.get_b_thickness is not Multilayer.get_b_thickness:
+            raise NotImplementedError('laterally graded multilayers (get_t_thickness / '
+                                      'get_b_thickness overridden) are not on the GPU path')
+        if self.nPairs < 1:
+            raise ValueError('a multilayer needs at least one period')
+        key = str(device)
+        if key not in self._records:
+            keep = []
+            rec = _structs.Multilayer()
+            rec.top = self._layer_struct(self.tLayer, device, keep)
+            rec.bottom = self._layer_struct(self.bLayer, device, keep)
+            rec.substrate = self._layer_struct(self.substrate, device, keep)
+            rec.npairs = int(self.nPairs)
+            rec.transmitted = 1 if 'tran' in self.geom else 0
+            rec.uniform = int(np.all(self.dti == self.dti[0]) and np.all(self.dbi == self.dbi[0]))
+            dti, dbi = _dev_f64(self.dti, device), _dev_f64(self.dbi, device)
+            rec.dti, rec.dbi = dti.data_ptr(), dbi.data_ptr()
+            rec.id2 = float(self.idThickness)**2
+            rec.bs_rough2 = rec.id2 if self.tLayer is not None else self.substRoughness**2
+            rec.subst_thickness = float(self.substThickness)
+            image = torch.frombuffer(bytearray(bytes(rec)), dtype=torch.uint8).to(device)
+            self._records[key] = (image, keep + [dti, dbi])
+        image, keep = self._records[key]
+        s = _structs.Material()
+        s.kind = _structs.MAT_MULTILAYER
+        s.from_vacuum = 1 if fromVacuum else 0
+        # kind 'multilayer' deflects like a Bragg crystal of spacing d (reflect.py:865-872);
+        # Coated is a 'mirror'
+        s.geom_bragg = 1 if self.kind == 'multilayer' else 0
+        s.geom_transmitted = 1 if (self.kind == 'multilayer' and
+                                   self.geom.endswith('transmitted')) else 0
+        s.d = self.d
+        s.layers = image.data_ptr()
+        s._keep = [image] + keep
+        return s
+
+    def get_amplitude(self, E, beamInDotNormal, x=None, y=None, ucl=None):
+        """(r_s, r_p) -- or (t_s, t_p) for geom 'transmitted' -- per ray,
+        multilayer.py:257-566."""
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        bdn = np.atleast_1d(np.asarray(beamInDotNormal, dtype=np.float64))
+        E = np.broadcast_to(np.asarray(E, dtype=np.float64), bdn.shape) \
+            if np.ndim(E) == 0 else np.asarray(E, dtype=np.float64)
+        bdn = np.broadcast_to(bdn, E.shape)
+        n = E.size
+        s = self.to_struct(True, dev)
+        dE, db = _dev_f64(E, dev), _dev_f64(bdn, dev)
+        rs = torch.empty(n, dtype=torch.complex128, device=dev)
+        rp = torch.empty(n, dtype=torch.complex128, device=dev)
+        _lib.check(lib.xrt_hip_multilayer_amplitude_f64_dev(
+            ctypes.byref(s), n, dE.data_ptr(), db.data_ptr(), rs.data_ptr(), rp.data_ptr(),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            'xrt_hip_multilayer_amplitude_f64_dev')
+        return rs.cpu().numpy(), rp.cpu().numpy()
+
+
+class GradedMultilayer(Multilayer):
+    """The reference keeps this name for depth-graded stacks (multilayer.py:569-574)."""
+
+
+class Coated(Multilayer):
+    """A mirror coating of *cThickness* [A] on a *substrate*, with *surfaceRoughness* and
+    *substRoughness* [A rms] (multilayer.py:577-625): one period without a top layer; the
+    element treats it as a mirror."""
+
+    def __init__(self, *args, **kwargs):
+        coating = kwargs.pop('coating', None)
+        thickness = kwargs.pop('cThickness', 0)
+        rough = kwargs.pop('surfaceRoughness', 0)
+        Multilayer.__init__(self, *args, bLayer=coating, bThickness=thickness,
+                            idThickness=rough, nPairs=1, **kwargs)
+        self.kind = 'mirror'
+
+    coating = property(lambda self: self.bLayer,
+                       lambda self, m: setattr(self, 'bLayer', m))
+    cThickness = property(lambda self: self.bThickness,
+                          lambda self, t: setattr(self, 'bThickness', t))
+    surfaceRoughness = property(lambda self: self.idThickness,
+                                lambda self, t: setattr(self, 'idThickness', t))
 
 
 def parse_hkl(hkl):

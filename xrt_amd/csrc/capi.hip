@@ -250,6 +250,7 @@ int xrt_hip_sizeof(int which) {
     case 8: return (int)sizeof(xrt_hip_plot);
     case 9: return (int)sizeof(xrt_hip_custom_field);
     case 10: return (int)sizeof(xrt_hip_bend);
+    case 11: return (int)sizeof(xrt_hip_multilayer);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -273,6 +274,14 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
     return fail(XRT_HIP_ERR_ARG, "rotation sequence longer than %d", XRT_HIP_MAX_ROT);
   if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_SAGITTAL)
     return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
+  if (material->kind == XRT_HIP_MAT_MULTILAYER) {
+    if (!material->layers)
+      return fail(XRT_HIP_ERR_ARG, "multilayer material without its xrt_hip_multilayer record");
+    if (material->geom_bragg && !(material->d > 0.))
+      return fail(XRT_HIP_ERR_ARG, "multilayer period d must be positive");
+    if (pass->grating)
+      return fail(XRT_HIP_ERR_ARG, "grating equation on a multilayer material");
+  }
   if (pass->surf_kind >= XRT_HIP_SURF_BLAZED && pass->surf_kind != XRT_HIP_SURF_SAGITTAL &&
       material->kind == XRT_HIP_MAT_CRYSTAL)
     return fail(XRT_HIP_ERR_ARG, "crystals on blazed / parametric surfaces are not supported");
@@ -290,9 +299,9 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
     return fail(XRT_HIP_ERR_ARG, "unknown shape %d", pass->shape);
   if (pass->shape == XRT_HIP_SHAPE_POLYGON && (pass->poly_n < 0 || (pass->poly_n > 0 && !pass->poly_xy)))
     return fail(XRT_HIP_ERR_ARG, "polygon shape without vertices");
-  if (material->kind < XRT_HIP_MAT_NONE || material->kind > XRT_HIP_MAT_CRYSTAL)
+  if (material->kind < XRT_HIP_MAT_NONE || material->kind > XRT_HIP_MAT_MULTILAYER)
     return fail(XRT_HIP_ERR_ARG, "unknown material kind %d", material->kind);
-  if (material->kind != XRT_HIP_MAT_NONE) {
+  if (material->kind != XRT_HIP_MAT_NONE && material->kind != XRT_HIP_MAT_MULTILAYER) {
     if (material->nelem < 1 || material->nelem > XRT_HIP_MAX_ELEM)
       return fail(XRT_HIP_ERR_ARG, "material needs 1..%d elements", XRT_HIP_MAX_ELEM);
     for (int e = 0; e < material->nelem; ++e)
@@ -595,6 +604,20 @@ int xrt_hip_material_amplitude_f64_dev(const xrt_hip_material* material, int64_t
   if (!E || !bdn || !rs_ri || !rp_ri) return fail(XRT_HIP_ERR_ARG, "NULL array");
   HIP_TRY(xrt::material_amplitude_launch(*material, n, E, bdn, rs_ri, rp_ri, mu, nk,
                                          reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_multilayer_amplitude_f64_dev(const xrt_hip_material* material, int64_t n,
+                                         const double* E, const double* bdn, double* rs_ri,
+                                         double* rp_ri, void* stream) {
+  if (!material) return fail(XRT_HIP_ERR_ARG, "NULL material");
+  if (material->kind != XRT_HIP_MAT_MULTILAYER || !material->layers)
+    return fail(XRT_HIP_ERR_ARG, "material is not a multilayer");
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (n == 0) return XRT_HIP_OK;
+  if (!E || !bdn || !rs_ri || !rp_ri) return fail(XRT_HIP_ERR_ARG, "NULL array");
+  HIP_TRY(xrt::multilayer_amplitude_launch(*material, n, E, bdn, rs_ri, rp_ri,
+                                           reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
 }
 

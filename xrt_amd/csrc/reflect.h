@@ -108,6 +108,9 @@ hipError_t wave_receive_launch(const xrt_hip_pass& P, int is_oe, const xrt_hip_b
 hipError_t material_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
                                      const double* bdn, double* rs, double* rp, double* mu,
                                      double* nk, hipStream_t st);
+hipError_t multilayer_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
+                                       const double* bdn, double* rs, double* rp,
+                                       hipStream_t st);
 hipError_t crystal_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
                                     const double* g0, const double* gh, const double* hns,
                                     double* S, double* P, hipStream_t st);

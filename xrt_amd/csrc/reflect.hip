@@ -250,12 +250,21 @@ __device__ __forceinline__ bool blazed_front(const xrt_hip_pass& P, double y, do
 #ifndef XRT_LEAN_WAVES
 #define XRT_LEAN_WAVES 4
 #endif
+// waves per SIMD of the kernels for layered materials (measured on 1e7 rays, W/Si x40 /
+// Rh coating: 2 waves 3.36 / 1.71 ms, 3 waves 2.93 / 1.49, 4 waves 3.03 / 1.56)
+#ifndef XRT_LAYERED_WAVES
+#define XRT_LAYERED_WAVES 3
+#endif
 template <int F_, int SK_, int MK_, bool PLAIN_>
 struct Spec {
   static constexpr int F = F_, SK = SK_, MK = MK_;
   static constexpr bool PLAIN = PLAIN_;
   // waves per SIMD the fused kernel is compiled for
-  static constexpr int WAVES = (PLAIN_ && SK_ >= 0 && MK_ >= 0) ? XRT_LEAN_WAVES : REFLECT_FUSED_WAVES;
+  // (layered materials: the Parratt recursion keeps ~30 complex numbers per ray alive and
+  // is compute bound -- 168 VGPRs, three waves)
+  static constexpr int WAVES = MK_ == XRT_HIP_MAT_MULTILAYER ? XRT_LAYERED_WAVES
+                               : (PLAIN_ && SK_ >= 0 && MK_ >= 0) ? XRT_LEAN_WAVES
+                                                                  : REFLECT_FUSED_WAVES;
   // crystal known to be thick (crystal.py:571-584): the thin-crystal forms with their
   // complex exp / cos / sin / tan are not compiled in
   static constexpr bool XTHICK = false;
@@ -265,6 +274,13 @@ template <int SK_>
 struct ThickXtal : Spec<0, SK_, XRT_HIP_MAT_CRYSTAL, false> {
   static constexpr bool XTHICK = true;
 };
+// Bragg crystals, and multilayers (geom_bragg set; a Coated mirror has it cleared): the
+// direction comes from the grating equation with the batch's sign of beamInDotNormal
+__host__ __device__ inline bool deflects_as_crystal(const xrt_hip_material& M) {
+  return M.kind == XRT_HIP_MAT_CRYSTAL || (M.kind == XRT_HIP_MAT_MULTILAYER && M.geom_bragg);
+}
+using Layered0 = Spec<0, -1, XRT_HIP_MAT_MULTILAYER, false>;
+using Layered1 = Spec<1, -1, XRT_HIP_MAT_MULTILAYER, false>;
 using Generic0 = Spec<0, -1, -1, false>;
 using Generic1 = Spec<1, -1, -1, false>;
 #define PSURF(P) (K::SK >= 0 ? K::SK : (P).surf_kind)
@@ -276,6 +292,12 @@ using Generic1 = Spec<1, -1, -1, false>;
 // F = surface family, a compile-time switch: 0 = flat / toroid / bent-flat (the
 // bulk ray-tracing kernels stay free of the code below), 1 = blazed grating and
 // parametric ellipse (fmod / atan2 / sincos in the solve)
+// kernels compiled for layered materials (Multilayer, Coated); no other kernel holds the
+// recursion
+template <class K>
+__device__ __forceinline__ constexpr bool layered() {
+  return K::MK == XRT_HIP_MAT_MULTILAYER;
+}
 template <class K>
 __device__ __forceinline__ bool surf_is_param(const xrt_hip_pass& P) {
   return K::F == 1 && PSURF(P) == XRT_HIP_SURF_ELLIPSE_PARAM;
@@ -1388,6 +1410,15 @@ __device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, do
   if (!(E >= w.elo && E < w.ehi)) {
     lo = 0;
     hi = n;
+    // no batch window (stand-alone calls, the layers of a multilayer, a ray of another
+    // energy): the coarse index, if the caller supplied one -- two dependent loads in
+    // place of ten
+    const int32_t* __restrict__ coarse = M.tab_bucket[e];
+    const long long k = (__double_as_longlong(E) >> XRT_HIP_BUCKET_SHIFT) - XRT_HIP_BUCKET_KEY0;
+    if (coarse && k >= 0 && k < XRT_HIP_BUCKETS) {
+      lo = coarse[k];
+      hi = coarse[k + 1];
+    }
   }
   while (lo < hi) {
     const int mid = lo + ((hi - lo) >> 1);
@@ -1560,6 +1591,139 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
   const cplx alpha = C((H2 * 0.5 - k0H) * frcp(k02), 0.) + (chi0 * 0.5) * (frcp(b) - 1.);
   A.rs = crystal_one_pol<THICK>(M, 1., alpha, chih, chih_, chi0, b, k02, k0s, kHs);
   A.rp = crystal_one_pol<THICK>(M, cos2thetaB, alpha, chih, chih_, chi0, b, k02, k0s, kHs);
+  A.mu = 0.;
+  A.nk = 0.;
+  return A;
+}
+
+// Multilayer / Coated, materials/multilayer.py:257-566: Parratt's recursion from the
+// substrate up, separately for s and p, every interface weakened by its Nevot-Croce
+// factor. Q_j = sqrt(Q^2 + 8 k^2 (n_j - 1)) with the conjugated tabulated index
+// (:335-345). Amplitudes are compared at 1e-5, so the arithmetic is free to be cheap:
+// one reciprocal per complex division, the phase factor of a layer by one exp + sincos.
+struct Interface {   // from medium a down into medium b
+  cplx rs, rp, ts, tp;
+};
+__device__ __forceinline__ Interface interface_ab(cplx Qa, cplx na, cplx Qb, cplx nb,
+                                                  double sigma2, bool want_t) {
+  Interface f;
+  cplx rough = C(1., 0.);
+  if (sigma2 != 0.) rough = cexp_((Qa * Qb) * (-0.5 * sigma2));
+  const cplx is = rough / (Qa + Qb);
+  f.rs = (Qa - Qb) * is;
+  const cplx A = (Qa / na) * nb, B = (Qb / nb) * na;
+  const cplx ip = rough / (A + B);
+  f.rp = (A - B) * ip;
+  f.ts = f.tp = C(0., 0.);
+  if (want_t) {
+    f.ts = (Qa * 2.) * is;
+    f.tp = (A * 2.) * ip;
+  }
+  return f;
+}
+
+__device__ __forceinline__ cplx layer_index(const xrt_hip_material& m, double E) {
+  if (m.nelem == 0) return C(1., 0.);
+  return conj(refractive_index(m, E, full_window()));
+}
+
+struct StackState {
+  cplx rs, rp, ts, tp;   // net amplitudes of everything below the present layer
+};
+// one layer of phase thickness phi = Q_layer * thickness on top of the state, under the
+// interface `f` (multilayer.py:417-429)
+template <bool TRAN>
+__device__ __forceinline__ void add_layer(StackState& s, cplx rs, cplx rp, cplx ts, cplx tp,
+                                          cplx p1, cplx p2) {
+  const cplx us = s.rs * p2, up = s.rp * p2;
+  const cplx ds = C(1., 0.) / (C(1., 0.) + rs * us), dp = C(1., 0.) / (C(1., 0.) + rp * up);
+  s.rs = (rs + us) * ds;
+  s.rp = (rp + up) * dp;
+  if (TRAN) {
+    s.ts = ((ts * s.ts) * p1) * ds;
+    s.tp = ((tp * s.tp) * p1) * dp;
+  }
+}
+__device__ __forceinline__ cplx half_phase(cplx Q, double thickness) {
+  if (isinf(thickness)) return C(0., 0.);   // an absorbing half space lets nothing through
+  return cexp_(C(-0.5 * Q.im * thickness, 0.5 * Q.re * thickness));
+}
+
+template <bool TRAN>
+__device__ __forceinline__ void multilayer_stack(const xrt_hip_multilayer& L, double E,
+                                                 double bdn, cplx& out_s, cplx& out_p) {
+  const double k = E / kCHBAR;
+  const cplx nt = layer_index(L.top, E), nb = layer_index(L.bottom, E),
+             ns = layer_index(L.substrate, E);
+  const double Q = 2. * k * fabs(bdn);
+  const double Q2 = Q * Q, k28 = 8. * (k * k);
+  const cplx Qv = C(Q, 0.), one = C(1., 0.);
+  const cplx Qt = csqrt_(C(Q2, 0.) + (nt - one) * k28);
+  const cplx Qb = csqrt_(C(Q2, 0.) + (nb - one) * k28);
+  const cplx Qs = csqrt_(C(Q2, 0.) + (ns - one) * k28);
+  const Interface vt = interface_ab(Qv, one, Qt, nt, L.id2, TRAN);
+  const Interface tb = interface_ab(Qt, nt, Qb, nb, L.id2, TRAN);
+  const Interface bs = interface_ab(Qb, nb, Qs, ns, L.bs_rough2, TRAN);
+  StackState s;
+  cplx bt_ts = C(0., 0.), bt_tp = C(0., 0.);
+  if (TRAN) {
+    // the far side of the substrate carries the substrate's roughness factor (:366-371)
+    const Interface sv = interface_ab(Qs, ns, Qv, one, 0., true);
+    const cplx rough = L.bs_rough2 != 0. ? cexp_((Qb * Qs) * (-0.5 * L.bs_rough2)) : one;
+    s.rs = sv.rs * rough;
+    s.rp = sv.rp * rough;
+    s.ts = sv.ts * rough;
+    s.tp = sv.tp * rough;
+    const cplx p1 = half_phase(Qs, L.subst_thickness);
+    add_layer<true>(s, bs.rs, bs.rp, bs.ts, bs.tp, p1, p1 * p1);
+    // bottom -> top interface: r = -r(top -> bottom), t with the roles swapped (:349-352)
+    const Interface bt = interface_ab(Qb, nb, Qt, nt, L.id2, true);
+    bt_ts = bt.ts;
+    bt_tp = bt.tp;
+  } else {
+    s.rs = bs.rs;
+    s.rp = bs.rp;
+    s.ts = s.tp = C(0., 0.);
+  }
+  cplx p1t = C(1., 0.), p2t = p1t, p1b = p1t, p2b = p1t;
+  if (L.uniform) {
+    p1t = half_phase(Qt, L.dti[0]);
+    p2t = p1t * p1t;
+    p1b = half_phase(Qb, L.dbi[0]);
+    p2b = p1b * p1b;
+  }
+  for (int pair = L.npairs - 1; pair >= 0; --pair) {
+    if (!L.uniform) {
+      p1b = half_phase(Qb, L.dbi[pair]);
+      p2b = p1b * p1b;
+      p1t = half_phase(Qt, L.dti[pair]);
+      p2t = p1t * p1t;
+    }
+    add_layer<TRAN>(s, tb.rs, tb.rp, tb.ts, tb.tp, p1b, p2b);
+    if (pair == 0)
+      add_layer<TRAN>(s, vt.rs, vt.rp, vt.ts, vt.tp, p1t, p2t);
+    else
+      add_layer<TRAN>(s, -tb.rs, -tb.rp, bt_ts, bt_tp, p1t, p2t);
+  }
+  if (TRAN) {
+    out_s = s.ts;
+    out_p = s.tp;
+  } else {
+    // a tabulated delta < 0 of the top layer turns the sign convention (:558-562; the
+    // reference looks at the first ray of the batch, here every ray at its own energy)
+    const bool flip = nt.re - 1. > 0.;
+    out_s = flip ? conj(s.rs) : s.rs;
+    out_p = flip ? conj(s.rp) : s.rp;
+  }
+}
+
+__device__ __forceinline__ Ampl multilayer_amplitude(const xrt_hip_multilayer& L, double E,
+                                                     double bdn) {
+  Ampl A;
+  if (L.transmitted)
+    multilayer_stack<true>(L, E, bdn, A.rs, A.rp);
+  else
+    multilayer_stack<false>(L, E, bdn, A.rs, A.rp);
   A.mu = 0.;
   A.nk = 0.;
   return A;
@@ -1752,15 +1916,19 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   int toWhere = 0;  // reflect.py:723-752
   if (MKIND(M) == XRT_HIP_MAT_PLATE)
     toWhere = 1;
-  else if (MKIND(M) == XRT_HIP_MAT_CRYSTAL && M.geom_transmitted)
+  else if ((MKIND(M) == XRT_HIP_MAT_CRYSTAL || layered<K>()) && M.geom_transmitted)
     toWhere = 2;
+  // a multilayer deflects like a Bragg crystal of its period (reflect.py:865-872), a
+  // coated mirror like a mirror
+  bool as_crystal = MKIND(M) == XRT_HIP_MAT_CRYSTAL;
+  if constexpr (layered<K>()) as_crystal = M.geom_bragg != 0;
 
   double ao = r.a, bo = r.b, co = r.c;  // a_out of the reference
   out.a = r.a;
   out.b = r.b;
   out.c = r.c;
   if (toWhere == 0 || toWhere == 2) {
-    if (MKIND(M) == XRT_HIP_MAT_CRYSTAL && toWhere == 0) {
+    if (as_crystal && toWhere == 0) {
       // crystal as a grating, reflect.py:568-612 + 451-469
       const double ndsn = n[0] * n[3] + n[1] * n[4] + n[2] * n[5];
       // sign of the batch mean of beamInDotNormal (reflect.py:573-574). In the
@@ -1869,7 +2037,11 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   A.rp = C(1., 0.);
   A.mu = 0.;
   A.nk = 0.;
-  if (MKIND(M) == XRT_HIP_MAT_CRYSTAL) {
+  if constexpr (layered<K>()) {
+    // reflect.py:999-1003 hands over beamInDotSurfaceNormal, :1031-1032 (Coated, kind
+    // 'mirror') beamInDotNormal
+    A = multilayer_amplitude(*M.layers, q.E, M.geom_bragg ? bdsn : bdn);
+  } else if (MKIND(M) == XRT_HIP_MAT_CRYSTAL) {
     const double bosn = ao * n[3] + bo * n[4] + co * n[5];
     A = crystal_amplitude<K::XTHICK>(M, q.E, bdsn, bosn, bdn, window_of(g), npre);
   } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
@@ -1908,7 +2080,8 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     Es = Es * A.rs;
     Ep = Ep * A.rp;
   }
-  if (!M.from_vacuum && MKIND(M) != XRT_HIP_MAT_NONE && MKIND(M) != XRT_HIP_MAT_CRYSTAL) {
+  if (!M.from_vacuum && MKIND(M) != XRT_HIP_MAT_NONE && MKIND(M) != XRT_HIP_MAT_CRYSTAL &&
+      !layered<K>()) {
     const double att = exp(-A.mu * h.t * 0.1);
     Jss *= att;
     Jpp *= att;
@@ -2248,7 +2421,7 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
 // are up does reflect_exact run the two-pass tail.
 // ---------------------------------------------------------------------------
 template <class K, int mode>
-__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, 4) void reflect_fused_xtal(
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_xtal(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     int* __restrict__ any_neg_pos, OptStat* __restrict__ opt) {
@@ -2463,7 +2636,7 @@ __device__ __forceinline__ void exact_pass(const xrt_hip_pass& P, const xrt_hip_
                                            const xrt_hip_beam& lb, const xrt_hip_beam& vb,
                                            const PassAux& A, bool full, unsigned& phase) {
   GStat* g = A.g;
-  const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  const bool need_mean = deflects_as_crystal(M) && !M.geom_transmitted;
   const bool blazed = P.surf_kind == XRT_HIP_SURF_BLAZED;
   bool tail = !full;
   if (full) {
@@ -2554,7 +2727,7 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_exact(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore, xrt_hip_beam lb,
     xrt_hip_beam vb, PassAux A) {
   __shared__ double lds_d[REFLECT_MAX_WAVES];
-  const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  const bool need_mean = deflects_as_crystal(M) && !M.geom_transmitted;
   const bool mixed = need_mean && A.g->any_neg && A.g->any_pos;
   const bool full = exact_gate(A.g, reinterpret_cast<const OptStat*>(A.part), lds_d);
   if (!full && !mixed) return;
@@ -3225,6 +3398,26 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void crystal_amplitude_kernel(
   P[i] = make_double2(A.rp.re, A.rp.im);
 }
 
+__global__ __launch_bounds__(REFLECT_BLOCK) void multilayer_amplitude_kernel(
+    xrt_hip_material M, int64_t n, const double* __restrict__ E,
+    const double* __restrict__ bdn, double2* __restrict__ rs, double2* __restrict__ rp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Ampl A = multilayer_amplitude(*M.layers, E[i], bdn[i]);
+  rs[i] = make_double2(A.rs.re, A.rs.im);
+  rp[i] = make_double2(A.rp.re, A.rp.im);
+}
+
+hipError_t multilayer_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
+                                       const double* bdn, double* rs, double* rp,
+                                       hipStream_t st) {
+  hipLaunchKernelGGL(multilayer_amplitude_kernel,
+                     dim3((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)),
+                     dim3(REFLECT_BLOCK), 0, st, M, n, E, bdn, reinterpret_cast<double2*>(rs),
+                     reinterpret_cast<double2*>(rp));
+  return hipGetLastError();
+}
+
 hipError_t material_amplitude_launch(const xrt_hip_material& M, int64_t n, const double* E,
                                      const double* bdn, double* rs, double* rp, double* mu,
                                      double* nk, hipStream_t st) {
@@ -3338,8 +3531,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const bool nis = P.no_intersection_search != 0;
   const bool searches = !nis && P.surf_kind != XRT_HIP_SURF_BLAZED;
   const bool optimistic = searches && !force_exact && !aliased;
-  const bool need_mean = M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  const bool need_mean = deflects_as_crystal(M) && !M.geom_transmitted;
   const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
+  const bool layers = M.kind == XRT_HIP_MAT_MULTILAYER;
   using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
   using AnyXtal = Spec<0, -1, XRT_HIP_MAT_CRYSTAL, false>;
   using ToroidMirror = Spec<0, XRT_HIP_SURF_TOROID, XRT_HIP_MAT_MIRROR, true>;
@@ -3355,7 +3549,11 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
 #define XRT_XTAL(SPEC)                                                                       \
   hipLaunchKernelGGL((reflect_fused_xtal<SPEC, mode>), grid, fblock, 0, st, P, M, in, restore, \
                      lb, vb, theta, g, &g->any_neg, opt)
-      if (M.thick && flat_xtal)
+      if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED)
+        XRT_XTAL(Layered1);
+      else if (layers)
+        XRT_XTAL(Layered0);
+      else if (M.thick && flat_xtal)
         XRT_XTAL(ThickXtal<XRT_HIP_SURF_FLAT>);
       else if (M.thick)
         XRT_XTAL(ThickXtal<-1>);
@@ -3370,7 +3568,11 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   hipLaunchKernelGGL((reflect_fused<SPEC, mode>), grid, fblock, 0, st, P, M, in, restore, lb, \
                      vb, theta, g, opt)
     const bool plain = !P.grating && !P.asymmetric && !P.no_intersection_search;
-    if (P.surf_kind >= XRT_HIP_SURF_BLAZED) {
+    if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED) {
+      XRT_FUSED(Layered1);
+    } else if (layers) {
+      XRT_FUSED(Layered0);
+    } else if (P.surf_kind >= XRT_HIP_SURF_BLAZED) {
       XRT_FUSED(Generic1);
     } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_TOROID) {
       XRT_FUSED(ToroidMirror);
@@ -3395,7 +3597,13 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   A.aliased = aliased ? 1 : 0;
   const dim3 xgrid(exact_blocks(n)), xblock(REFLECT_EXACT_BLOCK);
   auto launch_exact = [&]() {
-    if (P.surf_kind >= XRT_HIP_SURF_BLAZED)
+    if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED)
+      hipLaunchKernelGGL(reflect_exact<Layered1>, xgrid, xblock, 0, st, P, M, in, restore, lb,
+                         vb, A);
+    else if (layers)
+      hipLaunchKernelGGL(reflect_exact<Layered0>, xgrid, xblock, 0, st, P, M, in, restore, lb,
+                         vb, A);
+    else if (P.surf_kind >= XRT_HIP_SURF_BLAZED)
       hipLaunchKernelGGL(reflect_exact<Generic1>, xgrid, xblock, 0, st, P, M, in, restore, lb,
                          vb, A);
     else
