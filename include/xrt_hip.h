@@ -148,6 +148,15 @@ typedef struct xrt_hip_rotation {
 #define XRT_HIP_SURF_SAGITTAL 7    /* sagittally bent cylinder z = Rs - sqrt(Rs^2 - x^2), the
                                      second crystal of DCMwithSagittalFocusing
                                      (oes/__init__.py:639-664): surf_p = Rs, Rs^2 */
+#define XRT_HIP_SURF_BENT_BRAGG 8  /* bent crystal analysers, oes/bragg.py:104-343. surf_p[0] =
+                                     shape: 0 cylinder with a circular cross section (Johann /
+                                     JohanssonCylinder), 1 parabolic cylinder, 2 toroid (Johann /
+                                     Johansson / GeneralBraggToroid); [1] = atomic planes: 0 follow
+                                     the surface (Johann; turned by alpha), 1 ground (Johansson:
+                                     planes of twice the radius), 2 their own radii (General);
+                                     [2] Rm, [3] Rs, [4] cos(alpha), [5] sin(alpha), [6] alpha
+                                     given (!= 0), [7] RmBragg, [8] RsBragg. The pass's
+                                     `asymmetric` flag says whether the two normals differ. */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_SHAPE_POLYGON 2   /* optical surface outlined by a polygon in the local (x, y)

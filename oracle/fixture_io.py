@@ -154,6 +154,22 @@ def load_case(name):
         p['surface'] = rn.make_cone(float(g['surf_L0']), float(g['surf_theta']))
         p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,
                                          'mirror', float(g['mat_rho']))
+    elif name.startswith('g3_bent_'):
+        cls = str(g['surf_class'])
+        planes = 'general' if 'General' in cls else 'johansson' if 'Johansson' in cls \
+            else 'johann'
+        alpha = float(g['surf_alpha'])
+        surf = dict(kind='bent_toroid' if 'Toroid' in cls else 'bent_cylinder',
+                    Rm=float(g['surf_Rm']), planes=planes, alpha=alpha if alpha else None,
+                    crossSection=str(g['surf_crossSection']))
+        for key in ('Rs', 'RmBragg', 'RsBragg'):
+            if 'surf_' + key in g.files:
+                surf[key] = float(g['surf_' + key])
+        p['surface'] = surf
+        si = mn.load_element(tb, 'Si')
+        p['material'] = mn.make_crystal(si, (1, 1, 1), float(g['cr_d']), 'diamond',
+                                        'Bragg reflected', None, 1., float(g['cr_V']))
+        assert p['material']['chiToF'] == float(g['cr_chiToF'])
     elif name.startswith('g3_laue_plate'):
         alpha = float(g['alpha'])
         p['surface'] = dict(kind='flat', laue=True, alpha=alpha if alpha else None)

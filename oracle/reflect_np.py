@@ -213,6 +213,17 @@ def local_z(surf, x, y):
                         -yL * surf['tanAntiblaze'])
     if surf['kind'] == 'sagittal':                # DCMwithSagittalFocusing.local_z2, :655-656
         return surf['Rs'] - np.sqrt(surf['Rs']**2 - x**2)
+    if surf['kind'] == 'bent_cylinder':           # Johann/JohanssonCylinder, bragg.py:138-144
+        if surf['crossSection'].startswith('circ'):
+            sq = surf['Rm']**2 - y**2
+            return surf['Rm'] - np.sqrt(sq)
+        return y**2 / 2.0 / surf['Rm']
+    if surf['kind'] == 'bent_toroid':             # JohannToroid.local_z, bragg.py:236-241
+        Rm, Rs = surf['Rm'], surf['Rs']
+        z = Rm - Rs - (Rm**2 - y**2)**0.5
+        cosangle, sinangle = (z**2 - x**2)**0.5 / abs(z), -x/abs(z)
+        bla, z = rotate_y(0, z, cosangle, sinangle)
+        return z + Rs
     if surf['kind'] == 'cone':                    # ConicalMirror, oes/__init__.py:623-627
         t2t, L0, redfocus = surf['t2t'], surf['L0'], surf['redfocus']
         sqroot = np.sqrt(0.25*t2t**2*(y - L0)**2 - redfocus*t2t*x**2)
@@ -344,6 +355,37 @@ def local_r(surf, s, phi):        # parametric.py:225-231, 450-458, 690-696
     return np.where(abs(phi) > np.pi/2, r, np.ones_like(phi)*1e20)
 
 
+def _n_bent_cylinder(surf, x, y, R, alpha):      # JohannCylinder.local_n_cylinder
+    a = np.zeros_like(x)
+    b = -y / R
+    if surf['crossSection'].startswith('circ'):
+        c = (R**2 - y**2)**0.5 / R
+    else:
+        norm = (b**2 + 1)**0.5
+        b /= norm
+        c = 1. / norm
+    if alpha:
+        bAlpha, cAlpha = rotate_x(b, c, np.cos(alpha), -np.sin(alpha))
+        return [a, bAlpha, cAlpha, a, b, c]
+    return [a, b, c]
+
+
+def _n_bent_toroid(surf, x, y, Rm, Rs, alpha):     # JohannToroid.local_n_toroid
+    a = np.zeros_like(x)
+    b = -y / Rm
+    c = (Rm**2 - y**2)**0.5 / Rm
+    if alpha:
+        aAlpha = np.zeros_like(x)
+        bAlpha, cAlpha = rotate_x(b, c, np.cos(alpha), -np.sin(alpha))
+    r = Rs - (Rm - (Rm**2 - y**2)**0.5)
+    cosangle, sinangle = (r**2 - x**2)**0.5 / r, -x/r
+    a, c = rotate_y(a, c, cosangle, sinangle)
+    if alpha:
+        aAlpha, cAlpha = rotate_y(aAlpha, cAlpha, cosangle, sinangle)
+        return [aAlpha, bAlpha, cAlpha, a, b, c]
+    return [a, b, c]
+
+
 def local_n(surf, x, y):
     """3-list, or 6-list [n_H(3), n_surface(3)] for an asymmetric cut."""
     if surf['kind'] == 'flat' and surf.get('laue'):   # LauePlate.local_n, oes/laue.py:14-20
@@ -387,6 +429,40 @@ def local_n(surf, x, y):
         return [np.zeros_like(x),
                 np.where(yL > yC, -surf['sinBlaze'], surf['sinAntiblaze']),
                 np.where(yL > yC, surf['cosBlaze'], surf['cosAntiblaze'])]
+    if surf['kind'] == 'bent_cylinder':           # bragg.py:146-197
+        nSurf = _n_bent_cylinder(surf, x, y, surf['Rm'], surf.get('alpha'))
+        if surf['planes'] == 'johann':
+            return nSurf
+        nSurf = _n_bent_cylinder(surf, x, y, surf['Rm'], None)
+        a = np.zeros_like(x)
+        b = -y
+        c = (surf['Rm']**2 - y**2)**0.5 + surf['Rm']
+        if surf.get('alpha'):
+            b, c = rotate_x(b, c, np.cos(surf['alpha']), -np.sin(surf['alpha']))
+        norm = np.sqrt(b**2 + c**2)
+        return [a/norm, b/norm, c/norm, nSurf[-3], nSurf[-2], nSurf[-1]]
+    if surf['kind'] == 'bent_toroid':             # bragg.py:243-343
+        Rm, Rs = surf['Rm'], surf['Rs']
+        if surf['planes'] == 'johann':
+            return _n_bent_toroid(surf, x, y, Rm, Rs, surf.get('alpha'))
+        nSurf = _n_bent_toroid(surf, x, y, Rm, Rs, None)
+        if surf['planes'] == 'general':
+            nSurfBr = _n_bent_toroid(surf, x, y, surf['RmBragg'], surf['RsBragg'], None)
+            return [nSurfBr[0], nSurfBr[1], nSurfBr[2], nSurf[-3], nSurf[-2], nSurf[-1]]
+        a = np.zeros_like(x)
+        b = -y
+        c = (Rm**2 - y**2)**0.5 + Rm
+        norm = np.sqrt(b**2 + c**2)
+        b, c = b/norm, c/norm
+        alpha = surf.get('alpha')
+        if alpha:
+            b, c = rotate_x(b, c, np.cos(alpha), -np.sin(alpha))
+        r = Rs - (Rm - (Rm**2 - y**2)**0.5)
+        cosangle, sinangle = (r**2 - x**2)**0.5 / r, -x/r
+        a, c = rotate_y(a, c, cosangle, sinangle)
+        if alpha:
+            a, c = rotate_y(a, c, cosangle, sinangle)
+        return [a, b, c, nSurf[-3], nSurf[-2], nSurf[-1]]
     if surf['kind'] == 'sagittal':                # oes/__init__.py:658-662
         a = -x / surf['Rs']  # -dz/dx
         c = (surf['Rs']**2-x**2)**0.5 / surf['Rs']

@@ -180,6 +180,20 @@ def product_oe(name, g):
         m = rm.Material('Rh', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.ConicalMirror(bl, 'cone', L0=float(g['surf_L0']),
                                theta=float(g['surf_theta']), material=m, **common)
+    elif name.startswith('g3_bent_'):
+        si = rm.CrystalSi(hkl=(1, 1, 1))
+        assert si.d == float(g['cr_d']) and si.chiToF == float(g['cr_chiToF'])
+        cls = str(g['surf_class'])
+        kw = dict(Rm=float(g['surf_Rm']))
+        if 'Cylinder' in cls:
+            kw['crossSection'] = str(g['surf_crossSection'])
+        else:
+            kw['Rs'] = float(g['surf_Rs'])
+        if 'General' in cls:
+            kw.update(RmBragg=float(g['surf_RmBragg']), RsBragg=float(g['surf_RsBragg']))
+        alpha = float(g['surf_alpha'])
+        oe = getattr(roe, cls)(bl, 'an', material=si, alpha=alpha if alpha else None, **kw,
+                               **common)
     elif name.startswith('g3_laue_plate'):
         alpha = float(g['alpha'])
         si = rm.CrystalSi(hkl=(1, 1, 1), geom=str(g['cr_geom']), t=float(g['cr_t']))

@@ -685,3 +685,34 @@ def test_laterally_graded_multilayer_is_refused():
     ml = Lateral(rm.Material('W', rho=19.3), 12., si, 18., 10, si)
     with pytest.raises(NotImplementedError):
         ml.to_struct()
+
+
+# ---- bent crystal analysers (oes/bragg.py) ----------------------------------------
+@pytest.mark.parametrize('name', ['g3_bent_johann_cyl', 'g3_bent_johann_parab_asym',
+                                  'g3_bent_johansson_cyl', 'g3_bent_johann_tor',
+                                  'g3_bent_johann_tor_asym', 'g3_bent_johansson_tor',
+                                  'g3_bent_general_tor'])
+def test_bent_crystal_analysers_match_reference_golden(name):
+    """Johann / Johansson cylinders and toroids, GeneralBraggToroid: surface in the
+    reference's operation order (states bit-exact), the two normals per point (atomic
+    planes: following the surface, ground, or with radii of their own; asymmetric cut),
+    a divergent source on the Rowland circle."""
+    g = pc.load(name)
+    oe = pc.product_oe(name, g)
+    info = {}
+    gb, lb = oe.reflect(pc.product_beam(g), _info=info)
+    assert info['axis'] == int(g['axis']) and info['brent'] == bool(g['brent'])
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    assert np.abs(lb.theta - g['lb_theta']).max() < 1e-14
+    # the host class's surface functions are the device's
+    p, _, _ = fixture_io.load_case(name)
+    x, y = np.array([0., 3., -7., 11.]), np.array([0., 20., -31., 5.])
+    assert np.array_equal(oe.local_z(x, y), rn.local_z(p['surface'], x, y))
+    mine, ref = oe.local_n(x, y), rn.local_n(p['surface'], x, y)
+    assert len(mine) == len(ref)
+    for m, r in zip(mine, ref):
+        assert np.abs(m - r).max() < 1e-15
+    hit = g['lb_state'] == 1
+    flux = (lb.Jss + lb.Jpp)[hit] / (g['in_Jss'] + g['in_Jpp'])[hit]
+    assert flux.max() > 0.2       # some rays sit on or near the rocking curve

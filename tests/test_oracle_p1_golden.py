@@ -34,7 +34,10 @@ def check_beam(mine, g, prefix):
                                   'g2_capillary_hyperbola', 'g3_laue_plate', 'g3_laue_plate_asym',
                                   'g3_laue_plate_transmitted', 'g2_multilayer_flat',
                                   'g2_ellipse_multilayer', 'g2_multilayer_tran',
-                                  'g2_coated_toroid'])
+                                  'g2_coated_toroid', 'g3_bent_johann_cyl',
+                                  'g3_bent_johann_parab_asym', 'g3_bent_johansson_cyl',
+                                  'g3_bent_johann_tor', 'g3_bent_johann_tor_asym',
+                                  'g3_bent_johansson_tor', 'g3_bent_general_tor'])
 def test_oe_reflect_matches_reference(name):
     p, beam, g = fixture_io.load_case(name)
     info = {}

@@ -690,6 +690,89 @@ class ConicalMirror(_Curved):
                       self.redfocus, t2t, .5*t2t))
 
 
+class _BentBragg(_Curved):
+    """Bent crystal analysers (reference oes/bragg.py:104-343): surface kind
+    XRT_HIP_SURF_BENT_BRAGG. *_shape*: 0 circular cylinder, 1 parabolic cylinder, 2 toroid;
+    *_planes*: 0 the atomic planes follow the surface (Johann), 1 ground to twice the
+    radius (Johansson), 2 bent to radii of their own."""
+    _shape = _planes = 0
+
+    def local_n(self, x, y):
+        both = self._eval_surface(_SURF_N, x, y)
+        return both if self._planes or self.alpha else both[3:]
+
+    def _surface_params(self, p, second=False):
+        shape = self._shape
+        if shape == 0 and self.crossSection.startswith('parab'):
+            shape = 1
+        tilt = self.alpha if self.alpha else 0.
+        Rs = getattr(self, 'Rs', 0.)
+        self._curved(p, _structs.SURF_BENT_BRAGG,
+                     (shape, self._planes, self.Rm, Rs, np.cos(tilt), np.sin(tilt),
+                      1. if self.alpha else 0., getattr(self, 'RmBragg', self.Rm),
+                      getattr(self, 'RsBragg', Rs)))
+        p.asymmetric = 1 if self._planes or self.alpha else 0
+
+
+class JohannCylinder(_BentBragg):
+    """Cylindrically bent crystal, meridional radius *Rm*; *crossSection* 'circular' or
+    'parabolic' (bragg.py:104-176)."""
+
+    def __init__(self, *args, **kwargs):
+        self.Rm = kwargs.pop('Rm', 1000.)
+        self.crossSection = kwargs.pop('crossSection', 'circular')
+        if not self.crossSection.startswith(('circ', 'parab')):
+            raise ValueError('unknown crossSection!')
+        self.crossSectionInt = 0 if self.crossSection.startswith('circ') else 1
+        OE.__init__(self, *args, **kwargs)
+
+
+class JohanssonCylinder(JohannCylinder):
+    """Bent and ground: atomic planes of radius 2 Rm under a surface of radius Rm
+    (bragg.py:179-197)."""
+    _planes = 1
+
+
+class JohannToroid(_BentBragg):
+    """Doubly bent crystal, meridional *Rm* and sagittal *Rs* (= *Rm* if None)
+    (bragg.py:200-269)."""
+    _shape = 2
+
+    def __init__(self, *args, **kwargs):
+        kwargs = self.pop_kwargs(**kwargs)
+        OE.__init__(self, *args, **kwargs)
+
+    def pop_kwargs(self, **kwargs):
+        self.Rm = kwargs.pop('Rm', 1000.)
+        self.Rs = kwargs.pop('Rs', None)
+        return kwargs
+
+    Rs = property(lambda self: self.Rm if self._Rs is None else self._Rs,
+                  lambda self, v: setattr(self, '_Rs', v))
+
+
+class JohanssonToroid(JohannToroid):
+    """Doubly bent and ground (bragg.py:272-296)."""
+    _planes = 1
+
+
+class GeneralBraggToroid(JohannToroid):
+    """Four radii: *Rm*, *Rs* of the surface, *RmBragg*, *RsBragg* of the atomic planes
+    (each following its surface radius if None) (bragg.py:299-343)."""
+    _planes = 2
+
+    def pop_kwargs(self, **kwargs):
+        planes = kwargs.pop('RmBragg', None), kwargs.pop('RsBragg', None)
+        kwargs = JohannToroid.pop_kwargs(self, **kwargs)
+        self.RmBragg, self.RsBragg = planes
+        return kwargs
+
+    RmBragg = property(lambda self: self.Rm if self._RmBragg is None else self._RmBragg,
+                       lambda self, v: setattr(self, '_RmBragg', v))
+    RsBragg = property(lambda self: self.Rs if self._RsBragg is None else self._RsBragg,
+                       lambda self, v: setattr(self, '_RsBragg', v))
+
+
 class BlazedGrating(_Curved):
     """Saw-tooth grating of constant line density for WAVE propagation: the
     diffraction comes from the surface itself through the Kirchhoff integral,

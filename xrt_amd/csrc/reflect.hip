@@ -401,6 +401,16 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
   }
   if (PSURF(P) == XRT_HIP_SURF_SAGITTAL)  // oes/__init__.py:655-656 (crystals: family 0 too)
     return P.surf_p[0] - sqrt(P.surf_p[1] - x * x);
+  if (PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {  // oes/bragg.py:138-144, 236-241
+    const double Rm = P.surf_p[2], Rs = P.surf_p[3];
+    if (P.surf_p[0] == 1.) return y * y / 2.0 / Rm;
+    const double root = sqrt(Rm * Rm - y * y);
+    if (P.surf_p[0] == 0.) return Rm - root;
+    // toroid: the meridional circle turned about the sagittal axis
+    const double z = (Rm - Rs) - root;
+    const double cosangle = sqrt(z * z - x * x) / fabs(z);
+    return cosangle * z + Rs;
+  }
   if (surf_is_cone<K>(P)) {  // oes/__init__.py:623-627
     const double u = y - P.surf_p[0];
     const double root = sqrt(P.surf_p[1] * (u * u) - P.surf_p[2] * (x * x));
@@ -1795,6 +1805,89 @@ __device__ __forceinline__ constexpr bool early_fields() {
 // (the same unless the crystal is cut asymmetrically). (x, y): Cartesian hit point;
 // (px, py): what the reference hands to local_n -- the same, or (s, phi) on a
 // parametric surface.
+// Bent crystal analysers (oes/bragg.py:146-343): surface normal n[3..5] and the normal
+// of the atomic planes n[0..2]. rotate_x(y, z, c, s) = (c y - s z, s y + c z) is called
+// with -sin(alpha); rotate_y(x, z, c, s) = (c x + s z, -s x + c z).
+__device__ __forceinline__ void bent_toroid_normal(double x, double y, double Rm, double Rs,
+                                                   double& a, double& b, double& c,
+                                                   double& cosang, double& sinang) {
+  const double root = sqrt(Rm * Rm - y * y);
+  b = -y / Rm;
+  const double c0 = root / Rm;
+  const double r = Rs - (Rm - root);
+  cosang = sqrt(r * r - x * x) / r;
+  sinang = -x / r;
+  a = sinang * c0;
+  c = cosang * c0;
+}
+__device__ __forceinline__ void bent_bragg_normals(const xrt_hip_pass& P, double x, double y,
+                                                   double (&n)[6]) {
+  const int shape = (int)P.surf_p[0], planes = (int)P.surf_p[1];
+  const double Rm = P.surf_p[2], Rs = P.surf_p[3];
+  const double ca = P.surf_p[4], sa = P.surf_p[5];
+  const bool tilted = P.surf_p[6] != 0.;
+  const double root = sqrt(Rm * Rm - y * y);
+  double cosang = 1., sinang = 0.;
+  if (shape == 2) {
+    bent_toroid_normal(x, y, Rm, Rs, n[3], n[4], n[5], cosang, sinang);
+  } else {  // cylinder, :146-166
+    n[3] = 0.;
+    n[4] = -y / Rm;
+    if (shape == 0) {
+      n[5] = root / Rm;
+    } else {
+      const double norm = sqrt(n[4] * n[4] + 1.);
+      n[4] /= norm;
+      n[5] = 1. / norm;
+    }
+  }
+  if (planes == 0) {  // Johann: the planes follow the surface, turned by alpha about x
+    n[0] = n[3];
+    n[1] = n[4];
+    n[2] = n[5];
+    if (tilted) {
+      // (the toroid tilts its meridional normal first and turns it sagittally after, :254-266)
+      const double b0 = shape == 2 ? -y / Rm : n[4];
+      const double c0 = shape == 2 ? root / Rm : n[5];
+      n[1] = ca * b0 + sa * c0;
+      const double cA = -sa * b0 + ca * c0;
+      n[0] = shape == 2 ? sinang * cA : 0.;
+      n[2] = shape == 2 ? cosang * cA : cA;
+    }
+  } else if (planes == 1) {  // Johansson: planes bent to 2 Rm, :185-196, 279-295
+    double b = -y, c = root + Rm;
+    if (shape != 2 && tilted) {
+      const double b1 = ca * b + sa * c;
+      c = -sa * b + ca * c;
+      b = b1;
+    }
+    const double norm = sqrt(b * b + c * c);
+    b /= norm;
+    c /= norm;
+    double a = 0.;
+    if (shape == 2) {
+      if (tilted) {
+        const double b1 = ca * b + sa * c;
+        c = -sa * b + ca * c;
+        b = b1;
+      }
+      a = sinang * c;
+      c = cosang * c;
+      if (tilted) {  // the reference turns a tilted plane normal a second time (:292-293)
+        const double a1 = cosang * a + sinang * c;
+        c = -sinang * a + cosang * c;
+        a = a1;
+      }
+    }
+    n[0] = a;
+    n[1] = b;
+    n[2] = c;
+  } else {  // planes with their own radii, :336-342
+    double cb, sb;
+    bent_toroid_normal(x, y, P.surf_p[7], P.surf_p[8], n[0], n[1], n[2], cb, sb);
+  }
+}
+
 template <class K>
 __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, double y,
                                                double px, double py, double (&n)[6]) {
@@ -1825,6 +1918,8 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     n[0] = n[3] = -x / P.surf_p[0];
     n[1] = n[4] = 0.;
     n[2] = n[5] = sqrt(P.surf_p[1] - x * x) / P.surf_p[0];
+  } else if (PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {
+    bent_bragg_normals(P, x, y, n);
   } else if (surf_is_cone<K>(P)) {  // oes/__init__.py:629-636
     const double u = y - P.surf_p[0];
     const double root =
