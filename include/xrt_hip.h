@@ -290,7 +290,7 @@ typedef struct xrt_hip_material {
   double d2f_re, d2f_im;       /* crystals: 1 + exp(i pi/2 (h+k+l)), crystals_basic.py:77 */
   double rho, mass, t;         /* g/cm3, g/mol, thickness [mm] (thin mirror) */
   /* crystal (crystal.py:150-226, crystals_basic.py) */
-  int32_t structure;           /* 0 fcc, 1 diamond */
+  int32_t structure;           /* 0 fcc, 1 diamond, 2 from the unit cell (cell_* below) */
   int32_t hkl[3];
   int32_t geom_bragg;          /* 1 Bragg, 0 Laue */
   int32_t geom_transmitted;    /* 1 transmitted, 0 reflected */
@@ -302,6 +302,15 @@ typedef struct xrt_hip_material {
    * normal; 0: Coated (kind 'mirror'), mirror direction, amplitude at the cosine to the
    * local normal --, d and geom_transmitted. */
   const struct xrt_hip_multilayer* layers;
+  /* structure == 2, CrystalFromCell (crystals_basic.py:424-440): per element e of the
+   * material (its atoms in the cell, their fractions w_j and positions r_j) the sums
+   * cell_w = sum w_j, cell_s = sum w_j exp(2 pi i r_j.hkl), cell_sm = the same with
+   * -r_j, and f0 at sin(theta)/lambda = 1/2d. F0 = factDW sum_e cell_w (Z + f1 + i f2),
+   * F_hkl = factDW sum_e (f0 + f1 + i f2) cell_s, F_-h-k-l with cell_sm. */
+  double cell_w[XRT_HIP_MAX_ELEM];
+  double cell_f0[XRT_HIP_MAX_ELEM];
+  double cell_s[XRT_HIP_MAX_ELEM][2];
+  double cell_sm[XRT_HIP_MAX_ELEM][2];
 } xrt_hip_material;
 
 /* Multilayer / GradedMultilayer / Coated (materials/multilayer.py): npairs periods of a

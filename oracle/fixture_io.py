@@ -170,6 +170,14 @@ def load_case(name):
         p['material'] = mn.make_crystal(si, (1, 1, 1), float(g['cr_d']), 'diamond',
                                         'Bragg reflected', None, 1., float(g['cr_V']))
         assert p['material']['chiToF'] == float(g['cr_chiToF'])
+    elif name.startswith('g3_cell_'):
+        from . import gen_fixtures_cell as gc
+        if 'surf_Rm' in g.files:
+            p['surface'] = dict(kind='bent_cylinder', Rm=float(g['surf_Rm']), planes='johann',
+                                alpha=None, crossSection='circular')
+        else:
+            p['surface'] = dict(kind='flat', alpha=float(g['alpha']))
+        p['material'] = gc.oracle_cell(gc.all_tables(), str(g['cell']))
     elif name.startswith('g3_laue_plate'):
         alpha = float(g['alpha'])
         p['surface'] = dict(kind='flat', laue=True, alpha=alpha if alpha else None)

@@ -251,7 +251,47 @@ def make_crystal_si(elem_si, hkl=(1, 1, 1), tK=297.15, **kw):
     return make_crystal(elem_si, hkl, d, 'diamond', **kw)
 
 
+def make_crystal_from_cell(elems, atomsXYZ, hkl, a, b=None, c=None, alpha=90, beta=90,
+                           gamma=90, atomsFraction=None, geom='Bragg reflected', t=None,
+                           factDW=1.):
+    """CrystalFromCell (crystals_basic.py:157-440): *elems* = one element dict per atom of
+    the cell (the same dict object for atoms of one element)."""
+    b, c = b or a, c or a
+    fractions = [1 for _ in elems] if atomsFraction is None else atomsFraction
+    ca, cb, cg = np.cos(np.radians((alpha, beta, gamma)))
+    sa, sb, sg = np.sin(np.radians((alpha, beta, gamma)))
+    V = a * b * c * (1 - ca**2 - cb**2 - cg**2 + 2*ca*cb*cg)**0.5
+    h, k, l = hkl   # noqa: E741
+    d = V / (a * b * c) *\
+        ((h*sa/a)**2 + (k*sb/b)**2 + (l*sg/c)**2 +
+         2*h*k * (ca*cb - cg) / (a*b) +
+         2*h*l * (ca*cg - cb) / (a*c) +
+         2*k*l * (cb*cg - ca) / (b*c))**(-0.5)
+    if len(geom) < 6:
+        geom = geom.strip() + ' reflected'
+    return dict(kind='crystal', structure='cell', elements=list(elems),
+                atomsXYZ=[list(r) for r in atomsXYZ], atomsFraction=list(fractions),
+                hkl=tuple(hkl), d=d, V=V, chiToF=-R0 / PI / V, geom=geom, t=t,
+                factDW=factDW)
+
+
 def structure_factor(cr, E, sinThetaOverLambda=0):
+    if cr['structure'] == 'cell':                  # crystals_basic.py:424-440
+        F0, Fhkl, Fhkl_ = 0, 0, 0
+        unique = {}
+        for el, xyz, af in zip(cr['elements'], cr['atomsXYZ'], cr['atomsFraction']):
+            if el['Z'] in unique:
+                f0v, anomalousPart = unique[el['Z']]
+            else:
+                f0v = f0(el, sinThetaOverLambda)
+                anomalousPart = interp_f1f2(el, E)
+                unique[el['Z']] = f0v, anomalousPart
+            F0 += af * (el['Z']+anomalousPart) * cr['factDW']
+            fact = af * (f0v+anomalousPart) * cr['factDW']
+            expiHr = np.exp(2j * np.pi * np.dot(xyz, cr['hkl']))
+            Fhkl += fact * expiHr
+            Fhkl_ += fact / expiHr
+        return F0, Fhkl, Fhkl_
     elem = cr['elements'][0]
     anomalousPart = interp_f1f2(elem, E)
     F0 = 4 * (elem['Z']+anomalousPart) * cr['factDW']

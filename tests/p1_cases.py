@@ -63,6 +63,14 @@ def product_stack(name):
     return (rm.Coated if 'coating' in kw else rm.Multilayer)(**kw)
 
 
+def product_cell(name, **over):
+    """The xrt_amd CrystalFromCell of the cell *name* of oracle/gen_fixtures_cell.py."""
+    from oracle.gen_fixtures_cell import CELLS
+    kw = dict(CELLS[name])
+    kw.update(over)
+    return rm.CrystalFromCell(name, **kw)
+
+
 def product_oe(name, g):
     """-> the xrt_amd optical element for golden case *name*."""
     bl = raycing.BeamLine(azimuth=_az(g))
@@ -194,6 +202,12 @@ def product_oe(name, g):
         alpha = float(g['surf_alpha'])
         oe = getattr(roe, cls)(bl, 'an', material=si, alpha=alpha if alpha else None, **kw,
                                **common)
+    elif name.startswith('g3_cell_'):
+        m = product_cell(str(g['cell']))
+        if 'surf_Rm' in g.files:
+            oe = roe.JohannCylinder(bl, 'gr', Rm=float(g['surf_Rm']), material=m, **common)
+        else:
+            oe = roe.OE(bl, 'qz', material=m, alpha=float(g['alpha']), **common)
     elif name.startswith('g3_laue_plate'):
         alpha = float(g['alpha'])
         si = rm.CrystalSi(hkl=(1, 1, 1), geom=str(g['cr_geom']), t=float(g['cr_t']))

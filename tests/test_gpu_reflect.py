@@ -716,3 +716,33 @@ def test_bent_crystal_analysers_match_reference_golden(name):
     hit = g['lb_state'] == 1
     flux = (lb.Jss + lb.Jpp)[hit] / (g['in_Jss'] + g['in_Jpp'])[hit]
     assert flux.max() > 0.2       # some rays sit on or near the rocking curve
+
+
+# ---- crystals given by their unit cell (crystals_basic.py:157-440) ------------------
+def test_cell_crystal_rocking_curves_match_reference(golden_dir):
+    """CrystalFromCell.get_amplitude: quartz (1 0 2), graphite (0 0 2), quartz (2 0 3) with
+    partial occupancies and a Debye-Waller factor; thick / thin, Bragg / Laue, reflected /
+    transmitted, symmetric and asymmetric -- the per-element cell sums of the device against
+    the reference's loop over the atoms."""
+    import os
+    from test_oracle_p1_golden import _cell_curve_keys
+    g = np.load(os.path.join(golden_dir, 'g3_cell_rocking_curves.npz'))
+    for key, name, geom, t in _cell_curve_keys(g):
+        cr = pc.product_cell(name, geom=geom, t=t)
+        E, g0, gh, hns = g[key + '_in']
+        S, P = cr.get_amplitude(E, g0, gh, hns)
+        for mine, ref in ((S, g[key + '_S']), (P, g[key + '_P'])):
+            assert np.abs(mine - ref).max() < 1e-9 * np.abs(ref).max(), key
+
+
+@pytest.mark.parametrize('name', ['g3_cell_quartz_flat', 'g3_cell_graphite_johann'])
+def test_cell_crystal_elements_match_reference_golden(name):
+    g = pc.load(name)
+    oe = pc.product_oe(name, g)
+    info = {}
+    gb, lb = oe.reflect(pc.product_beam(g), _info=info)
+    assert info['axis'] == int(g['axis']) and info['brent'] == bool(g['brent'])
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    hit = g['lb_state'] == 1
+    assert ((lb.Jss + lb.Jpp)[hit] / (g['in_Jss'] + g['in_Jpp'])[hit]).max() > 0.3

@@ -37,7 +37,8 @@ def check_beam(mine, g, prefix):
                                   'g2_coated_toroid', 'g3_bent_johann_cyl',
                                   'g3_bent_johann_parab_asym', 'g3_bent_johansson_cyl',
                                   'g3_bent_johann_tor', 'g3_bent_johann_tor_asym',
-                                  'g3_bent_johansson_tor', 'g3_bent_general_tor'])
+                                  'g3_bent_johansson_tor', 'g3_bent_general_tor',
+                                  'g3_cell_quartz_flat', 'g3_cell_graphite_johann'])
 def test_oe_reflect_matches_reference(name):
     p, beam, g = fixture_io.load_case(name)
     info = {}
@@ -211,3 +212,27 @@ def test_multilayer_amplitudes_match_reference():
                                        g[name + '_bdn'])
         for mine, ref in ((s, g[name + '_s']), (p, g[name + '_p'])):
             assert np.abs(mine - ref).max() <= 1e-13 * np.abs(ref).max(), name
+
+
+def _cell_curve_keys(g):
+    for key in sorted(k[:-3] for k in g.files if k.endswith('_in')):
+        name, geom, thick, alpha = key.rsplit('_', 3)
+        geom = geom.replace('Bragg', 'Bragg ').replace('Laue', 'Laue ')
+        yield key, name, geom, None if thick == 'thick' else float(thick[:-2]) * 1e-3
+
+
+def test_cell_crystal_rocking_curves(golden_dir):
+    """CrystalFromCell (crystals_basic.py:157-440): structure factor summed over the atoms
+    of a hexagonal two-element cell, partial occupancies, Debye-Waller factor."""
+    from oracle import gen_fixtures_cell as gc
+    g = np.load(os.path.join(golden_dir, 'g3_cell_rocking_curves.npz'))
+    tb = gc.all_tables()
+    count = 0
+    for key, name, geom, t in _cell_curve_keys(g):
+        cr = gc.oracle_cell(tb, name, geom=geom, t=t)
+        E, g0, gh, hns = g[key + '_in']
+        S, P = mn.crystal_amplitude(cr, E.copy(), g0.copy(), gh.copy(), hns.copy())
+        for mine, ref in ((S, g[key + '_S']), (P, g[key + '_P'])):
+            assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max(), key
+        count += 1
+    assert count == 3 * 5 * 2

@@ -108,6 +108,10 @@ class Material(ctypes.Structure):
         ('fact_dw', ctypes.c_double),
         ('t_crystal', ctypes.c_double),
         ('layers', ctypes.c_void_p),
+        ('cell_w', ctypes.c_double * MAX_ELEM),
+        ('cell_f0', ctypes.c_double * MAX_ELEM),
+        ('cell_s', ctypes.c_double * 2 * MAX_ELEM),
+        ('cell_sm', ctypes.c_double * 2 * MAX_ELEM),
     ]
 
 

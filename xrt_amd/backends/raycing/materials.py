@@ -581,3 +581,105 @@ class CrystalSi(CrystalDiamond):
 
     def get_a(self):
         return self.a0 * (self.dl_l(self.tK) - self.dl_l(273.15 + 19.9) + 1)
+
+
+_DIAMOND_CELL = [[0., 0., 0.], [0., 0.5, 0.5], [0.5, 0.5, 0.], [0.5, 0., 0.5],
+                 [0.25, 0.25, 0.25], [0.25, 0.75, 0.75], [0.75, 0.25, 0.75],
+                 [0.75, 0.75, 0.25]]
+
+
+class CrystalFromCell(Crystal):
+    """Crystal given by its unit cell (crystals_basic.py:157-440): edges *a*, *b*, *c* [A]
+    (*b*, *c* default to *a*), angles *alpha*, *beta*, *gamma* [deg], ALL atoms of the cell
+    (*atoms*: Z or symbol each, *atomsXYZ*: fractional coordinates, *atomsFraction*:
+    occupancies). d spacing, cell volume, density and the structure factor follow.
+
+    On the GPU the sums over the atoms of one element are constants of the reflection
+    (``xrt_hip_material.cell_*``); the ray-dependent part is f1 + i f2 of each element --
+    at most four different elements per crystal. ``elements`` / ``quantities`` hold the
+    DISTINCT elements and their summed occupancies (the reference repeats them per atom)."""
+    structure = 2
+
+    def __init__(self, name='', hkl=(1, 1, 1), a=5.430710, b=None, c=None, alpha=90, beta=90,
+                 gamma=90, atoms=(14,)*8, atomsXYZ=_DIAMOND_CELL, atomsFraction=None, tK=0,
+                 t=None, factDW=1., geom='Bragg reflected', table='Chantler total',
+                 volumetricDiffraction=False, useTT=False, nu=0, mosaicity=0, **kwargs):
+        self.a, self.b, self.c = a, b or a, c or a
+        self.alpha, self.beta, self.gamma = alpha, beta, gamma
+        self.atoms = list(atoms)
+        self.atomsXYZ = [list(r) for r in atomsXYZ]
+        self.atomsFraction = [1 for _ in self.atoms] if atomsFraction is None \
+            else list(atomsFraction)
+        if not len(self.atoms) == len(self.atomsXYZ) == len(self.atomsFraction):
+            raise ValueError('atoms, atomsXYZ and atomsFraction differ in length')
+        distinct, per_atom = [], []
+        for atom in self.atoms:
+            e = Element(atom, table)
+            if e.Z not in [q.Z for q in distinct]:
+                distinct.append(e)
+            per_atom.append([q.Z for q in distinct].index(e.Z))
+        self._atom_element = per_atom
+        summed = [sum(f for f, k in zip(self.atomsFraction, per_atom) if k == i)
+                  for i in range(len(distinct))]
+        cosines = np.cos(np.radians((alpha, beta, gamma)))
+        sines = np.sin(np.radians((alpha, beta, gamma)))
+        ca, cb, cg = cosines
+        sa, sb, sg = sines
+        a, b, c = self.a, self.b, self.c
+        V = a * b * c * (1 - ca**2 - cb**2 - cg**2 + 2*ca*cb*cg)**0.5
+        h, k, l = hkl   # noqa: E741
+        # 1/d^2 of a triclinic lattice (crystals_basic.py:416-421, same operation order:
+        # d sets the Bragg angle the user aligns with)
+        d = V / (a * b * c) * \
+            ((h*sa/a)**2 + (k*sb/b)**2 + (l*sg/c)**2 + 2*h*k * (ca*cb - cg) / (a*b) +
+             2*h*l * (ca*cg - cb) / (a*c) + 2*k*l * (cb*cg - ca) / (b*c))**(-0.5)
+        Crystal.__init__(self, hkl=hkl, d=float(d), V=float(V), elements=distinct,
+                         quantities=summed, t=t, factDW=factDW, geom=geom, table=table,
+                         name=name, **kwargs)
+        self.mass = 0.
+        for f, idx in zip(self.atomsFraction, per_atom):     # per atom, as the reference sums
+            self.mass += f * distinct[idx].mass
+        self.rho = self.mass / AVOGADRO / self.V * 1e24
+        self.tK, self.nu = tK, nu
+        self.volumetricDiffraction, self.useTT, self.mosaicity = \
+            volumetricDiffraction, useTT, mosaicity
+
+    def _cell_sums(self):
+        """Per distinct element: (sum w, sum w e^{+i phase}, sum w e^{-i phase})."""
+        n = len(self.elements)
+        w, s, sm = np.zeros(n), np.zeros(n, complex), np.zeros(n, complex)
+        for f, idx, xyz in zip(self.atomsFraction, self._atom_element, self.atomsXYZ):
+            turn = np.exp(2j * np.pi * np.dot(xyz, self.hkl))
+            w[idx] += f
+            s[idx] += f * turn
+            sm[idx] += f / turn
+        return w, s, sm
+
+    def get_structure_factor(self, E, sinThetaOverLambda=0, needFhkl=True):
+        """(F0, F_hkl, F_-h-k-l) on the host (alignment helper)."""
+        E = np.asarray(E, dtype=float)
+        w, s, sm = self._cell_sums()
+        F0 = Fh = Fhm = 0
+        for e, we, se, sme in zip(self.elements, w, s, sm):
+            anomalous = np.interp(E, e.E, e.f1) + 1j * np.interp(E, e.E, e.f2)
+            f0 = e.get_f0(sinThetaOverLambda) if needFhkl else 0
+            F0 = F0 + we * (e.Z + anomalous) * self.factDW
+            Fh = Fh + (f0 + anomalous) * se * self.factDW
+            Fhm = Fhm + (f0 + anomalous) * sme * self.factDW
+        return F0, Fh, Fhm
+
+    def get_dtheta_symmetric_Bragg(self, E):
+        E = np.atleast_1d(np.asarray(E, dtype=float))
+        F0 = self.get_structure_factor(E, needFhkl=False)[0]
+        chi0 = F0.real * self.chiToF * (CH / E)**2
+        return chi0 / np.sin(2*self.get_Bragg_angle(E))
+
+    def to_struct(self, fromVacuum=True, device=None):
+        s = Crystal.to_struct(self, fromVacuum, device)
+        w, cs, csm = self._cell_sums()
+        for i, e in enumerate(self.elements):
+            s.cell_w[i] = float(w[i])
+            s.cell_f0[i] = float(e.get_f0(0.5 / self.d))
+            s.cell_s[i][0], s.cell_s[i][1] = float(cs[i].real), float(cs[i].imag)
+            s.cell_sm[i][0], s.cell_sm[i][1] = float(csm[i].real), float(csm[i].imag)
+        return s

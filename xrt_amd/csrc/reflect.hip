@@ -1579,17 +1579,32 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
     b = k0s * frcp(kHs);
   }
   // structure factors, crystals_basic.py:22-31, 76-80; chi, crystal.py:297-306
-  const cplx anom = apre ? *apre : interp_f1f2(M, 0, E, w);
-  cplx F0 = (C((double)M.Z[0], 0.) + anom) * 4. * M.fact_dw;
-  const int residue = (abs(M.hkl[0]) % 2) + (abs(M.hkl[1]) % 2) + (abs(M.hkl[2]) % 2);
-  cplx Fh = C(0., 0.), Fh_ = C(0., 0.);
-  if (residue == 0 || residue == 3) Fh = (C(M.f0_hkl, 0.) + anom) * 4. * M.fact_dw;
-  Fh_ = Fh;
-  if (M.structure == 1) {
-    const cplx d2f = C(M.d2f_re, M.d2f_im);
-    F0 = F0 * 2.;
-    Fh_ = Fh * conj(d2f);
-    Fh = Fh * d2f;
+  cplx F0 = C(0., 0.), Fh = C(0., 0.), Fh_ = C(0., 0.);
+  if (M.structure == 2) {
+    // from the unit cell, crystals_basic.py:424-440: the sums over the atoms of each
+    // element are constants of the reflection, only f1 + i f2 depends on the ray
+    for (int e = 0; e < M.nelem; ++e) {
+      const cplx anom = interp_f1f2(M, e, E, w);
+      F0 = F0 + (C((double)M.Z[e], 0.) + anom) * M.cell_w[e];
+      const cplx f = C(M.cell_f0[e], 0.) + anom;
+      Fh = Fh + f * C(M.cell_s[e][0], M.cell_s[e][1]);
+      Fh_ = Fh_ + f * C(M.cell_sm[e][0], M.cell_sm[e][1]);
+    }
+    F0 = F0 * M.fact_dw;
+    Fh = Fh * M.fact_dw;
+    Fh_ = Fh_ * M.fact_dw;
+  } else {
+    const cplx anom = apre ? *apre : interp_f1f2(M, 0, E, w);
+    F0 = (C((double)M.Z[0], 0.) + anom) * 4. * M.fact_dw;
+    const int residue = (abs(M.hkl[0]) % 2) + (abs(M.hkl[1]) % 2) + (abs(M.hkl[2]) % 2);
+    if (residue == 0 || residue == 3) Fh = (C(M.f0_hkl, 0.) + anom) * 4. * M.fact_dw;
+    Fh_ = Fh;
+    if (M.structure == 1) {
+      const cplx d2f = C(M.d2f_re, M.d2f_im);
+      F0 = F0 * 2.;
+      Fh_ = Fh * conj(d2f);
+      Fh = Fh * d2f;
+    }
   }
   const double c2l = M.chi_to_f * (waveLength * waveLength);
   const cplx chi0 = conj(F0) * c2l, chih = conj(Fh) * c2l, chih_ = conj(Fh_) * c2l;
@@ -3742,8 +3757,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
 // leaves in it
 bool reflect_dcm_fusable(const xrt_hip_pass& P1, const xrt_hip_material& M1,
                          const xrt_hip_pass& P2, const xrt_hip_material& M2) {
-  auto bragg = [](const xrt_hip_material& M) {
-    return M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted;
+  auto bragg = [](const xrt_hip_material& M) {   // (one-element lattices: the fused kernel
+    // looks the anomalous factor up once for both crystals)
+    return M.kind == XRT_HIP_MAT_CRYSTAL && !M.geom_transmitted && M.structure != 2;
   };
   auto flat = [](const xrt_hip_pass& P) {
     return P.surf_kind == XRT_HIP_SURF_FLAT && !P.no_intersection_search && !P.grating;
