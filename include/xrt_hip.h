@@ -482,6 +482,14 @@ typedef struct xrt_hip_screen {
   double compress_x, compress_z; /* 0 = none */
   int32_t lost_num;
   int32_t only_positive_path;
+  /* HemisphericScreen (screens.py:422-559): radius != 0 -> the rays are carried to the
+   * sphere of that radius about `center` (the far intersection), positions go into the
+   * screen's axes, directions stay global, and the two angles theta = asin(z / R) -
+   * theta_offset, phi = atan2(y, x) - phi_offset are written to out_theta / out_phi
+   * (device arrays of n doubles, may be NULL). */
+  double radius, theta_offset, phi_offset;
+  double* out_theta;
+  double* out_phi;
 } xrt_hip_screen;
 
 XRT_HIP_API int xrt_hip_screen_expose_f64_dev(const xrt_hip_screen* screen,

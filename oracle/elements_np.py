@@ -50,6 +50,40 @@ def screen_expose(beam, basis, center, lostNum, onlyPositivePath=False):
     return blo
 
 
+def hemispheric_expose(beam, basis, center, R, lostNum, phiOffset=0, thetaOffset=0,
+                       onlyPositivePath=False):
+    """HemisphericScreen.expose, screens.py:517-559. basis = (x, y, z) axes."""
+    blo = beam.copy()
+    sqb_2 = (beam.a * (beam.x-center[0]) +
+             beam.b * (beam.y-center[1]) +
+             beam.c * (beam.z-center[2]))
+    sqc = ((beam.x-center[0])**2 +
+           (beam.y-center[1])**2 +
+           (beam.z-center[2])**2 - R**2)
+    with np.errstate(invalid='ignore'):
+        path = -sqb_2 + (sqb_2**2 - sqc)**0.5
+    condBad = np.isnan(path) | np.isinf(path)
+    if onlyPositivePath:
+        condBad = condBad | (path < 0)
+    path[condBad] = 0.
+    blo.state[condBad] = lostNum
+    blo.path += path
+    rx = beam.x + beam.a*path - center[0]
+    ry = beam.y + beam.b*path - center[1]
+    rz = beam.z + beam.c*path - center[2]
+    ex, ey, ez = basis
+    blo.z = rx*ez[0] + ry*ez[1] + rz*ez[2]
+    blo.y = rx*ey[0] + ry*ey[1] + rz*ey[2]
+    blo.x = rx*ex[0] + ry*ex[1] + rz*ex[2]
+    blo.theta = np.arcsin(blo.z / R) - thetaOffset
+    blo.phi = np.arctan2(blo.y, blo.x) - phiOffset
+    if hasattr(blo, 'Es'):
+        propPhase = np.exp(1e7j * (blo.E / CHBAR) * path)
+        blo.Es *= propPhase
+        blo.Ep *= propPhase
+    return blo
+
+
 def aperture_propagate(beam, basis, center, blades, lostNum, azimuth_sc=(0., 1.),
                        isBeamStop=False, needNewGlobal=False, radius=None,
                        shadeFraction=None, vertices=None):

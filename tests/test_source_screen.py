@@ -272,3 +272,58 @@ def test_resident_chain_source_slit_mirror_screen_matches_oracle():
         assert np.abs(getattr(img, f) - r).max() <= 1e-12 * np.abs(r).max(), f
     good = oimg.state == 1
     assert np.abs(img.Jss - oimg.Jss)[good].max() <= 1e-10 * oimg.Jss.max()
+
+
+# ---- HemisphericScreen (screens.py:422-559) ---------------------------------------
+_HEMI = (('auto', dict(), False),
+         ('given', dict(x=(0, 1, 1), z=(1, 0, 0)), False),
+         ('positive', dict(), True))
+
+
+def test_hemispheric_screen_oracle_matches_reference(golden_dir):
+    from oracle import elements_np as en, reflect_np as rn
+    g = np.load(os.path.join(golden_dir, 'g1_hemispheric_screen.npz'))
+    beam = rn.Beam.from_dict(g, 'in_')
+    for tag, _, positive in _HEMI:
+        phi0, theta0 = g[tag + '_offsets']
+        lo = en.hemispheric_expose(beam, g[tag + '_axes'], g[tag + '_center'],
+                                   float(g[tag + '_R']), int(g[tag + '_lostNum']), phi0,
+                                   theta0, positive)
+        for f in FIELDS + ('state', 'Es', 'Ep', 'theta', 'phi'):
+            assert np.array_equal(getattr(lo, f), g['%s_%s' % (tag, f)], equal_nan=True), \
+                (tag, f)
+
+
+@pytest.mark.gpu
+def test_hemispheric_screen_matches_reference(golden_dir):
+    """Rays carried to the far intersection with the sphere, local position on it, the two
+    angles less their offsets; directions stay global; rays that miss the sphere (or reach
+    it backwards, onlyPositivePath) are lost at the screen's number."""
+    g = np.load(os.path.join(golden_dir, 'g1_hemispheric_screen.npz'))
+    bl = raycing.BeamLine(azimuth=float(g['azimuth']))
+    b = rs.Beam(nrays=len(g['in_x']), withAmplitudes=True)
+    for f in FIELDS + ('state', 'Es', 'Ep'):
+        setattr(b, f, g['in_' + f])
+    for tag, axes, positive in _HEMI:
+        phi0, theta0 = g[tag + '_offsets']
+        scr = rsc.HemisphericScreen(bl, tag, center=[float(v) for v in g[tag + '_center']],
+                                    R=float(g[tag + '_R']), phiOffset=phi0,
+                                    thetaOffset=theta0, **axes)
+        assert scr.lostNum == int(g[tag + '_lostNum'])
+        assert np.allclose(np.array([scr.x, scr.y, scr.z], dtype=float), g[tag + '_axes'],
+                           rtol=0, atol=1e-16)
+        lo = scr.expose(b, onlyPositivePath=positive)
+        assert np.array_equal(lo.state, g[tag + '_state'])
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp', 'theta', 'phi'):
+            ref = g['%s_%s' % (tag, f)]
+            fin = np.isfinite(ref)
+            assert np.array_equal(fin, np.isfinite(getattr(lo, f))), (tag, f)
+            assert np.abs(getattr(lo, f)[fin] - ref[fin]).max() <= \
+                1e-13 * max(np.abs(ref[fin]).max(), 1.), (tag, f)
+        for f in ('Es', 'Ep'):
+            assert np.abs(getattr(lo, f) - g['%s_%s' % (tag, f)]).max() <= \
+                1e-10 * np.abs(g[tag + '_Es']).max(), (tag, f)
+        glo = scr.expose_global(b)
+        ok = np.isfinite(g[tag + '_global_xyz'][0])
+        for mine, ref in zip((glo.x, glo.y, glo.z), g[tag + '_global_xyz']):
+            assert np.abs(mine[ok] - ref[ok]).max() < 1e-11, tag

@@ -139,7 +139,12 @@ class Screen(ctypes.Structure):
                 ('compress_x', ctypes.c_double),
                 ('compress_z', ctypes.c_double),
                 ('lost_num', ctypes.c_int32),
-                ('only_positive_path', ctypes.c_int32)]
+                ('only_positive_path', ctypes.c_int32),
+                ('radius', ctypes.c_double),
+                ('theta_offset', ctypes.c_double),
+                ('phi_offset', ctypes.c_double),
+                ('out_theta', ctypes.c_void_p),
+                ('out_phi', ctypes.c_void_p)]
 
 
 class Aperture(ctypes.Structure):

@@ -80,3 +80,61 @@ class Screen(object):
         xg, yg, zg = self.local_to_global(x=gx, z=gz)
         return rw.receiving_wave(self, prevOE, (gx, gy, gz), (xg, yg + dy, zg), cell,
                                  (np.ones_like(gx) * cell).sum(), prevOE.uuid)
+
+
+class HemisphericScreen(Screen):
+    """Screen on a sphere of radius *R* about *center* (reference screens.py:422-559): the
+    image carries the local position on the sphere and the angles ``theta`` (latitude
+    about the polar axis *z*) and ``phi`` (azimuth from *x*), each less its offset. 'auto'
+    axes: *x* along the beamline, *z* horizontal across it."""
+
+    def __init__(self, bl=None, name='', center=[0, 0, 0], R=1000., x='auto', z='auto',
+                 phiOffset=0, thetaOffset=0, **kwargs):
+        Screen.__init__(self, bl, name, center, x, z, **kwargs)
+        self.R, self.phiOffset, self.thetaOffset = R, phiOffset, thetaOffset
+
+    def set_orientation(self, x=None, z=None):
+        def unit(v):
+            v = np.asarray(v, dtype=float)
+            return list(v / sum(c**2 for c in v)**0.5)
+        s, c = (self.bl.sinAzimuth, self.bl.cosAzimuth) if self.bl is not None else (0., 1.)
+        self.x = (s, c, 0.) if x is None or isinstance(x, str) else unit(x)
+        self.z = (c, -s, 0.) if z is None or isinstance(z, str) else unit(z)
+        if abs(np.dot(self.x, self.z)) > 1e-8:
+            print('x and z must be orthogonal, got xz={0:.4e}'.format(np.dot(self.x, self.z)))
+        self.y = np.cross(self.z, self.x)
+
+    def local_to_global_sph(self, phi, theta, **kwargs):
+        """Angles on the sphere -> (x, y, z local, x, y, z global)."""
+        lat, az = theta + self.thetaOffset, phi + self.phiOffset
+        local = (np.cos(lat) * np.cos(az) * self.R, np.cos(lat) * np.sin(az) * self.R,
+                 np.sin(lat) * self.R)
+        return local + tuple(self.local_to_global(*local, **kwargs))
+
+    def expose(self, beam=None, onlyPositivePath=False):
+        _lib.require_gpu()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        image = rs.Beam.empty_like_on_device(beam, dev)
+        angles = [torch.empty(len(beam.x), dtype=torch.float64, device=dev) for _ in range(2)]
+        rec = self._record(onlyPositivePath)
+        rec.radius, rec.theta_offset, rec.phi_offset = \
+            float(self.R), float(self.thetaOffset), float(self.phiOffset)
+        rec.out_theta, rec.out_phi = angles[0].data_ptr(), angles[1].data_ptr()
+        _lib.check(_lib.load().xrt_hip_screen_expose_f64_dev(
+            ctypes.byref(rec), ctypes.byref(beam.to_struct(dev)),
+            ctypes.byref(image.to_struct(dev)),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            'xrt_hip_screen_expose_f64_dev')
+        image._d['theta'], image._d['phi'] = angles
+        rs.inherit_scalars(image, beam)
+        return image
+
+    def expose_global(self, beam=None):
+        """The image with its positions back in the global frame."""
+        glo = self.expose(beam)
+        x, y, z = self.local_to_global_sph(glo.phi, glo.theta)[3:]
+        glo.x, glo.y, glo.z = x, y, z
+        return glo
+
+    def prepare_wave(self, *args, **kwargs):
+        raise NotImplementedError('HemisphericScreen.prepare_wave')

@@ -20,7 +20,7 @@ defaultEnergy = 9.0e3
 
 _F64 = ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp')
 _C128 = ('Jsp', 'Es', 'Ep')
-_OPT_F64 = ('theta', 'order', 'xDiffr', 'yDiffr', 'zDiffr', 'rDiffr')
+_OPT_F64 = ('theta', 'phi', 'order', 'xDiffr', 'yDiffr', 'zDiffr', 'rDiffr')
 # accumulated Kirchhoff integrals of a receiving wave (waves.diffract)
 _OPT_C128 = ('EsAcc', 'EpAcc', 'aEacc', 'bEacc', 'cEacc')
 _SCALAR_ATTRS = ('sourceSIGMAx', 'sourceSIGMAz', 'filamentDX', 'filamentDZ',

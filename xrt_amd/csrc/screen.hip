@@ -21,6 +21,52 @@ __global__ __launch_bounds__(256) void screen_expose_kernel(xrt_hip_screen S, xr
   const double gy = in.y[i] - S.center[1];
   const double gz = in.z[i] - S.center[2];
   const double ga = in.a[i], gb = in.b[i], gc = in.c[i];
+  if (S.radius != 0.) {   // HemisphericScreen.expose, screens.py:526-555
+    const double half_b = (ga * gx + gb * gy) + gc * gz;
+    const double cq = ((gx * gx + gy * gy) + gz * gz) - S.radius * S.radius;
+    double path = -half_b + sqrt(half_b * half_b - cq);
+    int st = in.state[i];
+    bool bad = isnan(path) || isinf(path);
+    if (S.only_positive_path) bad = bad || (path < 0.);
+    if (bad) {
+      path = 0.;
+      st = S.lost_num;
+    }
+    const double E = in.E[i];
+    const double rx = in.x[i] + ga * path - S.center[0];
+    const double ry = in.y[i] + gb * path - S.center[1];
+    const double rz = in.z[i] + gc * path - S.center[2];
+    const double lx = (rx * S.ex[0] + ry * S.ex[1]) + rz * S.ex[2];
+    const double ly = (rx * S.ey[0] + ry * S.ey[1]) + rz * S.ey[2];
+    const double lz = (rx * S.ez[0] + ry * S.ez[1]) + rz * S.ez[2];
+    out.x[i] = lx;
+    out.y[i] = ly;
+    out.z[i] = lz;
+    out.a[i] = ga;
+    out.b[i] = gb;
+    out.c[i] = gc;
+    out.path[i] = in.path[i] + path;
+    out.E[i] = E;
+    out.Jss[i] = in.Jss[i];
+    out.Jpp[i] = in.Jpp[i];
+    reinterpret_cast<double2*>(out.Jsp_ri)[i] = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
+    out.state[i] = st;
+    if (S.out_theta) S.out_theta[i] = asin(lz / S.radius) - S.theta_offset;
+    if (S.out_phi) S.out_phi[i] = atan2(ly, lx) - S.phi_offset;
+    if (in.Es_ri) {
+      const double kCH = 6.626069573e-27 * 2.99792458e10 / 1.602176565e-12 * 1e8;
+      const double kCHBAR = kCH / 6.283185307179586476925286766559;
+      double s, co;
+      sincos_phase((1e7 * (E / kCHBAR)) * path, s, co);
+      const double2 es = reinterpret_cast<const double2*>(in.Es_ri)[i];
+      const double2 ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
+      reinterpret_cast<double2*>(out.Es_ri)[i] =
+          make_double2(es.x * co - es.y * s, es.x * s + es.y * co);
+      reinterpret_cast<double2*>(out.Ep_ri)[i] =
+          make_double2(ep.x * co - ep.y * s, ep.x * s + ep.y * co);
+    }
+    return;
+  }
   // sum(c*b for c, b in zip(basis, xyz)): ((0 + c0*x) + c1*y) + c2*z
   double x = (S.ex[0] * gx + S.ex[1] * gy) + S.ex[2] * gz;
   double y = (S.ey[0] * gx + S.ey[1] * gy) + S.ey[2] * gz;
