@@ -337,7 +337,7 @@ XRT_HIP_API size_t xrt_hip_reflect_workspace_bytes(int64_t n);
 
 /* sizeof() of the structs above, to let a binding verify its layout:
  * which = 0 beam, 1 rotation, 2 pass, 3 material, 4 screen, 5 aperture, 6 undulator,
- * 7 undulator_map, 8 plot, 9 custom_field, 10 bend, 11 multilayer. */
+ * 7 undulator_map, 8 plot, 9 custom_field, 10 bend, 11 multilayer, 12 gauss. */
 XRT_HIP_API int xrt_hip_sizeof(int which);
 
 /* in: incoming beam. out_local: "lb" of the reference (true local frame).
@@ -712,6 +712,25 @@ XRT_HIP_API int xrt_hip_bend_imap_f64_dev(const xrt_hip_bend* m, int64_t n, cons
                                           const double* theta, const double* psi,
                                           const double* gamma_ray, double* I, double* Es_ri,
                                           double* Ep_ri, void* stream);
+/* ---- GaussianBeam / LaguerreGaussianBeam / HermiteGaussianBeam.shine(wave=...)
+ * (sources/geoms.py:538-850): the analytical mode field on the points of a wave.
+ * x, y, z: the points in the source's frame (wave.xDiffr ...), E [eV] per point, dS: cell
+ * area per point (NULL: dS_scalar for all). amp_ri[2n]: field per point times sqrt(dS)
+ * (multiplies Es, Ep; |amp|^2 the coherency matrix); a, b, c: unit direction along the
+ * wavefront normal. */
+typedef struct xrt_hip_gauss {
+  double w0x, w0z;       /* waist; both used if astigmatic (w0 given as a pair) */
+  int32_t astigmatic;
+  int32_t mode;          /* 0 Gaussian, 1 Laguerre-Gauss (l, p), 2 Hermite-Gauss (m, n) */
+  int32_t l, p, m, n;
+  double clp;            /* mode normalisation: sqrt(p! / (|l| + p)!) or
+                            (2^(m+n) m! n!)^(-1/2) */
+} xrt_hip_gauss;
+XRT_HIP_API int xrt_hip_gaussian_beam_f64_dev(const xrt_hip_gauss* g, int64_t n, const double* x,
+                                              const double* y, const double* z,
+                                              const double* E, const double* dS,
+                                              double dS_scalar, double* amp_ri, double* a,
+                                              double* b, double* c, void* stream);
 /* building block (GPU tests): modified Bessel functions K_{1/3}, K_{2/3} */
 XRT_HIP_API int xrt_hip_debug_bessel_k_f64_dev(int64_t n, const double* x, double* k13,
                                                double* k23, void* stream);

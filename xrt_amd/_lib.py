@@ -79,6 +79,8 @@ SIGNATURES = {
     'xrt_hip_trajectory_f64_dev': (ctypes.c_int, [
         ctypes.c_int, i64, vp, vp, vp, vp, ctypes.c_double, ctypes.c_double,
         vp, vp, vp, vp, vp, vp, vp]),
+    'xrt_hip_gaussian_beam_f64_dev': (ctypes.c_int, [
+        vp, i64, vp, vp, vp, vp, vp, ctypes.c_double, vp, vp, vp, vp, vp]),
     'xrt_hip_bend_imap_f64_dev': (ctypes.c_int, [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_debug_bessel_k_f64_dev': (ctypes.c_int, [i64, vp, vp, vp, vp]),
     'xrt_hip_kirchhoff_report': (ctypes.c_int, [

@@ -230,5 +230,12 @@ class Bend(ctypes.Structure):
                 ('wiggler', ctypes.c_int32), ('per_bandwidth', ctypes.c_int32)]
 
 
+class Gauss(ctypes.Structure):
+    _fields_ = [('w0x', ctypes.c_double), ('w0z', ctypes.c_double),
+                ('astigmatic', ctypes.c_int32), ('mode', ctypes.c_int32),
+                ('l', ctypes.c_int32), ('p', ctypes.c_int32), ('m', ctypes.c_int32),
+                ('n', ctypes.c_int32), ('clp', ctypes.c_double)]
+
+
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
-           UndulatorMap, Plot, CustomField, Bend, Multilayer)
+           UndulatorMap, Plot, CustomField, Bend, Multilayer, Gauss)

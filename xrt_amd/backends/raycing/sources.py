@@ -624,3 +624,4 @@ class NESWSource(MeshSource):
 from .undulator import Undulator  # noqa: E402,F401  (needs Beam from this module)
 from .fieldsource import SourceFromField  # noqa: E402,F401
 from .bendsource import BendingMagnet, Wiggler  # noqa: E402,F401
+from .gaussbeam import GaussianBeam, LaguerreGaussianBeam, HermiteGaussianBeam  # noqa: E402,F401

@@ -251,6 +251,7 @@ int xrt_hip_sizeof(int which) {
     case 9: return (int)sizeof(xrt_hip_custom_field);
     case 10: return (int)sizeof(xrt_hip_bend);
     case 11: return (int)sizeof(xrt_hip_multilayer);
+    case 12: return (int)sizeof(xrt_hip_gauss);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -900,6 +901,24 @@ int xrt_hip_bend_imap_f64_dev(const xrt_hip_bend* m, int64_t n, const double* E,
   if (m->wiggler && !(m->K != 0.)) return fail(XRT_HIP_ERR_ARG, "a wiggler needs K");
   HIP_TRY(xrt::bend_imap_launch(*m, n, E, theta, psi, gamma_ray, I, Es_ri, Ep_ri,
                                 reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_gaussian_beam_f64_dev(const xrt_hip_gauss* g, int64_t n, const double* x,
+                                  const double* y, const double* z, const double* E,
+                                  const double* dS, double dS_scalar, double* amp_ri, double* a,
+                                  double* b, double* c, void* stream) {
+  if (!g) return fail(XRT_HIP_ERR_ARG, "NULL beam description");
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (n > 0 && (!x || !y || !z || !E || !amp_ri || !a || !b || !c))
+    return fail(XRT_HIP_ERR_ARG, "NULL array");
+  if (!(g->w0x > 0.) || (g->astigmatic && !(g->w0z > 0.)))
+    return fail(XRT_HIP_ERR_ARG, "waist size must be positive");
+  if (g->mode < 0 || g->mode > 2 || (g->mode == 1 && (g->p < 0 || g->astigmatic)) ||
+      (g->mode == 2 && (g->m < 0 || g->n < 0)))
+    return fail(XRT_HIP_ERR_ARG, "bad mode indices");
+  HIP_TRY(xrt::gauss_beam_launch(*g, n, x, y, z, E, dS, dS_scalar, amp_ri, a, b, c,
+                                 reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
 }
 

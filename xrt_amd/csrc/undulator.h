@@ -30,6 +30,10 @@ hipError_t trajectory_launch(int filament, int64_t n, const double* wt, const do
 hipError_t bend_imap_launch(const xrt_hip_bend& m, int64_t n, const double* E,
                             const double* theta, const double* psi, const double* gamma,
                             double* I, double* Es_ri, double* Ep_ri, hipStream_t st);
+hipError_t gauss_beam_launch(const xrt_hip_gauss& G, int64_t n, const double* x,
+                             const double* y, const double* z, const double* E,
+                             const double* dS, double dS_scalar, double* amp_ri, double* a,
+                             double* b, double* c, hipStream_t st);
 hipError_t bessel_k_probe_launch(int64_t n, const double* x, double* k13, double* k23,
                                  hipStream_t st);
 }

@@ -746,6 +746,129 @@ hipError_t bend_imap_launch(const xrt_hip_bend& m, int64_t n, const double* E,
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// GaussianBeam / LaguerreGaussianBeam / HermiteGaussianBeam.shine on the points of a wave
+// (sources/geoms.py:684-810): the analytical mode field per point, times sqrt(dS), and the
+// ray direction along the local wavefront normal. The carrier phase k y is ~1e11 rad: its
+// terms are rounded in numpy's order.
+// ---------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ double hermite_phys(int n, double x) {   // H_n, physicists'
+  double h0 = 1., h1 = 2. * x;
+  if (n == 0) return h0;
+  for (int k = 1; k < n; ++k) {
+    const double h2 = 2. * x * h1 - 2. * k * h0;
+    h0 = h1;
+    h1 = h2;
+  }
+  return h1;
+}
+__device__ __forceinline__ double laguerre_gen(int p, double alpha, double x) {   // L_p^alpha
+  double l0 = 1., l1 = 1. + alpha - x;
+  if (p == 0) return l0;
+  for (int k = 1; k < p; ++k) {
+    const double l2 = ((2. * k + 1. + alpha - x) * l1 - (k + alpha) * l0) / (k + 1.);
+    l0 = l1;
+    l1 = l2;
+  }
+  return l1;
+}
+__device__ __forceinline__ double ipow(double b, int e) {
+  double r = 1.;
+  for (int k = 0; k < e; ++k) r *= b;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void gauss_beam_kernel(
+    xrt_hip_gauss G, int64_t n, const double* __restrict__ xs, const double* __restrict__ ys,
+    const double* __restrict__ zs, const double* __restrict__ Es,
+    const double* __restrict__ dS, double dS_scalar, double2* __restrict__ amp_out,
+    double* __restrict__ oa, double* __restrict__ ob, double* __restrict__ oc) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double kCH = 6.626069573e-27 * 2.99792458e10 / 1.602176565e-12 * 1e8;
+  const double kCHBAR = kCH / 6.283185307179586476925286766559;
+  const double c0 = sqrt(2. / 3.141592653589793);
+  const double x = xs[i], y = ys[i], z = zs[i];
+  const double k = Es[i] / kCHBAR * 1e7;
+  const int gouy = G.mode == 1 ? abs(G.l) + 2 * G.p : G.mode == 2 ? G.m + G.n : 0;
+  double re, im;        // the field
+  double invR, wx, wz, rsq;
+  if (G.astigmatic) {
+    double s, c;
+    sincos_phase(k * y, s, c);
+    re = c0 * c;
+    im = c0 * s;
+    for (int ax = 0; ax < 2; ++ax) {
+      const double w0 = ax == 0 ? G.w0x : G.w0z;
+      const double yR = k / 2. * (w0 * w0);
+      invR = y / (y * y + yR * yR);
+      const double psi = (gouy + 1) * atan2(y, yR) * 0.5;
+      const double q = y / yR;
+      const double w = w0 * sqrt(1. + q * q);
+      rsq = ax == 0 ? x * x : z * z;
+      if (ax == 0) wx = w; else wz = w;
+      const double mag = exp(-rsq / (w * w)) / sqrt(w);
+      sincos(((0.5 * k) * rsq) * invR - psi, &s, &c);
+      const double r2 = (re * c - im * s) * mag, i2 = (re * s + im * c) * mag;
+      re = r2;
+      im = i2;
+    }
+  } else {
+    const double w0 = G.w0x;
+    const double yR = k / 2. * (w0 * w0);
+    invR = y / (y * y + yR * yR);
+    const double psi = (gouy + 1) * atan2(y, yR);
+    const double q = y / yR;
+    const double w = w0 * sqrt(1. + q * q);
+    wx = wz = w;
+    rsq = x * x + z * z;
+    const double theta = k * (y + (0.5 * rsq) * invR) - psi;
+    double s, c;
+    sincos_phase(theta, s, c);
+    const double mag = c0 / w * exp(-rsq / (w * w));
+    re = mag * c;
+    im = mag * s;
+  }
+  if (G.mode == 1) {          // Laguerre-Gauss, :758-765
+    const int al = abs(G.l);
+    double f = G.clp * ipow(sqrt(rsq * 2.) / wx, al);
+    if (G.p > 0) f *= laguerre_gen(G.p, (double)al, 2. * rsq / (wx * wx));
+    double s, c;
+    sincos((double)G.l * atan2(z, x), &s, &c);
+    const double r2 = (re * c - im * s) * f, i2 = (re * s + im * c) * f;
+    re = r2;
+    im = i2;
+  } else if (G.mode == 2) {   // Hermite-Gauss, :766-775
+    double f = G.clp;
+    const double r2 = sqrt(2.);
+    if (G.m > 0) f *= hermite_phys(G.m, r2 * x / wx);
+    if (G.n > 0) f *= hermite_phys(G.n, r2 * z / wz);
+    re *= f;
+    im *= f;
+  }
+  const double area = sqrt(dS ? dS[i] : dS_scalar);
+  amp_out[i] = make_double2(re * area, im * area);
+  // direction: along the radius of curvature (the last axis's, as the reference), :785-795
+  double b = invR == 0. ? 1e20 : 1. / invR;
+  b = sqrt(b * b - x * x - z * z);
+  const double norm = sqrt(x * x + b * b + z * z);
+  oa[i] = x / norm;
+  ob[i] = b / norm;
+  oc[i] = z / norm;
+}
+}  // namespace
+
+hipError_t gauss_beam_launch(const xrt_hip_gauss& G, int64_t n, const double* x,
+                             const double* y, const double* z, const double* E,
+                             const double* dS, double dS_scalar, double* amp_ri, double* a,
+                             double* b, double* c, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gauss_beam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, G,
+                     n, x, y, z, E, dS, dS_scalar, reinterpret_cast<double2*>(amp_ri), a, b, c);
+  return hipGetLastError();
+}
+
 hipError_t bessel_k_probe_launch(int64_t n, const double* x, double* k13, double* k23,
                                  hipStream_t st) {
   if (n <= 0) return hipSuccess;
