@@ -768,12 +768,27 @@ def points_in_polygon(vertices, x, y):
     inside = np.zeros(x.shape, dtype=bool)
     if len(v) < 3:
         return inside
-    for k in range(len(v)):
-        x0, y0 = v[k]
-        x1, y1 = v[(k + 1) % len(v)]
-        above0, above1 = y0 >= y, y1 >= y
-        crosses = ((y1 - y) * (x0 - x1) >= (x1 - x) * (y0 - y1)) == above1
-        inside ^= (above0 != above1) & crosses
+    # non-finite vertices split the outline into sub-polygons (matplotlib's PathNanRemover:
+    # the vertex after a gap is a MOVETO), each closed on itself; a point is inside if it
+    # is inside any of them (point_in_path_impl: inside_flag |= subpath_flag) -- GridAperture
+    finite = np.isfinite(v).all(axis=1)
+    k = 0
+    while k < len(v):
+        if not finite[k]:
+            k += 1
+            continue
+        start = k
+        while k < len(v) and finite[k]:
+            k += 1
+        sub = v[start:k]
+        part = np.zeros(x.shape, dtype=bool)
+        for j in range(len(sub)):
+            x0, y0 = sub[j]
+            x1, y1 = sub[(j + 1) % len(sub)]
+            above0, above1 = y0 >= y, y1 >= y
+            crosses = ((y1 - y) * (x0 - x1) >= (x1 - x) * (y0 - y1)) == above1
+            part ^= (above0 != above1) & crosses
+        inside |= part
     return inside & np.isfinite(x) & np.isfinite(y)
 
 

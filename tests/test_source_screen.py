@@ -327,3 +327,59 @@ def test_hemispheric_screen_matches_reference(golden_dir):
         ok = np.isfinite(g[tag + '_global_xyz'][0])
         for mine, ref in zip((glo.x, glo.y, glo.z), g[tag + '_global_xyz']):
             assert np.abs(mine[ok] - ref[ok]).max() < 1e-11, tag
+
+
+# ---- GridAperture / GridBeamStop / SiemensStar (apertures.py:1324-1528) ------------
+def test_oracle_grid_and_star_match_reference(golden_dir):
+    from oracle import elements_np as en
+    from oracle.gen_fixtures_grid import CASES
+    g0 = np.load(os.path.join(golden_dir, 'g7_stops_round.npz'))
+    g = np.load(os.path.join(golden_dir, 'g7_grid_star.npz'))
+    az = float(g0['azimuth'])
+    basis = ([np.cos(az), -np.sin(az), 0.], [np.sin(az), np.cos(az), 0.], [0., 0., 1.])
+    for tag, cls, _ in CASES:
+        b = _oracle_beam(g0, 'in_')
+        lo = en.aperture_propagate(b, basis, g[tag + '_center'], {}, int(g[tag + '_lostNum']),
+                                   (np.sin(az), np.cos(az)), isBeamStop=cls.endswith('Stop'),
+                                   vertices=g[tag + '_vertices'])
+        assert np.array_equal(b.state, g[tag + '_in_state_after'])
+        assert np.array_equal(lo.state, g[tag + '_lo_state'])
+
+
+def test_grid_and_star_outlines_are_the_references(golden_dir):
+    """The host classes build the outline the reference builds, bit for bit (the ray states
+    depend on it); changing a grid parameter lays the cells out again."""
+    import xrt_amd.backends.raycing.apertures as ra
+    from oracle.gen_fixtures_grid import CASES
+    g = np.load(os.path.join(golden_dir, 'g7_grid_star.npz'))
+    for tag, cls, kw in CASES:
+        ap = getattr(ra, cls)(None, tag, **kw)
+        assert np.array_equal(np.array(ap.vertices, dtype=float), g[tag + '_vertices'],
+                              equal_nan=True), tag
+        assert ap.isBeamStop == cls.endswith('Stop')
+    grid = ra.GridAperture(None, 'g', dx=0.1, dz=0.08, px=0.25, pz=0.2, nx=2, nz=1)
+    assert len(grid.get_render_cells()) == 15 and grid.nx == 2
+    assert np.allclose(grid.limOptX, [-0.55, 0.55]) and np.allclose(grid.limOptY, [-0.24, 0.24])
+    grid.nx = 1
+    assert len(grid.get_render_cells()) == 9 and np.allclose(grid.limOptX, [-0.3, 0.3])
+
+
+@pytest.mark.gpu
+def test_grid_and_star_apertures_match_reference(golden_dir):
+    import xrt_amd.backends.raycing.apertures as ra
+    from oracle.gen_fixtures_grid import CASES
+    g0 = np.load(os.path.join(golden_dir, 'g7_stops_round.npz'))
+    g = np.load(os.path.join(golden_dir, 'g7_grid_star.npz'))
+    for tag, cls, kw in CASES:
+        bl = raycing.BeamLine(azimuth=float(g0['azimuth']))
+        ap = getattr(ra, cls)(bl, tag, center=[float(v) for v in g[tag + '_center']], **kw)
+        assert ap.lostNum == int(g[tag + '_lostNum'])
+        b = rs.Beam(nrays=len(g0['in_x']), withAmplitudes=True)
+        for f in FIELDS + ('state', 'Es', 'Ep'):
+            setattr(b, f, g0['in_' + f])
+        lo = ap.propagate(b)
+        assert np.array_equal(b.state, g[tag + '_in_state_after']), tag
+        assert np.array_equal(lo.state, g[tag + '_lo_state']), tag
+        for f in ('x', 'z', 'path'):
+            r = g['%s_lo_%s' % (tag, f)]
+            assert np.abs(getattr(lo, f) - r).max() <= 1e-13 * np.abs(r).max(), (tag, f)

@@ -195,12 +195,94 @@ class PolygonalAperture(RectangularAperture):
                                      alarmLevel=alarmLevel, **kwargs)
         self.vertices = [tuple(v) for v in (opening if opening is not None else vertices)]
         self.shape = 'polygon'
-        corners = np.array(self.vertices, dtype=float)
-        self.limOptX = [corners[:, 0].min(), corners[:, 0].max()]
-        self.limOptY = [corners[:, 1].min(), corners[:, 1].max()]
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name == 'vertices':       # (NaN rows separate the cells of a grid)
+            corners = np.array(value, dtype=float)
+            self.limOptX = [np.nanmin(corners[:, 0]), np.nanmax(corners[:, 0])]
+            self.limOptY = [np.nanmin(corners[:, 1]), np.nanmax(corners[:, 1])]
 
     def prepare_wave(self, prevOE, nrays, rw=None):
         raise NotImplementedError('wave samples on a polygonal aperture')
 
 
 PolygonalBeamStop = _stop_of(PolygonalAperture, "PolygonalBeamStop", """The polygon is the solid part.""")
+
+
+class GridAperture(PolygonalAperture):
+    """A regular grid of rectangular openings *dx* x *dz* at the pitches *px*, *pz*:
+    (2 nx + 1) x (2 nz + 1) of them about the centre (reference apertures.py:1324-1447).
+    One outline: the closed rectangles, separated by NaN rows."""
+    _SHAPE = ('dx', 'dz', 'px', 'pz', 'nx', 'nz')
+
+    def __init__(self, bl=None, name='', center=[0, 0, 0], x='auto', z='auto', alarmLevel=None,
+                 dx=0.5, dz=0.5, px=1.0, pz=1.0, nx=7, nz=7, **kwargs):
+        object.__setattr__(self, '_grid', dict(dx=dx, dz=dz, px=px, pz=pz, nx=int(nx),
+                                               nz=int(nz)))
+        PolygonalAperture.__init__(self, bl=bl, name=name, center=center, x=x, z=z,
+                                   alarmLevel=alarmLevel, vertices=self._cells(), **kwargs)
+
+    def _cells(self):
+        q = self._grid
+        # one cell, walked from its (+, +) corner and closed, then the separator
+        walk_x = np.array([q['dx'], -q['dx'], -q['dx'], q['dx'], q['dx'], np.nan]) * 0.5
+        walk_z = np.array([q['dz'], q['dz'], -q['dz'], -q['dz'], q['dz'], np.nan]) * 0.5
+        at_x = np.linspace(-1, 1, 2*q['nx'] + 1) * q['px'] * q['nx']
+        at_z = np.linspace(-1, 1, 2*q['nz'] + 1) * q['pz'] * q['nz']
+        grid_x, grid_z = np.meshgrid(at_x, at_z)
+        xs = (grid_x.ravel(order='F') + walk_x[:, np.newaxis]).ravel(order='F')
+        zs = (grid_z.ravel(order='F') + walk_z[:, np.newaxis]).ravel(order='F')
+        return [tuple(v) for v in np.column_stack((xs, zs))]
+
+    def __getattr__(self, name):
+        grid = self.__dict__.get('_grid')
+        if grid is not None and name in grid:
+            return grid[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in self._SHAPE:
+            self._grid[name] = int(value) if name in ('nx', 'nz') else value
+            self.vertices = self._cells()
+        else:
+            PolygonalAperture.__setattr__(self, name, value)
+
+    def get_render_cells(self):
+        """(xmin, xmax, zmin, zmax) of every opening."""
+        rows = np.array(self.vertices, dtype=float).reshape(-1, 6, 2)[:, :4]
+        return [(c[:, 0].min(), c[:, 0].max(), c[:, 1].min(), c[:, 1].max()) for c in rows]
+
+
+GridBeamStop = _stop_of(GridAperture, "GridBeamStop", """The cells of the grid are the solid parts.""")
+
+
+class SiemensStar(PolygonalAperture):
+    """Star of *nSpokes* open sectors of radius *r* (or semi-axes *rx*, *rz*), turned by
+    *phi0*; *vortex* bends the spokes (by *vortex* spoke positions at the rim, drawn in
+    *vortexNradial* segments) (reference apertures.py:1462-1528). One closed outline
+    through the centre."""
+
+    def __init__(self, bl=None, name='', center=[0, 0, 0], x='auto', z='auto', alarmLevel=None,
+                 nSpokes=9, r=1, rx=0, rz=0, phi0=0, vortex=0, vortexNradial=7, **kwargs):
+        self.nSpokes, self.phi0 = nSpokes, phi0
+        self.rx, self.rz = (r, r) if r else (rx, rz)
+        edges = np.linspace(0, 2*np.pi, nSpokes*2, endpoint=False) - np.pi/nSpokes/2 - phi0
+        if vortex:
+            # every spoke: up its first edge ring by ring, down its second edge
+            cols_x, cols_z = [], []
+            for ring in reversed(range(vortexNradial)):
+                part = (ring + 1.) / vortexNradial
+                twist = 2*np.pi * vortex / nSpokes * part
+                px = (part * self.rx * np.sin(edges + twist)).reshape((nSpokes, 2))
+                pz = (part * self.rz * np.cos(edges + twist)).reshape((nSpokes, 2))
+                cols_x = [px[:, 0:1]] + cols_x + [px[:, 1:2]]
+                cols_z = [pz[:, 0:1]] + cols_z + [pz[:, 1:2]]
+        else:
+            cols_x = [(self.rx * np.sin(edges)).reshape((nSpokes, 2))]
+            cols_z = [(self.rz * np.cos(edges)).reshape((nSpokes, 2))]
+        hub = np.zeros((nSpokes, 1))
+        outline = zip(np.hstack(cols_x + [hub]).flatten(), np.hstack(cols_z + [hub]).flatten())
+        PolygonalAperture.__init__(self, bl=bl, name=name, center=center, x=x, z=z,
+                                   alarmLevel=alarmLevel, vertices=list(outline), **kwargs)
+

@@ -130,16 +130,31 @@ hipError_t screen_expose_launch(const xrt_hip_screen& S, const xrt_hip_beam& in,
 // horizontal through the point toggles `inside` when the crossing is to its right.
 __device__ __forceinline__ bool inside_polygon(const double* v, int n, double x, double y) {
   if (n < 3 || !(isfinite(x) && isfinite(y))) return false;
-  bool inside = false;
-  double x0 = v[2 * (n - 1)], y0 = v[2 * (n - 1) + 1];
-  for (int k = 0; k < n; ++k) {
-    const double x1 = v[2 * k], y1 = v[2 * k + 1];
-    const bool up0 = y0 >= y, up1 = y1 >= y;
-    if (up0 != up1 && (((y1 - y) * (x0 - x1) >= (x1 - x) * (y0 - y1)) == up1)) inside = !inside;
-    x0 = x1;
-    y0 = y1;
+  // non-finite vertices split the outline into sub-polygons, each closed on itself; inside
+  // any of them = inside (matplotlib: PathNanRemover + inside_flag |= subpath_flag) -- the
+  // cells of a GridAperture
+  bool any = false;
+  int k = 0;
+  while (k < n) {
+    if (!(isfinite(v[2 * k]) && isfinite(v[2 * k + 1]))) {
+      ++k;
+      continue;
+    }
+    const int start = k;
+    while (k < n && isfinite(v[2 * k]) && isfinite(v[2 * k + 1])) ++k;
+    bool inside = false;
+    double x0 = v[2 * (k - 1)], y0 = v[2 * (k - 1) + 1];
+    for (int j = start; j < k; ++j) {
+      const double x1 = v[2 * j], y1 = v[2 * j + 1];
+      const bool up0 = y0 >= y, up1 = y1 >= y;
+      if (up0 != up1 && (((y1 - y) * (x0 - x1) >= (x1 - x) * (y0 - y1)) == up1))
+        inside = !inside;
+      x0 = x1;
+      y0 = y1;
+    }
+    any = any || inside;
   }
-  return inside;
+  return any;
 }
 
 // RectangularAperture.propagate, apertures.py:334-413. Same streaming shape as
