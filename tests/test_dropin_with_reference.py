@@ -227,3 +227,33 @@ def test_reference_source_from_field_runs_through_the_dropin():
     assert type(fake).calls == 1 and type(fake).trajectories == 1
     for a, b in zip(got, ref):
         assert np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b)
+
+
+def test_host_only_classes_agree_with_the_reference():
+    """Classes that are pure host arithmetic, run side by side with the reference's:
+    SetOfRectangularAperturesOnZActuator (blades, actuator position and limits after
+    select_aperture), CollimatedMeshSource (the rays, bit for bit)."""
+    _refenv.activate()
+    import xrt.backends.raycing as rr
+    import xrt.backends.raycing.apertures as rar
+    import xrt.backends.raycing.sources as rsr
+    import xrt_amd.backends.raycing as mr
+    import xrt_amd.backends.raycing.apertures as mar
+    import xrt_amd.backends.raycing.sources as msr
+    args = dict(apertures=['big', 'small', 'top-edge'], centerZs=[5., -4., 12.],
+                dXs=[2., 0.5], dZs=[1., 0.2])
+    for name, target in (('big', 1401.), ('small', 1399.5), ('top-edge', 1400.)):
+        seen = []
+        for R, A in ((rr, rar), (mr, mar)):
+            bl = R.BeamLine(height=1400.)
+            s = A.SetOfRectangularAperturesOnZActuator(bl, 'set', [0, 1000., 1400.], **args)
+            s.select_aperture(name, target)
+            seen.append((dict(s.blades), s.zActuator, s.zlims, s.limOptX, s.limOptY,
+                         s.curAperture, s.lostNum))
+        assert seen[0] == seen[1], name
+    kw = dict(center=(1, 2, 3), dx=2., dz=1., nx=5, nz=4, totalFlux=1e10, polarization='v')
+    b0 = rsr.CollimatedMeshSource(rr.BeamLine(azimuth=0.1), 'c', **kw).shine()
+    b1 = msr.CollimatedMeshSource(mr.BeamLine(azimuth=0.1), 'c', **kw).shine()
+    for f in ('x', 'y', 'z', 'a', 'b', 'c', 'E', 'Jss', 'Jpp', 'Jsp', 'state'):
+        assert np.array_equal(getattr(b0, f), getattr(b1, f)), f
+    assert b0.sourceWeight == b1.sourceWeight and len(b1.x) == 21

@@ -249,3 +249,29 @@ def test_multilayer_thickness_profiles_and_angles():
     assert c.cThickness == 250. and c.dbi[0] == 250. and c.dti[0] == 0.
     c.cThickness = 300.
     assert c.dbi[0] == 300. and c.surfaceRoughness == 3.
+
+
+def test_z_actuator_aperture_set_and_collimated_mesh():
+    """SetOfRectangularAperturesOnZActuator.select_aperture (apertures.py:600-665) and
+    CollimatedMeshSource.shine (sources/geoms.py:1111-1245) -- host arithmetic, values
+    worked out by hand; run against the reference itself in
+    tests/test_dropin_with_reference.py."""
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.apertures as ra
+    import xrt_amd.backends.raycing.sources as rs
+    bl = raycing.BeamLine(height=1400.)
+    s = ra.SetOfRectangularAperturesOnZActuator(
+        bl, 'set', [0, 1000., 1400.], ['big', 'small', 'top-edge'], [5., -4., 12.],
+        [2., 0.5], [1., 0.2])
+    s.select_aperture('small', 1399.5)
+    assert s.blades == {'left': -0.25, 'right': 0.25, 'bottom': -0.6, 'top': -0.4}
+    assert s.zActuator == 1400. + 1399.5 + 4. and s.curAperture == 1
+    s.select_aperture('top-edge', 1400.)
+    assert s.blades == {'bottom': 12. - 1400.} and s.zActuator == 1400.
+    src = rs.CollimatedMeshSource(raycing.BeamLine(), 'c', dx=2., dz=1., nx=3, nz=2,
+                                  withCentralRay=False)
+    b = src.shine()
+    assert src.nrays == 6
+    assert np.array_equal(b.x, [-1., 0., 1., -1., 0., 1.])
+    assert np.array_equal(b.z, [0.5, 0.5, 0.5, -0.5, -0.5, -0.5])
+    assert not b.a.any() and not b.c.any() and np.array_equal(b.b, np.ones(6))

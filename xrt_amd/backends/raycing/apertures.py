@@ -132,6 +132,55 @@ class RectangularAperture(object):
                                  opened, self.uuid)
 
 
+class SetOfRectangularAperturesOnZActuator(RectangularAperture):
+    """Several openings in one plate that a vertical actuator moves into the beam
+    (reference apertures.py:555-665): *apertures* = their names, the last of which is the
+    plate's edge ('bottom-edge' or 'top-edge'); *centerZs* = heights of their centres (of
+    the edge) relative to center[2]; *dXs*, *dZs* = sizes of the openings.
+    ``select_aperture(name, targetZ)`` puts that opening at the height *targetZ*."""
+
+    def __init__(self, bl, name, center, apertures, centerZs, dXs, dZs, x='auto', z='auto',
+                 alarmLevel=None):
+        RectangularAperture.__init__(self, bl, name, center, blades={}, x=x, z=z,
+                                     alarmLevel=alarmLevel)
+        self.zActuator = self.z0 = center[2]
+        self.apertures, self.centerZs, self.dXs, self.dZs = apertures, centerZs, dXs, dZs
+        self.surface, self.zlims = apertures, None
+        half = [w * 0.5 for w in dXs]
+        self.limOptX = [[-h for h in half] + [-500], half + [500]]
+        self.limOptY = [0, 0]
+        self.shape, self.spotLimits = 'rect', [0, 0, 0, 0]
+
+    def select_aperture(self, apertureName, targetZ):
+        which = self.apertures.index(apertureName)
+        self.curAperture = which
+        level = self.bl.height
+        if which < len(self.apertures) - 1:
+            hx, hz = self.dXs[which] * 0.5, self.dZs[which] * 0.5
+            mid = targetZ - level
+            self.blades = {'left': -hx, 'right': hx, 'bottom': mid-hz, 'top': mid+hz}
+            self.zActuator = self.z0 + targetZ - self.centerZs[which]
+        else:
+            edge = self.apertures[-1]
+            if edge not in ('top-edge', 'bottom-edge'):
+                raise ValueError('not "top-edge" nor "bottom-edge"!')
+            self.blades = {'bottom' if edge == 'top-edge' else 'top':
+                           self.centerZs[-1] - level}
+            self.zActuator = self.z0
+        reach = max(self.dZs) * 0.5
+        moved = self.zActuator - self.z0
+        self.zlims = [min(min(self.centerZs) + moved, targetZ) - level - reach,
+                      max(max(self.centerZs) + moved, targetZ) - level + reach]
+        self.set_optical_limits()
+
+    def set_optical_limits(self):
+        """Outlines of all openings at the present actuator position (for footprints)."""
+        shift = -self.bl.height + self.zActuator - self.z0
+        pairs = list(zip(self.centerZs, self.dZs))
+        self.limOptY[0] = [cz + shift - dz*0.5 for cz, dz in pairs] + [self.centerZs[-1] + shift]
+        self.limOptY[1] = [cz + shift + dz*0.5 for cz, dz in pairs] + [200]
+
+
 RectangularBeamStop = _stop_of(RectangularAperture, "RectangularBeamStop", """The blades enclose the solid part: rays inside are stopped, rays outside pass.""")
 
 

@@ -605,6 +605,45 @@ class MeshSource(object):
         return bo
 
 
+class CollimatedMeshSource(MeshSource):
+    """Parallel rays from a regular *nx* by *nz* mesh of points over *dx* x *dz* (rows from
+    the top), optionally preceded by the central ray (reference sources/geoms.py:1111-1245)."""
+
+    def __init__(self, bl=None, name='', center=(0, 0, 0), dx=1., dz=1., nx=11, nz=11,
+                 distE='lines', energies=(defaultEnergy,), energyWeights=None,
+                 polarization='horizontal', withCentralRay=True, autoAppendToBL=False,
+                 totalFlux=None, **kwargs):
+        MeshSource.__init__(self, bl, name or 'CollimatedMeshSource', center, nx=nx, nz=nz,
+                            distE=distE, energies=energies, energyWeights=energyWeights,
+                            polarization=polarization, withCentralRay=withCentralRay,
+                            autoAppendToBL=autoAppendToBL, totalFlux=totalFlux, **kwargs)
+        self.dx, self.dz = dx, dz
+        for angular in ('minxprime', 'maxxprime', 'minzprime', 'maxzprime'):
+            del self.__dict__[angular]
+
+    def shine(self, toGlobal=True):
+        bo = Beam(self.nrays)
+        bo.state[:] = 1
+        across, up = np.meshgrid(np.linspace(-self.dx/2., self.dx/2., self.nx),
+                                 np.linspace(-self.dz/2., self.dz/2., self.nz))
+        first = int(self.withCentralRay)
+        bo.x[first:] = across.flatten()
+        bo.z[first:] = np.flipud(up).flatten()
+        if self.distE is not None:
+            bo.E[:] = make_energy(self.distE, self.energies, self.nrays,
+                                  energyWeights=self.energyWeights)
+        make_polarization(self.polarization, bo, self.nrays)
+        if np.isscalar(self.totalFlux) and self.totalFlux > 0:
+            total = (bo.Jss + bo.Jpp).sum()
+            if total > 0:
+                bo.sourceWeight = self.totalFlux / total
+                bo.seeded, bo.seededI, bo.accepted, bo.acceptedE = len(bo.E), 1., 1., 1.
+        if toGlobal:
+            raycing.virgin_local_to_global(self.bl, bo, self.center)
+        bo.parentId = self.uuid
+        return bo
+
+
 class NESWSource(MeshSource):
     """The four extreme rays of the fan: up, right, down, left, from 50 um above the
     centre (sources/geoms.py:1071-1108)."""
