@@ -311,6 +311,11 @@ typedef struct xrt_hip_material {
   double cell_f0[XRT_HIP_MAX_ELEM];
   double cell_s[XRT_HIP_MAX_ELEM][2];
   double cell_sm[XRT_HIP_MAX_ELEM][2];
+  /* Material(refractiveIndex = a number) (material.py:240-262, 364-373): n_fixed != 0 -> the
+   * refractive index is n_re + i n_im at every energy and the element tables are not
+   * consulted (nelem may be 0). */
+  int32_t n_fixed;
+  double n_re, n_im;
 } xrt_hip_material;
 
 /* Multilayer / GradedMultilayer / Coated (materials/multilayer.py): npairs periods of a

@@ -115,6 +115,11 @@ def load_case(name):
                   f1=np.array(g['Be_f1']), f2=np.array(g['Be_f2']))
         p['material'] = mn.make_material([be], None, 'plate', float(g['mat_rho']))
         p['material2'] = p['material']
+    elif name == 'g2_plate_glass':
+        from . import gen_fixtures_index as gi
+        p['surface'] = dict(kind='flat')
+        p['surface2'] = dict(kind='flat')
+        p['material'] = p['material2'] = gi.oracle_material('glass', 'plate')
     elif name.startswith('g2_fzp'):
         p['surface'] = dict(kind='flat')
         p['material'] = dict(kind='FZP')

@@ -63,6 +63,8 @@ def make_material(elements, quantities=None, kind='mirror', rho=0., t=None):
 
 
 def refractive_index(m, E):
+    if m.get('refractiveIndex') is not None:        # material.py:372-373: a constant
+        return m['refractiveIndex']
     xf = np.zeros_like(E) * 0j
     for elem, xi in zip(m['elements'], m['quantities']):
         xf += (elem['Z'] + interp_f1f2(elem, E)) * xi

@@ -160,6 +160,10 @@ def product_oe(name, g):
     elif name == 'g2_plate_be':
         m = rm.Material('Be', rho=float(g['mat_rho']), kind='plate')
         oe = roe.Plate(bl, 'win', material=m, t=float(g['plate_t']), **common)
+    elif name == 'g2_plate_glass':
+        from oracle.gen_fixtures_index import INDEX
+        m = rm.Material(kind='plate', refractiveIndex=INDEX['glass'])
+        oe = roe.Plate(bl, 'win', material=m, t=float(g['plate_t']), **common)
     elif name.startswith('g2_fzp'):
         m = rm.Material('Au', rho=19.3, kind='FZP')
         for key in ('limPhysX', 'limPhysY'):        # the zone plate sets its own outline

@@ -236,3 +236,24 @@ def test_cell_crystal_rocking_curves(golden_dir):
             assert np.abs(mine - ref).max() <= 1e-12 * np.abs(ref).max(), key
         count += 1
     assert count == 3 * 5 * 2
+
+
+def test_fixed_refractive_index(golden_dir):
+    """Material(refractiveIndex = a number) (material.py:240-262, 364-373): Fresnel
+    amplitudes at visible-light energies, and a glass plate traversed by rays."""
+    from oracle.gen_fixtures_index import INDEX, oracle_material
+    g = np.load(os.path.join(golden_dir, 'g5_fixed_index.npz'))
+    for name in INDEX:
+        for kind, t in (('mirror', None), ('thin mirror', 2e-4), ('plate', None)):
+            for fv in ((True, False) if kind == 'plate' else (True,)):
+                key = '%s_%s_%d' % (name, kind.replace(' ', ''), fv)
+                res = mn.material_amplitude(oracle_material(name, kind, t), g['E'].copy(),
+                                            g[key + '_bdn'].copy(), fv)
+                for i, lab in enumerate(('rs', 'rp', 'mu', 'nk')):
+                    assert np.allclose(res[i], g[key + '_' + lab], rtol=1e-13, atol=0), key
+    p, beam, g = fixture_io.load_case('g2_plate_glass')
+    gb2, lo1, lo2 = rn.dcm_double_reflect(p, beam, fromVacuum1=True, fromVacuum2=False,
+                                          is_plate=True)
+    check_beam(gb2, g, 'gb_')
+    check_beam(lo1, g, 'lo1_')
+    check_beam(lo2, g, 'lo2_')

@@ -112,6 +112,9 @@ class Material(ctypes.Structure):
         ('cell_f0', ctypes.c_double * MAX_ELEM),
         ('cell_s', ctypes.c_double * 2 * MAX_ELEM),
         ('cell_sm', ctypes.c_double * 2 * MAX_ELEM),
+        ('n_fixed', ctypes.c_int32),
+        ('n_re', ctypes.c_double),
+        ('n_im', ctypes.c_double),
     ]
 
 

@@ -106,7 +106,7 @@ class Material(object):
 
     def __init__(self, elements=None, quantities=None, kind='auto', rho=0, t=None,
                  table='Chantler total', efficiency=None, efficiencyFile=None, name='',
-                 **kwargs):
+                 refractiveIndex=None, **kwargs):
         if isinstance(elements, str):
             elements = elements,
         self.table = table
@@ -123,6 +123,11 @@ class Material(object):
         self.kind = kind
         self.rho = rho
         self.t = t
+        # a constant, energy-independent index (visible light, IR: outside the tables),
+        # material.py:240-262; tabulated n(E) is not on the GPU path
+        if refractiveIndex is not None and not isinstance(refractiveIndex, (int, float, complex)):
+            raise NotImplementedError('refractiveIndex as a table or a file')
+        self.refractiveIndex = None if refractiveIndex is None else complex(refractiveIndex)
         # gratings / zone plates: [order, efficiency] pairs used in place of the Fresnel
         # amplitudes (material.py:78-95, 391-413)
         if efficiencyFile is not None:
@@ -164,6 +169,10 @@ class Material(object):
         s.rho = float(self.rho)
         s.mass = float(self.mass)
         s.t = float(self.t) if self.t is not None else 0.
+        if self.refractiveIndex is not None:
+            s.n_fixed, s.n_re, s.n_im = 1, self.refractiveIndex.real, self.refractiveIndex.imag
+        elif not self.elements:
+            raise ValueError('a material needs elements or a refractiveIndex')
         if kind == 'thin mirror' and self.t is None:
             raise ValueError('thin mirror needs a thickness t')
         return s
@@ -198,6 +207,8 @@ class Material(object):
         """n(E) from (mu, Re(n) k) of the device function (material.py:348-378):
         n = nk*CHBAR/(E*1e8) + i*mu*CHBAR/(E*2e8); sign of Im(n) as tabulated
         (f2 > 0 -> Im(n) < 0)."""
+        if self.refractiveIndex is not None:
+            return self.refractiveIndex
         E = np.atleast_1d(np.asarray(E, dtype=np.float64))
         saved = self.kind
         try:

@@ -303,7 +303,7 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
   if (material->kind < XRT_HIP_MAT_NONE || material->kind > XRT_HIP_MAT_MULTILAYER)
     return fail(XRT_HIP_ERR_ARG, "unknown material kind %d", material->kind);
   if (material->kind != XRT_HIP_MAT_NONE && material->kind != XRT_HIP_MAT_MULTILAYER) {
-    if (material->nelem < 1 || material->nelem > XRT_HIP_MAX_ELEM)
+    if (material->nelem < (material->n_fixed ? 0 : 1) || material->nelem > XRT_HIP_MAX_ELEM)
       return fail(XRT_HIP_ERR_ARG, "material needs 1..%d elements", XRT_HIP_MAX_ELEM);
     for (int e = 0; e < material->nelem; ++e)
       if (!material->tab_E[e] || !material->tab_f1[e] || !material->tab_f2[e] ||
@@ -585,7 +585,7 @@ int xrt_hip_wave_receive_f64_dev(const xrt_hip_pass* receiver, int is_oe, xrt_hi
 
 static int check_material_tables(const xrt_hip_material* m) {
   if (!m) return fail(XRT_HIP_ERR_ARG, "NULL material");
-  if (m->nelem < 1 || m->nelem > XRT_HIP_MAX_ELEM)
+  if (m->nelem < (m->n_fixed ? 0 : 1) || m->nelem > XRT_HIP_MAX_ELEM)
     return fail(XRT_HIP_ERR_ARG, "material needs 1..%d elements", XRT_HIP_MAX_ELEM);
   for (int e = 0; e < m->nelem; ++e)
     if (!m->tab_E[e] || !m->tab_f1[e] || !m->tab_f2[e] || m->tab_n[e] < 2)

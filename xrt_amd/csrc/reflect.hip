@@ -1459,6 +1459,7 @@ __device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, do
 // material.py:348-378
 __device__ __forceinline__ cplx refractive_index(const xrt_hip_material& M, double E,
                                                  const TabWin& w) {
+  if (M.n_fixed) return C(M.n_re, M.n_im);
   cplx xf = C(0., 0.);
   for (int e = 0; e < M.nelem; ++e) {
     cplx f = interp_f1f2(M, e, E, w);
