@@ -157,6 +157,14 @@ typedef struct xrt_hip_rotation {
                                      [2] Rm, [3] Rs, [4] cos(alpha), [5] sin(alpha), [6] alpha
                                      given (!= 0), [7] RmBragg, [8] RsBragg. The pass's
                                      `asymmetric` flag says whether the two normals differ. */
+#define XRT_HIP_SURF_VFM 9         /* VFM, oes/__init__.py:417-478: sagittal cylinder r (levelled off
+                                     beyond the optical x limits), meridional parabola R with
+                                     fixed ends: surf_p = r, r^2, zMax (INFINITY: no optical
+                                     limits), limPhysY[0]^2, R, limOptX[0], limOptX[1] */
+#define XRT_HIP_SURF_DUALVFM 10    /* DualVFM, oes/__init__.py:480-587: two sagittal cylinders side
+                                     by side (x >= 0: r1 about x1, sunk by h1; x < 0: r2, x2, h2),
+                                     nowhere above z = 0: surf_p = r1 - h1, r1^2, x1, r2 - h2,
+                                     r2^2, x2, limPhysY[0]^2, R */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_SHAPE_POLYGON 2   /* optical surface outlined by a polygon in the local (x, y)

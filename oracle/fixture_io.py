@@ -183,6 +183,23 @@ def load_case(name):
         else:
             p['surface'] = dict(kind='flat', alpha=float(g['alpha']))
         p['material'] = gc.oracle_cell(gc.all_tables(), str(g['cell']))
+    elif name.startswith('g2_support_'):
+        from . import gen_fixtures_supports as gs
+        case = name[len('g2_support_'):]
+        cls, kw, stripes, select = gs.CASES[case]
+        y0 = kw['limPhysY'][0]
+        if case == 'vcm':
+            p['surface'] = dict(kind='bentflat', R=kw['R'], y0=y0)
+        elif case == 'vfm':
+            p['surface'] = dict(kind='vfm', r=kw['r'], R=kw['R'], y0=y0,
+                                limOptX=list(kw['limOptX']))
+        else:
+            p['surface'] = dict(kind='dualvfm', R=kw['R'], y0=y0, r1=70.0, xCylinder1=23.5,
+                                hCylinder1=3.7035, r2=35.98, xCylinder2=-25.0,
+                                hCylinder2=6.9504)
+        els, q, rho = gs.STRIPES[str(g['stripe'])]
+        p['material'] = mn.make_material([mn.load_element(tb, e) for e in els], list(q),
+                                         'mirror', rho)
     elif name.startswith('g3_laue_plate'):
         alpha = float(g['alpha'])
         p['surface'] = dict(kind='flat', laue=True, alpha=alpha if alpha else None)

@@ -213,6 +213,25 @@ def local_z(surf, x, y):
                         -yL * surf['tanAntiblaze'])
     if surf['kind'] == 'sagittal':                # DCMwithSagittalFocusing.local_z2, :655-656
         return surf['Rs'] - np.sqrt(surf['Rs']**2 - x**2)
+    if surf['kind'] == 'vfm':                     # VFM.local_z, oes/__init__.py:458-467
+        z = surf['r'] - (surf['r']**2 - x**2)**0.5
+        if surf.get('limOptX') is not None:
+            zMax = surf['r'] - (surf['r']**2 - surf['limOptX'][1]**2)**0.5
+            z[z > zMax] = zMax
+        z += (y**2 - surf['y0']**2) / 2.0 / surf['R']
+        return z
+    if surf['kind'] == 'dualvfm':                 # DualVFM.local_z, oes/__init__.py:532-550
+        z = np.zeros_like(x)
+        ind = x < 0
+        with np.errstate(invalid='ignore'):
+            tmp2 = surf['r2']**2 - (x[ind] - surf['xCylinder2'])**2
+            z[ind] = surf['r2'] - surf['hCylinder2'] - tmp2**0.5
+            tmp1 = surf['r1']**2 - (x[~ind] - surf['xCylinder1'])**2
+            z[~ind] = surf['r1'] - surf['hCylinder1'] - tmp1**0.5
+        z[np.isnan(z)] = 0.
+        z[z > 0] = 0.
+        z += (y**2 - surf['y0']**2) / 2.0 / surf['R']
+        return z
     if surf['kind'] == 'bent_cylinder':           # Johann/JohanssonCylinder, bragg.py:138-144
         if surf['crossSection'].startswith('circ'):
             sq = surf['Rm']**2 - y**2
@@ -429,6 +448,27 @@ def local_n(surf, x, y):
         return [np.zeros_like(x),
                 np.where(yL > yC, -surf['sinBlaze'], surf['sinAntiblaze']),
                 np.where(yL > yC, surf['cosBlaze'], surf['cosAntiblaze'])]
+    if surf['kind'] == 'vfm':                     # oes/__init__.py:469-477
+        a = -x * (surf['r']**2 - x**2)**(-0.5)
+        if surf.get('limOptX') is not None:
+            a[(x < surf['limOptX'][0]) | (x > surf['limOptX'][1])] = 0.0
+        b = -y / surf['R']
+        norm = (a**2 + b**2 + 1)**0.5
+        return [a/norm, b/norm, 1./norm]
+    if surf['kind'] == 'dualvfm':                 # oes/__init__.py:552-571
+        a = np.zeros_like(x)
+        ind = x < 0
+        with np.errstate(invalid='ignore'):
+            tmp2 = surf['r2']**2 - (x[ind] - surf['xCylinder2'])**2
+            a[ind] = -(x[ind] - surf['xCylinder2']) * tmp2**(-0.5)
+            tmp1 = surf['r1']**2 - (x[~ind] - surf['xCylinder1'])**2
+            a[~ind] = -(x[~ind] - surf['xCylinder1']) * tmp1**(-0.5)
+        z = local_z(surf, x, y)
+        a[np.isnan(a)] = 0.
+        a[z > 0] = 0.
+        b = -y / surf['R']
+        norm = (a**2 + b**2 + 1)**0.5
+        return [a/norm, b/norm, 1./norm]
     if surf['kind'] == 'bent_cylinder':           # bragg.py:146-197
         nSurf = _n_bent_cylinder(surf, x, y, surf['Rm'], surf.get('alpha'))
         if surf['planes'] == 'johann':

@@ -777,3 +777,30 @@ def test_fixed_refractive_index_matches_reference(golden_dir):
     compare(lo2, g, lambda f: g['lo2_' + f])
     with pytest.raises(NotImplementedError):
         rm.Material(refractiveIndex=np.ones((5, 3)))
+
+
+# ---- mirrors on their mechanical supports (oes/__init__.py:212-587, stages.py) --------
+@pytest.mark.parametrize('case', ['vcm', 'vfm', 'dualvfm'])
+def test_mirrors_on_supports_match_reference_golden(case):
+    """VCM with two coating stripes (the second selected: stage shift, its limits and
+    material), VFM (cylinder levelled off beyond the optical limits), DualVFM (second groove
+    selected and lifted into the beam): built and moved through the same jack / stage
+    arithmetic as the reference (get_orientation), then traced."""
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.materials as rm
+    import xrt_amd.backends.raycing.oes as roe
+    from oracle import gen_fixtures_supports as gs
+    g = pc.load('g2_support_' + case)
+    bl, oe = gs.build(raycing, roe, rm, case)
+    assert np.array_equal([oe.pitch, oe.roll, oe.yaw, oe.dx, oe.center[2]], g['orientation'])
+    assert oe.lostNum == int(g['oe_lostNum'])
+    info = {}
+    gb, lb = oe.reflect(pc.product_beam(g), _info=info)
+    assert info['axis'] == int(g['axis']) and info['brent'] == bool(g['brent'])
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    p, _, _ = fixture_io.load_case('g2_support_' + case)
+    x, y = np.array([0., 2.5, -4., 11., -30.]), np.array([0., 200., -310., 50., 10.])
+    assert np.array_equal(oe.local_z(x, y), rn.local_z(p['surface'], x, y))
+    for m, r in zip(oe.local_n(x, y), rn.local_n(p['surface'], x, y)):
+        assert np.abs(m - r).max() < 1e-15

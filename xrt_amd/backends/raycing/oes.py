@@ -27,6 +27,7 @@ import torch
 from .. import raycing
 from ... import _lib, _structs, hipcalls
 from . import sources as rs
+from . import stages as rst
 from .physconsts import CH
 
 _WIDE = raycing.maxHalfSizeOfOE
@@ -310,11 +311,11 @@ class OE(object):
         # limits of this surface (the second crystal has its own)
         suffix = '2' if is2ndXtal else ''
         for axis, lim in (('x', 'limPhysX'), ('y', 'limPhysY')):
-            lo, hi = getattr(self, lim + suffix)
+            lo, hi = self._limits_of(lim + suffix)
             target = getattr(p, 'phys_' + axis)
             target[0], target[1] = float(lo), float(hi)
         for axis, lim in (('x', 'limOptX'), ('y', 'limOptY')):
-            optical = getattr(self, lim + suffix, None)
+            optical = self._limits_of(lim + suffix)
             setattr(p, 'has_opt_' + axis, 0 if optical is None else 1)
             if optical is not None:
                 target = getattr(p, 'opt_' + axis)
@@ -345,12 +346,23 @@ class OE(object):
         self._grating_params(p, is2ndXtal)
         return p
 
-    @staticmethod
-    def _material_struct(material, fromVacuum, device):
-        if raycing.is_sequence(material):     # a list of coating stripes: one only
-            if len(material) != 1:
-                raise NotImplementedError('multi-stripe material lists')
-            material = material[0]
+    def _limits_of(self, name):
+        """(lo, hi) of the limits *name* for the present stripe: elements with several
+        surfaces (``surface`` = their names) give each limit as a sequence per stripe
+        (reference oes/base.py:1050-1092)."""
+        value = getattr(self, name, None)
+        if value is not None and raycing.is_sequence(value[0]):
+            return value[0][self.curSurface], value[1][self.curSurface]
+        return value
+
+    def get_surface_limits(self):
+        for kind in ('Phys', 'Opt'):
+            for axis in 'XY':
+                setattr(self, 'surf%s%s' % (kind, axis), self._limits_of('lim%s%s' % (kind, axis)))
+
+    def _material_struct(self, material, fromVacuum, device):
+        if raycing.is_sequence(material):     # coating stripes: the one in the beam
+            material = material[self.curSurface]
         if material is not None:
             return material.to_struct(fromVacuum, device)
         s = _structs.Material()
@@ -688,6 +700,83 @@ class ConicalMirror(_Curved):
         self._curved(p, _structs.SURF_CONE,
                      (self.L0, 0.25*t2t**2, self.redfocus*t2t, -0.5*t2t, np.sign(t2t),
                       self.redfocus, t2t, .5*t2t))
+
+
+class MirrorOnTripodWithTwoXStages(OE, rst.Tripod, rst.TwoXStages):
+    """A mirror on three jacks (*jack1..3*: [x, y, z], global) and two x stages (*tx1*, *tx2*:
+    [x, y], local; *dx*: nominal x shift) (reference oes/__init__.py:212-238)."""
+    _mirror = OE
+
+    def __init__(self, *args, **kwargs):
+        kwargs, jacks = rst.Tripod.pop_kwargs(self, **kwargs)
+        kwargs, stages = rst.TwoXStages.pop_kwargs(self, **kwargs)
+        self._mirror.__init__(self, *args, **kwargs)
+        rst.Tripod.__init__(self, *jacks)
+        rst.TwoXStages.__init__(self, *stages)
+
+    def get_orientation(self):
+        """x shift, height and the three angles from the stages and the jacks."""
+        rst.TwoXStages.get_orientation(self)
+        rst.Tripod.get_orientation(self)
+
+
+class VCM(MirrorOnTripodWithTwoXStages, BentFlatMirror):
+    """Vertically collimating (bent flat) mirror on its support (oes/__init__.py:309-317)."""
+    _mirror = BentFlatMirror
+
+
+class VFM(MirrorOnTripodWithTwoXStages, ToroidMirror):
+    """Vertically focusing mirror on its support: a sagittal cylinder of radius *r* --
+    levelled off beyond the optical x limits --, bent meridionally to *R* with fixed ends
+    (oes/__init__.py:417-478)."""
+    _mirror = ToroidMirror
+
+    def __init__(self, *args, **kwargs):
+        if kwargs.get('limPhysY') is None:
+            raise AttributeError('limPhysY must be given')
+        MirrorOnTripodWithTwoXStages.__init__(self, *args, **kwargs)
+
+    def _surface_params(self, p, second=False):
+        cap = np.inf
+        edges = (0., 0.)
+        if self.limOptX is not None:
+            edges = self.limOptX
+            cap = self.r - (self.r**2 - self.limOptX[1]**2)**0.5
+        self._curved(p, _structs.SURF_VFM, (self.r, self.r**2, cap, self.limPhysY[0]**2,
+                                            self.R, edges[0], edges[1]))
+
+
+class DualVFM(MirrorOnTripodWithTwoXStages, _Curved):
+    """Two focusing cylinders side by side in one substrate: radii *r1*, *r2*, axes at the
+    local x *xCylinder1*, *xCylinder2*, sunk by *hCylinder1*, *hCylinder2* below the flat
+    top; meridional radius *R* (oes/__init__.py:480-587)."""
+
+    def __init__(self, *args, **kwargs):
+        self.R = kwargs.pop('R', 5.0e6)
+        self.r1, self.xCylinder1, self.hCylinder1 = (
+            kwargs.pop('r1', 70.0), kwargs.pop('xCylinder1', 23.5),
+            kwargs.pop('hCylinder1', 3.7035))
+        self.r2, self.xCylinder2, self.hCylinder2 = (
+            kwargs.pop('r2', 35.98), kwargs.pop('xCylinder2', -25.0),
+            kwargs.pop('hCylinder2', 6.9504))
+        MirrorOnTripodWithTwoXStages.__init__(self, *args, **kwargs)
+        self.hCylinder = 0
+
+    def _surface_params(self, p, second=False):
+        y0 = self._limits_of('limPhysY')[0]
+        self._curved(p, _structs.SURF_DUALVFM,
+                     (self.r1 - self.hCylinder1, self.r1**2, self.xCylinder1,
+                      self.r2 - self.hCylinder2, self.r2**2, self.xCylinder2, y0**2, self.R))
+
+    def select_surface(self, surfaceName):
+        """Moves the cylinder of that name into the beam."""
+        self.curSurface = self.surface.index(surfaceName)
+        axis, self.hCylinder, self.r = (
+            (self.xCylinder1, self.hCylinder1, self.r1) if self.curSurface == 0 else
+            (self.xCylinder2, self.hCylinder2, self.r2))
+        self.dx = -axis
+        self.get_surface_limits()
+        self.set_x_stages()
 
 
 class _BentBragg(_Curved):
@@ -1132,6 +1221,33 @@ class DCM(OE):
         lo1._d['theta'], lo2._d['theta'] = angles
         self._adopt((lo1, lo2, gb2), beam)
         return gb2, lo1, lo2
+
+
+class DCMOnTripodWithOneXStage(DCM, rst.Tripod, rst.OneXStage):
+    """A double-crystal monochromator on three jacks and one x stage
+    (oes/__init__.py:669-707)."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs, jacks = rst.Tripod.pop_kwargs(self, **kwargs)
+        kwargs, stage = rst.OneXStage.pop_kwargs(self, **kwargs)
+        DCM.__init__(self, *args, **kwargs)
+        rst.Tripod.__init__(self, *jacks)
+        rst.OneXStage.__init__(self, *stage)
+        stripes = len(self.surface) if self.surface is not None else 0
+        for optical in (self.limOptX2, self.limOptY2):
+            if optical is None:
+                continue
+            if not (raycing.is_sequence(optical[0]) and raycing.is_sequence(optical[1])):
+                raise ValueError('"limOptX" must be a tuple of sequences!')
+            if not (len(optical[0]) == len(optical[1]) == stripes):
+                raise ValueError('len(self.limOptX[0,1]) != len(surface) !!!')
+        for edge in (self.limPhysX2[0], self.limPhysX2[1], self.limPhysY2[0],
+                     self.limPhysY2[1]):
+            if raycing.is_sequence(edge) and len(edge) != stripes:
+                raise ValueError('length of "surface" and "limPhys..." must be equal!')
+
+    def get_orientation(self):
+        rst.Tripod.get_orientation(self)
 
 
 class DCMwithSagittalFocusing(DCM):

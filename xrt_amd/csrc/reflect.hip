@@ -401,6 +401,18 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
   }
   if (PSURF(P) == XRT_HIP_SURF_SAGITTAL)  // oes/__init__.py:655-656 (crystals: family 0 too)
     return P.surf_p[0] - sqrt(P.surf_p[1] - x * x);
+  if (PSURF(P) == XRT_HIP_SURF_VFM) {  // oes/__init__.py:458-467
+    double z = P.surf_p[0] - sqrt(P.surf_p[1] - x * x);
+    if (z > P.surf_p[2]) z = P.surf_p[2];
+    return z + (y * y - P.surf_p[3]) / 2.0 / P.surf_p[4];
+  }
+  if (PSURF(P) == XRT_HIP_SURF_DUALVFM) {  // oes/__init__.py:532-550
+    const bool left = x < 0.;
+    const double u = x - (left ? P.surf_p[5] : P.surf_p[2]);
+    double z = (left ? P.surf_p[3] : P.surf_p[0]) - sqrt((left ? P.surf_p[4] : P.surf_p[1]) - u * u);
+    if (isnan(z) || z > 0.) z = 0.;
+    return z + (y * y - P.surf_p[6]) / 2.0 / P.surf_p[7];
+  }
   if (PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {  // oes/bragg.py:138-144, 236-241
     const double Rm = P.surf_p[2], Rs = P.surf_p[3];
     if (P.surf_p[0] == 1.) return y * y / 2.0 / Rm;
@@ -1936,6 +1948,31 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     n[2] = n[5] = sqrt(P.surf_p[1] - x * x) / P.surf_p[0];
   } else if (PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {
     bent_bragg_normals(P, x, y, n);
+  } else if (PSURF(P) == XRT_HIP_SURF_VFM) {  // oes/__init__.py:469-477
+    double na = -x / sqrt(P.surf_p[1] - x * x);
+    if (!isinf(P.surf_p[2]) && (x < P.surf_p[5] || x > P.surf_p[6])) na = 0.;
+    const double nb = -y / P.surf_p[4];
+    const double norm = sqrt(na * na + nb * nb + 1.);
+    n[0] = n[3] = na / norm;
+    n[1] = n[4] = nb / norm;
+    n[2] = n[5] = 1. / norm;
+  } else if (PSURF(P) == XRT_HIP_SURF_DUALVFM) {  // oes/__init__.py:552-571
+    const bool left = x < 0.;
+    const double u = x - (left ? P.surf_p[5] : P.surf_p[2]);
+    const double under = (left ? P.surf_p[4] : P.surf_p[1]) - u * u;
+    const double rise = (left ? P.surf_p[3] : P.surf_p[0]) - sqrt(under);
+    double na = -u / sqrt(under);
+    if (isnan(na) || isnan(rise)) na = 0.;
+    // the flat land between and beside the cylinders: local_z > 0 there (its meridional
+    // term included, as the reference tests the full height)
+    const double zfull = ((isnan(rise) || rise > 0.) ? 0. : rise) +
+                         (y * y - P.surf_p[6]) / 2.0 / P.surf_p[7];
+    if (zfull > 0.) na = 0.;
+    const double nb = -y / P.surf_p[7];
+    const double norm = sqrt(na * na + nb * nb + 1.);
+    n[0] = n[3] = na / norm;
+    n[1] = n[4] = nb / norm;
+    n[2] = n[5] = 1. / norm;
   } else if (surf_is_cone<K>(P)) {  // oes/__init__.py:629-636
     const double u = y - P.surf_p[0];
     const double root =
