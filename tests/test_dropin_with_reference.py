@@ -257,3 +257,28 @@ def test_host_only_classes_agree_with_the_reference():
     for f in ('x', 'y', 'z', 'a', 'b', 'c', 'E', 'Jss', 'Jpp', 'Jsp', 'state'):
         assert np.array_equal(getattr(b0, f), getattr(b1, f)), f
     assert b0.sourceWeight == b1.sourceWeight and len(b1.x) == 21
+
+
+def test_predefined_materials_agree_with_the_reference():
+    """Every class of the three catalogues against the reference's class of the same name:
+    formula, density, molar mass; d spacing, cell volume and chi/F factor of the crystals at
+    the default and at another reflection."""
+    _refenv.activate()
+    import xrt.backends.raycing.materials.elemental as rel
+    import xrt.backends.raycing.materials.compounds as rco
+    import xrt.backends.raycing.materials.crystals as rcr
+    import xrt_amd.backends.raycing.materials.elemental as xel
+    import xrt_amd.backends.raycing.materials.compounds as xco
+    import xrt_amd.backends.raycing.materials.crystals as xcr
+    for mine, ref in ((xel, rel), (xco, rco)):
+        assert set(mine.__all__) == set(ref.__all__)
+        for n in ref.__all__:
+            a, b = getattr(mine, n)(), getattr(ref, n)()
+            assert a.rho == b.rho and a.mass == b.mass, n
+            assert [e.name for e in a.elements] == [e.name for e in b.elements], n
+    assert set(xcr.__all__) == set(rcr.__all__)
+    for n in rcr.__all__:
+        for kw in ({}, dict(hkl=(2, 2, 0))):
+            a, b = getattr(xcr, n)(**kw), getattr(rcr, n)(**kw)
+            assert a.d == b.d and a.V == b.V and a.chiToF == b.chiToF, n
+            assert abs(a.rho - b.rho) <= 1e-14 * abs(b.rho), n

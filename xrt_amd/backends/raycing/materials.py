@@ -118,8 +118,6 @@ class Material(object):
             self.quantities = [quantities]
         else:
             self.quantities = list(quantities)
-        if len(self.elements) > _structs.MAX_ELEM:
-            raise ValueError('at most %d elements per material' % _structs.MAX_ELEM)
         self.kind = kind
         self.rho = rho
         self.t = t
@@ -142,6 +140,10 @@ class Material(object):
 
     # ---- struct for the kernels ---------------------------------------------
     def _fill_elements(self, s, device):
+        if len(self.elements) > _structs.MAX_ELEM:
+            raise NotImplementedError('the kernels take at most %d different elements per '
+                                      'material (%s has %d)' % (
+                                          _structs.MAX_ELEM, self.name, len(self.elements)))
         keep = []
         s.nelem = len(self.elements)
         for i, (e, xi) in enumerate(zip(self.elements, self.quantities)):
@@ -694,3 +696,53 @@ class CrystalFromCell(Crystal):
             s.cell_s[i][0], s.cell_s[i][1] = float(cs[i].real), float(cs[i].imag)
             s.cell_sm[i][0], s.cell_sm[i][1] = float(csm[i].real), float(csm[i].imag)
         return s
+
+
+# ---- predefined materials: materials.elemental / .compounds / .crystals ------------------
+def _predefined_modules():
+    """The reference's catalogues of ready-made materials (materials/elemental.py: one class
+    per element at its ambient density; compounds.py: common compounds and polymers;
+    crystals.py: crystal structures from their unit cells) as modules of classes built from
+    the data extract xrt_amd/data/materials.json (oracle/gen_material_data.py). A class takes
+    the keyword arguments of its base (``Material``, ``CrystalDiamond``, ``CrystalFromCell``)
+    on top of its defaults: ``xcryst.Ge(hkl=(2, 2, 0))``, ``xcomp.Silica(kind='plate')``."""
+    import json
+    import sys
+    import types
+    with open(os.path.join(os.path.dirname(_DATA), 'materials.json')) as f:
+        catalogue = json.load(f)
+
+    def make(base, defaults, label):
+        def __init__(self, *args, **kwargs):
+            for key, value in defaults.items():
+                kwargs.setdefault(key, value)
+            base.__init__(self, *args, **kwargs)
+        return type(label, (base,), {'__init__': __init__, '__doc__': '%s (%s)' % (
+            label, ', '.join('%s=%r' % kv for kv in sorted(defaults.items())
+                             if kv[0] not in ('atomsXYZ', 'atoms', 'atomsFraction')))})
+
+    modules = {}
+    for section in ('elemental', 'compounds', 'crystals'):
+        mod = types.ModuleType(__name__ + '.' + section, 'predefined materials: ' + section)
+        for label, d in catalogue[section].items():
+            if section != 'crystals':
+                defaults = dict(elements=tuple(d['elements']), quantities=tuple(d['quantities']),
+                                rho=d['rho'], name=d['name'])
+                cls = make(Material, defaults, label)
+            elif d['base'] == 'diamond':
+                cls = make(CrystalDiamond, dict(elements=d['elements'][0], a=d['a'],
+                                                name=d['name']), label)
+            else:
+                defaults = {k: d[k] for k in ('name', 'a', 'b', 'c', 'alpha', 'beta', 'gamma',
+                                              'atoms', 'atomsXYZ', 'atomsFraction')}
+                cls = make(CrystalFromCell, defaults, label)
+            cls.__module__ = mod.__name__
+            setattr(mod, label, cls)
+        mod.__all__ = tuple(catalogue[section])
+        sys.modules[mod.__name__] = mod
+        modules[section] = mod
+    return modules
+
+
+elemental, compounds, crystals = (_predefined_modules()[k]
+                                  for k in ('elemental', 'compounds', 'crystals'))
