@@ -275,6 +275,18 @@ typedef struct xrt_hip_pass {
 
 struct xrt_hip_multilayer;
 
+/* CrystalFromCell (crystals_basic.py:424-440): per element e of the material (its atoms in
+ * the cell, their fractions w_j and positions r_j) the sums w = sum w_j, s = sum w_j
+ * exp(2 pi i r_j.hkl), sm = the same with -r_j, and f0 at sin(theta)/lambda = 1/2d.
+ * F0 = factDW sum_e w (Z + f1 + i f2), F_hkl = factDW sum_e (f0 + f1 + i f2) s, F_-h-k-l
+ * with sm. */
+typedef struct xrt_hip_cell {
+  double w[4];
+  double f0[4];
+  double s[4][2];
+  double sm[4][2];
+} xrt_hip_cell;
+
 typedef struct xrt_hip_material {
   int32_t kind;
   int32_t from_vacuum;
@@ -310,15 +322,10 @@ typedef struct xrt_hip_material {
    * normal; 0: Coated (kind 'mirror'), mirror direction, amplitude at the cosine to the
    * local normal --, d and geom_transmitted. */
   const struct xrt_hip_multilayer* layers;
-  /* structure == 2, CrystalFromCell (crystals_basic.py:424-440): per element e of the
-   * material (its atoms in the cell, their fractions w_j and positions r_j) the sums
-   * cell_w = sum w_j, cell_s = sum w_j exp(2 pi i r_j.hkl), cell_sm = the same with
-   * -r_j, and f0 at sin(theta)/lambda = 1/2d. F0 = factDW sum_e cell_w (Z + f1 + i f2),
-   * F_hkl = factDW sum_e (f0 + f1 + i f2) cell_s, F_-h-k-l with cell_sm. */
-  double cell_w[XRT_HIP_MAX_ELEM];
-  double cell_f0[XRT_HIP_MAX_ELEM];
-  double cell_s[XRT_HIP_MAX_ELEM][2];
-  double cell_sm[XRT_HIP_MAX_ELEM][2];
+  /* structure == 2, CrystalFromCell: the sums over the atoms of the unit cell, a record in
+   * DEVICE memory (kept out of this record, which travels as a kernel argument: the DCM
+   * kernel takes two of them) */
+  const struct xrt_hip_cell* cell;
   /* Material(refractiveIndex = a number) (material.py:240-262, 364-373): n_fixed != 0 -> the
    * refractive index is n_re + i n_im at every energy and the element tables are not
    * consulted (nelem may be 0). */

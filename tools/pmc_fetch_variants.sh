@@ -1,0 +1,22 @@
+#!/bin/bash
+# FETCH_SIZE / WRITE_SIZE of reflect_fused for the libraries given as arguments ("" = the
+# built one): which part of the kernel reads more than the 100 B/ray of the input record?
+#   gpurun -- 'bash tools/pmc_fetch_variants.sh "" xrt_amd/ab/libxrt_late.so ...'
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+export PYTHONPATH=.
+for LIB in "$@"; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmcv
+    XRT_HIP_LIBRARY=$LIB rocprofv3 --kernel-trace --pmc $C -d /tmp/pmcv -o p -- python tools/profile_workload.py 1e7 --no-kirchhoff > /dev/null 2>&1
+    python - <<PY
+import sqlite3, glob
+db = glob.glob('/tmp/pmcv/**/*.db', recursive=True)
+c = sqlite3.connect(db[0])
+tabs = [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')")]
+view = [t for t in tabs if t.startswith('counters_collection')][0]
+for r in c.execute("select kernel_name, counter_name, avg(value), count(*) from %s where kernel_name like '%%reflect_fused%%' or kernel_name like '%%screen_expose%%' group by kernel_name, counter_name" % view):
+    print('[$LIB]', r[0][:50], r[1], '%.6g KB' % r[2], r[3])
+PY
+  done
+done

@@ -19,6 +19,9 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 reps = 3
 oe = workloads.cfg2_toroid()
 beam = workloads.synthetic_rays(n, 42)
+if '--tight' in sys.argv:      # every ray hits (no divergent lost / over lanes in a wave)
+    beam.z = beam.z * 0.2
+    beam.c = beam.c * 0.2
 for f in beam.array_fields():
     beam.dev(f)
 scr = rsc.Screen(raycing.BeamLine(), 'scr', [0, 30000., 0])

@@ -109,14 +109,16 @@ class Material(ctypes.Structure):
         ('fact_dw', ctypes.c_double),
         ('t_crystal', ctypes.c_double),
         ('layers', ctypes.c_void_p),
-        ('cell_w', ctypes.c_double * MAX_ELEM),
-        ('cell_f0', ctypes.c_double * MAX_ELEM),
-        ('cell_s', ctypes.c_double * 2 * MAX_ELEM),
-        ('cell_sm', ctypes.c_double * 2 * MAX_ELEM),
+        ('cell', ctypes.c_void_p),
         ('n_fixed', ctypes.c_int32),
         ('n_re', ctypes.c_double),
         ('n_im', ctypes.c_double),
     ]
+
+
+class Cell(ctypes.Structure):
+    _fields_ = [('w', ctypes.c_double * 4), ('f0', ctypes.c_double * 4),
+                ('s', ctypes.c_double * 2 * 4), ('sm', ctypes.c_double * 2 * 4)]
 
 
 class Multilayer(ctypes.Structure):

@@ -689,12 +689,18 @@ class CrystalFromCell(Crystal):
 
     def to_struct(self, fromVacuum=True, device=None):
         s = Crystal.to_struct(self, fromVacuum, device)
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
         w, cs, csm = self._cell_sums()
+        rec = _structs.Cell()
         for i, e in enumerate(self.elements):
-            s.cell_w[i] = float(w[i])
-            s.cell_f0[i] = float(e.get_f0(0.5 / self.d))
-            s.cell_s[i][0], s.cell_s[i][1] = float(cs[i].real), float(cs[i].imag)
-            s.cell_sm[i][0], s.cell_sm[i][1] = float(csm[i].real), float(csm[i].imag)
+            rec.w[i] = float(w[i])
+            rec.f0[i] = float(e.get_f0(0.5 / self.d))
+            rec.s[i][0], rec.s[i][1] = float(cs[i].real), float(cs[i].imag)
+            rec.sm[i][0], rec.sm[i][1] = float(csm[i].real), float(csm[i].imag)
+        image = torch.frombuffer(bytearray(bytes(rec)), dtype=torch.uint8).to(device)
+        s.cell = image.data_ptr()
+        s._keep = list(s._keep) + [image]
         return s
 
 

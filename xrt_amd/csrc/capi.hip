@@ -275,6 +275,8 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
     return fail(XRT_HIP_ERR_ARG, "rotation sequence longer than %d", XRT_HIP_MAX_ROT);
   if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_DUALVFM)
     return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
+  if (material->kind == XRT_HIP_MAT_CRYSTAL && material->structure == 2 && !material->cell)
+    return fail(XRT_HIP_ERR_ARG, "crystal from a unit cell without its xrt_hip_cell record");
   if (material->kind == XRT_HIP_MAT_MULTILAYER) {
     if (!material->layers)
       return fail(XRT_HIP_ERR_ARG, "multilayer material without its xrt_hip_multilayer record");
@@ -630,6 +632,8 @@ int xrt_hip_crystal_amplitude_f64_dev(const xrt_hip_material* material, int64_t 
   if (rc) return rc;
   if (material->kind != XRT_HIP_MAT_CRYSTAL)
     return fail(XRT_HIP_ERR_ARG, "material is not a crystal");
+  if (material->structure == 2 && !material->cell)
+    return fail(XRT_HIP_ERR_ARG, "crystal from a unit cell without its xrt_hip_cell record");
   if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
   if (n == 0) return XRT_HIP_OK;
   if (!E || !gamma0 || !gammah || !hns || !S_ri || !P_ri)

@@ -268,11 +268,18 @@ struct Spec {
   // crystal known to be thick (crystal.py:571-584): the thin-crystal forms with their
   // complex exp / cos / sin / tan are not compiled in
   static constexpr bool XTHICK = false;
+  // crystals given by their unit cell (structure code 2: up to four f1/f2 look-ups per ray)
+  // are compiled in
+  static constexpr bool XCELL = true;
 };
 // a thick (semi-infinite) crystal: what a DCM is made of
 template <int SK_>
 struct ThickXtal : Spec<0, SK_, XRT_HIP_MAT_CRYSTAL, false> {
   static constexpr bool XTHICK = true;
+  // one-element lattices only (the launcher sends cell crystals to the other crystal
+  // kernels): with the four-element look-ups compiled in, the fused DCM kernel spilled 194
+  // SGPRs instead of 79 and lost 2 %
+  static constexpr bool XCELL = false;
 };
 // Bragg crystals, and multilayers (geom_bragg set; a Coated mirror has it cleared): the
 // direction comes from the grating equation with the batch's sign of beamInDotNormal
@@ -297,6 +304,19 @@ using Generic1 = Spec<1, -1, -1, false>;
 template <class K>
 __device__ __forceinline__ constexpr bool layered() {
   return K::MK == XRT_HIP_MAT_MULTILAYER;
+}
+// Surface kinds beyond the blazed grating are dispatched to the family-1 kernels -- except
+// under a crystal, whose kernels are family 0 (bent analysers, the sagittal DCM crystal).
+// Keeping them out of the other family-0 kernels keeps those lean: the generic exact kernel
+// of a plain mirror pass went from 176 B to 1 KB of scratch (and the pass from 21 to 32 us of
+// launch overhead) with the new kinds compiled in.
+template <class K>
+__device__ __forceinline__ constexpr bool wide_surfaces() {
+  return K::F == 1;
+}
+template <class K>
+__device__ __forceinline__ constexpr bool bent_crystal_surfaces() {
+  return K::F == 1 || K::MK == XRT_HIP_MAT_CRYSTAL;
 }
 template <class K>
 __device__ __forceinline__ bool surf_is_param(const xrt_hip_pass& P) {
@@ -401,19 +421,19 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
   }
   if (PSURF(P) == XRT_HIP_SURF_SAGITTAL)  // oes/__init__.py:655-656 (crystals: family 0 too)
     return P.surf_p[0] - sqrt(P.surf_p[1] - x * x);
-  if (PSURF(P) == XRT_HIP_SURF_VFM) {  // oes/__init__.py:458-467
+  if (wide_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_VFM) {  // oes/__init__.py:458-467
     double z = P.surf_p[0] - sqrt(P.surf_p[1] - x * x);
     if (z > P.surf_p[2]) z = P.surf_p[2];
     return z + (y * y - P.surf_p[3]) / 2.0 / P.surf_p[4];
   }
-  if (PSURF(P) == XRT_HIP_SURF_DUALVFM) {  // oes/__init__.py:532-550
+  if (wide_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_DUALVFM) {  // oes/__init__.py:532-550
     const bool left = x < 0.;
     const double u = x - (left ? P.surf_p[5] : P.surf_p[2]);
     double z = (left ? P.surf_p[3] : P.surf_p[0]) - sqrt((left ? P.surf_p[4] : P.surf_p[1]) - u * u);
     if (isnan(z) || z > 0.) z = 0.;
     return z + (y * y - P.surf_p[6]) / 2.0 / P.surf_p[7];
   }
-  if (PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {  // oes/bragg.py:138-144, 236-241
+  if (bent_crystal_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {  // oes/bragg.py:138-144, 236-241
     const double Rm = P.surf_p[2], Rs = P.surf_p[3];
     if (P.surf_p[0] == 1.) return y * y / 2.0 / Rm;
     const double root = sqrt(Rm * Rm - y * y);
@@ -1473,7 +1493,9 @@ __device__ __forceinline__ cplx refractive_index(const xrt_hip_material& M, doub
                                                  const TabWin& w) {
   if (M.n_fixed) return C(M.n_re, M.n_im);
   cplx xf = C(0., 0.);
-  for (int e = 0; e < M.nelem; ++e) {
+#pragma unroll
+  for (int e = 0; e < XRT_HIP_MAX_ELEM; ++e) {
+    if (e >= M.nelem) break;
     cplx f = interp_f1f2(M, e, E, w);
     f.re += (double)M.Z[e];
     xf = xf + f * M.quantity[e];
@@ -1571,7 +1593,7 @@ __device__ __forceinline__ cplx crystal_one_pol(const xrt_hip_material& M, doubl
 }
 
 // apre: f1 + i f2 of the crystal's element at E, if the caller looked it up already
-template <bool THICK = false>
+template <bool THICK = false, bool CELL = true>
 __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, double E,
                                                   double bdsn, double bosn, double bdhn,
                                                   const TabWin& w, const cplx* apre = nullptr) {
@@ -1593,15 +1615,20 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
   }
   // structure factors, crystals_basic.py:22-31, 76-80; chi, crystal.py:297-306
   cplx F0 = C(0., 0.), Fh = C(0., 0.), Fh_ = C(0., 0.);
-  if (M.structure == 2) {
+  if (CELL && M.structure == 2) {
     // from the unit cell, crystals_basic.py:424-440: the sums over the atoms of each
     // element are constants of the reflection, only f1 + i f2 depends on the ray
-    for (int e = 0; e < M.nelem; ++e) {
+    // (constant indices after unrolling: a run-time index into the by-value material record
+    // would make the compiler keep a copy of it in scratch)
+    const xrt_hip_cell& cell = *M.cell;
+#pragma unroll
+    for (int e = 0; e < XRT_HIP_MAX_ELEM; ++e) {
+      if (e >= M.nelem) break;
       const cplx anom = interp_f1f2(M, e, E, w);
-      F0 = F0 + (C((double)M.Z[e], 0.) + anom) * M.cell_w[e];
-      const cplx f = C(M.cell_f0[e], 0.) + anom;
-      Fh = Fh + f * C(M.cell_s[e][0], M.cell_s[e][1]);
-      Fh_ = Fh_ + f * C(M.cell_sm[e][0], M.cell_sm[e][1]);
+      F0 = F0 + (C((double)M.Z[e], 0.) + anom) * cell.w[e];
+      const cplx f = C(cell.f0[e], 0.) + anom;
+      Fh = Fh + f * C(cell.s[e][0], cell.s[e][1]);
+      Fh_ = Fh_ + f * C(cell.sm[e][0], cell.sm[e][1]);
     }
     F0 = F0 * M.fact_dw;
     Fh = Fh * M.fact_dw;
@@ -1946,9 +1973,9 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     n[0] = n[3] = -x / P.surf_p[0];
     n[1] = n[4] = 0.;
     n[2] = n[5] = sqrt(P.surf_p[1] - x * x) / P.surf_p[0];
-  } else if (PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {
+  } else if (bent_crystal_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {
     bent_bragg_normals(P, x, y, n);
-  } else if (PSURF(P) == XRT_HIP_SURF_VFM) {  // oes/__init__.py:469-477
+  } else if (wide_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_VFM) {  // oes/__init__.py:469-477
     double na = -x / sqrt(P.surf_p[1] - x * x);
     if (!isinf(P.surf_p[2]) && (x < P.surf_p[5] || x > P.surf_p[6])) na = 0.;
     const double nb = -y / P.surf_p[4];
@@ -1956,7 +1983,7 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     n[0] = n[3] = na / norm;
     n[1] = n[4] = nb / norm;
     n[2] = n[5] = 1. / norm;
-  } else if (PSURF(P) == XRT_HIP_SURF_DUALVFM) {  // oes/__init__.py:552-571
+  } else if (wide_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_DUALVFM) {  // oes/__init__.py:552-571
     const bool left = x < 0.;
     const double u = x - (left ? P.surf_p[5] : P.surf_p[2]);
     const double under = (left ? P.surf_p[4] : P.surf_p[1]) - u * u;
@@ -2191,7 +2218,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     A = multilayer_amplitude(*M.layers, q.E, M.geom_bragg ? bdsn : bdn);
   } else if (MKIND(M) == XRT_HIP_MAT_CRYSTAL) {
     const double bosn = ao * n[3] + bo * n[4] + co * n[5];
-    A = crystal_amplitude<K::XTHICK>(M, q.E, bdsn, bosn, bdn, window_of(g), npre);
+    A = crystal_amplitude<K::XTHICK, K::XCELL>(M, q.E, bdsn, bosn, bdn, window_of(g), npre);
   } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
     A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g), npre);
   }
@@ -2380,27 +2407,60 @@ __device__ __forceinline__ Completed complete_ray(
   store_ray(lb, i, h.x, h.y, h.z, la, lbb, lc, lo.path, lo.E, lo.Jss, lo.Jpp, lo.Jsr, lo.Jsi,
             st, lo.Esr, lo.Esi, lo.Epr, lo.Epi, has_amp);
   const bool keep = P.only_state1_out ? (st == 1) : (st == 1 || st == 2);
-  if (!keep) {  // reflect.py:131-134: everything but the state comes from `restore`
-    if (!VREC) copy_ray(vb, restore, i, P.force_lost_out ? P.lost_num : st, has_amp, false);
-    return res;
-  }
-  res.kept = true;
-  // back to the virgin local frame, reflect.py:1115-1132
-  double x = h.x + P.shift[0], y = h.y + P.shift[1], z = h.z + P.shift[2];
-  rotate3(P.to_virgin, x, y, z);
-  rotate3(P.to_virgin, la, lbb, lc);
-  if (P.out_to_global) {  // beamline.py:267-287
-    if (P.sin_az != 0.) {
-      const double an = P.cos_az * la - (-P.sin_az) * lbb, bn = (-P.sin_az) * la + P.cos_az * lbb;
-      la = an;
-      lbb = bn;
-      const double xn = P.cos_az * x - (-P.sin_az) * y, yn = (-P.sin_az) * x + P.cos_az * y;
-      x = xn;
-      y = yn;
+  if (!keep && VREC) return res;
+  res.kept = keep;
+  double x, y, z;
+  int vst = st;
+  if (!keep) {
+    // reflect.py:131-134: everything but the state comes from `restore`. The record is
+    // fetched into the same registers the kept rays use, so that the outgoing beam is
+    // written by ONE store per array and wave: a wave that stores its lost / over lanes
+    // apart from the others writes partial lines, which the L2 completes by reading them
+    // from HBM (measured on cfg2: 0.13 GB per 1e7 rays, 77 % of the waves hold such a lane)
+    x = restore.x[i];
+    y = restore.y[i];
+    z = restore.z[i];
+    la = restore.a[i];
+    lbb = restore.b[i];
+    lc = restore.c[i];
+    lo.path = restore.path[i];
+    lo.E = restore.E[i];
+    vJss = restore.Jss[i];
+    vJpp = restore.Jpp[i];
+    const double2 js = reinterpret_cast<const double2*>(restore.Jsp_ri)[i];
+    vJsr = js.x;
+    vJsi = js.y;
+    vEsr = vEsi = vEpr = vEpi = 0.;
+    if (has_amp) {
+      const double2 es = reinterpret_cast<const double2*>(restore.Es_ri)[i];
+      const double2 ep = reinterpret_cast<const double2*>(restore.Ep_ri)[i];
+      vEsr = es.x;
+      vEsi = es.y;
+      vEpr = ep.x;
+      vEpi = ep.y;
     }
-    x += P.center[0];
-    y += P.center[1];
-    z += P.center[2];
+    if (P.force_lost_out) vst = P.lost_num;
+  } else {
+    // back to the virgin local frame, reflect.py:1115-1132
+    x = h.x + P.shift[0];
+    y = h.y + P.shift[1];
+    z = h.z + P.shift[2];
+    rotate3(P.to_virgin, x, y, z);
+    rotate3(P.to_virgin, la, lbb, lc);
+    if (P.out_to_global) {  // beamline.py:267-287
+      if (P.sin_az != 0.) {
+        const double an = P.cos_az * la - (-P.sin_az) * lbb,
+                     bn = (-P.sin_az) * la + P.cos_az * lbb;
+        la = an;
+        lbb = bn;
+        const double xn = P.cos_az * x - (-P.sin_az) * y, yn = (-P.sin_az) * x + P.cos_az * y;
+        x = xn;
+        y = yn;
+      }
+      x += P.center[0];
+      y += P.center[1];
+      z += P.center[2];
+    }
   }
   if (VREC) {
     res.v.x = x;
@@ -2422,7 +2482,7 @@ __device__ __forceinline__ Completed complete_ray(
     res.v.st = st;
     return res;
   }
-  store_ray(vb, i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, st, vEsr, vEsi,
+  store_ray(vb, i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, vst, vEsr, vEsi,
             vEpr, vEpi, has_amp);
   return res;
 }
@@ -3701,9 +3761,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
         XRT_XTAL(Layered1);
       else if (layers)
         XRT_XTAL(Layered0);
-      else if (M.thick && flat_xtal)
+      else if (M.thick && flat_xtal && M.structure != 2)
         XRT_XTAL(ThickXtal<XRT_HIP_SURF_FLAT>);
-      else if (M.thick)
+      else if (M.thick && M.structure != 2)
         XRT_XTAL(ThickXtal<-1>);
       else if (flat_xtal)
         XRT_XTAL(FlatXtal);
