@@ -934,7 +934,7 @@ struct LocalRay {
 };
 
 __device__ __forceinline__ LocalRay load_local(const xrt_hip_pass& P, const xrt_hip_beam& in,
-                                               int64_t i) {
+                                               int64_t i, LocalRay* raw = nullptr) {
   LocalRay r;
   r.x = in.x[i];
   r.y = in.y[i];
@@ -942,6 +942,7 @@ __device__ __forceinline__ LocalRay load_local(const xrt_hip_pass& P, const xrt_
   r.a = in.a[i];
   r.b = in.b[i];
   r.c = in.c[i];
+  if (raw) *raw = r;   // as it came, for a ray that leaves as it came
   local_pos(P, r.x, r.y, r.z);
   local_dir(P, r.a, r.b, r.c);
   return r;
@@ -2361,7 +2362,8 @@ __device__ __forceinline__ Completed complete_ray(
     const xrt_hip_pass& P, const xrt_hip_material& M, const GStat& g, const xrt_hip_beam& in,
     const xrt_hip_beam& restore, const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
     int64_t i, const LocalRay& r, const Hit& h, int st, bool has_amp, int own_sign = 0,
-    double* bdn_out = nullptr, RayIn qin = RayIn(), const cplx* npre = nullptr) {
+    double* bdn_out = nullptr, RayIn qin = RayIn(), const cplx* npre = nullptr,
+    const LocalRay* raw = nullptr) {
   Completed res;
   res.kept = false;
   RayIn q;
@@ -2412,11 +2414,22 @@ __device__ __forceinline__ Completed complete_ray(
   double x, y, z;
   int vst = st;
   if (!keep) {
-    // reflect.py:131-134: everything but the state comes from `restore`. The record is
-    // fetched into the same registers the kept rays use, so that the outgoing beam is
-    // written by ONE store per array and wave: a wave that stores its lost / over lanes
-    // apart from the others writes partial lines, which the L2 completes by reading them
-    // from HBM (measured on cfg2: 0.13 GB per 1e7 rays, 77 % of the waves hold such a lane)
+    // reflect.py:131-134: everything but the state comes from `restore`. The record goes
+    // into the registers the kept rays use, so that the outgoing beam is written by ONE
+    // store per array and wave (77 % of the cfg2 waves hold a lost / over lane; storing
+    // those lanes in a branch of their own cost 3.5-5 % of the kernel).
+    if (QREADY && raw && restore.x == in.x) {
+      // the lean kernels still hold the whole incoming record: nothing to fetch. One lane
+      // of a wave asking for its record again pulls 13 lines of 128 B, by then evicted from
+      // the L2, out of HBM: the kernel read 1.27 GB per 1e7 rays instead of 1.00 GB (PMC
+      // FETCH_SIZE 618 800 -> 489 263 KB with this branch)
+      x = raw->x;
+      y = raw->y;
+      z = raw->z;
+      la = raw->a;
+      lbb = raw->b;
+      lc = raw->c;
+    } else {
     x = restore.x[i];
     y = restore.y[i];
     z = restore.z[i];
@@ -2438,6 +2451,7 @@ __device__ __forceinline__ Completed complete_ray(
       vEsi = es.y;
       vEpr = ep.x;
       vEpi = ep.y;
+    }
     }
     if (P.force_lost_out) vst = P.lost_num;
   } else {
@@ -2549,7 +2563,8 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   // position and direction are requested together with the state, not after it has
   // been looked at: one memory round trip instead of two (nearly every ray enters)
   const int st0 = i < in.n ? in.state[i] : 0;
-  LocalRay r = load_local(P, in, i < in.n ? i : 0);
+  LocalRay raw;
+  LocalRay r = load_local(P, in, i < in.n ? i : 0, early_fields<K>() ? &raw : nullptr);
   const bool active = i < in.n && entering(P, st0);
   // Fresnel coatings: the refractive index now, so that its table look-up (dependent
   // loads) is in flight during the root solve
@@ -2599,7 +2614,7 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
 #ifndef XRT_LATE_FIELDS
       if (early_fields<K>())
         complete_ray<K, true>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 0,
-                              nullptr, qpre, NPRE ? &npre : nullptr);
+                              nullptr, qpre, NPRE ? &npre : nullptr, &raw);
       else
 #endif
       complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 0, nullptr,
