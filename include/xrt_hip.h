@@ -151,9 +151,12 @@ typedef struct xrt_hip_rotation {
 #define XRT_HIP_SURF_BENT_BRAGG 8  /* bent crystal analysers, oes/bragg.py:104-343. surf_p[0] =
                                      shape: 0 cylinder with a circular cross section (Johann /
                                      JohanssonCylinder), 1 parabolic cylinder, 2 toroid (Johann /
-                                     Johansson / GeneralBraggToroid); [1] = atomic planes: 0 follow
-                                     the surface (Johann; turned by alpha), 1 ground (Johansson:
-                                     planes of twice the radius), 2 their own radii (General);
+                                     Johansson / GeneralBraggToroid), 3 sphere, 4 paraboloid
+                                     (BentLaueSphere, oes/laue.py:478-507); [1] = atomic planes: 0
+                                     follow the surface (Johann; turned by alpha), 1 ground
+                                     (Johansson: planes of twice the radius), 2 their own radii
+                                     (General), 3 across the surface (BentLaueCylinder /
+                                     BentLaueSphere), 4 across, ground (GroundBentLaueCylinder);
                                      [2] Rm, [3] Rs, [4] cos(alpha), [5] sin(alpha), [6] alpha
                                      given (!= 0), [7] RmBragg, [8] RsBragg. The pass's
                                      `asymmetric` flag says whether the two normals differ. */

@@ -159,6 +159,16 @@ def load_case(name):
         p['surface'] = rn.make_cone(float(g['surf_L0']), float(g['surf_theta']))
         p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,
                                          'mirror', float(g['mat_rho']))
+    elif name.startswith('g3_bent_laue'):
+        cls = str(g['surf_class'])
+        alpha = float(g['surf_alpha'])
+        p['surface'] = dict(kind='laue_sphere' if 'Sphere' in cls else 'bent_cylinder',
+                            Rm=float(g['surf_Rm']), alpha=alpha if alpha else None,
+                            planes='laue_ground' if 'Ground' in cls else 'laue',
+                            crossSection=str(g['surf_crossSection']))
+        si = mn.load_element(tb, 'Si')
+        p['material'] = mn.make_crystal(si, (1, 1, 1), float(g['cr_d']), 'diamond',
+                                        'Laue reflected', float(g['cr_t']), 1., float(g['cr_V']))
     elif name.startswith('g3_bent_'):
         cls = str(g['surf_class'])
         planes = 'general' if 'General' in cls else 'johansson' if 'Johansson' in cls \

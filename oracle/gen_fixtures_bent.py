@@ -39,6 +39,24 @@ CASES = (
 )
 
 
+# bent crystals in Laue geometry (oes/laue.py:26-227, 455-507): Si(111) 'Laue reflected', 0.1 mm
+LAUE_CASES = (
+    ('g3_bent_laue_cyl', 'BentLaueCylinder', dict(R=3000.), 'laue'),
+    ('g3_bent_laue_cyl_circ_asym', 'BentLaueCylinder',
+     dict(R=2500., crossSection='circular', alpha=np.radians(6.)), 'laue'),
+    ('g3_bent_laue_ground', 'GroundBentLaueCylinder',
+     dict(R=2000., crossSection='circular', alpha=np.radians(-4.)), 'laue_ground'),
+    ('g3_bent_laue_sphere', 'BentLaueSphere', dict(R=4000., crossSection='circular'), 'laue'),
+    ('g3_bent_laue_paraboloid', 'BentLaueSphere', dict(R=4000.), 'laue'),
+)
+
+
+def laue_surface_of(cls_name, kw, planes):
+    return dict(kind='laue_sphere' if 'Sphere' in cls_name else 'bent_cylinder', Rm=kw['R'],
+                planes=planes, alpha=kw.get('alpha'),
+                crossSection=kw.get('crossSection', 'parabolic'))
+
+
 def surface_of(cls_name, kw, planes, thB):
     rs_ = RM * np.sin(thB)**2
     surf = dict(kind='bent_toroid' if 'Toroid' in cls_name else 'bent_cylinder', Rm=RM,
@@ -86,6 +104,27 @@ def main():
                        surf_crossSection=np.array(surf['crossSection']),
                        cr_d=np.array(si.d), cr_chiToF=np.array(si.chiToF),
                        cr_V=np.array(si.V), **extra)
+    for seed, (tag, cls_name, kw, planes) in enumerate(LAUE_CASES):
+        bl = raycing.BeamLine()
+        si = rm.CrystalSi(hkl=(1, 1, 1), geom='Laue reflected', t=0.1)
+        alpha = kw.get('alpha')
+        thB = si.get_Bragg_angle(E0) - si.get_dtheta(E0, alpha)
+        thB = float(thB[0] if np.ndim(thB) else thB)
+        oe = getattr(roe, cls_name)(bl, 'bl', center=[0, 10000., 0],
+                                    pitch=thB + (alpha if alpha else 0) + np.pi/2, material=si,
+                                    limPhysX=[-5, 5], limPhysY=[-1.5, 1.8], **kw)
+        beam = g1.make_rays(rs, n, 190 + seed, sx=0.6, sz=0.5, sa=3e-5, sc=3e-5,
+                            E=(E0 - 1., E0 + 1.), amplitudes=True, pol='mixed')
+        beam.state[2] = 2
+        beam.state[3] = -3
+        surf = laue_surface_of(cls_name, kw, planes)
+        par = g1.oe_params(oe, surf)
+        par['material'] = g1.crystal_dict(tables, si)
+        g1.run_reflect(tag, rs, oe, par, beam, surf_class=np.array(cls_name),
+                       surf_crossSection=np.array(surf['crossSection']),
+                       surf_Rm=np.array(kw['R']), surf_alpha=np.array(alpha if alpha else 0.),
+                       cr_d=np.array(si.d), cr_chiToF=np.array(si.chiToF), cr_V=np.array(si.V),
+                       cr_t=np.array(0.1))
 
 
 if __name__ == '__main__':

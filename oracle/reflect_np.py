@@ -232,6 +232,10 @@ def local_z(surf, x, y):
         z[z > 0] = 0.
         z += (y**2 - surf['y0']**2) / 2.0 / surf['R']
         return z
+    if surf['kind'] == 'laue_sphere':             # BentLaueSphere.local_z, laue.py:487-491
+        if surf['crossSection'].startswith('circ'):
+            return surf['Rm'] - np.sqrt(surf['Rm']**2 - x**2 - y**2)
+        return (x**2+y**2) / 2.0 / surf['Rm']
     if surf['kind'] == 'bent_cylinder':           # Johann/JohanssonCylinder, bragg.py:138-144
         if surf['crossSection'].startswith('circ'):
             sq = surf['Rm']**2 - y**2
@@ -469,6 +473,36 @@ def local_n(surf, x, y):
         b = -y / surf['R']
         norm = (a**2 + b**2 + 1)**0.5
         return [a/norm, b/norm, 1./norm]
+    if surf['kind'] == 'laue_sphere':             # laue.py:493-507
+        R = surf['Rm']
+        if surf['crossSection'].startswith('circ'):
+            a = -x * (R**2 - x**2 - y**2)**(-0.5)
+            b = -y * (R**2 - x**2 - y**2)**(-0.5)
+        else:
+            a = -x / R
+            b = -y / R
+        c = 1.
+        norm = (a**2 + b**2 + 1)**0.5
+        aB = 0.
+        bB = c
+        cB = -b
+        normB = (b**2 + c**2)**0.5
+        return [aB/normB, bB/normB, cB/normB, a/norm, b/norm, c/norm]
+    if surf['kind'] == 'bent_cylinder' and surf['planes'] in ('laue', 'laue_ground'):
+        alpha = surf.get('alpha')                 # laue.py:153-173, 457-470
+        nS = _n_bent_cylinder(surf, x, y, surf['Rm'], None)
+        a, b, c = nS
+        if surf['planes'] == 'laue_ground':
+            b = -y
+            c = (surf['Rm']**2 - y**2)**0.5 + surf['Rm']
+        if alpha:
+            bB, cB = rotate_x(b, c, -np.sin(alpha), -np.cos(alpha))
+        else:
+            bB, cB = c, -b
+        if surf['planes'] == 'laue_ground':
+            norm = np.sqrt(bB**2 + cB**2)
+            return [a/norm, bB/norm, cB/norm, nS[-3], nS[-2], nS[-1]]
+        return [a, bB, cB, nS[0], nS[1], nS[2]]
     if surf['kind'] == 'bent_cylinder':           # bragg.py:146-197
         nSurf = _n_bent_cylinder(surf, x, y, surf['Rm'], surf.get('alpha'))
         if surf['planes'] == 'johann':

@@ -192,6 +192,13 @@ def product_oe(name, g):
         m = rm.Material('Rh', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.ConicalMirror(bl, 'cone', L0=float(g['surf_L0']),
                                theta=float(g['surf_theta']), material=m, **common)
+    elif name.startswith('g3_bent_laue'):
+        si = rm.CrystalSi(hkl=(1, 1, 1), geom='Laue reflected', t=float(g['cr_t']))
+        assert si.d == float(g['cr_d']) and si.chiToF == float(g['cr_chiToF'])
+        alpha = float(g['surf_alpha'])
+        oe = getattr(roe, str(g['surf_class']))(
+            bl, 'bl', material=si, R=float(g['surf_Rm']), alpha=alpha if alpha else None,
+            crossSection=str(g['surf_crossSection']), **common)
     elif name.startswith('g3_bent_'):
         si = rm.CrystalSi(hkl=(1, 1, 1))
         assert si.d == float(g['cr_d']) and si.chiToF == float(g['cr_chiToF'])

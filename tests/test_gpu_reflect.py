@@ -691,12 +691,16 @@ def test_laterally_graded_multilayer_is_refused():
 @pytest.mark.parametrize('name', ['g3_bent_johann_cyl', 'g3_bent_johann_parab_asym',
                                   'g3_bent_johansson_cyl', 'g3_bent_johann_tor',
                                   'g3_bent_johann_tor_asym', 'g3_bent_johansson_tor',
-                                  'g3_bent_general_tor'])
+                                  'g3_bent_general_tor', 'g3_bent_laue_cyl',
+                                  'g3_bent_laue_cyl_circ_asym', 'g3_bent_laue_ground',
+                                  'g3_bent_laue_sphere', 'g3_bent_laue_paraboloid'])
 def test_bent_crystal_analysers_match_reference_golden(name):
     """Johann / Johansson cylinders and toroids, GeneralBraggToroid: surface in the
     reference's operation order (states bit-exact), the two normals per point (atomic
     planes: following the surface, ground, or with radii of their own; asymmetric cut),
-    a divergent source on the Rowland circle."""
+    a divergent source on the Rowland circle; the bent Laue crystals (BentLaueCylinder,
+    GroundBentLaueCylinder, BentLaueSphere: planes across the surface) in a collimated
+    beam."""
     g = pc.load(name)
     oe = pc.product_oe(name, g)
     info = {}

@@ -792,8 +792,8 @@ class _BentBragg(_Curved):
 
     def _surface_params(self, p, second=False):
         shape = self._shape
-        if shape == 0 and self.crossSection.startswith('parab'):
-            shape = 1
+        if shape in (0, 3) and self.crossSection.startswith('parab'):
+            shape += 1
         tilt = self.alpha if self.alpha else 0.
         Rs = getattr(self, 'Rs', 0.)
         self._curved(p, _structs.SURF_BENT_BRAGG,
@@ -820,6 +820,37 @@ class JohanssonCylinder(JohannCylinder):
     """Bent and ground: atomic planes of radius 2 Rm under a surface of radius Rm
     (bragg.py:179-197)."""
     _planes = 1
+
+
+class BentLaueCylinder(JohannCylinder):
+    """Cylindrically bent crystal in Laue geometry (du Mond): the diffracting planes stand
+    across the surface, turned by *alpha*; meridional radius *R* (a number or (p, q) for
+    the Coddington radius), *crossSection* 'parabolic' (default) or 'circular' (reference
+    oes/laue.py:26-227). The volumetric-diffraction and bent-crystal (TT) amplitude models
+    of the reference are not on the GPU path (the material says so)."""
+    _planes = 3
+
+    def __init__(self, *args, **kwargs):
+        bend = kwargs.pop('R', 1.0e4)
+        kwargs.setdefault('crossSection', 'parabolic')
+        JohannCylinder.__init__(self, *args, **kwargs)
+        self.R = bend
+
+    R = property(lambda self: self._RVal,
+                 lambda self, v: setattr(self, '_RVal',
+                                         np.inf if v in (None, 0) else
+                                         _radius(v, self.get_Rmer_from_Coddington)))
+    Rm = property(lambda self: self.R, lambda self, v: None)
+
+
+class GroundBentLaueCylinder(BentLaueCylinder):
+    """Bent and ground Laue crystal (laue.py:455-475)."""
+    _planes = 4
+
+
+class BentLaueSphere(BentLaueCylinder):
+    """Spherically (or paraboloidally) bent Laue crystal (laue.py:478-507)."""
+    _shape = 3
 
 
 class JohannToroid(_BentBragg):

@@ -436,6 +436,8 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
   if (bent_crystal_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {  // oes/bragg.py:138-144, 236-241
     const double Rm = P.surf_p[2], Rs = P.surf_p[3];
     if (P.surf_p[0] == 1.) return y * y / 2.0 / Rm;
+    if (P.surf_p[0] == 3.) return Rm - sqrt((Rm * Rm - x * x) - y * y);   // laue.py:488-489
+    if (P.surf_p[0] == 4.) return (x * x + y * y) / 2.0 / Rm;             // :491
     const double root = sqrt(Rm * Rm - y * y);
     if (P.surf_p[0] == 0.) return Rm - root;
     // toroid: the meridional circle turned about the sagittal axis
@@ -1884,6 +1886,25 @@ __device__ __forceinline__ void bent_bragg_normals(const xrt_hip_pass& P, double
   const bool tilted = P.surf_p[6] != 0.;
   const double root = sqrt(Rm * Rm - y * y);
   double cosang = 1., sinang = 0.;
+  if (shape >= 3) {  // BentLaueSphere, laue.py:493-507: planes across the surface
+    double a, b;
+    if (shape == 3) {
+      const double inv = 1. / sqrt((Rm * Rm - x * x) - y * y);
+      a = -x * inv;
+      b = -y * inv;
+    } else {
+      a = -x / Rm;
+      b = -y / Rm;
+    }
+    const double norm = sqrt(a * a + b * b + 1.), normB = sqrt(b * b + 1.);
+    n[0] = 0.;
+    n[1] = 1. / normB;
+    n[2] = -b / normB;
+    n[3] = a / norm;
+    n[4] = b / norm;
+    n[5] = 1. / norm;
+    return;
+  }
   if (shape == 2) {
     bent_toroid_normal(x, y, Rm, Rs, n[3], n[4], n[5], cosang, sinang);
   } else {  // cylinder, :146-166
@@ -1938,9 +1959,28 @@ __device__ __forceinline__ void bent_bragg_normals(const xrt_hip_pass& P, double
     n[0] = a;
     n[1] = b;
     n[2] = c;
-  } else {  // planes with their own radii, :336-342
+  } else if (planes == 2) {  // planes with their own radii, :336-342
     double cb, sb;
     bent_toroid_normal(x, y, P.surf_p[7], P.surf_p[8], n[0], n[1], n[2], cb, sb);
+  } else {
+    // Laue: the planes stand across the surface -- the surface normal (planes == 3,
+    // BentLaueCylinder, laue.py:153-173) or the radial direction of twice the radius
+    // (planes == 4, GroundBentLaueCylinder, :457-470) turned by 90 deg + alpha about x:
+    // rotate_x(b, c, -sin(alpha), -cos(alpha)), without alpha (c, -b)
+    double b = n[4], c = n[5];
+    if (planes == 4) {
+      b = -y;
+      c = root + Rm;
+    }
+    double bB = c, cB = -b;
+    if (tilted) {
+      bB = -sa * b + ca * c;
+      cB = -ca * b - sa * c;
+    }
+    const double norm = planes == 4 ? sqrt(bB * bB + cB * cB) : 1.;
+    n[0] = 0.;
+    n[1] = bB / norm;
+    n[2] = cB / norm;
   }
 }
 
