@@ -168,6 +168,13 @@ typedef struct xrt_hip_rotation {
                                      by side (x >= 0: r1 about x1, sunk by h1; x < 0: r2, x2, h2),
                                      nowhere above z = 0: surf_p = r1 - h1, r1^2, x1, r2 - h2,
                                      r2^2, x2, limPhysY[0]^2, R */
+#define XRT_HIP_SURF_DICED 11      /* DicedOE / DicedJohannToroid / DicedJohanssonToroid,
+                                     oes/bragg.py:8-101, 345-375: flat facets (or, Johansson,
+                                     facets ground to Rm) tangent to the base surface at the facet
+                                     centres, gaps between them absorb. surf_p = base (0 flat, 2
+                                     toroid), planes (0 Johann, 1 Johansson), Rm, Rs, cos(alpha),
+                                     sin(alpha), alpha given, xStep, yStep, dxFacet / 2,
+                                     dyFacet / 2 */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_SHAPE_POLYGON 2   /* optical surface outlined by a polygon in the local (x, y)

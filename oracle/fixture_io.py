@@ -159,6 +159,18 @@ def load_case(name):
         p['surface'] = rn.make_cone(float(g['surf_L0']), float(g['surf_theta']))
         p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,
                                          'mirror', float(g['mat_rho']))
+    elif name.startswith('g3_diced_'):
+        cls = str(g['surf_class'])
+        alpha = float(g['surf_alpha'])
+        surf = dict(kind='diced', base='flat' if cls == 'DicedOE' else 'toroid',
+                    planes='johansson' if 'Johansson' in cls else 'johann',
+                    alpha=alpha if alpha else None, crossSection='circular')
+        for key in ('Rm', 'Rs', 'RmBragg', 'RsBragg', 'xStep', 'yStep', 'dxFacet', 'dyFacet'):
+            surf[key] = float(g['surf_' + key])
+        p['surface'] = surf
+        si = mn.load_element(tb, 'Si')
+        p['material'] = mn.make_crystal(si, (1, 1, 1), float(g['cr_d']), 'diamond',
+                                        'Bragg reflected', None, 1., float(g['cr_V']))
     elif name.startswith('g3_bent_laue'):
         cls = str(g['surf_class'])
         alpha = float(g['surf_alpha'])

@@ -51,6 +51,27 @@ LAUE_CASES = (
 )
 
 
+# diced elements (oes/bragg.py:8-101, 345-375)
+DICED_CASES = (
+    ('g3_diced_flat', 'DicedOE', dict(dxFacet=2.1, dyFacet=1.4, dxGap=0.3, dyGap=0.2,
+                                      alpha=np.radians(1.5)), 'johann'),
+    ('g3_diced_johann_tor', 'DicedJohannToroid', dict(Rs='sagittal', dxFacet=1.8, dyFacet=2.5,
+                                                      dxGap=0.2, dyGap=0.25), 'johann'),
+    ('g3_diced_johansson_tor', 'DicedJohanssonToroid',
+     dict(Rs='sagittal', alpha=np.radians(2.), dxFacet=3., dyFacet=4., dxGap=0.1, dyGap=0.3),
+     'johansson'),
+)
+
+
+def diced_surface_of(cls_name, kw, planes, thB):
+    surf = dict(kind='diced', base='flat' if cls_name == 'DicedOE' else 'toroid', planes=planes,
+                alpha=kw.get('alpha'), Rm=RM, Rs=RM * np.sin(thB)**2, crossSection='circular',
+                xStep=kw['dxFacet'] + kw['dxGap'], yStep=kw['dyFacet'] + kw['dyGap'],
+                dxFacet=kw['dxFacet'], dyFacet=kw['dyFacet'])
+    surf['RmBragg'], surf['RsBragg'] = surf['Rm'], surf['Rs']
+    return surf
+
+
 def laue_surface_of(cls_name, kw, planes):
     return dict(kind='laue_sphere' if 'Sphere' in cls_name else 'bent_cylinder', Rm=kw['R'],
                 planes=planes, alpha=kw.get('alpha'),
@@ -102,6 +123,31 @@ def main():
                  if k not in ('kind', 'planes', 'crossSection')}
         g1.run_reflect(tag, rs, oe, par, beam, surf_class=np.array(cls_name),
                        surf_crossSection=np.array(surf['crossSection']),
+                       cr_d=np.array(si.d), cr_chiToF=np.array(si.chiToF),
+                       cr_V=np.array(si.V), **extra)
+    for seed, (tag, cls_name, kw, planes) in enumerate(DICED_CASES):
+        bl = raycing.BeamLine()
+        si = rm.CrystalSi(hkl=(1, 1, 1))
+        thB = float(si.get_Bragg_angle(E0))
+        surf = diced_surface_of(cls_name, kw, planes, thB)
+        args = {k: v for k, v in kw.items() if k != 'Rs'}
+        flat = cls_name == 'DicedOE'
+        if not flat:
+            args.update(Rs=surf['Rs'], Rm=RM)
+        alpha = kw.get('alpha') or 0.
+        p = RM * np.sin(thB + alpha)
+        oe = getattr(roe, cls_name)(bl, 'dc', center=[0, p, 0], pitch=thB + alpha, material=si,
+                                    limPhysX=[-12, 12], limPhysY=[-35, 35], **args)
+        spread = 1e-5 if flat else 1.5e-2
+        size = 2.5 if flat else 0.02
+        beam = g1.make_rays(rs, n, 210 + seed, sx=size, sz=size, sa=spread, sc=spread,
+                            E=(E0 - 2., E0 + 2.), amplitudes=True, pol='mixed')
+        beam.state[1] = 2
+        par = g1.oe_params(oe, surf)
+        par['material'] = g1.crystal_dict(tables, si)
+        extra = {'surf_' + k: np.array(v if v is not None else 0.) for k, v in surf.items()
+                 if k not in ('kind', 'planes', 'crossSection', 'base')}
+        g1.run_reflect(tag, rs, oe, par, beam, surf_class=np.array(cls_name),
                        cr_d=np.array(si.d), cr_chiToF=np.array(si.chiToF),
                        cr_V=np.array(si.V), **extra)
     for seed, (tag, cls_name, kw, planes) in enumerate(LAUE_CASES):

@@ -232,6 +232,10 @@ def local_z(surf, x, y):
         z[z > 0] = 0.
         z += (y**2 - surf['y0']**2) / 2.0 / surf['R']
         return z
+    if surf['kind'] == 'diced':                   # DicedOE.local_z, bragg.py:52-65
+        fx, fy, cz, cn = _diced_facet(surf, x, y)
+        dz = fy**2 / 2.0 / surf['Rm'] if surf['planes'] == 'johansson' else np.zeros_like(fx)
+        return cz + (dz - cn[-3]*fx - cn[-2]*fy) / cn[-1]
     if surf['kind'] == 'laue_sphere':             # BentLaueSphere.local_z, laue.py:487-491
         if surf['crossSection'].startswith('circ'):
             return surf['Rm'] - np.sqrt(surf['Rm']**2 - x**2 - y**2)
@@ -378,6 +382,17 @@ def local_r(surf, s, phi):        # parametric.py:225-231, 450-458, 690-696
     return np.where(abs(phi) > np.pi/2, r, np.ones_like(phi)*1e20)
 
 
+def _diced_facet(surf, x, y):
+    """DicedOE.local_z(skipReturnZ) + facet_center_z / facet_center_n, bragg.py:52-60,
+    353-362: facet coordinates, height and normal(s) of the base surface at the centre."""
+    cx = (x / surf['xStep']).round() * surf['xStep']
+    cy = (y / surf['yStep']).round() * surf['yStep']
+    if surf['base'] == 'flat':
+        return x - cx, y - cy, np.zeros_like(cy), [0, 0, 1]
+    base = dict(surf, kind='bent_toroid')
+    return x - cx, y - cy, local_z(base, cx, cy), local_n(base, cx, cy)
+
+
 def _n_bent_cylinder(surf, x, y, R, alpha):      # JohannCylinder.local_n_cylinder
     a = np.zeros_like(x)
     b = -y / R
@@ -473,6 +488,23 @@ def local_n(surf, x, y):
         b = -y / surf['R']
         norm = (a**2 + b**2 + 1)**0.5
         return [a/norm, b/norm, 1./norm]
+    if surf['kind'] == 'diced':                   # DicedOE.local_n, bragg.py:67-90
+        fx, fy, cz, cn = _diced_facet(surf, x, y)
+        cn = [np.array(v, dtype=float) * np.ones_like(fx) for v in cn]
+        if surf['planes'] == 'johansson':         # facet_delta_n, bragg.py:367-372
+            b = -fy / surf['Rm']
+            norm = (b**2 + 1)**0.5
+            cn[-1] = cn[-1] + 1./norm
+            cn[-2] = cn[-2] + b/norm
+            norm = (cn[-1]**2 + cn[-2]**2 + cn[-3]**2)**0.5
+            cn[-1] = cn[-1] / norm
+            cn[-2] = cn[-2] / norm
+            cn[-3] = cn[-3] / norm
+        alpha = surf.get('alpha')
+        if alpha:
+            bAlpha, cAlpha = rotate_x(cn[1], cn[2], np.cos(alpha), -np.sin(alpha))
+            return [cn[0], bAlpha, cAlpha, cn[-3], cn[-2], cn[-1]]
+        return cn
     if surf['kind'] == 'laue_sphere':             # laue.py:493-507
         R = surf['Rm']
         if surf['crossSection'].startswith('circ'):
@@ -1080,6 +1112,12 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
         lb.state[good], gNormal = fzp_rays_good_gn(oe, tX, tY)
     else:
         lb.state[good] = rays_good(oe, tX, tY, is2ndXtal)
+        if surf['kind'] == 'diced':               # DicedOE.rays_good, bragg.py:92-101
+            fx, fy = _diced_facet(surf, tX, tY)[:2]
+            inGaps = (abs(fx) > surf['dxFacet']/2) | (abs(fy) > surf['dyFacet']/2)
+            st = lb.state[good]
+            st[inGaps] = oe['lostNum']
+            lb.state[good] = st
     if _lost is not None:
         lb.state[np.where(good)[0][_lost]] = oe['lostNum']
 

@@ -192,6 +192,18 @@ def product_oe(name, g):
         m = rm.Material('Rh', rho=float(g['mat_rho']), kind='mirror')
         oe = roe.ConicalMirror(bl, 'cone', L0=float(g['surf_L0']),
                                theta=float(g['surf_theta']), material=m, **common)
+    elif name.startswith('g3_diced_'):
+        si = rm.CrystalSi(hkl=(1, 1, 1))
+        cls = str(g['surf_class'])
+        alpha = float(g['surf_alpha'])
+        dx, dy = float(g['surf_dxFacet']), float(g['surf_dyFacet'])
+        kw = dict(dxFacet=dx, dyFacet=dy, dxGap=float(g['surf_xStep']) - dx,
+                  dyGap=float(g['surf_yStep']) - dy)
+        if cls != 'DicedOE':
+            kw.update(Rm=float(g['surf_Rm']), Rs=float(g['surf_Rs']))
+        oe = getattr(roe, cls)(bl, 'dc', material=si, alpha=alpha if alpha else None, **kw,
+                               **common)
+        assert oe.xStep == float(g['surf_xStep']) and oe.yStep == float(g['surf_yStep'])
     elif name.startswith('g3_bent_laue'):
         si = rm.CrystalSi(hkl=(1, 1, 1), geom='Laue reflected', t=float(g['cr_t']))
         assert si.d == float(g['cr_d']) and si.chiToF == float(g['cr_chiToF'])

@@ -693,14 +693,17 @@ def test_laterally_graded_multilayer_is_refused():
                                   'g3_bent_johann_tor_asym', 'g3_bent_johansson_tor',
                                   'g3_bent_general_tor', 'g3_bent_laue_cyl',
                                   'g3_bent_laue_cyl_circ_asym', 'g3_bent_laue_ground',
-                                  'g3_bent_laue_sphere', 'g3_bent_laue_paraboloid'])
+                                  'g3_bent_laue_sphere', 'g3_bent_laue_paraboloid',
+                                  'g3_diced_flat', 'g3_diced_johann_tor',
+                                  'g3_diced_johansson_tor'])
 def test_bent_crystal_analysers_match_reference_golden(name):
     """Johann / Johansson cylinders and toroids, GeneralBraggToroid: surface in the
     reference's operation order (states bit-exact), the two normals per point (atomic
     planes: following the surface, ground, or with radii of their own; asymmetric cut),
     a divergent source on the Rowland circle; the bent Laue crystals (BentLaueCylinder,
     GroundBentLaueCylinder, BentLaueSphere: planes across the surface) in a collimated
-    beam."""
+    beam; the diced elements (DicedOE, DicedJohannToroid, DicedJohanssonToroid: facets
+    tangent to the base surface, rays in the gaps absorbed)."""
     g = pc.load(name)
     oe = pc.product_oe(name, g)
     info = {}
@@ -719,7 +722,9 @@ def test_bent_crystal_analysers_match_reference_golden(name):
         assert np.abs(m - r).max() < 1e-15
     hit = g['lb_state'] == 1
     flux = (lb.Jss + lb.Jpp)[hit] / (g['in_Jss'] + g['in_Jpp'])[hit]
-    assert flux.max() > 0.2       # some rays sit on or near the rocking curve
+    if name != 'g3_diced_johansson_tor':   # (there the reference turns the tilted plane normal
+        # by alpha twice and sagittally twice: every ray is far off the rocking curve)
+        assert flux.max() > 0.2       # some rays sit on or near the rocking curve
 
 
 # ---- crystals given by their unit cell (crystals_basic.py:157-440) ------------------

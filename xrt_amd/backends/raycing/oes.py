@@ -893,6 +893,47 @@ class GeneralBraggToroid(JohannToroid):
                        lambda self, v: setattr(self, '_RsBragg', v))
 
 
+class DicedOE(_BentBragg):
+    """Flat element cut into facets *dxFacet* x *dyFacet* with gaps *dxGap*, *dyGap* between
+    them; the gaps absorb (reference oes/bragg.py:8-101). Base of the diced analysers."""
+    _base = 0          # 0 flat, 2 toroid
+
+    def __init__(self, *args, **kwargs):
+        self._dice(kwargs)
+        OE.__init__(self, *args, **kwargs)
+
+    def _dice(self, kwargs):
+        self.dxFacet, self.dyFacet = kwargs.pop('dxFacet', 2.1), kwargs.pop('dyFacet', 1.4)
+        self.dxGap, self.dyGap = kwargs.pop('dxGap', 0.05), kwargs.pop('dyGap', 0.05)
+        self.xStep, self.yStep = self.dxFacet + self.dxGap, self.dyFacet + self.dyGap
+
+    def local_n(self, x, y):
+        both = self._eval_surface(_SURF_N, x, y)
+        return both if self._planes or self.alpha else both[3:]
+
+    def _surface_params(self, p, second=False):
+        tilt = self.alpha if self.alpha else 0.
+        self._curved(p, _structs.SURF_DICED,
+                     (self._base, self._planes, getattr(self, 'Rm', 0.), getattr(self, 'Rs', 0.),
+                      np.cos(tilt), np.sin(tilt), 1. if self.alpha else 0., self.xStep,
+                      self.yStep, self.dxFacet / 2, self.dyFacet / 2))
+        p.asymmetric = 1 if self._planes or self.alpha else 0
+
+
+class DicedJohannToroid(DicedOE, JohannToroid):
+    """Flat facets tangent to a Johann toroid at their centres (bragg.py:345-359)."""
+    _base = 2
+
+    def __init__(self, *args, **kwargs):
+        self._dice(kwargs)
+        JohannToroid.__init__(self, *args, **kwargs)
+
+
+class DicedJohanssonToroid(DicedJohannToroid, JohanssonToroid):
+    """Facets ground to the meridional radius, atomic planes of the Johansson toroid
+    (bragg.py:362-375)."""
+
+
 class BlazedGrating(_Curved):
     """Saw-tooth grating of constant line density for WAVE propagation: the
     diffraction comes from the surface itself through the Kirchhoff integral,

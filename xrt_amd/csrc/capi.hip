@@ -273,7 +273,7 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
   if (pass->to_local.n < 0 || pass->to_local.n > XRT_HIP_MAX_ROT || pass->to_virgin.n < 0 ||
       pass->to_virgin.n > XRT_HIP_MAX_ROT)
     return fail(XRT_HIP_ERR_ARG, "rotation sequence longer than %d", XRT_HIP_MAX_ROT);
-  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_DUALVFM)
+  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_DICED)
     return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
   if (material->kind == XRT_HIP_MAT_CRYSTAL && material->structure == 2 && !material->cell)
     return fail(XRT_HIP_ERR_ARG, "crystal from a unit cell without its xrt_hip_cell record");
@@ -286,7 +286,8 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
       return fail(XRT_HIP_ERR_ARG, "grating equation on a multilayer material");
   }
   if (pass->surf_kind >= XRT_HIP_SURF_BLAZED && pass->surf_kind != XRT_HIP_SURF_SAGITTAL &&
-      pass->surf_kind != XRT_HIP_SURF_BENT_BRAGG && material->kind == XRT_HIP_MAT_CRYSTAL)
+      pass->surf_kind != XRT_HIP_SURF_BENT_BRAGG && pass->surf_kind != XRT_HIP_SURF_DICED &&
+      material->kind == XRT_HIP_MAT_CRYSTAL)
     return fail(XRT_HIP_ERR_ARG, "crystals on blazed / parametric surfaces are not supported");
   if (pass->grating && (pass->grating_axis < -1 || pass->grating_axis > 1 ||
                         pass->g_ncoef < 0 || pass->g_ncoef > 8))
@@ -499,7 +500,7 @@ int xrt_hip_surface_eval_f64_dev(const xrt_hip_pass* pass, int what, int64_t n, 
   if (n == 0) return XRT_HIP_OK;
   if (!u || !v || !out || ((what == 3 || what == 4) && !w))
     return fail(XRT_HIP_ERR_ARG, "NULL array");
-  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_DUALVFM)
+  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_DICED)
     return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
   HIP_TRY(xrt::surface_eval_launch(*pass, what, n, u, v, w, out,
                                    reinterpret_cast<hipStream_t>(stream)));

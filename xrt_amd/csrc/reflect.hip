@@ -389,6 +389,73 @@ __device__ __forceinline__ double ell_local_r(const xrt_hip_pass& P, double s, d
   return fabs(phi) > kPI / 2. ? r : 1e20;
 }
 
+// Diced elements (oes/bragg.py:8-101, 345-375): the facet a point lies on -- its centre
+// (numpy's round: half to even), the point in facet coordinates, the height of the base
+// surface and the base normals at the centre (cn[0..2] atomic planes, cn[3..5] surface).
+struct Facet {
+  double fx, fy, cz;
+  double cn[6];
+};
+__device__ __forceinline__ Facet diced_facet(const xrt_hip_pass& P, double x, double y) {
+  Facet f;
+  const double cx = rint(x / P.surf_p[7]) * P.surf_p[7];
+  const double cy = rint(y / P.surf_p[8]) * P.surf_p[8];
+  f.fx = x - cx;
+  f.fy = y - cy;
+  if (P.surf_p[0] == 0.) {  // flat
+    f.cz = 0.;
+    f.cn[0] = f.cn[3] = 0.;
+    f.cn[1] = f.cn[4] = 0.;
+    f.cn[2] = f.cn[5] = 1.;
+    return f;
+  }
+  const double Rm = P.surf_p[2], Rs = P.surf_p[3];
+  const double root = sqrt(Rm * Rm - cy * cy);
+  // JohannToroid.local_z / local_n_toroid at the centre, bragg.py:236-269
+  const double z = (Rm - Rs) - root;
+  f.cz = (sqrt(z * z - cx * cx) / fabs(z)) * z + Rs;
+  const double b = -cy / Rm, c0 = root / Rm;
+  const double r = Rs - (Rm - root);
+  const double cosang = sqrt(r * r - cx * cx) / r, sinang = -cx / r;
+  f.cn[3] = sinang * c0;
+  f.cn[4] = b;
+  f.cn[5] = cosang * c0;
+  if (P.surf_p[1] == 0.) {  // Johann: the planes follow the base surface
+    f.cn[0] = f.cn[3];
+    f.cn[1] = f.cn[4];
+    f.cn[2] = f.cn[5];
+    if (P.surf_p[6] != 0.) {   // (alpha of the base class, :254-266)
+      const double ca = P.surf_p[4], sa = P.surf_p[5];
+      f.cn[1] = ca * b + sa * c0;
+      const double cA = -sa * b + ca * c0;
+      f.cn[0] = sinang * cA;
+      f.cn[2] = cosang * cA;
+    }
+  } else {  // Johansson, :279-295
+    double pb = -cy, pc = root + Rm;
+    const double norm = sqrt(pb * pb + pc * pc);
+    pb /= norm;
+    pc /= norm;
+    if (P.surf_p[6] != 0.) {
+      const double ca = P.surf_p[4], sa = P.surf_p[5];
+      const double b1 = ca * pb + sa * pc;
+      pc = -sa * pb + ca * pc;
+      pb = b1;
+    }
+    double pa = sinang * pc;
+    pc = cosang * pc;
+    if (P.surf_p[6] != 0.) {
+      const double a1 = cosang * pa + sinang * pc;
+      pc = -sinang * pa + cosang * pc;
+      pa = a1;
+    }
+    f.cn[0] = pa;
+    f.cn[1] = pb;
+    f.cn[2] = pc;
+  }
+  return f;
+}
+
 // surface height, oes/base.py:675-679 (flat), oes/__init__.py:398-401 (toroid)
 template <class K>
 __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double y) {
@@ -432,6 +499,12 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
     double z = (left ? P.surf_p[3] : P.surf_p[0]) - sqrt((left ? P.surf_p[4] : P.surf_p[1]) - u * u);
     if (isnan(z) || z > 0.) z = 0.;
     return z + (y * y - P.surf_p[6]) / 2.0 / P.surf_p[7];
+  }
+  if (bent_crystal_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_DICED) {  // bragg.py:52-65
+    const Facet f = diced_facet(P, x, y);
+    // Johansson facets are ground to the meridional radius (:365-366)
+    const double dz = P.surf_p[1] == 1. ? f.fy * f.fy / 2.0 / P.surf_p[2] : 0.;
+    return f.cz + ((dz - f.cn[3] * f.fx) - f.cn[4] * f.fy) / f.cn[5];
   }
   if (bent_crystal_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {  // oes/bragg.py:138-144, 236-241
     const double Rm = P.surf_p[2], Rs = P.surf_p[3];
@@ -1352,6 +1425,10 @@ __device__ __forceinline__ int rays_good_outline(const xrt_hip_pass& P, double x
 template <class K>
 __device__ __forceinline__ int rays_good(const xrt_hip_pass& P, double x, double y) {
   const int st = rays_good_outline(P, x, y);
+  if (bent_crystal_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_DICED) {  // bragg.py:92-101
+    const Facet f = diced_facet(P, x, y);
+    return fabs(f.fx) > P.surf_p[9] || fabs(f.fy) > P.surf_p[10] ? P.lost_num : st;
+  }
   if (PGRATING(P) == 2) {  // gratings.py:123-129: opaque zones absorb
     double r, rho;
     return fzp_zone(P, x, y, r, rho) && st == 1 ? 1 : P.lost_num;
@@ -2014,6 +2091,33 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     n[0] = n[3] = -x / P.surf_p[0];
     n[1] = n[4] = 0.;
     n[2] = n[5] = sqrt(P.surf_p[1] - x * x) / P.surf_p[0];
+  } else if (bent_crystal_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_DICED) {  // bragg.py:67-90
+    Facet f = diced_facet(P, x, y);
+    const bool six = P.surf_p[1] == 1. || (P.surf_p[0] != 0. && P.surf_p[6] != 0.);
+    if (P.surf_p[1] == 1.) {   // the ground facet's own slope joins the surface normal
+      const double db = -f.fy / P.surf_p[2];
+      const double dnorm = sqrt(db * db + 1.);
+      f.cn[5] += 1. / dnorm;
+      f.cn[4] += db / dnorm;
+      const double norm = sqrt(f.cn[5] * f.cn[5] + f.cn[4] * f.cn[4] + f.cn[3] * f.cn[3]);
+      f.cn[5] /= norm;
+      f.cn[4] /= norm;
+      f.cn[3] /= norm;
+    }
+    // a three-component base normal is the surface normal and the plane normal at once
+    double pa = six ? f.cn[0] : f.cn[3], pb = six ? f.cn[1] : f.cn[4], pc = six ? f.cn[2] : f.cn[5];
+    if (P.surf_p[6] != 0.) {   // the asymmetric cut turns the plane normal (again), :84-88
+      const double ca = P.surf_p[4], sa = P.surf_p[5];
+      const double b1 = ca * pb + sa * pc;
+      pc = -sa * pb + ca * pc;
+      pb = b1;
+    }
+    n[0] = pa;
+    n[1] = pb;
+    n[2] = pc;
+    n[3] = f.cn[3];
+    n[4] = f.cn[4];
+    n[5] = f.cn[5];
   } else if (bent_crystal_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_BENT_BRAGG) {
     bent_bragg_normals(P, x, y, n);
   } else if (wide_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_VFM) {  // oes/__init__.py:469-477
