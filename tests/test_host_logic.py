@@ -298,3 +298,26 @@ def test_predefined_material_catalogues():
     assert abs(quartz.d - 2.2811) < 1e-4 and abs(quartz.rho - 2.649) < 1e-3
     for name in xcr.__all__:
         getattr(xcr, name)()
+
+
+def test_beam_files_round_trip_and_beam_from_file(tmp_path):
+    """Beam.export_beam -> Beam(copyFrom=file) in the three formats, and the BeamFromFile
+    source (sources/geoms.py:1247-1300, beams.py:122-149)."""
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.sources as rs
+    np.random.seed(3)
+    bl = raycing.BeamLine()
+    src = rs.GeometricSource(bl, 'g', nrays=500, distE='flat', energies=(8000., 9000.))
+    beam = src.shine(withAmplitudes=True)
+    beam.state[7] = -3
+    for fmt, ext in (('npy', 'npy'), ('mat', 'mat'), ('pickle', 'pickle')):
+        path = str(tmp_path / ('b.' + ext))
+        beam.export_beam(path, fmt)
+        back = rs.Beam(copyFrom=path)
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'E', 'Jss', 'Jpp', 'Jsp', 'Es', 'Ep', 'state',
+                  'path'):
+            assert np.array_equal(getattr(back, f), getattr(beam, f)), (fmt, f)
+        assert back.state.dtype == np.int32
+    again = rs.BeamFromFile(raycing.BeamLine(), 'file', fileName=str(tmp_path / 'b.npy'))
+    assert again.nrays == 500 and np.array_equal(again.shine().E, beam.E)
+    assert rs.BeamFromFile(None, 'empty').nrays == raycing.nrays

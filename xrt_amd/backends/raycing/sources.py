@@ -68,6 +68,8 @@ class Beam(object):
                 for k in _SCALAR_ATTRS:
                     if hasattr(copyFrom, k):
                         object.__setattr__(self, k, getattr(copyFrom, k))
+        elif isinstance(copyFrom, str):
+            self._load(copyFrom, bl)
         else:
             nrays = int(nrays)
             self._h['x'] = np.zeros(nrays)
@@ -90,6 +92,28 @@ class Beam(object):
             self.state[:] = forceState
         if 'parentId' not in self.__dict__:
             object.__setattr__(self, 'parentId', None)
+
+    def _load(self, path, bl=None):
+        """A beam written by ``export_beam`` (numpy 'npy' dictionary, Matlab 'mat' or
+        pickle -- by this class or by the reference's, beams.py:122-149). The elements it
+        names (``fromOE``, ``toOE``, ``parentId``) are looked up on *bl*, if given."""
+        if path.endswith('mat'):
+            import scipy.io
+            record = {k: (np.squeeze(v) if isinstance(v, np.ndarray) else v)
+                      for k, v in scipy.io.loadmat(path).items() if not k.startswith('__')}
+        elif path.endswith('npy'):
+            record = np.load(path, allow_pickle=True).item()
+        else:
+            import pickle
+            with open(path, 'rb') as f:
+                record = pickle.load(f)
+        for key, value in record.items():
+            if key in _ARRAY_FIELDS:
+                self._h[key] = np.array(value, dtype=_np_dtype(key))
+            else:
+                if key in ('fromOE', 'toOE', 'parentId') and bl is not None:
+                    value = getattr(bl, 'oesDict', {}).get(value, [value])[0]
+                object.__setattr__(self, key, value)
 
     # ---- attribute protocol ------------------------------------------------
     def __getattr__(self, name):
@@ -642,6 +666,30 @@ class CollimatedMeshSource(MeshSource):
             raycing.virgin_local_to_global(self.bl, bo, self.center)
         bo.parentId = self.uuid
         return bo
+
+
+class BeamFromFile(object):
+    """A source that hands out a beam saved earlier with ``Beam.export_beam`` (reference
+    sources/geoms.py:1247-1300): a reproducible stand-in for an expensive source."""
+
+    def __init__(self, bl=None, name='', center=(0, 0, 0), fileName=None, **kwargs):
+        _enrol_source(self, bl, name or 'BeamFromFile', kwargs.get('uuid'))
+        self.center = center
+        self.fileName = fileName
+
+    @property
+    def fileName(self):
+        return self._fileName
+
+    @fileName.setter
+    def fileName(self, path):
+        self._fileName = path
+        self.fbeam = Beam(copyFrom=path) if path is not None else Beam()
+
+    nrays = property(lambda self: np.int64(np.asarray(self.fbeam.x).size))
+
+    def shine(self):
+        return self.fbeam
 
 
 class NESWSource(MeshSource):
