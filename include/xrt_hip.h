@@ -270,6 +270,15 @@ typedef struct xrt_hip_pass {
   int32_t eff_n;
   int32_t eff_order[8];
   double eff_amp[8];
+  /* GeneralFZPin0YZ (oes/gratings.py:140-313): its zones and groove densities follow from
+   * statistics over the whole batch (the lowest path difference; per zone the largest |x|,
+   * |y| of the rays that fell into it), so the caller works them out between two passes and
+   * hands them over per ray: state_ray[i] = what a ray that hit with state 1 becomes (1 or
+   * lost_num), g_ray_x / g_ray_y = its groove vector (z component 0), used with
+   * grating = 2 and sign +1. All three DEVICE arrays of n, or all NULL. */
+  const int32_t* state_ray;
+  const double* g_ray_x;
+  const double* g_ray_y;
 } xrt_hip_pass;
 
 #define XRT_HIP_MAT_NONE 0

@@ -120,6 +120,16 @@ def load_case(name):
         p['surface'] = dict(kind='flat')
         p['surface2'] = dict(kind='flat')
         p['material'] = p['material2'] = gi.oracle_material('glass', 'plate')
+    elif name.startswith('g2_gfzp'):
+        from .gen_fixtures_fzp import GENERAL
+        from .consts import CH
+        kw = GENERAL[name]
+        p['surface'] = dict(kind='flat')
+        p['material'] = dict(kind='FZP')
+        p['order'] = 1
+        p['gfzp'] = dict(f1=kw['f1'], f2=kw['f2'], lambdaE=CH / kw['E'] * 1e-7, N=kw['N'],
+                         phaseShift=float(g['gfzp_phaseShift']), vorticity=0,
+                         grazingAngle=kw['pitch'], minHalfLambda=None)
     elif name.startswith('g2_fzp'):
         p['surface'] = dict(kind='flat')
         p['material'] = dict(kind='FZP')

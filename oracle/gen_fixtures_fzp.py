@@ -59,6 +59,42 @@ def main():
         if np_seed is not None:
             extra['np_seed'] = np_seed
         g1.run_reflect(tag, rs, fzp, par, beam, **extra)
+    general_cases(raycing, rs, roe, rm)
+
+
+# GeneralFZPin0YZ (gratings.py:140-313): zones from two foci; batch statistics inside
+GENERAL = {
+    'g2_gfzp_normal': dict(center=[0, 10., 0], pitch=np.pi/2, f1='inf', f2=(0, 0, 2.), E=400.,
+                           N=100, phaseShift=np.pi),
+    'g2_gfzp_grazing': dict(center=[0, 2000., 0], pitch=0.02,
+                            f1=(0, -2000.*np.cos(0.02), 2000.*np.sin(0.02)),
+                            f2=(0, 900.*np.cos(0.02), 900.*np.sin(0.02)), E=9000., N=200,
+                            limPhysX=[-0.5, 0.5], limPhysY=[-12, 12]),
+}
+
+
+def general_cases(raycing, rs, roe, rm):
+    for seed, (tag, kw) in enumerate(GENERAL.items()):
+        bl = raycing.BeamLine()
+        mat = rm.Material('Au', rho=19.3, kind='FZP')
+        fzp = roe.GeneralFZPin0YZ(bl, 'gfzp', material=mat, **kw)
+        if tag.endswith('normal'):
+            beam = g1.make_rays(rs, 2048, 230 + seed, sx=0.02, sz=0.02, sa=1e-6, sc=1e-6,
+                                E=(399., 401.), amplitudes=True, pol='mixed')
+        else:
+            beam = g1.make_rays(rs, 2048, 230 + seed, sx=0.05, sz=0.05, sa=2e-5, sc=2e-5,
+                                E=(8999., 9001.), amplitudes=True, pol='mixed')
+        beam.state[3] = 3
+        beam.state[4] = -4
+        par = g1.oe_params(fzp, dict(kind='flat'))
+        par['material'] = dict(kind='FZP')
+        par['order'] = 1
+        par['gfzp'] = dict(f1=kw['f1'], f2=kw['f2'], lambdaE=fzp.lambdaE, N=fzp.N,
+                           phaseShift=fzp.phaseShift, vorticity=fzp.vorticity,
+                           grazingAngle=fzp.grazingAngle, minHalfLambda=None)
+        g1.run_reflect(tag, rs, fzp, par, beam, gfzp_phaseShift=np.array(fzp.phaseShift),
+                       order=np.array(1))
+        assert par['gfzp']['minHalfLambda'] == fzp.minHalfLambda
 
 
 if __name__ == '__main__':

@@ -993,6 +993,50 @@ def fzp_rays_good_gn(oe, x, y):
     return locState, (gx, gy, gz)
 
 
+def general_fzp_rays_good_gn(oe, x, y, z):
+    """GeneralFZPin0YZ.rays_good_gn, gratings.py:249-313. oe['gfzp'] = dict(f1, f2, lambdaE,
+    N, phaseShift (as stored: divided by pi), vorticity, grazingAngle, minHalfLambda)."""
+    q = oe['gfzp']
+    locState = rays_good(oe, x, y)
+    good = locState == 1
+
+    def dist(f):
+        if isinstance(f, str):
+            return y[good] * np.cos(q['grazingAngle'])
+        d = ((x[good]-f[0])**2 + (y[good]-f[1])**2 + (z[good]-f[2])**2)**0.5
+        if len(f) > 3:
+            d *= f[3]
+        return d
+    halfLambda = (dist(q['f1'])+dist(q['f2'])) / (q['lambdaE']/2)
+    phi = np.arctan2(y[good]*np.sin(q['grazingAngle']), x[good]) / np.pi
+    if q.get('minHalfLambda') is None:
+        q['minHalfLambda'] = halfLambda.min()
+    halfLambda -= q['minHalfLambda'] + q['phaseShift'] - phi*q['vorticity']
+    N = q['N']
+    zone = np.ones_like(x, dtype=np.int32) * (N+2)
+    zone[good] = np.floor(halfLambda).astype(np.int32)
+    goodN = (zone % 2 == 0) & (zone < N) & good
+    badN = ((zone % 2 == 1) | (zone >= N)) & good
+    locState[badN] = oe['lostNum']
+    a = np.zeros(N)
+    b = np.zeros(N)
+    for i in range(1, N+1, 2):
+        if (zone == i).sum() == 0:
+            continue
+        a[i] = max(abs(x[zone == i]))
+        b[i] = max(abs(y[zone == i]))
+    gz = np.zeros_like(x[goodN])
+    r = np.sqrt(x[goodN]**2 + y[goodN]**2)
+    diva = a[zone[goodN]+1] - a[zone[goodN]-1]
+    diva[diva == 0] = 1e20
+    divb = b[zone[goodN]+1] - b[zone[goodN]-1]
+    divb[divb == 0] = 1e20
+    xy = (x[goodN]**2/diva + y[goodN]**2/divb) / r**2
+    gx = -x[goodN] * xy / r
+    gy = -y[goodN] * xy / r
+    return locState, (gx, gy, gz)
+
+
 def local_g(oe, x, y):
     """Reciprocal groove vector [1/mm] of OE.local_g (base.py:688-717):
     polynomial line density ['x'|'y', rho0, p0, p1, ...] or a constant vector."""
@@ -1108,7 +1152,9 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
     else:
         tX, tY = lb.x[good], lb.y[good]
     gNormal = None
-    if 'fzp' in oe:                               # reflect.py:706-707
+    if 'gfzp' in oe:                              # reflect.py:706-707 (use_rays_good_gn)
+        lb.state[good], gNormal = general_fzp_rays_good_gn(oe, tX, tY, lb.z[good])
+    elif 'fzp' in oe:                             # reflect.py:706-707
         lb.state[good], gNormal = fzp_rays_good_gn(oe, tX, tY)
     else:
         lb.state[good] = rays_good(oe, tX, tY, is2ndXtal)

@@ -164,6 +164,13 @@ def product_oe(name, g):
         from oracle.gen_fixtures_index import INDEX
         m = rm.Material(kind='plate', refractiveIndex=INDEX['glass'])
         oe = roe.Plate(bl, 'win', material=m, t=float(g['plate_t']), **common)
+    elif name.startswith('g2_gfzp'):
+        from oracle.gen_fixtures_fzp import GENERAL
+        kw = {k: v for k, v in GENERAL[name].items()
+              if k in ('f1', 'f2', 'E', 'N', 'phaseShift')}
+        oe = roe.GeneralFZPin0YZ(bl, 'gfzp', material=rm.Material('Au', rho=19.3, kind='FZP'),
+                                 **kw, **common)
+        assert oe.phaseShift == float(g['gfzp_phaseShift'])
     elif name.startswith('g2_fzp'):
         m = rm.Material('Au', rho=19.3, kind='FZP')
         for key in ('limPhysX', 'limPhysY'):        # the zone plate sets its own outline

@@ -813,3 +813,27 @@ def test_mirrors_on_supports_match_reference_golden(case):
     assert np.array_equal(oe.local_z(x, y), rn.local_z(p['surface'], x, y))
     for m, r in zip(oe.local_n(x, y), rn.local_n(p['surface'], x, y)):
         assert np.abs(m - r).max() < 1e-15
+
+
+# ---- GeneralFZPin0YZ (oes/gratings.py:140-313) ----------------------------------------
+@pytest.mark.parametrize('name', ['g2_gfzp_normal', 'g2_gfzp_grazing'])
+def test_general_zone_plate_matches_reference_golden(name):
+    """Zones from two foci (one at infinity / both finite, normal / grazing incidence), the
+    lowest path difference of the batch as the origin of the zone count, groove densities
+    from the extent of the neighbouring zones in the batch: statistics over all rays, done
+    with torch reductions between two passes; a phase shift given to the constructor ends
+    up divided by pi three times, as in the reference."""
+    g = pc.load(name)
+    fzp = pc.product_oe(name, g)
+    gb, lb = fzp.reflect(pc.product_beam(g))
+    p, beam, _ = fixture_io.load_case(name)
+    rn.oe_reflect(p, beam)
+    assert fzp.minHalfLambda == p['gfzp']['minHalfLambda']
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    hit = g['lb_state'] == 1
+    assert 0.2 < hit.mean() < 0.6          # about half of the zones are opaque
+    # a second batch keeps the origin of the zone count found in the first one
+    first = fzp.minHalfLambda
+    fzp.reflect(pc.product_beam(g))
+    assert fzp.minHalfLambda == first

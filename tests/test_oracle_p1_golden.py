@@ -70,7 +70,8 @@ def test_lens_stacks_match_reference(name):
     check_beam(lo2, g, 'lo2_')
 
 
-@pytest.mark.parametrize('name', ['g2_fzp_first', 'g2_fzp_orders'])
+@pytest.mark.parametrize('name', ['g2_fzp_first', 'g2_fzp_orders', 'g2_gfzp_normal',
+                                  'g2_gfzp_grazing'])
 def test_zone_plate_matches_reference(name):
     """NormalFZP in ray mode (gratings.py:10-137): opaque zones absorb, the others
     deflect by the local zone density; one order or a seeded draw per ray."""
@@ -80,7 +81,9 @@ def test_zone_plate_matches_reference(name):
     gb, lb = rn.oe_reflect(p, beam)
     check_beam(gb, g, 'gb_')
     check_beam(lb, g, 'lb_')
-    assert int(g['axis']) == 2
+    assert int(g['axis']) == (1 if name == 'g2_gfzp_grazing' else 2)
+    if 'gfzp' in p:
+        assert p['gfzp']['minHalfLambda'] is not None
     if 'np_seed' in g.files:
         assert np.array_equal(lb.order, g['lb_order'])
 

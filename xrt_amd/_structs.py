@@ -78,6 +78,9 @@ class Pass(ctypes.Structure):
         ('eff_n', ctypes.c_int32),
         ('eff_order', ctypes.c_int32 * 8),
         ('eff_amp', ctypes.c_double * 8),
+        ('state_ray', ctypes.c_void_p),
+        ('g_ray_x', ctypes.c_void_p),
+        ('g_ray_y', ctypes.c_void_p),
     ]
 
 

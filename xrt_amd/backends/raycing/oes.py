@@ -230,6 +230,9 @@ class OE(object):
             p.eff_n = len(pairs)
             for k, (order, value) in enumerate(pairs):
                 p.eff_order[k], p.eff_amp[k] = int(order), float(np.float64(value)**0.5)
+        if hasattr(self, '_zones_between_passes'):
+            p.grating = 0                 # general zone plate: its first pass is geometry only
+            return
         if hasattr(self, 'rn'):           # zone plate: the zone radii instead of a groove vector
             held = self.__dict__.setdefault('_zone_table', {})     # in HBM, per device
             cached = held.get(str(_device()))
@@ -576,6 +579,9 @@ class OE(object):
         lb, gb, report = self._run_pass(
             p, self.material, True, beam, beam, want_info=_info is not None,
             timing=_timing is not None, out=None if out is None else (out[1], out[0]))
+        between = getattr(self, '_zones_between_passes', None)
+        if between is not None:       # zones that depend on the whole batch (general FZP)
+            lb, gb, report, held = between(p, beam, lb, gb, _info, _timing)
         if p.grating and raycing.is_sequence(self.order):
             lb, gb, report = self._with_ray_orders(p, beam, lb, gb, _info, _timing)
         clock = ('pass_ms', 'kernel_ms', 'exact_sequence')
@@ -932,6 +938,116 @@ class DicedJohannToroid(DicedOE, JohannToroid):
 class DicedJohanssonToroid(DicedJohannToroid, JohanssonToroid):
     """Facets ground to the meridional radius, atomic planes of the Johansson toroid
     (bragg.py:362-375)."""
+
+
+def _tracked(name):
+    """An attribute whose assignment re-derives the zone plate (GeneralFZPin0YZ.reset)."""
+    def assign(self, value):
+        self.__dict__['_' + name] = value
+        self.reset()
+    return property(lambda self: self.__dict__['_' + name], assign)
+
+
+class GeneralFZPin0YZ(OE):
+    """Zone plate on a flat element at grazing incidence, its zones set by the two foci
+    *f1*, *f2* -- points (x, y, z[, -1 for a negative path]) in the LOCAL frame, or a string
+    for 'at infinity' -- at the energy *E*: a ray belongs to zone floor((d1 + d2) / (lambda /
+    2) - the lowest such value of the first batch - phaseShift [+ vorticity phi / pi]);
+    even zones up to *N* transmit, the others absorb; the local groove density comes from
+    the extent of the neighbouring zones in the batch (reference oes/gratings.py:140-313).
+    The material must be of kind 'FZP'.
+
+    Those quantities are statistics over all rays, so the pass runs twice: hit points and
+    outline states first, then zones and groove vectors on the GPU (torch reductions), then
+    the pass again with them per ray. A ray that the intersection search loses is not part
+    of the statistics here (the reference counts its last trial point)."""
+
+    f1, f2, E, N = _tracked('f1'), _tracked('f2'), _tracked('E'), _tracked('N')
+    phaseShift = _tracked('phaseShift')
+
+    def __init__(self, *args, **kwargs):
+        # (assignment order and the repeated reset() are the reference's: a phase shift
+        # given to the constructor ends up divided by pi three times, one assigned later by
+        # pi once)
+        self.f1, self.f2, self.E = kwargs.pop('f1'), kwargs.pop('f2'), kwargs.pop('E')
+        self.N = kwargs.pop('N', 1000)
+        self.phaseShift = kwargs.pop('phaseShift', 0)
+        self.vorticity = kwargs.pop('vorticity', 0)
+        angle = kwargs.pop('grazingAngle', None)
+        OE.__init__(self, *args, **kwargs)
+        self.reset()      # (the reference's base constructor resets the element once, through
+        # its gratingDensity assignment; with the reset below that makes pi**3 in all)
+        self.use_rays_good_gn = True
+        self.grazingAngle = raycing.auto_units_angle(self.pitch if angle is None else angle)
+        self.reset()
+
+    def assign_auto_material_kind(self, material):
+        material.kind = 'FZP'
+
+    def reset(self):
+        if '_E' in self.__dict__ and '_phaseShift' in self.__dict__:
+            self.lambdaE = CH / self.E * 1e-7
+            self.minHalfLambda = None
+            self.set_phase_shift(self.phaseShift)
+
+    def set_phase_shift(self, phaseShift):
+        self.__dict__['_phaseShift'] = phaseShift
+        if phaseShift:
+            self.__dict__['_phaseShift'] = phaseShift / np.pi
+
+    def _is_grating(self):
+        return True
+
+    def _path_to(self, focus, x, y, z):
+        if isinstance(focus, str):
+            return y * np.cos(self.grazingAngle)
+        d = ((x - focus[0])**2 + (y - focus[1])**2 + (z - focus[2])**2)**0.5
+        return d * focus[3] if len(focus) > 3 else d
+
+    def _zones_between_passes(self, p, beam, lb, gb, _info, _timing):
+        dev = _device()
+        hit = lb.dev('state', dev) == 1
+        x, y, z = (lb.dev(f, dev)[hit] for f in 'xyz')
+        half = (self._path_to(self.f1, x, y, z) + self._path_to(self.f2, x, y, z)) / \
+            (self.lambdaE / 2)
+        if self.minHalfLambda is None:
+            self.minHalfLambda = float(half.min()) if half.numel() else 0.
+        phi = torch.atan2(y * np.sin(self.grazingAngle), x) / np.pi
+        half = half - (self.minHalfLambda + self.phaseShift - phi * self.vorticity)
+        N = int(self.N)
+        zone = torch.floor(half).to(torch.int64)
+        open_ = (torch.remainder(zone, 2) == 0) & (zone < N)
+        # extent of every zone in the batch (the reference keeps it for the odd ones, which
+        # is all the density of an even zone needs)
+        inside = (zone >= 0) & (zone < N)
+        extent = [torch.zeros(N, dtype=torch.float64, device=dev).scatter_reduce(
+            0, zone[inside], c[inside].abs(), 'amax', include_self=True) for c in (x, y)]
+        odd = torch.arange(N, device=dev) % 2 == 1
+        zo = zone[open_]
+        xo, yo = x[open_], y[open_]
+        spans = []
+        for ext in extent:
+            ext = torch.where(odd, ext, torch.zeros_like(ext))
+            span = ext[torch.remainder(zo + 1, N)] - ext[torch.remainder(zo - 1, N)]
+            spans.append(torch.where(span == 0, torch.full_like(span, 1e20), span))
+        r = torch.sqrt(xo * xo + yo * yo)
+        density = (xo * xo / spans[0] + yo * yo / spans[1]) / (r * r)
+        n = beam.nrays
+        state_ray = torch.ones(n, dtype=torch.int32, device=dev)
+        gx = torch.zeros(n, dtype=torch.float64, device=dev)
+        gy = torch.zeros(n, dtype=torch.float64, device=dev)
+        where = torch.nonzero(hit).ravel()
+        state_ray[where[~open_]] = int(self.lostNum)
+        gx[where[open_]] = -xo * density / r
+        gy[where[open_]] = -yo * density / r
+        p.grating, p.grating_axis = 2, -1
+        p.grating_order = int(self.order[0] if raycing.is_sequence(self.order) else self.order)
+        p.state_ray, p.g_ray_x, p.g_ray_y = state_ray.data_ptr(), gx.data_ptr(), gy.data_ptr()
+        lb, gb, report = self._run_pass(p, self.material, True, beam, beam,
+                                        want_info=_info is not None,
+                                        timing=_timing is not None, out=(lb, gb))
+        torch.cuda.current_stream().synchronize()
+        return lb, gb, report, (state_ray, gx, gy)
 
 
 class BlazedGrating(_Curved):

@@ -1429,7 +1429,7 @@ __device__ __forceinline__ int rays_good(const xrt_hip_pass& P, double x, double
     const Facet f = diced_facet(P, x, y);
     return fabs(f.fx) > P.surf_p[9] || fabs(f.fy) > P.surf_p[10] ? P.lost_num : st;
   }
-  if (PGRATING(P) == 2) {  // gratings.py:123-129: opaque zones absorb
+  if (PGRATING(P) == 2 && P.zone_r) {  // gratings.py:123-129: opaque zones absorb
     double r, rho;
     return fzp_zone(P, x, y, r, rho) && st == 1 ? 1 : P.lost_num;
   }
@@ -2279,7 +2279,12 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       double g0 = P.g_const[0], g1 = P.g_const[1], g2 = P.g_const[2];
       double gsig = -1.;
       took_order = P.order_ray ? P.order_ray[i] : P.grating_order;
-      if (P.grating == 2) {  // zone plate: gn of rays_good_gn, sign +1 (reflect.py:857)
+      if (P.grating == 2 && P.g_ray_x) {   // general zone plate: the caller's groove vectors
+        g0 = P.g_ray_x[i];
+        g1 = P.g_ray_y[i];
+        g2 = 0.;
+        gsig = 1.;
+      } else if (P.grating == 2) {  // zone plate: gn of rays_good_gn, sign +1 (reflect.py:857)
         double rad, rho;
         fzp_zone(P, h.x, h.y, rad, rho);
         g0 = -h.x / rad * rho;
@@ -2748,6 +2753,7 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   }
   if (active) {
     int st = rays_good<K>(P, h.x, h.y);
+    if (!K::PLAIN && P.state_ray && st == 1) st = P.state_ray[i];   // zones of a general FZP
     if (h.lost) st = P.lost_num;
     if (XTAL) {
       double bdn = 0.;
@@ -2823,6 +2829,7 @@ __device__ __forceinline__ void solve_body(const xrt_hip_pass& P, const xrt_hip_
     const LocalRay r = load_local(P, in, i);
     const Hit h = solve_ray<K>(P, g, r);
     int st = rays_good<K>(P, h.x, h.y);
+    if (!K::PLAIN && P.state_ray && st == 1) st = P.state_ray[i];
     if (h.lost) st = P.lost_num;
     ht[i] = h.t;
     hx[i] = h.x;
