@@ -1,0 +1,39 @@
+"""CPU: the kernels on the measured paths keep their resource budget in the built library.
+A by-value pass / material record that the compiler copies to scratch (a run-time index
+into it, or two loads merged into one through a selected pointer) does not fail any parity
+test -- it shows as 1 KB of private segment in the generic exact kernel and 12 us more launch
+overhead on EVERY pass, which happened twice while round 2 widened the element
+families."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                'tools'))
+import kernel_resources as kr  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(kr.READELF) and os.path.exists(kr.LIB)),
+                                reason='needs the built library and llvm-readelf')
+
+
+def _one(table, *parts):
+    hits = [v for k, v in table.items() if all(p in k for p in parts)]
+    assert len(hits) == 1, (parts, len(hits))
+    return hits[0]
+
+
+def test_hot_kernels_keep_their_budget():
+    table = kr.kernels()
+    lean = _one(table, 'reflect_fusedINS_4SpecILi0ELi1ELi1ELb1EEELi0')      # cfg2: toroid mirror
+    assert lean['scratch'] == 0 and lean['vgpr_spill'] == 0 and lean['vgpr'] <= 128
+    dcm = _one(table, 'reflect_fused_dcmINS_9ThickXtalILi0')                # cfg3
+    assert dcm['scratch'] == 0 and dcm['vgpr_spill'] == 0 and dcm['vgpr'] <= 128
+    gate = _one(table, 'reflect_exactINS_4SpecILi0ELin1ELin1ELb0')          # returns at once
+    assert gate['scratch'] <= 256
+    assert _one(table, 'reflect_dcm_exactINS_4SpecILi0ELin1ELin1ELb0')['scratch'] <= 256
+    for small in ('reflect_decide_opt', 'reflect_decide_dcm'):
+        assert _one(table, small)['scratch'] == 0
+    for name, r in table.items():
+        if 'kirchhoff_stream' in name:
+            assert r['scratch'] == 0 and r['vgpr_spill'] == 0, name

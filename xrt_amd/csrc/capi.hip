@@ -298,8 +298,11 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
       (pass->grating == 2 && !pass->g_ray_x && (pass->zone_n < 1 || !pass->zone_r)))
     return fail(XRT_HIP_ERR_ARG, "bad zone plate description");
   if ((pass->g_ray_x != nullptr) != (pass->g_ray_y != nullptr) ||
-      (pass->g_ray_x && pass->grating != 2))
-    return fail(XRT_HIP_ERR_ARG, "per-ray groove vectors need both components and grating = 2");
+      (pass->g_ray_x && (pass->grating != 2 || pass->surf_kind >= XRT_HIP_SURF_BLAZED ||
+                         material->kind == XRT_HIP_MAT_CRYSTAL ||
+                         material->kind == XRT_HIP_MAT_MULTILAYER)))
+    return fail(XRT_HIP_ERR_ARG, "per-ray groove vectors need both components, grating = 2, a "
+                                 "flat / toroidal surface and a non-crystal material");
   if (pass->invert_normal != 1 && pass->invert_normal != -1)
     return fail(XRT_HIP_ERR_ARG, "invert_normal must be +1 or -1");
   if (pass->shape < XRT_HIP_SHAPE_RECT || pass->shape > XRT_HIP_SHAPE_POLYGON)

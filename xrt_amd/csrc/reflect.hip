@@ -271,6 +271,8 @@ struct Spec {
   // crystals given by their unit cell (structure code 2: up to four f1/f2 look-ups per ray)
   // are compiled in
   static constexpr bool XCELL = true;
+  // zones and groove vectors per ray from the caller (general zone plate)
+  static constexpr bool RAYG = false;
 };
 // a thick (semi-infinite) crystal: what a DCM is made of
 template <int SK_>
@@ -286,6 +288,14 @@ struct ThickXtal : Spec<0, SK_, XRT_HIP_MAT_CRYSTAL, false> {
 __host__ __device__ inline bool deflects_as_crystal(const xrt_hip_material& M) {
   return M.kind == XRT_HIP_MAT_CRYSTAL || (M.kind == XRT_HIP_MAT_MULTILAYER && M.geom_bragg);
 }
+// The general zone plate's kernels: only they read xrt_hip_pass.state_ray / g_ray_*. (In the
+// generic kernels the two loads of a groove component -- from the caller's array or from
+// the pass record -- were merged into one load through a selected pointer, the by-value pass
+// record went to scratch for it, 1 KB per lane in the exact kernel, and EVERY pass paid 12 us
+// more launch overhead.)
+struct PerRayZones : Spec<0, -1, -1, false> {
+  static constexpr bool RAYG = true;
+};
 using Layered0 = Spec<0, -1, XRT_HIP_MAT_MULTILAYER, false>;
 using Layered1 = Spec<1, -1, XRT_HIP_MAT_MULTILAYER, false>;
 using Generic0 = Spec<0, -1, -1, false>;
@@ -2279,7 +2289,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       double g0 = P.g_const[0], g1 = P.g_const[1], g2 = P.g_const[2];
       double gsig = -1.;
       took_order = P.order_ray ? P.order_ray[i] : P.grating_order;
-      if (P.grating == 2 && P.g_ray_x) {   // general zone plate: the caller's groove vectors
+      if (K::RAYG && P.grating == 2 && P.g_ray_x) {   // general zone plate: the caller's vectors
         g0 = P.g_ray_x[i];
         g1 = P.g_ray_y[i];
         g2 = 0.;
@@ -2753,7 +2763,8 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   }
   if (active) {
     int st = rays_good<K>(P, h.x, h.y);
-    if (!K::PLAIN && P.state_ray && st == 1) st = P.state_ray[i];   // zones of a general FZP
+    if constexpr (K::RAYG)
+      if (P.state_ray && st == 1) st = P.state_ray[i];   // zones of a general FZP
     if (h.lost) st = P.lost_num;
     if (XTAL) {
       double bdn = 0.;
@@ -2829,7 +2840,8 @@ __device__ __forceinline__ void solve_body(const xrt_hip_pass& P, const xrt_hip_
     const LocalRay r = load_local(P, in, i);
     const Hit h = solve_ray<K>(P, g, r);
     int st = rays_good<K>(P, h.x, h.y);
-    if (!K::PLAIN && P.state_ray && st == 1) st = P.state_ray[i];
+    if constexpr (K::RAYG)
+      if (P.state_ray && st == 1) st = P.state_ray[i];
     if (h.lost) st = P.lost_num;
     ht[i] = h.t;
     hx[i] = h.x;
@@ -3942,7 +3954,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   hipLaunchKernelGGL((reflect_fused<SPEC, mode>), grid, fblock, 0, st, P, M, in, restore, lb, \
                      vb, theta, g, opt)
     const bool plain = !P.grating && !P.asymmetric && !P.no_intersection_search;
-    if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED) {
+    if (P.g_ray_x) {
+      XRT_FUSED(PerRayZones);
+    } else if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED) {
       XRT_FUSED(Layered1);
     } else if (layers) {
       XRT_FUSED(Layered0);
@@ -3971,7 +3985,10 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   A.aliased = aliased ? 1 : 0;
   const dim3 xgrid(exact_blocks(n)), xblock(REFLECT_EXACT_BLOCK);
   auto launch_exact = [&]() {
-    if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED)
+    if (P.g_ray_x)
+      hipLaunchKernelGGL(reflect_exact<PerRayZones>, xgrid, xblock, 0, st, P, M, in, restore, lb,
+                         vb, A);
+    else if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED)
       hipLaunchKernelGGL(reflect_exact<Layered1>, xgrid, xblock, 0, st, P, M, in, restore, lb,
                          vb, A);
     else if (layers)
