@@ -54,9 +54,24 @@ class GaussianBeam(object):
     def w(self, y, E=None, yR=None, w0=None):
         """Beam size at the distance *y* from the waist."""
         w0 = self._waist(w0)
-        if yR is None:
-            yR = self.rayleigh_range(E, w0)
-        return w0 * (1 + (y/yR)**2)**0.5
+        reduced = y / (self.rayleigh_range(E, w0) if yR is None else yR)
+        return w0 * (1 + reduced**2)**0.5
+
+    def _announce_energy(self):
+        """The beamline's alignment energy, unless the user fixed one: the first line, or the
+        middle of a flat band."""
+        if self.bl is None:
+            return
+        if not isinstance(self.bl.alignE, str):
+            self.bl._alignE = float(self.bl.alignE)
+            return
+        lines = np.atleast_1d(self.energies)
+        if len(lines) == 0:
+            self.bl._alignE = rs.defaultEnergy
+        elif self.distE == 'flat' and len(lines) == 2:
+            self.bl._alignE = 0.5 * (lines[0] + (lines[1] or lines[0]))
+        else:
+            self.bl._alignE = lines[0]
 
     def _mode(self):
         g = _structs.Gauss()
@@ -74,17 +89,7 @@ class GaussianBeam(object):
 
     def shine(self, toGlobal=True, wave=None, accuBeam=None):
         """The mode field on the points of *wave* -> the wave as a beam (global frame)."""
-        if self.bl is not None:
-            try:
-                self.bl._alignE = float(self.bl.alignE)
-            except ValueError:
-                lines = np.atleast_1d(self.energies)
-                if len(lines) == 0:
-                    self.bl._alignE = rs.defaultEnergy
-                elif self.distE == 'flat' and len(lines) == 2:
-                    self.bl._alignE = 0.5 * (lines[0] + (lines[1] or lines[0]))
-                else:
-                    self.bl._alignE = lines[0]
+        self._announce_energy()
         if wave is None or not hasattr(wave, 'rDiffr'):
             raise ValueError("run a `prepare_wave` before shine!")
         count = len(wave.rDiffr)
@@ -112,12 +117,9 @@ class GaussianBeam(object):
             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
             'xrt_hip_gaussian_beam_f64_dev')
         amp = amp.cpu().numpy()
-        wave.Es *= amp
-        wave.Ep *= amp
-        power = np.abs(amp)**2
-        wave.Jss *= power
-        wave.Jpp *= power
-        wave.Jsp *= power
+        for field, factor in (('Es', amp), ('Ep', amp)) + tuple(
+                (j, np.abs(amp)**2) for j in ('Jss', 'Jpp', 'Jsp')):
+            setattr(wave, field, getattr(wave, field) * factor)
         if np.isscalar(self.totalFlux) and self.totalFlux > 0:
             total = (wave.Jss + wave.Jpp).sum()
             if total > 0:
@@ -139,18 +141,16 @@ class GaussianBeam(object):
 class LaguerreGaussianBeam(GaussianBeam):
     """*vortex* = (l, p): azimuthal index and radial index p >= 0."""
 
-    def __init__(self, *args, **kwargs):
-        vortex = kwargs.pop('vortex', None)
-        GaussianBeam.__init__(self, *args, **kwargs)
+    def __init__(self, *args, vortex=None, **kwargs):
+        super().__init__(*args, **kwargs)
         if raycing.is_sequence(self.w0):
-            raise ValueError('w0 must be a value, not a sequence')
+            raise ValueError('w0 must be a value, not a sequence')   # one waist for a vortex
         self.vortex = vortex
 
 
 class HermiteGaussianBeam(GaussianBeam):
     """*TEM* = (m, n): mode orders along x and z."""
 
-    def __init__(self, *args, **kwargs):
-        tem = kwargs.pop('TEM', None)
-        GaussianBeam.__init__(self, *args, **kwargs)
-        self.tem = tem
+    def __init__(self, *args, TEM=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.tem = TEM

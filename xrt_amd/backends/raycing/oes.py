@@ -1426,13 +1426,14 @@ class DCMOnTripodWithOneXStage(DCM, rst.Tripod, rst.OneXStage):
             if optical is None:
                 continue
             if not (raycing.is_sequence(optical[0]) and raycing.is_sequence(optical[1])):
-                raise ValueError('"limOptX" must be a tuple of sequences!')
+                raise ValueError('optical limits of the second crystal: (lows, highs), each a '
+                                 'sequence per stripe')
             if not (len(optical[0]) == len(optical[1]) == stripes):
-                raise ValueError('len(self.limOptX[0,1]) != len(surface) !!!')
+                raise ValueError('one optical limit of the second crystal per stripe, please')
         for edge in (self.limPhysX2[0], self.limPhysX2[1], self.limPhysY2[0],
                      self.limPhysY2[1]):
             if raycing.is_sequence(edge) and len(edge) != stripes:
-                raise ValueError('length of "surface" and "limPhys..." must be equal!')
+                raise ValueError('one physical limit of the second crystal per stripe, please')
 
     def get_orientation(self):
         rst.Tripod.get_orientation(self)

@@ -16,8 +16,8 @@ class Tripod(object):
         above_floor = self.center[2] - self.bl.height
         self.jack1Offset, self.jack2Offset, self.jack3Offset = (
             above_floor - j[2] for j in self._jacks())
-        self.init_jacks_local()
-        self.set_jacks()
+        for step in (self.init_jacks_local, self.set_jacks):
+            step()
 
     def _jacks(self):
         return self.jack1, self.jack2, self.jack3
@@ -30,7 +30,7 @@ class Tripod(object):
         """The jacks relative to the element's centre, y along the beamline; the distance
         from the plane of the balls to the optical surface never changes."""
         if not (self.jack1[2] == self.jack2[2] == self.jack3[2]):
-            raise ValueError('The mirror must be initially horizontal!')
+            raise ValueError('the three jacks must start at one height (element horizontal)')
         self.jackToMirrorInvariant = self.center[2] - self.jack1[2]
         local = []
         for jack in self._jacks():
@@ -55,9 +55,8 @@ class Tripod(object):
                              self._jacks()):
             rel[2] = (level - nx*rel[0] - ny*rel[1]) / nz
             jack[2] = rel[2] + self.center[2]
-        self.jack1Calib = self.jack1[2] + self.jack1Offset
-        self.jack2Calib = self.jack2[2] + self.jack2Offset
-        self.jack3Calib = self.jack3[2] + self.jack3Offset
+        for k, jack in enumerate(self._jacks(), 1):      # what the jack encoders read
+            setattr(self, 'jack%dCalib' % k, jack[2] + getattr(self, 'jack%dOffset' % k))
 
     def get_orientation(self):
         """Height of the centre, pitch and roll from the three jack positions: the normal
@@ -88,21 +87,23 @@ class OneXStage(object):
 
     def __init__(self, dx=0):
         self.dx = dx
-        if self.surface is None:
+        names = self.surface
+        if names is None:
             return
-        if not raycing.is_sequence(self.surface):
-            raise ValueError('"surface" must be a sequence!')
-        stripes = len(self.surface)
+        if not raycing.is_sequence(names):
+            raise ValueError('"surface": the names of the stripes, a sequence')
+        stripes = len(names)
         for optical in (self.limOptX, self.limOptY):
             if optical is None:
                 continue
             if not (raycing.is_sequence(optical[0]) and raycing.is_sequence(optical[1])):
-                raise ValueError('"limOptX" must be a tuple of sequences!')
+                raise ValueError('optical limits of a multi-stripe element: (lows, highs), '
+                                 'each a sequence per stripe')
             if not (len(optical[0]) == len(optical[1]) == stripes):
-                raise ValueError('len(self.limOptX[0,1]) != len(surface) !!!')
+                raise ValueError('one optical limit per stripe, please')
         for edge in (self.limPhysX[0], self.limPhysX[1], self.limPhysY[0], self.limPhysY[1]):
             if raycing.is_sequence(edge) and len(edge) != stripes:
-                raise ValueError('length of "surface" and "limPhys..." must be equal!')
+                raise ValueError('one physical limit per stripe, please')
 
     def pop_kwargs(self, **kwargs):
         return kwargs, (kwargs.pop('dx', 0),)
@@ -123,8 +124,8 @@ class TwoXStages(OneXStage):
     def __init__(self, tx1, tx2, dx=0):
         self.tx1, self.tx2 = tx1, tx2
         if tx2[1] == tx1[1]:
-            raise ValueError('tx1 and tx2 stages must be at different y''s!')
-        OneXStage.__init__(self)
+            raise ValueError('the two x stages must sit at different y')
+        OneXStage.__init__(self)      # (its dx argument is not handed on, as in the reference)
         self.set_x_stages()
 
     def pop_kwargs(self, **kwargs):
@@ -133,21 +134,21 @@ class TwoXStages(OneXStage):
 
     def set_x_stages(self):
         slope = math.tan(self.yaw)
+        turned = self.positionRoll != 0
         for stage in (self.tx1, self.tx2):
             stage[0] = (-slope*stage[1] + self.dx)
-        if self.positionRoll != 0:
-            self.tx1[0] *= math.cos(self.positionRoll)
-            self.tx2[0] *= math.cos(self.positionRoll)
+            if turned:                   # the element hangs rolled: the stage sees the projection
+                stage[0] *= math.cos(self.positionRoll)
 
     def select_surface(self, surfaceName):
+        """The stripe of that name into the beam; both stages follow."""
         OneXStage.select_surface(self, surfaceName)
         self.set_x_stages()
 
     def get_orientation(self):
         x1, x2 = self.tx1[0], self.tx2[0]
         if self.positionRoll != 0:
-            x1 *= math.cos(self.positionRoll)
-            x2 *= math.cos(self.positionRoll)
+            x1, x2 = x1 * math.cos(self.positionRoll), x2 * math.cos(self.positionRoll)
         span = self.tx2[1] - self.tx1[1]
         self.dx = x1 - (x2-x1) * self.tx1[1] / span
         self.yaw = -math.atan((x2-x1) / span)
