@@ -837,3 +837,23 @@ def test_general_zone_plate_matches_reference_golden(name):
     first = fzp.minHalfLambda
     fzp.reflect(pc.product_beam(g))
     assert fzp.minHalfLambda == first
+
+
+def test_empty_material_keeps_the_amplitudes():
+    """EmptyMaterial (materials/__init__.py:101-113): a grating by the grating equation whose
+    material has no reflectivity -- directions as with a real coating, intensities untouched."""
+    import xrt_amd.backends.raycing.materials as rm
+    g = pc.load('g2_grating_const')
+    coated = pc.product_oe('g2_grating_const', g)
+    bare = pc.product_oe('g2_grating_const', g)
+    bare.material = rm.EmptyMaterial()
+    beam = pc.product_beam(g)
+    gb0, lb0 = coated.reflect(beam)
+    gb1, lb1 = bare.reflect(pc.product_beam(g))
+    assert np.array_equal(lb1.state, lb0.state)
+    for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):
+        assert np.array_equal(getattr(gb1, f), getattr(gb0, f)), f
+    hit = lb1.state == 1
+    total_in = (g['in_Jss'] + g['in_Jpp'])[hit]
+    assert np.abs((lb1.Jss + lb1.Jpp)[hit] - total_in).max() < 1e-12
+    assert ((lb0.Jss + lb0.Jpp)[hit] < total_in).all()

@@ -420,6 +420,22 @@ class Coated(Multilayer):
                                 lambda self, t: setattr(self, 'idThickness', t))
 
 
+class EmptyMaterial(object):
+    """A material without reflectivity that still tells the element what it is -- by default
+    a 'grating': the rays take the grating equation, their amplitudes stay (reference
+    materials/__init__.py:101-113)."""
+
+    def __init__(self, kind='grating', **kwargs):
+        self.kind, self.geom, self.name = kind, '', ''
+        self.uuid = kwargs.get('uuid')
+        self.efficiency = None
+
+    def to_struct(self, fromVacuum=True, device=None):
+        s = _structs.Material()
+        s.kind, s.from_vacuum, s._keep = _structs.MAT_NONE, int(bool(fromVacuum)), []
+        return s
+
+
 def parse_hkl(hkl):
     return tuple(int(i) for i in hkl)
 
