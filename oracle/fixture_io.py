@@ -184,8 +184,10 @@ def load_case(name):
     elif name.startswith('g3_bent_laue'):
         cls = str(g['surf_class'])
         alpha = float(g['surf_alpha'])
-        p['surface'] = dict(kind='laue_sphere' if 'Sphere' in cls else 'bent_cylinder',
-                            Rm=float(g['surf_Rm']), alpha=alpha if alpha else None,
+        p['surface'] = dict(kind='laue_2d' if cls == 'BentLaue2D' else
+                            'laue_sphere' if 'Sphere' in cls else 'bent_cylinder',
+                            Rm=float(g['surf_Rm']), Rs=float(g['surf_Rs']),
+                            alpha=alpha if alpha else None,
                             planes='laue_ground' if 'Ground' in cls else 'laue',
                             crossSection=str(g['surf_crossSection']))
         si = mn.load_element(tb, 'Si')

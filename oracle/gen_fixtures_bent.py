@@ -48,6 +48,7 @@ LAUE_CASES = (
      dict(R=2000., crossSection='circular', alpha=np.radians(-4.)), 'laue_ground'),
     ('g3_bent_laue_sphere', 'BentLaueSphere', dict(R=4000., crossSection='circular'), 'laue'),
     ('g3_bent_laue_paraboloid', 'BentLaueSphere', dict(R=4000.), 'laue'),
+    ('g3_bent_laue_2d', 'BentLaue2D', dict(Rm=3000., Rs=-9000., alpha=np.radians(5.)), 'laue'),
 )
 
 
@@ -73,6 +74,9 @@ def diced_surface_of(cls_name, kw, planes, thB):
 
 
 def laue_surface_of(cls_name, kw, planes):
+    if cls_name == 'BentLaue2D':
+        return dict(kind='laue_2d', Rm=kw['Rm'], Rs=kw['Rs'], alpha=kw.get('alpha'),
+                    planes=planes, crossSection='parabolic')
     return dict(kind='laue_sphere' if 'Sphere' in cls_name else 'bent_cylinder', Rm=kw['R'],
                 planes=planes, alpha=kw.get('alpha'),
                 crossSection=kw.get('crossSection', 'parabolic'))
@@ -168,7 +172,8 @@ def main():
         par['material'] = g1.crystal_dict(tables, si)
         g1.run_reflect(tag, rs, oe, par, beam, surf_class=np.array(cls_name),
                        surf_crossSection=np.array(surf['crossSection']),
-                       surf_Rm=np.array(kw['R']), surf_alpha=np.array(alpha if alpha else 0.),
+                       surf_Rm=np.array(surf['Rm']), surf_Rs=np.array(surf.get('Rs', 0.)),
+                       surf_alpha=np.array(alpha if alpha else 0.),
                        cr_d=np.array(si.d), cr_chiToF=np.array(si.chiToF), cr_V=np.array(si.V),
                        cr_t=np.array(0.1))
 

@@ -236,6 +236,8 @@ def local_z(surf, x, y):
         fx, fy, cz, cn = _diced_facet(surf, x, y)
         dz = fy**2 / 2.0 / surf['Rm'] if surf['planes'] == 'johansson' else np.zeros_like(fx)
         return cz + (dz - cn[-3]*fx - cn[-2]*fy) / cn[-1]
+    if surf['kind'] == 'laue_2d':                 # BentLaue2D.local_z, laue.py:364-365
+        return 0.5*x**2 / surf['Rs'] + 0.5*y**2 / surf['Rm']
     if surf['kind'] == 'laue_sphere':             # BentLaueSphere.local_z, laue.py:487-491
         if surf['crossSection'].startswith('circ'):
             return surf['Rm'] - np.sqrt(surf['Rm']**2 - x**2 - y**2)
@@ -505,6 +507,27 @@ def local_n(surf, x, y):
             bAlpha, cAlpha = rotate_x(cn[1], cn[2], np.cos(alpha), -np.sin(alpha))
             return [cn[0], bAlpha, cAlpha, cn[-3], cn[-2], cn[-1]]
         return cn
+    if surf['kind'] == 'laue_2d':                 # BentLaue2D.local_n, laue.py:424-452
+        a = -x / surf['Rs']
+        b = -y / surf['Rm']
+        c = 1.
+        norm = np.sqrt(a**2 + b**2 + 1)
+        a /= norm
+        b /= norm
+        c /= norm
+        sinpitch = -b
+        cospitch = np.sqrt(1 - b**2)
+        sinroll = -a
+        cosroll = np.sqrt(1 - a**2)
+        aB = np.zeros_like(a)
+        bB = np.ones_like(a)
+        cB = np.zeros_like(a)
+        if surf.get('alpha'):
+            bB, cB = rotate_x(bB, cB, np.cos(surf['alpha']), -np.sin(surf['alpha']))
+        aB, cB = rotate_y(aB, cB, cosroll, -sinroll)
+        bB, cB = rotate_x(bB, cB, cospitch, sinpitch)
+        normB = (bB**2 + cB**2 + aB**2)**0.5
+        return [aB/normB, bB/normB, cB/normB, a/norm, b/norm, c/norm]
     if surf['kind'] == 'laue_sphere':             # laue.py:493-507
         R = surf['Rm']
         if surf['crossSection'].startswith('circ'):

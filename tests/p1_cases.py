@@ -215,9 +215,13 @@ def product_oe(name, g):
         si = rm.CrystalSi(hkl=(1, 1, 1), geom='Laue reflected', t=float(g['cr_t']))
         assert si.d == float(g['cr_d']) and si.chiToF == float(g['cr_chiToF'])
         alpha = float(g['surf_alpha'])
-        oe = getattr(roe, str(g['surf_class']))(
-            bl, 'bl', material=si, R=float(g['surf_Rm']), alpha=alpha if alpha else None,
-            crossSection=str(g['surf_crossSection']), **common)
+        if str(g['surf_class']) == 'BentLaue2D':
+            oe = roe.BentLaue2D(bl, 'bl', material=si, Rm=float(g['surf_Rm']),
+                                Rs=float(g['surf_Rs']), alpha=alpha if alpha else None, **common)
+        else:
+            oe = getattr(roe, str(g['surf_class']))(
+                bl, 'bl', material=si, R=float(g['surf_Rm']), alpha=alpha if alpha else None,
+                crossSection=str(g['surf_crossSection']), **common)
     elif name.startswith('g3_bent_'):
         si = rm.CrystalSi(hkl=(1, 1, 1))
         assert si.d == float(g['cr_d']) and si.chiToF == float(g['cr_chiToF'])

@@ -694,7 +694,7 @@ def test_laterally_graded_multilayer_is_refused():
                                   'g3_bent_general_tor', 'g3_bent_laue_cyl',
                                   'g3_bent_laue_cyl_circ_asym', 'g3_bent_laue_ground',
                                   'g3_bent_laue_sphere', 'g3_bent_laue_paraboloid',
-                                  'g3_diced_flat', 'g3_diced_johann_tor',
+                                  'g3_bent_laue_2d', 'g3_diced_flat', 'g3_diced_johann_tor',
                                   'g3_diced_johansson_tor'])
 def test_bent_crystal_analysers_match_reference_golden(name):
     """Johann / Johansson cylinders and toroids, GeneralBraggToroid: surface in the

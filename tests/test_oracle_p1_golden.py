@@ -40,7 +40,7 @@ def check_beam(mine, g, prefix):
                                   'g3_bent_johansson_tor', 'g3_bent_general_tor',
                                   'g3_bent_laue_cyl', 'g3_bent_laue_cyl_circ_asym',
                                   'g3_bent_laue_ground', 'g3_bent_laue_sphere',
-                                  'g3_bent_laue_paraboloid', 'g3_diced_flat',
+                                  'g3_bent_laue_paraboloid', 'g3_bent_laue_2d', 'g3_diced_flat',
                                   'g3_diced_johann_tor', 'g3_diced_johansson_tor',
                                   'g3_cell_quartz_flat', 'g3_cell_graphite_johann',
                                   'g2_support_vcm', 'g2_support_vfm', 'g2_support_dualvfm'])

@@ -859,6 +859,26 @@ class BentLaueSphere(BentLaueCylinder):
     _shape = 3
 
 
+class BentLaue2D(_BentBragg):
+    """Doubly bent Laue crystal, z = x^2 / (2 Rs) + y^2 / (2 Rm): *Rm*, *Rs* of either sign
+    (concave, convex or saddle), numbers or (p, q) pairs for the Coddington radii (reference
+    oes/laue.py:229-452; its volumetric / TT amplitude models are not on the GPU path)."""
+    _shape, _planes = 5, 3
+
+    def __init__(self, *args, **kwargs):
+        radii = kwargs.pop('Rm', 1.0e4), kwargs.pop('Rs', -5.0e4)
+        self.crossSection = 'parabolic'
+        OE.__init__(self, *args, **kwargs)
+        self.Rm, self.Rs = radii
+
+    Rm = property(lambda self: self._RmVal,
+                  lambda self, v: setattr(self, '_RmVal', np.inf if v in (None, 0) else
+                                          _radius(v, self.get_Rmer_from_Coddington)))
+    Rs = property(lambda self: self._RsVal,
+                  lambda self, v: setattr(self, '_RsVal', np.inf if v in (None, 0) else
+                                          _radius(v, self.get_rsag_from_Coddington)))
+
+
 class JohannToroid(_BentBragg):
     """Doubly bent crystal, meridional *Rm* and sagittal *Rs* (= *Rm* if None)
     (bragg.py:200-269)."""

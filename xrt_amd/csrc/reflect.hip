@@ -521,6 +521,7 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
     if (P.surf_p[0] == 1.) return y * y / 2.0 / Rm;
     if (P.surf_p[0] == 3.) return Rm - sqrt((Rm * Rm - x * x) - y * y);   // laue.py:488-489
     if (P.surf_p[0] == 4.) return (x * x + y * y) / 2.0 / Rm;             // :491
+    if (P.surf_p[0] == 5.) return 0.5 * (x * x) / Rs + 0.5 * (y * y) / Rm;   // BentLaue2D, :365
     const double root = sqrt(Rm * Rm - y * y);
     if (P.surf_p[0] == 0.) return Rm - root;
     // toroid: the meridional circle turned about the sagittal axis
@@ -1973,6 +1974,32 @@ __device__ __forceinline__ void bent_bragg_normals(const xrt_hip_pass& P, double
   const bool tilted = P.surf_p[6] != 0.;
   const double root = sqrt(Rm * Rm - y * y);
   double cosang = 1., sinang = 0.;
+  if (shape == 5) {  // BentLaue2D.local_n, laue.py:424-452
+    const double a0 = -x / Rs, b0 = -y / Rm;
+    const double norm = sqrt(a0 * a0 + b0 * b0 + 1.);
+    const double a = a0 / norm, b = b0 / norm, c = 1. / norm;
+    const double sinpitch = -b, cospitch = sqrt(1. - b * b);
+    const double sinroll = -a, cosroll = sqrt(1. - a * a);
+    double aB = 0., bB = 1., cB = 0.;
+    if (tilted) {
+      bB = ca;
+      cB = -sa;
+    }
+    const double a1 = cosroll * aB - sinroll * cB;
+    cB = sinroll * aB + cosroll * cB;
+    aB = a1;
+    const double b1 = cospitch * bB - sinpitch * cB;
+    cB = sinpitch * bB + cospitch * cB;
+    bB = b1;
+    const double normB = sqrt(bB * bB + cB * cB + aB * aB);
+    n[0] = aB / normB;
+    n[1] = bB / normB;
+    n[2] = cB / normB;
+    n[3] = a / norm;   // (the reference divides the unit surface normal by its old norm once
+    n[4] = b / norm;   // more, :452)
+    n[5] = c / norm;
+    return;
+  }
   if (shape >= 3) {  // BentLaueSphere, laue.py:493-507: planes across the surface
     double a, b;
     if (shape == 3) {
