@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--skip-kirchhoff', action='store_true')
     ap.add_argument('--skip-undulator', action='store_true')
     ap.add_argument('--skip-softimax', action='store_true')
+    ap.add_argument('--skip-balder', action='store_true')
     ap.add_argument('--skip-cpu-baseline', action='store_true')
     ap.add_argument('--with-softi-shapes', action='store_true',
                     help='also time the two Kirchhoff shapes of the reference\'s '
@@ -431,6 +432,49 @@ def bench_undulator(with_cpu=True):
     return res
 
 
+def bench_balder(nrays, runs=5):
+    """A whole ray-tracing beamline, element after element on device-resident beams: the
+    reference's example Balder (examples/withRaycing/02_Balder_BL) from the front-end mask to
+    the sample -- diamond filter (two surfaces), bent collimating mirror, DCM Si(111) (two
+    crystals), toroidal focusing mirror = six ray-surface intersections per ray, four
+    apertures, two screens. The rays are a synthetic pencil that fills the front-end mask
+    (the wiggler's sampling is host-side numpy, as in the reference, and not part of this
+    number). Parity of this chain with the reference: tests/test_gpu_balder.py (golden
+    G17)."""
+    import numpy as np
+    import torch
+    from xrt_amd import workloads
+    import xrt_amd.backends.raycing.sources as rs
+    rng = np.random.default_rng(17)
+    beam = rs.Beam(nrays=nrays)
+    beam.x, beam.z = rng.normal(0, 0.05, nrays), rng.normal(0, 0.01, nrays)
+    beam.y = np.zeros(nrays)
+    a, c = rng.uniform(-1.9e-4, 1.9e-4, nrays), rng.uniform(-4.5e-5, 4.5e-5, nrays)
+    beam.a, beam.c, beam.b = a, c, np.sqrt(1 - a**2 - c**2)
+    beam.E = rng.uniform(8999., 9001., nrays)
+    beam.state = np.ones(nrays, dtype=np.int32)
+    beam.Jss, beam.Jpp, beam.Jsp = np.ones(nrays), np.zeros(nrays), np.zeros(nrays, complex)
+    for f in beam.array_fields():
+        beam.dev(f)
+    optics = workloads.balder_optics()
+    fresh = [rs.Beam(copyFrom=beam) for _ in range(runs + 1)]    # the chain marks its input
+    image = workloads.balder_trace(optics, fresh[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(runs):
+        image = workloads.balder_trace(optics, fresh[k + 1])
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / runs
+    arrived = float((image.state_count(1) if hasattr(image, 'state_count')
+                     else (image.state == 1).sum()) / nrays)
+    return {'metric': 'Balder example beamline, mask -> sample, seconds per pass of the beam',
+            'rays': nrays, 'seconds': sec, 'rays_per_s': nrays / sec,
+            'intersections_per_s': 6 * nrays / sec, 'surfaces': 6, 'apertures': 4,
+            'screens': 2, 'fraction_at_sample': arrived,
+            'note': 'device-resident beams through 12 elements; host glue of every element '
+                    'call is inside the time'}
+
+
 def bench_softimax(runs=3):
     """The reference's published wave benchmark, whole script body
     (tests/speed/3_Softi_CXIw2D_speed.py, BASELINE.md table: 17.5 s on 1 x A100,
@@ -598,6 +642,8 @@ def main():
         line['undulator'] = bench_undulator(not args.skip_cpu_baseline)
     if world == 1 and not args.skip_softimax:
         line['softimax'] = bench_softimax()
+    if world == 1 and not args.skip_balder:
+        line['balder'] = bench_balder(int(args.rays))
     if args.with_softi_shapes and world == 1:
         line['softi_shapes'] = bench_softi_shapes()
     if world == 1 and rank == 0 and not args.skip_cpu_baseline:

@@ -93,6 +93,71 @@ def kirchhoff_custom(ns, side, seed=7):
 # xrt's layout: this package's (bench, GPU tests) or the reference's (fixture
 # generation in the build container) - the same scene description serves both.
 # ---------------------------------------------------------------------------
+# The reference's example beamline Balder (examples/withRaycing/02_Balder_BL/BalderBL.py) as
+# its own align_beamline(energy = 9 keV) leaves it: the numbers of golden g17_balder_chain.
+BALDER = dict(
+    vcm_pitch=0.0020001648659604544, vcm_R=25287932.30316409, dcm_z=7.080621395080552,
+    dcm_bragg=0.2255730813145471, dcm_perp=11.105327057242667,
+    vfm_pitch=-0.0020001648659604544, vfm_R=15286250.102199329, vfm_z=42.79,
+    mask=[-3.15, 3.15, -0.7875000000000001, 0.7875000000000001],
+    slitDCM=[-7.0, 7.0, 35.2895172778329, 39.2895172778329], slitVFM=[-7.0, 7.0, 40.79, 44.79],
+    slitEH=[-1.3739999999999999, 1.3739999999999999, 35.79, 49.79])
+
+
+def balder_optics(par=BALDER):
+    """Everything of Balder downstream of the wiggler -> a namespace of elements."""
+    import math
+    import types
+    import xrt_amd.backends.raycing.apertures as ra
+    import xrt_amd.backends.raycing.screens as rsc
+    sides = ('left', 'right', 'bottom', 'top')
+    bl = raycing.BeamLine(azimuth=0, height=0)
+    b = types.SimpleNamespace(bl=bl)
+    b.fsm0 = rsc.Screen(bl, 'FSM0', (0, 15000, 0))
+    b.mask = ra.RectangularAperture(bl, 'FEFixedMask', (0, 15750, 0),
+                                    blades=dict(zip(sides, par['mask'])))
+    b.filter1 = roe.Plate(bl, 'Filter1', (0, 23620, 0), pitch=math.pi/2, limPhysX=(-9., 9.),
+                          limPhysY=(-4., 4.), material=rm.Material('C', rho=3.52, kind='plate'),
+                          t=0.06)
+    b.vcm = roe.SimpleVCM(bl, 'VCM', [0, 25290, 0], material=(rm.Material('Si', rho=2.33),),
+                          limPhysX=(-15., 15.), limPhysY=(-680., 680.), limOptX=(-6, 6),
+                          limOptY=(-670., 670.), R=par['vcm_R'], pitch=par['vcm_pitch'])
+    b.dcm = roe.DCM(bl, 'DCM', [0, 27060, par['dcm_z']],
+                    material=(rm.CrystalSi(hkl=(1, 1, 1), tK=-171+273.15),),
+                    material2=(rm.CrystalSi(hkl=(1, 1, 1), tK=-140+273.15),),
+                    limPhysX=(-10, 10), limPhysY=(-30, 30), cryst2perpTransl=par['dcm_perp'],
+                    cryst2longTransl=65, limPhysX2=(-10, 10), limPhysY2=(-90, 90),
+                    bragg=par['dcm_bragg'])
+    b.slitDCM = ra.RectangularAperture(bl, 'SlitAfterDCM', (0, 29200, 0),
+                                       blades=dict(zip(sides, par['slitDCM'])))
+    b.vfm = roe.SimpleVFM(bl, 'VFM', [0, 30575, par['vfm_z']],
+                          material=(rm.Material(('Si', 'O'), quantities=(1, 2), rho=2.2),),
+                          limPhysX=(-20., 20.), limPhysY=(-700., 700.), limOptX=(-10, 10),
+                          limOptY=(-700, 700), positionRoll=math.pi, R=par['vfm_R'], r=40.77,
+                          pitch=par['vfm_pitch'])
+    b.slitVFM = ra.RectangularAperture(bl, 'SlitAfterVFM', (0, 31720, 0),
+                                       blades=dict(zip(sides, par['slitVFM'])))
+    b.slitEH = ra.RectangularAperture(bl, 'slitEH', (0, 43000, 0),
+                                      blades=dict(zip(sides, par['slitEH'])))
+    b.sample = rsc.Screen(bl, 'FSM-Sample', (0, 45863, 0))
+    return b
+
+
+def balder_trace(b, beam):
+    """The ray path of the example's run_process from the front-end mask to the sample:
+    six surfaces, four apertures, two screens; everything stays in HBM. -> sample image."""
+    b.fsm0.expose(beam)
+    b.mask.propagate(beam)
+    after_filter = b.filter1.double_refract(beam)[0]
+    after_vcm = b.vcm.reflect(after_filter)[0]
+    after_dcm = b.dcm.double_reflect(after_vcm)[0]
+    b.slitDCM.propagate(after_dcm)
+    after_vfm = b.vfm.reflect(after_dcm)[0]
+    b.slitVFM.propagate(after_vfm)
+    b.slitEH.propagate(after_vfm)
+    return b.sample.expose(after_vfm)
+
+
 class SoftiMAX(object):
     E0 = 280.
     dE = 0.5
