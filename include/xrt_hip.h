@@ -279,6 +279,12 @@ typedef struct xrt_hip_pass {
   const int32_t* state_ray;
   const double* g_ray_x;
   const double* g_ray_y;
+  /* Optional memory of the element across passes (one DEVICE int32, zeroed by the caller
+   * once): the root-finding method the batch statistics chose last time (0 secant, 1 Brent,
+   * oes/base.py:871). The optimistic single pass assumes that method instead of always the
+   * secant; the verdict kernel checks the assumption as before and stores what the
+   * statistics say now. Results do not depend on it. NULL: assume the secant. */
+  int32_t* method_hint;
 } xrt_hip_pass;
 
 #define XRT_HIP_MAT_NONE 0

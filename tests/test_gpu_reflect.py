@@ -280,6 +280,15 @@ def test_plate_double_refract_matches_reference_golden():
     compare(gb2, g, lambda f: g['gb_' + f])
     compare(lo1, g, lambda f: g['lo1_' + f])
     compare(lo2, g, lambda f: g['lo2_' + f])
+    # The exit surface's batch statistics ask for Brent's method: the first call finds the
+    # optimistic (secant) pass contradicted and redoes it exactly; the element remembers, the
+    # second call assumes Brent and is not contradicted -- same bits.
+    again = plate.double_refract(pc.product_beam(g))
+    for first, second in zip((gb2, lo1, lo2), again):
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'Jss', 'Jpp', 'Jsp', 'Es', 'Ep', 'state'):
+            assert np.array_equal(getattr(first, f), getattr(second, f)), f
+    hints = {k: int(v.cpu()[0]) for k, v in plate._method_hints.items()}
+    assert sorted(hints.values()) == [0, 1], hints
 
 
 @pytest.mark.parametrize('name', ['g2_fzp_first', 'g2_fzp_orders'])

@@ -81,6 +81,7 @@ class Pass(ctypes.Structure):
         ('state_ray', ctypes.c_void_p),
         ('g_ray_x', ctypes.c_void_p),
         ('g_ray_y', ctypes.c_void_p),
+        ('method_hint', ctypes.c_void_p),
     ]
 
 

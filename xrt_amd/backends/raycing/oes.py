@@ -308,6 +308,14 @@ class OE(object):
         forth, back = self._turns(pitch, roll, yaw, is2ndXtal)
         _fill_rotation(p.to_local, forth)
         _fill_rotation(p.to_virgin, back)
+        # what the batch statistics of this surface chose last time (secant / Brent): the
+        # optimistic pass assumes it again (one int in HBM per surface, see xrt_hip.h)
+        if torch.cuda.is_available():       # (the record itself can be made without a GPU)
+            hints = self.__dict__.setdefault('_method_hints', {})
+            key = (str(_device()), bool(is2ndXtal), bool(fromVacuum))
+            if key not in hints:
+                hints[key] = torch.zeros(1, dtype=torch.int32, device=_device())
+            p.method_hint = hints[key].data_ptr()
         p.invert_normal = int(getattr(self, 'invertNormal', 1 if fromVacuum else -1))
         p.no_intersection_search = int(bool(noIntersectionSearch))
         self._surface_params(p, is2ndXtal)

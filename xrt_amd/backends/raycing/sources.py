@@ -49,7 +49,11 @@ class Beam(object):
                  xyzOnly=False, bl=None):
         object.__setattr__(self, '_h', {})
         object.__setattr__(self, '_d', {})
-        if copyFrom is not None and hasattr(copyFrom, 'a') and hasattr(copyFrom, 'x'):
+        # (a Beam is recognised by its type: asking it for .a / .x would pull those two arrays
+        # of a device-resident beam to the host -- 3 ms per 1e7 rays, and up again later)
+        if isinstance(copyFrom, Beam) or (
+                copyFrom is not None and not isinstance(copyFrom, str) and
+                hasattr(copyFrom, 'a') and hasattr(copyFrom, 'x')):
             if isinstance(copyFrom, Beam):
                 for name in copyFrom.array_fields():
                     if name in copyFrom._d:

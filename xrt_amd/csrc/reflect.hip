@@ -984,6 +984,11 @@ __device__ __forceinline__ bool decide_opt_body(const xrt_hip_pass& P, const xrt
   g->maxdz1 = 1.;          // secant
   g->maxdz2 = 0.;
   g->optimistic = 1;
+  if (P.method_hint && *P.method_hint) {   // this element's batches ask for Brent (the exit
+    g->maxdz1 = 0.;                        // surface of a plate does): assume that instead
+    g->maxdz2 = 1.;
+    g->optimistic = 2;
+  }
   return true;
 }
 
@@ -998,7 +1003,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
 // (reflect_exact's gate; 256 slots): true = an assumption was contradicted or the
 // bracket-end |dz| maxima ask for Brent, the pass has to be redone exactly.
 __device__ __forceinline__ bool fold_opt(const OptStat* slots, double* lds_d, double& m1o,
-                                         double& m2o) {
+                                         double& m2o, bool assumed_brent = false) {
   double m1 = 0., m2 = 0., viol = 0.;
   for (int k = threadIdx.x; k < REFLECT_OPT_SLOTS; k += blockDim.x) {
     m1 = fmax(m1, ld_agent(reinterpret_cast<const double*>(&slots[k].maxdz1)));
@@ -1012,7 +1017,7 @@ __device__ __forceinline__ bool fold_opt(const OptStat* slots, double* lds_d, do
   viol = block_reduce(viol, fmaxd, lds_d);
   m1o = m1;
   m2o = m2;
-  return viol != 0. || m2 > m1 * 20.;
+  return viol != 0. || (m2 > m1 * 20.) != assumed_brent;
 }
 
 struct LocalRay {
@@ -3117,13 +3122,15 @@ __device__ __forceinline__ void exact_pass(const xrt_hip_pass& P, const xrt_hip_
 #define REFLECT_EXACT_BLOCK 256
 // verdict on the optimistic kernel that ran before (every block folds the 256 report
 // slots itself); block 0 leaves it in g for the host's diagnostics
-__device__ __forceinline__ bool exact_gate(GStat* g, const OptStat* slots, double* lds_d) {
+__device__ __forceinline__ bool exact_gate(GStat* g, const OptStat* slots, double* lds_d,
+                                           int32_t* method_hint = nullptr) {
   bool full;
   if (g->optimistic) {
     double m1, m2;
-    full = fold_opt(slots, lds_d, m1, m2);
+    full = fold_opt(slots, lds_d, m1, m2, g->optimistic == 2);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       g->redo = full ? 1 : 0;
+      if (method_hint) *method_hint = m2 > m1 * 20. ? 1 : 0;   // for the element's next pass
       if (!full) {
         g->maxdz1 = m1;   // (diagnostics; the clamp range stays open)
         g->maxdz2 = m2;
@@ -3142,7 +3149,8 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_exact(
   __shared__ double lds_d[REFLECT_MAX_WAVES];
   const bool need_mean = deflects_as_crystal(M) && !M.geom_transmitted;
   const bool mixed = need_mean && A.g->any_neg && A.g->any_pos;
-  const bool full = exact_gate(A.g, reinterpret_cast<const OptStat*>(A.part), lds_d);
+  const bool full = exact_gate(A.g, reinterpret_cast<const OptStat*>(A.part), lds_d,
+                               P.method_hint);
   if (!full && !mixed) return;
   unsigned phase = 0;
   exact_pass<K>(P, M, in, restore, lb, vb, A, full, phase);
