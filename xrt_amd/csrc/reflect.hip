@@ -3960,6 +3960,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   using ToroidMirror = Spec<0, XRT_HIP_SURF_TOROID, XRT_HIP_MAT_MIRROR, true>;
   using FlatMirror = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_MIRROR, true>;
   using BentMirror = Spec<0, XRT_HIP_SURF_BENTFLAT, XRT_HIP_MAT_MIRROR, true>;
+  using FlatPlate = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_PLATE, true>;   // filters, windows
   // the solve + finish kernel of this (surface, material): mode 0 (optimistic) or 2
   auto launch_fused = [&](auto mode_tag) {
     constexpr int mode = decltype(mode_tag)::value;
@@ -4003,6 +4004,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       XRT_FUSED(FlatMirror);
     } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_BENTFLAT) {
       XRT_FUSED(BentMirror);
+    } else if (plain && M.kind == XRT_HIP_MAT_PLATE && P.surf_kind == XRT_HIP_SURF_FLAT) {
+      XRT_FUSED(FlatPlate);
     } else {
       XRT_FUSED(Generic0);
     }
