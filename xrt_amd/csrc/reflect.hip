@@ -1822,6 +1822,23 @@ __device__ __forceinline__ void multilayer_stack(const xrt_hip_multilayer& L, do
   const cplx Qt = csqrt_(C(Q2, 0.) + (nt - one) * k28);
   const cplx Qb = csqrt_(C(Q2, 0.) + (nb - one) * k28);
   const cplx Qs = csqrt_(C(Q2, 0.) + (ns - one) * k28);
+  // A coating (Coated: one period, no top layer, zero top thickness): the vacuum "layer" on
+  // top reflects nothing and has no phase -- r = (Q - Q) / 2Q = 0, p = 1, the step leaves the
+  // stack as it is (bit for bit) -- so its interface, roughness factor and step are skipped.
+  const bool bare_top = !TRAN && L.top.nelem == 0 && L.npairs == 1 && L.dti[0] == 0.;
+  if (bare_top) {   // (a path of its own: the loop below stays as the compiler likes it)
+    const Interface tb1 = interface_ab(Qt, nt, Qb, nb, L.id2, false);
+    const Interface bs1 = interface_ab(Qb, nb, Qs, ns, L.bs_rough2, false);
+    StackState c;
+    c.rs = bs1.rs;
+    c.rp = bs1.rp;
+    c.ts = c.tp = C(0., 0.);
+    const cplx p1 = half_phase(Qb, L.dbi[0]);
+    add_layer<false>(c, tb1.rs, tb1.rp, tb1.ts, tb1.tp, p1, p1 * p1);
+    out_s = c.rs;   // (n_t = 1: no sign flip)
+    out_p = c.rp;
+    return;
+  }
   const Interface vt = interface_ab(Qv, one, Qt, nt, L.id2, TRAN);
   const Interface tb = interface_ab(Qt, nt, Qb, nb, L.id2, TRAN);
   const Interface bs = interface_ab(Qb, nb, Qs, ns, L.bs_rough2, TRAN);
