@@ -298,8 +298,16 @@ struct PerRayZones : Spec<0, -1, -1, false> {
 };
 using Layered0 = Spec<0, -1, XRT_HIP_MAT_MULTILAYER, false>;
 using Layered1 = Spec<1, -1, XRT_HIP_MAT_MULTILAYER, false>;
+using Layered2 = Spec<2, -1, XRT_HIP_MAT_MULTILAYER, false>;
 using Generic0 = Spec<0, -1, -1, false>;
 using Generic1 = Spec<1, -1, -1, false>;
+// Surface families: 0 = flat / toroid / bent flat (+ sagittal, bent and diced under a crystal);
+// 1 = blazed grating, parametric conics, lenses, cone; 2 = bent-crystal shapes, diced elements,
+// VFM / DualVFM under a non-crystal material; 3 = all of them (the utility kernels). Keeping
+// family 2 out of family 1 keeps the parametric-mirror kernel at 128 VGPRs without spills (with
+// everything in one kernel it spilled 126 VGPRs and kept the pass record in scratch).
+using Generic2 = Spec<2, -1, -1, false>;
+using GenericAll = Spec<3, -1, -1, false>;
 #define PSURF(P) (K::SK >= 0 ? K::SK : (P).surf_kind)
 #define MKIND(M) (K::MK >= 0 ? K::MK : (M).kind)
 #define PGRATING(P) (K::PLAIN ? 0 : (P).grating)
@@ -320,30 +328,41 @@ __device__ __forceinline__ constexpr bool layered() {
 // Keeping them out of the other family-0 kernels keeps those lean: the generic exact kernel
 // of a plain mirror pass went from 176 B to 1 KB of scratch (and the pass from 21 to 32 us of
 // launch overhead) with the new kinds compiled in.
+// A parameter of the pass record as an opaque value. `c ? P.a : P.b` on two plain loads is
+// turned into ONE load through a selected address -- an address INTO the by-value record,
+// which then has to be copied to scratch for the whole kernel (1 KB per lane, and 12 us of
+// launch overhead per dispatch). Values that went through readfirstlane are selected as
+// values.
+__device__ __forceinline__ double pinned(double v) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)bits);
+  const int hi = __builtin_amdgcn_readfirstlane((int)(bits >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 template <class K>
 __device__ __forceinline__ constexpr bool wide_surfaces() {
-  return K::F == 1;
+  return K::F >= 2;
 }
 template <class K>
 __device__ __forceinline__ constexpr bool bent_crystal_surfaces() {
-  return K::F == 1 || K::MK == XRT_HIP_MAT_CRYSTAL;
+  return K::F >= 2 || K::MK == XRT_HIP_MAT_CRYSTAL;
 }
 template <class K>
 __device__ __forceinline__ bool surf_is_param(const xrt_hip_pass& P) {
-  return K::F == 1 && PSURF(P) == XRT_HIP_SURF_ELLIPSE_PARAM;
+  return (K::F & 1) && PSURF(P) == XRT_HIP_SURF_ELLIPSE_PARAM;
 }
 template <class K>
 __device__ __forceinline__ bool surf_is_blazed(const xrt_hip_pass& P) {
-  return K::F == 1 && PSURF(P) == XRT_HIP_SURF_BLAZED;
+  return (K::F & 1) && PSURF(P) == XRT_HIP_SURF_BLAZED;
 }
 
 template <class K>
 __device__ __forceinline__ bool surf_is_lens(const xrt_hip_pass& P) {
-  return K::F == 1 && PSURF(P) == XRT_HIP_SURF_PARABOLOID;
+  return (K::F & 1) && PSURF(P) == XRT_HIP_SURF_PARABOLOID;
 }
 template <class K>
 __device__ __forceinline__ bool surf_is_cone(const xrt_hip_pass& P) {
-  return K::F == 1 && PSURF(P) == XRT_HIP_SURF_CONE;
+  return (K::F & 1) && PSURF(P) == XRT_HIP_SURF_CONE;
 }
 // the paraboloid of a refractive lens before its cut-off, refractive.py:396, 411
 __device__ __forceinline__ double lens_parabola(const xrt_hip_pass& P, double& x, double y) {
@@ -490,7 +509,8 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
   }
   if (surf_is_blazed<K>(P)) {  // gratings.py:475-480
     double y1, yL;
-    return blazed_front(P, y, y1, yL) ? -(y1 - y) * P.surf_p[1] : -yL * P.surf_p[2];
+    return blazed_front(P, y, y1, yL) ? -(y1 - y) * pinned(P.surf_p[1])
+                                      : -yL * pinned(P.surf_p[2]);
   }
   if (surf_is_lens<K>(P)) {  // refractive.py:394-399
     const double z = lens_parabola(P, x, y);
@@ -505,8 +525,9 @@ __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double
   }
   if (wide_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_DUALVFM) {  // oes/__init__.py:532-550
     const bool left = x < 0.;
-    const double u = x - (left ? P.surf_p[5] : P.surf_p[2]);
-    double z = (left ? P.surf_p[3] : P.surf_p[0]) - sqrt((left ? P.surf_p[4] : P.surf_p[1]) - u * u);
+    const double u = x - (left ? pinned(P.surf_p[5]) : pinned(P.surf_p[2]));
+    double z = (left ? pinned(P.surf_p[3]) : pinned(P.surf_p[0])) -
+               sqrt((left ? pinned(P.surf_p[4]) : pinned(P.surf_p[1])) - u * u);
     if (isnan(z) || z > 0.) z = 0.;
     return z + (y * y - P.surf_p[6]) / 2.0 / P.surf_p[7];
   }
@@ -2144,8 +2165,8 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     double y1, yL;
     const bool front = blazed_front(P, py, y1, yL);
     n[0] = n[3] = 0.;
-    n[1] = n[4] = front ? -P.surf_p[3] : P.surf_p[5];
-    n[2] = n[5] = front ? P.surf_p[4] : P.surf_p[6];
+    n[1] = n[4] = front ? -pinned(P.surf_p[3]) : pinned(P.surf_p[5]);
+    n[2] = n[5] = front ? pinned(P.surf_p[4]) : pinned(P.surf_p[6]);
   } else if (PSURF(P) == XRT_HIP_SURF_SAGITTAL) {  // oes/__init__.py:658-662
     n[0] = n[3] = -x / P.surf_p[0];
     n[1] = n[4] = 0.;
@@ -2189,9 +2210,9 @@ __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, 
     n[2] = n[5] = 1. / norm;
   } else if (wide_surfaces<K>() && PSURF(P) == XRT_HIP_SURF_DUALVFM) {  // oes/__init__.py:552-571
     const bool left = x < 0.;
-    const double u = x - (left ? P.surf_p[5] : P.surf_p[2]);
-    const double under = (left ? P.surf_p[4] : P.surf_p[1]) - u * u;
-    const double rise = (left ? P.surf_p[3] : P.surf_p[0]) - sqrt(under);
+    const double u = x - (left ? pinned(P.surf_p[5]) : pinned(P.surf_p[2]));
+    const double under = (left ? pinned(P.surf_p[4]) : pinned(P.surf_p[1])) - u * u;
+    const double rise = (left ? pinned(P.surf_p[3]) : pinned(P.surf_p[0])) - sqrt(under);
     double na = -u / sqrt(under);
     if (isnan(na) || isnan(rise)) na = 0.;
     // the flat land between and beside the cylinders: local_z > 0 there (its meridional
@@ -3432,7 +3453,7 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_dcm_exact(
 __global__ __launch_bounds__(REFLECT_BLOCK) void surface_eval_kernel(
     xrt_hip_pass P, int what, int64_t n, const double* __restrict__ u,
     const double* __restrict__ v, const double* __restrict__ w, double* __restrict__ o) {
-  using K = Generic1;
+  using K = GenericAll;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double p = u[i], q = v[i], t = w ? w[i] : 0.;
@@ -3486,7 +3507,7 @@ hipError_t surface_eval_launch(const xrt_hip_pass& P, int what, int64_t n, const
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(REFLECT_BLOCK) void beam_to_global_kernel(xrt_hip_pass P,
                                                                        xrt_hip_beam b) {
-  using K = Generic1;
+  using K = GenericAll;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= b.n) return;
   double x = b.x[i] + P.shift[0], y = b.y[i] + P.shift[1], z = b.z[i] + P.shift[2];
@@ -3575,7 +3596,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void diffract_pre_kernel(
     double* __restrict__ ny, double* __restrict__ nz, double* __restrict__ nl,
     double* __restrict__ k, double2* __restrict__ Es, double2* __restrict__ Ep,
     double* __restrict__ part) {
-  using K = Generic1;
+  using K = GenericAll;
   __shared__ double lds_d[REFLECT_MAX_WAVES];
   double sumJ = 0., sumJn = 0., cnt = 0.;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -3700,7 +3721,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void basis_to_global_kernel(
 __global__ __launch_bounds__(REFLECT_BLOCK) void wave_receive_kernel(xrt_hip_pass P, int is_oe,
                                                                      xrt_hip_beam w,
                                                                      xrt_hip_beam g) {
-  using K = Generic1;
+  using K = GenericAll;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w.n) return;
   double a = g.a[i], b = g.b[i], c = g.c[i];
@@ -3972,6 +3993,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const bool need_mean = deflects_as_crystal(M) && !M.geom_transmitted;
   const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
   const bool layers = M.kind == XRT_HIP_MAT_MULTILAYER;
+  const bool wide = P.surf_kind == XRT_HIP_SURF_BENT_BRAGG || P.surf_kind == XRT_HIP_SURF_VFM ||
+                    P.surf_kind == XRT_HIP_SURF_DUALVFM || P.surf_kind == XRT_HIP_SURF_DICED;
   using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
   using AnyXtal = Spec<0, -1, XRT_HIP_MAT_CRYSTAL, false>;
   using ToroidMirror = Spec<0, XRT_HIP_SURF_TOROID, XRT_HIP_MAT_MIRROR, true>;
@@ -3988,7 +4011,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
 #define XRT_XTAL(SPEC)                                                                       \
   hipLaunchKernelGGL((reflect_fused_xtal<SPEC, mode>), grid, fblock, 0, st, P, M, in, restore, \
                      lb, vb, theta, g, &g->any_neg, opt)
-      if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED)
+      if (layers && wide)
+        XRT_XTAL(Layered2);
+      else if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED)
         XRT_XTAL(Layered1);
       else if (layers)
         XRT_XTAL(Layered0);
@@ -4009,10 +4034,14 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     const bool plain = !P.grating && !P.asymmetric && !P.no_intersection_search;
     if (P.g_ray_x) {
       XRT_FUSED(PerRayZones);
+    } else if (layers && wide) {
+      XRT_FUSED(Layered2);
     } else if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED) {
       XRT_FUSED(Layered1);
     } else if (layers) {
       XRT_FUSED(Layered0);
+    } else if (wide) {
+      XRT_FUSED(Generic2);
     } else if (P.surf_kind >= XRT_HIP_SURF_BLAZED) {
       XRT_FUSED(Generic1);
     } else if (plain && M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_TOROID) {
@@ -4043,11 +4072,17 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     if (P.g_ray_x)
       hipLaunchKernelGGL(reflect_exact<PerRayZones>, xgrid, xblock, 0, st, P, M, in, restore, lb,
                          vb, A);
+    else if (layers && wide)
+      hipLaunchKernelGGL(reflect_exact<Layered2>, xgrid, xblock, 0, st, P, M, in, restore, lb,
+                         vb, A);
     else if (layers && P.surf_kind >= XRT_HIP_SURF_BLAZED)
       hipLaunchKernelGGL(reflect_exact<Layered1>, xgrid, xblock, 0, st, P, M, in, restore, lb,
                          vb, A);
     else if (layers)
       hipLaunchKernelGGL(reflect_exact<Layered0>, xgrid, xblock, 0, st, P, M, in, restore, lb,
+                         vb, A);
+    else if (wide)
+      hipLaunchKernelGGL(reflect_exact<Generic2>, xgrid, xblock, 0, st, P, M, in, restore, lb,
                          vb, A);
     else if (P.surf_kind >= XRT_HIP_SURF_BLAZED)
       hipLaunchKernelGGL(reflect_exact<Generic1>, xgrid, xblock, 0, st, P, M, in, restore, lb,
