@@ -32,6 +32,13 @@ def test_hot_kernels_keep_their_budget():
     gate = _one(table, 'reflect_exactINS_4SpecILi0ELin1ELin1ELb0')          # returns at once
     assert gate['scratch'] <= 256
     assert _one(table, 'reflect_dcm_exactINS_4SpecILi0ELin1ELin1ELb0')['scratch'] <= 256
+    # the generic kernels of surface families 1 (conics, blazed, lenses) and 2 (bent crystals,
+    # diced, VFM): family 2 compiled into family 1 spilled 126 VGPRs / 1232 B there
+    for mode in ('Li0', 'Li2'):
+        conic = _one(table, 'reflect_fusedINS_4SpecILi1ELin1ELin1ELb0EEE' + mode)
+        assert conic['scratch'] <= 256 and conic['vgpr_spill'] <= 64 and conic['vgpr'] <= 128
+        bent = _one(table, 'reflect_fusedINS_4SpecILi2ELin1ELin1ELb0EEE' + mode)
+        assert bent['scratch'] <= 64 and bent['vgpr_spill'] == 0 and bent['vgpr'] <= 128
     for small in ('reflect_decide_opt', 'reflect_decide_dcm'):
         assert _one(table, small)['scratch'] == 0
     for name, r in table.items():
