@@ -11,10 +11,18 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libxrt_hip.so')
-SOURCES = ['kirchhoff.hip', 'reflect.hip', 'screen.hip', 'hist.hip', 'undulator.hip',
-           'capi.hip']
-HEADERS = ['fp64_math.h', 'kirchhoff.h', 'reflect.h', 'screen.h', 'hist.h', 'undulator.h',
+# the reflect kernels are instantiated in units of their own (reflect_tu.h): the slowest first
+SOURCES = ['reflect_exact1.hip', 'reflect_exact3.hip', 'reflect_exact0.hip',
+           'reflect_exact2.hip', 'reflect_layered_x.hip', 'reflect_layered_f.hip',
+           'reflect_generic.hip', 'reflect_xtal.hip', 'reflect.hip', 'reflect_hot.hip',
+           'kirchhoff.hip', 'undulator.hip', 'capi.hip', 'screen.hip', 'hist.hip']
+HEADERS = ['fp64_math.h', 'kirchhoff.h', 'reflect.h', 'reflect_impl.h', 'reflect_tu.h',
+           'screen.h', 'hist.h', 'undulator.h',
            os.path.join('..', '..', 'include', 'xrt_hip.h')]
+# headers only these sources depend on (everything else rebuilds on any header change)
+ONLY_FOR = {'reflect_impl.h': 'reflect', 'reflect_tu.h': 'reflect', 'kirchhoff.h': ('kirchhoff', 'capi'),
+            'hist.h': ('hist', 'capi'), 'screen.h': ('screen', 'capi'),
+            'undulator.h': ('undulator', 'capi')}
 # -ffp-contract=off: fused multiply-add only where the source says fma();
 # the reference (numpy) never fuses and ray states / the Kirchhoff phase
 # depend on bit-identical intermediate roundings.
@@ -36,21 +44,38 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def _headers_of(source):
+    out = []
+    for h in HEADERS:
+        users = ONLY_FOR.get(h)
+        if users is None or source.startswith(users):
+            out.append(os.path.join(HERE, h))
+    return out
+
+
+def build(force=False, verbose=False, jobs=None):
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
-    hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs = []
+    todo = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
     for s in srcs:
         src = os.path.join(HERE, s)
         obj = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
         objs.append(obj)
-        if force or _stale(obj, [src, __file__] + hdrs):
-            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
-            if verbose:
-                print(' '.join(cmd))
-            subprocess.check_call(cmd, cwd=HERE)
+        if force or _stale(obj, [src, __file__] + _headers_of(s)):
+            todo.append([hipcc] + FLAGS + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=HERE)
+
+    if todo:
+        from concurrent.futures import ThreadPoolExecutor
+        jobs = jobs or int(os.environ.get('XRT_HIP_BUILD_JOBS', 0)) or os.cpu_count() or 1
+        with ThreadPoolExecutor(max_workers=max(1, min(jobs, len(todo)))) as pool:
+            list(pool.map(run, todo))
     if force or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

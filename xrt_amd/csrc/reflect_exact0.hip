@@ -1,0 +1,17 @@
+// The exact sequence (verdict kernel + redo) of family-0 passes and of the fused DCM.
+#include "reflect_tu.h"
+
+namespace xrt {
+
+bool tu_exact0(int spec, const ExactLaunch& L) {
+  if (spec != SP_GENERIC0) return false;
+  launch_exact_k<Generic0>(L);
+  return true;
+}
+
+void tu_exact0_dcm(const DcmLaunch& L) {
+  hipLaunchKernelGGL(reflect_dcm_exact<Generic0>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2,
+                     *L.M2, *L.in, *L.lo1, *L.lo2, *L.gb2, L.A1, L.A2);
+}
+
+}  // namespace xrt

@@ -1,0 +1,101 @@
+// The kernel templates of reflect_impl.h are instantiated in several translation units so
+// that hipcc compiles them in parallel (the whole set in one file took three minutes) and a
+// change to the hot kernels recompiles one small file. Each unit exports plain launchers;
+// reflect.hip picks the unit by the spec id.
+#pragma once
+#include "reflect_impl.h"
+
+namespace xrt {
+
+using FlatXtal = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_CRYSTAL, false>;
+using AnyXtal = Spec<0, -1, XRT_HIP_MAT_CRYSTAL, false>;
+using ToroidMirror = Spec<0, XRT_HIP_SURF_TOROID, XRT_HIP_MAT_MIRROR, true>;
+using FlatMirror = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_MIRROR, true>;
+using BentMirror = Spec<0, XRT_HIP_SURF_BENTFLAT, XRT_HIP_MAT_MIRROR, true>;
+using FlatPlate = Spec<0, XRT_HIP_SURF_FLAT, XRT_HIP_MAT_PLATE, true>;   // filters, windows
+using ThickFlat = ThickXtal<XRT_HIP_SURF_FLAT>;
+using ThickAny = ThickXtal<-1>;
+
+enum SpecId {
+  SP_GENERIC0, SP_GENERIC1, SP_GENERIC2, SP_PER_RAY_ZONES,
+  SP_LAYERED0, SP_LAYERED1, SP_LAYERED2,
+  SP_TOROID_MIRROR, SP_FLAT_MIRROR, SP_BENT_MIRROR, SP_FLAT_PLATE,
+  SP_THICK_FLAT, SP_THICK_ANY, SP_FLAT_XTAL, SP_ANY_XTAL
+};
+
+struct FusedLaunch {   // one launch of reflect_fused / reflect_fused_xtal
+  dim3 grid, block;
+  hipStream_t st;
+  const xrt_hip_pass* P;
+  const xrt_hip_material* M;
+  const xrt_hip_beam *in, *restore, *lb, *vb;
+  double* theta;
+  GStat* g;
+  OptStat* opt;
+};
+struct ExactLaunch {   // reflect_exact
+  dim3 grid, block;
+  hipStream_t st;
+  const xrt_hip_pass* P;
+  const xrt_hip_material* M;
+  const xrt_hip_beam *in, *restore, *lb, *vb;
+  PassAux A;
+};
+struct DcmLaunch {     // reflect_fused_dcm / reflect_dcm_exact
+  dim3 grid, block;
+  hipStream_t st;
+  const xrt_hip_pass *P1, *P2;
+  const xrt_hip_material *M1, *M2;
+  const xrt_hip_beam *in, *lo1, *lo2, *gb2;
+  double *theta1, *theta2;
+  GStat *g1, *g2;
+  OptStat *opt1, *opt2;
+  PassAux A1, A2;      // (the exact redo)
+};
+
+template <class K>
+inline void launch_fused_k(int mode, const FusedLaunch& L) {
+  if (mode == 0)
+    hipLaunchKernelGGL((reflect_fused<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
+                       *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt);
+  else
+    hipLaunchKernelGGL((reflect_fused<K, 2>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
+                       *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt);
+}
+template <class K>
+inline void launch_xtal_k(int mode, const FusedLaunch& L) {
+  if (mode == 0)
+    hipLaunchKernelGGL((reflect_fused_xtal<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
+                       *L.restore, *L.lb, *L.vb, L.theta, L.g, &L.g->any_neg, L.opt);
+  else
+    hipLaunchKernelGGL((reflect_fused_xtal<K, 2>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
+                       *L.restore, *L.lb, *L.vb, L.theta, L.g, &L.g->any_neg, L.opt);
+}
+template <class K>
+inline void launch_exact_k(const ExactLaunch& L) {
+  hipLaunchKernelGGL(reflect_exact<K>, L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in, *L.restore,
+                     *L.lb, *L.vb, L.A);
+}
+template <class K>
+inline void launch_dcm_k(const DcmLaunch& L) {
+  hipLaunchKernelGGL(reflect_fused_dcm<K>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2, *L.M2,
+                     *L.in, *L.lo1, *L.lo2, *L.gb2, L.theta1, L.theta2, L.g1, L.g2,
+                     &L.g1->any_neg, &L.g2->any_neg, L.opt1, L.opt2);
+}
+
+// the units (each returns false for a spec it does not hold)
+bool tu_hot_fused(int spec, int mode, const FusedLaunch& L);        // reflect_hot.hip
+bool tu_hot_xtal(int spec, int mode, const FusedLaunch& L);
+bool tu_hot_dcm(int spec, const DcmLaunch& L);
+bool tu_xtal_xtal(int spec, int mode, const FusedLaunch& L);        // reflect_xtal.hip
+bool tu_xtal_dcm(int spec, const DcmLaunch& L);
+bool tu_generic_fused(int spec, int mode, const FusedLaunch& L);    // reflect_generic.hip
+bool tu_layered_fused(int spec, int mode, const FusedLaunch& L);    // reflect_layered_f.hip
+bool tu_layered_xtal(int spec, int mode, const FusedLaunch& L);     // reflect_layered_x.hip
+bool tu_exact0(int spec, const ExactLaunch& L);                     // reflect_exact0.hip
+void tu_exact0_dcm(const DcmLaunch& L);
+bool tu_exact1(int spec, const ExactLaunch& L);                     // reflect_exact1.hip
+bool tu_exact2(int spec, const ExactLaunch& L);                     // reflect_exact2.hip
+bool tu_exact3(int spec, const ExactLaunch& L);                     // reflect_exact3.hip
+
+}  // namespace xrt
