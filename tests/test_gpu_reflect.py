@@ -417,7 +417,15 @@ def test_rocking_curves_match_reference(golden_dir):
             scale = np.abs(ref[fin]).max()
             # non-finite reference values are NaN->0 further down the pipeline
             err = np.abs(mine[fin] - ref[fin]).max() / scale
-            assert err < 1e-9, (key, err)
+            # (bar: 1e-5.) Thick crystals: the amplitude is an algebraic function of alpha.
+            # Thin crystals carry exp(i k t (chi0 - alpha b) / 2 gamma0) with k t ~ 5e6 at
+            # 100 um: alpha = (H^2/2 - k0.H)/k^2 + ... cancels four digits at the Bragg
+            # angle, so ANY two orders of evaluating it (the reference's own included) differ
+            # by ~1e-12 relative, times that phase ~1e-9. The kernel shares the energy-
+            # dependent part between the crystals of a DCM and no longer follows the
+            # reference's order of operations there.
+            thin = not np.isnan(t)
+            assert err < (2e-8 if thin else 1e-9), (key, err)
 
 
 # ---- seeded random beams vs the oracle at larger sizes -------------------------

@@ -13,6 +13,53 @@ __device__ __forceinline__ double fma_(double a, double b, double c) {
   return __builtin_fma(a, b, c);
 }
 
+// ---------------------------------------------------------------------------
+// IEEE division without its range scaling. LLVM lowers an f64 '/' on AMDGPU to
+//   v_div_scale x2, v_rcp_f64, two Newton steps, q = a y, r = fma(-b, q, a),
+//   v_div_fmas (= fma(r, y, q) unless the scaling flag is up), v_div_fixup
+// -- 11 instructions. v_div_scale only rescales when an exponent is extreme (denominator or
+// quotient near the denormal or overflow range, numerator below 2^-969), v_div_fixup only
+// patches zeros / infinities / NaN / denormal results: with operands whose exponents are
+// ordinary the remaining core is the same sequence of roundings, i.e. the same correctly
+// rounded bits in 8 instructions (tools/probes/probe_fp64_seeds.hip: 1e9 random pairs
+// with exponents -60..60 agree with '/' bit for bit). Guarding it with exponent tests costs
+// more than it saves, so it is only used where the caller knows the operands are ordinary
+// (a = +-0 gives +0, b = 0 gives NaN).
+__device__ __forceinline__ double div_rn(double a, double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  y = fma_(fma_(-b, y, 1.0), y, y);
+  y = fma_(fma_(-b, y, 1.0), y, y);
+  const double q = a * y;
+  const double r = fma_(-b, q, a);
+  return fma_(r, y, q);
+}
+// acos as numpy computes it (libm, < 1 ulp) for the grazing and Bragg angles of a beamline,
+// |x| <= 0.5, without ocml's both-branches evaluation: fdlibm's rational form
+// acos(x) = pi/2 - (x + x R(x^2)), R = p/q (Sun's coefficients), 25 slots instead of ~95;
+// the library call for steeper incidence. Within 1 ulp (2.2e-16) of libm's value, which is
+// what theta = acos(.) - pi/2 is compared at.
+__device__ __forceinline__ double acos_np(double x) {
+  if (__builtin_expect(!(__builtin_fabs(x) <= 0.5), 0)) return acos(x);
+  const double z = x * x;
+  double p = 3.47933107596021167570e-05;
+  p = fma_(p, z, 7.91534994289814532176e-04);
+  p = fma_(p, z, -4.00555345006794114027e-02);
+  p = fma_(p, z, 2.01212532134862925881e-01);
+  p = fma_(p, z, -3.25565818622400915405e-01);
+  p = fma_(p, z, 1.66666666666666657415e-01);
+  p *= z;
+  double q = 7.70381505559019352791e-02;
+  q = fma_(q, z, -6.88283971605453293030e-01);
+  q = fma_(q, z, 2.02094576023350569471e+00);
+  q = fma_(q, z, -2.40339491173441421878e+00);
+  q = fma_(q, z, 1.0);
+  double y = __builtin_amdgcn_rcp(q);
+  y = fma_(fma_(-q, y, 1.0), y, y);
+  y = fma_(fma_(-q, y, 1.0), y, y);
+  const double r = p * y;
+  return 1.57079632679489655800e+00 - (x - (6.12323399573676603587e-17 - x * r));
+}
+
 // Correctly rounded sqrt(x) for normal positive x (no scaling / special cases:
 // callers guarantee 2^-700 < x < 2^700) that ALSO hands back 1/sqrt(x) to ~1 ulp
 // for free. Same Goldschmidt iteration LLVM emits for f64 sqrt on AMDGPU

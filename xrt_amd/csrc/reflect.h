@@ -9,13 +9,13 @@
 #define REFLECT_BLOCK 256
 // threads per block of the two big kernels (one ray per lane). Measured, three alternating
 // runs each on one box: reflect_fused 64 / 128 / 256 / 512 threads -> 0.672 / 0.695 / 0.712 /
-// 0.760 ms (64 costs the pass more than it gains the kernel), reflect_fused_dcm 64 / 128 / 256 /
-// 512 / 1024 -> 1.104 / 1.119 / 1.135 / 1.094 / 1.169 ms.
+// 0.760 ms (64 costs the pass more than it gains the kernel). reflect_fused_dcm (round 3, since
+// it ends without a block barrier): 128 / 256 / 512 threads -> 0.962 / 0.948 / 0.987 ms.
 #ifndef REFLECT_FUSED_BLOCK
 #define REFLECT_FUSED_BLOCK 128
 #endif
 #ifndef REFLECT_DCM_BLOCK
-#define REFLECT_DCM_BLOCK 512
+#define REFLECT_DCM_BLOCK 256
 #endif
 #define REFLECT_MAX_WAVES 16                      /* waves of the largest block (1024 lanes) */
 // waves per SIMD the fused kernel is compiled for (register budget 512/N VGPRs)

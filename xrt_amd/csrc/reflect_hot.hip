@@ -27,3 +27,13 @@ bool tu_hot_dcm(int spec, const DcmLaunch& L) {
 }
 
 }  // namespace xrt
+
+#ifdef XRT_PROBE_TIMING
+// the per-wave records of the last launch: [wave][8] = ticks of sections 0..4, [7] = start stamp
+extern "C" __attribute__((visibility("default"))) int xrt_probe_ticks(unsigned long long* out,
+                                                                      long long waves) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(xrt::g_probe_ticks), (size_t)waves * 64) != hipSuccess)
+    return -1;
+  return 0;
+}
+#endif

@@ -51,6 +51,51 @@ __device__ constexpr double kMaxHalfSize = 1000.; // :92
 __device__ constexpr double kMaxDepth = 100.;     // :94
 
 // ---------------------------------------------------------------------------
+// Which chunk of the beam a block works on. Hardware hands consecutive block ids to the
+// eight XCDs in turn; with XRT_XCD_CHUNKS every XCD walks ONE contiguous eighth of the beam,
+// so that the dirty lines of an output array in its L2 are neighbours in memory.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned beam_block() {
+#ifdef XRT_XCD_CHUNKS
+  const unsigned nb = gridDim.x, b = blockIdx.x;
+  const unsigned q = nb >> 3, rem = nb & 7u, x = b & 7u, j = b >> 3;
+  return x * q + (x < rem ? x : rem) + j;
+#else
+  return blockIdx.x;
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// Development probe (tools/build_variant.sh NAME -DXRT_PROBE_TIMING): shader-clock stamps
+// between the sections of a ray's life in the lean fused kernel, summed per wave into
+// g_probe_ticks (read back through xrt_probe_ticks of reflect_hot.hip). Not compiled into
+// the regular library.
+// ---------------------------------------------------------------------------
+#ifdef XRT_PROBE_TIMING
+#define XRT_PROBE_WAVES (1 << 18)
+__device__ unsigned long long g_probe_ticks[XRT_PROBE_WAVES * 8];   // one slot per wave
+struct ProbeClock {
+  unsigned long long t[8];
+  __device__ __forceinline__ void tick(int k, double dep) {
+    unsigned long long v;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "v"(dep) : "memory");
+    t[k] = v;
+  }
+  __device__ __forceinline__ void flush(int n) {
+    const unsigned long long w = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if ((threadIdx.x & 63) == 0 && w < XRT_PROBE_WAVES) {
+      for (int k = 0; k + 1 < n; ++k) g_probe_ticks[w * 8 + k] = t[k + 1] - t[k];
+      g_probe_ticks[w * 8 + 7] = t[0];
+    }
+  }
+};
+#define XRT_TICK(pc, k, dep) (pc).tick(k, dep)
+#else
+struct ProbeClock {};
+#define XRT_TICK(pc, k, dep) ((void)0)
+#endif
+
+// ---------------------------------------------------------------------------
 // complex helpers (numpy's algorithms where the choice is visible at 1e-16)
 // ---------------------------------------------------------------------------
 struct cplx {
@@ -1271,7 +1316,11 @@ template <class K, bool OPT = false>
 __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
                                          const LocalRay& r, SolveAux* aux = nullptr) {
   Hit h;
+#ifdef XRT_PROBE_NULL_COMPUTE
+  if (true) {
+#else
   if (PNIS(P)) {  // reflect.py:676-682
+#endif
     h.t = 0.;
     h.x = r.x;
     h.y = r.y;
@@ -1604,8 +1653,8 @@ __device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, do
     f2 = M.tab_f2[e][j];
   } else {
     const double dx = tE[j + 1] - tE[j];
-    const double s1 = (M.tab_f1[e][j + 1] - M.tab_f1[e][j]) / dx;
-    const double s2 = (M.tab_f2[e][j + 1] - M.tab_f2[e][j]) / dx;
+    const double s1 = div_rn(M.tab_f1[e][j + 1] - M.tab_f1[e][j], dx);
+    const double s2 = div_rn(M.tab_f2[e][j + 1] - M.tab_f2[e][j], dx);
     f1 = s1 * (E - tE[j]) + M.tab_f1[e][j];
     f2 = s2 * (E - tE[j]) + M.tab_f2[e][j];
   }
@@ -1624,7 +1673,7 @@ __device__ __forceinline__ cplx refractive_index(const xrt_hip_material& M, doub
     f.re += (double)M.Z[e];
     xf = xf + f * M.quantity[e];
   }
-  const double wl = kCH / E;
+  const double wl = div_rn(kCH, E);
   const double pre = 1e-24 * kAVOGADRO * kR0 / kPI2 * (wl * wl) * M.rho;
   const cplx v = (xf * pre) / M.mass;
   return C(1. - v.re, -v.im);
@@ -1671,73 +1720,39 @@ __device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, in
     A.rs = ((2. * n1cosAlpha) / (n1cosAlpha + n2cosBeta)) * tf;
     A.rp = ((2. * n1cosAlpha) / (n2 * cosAlpha + n1 * cosBeta)) * tf;
   }
-  A.mu = fabs(n.im) * E / kCHBAR * 2e8;   // exact division kept: mu, nk are compared bitwise
-  A.nk = n.re * E / kCHBAR * 1e8;
+  // (the exact quotients: mu, nk are compared bitwise)
+  A.mu = div_const(fabs(n.im) * E, kCHBAR, 1. / kCHBAR) * 2e8;
+  A.nk = div_const(n.re * E, kCHBAR, 1. / kCHBAR) * 1e8;
   return A;
 }
 
-// Bragg / Laue dynamical-diffraction amplitudes, crystal.py:492-645
-template <bool THICK = false>
-__device__ __forceinline__ cplx crystal_one_pol(const xrt_hip_material& M, double polFactor,
-                                                cplx alpha, cplx chih, cplx chih_, cplx chi0,
-                                                double b, double k02, double k0s,
-                                                double kHs) {
-  const cplx delta = csqrt_(alpha * alpha + ((chih * (polFactor * polFactor)) * chih_) / b);
-  const double sqb = sqrt(fabs(b));
-  if (THICK || M.thick) {
-    const cplx num = chih * polFactor;
-    cplx ra = num / (alpha + delta);
-    cplx ad = alpha - delta;
-    if (ad.re == 0. && ad.im == 0.) ad = C(1e-100, 0.);
-    const cplx rb = num / ad;
-    if (cisnan(ra)) ra = rb;
-    // the root of smaller modulus (crystal.py:577-583), compared through |.|^2
-    if (cnorm2(rb.re, rb.im) < cnorm2(ra.re, ra.im)) ra = rb;
-    return ra / sqb;
-  }
-  const double t = M.t_crystal * 1e7;
-  const cplx l = ((delta * t) * k02) / 2. / kHs;
-  const cplx I = C(0., 1.);
-  cplx ra;
-  // exp(1j k02 t (chi0 - alpha b) / 2 / k0s)
-  const cplx ph = cexp_(((I * (k02 * t)) * (chi0 - alpha * b)) / 2. / k0s);
-  if (M.geom_bragg) {
-    if (M.geom_transmitted)
-      ra = (C(1., 0.) / (ccos_(l) - ((I * alpha) * csin_(l)) / delta)) * ph;
-    else
-      ra = (chih * polFactor) / (alpha + (I * delta) / ctan_(l));
-  } else {
-    if (M.geom_transmitted)
-      ra = (ccos_(l) + ((I * alpha) * csin_(l)) / delta) * ph;
-    else
-      ra = (((chih * polFactor) * csin_(l)) / delta) * ph;
-  }
-  if (!M.geom_transmitted) ra = ra / sqb;
-  return ra;
-}
+// Bragg / Laue dynamical-diffraction amplitudes, crystal.py:492-645.
+// Amplitudes are compared at 1e-5 (observed ~1e-10), only ray STATES are bit-exact and they
+// do not depend on anything below: the arithmetic here is arranged for few issue slots
+// (one reciprocal per complex division, fused products, quantities that depend on the
+// photon energy only computed once per ray -- for BOTH crystals of a DCM).
+//
+// What the amplitude needs of (crystal, photon energy): get_F_chi (crystal.py:297-306),
+// the structure factors (crystals_basic.py:22-31, 76-80, 424-440), get_Bragg_angle (:1105-1120)
+struct XtalEnergy {
+  cplx chi0, chih, chih_;   // chi_0, chi_h, chi_hbar
+  cplx chihh;               // chi_h chi_hbar
+  double a1;                // H / k  (= 2 sin(thetaB))
+  double a0;                // H^2 / (2 k^2)
+  double cos2thetaB;        // the polarisation factor of p, crystal.py:643
+  double k;                 // the wavenumber [1/A] (thin crystals)
+};
 
 // apre: f1 + i f2 of the crystal's element at E, if the caller looked it up already
-template <bool THICK = false, bool CELL = true>
-__device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, double E,
-                                                  double bdsn, double bosn, double bdhn,
+template <bool CELL = true>
+__device__ __forceinline__ XtalEnergy xtal_energy(const xrt_hip_material& M, double E,
                                                   const TabWin& w, const cplx* apre = nullptr) {
-  Ampl A;
-  const double waveLength = kCH * frcp(E);
-  const double k = kPI2 * frcp(waveLength);
-  const double k0s = -bdsn * k;
-  double kHs = -bosn * k;
-  const double HH = kPI2 * frcp(M.d);
-  const double k0H = fabs(bdhn) * HH * k;
-  const double k02 = k * k;
-  const double H2 = HH * HH;
-  double b;
-  if (kHs == 0.) {
-    kHs = 1.;
-    b = -1.;
-  } else {
-    b = k0s * frcp(kHs);
-  }
-  // structure factors, crystals_basic.py:22-31, 76-80; chi, crystal.py:297-306
+  XtalEnergy X;
+  // a1 = H / k = (2 pi / d) (CH / (2 pi E)) = CH / (d E); the wavelength is a1 d
+  X.a1 = kCH * frcp(M.d * E);
+  const double waveLength = X.a1 * M.d;
+  X.k = E * (kPI2 / kCH);
+  X.a0 = 0.5 * (X.a1 * X.a1);
   cplx F0 = C(0., 0.), Fh = C(0., 0.), Fh_ = C(0., 0.);
   if (CELL && M.structure == 2) {
     // from the unit cell, crystals_basic.py:424-440: the sums over the atoms of each
@@ -1771,18 +1786,100 @@ __device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, dou
     }
   }
   const double c2l = M.chi_to_f * (waveLength * waveLength);
-  const cplx chi0 = conj(F0) * c2l, chih = conj(Fh) * c2l, chih_ = conj(Fh_) * c2l;
+  X.chi0 = conj(F0) * c2l;
+  X.chih = conj(Fh) * c2l;
+  X.chih_ = conj(Fh_) * c2l;
+  X.chihh = X.chih * X.chih_;
   // Bragg angle, crystal.py:1105-1120: only cos(2 thetaB) = 1 - 2 sin^2(thetaB) is used
-  double sb = kCH * frcp(2. * M.d * E);
+  double sb = 0.5 * X.a1;
   if (sb > 1.) sb = 1. - 1e-16;
   if (sb < -1.) sb = -1. + 1e-16;
-  const double cos2thetaB = 1. - 2. * (sb * sb);
-  const cplx alpha = C((H2 * 0.5 - k0H) * frcp(k02), 0.) + (chi0 * 0.5) * (frcp(b) - 1.);
-  A.rs = crystal_one_pol<THICK>(M, 1., alpha, chih, chih_, chi0, b, k02, k0s, kHs);
-  A.rp = crystal_one_pol<THICK>(M, cos2thetaB, alpha, chih, chih_, chi0, b, k02, k0s, kHs);
+  X.cos2thetaB = 1. - 2. * (sb * sb);
+  return X;
+}
+
+// one polarisation of a thin crystal / a Laue case, crystal.py:586-616
+__device__ __forceinline__ cplx crystal_thin_pol(const xrt_hip_material& M, double polFactor,
+                                                 cplx alpha, cplx delta, cplx chih, cplx chi0,
+                                                 double b, double k02, double k0s, double kHs) {
+  const double sqb = sqrt(fabs(b));
+  const double t = M.t_crystal * 1e7;
+  const cplx l = ((delta * t) * k02) / 2. / kHs;
+  const cplx I = C(0., 1.);
+  cplx ra;
+  // exp(1j k02 t (chi0 - alpha b) / 2 / k0s)
+  const cplx ph = cexp_(((I * (k02 * t)) * (chi0 - alpha * b)) / 2. / k0s);
+  if (M.geom_bragg) {
+    if (M.geom_transmitted)
+      ra = (C(1., 0.) / (ccos_(l) - ((I * alpha) * csin_(l)) / delta)) * ph;
+    else
+      ra = (chih * polFactor) / (alpha + (I * delta) / ctan_(l));
+  } else {
+    if (M.geom_transmitted)
+      ra = (ccos_(l) + ((I * alpha) * csin_(l)) / delta) * ph;
+    else
+      ra = (((chih * polFactor) * csin_(l)) / delta) * ph;
+  }
+  if (!M.geom_transmitted) ra = ra / sqb;
+  return ra;
+}
+
+// the thick Bragg case, crystal.py:571-584: chi_h C / (alpha +- delta), the root of smaller
+// modulus, over sqrt|b|. The smaller quotient has the LARGER denominator, and
+// |alpha + delta|^2 - |alpha - delta|^2 = 4 Re(alpha conj(delta)): one complex division.
+// (rsqb_pol = polFactor / sqrt|b|)
+__device__ __forceinline__ cplx crystal_thick_pol(cplx alpha, cplx delta, cplx chih,
+                                                  double rsqb_pol) {
+  const bool plus = fma_(alpha.re, delta.re, alpha.im * delta.im) >= 0.;
+  const cplx den = plus ? alpha + delta : alpha - delta;
+  const double scl = rsqb_pol * frcp(cnorm2(den.re, den.im));
+  return C(fma_(chih.re, den.re, chih.im * den.im) * scl,
+           fma_(chih.im, den.re, -(chih.re * den.im)) * scl);
+}
+
+template <bool THICK = false>
+__device__ __forceinline__ Ampl crystal_amplitude_at(const xrt_hip_material& M,
+                                                     const XtalEnergy& X, double bdsn,
+                                                     double bosn, double bdhn) {
+  Ampl A;
   A.mu = 0.;
   A.nk = 0.;
+  // b = k0s / kHs = (in . n_s) / (out . n_s); kHs == 0 -> b = -1 (crystal.py:634-637)
+  double b = -1., invb = -1.;
+  if (bosn != 0.) {
+    const double t = frcp(bdsn * bosn);
+    b = (bdsn * bdsn) * t;
+    invb = (bosn * bosn) * t;
+  }
+  // alpha = (H^2/2 - k0.H) / k^2 + chi0/2 (1/b - 1)
+  const double h = 0.5 * (invb - 1.);
+  const cplx alpha = C(fma_(X.chi0.re, h, fma_(-fabs(bdhn), X.a1, X.a0)), X.chi0.im * h);
+  const cplx alpha2 = C(fma_(alpha.re, alpha.re, -(alpha.im * alpha.im)),
+                        2. * (alpha.re * alpha.im));
+  const double c2 = X.cos2thetaB;
+  const cplx xb = X.chihh * invb;
+  const cplx delta_s = csqrt_(alpha2 + xb);
+  const cplx delta_p = csqrt_(alpha2 + xb * (c2 * c2));
+  if (THICK || M.thick) {
+    double rsqb;
+    (void)sqrt_rn_rinv(fabs(b), rsqb);
+    A.rs = crystal_thick_pol(alpha, delta_s, X.chih, rsqb);
+    A.rp = crystal_thick_pol(alpha, delta_p, X.chih, rsqb * c2);
+    return A;
+  }
+  const double k02 = X.k * X.k;
+  const double k0s = -bdsn * X.k;
+  const double kHs = bosn != 0. ? -bosn * X.k : 1.;
+  A.rs = crystal_thin_pol(M, 1., alpha, delta_s, X.chih, X.chi0, b, k02, k0s, kHs);
+  A.rp = crystal_thin_pol(M, c2, alpha, delta_p, X.chih, X.chi0, b, k02, k0s, kHs);
   return A;
+}
+
+template <bool THICK = false, bool CELL = true>
+__device__ __forceinline__ Ampl crystal_amplitude(const xrt_hip_material& M, double E,
+                                                  double bdsn, double bosn, double bdhn,
+                                                  const TabWin& w, const cplx* apre = nullptr) {
+  return crystal_amplitude_at<THICK>(M, xtal_energy<CELL>(M, E, w, apre), bdsn, bosn, bdhn);
 }
 
 // Multilayer / Coated, materials/multilayer.py:257-566: Parratt's recursion from the
@@ -2306,7 +2403,9 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
                                                const LocalRay& r, const Hit& h, RayIn q,
                                                const xrt_hip_beam& in, int64_t i,
                                                bool has_amp, int own_sign = 0,
-                                               const cplx* npre = nullptr) {
+                                               const cplx* npre = nullptr,
+                                               XtalEnergy* xe = nullptr,
+                                               bool xe_ready = false) {
   Finished out;
   q.path += h.t;
   // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
@@ -2315,7 +2414,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   double bdn = r.a * n[0] + r.b * n[1] + r.c * n[2];
   if (bdn < -1.) bdn = -1.;
   if (bdn > 1.) bdn = 1.;
-  out.theta = acos(bdn) - kPI / 2.;
+  out.theta = acos_np(bdn) - kPI / 2.;
   out.bdn = bdn;
   const double bdsn = PASYM(P) ? (r.a * n[3] + r.b * n[4] + r.c * n[5]) : bdn;
 
@@ -2343,23 +2442,24 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       // whenever all rays of the batch agree, which the any_neg / any_pos flags verify.
       const double bdnMean = own_sign ? bdn : g.sum_bdn / (double)g.n_good1;
       const double sgbdn = bdnMean < 0. ? 1. : -1.;
-      const double wHd = 1. / (M.d * 1e-7);
+      const double wHd = div_rn(1., M.d * 1e-7);
       const double g0 = (n[0] - ndsn * n[3]) * wHd * sgbdn;
       const double g1 = (n[1] - ndsn * n[4]) * wHd * sgbdn;
       const double g2 = (n[2] - ndsn * n[5]) * wHd * sgbdn;
       const double sig = M.geom_bragg ? -1. : 1.;
       const double bdg = r.a * g0 + r.b * g1 + r.c * g2;
       const double G2 = g0 * g0 + g1 * g1 + g2 * g2;
-      const double ol = 1. * kCH / q.E * 1e-7;
+      const double ol = div_rn(kCH, q.E) * 1e-7;
       const double u = bdsn * bdsn - 2. * bdg * ol - G2 * (ol * ol);
-      const double dn = bdsn + sig * sqrt(fabs(u));
+      const double dn = bdsn + sig * sqrt_unit(fabs(u));
       ao = r.a - n[3] * dn + g0 * ol;
       bo = r.b - n[4] * dn + g1 * ol;
       co = r.c - n[5] * dn + g2 * ol;
-      const double nm = sqrt(ao * ao + bo * bo + co * co);
-      ao /= nm;   // directions are compared at 1e-12: exact quotients here
-      bo /= nm;
-      co /= nm;
+      // (directions are compared at 1e-12: the correctly rounded root and quotients)
+      const double nm = sqrt_unit(ao * ao + bo * bo + co * co);
+      ao = div_rn(ao, nm);
+      bo = div_rn(bo, nm);
+      co = div_rn(co, nm);
     } else if (PGRATING(P)) {
       // grating equation, reflect.py:840-861 + 451-469 (sign -1); the groove
       // vector of OE.local_g (base.py:688-717)
@@ -2398,16 +2498,16 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       const double G2 = g0 * g0 + g1 * g1 + g2 * g2;
       // one order for all rays, or the caller's per-ray draw (reflect.py:455-459)
       const double ord = P.order_ray ? (double)P.order_ray[i] : (double)P.grating_order;
-      const double ol = ord * kCH / q.E * 1e-7;
+      const double ol = div_rn(ord * kCH, q.E) * 1e-7;
       const double u = bdsn * bdsn - 2. * bdg * ol - G2 * (ol * ol);
-      const double dn = bdsn + gsig * sqrt(fabs(u));
+      const double dn = bdsn + gsig * sqrt_unit(fabs(u));
       ao = r.a - n[3] * dn + g0 * ol;
       bo = r.b - n[4] * dn + g1 * ol;
       co = r.c - n[5] * dn + g2 * ol;
-      const double nm = sqrt(ao * ao + bo * bo + co * co);
-      ao /= nm;
-      bo /= nm;
-      co /= nm;
+      const double nm = sqrt_unit(ao * ao + bo * bo + co * co);
+      ao = div_rn(ao, nm);
+      bo = div_rn(bo, nm);
+      co = div_rn(co, nm);
     } else {  // specular, reflect.py:875-877
       ao = r.a - n[0] * 2. * bdn;
       bo = r.b - n[1] * 2. * bdn;
@@ -2435,7 +2535,8 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   // they come from the angle-addition formulas with cos/sin(atan2) = (n_z, n_x)/hyp
   double cosY = P.cos_roll, sinY = P.sin_roll;
   if (n[3] != 0.) {
-    const double ih = frcp(fhypot(n[3], n[5]));
+    double ih;   // 1 / hypot(n_x, n_z) falls out of the root's iteration
+    (void)sqrt_rn_rinv(fma_(n[3], n[3], n[5] * n[5]), ih);
     const double cphi = n[5] * ih, sphi = n[3] * ih;
     cosY = P.cos_roll * cphi - P.sin_roll * sphi;
     sinY = P.sin_roll * cphi + P.cos_roll * sphi;
@@ -2455,7 +2556,15 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     A = multilayer_amplitude(*M.layers, q.E, M.geom_bragg ? bdsn : bdn);
   } else if (MKIND(M) == XRT_HIP_MAT_CRYSTAL) {
     const double bosn = ao * n[3] + bo * n[4] + co * n[5];
-    A = crystal_amplitude<K::XTHICK, K::XCELL>(M, q.E, bdsn, bosn, bdn, window_of(g), npre);
+    // xe: the energy-dependent part is shared between the two crystals of a DCM
+    XtalEnergy X;
+    if (xe && xe_ready) {
+      X = *xe;
+    } else {
+      X = xtal_energy<K::XCELL>(M, q.E, window_of(g), npre);
+      if (xe) *xe = X;
+    }
+    A = crystal_amplitude_at<K::XTHICK>(M, X, bdsn, bosn, bdn);
   } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
     A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g), npre);
   }
@@ -2599,7 +2708,8 @@ __device__ __forceinline__ Completed complete_ray(
     const xrt_hip_beam& restore, const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
     int64_t i, const LocalRay& r, const Hit& h, int st, bool has_amp, int own_sign = 0,
     double* bdn_out = nullptr, RayIn qin = RayIn(), const cplx* npre = nullptr,
-    const LocalRay* raw = nullptr) {
+    const LocalRay* raw = nullptr, XtalEnergy* xe = nullptr, bool xe_ready = false,
+    ProbeClock* pc = nullptr) {
   Completed res;
   res.kept = false;
   RayIn q;
@@ -2613,8 +2723,13 @@ __device__ __forceinline__ Completed complete_ray(
   double la = r.a, lbb = r.b, lc = r.c, th = 0.;
   RayIn lo;
   double vJss, vJpp, vJsr, vJsi, vEsr, vEsi, vEpr, vEpi;
+#ifdef XRT_PROBE_NULL_COMPUTE
+  if (false) {
+#else
   if (st == 1) {
-    const Finished fin = finish_ray<K, QREADY>(P, M, g, r, h, q, in, i, has_amp, own_sign, npre);
+#endif
+    const Finished fin = finish_ray<K, QREADY>(P, M, g, r, h, q, in, i, has_amp, own_sign, npre,
+                                               xe, xe_ready);
     if (bdn_out) *bdn_out = fin.bdn;
     la = fin.a;
     lbb = fin.b;
@@ -2641,6 +2756,9 @@ __device__ __forceinline__ Completed complete_ray(
     vEpr = q.Epr;
     vEpi = q.Epi;
   }
+#ifdef XRT_PROBE_TIMING
+  if (pc) XRT_TICK(*pc, 3, la + vJss + lo.Jpp);
+#endif
   if (theta) theta[i] = th;
   store_ray(lb, i, h.x, h.y, h.z, la, lbb, lc, lo.path, lo.E, lo.Jss, lo.Jpp, lo.Jsr, lo.Jsi,
             st, lo.Esr, lo.Esi, lo.Epr, lo.Epi, has_amp);
@@ -2788,6 +2906,20 @@ __device__ __forceinline__ void report_opt(OptStat* slots, const SolveAux& aux, 
   }
 }
 
+// A crystal pass raises GStat::any_neg / any_pos for the signs of beamInDotNormal it saw.
+// Per wave, not per block (a block barrier at the end of the kernel keeps every wave's
+// registers allocated until the slowest wave of the block is through), and only by waves
+// that started before the flag was up (`seen`, read when the wave starts: one store per
+// wave and side would be 150 000 stores into one cache line).
+__device__ __forceinline__ void raise_sign_flags(int* __restrict__ flags, int seen_neg,
+                                                 int seen_pos, int neg, int pos) {
+  const bool wneg = __any(neg), wpos = __any(pos);
+  if ((threadIdx.x & 63) == 0) {
+    if (wneg && !seen_neg) flags[0] = 1;   // same-value racing stores; read only by the
+    if (wpos && !seen_pos) flags[1] = 1;   // kernels that follow
+  }
+}
+
 // one ray of the fused solve + finish; own_sign / neg / pos serve the crystal variant
 template <class K, int mode, bool XTAL>
 __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_material& M,
@@ -2796,6 +2928,8 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
                                           double* theta, const GStat& g, OptStat* opt,
                                           int64_t i, int& neg, int& pos) {
   const bool has_amp = in.Es_ri != nullptr;
+  ProbeClock pc;
+  XRT_TICK(pc, 0, 0.);
   // position and direction are requested together with the state, not after it has
   // been looked at: one memory round trip instead of two (nearly every ray enters)
   const int st0 = i < in.n ? in.state[i] : 0;
@@ -2823,6 +2957,7 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   }
 #endif
   if (i < in.n && !active) pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
+  XRT_TICK(pc, 1, r.x + r.a + r.z);
   Hit h;
   if (mode == 0) {
     // solve, then report while the wave is convergent and before the amplitude code
@@ -2838,6 +2973,7 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   } else if (active) {
     h = solve_ray<K>(P, g, r);
   }
+  XRT_TICK(pc, 2, active ? h.t : 0.);
   if (active) {
     int st = rays_good<K>(P, h.x, h.y);
     if constexpr (K::RAYG)
@@ -2852,13 +2988,19 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
 #ifndef XRT_LATE_FIELDS
       if (early_fields<K>())
         complete_ray<K, true>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 0,
-                              nullptr, qpre, NPRE ? &npre : nullptr, &raw);
+                              nullptr, qpre, NPRE ? &npre : nullptr, &raw, nullptr, false, &pc);
       else
 #endif
       complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 0, nullptr,
                       RayIn(), NPRE ? &npre : nullptr);
     }
   }
+#ifdef XRT_PROBE_TIMING
+  XRT_TICK(pc, 4, 0.);                     // stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  XRT_TICK(pc, 5, 0.);                     // stores acknowledged
+  pc.flush(6);
+#endif
 }
 
 template <class K, int mode>
@@ -2870,7 +3012,7 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
   const GStat g = *gp;
   int neg = 0, pos = 0;
   fused_ray<K, mode, false>(P, M, in, restore, lb, vb, theta, g, opt,
-                            (int64_t)blockIdx.x * blockDim.x + threadIdx.x, neg, pos);
+                            (int64_t)beam_block() * blockDim.x + threadIdx.x, neg, pos);
 }
 
 // ---------------------------------------------------------------------------
@@ -2888,16 +3030,11 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_x
     int* __restrict__ any_neg_pos, OptStat* __restrict__ opt) {
   if (fused_skips(gp, mode)) return;
   const GStat g = *gp;
+  const int seen_neg = any_neg_pos[0], seen_pos = any_neg_pos[1];
   int neg = 0, pos = 0;
   fused_ray<K, mode, true>(P, M, in, restore, lb, vb, theta, g, opt,
-                           (int64_t)blockIdx.x * blockDim.x + threadIdx.x, neg, pos);
-  // same-value racing stores; any_neg/any_pos are read only by the kernels that follow
-  neg = __syncthreads_or(neg);
-  pos = __syncthreads_or(pos);
-  if (threadIdx.x == 0) {
-    if (neg) any_neg_pos[0] = 1;
-    if (pos) any_neg_pos[1] = 1;
-  }
+                           (int64_t)beam_block() * blockDim.x + threadIdx.x, neg, pos);
+  raise_sign_flags(any_neg_pos, seen_neg, seen_pos, neg, pos);
 }
 
 // crystal path, first half: solve + state; stores t, local hit point and state,
@@ -3300,17 +3437,41 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
     int* __restrict__ flags1, int* __restrict__ flags2, OptStat* __restrict__ opt1,
     OptStat* __restrict__ opt2) {
   if (!g1p->optimistic) return;      // nothing could be assumed: dcm_exact does the work
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
   const bool has_amp = in.Es_ri != nullptr;
   const bool live = i < in.n;
+  const int seen1n = flags1[0], seen1p = flags1[1], seen2n = flags2[0], seen2p = flags2[1];
   int neg1 = 0, pos1 = 0, neg2 = 0, pos2 = 0;
   Rec v = {};         // the beam between the crystals (virgin local frame), this ray
   // the anomalous scattering factors at this ray's energy, looked up (dependent trips to
   // L2) before any geometry, once for both crystals if they are cut from one table
   cplx anom1 = C(0., 0.), anom2 = C(0., 0.);
+  // chi_0, chi_h, ... at this ray's energy: computed at the first crystal, used again at
+  // the second if both are the same reflection of the same crystal (the rule)
+  XtalEnergy xe;
+  bool have_xe = false;
+  const bool one_crystal =
+      M1.d == M2.d && M1.chi_to_f == M2.chi_to_f && M1.f0_hkl == M2.f0_hkl &&
+      M1.fact_dw == M2.fact_dw && M1.structure == M2.structure && M1.d2f_re == M2.d2f_re &&
+      M1.d2f_im == M2.d2f_im && M1.Z[0] == M2.Z[0] && M1.hkl[0] == M2.hkl[0] &&
+      M1.hkl[1] == M2.hkl[1] && M1.hkl[2] == M2.hkl[2] && M2.tab_E[0] == M1.tab_E[0] &&
+      M2.tab_f1[0] == M1.tab_f1[0] && M2.tab_f2[0] == M1.tab_f2[0];
 #ifdef XRT_DCM_EARLY
   RayIn q0 = RayIn();
 #endif
+  // position, direction and state are requested before the table search: its dependent
+  // trips to L2 then run under the record's trip to HBM instead of in front of it
+  const int st0 = live ? in.state[i] : 0;
+  LocalRay r_in;
+  {
+    const int64_t ii = live ? i : 0;
+    r_in.x = in.x[ii];
+    r_in.y = in.y[ii];
+    r_in.z = in.z[ii];
+    r_in.a = in.a[ii];
+    r_in.b = in.b[ii];
+    r_in.c = in.c[ii];
+  }
   if (live) {
     const double E0 = in.E[i];
     anom1 = interp_f1f2(M1, 0, E0, window_of(*g1p));
@@ -3327,8 +3488,9 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
   // ---- first crystal ----
   {
     const GStat g = *g1p;
-    const int st0 = live ? in.state[i] : 0;
-    const LocalRay r = load_local(P1, in, live ? i : 0);
+    LocalRay r = r_in;
+    local_pos(P1, r.x, r.y, r.z);
+    local_dir(P1, r.a, r.b, r.c);
     const bool active = live && entering(P1, st0);
     SolveAux aux;
     int viol = 0;
@@ -3345,12 +3507,14 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
       double bdn = 0.;
 #ifdef XRT_DCM_EARLY
       const Completed c1 = complete_ray<K, true, true>(P1, M1, g, in, in, lo1, lo1, theta1, i, r,
-                                                       h, st, has_amp, 1, &bdn, q0, &anom1);
+                                                       h, st, has_amp, 1, &bdn, q0, &anom1,
+                                                       nullptr, &xe, false);
 #else
       const Completed c1 = complete_ray<K, false, true>(P1, M1, g, in, in, lo1, lo1, theta1, i, r,
                                                         h, st, has_amp, 1, &bdn, RayIn(),
-                                                        &anom1);
+                                                        &anom1, nullptr, &xe, false);
 #endif
+      have_xe = one_crystal && st == 1;
       kept = c1.kept;
       neg1 |= st == 1 && bdn < 0.;
       pos1 |= st == 1 && !(bdn < 0.);
@@ -3395,7 +3559,7 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
       if (h.lost) st = P2.lost_num;
       double bdn = 0.;
       complete_ray<K, true>(P2, M2, g, in, in, lo2, gb2, theta2, i, r, h, st, has_amp, 1, &bdn,
-                            v.f, &anom2);
+                            v.f, &anom2, nullptr, &xe, have_xe);
       neg2 |= st == 1 && bdn < 0.;
       pos2 |= st == 1 && !(bdn < 0.);
     } else if (live) {
@@ -3407,16 +3571,8 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
       copy_ray(gb2, in, i, P2.force_lost_out ? P2.lost_num : v.st, has_amp, false);
     }
   }
-  neg1 = __syncthreads_or(neg1);
-  pos1 = __syncthreads_or(pos1);
-  neg2 = __syncthreads_or(neg2);
-  pos2 = __syncthreads_or(pos2);
-  if (threadIdx.x == 0) {
-    if (neg1) flags1[0] = 1;
-    if (pos1) flags1[1] = 1;
-    if (neg2) flags2[0] = 1;
-    if (pos2) flags2[1] = 1;
-  }
+  raise_sign_flags(flags1, seen1n, seen1p, neg1, pos1);
+  raise_sign_flags(flags2, seen2n, seen2p, neg2, pos2);
 }
 
 template <class K>
