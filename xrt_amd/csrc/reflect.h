@@ -50,7 +50,22 @@ struct GStat {
                                      // for: [win_lo, win_hi); -inf, +inf = the whole batch
   unsigned bar;                      // arrival counter of reflect_exact's grid barrier
   int hang;                          // a grid barrier gave up waiting (never expected)
+  const struct TabFast* tab_fast;    // this pass's TabFast records (one per element), or
+                                     // null: not prepared, or overwritten since (exact redo)
 };
+
+// np.interp on an element's (E, f1, f2) table for the energies of a beamline's beam, without
+// touching the table: the four knots around the head ray's energy and slope / offset of the
+// three intervals between them (slope = (f[j+1] - f[j]) / (E[j+1] - E[j]), the reference's own
+// quotient, element.py:252-263), written once per pass by the decide kernel. They are the same
+// for every ray: the fused kernels fetch them through the scalar cache and select the interval
+// with two compares -- no binary search of dependent loads, no divisions per ray. A ray whose
+// energy is outside [x[0], x[3]) searches the table as before.
+struct TabFast {
+  double x[4];
+  double f1[3], s1[3], f2[3], s2[3];
+};
+static_assert(sizeof(TabFast) == 128, "one record per 128-byte line");
 
 // What the optimistic fused pass reports back. Same-address atomics from 150 000
 // waves serialise at the memory side (3 ms for 1e7 rays, measured), so the reports

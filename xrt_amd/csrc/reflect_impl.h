@@ -741,6 +741,7 @@ __device__ __forceinline__ void gstat_reset(GStat* g, int redo) {
   }
   g->win_lo = -INFINITY;
   g->win_hi = INFINITY;
+  g->tab_fast = nullptr;
 }
 
 __device__ __forceinline__ void stats_dir_body(const xrt_hip_pass& P, const xrt_hip_beam& in,
@@ -795,6 +796,35 @@ __device__ __forceinline__ void stats_dir_body(const xrt_hip_pass& P, const xrt_
     o[6] = emin;
     o[7] = emax;
   }
+}
+
+// The TabFast records of a material around energy E0 (one thread). ub[e] = upper_bound of
+// E0 in element e's table. false if a table is too short there or a slope is not finite
+// (equal neighbouring energies at an absorption edge): the rays then search the tables.
+__device__ __forceinline__ bool tab_fast_build(const xrt_hip_material& M, const int* ub,
+                                               TabFast* tf) {
+  if (M.kind == XRT_HIP_MAT_NONE || M.n_fixed) return false;
+  for (int e = 0; e < M.nelem; ++e) {
+    const int n = M.tab_n[e], j0 = ub[e] - 2;
+    if (j0 < 0 || j0 + 3 > n - 2) return false;    // (j >= n - 1 is np.interp's end rule)
+    const double* tE = M.tab_E[e];
+    TabFast t;
+    for (int k = 0; k < 4; ++k) t.x[k] = tE[j0 + k];
+    for (int k = 0; k < 3; ++k) {
+      const double dx = t.x[k + 1] - t.x[k];
+      t.f1[k] = M.tab_f1[e][j0 + k];
+      t.f2[k] = M.tab_f2[e][j0 + k];
+      t.s1[k] = (M.tab_f1[e][j0 + k + 1] - t.f1[k]) / dx;
+      t.s2[k] = (M.tab_f2[e][j0 + k + 1] - t.f2[k]) / dx;
+      if (!(fabs(t.s1[k]) < INFINITY) || !(fabs(t.s2[k]) < INFINITY)) return false;
+    }
+    tf[e] = t;
+  }
+  return true;
+}
+// where they live: behind the report slots in the partial-record area of the pass
+__host__ __device__ inline TabFast* tab_fast_of(void* part) {
+  return reinterpret_cast<TabFast*>(reinterpret_cast<OptStat*>(part) + REFLECT_OPT_SLOTS);
 }
 
 // f1/f2 table window of a batch: upper_bound(E table, emin / emax) per element
@@ -872,6 +902,7 @@ __device__ __forceinline__ void decide_axis_body(const xrt_hip_pass& P,
     g->bracket_valid = 0;
     g->win_lo = -INFINITY;   // the windows below hold for the whole batch
     g->win_hi = INFINITY;
+    g->tab_fast = nullptr;   // (the exact statistics overwrite the area they lived in)
   }
   double ma = 0., mb = 0., mc = 0., nent = 0., nmain = 0., emin = INFINITY, emax = -INFINITY;
   unsigned long long first = ~0ull;
@@ -1020,6 +1051,7 @@ __device__ __forceinline__ bool decide_opt_body(const xrt_hip_pass& P, const xrt
   const double E0 = in.E[i0];
   table_windows_block(M, E0, E0, g, lds_u);
   if (threadIdx.x != 0) return true;
+  g->tab_fast = tab_fast_build(M, g->tab_lo, tab_fast_of(slots)) ? tab_fast_of(slots) : nullptr;
   double wlo = -INFINITY, whi = INFINITY;
   for (int e = 0; e < M.nelem && M.kind != XRT_HIP_MAT_NONE; ++e) {
     const int n = M.tab_n[e];
@@ -1590,6 +1622,7 @@ __device__ __forceinline__ int rays_good_outline(const xrt_hip_pass& P, double x
 struct TabWin {
   int lo[XRT_HIP_MAX_ELEM], hi[XRT_HIP_MAX_ELEM];
   double elo, ehi;   // energies it is valid for
+  const TabFast* fast;   // the pass's interval records, or null
 };
 __device__ __forceinline__ TabWin full_window() {
   TabWin w;
@@ -1599,6 +1632,7 @@ __device__ __forceinline__ TabWin full_window() {
   }
   w.elo = -INFINITY;
   w.ehi = INFINITY;
+  w.fast = nullptr;
   return w;
 }
 __device__ __forceinline__ TabWin window_of(const GStat& g) {
@@ -1609,11 +1643,35 @@ __device__ __forceinline__ TabWin window_of(const GStat& g) {
   }
   w.elo = g.win_lo;
   w.ehi = g.win_hi;
+  w.fast = g.tab_fast;
   return w;
+}
+
+// np.interp from the pass's TabFast record (see reflect.h); ok = false: E is outside its
+// knots. The record is the same for every lane and was written by an earlier kernel: it is
+// read through the constant address space, i.e. by scalar loads into SGPRs.
+__device__ __forceinline__ cplx interp_fast(const TabFast* rec, double E, bool& ok) {
+  typedef const double __attribute__((address_space(4))) kdouble;
+  kdouble* t = (kdouble*)(unsigned long long)rec;
+  const double x0 = t[0], x1 = t[1], x2 = t[2], x3 = t[3];
+  ok = E >= x0 && E < x3;
+  const bool k1 = E >= x1, k2 = E >= x2;
+  const double x = k2 ? x2 : (k1 ? x1 : x0);
+  const double f1 = k2 ? t[6] : (k1 ? t[5] : t[4]);
+  const double s1 = k2 ? t[9] : (k1 ? t[8] : t[7]);
+  const double f2 = k2 ? t[12] : (k1 ? t[11] : t[10]);
+  const double s2 = k2 ? t[15] : (k1 ? t[14] : t[13]);
+  const double dE = E - x;
+  return C(s1 * dE + f1, s2 * dE + f2);
 }
 
 __device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, double E,
                                             const TabWin& w) {
+  if (w.fast) {
+    bool ok;
+    const cplx f = interp_fast(w.fast + e, E, ok);
+    if (ok) return f;
+  }
   const double* __restrict__ tE = M.tab_E[e];
   const int n = M.tab_n[e];
   // upper_bound(E) lies in [w.lo, w.hi] for tE[w.lo - 1] <= E < tE[w.hi] (all elements:
@@ -2092,6 +2150,39 @@ __device__ __forceinline__ void load_fields(const xrt_hip_beam& in, int64_t i, b
 template <class K>
 __device__ __forceinline__ constexpr bool early_fields() {
   return K::PLAIN && K::MK >= 0 && K::SK >= 0;
+}
+
+// What a fused kernel asks memory for as its very first act -- before it has looked at the
+// pass's decisions, the ray's state or anything else that would put a round trip in front of
+// these loads: state, position, direction, energy, and (FIELDS) the rest of the record. One
+// trip to HBM per ray; the wave's prologue used to make three (state + position, then the
+// energy for the f1/f2 look-up, then the fields), each behind the other.
+struct RayRequest {
+  int st0;
+  LocalRay raw;
+  RayIn q;      // E always; path, J, E fields only with FIELDS
+};
+template <bool FIELDS>
+__device__ __forceinline__ RayRequest request_ray(const xrt_hip_beam& in, int64_t i,
+                                                  bool has_amp) {
+  RayRequest R;
+  const bool live = i < in.n;
+  const int64_t ii = live ? i : 0;
+  const int st = in.state[ii];
+  R.raw.x = in.x[ii];
+  R.raw.y = in.y[ii];
+  R.raw.z = in.z[ii];
+  R.raw.a = in.a[ii];
+  R.raw.b = in.b[ii];
+  R.raw.c = in.c[ii];
+  R.q = RayIn();
+  R.q.E = in.E[ii];
+  if (FIELDS) {
+    R.q.path = in.path[ii];
+    load_fields(in, ii, has_amp, R.q);
+  }
+  R.st0 = live ? st : 0;
+  return R;
 }
 
 // local_n at a hit point: n[0..2] = n_H (Bragg planes), n[3..5] = the surface normal
@@ -2926,15 +3017,16 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
                                           const xrt_hip_beam& in, const xrt_hip_beam& restore,
                                           const xrt_hip_beam& lb, const xrt_hip_beam& vb,
                                           double* theta, const GStat& g, OptStat* opt,
-                                          int64_t i, int& neg, int& pos) {
+                                          int64_t i, const RayRequest& req, int& neg,
+                                          int& pos) {
   const bool has_amp = in.Es_ri != nullptr;
   ProbeClock pc;
   XRT_TICK(pc, 0, 0.);
-  // position and direction are requested together with the state, not after it has
-  // been looked at: one memory round trip instead of two (nearly every ray enters)
-  const int st0 = i < in.n ? in.state[i] : 0;
-  LocalRay raw;
-  LocalRay r = load_local(P, in, i < in.n ? i : 0, early_fields<K>() ? &raw : nullptr);
+  const int st0 = req.st0;
+  const LocalRay raw = req.raw;
+  LocalRay r = raw;
+  local_pos(P, r.x, r.y, r.z);
+  local_dir(P, r.a, r.b, r.c);
   const bool active = i < in.n && entering(P, st0);
   // Fresnel coatings: the refractive index now, so that its table look-up (dependent
   // loads) is in flight during the root solve
@@ -2944,17 +3036,11 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   constexpr bool NPRE = K::PLAIN && K::MK == XRT_HIP_MAT_MIRROR;
 #endif
   cplx npre = C(1., 0.);
-  if (NPRE && active) npre = refractive_index(M, in.E[i], window_of(g));
+  if (NPRE && active) npre = refractive_index(M, req.q.E, window_of(g));
 #ifndef XRT_LATE_FIELDS
-  // the lean kernels have the registers to request the WHOLE input record before the
-  // solve: one trip to HBM per ray instead of two (measured on cfg2: 0.71 -> 0.68 ms, at
-  // four waves per SIMD instead of five)
-  RayIn qpre = RayIn();
-  if (early_fields<K>() && active) {
-    qpre.path = in.path[i];
-    qpre.E = in.E[i];
-    load_fields(in, i, has_amp, qpre);
-  }
+  // the lean kernels have the registers to hold the WHOLE input record during the solve
+  // (measured on cfg2: 0.71 -> 0.68 ms, at four waves per SIMD instead of five)
+  const RayIn qpre = req.q;
 #endif
   if (i < in.n && !active) pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
   XRT_TICK(pc, 1, r.x + r.a + r.z);
@@ -3008,11 +3094,16 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     OptStat* __restrict__ opt) {
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
+#ifdef XRT_LATE_FIELDS
+  const RayRequest req = request_ray<false>(in, i, in.Es_ri != nullptr);
+#else
+  const RayRequest req = request_ray<early_fields<K>()>(in, i, in.Es_ri != nullptr);
+#endif
   if (fused_skips(gp, mode)) return;
   const GStat g = *gp;
   int neg = 0, pos = 0;
-  fused_ray<K, mode, false>(P, M, in, restore, lb, vb, theta, g, opt,
-                            (int64_t)beam_block() * blockDim.x + threadIdx.x, neg, pos);
+  fused_ray<K, mode, false>(P, M, in, restore, lb, vb, theta, g, opt, i, req, neg, pos);
 }
 
 // ---------------------------------------------------------------------------
@@ -3028,12 +3119,13 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_x
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
     xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
     int* __restrict__ any_neg_pos, OptStat* __restrict__ opt) {
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
+  const RayRequest req = request_ray<false>(in, i, in.Es_ri != nullptr);
   if (fused_skips(gp, mode)) return;
   const GStat g = *gp;
   const int seen_neg = any_neg_pos[0], seen_pos = any_neg_pos[1];
   int neg = 0, pos = 0;
-  fused_ray<K, mode, true>(P, M, in, restore, lb, vb, theta, g, opt,
-                           (int64_t)beam_block() * blockDim.x + threadIdx.x, neg, pos);
+  fused_ray<K, mode, true>(P, M, in, restore, lb, vb, theta, g, opt, i, req, neg, pos);
   raise_sign_flags(any_neg_pos, seen_neg, seen_pos, neg, pos);
 }
 
@@ -3225,6 +3317,7 @@ __device__ __forceinline__ GStat load_gstat(const GStat* g) {
   r.win_hi = ld_agent(&g->win_hi);
   r.bar = 0;
   r.hang = 0;
+  r.tab_fast = nullptr;      // (the exact sequence searches the tables)
   return r;
 }
 
@@ -3268,12 +3361,14 @@ __device__ __forceinline__ void exact_pass(const xrt_hip_pass& P, const xrt_hip_
       int neg = 0, pos = 0;
       const int64_t stride = (int64_t)gridDim.x * blockDim.x;
       for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < in.n; base += stride) {
+        const RayRequest req = request_ray<early_fields<K>()>(in, base + threadIdx.x,
+                                                              in.Es_ri != nullptr);
         if (need_mean)
           fused_ray<K, 1, true>(P, M, in, restore, lb, vb, A.theta, gl, nullptr,
-                                base + threadIdx.x, neg, pos);
+                                base + threadIdx.x, req, neg, pos);
         else
           fused_ray<K, 1, false>(P, M, in, restore, lb, vb, A.theta, gl, nullptr,
-                                 base + threadIdx.x, neg, pos);
+                                 base + threadIdx.x, req, neg, pos);
       }
       if (need_mean) {
         neg = __syncthreads_or(neg);
@@ -3394,6 +3489,7 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_dcm(
   const double E0 = in.E[i0];
   table_windows_block(M2, E0, E0, g2, lds_u);
   if (threadIdx.x != 0) return;
+  g2->tab_fast = tab_fast_build(M2, g2->tab_lo, tab_fast_of(part2)) ? tab_fast_of(part2) : nullptr;
   double wlo = -INFINITY, whi = INFINITY;
   for (int e = 0; e < M2.nelem && M2.kind != XRT_HIP_MAT_NONE; ++e) {
     const int n = M2.tab_n[e];
@@ -3436,10 +3532,12 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
     double* theta2, const GStat* __restrict__ g1p, const GStat* __restrict__ g2p,
     int* __restrict__ flags1, int* __restrict__ flags2, OptStat* __restrict__ opt1,
     OptStat* __restrict__ opt2) {
-  if (!g1p->optimistic) return;      // nothing could be assumed: dcm_exact does the work
   const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
   const bool has_amp = in.Es_ri != nullptr;
   const bool live = i < in.n;
+  // the record is requested before anything else is looked at (see RayRequest)
+  const RayRequest req = request_ray<true>(in, i, has_amp);
+  if (!g1p->optimistic) return;      // nothing could be assumed: dcm_exact does the work
   const int seen1n = flags1[0], seen1p = flags1[1], seen2n = flags2[0], seen2p = flags2[1];
   int neg1 = 0, pos1 = 0, neg2 = 0, pos2 = 0;
   Rec v = {};         // the beam between the crystals (virgin local frame), this ray
@@ -3456,30 +3554,13 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
       M1.d2f_im == M2.d2f_im && M1.Z[0] == M2.Z[0] && M1.hkl[0] == M2.hkl[0] &&
       M1.hkl[1] == M2.hkl[1] && M1.hkl[2] == M2.hkl[2] && M2.tab_E[0] == M1.tab_E[0] &&
       M2.tab_f1[0] == M1.tab_f1[0] && M2.tab_f2[0] == M1.tab_f2[0];
-#ifdef XRT_DCM_EARLY
   RayIn q0 = RayIn();
-#endif
-  // position, direction and state are requested before the table search: its dependent
-  // trips to L2 then run under the record's trip to HBM instead of in front of it
-  const int st0 = live ? in.state[i] : 0;
-  LocalRay r_in;
-  {
-    const int64_t ii = live ? i : 0;
-    r_in.x = in.x[ii];
-    r_in.y = in.y[ii];
-    r_in.z = in.z[ii];
-    r_in.a = in.a[ii];
-    r_in.b = in.b[ii];
-    r_in.c = in.c[ii];
-  }
+  const int st0 = req.st0;
+  const LocalRay r_in = req.raw;
   if (live) {
-    const double E0 = in.E[i];
+    const double E0 = req.q.E;
     anom1 = interp_f1f2(M1, 0, E0, window_of(*g1p));
-#ifdef XRT_DCM_EARLY
-    q0.E = E0;
-    q0.path = in.path[i];
-    load_fields(in, i, has_amp, q0);
-#endif
+    q0 = req.q;
     anom2 = (M2.tab_E[0] == M1.tab_E[0] && M2.tab_f1[0] == M1.tab_f1[0] &&
              M2.tab_f2[0] == M1.tab_f2[0])
                 ? anom1
@@ -3505,15 +3586,9 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
       int st = rays_good<K>(P1, h.x, h.y);
       if (h.lost) st = P1.lost_num;
       double bdn = 0.;
-#ifdef XRT_DCM_EARLY
       const Completed c1 = complete_ray<K, true, true>(P1, M1, g, in, in, lo1, lo1, theta1, i, r,
                                                        h, st, has_amp, 1, &bdn, q0, &anom1,
                                                        nullptr, &xe, false);
-#else
-      const Completed c1 = complete_ray<K, false, true>(P1, M1, g, in, in, lo1, lo1, theta1, i, r,
-                                                        h, st, has_amp, 1, &bdn, RayIn(),
-                                                        &anom1, nullptr, &xe, false);
-#endif
       have_xe = one_crystal && st == 1;
       kept = c1.kept;
       neg1 |= st == 1 && bdn < 0.;
