@@ -663,6 +663,13 @@ __device__ __forceinline__ void bracket(const xrt_hip_pass& P, int axis, int pos
 }
 
 __device__ __forceinline__ int sgn(double v) { return (v > 0.) - (v < 0.); }
+// sgn(a) == sgn(b) for two numbers that are not NaN (false if either is)
+__device__ __forceinline__ bool same_sign(double a, double b) {
+  const bool ordered = !(a != a) && !(b != b);
+  const bool az = a == 0., bz = b == 0.;
+  const bool bits = (__double2hiint(a) ^ __double2hiint(b)) >= 0;
+  return ordered && (az == bz) && (az || bits);
+}
 
 // ---------------------------------------------------------------------------
 // reductions
@@ -1422,16 +1429,27 @@ __device__ __forceinline__ Hit solve_ray(const xrt_hip_pass& P, const GStat& g,
     // bracket-keeping secant, base.py:933-959. The first step is taken
     // unconditionally (the reference filters on |dz2| only after it).
     bool active = true;
+#ifdef XRT_PROBE_ITERS
+    while (active && numit < 2 + XRT_PROBE_ITERS) {
+#else
     while (active && numit < kMaxIteration) {
+#endif
       const double t = t1, dz = dz1;
       t1 = t2;
       dz1 = dz2;
       t2 = t - (t1 - t) * dz / (dz1 - dz);
-      if (OPT) aux->escaped |= (t2 < t1own) || (t2 > t2own);
-      if (t2 < tMinG) t2 = tMinG;
-      if (t2 > tMaxG) t2 = tMaxG;
+      if (OPT) {
+        // the optimistic pass runs without the batch's clamp (t1.min(), t2.max() are not
+        // known yet): an iterate that leaves the ray's own bracket is reported instead
+        aux->escaped |= (t2 < t1own) || (t2 > t2own);
+      } else {
+        if (t2 < tMinG) t2 = tMinG;
+        if (t2 > tMaxG) t2 = tMaxG;
+      }
       dz2 = find_dz<K>(P, t2, r.x, r.y, r.z, r.a, r.b, r.c, x2, y2, z2);
-      if (!isnan(dz2) && !isnan(dz1) && sgn(dz2) == sgn(dz1)) {
+      // np.sign(dz2) == np.sign(dz1) with both ordered: equal sign bits and both zero or
+      // both non-zero
+      if (same_sign(dz2, dz1)) {
         t1 = t;
         dz1 = dz;
       }
@@ -1753,11 +1771,24 @@ __device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, in
   Ampl A;
   const cplx n = npre ? *npre : refractive_index(M, E, w);
   const cplx one = C(1., 0.);
-  const cplx n1 = M.from_vacuum ? one : n;
-  const cplx n2 = M.from_vacuum ? n : one;
   const double cosAlpha = fabs(bdn);
   double sinAlpha2 = 1. - bdn * bdn;
   if (sinAlpha2 < 0.) sinAlpha2 = 0.;
+  if (M.from_vacuum && kind == XRT_HIP_MAT_MIRROR) {
+    // a mirror seen from vacuum (the rule): n1 = 1, n2 = n. The same values as the general
+    // form below (products with 1 + 0i are exact), without forming them.
+    const double inv = frcp(cnorm2(n.re, n.im));
+    const cplx rat = C(n.re * inv, -n.im * inv);
+    const cplx cosBeta = csqrt_(one - (rat * rat) * sinAlpha2);
+    const cplx nb = n * cosBeta, na = n * cosAlpha, ca = C(cosAlpha, 0.);
+    A.rs = (ca - nb) / (ca + nb);
+    A.rp = (na - cosBeta) / (na + cosBeta);
+    A.mu = div_const(fabs(n.im) * E, kCHBAR, 1. / kCHBAR) * 2e8;
+    A.nk = div_const(n.re * E, kCHBAR, 1. / kCHBAR) * 1e8;
+    return A;
+  }
+  const cplx n1 = M.from_vacuum ? one : n;
+  const cplx n2 = M.from_vacuum ? n : one;
   const cplx n1cosAlpha = n1 * cosAlpha;
   const cplx rat = n1 / n2;
   const cplx cosBeta = csqrt_(one - (rat * rat) * sinAlpha2);
@@ -2656,8 +2687,10 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       if (xe) *xe = X;
     }
     A = crystal_amplitude_at<K::XTHICK>(M, X, bdsn, bosn, bdn);
+#ifndef XRT_PROBE_NO_AMPL
   } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
     A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g), npre);
+#endif
   }
   if (PGRATING(P) && P.eff_n > 0) {  // tabulated efficiency of the order, material.py:391-413
     double amp = 0.;
@@ -3036,7 +3069,9 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   constexpr bool NPRE = K::PLAIN && K::MK == XRT_HIP_MAT_MIRROR;
 #endif
   cplx npre = C(1., 0.);
+#ifndef XRT_PROBE_NO_AMPL
   if (NPRE && active) npre = refractive_index(M, req.q.E, window_of(g));
+#endif
 #ifndef XRT_LATE_FIELDS
   // the lean kernels have the registers to hold the WHOLE input record during the solve
   // (measured on cfg2: 0.71 -> 0.68 ms, at four waves per SIMD instead of five)
