@@ -6,8 +6,13 @@
 #include <cstdio>
 #include <cstdlib>
 #define NIN 13
+#ifndef BLOCK
+#define BLOCK 128
+#endif
+#ifndef NOUT
 #define NOUT 26
-struct Arrays { double* p[32]; };
+#endif
+struct Arrays { double* p[48]; };
 
 template <int NI>
 __device__ __forceinline__ void work(const double (&t)[NIN], double (&o)[NOUT]) {
@@ -25,7 +30,7 @@ __device__ __forceinline__ void work(const double (&t)[NIN], double (&o)[NOUT]) 
 
 // VREG: highest VGPR touched -> allocation -> waves per SIMD = 512 / (VREG + 1) rounded down
 template <int NI, int VREG, int LDSB>
-__global__ __launch_bounds__(128) void kern(Arrays in, Arrays out, long n) {
+__global__ __launch_bounds__(BLOCK) void kern(Arrays in, Arrays out, long n) {
   __shared__ double lds[LDSB ? LDSB / 8 : 1];
   if (VREG == 63) asm volatile("" ::: "v63");
   if (VREG == 79) asm volatile("" ::: "v79");
@@ -51,10 +56,10 @@ void run(const Arrays& in, const Arrays& out, long n) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  unsigned grid = (unsigned)((n + 127) / 128);
-  for (int k = 0; k < 3; ++k) kern<NI, VREG, LDSB><<<grid, 128>>>(in, out, n);
+  unsigned grid = (unsigned)((n + BLOCK - 1) / BLOCK);
+  for (int k = 0; k < 3; ++k) kern<NI, VREG, LDSB><<<grid, BLOCK>>>(in, out, n);
   hipEventRecord(e0);
-  for (int k = 0; k < 10; ++k) kern<NI, VREG, LDSB><<<grid, 128>>>(in, out, n);
+  for (int k = 0; k < 10; ++k) kern<NI, VREG, LDSB><<<grid, BLOCK>>>(in, out, n);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -83,7 +88,7 @@ int main(int argc, char** argv) {
   for (int k = 0; k < NOUT; ++k) hipMalloc(&out.p[k], n * 8);
   sweep<16>(in, out, n);
   sweep<800>(in, out, n);
-  sweep<1200>(in, out, n);
   sweep<1600>(in, out, n);
+  sweep<2000>(in, out, n);
   return 0;
 }

@@ -730,7 +730,8 @@ static int check_undulator(const xrt_hip_undulator* u, int64_t nrays) {
 }
 
 size_t xrt_hip_undulator_workspace_bytes(int64_t jend) {
-  return (size_t)(jend < 1 ? 1 : jend) * xrt::UND_NODE_DOUBLES * sizeof(double);
+  return ((size_t)(jend < 1 ? 1 : jend) * xrt::UND_NODE_DOUBLES + xrt::UND_TAB_DOUBLES) *
+         sizeof(double);
 }
 
 int xrt_hip_undulator_f64_dev(const xrt_hip_undulator* u, int64_t nrays, const double* gamma,

@@ -6,7 +6,10 @@ using UndulatorArgs = xrt_hip_undulator;
 using UndulatorMap = xrt_hip_undulator_map;
 enum { UND_FAR = XRT_HIP_UND_FAR, UND_TAPER = XRT_HIP_UND_TAPER, UND_NF = XRT_HIP_UND_NF };
 constexpr int UND_NODE_DOUBLES = 16;
-// workspace: jend * UND_NODE_DOUBLES doubles (packed node records)
+// workspace: jend * UND_NODE_DOUBLES doubles (packed node records), then the (cos, sin) table of
+// the in-loop sincos (2048 double2): the pack kernels fill it once per call, every block of the
+// sum kernels copies it into LDS -- computing it per block was 300 of a ray's 4500 instructions
+constexpr int UND_TAB_DOUBLES = 2 * 2048;
 hipError_t undulator_pack_launch(const UndulatorArgs& a, void* workspace, hipStream_t st);
 hipError_t undulator_sum_launch(const UndulatorArgs& a, int64_t n, const double* gamma,
                                 const double* wu, const double* w, const double* ww1,
@@ -16,7 +19,7 @@ hipError_t undulator_imap_launch(const UndulatorArgs& a, const UndulatorMap& m, 
                                  const double* w, const double* theta, const double* psi,
                                  const double* gamma, double* I, double* Es_ri, double* Ep_ri,
                                  const void* workspace, hipStream_t st);
-// workspace: jend * UND_NODE_DOUBLES doubles as well
+// workspace: as above
 hipError_t custom_field_launch(const xrt_hip_custom_field& a, int64_t n, const double* emcg,
                                const double* gamma, const double* w, const double* ddphi,
                                const double* ddpsi, double* Is_ri, double* Ip_ri,

@@ -31,7 +31,28 @@ enum { N_TG, N_AG, N_S, N_C, N_SPH, N_CPH, N_S2X, N_S2XPH, N_SUM2, N_BPX, N_BPY,
        N_KX2S2XPH, N_PAD0, N_PAD1, N_PAD2, N_REC };
 static_assert(N_REC == UND_NODE_DOUBLES, "node record size");
 
+// the workspace's sincos table (behind the jend node records): entry k = (cos, sin) of k steps
+__device__ __forceinline__ void tab_pack(double* __restrict__ rec, int64_t jend) {
+  double2* gtab = reinterpret_cast<double2*>(rec + jend * N_REC);
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < SINCOS_TAB_N;
+       k += gridDim.x * blockDim.x) {
+    const double qt = (double)k * (4.0 / SINCOS_TAB_N);   // quarter turns, exact
+    const double n = __builtin_rint(qt);
+    double sn, cs;
+    sincos_quarter_turns(qt - n, (unsigned)(int)n, sn, cs);
+    gtab[k] = make_double2(cs, sn);
+  }
+}
+// ... and its copy into a block's LDS
+__device__ __forceinline__ void tab_fetch(double2* tab, const double* __restrict__ rec,
+                                          int64_t jend) {
+  const double2* __restrict__ gtab = reinterpret_cast<const double2*>(rec + jend * N_REC);
+  for (int k = threadIdx.x; k < SINCOS_TAB_N; k += blockDim.x) tab[k] = gtab[k];
+  __syncthreads();
+}
+
 __global__ void und_pack(UndulatorArgs a, double* __restrict__ rec) {
+  tab_pack(rec, a.jend);
   int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (j >= a.jend) return;
   double s = a.sintg[j], c = a.costg[j], sp = a.sintgph[j], cp = a.costgph[j];
@@ -113,6 +134,7 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
       double er, ei, betax, bPx, bPz;
       const double bPy = r[N_BPY];
       if (MODE == UND_FAR) {
+#pragma clang fp contract(fast)
         double A = (nky_dx * s + kx_dy * sp) + e8 * r[N_SUM2];
         double ucos = ww1 * tg + wwug * A;
         sincos_any(ucos, tab, kreg, ei, er);
@@ -157,21 +179,30 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
         bPz = h2 * r[N_SUM2];
       }
       const double betay = nkxg * cp;
+      // krel = 1 - n.beta ~ 3e-8: eight digits cancel and it enters squared -- its sum keeps
+      // the reference's roundings. krel is an ordinary number (1e-9 .. 2): the division
+      // without its range scaling, same bits (fp64_math.h).
       const double betaz = 1. - 0.5 * ((revg2 + betax * betax) + betay * betay);
       const double krel = ((1. - dirx * betax) - diry * betay) - dirz * betaz;
-      const double rkrel = 1. / krel;
-      const double fac = ag * (rkrel * rkrel);
-      er = er * fac;
-      ei = ei * fac;
-      const double bnx = dirx - betax, bny = diry - betay, bnz = dirz - betaz;
-      const double nbp = (dirx * bPx + diry * bPy) + dirz * bPz;
-      const double nbn = (dirx * bnx + diry * bny) + dirz * bnz;
-      const double ts = bnx * nbp - bPx * nbn;
-      const double tp = bny * nbp - bPy * nbn;
-      bsr += er * ts;
-      bsi += ei * ts;
-      bpr += er * tp;
-      bpi += ei * tp;
+      const double rkrel = div_rn(1., krel);
+      {
+        // Fields are compared at 1e-5 (observed 1e-16 when every rounding of the reference
+        // is reproduced): from here on products feeding sums are fused, a quarter of the
+        // node loop's instructions less.
+#pragma clang fp contract(fast)
+        const double fac = ag * (rkrel * rkrel);
+        er = er * fac;
+        ei = ei * fac;
+        const double bnx = dirx - betax, bny = diry - betay, bnz = dirz - betaz;
+        const double nbp = (dirx * bPx + diry * bPy) + dirz * bPz;
+        const double nbn = (dirx * bnx + diry * bny) + dirz * bnz;
+        const double ts = bnx * nbp - bPx * nbn;
+        const double tp = bny * nbp - bPy * nbn;
+        bsr += er * ts;
+        bsi += ei * ts;
+        bpr += er * tp;
+        bpi += ei * tp;
+      }
     }
   }
   const double f = wu * revg;
@@ -188,7 +219,7 @@ und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
         double2* __restrict__ Is, double2* __restrict__ Ip) {
   // (cos, sin) of 2048 steps per turn for the in-loop sincos, fp64_math.h
   __shared__ double2 tab[SINCOS_TAB_N];
-  sincos_tab_fill(tab);
+  tab_fetch(tab, rec, a.jend);
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   double2 s, p;
@@ -207,7 +238,7 @@ und_imap(UndulatorArgs a, UndulatorMap m, const double* __restrict__ rec, int64_
          const double* __restrict__ psi_, const double* __restrict__ gamma_,
          double* __restrict__ I, double2* __restrict__ Es, double2* __restrict__ Ep) {
   __shared__ double2 tab[SINCOS_TAB_N];
-  sincos_tab_fill(tab);
+  tab_fetch(tab, rec, a.jend);
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double w = w_[i], th = theta[i], ps = psi_[i];
@@ -252,6 +283,7 @@ enum { C_TG, C_AG, C_BX, C_BY, C_BZ, C_BETAX, C_BETAY, C_TRAJX, C_TRAJY, C_TRAJZ
 constexpr double EMC_ = 0.5866791802416487;   // physconsts.py:24
 
 __global__ void cust_pack(xrt_hip_custom_field a, double* __restrict__ rec) {
+  tab_pack(rec, a.jend);
   int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (j >= a.jend) return;
   double* r = rec + j * C_REC;
@@ -276,7 +308,7 @@ cust_sum(xrt_hip_custom_field a, const double* __restrict__ rec, int64_t n,
          const double* __restrict__ ddpsi, double2* __restrict__ Is,
          double2* __restrict__ Ip) {
   __shared__ double2 tab[SINCOS_TAB_N];
-  sincos_tab_fill(tab);
+  tab_fetch(tab, rec, a.jend);
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const SinCosTabRegs<> kreg;
