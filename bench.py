@@ -305,6 +305,28 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
     kms = [step(timing=True)[5] for _ in range(2)]
     k = float(np.mean(kms)) * 1e-3
     my_pairs = float(ns) * float(p1 - p0)
+    # the same launch through ONE process that tiles the receiving points over the GPUs itself
+    # (what waves.diffract does with devices = [...], multigpu.kirchhoff_devices): rank 0
+    # drives all of them while the other ranks wait
+    in_process = None
+    if world > 1:
+        barrier(dist)
+        if rank == 0:
+            fx, fy, fz = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (px, py, pz))
+            smp = [s[f] for f in ('sx', 'sy', 'sz', 'nx', 'ny', 'nz', 'nl', 'k', 'Es', 'Ep')]
+            devs = list(range(world))
+            multigpu.kirchhoff_devices((fx, fy, fz), smp, devs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                multigpu.kirchhoff_devices((fx, fy, fz), smp, devs)
+            torch.cuda.synchronize()
+            dti = time.perf_counter() - t0
+            in_process = dict(value=pairs * steps / dti, unit='pairs/s',
+                              ms_per_step=dti / steps * 1e3, devices=devs,
+                              note='one process, one stream per device, samples copied device '
+                                   'to device, tiles copied into the arrays on device 0')
+        barrier(dist)
     res = dict(
         metric='Kirchhoff sample*pixel pairs/s', value=pairs * steps / dt,
         unit='pairs/s', n_gpus=world, steps=steps, warmup=warmup,
@@ -312,7 +334,7 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
         config=dict(workload='cfg%d: %d samples -> %dx%d screen, fp64, pixel-tiled'
                              % (cfg, ns, side, side), samples=ns, pixels=npix,
                     parallelism='pixel tiles x%d + all_gather' % world),
-        kernel_ms=k * 1e3,
+        kernel_ms=k * 1e3, in_process=in_process,
         roofline=dict(bound='valu_fp64', kernel='kirchhoff_stream',
                       note='fp64 VALU kernel (no MFMA: profiles/r01_mfma_f64_probe.txt); '
                            'MI355X vector fp64 peak = matrix fp64 peak = 78.6 TFLOP/s '
@@ -328,6 +350,41 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
                                    'scalar cache by every block; unique bytes are ~0.15 GB '
                                    '(compute-bound kernel, HBM at <1 % of peak)'))
     return res, host
+
+
+def bench_kirchhoff_general(reps=3):
+    """The loop every mirror -> mirror wave transfer runs (both polarisations, per-sample
+    normals, receiving points off a plane: kirchhoff_stream's GEN_SP_N variant) on
+    workloads.kirchhoff_general: 2e5 samples x 2e5 points, the shape of the seven large
+    integrals of the reference's SoftiMAX speed test."""
+    from xrt_amd import hipcalls, workloads
+    dev = torch.device('cuda', torch.cuda.current_device())
+    h = workloads.kirchhoff_general()
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    args = [up(h[f]) for f in ('px', 'py', 'pz', 'sx', 'sy', 'sz', 'nx', 'ny', 'nz', 'nl', 'k',
+                               'Es', 'Ep')]
+    hipcalls.kirchhoff(*args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        hipcalls.kirchhoff(*args)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kms = float(np.mean([hipcalls.kirchhoff(*args, timing=True)[5] for _ in range(2)]))
+    pairs = float(h['ns']) * float(h['npix'])
+    variants = sorted(hipcalls.kirchhoff_report()['variants'])
+    return dict(
+        metric='Kirchhoff sample*pixel pairs/s, general loop', value=pairs / dt, unit='pairs/s',
+        samples=h['ns'], pixels=h['npix'], ms_per_call=dt * 1e3, kernel_ms=kms,
+        loop_variants=variants,
+        roofline=dict(
+            bound='valu_fp64', kernel='kirchhoff_stream (general geometry, Es and Ep, '
+                                      'per-sample normals)',
+            achieved=FLOP_PER_PAIR * pairs / (kms * 1e-3) / 1e12, peak=FP64_PEAK / 1e12,
+            unit='TFLOP/s', frac=FLOP_PER_PAIR * pairs / (kms * 1e-3) / FP64_PEAK, traffic=None,
+            note='57 flop per pair; this loop issues 57 VALU instructions per pair, one of them '
+                 'the quarter-rate v_rsq_f64 (60 issue slots): 57 / (2 x 60) = 0.475 of peak is '
+                 'what the formulation allows at full issue (DESIGN 5.1)'))
 
 
 def bench_softi_shapes():
@@ -404,11 +461,11 @@ def bench_undulator(with_cpu=True):
     res = dict(metric='undulator field map, ray-nodes/s (far field, fused '
                       'build_I_map)', rays=n, nodes=nodes, ms=ms,
                value=n * nodes / ms * 1e3, unit='ray-nodes/s', dtype='f64')
-    # Static count from the gfx950 ISA of und_imap<0>'s node loop: 37 mul +
-    # 23 add + 13 fma = 86 flop in 81 VALU instructions (one of them v_rcp_f64, a
-    # quarter-rate instruction: 84 issue slots); -ffp-contract=off keeps the reference's
-    # roundings, so most slots carry one flop, not two.
-    flop, slots = 86, 84
+    # Static count from the gfx950 ISA of und_imap<0>'s node loop: 86 flop
+    # (37 mul + 23 add + 13 fma as the reference writes them) in 63 VALU instructions since
+    # round 3 (one of them v_rcp_f64, a quarter-rate instruction: 66 issue slots): the sum
+    # of krel keeps the reference's roundings, the products behind it are fused.
+    flop, slots = 86, 66
     tf = flop * n * nodes / ms * 1e3 / 1e12
     res['roofline'] = dict(
         bound='valu_fp64', kernel='und_imap', achieved=tf, peak=78.6, unit='TFLOP/s',
@@ -505,13 +562,18 @@ def bench_softimax(runs=3):
             r = orig(*a, **k)
             kms[0] += rw.lastKernelMs
             return r
+        # the kernel seconds come from a run of their own (timing a kernel waits for the
+        # stream); the run that is timed as a whole does not measure them
         rw._kirchhoff_on_gpu = spy
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        rw.timeKernels = True
         try:
-            out = scene.run()
+            scene.run()
         finally:
             rw._kirchhoff_on_gpu = orig
+            rw.timeKernels = False
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out = scene.run()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t1)
         kernel.append(kms[0] * 1e-3)
@@ -638,6 +700,8 @@ def main():
             if cfg == 4 or host is None:
                 host = h
             line['kirchhoff' if 'kirchhoff' not in line else 'kirchhoff_cfg%d' % cfg] = kres
+    if world == 1 and not args.skip_kirchhoff:
+        line['kirchhoff_general'] = bench_kirchhoff_general()
     if world == 1 and not args.skip_undulator:
         line['undulator'] = bench_undulator(not args.skip_cpu_baseline)
     if world == 1 and not args.skip_softimax:

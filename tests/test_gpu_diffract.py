@@ -53,7 +53,60 @@ def test_diffract_from_aperture(golden_dir, name):
     check(glo, g, 'g_', [('x', 'y', 'z'), ('a', 'b', 'c'), ('Es', 'Ep'),
                          ('Jss', 'Jpp', 'Jsp')])
     assert wscr.diffract_repeats == 1 and glo.createdByDiffract
+    assert rw.lastKernelMs is None          # kernels are only timed on request
+
+
+def test_kernel_timing_on_request(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g4_slit_2000x32.npz'))
+    bl = raycing.BeamLine()
+    slit = ra.RectangularAperture(bl, 'slit', [float(v) for v in g['slit_center']],
+                                  ('left', 'right', 'bottom', 'top'), [-0.1, 0.1, -0.1, 0.1])
+    scr = rsc.Screen(bl, 'scr', [float(v) for v in g['screen_center']])
+    wscr = scr.prepare_wave(slit, g['xmesh'], g['zmesh'])
+    rw.timeKernels = True
+    try:
+        rw.diffract(surface_beam(g), wscr)
+    finally:
+        rw.timeKernels = False
     assert rw.lastKernelMs is not None and rw.lastKernelMs > 0
+
+
+@pytest.mark.parametrize('name', ['g4_slit_4000x48', 'g4_toroid_3000x24'])
+@pytest.mark.parametrize('devs', [[0, 0], [0, 0, 0]])
+def test_diffract_over_several_devices_is_the_single_device_result(golden_dir, name, devs):
+    """waves.diffract with its receiving points tiled over a list of devices (the reference
+    splits them over its OpenCL devices in every call, myopencl.py:455-533) -- here the same
+    device several times, each tile on a stream of its own: the wave and the returned beam
+    are bit-identical to the single-device result (every tile runs with the plan of the whole
+    launch)."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    bl = raycing.BeamLine()
+    if 'slit' in name:
+        oe = ra.RectangularAperture(bl, 'slit', [float(v) for v in g['slit_center']],
+                                    ('left', 'right', 'bottom', 'top'), [-0.1, 0.1, -0.1, 0.1])
+    else:
+        p, q, pitch, R, r = [float(v) for v in g['mirror']]
+        oe = roe.ToroidMirror(bl, 'tm', center=[0, p, 0], pitch=pitch, R=R, r=r,
+                              material=rm.Material('Pt', rho=21.45),
+                              limPhysX=[-10, 10], limPhysY=[-300, 300])
+    scr = rsc.Screen(bl, 'scr', [float(v) for v in g['screen_center']])
+    results = []
+    for devices in (None, devs):
+        wscr = scr.prepare_wave(oe, g['xmesh'], g['zmesh'])
+        rw.devices = devices
+        try:
+            glo = rw.diffract(surface_beam(g), wscr)
+        finally:
+            rw.devices = None
+        results.append((wscr, glo))
+    (w1, g1), (w2, g2) = results
+    for f in ('Es', 'Ep', 'Jss', 'Jpp', 'Jsp', 'a', 'b', 'c'):
+        assert np.array_equal(getattr(w1, f), getattr(w2, f)), 'wave ' + f
+        assert np.array_equal(getattr(g1, f), getattr(g2, f)), 'beam ' + f
+    # ... and through the targetOpenCL argument of the call
+    wscr = scr.prepare_wave(oe, g['xmesh'], g['zmesh'])
+    rw.diffract(surface_beam(g), wscr, targetOpenCL=devs)
+    assert np.array_equal(wscr.Es, w1.Es)
 
 
 def test_diffract_from_toroid_mirror(golden_dir):

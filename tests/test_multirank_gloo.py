@@ -99,3 +99,38 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1
+
+
+def test_in_process_device_list_and_tiles():
+    """The in-process split of waves.diffract (multigpu.kirchhoff_devices): which devices a
+    targetOpenCL-like spec / the XRT_HIP_DEVICES variable select, and that the tiles of any
+    device count cover every receiving point exactly once, in order."""
+    import os
+    from xrt_amd import multigpu
+    old = os.environ.pop('XRT_HIP_DEVICES', None)
+    try:
+        assert multigpu.parse_devices(None, 8) is None
+        assert multigpu.parse_devices('auto', 8) is None
+        assert multigpu.parse_devices('all', 8) == list(range(8))
+        assert multigpu.parse_devices('GPU', 2) == [0, 1]
+        assert multigpu.parse_devices(3, 8) == [3]
+        assert multigpu.parse_devices([0, 0, 1], 2) == [0, 0, 1]
+        os.environ['XRT_HIP_DEVICES'] = '0, 2,5'
+        assert multigpu.parse_devices('auto', 8) == [0, 2, 5]
+        os.environ['XRT_HIP_DEVICES'] = 'all'
+        assert multigpu.parse_devices(None, 4) == [0, 1, 2, 3]
+        try:
+            multigpu.parse_devices([4], 4)
+            raise AssertionError('ordinal 4 of 4 accepted')
+        except ValueError:
+            pass
+    finally:
+        os.environ.pop('XRT_HIP_DEVICES', None)
+        if old is not None:
+            os.environ['XRT_HIP_DEVICES'] = old
+    for n in (0, 1, 7, 262144, 4194304, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            edges = [multigpu.tile_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            assert all(p1 >= p0 for p0, p1 in edges)

@@ -19,7 +19,15 @@ from . import sources as rs
 from .physconsts import CH, CHBAR
 
 _DEBUG = 0
+# Milliseconds of the last Kirchhoff kernel -- only measured when `timeKernels` is set: the
+# measurement waits for the stream (bench.py sets it around the calls it times).
 lastKernelMs = None
+timeKernels = False
+# GPUs a diffract() call spreads its receiving points over, as the reference spreads them
+# over its OpenCL devices (myopencl.py:455-533): a list of ordinals, 'all', or None = what
+# the call's targetOpenCL / the XRT_HIP_DEVICES environment variable say (default: the
+# current device only).
+devices = None
 
 
 _ACCUMULATORS = ('EsAcc', 'EpAcc', 'aEacc', 'bEacc', 'cEacc')
@@ -190,13 +198,23 @@ def convex_hull_area(px, py):
     return 0.5 * abs(np.sum(x1*y2 - x2*y1))
 
 
-def _kirchhoff_on_gpu(points, samples):
+def _kirchhoff_on_gpu(points, samples, targetOpenCL='auto'):
     """The five integrals (Es, Ep, aE, bE, cE) of the reference's numpy kernel
     (waves.py:834-851) for receiving *points* (3 device tensors) and *samples* (the ten
-    device tensors of ``_sample_arrays``), by the HIP kernel -> 5 device tensors."""
+    device tensors of ``_sample_arrays``), by the HIP kernel -> 5 device tensors. On
+    several GPUs if asked (``devices``): pixel tiles, see multigpu.kirchhoff_devices."""
     global lastKernelMs
-    out = hipcalls.kirchhoff(*points, *samples, convention=0, timing=True)
-    lastKernelMs = out[5]
+    from ... import multigpu
+    devs = multigpu.parse_devices(devices if devices is not None else targetOpenCL,
+                                  torch.cuda.device_count())
+    if devs is not None and len(devs) > 1:
+        lastKernelMs = None
+        return multigpu.kirchhoff_devices(points, samples, devs, convention=0)
+    if devs is not None and devs[0] != points[0].device.index:
+        raise ValueError('the wave lives on cuda:%d, not on cuda:%d'
+                         % (points[0].device.index, devs[0]))
+    out = hipcalls.kirchhoff(*points, *samples, convention=0, timing=timeKernels)
+    lastKernelMs = out[5] if timeKernels else None
     return out[:5]
 
 
@@ -315,7 +333,7 @@ def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
     wave.beamReflSumJ += flux
     wave.beamReflSumJnl += flux_nl
     points = [wave.dev(name, dev) for name in ('xDiffr', 'yDiffr', 'zDiffr')]
-    fresh = _kirchhoff_on_gpu(points, samples)
+    fresh = _kirchhoff_on_gpu(points, samples, targetOpenCL)
     # Monte-Carlo weight of the integral: receiving cell x illuminated area x incoming flux
     # over (samples x obliquity-weighted flux x repeats), waves.py:735-749
     denom = wave.beamReflRays * wave.beamReflSumJnl * wave.diffract_repeats

@@ -81,6 +81,25 @@ def kirchhoff_custom(ns, side, seed=7):
                 n=[0, 1, 0], nl=nl, E=E, k=k, Es=Es, Ep=Ep)
 
 
+def kirchhoff_general(ns=200_000, npix=200_000, seed=3):
+    """The shape of a mirror -> mirror wave transfer (the seven large integrals of the
+    reference's published SoftiMAX speed test): samples on a footprint with their own
+    surface normals, both polarisations present, receiving points on the next element's
+    footprint -- not on one plane of the diffracting element's frame. 280 eV."""
+    rng = np.random.default_rng(seed)
+    nrm = rng.normal(size=(3, ns)) * 0.01 + np.array([[0.], [0.], [1.]])
+    nrm /= np.sqrt((nrm**2).sum(0))
+    return dict(
+        ns=ns, npix=npix,
+        sx=rng.uniform(-5, 5, ns), sy=rng.uniform(-100, 100, ns), sz=rng.uniform(-0.1, 0.1, ns),
+        nx=nrm[0].copy(), ny=nrm[1].copy(), nz=nrm[2].copy(),
+        k=np.full(ns, 280. / CHBAR * 1e7), nl=rng.uniform(0.01, 0.02, ns),
+        Es=rng.normal(size=ns) + 1j * rng.normal(size=ns),
+        Ep=rng.normal(size=ns) + 1j * rng.normal(size=ns),
+        px=rng.uniform(-5, 5, npix), py=2000. + rng.uniform(-100, 100, npix),
+        pz=20. + rng.uniform(-1, 1, npix))
+
+
 # ---------------------------------------------------------------------------
 # The reference's published wave benchmark (BASELINE.md section 1; reference
 # script tests/speed/3_Softi_CXIw2D_speed.py): SoftiMAX beamline at 280 eV,
