@@ -184,3 +184,63 @@ def test_sequential_wave_chain_matches_reference(golden_dir):
     rw.diffract(lo, wscr)
     assert abs(lo.area - float(g['m_area'])) <= 1e-10 * float(g['m_area'])
     check(wscr, g, 'w_', [('Es', 'Ep'), ('Jss', 'Jpp', 'Jsp'), ('a', 'b', 'c')])
+
+
+def test_zone_plate_in_wave_mode_matches_reference(golden_dir):
+    """N4: a NormalFZP used as a diffracting element (oes/gratings.py:10-137 through
+    prepare_wave / diffract / reflect(noIntersectionSearch)): the samples that survive on the
+    transparent zones, the field on them and the focus profile behind the plate, against the
+    same chain run by the reference (g8_fzp_wave)."""
+    import json
+    from oracle.gen_fixtures_n4_waves import FZP_Y, SLIT_Y, slit_field
+    g = np.load(os.path.join(golden_dir, 'g8_fzp_wave.npz'))
+    kw = json.loads(str(g['fzp']))
+    bl = raycing.BeamLine()
+    bl.src = rs.GeometricSource(bl, 'src', nrays=10)
+    fzp = roe.NormalFZP(bl, 'fzp', center=[0, FZP_Y, 0], pitch=np.pi/2,
+                        material=rm.Material('Au', rho=19.3, kind='FZP'), order=1, **kw)
+    assert np.array_equal(fzp.rn, g['rn'])
+    half = float(fzp.rn[-1])
+    slit = ra.RectangularAperture(bl, 'slit', [0, SLIT_Y, 0], ('left', 'right', 'bottom', 'top'),
+                                  [-1.2 * half, 1.2 * half, -1.2 * half, 1.2 * half])
+    np.random.seed(41)
+    wslit = slit.prepare_wave(bl.src, 1500)
+    slit_field(wslit, kw['E'], SLIT_Y)
+    for f in ('x', 'z', 'Es', 'a', 'b', 'c'):
+        assert np.array_equal(getattr(wslit, f), g['s_' + f]), f
+    np.random.seed(42)
+    wz = fzp.prepare_wave(slit, 3000)
+    assert len(wz.x) == len(g['z_x'])           # the same samples fall on open zones
+    glo, lo = fzp.reflect(rw.diffract(wslit, wz), noIntersectionSearch=True)
+    lo.parentId = fzp.uuid
+    assert np.array_equal(lo.state, g['z_state'])
+    check(lo, g, 'z_', [('x', 'y', 'z'), ('a', 'b', 'c'), ('Es', 'Ep'), ('Jss', 'Jpp', 'Jsp')])
+    scr = rsc.Screen(bl, 'scr', [0, FZP_Y + float(g['q']), 0])
+    wscr = scr.prepare_wave(fzp, g['xmesh'], g['zmesh'])
+    rw.diffract(lo, wscr)
+    check(wscr, g, 'w_', [('Es', 'Ep'), ('Jss', 'Jpp', 'Jsp'), ('a', 'b', 'c')])
+    J = wscr.Jss + wscr.Jpp
+    assert np.argmax(J) == len(J) // 2 and J.max() > 100 * J[0]      # it does focus
+
+
+def test_propagate_wave_from_a_source_matches_reference(golden_dir):
+    """N4: OE.propagate_wave with a source as the previous element (oes/reflect.py:405-449):
+    samples on the mirror, the undulator field on them (shine(wave=...)), reflect with the
+    intersection search -- against the reference (g8_source_mirror), same seed."""
+    import json
+    g = np.load(os.path.join(golden_dir, 'g8_source_mirror.npz'))
+    und, mirror = json.loads(str(g['und'])), json.loads(str(g['mirror']))
+    bl = raycing.BeamLine()
+    src = rs.Undulator(bl, 'und', **und)
+    m1 = roe.ToroidMirror(bl, 'm1', R=1e7, r=60., material=rm.Material('Pt', rho=21.45),
+                          **mirror)
+    trigger = rs.Beam(nrays=8)
+    trigger.parentId = src.uuid
+    np.random.seed(43)
+    glo, lo = m1.propagate_wave(wave=trigger, nrays=1200)
+    assert (src.quadm, src.gIntervals) == (int(g['quadm']), int(g['gIntervals']))
+    assert np.array_equal(lo.state, g['m_state'])
+    check(lo, g, 'm_', [('x', 'y', 'z'), ('a', 'b', 'c'), ('Es', 'Ep'), ('Jss', 'Jpp', 'Jsp')])
+    check(glo, g, 'mg_', [('x', 'y', 'z'), ('a', 'b', 'c'), ('Es', 'Ep'),
+                          ('Jss', 'Jpp', 'Jsp')])
+    assert lo.parentId == m1.uuid

@@ -528,12 +528,15 @@ class OE(object):
         aimed = self._to_global_points(x, y, self._surface_height(x, y))
         aimed.parentId = prevOE.uuid
         origin = prevOE._anchor() if hasattr(prevOE, 'rotationSequence') else prevOE.center
-        for direction, position, o in zip('abc', 'xyz', origin):
-            getattr(aimed, direction)[:] = getattr(aimed, position) - o
+        # rays from `origin` towards the sample points
+        aimed.a[:] = aimed.x - origin[0]
+        aimed.b[:] = aimed.y - origin[1]
+        aimed.c[:] = aimed.z - origin[2]
         length = (aimed.a**2 + aimed.b**2 + aimed.c**2)**0.5
-        for direction, position, o in zip('abc', 'xyz', origin):
-            getattr(aimed, direction).__itruediv__(length)
-            getattr(aimed, position)[:] = o
+        aimed.a /= length
+        aimed.b /= length
+        aimed.c /= length
+        aimed.x[:], aimed.y[:], aimed.z[:] = origin
         # projection of the area on the line of sight from prevOE: the local normal at the
         # origin of the surface against the direction to that origin
         pole = rs.Beam(nrays=1)
@@ -555,21 +558,25 @@ class OE(object):
         return waveLocal
 
     def propagate_wave(self, wave=None, beam=None, nrays='auto'):
-        """Kirchhoff-propagates *wave* (the local field on the previous element)
-        onto this surface and reflects it: -> (beamGlobal, beamLocal) usable for
-        further ray or wave propagation (oes/reflect.py:405-449). This is the
-        explicit sequence prepare_wave -> diffract -> reflect(noIntersectionSearch)
-        that the reference's wave examples spell out; the reference's own
-        propagate_wave additionally transforms *wave* in place while
-        auto-aligning (reflect.py:434-438), a side effect that is not reproduced
-        (golden case G8 is generated with the explicit sequence)."""
+        """Brings the field *wave* (the local beam on the previous element, or the beam of a
+        source) onto this surface as a wave and reflects it: -> (beamGlobal, beamLocal) usable
+        for further ray or wave propagation (oes/reflect.py:405-449). From an optical element
+        or aperture: prepare_wave -> diffract -> reflect(noIntersectionSearch) -- the sequence
+        the reference's wave examples spell out. From a source: prepare_wave, the source's
+        ``shine(wave=...)`` onto those samples, reflect with the intersection search. The
+        reference's own method additionally passes *wave* through the auto-alignment hooks,
+        which transform it in place (reflect.py:434-438); that side effect is not reproduced
+        (golden cases G8 are generated with explicit positions)."""
         from . import waves as rw
         prevOE = self.bl.oesDict[wave.parentId][0]
-        if hasattr(prevOE, 'shine'):
-            raise NotImplementedError('wave propagation directly from a source')
         size = len(wave.x) if nrays == 'auto' else int(nrays)
-        arriving = rw.diffract(wave, self.prepare_wave(prevOE, size, rw=rw))
-        glo, loc = self.reflect(arriving, noIntersectionSearch=True)
+        receiving = self.prepare_wave(prevOE, size, rw=rw)
+        if hasattr(prevOE, 'shine'):
+            arriving = prevOE.shine(wave=receiving)
+            glo, loc = self.reflect(arriving)
+        else:
+            arriving = rw.diffract(wave, receiving)
+            glo, loc = self.reflect(arriving, noIntersectionSearch=True)
         loc.parentId = self.uuid
         return glo, loc
 
