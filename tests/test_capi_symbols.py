@@ -48,3 +48,22 @@ def test_argument_validation_without_gpu():
     assert rc == -1 and b'negative' in lib.xrt_hip_last_error()
     with pytest.raises(_lib.XrtHipError):
         _lib.check(rc, 'plan')
+
+
+def test_crystal_on_a_conic_or_vfm_surface_is_refused():
+    """A Bragg crystal on a surface kind only the family-1 / family-2 kernels evaluate
+    (parametric conics, lenses, cone, blazed, VFM, DualVFM) is refused by the C ABI before any
+    GPU work: the crystal kernels are compiled for family 0 and would trace it as flat."""
+    import ctypes
+    from xrt_amd import _lib, _structs
+    lib = _lib.load(build_if_missing=False)
+    lib.xrt_hip_last_error.restype = ctypes.c_char_p
+    for kind in (3, 4, 5, 6, 9, 10):
+        p, m = _structs.Pass(), _structs.Material()
+        p.surf_kind = kind
+        m.kind = 4          # XRT_HIP_MAT_CRYSTAL
+        rc = lib.xrt_hip_reflect_pass_f64_dev(ctypes.byref(p), ctypes.byref(m), None, None, None,
+                                              None, None, None, ctypes.c_size_t(0), None, None,
+                                              None)
+        assert rc != 0, kind
+        assert b'crystals on blazed / parametric surfaces' in lib.xrt_hip_last_error()

@@ -41,17 +41,52 @@ class RectangularAperture(object):
         if unknown:
             raise ValueError('unknown blade(s) {0}'.format(sorted(unknown)))
         self.blades = {b: blades[b] for b in _BLADE_ORDER if b in blades}
+        self.set_optical_limits()
+        axes = [None if isinstance(v, str) else v for v in (x, z)]
+        self.xyz = raycing.xyz_from_xz(self, *axes)
+        self.x, self.y, self.z = self.xyz
+
+    def set_optical_limits(self):
+        """limOptX / limOptY (what prepare_wave samples and what the areas are taken from)
+        from the blades (reference apertures.py:107-131)."""
         wide = raycing.maxHalfSizeOfOE
         self.limOptX, self.limOptY = [-wide, wide], [-wide, wide]
         for blade, edge in self.blades.items():
             limit, end = _BLADES[blade]
             getattr(self, limit)[end] = float(edge)
-        axes = [None if isinstance(v, str) else v for v in (x, z)]
-        self.xyz = raycing.xyz_from_xz(self, *axes)
-        self.x, self.y, self.z = self.xyz
 
-    kind = property(lambda self: list(self.blades))
-    opening = property(lambda self: list(self.blades.values()))
+    # kind / opening as in the reference: parallel lists that can be assigned, e.g. in a scan
+    @property
+    def kind(self):
+        return list(self.blades)
+
+    @kind.setter
+    def kind(self, names):
+        names = [names] if isinstance(names, str) else list(names)
+        edges = self.opening
+        if len(edges) != len(names):
+            raise ValueError('`kind` and `opening` must have equal lengths')
+        self._set_blades(names, edges)
+
+    @property
+    def opening(self):
+        return list(self.blades.values())
+
+    @opening.setter
+    def opening(self, edges):
+        edges = list(edges) if raycing.is_sequence(edges) else [edges]
+        names = self.kind
+        if len(edges) != len(names):
+            raise ValueError('`kind` and `opening` must have equal lengths')
+        self._set_blades(names, edges)
+
+    def _set_blades(self, names, edges):
+        unknown = set(names) - set(_BLADES)
+        if unknown:
+            raise ValueError('unknown blade(s) {0}'.format(sorted(unknown)))
+        given = dict(zip(names, edges))
+        self.blades = {b: given[b] for b in _BLADE_ORDER if b in given}
+        self.set_optical_limits()
 
     def local_to_global(self, glo, returnBeam=False, **kwargs):
         """Positions and directions of a host beam from the aperture's frame to the
@@ -87,7 +122,7 @@ class RectangularAperture(object):
             held = self.__dict__.setdefault('_outline', {})
             dev = torch.device('cuda', torch.cuda.current_device())
             if str(dev) not in held or not np.array_equal(held[str(dev)][0], outline):
-                held[str(dev)] = (outline, torch.from_numpy(outline.copy()).to(dev))
+                held[str(dev)] = (outline.copy(), torch.from_numpy(outline.copy()).to(dev))
             a.poly_n, a.poly_xz, a.blade_mask = len(outline), held[str(dev)][1].data_ptr(), 0
         return a
 

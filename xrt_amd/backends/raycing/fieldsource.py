@@ -26,7 +26,7 @@ from scipy.interpolate import interp1d
 
 from ... import hipcalls
 from .physconsts import C, CHeVcm, PI2, SIE0, FINE_STR
-from .undulator import Undulator, clenshaw_curtis
+from .undulator import Undulator, clenshaw_curtis, _TABLE_LOCK
 
 SIM0 = 9.109383701528e-31       # electron mass [kg], reference physconsts.py:17
 EMC = 0.5866791802416487        # e / (m c) in the units of the field tables, physconsts.py:24
@@ -163,19 +163,22 @@ class SourceFromField(Undulator):
     def _node_tables(self):
         """The ten node tables of the field sum on the device + betam, for the present
         field table, grid and (filament beam) electron energy."""
+        dev = self._device()
         key = (id(self.customFieldData), bool(self.filamentBeam),
-               float(self.gamma) if self.filamentBeam else None, len(self.tg))
-        hit = self._trajectories.get(key)
+               float(self.gamma) if self.filamentBeam else None, len(self.tg), str(dev))
+        with _TABLE_LOCK:       # (workers of run_ray_tracing(threads=N) share this source)
+            hit = self._trajectories.get(key)
         if hit is None:
             Bx, By, Bz = self._magnetic_field()
             betax, betay, betazav, trajx, trajy, trajz = self.build_trajectory(Bx, By, Bz)
             Bxt, Byt, Bzt = self._magnetic_field(self.tg)
-            dev = self._device()
             host = dict(tg=self.tg, ag=self.ag, Bx=Bxt, By=Byt, Bz=Bzt, betax=betax,
                         betay=betay, trajx=trajx, trajy=trajy, trajz=trajz)
             tables = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(dev)
                       for k, v in host.items()}
-            hit = self._trajectories[key] = (tables, host, betazav[-1])
+            hit = (tables, host, betazav[-1])
+            with _TABLE_LOCK:
+                self._trajectories[key] = hit
         return hit
 
     # ---- the field integral ---------------------------------------------------------------

@@ -339,7 +339,7 @@ class OE(object):
             cached = held.get(str(_device()))
             if cached is None or not np.array_equal(cached[0], outline):
                 cached = held[str(_device())] = (
-                    outline, torch.from_numpy(outline.copy()).to(_device()))
+                    outline.copy(), torch.from_numpy(outline.copy()).to(_device()))
             p.shape, p.poly_n, p.poly_xy = _structs.SHAPE_POLYGON, len(outline), \
                 cached[1].data_ptr()
         elif self.shape[:2] in shapes:

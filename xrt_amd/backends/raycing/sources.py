@@ -115,8 +115,13 @@ class Beam(object):
             if key in _ARRAY_FIELDS:
                 self._h[key] = np.array(value, dtype=_np_dtype(key))
             else:
+                if isinstance(value, np.ndarray) and value.size == 1:
+                    value = value.item()       # what a 'mat' file makes of scalars and names
                 if key in ('fromOE', 'toOE', 'parentId') and bl is not None:
-                    value = getattr(bl, 'oesDict', {}).get(value, [value])[0]
+                    try:
+                        value = getattr(bl, 'oesDict', {}).get(value, [value])[0]
+                    except (KeyError, TypeError):
+                        pass                   # not a known element: the name stays as it is
                 object.__setattr__(self, key, value)
 
     # ---- attribute protocol ------------------------------------------------

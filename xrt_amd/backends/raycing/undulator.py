@@ -15,6 +15,8 @@ Not mirrored (raise NotImplementedError / absent): custom magnetic field
 (``intensities_on_mesh``, ``multi_electron_stack``, ``tuning_curves``, ``power_vs_K``) are in
 meshes.py.
 """
+import threading
+
 import numpy as np
 import torch
 from scipy import special
@@ -25,6 +27,8 @@ from .physconsts import (PI, PI2, C, EV2ERG, CHeVcm, CHBAR, M0, K2B, E2WC, SIE0,
                          SQ2, SQPI)
 from .sources import Beam
 from .meshes import MeshFunctions
+
+_TABLE_LOCK = threading.Lock()
 
 UND_FAR, UND_TAPER, UND_NF = 0, 1, 2
 
@@ -259,15 +263,23 @@ class Undulator(MeshFunctions):
         shifted = self.tg + self.phase                          # the horizontal field's phase
         self.sintg, self.costg = np.sin(self.tg), np.cos(self.tg)
         self.sintgph, self.costgph = np.sin(shifted), np.cos(shifted)
-        self._tables = None          # uploaded on first use
+        self._tables = {}            # per device, uploaded on first use there
 
     def _device_tables(self):
-        if self._tables is None:
-            dev = self._device()
-            self._tables = [torch.from_numpy(np.ascontiguousarray(t)).to(dev)
-                            for t in (self.tg, self.ag, self.sintg, self.costg,
-                                      self.sintgph, self.costgph)]
-        return self._tables
+        # (run_ray_tracing(threads=N) puts its workers on different GPUs: one copy per device,
+        # filled under a lock)
+        dev = self._device()
+        key = str(dev)
+        with _TABLE_LOCK:
+            tables = self._tables.get(key) if isinstance(self._tables, dict) else None
+            if tables is None:
+                if not isinstance(self._tables, dict):
+                    self._tables = {}
+                tables = self._tables[key] = [
+                    torch.from_numpy(np.ascontiguousarray(t)).to(dev)
+                    for t in (self.tg, self.ag, self.sintg, self.costg, self.sintgph,
+                              self.costgph)]
+        return tables
 
     def _device(self):
         if self.device is not None:

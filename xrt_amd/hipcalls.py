@@ -79,7 +79,13 @@ def kirchhoff_report(device=None):
     classification flags, the set of loop-variant names, the mesh row length."""
     lib = _lib.load()
     dev = device if device is not None else torch.device('cuda', torch.cuda.current_device())
-    ws = workspace(dev, 256, 'kirchhoff')
+    # the record lives at the head of the workspace the call used: none yet on this thread /
+    # stream -> nothing to report (a fresh buffer would hold garbage)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(index).cuda_stream, 'kirchhoff')
+    ws = _tls.__dict__.get('workspaces', {}).get(key)
+    if ws is None:
+        return None
     f, v, row = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_int64(0)
     with torch.cuda.device(dev):
         _lib.check(lib.xrt_hip_kirchhoff_report(
