@@ -387,6 +387,51 @@ def bench_kirchhoff_general(reps=3):
                  'what the formulation allows at full issue (DESIGN 5.1)'))
 
 
+def bench_hist(nrays):
+    """N2: the histograms of one XYCPlot (2-D flux + RGB planes, three 1-D histograms with
+    flux / R / G / B weights, ray counters) from a device-resident beam of *nrays* rays --
+    the step after the hot path in every run_ray_tracing iteration. Algorithmic bytes: 44 B
+    per ray (x, y, colour datum, state, Jss, Jpp), read once."""
+    from xrt_amd import workloads, plotter as xrtp, runner
+    oe = workloads.cfg2_toroid()
+    beam = workloads.synthetic_rays(nrays, 42)
+    for f in beam.array_fields():
+        beam.dev(f)
+    gb, lb = oe.reflect(beam)
+    res = dict(metric='plot histograms of one XYCPlot, rays/s', rays=nrays, unit='rays/s',
+               dtype='f64')
+    for bins in (128, 256):
+        plot = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis('x', 'mm', bins=bins),
+                            xrtp.XYCAxis('y', 'mm', bins=bins),
+                            caxis=xrtp.XYCAxis('energy', 'eV', bins=bins))
+        runner.accumulate_plot(plot, {'b': lb})          # sets the limits
+        torch.cuda.synchronize()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            runner.accumulate_plot(plot, {'b': lb})
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        key = 'bins%d' % bins
+        res[key] = dict(ms_per_plot=ms, value=nrays / ms * 1e3,
+                        note='accumulate_plot with its host glue (one memset, one copy of all '
+                             'bins back)')
+        if bins == 128:
+            res['value'] = nrays / ms * 1e3
+            res['ms_per_plot'] = ms
+            res['roofline'] = dict(
+                bound='hbm', kernel='plot_hist_lds (four passes at 128 x 128: one 128-KB plane '
+                                    'of the LDS each)',
+                achieved=44. * nrays / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
+                frac=44. * nrays / (ms * 1e-3) / HBM_PEAK, traffic=None,
+                note='44 B per ray algorithmic; every pass re-reads them (4 x 44 B of traffic): '
+                     'the four fp64 planes of a 128 x 128 plot are 512 KB, a CU has 160 KB of '
+                     'LDS, and global fp64 atomics run at 2.4e10 /s on this chip '
+                     '(tools/probes/probe_atomics.hip) = 1.7 ms for the 4e7 updates; 256 x 256 '
+                     'plots take that route')
+    return res
+
+
 def bench_softi_shapes():
     """The reference's only published P2 numbers are whole-script times of
     tests/speed/3_Softi_CXIw2D_speed.py: 7 diffract calls of <= 2e5 x 2e5 pairs
@@ -708,6 +753,7 @@ def main():
         line['softimax'] = bench_softimax()
     if world == 1 and not args.skip_balder:
         line['balder'] = bench_balder(int(args.rays))
+        line['hist'] = bench_hist(int(args.rays))
     if args.with_softi_shapes and world == 1:
         line['softi_shapes'] = bench_softi_shapes()
     if world == 1 and rank == 0 and not args.skip_cpu_baseline:

@@ -1,4 +1,5 @@
-"""Time of the per-plot histogram reduce (N2) on 1e7 rays: PYTHONPATH=. python tools/probe_hist.py"""
+"""Time of the per-plot histogram reduce (N2) on 1e7 rays, by bin count:
+PYTHONPATH=. python tools/probe_hist.py"""
 import time
 import torch
 from xrt_amd import workloads, plotter as xrtp, runner
@@ -9,14 +10,15 @@ beam = workloads.synthetic_rays(n, 42)
 for f in beam.array_fields():
     beam.dev(f)
 gb, lb = oe.reflect(beam)
-for name, b, xa, ya in (('footprint', lb, 'x', 'y'), ('global xz', gb, 'x', 'z')):
-    plot = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis(xa, 'mm', bins=128), xrtp.XYCAxis(ya, 'mm', bins=128),
-                        caxis=xrtp.XYCAxis('energy', 'eV', bins=128))
-    runner.accumulate_plot(plot, {'b': b})          # sets the limits
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        runner.accumulate_plot(plot, {'b': b})
-    torch.cuda.synchronize()
-    print('%-10s %.2f ms per accumulate_plot (host glue included), selected %d' % (
-        name, (time.perf_counter() - t0) / 5 * 1e3, plot.nRaysSelected))
+for bins in (64, 128, 256, 512):
+    for name, b, xa, ya in (('footprint', lb, 'x', 'y'), ('global xz', gb, 'x', 'z')):
+        plot = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis(xa, 'mm', bins=bins), xrtp.XYCAxis(ya, 'mm', bins=bins),
+                            caxis=xrtp.XYCAxis('energy', 'eV', bins=bins))
+        runner.accumulate_plot(plot, {'b': b})          # sets the limits
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            runner.accumulate_plot(plot, {'b': b})
+        torch.cuda.synchronize()
+        print('%3d bins %-10s %.2f ms per accumulate_plot (host glue included), selected %d' % (
+            bins, name, (time.perf_counter() - t0) / 5 * 1e3, plot.nRaysSelected))

@@ -55,10 +55,10 @@ def accumulate_plot(plot, beams):
             lo, hi = lo - 0.5, hi + 0.5
         cax.limits = [lo, hi]
     nx, ny, nc = plot.xaxis.bins, plot.yaxis.bins, cax.bins
-    z = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=dev)  # noqa: E731
-    hist, hist_rgb = z(ny, nx), z(ny, nx, 3)
-    hx, hy, hc = z(nx, 4), z(ny, 4), z(nc, 4)
-    counters = z(8)
+    # all results of the call in ONE device buffer: one memset, one copy back, one sync
+    sizes = (ny * nx, ny * nx * 3, nx * 4, ny * 4, nc * 4, 8)
+    flat = torch.zeros(sum(sizes), dtype=torch.float64, device=dev)
+    hist, hist_rgb, hx, hy, hc, counters = torch.split(flat, sizes)
     srcw = beam.nrays * beam.sourceWeight if hasattr(beam, 'sourceWeight') else 1.
     state_beam = beam if plot.beamState is None else beams[plot.beamState]
     s = beam.to_struct(dev)
@@ -86,14 +86,15 @@ def accumulate_plot(plot, beams):
         ptr(hist_rgb), ptr(hx), ptr(hy), ptr(hc) if plot.ePos else None, ptr(counters),
         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
         'xrt_hip_plot_hist_f64_dev')
-    plot.total2D_RGB += hist_rgb.cpu().numpy()      # (a sync: `keep` outlives the kernel)
+    host = flat.cpu().numpy()                        # (a sync: `keep` outlives the kernel)
     del keep
-    plot.xaxis.total1D4 += hx.cpu().numpy()
-    plot.yaxis.total1D4 += hy.cpu().numpy()
+    hist, hist_rgb, hx, hy, hc, c = np.split(host, np.cumsum(sizes)[:-1])
+    plot.total2D_RGB += hist_rgb.reshape(ny, nx, 3)
+    plot.xaxis.total1D4 += hx.reshape(nx, 4)
+    plot.yaxis.total1D4 += hy.reshape(ny, 4)
     if plot.ePos:
-        cax.total1D4 += hc.cpu().numpy()
-    c = counters.cpu().numpy()
-    plot.total2D += hist.cpu().numpy()
+        cax.total1D4 += hc.reshape(nc, 4)
+    plot.total2D += hist.reshape(ny, nx)
     plot.nRaysAll += beam.nrays
     plot.nRaysSelected += int(c[0])
     plot.intensity += float(c[1])
