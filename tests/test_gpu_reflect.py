@@ -103,15 +103,17 @@ def test_softimax_surface_kinds_match_reference_golden(name):
     print('%s: |dE|/|E| = %.2e, k*|dt| = %.2e rad (%.1f ulp of path)' % (
         name, field_err, phase_noise,
         dt.max() / np.spacing(np.abs(g['lb_path'][hit]).max())))
-    # the complex amplitudes agree to the propagation-phase noise of the path length
-    # (k*dt, each side < 1 ulp in atan2 / cos of the parametric solve), and to 1e-10
-    # where no parametric surface is involved
-    amp_tol = max(2. * phase_noise, AMP_TOL) if parametric else AMP_TOL
-    assert phase_noise < 1e-3 and field_err < 5e-5
+    # Round 3: arctan2 / cos of the parametric solve are rounded as libm rounds them
+    # (fp64_math.h: atan2_np, cos_np), so every ray stops at the iteration the reference stops
+    # at and the path lengths are the reference's own doubles. (With ocml's < 1-ulp functions
+    # ~1 % of the rays took one secant step more or less: paths off by up to 8 ulp,
+    # |dE|/|E| = 1.8e-5 on the cylindrical conics.)
+    amp_tol = max(2. * phase_noise, 1e-9) if parametric else AMP_TOL
+    assert phase_noise < 1e-9 and field_err < 1e-9
     compare(gb, g, lambda f: g['gb_' + f], geo_tol=4e-12, amp_tol=amp_tol)
     compare(lb, g, lambda f: g['lb_' + f], geo_tol=4e-12, amp_tol=amp_tol)
     assert np.abs(lb.path - g['lb_path'])[hit].max() <= \
-        8 * np.spacing(np.abs(g['lb_path'][hit]).max())
+        np.spacing(np.abs(g['lb_path'][hit]).max())
     for f in ('Es', 'Ep'):
         assert np.abs(np.abs(getattr(lb, f)) - np.abs(g['lb_' + f])).max() <= \
             AMP_TOL * np.abs(g['lb_Es']).max()

@@ -60,6 +60,106 @@ __device__ __forceinline__ double acos_np(double x) {
   return 1.57079632679489655800e+00 - (x - (6.12323399573676603587e-17 - x * r));
 }
 
+// ---------------------------------------------------------------------------
+// arctan2 and cos as libm rounds them, for the arguments of a parametric (cylindrical) conic
+// at grazing incidence. The reference's root solve in (s, phi, r) stops at |dz| <= 1e-12 mm: a
+// ray whose residual lands within rounding noise of that threshold takes one iteration more or
+// less depending on the LAST BIT of phi = arctan2(x, z') and of cos(phi), and its path then
+// moves by ~1e-12 / sin(grazing angle) -- several ulp, k dt ~ 1e-5 rad at 280 eV. glibc's
+// functions are correctly rounded but for ~1 % of arguments (<= 0.52 / 0.55 ulp); ocml's are
+// < 1 ulp, i.e. differ on ~1/4 of them. Here: z' < 0 and |x| <= |z'| / 16 (the surface lies
+// around phi = +-pi), resp. |phi| > 3: the function evaluated in double-double and rounded
+// once. Everything else goes to the library.
+// ---------------------------------------------------------------------------
+struct dd_t {
+  double hi, lo;
+};
+__device__ __forceinline__ dd_t dd_two_sum(double a, double b) {
+  const double s = a + b, bb = s - a;
+  return dd_t{s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ dd_t dd_fast_sum(double a, double b) {   // |a| >= |b|
+  const double s = a + b;
+  return dd_t{s, b - (s - a)};
+}
+__device__ __forceinline__ dd_t dd_prod(double a, double b) {
+  const double p = a * b;
+  return dd_t{p, fma_(a, b, -p)};
+}
+__device__ __forceinline__ dd_t dd_add(dd_t a, dd_t b) {
+  dd_t s = dd_two_sum(a.hi, b.hi);
+  s.lo += a.lo + b.lo;
+  return dd_fast_sum(s.hi, s.lo);
+}
+__device__ __forceinline__ dd_t dd_neg(dd_t a) { return dd_t{-a.hi, -a.lo}; }
+__device__ __forceinline__ dd_t dd_mul(dd_t a, dd_t b) {
+  dd_t p = dd_prod(a.hi, b.hi);
+  p.lo += a.hi * b.lo + a.lo * b.hi;
+  return dd_fast_sum(p.hi, p.lo);
+}
+__device__ __forceinline__ dd_t dd_mul_d(dd_t a, double b) {
+  dd_t p = dd_prod(a.hi, b);
+  p.lo += a.lo * b;
+  return dd_fast_sum(p.hi, p.lo);
+}
+// pi = PI_HI + PI_LO to 107 bits
+#define XRT_PI_HI 0x1.921fb54442d18p+1
+#define XRT_PI_LO 0x1.1a62633145c07p-53
+
+__device__ __forceinline__ double atan2_np(double y, double x) {
+  const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+  if (__builtin_expect(!(x < 0. && ay <= ax * 0.0625 && ay > ax * 0x1p-40 && ax < 0x1p500 &&
+                         ax > 0x1p-500), 0))
+    return atan2(y, x);
+  // t = |y| / |x| to double-double: quotient, exact remainder, its quotient
+  const double q1 = ay / ax;
+  const double q2 = fma_(-q1, ax, ay) / ax;
+  const dd_t t = dd_fast_sum(q1, q2);
+  // atan t = t - t^3/3 + t^5 (1/5 - t^2/7 + ... ), t <= 1/16: the tail in plain doubles
+  const dd_t t2 = dd_mul(t, t);
+  const dd_t t3 = dd_mul(t2, t);
+  const dd_t third = dd_t{0x1.5555555555555p-2, 0x1.5555555555555p-56};
+  const double w = t2.hi;
+  double tail = 1. / 19.;
+  tail = fma_(-tail, w, 1. / 17.);
+  tail = fma_(-tail, w, 1. / 15.);
+  tail = fma_(-tail, w, 1. / 13.);
+  tail = fma_(-tail, w, 1. / 11.);
+  tail = fma_(-tail, w, 1. / 9.);
+  tail = fma_(-tail, w, 1. / 7.);
+  tail = fma_(-tail, w, 1. / 5.);
+  tail *= (w * w) * t.hi;
+  dd_t a = dd_add(t, dd_neg(dd_mul(t3, third)));
+  a = dd_add(a, dd_t{tail, 0.});
+  const dd_t phi = dd_add(dd_t{XRT_PI_HI, XRT_PI_LO}, dd_neg(a));
+  const double r = phi.hi + phi.lo;
+  return y < 0. ? -r : r;
+}
+
+__device__ __forceinline__ double cos_np(double phi) {
+  const double ap = __builtin_fabs(phi);
+  if (__builtin_expect(!(ap > 3.0 && ap < 3.3), 0)) return cos(phi);
+  // d = pi - |phi| (the first difference is exact), |d| < 0.16; cos phi = -cos d
+  const dd_t d = dd_fast_sum(XRT_PI_HI - ap, XRT_PI_LO);
+  const dd_t d2 = dd_mul(d, d);
+  const dd_t u = dd_mul_d(d2, 0.5);                 // d^2 / 2
+  const dd_t sixth = dd_t{0x1.5555555555555p-3, 0x1.5555555555555p-57};
+  const dd_t u2 = dd_mul(dd_mul(u, u), sixth);      // d^4 / 24
+  const double w = d2.hi;
+  // - d^6/720 + d^8/40320 - ... in plain doubles
+  double tail = 1. / 20922789888000.;               // 1/16!
+  tail = fma_(-tail, w, 1. / 87178291200.);         // 1/14!
+  tail = fma_(-tail, w, 1. / 479001600.);           // 1/12!
+  tail = fma_(-tail, w, 1. / 3628800.);             // 1/10!
+  tail = fma_(-tail, w, 1. / 40320.);               // 1/8!
+  tail = fma_(-tail, w, 1. / 720.);                 // 1/6!
+  tail *= -((w * w) * w);
+  dd_t c = dd_add(dd_t{1., 0.}, dd_neg(u));
+  c = dd_add(c, u2);
+  c = dd_add(c, dd_t{tail, 0.});
+  return -(c.hi + c.lo);
+}
+
 // Correctly rounded sqrt(x) for normal positive x (no scaling / special cases:
 // callers guarantee 2^-700 < x < 2^700) that ALSO hands back 1/sqrt(x) to ~1 ulp
 // for free. Same Goldschmidt iteration LLVM emits for f64 sqrt on AMDGPU

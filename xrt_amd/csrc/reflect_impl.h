@@ -429,7 +429,7 @@ __device__ __forceinline__ void ell_xyz_to_param(const xrt_hip_pass& P, double x
   const double yN = cg * yy - sg * zz;
   const double zN = sg * yy + cg * zz;
   s = yN;
-  phi = atan2(x, zN);
+  phi = atan2_np(x, zN);
   r = sqrt(x * x + zN * zN);
 }
 
@@ -462,7 +462,7 @@ __device__ __forceinline__ double ell_local_r(const xrt_hip_pass& P, double s, d
   } else {
     r = B * sqrt(fabs(1. - (s * s) / (A * A)));
   }
-  if (P.surf_p[6] != 0.) r /= fabs(cos(phi));
+  if (P.surf_p[6] != 0.) r /= fabs(cos_np(phi));
   if (P.surf_p[7] != 0.) return r;
   if (conic == 2) return fabs(phi) < kPI / 2. ? r : 1e20;
   return fabs(phi) > kPI / 2. ? r : 1e20;
