@@ -219,6 +219,20 @@ def bench_reflect(args, world, rank, dist, dcm=False):
     return res
 
 
+def host_cpu():
+    """CPU model string and core count of the box (SURVEY 8d asks for both)."""
+    model = None
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.lower().startswith('model name'):
+                    model = ln.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(cpu_model=model, nproc=os.cpu_count())
+
+
 def cpu_baseline_reflect(nrays=10_000_000, numpy_rays=4_000_000):
     """The same cfg2 workload on the host: the numpy oracle on one core (bounded sample:
     the first *numpy_rays* rays) and its C/OpenMP restatement on all cores."""
@@ -236,8 +250,10 @@ def cpu_baseline_reflect(nrays=10_000_000, numpy_rays=4_000_000):
     rn.oe_reflect(params, part)
     dt = time.perf_counter() - t0
     res = dict(value=m / dt, unit='intersections/s', cores=1, kind='port',
-               sample='%d rays of cfg2 through oracle/reflect_np.py (numpy, 1 '
-                      'thread), %.1f s' % (m, dt))
+               sampled=m < nrays,
+               sample='a SAMPLE of the workload: the first %d of its %d rays through '
+                      'oracle/reflect_np.py (numpy, 1 thread), %.1f s' % (m, nrays, dt))
+    res.update(host_cpu())
     # all host cores: the C/OpenMP restatement of the same pass (oracle/reflect_c.c,
     # validated against reflect_np and the reference's golden G2 by
     # tests/test_oracle_reflect_c.py), same 1e7 rays
@@ -528,9 +544,11 @@ def bench_undulator(with_cpu=True):
                          ps[:m])
         dt = time.perf_counter() - t0
         res['cpu_baseline'] = dict(
-            value=m * nodes / dt, unit='ray-nodes/s', cores=1, kind='port',
-            sample='%d rays x %d nodes through oracle/undulator_np.py (numpy '
-                   'restatement of the reference\'s _sp_sum), %.1f s' % (m, nodes, dt))
+            value=m * nodes / dt, unit='ray-nodes/s', cores=1, kind='port', sampled=True,
+            sample='a SAMPLE of the workload: %d of its %d rays x %d nodes through '
+                   'oracle/undulator_np.py (numpy restatement of the reference\'s _sp_sum), '
+                   '%.1f s' % (m, n, nodes, dt))
+        res['cpu_baseline'].update(host_cpu())
     return res
 
 
@@ -648,10 +666,11 @@ def cpu_baseline_kirchhoff(host, npix=256):
                       host['E'], host['Es'], host['Ep'])
     dt = time.perf_counter() - t0
     ns = host['sx'].size
-    res = dict(value=npix * ns / dt, unit='pairs/s', cores=1, kind='port',
-               sample='%d pixels x %d samples of cfg4 through '
-                      'oracle/kirchhoff_np.py (numpy, 1 thread), %.1f s; the '
+    res = dict(value=npix * ns / dt, unit='pairs/s', cores=1, kind='port', sampled=True,
+               sample='a SAMPLE of the workload: %d of its pixels x all %d samples of cfg4 '
+                      'through oracle/kirchhoff_np.py (numpy, 1 thread), %.1f s; the '
                       'integral is linear in pixels' % (npix, ns, dt))
+    res.update(host_cpu())
     try:        # all host cores: the C/OpenMP restatement
         from oracle import kirchhoff_c as kc
         from oracle.consts import CHBAR

@@ -17,4 +17,13 @@ echo "dbs: $T $F $W"
 python tools/rocpd_summary.py $RND "$T" "$F" "$W" 1e7
 mkdir -p $O/summaries && cp profiles/r${RND}_kernel_stats.csv profiles/hbm_traffic.json $O/summaries/
 tail -c 600 $O/bench_under_rocprof.json | head -c 600; echo
+# SQ counters of the reflect kernels and the stand-alone probes the DESIGN quotes
+bash tools/pmc_reflect.sh > profiles/r${RND}_reflect_pmc.txt 2>&1
+for P in probe_stream probe_occupancy probe_atomics probe_fp64_seeds; do
+  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/probes/$P.hip -o /tmp/$P 2>/dev/null && \
+    timeout 300 /tmp/$P > profiles/r${RND}_$P.txt 2>&1
+done
+hipcc --offload-arch=gfx950 -O3 -DNOUT=40 -DBLOCK=256 tools/probes/probe_occupancy.hip -o /tmp/po40 2>/dev/null && \
+  timeout 300 /tmp/po40 > profiles/r${RND}_probe_occupancy_dcm_shape.txt 2>&1
+cp profiles/r${RND}_*.txt $O/summaries/ 2>/dev/null
 find $O -name '*.db' -size +40M -delete
