@@ -32,4 +32,5 @@ scene.run()
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(22)
+st.sort_stats('tottime').print_stats(14)
+st.sort_stats('cumtime').print_stats(45)

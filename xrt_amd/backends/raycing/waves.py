@@ -333,17 +333,27 @@ def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
     wave.beamReflSumJ += flux
     wave.beamReflSumJnl += flux_nl
     points = [wave.dev(name, dev) for name in ('xDiffr', 'yDiffr', 'zDiffr')]
+    # everything that has to be uploaded goes up BEFORE the integral is launched: a copy from
+    # the host queued behind it would hold the host until the kernel is through, and with it
+    # the next element's prepare_wave, which could run meanwhile. Accumulators that
+    # prepare_wave has just zeroed are made on the device.
+    for name in _ACCUMULATORS:
+        if name not in wave._d and not np.any(wave._h[name]):
+            wave._h.pop(name)
+            wave._d[name] = torch.zeros(wave.nrays, dtype=torch.complex128, device=dev)
+    acc = [wave.dev(name, dev) for name in _ACCUMULATORS]
+    wave_rec = wave.to_struct(dev)
+    energy = oeLocal.dev('E', dev)
     fresh = _kirchhoff_on_gpu(points, samples, targetOpenCL)
     # Monte-Carlo weight of the integral: receiving cell x illuminated area x incoming flux
     # over (samples x obliquity-weighted flux x repeats), waves.py:735-749
     denom = wave.beamReflRays * wave.beamReflSumJnl * wave.diffract_repeats
     scale = wave.dS * oeLocal.area * wave.beamReflSumJ / denom if denom > 0 else 0
-    acc = [wave.dev(name, dev) for name in _ACCUMULATORS]
     pointers = ctypes.c_void_p * 5
     _lib.check(lib.xrt_hip_wave_fields_f64_dev(
         wave.nrays, pointers(*[t.data_ptr() for t in fresh]),
-        pointers(*[t.data_ptr() for t in acc]), _ptr(oeLocal.dev('E', dev)), float(scale),
-        1 if hasattr(oe, 'rotationSequence') else 0, ctypes.byref(wave.to_struct(dev)),
+        pointers(*[t.data_ptr() for t in acc]), _ptr(energy), float(scale),
+        1 if hasattr(oe, 'rotationSequence') else 0, ctypes.byref(wave_rec),
         stream), 'xrt_hip_wave_fields_f64_dev')
     _forget_host(wave, _WAVE_FIELDS + _ACCUMULATORS)
     if hasattr(oeLocal, 'accepted'):         # source bookkeeping for absolute flux
