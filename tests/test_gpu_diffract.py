@@ -244,3 +244,22 @@ def test_propagate_wave_from_a_source_matches_reference(golden_dir):
     check(glo, g, 'mg_', [('x', 'y', 'z'), ('a', 'b', 'c'), ('Es', 'Ep'),
                           ('Jss', 'Jpp', 'Jsp')])
     assert lo.parentId == m1.uuid
+
+
+def test_hull_area_on_device_is_the_host_value():
+    """The footprint area from points on the GPU (pre-filter there, chain on the host) is the
+    area of the host routine, bit for bit -- the hull is the same set of vertices."""
+    import torch
+    rng = np.random.default_rng(5)
+    for n, shape in ((200000, 'disc'), (50000, 'box'), (10000, 'line-ish')):
+        if shape == 'disc':
+            r, t = np.sqrt(rng.random(n)) * 3., rng.random(n) * 2 * np.pi
+            x, y = r * np.cos(t) + 0.3, 40. * r * np.sin(t)
+        elif shape == 'box':
+            x, y = rng.uniform(-1, 1, n), rng.uniform(-70, 70, n)
+        else:
+            x = rng.uniform(-1, 1, n)
+            y = 2. * x + rng.normal(0, 1e-3, n)
+        want = rw.convex_hull_area(x, y)
+        got = rw.convex_hull_area_on_device(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda())
+        assert got == want, (shape, got, want)

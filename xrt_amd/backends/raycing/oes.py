@@ -178,6 +178,24 @@ class OE(object):
         res = out.cpu().numpy()[:nout * count].reshape(nout, count)
         return [r.reshape(shape) for r in res]
 
+    def _eval_surface_dev(self, what, u, v):
+        """The same for points that are on the GPU already (1-D float64 tensors) -> a
+        [nout, n] tensor there."""
+        count = u.numel()
+        nout = (1, 6, 1, 3, 3, 1)[what]
+        out = torch.empty((nout, max(count, 1)), dtype=torch.float64, device=u.device)
+        if what == _SURF_STATE:
+            p = self._make_pass(*self._own_angles()[:4])
+        else:
+            p = _structs.Pass()
+            p.invert_normal = 1
+            self._surface_params(p)
+        _lib.check(_lib.load().xrt_hip_surface_eval_f64_dev(
+            ctypes.byref(p), what, count, ctypes.c_void_p(u.data_ptr()),
+            ctypes.c_void_p(v.data_ptr()), None, ctypes.c_void_p(out.data_ptr()), _stream()),
+            'xrt_hip_surface_eval_f64_dev')
+        return out[:, :count]
+
     def rays_good(self, x, y, z=None, is2ndXtal=False):
         """State of a ray that hits the surface at local (x, y): 1 good, 2 out, 3 over,
         ``lostNum`` absorbed (reference oes/base.py:1094-1163) -- evaluated on the GPU."""
@@ -525,18 +543,32 @@ class OE(object):
         if rw is None:
             from . import waves as rw
         x, y, area = self._wave_samples(nrays, self.shape if shape == 'auto' else shape, area)
-        aimed = self._to_global_points(x, y, self._surface_height(x, y))
+        # The sample points are drawn on the host (numpy's generator, in the reference's
+        # order); everything after that stays on the GPU: surface height, frame changes,
+        # aiming, the ray pass, the selection of the survivors, their coordinates in
+        # prevOE's frame -- the same IEEE operations in the same order as the reference's
+        # numpy expressions (products and sums as separate elementwise operations).
+        dev = _device()
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+        xd, yd = up(x), up(y)
+        if type(self).local_z is OE.local_z and not self.isParametric:
+            zd = up(self.local_z(x, y))
+        else:
+            zd = self._eval_surface_dev(_SURF_Z, xd, yd)[0].contiguous()
+        aimed = rs.Beam.on_device(len(x), dev, withAmplitudes=True, state=1)
+        aimed.x, aimed.y, aimed.z = xd, yd, zd
+        self.local_to_global(aimed)
         aimed.parentId = prevOE.uuid
         origin = prevOE._anchor() if hasattr(prevOE, 'rotationSequence') else prevOE.center
         # rays from `origin` towards the sample points
-        aimed.a[:] = aimed.x - origin[0]
-        aimed.b[:] = aimed.y - origin[1]
-        aimed.c[:] = aimed.z - origin[2]
-        length = (aimed.a**2 + aimed.b**2 + aimed.c**2)**0.5
-        aimed.a /= length
-        aimed.b /= length
-        aimed.c /= length
-        aimed.x[:], aimed.y[:], aimed.z[:] = origin
+        da = aimed.dev('x', dev) - float(origin[0])
+        db = aimed.dev('y', dev) - float(origin[1])
+        dc = aimed.dev('z', dev) - float(origin[2])
+        length = torch.sqrt(da * da + db * db + dc * dc)
+        aimed.a, aimed.b, aimed.c = da / length, db / length, dc / length
+        aimed.x = torch.full_like(da, float(origin[0]))
+        aimed.y = torch.full_like(da, float(origin[1]))
+        aimed.z = torch.full_like(da, float(origin[2]))
         # projection of the area on the line of sight from prevOE: the local normal at the
         # origin of the surface against the direction to that origin
         pole = rs.Beam(nrays=1)
@@ -547,14 +579,16 @@ class OE(object):
         tilt = abs(float(((sight[0]*pole.a[0] + sight[1]*pole.b[0] + sight[2]*pole.c[0])
                           / reach)[0]))
         waveGlobal, waveLocal = self.reflect(aimed)        # HIP kernels
-        alive = (waveLocal.state == 1) | (waveLocal.state == 2)
+        state = waveLocal.dev('state', dev)
+        alive = (state == 1) | (state == 2)
         waveGlobal.filter_by_index(alive)
         waveLocal.filter_by_index(alive)
-        area *= alive.sum() / float(len(alive))
+        area *= int(alive.sum()) / float(len(x))           # (the one number that crosses back)
         waveLocal.area, waveLocal.areaNormal = area, area * tilt
-        waveLocal.dS = area / float(len(alive))
+        waveLocal.dS = area / float(len(x))
         waveLocal.toOE, waveLocal.parentId = self, self.uuid
-        rw.prepare_wave(prevOE, waveLocal, waveGlobal.x, waveGlobal.y, waveGlobal.z)
+        rw.prepare_wave(prevOE, waveLocal, waveGlobal.dev('x', dev), waveGlobal.dev('y', dev),
+                        waveGlobal.dev('z', dev))
         return waveLocal
 
     def propagate_wave(self, wave=None, beam=None, nrays='auto'):

@@ -160,7 +160,15 @@ class Beam(object):
             object.__delattr__(self, name)
 
     def filter_by_index(self, indarr):
-        """Keeps the rays selected by *indarr* (sources/beams.py:296-318)."""
+        """Keeps the rays selected by *indarr* (sources/beams.py:296-318). With a mask that
+        lives on the GPU the arrays are filtered there and stay there."""
+        if isinstance(indarr, torch.Tensor) and indarr.is_cuda:
+            for name in self.array_fields():
+                kept = self.dev(name, indarr.device)[indarr]
+                self._h.pop(name, None)
+                self._d[name] = kept
+            self.__dict__.pop('_struct', None)
+            return
         for name in self.array_fields():
             setattr(self, name, getattr(self, name)[indarr])
 
@@ -292,6 +300,26 @@ class Beam(object):
         if name in self._d:
             return self._d[name].cpu().numpy()
         return self._h[name]
+
+    @classmethod
+    def on_device(cls, nrays, device, withAmplitudes=True, state=1):
+        """What ``Beam(nrays=..., forceState=state, withAmplitudes=...)`` makes (zero positions,
+        direction along y, unit Jss, `defaultEnergy`), made on the GPU: nothing to upload."""
+        b = cls.__new__(cls)
+        object.__setattr__(b, '_h', {})
+        object.__setattr__(b, '_d', {})
+        f64 = lambda v: torch.full((int(nrays),), float(v), dtype=torch.float64,  # noqa: E731
+                                   device=device)
+        c128 = lambda: torch.zeros(int(nrays), dtype=torch.complex128, device=device)  # noqa: E731
+        for name, value in (('x', 0.), ('y', 0.), ('z', 0.), ('a', 0.), ('b', 1.), ('c', 0.),
+                            ('path', 0.), ('E', defaultEnergy), ('Jss', 1.), ('Jpp', 0.)):
+            b._d[name] = f64(value)
+        b._d['Jsp'] = c128()
+        b._d['state'] = torch.full((int(nrays),), int(state), dtype=torch.int32, device=device)
+        if withAmplitudes:
+            b._d['Es'], b._d['Ep'] = c128(), c128()
+        object.__setattr__(b, 'parentId', None)
+        return b
 
     @classmethod
     def empty_like_on_device(cls, other, device):

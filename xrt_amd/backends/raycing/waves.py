@@ -37,11 +37,16 @@ def _into_frame_of(element, xglo, yglo, zglo):
     """Global points -> the local frame of *element*: shift to its centre, undo
     the beamline azimuth and, for an optical element, its own rotations
     (waves.py:529-560)."""
-    px = np.array(xglo, dtype=float) - element.center[0]
-    py = np.array(yglo, dtype=float) - element.center[1]
-    pz = np.array(zglo, dtype=float) - element.center[2]
+    if isinstance(xglo, torch.Tensor):      # points on the GPU: the same arithmetic there
+        px = xglo - float(element.center[0])
+        py = yglo - float(element.center[1])
+        pz = zglo - float(element.center[2])
+    else:
+        px = np.array(xglo, dtype=float) - element.center[0]
+        py = np.array(yglo, dtype=float) - element.center[1]
+        pz = np.array(zglo, dtype=float) - element.center[2]
     bl = element.bl
-    px[:], py[:] = raycing.rotate_z(px, py, bl.cosAzimuth, bl.sinAzimuth)
+    px, py = raycing.rotate_z(px, py, bl.cosAzimuth, bl.sinAzimuth)
     if hasattr(element, 'rotationSequence'):
         if hasattr(element, 'local_n2') and hasattr(element, 'cryst2pitch'):
             raise NotImplementedError('wave propagation from a DCM/plate 2nd '
@@ -63,24 +68,40 @@ def prepare_wave(fromOE, wave, xglo, yglo, zglo):
     to the diffracting element *fromOE*: their coordinates in its local frame
     (``xDiffr`` ...), unit directions from its centre, and empty field
     accumulators (reference: waves.py:505-584)."""
-    nsamples = len(wave.x)
-    if hasattr(wave, 'Es'):
-        wave.Es[:] = 0
-        wave.Ep[:] = 0
+    if isinstance(xglo, torch.Tensor):
+        # a wave that lives on the GPU (OE.prepare_wave): fields and accumulators are made
+        # there, the frame change runs there
+        dev = xglo.device
+        nsamples = xglo.numel()
+        zeros_c = lambda: torch.zeros(nsamples, dtype=torch.complex128, device=dev)  # noqa: E731
+        zeros_f = lambda: torch.zeros(nsamples, dtype=torch.float64, device=dev)     # noqa: E731
+        wave.Es, wave.Ep, wave.Jsp = zeros_c(), zeros_c(), zeros_c()
+        for name in _ACCUMULATORS:
+            setattr(wave, name, zeros_c())
+        wave.Jss, wave.Jpp, wave.path = zeros_f(), zeros_f(), zeros_f()
+        px, py, pz = _into_frame_of(fromOE, xglo, yglo, zglo)
+        dist = torch.sqrt(px * px + py * py + pz * pz)
+        wave.xDiffr, wave.yDiffr, wave.zDiffr, wave.rDiffr = px, py, pz, dist
+        wave.a, wave.b, wave.c = px / dist, py / dist, pz / dist
     else:
-        wave.Es = np.zeros(nsamples, dtype=complex)
-        wave.Ep = np.zeros(nsamples, dtype=complex)
-    for name in _ACCUMULATORS:
-        setattr(wave, name, np.zeros(nsamples, dtype=complex))
-    for component in (wave.Jss, wave.Jpp, wave.Jsp):
-        component[:] = 0
-    px, py, pz = _into_frame_of(fromOE, xglo, yglo, zglo)
-    dist = (px**2 + py**2 + pz**2)**0.5
-    wave.xDiffr, wave.yDiffr, wave.zDiffr, wave.rDiffr = px, py, pz, dist
-    wave.a[:] = px / dist
-    wave.b[:] = py / dist
-    wave.c[:] = pz / dist
-    wave.path[:] = 0.
+        nsamples = len(wave.x)
+        if hasattr(wave, 'Es'):
+            wave.Es[:] = 0
+            wave.Ep[:] = 0
+        else:
+            wave.Es = np.zeros(nsamples, dtype=complex)
+            wave.Ep = np.zeros(nsamples, dtype=complex)
+        for name in _ACCUMULATORS:
+            setattr(wave, name, np.zeros(nsamples, dtype=complex))
+        for component in (wave.Jss, wave.Jpp, wave.Jsp):
+            component[:] = 0
+        px, py, pz = _into_frame_of(fromOE, xglo, yglo, zglo)
+        dist = (px**2 + py**2 + pz**2)**0.5
+        wave.xDiffr, wave.yDiffr, wave.zDiffr, wave.rDiffr = px, py, pz, dist
+        wave.a[:] = px / dist
+        wave.b[:] = py / dist
+        wave.c[:] = pz / dist
+        wave.path[:] = 0.
     wave.fromOE = fromOE
     wave.beamReflRays = np.int64(0)       # running sums over repeated diffract()
     wave.beamReflSumJ = 0.
@@ -198,6 +219,34 @@ def convex_hull_area(px, py):
     return 0.5 * abs(np.sum(x1*y2 - x2*y1))
 
 
+def convex_hull_area_on_device(px, py):
+    """The same area for points that live on the GPU: the polygon of the extremes in 64
+    directions is found there and everything strictly inside it dropped there; the few points
+    that are left (every hull vertex is among them) go through the host's monotone chain."""
+    n = px.numel()
+    if n < 4096:
+        return convex_hull_area(px.cpu().numpy(), py.cpu().numpy())
+    ang = torch.arange(64, dtype=torch.float64, device=px.device) * (2 * np.pi / 64)
+    proj = torch.cos(ang)[:, None] * px[None, :] + torch.sin(ang)[:, None] * py[None, :]
+    pick = proj.argmax(dim=1)
+    ext = torch.stack((px[pick], py[pick]), dim=1).cpu().numpy()
+    corners = []
+    for q in map(tuple, ext):           # consecutive duplicates dropped, like _extremes
+        if not corners or q != corners[-1]:
+            corners.append(q)
+    if len(corners) > 1 and corners[0] == corners[-1]:
+        corners.pop()
+    if len(corners) < 3:
+        return convex_hull_area(px.cpu().numpy(), py.cpu().numpy())
+    c = torch.tensor(corners, dtype=torch.float64, device=px.device)
+    x1, y1 = c[:, 0], c[:, 1]
+    x2, y2 = torch.roll(x1, -1), torch.roll(y1, -1)
+    cross = (x2 - x1)[None, :] * (py[:, None] - y1[None, :]) - \
+        (y2 - y1)[None, :] * (px[:, None] - x1[None, :])
+    keep = ~(cross > 0).all(dim=1)
+    return convex_hull_area(px[keep].cpu().numpy(), py[keep].cpu().numpy())
+
+
 def _kirchhoff_on_gpu(points, samples, targetOpenCL='auto'):
     """The five integrals (Es, Ep, aE, bE, cE) of the reference's numpy kernel
     (waves.py:834-851) for receiving *points* (3 device tensors) and *samples* (the ten
@@ -225,15 +274,19 @@ def _illuminated_area(oe, field):
     area = getattr(field, 'area', None)
     if area is not None and area > 0:
         return area
-    lit = field.peek('state') == 1
     if hasattr(oe, 'rotationSequence'):
-        along = field.peek('y')              # an optical element: (x, y)
+        second = 'y'                         # an optical element: (x, y)
     elif hasattr(oe, 'propagate') or hasattr(oe, 'prepare_wave') or \
             hasattr(oe, 'shine'):
-        along = field.peek('z')              # aperture / screen / source: (x, z)
+        second = 'z'                         # aperture / screen / source: (x, z)
     else:
         raise ValueError('Unknown diffracting element!')
-    area = convex_hull_area(field.peek('x')[lit], along[lit])
+    if all(name in field._d for name in ('state', 'x', second)):
+        lit = field._d['state'] == 1
+        area = convex_hull_area_on_device(field._d['x'][lit], field._d[second][lit])
+    else:
+        lit = field.peek('state') == 1
+        area = convex_hull_area(field.peek('x')[lit], field.peek(second)[lit])
     if hasattr(field, 'areaFraction'):
         area *= field.areaFraction
     return area
@@ -338,7 +391,7 @@ def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
     # the next element's prepare_wave, which could run meanwhile. Accumulators that
     # prepare_wave has just zeroed are made on the device.
     for name in _ACCUMULATORS:
-        if name not in wave._d and not np.any(wave._h[name]):
+        if name not in wave._d and name in wave._h and not np.any(wave._h[name]):
             wave._h.pop(name)
             wave._d[name] = torch.zeros(wave.nrays, dtype=torch.complex128, device=dev)
     acc = [wave.dev(name, dev) for name in _ACCUMULATORS]
