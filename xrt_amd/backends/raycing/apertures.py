@@ -41,7 +41,7 @@ class RectangularAperture(object):
         if unknown:
             raise ValueError('unknown blade(s) {0}'.format(sorted(unknown)))
         self.blades = {b: blades[b] for b in _BLADE_ORDER if b in blades}
-        self.set_optical_limits()
+        RectangularAperture.set_optical_limits(self)    # (a subclass's own comes later)
         axes = [None if isinstance(v, str) else v for v in (x, z)]
         self.xyz = raycing.xyz_from_xz(self, *axes)
         self.x, self.y, self.z = self.xyz
@@ -86,7 +86,7 @@ class RectangularAperture(object):
             raise ValueError('unknown blade(s) {0}'.format(sorted(unknown)))
         given = dict(zip(names, edges))
         self.blades = {b: given[b] for b in _BLADE_ORDER if b in given}
-        self.set_optical_limits()
+        RectangularAperture.set_optical_limits(self)
 
     def local_to_global(self, glo, returnBeam=False, **kwargs):
         """Positions and directions of a host beam from the aperture's frame to the
