@@ -328,20 +328,29 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
     if world > 1:
         barrier(dist)
         if rank == 0:
-            fx, fy, fz = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (px, py, pz))
-            smp = [s[f] for f in ('sx', 'sy', 'sz', 'nx', 'ny', 'nz', 'nl', 'k', 'Es', 'Ep')]
-            devs = list(range(world))
-            multigpu.kirchhoff_devices((fx, fy, fz), smp, devs)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
+            try:        # (a figure beside the main one: it must never take the line down)
+                fx, fy, fz = (torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+                              for a in (px, py, pz))
+                smp = [s[f] for f in ('sx', 'sy', 'sz', 'nx', 'ny', 'nz', 'nl', 'k', 'Es', 'Ep')]
+                devs = list(range(world))
+
+                def sync_all():
+                    for d in devs:
+                        torch.cuda.synchronize(d)
                 multigpu.kirchhoff_devices((fx, fy, fz), smp, devs)
-            torch.cuda.synchronize()
-            dti = time.perf_counter() - t0
-            in_process = dict(value=pairs * steps / dti, unit='pairs/s',
-                              ms_per_step=dti / steps * 1e3, devices=devs,
-                              note='one process, one stream per device, samples copied device '
-                                   'to device, tiles copied into the arrays on device 0')
+                sync_all()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    multigpu.kirchhoff_devices((fx, fy, fz), smp, devs)
+                sync_all()
+                dti = time.perf_counter() - t0
+                in_process = dict(value=pairs * steps / dti, unit='pairs/s',
+                                  ms_per_step=dti / steps * 1e3, devices=devs,
+                                  note='one process, one stream per device, samples copied '
+                                       'device to device, tiles copied into the arrays on '
+                                       'device 0')
+            except Exception as e:  # noqa: BLE001
+                in_process = dict(error=repr(e))
         barrier(dist)
     res = dict(
         metric='Kirchhoff sample*pixel pairs/s', value=pairs * steps / dt,

@@ -2160,15 +2160,16 @@ struct Finished {
 // keeping them live across that code was what spilled to scratch.
 __device__ __forceinline__ void load_fields(const xrt_hip_beam& in, int64_t i, bool has_amp,
                                             RayIn& q) {
-  q.Jss = in.Jss[i];
-  q.Jpp = in.Jpp[i];
-  const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  q.Jss = __builtin_nontemporal_load(&in.Jss[i]);
+  q.Jpp = __builtin_nontemporal_load(&in.Jpp[i]);
+  const v2d js = __builtin_nontemporal_load(&reinterpret_cast<const v2d*>(in.Jsp_ri)[i]);
   q.Jsr = js.x;
   q.Jsi = js.y;
   q.Esr = q.Esi = q.Epr = q.Epi = 0.;
   if (has_amp) {
-    const double2 es = reinterpret_cast<const double2*>(in.Es_ri)[i];
-    const double2 ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
+    const v2d es = __builtin_nontemporal_load(&reinterpret_cast<const v2d*>(in.Es_ri)[i]);
+    const v2d ep = __builtin_nontemporal_load(&reinterpret_cast<const v2d*>(in.Ep_ri)[i]);
     q.Esr = es.x;
     q.Esi = es.y;
     q.Epr = ep.x;
@@ -2199,17 +2200,18 @@ __device__ __forceinline__ RayRequest request_ray(const xrt_hip_beam& in, int64_
   RayRequest R;
   const bool live = i < in.n;
   const int64_t ii = live ? i : 0;
-  const int st = in.state[ii];
-  R.raw.x = in.x[ii];
-  R.raw.y = in.y[ii];
-  R.raw.z = in.z[ii];
-  R.raw.a = in.a[ii];
-  R.raw.b = in.b[ii];
-  R.raw.c = in.c[ii];
+  // (non-temporal: read once; -1 % at 1e7 rays, same-box A/B)
+  const int st = __builtin_nontemporal_load(&in.state[ii]);
+  R.raw.x = __builtin_nontemporal_load(&in.x[ii]);
+  R.raw.y = __builtin_nontemporal_load(&in.y[ii]);
+  R.raw.z = __builtin_nontemporal_load(&in.z[ii]);
+  R.raw.a = __builtin_nontemporal_load(&in.a[ii]);
+  R.raw.b = __builtin_nontemporal_load(&in.b[ii]);
+  R.raw.c = __builtin_nontemporal_load(&in.c[ii]);
   R.q = RayIn();
-  R.q.E = in.E[ii];
+  R.q.E = __builtin_nontemporal_load(&in.E[ii]);
   if (FIELDS) {
-    R.q.path = in.path[ii];
+    R.q.path = __builtin_nontemporal_load(&in.path[ii]);
     load_fields(in, ii, has_amp, R.q);
   }
   R.st0 = live ? st : 0;
@@ -2787,21 +2789,26 @@ __device__ __forceinline__ void store_ray(const xrt_hip_beam& o, int64_t i, doub
                                           double E, double Jss, double Jpp, double Jsr,
                                           double Jsi, int st, double Esr, double Esi,
                                           double Epr, double Epi, bool has_amp) {
-  o.x[i] = x;
-  o.y[i] = y;
-  o.z[i] = z;
-  o.a[i] = a;
-  o.b[i] = b;
-  o.c[i] = c;
-  o.path[i] = path;
-  o.E[i] = E;
-  o.Jss[i] = Jss;
-  o.Jpp[i] = Jpp;
-  reinterpret_cast<double2*>(o.Jsp_ri)[i] = make_double2(Jsr, Jsi);
-  o.state[i] = st;
+  // Non-temporal stores: the outgoing records are streamed out once, never read again by this
+  // kernel, and three times the size of any cache. Same-box A/B at 1e7 rays: cfg2 0.585 ->
+  // 0.571 ms, DCM 0.869 -> 0.853 ms. (No effect in round 2, when the kernels were a prologue
+  // away from their streaming floor; the floor itself gains 1-4 %, profiles/r03_probe_stream.txt.)
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  __builtin_nontemporal_store(x, &o.x[i]);
+  __builtin_nontemporal_store(y, &o.y[i]);
+  __builtin_nontemporal_store(z, &o.z[i]);
+  __builtin_nontemporal_store(a, &o.a[i]);
+  __builtin_nontemporal_store(b, &o.b[i]);
+  __builtin_nontemporal_store(c, &o.c[i]);
+  __builtin_nontemporal_store(path, &o.path[i]);
+  __builtin_nontemporal_store(E, &o.E[i]);
+  __builtin_nontemporal_store(Jss, &o.Jss[i]);
+  __builtin_nontemporal_store(Jpp, &o.Jpp[i]);
+  __builtin_nontemporal_store(v2d{Jsr, Jsi}, &reinterpret_cast<v2d*>(o.Jsp_ri)[i]);
+  __builtin_nontemporal_store(st, &o.state[i]);
   if (has_amp) {
-    reinterpret_cast<double2*>(o.Es_ri)[i] = make_double2(Esr, Esi);
-    reinterpret_cast<double2*>(o.Ep_ri)[i] = make_double2(Epr, Epi);
+    __builtin_nontemporal_store(v2d{Esr, Esi}, &reinterpret_cast<v2d*>(o.Es_ri)[i]);
+    __builtin_nontemporal_store(v2d{Epr, Epi}, &reinterpret_cast<v2d*>(o.Ep_ri)[i]);
   }
 }
 

@@ -13,6 +13,12 @@
 
 namespace xrt {
 
+// streamed out once, never read again by the kernel: non-temporal (reflect_impl.h: store_ray)
+template <class T>
+__device__ __forceinline__ void put(T* p, int64_t i, T v) {
+  __builtin_nontemporal_store(v, &p[i]);
+}
+
 __global__ __launch_bounds__(256) void screen_expose_kernel(xrt_hip_screen S, xrt_hip_beam in,
                                                            xrt_hip_beam out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,16 +45,16 @@ __global__ __launch_bounds__(256) void screen_expose_kernel(xrt_hip_screen S, xr
     const double lx = (rx * S.ex[0] + ry * S.ex[1]) + rz * S.ex[2];
     const double ly = (rx * S.ey[0] + ry * S.ey[1]) + rz * S.ey[2];
     const double lz = (rx * S.ez[0] + ry * S.ez[1]) + rz * S.ez[2];
-    out.x[i] = lx;
-    out.y[i] = ly;
-    out.z[i] = lz;
-    out.a[i] = ga;
-    out.b[i] = gb;
-    out.c[i] = gc;
-    out.path[i] = in.path[i] + path;
-    out.E[i] = E;
-    out.Jss[i] = in.Jss[i];
-    out.Jpp[i] = in.Jpp[i];
+    put(out.x, i, lx);
+    put(out.y, i, ly);
+    put(out.z, i, lz);
+    put(out.a, i, ga);
+    put(out.b, i, gb);
+    put(out.c, i, gc);
+    put(out.path, i, in.path[i] + path);
+    put(out.E, i, E);
+    put(out.Jss, i, in.Jss[i]);
+    put(out.Jpp, i, in.Jpp[i]);
     reinterpret_cast<double2*>(out.Jsp_ri)[i] = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
     out.state[i] = st;
     if (S.out_theta) S.out_theta[i] = asin(lz / S.radius) - S.theta_offset;
@@ -87,17 +93,17 @@ __global__ __launch_bounds__(256) void screen_expose_kernel(xrt_hip_screen S, xr
   y = 0.;
   if (S.compress_x != 0.) x *= S.compress_x;
   if (S.compress_z != 0.) z *= S.compress_z;
-  out.x[i] = x;
-  out.y[i] = y;
-  out.z[i] = z;
-  out.a[i] = a;
-  out.b[i] = b;
-  out.c[i] = c;
+  put(out.x, i, x);
+  put(out.y, i, y);
+  put(out.z, i, z);
+  put(out.a, i, a);
+  put(out.b, i, b);
+  put(out.c, i, c);
   const double E = in.E[i];
-  out.path[i] = in.path[i] + path;
-  out.E[i] = E;
-  out.Jss[i] = in.Jss[i];
-  out.Jpp[i] = in.Jpp[i];
+  put(out.path, i, in.path[i] + path);
+  put(out.E, i, E);
+  put(out.Jss, i, in.Jss[i]);
+  put(out.Jpp, i, in.Jpp[i]);
   reinterpret_cast<double2*>(out.Jsp_ri)[i] = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
   out.state[i] = st;
   if (in.Es_ri) {
@@ -251,16 +257,16 @@ __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_apertur
       z += A.center[2];
       if (A.glo_adds_path) path = path + path_in;   // DoubleSlit, apertures.py:1013
     }
-    glo.x[i] = x;
-    glo.y[i] = y;
-    glo.z[i] = z;
-    glo.a[i] = a;
-    glo.b[i] = b;
-    glo.c[i] = c;
-    glo.path[i] = path;
-    glo.E[i] = E;
-    glo.Jss[i] = Jss;
-    glo.Jpp[i] = Jpp;
+    put(glo.x, i, x);
+    put(glo.y, i, y);
+    put(glo.z, i, z);
+    put(glo.a, i, a);
+    put(glo.b, i, b);
+    put(glo.c, i, c);
+    put(glo.path, i, path);
+    put(glo.E, i, E);
+    put(glo.Jss, i, Jss);
+    put(glo.Jpp, i, Jpp);
     reinterpret_cast<double2*>(glo.Jsp_ri)[i] = js;
     glo.state[i] = st;
     if (has_amp) {
