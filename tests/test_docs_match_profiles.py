@@ -1,0 +1,52 @@
+"""CPU: the kernel times DESIGN.md quotes for the current round are the ones in the committed
+rocprofv3 summary (profiles/r03_kernel_stats.csv) -- the documents drifted from the profiles
+once."""
+import csv
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def averages():
+    """{(kernel variant, grid): (calls, average ns)}"""
+    out = {}
+    with open(os.path.join(ROOT, 'profiles', 'r03_kernel_stats.csv')) as f:
+        rows = list(csv.reader(f))
+    for r in rows[1:]:
+        out[(r[0], int(r[1]))] = (int(r[2]), float(r[4]))
+    return out
+
+
+def quoted(text, pattern):
+    m = re.search(pattern, text)
+    assert m, pattern
+    return float(m.group(1))
+
+
+def test_design_quotes_the_committed_profile():
+    avg = averages()
+    text = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    cfg2 = [v for (k, g), v in avg.items()
+            if k.startswith('reflect_fused<xrt::Spec<0, 1, 1, true>, 0>') and g >= 10_000_000]
+    dcm = [v for (k, g), v in avg.items()
+           if k.startswith('reflect_fused_dcm<xrt::ThickXtal<0>') and g >= 10_000_000]
+    k4 = [v for (k, g), v in avg.items() if k == 'kirchhoff_stream<4>' and v[0] <= 12 and
+          v[1] > 2e8]
+    kg = [v for (k, g), v in avg.items() if k == 'kirchhoff_stream<4>' and g == 4515840]
+    und = [v for (k, g), v in avg.items() if k.startswith('und_imap<0>') and g >= 1 << 20]
+    assert len(cfg2) == len(dcm) == len(k4) == len(kg) == len(und) == 1
+    checks = (
+        (cfg2[0], r'rocprofv3 average over (\d+) launches \*\*([\d.]+) µs\*\*', 1e-3),
+        (dcm[0], r'kernel \*\*([\d.]+) µs\*\* \(rocprofv3, (\d+) launches\)', 1e-3),
+    )
+    m = re.search(checks[0][1], text)
+    assert m and int(m.group(1)) == cfg2[0][0] and abs(float(m.group(2)) - cfg2[0][1] * 1e-3) < 0.06
+    m = re.search(checks[1][1], text)
+    assert m and int(m.group(2)) == dcm[0][0] and abs(float(m.group(1)) - dcm[0][1] * 1e-3) < 0.06
+    ms = quoted(text, r'rocprofv3 average ([\d.]+) ms over 6 launches, HIP events in the same run')
+    assert abs(ms - k4[0][1] * 1e-6) < 0.06
+    ms = quoted(text, r'grid 4515840, ([\d.]+) ms over (?:\d+) launches')
+    assert abs(ms - kg[0][1] * 1e-6) < 0.006
+    us = quoted(text, r'`und_imap` 2\^20 rays × 48 nodes \*\*([\d.]+) µs')
+    assert abs(us - und[0][1] * 1e-3) < 0.06
