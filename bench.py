@@ -436,24 +436,31 @@ def bench_hist(nrays):
         for _ in range(reps):
             runner.accumulate_plot(plot, {'b': lb})
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / reps * 1e3
+        t1 = time.perf_counter()
+        total = plot.total2D.sum()                       # brings the accumulators home
+        t2 = time.perf_counter()
+        ms = (t1 - t0) / reps * 1e3
         key = 'bins%d' % bins
-        res[key] = dict(ms_per_plot=ms, value=nrays / ms * 1e3,
-                        note='accumulate_plot with its host glue (one memset, one copy of all '
-                             'bins back)')
-        if bins == 128:
+        res[key] = dict(ms_per_plot=ms, value=nrays / ms * 1e3, read_back_ms=(t2 - t1) * 1e3,
+                        flux_in_range=float(total),
+                        note='accumulate_plot per iteration (the plot\'s accumulators stay on the '
+                             'device: no copy, no sync per iteration); read_back_ms = once, when '
+                             'the plot is read')
+        if bins == 256:
             res['value'] = nrays / ms * 1e3
             res['ms_per_plot'] = ms
             res['roofline'] = dict(
-                bound='hbm', kernel='plot_hist_lds (four passes at 128 x 128: one 128-KB plane '
-                                    'of the LDS each)',
+                bound='hbm', kernel='plot_hist_rays + plot_hist_tiles + plot_hist_reduce '
+                                    '(256 x 256 bins + 3 x 1-D)',
                 achieved=44. * nrays / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
                 frac=44. * nrays / (ms * 1e-3) / HBM_PEAK, traffic=None,
-                note='44 B per ray algorithmic; every pass re-reads them (4 x 44 B of traffic): '
-                     'the four fp64 planes of a 128 x 128 plot are 512 KB, a CU has 160 KB of '
-                     'LDS, and global fp64 atomics run at 2.4e10 /s on this chip '
-                     '(tools/probes/probe_atomics.hip) = 1.7 ms for the 4e7 updates; 256 x 256 '
-                     'plots take that route')
+                note='44 B per ray algorithmic (x, y, colour datum, state, Jss, Jpp, read once); '
+                     'the four fp64 planes of the plot are 2 MB, a CU has 160 KB of LDS, and '
+                     'global fp64 atomics run at 2.4e10 /s on this chip (tools/probes/'
+                     'probe_atomics.hip = 1.7 ms for the 4e7 updates): the rays are sorted by '
+                     'tile of 64 x 64 bins on the way (20 B per ray written and read again) and '
+                     'accumulated in LDS, so the traffic is 84 B per ray + 64 MB of per-CU plane '
+                     'copies')
     return res
 
 

@@ -92,14 +92,16 @@ def test_rays_on_bin_edges_follow_numpy():
     assert plot.intensityInRange == ref.sum() and plot.intensity == n
 
 
-@pytest.mark.parametrize('bx,by,bc', [(40, 36, 50), (128, 128, 128), (100, 90, 2000),
-                                      (300, 200, 64)])
+@pytest.mark.parametrize('bx,by,bc', [(40, 36, 50), (64, 64, 64), (128, 128, 128),
+                                      (256, 256, 256), (100, 90, 2000), (300, 200, 64),
+                                      (700, 600, 32)])
 def test_colour_and_1d_histograms_match_numpy_and_matplotlib(bx, by, bc):
     """The complete per-plot reduce of multipro.py:316-361: hue from the colour
     axis (energy), hsv_to_rgb with value = flux, three 1-D histograms with
     flux / R / G / B weights, 2-D intensity and RGB histograms. Bin counts: all four
-    2-D planes in one LDS pass; one plane per pass (128 x 128 = 128 KB); 1-D cells
-    beyond the LDS budget; a 2-D plane beyond it (both through the global-atomic form)."""
+    2-D planes in the LDS of one block (up to 64 x 64); rays sorted by tile and accumulated
+    tile by tile (4, 16, 14 tiles); 1-D cells beyond the LDS budget and more tiles than the
+    sort takes (both through the global-atomic form)."""
     import matplotlib.colors as mc
     bl = build()
     kept = []
@@ -150,6 +152,47 @@ def test_colour_and_1d_histograms_match_numpy_and_matplotlib(bx, by, bc):
     # the 1-D histograms see rays that fall outside the other axis' range
     assert plot.total1D_x.sum() > plot.total2D.sum() * (1 + 1e-6)
     assert np.array_equal(plot.total1D_c, plot.caxis.total1D4[:, 0])
+
+
+def test_histograms_of_two_million_rays_match_numpy():
+    """The bench's histogram workload at a size numpy still handles: 2e6 rays off the cfg2
+    mirror (many chunks per block, ragged last chunk), 256 x 256 bins, accumulated twice on the
+    device before the plot is read."""
+    n = 2_000_003
+    oe = workloads.cfg2_toroid()
+    beam = workloads.synthetic_rays(n, 7)
+    gb, lb = oe.reflect(beam)
+    plot = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis('x', 'mm', bins=256),
+                        xrtp.XYCAxis('y', 'mm', bins=256),
+                        caxis=xrtp.XYCAxis('energy', 'eV', bins=256))
+    xrtr.accumulate_plot(plot, {'b': lb})
+    xrtr.accumulate_plot(plot, {'b': lb})
+    sel = np.array(lb.state) == 1
+    x, y, e = np.array(lb.x)[sel], np.array(lb.y)[sel], np.array(lb.E)[sel]
+    flux = (np.array(lb.Jss) + np.array(lb.Jpp))[sel]
+    xl, yl, cl = plot.xaxis.limits, plot.yaxis.limits, plot.caxis.limits
+    ref = 2 * np.histogram2d(y, x, bins=[256, 256], range=[yl, xl], weights=flux)[0]
+    assert np.abs(plot.total2D - ref).max() <= 1e-10 * ref.max()
+    for axis, v, lim in ((plot.xaxis, x, xl), (plot.yaxis, y, yl), (plot.caxis, e, cl)):
+        r1 = 2 * np.histogram(v, bins=256, range=lim, weights=flux)[0]
+        assert np.abs(axis.total1D4[:, 0] - r1).max() <= 1e-10 * r1.max()
+    assert plot.nRaysSelected == 2 * int(sel.sum()) and plot.nRaysAll == 2 * n
+    assert abs(plot.intensity - 2 * flux.sum()) <= 1e-10 * flux.sum()
+    # a second read changes nothing; a zoomed plot drops the rays outside it from the 2-D
+    # planes only
+    assert np.array_equal(plot.total2D, plot.total2D)
+    zoom = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis('x', 'mm', bins=256,
+                                                limits=[0.5 * xl[0], 0.5 * xl[1]]),
+                        xrtp.XYCAxis('y', 'mm', bins=256, limits=[0.25 * yl[0], 0.25 * yl[1]]),
+                        caxis=xrtp.XYCAxis('energy', 'eV', bins=256, limits=cl))
+    xrtr.accumulate_plot(zoom, {'b': lb})
+    ref = np.histogram2d(y, x, bins=[256, 256], range=[zoom.yaxis.limits, zoom.xaxis.limits],
+                         weights=flux)[0]
+    assert np.abs(zoom.total2D - ref).max() <= 1e-10 * ref.max()
+    r1 = np.histogram(x, bins=256, range=zoom.xaxis.limits, weights=flux)[0]
+    assert np.abs(zoom.total1D_x - r1).max() <= 1e-10 * r1.max()
+    assert zoom.total1D_x.sum() > zoom.total2D.sum() * 1.01
+    assert abs(zoom.intensityInRange - ref.sum()) <= 1e-10 * ref.sum()
 
 
 def test_plot_histograms_of_an_empty_selection():

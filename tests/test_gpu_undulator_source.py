@@ -140,3 +140,41 @@ def test_configuration4_chain_undulator_slit_screen(golden_dir, tag, ns, npx, se
         assert rel(getattr(wscr, f), g['w_' + f]) < 1e-9, 'screen ' + f
     for f in ('a', 'b', 'c'):
         assert np.abs(getattr(wscr, f) - g['w_' + f]).max() < 1e-9, 'screen ' + f
+
+
+def test_worker_threads_share_one_undulator(golden_dir):
+    """What run_ray_tracing(threads=N) does to a source: N threads on their own streams call
+    build_I_map of ONE Undulator at the same time, the first of them on a cold table cache
+    (filled under a lock, keyed by device). Every thread gets the serial map, bit for bit, and
+    the cache ends with one entry for this device."""
+    import threading
+
+    import torch
+    g = load(golden_dir, 'rays_planar')
+    src, _, _ = build(g)
+    src.reset()
+    rng = np.random.RandomState(2)
+    args = [(rng.uniform(src.E_min, src.E_max, 20000),
+             rng.uniform(src.Theta_min, src.Theta_max, 20000),
+             rng.uniform(src.Psi_min, src.Psi_max, 20000)) for _ in range(4)]
+    serial = [src.build_I_map(*a) for a in args]
+    src.reset()                                   # cold cache again
+    src._tables = {}
+    got = [None] * len(args)
+    errors = []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):
+                    got[i] = src.build_I_map(*args[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(args))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for s, t in zip(serial, got):
+        for a, b in zip(s, t):
+            assert np.array_equal(a, b)
+    assert list(src._tables) == [str(torch.device('cuda', torch.cuda.current_device()))]

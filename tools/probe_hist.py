@@ -17,8 +17,11 @@ for bins in (64, 128, 256, 512):
         runner.accumulate_plot(plot, {'b': b})          # sets the limits
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(10):
             runner.accumulate_plot(plot, {'b': b})
         torch.cuda.synchronize()
-        print('%3d bins %-10s %.2f ms per accumulate_plot (host glue included), selected %d' % (
-            bins, name, (time.perf_counter() - t0) / 5 * 1e3, plot.nRaysSelected))
+        t1 = time.perf_counter()
+        nsel = plot.nRaysSelected                       # brings the accumulator home
+        t2 = time.perf_counter()
+        print('%3d bins %-10s %.3f ms per accumulate_plot (device accumulators), %.2f ms to read '
+              'the plot back, selected %d' % (bins, name, (t1 - t0) / 10 * 1e3, (t2 - t1) * 1e3, nsel))

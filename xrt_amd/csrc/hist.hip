@@ -1,92 +1,51 @@
-// Weighted 2-D histogram of a device-resident beam (the reduce step after the hot
+// Weighted histograms of a device-resident beam (the reduce step after the hot
 // path in every run_ray_tracing iteration; xrt/multipro.py:111-177,
-// raycing/__init__.py:170-300). One lane = one ray: two coalesced 8-B loads for
-// the coordinates, the state and the J components for the weight, one fp64
-// atomic add into the bin. Bin search = numpy's: estimate by scaling, then fix
+// raycing/__init__.py:170-300). Bin search = numpy's: estimate by scaling, then fix
 // against the linspace edges so that rays on an edge land where np.histogram2d
 // puts them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/xrt_hip.h"
+#include "fp64_math.h"
 #include "hist.h"
 
 namespace xrt {
 
-__device__ __forceinline__ int find_bin(double v, double lo, double hi, int bins) {
-  if (!(v >= lo && v <= hi)) return -1;
-  const double step = (hi - lo) / (double)bins;   // np.linspace: arange*step + start
-  int b = (int)(((v - lo) / (hi - lo)) * (double)bins);
-  if (b >= bins) b = bins - 1;
-  if (b < 0) b = 0;
-  // edges[j] = j*step + lo, edges[bins] = hi exactly
-  auto edge = [&](int j) { return j == bins ? hi : (double)j * step + lo; };
-  while (b > 0 && v < edge(b)) --b;
-  while (b < bins - 1 && v >= edge(b + 1)) ++b;
-  return b;
+// One histogram axis: np.linspace(lo, hi, bins + 1) has edges[j] = j*step + lo with
+// step = (hi - lo)/bins (one division, one multiplication, one addition: formed here
+// with the same three roundings) and edges[bins] = hi exactly. `scale` only feeds the
+// first guess of the bin, which the edge tests then correct: any rounding of it will do.
+struct AxisBins {
+  double lo, hi, step, scale;
+  int bins;
+};
+static inline AxisBins axis_bins(double lo, double hi, int bins) {
+  AxisBins a;
+  a.lo = lo;
+  a.hi = hi;
+  a.step = (hi - lo) / (double)bins;
+  a.scale = (double)bins / (hi - lo);
+  a.bins = bins;
+  return a;
 }
-
-__global__ __launch_bounds__(256) void hist2d_kernel(
-    xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
-    double xf, double yf, int ray_flags, int flux_kind, double srcw, int bx, double xlo,
-    double xhi, int by, double ylo, double yhi, double* __restrict__ hist,
-    double* __restrict__ counters) {
-  __shared__ double lds[8][4];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (i < beam.n) {
-    const int st = beam.state[i];
-    if (st > 0) c[3] = 1.;
-    if (st == 1) c[4] = 1.;
-    if (st == 2) c[5] = 1.;
-    if (st == 3) c[6] = 1.;
-    if (st < 0) c[7] = 1.;
-    bool sel = false;
-    if ((ray_flags & 1) && st == 1) sel = true;
-    if ((ray_flags & 2) && st == 2) sel = true;
-    if ((ray_flags & 4) && st == 3) sel = true;
-    if ((ray_flags & 8) && st < 0) sel = true;
-    if ((ray_flags & 16) && st > 0) sel = true;
-    if (sel) {
-      double w;
-      if (flux_kind == 1)
-        w = beam.Jss[i];
-      else if (flux_kind == 2)
-        w = beam.Jpp[i];
-      else if (flux_kind == 3)
-        w = 2. * beam.Jsp_ri[2 * i];
-      else if (flux_kind == 4)
-        w = 2. * beam.Jsp_ri[2 * i + 1];
-      else if (flux_kind == 5)
-        w = (beam.Jss[i] + beam.Jpp[i]) * beam.E[i] * 1.602176565e-19;
-      else
-        w = beam.Jss[i] + beam.Jpp[i];
-      w *= srcw;
-      c[0] = 1.;
-      c[1] = w;
-      const int ix = find_bin(x[i] * xf, xlo, xhi, bx);
-      const int iy = find_bin(y[i] * yf, ylo, yhi, by);
-      if (ix >= 0 && iy >= 0) {
-        c[2] = w;
-        atomicAdd(&hist[(int64_t)iy * bx + ix], w);
-      }
-    }
-  }
-  if (counters) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      double v = c[k];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if ((threadIdx.x & 63) == 0) lds[k][threadIdx.x >> 6] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-      const double v = lds[threadIdx.x][0] + lds[threadIdx.x][1] + lds[threadIdx.x][2] +
-                       lds[threadIdx.x][3];
-      if (v != 0.) atomicAdd(&counters[threadIdx.x], v);
-    }
-  }
+struct PlotAxes {
+  AxisBins x, y, c;
+};
+__device__ __forceinline__ double bin_edge(const AxisBins& a, int j) {
+  return j == a.bins ? a.hi : (double)j * a.step + a.lo;
+}
+// numpy's own search on uniform bins (lib/histograms.py: scale, truncate, one step down and one
+// step up against the real edges). The guess is within one bin of the answer for any axis
+// whose step is not lost in the rounding of its limits, and for monotone edges the result is
+// then searchsorted's (np.histogram2d), the last edge belonging to the last bin.
+__device__ __forceinline__ int find_bin(double v, const AxisBins& a) {
+  if (!(v >= a.lo && v <= a.hi)) return -1;
+  int b = (int)((v - a.lo) * a.scale);
+  b = min(max(b, 0), a.bins - 1);
+  b -= (b > 0 && v < (double)b * a.step + a.lo) ? 1 : 0;
+  b += (b < a.bins - 1 && v >= (double)(b + 1) * a.step + a.lo) ? 1 : 0;
+  return b;
 }
 
 // ---------------------------------------------------------------------------
@@ -132,8 +91,8 @@ __device__ __forceinline__ void count_state(int st, double (&c)[8]) {
 
 __device__ __forceinline__ PlotRay plot_ray(const xrt_hip_beam& beam, const double* x,
                                             const double* y, const double* cd,
-                                            const xrt_hip_plot& P, int64_t i, int st,
-                                            bool want_c) {
+                                            const xrt_hip_plot& P, const PlotAxes& A,
+                                            int64_t i, int st, bool want_c) {
   PlotRay r;
   r.ix = r.iy = r.ic = -1;
   r.w = 0.;
@@ -162,13 +121,13 @@ __device__ __forceinline__ PlotRay plot_ray(const xrt_hip_beam& beam, const doub
   w *= P.source_weight;
   r.w = w;
   const double cv = cd[i] * P.c_factor;
-  double h01 = ((cv - P.c_lim[0]) * P.color_factor) / (P.c_lim[1] - P.c_lim[0]);
+  double h01 = div_rn((cv - A.c.lo) * P.color_factor, A.c.hi - A.c.lo);
   if (h01 < 0.) h01 = 0.;
   if (h01 > 1.) h01 = 1.;
   hsv_to_rgb(h01, P.color_saturation, w, r.rgb[0], r.rgb[1], r.rgb[2]);
-  r.ix = find_bin(x[i] * P.x_factor, P.x_lim[0], P.x_lim[1], P.bins_x);
-  r.iy = find_bin(y[i] * P.y_factor, P.y_lim[0], P.y_lim[1], P.bins_y);
-  if (want_c) r.ic = find_bin(cv, P.c_lim[0], P.c_lim[1], P.bins_c);
+  r.ix = find_bin(x[i] * P.x_factor, A.x);
+  r.iy = find_bin(y[i] * P.y_factor, A.y);
+  if (want_c) r.ic = find_bin(cv, A.c);
   return r;
 }
 
@@ -195,7 +154,7 @@ __device__ __forceinline__ void flush_counters(double (&c)[8], double* counters,
 // whatever does not fit the LDS-privatised kernels below.
 __global__ __launch_bounds__(256) void plot_hist_kernel(
     xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
-    const double* __restrict__ cd, xrt_hip_plot P, double* __restrict__ h2,
+    const double* __restrict__ cd, xrt_hip_plot P, PlotAxes A, double* __restrict__ h2,
     double* __restrict__ h2rgb, double* __restrict__ hx, double* __restrict__ hy,
     double* __restrict__ hc, double* __restrict__ counters, int parts) {
   __shared__ double lds[8][16];
@@ -204,7 +163,7 @@ __global__ __launch_bounds__(256) void plot_hist_kernel(
   if (i < beam.n) {
     const int st = beam.state[i];
     count_state(st, c);
-    const PlotRay r = plot_ray(beam, x, y, cd, P, i, st, hc != nullptr);
+    const PlotRay r = plot_ray(beam, x, y, cd, P, A, i, st, hc != nullptr);
     if (r.sel) {
       c[0] = 1.;
       c[1] = r.w;
@@ -237,245 +196,421 @@ __global__ __launch_bounds__(256) void plot_hist_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// LDS-privatised forms. With global atomics only, 1e7 rays issue 1.6e8 fp64 atomics,
-// most of them onto the few hundred cells of the 1-D histograms: 27 ms measured, 35x
-// the reflect pass that produced the beam. Here every block keeps its own copy of
-// the cells in LDS (ds_add_f64), strides over the beam and adds its non-zero cells to
-// the global arrays once.
-//   plot_hist1d_lds: the three 1-D histograms (4 values per bin) + the counters;
-//   plot_hist_lds: the fused form further down (2-D planes + the 1-D work of the first pass).
+// LDS-privatised forms. Global fp64 atomics run at 2.4e10 per second on this chip whatever the
+// table size, the scope of the atomic or the spread of the addresses (tools/probes/
+// probe_atomics.hip): the 1.6e8 updates of a plot of 1e7 rays take 27 ms that way (round 2's
+// first version), the 4e7 updates of the four 2-D planes (flux, R, G, B) alone 1.7 ms. So every
+// cell is accumulated in LDS (ds_add_f64), per-block copies go to a stream-ordered scratch area
+// as plain coalesced stores, and a small reduce kernel adds the copies up.
+//
+//   plot_hist_rays -- every ray read ONCE, in chunks of 1024 consecutive rays per block step,
+//     loads four rays deep: weight, hue and the three bins of every ray; the ray counters; the
+//     1-D histograms in LDS, laid out [weight][bin] so that the lanes of one ds_add_f64 spread
+//     over the banks ([bin][weight] put them on 8 of 64); and
+//       DIRECT  -- the 2-D planes fit the LDS beside them (64 x 64 bins): accumulated here, one
+//                  1024-lane block per CU;
+//       RECORDS -- they do not (the four planes of a 128 x 128 plot are 512 KB, of a 256 x 256
+//                  plot 2 MB; a CU has 160 KB). The plot is cut into T rectangular TILES of bins
+//                  whose planes do fit (64 x 64 bins: T = 4 / 16), and the chunk is SORTED BY
+//                  TILE in LDS (count, prefix, scatter) and written out as (w, hue, cell within
+//                  the tile) in that order, with the T + 1 run starts of the chunk -- 20 B per
+//                  ray, coalesced, no atomics between blocks.
+//   plot_hist_tiles -- block (tile, slice), 1024 lanes, one per CU: its waves walk through the
+//     chunks of the slice, read the tile's run of each (contiguous: the runs of four chunks are
+//     taken together so that all lanes have a ray), hue -> RGB, ds_add_f64 into the tile's planes.
+//     Each ray is read by exactly one block; scanning every ray in every tile's block instead
+//     cost T times the issue slots (1.25 ms at 256 x 256), a per-wave queue in front of the
+//     work 0.4 ms.
+//   plot_hist_reduce -- adds the copies up.
 // ---------------------------------------------------------------------------
-#define HIST_LDS_BUDGET (156 * 1024)
+#define HIST_LDS_BUDGET (159 * 1024)
+#define HIST_BLOCK 1024          // lanes of a block that owns a CU's LDS
+#define HIST_CHUNK 1024          // rays per block step
+#define HIST_MAX_TILES 64
+#define HIST_MAX_RAYS 0x7fffffffll
+#define HIST_REDUCE_PARTS 16
 
-__global__ __launch_bounds__(256) void plot_hist1d_lds(
-    xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
-    const double* __restrict__ cd, xrt_hip_plot P, double* __restrict__ hx,
-    double* __restrict__ hy, double* __restrict__ hc, double* __restrict__ counters) {
-  extern __shared__ double cells[];     // [bx*4 | by*4 | bc*4]
-  __shared__ double lds[8][16];
-  const int nx = hx ? 4 * P.bins_x : 0, ny = hy ? 4 * P.bins_y : 0;
-  const int nc = hc ? 4 * P.bins_c : 0;
-  double* lx = cells;
-  double* ly = cells + nx;
-  double* lc = ly + ny;
-  for (int k = threadIdx.x; k < nx + ny + nc; k += blockDim.x) cells[k] = 0.;
-  __syncthreads();
-  double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < beam.n; i += stride) {
-    const int st = beam.state[i];
-    count_state(st, c);
-    const PlotRay r = plot_ray(beam, x, y, cd, P, i, st, hc != nullptr);
-    if (!r.sel) continue;
-    c[0] += 1.;
-    c[1] += r.w;
-    if (r.ix >= 0 && r.iy >= 0) c[2] += r.w;
-    if (hx && r.ix >= 0) {
-      atomicAdd(&lx[4 * r.ix], r.w);
-      for (int k = 0; k < 3; ++k) atomicAdd(&lx[4 * r.ix + 1 + k], r.rgb[k]);
-    }
-    if (hy && r.iy >= 0) {
-      atomicAdd(&ly[4 * r.iy], r.w);
-      for (int k = 0; k < 3; ++k) atomicAdd(&ly[4 * r.iy + 1 + k], r.rgb[k]);
-    }
-    if (hc && r.ic >= 0) {
-      atomicAdd(&lc[4 * r.ic], r.w);
-      for (int k = 0; k < 3; ++k) atomicAdd(&lc[4 * r.ic + 1 + k], r.rgb[k]);
-    }
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < nx; k += blockDim.x)
-    if (lx[k] != 0.) atomicAdd(&hx[k], lx[k]);
-  for (int k = threadIdx.x; k < ny; k += blockDim.x)
-    if (ly[k] != 0.) atomicAdd(&hy[k], ly[k]);
-  for (int k = threadIdx.x; k < nc; k += blockDim.x)
-    if (lc[k] != 0.) atomicAdd(&hc[k], lc[k]);
-  if (counters) flush_counters(c, counters, lds);
+struct HistPlan {
+  int ntx, nty;      // tiles along x, y
+  int tx, ty;        // bins per tile
+  int slices;        // chunk slices of plot_hist_tiles
+  int nchan;         // 1 (flux) or 4 (flux, R, G, B)
+  int lines;         // the 1-D histograms and counters are wanted
+};
+
+// the sorted chunks: ray records in tile order and, per chunk, where each tile's run starts
+struct HistRecords {
+  double* w;
+  double* hue;
+  unsigned* cell;
+  unsigned* start;   // [chunk][T + 2]: start[t] .. start[t + 1]; bucket T = rays outside the plot
+};
+
+__device__ __forceinline__ bool ray_selected(int st, int ray_flags) {
+  bool sel = false;
+  if ((ray_flags & 1) && st == 1) sel = true;
+  if ((ray_flags & 2) && st == 2) sel = true;
+  if ((ray_flags & 4) && st == 3) sel = true;
+  if ((ray_flags & 8) && st < 0) sel = true;
+  if ((ray_flags & 16) && st > 0) sel = true;
+  return sel;
 }
 
-// ---- one fused, LDS-privatised pass ----------------------------------------------------------
-// A block (1024 lanes, one per CU) keeps `nch` of the four 2-D planes (flux, R, G, B; from
-// `ch0` on) and, in the pass that has ch0 == 0 (if `counters` is given), the three 1-D
-// histograms and the ray counters in LDS (ds_add_f64), strides over the beam and adds its
-// non-zero cells to the global arrays once. A 128 x 128 plot is four passes (one 128-KB plane
-// each; the first carries the 1-D work), a 64 x 64 plot one. Global fp64 atomics, the
-// alternative, run at 2.4e10 per second on this chip whatever the table size, scope or
-// distribution (tools/probes/probe_atomics.hip): the 4e7 updates of the 2-D planes alone
-// would take 1.7 ms.
-// The loop is unrolled four rays deep with every load issued before the first use: the version
-// that fetched a ray's fields after looking at its state ran at 1.6 TB/s (two dependent trips
-// per ray, 16 waves per CU).
+enum { HIST_LINES_ONLY = 0, HIST_DIRECT = 1, HIST_RECORDS = 2 };
+
 struct RayData {
   int st;
   double x, y, c, jss, jpp, extra;
 };
-__device__ __forceinline__ RayData fetch_ray(const xrt_hip_beam& beam, const double* x,
-                                             const double* y, const double* cd,
-                                             const xrt_hip_plot& P, int64_t i) {
-  RayData d;
-  d.st = beam.state[i];
-  d.x = x[i];
-  d.y = y[i];
-  d.c = cd[i];
-  d.jss = beam.Jss[i];
-  d.jpp = beam.Jpp[i];
-  d.extra = 0.;
-  if (P.flux_kind == 3)
-    d.extra = beam.Jsp_ri[2 * i];
-  else if (P.flux_kind == 4)
-    d.extra = beam.Jsp_ri[2 * i + 1];
-  else if (P.flux_kind == 5)
-    d.extra = beam.E[i];
-  return d;
-}
-// plot_ray on fetched data (same arithmetic)
-__device__ __forceinline__ PlotRay eval_ray(const RayData& d, const xrt_hip_plot& P,
-                                            bool want_c) {
-  PlotRay r;
-  r.ix = r.iy = r.ic = -1;
-  r.w = 0.;
-  r.rgb[0] = r.rgb[1] = r.rgb[2] = 0.;
-  const int st = d.st;
-  bool sel = false;
-  if ((P.ray_flags & 1) && st == 1) sel = true;
-  if ((P.ray_flags & 2) && st == 2) sel = true;
-  if ((P.ray_flags & 4) && st == 3) sel = true;
-  if ((P.ray_flags & 8) && st < 0) sel = true;
-  if ((P.ray_flags & 16) && st > 0) sel = true;
-  r.sel = sel;
-  if (!sel) return r;
-  double w;
-  if (P.flux_kind == 1)
-    w = d.jss;
-  else if (P.flux_kind == 2)
-    w = d.jpp;
-  else if (P.flux_kind == 3 || P.flux_kind == 4)
-    w = 2. * d.extra;
-  else if (P.flux_kind == 5)
-    w = (d.jss + d.jpp) * d.extra * 1.602176565e-19;
-  else
-    w = d.jss + d.jpp;
-  w *= P.source_weight;
-  r.w = w;
-  const double cv = d.c * P.c_factor;
-  double h01 = ((cv - P.c_lim[0]) * P.color_factor) / (P.c_lim[1] - P.c_lim[0]);
-  if (h01 < 0.) h01 = 0.;
-  if (h01 > 1.) h01 = 1.;
-  hsv_to_rgb(h01, P.color_saturation, w, r.rgb[0], r.rgb[1], r.rgb[2]);
-  r.ix = find_bin(d.x * P.x_factor, P.x_lim[0], P.x_lim[1], P.bins_x);
-  r.iy = find_bin(d.y * P.y_factor, P.y_lim[0], P.y_lim[1], P.bins_y);
-  if (want_c) r.ic = find_bin(cv, P.c_lim[0], P.c_lim[1], P.bins_c);
-  return r;
-}
 
-#define HIST_UNROLL 4
-__global__ __launch_bounds__(1024) void plot_hist_lds(
+// (only DIRECT needs the LDS of a whole CU: the others run as 256-lane blocks, several per CU)
+template <int MODE>
+__global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256) void plot_hist_rays(
     xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
-    const double* __restrict__ cd, xrt_hip_plot P, double* __restrict__ h2,
-    double* __restrict__ h2rgb, int ch0, int nch, double* __restrict__ hx,
-    double* __restrict__ hy, double* __restrict__ hc, double* __restrict__ counters,
-    double* __restrict__ scratch) {
-  extern __shared__ double cells[];     // [nch][by][bx] | bx*4 | by*4 | bc*4
+    const double* __restrict__ cd, xrt_hip_plot P, PlotAxes A, HistPlan H,
+    double* __restrict__ counters, double* __restrict__ plane_copies,
+    double* __restrict__ line_copies, HistRecords R) {
+  constexpr int LANES = MODE == HIST_DIRECT ? HIST_BLOCK : 256;
+  constexpr int U = HIST_CHUNK / LANES;     // rays per lane and step: 1 (DIRECT: depth comes from
+                                            // the prefetch below) or 4
+  extern __shared__ double cells[];   // DIRECT: [nchan][by][bx] | then [4][bx] [4][by] [4][bc] |
+                                      // RECORDS: staging w, hue [1024], cell [1024]
   __shared__ double lds[8][16];
-  const bool lines = ch0 == 0 && counters != nullptr;   // this pass carries the 1-D work
-  const int plane = P.bins_x * P.bins_y;
-  const int nx = lines && hx ? 4 * P.bins_x : 0, ny = lines && hy ? 4 * P.bins_y : 0;
-  const int nc = lines && hc ? 4 * P.bins_c : 0;
-  double* lx = cells + (int64_t)nch * plane;
-  double* ly = lx + nx;
-  double* lc = ly + ny;
-  for (int k = threadIdx.x; k < nch * plane + nx + ny + nc; k += blockDim.x) cells[k] = 0.;
+  __shared__ unsigned bucket[HIST_MAX_TILES + 2], first[HIST_MAX_TILES + 2];
+  const bool lines = H.lines != 0;
+  const int plane = A.x.bins * A.y.bins;
+  const int n2 = MODE == HIST_DIRECT ? H.nchan * plane : 0;
+  const int nx = lines ? A.x.bins : 0, ny = lines ? A.y.bins : 0, nc = lines ? A.c.bins : 0;
+  double* lx = cells + n2;
+  double* ly = lx + 4 * nx;
+  double* lc = ly + 4 * ny;
+  const int ncells = n2 + 4 * (nx + ny + nc);
+  double* stage_w = cells + ncells;
+  double* stage_h = stage_w + HIST_CHUNK;
+  unsigned* stage_c = reinterpret_cast<unsigned*>(stage_h + HIST_CHUNK);
+  const int T = H.ntx * H.nty;
+  for (int k = threadIdx.x; k < ncells; k += LANES) cells[k] = 0.;
   __syncthreads();
-  double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < beam.n;
-       i0 += HIST_UNROLL * stride) {
-    RayData d[HIST_UNROLL];
+  int cn[6] = {0, 0, 0, 0, 0, 0};      // selected, alive, good, out, over, dead
+  double cw = 0., cw_in = 0.;          // flux of the selected rays, of those inside the 2-D range
+  const double crange = A.c.hi - A.c.lo;
+  const int64_t nchunks = (beam.n + HIST_CHUNK - 1) / HIST_CHUNK;
+
+  auto fetch = [&](int64_t chunk, RayData (&d)[U]) {
 #pragma unroll
-    for (int u = 0; u < HIST_UNROLL; ++u) {
-      const int64_t i = i0 + u * stride;
-      d[u] = fetch_ray(beam, x, y, cd, P, i < beam.n ? i : i0);
-      if (i >= beam.n) d[u].st = 0;      // (state 0: counted nowhere, selected by no flag)
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = chunk * HIST_CHUNK + u * LANES + threadIdx.x;
+      const int64_t j = i < beam.n ? i : beam.n - 1;
+      d[u].st = __builtin_nontemporal_load(beam.state + j);
+      d[u].x = __builtin_nontemporal_load(x + j);
+      d[u].y = __builtin_nontemporal_load(y + j);
+      d[u].c = __builtin_nontemporal_load(cd + j);
+      d[u].jss = __builtin_nontemporal_load(beam.Jss + j);
+      d[u].jpp = __builtin_nontemporal_load(beam.Jpp + j);
+      d[u].extra = 0.;
+      if (P.flux_kind == 3)
+        d[u].extra = beam.Jsp_ri[2 * j];
+      else if (P.flux_kind == 4)
+        d[u].extra = beam.Jsp_ri[2 * j + 1];
+      else if (P.flux_kind == 5)
+        d[u].extra = beam.E[j];
+      if (i >= beam.n) d[u].st = 0;     // (state 0: counted nowhere, selected by no flag)
+    }
+  };
+
+  RayData nxt[U];
+  if ((int64_t)blockIdx.x < nchunks) fetch(blockIdx.x, nxt);
+  for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    RayData d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) d[u] = nxt[u];
+    // the next chunk is requested before this one is worked on
+    fetch(chunk + gridDim.x < nchunks ? chunk + gridDim.x : chunk, nxt);
+    unsigned tl[U], cell[U];
+    double rw[U], rh[U];
+    if (MODE == HIST_RECORDS) {
+      if (threadIdx.x < T + 1) bucket[threadIdx.x] = 0;
+      __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < HIST_UNROLL; ++u) {
-      if (lines) count_state(d[u].st, c);
-      const PlotRay r = eval_ray(d[u], P, nc != 0);
-      if (!r.sel) continue;
+    for (int u = 0; u < U; ++u) {
+      const int st = d[u].st;
       if (lines) {
-        c[0] += 1.;
-        c[1] += r.w;
-        if (r.ix >= 0 && r.iy >= 0) c[2] += r.w;
-        if (nx && r.ix >= 0) {
-          atomicAdd(&lx[4 * r.ix], r.w);
-          for (int k = 0; k < 3; ++k) atomicAdd(&lx[4 * r.ix + 1 + k], r.rgb[k]);
+        cn[1] += st > 0;
+        cn[2] += st == 1;
+        cn[3] += st == 2;
+        cn[4] += st == 3;
+        cn[5] += st < 0;
+      }
+      tl[u] = T;
+      cell[u] = 0;
+      rw[u] = rh[u] = 0.;
+      if (ray_selected(st, P.ray_flags)) {
+        double w;
+        if (P.flux_kind == 1)
+          w = d[u].jss;
+        else if (P.flux_kind == 2)
+          w = d[u].jpp;
+        else if (P.flux_kind == 3 || P.flux_kind == 4)
+          w = 2. * d[u].extra;
+        else if (P.flux_kind == 5)
+          w = (d[u].jss + d[u].jpp) * d[u].extra * 1.602176565e-19;
+        else
+          w = d[u].jss + d[u].jpp;
+        w *= P.source_weight;
+        const double cv = d[u].c * P.c_factor;
+        double h01 = div_rn((cv - A.c.lo) * P.color_factor, crange);
+        if (h01 < 0.) h01 = 0.;
+        if (h01 > 1.) h01 = 1.;
+        const int ix = find_bin(d[u].x * P.x_factor, A.x);
+        const int iy = find_bin(d[u].y * P.y_factor, A.y);
+        const bool inside = ix >= 0 && iy >= 0;
+        if (lines || MODE == HIST_DIRECT) {
+          double r, g, b;
+          hsv_to_rgb(h01, P.color_saturation, w, r, g, b);
+          if (lines) {
+            cn[0] += 1;
+            cw += w;
+            if (inside) cw_in += w;
+            if (ix >= 0) {
+              atomicAdd(&lx[ix], w);
+              atomicAdd(&lx[nx + ix], r);
+              atomicAdd(&lx[2 * nx + ix], g);
+              atomicAdd(&lx[3 * nx + ix], b);
+            }
+            if (iy >= 0) {
+              atomicAdd(&ly[iy], w);
+              atomicAdd(&ly[ny + iy], r);
+              atomicAdd(&ly[2 * ny + iy], g);
+              atomicAdd(&ly[3 * ny + iy], b);
+            }
+            const int ic = find_bin(cv, A.c);
+            if (ic >= 0) {
+              atomicAdd(&lc[ic], w);
+              atomicAdd(&lc[nc + ic], r);
+              atomicAdd(&lc[2 * nc + ic], g);
+              atomicAdd(&lc[3 * nc + ic], b);
+            }
+          }
+          if (MODE == HIST_DIRECT && inside) {
+            const int bb = iy * A.x.bins + ix;
+            if (w != 0.) atomicAdd(&cells[bb], w);
+            if (H.nchan > 1) {
+              if (r != 0.) atomicAdd(&cells[plane + bb], r);
+              if (g != 0.) atomicAdd(&cells[2 * plane + bb], g);
+              if (b != 0.) atomicAdd(&cells[3 * plane + bb], b);
+            }
+          }
         }
-        if (ny && r.iy >= 0) {
-          atomicAdd(&ly[4 * r.iy], r.w);
-          for (int k = 0; k < 3; ++k) atomicAdd(&ly[4 * r.iy + 1 + k], r.rgb[k]);
-        }
-        if (nc && r.ic >= 0) {
-          atomicAdd(&lc[4 * r.ic], r.w);
-          for (int k = 0; k < 3; ++k) atomicAdd(&lc[4 * r.ic + 1 + k], r.rgb[k]);
+        if (MODE == HIST_RECORDS && inside) {
+          const int tjx = ix / H.tx, tjy = iy / H.ty;
+          tl[u] = (unsigned)(tjy * H.ntx + tjx);
+          cell[u] = (unsigned)((iy - tjy * H.ty) * H.tx + (ix - tjx * H.tx));
+          rw[u] = w;
+          rh[u] = h01;
         }
       }
-      if (r.ix < 0 || r.iy < 0) continue;
-      const int b = r.iy * P.bins_x + r.ix;
-      for (int k = 0; k < nch; ++k) {
-        const int ch = ch0 + k;
-        const double v = ch == 0 ? r.w : r.rgb[ch - 1];
-        if (v != 0.) atomicAdd(&cells[k * plane + b], v);
+    }
+    if (MODE == HIST_RECORDS) {
+      // counting sort of the chunk by tile: rank within the bucket, bucket starts, scatter into
+      // the staging arrays, coalesced copy out
+      unsigned rank[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) rank[u] = atomicAdd(&bucket[tl[u]], 1u);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int t = 0; t <= T; ++t) {
+          first[t] = run;
+          run += bucket[t];
+        }
+        first[T + 1] = run;
+      }
+      __syncthreads();
+      if (threadIdx.x < T + 2) R.start[chunk * (T + 2) + threadIdx.x] = first[threadIdx.x];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned pos = first[tl[u]] + rank[u];
+        stage_w[pos] = rw[u];
+        stage_h[pos] = rh[u];
+        stage_c[pos] = cell[u];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = u * LANES + threadIdx.x;
+        const int64_t o = chunk * HIST_CHUNK + k;
+        __builtin_nontemporal_store(stage_w[k], R.w + o);
+        __builtin_nontemporal_store(stage_h[k], R.hue + o);
+        __builtin_nontemporal_store(stage_c[k], R.cell + o);
       }
     }
   }
   __syncthreads();
-  if (scratch) {
-    // the block's planes go to its slot of the scratch area as they are (coalesced stores);
-    // plot_hist_reduce adds the slots up. 256 blocks flushing 16 384 cells each through
-    // global atomics were 4e6 atomics = 0.17 ms of a 0.24-ms pass.
-    double* slot = scratch + (int64_t)blockIdx.x * nch * plane;
-    for (int b = threadIdx.x; b < nch * plane; b += blockDim.x) slot[b] = cells[b];
-  } else {
-    for (int k = 0; k < nch; ++k) {
-      const int ch = ch0 + k;
-      for (int b = threadIdx.x; b < plane; b += blockDim.x) {
-        const double v = cells[k * plane + b];
-        if (v == 0.) continue;
-        if (ch == 0)
-          atomicAdd(&h2[b], v);
-        else
-          atomicAdd(&h2rgb[3 * (int64_t)b + ch - 1], v);
-      }
+  // this block's copies, as they are (coalesced stores): the reduce kernel adds the blocks up
+  if (MODE == HIST_DIRECT) {
+    double* out = plane_copies + (int64_t)blockIdx.x * n2;
+    for (int k = threadIdx.x; k < n2; k += LANES) out[k] = cells[k];
+  }
+  if (lines) {
+    const int nl = 4 * (nx + ny + nc);
+    double* out = line_copies + (int64_t)blockIdx.x * nl;
+    for (int k = threadIdx.x; k < nl; k += LANES) out[k] = lx[k];
+    if (counters) {
+      double c[8] = {(double)cn[0], cw,           cw_in,         (double)cn[1],
+                     (double)cn[2], (double)cn[3], (double)cn[4], (double)cn[5]};
+      flush_counters(c, counters, lds);
     }
   }
-  for (int k = threadIdx.x; k < nx; k += blockDim.x)
-    if (lx[k] != 0.) atomicAdd(&hx[k], lx[k]);
-  for (int k = threadIdx.x; k < ny; k += blockDim.x)
-    if (ly[k] != 0.) atomicAdd(&hy[k], ly[k]);
-  for (int k = threadIdx.x; k < nc; k += blockDim.x)
-    if (lc[k] != 0.) atomicAdd(&hc[k], lc[k]);
-  if (lines) flush_counters(c, counters, lds);
 }
 
-// sums the per-block planes of one plot_hist_lds pass into the histograms: blockIdx.y takes
-// one of HIST_REDUCE_PARTS groups of slots, one atomic per cell and group
-#define HIST_REDUCE_PARTS 8
-__global__ __launch_bounds__(256) void plot_hist_reduce(const double* __restrict__ scratch,
-                                                        int nblocks, int plane, int ch0, int nch,
-                                                        double* __restrict__ h2,
-                                                        double* __restrict__ h2rgb) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= nch * plane) return;
-  const int per = (nblocks + HIST_REDUCE_PARTS - 1) / HIST_REDUCE_PARTS;
-  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
-  double v = 0.;
-  for (int blk = b0; blk < b1; ++blk) v += scratch[(int64_t)blk * nch * plane + j];
+#define HIST_GROUP 4     // chunks whose runs a wave takes together
+template <int NCH>
+__global__ __launch_bounds__(HIST_BLOCK) void plot_hist_tiles(
+    int64_t nchunks, HistRecords R, double saturation, PlotAxes A, HistPlan H,
+    double* __restrict__ plane_copies) {
+  extern __shared__ double cells[];     // [NCH][ty][tx]
+  const int T = H.ntx * H.nty;
+  const int tile = blockIdx.x % T, slice = blockIdx.x / T;
+  const int x0 = (tile % H.ntx) * H.tx, y0 = (tile / H.ntx) * H.ty;
+  const int tw = min(A.x.bins, x0 + H.tx) - x0, th = min(A.y.bins, y0 + H.ty) - y0;
+  const int tcells = H.tx * H.ty;
+  for (int k = threadIdx.x; k < NCH * tcells; k += blockDim.x) cells[k] = 0.;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  // the chunks of the slice: slice, slice + S, ...; wave w takes them HIST_GROUP at a time
+  const int64_t mine = slice < nchunks ? (nchunks - slice + H.slices - 1) / H.slices : 0;
+  for (int64_t j0 = (int64_t)wave * HIST_GROUP; j0 < mine; j0 += (int64_t)nwaves * HIST_GROUP) {
+    // lanes 0..3 fetch the run of one chunk each; everybody gets all four
+    int64_t c_l = -1;
+    unsigned s_l = 0, e_l = 0;
+    if (lane < HIST_GROUP && j0 + lane < mine) {
+      c_l = slice + (j0 + lane) * H.slices;
+      s_l = R.start[c_l * (T + 2) + tile];
+      e_l = R.start[c_l * (T + 2) + tile + 1];
+    }
+    int64_t base[HIST_GROUP];
+    int upto[HIST_GROUP];
+    int total = 0;
+    const int64_t safe = __shfl(c_l, 0) * HIST_CHUNK;   // what lanes without a ray read
+#pragma unroll
+    for (int g = 0; g < HIST_GROUP; ++g) {
+      const int64_t c = __shfl(c_l, g);
+      const unsigned s0 = __shfl(s_l, g), e0 = __shfl(e_l, g);
+      base[g] = c * HIST_CHUNK + s0 - total;     // record index = base[g] + position in the group
+      total += (int)(e0 - s0);
+      upto[g] = total;
+    }
+    for (int i0 = 0; i0 < total; i0 += 64 * 4) {
+      double w[4], hue[4];
+      unsigned cell[4];
+      bool on[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 64 + lane;
+        on[u] = i < total;
+        const int g = i < upto[0] ? 0 : i < upto[1] ? 1 : i < upto[2] ? 2 : 3;
+        const int64_t k = on[u] ? base[g] + i : safe;
+        w[u] = __builtin_nontemporal_load(R.w + k);
+        hue[u] = __builtin_nontemporal_load(R.hue + k);
+        cell[u] = __builtin_nontemporal_load(R.cell + k);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!on[u] || cell[u] >= (unsigned)tcells) continue;
+        if (NCH > 1) {
+          double r, g, b;
+          hsv_to_rgb(hue[u], saturation, w[u], r, g, b);
+          if (r != 0.) atomicAdd(&cells[tcells + cell[u]], r);
+          if (g != 0.) atomicAdd(&cells[2 * tcells + cell[u]], g);
+          if (b != 0.) atomicAdd(&cells[3 * tcells + cell[u]], b);
+        }
+        if (w[u] != 0.) atomicAdd(&cells[cell[u]], w[u]);
+      }
+    }
+  }
+  __syncthreads();
+  // the tile into this slice's copy of the planes, [slice][chan][by][bx]
+  const int64_t plane = (int64_t)A.x.bins * A.y.bins;
+  double* out = plane_copies + (int64_t)slice * NCH * plane;
+  for (int k = 0; k < NCH; ++k)
+    for (int b = threadIdx.x; b < tw * th; b += blockDim.x) {
+      const int r = b / tw, q = b - r * tw;
+      out[k * plane + (int64_t)(y0 + r) * A.x.bins + x0 + q] = cells[k * tcells + r * H.tx + q];
+    }
+}
+
+// Adds the copies up into the histograms, one launch: blocks [0, nb2) take the 2-D planes
+// ([copy][chan][by][bx] -> h2, h2rgb), the rest the 1-D histograms ([copy][ [4][bx] | [4][by] |
+// [4][bc] ] -> h[bin][4]); blockIdx.y takes one of gridDim.y groups of copies (one atomic per
+// cell and group), four independent sums per thread so that the loads overlap.
+__device__ __forceinline__ double sum_copies(const double* __restrict__ p, int64_t pitch, int s0,
+                                             int s1) {
+  double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+  int sl = s0;
+  for (; sl + 3 < s1; sl += 4) {
+    a0 += p[(int64_t)sl * pitch];
+    a1 += p[(int64_t)(sl + 1) * pitch];
+    a2 += p[(int64_t)(sl + 2) * pitch];
+    a3 += p[(int64_t)(sl + 3) * pitch];
+  }
+  for (; sl < s1; ++sl) a0 += p[(int64_t)sl * pitch];
+  return (a0 + a1) + (a2 + a3);
+}
+__global__ __launch_bounds__(256) void plot_hist_reduce(
+    const double* __restrict__ planes, int ncopies, int plane, int nchan, int nb2,
+    const double* __restrict__ lines, int nline_copies, int nx, int ny, int nc,
+    double* __restrict__ h2, double* __restrict__ h2rgb, double* __restrict__ hx,
+    double* __restrict__ hy, double* __restrict__ hc) {
+  if ((int)blockIdx.x < nb2) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nchan * plane) return;
+    const int per = (ncopies + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int s0 = blockIdx.y * per, s1 = min(ncopies, s0 + per);
+    const double v = sum_copies(planes + j, (int64_t)nchan * plane, s0, s1);
+    if (v == 0.) return;
+    const int ch = j / plane, b = j - ch * plane;
+    if (ch == 0)
+      atomicAdd(&h2[b], v);
+    else
+      atomicAdd(&h2rgb[3 * (int64_t)b + ch - 1], v);
+    return;
+  }
+  const int nl = 4 * (nx + ny + nc);
+  const int j = ((int)blockIdx.x - nb2) * blockDim.x + threadIdx.x;
+  if (j >= nl) return;
+  const int per = (nline_copies + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int s0 = blockIdx.y * per, s1 = min(nline_copies, s0 + per);
+  const double v = sum_copies(lines + j, nl, s0, s1);
   if (v == 0.) return;
-  const int k = j / plane, b = j - k * plane, ch = ch0 + k;
-  if (ch == 0)
-    atomicAdd(&h2[b], v);
-  else
-    atomicAdd(&h2rgb[3 * (int64_t)b + ch - 1], v);
+  if (j < 4 * nx) {
+    if (hx) atomicAdd(&hx[4 * (j % nx) + j / nx], v);
+  } else if (j < 4 * (nx + ny)) {
+    const int k = j - 4 * nx;
+    if (hy) atomicAdd(&hy[4 * (k % ny) + k / ny], v);
+  } else {
+    const int k = j - 4 * (nx + ny);
+    if (hc) atomicAdd(&hc[4 * (k % nc) + k / nc], v);
+  }
+}
+
+// the smallest number of tiles whose planes fit `budget` bytes of LDS
+static bool plan_tiles(int bx, int by, int nchan, size_t budget, int max_tiles, HistPlan& H) {
+  int best = 0;
+  for (int a = 1; a <= max_tiles; ++a)
+    for (int b = 1; a * b <= max_tiles; ++b) {
+      const int tx = (bx + a - 1) / a, ty = (by + b - 1) / b;
+      if ((size_t)tx * ty * nchan * sizeof(double) > budget || tx * ty > 0xfffff) continue;
+      // fewer tiles first; then rows as long as possible (coalesced flush)
+      if (!best || a * b < best || (a * b == best && a < H.ntx)) {
+        best = a * b;
+        H.ntx = a;
+        H.nty = b;
+        H.tx = tx;
+        H.ty = ty;
+      }
+    }
+  return best != 0;
 }
 
 hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const double* y,
@@ -483,83 +618,114 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
                             double* hx, double* hy, double* hc, double* counters,
                             hipStream_t st) {
   if (beam.n <= 0) return hipSuccess;
-  const dim3 full((unsigned)((beam.n + 255) / 256));
-  int general = 0;   // parts left to the global-atomics kernel
-  const size_t b1 = sizeof(double) * 4 *
-                    ((hx ? P.bins_x : 0) + (hy ? P.bins_y : 0) + (hc ? P.bins_c : 0));
-  const size_t plane = sizeof(double) * (size_t)P.bins_x * (size_t)P.bins_y;
-  const int nchan = h2rgb ? 4 : 1;
+  PlotAxes A;
+  A.x = axis_bins(P.x_lim[0], P.x_lim[1], P.bins_x);
+  A.y = axis_bins(P.y_lim[0], P.y_lim[1], P.bins_y);
+  A.c = axis_bins(P.c_lim[0], P.c_lim[1], P.bins_c > 0 ? P.bins_c : 1);
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  unsigned lds_blocks = (unsigned)((beam.n + 1023) / 1024);
-  if (lds_blocks > (unsigned)cus) lds_blocks = (unsigned)cus;   // one block per CU
-  if (plane > 0 && plane <= HIST_LDS_BUDGET) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plot_hist_lds),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       HIST_LDS_BUDGET);
-    if (e != hipSuccess) return e;
+  const bool want_lines = hx || hy || hc || counters;
+  // (the kernel keeps all three 1-D histograms; absent ones are dropped by the reduce)
+  const size_t b1 = sizeof(double) * 4 * ((size_t)A.x.bins + A.y.bins + A.c.bins);
+  const size_t plane = sizeof(double) * (size_t)P.bins_x * (size_t)P.bins_y;
+  const size_t stage = HIST_CHUNK * (8 + 8 + 4);
+  HistPlan H = {};
+  H.nchan = h2rgb ? 4 : 1;
+  H.ntx = H.nty = 1;
+  H.tx = P.bins_x;
+  H.ty = P.bins_y;
+  const bool fits = beam.n < HIST_MAX_RAYS;
+  const bool lines = fits && want_lines && b1 <= 64 * 1024;
+  H.lines = lines;
+  int mode = HIST_LINES_ONLY;
+  if (h2 && fits) {
+    if (H.nchan * plane + (lines ? b1 : 0) <= HIST_LDS_BUDGET - 2048)
+      mode = HIST_DIRECT;
+    else if (plan_tiles(P.bins_x, P.bins_y, H.nchan, HIST_LDS_BUDGET,
+                        cus < HIST_MAX_TILES ? cus : HIST_MAX_TILES, H))
+      mode = HIST_RECORDS;
   }
-  // scratch for the per-block planes of a pass (stream-ordered allocation: the pool keeps it
-  // between calls); without it the blocks flush through atomics
-  double* scratch = nullptr;
-  const size_t cells_pp = plane / sizeof(double);
-  auto pass = [&](int ch0, int nch, size_t extra, bool lines) {
-    hipLaunchKernelGGL(plot_hist_lds, dim3(lds_blocks), dim3(1024), nch * plane + extra, st, beam,
-                       x, y, c, P, h2, h2rgb, ch0, nch, lines ? hx : nullptr,
-                       lines ? hy : nullptr, lines ? hc : nullptr, lines ? counters : nullptr,
-                       scratch);
-    if (scratch) {
-      const int total = (int)(nch * cells_pp);
-      hipLaunchKernelGGL(plot_hist_reduce, dim3((total + 255) / 256, HIST_REDUCE_PARTS), dim3(256), 0, st, scratch,
-                         (int)lds_blocks, (int)cells_pp, ch0, nch, h2, h2rgb);
+  int general = (h2 && mode == HIST_LINES_ONLY ? 1 : 0) | (want_lines && !lines ? 2 : 0);
+  if (mode != HIST_LINES_ONLY || lines) {
+    const int64_t chunks = (beam.n + HIST_CHUNK - 1) / HIST_CHUNK;
+    const int64_t most = (int64_t)cus * (mode == HIST_DIRECT ? 1 : 3);
+    const int nblk = (int)(chunks < most ? chunks : most);        // plot_hist_rays: fills the CUs
+    const int T = H.ntx * H.nty;
+    int ncopies = nblk;                                           // copies of the planes
+    if (mode == HIST_RECORDS) {
+      int S = cus / T;
+      if (S > chunks) S = (int)chunks;
+      if (S < 1) S = 1;
+      H.slices = S;
+      ncopies = S;
     }
-  };
-  if (plane > 0 && plane <= HIST_LDS_BUDGET && lds_blocks > 8) {
-    int most = (int)(HIST_LDS_BUDGET / plane);
-    if (most > nchan) most = nchan;
-    if (hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)lds_blocks * most * plane,
+    auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t nl = b1 / sizeof(double);
+    const size_t planes_b = pad(mode == HIST_LINES_ONLY ? 0 : (size_t)ncopies * H.nchan * plane);
+    const size_t lines_b = pad(lines ? (size_t)nblk * b1 : 0);
+    const size_t recs = mode == HIST_RECORDS ? (size_t)chunks * HIST_CHUNK : 0;
+    const size_t start_b = pad(mode == HIST_RECORDS ? (size_t)chunks * (T + 2) * 4 : 0);
+    char* scratch = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void**>(&scratch),
+                       planes_b + lines_b + pad(recs * 8) * 2 + pad(recs * 4) + start_b + 256,
                        st) != hipSuccess) {
       (void)hipGetLastError();
       scratch = nullptr;
     }
-  }
-  if (plane > 0 && plane + b1 <= HIST_LDS_BUDGET && counters) {
-    // the fused passes: as many of the (flux, R, G, B) planes per pass as fit the LDS, the
-    // 1-D histograms and the counters riding with the first
-    for (int ch0 = 0; ch0 < nchan;) {
-      const size_t extra = ch0 == 0 ? b1 : 0;
-      int nch = (int)((HIST_LDS_BUDGET - extra) / plane);
-      if (nch > nchan - ch0) nch = nchan - ch0;
-      pass(ch0, nch, extra, true);
-      ch0 += nch;
+    if (scratch) {
+      char* q = scratch;
+      double* plane_copies = reinterpret_cast<double*>(q);
+      q += planes_b;
+      double* line_copies = reinterpret_cast<double*>(q);
+      q += lines_b;
+      HistRecords R;
+      R.w = reinterpret_cast<double*>(q);
+      q += pad(recs * 8);
+      R.hue = reinterpret_cast<double*>(q);
+      q += pad(recs * 8);
+      R.cell = reinterpret_cast<unsigned*>(q);
+      q += pad(recs * 4);
+      R.start = reinterpret_cast<unsigned*>(q);
+      const size_t lds1 = (mode == HIST_DIRECT ? H.nchan * plane : 0) + (lines ? b1 : 0) +
+                          (mode == HIST_RECORDS ? stage : 0);
+      auto rays = mode == HIST_DIRECT    ? plot_hist_rays<HIST_DIRECT>
+                  : mode == HIST_RECORDS ? plot_hist_rays<HIST_RECORDS>
+                                         : plot_hist_rays<HIST_LINES_ONLY>;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rays),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(rays, dim3((unsigned)nblk), dim3(mode == HIST_DIRECT ? HIST_BLOCK : 256),
+                         lds1, st, beam, x, y, c, P, A, H, counters, plane_copies, line_copies, R);
+      if (mode == HIST_RECORDS) {
+        auto tiles = H.nchan > 1 ? plot_hist_tiles<4> : plot_hist_tiles<1>;
+        const size_t lds2 = sizeof(double) * (size_t)H.nchan * H.tx * H.ty;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiles),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(tiles, dim3((unsigned)(T * H.slices)), dim3(HIST_BLOCK), lds2, st,
+                           chunks, R, P.color_saturation, A, H, plane_copies);
+      }
+      {
+        const int total = mode != HIST_LINES_ONLY ? H.nchan * P.bins_x * P.bins_y : 0;
+        const int nb2 = (total + 255) / 256;
+        const int nbl = lines && (hx || hy || hc) ? (int)((nl + 255) / 256) : 0;
+        if (nb2 + nbl > 0)
+          hipLaunchKernelGGL(plot_hist_reduce, dim3((unsigned)(nb2 + nbl), HIST_REDUCE_PARTS),
+                             dim3(256), 0, st, plane_copies, ncopies, P.bins_x * P.bins_y, H.nchan,
+                             nb2, line_copies, nblk, lines ? A.x.bins : 0, lines ? A.y.bins : 0,
+                             lines ? A.c.bins : 0, h2, h2rgb, hx, hy, hc);
+      }
+      (void)hipFreeAsync(scratch, st);
+    } else {
+      general = (h2 ? 1 : 0) | (want_lines ? 2 : 0);
     }
-    if (scratch) (void)hipFreeAsync(scratch, st);
-    return hipGetLastError();
   }
-  // 1-D histograms + counters
-  if (b1 <= 48 * 1024) {
-    unsigned blocks = full.x < 2048u ? full.x : 2048u;
-    hipLaunchKernelGGL(plot_hist1d_lds, dim3(blocks), dim3(256), b1, st, beam, x, y, c, P, hx, hy,
-                       hc, counters);
-  } else {
-    general |= 2;
+  if (general) {
+    const dim3 full((unsigned)((beam.n + 255) / 256));
+    hipLaunchKernelGGL(plot_hist_kernel, full, dim3(256), 0, st, beam, x, y, c, P, A, h2, h2rgb,
+                       hx, hy, hc, counters, general);
   }
-  // 2-D histograms: as many of the (flux, R, G, B) planes per pass as fit the LDS
-  if (plane > 0 && plane <= HIST_LDS_BUDGET) {
-    int per_pass = (int)(HIST_LDS_BUDGET / plane);
-    if (per_pass > nchan) per_pass = nchan;
-    for (int ch0 = 0; ch0 < nchan; ch0 += per_pass) {
-      const int nch = ch0 + per_pass <= nchan ? per_pass : nchan - ch0;
-      pass(ch0, nch, 0, false);
-    }
-  } else if (plane > 0) {
-    general |= 1;
-  }
-  if (scratch) (void)hipFreeAsync(scratch, st);
-  if (general)
-    hipLaunchKernelGGL(plot_hist_kernel, full, dim3(256), 0, st, beam, x, y, c, P, h2, h2rgb, hx,
-                       hy, hc, counters, general);
   return hipGetLastError();
 }
 
@@ -568,34 +734,27 @@ hipError_t hist2d_launch(const xrt_hip_beam& beam, const double* x, const double
                          double xlo, double xhi, int by, double ylo, double yhi, double* hist,
                          double* counters, hipStream_t st) {
   if (beam.n <= 0) return hipSuccess;
-  const size_t plane = sizeof(double) * (size_t)bx * (size_t)by;
-  if (plane > 0 && plane <= HIST_LDS_BUDGET) {
-    // the flux plane of a plot without colour axis: same LDS-privatised kernels
-    xrt_hip_plot P;
-    P.x_factor = xf;
-    P.y_factor = yf;
-    P.c_factor = 0.;
-    P.source_weight = srcw;
-    P.x_lim[0] = xlo;
-    P.x_lim[1] = xhi;
-    P.y_lim[0] = ylo;
-    P.y_lim[1] = yhi;
-    P.c_lim[0] = 0.;
-    P.c_lim[1] = 1.;
-    P.color_factor = 0.;
-    P.color_saturation = 0.;
-    P.bins_x = bx;
-    P.bins_y = by;
-    P.bins_c = 1;
-    P.ray_flags = ray_flags;
-    P.flux_kind = flux_kind;
-    return plot_hist_launch(beam, x, y, x, P, hist, nullptr, nullptr, nullptr, nullptr, counters,
-                            st);
-  }
-  hipLaunchKernelGGL(hist2d_kernel, dim3((unsigned)((beam.n + 255) / 256)), dim3(256), 0, st,
-                     beam, x, y, xf, yf, ray_flags, flux_kind, srcw, bx, xlo, xhi, by, ylo, yhi,
-                     hist, counters);
-  return hipGetLastError();
+  // the flux plane of a plot without colour axis: the same kernels
+  xrt_hip_plot P;
+  P.x_factor = xf;
+  P.y_factor = yf;
+  P.c_factor = 0.;
+  P.source_weight = srcw;
+  P.x_lim[0] = xlo;
+  P.x_lim[1] = xhi;
+  P.y_lim[0] = ylo;
+  P.y_lim[1] = yhi;
+  P.c_lim[0] = 0.;
+  P.c_lim[1] = 1.;
+  P.color_factor = 0.;
+  P.color_saturation = 0.;
+  P.bins_x = bx;
+  P.bins_y = by;
+  P.bins_c = 1;
+  P.ray_flags = ray_flags;
+  P.flux_kind = flux_kind;
+  return plot_hist_launch(beam, x, y, x, P, hist, nullptr, nullptr, nullptr, nullptr, counters,
+                          st);
 }
 
 }  // namespace xrt

@@ -2,7 +2,12 @@
 runner needs: ``XYCAxis`` / ``XYCPlot`` as accumulators of the 2-D histogram,
 its 1-D projections and the ray counters (xrt/plotter.py:227-330, 684-900;
 xrt/multipro.py:53-177). Drawing, colour (hue) histograms, KDE and persistence
-are out of scope (plotter OOS)."""
+are out of scope (plotter OOS).
+
+The accumulators of a plot live ON THE DEVICE between iterations (the histogram kernels add
+into them, nothing is copied or waited for per iteration); ``total2D``, ``total2D_RGB``, the
+axes' ``total1D4`` and the ray counters are read through properties that bring the device part
+home first. On a machine without a GPU they are plain numpy arrays."""
 import numpy as np
 
 _UNIT_FACTORS = {'mm': 1., 'm': 1e-3, 'um': 1e3, u'µm': 1e3, 'nm': 1e6,
@@ -19,6 +24,22 @@ class XYCAxis(object):
             setattr(self, key, given[key])
         self.factor = _UNIT_FACTORS.get(unit, 1.) if factor is None else factor
         self.bins = int(bins)
+        self._plot, self._slot = None, None      # the accumulator this axis belongs to
+        self._total1D4 = np.zeros((self.bins, 4))
+
+    @property
+    def total1D4(self):
+        """[bin][flux, R, G, B] of the 1-D histogram along this axis."""
+        if self._plot is not None:
+            return self._plot._part(self._slot)
+        return self._total1D4
+
+    @total1D4.setter
+    def total1D4(self, value):
+        if self._plot is not None:
+            self._plot._part(self._slot)[...] = value
+        else:
+            self._total1D4 = np.array(value, dtype=float)
 
     def field(self):
         """Which beam quantity this axis shows (label convention of xrt:
@@ -47,27 +68,61 @@ class XYCPlot(object):
         self.fluxKind, self.beamState = fluxKind, beamState
         self.reset_bins2D()
 
+    # layout of the accumulator: what the histogram kernels fill in one call
+    _PARTS = ('total2D', 'total2D_RGB', 'x', 'y', 'c', 'counters')
+    # counters[k]: selected, flux, flux inside the limits, alive, good, out, over, dead
+    _COUNTER_SLOTS = {'nRaysSelected': 0, 'intensity': 1, 'intensityInRange': 2,
+                      'nRaysAlive': 3, 'nRaysGood': 4, 'nRaysOut': 5, 'nRaysOver': 6,
+                      'nRaysDead': 7}
+
+    def part_sizes(self):
+        nx, ny, nc = self.xaxis.bins, self.yaxis.bins, self.caxis.bins
+        return (ny * nx, ny * nx * 3, nx * 4, ny * 4, nc * 4, 8)
+
     def reset_bins2D(self):
-        self.total2D = np.zeros((self.yaxis.bins, self.xaxis.bins))
-        self.total2D_RGB = np.zeros((self.yaxis.bins, self.xaxis.bins, 3))
+        nx, ny, nc = self.xaxis.bins, self.yaxis.bins, self.caxis.bins
+        sizes = self.part_sizes()
+        self._flat = np.zeros(sum(sizes))                  # host part of the accumulator
+        self._device_flat = None                           # device part (a torch tensor)
+        cuts = np.cumsum((0,) + sizes)
+        shapes = ((ny, nx), (ny, nx, 3), (nx, 4), (ny, 4), (nc, 4), (8,))
+        self._views = {name: self._flat[cuts[k]:cuts[k + 1]].reshape(shapes[k])
+                       for k, name in enumerate(self._PARTS)}
         # 1-D histograms, accumulated like xrt/plotter.py's *axis.total1D* and
         # *total1D_RGB*: column 0 = flux weights, columns 1..3 = R, G, B
-        self.xaxis.total1D4 = np.zeros((self.xaxis.bins, 4))
-        self.yaxis.total1D4 = np.zeros((self.yaxis.bins, 4))
-        self.caxis.total1D4 = np.zeros((self.caxis.bins, 4))
+        for axis, slot in ((self.xaxis, 'x'), (self.yaxis, 'y'), (self.caxis, 'c')):
+            axis._plot, axis._slot = self, slot
         self.nRaysAll = 0
-        self.nRaysSelected = 0
-        self.nRaysAlive = 0
-        self.nRaysGood = 0
-        self.nRaysOut = 0
-        self.nRaysOver = 0
-        self.nRaysDead = 0
-        self.intensity = 0.          # sum of weights of the selected rays
-        self.intensityInRange = 0.   # ... of those inside the plot limits
         self.iteration = 0
 
-    _COUNTERS = ('nRaysAll', 'nRaysSelected', 'nRaysAlive', 'nRaysGood', 'nRaysOut',
-                 'nRaysOver', 'nRaysDead', 'intensity', 'intensityInRange', 'iteration')
+    def device_accumulator(self, device):
+        """The device part of the accumulator (zeros when new): the kernels ADD into it."""
+        import torch
+        if self._device_flat is not None and self._device_flat.device != device:
+            self.bring_home()
+        if self._device_flat is None:
+            self._device_flat = torch.zeros(self._flat.size, dtype=torch.float64, device=device)
+        return self._device_flat
+
+    def bring_home(self):
+        """Adds what the device holds to the host arrays (one copy, one sync)."""
+        if self._device_flat is not None:
+            import torch
+            # (the kernels may have run on any stream of that device)
+            torch.cuda.synchronize(self._device_flat.device)
+            self._flat += self._device_flat.cpu().numpy()
+            self._device_flat = None
+
+    def _part(self, name):
+        self.bring_home()
+        return self._views[name]
+
+    total2D = property(lambda self: self._part('total2D'),
+                       lambda self, v: self._part('total2D').__setitem__(Ellipsis, v))
+    total2D_RGB = property(lambda self: self._part('total2D_RGB'),
+                           lambda self, v: self._part('total2D_RGB').__setitem__(Ellipsis, v))
+
+    _COUNTERS = ('nRaysAll', 'iteration')
 
     def spawn(self):
         """An empty accumulator with this plot's settings (axes copied, limits as they are
@@ -81,11 +136,9 @@ class XYCPlot(object):
 
     def absorb(self, other):
         """Adds a worker's histograms and counters to this plot."""
-        self.total2D += other.total2D
-        self.total2D_RGB += other.total2D_RGB
-        for mine, theirs in ((self.xaxis, other.xaxis), (self.yaxis, other.yaxis),
-                             (self.caxis, other.caxis)):
-            mine.total1D4 += theirs.total1D4
+        other.bring_home()
+        self.bring_home()
+        self._flat += other._flat
         for name in self._COUNTERS:
             setattr(self, name, getattr(self, name) + getattr(other, name))
 
@@ -132,3 +185,17 @@ class XYCPlot(object):
                             self.xaxis.bins + 1),
                 np.linspace(self.yaxis.limits[0], self.yaxis.limits[1],
                             self.yaxis.bins + 1))
+
+
+def _counter_property(slot, integer):
+    def get(self):
+        v = self._part('counters')[slot]
+        return int(round(v)) if integer else float(v)
+
+    def put(self, value):
+        self._part('counters')[slot] = value
+    return property(get, put)
+
+
+for _name, _slot in XYCPlot._COUNTER_SLOTS.items():
+    setattr(XYCPlot, _name, _counter_property(_slot, _name.startswith('nRays')))

@@ -54,22 +54,20 @@ def accumulate_plot(plot, beams):
         if hi <= lo:
             lo, hi = lo - 0.5, hi + 0.5
         cax.limits = [lo, hi]
-    nx, ny, nc = plot.xaxis.bins, plot.yaxis.bins, cax.bins
-    # all results of the call in ONE device buffer: one memset, one copy back, one sync
-    sizes = (ny * nx, ny * nx * 3, nx * 4, ny * 4, nc * 4, 8)
-    flat = torch.zeros(sum(sizes), dtype=torch.float64, device=dev)
-    hist, hist_rgb, hx, hy, hc, counters = torch.split(flat, sizes)
+    # all results of the call go into ONE device buffer, the plot's own accumulator: no memset,
+    # no copy back, no sync per iteration (the plot brings it home when it is read)
+    flat = plot.device_accumulator(dev)
+    hist, hist_rgb, hx, hy, hc, counters = torch.split(flat, plot.part_sizes())
     srcw = beam.nrays * beam.sourceWeight if hasattr(beam, 'sourceWeight') else 1.
     state_beam = beam if plot.beamState is None else beams[plot.beamState]
     s = beam.to_struct(dev)
-    keep = None
     if state_beam is not beam:
         # the struct is the beam's cached one: the other beam's state goes into a
-        # private copy of it, alive for this call only
+        # private copy of it, alive for this call only (the state tensor itself is the
+        # other beam's; the launch is ordered on this stream)
         cached, s = s, _structs.Beam()
         ctypes.memmove(ctypes.byref(s), ctypes.byref(cached), ctypes.sizeof(s))
-        keep = state_beam.dev('state', dev)
-        s.state = keep.data_ptr()
+        s.state = state_beam.dev('state', dev).data_ptr()
     P = _structs.Plot()
     P.x_factor, P.y_factor, P.c_factor = (float(plot.xaxis.factor),
                                           float(plot.yaxis.factor), float(cax.factor))
@@ -78,7 +76,7 @@ def accumulate_plot(plot, beams):
         lim[0], lim[1] = float(axis.limits[0]), float(axis.limits[1])
     P.color_factor = float(plot.colorFactor)
     P.color_saturation = float(plot.colorSaturation)
-    P.bins_x, P.bins_y, P.bins_c = nx, ny, nc
+    P.bins_x, P.bins_y, P.bins_c = plot.xaxis.bins, plot.yaxis.bins, cax.bins
     P.ray_flags, P.flux_kind = plot.ray_flag_mask, plot.flux_kind_code
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     _lib.check(lib.xrt_hip_plot_hist_f64_dev(
@@ -86,24 +84,7 @@ def accumulate_plot(plot, beams):
         ptr(hist_rgb), ptr(hx), ptr(hy), ptr(hc) if plot.ePos else None, ptr(counters),
         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
         'xrt_hip_plot_hist_f64_dev')
-    host = flat.cpu().numpy()                        # (a sync: `keep` outlives the kernel)
-    del keep
-    hist, hist_rgb, hx, hy, hc, c = np.split(host, np.cumsum(sizes)[:-1])
-    plot.total2D_RGB += hist_rgb.reshape(ny, nx, 3)
-    plot.xaxis.total1D4 += hx.reshape(nx, 4)
-    plot.yaxis.total1D4 += hy.reshape(ny, 4)
-    if plot.ePos:
-        cax.total1D4 += hc.reshape(nc, 4)
-    plot.total2D += hist.reshape(ny, nx)
     plot.nRaysAll += beam.nrays
-    plot.nRaysSelected += int(c[0])
-    plot.intensity += float(c[1])
-    plot.intensityInRange += float(c[2])
-    plot.nRaysAlive += int(c[3])
-    plot.nRaysGood += int(c[4])
-    plot.nRaysOut += int(c[5])
-    plot.nRaysOver += int(c[6])
-    plot.nRaysDead += int(c[7])
     plot.iteration += 1
 
 
