@@ -539,17 +539,19 @@ def bench_undulator(with_cpu=True):
                       'build_I_map)', rays=n, nodes=nodes, ms=ms,
                value=n * nodes / ms * 1e3, unit='ray-nodes/s', dtype='f64')
     # Static count from the gfx950 ISA of und_imap<0>'s node loop: 86 flop
-    # (37 mul + 23 add + 13 fma as the reference writes them) in 63 VALU instructions since
-    # round 3 (one of them v_rcp_f64, a quarter-rate instruction: 66 issue slots): the sum
-    # of krel keeps the reference's roundings, the products behind it are fused.
-    flop, slots = 86, 66
+    # (37 mul + 23 add + 13 fma as the reference writes them) in 50 VALU instructions for a
+    # planar undulator (Kx = 0: every term with Kx in it is an exact zero added to something
+    # and is left out, same bits; 60 with both fields; 81 in round 2), one of them v_rcp_f64,
+    # a quarter-rate instruction: 53 issue slots. The sum of krel keeps the reference's
+    # roundings, the products behind it are fused.
+    flop, slots = 86, 53
     tf = flop * n * nodes / ms * 1e3 / 1e12
     res['roofline'] = dict(
         bound='valu_fp64', kernel='und_imap', achieved=tf, peak=78.6, unit='TFLOP/s',
         frac=tf / 78.6, traffic=None,
         note='%d flop / %d VALU issue slots per ray-node; issue-slot use = %.2f of the '
-             '3.93e13 lane-slots/s of 256 CUs x 4 SIMDs at 2.4 GHz; 64 B of HBM traffic '
-             'per ray' % (flop, slots, slots * n * nodes / ms * 1e3 / 3.93e13))
+             '3.93e13 lane-slots/s of 256 CUs x 4 SIMDs at 2.4 GHz (fp64-dense code runs at '
+             '2.0-2.15 GHz: tools/probes/probe_fp64_rates.hip); 64 B of HBM traffic per ray' % (flop, slots, slots * n * nodes / ms * 1e3 / 3.93e13))
     if with_cpu:
         from oracle import undulator_np as un
         m = 100_000

@@ -745,7 +745,22 @@ class NESWSource(MeshSource):
         return bo
 
 
-from .undulator import Undulator  # noqa: E402,F401  (needs Beam from this module)
-from .fieldsource import SourceFromField  # noqa: E402,F401
-from .bendsource import BendingMagnet, Wiggler  # noqa: E402,F401
-from .gaussbeam import GaussianBeam, LaguerreGaussianBeam, HermiteGaussianBeam  # noqa: E402,F401
+# The source classes that live in modules of their own (they need Beam from this one) are
+# re-exported on first use, so that each of those modules can also be imported first.
+_LAZY = {'Undulator': 'undulator', 'SourceFromField': 'fieldsource',
+         'BendingMagnet': 'bendsource', 'Wiggler': 'bendsource',
+         'GaussianBeam': 'gaussbeam', 'LaguerreGaussianBeam': 'gaussbeam',
+         'HermiteGaussianBeam': 'gaussbeam'}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+        value = getattr(importlib.import_module('.' + _LAZY[name], __package__), name)
+        globals()[name] = value
+        return value
+    raise AttributeError('module %r has no attribute %r' % (__name__, name))
+
+
+def __dir__():
+    return sorted(set(globals()) | set(_LAZY))

@@ -324,7 +324,9 @@ struct SinCosTabRegs {
 // itself, k r ~ 4e11 rad, is only known to 6e-5 rad), and the byte offset of the entry
 // is ONE instruction: an SDWA shift whose 16-bit destination keeps exactly the 12 index
 // bits times 16.
-template <int N = SINCOS_TAB_N>
+// LEAN (N = 2048): cos theta without its theta^4 term, 2.3e-13 absolute -- for sums that are
+// compared at 1e-9.
+template <int N = SINCOS_TAB_N, bool LEAN = false>
 __device__ __forceinline__ void sincos_tab(double phi, const double2* tab,
                                            const SinCosTabRegs<N>& k, double& sn,
                                            double& cs) {
@@ -356,7 +358,7 @@ __device__ __forceinline__ void sincos_tab(double phi, const double2* tab,
   u = fma_(phi, STEPS_PER_RAD_LO, u);
   const double w = u * u;
   const double s = fma_(S1, w, k.s0) * u;
-  const double c = N == 2048 ? fma_(fma_(C2, w, k.c1), w, 1.0) : fma_(k.c1, w, 1.0);
+  const double c = N == 2048 && !LEAN ? fma_(fma_(C2, w, k.c1), w, 1.0) : fma_(k.c1, w, 1.0);
   cs = T.x * c;
   cs = fma_(-T.y, s, cs);
   sn = T.y * c;

@@ -84,8 +84,24 @@ __device__ __forceinline__ double div_known(double a, double b, double y) {
   return fma_(r, y, q);
 }
 
-// The per-ray sum; returns wu/γ·Σ (synchr.py:2038).
-template <int MODE>
+// sincos of a node phase: SAFE = the caller has bounded every phase of the wave's rays below
+// 2^42 (sincos_tab's range), so the loop body has no branch
+template <bool SAFE>
+__device__ __forceinline__ void sincos_node(double phi, const double2* tab,
+                                            const SinCosTabRegs<>& k, double& sn, double& cs) {
+  if (SAFE)
+    sincos_tab<SINCOS_TAB_N, true>(phi, tab, k, sn, cs);
+  else
+    sincos_any(phi, tab, k, sn, cs);
+}
+
+// The per-ray sum; returns wu/γ·Σ (synchr.py:2038). The record of node j + 1 is requested
+// (scalar loads: the address is wave-uniform) before node j is worked on: the loop used to
+// wait for its record at the top of every node.
+// PLANAR: Kx = 0 (the usual undulator). Every term with Kx in it is then an exact zero that is
+// added to or subtracted from something: leaving those operations out gives the same bits
+// (x + 0 = x, fma(0, y, x) = x) with nine instructions per node less.
+template <int MODE, bool SAFE, bool PLANAR>
 __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __restrict__ rec,
                                         const double2* tab, double g, double wu, double w,
                                         double ww1, double phi, double psi, double2& out_s,
@@ -127,17 +143,24 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
   const int nper = (MODE == UND_FAR) ? 1 : a.nper;
   for (int ip = 0; ip < nper; ++ip) {
     const double z0 = (double)(-(nper - 1)) * PI_ + (double)ip * PI2_;
-    const double* __restrict__ r = rec;
-    for (int64_t j = 0; j < a.jend; ++j, r += N_REC) {
+    const double* __restrict__ ahead = rec;
+    double r[N_REC], rn[N_REC];
+#pragma unroll
+    for (int k = 0; k < N_PAD0; ++k) r[k] = ahead[k];
+    for (int64_t j = 0; j < a.jend; ++j) {
+      if (j + 1 < a.jend) ahead += N_REC;
+#pragma unroll
+      for (int k = 0; k < N_PAD0; ++k) rn[k] = ahead[k];
       const double tg = r[N_TG], ag = r[N_AG], s = r[N_S], c = r[N_C];
-      const double sp = r[N_SPH], cp = r[N_CPH];
+      const double sp = PLANAR ? 0. : r[N_SPH], cp = PLANAR ? 0. : r[N_CPH];
       double er, ei, betax, bPx, bPz;
-      const double bPy = r[N_BPY];
+      const double bPy = PLANAR ? 0. : r[N_BPY];
       if (MODE == UND_FAR) {
 #pragma clang fp contract(fast)
-        double A = (nky_dx * s + kx_dy * sp) + e8 * r[N_SUM2];
+        double A = PLANAR ? nky_dx * s + e8 * r[N_SUM2]
+                          : (nky_dx * s + kx_dy * sp) + e8 * r[N_SUM2];
         double ucos = ww1 * tg + wwug * A;
-        sincos_any(ucos, tab, kreg, ei, er);
+        sincos_node<SAFE>(ucos, tab, kreg, ei, er);
         betax = kyg * c;
         bPx = r[N_BPX];
         bPz = h2 * r[N_SUM2];
@@ -149,12 +172,15 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
         double u2 = (zloc * zloc + r[N_C2]) + zloc * s2x;     // wave-uniform
         double T1 = nky_dx * (s + aw * u1);
         double T2 = kx_dy * s;                                // sic: sintg, not sintgph
-        double T3 = e8 * (r[N_KX2S2XPH] + ky2 * (s2x - aw2 * u2));
-        double ucos = ww1 * zloc + wwug * ((T1 + T2) + T3);
-        sincos_any(ucos, tab, kreg, ei, er);
+        double T3 = PLANAR ? e8 * (ky2 * (s2x - aw2 * u2))
+                           : e8 * (r[N_KX2S2XPH] + ky2 * (s2x - aw2 * u2));
+        double ucos = ww1 * zloc + wwug * (PLANAR ? T1 + T3 : (T1 + T2) + T3);
+        sincos_node<SAFE>(ucos, tab, kreg, ei, er);
         betax = ((taperC * Ky) * revg) * c;
         bPx = (-Ky) * (a.alpha_s * c + taperC * s);
-        bPz = h2 * ((ky2 * taperC) * (a.alpha_s * r[N_C2] + taperC * s2x) + r[N_KX2S2XPH]);
+        bPz = PLANAR ? h2 * ((ky2 * taperC) * (a.alpha_s * r[N_C2] + taperC * s2x))
+                     : h2 * ((ky2 * taperC) * (a.alpha_s * r[N_C2] + taperC * s2x) +
+                             r[N_KX2S2XPH]);
       } else {
         const double zloc = z0 + tg;
         double zterm = (0.5 * r[N_SUM2]) * revg;
@@ -162,13 +188,13 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
         double rx = (Ky * s) * revg;
         double ry = (Kx * sp) * revg;
         double rz = betam * zloc - q4;
-        double drx = r0x - rx, dry = r0y - ry, drz = r0zv - rz;
+        double drx = r0x - rx, dry = PLANAR ? r0y : r0y - ry, drz = r0zv - rz;
         double dxy = drx * drx + dry * dry;
         double dist = __builtin_sqrt(dxy + drz * drz);
         double drs = (0.5 * dxy) / drz;
         double sz, cz, sd, cd;
-        sincos_any((wwu * zloc) * omb, tab, kreg, sz, cz);
-        sincos_any(wwu * (drs + q4), tab, kreg, sd, cd);
+        sincos_node<SAFE>((wwu * zloc) * omb, tab, kreg, sz, cz);
+        sincos_node<SAFE>(wwu * (drs + q4), tab, kreg, sd, cd);
         er = ((((-sr0) * sz) * cd - (sr0 * cz) * sd) - (cr0 * sz) * sd) + (cr0 * cz) * cd;
         ei = ((((-sr0) * sz) * sd + (sr0 * cz) * cd) + (cr0 * sz) * cd) + (cr0 * cz) * sd;
         dirx = drx / dist;
@@ -178,13 +204,19 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
         bPx = r[N_BPX];
         bPz = h2 * r[N_SUM2];
       }
-      const double betay = nkxg * cp;
+      const double betay = PLANAR ? 0. : nkxg * cp;
       // krel = 1 - n.beta ~ 3e-8: eight digits cancel and it enters squared -- its sum keeps
       // the reference's roundings. krel is an ordinary number (1e-9 .. 2): the division
       // without its range scaling, same bits (fp64_math.h).
-      const double betaz = 1. - 0.5 * ((revg2 + betax * betax) + betay * betay);
-      const double krel = ((1. - dirx * betax) - diry * betay) - dirz * betaz;
-      const double rkrel = div_rn(1., krel);
+      const double betaz = PLANAR ? 1. - 0.5 * (revg2 + betax * betax)
+                                  : 1. - 0.5 * ((revg2 + betax * betax) + betay * betay);
+      const double krel = PLANAR ? (1. - dirx * betax) - dirz * betaz
+                                 : ((1. - dirx * betax) - diry * betay) - dirz * betaz;
+      // 1/krel: the hardware seed (2^-24) and ONE Newton step = 2e-15 relative (profiles/
+      // r03_probe_fp64_seeds.txt); the correctly rounded quotient took four more instructions
+      // per node for digits that the 1e-9 the fields are held to does not see.
+      double rkrel = __builtin_amdgcn_rcp(krel);
+      rkrel = fma_(fma_(-krel, rkrel, 1.0), rkrel, rkrel);
       {
         // Fields are compared at 1e-5 (observed 1e-16 when every rounding of the reference
         // is reproduced): from here on products feeding sums are fused, a quarter of the
@@ -193,16 +225,18 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
         const double fac = ag * (rkrel * rkrel);
         er = er * fac;
         ei = ei * fac;
-        const double bnx = dirx - betax, bny = diry - betay, bnz = dirz - betaz;
-        const double nbp = (dirx * bPx + diry * bPy) + dirz * bPz;
+        const double bnx = dirx - betax, bny = PLANAR ? diry : diry - betay, bnz = dirz - betaz;
+        const double nbp = PLANAR ? dirx * bPx + dirz * bPz : (dirx * bPx + diry * bPy) + dirz * bPz;
         const double nbn = (dirx * bnx + diry * bny) + dirz * bnz;
         const double ts = bnx * nbp - bPx * nbn;
-        const double tp = bny * nbp - bPy * nbn;
+        const double tp = PLANAR ? bny * nbp : bny * nbp - bPy * nbn;
         bsr += er * ts;
         bsi += ei * ts;
         bpr += er * tp;
         bpi += ei * tp;
       }
+#pragma unroll
+      for (int k = 0; k < N_PAD0; ++k) r[k] = rn[k];
     }
   }
   const double f = wu * revg;
@@ -210,8 +244,43 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
   out_p = make_double2(f * bpr, f * bpi);
 }
 
+// An upper bound of every node phase of a ray (far field, tapered gap), from |sin|, |cos| <= 1
+// and |tg| <= pi: below 2^42 the table sincos serves the whole loop. The near field's second
+// phase has a quotient in it: no bound, the general form.
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__device__ __forceinline__ bool phases_small(const UndulatorArgs& a, double g, double wu,
+                                             double w, double ww1, double phi, double psi) {
+  if (MODE == UND_NF) return false;
+  const double kx2 = a.Kx * a.Kx, ky2 = a.Ky * a.Ky;
+  const double Z = (MODE == UND_FAR ? 1. : (double)a.nper) * PI_;
+  const double aw = MODE == UND_TAPER ? __builtin_fabs(a.alpha_s / wu) : 0.;
+  const double A = __builtin_fabs(a.Ky * phi) * (1. + aw * (2. + Z)) + __builtin_fabs(a.Kx * psi) +
+                   (0.125 / g) * (kx2 + ky2 * (1. + 2. * aw * ((Z * Z + 1.) + Z)));
+  const double bound = __builtin_fabs(ww1) * Z + __builtin_fabs((w / wu) / g) * A;
+  return bound < 0x1p42;      // (false for NaN)
+}
+
+// the per-ray sum with the loop form its wave qualifies for
+template <int MODE>
+__device__ __forceinline__ void und_ray_any(const UndulatorArgs& a,
+                                            const double* __restrict__ rec, const double2* tab,
+                                            double g, double wu, double w, double ww1, double phi,
+                                            double psi, double2& s, double2& p) {
+  // (the general sincos only with the general field: one loop less to keep in registers)
+  if (a.Kx == 0. && __all(phases_small<MODE>(a, g, wu, w, ww1, phi, psi)))
+    und_ray<MODE, true, true>(a, rec, tab, g, wu, w, ww1, phi, psi, s, p);
+  else if (__all(phases_small<MODE>(a, g, wu, w, ww1, phi, psi)))
+    und_ray<MODE, true, false>(a, rec, tab, g, wu, w, ww1, phi, psi, s, p);
+  else
+    und_ray<MODE, false, false>(a, rec, tab, g, wu, w, ww1, phi, psi, s, p);
+}
+
+// The kernels are persistent: UND_WAVES waves per SIMD (the launch is sized by the occupancy),
+// every block copies the sincos table once and walks over tiles of 256 rays. Four waves per
+// SIMD divide the 16 per SIMD of a 2^20-ray map evenly (five left a fifth of the last round).
+#define UND_WAVES 4      // (the multi-period modes: one less, their three loop forms need the registers)
+template <int MODE>
+__global__ void __launch_bounds__(256, MODE == UND_FAR ? UND_WAVES : UND_WAVES - 1)
 und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
         const double* __restrict__ gamma, const double* __restrict__ wu,
         const double* __restrict__ w, const double* __restrict__ ww1,
@@ -220,55 +289,82 @@ und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
   // (cos, sin) of 2048 steps per turn for the in-loop sincos, fp64_math.h
   __shared__ double2 tab[SINCOS_TAB_N];
   tab_fetch(tab, rec, a.jend);
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double2 s, p;
-  und_ray<MODE>(a, rec, tab, gamma[i], wu[i], w[i], ww1[i], ddphi[i], ddpsi[i], s, p);
-  Is[i] = s;
-  Ip[i] = p;
+  const int64_t tiles = (n + blockDim.x - 1) / blockDim.x;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t i = t * blockDim.x + threadIdx.x;
+    const int64_t k = i < n ? i : n - 1;      // (idle lanes repeat the last ray)
+    double2 s, p;
+    und_ray_any<MODE>(a, rec, tab, gamma[k], wu[k], w[k], ww1[k], ddphi[k], ddpsi[k], s, p);
+    if (i < n) {
+      Is[i] = s;
+      Ip[i] = p;
+    }
+  }
 }
 
 // Whole Undulator._build_I_map_conv (synchr.py:2050-2108) in one kernel: the
 // pre-factors wu, ww1, ab from (w, theta, psi, gamma), the sum, the harmonic
 // window and the Amp2Flux scaling. numpy's operation order throughout.
 template <int MODE>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MODE == UND_FAR ? UND_WAVES : UND_WAVES - 1)
 und_imap(UndulatorArgs a, UndulatorMap m, const double* __restrict__ rec, int64_t n,
          const double* __restrict__ w_, const double* __restrict__ theta,
          const double* __restrict__ psi_, const double* __restrict__ gamma_,
          double* __restrict__ I, double2* __restrict__ Es, double2* __restrict__ Ep) {
   __shared__ double2 tab[SINCOS_TAB_N];
   tab_fetch(tab, rec, a.jend);
-  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double w = w_[i], th = theta[i], ps = psi_[i];
-  const double g = gamma_ ? gamma_[i] : m.gamma0;
-  const double kx2 = a.Kx * a.Kx, ky2 = a.Ky * a.Ky;
-  const double g2 = g * g;
-  const double wu = ((((PI_ / m.L0) / g2) * 1.0) * (((2 * g2 - 1) - 0.5 * kx2) - 0.5 * ky2)) / E2WC_;
-  const double ww1 = (w * (((1. + 0.5 * kx2) + 0.5 * ky2) + g2 * (th * th + ps * ps))) /
-                     ((2. * g2) * wu);
-  double ab = (1. / PI2_) / wu;
-  if (MODE == UND_FAR) {
-    double s1, c1, s2, c2;
-    sincos_phase((PI_ * m.Np) * ww1, s1, c1);
-    sincos_phase(PI_ * ww1, s2, c2);
-    ab = (ab * s1) / s2;
+  const int64_t tiles = (n + blockDim.x - 1) / blockDim.x;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t i0 = t * blockDim.x + threadIdx.x;
+    const int64_t i = i0 < n ? i0 : n - 1;    // (idle lanes repeat the last ray)
+    const double w = w_[i], th = theta[i], ps = psi_[i];
+    const double g = gamma_ ? gamma_[i] : m.gamma0;
+    const double kx2 = a.Kx * a.Kx, ky2 = a.Ky * a.Ky;
+    const double g2 = g * g;
+    const double wu =
+        ((((PI_ / m.L0) / g2) * 1.0) * (((2 * g2 - 1) - 0.5 * kx2) - 0.5 * ky2)) / E2WC_;
+    const double ww1 = (w * (((1. + 0.5 * kx2) + 0.5 * ky2) + g2 * (th * th + ps * ps))) /
+                       ((2. * g2) * wu);
+    double ab = (1. / PI2_) / wu;
+    if (MODE == UND_FAR) {
+      double s1, c1, s2, c2;
+      sincos_phase((PI_ * m.Np) * ww1, s1, c1);
+      sincos_phase(PI_ * ww1, s2, c2);
+      ab = (ab * s1) / s2;
+    }
+    double2 s, p;
+    und_ray_any<MODE>(a, rec, tab, g, wu, w, ww1, th, ps, s, p);
+    if (m.has_harmonic && (ww1 > m.harmonic + 0.5 || ww1 < m.harmonic - 0.5)) {
+      s = make_double2(0., 0.);
+      p = make_double2(0., 0.);
+    }
+    const double bw = m.dist_bw ? 0.001 : 1. / w;
+    const double a2f = ((FINE_STR_ * bw) * m.eI) / SIE0_;
+    // |Es|^2 + |Ep|^2 (numpy: abs(.)**2 through hypot; the squares themselves agree to an ulp)
+    const double field = (s.x * s.x + s.y * s.y) + (p.x * p.x + p.y * p.y);
+    const double f = __builtin_sqrt(a2f) * ab;
+    if (i0 < n) {
+      I[i] = (((a2f * (ab * ab)) * 0.25) * (m.dstep * m.dstep)) * field;
+      Es[i] = make_double2(((f * s.x) * 0.5) * m.dstep, ((f * s.y) * 0.5) * m.dstep);
+      Ep[i] = make_double2(((f * p.x) * 0.5) * m.dstep, ((f * p.y) * 0.5) * m.dstep);
+    }
   }
-  double2 s, p;
-  und_ray<MODE>(a, rec, tab, g, wu, w, ww1, th, ps, s, p);
-  if (m.has_harmonic && (ww1 > m.harmonic + 0.5 || ww1 < m.harmonic - 0.5)) {
-    s = make_double2(0., 0.);
-    p = make_double2(0., 0.);
+}
+
+// blocks of a persistent launch: what fits the chip at once, or one per tile if that is less
+template <class K>
+static unsigned persistent_grid(K kernel, int64_t n) {
+  int dev = 0, cus = 256, per_cu = UND_WAVES;
+  if (hipGetDevice(&dev) == hipSuccess)
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess ||
+      per_cu < 1) {
+    (void)hipGetLastError();
+    per_cu = UND_WAVES;
   }
-  const double bw = m.dist_bw ? 0.001 : 1. / w;
-  const double a2f = ((FINE_STR_ * bw) * m.eI) / SIE0_;
-  const double as = hypot(s.x, s.y), ap = hypot(p.x, p.y);
-  const double field = as * as + ap * ap;
-  I[i] = (((a2f * (ab * ab)) * 0.25) * (m.dstep * m.dstep)) * field;
-  const double f = __builtin_sqrt(a2f) * ab;
-  Es[i] = make_double2(((f * s.x) * 0.5) * m.dstep, ((f * s.y) * 0.5) * m.dstep);
-  Ep[i] = make_double2(((f * p.x) * 0.5) * m.dstep, ((f * p.y) * 0.5) * m.dstep);
+  if (per_cu > UND_WAVES) per_cu = UND_WAVES;
+  const int64_t tiles = (n + 255) / 256, fit = (int64_t)cus * per_cu;
+  return (unsigned)(tiles < fit ? tiles : fit);
 }
 
 }  // namespace
@@ -445,21 +541,21 @@ hipError_t undulator_sum_launch(const UndulatorArgs& a, int64_t n, const double*
                                 double* Ip_ri, const void* workspace, hipStream_t st) {
   const double* rec = reinterpret_cast<const double*>(workspace);
   if (n <= 0) return hipSuccess;
-  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  dim3 block(256);
   double2* is = reinterpret_cast<double2*>(Is_ri);
   double2* ip = reinterpret_cast<double2*>(Ip_ri);
   switch (a.mode) {
     case UND_FAR:
-      hipLaunchKernelGGL(und_sum<UND_FAR>, grid, block, 0, st, a, rec, n, gamma, wu, w, ww1,
-                         ddphi, ddpsi, is, ip);
+      hipLaunchKernelGGL(und_sum<UND_FAR>, dim3(persistent_grid(und_sum<UND_FAR>, n)), block, 0,
+                         st, a, rec, n, gamma, wu, w, ww1, ddphi, ddpsi, is, ip);
       break;
     case UND_TAPER:
-      hipLaunchKernelGGL(und_sum<UND_TAPER>, grid, block, 0, st, a, rec, n, gamma, wu, w, ww1,
-                         ddphi, ddpsi, is, ip);
+      hipLaunchKernelGGL(und_sum<UND_TAPER>, dim3(persistent_grid(und_sum<UND_TAPER>, n)), block,
+                         0, st, a, rec, n, gamma, wu, w, ww1, ddphi, ddpsi, is, ip);
       break;
     case UND_NF:
-      hipLaunchKernelGGL(und_sum<UND_NF>, grid, block, 0, st, a, rec, n, gamma, wu, w, ww1,
-                         ddphi, ddpsi, is, ip);
+      hipLaunchKernelGGL(und_sum<UND_NF>, dim3(persistent_grid(und_sum<UND_NF>, n)), block, 0, st,
+                         a, rec, n, gamma, wu, w, ww1, ddphi, ddpsi, is, ip);
       break;
     default:
       return hipErrorInvalidValue;
@@ -473,21 +569,21 @@ hipError_t undulator_imap_launch(const UndulatorArgs& a, const UndulatorMap& m, 
                                  const void* workspace, hipStream_t st) {
   const double* rec = reinterpret_cast<const double*>(workspace);
   if (n <= 0) return hipSuccess;
-  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  dim3 block(256);
   double2* es = reinterpret_cast<double2*>(Es_ri);
   double2* ep = reinterpret_cast<double2*>(Ep_ri);
   switch (a.mode) {
     case UND_FAR:
-      hipLaunchKernelGGL(und_imap<UND_FAR>, grid, block, 0, st, a, m, rec, n, w, theta, psi,
-                         gamma, I, es, ep);
+      hipLaunchKernelGGL(und_imap<UND_FAR>, dim3(persistent_grid(und_imap<UND_FAR>, n)), block, 0,
+                         st, a, m, rec, n, w, theta, psi, gamma, I, es, ep);
       break;
     case UND_TAPER:
-      hipLaunchKernelGGL(und_imap<UND_TAPER>, grid, block, 0, st, a, m, rec, n, w, theta, psi,
-                         gamma, I, es, ep);
+      hipLaunchKernelGGL(und_imap<UND_TAPER>, dim3(persistent_grid(und_imap<UND_TAPER>, n)), block,
+                         0, st, a, m, rec, n, w, theta, psi, gamma, I, es, ep);
       break;
     case UND_NF:
-      hipLaunchKernelGGL(und_imap<UND_NF>, grid, block, 0, st, a, m, rec, n, w, theta, psi,
-                         gamma, I, es, ep);
+      hipLaunchKernelGGL(und_imap<UND_NF>, dim3(persistent_grid(und_imap<UND_NF>, n)), block, 0, st,
+                         a, m, rec, n, w, theta, psi, gamma, I, es, ep);
       break;
     default:
       return hipErrorInvalidValue;
