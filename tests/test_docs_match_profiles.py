@@ -34,8 +34,7 @@ def test_design_quotes_the_committed_profile():
     k4 = [v for (k, g), v in avg.items() if k == 'kirchhoff_stream<4>' and v[0] <= 12 and
           v[1] > 2e8]
     kg = [v for (k, g), v in avg.items() if k == 'kirchhoff_stream<4>' and g == 4515840]
-    und = [v for (k, g), v in avg.items() if k.startswith('und_imap<0>') and g >= 1 << 20]
-    assert len(cfg2) == len(dcm) == len(k4) == len(kg) == len(und) == 1
+    assert len(cfg2) == len(dcm) == len(k4) == len(kg) == 1
     checks = (
         (cfg2[0], r'rocprofv3 average over (\d+) launches \*\*([\d.]+) µs\*\*', 1e-3),
         (dcm[0], r'kernel \*\*([\d.]+) µs\*\* \(rocprofv3, (\d+) launches\)', 1e-3),
@@ -48,5 +47,10 @@ def test_design_quotes_the_committed_profile():
     assert abs(ms - k4[0][1] * 1e-6) < 0.06
     ms = quoted(text, r'grid 4515840, ([\d.]+) ms over (?:\d+) launches')
     assert abs(ms - kg[0][1] * 1e-6) < 0.006
-    us = quoted(text, r'`und_imap` 2\^20 rays × 48 nodes \*\*([\d.]+) µs')
-    assert abs(us - und[0][1] * 1e-3) < 0.06
+    # (the map kernel is a persistent launch: its grid no longer tells the 2^20-ray call from
+    # the others, so the document quotes the bench line of the profiled run)
+    import json
+    with open(os.path.join(ROOT, 'profiles', 'r03_bench_under_rocprof.json')) as f:
+        und_ms = json.load(f)['undulator']['ms']
+    ms = quoted(text, r'`und_imap` 2\^20 rays × 48 nodes \*\*([\d.]+) ms in\s+the bench')
+    assert abs(ms - und_ms) < 0.0006

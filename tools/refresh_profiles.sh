@@ -19,6 +19,10 @@ mkdir -p $O/summaries && cp profiles/r${RND}_kernel_stats.csv profiles/hbm_traff
 tail -c 600 $O/bench_under_rocprof.json | head -c 600; echo
 # SQ counters of the reflect kernels and the stand-alone probes the DESIGN quotes
 bash tools/pmc_reflect.sh > profiles/r${RND}_reflect_pmc.txt 2>&1
+bash tools/pmc_und.sh > profiles/r${RND}_und_pmc.txt 2>&1
+bash tools/prof_hist.sh > profiles/r${RND}_hist_kernels.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/probes/probe_fp64_rates.hip -o /tmp/probe_fp64_rates 2>/dev/null && \
+  timeout 300 /tmp/probe_fp64_rates > profiles/r${RND}_probe_fp64_rates.txt 2>&1
 for P in probe_stream probe_occupancy probe_atomics probe_fp64_seeds; do
   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/probes/$P.hip -o /tmp/$P 2>/dev/null && \
     timeout 300 /tmp/$P > profiles/r${RND}_$P.txt 2>&1
