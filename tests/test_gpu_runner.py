@@ -195,6 +195,43 @@ def test_histograms_of_two_million_rays_match_numpy():
     assert abs(zoom.intensityInRange - ref.sum()) <= 1e-10 * ref.sum()
 
 
+@pytest.mark.parametrize('bx,by,with_counters', [(50, 40, True), (140, 141, False),
+                                                 (300, 280, True), (1500, 1200, True)])
+def test_plain_2d_histogram_entry_point(bx, by, with_counters):
+    """xrt_hip_hist2d_f64_dev (one flux plane, no colour axis; what a plot without caxis needs):
+    the plane in the LDS of one block, sorted by tile (one plane per tile), and beyond the
+    tiles the sort takes; it ADDS into what it is given."""
+    import ctypes
+    import torch
+    from xrt_amd import _lib
+    n = 300_001
+    oe = workloads.cfg2_toroid()
+    gb, lb = oe.reflect(workloads.synthetic_rays(n, 3))
+    dev = torch.device('cuda', torch.cuda.current_device())
+    x, y = lb.dev('x', dev), lb.dev('y', dev)
+    hx, hy = np.array(lb.x), np.array(lb.y)
+    st = np.array(lb.state)
+    sel = (st == 1) | (st == 3)
+    xl = [float(hx[sel].min()), float(hx[sel].max())]
+    yl = [0.6 * float(hy[sel].min()), 0.6 * float(hy[sel].max())]
+    hist = torch.full((by, bx), 1.0, dtype=torch.float64, device=dev)
+    counters = torch.zeros(8, dtype=torch.float64, device=dev)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    _lib.check(_lib.load().xrt_hip_hist2d_f64_dev(
+        ctypes.byref(lb.to_struct(dev)), ptr(x), ptr(y), 1., 1., 1 | 4, 1, 2.5, bx, xl[0], xl[1],
+        by, yl[0], yl[1], ptr(hist), ptr(counters) if with_counters else None,
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'xrt_hip_hist2d_f64_dev')
+    w = 2.5 * np.array(lb.Jss)[sel]
+    ref = np.histogram2d(hy[sel], hx[sel], bins=[by, bx], range=[yl, xl], weights=w)[0]
+    got = hist.cpu().numpy() - 1.0
+    assert np.abs(got - ref).max() <= 1e-10 * ref.max()
+    if with_counters:
+        c = counters.cpu().numpy()
+        assert c[0] == sel.sum() and abs(c[1] - w.sum()) <= 1e-10 * w.sum()
+        assert abs(c[2] - ref.sum()) <= 1e-10 * ref.sum()
+        assert c[3] == (st > 0).sum() and c[4] == (st == 1).sum() and c[7] == (st < 0).sum()
+
+
 def test_plot_histograms_of_an_empty_selection():
     """No ray matches the ray flag: all histograms stay zero, counters count."""
     bl = build()
