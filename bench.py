@@ -115,7 +115,18 @@ def setup_dist(args):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        # a CPU-side group for waits during which the GPUs must stay free (the in-process
+        # multi-GPU leg: rank 0 drives every GPU while the others wait; an RCCL barrier would
+        # park a spinning kernel on each of them)
+        global CPU_GROUP
+        try:
+            CPU_GROUP = dist.new_group(backend='gloo')
+        except Exception:  # noqa: BLE001
+            CPU_GROUP = None
     return world, rank, local, dist
+
+
+CPU_GROUP = None
 
 
 def barrier(dist):
@@ -325,7 +336,7 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
     # (what waves.diffract does with devices = [...], multigpu.kirchhoff_devices): rank 0
     # drives all of them while the other ranks wait
     in_process = None
-    if world > 1:
+    if world > 1 and CPU_GROUP is not None:
         barrier(dist)
         if rank == 0:
             try:        # (a figure beside the main one: it must never take the line down)
@@ -351,6 +362,7 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
                                        'device 0')
             except Exception as e:  # noqa: BLE001
                 in_process = dict(error=repr(e))
+        dist.barrier(group=CPU_GROUP)       # (the other ranks wait here on the CPU)
         barrier(dist)
     res = dict(
         metric='Kirchhoff sample*pixel pairs/s', value=pairs * steps / dt,
