@@ -232,6 +232,26 @@ def test_plain_2d_histogram_entry_point(bx, by, with_counters):
         assert c[3] == (st > 0).sum() and c[4] == (st == 1).sum() and c[7] == (st < 0).sum()
 
 
+@pytest.mark.parametrize('n', [1, 63, 777, 1025, 5000])
+def test_small_beams_through_the_tile_sort(n):
+    """Fewer rays than one chunk / a ragged second chunk, 200 x 200 bins (sorted by tile), one
+    bin on the colour axis."""
+    oe = workloads.cfg2_toroid()
+    gb, lb = oe.reflect(workloads.synthetic_rays(n, 11))
+    plot = xrtp.XYCPlot('b', (1, 2, 3), xrtp.XYCAxis('x', 'mm', bins=200, limits=[-5., 5.]),
+                        xrtp.XYCAxis('y', 'mm', bins=200, limits=[-400., 400.]),
+                        caxis=xrtp.XYCAxis('energy', 'eV', bins=1, limits=[8000., 10000.]))
+    xrtr.accumulate_plot(plot, {'b': lb})
+    st = np.array(lb.state)
+    sel = (st >= 1) & (st <= 3)
+    flux = (np.array(lb.Jss) + np.array(lb.Jpp))[sel]
+    ref = np.histogram2d(np.array(lb.y)[sel], np.array(lb.x)[sel], bins=[200, 200],
+                         range=[[-400., 400.], [-5., 5.]], weights=flux)[0]
+    assert np.abs(plot.total2D - ref).max() <= 1e-10 * max(ref.max(), 1e-300)
+    assert plot.nRaysSelected == int(sel.sum()) and plot.nRaysAll == n
+    assert abs(plot.caxis.total1D4[0, 0] - flux.sum()) <= 1e-10 * max(flux.sum(), 1e-300)
+
+
 def test_plot_histograms_of_an_empty_selection():
     """No ray matches the ray flag: all histograms stay zero, counters count."""
     bl = build()
