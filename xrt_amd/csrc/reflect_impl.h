@@ -861,9 +861,15 @@ __device__ __forceinline__ void table_windows(const xrt_hip_material& M, double 
 
 // the same by the whole block: upper_bound(x) in a sorted table = number of entries <= x,
 // counted in parallel (a one-thread binary search is 20 dependent memory round trips)
+// (ub_lo / ub_hi: the same numbers in every thread's registers, so that the thread that goes on
+// with them does not read them back from memory)
 __device__ __forceinline__ void table_windows_block(const xrt_hip_material& M, double emin,
                                                     double emax, GStat* g,
-                                                    unsigned long long* lds_u) {
+                                                    unsigned long long* lds_u,
+                                                    int (&ub_lo)[XRT_HIP_MAX_ELEM],
+                                                    int (&ub_hi)[XRT_HIP_MAX_ELEM]) {
+#pragma unroll
+  for (int e = 0; e < XRT_HIP_MAX_ELEM; ++e) ub_lo[e] = ub_hi[e] = 0;
   if (M.kind == XRT_HIP_MAT_NONE || !(emin <= emax)) {
     if (threadIdx.x == 0) {
       g->emin = emin;
@@ -872,7 +878,9 @@ __device__ __forceinline__ void table_windows_block(const xrt_hip_material& M, d
     return;
   }
   auto faddu = [](unsigned long long u, unsigned long long v) { return u + v; };
-  for (int e = 0; e < M.nelem; ++e) {
+#pragma unroll
+  for (int e = 0; e < XRT_HIP_MAX_ELEM; ++e) {
+    if (e >= M.nelem) break;
     const double* tE = M.tab_E[e];
     const int n = M.tab_n[e];
     unsigned long long lo = 0, hi = 0;
@@ -881,11 +889,13 @@ __device__ __forceinline__ void table_windows_block(const xrt_hip_material& M, d
       lo += v <= emin;
       hi += v <= emax;
     }
-    lo = block_reduce(lo, faddu, lds_u);
-    hi = block_reduce(hi, faddu, lds_u);
+    // both counts in one reduction (they are below 2^32)
+    const unsigned long long both = block_reduce(lo << 32 | hi, faddu, lds_u);
+    ub_lo[e] = (int)(both >> 32);
+    ub_hi[e] = (int)(both & 0xffffffffu);
     if (threadIdx.x == 0) {
-      g->tab_lo[e] = (int)lo;
-      g->tab_hi[e] = (int)hi;
+      g->tab_lo[e] = ub_lo[e];
+      g->tab_hi[e] = ub_hi[e];
     }
   }
   if (threadIdx.x == 0) {
@@ -993,6 +1003,31 @@ __device__ __forceinline__ void decide_axis_body(const xrt_hip_pass& P,
   }
 }
 
+// One thread: the f1/f2 window of the pass (the table interval of the head ray's energy and its
+// two neighbours; rays outside it search the whole table, interp_f1f2) and the TabFast records,
+// from the upper bounds the block has counted. The window edges are fetched before the records
+// are built and stored, so that all table loads are one trip.
+__device__ __forceinline__ void decide_windows(const xrt_hip_material& M,
+                                               const int (&ub_lo)[XRT_HIP_MAX_ELEM],
+                                               const int (&ub_hi)[XRT_HIP_MAX_ELEM], GStat* g,
+                                               TabFast* tf) {
+  double wlo = -INFINITY, whi = INFINITY;
+#pragma unroll
+  for (int e = 0; e < XRT_HIP_MAX_ELEM; ++e) {
+    if (e >= M.nelem || M.kind == XRT_HIP_MAT_NONE) break;
+    const int n = M.tab_n[e];
+    const int lo = ub_lo[e] > 0 ? ub_lo[e] - 1 : 0;
+    const int hi = ub_hi[e] + 1 < n ? ub_hi[e] + 1 : n;
+    g->tab_lo[e] = lo;
+    g->tab_hi[e] = hi;
+    if (lo > 0) wlo = fmax(wlo, M.tab_E[e][lo - 1]);
+    if (hi < n) whi = fmin(whi, M.tab_E[e][hi]);
+  }
+  g->win_lo = wlo;     // one energy interval in which every element's window holds
+  g->win_hi = whi;
+  g->tab_fast = tab_fast_build(M, ub_lo, tf) ? tf : nullptr;
+}
+
 // ---------------------------------------------------------------------------
 // The optimistic single pass. The reference takes four decisions from the whole
 // batch before it moves a single ray: the bracketing axis (largest direction
@@ -1020,9 +1055,14 @@ __device__ __forceinline__ void decide_axis_body(const xrt_hip_pass& P,
 // what the optimistic pass assumes, from the head of the beam (one block of
 // REFLECT_BLOCK lanes). Returns false (and raises g->redo) when no ray of the head
 // enters: the exact sequence then does the pass.
+// ub_lo / ub_hi, dir0: what the DCM's decide kernel reuses (the counted upper bounds of the
+// head ray's energy in M's tables; the head ray's direction in the beam's frame)
 __device__ __forceinline__ bool decide_opt_body(const xrt_hip_pass& P, const xrt_hip_material& M,
                                                 const xrt_hip_beam& in, OptStat* slots,
-                                                GStat* g, unsigned long long* lds_u) {
+                                                GStat* g, unsigned long long* lds_u,
+                                                int (&ub_lo)[XRT_HIP_MAX_ELEM],
+                                                int (&ub_hi)[XRT_HIP_MAX_ELEM],
+                                                double (&dir0)[3]) {
   for (int k = threadIdx.x; k < REFLECT_OPT_SLOTS; k += blockDim.x) {
     slots[k].maxdz1 = 0;
     slots[k].maxdz2 = 0;
@@ -1053,24 +1093,27 @@ __device__ __forceinline__ bool decide_opt_body(const xrt_hip_pass& P, const xrt
     return false;
   }
   __syncthreads();                        // the reset precedes the window stores
+  // the two head rays the last step needs: requested now, used after the table has been counted
+  double a0 = 0., b0 = 0., c0 = 0., a1 = 0., b1 = 0., c1 = 0.;
+  if (threadIdx.x == 0) {
+    a0 = in.a[i0];
+    b0 = in.b[i0];
+    c0 = in.c[i0];
+    dir0[0] = a0;
+    dir0[1] = b0;
+    dir0[2] = c0;
+    if (i1 != ~0ull) {
+      a1 = in.a[i1];
+      b1 = in.b[i1];
+      c1 = in.c[i1];
+    }
+  }
   // f1/f2 window: the table interval of that ray's energy and its two neighbours; rays
   // outside it search the whole table (interp_f1f2)
   const double E0 = in.E[i0];
-  table_windows_block(M, E0, E0, g, lds_u);
+  table_windows_block(M, E0, E0, g, lds_u, ub_lo, ub_hi);
   if (threadIdx.x != 0) return true;
-  g->tab_fast = tab_fast_build(M, g->tab_lo, tab_fast_of(slots)) ? tab_fast_of(slots) : nullptr;
-  double wlo = -INFINITY, whi = INFINITY;
-  for (int e = 0; e < M.nelem && M.kind != XRT_HIP_MAT_NONE; ++e) {
-    const int n = M.tab_n[e];
-    const int lo = g->tab_lo[e] > 0 ? g->tab_lo[e] - 1 : 0;
-    const int hi = g->tab_hi[e] + 1 < n ? g->tab_hi[e] + 1 : n;
-    g->tab_lo[e] = lo;
-    g->tab_hi[e] = hi;
-    if (lo > 0) wlo = fmax(wlo, M.tab_E[e][lo - 1]);
-    if (hi < n) whi = fmin(whi, M.tab_E[e][hi]);
-  }
-  g->win_lo = wlo;     // one energy interval in which every element's window holds
-  g->win_hi = whi;
+  decide_windows(M, ub_lo, ub_hi, g, tab_fast_of(slots));
   // axis: the largest direction cosine of the first state-1 ray (y along a beamline, z at
   // normal incidence); every state-1 ray then checks that the same cosine strictly
   // dominates its own. No state-1 ray in the head: y, which is also what the reference
@@ -1078,12 +1121,10 @@ __device__ __forceinline__ bool decide_opt_body(const xrt_hip_pass& P, const xrt
   // further down still has to agree.
   int axis = 1;
   if (i1 != ~0ull) {
-    double a1 = in.a[i1], b1 = in.b[i1], c1 = in.c[i1];
     local_dir(P, a1, b1, c1);
     const double m1 = fmax(fmax(fabs(a1), fabs(b1)), fabs(c1));
     axis = m1 == fabs(a1) ? 0 : (m1 == fabs(b1) ? 1 : 2);
   }
-  double a0 = in.a[i0], b0 = in.b[i0], c0 = in.c[i0];
   local_dir(P, a0, b0, c0);
   const double comp0 = axis == 0 ? a0 : (axis == 1 ? b0 : c0);
   g->first_good = i0;
@@ -1106,8 +1147,10 @@ __device__ __forceinline__ bool decide_opt_body(const xrt_hip_pass& P, const xrt
 __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, double* part, GStat* g) {
   __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
+  int ub_lo[XRT_HIP_MAX_ELEM], ub_hi[XRT_HIP_MAX_ELEM];
+  double dir0[3] = {0., 0., 0.};
   // the (idle) partial-record area holds the report slots of the fused kernel
-  decide_opt_body(P, M, in, reinterpret_cast<OptStat*>(part), g, lds_u);
+  decide_opt_body(P, M, in, reinterpret_cast<OptStat*>(part), g, lds_u, ub_lo, ub_hi, dir0);
 }
 #endif
 
@@ -3524,28 +3567,33 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_dcm(
     g2->bar = 0;
     g2->hang = 0;
   }
-  const bool ok = decide_opt_body(P1, M1, in, reinterpret_cast<OptStat*>(part1), g1, lds_u);
+  int ub_lo[XRT_HIP_MAX_ELEM], ub_hi[XRT_HIP_MAX_ELEM];
+  double dir0[3] = {0., 0., 0.};
+  // (first_good of the first crystal = the head ray: its index comes back through g1, read by
+  // every thread after the barrier below; its direction through dir0 in thread 0)
+  const bool ok = decide_opt_body(P1, M1, in, reinterpret_cast<OptStat*>(part1), g1, lds_u, ub_lo,
+                                  ub_hi, dir0);
   if (!ok) return;     // g1->redo is up: dcm_exact does both passes
-  __syncthreads();
-  const int64_t i0 = (int64_t)g1->first_good;
-  const double E0 = in.E[i0];
-  table_windows_block(M2, E0, E0, g2, lds_u);
-  if (threadIdx.x != 0) return;
-  g2->tab_fast = tab_fast_build(M2, g2->tab_lo, tab_fast_of(part2)) ? tab_fast_of(part2) : nullptr;
-  double wlo = -INFINITY, whi = INFINITY;
-  for (int e = 0; e < M2.nelem && M2.kind != XRT_HIP_MAT_NONE; ++e) {
-    const int n = M2.tab_n[e];
-    const int lo = g2->tab_lo[e] > 0 ? g2->tab_lo[e] - 1 : 0;
-    const int hi = g2->tab_hi[e] + 1 < n ? g2->tab_hi[e] + 1 : n;
-    g2->tab_lo[e] = lo;
-    g2->tab_hi[e] = hi;
-    if (lo > 0) wlo = fmax(wlo, M2.tab_E[e][lo - 1]);
-    if (hi < n) whi = fmin(whi, M2.tab_E[e][hi]);
+  // the second crystal's tables are usually the first one's (one crystal cut twice): the
+  // counts then hold for it as they are
+  bool same = M2.kind == M1.kind && M2.nelem == M1.nelem;
+  for (int e = 0; e < M2.nelem && same; ++e)
+    same = M2.tab_E[e] == M1.tab_E[e] && M2.tab_n[e] == M1.tab_n[e];
+  if (!same) {
+    __syncthreads();
+    const int64_t i0 = (int64_t)g1->first_good;
+    const double E0 = in.E[i0];
+    table_windows_block(M2, E0, E0, g2, lds_u, ub_lo, ub_hi);
   }
-  g2->win_lo = wlo;
-  g2->win_hi = whi;
+  if (threadIdx.x != 0) return;
+  if (same) {
+    g2->emin = g1->emin;
+    g2->emax = g1->emax;
+  }
+  const int64_t i0 = (int64_t)g1->first_good;
+  decide_windows(M2, ub_lo, ub_hi, g2, tab_fast_of(part2));
   // the head ray mirrored at the first crystal's surface, seen from the second crystal
-  double a = in.a[i0], b = in.b[i0], c = in.c[i0];
+  double a = dir0[0], b = dir0[1], c = dir0[2];
   local_dir(P1, a, b, c);
   const double dn = a * P1.n_const[3] + b * P1.n_const[4] + c * P1.n_const[5];
   a -= 2. * dn * P1.n_const[3];
