@@ -644,6 +644,11 @@ typedef struct xrt_hip_undulator {
   double r0z;
   int64_t jend;
   const double *tg, *ag, *sintg, *costg, *sintgph, *costgph;
+  /* nonzero: `workspace` still holds the node records an earlier _dev call on this stream made
+   * from these tables, Kx, Ky and jend (Undulator.shine calls build_I_map many times with one
+   * set of tables): the pack launch in front of the sum is skipped */
+  int32_t workspace_packed;
+  int32_t reserved;
 } xrt_hip_undulator;
 
 /* bytes of device scratch the _dev entry point needs for `jend` nodes */

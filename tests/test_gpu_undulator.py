@@ -210,3 +210,44 @@ def test_custom_field_empty_and_bad_arguments():
     assert torch.all(Is == 0) and torch.all(Ip == 0)
     with pytest.raises(_lib.XrtHipError):
         hipcalls.custom_field(tabs, one, one, one, one, one, 1.0, R0=-5.)
+
+
+def test_node_records_are_packed_once_per_table_set(golden_dir):
+    """The workspace keeps the packed node records between calls with the same table tensors
+    (xrt_hip_undulator.workspace_packed); a table changed in place, other tensors, another K
+    or a custom-field call in between make the next call pack again."""
+    import torch
+    from xrt_amd import hipcalls
+    g = np.load(os.path.join(golden_dir, 'g9_undulator_far_planar.npz'))
+    dev = torch.device('cuda', torch.cuda.current_device())
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+    tabs = [up(g[k]) for k in ('tg', 'ag', 'sintg', 'costg', 'sintgph', 'costgph')]
+    rays = [up(g[k]) for k in ('gamma', 'wu', 'w', 'ww1', 'ddphi', 'ddpsi')]
+    Kx, Ky = float(g['Kx']), float(g['Ky'])
+
+    def run(tables, ky=Ky):
+        Is, Ip = hipcalls.undulator(0, Kx, ky, tables, *rays)
+        return Is.cpu().numpy(), Ip.cpu().numpy()
+
+    def packed():
+        ws = hipcalls.workspace(dev, 256, 'undulator')
+        return getattr(ws, '_xrt_packed', None)
+    first = run(tabs)
+    key = packed()
+    again = run(tabs)                                   # served from the packed records
+    assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+    assert packed()[1] == key[1]
+    # a table modified in place: version counter moves, the records are made again
+    tabs[1].mul_(2.)
+    doubled = run(tabs)
+    assert np.allclose(doubled[0], 2. * first[0], rtol=1e-13, atol=0)
+    tabs[1].mul_(0.5)
+    assert np.array_equal(run(tabs)[0], first[0])
+    # other tensor objects with other contents
+    other = [t.clone() for t in tabs]
+    other[1] *= 3.
+    assert np.allclose(run(other)[0], 3. * first[0], rtol=1e-13, atol=0)
+    assert np.array_equal(run(tabs)[0], first[0])
+    # another deflection parameter
+    assert not np.array_equal(run(tabs, ky=1.1 * Ky)[0], first[0])
+    assert np.array_equal(run(tabs)[0], first[0])

@@ -191,7 +191,9 @@ class Undulator(ctypes.Structure):
                 ('sintg', ctypes.c_void_p),
                 ('costg', ctypes.c_void_p),
                 ('sintgph', ctypes.c_void_p),
-                ('costgph', ctypes.c_void_p)]
+                ('costgph', ctypes.c_void_p),
+                ('workspace_packed', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
 
 
 class UndulatorMap(ctypes.Structure):

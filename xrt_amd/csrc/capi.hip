@@ -747,7 +747,7 @@ int xrt_hip_undulator_f64_dev(const xrt_hip_undulator* u, int64_t nrays, const d
     return fail(XRT_HIP_ERR_ARG, "workspace too small: %zu < %zu", workspace_bytes,
                 xrt_hip_undulator_workspace_bytes(u->jend));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  HIP_TRY(xrt::undulator_pack_launch(*u, workspace, st));
+  if (!u->workspace_packed) HIP_TRY(xrt::undulator_pack_launch(*u, workspace, st));
   if (!kernel_ms) {
     HIP_TRY(xrt::undulator_sum_launch(*u, nrays, gamma, wu, w, ww1, ddphi, ddpsi, Is_ri, Ip_ri,
                                       workspace, st));
@@ -785,7 +785,7 @@ int xrt_hip_undulator_imap_f64_dev(const xrt_hip_undulator* u, const xrt_hip_und
     return fail(XRT_HIP_ERR_ARG, "workspace too small: %zu < %zu", workspace_bytes,
                 xrt_hip_undulator_workspace_bytes(u->jend));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  HIP_TRY(xrt::undulator_pack_launch(*u, workspace, st));
+  if (!u->workspace_packed) HIP_TRY(xrt::undulator_pack_launch(*u, workspace, st));
   HIP_TRY(xrt::undulator_imap_launch(*u, *m, nrays, w, theta, psi, gamma, I, Es_ri, Ep_ri,
                                      workspace, st));
   return XRT_HIP_OK;

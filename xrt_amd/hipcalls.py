@@ -54,6 +54,19 @@ def workspace(device, nbytes, tag='default'):
     return ws
 
 
+def packed_workspace(device, nbytes, tables, scalars):
+    """The undulator workspace and whether it still holds the node records of *tables* (the
+    same tensor objects, unmodified since: identity and version counters) with *scalars*."""
+    import weakref
+    ws = workspace(device, nbytes, 'undulator')
+    was = getattr(ws, '_xrt_packed', None)
+    versions = tuple(t._version for t in tables)
+    same = was is not None and was[1] == versions and was[2] == scalars and \
+        len(was[0]) == len(tables) and all(r() is t for r, t in zip(was[0], tables))
+    ws._xrt_packed = (tuple(weakref.ref(t) for t in tables), versions, scalars)
+    return ws, same
+
+
 def kirchhoff_plan(npix, ns, nsplit=0, ppt=0):
     lib = _lib.load()
     wsb = ctypes.c_size_t(0)
@@ -194,7 +207,8 @@ def undulator(mode, Kx, Ky, tables, gamma, wu, w, ww1, ddphi, ddpsi, nper=1,
                        tables):
         setattr(u, name, _f64(t, jend, name).value)
     wsb = lib.xrt_hip_undulator_workspace_bytes(jend)
-    ws = workspace(dev, wsb, 'undulator')
+    ws, packed = packed_workspace(dev, wsb, tables, (u.Kx, u.Ky, jend))
+    u.workspace_packed = 1 if packed else 0
     ms = ctypes.c_float(0.)
     with torch.cuda.device(dev):
         rc = lib.xrt_hip_undulator_f64_dev(
@@ -240,7 +254,8 @@ def undulator_imap(mode, Kx, Ky, tables, w, theta, psi, L0, Np, gamma0, eI, dste
     Es = torch.empty(n, dtype=torch.complex128, device=dev)
     Ep = torch.empty(n, dtype=torch.complex128, device=dev)
     wsb = lib.xrt_hip_undulator_workspace_bytes(u.jend)
-    ws = workspace(dev, wsb, 'undulator')
+    ws, packed = packed_workspace(dev, wsb, tables, (u.Kx, u.Ky, int(u.jend)))
+    u.workspace_packed = 1 if packed else 0
     with torch.cuda.device(dev):
         rc = lib.xrt_hip_undulator_imap_f64_dev(
             ctypes.byref(u), ctypes.byref(m), n, _f64(w, n, 'w'),
@@ -337,6 +352,7 @@ def custom_field(tables, emcg, gamma, w, ddphi, ddpsi, betam, filament=False, R0
     Ip = torch.empty(n, dtype=torch.complex128, device=dev)
     wsb = lib.xrt_hip_undulator_workspace_bytes(jend)
     ws = workspace(dev, wsb, 'undulator')
+    ws._xrt_packed = None          # (its records replace the undulator's)
     ms = ctypes.c_float(0.)
     with torch.cuda.device(dev):
         rc = lib.xrt_hip_custom_field_f64_dev(
