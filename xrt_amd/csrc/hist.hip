@@ -480,15 +480,22 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_hist_tiles(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   // the chunks of the slice: slice, slice + S, ...; wave w takes them HIST_GROUP at a time
   const int64_t mine = slice < nchunks ? (nchunks - slice + H.slices - 1) / H.slices : 0;
-  for (int64_t j0 = (int64_t)wave * HIST_GROUP; j0 < mine; j0 += (int64_t)nwaves * HIST_GROUP) {
-    // lanes 0..3 fetch the run of one chunk each; everybody gets all four
-    int64_t c_l = -1;
-    unsigned s_l = 0, e_l = 0;
+  // lanes 0..3 fetch the run of one chunk each (everybody gets all four below); the runs of the
+  // NEXT group are requested before this group's records are
+  auto runs_of = [&](int64_t j0, int64_t& c_l, unsigned& s_l, unsigned& e_l) {
+    c_l = -1;
+    s_l = e_l = 0;
     if (lane < HIST_GROUP && j0 + lane < mine) {
       c_l = slice + (j0 + lane) * H.slices;
       s_l = R.start[c_l * (T + 2) + tile];
       e_l = R.start[c_l * (T + 2) + tile + 1];
     }
+  };
+  int64_t c_l, c_n;
+  unsigned s_l, e_l, s_n, e_n;
+  runs_of((int64_t)wave * HIST_GROUP, c_l, s_l, e_l);
+  for (int64_t j0 = (int64_t)wave * HIST_GROUP; j0 < mine; j0 += (int64_t)nwaves * HIST_GROUP) {
+    runs_of(j0 + (int64_t)nwaves * HIST_GROUP, c_n, s_n, e_n);
     int64_t base[HIST_GROUP];
     int upto[HIST_GROUP];
     int total = 0;
@@ -528,6 +535,9 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_hist_tiles(
         if (w[u] != 0.) atomicAdd(&cells[cell[u]], w[u]);
       }
     }
+    c_l = c_n;
+    s_l = s_n;
+    e_l = e_n;
   }
   __syncthreads();
   // the tile into this slice's copy of the planes, [slice][chan][by][bx]
