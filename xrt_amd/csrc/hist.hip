@@ -604,6 +604,21 @@ __global__ __launch_bounds__(256) void plot_hist_reduce(
   }
 }
 
+// The scratch of a call comes from the device's stream-ordered pool, which by default hands its
+// memory back at every synchronisation: a plot per iteration would allocate a quarter of a
+// gigabyte from the driver each time (0.15 ms). Once per device: keep it.
+static void keep_pool_memory(int dev) {
+  static bool done[64] = {};
+  if (dev < 0 || dev >= 64 || done[dev]) return;
+  done[dev] = true;
+  hipMemPool_t pool = nullptr;
+  if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+    uint64_t keep = UINT64_MAX;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+  }
+  (void)hipGetLastError();
+}
+
 // the smallest number of tiles whose planes fit `budget` bytes of LDS
 static bool plan_tiles(int bx, int by, int nchan, size_t budget, int max_tiles, HistPlan& H) {
   int best = 0;
@@ -635,6 +650,7 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  keep_pool_memory(dev);
   const bool want_lines = hx || hy || hc || counters;
   // (the kernel keeps all three 1-D histograms; absent ones are dropped by the reduce)
   const size_t b1 = sizeof(double) * 4 * ((size_t)A.x.bins + A.y.bins + A.c.bins);
