@@ -580,10 +580,10 @@ class OE(object):
                           / reach)[0]))
         waveGlobal, waveLocal = self.reflect(aimed)        # HIP kernels
         state = waveLocal.dev('state', dev)
-        alive = (state == 1) | (state == 2)
+        alive = torch.nonzero((state == 1) | (state == 2)).squeeze(1)
         waveGlobal.filter_by_index(alive)
         waveLocal.filter_by_index(alive)
-        area *= int(alive.sum()) / float(len(x))           # (the one number that crosses back)
+        area *= int(alive.numel()) / float(len(x))         # (the one number that crosses back)
         waveLocal.area, waveLocal.areaNormal = area, area * tilt
         waveLocal.dS = area / float(len(x))
         waveLocal.toOE, waveLocal.parentId = self, self.uuid

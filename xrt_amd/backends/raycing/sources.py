@@ -163,8 +163,12 @@ class Beam(object):
         """Keeps the rays selected by *indarr* (sources/beams.py:296-318). With a mask that
         lives on the GPU the arrays are filtered there and stay there."""
         if isinstance(indarr, torch.Tensor) and indarr.is_cuda:
+            # a mask is turned into indices ONCE (one scan, one sync) and every array is
+            # gathered with them (one kernel each); index tensors are taken as they are, so
+            # that two beams filtered alike share the scan
+            index = torch.nonzero(indarr).squeeze(1) if indarr.dtype == torch.bool else indarr
             for name in self.array_fields():
-                kept = self.dev(name, indarr.device)[indarr]
+                kept = self.dev(name, indarr.device).index_select(0, index)
                 self._h.pop(name, None)
                 self._d[name] = kept
             self.__dict__.pop('_struct', None)
