@@ -160,7 +160,14 @@ class RectangularAperture(object):
         spans = [lim[1] - lim[0] for lim in (self.limOptX, self.limOptY)]
         px = draw[:, 0] * spans[0] + self.limOptX[0]
         pz = draw[:, 1] * spans[1] + self.limOptY[0]
-        py = np.zeros(count)
+        if torch.cuda.is_available():
+            # the points go up once; the wave is made and stays on the GPU (the same
+            # elementwise operations in the same order as with host arrays)
+            dev = torch.device('cuda', torch.cuda.current_device())
+            px, pz = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (px, pz))
+            py = torch.zeros(count, dtype=torch.float64, device=dev)
+        else:
+            py = np.zeros(count)
         there = raycing.along_basis((self.x, self.y, self.z), px, py, pz, self.center)
         opened = spans[0] * spans[1]
         return rw.receiving_wave(self, prevOE, (px, py, pz), there, opened / count,

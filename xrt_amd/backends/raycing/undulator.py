@@ -604,10 +604,13 @@ class Undulator(MeshFunctions):
         wave's points (reference: sybase.py:1470-1810)."""
         self._ready_to_shine()
         if wave is not None:
-            if not hasattr(wave, 'rDiffr'):
+            if 'rDiffr' not in wave.array_fields():
                 raise ValueError("If you want to use a `wave`, run a "
                                  "`prepare_wave` before shine!")
             self.uniformRayDensity = True
+            if all(k in wave._d for k in ('xDiffr', 'yDiffr', 'zDiffr')) and \
+                    not (self.pitch or self.yaw):
+                return self._shine_wave_on_device(wave, toGlobal, fixedEnergy, accuBeam)
         batch = len(wave.a) if wave is not None else self.nrays
         if self.uniformRayDensity:
             withAmplitudes = True
@@ -697,6 +700,109 @@ class Undulator(MeshFunctions):
         return out
 
 
+def _shine_wave_on_device(self, wave, toGlobal, fixedEnergy, accuBeam):
+    """``shine(wave=...)`` for a wave whose samples live on the GPU (what the apertures' and
+    elements' ``prepare_wave`` make): the random numbers are drawn on the host in the
+    reference's order and uploaded, everything else -- observation angles, the field map,
+    distances and directions, coherency matrix, the spherical phase, the source beam -- is
+    the host form's arithmetic as tensor operations in the same order (+, -, *, / and sqrt
+    round the same way on both sides; sybase.py:1470-1810)."""
+    dev = wave._d['xDiffr'].device
+    n = wave.nrays
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)  # noqa: E731
+    full = lambda v: torch.full((n,), float(v), dtype=torch.float64, device=dev)  # noqa: E731
+    el = self._draw_filament(accuBeam) if self.filamentBeam else None
+    seeded = (el['seeded'] if el is not None else np.int64(0)) + n
+    seededI = el['seededI'] if el is not None else 0.
+    # -- _draw_observation
+    if el is not None or fixedEnergy:
+        E_host = (fixedEnergy if fixedEnergy else el['E']) * np.ones(n)
+        E = full(E_host[0])
+    else:
+        E_host = np.random.rand(n) * float(self.E_max - self.E_min) + self.E_min
+        E = up(E_host)
+    self.xzE = (self.E_max - self.E_min)
+    xD, yD, zD = (wave._d[k] for k in ('xDiffr', 'yDiffr', 'zDiffr'))
+    if el is not None:
+        sx, sz = el['x'], el['z']
+    else:
+        sx = up(np.random.normal(0, self.dx, n)) if self.dx > 0 else 0
+        sz = up(np.random.normal(0, self.dz, n)) if self.dz > 0 else 0
+    x, z = xD + sx, zD + sz
+    r = torch.sqrt((x * x + yD * yD) + z * z)
+    theta, psi = x / r, z / r
+    if el is not None:
+        theta, psi = theta + el['xp'], psi + el['zp']
+    else:
+        if self.dxprime > 0:
+            theta = theta + up(np.random.normal(0, self.dxprime, n))
+        if self.dzprime > 0:
+            psi = psi + up(np.random.normal(0, self.dzprime, n))
+    # -- build_I_map (its energy-spread draw comes here in the order of calls)
+    gamma = None
+    if self.eEspread > 0:
+        g = self.gamma
+        if el is not None and el['dgamma'] is not None:
+            g = g + el['dgamma']
+        else:
+            g = g + g * self.eEspread * np.random.normal(size=1 if self.filamentBeam else n)
+        gamma = up(g * np.ones(n))
+    intensity, fs, fp = self.build_I_map_device(E, theta, psi, None, gamma)
+    seededI += n * self.xzE
+    top = float(intensity.max())
+    if top > self.Imax:
+        self.Imax = top
+        self.fluxConst = self.Imax * self.xzE
+    # -- the wave's samples as seen from the emission points
+    wave.state = torch.ones(n, dtype=torch.int32, device=dev)
+    wave.E = E
+    if el is not None:
+        px, pz = el['x'], el['z']
+    else:
+        wave.sourceSIGMAx, wave.sourceSIGMAz = self.get_SIGMA(E_host, onlyOddHarmonics=False)
+        px = up(np.random.normal(0, wave.sourceSIGMAx, n))
+        pz = up(np.random.normal(0, wave.sourceSIGMAz, n))
+    dx_, dz_ = xD - px, zD - pz
+    dist = torch.sqrt((dx_ * dx_ + yD * yD) + dz_ * dz_)
+    wave.rDiffr = dist
+    wave.path = torch.zeros(n, dtype=torch.float64, device=dev)
+    a, b, c = dx_ / dist, yD / dist, dz_ / dist
+    area = wave.areaNormal if hasattr(wave, 'areaNormal') else wave.area
+    spread = area**0.5 / dist                # field per sample area
+    fs, fp = fs * spread, fp * spread
+    # -- _set_polarisation with uniform ray density (no normalisation per ray)
+    wave.Jsp = fs * torch.conj(fp)
+    wave.Jss = (fs * torch.conj(fs)).real.contiguous()
+    wave.Jpp = (fp * torch.conj(fp)).real.contiguous()
+    wave.Es, wave.Ep = fs, fp
+    self._book_flux(wave, n, seeded, seededI, self.xzE / n, energy_sum=E_host.sum())
+    if el is not None:
+        wave.filamentDtheta, wave.filamentDpsi = el['xp'], el['zp']
+        wave.filamentDX, wave.filamentDZ = el['x'], el['z']
+        wave.filamentDgamma = el['dgamma']
+    length = torch.sqrt((a * a + b * b) + c * c)
+    wave.a, wave.b, wave.c = a / length, b / length, c / length
+    out = Beam(copyFrom=wave)
+    out.x = px if isinstance(px, torch.Tensor) else full(px)
+    out.y = torch.zeros(n, dtype=torch.float64, device=dev)
+    out.z = pz if isinstance(pz, torch.Tensor) else full(pz)
+    if self.R0 is None:     # far field: carry the spherical-wave phase
+        out.path = torch.zeros(n, dtype=torch.float64, device=dev)
+        # numpy's exp(1e7j E / CHBAR r): the argument is ((1e7 E) (1 / CHBAR)) r in its complex
+        # arithmetic, exp of a pure imaginary number is (cos, sin)
+        phi = ((1e7 * E) * (1. / CHBAR)) * dist
+        phase = torch.complex(torch.cos(phi), torch.sin(phi))
+        wave.Es, wave.Ep = fs * phase, fp * phase
+    out.parentId = self.uuid
+    if toGlobal:
+        undo = [(2, self.bl.cosAzimuth, -self.bl.sinAzimuth)] if self.bl.sinAzimuth != 0 else []
+        raycing.turn([out._d['a'], out._d['b'], out._d['c']], undo)
+        position = raycing.turn([out._d['x'], out._d['y'], out._d['z']], undo)
+        for coordinate, c0 in zip(position, self.center):
+            coordinate += c0
+    return out
+
+
 def _ready_to_shine(self):
     """Pending reset; the beamline's alignment energy defaults to the middle of the range."""
     if self.needReset:
@@ -708,10 +814,11 @@ def _ready_to_shine(self):
             self.bl._alignE = 0.5 * (self.eMin + self.eMax)
 
 
-def _book_flux(self, bo, length, seeded, seededI, weight):
+def _book_flux(self, bo, length, seeded, seededI, weight, energy_sum=None):
     """What the beam says about the flux it represents (the rays accepted of those seeded)."""
     bo.accepted, bo.acceptedE = (length * self.fluxConst,
-                                 bo.E.sum() * self.fluxConst * SIE0)
+                                 (bo.E.sum() if energy_sum is None else energy_sum) *
+                                 self.fluxConst * SIE0)
     bo.seeded, bo.seededI, bo.sourceWeight = seeded, seededI, weight
 
 
@@ -723,6 +830,7 @@ def _unit_directions(self, bo, length):
         raycing.rotate_beam(bo, pitch=self.pitch, yaw=self.yaw)
 
 
+Undulator._shine_wave_on_device = _shine_wave_on_device
 Undulator._ready_to_shine = _ready_to_shine
 Undulator._book_flux = _book_flux
 Undulator._unit_directions = _unit_directions

@@ -113,9 +113,13 @@ def prepare_wave(fromOE, wave, xglo, yglo, zglo):
 def receiving_wave(element, prevOE, local, glob, dS, area, parent):
     """Wave samples at the points *local* (x, y, z in the frame of *element*, which
     owns them) = *glob* in the global frame, bound to the diffracting *prevOE*."""
-    wave = rs.Beam(nrays=len(local[0]), forceState=1, withAmplitudes=True)
-    for name, values in zip('xyz', local):
-        getattr(wave, name)[:] = values
+    if isinstance(local[0], torch.Tensor):          # points that live on the GPU: so does the wave
+        wave = rs.Beam.on_device(local[0].numel(), local[0].device, withAmplitudes=True, state=1)
+        wave.x, wave.y, wave.z = local
+    else:
+        wave = rs.Beam(nrays=len(local[0]), forceState=1, withAmplitudes=True)
+        for name, values in zip('xyz', local):
+            getattr(wave, name)[:] = values
     wave.dS, wave.area, wave.toOE, wave.parentId = dS, area, element, parent
     return prepare_wave(prevOE, wave, *glob)
 
