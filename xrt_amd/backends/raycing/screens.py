@@ -76,10 +76,19 @@ class Screen(object):
         cell = 1. if None in steps else steps[0] * steps[1]
         if callable(condition):
             gx, gz = condition(gx, gz)
-        gy = np.zeros_like(gx) + dy
+        area = (np.ones_like(gx) * cell).sum()
+        if torch.cuda.is_available():
+            # the mesh goes up once; the wave is made and stays on the GPU (the same
+            # elementwise operations in the same order as with host arrays)
+            dev = torch.device('cuda', torch.cuda.current_device())
+            gx, gz = (torch.from_numpy(np.ascontiguousarray(g, dtype=np.float64)).to(dev)
+                      for g in (gx, gz))
+            gy = torch.zeros_like(gx) + dy
+        else:
+            gy = np.zeros_like(gx) + dy
         xg, yg, zg = self.local_to_global(x=gx, z=gz)
-        return rw.receiving_wave(self, prevOE, (gx, gy, gz), (xg, yg + dy, zg), cell,
-                                 (np.ones_like(gx) * cell).sum(), prevOE.uuid)
+        return rw.receiving_wave(self, prevOE, (gx, gy, gz), (xg, yg + dy, zg), cell, area,
+                                 prevOE.uuid)
 
 
 class HemisphericScreen(Screen):

@@ -8,6 +8,7 @@ the reference. Sign convention: the numpy path of the reference
 (``_diffraction_integral_conv``, +i k/4pi).
 """
 import ctypes
+import threading
 import time
 
 import numpy as np
@@ -223,13 +224,51 @@ def convex_hull_area(px, py):
     return 0.5 * abs(np.sum(x1*y2 - x2*y1))
 
 
-def convex_hull_area_on_device(px, py):
+_pinned = threading.local()
+
+
+def _later(tensor):
+    """Starts a copy of a small device tensor to the host that does not hold the host up;
+    -> a function that returns it as a numpy array (waiting for the copy if it has to)."""
+    n = tensor.numel()
+    pool = _pinned.__dict__.setdefault('buffers', {})
+    buf = pool.get(tensor.dtype)
+    if buf is None or buf.numel() < n:
+        buf = pool[tensor.dtype] = torch.empty(max(n, 4096), dtype=tensor.dtype, pin_memory=True)
+    view = buf[:n].view(tensor.shape)
+    view.copy_(tensor, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+
+    def fetch():
+        done.synchronize()
+        return view.numpy().copy()
+    return fetch
+
+
+def convex_hull_area_on_device(px, py, deferred=False):
     """The same area for points that live on the GPU: the polygon of the extremes in 64
     directions is found there and everything strictly inside it dropped there; the few points
-    that are left (every hull vertex is among them) go through the host's monotone chain."""
-    n = px.numel()
-    if n < 4096:
-        return convex_hull_area(px.cpu().numpy(), py.cpu().numpy())
+    that are left (every hull vertex is among them) go through the host's monotone chain.
+    *deferred*: -> a function that does the host part when it is called; the copy of the
+    candidates is under way meanwhile (waves.diffract calls it after it has launched the
+    integral, so that the GPU is busy while the host walks the chain)."""
+    keep = _hull_candidates(px, py) if px.numel() >= 4096 else None
+    both = torch.stack((px, py)) if keep is None else torch.stack((px[keep], py[keep]))
+    if deferred:
+        fetch = _later(both)
+
+        def area():
+            q = fetch()
+            return convex_hull_area(q[0], q[1])
+        return area
+    q = both.cpu().numpy()
+    return convex_hull_area(q[0], q[1])
+
+
+def _hull_candidates(px, py):
+    """Mask of the points that are not strictly inside the polygon of the extremes in 64
+    directions (None if that polygon is degenerate)."""
     ang = torch.arange(64, dtype=torch.float64, device=px.device) * (2 * np.pi / 64)
     proj = torch.cos(ang)[:, None] * px[None, :] + torch.sin(ang)[:, None] * py[None, :]
     pick = proj.argmax(dim=1)
@@ -241,14 +280,13 @@ def convex_hull_area_on_device(px, py):
     if len(corners) > 1 and corners[0] == corners[-1]:
         corners.pop()
     if len(corners) < 3:
-        return convex_hull_area(px.cpu().numpy(), py.cpu().numpy())
+        return None
     c = torch.tensor(corners, dtype=torch.float64, device=px.device)
     x1, y1 = c[:, 0], c[:, 1]
     x2, y2 = torch.roll(x1, -1), torch.roll(y1, -1)
     cross = (x2 - x1)[None, :] * (py[:, None] - y1[None, :]) - \
         (y2 - y1)[None, :] * (px[:, None] - x1[None, :])
-    keep = ~(cross > 0).all(dim=1)
-    return convex_hull_area(px[keep].cpu().numpy(), py[keep].cpu().numpy())
+    return ~(cross > 0).all(dim=1)
 
 
 def _kirchhoff_on_gpu(points, samples, targetOpenCL='auto'):
@@ -274,10 +312,12 @@ def _kirchhoff_on_gpu(points, samples, targetOpenCL='auto'):
 def _illuminated_area(oe, field):
     """Footprint of the lit samples on the diffracting element, for the flux
     normalisation: given by whoever made *field*, else the convex hull in the
-    element's surface coordinates (waves.py:642-670)."""
+    element's surface coordinates (waves.py:642-670). -> a function that returns the area:
+    the device part of the hull (which points can be vertices at all) is queued now, the
+    host part runs when the function is called."""
     area = getattr(field, 'area', None)
     if area is not None and area > 0:
-        return area
+        return lambda: area
     if hasattr(oe, 'rotationSequence'):
         second = 'y'                         # an optical element: (x, y)
     elif hasattr(oe, 'propagate') or hasattr(oe, 'prepare_wave') or \
@@ -285,15 +325,16 @@ def _illuminated_area(oe, field):
         second = 'z'                         # aperture / screen / source: (x, z)
     else:
         raise ValueError('Unknown diffracting element!')
+    fraction = getattr(field, 'areaFraction', None)
     if all(name in field._d for name in ('state', 'x', second)):
         lit = field._d['state'] == 1
-        area = convex_hull_area_on_device(field._d['x'][lit], field._d[second][lit])
+        hull = convex_hull_area_on_device(field._d['x'][lit], field._d[second][lit],
+                                          deferred=True)
     else:
         lit = field.peek('state') == 1
-        area = convex_hull_area(field.peek('x')[lit], field.peek(second)[lit])
-    if hasattr(field, 'areaFraction'):
-        area *= field.areaFraction
-    return area
+        px, py = field.peek('x')[lit], field.peek(second)[lit]
+        hull = lambda: convex_hull_area(px, py)     # noqa: E731
+    return hull if fraction is None else (lambda: hull() * fraction)
 
 
 def _element_pass(element, lib_pass=None):
@@ -384,7 +425,7 @@ def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
     if wave.nrays == 0 or 'xDiffr' not in wave.array_fields():
         print("No wave samples on {0}".format(oe.name))
         return rs.Beam(nlit)
-    oeLocal.area = _illuminated_area(oe, oeLocal)
+    footprint = _illuminated_area(oe, oeLocal)     # (started; finished behind the launch below)
     wave.diffract_repeats += 1
     wave.beamReflRays += nlit
     wave.beamReflSumJ += flux
@@ -402,6 +443,7 @@ def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
     wave_rec = wave.to_struct(dev)
     energy = oeLocal.dev('E', dev)
     fresh = _kirchhoff_on_gpu(points, samples, targetOpenCL)
+    oeLocal.area = footprint()       # the host's share of the hull, while the integral runs
     # Monte-Carlo weight of the integral: receiving cell x illuminated area x incoming flux
     # over (samples x obliquity-weighted flux x repeats), waves.py:735-749
     denom = wave.beamReflRays * wave.beamReflSumJnl * wave.diffract_repeats
