@@ -46,6 +46,13 @@ for a, b in zip(seg, seg[1:]):
     busy += a[2] - a[1]
 print('last run window: busy %.1f ms, idle %.1f ms, kernels %d' % (busy / 1e6, idle / 1e6, len(seg)))
 gaps.sort(reverse=True)
-for g, a, b in gaps[:25]:
+for g, a, b in gaps[:12]:
     print('%7.2f ms  after %-40s before %s' % (g / 1e6, a, b))
+from collections import Counter
+cnt = Counter(r[0].split('(')[0][-48:] for r in seg)
+tim = Counter()
+for r in seg:
+    tim[r[0].split('(')[0][-48:]] += r[2] - r[1]
+for name, k in cnt.most_common(16):
+    print('%5d x %-50s %8.2f ms' % (k, name, tim[name] / 1e6))
 PY
