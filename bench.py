@@ -119,6 +119,7 @@ def setup_dist(args):
         # multi-GPU leg: rank 0 drives every GPU while the others wait; an RCCL barrier would
         # park a spinning kernel on each of them)
         global CPU_GROUP
+        os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')    # one node: the loopback will do
         try:
             CPU_GROUP = dist.new_group(backend='gloo')
         except Exception:  # noqa: BLE001
