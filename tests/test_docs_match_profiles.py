@@ -54,3 +54,14 @@ def test_design_quotes_the_committed_profile():
         und_ms = json.load(f)['undulator']['ms']
     ms = quoted(text, r'`und_imap` 2\^20 rays × 48 nodes \*\*([\d.]+) ms in\s+the bench')
     assert abs(ms - und_ms) < 0.0006
+
+
+def test_profile_index_is_whole():
+    """profiles/README.md is the index that says which file backs which claim: it stays a
+    short table and names every file next to it (a refresh once blew it up to 17k lines,
+    VERDICT r3 weak #3)."""
+    pdir = os.path.join(ROOT, 'profiles')
+    text = open(os.path.join(pdir, 'README.md')).read()
+    assert len(text.splitlines()) < 200 and len(text) < 60_000
+    missing = [f for f in sorted(os.listdir(pdir)) if f != 'README.md' and f not in text]
+    assert not missing, missing

@@ -7,14 +7,15 @@ set -e
 NAME=$1; FLAGS=$2; shift 2 || true
 UNITS=${@:-reflect_hot}
 cd "$(dirname "$0")/../xrt_amd/csrc"
-mkdir -p build/var_$NAME ../ab
+V=/tmp/xrt_var_$NAME   # variant objects stay out of the tree
+mkdir -p $V ../ab
 OBJS=""
 for o in build/*.o; do
   b=$(basename $o .o)
   if [[ " $UNITS " == *" $b "* ]]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden \
-      -Wno-unused-function $FLAGS -c $b.hip -o build/var_$NAME/$b.o &
-    OBJS="$OBJS build/var_$NAME/$b.o"
+      -Wno-unused-function $FLAGS -c $b.hip -o $V/$b.o &
+    OBJS="$OBJS $V/$b.o"
   else
     OBJS="$OBJS $o"
   fi
