@@ -55,6 +55,7 @@ def parse():
     ap.add_argument('--skip-undulator', action='store_true')
     ap.add_argument('--skip-softimax', action='store_true')
     ap.add_argument('--skip-balder', action='store_true')
+    ap.add_argument('--skip-e2e', action='store_true')
     ap.add_argument('--skip-cpu-baseline', action='store_true')
     ap.add_argument('--with-softi-shapes', action='store_true',
                     help='also time the two Kirchhoff shapes of the reference\'s '
@@ -477,6 +478,80 @@ def bench_hist(nrays):
     return res
 
 
+def bench_e2e(nrays, repeats=20):
+    """One whole ``run_ray_tracing`` job, nothing resident beforehand: every iteration makes its
+    rays (GeometricSource on the device: csrc/source.hip), reflects them on the cfg2 toroid,
+    exposes a screen at the focus and adds the screen beam to one 256 x 256 XYCPlot (2-D flux +
+    RGB, three 1-D histograms); the reference's loop is xrt/runner.py:513-719. Reported: ms per
+    iteration by the host clock over *repeats* iterations, the GPU time of the same work
+    (HIP events around the four steps of separately instrumented iterations) and their ratio
+    = the fraction of the wall time the GPU is busy; beside it the same job with the host
+    source (numpy in the reference's RNG order, rays uploaded)."""
+    from xrt_amd import workloads, runner
+    from xrt_amd.backends.raycing import run as rr
+    bl, run_process, make_plot = workloads.e2e_beamline(nrays)
+    rr.run_process = run_process
+    runner.run_ray_tracing([make_plot()], repeats=3, beamLine=bl)           # warm up
+    torch.cuda.synchronize()
+    plot = make_plot()
+    t0 = time.perf_counter()
+    runner.run_ray_tracing([plot], repeats=repeats, beamLine=bl)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / repeats
+    t1 = time.perf_counter()
+    flux = float(plot.total2D.sum())
+    read_back = time.perf_counter() - t1
+    # GPU time per step of an iteration: events on the launch stream
+    steps = ('source', 'reflect', 'screen', 'histograms')
+    dev_ms = dict.fromkeys(steps, 0.)
+    probe = make_plot()
+    n_probe = 5
+    for _ in range(n_probe):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        src = bl.source.shine()
+        ev[1].record()
+        gb, lb = bl.mirror.reflect(src)
+        ev[2].record()
+        img = bl.screen.expose(gb)
+        ev[3].record()
+        runner.accumulate_plot(probe, {'focus': img})
+        ev[4].record()
+        torch.cuda.synchronize()
+        for k, name in enumerate(steps):
+            dev_ms[name] += ev[k].elapsed_time(ev[k + 1]) / n_probe
+    gpu_ms = sum(dev_ms.values())
+    res = dict(
+        metric='run_ray_tracing end to end: source -> toroid mirror -> screen -> XYCPlot, '
+               'rays/s', rays=nrays, repeats=repeats, ms_per_iteration=wall * 1e3,
+        value=nrays / wall, unit='rays/s', dtype='f64', source='device (Philox4x32-10)',
+        gpu_ms_per_iteration=gpu_ms, gpu_ms_by_step=dev_ms, gpu_busy=gpu_ms / (wall * 1e3),
+        read_back_ms_once=read_back * 1e3, flux_in_plot=flux,
+        bytes_per_ray=dict(source=100, reflect=308, screen=200, histograms=44),
+        roofline=dict(bound='hbm', kernel='the four steps of one iteration',
+                      achieved=652. * nrays / wall / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
+                      frac=652. * nrays / wall / HBM_PEAK, traffic=None,
+                      note='652 B per ray algorithmic: 100 written by the source, 308 by '
+                           'OE.reflect (SURVEY 8d), 200 by Screen.expose, 44 read by the plot'))
+    # the same job with the host source
+    blh, run_h, make_h = workloads.e2e_beamline(nrays, rng='host')
+    rr.run_process = run_h
+    np.random.seed(0)
+    hp = make_h()
+    runner.run_ray_tracing([hp], repeats=1, beamLine=blh)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    runner.run_ray_tracing([hp], repeats=2, beamLine=blh)
+    torch.cuda.synchronize()
+    host_wall = (time.perf_counter() - t0) / 2
+    res['host_source'] = dict(ms_per_iteration=host_wall * 1e3, value=nrays / host_wall,
+                              note='GeometricSource(rng=\'host\'): numpy sampling on one core in '
+                                   'the reference\'s order + upload of the beam, then the same '
+                                   'three GPU steps')
+    res['speedup_vs_host_source'] = host_wall / wall
+    return res
+
+
 def bench_softi_shapes():
     """The reference's only published P2 numbers are whole-script times of
     tests/speed/3_Softi_CXIw2D_speed.py: 7 diffract calls of <= 2e5 x 2e5 pairs
@@ -804,6 +879,8 @@ def main():
     if world == 1 and not args.skip_balder:
         line['balder'] = bench_balder(int(args.rays))
         line['hist'] = bench_hist(int(args.rays))
+    if world == 1 and not args.skip_e2e:
+        line['e2e'] = bench_e2e(int(args.rays))
     if args.with_softi_shapes and world == 1:
         line['softi_shapes'] = bench_softi_shapes()
     if world == 1 and rank == 0 and not args.skip_cpu_baseline:

@@ -577,6 +577,53 @@ XRT_HIP_API int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* apert
                                                    xrt_hip_beam* out_local,
                                                    xrt_hip_beam* out_global, void* stream);
 
+/* ---- GeometricSource.shine on the device ------------
+ * Replaces the host sampling of GeometricSource.shine (sources/geoms.py:420-535) with one
+ * kernel that writes the 13 (15) SoA arrays of the beam straight into HBM. The laws are the
+ * reference's (_apply_distribution geoms.py:370-407, _set_annulus :409-418, make_energy
+ * :16-60, make_polarization :63-179, b from a and c :497-505, rotate_beam and
+ * virgin_local_to_global :514-518); the random numbers are Philox4x32-10 blocks
+ * (Salmon et al., SC'11) addressed by (ray index, slot, call number) under a 64-bit seed --
+ * the stream layout is written out in oracle/geosource_np.py, the CPU restatement the GPU
+ * tests compare with. law[k] / p0[k] / p1[k] for k = y, x, z, x', z':
+ *   NORMAL: p0 = sigma;  FLAT: [p0, p1);  NORMAL_UNIFORM (uniformRayDensity): sigma p0,
+ *   uniform in [-p1, p1], the Gaussian goes into Jss, Jpp, Jsp (and its root into Es, Ep).
+ * annulus_xz / annulus_ac: that pair is (r, phi) uniform over the ring ann_* = {rMin, rMax,
+ * phiMin, phiMax}. e_law: 0 = every ray has E = e_p0; 1 normal (e_p0, e_p1);
+ * 2 flat [e_p0, e_p1); 3 one of n_lines values e_lines[] by the cumulative weights e_cdf[].
+ * slopes != 0: a, c are slopes, (a, c, 1) / sqrt(1 + a^2 + c^2) (the reference takes this
+ * branch when ANY ray has a^2 + c^2 > 1; xrt_hip_geosource_probe_f64_dev answers that). */
+#define XRT_HIP_LAW_NONE 0
+#define XRT_HIP_LAW_NORMAL 1
+#define XRT_HIP_LAW_FLAT 2
+#define XRT_HIP_LAW_NORMAL_UNIFORM 3
+#define XRT_HIP_MAX_LINES 16
+typedef struct xrt_hip_geosource {
+  uint64_t seed;
+  uint32_t call;
+  int32_t slopes;
+  int32_t law[5];
+  double p0[5], p1[5];
+  int32_t annulus_xz, annulus_ac;
+  double ann_xz[4], ann_ac[4];
+  int32_t e_law, filament, n_lines, random_ep;
+  double e_p0, e_p1;
+  double e_lines[XRT_HIP_MAX_LINES], e_cdf[XRT_HIP_MAX_LINES];
+  double Jss, Jpp, Jsp[2], Es[2], Ep[2];
+  xrt_hip_rotation rot;         /* pitch / roll / yaw of the source, as rotate_beam applies them */
+  int32_t to_global;            /* undo the beamline azimuth, add center */
+  int32_t state;                /* the state every ray gets (1) */
+  double sin_az, cos_az, center[3];
+} xrt_hip_geosource;
+
+/* out: device arrays of out->n rays, all overwritten (Es_ri / Ep_ri NULL = no amplitudes). */
+XRT_HIP_API int xrt_hip_geosource_shine_f64_dev(const xrt_hip_geosource* source,
+                                                xrt_hip_beam* out, void* stream);
+/* any_above_one (device int32, zeroed by the caller) becomes 1 if some ray of the n would have
+ * a^2 + c^2 > 1 with this source. */
+XRT_HIP_API int xrt_hip_geosource_probe_f64_dev(const xrt_hip_geosource* source, int64_t n,
+                                                int32_t* any_above_one, void* stream);
+
 /* ---- weighted 2-D histogram of a device-resident beam ---------------------
  * The reduce step of every run_ray_tracing iteration: raycing.get_output
  * (raycing/__init__.py:170-300) selects rays by state and forms the intensity,

@@ -58,6 +58,8 @@ SIGNATURES = {
         vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_screen_expose_f64_dev': (ctypes.c_int, [vp, vp, vp, vp]),
     'xrt_hip_aperture_propagate_f64_dev': (ctypes.c_int, [vp, vp, vp, vp, vp]),
+    'xrt_hip_geosource_shine_f64_dev': (ctypes.c_int, [vp, vp, vp]),
+    'xrt_hip_geosource_probe_f64_dev': (ctypes.c_int, [vp, i64, vp, vp]),
     'xrt_hip_hist2d_f64_dev': (ctypes.c_int, [
         vp, vp, vp, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
         ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double,

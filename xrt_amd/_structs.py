@@ -249,5 +249,41 @@ class Gauss(ctypes.Structure):
                 ('n', ctypes.c_int32), ('clp', ctypes.c_double)]
 
 
+LAW_NONE, LAW_NORMAL, LAW_FLAT, LAW_NORMAL_UNIFORM = 0, 1, 2, 3
+MAX_LINES = 16
+
+
+class GeoSource(ctypes.Structure):
+    _fields_ = [('seed', ctypes.c_uint64),
+                ('call', ctypes.c_uint32),
+                ('slopes', ctypes.c_int32),
+                ('law', ctypes.c_int32 * 5),
+                ('p0', ctypes.c_double * 5),
+                ('p1', ctypes.c_double * 5),
+                ('annulus_xz', ctypes.c_int32),
+                ('annulus_ac', ctypes.c_int32),
+                ('ann_xz', ctypes.c_double * 4),
+                ('ann_ac', ctypes.c_double * 4),
+                ('e_law', ctypes.c_int32),
+                ('filament', ctypes.c_int32),
+                ('n_lines', ctypes.c_int32),
+                ('random_ep', ctypes.c_int32),
+                ('e_p0', ctypes.c_double),
+                ('e_p1', ctypes.c_double),
+                ('e_lines', ctypes.c_double * MAX_LINES),
+                ('e_cdf', ctypes.c_double * MAX_LINES),
+                ('Jss', ctypes.c_double),
+                ('Jpp', ctypes.c_double),
+                ('Jsp', ctypes.c_double * 2),
+                ('Es', ctypes.c_double * 2),
+                ('Ep', ctypes.c_double * 2),
+                ('rot', Rotation),
+                ('to_global', ctypes.c_int32),
+                ('state', ctypes.c_int32),
+                ('sin_az', ctypes.c_double),
+                ('cos_az', ctypes.c_double),
+                ('center', ctypes.c_double * 3)]
+
+
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
-           UndulatorMap, Plot, CustomField, Bend, Multilayer, Gauss)
+           UndulatorMap, Plot, CustomField, Bend, Multilayer, Gauss, GeoSource)

@@ -328,12 +328,17 @@ class Beam(object):
     @classmethod
     def empty_like_on_device(cls, other, device):
         """New beam with uninitialised device arrays of other's shape."""
+        return cls.empty_on_device(other.nrays, device, other.has_amplitudes())
+
+    @classmethod
+    def empty_on_device(cls, nrays, device, withAmplitudes=False):
+        """New beam of *nrays* rays with uninitialised device arrays."""
         b = cls.__new__(cls)
         object.__setattr__(b, '_h', {})
         object.__setattr__(b, '_d', {})
-        n = other.nrays
+        n = int(nrays)
         names = list(_F64) + ['Jsp', 'state']
-        if other.has_amplitudes():
+        if withAmplitudes:
             names += ['Es', 'Ep']
         for name in names:
             b._d[name] = torch.empty(n, dtype=_TORCH_DTYPE[np.dtype(_np_dtype(name))],
@@ -526,12 +531,22 @@ class GeometricSource(object):
                  distzprime='normal', dzprime=1e-4, distE='lines',
                  energies=(defaultEnergy,), energyWeights=None,
                  polarization='horizontal', filamentBeam=False,
-                 uniformRayDensity=False, pitch=0, roll=0, yaw=0, **kwargs):
+                 uniformRayDensity=False, pitch=0, roll=0, yaw=0, totalFlux=None,
+                 rng='host', seed=None, **kwargs):
+        """*rng*: 'host' (default) samples with numpy's global generator in the reference's
+        order -- a script that seeds ``np.random`` gets the reference's very rays; 'device'
+        samples on the GPU (one kernel, counter-based Philox4x32-10 under *seed*, nothing
+        crosses PCIe): the same laws, other random numbers. *seed* None = drawn from
+        ``np.random`` at the first ``shine`` (a seeded script stays reproducible); every
+        ``shine`` call takes the next sub-stream."""
         given = dict(locals())
         _enrol_source(self, bl, name or 'GeometricSource', kwargs.get('uuid'))
         self.nrays = int(nrays)
+        if rng not in ('host', 'device'):
+            raise ValueError("rng must be 'host' or 'device'")
+        self.rng, self.seed, self._calls = rng, seed, 0
         for key in ('center', 'distE', 'energies', 'energyWeights', 'polarization',
-                    'filamentBeam', 'uniformRayDensity', 'pitch', 'roll', 'yaw'):
+                    'filamentBeam', 'uniformRayDensity', 'pitch', 'roll', 'yaw', 'totalFlux'):
             setattr(self, key, given[key])
         for coord in self._FIELD:
             setattr(self, 'dist' + coord, given['dist' + coord])
@@ -587,8 +602,144 @@ class GeometricSource(object):
             for field, law, size in zip(fields, laws, sizes):
                 self._apply_distribution(field, law, size, bo)
 
+    # ---- rng='device': the same laws as plain numbers for csrc/source.hip ----------------
+    def _law(self, coord):
+        """(law, p0, p1) of one coordinate (the branches of _apply_distribution)."""
+        dist, size = getattr(self, 'dist' + coord), getattr(self, 'd' + coord)
+        if dist == 'normal' and self.uniformRayDensity:
+            widths = np.atleast_1d(size)
+            return (_structs.LAW_NORMAL_UNIFORM, float(widths[0]),
+                    float(widths[-1] if len(widths) > 1 else 5 * abs(widths[0])))
+        if dist == 'normal':
+            sigma = float(size[0] if isinstance(size, (list, tuple)) else size)
+            # (numpy refuses a negative sigma and the reference then leaves zeros)
+            return (_structs.LAW_NORMAL, sigma, 0.) if sigma >= 0 else (_structs.LAW_NONE, 0., 0.)
+        if dist == 'flat':
+            if raycing.is_sequence(size):
+                return _structs.LAW_FLAT, float(size[0]), float(size[1])
+            if size > 0:
+                return _structs.LAW_FLAT, -size*0.5, size*0.5
+        return _structs.LAW_NONE, 0., 0.
+
+    def _reach(self, law):
+        """The largest |value| a coordinate can take under *law*: Box-Muller on 53-bit
+        uniforms ends at sqrt(-2 ln 2^-53) = 8.572 sigma."""
+        kind, p0, p1 = law
+        if kind == _structs.LAW_NORMAL:
+            return 8.58 * abs(p0)
+        if kind == _structs.LAW_FLAT:
+            return max(abs(p0), abs(p1))
+        return abs(p1) if kind == _structs.LAW_NORMAL_UNIFORM else 0.
+
+    def device_spec(self, toGlobal=True):
+        """The ``xrt_hip_geosource`` record of this source (all but ``slopes``)."""
+        g = _structs.GeoSource()
+        if self.seed is None:
+            self.seed = int(np.random.randint(0, 2**62, dtype=np.int64))
+        g.seed, g.call = int(self.seed) & (2**64 - 1), self._calls & 0xFFFFFFFF
+        laws = [self._law(c) for c in ('y', 'x', 'z', 'xprime', 'zprime')]
+        for k, (kind, p0, p1) in enumerate(laws):
+            g.law[k], g.p0[k], g.p1[k] = kind, p0, p1
+        reach = []
+        for flag, ring, first, second in (('annulus_xz', g.ann_xz, 'x', 'z'),
+                                          ('annulus_ac', g.ann_ac, 'xprime', 'zprime')):
+            dists = [getattr(self, 'dist' + c) for c in (first, second)]
+            sizes = [getattr(self, 'd' + c) for c in (first, second)]
+            if 'annulus' in dists and raycing.is_sequence(sizes[0]):
+                arc = sizes[1] if raycing.is_sequence(sizes[1]) else (0, PI2)
+                setattr(g, flag, 1)
+                ring[0], ring[1], ring[2], ring[3] = (float(sizes[0][0]), float(sizes[0][1]),
+                                                      float(arc[0]), float(arc[1]))
+                reach.append(max(abs(ring[0]), abs(ring[1]))**2)
+            else:
+                k = 1 if first == 'x' else 3
+                reach.append(self._reach(laws[k])**2 + self._reach(laws[k + 1])**2)
+        g.e_p0 = defaultEnergy
+        if self.distE is not None:
+            values = np.atleast_1d(np.asarray(self.energies, dtype=float))
+            pair = len(values) == 2
+            g.filament = 1 if self.filamentBeam else 0
+            if self.distE == 'normal':
+                spread = abs(values[1]) if pair else 0.
+                g.e_law, g.e_p0, g.e_p1 = 1, values[0], \
+                    0. if spread > 0.1*abs(values[0]) else spread
+            elif self.distE == 'flat':
+                g.e_law, g.e_p0, g.e_p1 = 2, values[0], \
+                    (values[1] or values[0]) if pair else values[0]
+            elif self.distE == 'lines':
+                if 0 in values:
+                    values = values[values > 0]
+                weights = None if self.energyWeights is None else \
+                    np.atleast_1d(self.energyWeights).astype(float)
+                if weights is None or len(weights) != len(values):
+                    weights = np.ones(len(values))
+                if not 1 <= len(values) <= _structs.MAX_LINES:
+                    raise ValueError("rng='device' takes 1..%d energy lines (use rng='host')"
+                                     % _structs.MAX_LINES)
+                cdf = np.cumsum(weights) / np.sum(weights)
+                cdf[-1] = 1.
+                g.e_law, g.n_lines = 3, len(values)
+                for k in range(len(values)):
+                    g.e_lines[k], g.e_cdf[k] = values[k], cdf[k]
+            else:
+                raise ValueError('unknown distE')
+        jss, jpp, jsp, es, ep = _polarization_state(self.polarization)
+        g.Jss, g.Jpp = float(jss), float(jpp)
+        g.Jsp[0], g.Jsp[1] = complex(jsp).real, complex(jsp).imag
+        if es is not None:
+            g.Es[0], g.Es[1] = complex(es).real, complex(es).imag
+            if isinstance(ep, str):
+                g.random_ep = 1
+            else:
+                g.Ep[0], g.Ep[1] = complex(ep).real, complex(ep).imag
+        steps = raycing.rotation_steps(pitch=self.pitch, roll=self.roll, yaw=self.yaw)
+        g.rot.n = len(steps)
+        for k, (axis, cs, sn) in enumerate(steps):
+            g.rot.axis[k], g.rot.cosa[k], g.rot.sina[k] = axis, cs, sn
+        g.state = 1
+        if toGlobal:
+            g.to_global = 1
+            g.sin_az, g.cos_az = float(self.bl.sinAzimuth), float(self.bl.cosAzimuth)
+            for k in range(3):
+                g.center[k] = float(self.center[k])
+        return g, reach[1]
+
+    def _shine_device(self, toGlobal, withAmplitudes, accuBeam):
+        import ctypes
+        from ... import _lib
+        _lib.require_gpu()
+        lib = _lib.load()
+        dev = torch.device('cuda', torch.cuda.current_device())
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        g, reach2 = self.device_spec(toGlobal)
+        self._calls += 1
+        if reach2 > 1:
+            # tangents that CAN leave the unit circle: the reference forms b from slopes if
+            # any ray of the batch does (geoms.py:497-505) -- ask the generator
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(lib.xrt_hip_geosource_probe_f64_dev(
+                ctypes.byref(g), self.nrays, ctypes.c_void_p(flag.data_ptr()), stream),
+                'xrt_hip_geosource_probe_f64_dev')
+            g.slopes = int(flag.item())
+        bo = Beam.empty_on_device(self.nrays, dev, withAmplitudes or self.uniformRayDensity)
+        _lib.check(lib.xrt_hip_geosource_shine_f64_dev(
+            ctypes.byref(g), ctypes.byref(bo.to_struct(dev)), stream),
+            'xrt_hip_geosource_shine_f64_dev')
+        if np.isscalar(self.totalFlux) and self.totalFlux > 0:      # make_flux_normalization
+            total = self.nrays * (g.Jss + g.Jpp) if not self.uniformRayDensity else \
+                float((bo.dev('Jss') + bo.dev('Jpp')).sum())
+            if total > 0:
+                bo.sourceWeight = self.totalFlux / total
+                bo.seeded, bo.seededI, bo.accepted, bo.acceptedE = self.nrays, 1., 1., 1.
+        if self.distE is not None and accuBeam is not None:
+            bo.E = accuBeam.dev('E', dev).clone()
+        bo.parentId = self.uuid
+        return bo
+
     def shine(self, toGlobal=True, withAmplitudes=False, accuBeam=None):
         """One beam of ``nrays`` rays, in the global frame if *toGlobal*."""
+        if self.rng == 'device':
+            return self._shine_device(toGlobal, withAmplitudes, accuBeam)
         bo = Beam(self.nrays, withAmplitudes=withAmplitudes or self.uniformRayDensity)
         bo.state[:] = 1
         make_polarization(self.polarization, bo, self.nrays)
@@ -608,6 +759,11 @@ class GeometricSource(object):
             bo.b[:] = 1.0 / length
         else:
             bo.b[:] = (1 - transverse)**0.5
+        if np.isscalar(self.totalFlux) and self.totalFlux > 0:      # make_flux_normalization,
+            total = (bo.Jss + bo.Jpp).sum()                         # geoms.py:182-190
+            if total > 0:
+                bo.sourceWeight = self.totalFlux / total
+                bo.seeded, bo.seededI, bo.accepted, bo.acceptedE = len(bo.E), 1., 1., 1.
         if self.distE is not None:
             bo.E[:] = accuBeam.E[:] if accuBeam is not None else make_energy(
                 self.distE, self.energies, self.nrays, self.filamentBeam,

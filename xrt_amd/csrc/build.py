@@ -15,13 +15,13 @@ LIB = os.path.join(PKG, 'libxrt_hip.so')
 SOURCES = ['reflect_exact1.hip', 'reflect_exact3.hip', 'reflect_exact0.hip',
            'reflect_exact2.hip', 'reflect_layered_x.hip', 'reflect_layered_f.hip',
            'reflect_generic.hip', 'reflect_xtal.hip', 'reflect.hip', 'reflect_hot.hip',
-           'kirchhoff.hip', 'undulator.hip', 'capi.hip', 'screen.hip', 'hist.hip']
+           'kirchhoff.hip', 'undulator.hip', 'capi.hip', 'screen.hip', 'hist.hip', 'source.hip']
 HEADERS = ['fp64_math.h', 'kirchhoff.h', 'reflect.h', 'reflect_impl.h', 'reflect_tu.h',
-           'screen.h', 'hist.h', 'undulator.h',
+           'screen.h', 'hist.h', 'undulator.h', 'source.h',
            os.path.join('..', '..', 'include', 'xrt_hip.h')]
 # headers only these sources depend on (everything else rebuilds on any header change)
 ONLY_FOR = {'reflect_impl.h': 'reflect', 'reflect_tu.h': 'reflect', 'kirchhoff.h': ('kirchhoff', 'capi'),
-            'hist.h': ('hist', 'capi'), 'screen.h': ('screen', 'capi'),
+            'hist.h': ('hist', 'capi'), 'screen.h': ('screen', 'capi'), 'source.h': ('source', 'capi'),
             'undulator.h': ('undulator', 'capi')}
 # -ffp-contract=off: fused multiply-add only where the source says fma();
 # the reference (numpy) never fuses and ray states / the Kirchhoff phase

@@ -10,6 +10,7 @@
 #include "kirchhoff.h"
 #include "reflect.h"
 #include "screen.h"
+#include "source.h"
 #include "hist.h"
 #include "undulator.h"
 
@@ -252,6 +253,7 @@ int xrt_hip_sizeof(int which) {
     case 10: return (int)sizeof(xrt_hip_bend);
     case 11: return (int)sizeof(xrt_hip_multilayer);
     case 12: return (int)sizeof(xrt_hip_gauss);
+    case 13: return (int)sizeof(xrt_hip_geosource);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -647,6 +649,43 @@ int xrt_hip_crystal_amplitude_f64_dev(const xrt_hip_material* material, int64_t 
     return fail(XRT_HIP_ERR_ARG, "NULL array");
   HIP_TRY(xrt::crystal_amplitude_launch(*material, n, E, gamma0, gammah, hns, S_ri, P_ri,
                                         reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+static int check_geosource(const xrt_hip_geosource* g) {
+  if (!g) return fail(XRT_HIP_ERR_ARG, "NULL source");
+  for (int k = 0; k < 5; ++k)
+    if (g->law[k] < 0 || g->law[k] > XRT_HIP_LAW_NORMAL_UNIFORM)
+      return fail(XRT_HIP_ERR_ARG, "source: unknown law %d of coordinate %d", g->law[k], k);
+  if (g->e_law < 0 || g->e_law > 3) return fail(XRT_HIP_ERR_ARG, "source: unknown energy law");
+  if (g->e_law == 3 && (g->n_lines < 1 || g->n_lines > XRT_HIP_MAX_LINES))
+    return fail(XRT_HIP_ERR_ARG, "source: %d energy lines (1..%d)", g->n_lines,
+                XRT_HIP_MAX_LINES);
+  if (g->rot.n < 0 || g->rot.n > XRT_HIP_MAX_ROT)
+    return fail(XRT_HIP_ERR_ARG, "source: %d rotation steps", g->rot.n);
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_geosource_shine_f64_dev(const xrt_hip_geosource* source, xrt_hip_beam* out,
+                                    void* stream) {
+  int rc;
+  if ((rc = check_geosource(source))) return rc;
+  if (!out) return fail(XRT_HIP_ERR_ARG, "NULL beam");
+  if (out->n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if ((rc = check_beam(out, "out", out->n, out->Es_ri != nullptr || out->Ep_ri != nullptr)))
+    return rc;
+  HIP_TRY(xrt::geosource_shine_launch(*source, *out, reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_geosource_probe_f64_dev(const xrt_hip_geosource* source, int64_t n,
+                                    int32_t* any_above_one, void* stream) {
+  int rc;
+  if ((rc = check_geosource(source))) return rc;
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  if (!any_above_one) return fail(XRT_HIP_ERR_ARG, "NULL flag");
+  HIP_TRY(xrt::geosource_probe_launch(*source, n, any_above_one,
+                                      reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
 }
 

@@ -63,8 +63,16 @@ def packed_workspace(device, nbytes, tables, scalars):
     versions = tuple(t._version for t in tables)
     same = was is not None and was[1] == versions and was[2] == scalars and \
         len(was[0]) == len(tables) and all(r() is t for r, t in zip(was[0], tables))
-    ws._xrt_packed = (tuple(weakref.ref(t) for t in tables), versions, scalars)
+    # the record of what the workspace holds is set by mark_packed() AFTER the call that packs
+    # succeeded: a call that failed before its pack kernel must not leave the claim behind
+    ws._xrt_packed = None
+    ws._xrt_packing = (tuple(weakref.ref(t) for t in tables), versions, scalars)
     return ws, same
+
+
+def mark_packed(ws):
+    """The C call that packed (or reused) the node records of *ws* returned success."""
+    ws._xrt_packed = ws._xrt_packing
 
 
 def kirchhoff_plan(npix, ns, nsplit=0, ppt=0):
@@ -218,6 +226,7 @@ def undulator(mode, Kx, Ky, tables, gamma, wu, w, ww1, ddphi, ddpsi, nper=1,
             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr(),
             ctypes.byref(ms) if timing else None)
     _lib.check(rc, 'xrt_hip_undulator_f64_dev')
+    mark_packed(ws)
     return (Is, Ip, ms.value) if timing else (Is, Ip)
 
 
@@ -264,6 +273,7 @@ def undulator_imap(mode, Kx, Ky, tables, w, theta, psi, L0, Np, gamma0, eI, dste
             _c128(Es, n, 'Es'), _c128(Ep, n, 'Ep'),
             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream_ptr())
     _lib.check(rc, 'xrt_hip_undulator_imap_f64_dev')
+    mark_packed(ws)
     return I, Es, Ep
 
 

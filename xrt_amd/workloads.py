@@ -54,6 +54,35 @@ def synthetic_rays(n, seed, sa=2e-4, sc=2e-5, E=(8990., 9010.), amplitudes=False
     return b
 
 
+def e2e_beamline(nrays, rng='device', seed=42):
+    """A whole ``run_ray_tracing`` scene on the cfg2 shapes: GeometricSource with the ray laws of
+    ``synthetic_rays`` -> the cfg2 toroid mirror -> a Screen at its focus -> one XYCPlot of the
+    screen beam. -> (beamLine, run_process, plot factory)."""
+    from . import plotter as xrtp
+    from .backends.raycing import screens as rsc
+    bl = raycing.BeamLine()
+    bl.source = rs.GeometricSource(
+        bl, 'source', nrays=int(nrays), dx=0.1, dz=0.1, dxprime=2e-4, dzprime=2e-5,
+        distE='flat', energies=(8990., 9010.), polarization='h', rng=rng, seed=seed)
+    bl.mirror = cfg2_toroid(bl)
+    q, pitch = 10000., 4e-3
+    bl.screen = rsc.Screen(bl, 'focus', center=[0, 20000. + q * np.cos(2 * pitch),
+                                                q * np.sin(2 * pitch)])
+
+    def run_process(beamLine):
+        source = beamLine.source.shine()
+        mirror_global, mirror_local = beamLine.mirror.reflect(source)
+        at_focus = beamLine.screen.expose(mirror_global)
+        return {'source': source, 'mirrorGlobal': mirror_global, 'mirrorLocal': mirror_local,
+                'focus': at_focus}
+
+    def plot(bins=256):
+        return xrtp.XYCPlot('focus', (1,), xrtp.XYCAxis('x', 'mm', bins=bins, limits=[-1, 1]),
+                            xrtp.XYCAxis('z', 'mm', bins=bins, limits=[-1, 1]),
+                            caxis=xrtp.XYCAxis('energy', 'eV', bins=bins, limits=[8990, 9010]))
+    return bl, run_process, plot
+
+
 def kirchhoff_case(cfg):
     """cfg4 / cfg5 of SURVEY 8d: Gaussian-spherical field sampled uniformly on a
     0.2 x 0.2 mm slit 44 m from the source point, E = 7900 eV, Ep = 0, receiving
