@@ -318,9 +318,8 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
         r = hipcalls.kirchhoff(tx, ty, tz, s['sx'], s['sy'], s['sz'], s['nx'],
                                s['ny'], s['nz'], s['nl'], s['k'], s['Es'], s['Ep'],
                                convention=0, out=out, timing=timing)
-        if dist is not None:        # assemble the full field on every rank (RCCL)
-            for o in out:
-                multigpu.all_gather_tiles(o, npix, dist, rank, world)
+        if dist is not None:        # assemble the full field on every rank: ONE RCCL
+            multigpu.all_gather_packed(out, npix, dist, rank, world)   # all_gather of [5, tile]
         return r
     for _ in range(warmup):
         step()
@@ -334,6 +333,18 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
     kms = [step(timing=True)[5] for _ in range(2)]
     k = float(np.mean(kms)) * 1e-3
     my_pairs = float(ns) * float(p1 - p0)
+    # who was there: the size of the RCCL group as the collective itself sees it, and every
+    # rank's kernel time (the slowest tile sets the step)
+    rccl_ranks, kernel_ms_by_rank = 1, [k * 1e3]
+    if dist is not None:
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size() == world
+        mine = torch.zeros(world, dtype=torch.float64, device=dev)
+        mine[rank] = k * 1e3
+        dist.all_reduce(mine)
+        kernel_ms_by_rank = [float(v) for v in mine.tolist()]
     # the same launch through ONE process that tiles the receiving points over the GPUs itself
     # (what waves.diffract does with devices = [...], multigpu.kirchhoff_devices): rank 0
     # drives all of them while the other ranks wait
@@ -373,7 +384,10 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
         config=dict(workload='cfg%d: %d samples -> %dx%d screen, fp64, pixel-tiled'
                              % (cfg, ns, side, side), samples=ns, pixels=npix,
                     parallelism='pixel tiles x%d + all_gather' % world),
-        kernel_ms=k * 1e3, in_process=in_process,
+        kernel_ms=k * 1e3, kernel_ms_by_rank=kernel_ms_by_rank, rccl_ranks=rccl_ranks,
+        gather='one all_gather_into_tensor of the packed [5, tile] complex results per step '
+               '(%.1f MB per rank)' % (5 * 16 * (p1 - p0) / 1e6) if world > 1 else None,
+        in_process=in_process,
         roofline=dict(bound='valu_fp64', kernel='kirchhoff_stream',
                       note='fp64 VALU kernel (no MFMA: profiles/r01_mfma_f64_probe.txt); '
                            'MI355X vector fp64 peak = matrix fp64 peak = 78.6 TFLOP/s '
@@ -533,6 +547,8 @@ def bench_e2e(nrays, repeats=20):
                       frac=652. * nrays / wall / HBM_PEAK, traffic=None,
                       note='652 B per ray algorithmic: 100 written by the source, 308 by '
                            'OE.reflect (SURVEY 8d), 200 by Screen.expose, 44 read by the plot'))
+    if os.environ.get('XRT_E2E_NO_HOST'):
+        return res
     # the same job with the host source
     blh, run_h, make_h = workloads.e2e_beamline(nrays, rng='host')
     rr.run_process = run_h

@@ -37,16 +37,31 @@ def _worker(rank, world, port, npix_side, ns, q):
                                  h['E'], h['Es'], h['Ep'])
         full = [multigpu.all_gather_tiles(torch.from_numpy(t), n, dist, rank, world)
                 for t in tile]
+        # the five arrays in ONE collective (what bench.py and kirchhoff_tiled use)
+        packed = multigpu.all_gather_packed([torch.from_numpy(t) for t in tile], n, dist,
+                                            rank, world)
+        assert all(torch.equal(a, b) for a, b in zip(full, packed))
+        # a real-valued array rides along with complex ones of the same tiling
+        mixed = multigpu.all_gather_packed(
+            [torch.from_numpy(tile[0]), torch.from_numpy(h['px'][p0:p1].copy())], n, dist,
+            rank, world)
+        assert torch.equal(mixed[1], torch.from_numpy(h['px'])) and torch.equal(mixed[0], full[0])
+        ones = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(ones)
+        assert int(ones.item()) == world == dist.get_world_size()
         if rank == 0:
-            q.put([f.numpy() for f in full])
+            q.put([f.numpy() for f in packed])
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-@pytest.mark.parametrize('npix_side', [8, 7])     # 64 pixels (even) / 49 (uneven tiles)
-def test_two_rank_pixel_tiling_matches_single_rank(npix_side):
-    world, ns = 2, 300
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize('world,npix_side', [
+    (2, 8), (2, 7),      # 64 pixels (even) / 49 (uneven tiles)
+    (4, 7), (8, 7),      # 49 pixels over 4 / 8 ranks: tiles of 12-13 / 6-7 points
+    (8, 2)])             # 4 pixels over 8 ranks: half of the ranks hold an EMPTY tile
+def test_pixel_tiling_over_ranks_matches_single_rank(world, npix_side):
+    ns = 300 if world == 2 else 60
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -99,6 +114,28 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1
+
+
+def test_device_specifications_of_the_reference():
+    """targetOpenCL values that are legal in the reference (myopencl.py:187-231) select
+    sensible GPUs instead of failing: 'CPU' / 'auto' -> the current device,
+    'ALL' / 'GPU' in any case -> all, a (platform, device) tuple -> that device, a list of
+    such tuples -> those devices; a LIST of ints stays a list of ordinals."""
+    pd = multigpu.parse_devices
+    old = os.environ.pop('XRT_HIP_DEVICES', None)
+    try:
+        assert pd('CPU', 8) is None and pd('cpu', 8) is None
+        assert pd('ALL', 3) == [0, 1, 2] and pd('gpu', 2) == [0, 1]
+        assert pd((0, 1), 8) == [1]
+        assert pd([(0, 0), (0, 1)], 8) == [0, 1] and pd(((0, 2),), 8) == [2]
+        assert pd([0, 1], 8) == [0, 1] and pd('0,3', 8) == [0, 3]
+        with pytest.raises(ValueError):
+            pd('fpga', 8)
+        with pytest.raises(ValueError):
+            pd((0, 9), 8)
+    finally:
+        if old is not None:
+            os.environ['XRT_HIP_DEVICES'] = old
 
 
 def test_in_process_device_list_and_tiles():

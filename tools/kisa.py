@@ -4,7 +4,8 @@
 import re
 import sys
 from collections import Counter
-path = 'xrt_amd/csrc/build/kirchhoff-hip-amdgcn-amd-amdhsa-gfx950.s'
+import os
+path = os.environ.get('KISA', '/tmp/kisa/kirchhoff-hip-amdgcn-amd-amdhsa-gfx950.s')
 s = open(path).read()
 for m in re.finditer(r'\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n\s+\.sgpr_count:\s+(\d+)\n\s+\.sgpr_spill_count:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)', s):
     n = m.group(1)
