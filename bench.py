@@ -481,14 +481,18 @@ def bench_hist(nrays):
                 bound='hbm', kernel='plot_hist_rays + plot_hist_tiles + plot_hist_reduce '
                                     '(256 x 256 bins + 3 x 1-D)',
                 achieved=44. * nrays / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
-                frac=44. * nrays / (ms * 1e-3) / HBM_PEAK, traffic=None,
+                frac=44. * nrays / (ms * 1e-3) / HBM_PEAK,
+                traffic=load_hist_traffic(bins) if nrays == 10_000_000 else None,
+                traffic_source='profiles/hist_traffic.json: PMC passes of tools/pmc_hist.sh, '
+                               'committed -- static, not collected in this run',
                 note='44 B per ray algorithmic (x, y, colour datum, state, Jss, Jpp, read once); '
                      'the four fp64 planes of the plot are 2 MB, a CU has 160 KB of LDS, and '
                      'global fp64 atomics run at 2.4e10 /s on this chip (tools/probes/'
                      'probe_atomics.hip = 1.7 ms for the 4e7 updates): the rays are sorted by '
                      'tile of 64 x 64 bins on the way (20 B per ray written and read again) and '
-                     'accumulated in LDS, so the traffic is 84 B per ray + 64 MB of per-CU plane '
-                     'copies')
+                     'accumulated in LDS, so the traffic is 84 B per ray + the per-CU plane '
+                     'copies; the blocks of the tile pass are shared out by the tiles\' ray '
+                     'counts and table walks (round 4)')
     return res
 
 
@@ -818,6 +822,15 @@ def cpu_baseline_kirchhoff(host, npix=256):
 
 TRAFFIC_SOURCE = ('profiles/hbm_traffic.json: PMC passes of tools/refresh_profiles.sh on the '
                   'same command, committed -- static, not collected in this run')
+
+
+def load_hist_traffic(bins):
+    """HBM bytes per plot of the histogram kernels from the committed PMC summary, or None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'hist_traffic.json')) as f:
+            return json.load(f).get('bins%d' % bins, {}).get('hbm_bytes_per_plot')
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def load_traffic(kernel):

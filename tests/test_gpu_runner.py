@@ -195,6 +195,43 @@ def test_histograms_of_two_million_rays_match_numpy():
     assert abs(zoom.intensityInRange - ref.sum()) <= 1e-10 * ref.sum()
 
 
+@pytest.mark.parametrize('centre', [(0., 0.), (0.31, -0.52), (0.999, 0.999)])
+def test_histograms_of_a_focused_beam(centre):
+    """All rays in a spot of a few bins -- what a screen at a focus shows: the spot sits on the
+    corner shared by four tiles of the 256 x 256 plot, inside one tile, and in the last bins of
+    the plot (rays beyond the limits). The tile kernel shares its blocks out by the ray counts
+    of the tiles (one tile may hold everything); empty tiles get none."""
+    n = 1_000_003
+    rng = np.random.default_rng(5)
+    beam = rs.Beam(nrays=n)
+    beam.x = centre[0] + rng.normal(0, 0.01, n)
+    beam.z = centre[1] + rng.normal(0, 0.002, n)
+    beam.E = rng.uniform(8990., 9010., n)
+    beam.Jss, beam.Jpp = rng.uniform(0.5, 1., n), rng.uniform(0., 0.2, n)
+    beam.state = np.where(rng.uniform(size=n) < 0.97, 1, 2).astype(np.int32)
+    plot = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis('x', 'mm', bins=256, limits=[-1, 1]),
+                        xrtp.XYCAxis('z', 'mm', bins=256, limits=[-1, 1]),
+                        caxis=xrtp.XYCAxis('energy', 'eV', bins=256, limits=[8990, 9010]))
+    hx, hz, he = beam.x.copy(), beam.z.copy(), beam.E.copy()
+    flux, st = beam.Jss + beam.Jpp, beam.state.copy()
+    xrtr.accumulate_plot(plot, {'b': beam})
+    xrtr.accumulate_plot(plot, {'b': beam})
+    sel = st == 1
+    ref = 2 * np.histogram2d(hz[sel], hx[sel], bins=[256, 256], range=[[-1, 1], [-1, 1]],
+                             weights=flux[sel])[0]
+    assert ref.max() > 0 and np.abs(plot.total2D - ref).max() <= 1e-10 * ref.max()
+    for axis, v in ((plot.xaxis, hx), (plot.yaxis, hz), (plot.caxis, he)):
+        r1 = 2 * np.histogram(v[sel], bins=256, range=axis.limits, weights=flux[sel])[0]
+        assert np.abs(axis.total1D4[:, 0] - r1).max() <= 1e-10 * r1.max()
+    # the colour planes add up to what the flux plane holds: R + G + B of hsv(h, s, v) is
+    # v (3 - s) - s v (f or 1 - f), bounded by v (3 - 2 s) and v (3 - s)
+    rgb = plot.total2D_RGB.sum(axis=2)
+    s_ = plot.colorSaturation
+    assert (rgb <= ref * (3 - s_) * (1 + 1e-9) + 1e-9).all() and \
+        (rgb >= ref * (3 - 2 * s_) * (1 - 1e-9) - 1e-9).all()
+    assert plot.nRaysSelected == 2 * int(sel.sum())
+
+
 @pytest.mark.parametrize('bx,by,with_counters', [(50, 40, True), (140, 141, False),
                                                  (300, 280, True), (1500, 1200, True)])
 def test_plain_2d_histogram_entry_point(bx, by, with_counters):

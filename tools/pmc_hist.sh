@@ -28,7 +28,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -o p -- python /tmp/hist_run.py $BINS > /tmp/pmc_run.log 2>&1 || tail -3 /tmp/pmc_run.log
 done
 echo "# $BINS x $BINS bins, 1e7 rays"
-python - <<'PY'
+BINS=$BINS python - <<'PY'
 import sqlite3, glob, json
 out = {}
 for C in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -49,5 +49,13 @@ for key, d in sorted(out.items()):
     tot['r'] = tot.get('r', 0) + rd; tot['w'] = tot.get('w', 0) + wr
     print('%-72s read %.1f MB  written %.1f MB  (launches %d)' % (key, rd / 1e6, wr / 1e6, d.get('FETCH_SIZE', (0, 0))[1]))
 print('per plot: read %.1f MB + written %.1f MB = %.1f MB (algorithmic 440 MB)' % (tot.get('r', 0) / 1e6, tot.get('w', 0) / 1e6, (tot.get('r', 0) + tot.get('w', 0)) / 1e6))
+import os
+path = os.path.join(os.environ.get('GRAFT_REPO_ROOT', '.'), 'profiles', 'hist_traffic.json')
+try:
+    rec = json.load(open(path))
+except Exception:
+    rec = {}
+rec['bins%s' % os.environ['BINS']] = dict(rays=10000000, read_bytes=tot.get('r', 0), write_bytes=tot.get('w', 0), hbm_bytes_per_plot=tot.get('r', 0) + tot.get('w', 0), note='FETCH_SIZE x 1024 x 2 (gfx950 half-count of coalesced reads, calibrated on screen_expose_kernel in hbm_traffic.json) + WRITE_SIZE x 1024, separate --pmc passes, summed over plot_hist_rays / plot_hist_tiles / plot_hist_reduce')
+json.dump(rec, open(path, 'w'), indent=1)
 PY
 done

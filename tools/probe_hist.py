@@ -10,7 +10,8 @@ beam = workloads.synthetic_rays(n, 42)
 for f in beam.array_fields():
     beam.dev(f)
 gb, lb = oe.reflect(beam)
-for bins in (64, 128, 256, 512):
+import sys
+for bins in ([int(v) for v in sys.argv[1:]] or [64, 128, 256, 512]):
     for name, b, xa, ya in (('footprint', lb, 'x', 'y'), ('global xz', gb, 'x', 'z')):
         plot = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis(xa, 'mm', bins=bins), xrtp.XYCAxis(ya, 'mm', bins=bins),
                             caxis=xrtp.XYCAxis('energy', 'eV', bins=bins))

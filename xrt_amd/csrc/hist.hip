@@ -244,7 +244,75 @@ struct HistRecords {
   double* hue;
   unsigned* cell;
   unsigned* start;   // [chunk][T + 2]: start[t] .. start[t + 1]; bucket T = rays outside the plot
+  unsigned* counts;  // [block of plot_hist_rays][T]: its rays per tile
+  int* share;        // [T + 1]: which blocks of plot_hist_tiles take which tile
+  int nsrc;          // blocks of plot_hist_rays
 };
+
+// How the blocks of plot_hist_tiles are shared out among the tiles: every tile that has rays
+// gets one block, the rest go in proportion to the rays (a focused beam puts ALL its rays into
+// one or four of the 16 tiles of a 256 x 256 plot: with a fixed number of blocks per tile
+// 1/16 or 1/4 of the chip did all the work). share[t] .. share[t + 1] are tile t's blocks.
+// plot_hist_rays leaves its per-block ray counts per tile ([block][T], plain stores: atomics on
+// a handful of shared addresses cost 8 ns EACH on this chip -- 13 000 of them made that kernel
+// 100 us slower); every block of plot_hist_tiles adds them up for itself (48 KB out of L2) and
+// derives the same table; block 0 leaves it for plot_hist_reduce.
+__device__ __forceinline__ void make_tile_shares(const unsigned* __restrict__ counts, int nsrc,
+                                                 int T, int nblocks, int64_t nchunks,
+                                                 unsigned* tot, int* share, int* table_out) {
+  if (threadIdx.x < T) tot[threadIdx.x] = 0;
+  __syncthreads();
+  {
+    // thread i takes the counts i, i + blockDim, ...: consecutive threads, consecutive words
+    unsigned acc = 0;
+    const int n = nsrc * T;
+    int t = threadIdx.x % T;               // (blockDim is a multiple of T only if T is a power
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {       // of two: keep it general)
+      t = i % T;
+      acc = counts[i];
+      if (acc) atomicAdd(&tot[t], acc);
+    }
+  }
+  __syncthreads();
+  // what a tile costs: its rays, and the walk over the run table of EVERY chunk, which a wave
+  // does four chunks at a time -- one round of loads, as many as 256 rays take. (Shared out by
+  // rays alone, the tiles at the rim of a Gaussian footprint got one block each, which then
+  // walked the 9766 chunks of 1e7 rays on its own: 260 us.)
+  const double walk = 64. * (double)nchunks;
+  double sum = 0.;
+  int nonempty = 0;
+  for (int t = 0; t < T; ++t) {
+    if (tot[t]) {
+      sum += (double)tot[t] + walk;
+      ++nonempty;
+    }
+  }
+  long long n = 0;
+  if (threadIdx.x < T && tot[threadIdx.x]) {
+    n = 1 + (long long)((double)(nblocks - nonempty) *
+                        (((double)tot[threadIdx.x] + walk) / sum));
+    if (n > nchunks) n = nchunks;                    // a slice takes whole chunks
+  }
+  __syncthreads();
+  if (threadIdx.x < T) tot[threadIdx.x] = (unsigned)n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < T; ++t) {
+      share[t] = run;
+      run += (int)tot[t];
+    }
+    // (each quotient is rounded down and the ones add up to `nonempty`: never above nblocks)
+    share[T] = run < nblocks ? run : nblocks;
+  }
+  __syncthreads();
+  if (table_out && (int)threadIdx.x <= T) table_out[threadIdx.x] = share[threadIdx.x];
+}
+__device__ __forceinline__ void load_tile_shares(const int* __restrict__ table, int T,
+                                                 int* share) {
+  if ((int)threadIdx.x <= T) share[threadIdx.x] = table[threadIdx.x];
+  __syncthreads();
+}
 
 __device__ __forceinline__ bool ray_selected(int st, int ray_flags) {
   bool sel = false;
@@ -277,6 +345,8 @@ __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256) void plot_h
                                       // RECORDS: staging w, hue [1024], cell [1024]
   __shared__ double lds[8][16];
   __shared__ unsigned bucket[HIST_MAX_TILES + 2], first[HIST_MAX_TILES + 2];
+  __shared__ unsigned tile_sum[HIST_MAX_TILES];
+  if (MODE == HIST_RECORDS && threadIdx.x < HIST_MAX_TILES) tile_sum[threadIdx.x] = 0;
   const bool lines = H.lines != 0;
   const int plane = A.x.bins * A.y.bins;
   const int n2 = MODE == HIST_DIRECT ? H.nchan * plane : 0;
@@ -428,6 +498,7 @@ __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256) void plot_h
       }
       __syncthreads();
       if (threadIdx.x < T + 2) R.start[chunk * (T + 2) + threadIdx.x] = first[threadIdx.x];
+      if (threadIdx.x < T) tile_sum[threadIdx.x] += bucket[threadIdx.x];   // (its own thread's)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const unsigned pos = first[tl[u]] + rank[u];
@@ -447,6 +518,8 @@ __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256) void plot_h
     }
   }
   __syncthreads();
+  if (MODE == HIST_RECORDS && threadIdx.x < T)
+    R.counts[(int64_t)blockIdx.x * T + threadIdx.x] = tile_sum[threadIdx.x];
   // this block's copies, as they are (coalesced stores): the reduce kernel adds the blocks up
   if (MODE == HIST_DIRECT) {
     double* out = plane_copies + (int64_t)blockIdx.x * n2;
@@ -470,23 +543,67 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_hist_tiles(
     int64_t nchunks, HistRecords R, double saturation, PlotAxes A, HistPlan H,
     double* __restrict__ plane_copies) {
   extern __shared__ double cells[];     // [NCH][ty][tx]
+  __shared__ int share[HIST_MAX_TILES + 1];
+  __shared__ unsigned tot[HIST_MAX_TILES];
   const int T = H.ntx * H.nty;
-  const int tile = blockIdx.x % T, slice = blockIdx.x / T;
-  const int x0 = (tile % H.ntx) * H.tx, y0 = (tile / H.ntx) * H.ty;
-  const int tw = min(A.x.bins, x0 + H.tx) - x0, th = min(A.y.bins, y0 + H.ty) - y0;
+#ifdef HIST_STATIC_SHARES
+  if (threadIdx.x <= T) share[threadIdx.x] = threadIdx.x * ((int)gridDim.x / T);
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x <= T) R.share[threadIdx.x] = share[threadIdx.x];
+#else
+  make_tile_shares(R.counts, R.nsrc, T, (int)gridDim.x, nchunks, tot, share,
+                   blockIdx.x == 0 ? R.share : nullptr);
+#endif
+  int tile = 0;
+#ifdef HIST_INTERLEAVE
+  // block b -> the b-th entry of the round-robin over the tiles' remaining shares
+  int sl = 0;
+  {
+    int left = (int)blockIdx.x, round = 0, found = -1;
+    while (found < 0) {
+      int live = 0;
+      for (int t = 0; t < T; ++t) live += share[t + 1] - share[t] > round;
+      if (!live) break;
+      if (left < live) {
+        for (int t = 0; t < T; ++t)
+          if (share[t + 1] - share[t] > round && left-- == 0) {
+            found = t;
+            sl = round;
+            break;
+          }
+      } else {
+        left -= live;
+        ++round;
+      }
+    }
+    if (found < 0) return;
+    tile = found;
+  }
+  const int slice = sl, slices = share[tile + 1] - share[tile];
+  const int copy_slot = share[tile] + slice;
+#else
+  while (tile < T && (int)blockIdx.x >= share[tile + 1]) ++tile;
+  if (tile >= T) return;                // (more blocks than the tiles take)
+  const int slice = (int)blockIdx.x - share[tile], slices = share[tile + 1] - share[tile];
+  const int copy_slot = (int)blockIdx.x;
+#endif
   const int tcells = H.tx * H.ty;
   for (int k = threadIdx.x; k < NCH * tcells; k += blockDim.x) cells[k] = 0.;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   // the chunks of the slice: slice, slice + S, ...; wave w takes them HIST_GROUP at a time
-  const int64_t mine = slice < nchunks ? (nchunks - slice + H.slices - 1) / H.slices : 0;
+#ifdef HIST_SKIP_LOOP
+  const int64_t mine = 0;
+#else
+  const int64_t mine = slice < nchunks ? (nchunks - slice + slices - 1) / slices : 0;
+#endif
   // lanes 0..3 fetch the run of one chunk each (everybody gets all four below); the runs of the
   // NEXT group are requested before this group's records are
   auto runs_of = [&](int64_t j0, int64_t& c_l, unsigned& s_l, unsigned& e_l) {
     c_l = -1;
     s_l = e_l = 0;
     if (lane < HIST_GROUP && j0 + lane < mine) {
-      c_l = slice + (j0 + lane) * H.slices;
+      c_l = slice + (j0 + lane) * slices;
       s_l = R.start[c_l * (T + 2) + tile];
       e_l = R.start[c_l * (T + 2) + tile + 1];
     }
@@ -540,14 +657,9 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_hist_tiles(
     e_l = e_n;
   }
   __syncthreads();
-  // the tile into this slice's copy of the planes, [slice][chan][by][bx]
-  const int64_t plane = (int64_t)A.x.bins * A.y.bins;
-  double* out = plane_copies + (int64_t)slice * NCH * plane;
-  for (int k = 0; k < NCH; ++k)
-    for (int b = threadIdx.x; b < tw * th; b += blockDim.x) {
-      const int r = b / tw, q = b - r * tw;
-      out[k * plane + (int64_t)(y0 + r) * A.x.bins + x0 + q] = cells[k * tcells + r * H.tx + q];
-    }
+  // the tile as it is into this block's copy, [block][chan][ty][tx] (coalesced)
+  double* out = plane_copies + (int64_t)copy_slot * NCH * tcells;
+  for (int k = threadIdx.x; k < NCH * tcells; k += blockDim.x) out[k] = cells[k];
 }
 
 // Adds the copies up into the histograms, one launch: blocks [0, nb2) take the 2-D planes
@@ -571,19 +683,41 @@ __global__ __launch_bounds__(256) void plot_hist_reduce(
     const double* __restrict__ planes, int ncopies, int plane, int nchan, int nb2,
     const double* __restrict__ lines, int nline_copies, int nx, int ny, int nc,
     double* __restrict__ h2, double* __restrict__ h2rgb, double* __restrict__ hx,
-    double* __restrict__ hy, double* __restrict__ hc) {
+    double* __restrict__ hy, double* __restrict__ hc, HistPlan H, int bins_x, int bins_y,
+    const int* __restrict__ tile_share, int plane_parts) {
+  __shared__ int share[HIST_MAX_TILES + 1];
+  const bool tiled = tile_share != nullptr;     // copies of plot_hist_tiles: [block][chan][ty][tx]
+  if (tiled) load_tile_shares(tile_share, H.ntx * H.nty, share);
   if ((int)blockIdx.x < nb2) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nchan * plane) return;
-    const int per = (ncopies + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int s0 = blockIdx.y * per, s1 = min(ncopies, s0 + per);
-    const double v = sum_copies(planes + j, (int64_t)nchan * plane, s0, s1);
-    if (v == 0.) return;
     const int ch = j / plane, b = j - ch * plane;
-    if (ch == 0)
-      atomicAdd(&h2[b], v);
+    int c0 = 0, cn = ncopies;
+    int64_t pitch = (int64_t)nchan * plane;
+    const double* src = planes + j;
+    if (tiled) {
+      const int by = b / bins_x, bx = b - by * bins_x;
+      const int tjx = bx / H.tx, tjy = by / H.ty;
+      const int t = tjy * H.ntx + tjx, tcells = H.tx * H.ty;
+      c0 = share[t];
+      cn = share[t + 1];
+      pitch = (int64_t)nchan * tcells;
+      src = planes + (int64_t)ch * tcells + (by - tjy * H.ty) * H.tx + (bx - tjx * H.tx);
+    }
+    // (plane_parts groups of copies per cell; ONE group for the larger plots: every cell then
+    // has one thread and adds without an atomic -- at 2.4e10 global atomics per second the 16
+    // groups of a 256 x 256 plot cost 44 us)
+    if ((int)blockIdx.y >= plane_parts) return;
+    const int per = (cn - c0 + plane_parts - 1) / plane_parts;
+    const int s0 = c0 + blockIdx.y * per, s1 = min(cn, s0 + per);
+    if (s0 >= s1) return;
+    const double v = sum_copies(src, pitch, s0, s1);
+    if (v == 0.) return;
+    double* dst = ch == 0 ? &h2[b] : &h2rgb[3 * (int64_t)b + ch - 1];
+    if (plane_parts == 1)
+      *dst += v;
     else
-      atomicAdd(&h2rgb[3 * (int64_t)b + ch - 1], v);
+      atomicAdd(dst, v);
     return;
   }
   const int nl = 4 * (nx + ny + nc);
@@ -680,21 +814,24 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
     const int T = H.ntx * H.nty;
     int ncopies = nblk;                                           // copies of the planes
     if (mode == HIST_RECORDS) {
-      int S = cus / T;
-      if (S > chunks) S = (int)chunks;
-      if (S < 1) S = 1;
-      H.slices = S;
-      ncopies = S;
+      // plot_hist_tiles: one block per CU, shared out among the tiles by their ray counts
+      // (tile_shares); every block leaves a copy of ITS tile
+      ncopies = cus > T ? cus : T;
+      H.slices = ncopies;
     }
     auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t nl = b1 / sizeof(double);
-    const size_t planes_b = pad(mode == HIST_LINES_ONLY ? 0 : (size_t)ncopies * H.nchan * plane);
+    const size_t planes_b = pad(mode == HIST_LINES_ONLY ? 0
+                                : mode == HIST_RECORDS
+                                    ? (size_t)ncopies * H.nchan * H.tx * H.ty * sizeof(double)
+                                    : (size_t)ncopies * H.nchan * plane);
     const size_t lines_b = pad(lines ? (size_t)nblk * b1 : 0);
     const size_t recs = mode == HIST_RECORDS ? (size_t)chunks * HIST_CHUNK : 0;
     const size_t start_b = pad(mode == HIST_RECORDS ? (size_t)chunks * (T + 2) * 4 : 0);
+    const size_t counts_b = pad(mode == HIST_RECORDS ? (size_t)nblk * T * 4 : 0);
     char* scratch = nullptr;
     if (hipMallocAsync(reinterpret_cast<void**>(&scratch),
-                       planes_b + lines_b + pad(recs * 8) * 2 + pad(recs * 4) + start_b + 256,
+                       planes_b + lines_b + pad(recs * 8) * 2 + pad(recs * 4) + start_b + counts_b + 1024,
                        st) != hipSuccess) {
       (void)hipGetLastError();
       scratch = nullptr;
@@ -713,14 +850,23 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
       R.cell = reinterpret_cast<unsigned*>(q);
       q += pad(recs * 4);
       R.start = reinterpret_cast<unsigned*>(q);
+      q += start_b;
+      R.counts = reinterpret_cast<unsigned*>(q);
+      q += counts_b;
+      R.share = reinterpret_cast<int*>(q);
+      R.nsrc = nblk;
+      hipError_t e = hipSuccess;
       const size_t lds1 = (mode == HIST_DIRECT ? H.nchan * plane : 0) + (lines ? b1 : 0) +
                           (mode == HIST_RECORDS ? stage : 0);
       auto rays = mode == HIST_DIRECT    ? plot_hist_rays<HIST_DIRECT>
                   : mode == HIST_RECORDS ? plot_hist_rays<HIST_RECORDS>
                                          : plot_hist_rays<HIST_LINES_ONLY>;
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rays),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(rays),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      if (e != hipSuccess) {
+        (void)hipFreeAsync(scratch, st);
+        return e;
+      }
       hipLaunchKernelGGL(rays, dim3((unsigned)nblk), dim3(mode == HIST_DIRECT ? HIST_BLOCK : 256),
                          lds1, st, beam, x, y, c, P, A, H, counters, plane_copies, line_copies, R);
       if (mode == HIST_RECORDS) {
@@ -728,9 +874,12 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
         const size_t lds2 = sizeof(double) * (size_t)H.nchan * H.tx * H.ty;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiles),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(tiles, dim3((unsigned)(T * H.slices)), dim3(HIST_BLOCK), lds2, st,
-                           chunks, R, P.color_saturation, A, H, plane_copies);
+        if (e != hipSuccess) {
+          (void)hipFreeAsync(scratch, st);
+          return e;
+        }
+        hipLaunchKernelGGL(tiles, dim3((unsigned)ncopies), dim3(HIST_BLOCK), lds2, st, chunks, R,
+                           P.color_saturation, A, H, plane_copies);
       }
       {
         const int total = mode != HIST_LINES_ONLY ? H.nchan * P.bins_x * P.bins_y : 0;
@@ -740,7 +889,9 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
           hipLaunchKernelGGL(plot_hist_reduce, dim3((unsigned)(nb2 + nbl), HIST_REDUCE_PARTS),
                              dim3(256), 0, st, plane_copies, ncopies, P.bins_x * P.bins_y, H.nchan,
                              nb2, line_copies, nblk, lines ? A.x.bins : 0, lines ? A.y.bins : 0,
-                             lines ? A.c.bins : 0, h2, h2rgb, hx, hy, hc);
+                             lines ? A.c.bins : 0, h2, h2rgb, hx, hy, hc, H, P.bins_x, P.bins_y,
+                             mode == HIST_RECORDS ? R.share : nullptr,
+                             total >= 32768 ? 1 : HIST_REDUCE_PARTS);
       }
       (void)hipFreeAsync(scratch, st);
     } else {
