@@ -175,6 +175,15 @@ typedef struct xrt_hip_rotation {
                                      toroid), planes (0 Johann, 1 Johansson), Rm, Rs, cos(alpha),
                                      sin(alpha), alpha given, xStep, yStep, dxFacet / 2,
                                      dyFacet / 2 */
+#define XRT_HIP_SURF_USER 12       /* a surface the USER defines, the reference's way of adding
+                                     one: an OE subclass whose local_z / local_n are handed to the
+                                     accelerated path as source snippets (oes/base.py:69-90
+                                     cl_local_z / cl_local_n / cl_plist, spliced into the kernel
+                                     at :552-564). Here: two C expressions over (x, y, p[]) compiled
+                                     once per class into a unit of their own (hipcc, the ray
+                                     kernels instantiated around them) and loaded with
+                                     xrt_hip_user_surface_load; surf_p = the class's parameter
+                                     list p[0..11]; xrt_hip_pass.user_unit = the handle */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_SHAPE_POLYGON 2   /* optical surface outlined by a polygon in the local (x, y)
@@ -285,7 +294,20 @@ typedef struct xrt_hip_pass {
    * secant; the verdict kernel checks the assumption as before and stores what the
    * statistics say now. Results do not depend on it. NULL: assume the secant. */
   int32_t* method_hint;
+  /* surf_kind == XRT_HIP_SURF_USER: the handle xrt_hip_user_surface_load returned. */
+  void* user_unit;
 } xrt_hip_pass;
+
+/* ---- user-defined surfaces -------------------------------------------------------------
+ * path: a shared library made from csrc/user_unit.hip.in around the user's two snippets
+ * (xrt_amd/usersurf.py writes and compiles it: `hipcc --offload-arch=gfx950 -shared`). It is
+ * opened with dlopen, checked against this library's build (xrt_hip_user_unit_abi) and kept
+ * until xrt_hip_user_surface_unload. The handle is an opaque pointer; it is only valid in the
+ * process that loaded it. Crystals and multilayers on user surfaces are refused (their
+ * kernels need the second normal of the atomic planes). */
+XRT_HIP_API int xrt_hip_user_unit_abi(void);
+XRT_HIP_API int xrt_hip_user_surface_load(const char* path, void** handle);
+XRT_HIP_API int xrt_hip_user_surface_unload(void* handle);
 
 #define XRT_HIP_MAT_NONE 0
 #define XRT_HIP_MAT_MIRROR 1

@@ -1,0 +1,52 @@
+"""TEST INFRASTRUCTURE ONLY -- regenerates tests/golden/g2_user_surface.npz by RUNNING THE
+REFERENCE (imported from /root/reference, build container only): an OE subclass that defines
+its surface the reference's usual way, by overriding local_z / local_n with numpy code
+(tests/user_surface_case.py), reflecting 4096 rays with a Pt coating: the bulk of the cfg2
+generator plus rays that miss, fall off the edges and graze the surface. While generating,
+oracle/reflect_np.py (surface kind 'user' = the same two callables) is asserted against the
+reference's beams.
+
+Run:  python -m oracle.gen_fixtures_user_surface
+"""
+import os
+import sys
+
+import numpy as np
+
+from . import _refenv
+from . import gen_fixtures_p1 as g1
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                'tests'))
+
+
+def main():
+    _refenv.activate()
+    import xrt.backends.raycing as raycing
+    import xrt.backends.raycing.sources as rs
+    import xrt.backends.raycing.oes as roe
+    import xrt.backends.raycing.materials as rm
+    import user_surface_case as case
+    from .fixture_io import tables as load_tables
+    bl = raycing.BeamLine()
+    pt = rm.Material('Pt', rho=21.45, kind='mirror')
+    oe = case.subclass(roe)(bl, 'figured', center=[0, case.P, 0], pitch=case.PITCH,
+                            material=pt, **case.LIMITS)
+    beam = g1.make_rays(rs, 4096, 61, amplitudes=True, pol='mixed')
+    # edge rays: wide in x (off the sides), steep (over the ends / missing), one grazing
+    beam.x[:64] = np.linspace(-14., 14., 64)
+    beam.c[64:128] = np.linspace(-3e-5, 3e-5, 64)
+    beam.z[128:160] = np.linspace(-1.5, 1.5, 32)
+    beam.a[:], beam.c[:] = beam.a, beam.c
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.state[200] = 2
+    beam.state[201] = -3
+    par = g1.oe_params(oe, dict(kind='user', z=case.numpy_local_z, n=case.numpy_local_n))
+    par['material'] = g1.material_dict(load_tables(), pt)
+    g1.run_reflect('g2_user_surface', rs, oe, par, beam,
+                   surface_parameters=np.array([case.RS, case.RM, case.K3, case.KT]),
+                   mat_rho=np.array(21.45))
+
+
+if __name__ == '__main__':
+    main()

@@ -198,6 +198,8 @@ def rotate_coherency_matrix(b, idx, roll):
 # surfaces
 # --------------------------------------------------------------------------
 def local_z(surf, x, y):
+    if surf['kind'] == 'user':                    # an OE subclass's own local_z (numpy callables)
+        return surf['z'](x, y)
     if surf['kind'] == 'flat':                    # oes/base.py:675-679
         return np.zeros_like(y)
     if surf['kind'] == 'toroid':                  # oes/__init__.py:398-401
@@ -428,6 +430,8 @@ def _n_bent_toroid(surf, x, y, Rm, Rs, alpha):     # JohannToroid.local_n_toroid
 
 def local_n(surf, x, y):
     """3-list, or 6-list [n_H(3), n_surface(3)] for an asymmetric cut."""
+    if surf['kind'] == 'user':
+        return list(surf['n'](x, y))
     if surf['kind'] == 'flat' and surf.get('laue'):   # LauePlate.local_n, oes/laue.py:14-20
         a, b, c = 0, 0, 1
         if surf.get('alpha'):

@@ -10,7 +10,7 @@ c_int32_p = ctypes.POINTER(ctypes.c_int32)
 
 SURF_FLAT, SURF_TOROID, SURF_BENTFLAT, SURF_BLAZED, SURF_ELLIPSE_PARAM = 0, 1, 2, 3, 4
 SURF_PARABOLOID, SURF_CONE, SURF_SAGITTAL, SURF_BENT_BRAGG = 5, 6, 7, 8
-SURF_VFM, SURF_DUALVFM, SURF_DICED = 9, 10, 11
+SURF_VFM, SURF_DUALVFM, SURF_DICED, SURF_USER = 9, 10, 11, 12
 SHAPE_RECT, SHAPE_ROUND, SHAPE_POLYGON = 0, 1, 2
 OVER_XMIN, OVER_XMAX, OVER_YMIN, OVER_YMAX = 1, 2, 4, 8
 MAT_NONE, MAT_MIRROR, MAT_THIN_MIRROR, MAT_PLATE, MAT_CRYSTAL, MAT_MULTILAYER = 0, 1, 2, 3, 4, 5
@@ -82,6 +82,7 @@ class Pass(ctypes.Structure):
         ('g_ray_x', ctypes.c_void_p),
         ('g_ray_y', ctypes.c_void_p),
         ('method_hint', ctypes.c_void_p),
+        ('user_unit', ctypes.c_void_p),
     ]
 
 

@@ -119,10 +119,18 @@ class OE(object):
         nH = [0., -tilt if second else tilt, self.cosalpha if self.alpha else 1.]
         return nH + [0., 0., 1.]
 
+    def _has_source_surface(self):
+        from ... import usersurf
+        return usersurf.snippets_of(self) is not None
+
     def local_z(self, x, y):
+        if self._has_source_surface():       # hip_local_z, evaluated by its own kernel code
+            return self._eval_surface(_SURF_Z, x, y)[0]
         return np.zeros_like(y)
 
     def local_n(self, x, y):
+        if self._has_source_surface():
+            return list(self._eval_surface(_SURF_N, x, y)[3:])
         both = self._flat_normals()
         return both if self.alpha else both[:3]
 
@@ -133,12 +141,25 @@ class OE(object):
         # a subclass that brings its own numpy local_z / local_n (the usual way to define a
         # surface in an xrt script) cannot be evaluated by the kernels: say so instead of
         # tracing a flat surface
+        from ... import usersurf
+        if usersurf.snippets_of(self) is not None:
+            # the class brings its surface as HIP source (the reference: cl_local_z /
+            # cl_local_n, oes/base.py:69-90): the ray kernels compiled around it
+            p.surf_kind = _structs.SURF_USER
+            for k, value in enumerate(usersurf.parameters_of(self)):
+                p.surf_p[k] = value
+            p.user_unit = usersurf.unit_for(self)
+            p.asymmetric = 0
+            for k, value in enumerate((0., 0., 1., 0., 0., 1.)):
+                p.n_const[k] = value
+            return
         for name in ('local_z', 'local_n'):
             if getattr(type(self), name) is not getattr(OE, name) and \
                     type(self)._surface_params is OE._surface_params:
                 raise NotImplementedError(
-                    '%s.%s is user-defined: only the built-in surface kinds run on the GPU'
-                    % (type(self).__name__, name))
+                    '%s.%s is user-defined in Python: give the class its surface as source '
+                    '(hip_local_z / hip_local_n / hip_plist, see xrt_amd/usersurf.py) to run it '
+                    'on the GPU' % (type(self).__name__, name))
         p.surf_kind = _structs.SURF_FLAT
         p.asymmetric = 1 if self.alpha else 0
         for k, value in enumerate(self._flat_normals(second and hasattr(self, 'cryst2pitch'))):
@@ -206,7 +227,8 @@ class OE(object):
     def _surface_height(self, x, y):
         """z of the surface above (x, y) -- on a parametric surface the point of the
         surface that has these x and y."""
-        if type(self).local_z is OE.local_z and not self.isParametric:
+        if type(self).local_z is OE.local_z and not self.isParametric and \
+                not self._has_source_surface():
             return self.local_z(x, y)
         return self._eval_surface(_SURF_Z, x, y)[0]
 

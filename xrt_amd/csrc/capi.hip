@@ -1,5 +1,6 @@
 // C ABI of libxrt_hip.so (see include/xrt_hip.h for the contract).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdlib.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -275,8 +276,19 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
   if (pass->to_local.n < 0 || pass->to_local.n > XRT_HIP_MAX_ROT || pass->to_virgin.n < 0 ||
       pass->to_virgin.n > XRT_HIP_MAX_ROT)
     return fail(XRT_HIP_ERR_ARG, "rotation sequence longer than %d", XRT_HIP_MAX_ROT);
-  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_DICED)
+  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_USER)
     return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
+  if (pass->surf_kind == XRT_HIP_SURF_USER) {
+    if (!pass->user_unit)
+      return fail(XRT_HIP_ERR_ARG, "user-defined surface without its compiled unit "
+                                   "(xrt_hip_user_surface_load)");
+    if (material->kind == XRT_HIP_MAT_CRYSTAL || material->kind == XRT_HIP_MAT_MULTILAYER)
+      return fail(XRT_HIP_ERR_ARG, "crystals and multilayers on user-defined surfaces are not "
+                                   "supported (their kernels need the normal of the atomic "
+                                   "planes as well)");
+    if (pass->grating || pass->asymmetric)
+      return fail(XRT_HIP_ERR_ARG, "gratings on user-defined surfaces are not supported");
+  }
   if (material->kind == XRT_HIP_MAT_CRYSTAL && material->structure == 2 && !material->cell)
     return fail(XRT_HIP_ERR_ARG, "crystal from a unit cell without its xrt_hip_cell record");
   if (material->kind == XRT_HIP_MAT_MULTILAYER) {
@@ -508,8 +520,12 @@ int xrt_hip_surface_eval_f64_dev(const xrt_hip_pass* pass, int what, int64_t n, 
   if (n == 0) return XRT_HIP_OK;
   if (!u || !v || !out || ((what == 3 || what == 4) && !w))
     return fail(XRT_HIP_ERR_ARG, "NULL array");
-  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_DICED)
+  if (pass->surf_kind < XRT_HIP_SURF_FLAT || pass->surf_kind > XRT_HIP_SURF_USER)
     return fail(XRT_HIP_ERR_ARG, "unknown surface kind %d", pass->surf_kind);
+  if (pass->surf_kind == XRT_HIP_SURF_USER && (!pass->user_unit || what == 2 || what == 3 ||
+                                               what == 4))
+    return fail(XRT_HIP_ERR_ARG, "user-defined surface: no compiled unit, or a function of "
+                                 "parametric surfaces asked for");
   HIP_TRY(xrt::surface_eval_launch(*pass, what, n, u, v, w, out,
                                    reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;
@@ -649,6 +665,46 @@ int xrt_hip_crystal_amplitude_f64_dev(const xrt_hip_material* material, int64_t 
     return fail(XRT_HIP_ERR_ARG, "NULL array");
   HIP_TRY(xrt::crystal_amplitude_launch(*material, n, E, gamma0, gammah, hns, S_ri, P_ri,
                                         reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_user_unit_abi(void) { return xrt::user_unit_abi(); }
+
+int xrt_hip_user_surface_load(const char* path, void** handle) {
+  if (!path || !handle) return fail(XRT_HIP_ERR_ARG, "NULL path / handle");
+  *handle = nullptr;
+  void* dl = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!dl) return fail(XRT_HIP_ERR_ARG, "cannot open the surface unit %s: %s", path, dlerror());
+  auto abi = reinterpret_cast<int (*)()>(dlsym(dl, "xrt_user_unit_abi"));
+  xrt::UserUnit* u = new xrt::UserUnit();
+  u->dl = dl;
+  u->fused = reinterpret_cast<int (*)(int, const void*)>(dlsym(dl, "xrt_user_unit_fused"));
+  u->exact = reinterpret_cast<int (*)(const void*)>(dlsym(dl, "xrt_user_unit_exact"));
+  u->eval = reinterpret_cast<int (*)(const xrt_hip_pass*, int, int64_t, const double*,
+                                     const double*, double*, void*)>(
+      dlsym(dl, "xrt_user_unit_eval"));
+  if (!abi || !u->fused || !u->exact || !u->eval) {
+    delete u;
+    dlclose(dl);
+    return fail(XRT_HIP_ERR_ARG, "%s is not a surface unit (entry points missing)", path);
+  }
+  if (abi() != xrt::user_unit_abi()) {
+    const int theirs = abi();
+    delete u;
+    dlclose(dl);
+    return fail(XRT_HIP_ERR_ARG, "%s was built against other headers (unit abi %d, library %d): "
+                                 "rebuild it", path, theirs, xrt::user_unit_abi());
+  }
+  *handle = u;
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_user_surface_unload(void* handle) {
+  if (!handle) return XRT_HIP_OK;
+  xrt::UserUnit* u = static_cast<xrt::UserUnit*>(handle);
+  // (the unit's code objects stay registered with the HIP runtime: the library is not closed,
+  // kernels of it may still be in flight)
+  delete u;
   return XRT_HIP_OK;
 }
 

@@ -81,6 +81,19 @@ struct OptStat {
 };
 static_assert(sizeof(OptStat) == 128, "one slot per 128-byte line");
 
+// The kernels of a user-defined surface (XRT_HIP_SURF_USER), compiled at run time into a unit
+// of their own (csrc/user_unit.hip.in) and opened by xrt_hip_user_surface_load: what
+// xrt_hip_pass.user_unit points to. The launch records (reflect_tu.h) cross the boundary as
+// they are; user_unit_abi() of both sides must agree.
+struct UserUnit {
+  void* dl;
+  int (*fused)(int mode, const void* fused_launch);
+  int (*exact)(const void* exact_launch);
+  int (*eval)(const xrt_hip_pass* P, int what, int64_t n, const double* u, const double* v,
+              double* o, void* stream);
+};
+int user_unit_abi();
+
 size_t reflect_workspace_bytes(int64_t n);
 
 hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,

@@ -61,6 +61,11 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void surface_eval_kernel(
 
 hipError_t surface_eval_launch(const xrt_hip_pass& P, int what, int64_t n, const double* u,
                                const double* v, const double* w, double* o, hipStream_t st) {
+  if (P.surf_kind == XRT_HIP_SURF_USER) {   // the user's own functions, from their unit
+    const UserUnit* unit = static_cast<const UserUnit*>(P.user_unit);
+    if (!unit || !(what == 0 || what == 1 || what == 5)) return hipErrorInvalidValue;
+    return unit->eval(&P, what, n, u, v, o, st) == 0 ? hipSuccess : hipErrorLaunchFailure;
+  }
   hipLaunchKernelGGL(surface_eval_kernel,
                      dim3((unsigned)((n + REFLECT_BLOCK - 1) / REFLECT_BLOCK)),
                      dim3(REFLECT_BLOCK), 0, st, P, what, n, u, v, w, o);
@@ -536,6 +541,8 @@ static WsLayout ws_layout(void* workspace, int64_t n) {
   return L;
 }
 
+int user_unit_abi() { return XRT_USER_UNIT_ABI; }
+
 hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                const xrt_hip_beam& in, const xrt_hip_beam& restore,
                                const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
@@ -608,9 +615,15 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const ExactLaunch XL{dim3(exact_blocks(n)), dim3(REFLECT_EXACT_BLOCK), st, &P, &M, &in,
                        &restore, &lb, &vb, A};
   bool launched = true;
+  const UserUnit* unit = P.surf_kind == XRT_HIP_SURF_USER
+                             ? static_cast<const UserUnit*>(P.user_unit) : nullptr;
+  if (P.surf_kind == XRT_HIP_SURF_USER && (!unit || need_mean || layers))
+    return hipErrorInvalidValue;        // (capi.hip says why before it gets here)
   // the solve + finish kernel: mode 0 (optimistic) or 2 (no statistics needed)
   auto launch_fused = [&](int mode) {
-    if (need_mean)
+    if (unit)
+      launched &= unit->fused(mode, &FL) == 0;
+    else if (need_mean)
       launched &= tu_hot_xtal(spec, mode, FL) || tu_xtal_xtal(spec, mode, FL) ||
                   tu_layered_xtal(spec, mode, FL);
     else
@@ -618,8 +631,11 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                   tu_layered_fused(spec, mode, FL);
   };
   auto launch_exact = [&]() {
-    launched &= tu_exact0(family_spec, XL) || tu_exact1(family_spec, XL) ||
-                tu_exact2(family_spec, XL) || tu_exact3(family_spec, XL);
+    if (unit)
+      launched &= unit->exact(&XL) == 0;
+    else
+      launched &= tu_exact0(family_spec, XL) || tu_exact1(family_spec, XL) ||
+                  tu_exact2(family_spec, XL) || tu_exact3(family_spec, XL);
   };
   if (ev0) (void)hipEventRecord(ev0, st);
   if (optimistic) {

@@ -391,11 +391,18 @@ __device__ __forceinline__ double pinned(double v) {
 }
 template <class K>
 __device__ __forceinline__ constexpr bool wide_surfaces() {
-  return K::F >= 2;
+  return K::F == 2 || K::F == 3;
 }
 template <class K>
 __device__ __forceinline__ constexpr bool bent_crystal_surfaces() {
-  return K::F >= 2 || K::MK == XRT_HIP_MAT_CRYSTAL;
+  return K::F == 2 || K::F == 3 || (K::F != 4 && K::MK == XRT_HIP_MAT_CRYSTAL);
+}
+// family 4: a user-defined surface. Only a unit compiled around the user's two functions
+// (csrc/user_unit.hip.in defines XRT_USER_SURFACE and xrt_user::local_z / local_n before it
+// includes this file) instantiates it.
+template <class K>
+__device__ __forceinline__ constexpr bool user_surface() {
+  return K::F == 4;
 }
 template <class K>
 __device__ __forceinline__ bool surf_is_param(const xrt_hip_pass& P) {
@@ -538,6 +545,9 @@ __device__ __forceinline__ Facet diced_facet(const xrt_hip_pass& P, double x, do
 // surface height, oes/base.py:675-679 (flat), oes/__init__.py:398-401 (toroid)
 template <class K>
 __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double y) {
+#ifdef XRT_USER_SURFACE
+  if (user_surface<K>()) return xrt_user::local_z(x, y, P.surf_p);
+#endif
   if (PSURF(P) == XRT_HIP_SURF_TOROID) {
     const double R = P.surf_p[0], r = P.surf_p[1];
     double q, h;
@@ -2415,6 +2425,16 @@ __device__ __forceinline__ void bent_bragg_normals(const xrt_hip_pass& P, double
 template <class K>
 __device__ __forceinline__ void surface_normal(const xrt_hip_pass& P, double x, double y,
                                                double px, double py, double (&n)[6]) {
+#ifdef XRT_USER_SURFACE
+  if (user_surface<K>()) {
+    double v[3] = {0., 0., 1.};
+    xrt_user::local_n(x, y, P.surf_p, v);
+    n[0] = n[3] = v[0];
+    n[1] = n[4] = v[1];
+    n[2] = n[5] = v[2];
+    return;
+  }
+#endif
   if (PSURF(P) == XRT_HIP_SURF_TOROID) {  // oes/__init__.py:403-411
     const double R = P.surf_p[0], rr = P.surf_p[1];
     const double qx = x * frcp(rr);

@@ -53,6 +53,11 @@ struct DcmLaunch {     // reflect_fused_dcm / reflect_dcm_exact
   PassAux A1, A2;      // (the exact redo)
 };
 
+// what a user-surface unit and the library that loads it must agree on
+#define XRT_USER_UNIT_ABI                                                                     \
+  ((int)(sizeof(xrt_hip_pass) * 31 + sizeof(xrt_hip_material) * 17 + sizeof(xrt_hip_beam) * 5 + \
+         sizeof(xrt::FusedLaunch) * 7 + sizeof(xrt::ExactLaunch) * 3 + sizeof(xrt::GStat)))
+
 template <class K>
 inline void launch_fused_k(int mode, const FusedLaunch& L) {
   if (mode == 0)
