@@ -407,7 +407,9 @@ XRT_HIP_API size_t xrt_hip_reflect_workspace_bytes(int64_t n);
  * 7 undulator_map, 8 plot, 9 custom_field, 10 bend, 11 multilayer, 12 gauss. */
 XRT_HIP_API int xrt_hip_sizeof(int which);
 
-/* in: incoming beam. out_local: "lb" of the reference (true local frame).
+/* in: incoming beam. out_local: "lb" of the reference (true local frame); NULL (mirrors,
+ * plates and gratings only; with theta NULL as well) = not wanted, the reference's
+ * needLocal=False (oes/reflect.py:104-108): the pass then writes 200 B per ray instead of 308.
  * out_virgin: "gb"/"vlb" (virgin local or global, see xrt_hip_pass).
  * restore: beam whose x..E,J are copied into out_virgin for rays that did not
  * end in state {1,2} (reflect.py:131-134; dcm.py:330-335 passes the ORIGINAL

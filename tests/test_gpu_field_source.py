@@ -139,3 +139,30 @@ def test_get_trajectory_through_the_dropin_object(golden_dir, tag):
         name, scalars, None, [g['wtGrid'], g['Bx'], g['By'], g['Bz']], None, rw, 1)
     assert np.array_equal(betax, g['betax']) and np.array_equal(trajz, g['trajz'])
     assert betazav[-1] == float(g['betam']) and np.array_equal(rw[3], g['trajx'])
+
+
+def test_shine_onto_a_wave_takes_the_host_map(golden_dir):
+    """a wave from prepare_wave holds its points on the GPU; ``shine(wave=...)`` of a
+    source WITHOUT a device intensity map (SourceFromField inherits Undulator.shine) must take
+    the host path instead of the undulator's device path -- it raised NotImplementedError. The
+    same wave with its points pulled to the host first gives the same field."""
+    import xrt_amd.backends.raycing.apertures as ra
+    g = np.load(os.path.join(golden_dir, 'g13_sff_rays.npz'))
+    src = make_source(g)
+    assert not src._map_on_device()
+    slit = ra.RectangularAperture(src.bl, 'slit', [0, 20000., 0], ('left', 'right', 'bottom', 'top'),
+                                  [-1., 1., -1., 1.])
+    results = []
+    for pull in (False, True):
+        np.random.seed(4)
+        wave = slit.prepare_wave(src, 500)
+        assert 'xDiffr' in wave._d
+        if pull:
+            for f in ('xDiffr', 'yDiffr', 'zDiffr'):
+                getattr(wave, f)                       # host copies become the masters
+        np.random.seed(5)
+        out = src.shine(wave=wave)
+        results.append((np.array(out.Es), np.array(out.Ep), np.array(out.E)))
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+    assert np.abs(results[0][0]).max() > 0

@@ -876,3 +876,22 @@ def test_empty_material_keeps_the_amplitudes():
     total_in = (g['in_Jss'] + g['in_Jpp'])[hit]
     assert np.abs((lb1.Jss + lb1.Jpp)[hit] - total_in).max() < 1e-12
     assert ((lb0.Jss + lb0.Jpp)[hit] < total_in).all()
+
+
+def test_reflect_without_the_local_beam():
+    """needLocal=False (reference oes/reflect.py:104-108: ``lb = gb``): the global beam is what
+    the full pass gives, bit for bit; no local beam or theta is written; crystals keep theirs."""
+    from xrt_amd import workloads
+    oe = workloads.cfg2_toroid()
+    beam = workloads.synthetic_rays(200_003, 5, amplitudes=True)
+    gb, lb = oe.reflect(beam)
+    gb2, lb2 = oe.reflect(beam, needLocal=False)
+    assert lb2 is gb2 and 'theta' not in gb2.array_fields()
+    for f in gb.array_fields():
+        assert np.array_equal(gb.peek(f), gb2.peek(f)), f
+    again = oe.reflect(beam, needLocal=False, out=(gb2, lb2))       # in place
+    assert again[0] is gb2 and np.array_equal(gb.peek('x'), again[0].peek('x'))
+    dcm = workloads.cfg3_dcm()
+    g3, l3 = dcm.reflect(workloads.synthetic_rays(20_000, 5, sa=1e-4, E=(8995., 9005.)),
+                         needLocal=False)
+    assert l3 is not g3 and 'theta' in l3.array_fields()

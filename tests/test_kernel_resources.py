@@ -36,13 +36,26 @@ def test_hot_kernels_keep_their_budget():
     # diced, VFM): family 2 compiled into family 1 spilled 126 VGPRs / 1232 B there
     for mode in ('Li0', 'Li2'):
         conic = _one(table, 'reflect_fusedINS_4SpecILi1ELin1ELin1ELb0EEE' + mode)
-        assert conic['scratch'] <= 256 and conic['vgpr_spill'] <= 64 and conic['vgpr'] <= 128
+        assert conic['scratch'] <= 192 and conic['vgpr_spill'] <= 48 and conic['vgpr'] <= 128
         bent = _one(table, 'reflect_fusedINS_4SpecILi2ELin1ELin1ELb0EEE' + mode)
         # (a private segment of ~130 B is reserved -- the out-parameter of ocml's sincos -- but the
         # kernel holds no scratch instruction: no spills)
         assert bent['scratch'] <= 256 and bent['vgpr_spill'] == 0 and bent['vgpr'] <= 128
+    # the kernels of layered materials (Parratt recursion; compiled for three waves per SIMD =
+    # 168 VGPRs because that measured faster than two waves without spills, reflect_impl.h) and
+    # the family-1 generic kernel: their spills are a chosen trade, bounded here
+    for fam in ('Li0', 'Li1', 'Li2'):
+        for mode in ('Li0', 'Li2'):
+            lay = _one(table, 'reflect_fusedINS_4SpecI%sELin1ELi5ELb0EEE%s' % (fam, mode))
+            assert lay['vgpr'] <= 168 and lay['vgpr_spill'] <= 56 and lay['scratch'] <= 160, lay
+    for mode in ('Li0', 'Li2'):
+        lay = _one(table, 'reflect_fused_xtalINS_4SpecILi0ELin1ELi5ELb0EEE' + mode)
+        assert lay['vgpr'] <= 168 and lay['vgpr_spill'] <= 56 and lay['scratch'] <= 224, lay
     for small in ('reflect_decide_opt', 'reflect_decide_dcm'):
         assert _one(table, small)['scratch'] == 0
     for name, r in table.items():
         if 'kirchhoff_stream' in name:
+            assert r['scratch'] == 0 and r['vgpr_spill'] == 0, name
+            assert r.get('sgpr_spill', 0) <= 160, name     # (SGPRs spilled to VGPR lanes)
+        if 'geosource_shine' in name or 'plot_hist' in name and 'plot_hist_kernel' not in name:
             assert r['scratch'] == 0 and r['vgpr_spill'] == 0, name

@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 for ROUND in 1 2 3; do
   for LIB in "$@"; do
     XRT_HIP_LIBRARY=$LIB python bench.py --steps 40 --warmup 5 --skip-kirchhoff --skip-undulator \
-      --skip-softimax --skip-cpu-baseline 2>/dev/null | python -c "
+      --skip-softimax --skip-cpu-baseline --skip-balder --skip-e2e $AB_EXTRA 2>/dev/null | python -c "
 import json, sys
 d = json.loads(sys.stdin.readline())
 print('[%s] kernel %.4f ms  pass %.4f ms  step %.4f ms  dcm %.4f ms' % ('$LIB', d['kernel_ms'], d['pass_ms'], d['ms_per_step'], d.get('dcm', {}).get('ms_per_step', float('nan'))))"

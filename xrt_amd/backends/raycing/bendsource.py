@@ -90,6 +90,7 @@ class BendingMagnet(Undulator):
 
     def build_I_map_device(self, *args, **kwargs):
         raise NotImplementedError('use build_I_map')
+    build_I_map_device._no_device_map = True
 
     # ---- sampling -----------------------------------------------------------------------
     def _filament_electron(self, accuBeam):

@@ -234,3 +234,4 @@ class SourceFromField(Undulator):
 
     def build_I_map_device(self, *args, **kwargs):
         raise NotImplementedError('SourceFromField: use build_I_map')
+    build_I_map_device._no_device_map = True

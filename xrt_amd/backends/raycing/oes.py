@@ -426,10 +426,11 @@ class OE(object):
             b.parentId = self.uuid
 
     def _run_pass(self, p, material, fromVacuum, beam_in, restore, want_info=False,
-                  timing=False, out=None):
+                  timing=False, out=None, local=True):
         """-> (lb, vlb) device-resident beams (+ info dict). *out*: an (lb, vlb)
         pair from an earlier call on a beam of the same size to be overwritten
-        instead of allocating new arrays."""
+        instead of allocating new arrays. *local* False: no local beam is made (lb is
+        returned as None; mirrors, plates and gratings only)."""
         _lib.require_gpu()
         lib = _lib.load()
         dev = _device()
@@ -437,11 +438,13 @@ class OE(object):
         s_in = beam_in.to_struct(dev)
         s_re = s_in if restore is beam_in else restore.to_struct(dev)
         n = beam_in.nrays
-        reusable = out is not None and all(
-            b.nrays == n and not b._h_dirty() and
-            b.has_amplitudes() == beam_in.has_amplitudes() for b in out) and \
-            'theta' in out[0]._d
-        if reusable:
+        usable = lambda b: b is not None and b.nrays == n and not b._h_dirty() and \
+            b.has_amplitudes() == beam_in.has_amplitudes()      # noqa: E731
+        if not local:
+            lb, theta = None, None
+            vb = out[1] if out is not None and usable(out[1]) else \
+                rs.Beam.empty_like_on_device(beam_in, dev)
+        elif out is not None and all(usable(b) for b in out) and 'theta' in out[0]._d:
             lb, vb = out
             theta = lb._d['theta']
         else:
@@ -453,13 +456,14 @@ class OE(object):
         ms_out = (ctypes.c_float * 3)() if timing else None
         _lib.check(lib.xrt_hip_reflect_pass_f64_dev(
             ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_re),
-            ctypes.byref(lb.to_struct(dev)), ctypes.byref(vb.to_struct(dev)),
-            ctypes.c_void_p(theta.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+            ctypes.byref(lb.to_struct(dev)) if local else None, ctypes.byref(vb.to_struct(dev)),
+            ctypes.c_void_p(theta.data_ptr()) if local else None,
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(),
             _stream(), info, ms_out), 'xrt_hip_reflect_pass_f64_dev')
-        if lb._d.get('theta') is not theta:
+        if local and lb._d.get('theta') is not theta:
             lb._h.pop('theta', None)
             lb._d['theta'] = theta
-        self._adopt((lb, vb), beam_in)
+        self._adopt((lb, vb) if local else (vb,), beam_in)
         report = None
         if want_info:
             v = list(info)
@@ -638,18 +642,30 @@ class OE(object):
 
     def reflect(self, beam=None, needLocal=True, noIntersectionSearch=False,
                 returnLocalAbsorbed=None, _info=None, out=None, _timing=None):
-        """-> (beamGlobal, beamLocal). *out* (extension): the pair returned by an
-        earlier call, to be overwritten in place (no new HBM allocations).
-        *_info* (dict) receives the batch statistics (this takes the exact kernel
-        sequence); *_timing* (dict) the pass / kernel milliseconds and whether the
+        """-> (beamGlobal, beamLocal). *needLocal* False: no local beam is made and the
+        global beam is returned in its place, as in the reference (oes/reflect.py:104-108:
+        ``lb = gb``) -- the pass then writes 200 B per ray instead of 308 (mirrors, plates,
+        single-order gratings; crystals and zone plates keep theirs). *out* (extension): the
+        pair returned by an earlier call, to be overwritten in place (no new HBM
+        allocations). *_info* (dict) receives the batch statistics (this takes the exact
+        kernel sequence); *_timing* (dict) the pass / kernel milliseconds and whether the
         exact sequence had to run."""
+        from . import materials as _rm
+        stripes = self.material if raycing.is_sequence(self.material) else (self.material,)
+        crystal_like = any(isinstance(m, (_rm.Crystal, _rm.Multilayer)) for m in stripes)
+        local = bool(needLocal) or crystal_like or \
+            getattr(self, '_zones_between_passes', None) is not None or \
+            raycing.is_sequence(getattr(self, 'order', None))
         p = self._make_pass(
             self.pitch + getattr(self, 'bragg', 0), self.roll + self.positionRoll,
             self.yaw, self.dx, noIntersectionSearch=noIntersectionSearch,
             only_state1_out=hasattr(beam, 'createdByDiffract'))
         lb, gb, report = self._run_pass(
             p, self.material, True, beam, beam, want_info=_info is not None,
-            timing=_timing is not None, out=None if out is None else (out[1], out[0]))
+            timing=_timing is not None, out=None if out is None else (out[1], out[0]),
+            local=local)
+        if not local:
+            lb = gb
         between = getattr(self, '_zones_between_passes', None)
         if between is not None:       # zones that depend on the whole batch (general FZP)
             lb, gb, report, held = between(p, beam, lb, gb, _info, _timing)

@@ -597,6 +597,11 @@ class Undulator(MeshFunctions):
                     bot.Es[:] = fs / s2**0.5
                     bot.Ep[:] = fp / p2**0.5
 
+    def _map_on_device(self):
+        """Does this class implement ``build_I_map_device`` (Undulator does; subclasses that
+        replace it with a refusal say so with ``_no_device_map``)?"""
+        return not getattr(type(self).build_I_map_device, '_no_device_map', False)
+
     def shine(self, toGlobal=True, withAmplitudes=True, fixedEnergy=False,
               wave=None, accuBeam=None):
         """The source beam (rays sampled by rejection on the intensity map) or,
@@ -608,8 +613,10 @@ class Undulator(MeshFunctions):
                 raise ValueError("If you want to use a `wave`, run a "
                                  "`prepare_wave` before shine!")
             self.uniformRayDensity = True
+            # (the device path needs this class's map on the device: SourceFromField and the
+            # bending magnets keep theirs on the host and take the host path below -- ADVICE r3)
             if all(k in wave._d for k in ('xDiffr', 'yDiffr', 'zDiffr')) and \
-                    not (self.pitch or self.yaw):
+                    not (self.pitch or self.yaw) and self._map_on_device():
                 return self._shine_wave_on_device(wave, toGlobal, fixedEnergy, accuBeam)
         batch = len(wave.a) if wave is not None else self.nrays
         if self.uniformRayDensity:

@@ -378,7 +378,19 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
   const bool amp = in->Es_ri != nullptr || in->Ep_ri != nullptr;
   if ((rc = check_beam(in, "in", n, amp))) return rc;
   if ((rc = check_beam(restore, "restore", n, amp))) return rc;
-  if ((rc = check_beam(out_local, "out_local", n, amp))) return rc;
+  // out_local NULL: the beam in the element's local frame is not wanted (the reference's
+  // needLocal=False, oes/reflect.py:104-108) -- 100 B per ray less to write
+  xrt_hip_beam no_local;
+  memset(&no_local, 0, sizeof(no_local));
+  no_local.n = n;
+  if (!out_local) {
+    if (material->kind == XRT_HIP_MAT_CRYSTAL ||
+        (material->kind == XRT_HIP_MAT_MULTILAYER && material->geom_bragg))
+      return fail(XRT_HIP_ERR_ARG, "crystal passes keep their local beam (out_local NULL)");
+    out_local = &no_local;
+  } else if ((rc = check_beam(out_local, "out_local", n, amp))) {
+    return rc;
+  }
   if ((rc = check_beam(out_virgin, "out_virgin", n, amp))) return rc;
   if (n == 0) return XRT_HIP_OK;
   if (!workspace || workspace_bytes < xrt::reflect_workspace_bytes(n))

@@ -389,6 +389,16 @@ __device__ __forceinline__ double pinned(double v) {
   const int hi = __builtin_amdgcn_readfirstlane((int)(bits >> 32));
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
+// passes whose local beam may be left out (xrt_hip_reflect_pass_f64_dev with out_local NULL):
+// not the crystal / layered kernels
+template <class K>
+__device__ __forceinline__ constexpr bool optional_local() {
+#ifdef XRT_NO_OPTIONAL_LOCAL      /* A/B: what the test costs the hot kernel */
+  return false;
+#else
+  return K::MK != XRT_HIP_MAT_CRYSTAL && K::MK != XRT_HIP_MAT_MULTILAYER;
+#endif
+}
 template <class K>
 __device__ __forceinline__ constexpr bool wide_surfaces() {
   return K::F == 2 || K::F == 3;
@@ -2847,6 +2857,10 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
 // ---------------------------------------------------------------------------
 // stores
 // ---------------------------------------------------------------------------
+// OPTIONAL: the record may be one nobody asked for (o.x null: OE.reflect(needLocal=False) makes
+// no local beam). Only the passes that can be called that way pay the test: with it in the
+// kernels of layered materials their spills went from 50 to 72 VGPRs.
+template <bool OPTIONAL = false>
 __device__ __forceinline__ void store_ray(const xrt_hip_beam& o, int64_t i, double x, double y,
                                           double z, double a, double b, double c, double path,
                                           double E, double Jss, double Jpp, double Jsr,
@@ -2857,6 +2871,7 @@ __device__ __forceinline__ void store_ray(const xrt_hip_beam& o, int64_t i, doub
   // 0.571 ms, DCM 0.869 -> 0.853 ms. (No effect in round 2, when the kernels were a prologue
   // away from their streaming floor; the floor itself gains 1-4 %, profiles/r03_probe_stream.txt.)
   typedef double v2d __attribute__((ext_vector_type(2)));
+  if (OPTIONAL && !o.x) return;
   __builtin_nontemporal_store(x, &o.x[i]);
   __builtin_nontemporal_store(y, &o.y[i]);
   __builtin_nontemporal_store(z, &o.z[i]);
@@ -2875,8 +2890,10 @@ __device__ __forceinline__ void store_ray(const xrt_hip_beam& o, int64_t i, doub
   }
 }
 
+template <bool OPTIONAL = false>
 __device__ __forceinline__ void copy_ray(const xrt_hip_beam& o, const xrt_hip_beam& s,
                                          int64_t i, int st, bool has_amp, bool zero_xyz) {
+  if (OPTIONAL && !o.x) return;
   double2 js = reinterpret_cast<const double2*>(s.Jsp_ri)[i];
   double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
   if (has_amp) {
@@ -2954,8 +2971,8 @@ __device__ __forceinline__ Completed complete_ray(
   if (pc) XRT_TICK(*pc, 3, la + vJss + lo.Jpp);
 #endif
   if (theta) theta[i] = th;
-  store_ray(lb, i, h.x, h.y, h.z, la, lbb, lc, lo.path, lo.E, lo.Jss, lo.Jpp, lo.Jsr, lo.Jsi,
-            st, lo.Esr, lo.Esi, lo.Epr, lo.Epi, has_amp);
+  store_ray<optional_local<K>()>(lb, i, h.x, h.y, h.z, la, lbb, lc, lo.path, lo.E, lo.Jss, lo.Jpp,
+                                 lo.Jsr, lo.Jsi, st, lo.Esr, lo.Esi, lo.Epr, lo.Epi, has_amp);
   const bool keep = P.only_state1_out ? (st == 1) : (st == 1 || st == 2);
   if (!keep && VREC) return res;
   res.kept = keep;
@@ -3049,6 +3066,7 @@ __device__ __forceinline__ Completed complete_ray(
   return res;
 }
 
+template <class K>
 __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hip_beam& in,
                                              const xrt_hip_beam& restore,
                                              const xrt_hip_beam& lb, const xrt_hip_beam& vb,
@@ -3056,9 +3074,9 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
   // not entering: both outputs are copies (reflect.py:104-108); dcm.py:298-303
   // zeroes the local record of rays that never reached the 2nd crystal
   if (P.zero_local_not_entering)
-    copy_ray(lb, in, i, 0, has_amp, true);
+    copy_ray<optional_local<K>()>(lb, in, i, 0, has_amp, true);
   else
-    copy_ray(lb, in, i, st, has_amp, false);
+    copy_ray<optional_local<K>()>(lb, in, i, st, has_amp, false);
   copy_ray(vb, restore, i, P.force_lost_out ? P.lost_num : st, has_amp, false);
   if (theta) theta[i] = 0.;
 }
@@ -3147,7 +3165,7 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   // (measured on cfg2: 0.71 -> 0.68 ms, at four waves per SIMD instead of five)
   const RayIn qpre = req.q;
 #endif
-  if (i < in.n && !active) pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
+  if (i < in.n && !active) pass_through<K>(P, in, restore, lb, vb, theta, i, st0, has_amp);
   XRT_TICK(pc, 1, r.x + r.a + r.z);
   Hit h;
   if (mode == 0) {
@@ -3310,7 +3328,7 @@ __device__ __forceinline__ void finish_body(const xrt_hip_pass& P, const xrt_hip
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
     const int st0 = in.state[i];
     if (!entering(P, st0)) {
-      pass_through(P, in, restore, lb, vb, theta, i, st0, has_amp);
+      pass_through<K>(P, in, restore, lb, vb, theta, i, st0, has_amp);
       continue;
     }
     LocalRay r;
