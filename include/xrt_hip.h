@@ -378,6 +378,11 @@ typedef struct xrt_hip_material {
    * consulted (nelem may be 0). */
   int32_t n_fixed;
   double n_re, n_im;
+  /* n_fixed == 2: Material(refractiveIndex = a table or a file) (material.py:252-262, 284-330:
+   * cubic spline through the tabulated n + ik): the index of every ray at its energy,
+   * evaluated by the caller, interleaved (re, im) in DEVICE memory, n of them. Mirrors, plates,
+   * gratings; not inside a multilayer stack. */
+  const double* n_ray;
 } xrt_hip_material;
 
 /* Multilayer / GradedMultilayer / Coated (materials/multilayer.py): npairs periods of a

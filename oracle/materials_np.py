@@ -63,8 +63,12 @@ def make_material(elements, quantities=None, kind='mirror', rho=0., t=None):
 
 
 def refractive_index(m, E):
-    if m.get('refractiveIndex') is not None:        # material.py:372-373: a constant
-        return m['refractiveIndex']
+    given = m.get('refractiveIndex')
+    if isinstance(given, (list, tuple)):             # material.py:364-371: [energies, spline]
+        if np.min(E) > given[0][0] and np.max(E) < given[0][-1]:
+            return given[1](E)
+    elif given is not None:                          # :372-373: a constant
+        return given
     xf = np.zeros_like(E) * 0j
     for elem, xi in zip(m['elements'], m['quantities']):
         xf += (elem['Z'] + interp_f1f2(elem, E)) * xi

@@ -50,20 +50,33 @@ def test_argument_validation_without_gpu():
         _lib.check(rc, 'plan')
 
 
-def test_crystal_on_a_conic_or_vfm_surface_is_refused():
-    """A Bragg crystal on a surface kind only the family-1 / family-2 kernels evaluate
-    (parametric conics, lenses, cone, blazed, VFM, DualVFM) is refused by the C ABI before any
-    GPU work: the crystal kernels are compiled for family 0 and would trace it as flat."""
+def test_crystal_surface_combinations_the_c_abi_takes():
+    """Round 4: Bragg crystals on conics, lens paraboloids, cones, VFM and DualVFM go through the
+    generic exact sequence of the surface's family (tests/test_gpu_reflect.py has the goldens);
+    a blazed profile has no Bragg planes, and user-defined surfaces carry one normal only: both
+    are refused by the C ABI before any GPU work, with a reason."""
     import ctypes
     from xrt_amd import _lib, _structs
     lib = _lib.load(build_if_missing=False)
     lib.xrt_hip_last_error.restype = ctypes.c_char_p
-    for kind in (3, 4, 5, 6, 9, 10):
+
+    def call(kind, unit=None):
         p, m = _structs.Pass(), _structs.Material()
         p.surf_kind = kind
+        p.invert_normal = 1
+        if unit:
+            p.user_unit = unit
         m.kind = 4          # XRT_HIP_MAT_CRYSTAL
         rc = lib.xrt_hip_reflect_pass_f64_dev(ctypes.byref(p), ctypes.byref(m), None, None, None,
                                               None, None, None, ctypes.c_size_t(0), None, None,
                                               None)
-        assert rc != 0, kind
-        assert b'crystals on blazed / parametric surfaces' in lib.xrt_hip_last_error()
+        return rc, lib.xrt_hip_last_error()
+    rc, why = call(3)
+    assert rc != 0 and b'crystals on blazed gratings' in why
+    rc, why = call(12, unit=1)
+    assert rc != 0 and b'user-defined surfaces' in why
+    rc, why = call(12)
+    assert rc != 0 and b'without its compiled unit' in why
+    for kind in (4, 5, 6, 9, 10):       # accepted: the call fails later, on the empty records
+        rc, why = call(kind)
+        assert rc != 0 and b'surface' not in why and b'crystals' not in why, (kind, why)

@@ -138,9 +138,11 @@ def test_device_record_of_a_source():
 
 # --------------------------------------------------------------------------- GPU
 def _close(got, want, ulps, what):
-    scale = np.maximum(np.abs(want), 1e-300)
-    err = np.abs(got - want) / scale
-    assert err.max() <= ulps * 2.3e-16, (what, err.max())
+    # norm-wise: a Gaussian deviate radius * cos(2 pi u) near a zero of the cosine is tiny, and
+    # numpy rounds the angle 2 pi u before taking the cosine (an absolute error of ~1e-16 of
+    # the radius), the kernel reduces u exactly -- what matters is the error against sigma
+    err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
+    assert err <= ulps * 2.3e-16, (what, err)
 
 
 @pytest.mark.gpu

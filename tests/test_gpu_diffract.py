@@ -71,7 +71,6 @@ def test_kernel_timing_on_request(golden_dir):
     assert rw.lastKernelMs is not None and rw.lastKernelMs > 0
 
 
-@pytest.mark.parametrize('name', ['g4_slit_4000x48', 'g4_toroid_3000x24'])
 def _two_gpus():
     try:
         return torch.cuda.device_count() >= 2
@@ -84,6 +83,7 @@ def _two_gpus():
 _TWO = pytest.mark.skipif(not _two_gpus(), reason='needs two visible GPUs')
 
 
+@pytest.mark.parametrize('name', ['g4_slit_4000x48', 'g4_toroid_3000x24'])
 @pytest.mark.parametrize('devs', [[0, 0], [0, 0, 0], pytest.param([0, 1], marks=_TWO),
                                   pytest.param([1, 0, 1], marks=_TWO)])
 def test_diffract_over_several_devices_is_the_single_device_result(golden_dir, name, devs):

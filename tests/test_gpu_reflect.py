@@ -803,8 +803,50 @@ def test_fixed_refractive_index_matches_reference(golden_dir):
     compare(gb2, g, lambda f: g['gb_' + f])
     compare(lo1, g, lambda f: g['lo1_' + f])
     compare(lo2, g, lambda f: g['lo2_' + f])
-    with pytest.raises(NotImplementedError):
-        rm.Material(refractiveIndex=np.ones((5, 3)))
+
+
+def test_tabulated_refractive_index_matches_reference(golden_dir):
+    """Material(refractiveIndex = a table | a file) (VERDICT r3 missing #5; material.py:240-262,
+    284-330, 364-373): the cubic spline through n + ik evaluated per ray on the GPU; amplitudes
+    of a mirror and a plate from the array and from the reference's text format (k on a sparser
+    grid), the whole-call fall-back to the element tables when an energy leaves the table, and
+    a mirror of the material in a beamline. Golden: oracle/gen_fixtures_index_table.py."""
+    import os
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.materials as rm
+    import xrt_amd.backends.raycing.oes as roe
+    g = np.load(os.path.join(golden_dir, 'g5_index_table.npz'))
+    csv = os.path.join(golden_dir, 'g5_index_table.csv')
+    for form, spec in (('array', g['table']), ('file', csv)):
+        for kind in ('mirror', 'plate'):
+            m = rm.Material('Au', rho=19.32, kind=kind, refractiveIndex=spec)
+            res = m.get_amplitude(g['E'], g['bdn'], True)
+            for i, lab in enumerate(('rs', 'rp', 'mu', 'nk')):
+                ref = g['amp_%s_%s_%s' % (form, kind, lab)]
+                assert np.abs(res[i] - ref).max() <= 1e-11 * np.abs(ref).max(), (form, kind, lab)
+        assert np.abs(m.get_refractive_index(g['E']) - g['n_' + form]).max() < 1e-13
+    m = rm.Material('Au', rho=19.32, kind='mirror', refractiveIndex=g['table'])
+    res = m.get_amplitude(g['E_out'], g['bdn'], True)          # one energy outside the table
+    for i, lab in enumerate(('rs', 'rp', 'mu', 'nk')):
+        ref = g['out_' + lab]
+        assert np.abs(res[i] - ref).max() <= 1e-9 * np.abs(ref).max(), lab
+    bl = raycing.BeamLine()
+    oe = roe.OE(bl, 'vuv', center=[0, 1000., 0], pitch=np.radians(10.), material=m,
+                limPhysX=[-5, 5], limPhysY=[-20, 20])
+    gb, lb = oe.reflect(pc.product_beam(g))
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    # the reflectivity really comes from the table: ~10 x a mirror from the element tables
+    hit = g['lb_state'] == 1
+    plain = roe.OE(raycing.BeamLine(), 'p', center=[0, 1000., 0], pitch=np.radians(10.),
+                   material=rm.Material('Au', rho=19.32, kind='mirror'), limPhysX=[-5, 5],
+                   limPhysY=[-20, 20]).reflect(pc.product_beam(g))[1]
+    assert np.abs((lb.Jss + lb.Jpp)[hit] - (plain.Jss + plain.Jpp)[hit]).max() > 0.05
+    with pytest.raises(ValueError):
+        rm.Material(refractiveIndex=np.ones((5, 2)))
+    with pytest.raises(NotImplementedError):        # not inside a layered material
+        rm.Coated(coating=m, cThickness=100., substrate=rm.Material('Si', rho=2.33),
+                  surfaceRoughness=0, substRoughness=0).to_struct()
 
 
 # ---- mirrors on their mechanical supports (oes/__init__.py:212-587, stages.py) --------
@@ -895,3 +937,43 @@ def test_reflect_without_the_local_beam():
     g3, l3 = dcm.reflect(workloads.synthetic_rays(20_000, 5, sa=1e-4, E=(8995., 9005.)),
                          needLocal=False)
     assert l3 is not g3 and 'theta' in l3.array_fields()
+
+
+# ---- crystals on surfaces outside the crystal kernels' families (VERDICT r3 missing #4) -----
+@pytest.mark.parametrize('case', ['parabola', 'vfm'])
+def test_crystals_on_conic_and_vfm_surfaces_match_reference_golden(case):
+    """Si(111) on a focusing paraboloid (parametric solve) and on a VFM, at the Bragg angle: the
+    reference's _reflect_local is generic in (surface, material), oes/reflect.py:551-1139. The
+    fused crystal kernels know flat and bent-crystal shapes only; these go through the generic
+    exact sequence of the surface's family. Goldens: oracle/gen_fixtures_conic_crystal.py."""
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.materials as rm
+    import xrt_amd.backends.raycing.oes as roe
+    g = pc.load('g3_conic_crystal_' + case)
+    si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    thB = float(g['bragg'])
+    assert thB == float(np.ravel(si.get_Bragg_angle(9000.) - si.get_dtheta(9000.))[0])
+    bl = raycing.BeamLine()
+    if case == 'parabola':
+        oe = roe.ParabolicalMirrorParam(bl, 'analyser', center=[0, 30000., 0], material=si,
+                                        pitch=thB, p=None, q=8000., limPhysX=(-1.5, 1.5),
+                                        limPhysY=(-20., 20.))
+    else:
+        support = dict(jack1=[-50., 24700., 0.], jack2=[60., 25000., 0.],
+                       jack3=[-40., 25300., 0.], tx1=[0., -300.], tx2=[0., 300.])
+        oe = roe.VFM(bl, 'vfm', [0., 25000., 0.], material=(si,), surface=None,
+                     limPhysX=(-20., 20.), limPhysY=(-60., 60.), limOptX=(-3., 3.),
+                     limOptY=(-50., 50.), R=6e6, r=35., pitch=thB, **support)
+    assert oe.lostNum == int(g['oe_lostNum'])
+    gb, lb = oe.reflect(pc.product_beam(g))
+    # the parametric solve ends within an ulp or two of the reference's path; k dt ~ 1e-6 rad
+    tol = dict(geo_tol=4e-12, amp_tol=1e-8) if case == 'parabola' else {}
+    compare(gb, g, lambda f: g['gb_' + f], **tol)
+    compare(lb, g, lambda f: g['lb_' + f], **tol)
+    assert (g['lb_state'] == 1).mean() > 0.8
+    assert np.abs(lb.theta - g['lb_theta']).max() < 1e-12
+    # the reflectivity is a Bragg curve, not a mirror's: most of the flux survives at the angle
+    hit = g['lb_state'] == 1
+    # (the VFM's sagittal cylinder takes most rays off the Bragg angle)
+    assert (lb.Jss + lb.Jpp)[hit].mean() > (0.3 if case == 'parabola' else 0.05) * \
+        (g['in_Jss'] + g['in_Jpp'])[hit].mean()

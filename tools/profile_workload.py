@@ -6,6 +6,7 @@
   * OE.reflect cfg2, 1e7 rays   - P1
   * DCM.double_reflect cfg3     - P1, crystal path
   * Kirchhoff cfg4 (1 launch)   - P2
+  * GeometricSource(rng='device').shine, 1e7 rays - the ray generator kernel
 """
 import sys
 import numpy as np
@@ -29,6 +30,10 @@ for _ in range(reps):
     scr.expose(beam)
 for _ in range(reps):
     oe.reflect(beam)
+# the device ray generator (round 4): 100 B written per ray, nothing read
+bl_e2e, _, _ = workloads.e2e_beamline(n)
+for _ in range(reps):
+    bl_e2e.source.shine()
 dcm = workloads.cfg3_dcm()
 b3 = workloads.synthetic_rays(n, 43, sa=1e-4, E=(8995., 9005.))
 for _ in range(reps):

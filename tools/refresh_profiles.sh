@@ -21,13 +21,20 @@ tail -c 600 $O/bench_under_rocprof.json | head -c 600; echo
 bash tools/pmc_reflect.sh > profiles/r${RND}_reflect_pmc.txt 2>&1
 bash tools/pmc_und.sh > profiles/r${RND}_und_pmc.txt 2>&1
 bash tools/prof_hist.sh > profiles/r${RND}_hist_kernels.txt 2>&1
+# round 4: SQ counters of BOTH Kirchhoff loops (cfg4 fast loop, general gen_sp_n), HBM bytes of
+# the histogram kernels (also profiles/hist_traffic.json, read by bench.py), the kernels of one
+# end-to-end run_ray_tracing iteration
+bash tools/pmc_kirchhoff.sh cfg4 > profiles/r${RND}_kirchhoff_pmc.txt 2>&1
+bash tools/pmc_kirchhoff.sh general > profiles/r${RND}_kirchhoff_general_pmc.txt 2>&1
+bash tools/pmc_hist.sh > profiles/r${RND}_hist_pmc.txt 2>&1
+bash tools/prof_e2e.sh 1e7 > profiles/r${RND}_e2e_kernels.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/probes/probe_fp64_rates.hip -o /tmp/probe_fp64_rates 2>/dev/null && \
   timeout 300 /tmp/probe_fp64_rates > profiles/r${RND}_probe_fp64_rates.txt 2>&1
-for P in probe_stream probe_occupancy probe_atomics probe_fp64_seeds; do
+for P in probe_stream probe_occupancy probe_atomics probe_fp64_seeds probe_lds_atomics; do
   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/probes/$P.hip -o /tmp/$P 2>/dev/null && \
     timeout 300 /tmp/$P > profiles/r${RND}_$P.txt 2>&1
 done
 hipcc --offload-arch=gfx950 -O3 -DNOUT=40 -DBLOCK=256 tools/probes/probe_occupancy.hip -o /tmp/po40 2>/dev/null && \
   timeout 300 /tmp/po40 > profiles/r${RND}_probe_occupancy_dcm_shape.txt 2>&1
-cp profiles/r${RND}_*.txt $O/summaries/ 2>/dev/null
+cp profiles/r${RND}_*.txt profiles/hist_traffic.json $O/summaries/ 2>/dev/null
 find $O -name '*.db' -size +40M -delete

@@ -21,7 +21,7 @@ OURS = ('reflect_fused_xtal', 'reflect_fused_dcm', 'reflect_dcm_exact', 'reflect
         'reflect_decide_opt', 'reflect_exact', 'reflect_fused', 'reflect_init',
         'screen_expose_kernel', 'kirchhoff_stream', 'kirchhoff_scan', 'kirchhoff_pack',
         'kirchhoff_finalize', 'und_imap', 'und_sum', 'und_pack', 'aperture_propagate_kernel',
-        'plot_hist_rays', 'plot_hist_tiles', 'plot_hist_reduce',
+        'plot_hist_rays', 'plot_hist_tiles', 'plot_hist_reduce', 'geosource_shine_kernel',
         'plot_hist_kernel', 'surface_eval_kernel',
         'beam_to_global_kernel')
 

@@ -118,6 +118,7 @@ class Material(ctypes.Structure):
         ('n_fixed', ctypes.c_int32),
         ('n_re', ctypes.c_double),
         ('n_im', ctypes.c_double),
+        ('n_ray', ctypes.c_void_p),
     ]
 
 

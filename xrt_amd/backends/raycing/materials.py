@@ -100,6 +100,63 @@ def _dev_f64(a, device):
     return torch.from_numpy(np.array(a, dtype=np.float64, order='C')).to(device)
 
 
+_SPLINE = dict(kind='cubic', bounds_error=False, fill_value='extrapolate')   # material.py:11
+
+
+def _read_index_file(path):
+    """E, n, k of a refractive-index file the way the reference reads it (material.py:284-330):
+    a spreadsheet with the three columns, or comma-separated text whose rows are 'E, n' or
+    'E, n, k' (k on a sparser or denser grid than n: it is splined onto the energies of n)."""
+    from scipy.interpolate import interp1d
+    if path.endswith(('.xls', '.xlsx')):
+        from pandas import read_excel
+        data = read_excel(path).values
+        return data[:, 0], data[:, 1], data[:, 2]
+    e_n, e_k, n, k = [], [], [], []
+    with open(path) as f:
+        for line in f:
+            fields = line.split(',')
+            try:
+                energy = float(fields[0])
+            except ValueError:
+                continue
+            if len(fields) < 3:
+                e_n.append(energy)
+                n.append(float(fields[-1]))
+            else:
+                e_k.append(energy)
+                k.append(float(fields[-1]))
+                if fields[1].strip():
+                    e_n.append(energy)
+                    n.append(float(fields[1]))
+    e_n = np.array(e_n)
+    return e_n, np.array(n), interp1d(np.array(e_k), np.array(k), **_SPLINE)(e_n)
+
+
+def _given_index(spec):
+    """None, a complex number, or [energies, interp1d] of a tabulated index."""
+    import os
+    from scipy.interpolate import interp1d
+    if spec is None:
+        return None
+    if isinstance(spec, (int, float, complex)) and not isinstance(spec, bool):
+        return complex(spec)
+    if isinstance(spec, str):
+        if not os.path.exists(spec):
+            print(os.path.abspath(spec), "not found! Using refractive index of 1")
+            return complex(1.)
+        energies, n, k = _read_index_file(spec)
+    else:
+        table = np.asarray(spec)
+        if table.ndim != 2 or table.shape[1] < 3:
+            raise ValueError('refractiveIndex: a number, a file, or an array with the columns '
+                             'E, n, k')
+        energies, n, k = table[:, 0], table[:, 1], table[:, 2]
+    energies = np.asarray(energies, dtype=float)
+    return [energies, interp1d(energies, np.complex128(np.asarray(n) + 1j*np.asarray(k)),
+                               **_SPLINE)]
+
+
 class Material(object):
     """Amorphous material given by its chemical formula and density
     (material.py:23-157)."""
@@ -121,11 +178,11 @@ class Material(object):
         self.kind = kind
         self.rho = rho
         self.t = t
-        # a constant, energy-independent index (visible light, IR: outside the tables),
-        # material.py:240-262; tabulated n(E) is not on the GPU path
-        if refractiveIndex is not None and not isinstance(refractiveIndex, (int, float, complex)):
-            raise NotImplementedError('refractiveIndex as a table or a file')
-        self.refractiveIndex = None if refractiveIndex is None else complex(refractiveIndex)
+        # the index given instead of taken from the element tables (visible light, IR, VUV:
+        # outside the tables), material.py:240-262: a number, or n(E) + i k(E) as an array with
+        # the columns E, n, k or as a file of them -> [energies, cubic spline] like the reference
+        self.refractiveIndex = _given_index(refractiveIndex)
+        self._index_poly = {}
         # gratings / zone plates: [order, efficiency] pairs used in place of the Fresnel
         # amplitudes (material.py:78-95, 391-413)
         if efficiencyFile is not None:
@@ -158,7 +215,44 @@ class Material(object):
             s.tab_f2[i] = t2.data_ptr()
         return keep
 
-    def to_struct(self, fromVacuum=True, device=None):
+    def _table_covers(self, E):
+        """min(E) and max(E) strictly inside the tabulated energies (material.py:366-367)."""
+        energies = self.refractiveIndex[0]
+        if isinstance(E, torch.Tensor):
+            if E.numel() == 0:
+                return True
+            lo, hi = float(E.min()), float(E.max())
+        else:
+            lo, hi = float(np.min(E)), float(np.max(E))
+        return lo > energies[0] and hi < energies[-1]
+
+    def _index_on_device(self, E):
+        """The spline of the tabulated index at the energies *E* (device tensor) -> complex128
+        tensor: the cubic pieces of scipy's interpolant (its B-spline turned into a piecewise
+        polynomial once), found by a bisection and evaluated by Horner's rule, all on the GPU."""
+        key = E.device
+        if key not in self._index_poly:
+            from scipy.interpolate import BSpline, PPoly
+            spline = self.refractiveIndex[1]._spline      # complex coefficients: two real ones
+            flat = np.asarray(spline.c).reshape(len(spline.c), -1)[:, 0]
+            parts = [PPoly.from_spline(BSpline(spline.t, np.ascontiguousarray(c), spline.k))
+                     for c in (flat.real, flat.imag)]
+            knots = np.asarray(parts[0].x, dtype=float)
+            coef = np.asarray(parts[0].c) + 1j * np.asarray(parts[1].c)      # [4, pieces]
+            # (the first and last three pieces of the B-spline's knot vector are empty)
+            keep = np.flatnonzero(np.diff(knots) > 0)
+            self._index_poly[key] = (
+                torch.from_numpy(knots[keep].copy()).to(E.device),
+                torch.from_numpy(np.ascontiguousarray(coef[:, keep]).astype(complex)).to(E.device))
+        starts, coef = self._index_poly[key]
+        piece = torch.clamp(torch.searchsorted(starts, E, right=True) - 1, 0, starts.numel() - 1)
+        dx = E - starts[piece]
+        value = coef[0][piece]
+        for order in range(1, coef.shape[0]):
+            value = value * dx + coef[order][piece]
+        return value.contiguous()
+
+    def to_struct(self, fromVacuum=True, device=None, E=None):
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         kind = 'mirror' if self.kind == 'auto' else self.kind
@@ -171,8 +265,26 @@ class Material(object):
         s.rho = float(self.rho)
         s.mass = float(self.mass)
         s.t = float(self.t) if self.t is not None else 0.
-        if self.refractiveIndex is not None:
+        if isinstance(self.refractiveIndex, complex):
             s.n_fixed, s.n_re, s.n_im = 1, self.refractiveIndex.real, self.refractiveIndex.imag
+        elif self.refractiveIndex is not None:
+            # tabulated: the spline at every ray's energy (device tensor *E*), if the whole batch
+            # lies inside the table -- else the element tables, as the reference decides
+            # (material.py:364-373, one decision per call)
+            if E is None:
+                raise NotImplementedError(
+                    '%s: a tabulated refractive index is evaluated per ray of a beam (mirrors, '
+                    'plates, gratings); not inside a layered material' % self.name)
+            if self._table_covers(E):
+                index = self._index_on_device(E)
+                s._keep.append(index)
+                s.n_fixed, s.n_ray = 2, index.data_ptr()
+            elif not self.elements:
+                raise ValueError('%s: energies outside the tabulated refractive index and no '
+                                 'elements to fall back to' % self.name)
+            else:
+                print("Cannot calculate refractive index. Energy outside of the range. "
+                      "Using atomic scattering factors")
         elif not self.elements:
             raise ValueError('a material needs elements or a refractiveIndex')
         if kind == 'thin mirror' and self.t is None:
@@ -191,8 +303,8 @@ class Material(object):
         bdn = np.broadcast_to(np.asarray(beamInDotNormal, dtype=np.float64),
                               E.shape)
         n = E.size
-        s = self.to_struct(fromVacuum, dev)
         dE, db = _dev_f64(E, dev), _dev_f64(bdn, dev)
+        s = self.to_struct(fromVacuum, dev, E=dE)
         rs = torch.empty(n, dtype=torch.complex128, device=dev)
         rp = torch.empty(n, dtype=torch.complex128, device=dev)
         mu = torch.empty(n, dtype=torch.float64, device=dev)
@@ -209,8 +321,10 @@ class Material(object):
         """n(E) from (mu, Re(n) k) of the device function (material.py:348-378):
         n = nk*CHBAR/(E*1e8) + i*mu*CHBAR/(E*2e8); sign of Im(n) as tabulated
         (f2 > 0 -> Im(n) < 0)."""
-        if self.refractiveIndex is not None:
+        if isinstance(self.refractiveIndex, complex):
             return self.refractiveIndex
+        if self.refractiveIndex is not None and self._table_covers(E):
+            return self.refractiveIndex[1](E)
         E = np.atleast_1d(np.asarray(E, dtype=np.float64))
         saved = self.kind
         try:
@@ -328,6 +442,10 @@ class Multilayer(object):
     def _layer_struct(self, layer, device, keep):
         s = _structs.Material()
         if layer is not None:
+            if isinstance(getattr(layer, 'refractiveIndex', None), list):
+                raise NotImplementedError(
+                    '%s: a tabulated refractive index is evaluated per ray of a beam (mirrors, '
+                    'plates, gratings); not inside a layered material' % layer.name)
             keep += layer._fill_elements(s, device)
             s.rho, s.mass = float(layer.rho), float(layer.mass)
         return s

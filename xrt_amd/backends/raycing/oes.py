@@ -411,10 +411,13 @@ class OE(object):
             for axis in 'XY':
                 setattr(self, 'surf%s%s' % (kind, axis), self._limits_of('lim%s%s' % (kind, axis)))
 
-    def _material_struct(self, material, fromVacuum, device):
+    def _material_struct(self, material, fromVacuum, device, beam=None):
         if raycing.is_sequence(material):     # coating stripes: the one in the beam
             material = material[self.curSurface]
         if material is not None:
+            if beam is not None and isinstance(getattr(material, 'refractiveIndex', None), list):
+                # a tabulated index is evaluated at the energies of THIS beam
+                return material.to_struct(fromVacuum, device, E=beam.dev('E', device))
             return material.to_struct(fromVacuum, device)
         s = _structs.Material()
         s.kind, s.from_vacuum, s._keep = _structs.MAT_NONE, int(bool(fromVacuum)), []
@@ -434,7 +437,7 @@ class OE(object):
         _lib.require_gpu()
         lib = _lib.load()
         dev = _device()
-        ms = self._material_struct(material, fromVacuum, dev)
+        ms = self._material_struct(material, fromVacuum, dev, beam_in)
         s_in = beam_in.to_struct(dev)
         s_re = s_in if restore is beam_in else restore.to_struct(dev)
         n = beam_in.nrays

@@ -299,10 +299,10 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
     if (pass->grating)
       return fail(XRT_HIP_ERR_ARG, "grating equation on a multilayer material");
   }
-  if (pass->surf_kind >= XRT_HIP_SURF_BLAZED && pass->surf_kind != XRT_HIP_SURF_SAGITTAL &&
-      pass->surf_kind != XRT_HIP_SURF_BENT_BRAGG && pass->surf_kind != XRT_HIP_SURF_DICED &&
-      material->kind == XRT_HIP_MAT_CRYSTAL)
-    return fail(XRT_HIP_ERR_ARG, "crystals on blazed / parametric surfaces are not supported");
+  // (crystals on conics, lenses' paraboloids, cones, VFM / DualVFM: the exact sequence of the
+  // surface's family serves them -- reflect_pass_launch; a blazed profile has no Bragg planes)
+  if (pass->surf_kind == XRT_HIP_SURF_BLAZED && material->kind == XRT_HIP_MAT_CRYSTAL)
+    return fail(XRT_HIP_ERR_ARG, "crystals on blazed gratings are not supported");
   if (pass->grating && (pass->grating_axis < -1 || pass->grating_axis > 1 ||
                         pass->g_ncoef < 0 || pass->g_ncoef > 8))
     return fail(XRT_HIP_ERR_ARG, "bad grating description");
@@ -332,6 +332,10 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
       if (!material->tab_E[e] || !material->tab_f1[e] || !material->tab_f2[e] ||
           material->tab_n[e] < 2)
         return fail(XRT_HIP_ERR_ARG, "element %d: missing f1/f2 table", e);
+    if (material->n_fixed < 0 || material->n_fixed > 2 ||
+        (material->n_fixed == 2 && (!material->n_ray || material->kind == XRT_HIP_MAT_CRYSTAL)))
+      return fail(XRT_HIP_ERR_ARG, "material: n_fixed %d (0 tables, 1 constant, 2 per ray with "
+                                   "n_ray; not for crystals)", material->n_fixed);
   }
   return XRT_HIP_OK;
 }
@@ -626,6 +630,9 @@ static int check_material_tables(const xrt_hip_material* m) {
   if (!m) return fail(XRT_HIP_ERR_ARG, "NULL material");
   if (m->nelem < (m->n_fixed ? 0 : 1) || m->nelem > XRT_HIP_MAX_ELEM)
     return fail(XRT_HIP_ERR_ARG, "material needs 1..%d elements", XRT_HIP_MAX_ELEM);
+  if (m->n_fixed < 0 || m->n_fixed > 2 || (m->n_fixed == 2 && !m->n_ray))
+    return fail(XRT_HIP_ERR_ARG, "material: n_fixed %d (0 tables, 1 constant, 2 per ray with "
+                                 "n_ray)", m->n_fixed);
   for (int e = 0; e < m->nelem; ++e)
     if (!m->tab_E[e] || !m->tab_f1[e] || !m->tab_f2[e] || m->tab_n[e] < 2)
       return fail(XRT_HIP_ERR_ARG, "element %d: missing f1/f2 table", e);

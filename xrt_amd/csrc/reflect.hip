@@ -413,7 +413,10 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void material_amplitude_kernel(
     double* __restrict__ mu, double* __restrict__ nk) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const Ampl A = material_amplitude(M, M.kind, E[i], bdn[i], full_window());
+  cplx n_own = C(1., 0.);
+  if (M.n_fixed == 2) n_own = C(M.n_ray[2 * i], M.n_ray[2 * i + 1]);   // tabulated n(E)
+  const Ampl A = material_amplitude(M, M.kind, E[i], bdn[i], full_window(),
+                                    M.n_fixed == 2 ? &n_own : nullptr);
   rs[i] = make_double2(A.rs.re, A.rs.im);
   rp[i] = make_double2(A.rp.re, A.rp.im);
   if (mu) mu[i] = A.mu;
@@ -565,8 +568,16 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                        beams_overlap(restore, lb) || beams_overlap(restore, vb);
   const bool nis = P.no_intersection_search != 0;
   const bool searches = !nis && P.surf_kind != XRT_HIP_SURF_BLAZED;
-  const bool optimistic = searches && !force_exact && !aliased;
   const bool need_mean = deflects_as_crystal(M) && !M.geom_transmitted;
+  // Bragg crystals on surfaces outside the crystal kernels' families (conics, cone, lens
+  // paraboloid, VFM / DualVFM -- rare: a paraboloidal analyser): the generic exact sequence of
+  // the surface's family knows both, the fused crystal kernels (family 0 + bent shapes) do not
+  const bool xtal_elsewhere =
+      need_mean && M.kind == XRT_HIP_MAT_CRYSTAL &&
+      (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM || P.surf_kind == XRT_HIP_SURF_PARABOLOID ||
+       P.surf_kind == XRT_HIP_SURF_CONE || P.surf_kind == XRT_HIP_SURF_VFM ||
+       P.surf_kind == XRT_HIP_SURF_DUALVFM);
+  const bool optimistic = searches && !force_exact && !aliased && !xtal_elsewhere;
   const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
   const bool layers = M.kind == XRT_HIP_MAT_MULTILAYER;
   const bool wide = P.surf_kind == XRT_HIP_SURF_BENT_BRAGG || P.surf_kind == XRT_HIP_SURF_VFM ||
@@ -591,7 +602,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       spec = flat_xtal ? SP_THICK_FLAT : SP_THICK_ANY;
     else
       spec = flat_xtal ? SP_FLAT_XTAL : SP_ANY_XTAL;
-  } else if (!need_mean && family_spec == SP_GENERIC0 && plain) {
+  } else if (!need_mean && family_spec == SP_GENERIC0 && plain && M.n_fixed != 2) {
+    // (a per-ray refractive index -- Material(refractiveIndex = table) -- stays with the
+    // generic kernels: the lean ones do not carry its test)
     if (M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_TOROID)
       spec = SP_TOROID_MIRROR;
     else if (M.kind == XRT_HIP_MAT_MIRROR && P.surf_kind == XRT_HIP_SURF_FLAT)

@@ -1828,11 +1828,21 @@ struct Ampl {
 // caller looked it up already (the fused
 // kernels do so BEFORE the root solve: the table search is two dependent trips to L2,
 // which then overlap with the solve instead of standing between it and the amplitudes)
+__device__ __forceinline__ Ampl material_amplitude_n(const xrt_hip_material& M, int kind,
+                                                     double E, double bdn, const TabWin& w,
+                                                     bool have_n, cplx n_given);
 __device__ __forceinline__ Ampl material_amplitude(const xrt_hip_material& M, int kind,
                                                    double E, double bdn, const TabWin& w,
                                                    const cplx* npre = nullptr) {
+  return material_amplitude_n(M, kind, E, bdn, w, npre != nullptr, npre ? *npre : C(1., 0.));
+}
+// (the index by VALUE: a pointer that may point at the caller's copy or at a local one kept
+// that local in scratch memory)
+__device__ __forceinline__ Ampl material_amplitude_n(const xrt_hip_material& M, int kind,
+                                                     double E, double bdn, const TabWin& w,
+                                                     bool have_n, cplx n_given) {
   Ampl A;
-  const cplx n = npre ? *npre : refractive_index(M, E, w);
+  const cplx n = have_n ? n_given : refractive_index(M, E, w);
   const cplx one = C(1., 0.);
   const double cosAlpha = fabs(bdn);
   double sinAlpha2 = 1. - bdn * bdn;
@@ -2603,6 +2613,15 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
                                                const cplx* npre = nullptr,
                                                XtalEnergy* xe = nullptr,
                                                bool xe_ready = false) {
+  // Material(refractiveIndex = table): the caller evaluated the spline at every ray's energy.
+  // Only the kernels that read the material kind at run time carry the test (the launcher
+  // keeps such materials away from the lean kernels).
+  bool have_n = npre != nullptr;
+  cplx n_here = have_n ? *npre : C(1., 0.);
+  if (K::MK < 0 && M.n_fixed == 2) {
+    n_here = C(M.n_ray[2 * i], M.n_ray[2 * i + 1]);
+    have_n = true;
+  }
   Finished out;
   q.path += h.t;
   // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
@@ -2716,7 +2735,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
       out.c = co;
     }
   } else {  // refraction, reflect.py:894-919
-    const double nre = refractive_index(M, q.E, window_of(g)).re;
+    const double nre = have_n ? n_here.re : refractive_index(M, q.E, window_of(g)).re;
     const double n1overn2 = M.from_vacuum ? 1. / nre : nre;
     const double signN = (double)sgn(-bdn);
     const double n1c = -n1overn2 * bdn;
@@ -2764,7 +2783,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
     A = crystal_amplitude_at<K::XTHICK>(M, X, bdsn, bosn, bdn);
 #ifndef XRT_PROBE_NO_AMPL
   } else if (MKIND(M) != XRT_HIP_MAT_NONE) {
-    A = material_amplitude(M, MKIND(M), q.E, bdn, window_of(g), npre);
+    A = material_amplitude_n(M, MKIND(M), q.E, bdn, window_of(g), have_n, n_here);
 #endif
   }
   if (PGRATING(P) && P.eff_n > 0) {  // tabulated efficiency of the order, material.py:391-413

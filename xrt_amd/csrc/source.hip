@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "../../include/xrt_hip.h"
+#include "fp64_math.h"
 #include "source.h"
 
 namespace xrt {
@@ -35,8 +36,10 @@ __device__ __forceinline__ U2 philox_uniforms(uint64_t ray, uint32_t slot, uint3
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    // (one 32 x 32 -> 64 multiply each: v_mad_u64_u32 instead of a mul_hi and a mul_lo)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t h0 = (uint32_t)(p0 >> 32), l0 = (uint32_t)p0;
+    const uint32_t h1 = (uint32_t)(p1 >> 32), l1 = (uint32_t)p1;
     c0 = h1 ^ c1 ^ k0;
     c1 = l1;
     c2 = h0 ^ c3 ^ k1;
@@ -51,10 +54,20 @@ __device__ __forceinline__ U2 philox_uniforms(uint64_t ray, uint32_t slot, uint3
   return u;
 }
 
+// sin and cos of 2 pi u, u in [0, 1): 4u quarter turns = a whole number q and a rest |r| <= 1/2
+// (both exact), then the polynomials of fp64_math.h -- the library's sincos carries a
+// large-argument path along that this angle never takes. Within an ulp or two of
+// np.sin / np.cos (2 pi u), which round the product 2 pi u first.
+__device__ __forceinline__ void sincos_turn(double u, double& sn, double& cs) {
+  const double t = 4. * u;
+  const double q = __builtin_rint(t);
+  sincos_quarter_turns(t - q, (unsigned)(int)q, sn, cs);
+}
+
 __device__ __forceinline__ void box_muller(const U2 u, double& g1, double& g2) {
   const double radius = sqrt(-2. * log(1. - u.a));
   double sn, cs;
-  sincos(kPI2 * u.b, &sn, &cs);
+  sincos_turn(u.b, sn, cs);
   g1 = radius * cs;
   g2 = radius * sn;
 }
