@@ -195,20 +195,18 @@ def bench_reflect(args, world, rank, dist, dcm=False):
         beam.dev(f)
     torch.cuda.synchronize()
     out = None
-    kw = {} if dcm else {'out': None}
+    kw = {'out': None}
     # untimed spin-up (not a step): a sub-millisecond step measured right after an idle
     # GPU sees its clocks and the allocator still ramping (5 steps after 2 warm-up steps
     # measured 10 % slower than 20 after 3)
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < 0.25:
         out = op(beam, **kw)
-        if not dcm:
-            kw['out'] = out
+        kw['out'] = out
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = op(beam, **kw)
-        if not dcm:
-            kw['out'] = out          # steady state: outputs overwritten in place
+        kw['out'] = out              # steady state: outputs overwritten in place
     # HIP events around every pass of the timed region and around its dominant kernel,
     # recorded on the launch stream by the library without a host sync
     # (xrt_hip_reflect_time_next_pass) and read after the region

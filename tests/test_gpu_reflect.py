@@ -977,3 +977,24 @@ def test_crystals_on_conic_and_vfm_surfaces_match_reference_golden(case):
     # (the VFM's sagittal cylinder takes most rays off the Bragg angle)
     assert (lb.Jss + lb.Jpp)[hit].mean() > (0.3 if case == 'parabola' else 0.05) * \
         (g['in_Jss'] + g['in_Jpp'])[hit].mean()
+
+
+def test_double_reflect_into_the_beams_of_an_earlier_call():
+    """DCM.double_reflect(out=...) overwrites the triple it returned before (no new arrays) and
+    gives the same beams as a fresh call."""
+    from xrt_amd import workloads
+    dcm = workloads.cfg3_dcm()
+    b1 = workloads.synthetic_rays(50_001, 8, sa=1e-4, E=(8995., 9005.))
+    b2 = workloads.synthetic_rays(50_001, 9, sa=1e-4, E=(8995., 9005.))
+    first = dcm.double_reflect(b1)
+    ptr = first[0].dev('x').data_ptr()
+    again = dcm.double_reflect(b2, out=first)
+    fresh = dcm.double_reflect(b2)
+    assert all(a is b for a, b in zip(again, first)) and again[0].dev('x').data_ptr() == ptr
+    for a, b in zip(again, fresh):
+        for f in b.array_fields():
+            assert np.array_equal(a.peek(f), b.peek(f)), f
+    # a triple of the wrong size is not reused
+    other = dcm.double_reflect(workloads.synthetic_rays(1000, 1, sa=1e-4, E=(8995., 9005.)),
+                               out=first)
+    assert other[0] is not first[0] and other[0].nrays == 1000

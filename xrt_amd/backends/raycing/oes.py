@@ -1473,8 +1473,12 @@ class DCM(OE):
         return both if self.alpha else both[:3]
 
     def double_reflect(self, beam=None, needLocal=True, fromVacuum1=True,
-                       fromVacuum2=True, returnLocalAbsorbed=None, _timing=None):
-        """-> (beamGlobal, beamLocal1, beamLocal2), dcm.py:248-354."""
+                       fromVacuum2=True, returnLocalAbsorbed=None, _timing=None, out=None):
+        """-> (beamGlobal, beamLocal1, beamLocal2), dcm.py:248-354. *out* (extension, as in
+        ``OE.reflect``): the triple an earlier call on a beam of the same size returned, to be
+        overwritten in place -- a loop over the same beamline then allocates nothing (giving
+        three 1-GB beams back to the allocator and taking three new ones every step cost the
+        cfg3 loop 20-90 us of idle GPU per pass)."""
         first = self._own_angles(False)
         second = self._own_angles(True)
         p1 = self._make_pass(*first[:4], fromVacuum=fromVacuum1, out_to_global=False)
@@ -1484,14 +1488,14 @@ class DCM(OE):
                              force_lost_out=hasattr(self, 't'))
         # (XRT_HIP_DCM_TWO_PASSES=1: the two separate passes, for comparison)
         if os.environ.get('XRT_HIP_DCM_TWO_PASSES', '') != '1':
-            fused = self._run_double(p1, p2, fromVacuum1, fromVacuum2, beam, _timing)
+            fused = self._run_double(p1, p2, fromVacuum1, fromVacuum2, beam, _timing, out)
             if fused is not None:
                 return fused
         lo1, between, _ = self._run_pass(p1, self.material, fromVacuum1, beam, beam)
         lo2, gb2, _ = self._run_pass(p2, self.material2, fromVacuum2, between, beam)
         return gb2, lo1, lo2
 
-    def _run_double(self, p1, p2, fromVacuum1, fromVacuum2, beam, timing=None):
+    def _run_double(self, p1, p2, fromVacuum1, fromVacuum2, beam, timing=None, out=None):
         """Both crystals in one pass over the beam (xrt_hip_double_reflect_f64_dev) when
         the pair qualifies (flat Bragg crystals), else None. -> (gb2, lo1, lo2)"""
         _lib.require_gpu()
@@ -1503,8 +1507,16 @@ class DCM(OE):
                                                   ctypes.byref(p2), ctypes.byref(m2)):
             return None
         n = beam.nrays
-        lo1, lo2, gb2 = (rs.Beam.empty_like_on_device(beam, dev) for _ in range(3))
-        angles = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
+        usable = out is not None and len(out) == 3 and all(
+            b is not None and b is not beam and b.nrays == n and not b._h_dirty() and
+            b.has_amplitudes() == beam.has_amplitudes() for b in out) and \
+            all('theta' in b._d for b in out[1:])
+        if usable:
+            gb2, lo1, lo2 = out
+            angles = [lo1._d['theta'], lo2._d['theta']]
+        else:
+            lo1, lo2, gb2 = (rs.Beam.empty_like_on_device(beam, dev) for _ in range(3))
+            angles = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
         ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(n), 'reflect')
         ms = (ctypes.c_float * 3)() if timing is not None else None
         _lib.check(lib.xrt_hip_double_reflect_f64_dev(
