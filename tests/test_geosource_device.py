@@ -248,3 +248,29 @@ def test_device_source_flux_accu_beam_and_chain():
     gb2, lb2 = oe.reflect(twin)
     assert np.array_equal(gb.peek('state'), gb2.peek('state'))
     assert np.array_equal(lb.peek('x'), lb2.peek('x')) and (gb.peek('state') == 1).mean() > 0.9
+
+
+@pytest.mark.gpu
+def test_concurrent_shines_take_different_substreams():
+    """run_ray_tracing(threads=N) calls shine() from N threads: every call takes its own call
+    number (sub-stream of the generator), none is handed out twice."""
+    import threading
+    import torch
+    src = make('default', 10_000, azimuth=0.)
+    got, calls = [], 24
+
+    def work():
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for _ in range(calls // 4):
+                b = src.shine()
+                torch.cuda.current_stream().synchronize()
+                got.append(b.peek('x')[:8].copy())
+    pool = [threading.Thread(target=work) for _ in range(4)]
+    for t in pool:
+        t.start()
+    for t in pool:
+        t.join()
+    assert len(got) == calls and src._calls == calls
+    assert len({g.tobytes() for g in got}) == calls
+    first = [og.shine(spec_of(src, call=k))['x'][0] for k in range(calls)]
+    assert sorted(round(float(g[0]), 9) for g in got) == sorted(round(float(v), 9) for v in first)

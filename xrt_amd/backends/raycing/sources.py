@@ -545,6 +545,8 @@ class GeometricSource(object):
         if rng not in ('host', 'device'):
             raise ValueError("rng must be 'host' or 'device'")
         self.rng, self.seed, self._calls = rng, seed, 0
+        import threading
+        self._call_lock = threading.Lock()      # run_ray_tracing(threads=N): one sub-stream per call
         for key in ('center', 'distE', 'energies', 'energyWeights', 'polarization',
                     'filamentBeam', 'uniformRayDensity', 'pitch', 'roll', 'yaw', 'totalFlux'):
             setattr(self, key, given[key])
@@ -631,12 +633,15 @@ class GeometricSource(object):
             return max(abs(p0), abs(p1))
         return abs(p1) if kind == _structs.LAW_NORMAL_UNIFORM else 0.
 
-    def device_spec(self, toGlobal=True):
-        """The ``xrt_hip_geosource`` record of this source (all but ``slopes``)."""
+    def device_spec(self, toGlobal=True, call=None):
+        """The ``xrt_hip_geosource`` record of this source (all but ``slopes``) for sub-stream
+        *call* (default: the next one)."""
         g = _structs.GeoSource()
-        if self.seed is None:
-            self.seed = int(np.random.randint(0, 2**62, dtype=np.int64))
-        g.seed, g.call = int(self.seed) & (2**64 - 1), self._calls & 0xFFFFFFFF
+        with self._call_lock:
+            if self.seed is None:
+                self.seed = int(np.random.randint(0, 2**62, dtype=np.int64))
+            call = self._calls if call is None else call
+        g.seed, g.call = int(self.seed) & (2**64 - 1), call & 0xFFFFFFFF
         laws = [self._law(c) for c in ('y', 'x', 'z', 'xprime', 'zprime')]
         for k, (kind, p0, p1) in enumerate(laws):
             g.law[k], g.p0[k], g.p1[k] = kind, p0, p1
@@ -711,8 +716,10 @@ class GeometricSource(object):
         lib = _lib.load()
         dev = torch.device('cuda', torch.cuda.current_device())
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        g, reach2 = self.device_spec(toGlobal)
-        self._calls += 1
+        with self._call_lock:            # every shine() takes its own sub-stream, also from threads
+            call = self._calls
+            self._calls += 1
+        g, reach2 = self.device_spec(toGlobal, call)
         if reach2 > 1:
             # tangents that CAN leave the unit circle: the reference forms b from slopes if
             # any ray of the batch does (geoms.py:497-505) -- ask the generator

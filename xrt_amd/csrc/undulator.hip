@@ -147,6 +147,9 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
     double r[N_REC], rn[N_REC];
 #pragma unroll
     for (int k = 0; k < N_PAD0; ++k) r[k] = ahead[k];
+#ifdef UND_UNROLL
+#pragma unroll UND_UNROLL
+#endif
     for (int64_t j = 0; j < a.jend; ++j) {
       if (j + 1 < a.jend) ahead += N_REC;
 #pragma unroll
@@ -278,7 +281,9 @@ __device__ __forceinline__ void und_ray_any(const UndulatorArgs& a,
 // The kernels are persistent: UND_WAVES waves per SIMD (the launch is sized by the occupancy),
 // every block copies the sincos table once and walks over tiles of 256 rays. Four waves per
 // SIMD divide the 16 per SIMD of a 2^20-ray map evenly (five left a fifth of the last round).
-#define UND_WAVES 4      // (the multi-period modes: one less, their three loop forms need the registers)
+#ifndef UND_WAVES
+#define UND_WAVES 4
+#endif                   // (the multi-period modes: one less, their three loop forms need the registers)
 template <int MODE>
 __global__ void __launch_bounds__(256, MODE == UND_FAR ? UND_WAVES : UND_WAVES - 1)
 und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
