@@ -555,38 +555,10 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_hist_tiles(
                    blockIdx.x == 0 ? R.share : nullptr);
 #endif
   int tile = 0;
-#ifdef HIST_INTERLEAVE
-  // block b -> the b-th entry of the round-robin over the tiles' remaining shares
-  int sl = 0;
-  {
-    int left = (int)blockIdx.x, round = 0, found = -1;
-    while (found < 0) {
-      int live = 0;
-      for (int t = 0; t < T; ++t) live += share[t + 1] - share[t] > round;
-      if (!live) break;
-      if (left < live) {
-        for (int t = 0; t < T; ++t)
-          if (share[t + 1] - share[t] > round && left-- == 0) {
-            found = t;
-            sl = round;
-            break;
-          }
-      } else {
-        left -= live;
-        ++round;
-      }
-    }
-    if (found < 0) return;
-    tile = found;
-  }
-  const int slice = sl, slices = share[tile + 1] - share[tile];
-  const int copy_slot = share[tile] + slice;
-#else
   while (tile < T && (int)blockIdx.x >= share[tile + 1]) ++tile;
   if (tile >= T) return;                // (more blocks than the tiles take)
   const int slice = (int)blockIdx.x - share[tile], slices = share[tile + 1] - share[tile];
   const int copy_slot = (int)blockIdx.x;
-#endif
   const int tcells = H.tx * H.ty;
   for (int k = threadIdx.x; k < NCH * tcells; k += blockDim.x) cells[k] = 0.;
   __syncthreads();
