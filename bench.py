@@ -86,7 +86,7 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def dry_run(args):
+def dry_run(args, line_out=sys.stdout):
     import datetime
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -100,8 +100,9 @@ def dry_run(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(dict(dry_run=True, n_gpus=world, steps=args.steps,
-                              warmup=args.warmup)))
+        line_out.write(json.dumps(dict(dry_run=True, n_gpus=world, steps=args.steps,
+                                       warmup=args.warmup)) + '\n')
+        line_out.flush()
 
 
 def setup_dist(args):
@@ -110,12 +111,23 @@ def setup_dist(args):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    # (rehearsal on a box with fewer GPUs than ranks: XRT_BENCH_SHARE_GPU=1 maps the ranks onto
+    # the visible GPUs in turn and XRT_BENCH_BACKEND=gloo carries the collectives -- RCCL refuses
+    # two ranks on one GPU; the driver's runs use neither)
+    share = os.environ.get('XRT_BENCH_SHARE_GPU', '') == '1'
+    backend = os.environ.get('XRT_BENCH_BACKEND', 'nccl')
+    if share:
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+            dist.init_process_group(backend)
         # a CPU-side group for waits during which the GPUs must stay free (the in-process
         # multi-GPU leg: rank 0 drives every GPU while the others wait; an RCCL barrier would
         # park a spinning kernel on each of them)
@@ -140,7 +152,8 @@ def barrier(dist):
 def max_over_ranks(dist, seconds):
     if dist is None:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device='cuda')
+    t = torch.tensor([seconds], dtype=torch.float64,
+                     device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -365,11 +378,12 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
     # rank's kernel time (the slowest tile sets the step)
     rccl_ranks, kernel_ms_by_rank = 1, [k * 1e3]
     if dist is not None:
-        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        cdev = dev if dist.get_backend() == 'nccl' else torch.device('cpu')
+        ones = torch.ones(1, dtype=torch.float64, device=cdev)
         dist.all_reduce(ones)
         rccl_ranks = int(ones.item())
         assert rccl_ranks == dist.get_world_size() == world
-        mine = torch.zeros(world, dtype=torch.float64, device=dev)
+        mine = torch.zeros(world, dtype=torch.float64, device=cdev)
         mine[rank] = k * 1e3
         dist.all_reduce(mine)
         kernel_ms_by_rank = [float(v) for v in mine.tolist()]
@@ -384,7 +398,7 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
                 fx, fy, fz = (torch.from_numpy(np.ascontiguousarray(a)).to(dev)
                               for a in (px, py, pz))
                 smp = [s[f] for f in ('sx', 'sy', 'sz', 'nx', 'ny', 'nz', 'nl', 'k', 'Es', 'Ep')]
-                devs = list(range(world))
+                devs = [d % torch.cuda.device_count() for d in range(world)]
 
                 def sync_all():
                     for d in devs:
@@ -877,12 +891,23 @@ def load_traffic(kernel):
         return None
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout. Libraries write there too (gloo announces its
+    connections on fd 1 when the CPU-side group is made): everything but the line goes to
+    stderr from here on, the line itself to the original stdout (returned as a file)."""
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+    return line_out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
+    line_out = claim_stdout()
     if args.dry_run:
-        return dry_run(args)
+        return dry_run(args, line_out)
     from xrt_amd import _lib
     _lib.require_gpu()                    # no CPU fallback: fail loudly
     world, rank, local, dist = setup_dist(args)
@@ -954,7 +979,8 @@ def main():
         if host is not None and 'kirchhoff' in line:
             line['kirchhoff']['cpu_baseline'] = cpu_baseline_kirchhoff(host)
     if rank == 0:
-        print(json.dumps(line))
+        line_out.write(json.dumps(line) + '\n')
+        line_out.flush()
     if dist is not None:
         dist.destroy_process_group()
 

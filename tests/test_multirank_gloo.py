@@ -110,8 +110,9 @@ def test_bench_launches_its_own_ranks():
                         '--steps', '2', '--warmup', '1', '--dry-run'],
                        capture_output=True, text=True, timeout=280, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, r.stdout
+    # ONE line on stdout, nothing else (gloo's connection notes and the like go to stderr)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1
 

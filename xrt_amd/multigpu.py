@@ -75,8 +75,14 @@ def all_gather_packed(tiles, n_total, dist, rank, world):
     pack = torch.zeros(offs[-1], dtype=real[0].dtype, device=real[0].device)
     for t, o in zip(real, offs):
         pack[o:o + t.numel()] = t
-    full = torch.empty(world * offs[-1], dtype=pack.dtype, device=pack.device)
-    dist.all_gather_into_tensor(full, pack)
+    if pack.is_cuda and dist.get_backend() != 'nccl':
+        # (a CPU backend under device tensors -- rehearsals only: through the host)
+        host = torch.empty(world * offs[-1], dtype=pack.dtype)
+        dist.all_gather_into_tensor(host, pack.cpu())
+        full = host.to(pack.device)
+    else:
+        full = torch.empty(world * offs[-1], dtype=pack.dtype, device=pack.device)
+        dist.all_gather_into_tensor(full, pack)
     full = full.reshape(world, offs[-1])
     out = []
     for k, (w, c) in enumerate(zip(width, cplx)):
