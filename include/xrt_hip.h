@@ -183,7 +183,9 @@ typedef struct xrt_hip_rotation {
                                      once per class into a unit of their own (hipcc, the ray
                                      kernels instantiated around them) and loaded with
                                      xrt_hip_user_surface_load; surf_p = the class's parameter
-                                     list p[0..11]; xrt_hip_pass.user_unit = the handle */
+                                     list p[0..11]; xrt_hip_pass.user_unit = the handle; with
+                                     grating = 1 and grating_axis = 2 the groove vector comes
+                                     from the unit's local_g (the reference's cl_local_g) */
 #define XRT_HIP_SHAPE_RECT 0
 #define XRT_HIP_SHAPE_ROUND 1
 #define XRT_HIP_SHAPE_POLYGON 2   /* optical surface outlined by a polygon in the local (x, y)

@@ -105,7 +105,7 @@ def flat_params(p):
     out = {}
     for k, v in p.items():
         if k in ('surface', 'surface2', 'material', 'material2', 'gratingDensity',
-                 'gVector', 'order', 'fzp', 'gfzp'):
+                 'gVector', 'order', 'fzp', 'gfzp', 'local_g'):
             continue
         if v is None:
             out['oe_' + k] = np.array(np.nan)

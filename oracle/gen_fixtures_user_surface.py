@@ -6,6 +6,9 @@ generator plus rays that miss, fall off the edges and graze the surface. While g
 oracle/reflect_np.py (surface kind 'user' = the same two callables) is asserted against the
 reference's beams.
 
+  g2_user_grating  a plane grating whose groove vector is a function of (x, y) given by the
+                   subclass's local_g (a fan of lines with a quadratic density law), order -1
+
 Run:  python -m oracle.gen_fixtures_user_surface
 """
 import os
@@ -46,6 +49,21 @@ def main():
     g1.run_reflect('g2_user_surface', rs, oe, par, beam,
                    surface_parameters=np.array([case.RS, case.RM, case.K3, case.KT]),
                    mat_rho=np.array(21.45))
+    # a grating whose groove vector the subclass defines (order -1, Au, 280 eV)
+    bl = raycing.BeamLine()
+    au = rm.Material('Au', rho=19.32, kind='grating')
+    gr = case.grating_subclass(roe)(bl, 'fan', center=[0, 2000., 0.], pitch=np.radians(2.2),
+                                    material=au, order=-1, alarmLevel=None, **case.G_LIMITS)
+    beam = g1.make_rays(rs, 2048, 63, sx=1.0, sz=0.9, sa=3e-5, sc=2e-5, E=(270., 290.),
+                        amplitudes=True, pol='mixed')
+    beam.state[3] = 3
+    beam.state[4] = -4
+    par = g1.oe_params(gr, dict(kind='flat'))
+    par['material'] = g1.material_dict(load_tables(), au)
+    par['local_g'] = case.numpy_local_g
+    par['order'] = -1
+    g1.run_reflect('g2_user_grating', rs, gr, par, beam,
+                   groove_parameters=np.array([case.G_RHO0, case.G_B1, case.G_B2, case.G_BX]))
 
 
 if __name__ == '__main__':

@@ -1067,6 +1067,8 @@ def general_fzp_rays_good_gn(oe, x, y, z):
 def local_g(oe, x, y):
     """Reciprocal groove vector [1/mm] of OE.local_g (base.py:688-717):
     polynomial line density ['x'|'y', rho0, p0, p1, ...] or a constant vector."""
+    if callable(oe.get('local_g')):                 # an OE subclass's own local_g (numpy)
+        return oe['local_g'](x, y)
     rhoList = oe.get('gratingDensity')
     if rhoList is not None:
         coord = x if rhoList[0] == 'x' else y

@@ -150,3 +150,28 @@ def test_user_surface_at_full_size_and_refusals():
     xtal = element(rm.CrystalSi(hkl=(1, 1, 1)))
     with pytest.raises(_lib.XrtHipError, match='user-defined surfaces'):
         xtal.reflect(workloads.synthetic_rays(1000, 3))
+
+
+@pytest.mark.gpu
+def test_user_grating_matches_the_reference(golden_dir):
+    """hip_local_g (the reference's cl_local_g): a plane grating whose groove vector is a function
+    of (x, y) -- the reference ran the same subclass with a numpy local_g (golden
+    g2_user_grating, order -1): states bit-exact, directions at 1e-12."""
+    g = np.load(os.path.join(golden_dir, 'g2_user_grating.npz'))
+    bl = raycing.BeamLine()
+    au = rm.Material('Au', rho=19.32, kind='grating')
+    gr = case.grating_subclass(roe)(bl, 'fan', center=[0, 2000., 0.], pitch=np.radians(2.2),
+                                    material=au, order=-1, **case.G_LIMITS)
+    beam = rs.Beam(nrays=len(g['in_x']), withAmplitudes=True)
+    for f in GEOM + ('E', 'Jss', 'Jpp', 'Jsp', 'state', 'Es', 'Ep'):
+        setattr(beam, f, g['in_' + f])
+    gb, lb = gr.reflect(beam)
+    for name, out in (('gb', gb), ('lb', lb)):
+        assert np.array_equal(out.state, g[name + '_state']), name
+        for f in GEOM:
+            _close(getattr(out, f), g['%s_%s' % (name, f)], 1e-12, (name, f))
+        for f in ('Jss', 'Jpp', 'Jsp', 'Es', 'Ep'):
+            _close(getattr(out, f), g['%s_%s' % (name, f)], 1e-9, (name, f))
+    # the fan really deflects sideways: a constant groove vector would leave a untouched
+    hit = g['lb_state'] == 1
+    assert np.abs(lb.a[hit] - g['in_a'][hit]).max() > 3e-7

@@ -52,3 +52,33 @@ def subclass(roe):
         def local_n(self, x, y):
             return numpy_local_n(x, y)
     return FiguredParaboloid
+
+
+# ---- a user-defined GRATING: a plane whose groove vector is a function of (x, y) -- a fan of
+# lines with a quadratic density law, as the reference takes it from a subclass's local_g
+# (oes/base.py:688-717; cl_local_g on its OpenCL path). p = (rho0, b1, b2, bx)
+G_RHO0, G_B1, G_B2, G_BX = 300., 2.4e-4, -3.1e-8, 1.5e-4
+G_LIMITS = dict(limPhysX=(-3, 3), limPhysY=(-45, 45))
+
+
+def numpy_local_g(x, y, rho0=G_RHO0, b1=G_B1, b2=G_B2, bx=G_BX):
+    return rho0 * bx * x, rho0 * (1 + b1 * y + b2 * y * y), x * 0.
+
+
+HIP_FLAT_Z = 'return 0.;'
+HIP_FLAT_N = 'n[0] = 0.; n[1] = 0.; n[2] = 1.;'
+HIP_LOCAL_G = '''
+  g[0] = p[0] * p[3] * x;
+  g[1] = p[0] * (1 + p[1] * y + p[2] * y * y);
+  g[2] = x * 0.;
+'''
+
+
+def grating_subclass(roe):
+    class FanGrating(roe.OE):
+        hip_local_z, hip_local_n, hip_local_g = HIP_FLAT_Z, HIP_FLAT_N, HIP_LOCAL_G
+        hip_plist = (G_RHO0, G_B1, G_B2, G_BX)
+
+        def local_g(self, x, y, rho=None):
+            return numpy_local_g(x, y)
+    return FanGrating

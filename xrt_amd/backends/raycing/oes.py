@@ -284,6 +284,10 @@ class OE(object):
             p.zone_n, p.zone_black = len(self.rn) - 1, int(bool(self.isCentralZoneBlack))
             p.zone_r = cached[1].data_ptr()
             return
+        from ... import usersurf
+        if usersurf.snippets_of(self) is not None and usersurf.groove_snippet_of(self):
+            p.grating_axis = 2            # the groove function compiled into the class's unit
+            return
         spec = self.gratingDensity
         if spec is not None and type(self).local_g is OE.local_g:
             coefs = [float(c) for c in spec[2:]]

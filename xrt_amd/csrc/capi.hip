@@ -286,8 +286,9 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
       return fail(XRT_HIP_ERR_ARG, "crystals and multilayers on user-defined surfaces are not "
                                    "supported (their kernels need the normal of the atomic "
                                    "planes as well)");
-    if (pass->grating || pass->asymmetric)
-      return fail(XRT_HIP_ERR_ARG, "gratings on user-defined surfaces are not supported");
+    if (pass->asymmetric || (pass->grating && (pass->grating != 1 || pass->g_ray_x)))
+      return fail(XRT_HIP_ERR_ARG, "user-defined surfaces take plain gratings only (no zone "
+                                   "plates, no asymmetric cut)");
   }
   if (material->kind == XRT_HIP_MAT_CRYSTAL && material->structure == 2 && !material->cell)
     return fail(XRT_HIP_ERR_ARG, "crystal from a unit cell without its xrt_hip_cell record");
@@ -303,7 +304,10 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
   // surface's family serves them -- reflect_pass_launch; a blazed profile has no Bragg planes)
   if (pass->surf_kind == XRT_HIP_SURF_BLAZED && material->kind == XRT_HIP_MAT_CRYSTAL)
     return fail(XRT_HIP_ERR_ARG, "crystals on blazed gratings are not supported");
-  if (pass->grating && (pass->grating_axis < -1 || pass->grating_axis > 1 ||
+  // grating_axis: -1 constant vector, 0 / 1 density polynomial along x / y, 2 the groove
+  // function of a user-defined surface's unit
+  if (pass->grating && (pass->grating_axis < -1 ||
+                        pass->grating_axis > (pass->surf_kind == XRT_HIP_SURF_USER ? 2 : 1) ||
                         pass->g_ncoef < 0 || pass->g_ncoef > 8))
     return fail(XRT_HIP_ERR_ARG, "bad grating description");
   if (pass->grating && material->kind == XRT_HIP_MAT_CRYSTAL)

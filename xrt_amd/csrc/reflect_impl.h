@@ -2694,6 +2694,14 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
         g1 = -h.y / rad * rho;
         g2 = 0.;
         gsig = 1.;
+#ifdef XRT_USER_SURFACE
+      } else if (user_surface<K>() && P.grating_axis == 2) {   // the class's hip_local_g
+        double gv[3] = {0., 0., 0.};
+        xrt_user::local_g(h.x, h.y, P.surf_p, gv);
+        g0 = gv[0];
+        g1 = gv[1];
+        g2 = gv[2];
+#endif
       } else if (P.grating_axis >= 0) {
         const double coord = P.grating_axis == 0 ? h.x : h.y;
         double poly = 0.;

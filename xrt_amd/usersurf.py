@@ -7,6 +7,7 @@ splices them into its kernel (oes/base.py:552-564, ``find_intersection_CL`` :887
 
     class Saddle(roe.OE):
         hip_plist = property(lambda self: (self.cx, self.cy))       # up to 12 numbers -> p[]
+        # (a grating may add hip_local_g = 'g[0] = 0.; g[1] = p[2] * (1 + p[3] * y); g[2] = 0.;')
         hip_local_z = 'return p[0] * x * x - p[1] * y * y;'
         hip_local_n = '''double a = -2. * p[0] * x, b = 2. * p[1] * y;
                          double r = 1. / sqrt(a * a + b * b + 1.);
@@ -53,20 +54,26 @@ def _headers_digest():
     return h.hexdigest()
 
 
-def unit_source(local_z, local_n):
-    """The HIP source of the unit around the two snippets."""
+_NO_GROOVES = 'g[0] = 0.; g[1] = 0.; g[2] = 0.;'
+
+
+def unit_source(local_z, local_n, local_g=None):
+    """The HIP source of the unit around the snippets (*local_g*: the groove vector of a
+    grating, optional)."""
     with open(os.path.join(_CSRC, 'user_unit.hip.in')) as f:
         text = f.read()
-    for marker, body in (('@LOCAL_Z@', local_z), ('@LOCAL_N@', local_n)):
+    for marker, body in (('@LOCAL_Z@', local_z), ('@LOCAL_N@', local_n),
+                         ('@LOCAL_G@', _NO_GROOVES if local_g is None else local_g)):
         if not isinstance(body, str) or not body.strip():
-            raise ValueError('hip_local_z / hip_local_n must be non-empty source strings')
+            raise ValueError('hip_local_z / hip_local_n / hip_local_g must be non-empty source '
+                             'strings')
         text = text.replace(marker, body)
     return text.replace('@CSRC@', _CSRC)
 
 
-def build_unit(local_z, local_n, verbose=False):
-    """Compiles (or finds in the cache) the unit of the two snippets -> path of its .so."""
-    source = unit_source(local_z, local_n)
+def build_unit(local_z, local_n, verbose=False, local_g=None):
+    """Compiles (or finds in the cache) the unit of the snippets -> path of its .so."""
+    source = unit_source(local_z, local_n, local_g)
     key = hashlib.sha256((source + _headers_digest() + ' '.join(_FLAGS)).encode()).hexdigest()[:24]
     out = os.path.join(cache_dir(), 'surface_%s.so' % key)
     with _lock:
@@ -114,6 +121,15 @@ def snippets_of(oe):
     return z, n
 
 
+def groove_snippet_of(oe):
+    """hip_local_g of an element's class (the body of
+    ``void local_g(double x, double y, const double* p, double* g)``), or None."""
+    g = getattr(oe, 'hip_local_g', None)
+    if g is not None and not isinstance(g, str):
+        raise ValueError('%s: hip_local_g is a source string' % type(oe).__name__)
+    return g
+
+
 def parameters_of(oe):
     """p[0..11] of an element: its hip_plist (attribute, property or method)."""
     plist = getattr(oe, 'hip_plist', ())
@@ -128,4 +144,4 @@ def parameters_of(oe):
 def unit_for(oe):
     """The loaded unit of the element's class (compiled on first use) -> handle."""
     z, n = snippets_of(oe)
-    return load_unit(build_unit(z, n))
+    return load_unit(build_unit(z, n, local_g=groove_snippet_of(oe)))
