@@ -586,6 +586,10 @@ def bench_e2e(nrays, repeats=20):
                'rays/s', rays=nrays, repeats=repeats, ms_per_iteration=wall * 1e3,
         value=nrays / wall, unit='rays/s', dtype='f64', source='device (Philox4x32-10)',
         gpu_ms_per_iteration=gpu_ms, gpu_ms_by_step=dev_ms, gpu_busy=gpu_ms / (wall * 1e3),
+        gpu_busy_note='GPU time of one iteration (HIP events around its four steps, %d '
+                      'instrumented iterations with a sync each) / host-clock time per iteration '
+                      'of the free-running loop; ~1 = the loop is GPU-bound (the instrumented '
+                      'iterations carry a few us of event gaps: the ratio can exceed 1)' % n_probe,
         read_back_ms_once=read_back * 1e3, flux_in_plot=flux,
         bytes_per_ray=dict(source=100, reflect=308, screen=200, histograms=44),
         roofline=dict(bound='hbm', kernel='the four steps of one iteration',
