@@ -298,6 +298,14 @@ typedef struct xrt_hip_pass {
   int32_t* method_hint;
   /* surf_kind == XRT_HIP_SURF_USER: the handle xrt_hip_user_surface_load returned. */
   void* user_unit;
+  /* Material(efficiency = [[order, column], ...], efficiencyFile = ...) (material.py:335-346,
+   * 391-413): the efficiency of order eff_order[k] as a function of energy, np.interp on a
+   * table: eff_tab_n energies eff_tab_E[] and the rows eff_tab_I[k * eff_tab_n + j] (DEVICE
+   * arrays); the amplitude is its square root. eff_tab_n = 0: the constants eff_amp[]. The
+   * caller checks that every energy lies inside the table (the reference raises otherwise). */
+  int32_t eff_tab_n;
+  const double* eff_tab_E;
+  const double* eff_tab_I;
 } xrt_hip_pass;
 
 /* ---- user-defined surfaces -------------------------------------------------------------

@@ -70,6 +70,8 @@ def load_case(name):
             tuple(int(o) for o in g['order'])
         if 'efficiency' in g.files:
             p['material']['efficiency'] = [[int(o), float(v)] for o, v in g['efficiency']]
+        if 'eff_E' in g.files:            # efficiencyFile: [order, row of the table]
+            p['material']['efficiency_table'] = (g['eff_E'], g['eff_I'])
         if 'gd_axis' in g.files:
             p['gratingDensity'] = [str(g['gd_axis'])] + \
                 [float(v) for v in g['gd_coeffs']]

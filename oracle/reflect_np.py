@@ -1300,11 +1300,22 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
             elif matSur.get('layered'):               # Coated, kind 'mirror': :1031-1032
                 refl = mat.multilayer_amplitude(matSur, lb.E[goodN], beamInDotNormal)
             elif kind in ('grating', 'FZP') and matSur.get('efficiency') is not None:
-                # Material.get_grating_efficiency, material.py:391-413 (constant values)
+                # Material.get_grating_efficiency, material.py:391-413: constant values, or
+                # (efficiencyFile) columns of a table against energy
                 resI = np.zeros(goodN.sum())
                 order = lb.order[goodN]
-                for eff in matSur['efficiency']:
-                    resI[order == eff[0]] = eff[1]
+                if matSur.get('efficiency_table') is None:
+                    for eff in matSur['efficiency']:
+                        resI[order == eff[0]] = eff[1]
+                else:
+                    tabE, tabI = matSur['efficiency_table']
+                    E = lb.E[goodN]
+                    if np.any(E < tabE[0]) or np.any(E > tabE[-1]):         # :399-407
+                        raise ValueError('E={0} is out of the efficiency table range [{1}, {2}]'
+                                         .format(E[(E < tabE[0]) | (E > tabE[-1])],
+                                                 tabE[0], tabE[-1]))
+                    for ieff, eff in enumerate(matSur['efficiency']):
+                        resI[order == eff[0]] = np.interp(E[order == eff[0]], tabE, tabI[ieff])
                 resA = resI**0.5
                 refl = resA, resA, 0
             else:

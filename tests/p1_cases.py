@@ -109,7 +109,12 @@ def product_oe(name, g):
     elif name.startswith('g2_grating'):
         eff = [[int(o), float(v)] for o, v in g['efficiency']] if 'efficiency' in g.files \
             else None
-        m = rm.Material('Au', rho=float(g['mat_rho']), kind='grating', efficiency=eff)
+        if 'eff_E' in g.files:            # the columns of the data file next to the golden
+            eff = [[int(o), int(c)] for o, c in g['efficiency']]
+            m = rm.Material('Au', rho=float(g['mat_rho']), kind='grating', efficiency=eff,
+                            efficiencyFile=os.path.join(GOLDEN, name + '.txt'))
+        else:
+            m = rm.Material('Au', rho=float(g['mat_rho']), kind='grating', efficiency=eff)
         if 'gd_axis' in g.files:
             oe = roe.OE(bl, 'gr', material=m,
                         order=int(g['order']) if g['order'].ndim == 0 else

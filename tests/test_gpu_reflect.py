@@ -190,6 +190,45 @@ def test_grating_efficiency_per_order_matches_reference_golden():
         assert sel.sum() > 300 and np.abs(ratio - table.get(order, 0.)).max() < 1e-12
 
 
+def test_grating_efficiency_file_matches_reference_golden():
+    """Material(kind='grating', efficiency=[[order, column], ...], efficiencyFile=...): the
+    efficiency of the ray's order interpolated at its energy in the file's table
+    (material.py:335-346, 403-410), per ray in the kernel; energies on the nodes and on both
+    ends of the table are among the rays."""
+    g = pc.load('g2_grating_efffile')
+    oe = pc.product_oe('g2_grating_efffile', g)
+    assert np.array_equal(oe.material.efficiency_E, g['eff_E'])
+    assert np.array_equal(oe.material.efficiency_I, g['eff_I'])
+    np.random.seed(int(g['np_seed']))
+    gb, lb = oe.reflect(pc.product_beam(g))
+    compare(gb, g, lambda f: g['gb_' + f])
+    compare(lb, g, lambda f: g['lb_' + f])
+    assert np.array_equal(lb.order, g['lb_order'])
+    hit = g['lb_state'] == 1
+    flux_in = (g['in_Jss'] + g['in_Jpp'])
+    for row, (order, _) in enumerate(g['efficiency']):
+        sel = hit & (g['lb_order'] == order)
+        want = np.interp(g['in_E'][sel], g['eff_E'], g['eff_I'][row])
+        ratio = (lb.Jss + lb.Jpp)[sel] / flux_in[sel]
+        assert sel.sum() > 300 and np.abs(ratio / want - 1).max() < 1e-13
+    assert not (lb.Jss + lb.Jpp)[hit & (g['lb_order'] == 0)].any()
+
+
+def test_energy_outside_the_efficiency_file_is_refused():
+    """The reference raises ValueError (material.py:399-407); so does the product, before
+    the launch."""
+    g = pc.load('g2_grating_efffile')
+    oe = pc.product_oe('g2_grating_efffile', g)
+    beam = pc.product_beam(g)
+    beam.E[100] = 400.
+    np.random.seed(int(g['np_seed']))
+    with pytest.raises(ValueError, match='out of the efficiency table range'):
+        oe.reflect(beam)
+    beam.E[100] = 280.
+    beam.E[4] = 400.          # a ray that does not enter (state -4) is not looked at
+    oe.reflect(beam)
+
+
 def test_position_dependent_user_local_g_is_refused():
     import xrt_amd.backends.raycing as raycing
     import xrt_amd.backends.raycing.materials as rm

@@ -88,12 +88,14 @@ def test_zone_plate_matches_reference(name):
         assert np.array_equal(lb.order, g['lb_order'])
 
 
-@pytest.mark.parametrize('name', ['g2_grating_orders', 'g2_grating_efficiency'])
+@pytest.mark.parametrize('name', ['g2_grating_orders', 'g2_grating_efficiency',
+                                  'g2_grating_efffile'])
 def test_random_diffraction_orders_follow_the_references_draw(name):
     """order=(1, -1, 2, 0): one order per hit ray from numpy's global generator
     (reflect.py:455-458); with the reference's seed the oracle draws the same. With a
     table of efficiencies per order (material.py:391-413) the amplitudes are its square
-    roots, zero for an order the table does not list."""
+    roots, zero for an order the table does not list; with an efficiency FILE the table is
+    a function of energy (np.interp, :403-410)."""
     p, beam, g = fixture_io.load_case(name)
     np.random.seed(int(g['np_seed']))
     gb, lb = rn.oe_reflect(p, beam)
@@ -265,3 +267,12 @@ def test_fixed_refractive_index(golden_dir):
     check_beam(gb2, g, 'gb_')
     check_beam(lo1, g, 'lo1_')
     check_beam(lo2, g, 'lo2_')
+
+
+def test_energy_outside_the_efficiency_file_is_an_error():
+    """material.py:399-407: the reference raises rather than extrapolate."""
+    p, beam, g = fixture_io.load_case('g2_grating_efffile')
+    beam.E[100] = 400.
+    np.random.seed(int(g['np_seed']))
+    with pytest.raises(ValueError, match='out of the efficiency table range'):
+        rn.oe_reflect(p, beam)

@@ -6,6 +6,8 @@
 set -e
 NAME=$1; FLAGS=$2; shift 2 || true
 UNITS=${@:-reflect_hot}
+# (ELIDE= in the environment: without the raised elision limit of csrc/build.py)
+ELIDE=${ELIDE--mllvm -instcombine-max-copied-from-constant-users=100000}
 cd "$(dirname "$0")/../xrt_amd/csrc"
 V=/tmp/xrt_var_$NAME   # variant objects stay out of the tree
 mkdir -p $V ../ab
@@ -14,6 +16,7 @@ for o in build/*.o; do
   b=$(basename $o .o)
   if [[ " $UNITS " == *" $b "* ]]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden \
+      $ELIDE \
       -Wno-unused-function $FLAGS -c $b.hip -o $V/$b.o &
     OBJS="$OBJS $V/$b.o"
   else

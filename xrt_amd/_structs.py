@@ -83,6 +83,9 @@ class Pass(ctypes.Structure):
         ('g_ray_y', ctypes.c_void_p),
         ('method_hint', ctypes.c_void_p),
         ('user_unit', ctypes.c_void_p),
+        ('eff_tab_n', ctypes.c_int32),
+        ('eff_tab_E', ctypes.c_void_p),
+        ('eff_tab_I', ctypes.c_void_p),
     ]
 
 

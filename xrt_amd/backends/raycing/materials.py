@@ -185,15 +185,47 @@ class Material(object):
         self._index_poly = {}
         # gratings / zone plates: [order, efficiency] pairs used in place of the Fresnel
         # amplitudes (material.py:78-95, 391-413)
+        # with *efficiencyFile* the second number of a pair is a column of that file: efficiency
+        # against energy, interpolated per ray (material.py:335-346, 403-410)
+        self.efficiency, self.efficiencyFile = efficiency, efficiencyFile
+        self._efficiency_dev = {}
         if efficiencyFile is not None:
-            raise NotImplementedError('efficiency tables from a file')
-        self.efficiency, self.efficiencyFile = efficiency, None
+            self.read_efficiency_file()
         self.geom = ''
         self.mass = 0.
         for elem, xi in zip(self.elements, self.quantities):
             self.mass += xi * elem.mass
         self.name = name or ''.join(e.name for e in self.elements)
         self.uuid = kwargs.get('uuid')
+
+    def read_efficiency_file(self):
+        """material.py:335-346: a pickle of (energies, table[energy, column]) or a text file
+        whose first column is the energy."""
+        cols = [int(c[1]) for c in self.efficiency]
+        if self.efficiencyFile.endswith('.pickle'):
+            import pickle
+            with open(self.efficiencyFile, 'rb') as f:
+                res = pickle.load(f)
+            es, eff = np.asarray(res[0]), np.asarray(res[1]).T[cols, :]
+        else:
+            es = np.loadtxt(self.efficiencyFile, usecols=(0,), unpack=True)
+            eff = np.loadtxt(self.efficiencyFile, usecols=cols,
+                             unpack=True).reshape(len(cols), -1)
+        self.efficiency_E = np.ascontiguousarray(es, dtype=np.float64)
+        self.efficiency_I = np.ascontiguousarray(eff, dtype=np.float64)
+        self._efficiency_dev.clear()
+
+    def efficiency_on_device(self, device):
+        """(energies, rows) of the efficiency table in HBM, one row per entry of
+        *efficiency* (xrt_hip_pass.eff_tab_E / eff_tab_I)."""
+        import torch
+        held = self._efficiency_dev.get(str(device))
+        if held is None or held[0] is not self.efficiency_I:
+            held = self._efficiency_dev[str(device)] = (
+                self.efficiency_I,
+                torch.from_numpy(self.efficiency_E.copy()).to(device),
+                torch.from_numpy(self.efficiency_I.copy()).to(device).contiguous())
+        return held[1], held[2]
 
     # ---- struct for the kernels ---------------------------------------------
     def _fill_elements(self, s, device):

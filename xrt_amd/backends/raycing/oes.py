@@ -268,8 +268,19 @@ class OE(object):
             if len(pairs) > 8:
                 raise NotImplementedError('more than 8 efficiency entries')
             p.eff_n = len(pairs)
-            for k, (order, value) in enumerate(pairs):
-                p.eff_order[k], p.eff_amp[k] = int(order), float(np.float64(value)**0.5)
+            if getattr(material, 'efficiencyFile', None) is not None:
+                # the second number is a column of the file: a row of the table in HBM,
+                # interpolated at each ray's energy by the kernel
+                tab_E, tab_I = material.efficiency_on_device(_device())
+                p.eff_tab_n = int(tab_E.numel())
+                p.eff_tab_E, p.eff_tab_I = tab_E.data_ptr(), tab_I.data_ptr()
+                p._keep_eff = (tab_E, tab_I)
+                p._eff_range = (float(material.efficiency_E[0]), float(material.efficiency_E[-1]))
+                for k, (order, column) in enumerate(pairs):
+                    p.eff_order[k], p.eff_amp[k] = int(order), 0.
+            else:
+                for k, (order, value) in enumerate(pairs):
+                    p.eff_order[k], p.eff_amp[k] = int(order), float(np.float64(value)**0.5)
         if hasattr(self, '_zones_between_passes'):
             p.grating = 0                 # general zone plate: its first pass is geometry only
             return
@@ -432,6 +443,20 @@ class OE(object):
             rs.inherit_scalars(b, parent)
             b.parentId = self.uuid
 
+    @staticmethod
+    def _check_efficiency_range(p, beam, dev):
+        """The reference refuses energies outside the efficiency table (material.py:399-407);
+        so does this, before the launch, for the rays that enter the pass (one reduction on
+        the device and one number read back)."""
+        E, state = beam.dev('E', dev), beam.dev('state', dev)
+        enters = state > 0 if p.good_mode == 0 else (state == 1) | (state == 2)
+        Emin, Emax = p._eff_range
+        bad = enters & ((E < Emin) | (E > Emax))
+        if bool(bad.any()):
+            raise ValueError(
+                'E={0} is out of the efficiency table range [{1}, {2}]!!! Use another '
+                'table.'.format(E[bad].cpu().numpy(), Emin, Emax))
+
     def _run_pass(self, p, material, fromVacuum, beam_in, restore, want_info=False,
                   timing=False, out=None, local=True):
         """-> (lb, vlb) device-resident beams (+ info dict). *out*: an (lb, vlb)
@@ -442,6 +467,8 @@ class OE(object):
         lib = _lib.load()
         dev = _device()
         ms = self._material_struct(material, fromVacuum, dev, beam_in)
+        if p.eff_tab_n > 0:
+            self._check_efficiency_range(p, beam_in, dev)
         s_in = beam_in.to_struct(dev)
         s_re = s_in if restore is beam_in else restore.to_struct(dev)
         n = beam_in.nrays

@@ -26,8 +26,14 @@ ONLY_FOR = {'reflect_impl.h': 'reflect', 'reflect_tu.h': 'reflect', 'kirchhoff.h
 # -ffp-contract=off: fused multiply-add only where the source says fma();
 # the reference (numpy) never fuses and ray states / the Kirchhoff phase
 # depend on bit-identical intermediate roundings.
+# -instcombine-max-copied-from-constant-users: the by-value records (xrt_hip_pass, 1 KB) reach a
+# kernel as a private copy of the kernarg segment, which the optimiser drops again only if it can
+# see that the copy is never written -- and it stops looking after 300 uses. The generic kernels
+# read the pass record more often than that; past the limit the whole record lives in scratch
+# (1 KB per lane, 12 us of launch overhead on every pass).
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
-         '-fPIC', '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
+         '-fPIC', '-fvisibility=hidden', '-Wall', '-Wno-unused-function',
+         '-mllvm', '-instcombine-max-copied-from-constant-users=100000']
 
 
 def _hipcc():

@@ -312,6 +312,13 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
     return fail(XRT_HIP_ERR_ARG, "bad grating description");
   if (pass->grating && material->kind == XRT_HIP_MAT_CRYSTAL)
     return fail(XRT_HIP_ERR_ARG, "grating equation on a crystal material");
+  if (pass->eff_tab_n < 0 || (pass->eff_tab_n > 0 && (pass->eff_tab_n < 2 || !pass->eff_tab_E ||
+                                                     !pass->eff_tab_I || pass->eff_n < 1)))
+    return fail(XRT_HIP_ERR_ARG, "efficiency table: needs >= 2 energies, both arrays and "
+                                 "eff_n rows");
+  if (pass->eff_tab_n > 0 && (material->kind == XRT_HIP_MAT_MULTILAYER ||
+                              material->kind == XRT_HIP_MAT_CRYSTAL))
+    return fail(XRT_HIP_ERR_ARG, "efficiency table with a layered or crystal material");
   if (pass->grating < 0 || pass->grating > 2 ||
       (pass->grating == 2 && !pass->g_ray_x && (pass->zone_n < 1 || !pass->zone_r)))
     return fail(XRT_HIP_ERR_ARG, "bad zone plate description");

@@ -1800,6 +1800,24 @@ __device__ __forceinline__ cplx interp_f1f2(const xrt_hip_material& M, int e, do
   return C(f1, f2);
 }
 
+// np.interp(E, tE, tI) for one ray (grating efficiency from a file, material.py:408-410)
+__device__ __forceinline__ double efficiency_at(const double* __restrict__ tE,
+                                             const double* __restrict__ tI, int n, double E) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (E >= tE[mid])
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  const int j = lo - 1;
+  if (j < 0) return tI[0];
+  if (j >= n - 1) return tI[n - 1];
+  if (tE[j] == E) return tI[j];
+  return div_rn(tI[j + 1] - tI[j], tE[j + 1] - tE[j]) * (E - tE[j]) + tI[j];
+}
+
 // material.py:348-378
 __device__ __forceinline__ cplx refractive_index(const xrt_hip_material& M, double E,
                                                  const TabWin& w) {
@@ -2796,8 +2814,19 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   }
   if (PGRATING(P) && P.eff_n > 0) {  // tabulated efficiency of the order, material.py:391-413
     double amp = 0.;
-    for (int k = 0; k < P.eff_n; ++k)
-      if (P.eff_order[k] == took_order) amp = P.eff_amp[k];
+    int row = -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < P.eff_n && P.eff_order[k] == took_order) {
+        amp = P.eff_amp[k];
+        row = k;
+      }
+    // efficiency file: np.interp on (E, row), :408-410 (not compiled into the kernels of
+    // layered materials and crystals: a grating's material is neither, capi.hip refuses it)
+    if (K::MK != XRT_HIP_MAT_MULTILAYER && K::MK != XRT_HIP_MAT_CRYSTAL && P.eff_tab_n > 0 &&
+        row >= 0)
+      amp = sqrt(efficiency_at(P.eff_tab_E, P.eff_tab_I + (int64_t)row * P.eff_tab_n,
+                               P.eff_tab_n, q.E));
     A.rs = A.rp = C(amp, 0.);
     A.mu = A.nk = 0.;
   }

@@ -33,7 +33,8 @@ from . import _lib
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
 _FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
-          '-fvisibility=hidden', '-Wno-unused-function', '-shared']
+          '-fvisibility=hidden', '-Wno-unused-function', '-shared',
+          '-mllvm', '-instcombine-max-copied-from-constant-users=100000']     # (csrc/build.py)
 _lock = threading.Lock()
 _handles = {}       # unit path -> handle
 
