@@ -597,6 +597,32 @@ def bench_e2e(nrays, repeats=20):
                       frac=652. * nrays / wall / HBM_PEAK, traffic=None,
                       note='652 B per ray algorithmic: 100 written by the source, 308 by '
                            'OE.reflect (SURVEY 8d), 200 by Screen.expose, 44 read by the plot'))
+    # beams of the size most xrt scripts trace (1e5 rays per iteration): the host, not the GPU,
+    # bounds the eager loop; run_ray_tracing(graph=True) replays one HIP graph per iteration
+    small = {}
+    for n_small in (100_000, 1_000_000):
+        bls, run_s, make_s = workloads.e2e_beamline(n_small)
+        rr.run_process = run_s
+        row = {}
+        for mode in ('eager', 'graph'):
+            reps = 200
+            runner.run_ray_tracing([make_s()], repeats=3, beamLine=bls, graph=mode == 'graph')
+            torch.cuda.synchronize()
+            ps = make_s()
+            t0 = time.perf_counter()
+            runner.run_ray_tracing([ps], repeats=reps, beamLine=bls, graph=mode == 'graph')
+            torch.cuda.synchronize()
+            # (the graph run spends its first two iterations eagerly and records the third)
+            row[mode + '_ms_per_iteration'] = (time.perf_counter() - t0) / reps * 1e3
+            row[mode + '_flux'] = float(ps.total2D.sum())
+        row['speedup'] = row['eager_ms_per_iteration'] / row['graph_ms_per_iteration']
+        small['%d_rays' % n_small] = row
+    res['small_beams'] = dict(
+        small, note='the same job at 1e5 and 1e6 rays per iteration, 200 iterations: eager loop '
+                    '(Python + ctypes per element) against run_ray_tracing(graph=True) (one HIP '
+                    'graph launch per iteration, xrt_amd/graphs.py); the graph time includes its '
+                    'two eager iterations and the recording')
+    rr.run_process = run_process
     if os.environ.get('XRT_E2E_NO_HOST'):
         return res
     # the same job with the host source

@@ -653,6 +653,10 @@ typedef struct xrt_hip_geosource {
   int32_t to_global;            /* undo the beamline azimuth, add center */
   int32_t state;                /* the state every ray gets (1) */
   double sin_az, cos_az, center[3];
+  /* NULL, or a DEVICE cell whose value is added to `call` (modulo 2^32) when the kernel runs: a
+   * launch captured in a HIP graph is replayed with the same record, the owner of the graph
+   * increments the cell between replays and every replay draws new rays */
+  const uint32_t* call_dev;
 } xrt_hip_geosource;
 
 /* out: device arrays of out->n rays, all overwritten (Es_ri / Ep_ri NULL = no amplitudes). */
@@ -705,6 +709,19 @@ XRT_HIP_API int xrt_hip_plot_hist_f64_dev(
     const xrt_hip_beam* beam, const double* x, const double* y, const double* c,
     const xrt_hip_plot* plot, double* hist2d, double* hist2d_rgb, double* hist_x,
     double* hist_y, double* hist_c, double* counters, void* stream);
+/* The same with scratch of the caller (DEVICE memory, `workspace_bytes` from
+ * xrt_hip_plot_hist_workspace_bytes for this ray count, plot and set of outputs; used in stream
+ * order). xrt_hip_plot_hist_f64_dev takes its scratch from the device's stream-ordered pool
+ * (hipMallocAsync / hipFreeAsync per call); this form allocates nothing, which is also what a
+ * call recorded into a HIP graph needs. A workspace that is NULL or too small falls back to
+ * the pool. with_lines: any of hist_x / hist_y / hist_c / counters is asked for. */
+XRT_HIP_API int xrt_hip_plot_hist_workspace_bytes(int64_t nrays, const xrt_hip_plot* plot,
+                                                  int with_rgb, int with_lines, size_t* bytes);
+XRT_HIP_API int xrt_hip_plot_hist_ws_f64_dev(
+    const xrt_hip_beam* beam, const double* x, const double* y, const double* c,
+    const xrt_hip_plot* plot, double* hist2d, double* hist2d_rgb, double* hist_x,
+    double* hist_y, double* hist_c, double* counters, void* workspace, size_t workspace_bytes,
+    void* stream);
 
 /* ---- undulator field integral -------------------------
  * Replaces run_parallel('undulator' | 'undulator_taper' | 'undulator_nf', ...)

@@ -51,9 +51,13 @@ clock('accumulate_plot', lambda: runner.accumulate_plot(plot, {'focus': img}))
 clock('run_process (source, mirror, screen)', lambda: run_process(bl))
 import cProfile
 import pstats
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(200):
-    dcm.double_reflect(b3)
-pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+for what, fn in (('OE.reflect', lambda: oe.reflect(beam)),
+                 ('DCM.double_reflect', lambda: dcm.double_reflect(b3))):
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(200):
+        fn()
+    pr.disable()
+    print('==== cProfile of 200 x %s' % what)
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(30)
+    pstats.Stats(pr).sort_stats('tottime').print_stats(20)

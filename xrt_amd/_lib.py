@@ -69,6 +69,10 @@ SIGNATURES = {
         ctypes.c_int, ctypes.c_double, ctypes.c_double, vp, vp, vp]),
     'xrt_hip_plot_hist_f64_dev': (ctypes.c_int, [
         vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'xrt_hip_plot_hist_ws_f64_dev': (ctypes.c_int, [
+        vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    'xrt_hip_plot_hist_workspace_bytes': (ctypes.c_int, [
+        i64, vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     'xrt_hip_undulator_workspace_bytes': (ctypes.c_size_t, [i64]),
     'xrt_hip_undulator_f64_dev': (ctypes.c_int, [
         vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp,

@@ -287,7 +287,8 @@ class GeoSource(ctypes.Structure):
                 ('state', ctypes.c_int32),
                 ('sin_az', ctypes.c_double),
                 ('cos_az', ctypes.c_double),
-                ('center', ctypes.c_double * 3)]
+                ('center', ctypes.c_double * 3),
+                ('call_dev', ctypes.c_void_p)]
 
 
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,

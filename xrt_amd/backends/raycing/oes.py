@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from .. import raycing
-from ... import _lib, _structs, hipcalls
+from ... import _lib, _structs, graphs, hipcalls
 from . import sources as rs
 from . import stages as rst
 from .physconsts import CH
@@ -467,7 +467,8 @@ class OE(object):
         lib = _lib.load()
         dev = _device()
         ms = self._material_struct(material, fromVacuum, dev, beam_in)
-        if p.eff_tab_n > 0:
+        if p.eff_tab_n > 0 and graphs.capturing() is None:
+            # (recorded into a HIP graph: checked by the eager iteration before it)
             self._check_efficiency_range(p, beam_in, dev)
         s_in = beam_in.to_struct(dev)
         s_re = s_in if restore is beam_in else restore.to_struct(dev)
@@ -719,6 +720,7 @@ def _ray_orders(self, p, beam, lb, gb, _info, _timing):
     generator the way the reference draws it (oes/reflect.py:455-458, one randint call of
     the size of the hit set, in ray order), then the pass is repeated with the draw as a
     per-ray array. The local beam carries it as *order* like the reference's."""
+    graphs.refuse('diffraction orders drawn per ray with numpy\'s generator')
     dev = _device()
     hit = lb.dev('state', dev) == 1
     count = int(hit.sum())

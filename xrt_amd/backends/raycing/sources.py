@@ -290,6 +290,8 @@ class Beam(object):
             raise AttributeError(name)
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
+        from ... import graphs
+        graphs.refuse('upload of the host array %r of a beam' % name)
         h = np.ascontiguousarray(self._h[name], dtype=_np_dtype(name))
         t = torch.from_numpy(h).to(device)
         self._d[name] = t
@@ -709,6 +711,19 @@ class GeometricSource(object):
                 g.center[k] = float(self.center[k])
         return g, reach[1]
 
+    def _replay_cell(self, dev):
+        """(device cell, its value as the host knows it) counting the replays of the graphs this
+        source was recorded into; made outside any recording."""
+        cells = self.__dict__.setdefault('_replay_cells', {})
+        held = cells.get(str(dev))
+        if held is None:
+            from ... import graphs
+            if graphs.capturing() is not None:
+                raise graphs.CaptureError('the source has not been used eagerly on this device '
+                                          'before the recording')
+            held = cells[str(dev)] = [torch.zeros(1, dtype=torch.int32, device=dev), 0]
+        return held
+
     def _shine_device(self, toGlobal, withAmplitudes, accuBeam):
         import ctypes
         from ... import _lib
@@ -716,10 +731,27 @@ class GeometricSource(object):
         lib = _lib.load()
         dev = torch.device('cuda', torch.cuda.current_device())
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        from ... import graphs
+        rec = graphs.capturing()
         with self._call_lock:            # every shine() takes its own sub-stream, also from threads
-            call = self._calls
-            self._calls += 1
+            if rec is None:
+                call = self._calls
+                self._calls += 1
+                self._replay_cell(dev)   # (exists before any recording)
+            else:
+                # recorded into a HIP graph: replay k must draw what the k-th eager call would
+                # have -- the kernel adds a device cell, incremented by the graph itself, to
+                # the call number of the record (this call's number less the cell's value now)
+                cell, value = self._replay_cell(dev)
+                ahead = rec.pending_calls.get(self, 0)
+                rec.pending_calls[self] = ahead + 1
+                call = (self._calls + ahead - value) & 0xffffffff
         g, reach2 = self.device_spec(toGlobal, call)
+        if rec is not None:
+            g.call_dev = cell.data_ptr()
+            if reach2 > 1:
+                graphs.refuse('a source whose tangents can leave the unit circle (the whole-batch '
+                              'decision on how b is formed is read back)')
         if reach2 > 1:
             # tangents that CAN leave the unit circle: the reference forms b from slopes if
             # any ray of the batch does (geoms.py:497-505) -- ask the generator
@@ -732,7 +764,19 @@ class GeometricSource(object):
         _lib.check(lib.xrt_hip_geosource_shine_f64_dev(
             ctypes.byref(g), ctypes.byref(bo.to_struct(dev)), stream),
             'xrt_hip_geosource_shine_f64_dev')
+        if rec is not None and rec.pending_calls[self] == 1:
+            cell.add_(1)                 # (recorded: once per replay, after the generator ran)
+
+            def count():
+                with self._call_lock:
+                    self._calls += rec.pending_calls[self]
+                    self._replay_cells[str(dev)][1] += 1
+            rec.after_replay.append(count)
+        elif rec is not None:
+            graphs.refuse('a second shine() of one source in an iteration')
         if np.isscalar(self.totalFlux) and self.totalFlux > 0:      # make_flux_normalization
+            if self.uniformRayDensity:
+                graphs.refuse('totalFlux of a source with uniformRayDensity (a sum read back)')
             total = self.nrays * (g.Jss + g.Jpp) if not self.uniformRayDensity else \
                 float((bo.dev('Jss') + bo.dev('Jpp')).sum())
             if total > 0:

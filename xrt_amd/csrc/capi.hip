@@ -823,22 +823,54 @@ int xrt_hip_hist2d_f64_dev(const xrt_hip_beam* beam, const double* x, const doub
   return XRT_HIP_OK;
 }
 
-int xrt_hip_plot_hist_f64_dev(const xrt_hip_beam* beam, const double* x, const double* y,
-                              const double* c, const xrt_hip_plot* plot, double* hist2d,
-                              double* hist2d_rgb, double* hist_x, double* hist_y,
-                              double* hist_c, double* counters, void* stream) {
-  if (!beam || !plot) return fail(XRT_HIP_ERR_ARG, "NULL beam / plot");
-  int rc;
-  if ((rc = check_beam(beam, "beam", beam->n, false))) return rc;
-  if (plot->bins_x < 1 || plot->bins_y < 1 || (hist_c && plot->bins_c < 1))
+static int check_plot(const xrt_hip_plot* plot, bool with_c) {
+  if (plot->bins_x < 1 || plot->bins_y < 1 || (with_c && plot->bins_c < 1))
     return fail(XRT_HIP_ERR_ARG, "bins must be >= 1");
   if (!(plot->x_lim[1] > plot->x_lim[0]) || !(plot->y_lim[1] > plot->y_lim[0]) ||
       !(plot->c_lim[1] > plot->c_lim[0]))
     return fail(XRT_HIP_ERR_ARG, "empty histogram range");
   if (plot->flux_kind < 0 || plot->flux_kind > 5) return fail(XRT_HIP_ERR_ARG, "unknown flux kind");
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_plot_hist_ws_f64_dev(const xrt_hip_beam* beam, const double* x, const double* y,
+                                 const double* c, const xrt_hip_plot* plot, double* hist2d,
+                                 double* hist2d_rgb, double* hist_x, double* hist_y,
+                                 double* hist_c, double* counters, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (!beam || !plot) return fail(XRT_HIP_ERR_ARG, "NULL beam / plot");
+  int rc;
+  if ((rc = check_beam(beam, "beam", beam->n, false))) return rc;
+  if ((rc = check_plot(plot, hist_c != nullptr))) return rc;
   if (beam->n > 0 && (!x || !y || !c || !hist2d)) return fail(XRT_HIP_ERR_ARG, "NULL array");
   HIP_TRY(xrt::plot_hist_launch(*beam, x, y, c, *plot, hist2d, hist2d_rgb, hist_x, hist_y,
-                                hist_c, counters, reinterpret_cast<hipStream_t>(stream)));
+                                hist_c, counters, reinterpret_cast<hipStream_t>(stream),
+                                workspace, workspace ? workspace_bytes : 0, nullptr));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_plot_hist_f64_dev(const xrt_hip_beam* beam, const double* x, const double* y,
+                              const double* c, const xrt_hip_plot* plot, double* hist2d,
+                              double* hist2d_rgb, double* hist_x, double* hist_y,
+                              double* hist_c, double* counters, void* stream) {
+  return xrt_hip_plot_hist_ws_f64_dev(beam, x, y, c, plot, hist2d, hist2d_rgb, hist_x, hist_y,
+                                      hist_c, counters, nullptr, 0, stream);
+}
+
+int xrt_hip_plot_hist_workspace_bytes(int64_t nrays, const xrt_hip_plot* plot, int with_rgb,
+                                      int with_lines, size_t* bytes) {
+  if (!plot || !bytes) return fail(XRT_HIP_ERR_ARG, "NULL plot / result");
+  if (nrays < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  int rc;
+  if ((rc = check_plot(plot, false))) return rc;
+  xrt_hip_beam beam;
+  memset(&beam, 0, sizeof(beam));
+  beam.n = nrays;
+  double* some = reinterpret_cast<double*>(uintptr_t(256));   // (never dereferenced: size only)
+  HIP_TRY(xrt::plot_hist_launch(beam, some, some, some, *plot, some, with_rgb ? some : nullptr,
+                                with_lines ? some : nullptr, with_lines ? some : nullptr,
+                                nullptr, with_lines ? some : nullptr, nullptr, nullptr, 0,
+                                bytes));
   return XRT_HIP_OK;
 }
 

@@ -744,10 +744,14 @@ static bool plan_tiles(int bx, int by, int nchan, size_t budget, int max_tiles, 
   return best != 0;
 }
 
+// *ws* / *ws_bytes*: scratch of the caller (size from plot_hist_scratch_bytes), used in stream
+// order; NULL or too small: taken from the device's stream-ordered pool for this call. With
+// *need* set nothing is launched: the size a call with these arguments would use is returned.
 hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const double* y,
                             const double* c, const xrt_hip_plot& P, double* h2, double* h2rgb,
                             double* hx, double* hy, double* hc, double* counters,
-                            hipStream_t st) {
+                            hipStream_t st, void* ws, size_t ws_bytes, size_t* need) {
+  if (need) *need = 0;
   if (beam.n <= 0) return hipSuccess;
   PlotAxes A;
   A.x = axis_bins(P.x_lim[0], P.x_lim[1], P.bins_x);
@@ -756,7 +760,7 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  keep_pool_memory(dev);
+  if (!need && !ws) keep_pool_memory(dev);
   const bool want_lines = hx || hy || hc || counters;
   // (the kernel keeps all three 1-D histograms; absent ones are dropped by the reduce)
   const size_t b1 = sizeof(double) * 4 * ((size_t)A.x.bins + A.y.bins + A.c.bins);
@@ -788,6 +792,9 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
     if (mode == HIST_RECORDS) {
       // plot_hist_tiles: one block per CU, shared out among the tiles by their ray counts
       // (tile_shares); every block leaves a copy of ITS tile
+      // (fewer blocks for small beams -- less to zero, write and reduce -- was tried: at 1e5
+      // rays 55 blocks took 29.8 us where 256 take 18.4; the launch is bound by the latency of
+      // a block's phases, not by the 32 MB of copies)
       ncopies = cus > T ? cus : T;
       H.slices = ncopies;
     }
@@ -801,12 +808,24 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
     const size_t recs = mode == HIST_RECORDS ? (size_t)chunks * HIST_CHUNK : 0;
     const size_t start_b = pad(mode == HIST_RECORDS ? (size_t)chunks * (T + 2) * 4 : 0);
     const size_t counts_b = pad(mode == HIST_RECORDS ? (size_t)nblk * T * 4 : 0);
+    const size_t scratch_b =
+        planes_b + lines_b + pad(recs * 8) * 2 + pad(recs * 4) + start_b + counts_b + 1024;
+    if (need) {
+      *need = scratch_b + 256;       // (+ alignment of the caller's pointer)
+      return hipSuccess;
+    }
     char* scratch = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void**>(&scratch),
-                       planes_b + lines_b + pad(recs * 8) * 2 + pad(recs * 4) + start_b + counts_b + 1024,
-                       st) != hipSuccess) {
-      (void)hipGetLastError();
-      scratch = nullptr;
+    bool own = false;
+    if (ws) {
+      char* aligned = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 255) / 256 * 256);
+      if (aligned + scratch_b <= static_cast<char*>(ws) + ws_bytes) scratch = aligned;
+    }
+    if (!scratch) {
+      own = true;
+      if (hipMallocAsync(reinterpret_cast<void**>(&scratch), scratch_b, st) != hipSuccess) {
+        (void)hipGetLastError();
+        scratch = nullptr;
+      }
     }
     if (scratch) {
       char* q = scratch;
@@ -836,7 +855,7 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(rays),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
       if (e != hipSuccess) {
-        (void)hipFreeAsync(scratch, st);
+        if (own) (void)hipFreeAsync(scratch, st);
         return e;
       }
       hipLaunchKernelGGL(rays, dim3((unsigned)nblk), dim3(mode == HIST_DIRECT ? HIST_BLOCK : 256),
@@ -847,7 +866,7 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiles),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         if (e != hipSuccess) {
-          (void)hipFreeAsync(scratch, st);
+          if (own) (void)hipFreeAsync(scratch, st);
           return e;
         }
         hipLaunchKernelGGL(tiles, dim3((unsigned)ncopies), dim3(HIST_BLOCK), lds2, st, chunks, R,
@@ -865,11 +884,12 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
                              mode == HIST_RECORDS ? R.share : nullptr,
                              total >= 32768 ? 1 : HIST_REDUCE_PARTS);
       }
-      (void)hipFreeAsync(scratch, st);
+      if (own) (void)hipFreeAsync(scratch, st);
     } else {
       general = (h2 ? 1 : 0) | (want_lines ? 2 : 0);
     }
   }
+  if (need) return hipSuccess;
   if (general) {
     const dim3 full((unsigned)((beam.n + 255) / 256));
     hipLaunchKernelGGL(plot_hist_kernel, full, dim3(256), 0, st, beam, x, y, c, P, A, h2, h2rgb,
@@ -903,7 +923,7 @@ hipError_t hist2d_launch(const xrt_hip_beam& beam, const double* x, const double
   P.ray_flags = ray_flags;
   P.flux_kind = flux_kind;
   return plot_hist_launch(beam, x, y, x, P, hist, nullptr, nullptr, nullptr, nullptr, counters,
-                          st);
+                          st, nullptr, 0, nullptr);
 }
 
 }  // namespace xrt

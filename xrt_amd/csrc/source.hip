@@ -72,6 +72,12 @@ __device__ __forceinline__ void box_muller(const U2 u, double& g1, double& g2) {
   g2 = radius * sn;
 }
 
+// the call number of this launch: the record's, plus what the caller keeps in device memory (a
+// launch captured in a HIP graph is replayed with the same record: the cell counts the replays)
+__device__ __forceinline__ uint32_t call_of(const xrt_hip_geosource& G) {
+  return G.call + (G.call_dev ? *G.call_dev : 0u);
+}
+
 struct Ray {
   double Jss, Jpp, Jre, Jim, Esr, Esi, Epr, Epi;
 };
@@ -93,11 +99,11 @@ __device__ __forceinline__ void weigh_down(Ray& r, double v, double sigma, doubl
   }
 }
 
-__device__ __forceinline__ double one_number(const xrt_hip_geosource& G, int k, uint64_t i,
-                                             uint32_t slot, Ray& r, bool amp) {
+__device__ __forceinline__ double one_number(const xrt_hip_geosource& G, uint32_t call, int k,
+                                             uint64_t i, uint32_t slot, Ray& r, bool amp) {
   const int law = G.law[k];
   if (law == XRT_HIP_LAW_NONE) return 0.;
-  const U2 u = philox_uniforms(i, slot, G.call, G.seed);
+  const U2 u = philox_uniforms(i, slot, call, G.seed);
   if (law == XRT_HIP_LAW_NORMAL) {
     double g1, g2;
     box_muller(u, g1, g2);
@@ -110,11 +116,12 @@ __device__ __forceinline__ double one_number(const xrt_hip_geosource& G, int k, 
   return v;
 }
 
-__device__ __forceinline__ void one_pair(const xrt_hip_geosource& G, int k, bool annulus,
-                                         const double* ann, uint64_t i, uint32_t slot, Ray& r,
-                                         bool amp, double& first, double& second) {
+__device__ __forceinline__ void one_pair(const xrt_hip_geosource& G, uint32_t call, int k,
+                                         bool annulus, const double* ann, uint64_t i,
+                                         uint32_t slot, Ray& r, bool amp, double& first,
+                                         double& second) {
   if (annulus) {          // _set_annulus, geoms.py:409-418
-    const U2 u = philox_uniforms(i, slot, G.call, G.seed);
+    const U2 u = philox_uniforms(i, slot, call, G.seed);
     double radius = ann[1];
     if (ann[1] > ann[0]) {
       const double density = 2. / (ann[1] * ann[1] - ann[0] * ann[0]);
@@ -129,13 +136,13 @@ __device__ __forceinline__ void one_pair(const xrt_hip_geosource& G, int k, bool
   }
   if (G.law[k] == XRT_HIP_LAW_NORMAL && G.law[k + 1] == XRT_HIP_LAW_NORMAL) {
     double g1, g2;
-    box_muller(philox_uniforms(i, slot, G.call, G.seed), g1, g2);
+    box_muller(philox_uniforms(i, slot, call, G.seed), g1, g2);
     first = g1 * G.p0[k];
     second = g2 * G.p0[k + 1];
     return;
   }
-  first = one_number(G, k, i, slot, r, amp);
-  second = one_number(G, k + 1, i, slot + 1, r, amp);
+  first = one_number(G, call, k, i, slot, r, amp);
+  second = one_number(G, call, k + 1, i, slot + 1, r, amp);
 }
 
 __device__ __forceinline__ void turn(const xrt_hip_rotation& R, double& x, double& y,
@@ -165,15 +172,16 @@ __global__ __launch_bounds__(256) void geosource_shine_kernel(xrt_hip_geosource 
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= out.n) return;
   const bool amp = out.Es_ri != nullptr;
+  const uint32_t call = call_of(G);
   Ray r{G.Jss, G.Jpp, G.Jsp[0], G.Jsp[1], G.Es[0], G.Es[1], G.Ep[0], G.Ep[1]};
   if (amp && G.random_ep) {     // make_polarization: Ep = uniform * 2**-0.5, geoms.py:136-137
-    r.Epr = philox_uniforms((uint64_t)i, SLOT_PHASE, G.call, G.seed).a * 0.70710678118654757;
+    r.Epr = philox_uniforms((uint64_t)i, SLOT_PHASE, call, G.seed).a * 0.70710678118654757;
     r.Epi = 0.;
   }
   double x, y, z, a, c;
-  y = one_number(G, 0, (uint64_t)i, SLOT_Y, r, amp);
-  one_pair(G, 1, G.annulus_xz != 0, G.ann_xz, (uint64_t)i, SLOT_XZ, r, amp, x, z);
-  one_pair(G, 3, G.annulus_ac != 0, G.ann_ac, (uint64_t)i, SLOT_AC, r, amp, a, c);
+  y = one_number(G, call, 0, (uint64_t)i, SLOT_Y, r, amp);
+  one_pair(G, call, 1, G.annulus_xz != 0, G.ann_xz, (uint64_t)i, SLOT_XZ, r, amp, x, z);
+  one_pair(G, call, 3, G.annulus_ac != 0, G.ann_ac, (uint64_t)i, SLOT_AC, r, amp, a, c);
   const double ac = a * a + c * c;
   double b;
   if (G.slopes) {               // geoms.py:499-503
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) void geosource_shine_kernel(xrt_hip_geosource 
   }
   double E = G.e_p0;
   if (G.e_law) {
-    const U2 u = philox_uniforms(G.filament ? 0ull : (uint64_t)i, SLOT_E, G.call, G.seed);
+    const U2 u = philox_uniforms(G.filament ? 0ull : (uint64_t)i, SLOT_E, call, G.seed);
     if (G.e_law == 1) {
       double g1, g2;
       box_muller(u, g1, g2);
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(256) void geosource_probe_kernel(xrt_hip_geosource 
   if (i >= n) return;
   Ray r{};
   double a, c;
-  one_pair(G, 3, G.annulus_ac != 0, G.ann_ac, (uint64_t)i, SLOT_AC, r, false, a, c);
+  one_pair(G, call_of(G), 3, G.annulus_ac != 0, G.ann_ac, (uint64_t)i, SLOT_AC, r, false, a,
+           c);
   if (a * a + c * c > 1.) atomicOr(flag, 1);
 }
 

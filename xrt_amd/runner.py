@@ -17,7 +17,7 @@ import threading
 import numpy as np
 import torch
 
-from . import _lib, _structs
+from . import _lib, _structs, graphs, hipcalls
 from .backends.raycing import run as rr
 
 
@@ -39,6 +39,7 @@ def accumulate_plot(plot, beams):
     y = _axis_tensor(beam, plot.yaxis.field(), dev).contiguous()
     for axis, t in ((plot.xaxis, x), (plot.yaxis, y)):
         if axis.limits is None:      # auto limits from the first batch
+            graphs.refuse('automatic plot limits (read back from the first beam)')
             sel = beam.dev('state', dev) == 1
             v = t[sel] * axis.factor if bool(sel.any()) else t * axis.factor
             lo, hi = float(v.min()), float(v.max())
@@ -48,6 +49,7 @@ def accumulate_plot(plot, beams):
     cax = plot.caxis
     cdat = _axis_tensor(beam, cax.field(), dev).contiguous()
     if cax.limits is None:
+        graphs.refuse('automatic plot limits (read back from the first beam)')
         sel = beam.dev('state', dev) == 1
         v = cdat[sel] * cax.factor if bool(sel.any()) else cdat * cax.factor
         lo, hi = float(v.min()), float(v.max())
@@ -79,13 +81,24 @@ def accumulate_plot(plot, beams):
     P.bins_x, P.bins_y, P.bins_c = plot.xaxis.bins, plot.yaxis.bins, cax.bins
     P.ray_flags, P.flux_kind = plot.ray_flag_mask, plot.flux_kind_code
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
-    _lib.check(lib.xrt_hip_plot_hist_f64_dev(
+    # scratch from torch's allocator, one per (thread, stream): nothing is allocated per call
+    # (and a call recorded into a HIP graph keeps pointing at memory the graph owns)
+    need = ctypes.c_size_t(0)
+    _lib.check(lib.xrt_hip_plot_hist_workspace_bytes(beam.nrays, ctypes.byref(P), 1, 1,
+                                                     ctypes.byref(need)),
+               'xrt_hip_plot_hist_workspace_bytes')
+    ws = hipcalls.workspace(dev, need.value, 'hist')
+    _lib.check(lib.xrt_hip_plot_hist_ws_f64_dev(
         ctypes.byref(s), ptr(x), ptr(y), ptr(cdat), ctypes.byref(P), ptr(hist),
         ptr(hist_rgb), ptr(hx), ptr(hy), ptr(hc) if plot.ePos else None, ptr(counters),
-        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-        'xrt_hip_plot_hist_f64_dev')
-    plot.nRaysAll += beam.nrays
-    plot.iteration += 1
+        ptr(ws), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+        'xrt_hip_plot_hist_ws_f64_dev')
+    nrays = beam.nrays
+
+    def count():
+        plot.nRaysAll += nrays
+        plot.iteration += 1
+    graphs.per_iteration(count)
 
 
 def _parallel_iterations(plots, beamLine, count):
@@ -122,10 +135,19 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
                     energyRange=None, backend='raycing', beamLine=None, threads=1,
                     processes=1, generator=None, generatorArgs=[],
                     generatorKWargs='auto', globalNorm=0, afterScript=None,
-                    afterScriptArgs=[], afterScriptKWargs={}):
+                    afterScriptArgs=[], afterScriptKWargs={}, graph=False):
     """Runs ``raycing.run.run_process(beamLine)`` *repeats* times per generator
     step and sums the histograms of *plots* (rays are never accumulated, only
-    their histograms — runner.py:520-526)."""
+    their histograms — runner.py:520-526).
+
+    *graph* (not in the reference): after the iterations that fix the automatic plot limits
+    and one more eager one, an iteration -- ``run_process`` and the histograms of all plots --
+    is recorded into a HIP graph and the remaining ones are replays of it: one launch per
+    iteration instead of ~200 us of Python per element chain, which is what bounds beams of
+    up to ~1e6 rays (xrt_amd/graphs.py). Needs a ``run_process`` whose host side does the
+    same thing every time: device ray generator (``GeometricSource(rng='device')``), no
+    host random numbers, no host access to the rays; anything else raises
+    ``graphs.CaptureError`` while recording. One worker."""
     if backend != 'raycing':
         raise NotImplementedError("only the 'raycing' backend is accelerated")
     if not isinstance(plots, (list, tuple)):
@@ -133,15 +155,30 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
 
     workers = max(int(threads), int(processes), 1)
 
+    def iteration():
+        beams = rr.run_process(beamLine)
+        for plot in plots:
+            accumulate_plot(plot, beams)
+
     def one_scan():
         left = int(repeats)
+        recorded, eager_done = None, 0
         while left > 0:
+            if graph and workers == 1 and not any(
+                    a.limits is None for p in plots for a in (p.xaxis, p.yaxis, p.caxis)):
+                # the first iteration with all limits known runs eagerly (workspaces, tables,
+                # compiled units: what only the first call does), the next one is recorded
+                if eager_done and recorded is None and left > 1:
+                    recorded = graphs.IterationGraph(iteration)
+                if recorded is not None:
+                    recorded.replay()
+                    left -= 1
+                    continue
+                eager_done += 1
             auto = any(a.limits is None for p in plots for a in (p.xaxis, p.yaxis, p.caxis))
             batch = 1 if (auto or workers == 1) else min(workers, left)
             if batch == 1:
-                beams = rr.run_process(beamLine)
-                for plot in plots:
-                    accumulate_plot(plot, beams)
+                iteration()
             else:
                 _parallel_iterations(plots, beamLine, batch)
             left -= batch
