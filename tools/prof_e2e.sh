@@ -9,7 +9,7 @@ r = bench.bench_e2e(int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 r.pop('host_source', None)
 print(json.dumps(r))
 PY
-rocprofv3 --kernel-trace --stats -d /tmp/e2e -o e2e -- env PYTHONPATH=. XRT_E2E_NO_HOST=1 python /tmp/e2e_run.py ${1:-1e7} 2> /tmp/e2e.err | tail -1
+rocprofv3 --kernel-trace --stats -d /tmp/e2e -o e2e -- env PYTHONPATH=. XRT_E2E_NO_HOST=1 XRT_E2E_NO_SMALL=1 python /tmp/e2e_run.py ${1:-1e7} 2> /tmp/e2e.err | tail -1
 python - <<PY
 import sqlite3, glob
 db = glob.glob("/tmp/e2e/**/*.db", recursive=True)[0]

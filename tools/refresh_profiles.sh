@@ -28,6 +28,11 @@ bash tools/pmc_kirchhoff.sh cfg4 > profiles/r${RND}_kirchhoff_pmc.txt 2>&1
 bash tools/pmc_kirchhoff.sh general > profiles/r${RND}_kirchhoff_general_pmc.txt 2>&1
 bash tools/pmc_hist.sh > profiles/r${RND}_hist_pmc.txt 2>&1
 bash tools/prof_e2e.sh 1e7 > profiles/r${RND}_e2e_kernels.txt 2>&1
+# small beams: the kernels of the same iteration at 2e3 / 1e5 / 1e6 rays (the fixed cost of every
+# launch), and the host time of every element call
+for n in 2e3 1e5 1e6; do echo "== $n rays"; bash tools/prof_e2e.sh $n 2>&1 | grep -v '^{'; done \
+  > profiles/r${RND}_e2e_small_kernels.txt
+PYTHONPATH=. python tools/probe_host_overhead.py 2>&1 | grep 'us per call' > profiles/r${RND}_host_overhead.txt
 hipcc --offload-arch=gfx950 -O3 tools/probes/probe_fp64_rates.hip -o /tmp/probe_fp64_rates 2>/dev/null && \
   timeout 300 /tmp/probe_fp64_rates > profiles/r${RND}_probe_fp64_rates.txt 2>&1
 for P in probe_stream probe_occupancy probe_atomics probe_fp64_seeds probe_lds_atomics; do
