@@ -62,19 +62,20 @@ def same_plots(one, two):
         assert np.allclose(a.total1D_x, b.total1D_x, rtol=1e-12, atol=0)
 
 
-def test_replayed_iterations_equal_the_eager_run():
+@pytest.mark.parametrize('repeats, python_calls', [(9, 2), (40, 2)])
+def test_replayed_iterations_equal_the_eager_run(repeats, python_calls):
     bl1, run1, calls1 = beamline()
     rr.run_process = run1
-    eager = xrtr.run_ray_tracing(plots(), repeats=9, beamLine=bl1)
-    assert len(calls1) == 9
+    eager = xrtr.run_ray_tracing(plots(), repeats=repeats, beamLine=bl1)
+    assert len(calls1) == repeats
     bl2, run2, calls2 = beamline()
     rr.run_process = run2
-    replayed = xrtr.run_ray_tracing(plots(), repeats=9, beamLine=bl2, graph=True)
-    # the first iteration fixes the automatic limits, the second is the eager one with all
-    # limits known, the third call of run_process is the recording; six replays follow it
-    assert len(calls2) == 3
+    replayed = xrtr.run_ray_tracing(plots(), repeats=repeats, beamLine=bl2, graph=True)
+    # the first iteration fixes the automatic limits, the second call of run_process is the
+    # recording; the replays run no Python of the beamline
+    assert len(calls2) == python_calls
     same_plots(eager, replayed)
-    assert bl1.src._calls == bl2.src._calls == 9
+    assert bl1.src._calls == bl2.src._calls == repeats
     # ... and the generator goes on where the replays left it
     a, b = bl1.src.shine(), bl2.src.shine()
     for f in ('x', 'z', 'a', 'c', 'E'):
@@ -110,3 +111,19 @@ def test_short_runs_never_record():
     rr.run_process = run
     out = xrtr.run_ray_tracing(plots(), repeats=2, beamLine=bl, graph=True)
     assert len(calls) == 2 and out[0].iteration == 2
+
+
+def test_two_shines_of_one_source_in_an_iteration():
+    """Every recorded shine() increments the device cell: replay r draws calls 2r and 2r + 1."""
+    bl1, _, _ = beamline(n=4000)
+    bl2, _, _ = beamline(n=4000)
+
+    def run_process(beamLine):
+        first, second = beamLine.src.shine(), beamLine.src.shine()
+        return {'mirror': beamLine.m1.reflect(first)[1], 'screen': beamLine.scr.expose(second),
+                'dcm2': beamLine.dcm.double_reflect(second)[2]}
+    rr.run_process = run_process
+    eager = xrtr.run_ray_tracing(plots(), repeats=6, beamLine=bl1)
+    replayed = xrtr.run_ray_tracing(plots(), repeats=6, beamLine=bl2, graph=True)
+    same_plots(eager, replayed)
+    assert bl1.src._calls == bl2.src._calls == 12

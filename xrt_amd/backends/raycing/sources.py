@@ -26,6 +26,7 @@ _OPT_C128 = ('EsAcc', 'EpAcc', 'aEacc', 'bEacc', 'cEacc')
 _SCALAR_ATTRS = ('sourceSIGMAx', 'sourceSIGMAz', 'filamentDX', 'filamentDZ',
                  'filamentDtheta', 'filamentDpsi', 'filamentDgamma', 'accepted',
                  'acceptedE', 'seeded', 'seededI', 'sourceWeight')
+_ALWAYS = frozenset(_F64 + ('Jsp', 'state'))        # what every beam holds
 _ARRAY_FIELDS = set(_F64) | set(_C128) | set(_OPT_F64) | set(_OPT_C128) | {'state'}
 _TORCH_DTYPE = {np.dtype('float64'): torch.float64,
                 np.dtype('complex128'): torch.complex128,
@@ -401,10 +402,10 @@ class Beam(object):
 
     def _h_dirty(self):
         """True if some array field has no device copy (host access drops it)."""
-        need = ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp', 'state')
-        if any(n not in self._d for n in need):
+        held = self._d.keys()
+        if not _ALWAYS <= held:
             return True
-        return self.has_amplitudes() and ('Es' not in self._d or 'Ep' not in self._d)
+        return self.has_amplitudes() and not ('Es' in held and 'Ep' in held)
 
 
 def inherit_scalars(new, old):
@@ -765,10 +766,12 @@ class GeometricSource(object):
                 # recorded into a HIP graph: replay k must draw what the k-th eager call would
                 # have -- the kernel adds a device cell, incremented by the graph itself, to
                 # the call number of the record (this call's number less the cell's value now)
+                # (the cell is incremented after EVERY recorded shine of this source, so one
+                # record value serves all of them: the j-th shine of replay r finds the cell at
+                # value + r * shines + j and must draw call _calls + r * shines + j)
                 cell, value = self._replay_cell(dev)
-                ahead = rec.pending_calls.get(self, 0)
-                rec.pending_calls[self] = ahead + 1
-                call = (self._calls + ahead - value) & 0xffffffff
+                rec.pending_calls[self] = rec.pending_calls.get(self, 0) + 1
+                call = (self._calls - value) & 0xffffffff
         g, reach2 = self.device_spec(toGlobal, call)
         if rec is not None:
             g.call_dev = cell.data_ptr()
@@ -787,16 +790,14 @@ class GeometricSource(object):
         _lib.check(lib.xrt_hip_geosource_shine_f64_dev(
             ctypes.byref(g), ctypes.byref(bo.to_struct(dev)), stream),
             'xrt_hip_geosource_shine_f64_dev')
-        if rec is not None and rec.pending_calls[self] == 1:
-            cell.add_(1)                 # (recorded: once per replay, after the generator ran)
-
-            def count():
-                with self._call_lock:
-                    self._calls += rec.pending_calls[self]
-                    self._replay_cells[str(dev)][1] += 1
-            rec.after_replay.append(count)
-        elif rec is not None:
-            graphs.refuse('a second shine() of one source in an iteration')
+        if rec is not None:
+            cell.add_(1)                 # (recorded: after the generator ran)
+            if rec.pending_calls[self] == 1:
+                def count():
+                    with self._call_lock:
+                        self._calls += rec.pending_calls[self]
+                        self._replay_cells[str(dev)][1] += rec.pending_calls[self]
+                rec.after_replay.append(count)
         if np.isscalar(self.totalFlux) and self.totalFlux > 0:      # make_flux_normalization
             if self.uniformRayDensity:
                 graphs.refuse('totalFlux of a source with uniformRayDensity (a sum read back)')

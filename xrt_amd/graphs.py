@@ -18,6 +18,7 @@ replay k draws the rays the k-th eager call would have drawn.
 Host-side counters of an iteration (rays seen by a plot, calls of a source) are not advanced
 while recording; they are handed to :func:`per_iteration` and run after every replay.
 """
+import gc
 import threading
 
 import torch
@@ -63,6 +64,11 @@ class IterationGraph(object):
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         _tls.recording = self
+        # no automatic garbage collection while recording: a collected tensor is harmless, a
+        # collected graph of an earlier run is not (hipGraphDestroy on a capturing stream is an
+        # error, thrown from a destructor: the process ends)
+        collects = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.result = fn()
@@ -73,7 +79,17 @@ class IterationGraph(object):
                                'run it with graph=False' % (type(e).__name__, e)) from e
         finally:
             _tls.recording = None
+            if collects:
+                gc.enable()
         self.replays = 0
+
+    def close(self):
+        """Drops the graph, the recorded beams and the hooks (which refer back to this object:
+        without this the graph lives until some later garbage collection)."""
+        self.after_replay = []
+        self.pending_calls = {}
+        self.result = None
+        self.graph = None
 
     def replay(self):
         self.graph.replay()
