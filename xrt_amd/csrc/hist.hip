@@ -236,6 +236,9 @@ struct HistPlan {
   int slices;        // chunk slices of plot_hist_tiles
   int nchan;         // 1 (flux) or 4 (flux, R, G, B)
   int lines;         // the 1-D histograms and counters are wanted
+  int derive;        // the x and y histograms of the rays INSIDE the 2-D range are the column and
+                     // row sums of the planes (same linspace edges, same find_bin): the reduce
+                     // adds those; plot_hist_rays keeps the 1-D updates of the other rays only
 };
 
 // the sorted chunks: ray records in tile order and, per chunk, where each tile's run starts
@@ -442,13 +445,15 @@ __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256) void plot_h
             cn[0] += 1;
             cw += w;
             if (inside) cw_in += w;
-            if (ix >= 0) {
+            // (8 of the 16 ds_add_f64 per ray, 40-50 us per 1e7 rays, for sums the planes hold)
+            const bool own_xy = !(H.derive && inside);
+            if (own_xy && ix >= 0) {
               atomicAdd(&lx[ix], w);
               atomicAdd(&lx[nx + ix], r);
               atomicAdd(&lx[2 * nx + ix], g);
               atomicAdd(&lx[3 * nx + ix], b);
             }
-            if (iy >= 0) {
+            if (own_xy && iy >= 0) {
               atomicAdd(&ly[iy], w);
               atomicAdd(&ly[ny + iy], r);
               atomicAdd(&ly[2 * ny + iy], g);
@@ -661,35 +666,62 @@ __global__ __launch_bounds__(256) void plot_hist_reduce(
   const bool tiled = tile_share != nullptr;     // copies of plot_hist_tiles: [block][chan][ty][tx]
   if (tiled) load_tile_shares(tile_share, H.ntx * H.nty, share);
   if ((int)blockIdx.x < nb2) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nchan * plane) return;
-    const int ch = j / plane, b = j - ch * plane;
-    int c0 = 0, cn = ncopies;
-    int64_t pitch = (int64_t)nchan * plane;
-    const double* src = planes + j;
-    if (tiled) {
-      const int by = b / bins_x, bx = b - by * bins_x;
-      const int tjx = bx / H.tx, tjy = by / H.ty;
-      const int t = tjy * H.ntx + tjx, tcells = H.tx * H.ty;
-      c0 = share[t];
-      cn = share[t + 1];
-      pitch = (int64_t)nchan * tcells;
-      src = planes + (int64_t)ch * tcells + (by - tjy * H.ty) * H.tx + (bx - tjx * H.tx);
+    // block = (channel, 8 rows, 32 columns) of the plot: 256-B row segments of every copy, and
+    // with H.derive the patch's column and row sums for the 1-D histograms of x and y
+    __shared__ double scol[32], srow[8];
+    const int nbx = (bins_x + 31) / 32, nby = (bins_y + 7) / 8;
+    int q = (int)blockIdx.x;
+    const int ibx = q % nbx;
+    q /= nbx;
+    const int iby = q % nby, ch = q / nby;
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int bx = ibx * 32 + cx, by = iby * 8 + ry;
+    if (H.derive) {
+      if (threadIdx.x < 32) scol[threadIdx.x] = 0.;
+      if (threadIdx.x < 8) srow[threadIdx.x] = 0.;
+      __syncthreads();
     }
-    // (plane_parts groups of copies per cell; ONE group for the larger plots: every cell then
-    // has one thread and adds without an atomic -- at 2.4e10 global atomics per second the 16
-    // groups of a 256 x 256 plot cost 44 us)
-    if ((int)blockIdx.y >= plane_parts) return;
-    const int per = (cn - c0 + plane_parts - 1) / plane_parts;
-    const int s0 = c0 + blockIdx.y * per, s1 = min(cn, s0 + per);
-    if (s0 >= s1) return;
-    const double v = sum_copies(src, pitch, s0, s1);
-    if (v == 0.) return;
-    double* dst = ch == 0 ? &h2[b] : &h2rgb[3 * (int64_t)b + ch - 1];
-    if (plane_parts == 1)
-      *dst += v;
-    else
-      atomicAdd(dst, v);
+    double v = 0.;
+    if (bx < bins_x && by < bins_y && ch < nchan && (int)blockIdx.y < plane_parts) {
+      const int b = by * bins_x + bx;
+      int c0 = 0, cn = ncopies;
+      int64_t pitch = (int64_t)nchan * plane;
+      const double* src = planes + (int64_t)ch * plane + b;
+      if (tiled) {
+        const int tjx = bx / H.tx, tjy = by / H.ty;
+        const int t = tjy * H.ntx + tjx, tcells = H.tx * H.ty;
+        c0 = share[t];
+        cn = share[t + 1];
+        pitch = (int64_t)nchan * tcells;
+        src = planes + (int64_t)ch * tcells + (by - tjy * H.ty) * H.tx + (bx - tjx * H.tx);
+      }
+      // (plane_parts groups of copies per cell; ONE group for the larger plots: every cell then
+      // has one thread and adds without an atomic -- at 2.4e10 global atomics per second the 16
+      // groups of a 256 x 256 plot cost 44 us)
+      const int per = (cn - c0 + plane_parts - 1) / plane_parts;
+      const int s0 = c0 + blockIdx.y * per, s1 = min(cn, s0 + per);
+      if (s0 < s1) v = sum_copies(src, pitch, s0, s1);
+      if (v != 0.) {
+        double* dst = ch == 0 ? &h2[b] : &h2rgb[3 * (int64_t)b + ch - 1];
+        if (plane_parts == 1)
+          *dst += v;
+        else
+          atomicAdd(dst, v);
+      }
+    }
+    if (H.derive) {
+      if (v != 0.) {
+        atomicAdd(&scol[cx], v);
+        atomicAdd(&srow[ry], v);
+      }
+      __syncthreads();
+      if (threadIdx.x < 32) {
+        if (hx && bx < bins_x && scol[cx] != 0.) atomicAdd(&hx[4 * bx + ch], scol[cx]);
+      } else if (threadIdx.x < 40) {
+        const int r = threadIdx.x - 32, yy = iby * 8 + r;
+        if (hy && yy < bins_y && srow[r] != 0.) atomicAdd(&hy[4 * yy + ch], srow[r]);
+      }
+    }
     return;
   }
   const int nl = 4 * (nx + ny + nc);
@@ -774,6 +806,7 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
   const bool fits = beam.n < HIST_MAX_RAYS;
   const bool lines = fits && want_lines && b1 <= 64 * 1024;
   H.lines = lines;
+  H.derive = 0;
   int mode = HIST_LINES_ONLY;
   if (h2 && fits) {
     if (H.nchan * plane + (lines ? b1 : 0) <= HIST_LDS_BUDGET - 2048)
@@ -782,6 +815,8 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
                         cus < HIST_MAX_TILES ? cus : HIST_MAX_TILES, H))
       mode = HIST_RECORDS;
   }
+  // (the 1-D weights are flux, R, G, B: derivable when all four planes are made)
+  H.derive = lines && mode != HIST_LINES_ONLY && H.nchan == 4;
   int general = (h2 && mode == HIST_LINES_ONLY ? 1 : 0) | (want_lines && !lines ? 2 : 0);
   if (mode != HIST_LINES_ONLY || lines) {
     const int64_t chunks = (beam.n + HIST_CHUNK - 1) / HIST_CHUNK;
@@ -874,7 +909,8 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
       }
       {
         const int total = mode != HIST_LINES_ONLY ? H.nchan * P.bins_x * P.bins_y : 0;
-        const int nb2 = (total + 255) / 256;
+        const int nb2 =
+            total ? H.nchan * ((P.bins_x + 31) / 32) * ((P.bins_y + 7) / 8) : 0;   // 8 x 32 patches
         const int nbl = lines && (hx || hy || hc) ? (int)((nl + 255) / 256) : 0;
         if (nb2 + nbl > 0)
           hipLaunchKernelGGL(plot_hist_reduce, dim3((unsigned)(nb2 + nbl), HIST_REDUCE_PARTS),
