@@ -6,6 +6,7 @@ generator plus rays that miss, fall off the edges and graze the surface. While g
 oracle/reflect_np.py (surface kind 'user' = the same two callables) is asserted against the
 reference's beams.
 
+  g3_user_crystal  the same figured surface with Si(111) at its Bragg angle (9 keV)
   g2_user_grating  a plane grating whose groove vector is a function of (x, y) given by the
                    subclass's local_g (a fan of lines with a quadratic density law), order -1
 
@@ -64,6 +65,21 @@ def main():
     par['order'] = -1
     g1.run_reflect('g2_user_grating', rs, gr, par, beam,
                    groove_parameters=np.array([case.G_RHO0, case.G_B1, case.G_B2, case.G_BX]))
+    # the figured surface as a Si(111) crystal at the Bragg angle for 9 keV
+    raycing._VERBOSITY_ = 0
+    bl = raycing.BeamLine()
+    si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    thB = float(np.ravel(si.get_Bragg_angle(9000.) - si.get_dtheta(9000.))[0])
+    xt = case.crystal_element(roe, bl, si, thB)
+    beam = g1.make_rays(rs, 2048, 67, sx=0.3, sz=0.05, sa=2e-5, sc=8e-6, E=(8999., 9001.),
+                        amplitudes=True, pol='mixed')
+    beam.x[0] = 9.
+    beam.state[1] = 3
+    beam.state[2] = -2
+    par = g1.oe_params(xt, dict(kind='user', z=case.numpy_local_z, n=case.numpy_local_n))
+    par['material'] = g1.crystal_dict(load_tables(), si)
+    g1.run_reflect('g3_user_crystal', rs, xt, par, beam, bragg=np.array(thB),
+                   surface_parameters=np.array([case.RS, case.RM, case.K3, case.KT]))
 
 
 if __name__ == '__main__':

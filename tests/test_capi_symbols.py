@@ -53,28 +53,32 @@ def test_argument_validation_without_gpu():
 def test_crystal_surface_combinations_the_c_abi_takes():
     """Round 4: Bragg crystals on conics, lens paraboloids, cones, VFM and DualVFM go through the
     generic exact sequence of the surface's family (tests/test_gpu_reflect.py has the goldens);
-    a blazed profile has no Bragg planes, and user-defined surfaces carry one normal only: both
-    are refused by the C ABI before any GPU work, with a reason."""
+    a blazed profile has no Bragg planes and is refused by the C ABI before any GPU work, with a
+    reason; a user-defined surface takes crystals (its one normal serves the atomic planes too,
+    golden g3_user_crystal) but no multilayers: its unit is compiled without the layered
+    kernels."""
     import ctypes
     from xrt_amd import _lib, _structs
     lib = _lib.load(build_if_missing=False)
     lib.xrt_hip_last_error.restype = ctypes.c_char_p
 
-    def call(kind, unit=None):
+    def call(kind, unit=None, mat=4):     # 4: XRT_HIP_MAT_CRYSTAL
         p, m = _structs.Pass(), _structs.Material()
         p.surf_kind = kind
         p.invert_normal = 1
         if unit:
             p.user_unit = unit
-        m.kind = 4          # XRT_HIP_MAT_CRYSTAL
+        m.kind = mat
         rc = lib.xrt_hip_reflect_pass_f64_dev(ctypes.byref(p), ctypes.byref(m), None, None, None,
                                               None, None, None, ctypes.c_size_t(0), None, None,
                                               None)
         return rc, lib.xrt_hip_last_error()
     rc, why = call(3)
     assert rc != 0 and b'crystals on blazed gratings' in why
+    rc, why = call(12, unit=1, mat=_structs.MAT_MULTILAYER)
+    assert rc != 0 and b'multilayers on user-defined surfaces' in why
     rc, why = call(12, unit=1)
-    assert rc != 0 and b'user-defined surfaces' in why
+    assert rc != 0 and b'surface' not in why and b'crystals' not in why, why
     rc, why = call(12)
     assert rc != 0 and b'without its compiled unit' in why
     for kind in (4, 5, 6, 9, 10):       # accepted: the call fails later, on the empty records

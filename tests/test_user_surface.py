@@ -138,7 +138,7 @@ def test_host_methods_evaluate_the_units_code():
 @pytest.mark.gpu
 def test_user_surface_at_full_size_and_refusals():
     """1e6 rays: every hit point lies on the user's surface, the optimistic single pass is
-    taken; crystals on user surfaces are refused with a reason."""
+    taken; multilayers on user surfaces are refused with a reason."""
     from xrt_amd import workloads
     oe = element()
     beam = workloads.synthetic_rays(1_000_000, 3)
@@ -147,9 +147,38 @@ def test_user_surface_at_full_size_and_refusals():
     assert good.mean() > 0.95
     dz = lb.z[good] - case.numpy_local_z(lb.x[good], lb.y[good])
     assert np.abs(dz).max() < 2e-12
-    xtal = element(rm.CrystalSi(hkl=(1, 1, 1)))
+    layered = element(rm.Multilayer(rm.Material('W', rho=19.3), 12., rm.Material('Si', rho=2.33),
+                                    18., 40, rm.Material('Si', rho=2.33)))
     with pytest.raises(_lib.XrtHipError, match='user-defined surfaces'):
-        xtal.reflect(workloads.synthetic_rays(1000, 3))
+        layered.reflect(workloads.synthetic_rays(1000, 3))
+
+
+@pytest.mark.gpu
+def test_crystal_on_a_user_surface_matches_the_reference(golden_dir):
+    """Si(111) on the figured surface at the Bragg angle for 9 keV: the reference traced the same
+    subclass (numpy methods, a three-component local_n serving as the normal of the surface and
+    of the atomic planes; golden g3_user_crystal). Here the unit's generic exact sequence runs
+    it, as for crystals on conics."""
+    g = np.load(os.path.join(golden_dir, 'g3_user_crystal.npz'))
+    si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    thB = float(g['bragg'])
+    assert thB == float(np.ravel(si.get_Bragg_angle(9000.) - si.get_dtheta(9000.))[0])
+    xt = case.crystal_element(roe, raycing.BeamLine(), si, thB)
+    beam = rs.Beam(nrays=len(g['in_x']), withAmplitudes=True)
+    for f in GEOM + ('E', 'Jss', 'Jpp', 'Jsp', 'state', 'Es', 'Ep'):
+        setattr(beam, f, g['in_' + f])
+    gb, lb = xt.reflect(beam)
+    for name, out in (('gb', gb), ('lb', lb)):
+        assert np.array_equal(out.state, g[name + '_state']), name
+        for f in GEOM:
+            _close(getattr(out, f), g['%s_%s' % (name, f)], 1e-12, (name, f))
+        for f in ('Jss', 'Jpp', 'Jsp', 'Es', 'Ep'):
+            _close(getattr(out, f), g['%s_%s' % (name, f)], 1e-9, (name, f))
+    _close(lb.theta, g['lb_theta'], 1e-12, 'theta')
+    # a Bragg curve, not a mirror's reflectivity: most of the flux survives at the angle
+    hit = g['lb_state'] == 1
+    assert hit.sum() > 2000
+    assert (lb.Jss + lb.Jpp)[hit].mean() > 0.3 * (g['in_Jss'] + g['in_Jpp'])[hit].mean()
 
 
 @pytest.mark.gpu

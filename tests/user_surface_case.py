@@ -82,3 +82,14 @@ def grating_subclass(roe):
         def local_g(self, x, y, rho=None):
             return numpy_local_g(x, y)
     return FanGrating
+
+
+# ---- the same figured surface as a Bragg CRYSTAL (Si 111 at its Bragg angle for 9 keV): the
+# atomic planes follow the surface, local_n's one normal serves as both (oes/reflect.py takes
+# the last three components of whatever local_n returns)
+X_CENTER, X_LIMITS = [0, 30000., 0], dict(limPhysX=[-4, 4], limPhysY=[-40, 40])
+
+
+def crystal_element(roe, bl, si, pitch):
+    return subclass(roe)(bl, 'figured crystal', center=X_CENTER, pitch=pitch, material=si,
+                         **X_LIMITS)

@@ -282,10 +282,11 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
     if (!pass->user_unit)
       return fail(XRT_HIP_ERR_ARG, "user-defined surface without its compiled unit "
                                    "(xrt_hip_user_surface_load)");
-    if (material->kind == XRT_HIP_MAT_CRYSTAL || material->kind == XRT_HIP_MAT_MULTILAYER)
-      return fail(XRT_HIP_ERR_ARG, "crystals and multilayers on user-defined surfaces are not "
-                                   "supported (their kernels need the normal of the atomic "
-                                   "planes as well)");
+    // (a crystal's atomic planes follow the user's surface: local_n gives one normal, which
+    // serves as both -- the reference does the same with a three-component local_n)
+    if (material->kind == XRT_HIP_MAT_MULTILAYER)
+      return fail(XRT_HIP_ERR_ARG, "multilayers on user-defined surfaces are not supported "
+                                   "(a unit is compiled without the layered kernels)");
     if (pass->asymmetric || (pass->grating && (pass->grating != 1 || pass->g_ray_x)))
       return fail(XRT_HIP_ERR_ARG, "user-defined surfaces take plain gratings only (no zone "
                                    "plates, no asymmetric cut)");

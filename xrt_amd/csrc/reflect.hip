@@ -576,7 +576,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       need_mean && M.kind == XRT_HIP_MAT_CRYSTAL &&
       (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM || P.surf_kind == XRT_HIP_SURF_PARABOLOID ||
        P.surf_kind == XRT_HIP_SURF_CONE || P.surf_kind == XRT_HIP_SURF_VFM ||
-       P.surf_kind == XRT_HIP_SURF_DUALVFM);
+       P.surf_kind == XRT_HIP_SURF_DUALVFM || P.surf_kind == XRT_HIP_SURF_USER);
   const bool optimistic = searches && !force_exact && !aliased && !xtal_elsewhere;
   const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
   const bool layers = M.kind == XRT_HIP_MAT_MULTILAYER;
@@ -630,7 +630,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   bool launched = true;
   const UserUnit* unit = P.surf_kind == XRT_HIP_SURF_USER
                              ? static_cast<const UserUnit*>(P.user_unit) : nullptr;
-  if (P.surf_kind == XRT_HIP_SURF_USER && (!unit || need_mean || layers))
+  if (P.surf_kind == XRT_HIP_SURF_USER && (!unit || layers || (need_mean && (!xtal_elsewhere || nis))))
     return hipErrorInvalidValue;        // (capi.hip says why before it gets here)
   // the solve + finish kernel: mode 0 (optimistic) or 2 (no statistics needed)
   auto launch_fused = [&](int mode) {
