@@ -313,8 +313,10 @@ typedef struct xrt_hip_pass {
  * (xrt_amd/usersurf.py writes and compiles it: `hipcc --offload-arch=gfx950 -shared`). It is
  * opened with dlopen, checked against this library's build (xrt_hip_user_unit_abi) and kept
  * until xrt_hip_user_surface_unload. The handle is an opaque pointer; it is only valid in the
- * process that loaded it. Crystals and multilayers on user surfaces are refused (their
- * kernels need the second normal of the atomic planes). */
+ * process that loaded it. A unit comes in two flavours: the general one (material kind read at
+ * run time: mirrors, plates, gratings, Bragg crystals -- local_n's normal serves the atomic
+ * planes as well) and the layered one, compiled around Parratt's recursion for
+ * XRT_HIP_MAT_MULTILAYER; a pass whose material does not fit the unit's flavour is refused. */
 XRT_HIP_API int xrt_hip_user_unit_abi(void);
 XRT_HIP_API int xrt_hip_user_surface_load(const char* path, void** handle);
 XRT_HIP_API int xrt_hip_user_surface_unload(void* handle);

@@ -7,6 +7,8 @@ oracle/reflect_np.py (surface kind 'user' = the same two callables) is asserted 
 reference's beams.
 
   g3_user_crystal  the same figured surface with Si(111) at its Bragg angle (9 keV)
+  g2_user_multilayer / g2_user_coated  the figured surface under a W/Si multilayer at its
+                   Bragg angle and under a Rh coating (layered flavour of the unit)
   g2_user_grating  a plane grating whose groove vector is a function of (x, y) given by the
                    subclass's local_g (a fan of lines with a quadratic density law), order -1
 
@@ -80,6 +82,28 @@ def main():
     par['material'] = g1.crystal_dict(load_tables(), si)
     g1.run_reflect('g3_user_crystal', rs, xt, par, beam, bragg=np.array(thB),
                    surface_parameters=np.array([case.RS, case.RM, case.K3, case.KT]))
+    # the figured surface under layered materials: a periodic W/Si multilayer at its
+    # refraction-corrected Bragg angle for 9 keV (deflects like a crystal of its period) and a
+    # Rh coating on Si at 4 mrad (a mirror); stacks of oracle/gen_fixtures_multilayer.py
+    from . import gen_fixtures_multilayer as gm
+    tables = gm.all_tables()
+    for tag, stack, energy in (('g2_user_multilayer', 'wsi', 9000.),
+                               ('g2_user_coated', 'rh_coated', None)):
+        bl = raycing.BeamLine()
+        ml = gm.ref_stack(rm, stack)
+        pitch = case.PITCH if energy is None else \
+            float(ml.get_Bragg_angle(energy) - ml.get_dtheta(energy))
+        oe = case.subclass(roe)(bl, 'figured', center=[0, case.P, 0], pitch=pitch, material=ml,
+                                **case.LIMITS)
+        beam = g1.make_rays(rs, 2048, 71, sx=0.3, sz=0.1, sa=5e-5, sc=1.5e-4,
+                            E=(8950., 9050.), amplitudes=True, pol='mixed')
+        beam.state[3] = 2
+        beam.state[4] = -3
+        beam.x[5] = 14.
+        par = g1.oe_params(oe, dict(kind='user', z=case.numpy_local_z, n=case.numpy_local_n))
+        par['material'] = gm.oracle_stack(tables, stack)
+        g1.run_reflect(tag, rs, oe, par, beam, stack=np.array(stack), pitch=np.array(pitch),
+                       surface_parameters=np.array([case.RS, case.RM, case.K3, case.KT]))
 
 
 if __name__ == '__main__':

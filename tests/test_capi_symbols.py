@@ -55,8 +55,8 @@ def test_crystal_surface_combinations_the_c_abi_takes():
     generic exact sequence of the surface's family (tests/test_gpu_reflect.py has the goldens);
     a blazed profile has no Bragg planes and is refused by the C ABI before any GPU work, with a
     reason; a user-defined surface takes crystals (its one normal serves the atomic planes too,
-    golden g3_user_crystal) but no multilayers: its unit is compiled without the layered
-    kernels."""
+    golden g3_user_crystal) on its general unit and Multilayer / Coated on the layered flavour
+    of it (goldens g2_user_multilayer, g2_user_coated); the wrong flavour is refused."""
     import ctypes
     from xrt_amd import _lib, _structs
     lib = _lib.load(build_if_missing=False)
@@ -75,10 +75,22 @@ def test_crystal_surface_combinations_the_c_abi_takes():
         return rc, lib.xrt_hip_last_error()
     rc, why = call(3)
     assert rc != 0 and b'crystals on blazed gratings' in why
-    rc, why = call(12, unit=1, mat=_structs.MAT_MULTILAYER)
-    assert rc != 0 and b'multilayers on user-defined surfaces' in why
-    rc, why = call(12, unit=1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import user_surface_case as case
+    from xrt_amd import usersurf
+    general = usersurf.load_unit(usersurf.build_unit(case.HIP_LOCAL_Z, case.HIP_LOCAL_N))
+    layered = usersurf.load_unit(usersurf.build_unit(case.HIP_LOCAL_Z, case.HIP_LOCAL_N,
+                                                     layered=True))
+    assert general != layered
+    rc, why = call(12, unit=general, mat=_structs.MAT_MULTILAYER)
+    assert rc != 0 and b'need the layered flavour' in why and b'this unit: general' in why
+    rc, why = call(12, unit=layered)
+    assert rc != 0 and b'need the layered flavour' in why and b'this unit: layered' in why
+    rc, why = call(12, unit=general)       # a crystal on the general unit: accepted so far
     assert rc != 0 and b'surface' not in why and b'crystals' not in why, why
+    rc, why = call(12, unit=layered, mat=_structs.MAT_MULTILAYER)
+    assert rc != 0 and b'flavour' not in why, why
     rc, why = call(12)
     assert rc != 0 and b'without its compiled unit' in why
     for kind in (4, 5, 6, 9, 10):       # accepted: the call fails later, on the empty records

@@ -138,7 +138,7 @@ def test_host_methods_evaluate_the_units_code():
 @pytest.mark.gpu
 def test_user_surface_at_full_size_and_refusals():
     """1e6 rays: every hit point lies on the user's surface, the optimistic single pass is
-    taken; multilayers on user surfaces are refused with a reason."""
+    taken."""
     from xrt_amd import workloads
     oe = element()
     beam = workloads.synthetic_rays(1_000_000, 3)
@@ -147,10 +147,40 @@ def test_user_surface_at_full_size_and_refusals():
     assert good.mean() > 0.95
     dz = lb.z[good] - case.numpy_local_z(lb.x[good], lb.y[good])
     assert np.abs(dz).max() < 2e-12
-    layered = element(rm.Multilayer(rm.Material('W', rho=19.3), 12., rm.Material('Si', rho=2.33),
-                                    18., 40, rm.Material('Si', rho=2.33)))
-    with pytest.raises(_lib.XrtHipError, match='user-defined surfaces'):
-        layered.reflect(workloads.synthetic_rays(1000, 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['g2_user_multilayer', 'g2_user_coated'])
+def test_layered_materials_on_a_user_surface_match_the_reference(golden_dir, tag):
+    """The figured surface under a periodic W/Si multilayer at its Bragg angle (deflects like a
+    crystal of its period, reflect.py:865-872) and under a Rh coating on Si: the LAYERED
+    flavour of the class's unit (compiled around Parratt's recursion) against the reference
+    tracing the same subclass with numpy methods."""
+    import p1_cases as pc
+    g = np.load(os.path.join(golden_dir, tag + '.npz'))
+    oe = element(pc.product_stack(str(g['stack'])))
+    oe.pitch = float(g['pitch'])
+    from xrt_amd import _structs
+    rec = _structs.Pass()
+    oe._surface_params(rec)
+    assert rec.user_unit != element()._make_pass(oe.pitch, 0, 0).user_unit    # its own unit
+    beam = rs.Beam(nrays=len(g['in_x']), withAmplitudes=True)
+    for f in GEOM + ('E', 'Jss', 'Jpp', 'Jsp', 'state', 'Es', 'Ep'):
+        setattr(beam, f, g['in_' + f])
+    gb, lb = oe.reflect(beam)
+    for name, out in (('gb', gb), ('lb', lb)):
+        assert np.array_equal(out.state, g[name + '_state']), name
+        for f in GEOM:
+            _close(getattr(out, f), g['%s_%s' % (name, f)], 1e-12, (name, f))
+        for f in ('Jss', 'Jpp', 'Jsp', 'Es', 'Ep'):
+            _close(getattr(out, f), g['%s_%s' % (name, f)], 1e-9, (name, f))
+    _close(lb.theta, g['lb_theta'], 1e-12, 'theta')
+    hit = g['lb_state'] == 1
+    assert hit.sum() > 600
+    assert (lb.Jss + lb.Jpp)[hit].mean() > 0.1 * (g['in_Jss'] + g['in_Jpp'])[hit].mean()
+    gb2, lb2 = oe.reflect(beam)                      # the optimistic route: the same bits
+    for f in GEOM + ('Jss', 'Jpp', 'state'):
+        assert np.array_equal(getattr(lb2, f), getattr(lb, f)), f
 
 
 @pytest.mark.gpu

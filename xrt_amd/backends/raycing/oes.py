@@ -148,7 +148,13 @@ class OE(object):
             p.surf_kind = _structs.SURF_USER
             for k, value in enumerate(usersurf.parameters_of(self)):
                 p.surf_p[k] = value
-            p.user_unit = usersurf.unit_for(self)
+            # (Multilayer / Coated: the unit's flavour that holds Parratt's recursion)
+            from . import materials as rmat
+            material = getattr(self, 'material2', None) if second else None
+            material = material if material is not None else getattr(self, 'material', None)
+            if raycing.is_sequence(material):
+                material = material[self.curSurface]
+            p.user_unit = usersurf.unit_for(self, layered=isinstance(material, rmat.Multilayer))
             p.asymmetric = 0
             for k, value in enumerate((0., 0., 1., 0., 0., 1.)):
                 p.n_const[k] = value

@@ -284,9 +284,16 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
                                    "(xrt_hip_user_surface_load)");
     // (a crystal's atomic planes follow the user's surface: local_n gives one normal, which
     // serves as both -- the reference does the same with a three-component local_n)
-    if (material->kind == XRT_HIP_MAT_MULTILAYER)
-      return fail(XRT_HIP_ERR_ARG, "multilayers on user-defined surfaces are not supported "
-                                   "(a unit is compiled without the layered kernels)");
+    // Multilayer / Coated: Parratt's recursion lives in the LAYERED flavour of a unit only
+    const xrt::UserUnit* unit = static_cast<const xrt::UserUnit*>(pass->user_unit);
+    if ((material->kind == XRT_HIP_MAT_MULTILAYER) != (unit->layered != 0))
+      return fail(XRT_HIP_ERR_ARG, "multilayers on user-defined surfaces need the layered "
+                                   "flavour of the surface's unit, every other material the "
+                                   "general one (this unit: %s)",
+                  unit->layered ? "layered" : "general");
+    if (pass->no_intersection_search && material->kind == XRT_HIP_MAT_CRYSTAL)
+      return fail(XRT_HIP_ERR_ARG, "crystals on user-defined surfaces: not without the "
+                                   "intersection search");
     if (pass->asymmetric || (pass->grating && (pass->grating != 1 || pass->g_ray_x)))
       return fail(XRT_HIP_ERR_ARG, "user-defined surfaces take plain gratings only (no zone "
                                    "plates, no asymmetric cut)");
@@ -714,7 +721,10 @@ int xrt_hip_user_surface_load(const char* path, void** handle) {
   u->eval = reinterpret_cast<int (*)(const xrt_hip_pass*, int, int64_t, const double*,
                                      const double*, double*, void*)>(
       dlsym(dl, "xrt_user_unit_eval"));
-  if (!abi || !u->fused || !u->exact || !u->eval) {
+  u->xtal = reinterpret_cast<int (*)(int, const void*)>(dlsym(dl, "xrt_user_unit_xtal"));
+  auto flavour = reinterpret_cast<int (*)()>(dlsym(dl, "xrt_user_unit_layered"));
+  u->layered = flavour ? flavour() : 0;
+  if (!abi || !u->fused || !u->exact || !u->eval || (u->layered && !u->xtal)) {
     delete u;
     dlclose(dl);
     return fail(XRT_HIP_ERR_ARG, "%s is not a surface unit (entry points missing)", path);

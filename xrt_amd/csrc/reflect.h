@@ -89,6 +89,8 @@ struct UserUnit {
   void* dl;
   int (*fused)(int mode, const void* fused_launch);
   int (*exact)(const void* exact_launch);
+  int (*xtal)(int mode, const void* fused_launch);   // layered flavour only (else NULL)
+  int layered;                                       // the unit holds the layered kernels
   int (*eval)(const xrt_hip_pass* P, int what, int64_t n, const double* u, const double* v,
               double* o, void* stream);
 };

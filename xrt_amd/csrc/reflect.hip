@@ -630,12 +630,14 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   bool launched = true;
   const UserUnit* unit = P.surf_kind == XRT_HIP_SURF_USER
                              ? static_cast<const UserUnit*>(P.user_unit) : nullptr;
-  if (P.surf_kind == XRT_HIP_SURF_USER && (!unit || layers || (need_mean && (!xtal_elsewhere || nis))))
+  if (P.surf_kind == XRT_HIP_SURF_USER &&
+      (!unit || layers != (unit->layered != 0) ||
+       (need_mean && !layers && (!xtal_elsewhere || nis))))
     return hipErrorInvalidValue;        // (capi.hip says why before it gets here)
   // the solve + finish kernel: mode 0 (optimistic) or 2 (no statistics needed)
   auto launch_fused = [&](int mode) {
-    if (unit)
-      launched &= unit->fused(mode, &FL) == 0;
+    if (unit)      // (need_mean here: a multilayer deflecting as a crystal -- layered flavour)
+      launched &= (need_mean ? unit->xtal(mode, &FL) : unit->fused(mode, &FL)) == 0;
     else if (need_mean)
       launched &= tu_hot_xtal(spec, mode, FL) || tu_xtal_xtal(spec, mode, FL) ||
                   tu_layered_xtal(spec, mode, FL);

@@ -58,9 +58,10 @@ def _headers_digest():
 _NO_GROOVES = 'g[0] = 0.; g[1] = 0.; g[2] = 0.;'
 
 
-def unit_source(local_z, local_n, local_g=None):
+def unit_source(local_z, local_n, local_g=None, layered=False):
     """The HIP source of the unit around the snippets (*local_g*: the groove vector of a
-    grating, optional)."""
+    grating, optional; *layered*: the flavour compiled around Parratt's recursion, for
+    Multilayer / Coated materials)."""
     with open(os.path.join(_CSRC, 'user_unit.hip.in')) as f:
         text = f.read()
     for marker, body in (('@LOCAL_Z@', local_z), ('@LOCAL_N@', local_n),
@@ -69,12 +70,12 @@ def unit_source(local_z, local_n, local_g=None):
             raise ValueError('hip_local_z / hip_local_n / hip_local_g must be non-empty source '
                              'strings')
         text = text.replace(marker, body)
-    return text.replace('@CSRC@', _CSRC)
+    return text.replace('@CSRC@', _CSRC).replace('@LAYERED@', '1' if layered else '0')
 
 
-def build_unit(local_z, local_n, verbose=False, local_g=None):
+def build_unit(local_z, local_n, verbose=False, local_g=None, layered=False):
     """Compiles (or finds in the cache) the unit of the snippets -> path of its .so."""
-    source = unit_source(local_z, local_n, local_g)
+    source = unit_source(local_z, local_n, local_g, layered)
     key = hashlib.sha256((source + _headers_digest() + ' '.join(_FLAGS)).encode()).hexdigest()[:24]
     out = os.path.join(cache_dir(), 'surface_%s.so' % key)
     with _lock:
@@ -142,7 +143,8 @@ def parameters_of(oe):
     return values + [0.] * (12 - len(values))
 
 
-def unit_for(oe):
-    """The loaded unit of the element's class (compiled on first use) -> handle."""
+def unit_for(oe, layered=False):
+    """The loaded unit of the element's class (compiled on first use) -> handle. *layered*:
+    the flavour for Multilayer / Coated materials (a second unit of the same snippets)."""
     z, n = snippets_of(oe)
-    return load_unit(build_unit(z, n, local_g=groove_snippet_of(oe)))
+    return load_unit(build_unit(z, n, local_g=groove_snippet_of(oe), layered=layered))
