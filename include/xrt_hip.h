@@ -306,6 +306,21 @@ typedef struct xrt_hip_pass {
   int32_t eff_tab_n;
   const double* eff_tab_E;
   const double* eff_tab_I;
+  /* OE(figureError = ...) (oes/base.py:681-684, 744-770, 826-830; figure_error.py:207-265): a
+   * height map [nm] on the surface, held as the tensor-product spline scipy's
+   * RectBivariateSpline(y1d, x1d, z) makes of it -- first spline axis = the element's y.
+   * fe_ty [fe_nty] / fe_tx [fe_ntx]: its knots, fe_c [(fe_nty - fe_k - 1) * (fe_ntx - fe_k - 1)]
+   * its coefficients (row = y), degree fe_k (1..3) on both axes; fe_cy / fe_cx: the
+   * coefficients of its partial derivatives along y / x (FITPACK's parder: degree fe_k - 1 on
+   * that axis, knots without the first and the last one). All DEVICE arrays. The height at
+   * (x + fe_shift[0], y + fe_shift[1]) * 1e-6 is added to local_z inside the intersection
+   * search (find_dz); at the hit point the normal is turned about x by atan(dz/dy) and then
+   * about y by -atan(dz/dx) (reflect.py:767-775). Arguments outside the knot range evaluate at
+   * its edge (FITPACK's fpbisp). fe_c NULL: no figure error. Not with parametric surfaces,
+   * user-defined surfaces or layered materials. */
+  int32_t fe_ntx, fe_nty, fe_k, fe_reserved;
+  const double *fe_tx, *fe_ty, *fe_c, *fe_cx, *fe_cy;
+  double fe_shift[2];
 } xrt_hip_pass;
 
 /* ---- user-defined surfaces -------------------------------------------------------------

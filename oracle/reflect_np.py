@@ -732,6 +732,8 @@ def find_dz(surf, t, x0, y0, z0, a, b, c, invertNormal):
     else:
         s = local_z(surf, x, y)
         diffSign = 1
+        if surf.get('figure_z') is not None:      # base.py:826-830: surf += z_distorted
+            s = s + surf['figure_z'](x, y)
     ind = np.isnan(s)
     if ind.sum() > 0:
         s[ind] = 0
@@ -1218,6 +1220,14 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
                 raise ValueError('unsupported material kind ' + kind)
 
         oeNormal = list(local_n(surf, lb.x[goodN], lb.y[goodN]))
+        if surf.get('figure_n') is not None:      # reflect.py:767-775: [d_pitch, d_roll]
+            d_pitch, d_roll = surf['figure_n'](lb.x[goodN], lb.y[goodN])
+            cosX, sinX = np.cos(d_pitch), np.sin(d_pitch)
+            oeNormal[-2], oeNormal[-1] = (cosX*oeNormal[-2] - sinX*oeNormal[-1],
+                                          sinX*oeNormal[-2] + cosX*oeNormal[-1])
+            cosY, sinY = np.cos(d_roll), np.sin(d_roll)
+            oeNormal[-3], oeNormal[-1] = (cosY*oeNormal[-3] + sinY*oeNormal[-1],
+                                          -sinY*oeNormal[-3] + cosY*oeNormal[-1])
         isAsymmetric = len(oeNormal) == 6
         oeNormal = np.asarray(
             [np.broadcast_to(np.asarray(v, dtype=float), lb.x[goodN].shape)

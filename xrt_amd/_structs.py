@@ -86,6 +86,16 @@ class Pass(ctypes.Structure):
         ('eff_tab_n', ctypes.c_int32),
         ('eff_tab_E', ctypes.c_void_p),
         ('eff_tab_I', ctypes.c_void_p),
+        ('fe_ntx', ctypes.c_int32),
+        ('fe_nty', ctypes.c_int32),
+        ('fe_k', ctypes.c_int32),
+        ('fe_reserved', ctypes.c_int32),
+        ('fe_tx', ctypes.c_void_p),
+        ('fe_ty', ctypes.c_void_p),
+        ('fe_c', ctypes.c_void_p),
+        ('fe_cx', ctypes.c_void_p),
+        ('fe_cy', ctypes.c_void_p),
+        ('fe_shift', ctypes.c_double * 2),
     ]
 
 

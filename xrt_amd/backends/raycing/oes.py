@@ -81,9 +81,9 @@ class OE(object):
                  limPhysY=[-_WIDE, _WIDE], limOptY=None, isParametric=False,
                  shape='rect', gratingDensity=None, order=None, **kwargs):
         given = dict(locals())
-        if figureError is not None or isParametric:
-            raise NotImplementedError('figure error / user-defined parametric OEs '
-                                      'are outside the accelerated path')
+        if isParametric:
+            raise NotImplementedError('user-defined parametric OEs are outside the '
+                                      'accelerated path')
         if not isinstance(shape, str) and not raycing.is_sequence(shape):
             raise ValueError('Unknown shape of OE {0}!'.format(name))
         raycing.enrol(self, bl, 'oes', 0, name, type(self).__name__, kwargs.get('uuid'))
@@ -91,6 +91,9 @@ class OE(object):
         for key in self._PLAIN:
             setattr(self, key, given[key])
         self.overEdge = kwargs.get('overEdge', 'yMax')
+        # a height map added to the surface (figure_error.py; oes/base.py:160, 310): evaluated
+        # by the ray kernels, see _figure_params
+        self.figureError = figureError
         # one diffraction order, or a sequence to draw from per hit ray
         if order is None:
             self.order = 1
@@ -136,6 +139,38 @@ class OE(object):
 
     def local_n2(self, x, y):
         return self.local_n(x, y)
+
+    def local_z_distorted(self, x, y):
+        """The height the figure error adds at (x, y) [mm], or None (oes/base.py:681-686)."""
+        fe = self.figureError
+        if fe is not None and hasattr(fe, 'local_z_distorted'):
+            return fe.local_z_distorted(x, y)
+
+    def local_n_distorted(self, x, y):
+        """[d_pitch, d_roll] by which the figure error turns the normal at (x, y), or None
+        (oes/base.py:744-772)."""
+        fe = self.figureError
+        if fe is not None and hasattr(fe, 'local_n_distorted'):
+            return fe.local_n_distorted(x, y)
+
+    def _figure_params(self, p):
+        """OE(figureError=...): the map's spline in HBM -> xrt_hip_pass.fe_* (the kernels add
+        its height inside find_dz and turn the normal at the hit point)."""
+        fe = getattr(self, 'figureError', None)
+        if fe is None:
+            return
+        if not hasattr(fe, 'device_record'):
+            raise NotImplementedError(
+                'figureError must be one of xrt_amd.backends.raycing.figure_error (a height map '
+                'as a spline: the kernels evaluate it); %r is not' % type(fe).__name__)
+        if self.isParametric or self._has_source_surface():
+            raise NotImplementedError('figure error on a parametric or user-defined surface')
+        rec = fe.device_record(_device())
+        p.fe_k, p.fe_nty, p.fe_ntx = rec['k'], rec['nty'], rec['ntx']
+        p.fe_ty, p.fe_tx, p.fe_c = rec['ty'], rec['tx'], rec['c']
+        p.fe_cy, p.fe_cx = rec['cy'], rec['cx']
+        p.fe_shift[0], p.fe_shift[1] = rec['shift']
+        p._keep_fe = rec['_keep']
 
     def _surface_params(self, p, second=False):
         # a subclass that brings its own numpy local_z / local_n (the usual way to define a
@@ -416,6 +451,7 @@ class OE(object):
         p.zero_local_not_entering = int(bool(zero_local_not_entering))
         p.force_lost_out = int(bool(force_lost_out))
         self._grating_params(p, is2ndXtal)
+        self._figure_params(p)
         return p
 
     def _limits_of(self, name):

@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libxrt_hip.so')
 # the reflect kernels are instantiated in units of their own (reflect_tu.h): the slowest first
-SOURCES = ['reflect_exact1.hip', 'reflect_exact3.hip', 'reflect_exact0.hip',
+SOURCES = ['reflect_figured_x1.hip', 'reflect_figured_x0.hip', 'reflect_figured_f.hip',
+           'reflect_exact1.hip', 'reflect_exact3.hip', 'reflect_exact0.hip',
            'reflect_exact2.hip', 'reflect_layered_x.hip', 'reflect_layered_f.hip',
            'reflect_generic.hip', 'reflect_xtal.hip', 'reflect.hip', 'reflect_hot.hip',
            'kirchhoff.hip', 'undulator.hip', 'capi.hip', 'screen.hip', 'hist.hip', 'source.hip']

@@ -298,6 +298,22 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
       return fail(XRT_HIP_ERR_ARG, "user-defined surfaces take plain gratings only (no zone "
                                    "plates, no asymmetric cut)");
   }
+  if (pass->fe_c) {       // OE(figureError = ...)
+    if (!pass->fe_tx || !pass->fe_ty || !pass->fe_cx || !pass->fe_cy || pass->fe_k < 1 ||
+        pass->fe_k > 3 || pass->fe_ntx < 2 * pass->fe_k + 2 || pass->fe_nty < 2 * pass->fe_k + 2)
+      return fail(XRT_HIP_ERR_ARG, "figure error: knots, coefficients and both derivative "
+                                   "arrays of a spline of degree 1..3");
+    if (pass->surf_kind == XRT_HIP_SURF_USER || pass->surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM)
+      return fail(XRT_HIP_ERR_ARG, "figure error on a parametric or user-defined surface is "
+                                   "not supported");
+    if (material->kind == XRT_HIP_MAT_MULTILAYER)
+      return fail(XRT_HIP_ERR_ARG, "figure error under a layered material is not supported");
+    if (pass->g_ray_x)
+      return fail(XRT_HIP_ERR_ARG, "figure error on a general zone plate is not supported");
+    if (pass->no_intersection_search && material->kind == XRT_HIP_MAT_CRYSTAL)
+      return fail(XRT_HIP_ERR_ARG, "figure error on a crystal: not without the intersection "
+                                   "search");
+  }
   if (material->kind == XRT_HIP_MAT_CRYSTAL && material->structure == 2 && !material->cell)
     return fail(XRT_HIP_ERR_ARG, "crystal from a unit cell without its xrt_hip_cell record");
   if (material->kind == XRT_HIP_MAT_MULTILAYER) {

@@ -577,7 +577,11 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       (P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM || P.surf_kind == XRT_HIP_SURF_PARABOLOID ||
        P.surf_kind == XRT_HIP_SURF_CONE || P.surf_kind == XRT_HIP_SURF_VFM ||
        P.surf_kind == XRT_HIP_SURF_DUALVFM || P.surf_kind == XRT_HIP_SURF_USER);
-  const bool optimistic = searches && !force_exact && !aliased && !xtal_elsewhere;
+  // OE(figureError = ...): the Figured kernels hold the height-map spline; a Bragg crystal with
+  // a figure error takes their exact sequence (its fused crystal kernels do not)
+  const bool figured = P.fe_c != nullptr;
+  const bool xtal_figured = figured && need_mean && M.kind == XRT_HIP_MAT_CRYSTAL;
+  const bool optimistic = searches && !force_exact && !aliased && !xtal_elsewhere && !xtal_figured;
   const bool flat_xtal = P.surf_kind == XRT_HIP_SURF_FLAT;
   const bool layers = M.kind == XRT_HIP_MAT_MULTILAYER;
   const bool wide = P.surf_kind == XRT_HIP_SURF_BENT_BRAGG || P.surf_kind == XRT_HIP_SURF_VFM ||
@@ -591,8 +595,16 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     family_spec = wide ? SP_LAYERED2 : (P.surf_kind >= XRT_HIP_SURF_BLAZED ? SP_LAYERED1 : SP_LAYERED0);
   else
     family_spec = wide ? SP_GENERIC2 : (P.surf_kind >= XRT_HIP_SURF_BLAZED ? SP_GENERIC1 : SP_GENERIC0);
+  if (figured) {
+    if (layers || P.g_ray_x || (need_mean && (!xtal_figured || nis)) ||
+        P.surf_kind == XRT_HIP_SURF_USER || P.surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM)
+      return hipErrorInvalidValue;      // (capi.hip says why before it gets here)
+    family_spec = wide ? SP_FIGURED2 : (P.surf_kind >= XRT_HIP_SURF_BLAZED ? SP_FIGURED1 : SP_FIGURED0);
+  }
   int spec = family_spec;
-  if (need_mean && layers) {
+  if (figured) {
+    // (no lean kernel, no crystal kernel)
+  } else if (need_mean && layers) {
     spec = wide ? SP_LAYERED2 : (P.surf_kind >= XRT_HIP_SURF_BLAZED ? SP_LAYERED1 : SP_LAYERED0);
   } else if (need_mean) {
     // Bragg-reflecting crystals sit on flat surfaces in practice (DCM): that case is
@@ -638,6 +650,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   auto launch_fused = [&](int mode) {
     if (unit)      // (need_mean here: a multilayer deflecting as a crystal -- layered flavour)
       launched &= (need_mean ? unit->xtal(mode, &FL) : unit->fused(mode, &FL)) == 0;
+    else if (figured)
+      launched &= tu_figured_fused(spec, mode, FL);
     else if (need_mean)
       launched &= tu_hot_xtal(spec, mode, FL) || tu_xtal_xtal(spec, mode, FL) ||
                   tu_layered_xtal(spec, mode, FL);
@@ -648,6 +662,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   auto launch_exact = [&]() {
     if (unit)
       launched &= unit->exact(&XL) == 0;
+    else if (figured)
+      launched &= tu_figured_exact0(family_spec, XL) || tu_figured_exact1(family_spec, XL);
     else
       launched &= tu_exact0(family_spec, XL) || tu_exact1(family_spec, XL) ||
                   tu_exact2(family_spec, XL) || tu_exact3(family_spec, XL);
@@ -697,6 +713,7 @@ bool reflect_dcm_fusable(const xrt_hip_pass& P1, const xrt_hip_material& M1,
   auto flat = [](const xrt_hip_pass& P) {
     return P.surf_kind == XRT_HIP_SURF_FLAT && !P.no_intersection_search && !P.grating;
   };
+  if (P1.fe_c || P2.fe_c) return false;     // a figure error: two passes of the Figured kernels
   return bragg(M1) && bragg(M2) && flat(P1) && flat(P2) && (M1.thick != 0) == (M2.thick != 0) &&
          !P1.out_to_global && !P2.in_is_global && !P1.only_state1_out && !P2.only_state1_out;
 }

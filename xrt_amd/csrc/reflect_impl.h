@@ -323,6 +323,9 @@ struct Spec {
   static constexpr bool XCELL = true;
   // zones and groove vectors per ray from the caller (general zone plate)
   static constexpr bool RAYG = false;
+  // the height map of OE(figureError=...) is evaluated (xrt_hip_pass.fe_*): only the Figured
+  // kernels below carry the spline code
+  static constexpr bool FE = false;
 };
 // a thick (semi-infinite) crystal: what a DCM is made of
 template <int SK_>
@@ -345,6 +348,12 @@ __host__ __device__ inline bool deflects_as_crystal(const xrt_hip_material& M) {
 // more launch overhead.)
 struct PerRayZones : Spec<0, -1, -1, false> {
   static constexpr bool RAYG = true;
+};
+// OE(figureError = ...): surface family F with the figure-error spline in find_dz and in the
+// normal, surface and material kinds read at run time
+template <int F_>
+struct Figured : Spec<F_, -1, -1, false> {
+  static constexpr bool FE = true;
 };
 using Layered0 = Spec<0, -1, XRT_HIP_MAT_MULTILAYER, false>;
 using Layered1 = Spec<1, -1, XRT_HIP_MAT_MULTILAYER, false>;
@@ -553,6 +562,79 @@ __device__ __forceinline__ Facet diced_facet(const xrt_hip_pass& P, double x, do
 }
 
 // surface height, oes/base.py:675-679 (flat), oes/__init__.py:398-401 (toroid)
+// ---------------------------------------------------------------------------
+// Figure error: scipy's RectBivariateSpline.ev (FITPACK bispev / parder) on the device.
+// fe_interval = fpbisp's argument clamp and knot search (the guess by scaling is exact for
+// the uniform interior knots of a linspace grid; the loops fix the ends of a not-a-knot
+// sequence and serve any other grid), fe_basis = fpbspl's recurrence for the k + 1 B-splines
+// that are not zero on the interval, fe_sum = fpbisp's double sum in its order.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int fe_interval(const double* __restrict__ t, int n, int k,
+                                           double& arg) {
+  const double tb = t[k], te = t[n - k - 1];
+  if (arg < tb) arg = tb;
+  if (arg > te) arg = te;
+  const int last = n - k - 2;                   // l <= last: t[l] <= arg <= t[l + 1]
+  int l = k + (int)((arg - tb) / (te - tb) * (double)(last - k + 1));
+  l = l < k ? k : (l > last ? last : l);
+  while (l > k && arg < t[l]) --l;
+  while (l < last && arg >= t[l + 1]) ++l;
+  return l;
+}
+__device__ __forceinline__ void fe_basis(const double* __restrict__ t, int k, double x, int l,
+                                         double (&h)[4]) {
+  double hh[3];
+  h[0] = 1.;
+  h[1] = h[2] = h[3] = 0.;
+  for (int j = 1; j <= k; ++j) {
+    for (int i = 0; i < j; ++i) hh[i] = h[i];
+    h[0] = 0.;
+    for (int i = 0; i < j; ++i) {
+      const double hi = t[l + 1 + i], lo = t[l + 1 + i - j];
+      const double f = hh[i] / (hi - lo);
+      h[i] = h[i] + f * (hi - x);
+      h[i + 1] = f * (x - lo);
+    }
+  }
+}
+// the spline of degrees (ku, kv) on knots tu [nu], tv [nv] with coefficients c (row = u) at (u, v)
+__device__ __forceinline__ double fe_spline(const double* __restrict__ tu, int nu, int ku,
+                                            const double* __restrict__ tv, int nv, int kv,
+                                            const double* __restrict__ c, double u, double v) {
+  const int lu = fe_interval(tu, nu, ku, u), lv = fe_interval(tv, nv, kv, v);
+  double hu[4], hv[4];
+  fe_basis(tu, ku, u, lu, hu);
+  fe_basis(tv, kv, v, lv, hv);
+  const int ncv = nv - kv - 1;
+  const double* row = c + (int64_t)(lu - ku) * ncv + (lv - kv);
+  double sp = 0.;
+  for (int i = 0; i <= ku; ++i, row += ncv)
+    for (int j = 0; j <= kv; ++j) sp += row[j] * hu[i] * hv[j];
+  return sp;
+}
+// local_z_distorted, figure_error.py:214-235 [mm]
+__device__ __forceinline__ double figure_height(const xrt_hip_pass& P, double x, double y) {
+  return fe_spline(P.fe_ty, P.fe_nty, P.fe_k, P.fe_tx, P.fe_ntx, P.fe_k, P.fe_c,
+                   y + P.fe_shift[1], x + P.fe_shift[0]) * 1e-6;
+}
+// local_n_distorted -> [d_pitch, d_roll] (figure_error.py:237-265) applied to the surface
+// normal as reflect.py:767-775 does: rotate_x by d_pitch, then rotate_y by d_roll
+__device__ __forceinline__ void figure_turn_normal(const xrt_hip_pass& P, double x, double y,
+                                                   double& nx, double& ny, double& nz) {
+  const double u = y + P.fe_shift[1], v = x + P.fe_shift[0];
+  const int k = P.fe_k;
+  const double a = fe_spline(P.fe_ty, P.fe_nty, k, P.fe_tx + 1, P.fe_ntx - 2, k - 1, P.fe_cx, u, v) * 1e-6;
+  const double b = fe_spline(P.fe_ty + 1, P.fe_nty - 2, k - 1, P.fe_tx, P.fe_ntx, k, P.fe_cy, u, v) * 1e-6;
+  double sX, cX, sY, cY;
+  sincos(atan(b), &sX, &cX);
+  sincos(-atan(a), &sY, &cY);
+  const double y1 = cX * ny - sX * nz, z1 = sX * ny + cX * nz;      // _rotate.py:5-8
+  const double x2 = cY * nx + sY * z1, z2 = -sY * nx + cY * z1;     // _rotate.py:11-14
+  nx = x2;
+  ny = y1;
+  nz = z2;
+}
+
 template <class K>
 __device__ __forceinline__ double surf_z(const xrt_hip_pass& P, double x, double y) {
 #ifdef XRT_USER_SURFACE
@@ -647,6 +729,9 @@ __device__ __forceinline__ double find_dz(const xrt_hip_pass& P, double t, doubl
     return (z - s) * -1. * (double)P.invert_normal;
   }
   double s = surf_z<K>(P, x, y);
+  if constexpr (K::FE) {                  // base.py:826-830: surf += z_distorted
+    if (P.fe_c) s += figure_height(P, x, y);
+  }
   if (isnan(s)) s = 0.;
   return (z - s) * (double)P.invert_normal;
 }
@@ -2645,6 +2730,18 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
   // normals: n[0..2] = n_H (Bragg planes), n[3..5] = surface
   double n[6];
   surface_normal<K>(P, h.x, h.y, h.px, h.py, n);
+  if constexpr (K::FE) {
+    // reflect.py:767-775 turns oeNormal[-3:]: the surface normal -- which is also the normal
+    // of the atomic planes unless the cut is asymmetric (six components)
+    if (P.fe_c) {
+      figure_turn_normal(P, h.x, h.y, n[3], n[4], n[5]);
+      if (!PASYM(P)) {
+        n[0] = n[3];
+        n[1] = n[4];
+        n[2] = n[5];
+      }
+    }
+  }
   double bdn = r.a * n[0] + r.b * n[1] + r.c * n[2];
   if (bdn < -1.) bdn = -1.;
   if (bdn > 1.) bdn = 1.;

@@ -20,7 +20,8 @@ enum SpecId {
   SP_GENERIC0, SP_GENERIC1, SP_GENERIC2, SP_PER_RAY_ZONES,
   SP_LAYERED0, SP_LAYERED1, SP_LAYERED2,
   SP_TOROID_MIRROR, SP_FLAT_MIRROR, SP_BENT_MIRROR, SP_FLAT_PLATE,
-  SP_THICK_FLAT, SP_THICK_ANY, SP_FLAT_XTAL, SP_ANY_XTAL
+  SP_THICK_FLAT, SP_THICK_ANY, SP_FLAT_XTAL, SP_ANY_XTAL,
+  SP_FIGURED0, SP_FIGURED1, SP_FIGURED2
 };
 
 struct FusedLaunch {   // one launch of reflect_fused / reflect_fused_xtal
@@ -97,6 +98,9 @@ bool tu_xtal_dcm(int spec, const DcmLaunch& L);
 bool tu_generic_fused(int spec, int mode, const FusedLaunch& L);    // reflect_generic.hip
 bool tu_layered_fused(int spec, int mode, const FusedLaunch& L);    // reflect_layered_f.hip
 bool tu_layered_xtal(int spec, int mode, const FusedLaunch& L);     // reflect_layered_x.hip
+bool tu_figured_fused(int spec, int mode, const FusedLaunch& L);    // reflect_figured_f.hip
+bool tu_figured_exact0(int spec, const ExactLaunch& L);             // reflect_figured_x0.hip
+bool tu_figured_exact1(int spec, const ExactLaunch& L);             // reflect_figured_x1.hip
 bool tu_exact0(int spec, const ExactLaunch& L);                     // reflect_exact0.hip
 void tu_exact0_dcm(const DcmLaunch& L);
 bool tu_exact1(int spec, const ExactLaunch& L);                     // reflect_exact1.hip
