@@ -190,6 +190,41 @@ def bench_reflect_nolocal(nrays, steps=20):
                      'OE.reflect with both beams')
 
 
+def bench_reflect_figure(nrays, steps=10):
+    """The cfg2 toroid under a figure error (OE(figureError=RandomRoughness): a 512 x 128 height
+    map as a bicubic spline, evaluated per ray in every step of the intersection search and
+    twice more for the normal: oes/base.py:826-830, reflect.py:767-775) -- the Figured kernels
+    against the lean pass of the primary metric."""
+    from xrt_amd import workloads as pc
+    from xrt_amd.backends.raycing import figure_error as rfe
+    oe = pc.cfg2_toroid()
+    oe.figureError = rfe.RandomRoughness(rms=3., corrLength=4., seed=11, limPhysX=[-10, 10],
+                                         limPhysY=[-300, 300], gridStep=2.)
+    beam = pc.synthetic_rays(nrays, 42)
+    for f in beam.array_fields():
+        beam.dev(f)
+    out = None
+    for _ in range(3):
+        out = oe.reflect(beam, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = oe.reflect(beam, out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n_enter = int((beam.peek('state') > 0).sum())
+    good = out[1].dev('state') == 1
+    z = out[1].dev('z')[good][:100000].cpu().numpy()
+    x, y = out[1].dev('x')[good][:100000].cpu().numpy(), out[1].dev('y')[good][:100000].cpu().numpy()
+    return dict(metric='ray-surface intersections/s, toroid with a figure-error map',
+                value=n_enter / dt, ms_per_step=dt * 1e3, map='RandomRoughness 3 nm rms, 512 x 128 '
+                'nodes, bicubic spline',
+                hit_points_off_the_distorted_surface_mm=float(np.abs(
+                    z - oe.local_z(x, y) - oe.local_z_distorted(x, y)).max()),
+                note='~11 spline evaluations per ray (16 coefficients each) inside the root '
+                     'search: bound by their dependent loads and fp64 arithmetic, not by HBM')
+
+
 def bench_reflect(args, world, rank, dist, dcm=False):
     from xrt_amd import workloads as pc
     n = int(args.rays)
@@ -1000,6 +1035,8 @@ def main():
         line['hist'] = bench_hist(int(args.rays))
     if world == 1 and not args.skip_dcm:
         line['reflect_nolocal'] = bench_reflect_nolocal(int(args.rays))
+    if world == 1 and not args.skip_dcm:
+        line['reflect_figure'] = bench_reflect_figure(int(args.rays))
     if world == 1 and not args.skip_e2e:
         line['e2e'] = bench_e2e(int(args.rays))
     if args.with_softi_shapes and world == 1:

@@ -5,16 +5,18 @@ surface (reference: xrt/backends/raycing/figure_error.py; the hooks on the ray p
 on the normal at the hit point, oes/reflect.py:767-775).
 
 The map lives where the reference keeps it: a ``scipy.interpolate.RectBivariateSpline`` through
-heights [nm] on a regular (x, y) grid, built on the host once per change of a parameter. What is
-new is where it is EVALUATED: the spline's knots and coefficients, and the coefficients of its
-two partial derivatives (formed here the way FITPACK's ``parder`` forms them), go to HBM
+heights [nm] on a regular (x, y) grid, rebuilt on the host whenever a parameter is assigned.
+What is new is where it is EVALUATED: the spline's knots and coefficients, and the coefficients
+of its two partial derivatives (formed here the way FITPACK's ``parder`` forms them), go to HBM
 (``device_record``) and the ray kernels evaluate them per ray inside the intersection search and
 at the hit point (csrc/reflect_impl.h: fe_spline, figure_height, figure_turn_normal; pass
-record fields ``xrt_hip_pass.fe_*``). The numpy methods below (``local_z_distorted``,
-``local_n_distorted``) are the reference's, for scripts that look at a map themselves.
+record fields ``xrt_hip_pass.fe_*``). ``local_z_distorted`` / ``local_n_distorted`` below are
+the reference's numpy methods, for scripts that look at a map themselves.
 
-Classes as in the reference: RandomRoughness, GaussianBump, Waviness, PlanarRidge,
-FigureErrorImported; maps add up through *baseFE*.
+The classes and their arguments are the reference's (RandomRoughness, GaussianBump, Waviness,
+PlanarRidge, FigureErrorImported; maps add up through *baseFE*), and so is every map: the
+generators keep the reference's order of floating-point operations, and
+tests/test_figure_error.py holds their splines against splines made inside the reference.
 """
 import os
 
@@ -26,15 +28,37 @@ __all__ = ('RandomRoughness', 'GaussianBump', 'Waviness', 'FigureErrorImported')
 maxFeHalfSize = 100      # [mm] default half size of a map (figure_error.py:42)
 
 
-def _rebuilding(name):
-    """A constructor argument kept as ``_name`` whose assignment rebuilds the spline."""
-    def get(self):
-        return getattr(self, '_' + name)
+class _Param(object):
+    """A constructor argument of a map, kept on the instance under ``_<name>``: assigning it
+    rebuilds the spline (what the reference does with one property pair per argument).
+    *convert*: applied to an assigned value; *when*: a predicate of the instance that must
+    hold for the rebuild."""
 
-    def put(self, value):
-        setattr(self, '_' + name, value)
-        self.build_spline()
-    return property(get, put)
+    def __init__(self, convert=None, when=None):
+        self.convert, self.when = convert, when
+
+    def __set_name__(self, owner, name):
+        self.slot = '_' + name
+
+    def __get__(self, obj, owner=None):
+        return self if obj is None else getattr(obj, self.slot)
+
+    def __set__(self, obj, value):
+        setattr(obj, self.slot, value if self.convert is None else self.convert(value))
+        if getattr(obj, '_built', False) and (self.when is None or self.when(obj)):
+            obj.build_spline()
+
+
+def _extent(lim):
+    return [-maxFeHalfSize, maxFeHalfSize] if lim is None else list(lim)
+
+
+def _nodes(lim, step):
+    """(number of nodes, cell size, nodes) along one axis of a generated map: the next power of
+    two of extent / step, at least 128 (figure_error.py:167-181)."""
+    length = np.abs(lim[-1] - lim[0])
+    n = max(1 << int(np.ceil(np.log2(length / step))), 128)
+    return n, length / n, np.linspace(min(lim), max(lim), n)
 
 
 class FigureErrorBase(object):
@@ -44,130 +68,112 @@ class FigureErrorBase(object):
     extent of the map [mm] (default +-100). *gridStep* [mm]: the number of nodes per axis is
     the next power of two of extent / gridStep, at least 128."""
 
+    baseFE = _Param()
+    gridStep = _Param()
+    splineOrder = _Param()
+    limPhysX = _Param(_extent)
+    limPhysY = _Param(_extent)
+
     def __init__(self, name='', baseFE=None, limPhysX=None, limPhysY=None, gridStep=0.5,
                  **kwargs):
-        self.name = name
-        self.bl = kwargs.get('bl')
-        self._baseFE = baseFE
-        self._gridStep = gridStep
-        self._splineOrder = 3
-        self.xShift = 0.
-        self.yShift = 0.
-        self._limPhysX = self._limits(limPhysX)
-        self._limPhysY = self._limits(limPhysY)
+        self._built = False
+        self.name, self.bl = name, kwargs.get('bl')
+        self.xShift = self.yShift = 0.
+        self.baseFE, self.gridStep, self.splineOrder = baseFE, gridStep, 3
+        self.limPhysX, self.limPhysY = limPhysX, limPhysY
         self._device = {}
+        self._built = True
         if 'skip_build_spline' not in kwargs:
             self.build_spline()
 
-    @staticmethod
-    def _limits(lim):
-        return [-maxFeHalfSize, maxFeHalfSize] if lim is None else list(lim)
-
-    baseFE = _rebuilding('baseFE')
-    gridStep = _rebuilding('gridStep')
-    splineOrder = _rebuilding('splineOrder')
-
-    @property
-    def limPhysX(self):
-        return self._limPhysX
-
-    @limPhysX.setter
-    def limPhysX(self, limPhysX):
-        self._limPhysX = self._limits(limPhysX)
-        self.build_spline()
-
-    @property
-    def limPhysY(self):
-        return self._limPhysY
-
-    @limPhysY.setter
-    def limPhysY(self, limPhysY):
-        self._limPhysY = self._limits(limPhysY)
-        self.build_spline()
-
     # ---- diagnostics (figure_error.py:157-200) ------------------------------------------
+    def _heights_nm(self):
+        return self.local_z_distorted(self.x2d, self.y2d) * 1e6
+
     def get_rms(self):
         """rms height of the map [nm]."""
-        z = self.local_z_distorted(self.x2d, self.y2d) * 1e6
-        return np.sqrt(((z - z.mean())**2).mean())
+        centred = self._heights_nm()
+        centred = centred - centred.mean()
+        return np.sqrt((centred**2).mean())
 
     def get_rms_slope(self):
         """(rms pitch, rms roll) slope errors [rad]."""
-        d_pitch, d_roll = self.local_n_distorted(self.x2d, self.y2d)
-        return np.sqrt((d_pitch**2).mean()), np.sqrt((d_roll**2).mean())
+        return tuple(np.sqrt((angle**2).mean())
+                     for angle in self.local_n_distorted(self.x2d, self.y2d))
 
     def next_pow2(self, n):
         return 1 << int(np.ceil(np.log2(n)))
 
     def get_dimensions(self):
-        xlength = np.abs(self.limPhysX[-1] - self.limPhysX[0])
-        ylength = np.abs(self.limPhysY[-1] - self.limPhysY[0])
-        self.nx = max(self.next_pow2(xlength / self.gridStep), 128)
-        self.ny = max(self.next_pow2(ylength / self.gridStep), 128)
-        self.dx = xlength / self.nx
-        self.dy = ylength / self.ny
+        self.nx, self.dx, _ = _nodes(self.limPhysX, self.gridStep)
+        self.ny, self.dy, _ = _nodes(self.limPhysY, self.gridStep)
 
     def get_grids(self):
-        self.get_dimensions()
-        self.x1d = np.linspace(min(self.limPhysX), max(self.limPhysX), self.nx)
-        self.y1d = np.linspace(min(self.limPhysY), max(self.limPhysY), self.ny)
+        self.nx, self.dx, self.x1d = _nodes(self.limPhysX, self.gridStep)
+        self.ny, self.dy, self.y1d = _nodes(self.limPhysY, self.gridStep)
         self.x2d, self.y2d = np.meshgrid(self.x1d, self.y1d)
 
     def get_angles(self):
-        self.a2d, self.b2d = np.gradient(self.z2d * 1e-6, self.y1d, self.x1d)
-        self.a2d = np.arctan(self.a2d)
-        self.b2d = np.arctan(self.b2d)
+        """Slope angles of the map on its grid (a2d along y, b2d along x)."""
+        along_y, along_x = np.gradient(self.z2d * 1e-6, self.y1d, self.x1d)
+        self.a2d, self.b2d = np.arctan(along_y), np.arctan(along_x)
 
     def get_psd(self):
         """(KX, KY, PSD) of the map."""
-        z = self.local_z_distorted(self.x2d, self.y2d) * 1e6
-        nrow, ncol = z.shape
-        H = np.fft.fftshift(np.fft.fft2(z - z.mean()))
-        PSD = np.abs(H)**2 / (nrow * ncol)
-        dx = np.abs(self.limPhysX[-1] - self.limPhysX[0]) / nrow
-        dy = np.abs(self.limPhysY[-1] - self.limPhysY[0]) / ncol
-        kx = 2 * np.pi * np.fft.fftshift(np.fft.fftfreq(nrow, d=dx))
-        ky = 2 * np.pi * np.fft.fftshift(np.fft.fftfreq(ncol, d=dy))
-        KX, KY = np.meshgrid(kx, ky, indexing='xy')
+        z = self._heights_nm()
+        rows, cols = z.shape
+        PSD = np.abs(np.fft.fftshift(np.fft.fft2(z - z.mean())))**2 / (rows * cols)
+        step_x = np.abs(self.limPhysX[-1] - self.limPhysX[0]) / rows
+        step_y = np.abs(self.limPhysY[-1] - self.limPhysY[0]) / cols
+        KX, KY = np.meshgrid(2 * np.pi * np.fft.fftshift(np.fft.fftfreq(rows, d=step_x)),
+                             2 * np.pi * np.fft.fftshift(np.fft.fftfreq(cols, d=step_y)),
+                             indexing='xy')
         return KX, KY, PSD
 
     # ---- the map ----------------------------------------------------------------------
     def _base_profile(self):
         """The map of *baseFE* on this one's grid [nm] (zeros without one)."""
-        if self.baseFE is not None and hasattr(self.baseFE, 'local_z_distorted'):
-            return self.baseFE.local_z_distorted(self.x2d, self.y2d) * 1e6
+        under = self.baseFE
+        if under is not None and hasattr(under, 'local_z_distorted'):
+            return under.local_z_distorted(self.x2d, self.y2d) * 1e6
+        return np.zeros_like(self.x2d)
+
+    def _own_profile(self):
+        """This class's heights [nm] on the (y, x) grid (the subclasses' part)."""
         return np.zeros_like(self.x2d)
 
     def generate_profile(self):
-        """Heights [nm] on the (y, x) grid; overridden by the subclasses."""
+        """Heights [nm] on the (y, x) grid: the class's own map on top of *baseFE*'s."""
         self.get_grids()
-        return np.zeros_like(self.x2d)
+        under = self._base_profile()
+        return self._own_profile() + under
+
+    def _fit(self, heights):
+        self.local_z_spline = interpolate.RectBivariateSpline(
+            self.y1d, self.x1d, heights, kx=self.splineOrder, ky=self.splineOrder)
+        self._device = {}               # (the copies in HBM are of the old spline)
 
     def build_spline(self):
-        z = self.generate_profile()
-        self.local_z_spline = interpolate.RectBivariateSpline(
-            self.y1d, self.x1d, z, kx=self.splineOrder, ky=self.splineOrder)
-        self._device = {}               # (the copies in HBM are of the old spline)
-        self.z2d = self.local_z_distorted(self.x2d, self.y2d) * 1e6       # [nm]
+        self._fit(self.generate_profile())
+        self.z2d = self._heights_nm()
         self.get_angles()
 
-    def _flat_args(self, x, y):
+    def _ev(self, x, y, **derivative):
         x, y = np.asarray(x, dtype=float), np.asarray(y, dtype=float)
-        return x.shape, x.ravel(), y.ravel()
+        values = self.local_z_spline.ev(y.ravel() + self.yShift, x.ravel() + self.xShift,
+                                        **derivative)
+        return values.reshape(x.shape)
 
     def local_z_distorted(self, x, y):
         """Height of the map at (x, y) [mm] (figure_error.py:214-235)."""
-        shape, x, y = self._flat_args(x, y)
-        z = self.local_z_spline.ev(y + self.yShift, x + self.xShift)
-        return z.reshape(shape) * 1e-6
+        return self._ev(x, y) * 1e-6
 
     def local_n_distorted(self, x, y):
         """[d_pitch, d_roll]: the two angles the local normal is turned by
         (figure_error.py:237-265)."""
-        shape, x, y = self._flat_args(x, y)
-        a = self.local_z_spline.ev(y + self.yShift, x + self.xShift, dx=0, dy=1) * 1e-6
-        b = self.local_z_spline.ev(y + self.yShift, x + self.xShift, dx=1, dy=0) * 1e-6
-        return [np.arctan(b.reshape(shape)), -np.arctan(a.reshape(shape))]
+        slope_x = self._ev(x, y, dx=0, dy=1) * 1e-6
+        slope_y = self._ev(x, y, dx=1, dy=0) * 1e-6
+        return [np.arctan(slope_y), -np.arctan(slope_x)]
 
     # ---- what the kernels read ---------------------------------------------------------
     def spline_arrays(self):
@@ -209,137 +215,106 @@ class FigureErrorBase(object):
         return rec
 
 
+def _fresh_seed(seed):
+    return np.random.SeedSequence().entropy if seed is None else seed
+
+
+def _scalar_rms(fe):
+    """(a height rms must be one number: a pair is kept but builds nothing,
+    figure_error.py:531-549)"""
+    return not (fe._rmsKind == 'height' and isinstance(fe._rms, (tuple, list)))
+
+
 class RandomRoughness(FigureErrorBase):
     """A random map of given rms height [nm] (*rmsKind* 'height') or rms slope [urad] ('slope':
     one number, or (pitch, roll)), smoothed to the correlation length *corrLength* [mm] by a
     Gaussian filter in the spatial-frequency domain; *seed* makes it reproducible
     (figure_error.py:463-620)."""
 
+    rms = _Param(when=_scalar_rms)
+    rmsKind = _Param(when=_scalar_rms)
+    corrLength = _Param()
+    seed = _Param(_fresh_seed)
+
     def __init__(self, rms=1., rmsKind='height', corrLength=5., seed=None, **kwargs):
-        self._rmsKind = rmsKind
-        self._rms = rms
-        self._corrLength = corrLength
-        self._seed = np.random.SeedSequence().entropy if seed is None else seed
-        kwargs.setdefault('name', 'random roughness')
-        super().__init__(**kwargs)
+        self._built = False
+        self.rmsKind, self.rms, self.corrLength, self.seed = rmsKind, rms, corrLength, seed
+        super().__init__(**dict(kwargs, name=kwargs.get('name', 'random roughness')))
 
-    def _directional_height(self):
-        return self._rmsKind == 'height' and isinstance(self._rms, (tuple, list))
-
-    @property
-    def rms(self):
-        return self._rms
-
-    @rms.setter
-    def rms(self, rms):
-        self._rms = rms
-        if not self._directional_height():
-            self.build_spline()
-
-    @property
-    def rmsKind(self):
-        return self._rmsKind
-
-    @rmsKind.setter
-    def rmsKind(self, rmsKind):
-        self._rmsKind = rmsKind
-        if not self._directional_height():
-            self.build_spline()
-
-    corrLength = _rebuilding('corrLength')
-
-    @property
-    def seed(self):
-        return self._seed
-
-    @seed.setter
-    def seed(self, seed):
-        self._seed = np.random.SeedSequence().entropy if seed is None else seed
-        self.build_spline()
-
-    def generate_profile(self):
-        rng = np.random.default_rng(self.seed)
-        self.get_grids()
-        base_z = self._base_profile()
-        z = rng.normal(loc=0.0, scale=1.0, size=(self.ny, self.nx))
+    def _own_profile(self):
+        # (numbers are drawn and combined in the reference's order: the map is the same bits)
+        noise = np.random.default_rng(self.seed).normal(loc=0.0, scale=1.0,
+                                                        size=(self.ny, self.nx))
+        pair = isinstance(self.rms, (tuple, list))
+        KX = KY = None
         if self.corrLength is not None:
-            spectrum = np.fft.rfft2(z)
-            kx = 2 * np.pi * np.fft.rfftfreq(self.nx, d=self.dx)
-            ky = 2 * np.pi * np.fft.fftfreq(self.ny, d=self.dy)
-            KX, KY = np.meshgrid(kx, ky, indexing='xy')
-            if isinstance(self.rms, (tuple, list)):      # the smaller rms, the longer
-                corrY = self.corrLength                                      # pitch
-                corrX = self.corrLength * self.rms[0] / self.rms[1]          # roll
-            else:
-                corrX = corrY = self.corrLength
-            z = np.fft.irfft2(spectrum * np.exp(-0.5*(KX**2*corrX**2 + KY**2*corrY**2)),
-                              s=(self.ny, self.nx))
-        z -= z.mean()
+            KX, KY = np.meshgrid(2 * np.pi * np.fft.rfftfreq(self.nx, d=self.dx),
+                                 2 * np.pi * np.fft.fftfreq(self.ny, d=self.dy), indexing='xy')
+            # two rms slopes: the smaller one gets the longer correlation
+            along_y = self.corrLength                                            # pitch
+            along_x = self.corrLength * self.rms[0] / self.rms[1] if pair else along_y   # roll
+            window = np.exp(-0.5*(KX**2*along_x**2 + KY**2*along_y**2))
+            noise = np.fft.irfft2(np.fft.rfft2(noise) * window, s=(self.ny, self.nx))
+        noise -= noise.mean()
         if self.rmsKind == 'height':
-            current = np.sqrt((z**2).mean())
-            if current > 0:
-                z *= (self.rms / current)
+            now = np.sqrt((noise**2).mean())
+            if now > 0:
+                noise *= (self.rms / now)
         elif self.rmsKind == 'slope':
-            a2d, b2d = np.gradient(z*1e-6, self.y1d, self.x1d)
-            rms_pitch = np.sqrt((np.arctan(a2d)**2).mean())
-            rms_roll = np.sqrt((np.arctan(b2d)**2).mean())
-            if isinstance(self.rms, (list, tuple)):
-                scale_y = self.rms[0] * 1e-6 / rms_pitch
-                scale_x = self.rms[1] * 1e-6 / rms_roll
-                spectrum = np.fft.rfft2(z)
-                spectrum *= np.sqrt((scale_x * KX)**2 + (scale_y * KY)**2) /\
+            along_y, along_x = np.gradient(noise*1e-6, self.y1d, self.x1d)
+            pitch_now = np.sqrt((np.arctan(along_y)**2).mean())
+            roll_now = np.sqrt((np.arctan(along_x)**2).mean())
+            if pair:
+                gain_y = self.rms[0] * 1e-6 / pitch_now
+                gain_x = self.rms[1] * 1e-6 / roll_now
+                spectrum = np.fft.rfft2(noise)
+                spectrum *= np.sqrt((gain_x * KX)**2 + (gain_y * KY)**2) /\
                     np.sqrt(KX**2 + KY**2 + 1e-30)
-                z = np.fft.irfft2(spectrum, s=(self.ny, self.nx))
+                noise = np.fft.irfft2(spectrum, s=(self.ny, self.nx))
             else:
-                z *= self.rms * 1e-6 / np.sqrt(0.5 * (rms_pitch**2 + rms_roll**2))
-        return z + base_z
+                noise *= self.rms * 1e-6 / np.sqrt(0.5 * (pitch_now**2 + roll_now**2))
+        return noise
 
 
 class GaussianBump(FigureErrorBase):
     """A Gaussian bump of *bumpHeight* [nm] at (*cX*, *cY*) with widths *sigmaX*, *sigmaY*
     [mm] (figure_error.py:623-700)."""
 
+    bumpHeight = _Param()
+    sigmaX = _Param()
+    sigmaY = _Param()
+    cX = _Param()
+    cY = _Param()
+
     def __init__(self, bumpHeight=10., cX=0., cY=0., sigmaX=10., sigmaY=10., **kwargs):
-        self._bumpHeight, self._sigmaX, self._sigmaY = bumpHeight, sigmaX, sigmaY
-        self._cX, self._cY = cX, cY
-        kwargs.setdefault('name', 'gaussian bump')
-        super().__init__(**kwargs)
+        self._built = False
+        self.bumpHeight, self.cX, self.cY = bumpHeight, cX, cY
+        self.sigmaX, self.sigmaY = sigmaX, sigmaY
+        super().__init__(**dict(kwargs, name=kwargs.get('name', 'gaussian bump')))
 
-    bumpHeight = _rebuilding('bumpHeight')
-    sigmaX = _rebuilding('sigmaX')
-    sigmaY = _rebuilding('sigmaY')
-    cX = _rebuilding('cX')
-    cY = _rebuilding('cY')
-
-    def generate_profile(self):
-        self.get_grids()
-        base_z = self._base_profile()
-        z = self.bumpHeight *\
-            np.exp(-(self.x2d-self.cX)**2/self.sigmaX**2
-                   - (self.y2d-self.cY)**2/self.sigmaY**2)
-        return z + base_z
+    def _own_profile(self):
+        exponent = -(self.x2d - self.cX)**2 / self.sigmaX**2 \
+            - (self.y2d - self.cY)**2 / self.sigmaY**2
+        return self.bumpHeight * np.exp(exponent)
 
 
 class Waviness(FigureErrorBase):
     """A product of two cosines of *amplitude* [nm] and periods *xWaveLength*, *yWaveLength*
     [mm] (figure_error.py:703-760)."""
 
+    amplitude = _Param()
+    xWaveLength = _Param()
+    yWaveLength = _Param()
+
     def __init__(self, amplitude=10., xWaveLength=20., yWaveLength=50., **kwargs):
-        self._amplitude = amplitude
-        self._xWaveLength, self._yWaveLength = xWaveLength, yWaveLength
-        kwargs.setdefault('name', 'waviness')
-        super().__init__(**kwargs)
+        self._built = False
+        self.amplitude, self.xWaveLength, self.yWaveLength = amplitude, xWaveLength, yWaveLength
+        super().__init__(**dict(kwargs, name=kwargs.get('name', 'waviness')))
 
-    amplitude = _rebuilding('amplitude')
-    xWaveLength = _rebuilding('xWaveLength')
-    yWaveLength = _rebuilding('yWaveLength')
-
-    def generate_profile(self):
-        self.get_grids()
-        base_z = self._base_profile()
-        z = self.amplitude * np.cos(2*np.pi*self.x2d/self.xWaveLength) *\
-            np.cos(2*np.pi*self.y2d/self.yWaveLength)
-        return z + base_z
+    def _own_profile(self):
+        across = np.cos(2*np.pi*self.x2d/self.xWaveLength)
+        along = np.cos(2*np.pi*self.y2d/self.yWaveLength)
+        return self.amplitude * across * along
 
 
 class PlanarRidge(FigureErrorBase):
@@ -347,23 +322,27 @@ class PlanarRidge(FigureErrorBase):
     inclined by *slopeAngle* [rad], the ridge turned by *orientationAngle* from the x axis (the
     reference's own test shape, figure_error.py:763-840)."""
 
+    amplitude = _Param()
+    slopeAngle = _Param()
+    orientationAngle = _Param()
+
     def __init__(self, amplitude=1., slopeAngle=1e-3, orientationAngle=0, **kwargs):
-        self._amplitude = amplitude
-        self._slopeAngle, self._orientationAngle = slopeAngle, orientationAngle
-        kwargs.setdefault('name', 'ridge')
-        super().__init__(**kwargs)
+        self._built = False
+        self.amplitude, self.slopeAngle = amplitude, slopeAngle
+        self.orientationAngle = orientationAngle
+        super().__init__(**dict(kwargs, name=kwargs.get('name', 'ridge')))
 
-    amplitude = _rebuilding('amplitude')
-    slopeAngle = _rebuilding('slopeAngle')
-    orientationAngle = _rebuilding('orientationAngle')
+    def _own_profile(self):
+        turn = self.orientationAngle
+        off_ridge = -self.x2d*np.sin(turn) + self.y2d*np.cos(turn)
+        return (self.amplitude - np.tan(self.slopeAngle)*np.abs(off_ridge)) * 1e6
 
-    def generate_profile(self):
-        self.get_grids()
-        base_z = self._base_profile()
-        across = -self.x2d*np.sin(self.orientationAngle) +\
-            self.y2d*np.cos(self.orientationAngle)
-        z = self.amplitude - np.tan(self.slopeAngle)*np.abs(across)
-        return z*1e6 + base_z
+
+def _three_factors(factors):
+    try:
+        return [f*1.0 for f in factors[:3]]
+    except Exception:  # noqa: BLE001 -- not three numbers
+        return [1, 1, 1]
 
 
 class FigureErrorImported(FigureErrorBase):
@@ -373,13 +352,12 @@ class FigureErrorImported(FigureErrorBase):
 
     def __init__(self, fileName=None, recenter=False, orientation='XYZ',
                  columnFactors=[1, 1, 1], **kwargs):
-        self.surfArrays = {}
-        kwargs.setdefault('name', 'NOM surface')
-        self._recenter, self._orientation = recenter, orientation
-        self._fileName = None
-        self.columnFactors = columnFactors
-        kwargs['skip_build_spline'] = True
-        super().__init__(**kwargs)
+        self._built = False
+        self.surfArrays, self.z2d = {}, None
+        self._recenter, self._orientation, self._fileName = recenter, orientation, None
+        self._columnFactors = _three_factors(columnFactors)
+        super().__init__(**dict(kwargs, name=kwargs.get('name', 'NOM surface'),
+                                skip_build_spline=True))
         self._baseFE = None
         self.fileName = fileName
 
@@ -388,100 +366,85 @@ class FigureErrorImported(FigureErrorBase):
             self.align_arrays()
             self.build_spline()
 
-    @property
-    def orientation(self):
-        return self._orientation
+    def _reload(self):
+        if self._fileName is not None:
+            self.read_file(self._fileName)
+            self._realign()
+
+    orientation = property(lambda self: self._orientation)
+    recenter = property(lambda self: self._recenter)
+    columnFactors = property(lambda self: self._columnFactors)
+    fileName = property(lambda self: self._fileName)
 
     @orientation.setter
-    def orientation(self, orientation):
-        self._orientation = orientation
+    def orientation(self, value):
+        self._orientation = value
         self._realign()
-
-    @property
-    def recenter(self):
-        return self._recenter
 
     @recenter.setter
-    def recenter(self, recenter):
-        self._recenter = recenter
+    def recenter(self, value):
+        self._recenter = value
         self._realign()
 
-    @property
-    def columnFactors(self):
-        return self._columnFactors
-
     @columnFactors.setter
-    def columnFactors(self, columnFactors):
-        try:
-            self._columnFactors = [cf*1.0 for cf in columnFactors[:3]]
-        except Exception:  # noqa: BLE001 -- not three numbers
-            self._columnFactors = [1, 1, 1]
-        if self._fileName is not None:
-            self.read_file(self.fileName)
-            self._realign()
-
-    @property
-    def fileName(self):
-        return self._fileName
+    def columnFactors(self, value):
+        self._columnFactors = _three_factors(value)
+        self._reload()
 
     @fileName.setter
-    def fileName(self, fileName):
-        self._fileName = fileName
-        if fileName is None:
+    def fileName(self, value):
+        self._fileName = value
+        if value is None:
             self._init_empty()
         else:
-            self.read_file(fileName)
-            self._realign()
+            self._reload()
 
     def read_file(self, fileName):
         if not os.path.isfile(str(fileName)):
             raise ValueError('The figure error file does not exist')
-        data = np.loadtxt(str(fileName))
-        if data.ndim != 2 or data.shape[1] < 3:
+        table = np.loadtxt(str(fileName))
+        if table.ndim != 2 or table.shape[1] < 3:
             raise ValueError('Invalid figure error file')
-        x, y, z = [col * f for col, f in zip(data.T[:3], self.columnFactors)]
-        self.surfArrays = {'x': x, 'y': y, 'z': z}
+        self.surfArrays = {axis: column * factor for axis, column, factor in
+                           zip('xyz', table.T[:3], self._columnFactors)}
 
     def align_arrays(self):
-        order = str(self.orientation).lower()
-        x, y, z = (self.surfArrays.get(order[0]), self.surfArrays.get(order[1]),
-                   self.surfArrays.get(order[-1]))
+        """File columns -> the (y, x) grid of the map (figure_error.py:384-431)."""
+        names = str(self.orientation).lower()
+        x, y, z = (self.surfArrays.get(names[0]), self.surfArrays.get(names[1]),
+                   self.surfArrays.get(names[-1]))
         if self.recenter:
             x -= 0.5*(np.min(x) + np.max(x))
             y -= 0.5*(np.min(y) + np.max(y))
-        self._limPhysX = [np.min(x), np.max(x)]
-        self._limPhysY = [np.min(y), np.max(y)]
-        x1d, y1d = np.unique(x), np.unique(y)
-        nx, ny = len(x1d), len(y1d)
-        if nx*ny != len(x):
+        self._limPhysX, self._limPhysY = [np.min(x), np.max(x)], [np.min(y), np.max(y)]
+        xs, ys = np.unique(x), np.unique(y)
+        if len(xs) * len(ys) != len(x):
             print('Input data does not form a grid')
             return
-        self.nx, self.ny = nx, ny
-        by_rows = np.all(np.diff(x[:nx]) > 0) and np.all(y[:nx] == y[0])
-        z2d = z.reshape((ny, nx)) if by_rows else z.reshape((nx, ny)).T
-        self.x1d, self.y1d = x1d, y1d
-        self.x2d, self.y2d = np.meshgrid(self.x1d, self.y1d)
-        self.z2d = z2d
+        self.nx, self.ny = len(xs), len(ys)
+        x_runs_first = np.all(np.diff(x[:self.nx]) > 0) and np.all(y[:self.nx] == y[0])
+        self.z2d = z.reshape((self.ny, self.nx)) if x_runs_first else \
+            z.reshape((self.nx, self.ny)).T
+        self.x1d, self.y1d = xs, ys
+        self.x2d, self.y2d = np.meshgrid(xs, ys)
         self.get_angles()
 
     def _init_empty(self):
-        self.x1d = np.array(np.linspace(-1, 1, 5))
-        self.y1d = np.array(np.linspace(-1, 1, 5))
-        self.nx, self.ny = len(self.x1d), len(self.y1d)
+        """No file: a flat map on a 5 x 5 grid."""
+        self.x1d = self.y1d = np.array(np.linspace(-1, 1, 5))
+        self.nx = self.ny = 5
         self.x2d, self.y2d = np.meshgrid(self.x1d, self.y1d)
-        self.z2d = np.zeros((self.ny, self.nx))
-        self.local_z_spline = interpolate.RectBivariateSpline(
-            self.y1d, self.x1d, self.z2d, kx=self.splineOrder, ky=self.splineOrder)
-        self._device = {}
+        self.z2d = np.zeros((5, 5))
+        self._fit(self.z2d)
         self.get_angles()
 
-    def get_grids(self):
+    def get_grids(self):            # (the grid is the file's)
         pass
 
     def get_dimensions(self):
         pass
 
-    def generate_profile(self):
-        base_z = self._base_profile()
-        z = self.z2d if (self.surfArrays and self.z2d is not None) else np.zeros_like(self.x2d)
-        return z + base_z
+    def _own_profile(self):
+        if self.surfArrays and self.z2d is not None:
+            return self.z2d
+        return np.zeros_like(self.x2d)

@@ -581,14 +581,18 @@ __device__ __forceinline__ int fe_interval(const double* __restrict__ t, int n, 
   while (l < last && arg >= t[l + 1]) ++l;
   return l;
 }
-__device__ __forceinline__ void fe_basis(const double* __restrict__ t, int k, double x, int l,
-                                         double (&h)[4]) {
-  double hh[3];
+template <int K>
+__device__ __forceinline__ void fe_basis(const double* __restrict__ t, double x, int l,
+                                         double (&h)[K + 1]) {
+  // (compile-time degree: the recurrence unrolls and h stays in registers)
+  double hh[K + 1];
   h[0] = 1.;
-  h[1] = h[2] = h[3] = 0.;
-  for (int j = 1; j <= k; ++j) {
+#pragma unroll
+  for (int j = 1; j <= K; ++j) {
+#pragma unroll
     for (int i = 0; i < j; ++i) hh[i] = h[i];
     h[0] = 0.;
+#pragma unroll
     for (int i = 0; i < j; ++i) {
       const double hi = t[l + 1 + i], lo = t[l + 1 + i - j];
       const double f = hh[i] / (hi - lo);
@@ -597,34 +601,48 @@ __device__ __forceinline__ void fe_basis(const double* __restrict__ t, int k, do
     }
   }
 }
-// the spline of degrees (ku, kv) on knots tu [nu], tv [nv] with coefficients c (row = u) at (u, v)
-__device__ __forceinline__ double fe_spline(const double* __restrict__ tu, int nu, int ku,
-                                            const double* __restrict__ tv, int nv, int kv,
-                                            const double* __restrict__ c, double u, double v) {
-  const int lu = fe_interval(tu, nu, ku, u), lv = fe_interval(tv, nv, kv, v);
-  double hu[4], hv[4];
-  fe_basis(tu, ku, u, lu, hu);
-  fe_basis(tv, kv, v, lv, hv);
-  const int ncv = nv - kv - 1;
-  const double* row = c + (int64_t)(lu - ku) * ncv + (lv - kv);
+// the spline of degrees (KU, KV) on knots tu [nu], tv [nv] with coefficients c (row = u) at (u, v)
+template <int KU, int KV>
+__device__ __forceinline__ double fe_spline_k(const double* __restrict__ tu, int nu,
+                                              const double* __restrict__ tv, int nv,
+                                              const double* __restrict__ c, double u, double v) {
+  const int lu = fe_interval(tu, nu, KU, u), lv = fe_interval(tv, nv, KV, v);
+  double hu[KU + 1], hv[KV + 1];
+  fe_basis<KU>(tu, u, lu, hu);
+  fe_basis<KV>(tv, v, lv, hv);
+  const int ncv = nv - KV - 1;
+  const double* row = c + (int64_t)(lu - KU) * ncv + (lv - KV);
   double sp = 0.;
-  for (int i = 0; i <= ku; ++i, row += ncv)
-    for (int j = 0; j <= kv; ++j) sp += row[j] * hu[i] * hv[j];
+#pragma unroll
+  for (int i = 0; i <= KU; ++i, row += ncv) {
+#pragma unroll
+    for (int j = 0; j <= KV; ++j) sp += row[j] * hu[i] * hv[j];
+  }
   return sp;
+}
+// du, dv: 1 = the partial derivative along that axis (one degree less, FITPACK's parder)
+template <int DU, int DV>
+__device__ __forceinline__ double fe_spline(int k, const double* __restrict__ tu, int nu,
+                                            const double* __restrict__ tv, int nv,
+                                            const double* __restrict__ c, double u, double v) {
+  if (k == 3) return fe_spline_k<3 - DU, 3 - DV>(tu, nu, tv, nv, c, u, v);
+  if (k == 2) return fe_spline_k<2 - DU, 2 - DV>(tu, nu, tv, nv, c, u, v);
+  return fe_spline_k<1 - DU, 1 - DV>(tu, nu, tv, nv, c, u, v);
 }
 // local_z_distorted, figure_error.py:214-235 [mm]
 __device__ __forceinline__ double figure_height(const xrt_hip_pass& P, double x, double y) {
-  return fe_spline(P.fe_ty, P.fe_nty, P.fe_k, P.fe_tx, P.fe_ntx, P.fe_k, P.fe_c,
-                   y + P.fe_shift[1], x + P.fe_shift[0]) * 1e-6;
+  return fe_spline<0, 0>(P.fe_k, P.fe_ty, P.fe_nty, P.fe_tx, P.fe_ntx, P.fe_c,
+                         y + P.fe_shift[1], x + P.fe_shift[0]) * 1e-6;
 }
 // local_n_distorted -> [d_pitch, d_roll] (figure_error.py:237-265) applied to the surface
 // normal as reflect.py:767-775 does: rotate_x by d_pitch, then rotate_y by d_roll
 __device__ __forceinline__ void figure_turn_normal(const xrt_hip_pass& P, double x, double y,
                                                    double& nx, double& ny, double& nz) {
   const double u = y + P.fe_shift[1], v = x + P.fe_shift[0];
-  const int k = P.fe_k;
-  const double a = fe_spline(P.fe_ty, P.fe_nty, k, P.fe_tx + 1, P.fe_ntx - 2, k - 1, P.fe_cx, u, v) * 1e-6;
-  const double b = fe_spline(P.fe_ty + 1, P.fe_nty - 2, k - 1, P.fe_tx, P.fe_ntx, k, P.fe_cy, u, v) * 1e-6;
+  const double a = fe_spline<0, 1>(P.fe_k, P.fe_ty, P.fe_nty, P.fe_tx + 1, P.fe_ntx - 2, P.fe_cx,
+                                   u, v) * 1e-6;
+  const double b = fe_spline<1, 0>(P.fe_k, P.fe_ty + 1, P.fe_nty - 2, P.fe_tx, P.fe_ntx, P.fe_cy,
+                                   u, v) * 1e-6;
   double sX, cX, sY, cY;
   sincos(atan(b), &sX, &cX);
   sincos(-atan(a), &sY, &cY);
