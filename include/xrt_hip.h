@@ -308,19 +308,31 @@ typedef struct xrt_hip_pass {
   const double* eff_tab_I;
   /* OE(figureError = ...) (oes/base.py:681-684, 744-770, 826-830; figure_error.py:207-265): a
    * height map [nm] on the surface, held as the tensor-product spline scipy's
-   * RectBivariateSpline(y1d, x1d, z) makes of it -- first spline axis = the element's y.
-   * fe_ty [fe_nty] / fe_tx [fe_ntx]: its knots, fe_c [(fe_nty - fe_k - 1) * (fe_ntx - fe_k - 1)]
-   * its coefficients (row = y), degree fe_k (1..3) on both axes; fe_cy / fe_cx: the
-   * coefficients of its partial derivatives along y / x (FITPACK's parder: degree fe_k - 1 on
-   * that axis, knots without the first and the last one). All DEVICE arrays. The height at
-   * (x + fe_shift[0], y + fe_shift[1]) * 1e-6 is added to local_z inside the intersection
-   * search (find_dz); at the hit point the normal is turned about x by atan(dz/dy) and then
-   * about y by -atan(dz/dx) (reflect.py:767-775). Arguments outside the knot range evaluate at
-   * its edge (FITPACK's fpbisp). fe_c NULL: no figure error. Not with parametric surfaces,
-   * user-defined surfaces or layered materials. */
+   * RectBivariateSpline(y1d, x1d, z) makes of it -- first spline axis = the element's y --
+   * of degree fe_k (1..3) on both axes. fe_ty [fe_nty] / fe_tx [fe_ntx]: its knots. Its
+   * coefficients come as PAIRS of rows: with C [ncy][ncx] (ncy = fe_nty - fe_k - 1, ncx =
+   * fe_ntx - fe_k - 1, row = y) fe_c [ncy][ncx][2] holds (C[i][j], C[i + 1][j]), the last
+   * row paired with zeros (a kernel reads a 4 x 4 block as 8 loads of 16 bytes); fe_cy / fe_cx
+   * hold in the same form the coefficients of the partial derivatives along y / x as FITPACK's
+   * parder forms them: [ncy - 1][ncx][2] and [ncy][ncx - 1][2], one degree less on that axis,
+   * knots without the first and the last one. All DEVICE arrays, 16-byte aligned.
+   * fe_grid[a] (a = 0: y, 1: x) != 0: the knots of that axis are those of an interpolating
+   * spline through a numpy linspace of N = n - 4 nodes -- x[0] four times, x[2] .. x[N - 3],
+   * x[N - 1] four times with x[j] = j * fe_step[a] + fe_lo[a] (a product, then a sum) and
+   * x[N - 1] = fe_hi[a] -- and the kernels compute them instead of loading them (the caller
+   * has compared the knots with this formula bit for bit), and fe_inv[a][j - 1] = 1 / (j *
+   * fe_step[a]), j = 1..3, stands for the division by a difference of j interior knots; 0: the
+   * knots are loaded.
+   * The height at (x + fe_shift[0], y + fe_shift[1]) * 1e-6 is added to local_z inside the
+   * intersection search (find_dz); at the hit point the normal is turned about x by
+   * atan(dz/dy) and then about y by -atan(dz/dx) (reflect.py:767-775). Arguments outside the
+   * knot range evaluate at its edge (FITPACK's fpbisp). fe_c NULL: no figure error. Not with
+   * parametric surfaces, user-defined surfaces or layered materials. */
   int32_t fe_ntx, fe_nty, fe_k, fe_reserved;
   const double *fe_tx, *fe_ty, *fe_c, *fe_cx, *fe_cy;
   double fe_shift[2];
+  int32_t fe_grid[2];
+  double fe_lo[2], fe_step[2], fe_hi[2], fe_inv[2][3];
 } xrt_hip_pass;
 
 /* ---- user-defined surfaces -------------------------------------------------------------

@@ -115,6 +115,28 @@ def test_the_c_abi_refuses_what_the_kernels_do_not_hold():
     assert rc != 0 and b'figure' not in why
 
 
+def test_linspace_knots_and_paired_rows():
+    """What the kernels compute instead of loading: the knots of a generated map are a linspace's
+    (bit for bit, or the flag stays down -- a map from a file with uneven steps); coefficients
+    travel as pairs of rows."""
+    fe = fc.figure_error('g2_figure_flat')
+    k, ty, tx, c, cy, cx = fe.spline_arrays()
+    for t, nodes in ((ty, fe.y1d), (tx, fe.x1d)):
+        lo, step, hi = fe.linspace_of(t, k)
+        assert (lo, hi) == (nodes[0], nodes[-1]) and step == (hi - lo) / (len(nodes) - 1)
+        i = np.arange(4, len(t) - 4)
+        assert np.array_equal((i - 2) * step + lo, t[4:-4])
+    uneven = ty.copy()
+    uneven[10] += 1e-9
+    assert fe.linspace_of(uneven, k) is None and fe.linspace_of(ty, 2) is None
+    # (the map file's 1-mm and 0.5-mm steps ARE such grids; one moved node is not)
+    imported = fc.figure_error('g2_figure_imported')
+    assert imported.linspace_of(imported.spline_arrays()[1], 3) == (-80., 1., 80.)
+    p = fe.paired_rows(c)
+    assert p.shape == c.shape + (2,) and np.array_equal(p[..., 0], c)
+    assert np.array_equal(p[:-1, :, 1], c[1:]) and not p[-1, :, 1].any()
+
+
 def test_pass_record_carries_the_spline():
     g = load('g2_figure_flat')
     oe = fc.element('g2_figure_flat', g)
@@ -131,6 +153,7 @@ def test_pass_record_carries_the_spline():
         return
     rec = oe.figureError.device_record(torch.device('cuda', 0))
     assert rec['k'] == 3 and rec['nty'] == len(g['fe_ty']) and rec['ntx'] == len(g['fe_tx'])
+    assert all(grid is not None for grid in rec['grid'])
 
 
 # ------------------------------------------------------------------------------ GPU

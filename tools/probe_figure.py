@@ -18,7 +18,15 @@ for label, step in (('toroid + roughness map 512 x 128', 2.), ('toroid + roughne
                                 limPhysY=[-300, 300], gridStep=step)
     print(label, 'spline', len(fe.local_z_spline.tck[0]), 'x', len(fe.local_z_spline.tck[1]), 'knots')
     cases.append((label, fc.element('g2_figure_toroid', g, fe)))
-for name, oe in cases:
+# the same rays pulled towards the axis: every ray lands on the mirror (no lane of a wave at the
+# ends of the knot sequence: the computed-knot path serves whole waves)
+narrow = workloads.synthetic_rays(n, 42)
+for f in ('x', 'a'):
+    narrow.dev(f).mul_(0.2)
+for f in narrow.array_fields():
+    narrow.dev(f)
+runs = [(name, oe, beam) for name, oe in cases] + [(cases[1][0] + ', underfilled', cases[1][1], narrow)]
+for name, oe, beam in runs:
     out = None
     for _ in range(5):
         out = oe.reflect(beam, out=out)

@@ -96,6 +96,11 @@ class Pass(ctypes.Structure):
         ('fe_cx', ctypes.c_void_p),
         ('fe_cy', ctypes.c_void_p),
         ('fe_shift', ctypes.c_double * 2),
+        ('fe_grid', ctypes.c_int32 * 2),
+        ('fe_lo', ctypes.c_double * 2),
+        ('fe_step', ctypes.c_double * 2),
+        ('fe_hi', ctypes.c_double * 2),
+        ('fe_inv', (ctypes.c_double * 3) * 2),
     ]
 
 

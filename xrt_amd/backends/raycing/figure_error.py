@@ -196,20 +196,49 @@ class FigureErrorBase(object):
         return k, np.ascontiguousarray(ty, dtype=float), np.ascontiguousarray(tx, dtype=float), \
             np.ascontiguousarray(c), np.ascontiguousarray(cy), np.ascontiguousarray(cx)
 
+    @staticmethod
+    def paired_rows(c):
+        """[rows][cols] -> [rows][cols][2] with (c[i][j], c[i + 1][j]), zeros under the last row:
+        the form the kernels read coefficients in (two rows per 16-byte load)."""
+        below = np.vstack([c[1:], np.zeros((1, c.shape[1]))])
+        return np.ascontiguousarray(np.stack([c, below], axis=-1))
+
+    @staticmethod
+    def linspace_of(knots, k):
+        """(lo, step, hi) if the knots are those of an interpolating cubic spline through a
+        numpy linspace -- x[0] four times, x[2] .. x[N - 3], x[N - 1] four times, x[j] = j * step +
+        lo in linspace's two roundings -- bit for bit, else None. The kernels then compute the
+        knots instead of loading them."""
+        n = len(knots) - 4
+        if k != 3 or n < 8:
+            return None
+        lo, hi = float(knots[0]), float(knots[-1])
+        step = (hi - lo) / (n - 1)
+        nodes = np.arange(0, n) * step + lo
+        nodes[-1] = hi
+        built = np.concatenate([[lo] * 4, nodes[2:n - 2], [hi] * 4])
+        if step > 0 and np.array_equal(built, knots):
+            return lo, step, hi
+        return None
+
     def device_record(self, device):
         """The spline in HBM (one block, kept per device until the map changes) ->
-        dict(k, nty, ntx, ty, tx, c, cy, cx: device addresses, shift)."""
+        dict(k, nty, ntx; ty, tx, c, cy, cx: device addresses; grid, shift): the knots, the
+        coefficients and those of the two partial derivatives as paired rows, and per axis
+        (y, x) the linspace its knots follow, if they do."""
         import torch
         key = str(device)
         if key not in self._device:
             k, ty, tx, c, cy, cx = self.spline_arrays()
-            parts = [ty, tx, c.ravel(), cy.ravel(), cx.ravel()]
+            parts = [ty, tx, self.paired_rows(c).ravel(), self.paired_rows(cy).ravel(),
+                     self.paired_rows(cx).ravel()]
+            parts = [np.concatenate([p, np.zeros(len(p) % 2)]) for p in parts]   # 16-B starts
             block = torch.from_numpy(np.concatenate(parts)).to(device)
             offsets = np.cumsum([0] + [len(p) for p in parts[:-1]])
-            base = block.data_ptr()
-            addr = [base + 8 * int(o) for o in offsets]
+            addr = [block.data_ptr() + 8 * int(o) for o in offsets]
             self._device[key] = dict(k=k, nty=len(ty), ntx=len(tx), ty=addr[0], tx=addr[1],
-                                     c=addr[2], cy=addr[3], cx=addr[4], _keep=block)
+                                     c=addr[2], cy=addr[3], cx=addr[4], _keep=block,
+                                     grid=(self.linspace_of(ty, k), self.linspace_of(tx, k)))
         rec = dict(self._device[key])
         rec['shift'] = (float(self.xShift), float(self.yShift))
         return rec

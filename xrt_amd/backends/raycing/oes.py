@@ -170,6 +170,12 @@ class OE(object):
         p.fe_ty, p.fe_tx, p.fe_c = rec['ty'], rec['tx'], rec['c']
         p.fe_cy, p.fe_cx = rec['cy'], rec['cx']
         p.fe_shift[0], p.fe_shift[1] = rec['shift']
+        for axis, grid in enumerate(rec['grid']):       # (y, x): knots the kernels compute
+            p.fe_grid[axis] = 0 if grid is None else 1
+            if grid is not None:
+                p.fe_lo[axis], p.fe_step[axis], p.fe_hi[axis] = grid
+                for j in range(3):
+                    p.fe_inv[axis][j] = 1. / ((j + 1) * grid[1])
         p._keep_fe = rec['_keep']
 
     def _surface_params(self, p, second=False):

@@ -303,6 +303,11 @@ static int check_pass(const xrt_hip_pass* pass, const xrt_hip_material* material
         pass->fe_k > 3 || pass->fe_ntx < 2 * pass->fe_k + 2 || pass->fe_nty < 2 * pass->fe_k + 2)
       return fail(XRT_HIP_ERR_ARG, "figure error: knots, coefficients and both derivative "
                                    "arrays of a spline of degree 1..3");
+    for (int a = 0; a < 2; ++a)
+      if (pass->fe_grid[a] && (pass->fe_k != 3 || !(pass->fe_step[a] > 0.) ||
+                               !(pass->fe_hi[a] > pass->fe_lo[a])))
+        return fail(XRT_HIP_ERR_ARG, "figure error: computed knots need a cubic spline and an "
+                                     "ascending grid");
     if (pass->surf_kind == XRT_HIP_SURF_USER || pass->surf_kind == XRT_HIP_SURF_ELLIPSE_PARAM)
       return fail(XRT_HIP_ERR_ARG, "figure error on a parametric or user-defined surface is "
                                    "not supported");

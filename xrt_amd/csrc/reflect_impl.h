@@ -354,6 +354,9 @@ struct PerRayZones : Spec<0, -1, -1, false> {
 template <int F_>
 struct Figured : Spec<F_, -1, -1, false> {
   static constexpr bool FE = true;
+  // (the 4 x 4 coefficient block and two sets of basis functions on top of the generic pass:
+  // 22 VGPRs spilled at four waves per SIMD, none at three)
+  static constexpr int WAVES = XRT_LAYERED_WAVES;
 };
 using Layered0 = Spec<0, -1, XRT_HIP_MAT_MULTILAYER, false>;
 using Layered1 = Spec<1, -1, XRT_HIP_MAT_MULTILAYER, false>;
@@ -564,27 +567,59 @@ __device__ __forceinline__ Facet diced_facet(const xrt_hip_pass& P, double x, do
 // surface height, oes/base.py:675-679 (flat), oes/__init__.py:398-401 (toroid)
 // ---------------------------------------------------------------------------
 // Figure error: scipy's RectBivariateSpline.ev (FITPACK bispev / parder) on the device.
-// fe_interval = fpbisp's argument clamp and knot search (the guess by scaling is exact for
-// the uniform interior knots of a linspace grid; the loops fix the ends of a not-a-knot
-// sequence and serve any other grid), fe_basis = fpbspl's recurrence for the k + 1 B-splines
-// that are not zero on the interval, fe_sum = fpbisp's double sum in its order.
+// fe_interval = fpbisp's argument clamp and knot search (a guess by scaling, exact for the
+// uniform interior of a linspace grid, corrected against the knots), fe_basis = fpbspl's
+// recurrence for the K + 1 B-splines that are not zero on the interval, fe_spline_k = fpbisp's
+// double sum in its order.
+// What bounds it is the number of scattered loads -- every lane is somewhere else on the map,
+// a gather of 64 addresses occupies the CU's address unit for 16 cycles, and the root search
+// evaluates the map ~9 times per ray one after the other. The first version read 12 knots and
+// 16 coefficients per evaluation (3.2 ms per 1e7 rays). Now:
+//   * knots are COMPUTED where the map's grid is a numpy linspace (every generated map): the
+//     not-a-knot sequence is x[0] four times, x[2] .. x[N - 3], x[N - 1] four times with
+//     x[j] = j * step + lo in linspace's own two roundings -- the same bits, no load (FeKnots;
+//     the host checks the knots against the formula before it sets fe_grid; maps read from a
+//     file keep the loads);
+//   * coefficients come as PAIRS of rows, pc[i][j] = (c[i][j], c[i + 1][j]): a 4 x 4 block is
+//     8 loads of 16 B instead of 16 of 8 B.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int fe_interval(const double* __restrict__ t, int n, int k,
-                                           double& arg) {
-  const double tb = t[k], te = t[n - k - 1];
+struct FeKnots {
+  const double* t;      // the knots (used when !grid)
+  int n;                // their number
+  int off;              // index shift: the derivative axes drop the first knot (off = 1)
+  int grid;             // computed: t[i] = x[clamp(i - 2)] of a linspace
+  double lo, step, hi;  // x[0], linspace's step, x[N - 1]; N = n0 - 4 nodes (n0 = n + 2 off)
+  double inv[3];        // 1 / (j step), j = 1..3: the knot differences of the uniform interior
+  // the 2 K knots fpbspl reads on interval l all lie in the uniform interior
+  __device__ __forceinline__ bool inner(int l, int K) const {
+    return grid && l + 1 - K + off >= 4 && l + K + off < n + 2 * off - 4;
+  }
+  __device__ __forceinline__ double at(int i) const {
+    if (!grid) return t[i];
+    const int i0 = i + off, n0 = n + 2 * off;
+    if (i0 < 4) return lo;
+    if (i0 >= n0 - 4) return hi;
+    return (double)(i0 - 2) * step + lo;
+  }
+};
+template <int K>
+__device__ __forceinline__ int fe_interval(const FeKnots& T, double& arg) {
+  const double tb = T.at(K), te = T.at(T.n - K - 1);
   if (arg < tb) arg = tb;
   if (arg > te) arg = te;
-  const int last = n - k - 2;                   // l <= last: t[l] <= arg <= t[l + 1]
-  int l = k + (int)((arg - tb) / (te - tb) * (double)(last - k + 1));
-  l = l < k ? k : (l > last ? last : l);
-  while (l > k && arg < t[l]) --l;
-  while (l < last && arg >= t[l + 1]) ++l;
+  const int last = T.n - K - 2;                 // l <= last: t[l] <= arg <= t[l + 1]
+  int l = K + (int)((arg - tb) * frcp(te - tb) * (double)(last - K + 1));
+  l = l < K ? K : (l > last ? last : l);
+  while (l > K && arg < T.at(l)) --l;
+  while (l < last && arg >= T.at(l + 1)) ++l;
   return l;
 }
 template <int K>
-__device__ __forceinline__ void fe_basis(const double* __restrict__ t, double x, int l,
-                                         double (&h)[K + 1]) {
+__device__ __forceinline__ void fe_basis(const FeKnots& T, double x, int l, double (&h)[K + 1]) {
   // (compile-time degree: the recurrence unrolls and h stays in registers)
+  double kn[2 * K > 0 ? 2 * K : 1];
+#pragma unroll
+  for (int i = 0; i < 2 * K; ++i) kn[i] = T.at(l + 1 - K + i);      // t[l + 1 - K .. l + K]
   double hh[K + 1];
   h[0] = 1.;
 #pragma unroll
@@ -594,44 +629,125 @@ __device__ __forceinline__ void fe_basis(const double* __restrict__ t, double x,
     h[0] = 0.;
 #pragma unroll
     for (int i = 0; i < j; ++i) {
-      const double hi = t[l + 1 + i], lo = t[l + 1 + i - j];
+      const double hi = kn[K + i], lo = kn[K + i - j];     // t[l + 1 + i], t[l + 1 + i - j]
       const double f = hh[i] / (hi - lo);
       h[i] = h[i] + f * (hi - x);
       h[i + 1] = f * (x - lo);
     }
   }
 }
-// the spline of degrees (KU, KV) on knots tu [nu], tv [nv] with coefficients c (row = u) at (u, v)
+// One axis of a map on a linspace grid, everything from the ray's coordinate: clamp, interval by
+// scaling, the 2 K knots from ONE integer conversion (x[j] = j step + lo), the recurrence with
+// products by 1 / (j step) where FITPACK divides by a difference of j knots (the quotient by the
+// rounded difference and the product differ in the last bit or two -- of nanometres). false:
+// the interval touches the ends of the knot sequence, or the scaled guess missed it by one --
+// the wave then takes fe_interval / fe_basis. (Through T.at() each of the 20 knots an
+// evaluation looks at cost a conversion, two comparisons and two selects: 240 of its 440
+// issue slots; this form takes ~60 per axis.)
+template <int K>
+__device__ __forceinline__ bool fe_axis_grid(const FeKnots& T, double& arg, int& l,
+                                             double (&h)[K + 1]) {
+  if (arg < T.lo) arg = T.lo;
+  if (arg > T.hi) arg = T.hi;
+  const int last = T.n - K - 2;
+  // (node j = floor((arg - lo) / step) lies at knot j + 2 of the full sequence: two nodes are
+  // not knots of a not-a-knot spline)
+  l = 2 - T.off + (int)((arg - T.lo) * T.inv[0]);
+  l = l < K ? K : (l > last ? last : l);
+  const double d0 = (double)(l + T.off - K - 1);
+  double kn[2 * K > 0 ? 2 * K : 2];
+#pragma unroll
+  for (int i = 0; i < 2 * K; ++i) kn[i] = (d0 + (double)i) * T.step + T.lo;
+  if (K == 0) {
+    kn[0] = d0 * T.step + T.lo;
+    kn[1] = (d0 + 1.) * T.step + T.lo;
+  }
+  constexpr int LO = K > 0 ? K - 1 : 0;
+  const bool ok = T.inner(l, K > 0 ? K : 1) && arg >= kn[LO] && arg < kn[LO + 1];
+  double hh[K + 1];
+  h[0] = 1.;
+#pragma unroll
+  for (int j = 1; j <= K; ++j) {
+#pragma unroll
+    for (int i = 0; i < j; ++i) hh[i] = h[i];
+    h[0] = 0.;
+#pragma unroll
+    for (int i = 0; i < j; ++i) {
+      const double f = hh[i] * T.inv[j - 1];
+      h[i] = h[i] + f * (kn[K + i] - arg);
+      h[i + 1] = f * (arg - kn[K + i - j]);
+    }
+  }
+  return ok;
+}
+// the spline of degrees (KU, KV) on knots U, V with paired coefficient rows pc (row = u) at (u, v)
 template <int KU, int KV>
-__device__ __forceinline__ double fe_spline_k(const double* __restrict__ tu, int nu,
-                                              const double* __restrict__ tv, int nv,
-                                              const double* __restrict__ c, double u, double v) {
-  const int lu = fe_interval(tu, nu, KU, u), lv = fe_interval(tv, nv, KV, v);
+__device__ __forceinline__ double fe_spline_k(const FeKnots& U, const FeKnots& V,
+                                              const double* __restrict__ pc, double u, double v) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  int lu, lv;
   double hu[KU + 1], hv[KV + 1];
-  fe_basis<KU>(tu, u, lu, hu);
-  fe_basis<KV>(tv, v, lv, hv);
-  const int ncv = nv - KV - 1;
-  const double* row = c + (int64_t)(lu - KU) * ncv + (lv - KV);
+  bool have = false;
+  if (U.grid && V.grid) {
+    const bool oku = fe_axis_grid<KU>(U, u, lu, hu);
+    const bool okv = fe_axis_grid<KV>(V, v, lv, hv);
+    have = __builtin_amdgcn_ballot_w64(!(oku && okv)) == 0ull;   // (the whole wave, or none of it)
+  }
+  if (!have) {
+    lu = fe_interval<KU>(U, u);
+    lv = fe_interval<KV>(V, v);
+  }
+  const int ncv = V.n - KV - 1;
+  const v2d* row = reinterpret_cast<const v2d*>(pc) + (int64_t)(lu - KU) * ncv + (lv - KV);
+  // (requested before the basis is worked out) rows i and i + 1 arrive together
+  double cf[KU + 2][KV + 1];
+#pragma unroll
+  for (int i = 0; i <= KU; i += 2) {
+#pragma unroll
+    for (int j = 0; j <= KV; ++j) {
+      const v2d q = row[(int64_t)i * ncv + j];
+      cf[i][j] = q.x;
+      cf[i + 1][j] = q.y;
+    }
+  }
+  if (!have) {
+    fe_basis<KU>(U, u, lu, hu);
+    fe_basis<KV>(V, v, lv, hv);
+  }
   double sp = 0.;
 #pragma unroll
-  for (int i = 0; i <= KU; ++i, row += ncv) {
+  for (int i = 0; i <= KU; ++i) {
 #pragma unroll
-    for (int j = 0; j <= KV; ++j) sp += row[j] * hu[i] * hv[j];
+    for (int j = 0; j <= KV; ++j) sp += cf[i][j] * hu[i] * hv[j];
   }
   return sp;
 }
-// du, dv: 1 = the partial derivative along that axis (one degree less, FITPACK's parder)
+// DU, DV: 1 = the partial derivative along that axis (one degree less, FITPACK's parder)
 template <int DU, int DV>
-__device__ __forceinline__ double fe_spline(int k, const double* __restrict__ tu, int nu,
-                                            const double* __restrict__ tv, int nv,
-                                            const double* __restrict__ c, double u, double v) {
-  if (k == 3) return fe_spline_k<3 - DU, 3 - DV>(tu, nu, tv, nv, c, u, v);
-  if (k == 2) return fe_spline_k<2 - DU, 2 - DV>(tu, nu, tv, nv, c, u, v);
-  return fe_spline_k<1 - DU, 1 - DV>(tu, nu, tv, nv, c, u, v);
+__device__ __forceinline__ double fe_spline(int k, const FeKnots& U, const FeKnots& V,
+                                            const double* __restrict__ pc, double u, double v) {
+  if (k == 3) return fe_spline_k<3 - DU, 3 - DV>(U, V, pc, u, v);
+  if (k == 2) return fe_spline_k<2 - DU, 2 - DV>(U, V, pc, u, v);
+  return fe_spline_k<1 - DU, 1 - DV>(U, V, pc, u, v);
+}
+// the knots of axis 0 (y) / 1 (x) of the pass's map; deriv: without the first and the last one
+__device__ __forceinline__ FeKnots fe_knots(const xrt_hip_pass& P, int axis, int deriv) {
+  FeKnots T;
+  T.t = (axis ? P.fe_tx : P.fe_ty) + deriv;
+  T.n = (axis ? P.fe_ntx : P.fe_nty) - 2 * deriv;
+  T.off = deriv;
+  T.grid = P.fe_grid[axis];
+  T.lo = P.fe_lo[axis];
+  T.step = P.fe_step[axis];
+  T.hi = P.fe_hi[axis];
+  T.inv[0] = P.fe_inv[axis][0];
+  T.inv[1] = P.fe_inv[axis][1];
+  T.inv[2] = P.fe_inv[axis][2];
+  return T;
 }
 // local_z_distorted, figure_error.py:214-235 [mm]
 __device__ __forceinline__ double figure_height(const xrt_hip_pass& P, double x, double y) {
-  return fe_spline<0, 0>(P.fe_k, P.fe_ty, P.fe_nty, P.fe_tx, P.fe_ntx, P.fe_c,
+  return fe_spline<0, 0>(P.fe_k, fe_knots(P, 0, 0), fe_knots(P, 1, 0), P.fe_c,
                          y + P.fe_shift[1], x + P.fe_shift[0]) * 1e-6;
 }
 // local_n_distorted -> [d_pitch, d_roll] (figure_error.py:237-265) applied to the surface
@@ -639,10 +755,8 @@ __device__ __forceinline__ double figure_height(const xrt_hip_pass& P, double x,
 __device__ __forceinline__ void figure_turn_normal(const xrt_hip_pass& P, double x, double y,
                                                    double& nx, double& ny, double& nz) {
   const double u = y + P.fe_shift[1], v = x + P.fe_shift[0];
-  const double a = fe_spline<0, 1>(P.fe_k, P.fe_ty, P.fe_nty, P.fe_tx + 1, P.fe_ntx - 2, P.fe_cx,
-                                   u, v) * 1e-6;
-  const double b = fe_spline<1, 0>(P.fe_k, P.fe_ty + 1, P.fe_nty - 2, P.fe_tx, P.fe_ntx, P.fe_cy,
-                                   u, v) * 1e-6;
+  const double a = fe_spline<0, 1>(P.fe_k, fe_knots(P, 0, 0), fe_knots(P, 1, 1), P.fe_cx, u, v) * 1e-6;
+  const double b = fe_spline<1, 0>(P.fe_k, fe_knots(P, 0, 1), fe_knots(P, 1, 0), P.fe_cy, u, v) * 1e-6;
   double sX, cX, sY, cY;
   sincos(atan(b), &sX, &cX);
   sincos(-atan(a), &sY, &cY);
