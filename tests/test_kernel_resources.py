@@ -56,6 +56,13 @@ def test_hot_kernels_keep_their_budget():
     for mode in ('Li0', 'Li2'):
         lay = _one(table, 'reflect_fused_xtalINS_4SpecILi0ELin1ELi5ELb0EEE' + mode)
         assert lay['vgpr'] <= 168 and lay['vgpr_spill'] <= 56 and lay['scratch'] <= 224, lay
+    # OE(figureError=...): the generic pass + the height-map spline (a 4 x 4 coefficient block
+    # and two sets of basis functions), three waves per SIMD; families 0 and 2 without spills,
+    # family 1 (conic / blazed / lens code on top) bounded
+    for fam, spill in (('Li0', 0), ('Li1', 96), ('Li2', 0)):
+        for mode in ('Li0', 'Li2'):
+            fig = _one(table, 'reflect_fusedINS_7FiguredI%sEEE%s' % (fam, mode))
+            assert fig['vgpr'] <= 168 and fig['vgpr_spill'] <= spill and fig['scratch'] <= 320, fig
     for small in ('reflect_decide_opt', 'reflect_decide_dcm'):
         assert _one(table, small)['scratch'] == 0
     for name, r in table.items():
