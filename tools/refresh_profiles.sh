@@ -39,6 +39,11 @@ for P in probe_stream probe_occupancy probe_atomics probe_fp64_seeds probe_lds_a
   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/probes/$P.hip -o /tmp/$P 2>/dev/null && \
     timeout 300 /tmp/$P > profiles/r${RND}_$P.txt 2>&1
 done
+hipcc --offload-arch=gfx950 -O3 tools/probes/probe_stream_wide.hip -o /tmp/probe_stream_wide 2>/dev/null && \
+  timeout 300 /tmp/probe_stream_wide > profiles/r${RND}_probe_stream_wide.txt 2>&1
+# OE(figureError=...): the Figured kernel against the lean pass, and its SQ counters
+PYTHONPATH=.:tests timeout 600 python tools/probe_figure.py 2>&1 | grep -v amdgpu.ids > profiles/r${RND}_figure_pass.txt
+bash tools/pmc_figure.sh > profiles/r${RND}_figure_pmc.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -DNOUT=40 -DBLOCK=256 tools/probes/probe_occupancy.hip -o /tmp/po40 2>/dev/null && \
   timeout 300 /tmp/po40 > profiles/r${RND}_probe_occupancy_dcm_shape.txt 2>&1
 cp profiles/r${RND}_*.txt profiles/hist_traffic.json $O/summaries/ 2>/dev/null
