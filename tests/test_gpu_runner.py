@@ -195,6 +195,40 @@ def test_histograms_of_two_million_rays_match_numpy():
     assert abs(zoom.intensityInRange - ref.sum()) <= 1e-10 * ref.sum()
 
 
+@pytest.mark.parametrize('lines', [(9000.,), (8995., 9005.), (8991., 8996., 9000.5, 9009.)])
+def test_colour_histogram_of_a_few_energies(lines):
+    """A monochromatic beam (every ray in ONE bin of the energy axis) and beams of two and four
+    lines: the wave adds the weights of lanes that share a bin across its lanes before one of
+    them updates the cell (hist.hip: colour_line_update); sums against numpy / matplotlib."""
+    import matplotlib.colors as mc
+    n = 300_001
+    oe = workloads.cfg2_toroid()
+    beam = workloads.synthetic_rays(n, 11)
+    rng = np.random.default_rng(2)
+    beam.E[:] = np.asarray(lines)[rng.integers(0, len(lines), n)]
+    gb, lb = oe.reflect(beam)
+    plot = xrtp.XYCPlot('b', (1,), xrtp.XYCAxis('x', 'mm', bins=256),
+                        xrtp.XYCAxis('y', 'mm', bins=256),
+                        caxis=xrtp.XYCAxis('energy', 'eV', bins=128, limits=[8990., 9010.]))
+    xrtr.accumulate_plot(plot, {'b': lb})
+    sel = np.array(lb.state) == 1
+    e = np.array(lb.E)[sel]
+    flux = (np.array(lb.Jss) + np.array(lb.Jpp))[sel]
+    c01 = np.clip((e - 8990.) * plot.colorFactor / 20., 0., 1.).reshape(-1, 1)
+    hsv = np.dstack((c01, np.ones_like(c01) * plot.colorSaturation, flux.reshape(-1, 1)))
+    rgb = mc.hsv_to_rgb(hsv).reshape(-1, 3)
+    ref = np.zeros((128, 4))
+    ref[:, 0] = np.histogram(e, bins=128, range=(8990., 9010.), weights=flux)[0]
+    for k in range(3):
+        ref[:, 1 + k] = np.histogram(e, bins=128, range=(8990., 9010.), weights=rgb[:, k])[0]
+    assert (ref[:, 0] > 0).sum() == len(lines)
+    assert np.abs(plot.caxis.total1D4 - ref).max() <= 1e-10 * ref.max()
+    xl, yl = plot.xaxis.limits, plot.yaxis.limits
+    r2 = np.histogram2d(np.array(lb.y)[sel], np.array(lb.x)[sel], bins=[256, 256],
+                        range=[yl, xl], weights=flux)[0]
+    assert np.abs(plot.total2D - r2).max() <= 1e-10 * r2.max()
+
+
 @pytest.mark.parametrize('centre', [(0., 0.), (0.31, -0.52), (0.999, 0.999)])
 def test_histograms_of_a_focused_beam(centre):
     """All rays in a spot of a few bins -- what a screen at a focus shows: the spot sits on the
