@@ -336,7 +336,14 @@ struct RayData {
 
 // (only DIRECT needs the LDS of a whole CU: the others run as 256-lane blocks, several per CU)
 template <int MODE>
-__global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256) void plot_hist_rays(
+#ifndef HIST_RAYS_PER_CU
+#define HIST_RAYS_PER_CU 3      // blocks of plot_hist_rays per CU (RECORDS / LINES_ONLY)
+#endif
+#ifndef HIST_RAYS_MIN_BLOCKS
+#define HIST_RAYS_MIN_BLOCKS 1  // second argument of its launch bounds
+#endif
+__global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256,
+                             MODE == HIST_DIRECT ? 1 : HIST_RAYS_MIN_BLOCKS) void plot_hist_rays(
     xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
     const double* __restrict__ cd, xrt_hip_plot P, PlotAxes A, HistPlan H,
     double* __restrict__ counters, double* __restrict__ plane_copies,
@@ -820,7 +827,7 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
   int general = (h2 && mode == HIST_LINES_ONLY ? 1 : 0) | (want_lines && !lines ? 2 : 0);
   if (mode != HIST_LINES_ONLY || lines) {
     const int64_t chunks = (beam.n + HIST_CHUNK - 1) / HIST_CHUNK;
-    const int64_t most = (int64_t)cus * (mode == HIST_DIRECT ? 1 : 3);
+    const int64_t most = (int64_t)cus * (mode == HIST_DIRECT ? 1 : HIST_RAYS_PER_CU);
     const int nblk = (int)(chunks < most ? chunks : most);        // plot_hist_rays: fills the CUs
     const int T = H.ntx * H.nty;
     int ncopies = nblk;                                           // copies of the planes
