@@ -82,6 +82,35 @@ def test_replayed_iterations_equal_the_eager_run(repeats, python_calls):
         assert np.array_equal(getattr(a, f), getattr(b, f)), f
 
 
+def test_replay_with_figure_errors_on_the_elements():
+    """OE(figureError=...) on the mirror and on the DCM (its crystals take the exact sequence of the
+    Figured kernels): the map's spline is in HBM before the recording starts, the replays equal
+    the eager run -- and differ from the run without maps."""
+    from xrt_amd.backends.raycing import figure_error as rfe
+
+    def with_maps():
+        bl, run, calls = beamline()
+        bl.m1.figureError = rfe.RandomRoughness(rms=4., corrLength=3., seed=5, limPhysX=[-10, 10],
+                                                limPhysY=[-300, 300], gridStep=2.)
+        bl.dcm.figureError = rfe.Waviness(amplitude=6., xWaveLength=5., yWaveLength=12.,
+                                          limPhysX=[-10, 10], limPhysY=[-40, 160], gridStep=0.5)
+        return bl, run, calls
+    bl1, run1, _ = with_maps()
+    rr.run_process = run1
+    eager = xrtr.run_ray_tracing(plots(), repeats=7, beamLine=bl1)
+    bl2, run2, calls2 = with_maps()
+    rr.run_process = run2
+    replayed = xrtr.run_ray_tracing(plots(), repeats=7, beamLine=bl2, graph=True)
+    assert len(calls2) == 2
+    same_plots(eager, replayed)
+    bl3, run3, _ = beamline()
+    rr.run_process = run3
+    plain = xrtr.run_ray_tracing(plots(), repeats=7, beamLine=bl3)
+    screen_maps, screen_plain = eager[1].total2D, plain[1].total2D
+    assert eager[1].xaxis.limits != plain[1].xaxis.limits or \
+        np.abs(screen_maps - screen_plain).max() > 1e-3 * screen_plain.max()
+
+
 def test_a_second_run_records_again_and_continues_the_sequence():
     bl1, run1, _ = beamline(n=5000)
     bl2, run2, _ = beamline(n=5000)
