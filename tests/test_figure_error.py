@@ -247,6 +247,21 @@ def test_figure_error_on_a_dcm_and_refusals():
     good = ref[0].state == 1
     dev = np.abs(out[0].c - ref[0].c)[good]
     assert 1e-9 < dev.max() < 1e-4
+    # ... and against the oracle with the map on both crystals (find_dz adds it whatever the
+    # surface function is, base.py:826-830; the normal of either crystal is turned)
+    hooks = dict(figure_z=fe.local_z_distorted, figure_n=fe.local_n_distorted)
+    par = oracle_params(dcm)
+    par['surface'] = dict(par['surface'], **hooks)
+    par['surface2'] = dict(par['surface2'], **hooks)
+    o2, o1l, o2l = rn.dcm_double_reflect(par, to_oracle_beam(beam))
+    for got, want in ((out[0], o2), (out[1], o1l), (out[2], o2l)):
+        assert np.array_equal(got.state, want.state)
+        for f in GEOM:
+            r = getattr(want, f)
+            # (the local z of a flat crystal IS the map, nanometres: held to the solver's zEps)
+            assert np.abs(getattr(got, f) - r).max() <= 1e-12 * max(np.abs(r).max(), 1.), f
+        scale = (want.Jss + want.Jpp).max()
+        assert np.abs(got.Jss - want.Jss).max() <= 1e-10 * scale
     em = fc.roe.EllipticalMirrorParam(raycing.BeamLine(), 'e', center=[0, 10000., 0], pitch=4e-3,
                                       p=10000., q=1000., material=rm.Material('Pt', rho=21.45),
                                       figureError=fe)
