@@ -230,6 +230,47 @@ def test_1e6_rays_on_a_rough_toroid_match_the_oracle():
 
 
 @pytest.mark.gpu
+def test_map_on_an_uneven_grid_takes_the_loaded_knots(tmp_path):
+    """A measured map whose nodes are NOT equally spaced (np.unique of the file's columns, as the
+    reference builds its grid): the knots are no linspace's, the kernels load them (fe_interval /
+    fe_basis, FITPACK's sequence as it stands) -- 20000 rays on a bent mirror against the oracle
+    with scipy evaluating the same spline; and the same map on the even grid next to it takes
+    the computed knots and differs."""
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.materials as rm
+    from xrt_amd import workloads
+    rng = np.random.default_rng(8)
+    x = np.sort(np.concatenate([[-10., 10.], rng.uniform(-10, 10, 38)]))
+    y = np.sort(np.concatenate([[-80., 80.], rng.uniform(-80, 80, 118)]))
+    X, Y = np.meshgrid(x, y, indexing='ij')
+    Z = 5. * np.cos(2 * np.pi * Y / 47.) * (1 + 0.1 * X) + 2. * np.sin(X)          # [nm]
+    path = tmp_path / 'uneven.txt'
+    np.savetxt(path, np.column_stack([X.ravel(), Y.ravel(), Z.ravel()]), fmt='%.17g')
+    fe = fc.rfe.FigureErrorImported(fileName=str(path))
+    k, ty, tx, *_ = fe.spline_arrays()
+    assert fe.linspace_of(ty, k) is None and fe.linspace_of(tx, k) is None
+    pt = rm.Material('Pt', rho=21.45, kind='mirror')
+    bm = fc.roe.BentFlatMirror(raycing.BeamLine(), 'bent', center=[0, 18000., 0], pitch=3.5e-3,
+                               material=pt, R=5e6, limPhysX=[-10, 10], limPhysY=[-80, 80],
+                               figureError=fe)
+    beam = workloads.synthetic_rays(20000, 9)
+    beam.x[:] = beam.x * 20.                    # over the whole width, some rays past the edges
+    gb, lb = bm.reflect(beam)
+    par = oracle_params(bm)
+    par['surface'] = dict(par['surface'], figure_z=fe.local_z_distorted,
+                          figure_n=fe.local_n_distorted)
+    ogb, olb = rn.oe_reflect(par, to_oracle_beam(beam))
+    assert np.array_equal(lb.state, olb.state) and (olb.state == 1).mean() > 0.5
+    assert (olb.state != 1).sum() > 100
+    for f in GEOM:
+        r = getattr(ogb, f)
+        assert np.abs(getattr(gb, f) - r).max() <= 1e-12 * max(np.abs(r).max(), 1.), f
+    good = olb.state == 1
+    assert np.abs(lb.z[good] - bm.local_z(lb.x[good], lb.y[good])
+                  - fe.local_z_distorted(lb.x[good], lb.y[good])).max() < 2e-12
+
+
+@pytest.mark.gpu
 def test_figure_error_on_a_dcm_and_refusals():
     """Both crystals of a DCM take the map (two passes, exact sequence each); parametric
     surfaces refuse it in Python."""
