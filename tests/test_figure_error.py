@@ -271,6 +271,36 @@ def test_map_on_an_uneven_grid_takes_the_loaded_knots(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('order', [2])
+def test_spline_orders_below_three(order):
+    """figure_error.py keeps the spline order settable (splineOrder, default 3): a quadratic
+    spline goes through the same kernels (degree at run time, knots loaded). (Order 1 has no
+    slopes in scipy -- pardeu refuses the derivative of a linear spline -- so the reference
+    cannot trace it either.)"""
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.materials as rm
+    from xrt_amd import workloads
+    fe = fc.rfe.Waviness(amplitude=8., xWaveLength=6., yWaveLength=40., limPhysX=[-8, 8],
+                         limPhysY=[-150, 150], gridStep=1.)
+    fe.splineOrder = order
+    assert fe.local_z_spline.degrees == (order, order)
+    oe = fc.roe.OE(raycing.BeamLine(), 'flat', center=[0, 15000., 0], pitch=5e-3,
+                   material=rm.Material('Pt', rho=21.45, kind='mirror'), limPhysX=[-8, 8],
+                   limPhysY=[-150, 150], figureError=fe)
+    beam = workloads.synthetic_rays(8000, 4)
+    beam.x[:] = beam.x * 15.
+    gb, lb = oe.reflect(beam)
+    par = oracle_params(oe)
+    par['surface'] = dict(par['surface'], figure_z=fe.local_z_distorted,
+                          figure_n=fe.local_n_distorted)
+    ogb, olb = rn.oe_reflect(par, to_oracle_beam(beam))
+    assert np.array_equal(lb.state, olb.state) and (olb.state == 1).mean() > 0.5
+    for f in GEOM:
+        r = getattr(ogb, f)
+        assert np.abs(getattr(gb, f) - r).max() <= 1e-12 * max(np.abs(r).max(), 1.), f
+
+
+@pytest.mark.gpu
 def test_figure_error_on_a_dcm_and_refusals():
     """Both crystals of a DCM take the map (two passes, exact sequence each); parametric
     surfaces refuse it in Python."""
