@@ -167,6 +167,19 @@ def load_case(name):
                             'ctd': ctd}
         p['material'] = mn.make_material([mn.load_element(tb, 'Au')], None,
                                          'mirror', float(g['mat_rho']))
+    elif name.startswith('g2_multi_'):        # OE.multiple_reflect (gen_fixtures_multi.py)
+        import sys
+        sys.path.insert(0, os.path.dirname(GOLDEN))
+        import multi_cases as case
+        if name == 'g2_multi_cylinder':
+            p['surface'] = dict(kind='user', z=case.numpy_cyl_z, n=case.numpy_cyl_n)
+        elif name == 'g2_multi_flat':
+            p['surface'] = dict(kind='flat')
+        else:
+            p['surface'] = dict(kind='toroid', R=float(g['surf_R']), r=float(g['surf_r']))
+        p['material'] = mn.make_material(
+            [mn.load_element(tb, 'Pt' if name == 'g2_multi_edges' else 'Au')], None, 'mirror',
+            float(g['mat_rho']))
     elif name == 'g2_cone_rh':
         p['surface'] = rn.make_cone(float(g['surf_L0']), float(g['surf_theta']))
         p['material'] = mn.make_material([mn.load_element(tb, 'Rh')], None,

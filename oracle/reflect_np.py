@@ -43,6 +43,7 @@ from .consts import CH, CHBAR
 zEps = 1e-12            # raycing/__init__.py:86
 maxIteration = 100      # :88
 dt = 1e-5               # :90 bracket margin [mm]
+ds = 0.                 # :91 margin used in multiple reflections [mm]
 maxHalfSizeOfOE = 1000.  # :92
 maxDepthOfOE = 100.      # :94
 
@@ -65,6 +66,15 @@ class Beam(object):
 
     def copy(self):
         return copy.deepcopy(self)
+
+    def concatenate(self, beam):
+        """sources/beams.py:230-294: the arrays both beams hold, one after the other."""
+        always = list(F64) + ['Jsp', 'state']
+        optional = ['nRefl', 'elevationD', 'elevationX', 'elevationY', 'elevationZ', 's',
+                    'phi', 'r', 'theta', 'order', 'Es', 'Ep']
+        for name in always + [o for o in optional
+                              if hasattr(self, o) and hasattr(beam, o)]:
+            setattr(self, name, np.concatenate((getattr(self, name), getattr(beam, name))))
 
     def fields(self):
         names = list(F64) + ['Jsp', 'state']
@@ -695,7 +705,12 @@ def _set_t(xyz, abc, surfPhys=None, defSize=maxHalfSizeOfOE):
     return tMin, tMax
 
 
-def bracket(oe, x, y, z, a, b, c, is2ndXtal, mainPart, info=None):
+def bracket(oe, x, y, z, a, b, c, is2ndXtal, mainPart, info=None, isMulti=False,
+            needElevationMap=False, surf=None, invertNormal=1):
+    """-> tMin, tMax, elevation. *isMulti* (a further bounce of multiple_reflect,
+    base.py:1279-1289): the search starts where the ray is farthest from the surface it has
+    just left -- the root of ray . normal between 0 and tMax (find_intersection with
+    derivOrder=1) -- and *elevation* (needElevationMap) = find_dz there."""
     sfx = '2' if is2ndXtal else ''
     surfPhysX = oe['surfPhysX' + sfx]
     surfPhysY = oe['surfPhysY' + sfx]
@@ -718,13 +733,32 @@ def bracket(oe, x, y, z, a, b, c, is2ndXtal, mainPart, info=None):
     tMin[tMin < -1e6*zEps] = -1e6*zEps            # base.py:1275
     if info is not None:
         info['axis'] = axis
-    return tMin, tMax
+    elevation = None
+    if isMulti:                                   # base.py:1279-1289
+        tMin[:] = 0
+        tMaxTmp = np.copy(tMax)
+        tangency = {} if info is not None else None
+        tMax = find_intersection(surf, tMin, tMax, x, y, z, a, b, c, invertNormal,
+                                 tangency, derivOrder=1)[0]
+        if needElevationMap:
+            elevation = find_dz(surf, tMax, x, y, z, a, b, c, invertNormal)
+        tMin = tMax + ds
+        tMax = tMaxTmp
+        if info is not None:
+            info['tangency'] = tangency
+    return tMin, tMax, elevation
 
 
-def find_dz(surf, t, x0, y0, z0, a, b, c, invertNormal):
+def find_dz(surf, t, x0, y0, z0, a, b, c, invertNormal, derivOrder=0):
     x = x0 + a*t
     y = y0 + b*t
     z = z0 + c*t
+    if derivOrder:                                # base.py:819-821, 842-845: ray . normal
+        if is_param(surf):
+            x, y, z = xyz_to_param(surf, x, y, z)
+        n = local_n(surf, x, y)
+        dz = (a*n[-3] + b*n[-2] + c*n[-1]) * invertNormal
+        return dz, x, y, z
     if is_param(surf):                            # base.py:822-841, diffSign = -1
         x, y, z = xyz_to_param(surf, x, y, z)     # s, phi, r
         s = local_r(surf, x, y)
@@ -768,14 +802,15 @@ def blazed_find_intersection(surf, x, y, z, a, b, c):
     return t2, x2, y2, z2
 
 
-def find_intersection(surf, t1, t2, x, y, z, a, b, c, invertNormal, info=None):
+def find_intersection(surf, t1, t2, x, y, z, a, b, c, invertNormal, info=None,
+                      derivOrder=0):
     if surf['kind'] == 'blazed':
         if info is not None:
             info.update(brent=False, numit=0, tMinGlobal=np.nan,
                         tMaxGlobal=np.nan)
         return blazed_find_intersection(surf, x, y, z, a, b, c) + (None,)
-    dz1, x1, y1, z1 = find_dz(surf, t1, x, y, z, a, b, c, invertNormal)
-    dz2, x2, y2, z2 = find_dz(surf, t2, x, y, z, a, b, c, invertNormal)
+    dz1, x1, y1, z1 = find_dz(surf, t1, x, y, z, a, b, c, invertNormal, derivOrder)
+    dz2, x2, y2, z2 = find_dz(surf, t2, x, y, z, a, b, c, invertNormal, derivOrder)
     tMin = t1.min()
     tMax = t2.max()
     ind1 = dz1 <= 0
@@ -790,7 +825,7 @@ def find_intersection(surf, t1, t2, x, y, z, a, b, c, invertNormal, info=None):
     solver = brent if use_brent else secant
     t2, x2, y2, z2, numit = solver(
         surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
-        x2, y2, z2, ind)
+        x2, y2, z2, ind, derivOrder)
     if info is not None:
         info.update(brent=use_brent, numit=numit, tMinGlobal=tMin,
                     tMaxGlobal=tMax)
@@ -798,7 +833,7 @@ def find_intersection(surf, t1, t2, x, y, z, a, b, c, invertNormal, info=None):
 
 
 def secant(surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
-           x2, y2, z2, ind):
+           x2, y2, z2, ind, derivOrder=0):
     """base.py:933-959."""
     numit = 2
     while (ind.sum() > 0) and (numit < maxIteration):
@@ -813,7 +848,7 @@ def secant(surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
         t2[where[t2[ind] > tMax]] = tMax
         dz2[ind], x2[ind], y2[ind], z2[ind] = find_dz(
             surf, t2[ind], x[ind], y[ind], z[ind], a[ind], b[ind], c[ind],
-            invertNormal)
+            invertNormal, derivOrder)
         swap = np.sign(dz2[ind]) == np.sign(dz1[ind])
         t1[where[swap]] = t[swap]
         dz1[where[swap]] = dz[swap]
@@ -823,7 +858,7 @@ def secant(surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
 
 
 def brent(surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
-          x2, y2, z2, ind):
+          x2, y2, z2, ind, derivOrder=0):
     """base.py:961-1048."""
     where = np.where(ind)[0]
     swap = abs(dz1[ind]) < abs(dz2[ind])
@@ -867,7 +902,7 @@ def brent(surf, t1, t2, x, y, z, a, b, c, invertNormal, dz1, dz2, tMin, tMax,
         mf = conds
         fs, x2[ind], y2[ind], z2[ind] = find_dz(
             surf, xs, x[ind], y[ind], z[ind], a[ind], b[ind], c[ind],
-            invertNormal)
+            invertNormal, derivOrder)
         xd[:] = xc[:]
         xc[:] = xb[:]
         fc[:] = fb[:]
@@ -1129,7 +1164,8 @@ def asymmetric_reflection_grating(matSur, a, b, c, E, oeNormal,
 # --------------------------------------------------------------------------
 def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
                   dz=None, surf=None, fromVacuum=True, material=None,
-                  is2ndXtal=False, noIntersectionSearch=False, info=None):
+                  is2ndXtal=False, noIntersectionSearch=False, info=None,
+                  needElevationMap=False, isMulti=False):
     if surf is None:
         surf = oe['surface']
     rotSeq = oe.get('rotationSequence', 'RzRyRx')
@@ -1158,9 +1194,19 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
     mainPart = lb.state[good] == 1
     tMin = np.zeros_like(lb.x)
     tMax = np.zeros_like(lb.x)
-    tMin[good], tMax[good] = bracket(
+    tMin[good], tMax[good], elev = bracket(
         oe, lb.x[good], lb.y[good], lb.z[good], lb.a[good], lb.b[good],
-        lb.c[good], is2ndXtal, mainPart, info)
+        lb.c[good], is2ndXtal, mainPart, info, isMulti, needElevationMap, surf,
+        invertNormal)
+    if needElevationMap and elev:                 # reflect.py:651-659
+        lb.elevationD[good] = elev[0]
+        if is_param(surf):
+            tX, tY, tZ = param_to_xyz(surf, elev[1], elev[2], elev[3])
+        else:
+            tX, tY, tZ = elev[1], elev[2], elev[3]
+        lb.elevationX[good] = tX
+        lb.elevationY[good] = tY
+        lb.elevationZ[good] = tZ
     if info is not None:
         info['tMin'] = tMin.copy()
         info['tMax0'] = tMax.copy()
@@ -1368,6 +1414,9 @@ def reflect_local(oe, good, lb, vlb, pitch, roll, yaw, dx=None, dy=None,
                 lb.Es[goodN], lb.Ep[goodN], cosY, sinY)
 
     if is_param(surf):                            # reflect.py:1066-1071
+        lb.s = np.copy(lb.x)
+        lb.phi = np.copy(lb.y)
+        lb.r = np.copy(lb.z)
         lb.x[good], lb.y[good], lb.z[good] = param_to_xyz(
             surf, lb.x[good], lb.y[good], lb.z[good])
 
@@ -1413,6 +1462,63 @@ def oe_reflect(oe, beam, noIntersectionSearch=False, createdByDiffract=False,
     if notGood.sum() > 0:
         copy_beam(gb, beam, notGood)
     return gb, lb
+
+
+def oe_multiple_reflect(oe, beam, maxReflections=1000, needElevationMap=False,
+                        info=None):
+    """OE.multiple_reflect (reflect.py:165-264) -> (gb, lbN): up to *maxReflections* bounces
+    off the same surface. The beam stays in the element's virgin local frame between the
+    bounces (``lb is gb``); lbN holds a copy of ALL rays after every bounce, one after the
+    other, with ``nRefl`` (and, on request, the elevation fields of the points between two
+    bounces where a ray was farthest from the surface). *info*: a list that receives one
+    dictionary of batch statistics per bounce."""
+    gb = beam.copy()
+    lb = gb
+    good = beam.state > 0
+    if good.sum() == 0:
+        return gb, lb
+    global_to_virgin_local(oe['azimuth_sc'], beam, lb, oe['center'], good)
+    iRefl = 0
+    isMulti = False
+    lbN = None
+    while iRefl < maxReflections:
+        tmpX, tmpY, tmpZ = np.copy(lb.x[good]), np.copy(lb.y[good]), np.copy(lb.z[good])
+        if iRefl == 0 and needElevationMap:
+            lb.elevationD = -np.ones_like(lb.x)
+            lb.elevationX = -np.ones_like(lb.x)*maxHalfSizeOfOE
+            lb.elevationY = -np.ones_like(lb.x)*maxHalfSizeOfOE
+            lb.elevationZ = -np.ones_like(lb.x)*maxHalfSizeOfOE
+        one = {} if info is not None else None
+        reflect_local(oe, good, lb, gb, oe['pitch'], oe['roll'] + oe['positionRoll'],
+                      oe['yaw'], oe.get('dx', 0), material=oe.get('material'), info=one,
+                      needElevationMap=needElevationMap, isMulti=isMulti)
+        if info is not None:
+            info.append(one)
+        if iRefl == 0:
+            isMulti = True
+            lb.nRefl = np.zeros_like(lb.state)
+        ov = lb.state[good] == 3                  # over the edge: back to where it was
+        where = np.where(good)[0][ov]
+        lb.x[where] = tmpX[ov]
+        lb.y[where] = tmpY[ov]
+        lb.z[where] = tmpZ[ov]
+        good = (lb.state == 1) | (lb.state == 2)
+        lb.nRefl[good] += 1
+        if iRefl == 0:
+            lbN = lb.copy()
+        else:
+            lbN.concatenate(lb)
+        iRefl += 1
+        if good.sum() == 0:
+            break
+    goodAfter = gb.nRefl > 0
+    gb.state[goodAfter] = 1
+    if goodAfter.sum() > 0:
+        virgin_local_to_global(oe['azimuth_sc'], gb, oe['center'], goodAfter)
+    notGood = ~goodAfter
+    if notGood.sum() > 0:
+        copy_beam(gb, beam, notGood)
+    return gb, lbN
 
 
 def dcm_double_reflect(oe, beam, fromVacuum1=True, fromVacuum2=True,
