@@ -17,10 +17,12 @@
  *   xrt_hip_kirchhoff_f64_dev  <- the same integral, numpy form
  *                                 _diffraction_integral_conv (waves.py:834-851),
  *                                 on device-resident SoA arrays
- *   xrt_hip_reflect_f64_dev    <- OE._reflect_local + the global<->local
+ *   xrt_hip_reflect_pass_f64_dev <- OE._reflect_local + the global<->local
  *                                 transforms around it in OE.reflect
  *                                 (oes/reflect.py:18-163, 551-1139;
  *                                  oes/base.py:801-1048, 1094-1163, 1231-1295)
+ *   xrt_hip_reflect_bounce_f64_dev <- one turn of OE.multiple_reflect's loop
+ *                                 (oes/reflect.py:165-264; base.py:1279-1289, 842-845)
  *   xrt_hip_screen_expose_f64_dev <- Screen.expose (screens.py:226-302)
  */
 #ifndef XRT_HIP_H
@@ -333,6 +335,13 @@ typedef struct xrt_hip_pass {
   double fe_shift[2];
   int32_t fe_grid[2];
   double fe_lo[2], fe_step[2], fe_hi[2], fe_inv[2][3];
+  /* _reflect_local(..., needElevationMap, isMulti) (oes/reflect.py:551-555): a further bounce
+   * of OE.multiple_reflect. is_multi = 1: the brackets of _bracketing(isMulti=True)
+   * (oes/base.py:1279-1289) -- tMin = the root of ray . normal on [0, tMax], searched with
+   * find_dz(derivOrder = 1) (base.py:819-821, 842-845). need_elevation_map = 1: find_dz at
+   * that point goes into the beam's elevation fields (reflect.py:651-659). Read by
+   * xrt_hip_reflect_bounce_f64_dev only; the single passes require both to be 0. */
+  int32_t is_multi, need_elevation_map;
 } xrt_hip_pass;
 
 /* ---- user-defined surfaces -------------------------------------------------------------
@@ -448,11 +457,13 @@ XRT_HIP_API size_t xrt_hip_reflect_workspace_bytes(int64_t n);
 
 /* sizeof() of the structs above, to let a binding verify its layout:
  * which = 0 beam, 1 rotation, 2 pass, 3 material, 4 screen, 5 aperture, 6 undulator,
- * 7 undulator_map, 8 plot, 9 custom_field, 10 bend, 11 multilayer, 12 gauss. */
+ * 7 undulator_map, 8 plot, 9 custom_field, 10 bend, 11 multilayer, 12 gauss, 13 geosource,
+ * 14 bounce. */
 XRT_HIP_API int xrt_hip_sizeof(int which);
 
 /* in: incoming beam. out_local: "lb" of the reference (true local frame); NULL (mirrors,
- * plates and gratings only; with theta NULL as well) = not wanted, the reference's
+ * plates and gratings only -- not crystals, not layered materials of either kind, Multilayer
+ * or Coated; with theta NULL as well) = not wanted, the reference's
  * needLocal=False (oes/reflect.py:104-108): the pass then writes 200 B per ray instead of 308.
  * out_virgin: "gb"/"vlb" (virgin local or global, see xrt_hip_pass).
  * restore: beam whose x..E,J are copied into out_virgin for rays that did not
@@ -480,6 +491,56 @@ XRT_HIP_API int xrt_hip_reflect_pass_f64_dev(
     const xrt_hip_beam* in, const xrt_hip_beam* restore, xrt_hip_beam* out_local,
     xrt_hip_beam* out_virgin, double* theta, void* workspace,
     size_t workspace_bytes, void* stream, double* info_host, float* kernel_ms);
+
+/* ---- OE.multiple_reflect (oes/reflect.py:165-264): up to maxReflections bounces off the
+ * same surface (capillaries, whispering-gallery mirrors, Montel pairs). One call = one turn
+ * of its loop over a device-resident beam: _reflect_local as the loop calls it (`lb is vlb`:
+ * the beam arrives and leaves in the element's VIRGIN local frame -- on the first bounce it
+ * arrives in the global frame, pass->in_is_global = 1, good_mode = 0; afterwards
+ * in_is_global = 0, good_mode = 1, is_multi = 1), the return of rays over the edge (state 3)
+ * to where they were (:225-228) and the count of the rays left in state 1 or 2 (:229-230).
+ * `out` (n rays, not sharing arrays with `in`) is the beam after the bounce and at the same
+ * time this bounce's footprint: lbN of the reference is the `out` beams of all bounces, one
+ * after the other, so a caller hands in consecutive n-ray slices of its lbN arrays and feeds
+ * each back as the next `in`.
+ * Mirrors, plates, gratings with a single order, no material; flat / toroidal / bent-flat
+ * surfaces, the parametric conics (capillaries), cone, lens paraboloid, VFM / DualVFM and
+ * user-defined surfaces (general flavour). Refused: Bragg crystals and layered materials (their
+ * deflection needs a batch mean / their kernels are not instantiated for it), blazed
+ * profiles, zone plates, per-ray orders, figure errors, no_intersection_search. */
+typedef struct xrt_hip_bounce {
+  const int32_t* nrefl_in;   /* lb.nRefl [n] before the bounce; NULL on the first (zeros) */
+  int32_t* nrefl_out;        /* [n] after it */
+  double* theta;             /* [n] lb.theta of this bounce: 0 where the ray did not hit. (The
+                                reference leaves lb.theta untouched by a bounce in which NO ray
+                                hits, reflect.py:793: the caller looks at counts[1].) */
+  /* elevationD / X / Y / Z (reflect.py:214-218, 651-659), [n] each, or all NULL;
+   * elev_in NULL (first bounce) = the initial values -1, -1000, -1000, -1000 */
+  const double* elev_in[4];
+  double* elev_out[4];
+  /* lb.s / phi / r of a parametric surface (reflect.py:1066-1069), [n] each, or NULL */
+  double* spr_out[3];
+} xrt_hip_bounce;
+
+XRT_HIP_API size_t xrt_hip_bounce_workspace_bytes(int64_t n);
+
+/* counts_host (optional, 2 int64, forces a sync): rays in state 1 or 2 after the bounce
+ * (0: the loop ends), rays in state 1. Without it the two numbers stay in the first 16
+ * bytes of `workspace` (uint64) for the caller to fetch. info_host (optional, 16 doubles,
+ * forces a sync): [0] bracketing axis, [1] first-ray sign, [2] Brent? for the hit search,
+ * [3] entering rays, [4] Brent? for the tangency search, [5] / [6] its clamp range,
+ * [7] / [8] the clamp range t1.min(), t2.max() of the hit search. */
+XRT_HIP_API int xrt_hip_reflect_bounce_f64_dev(
+    const xrt_hip_pass* pass, const xrt_hip_material* material, const xrt_hip_beam* in,
+    xrt_hip_beam* out, const xrt_hip_bounce* bounce, void* workspace, size_t workspace_bytes,
+    void* stream, int64_t* counts_host, double* info_host);
+
+/* The end of multiple_reflect (reflect.py:246-255): rays with nrefl > 0 leave with state 1
+ * in the global frame (pass: sin_az / cos_az, center), the others are the rays of `original`
+ * with the state they ended in. `last` = the beam after the last bounce. */
+XRT_HIP_API int xrt_hip_multiple_reflect_out_f64_dev(
+    const xrt_hip_pass* pass, const xrt_hip_beam* last, const xrt_hip_beam* original,
+    const int32_t* nrefl, xrt_hip_beam* out_global, void* stream);
 
 /* DCM.double_reflect (oes/dcm.py:248-354) as ONE pass over the beam: both crystals
  * per ray, the beam between them never goes to memory (416 B of HBM traffic per ray

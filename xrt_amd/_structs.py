@@ -101,6 +101,8 @@ class Pass(ctypes.Structure):
         ('fe_step', ctypes.c_double * 2),
         ('fe_hi', ctypes.c_double * 2),
         ('fe_inv', (ctypes.c_double * 3) * 2),
+        ('is_multi', ctypes.c_int32),
+        ('need_elevation_map', ctypes.c_int32),
     ]
 
 
@@ -306,5 +308,16 @@ class GeoSource(ctypes.Structure):
                 ('call_dev', ctypes.c_void_p)]
 
 
+class Bounce(ctypes.Structure):
+    _fields_ = [
+        ('nrefl_in', ctypes.c_void_p),
+        ('nrefl_out', ctypes.c_void_p),
+        ('theta', ctypes.c_void_p),
+        ('elev_in', ctypes.c_void_p * 4),
+        ('elev_out', ctypes.c_void_p * 4),
+        ('spr_out', ctypes.c_void_p * 3),
+    ]
+
+
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
-           UndulatorMap, Plot, CustomField, Bend, Multilayer, Gauss, GeoSource)
+           UndulatorMap, Plot, CustomField, Bend, Multilayer, Gauss, GeoSource, Bounce)

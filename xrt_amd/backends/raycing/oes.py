@@ -790,6 +790,172 @@ def _ray_orders(self, p, beam, lb, gb, _info, _timing):
 OE._with_ray_orders = _ray_orders
 
 
+class _Footprints(object):
+    """The arrays of lbN -- every ray after every bounce of ``multiple_reflect``, bounce after
+    bounce (reference: ``lbN.concatenate(lb)``, oes/reflect.py:231-235) -- in HBM: one tensor
+    per field with room for *cap* bounces, doubled when it runs out. A bounce kernel writes
+    slice k and reads slice k - 1: the beam never exists anywhere else."""
+
+    def __init__(self, n, dev, amplitudes, elevation, parametric, cap):
+        self.n, self.dev, self.cap = int(n), dev, max(int(cap), 1)
+        f64 = list(rs._F64) + ['theta']
+        if elevation:
+            f64 += ['elevationD', 'elevationX', 'elevationY', 'elevationZ']
+        if parametric:
+            f64 += ['s', 'phi', 'r']
+        self.kinds = [(name, torch.float64) for name in f64]
+        self.kinds += [('Jsp', torch.complex128)]
+        if amplitudes:
+            self.kinds += [('Es', torch.complex128), ('Ep', torch.complex128)]
+        self.kinds += [('state', torch.int32), ('nRefl', torch.int32)]
+        self.t = {name: torch.empty(self.cap * self.n, dtype=dt, device=dev)
+                  for name, dt in self.kinds}
+
+    def grow(self, used):
+        cap = self.cap * 2
+        for name, dt in self.kinds:
+            t = torch.empty(cap * self.n, dtype=dt, device=self.dev)
+            t[:used * self.n] = self.t[name][:used * self.n]
+            self.t[name] = t
+        self.cap = cap
+
+    def ptr(self, name, k):
+        t = self.t[name]
+        return t.data_ptr() + k * self.n * t.element_size()
+
+    def beam_struct(self, k):
+        s = _structs.Beam()
+        s.n = self.n
+        for cname, name in (('x', 'x'), ('y', 'y'), ('z', 'z'), ('a', 'a'), ('b', 'b'),
+                            ('c', 'c'), ('path', 'path'), ('E', 'E'), ('Jss', 'Jss'),
+                            ('Jpp', 'Jpp'), ('Jsp_ri', 'Jsp'), ('state', 'state')):
+            setattr(s, cname, self.ptr(name, k))
+        if 'Es' in self.t:
+            s.Es_ri, s.Ep_ri = self.ptr('Es', k), self.ptr('Ep', k)
+        else:
+            s.Es_ri = s.Ep_ri = None
+        s._keep = list(self.t.values())
+        return s
+
+    def slice(self, name, k):
+        return self.t[name][k * self.n:(k + 1) * self.n]
+
+    def beam(self, first, last, skip=()):
+        """Beam over the bounces first..last-1 (views of the buffers)."""
+        b = rs.Beam.__new__(rs.Beam)
+        object.__setattr__(b, '_h', {})
+        object.__setattr__(b, '_d', {})
+        for name, _ in self.kinds:
+            if name not in skip:
+                b._d[name] = self.t[name][first * self.n:last * self.n]
+        object.__setattr__(b, 'parentId', None)
+        return b
+
+
+def _multiple_reflect(self, beam=None, maxReflections=1000, needElevationMap=False,
+                      returnLocalAbsorbed=None, _info=None):
+    """-> (beamGlobal, beamLocalN): like :meth:`reflect`, with up to *maxReflections*
+    reflections off the same surface (reference oes/reflect.py:165-264). The returned beams
+    carry *nRefl*, and with *needElevationMap* *elevationD*, *elevationX/Y/Z*: the greatest
+    distance between ray and surface on the way from one impact point to the next, and where.
+    beamLocalN holds ALL rays after every bounce (the footprints), bounce after bounce, in the
+    element's virgin local frame like the reference's.
+
+    On the GPU one launch per bounce (csrc/reflect_multi_impl.h); the beam stays in HBM, two
+    numbers per bounce come back (how many rays are left, how many hit). Mirrors, plates,
+    single-order gratings and bare surfaces; flat / toroidal / bent-flat surfaces, parametric
+    conics (capillaries), cones, VFMs and user-defined surfaces. *_info* (list) receives one
+    dictionary of batch decisions per bounce."""
+    from . import materials as _rm
+    graphs.refuse('multiple_reflect (the rays decide how many bounces there are)')
+    _lib.require_gpu()
+    lib = _lib.load()
+    dev = _device()
+    self.footprint = []
+    stripes = self.material if raycing.is_sequence(self.material) else (self.material,)
+    if any(isinstance(m, (_rm.Crystal, _rm.Multilayer)) for m in stripes):
+        raise NotImplementedError('multiple_reflect with crystals or layered materials')
+    if getattr(self, '_zones_between_passes', None) is not None or \
+            raycing.is_sequence(getattr(self, 'order', None)):
+        raise NotImplementedError('multiple_reflect with zone plates / several orders')
+    n = beam.nrays
+    if n == 0 or not bool((beam.dev('state', dev) > 0).any()):    # reflect.py:203-205
+        gb = rs.Beam(copyFrom=beam)
+        self._adopt((gb,), beam)
+        return gb, gb
+    first = self._make_pass(self.pitch, self.roll + self.positionRoll, self.yaw, self.dx,
+                            out_to_global=False)
+    later = self._make_pass(self.pitch, self.roll + self.positionRoll, self.yaw, self.dx,
+                            in_is_global=False, good_mode=1, out_to_global=False)
+    later.is_multi = 1
+    first.need_elevation_map = later.need_elevation_map = int(bool(needElevationMap))
+    for p in (first, later):
+        if p.eff_tab_n > 0:
+            self._check_efficiency_range(p, beam, dev)
+    ms = self._material_struct(self.material, True, dev, beam)
+    amplitudes = beam.has_amplitudes()
+    fp = _Footprints(n, dev, amplitudes, needElevationMap, bool(self.isParametric),
+                     min(int(maxReflections), 8))
+    ws = hipcalls.workspace(dev, lib.xrt_hip_bounce_workspace_bytes(n), 'bounce')
+    counts = (ctypes.c_int64 * 2)()
+    stats = (ctypes.c_double * 16)() if _info is not None else None
+    elevation = ('elevationD', 'elevationX', 'elevationY', 'elevationZ')
+    k, hits_first, hits_any = 0, False, False
+    while k < maxReflections:
+        if k == fp.cap:
+            fp.grow(k)
+        bounce = _structs.Bounce()
+        bounce.nrefl_in = None if k == 0 else fp.ptr('nRefl', k - 1)
+        bounce.nrefl_out = fp.ptr('nRefl', k)
+        bounce.theta = fp.ptr('theta', k)
+        for j, name in enumerate(elevation):
+            if needElevationMap:
+                bounce.elev_in[j] = None if k == 0 else fp.ptr(name, k - 1)
+                bounce.elev_out[j] = fp.ptr(name, k)
+        if self.isParametric:
+            for j, name in enumerate(('s', 'phi', 'r')):
+                bounce.spr_out[j] = fp.ptr(name, k)
+        s_in = beam.to_struct(dev) if k == 0 else fp.beam_struct(k - 1)
+        s_out = fp.beam_struct(k)
+        _lib.check(lib.xrt_hip_reflect_bounce_f64_dev(
+            ctypes.byref(first if k == 0 else later), ctypes.byref(ms), ctypes.byref(s_in),
+            ctypes.byref(s_out), ctypes.byref(bounce), ctypes.c_void_p(ws.data_ptr()),
+            ws.numel(), _stream(), counts, stats), 'xrt_hip_reflect_bounce_f64_dev')
+        left, hit = int(counts[0]), int(counts[1])
+        if hit == 0 and k > 0:
+            # a bounce in which no ray hits leaves lb.theta as it was (reflect.py:791-796)
+            fp.slice('theta', k).copy_(fp.slice('theta', k - 1))
+        hits_first = hits_first or (k == 0 and hit > 0)
+        hits_any = hits_any or hit > 0
+        if _info is not None:
+            v = list(stats)
+            one = dict(axis=int(v[0]), positive=bool(v[1]), brent=bool(v[2]),
+                       n_enter=int(v[3]), tMinGlobal=v[7], tMaxGlobal=v[8], left=left, hit=hit)
+            if k > 0:
+                one['tangency'] = dict(brent=bool(v[4]), tMinGlobal=v[5], tMaxGlobal=v[6])
+            _info.append(one)
+        k += 1
+        if left == 0:
+            break
+    # lb.theta exists from the first bounce with a hit on; lbN took (or did not take) it at
+    # bounce 0 and concatenate() keeps what both sides have (sources/beams.py:271-272)
+    lbN = fp.beam(0, k, skip=() if hits_first else ('theta',))
+    last = fp.beam(k - 1, k, skip=() if hits_any else ('theta',))
+    gb = rs.Beam.empty_like_on_device(beam, dev)
+    _lib.check(lib.xrt_hip_multiple_reflect_out_f64_dev(
+        ctypes.byref(first), ctypes.byref(fp.beam_struct(k - 1)),
+        ctypes.byref(beam.to_struct(dev)), ctypes.c_void_p(fp.ptr('nRefl', k - 1)),
+        ctypes.byref(gb.to_struct(dev)), _stream()), 'xrt_hip_multiple_reflect_out_f64_dev')
+    for name in last.array_fields():       # gb is lb: it carries the bounce's other arrays
+        if name not in gb._d:
+            gb._d[name] = last._d[name].clone()
+    self._adopt((gb, lbN), beam)
+    return gb, lbN
+
+
+OE.multiple_reflect = _multiple_reflect
+
+
 class _Curved(OE):
     """Surfaces whose height and normal the GPU evaluates."""
 

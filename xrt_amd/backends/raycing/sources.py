@@ -20,21 +20,25 @@ defaultEnergy = 9.0e3
 
 _F64 = ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp')
 _C128 = ('Jsp', 'Es', 'Ep')
-_OPT_F64 = ('theta', 'phi', 'order', 'xDiffr', 'yDiffr', 'zDiffr', 'rDiffr')
+_OPT_F64 = ('theta', 'phi', 'order', 'xDiffr', 'yDiffr', 'zDiffr', 'rDiffr',
+            # OE.multiple_reflect: the points of greatest elevation between two bounces, the
+            # impact points in the parametric coordinates (sources/beams.py:80-91)
+            'elevationD', 'elevationX', 'elevationY', 'elevationZ', 's', 'r')
+_OPT_I32 = ('nRefl',)           # number of reflections (multiple_reflect)
 # accumulated Kirchhoff integrals of a receiving wave (waves.diffract)
 _OPT_C128 = ('EsAcc', 'EpAcc', 'aEacc', 'bEacc', 'cEacc')
 _SCALAR_ATTRS = ('sourceSIGMAx', 'sourceSIGMAz', 'filamentDX', 'filamentDZ',
                  'filamentDtheta', 'filamentDpsi', 'filamentDgamma', 'accepted',
                  'acceptedE', 'seeded', 'seededI', 'sourceWeight')
 _ALWAYS = frozenset(_F64 + ('Jsp', 'state'))        # what every beam holds
-_ARRAY_FIELDS = set(_F64) | set(_C128) | set(_OPT_F64) | set(_OPT_C128) | {'state'}
+_ARRAY_FIELDS = set(_F64) | set(_C128) | set(_OPT_F64) | set(_OPT_C128) | set(_OPT_I32) | {'state'}
 _TORCH_DTYPE = {np.dtype('float64'): torch.float64,
                 np.dtype('complex128'): torch.complex128,
                 np.dtype('int32'): torch.int32}
 
 
 def _np_dtype(name):
-    if name == 'state':
+    if name == 'state' or name in _OPT_I32:
         return np.int32
     if name in _C128 or name in _OPT_C128:
         return np.complex128
@@ -266,7 +270,7 @@ class Beam(object):
                 pickle.dump(record, f, protocol=2)
 
     def array_fields(self):
-        return [n for n in (_F64 + _C128 + _OPT_F64 + _OPT_C128 + ('state',))
+        return [n for n in (_F64 + _C128 + _OPT_F64 + _OPT_C128 + _OPT_I32 + ('state',))
                 if n in self._h or n in self._d]
 
     @property

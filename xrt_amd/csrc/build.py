@@ -12,16 +12,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, 'libxrt_hip.so')
 # the reflect kernels are instantiated in units of their own (reflect_tu.h): the slowest first
-SOURCES = ['reflect_figured_x1.hip', 'reflect_figured_x0.hip', 'reflect_figured_f.hip',
+SOURCES = ['reflect_multi.hip', 'reflect_figured_x1.hip', 'reflect_figured_x0.hip', 'reflect_figured_f.hip',
            'reflect_exact1.hip', 'reflect_exact3.hip', 'reflect_exact0.hip',
            'reflect_exact2.hip', 'reflect_layered_x.hip', 'reflect_layered_f.hip',
            'reflect_generic.hip', 'reflect_xtal.hip', 'reflect.hip', 'reflect_hot.hip',
            'kirchhoff.hip', 'undulator.hip', 'capi.hip', 'screen.hip', 'hist.hip', 'source.hip']
 HEADERS = ['fp64_math.h', 'kirchhoff.h', 'reflect.h', 'reflect_impl.h', 'reflect_tu.h',
+           'reflect_multi_impl.h',
            'screen.h', 'hist.h', 'undulator.h', 'source.h',
            os.path.join('..', '..', 'include', 'xrt_hip.h')]
 # headers only these sources depend on (everything else rebuilds on any header change)
-ONLY_FOR = {'reflect_impl.h': 'reflect', 'reflect_tu.h': 'reflect', 'kirchhoff.h': ('kirchhoff', 'capi'),
+ONLY_FOR = {'reflect_impl.h': 'reflect', 'reflect_tu.h': 'reflect',
+            'reflect_multi_impl.h': 'reflect_multi', 'kirchhoff.h': ('kirchhoff', 'capi'),
             'hist.h': ('hist', 'capi'), 'screen.h': ('screen', 'capi'), 'source.h': ('source', 'capi'),
             'undulator.h': ('undulator', 'capi')}
 # -ffp-contract=off: fused multiply-add only where the source says fma();

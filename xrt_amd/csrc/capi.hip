@@ -255,6 +255,7 @@ int xrt_hip_sizeof(int which) {
     case 11: return (int)sizeof(xrt_hip_multilayer);
     case 12: return (int)sizeof(xrt_hip_gauss);
     case 13: return (int)sizeof(xrt_hip_geosource);
+    case 14: return (int)sizeof(xrt_hip_bounce);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -416,6 +417,9 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
   const ArmedEvents armed;
   int rc;
   if ((rc = check_pass(pass, material))) return rc;
+  if (pass->is_multi || pass->need_elevation_map)
+    return fail(XRT_HIP_ERR_ARG, "is_multi / need_elevation_map: a bounce of multiple_reflect "
+                                 "goes through xrt_hip_reflect_bounce_f64_dev");
   if (!in) return fail(XRT_HIP_ERR_ARG, "NULL input beam");
   const int64_t n = in->n;
   if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative ray count");
@@ -428,9 +432,11 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
   memset(&no_local, 0, sizeof(no_local));
   no_local.n = n;
   if (!out_local) {
-    if (material->kind == XRT_HIP_MAT_CRYSTAL ||
-        (material->kind == XRT_HIP_MAT_MULTILAYER && material->geom_bragg))
-      return fail(XRT_HIP_ERR_ARG, "crystal passes keep their local beam (out_local NULL)");
+    // (the layered kernels -- Multilayer AND Coated -- are compiled without the test for a
+    // missing local beam, reflect_impl.h:optional_local)
+    if (material->kind == XRT_HIP_MAT_CRYSTAL || material->kind == XRT_HIP_MAT_MULTILAYER)
+      return fail(XRT_HIP_ERR_ARG, "passes of crystals and layered materials keep their local "
+                                   "beam (out_local NULL)");
     out_local = &no_local;
   } else if ((rc = check_beam(out_local, "out_local", n, amp))) {
     return rc;
@@ -727,6 +733,110 @@ int xrt_hip_crystal_amplitude_f64_dev(const xrt_hip_material* material, int64_t 
   return XRT_HIP_OK;
 }
 
+size_t xrt_hip_bounce_workspace_bytes(int64_t n) {
+  return xrt::bounce_workspace_bytes(n < 0 ? 0 : n);
+}
+
+int xrt_hip_reflect_bounce_f64_dev(const xrt_hip_pass* pass, const xrt_hip_material* material,
+                                   const xrt_hip_beam* in, xrt_hip_beam* out,
+                                   const xrt_hip_bounce* bounce, void* workspace,
+                                   size_t workspace_bytes, void* stream, int64_t* counts_host,
+                                   double* info_host) {
+  int rc;
+  if ((rc = check_pass(pass, material))) return rc;
+  if (!in || !bounce) return fail(XRT_HIP_ERR_ARG, "NULL input beam / bounce record");
+  const int64_t n = in->n;
+  if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative ray count");
+  const bool amp = in->Es_ri != nullptr || in->Ep_ri != nullptr;
+  if ((rc = check_beam(in, "in", n, amp))) return rc;
+  if ((rc = check_beam(out, "out", n, amp))) return rc;
+  // what the bounce kernels do not hold (see xrt_hip.h)
+  if (material->kind == XRT_HIP_MAT_CRYSTAL || material->kind == XRT_HIP_MAT_MULTILAYER)
+    return fail(XRT_HIP_ERR_ARG, "multiple_reflect: Bragg crystals and layered materials are "
+                                 "not supported (mirrors, plates, gratings, no material)");
+  if (pass->surf_kind == XRT_HIP_SURF_BLAZED || pass->surf_kind == XRT_HIP_SURF_BENT_BRAGG ||
+      pass->surf_kind == XRT_HIP_SURF_DICED || pass->surf_kind == XRT_HIP_SURF_SAGITTAL)
+    return fail(XRT_HIP_ERR_ARG, "multiple_reflect: surface kind %d is not supported",
+                pass->surf_kind);
+  if (pass->grating == 2 || pass->g_ray_x || pass->state_ray || pass->order_ray)
+    return fail(XRT_HIP_ERR_ARG, "multiple_reflect: no zone plates, no per-ray orders");
+  if (pass->fe_c) return fail(XRT_HIP_ERR_ARG, "multiple_reflect: no figure error");
+  if (pass->no_intersection_search)
+    return fail(XRT_HIP_ERR_ARG, "multiple_reflect searches its intersections");
+  if (pass->asymmetric) return fail(XRT_HIP_ERR_ARG, "multiple_reflect: no asymmetric cut");
+  if (material->n_fixed == 2)
+    return fail(XRT_HIP_ERR_ARG, "multiple_reflect: no per-ray refractive index");
+  if (pass->surf_kind == XRT_HIP_SURF_USER &&
+      !static_cast<const xrt::UserUnit*>(pass->user_unit)->multi)
+    return fail(XRT_HIP_ERR_ARG, "multiple_reflect: the surface's unit holds no bounce kernel "
+                                 "(layered flavour, or built before round 5)");
+  if (pass->is_multi ? (pass->in_is_global || pass->good_mode != 1 || !bounce->nrefl_in)
+                     : (pass->good_mode != 0 || bounce->nrefl_in != nullptr))
+    return fail(XRT_HIP_ERR_ARG, "bounce: the first takes the beam with state > 0 (good_mode 0, "
+                                 "nrefl_in NULL), the others (is_multi) the virgin-local beam "
+                                 "of the bounce before with states 1, 2 (good_mode 1, nrefl_in)");
+  if (!bounce->nrefl_out || !bounce->theta)
+    return fail(XRT_HIP_ERR_ARG, "bounce: nrefl_out and theta are required");
+  int have_out = 0, have_in = 0, have_spr = 0;
+  for (int k = 0; k < 4; ++k) {
+    have_out += bounce->elev_out[k] != nullptr;
+    have_in += bounce->elev_in[k] != nullptr;
+  }
+  for (int k = 0; k < 3; ++k) have_spr += bounce->spr_out[k] != nullptr;
+  if ((have_out != 0 && have_out != 4) || (have_in != 0 && have_in != 4) ||
+      (have_spr != 0 && have_spr != 3) || (have_out == 4) != (pass->need_elevation_map != 0) ||
+      (have_in == 4 && have_out != 4))
+    return fail(XRT_HIP_ERR_ARG, "bounce: the elevation arrays come in fours (out iff "
+                                 "need_elevation_map), s / phi / r in threes");
+  const void* ins[] = {in->x, in->y, in->z, in->a, in->b, in->c, in->path, in->E, in->Jss,
+                       in->Jpp, in->Jsp_ri, in->state, in->Es_ri, in->Ep_ri};
+  const void* outs[] = {out->x, out->y, out->z, out->a, out->b, out->c, out->path, out->E,
+                        out->Jss, out->Jpp, out->Jsp_ri, out->state, out->Es_ri, out->Ep_ri};
+  for (const void* u : ins)
+    for (const void* v : outs)
+      if (u && u == v) return fail(XRT_HIP_ERR_ARG, "bounce: `out` shares an array with `in`");
+  if (n == 0) {
+    if (counts_host) counts_host[0] = counts_host[1] = 0;
+    return XRT_HIP_OK;
+  }
+  if (!workspace || workspace_bytes < xrt::bounce_workspace_bytes(n))
+    return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes,
+                xrt::bounce_workspace_bytes(n));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e = xrt::reflect_bounce_launch(*pass, *material, *in, *out, *bounce, workspace, st);
+  if (e != hipSuccess) return fail(XRT_HIP_ERR_HIP, "bounce launch: %s", hipGetErrorString(e));
+  if (counts_host || info_host) {
+    unsigned long long head[32];   // counts (16 B) ... diag at byte 128 (16 doubles)
+    HIP_TRY(hipMemcpyAsync(head, workspace, sizeof(head), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    xrt::GStat g;
+    HIP_TRY(hipMemcpy(&g, reinterpret_cast<char*>(workspace) + 256, sizeof(g),
+                      hipMemcpyDeviceToHost));
+    if (g.hang) return fail(XRT_HIP_ERR_HIP, "bounce: a grid barrier gave up waiting");
+    if (counts_host) {
+      counts_host[0] = (int64_t)head[0];
+      counts_host[1] = (int64_t)head[1];
+    }
+    if (info_host) memcpy(info_host, head + 16, 16 * sizeof(double));
+  }
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_multiple_reflect_out_f64_dev(const xrt_hip_pass* pass, const xrt_hip_beam* last,
+                                         const xrt_hip_beam* original, const int32_t* nrefl,
+                                         xrt_hip_beam* out_global, void* stream) {
+  if (!pass || !last || !nrefl) return fail(XRT_HIP_ERR_ARG, "NULL pass / beam / nrefl");
+  const int64_t n = last->n;
+  const bool amp = last->Es_ri != nullptr || last->Ep_ri != nullptr;
+  int rc;
+  if ((rc = check_beam(last, "last", n, amp))) return rc;
+  if ((rc = check_beam(original, "original", n, amp))) return rc;
+  if ((rc = check_beam(out_global, "out_global", n, amp))) return rc;
+  HIP_TRY(xrt::multi_to_global_launch(*pass, *last, *original, nrefl, *out_global,
+                                      reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
 int xrt_hip_user_unit_abi(void) { return xrt::user_unit_abi(); }
 
 int xrt_hip_user_surface_load(const char* path, void** handle) {
@@ -743,6 +853,7 @@ int xrt_hip_user_surface_load(const char* path, void** handle) {
                                      const double*, double*, void*)>(
       dlsym(dl, "xrt_user_unit_eval"));
   u->xtal = reinterpret_cast<int (*)(int, const void*)>(dlsym(dl, "xrt_user_unit_xtal"));
+  u->multi = reinterpret_cast<int (*)(const void*)>(dlsym(dl, "xrt_user_unit_multi"));
   auto flavour = reinterpret_cast<int (*)()>(dlsym(dl, "xrt_user_unit_layered"));
   u->layered = flavour ? flavour() : 0;
   if (!abi || !u->fused || !u->exact || !u->eval || (u->layered && !u->xtal)) {

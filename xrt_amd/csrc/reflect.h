@@ -93,6 +93,7 @@ struct UserUnit {
   int layered;                                       // the unit holds the layered kernels
   int (*eval)(const xrt_hip_pass* P, int what, int64_t n, const double* u, const double* v,
               double* o, void* stream);
+  int (*multi)(const void* multi_launch);            // general flavour only (else NULL)
 };
 int user_unit_abi();
 
@@ -117,6 +118,16 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
                               double* theta1, double* theta2, void* workspace,
                               hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
                               hipEvent_t evk0, hipEvent_t evk1, bool force_exact);
+
+// One bounce of OE.multiple_reflect (reflect_multi_impl.h); workspace: counts (16 B) | diag
+// (128 B) | GStat (256 B) | partial records | tang [n].
+size_t bounce_workspace_bytes(int64_t n);
+hipError_t reflect_bounce_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
+                                 const xrt_hip_beam& in, const xrt_hip_beam& out,
+                                 const xrt_hip_bounce& B, void* workspace, hipStream_t st);
+hipError_t multi_to_global_launch(const xrt_hip_pass& P, const xrt_hip_beam& last,
+                                  const xrt_hip_beam& orig, const int32_t* nrefl,
+                                  const xrt_hip_beam& gb, hipStream_t st);
 
 hipError_t surface_eval_launch(const xrt_hip_pass& P, int what, int64_t n, const double* u,
                                const double* v, const double* w, double* o, hipStream_t st);

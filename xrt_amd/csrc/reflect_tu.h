@@ -54,10 +54,34 @@ struct DcmLaunch {     // reflect_fused_dcm / reflect_dcm_exact
   PassAux A1, A2;      // (the exact redo)
 };
 
+// one bounce of OE.multiple_reflect (reflect_multi_impl.h)
+struct MultiAux {
+  GStat* g;
+  double* part;                 // partial records, one per block
+  double* tang;                 // [n] ray parameter of the tangency point of each entering ray
+  double* diag;                 // [16] what the host may ask about the batch decisions
+  unsigned long long* counts;   // [0] rays in state 1 or 2 after the bounce, [1] in state 1
+  const int32_t* nrefl_in;      // lb.nRefl before the bounce; NULL (first bounce) = zeros
+  int32_t* nrefl_out;
+  double* theta;                // lb.theta of this bounce (0 where the ray did not hit)
+  const double* elev_in[4];     // elevationD / X / Y / Z before the bounce; NULL = the
+  double* elev_out[4];          //   initial values (reflect.py:214-218); out NULL = not wanted
+  double* spr[3];               // lb.s / phi / r of a parametric surface, or NULL
+};
+struct MultiLaunch {   // one launch of reflect_multi
+  hipStream_t st;
+  const xrt_hip_pass* P;
+  const xrt_hip_material* M;
+  const xrt_hip_beam *in, *out;
+  MultiAux A;
+  int cus;             // compute units of the device
+};
+
 // what a user-surface unit and the library that loads it must agree on
 #define XRT_USER_UNIT_ABI                                                                     \
   ((int)(sizeof(xrt_hip_pass) * 31 + sizeof(xrt_hip_material) * 17 + sizeof(xrt_hip_beam) * 5 + \
-         sizeof(xrt::FusedLaunch) * 7 + sizeof(xrt::ExactLaunch) * 3 + sizeof(xrt::GStat)))
+         sizeof(xrt::FusedLaunch) * 7 + sizeof(xrt::ExactLaunch) * 3 + sizeof(xrt::GStat) +    \
+         sizeof(xrt::MultiLaunch) * 11))
 
 template <class K>
 inline void launch_fused_k(int mode, const FusedLaunch& L) {
@@ -106,5 +130,6 @@ void tu_exact0_dcm(const DcmLaunch& L);
 bool tu_exact1(int spec, const ExactLaunch& L);                     // reflect_exact1.hip
 bool tu_exact2(int spec, const ExactLaunch& L);                     // reflect_exact2.hip
 bool tu_exact3(int spec, const ExactLaunch& L);                     // reflect_exact3.hip
+bool tu_multi(int spec, const MultiLaunch& L);                      // reflect_multi.hip
 
 }  // namespace xrt
