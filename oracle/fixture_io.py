@@ -175,6 +175,9 @@ def load_case(name):
             p['surface'] = dict(kind='user', z=case.numpy_cyl_z, n=case.numpy_cyl_n)
         elif name == 'g2_multi_flat':
             p['surface'] = dict(kind='flat')
+        elif name == 'g2_multi_capillary':
+            p['surface'] = dict(kind='ellipse_capillary', ellipseA=case.CAPILLARY['ellipseA'],
+                                ellipseB=case.CAPILLARY['ellipseB'], ctd=float(g['cap_ctd']))
         else:
             p['surface'] = dict(kind='toroid', R=float(g['surf_R']), r=float(g['surf_r']))
         p['material'] = mn.make_material(

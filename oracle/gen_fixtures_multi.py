@@ -11,6 +11,9 @@ brackets the reference hands to each of its find_intersection calls (tangency an
   g2_multi_edges       optical limits, roll / yaw, dead and 'out' incoming rays, rays that miss
                        or leave over the end, maxReflections = 3 (the loop is cut short)
   g2_multi_flat        flat mirror: one bounce, then nothing
+  g2_multi_capillary   EllipsoidCapillaryMirror (parametric, closed surface of revolution) lit
+                       off its focus: up to four bounces down the bore, lb.s / phi / r, the
+                       elevation map through param_to_xyz
 
 Run:  python -m oracle.gen_fixtures_multi
 """
@@ -105,7 +108,7 @@ def run_multi(tag, oe, params, beam, maxReflections=1000, needElevationMap=False
     g1.save(tag, **out)
 
 
-def main():
+def main(only=None):
     _refenv.activate()
     import xrt.backends.raycing as raycing
     import xrt.backends.raycing.sources as rs
@@ -158,6 +161,16 @@ def main():
     par = g1.oe_params(flat, dict(kind='flat'))
     par['material'] = g1.material_dict(tb, au)
     run_multi('g2_multi_flat', flat, par, beam, maxReflections=10, mat_rho=np.array(19.3))
+
+    # a capillary: the parametric branches (s, phi, r), ray . normal in them
+    bl = raycing.BeamLine()
+    cap = roe.EllipsoidCapillaryMirror(bl, 'cap', material=au, **case.CAPILLARY)
+    beam = case.point_source_rays(rs, 1024, 89, dxprime=3e-3, dzprime=3e-3, E=9000.)
+    par = g1.oe_params(cap, dict(kind='ellipse_capillary', ellipseA=cap.ellipseA,
+                                 ellipseB=cap.ellipseB, ctd=cap.ctd))
+    par['material'] = g1.material_dict(tb, au)
+    run_multi('g2_multi_capillary', cap, par, beam, maxReflections=20, needElevationMap=True,
+              mat_rho=np.array(19.3), cap_ctd=np.array(cap.ctd))
 
 
 if __name__ == '__main__':

@@ -75,6 +75,10 @@ def edges_on(bl):
     return kw
 
 
+# an ellipsoidal capillary lit from 300 mm upstream of its middle (far from the ellipsoid's
+# focus): the rays spiral down the bore, up to four bounces
+CAPILLARY = dict(center=[0, 300., 0], limPhysY=[-200, 200], ellipseA=1000., ellipseB=0.5,
+                 workingDistance=100.)
 FLAT = dict(center=[0, 1000, 0], pitch=4e-3, limPhysX=[-5, 5], limPhysY=[-100, 100.])
 
 

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 GEOM = ('x', 'y', 'z', 'a', 'b', 'c', 'path')
 FIELD = ('Jss', 'Jpp', 'Jsp', 'Es', 'Ep')
-EXTRA = ('theta', 'elevationD', 'elevationX', 'elevationY', 'elevationZ')
+EXTRA = ('theta', 'elevationD', 'elevationX', 'elevationY', 'elevationZ', 's', 'phi', 'r')
 
 
 @pytest.fixture(scope='module', autouse=True)
@@ -46,6 +46,8 @@ def element(name):
         return case.cylinder_subclass(roe)(bl, 'Cylinder', material=au, **case.CYL)
     if name == 'g2_multi_toroid':
         return roe.ToroidMirror(bl, 'toroid', material=au, **case.TOROID)
+    if name == 'g2_multi_capillary':
+        return roe.EllipsoidCapillaryMirror(bl, 'cap', material=au, **case.CAPILLARY)
     return roe.OE(bl, 'flat', material=au, **case.FLAT)
 
 
@@ -98,7 +100,7 @@ def on_surface(oe, lbN, local_z, tol=3e-12):
 
 
 @pytest.mark.parametrize('name', ['g2_multi_cylinder', 'g2_multi_toroid', 'g2_multi_edges',
-                                  'g2_multi_flat'])
+                                  'g2_multi_flat', 'g2_multi_capillary'])
 def test_multiple_reflect_matches_reference(name):
     g = np.load(os.path.join(GOLDEN, name + '.npz'))
     oe = element(name)

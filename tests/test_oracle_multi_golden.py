@@ -6,8 +6,9 @@ import pytest
 
 from oracle import fixture_io, reflect_np as rn
 
-CASES = ['g2_multi_cylinder', 'g2_multi_toroid', 'g2_multi_edges', 'g2_multi_flat']
-EXTRA = ('theta', 'elevationD', 'elevationX', 'elevationY', 'elevationZ')
+CASES = ['g2_multi_cylinder', 'g2_multi_toroid', 'g2_multi_edges', 'g2_multi_flat',
+         'g2_multi_capillary']
+EXTRA = ('theta', 'elevationD', 'elevationX', 'elevationY', 'elevationZ', 's', 'phi', 'r')
 
 
 def check(mine, g, prefix):

@@ -13,7 +13,7 @@ import test_gpu_multiple_reflect as t            # noqa: E402
 from p1_cases import GOLDEN, product_beam       # noqa: E402
 
 names = sys.argv[1:] or ['g2_multi_cylinder', 'g2_multi_toroid', 'g2_multi_edges',
-                         'g2_multi_flat']
+                         'g2_multi_flat', 'g2_multi_capillary']
 os.environ.setdefault('XRT_HIP_USER_CACHE', '/tmp/xrt_units')
 for name in names:
     g = np.load(os.path.join(GOLDEN, name + '.npz'))
@@ -26,7 +26,7 @@ for name in names:
     nb = lbN.nrays // n
     print(name, 'bounces', nb, 'golden', int(g['bounces']))
     fields = [f for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'Jss', 'Jsp', 'Es', 'theta',
-                          'elevationD', 'elevationY') if 'lbN_' + f in g.files]
+                          'elevationD', 'elevationY', 's', 'phi', 'r') if 'lbN_' + f in g.files]
     for k in range(min(nb, int(g['bounces']))):
         sl = slice(k * n, (k + 1) * n)
         row = ['%s %.1e' % (f, np.abs(getattr(lbN, f)[sl] - g['lbN_' + f][sl]).max())
