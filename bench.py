@@ -64,6 +64,11 @@ def parse():
                     help='(default on one GPU) also time cfg3 (DCM Si111, 2 intersections '
                          'per ray)')
     ap.add_argument('--skip-dcm', action='store_true')
+    ap.add_argument('--dry-ranks', action='store_true',
+                    help='no GPU work: the whole rank choreography of --gpus N (tiles, barriers, '
+                         'max over ranks, the packed gather, who-was-there, the line with every '
+                         'key the driver keeps) on gloo with stand-in kernels -- runs in the CPU '
+                         'suite at N = 8')
     ap.add_argument('--dry-run', action='store_true',
                     help='no GPU work: the ranks only rendezvous (gloo) and rank 0 prints '
                          'the line skeleton -- checks the launch path on a CPU box')
@@ -105,12 +110,26 @@ def dry_run(args, line_out=sys.stdout):
         line_out.flush()
 
 
+DRY_RANKS = False     # --dry-ranks: stand-in kernels, CPU tensors, gloo
+
+
 def setup_dist(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    global CPU_GROUP
+    if DRY_RANKS:
+        dist = None
+        if world > 1:
+            import datetime
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+            dist.init_process_group('gloo', timeout=datetime.timedelta(seconds=180))
+            CPU_GROUP = dist.new_group(backend='gloo')
+        return world, rank, local, dist
     # (rehearsal on a box with fewer GPUs than ranks: XRT_BENCH_SHARE_GPU=1 maps the ranks onto
     # the visible GPUs in turn and XRT_BENCH_BACKEND=gloo carries the collectives -- RCCL refuses
     # two ranks on one GPU; the driver's runs use neither)
@@ -131,7 +150,6 @@ def setup_dist(args):
         # a CPU-side group for waits during which the GPUs must stay free (the in-process
         # multi-GPU leg: rank 0 drives every GPU while the others wait; an RCCL barrier would
         # park a spinning kernel on each of them)
-        global CPU_GROUP
         os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')    # one node: the loopback will do
         try:
             CPU_GROUP = dist.new_group(backend='gloo')
@@ -146,7 +164,8 @@ CPU_GROUP = None
 def barrier(dist):
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    if not DRY_RANKS:
+        torch.cuda.synchronize()
 
 
 def max_over_ranks(dist, seconds):
@@ -225,7 +244,27 @@ def bench_reflect_figure(nrays, steps=10):
                      'search: bound by their dependent loads and fp64 arithmetic, not by HBM')
 
 
+def dry_reflect(args, world, rank, dist):
+    """--dry-ranks: the timed region of bench_reflect with a sleep in place of the pass."""
+    n = int(args.rays)
+    barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3 * (1 + rank % 2))
+    barrier(dist)
+    dt = max_over_ranks(dist, time.perf_counter() - t0)
+    k = 1e-3
+    return dict(value=world * n * args.steps / dt, ms_per_step=dt / args.steps * 1e3, rays=n,
+                n_enter=n, surfaces=1, good_fraction=1., kernel_ms=k * 1e3, pass_ms=k * 1e3,
+                roofline=dict(bound='hbm', kernel='reflect_fused (stand-in)',
+                              achieved=BYTES_PER_INTERSECTION * n / k / 1e9, peak=HBM_PEAK / 1e9,
+                              unit='GB/s', frac=BYTES_PER_INTERSECTION * n / k / HBM_PEAK,
+                              traffic=None, traffic_source=None))
+
+
 def bench_reflect(args, world, rank, dist, dcm=False):
+    if DRY_RANKS:
+        return dry_reflect(args, world, rank, dist)
     from xrt_amd import workloads as pc
     n = int(args.rays)
     seed = (43 if dcm else 42) + 1000 * rank          # replicas: own rays per rank
@@ -380,23 +419,45 @@ def kirchhoff_inputs(cfg, device):
 
 
 def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
-    from xrt_amd import hipcalls, multigpu
-    dev = torch.device('cuda', torch.cuda.current_device())
-    s, (px, py, pz), host, ns, side = kirchhoff_inputs(cfg, dev)
-    npix = px.size
-    p0, p1 = multigpu.tile_range(npix, rank, world)             # pixel tile
-    up = lambda a: torch.from_numpy(np.ascontiguousarray(a[p0:p1])).to(dev)  # noqa: E731
-    tx, ty, tz = up(px), up(py), up(pz)
-    out = tuple(torch.empty(p1 - p0, dtype=torch.complex128, device=dev)
-                for _ in range(5))
+    from xrt_amd import multigpu
+    if DRY_RANKS:
+        # stand-in: a small mesh whose tiles are uneven, the "kernel" writes the rank's number
+        dev = torch.device('cpu')
+        ns, side = {4: (1000, 35), 5: (4000, 51)}[cfg]
+        npix = side * side
+        host, s = None, None
+        p0, p1 = multigpu.tile_range(npix, rank, world)
+        out = tuple(torch.empty(p1 - p0, dtype=torch.complex128) for _ in range(5))
 
-    def step(timing=False):
-        r = hipcalls.kirchhoff(tx, ty, tz, s['sx'], s['sy'], s['sz'], s['nx'],
-                               s['ny'], s['nz'], s['nl'], s['k'], s['Es'], s['Ep'],
-                               convention=0, out=out, timing=timing)
-        if dist is not None:        # assemble the full field on every rank: ONE RCCL
-            multigpu.all_gather_packed(out, npix, dist, rank, world)   # all_gather of [5, tile]
-        return r
+        def step(timing=False):
+            for j, t in enumerate(out):
+                t[:] = complex(rank, j)
+            time.sleep(1e-3)
+            full = out
+            if dist is not None:
+                full = multigpu.all_gather_packed(out, npix, dist, rank, world)
+                for r in range(world):          # every rank sees every tile where it belongs
+                    q0, q1 = multigpu.tile_range(npix, r, world)
+                    assert all(bool((full[j][q0:q1] == complex(r, j)).all()) for j in range(5))
+            return list(full) + [1.0 + rank]
+    else:
+        from xrt_amd import hipcalls
+        dev = torch.device('cuda', torch.cuda.current_device())
+        s, (px, py, pz), host, ns, side = kirchhoff_inputs(cfg, dev)
+        npix = px.size
+        p0, p1 = multigpu.tile_range(npix, rank, world)             # pixel tile
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a[p0:p1])).to(dev)  # noqa: E731
+        tx, ty, tz = up(px), up(py), up(pz)
+        out = tuple(torch.empty(p1 - p0, dtype=torch.complex128, device=dev)
+                    for _ in range(5))
+
+        def step(timing=False):
+            r = hipcalls.kirchhoff(tx, ty, tz, s['sx'], s['sy'], s['sz'], s['nx'],
+                                   s['ny'], s['nz'], s['nl'], s['k'], s['Es'], s['Ep'],
+                                   convention=0, out=out, timing=timing)
+            if dist is not None:        # assemble the full field on every rank: ONE RCCL
+                multigpu.all_gather_packed(out, npix, dist, rank, world)   # all_gather of [5, tile]
+            return r
     for _ in range(warmup):
         step()
     barrier(dist)
@@ -426,7 +487,7 @@ def bench_kirchhoff(cfg, steps, warmup, world, rank, dist):
     # (what waves.diffract does with devices = [...], multigpu.kirchhoff_devices): rank 0
     # drives all of them while the other ranks wait
     in_process = None
-    if world > 1 and CPU_GROUP is not None:
+    if world > 1 and CPU_GROUP is not None and not DRY_RANKS:
         barrier(dist)
         if rank == 0:
             try:        # (a figure beside the main one: it must never take the line down)
@@ -974,8 +1035,14 @@ def main():
     line_out = claim_stdout()
     if args.dry_run:
         return dry_run(args, line_out)
-    from xrt_amd import _lib
-    _lib.require_gpu()                    # no CPU fallback: fail loudly
+    global DRY_RANKS
+    DRY_RANKS = bool(args.dry_ranks)
+    if DRY_RANKS:       # the choreography and the line only: every single-GPU leg is skipped
+        args.skip_undulator = args.skip_softimax = args.skip_balder = args.skip_e2e = True
+        args.skip_cpu_baseline = args.skip_dcm = True
+    else:
+        from xrt_amd import _lib
+        _lib.require_gpu()                    # no CPU fallback: fail loudly
     world, rank, local, dist = setup_dist(args)
     main_res = bench_reflect(args, world, rank, dist)
     line = dict(
@@ -1024,7 +1091,7 @@ def main():
             if cfg == 4 or host is None:
                 host = h
             line['kirchhoff' if 'kirchhoff' not in line else 'kirchhoff_cfg%d' % cfg] = kres
-    if world == 1 and not args.skip_kirchhoff:
+    if world == 1 and not args.skip_kirchhoff and not DRY_RANKS:
         line['kirchhoff_general'] = bench_kirchhoff_general()
     if world == 1 and not args.skip_undulator:
         line['undulator'] = bench_undulator(not args.skip_cpu_baseline)
@@ -1046,11 +1113,73 @@ def main():
         line['cpu_baseline']['host_cpus'] = os.cpu_count()
         if host is not None and 'kirchhoff' in line:
             line['kirchhoff']['cpu_baseline'] = cpu_baseline_kirchhoff(host)
+    compact_for_the_record(line, world)
+    if DRY_RANKS:
+        line['dry_ranks'] = True
     if rank == 0:
         line_out.write(json.dumps(line) + '\n')
         line_out.flush()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def compact_for_the_record(line, world):
+    """The driver's record of a run keeps `roofline`, `config` and `cpu_baseline` whole and
+    only the NAMES of everything else: the second half of BASELINE.json's
+    metric -- Kirchhoff pairs/s -- and the one-number summaries of the other legs are repeated
+    there in compact form. Checks who was there before anything is printed."""
+    roof = line.setdefault('roofline', {}) or {}
+    line['roofline'] = roof
+    for key in ('kirchhoff', 'kirchhoff_cfg5'):
+        k = line.get(key)
+        if not k:
+            continue
+        # a multi-rank figure counts only if every rank took part and timed its own tile
+        assert k['rccl_ranks'] == world, (key, k['rccl_ranks'], world)
+        assert len(k['kernel_ms_by_rank']) == world and min(k['kernel_ms_by_rank']) > 0., \
+            (key, k['kernel_ms_by_rank'])
+        name = 'kirchhoff_cfg%d' % (5 if 'cfg5' in k['config']['workload'] else 4)
+        roof[name] = dict(pairs_per_s=k['value'], ms_per_step=k['ms_per_step'],
+                          frac=k['roofline']['frac'], kernel_ms=k['kernel_ms'],
+                          rccl_ranks=k['rccl_ranks'], n_gpus=k['n_gpus'], scaling=k['scaling'],
+                          bound='valu_fp64', peak_tflops=k['roofline']['peak'])
+        base = k.get('cpu_baseline')
+        if base and isinstance(line.get('cpu_baseline'), dict):
+            line['cpu_baseline'][name] = {
+                kk: base[kk] for kk in ('value', 'unit', 'cores', 'kind', 'sample') if kk in base}
+            if 'all_cores' in base:
+                line['cpu_baseline'][name]['all_cores'] = {
+                    kk: base['all_cores'][kk] for kk in ('value', 'cores', 'sample')
+                    if kk in base['all_cores']}
+    legs = {}
+    g = line.get('kirchhoff_general')
+    if g:
+        legs['kirchhoff_general'] = dict(frac=g['roofline']['frac'], kernel_ms=g.get('kernel_ms'))
+        if 'relaxed' in g:
+            legs['kirchhoff_general']['relaxed'] = g['relaxed']
+    for key, pick in (('dcm', lambda d: dict(frac=d['roofline']['frac'],
+                                              ms_per_step=d['ms_per_step'])),
+                      ('undulator', lambda d: dict(frac=d['roofline']['frac'], ms=d.get('ms'))),
+                      ('hist', lambda d: dict(frac=d['roofline']['frac'],
+                                              ms_per_plot=d.get('ms_per_plot'),
+                                              traffic=d['roofline'].get('traffic'))),
+                      ('softimax', lambda d: dict(seconds=d.get('seconds_per_run',
+                                                                d.get('value')))),
+                      ('balder', lambda d: dict(ms_per_step=d.get('ms_per_step'))),
+                      ('e2e', lambda d: dict(
+                          ms_per_iteration=d.get('ms_per_iteration'),
+                          bytes_per_ray=d.get('bytes_per_ray'),
+                          small_1e5_ms=(d.get('small_beams', {}).get('100000_rays', {})),
+                          small_1e6_ms=(d.get('small_beams', {}).get('1000000_rays', {})))),
+                      ('multiple_reflect', lambda d: d)):
+        d = line.get(key)
+        if d:
+            try:
+                legs[key] = pick(d)
+            except (KeyError, TypeError):
+                pass
+    if legs:
+        roof['legs'] = legs
 
 
 if __name__ == '__main__':

@@ -84,7 +84,7 @@ _TWO = pytest.mark.skipif(not _two_gpus(), reason='needs two visible GPUs')
 
 
 @pytest.mark.parametrize('name', ['g4_slit_4000x48', 'g4_toroid_3000x24'])
-@pytest.mark.parametrize('devs', [[0, 0], [0, 0, 0], pytest.param([0, 1], marks=_TWO),
+@pytest.mark.parametrize('devs', [[0, 0], [0, 0, 0], [0] * 8, pytest.param([0, 1], marks=_TWO),
                                   pytest.param([1, 0, 1], marks=_TWO)])
 def test_diffract_over_several_devices_is_the_single_device_result(golden_dir, name, devs):
     """waves.diffract with its receiving points tiled over a list of devices (the reference

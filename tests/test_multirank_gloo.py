@@ -117,6 +117,38 @@ def test_bench_launches_its_own_ranks():
     assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('gpus', [1, 8])
+def test_bench_rank_choreography_without_gpus(gpus):
+    """`bench.py --gpus N --dry-ranks`: everything bench.py does AROUND its kernels on a
+    multi-GPU node -- self-launch, rendezvous, uneven pixel tiles, barriers, max over ranks, the
+    packed all_gather (every rank checks every tile where it belongs), who-was-there, cfg5 at 8
+    ranks -- with stand-in kernels on gloo, and the line the driver keeps: both halves of
+    BASELINE.json's metric inside `roofline`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '2'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus),
+                        '--steps', '3', '--warmup', '1', '--dry-ranks'],
+                       capture_output=True, text=True, timeout=580, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), r.stdout
+    line = json.loads(lines[0])
+    assert line['dry_ranks'] and line['n_gpus'] == gpus and line['steps'] == 3
+    assert line['metric'].startswith('ray-surface intersections/sec/GPU; Kirchhoff')
+    k4 = line['roofline']['kirchhoff_cfg4']
+    assert k4['rccl_ranks'] == gpus and k4['n_gpus'] == gpus and k4['pairs_per_s'] > 0
+    assert set(k4) >= {'pairs_per_s', 'ms_per_step', 'frac', 'kernel_ms', 'rccl_ranks'}
+    assert line['kirchhoff']['kernel_ms_by_rank'] == [1.0 + r for r in range(gpus)]
+    assert ('kirchhoff_cfg5' in line['roofline']) == (gpus == 8)
+    assert line['roofline']['frac'] > 0 and line['value'] > 0
+
+
 def test_device_specifications_of_the_reference():
     """targetOpenCL values that are legal in the reference (myopencl.py:187-231) select
     sensible GPUs instead of failing: 'CPU' / 'auto' -> the current device,
