@@ -209,6 +209,64 @@ def bench_reflect_nolocal(nrays, steps=20):
                      'OE.reflect with both beams')
 
 
+def bench_multiple_reflect(nrays, reps=3, cpu=True):
+    """OE.multiple_reflect (round 5): the toroid of tests/multi_cases.py (3 mrad, 190 mm, a point
+    source 1 m upstream -- the geometry of the reference's 10_MultipleReflect example with a
+    toroid), all bounces of one call; every bounce is a pass over ALL rays (the footprint
+    beam lbN holds them all)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import multi_cases as case
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.materials as rm
+    import xrt_amd.backends.raycing.oes as roe
+    import xrt_amd.backends.raycing.sources as rs
+    bl = raycing.BeamLine(height=0)
+    oe = roe.ToroidMirror(bl, 'toroid', material=rm.Material('Au', rho=19.3, kind='mirror'),
+                          **case.TOROID)
+    beam = case.point_source_rays(rs, nrays, 5)
+    beam.to_struct(torch.device('cuda', torch.cuda.current_device()))
+    times = []
+    for _ in range(reps + 1):
+        info = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gb, lbN = oe.multiple_reflect(beam, maxReflections=100, _info=info)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = min(times[1:])
+    bounces = lbN.nrays // nrays
+    entered = sum(one['n_enter'] for one in info)
+    per_ray = 112 + (32 if beam.has_amplitudes() else 0)       # x..Jsp, state, nRefl, theta
+    moved = bounces * nrays * 2 * per_ray
+    res = dict(metric='ray-surface intersections/s, OE.multiple_reflect', value=entered / dt,
+               unit='intersections/s', rays=nrays, bounces=bounces, intersections=entered,
+               ms_per_call=dt * 1e3, ms_per_bounce=dt * 1e3 / bounces,
+               hbm_fraction=moved / dt / HBM_PEAK,
+               note='one launch per bounce (reflect_multi: four phases between grid barriers); '
+                    'the third bounce runs the reference\'s bracket-keeping secant to its '
+                    'iteration limit (100) for every ray: instruction-bound by the '
+                    'reference\'s own search, not by HBM')
+    if cpu:
+        from oracle import fixture_io, reflect_np as rn
+        p, _, _ = fixture_io.load_case('g2_multi_toroid')
+        m = 200000
+        ob = rn.Beam(m, with_amplitudes=True)
+        src = case.point_source_rays(rs, m, 5)
+        for f in ob.fields():
+            setattr(ob, f, np.array(getattr(src, f)))
+        t0 = time.perf_counter()
+        cnt = []
+        rn.oe_multiple_reflect(p, ob, 100, False, info=cnt)
+        cdt = time.perf_counter() - t0
+        centered = sum(int((one['tMin'] != 0).sum()) if k == 0 else 0 for k, one in enumerate(cnt))
+        res['cpu_baseline'] = dict(
+            value=entered / nrays * m / cdt, unit='intersections/s', cores=1, kind='port',
+            sample='%d rays through oracle/reflect_np.py:oe_multiple_reflect (numpy, 1 thread), '
+                   '%.1f s' % (m, cdt))
+        del centered
+    return res
+
+
 def bench_reflect_figure(nrays, steps=10):
     """The cfg2 toroid under a figure error (OE(figureError=RandomRoughness): a 512 x 128 height
     map as a bicubic spline, evaluated per ray in every step of the intersection search and
@@ -564,7 +622,21 @@ def bench_kirchhoff_general(reps=3):
     kms = float(np.mean([hipcalls.kirchhoff(*args, timing=True)[5] for _ in range(2)]))
     pairs = float(h['ns']) * float(h['npix'])
     variants = sorted(hipcalls.kirchhoff_report()['variants'])
+    # the opt-in relaxed loop on the same inputs: its time, and what it loses against the exact
+    # sums of the same launch (norm-wise)
+    exact = [o.clone() for o in hipcalls.kirchhoff(*args)[:5]]
+    rel = hipcalls.kirchhoff(*args, relaxed=True, timing=True)
+    rms = float(np.mean([hipcalls.kirchhoff(*args, relaxed=True, timing=True)[5]
+                         for _ in range(2)]))
+    rvariants = sorted(hipcalls.kirchhoff_report()['variants'])
+    loss = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(rel[:5], exact))
+    relaxed = dict(kernel_ms=rms, frac=FLOP_PER_PAIR * pairs / (rms * 1e-3) / FP64_PEAK,
+                   loop_variants=rvariants, normwise_difference_from_exact=loss,
+                   note='opt-in (waves.precision = "relaxed", XRT_HIP_KIRCHHOFF_RELAXED): d.d '
+                        'contracted, the root without its last correction, k folded into the '
+                        'phase reduction; 57 flop per pair counted as for the exact loop')
     return dict(
+        relaxed=relaxed,
         metric='Kirchhoff sample*pixel pairs/s, general loop', value=pairs / dt, unit='pairs/s',
         samples=h['ns'], pixels=h['npix'], ms_per_call=dt * 1e3, kernel_ms=kms,
         loop_variants=variants,
@@ -942,7 +1014,29 @@ def bench_softimax(runs=3):
     best = min(times)
     pairs = 7 * 2e5 * 2e5 + 3 * 2e5 * 4096
     focus = out['beamFSMExp01']
+    # the same script with waves.precision = 'relaxed' (opt-in): seconds, and the flux in the
+    # focus against the exact run's
+    rw.precision = 'relaxed'
+    try:
+        rtimes = []
+        for _ in range(2):
+            np.random.seed(1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            rout = scene.run()
+            torch.cuda.synchronize()
+            rtimes.append(time.perf_counter() - t1)
+        rfocus = rout['beamFSMExp01']
+        rflux = float((rfocus.Jss + rfocus.Jpp).sum())
+    finally:
+        rw.precision = 'exact'
+    np.random.seed(1)
+    xfocus = scene.run()['beamFSMExp01']
+    xflux = float((xfocus.Jss + xfocus.Jpp).sum())
+    relaxed = dict(seconds=min(rtimes), focus_flux=rflux, focus_flux_exact_same_seed=xflux,
+                   relative_flux_difference=abs(rflux - xflux) / abs(xflux))
     return dict(
+        relaxed=relaxed,
         metric='SoftiMAX wave chain (reference speed test 3_Softi_CXIw2D), seconds '
                'per run', seconds=best, seconds_first_run_incl_setup=first,
         kirchhoff_kernel_seconds=min(kernel),
@@ -1106,6 +1200,9 @@ def main():
         line['reflect_figure'] = bench_reflect_figure(int(args.rays))
     if world == 1 and not args.skip_e2e:
         line['e2e'] = bench_e2e(int(args.rays))
+    if world == 1 and not args.skip_dcm:
+        line['multiple_reflect'] = bench_multiple_reflect(int(args.rays),
+                                                          cpu=not args.skip_cpu_baseline)
     if args.with_softi_shapes and world == 1:
         line['softi_shapes'] = bench_softi_shapes()
     if world == 1 and rank == 0 and not args.skip_cpu_baseline:
@@ -1163,15 +1260,18 @@ def compact_for_the_record(line, world):
                       ('hist', lambda d: dict(frac=d['roofline']['frac'],
                                               ms_per_plot=d.get('ms_per_plot'),
                                               traffic=d['roofline'].get('traffic'))),
-                      ('softimax', lambda d: dict(seconds=d.get('seconds_per_run',
-                                                                d.get('value')))),
+                      ('softimax', lambda d: dict(
+                          seconds=d.get('seconds'), first=d.get('seconds_first_run_incl_setup'),
+                          relaxed_seconds=d.get('relaxed', {}).get('seconds'))),
                       ('balder', lambda d: dict(ms_per_step=d.get('ms_per_step'))),
                       ('e2e', lambda d: dict(
                           ms_per_iteration=d.get('ms_per_iteration'),
                           bytes_per_ray=d.get('bytes_per_ray'),
                           small_1e5_ms=(d.get('small_beams', {}).get('100000_rays', {})),
                           small_1e6_ms=(d.get('small_beams', {}).get('1000000_rays', {})))),
-                      ('multiple_reflect', lambda d: d)):
+                      ('multiple_reflect', lambda d: dict(
+                          value=d['value'], ms_per_bounce=d['ms_per_bounce'],
+                          bounces=d['bounces'], cpu=d.get('cpu_baseline', {}).get('value')))):
         d = line.get(key)
         if d:
             try:

@@ -65,6 +65,12 @@ XRT_HIP_API const char* xrt_hip_last_error(void);   /* thread-local, never NULL 
  * loop with the oracle that way). Outputs may be NULL. */
 #define XRT_HIP_KIRCHHOFF_NO_FAST 0x100   /* no planar / paraxial specialisation */
 #define XRT_HIP_KIRCHHOFF_NO_SHARE 0x200  /* no sharing of a receiving-mesh column */
+/* Opt-in: the loops for samples with general normals (mirror -> mirror transfers) in a relaxed
+ * form -- d.d contracted, the root without its last correction, k folded into the phase
+ * reduction: 5 of 60 issue slots per pair less. Results are no longer the doubles numpy's
+ * _diffraction_integral_conv (waves.py:836-850) produces but agree with them norm-wise to
+ * ~1e-8 (reported by tests/test_gpu_kirchhoff.py and bench.py); the default stays exact. */
+#define XRT_HIP_KIRCHHOFF_RELAXED 0x400
 XRT_HIP_API int xrt_hip_kirchhoff_plan(int64_t np, int64_t ns, int nsplit_req, int ppt_req,
                            size_t* workspace_bytes, int* nsplit, int* ppt);
 

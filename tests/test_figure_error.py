@@ -338,3 +338,32 @@ def test_figure_error_on_a_dcm_and_refusals():
                                       figureError=fe)
     with pytest.raises(NotImplementedError, match='parametric'):
         em.reflect(workloads.synthetic_rays(1000, 5))
+
+
+def test_imported_map_on_top_of_a_base_map(tmp_path):
+    """FigureErrorImported(fileName=..., baseFE=...): the base map is added (it was
+    dropped without a word). The measured heights plus the base map's on the same grid; with
+    the reference at hand (build container), its map bit for bit."""
+    from oracle import _refenv
+    x = np.linspace(-10, 10, 41)
+    y = np.linspace(-80, 80, 161)
+    X, Y = np.meshgrid(x, y, indexing='ij')
+    Z = 5. * np.cos(2 * np.pi * Y / 47.) * (1 + 0.1 * X)
+    path = tmp_path / 'map.txt'
+    np.savetxt(path, np.column_stack([X.ravel(), Y.ravel(), Z.ravel()]), fmt='%.17g')
+
+    def maps(module):
+        bump = module.GaussianBump(bumpHeight=30., sigmaX=3., sigmaY=20., limPhysX=[-10, 10],
+                                   limPhysY=[-80, 80], gridStep=0.5)
+        both = module.FigureErrorImported(fileName=str(path), baseFE=bump)
+        alone = module.FigureErrorImported(fileName=str(path))
+        return bump, both, alone
+    bump, both, alone = maps(fc.rfe)
+    assert both.baseFE is bump
+    under = bump.local_z_distorted(both.x2d, both.y2d) * 1e6
+    assert np.abs(both.z2d - alone.z2d).max() > 29. and \
+        np.allclose(both.z2d - alone.z2d, under, rtol=0, atol=1e-9)
+    if _refenv.available():
+        _refenv.activate()
+        import xrt.backends.raycing.figure_error as ref
+        assert np.array_equal(maps(ref)[1].z2d, both.z2d)

@@ -385,9 +385,10 @@ class FigureErrorImported(FigureErrorBase):
         self.surfArrays, self.z2d = {}, None
         self._recenter, self._orientation, self._fileName = recenter, orientation, None
         self._columnFactors = _three_factors(columnFactors)
+        # (nothing may reset baseFE after this call: the constructor argument is honoured as in
+        # the reference, figure_error.py:306-309 -- ADVICE r4)
         super().__init__(**dict(kwargs, name=kwargs.get('name', 'NOM surface'),
                                 skip_build_spline=True))
-        self._baseFE = None
         self.fileName = fileName
 
     def _realign(self):

@@ -29,6 +29,11 @@ timeKernels = False
 # the call's targetOpenCL / the XRT_HIP_DEVICES environment variable say (default: the
 # current device only).
 devices = None
+# 'exact' (default): the integrals are the doubles of the reference's numpy kernel
+# (_diffraction_integral_conv, waves.py:834-851) to ~1e-12. 'relaxed' (opt-in): transfers from
+# samples with general normals (mirror -> mirror) run a loop with 8 % fewer instructions whose
+# sums agree to ~1e-8 norm-wise (hipcalls.kirchhoff(relaxed=True), include/xrt_hip.h).
+precision = 'exact'
 
 
 _ACCUMULATORS = ('EsAcc', 'EpAcc', 'aEacc', 'bEacc', 'cEacc')
@@ -296,15 +301,20 @@ def _kirchhoff_on_gpu(points, samples, targetOpenCL='auto'):
     several GPUs if asked (``devices``): pixel tiles, see multigpu.kirchhoff_devices."""
     global lastKernelMs
     from ... import multigpu
+    if precision not in ('exact', 'relaxed'):
+        raise ValueError("waves.precision is 'exact' or 'relaxed'")
+    relaxed = precision == 'relaxed'
     devs = multigpu.parse_devices(devices if devices is not None else targetOpenCL,
                                   torch.cuda.device_count())
     if devs is not None and len(devs) > 1:
         lastKernelMs = None
-        return multigpu.kirchhoff_devices(points, samples, devs, convention=0)
+        return multigpu.kirchhoff_devices(points, samples, devs, convention=0,
+                                          relaxed=relaxed)
     if devs is not None and devs[0] != points[0].device.index:
         raise ValueError('the wave lives on cuda:%d, not on cuda:%d'
                          % (points[0].device.index, devs[0]))
-    out = hipcalls.kirchhoff(*points, *samples, convention=0, timing=timeKernels)
+    out = hipcalls.kirchhoff(*points, *samples, convention=0, timing=timeKernels,
+                             relaxed=relaxed)
     lastKernelMs = out[5] if timeKernels else None
     return out[:5]
 

@@ -365,6 +365,43 @@ __device__ __forceinline__ void sincos_tab(double phi, const double2* tab,
   sn = fma_(T.x, s, sn);
 }
 
+// The same for phi = kr * r with the factor N / (2 pi) folded into kr on the host side of the
+// loop: ks = k N / (2 pi) as a double-double (ksh, ksl), the multiplication k r is not formed at
+// all (the relaxed Kirchhoff loop: one slot less, and the steps come out more accurately than
+// from the rounded product k r -- but not as numpy rounds them).
+template <int N = SINCOS_TAB_N>
+__device__ __forceinline__ void sincos_tab_scaled(double r, double ksh, double ksl,
+                                                  const double2* tab, const SinCosTabRegs<N>& k,
+                                                  double& sn, double& cs) {
+  static_assert(N == 2048 || N == 4096, "table sizes the offset arithmetic knows");
+  constexpr double DELTA = 0x1.921fb54442d18p+1 * (2.0 / N);
+  constexpr double S1 = -(DELTA * DELTA * DELTA) / 6.0;
+  constexpr double C2 = (DELTA * DELTA) * (DELTA * DELTA) / 24.0;
+  const double MAGIC = 0x1.8p52;
+  const double m = fma_(r, ksh, MAGIC);
+  const double n = m - MAGIC;
+  unsigned off;
+  if (N == 2048)
+    asm("v_lshlrev_b32 %0, 4, %1\n\tv_and_b32 %0, 0x7ff0, %0"
+        : "=v"(off)
+        : "v"((unsigned)__double2loint(m)));
+  else
+    asm("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD "
+        "src0_sel:DWORD src1_sel:DWORD"
+        : "=v"(off)
+        : "v"((unsigned)__double2loint(m)));
+  const double2 T = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(tab) + off);
+  double u = fma_(r, ksh, -n);
+  u = fma_(r, ksl, u);
+  const double w = u * u;
+  const double s = fma_(S1, w, k.s0) * u;
+  const double c = N == 2048 ? fma_(fma_(C2, w, k.c1), w, 1.0) : fma_(k.c1, w, 1.0);
+  cs = T.x * c;
+  cs = fma_(-T.y, s, cs);
+  sn = T.y * c;
+  sn = fma_(T.x, s, sn);
+}
+
 // table form where its bound holds, the general polynomial form otherwise (the
 // branch is taken per lane; a wave whose lanes all qualify skips the slow side)
 __device__ __forceinline__ void sincos_any(double phi, const double2* tab,

@@ -17,6 +17,8 @@
 // bits of ppt_req above the point count (testing knobs, see include/xrt_hip.h)
 #define KIRCHHOFF_OPT_NO_FAST 0x100   /* keep the general-geometry loops */
 #define KIRCHHOFF_OPT_NO_SHARE 0x200  /* no per-lane sharing of the mesh column */
+#define KIRCHHOFF_OPT_RELAXED 0x400   /* the general-normal loops in their relaxed form */
+#define KIRCHHOFF_OPT_TAB4096 0x800   /* (internal) the launch uses the 4096-step table */
 
 namespace xrt {
 

@@ -223,6 +223,17 @@ __global__ __launch_bounds__(256) void kirchhoff_pack(
     o[5] = make_double2(k2 * (2. * vz), ep.x);
     o[6] = make_double2(ep.y, q.x);
     o[7] = make_double2(q.y, 0.);
+    if (info->opts & KIRCHHOFF_OPT_RELAXED) {
+      // relaxed loops: ks = k N / (2 pi), table steps per mm, as a double-double in the two
+      // slots the loop variant does not read otherwise ([15]; [8] = 2k^2 when Ep is there,
+      // [11] = Re Ep = 0 when it is not)
+      const double scale = (info->opts & KIRCHHOFF_OPT_TAB4096) ? 1024. : 512.;
+      const double SH = 0x1.45f306dc9c883p-1 * scale, SL = -0x1.6b01ec5417056p-55 * scale;
+      const double ksh = kk * SH;
+      const double ksl = fma_(kk, SL, fma_(kk, SH, -ksh));
+      rec[i * KIRCHHOFF_REC_DOUBLES + 15] = ksh;
+      rec[i * KIRCHHOFF_REC_DOUBLES + ((info->flags & KIRCHHOFF_FLAG_EP) ? 8 : 11)] = ksl;
+    }
   }
 }
 
@@ -298,9 +309,15 @@ __device__ __forceinline__ void accumulate(const Mid& m, double esr, double esi,
 // The update of one (receiving point, sample) pair comes in two halves so that the
 // loop can put its scalar prefetch between them (see stream_loop): head ends with the
 // first use of the LDS table entry, tail is pure accumulation.
-template <bool HAS_P, bool GEN_N, bool TAB>
+// RELAX (opt-in, XRT_HIP_KIRCHHOFF_RELAXED; TAB only): d.d contracted into two fma, the root
+// without its last correction step (r to ~1 ulp instead of correctly rounded, 1/(2r) as
+// before), k r not formed -- the table steps come from r times a double-double k N / (2 pi)
+// (sincos_tab_scaled). 5 issue slots of 60 less; the results are no longer numpy's doubles
+// (a pair's phase moves by up to an ulp of k r ~ 6e-5 rad at cfg4's distances, as numpy's own
+// rounding of k r does against the true product).
+template <bool HAS_P, bool GEN_N, bool TAB, bool RELAX = false>
 struct GenKern {
-  static constexpr int NDW = (HAS_P || GEN_N) ? 32 : 18;
+  static constexpr int NDW = (HAS_P || GEN_N || RELAX) ? 32 : 18;
   struct Shared {};
   template <int PPT>
   static __device__ __forceinline__ void pre(const Pts<PPT>&,
@@ -317,9 +334,19 @@ struct GenKern {
     m.dx = p.x[j] - sx;
     m.dy = p.y[j] - sy;
     m.dz = p.z[j] - sz;
-    const double s2 = (m.dx * m.dx + m.dy * m.dy) + m.dz * m.dz;
-    const double rr = sqrt_rn_halfinv(s2, m.h);   // h = 1/(2r)
-    const double phase = k * rr;
+    double rr, phase = 0.;
+    if (RELAX) {
+      const double s2 = fma_(m.dz, m.dz, fma_(m.dy, m.dy, m.dx * m.dx));
+      const double y = __builtin_amdgcn_rsq(s2);
+      const double g = s2 * y, h = 0.5 * y;
+      const double r0 = fma_(-h, g, 0.5);
+      rr = fma_(g, r0, g);
+      m.h = fma_(h, r0, h);
+    } else {
+      const double s2 = (m.dx * m.dx + m.dy * m.dy) + m.dz * m.dz;
+      rr = sqrt_rn_halfinv(s2, m.h);   // h = 1/(2r)
+      phase = k * rr;
+    }
     // --- the rest only needs ~1e-16 relative accuracy ---
     double dn;
     if (GEN_N) {
@@ -331,7 +358,9 @@ struct GenKern {
     }
     const double cr = m.h * fma_(dn, m.h, knl);   // (k/r)(d.n/r + nl)
     double sn, cs;
-    if (TAB)
+    if (RELAX)
+      sincos_tab_scaled<TN>(rr, r[15], HAS_P ? r[8] : r[11], tab, kreg, sn, cs);
+    else if (TAB)
       sincos_tab<TN>(phase, tab, kreg, sn, cs);
     else
       sincos_phase(phase, sn, cs);
@@ -342,7 +371,9 @@ struct GenKern {
   static __device__ __forceinline__ void tail(const Mid& m, const Shared&,
                                               const double (&r)[KIRCHHOFF_REC_DOUBLES],
                                               Acc& a) {
-    accumulate<HAS_P, false>(m, r[6], r[7], r[11], r[12], r[13], r[14], r[8], a);
+    // (RELAX without Ep: [11] holds the low part of ks, Ep is zero)
+    accumulate<HAS_P, false>(m, r[6], r[7], RELAX && !HAS_P ? 0. : r[11], r[12], r[13], r[14],
+                             r[8], a);
   }
 };
 
@@ -595,7 +626,9 @@ enum {
   KV_FAST_S_SHARE = 9,    // mesh column per lane                        (+1: UNIK)
   KV_FAST_SP_SHARE = 11,
   KV_FAST_S_NOTAB = 12,   //                                             (+1: UNIK)
-  KV_FAST_SP_NOTAB = 14
+  KV_FAST_SP_NOTAB = 14,
+  KV_GEN_S_N_RELAX = 15,  // XRT_HIP_KIRCHHOFF_RELAXED: the general-normal loops, relaxed
+  KV_GEN_SP_N_RELAX = 16
 };
 
 template <int PPT>
@@ -656,6 +689,7 @@ __global__ __launch_bounds__(KIRCHHOFF_BLOCK, PPT > 2 ? 2 : KIRCHHOFF_WAVES) voi
   const bool share = PPT > 1 && L != KIRCHHOFF_BLOCK && __all(onex);
   const bool has_p = f & KIRCHHOFF_FLAG_EP;
   const bool gen_n = f & KIRCHHOFF_FLAG_NXZ;
+  const bool relaxed = __builtin_amdgcn_readfirstlane(info->opts) & KIRCHHOFF_OPT_RELAXED;
   int v;
 #define KIRCHHOFF_RUN(vid, ...)                                   \
   do {                                                            \
@@ -693,10 +727,14 @@ __global__ __launch_bounds__(KIRCHHOFF_BLOCK, PPT > 2 ? 2 : KIRCHHOFF_WAVES) voi
   } else if (!has_p) {
     if (!gen_n)
       KIRCHHOFF_RUN(KV_GEN_S_Y, GenKern<false, false, true>);
+    else if (relaxed)
+      KIRCHHOFF_RUN(KV_GEN_S_N_RELAX, GenKern<false, true, true, true>);
     else
       KIRCHHOFF_RUN(KV_GEN_S_N, GenKern<false, true, true>);
   } else if (!gen_n) {
     KIRCHHOFF_RUN(KV_GEN_SP_Y, GenKern<true, false, true>);
+  } else if (relaxed) {
+    KIRCHHOFF_RUN(KV_GEN_SP_N_RELAX, GenKern<true, true, true, true>);
   } else {
     KIRCHHOFF_RUN(KV_GEN_SP_N, GenKern<true, true, true>);
   }
@@ -907,7 +945,8 @@ hipError_t kirchhoff_launch(const KirchhoffPlan& pl, int64_t np, const double* p
     const int nbp = (int)(wp < 256 ? wp : 256), nbs = (int)(wsm < 256 ? wsm : 256);
     hipLaunchKernelGGL(kirchhoff_scan, dim3((unsigned)(nbp + nbs)), dim3(256), 0, stream, np,
                        px, py, pz, ns, sx, sy, sz, pstride, nx, nz, nstride, k,
-                       reinterpret_cast<const double2*>(Ep), nbp, (unsigned)pl.opts, info);
+                       reinterpret_cast<const double2*>(Ep), nbp,
+                       (unsigned)(pl.opts | (pl.ppt >= 4 ? KIRCHHOFF_OPT_TAB4096 : 0)), info);
   }
   if (ns > 0) {
     hipLaunchKernelGGL(kirchhoff_pack, dim3((unsigned)((ns + 255) / 256)), dim3(256),

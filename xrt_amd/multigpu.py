@@ -167,7 +167,7 @@ def _side_stream(device_index, slot):
     return st
 
 
-def kirchhoff_devices(points, samples, devices, convention=0):
+def kirchhoff_devices(points, samples, devices, convention=0, relaxed=False):
     """The five integrals for *points* (3 tensors) from *samples* (10 tensors), all on the
     current device, computed on *devices* (ordinals, repeats allowed) -> 5 tensors on the
     current device, ordered after its current stream.
@@ -216,7 +216,7 @@ def kirchhoff_devices(points, samples, devices, convention=0):
     for w in work:                       # 2. kernels
         with on(w):
             w['tile'] = hipcalls.kirchhoff(*w['pts'], *w['smp'], convention=convention,
-                                           nsplit=nsplit, ppt=ppt)
+                                           nsplit=nsplit, ppt=ppt, relaxed=relaxed)
     for w in work:                       # 3. copies back into the arrays on the home device
         with on(w):
             for o, t in zip(out, w['tile']):
