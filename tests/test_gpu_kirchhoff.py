@@ -202,8 +202,23 @@ def test_every_loop_variant_matches_oracle(loop, ppt):
 
 
 # ---- the opt-in relaxed loops (include/xrt_hip.h XRT_HIP_KIRCHHOFF_RELAXED) --
+# What the relaxed loops can and cannot keep: at these distances k r ~ 4e11 rad, one ulp of
+# which is 6e-5 rad. numpy rounds r and then k r; ANY other rounding of either -- the contracted
+# d.d, the root one correction short, the unrounded product -- moves a pair's phase by up to
+# that much (as numpy's own roundings do against the true product). On sums of samples with
+# RANDOM amplitudes (these cases) the result then differs by the same 1e-5..1e-4 norm-wise, on
+# the smooth fields of a beamline by 1e-6..1e-7 (bench.py reports both). The exact loops stay at
+# 1e-12 only because they are numpy's operations bit for bit. So relaxed is NOT inside the 1e-5
+# parity bar for incoherent sums at hard-X-ray distances: it is an opt-in for throughput.
 RELAXED = 0x400
-RELAXED_TOL = 1e-7          # norm-wise, against the bar of 1e-5 (exact mode: asserted at 1e-9)
+
+
+
+def relaxed_tol(case):
+    """Three ulps of the largest phase k r of the case, norm-wise (exact mode: 1e-9)."""
+    px, py, pz, sx, sy, sz, n, nl, E = case[:9]
+    reach = np.abs(np.asarray(py)).max() + 1.
+    return 3 * 2.**-52 * (np.max(E) / CHBAR * 1e7) * reach
 
 
 def _normwise(mine, ref):
@@ -215,8 +230,8 @@ def _normwise(mine, ref):
                                        ('gen_sp_n', dict(dist=40000., one_k=True))])
 def test_relaxed_loops_against_the_oracle(loop, opts, ppt, record_property):
     """General normals take the relaxed loop when asked; what they lose is REPORTED (pytest
-    -rP / junit property) and bounded at 1e-7 norm-wise; the exact call on the same inputs
-    stays at 1e-9 and runs the exact loop."""
+    -rP / junit property) and bounded (see RELAXED_TOL above); the exact call on the same
+    inputs stays at 1e-9 and runs the exact loop."""
     from xrt_amd import hipcalls
     case = random_case(96 * 37 + 5, 3000, seed=77 + ppt, **opts)
     ref = kn.kirchhoff_conv(*case)
@@ -225,7 +240,7 @@ def test_relaxed_loops_against_the_oracle(loop, opts, ppt, record_property):
     err = _normwise(mine, ref)
     record_property('relaxed_normwise_error', err)
     print('relaxed %s ppt %d: norm-wise error %.2e' % (loop, ppt, err))
-    assert err <= RELAXED_TOL, err
+    assert err <= relaxed_tol(case), (err, relaxed_tol(case))
     exact = run_hip(*case, ppt=ppt, nsplit=8)
     assert hipcalls.kirchhoff_report()['variants'] == {loop}
     assert_close(exact, ref)
@@ -257,7 +272,7 @@ def test_relaxed_on_the_reference_golden(golden_dir, record_property):
     err = _normwise(mine, g['raw'])
     record_property('relaxed_normwise_error_g4_toroid', err)
     print('relaxed, g4_toroid_3000x24: norm-wise error %.2e' % err)
-    assert err <= RELAXED_TOL
+    assert err <= relaxed_tol(golden_inputs(g))
 
 
 def test_planar_but_wide_angle_keeps_the_general_loop():
