@@ -676,6 +676,22 @@ XRT_HIP_API int xrt_hip_screen_expose_f64_dev(const xrt_hip_screen* screen,
                                               const xrt_hip_beam* in, xrt_hip_beam* out,
                                               void* stream);
 
+/* OE.reflect whose global beam goes straight into Screen.expose, as ONE pass over the beam
+ * (N1 of SURVEY 8f, "fused aperture / screen ops"; oes/reflect.py:18-163 followed by
+ * screens.py:226-302): xrt_hip_reflect_pass_f64_dev with the screen's image `out_screen` made in
+ * the tail of the pass, from the registers that hold the outgoing ray. keep_virgin = 0: nobody
+ * else reads the global beam -- out_virgin (still a full beam: scratch) is then written only
+ * if the exact sequence has to redo the pass, and its contents are undefined on return
+ * otherwise: 308 B per ray cross HBM (100 in, 100 + 8 local, 100 image) instead of the 508 of
+ * the two passes. The lean mirror / plate kernels carry the screen (flat screens); any other
+ * pass is followed by the screen's own launch inside this call -- *fused (optional) tells
+ * which (1 / 0). Same bits as the two calls one after the other. */
+XRT_HIP_API int xrt_hip_reflect_screen_f64_dev(
+    const xrt_hip_pass* pass, const xrt_hip_material* material, const xrt_hip_beam* in,
+    const xrt_hip_beam* restore, xrt_hip_beam* out_local, xrt_hip_beam* out_virgin,
+    double* theta, const xrt_hip_screen* screen, xrt_hip_beam* out_screen, int keep_virgin,
+    void* workspace, size_t workspace_bytes, void* stream, int* fused, float* kernel_ms);
+
 /* ---- RectangularAperture.propagate / RoundAperture.propagate (apertures.py:334-413, 770-846)
  * Rays with state > 0 are taken to the aperture plane (local y = 0); those
  * outside the blades (inside, for a beam stop) get state lost_num = -ordinal-1000

@@ -1,0 +1,222 @@
+"""GPU: a consumer fused into its producer (N1 of SURVEY 8f). OE.reflect hands
+out its beams before anything is launched (sources.LazyBeam); if the script's first use of the
+global beam is Screen.expose, the image is made in the tail of the SAME pass
+(xrt_hip_reflect_screen_f64_dev, reflect_fused_scr) and the global beam is written only if
+somebody asks for it afterwards. Everything must be bit-identical to the two separate launches
+(reference: oes/reflect.py:18-163 followed by screens.py:226-302), whatever the order in which
+the script touches the beams."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import xrt_amd.backends.raycing as raycing
+import xrt_amd.backends.raycing.apertures as ra
+import xrt_amd.backends.raycing.materials as rm
+import xrt_amd.backends.raycing.oes as roe
+import xrt_amd.backends.raycing.run as rr
+import xrt_amd.backends.raycing.screens as rsc
+import xrt_amd.backends.raycing.sources as rs
+from xrt_amd import plotter as xrtp, runner as xrtr, workloads
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp', 'state')
+
+
+def same(a, b, what, extra=()):
+    names = FIELDS + (('Es', 'Ep') if a.has_amplitudes() else ()) + tuple(extra)
+    for f in names:
+        u, v = a.peek(f), b.peek(f)
+        assert np.array_equal(u, v, equal_nan=True), (what, f, np.abs(u - v).max())
+
+
+def scene(n=200000, amplitudes=True, bad=True):
+    bl = raycing.BeamLine(azimuth=0.02)
+    oe = workloads.cfg2_toroid(bl)
+    scr = rsc.Screen(bl, 'focus', center=[0, 20000. + 10000. * np.cos(8e-3),
+                                          10000. * np.sin(8e-3)])
+    beam = workloads.synthetic_rays(n, 7, amplitudes=amplitudes)
+    if bad:
+        beam.state[::97] = -3          # dead on arrival
+        beam.state[5::101] = 2
+        beam.x[::53] *= 300.           # off the mirror
+        beam.c[3::211] = -beam.c[3::211] - 1e-2   # away from it
+        beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    return bl, oe, scr, beam
+
+
+def eager(oe, scr, beam, **kw):
+    old = roe.fuseConsumers
+    roe.fuseConsumers = False
+    try:
+        gb, lb = oe.reflect(beam)
+        img = scr.expose(gb, **kw)
+    finally:
+        roe.fuseConsumers = old
+    return gb, lb, img
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+def test_screen_in_the_tail_of_the_pass_is_the_two_launches(amplitudes):
+    bl, oe, scr, beam = scene(amplitudes=amplitudes)
+    gb0, lb0, img0 = eager(oe, scr, beam)
+    gb, lb = oe.reflect(beam)
+    assert type(gb) is rs.LazyBeam and gb.__dict__['_op'].state == 'pending'
+    img = scr.expose(gb)
+    op = gb.__dict__['_op']
+    assert op.state == 'imaged' and not gb.__dict__['_filled']        # the lean kernel took it
+    same(img, img0, 'image')
+    same(lb, lb0, 'local', extra=('theta',))
+    assert img.parentId == img0.parentId and lb.parentId == lb0.parentId
+    # ... and the global beam, asked for afterwards, is the eager one
+    same(gb, gb0, 'global')
+    assert op.state == 'done'
+    # a second screen on the now existing beam: the plain launch
+    same(scr.expose(gb, onlyPositivePath=True), eager(oe, scr, beam, onlyPositivePath=True)[2],
+         'second image')
+
+
+def test_any_other_first_use_launches_the_plain_pass():
+    bl, oe, scr, beam = scene(n=50000)
+    gb0, lb0, img0 = eager(oe, scr, beam)
+    gb, lb = oe.reflect(beam)
+    assert lb.nrays == beam.nrays                 # the local beam is looked at first
+    assert gb.__dict__['_op'].state == 'done' and gb.__dict__['_filled']
+    same(lb, lb0, 'local', extra=('theta',))
+    same(scr.expose(gb), img0, 'image')
+    same(gb, gb0, 'global')
+    # attributes of an xrt script on a pending beam
+    gb, lb = oe.reflect(beam)
+    assert np.array_equal(gb.state, gb0.state) and hasattr(lb, 'theta')
+    # a copy
+    gb, lb = oe.reflect(beam)
+    same(rs.Beam(copyFrom=gb), gb0, 'copy')
+
+
+def test_a_contradicted_pass_is_redone_and_imaged_from_the_real_beam():
+    """Rays for which the batch statistics ask for Brent's method (golden g2_toroid_brent): the
+    optimistic pass with the screen in its tail is contradicted, the exact sequence writes the
+    global beam and the image is made from it."""
+    import p1_cases
+    g = np.load(os.path.join(p1_cases.GOLDEN, 'g2_toroid_brent.npz'))
+    oe = p1_cases.product_oe('g2_toroid_brent', g)
+    beam = p1_cases.product_beam(g)
+    scr = rsc.Screen(oe.bl, 'after', center=[0, float(g['oe_center'][1]) + 3000., 10.])
+    info = {}
+    oe.reflect(beam, _info=info)
+    assert info['brent']
+    gb0, lb0, img0 = eager(oe, scr, beam)
+    gb, lb = oe.reflect(beam)
+    img = scr.expose(gb)
+    same(img, img0, 'image')
+    same(lb, lb0, 'local', extra=('theta',))
+    same(gb, gb0, 'global')
+
+
+def test_elements_whose_kernels_do_not_carry_a_screen():
+    """A Bragg crystal (not a lean kernel): the same call, the screen's own launch inside it."""
+    bl = raycing.BeamLine()
+    si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    thB = float(np.ravel(si.get_Bragg_angle(9000.) - si.get_dtheta(9000.))[0])
+    xt = roe.OE(bl, 'xtal', center=[0, 20000., 0], pitch=thB, material=si, limPhysX=[-10, 10],
+                limPhysY=[-50, 50])
+    scr = rsc.Screen(bl, 'after', center=[0, 21000., 1000. * np.tan(2 * thB)])
+    beam = workloads.synthetic_rays(60000, 3, sa=1e-4, E=(8995., 9005.), amplitudes=True)
+    gb0, lb0, img0 = eager(xt, scr, beam)
+    gb, lb = xt.reflect(beam)
+    img = scr.expose(gb)
+    assert gb.__dict__['_op'].state == 'done'
+    same(img, img0, 'image')
+    same(gb, gb0, 'global')
+    same(lb, lb0, 'local', extra=('theta',))
+    # a hemispheric screen reads the stored beam
+    hs = rsc.HemisphericScreen(bl, 'sphere', center=[0, 20000., 0], R=500.)
+    m = workloads.cfg2_toroid(bl)
+    beam = workloads.synthetic_rays(20000, 4)
+    g1, _ = m.reflect(beam)
+    i1 = hs.expose(g1)
+    roe.fuseConsumers = False
+    try:
+        g2, _ = m.reflect(beam)
+        i2 = hs.expose(g2)
+    finally:
+        roe.fuseConsumers = True
+    same(i1, i2, 'sphere', extra=('theta', 'phi'))
+
+
+def test_changes_in_place_come_after_the_pending_pass():
+    """aperture.propagate writes beam.state in place: a pass still waiting that reads the beam is
+    launched first, as in program order."""
+    bl, oe, scr, beam = scene(n=40000, bad=False)
+    slit = ra.RectangularAperture(bl, 'slit', [0, 15000., 0], ('left', 'right'), [-0.02, 0.02])
+    roe.fuseConsumers = False
+    try:
+        b0 = rs.Beam(copyFrom=beam)
+        gb0, lb0 = oe.reflect(b0)
+        slit.propagate(b0)
+    finally:
+        roe.fuseConsumers = True
+    b1 = rs.Beam(copyFrom=beam)
+    gb, lb = oe.reflect(b1)
+    slit.propagate(b1)                                   # (would kill most rays)
+    same(lb, lb0, 'local', extra=('theta',))
+    same(gb, gb0, 'global')
+    assert np.array_equal(b1.state, b0.state) and (b1.state < 0).sum() > 1000
+    # the input edited on the host afterwards does not reach the pass either
+    b2 = rs.Beam(copyFrom=beam)
+    gb, lb = oe.reflect(b2)
+    b2.x[:] = 1e6
+    same(lb, lb0, 'local', extra=('theta',))
+
+
+def test_run_ray_tracing_with_and_without_fusion():
+    def run(fuse, graph):
+        roe.fuseConsumers = fuse
+        try:
+            bl, run_process, make_plot = workloads.e2e_beamline(100000, seed=5)
+            rr.run_process = run_process
+            plots = [make_plot(),
+                     xrtp.XYCPlot('mirrorLocal', (1,), xrtp.XYCAxis('x', 'mm', limits=[-3, 3]),
+                                  xrtp.XYCAxis('y', 'mm', limits=[-300, 300]))]
+            xrtr.run_ray_tracing(plots, repeats=6, beamLine=bl, graph=graph)
+            torch.cuda.synchronize()
+            return plots
+        finally:
+            roe.fuseConsumers = True
+    ref = run(False, False)
+    for graph in (False, True):
+        got = run(True, graph)
+        for a, b in zip(got, ref):
+            assert a.nRaysAll == b.nRaysAll and a.total2D.max() > 0
+            assert np.abs(a.total2D - b.total2D).max() <= 1e-12 * b.total2D.max()
+            assert abs(a.intensity - b.intensity) <= 1e-12 * b.intensity
+
+
+def test_c_abi_keeps_the_global_beam_on_request():
+    """xrt_hip_reflect_screen_f64_dev(keep_virgin=1): all three beams from one call."""
+    import ctypes
+    from xrt_amd import _lib, hipcalls
+    bl, oe, scr, beam = scene(n=30000)
+    gb0, lb0, img0 = eager(oe, scr, beam)
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    p = oe._make_pass(oe.pitch, oe.roll + oe.positionRoll, oe.yaw, oe.dx)
+    ms = oe._material_struct(oe.material, True, dev, beam)
+    lb, gb, img = (rs.Beam.empty_like_on_device(beam, dev) for _ in range(3))
+    theta = torch.empty(beam.nrays, dtype=torch.float64, device=dev)
+    ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(beam.nrays), 'reflect')
+    fused = ctypes.c_int(-1)
+    s_in = beam.to_struct(dev)
+    _lib.check(lib.xrt_hip_reflect_screen_f64_dev(
+        ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in),
+        ctypes.byref(lb.to_struct(dev)), ctypes.byref(gb.to_struct(dev)),
+        ctypes.c_void_p(theta.data_ptr()), ctypes.byref(scr._record(False)),
+        ctypes.byref(img.to_struct(dev)), 1, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(fused), None),
+        'xrt_hip_reflect_screen_f64_dev')
+    assert fused.value == 1
+    same(img, img0, 'image')
+    same(gb, gb0, 'global')
+    same(lb, lb0, 'local')

@@ -133,6 +133,8 @@ class RectangularAperture(object):
         the new global beam if *needNewGlobal*."""
         _lib.require_gpu()
         dev = torch.device('cuda', torch.cuda.current_device())
+        beam.to_struct(dev)
+        rs.flush_pending(beam)           # (beam.state changes in place below)
         local = rs.Beam.empty_like_on_device(beam, dev)
         glo = rs.Beam.empty_like_on_device(beam, dev) if needNewGlobal else None
         rec = self._record()

@@ -514,6 +514,10 @@ class OE(object):
         _lib.require_gpu()
         lib = _lib.load()
         dev = _device()
+        if out is not None:              # (beams about to be overwritten in place)
+            for b in out:
+                if b is not None and type(b) is not rs.LazyBeam:
+                    rs.flush_pending(b)
         ms = self._material_struct(material, fromVacuum, dev, beam_in)
         if p.eff_tab_n > 0 and graphs.capturing() is None:
             # (recorded into a HIP graph: checked by the eager iteration before it)
@@ -584,6 +588,8 @@ class OE(object):
         turn = self.roll + self.positionRoll
         p.roll, p.cos_roll, p.sin_roll = float(turn), float(np.cos(turn)), float(np.sin(turn))
         dev = _device()
+        lb.to_struct(dev)
+        rs.flush_pending(lb)             # (lb changes in place)
         _lib.check(_lib.load().xrt_hip_local_to_global_f64_dev(
             ctypes.byref(p), ctypes.byref(lb.to_struct(dev)), _stream()),
             'xrt_hip_local_to_global_f64_dev')
@@ -743,6 +749,13 @@ class OE(object):
             self.pitch + getattr(self, 'bragg', 0), self.roll + self.positionRoll,
             self.yaw, self.dx, noIntersectionSearch=noIntersectionSearch,
             only_state1_out=hasattr(beam, 'createdByDiffract'))
+        rs.flush_pending()             # (at most one pass is ever waiting for its consumer)
+        if fuseConsumers and local and out is None and _info is None and _timing is None and \
+                getattr(self, '_zones_between_passes', None) is None and \
+                not (p.grating and raycing.is_sequence(self.order)) and not p.eff_tab_n:
+            # not launched yet: Screen.expose of the global beam may still join the pass
+            op = _DeferredReflect(self, p, beam, out)
+            return op.gb, op.lb
         lb, gb, report = self._run_pass(
             p, self.material, True, beam, beam, want_info=_info is not None,
             timing=_timing is not None, out=None if out is None else (out[1], out[0]),
@@ -760,6 +773,99 @@ class OE(object):
         if _timing is not None:
             _timing.update({k: report[k] for k in clock})
         return gb, lb
+
+
+# OE.reflect -> Screen.expose as one pass (see sources.LazyBeam). XRT_HIP_NO_FUSE=1 in the
+# environment, or oes.fuseConsumers = False, keeps every call an immediate launch.
+fuseConsumers = os.environ.get('XRT_HIP_NO_FUSE', '') != '1'
+
+
+class _DeferredReflect(object):
+    """OE.reflect not launched yet. States: pending -> done (plain pass: both beams), or
+    pending -> imaged (the pass with a screen in its tail: local beam and image; the global
+    beam was not written) -> done (the global beam alone, on demand)."""
+
+    def __init__(self, oe, p, beam, out=None):
+        dev = _device()
+        beam.to_struct(dev)                      # everything up in HBM now
+        snap = rs.Beam.__new__(rs.Beam)          # the input as it is at this moment
+        object.__setattr__(snap, '_h', {})
+        object.__setattr__(snap, '_d', dict(beam._d))
+        rs.inherit_scalars(snap, beam)
+        object.__setattr__(snap, 'parentId', getattr(beam, 'parentId', None))
+        if 'createdByDiffract' in beam.__dict__:
+            snap.createdByDiffract = beam.createdByDiffract
+        self.oe, self.p, self.beam, self.out = oe, p, snap, out
+        self.tensors = set(id(t) for t in snap._d.values())
+        self.state = 'pending'
+        self.gb, self.lb = rs.LazyBeam(self, 'gb'), rs.LazyBeam(self, 'lb')
+        oe._adopt((self.gb, self.lb), beam)
+        rs._PENDING.add(self)
+
+    def reads(self, beam):
+        d = beam.__dict__.get('_real_d', beam.__dict__.get('_d')) or {}
+        return any(id(t) in self.tensors for t in d.values())
+
+    def materialize(self, which=None):
+        oe = self.oe
+        if self.state == 'pending':
+            rs._PENDING.discard(self)
+            self.state = 'done'
+            lb, gb, _ = oe._run_pass(self.p, oe.material, True, self.beam, self.beam,
+                                     out=None if self.out is None else (self.out[1], self.out[0]))
+            self.lb._adopt_arrays(lb)
+            self.gb._adopt_arrays(gb)
+        elif self.state == 'imaged' and which == 'gb':
+            # somebody wants the global beam after all: the pass without its local beam
+            self.state = 'done'
+            _, gb, _ = oe._run_pass(self.p, oe.material, True, self.beam, self.beam, local=False)
+            self.gb._adopt_arrays(gb)
+        self.beam = None if self.state == 'done' else self.beam
+
+    def image_on(self, screen, rec):
+        """The pass with *screen* in its tail -> the screen's image (a plain Beam)."""
+        oe = self.oe
+        rs._PENDING.discard(self)
+        lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, self.beam, rec)
+        self.lb._adopt_arrays(lb)
+        if fused:
+            self.state = 'imaged'
+            self._scratch = gb            # (the redo's scratch: freed with this record)
+        else:
+            self.state = 'done'
+            self.gb._adopt_arrays(gb)
+            self.beam = None
+        return image
+
+
+def _run_pass_screen(self, p, material, beam_in, screen_record):
+    """OE.reflect + Screen.expose in one C call (xrt_hip_reflect_screen_f64_dev) ->
+    (lb, gb, image, fused): fused = the lean kernel carried the screen and gb holds nothing."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    dev = _device()
+    ms = self._material_struct(material, True, dev, beam_in)
+    s_in = beam_in.to_struct(dev)
+    n = beam_in.nrays
+    lb = rs.Beam.empty_like_on_device(beam_in, dev)
+    gb = rs.Beam.empty_like_on_device(beam_in, dev)
+    image = rs.Beam.empty_like_on_device(beam_in, dev)
+    theta = torch.empty(n, dtype=torch.float64, device=dev)
+    ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(n), 'reflect')
+    fused = ctypes.c_int(0)
+    _lib.check(lib.xrt_hip_reflect_screen_f64_dev(
+        ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in),
+        ctypes.byref(lb.to_struct(dev)), ctypes.byref(gb.to_struct(dev)),
+        ctypes.c_void_p(theta.data_ptr()), ctypes.byref(screen_record),
+        ctypes.byref(image.to_struct(dev)), 0, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+        _stream(), ctypes.byref(fused), None), 'xrt_hip_reflect_screen_f64_dev')
+    lb._d['theta'] = theta
+    self._adopt((lb, gb), beam_in)
+    rs.inherit_scalars(image, beam_in)
+    return lb, gb, image, bool(fused.value)
+
+
+OE._run_pass_screen = _run_pass_screen
 
 
 def _ray_orders(self, p, beam, lb, gb, _info, _timing):

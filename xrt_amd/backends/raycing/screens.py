@@ -53,8 +53,13 @@ class Screen(object):
         (reference screens.py:226-302)."""
         _lib.require_gpu()
         dev = torch.device('cuda', torch.cuda.current_device())
-        image = rs.Beam.empty_like_on_device(beam, dev)
         rec = self._record(onlyPositivePath)
+        op = beam.__dict__.get('_op') if type(beam) is rs.LazyBeam else None
+        if op is not None and op.state == 'pending' and beam is op.gb and op.p.out_to_global:
+            # the element's pass has not been launched: the image is made in its tail, the
+            # global beam is not written unless somebody else asks for it (sources.LazyBeam)
+            return op.image_on(self, rec)
+        image = rs.Beam.empty_like_on_device(beam, dev)
         _lib.check(_lib.load().xrt_hip_screen_expose_f64_dev(
             ctypes.byref(rec), ctypes.byref(beam.to_struct(dev)),
             ctypes.byref(image.to_struct(dev)),

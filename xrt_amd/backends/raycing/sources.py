@@ -412,6 +412,59 @@ class Beam(object):
         return self.has_amplitudes() and not ('Es' in held and 'Ep' in held)
 
 
+# ---- beams whose pass has not been launched yet -------------------------------------------------
+# OE.reflect hands out its two beams before it launches anything: if the first thing the script
+# does with the global beam is Screen.expose, the screen's image is made in the tail of the
+# SAME pass (csrc/reflect_impl.h: reflect_fused_scr) and the global beam itself is not written
+# unless somebody asks for it later. Any other use of either beam -- an attribute, a plot, the
+# next element -- launches the plain pass at that moment: same kernels, same bits, a little
+# later on the stream.
+_PENDING = set()        # the operations not launched yet (strong references: they own inputs)
+
+
+def flush_pending(beam=None):
+    """Launches what is still pending -- all of it, or what reads *beam* (called by whoever is
+    about to change a beam's arrays in place)."""
+    for op in list(_PENDING):
+        if beam is None or op.reads(beam):
+            op.materialize()
+
+
+class LazyBeam(Beam):
+    """A beam that an operation (*op*, with ``materialize(which)``) will fill: its arrays
+    come into being when first looked at."""
+
+    def __init__(self, op, role):
+        object.__setattr__(self, '_op', op)
+        object.__setattr__(self, '_role', role)
+        object.__setattr__(self, '_real_h', {})
+        object.__setattr__(self, '_real_d', {})
+        object.__setattr__(self, '_filled', False)
+        object.__setattr__(self, 'parentId', None)
+
+    def _fill(self):
+        if not self.__dict__['_filled']:
+            self.__dict__['_op'].materialize(self.__dict__['_role'])
+
+    def _adopt_arrays(self, real):
+        """Takes over the arrays of the beam the launch made."""
+        object.__setattr__(self, '_real_d', real.__dict__['_d'])
+        object.__setattr__(self, '_real_h', real.__dict__['_h'])
+        if '_struct' in real.__dict__:
+            object.__setattr__(self, '_struct', real.__dict__['_struct'])
+        object.__setattr__(self, '_filled', True)
+
+    @property
+    def _d(self):
+        self._fill()
+        return self.__dict__['_real_d']
+
+    @property
+    def _h(self):
+        self._fill()
+        return self.__dict__['_real_h']
+
+
 def inherit_scalars(new, old):
     """Per-beam scalars (source bookkeeping, flags) follow the rays into a new beam."""
     for key in _SCALAR_ATTRS:

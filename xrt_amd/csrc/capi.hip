@@ -409,14 +409,22 @@ struct OwnEvents {
   }
 };
 
-int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_material* material,
-                                 const xrt_hip_beam* in, const xrt_hip_beam* restore,
-                                 xrt_hip_beam* out_local, xrt_hip_beam* out_virgin,
-                                 double* theta, void* workspace, size_t workspace_bytes,
-                                 void* stream, double* info_host, float* kernel_ms) {
+static int reflect_pass_impl(const xrt_hip_pass* pass, const xrt_hip_material* material,
+                             const xrt_hip_beam* in, const xrt_hip_beam* restore,
+                             xrt_hip_beam* out_local, xrt_hip_beam* out_virgin, double* theta,
+                             void* workspace, size_t workspace_bytes, void* stream,
+                             double* info_host, float* kernel_ms,
+                             const xrt_hip_screen* screen, xrt_hip_beam* out_screen,
+                             int keep_virgin, int* fused) {
   const ArmedEvents armed;
   int rc;
   if ((rc = check_pass(pass, material))) return rc;
+  if (screen) {
+    if (!in || !out_screen) return fail(XRT_HIP_ERR_ARG, "screen without its image beam");
+    if ((rc = check_beam(out_screen, "out_screen", in->n,
+                         in->Es_ri != nullptr || in->Ep_ri != nullptr)))
+      return rc;
+  }
   if (pass->is_multi || pass->need_elevation_map)
     return fail(XRT_HIP_ERR_ARG, "is_multi / need_elevation_map: a bounce of multiple_reflect "
                                  "goes through xrt_hip_reflect_bounce_f64_dev");
@@ -467,7 +475,8 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
   const bool force_exact = info_host != nullptr || (ex && ex[0] == '1');
   hipError_t e = xrt::reflect_pass_launch(*pass, *material, *in, *restore, *out_local,
                                           *out_virgin, theta, workspace, st, e0, e1, k0, k1,
-                                          force_exact);
+                                          force_exact, screen, out_screen, keep_virgin != 0,
+                                          fused);
   if (e != hipSuccess) return fail(XRT_HIP_ERR_HIP, "reflect launch: %s", hipGetErrorString(e));
   if (kernel_ms) {
     HIP_TRY(hipEventSynchronize(e1));
@@ -498,6 +507,34 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
     if (g.hang) return fail(XRT_HIP_ERR_HIP, "reflect: a grid barrier of the exact sequence timed out");
   }
   return XRT_HIP_OK;
+}
+
+int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_material* material,
+                                 const xrt_hip_beam* in, const xrt_hip_beam* restore,
+                                 xrt_hip_beam* out_local, xrt_hip_beam* out_virgin,
+                                 double* theta, void* workspace, size_t workspace_bytes,
+                                 void* stream, double* info_host, float* kernel_ms) {
+  return reflect_pass_impl(pass, material, in, restore, out_local, out_virgin, theta, workspace,
+                           workspace_bytes, stream, info_host, kernel_ms, nullptr, nullptr, 1,
+                           nullptr);
+}
+
+int xrt_hip_reflect_screen_f64_dev(const xrt_hip_pass* pass, const xrt_hip_material* material,
+                                   const xrt_hip_beam* in, const xrt_hip_beam* restore,
+                                   xrt_hip_beam* out_local, xrt_hip_beam* out_virgin,
+                                   double* theta, const xrt_hip_screen* screen,
+                                   xrt_hip_beam* out_screen, int keep_virgin, void* workspace,
+                                   size_t workspace_bytes, void* stream, int* fused,
+                                   float* kernel_ms) {
+  if (!screen) return fail(XRT_HIP_ERR_ARG, "NULL screen");
+  if (screen->radius != 0. && !keep_virgin)
+    return fail(XRT_HIP_ERR_ARG, "a hemispheric screen takes the stored global beam "
+                                 "(keep_virgin = 1)");
+  if (!pass || !pass->out_to_global)
+    return fail(XRT_HIP_ERR_ARG, "a screen takes the beam in the global frame (out_to_global)");
+  return reflect_pass_impl(pass, material, in, restore, out_local, out_virgin, theta, workspace,
+                           workspace_bytes, stream, nullptr, kernel_ms, screen, out_screen,
+                           keep_virgin, fused);
 }
 
 int xrt_hip_double_reflect_fusable(const xrt_hip_pass* pass1, const xrt_hip_material* material1,

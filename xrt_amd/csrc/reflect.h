@@ -104,7 +104,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
                                void* workspace, hipStream_t st, hipEvent_t ev0,
                                hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1,
-                               bool force_exact);
+                               bool force_exact, const xrt_hip_screen* scr = nullptr,
+                               const xrt_hip_beam* sb = nullptr, bool keep_virgin = true,
+                               int* fused = nullptr);
 
 // DCM.double_reflect in one kernel: both crystals per ray, the beam between them stays
 // in registers. lo1 / lo2: local beams of the two crystals, gb2: global beam after the

@@ -4,6 +4,7 @@
 #define XRT_REFLECT_MAIN_TU
 #include "reflect_impl.h"
 #include "reflect_tu.h"
+#include "screen.h"
 
 namespace xrt {
 
@@ -551,8 +552,10 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
                                void* workspace, hipStream_t st, hipEvent_t ev0,
                                hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1,
-                               bool force_exact) {
+                               bool force_exact, const xrt_hip_screen* scr,
+                               const xrt_hip_beam* sb, bool keep_virgin, int* fused) {
   static_assert(sizeof(GStat) <= 256, "workspace head slot");
+  if (fused) *fused = 0;
   static_assert(REFLECT_OPT_SLOTS * sizeof(OptStat) <= REFLECT_PART_BYTES, "report slots");
   const int64_t n = in.n;
   if (n <= 0) return hipSuccess;
@@ -636,7 +639,23 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   A.hz = L.hz;
   A.hst = L.hst;
   A.aliased = aliased ? 1 : 0;
-  const FusedLaunch FL{grid, fblock, st, &P, &M, &in, &restore, &lb, &vb, theta, g, opt};
+  // A screen in the tail of the pass (Screen.expose of the global beam, flat screens): the
+  // lean kernels carry it; every other pass is followed by the screen's own launch. In the
+  // fused form `vb` is written only if the caller keeps it (or if the exact sequence has to
+  // redo the pass: then the image is made from it afterwards).
+  const bool lean = spec == SP_TOROID_MIRROR || spec == SP_FLAT_MIRROR ||
+                    spec == SP_BENT_MIRROR || spec == SP_FLAT_PLATE;
+  const bool fuse_screen = scr && sb && optimistic && lean && scr->radius == 0.;
+  xrt_hip_beam vb_fused = vb;
+  if (fuse_screen && !keep_virgin) {
+    vb_fused.x = vb_fused.y = vb_fused.z = vb_fused.a = vb_fused.b = vb_fused.c = nullptr;
+    vb_fused.path = vb_fused.E = vb_fused.Jss = vb_fused.Jpp = vb_fused.Jsp_ri = nullptr;
+    vb_fused.state = nullptr;
+    vb_fused.Es_ri = vb_fused.Ep_ri = nullptr;
+  }
+  const FusedLaunch FL{grid, fblock, st, &P, &M, &in, &restore, &lb,
+                       fuse_screen ? &vb_fused : &vb, theta, g, opt,
+                       fuse_screen ? scr : nullptr, fuse_screen ? sb : nullptr};
   const ExactLaunch XL{dim3(exact_blocks(n)), dim3(REFLECT_EXACT_BLOCK), st, &P, &M, &in,
                        &restore, &lb, &vb, A};
   bool launched = true;
@@ -648,7 +667,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     return hipErrorInvalidValue;        // (capi.hip says why before it gets here)
   // the solve + finish kernel: mode 0 (optimistic) or 2 (no statistics needed)
   auto launch_fused = [&](int mode) {
-    if (unit)      // (need_mean here: a multilayer deflecting as a crystal -- layered flavour)
+    if (fuse_screen)
+      launched &= tu_hot_fused_scr(spec, mode, FL);
+    else if (unit)      // (need_mean here: a multilayer deflecting as a crystal -- layered flavour)
       launched &= (need_mean ? unit->xtal(mode, &FL) : unit->fused(mode, &FL)) == 0;
     else if (figured)
       launched &= tu_figured_fused(spec, mode, FL);
@@ -695,6 +716,15 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     if (evk0) (void)hipEventRecord(evk0, st);
     launch_exact();
     if (evk1) (void)hipEventRecord(evk1, st);
+  }
+  if (scr && sb) {
+    hipError_t se;
+    if (fuse_screen)      // (only if the exact sequence redid the pass: from the real vb)
+      se = screen_expose_if_launch(&g->redo, *scr, vb, *sb, st);
+    else
+      se = screen_expose_launch(*scr, vb, *sb, st);
+    if (se != hipSuccess) return se;
+    if (fused) *fused = fuse_screen ? 1 : 0;
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   if (!launched) return hipErrorInvalidDeviceFunction;   // no unit holds this spec

@@ -34,6 +34,7 @@
 #include "../../include/xrt_hip.h"
 #include "fp64_math.h"
 #include "reflect.h"
+#include "screen_impl.h"
 
 namespace xrt {
 
@@ -3244,6 +3245,27 @@ __device__ __forceinline__ void copy_ray(const xrt_hip_beam& o, const xrt_hip_be
             es.x, es.y, ep.x, ep.y, has_amp);
 }
 
+// What a pass does with the outgoing ("virgin" / global) record of a ray besides storing it: a
+// consumer fused into the producer (N1 of SURVEY 8f). The script hands the global beam of an
+// element straight on to a screen more often than not; the screen's image is then made here,
+// from the registers, instead of by a pass of its own that reads the beam back (100 B per ray
+// less to read, and 100 B less to write when nobody else wants the global beam: vb.x null).
+struct NoConsumer {
+  static constexpr bool ON = false;
+};
+struct ScreenConsumer {        // Screen.expose, flat screens (screen_impl.h)
+  static constexpr bool ON = true;
+  xrt_hip_screen S;
+  xrt_hip_beam out;
+  __device__ __forceinline__ void take(int64_t i, double x, double y, double z, double a,
+                                       double b, double c, double path, double E, double Jss,
+                                       double Jpp, double Jsr, double Jsi, int st, double Esr,
+                                       double Esi, double Epr, double Epi, bool has_amp) const {
+    expose_flat_store(S, out, i, x, y, z, a, b, c, path, E, Jss, Jpp, Jsr, Jsi, st, Esr, Esi,
+                      Epr, Epi, has_amp);
+  }
+};
+
 // everything after the solve for one entering ray: state, finish, both stores.
 // QREADY: the ray's fields come in qin instead of from `in`. VREC: the outgoing
 // ("virgin") record is handed back in registers instead of being stored, with `kept` =
@@ -3252,14 +3274,14 @@ struct Completed {
   bool kept;
   Rec v;
 };
-template <class K, bool QREADY = false, bool VREC = false>
+template <class K, bool QREADY = false, bool VREC = false, class CONS = NoConsumer>
 __device__ __forceinline__ Completed complete_ray(
     const xrt_hip_pass& P, const xrt_hip_material& M, const GStat& g, const xrt_hip_beam& in,
     const xrt_hip_beam& restore, const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
     int64_t i, const LocalRay& r, const Hit& h, int st, bool has_amp, int own_sign = 0,
     double* bdn_out = nullptr, RayIn qin = RayIn(), const cplx* npre = nullptr,
     const LocalRay* raw = nullptr, XtalEnergy* xe = nullptr, bool xe_ready = false,
-    ProbeClock* pc = nullptr) {
+    ProbeClock* pc = nullptr, const CONS& cons = CONS()) {
   Completed res;
   res.kept = false;
   RayIn q;
@@ -3400,23 +3422,46 @@ __device__ __forceinline__ Completed complete_ray(
     res.v.st = st;
     return res;
   }
-  store_ray(vb, i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, vst, vEsr, vEsi,
-            vEpr, vEpi, has_amp);
+  if (!CONS::ON || vb.x)
+    store_ray(vb, i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, vst, vEsr,
+              vEsi, vEpr, vEpi, has_amp);
+  if constexpr (CONS::ON)
+    cons.take(i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, vst, vEsr, vEsi,
+              vEpr, vEpi, has_amp);
   return res;
 }
 
-template <class K>
+template <class K, class CONS = NoConsumer>
 __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hip_beam& in,
                                              const xrt_hip_beam& restore,
                                              const xrt_hip_beam& lb, const xrt_hip_beam& vb,
-                                             double* theta, int64_t i, int st, bool has_amp) {
+                                             double* theta, int64_t i, int st, bool has_amp,
+                                             const CONS& cons = CONS()) {
   // not entering: both outputs are copies (reflect.py:104-108); dcm.py:298-303
   // zeroes the local record of rays that never reached the 2nd crystal
   if (P.zero_local_not_entering)
     copy_ray<optional_local<K>()>(lb, in, i, 0, has_amp, true);
   else
     copy_ray<optional_local<K>()>(lb, in, i, st, has_amp, false);
-  copy_ray(vb, restore, i, P.force_lost_out ? P.lost_num : st, has_amp, false);
+  const int vst = P.force_lost_out ? P.lost_num : st;
+  if constexpr (CONS::ON) {
+    const xrt_hip_beam& s = restore;
+    const double2 js = reinterpret_cast<const double2*>(s.Jsp_ri)[i];
+    double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+    if (has_amp) {
+      es = reinterpret_cast<const double2*>(s.Es_ri)[i];
+      ep = reinterpret_cast<const double2*>(s.Ep_ri)[i];
+    }
+    const double x = s.x[i], y = s.y[i], z = s.z[i], a = s.a[i], b = s.b[i], c = s.c[i];
+    const double path = s.path[i], E = s.E[i], Jss = s.Jss[i], Jpp = s.Jpp[i];
+    if (vb.x)
+      store_ray(vb, i, x, y, z, a, b, c, path, E, Jss, Jpp, js.x, js.y, vst, es.x, es.y, ep.x,
+                ep.y, has_amp);
+    cons.take(i, x, y, z, a, b, c, path, E, Jss, Jpp, js.x, js.y, vst, es.x, es.y, ep.x, ep.y,
+              has_amp);
+  } else {
+    copy_ray(vb, restore, i, vst, has_amp, false);
+  }
   if (theta) theta[i] = 0.;
 }
 
@@ -3472,13 +3517,13 @@ __device__ __forceinline__ void raise_sign_flags(int* __restrict__ flags, int se
 }
 
 // one ray of the fused solve + finish; own_sign / neg / pos serve the crystal variant
-template <class K, int mode, bool XTAL>
+template <class K, int mode, bool XTAL, class CONS = NoConsumer>
 __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_material& M,
                                           const xrt_hip_beam& in, const xrt_hip_beam& restore,
                                           const xrt_hip_beam& lb, const xrt_hip_beam& vb,
                                           double* theta, const GStat& g, OptStat* opt,
                                           int64_t i, const RayRequest& req, int& neg,
-                                          int& pos) {
+                                          int& pos, const CONS& cons = CONS()) {
   const bool has_amp = in.Es_ri != nullptr;
   ProbeClock pc;
   XRT_TICK(pc, 0, 0.);
@@ -3504,7 +3549,8 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
   // (measured on cfg2: 0.71 -> 0.68 ms, at four waves per SIMD instead of five)
   const RayIn qpre = req.q;
 #endif
-  if (i < in.n && !active) pass_through<K>(P, in, restore, lb, vb, theta, i, st0, has_amp);
+  if (i < in.n && !active)
+    pass_through<K, CONS>(P, in, restore, lb, vb, theta, i, st0, has_amp, cons);
   XRT_TICK(pc, 1, r.x + r.a + r.z);
   Hit h;
   if (mode == 0) {
@@ -3529,18 +3575,22 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
     if (h.lost) st = P.lost_num;
     if (XTAL) {
       double bdn = 0.;
-      complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 1, &bdn);
+      complete_ray<K, false, false, CONS>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp,
+                                       1, &bdn, RayIn(), nullptr, nullptr, nullptr, false,
+                                       nullptr, cons);
       neg |= st == 1 && bdn < 0.;
       pos |= st == 1 && !(bdn < 0.);
     } else {
 #ifndef XRT_LATE_FIELDS
       if (early_fields<K>())
-        complete_ray<K, true>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 0,
-                              nullptr, qpre, NPRE ? &npre : nullptr, &raw, nullptr, false, &pc);
+        complete_ray<K, true, false, CONS>(P, M, g, in, restore, lb, vb, theta, i, r, h, st,
+                                        has_amp, 0, nullptr, qpre, NPRE ? &npre : nullptr, &raw,
+                                        nullptr, false, &pc, cons);
       else
 #endif
-      complete_ray<K>(P, M, g, in, restore, lb, vb, theta, i, r, h, st, has_amp, 0, nullptr,
-                      RayIn(), NPRE ? &npre : nullptr);
+      complete_ray<K, false, false, CONS>(P, M, g, in, restore, lb, vb, theta, i, r, h, st,
+                                       has_amp, 0, nullptr, RayIn(), NPRE ? &npre : nullptr,
+                                       nullptr, nullptr, false, nullptr, cons);
     }
   }
 #ifdef XRT_PROBE_TIMING
@@ -3566,6 +3616,24 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
   const GStat g = *gp;
   int neg = 0, pos = 0;
   fused_ray<K, mode, false>(P, M, in, restore, lb, vb, theta, g, opt, i, req, neg, pos);
+}
+
+// The same pass with a screen in its tail: OE.reflect whose global beam goes straight into
+// Screen.expose. `vb` with null arrays: the global beam itself is not wanted (nothing but the
+// screen reads it). The optimistic form only (mode 0 / 2): a contradicted pass is redone by
+// reflect_exact into the real `vb`, and screen_expose_if_kernel makes the image from that.
+template <class K, int mode>
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_scr(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
+    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
+    OptStat* __restrict__ opt, ScreenConsumer cons) {
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
+  const RayRequest req = request_ray<early_fields<K>()>(in, i, in.Es_ri != nullptr);
+  if (fused_skips(gp, mode)) return;
+  const GStat g = *gp;
+  int neg = 0, pos = 0;
+  fused_ray<K, mode, false, ScreenConsumer>(P, M, in, restore, lb, vb, theta, g, opt, i, req,
+                                            neg, pos, cons);
 }
 
 // ---------------------------------------------------------------------------

@@ -10,14 +10,9 @@
 #include "../../include/xrt_hip.h"
 #include "fp64_math.h"
 #include "screen.h"
+#include "screen_impl.h"
 
 namespace xrt {
-
-// streamed out once, never read again by the kernel: non-temporal (reflect_impl.h: store_ray)
-template <class T>
-__device__ __forceinline__ void put(T* p, int64_t i, T v) {
-  __builtin_nontemporal_store(v, &p[i]);
-}
 
 __global__ __launch_bounds__(256) void screen_expose_kernel(xrt_hip_screen S, xrt_hip_beam in,
                                                            xrt_hip_beam out) {
@@ -73,53 +68,45 @@ __global__ __launch_bounds__(256) void screen_expose_kernel(xrt_hip_screen S, xr
     }
     return;
   }
-  // sum(c*b for c, b in zip(basis, xyz)): ((0 + c0*x) + c1*y) + c2*z
-  double x = (S.ex[0] * gx + S.ex[1] * gy) + S.ex[2] * gz;
-  double y = (S.ey[0] * gx + S.ey[1] * gy) + S.ey[2] * gz;
-  double z = (S.ez[0] * gx + S.ez[1] * gy) + S.ez[2] * gz;
-  const double a = (S.ex[0] * ga + S.ex[1] * gb) + S.ex[2] * gc;
-  const double b = (S.ey[0] * ga + S.ey[1] * gb) + S.ey[2] * gc;
-  const double c = (S.ez[0] * ga + S.ez[1] * gb) + S.ez[2] * gc;
-  double path = -y / b;
-  int st = in.state[i];
-  bool bad = isnan(path) || isinf(path);
-  if (S.only_positive_path) bad = bad || (path < 0.);
-  if (bad) {
-    path = 0.;
-    st = S.lost_num;
+  const bool has_amp = in.Es_ri != nullptr;
+  const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
+  double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+  if (has_amp) {
+    es = reinterpret_cast<const double2*>(in.Es_ri)[i];
+    ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
   }
-  x = x + a * path;
-  z = z + c * path;
-  y = 0.;
-  if (S.compress_x != 0.) x *= S.compress_x;
-  if (S.compress_z != 0.) z *= S.compress_z;
-  put(out.x, i, x);
-  put(out.y, i, y);
-  put(out.z, i, z);
-  put(out.a, i, a);
-  put(out.b, i, b);
-  put(out.c, i, c);
-  const double E = in.E[i];
-  put(out.path, i, in.path[i] + path);
-  put(out.E, i, E);
-  put(out.Jss, i, in.Jss[i]);
-  put(out.Jpp, i, in.Jpp[i]);
-  reinterpret_cast<double2*>(out.Jsp_ri)[i] = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
-  out.state[i] = st;
-  if (in.Es_ri) {
-    // exp(1e7j * (E/CHBAR) * path), screens.py:271-274
-    const double kCH = 6.626069573e-27 * 2.99792458e10 / 1.602176565e-12 * 1e8;
-    const double kCHBAR = kCH / 6.283185307179586476925286766559;
-    const double ph = (1e7 * (E / kCHBAR)) * path;
-    double s, co;
-    sincos_phase(ph, s, co);
-    const double2 es = reinterpret_cast<const double2*>(in.Es_ri)[i];
-    const double2 ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
-    reinterpret_cast<double2*>(out.Es_ri)[i] =
-        make_double2(es.x * co - es.y * s, es.x * s + es.y * co);
-    reinterpret_cast<double2*>(out.Ep_ri)[i] =
-        make_double2(ep.x * co - ep.y * s, ep.x * s + ep.y * co);
+  expose_flat_store(S, out, i, in.x[i], in.y[i], in.z[i], ga, gb, gc, in.path[i], in.E[i],
+                    in.Jss[i], in.Jpp[i], js.x, js.y, in.state[i], es.x, es.y, ep.x, ep.y,
+                    has_amp);
+}
+
+// The same on a beam that a ray pass left out of the fused form (xrt_hip_reflect_screen_f64_dev:
+// the optimistic pass with the screen in its tail was contradicted and the exact sequence wrote
+// the global beam instead): runs only if the pass record says so.
+__global__ __launch_bounds__(256) void screen_expose_if_kernel(const int* flag, xrt_hip_screen S,
+                                                              xrt_hip_beam in, xrt_hip_beam out) {
+  if (!*flag) return;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= in.n) return;
+  const bool has_amp = in.Es_ri != nullptr;
+  const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
+  double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+  if (has_amp) {
+    es = reinterpret_cast<const double2*>(in.Es_ri)[i];
+    ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
   }
+  expose_flat_store(S, out, i, in.x[i], in.y[i], in.z[i], in.a[i], in.b[i], in.c[i], in.path[i],
+                    in.E[i], in.Jss[i], in.Jpp[i], js.x, js.y, in.state[i], es.x, es.y, ep.x,
+                    ep.y, has_amp);
+}
+
+hipError_t screen_expose_if_launch(const int* flag, const xrt_hip_screen& S,
+                                   const xrt_hip_beam& in, const xrt_hip_beam& out,
+                                   hipStream_t st) {
+  if (in.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(screen_expose_if_kernel, dim3((unsigned)((in.n + 255) / 256)), dim3(256), 0,
+                     st, flag, S, in, out);
+  return hipGetLastError();
 }
 
 hipError_t screen_expose_launch(const xrt_hip_screen& S, const xrt_hip_beam& in,

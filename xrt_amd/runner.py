@@ -159,6 +159,10 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
         beams = rr.run_process(beamLine)
         for plot in plots:
             accumulate_plot(plot, beams)
+        # (an element pass nobody has looked at yet is launched now: an iteration leaves
+        # nothing behind -- also what a recorded iteration has to contain)
+        from .backends.raycing import sources as rs
+        rs.flush_pending()
         return beams
 
     def one_scan():
