@@ -759,12 +759,19 @@ def bench_e2e(nrays, repeats=20):
                       'of the free-running loop; ~1 = the loop is GPU-bound (the instrumented '
                       'iterations carry a few us of event gaps: the ratio can exceed 1)' % n_probe,
         read_back_ms_once=read_back * 1e3, flux_in_plot=flux,
-        bytes_per_ray=dict(source=100, reflect=308, screen=200, histograms=44),
-        roofline=dict(bound='hbm', kernel='the four steps of one iteration',
-                      achieved=652. * nrays / wall / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
-                      frac=652. * nrays / wall / HBM_PEAK, traffic=None,
-                      note='652 B per ray algorithmic: 100 written by the source, 308 by '
-                           'OE.reflect (SURVEY 8d), 200 by Screen.expose, 44 read by the plot'))
+        bytes_per_ray=dict(source=100, reflect_and_screen=308, histograms=44,
+                           as_separate_passes=652),
+        fused='Screen.expose runs in the tail of the mirror pass (reflect_fused_scr): the '
+              '"reflect" step of gpu_ms_by_step only hands out the beams, the "screen" step is '
+              'the one pass that makes the local beam and the image; the global beam is not '
+              'written (nobody reads it)',
+        roofline=dict(bound='hbm', kernel='the three passes of one iteration',
+                      achieved=452. * nrays / wall / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
+                      frac=452. * nrays / wall / HBM_PEAK, traffic=None,
+                      note='452 B per ray algorithmic as built: 100 written by the source; 100 '
+                           'read + 108 (local beam, theta) + 100 (image) written by the mirror '
+                           'pass with the screen in its tail; 44 read by the plot. (652 B as '
+                           'four separate passes, round 4.)'))
     # beams of the size most xrt scripts trace (1e5 rays per iteration): the host, not the GPU,
     # bounds the eager loop; run_ray_tracing(graph=True) replays one HIP graph per iteration
     small = {}
@@ -783,6 +790,8 @@ def bench_e2e(nrays, repeats=20):
             # (the graph run spends its first two iterations eagerly and records the third)
             row[mode + '_ms_per_iteration'] = (time.perf_counter() - t0) / reps * 1e3
             row[mode + '_flux'] = float(ps.total2D.sum())
+            if mode == 'graph':     # what the graph route measured on this box and chose
+                row['graph_choice'] = getattr(ps, 'graphChoice', None)
         row['speedup'] = row['eager_ms_per_iteration'] / row['graph_ms_per_iteration']
         small['%d_rays' % n_small] = row
     if small:

@@ -41,9 +41,12 @@ for P in probe_stream probe_occupancy probe_atomics probe_fp64_seeds probe_lds_a
 done
 hipcc --offload-arch=gfx950 -O3 tools/probes/probe_stream_wide.hip -o /tmp/probe_stream_wide 2>/dev/null && \
   timeout 300 /tmp/probe_stream_wide > profiles/r${RND}_probe_stream_wide.txt 2>&1
-# OE(figureError=...): the Figured kernel against the lean pass, and its SQ counters
-PYTHONPATH=.:tests timeout 600 python tools/probe_figure.py 2>&1 | grep -v amdgpu.ids > profiles/r${RND}_figure_pass.txt
-bash tools/pmc_figure.sh > profiles/r${RND}_figure_pmc.txt 2>&1
+# (OE(figureError=...) is frozen since round 4: profiles/r04_figure_pass.txt, r04_figure_pmc.txt)
+# round 5: OE.multiple_reflect (all bounces of one call), the e2e iteration at three beam sizes
+# eager / graph with the fusion and the small-beam histogram switched off in turn
+PYTHONPATH=.:tests timeout 300 python tools/probe_multi.py 1e6 5 2>&1 | grep -v amdgpu.ids > profiles/r${RND}_multiple_reflect.txt
+PYTHONPATH=.:tests timeout 300 python tools/probe_multi.py 1e7 3 2>&1 | grep -v amdgpu.ids >> profiles/r${RND}_multiple_reflect.txt
+for env in "" "XRT_HIP_HIST_NO_SMALL=1" "XRT_HIP_NO_FUSE=1"; do echo "== [$env]"; env PYTHONPATH=. $env python tools/probe_e2e_sizes.py 200 2>&1 | grep rays; done > profiles/r${RND}_e2e_sizes.txt
 hipcc --offload-arch=gfx950 -O3 -DNOUT=40 -DBLOCK=256 tools/probes/probe_occupancy.hip -o /tmp/po40 2>/dev/null && \
   timeout 300 /tmp/po40 > profiles/r${RND}_probe_occupancy_dcm_shape.txt 2>&1
 cp profiles/r${RND}_*.txt profiles/hist_traffic.json $O/summaries/ 2>/dev/null

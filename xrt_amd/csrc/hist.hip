@@ -5,6 +5,7 @@
 // puts them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/xrt_hip.h"
 #include "fp64_math.h"
@@ -193,6 +194,70 @@ __global__ __launch_bounds__(256) void plot_hist_kernel(
     }
   }
   if (counters && (parts & 2)) flush_counters(c, counters, lds);
+}
+
+// Small beams: ONE launch. The three-kernel route below costs 45-50 us whatever the beam
+// (zeroing, writing and adding up 32 MB of plane copies; three dependent launches). Here the
+// planes take global atomics (4 per ray inside the plot), the 1-D histograms are kept per block
+// in LDS and flushed once. Same per-ray arithmetic (plot_ray), sums in another order. Measured
+// (tools/probe_e2e_sizes.py, graph replays, same box): 2e3 rays 0.110 -> 0.091 ms per iteration;
+// at 1e5 rays the atomics of a focused beam (many rays per cell) make it 5 us SLOWER than the
+// three kernels (0.111 against 0.106): the limit is set below that.
+#define HIST_SMALL_RAYS 32768
+__global__ __launch_bounds__(256) void plot_hist_small(
+    xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
+    const double* __restrict__ cd, xrt_hip_plot P, PlotAxes A, double* __restrict__ h2,
+    double* __restrict__ h2rgb, double* __restrict__ hx, double* __restrict__ hy,
+    double* __restrict__ hc, double* __restrict__ counters) {
+  extern __shared__ double cells[];      // [bx][4] | [by][4] | [bc][4]
+  __shared__ double lds[8][16];
+  const int nx = hx ? A.x.bins : 0, ny = hy ? A.y.bins : 0, nc = hc ? A.c.bins : 0;
+  double* lx = cells;
+  double* ly = lx + 4 * nx;
+  double* lc = ly + 4 * ny;
+  const int nl = 4 * (nx + ny + nc);
+  for (int k = threadIdx.x; k < nl; k += blockDim.x) cells[k] = 0.;
+  __syncthreads();
+  double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < beam.n; i += stride) {
+    const int st = beam.state[i];
+    count_state(st, c);
+    const PlotRay r = plot_ray(beam, x, y, cd, P, A, i, st, hc != nullptr);
+    if (!r.sel) continue;
+    c[0] += 1.;
+    c[1] += r.w;
+    if (r.ix >= 0 && r.iy >= 0) {
+      c[2] += r.w;
+      if (h2) {
+        const int64_t b = (int64_t)r.iy * P.bins_x + r.ix;
+        atomicAdd(&h2[b], r.w);
+        if (h2rgb)
+          for (int k = 0; k < 3; ++k) atomicAdd(&h2rgb[3 * b + k], r.rgb[k]);
+      }
+    }
+    if (nx && r.ix >= 0) {
+      atomicAdd(&lx[4 * r.ix], r.w);
+      for (int k = 0; k < 3; ++k) atomicAdd(&lx[4 * r.ix + 1 + k], r.rgb[k]);
+    }
+    if (ny && r.iy >= 0) {
+      atomicAdd(&ly[4 * r.iy], r.w);
+      for (int k = 0; k < 3; ++k) atomicAdd(&ly[4 * r.iy + 1 + k], r.rgb[k]);
+    }
+    if (nc && r.ic >= 0) {
+      atomicAdd(&lc[4 * r.ic], r.w);
+      for (int k = 0; k < 3; ++k) atomicAdd(&lc[4 * r.ic + 1 + k], r.rgb[k]);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nl; k += blockDim.x) {
+    const double v = cells[k];
+    if (v == 0.) continue;
+    double* dst = k < 4 * nx ? hx + k : (k < 4 * (nx + ny) ? hy + (k - 4 * nx)
+                                                           : hc + (k - 4 * (nx + ny)));
+    atomicAdd(dst, v);
+  }
+  if (counters) flush_counters(c, counters, lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -825,6 +890,19 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
   // (the 1-D weights are flux, R, G, B: derivable when all four planes are made)
   H.derive = lines && mode != HIST_LINES_ONLY && H.nchan == 4;
   int general = (h2 && mode == HIST_LINES_ONLY ? 1 : 0) | (want_lines && !lines ? 2 : 0);
+  // small beams: the one-launch form (the caller's scratch is not needed: *need stays 0)
+  static const bool no_small = getenv("XRT_HIP_HIST_NO_SMALL") != nullptr;
+  if (beam.n <= HIST_SMALL_RAYS && b1 <= 64 * 1024 && !no_small) {
+    if (need) return hipSuccess;
+    const int64_t want = (beam.n + 1023) / 1024;
+    const unsigned nblk = (unsigned)(want < cus ? want : cus);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plot_hist_small),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)b1);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(plot_hist_small, dim3(nblk), dim3(256), b1, st, beam, x, y, c, P, A, h2,
+                       h2rgb, hx, hy, hc, counters);
+    return hipGetLastError();
+  }
   if (mode != HIST_LINES_ONLY || lines) {
     const int64_t chunks = (beam.n + HIST_CHUNK - 1) / HIST_CHUNK;
     const int64_t most = (int64_t)cus * (mode == HIST_DIRECT ? 1 : HIST_RAYS_PER_CU);

@@ -13,6 +13,7 @@ alone, as in the reference (its ``uniqueFirstRun``). numpy's global generator is
 by the workers (as it is by the reference's threads): reproducible runs use 1 thread."""
 import ctypes
 import threading
+import time
 
 import numpy as np
 import torch
@@ -154,6 +155,7 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
         plots = [plots]
 
     workers = max(int(threads), int(processes), 1)
+    graph_choice = {}            # (what the graph route measured and chose; plots[0].graphChoice)
 
     def iteration():
         beams = rr.run_process(beamLine)
@@ -167,7 +169,7 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
 
     def one_scan():
         left = int(repeats)
-        recorded, ran_eagerly = None, False
+        recorded, ran_eagerly, refused = None, False, False
         while left > 0:
             if graph and workers == 1 and not any(
                     a.limits is None for p in plots for a in (p.xaxis, p.yaxis, p.caxis)):
@@ -176,8 +178,30 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
                 # (Several iterations per graph were tried: 0.144 ms per 1e5-ray iteration
                 # against 0.135-0.15 with one -- the time of a replay is the gaps between its
                 # dependent nodes, not the launch of the graph.)
-                if ran_eagerly and recorded is None and left > 1:
+                if ran_eagerly and recorded is None and left > 1 and not refused:
                     recorded = graphs.IterationGraph(iteration)
+                    if left >= 60:
+                        # Which is faster HERE: a replay or the eager loop? A stream takes
+                        # kernels back to back while the host runs ahead; the nodes of a graph
+                        # wait for one another through barrier packets (~8 us each). Beams of
+                        # ~1e6 rays and more are GPU-bound and lose by replaying (BENCH_r04:
+                        # 0.93x). Six iterations each way, all of them counted.
+                        clock = []
+                        for run in (recorded.replay, iteration):
+                            torch.cuda.current_stream().synchronize()
+                            t0 = time.perf_counter()
+                            for _ in range(6):
+                                run()
+                            torch.cuda.current_stream().synchronize()
+                            clock.append(time.perf_counter() - t0)
+                        left -= 12
+                        graph_choice['replay_ms'] = clock[0] / 6 * 1e3
+                        graph_choice['eager_ms'] = clock[1] / 6 * 1e3
+                        if clock[0] > clock[1]:
+                            recorded.close()
+                            recorded, refused = None, True
+                        graph_choice['replaying'] = not refused
+                        continue
                 if recorded is not None:
                     recorded.replay()
                     left -= 1
@@ -208,4 +232,6 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
                 plot.reset_bins2D()
     if afterScript:
         afterScript(*afterScriptArgs, **afterScriptKWargs)
+    if graph and plots:
+        plots[0].graphChoice = graph_choice
     return plots
