@@ -262,8 +262,12 @@ class Material(object):
         """The spline of the tabulated index at the energies *E* (device tensor) -> complex128
         tensor: the cubic pieces of scipy's interpolant (its B-spline turned into a piecewise
         polynomial once), found by a bisection and evaluated by Horner's rule, all on the GPU."""
-        key = E.device
+        # (keyed on the interpolant too: assigning another table to refractiveIndex must not
+        # leave the old spline on the GPU -- ADVICE r4)
+        key = (E.device, id(self.refractiveIndex[1]))
         if key not in self._index_poly:
+            for stale in [k for k in self._index_poly if k[1] != key[1]]:
+                del self._index_poly[stale]
             from scipy.interpolate import BSpline, PPoly
             spline = self.refractiveIndex[1]._spline      # complex coefficients: two real ones
             flat = np.asarray(spline.c).reshape(len(spline.c), -1)[:, 0]

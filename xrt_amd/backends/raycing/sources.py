@@ -805,6 +805,15 @@ class GeometricSource(object):
             held = cells[str(dev)] = [torch.zeros(1, dtype=torch.int32, device=dev), 0]
         return held
 
+    def _sync_replay_cell(self):
+        """Before a replay: the eager shine() calls since the last one move the device cell."""
+        for key, lag in self.__dict__.get('_cell_lag', {}).items():
+            held = self.__dict__.get('_replay_cells', {}).get(key)
+            if held is not None and lag:
+                held[0].add_(lag)
+                held[1] += lag
+            self._cell_lag[key] = 0
+
     def _shine_device(self, toGlobal, withAmplitudes, accuBeam):
         import ctypes
         from ... import _lib
@@ -819,7 +828,12 @@ class GeometricSource(object):
                 call = self._calls
                 self._calls += 1
                 self._replay_cell(dev)   # (exists before any recording)
+                # an eager call between the replays of a graph: the graph's cell has to move
+                # with the call counter (applied before the next replay, _sync_replay_cell)
+                lag = self.__dict__.setdefault('_cell_lag', {})
+                lag[str(dev)] = lag.get(str(dev), 0) + 1
             else:
+                self.__dict__.setdefault('_cell_lag', {})[str(dev)] = 0   # (absorbed below)
                 # recorded into a HIP graph: replay k must draw what the k-th eager call would
                 # have -- the kernel adds a device cell, incremented by the graph itself, to
                 # the call number of the record (this call's number less the cell's value now)

@@ -92,6 +92,8 @@ class IterationGraph(object):
         self.graph = None
 
     def replay(self):
+        for source in self.pending_calls:        # (eager calls in between move the call number)
+            source._sync_replay_cell()
         self.graph.replay()
         self.replays += 1
         for bookkeeping in self.after_replay:

@@ -32,9 +32,9 @@ from . import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, 'csrc')
-_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
-          '-fvisibility=hidden', '-Wno-unused-function', '-shared',
-          '-mllvm', '-instcombine-max-copied-from-constant-users=100000']     # (csrc/build.py)
+from .csrc.build import FLAGS as _BUILD_FLAGS     # the library's own flags: one place
+
+_FLAGS = [f for f in _BUILD_FLAGS if f != '-Wall'] + ['-shared']
 _lock = threading.Lock()
 _handles = {}       # unit path -> handle
 
@@ -85,7 +85,10 @@ def build_unit(local_z, local_n, verbose=False, local_g=None, layered=False):
         if not os.path.exists(hipcc):
             raise _lib.XrtHipError('hipcc not found: a user-defined surface is compiled at run '
                                    'time (there is no CPU fallback)')
-        src = out[:-3] + '.hip'
+        # several ranks may build the same class at once: each writes its own source and object
+        # (the pid in the names) and moves the result into place; whoever comes second
+        # overwrites the same bytes (one shared .hip was truncated under a reader)
+        src = out[:-3] + '.%d.hip' % os.getpid()
         with open(src, 'w') as f:
             f.write(source)
         tmp = out + '.%d.tmp' % os.getpid()
@@ -93,6 +96,10 @@ def build_unit(local_z, local_n, verbose=False, local_g=None, layered=False):
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
+        try:
+            os.remove(src)
+        except OSError:
+            pass
         if r.returncode != 0:
             raise _lib.XrtHipError('the surface snippets do not compile:\n' + r.stderr[-4000:])
         os.replace(tmp, out)
