@@ -233,20 +233,30 @@ __global__ __launch_bounds__(256) void plot_hist_small(
         const int64_t b = (int64_t)r.iy * P.bins_x + r.ix;
         atomicAdd(&h2[b], r.w);
         if (h2rgb)
-          for (int k = 0; k < 3; ++k) atomicAdd(&h2rgb[3 * b + k], r.rgb[k]);
+        {
+          atomicAdd(&h2rgb[3 * b], r.rgb[0]);
+          atomicAdd(&h2rgb[3 * b + 1], r.rgb[1]);
+          atomicAdd(&h2rgb[3 * b + 2], r.rgb[2]);
+        }
       }
     }
     if (nx && r.ix >= 0) {
       atomicAdd(&lx[4 * r.ix], r.w);
-      for (int k = 0; k < 3; ++k) atomicAdd(&lx[4 * r.ix + 1 + k], r.rgb[k]);
+      atomicAdd(&lx[4 * r.ix + 1], r.rgb[0]);
+      atomicAdd(&lx[4 * r.ix + 2], r.rgb[1]);
+      atomicAdd(&lx[4 * r.ix + 3], r.rgb[2]);
     }
     if (ny && r.iy >= 0) {
       atomicAdd(&ly[4 * r.iy], r.w);
-      for (int k = 0; k < 3; ++k) atomicAdd(&ly[4 * r.iy + 1 + k], r.rgb[k]);
+      atomicAdd(&ly[4 * r.iy + 1], r.rgb[0]);
+      atomicAdd(&ly[4 * r.iy + 2], r.rgb[1]);
+      atomicAdd(&ly[4 * r.iy + 3], r.rgb[2]);
     }
     if (nc && r.ic >= 0) {
       atomicAdd(&lc[4 * r.ic], r.w);
-      for (int k = 0; k < 3; ++k) atomicAdd(&lc[4 * r.ic + 1 + k], r.rgb[k]);
+      atomicAdd(&lc[4 * r.ic + 1], r.rgb[0]);
+      atomicAdd(&lc[4 * r.ic + 2], r.rgb[1]);
+      atomicAdd(&lc[4 * r.ic + 3], r.rgb[2]);
     }
   }
   __syncthreads();
