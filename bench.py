@@ -759,19 +759,20 @@ def bench_e2e(nrays, repeats=20):
                       'of the free-running loop; ~1 = the loop is GPU-bound (the instrumented '
                       'iterations carry a few us of event gaps: the ratio can exceed 1)' % n_probe,
         read_back_ms_once=read_back * 1e3, flux_in_plot=flux,
-        bytes_per_ray=dict(source=100, reflect_and_screen=308, histograms=44,
-                           as_separate_passes=652),
-        fused='Screen.expose runs in the tail of the mirror pass (reflect_fused_scr): the '
-              '"reflect" step of gpu_ms_by_step only hands out the beams, the "screen" step is '
-              'the one pass that makes the local beam and the image; the global beam is not '
-              'written (nobody reads it)',
-        roofline=dict(bound='hbm', kernel='the three passes of one iteration',
-                      achieved=452. * nrays / wall / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
-                      frac=452. * nrays / wall / HBM_PEAK, traffic=None,
-                      note='452 B per ray algorithmic as built: 100 written by the source; 100 '
-                           'read + 108 (local beam, theta) + 100 (image) written by the mirror '
-                           'pass with the screen in its tail; 44 read by the plot. (652 B as '
-                           'four separate passes, round 4.)'))
+        bytes_per_ray=dict(source_mirror_screen=208, histograms=44, as_separate_passes=652),
+        fused='GeometricSource.shine, OE.reflect and Screen.expose are ONE pass '
+              '(reflect_fused_gen_scr): the rays are made in the registers of the mirror kernel, '
+              'the screen\'s image comes out of its tail; the "source" and "reflect" steps of '
+              'gpu_ms_by_step only hand out beams, the "screen" step is the pass; neither the '
+              'source beam nor the global beam is written (nobody reads them; either can still '
+              'be made on demand)',
+        roofline=dict(bound='hbm', kernel='the pass and the plot of one iteration',
+                      achieved=252. * nrays / wall / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
+                      frac=252. * nrays / wall / HBM_PEAK, traffic=None,
+                      note='252 B per ray algorithmic as built: 108 (local beam, theta) + 100 '
+                           '(image) written by the one pass, 44 read by the plot -- the pass is '
+                           'now bound by its arithmetic (Philox, Box-Muller, the root search), '
+                           'not by HBM. (652 B as four separate passes, round 4.)'))
     # beams of the size most xrt scripts trace (1e5 rays per iteration): the host, not the GPU,
     # bounds the eager loop; run_ray_tracing(graph=True) replays one HIP graph per iteration
     small = {}

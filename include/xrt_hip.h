@@ -548,6 +548,25 @@ XRT_HIP_API int xrt_hip_multiple_reflect_out_f64_dev(
     const xrt_hip_pass* pass, const xrt_hip_beam* last, const xrt_hip_beam* original,
     const int32_t* nrefl, xrt_hip_beam* out_global, void* stream);
 
+/* GeometricSource.shine (device generator, below) -> OE.reflect -> Screen.expose as ONE pass:
+ * xrt_hip_reflect_screen_f64_dev whose incoming rays are made in registers from the source's
+ * record instead of being read (sources/geoms.py:420-535 followed by oes/reflect.py:18-163 and
+ * screens.py:226-302). The generator is counter-based: the same record makes the same rays
+ * again whenever somebody wants the source's beam itself. `source_beam` (n rays, with Es / Ep
+ * iff amplitudes are wanted): scratch that is written only if the exact sequence has to redo
+ * the pass, or when the pass is not one of the lean mirror kernels (then the generator's own
+ * launch fills it first). *fused (optional): bit 0 = the screen was in the tail of the pass,
+ * bit 1 = the source was in its head (source_beam holds nothing). 208 B per ray cross HBM
+ * (108 local beam + 100 image) instead of 608. */
+struct xrt_hip_geosource;
+struct xrt_hip_screen;
+XRT_HIP_API int xrt_hip_shine_reflect_screen_f64_dev(
+    const struct xrt_hip_geosource* source, const xrt_hip_pass* pass,
+    const xrt_hip_material* material, xrt_hip_beam* source_beam, xrt_hip_beam* out_local,
+    xrt_hip_beam* out_virgin, double* theta, const struct xrt_hip_screen* screen,
+    xrt_hip_beam* out_screen, int keep_virgin, void* workspace, size_t workspace_bytes,
+    void* stream, int* fused);
+
 /* DCM.double_reflect (oes/dcm.py:248-354) as ONE pass over the beam: both crystals
  * per ray, the beam between them never goes to memory (416 B of HBM traffic per ray
  * instead of 716). pass1 / pass2 are what two xrt_hip_reflect_pass_f64_dev calls

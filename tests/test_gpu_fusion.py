@@ -220,3 +220,89 @@ def test_c_abi_keeps_the_global_beam_on_request():
     same(img, img0, 'image')
     same(gb, gb0, 'global')
     same(lb, lb0, 'local')
+
+
+# ---- the source in the head of the pass ------------------------------------------------------
+def source_scene(n=150000, wide=False, amplitudes=False):
+    bl = raycing.BeamLine()
+    kw = dict(dxprime=0.9, distxprime='flat') if wide else dict(dxprime=2e-4)
+    bl.source = rs.GeometricSource(bl, 'source', nrays=n, dx=0.1, dz=0.1, dzprime=2e-5,
+                                   distE='flat', energies=(8990., 9010.), polarization='h',
+                                   rng='device', seed=17, **kw)
+    bl.mirror = workloads.cfg2_toroid(bl)
+    bl.screen = rsc.Screen(bl, 'focus', center=[0, 20000. + 10000. * np.cos(8e-3),
+                                                10000. * np.sin(8e-3)])
+    return bl, amplitudes
+
+
+def run_chain(bl, amplitudes, fuse):
+    old = roe.fuseConsumers
+    roe.fuseConsumers = fuse
+    try:
+        bl.source._calls = 0
+        src = bl.source.shine(withAmplitudes=amplitudes)
+        gb, lb = bl.mirror.reflect(src)
+        img = bl.screen.expose(gb)
+    finally:
+        roe.fuseConsumers = old
+    return src, gb, lb, img
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+def test_source_mirror_screen_in_one_pass(amplitudes):
+    bl, amp = source_scene(amplitudes=amplitudes)
+    src0, gb0, lb0, img0 = run_chain(bl, amp, False)
+    src, gb, lb, img = run_chain(bl, amp, True)
+    assert type(src) is rs.LazyBeam and src.__dict__['_op'].state == 'inflight'
+    assert not src.__dict__['_filled'] and gb.__dict__['_op'].state == 'imaged'
+    same(img, img0, 'image')
+    same(lb, lb0, 'local', extra=('theta',))
+    assert img.parentId == img0.parentId
+    # the beams nobody had asked for, afterwards: the same rays again
+    same(src, src0, 'source')
+    same(gb, gb0, 'global')
+    assert src.parentId == src0.parentId == bl.source.uuid
+
+
+def test_source_looked_at_first_and_redo_with_a_source():
+    bl, amp = source_scene(n=40000)
+    src0, gb0, lb0, img0 = run_chain(bl, amp, False)
+    # the script looks at the source before anything else: the generator's own launch
+    bl.source._calls = 0
+    src = bl.source.shine()
+    assert src.nrays == 40000 and src.__dict__['_op'].state == 'done'
+    gb, lb = bl.mirror.reflect(src)
+    same(bl.screen.expose(gb), img0, 'image')
+    same(src, src0, 'source')
+    # rays all over the place: the optimistic pass is contradicted (a ray's largest direction
+    # cosine is not y), the beam is generated after all and the exact sequence does the pass
+    bl, amp = source_scene(n=40000, wide=True)
+    src0, gb0, lb0, img0 = run_chain(bl, amp, False)
+    src, gb, lb, img = run_chain(bl, amp, True)
+    same(img, img0, 'wide image')
+    same(lb, lb0, 'wide local', extra=('theta',))
+    same(gb, gb0, 'wide global')
+    same(src, src0, 'wide source')
+
+
+def test_an_aperture_on_the_pending_source_beam():
+    bl, amp = source_scene(n=30000)
+    slit = ra.RectangularAperture(bl, 'slit', [0, 15000., 0], ('left', 'right'), [-0.5, 0.5])
+
+    def chain(fuse):
+        roe.fuseConsumers = fuse
+        try:
+            bl.source._calls = 0
+            src = bl.source.shine()
+            gb, lb = bl.mirror.reflect(src)      # before the slit: sees every ray
+            slit.propagate(src)
+            img = bl.screen.expose(gb)
+            return src, lb, img
+        finally:
+            roe.fuseConsumers = True
+    s0, l0, i0 = chain(False)
+    s1, l1, i1 = chain(True)
+    same(i1, i0, 'image')
+    same(l1, l0, 'local', extra=('theta',))
+    same(s1, s0, 'source after the slit')
+    assert (s1.state < 0).sum() > 100

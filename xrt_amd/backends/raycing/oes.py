@@ -749,7 +749,8 @@ class OE(object):
             self.pitch + getattr(self, 'bragg', 0), self.roll + self.positionRoll,
             self.yaw, self.dx, noIntersectionSearch=noIntersectionSearch,
             only_state1_out=hasattr(beam, 'createdByDiffract'))
-        rs.flush_pending()             # (at most one pass is ever waiting for its consumer)
+        # (at most one chain -- a source and the pass that takes its beam -- ever waits)
+        rs.flush_pending(keep=beam.__dict__.get('_op') if type(beam) is rs.LazyBeam else None)
         if fuseConsumers and local and out is None and _info is None and _timing is None and \
                 getattr(self, '_zones_between_passes', None) is None and \
                 not (p.grating and raycing.is_sequence(self.order)) and not p.eff_tab_n:
@@ -787,22 +788,32 @@ class _DeferredReflect(object):
 
     def __init__(self, oe, p, beam, out=None):
         dev = _device()
-        beam.to_struct(dev)                      # everything up in HBM now
-        snap = rs.Beam.__new__(rs.Beam)          # the input as it is at this moment
-        object.__setattr__(snap, '_h', {})
-        object.__setattr__(snap, '_d', dict(beam._d))
-        rs.inherit_scalars(snap, beam)
-        object.__setattr__(snap, 'parentId', getattr(beam, 'parentId', None))
-        if 'createdByDiffract' in beam.__dict__:
-            snap.createdByDiffract = beam.createdByDiffract
+        self.src_op = None
+        made_by = beam.__dict__.get('_op') if type(beam) is rs.LazyBeam else None
+        if isinstance(made_by, rs._DeferredShine) and made_by.state == 'pending':
+            # the beam of a device source that has not run either: kept as it is (its rays
+            # can be made inside this element's pass, image_on)
+            self.src_op, snap = made_by, beam
+            self.tensors = set()
+        else:
+            beam.to_struct(dev)                      # everything up in HBM now
+            snap = rs.Beam.__new__(rs.Beam)          # the input as it is at this moment
+            object.__setattr__(snap, '_h', {})
+            object.__setattr__(snap, '_d', dict(beam._d))
+            rs.inherit_scalars(snap, beam)
+            object.__setattr__(snap, 'parentId', getattr(beam, 'parentId', None))
+            if 'createdByDiffract' in beam.__dict__:
+                snap.createdByDiffract = beam.createdByDiffract
+            self.tensors = set(id(t) for t in snap._d.values())
         self.oe, self.p, self.beam, self.out = oe, p, snap, out
-        self.tensors = set(id(t) for t in snap._d.values())
         self.state = 'pending'
         self.gb, self.lb = rs.LazyBeam(self, 'gb'), rs.LazyBeam(self, 'lb')
         oe._adopt((self.gb, self.lb), beam)
         rs._PENDING.add(self)
 
     def reads(self, beam):
+        if beam is self.beam:
+            return True
         d = beam.__dict__.get('_real_d', beam.__dict__.get('_d')) or {}
         return any(id(t) in self.tensors for t in d.values())
 
@@ -826,7 +837,13 @@ class _DeferredReflect(object):
         """The pass with *screen* in its tail -> the screen's image (a plain Beam)."""
         oe = self.oe
         rs._PENDING.discard(self)
-        lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, self.beam, rec)
+        src = self.src_op
+        stripes = oe.material if raycing.is_sequence(oe.material) else (oe.material,)
+        tabulated = any(isinstance(getattr(m, 'refractiveIndex', None), list) for m in stripes)
+        if src is not None and src.state == 'pending' and not tabulated:
+            lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, None, rec, source=src)
+        else:
+            lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, self.beam, rec)
         self.lb._adopt_arrays(lb)
         if fused:
             self.state = 'imaged'
@@ -838,31 +855,51 @@ class _DeferredReflect(object):
         return image
 
 
-def _run_pass_screen(self, p, material, beam_in, screen_record):
+def _run_pass_screen(self, p, material, beam_in, screen_record, source=None):
     """OE.reflect + Screen.expose in one C call (xrt_hip_reflect_screen_f64_dev) ->
-    (lb, gb, image, fused): fused = the lean kernel carried the screen and gb holds nothing."""
+    (lb, gb, image, fused): fused = the lean kernel carried the screen and gb holds nothing.
+    *source* (a pending sources._DeferredShine, with beam_in None): the rays are made by the
+    source's record inside the same call (xrt_hip_shine_reflect_screen_f64_dev)."""
     _lib.require_gpu()
     lib = _lib.load()
     dev = _device()
-    ms = self._material_struct(material, True, dev, beam_in)
-    s_in = beam_in.to_struct(dev)
-    n = beam_in.nrays
-    lb = rs.Beam.empty_like_on_device(beam_in, dev)
-    gb = rs.Beam.empty_like_on_device(beam_in, dev)
-    image = rs.Beam.empty_like_on_device(beam_in, dev)
+    if source is not None:
+        n, amp = source.n, source.amplitudes
+        parent = source.beam
+        ms = self._material_struct(material, True, dev, None)
+        scratch = rs.Beam.empty_on_device(n, dev, amp)      # (written only for a redo)
+    else:
+        n, amp, parent = beam_in.nrays, beam_in.has_amplitudes(), beam_in
+        ms = self._material_struct(material, True, dev, beam_in)
+        s_in = beam_in.to_struct(dev)
+    lb, gb, image = (rs.Beam.empty_on_device(n, dev, amp) for _ in range(3))
     theta = torch.empty(n, dtype=torch.float64, device=dev)
     ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(n), 'reflect')
     fused = ctypes.c_int(0)
-    _lib.check(lib.xrt_hip_reflect_screen_f64_dev(
-        ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in),
-        ctypes.byref(lb.to_struct(dev)), ctypes.byref(gb.to_struct(dev)),
-        ctypes.c_void_p(theta.data_ptr()), ctypes.byref(screen_record),
-        ctypes.byref(image.to_struct(dev)), 0, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
-        _stream(), ctypes.byref(fused), None), 'xrt_hip_reflect_screen_f64_dev')
+    if source is not None:
+        _lib.check(lib.xrt_hip_shine_reflect_screen_f64_dev(
+            ctypes.byref(source.g), ctypes.byref(p), ctypes.byref(ms),
+            ctypes.byref(scratch.to_struct(dev)), ctypes.byref(lb.to_struct(dev)),
+            ctypes.byref(gb.to_struct(dev)), ctypes.c_void_p(theta.data_ptr()),
+            ctypes.byref(screen_record), ctypes.byref(image.to_struct(dev)), 0,
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(), ctypes.byref(fused)),
+            'xrt_hip_shine_reflect_screen_f64_dev')
+        if fused.value & 2:
+            rs._PENDING.discard(source)
+            source.state = 'inflight'       # (still makes its beam if somebody asks for it)
+        else:
+            source.adopt(scratch)           # the generator's own launch has filled it
+    else:
+        _lib.check(lib.xrt_hip_reflect_screen_f64_dev(
+            ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in),
+            ctypes.byref(lb.to_struct(dev)), ctypes.byref(gb.to_struct(dev)),
+            ctypes.c_void_p(theta.data_ptr()), ctypes.byref(screen_record),
+            ctypes.byref(image.to_struct(dev)), 0, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+            _stream(), ctypes.byref(fused), None), 'xrt_hip_reflect_screen_f64_dev')
     lb._d['theta'] = theta
-    self._adopt((lb, gb), beam_in)
-    rs.inherit_scalars(image, beam_in)
-    return lb, gb, image, bool(fused.value)
+    self._adopt((lb, gb), parent)
+    rs.inherit_scalars(image, parent)
+    return lb, gb, image, bool(fused.value & 1)
 
 
 OE._run_pass_screen = _run_pass_screen

@@ -419,15 +419,85 @@ class Beam(object):
 # unless somebody asks for it later. Any other use of either beam -- an attribute, a plot, the
 # next element -- launches the plain pass at that moment: same kernels, same bits, a little
 # later on the stream.
-_PENDING = set()        # the operations not launched yet (strong references: they own inputs)
+import threading as _threading
 
 
-def flush_pending(beam=None):
-    """Launches what is still pending -- all of it, or what reads *beam* (called by whoever is
-    about to change a beam's arrays in place)."""
+class _PendingOps(object):
+    """The operations not launched yet, per Python thread (every thread of a parallel
+    run_ray_tracing traces its own beams on its own stream)."""
+
+    def __init__(self):
+        self._tls = _threading.local()
+
+    def _mine(self):
+        ops = self._tls.__dict__.get('ops')
+        if ops is None:
+            ops = self._tls.ops = set()
+        return ops
+
+    def add(self, op):
+        self._mine().add(op)
+
+    def discard(self, op):
+        self._mine().discard(op)
+
+    def __iter__(self):
+        return iter(list(self._mine()))
+
+
+_PENDING = _PendingOps()
+_FILL_LOCK = _threading.RLock()      # a beam looked at from another thread: one launch, complete
+
+
+def flush_pending(beam=None, keep=None):
+    """Launches what is still pending -- all of it (but *keep*), or what reads *beam* (called by
+    whoever is about to change a beam's arrays in place)."""
     for op in list(_PENDING):
-        if beam is None or op.reads(beam):
+        if op is not keep and (beam is None or op.reads(beam)):
             op.materialize()
+
+
+class _DeferredShine(object):
+    """GeometricSource.shine(rng='device') not launched yet: the generator is counter-based, the
+    record *g* makes the same rays whenever it runs. States: pending -> done (its own launch), or
+    pending -> inflight (an element's pass made the rays in its registers,
+    xrt_hip_shine_reflect_screen_f64_dev; the beam itself can still be made on demand) -> done."""
+
+    def __init__(self, source, g, nrays, amplitudes, device, scalars):
+        self.source, self.g, self.n, self.amplitudes, self.device = \
+            source, g, int(nrays), bool(amplitudes), device
+        self.state = 'pending'
+        self.beam = LazyBeam(self, 'beam')
+        for key, value in scalars.items():
+            object.__setattr__(self.beam, key, value)
+        _PENDING.add(self)
+
+    def reads(self, beam):
+        return False
+
+    def launch_into(self, bo):
+        import ctypes
+        from ... import _lib
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().xrt_hip_geosource_shine_f64_dev(
+                ctypes.byref(self.g), ctypes.byref(bo.to_struct(self.device)),
+                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                'xrt_hip_geosource_shine_f64_dev')
+
+    def materialize(self, which=None):
+        _PENDING.discard(self)
+        if self.state != 'done':
+            self.state = 'done'
+            bo = Beam.empty_on_device(self.n, self.device, self.amplitudes)
+            self.launch_into(bo)
+            self.beam._adopt_arrays(bo)
+
+    def adopt(self, bo):
+        """*bo* holds the rays already (somebody else ran the generator into it)."""
+        _PENDING.discard(self)
+        if self.state != 'done':
+            self.state = 'done'
+            self.beam._adopt_arrays(bo)
 
 
 class LazyBeam(Beam):
@@ -444,7 +514,9 @@ class LazyBeam(Beam):
 
     def _fill(self):
         if not self.__dict__['_filled']:
-            self.__dict__['_op'].materialize(self.__dict__['_role'])
+            with _FILL_LOCK:
+                if not self.__dict__['_filled']:
+                    self.__dict__['_op'].materialize(self.__dict__['_role'])
 
     def _adopt_arrays(self, real):
         """Takes over the arrays of the beam the launch made."""
@@ -857,7 +929,22 @@ class GeometricSource(object):
                 ctypes.byref(g), self.nrays, ctypes.c_void_p(flag.data_ptr()), stream),
                 'xrt_hip_geosource_probe_f64_dev')
             g.slopes = int(flag.item())
-        bo = Beam.empty_on_device(self.nrays, dev, withAmplitudes or self.uniformRayDensity)
+        amplitudes = withAmplitudes or self.uniformRayDensity
+        if rec is None and reach2 <= 1 and accuBeam is None and not self.uniformRayDensity:
+            from . import oes as _oes
+            if _oes.fuseConsumers:
+                # not launched yet: an element's pass may make these rays in its own registers
+                # (oes._DeferredReflect); anything else that looks at the beam launches the
+                # generator -- the record draws the same rays whenever it runs
+                flush_pending()
+                scalars = dict(parentId=self.uuid)
+                if np.isscalar(self.totalFlux) and self.totalFlux > 0:
+                    total = self.nrays * (g.Jss + g.Jpp)
+                    if total > 0:
+                        scalars.update(sourceWeight=self.totalFlux / total, seeded=self.nrays,
+                                       seededI=1., accepted=1., acceptedE=1.)
+                return _DeferredShine(self, g, self.nrays, amplitudes, dev, scalars).beam
+        bo = Beam.empty_on_device(self.nrays, dev, amplitudes)
         _lib.check(lib.xrt_hip_geosource_shine_f64_dev(
             ctypes.byref(g), ctypes.byref(bo.to_struct(dev)), stream),
             'xrt_hip_geosource_shine_f64_dev')

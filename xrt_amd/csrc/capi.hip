@@ -409,13 +409,16 @@ struct OwnEvents {
   }
 };
 
+static int check_geosource(const xrt_hip_geosource* g);
+
 static int reflect_pass_impl(const xrt_hip_pass* pass, const xrt_hip_material* material,
                              const xrt_hip_beam* in, const xrt_hip_beam* restore,
                              xrt_hip_beam* out_local, xrt_hip_beam* out_virgin, double* theta,
                              void* workspace, size_t workspace_bytes, void* stream,
                              double* info_host, float* kernel_ms,
                              const xrt_hip_screen* screen, xrt_hip_beam* out_screen,
-                             int keep_virgin, int* fused) {
+                             int keep_virgin, int* fused,
+                             const xrt_hip_geosource* source = nullptr) {
   const ArmedEvents armed;
   int rc;
   if ((rc = check_pass(pass, material))) return rc;
@@ -476,7 +479,7 @@ static int reflect_pass_impl(const xrt_hip_pass* pass, const xrt_hip_material* m
   hipError_t e = xrt::reflect_pass_launch(*pass, *material, *in, *restore, *out_local,
                                           *out_virgin, theta, workspace, st, e0, e1, k0, k1,
                                           force_exact, screen, out_screen, keep_virgin != 0,
-                                          fused);
+                                          fused, source);
   if (e != hipSuccess) return fail(XRT_HIP_ERR_HIP, "reflect launch: %s", hipGetErrorString(e));
   if (kernel_ms) {
     HIP_TRY(hipEventSynchronize(e1));
@@ -517,6 +520,25 @@ int xrt_hip_reflect_pass_f64_dev(const xrt_hip_pass* pass, const xrt_hip_materia
   return reflect_pass_impl(pass, material, in, restore, out_local, out_virgin, theta, workspace,
                            workspace_bytes, stream, info_host, kernel_ms, nullptr, nullptr, 1,
                            nullptr);
+}
+
+int xrt_hip_shine_reflect_screen_f64_dev(
+    const xrt_hip_geosource* source, const xrt_hip_pass* pass, const xrt_hip_material* material,
+    xrt_hip_beam* source_beam, xrt_hip_beam* out_local, xrt_hip_beam* out_virgin, double* theta,
+    const xrt_hip_screen* screen, xrt_hip_beam* out_screen, int keep_virgin, void* workspace,
+    size_t workspace_bytes, void* stream, int* fused) {
+  int rc;
+  if ((rc = check_geosource(source))) return rc;
+  if (!screen) return fail(XRT_HIP_ERR_ARG, "NULL screen");
+  if (screen->radius != 0. && !keep_virgin)
+    return fail(XRT_HIP_ERR_ARG, "a hemispheric screen takes the stored global beam "
+                                 "(keep_virgin = 1)");
+  if (!pass || !pass->out_to_global || !pass->in_is_global || !source->to_global)
+    return fail(XRT_HIP_ERR_ARG, "source, element and screen meet in the global frame "
+                                 "(source to_global, pass in_is_global / out_to_global)");
+  return reflect_pass_impl(pass, material, source_beam, source_beam, out_local, out_virgin, theta,
+                           workspace, workspace_bytes, stream, nullptr, nullptr, screen,
+                           out_screen, keep_virgin, fused, source);
 }
 
 int xrt_hip_reflect_screen_f64_dev(const xrt_hip_pass* pass, const xrt_hip_material* material,

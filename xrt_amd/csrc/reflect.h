@@ -106,7 +106,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1,
                                bool force_exact, const xrt_hip_screen* scr = nullptr,
                                const xrt_hip_beam* sb = nullptr, bool keep_virgin = true,
-                               int* fused = nullptr);
+                               int* fused = nullptr, const xrt_hip_geosource* src = nullptr);
 
 // DCM.double_reflect in one kernel: both crystals per ray, the beam between them stays
 // in registers. lo1 / lo2: local beams of the two crystals, gb2: global beam after the

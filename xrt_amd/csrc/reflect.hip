@@ -2,9 +2,11 @@
 // code is in reflect_impl.h; the big kernel templates are instantiated in their own
 // translation units (reflect_tu.h).
 #define XRT_REFLECT_MAIN_TU
+#include <string.h>
 #include "reflect_impl.h"
 #include "reflect_tu.h"
 #include "screen.h"
+#include "source.h"
 
 namespace xrt {
 
@@ -553,7 +555,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                void* workspace, hipStream_t st, hipEvent_t ev0,
                                hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1,
                                bool force_exact, const xrt_hip_screen* scr,
-                               const xrt_hip_beam* sb, bool keep_virgin, int* fused) {
+                               const xrt_hip_beam* sb, bool keep_virgin, int* fused,
+                               const xrt_hip_geosource* src) {
   static_assert(sizeof(GStat) <= 256, "workspace head slot");
   if (fused) *fused = 0;
   static_assert(REFLECT_OPT_SLOTS * sizeof(OptStat) <= REFLECT_PART_BYTES, "report slots");
@@ -653,9 +656,20 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     vb_fused.state = nullptr;
     vb_fused.Es_ri = vb_fused.Ep_ri = nullptr;
   }
+  // The source in the head of the pass (GeometricSource.shine on the device): `in` is then a
+  // scratch beam that is filled only if the exact sequence has to redo the pass. Mirrors only
+  // (the lean kernels), with the screen in the tail; otherwise the generator's own launch
+  // fills `in` first and everything is as usual.
+  const bool fuse_source = src && fuse_screen && spec != SP_FLAT_PLATE && src->state > 0 &&
+                           P.good_mode == 0 && restore.x == in.x;
+  if (src && !fuse_source) {
+    const hipError_t ge = geosource_shine_launch(*src, in, st);
+    if (ge != hipSuccess) return ge;
+  }
   const FusedLaunch FL{grid, fblock, st, &P, &M, &in, &restore, &lb,
                        fuse_screen ? &vb_fused : &vb, theta, g, opt,
-                       fuse_screen ? scr : nullptr, fuse_screen ? sb : nullptr};
+                       fuse_screen ? scr : nullptr, fuse_screen ? sb : nullptr,
+                       fuse_source ? src : nullptr};
   const ExactLaunch XL{dim3(exact_blocks(n)), dim3(REFLECT_EXACT_BLOCK), st, &P, &M, &in,
                        &restore, &lb, &vb, A};
   bool launched = true;
@@ -690,7 +704,29 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                   tu_exact2(family_spec, XL) || tu_exact3(family_spec, XL);
   };
   if (ev0) (void)hipEventRecord(ev0, st);
-  if (optimistic) {
+  if (fuse_source) {
+    // ray 0 made by the decide kernel stands for the head of the beam; the pass makes its rays
+    // itself; the beam is written out only for a redo
+    xrt_hip_beam head;
+    memset(&head, 0, sizeof(head));
+    head.n = 1;
+    head.state = reinterpret_cast<int32_t*>(L.ht);
+    head.a = L.ht + 1;
+    head.b = L.ht + 2;
+    head.c = L.ht + 3;
+    head.E = L.ht + 4;
+    head.x = head.y = head.z = head.path = head.Jss = head.Jpp = L.ht + 5;
+    head.Jsp_ri = L.ht + 6;
+    hipLaunchKernelGGL(reflect_decide_opt_gen, dim3(1), block, 0, st, P, M, *src, head, part, g);
+    if (evk0) (void)hipEventRecord(evk0, st);
+    launched &= tu_hot_fused_gen_scr(spec, FL);
+    if (evk1) (void)hipEventRecord(evk1, st);
+    // (every block folds the reports itself before it knows whether there is work: few blocks)
+    const int64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(geosource_shine_if_redo, dim3((unsigned)(want < 256 ? want : 256)),
+                       dim3(256), 0, st, g, opt, *src, in);
+    launch_exact();
+  } else if (optimistic) {
     // assumptions from the head of the beam -> the pass on them, every ray checking ->
     // reflect_exact: folds the reports, returns at once unless one was contradicted
     hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, g);
@@ -724,7 +760,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     else
       se = screen_expose_launch(*scr, vb, *sb, st);
     if (se != hipSuccess) return se;
-    if (fused) *fused = fuse_screen ? 1 : 0;
+    if (fused) *fused = (fuse_screen ? 1 : 0) | (fuse_source ? 2 : 0);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   if (!launched) return hipErrorInvalidDeviceFunction;   // no unit holds this spec

@@ -35,6 +35,7 @@
 #include "fp64_math.h"
 #include "reflect.h"
 #include "screen_impl.h"
+#include "source_impl.h"
 
 namespace xrt {
 
@@ -1444,6 +1445,27 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt(
   // the (idle) partial-record area holds the report slots of the fused kernel
   decide_opt_body(P, M, in, reinterpret_cast<OptStat*>(part), g, lds_u, ub_lo, ub_hi, dir0);
 }
+// the same for a beam that exists only as its source's record: ray 0 is made here (into the
+// one-ray beam `head`, scratch of the pass) and stands for the head of the beam -- every ray of
+// a source enters with the same state, so the first entering ray IS ray 0
+__global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_opt_gen(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_geosource G, xrt_hip_beam head, double* part,
+    GStat* g) {
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
+  if (threadIdx.x == 0) {
+    const gen::GenRay r = gen::make_ray(G, gen::call_of(G), 0, false);
+    head.state[0] = G.state;
+    head.a[0] = r.a;
+    head.b[0] = r.b;
+    head.c[0] = r.c;
+    head.E[0] = r.E;
+  }
+  __threadfence_block();
+  __syncthreads();
+  int ub_lo[XRT_HIP_MAX_ELEM], ub_hi[XRT_HIP_MAX_ELEM];
+  double dir0[3] = {0., 0., 0.};
+  decide_opt_body(P, M, head, reinterpret_cast<OptStat*>(part), g, lds_u, ub_lo, ub_hi, dir0);
+}
 #endif
 
 // What the optimistic pass reported, folded by every block that needs the verdict
@@ -1466,6 +1488,31 @@ __device__ __forceinline__ bool fold_opt(const OptStat* slots, double* lds_d, do
   m2o = m2;
   return viol != 0. || (m2 > m1 * 20.) != assumed_brent;
 }
+
+#ifdef XRT_REFLECT_MAIN_TU
+// The source's beam after all, for the exact sequence: runs only if the optimistic pass that
+// made its rays in registers was contradicted (the verdict reflect_exact's gate will reach: the
+// same fold of the same reports) or never ran. A small grid that strides.
+__global__ __launch_bounds__(256) void geosource_shine_if_redo(const GStat* g,
+                                                              const OptStat* slots,
+                                                              xrt_hip_geosource G,
+                                                              xrt_hip_beam out) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  bool full;
+  if (g->optimistic) {
+    double m1, m2;
+    full = fold_opt(slots, lds_d, m1, m2, g->optimistic == 2);
+  } else {
+    full = g->redo != 0;
+  }
+  if (!full) return;
+  const bool amp = out.Es_ri != nullptr;
+  const uint32_t call = gen::call_of(G);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < out.n; i += stride)
+    gen::store_gen_ray(out, i, gen::make_ray(G, call, i, amp), G.state, amp);
+}
+#endif
 
 struct LocalRay {
   double x, y, z, a, b, c;
@@ -3634,6 +3681,44 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_s
   int neg = 0, pos = 0;
   fused_ray<K, mode, false, ScreenConsumer>(P, M, in, restore, lb, vb, theta, g, opt, i, req,
                                             neg, pos, cons);
+}
+
+// ... and with the SOURCE in its head: GeometricSource.shine -> OE.reflect -> Screen.expose as one
+// pass. The ray is made in registers (source_impl.h: counter-based, so it can be made again
+// whenever somebody asks for the source's beam); `in` points at a beam-sized scratch that this
+// kernel neither reads nor writes -- it is filled only if the pass has to be redone exactly
+// (geosource_shine_if_redo). Every ray of a source has the same state (> 0: all enter).
+template <class K>
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_gen_scr(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_geosource G, xrt_hip_beam in, xrt_hip_beam lb,
+    xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp, OptStat* __restrict__ opt,
+    ScreenConsumer cons) {
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
+  if (fused_skips(gp, 0)) return;
+  const bool has_amp = in.Es_ri != nullptr;
+  const gen::GenRay made = gen::make_ray(G, gen::call_of(G), i < in.n ? i : 0, has_amp);
+  RayRequest req;
+  req.st0 = i < in.n ? G.state : 0;
+  req.raw.x = made.x;
+  req.raw.y = made.y;
+  req.raw.z = made.z;
+  req.raw.a = made.a;
+  req.raw.b = made.b;
+  req.raw.c = made.c;
+  req.q.path = 0.;
+  req.q.E = made.E;
+  req.q.Jss = made.r.Jss;
+  req.q.Jpp = made.r.Jpp;
+  req.q.Jsr = made.r.Jre;
+  req.q.Jsi = made.r.Jim;
+  req.q.Esr = has_amp ? made.r.Esr : 0.;
+  req.q.Esi = has_amp ? made.r.Esi : 0.;
+  req.q.Epr = has_amp ? made.r.Epr : 0.;
+  req.q.Epi = has_amp ? made.r.Epi : 0.;
+  const GStat g = *gp;
+  int neg = 0, pos = 0;
+  fused_ray<K, 0, false, ScreenConsumer>(P, M, in, in, lb, vb, theta, g, opt, i, req, neg, pos,
+                                         cons);
 }
 
 // ---------------------------------------------------------------------------

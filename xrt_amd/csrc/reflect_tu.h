@@ -35,6 +35,7 @@ struct FusedLaunch {   // one launch of reflect_fused / reflect_fused_xtal
   OptStat* opt;
   const xrt_hip_screen* scr;   // a screen in the tail of the pass (reflect_fused_scr), or null
   const xrt_hip_beam* sb;      //   its image
+  const xrt_hip_geosource* src;   // the source in its head (reflect_fused_gen_scr), or null
 };
 struct ExactLaunch {   // reflect_exact
   dim3 grid, block;
@@ -107,6 +108,14 @@ inline void launch_fused_scr_k(int mode, const FusedLaunch& L) {
                        *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt, cons);
 }
 template <class K>
+inline void launch_fused_gen_scr_k(const FusedLaunch& L) {
+  ScreenConsumer cons;
+  cons.S = *L.scr;
+  cons.out = *L.sb;
+  hipLaunchKernelGGL(reflect_fused_gen_scr<K>, L.grid, L.block, 0, L.st, *L.P, *L.M, *L.src, *L.in,
+                     *L.lb, *L.vb, L.theta, L.g, L.opt, cons);
+}
+template <class K>
 inline void launch_xtal_k(int mode, const FusedLaunch& L) {
   if (mode == 0)
     hipLaunchKernelGGL((reflect_fused_xtal<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
@@ -130,6 +139,7 @@ inline void launch_dcm_k(const DcmLaunch& L) {
 // the units (each returns false for a spec it does not hold)
 bool tu_hot_fused(int spec, int mode, const FusedLaunch& L);        // reflect_hot.hip
 bool tu_hot_fused_scr(int spec, int mode, const FusedLaunch& L);    // reflect_hot_scr.hip
+bool tu_hot_fused_gen_scr(int spec, const FusedLaunch& L);          // reflect_hot_gen.hip
 bool tu_hot_xtal(int spec, int mode, const FusedLaunch& L);
 bool tu_hot_dcm(int spec, const DcmLaunch& L);
 bool tu_xtal_xtal(int spec, int mode, const FusedLaunch& L);        // reflect_xtal.hip

@@ -48,7 +48,7 @@ def cache_dir():
 
 def _headers_digest():
     h = hashlib.sha256()
-    for name in ('reflect_impl.h', 'screen_impl.h', 'reflect_multi_impl.h', 'reflect_tu.h', 'reflect.h', 'fp64_math.h', 'user_unit.hip.in',
+    for name in ('reflect_impl.h', 'screen_impl.h', 'source_impl.h', 'reflect_multi_impl.h', 'reflect_tu.h', 'reflect.h', 'fp64_math.h', 'user_unit.hip.in',
                  os.path.join('..', '..', 'include', 'xrt_hip.h')):
         with open(os.path.join(_CSRC, name), 'rb') as f:
             h.update(f.read())
