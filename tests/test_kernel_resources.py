@@ -63,7 +63,7 @@ def test_hot_kernels_keep_their_budget():
         for mode in ('Li0', 'Li2'):
             fig = _one(table, 'reflect_fusedINS_7FiguredI%sEEE%s' % (fam, mode))
             assert fig['vgpr'] <= 168 and fig['vgpr_spill'] <= spill and fig['scratch'] <= 320, fig
-    for small in ('reflect_decide_opt', 'reflect_decide_dcm'):
+    for small in ('reflect_decide_optE', 'reflect_decide_opt_gen', 'reflect_decide_dcm'):
         assert _one(table, small)['scratch'] == 0
     for name, r in table.items():
         if 'kirchhoff_stream' in name:
@@ -73,7 +73,8 @@ def test_hot_kernels_keep_their_budget():
         if 'geosource_shine' in name or 'plot_hist' in name and 'plot_hist_kernel' not in name \
                 and 'plot_hist_small' not in name:
             assert r['scratch'] == 0 and r['vgpr_spill'] == 0, name
-        if 'plot_hist_small' in name or 'reflect_fused_scr' in name:
+        if 'plot_hist_small' in name or 'reflect_fused_scr' in name or \
+                'reflect_fused_gen_scr' in name:
             assert r['vgpr_spill'] == 0 and r['scratch'] <= 32, name
         if 'reflect_multi' in name:      # two blocks per CU by choice (profiles/r05_multi_percu_ab.txt)
             assert r['vgpr'] <= 256 and r['vgpr_spill'] <= 112 and r['scratch'] <= 512, name
