@@ -721,10 +721,10 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     if (evk0) (void)hipEventRecord(evk0, st);
     launched &= tu_hot_fused_gen_scr(spec, FL);
     if (evk1) (void)hipEventRecord(evk1, st);
-    // (every block folds the reports itself before it knows whether there is work: few blocks)
-    const int64_t want = (n + 255) / 256;
-    hipLaunchKernelGGL(geosource_shine_if_redo, dim3((unsigned)(want < 256 ? want : 256)),
-                       dim3(256), 0, st, g, opt, *src, in);
+    int* redo_flag = reinterpret_cast<int*>(L.ht + 16);
+    hipLaunchKernelGGL(reflect_redo_verdict, dim3(1), dim3(256), 0, st, g, opt, redo_flag);
+    const hipError_t ge = geosource_shine_if_launch(redo_flag, *src, in, st);
+    if (ge != hipSuccess) return ge;
     launch_exact();
   } else if (optimistic) {
     // assumptions from the head of the beam -> the pass on them, every ray checking ->

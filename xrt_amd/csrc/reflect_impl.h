@@ -1490,13 +1490,11 @@ __device__ __forceinline__ bool fold_opt(const OptStat* slots, double* lds_d, do
 }
 
 #ifdef XRT_REFLECT_MAIN_TU
-// The source's beam after all, for the exact sequence: runs only if the optimistic pass that
-// made its rays in registers was contradicted (the verdict reflect_exact's gate will reach: the
-// same fold of the same reports) or never ran. A small grid that strides.
-__global__ __launch_bounds__(256) void geosource_shine_if_redo(const GStat* g,
-                                                              const OptStat* slots,
-                                                              xrt_hip_geosource G,
-                                                              xrt_hip_beam out) {
+// Will reflect_exact redo the pass? The verdict its gate is going to reach (the same fold of the
+// same reports), one block, ahead of it: a pass that made its rays in registers has to write the
+// source's beam out first (geosource_shine_if_kernel, source.hip).
+__global__ __launch_bounds__(256) void reflect_redo_verdict(const GStat* g, const OptStat* slots,
+                                                           int* flag) {
   __shared__ double lds_d[REFLECT_MAX_WAVES];
   bool full;
   if (g->optimistic) {
@@ -1505,12 +1503,7 @@ __global__ __launch_bounds__(256) void geosource_shine_if_redo(const GStat* g,
   } else {
     full = g->redo != 0;
   }
-  if (!full) return;
-  const bool amp = out.Es_ri != nullptr;
-  const uint32_t call = gen::call_of(G);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < out.n; i += stride)
-    gen::store_gen_ray(out, i, gen::make_ray(G, call, i, amp), G.state, amp);
+  if (threadIdx.x == 0) *flag = full ? 1 : 0;
 }
 #endif
 
