@@ -306,3 +306,21 @@ def test_an_aperture_on_the_pending_source_beam():
     same(l1, l0, 'local', extra=('theta',))
     same(s1, s0, 'source after the slit')
     assert (s1.state < 0).sum() > 100
+
+
+def test_elements_and_sources_remember_what_was_wanted():
+    """A global beam (a source's beam) that was left out and then asked for after all costs a
+    second launch ONCE: from then on the element's fused pass writes it (the source launches its
+    generator at once)."""
+    bl, amp = source_scene(n=20000)
+    src0, gb0, lb0, img0 = run_chain(bl, amp, False)
+    src, gb, lb, img = run_chain(bl, amp, True)
+    assert gb.__dict__['_op'].state == 'imaged' and src.__dict__['_op'].state == 'inflight'
+    same(gb, gb0, 'global')                  # asked for: the element remembers
+    same(src, src0, 'source')                # ... and so does the source
+    src, gb, lb, img = run_chain(bl, amp, True)
+    assert type(src) is not rs.LazyBeam      # its own launch, at once
+    assert gb.__dict__['_op'].state == 'done' and gb.__dict__['_filled']   # written by the pass
+    same(gb, gb0, 'global, kept')
+    same(img, img0, 'image')
+    same(lb, lb0, 'local', extra=('theta',))

@@ -827,7 +827,9 @@ class _DeferredReflect(object):
             self.lb._adopt_arrays(lb)
             self.gb._adopt_arrays(gb)
         elif self.state == 'imaged' and which == 'gb':
-            # somebody wants the global beam after all: the pass without its local beam
+            # somebody wants the global beam after all: the pass without its local beam -- and
+            # the element remembers: next time the fused pass writes the global beam as well
+            oe.__dict__['_global_beam_wanted'] = True
             self.state = 'done'
             _, gb, _ = oe._run_pass(self.p, oe.material, True, self.beam, self.beam, local=False)
             self.gb._adopt_arrays(gb)
@@ -840,12 +842,15 @@ class _DeferredReflect(object):
         src = self.src_op
         stripes = oe.material if raycing.is_sequence(oe.material) else (oe.material,)
         tabulated = any(isinstance(getattr(m, 'refractiveIndex', None), list) for m in stripes)
+        keep = bool(oe.__dict__.get('_global_beam_wanted'))
         if src is not None and src.state == 'pending' and not tabulated:
-            lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, None, rec, source=src)
+            lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, None, rec, source=src,
+                                                       keep_global=keep)
         else:
-            lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, self.beam, rec)
+            lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, self.beam, rec,
+                                                       keep_global=keep)
         self.lb._adopt_arrays(lb)
-        if fused:
+        if fused and not keep:
             self.state = 'imaged'
             self._scratch = gb            # (the redo's scratch: freed with this record)
         else:
@@ -855,7 +860,7 @@ class _DeferredReflect(object):
         return image
 
 
-def _run_pass_screen(self, p, material, beam_in, screen_record, source=None):
+def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, keep_global=False):
     """OE.reflect + Screen.expose in one C call (xrt_hip_reflect_screen_f64_dev) ->
     (lb, gb, image, fused): fused = the lean kernel carried the screen and gb holds nothing.
     *source* (a pending sources._DeferredShine, with beam_in None): the rays are made by the
@@ -881,7 +886,7 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None):
             ctypes.byref(source.g), ctypes.byref(p), ctypes.byref(ms),
             ctypes.byref(scratch.to_struct(dev)), ctypes.byref(lb.to_struct(dev)),
             ctypes.byref(gb.to_struct(dev)), ctypes.c_void_p(theta.data_ptr()),
-            ctypes.byref(screen_record), ctypes.byref(image.to_struct(dev)), 0,
+            ctypes.byref(screen_record), ctypes.byref(image.to_struct(dev)), int(keep_global),
             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(), ctypes.byref(fused)),
             'xrt_hip_shine_reflect_screen_f64_dev')
         if fused.value & 2:
@@ -894,8 +899,8 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None):
             ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in),
             ctypes.byref(lb.to_struct(dev)), ctypes.byref(gb.to_struct(dev)),
             ctypes.c_void_p(theta.data_ptr()), ctypes.byref(screen_record),
-            ctypes.byref(image.to_struct(dev)), 0, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
-            _stream(), ctypes.byref(fused), None), 'xrt_hip_reflect_screen_f64_dev')
+            ctypes.byref(image.to_struct(dev)), int(keep_global), ctypes.c_void_p(ws.data_ptr()),
+            ws.numel(), _stream(), ctypes.byref(fused), None), 'xrt_hip_reflect_screen_f64_dev')
     lb._d['theta'] = theta
     self._adopt((lb, gb), parent)
     rs.inherit_scalars(image, parent)

@@ -487,6 +487,11 @@ class _DeferredShine(object):
     def materialize(self, which=None):
         _PENDING.discard(self)
         if self.state != 'done':
+            if self.state == 'inflight':
+                # an element's pass had made these rays in its registers and now somebody wants
+                # the beam as well: the source remembers and launches its generator at once
+                # from the next shine() on
+                self.source.__dict__['_beam_wanted'] = True
             self.state = 'done'
             bo = Beam.empty_on_device(self.n, self.device, self.amplitudes)
             self.launch_into(bo)
@@ -932,7 +937,7 @@ class GeometricSource(object):
         amplitudes = withAmplitudes or self.uniformRayDensity
         if rec is None and reach2 <= 1 and accuBeam is None and not self.uniformRayDensity:
             from . import oes as _oes
-            if _oes.fuseConsumers:
+            if _oes.fuseConsumers and not self.__dict__.get('_beam_wanted'):
                 # not launched yet: an element's pass may make these rays in its own registers
                 # (oes._DeferredReflect); anything else that looks at the beam launches the
                 # generator -- the record draws the same rays whenever it runs
