@@ -742,6 +742,9 @@ typedef struct xrt_hip_aperture {
   const double* poly_xz;
 } xrt_hip_aperture;
 
+/* out_local may be NULL (then out_global must be too): only the states in beam_inout are
+ * updated -- 52 B read and <= 4 B written per ray; the beam in the aperture's frame can be made
+ * later by a second call on the same arrays with a copy of the states as they were. */
 XRT_HIP_API int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* aperture,
                                                    xrt_hip_beam* beam_inout,
                                                    xrt_hip_beam* out_local,

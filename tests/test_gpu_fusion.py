@@ -324,3 +324,119 @@ def test_elements_and_sources_remember_what_was_wanted():
     same(gb, gb0, 'global, kept')
     same(img, img0, 'image')
     same(lb, lb0, 'local', extra=('theta',))
+
+
+def _apertures(bl, gb=None):
+    """Five kinds of aperture half way to the screen, each cutting a good part of the beam."""
+    at = [0, 20000. + 5000. * np.cos(8e-3), 5000. * np.sin(8e-3)]
+    sx = sz = 1.
+    if gb is not None:      # sized by the beam as a wide-open slit sees it
+        roe.fuseConsumers = False
+        try:
+            seen = ra.RectangularAperture(bl, 'open', at, ('left',), [-1e9]).propagate(
+                rs.Beam(copyFrom=gb))
+        finally:
+            roe.fuseConsumers = True
+        ok = seen.state == 1
+        sx, sz = np.abs(seen.x[ok]).mean() * 2, np.abs(seen.z[ok]).mean() * 2
+    return [ra.RectangularAperture(bl, 'slit', at, ('left', 'right', 'top'),
+                                   [-0.6 * sx, 0.4 * sx, 0.3 * sz]),
+            ra.RectangularBeamStop(bl, 'stop', at, ('left', 'right', 'bottom', 'top'),
+                                   [-0.3 * sx, 0.3 * sx, -0.4 * sz, 0.4 * sz]),
+            ra.RoundAperture(bl, 'pipe', at, r=0.5 * min(sx, sz)),
+            ra.DoubleSlit(bl, 'two', at, ('bottom', 'top'), [-0.5 * sz, 0.5 * sz],
+                          shadeFraction=0.3),
+            ra.PolygonalAperture(bl, 'tri', at, opening=[(-0.5 * sx, -0.4 * sz),
+                                                         (0.6 * sx, -0.3 * sz), (0., 0.5 * sz)])]
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+def test_aperture_local_beam_made_on_demand(amplitudes):
+    """propagate() marks the stopped rays at once (states only) and makes the beam in the
+    aperture's frame when it is first looked at: the bits of the one full launch, also after
+    the incoming beam went through another aperture in between."""
+    bl, oe, scr, beam = scene(n=60000, amplitudes=amplitudes)
+    gb0 = eager(oe, scr, beam)[0]
+    kinds = _apertures(bl, gb0)
+    for ap, other in zip(kinds, kinds[1:] + kinds[:1]):
+        roe.fuseConsumers = False
+        try:
+            b0 = rs.Beam(copyFrom=gb0)
+            l0 = ap.propagate(b0)
+            after_first = b0.state.copy()
+            other.propagate(b0)
+        finally:
+            roe.fuseConsumers = True
+        b1 = rs.Beam(copyFrom=gb0)
+        l1 = ap.propagate(b1)
+        assert type(l1) is rs.LazyBeam and not l1.__dict__['_filled']
+        assert np.array_equal(b1.state, after_first), ap.name
+        assert 1000 < (after_first != gb0.state).sum() < 0.97 * len(b1), ap.name
+        l2 = other.propagate(b1)                 # changes b1.state again, in place
+        assert not l1.__dict__['_filled']
+        assert np.array_equal(b1.state, b0.state), ap.name
+        same(l1, l0, 'local of ' + ap.name)
+        assert l1.__dict__['_filled'] and not l2.__dict__['_filled']
+        # with the new global beam: the full launch at once, as before
+        b2 = rs.Beam(copyFrom=gb0)
+        g2, l3 = ap.propagate(b2, needNewGlobal=True)
+        assert type(l3) is rs.Beam
+        same(l3, l0, 'local with global of ' + ap.name)
+
+
+def test_aperture_local_beam_never_looked_at_costs_nothing_more():
+    import gc
+    bl, oe, scr, beam = scene(n=20000, bad=False)
+    gb = eager(oe, scr, beam)[0]
+    slit = _apertures(bl, gb)[0]
+    local = slit.propagate(gb)
+    op = local.__dict__['_op']
+    assert op in rs._PENDING.optional()
+    rs.flush_pending()                            # (the end of an iteration)
+    assert not local.__dict__['_filled']
+    # a change of the incoming arrays in place comes after the reader
+    l0 = None
+    roe.fuseConsumers = False
+    try:
+        g0 = rs.Beam(copyFrom=eager(oe, scr, beam)[0])
+        l0 = slit.propagate(g0)
+    finally:
+        roe.fuseConsumers = True
+    rs.flush_pending(gb)
+    assert local.__dict__['_filled'] and op not in rs._PENDING.optional()
+    same(local, l0, 'local before the change')
+    # dropped unseen: gone with its beam
+    import weakref
+    local = slit.propagate(gb)
+    gone = weakref.ref(local.__dict__['_op'])
+    assert gone() in rs._PENDING.optional()
+    del local, op
+    gc.collect()
+    assert gone() is None and None not in rs._PENDING.optional()
+
+
+def test_c_abi_aperture_states_only():
+    import ctypes
+    from xrt_amd import _lib
+    bl, oe, scr, beam = scene(n=30000)
+    gb = eager(oe, scr, beam)[0]
+    slit = _apertures(bl, gb)[0]
+    roe.fuseConsumers = False
+    try:
+        b0 = rs.Beam(copyFrom=gb)
+        slit.propagate(b0)
+    finally:
+        roe.fuseConsumers = True
+    dev = torch.device('cuda', 0)
+    b1 = rs.Beam(copyFrom=gb)
+    glo = rs.Beam.empty_like_on_device(b1, dev)
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rec = slit._record()
+    rc = lib.xrt_hip_aperture_propagate_f64_dev(ctypes.byref(rec), ctypes.byref(b1.to_struct(dev)),
+                                                None, ctypes.byref(glo.to_struct(dev)), stream)
+    assert rc != 0 and b'out_global' in lib.xrt_hip_last_error()
+    _lib.check(lib.xrt_hip_aperture_propagate_f64_dev(
+        ctypes.byref(rec), ctypes.byref(b1.to_struct(dev)), None, None, stream), 'states only')
+    b1._h.pop('state', None)
+    assert np.array_equal(b1.state, b0.state)

@@ -134,7 +134,10 @@ class RectangularAperture(object):
         _lib.require_gpu()
         dev = torch.device('cuda', torch.cuda.current_device())
         beam.to_struct(dev)
-        rs.flush_pending(beam)           # (beam.state changes in place below)
+        rs.flush_pending(beam, only_state=True)    # (beam.state changes in place below)
+        from . import oes as roe
+        if not needNewGlobal and roe.fuseConsumers:
+            return _DeferredLocal(self, beam, dev).local
         local = rs.Beam.empty_like_on_device(beam, dev)
         glo = rs.Beam.empty_like_on_device(beam, dev) if needNewGlobal else None
         rec = self._record()
@@ -174,6 +177,57 @@ class RectangularAperture(object):
         opened = spans[0] * spans[1]
         return rw.receiving_wave(self, prevOE, (px, py, pz), there, opened / count,
                                  opened, self.uuid)
+
+
+class _DeferredLocal(object):
+    """``propagate`` when only the states are certain to be needed: ONE launch reads the
+    geometry and marks the stopped rays in the incoming beam (52 B read, <= 4 B written per ray
+    -- out_local NULL in xrt_hip_aperture_propagate_f64_dev); the beam in the aperture's frame
+    (another ~100 B read and 100 B written per ray) is made by the full kernel, from the very
+    same arrays and a copy of the states as they were, when somebody first looks at it --
+    the same bits, or no launch at all if nobody does (a slit between two mirrors whose local
+    beam no plot shows)."""
+    optional = True
+
+    def __init__(self, aperture, beam, dev):
+        self.aperture, self.device = aperture, dev
+        self.record = aperture._record()
+        # the rays as they are NOW: the same tensors (whoever writes into them in place flushes
+        # the readers first, sources.flush_pending) and the states before this aperture
+        was = rs.Beam.__new__(rs.Beam)
+        object.__setattr__(was, '_h', {})
+        object.__setattr__(was, '_d', dict(beam._d))
+        object.__setattr__(was, 'parentId', None)
+        was._d['state'] = beam._d['state'].clone()
+        self.was = was
+        self.tensors = {id(t) for t in beam._d.values()}
+        self.state = 'pending'
+        self._launch(beam, None)
+        beam._h.pop('state', None)       # the kernel updated beam.state in HBM
+        self.local = rs.LazyBeam(self, 'local')
+        rs.inherit_scalars(self.local, beam)
+        rs._PENDING.add(self)
+
+    def _launch(self, beam, local):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().xrt_hip_aperture_propagate_f64_dev(
+                ctypes.byref(self.record), ctypes.byref(beam.to_struct(self.device)),
+                ctypes.byref(local.to_struct(self.device)) if local is not None else None,
+                None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                'xrt_hip_aperture_propagate_f64_dev')
+
+    def reads(self, beam):
+        d = beam.__dict__.get('_real_d', beam.__dict__.get('_d')) or {}
+        return any(id(t) in self.tensors for t in d.values())
+
+    def materialize(self, which=None):
+        rs._PENDING.discard(self)
+        if self.state != 'done':
+            self.state = 'done'
+            local = rs.Beam.empty_like_on_device(self.was, self.device)
+            self._launch(self.was, local)
+            self.local._adopt_arrays(local)
+            self.was = self.tensors = None
 
 
 class SetOfRectangularAperturesOnZActuator(RectangularAperture):

@@ -420,6 +420,7 @@ class Beam(object):
 # next element -- launches the plain pass at that moment: same kernels, same bits, a little
 # later on the stream.
 import threading as _threading
+import weakref as _weakref
 
 
 class _PendingOps(object):
@@ -435,26 +436,43 @@ class _PendingOps(object):
             ops = self._tls.ops = set()
         return ops
 
+    def _mine_optional(self):
+        ops = self._tls.__dict__.get('optional')
+        if ops is None:
+            ops = self._tls.optional = _weakref.WeakSet()
+        return ops
+
     def add(self, op):
-        self._mine().add(op)
+        # an *optional* operation has no effect but the beam it would fill: it lives as long as
+        # that beam does and may never run at all
+        (self._mine_optional() if getattr(op, 'optional', False) else self._mine()).add(op)
 
     def discard(self, op):
         self._mine().discard(op)
+        self._mine_optional().discard(op)
 
     def __iter__(self):
         return iter(list(self._mine()))
+
+    def optional(self):
+        return list(self._mine_optional())
 
 
 _PENDING = _PendingOps()
 _FILL_LOCK = _threading.RLock()      # a beam looked at from another thread: one launch, complete
 
 
-def flush_pending(beam=None, keep=None):
+def flush_pending(beam=None, keep=None, only_state=False):
     """Launches what is still pending -- all of it (but *keep*), or what reads *beam* (called by
-    whoever is about to change a beam's arrays in place)."""
+    whoever is about to change a beam's arrays in place; *only_state*: nothing but its states,
+    of which the optional operations hold their own copy)."""
     for op in list(_PENDING):
         if op is not keep and (beam is None or op.reads(beam)):
             op.materialize()
+    if beam is not None and not only_state:
+        for op in _PENDING.optional():
+            if op is not keep and op.reads(beam):
+                op.materialize()
 
 
 class _DeferredShine(object):

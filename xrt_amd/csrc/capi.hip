@@ -997,11 +997,14 @@ int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* aperture,
   const bool amp = beam_inout->Es_ri != nullptr || beam_inout->Ep_ri != nullptr;
   int rc;
   if ((rc = check_beam(beam_inout, "beam", n, amp))) return rc;
-  if ((rc = check_beam(out_local, "out_local", n, amp))) return rc;
+  // out_local NULL: only the states of beam_inout are updated (no beam is written)
+  if (!out_local && out_global)
+    return fail(XRT_HIP_ERR_ARG, "out_global without out_local");
+  if (out_local && (rc = check_beam(out_local, "out_local", n, amp))) return rc;
   xrt_hip_beam none;
   memset(&none, 0, sizeof(none));
   if (out_global && (rc = check_beam(out_global, "out_global", n, amp))) return rc;
-  HIP_TRY(xrt::aperture_propagate_launch(*aperture, *beam_inout, *out_local,
+  HIP_TRY(xrt::aperture_propagate_launch(*aperture, *beam_inout, out_local ? *out_local : none,
                                          out_global ? *out_global : none,
                                          reinterpret_cast<hipStream_t>(stream)));
   return XRT_HIP_OK;

@@ -156,19 +156,23 @@ __device__ __forceinline__ bool inside_polygon(const double* v, int n, double x,
 
 // RectangularAperture.propagate, apertures.py:334-413. Same streaming shape as
 // screen_expose; additionally writes the new state back into the incoming beam.
+// FULL = false: only the states are wanted (out_local NULL: nobody looks at the beam in the
+// aperture's frame -- the caller can make it later from the same arrays and a copy of the states
+// as they were): 52 B read and at most 4 written per ray instead of 100 + 100.
+template <bool FULL>
 __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_aperture A,
                                                                 xrt_hip_beam in,
                                                                 xrt_hip_beam lo,
                                                                 xrt_hip_beam glo) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= in.n) return;
-  const bool has_amp = in.Es_ri != nullptr;
-  const bool want_glo = glo.x != nullptr;
+  const bool has_amp = FULL && in.Es_ri != nullptr;
+  const bool want_glo = FULL && glo.x != nullptr;
   int st = in.state[i];
   double x = in.x[i], y = in.y[i], z = in.z[i];
   double a = in.a[i], b = in.b[i], c = in.c[i];
-  double path = in.path[i];
-  const double E = in.E[i];
+  double path = FULL ? in.path[i] : 0.;
+  const double E = FULL ? in.E[i] : 0.;
   double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
   if (has_amp) {
     es = reinterpret_cast<const double2*>(in.Es_ri)[i];
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_apertur
   }
   if (!good && A.poly_n > 0 && !inside_polygon(A.poly_xz, A.poly_n, x, z))
     in.state[i] = A.lost_num;   // apertures.py:1198-1203: the incoming beam only
+  if (!FULL) return;
   const double path_in = in.path[i];
   const double Jss = in.Jss[i], Jpp = in.Jpp[i];
   const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
@@ -271,7 +276,12 @@ hipError_t aperture_propagate_launch(const xrt_hip_aperture& A, const xrt_hip_be
                                      const xrt_hip_beam& lo, const xrt_hip_beam& glo,
                                      hipStream_t st) {
   if (in.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(aperture_propagate_kernel, dim3((unsigned)((in.n + 255) / 256)), dim3(256),
+  if (!lo.x) {
+    hipLaunchKernelGGL(aperture_propagate_kernel<false>, dim3((unsigned)((in.n + 255) / 256)),
+                       dim3(256), 0, st, A, in, lo, glo);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(aperture_propagate_kernel<true>, dim3((unsigned)((in.n + 255) / 256)), dim3(256),
                      0, st, A, in, lo, glo);
   return hipGetLastError();
 }
