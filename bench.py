@@ -729,6 +729,19 @@ def bench_e2e(nrays, repeats=20):
     t1 = time.perf_counter()
     flux = float(plot.total2D.sum())
     read_back = time.perf_counter() - t1
+    # the same job with every call an immediate launch and every beam written, looked at or not
+    # (what rounds 1-4 did)
+    from xrt_amd.backends.raycing import oes as roe
+    roe.fuseConsumers = False
+    try:
+        runner.run_ray_tracing([make_plot()], repeats=3, beamLine=bl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.run_ray_tracing([make_plot()], repeats=repeats, beamLine=bl)
+        torch.cuda.synchronize()
+        wall_all = (time.perf_counter() - t0) / repeats
+    finally:
+        roe.fuseConsumers = True
     # GPU time per step of an iteration: events on the launch stream
     steps = ('source', 'reflect', 'screen', 'histograms')
     dev_ms = dict.fromkeys(steps, 0.)
@@ -759,20 +772,24 @@ def bench_e2e(nrays, repeats=20):
                       'of the free-running loop; ~1 = the loop is GPU-bound (the instrumented '
                       'iterations carry a few us of event gaps: the ratio can exceed 1)' % n_probe,
         read_back_ms_once=read_back * 1e3, flux_in_plot=flux,
-        bytes_per_ray=dict(source_mirror_screen=208, histograms=44, as_separate_passes=652),
+        ms_per_iteration_every_beam_written=wall_all * 1e3,
+        bytes_per_ray=dict(source_mirror_screen=100, histograms=44, as_separate_passes=652),
         fused='GeometricSource.shine, OE.reflect and Screen.expose are ONE pass '
               '(reflect_fused_gen_scr): the rays are made in the registers of the mirror kernel, '
               'the screen\'s image comes out of its tail; the "source" and "reflect" steps of '
-              'gpu_ms_by_step only hand out beams, the "screen" step is the pass; neither the '
-              'source beam nor the global beam is written (nobody reads them; either can still '
-              'be made on demand)',
+              'gpu_ms_by_step only hand out beams, the "screen" step is the pass. The script '
+              'plots the screen\'s image and nothing else: the source beam, the mirror\'s local '
+              'and global beams are not written (each is made on demand, by the same kernels, '
+              'the first time somebody looks at it, and written at once from then on -- '
+              'tests/test_gpu_fusion.py); ms_per_iteration_every_beam_written = the same job '
+              'as four immediate launches that write all of them (oes.fuseConsumers = False)',
         roofline=dict(bound='hbm', kernel='the pass and the plot of one iteration',
-                      achieved=252. * nrays / wall / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
-                      frac=252. * nrays / wall / HBM_PEAK, traffic=None,
-                      note='252 B per ray algorithmic as built: 108 (local beam, theta) + 100 '
-                           '(image) written by the one pass, 44 read by the plot -- the pass is '
-                           'now bound by its arithmetic (Philox, Box-Muller, the root search), '
-                           'not by HBM. (652 B as four separate passes, round 4.)'))
+                      achieved=144. * nrays / wall / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
+                      frac=144. * nrays / wall / HBM_PEAK, traffic=None,
+                      note='144 B per ray algorithmic as built: 100 (image) written by the one '
+                           'pass, 44 read by the plot -- the pass is bound by its arithmetic '
+                           '(Philox, Box-Muller, the root search), not by HBM. (652 B as four '
+                           'separate passes that write every beam, round 4.)'))
     # beams of the size most xrt scripts trace (1e5 rays per iteration): the host, not the GPU,
     # bounds the eager loop; run_ray_tracing(graph=True) replays one HIP graph per iteration
     small = {}
@@ -964,8 +981,29 @@ def bench_balder(nrays, runs=5):
     sec = (time.perf_counter() - t0) / runs
     arrived = float((image.state_count(1) if hasattr(image, 'state_count')
                      else (image.state == 1).sum()) / nrays)
+    # ... and with every beam of every element written, looked at or not (rounds 1-4)
+    from xrt_amd.backends.raycing import oes as roe
+    roe.fuseConsumers = False
+    try:
+        fresh = [rs.Beam(copyFrom=beam) for _ in range(runs + 1)]
+        workloads.balder_trace(optics, fresh[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(runs):
+            workloads.balder_trace(optics, fresh[k + 1])
+        torch.cuda.synchronize()
+        sec_all = (time.perf_counter() - t0) / runs
+    finally:
+        roe.fuseConsumers = True
+    del fresh
     return {'metric': 'Balder example beamline, mask -> sample, seconds per pass of the beam',
-            'rays': nrays, 'seconds': sec, 'rays_per_s': nrays / sec,
+            'rays': nrays, 'seconds': sec, 'seconds_every_beam_written': sec_all,
+            'on_demand': 'the chain hands the global beam from element to element and shows the '
+                         'two screens: the local beams of the mirrors and of the filter (308 -> '
+                         '200 B per ray and surface) and the beams in the frames of the four '
+                         'apertures (200 -> 52 B) are not written; each is made, by the same '
+                         'kernels on the same input, the first time somebody looks at it',
+            'rays_per_s': nrays / sec,
             'intersections_per_s': 6 * nrays / sec, 'surfaces': 6, 'apertures': 4,
             'screens': 2, 'fraction_at_sample': arrived,
             'note': 'device-resident beams through 12 elements; host glue of every element '
@@ -1273,9 +1311,11 @@ def compact_for_the_record(line, world):
                       ('softimax', lambda d: dict(
                           seconds=d.get('seconds'), first=d.get('seconds_first_run_incl_setup'),
                           relaxed_seconds=d.get('relaxed', {}).get('seconds'))),
-                      ('balder', lambda d: dict(ms_per_step=d.get('ms_per_step'))),
+                      ('balder', lambda d: dict(seconds=d.get('seconds'), every_beam_written=d.get(
+                          'seconds_every_beam_written'))),
                       ('e2e', lambda d: dict(
                           ms_per_iteration=d.get('ms_per_iteration'),
+                          every_beam_written_ms=d.get('ms_per_iteration_every_beam_written'),
                           bytes_per_ray=d.get('bytes_per_ray'),
                           small_1e5_ms=(d.get('small_beams', {}).get('100000_rays', {})),
                           small_1e6_ms=(d.get('small_beams', {}).get('1000000_rays', {})))),

@@ -320,10 +320,15 @@ def test_elements_and_sources_remember_what_was_wanted():
     same(src, src0, 'source')                # ... and so does the source
     src, gb, lb, img = run_chain(bl, amp, True)
     assert type(src) is not rs.LazyBeam      # its own launch, at once
-    assert gb.__dict__['_op'].state == 'done' and gb.__dict__['_filled']   # written by the pass
+    assert gb.__dict__['_filled']            # written by the pass
+    assert not lb.__dict__['_filled'] and not bl.mirror.__dict__.get('_local_beams_wanted')
     same(gb, gb0, 'global, kept')
     same(img, img0, 'image')
-    same(lb, lb0, 'local', extra=('theta',))
+    same(lb, lb0, 'local', extra=('theta',))     # asked for: remembered as well
+    assert bl.mirror.__dict__['_local_beams_wanted']
+    src, gb, lb, img = run_chain(bl, amp, True)
+    assert gb.__dict__['_op'].state == 'done' and lb.__dict__['_filled']
+    same(lb, lb0, 'local, kept', extra=('theta',))
 
 
 def _apertures(bl, gb=None):
@@ -440,3 +445,97 @@ def test_c_abi_aperture_states_only():
         ctypes.byref(rec), ctypes.byref(b1.to_struct(dev)), None, None, stream), 'states only')
     b1._h.pop('state', None)
     assert np.array_equal(b1.state, b0.state)
+
+
+def test_local_beam_made_on_demand():
+    """The global beam goes on to the next element and nobody looks at the local one: the pass
+    leaves it out (200 instead of 308 B per ray). Looked at later it is made by the pass run
+    again -- on the input as it was, whatever an aperture did to its states since -- and the
+    element writes it at once from then on."""
+    bl, oe, scr, beam = scene(n=50000)
+    gb0, lb0, _ = eager(oe, scr, beam)
+    slit = ra.RectangularAperture(bl, 'half', [0., 19000., 0.], ('left',), [0.])   # (upstream)
+    b1 = rs.Beam(copyFrom=beam)
+    gb, lb = oe.reflect(b1)
+    again = oe.reflect(gb)                           # the next element takes the global beam
+    op = lb.__dict__['_op']
+    assert op.state == 'global' and gb.__dict__['_filled'] and not lb.__dict__['_filled']
+    assert op in rs._PENDING.optional()
+    same(gb, gb0, 'global')
+    before = b1.state.copy()
+    slit.propagate(b1)                               # the input's states change in place
+    assert (b1.state != before).sum() > 100 and not lb.__dict__['_filled']
+    rs.flush_pending()                               # (the end of an iteration)
+    assert not lb.__dict__['_filled'] and not oe.__dict__.get('_local_beams_wanted')
+    same(lb, lb0, 'local', extra=('theta',))
+    assert op.state == 'done' and oe.__dict__['_local_beams_wanted']
+    assert op not in rs._PENDING.optional()
+    gb, lb = oe.reflect(rs.Beam(copyFrom=beam))
+    again = oe.reflect(gb)
+    assert lb.__dict__['_filled'] and lb.__dict__['_op'].state == 'done'
+    same(lb, lb0, 'local, at once', extra=('theta',))
+    del again
+    # the local beam looked at FIRST: both beams by the one plain pass
+    del oe.__dict__['_local_beams_wanted']
+    gb, lb = oe.reflect(rs.Beam(copyFrom=beam))
+    same(lb, lb0, 'local first', extra=('theta',))
+    assert gb.__dict__['_filled'] and not oe.__dict__.get('_local_beams_wanted')
+
+
+def test_local_beam_on_demand_after_a_contradicted_pass():
+    import p1_cases
+    g = np.load(os.path.join(p1_cases.GOLDEN, 'g2_toroid_brent.npz'))
+    oe = p1_cases.product_oe('g2_toroid_brent', g)
+    beam = p1_cases.product_beam(g)
+    scr = rsc.Screen(oe.bl, 'after', center=[0, float(g['oe_center'][1]) + 3000., 10.])
+    gb0, lb0, img0 = eager(oe, scr, beam)
+    gb, lb = oe.reflect(beam)
+    gb.to_struct(torch.device('cuda', 0))
+    assert lb.__dict__['_op'].state == 'global'
+    same(gb, gb0, 'global')
+    same(lb, lb0, 'local', extra=('theta',))
+    del oe.__dict__['_local_beams_wanted']
+    gb, lb = oe.reflect(beam)                        # ... and with the screen in the tail
+    img = scr.expose(gb)
+    assert not lb.__dict__['_filled']
+    same(img, img0, 'image')
+    same(lb, lb0, 'local', extra=('theta',))
+    same(gb, gb0, 'global')
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+def test_plate_local_beams_made_on_demand(amplitudes):
+    bl = raycing.BeamLine(azimuth=-0.1)
+    mat = rm.Material(('Si', 'O'), quantities=(1, 2), rho=2.2, kind='plate')
+    plate = roe.Plate(bl, 'w', center=[20000. * bl.sinAzimuth, 20000. * bl.cosAzimuth, 0.],
+                      pitch=1.1, material=mat, t=0.2, wedgeAngle=2e-3, limPhysX=[-4., 5.],
+                      limPhysY=[-4., 4.])
+    rng = np.random.default_rng(5)
+    n = 30000
+    beam = rs.Beam(nrays=n, withAmplitudes=amplitudes)
+    beam.x[:], beam.z[:] = rng.normal(0, 1.5, n), rng.normal(0, 1.5, n)
+    beam.a[:], beam.c[:] = rng.normal(0, 1e-4, n), rng.normal(0, 1e-4, n)
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    for u, v in (('x', 'y'), ('a', 'b')):
+        pu, qv = raycing.rotate_z(getattr(beam, u).copy(), getattr(beam, v).copy(),
+                                  bl.cosAzimuth, -bl.sinAzimuth)
+        getattr(beam, u)[:], getattr(beam, v)[:] = pu, qv
+    beam.E[:] = rng.uniform(7000., 12000., n)
+    beam.state[::41] = -2
+    roe.fuseConsumers = False
+    try:
+        g0, a0, b0 = plate.double_refract(rs.Beam(copyFrom=beam))
+    finally:
+        roe.fuseConsumers = True
+    assert type(a0) is rs.Beam
+    g1, a1, b1 = plate.double_refract(rs.Beam(copyFrom=beam))
+    assert type(a1) is rs.LazyBeam and not a1.__dict__['_filled']
+    same(g1, g0, 'global')
+    assert not b1.__dict__['_filled']
+    same(b1, b0, 'second local', extra=('theta',))
+    assert a1.__dict__['_filled'] and plate.__dict__['_local_beams_wanted']
+    same(a1, a0, 'first local', extra=('theta',))
+    g2, a2, b2 = plate.double_refract(rs.Beam(copyFrom=beam))
+    assert type(a2) is rs.Beam
+    same(a2, a0, 'first local, at once', extra=('theta',))
+    same(g2, g0, 'global, at once')

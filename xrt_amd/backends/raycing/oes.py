@@ -781,10 +781,77 @@ class OE(object):
 fuseConsumers = os.environ.get('XRT_HIP_NO_FUSE', '') != '1'
 
 
+def _as_it_is(beam, own_states=False):
+    """-> (a beam of the same device arrays as *beam* has at this moment, their ids). Later
+    assignments to *beam* replace its arrays and do not reach the copy; writes INTO the arrays
+    come after their readers (sources.flush_pending). *own_states*: with a copy of the states,
+    which apertures change in place at any time."""
+    snap = rs.Beam.__new__(rs.Beam)
+    object.__setattr__(snap, '_h', {})
+    object.__setattr__(snap, '_d', dict(beam._d))
+    rs.inherit_scalars(snap, beam)
+    object.__setattr__(snap, 'parentId', getattr(beam, 'parentId', None))
+    if 'createdByDiffract' in beam.__dict__:
+        snap.createdByDiffract = beam.createdByDiffract
+    held = set(id(t) for t in snap._d.values())
+    if own_states:
+        snap._d['state'] = snap._d['state'].clone()
+    return snap, held
+
+
+def _locals_on_demand(oe, *materials):
+    """True if the element's passes may leave their local beams out (written -- by the same
+    pass run again -- when somebody first looks at one, after which the element writes them
+    at once): not the crystal / layered kernels, not an element that was asked before."""
+    from . import materials as _rm
+    if not fuseConsumers or oe.__dict__.get('_local_beams_wanted'):
+        return False
+    for material in materials:
+        stripes = material if raycing.is_sequence(material) else (material,)
+        if any(isinstance(m, (_rm.Crystal, _rm.Multilayer)) for m in stripes):
+            return False
+    return True
+
+
+class _LocalsOnDemand(object):
+    """The local beams of an element whose pass has written the global beam only (308 -> 200 B
+    per ray and surface): *run(beam)* -> the real local beams, called with the input as it was
+    (its own copy of the states) the first time one of them is looked at. The element then
+    remembers (``_local_beams_wanted``) and writes them in its pass from the next call on."""
+    optional = True
+
+    def __init__(self, oe, beam, count, run):
+        self.oe, self.run = oe, run
+        beam.to_struct(_device())                    # everything up in HBM now
+        self.was, self.tensors = _as_it_is(beam, own_states=True)
+        self.locals = [rs.LazyBeam(self, k) for k in range(count)]
+        oe._adopt(self.locals, beam)
+        self.state = 'pending'
+        rs._PENDING.add(self)
+
+    def reads(self, beam):
+        d = beam.__dict__.get('_real_d', beam.__dict__.get('_d')) or {}
+        return any(id(t) in self.tensors for t in d.values())
+
+    def materialize(self, which=None):
+        rs._PENDING.discard(self)
+        if self.state != 'done':
+            self.state = 'done'
+            self.oe.__dict__['_local_beams_wanted'] = True
+            for lazy, real in zip(self.locals, self.run(self.was)):
+                lazy._adopt_arrays(real)
+            self.was = self.run = None
+            self.tensors = ()
+
+
 class _DeferredReflect(object):
     """OE.reflect not launched yet. States: pending -> done (plain pass: both beams), or
-    pending -> imaged (the pass with a screen in its tail: local beam and image; the global
-    beam was not written) -> done (the global beam alone, on demand)."""
+    pending -> global (the next element took the global beam: the pass without its local beam,
+    200 instead of 308 B per ray) -> done (the local beam, by the pass run again, if somebody
+    looks at it), or pending -> imaged (the pass with a screen in its tail: the image, and the
+    local beam if the element knows it is looked at; the global beam was not written) -> done
+    (the beam asked for, on demand). From its first launch on the record holds its own copy
+    of the input's states and lives as long as its beams do (``optional``)."""
 
     def __init__(self, oe, p, beam, out=None):
         dev = _device()
@@ -797,14 +864,7 @@ class _DeferredReflect(object):
             self.tensors = set()
         else:
             beam.to_struct(dev)                      # everything up in HBM now
-            snap = rs.Beam.__new__(rs.Beam)          # the input as it is at this moment
-            object.__setattr__(snap, '_h', {})
-            object.__setattr__(snap, '_d', dict(beam._d))
-            rs.inherit_scalars(snap, beam)
-            object.__setattr__(snap, 'parentId', getattr(beam, 'parentId', None))
-            if 'createdByDiffract' in beam.__dict__:
-                snap.createdByDiffract = beam.createdByDiffract
-            self.tensors = set(id(t) for t in snap._d.values())
+            snap, self.tensors = _as_it_is(beam)     # the input as it is at this moment
         self.oe, self.p, self.beam, self.out = oe, p, snap, out
         self.state = 'pending'
         self.gb, self.lb = rs.LazyBeam(self, 'gb'), rs.LazyBeam(self, 'lb')
@@ -817,23 +877,56 @@ class _DeferredReflect(object):
         d = beam.__dict__.get('_real_d', beam.__dict__.get('_d')) or {}
         return any(id(t) in self.tensors for t in d.values())
 
+    def _waits_with_its_own_states(self):
+        """After a launch that left a beam out: what is needed to make it later."""
+        held = self.beam
+        if type(held) is not rs.LazyBeam or held.__dict__['_filled']:
+            self.beam, self.tensors = _as_it_is(held, own_states=True)
+        # (else: the rays of a source that were made in this pass's registers -- its record
+        # makes them again)
+        self.optional = True
+        rs._PENDING.add(self)
+
     def materialize(self, which=None):
         oe = self.oe
+        filled = lambda b: b.__dict__['_filled']      # noqa: E731
         if self.state == 'pending':
             rs._PENDING.discard(self)
+            if which != 'lb' and self.out is None and _locals_on_demand(oe, oe.material):
+                self.state = 'global'
+                _, gb, _ = oe._run_pass(self.p, oe.material, True, self.beam, self.beam,
+                                        local=False)
+                self.gb._adopt_arrays(gb)
+                self._waits_with_its_own_states()
+                return
             self.state = 'done'
             lb, gb, _ = oe._run_pass(self.p, oe.material, True, self.beam, self.beam,
                                      out=None if self.out is None else (self.out[1], self.out[0]))
             self.lb._adopt_arrays(lb)
             self.gb._adopt_arrays(gb)
-        elif self.state == 'imaged' and which == 'gb':
-            # somebody wants the global beam after all: the pass without its local beam -- and
-            # the element remembers: next time the fused pass writes the global beam as well
-            oe.__dict__['_global_beam_wanted'] = True
-            self.state = 'done'
-            _, gb, _ = oe._run_pass(self.p, oe.material, True, self.beam, self.beam, local=False)
-            self.gb._adopt_arrays(gb)
-        self.beam = None if self.state == 'done' else self.beam
+        elif self.state in ('global', 'imaged'):
+            # somebody wants a beam that was left out after all: the pass again -- and the
+            # element remembers: next time its pass writes that beam as well
+            want_lb = not filled(self.lb) and which != 'gb'
+            want_gb = not filled(self.gb) and which != 'lb'
+            if want_lb:
+                oe.__dict__['_local_beams_wanted'] = True
+            if want_gb:
+                oe.__dict__['_global_beam_wanted'] = True
+            if want_lb or want_gb:
+                rays = self.beam
+                if type(rays) is rs.LazyBeam and not rays.__dict__['_filled']:
+                    rays = self.src_op.rays_again()
+                lb, gb, _ = oe._run_pass(self.p, oe.material, True, rays, rays, local=want_lb)
+                if want_lb:
+                    self.lb._adopt_arrays(lb)
+                if want_gb:
+                    self.gb._adopt_arrays(gb)
+            if filled(self.lb) and filled(self.gb):
+                rs._PENDING.discard(self)
+                self.state = 'done'
+        if self.state == 'done':
+            self.beam, self.tensors = None, ()
 
     def image_on(self, screen, rec):
         """The pass with *screen* in its tail -> the screen's image (a plain Beam)."""
@@ -843,26 +936,33 @@ class _DeferredReflect(object):
         stripes = oe.material if raycing.is_sequence(oe.material) else (oe.material,)
         tabulated = any(isinstance(getattr(m, 'refractiveIndex', None), list) for m in stripes)
         keep = bool(oe.__dict__.get('_global_beam_wanted'))
+        local = not _locals_on_demand(oe, oe.material)
         if src is not None and src.state == 'pending' and not tabulated:
             lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, None, rec, source=src,
-                                                       keep_global=keep)
+                                                       keep_global=keep, local=local)
         else:
             lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, self.beam, rec,
-                                                       keep_global=keep)
-        self.lb._adopt_arrays(lb)
+                                                       keep_global=keep, local=local)
+        if local:
+            self.lb._adopt_arrays(lb)
         if fused and not keep:
-            self.state = 'imaged'
             self._scratch = gb            # (the redo's scratch: freed with this record)
         else:
-            self.state = 'done'
             self.gb._adopt_arrays(gb)
-            self.beam = None
+        if local and not (fused and not keep):
+            self.state = 'done'
+            self.beam, self.tensors = None, ()
+        else:
+            self.state = 'imaged'
+            self._waits_with_its_own_states()
         return image
 
 
-def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, keep_global=False):
+def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, keep_global=False,
+                     local=True):
     """OE.reflect + Screen.expose in one C call (xrt_hip_reflect_screen_f64_dev) ->
-    (lb, gb, image, fused): fused = the lean kernel carried the screen and gb holds nothing.
+    (lb, gb, image, fused): fused = the lean kernel carried the screen and gb holds nothing;
+    *local* False: no local beam either (lb None).
     *source* (a pending sources._DeferredShine, with beam_in None): the rays are made by the
     source's record inside the same call (xrt_hip_shine_reflect_screen_f64_dev)."""
     _lib.require_gpu()
@@ -877,15 +977,18 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
         n, amp, parent = beam_in.nrays, beam_in.has_amplitudes(), beam_in
         ms = self._material_struct(material, True, dev, beam_in)
         s_in = beam_in.to_struct(dev)
-    lb, gb, image = (rs.Beam.empty_on_device(n, dev, amp) for _ in range(3))
-    theta = torch.empty(n, dtype=torch.float64, device=dev)
+    gb, image = (rs.Beam.empty_on_device(n, dev, amp) for _ in range(2))
+    lb = rs.Beam.empty_on_device(n, dev, amp) if local else None
+    theta = torch.empty(n, dtype=torch.float64, device=dev) if local else None
+    lb_ref = ctypes.byref(lb.to_struct(dev)) if local else None
+    theta_ref = ctypes.c_void_p(theta.data_ptr()) if local else None
     ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(n), 'reflect')
     fused = ctypes.c_int(0)
     if source is not None:
         _lib.check(lib.xrt_hip_shine_reflect_screen_f64_dev(
             ctypes.byref(source.g), ctypes.byref(p), ctypes.byref(ms),
-            ctypes.byref(scratch.to_struct(dev)), ctypes.byref(lb.to_struct(dev)),
-            ctypes.byref(gb.to_struct(dev)), ctypes.c_void_p(theta.data_ptr()),
+            ctypes.byref(scratch.to_struct(dev)), lb_ref,
+            ctypes.byref(gb.to_struct(dev)), theta_ref,
             ctypes.byref(screen_record), ctypes.byref(image.to_struct(dev)), int(keep_global),
             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(), ctypes.byref(fused)),
             'xrt_hip_shine_reflect_screen_f64_dev')
@@ -897,12 +1000,13 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
     else:
         _lib.check(lib.xrt_hip_reflect_screen_f64_dev(
             ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in),
-            ctypes.byref(lb.to_struct(dev)), ctypes.byref(gb.to_struct(dev)),
-            ctypes.c_void_p(theta.data_ptr()), ctypes.byref(screen_record),
+            lb_ref, ctypes.byref(gb.to_struct(dev)),
+            theta_ref, ctypes.byref(screen_record),
             ctypes.byref(image.to_struct(dev)), int(keep_global), ctypes.c_void_p(ws.data_ptr()),
             ws.numel(), _stream(), ctypes.byref(fused), None), 'xrt_hip_reflect_screen_f64_dev')
-    lb._d['theta'] = theta
-    self._adopt((lb, gb), parent)
+    if local:
+        lb._d['theta'] = theta
+    self._adopt((lb, gb) if local else (gb,), parent)
     rs.inherit_scalars(image, parent)
     return lb, gb, image, bool(fused.value & 1)
 
@@ -1886,9 +1990,19 @@ class DCM(OE):
             fused = self._run_double(p1, p2, fromVacuum1, fromVacuum2, beam, _timing, out)
             if fused is not None:
                 return fused
-        lo1, between, _ = self._run_pass(p1, self.material, fromVacuum1, beam, beam)
-        lo2, gb2, _ = self._run_pass(p2, self.material2, fromVacuum2, between, beam)
-        return gb2, lo1, lo2
+        def both(beam, local=True):
+            lo1, between, _ = self._run_pass(p1, self.material, fromVacuum1, beam, beam,
+                                             local=local)
+            lo2, gb2, _ = self._run_pass(p2, self.material2, fromVacuum2, between, beam,
+                                         local=local)
+            return gb2, lo1, lo2
+        if out is None and _timing is None and \
+                _locals_on_demand(self, self.material, self.material2):
+            # (a plate: two surfaces, two passes) the global beam now, the two local beams when
+            # somebody looks at them
+            later = _LocalsOnDemand(self, beam, 2, lambda was: both(was)[1:])
+            return (both(beam, local=False)[0],) + tuple(later.locals)
+        return both(beam)
 
     def _run_double(self, p1, p2, fromVacuum1, fromVacuum2, beam, timing=None, out=None):
         """Both crystals in one pass over the beam (xrt_hip_double_reflect_f64_dev) when

@@ -515,6 +515,16 @@ class _DeferredShine(object):
             self.launch_into(bo)
             self.beam._adopt_arrays(bo)
 
+    def rays_again(self):
+        """-> the same rays in a new beam (for whoever has to run a pass on them again: this
+        beam itself stays as it is, asked for or not)."""
+        if self.state == 'done':
+            return self.beam
+        bo = Beam.empty_on_device(self.n, self.device, self.amplitudes)
+        self.launch_into(bo)
+        inherit_scalars(bo, self.beam)
+        return bo
+
     def adopt(self, bo):
         """*bo* holds the rays already (somebody else ran the generator into it)."""
         _PENDING.discard(self)
