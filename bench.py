@@ -1000,7 +1000,8 @@ def bench_balder(nrays, runs=5):
             'rays': nrays, 'seconds': sec, 'seconds_every_beam_written': sec_all,
             'on_demand': 'the chain hands the global beam from element to element and shows the '
                          'two screens: the local beams of the mirrors and of the filter (308 -> '
-                         '200 B per ray and surface) and the beams in the frames of the four '
+                         '200 B per ray and surface), of the two crystals (416 -> 200 B per '
+                         'ray) and the beams in the frames of the four '
                          'apertures (200 -> 52 B) are not written; each is made, by the same '
                          'kernels on the same input, the first time somebody looks at it',
             'rays_per_s': nrays / sec,

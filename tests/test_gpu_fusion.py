@@ -127,7 +127,7 @@ def test_elements_whose_kernels_do_not_carry_a_screen():
     gb0, lb0, img0 = eager(xt, scr, beam)
     gb, lb = xt.reflect(beam)
     img = scr.expose(gb)
-    assert gb.__dict__['_op'].state == 'done'
+    assert gb.__dict__['_filled'] and not lb.__dict__['_filled']
     same(img, img0, 'image')
     same(gb, gb0, 'global')
     same(lb, lb0, 'local', extra=('theta',))
@@ -539,3 +539,43 @@ def test_plate_local_beams_made_on_demand(amplitudes):
     assert type(a2) is rs.Beam
     same(a2, a0, 'first local, at once', extra=('theta',))
     same(g2, g0, 'global, at once')
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+def test_dcm_local_beams_made_on_demand(amplitudes):
+    """The fused pass over both crystals with the global beam alone (xrt_hip_double_reflect_f64_dev
+    with out_local1 = out_local2 = NULL: 200 instead of 416 B per ray), then the two local beams
+    by the pass run again; a single crystal likewise."""
+    bl = raycing.BeamLine()
+    dcm = workloads.cfg3_dcm(bl)
+    beam = workloads.synthetic_rays(80000, 11, sa=1e-4, E=(8995., 9005.), amplitudes=amplitudes)
+    beam.state[::37] = -2
+    beam.x[::29] *= 400.
+    roe.fuseConsumers = False
+    try:
+        g0, a0, b0 = dcm.double_reflect(rs.Beam(copyFrom=beam))
+    finally:
+        roe.fuseConsumers = True
+    assert (g0.state == 1).sum() > 1000 and (g0.state != 1).sum() > 1000
+    b1 = rs.Beam(copyFrom=beam)
+    g1, a1, b1l = dcm.double_reflect(b1)
+    assert type(a1) is rs.LazyBeam and not a1.__dict__['_filled']
+    same(g1, g0, 'global')
+    b1.state[:] = 3                                  # (the input's states afterwards)
+    same(a1, a0, 'first crystal', extra=('theta',))
+    assert b1l.__dict__['_filled'] and dcm.__dict__['_local_beams_wanted']
+    same(b1l, b0, 'second crystal', extra=('theta',))
+    g2, a2, b2 = dcm.double_reflect(rs.Beam(copyFrom=beam))
+    assert type(a2) is rs.Beam
+    same(g2, g0, 'global, at once')
+    same(b2, b0, 'second crystal, at once', extra=('theta',))
+    del dcm.__dict__['_local_beams_wanted']
+    os.environ['XRT_HIP_DCM_TWO_PASSES'] = '1'       # ... and as two single-crystal passes
+    try:
+        g3, a3, b3 = dcm.double_reflect(rs.Beam(copyFrom=beam))
+        assert type(a3) is rs.LazyBeam
+        same(g3, g0, 'global, two passes')
+        same(a3, a0, 'first crystal, two passes', extra=('theta',))
+        same(b3, b0, 'second crystal, two passes', extra=('theta',))
+    finally:
+        del os.environ['XRT_HIP_DCM_TWO_PASSES']

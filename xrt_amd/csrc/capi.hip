@@ -445,9 +445,9 @@ static int reflect_pass_impl(const xrt_hip_pass* pass, const xrt_hip_material* m
   if (!out_local) {
     // (the layered kernels -- Multilayer AND Coated -- are compiled without the test for a
     // missing local beam, reflect_impl.h:optional_local)
-    if (material->kind == XRT_HIP_MAT_CRYSTAL || material->kind == XRT_HIP_MAT_MULTILAYER)
-      return fail(XRT_HIP_ERR_ARG, "passes of crystals and layered materials keep their local "
-                                   "beam (out_local NULL)");
+    if (material->kind == XRT_HIP_MAT_MULTILAYER)
+      return fail(XRT_HIP_ERR_ARG, "passes of layered materials keep their local beam "
+                                   "(out_local NULL)");
     out_local = &no_local;
   } else if ((rc = check_beam(out_local, "out_local", n, amp))) {
     return rc;
@@ -584,15 +584,27 @@ int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_mate
   if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative ray count");
   const bool amp = in->Es_ri != nullptr || in->Ep_ri != nullptr;
   if ((rc = check_beam(in, "in", n, amp))) return rc;
-  if ((rc = check_beam(out_local1, "out_local1", n, amp))) return rc;
-  if ((rc = check_beam(out_local2, "out_local2", n, amp))) return rc;
+  // out_local1 and out_local2 NULL (both or neither): the beams on the two crystals are not
+  // wanted -- 200 instead of 416 B per ray
+  if ((out_local1 == nullptr) != (out_local2 == nullptr))
+    return fail(XRT_HIP_ERR_ARG, "double_reflect: both local beams or neither");
+  xrt_hip_beam no_local;
+  memset(&no_local, 0, sizeof(no_local));
+  no_local.n = n;
+  if (!out_local1) {
+    out_local1 = out_local2 = &no_local;
+    theta1 = theta2 = nullptr;
+  } else {
+    if ((rc = check_beam(out_local1, "out_local1", n, amp))) return rc;
+    if ((rc = check_beam(out_local2, "out_local2", n, amp))) return rc;
+  }
   if ((rc = check_beam(out_global, "out_global", n, amp))) return rc;
   if (n == 0) return XRT_HIP_OK;
   if (!workspace || workspace_bytes < xrt::reflect_workspace_bytes(n))
     return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes,
                 xrt::reflect_workspace_bytes(n));
   for (const xrt_hip_beam* o : {out_local1, out_local2, out_global})
-    if (o->x == in->x || o->state == in->state)
+    if (o->x && (o->x == in->x || o->state == in->state))
       return fail(XRT_HIP_ERR_ARG, "double_reflect: outputs must not share arrays with the input");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipEvent_t e0 = nullptr, e1 = nullptr, k0 = nullptr, k1 = nullptr;

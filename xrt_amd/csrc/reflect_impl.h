@@ -404,13 +404,14 @@ __device__ __forceinline__ double pinned(double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 // passes whose local beam may be left out (xrt_hip_reflect_pass_f64_dev with out_local NULL):
-// not the crystal / layered kernels
+// not the layered kernels (since round 5 the crystal kernels, the fused DCM among them, take the
+// test: a scalar compare per store)
 template <class K>
 __device__ __forceinline__ constexpr bool optional_local() {
 #ifdef XRT_NO_OPTIONAL_LOCAL      /* A/B: what the test costs the hot kernel */
   return false;
 #else
-  return K::MK != XRT_HIP_MAT_CRYSTAL && K::MK != XRT_HIP_MAT_MULTILAYER;
+  return K::MK != XRT_HIP_MAT_MULTILAYER;
 #endif
 }
 template <class K>
@@ -4214,8 +4215,9 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
       }
     } else if (live) {
       load_rec(v, in, i, has_amp);
-      store_rec(lo1, i, v, P1.zero_local_not_entering ? 0 : st0, has_amp,
-                P1.zero_local_not_entering != 0);
+      if (lo1.x)
+        store_rec(lo1, i, v, P1.zero_local_not_entering ? 0 : st0, has_amp,
+                  P1.zero_local_not_entering != 0);
       if (theta1) theta1[i] = 0.;
       v.st = P1.force_lost_out ? P1.lost_num : st0;
     }
@@ -4253,8 +4255,9 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
     } else if (live) {
       // dcm.py:298-303 zeroes the local record of rays that never reached the crystal;
       // the global beam gets the ORIGINAL ray back (dcm.py:330-335)
-      store_rec(lo2, i, v, P2.zero_local_not_entering ? 0 : v.st, has_amp,
-                P2.zero_local_not_entering != 0);
+      if (lo2.x)
+        store_rec(lo2, i, v, P2.zero_local_not_entering ? 0 : v.st, has_amp,
+                  P2.zero_local_not_entering != 0);
       if (theta2) theta2[i] = 0.;
       copy_ray(gb2, in, i, P2.force_lost_out ? P2.lost_num : v.st, has_amp, false);
     }
