@@ -946,7 +946,7 @@ def bench_undulator(with_cpu=True):
     return res
 
 
-def bench_balder(nrays, runs=5):
+def bench_balder(nrays, runs=5, both=True):
     """A whole ray-tracing beamline, element after element on device-resident beams: the
     reference's example Balder (examples/withRaycing/02_Balder_BL) from the front-end mask to
     the sample -- diamond filter (two surfaces), bent collimating mirror, DCM Si(111) (two
@@ -983,7 +983,7 @@ def bench_balder(nrays, runs=5):
                      else (image.state == 1).sum()) / nrays)
     # ... and with every beam of every element written, looked at or not (rounds 1-4)
     from xrt_amd.backends.raycing import oes as roe
-    roe.fuseConsumers = False
+    roe.fuseConsumers = not both
     try:
         fresh = [rs.Beam(copyFrom=beam) for _ in range(runs + 1)]
         workloads.balder_trace(optics, fresh[0])

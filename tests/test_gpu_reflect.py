@@ -215,17 +215,23 @@ def test_grating_efficiency_file_matches_reference_golden():
 
 
 def test_energy_outside_the_efficiency_file_is_refused():
-    """The reference raises ValueError (material.py:399-407); so does the product, before
-    the launch."""
+    """The reference raises ValueError (material.py:399-407) for a ray that HITS the grating
+    with an energy outside the file; so does the product, right after the launch."""
     g = pc.load('g2_grating_efffile')
     oe = pc.product_oe('g2_grating_efffile', g)
     beam = pc.product_beam(g)
-    beam.E[100] = 400.
+    hit = np.flatnonzero(g['lb_state'] == 1)[50]
+    beam.E[hit] = 400.
     np.random.seed(int(g['np_seed']))
     with pytest.raises(ValueError, match='out of the efficiency table range'):
         oe.reflect(beam)
-    beam.E[100] = 280.
-    beam.E[4] = 400.          # a ray that does not enter (state -4) is not looked at
+    beam.E[hit] = g['in_E'][hit]
+    # a ray that does not enter (state -4), and one that enters but misses the grating, are
+    # not looked at (the reference's `good`)
+    beam.E[4] = 400.
+    missed = np.flatnonzero((g['in_state'] > 0) & (g['lb_state'] != 1))
+    if len(missed):
+        beam.E[missed[0]] = 400.
     oe.reflect(beam)
 
 

@@ -2,7 +2,7 @@
 several beam sizes: ms per iteration, eager and graph=True, with the options named in the
 environment (XRT_HIP_NO_FUSE=1: no screen in the tail of the pass; XRT_HIP_HIST_NO_SMALL=1: the
 three-kernel histogram route also for small beams).
-    python tools/probe_e2e_sizes.py [iterations]"""
+    python tools/probe_e2e_sizes.py [iterations [rays ...]]"""
 import sys
 import time
 
@@ -12,7 +12,8 @@ from xrt_amd import runner, workloads
 from xrt_amd.backends.raycing import run as rr
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-for n in (2000, 100000, 1000000):
+sizes = [int(float(a)) for a in sys.argv[2:]] or [2000, 100000, 1000000]
+for n in sizes:
     bl, run_process, make_plot = workloads.e2e_beamline(n)
     rr.run_process = run_process
     row = []

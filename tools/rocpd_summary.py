@@ -17,7 +17,9 @@ import os
 import sqlite3
 import sys
 
-OURS = ('reflect_fused_xtal', 'reflect_fused_dcm', 'reflect_dcm_exact', 'reflect_decide_dcm',
+OURS = ('reflect_fused_gen_scr', 'reflect_fused_scr', 'reflect_decide_opt_gen',
+        'reflect_redo_verdict', 'geosource_shine_if_kernel', 'screen_expose_if_kernel',
+        'reflect_multi', 'multi_to_global_kernel', 'plot_hist_small', 'reflect_fused_xtal', 'reflect_fused_dcm', 'reflect_dcm_exact', 'reflect_decide_dcm',
         'reflect_decide_opt', 'reflect_exact', 'reflect_fused', 'reflect_init',
         'screen_expose_kernel', 'kirchhoff_stream', 'kirchhoff_scan', 'kirchhoff_pack',
         'kirchhoff_finalize', 'und_imap', 'und_sum', 'und_pack', 'aperture_propagate_kernel',

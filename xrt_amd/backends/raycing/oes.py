@@ -492,14 +492,19 @@ class OE(object):
             b.parentId = self.uuid
 
     @staticmethod
-    def _check_efficiency_range(p, beam, dev):
-        """The reference refuses energies outside the efficiency table (material.py:399-407);
-        so does this, before the launch, for the rays that enter the pass (one reduction on
-        the device and one number read back)."""
-        E, state = beam.dev('E', dev), beam.dev('state', dev)
-        enters = state > 0 if p.good_mode == 0 else (state == 1) | (state == 2)
+    def _check_efficiency_range(p, beam, made, dev):
+        """The reference refuses energies outside the efficiency table (material.py:399-407)
+        among the rays that HIT the grating (its `good`: state 1 in the beam the pass *made*);
+        so does this, right after the launch (one reduction on the device and one number read
+        back). Not while a HIP graph is recorded or replayed: the eager iteration before the
+        recording checks, the replays interpolate with the table's end values."""
+        E = beam.dev('E', dev)
         Emin, Emax = p._eff_range
-        bad = enters & ((E < Emin) | (E > Emax))
+        if made is None:        # (multiple_reflect: before its loop, the rays that enter it)
+            hit = beam.dev('state', dev) > 0
+        else:
+            hit = made.dev('state', dev) == 1
+        bad = hit & ((E < Emin) | (E > Emax))
         if bool(bad.any()):
             raise ValueError(
                 'E={0} is out of the efficiency table range [{1}, {2}]!!! Use another '
@@ -519,9 +524,6 @@ class OE(object):
                 if b is not None and type(b) is not rs.LazyBeam:
                     rs.flush_pending(b)
         ms = self._material_struct(material, fromVacuum, dev, beam_in)
-        if p.eff_tab_n > 0 and graphs.capturing() is None:
-            # (recorded into a HIP graph: checked by the eager iteration before it)
-            self._check_efficiency_range(p, beam_in, dev)
         s_in = beam_in.to_struct(dev)
         s_re = s_in if restore is beam_in else restore.to_struct(dev)
         n = beam_in.nrays
@@ -550,6 +552,9 @@ class OE(object):
         if local and lb._d.get('theta') is not theta:
             lb._h.pop('theta', None)
             lb._d['theta'] = theta
+        if p.eff_tab_n > 0 and graphs.capturing() is None:
+            # (recorded into a HIP graph: checked by the eager iteration before it)
+            self._check_efficiency_range(p, beam_in, lb if local else vb, dev)
         self._adopt((lb, vb) if local else (vb,), beam_in)
         report = None
         if want_info:
@@ -1143,7 +1148,7 @@ def _multiple_reflect(self, beam=None, maxReflections=1000, needElevationMap=Fal
     first.need_elevation_map = later.need_elevation_map = int(bool(needElevationMap))
     for p in (first, later):
         if p.eff_tab_n > 0:
-            self._check_efficiency_range(p, beam, dev)
+            self._check_efficiency_range(p, beam, None, dev)
     ms = self._material_struct(self.material, True, dev, beam)
     amplitudes = beam.has_amplitudes()
     fp = _Footprints(n, dev, amplitudes, needElevationMap, bool(self.isParametric),

@@ -721,11 +721,14 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     if (evk0) (void)hipEventRecord(evk0, st);
     launched &= tu_hot_fused_gen_scr(spec, FL);
     if (evk1) (void)hipEventRecord(evk1, st);
-    int* redo_flag = reinterpret_cast<int*>(L.ht + 16);
-    hipLaunchKernelGGL(reflect_redo_verdict, dim3(1), dim3(256), 0, st, g, opt, redo_flag);
-    const hipError_t ge = geosource_shine_if_launch(redo_flag, *src, in, st);
-    if (ge != hipSuccess) return ge;
-    launch_exact();
+    // verdict, and only if it was contradicted: the source's beam, the exact sequence, the image
+    tu_exact0_redo_scr(XL, *scr, *sb, src);
+  } else if (fuse_screen) {
+    hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, g);
+    if (evk0) (void)hipEventRecord(evk0, st);
+    launch_fused(0);
+    if (evk1) (void)hipEventRecord(evk1, st);
+    tu_exact0_redo_scr(XL, *scr, *sb, nullptr);
   } else if (optimistic) {
     // assumptions from the head of the beam -> the pass on them, every ray checking ->
     // reflect_exact: folds the reports, returns at once unless one was contradicted
@@ -754,12 +757,11 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     if (evk1) (void)hipEventRecord(evk1, st);
   }
   if (scr && sb) {
-    hipError_t se;
-    if (fuse_screen)      // (only if the exact sequence redid the pass: from the real vb)
-      se = screen_expose_if_launch(&g->redo, *scr, vb, *sb, st);
-    else
-      se = screen_expose_launch(*scr, vb, *sb, st);
-    if (se != hipSuccess) return se;
+    // (fused: the redo, if any, has made the image from the real vb -- reflect_redo_scr)
+    if (!fuse_screen) {
+      const hipError_t se = screen_expose_launch(*scr, vb, *sb, st);
+      if (se != hipSuccess) return se;
+    }
     if (fused) *fused = (fuse_screen ? 1 : 0) | (fuse_source ? 2 : 0);
   }
   if (ev1) (void)hipEventRecord(ev1, st);

@@ -9,6 +9,18 @@ bool tu_exact0(int spec, const ExactLaunch& L) {
   return true;
 }
 
+// (the lean kernels are family 0: Generic0 redoes their passes)
+void tu_exact0_redo_scr(const ExactLaunch& L, const xrt_hip_screen& S, const xrt_hip_beam& sb,
+                        const xrt_hip_geosource* src) {
+  const xrt_hip_geosource none{};
+  if (src)
+    hipLaunchKernelGGL((reflect_redo_scr<Generic0, true>), L.grid, L.block, 0, L.st, *L.P, *L.M,
+                       *src, *L.in, *L.restore, *L.lb, *L.vb, L.A, S, sb);
+  else
+    hipLaunchKernelGGL((reflect_redo_scr<Generic0, false>), L.grid, L.block, 0, L.st, *L.P, *L.M,
+                       none, *L.in, *L.restore, *L.lb, *L.vb, L.A, S, sb);
+}
+
 void tu_exact0_dcm(const DcmLaunch& L) {
   hipLaunchKernelGGL(reflect_dcm_exact<Generic0>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2,
                      *L.M2, *L.in, *L.lo1, *L.lo2, *L.gb2, L.A1, L.A2);

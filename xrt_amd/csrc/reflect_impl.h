@@ -1490,23 +1490,6 @@ __device__ __forceinline__ bool fold_opt(const OptStat* slots, double* lds_d, do
   return viol != 0. || (m2 > m1 * 20.) != assumed_brent;
 }
 
-#ifdef XRT_REFLECT_MAIN_TU
-// Will reflect_exact redo the pass? The verdict its gate is going to reach (the same fold of the
-// same reports), one block, ahead of it: a pass that made its rays in registers has to write the
-// source's beam out first (geosource_shine_if_kernel, source.hip).
-__global__ __launch_bounds__(256) void reflect_redo_verdict(const GStat* g, const OptStat* slots,
-                                                           int* flag) {
-  __shared__ double lds_d[REFLECT_MAX_WAVES];
-  bool full;
-  if (g->optimistic) {
-    double m1, m2;
-    full = fold_opt(slots, lds_d, m1, m2, g->optimistic == 2);
-  } else {
-    full = g->redo != 0;
-  }
-  if (threadIdx.x == 0) *flag = full ? 1 : 0;
-}
-#endif
 
 struct LocalRay {
   double x, y, z, a, b, c;
@@ -3662,7 +3645,7 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
 // The same pass with a screen in its tail: OE.reflect whose global beam goes straight into
 // Screen.expose. `vb` with null arrays: the global beam itself is not wanted (nothing but the
 // screen reads it). The optimistic form only (mode 0 / 2): a contradicted pass is redone by
-// reflect_exact into the real `vb`, and screen_expose_if_kernel makes the image from that.
+// reflect_redo_scr into the real `vb`, which then makes the image from that.
 template <class K, int mode>
 __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_scr(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
@@ -4040,6 +4023,44 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_exact(
   if (!full && !mixed) return;
   unsigned phase = 0;
   exact_pass<K>(P, M, in, restore, lb, vb, A, full, phase);
+}
+
+// reflect_exact behind a pass that had a screen in its tail (and, SRC, the source in its head):
+// ONE launch that returns at once in the usual case -- the verdict, the source's beam written
+// out for the redo, the exact sequence and the image from the real global beam were four
+// launches of ~5 us each, a third of a 1e5-ray iteration. Same device functions, same bits.
+template <class K, bool SRC>
+__global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_redo_scr(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_geosource G, xrt_hip_beam in, xrt_hip_beam restore,
+    xrt_hip_beam lb, xrt_hip_beam vb, PassAux A, xrt_hip_screen S, xrt_hip_beam sb) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  const bool full = exact_gate(A.g, reinterpret_cast<const OptStat*>(A.part), lds_d,
+                               P.method_hint);
+  if (!full) return;        // (the lean kernels: no crystal tail)
+  unsigned phase = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (SRC) {
+    // the pass made its rays in registers: now the beam itself, for every block to read
+    const bool amp = in.Es_ri != nullptr;
+    for (int64_t i = first; i < in.n; i += stride)
+      gen::store_gen_ray(in, i, gen::make_ray(G, gen::call_of(G), i, amp), G.state, amp);
+    grid_barrier(A.g, phase);
+  }
+  exact_pass<K>(P, M, in, restore, lb, vb, A, true, phase);
+  grid_barrier(A.g, phase);
+  const bool has_amp = vb.Es_ri != nullptr;
+  for (int64_t i = first; i < vb.n; i += stride) {
+    const double2 js = reinterpret_cast<const double2*>(vb.Jsp_ri)[i];
+    double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+    if (has_amp) {
+      es = reinterpret_cast<const double2*>(vb.Es_ri)[i];
+      ep = reinterpret_cast<const double2*>(vb.Ep_ri)[i];
+    }
+    expose_flat_store(S, sb, i, vb.x[i], vb.y[i], vb.z[i], vb.a[i], vb.b[i], vb.c[i], vb.path[i],
+                      vb.E[i], vb.Jss[i], vb.Jpp[i], js.x, js.y, vb.state[i], es.x, es.y, ep.x,
+                      ep.y, has_amp);
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -151,6 +151,8 @@ bool tu_figured_fused(int spec, int mode, const FusedLaunch& L);    // reflect_f
 bool tu_figured_exact0(int spec, const ExactLaunch& L);             // reflect_figured_x0.hip
 bool tu_figured_exact1(int spec, const ExactLaunch& L);             // reflect_figured_x1.hip
 bool tu_exact0(int spec, const ExactLaunch& L);                     // reflect_exact0.hip
+void tu_exact0_redo_scr(const ExactLaunch& L, const xrt_hip_screen& S, const xrt_hip_beam& sb,
+                        const xrt_hip_geosource* src);
 void tu_exact0_dcm(const DcmLaunch& L);
 bool tu_exact1(int spec, const ExactLaunch& L);                     // reflect_exact1.hip
 bool tu_exact2(int spec, const ExactLaunch& L);                     // reflect_exact2.hip

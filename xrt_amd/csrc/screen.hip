@@ -80,39 +80,6 @@ __global__ __launch_bounds__(256) void screen_expose_kernel(xrt_hip_screen S, xr
                     has_amp);
 }
 
-// The same on a beam that a ray pass left out of the fused form (xrt_hip_reflect_screen_f64_dev:
-// the optimistic pass with the screen in its tail was contradicted and the exact sequence wrote
-// the global beam instead): runs only if the pass record says so.
-__global__ __launch_bounds__(256) void screen_expose_if_kernel(const int* flag, xrt_hip_screen S,
-                                                              xrt_hip_beam in, xrt_hip_beam out) {
-  if (!*flag) return;
-  // (a small grid that strides: the launch returns at once in the usual case -- one block per
-  // 256 rays took 11 us to start and end 39 000 blocks that had nothing to do)
-  const bool has_amp = in.Es_ri != nullptr;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < in.n; i += stride) {
-    const double2 js = reinterpret_cast<const double2*>(in.Jsp_ri)[i];
-    double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
-    if (has_amp) {
-      es = reinterpret_cast<const double2*>(in.Es_ri)[i];
-      ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
-    }
-    expose_flat_store(S, out, i, in.x[i], in.y[i], in.z[i], in.a[i], in.b[i], in.c[i],
-                      in.path[i], in.E[i], in.Jss[i], in.Jpp[i], js.x, js.y, in.state[i], es.x,
-                      es.y, ep.x, ep.y, has_amp);
-  }
-}
-
-hipError_t screen_expose_if_launch(const int* flag, const xrt_hip_screen& S,
-                                   const xrt_hip_beam& in, const xrt_hip_beam& out,
-                                   hipStream_t st) {
-  if (in.n <= 0) return hipSuccess;
-  const int64_t want = (in.n + 255) / 256;
-  hipLaunchKernelGGL(screen_expose_if_kernel, dim3((unsigned)(want < 2048 ? want : 2048)),
-                     dim3(256), 0, st, flag, S, in, out);
-  return hipGetLastError();
-}
-
 hipError_t screen_expose_launch(const xrt_hip_screen& S, const xrt_hip_beam& in,
                                 const xrt_hip_beam& out, hipStream_t st) {
   if (in.n <= 0) return hipSuccess;

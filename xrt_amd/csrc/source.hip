@@ -25,28 +25,6 @@ __global__ __launch_bounds__(256) void geosource_shine_kernel(xrt_hip_geosource 
   store_gen_ray(out, i, make_ray(G, call_of(G), i, amp), G.state, amp);
 }
 
-// The beam of a source whose rays an element's pass made in its own registers, written out after
-// all (the pass has to be redone exactly and reads it): only if *flag says so. A small grid that
-// strides, so that the usual launch ends at once.
-__global__ __launch_bounds__(256) void geosource_shine_if_kernel(const int* flag,
-                                                                xrt_hip_geosource G,
-                                                                xrt_hip_beam out) {
-  if (!*flag) return;
-  const bool amp = out.Es_ri != nullptr;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < out.n; i += stride)
-    store_gen_ray(out, i, make_ray(G, call_of(G), i, amp), G.state, amp);
-}
-
-hipError_t geosource_shine_if_launch(const int* flag, const xrt_hip_geosource& G,
-                                     const xrt_hip_beam& out, hipStream_t st) {
-  if (out.n <= 0) return hipSuccess;
-  const int64_t want = (out.n + 255) / 256;
-  hipLaunchKernelGGL(geosource_shine_if_kernel, dim3((unsigned)(want < 2048 ? want : 2048)),
-                     dim3(256), 0, st, flag, G, out);
-  return hipGetLastError();
-}
-
 __global__ __launch_bounds__(256) void geosource_probe_kernel(xrt_hip_geosource G, int64_t n,
                                                              int32_t* flag) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
