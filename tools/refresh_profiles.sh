@@ -49,7 +49,7 @@ PYTHONPATH=.:tests timeout 300 python tools/probe_multi.py 1e7 3 2>&1 | grep -v 
 for env in "" "XRT_HIP_HIST_NO_SMALL=1" "XRT_HIP_NO_FUSE=1"; do echo "== [$env]"; env PYTHONPATH=. $env python tools/probe_e2e_sizes.py 200 2>&1 | grep rays; done > profiles/r${RND}_e2e_sizes.txt
 # the kernels of the Balder chain (bench.py balder leg) in launch order, one pass of the beam
 ( cd /tmp && rm -rf /tmp/pb && rocprofv3 --kernel-trace --stats -d /tmp/pb -o pb -- python $GRAFT_REPO_ROOT/tools/probe_balder.py > /tmp/pb.log 2>&1 )
-{ tail -1 /tmp/pb.log | cut -c1-400; python tools/prof_sequence.py /tmp/pb 30; } > profiles/r${RND}_balder_kernels.txt 2>&1
+{ grep '^{' /tmp/pb.log | cut -c1-400; python tools/prof_sequence.py /tmp/pb 30; } > profiles/r${RND}_balder_kernels.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -DNOUT=40 -DBLOCK=256 tools/probes/probe_occupancy.hip -o /tmp/po40 2>/dev/null && \
   timeout 300 /tmp/po40 > profiles/r${RND}_probe_occupancy_dcm_shape.txt 2>&1
 cp profiles/r${RND}_*.txt profiles/hist_traffic.json $O/summaries/ 2>/dev/null
