@@ -579,3 +579,40 @@ def test_dcm_local_beams_made_on_demand(amplitudes):
         same(b3, b0, 'second crystal, two passes', extra=('theta',))
     finally:
         del os.environ['XRT_HIP_DCM_TWO_PASSES']
+
+
+def test_beams_of_a_recorded_iteration_looked_at_after_its_replays():
+    """Inside a HIP graph the source is in the head of the pass as well (the graph moves the call
+    cell as its last node); the beams that were left out, asked for after the replays, are the
+    ones of the last replay."""
+    from xrt_amd import graphs
+
+    def iteration(bl, amp):
+        src = bl.source.shine(withAmplitudes=amp)
+        gb, lb = bl.mirror.reflect(src)
+        img = bl.screen.expose(gb)
+        rs.flush_pending()
+        return src, gb, lb, img
+    bl0, amp = source_scene(n=20000)
+    roe.fuseConsumers = False
+    try:
+        for _ in range(4):
+            src0, gb0, lb0, img0 = iteration(bl0, amp)
+    finally:
+        roe.fuseConsumers = True
+    bl, amp = source_scene(n=20000)
+    iteration(bl, amp)                           # (eagerly once: cells and workspaces exist)
+    rec = graphs.IterationGraph(lambda: iteration(bl, amp))
+    src, gb, lb, img = rec.result
+    assert src.__dict__['_op'].state == 'inflight' and not lb.__dict__['_filled']
+    for _ in range(3):
+        rec.replay()
+    torch.cuda.synchronize()
+    assert bl.source._calls == bl0.source._calls == 4
+    same(img, img0, 'image of the last replay')
+    same(lb, lb0, 'local beam, made afterwards', extra=('theta',))
+    same(src, src0, 'source beam, made afterwards')
+    same(gb, gb0, 'global beam, made afterwards')
+    rec.close()
+    nxt0, nxt = bl0.source.shine(), bl.source.shine()       # ... and the sequence goes on
+    same(nxt, nxt0, 'next shine')

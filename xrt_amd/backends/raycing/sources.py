@@ -481,9 +481,10 @@ class _DeferredShine(object):
     pending -> inflight (an element's pass made the rays in its registers,
     xrt_hip_shine_reflect_screen_f64_dev; the beam itself can still be made on demand) -> done."""
 
-    def __init__(self, source, g, nrays, amplitudes, device, scalars):
+    def __init__(self, source, g, nrays, amplitudes, device, scalars, rec=None):
         self.source, self.g, self.n, self.amplitudes, self.device = \
             source, g, int(nrays), bool(amplitudes), device
+        self.rec = rec               # the HIP graph this shine is recorded into, if any
         self.state = 'pending'
         self.beam = LazyBeam(self, 'beam')
         for key, value in scalars.items():
@@ -495,10 +496,16 @@ class _DeferredShine(object):
 
     def launch_into(self, bo):
         import ctypes
-        from ... import _lib
+        from ... import _lib, graphs
+        g = self.g
+        if self.rec is not None and graphs.capturing() is not self.rec:
+            # recorded into a graph and asked for after its replays: the graph's cell has moved
+            # on to the next replay, these are the rays of the last one
+            g = type(g).from_buffer_copy(g)
+            g.call = (g.call - self.rec.pending_calls.get(self.source, 0)) & 0xffffffff
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().xrt_hip_geosource_shine_f64_dev(
-                ctypes.byref(self.g), ctypes.byref(bo.to_struct(self.device)),
+                ctypes.byref(g), ctypes.byref(bo.to_struct(self.device)),
                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                 'xrt_hip_geosource_shine_f64_dev')
 
@@ -940,14 +947,16 @@ class GeometricSource(object):
             else:
                 self.__dict__.setdefault('_cell_lag', {})[str(dev)] = 0   # (absorbed below)
                 # recorded into a HIP graph: replay k must draw what the k-th eager call would
-                # have -- the kernel adds a device cell, incremented by the graph itself, to
-                # the call number of the record (this call's number less the cell's value now)
-                # (the cell is incremented after EVERY recorded shine of this source, so one
-                # record value serves all of them: the j-th shine of replay r finds the cell at
-                # value + r * shines + j and must draw call _calls + r * shines + j)
+                # have -- the kernel adds a device cell to the call number of the record. The
+                # graph increments the cell ONCE, as its last node, by the number of shines it
+                # holds: within an iteration the cell stands still (the rays of a shine are the
+                # same wherever they are made -- its own launch, the head of an element's pass,
+                # a redo), and the j-th shine of replay r finds the cell at value + r * shines and
+                # draws call _calls + r * shines + j
                 cell, value = self._replay_cell(dev)
-                rec.pending_calls[self] = rec.pending_calls.get(self, 0) + 1
-                call = (self._calls - value) & 0xffffffff
+                j = rec.pending_calls.get(self, 0)
+                rec.pending_calls[self] = j + 1
+                call = (self._calls - value + j) & 0xffffffff
         g, reach2 = self.device_spec(toGlobal, call)
         if rec is not None:
             g.call_dev = cell.data_ptr()
@@ -963,7 +972,15 @@ class GeometricSource(object):
                 'xrt_hip_geosource_probe_f64_dev')
             g.slopes = int(flag.item())
         amplitudes = withAmplitudes or self.uniformRayDensity
-        if rec is None and reach2 <= 1 and accuBeam is None and not self.uniformRayDensity:
+        if rec is not None and rec.pending_calls[self] == 1:
+            rec.before_end.append(lambda: cell.add_(rec.pending_calls[self]))
+
+            def count():
+                with self._call_lock:
+                    self._calls += rec.pending_calls[self]
+                    self._replay_cells[str(dev)][1] += rec.pending_calls[self]
+            rec.after_replay.append(count)
+        if reach2 <= 1 and accuBeam is None and not self.uniformRayDensity:
             from . import oes as _oes
             if _oes.fuseConsumers and not self.__dict__.get('_beam_wanted'):
                 # not launched yet: an element's pass may make these rays in its own registers
@@ -976,19 +993,11 @@ class GeometricSource(object):
                     if total > 0:
                         scalars.update(sourceWeight=self.totalFlux / total, seeded=self.nrays,
                                        seededI=1., accepted=1., acceptedE=1.)
-                return _DeferredShine(self, g, self.nrays, amplitudes, dev, scalars).beam
+                return _DeferredShine(self, g, self.nrays, amplitudes, dev, scalars, rec).beam
         bo = Beam.empty_on_device(self.nrays, dev, amplitudes)
         _lib.check(lib.xrt_hip_geosource_shine_f64_dev(
             ctypes.byref(g), ctypes.byref(bo.to_struct(dev)), stream),
             'xrt_hip_geosource_shine_f64_dev')
-        if rec is not None:
-            cell.add_(1)                 # (recorded: after the generator ran)
-            if rec.pending_calls[self] == 1:
-                def count():
-                    with self._call_lock:
-                        self._calls += rec.pending_calls[self]
-                        self._replay_cells[str(dev)][1] += rec.pending_calls[self]
-                rec.after_replay.append(count)
         if np.isscalar(self.totalFlux) and self.totalFlux > 0:      # make_flux_normalization
             if self.uniformRayDensity:
                 graphs.refuse('totalFlux of a source with uniformRayDensity (a sum read back)')

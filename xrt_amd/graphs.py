@@ -12,8 +12,10 @@ numbers (host ray generators, random diffraction orders, wave sampling), uploads
 arrays, read-backs that steer the Python code (automatic plot limits). Uploads and read-backs
 fail inside a capture by themselves (HIP refuses them on a capturing stream); the sites that
 would merely repeat a host decision ask :func:`refuse`. The device ray generator takes its call
-number from a device cell that the graph increments (``xrt_hip_geosource.call_dev``), so that
-replay k draws the rays the k-th eager call would have drawn.
+number from a device cell that the graph increments as its last node
+(``xrt_hip_geosource.call_dev``), so that replay k draws the rays the k-th eager call would have
+drawn -- wherever in the iteration the rays are made (the generator's own launch, the head of an
+element's pass, a redo).
 
 Host-side counters of an iteration (rays seen by a plot, calls of a source) are not advanced
 while recording; they are handed to :func:`per_iteration` and run after every replay.
@@ -59,6 +61,7 @@ class IterationGraph(object):
 
     def __init__(self, fn):
         self.after_replay = []
+        self.before_end = []         # recorded after fn(): the last nodes of the graph
         self.pending_calls = {}      # source -> shine() calls recorded so far
         self.graph = torch.cuda.CUDAGraph()
         self.stream = torch.cuda.Stream()
@@ -72,6 +75,8 @@ class IterationGraph(object):
         try:
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.result = fn()
+                for last in self.before_end:
+                    last()
         except CaptureError:
             raise
         except Exception as e:          # noqa: BLE001  (HIP refuses syncs / uploads in a capture)
@@ -87,8 +92,8 @@ class IterationGraph(object):
         """Drops the graph, the recorded beams and the hooks (which refer back to this object:
         without this the graph lives until some later garbage collection)."""
         self.after_replay = []
-        self.pending_calls = {}
-        self.result = None
+        self.before_end = []
+        self.result = None      # (pending_calls stays: a recorded beam made later needs the count)
         self.graph = None
 
     def replay(self):
