@@ -227,7 +227,7 @@ class _DeferredLocal(object):
             local = rs.Beam.empty_like_on_device(self.was, self.device)
             self._launch(self.was, local)
             self.local._adopt_arrays(local)
-            self.was = self.tensors = None
+            self.was, self.tensors = None, ()
 
 
 class SetOfRectangularAperturesOnZActuator(RectangularAperture):
