@@ -323,6 +323,18 @@ def dry_reflect(args, world, rank, dist):
 def bench_reflect(args, world, rank, dist, dcm=False):
     if DRY_RANKS:
         return dry_reflect(args, world, rank, dist)
+    # The primary metric is the FULL pass: every step writes the local and the global beam
+    # (308 B per intersection), an immediate launch per call -- the beams-on-demand route of
+    # round 5 (oes.fuseConsumers) is switched off for these legs.
+    from xrt_amd.backends.raycing import oes as roe
+    fuse, roe.fuseConsumers = roe.fuseConsumers, False
+    try:
+        return _bench_reflect(args, world, rank, dist, dcm)
+    finally:
+        roe.fuseConsumers = fuse
+
+
+def _bench_reflect(args, world, rank, dist, dcm=False):
     from xrt_amd import workloads as pc
     n = int(args.rays)
     seed = (43 if dcm else 42) + 1000 * rank          # replicas: own rays per rank
