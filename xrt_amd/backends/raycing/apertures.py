@@ -7,6 +7,8 @@ import ctypes
 import numpy as np
 import torch
 
+from ... import hipcalls as _hipcalls
+
 from .. import raycing
 from ... import _lib, _structs
 from . import sources as rs
@@ -145,7 +147,7 @@ class RectangularAperture(object):
             ctypes.byref(rec), ctypes.byref(beam.to_struct(dev)),
             ctypes.byref(local.to_struct(dev)),
             ctypes.byref(glo.to_struct(dev)) if glo is not None else None,
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            _hipcalls.stream_ptr()),
             'xrt_hip_aperture_propagate_f64_dev')
         beam._h.pop('state', None)       # the kernel updated beam.state in HBM
         rs.inherit_scalars(local, beam)
@@ -213,7 +215,7 @@ class _DeferredLocal(object):
             _lib.check(_lib.load().xrt_hip_aperture_propagate_f64_dev(
                 ctypes.byref(self.record), ctypes.byref(beam.to_struct(self.device)),
                 ctypes.byref(local.to_struct(self.device)) if local is not None else None,
-                None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                None, _hipcalls.stream_ptr()),
                 'xrt_hip_aperture_propagate_f64_dev')
 
     def reads(self, beam):

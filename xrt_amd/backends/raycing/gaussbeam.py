@@ -11,6 +11,8 @@ from math import factorial
 import numpy as np
 import torch
 
+from ... import hipcalls as _hipcalls
+
 from .. import raycing
 from ... import _lib, _structs
 from . import sources as rs
@@ -114,7 +116,7 @@ class GaussianBeam(object):
             cells.data_ptr() if cells is not None else None,
             float(wave.dS) if cells is None else 0., amp.data_ptr(),
             *[t.data_ptr() for t in dirs],
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            _hipcalls.stream_ptr()),
             'xrt_hip_gaussian_beam_f64_dev')
         amp = amp.cpu().numpy()
         for field, factor in (('Es', amp), ('Ep', amp)) + tuple(

@@ -13,6 +13,8 @@ import os
 import numpy as np
 import torch
 
+from ... import hipcalls as _hipcalls
+
 from ... import _lib, _structs
 from .physconsts import AVOGADRO, CH, CHBAR, PI, PI2, R0
 
@@ -348,7 +350,7 @@ class Material(object):
         _lib.check(lib.xrt_hip_material_amplitude_f64_dev(
             ctypes.byref(s), n, dE.data_ptr(), db.data_ptr(), rs.data_ptr(),
             rp.data_ptr(), mu.data_ptr(), nk.data_ptr(),
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            _hipcalls.stream_ptr()),
             'xrt_hip_material_amplitude_f64_dev')
         return (rs.cpu().numpy(), rp.cpu().numpy(), mu.cpu().numpy(),
                 nk.cpu().numpy())
@@ -544,7 +546,7 @@ class Multilayer(object):
         rp = torch.empty(n, dtype=torch.complex128, device=dev)
         _lib.check(lib.xrt_hip_multilayer_amplitude_f64_dev(
             ctypes.byref(s), n, dE.data_ptr(), db.data_ptr(), rs.data_ptr(), rp.data_ptr(),
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            _hipcalls.stream_ptr()),
             'xrt_hip_multilayer_amplitude_f64_dev')
         return rs.cpu().numpy(), rp.cpu().numpy()
 
@@ -680,7 +682,7 @@ class Crystal(Material):
         _lib.check(lib.xrt_hip_crystal_amplitude_f64_dev(
             ctypes.byref(s), n, *[a.data_ptr() for a in args], S.data_ptr(),
             P.data_ptr(),
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            _hipcalls.stream_ptr()),
             'xrt_hip_crystal_amplitude_f64_dev')
         return S.cpu().numpy(), P.cpu().numpy()
 

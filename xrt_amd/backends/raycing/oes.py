@@ -42,7 +42,7 @@ def _device():
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return hipcalls.stream_ptr()
 
 
 def _fill_rotation(record, steps):
@@ -963,6 +963,31 @@ class _DeferredReflect(object):
         return image
 
 
+def _scratch_beam(role, n, dev, amplitudes):
+    """A beam-sized scratch that a fused pass writes only if it has to be redone, kept from call
+    to call per (thread, stream) for the beams of the size the host bounds (three allocations
+    and a record per beam = 13 us of a 0.2-ms iteration); ``taken`` when the call turned it
+    into a real beam after all."""
+    if n > _SCRATCH_RAYS:
+        return rs.Beam.empty_on_device(n, dev, amplitudes)
+    held = hipcalls._tls.__dict__.setdefault('scratch_beams', {})
+    key = (role, dev.index, hipcalls.raw_stream(dev.index), int(n), bool(amplitudes))
+    beam = held.get(key)
+    if beam is None:
+        beam = held[key] = rs.Beam.empty_on_device(n, dev, amplitudes)
+    return beam
+
+
+def _scratch_taken(role, beam):
+    held = hipcalls._tls.__dict__.get('scratch_beams', {})
+    for key in [k for k, b in held.items() if b is beam]:
+        del held[key]
+
+
+_scratch_beam.taken = _scratch_taken
+_SCRATCH_RAYS = 2_000_000
+
+
 def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, keep_global=False,
                      local=True):
     """OE.reflect + Screen.expose in one C call (xrt_hip_reflect_screen_f64_dev) ->
@@ -977,12 +1002,14 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
         n, amp = source.n, source.amplitudes
         parent = source.beam
         ms = self._material_struct(material, True, dev, None)
-        scratch = rs.Beam.empty_on_device(n, dev, amp)      # (written only for a redo)
+        scratch = _scratch_beam('source', n, dev, amp)      # (written only for a redo)
     else:
         n, amp, parent = beam_in.nrays, beam_in.has_amplitudes(), beam_in
         ms = self._material_struct(material, True, dev, beam_in)
         s_in = beam_in.to_struct(dev)
-    gb, image = (rs.Beam.empty_on_device(n, dev, amp) for _ in range(2))
+    # (the global beam nobody keeps: the redo's scratch)
+    gb = rs.Beam.empty_on_device(n, dev, amp) if keep_global else _scratch_beam('global', n, dev, amp)
+    image = rs.Beam.empty_on_device(n, dev, amp)
     lb = rs.Beam.empty_on_device(n, dev, amp) if local else None
     theta = torch.empty(n, dtype=torch.float64, device=dev) if local else None
     lb_ref = ctypes.byref(lb.to_struct(dev)) if local else None
@@ -1001,6 +1028,7 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
             rs._PENDING.discard(source)
             source.state = 'inflight'       # (still makes its beam if somebody asks for it)
         else:
+            _scratch_beam.taken('source', scratch)
             source.adopt(scratch)           # the generator's own launch has filled it
     else:
         _lib.check(lib.xrt_hip_reflect_screen_f64_dev(
@@ -1011,6 +1039,8 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
             ws.numel(), _stream(), ctypes.byref(fused), None), 'xrt_hip_reflect_screen_f64_dev')
     if local:
         lb._d['theta'] = theta
+    if not (fused.value & 1):
+        _scratch_beam.taken('global', gb)      # (it holds the element's global beam after all)
     self._adopt((lb, gb) if local else (gb,), parent)
     rs.inherit_scalars(image, parent)
     return lb, gb, image, bool(fused.value & 1)

@@ -6,6 +6,8 @@ import ctypes
 import numpy as np
 import torch
 
+from ... import hipcalls as _hipcalls
+
 from .. import raycing
 from ... import _lib, _structs
 from . import sources as rs
@@ -63,7 +65,7 @@ class Screen(object):
         _lib.check(_lib.load().xrt_hip_screen_expose_f64_dev(
             ctypes.byref(rec), ctypes.byref(beam.to_struct(dev)),
             ctypes.byref(image.to_struct(dev)),
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            _hipcalls.stream_ptr()),
             'xrt_hip_screen_expose_f64_dev')
         rs.inherit_scalars(image, beam)
         return image
@@ -137,7 +139,7 @@ class HemisphericScreen(Screen):
         _lib.check(_lib.load().xrt_hip_screen_expose_f64_dev(
             ctypes.byref(rec), ctypes.byref(beam.to_struct(dev)),
             ctypes.byref(image.to_struct(dev)),
-            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            _hipcalls.stream_ptr()),
             'xrt_hip_screen_expose_f64_dev')
         image._d['theta'], image._d['phi'] = angles
         rs.inherit_scalars(image, beam)

@@ -12,6 +12,8 @@ re-uploaded on the next GPU operation.
 import numpy as np
 import torch
 
+from ... import hipcalls as _hipcalls
+
 from .. import raycing
 from ... import _structs
 from .physconsts import PI2
@@ -506,7 +508,7 @@ class _DeferredShine(object):
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().xrt_hip_geosource_shine_f64_dev(
                 ctypes.byref(g), ctypes.byref(bo.to_struct(self.device)),
-                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                _hipcalls.stream_ptr()),
                 'xrt_hip_geosource_shine_f64_dev')
 
     def materialize(self, which=None):
@@ -932,7 +934,7 @@ class GeometricSource(object):
         _lib.require_gpu()
         lib = _lib.load()
         dev = torch.device('cuda', torch.cuda.current_device())
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = _hipcalls.stream_ptr()
         from ... import graphs
         rec = graphs.capturing()
         with self._call_lock:            # every shine() takes its own sub-stream, also from threads

@@ -14,6 +14,8 @@ import time
 import numpy as np
 import torch
 
+from ... import hipcalls as _hipcalls
+
 from .. import raycing
 from ... import _lib, _structs, hipcalls
 from . import sources as rs
@@ -376,7 +378,7 @@ def _sample_arrays(oe, field, dev):
     _lib.check(_lib.load().xrt_hip_diffract_pre_f64_dev(
         ctypes.byref(p), is_oe, ctypes.byref(field.to_struct(dev)), *[_ptr(t) for t in f64],
         *[_ptr(t) for t in c128], _ptr(ws), ws.numel(),
-        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), sums),
+        _hipcalls.stream_ptr(), sums),
         'xrt_hip_diffract_pre_f64_dev')
     return f64 + c128, sums[0], abs(sums[1]), int(sums[2])
 
@@ -394,7 +396,7 @@ def _as_global_beam(oe, wave, dev):
         glo._d[name].copy_(wave.dev(source, dev))
     rs.inherit_scalars(glo, wave)
     glo.parentId = oe.uuid
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    stream = _hipcalls.stream_ptr()
     if hasattr(oe, 'rotationSequence'):
         oe.local_to_global(glo)
     elif hasattr(oe, 'local_to_global'):
@@ -424,7 +426,7 @@ def diffract(oeLocal, wave, targetOpenCL=raycing.targetOpenCL,
     _lib.require_gpu()
     lib = _lib.load()
     dev = torch.device('cuda', torch.cuda.current_device())
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    stream = _hipcalls.stream_ptr()
     oe = wave.fromOE
     t0 = time.time()
     samples, flux, flux_nl, nlit = _sample_arrays(oe, oeLocal, dev)

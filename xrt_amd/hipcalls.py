@@ -14,8 +14,20 @@ from . import _lib
 _tls = threading.local()
 
 
-def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def raw_stream(index=None):
+    """The HIP stream the calling thread launches on (torch's current stream of the device) as a
+    number: ``torch.cuda.current_stream().cuda_stream`` without the Stream object it makes
+    (3 us a time, five times per element chain)."""
+    if index is None:
+        index = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(index)
+
+
+def stream_ptr(index=None):
+    return ctypes.c_void_p(raw_stream(index))
+
+
+_stream_ptr = stream_ptr
 
 
 def _f64(t, n=None, name='array'):
@@ -46,7 +58,7 @@ def workspace(device, nbytes, tag='default'):
     threads, or two streams of one thread, never share one."""
     cache = _tls.__dict__.setdefault('workspaces', {})
     index = device.index if device.index is not None else torch.cuda.current_device()
-    key = (index, torch.cuda.current_stream(index).cuda_stream, tag)
+    key = (index, raw_stream(index), tag)
     ws = cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -105,7 +117,7 @@ def kirchhoff_report(device=None):
     # the record lives at the head of the workspace the call used: none yet on this thread /
     # stream -> nothing to report (a fresh buffer would hold garbage)
     index = dev.index if dev.index is not None else torch.cuda.current_device()
-    key = (index, torch.cuda.current_stream(index).cuda_stream, 'kirchhoff')
+    key = (index, raw_stream(index), 'kirchhoff')
     ws = _tls.__dict__.get('workspaces', {}).get(key)
     if ws is None:
         return None

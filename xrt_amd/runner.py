@@ -18,6 +18,8 @@ import time
 import numpy as np
 import torch
 
+from . import hipcalls as _hipcalls
+
 from . import _lib, _structs, graphs, hipcalls
 from .backends.raycing import run as rr
 
@@ -92,7 +94,7 @@ def accumulate_plot(plot, beams):
     _lib.check(lib.xrt_hip_plot_hist_ws_f64_dev(
         ctypes.byref(s), ptr(x), ptr(y), ptr(cdat), ctypes.byref(P), ptr(hist),
         ptr(hist_rgb), ptr(hx), ptr(hy), ptr(hc) if plot.ePos else None, ptr(counters),
-        ptr(ws), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+        ptr(ws), ws.numel(), _hipcalls.stream_ptr()),
         'xrt_hip_plot_hist_ws_f64_dev')
     nrays = beam.nrays
 
