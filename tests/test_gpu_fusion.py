@@ -616,3 +616,31 @@ def test_beams_of_a_recorded_iteration_looked_at_after_its_replays():
     rec.close()
     nxt0, nxt = bl0.source.shine(), bl.source.shine()       # ... and the sequence goes on
     same(nxt, nxt0, 'next shine')
+
+
+def test_an_aperture_on_the_source_beam_after_the_fused_pass():
+    """The pass made the source's rays in its registers; afterwards the script stops part of the
+    source beam with a slit (states change in place) and only then looks at the mirror's local
+    beam: it is the one of the rays as they were."""
+    bl, amp = source_scene(n=30000)
+    slit = ra.RectangularAperture(bl, 'slit', [0, 15000., 0], ('left', 'right'), [-0.5, 0.5])
+    roe.fuseConsumers = False
+    try:
+        bl.source._calls = 0
+        s0 = bl.source.shine()
+        g0, l0 = bl.mirror.reflect(s0)
+        i0 = bl.screen.expose(g0)
+        slit.propagate(s0)
+    finally:
+        roe.fuseConsumers = True
+    bl.source._calls = 0
+    s1 = bl.source.shine()
+    g1, l1 = bl.mirror.reflect(s1)
+    i1 = bl.screen.expose(g1)
+    assert s1.__dict__['_op'].state == 'inflight'
+    slit.propagate(s1)
+    assert (s1.state < 0).sum() > 100 and not l1.__dict__['_filled']
+    same(i1, i0, 'image')
+    same(s1, s0, 'source after the slit')
+    same(l1, l0, 'local', extra=('theta',))
+    same(g1, g0, 'global')

@@ -920,7 +920,7 @@ class _DeferredReflect(object):
                 oe.__dict__['_global_beam_wanted'] = True
             if want_lb or want_gb:
                 rays = self.beam
-                if type(rays) is rs.LazyBeam and not rays.__dict__['_filled']:
+                if type(rays) is rs.LazyBeam:      # (a source's, not made when the pass ran)
                     rays = self.src_op.rays_again()
                 lb, gb, _ = oe._run_pass(self.p, oe.material, True, rays, rays, local=want_lb)
                 if want_lb:

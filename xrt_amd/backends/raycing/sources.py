@@ -525,10 +525,9 @@ class _DeferredShine(object):
             self.beam._adopt_arrays(bo)
 
     def rays_again(self):
-        """-> the same rays in a new beam (for whoever has to run a pass on them again: this
-        beam itself stays as it is, asked for or not)."""
-        if self.state == 'done':
-            return self.beam
+        """-> the same rays in a NEW beam (for whoever has to run a pass on them again: this
+        beam itself stays as it is, asked for or not -- and if it exists, an aperture may have
+        changed its states since)."""
         bo = Beam.empty_on_device(self.n, self.device, self.amplitudes)
         self.launch_into(bo)
         inherit_scalars(bo, self.beam)
