@@ -10,6 +10,8 @@ same lists (``xrt_hip_rotation``), so host and device walk one description and r
 the same way."""
 import uuid
 
+import functools as _functools
+
 import numpy as np
 
 # ray states and solver constants
@@ -51,13 +53,23 @@ def rotation_steps(rotationSequence='RzRyRx', pitch=0, roll=0, yaw=0):
     """[(axis, cos, sin)] in the order the reference's rotate_beam applies them: the
     letters of e.g. 'RzRyRx' left to right, right to left behind a leading '-';
     zero angles drop out; cos/sin of the scalar angle are taken here, once."""
+    try:
+        return list(_rotation_steps(rotationSequence, pitch, roll, yaw))
+    except TypeError:           # (an angle that does not hash: an array of one)
+        return list(_rotation_steps.__wrapped__(rotationSequence, pitch, roll, yaw))
+
+
+@_functools.lru_cache(maxsize=4096)
+def _rotation_steps(rotationSequence, pitch, roll, yaw):
+    # (a pure function of four numbers that every element call asks for again: numpy's scalar
+    # cos / sin are 0.7 us each, twelve of them per pass record)
     angle_of = (pitch, roll, yaw)
     letters = [ch for ch in rotationSequence if ch in _AXIS]
     if rotationSequence.startswith('-'):
         letters.reverse()
-    return [(_AXIS[ch], float(np.cos(angle_of[_AXIS[ch]])),
-             float(np.sin(angle_of[_AXIS[ch]])))
-            for ch in letters if angle_of[_AXIS[ch]] != 0]
+    return tuple((_AXIS[ch], float(np.cos(angle_of[_AXIS[ch]])),
+                  float(np.sin(angle_of[_AXIS[ch]])))
+                 for ch in letters if angle_of[_AXIS[ch]] != 0)
 
 
 def turn(triple, steps, part=None):

@@ -347,35 +347,28 @@ class Beam(object):
         their addresses -- an element call makes two or three of these, and fifteen
         ``torch.empty`` + as many ``data_ptr`` were a quarter of its host time."""
         b = cls.__new__(cls)
-        object.__setattr__(b, '_h', {})
-        object.__setattr__(b, '_d', {})
         n = int(nrays)
         row = (n + 63) // 64 * 64
         f = torch.empty((len(_F64), row), dtype=torch.float64, device=device)
         c = torch.empty((3 if withAmplitudes else 1, row), dtype=torch.complex128, device=device)
         state = torch.empty(n, dtype=torch.int32, device=device)
-        d = b._d
-        for name, t in zip(_F64, f[:, :n].unbind(0)):
-            d[name] = t
-        rows = c[:, :n].unbind(0)
+        whole = n == row
+        d = dict(zip(_F64, (f if whole else f[:, :n]).unbind(0)))
+        rows = (c if whole else c[:, :n]).unbind(0)
         d['Jsp'] = rows[0]
         d['state'] = state
-        s = _structs.Beam()
-        s.n = n
-        base = f.data_ptr()
-        for k, cname in enumerate(_F64):
-            setattr(s, cname, base + k * row * 8)
-        base = c.data_ptr()
-        s.Jsp_ri = base
-        s.state = state.data_ptr()
+        fb, cb, step = f.data_ptr(), c.data_ptr(), row * 8
         if withAmplitudes:
             d['Es'], d['Ep'] = rows[1], rows[2]
-            s.Es_ri, s.Ep_ri = base + row * 16, base + 2 * row * 16
-        else:
-            s.Es_ri = s.Ep_ri = None
+        # (positional: n, the ten f64 rows in _F64's order, Jsp, state, Es, Ep -- one call
+        # instead of fifteen attribute stores)
+        s = _structs.Beam(n, fb, fb + step, fb + 2 * step, fb + 3 * step, fb + 4 * step,
+                          fb + 5 * step, fb + 6 * step, fb + 7 * step, fb + 8 * step,
+                          fb + 9 * step, cb, state.data_ptr(),
+                          cb + 2 * step if withAmplitudes else None,
+                          cb + 4 * step if withAmplitudes else None)
         s._keep = (f, c, state)
-        object.__setattr__(b, '_struct', s)
-        object.__setattr__(b, 'parentId', None)
+        vars(b).update(_h={}, _d=d, _struct=s, parentId=None)
         return b
 
     def to_struct(self, device=None):
