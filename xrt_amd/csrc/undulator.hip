@@ -283,9 +283,13 @@ __device__ __forceinline__ void und_ray_any(const UndulatorArgs& a,
 // SIMD divide the 16 per SIMD of a 2^20-ray map evenly (five left a fifth of the last round).
 #ifndef UND_WAVES
 #define UND_WAVES 4
-#endif                   // (the multi-period modes: one less, their three loop forms need the registers)
+#endif
+#ifndef UND_BLOCK          /* lanes per block (A/B: 1024 = one table copy per CU instead of four) */
+#define UND_BLOCK 256
+#endif
+#define UND_PER_CU(waves) ((waves) * 256 / UND_BLOCK > 0 ? (waves) * 256 / UND_BLOCK : 1)                   // (the multi-period modes: one less, their three loop forms need the registers)
 template <int MODE>
-__global__ void __launch_bounds__(256, MODE == UND_FAR ? UND_WAVES : UND_WAVES - 1)
+__global__ void __launch_bounds__(UND_BLOCK, UND_PER_CU(MODE == UND_FAR ? UND_WAVES : UND_WAVES - 1))
 und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
         const double* __restrict__ gamma, const double* __restrict__ wu,
         const double* __restrict__ w, const double* __restrict__ ww1,
@@ -311,7 +315,7 @@ und_sum(UndulatorArgs a, const double* __restrict__ rec, int64_t n,
 // pre-factors wu, ww1, ab from (w, theta, psi, gamma), the sum, the harmonic
 // window and the Amp2Flux scaling. numpy's operation order throughout.
 template <int MODE>
-__global__ void __launch_bounds__(256, MODE == UND_FAR ? UND_WAVES : UND_WAVES - 1)
+__global__ void __launch_bounds__(UND_BLOCK, UND_PER_CU(MODE == UND_FAR ? UND_WAVES : UND_WAVES - 1))
 und_imap(UndulatorArgs a, UndulatorMap m, const double* __restrict__ rec, int64_t n,
          const double* __restrict__ w_, const double* __restrict__ theta,
          const double* __restrict__ psi_, const double* __restrict__ gamma_,
@@ -362,13 +366,13 @@ static unsigned persistent_grid(K kernel, int64_t n) {
   int dev = 0, cus = 256, per_cu = UND_WAVES;
   if (hipGetDevice(&dev) == hipSuccess)
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess ||
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, UND_BLOCK, 0) != hipSuccess ||
       per_cu < 1) {
     (void)hipGetLastError();
-    per_cu = UND_WAVES;
+    per_cu = UND_PER_CU(UND_WAVES);
   }
-  if (per_cu > UND_WAVES) per_cu = UND_WAVES;
-  const int64_t tiles = (n + 255) / 256, fit = (int64_t)cus * per_cu;
+  if (per_cu > UND_PER_CU(UND_WAVES)) per_cu = UND_PER_CU(UND_WAVES);
+  const int64_t tiles = (n + UND_BLOCK - 1) / UND_BLOCK, fit = (int64_t)cus * per_cu;
   return (unsigned)(tiles < fit ? tiles : fit);
 }
 
@@ -546,7 +550,7 @@ hipError_t undulator_sum_launch(const UndulatorArgs& a, int64_t n, const double*
                                 double* Ip_ri, const void* workspace, hipStream_t st) {
   const double* rec = reinterpret_cast<const double*>(workspace);
   if (n <= 0) return hipSuccess;
-  dim3 block(256);
+  dim3 block(UND_BLOCK);
   double2* is = reinterpret_cast<double2*>(Is_ri);
   double2* ip = reinterpret_cast<double2*>(Ip_ri);
   switch (a.mode) {
@@ -574,7 +578,7 @@ hipError_t undulator_imap_launch(const UndulatorArgs& a, const UndulatorMap& m, 
                                  const void* workspace, hipStream_t st) {
   const double* rec = reinterpret_cast<const double*>(workspace);
   if (n <= 0) return hipSuccess;
-  dim3 block(256);
+  dim3 block(UND_BLOCK);
   double2* es = reinterpret_cast<double2*>(Es_ri);
   double2* ep = reinterpret_cast<double2*>(Ep_ri);
   switch (a.mode) {
