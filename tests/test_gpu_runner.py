@@ -229,13 +229,14 @@ def test_colour_histogram_of_a_few_energies(lines):
     assert np.abs(plot.total2D - r2).max() <= 1e-10 * r2.max()
 
 
+@pytest.mark.parametrize('n', [1_000_003, 100_003])
 @pytest.mark.parametrize('centre', [(0., 0.), (0.31, -0.52), (0.999, 0.999)])
-def test_histograms_of_a_focused_beam(centre):
+def test_histograms_of_a_focused_beam(centre, n):
     """All rays in a spot of a few bins -- what a screen at a focus shows: the spot sits on the
     corner shared by four tiles of the 256 x 256 plot, inside one tile, and in the last bins of
     the plot (rays beyond the limits). The tile kernel shares its blocks out by the ray counts
-    of the tiles (one tile may hold everything); empty tiles get none."""
-    n = 1_000_003
+    of the tiles (one tile may hold everything); empty tiles get none. Also at 1e5 rays
+    (a hundred chunks: most blocks of the tile kernel have one chunk or none)."""
     rng = np.random.default_rng(5)
     beam = rs.Beam(nrays=n)
     beam.x = centre[0] + rng.normal(0, 0.01, n)
@@ -266,16 +267,16 @@ def test_histograms_of_a_focused_beam(centre):
     assert plot.nRaysSelected == 2 * int(sel.sum())
 
 
+@pytest.mark.parametrize('n', [300_001, 90_001])
 @pytest.mark.parametrize('bx,by,with_counters', [(50, 40, True), (140, 141, False),
                                                  (300, 280, True), (1500, 1200, True)])
-def test_plain_2d_histogram_entry_point(bx, by, with_counters):
+def test_plain_2d_histogram_entry_point(bx, by, with_counters, n):
     """xrt_hip_hist2d_f64_dev (one flux plane, no colour axis; what a plot without caxis needs):
     the plane in the LDS of one block, sorted by tile (one plane per tile), and beyond the
     tiles the sort takes; it ADDS into what it is given."""
     import ctypes
     import torch
     from xrt_amd import _lib
-    n = 300_001
     oe = workloads.cfg2_toroid()
     gb, lb = oe.reflect(workloads.synthetic_rays(n, 3))
     dev = torch.device('cuda', torch.cuda.current_device())
