@@ -644,3 +644,65 @@ def test_an_aperture_on_the_source_beam_after_the_fused_pass():
     same(s1, s0, 'source after the slit')
     same(l1, l0, 'local', extra=('theta',))
     same(g1, g0, 'global')
+
+
+def test_c_abi_rules_for_a_missing_local_beam():
+    """out_local NULL through the C ABI itself: a crystal pass leaves its local beam out (round
+    5) and gives the global beam of the full pass; a layered mirror refuses; the fused DCM takes
+    both local beams or neither."""
+    import ctypes
+    from xrt_amd import _lib, hipcalls
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    stream = hipcalls.stream_ptr()
+    bl = raycing.BeamLine()
+    si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    thB = float(np.ravel(si.get_Bragg_angle(9000.) - si.get_dtheta(9000.))[0])
+    xt = roe.OE(bl, 'xtal', center=[0, 20000., 0], pitch=thB, material=si, limPhysX=[-10, 10],
+                limPhysY=[-50, 50])
+    beam = workloads.synthetic_rays(30000, 3, sa=1e-4, E=(8995., 9005.), amplitudes=True)
+    roe.fuseConsumers = False
+    try:
+        gb0, lb0 = xt.reflect(rs.Beam(copyFrom=beam))
+    finally:
+        roe.fuseConsumers = True
+    assert (gb0.state == 1).sum() > 1000
+
+    def run(oe, material):
+        p = oe._make_pass(oe.pitch + getattr(oe, 'bragg', 0), oe.roll + oe.positionRoll, oe.yaw,
+                          oe.dx)
+        ms = oe._material_struct(material, True, dev, beam)
+        out = rs.Beam.empty_like_on_device(beam, dev)
+        ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(beam.nrays), 'reflect')
+        s_in = beam.to_struct(dev)
+        rc = lib.xrt_hip_reflect_pass_f64_dev(
+            ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in), None,
+            ctypes.byref(out.to_struct(dev)), None, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+            stream, None, None)
+        return rc, out
+    rc, gb = run(xt, si)
+    assert rc == 0, lib.xrt_hip_last_error()
+    same(gb, gb0, 'crystal, global beam alone')
+    coated = roe.OE(bl, 'coated', center=[0, 20000., 0], pitch=4e-3, limPhysX=[-10, 10],
+                    limPhysY=[-300, 300],
+                    material=rm.Coated(coating=rm.Material('Rh', rho=12.41), cThickness=300.,
+                                       substrate=rm.Material('Si', rho=2.33),
+                                       surfaceRoughness=3.))
+    rc, _ = run(coated, coated.material)
+    assert rc != 0 and b'layered' in lib.xrt_hip_last_error()
+    # the fused DCM: one local beam without the other is refused
+    dcm = workloads.cfg3_dcm(bl)
+    first, second = dcm._own_angles(False), dcm._own_angles(True)
+    p1 = dcm._make_pass(*first[:4], out_to_global=False)
+    p2 = dcm._make_pass(*second, is2ndXtal=True, in_is_global=False, good_mode=1,
+                        out_to_global=True, zero_local_not_entering=True)
+    m1, m2 = (dcm._material_struct(m, True, dev) for m in (dcm.material, dcm.material2))
+    lo1, gb2 = (rs.Beam.empty_like_on_device(beam, dev) for _ in range(2))
+    theta = torch.empty(beam.nrays, dtype=torch.float64, device=dev)
+    ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(beam.nrays), 'reflect')
+    rc = lib.xrt_hip_double_reflect_f64_dev(
+        ctypes.byref(p1), ctypes.byref(m1), ctypes.byref(p2), ctypes.byref(m2),
+        ctypes.byref(beam.to_struct(dev)), ctypes.byref(lo1.to_struct(dev)), None,
+        ctypes.byref(gb2.to_struct(dev)), ctypes.c_void_p(theta.data_ptr()), None,
+        ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream, None)
+    assert rc != 0 and b'both local beams or neither' in lib.xrt_hip_last_error()
