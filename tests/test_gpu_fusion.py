@@ -706,3 +706,92 @@ def test_c_abi_rules_for_a_missing_local_beam():
         ctypes.byref(gb2.to_struct(dev)), ctypes.c_void_p(theta.data_ptr()), None,
         ctypes.c_void_p(ws.data_ptr()), ws.numel(), stream, None)
     assert rc != 0 and b'both local beams or neither' in lib.xrt_hip_last_error()
+
+
+# ---- ADVICE r5 -----------------------------------------------------------------------------------
+def test_screen_on_lazy_beams_that_are_not_an_elements_global_beam():
+    """Screen.expose of a pending beam that is NOT the global beam of a deferred OE.reflect: a
+    device source's beam (source -> screen is the most common script pattern), an aperture's
+    local beam made on demand, a DCM's local beams on demand. Each is simply made and imaged."""
+    bl, _ = source_scene(n=30000)
+    roe.fuseConsumers = False
+    try:
+        bl.source._calls = 0
+        i0 = bl.screen.expose(bl.source.shine())
+    finally:
+        roe.fuseConsumers = True
+    bl.source._calls = 0
+    src = bl.source.shine()
+    assert type(src) is rs.LazyBeam and not src.__dict__['_filled']
+    same(bl.screen.expose(src), i0, 'source -> screen')
+    # an aperture's local beam
+    slit = ra.RectangularAperture(bl, 'slit', [0, 15000., 0], ('left', 'right'), [-0.5, 0.5])
+    roe.fuseConsumers = False
+    try:
+        bl.source._calls = 0
+        l0 = slit.propagate(bl.source.shine())
+        j0 = bl.screen.expose(l0)
+    finally:
+        roe.fuseConsumers = True
+    bl.source._calls = 0
+    l1 = slit.propagate(bl.source.shine())
+    assert type(l1) is rs.LazyBeam and not l1.__dict__['_filled']
+    same(bl.screen.expose(l1), j0, 'aperture local -> screen')
+    # a DCM's local beams
+    dcm = workloads.cfg3_dcm(raycing.BeamLine())
+    beam = workloads.synthetic_rays(20000, 11, sa=1e-4, E=(8995., 9005.))
+    roe.fuseConsumers = False
+    try:
+        g0, a0, b0 = dcm.double_reflect(rs.Beam(copyFrom=beam))
+        k0 = bl.screen.expose(b0)
+    finally:
+        roe.fuseConsumers = True
+    g1, a1, b1 = dcm.double_reflect(rs.Beam(copyFrom=beam))
+    assert type(b1) is rs.LazyBeam and not b1.__dict__['_filled']
+    same(bl.screen.expose(b1), k0, 'DCM local -> screen')
+
+
+def test_out_beams_reused_in_place_wait_for_their_readers():
+    """reflect -> propagate (lazy local beam of the slit, reads gb's arrays) -> reflect(out=the
+    previous pair) overwrites those arrays: the slit's local beam is made first, from the data of
+    ITS iteration. Same for DCM.double_reflect(out=...)."""
+    bl, oe, scr, beam = scene(n=50000)
+    slit = ra.RectangularAperture(bl, 'slit', [0, 25000., 0], ('left', 'right'), [-0.2, 0.2])
+    other = workloads.synthetic_rays(50000, 8, amplitudes=True)
+    roe.fuseConsumers = False
+    try:
+        gb0, lb0 = oe.reflect(beam)
+        l0 = slit.propagate(gb0)
+    finally:
+        roe.fuseConsumers = True
+    gb, lb = oe.reflect(beam)
+    gb.dev('x')                                      # (filled LazyBeams)
+    lb.dev('x')
+    loc = slit.propagate(gb)
+    assert type(loc) is rs.LazyBeam and not loc.__dict__['_filled']
+    gb2, lb2 = oe.reflect(other, out=(gb, lb))
+    gb2.dev('x')                                     # the launch that overwrites gb's arrays
+    same(loc, l0, 'slit local after out= reuse')
+    # the DCM
+    dcm = workloads.cfg3_dcm(raycing.BeamLine())
+    b3 = workloads.synthetic_rays(30000, 11, sa=1e-4, E=(8995., 9005.))
+    b4 = workloads.synthetic_rays(30000, 12, sa=1e-4, E=(8995., 9005.))
+    dslit = ra.RectangularAperture(dcm.bl, 'dslit', [0, 25000., 20.], ('left', 'right'), [-0.05, 0.05])
+    roe.fuseConsumers = False
+    try:
+        trio = dcm.double_reflect(b3)
+        m0 = dslit.propagate(rs.Beam(copyFrom=trio[0]))
+    finally:
+        roe.fuseConsumers = True
+    dcm.__dict__['_local_beams_wanted'] = True       # (out= needs the three real beams)
+    trio = dcm.double_reflect(b3)
+    m1 = dslit.propagate(trio[0])
+    assert type(m1) is rs.LazyBeam and not m1.__dict__['_filled']
+    dcm.double_reflect(b4, out=trio)
+    same(m1, m0, 'slit local after DCM out= reuse')
+
+
+def test_multiple_reflect_refuses_no_bounce_at_all():
+    bl, oe, scr, beam = scene(n=1000)
+    with pytest.raises(ValueError):
+        oe.multiple_reflect(beam, maxReflections=0)

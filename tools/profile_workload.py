@@ -7,6 +7,12 @@
   * DCM.double_reflect cfg3     - P1, crystal path
   * Kirchhoff cfg4 (1 launch)   - P2
   * GeometricSource(rng='device').shine, 1e7 rays - the ray generator kernel
+
+The cfg2 / cfg3 launches are the ones bench.py times: the FULL pass, both beams written (308 B /
+416 B per ray) -- the beams-on-demand route (oes.fuseConsumers) is switched off for them as
+bench.py's primary legs do. ``--nolocal`` runs ONLY the passes without their local beams
+(200 B per ray: OE.reflect(needLocal=False), DCM.double_reflect with the local beams left out)
+after the calibration kernel, for the ``*_nolocal`` entries of profiles/hbm_traffic.json.
 """
 import sys
 import numpy as np
@@ -14,6 +20,7 @@ import torch
 sys.path.insert(0, '.')
 from xrt_amd import hipcalls, workloads  # noqa: E402
 import xrt_amd.backends.raycing as raycing  # noqa: E402
+import xrt_amd.backends.raycing.oes as roe  # noqa: E402
 import xrt_amd.backends.raycing.screens as rsc  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
@@ -28,17 +35,30 @@ for f in beam.array_fields():
 scr = rsc.Screen(raycing.BeamLine(), 'scr', [0, 30000., 0])
 for _ in range(reps):
     scr.expose(beam)
+NOLOCAL = '--nolocal' in sys.argv
+dcm = workloads.cfg3_dcm()
+b3 = workloads.synthetic_rays(n, 43, sa=1e-4, E=(8995., 9005.))
+if NOLOCAL:
+    # the 200-B forms: what an element does whose global beam goes on to the next element
+    for _ in range(reps):
+        oe.reflect(beam, needLocal=False)
+    for _ in range(reps):
+        gb3 = dcm.double_reflect(b3)[0]
+        gb3.dev('x')            # the global beam is looked at, the local beams are not
+    torch.cuda.synchronize()
+    print('done (nolocal)')
+    sys.exit(0)
+roe.fuseConsumers = False       # the timed shape of bench.py: every beam written, at once
 for _ in range(reps):
     oe.reflect(beam)
 # the device ray generator (round 4): 100 B written per ray, nothing read
 bl_e2e, _, _ = workloads.e2e_beamline(n)
 for _ in range(reps):
     bl_e2e.source.shine()
-dcm = workloads.cfg3_dcm()
-b3 = workloads.synthetic_rays(n, 43, sa=1e-4, E=(8995., 9005.))
 for _ in range(reps):
     dcm.double_reflect(b3)
 torch.cuda.synchronize()
+roe.fuseConsumers = True
 if '--no-kirchhoff' not in sys.argv:
     h = workloads.kirchhoff_case(4)
     dev = torch.device('cuda', 0)

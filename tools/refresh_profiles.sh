@@ -12,9 +12,12 @@ rm -rf $O && mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/trace -o trace -- python bench.py > $O/bench_under_rocprof.json 2> $O/trace.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch -- python tools/profile_workload.py > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o write -- python tools/profile_workload.py > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_nl -o fetch -- python tools/profile_workload.py 1e7 --nolocal > $O/fetch_nl.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_nl -o write -- python tools/profile_workload.py 1e7 --nolocal > $O/write_nl.log 2>&1
+FN=$(find $O/fetch_nl -name '*.db' | head -1); WN=$(find $O/write_nl -name '*.db' | head -1)
 T=$(find $O/trace -name '*.db' | head -1); F=$(find $O/fetch -name '*.db' | head -1); W=$(find $O/write -name '*.db' | head -1)
 echo "dbs: $T $F $W"
-python tools/rocpd_summary.py $RND "$T" "$F" "$W" 1e7
+python tools/rocpd_summary.py $RND "$T" "$F" "$W" 1e7 "$FN" "$WN"
 mkdir -p $O/summaries && cp profiles/r${RND}_kernel_stats.csv profiles/hbm_traffic.json $O/summaries/
 tail -c 600 $O/bench_under_rocprof.json | head -c 600; echo
 # SQ counters of the reflect kernels and the stand-alone probes the DESIGN quotes

@@ -1,7 +1,7 @@
 """Turns rocprofv3's rocpd sqlite outputs into the committed summaries under
 profiles/:
 
-  python tools/rocpd_summary.py ROUND trace.db [fetch.db write.db [nrays]]
+  python tools/rocpd_summary.py ROUND trace.db [fetch.db write.db [nrays [fetch_nl.db write_nl.db]]]
 
   profiles/rROUND_kernel_stats.csv   per-kernel calls / total / average (ns)
   profiles/hbm_traffic.json          per-launch HBM bytes of our kernels from
@@ -10,6 +10,10 @@ profiles/:
                                      calibration kernel (screen_expose: exactly
                                      100 B read + 100 B written per ray), as
                                      MI355X_MICROARCH.md (HBM) prescribes.
+                                     fetch.db / write.db: tools/profile_workload.py (the
+                                     FULL passes bench.py times, 308 / 416 B per ray);
+                                     fetch_nl.db / write_nl.db: the same script with
+                                     --nolocal (200 B per ray) -> the *_nolocal entries.
 """
 import csv
 import json
@@ -83,15 +87,16 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, 'profiles')
     os.makedirs(out, exist_ok=True)
-    stats = kernel_stats(trace)
+    stats = kernel_stats(trace) if trace != '-' else []    # ('-': the counter passes alone)
     path = os.path.join(out, 'r%s_kernel_stats.csv' % rnd)
-    with open(path, 'w', newline='') as f:
-        w = csv.writer(f)
-        w.writerow(['kernel', 'grid_threads', 'calls', 'total_ns', 'avg_ns', 'min_ns',
-                    'max_ns'])
-        for r in stats:
-            w.writerow([r[0], r[1], r[2], int(r[3]), round(r[4], 1), r[5], r[6]])
-    print('wrote', path)
+    if stats:
+        with open(path, 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow(['kernel', 'grid_threads', 'calls', 'total_ns', 'avg_ns', 'min_ns',
+                        'max_ns'])
+            for r in stats:
+                w.writerow([r[0], r[1], r[2], int(r[3]), round(r[4], 1), r[5], r[6]])
+        print('wrote', path)
     for r in stats[:14]:
         print('  %-28s grid %9d calls %4d  avg %12.1f us' % (r[0], r[1], r[2], r[4] / 1e3))
     if len(sys.argv) >= 5:
@@ -117,6 +122,26 @@ def main():
                               WRITE_SIZE_KB=write[k][0],
                               launches=fetch[k][1], read_bytes=rb, write_bytes=wb,
                               hbm_bytes_per_launch=rb + wb)
+        if len(sys.argv) >= 8:
+            # the passes that leave their local beams out, from a run of their own (the kernel
+            # names are the same: out_local == NULL is a run-time switch)
+            f_nl = counter_per_launch(sys.argv[6], 'FETCH_SIZE')
+            w_nl = counter_per_launch(sys.argv[7], 'WRITE_SIZE')
+            c_r = 100. * nrays / (f_nl['screen_expose_kernel'][0] * 1024.)
+            c_w = 100. * nrays / (w_nl['screen_expose_kernel'][0] * 1024.)
+            for k in ('reflect_fused', 'reflect_fused_dcm'):
+                if k in f_nl and k in w_nl:
+                    rb = f_nl[k][0] * 1024. * c_r
+                    wb = w_nl[k][0] * 1024. * c_w
+                    res[k + '_nolocal'] = dict(
+                        variant=f_nl[k][2], FETCH_SIZE_KB=f_nl[k][0], WRITE_SIZE_KB=w_nl[k][0],
+                        launches=f_nl[k][1], read_bytes=rb, write_bytes=wb,
+                        hbm_bytes_per_launch=rb + wb, read_correction=c_r, write_correction=c_w,
+                        shape='out_local NULL: 100 B read + 100 B written per ray')
+        for k, b in (('reflect_fused', 308.), ('reflect_fused_dcm', 416.)):
+            if k in res:
+                res[k]['shape'] = 'the full pass bench.py times: %d B per ray' % b
+                res[k]['algorithmic_bytes'] = b * nrays
         path = os.path.join(out, 'hbm_traffic.json')
         with open(path, 'w') as f:
             json.dump(res, f, indent=1)

@@ -194,6 +194,9 @@ class _DeferredLocal(object):
     def __init__(self, aperture, beam, dev):
         self.aperture, self.device = aperture, dev
         self.record = aperture._record()
+        # (the record points at the polygon's vertices in HBM: they live as long as it does,
+        # whatever the script assigns to aperture.vertices in the meantime)
+        self._keep = list(aperture.__dict__.get('_outline', {}).values())
         # the rays as they are NOW: the same tensors (whoever writes into them in place flushes
         # the readers first, sources.flush_pending) and the states before this aperture
         was = rs.Beam.__new__(rs.Beam)
@@ -225,9 +228,9 @@ class _DeferredLocal(object):
     def materialize(self, which=None):
         rs._PENDING.discard(self)
         if self.state != 'done':
-            self.state = 'done'
             local = rs.Beam.empty_like_on_device(self.was, self.device)
-            self._launch(self.was, local)
+            self._launch(self.was, local)     # (one that raises is raised again by the next look)
+            self.state = 'done'
             self.local._adopt_arrays(local)
             self.was, self.tensors = None, ()
 

@@ -521,7 +521,9 @@ class OE(object):
         dev = _device()
         if out is not None:              # (beams about to be overwritten in place)
             for b in out:
-                if b is not None and type(b) is not rs.LazyBeam:
+                # (also a LazyBeam that has its arrays: snapshots of them may wait to be read,
+                # reads() looks at what is there without filling anything)
+                if b is not None and (type(b) is not rs.LazyBeam or b.__dict__['_filled']):
                     rs.flush_pending(b)
         ms = self._material_struct(material, fromVacuum, dev, beam_in)
         s_in = beam_in.to_struct(dev)
@@ -841,9 +843,12 @@ class _LocalsOnDemand(object):
     def materialize(self, which=None):
         rs._PENDING.discard(self)
         if self.state != 'done':
-            self.state = 'done'
             self.oe.__dict__['_local_beams_wanted'] = True
-            for lazy, real in zip(self.locals, self.run(self.was)):
+            # (the state changes when the launch has returned: a launch that raises is raised
+            # again by the next look at the beam instead of leaving it empty)
+            made = self.run(self.was)
+            self.state = 'done'
+            for lazy, real in zip(self.locals, made):
                 lazy._adopt_arrays(real)
             self.was = self.run = None
             self.tensors = ()
@@ -871,6 +876,12 @@ class _DeferredReflect(object):
             beam.to_struct(dev)                      # everything up in HBM now
             snap, self.tensors = _as_it_is(beam)     # the input as it is at this moment
         self.oe, self.p, self.beam, self.out = oe, p, snap, out
+        # the material (the stripe in the beam) as the element has it NOW: the pass record was
+        # made at this moment too, a scan loop may set another before anybody looks at a beam
+        material = oe.material
+        if raycing.is_sequence(material):
+            material = material[oe.curSurface]
+        self.material = material
         self.state = 'pending'
         self.gb, self.lb = rs.LazyBeam(self, 'gb'), rs.LazyBeam(self, 'lb')
         oe._adopt((self.gb, self.lb), beam)
@@ -897,16 +908,18 @@ class _DeferredReflect(object):
         filled = lambda b: b.__dict__['_filled']      # noqa: E731
         if self.state == 'pending':
             rs._PENDING.discard(self)
-            if which != 'lb' and self.out is None and _locals_on_demand(oe, oe.material):
-                self.state = 'global'
-                _, gb, _ = oe._run_pass(self.p, oe.material, True, self.beam, self.beam,
+            # (the state changes when the launch has returned: one that raises is raised again
+            # by the next look at a beam instead of leaving the beams empty)
+            if which != 'lb' and self.out is None and _locals_on_demand(oe, self.material):
+                _, gb, _ = oe._run_pass(self.p, self.material, True, self.beam, self.beam,
                                         local=False)
+                self.state = 'global'
                 self.gb._adopt_arrays(gb)
                 self._waits_with_its_own_states()
                 return
-            self.state = 'done'
-            lb, gb, _ = oe._run_pass(self.p, oe.material, True, self.beam, self.beam,
+            lb, gb, _ = oe._run_pass(self.p, self.material, True, self.beam, self.beam,
                                      out=None if self.out is None else (self.out[1], self.out[0]))
+            self.state = 'done'
             self.lb._adopt_arrays(lb)
             self.gb._adopt_arrays(gb)
         elif self.state in ('global', 'imaged'):
@@ -922,7 +935,7 @@ class _DeferredReflect(object):
                 rays = self.beam
                 if type(rays) is rs.LazyBeam:      # (a source's, not made when the pass ran)
                     rays = self.src_op.rays_again()
-                lb, gb, _ = oe._run_pass(self.p, oe.material, True, rays, rays, local=want_lb)
+                lb, gb, _ = oe._run_pass(self.p, self.material, True, rays, rays, local=want_lb)
                 if want_lb:
                     self.lb._adopt_arrays(lb)
                 if want_gb:
@@ -938,15 +951,14 @@ class _DeferredReflect(object):
         oe = self.oe
         rs._PENDING.discard(self)
         src = self.src_op
-        stripes = oe.material if raycing.is_sequence(oe.material) else (oe.material,)
-        tabulated = any(isinstance(getattr(m, 'refractiveIndex', None), list) for m in stripes)
+        tabulated = isinstance(getattr(self.material, 'refractiveIndex', None), list)
         keep = bool(oe.__dict__.get('_global_beam_wanted'))
-        local = not _locals_on_demand(oe, oe.material)
+        local = not _locals_on_demand(oe, self.material)
         if src is not None and src.state == 'pending' and not tabulated:
-            lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, None, rec, source=src,
+            lb, gb, image, fused = oe._run_pass_screen(self.p, self.material, None, rec, source=src,
                                                        keep_global=keep, local=local)
         else:
-            lb, gb, image, fused = oe._run_pass_screen(self.p, oe.material, self.beam, rec,
+            lb, gb, image, fused = oe._run_pass_screen(self.p, self.material, self.beam, rec,
                                                        keep_global=keep, local=local)
         if local:
             self.lb._adopt_arrays(lb)
@@ -1154,6 +1166,8 @@ def _multiple_reflect(self, beam=None, maxReflections=1000, needElevationMap=Fal
     conics (capillaries), cones, VFMs and user-defined surfaces. *_info* (list) receives one
     dictionary of batch decisions per bounce."""
     from . import materials as _rm
+    if int(maxReflections) < 1:
+        raise ValueError('maxReflections must be at least 1 (got %r)' % (maxReflections,))
     graphs.refuse('multiple_reflect (the rays decide how many bounces there are)')
     _lib.require_gpu()
     lib = _lib.load()
@@ -2063,6 +2077,9 @@ class DCM(OE):
             gb2 = rs.Beam.empty_like_on_device(beam, dev)
         elif usable:
             gb2, lo1, lo2 = out
+            for b in out:               # (overwritten in place: their readers first)
+                if type(b) is not rs.LazyBeam or b.__dict__['_filled']:
+                    rs.flush_pending(b)
             angles = [lo1._d['theta'], lo2._d['theta']]
         else:
             lo1, lo2, gb2 = (rs.Beam.empty_like_on_device(beam, dev) for _ in range(3))

@@ -57,7 +57,10 @@ class Screen(object):
         dev = torch.device('cuda', torch.cuda.current_device())
         rec = self._record(onlyPositivePath)
         op = beam.__dict__.get('_op') if type(beam) is rs.LazyBeam else None
-        if op is not None and op.state == 'pending' and beam is op.gb and op.p.out_to_global:
+        # (only the global beam of an element's deferred pass: a device source's beam, an
+        # aperture's lazy local beam or a DCM's beams on demand are other kinds of record)
+        if op is not None and getattr(op, 'gb', None) is beam and op.state == 'pending' and \
+                getattr(getattr(op, 'p', None), 'out_to_global', 0):
             # the element's pass has not been launched: the image is made in its tail, the
             # global beam is not written unless somebody else asks for it (sources.LazyBeam)
             return op.image_on(self, rec)
