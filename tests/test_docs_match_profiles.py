@@ -65,3 +65,30 @@ def test_profile_index_is_whole():
     assert len(text.splitlines()) < 200 and len(text) < 60_000
     missing = [f for f in sorted(os.listdir(pdir)) if f != 'README.md' and f not in text]
     assert not missing, missing
+
+
+def test_counter_traffic_belongs_to_the_timed_launch():
+    """profiles/hbm_traffic.json's figures under the headline are those of the launches
+    bench.py times -- the full passes, 308 B (cfg2) and 416 B (cfg3) per ray -- not of the
+    200-B forms that leave the local beams out (the file once held the
+    latter while the bench line and this document quoted it for the former); the 200-B forms
+    have entries of their own; DESIGN.md quotes the file's GB; bench.py hands out a figure only
+    for a launch of the matching shape."""
+    import importlib.util
+    import json
+    with open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')) as f:
+        t = json.load(f)
+    n = t['_calibration']['rays']
+    for kernel, per_ray in (('reflect_fused', 308.), ('reflect_fused_dcm', 416.),
+                            ('reflect_fused_nolocal', 200.), ('reflect_fused_dcm_nolocal', 200.)):
+        ratio = t[kernel]['hbm_bytes_per_launch'] / (per_ray * n)
+        assert 0.97 <= ratio <= 1.15, (kernel, ratio)
+    text = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    gb = quoted(text, r'PMC ([\d.]+) GB moved \(`hbm_traffic.json`\)')
+    assert abs(gb - t['reflect_fused']['hbm_bytes_per_launch'] / 1e9) < 0.006
+    spec = importlib.util.spec_from_file_location('bench_for_test', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.load_traffic('reflect_fused', 308. * n) == t['reflect_fused']['hbm_bytes_per_launch']
+    assert bench.load_traffic('reflect_fused_nolocal', 308. * n) is None     # another shape
+    assert bench.load_traffic('reflect_fused', 200. * n) is None

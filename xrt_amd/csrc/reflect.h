@@ -28,6 +28,29 @@
 
 namespace xrt {
 
+// Kernels that synchronise their blocks with grid barriers (reflect_exact, reflect_dcm_exact,
+// reflect_redo_scr, reflect_multi: every block must be resident) are safe alone on the device
+// and in stream order; two of them launched on DIFFERENT streams (run_ray_tracing(threads=N):
+// one stream per worker, the reference's xrt/runner.py:311-320) could be co-scheduled half
+// resident each and spin on one another. While a process has used ONE stream for them this
+// guard costs a mutex and nothing on the device; from the moment a second stream shows up
+// (one hipDeviceSynchronize, once) every such launch waits for the event recorded behind the
+// previous one -- on the device, the host does not block -- so that they run one after another
+// whatever their streams ("re-entrant per device or serialise"). Launches recorded
+// into a HIP graph are left alone (one worker records and replays, runner.py).
+class BarrierSerial {
+ public:
+  explicit BarrierSerial(hipStream_t st);
+  ~BarrierSerial();
+  BarrierSerial(const BarrierSerial&) = delete;
+  BarrierSerial& operator=(const BarrierSerial&) = delete;
+
+ private:
+  hipStream_t st_;
+  int dev_;
+  bool chain_;
+};
+
 // batch-global decisions of one pass, kept in device memory (workspace head)
 struct GStat {
   double maxa, maxb, maxc;           // max |a|,|b|,|c| over entering rays with state 1

@@ -3,12 +3,60 @@
 // translation units (reflect_tu.h).
 #define XRT_REFLECT_MAIN_TU
 #include <string.h>
+
+#include <mutex>
+
 #include "reflect_impl.h"
 #include "reflect_tu.h"
 #include "screen.h"
 #include "source.h"
 
 namespace xrt {
+
+// ---- BarrierSerial (reflect.h) ---------------------------------------------------------------
+namespace {
+constexpr int kMaxDev = 16, kRing = 32;
+struct BarrierChain {
+  bool seen = false, multi = false;
+  hipStream_t only = nullptr;
+  hipEvent_t ring[kRing] = {};
+  hipEvent_t last = nullptr;
+  unsigned head = 0;
+};
+std::mutex g_barrier_mu;
+BarrierChain g_barrier[kMaxDev];
+}  // namespace
+
+BarrierSerial::BarrierSerial(hipStream_t st) : st_(st), dev_(0), chain_(false) {
+  g_barrier_mu.lock();
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) (void)hipGetLastError();
+  if (cap != hipStreamCaptureStatusNone) return;       // (recorded into a graph: one worker)
+  if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= kMaxDev) dev_ = 0;
+  BarrierChain& C = g_barrier[dev_];
+  if (!C.seen) {
+    C.seen = true;
+    C.only = st;
+  } else if (!C.multi && st != C.only) {
+    // a second stream: whatever the first one still has in flight ends before this launch,
+    // and from now on the launches are chained by events
+    (void)hipDeviceSynchronize();
+    C.multi = true;
+  }
+  chain_ = C.multi;
+  if (chain_ && C.last) (void)hipStreamWaitEvent(st, C.last, 0);
+}
+
+BarrierSerial::~BarrierSerial() {
+  if (chain_) {
+    BarrierChain& C = g_barrier[dev_];
+    hipEvent_t& e = C.ring[C.head++ % kRing];
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    if (e && hipEventRecord(e, st_) == hipSuccess) C.last = e;
+  }
+  g_barrier_mu.unlock();
+}
+
 
 // ---------------------------------------------------------------------------
 // The surface functions of an element, for the host classes: OE.local_z / local_n /
@@ -695,6 +743,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                   tu_layered_fused(spec, mode, FL);
   };
   auto launch_exact = [&]() {
+    BarrierSerial one_at_a_time(st);      // (grid barriers: reflect.h)
     if (unit)
       launched &= unit->exact(&XL) == 0;
     else if (figured)
@@ -722,13 +771,19 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     launched &= tu_hot_fused_gen_scr(spec, FL);
     if (evk1) (void)hipEventRecord(evk1, st);
     // verdict, and only if it was contradicted: the source's beam, the exact sequence, the image
-    tu_exact0_redo_scr(XL, *scr, *sb, src);
+    {
+      BarrierSerial one_at_a_time(st);
+      tu_exact0_redo_scr(XL, *scr, *sb, src);
+    }
   } else if (fuse_screen) {
     hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, g);
     if (evk0) (void)hipEventRecord(evk0, st);
     launch_fused(0);
     if (evk1) (void)hipEventRecord(evk1, st);
-    tu_exact0_redo_scr(XL, *scr, *sb, nullptr);
+    {
+      BarrierSerial one_at_a_time(st);
+      tu_exact0_redo_scr(XL, *scr, *sb, nullptr);
+    }
   } else if (optimistic) {
     // assumptions from the head of the beam -> the pass on them, every ray checking ->
     // reflect_exact: folds the reports, returns at once unless one was contradicted
@@ -833,7 +888,10 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
   DcmLaunch XD = DL;
   XD.grid = dim3(exact_blocks(n));
   XD.block = dim3(REFLECT_EXACT_BLOCK);
-  tu_exact0_dcm(XD);
+  {
+    BarrierSerial one_at_a_time(st);
+    tu_exact0_dcm(XD);
+  }
   if (force_exact && evk1) (void)hipEventRecord(evk1, st);
   if (ev1) (void)hipEventRecord(ev1, st);
   return hipGetLastError();

@@ -82,6 +82,7 @@ hipError_t reflect_bounce_launch(const xrt_hip_pass& P, const xrt_hip_material& 
   for (int k = 0; k < 3; ++k) L.A.spr[k] = B.spr_out[k];
   hipLaunchKernelGGL(multi_init, dim3(1), dim3(1), 0, st, W.g);
   bool launched;
+  BarrierSerial one_at_a_time(st);        // (grid barriers between the phases: reflect.h)
   if (P.surf_kind == XRT_HIP_SURF_USER) {
     const UserUnit* unit = static_cast<const UserUnit*>(P.user_unit);
     if (!unit || !unit->multi) return hipErrorInvalidValue;
