@@ -857,6 +857,62 @@ XRT_HIP_API int xrt_hip_plot_hist_ws_f64_dev(
     double* hist_y, double* hist_c, double* counters, void* workspace, size_t workspace_bytes,
     void* stream);
 
+/* ---- a plot in the tail of a pass (round 6) -------------------------------------------------
+ * run_ray_tracing adds the image of a screen to an XYCPlot right after the pass that made it
+ * (xrt/multipro.py:316-361 after raycing/__init__.py:170-300: get_output, do_hist2d). When
+ * nothing else reads that image the plot joins the pass as Screen.expose does: the tail of
+ * the ray kernel takes the image record from its registers, forms weight, hue and bins, every
+ * wave sorts its 64 rays by tile of the 2-D histogram and writes 20-B records; two small
+ * kernels inside the same call add them up into the accumulators. The image itself (100 B per
+ * ray) is written only on request (keep_screen); what xrt_hip_plot_hist_ws_f64_dev would have
+ * read (44 B per ray) and its sorting pass disappear.
+ * x_field / y_field / c_field: which quantity of the IMAGE each axis shows. Accumulators as in
+ * xrt_hip_plot_hist_ws_f64_dev, all of hist2d, hist2d_rgb, hist_x, hist_y and counters
+ * present (hist_c optional). workspace: DEVICE scratch of xrt_hip_plot_tail_workspace_bytes
+ * (0 bytes = this plot cannot ride a pass: more than 2046 bins along x or y, more than 510 colour
+ * bins, more than 56 tiles). Sums are formed in another order than by the stand-alone kernels:
+ * equal to ~1e-15 relative, bins and counts identical. */
+enum {
+  XRT_HIP_FIELD_X = 0, XRT_HIP_FIELD_Y = 1, XRT_HIP_FIELD_Z = 2, XRT_HIP_FIELD_A = 3,
+  XRT_HIP_FIELD_B = 4, XRT_HIP_FIELD_C = 5, XRT_HIP_FIELD_PATH = 6, XRT_HIP_FIELD_E = 7,
+  XRT_HIP_FIELD_XPRIME = 8, XRT_HIP_FIELD_ZPRIME = 9
+};
+typedef struct xrt_hip_plot_tail {
+  xrt_hip_plot plot;
+  int32_t x_field, y_field, c_field;
+  int32_t reserved;
+  double *hist2d, *hist2d_rgb, *hist_x, *hist_y, *hist_c, *counters;
+  void* workspace;
+  size_t workspace_bytes;
+} xrt_hip_plot_tail;
+XRT_HIP_API int xrt_hip_plot_tail_workspace_bytes(int64_t nrays, const xrt_hip_plot_tail* tail,
+                                                  size_t* bytes);
+/* 1: this pass would carry screen and plot in its tail (a lean mirror / plate kernel, a flat
+ * screen, a plot the tail can serve); 0: use xrt_hip_reflect_screen_f64_dev and the histogram
+ * call. */
+XRT_HIP_API int xrt_hip_reflect_screen_plot_fusable(const xrt_hip_pass* pass,
+                                                    const xrt_hip_material* material,
+                                                    const struct xrt_hip_screen* screen,
+                                                    const xrt_hip_plot_tail* tail, int64_t nrays);
+/* xrt_hip_reflect_screen_f64_dev / xrt_hip_shine_reflect_screen_f64_dev with the plot behind
+ * the screen. keep_screen = 0: nobody else reads the image -- out_screen may be NULL.
+ * Refused (XRT_HIP_ERR_ARG) where xrt_hip_reflect_screen_plot_fusable says 0. *fused: bit 0
+ * screen, bit 1 source, bit 2 plot. A contradicted optimistic pass is redone inside the call
+ * and the records are made from the real image (reflect_redo_scr). */
+XRT_HIP_API int xrt_hip_reflect_screen_plot_f64_dev(
+    const xrt_hip_pass* pass, const xrt_hip_material* material, const xrt_hip_beam* in,
+    const xrt_hip_beam* restore, xrt_hip_beam* out_local, xrt_hip_beam* out_virgin,
+    double* theta, const struct xrt_hip_screen* screen, xrt_hip_beam* out_screen,
+    int keep_virgin, int keep_screen, const xrt_hip_plot_tail* tail, void* workspace,
+    size_t workspace_bytes, void* stream, int* fused);
+XRT_HIP_API int xrt_hip_shine_reflect_screen_plot_f64_dev(
+    const struct xrt_hip_geosource* source, const xrt_hip_pass* pass,
+    const xrt_hip_material* material, xrt_hip_beam* source_beam, xrt_hip_beam* out_local,
+    xrt_hip_beam* out_virgin, double* theta, const struct xrt_hip_screen* screen,
+    xrt_hip_beam* out_screen, int keep_virgin, int keep_screen, const xrt_hip_plot_tail* tail,
+    void* workspace, size_t workspace_bytes, void* stream, int* fused);
+
+
 /* ---- undulator field integral -------------------------
  * Replaces run_parallel('undulator' | 'undulator_taper' | 'undulator_nf', ...)
  * as issued by Undulator._build_I_map_CL (sources/synchr.py:2110-2176; kernels

@@ -66,6 +66,9 @@ def test_screen_in_the_tail_of_the_pass_is_the_two_launches(amplitudes):
     assert type(gb) is rs.LazyBeam and gb.__dict__['_op'].state == 'pending'
     img = scr.expose(gb)
     op = gb.__dict__['_op']
+    # (round 6: the image is handed out before the launch as well -- a plot may still join)
+    assert type(img) is rs.LazyBeam and op.state == 'pending' and not img.__dict__['_filled']
+    assert img.nrays == beam.nrays              # looked at: the pass with the screen in its tail
     assert op.state == 'imaged' and not gb.__dict__['_filled']        # the lean kernel took it
     same(img, img0, 'image')
     same(lb, lb0, 'local', extra=('theta',))
@@ -127,6 +130,7 @@ def test_elements_whose_kernels_do_not_carry_a_screen():
     gb0, lb0, img0 = eager(xt, scr, beam)
     gb, lb = xt.reflect(beam)
     img = scr.expose(gb)
+    assert img.nrays == beam.nrays
     assert gb.__dict__['_filled'] and not lb.__dict__['_filled']
     same(img, img0, 'image')
     same(gb, gb0, 'global')
@@ -243,6 +247,7 @@ def run_chain(bl, amplitudes, fuse):
         src = bl.source.shine(withAmplitudes=amplitudes)
         gb, lb = bl.mirror.reflect(src)
         img = bl.screen.expose(gb)
+        img.nrays                   # (the first look at the image launches the pass)
     finally:
         roe.fuseConsumers = old
     return src, gb, lb, img
@@ -637,7 +642,7 @@ def test_an_aperture_on_the_source_beam_after_the_fused_pass():
     s1 = bl.source.shine()
     g1, l1 = bl.mirror.reflect(s1)
     i1 = bl.screen.expose(g1)
-    assert s1.__dict__['_op'].state == 'inflight'
+    assert i1.nrays == 30000 and s1.__dict__['_op'].state == 'inflight'
     slit.propagate(s1)
     assert (s1.state < 0).sum() > 100 and not l1.__dict__['_filled']
     same(i1, i0, 'image')
@@ -795,3 +800,209 @@ def test_multiple_reflect_refuses_no_bounce_at_all():
     bl, oe, scr, beam = scene(n=1000)
     with pytest.raises(ValueError):
         oe.multiple_reflect(beam, maxReflections=0)
+
+
+# ---- the plot in the tail of the pass (round 6) -----------------------------------------------------
+def _plot(bins=256, **kw):
+    """The XYCPlot of workloads.e2e_beamline with fixed limits around the focus."""
+    return xrtp.XYCPlot('focus', (1,),
+                        xaxis=xrtp.XYCAxis('x', 'mm', limits=[-0.4, 0.4], bins=bins),
+                        yaxis=xrtp.XYCAxis('z', 'mm', limits=[-0.05, 0.05], bins=bins),
+                        caxis=xrtp.XYCAxis('energy', 'eV', limits=[8989., 9011.], bins=128), **kw)
+
+
+def _same_plot(p, q, what):
+    """Bins and counts identical; sums to rounding (another order of addition)."""
+    for name in ('total2D', 'total2D_RGB'):
+        a, b = getattr(p, name), getattr(q, name)
+        assert (a != 0).sum() > 50, (what, name)
+        assert np.array_equal(a != 0, b != 0), (what, name)
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (what, name, np.abs(a - b).max())
+    for axis in ('xaxis', 'yaxis', 'caxis'):
+        a, b = getattr(p, axis).total1D4, getattr(q, axis).total1D4
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (what, axis)
+    for name in ('nRaysAll', 'nRaysSelected', 'nRaysAlive', 'nRaysGood', 'nRaysOut', 'nRaysOver',
+                 'nRaysDead'):
+        assert getattr(p, name) == getattr(q, name), (what, name)
+    for name in ('intensity', 'intensityInRange'):
+        assert abs(getattr(p, name) - getattr(q, name)) <= 1e-12 * abs(getattr(q, name)), (what, name)
+
+
+def _plot_chain(bl, amp, fuse, plot, look=(), source=True, beam=None):
+    """source -> mirror -> screen -> plot as run_ray_tracing's iteration does it; *look*: beams
+    the script looks at AFTER the plot."""
+    old = roe.fuseConsumers
+    roe.fuseConsumers = fuse
+    try:
+        if source:
+            bl.source._calls = 0
+            src = bl.source.shine(withAmplitudes=amp)
+        else:
+            src = beam
+        gb, lb = bl.mirror.reflect(src)
+        img = bl.screen.expose(gb)
+        xrtr.accumulate_plot(plot, {'focus': img})
+        rs.flush_pending()
+        beams = dict(src=src, gb=gb, lb=lb, img=img)
+        for name in look:
+            beams[name].nrays
+    finally:
+        roe.fuseConsumers = old
+    return beams
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+@pytest.mark.parametrize('bins', [64, 256])
+def test_the_plot_rides_in_the_tail_of_the_pass(amplitudes, bins):
+    """accumulate_plot of the image of a pending pass: weight, hue and bins of every ray come from
+    the registers of the ray kernel (reflect_fused_gen_scr_plot / reflect_fused_scr_plot), the
+    image is not written; the plot equals the one the separate launches fill, and every beam
+    that was left out is made on demand, bit-identical."""
+    bl, amp = source_scene(n=300000, amplitudes=amplitudes)
+    p0, p1 = _plot(bins), _plot(bins)
+    b0 = _plot_chain(bl, amp, False, p0)
+    b1 = _plot_chain(bl, amp, True, p1)
+    op = b1['gb'].__dict__['_op']
+    assert op.state == 'imaged' and not b1['img'].__dict__['_filled']
+    assert not b1['gb'].__dict__['_filled'] and b1['src'].__dict__['_op'].state == 'inflight'
+    _same_plot(p1, p0, 'source in the head')
+    assert p1.nRaysAll == 300000 and p1.iteration == 1
+    # the image nobody had asked for: the same rays, and the screen remembers
+    same(b1['img'], b0['img'], 'image on demand')
+    assert bl.screen.__dict__['_image_wanted']
+    same(b1['lb'], b0['lb'], 'local on demand', extra=('theta',))
+    same(b1['gb'], b0['gb'], 'global on demand')
+    same(b1['src'], b0['src'], 'source on demand')
+    # ... from now on the pass writes the image as well (and the other beams that were wanted)
+    p2 = _plot(bins)
+    b2 = _plot_chain(bl, amp, True, p2)
+    assert b2['img'].__dict__['_filled'] and b2['gb'].__dict__['_filled']
+    _same_plot(p2, p0, 'image kept')
+    same(b2['img'], b0['img'], 'image written by the pass')
+    # a resident beam instead of the device source (reflect_fused_scr_plot)
+    bl, amp = source_scene(n=300000, amplitudes=amplitudes)
+    rays = workloads.synthetic_rays(250000, 5, amplitudes=amplitudes)
+    rays.state[::97] = -3
+    rays.state[5::101] = 2
+    rays.x[::53] *= 300.
+    q0, q1 = _plot(bins, rayFlag=(1, 2, 3, -1)), _plot(bins, rayFlag=(1, 2, 3, -1))
+    c0 = _plot_chain(bl, amp, False, q0, source=False, beam=rays)
+    c1 = _plot_chain(bl, amp, True, q1, source=False, beam=rays)
+    assert c1['gb'].__dict__['_op'].state == 'imaged' and not c1['img'].__dict__['_filled']
+    _same_plot(q1, q0, 'resident beam')
+    same(c1['img'], c0['img'], 'image on demand, resident beam')
+
+
+def test_plots_that_do_not_ride():
+    """Automatic limits, a second plot of the same beam, another beam's states, an axis the tail
+    does not know: the usual route, the same numbers."""
+    bl, amp = source_scene(n=100000)
+    p0 = _plot()
+    _plot_chain(bl, amp, False, p0)
+    auto = xrtp.XYCPlot('focus', (1,), xaxis=xrtp.XYCAxis('x', 'mm', bins=64),
+                        yaxis=xrtp.XYCAxis('z', 'mm', bins=64),
+                        caxis=xrtp.XYCAxis('energy', 'eV', bins=32))
+    b = _plot_chain(bl, amp, True, auto)
+    assert b['img'].__dict__['_filled'] and auto.xaxis.limits is not None
+    # two plots of one beam: neither rides (the image is read twice anyway)
+    pa, pb = _plot(), _plot(128)
+    roe.fuseConsumers = True
+    bl.source._calls = 0
+    gb, lb = bl.mirror.reflect(bl.source.shine())
+    img = bl.screen.expose(gb)
+    for plot in (pa, pb):
+        xrtr.accumulate_plot(plot, {'focus': img}, sole=False)
+    assert img.__dict__['_filled']
+    _same_plot(pa, p0, 'one of two plots')
+
+
+def test_a_contradicted_pass_with_a_plot_in_its_tail():
+    """The optimistic pass is contradicted (Brent's method: golden g2_toroid_brent): the redo
+    makes the plot's records from the real image (reflect_redo_scr)."""
+    import p1_cases
+    g = np.load(os.path.join(p1_cases.GOLDEN, 'g2_toroid_brent.npz'))
+    oe = p1_cases.product_oe('g2_toroid_brent', g)
+    beam = p1_cases.product_beam(g)
+    scr = rsc.Screen(oe.bl, 'after', center=[0, float(g['oe_center'][1]) + 3000., 10.])
+
+    def plot():
+        return xrtp.XYCPlot('after', (1, 2, 3, -1),
+                            xaxis=xrtp.XYCAxis('x', 'mm', limits=[-30., 30.], bins=96),
+                            yaxis=xrtp.XYCAxis('z', 'mm', limits=[-40., 40.], bins=160),
+                            caxis=xrtp.XYCAxis('energy', 'eV', limits=[1000., 30000.], bins=64))
+    gb0, lb0, img0 = eager(oe, scr, beam)
+    p0, p1 = plot(), plot()
+    roe.fuseConsumers = False
+    try:
+        xrtr.accumulate_plot(p0, {'after': img0})
+    finally:
+        roe.fuseConsumers = True
+    gb, lb = oe.reflect(beam)
+    img = scr.expose(gb)
+    xrtr.accumulate_plot(p1, {'after': img})
+    assert gb.__dict__['_op'].state == 'imaged' and not img.__dict__['_filled']
+    for name in ('total2D', 'total2D_RGB'):
+        a, b = getattr(p1, name), getattr(p0, name)
+        assert np.array_equal(a != 0, b != 0) and np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+    assert p1.nRaysGood == p0.nRaysGood and p1.nRaysDead == p0.nRaysDead
+    assert abs(p1.intensity - p0.intensity) <= 1e-12 * abs(p0.intensity)
+    same(img, img0, 'image on demand after the redo')
+    same(gb, gb0, 'global')
+
+
+def test_the_fused_chain_against_the_oracle_directly():
+    """the fused kernels were pinned only through the immediate launches. Here the
+    whole chain at 1e6 rays -- device source -> toroid mirror -> screen -> plot as ONE pass --
+    against the oracle: geosource_np -> reflect_np.oe_reflect -> elements_np.screen_expose ->
+    numpy histograms (reference: geoms.py:420-535, oes/reflect.py:18-163, screens.py:226-302,
+    multipro.py:316-361). States bit for bit, geometry 1e-12, the plot 1e-12."""
+    from oracle import elements_np as en, geosource_np as og, reflect_np as rn
+    from oracle.adapters import oracle_params
+    n = 1_000_000
+    bl = raycing.BeamLine()
+    bl.source = rs.GeometricSource(bl, 'source', nrays=n, dx=0.1, dz=0.1, dxprime=2e-4,
+                                   dzprime=2e-5, distE='flat', energies=(8990., 9010.),
+                                   polarization='h', rng='device', seed=23)
+    bl.mirror = workloads.cfg2_toroid(bl)
+    bl.screen = rsc.Screen(bl, 'focus', center=[0, 20000. + 10000. * np.cos(8e-3),
+                                                10000. * np.sin(8e-3)])
+    plot = _plot(256, rayFlag=(1, 2))
+    b = _plot_chain(bl, False, True, plot)
+    assert b['gb'].__dict__['_op'].state == 'imaged' and not b['img'].__dict__['_filled']
+    # the oracle's chain
+    born = og.shine(og.Spec(n, seed=23, call=0, dx=0.1, dz=0.1, dxprime=2e-4, dzprime=2e-5,
+                            distE='flat', energies=(8990., 9010.), azimuth=(1., 0.),
+                            center=(0, 0, 0)))
+    ob = rn.Beam(n, with_amplitudes=False)
+    for f in ob.fields():
+        if f in born:
+            setattr(ob, f, np.array(born[f]))
+    # (the normal laws of the device generator agree with the oracle's libm to 1e-14: the rays
+    # the GPU made are the input of the oracle's pass, their uniform laws checked bit for bit)
+    src = b['src']
+    assert np.array_equal(src.peek('E'), born['E'])
+    for f in ('x', 'z', 'a', 'c'):
+        assert np.abs(src.peek(f) - born[f]).max() <= 1e-14 * np.abs(born[f]).max(), f
+    for f in ob.fields():
+        setattr(ob, f, np.array(src.peek(f)))
+    ogb, olb = rn.oe_reflect(oracle_params(bl.mirror), ob)
+    oimg = en.screen_expose(ogb, (bl.screen.x, bl.screen.y, bl.screen.z), bl.screen.center,
+                            bl.screen.lostNum)
+    img = b['img']
+    assert np.array_equal(img.state, oimg.state)
+    for f in ('x', 'z', 'path'):
+        r = getattr(oimg, f)
+        assert np.abs(getattr(img, f) - r).max() <= 1e-12 * np.abs(r).max(), f
+    sel = (oimg.state == 1) | (oimg.state == 2)
+    w = (oimg.Jss + oimg.Jpp)[sel]
+    h2, _, _ = np.histogram2d(oimg.z[sel], oimg.x[sel], bins=[256, 256],
+                              range=[[-0.05, 0.05], [-0.4, 0.4]], weights=w)
+    assert h2.sum() > 0.5 * w.sum()
+    assert np.abs(plot.total2D - h2).max() <= 1e-12 * h2.max()
+    hx, _ = np.histogram(oimg.x[sel], bins=256, range=(-0.4, 0.4), weights=w)
+    hc, _ = np.histogram(oimg.E[sel], bins=128, range=(8989., 9011.), weights=w)
+    assert np.abs(plot.total1D_x - hx).max() <= 1e-12 * hx.max()
+    assert np.abs(plot.total1D_c - hc).max() <= 1e-12 * hc.max()
+    assert plot.nRaysGood == int((oimg.state == 1).sum())
+    assert plot.nRaysOut == int((oimg.state == 2).sum())
+    assert plot.nRaysDead == int((oimg.state < 0).sum())

@@ -246,6 +246,28 @@ class Plot(ctypes.Structure):
                 ('flux_kind', ctypes.c_int32)]
 
 
+# which quantity of a screen's image a plot axis shows (XRT_HIP_FIELD_*)
+PLOT_FIELDS = {'x': 0, 'y': 1, 'z': 2, 'a': 3, 'b': 4, 'c': 5, 'path': 6, 'E': 7,
+               'xprime': 8, 'zprime': 9}
+
+
+class PlotTail(ctypes.Structure):
+    """xrt_hip_plot_tail: an XYCPlot in the tail of a pass (include/xrt_hip.h)."""
+    _fields_ = [('plot', Plot),
+                ('x_field', ctypes.c_int32),
+                ('y_field', ctypes.c_int32),
+                ('c_field', ctypes.c_int32),
+                ('reserved', ctypes.c_int32),
+                ('hist2d', ctypes.c_void_p),
+                ('hist2d_rgb', ctypes.c_void_p),
+                ('hist_x', ctypes.c_void_p),
+                ('hist_y', ctypes.c_void_p),
+                ('hist_c', ctypes.c_void_p),
+                ('counters', ctypes.c_void_p),
+                ('workspace', ctypes.c_void_p),
+                ('workspace_bytes', ctypes.c_size_t)]
+
+
 class CustomField(ctypes.Structure):
     _fields_ = [('filament', ctypes.c_int32),
                 ('near_field', ctypes.c_int32),
@@ -320,4 +342,4 @@ class Bounce(ctypes.Structure):
 
 
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
-           UndulatorMap, Plot, CustomField, Bend, Multilayer, Gauss, GeoSource, Bounce)
+           UndulatorMap, Plot, CustomField, Bend, Multilayer, Gauss, GeoSource, Bounce, PlotTail)

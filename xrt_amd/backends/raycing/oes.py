@@ -882,6 +882,8 @@ class _DeferredReflect(object):
         if raycing.is_sequence(material):
             material = material[oe.curSurface]
         self.material = material
+        self.n = self.src_op.n if self.src_op is not None else snap.nrays
+        self.screen = self.screen_rec = self.image = None
         self.state = 'pending'
         self.gb, self.lb = rs.LazyBeam(self, 'gb'), rs.LazyBeam(self, 'lb')
         oe._adopt((self.gb, self.lb), beam)
@@ -903,9 +905,23 @@ class _DeferredReflect(object):
         self.optional = True
         rs._PENDING.add(self)
 
+    def expose_later(self, screen, rec):
+        """Screen.expose of the global beam while the pass is still pending: the image is handed
+        out before anything is launched as well, so that a plot of it may still join the pass
+        (plot_on: run_ray_tracing's accumulate_plot). Whoever looks at a beam first launches."""
+        self.screen, self.screen_rec = screen, rec
+        self.image = rs.LazyBeam(self, 'image')
+        rs.inherit_scalars(self.image, self.beam)
+        return self.image
+
     def materialize(self, which=None):
         oe = self.oe
         filled = lambda b: b.__dict__['_filled']      # noqa: E731
+        if self.state == 'pending' and self.screen_rec is not None:
+            # the pass with the screen in its tail; then the beam asked for, if it was left out
+            self._launch_with_screen()
+            if which in (None, 'image') or filled(self.gb if which == 'gb' else self.lb):
+                return
         if self.state == 'pending':
             rs._PENDING.discard(self)
             # (the state changes when the launch has returned: one that raises is raised again
@@ -922,6 +938,20 @@ class _DeferredReflect(object):
             self.state = 'done'
             self.lb._adopt_arrays(lb)
             self.gb._adopt_arrays(gb)
+        elif self.state in ('global', 'imaged') and which == 'image':
+            # the image of a pass that fed a plot and nothing else (plot_on): the pass with the
+            # screen again -- and the screen remembers: next time the image is written as well
+            if self.image is not None and not filled(self.image):
+                self.screen.__dict__['_image_wanted'] = True
+                rays = self.beam
+                if type(rays) is rs.LazyBeam:      # (a source's, not made when the pass ran)
+                    rays = self.src_op.rays_again()
+                _, _, image, _ = oe._run_pass_screen(self.p, self.material, rays, self.screen_rec,
+                                                     keep_global=False, local=False)
+                self.image._adopt_arrays(image)
+            if filled(self.lb) and filled(self.gb):
+                rs._PENDING.discard(self)
+                self.state = 'done'
         elif self.state in ('global', 'imaged'):
             # somebody wants a beam that was left out after all: the pass again -- and the
             # element remembers: next time its pass writes that beam as well
@@ -940,39 +970,63 @@ class _DeferredReflect(object):
                     self.lb._adopt_arrays(lb)
                 if want_gb:
                     self.gb._adopt_arrays(gb)
-            if filled(self.lb) and filled(self.gb):
+            if filled(self.lb) and filled(self.gb) and (self.image is None or
+                                                        filled(self.image)):
                 rs._PENDING.discard(self)
                 self.state = 'done'
         if self.state == 'done':
             self.beam, self.tensors = None, ()
 
-    def image_on(self, screen, rec):
-        """The pass with *screen* in its tail -> the screen's image (a plain Beam)."""
+    def _launch_with_screen(self, plot=None):
+        """The pass with the screen in its tail (and *plot*, a _structs.PlotTail showing the
+        screen's image, behind it) -> True; False if *plot* cannot ride this pass (nothing
+        has been launched then)."""
         oe = self.oe
-        rs._PENDING.discard(self)
         src = self.src_op
         tabulated = isinstance(getattr(self.material, 'refractiveIndex', None), list)
         keep = bool(oe.__dict__.get('_global_beam_wanted'))
+        keep_image = plot is None or bool(self.screen.__dict__.get('_image_wanted'))
         local = not _locals_on_demand(oe, self.material)
-        if src is not None and src.state == 'pending' and not tabulated:
-            lb, gb, image, fused = oe._run_pass_screen(self.p, self.material, None, rec, source=src,
-                                                       keep_global=keep, local=local)
-        else:
-            lb, gb, image, fused = oe._run_pass_screen(self.p, self.material, self.beam, rec,
-                                                       keep_global=keep, local=local)
+        from_source = src is not None and src.state == 'pending' and not tabulated
+        made = oe._run_pass_screen(self.p, self.material, None if from_source else self.beam,
+                                   self.screen_rec, source=src if from_source else None,
+                                   keep_global=keep, local=local, plot=plot,
+                                   keep_image=keep_image)
+        if made is None:
+            return False
+        rs._PENDING.discard(self)
+        lb, gb, image, fused = made
         if local:
             self.lb._adopt_arrays(lb)
         if fused and not keep:
             self._scratch = gb            # (the redo's scratch: freed with this record)
         else:
             self.gb._adopt_arrays(gb)
-        if local and not (fused and not keep):
+        if keep_image:
+            self.image._adopt_arrays(image)
+        if local and keep_image and not (fused and not keep):
             self.state = 'done'
             self.beam, self.tensors = None, ()
         else:
             self.state = 'imaged'
             self._waits_with_its_own_states()
+        return True
+
+    def image_on(self, screen, rec):
+        """The pass with *screen* in its tail, at once -> the screen's image."""
+        image = self.expose_later(screen, rec)
+        self._launch_with_screen()
         return image
+
+    def plot_on(self, tail):
+        """run_ray_tracing adds the screen's image to a plot and nothing else has looked at
+        it: the plot joins the pass (reference: raycing/__init__.py:170-300 + multipro.py:
+        316-361 right after screens.py:226-302). The image itself is written only if the
+        screen has been asked for it before (``_image_wanted``); -> False if this pass or this
+        plot cannot do that (nothing launched: the caller takes the usual route)."""
+        if self.state != 'pending' or self.screen_rec is None:
+            return False
+        return self._launch_with_screen(plot=tail)
 
 
 def _scratch_beam(role, n, dev, amplitudes):
@@ -1001,12 +1055,15 @@ _SCRATCH_RAYS = 2_000_000
 
 
 def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, keep_global=False,
-                     local=True):
+                     local=True, plot=None, keep_image=True):
     """OE.reflect + Screen.expose in one C call (xrt_hip_reflect_screen_f64_dev) ->
     (lb, gb, image, fused): fused = the lean kernel carried the screen and gb holds nothing;
     *local* False: no local beam either (lb None).
     *source* (a pending sources._DeferredShine, with beam_in None): the rays are made by the
-    source's record inside the same call (xrt_hip_shine_reflect_screen_f64_dev)."""
+    source's record inside the same call (xrt_hip_shine_reflect_screen_f64_dev).
+    *plot* (a _structs.PlotTail): the plot of the image behind the screen
+    (xrt_hip_reflect_screen_plot_f64_dev); the image itself only with *keep_image*. -> None,
+    and nothing is launched, if this pass cannot carry the plot."""
     _lib.require_gpu()
     lib = _lib.load()
     dev = _device()
@@ -1019,16 +1076,35 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
         n, amp, parent = beam_in.nrays, beam_in.has_amplitudes(), beam_in
         ms = self._material_struct(material, True, dev, beam_in)
         s_in = beam_in.to_struct(dev)
+    if plot is not None and not lib.xrt_hip_reflect_screen_plot_fusable(
+            ctypes.byref(p), ctypes.byref(ms), ctypes.byref(screen_record), ctypes.byref(plot), n):
+        return None
     # (the global beam nobody keeps: the redo's scratch)
     gb = rs.Beam.empty_on_device(n, dev, amp) if keep_global else _scratch_beam('global', n, dev, amp)
-    image = rs.Beam.empty_on_device(n, dev, amp)
+    image = rs.Beam.empty_on_device(n, dev, amp) if keep_image else None
+    image_ref = ctypes.byref(image.to_struct(dev)) if keep_image else None
     lb = rs.Beam.empty_on_device(n, dev, amp) if local else None
     theta = torch.empty(n, dtype=torch.float64, device=dev) if local else None
     lb_ref = ctypes.byref(lb.to_struct(dev)) if local else None
     theta_ref = ctypes.c_void_p(theta.data_ptr()) if local else None
     ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(n), 'reflect')
     fused = ctypes.c_int(0)
-    if source is not None:
+    if source is not None and plot is not None:
+        _lib.check(lib.xrt_hip_shine_reflect_screen_plot_f64_dev(
+            ctypes.byref(source.g), ctypes.byref(p), ctypes.byref(ms),
+            ctypes.byref(scratch.to_struct(dev)), lb_ref,
+            ctypes.byref(gb.to_struct(dev)), theta_ref,
+            ctypes.byref(screen_record), image_ref, int(keep_global), int(keep_image),
+            ctypes.byref(plot), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(),
+            ctypes.byref(fused)), 'xrt_hip_shine_reflect_screen_plot_f64_dev')
+    elif plot is not None:
+        _lib.check(lib.xrt_hip_reflect_screen_plot_f64_dev(
+            ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in),
+            lb_ref, ctypes.byref(gb.to_struct(dev)), theta_ref, ctypes.byref(screen_record),
+            image_ref, int(keep_global), int(keep_image), ctypes.byref(plot),
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(), ctypes.byref(fused)),
+            'xrt_hip_reflect_screen_plot_f64_dev')
+    elif source is not None:
         _lib.check(lib.xrt_hip_shine_reflect_screen_f64_dev(
             ctypes.byref(source.g), ctypes.byref(p), ctypes.byref(ms),
             ctypes.byref(scratch.to_struct(dev)), lb_ref,
@@ -1036,12 +1112,6 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
             ctypes.byref(screen_record), ctypes.byref(image.to_struct(dev)), int(keep_global),
             ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(), ctypes.byref(fused)),
             'xrt_hip_shine_reflect_screen_f64_dev')
-        if fused.value & 2:
-            rs._PENDING.discard(source)
-            source.state = 'inflight'       # (still makes its beam if somebody asks for it)
-        else:
-            _scratch_beam.taken('source', scratch)
-            source.adopt(scratch)           # the generator's own launch has filled it
     else:
         _lib.check(lib.xrt_hip_reflect_screen_f64_dev(
             ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in),
@@ -1049,12 +1119,20 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
             theta_ref, ctypes.byref(screen_record),
             ctypes.byref(image.to_struct(dev)), int(keep_global), ctypes.c_void_p(ws.data_ptr()),
             ws.numel(), _stream(), ctypes.byref(fused), None), 'xrt_hip_reflect_screen_f64_dev')
+    if source is not None:
+        if fused.value & 2:
+            rs._PENDING.discard(source)
+            source.state = 'inflight'       # (still makes its beam if somebody asks for it)
+        else:
+            _scratch_beam.taken('source', scratch)
+            source.adopt(scratch)           # the generator's own launch has filled it
     if local:
         lb._d['theta'] = theta
     if not (fused.value & 1):
         _scratch_beam.taken('global', gb)      # (it holds the element's global beam after all)
     self._adopt((lb, gb) if local else (gb,), parent)
-    rs.inherit_scalars(image, parent)
+    if image is not None:
+        rs.inherit_scalars(image, parent)
     return lb, gb, image, bool(fused.value & 1)
 
 

@@ -62,8 +62,12 @@ class Screen(object):
         if op is not None and getattr(op, 'gb', None) is beam and op.state == 'pending' and \
                 getattr(getattr(op, 'p', None), 'out_to_global', 0):
             # the element's pass has not been launched: the image is made in its tail, the
-            # global beam is not written unless somebody else asks for it (sources.LazyBeam)
-            return op.image_on(self, rec)
+            # global beam is not written unless somebody else asks for it (sources.LazyBeam).
+            # Nor is the pass launched now: the image is handed out first, a plot of it may
+            # still join (runner.accumulate_plot -> op.plot_on)
+            if op.screen_rec is None and type(self) is Screen:
+                return op.expose_later(self, rec)
+            op.materialize('gb')
         image = rs.Beam.empty_like_on_device(beam, dev)
         _lib.check(_lib.load().xrt_hip_screen_expose_f64_dev(
             ctypes.byref(rec), ctypes.byref(beam.to_struct(dev)),

@@ -256,6 +256,7 @@ int xrt_hip_sizeof(int which) {
     case 12: return (int)sizeof(xrt_hip_gauss);
     case 13: return (int)sizeof(xrt_hip_geosource);
     case 14: return (int)sizeof(xrt_hip_bounce);
+    case 15: return (int)sizeof(xrt_hip_plot_tail);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -411,6 +412,8 @@ struct OwnEvents {
 
 static int check_geosource(const xrt_hip_geosource* g);
 
+static int check_plot(const xrt_hip_plot* plot, bool with_c);
+
 static int reflect_pass_impl(const xrt_hip_pass* pass, const xrt_hip_material* material,
                              const xrt_hip_beam* in, const xrt_hip_beam* restore,
                              xrt_hip_beam* out_local, xrt_hip_beam* out_virgin, double* theta,
@@ -418,15 +421,36 @@ static int reflect_pass_impl(const xrt_hip_pass* pass, const xrt_hip_material* m
                              double* info_host, float* kernel_ms,
                              const xrt_hip_screen* screen, xrt_hip_beam* out_screen,
                              int keep_virgin, int* fused,
-                             const xrt_hip_geosource* source = nullptr) {
+                             const xrt_hip_geosource* source = nullptr,
+                             const xrt_hip_plot_tail* tail = nullptr, int keep_screen = 1) {
   const ArmedEvents armed;
   int rc;
   if ((rc = check_pass(pass, material))) return rc;
+  xrt_hip_beam no_image;
   if (screen) {
-    if (!in || !out_screen) return fail(XRT_HIP_ERR_ARG, "screen without its image beam");
-    if ((rc = check_beam(out_screen, "out_screen", in->n,
-                         in->Es_ri != nullptr || in->Ep_ri != nullptr)))
-      return rc;
+    if (!in) return fail(XRT_HIP_ERR_ARG, "screen without an incoming beam");
+    if (tail && !keep_screen && !out_screen) {
+      // (a plot behind the screen and nobody else reads the image: no image beam needed)
+      memset(&no_image, 0, sizeof(no_image));
+      no_image.n = in->n;
+      out_screen = &no_image;
+    } else {
+      if (!out_screen) return fail(XRT_HIP_ERR_ARG, "screen without its image beam");
+      if ((rc = check_beam(out_screen, "out_screen", in->n,
+                           in->Es_ri != nullptr || in->Ep_ri != nullptr)))
+        return rc;
+    }
+  }
+  xrt::PlotTailPlan plan;
+  if (tail) {
+    if (!screen) return fail(XRT_HIP_ERR_ARG, "a plot in the tail of a pass shows a screen's image");
+    if ((rc = check_plot(&tail->plot, false))) return rc;
+    if (!xrt_hip_reflect_screen_plot_fusable(pass, material, screen, tail, in->n))
+      return fail(XRT_HIP_ERR_ARG, "this pass does not carry screen and plot in its tail "
+                                   "(xrt_hip_reflect_screen_plot_fusable)");
+    if (xrt::plot_tail_plan(in->n, *tail, &plan, nullptr) != hipSuccess)
+      return fail(XRT_HIP_ERR_ARG, "plot tail: accumulators missing or workspace below "
+                                   "xrt_hip_plot_tail_workspace_bytes");
   }
   if (pass->is_multi || pass->need_elevation_map)
     return fail(XRT_HIP_ERR_ARG, "is_multi / need_elevation_map: a bounce of multiple_reflect "
@@ -479,7 +503,7 @@ static int reflect_pass_impl(const xrt_hip_pass* pass, const xrt_hip_material* m
   hipError_t e = xrt::reflect_pass_launch(*pass, *material, *in, *restore, *out_local,
                                           *out_virgin, theta, workspace, st, e0, e1, k0, k1,
                                           force_exact, screen, out_screen, keep_virgin != 0,
-                                          fused, source);
+                                          fused, source, tail ? &plan : nullptr, keep_screen != 0);
   if (e != hipSuccess) return fail(XRT_HIP_ERR_HIP, "reflect launch: %s", hipGetErrorString(e));
   if (kernel_ms) {
     HIP_TRY(hipEventSynchronize(e1));
@@ -557,6 +581,60 @@ int xrt_hip_reflect_screen_f64_dev(const xrt_hip_pass* pass, const xrt_hip_mater
   return reflect_pass_impl(pass, material, in, restore, out_local, out_virgin, theta, workspace,
                            workspace_bytes, stream, nullptr, kernel_ms, screen, out_screen,
                            keep_virgin, fused);
+}
+
+int xrt_hip_plot_tail_workspace_bytes(int64_t nrays, const xrt_hip_plot_tail* tail, size_t* bytes) {
+  if (!tail || !bytes) return fail(XRT_HIP_ERR_ARG, "NULL plot tail / result");
+  if (nrays < 0) return fail(XRT_HIP_ERR_ARG, "negative size");
+  int rc;
+  if ((rc = check_plot(&tail->plot, false))) return rc;
+  *bytes = 0;
+  if (nrays > 0) HIP_TRY(xrt::plot_tail_plan(nrays, *tail, nullptr, bytes));
+  return XRT_HIP_OK;
+}
+
+int xrt_hip_reflect_screen_plot_fusable(const xrt_hip_pass* pass, const xrt_hip_material* material,
+                                        const xrt_hip_screen* screen,
+                                        const xrt_hip_plot_tail* tail, int64_t nrays) {
+  if (!pass || !material || !screen || !tail || nrays <= 0) return 0;
+  const char* ex = getenv("XRT_HIP_REFLECT_EXACT");
+  if (ex && ex[0] == '1') return 0;
+  if (!pass->out_to_global || pass->is_multi || pass->need_elevation_map) return 0;
+  if (!xrt::reflect_pass_carries_screen(*pass, *material, *screen)) return 0;
+  size_t need = 0;
+  if (xrt::plot_tail_plan(nrays, *tail, nullptr, &need) != hipSuccess || need == 0) return 0;
+  return 1;
+}
+
+int xrt_hip_reflect_screen_plot_f64_dev(
+    const xrt_hip_pass* pass, const xrt_hip_material* material, const xrt_hip_beam* in,
+    const xrt_hip_beam* restore, xrt_hip_beam* out_local, xrt_hip_beam* out_virgin,
+    double* theta, const xrt_hip_screen* screen, xrt_hip_beam* out_screen, int keep_virgin,
+    int keep_screen, const xrt_hip_plot_tail* tail, void* workspace, size_t workspace_bytes,
+    void* stream, int* fused) {
+  if (!screen || !tail) return fail(XRT_HIP_ERR_ARG, "NULL screen / plot tail");
+  if (!pass || !pass->out_to_global)
+    return fail(XRT_HIP_ERR_ARG, "a screen takes the beam in the global frame (out_to_global)");
+  return reflect_pass_impl(pass, material, in, restore, out_local, out_virgin, theta, workspace,
+                           workspace_bytes, stream, nullptr, nullptr, screen, out_screen,
+                           keep_virgin, fused, nullptr, tail, keep_screen);
+}
+
+int xrt_hip_shine_reflect_screen_plot_f64_dev(
+    const xrt_hip_geosource* source, const xrt_hip_pass* pass, const xrt_hip_material* material,
+    xrt_hip_beam* source_beam, xrt_hip_beam* out_local, xrt_hip_beam* out_virgin, double* theta,
+    const xrt_hip_screen* screen, xrt_hip_beam* out_screen, int keep_virgin, int keep_screen,
+    const xrt_hip_plot_tail* tail, void* workspace, size_t workspace_bytes, void* stream,
+    int* fused) {
+  int rc;
+  if ((rc = check_geosource(source))) return rc;
+  if (!screen || !tail) return fail(XRT_HIP_ERR_ARG, "NULL screen / plot tail");
+  if (!pass || !pass->out_to_global || !pass->in_is_global || !source->to_global)
+    return fail(XRT_HIP_ERR_ARG, "source, element and screen meet in the global frame "
+                                 "(source to_global, pass in_is_global / out_to_global)");
+  return reflect_pass_impl(pass, material, source_beam, source_beam, out_local, out_virgin, theta,
+                           workspace, workspace_bytes, stream, nullptr, nullptr, screen,
+                           out_screen, keep_virgin, fused, source, tail, keep_screen);
 }
 
 int xrt_hip_double_reflect_fusable(const xrt_hip_pass* pass1, const xrt_hip_material* material1,

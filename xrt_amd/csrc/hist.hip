@@ -10,70 +10,9 @@
 #include "../../include/xrt_hip.h"
 #include "fp64_math.h"
 #include "hist.h"
+#include "plot_tail.h"
 
 namespace xrt {
-
-// One histogram axis: np.linspace(lo, hi, bins + 1) has edges[j] = j*step + lo with
-// step = (hi - lo)/bins (one division, one multiplication, one addition: formed here
-// with the same three roundings) and edges[bins] = hi exactly. `scale` only feeds the
-// first guess of the bin, which the edge tests then correct: any rounding of it will do.
-struct AxisBins {
-  double lo, hi, step, scale;
-  int bins;
-};
-static inline AxisBins axis_bins(double lo, double hi, int bins) {
-  AxisBins a;
-  a.lo = lo;
-  a.hi = hi;
-  a.step = (hi - lo) / (double)bins;
-  a.scale = (double)bins / (hi - lo);
-  a.bins = bins;
-  return a;
-}
-struct PlotAxes {
-  AxisBins x, y, c;
-};
-__device__ __forceinline__ double bin_edge(const AxisBins& a, int j) {
-  return j == a.bins ? a.hi : (double)j * a.step + a.lo;
-}
-// numpy's own search on uniform bins (lib/histograms.py: scale, truncate, one step down and one
-// step up against the real edges). The guess is within one bin of the answer for any axis
-// whose step is not lost in the rounding of its limits, and for monotone edges the result is
-// then searchsorted's (np.histogram2d), the last edge belonging to the last bin.
-__device__ __forceinline__ int find_bin(double v, const AxisBins& a) {
-  if (!(v >= a.lo && v <= a.hi)) return -1;
-  int b = (int)((v - a.lo) * a.scale);
-  b = min(max(b, 0), a.bins - 1);
-  b -= (b > 0 && v < (double)b * a.step + a.lo) ? 1 : 0;
-  b += (b < a.bins - 1 && v >= (double)(b + 1) * a.step + a.lo) ? 1 : 0;
-  return b;
-}
-
-// ---------------------------------------------------------------------------
-// All histograms of one XYCPlot in one pass (multipro.py:316-361): the 2-D
-// intensity histogram, its RGB twin colourised by the colour axis (hue = the
-// normalised colour datum, saturation, value = flux; matplotlib's hsv_to_rgb),
-// and the 1-D histograms of x, y and the colour datum, each with flux and RGB
-// weights. The 1-D histograms are independent of the 2-D range, like the three
-// separate np.histogram calls of the reference.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void hsv_to_rgb(double h, double s, double v, double& r, double& g,
-                                           double& b) {
-  const int i = (int)(h * 6.0);
-  const double f = h * 6.0 - (double)i;
-  const double p = v * (1.0 - s);
-  const double q = v * (1.0 - s * f);
-  const double t = v * (1.0 - s * (1.0 - f));
-  switch (i % 6) {
-    case 0: r = v; g = t; b = p; break;
-    case 1: r = q; g = v; b = p; break;
-    case 2: r = p; g = v; b = t; break;
-    case 3: r = p; g = q; b = v; break;
-    case 4: r = t; g = p; b = v; break;
-    default: r = v; g = p; b = q; break;
-  }
-  if (s == 0.) r = g = b = v;
-}
 
 // what one ray contributes to the histograms of a plot
 struct PlotRay {
@@ -390,16 +329,6 @@ __device__ __forceinline__ void load_tile_shares(const int* __restrict__ table, 
                                                  int* share) {
   if ((int)threadIdx.x <= T) share[threadIdx.x] = table[threadIdx.x];
   __syncthreads();
-}
-
-__device__ __forceinline__ bool ray_selected(int st, int ray_flags) {
-  bool sel = false;
-  if ((ray_flags & 1) && st == 1) sel = true;
-  if ((ray_flags & 2) && st == 2) sel = true;
-  if ((ray_flags & 4) && st == 3) sel = true;
-  if ((ray_flags & 8) && st < 0) sel = true;
-  if ((ray_flags & 16) && st > 0) sel = true;
-  return sel;
 }
 
 enum { HIST_LINES_ONLY = 0, HIST_DIRECT = 1, HIST_RECORDS = 2 };
@@ -721,6 +650,203 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_hist_tiles(
   for (int k = threadIdx.x; k < NCH * tcells; k += blockDim.x) out[k] = cells[k];
 }
 
+// ---------------------------------------------------------------------------
+// plot_tail_tiles: the records a ray kernel wrote in its tail (plot_tail.h: every WAVE's 64
+// rays sorted by tile, one row of a byte table per wave) added up per tile in LDS -- what
+// plot_hist_tiles does for the 1024-ray chunks of plot_hist_rays. Buckets 0 .. T - 1 are the
+// tiles of the 2-D histogram, bucket T holds the rays outside it (they still count for the
+// 1-D histograms of the axis they are inside of, and for the colour histogram) and the rays the
+// plot does not select. Block = (bucket, slice of the chunks); a wave takes 64 consecutive
+// chunks at a time: lane l the run of chunk l, a prefix sum over the lanes gives every ray of
+// the 64 runs a number, and lane j of a round finds its ray's chunk by a binary search over the
+// 64 sums (LDS). The colour histogram is kept here as well (the pass has no LDS to keep it in);
+// the x and y histograms of the rays inside the plot are the row and column sums of the planes
+// (plot_hist_reduce, `derive`). Bucket T's blocks also add up the five state counts per wave.
+// ---------------------------------------------------------------------------
+#define TAIL_SAMPLE 2048
+__device__ __forceinline__ void make_tail_shares(const PlotTail& Q, int64_t nchunks, int nblocks,
+                                                 unsigned* tot, int* share) {
+  const int T1 = Q.T + 1;
+  if ((int)threadIdx.x < T1) tot[threadIdx.x] = 0;
+  __syncthreads();
+  // how the rays are spread over the buckets: from a sample of the waves (the shares only
+  // balance the work; every bucket gets a block whether the sample saw a ray of it or not)
+  const int64_t S = nchunks < TAIL_SAMPLE ? nchunks : TAIL_SAMPLE;
+  const int64_t step = nchunks / S;
+  for (int64_t k = threadIdx.x; k < S; k += blockDim.x) {
+    const unsigned char* row = Q.tab + k * step * Q.pitch;
+    unsigned prev = row[0];
+    for (int t = 0; t < T1; ++t) {
+      const unsigned nxt = row[t + 1];
+      if (nxt != prev) atomicAdd(&tot[t], nxt - prev);
+      prev = nxt;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double walk = 0.5 * (double)S;      // a bucket's walk over the table, in rays
+    double sum = 0.;
+    for (int t = 0; t < T1; ++t) sum += (double)tot[t] + walk;
+    const int rest = nblocks - T1;
+    const int64_t most = (nchunks + 63) / 64;          // a slice takes 64 chunks at least
+    int run = 0, biggest = 0;
+    for (int t = 0; t < T1; ++t) {
+      if (tot[t] > tot[biggest]) biggest = t;
+      long long nb = 1 + (long long)((double)rest * (((double)tot[t] + walk) / sum));
+      if (nb > most) nb = most;
+      share[t] = run;
+      run += (int)nb;
+      tot[t] = (unsigned)nb;
+    }
+    share[T1] = run < nblocks ? run : nblocks;
+  }
+  __syncthreads();
+}
+
+template <int NCH>
+__global__ __launch_bounds__(HIST_BLOCK) void plot_tail_tiles(
+    int64_t nchunks, PlotTail Q, double* __restrict__ plane_copies,
+    double* __restrict__ line_copies, int* __restrict__ share_out,
+    double* __restrict__ counters) {
+  extern __shared__ double cells[];     // [NCH][ty][tx] | [4][nx] [4][ny] [4][nc] | search tables
+  __shared__ int share[HIST_MAX_TILES + 2];
+  __shared__ unsigned tot[HIST_MAX_TILES + 1];
+  __shared__ double lds[8][16];
+  const int T = Q.T;
+  make_tail_shares(Q, nchunks, (int)gridDim.x, tot, share);
+  if (blockIdx.x == 0 && (int)threadIdx.x <= T) share_out[threadIdx.x] = share[threadIdx.x];
+  int tile = 0;
+  while (tile <= T && (int)blockIdx.x >= share[tile + 1]) ++tile;
+  const bool idle = tile > T;           // (more blocks than the buckets take)
+  const bool rest = tile == T;          // the rays outside the 2-D histogram
+  const int tcells = Q.tx * Q.ty;
+  const int nx = Q.A.x.bins, ny = Q.A.y.bins, nc = Q.A.c.bins;
+  const int nl = 4 * (nx + ny + nc);
+  const int nplane = rest || idle ? 0 : NCH * tcells;
+  // a tile's block keeps the colour histogram only ([4][nc] behind its planes), the others the
+  // three of them
+  double* lx = cells + nplane;
+  double* ly = lx + (nplane ? 0 : 4 * nx);
+  double* lc = ly + (nplane ? 0 : 4 * ny);
+  const int nlines = nplane ? 4 * nc : nl;
+  for (int k = threadIdx.x; k < nplane + nlines; k += blockDim.x) cells[k] = 0.;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  int* pre = reinterpret_cast<int*>(cells + (nplane + nlines)) + wave * 128;   // [64] sums
+  int* bas = pre + 64;                                                        // [64] bases
+  __syncthreads();
+  int n_sel = 0, cnt[5] = {0, 0, 0, 0, 0};
+  double w_all = 0., w_in = 0.;
+  if (!idle) {
+    const int slice = (int)blockIdx.x - share[tile], slices = share[tile + 1] - share[tile];
+    int64_t per = (nchunks + slices - 1) / slices;
+    per = (per + 63) / 64 * 64;
+    const int64_t c0 = slice * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+    for (int64_t g0 = c0 + (int64_t)wave * 64; g0 < c1; g0 += (int64_t)nwaves * 64) {
+      const int64_t c = g0 + lane;
+      unsigned s0 = 0, e0 = 0;
+      if (c < c1) {
+        const unsigned char* row = Q.tab + c * Q.pitch;
+        s0 = row[tile];
+        e0 = row[tile + 1];
+        if (rest) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) cnt[k] += row[T + 2 + k];
+        }
+      }
+      const int len = (int)(e0 - s0);
+      int incl = len;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+      }
+      const int total = __shfl(incl, 63);
+      pre[lane] = incl;
+      bas[lane] = (int)(c * 64 + s0) - (incl - len);     // record = bas[chunk] + number
+      const int safe = (int)(g0 * 64);                   // what lanes without a ray read
+      for (int j0 = 0; j0 < total; j0 += 128) {
+        double w[2], hue[2];
+        unsigned word[2];
+        bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = j0 + u * 64 + lane;
+          on[u] = j < total;
+          int g = 0;
+#pragma unroll
+          for (int stp = 32; stp > 0; stp >>= 1)
+            if (pre[g + stp - 1] <= j) g += stp;
+          const int64_t k = on[u] ? (int64_t)(bas[g] + j) : (int64_t)safe;
+          w[u] = __builtin_nontemporal_load(Q.w + k);
+          hue[u] = __builtin_nontemporal_load(Q.hue + k);
+          word[u] = __builtin_nontemporal_load(Q.word + k);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (!on[u]) continue;
+          if (rest && !(word[u] & PLOT_TAIL_SELECTED)) continue;
+          double r, g, b;
+          hsv_to_rgb(hue[u], Q.P.color_saturation, w[u], r, g, b);
+          n_sel += 1;
+          w_all += w[u];
+          int ic;
+          if (!rest) {
+            w_in += w[u];
+            const unsigned cell = word[u] & 0xffffu;
+            ic = (int)(word[u] >> 16) - 1;
+            if (cell < (unsigned)tcells) {
+              if (w[u] != 0.) atomicAdd(&cells[cell], w[u]);
+              if (NCH > 1) {
+                if (r != 0.) atomicAdd(&cells[tcells + cell], r);
+                if (g != 0.) atomicAdd(&cells[2 * tcells + cell], g);
+                if (b != 0.) atomicAdd(&cells[3 * tcells + cell], b);
+              }
+            }
+          } else {
+            const int ix = (int)(word[u] & 0x7ffu) - 1, iy = (int)((word[u] >> 11) & 0x7ffu) - 1;
+            ic = (int)((word[u] >> 22) & 0x1ffu) - 1;
+            if (ix >= 0) {
+              atomicAdd(&lx[ix], w[u]);
+              atomicAdd(&lx[nx + ix], r);
+              atomicAdd(&lx[2 * nx + ix], g);
+              atomicAdd(&lx[3 * nx + ix], b);
+            }
+            if (iy >= 0) {
+              atomicAdd(&ly[iy], w[u]);
+              atomicAdd(&ly[ny + iy], r);
+              atomicAdd(&ly[2 * ny + iy], g);
+              atomicAdd(&ly[3 * ny + iy], b);
+            }
+          }
+          if (ic >= 0) {
+            atomicAdd(&lc[ic], w[u]);
+            atomicAdd(&lc[nc + ic], r);
+            atomicAdd(&lc[2 * nc + ic], g);
+            atomicAdd(&lc[3 * nc + ic], b);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // this block's copies as they are: the tile [chan][ty][tx], the lines [4][nx] [4][ny] [4][nc]
+  if (nplane) {
+    double* out = plane_copies + (int64_t)blockIdx.x * NCH * tcells;
+    for (int k = threadIdx.x; k < nplane; k += blockDim.x) out[k] = cells[k];
+  }
+  {
+    double* out = line_copies + (int64_t)blockIdx.x * nl;
+    const int head = nplane ? 4 * (nx + ny) : 0;       // (a tile's block: zeros for x and y)
+    for (int k = threadIdx.x; k < nl; k += blockDim.x)
+      out[k] = k < head ? 0. : lx[k - head];
+  }
+  if (counters) {
+    double c[8] = {(double)n_sel, w_all, w_in, (double)cnt[0], (double)cnt[1], (double)cnt[2],
+                   (double)cnt[3], (double)cnt[4]};
+    flush_counters(c, counters, lds);
+  }
+}
+
 // Adds the copies up into the histograms, one launch: blocks [0, nb2) take the 2-D planes
 // ([copy][chan][by][bx] -> h2, h2rgb), the rest the 1-D histograms ([copy][ [4][bx] | [4][by] |
 // [4][bc] ] -> h[bin][4]); blockIdx.y takes one of gridDim.y groups of copies (one atomic per
@@ -1026,6 +1152,122 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
     hipLaunchKernelGGL(plot_hist_kernel, full, dim3(256), 0, st, beam, x, y, c, P, A, h2, h2rgb,
                        hx, hy, hc, counters, general);
   }
+  return hipGetLastError();
+}
+
+// ---- a plot in the tail of a pass: the host side (hist.h) ---------------------------------------
+hipError_t plot_tail_plan(int64_t n, const xrt_hip_plot_tail& t, PlotTailPlan* plan, size_t* need) {
+  if (need) *need = 0;
+  const xrt_hip_plot& P = t.plot;
+  const bool fields_ok = t.x_field >= 0 && t.x_field <= XRT_HIP_FIELD_ZPRIME && t.y_field >= 0 &&
+                         t.y_field <= XRT_HIP_FIELD_ZPRIME && t.c_field >= 0 &&
+                         t.c_field <= XRT_HIP_FIELD_ZPRIME;
+  const bool shape_ok = n > 0 && n < HIST_MAX_RAYS && P.bins_x >= 1 && P.bins_y >= 1 &&
+                        P.bins_x <= PLOT_TAIL_MAX_BINS_XY && P.bins_y <= PLOT_TAIL_MAX_BINS_XY &&
+                        P.bins_c >= 1 && P.bins_c <= PLOT_TAIL_MAX_BINS_C && fields_ok;
+  if (!shape_ok) return plan ? hipErrorInvalidValue : hipSuccess;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess)
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  PlotTail Q = {};
+  Q.P = P;
+  Q.A.x = axis_bins(P.x_lim[0], P.x_lim[1], P.bins_x);
+  Q.A.y = axis_bins(P.y_lim[0], P.y_lim[1], P.bins_y);
+  Q.A.c = axis_bins(P.c_lim[0], P.c_lim[1], P.bins_c);
+  Q.fx = t.x_field;
+  Q.fy = t.y_field;
+  Q.fc = t.c_field;
+  // tiles whose four planes fit the LDS beside the colour histogram and the search tables
+  const size_t b1 = sizeof(double) * 4 * ((size_t)P.bins_x + P.bins_y + P.bins_c);
+  const size_t search = (HIST_BLOCK / 64) * 128 * sizeof(int);
+  const size_t beside = sizeof(double) * 4 * (size_t)P.bins_c + search + 256;
+  if (b1 + search + 256 > HIST_LDS_BUDGET || beside >= HIST_LDS_BUDGET)
+    return plan ? hipErrorInvalidValue : hipSuccess;
+  HistPlan H = {};
+  H.nchan = 4;
+  const int most = cus < PLOT_TAIL_MAX_TILES ? cus : PLOT_TAIL_MAX_TILES;
+  if (!plan_tiles(P.bins_x, P.bins_y, 4, HIST_LDS_BUDGET - beside, most, H) || H.tx * H.ty > 0xffff)
+    return plan ? hipErrorInvalidValue : hipSuccess;
+  Q.T = H.ntx * H.nty;
+  Q.ntx = H.ntx;
+  Q.tx = H.tx;
+  Q.ty = H.ty;
+  Q.mtx = H.tx == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)H.tx) + 1u;
+  Q.mty = H.ty == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)H.ty) + 1u;
+  Q.pitch = Q.T + 7 <= 32 ? 32 : 64;
+  const int64_t chunks = (n + 63) / 64;
+  const int ncopies = cus > Q.T + 1 ? cus : Q.T + 1;
+  auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t recs = (size_t)chunks * 64;
+  const size_t planes_b = pad((size_t)ncopies * 4 * H.tx * H.ty * sizeof(double));
+  const size_t lines_b = pad((size_t)ncopies * b1);
+  const size_t tab_b = pad((size_t)chunks * Q.pitch);
+  const size_t total = planes_b + lines_b + 2 * pad(recs * 8) + pad(recs * 4) + tab_b + 1024 + 256;
+  if (need) *need = total;
+  if (!plan) return hipSuccess;
+  if (!t.hist2d || !t.hist2d_rgb || !t.hist_x || !t.hist_y || !t.counters || !t.workspace)
+    return hipErrorInvalidValue;
+  char* q = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(t.workspace) + 255) / 256 * 256);
+  if (q + total - 256 > static_cast<char*>(t.workspace) + t.workspace_bytes)
+    return hipErrorInvalidValue;
+  plan->plane_copies = reinterpret_cast<double*>(q);
+  q += planes_b;
+  plan->line_copies = reinterpret_cast<double*>(q);
+  q += lines_b;
+  Q.w = reinterpret_cast<double*>(q);
+  q += pad(recs * 8);
+  Q.hue = reinterpret_cast<double*>(q);
+  q += pad(recs * 8);
+  Q.word = reinterpret_cast<unsigned*>(q);
+  q += pad(recs * 4);
+  Q.tab = reinterpret_cast<unsigned char*>(q);
+  q += tab_b;
+  plan->share = reinterpret_cast<int*>(q);
+  Q.want_c = t.hist_c != nullptr;
+  plan->Q = Q;
+  plan->n = n;
+  plan->chunks = chunks;
+  plan->ncopies = ncopies;
+  plan->cus = cus;
+  plan->tiles_x = H.ntx;
+  plan->tiles_y = H.nty;
+  plan->h2 = t.hist2d;
+  plan->h2rgb = t.hist2d_rgb;
+  plan->hx = t.hist_x;
+  plan->hy = t.hist_y;
+  plan->hc = t.hist_c;
+  plan->counters = t.counters;
+  return hipSuccess;
+}
+
+hipError_t plot_tail_finish(const PlotTailPlan& L, hipStream_t st) {
+  const PlotTail& Q = L.Q;
+  const int nx = Q.A.x.bins, ny = Q.A.y.bins, nc = Q.A.c.bins;
+  const size_t nl = 4 * ((size_t)nx + ny + nc);
+  const size_t tile_b = sizeof(double) * (4 * (size_t)Q.tx * Q.ty + 4 * (size_t)nc);
+  const size_t lds = (tile_b > nl * sizeof(double) ? tile_b : nl * sizeof(double)) +
+                     (HIST_BLOCK / 64) * 128 * sizeof(int);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(plot_tail_tiles<4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(plot_tail_tiles<4>, dim3((unsigned)L.ncopies), dim3(HIST_BLOCK), lds, st,
+                     L.chunks, Q, L.plane_copies, L.line_copies, L.share, L.counters);
+  HistPlan H = {};
+  H.ntx = L.tiles_x;
+  H.nty = L.tiles_y;
+  H.tx = Q.tx;
+  H.ty = Q.ty;
+  H.nchan = 4;
+  H.lines = 1;
+  H.derive = 1;
+  H.slices = L.ncopies;
+  const int total = 4 * nx * ny;
+  const int nb2 = 4 * ((nx + 31) / 32) * ((ny + 7) / 8);
+  const int nbl = (int)((nl + 255) / 256);
+  hipLaunchKernelGGL(plot_hist_reduce, dim3((unsigned)(nb2 + nbl), HIST_REDUCE_PARTS), dim3(256),
+                     0, st, L.plane_copies, L.ncopies, nx * ny, 4, nb2, L.line_copies, L.ncopies,
+                     nx, ny, nc, L.h2, L.h2rgb, L.hx, L.hy, L.hc, H, nx, ny, L.share,
+                     total >= 32768 ? 1 : HIST_REDUCE_PARTS);
   return hipGetLastError();
 }
 

@@ -129,7 +129,12 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1,
                                bool force_exact, const xrt_hip_screen* scr = nullptr,
                                const xrt_hip_beam* sb = nullptr, bool keep_virgin = true,
-                               int* fused = nullptr, const xrt_hip_geosource* src = nullptr);
+                               int* fused = nullptr, const xrt_hip_geosource* src = nullptr,
+                               const struct PlotTailPlan* plot = nullptr,
+                               bool keep_screen = true);
+// would this pass carry a screen (and a plot) in its tail: one of the lean kernels, optimistic
+bool reflect_pass_carries_screen(const xrt_hip_pass& P, const xrt_hip_material& M,
+                                 const xrt_hip_screen& S);
 
 // DCM.double_reflect in one kernel: both crystals per ray, the beam between them stays
 // in registers. lo1 / lo2: local beams of the two crystals, gb2: global beam after the

@@ -8,6 +8,7 @@
 
 #include "reflect_impl.h"
 #include "reflect_tu.h"
+#include "hist.h"
 #include "screen.h"
 #include "source.h"
 
@@ -597,6 +598,24 @@ static WsLayout ws_layout(void* workspace, int64_t n) {
 
 int user_unit_abi() { return XRT_USER_UNIT_ABI; }
 
+// (the conditions under which reflect_pass_launch below picks a lean kernel and the optimistic
+// single pass, for a caller that has to know beforehand)
+bool reflect_pass_carries_screen(const xrt_hip_pass& P, const xrt_hip_material& M,
+                                 const xrt_hip_screen& S) {
+  const bool nis = P.no_intersection_search != 0;
+  const bool need_mean = deflects_as_crystal(M) && !M.geom_transmitted;
+  const bool wide = P.surf_kind == XRT_HIP_SURF_BENT_BRAGG || P.surf_kind == XRT_HIP_SURF_VFM ||
+                    P.surf_kind == XRT_HIP_SURF_DUALVFM || P.surf_kind == XRT_HIP_SURF_DICED;
+  if (nis || need_mean || wide || P.fe_c || P.g_ray_x || M.kind == XRT_HIP_MAT_MULTILAYER ||
+      P.surf_kind >= XRT_HIP_SURF_BLAZED || P.grating || P.asymmetric || M.n_fixed == 2 ||
+      S.radius != 0.)
+    return false;
+  if (M.kind == XRT_HIP_MAT_MIRROR)
+    return P.surf_kind == XRT_HIP_SURF_TOROID || P.surf_kind == XRT_HIP_SURF_FLAT ||
+           P.surf_kind == XRT_HIP_SURF_BENTFLAT;
+  return M.kind == XRT_HIP_MAT_PLATE && P.surf_kind == XRT_HIP_SURF_FLAT;
+}
+
 hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                const xrt_hip_beam& in, const xrt_hip_beam& restore,
                                const xrt_hip_beam& lb, const xrt_hip_beam& vb, double* theta,
@@ -604,7 +623,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                hipEvent_t ev1, hipEvent_t evk0, hipEvent_t evk1,
                                bool force_exact, const xrt_hip_screen* scr,
                                const xrt_hip_beam* sb, bool keep_virgin, int* fused,
-                               const xrt_hip_geosource* src) {
+                               const xrt_hip_geosource* src, const PlotTailPlan* plot,
+                               bool keep_screen) {
   static_assert(sizeof(GStat) <= 256, "workspace head slot");
   if (fused) *fused = 0;
   static_assert(REFLECT_OPT_SLOTS * sizeof(OptStat) <= REFLECT_PART_BYTES, "report slots");
@@ -697,6 +717,19 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const bool lean = spec == SP_TOROID_MIRROR || spec == SP_FLAT_MIRROR ||
                     spec == SP_BENT_MIRROR || spec == SP_FLAT_PLATE;
   const bool fuse_screen = scr && sb && optimistic && lean && scr->radius == 0.;
+  // ... and the plot of the screen's image behind it (plot_tail.h): only in a tail
+  if (plot && !fuse_screen) return hipErrorInvalidValue;   // (capi.hip asks ..._fusable first)
+  xrt_hip_beam sb_fused;
+  if (plot) {
+    sb_fused = *sb;
+    if (!keep_screen) {       // the image itself is not wanted: its records are all that leaves
+      sb_fused.x = sb_fused.y = sb_fused.z = sb_fused.a = sb_fused.b = sb_fused.c = nullptr;
+      sb_fused.path = sb_fused.E = sb_fused.Jss = sb_fused.Jpp = sb_fused.Jsp_ri = nullptr;
+      sb_fused.state = nullptr;
+      sb_fused.Es_ri = sb_fused.Ep_ri = nullptr;
+    }
+    sb = &sb_fused;
+  }
   xrt_hip_beam vb_fused = vb;
   if (fuse_screen && !keep_virgin) {
     vb_fused.x = vb_fused.y = vb_fused.z = vb_fused.a = vb_fused.b = vb_fused.c = nullptr;
@@ -717,7 +750,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const FusedLaunch FL{grid, fblock, st, &P, &M, &in, &restore, &lb,
                        fuse_screen ? &vb_fused : &vb, theta, g, opt,
                        fuse_screen ? scr : nullptr, fuse_screen ? sb : nullptr,
-                       fuse_source ? src : nullptr};
+                       fuse_source ? src : nullptr, plot ? &plot->Q : nullptr};
   const ExactLaunch XL{dim3(exact_blocks(n)), dim3(REFLECT_EXACT_BLOCK), st, &P, &M, &in,
                        &restore, &lb, &vb, A};
   bool launched = true;
@@ -729,7 +762,9 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     return hipErrorInvalidValue;        // (capi.hip says why before it gets here)
   // the solve + finish kernel: mode 0 (optimistic) or 2 (no statistics needed)
   auto launch_fused = [&](int mode) {
-    if (fuse_screen)
+    if (plot)
+      launched &= tu_hot_fused_scr_plot(spec, mode, FL);
+    else if (fuse_screen)
       launched &= tu_hot_fused_scr(spec, mode, FL);
     else if (unit)      // (need_mean here: a multilayer deflecting as a crystal -- layered flavour)
       launched &= (need_mean ? unit->xtal(mode, &FL) : unit->fused(mode, &FL)) == 0;
@@ -768,12 +803,12 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     head.Jsp_ri = L.ht + 6;
     hipLaunchKernelGGL(reflect_decide_opt_gen, dim3(1), block, 0, st, P, M, *src, head, part, g);
     if (evk0) (void)hipEventRecord(evk0, st);
-    launched &= tu_hot_fused_gen_scr(spec, FL);
+    launched &= plot ? tu_hot_fused_gen_scr_plot(spec, FL) : tu_hot_fused_gen_scr(spec, FL);
     if (evk1) (void)hipEventRecord(evk1, st);
     // verdict, and only if it was contradicted: the source's beam, the exact sequence, the image
     {
       BarrierSerial one_at_a_time(st);
-      tu_exact0_redo_scr(XL, *scr, *sb, src);
+      tu_exact0_redo_scr(XL, *scr, *sb, src, plot ? &plot->Q : nullptr);
     }
   } else if (fuse_screen) {
     hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, g);
@@ -782,7 +817,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     if (evk1) (void)hipEventRecord(evk1, st);
     {
       BarrierSerial one_at_a_time(st);
-      tu_exact0_redo_scr(XL, *scr, *sb, nullptr);
+      tu_exact0_redo_scr(XL, *scr, *sb, nullptr, plot ? &plot->Q : nullptr);
     }
   } else if (optimistic) {
     // assumptions from the head of the beam -> the pass on them, every ray checking ->
@@ -817,7 +852,12 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
       const hipError_t se = screen_expose_launch(*scr, vb, *sb, st);
       if (se != hipSuccess) return se;
     }
-    if (fused) *fused = (fuse_screen ? 1 : 0) | (fuse_source ? 2 : 0);
+    if (fused) *fused = (fuse_screen ? 1 : 0) | (fuse_source ? 2 : 0) | (plot ? 4 : 0);
+  }
+  if (plot) {
+    // the records of the pass (or of its redo) into the plot's accumulators: two small kernels
+    const hipError_t pe = plot_tail_finish(*plot, st);
+    if (pe != hipSuccess) return pe;
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   if (!launched) return hipErrorInvalidDeviceFunction;   // no unit holds this spec

@@ -35,6 +35,7 @@
 #include "fp64_math.h"
 #include "reflect.h"
 #include "screen_impl.h"
+#include "plot_tail.h"
 #include "source_impl.h"
 
 namespace xrt {
@@ -3290,6 +3291,37 @@ struct ScreenConsumer {        // Screen.expose, flat screens (screen_impl.h)
   }
 };
 
+// ... and with a PLOT behind the screen (run_ray_tracing's accumulate_plot of that image,
+// plot_tail.h): the image is stored only if somebody else reads it (out.x), its ray's weight,
+// hue and bins are left in *stash* -- registers of the kernel -- for the wave to sort and write
+// when all its lanes are back together (plot_tail_emit at the end of the kernel: take() runs
+// inside divergent branches). References to the kernel's arguments and a pointer to a local: a
+// member written in an argument would send the whole record to scratch memory.
+struct ScreenPlotConsumer {
+  static constexpr bool ON = true;
+  const xrt_hip_screen& S;
+  const xrt_hip_beam& out;
+  const PlotTail& Q;
+  PlotStash* stash;
+  __device__ __forceinline__ void take(int64_t i, double x, double y, double z, double a,
+                                       double b, double c, double path, double E, double Jss,
+                                       double Jpp, double Jsr, double Jsi, int st, double Esr,
+                                       double Esi, double Epr, double Epi, bool has_amp) const {
+    const ImageRay r = expose_flat(S, x, y, z, a, b, c, st);
+    if (out.x) store_image(out, i, r, path, E, Jss, Jpp, Jsr, Jsi, Esr, Esi, Epr, Epi, has_amp);
+    *stash = plot_tail_take(Q, r.x, 0., r.z, r.a, r.b, r.c, path + r.path, E, Jss, Jpp, Jsr, Jsi,
+                            r.st);
+  }
+};
+__device__ __forceinline__ PlotStash no_plot_ray(const PlotTail& Q) {
+  PlotStash s;
+  s.w = s.hue = 0.;
+  s.word = 0;
+  s.tile = Q.T;
+  s.st = 0;
+  return s;
+}
+
 // everything after the solve for one entering ray: state, finish, both stores.
 // QREADY: the ray's fields come in qin instead of from `in`. VREC: the outgoing
 // ("virgin") record is handed back in registers instead of being stored, with `kept` =
@@ -3698,6 +3730,62 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_g
                                          cons);
 }
 
+// ... and with the plot of that image behind the screen (ScreenPlotConsumer): OE.reflect ->
+// Screen.expose -> accumulate_plot as one pass; `scr.out` with null arrays: the image itself is
+// not wanted either. The wave writes its rays' plot records when the pass is through.
+template <class K, int mode>
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_scr_plot(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
+    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
+    OptStat* __restrict__ opt, ScreenConsumer scr, PlotTail Q) {
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
+  const RayRequest req = request_ray<early_fields<K>()>(in, i, in.Es_ri != nullptr);
+  if (fused_skips(gp, mode)) return;
+  const GStat g = *gp;
+  int neg = 0, pos = 0;
+  PlotStash stash = no_plot_ray(Q);
+  const ScreenPlotConsumer cons{scr.S, scr.out, Q, &stash};
+  fused_ray<K, mode, false, ScreenPlotConsumer>(P, M, in, restore, lb, vb, theta, g, opt, i, req,
+                                                neg, pos, cons);
+  plot_tail_emit(Q, i >> 6, stash);
+}
+
+template <class K>
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_gen_scr_plot(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_geosource G, xrt_hip_beam in, xrt_hip_beam lb,
+    xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp, OptStat* __restrict__ opt,
+    ScreenConsumer scr, PlotTail Q) {
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
+  if (fused_skips(gp, 0)) return;
+  const bool has_amp = in.Es_ri != nullptr;
+  const gen::GenRay made = gen::make_ray(G, gen::call_of(G), i < in.n ? i : 0, has_amp);
+  RayRequest req;
+  req.st0 = i < in.n ? G.state : 0;
+  req.raw.x = made.x;
+  req.raw.y = made.y;
+  req.raw.z = made.z;
+  req.raw.a = made.a;
+  req.raw.b = made.b;
+  req.raw.c = made.c;
+  req.q.path = 0.;
+  req.q.E = made.E;
+  req.q.Jss = made.r.Jss;
+  req.q.Jpp = made.r.Jpp;
+  req.q.Jsr = made.r.Jre;
+  req.q.Jsi = made.r.Jim;
+  req.q.Esr = has_amp ? made.r.Esr : 0.;
+  req.q.Esi = has_amp ? made.r.Esi : 0.;
+  req.q.Epr = has_amp ? made.r.Epr : 0.;
+  req.q.Epi = has_amp ? made.r.Epi : 0.;
+  const GStat g = *gp;
+  int neg = 0, pos = 0;
+  PlotStash stash = no_plot_ray(Q);
+  const ScreenPlotConsumer cons{scr.S, scr.out, Q, &stash};
+  fused_ray<K, 0, false, ScreenPlotConsumer>(P, M, in, in, lb, vb, theta, g, opt, i, req, neg,
+                                             pos, cons);
+  plot_tail_emit(Q, i >> 6, stash);
+}
+
 // ---------------------------------------------------------------------------
 // Bragg-reflecting crystals in ONE pass. The reference needs a batch-global sign
 // (of the mean beamInDotNormal) before it can deflect a single ray, which is why
@@ -4032,7 +4120,7 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_exact(
 template <class K, bool SRC>
 __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_redo_scr(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_geosource G, xrt_hip_beam in, xrt_hip_beam restore,
-    xrt_hip_beam lb, xrt_hip_beam vb, PassAux A, xrt_hip_screen S, xrt_hip_beam sb) {
+    xrt_hip_beam lb, xrt_hip_beam vb, PassAux A, xrt_hip_screen S, xrt_hip_beam sb, PlotTail Q) {
   __shared__ double lds_d[REFLECT_MAX_WAVES];
   const bool full = exact_gate(A.g, reinterpret_cast<const OptStat*>(A.part), lds_d,
                                P.method_hint);
@@ -4049,17 +4137,28 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_redo_scr(
   }
   exact_pass<K>(P, M, in, restore, lb, vb, A, true, phase);
   grid_barrier(A.g, phase);
+  // the image from the real global beam (sb.x null: nobody wants the image itself) and, with a
+  // plot behind the screen (Q.w), its records: whole waves stay together for plot_tail_emit
   const bool has_amp = vb.Es_ri != nullptr;
-  for (int64_t i = first; i < vb.n; i += stride) {
-    const double2 js = reinterpret_cast<const double2*>(vb.Jsp_ri)[i];
-    double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
-    if (has_amp) {
-      es = reinterpret_cast<const double2*>(vb.Es_ri)[i];
-      ep = reinterpret_cast<const double2*>(vb.Ep_ri)[i];
+  for (int64_t base = first - (threadIdx.x & 63); base < vb.n; base += stride) {
+    const int64_t i = base + (threadIdx.x & 63);
+    PlotStash stash = no_plot_ray(Q);
+    if (i < vb.n) {
+      const double2 js = reinterpret_cast<const double2*>(vb.Jsp_ri)[i];
+      double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+      if (has_amp) {
+        es = reinterpret_cast<const double2*>(vb.Es_ri)[i];
+        ep = reinterpret_cast<const double2*>(vb.Ep_ri)[i];
+      }
+      const double path = vb.path[i], E = vb.E[i], Jss = vb.Jss[i], Jpp = vb.Jpp[i];
+      const ImageRay r = expose_flat(S, vb.x[i], vb.y[i], vb.z[i], vb.a[i], vb.b[i], vb.c[i],
+                                     vb.state[i]);
+      if (sb.x) store_image(sb, i, r, path, E, Jss, Jpp, js.x, js.y, es.x, es.y, ep.x, ep.y, has_amp);
+      if (Q.w)
+        stash = plot_tail_take(Q, r.x, 0., r.z, r.a, r.b, r.c, path + r.path, E, Jss, Jpp, js.x,
+                               js.y, r.st);
     }
-    expose_flat_store(S, sb, i, vb.x[i], vb.y[i], vb.z[i], vb.a[i], vb.b[i], vb.c[i], vb.path[i],
-                      vb.E[i], vb.Jss[i], vb.Jpp[i], js.x, js.y, vb.state[i], es.x, es.y, ep.x,
-                      ep.y, has_amp);
+    if (Q.w) plot_tail_emit(Q, i >> 6, stash);
   }
 }
 

@@ -36,6 +36,7 @@ struct FusedLaunch {   // one launch of reflect_fused / reflect_fused_xtal
   const xrt_hip_screen* scr;   // a screen in the tail of the pass (reflect_fused_scr), or null
   const xrt_hip_beam* sb;      //   its image
   const xrt_hip_geosource* src;   // the source in its head (reflect_fused_gen_scr), or null
+  const PlotTail* plot;        // a plot behind the screen (reflect_fused_scr_plot), or null
 };
 struct ExactLaunch {   // reflect_exact
   dim3 grid, block;
@@ -116,6 +117,26 @@ inline void launch_fused_gen_scr_k(const FusedLaunch& L) {
                      *L.lb, *L.vb, L.theta, L.g, L.opt, cons);
 }
 template <class K>
+inline void launch_fused_scr_plot_k(int mode, const FusedLaunch& L) {
+  ScreenConsumer cons;
+  cons.S = *L.scr;
+  cons.out = *L.sb;
+  if (mode == 0)
+    hipLaunchKernelGGL((reflect_fused_scr_plot<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
+                       *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt, cons, *L.plot);
+  else
+    hipLaunchKernelGGL((reflect_fused_scr_plot<K, 2>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
+                       *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt, cons, *L.plot);
+}
+template <class K>
+inline void launch_fused_gen_scr_plot_k(const FusedLaunch& L) {
+  ScreenConsumer cons;
+  cons.S = *L.scr;
+  cons.out = *L.sb;
+  hipLaunchKernelGGL(reflect_fused_gen_scr_plot<K>, L.grid, L.block, 0, L.st, *L.P, *L.M, *L.src,
+                     *L.in, *L.lb, *L.vb, L.theta, L.g, L.opt, cons, *L.plot);
+}
+template <class K>
 inline void launch_xtal_k(int mode, const FusedLaunch& L) {
   if (mode == 0)
     hipLaunchKernelGGL((reflect_fused_xtal<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
@@ -140,6 +161,8 @@ inline void launch_dcm_k(const DcmLaunch& L) {
 bool tu_hot_fused(int spec, int mode, const FusedLaunch& L);        // reflect_hot.hip
 bool tu_hot_fused_scr(int spec, int mode, const FusedLaunch& L);    // reflect_hot_scr.hip
 bool tu_hot_fused_gen_scr(int spec, const FusedLaunch& L);          // reflect_hot_gen.hip
+bool tu_hot_fused_scr_plot(int spec, int mode, const FusedLaunch& L);      // reflect_hot_plot.hip
+bool tu_hot_fused_gen_scr_plot(int spec, const FusedLaunch& L);
 bool tu_hot_xtal(int spec, int mode, const FusedLaunch& L);
 bool tu_hot_dcm(int spec, const DcmLaunch& L);
 bool tu_xtal_xtal(int spec, int mode, const FusedLaunch& L);        // reflect_xtal.hip
@@ -152,7 +175,7 @@ bool tu_figured_exact0(int spec, const ExactLaunch& L);             // reflect_f
 bool tu_figured_exact1(int spec, const ExactLaunch& L);             // reflect_figured_x1.hip
 bool tu_exact0(int spec, const ExactLaunch& L);                     // reflect_exact0.hip
 void tu_exact0_redo_scr(const ExactLaunch& L, const xrt_hip_screen& S, const xrt_hip_beam& sb,
-                        const xrt_hip_geosource* src);
+                        const xrt_hip_geosource* src, const PlotTail* plot);
 void tu_exact0_dcm(const DcmLaunch& L);
 bool tu_exact1(int spec, const ExactLaunch& L);                     // reflect_exact1.hip
 bool tu_exact2(int spec, const ExactLaunch& L);                     // reflect_exact2.hip

@@ -32,12 +32,75 @@ def _axis_tensor(beam, field, dev):
     return beam.dev(field, dev)
 
 
-def accumulate_plot(plot, beams):
-    """One iteration of get_output + do_hist2d for *plot* on the device."""
+def _plot_record(plot, srcw):
+    P = _structs.Plot()
+    P.x_factor, P.y_factor, P.c_factor = (float(plot.xaxis.factor),
+                                          float(plot.yaxis.factor), float(plot.caxis.factor))
+    P.source_weight = float(srcw)
+    for lim, axis in ((P.x_lim, plot.xaxis), (P.y_lim, plot.yaxis), (P.c_lim, plot.caxis)):
+        lim[0], lim[1] = float(axis.limits[0]), float(axis.limits[1])
+    P.color_factor = float(plot.colorFactor)
+    P.color_saturation = float(plot.colorSaturation)
+    P.bins_x, P.bins_y, P.bins_c = plot.xaxis.bins, plot.yaxis.bins, plot.caxis.bins
+    P.ray_flags, P.flux_kind = plot.ray_flag_mask, plot.flux_kind_code
+    return P
+
+
+def _join_the_pass(plot, beam, dev, lib):
+    """*beam* is the image of a screen whose pass has not been launched (Screen.expose of the
+    pending global beam of OE.reflect, sources.LazyBeam) and this plot is the first to look at
+    it: the plot rides in the tail of that pass (oes._DeferredReflect.plot_on) -- the rays'
+    weights, hues and bins are formed from the registers that hold the image, which itself is
+    not written unless somebody has asked the screen for it before. -> True if it did. Fixed
+    limits only (automatic ones are read back from the first beam: the usual route)."""
+    from .backends.raycing import oes as roe
+    op = beam.__dict__.get('_op')
+    if not roe.fuseConsumers or getattr(op, 'image', None) is not beam or op.state != 'pending' \
+            or plot.beamState is not None:
+        return False
+    axes = (plot.xaxis, plot.yaxis, plot.caxis)
+    if any(a.limits is None for a in axes) or \
+            any(a.field() not in _structs.PLOT_FIELDS for a in axes):
+        return False
+    srcw = op.n * beam.sourceWeight if 'sourceWeight' in beam.__dict__ else 1.
+    tail = _structs.PlotTail()
+    tail.plot = _plot_record(plot, srcw)
+    tail.x_field, tail.y_field, tail.c_field = (_structs.PLOT_FIELDS[a.field()] for a in axes)
+    need = ctypes.c_size_t(0)
+    _lib.check(lib.xrt_hip_plot_tail_workspace_bytes(op.n, ctypes.byref(tail), ctypes.byref(need)),
+               'xrt_hip_plot_tail_workspace_bytes')
+    if need.value == 0:
+        return False
+    flat = plot.device_accumulator(dev)
+    hist, hist_rgb, hx, hy, hc, counters = torch.split(flat, plot.part_sizes())
+    tail.hist2d, tail.hist2d_rgb, tail.hist_x, tail.hist_y = (
+        t.data_ptr() for t in (hist, hist_rgb, hx, hy))
+    tail.hist_c = hc.data_ptr() if plot.ePos else None
+    tail.counters = counters.data_ptr()
+    ws = hipcalls.workspace(dev, need.value, 'plot_tail')
+    tail.workspace, tail.workspace_bytes = ws.data_ptr(), ws.numel()
+    if not op.plot_on(tail):
+        return False
+    nrays = op.n
+
+    def count():
+        plot.nRaysAll += nrays
+        plot.iteration += 1
+    graphs.per_iteration(count)
+    return True
+
+
+def accumulate_plot(plot, beams, sole=True):
+    """One iteration of get_output + do_hist2d for *plot* on the device. *sole*: no other plot
+    of this iteration shows the same beam (then the plot may ride in the tail of the pass that
+    makes the beam, _join_the_pass)."""
     _lib.require_gpu()
     lib = _lib.load()
     dev = torch.device('cuda', torch.cuda.current_device())
     beam = beams[plot.beam]
+    from .backends.raycing import sources as _rs
+    if sole and type(beam) is _rs.LazyBeam and _join_the_pass(plot, beam, dev, lib):
+        return
     x = _axis_tensor(beam, plot.xaxis.field(), dev).contiguous()
     y = _axis_tensor(beam, plot.yaxis.field(), dev).contiguous()
     for axis, t in ((plot.xaxis, x), (plot.yaxis, y)):
@@ -73,16 +136,7 @@ def accumulate_plot(plot, beams):
         cached, s = s, _structs.Beam()
         ctypes.memmove(ctypes.byref(s), ctypes.byref(cached), ctypes.sizeof(s))
         s.state = state_beam.dev('state', dev).data_ptr()
-    P = _structs.Plot()
-    P.x_factor, P.y_factor, P.c_factor = (float(plot.xaxis.factor),
-                                          float(plot.yaxis.factor), float(cax.factor))
-    P.source_weight = float(srcw)
-    for lim, axis in ((P.x_lim, plot.xaxis), (P.y_lim, plot.yaxis), (P.c_lim, cax)):
-        lim[0], lim[1] = float(axis.limits[0]), float(axis.limits[1])
-    P.color_factor = float(plot.colorFactor)
-    P.color_saturation = float(plot.colorSaturation)
-    P.bins_x, P.bins_y, P.bins_c = plot.xaxis.bins, plot.yaxis.bins, cax.bins
-    P.ray_flags, P.flux_kind = plot.ray_flag_mask, plot.flux_kind_code
+    P = _plot_record(plot, srcw)
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     # scratch from torch's allocator, one per (thread, stream): nothing is allocated per call
     # (and a call recorded into a HIP graph keeps pointing at memory the graph owns)
@@ -116,8 +170,9 @@ def _parallel_iterations(plots, beamLine, count):
                 with torch.cuda.stream(stream):
                     mine = [p.spawn() for p in plots]
                     beams = rr.run_process(beamLine)
+                    shown = [p.beam for p in mine]
                     for plot in mine:
-                        accumulate_plot(plot, beams)
+                        accumulate_plot(plot, beams, sole=shown.count(plot.beam) == 1)
                     stream.synchronize()
             results[k] = mine
         except BaseException as e:   # noqa: BLE001  (re-raised in the caller's thread)
@@ -161,8 +216,9 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
 
     def iteration():
         beams = rr.run_process(beamLine)
+        shown = [p.beam for p in plots]
         for plot in plots:
-            accumulate_plot(plot, beams)
+            accumulate_plot(plot, beams, sole=shown.count(plot.beam) == 1)
         # (an element pass nobody has looked at yet is launched now: an iteration leaves
         # nothing behind -- also what a recorded iteration has to contain)
         from .backends.raycing import sources as rs
