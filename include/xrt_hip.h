@@ -869,7 +869,7 @@ XRT_HIP_API int xrt_hip_plot_hist_ws_f64_dev(
  * x_field / y_field / c_field: which quantity of the IMAGE each axis shows. Accumulators as in
  * xrt_hip_plot_hist_ws_f64_dev, all of hist2d, hist2d_rgb, hist_x, hist_y and counters
  * present (hist_c optional). workspace: DEVICE scratch of xrt_hip_plot_tail_workspace_bytes
- * (0 bytes = this plot cannot ride a pass: more than 2046 bins along x or y, more than 510 colour
+ * (0 bytes = this plot cannot ride a pass: more than 2046 bins along x or y, more than 4094 colour
  * bins, more than 56 tiles). Sums are formed in another order than by the stand-alone kernels:
  * equal to ~1e-15 relative, bins and counts identical. */
 enum {

@@ -803,9 +803,9 @@ def test_multiple_reflect_refuses_no_bounce_at_all():
 
 
 # ---- the plot in the tail of the pass (round 6) -----------------------------------------------------
-def _plot(bins=256, **kw):
+def _plot(bins=256, rayFlag=(1,), **kw):
     """The XYCPlot of workloads.e2e_beamline with fixed limits around the focus."""
-    return xrtp.XYCPlot('focus', (1,),
+    return xrtp.XYCPlot('focus', rayFlag,
                         xaxis=xrtp.XYCAxis('x', 'mm', limits=[-0.4, 0.4], bins=bins),
                         yaxis=xrtp.XYCAxis('z', 'mm', limits=[-0.05, 0.05], bins=bins),
                         caxis=xrtp.XYCAxis('energy', 'eV', limits=[8989., 9011.], bins=128), **kw)
@@ -917,37 +917,39 @@ def test_plots_that_do_not_ride():
 
 
 def test_a_contradicted_pass_with_a_plot_in_its_tail():
-    """The optimistic pass is contradicted (Brent's method: golden g2_toroid_brent): the redo
-    makes the plot's records from the real image (reflect_redo_scr)."""
-    import p1_cases
-    g = np.load(os.path.join(p1_cases.GOLDEN, 'g2_toroid_brent.npz'))
-    oe = p1_cases.product_oe('g2_toroid_brent', g)
-    beam = p1_cases.product_beam(g)
-    scr = rsc.Screen(oe.bl, 'after', center=[0, float(g['oe_center'][1]) + 3000., 10.])
-
+    """Rays all over the place: the optimistic pass is contradicted (a ray's largest direction
+    cosine is not y), the redo makes the plot's records from the real image (reflect_redo_scr);
+    likewise for a resident beam whose batch statistics ask for Brent's method."""
     def plot():
-        return xrtp.XYCPlot('after', (1, 2, 3, -1),
-                            xaxis=xrtp.XYCAxis('x', 'mm', limits=[-30., 30.], bins=96),
-                            yaxis=xrtp.XYCAxis('z', 'mm', limits=[-40., 40.], bins=160),
-                            caxis=xrtp.XYCAxis('energy', 'eV', limits=[1000., 30000.], bins=64))
-    gb0, lb0, img0 = eager(oe, scr, beam)
+        return xrtp.XYCPlot('focus', (1, 2, 3, -1),
+                            xaxis=xrtp.XYCAxis('x', 'mm', limits=[-3000., 3000.], bins=96),
+                            yaxis=xrtp.XYCAxis('z', 'mm', limits=[-200., 200.], bins=160),
+                            caxis=xrtp.XYCAxis('energy', 'eV', limits=[8989., 9011.], bins=64))
+    bl, amp = source_scene(n=40000, wide=True)
     p0, p1 = plot(), plot()
-    roe.fuseConsumers = False
-    try:
-        xrtr.accumulate_plot(p0, {'after': img0})
-    finally:
-        roe.fuseConsumers = True
-    gb, lb = oe.reflect(beam)
-    img = scr.expose(gb)
-    xrtr.accumulate_plot(p1, {'after': img})
-    assert gb.__dict__['_op'].state == 'imaged' and not img.__dict__['_filled']
+    b0 = _plot_chain(bl, amp, False, p0)
+    b1 = _plot_chain(bl, amp, True, p1)
+    assert b1['gb'].__dict__['_op'].state == 'imaged' and not b1['img'].__dict__['_filled']
+    _same_plot(p1, p0, 'wide source, redone')
+    same(b1['img'], b0['img'], 'image on demand after the redo')
+    same(b1['gb'], b0['gb'], 'global')
+    same(b1['src'], b0['src'], 'source')
+    # a resident beam, Brent's method
+    rays = workloads.synthetic_rays(60000, 9)
+    rays.c[::7] = 0.3                       # steep rays: dz at the far bracket end is large
+    rays.b[:] = np.sqrt(1 - rays.a**2 - rays.c**2)
+    bl, amp = source_scene(n=1000)
+    info = {}
+    bl.mirror.reflect(rays, _info=info)
+    q0, q1 = plot(), plot()
+    c0 = _plot_chain(bl, amp, False, q0, source=False, beam=rays)
+    c1 = _plot_chain(bl, amp, True, q1, source=False, beam=rays)
+    assert c1['gb'].__dict__['_op'].state == 'imaged' and not c1['img'].__dict__['_filled']
     for name in ('total2D', 'total2D_RGB'):
-        a, b = getattr(p1, name), getattr(p0, name)
+        a, b = getattr(q1, name), getattr(q0, name)
         assert np.array_equal(a != 0, b != 0) and np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
-    assert p1.nRaysGood == p0.nRaysGood and p1.nRaysDead == p0.nRaysDead
-    assert abs(p1.intensity - p0.intensity) <= 1e-12 * abs(p0.intensity)
-    same(img, img0, 'image on demand after the redo')
-    same(gb, gb0, 'global')
+    assert q1.nRaysGood == q0.nRaysGood and q1.nRaysDead == q0.nRaysDead
+    same(c1['img'], c0['img'], 'image on demand, resident beam')
 
 
 def test_the_fused_chain_against_the_oracle_directly():
@@ -997,7 +999,7 @@ def test_the_fused_chain_against_the_oracle_directly():
     w = (oimg.Jss + oimg.Jpp)[sel]
     h2, _, _ = np.histogram2d(oimg.z[sel], oimg.x[sel], bins=[256, 256],
                               range=[[-0.05, 0.05], [-0.4, 0.4]], weights=w)
-    assert h2.sum() > 0.5 * w.sum()
+    assert h2.sum() > 0.2 * w.sum()
     assert np.abs(plot.total2D - h2).max() <= 1e-12 * h2.max()
     hx, _ = np.histogram(oimg.x[sel], bins=256, range=(-0.4, 0.4), weights=w)
     hc, _ = np.histogram(oimg.E[sel], bins=128, range=(8989., 9011.), weights=w)

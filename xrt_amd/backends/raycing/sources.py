@@ -447,7 +447,15 @@ class _PendingOps(object):
         self._mine_optional().discard(op)
 
     def __iter__(self):
-        return iter(list(self._mine()))
+        # consumers first: an element's deferred pass makes the rays of a pending device source
+        # in its own head (and takes the source's record off this list); the other way round the
+        # source would launch its generator for nothing
+        ops = list(self._mine())
+        return iter([op for op in ops if hasattr(op, 'src_op')] +
+                    [op for op in ops if not hasattr(op, 'src_op')])
+
+    def __contains__(self, op):
+        return op in self._mine() or op in self._mine_optional()
 
     def optional(self):
         return list(self._mine_optional())
@@ -462,11 +470,13 @@ def flush_pending(beam=None, keep=None, only_state=False):
     whoever is about to change a beam's arrays in place; *only_state*: nothing but its states,
     of which the optional operations hold their own copy)."""
     for op in list(_PENDING):
-        if op is not keep and (beam is None or op.reads(beam)):
+        # (an operation launched earlier in this loop may have taken another one off the list:
+        # the pass that makes a pending source's rays itself)
+        if op is not keep and op in _PENDING and (beam is None or op.reads(beam)):
             op.materialize()
     if beam is not None and not only_state:
         for op in _PENDING.optional():
-            if op is not keep and op.reads(beam):
+            if op is not keep and op in _PENDING and op.reads(beam):
                 op.materialize()
 
 

@@ -736,96 +736,126 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_tail_tiles(
   __syncthreads();
   int n_sel = 0, cnt[5] = {0, 0, 0, 0, 0};
   double w_all = 0., w_in = 0.;
+  const double crange = Q.A.c.hi - Q.A.c.lo;
   if (!idle) {
     const int slice = (int)blockIdx.x - share[tile], slices = share[tile + 1] - share[tile];
     int64_t per = (nchunks + slices - 1) / slices;
     per = (per + 63) / 64 * 64;
     const int64_t c0 = slice * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
-    for (int64_t g0 = c0 + (int64_t)wave * 64; g0 < c1; g0 += (int64_t)nwaves * 64) {
-      const int64_t c = g0 + lane;
-      unsigned s0 = 0, e0 = 0;
+    // lane l takes the run of chunk g0 + l; the bytes of the NEXT 64 chunks are requested before
+    // this group is worked on (a bucket with few rays is all walk: one dependent load per step
+    // made a cold tile's block the last to finish, 0.3 ms at 1e7 rays)
+    auto row_of = [&](int64_t c, unsigned& s_, unsigned& e_, unsigned (&k_)[5]) {
+      s_ = e_ = 0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) k_[k] = 0;
       if (c < c1) {
         const unsigned char* row = Q.tab + c * Q.pitch;
-        s0 = row[tile];
-        e0 = row[tile + 1];
+        s_ = row[tile];
+        e_ = row[tile + 1];
         if (rest) {
 #pragma unroll
-          for (int k = 0; k < 5; ++k) cnt[k] += row[T + 2 + k];
+          for (int k = 0; k < 5; ++k) k_[k] = row[T + 2 + k];
         }
       }
+    };
+    unsigned s0, e0, k0[5], sn, en, kn[5];
+    row_of(c0 + (int64_t)wave * 64 + lane, s0, e0, k0);
+    for (int64_t g0 = c0 + (int64_t)wave * 64; g0 < c1; g0 += (int64_t)nwaves * 64) {
+      row_of(g0 + (int64_t)nwaves * 64 + lane, sn, en, kn);
+      const int64_t c = g0 + lane;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) cnt[k] += (int)k0[k];
       const int len = (int)(e0 - s0);
-      int incl = len;
+      if (__ballot(len != 0) != 0ull) {
+        int incl = len;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-      }
-      const int total = __shfl(incl, 63);
-      pre[lane] = incl;
-      bas[lane] = (int)(c * 64 + s0) - (incl - len);     // record = bas[chunk] + number
-      const int safe = (int)(g0 * 64);                   // what lanes without a ray read
-      for (int j0 = 0; j0 < total; j0 += 128) {
-        double w[2], hue[2];
-        unsigned word[2];
-        bool on[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int j = j0 + u * 64 + lane;
-          on[u] = j < total;
-          int g = 0;
-#pragma unroll
-          for (int stp = 32; stp > 0; stp >>= 1)
-            if (pre[g + stp - 1] <= j) g += stp;
-          const int64_t k = on[u] ? (int64_t)(bas[g] + j) : (int64_t)safe;
-          w[u] = __builtin_nontemporal_load(Q.w + k);
-          hue[u] = __builtin_nontemporal_load(Q.hue + k);
-          word[u] = __builtin_nontemporal_load(Q.word + k);
+        for (int off = 1; off < 64; off <<= 1) {
+          const int v = __shfl_up(incl, off);
+          if (lane >= off) incl += v;
         }
+        const int total = __shfl(incl, 63);
+        // every run whole (a focused beam: all rays of these waves in this tile): ray j is
+        // record g0 * 64 + j, nothing to search
+        const bool whole = total == 4096;
+        if (!whole) {
+          pre[lane] = incl;
+          bas[lane] = (int)(c * 64 + s0) - (incl - len);   // record = bas[chunk] + number
+        }
+        const int safe = (int)(g0 * 64);                   // what lanes without a ray read
+        for (int j0 = 0; j0 < total; j0 += 256) {
+          double w[4], hue[4];
+          unsigned word[4];
+          bool on[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          if (!on[u]) continue;
-          if (rest && !(word[u] & PLOT_TAIL_SELECTED)) continue;
-          double r, g, b;
-          hsv_to_rgb(hue[u], Q.P.color_saturation, w[u], r, g, b);
-          n_sel += 1;
-          w_all += w[u];
-          int ic;
-          if (!rest) {
-            w_in += w[u];
-            const unsigned cell = word[u] & 0xffffu;
-            ic = (int)(word[u] >> 16) - 1;
-            if (cell < (unsigned)tcells) {
-              if (w[u] != 0.) atomicAdd(&cells[cell], w[u]);
-              if (NCH > 1) {
-                if (r != 0.) atomicAdd(&cells[tcells + cell], r);
-                if (g != 0.) atomicAdd(&cells[2 * tcells + cell], g);
-                if (b != 0.) atomicAdd(&cells[3 * tcells + cell], b);
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 64 + lane;
+            on[u] = j < total;
+            int64_t k = safe + j;
+            if (!whole) {
+              int g = 0;
+#pragma unroll
+              for (int stp = 32; stp > 0; stp >>= 1)
+                if (pre[g + stp - 1] <= j) g += stp;
+              k = on[u] ? (int64_t)(bas[g] + j) : (int64_t)safe;
+            }
+            w[u] = Q.w[k];
+            hue[u] = Q.hue[k];
+            word[u] = Q.word[k];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (!on[u]) continue;
+            if (rest && !(word[u] & PLOT_TAIL_SELECTED)) continue;
+            // hue and colour bin from the colour datum (plot_hist_rays' arithmetic)
+            const double cv = hue[u];
+            double h01 = div_rn((cv - Q.A.c.lo) * Q.P.color_factor, crange);
+            if (h01 < 0.) h01 = 0.;
+            if (h01 > 1.) h01 = 1.;
+            const int ic = Q.want_c ? find_bin(cv, Q.A.c) : -1;
+            double r, g, b;
+            hsv_to_rgb(h01, Q.P.color_saturation, w[u], r, g, b);
+            n_sel += 1;
+            w_all += w[u];
+            if (!rest) {
+              w_in += w[u];
+              const unsigned cell = word[u];
+              if (cell < (unsigned)tcells) {
+                if (w[u] != 0.) atomicAdd(&cells[cell], w[u]);
+                if (NCH > 1) {
+                  if (r != 0.) atomicAdd(&cells[tcells + cell], r);
+                  if (g != 0.) atomicAdd(&cells[2 * tcells + cell], g);
+                  if (b != 0.) atomicAdd(&cells[3 * tcells + cell], b);
+                }
+              }
+            } else {
+              const int ix = (int)(word[u] & 0x7ffu) - 1, iy = (int)((word[u] >> 11) & 0x7ffu) - 1;
+              if (ix >= 0) {
+                atomicAdd(&lx[ix], w[u]);
+                atomicAdd(&lx[nx + ix], r);
+                atomicAdd(&lx[2 * nx + ix], g);
+                atomicAdd(&lx[3 * nx + ix], b);
+              }
+              if (iy >= 0) {
+                atomicAdd(&ly[iy], w[u]);
+                atomicAdd(&ly[ny + iy], r);
+                atomicAdd(&ly[2 * ny + iy], g);
+                atomicAdd(&ly[3 * ny + iy], b);
               }
             }
-          } else {
-            const int ix = (int)(word[u] & 0x7ffu) - 1, iy = (int)((word[u] >> 11) & 0x7ffu) - 1;
-            ic = (int)((word[u] >> 22) & 0x1ffu) - 1;
-            if (ix >= 0) {
-              atomicAdd(&lx[ix], w[u]);
-              atomicAdd(&lx[nx + ix], r);
-              atomicAdd(&lx[2 * nx + ix], g);
-              atomicAdd(&lx[3 * nx + ix], b);
+            if (ic >= 0) {
+              atomicAdd(&lc[ic], w[u]);
+              atomicAdd(&lc[nc + ic], r);
+              atomicAdd(&lc[2 * nc + ic], g);
+              atomicAdd(&lc[3 * nc + ic], b);
             }
-            if (iy >= 0) {
-              atomicAdd(&ly[iy], w[u]);
-              atomicAdd(&ly[ny + iy], r);
-              atomicAdd(&ly[2 * ny + iy], g);
-              atomicAdd(&ly[3 * ny + iy], b);
-            }
-          }
-          if (ic >= 0) {
-            atomicAdd(&lc[ic], w[u]);
-            atomicAdd(&lc[nc + ic], r);
-            atomicAdd(&lc[2 * nc + ic], g);
-            atomicAdd(&lc[3 * nc + ic], b);
           }
         }
       }
+      s0 = sn;
+      e0 = en;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) k0[k] = kn[k];
     }
   }
   __syncthreads();
@@ -1224,6 +1254,7 @@ hipError_t plot_tail_plan(int64_t n, const xrt_hip_plot_tail& t, PlotTailPlan* p
   q += tab_b;
   plan->share = reinterpret_cast<int*>(q);
   Q.want_c = t.hist_c != nullptr;
+  Q.chunks = chunks;
   plan->Q = Q;
   plan->n = n;
   plan->chunks = chunks;

@@ -97,7 +97,7 @@ __device__ __forceinline__ bool ray_selected(int st, int ray_flags) {
 // ---- the plot in the tail of a pass ------------------------------------------------------------
 #define PLOT_TAIL_MAX_TILES 56          // T + 2 run starts + 5 state counts in <= 64 bytes
 #define PLOT_TAIL_MAX_BINS_XY 2046      // 11 bits each for ix + 1, iy + 1 of a ray outside the tiles
-#define PLOT_TAIL_MAX_BINS_C 510        //  9 bits for ic + 1
+#define PLOT_TAIL_MAX_BINS_C 4094       // (the colour histogram lives in LDS beside the planes)
 #define PLOT_TAIL_SELECTED 0x80000000u
 
 struct PlotTail {
@@ -108,10 +108,12 @@ struct PlotTail {
   unsigned mtx, mty;       // floor(2^32 / tx) + 1 (0 for tx = 1): ix / tx = umulhi(ix, mtx)
   int pitch;               // bytes per wave (64 rays) of the run table: 32 or 64
   int want_c;              // the colour histogram is wanted (ePos)
+  int64_t chunks;          // waves of 64 rays the beam has
   double* w;               // [chunks * 64] records, each wave's rays sorted by tile
-  double* hue;
-  unsigned* word;          // a tile's ray: cell in the tile | (ic + 1) << 16;
-                           // others (bucket T): (ix + 1) | (iy + 1) << 11 | (ic + 1) << 22
+  double* hue;             // the colour DATUM (x c_factor): hue and colour bin are formed by
+                           // plot_tail_tiles, whose arithmetic units idle behind the LDS
+  unsigned* word;          // a tile's ray: cell in the tile;
+                           // others (bucket T): (ix + 1) | (iy + 1) << 11
                            //                    | PLOT_TAIL_SELECTED if the plot's ray flags take it
   unsigned char* tab;      // [chunk][pitch]: run starts of buckets 0 .. T + 1, then the five counts
 };
@@ -166,23 +168,18 @@ __device__ __forceinline__ PlotStash plot_tail_take(const PlotTail& Q, double x,
     w = Jss + Jpp;
   w *= Q.P.source_weight;
   const double cv = plot_field(Q.fc, x, y, z, a, b, c, path, E) * Q.P.c_factor;
-  double h01 = div_rn((cv - Q.A.c.lo) * Q.P.color_factor, Q.A.c.hi - Q.A.c.lo);
-  if (h01 < 0.) h01 = 0.;
-  if (h01 > 1.) h01 = 1.;
   const int ix = find_bin(plot_field(Q.fx, x, y, z, a, b, c, path, E) * Q.P.x_factor, Q.A.x);
   const int iy = find_bin(plot_field(Q.fy, x, y, z, a, b, c, path, E) * Q.P.y_factor, Q.A.y);
-  const int ic = Q.want_c ? find_bin(cv, Q.A.c) : -1;
   s.w = w;
-  s.hue = h01;
+  s.hue = cv;
   if (ix >= 0 && iy >= 0) {
     // (exact for ix < 2^16: the bins of a plot)
     const int tjx = Q.mtx ? (int)__umulhi((unsigned)ix, Q.mtx) : ix;
     const int tjy = Q.mty ? (int)__umulhi((unsigned)iy, Q.mty) : iy;
     s.tile = tjy * Q.ntx + tjx;
-    s.word = (unsigned)((iy - tjy * Q.ty) * Q.tx + (ix - tjx * Q.tx)) | (unsigned)(ic + 1) << 16;
+    s.word = (unsigned)((iy - tjy * Q.ty) * Q.tx + (ix - tjx * Q.tx));
   } else {
-    s.word = (unsigned)(ix + 1) | (unsigned)(iy + 1) << 11 | (unsigned)(ic + 1) << 22 |
-             PLOT_TAIL_SELECTED;
+    s.word = (unsigned)(ix + 1) | (unsigned)(iy + 1) << 11 | PLOT_TAIL_SELECTED;
   }
   return s;
 }
@@ -196,6 +193,7 @@ __device__ __forceinline__ double permute_f64(int dst, double v) {
 
 // All 64 lanes of the wave, converged; lane l holds the record of ray 64 * chunk + l (st 0: none).
 __device__ __forceinline__ void plot_tail_emit(const PlotTail& Q, int64_t chunk, const PlotStash& s) {
+  if (chunk >= Q.chunks) return;       // (the last block's waves beyond the end of the beam)
   const int lane = (int)__lane_id();
   const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
   // rank of every ray within its bucket; lane t: how many rays bucket t has
@@ -233,9 +231,11 @@ __device__ __forceinline__ void plot_tail_emit(const PlotTail& Q, int64_t chunk,
   const double w = permute_f64(pos, s.w), hue = permute_f64(pos, s.hue);
   const unsigned word = (unsigned)__builtin_amdgcn_ds_permute(pos << 2, (int)s.word);
   const int64_t o = chunk * 64 + lane;
-  __builtin_nontemporal_store(w, Q.w + o);
-  __builtin_nontemporal_store(hue, Q.hue + o);
-  __builtin_nontemporal_store(word, Q.word + o);
+  // (plain stores: plot_tail_tiles reads the records right behind this kernel, several tiles'
+  // blocks each line of a wide beam -- out of the memory-side cache if they are still there)
+  Q.w[o] = w;
+  Q.hue[o] = hue;
+  Q.word[o] = word;
 }
 
 }  // namespace xrt
