@@ -738,13 +738,17 @@ typedef struct xrt_hip_aperture {
    * the reference the test also runs on the rays that do NOT enter (state <= 0), on their
    * untransformed coordinates, and relabels them in the incoming beam (:1198-1203). */
   int32_t poly_n;
-  int32_t reserved;
+  int32_t own_marks;           /* 1: the states of beam_inout already carry THIS aperture's marks
+                                  (the call that makes the beam in the aperture's frame after a
+                                  states-only call on the same arrays): a ray in state lost_num
+                                  was alive when it arrived. Not with a polygon (see above). */
   const double* poly_xz;
 } xrt_hip_aperture;
 
 /* out_local may be NULL (then out_global must be too): only the states in beam_inout are
  * updated -- 52 B read and <= 4 B written per ray; the beam in the aperture's frame can be made
- * later by a second call on the same arrays with a copy of the states as they were. */
+ * later by a second call on the same arrays, with a copy of the states as they were or, the
+ * states as this call left them, with own_marks = 1. */
 XRT_HIP_API int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* aperture,
                                                    xrt_hip_beam* beam_inout,
                                                    xrt_hip_beam* out_local,

@@ -196,7 +196,7 @@ class Aperture(ctypes.Structure):
                 ('glo_adds_path', ctypes.c_int32),
                 ('shade', ctypes.c_double * 2),
                 ('poly_n', ctypes.c_int32),
-                ('reserved', ctypes.c_int32),
+                ('own_marks', ctypes.c_int32),
                 ('poly_xz', ctypes.c_void_p)]
 
 

@@ -137,6 +137,7 @@ class RectangularAperture(object):
         dev = torch.device('cuda', torch.cuda.current_device())
         beam.to_struct(dev)
         rs.flush_pending(beam, only_state=True)    # (beam.state changes in place below)
+        rs.before_states_change(beam)
         from . import oes as roe
         if not needNewGlobal and roe.fuseConsumers:
             return _DeferredLocal(self, beam, dev).local
@@ -181,7 +182,7 @@ class RectangularAperture(object):
                                  opened, self.uuid)
 
 
-class _DeferredLocal(object):
+class _DeferredLocal(rs.SharesStates):
     """``propagate`` when only the states are certain to be needed: ONE launch reads the
     geometry and marks the stopped rays in the incoming beam (52 B read, <= 4 B written per ray
     -- out_local NULL in xrt_hip_aperture_propagate_f64_dev); the beam in the aperture's frame
@@ -203,11 +204,22 @@ class _DeferredLocal(object):
         object.__setattr__(was, '_h', {})
         object.__setattr__(was, '_d', dict(beam._d))
         object.__setattr__(was, 'parentId', None)
-        was._d['state'] = beam._d['state'].clone()
+        # the states the later launch starts from: as THIS launch leaves them (the rays it stops
+        # carry its own number: own_marks), shared until another aperture is about to mark the
+        # same beam. A polygon also relabels rays that were dead already, and a beam that has
+        # been through this aperture before holds its number from then: a copy of the states as
+        # they are now, as before round 6.
+        seen = beam.__dict__.setdefault('_stopped_by', set())
+        self.own_marks = not hasattr(aperture, 'vertices') and aperture.lostNum not in seen
+        seen.add(aperture.lostNum)
+        if not self.own_marks:
+            was._d['state'] = beam._d['state'].clone()
         self.was = was
         self.tensors = {id(t) for t in beam._d.values()}
         self.state = 'pending'
         self._launch(beam, None)
+        if self.own_marks:
+            self._share_states(was)
         beam._h.pop('state', None)       # the kernel updated beam.state in HBM
         self.local = rs.LazyBeam(self, 'local')
         rs.inherit_scalars(self.local, beam)
@@ -229,6 +241,7 @@ class _DeferredLocal(object):
         rs._PENDING.discard(self)
         if self.state != 'done':
             local = rs.Beam.empty_like_on_device(self.was, self.device)
+            self.record.own_marks = int(self.own_marks)
             self._launch(self.was, local)     # (one that raises is raised again by the next look)
             self.state = 'done'
             self.local._adopt_arrays(local)

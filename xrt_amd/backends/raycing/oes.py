@@ -788,7 +788,7 @@ class OE(object):
 fuseConsumers = os.environ.get('XRT_HIP_NO_FUSE', '') != '1'
 
 
-def _as_it_is(beam, own_states=False):
+def _as_it_is(beam, own_states=False, sharer=None):
     """-> (a beam of the same device arrays as *beam* has at this moment, their ids). Later
     assignments to *beam* replace its arrays and do not reach the copy; writes INTO the arrays
     come after their readers (sources.flush_pending). *own_states*: with a copy of the states,
@@ -801,7 +801,9 @@ def _as_it_is(beam, own_states=False):
     if 'createdByDiffract' in beam.__dict__:
         snap.createdByDiffract = beam.createdByDiffract
     held = set(id(t) for t in snap._d.values())
-    if own_states:
+    if own_states and sharer is not None:
+        sharer._share_states(snap)        # (its own copy when an aperture is about to write them)
+    elif own_states:
         snap._d['state'] = snap._d['state'].clone()
     return snap, held
 
@@ -820,7 +822,7 @@ def _locals_on_demand(oe, *materials):
     return True
 
 
-class _LocalsOnDemand(object):
+class _LocalsOnDemand(rs.SharesStates):
     """The local beams of an element whose pass has written the global beam only (308 -> 200 B
     per ray and surface): *run(beam)* -> the real local beams, called with the input as it was
     (its own copy of the states) the first time one of them is looked at. The element then
@@ -830,7 +832,7 @@ class _LocalsOnDemand(object):
     def __init__(self, oe, beam, count, run):
         self.oe, self.run = oe, run
         beam.to_struct(_device())                    # everything up in HBM now
-        self.was, self.tensors = _as_it_is(beam, own_states=True)
+        self.was, self.tensors = _as_it_is(beam, own_states=True, sharer=self)
         self.locals = [rs.LazyBeam(self, k) for k in range(count)]
         oe._adopt(self.locals, beam)
         self.state = 'pending'
@@ -854,7 +856,7 @@ class _LocalsOnDemand(object):
             self.tensors = ()
 
 
-class _DeferredReflect(object):
+class _DeferredReflect(rs.SharesStates):
     """OE.reflect not launched yet. States: pending -> done (plain pass: both beams), or
     pending -> global (the next element took the global beam: the pass without its local beam,
     200 instead of 308 B per ray) -> done (the local beam, by the pass run again, if somebody
@@ -899,7 +901,7 @@ class _DeferredReflect(object):
         """After a launch that left a beam out: what is needed to make it later."""
         held = self.beam
         if type(held) is not rs.LazyBeam or held.__dict__['_filled']:
-            self.beam, self.tensors = _as_it_is(held, own_states=True)
+            self.beam, self.tensors = _as_it_is(held, own_states=True, sharer=self)
         # (else: the rays of a source that were made in this pass's registers -- its record
         # makes them again)
         self.optional = True

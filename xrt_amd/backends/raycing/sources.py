@@ -70,6 +70,8 @@ class Beam(object):
                 for k in _SCALAR_ATTRS:     # listOfAttrs, beams.py:95-105
                     if k in copyFrom.__dict__:
                         object.__setattr__(self, k, copyFrom.__dict__[k])
+                if '_stopped_by' in copyFrom.__dict__:
+                    self.__dict__['_stopped_by'] = set(copyFrom.__dict__['_stopped_by'])
             else:   # any object with xrt's Beam attributes (e.g. the reference's)
                 for name in _ARRAY_FIELDS:
                     if hasattr(copyFrom, name):
@@ -462,6 +464,37 @@ class _PendingOps(object):
 
 
 _PENDING = _PendingOps()
+
+# Records that keep the STATES of a beam as they are at some moment (to make a beam that was left
+# out later, from the same input) share the state tensor until somebody is about to change it in
+# place -- apertures are the only ones who do -- and take their own copy then (a copy per record
+# at once was ten 40-MB copy launches in a pass of the Balder chain, five of them never needed).
+_STATE_SHARERS = _weakref.WeakSet()
+
+
+class SharesStates(object):
+    """Mixin of such a record: ``_share_states(snapshot)`` after taking the snapshot."""
+
+    def _share_states(self, snap):
+        self._sharing = snap
+        _STATE_SHARERS.add(self)
+
+    def own_states_now(self):
+        snap = self.__dict__.pop('_sharing', None)
+        _STATE_SHARERS.discard(self)
+        if snap is not None and 'state' in snap._d:
+            snap.state = snap._d['state'].clone()
+
+
+def before_states_change(beam):
+    """Called by whoever is about to write the states of *beam* in place."""
+    t = (beam.__dict__.get('_real_d') or beam.__dict__.get('_d') or {}).get('state')
+    if t is None:
+        return
+    for op in list(_STATE_SHARERS):
+        snap = op.__dict__.get('_sharing')
+        if snap is not None and snap._d.get('state') is t:
+            op.own_states_now()
 _FILL_LOCK = _threading.RLock()      # a beam looked at from another thread: one launch, complete
 
 
@@ -586,6 +619,8 @@ def inherit_scalars(new, old):
     for key in _SCALAR_ATTRS:
         if key in old.__dict__:
             object.__setattr__(new, key, old.__dict__[key])
+    if '_stopped_by' in old.__dict__:     # (apertures whose marks the states may carry)
+        new.__dict__.setdefault('_stopped_by', set()).update(old.__dict__['_stopped_by'])
 
 
 def copy_beam(beamTo, beamFrom, indarr, includeState=False, includeJspEsp=True):

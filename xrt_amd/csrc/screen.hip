@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_apertur
     es = reinterpret_cast<const double2*>(in.Es_ri)[i];
     ep = reinterpret_cast<const double2*>(in.Ep_ri)[i];
   }
-  const bool good = st > 0;
+  // (own_marks: the states are those a states-only call of this aperture left behind -- a ray it
+  // stopped then was alive when it arrived, and is stopped again by the same test)
+  const bool good = st > 0 || (A.own_marks && st == A.lost_num);
   if (good) {
     const double gx = x - A.center[0], gy = y - A.center[1], gz = z - A.center[2];
     const double ga = a, gb = b, gc = c;
