@@ -36,6 +36,10 @@ for elev in (False, True):
     nb = lbN.nrays // n
     entered = sum(one['n_enter'] for one in info)
     best = min(times)
+    if not elev:
+        print('live lanes per bounce (rays that enter / all rays): ' +
+              ' '.join('%.3f' % (one['n_enter'] / n) for one in info) +
+              '; hit: ' + ' '.join('%.3f' % (one['hit'] / n) for one in info))
     print('n %d elevation %s: %d bounces, %d ray-bounces, best %.3f ms (median %.3f) = %.3g '
           'ray-surface intersections / s; %.3f ms per bounce'
           % (n, elev, nb, entered, best * 1e3, np.median(times) * 1e3, entered / best,

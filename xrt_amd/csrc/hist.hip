@@ -747,6 +747,11 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_tail_tiles(
     int64_t per = (nchunks + slices - 1) / slices;
     per = (per + 63) / 64 * 64;
     const int64_t c0 = slice * per, c1 = c0 + per < nchunks ? c0 + per : nchunks;
+    // rows a wave takes at a time: 64 (a lane each), or fewer when the slice is short -- a beam of
+    // 1e5 rays is 1563 rows, 64 of them 4096 rays that ONE wave would add up while the other
+    // fifteen of its block watch (70 us instead of 20); all 64 lanes work on the rays either way
+    int G = 64;
+    while (G > 4 && (c1 - c0) < (int64_t)nwaves * 2 * G) G >>= 1;
     // lane l takes the run of chunk g0 + l; the bytes of the NEXT 64 chunks are requested before
     // this group is worked on (a bucket with few rays is all walk: one dependent load per step
     // made a cold tile's block the last to finish, 0.3 ms at 1e7 rays)
@@ -754,7 +759,7 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_tail_tiles(
       s_ = e_ = 0;
 #pragma unroll
       for (int k = 0; k < 5; ++k) k_[k] = 0;
-      if (c < c1) {
+      if (c < c1 && lane < G) {
         const unsigned char* row = Q.tab + c * Q.pitch;
         s_ = row[tile];
         e_ = row[tile + 1];
@@ -764,10 +769,22 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_tail_tiles(
         }
       }
     };
-    unsigned s0, e0, k0[5], sn, en, kn[5];
-    row_of(c0 + (int64_t)wave * 64 + lane, s0, e0, k0);
-    for (int64_t g0 = c0 + (int64_t)wave * 64; g0 < c1; g0 += (int64_t)nwaves * 64) {
-      row_of(g0 + (int64_t)nwaves * 64 + lane, sn, en, kn);
+    // (four groups of 64 waves' rows are requested at a time: a bucket with few rays is all walk,
+    // and one dependent byte load per 64 rows made a cold tile's blocks the last to finish)
+    constexpr int AHEAD = 4;
+    const int64_t hop = (int64_t)nwaves * G;
+    unsigned sa[AHEAD], ea[AHEAD], ka[AHEAD][5], sb[AHEAD], eb[AHEAD], kb[AHEAD][5];
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) row_of(c0 + (int64_t)wave * G + q * hop + lane, sa[q], ea[q], ka[q]);
+    for (int64_t gq = c0 + (int64_t)wave * G; gq < c1; gq += AHEAD * hop) {
+#pragma unroll
+      for (int q = 0; q < AHEAD; ++q) row_of(gq + (AHEAD + q) * hop + lane, sb[q], eb[q], kb[q]);
+#pragma unroll
+      for (int q = 0; q < AHEAD; ++q) {
+      const int64_t g0 = gq + q * hop;
+      if (g0 >= c1) break;
+      const unsigned s0 = sa[q], e0 = ea[q];
+      const unsigned (&k0)[5] = ka[q];
       const int64_t c = g0 + lane;
 #pragma unroll
       for (int k = 0; k < 5; ++k) cnt[k] += (int)k0[k];
@@ -782,7 +799,7 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_tail_tiles(
         const int total = __shfl(incl, 63);
         // every run whole (a focused beam: all rays of these waves in this tile): ray j is
         // record g0 * 64 + j, nothing to search
-        const bool whole = total == 4096;
+        const bool whole = total == 64 * G;
         if (!whole) {
           pre[lane] = incl;
           bas[lane] = (int)(c * 64 + s0) - (incl - len);   // record = bas[chunk] + number
@@ -861,10 +878,14 @@ __global__ __launch_bounds__(HIST_BLOCK) void plot_tail_tiles(
           }
         }
       }
-      s0 = sn;
-      e0 = en;
+      }
 #pragma unroll
-      for (int k = 0; k < 5; ++k) k0[k] = kn[k];
+      for (int q = 0; q < AHEAD; ++q) {
+        sa[q] = sb[q];
+        ea[q] = eb[q];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ka[q][k] = kb[q][k];
+      }
     }
   }
   __syncthreads();

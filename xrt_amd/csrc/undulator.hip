@@ -150,8 +150,11 @@ __device__ __forceinline__ void und_ray(const UndulatorArgs& a, const double* __
 #ifdef UND_UNROLL
 #pragma unroll UND_UNROLL
 #endif
-    for (int64_t j = 0; j < a.jend; ++j) {
-      if (j + 1 < a.jend) ahead += N_REC;
+    // (a 32-bit node counter: the 64-bit comparison has no scalar form and cost every node two
+    // vector instructions, tools/kisa_audit.py)
+    const int jend = (int)a.jend;
+    for (int j = 0; j < jend; ++j) {
+      if (j + 1 < jend) ahead += N_REC;
 #pragma unroll
       for (int k = 0; k < N_PAD0; ++k) rn[k] = ahead[k];
       const double tg = r[N_TG], ag = r[N_AG], s = r[N_S], c = r[N_C];

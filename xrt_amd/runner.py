@@ -238,24 +238,31 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
                 # dependent nodes, not the launch of the graph.)
                 if ran_eagerly and recorded is None and left > 1 and not refused:
                     recorded = graphs.IterationGraph(iteration)
-                    if left >= 60:
+                    if left >= 120:
                         # Which is faster HERE: a replay or the eager loop? A stream takes
                         # kernels back to back while the host runs ahead; the nodes of a graph
                         # wait for one another through barrier packets (~8 us each). Beams of
-                        # ~1e6 rays and more are GPU-bound and lose by replaying (BENCH_r04:
-                        # 0.93x). Six iterations each way, all of them counted.
-                        clock = []
-                        for run in (recorded.replay, iteration):
-                            torch.cuda.current_stream().synchronize()
-                            t0 = time.perf_counter()
-                            for _ in range(6):
-                                run()
-                            torch.cuda.current_stream().synchronize()
-                            clock.append(time.perf_counter() - t0)
-                        left -= 12
-                        graph_choice['replay_ms'] = clock[0] / 6 * 1e3
-                        graph_choice['eager_ms'] = clock[1] / 6 * 1e3
-                        if clock[0] > clock[1]:
+                        # ~1e6 rays and more are GPU-bound and lose by replaying. Both ways
+                        # warm (the eager one has been since before the recording; the replay's
+                        # first launches upload the graph), then four rounds of five iterations
+                        # each way, ALTERNATELY -- a cold eager loop measured after a warm
+                        # replay made the graph look better than it is --
+                        # and the graph stays only if it wins by more than 3 %.
+                        for run in (recorded.replay, recorded.replay, iteration, iteration):
+                            run()
+                        clock = [0., 0.]
+                        for _ in range(4):
+                            for which, run in enumerate((recorded.replay, iteration)):
+                                torch.cuda.current_stream().synchronize()
+                                t0 = time.perf_counter()
+                                for _ in range(5):
+                                    run()
+                                torch.cuda.current_stream().synchronize()
+                                clock[which] += time.perf_counter() - t0
+                        left -= 44
+                        graph_choice['replay_ms'] = clock[0] / 20 * 1e3
+                        graph_choice['eager_ms'] = clock[1] / 20 * 1e3
+                        if clock[0] > 0.97 * clock[1]:
                             recorded.close()
                             recorded, refused = None, True
                         graph_choice['replaying'] = not refused
