@@ -476,6 +476,56 @@ def cpu_baseline_reflect(nrays=10_000_000, numpy_rays=10_000_000):
 # ----------------------------------------------------------------------------
 # P2
 # ----------------------------------------------------------------------------
+def multi_gpu_self_check(world, rank, dist):
+    """N > 1 only, before anything is timed: a small Kirchhoff integral (2e4 samples x 64 x 64
+    points) computed THREE ways -- every rank its pixel tile + the packed all_gather over RCCL
+    (what the timed steps do), rank 0 alone on its own GPU, and rank 0 driving two DISTINCT GPUs
+    in one process (multigpu.kirchhoff_devices on devices [0, 1]: peer copies between real
+    devices, the parametrisations of tests/test_gpu_kirchhoff.py and test_gpu_diffract.py that
+    skip on a one-GPU box) -- must agree to 1e-12 norm-wise. The outcome goes into the line
+    (`roofline.multi_gpu_self_check` 1 / 0 and a message): a failure is reported, it does not
+    take the measured numbers down with it (the split mirrored is
+    xrt/backends/raycing/myopencl.py:455-533)."""
+    from xrt_amd import hipcalls, multigpu, workloads
+    out = dict(ok=False, ranks=world)
+    try:
+        dev = torch.device('cuda', torch.cuda.current_device())
+        h = workloads.kirchhoff_custom(20000, 64)
+        up = lambda a, dt=np.float64: torch.from_numpy(  # noqa: E731
+            np.ascontiguousarray(a, dtype=dt)).to(dev)
+        ns, npix = h['ns'], h['px'].size
+        smp = [up(h['sx']), up(h['sy']), up(h['sz']), up(np.zeros(ns)), up(np.ones(ns)),
+               up(np.zeros(ns)), up(h['nl']), up(h['k']), up(h['Es'], np.complex128),
+               up(h['Ep'], np.complex128)]
+        p0, p1 = multigpu.tile_range(npix, rank, world)
+        tile = hipcalls.kirchhoff(up(h['px'][p0:p1]), up(h['py'][p0:p1]), up(h['pz'][p0:p1]),
+                                  *smp)[:5]
+        full = multigpu.all_gather_packed(tile, npix, dist, rank, world)
+        alone = hipcalls.kirchhoff(up(h['px']), up(h['py']), up(h['pz']), *smp)[:5]
+        worst = 0.
+        for a, b in zip(full, alone):
+            worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-300)))
+        out['gather_vs_one_gpu'] = worst
+        ok = worst <= 1e-12
+        if rank == 0 and torch.cuda.device_count() >= 2 and \
+                not os.environ.get('XRT_BENCH_SHARE_GPU'):
+            both = multigpu.kirchhoff_devices((up(h['px']), up(h['py']), up(h['pz'])), smp, [0, 1])
+            for d in (0, 1):
+                torch.cuda.synchronize(d)
+            w2 = 0.
+            for a, b in zip(both, alone):
+                w2 = max(w2, float((a.to(dev) - b).abs().max() / b.abs().max().clamp_min(1e-300)))
+            out['two_devices_in_one_process_vs_one_gpu'] = w2
+            ok = ok and w2 <= 1e-12
+        flag = torch.tensor([1. if ok else 0.], dtype=torch.float64,
+                            device=dev if dist.get_backend() == 'nccl' else torch.device('cpu'))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        out['ok'] = bool(flag.item() > 0.5)
+    except Exception as e:  # noqa: BLE001  (reported, never fatal: see the docstring)
+        out['error'] = repr(e)[:300]
+    return out
+
+
 def kirchhoff_inputs(cfg, device):
     """SURVEY 8d cfg4 / cfg5 (xrt_amd.workloads.kirchhoff_case), samples
     uploaded to HBM."""
@@ -744,6 +794,33 @@ def bench_e2e(nrays, repeats=20):
     t1 = time.perf_counter()
     flux = float(plot.total2D.sum())
     read_back = time.perf_counter() - t1
+    # the same job with the plot as launches of its own (round 5: the screen alone rides the pass,
+    # the 100-B image is written and read back) ...
+    os.environ['XRT_PLOT_TAIL_OFF'] = '1'
+    try:
+        runner.run_ray_tracing([make_plot()], repeats=3, beamLine=bl)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.run_ray_tracing([make_plot()], repeats=repeats, beamLine=bl)
+        torch.cuda.synchronize()
+        wall_own = (time.perf_counter() - t0) / repeats
+    finally:
+        del os.environ['XRT_PLOT_TAIL_OFF']
+    # ... and without any plot (the pass with the screen in its tail alone): what the plot adds
+    from xrt_amd.backends.raycing import sources as _rs
+
+    def no_plot():
+        beams = run_process(bl)
+        beams['focus'].nrays                  # (the first look at the image launches the pass)
+        _rs.flush_pending()
+    for _ in range(3):
+        no_plot()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        no_plot()
+    torch.cuda.synchronize()
+    wall_pass = (time.perf_counter() - t0) / repeats
     # the same job with every call an immediate launch and every beam written, looked at or not
     # (what rounds 1-4 did)
     from xrt_amd.backends.raycing import oes as roe
@@ -788,23 +865,33 @@ def bench_e2e(nrays, repeats=20):
                       'iterations carry a few us of event gaps: the ratio can exceed 1)' % n_probe,
         read_back_ms_once=read_back * 1e3, flux_in_plot=flux,
         ms_per_iteration_every_beam_written=wall_all * 1e3,
-        bytes_per_ray=dict(source_mirror_screen=100, histograms=44, as_separate_passes=652),
-        fused='GeometricSource.shine, OE.reflect and Screen.expose are ONE pass '
-              '(reflect_fused_gen_scr): the rays are made in the registers of the mirror kernel, '
-              'the screen\'s image comes out of its tail; the "source" and "reflect" steps of '
-              'gpu_ms_by_step only hand out beams, the "screen" step is the pass. The script '
-              'plots the screen\'s image and nothing else: the source beam, the mirror\'s local '
-              'and global beams are not written (each is made on demand, by the same kernels, '
-              'the first time somebody looks at it, and written at once from then on -- '
-              'tests/test_gpu_fusion.py); ms_per_iteration_every_beam_written = the same job '
-              'as four immediate launches that write all of them (oes.fuseConsumers = False)',
+        ms_per_iteration_plot_as_own_launches=wall_own * 1e3,
+        ms_per_iteration_without_plot=wall_pass * 1e3,
+        plot_adds_ms=(wall - wall_pass) * 1e3,
+        bytes_per_ray=dict(plot_records_written=20.5, plot_records_read=20.5,
+                           round5_image_and_histograms=184, as_separate_passes=652),
+        fused='GeometricSource.shine, OE.reflect, Screen.expose and the XYCPlot of the image are '
+              'ONE pass (reflect_fused_gen_scr_plot, round 6): the rays are made in the '
+              'registers of the mirror kernel, the screen\'s image stays in registers, the tail '
+              'forms weight, hue and bins and every wave writes its 64 rays sorted by tile of '
+              'the 2-D histogram as 20-B records; plot_tail_tiles and plot_hist_reduce add them '
+              'up. Neither the source beam, the mirror\'s beams nor the image are written (each '
+              'is made on demand, by the same kernels, the first time somebody looks at it, '
+              'and written at once from then on -- tests/test_gpu_fusion.py). '
+              'ms_per_iteration_plot_as_own_launches = round 5\'s route (the image written, '
+              'plot_hist_rays / tiles / reduce); ms_per_iteration_without_plot = the pass with '
+              'the screen alone; ms_per_iteration_every_beam_written = four immediate launches '
+              'that write everything (oes.fuseConsumers = False). The "histograms" step of '
+              'gpu_ms_by_step is the pass AND the plot now (accumulate_plot launches both)',
         roofline=dict(bound='hbm', kernel='the pass and the plot of one iteration',
-                      achieved=144. * nrays / wall / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
-                      frac=144. * nrays / wall / HBM_PEAK, traffic=None,
-                      note='144 B per ray algorithmic as built: 100 (image) written by the one '
-                           'pass, 44 read by the plot -- the pass is bound by its arithmetic '
-                           '(Philox, Box-Muller, the root search), not by HBM. (652 B as four '
-                           'separate passes that write every beam, round 4.)'))
+                      achieved=41. * nrays / wall / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s',
+                      frac=41. * nrays / wall / HBM_PEAK,
+                      traffic=load_plot_tail_traffic() if nrays == 10_000_000 else None,
+                      traffic_source='profiles/plot_tail_traffic.json (tools/pmc_plot_tail.sh)',
+                      note='41 B per ray algorithmic as built (20.5 written by the pass, 20.5 '
+                           'read by plot_tail_tiles; round 5: 184) -- the pass is bound by its '
+                           'arithmetic (Philox, Box-Muller, the root search, the bins), not by '
+                           'HBM.'))
     # beams of the size most xrt scripts trace (1e5 rays per iteration): the host, not the GPU,
     # bounds the eager loop; run_ray_tracing(graph=True) replays one HIP graph per iteration
     small = {}
@@ -1166,6 +1253,15 @@ def load_hist_traffic(bins):
         return None
 
 
+def load_plot_tail_traffic():
+    """HBM bytes of one e2e iteration with the plot in the tail of the pass (PMC summary)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'plot_tail_traffic.json')) as f:
+            return json.load(f)['tail']['hbm_bytes_per_iteration']
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def load_traffic(kernel, algorithmic=None):
     """HBM bytes per launch from the committed PMC summary (profiles/), or None. *algorithmic*:
     the bytes the timed launch moves by its contract -- the counter figure is only reported for
@@ -1210,6 +1306,8 @@ def main():
         from xrt_amd import _lib
         _lib.require_gpu()                    # no CPU fallback: fail loudly
     world, rank, local, dist = setup_dist(args)
+    self_check = multi_gpu_self_check(world, rank, dist) \
+        if world > 1 and dist is not None and not DRY_RANKS else None
     main_res = bench_reflect(args, world, rank, dist)
     line = dict(
         # BASELINE.json's metric, verbatim; `value` is its first quantity, the second one
@@ -1285,6 +1383,9 @@ def main():
             line['kirchhoff']['cpu_baseline'] = cpu_baseline_kirchhoff(host)
     if DRY_RANKS:
         line['dry_ranks'] = True
+    if self_check is not None:
+        line['multi_gpu_self_check'] = self_check
+        line['roofline']['multi_gpu_self_check'] = 1 if self_check.get('ok') else 0
     compact_for_the_record(line, world)          # (writes `summary`, the LAST key of the line)
     if rank == 0:
         line_out.write(json.dumps(line) + '\n')
@@ -1375,6 +1476,9 @@ def compact_for_the_record(line, world):
         ('balder_every_beam_written_ms', ('balder', 'seconds_every_beam_written')),
         ('balder_launches', ('balder', 'launches_per_pass')),
         ('e2e_ms_per_iteration', ('e2e', 'ms_per_iteration')),
+        ('e2e_plot_adds_ms', ('e2e', 'plot_adds_ms')),
+        ('e2e_plot_as_own_launches_ms', ('e2e', 'ms_per_iteration_plot_as_own_launches')),
+        ('e2e_traffic', ('e2e', 'roofline', 'traffic')),
         ('e2e_every_beam_written_ms', ('e2e', 'ms_per_iteration_every_beam_written')),
         ('e2e_1e5_eager_ms', ('e2e', 'small_beams', '100000_rays', 'eager_ms_per_iteration')),
         ('e2e_1e5_graph_ms', ('e2e', 'small_beams', '100000_rays', 'graph_ms_per_iteration')),

@@ -526,6 +526,11 @@ typedef struct xrt_hip_bounce {
   double* elev_out[4];
   /* lb.s / phi / r of a parametric surface (reflect.py:1066-1069), [n] each, or NULL */
   double* spr_out[3];
+  /* How many rays of `in` still enter (what the previous bounce returned in counts[0]), or 0 =
+   * not known. A hint that changes speed only: below a quarter of the rays the bounce runs in
+   * its sparse form (an index of the entering rays, lanes that take the next ray when theirs
+   * is done), whose results are bit for bit those of the dense one. */
+  int64_t entering_hint;
 } xrt_hip_bounce;
 
 XRT_HIP_API size_t xrt_hip_bounce_workspace_bytes(int64_t n);

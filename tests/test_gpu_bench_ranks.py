@@ -34,5 +34,9 @@ def test_two_ranks_on_one_gpu():
     assert 'all_gather_into_tensor' in k['gather']
     assert k['in_process'] and 'error' not in k['in_process'], k['in_process']
     assert k['in_process']['devices'] == [0, 0] and k['in_process']['value'] > 1e11
+    # the self-check that runs before the timed steps when N > 1 (tiles + gather against one GPU)
+    chk = d['multi_gpu_self_check']
+    assert chk['ok'] and chk['gather_vs_one_gpu'] <= 1e-12, chk
+    assert d['roofline']['multi_gpu_self_check'] == 1
     for leg in ('e2e', 'softimax', 'hist'):          # single-GPU legs stay out of a multi-rank line
         assert leg not in d

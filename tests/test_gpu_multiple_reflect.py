@@ -180,3 +180,32 @@ def test_one_million_rays_against_the_oracle():
     # every footprint with state 1 lies on the toroid (true local frame of the element)
     k = lbN.nrays // n
     assert k >= 5 and np.bincount(gb.nRefl).argmax() >= 3
+
+
+def test_sparse_and_dense_bounces_are_the_same_bits():
+    """Round 6: a bounce in which fewer than a quarter of the rays still enter runs in its sparse
+    form (xrt_hip_bounce.entering_hint: an index of the entering rays, the hit search with lanes
+    that take the next ray when theirs is done, a dense finish -- three launches); the dense
+    kernel walks every lane through every phase. Every array of gb and of all footprints is
+    identical whichever form the bounces take: all dense, all sparse, or chosen by the hint."""
+    tor = element('g2_multi_toroid')
+    rays = case.point_source_rays(rs, 300000, 11)
+    got = {}
+    for form in ('dense', 'sparse', ''):
+        if form:
+            os.environ['XRT_HIP_MULTI_FORM'] = form
+        else:
+            os.environ.pop('XRT_HIP_MULTI_FORM', None)
+        try:
+            gb, lbN = tor.multiple_reflect(rays, maxReflections=50, needElevationMap=True)
+        finally:
+            os.environ.pop('XRT_HIP_MULTI_FORM', None)
+        got[form] = {(n, f): np.array(b.peek(f)) for n, b in (('gb', gb), ('lbN', lbN))
+                     for f in GEOM + ('E', 'state', 'nRefl', 'Jss', 'Jpp', 'Jsp', 'Es', 'Ep', 'theta',
+                                      'elevationD', 'elevationX', 'elevationY', 'elevationZ')}
+    assert got['dense'][('lbN', 'x')].size >= 4 * 300000          # several bounces
+    last = got['dense'][('lbN', 'state')][-300000:]
+    assert 0 < ((last == 1) | (last == 2)).sum() < 75000            # ... the last ones sparse by the hint
+    for form in ('sparse', ''):
+        for key, want in got['dense'].items():
+            assert np.array_equal(got[form][key], want, equal_nan=True), (form or 'hinted', key)

@@ -53,6 +53,11 @@ for env in "" "XRT_HIP_HIST_NO_SMALL=1" "XRT_HIP_NO_FUSE=1"; do echo "== [$env]"
 # the kernels of the Balder chain (bench.py balder leg) in launch order, one pass of the beam
 ( cd /tmp && rm -rf /tmp/pb && rocprofv3 --kernel-trace --stats -d /tmp/pb -o pb -- python $GRAFT_REPO_ROOT/tools/probe_balder.py > /tmp/pb.log 2>&1 )
 { grep '^{' /tmp/pb.log | cut -c1-400; python tools/prof_sequence.py /tmp/pb 30; } > profiles/r${RND}_balder_kernels.txt 2>&1
+# round 6: the plot in the tail of the pass -- HBM bytes of an e2e iteration either way
+# (profiles/plot_tail_traffic.json, read by bench.py), ms per iteration with focused / wide plot limits
+bash tools/pmc_plot_tail.sh > profiles/r${RND}_plot_tail_pmc.txt 2>&1
+{ python tools/probe_plot_tail.py 1e7 20; python tools/probe_plot_tail.py 1e5 200; } 2>&1 | grep -v amdgpu.ids > profiles/r${RND}_plot_tail.txt
+cp profiles/plot_tail_traffic.json $O/summaries/ 2>/dev/null
 hipcc --offload-arch=gfx950 -O3 -DNOUT=40 -DBLOCK=256 tools/probes/probe_occupancy.hip -o /tmp/po40 2>/dev/null && \
   timeout 300 /tmp/po40 > profiles/r${RND}_probe_occupancy_dcm_shape.txt 2>&1
 cp profiles/r${RND}_*.txt profiles/hist_traffic.json $O/summaries/ 2>/dev/null

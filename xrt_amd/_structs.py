@@ -338,6 +338,7 @@ class Bounce(ctypes.Structure):
         ('elev_in', ctypes.c_void_p * 4),
         ('elev_out', ctypes.c_void_p * 4),
         ('spr_out', ctypes.c_void_p * 3),
+        ('entering_hint', ctypes.c_int64),
     ]
 
 

@@ -1287,6 +1287,7 @@ def _multiple_reflect(self, beam=None, maxReflections=1000, needElevationMap=Fal
             fp.grow(k)
         bounce = _structs.Bounce()
         bounce.nrefl_in = None if k == 0 else fp.ptr('nRefl', k - 1)
+        bounce.entering_hint = 0 if k == 0 else left     # (rays in state 1 or 2 after bounce k - 1)
         bounce.nrefl_out = fp.ptr('nRefl', k)
         bounce.theta = fp.ptr('theta', k)
         for j, name in enumerate(elevation):

@@ -1,6 +1,8 @@
 // OE.multiple_reflect: the instantiations of reflect_multi for the built-in surface families
 // (user-defined surfaces bring theirs in their unit, user_unit.hip.in) and the launch logic
 // of one bounce.
+#include <stdlib.h>
+
 #include "reflect_multi_impl.h"
 
 namespace xrt {
@@ -26,20 +28,43 @@ struct MultiWs {
   GStat* g;
   double* part;
   double* tang;
+  double *ht, *hx, *hy, *hz;        // (the sparse form's hit records and index)
+  int32_t *hlost, *idx, *cnt;
+  int nseg;
 };
-static MultiWs multi_ws(void* workspace) {
+static size_t pad256(size_t b) { return (b + 255) / 256 * 256; }
+static MultiWs multi_ws(void* workspace, int64_t n) {
   char* w = reinterpret_cast<char*>(workspace);
   MultiWs L;
   L.counts = reinterpret_cast<unsigned long long*>(w);
   L.diag = reinterpret_cast<double*>(w + 128);
   L.g = reinterpret_cast<GStat*>(w + 256);
   L.part = reinterpret_cast<double*>(w + 512);
-  L.tang = reinterpret_cast<double*>(w + 512 + REFLECT_PART_BYTES);
+  char* q = w + 512 + REFLECT_PART_BYTES;
+  const size_t d = pad256((size_t)n * 8), i4 = pad256((size_t)n * 4);
+  L.nseg = (int)((n + MULTI_SEG - 1) / MULTI_SEG);
+  L.tang = reinterpret_cast<double*>(q);
+  q += d;
+  L.ht = reinterpret_cast<double*>(q);
+  q += d;
+  L.hx = reinterpret_cast<double*>(q);
+  q += d;
+  L.hy = reinterpret_cast<double*>(q);
+  q += d;
+  L.hz = reinterpret_cast<double*>(q);
+  q += d;
+  L.hlost = reinterpret_cast<int32_t*>(q);
+  q += i4;
+  L.idx = reinterpret_cast<int32_t*>(q);
+  q += pad256((size_t)L.nseg * MULTI_SEG * 4);
+  L.cnt = reinterpret_cast<int32_t*>(q);
   return L;
 }
 
 size_t bounce_workspace_bytes(int64_t n) {
-  return 512 + REFLECT_PART_BYTES + ((size_t)n * 8 + 255) / 256 * 256;
+  const size_t nseg = (size_t)((n + MULTI_SEG - 1) / MULTI_SEG);
+  return 512 + REFLECT_PART_BYTES + 5 * pad256((size_t)n * 8) + pad256((size_t)n * 4) +
+         pad256(nseg * MULTI_SEG * 4) + pad256(nseg * 4);
 }
 
 static int device_cus() {
@@ -59,7 +84,7 @@ hipError_t reflect_bounce_launch(const xrt_hip_pass& P, const xrt_hip_material& 
                                  const xrt_hip_bounce& B, void* workspace, hipStream_t st) {
   static_assert(sizeof(GStat) <= 256, "workspace slot");
   if (in.n <= 0) return hipSuccess;
-  const MultiWs W = multi_ws(workspace);
+  const MultiWs W = multi_ws(workspace, in.n);
   MultiLaunch L;
   L.st = st;
   L.P = &P;
@@ -80,6 +105,19 @@ hipError_t reflect_bounce_launch(const xrt_hip_pass& P, const xrt_hip_material& 
     L.A.elev_out[k] = B.elev_out[k];
   }
   for (int k = 0; k < 3; ++k) L.A.spr[k] = B.spr_out[k];
+  L.A.idx = W.idx;
+  L.A.cnt = W.cnt;
+  L.A.nseg = W.nseg;
+  L.A.ht = W.ht;
+  L.A.hx = W.hx;
+  L.A.hy = W.hy;
+  L.A.hz = W.hz;
+  L.A.hlost = W.hlost;
+  // (XRT_HIP_MULTI_FORM = dense / sparse: one form for every bounce, for A/B runs and tests)
+  const char* form = getenv("XRT_HIP_MULTI_FORM");
+  L.sparse = B.entering_hint > 0 && B.entering_hint * 4 < in.n;
+  if (form && form[0] == 'd') L.sparse = 0;
+  if (form && form[0] == 's') L.sparse = 1;
   hipLaunchKernelGGL(multi_init, dim3(1), dim3(1), 0, st, W.g);
   bool launched;
   BarrierSerial one_at_a_time(st);        // (grid barriers between the phases: reflect.h)

@@ -71,6 +71,14 @@ struct MultiAux {
   const double* elev_in[4];     // elevationD / X / Y / Z before the bounce; NULL = the
   double* elev_out[4];          //   initial values (reflect.py:214-218); out NULL = not wanted
   double* spr[3];               // lb.s / phi / r of a parametric surface, or NULL
+  // the sparse form of a bounce (reflect_multi_impl.h): the index of the entering rays in
+  // segments of MULTI_SEG rays (offsets within the segment, ascending; cnt[seg] of them), the hit
+  // records between its solve and its finish kernel
+  int32_t* idx;
+  int32_t* cnt;
+  int nseg;
+  double *ht, *hx, *hy, *hz;
+  int32_t* hlost;
 };
 struct MultiLaunch {   // one launch of reflect_multi
   hipStream_t st;
@@ -79,6 +87,7 @@ struct MultiLaunch {   // one launch of reflect_multi
   const xrt_hip_beam *in, *out;
   MultiAux A;
   int cus;             // compute units of the device
+  int sparse;          // few rays still enter: index + three launches instead of the one
 };
 
 // what a user-surface unit and the library that loads it must agree on

@@ -12,6 +12,7 @@ order of the iterations. While any plot limit is still automatic the first itera
 alone, as in the reference (its ``uniqueFirstRun``). numpy's global generator is shared
 by the workers (as it is by the reference's threads): reproducible runs use 1 thread."""
 import ctypes
+import os as _os
 import threading
 import time
 
@@ -56,8 +57,8 @@ def _join_the_pass(plot, beam, dev, lib):
     from .backends.raycing import oes as roe
     op = beam.__dict__.get('_op')
     if not roe.fuseConsumers or getattr(op, 'image', None) is not beam or op.state != 'pending' \
-            or plot.beamState is not None:
-        return False
+            or plot.beamState is not None or _os.environ.get('XRT_PLOT_TAIL_OFF', '') == '1':
+        return False            # (XRT_PLOT_TAIL_OFF=1: the plot's own launches, for A/B runs)
     axes = (plot.xaxis, plot.yaxis, plot.caxis)
     if any(a.limits is None for a in axes) or \
             any(a.field() not in _structs.PLOT_FIELDS for a in axes):
