@@ -1,5 +1,5 @@
 """CPU: the kernel times DESIGN.md quotes for the current round are the ones in the committed
-rocprofv3 summary (profiles/r05_kernel_stats.csv) -- the documents drifted from the profiles
+rocprofv3 summary (profiles/r06_kernel_stats.csv) -- the documents drifted from the profiles
 once."""
 import csv
 import os
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def averages():
     """{(kernel variant, grid): (calls, average ns)}"""
     out = {}
-    with open(os.path.join(ROOT, 'profiles', 'r05_kernel_stats.csv')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r06_kernel_stats.csv')) as f:
         rows = list(csv.reader(f))
     for r in rows[1:]:
         out[(r[0], int(r[1]))] = (int(r[2]), float(r[4]))
@@ -50,7 +50,7 @@ def test_design_quotes_the_committed_profile():
     # (the map kernel is a persistent launch: its grid no longer tells the 2^20-ray call from
     # the others, so the document quotes the bench line of the profiled run)
     import json
-    with open(os.path.join(ROOT, 'profiles', 'r05_bench_under_rocprof.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', 'r06_bench_under_rocprof.json')) as f:
         und_ms = json.load(f)['undulator']['ms']
     ms = quoted(text, r'`und_imap` 2\^20 rays × 48 nodes \*\*([\d.]+) ms in\s+the bench')
     assert abs(ms - und_ms) < 0.0006

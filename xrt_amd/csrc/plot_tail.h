@@ -167,9 +167,17 @@ __device__ __forceinline__ PlotStash plot_tail_take(const PlotTail& Q, double x,
   else
     w = Jss + Jpp;
   w *= Q.P.source_weight;
-  const double cv = plot_field(Q.fc, x, y, z, a, b, c, path, E) * Q.P.c_factor;
-  const int ix = find_bin(plot_field(Q.fx, x, y, z, a, b, c, path, E) * Q.P.x_factor, Q.A.x);
-  const int iy = find_bin(plot_field(Q.fy, x, y, z, a, b, c, path, E) * Q.P.y_factor, Q.A.y);
+  // (x, z, energy -- the plot of a screen image -- without the selects: a branch on uniform values)
+  const bool usual = Q.fx == XRT_HIP_FIELD_X && Q.fy == XRT_HIP_FIELD_Z && Q.fc == XRT_HIP_FIELD_E;
+  double vx = x, vy = z, vc = E;
+  if (!usual) {
+    vx = plot_field(Q.fx, x, y, z, a, b, c, path, E);
+    vy = plot_field(Q.fy, x, y, z, a, b, c, path, E);
+    vc = plot_field(Q.fc, x, y, z, a, b, c, path, E);
+  }
+  const double cv = vc * Q.P.c_factor;
+  const int ix = find_bin(vx * Q.P.x_factor, Q.A.x);
+  const int iy = find_bin(vy * Q.P.y_factor, Q.A.y);
   s.w = w;
   s.hue = cv;
   if (ix >= 0 && iy >= 0) {
@@ -184,11 +192,18 @@ __device__ __forceinline__ PlotStash plot_tail_take(const PlotTail& Q, double x,
   return s;
 }
 
-__device__ __forceinline__ double permute_f64(int dst, double v) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  const int lo = __builtin_amdgcn_ds_permute(dst << 2, (int)(unsigned)u);
-  const int hi = __builtin_amdgcn_ds_permute(dst << 2, (int)(unsigned)(u >> 32));
-  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+// inclusive prefix sum over the 64 lanes in data-parallel-primitive moves (no trip through the LDS
+// crossbar: six dependent ds_bpermute at the very end of a wave cost more than the arithmetic)
+__device__ __forceinline__ unsigned wave_prefix_sum(unsigned v) {
+  // row_shr:1, 2, 4, 8 within rows of 16 lanes (zeros shifted in), then lane 15 of row 0 / 2 into
+  // rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31)
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+  return v;
 }
 
 // All 64 lanes of the wave, converged; lane l holds the record of ray 64 * chunk + l (st 0: none).
@@ -209,12 +224,7 @@ __device__ __forceinline__ void plot_tail_emit(const PlotTail& Q, int64_t chunk,
     rem &= ~m;
   }
   // bucket starts: exclusive prefix over the lanes (lane T + 1 and up: the total, 64)
-  unsigned incl = here;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const unsigned v = __shfl_up(incl, off);
-    if (lane >= off) incl += v;
-  }
+  const unsigned incl = wave_prefix_sum(here);
   const unsigned start = incl - here;
   const int pos = (int)__shfl(start, s.tile) + rank;
   // the row of the byte table
@@ -227,15 +237,14 @@ __device__ __forceinline__ void plot_tail_emit(const PlotTail& Q, int64_t chunk,
   const unsigned byte = k < 0 ? start : k == 0 ? alive : k == 1 ? good : k == 2 ? out
                         : k == 3 ? over : k == 4 ? dead : 0u;
   if (lane < Q.pitch) Q.tab[chunk * Q.pitch + lane] = (unsigned char)byte;
-  // the records in bucket order (a push permutation in registers), coalesced stores
-  const double w = permute_f64(pos, s.w), hue = permute_f64(pos, s.hue);
-  const unsigned word = (unsigned)__builtin_amdgcn_ds_permute(pos << 2, (int)s.word);
-  const int64_t o = chunk * 64 + lane;
+  // the records in bucket order: every lane stores at its place within the wave's 512-B (256-B)
+  // window -- the same lines as an ordered store, no permutation through the LDS crossbar.
   // (plain stores: plot_tail_tiles reads the records right behind this kernel, several tiles'
   // blocks each line of a wide beam -- out of the memory-side cache if they are still there)
-  Q.w[o] = w;
-  Q.hue[o] = hue;
-  Q.word[o] = word;
+  const int64_t o = chunk * 64 + pos;
+  Q.w[o] = s.w;
+  Q.hue[o] = s.hue;
+  Q.word[o] = s.word;
 }
 
 }  // namespace xrt
