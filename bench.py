@@ -1385,6 +1385,7 @@ def main():
         line['dry_ranks'] = True
     if self_check is not None:
         line['multi_gpu_self_check'] = self_check
+        line['roofline'] = line.get('roofline') or {}
         line['roofline']['multi_gpu_self_check'] = 1 if self_check.get('ok') else 0
     compact_for_the_record(line, world)          # (writes `summary`, the LAST key of the line)
     if rank == 0:
@@ -1492,15 +1493,25 @@ def compact_for_the_record(line, world):
         ('multiple_reflect_numpy_intersections_per_s',
          ('multiple_reflect', 'cpu_baseline', 'value')),
     )
+    in_summary = ('dcm_frac', 'dcm_ms_per_step', 'kirchhoff_general_frac',
+                  'kirchhoff_general_relaxed_frac', 'und_imap_frac', 'hist_frac', 'hist_ms_per_plot',
+                  'hist_traffic', 'nolocal_ms_per_step', 'softimax_seconds', 'balder_ms',
+                  'e2e_ms_per_iteration', 'e2e_plot_adds_ms', 'e2e_plot_as_own_launches_ms',
+                  'e2e_traffic', 'e2e_every_beam_written_ms', 'e2e_1e5_eager_ms',
+                  'e2e_1e5_graph_ms', 'e2e_1e5_speedup', 'e2e_1e6_speedup',
+                  'multiple_reflect_ms_per_bounce', 'multiple_reflect_intersections_per_s')
     for name, path in flat_legs:
         v = _dig(line, *path)
         if isinstance(v, (int, float)) and not isinstance(v, bool):
             roof[name] = v
-            summary[name] = v
+            if name in in_summary:
+                summary[name] = v
     # (balder 'seconds' is per pass of the chain: report it in ms under its flat name)
     for name in ('balder_ms', 'balder_every_beam_written_ms'):
         if name in roof:
-            roof[name] = summary[name] = roof[name] * 1e3
+            roof[name] = roof[name] * 1e3
+            if name in summary:
+                summary[name] = roof[name]
     # the short form at the very end of the line: the driver's tail of stdout holds it whole
     text = json.dumps({k: (float('%.5g' % v) if isinstance(v, float) else v)
                        for k, v in summary.items() if v is not None})

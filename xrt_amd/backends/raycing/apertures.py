@@ -140,7 +140,7 @@ class RectangularAperture(object):
         rs.before_states_change(beam)
         from . import oes as roe
         if not needNewGlobal and roe.fuseConsumers:
-            return _DeferredLocal(self, beam, dev).local
+            return _DeferredLocal(self, beam, dev).hand_out()
         local = rs.Beam.empty_like_on_device(beam, dev)
         glo = rs.Beam.empty_like_on_device(beam, dev) if needNewGlobal else None
         rec = self._record()
@@ -182,7 +182,7 @@ class RectangularAperture(object):
                                  opened, self.uuid)
 
 
-class _DeferredLocal(rs.SharesStates):
+class _DeferredLocal(rs.SharesStates, rs.FillsBeams):
     """``propagate`` when only the states are certain to be needed: ONE launch reads the
     geometry and marks the stopped rays in the incoming beam (52 B read, <= 4 B written per ray
     -- out_local NULL in xrt_hip_aperture_propagate_f64_dev); the beam in the aperture's frame
@@ -221,8 +221,7 @@ class _DeferredLocal(rs.SharesStates):
         if self.own_marks:
             self._share_states(was)
         beam._h.pop('state', None)       # the kernel updated beam.state in HBM
-        self.local = rs.LazyBeam(self, 'local')
-        rs.inherit_scalars(self.local, beam)
+        rs.inherit_scalars(self._make('local'), beam)
         rs._PENDING.add(self)
 
     def _launch(self, beam, local):
@@ -244,7 +243,7 @@ class _DeferredLocal(rs.SharesStates):
             self.record.own_marks = int(self.own_marks)
             self._launch(self.was, local)     # (one that raises is raised again by the next look)
             self.state = 'done'
-            self.local._adopt_arrays(local)
+            rs.adopt_into(self._beam('local'), local)
             self.was, self.tensors = None, ()
 
 

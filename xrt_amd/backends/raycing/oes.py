@@ -762,8 +762,7 @@ class OE(object):
                 getattr(self, '_zones_between_passes', None) is None and \
                 not (p.grating and raycing.is_sequence(self.order)) and not p.eff_tab_n:
             # not launched yet: Screen.expose of the global beam may still join the pass
-            op = _DeferredReflect(self, p, beam, out)
-            return op.gb, op.lb
+            return _DeferredReflect(self, p, beam, out).hand_out()
         lb, gb, report = self._run_pass(
             p, self.material, True, beam, beam, want_info=_info is not None,
             timing=_timing is not None, out=None if out is None else (out[1], out[0]),
@@ -822,7 +821,7 @@ def _locals_on_demand(oe, *materials):
     return True
 
 
-class _LocalsOnDemand(rs.SharesStates):
+class _LocalsOnDemand(rs.SharesStates, rs.FillsBeams):
     """The local beams of an element whose pass has written the global beam only (308 -> 200 B
     per ray and surface): *run(beam)* -> the real local beams, called with the input as it was
     (its own copy of the states) the first time one of them is looked at. The element then
@@ -833,8 +832,8 @@ class _LocalsOnDemand(rs.SharesStates):
         self.oe, self.run = oe, run
         beam.to_struct(_device())                    # everything up in HBM now
         self.was, self.tensors = _as_it_is(beam, own_states=True, sharer=self)
-        self.locals = [rs.LazyBeam(self, k) for k in range(count)]
-        oe._adopt(self.locals, beam)
+        self.count = count
+        oe._adopt([self._make(k) for k in range(count)], beam)
         self.state = 'pending'
         rs._PENDING.add(self)
 
@@ -850,13 +849,13 @@ class _LocalsOnDemand(rs.SharesStates):
             # again by the next look at the beam instead of leaving it empty)
             made = self.run(self.was)
             self.state = 'done'
-            for lazy, real in zip(self.locals, made):
-                lazy._adopt_arrays(real)
+            for k, real in enumerate(made):
+                rs.adopt_into(self._beam(k), real)
             self.was = self.run = None
             self.tensors = ()
 
 
-class _DeferredReflect(rs.SharesStates):
+class _DeferredReflect(rs.SharesStates, rs.FillsBeams):
     """OE.reflect not launched yet. States: pending -> done (plain pass: both beams), or
     pending -> global (the next element took the global beam: the pass without its local beam,
     200 instead of 308 B per ray) -> done (the local beam, by the pass run again, if somebody
@@ -885,11 +884,15 @@ class _DeferredReflect(rs.SharesStates):
             material = material[oe.curSurface]
         self.material = material
         self.n = self.src_op.n if self.src_op is not None else snap.nrays
-        self.screen = self.screen_rec = self.image = None
+        self.screen = self.screen_rec = None
         self.state = 'pending'
-        self.gb, self.lb = rs.LazyBeam(self, 'gb'), rs.LazyBeam(self, 'lb')
-        oe._adopt((self.gb, self.lb), beam)
+        oe._adopt((self._make('gb'), self._make('lb')), beam)
         rs._PENDING.add(self)
+
+    # (weak: sources.FillsBeams)
+    gb = property(lambda self: self._beam('gb'))
+    lb = property(lambda self: self._beam('lb'))
+    image = property(lambda self: self._beam('image'))
 
     def reads(self, beam):
         if beam is self.beam:
@@ -912,13 +915,12 @@ class _DeferredReflect(rs.SharesStates):
         out before anything is launched as well, so that a plot of it may still join the pass
         (plot_on: run_ray_tracing's accumulate_plot). Whoever looks at a beam first launches."""
         self.screen, self.screen_rec = screen, rec
-        self.image = rs.LazyBeam(self, 'image')
-        rs.inherit_scalars(self.image, self.beam)
-        return self.image
+        rs.inherit_scalars(self._make('image'), self.beam)
+        return self.hand_out()
 
     def materialize(self, which=None):
         oe = self.oe
-        filled = lambda b: b.__dict__['_filled']      # noqa: E731
+        filled = rs.filled
         if self.state == 'pending' and self.screen_rec is not None:
             # the pass with the screen in its tail; then the beam asked for, if it was left out
             self._launch_with_screen()
@@ -932,25 +934,25 @@ class _DeferredReflect(rs.SharesStates):
                 _, gb, _ = oe._run_pass(self.p, self.material, True, self.beam, self.beam,
                                         local=False)
                 self.state = 'global'
-                self.gb._adopt_arrays(gb)
+                rs.adopt_into(self.gb, gb)
                 self._waits_with_its_own_states()
                 return
             lb, gb, _ = oe._run_pass(self.p, self.material, True, self.beam, self.beam,
                                      out=None if self.out is None else (self.out[1], self.out[0]))
             self.state = 'done'
-            self.lb._adopt_arrays(lb)
-            self.gb._adopt_arrays(gb)
+            rs.adopt_into(self.lb, lb)
+            rs.adopt_into(self.gb, gb)
         elif self.state in ('global', 'imaged') and which == 'image':
             # the image of a pass that fed a plot and nothing else (plot_on): the pass with the
             # screen again -- and the screen remembers: next time the image is written as well
-            if self.image is not None and not filled(self.image):
+            if not filled(self.image):
                 self.screen.__dict__['_image_wanted'] = True
                 rays = self.beam
                 if type(rays) is rs.LazyBeam:      # (a source's, not made when the pass ran)
                     rays = self.src_op.rays_again()
                 _, _, image, _ = oe._run_pass_screen(self.p, self.material, rays, self.screen_rec,
                                                      keep_global=False, local=False)
-                self.image._adopt_arrays(image)
+                rs.adopt_into(self.image, image)
             if filled(self.lb) and filled(self.gb):
                 rs._PENDING.discard(self)
                 self.state = 'done'
@@ -969,11 +971,10 @@ class _DeferredReflect(rs.SharesStates):
                     rays = self.src_op.rays_again()
                 lb, gb, _ = oe._run_pass(self.p, self.material, True, rays, rays, local=want_lb)
                 if want_lb:
-                    self.lb._adopt_arrays(lb)
+                    rs.adopt_into(self.lb, lb)
                 if want_gb:
-                    self.gb._adopt_arrays(gb)
-            if filled(self.lb) and filled(self.gb) and (self.image is None or
-                                                        filled(self.image)):
+                    rs.adopt_into(self.gb, gb)
+            if filled(self.lb) and filled(self.gb) and filled(self.image):
                 rs._PENDING.discard(self)
                 self.state = 'done'
         if self.state == 'done':
@@ -999,13 +1000,13 @@ class _DeferredReflect(rs.SharesStates):
         rs._PENDING.discard(self)
         lb, gb, image, fused = made
         if local:
-            self.lb._adopt_arrays(lb)
+            rs.adopt_into(self.lb, lb)
         if fused and not keep:
             self._scratch = gb            # (the redo's scratch: freed with this record)
         else:
-            self.gb._adopt_arrays(gb)
+            rs.adopt_into(self.gb, gb)
         if keep_image:
-            self.image._adopt_arrays(image)
+            rs.adopt_into(self.image, image)
         if local and keep_image and not (fused and not keep):
             self.state = 'done'
             self.beam, self.tensors = None, ()
@@ -2132,7 +2133,7 @@ class DCM(OE):
                 _locals_on_demand(self, self.material, self.material2):
             # the global beam now, the beams on the two surfaces when somebody looks at them
             later = _LocalsOnDemand(self, beam, 2, lambda was: both(was)[1:])
-            return (both(beam, local=False)[0],) + tuple(later.locals)
+            return (both(beam, local=False)[0],) + later.hand_out(always_tuple=True)
         return both(beam)
 
     def _run_double(self, p1, p2, fromVacuum1, fromVacuum2, beam, timing=None, out=None,

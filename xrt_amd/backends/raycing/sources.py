@@ -513,7 +513,40 @@ def flush_pending(beam=None, keep=None, only_state=False):
                 op.materialize()
 
 
-class _DeferredShine(object):
+class FillsBeams(object):
+    """Mixin of a record that will fill LazyBeams: the beams refer to their record, the record
+    refers to its beams WEAKLY. As a cycle, a beam the script had dropped kept its record and
+    everything that holds -- the input's arrays, a beam-sized scratch, its own gigabyte -- until
+    Python's cycle collector came by: tens of GB of garbage between collections, and new device
+    allocations (milliseconds each) in loops that had been allocation-free. ``_make(role, ...)``
+    creates a beam and keeps it alive until ``hand_out()`` gives it to the caller."""
+
+    def _make(self, role, key=None):
+        beam = LazyBeam(self, role)
+        self.__dict__.setdefault('_fresh', []).append(beam)
+        self.__dict__.setdefault('_weak', {})[role if key is None else key] = _weakref.ref(beam)
+        return beam
+
+    def _beam(self, key):
+        ref = self.__dict__.get('_weak', {}).get(key)
+        return None if ref is None else ref()
+
+    def hand_out(self, always_tuple=False):
+        fresh = self.__dict__.pop('_fresh', [])
+        return fresh[0] if len(fresh) == 1 and not always_tuple else tuple(fresh)
+
+
+def filled(beam):
+    """A lazy beam has its arrays -- or nobody holds it any more (nothing to fill)."""
+    return beam is None or beam.__dict__['_filled']
+
+
+def adopt_into(beam, real):
+    if beam is not None:
+        beam._adopt_arrays(real)
+
+
+class _DeferredShine(FillsBeams):
     """GeometricSource.shine(rng='device') not launched yet: the generator is counter-based, the
     record *g* makes the same rays whenever it runs. States: pending -> done (its own launch), or
     pending -> inflight (an element's pass made the rays in its registers,
@@ -524,10 +557,13 @@ class _DeferredShine(object):
             source, g, int(nrays), bool(amplitudes), device
         self.rec = rec               # the HIP graph this shine is recorded into, if any
         self.state = 'pending'
-        self.beam = LazyBeam(self, 'beam')
+        self.scalars = dict(scalars)
+        beam = self._make('beam')
         for key, value in scalars.items():
-            object.__setattr__(self.beam, key, value)
+            object.__setattr__(beam, key, value)
         _PENDING.add(self)
+
+    beam = property(lambda self: self._beam('beam'))
 
     def reads(self, beam):
         return False
@@ -558,7 +594,7 @@ class _DeferredShine(object):
             self.state = 'done'
             bo = Beam.empty_on_device(self.n, self.device, self.amplitudes)
             self.launch_into(bo)
-            self.beam._adopt_arrays(bo)
+            adopt_into(self.beam, bo)
 
     def rays_again(self):
         """-> the same rays in a NEW beam (for whoever has to run a pass on them again: this
@@ -566,7 +602,8 @@ class _DeferredShine(object):
         changed its states since)."""
         bo = Beam.empty_on_device(self.n, self.device, self.amplitudes)
         self.launch_into(bo)
-        inherit_scalars(bo, self.beam)
+        for key, value in self.scalars.items():
+            object.__setattr__(bo, key, value)
         return bo
 
     def adopt(self, bo):
@@ -574,7 +611,7 @@ class _DeferredShine(object):
         _PENDING.discard(self)
         if self.state != 'done':
             self.state = 'done'
-            self.beam._adopt_arrays(bo)
+            adopt_into(self.beam, bo)
 
 
 class LazyBeam(Beam):
@@ -1032,7 +1069,7 @@ class GeometricSource(object):
                     if total > 0:
                         scalars.update(sourceWeight=self.totalFlux / total, seeded=self.nrays,
                                        seededI=1., accepted=1., acceptedE=1.)
-                return _DeferredShine(self, g, self.nrays, amplitudes, dev, scalars, rec).beam
+                return _DeferredShine(self, g, self.nrays, amplitudes, dev, scalars, rec).hand_out()
         bo = Beam.empty_on_device(self.nrays, dev, amplitudes)
         _lib.check(lib.xrt_hip_geosource_shine_f64_dev(
             ctypes.byref(g), ctypes.byref(bo.to_struct(dev)), stream),
