@@ -900,7 +900,9 @@ def bench_e2e(nrays, repeats=20):
         rr.run_process = run_s
         row = {}
         for mode in ('eager', 'graph'):
-            reps = 200
+            # (long enough for the recording -- ~6 ms -- and the 44 iterations of the contest of
+            # the graph route to be what they are in a real run: a small part)
+            reps = 1000 if n_small <= 100_000 else 500
             runner.run_ray_tracing([make_s()], repeats=3, beamLine=bls, graph=mode == 'graph')
             torch.cuda.synchronize()
             ps = make_s()
@@ -915,7 +917,7 @@ def bench_e2e(nrays, repeats=20):
         row['speedup'] = row['eager_ms_per_iteration'] / row['graph_ms_per_iteration']
         small['%d_rays' % n_small] = row
     if small:
-        small['note'] = ('the same job at 1e5 and 1e6 rays per iteration, 200 iterations: eager '
+        small['note'] = ('the same job at 1e5 and 1e6 rays per iteration, 1000 / 500 iterations: eager '
                          'loop (Python + ctypes per element) against run_ray_tracing(graph=True) '
                          '(one HIP graph launch per iteration, xrt_amd/graphs.py); the graph time '
                          'includes its two eager iterations and the recording')
@@ -1484,6 +1486,7 @@ def compact_for_the_record(line, world):
         ('e2e_1e5_eager_ms', ('e2e', 'small_beams', '100000_rays', 'eager_ms_per_iteration')),
         ('e2e_1e5_graph_ms', ('e2e', 'small_beams', '100000_rays', 'graph_ms_per_iteration')),
         ('e2e_1e5_speedup', ('e2e', 'small_beams', '100000_rays', 'speedup')),
+        ('e2e_1e5_replay_ms', ('e2e', 'small_beams', '100000_rays', 'graph_choice', 'replay_ms')),
         ('e2e_1e6_eager_ms', ('e2e', 'small_beams', '1000000_rays', 'eager_ms_per_iteration')),
         ('e2e_1e6_graph_ms', ('e2e', 'small_beams', '1000000_rays', 'graph_ms_per_iteration')),
         ('e2e_1e6_speedup', ('e2e', 'small_beams', '1000000_rays', 'speedup')),
@@ -1498,7 +1501,7 @@ def compact_for_the_record(line, world):
                   'hist_traffic', 'nolocal_ms_per_step', 'softimax_seconds', 'balder_ms',
                   'e2e_ms_per_iteration', 'e2e_plot_adds_ms', 'e2e_plot_as_own_launches_ms',
                   'e2e_traffic', 'e2e_every_beam_written_ms', 'e2e_1e5_eager_ms',
-                  'e2e_1e5_graph_ms', 'e2e_1e5_speedup', 'e2e_1e6_speedup',
+                  'e2e_1e5_graph_ms', 'e2e_1e5_replay_ms', 'e2e_1e5_speedup', 'e2e_1e6_speedup',
                   'multiple_reflect_ms_per_bounce', 'multiple_reflect_intersections_per_s')
     for name, path in flat_legs:
         v = _dig(line, *path)

@@ -1,3 +1,8 @@
+"""Device memory held by the e2e loops of bench.py (plot in the tail of the pass / plot as launches of its
+own / no plot), and their ms per iteration: torch allocator statistics after each loop. Round 6: the records of
+deferred passes refer to their beams weakly -- 4.5 GB reserved and no device allocation after the first loop, where
+reference cycles had kept 15-20 GB of dropped beams alive between runs of Python's cycle collector (33 GB reserved).
+    python tools/probe_alloc.py"""
 import os, sys, time, torch
 sys.path.insert(0, '.')
 from xrt_amd import workloads, runner

@@ -245,18 +245,20 @@ def run_ray_tracing(plots=[], repeats=1, updateEvery=1, pickleEvery=None,
                         # wait for one another through barrier packets (~8 us each). Beams of
                         # ~1e6 rays and more are GPU-bound and lose by replaying. Both ways
                         # warm (the eager one has been since before the recording; the replay's
-                        # first launches upload the graph), then four rounds of five iterations
-                        # each way, ALTERNATELY -- a cold eager loop measured after a warm
+                        # first launches upload the graph), then two rounds of ten iterations
+                        # each way (a stream sync per block only: at 1e6 rays a sync every
+                        # five iterations made the eager loop look 15 % slower than it runs
+                        # freely), ALTERNATELY -- a cold eager loop measured after a warm
                         # replay made the graph look better than it is --
                         # and the graph stays only if it wins by more than 3 %.
                         for run in (recorded.replay, recorded.replay, iteration, iteration):
                             run()
                         clock = [0., 0.]
-                        for _ in range(4):
+                        for _ in range(2):
                             for which, run in enumerate((recorded.replay, iteration)):
                                 torch.cuda.current_stream().synchronize()
                                 t0 = time.perf_counter()
-                                for _ in range(5):
+                                for _ in range(10):
                                     run()
                                 torch.cuda.current_stream().synchronize()
                                 clock[which] += time.perf_counter() - t0
