@@ -227,12 +227,15 @@ def bench_multiple_reflect(nrays, reps=3, cpu=True):
                           **case.TOROID)
     beam = case.point_source_rays(rs, nrays, 5)
     beam.to_struct(torch.device('cuda', torch.cuda.current_device()))
+    # (the batch statistics -- _info -- come from the exact phases only: one untimed call for the
+    # counts, the timed ones without, as a script calls it: full bounces in their optimistic form)
+    info = []
+    oe.multiple_reflect(beam, maxReflections=100, _info=info)
     times = []
     for _ in range(reps + 1):
-        info = []
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        gb, lbN = oe.multiple_reflect(beam, maxReflections=100, _info=info)
+        gb, lbN = oe.multiple_reflect(beam, maxReflections=100)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     dt = min(times[1:])
@@ -244,10 +247,12 @@ def bench_multiple_reflect(nrays, reps=3, cpu=True):
                unit='intersections/s', rays=nrays, bounces=bounces, intersections=entered,
                ms_per_call=dt * 1e3, ms_per_bounce=dt * 1e3 / bounces,
                hbm_fraction=moved / dt / HBM_PEAK,
-               note='one launch per bounce (reflect_multi: four phases between grid barriers); '
-                    'the third bounce runs the reference\'s bracket-keeping secant to its '
-                    'iteration limit (100) for every ray: instruction-bound by the '
-                    'reference\'s own search, not by HBM')
+               note='a full bounce in its optimistic form (reflect_multi_opt: tangency search, hit '
+                    'search, reflection and stores per ray without batch statistics, verified per '
+                    'ray; reflect_multi redoes a contradicted bounce exactly), a bounce that few '
+                    'rays still enter over an index of them (three launches); instruction-bound '
+                    'by the reference\'s own bracket-keeping secant (20-50 iterations per ray), '
+                    'not by HBM')
     if cpu:
         from oracle import fixture_io, reflect_np as rn
         p, _, _ = fixture_io.load_case('g2_multi_toroid')

@@ -531,6 +531,18 @@ typedef struct xrt_hip_bounce {
    * its sparse form (an index of the entering rays, lanes that take the next ray when theirs
    * is done), whose results are bit for bit those of the dense one. */
   int64_t entering_hint;
+  /* A full bounce runs in an OPTIMISTIC form: no batch statistics, the decisions the reference
+   * takes from the whole batch are assumed -- bracketing axis and sign from the head of the
+   * beam, and for each of the two searches of a bounce (tangency point, hit) secant or Brent as
+   * given HERE (1 = Brent; what the same bounce found last time is a good guess, or the bounce
+   * before) -- and verified by every ray; a contradicted bounce is redone exactly inside the
+   * call. assume_hit_brent = -1: the exact form at once. Results are the same bits either way.
+   * found_host (optional, 4 int32 of HOST memory, filled when counts_host is given): [0] the hit
+   * search of this batch takes Brent, [1] the tangency search does, [2] the bounce was redone,
+   * [3] the form it ran in (0 exact, 1 optimistic, 2 sparse). */
+  int32_t assume_hit_brent;
+  int32_t assume_tangency_brent;
+  int32_t* found_host;
 } xrt_hip_bounce;
 
 XRT_HIP_API size_t xrt_hip_bounce_workspace_bytes(int64_t n);

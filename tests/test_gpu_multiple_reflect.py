@@ -187,11 +187,13 @@ def test_sparse_and_dense_bounces_are_the_same_bits():
     form (xrt_hip_bounce.entering_hint: an index of the entering rays, the hit search with lanes
     that take the next ray when theirs is done, a dense finish -- three launches); the dense
     kernel walks every lane through every phase. Every array of gb and of all footprints is
-    identical whichever form the bounces take: all dense, all sparse, or chosen by the hint."""
+    identical whichever form the bounces take: all exact (the round-5 kernel: statistics phases
+    between grid barriers), full bounces optimistic (no statistics: assumed from the head of the
+    beam, verified per ray) with or without the sparse form for the late ones, all sparse."""
     tor = element('g2_multi_toroid')
     rays = case.point_source_rays(rs, 300000, 11)
     got = {}
-    for form in ('dense', 'sparse', ''):
+    for form in ('exact', 'dense', 'sparse', ''):
         if form:
             os.environ['XRT_HIP_MULTI_FORM'] = form
         else:
@@ -203,11 +205,11 @@ def test_sparse_and_dense_bounces_are_the_same_bits():
         got[form] = {(n, f): np.array(b.peek(f)) for n, b in (('gb', gb), ('lbN', lbN))
                      for f in GEOM + ('E', 'state', 'nRefl', 'Jss', 'Jpp', 'Jsp', 'Es', 'Ep', 'theta',
                                       'elevationD', 'elevationX', 'elevationY', 'elevationZ')}
-    assert got['dense'][('lbN', 'x')].size >= 4 * 300000          # several bounces
-    st = got['dense'][('lbN', 'state')].reshape(-1, 300000)
+    assert got['exact'][('lbN', 'x')].size >= 4 * 300000          # several bounces
+    st = got['exact'][('lbN', 'state')].reshape(-1, 300000)
     left = ((st == 1) | (st == 2)).sum(axis=1)         # rays that enter the NEXT bounce
     assert ((left[:-1] > 0) & (left[:-1] < 75000)).any()     # ... some bounces sparse by the hint
     assert (left[:-1] >= 75000).any()                         # ... and some dense
-    for form in ('sparse', ''):
-        for key, want in got['dense'].items():
+    for form in ('dense', 'sparse', ''):
+        for key, want in got['exact'].items():
             assert np.array_equal(got[form][key], want, equal_nan=True), (form or 'hinted', key)

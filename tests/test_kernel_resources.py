@@ -77,4 +77,7 @@ def test_hot_kernels_keep_their_budget():
                 'reflect_fused_gen_scr' in name:
             assert r['vgpr_spill'] == 0 and r['scratch'] <= 32, name
         if 'reflect_multi' in name:      # two blocks per CU by choice (profiles/r05_multi_percu_ab.txt)
-            assert r['vgpr'] <= 256 and r['vgpr_spill'] <= 112 and r['scratch'] <= 512, name
+            # (the optimistic bounce of family 1 -- conics, blazed, lens: both searches AND the
+            # reflection in one pass per ray -- spills more than the phase-wise kernel)
+            spill = 176 if 'reflect_multi_optINS_4SpecILi1E' in name else 112
+            assert r['vgpr'] <= 256 and r['vgpr_spill'] <= spill and r['scratch'] <= 768, name

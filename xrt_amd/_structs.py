@@ -339,6 +339,9 @@ class Bounce(ctypes.Structure):
         ('elev_out', ctypes.c_void_p * 4),
         ('spr_out', ctypes.c_void_p * 3),
         ('entering_hint', ctypes.c_int64),
+        ('assume_hit_brent', ctypes.c_int32),
+        ('assume_tangency_brent', ctypes.c_int32),
+        ('found_host', ctypes.c_void_p),
     ]
 
 

@@ -1281,6 +1281,11 @@ def _multiple_reflect(self, beam=None, maxReflections=1000, needElevationMap=Fal
     ws = hipcalls.workspace(dev, lib.xrt_hip_bounce_workspace_bytes(n), 'bounce')
     counts = (ctypes.c_int64 * 2)()
     stats = (ctypes.c_double * 16)() if _info is not None else None
+    # which method (secant / Brent) the two searches of bounce k took the last time this element
+    # was called: the guess the optimistic form of the bounce starts from (xrt_hip_bounce)
+    found = (ctypes.c_int32 * 4)()
+    methods = self.__dict__.setdefault('_multi_methods', {})
+    guess = (0, 0)
     elevation = ('elevationD', 'elevationX', 'elevationY', 'elevationZ')
     k, hits_first, hits_any = 0, False, False
     while k < maxReflections:
@@ -1289,6 +1294,9 @@ def _multiple_reflect(self, beam=None, maxReflections=1000, needElevationMap=Fal
         bounce = _structs.Bounce()
         bounce.nrefl_in = None if k == 0 else fp.ptr('nRefl', k - 1)
         bounce.entering_hint = 0 if k == 0 else left     # (rays in state 1 or 2 after bounce k - 1)
+        hit_brent, tan_brent = methods.get(k, guess)
+        bounce.assume_hit_brent, bounce.assume_tangency_brent = int(hit_brent), int(tan_brent)
+        bounce.found_host = ctypes.addressof(found)
         bounce.nrefl_out = fp.ptr('nRefl', k)
         bounce.theta = fp.ptr('theta', k)
         for j, name in enumerate(elevation):
@@ -1305,6 +1313,7 @@ def _multiple_reflect(self, beam=None, maxReflections=1000, needElevationMap=Fal
             ctypes.byref(s_out), ctypes.byref(bounce), ctypes.c_void_p(ws.data_ptr()),
             ws.numel(), _stream(), counts, stats), 'xrt_hip_reflect_bounce_f64_dev')
         left, hit = int(counts[0]), int(counts[1])
+        guess = methods[k] = (int(found[0]), int(found[1]))   # (the next bounce's guess, too)
         if hit == 0 and k > 0:
             # a bounce in which no ray hits leaves lb.theta as it was (reflect.py:791-796)
             fp.slice('theta', k).copy_(fp.slice('theta', k - 1))

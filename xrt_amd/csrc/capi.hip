@@ -952,7 +952,8 @@ int xrt_hip_reflect_bounce_f64_dev(const xrt_hip_pass* pass, const xrt_hip_mater
     return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes,
                 xrt::bounce_workspace_bytes(n));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipError_t e = xrt::reflect_bounce_launch(*pass, *material, *in, *out, *bounce, workspace, st);
+  hipError_t e = xrt::reflect_bounce_launch(*pass, *material, *in, *out, *bounce, workspace, st,
+                                            info_host != nullptr);
   if (e != hipSuccess) return fail(XRT_HIP_ERR_HIP, "bounce launch: %s", hipGetErrorString(e));
   if (counts_host || info_host) {
     unsigned long long head[32];   // counts (16 B) ... diag at byte 128 (16 doubles)
@@ -967,6 +968,13 @@ int xrt_hip_reflect_bounce_f64_dev(const xrt_hip_pass* pass, const xrt_hip_mater
       counts_host[1] = (int64_t)head[1];
     }
     if (info_host) memcpy(info_host, head + 16, 16 * sizeof(double));
+    if (bounce->found_host) {
+      const double* diag = reinterpret_cast<const double*>(head + 16);
+      bounce->found_host[0] = diag[9] != 0.;
+      bounce->found_host[1] = diag[10] != 0.;
+      bounce->found_host[2] = diag[11] != 0.;
+      bounce->found_host[3] = (int32_t)diag[12];
+    }
   }
   return XRT_HIP_OK;
 }

@@ -131,7 +131,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                const xrt_hip_beam* sb = nullptr, bool keep_virgin = true,
                                int* fused = nullptr, const xrt_hip_geosource* src = nullptr,
                                const struct PlotTailPlan* plot = nullptr,
-                               bool keep_screen = true);
+                               bool keep_screen = true,
+                               const struct TailApertures* ap = nullptr);
 // would this pass carry a screen (and a plot) in its tail: one of the lean kernels, optimistic
 bool reflect_pass_carries_screen(const xrt_hip_pass& P, const xrt_hip_material& M,
                                  const xrt_hip_screen& S);
@@ -154,7 +155,8 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
 size_t bounce_workspace_bytes(int64_t n);
 hipError_t reflect_bounce_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                  const xrt_hip_beam& in, const xrt_hip_beam& out,
-                                 const xrt_hip_bounce& B, void* workspace, hipStream_t st);
+                                 const xrt_hip_bounce& B, void* workspace, hipStream_t st,
+                                 bool want_info = false);
 hipError_t multi_to_global_launch(const xrt_hip_pass& P, const xrt_hip_beam& last,
                                   const xrt_hip_beam& orig, const int32_t* nrefl,
                                   const xrt_hip_beam& gb, hipStream_t st);

@@ -624,8 +624,22 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                bool force_exact, const xrt_hip_screen* scr,
                                const xrt_hip_beam* sb, bool keep_virgin, int* fused,
                                const xrt_hip_geosource* src, const PlotTailPlan* plot,
-                               bool keep_screen) {
+                               bool keep_screen, const TailApertures* ap) {
   static_assert(sizeof(GStat) <= 256, "workspace head slot");
+  // apertures right behind the element (their marks in the outgoing beam's states) with or
+  // without a screen behind them: a screen that images nothing stands in
+  xrt_hip_screen no_screen;
+  xrt_hip_beam no_image;
+  if (ap && ap->n == 0) ap = nullptr;
+  if (ap && !scr) {
+    memset(&no_screen, 0, sizeof(no_screen));
+    memset(&no_image, 0, sizeof(no_image));
+    no_image.n = in.n;
+    scr = &no_screen;
+    sb = &no_image;
+    keep_virgin = true;          // (the marked global beam is what the caller wants)
+  }
+  const bool real_screen = scr && scr != &no_screen;
   if (fused) *fused = 0;
   static_assert(REFLECT_OPT_SLOTS * sizeof(OptStat) <= REFLECT_PART_BYTES, "report slots");
   const int64_t n = in.n;
@@ -717,6 +731,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const bool lean = spec == SP_TOROID_MIRROR || spec == SP_FLAT_MIRROR ||
                     spec == SP_BENT_MIRROR || spec == SP_FLAT_PLATE;
   const bool fuse_screen = scr && sb && optimistic && lean && scr->radius == 0.;
+  const TailApertures none{};
   // ... and the plot of the screen's image behind it (plot_tail.h): only in a tail
   if (plot && !fuse_screen) return hipErrorInvalidValue;   // (capi.hip asks ..._fusable first)
   xrt_hip_beam sb_fused;
@@ -750,7 +765,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   const FusedLaunch FL{grid, fblock, st, &P, &M, &in, &restore, &lb,
                        fuse_screen ? &vb_fused : &vb, theta, g, opt,
                        fuse_screen ? scr : nullptr, fuse_screen ? sb : nullptr,
-                       fuse_source ? src : nullptr, plot ? &plot->Q : nullptr};
+                       fuse_source ? src : nullptr, plot ? &plot->Q : nullptr,
+                       fuse_screen && ap ? ap : &none};
   const ExactLaunch XL{dim3(exact_blocks(n)), dim3(REFLECT_EXACT_BLOCK), st, &P, &M, &in,
                        &restore, &lb, &vb, A};
   bool launched = true;
@@ -808,7 +824,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     // verdict, and only if it was contradicted: the source's beam, the exact sequence, the image
     {
       BarrierSerial one_at_a_time(st);
-      tu_exact0_redo_scr(XL, *scr, *sb, src, plot ? &plot->Q : nullptr);
+      tu_exact0_redo_scr(XL, *scr, *sb, src, plot ? &plot->Q : nullptr, ap ? ap : &none);
     }
   } else if (fuse_screen) {
     hipLaunchKernelGGL(reflect_decide_opt, dim3(1), block, 0, st, P, M, in, part, g);
@@ -817,7 +833,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     if (evk1) (void)hipEventRecord(evk1, st);
     {
       BarrierSerial one_at_a_time(st);
-      tu_exact0_redo_scr(XL, *scr, *sb, nullptr, plot ? &plot->Q : nullptr);
+      tu_exact0_redo_scr(XL, *scr, *sb, nullptr, plot ? &plot->Q : nullptr, ap ? ap : &none);
     }
   } else if (optimistic) {
     // assumptions from the head of the beam -> the pass on them, every ray checking ->
@@ -847,12 +863,26 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
     if (evk1) (void)hipEventRecord(evk1, st);
   }
   if (scr && sb) {
-    // (fused: the redo, if any, has made the image from the real vb -- reflect_redo_scr)
+    // (fused: the redo, if any, has marked the real vb and made the image from it --
+    // reflect_redo_scr); otherwise the apertures' and the screen's own launches
     if (!fuse_screen) {
-      const hipError_t se = screen_expose_launch(*scr, vb, *sb, st);
-      if (se != hipSuccess) return se;
+      if (ap) {
+        xrt_hip_beam nothing;
+        memset(&nothing, 0, sizeof(nothing));
+        nothing.n = in.n;
+        for (int k = 0; k < ap->n; ++k) {
+          const hipError_t ae = aperture_propagate_launch(ap->a[k], vb, nothing, nothing, st);
+          if (ae != hipSuccess) return ae;
+        }
+      }
+      if (real_screen) {
+        const hipError_t se = screen_expose_launch(*scr, vb, *sb, st);
+        if (se != hipSuccess) return se;
+      }
     }
-    if (fused) *fused = (fuse_screen ? 1 : 0) | (fuse_source ? 2 : 0) | (plot ? 4 : 0);
+    if (fused)
+      *fused = (fuse_screen && real_screen ? 1 : 0) | (fuse_source ? 2 : 0) | (plot ? 4 : 0) |
+               (fuse_screen && ap ? 8 : 0);
   }
   if (plot) {
     // the records of the pass (or of its redo) into the plot's accumulators: two small kernels

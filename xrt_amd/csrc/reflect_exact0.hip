@@ -11,16 +11,17 @@ bool tu_exact0(int spec, const ExactLaunch& L) {
 
 // (the lean kernels are family 0: Generic0 redoes their passes)
 void tu_exact0_redo_scr(const ExactLaunch& L, const xrt_hip_screen& S, const xrt_hip_beam& sb,
-                        const xrt_hip_geosource* src, const PlotTail* plot) {
+                        const xrt_hip_geosource* src, const PlotTail* plot,
+                        const TailApertures* ap) {
   const xrt_hip_geosource none{};
   const PlotTail no_plot{};           // (w null: no plot behind the screen)
   const PlotTail& Q = plot ? *plot : no_plot;
   if (src)
     hipLaunchKernelGGL((reflect_redo_scr<Generic0, true>), L.grid, L.block, 0, L.st, *L.P, *L.M,
-                       *src, *L.in, *L.restore, *L.lb, *L.vb, L.A, S, sb, Q);
+                       *src, *L.in, *L.restore, *L.lb, *L.vb, L.A, S, sb, Q, *ap);
   else
     hipLaunchKernelGGL((reflect_redo_scr<Generic0, false>), L.grid, L.block, 0, L.st, *L.P, *L.M,
-                       none, *L.in, *L.restore, *L.lb, *L.vb, L.A, S, sb, Q);
+                       none, *L.in, *L.restore, *L.lb, *L.vb, L.A, S, sb, Q, *ap);
 }
 
 void tu_exact0_dcm(const DcmLaunch& L) {

@@ -3275,19 +3275,29 @@ __device__ __forceinline__ void copy_ray(const xrt_hip_beam& o, const xrt_hip_be
 // element straight on to a screen more often than not; the screen's image is then made here,
 // from the registers, instead of by a pass of its own that reads the beam back (100 B per ray
 // less to read, and 100 B less to write when nobody else wants the global beam: vb.x null).
+// Round 6: apertures that follow the element directly (aperture.propagate(gb) before anybody
+// else looks at gb) ride as well: the state of the outgoing record is what they leave in
+// gb.state (apertures.py:373) -- four compares per aperture instead of a launch that reads 52 B
+// per ray -- and a screen behind them sees the marked states (`ap`, screen_impl.h).
 struct NoConsumer {
   static constexpr bool ON = false;
 };
-struct ScreenConsumer {        // Screen.expose, flat screens (screen_impl.h)
+struct ScreenConsumer {        // [apertures ->] Screen.expose, flat screens (screen_impl.h)
   static constexpr bool ON = true;
   xrt_hip_screen S;
-  xrt_hip_beam out;
+  xrt_hip_beam out;            // the image (x null: no screen, or nobody wants the image itself)
+  TailApertures ap;
+  __device__ __forceinline__ int mark(double x, double y, double z, double a, double b, double c,
+                                      int st) const {
+    return ap.n ? apertures_mark(ap, x, y, z, a, b, c, st) : st;
+  }
   __device__ __forceinline__ void take(int64_t i, double x, double y, double z, double a,
                                        double b, double c, double path, double E, double Jss,
                                        double Jpp, double Jsr, double Jsi, int st, double Esr,
                                        double Esi, double Epr, double Epi, bool has_amp) const {
-    expose_flat_store(S, out, i, x, y, z, a, b, c, path, E, Jss, Jpp, Jsr, Jsi, st, Esr, Esi,
-                      Epr, Epi, has_amp);
+    if (out.x)
+      expose_flat_store(S, out, i, x, y, z, a, b, c, path, E, Jss, Jpp, Jsr, Jsi, st, Esr, Esi,
+                        Epr, Epi, has_amp);
   }
 };
 
@@ -3303,6 +3313,11 @@ struct ScreenPlotConsumer {
   const xrt_hip_beam& out;
   const PlotTail& Q;
   PlotStash* stash;
+  const TailApertures& ap;
+  __device__ __forceinline__ int mark(double x, double y, double z, double a, double b, double c,
+                                      int st) const {
+    return ap.n ? apertures_mark(ap, x, y, z, a, b, c, st) : st;
+  }
   __device__ __forceinline__ void take(int64_t i, double x, double y, double z, double a,
                                        double b, double c, double path, double E, double Jss,
                                        double Jpp, double Jsr, double Jsi, int st, double Esr,
@@ -3478,6 +3493,7 @@ __device__ __forceinline__ Completed complete_ray(
     res.v.st = st;
     return res;
   }
+  if constexpr (CONS::ON) vst = cons.mark(x, y, z, la, lbb, lc, vst);    // apertures behind it
   if (!CONS::ON || vb.x)
     store_ray(vb, i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, vst, vEsr,
               vEsi, vEpr, vEpi, has_amp);
@@ -3499,7 +3515,7 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
     copy_ray<optional_local<K>()>(lb, in, i, 0, has_amp, true);
   else
     copy_ray<optional_local<K>()>(lb, in, i, st, has_amp, false);
-  const int vst = P.force_lost_out ? P.lost_num : st;
+  int vst = P.force_lost_out ? P.lost_num : st;
   if constexpr (CONS::ON) {
     const xrt_hip_beam& s = restore;
     const double2 js = reinterpret_cast<const double2*>(s.Jsp_ri)[i];
@@ -3510,6 +3526,7 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
     }
     const double x = s.x[i], y = s.y[i], z = s.z[i], a = s.a[i], b = s.b[i], c = s.c[i];
     const double path = s.path[i], E = s.E[i], Jss = s.Jss[i], Jpp = s.Jpp[i];
+    vst = cons.mark(x, y, z, a, b, c, vst);
     if (vb.x)
       store_ray(vb, i, x, y, z, a, b, c, path, E, Jss, Jpp, js.x, js.y, vst, es.x, es.y, ep.x,
                 ep.y, has_amp);
@@ -3744,7 +3761,7 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_s
   const GStat g = *gp;
   int neg = 0, pos = 0;
   PlotStash stash = no_plot_ray(Q);
-  const ScreenPlotConsumer cons{scr.S, scr.out, Q, &stash};
+  const ScreenPlotConsumer cons{scr.S, scr.out, Q, &stash, scr.ap};
   fused_ray<K, mode, false, ScreenPlotConsumer>(P, M, in, restore, lb, vb, theta, g, opt, i, req,
                                                 neg, pos, cons);
   plot_tail_emit(Q, i >> 6, stash);
@@ -3780,7 +3797,7 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_g
   const GStat g = *gp;
   int neg = 0, pos = 0;
   PlotStash stash = no_plot_ray(Q);
-  const ScreenPlotConsumer cons{scr.S, scr.out, Q, &stash};
+  const ScreenPlotConsumer cons{scr.S, scr.out, Q, &stash, scr.ap};
   fused_ray<K, 0, false, ScreenPlotConsumer>(P, M, in, in, lb, vb, theta, g, opt, i, req, neg,
                                              pos, cons);
   plot_tail_emit(Q, i >> 6, stash);
@@ -4120,7 +4137,8 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_exact(
 template <class K, bool SRC>
 __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_redo_scr(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_geosource G, xrt_hip_beam in, xrt_hip_beam restore,
-    xrt_hip_beam lb, xrt_hip_beam vb, PassAux A, xrt_hip_screen S, xrt_hip_beam sb, PlotTail Q) {
+    xrt_hip_beam lb, xrt_hip_beam vb, PassAux A, xrt_hip_screen S, xrt_hip_beam sb, PlotTail Q,
+    TailApertures ap) {
   __shared__ double lds_d[REFLECT_MAX_WAVES];
   const bool full = exact_gate(A.g, reinterpret_cast<const OptStat*>(A.part), lds_d,
                                P.method_hint);
@@ -4151,8 +4169,14 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_redo_scr(
         ep = reinterpret_cast<const double2*>(vb.Ep_ri)[i];
       }
       const double path = vb.path[i], E = vb.E[i], Jss = vb.Jss[i], Jpp = vb.Jpp[i];
+      int vst = vb.state[i];
+      if (ap.n) {      // the apertures behind the element mark the real global beam
+        const int marked = apertures_mark(ap, vb.x[i], vb.y[i], vb.z[i], vb.a[i], vb.b[i], vb.c[i], vst);
+        if (marked != vst) vb.state[i] = marked;
+        vst = marked;
+      }
       const ImageRay r = expose_flat(S, vb.x[i], vb.y[i], vb.z[i], vb.a[i], vb.b[i], vb.c[i],
-                                     vb.state[i]);
+                                     vst);
       if (sb.x) store_image(sb, i, r, path, E, Jss, Jpp, js.x, js.y, es.x, es.y, ep.x, ep.y, has_amp);
       if (Q.w)
         stash = plot_tail_take(Q, r.x, 0., r.z, r.a, r.b, r.c, path + r.path, E, Jss, Jpp, js.x,

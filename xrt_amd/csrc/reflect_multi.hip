@@ -81,7 +81,8 @@ static int device_cus() {
 
 hipError_t reflect_bounce_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                  const xrt_hip_beam& in, const xrt_hip_beam& out,
-                                 const xrt_hip_bounce& B, void* workspace, hipStream_t st) {
+                                 const xrt_hip_bounce& B, void* workspace, hipStream_t st,
+                                 bool want_info) {
   static_assert(sizeof(GStat) <= 256, "workspace slot");
   if (in.n <= 0) return hipSuccess;
   const MultiWs W = multi_ws(workspace, in.n);
@@ -113,11 +114,18 @@ hipError_t reflect_bounce_launch(const xrt_hip_pass& P, const xrt_hip_material& 
   L.A.hy = W.hy;
   L.A.hz = W.hz;
   L.A.hlost = W.hlost;
-  // (XRT_HIP_MULTI_FORM = dense / sparse: one form for every bounce, for A/B runs and tests)
+  // (XRT_HIP_MULTI_FORM = dense / sparse / exact: one form for every bounce -- full bounces
+  // optimistic / all bounces over an index / the exact dense kernel --, for A/B runs and tests)
   const char* form = getenv("XRT_HIP_MULTI_FORM");
   L.sparse = B.entering_hint > 0 && B.entering_hint * 4 < in.n;
-  if (form && form[0] == 'd') L.sparse = 0;
+  if (form && (form[0] == 'd' || form[0] == 'e')) L.sparse = 0;
   if (form && form[0] == 's') L.sparse = 1;
+  // the optimistic form of a full bounce, unless the caller wants the batch statistics (only the
+  // exact phases collect them) or XRT_HIP_REFLECT_EXACT=1 / XRT_HIP_MULTI_FORM=exact says no
+  const char* ex = getenv("XRT_HIP_REFLECT_EXACT");
+  L.A.gate = !L.sparse && !want_info && B.assume_hit_brent >= 0 && !(ex && ex[0] == '1') &&
+             !(form && form[0] == 'e');
+  L.A.assume = (B.assume_hit_brent > 0 ? 1 : 0) | (B.assume_tangency_brent > 0 ? 2 : 0);
   hipLaunchKernelGGL(multi_init, dim3(1), dim3(1), 0, st, W.g);
   bool launched;
   BarrierSerial one_at_a_time(st);        // (grid barriers between the phases: reflect.h)

@@ -72,12 +72,20 @@ __device__ __forceinline__ Ends bracket_ends(const xrt_hip_pass& P, const LocalR
 // find_intersection (base.py:848-885) between given ends, with the batch's clamp range and
 // method: the iteration of solve_ray for either derivOrder. -> t, the point there as find_dz
 // returns it ((s, phi, r) on a parametric surface) and ind1.
-template <class K, int DERIV>
+// OPT: the optimistic form (as solve_ray<K, true> of the single pass): secant, no clamp -- the
+// batch's range is not known -- and an iterate that leaves the ray's own bracket is reported
+// instead, with |f| at the bracket ends for the batch's secant-or-Brent decision.
+template <class K, int DERIV, bool OPT = false>
 __device__ __forceinline__ Hit solve_between(const xrt_hip_pass& P, const LocalRay& r, double t1,
                                              double t2, double tMinG, double tMaxG,
-                                             bool use_brent) {
+                                             bool use_brent, SolveAux* aux = nullptr) {
   Hit h;
   const Ends e = bracket_ends<K, DERIV>(P, r, t1, t2);
+  const double t1own = t1, t2own = t2;
+  if (OPT) {
+    aux->adz1 = fabs(e.dz1);
+    aux->adz2 = (e.ind1 || e.ind2) ? 0. : fabs(e.dz2);   // base.py:863-865
+  }
   h.lost = e.ind1 ? 1 : 0;
   h.px = h.py = 0.;
   if (e.ind1) {
@@ -103,8 +111,12 @@ __device__ __forceinline__ Hit solve_between(const xrt_hip_pass& P, const LocalR
       t1 = t2;
       dz1 = dz2;
       t2 = t - (t1 - t) * dz / (dz1 - dz);
-      if (t2 < tMinG) t2 = tMinG;
-      if (t2 > tMaxG) t2 = tMaxG;
+      if (OPT) {
+        aux->escaped |= (t2 < t1own) || (t2 > t2own);
+      } else {
+        if (t2 < tMinG) t2 = tMinG;
+        if (t2 > tMaxG) t2 = tMaxG;
+      }
       dz2 = multi_f<K, DERIV>(P, t2, r, x2, y2, z2);
       if (same_sign(dz2, dz1)) {
         t1 = t;
@@ -414,12 +426,222 @@ __device__ __forceinline__ void multi_finish(const xrt_hip_pass& P, const xrt_hi
   }
 }
 
+// ---------------------------------------------------------------------------
+// Round 6: the OPTIMISTIC form of a full bounce. The statistics phases of reflect_multi below are
+// four passes over the beam and five grid barriers (0.7 ms of a 2.2-ms bounce at 1e7 rays) for
+// decisions that come out the same for every beam that travels along the element: the axis of
+// the largest direction cosine, the sign of the first entering ray, clamp ranges that never
+// bite (a bracket-keeping secant iterate stays inside its own bracket, which lies inside the
+// batch's range) and secant rather than Brent -- for BOTH searches of a bounce, the tangency
+// point and the hit. So, as the single pass does (reflect_impl.h: decide_opt_body, fused_ray):
+// multi_decide_opt assumes them from the head of the beam, reflect_multi_opt does the whole
+// bounce per ray without any synchronisation -- tangency search, hit search, reflection, stores
+// -- while every ray verifies the assumptions for itself and the |f| maxima at the bracket ends
+// are collected (two sets of report slots, one per search); reflect_multi then opens with the
+// verdict and returns at once unless something was contradicted, in which case it redoes the
+// bounce exactly (same bits either way: the per-ray arithmetic is the same code). Which method
+// each search takes is the caller's guess (xrt_hip_bounce.assume_*: the toroid's first two
+// bounces take Brent for the hit, the later ones the secant; the verdict reports what the batch
+// asks for, and the host remembers it per element and bounce).
+// ---------------------------------------------------------------------------
+#define MULTI_SLOTS2 (REFLECT_OPT_SLOTS + 8)      /* second set of report slots: behind the TabFast records */
+
+template <class K>
+__global__ __launch_bounds__(REFLECT_BLOCK) void multi_decide_opt(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, MultiAux A) {
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
+  int ub_lo[XRT_HIP_MAX_ELEM], ub_hi[XRT_HIP_MAX_ELEM];
+  double dir0[3] = {0., 0., 0.};
+  OptStat* slots = reinterpret_cast<OptStat*>(A.part);
+  for (int k = threadIdx.x; k < REFLECT_OPT_SLOTS; k += blockDim.x) {
+    slots[MULTI_SLOTS2 + k].maxdz1 = 0;
+    slots[MULTI_SLOTS2 + k].maxdz2 = 0;
+    slots[MULTI_SLOTS2 + k].viol = 0;
+  }
+  if (threadIdx.x == 0) {
+    A.counts[0] = 0;
+    A.counts[1] = 0;
+  }
+  // (P.method_hint is NULL here -- the launcher sees to it --: the single passes' hint is about
+  // one search, a bounce has two)
+  decide_opt_body(P, M, in, slots, A.g, lds_u, ub_lo, ub_hi, dir0);
+}
+
+template <class K>
+__global__ __launch_bounds__(REFLECT_MULTI_BLOCK, REFLECT_MULTI_PER_CU) void reflect_multi_opt(
+    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam out, MultiAux A) {
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
+  if (!A.g->optimistic) return;             // nothing could be assumed: reflect_multi does the bounce
+  const GStat g = *A.g;
+  OptStat* slots1 = reinterpret_cast<OptStat*>(A.part);
+  OptStat* slots2 = slots1 + MULTI_SLOTS2;
+  const bool has_amp = in.Es_ri != nullptr;
+  const bool param = surf_is_param<K>(P);
+  const bool elevate = A.elev_out[0] != nullptr;
+  unsigned long long kept = 0, hit = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < in.n; base += stride) {
+    const int64_t i = base + threadIdx.x;
+    const bool live = i < in.n;
+    const int64_t j = live ? i : in.n - 1;
+    const int st0 = live ? in.state[j] : 0;
+    LocalRay raw;
+    raw.x = in.x[j];
+    raw.y = in.y[j];
+    raw.z = in.z[j];
+    raw.a = in.a[j];
+    raw.b = in.b[j];
+    raw.c = in.c[j];
+    const bool active = live && entering(P, st0);
+    SolveAux aux1, aux2;
+    int viol = 0;
+    if (live && !active) {
+      const int nr0 = A.nrefl_in ? A.nrefl_in[i] : 0;
+      copy_ray(out, in, i, st0, has_amp, false);
+      A.nrefl_out[i] = nr0;
+      A.theta[i] = 0.;
+      if (elevate) {
+        const double el0[4] = {-1., -kMaxHalfSize, -kMaxHalfSize, -kMaxHalfSize};
+        for (int k = 0; k < 4; ++k) A.elev_out[k][i] = A.elev_in[0] ? A.elev_in[k][i] : el0[k];
+      }
+      if (A.spr[0]) {   // reflect.py:1067-1069: copies of lb.x, y, z as they are
+        A.spr[0][i] = raw.x;
+        A.spr[1][i] = raw.y;
+        A.spr[2][i] = raw.z;
+      }
+    }
+    if (active) {
+      const int nr0 = A.nrefl_in ? A.nrefl_in[i] : 0;
+      double el[4] = {-1., -kMaxHalfSize, -kMaxHalfSize, -kMaxHalfSize};   // reflect.py:214-218
+      if (elevate && A.elev_in[0])
+        for (int k = 0; k < 4; ++k) el[k] = A.elev_in[k][i];
+      double vx, vy, vz;
+      const LocalRay r = multi_local(P, raw, vx, vy, vz);
+      // the axis stands only if its cosine dominates every state-1 ray's own (fused_ray)
+      viol = st0 == 1 && !dominates(g.axis, r);
+      double t1, t2;
+      bracket(P, g.axis, g.positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
+      if (P.is_multi) {
+        const Hit hp = solve_between<K, 1, true>(P, r, 0., t2, 0., 0., (A.assume & 2) != 0, &aux1);
+        const double tg = hp.t;
+        if (elevate) {   // base.py:1284-1286, reflect.py:651-659: find_dz at the tangency point
+          double ex, ey, ez;
+          el[0] = multi_f<K, 0>(P, tg, r, ex, ey, ez);
+          if (param) {
+            double cx, cy, cz;
+            ell_param_to_xyz(P, ex, ey, ez, cx, cy, cz);
+            ex = cx;
+            ey = cy;
+            ez = cz;
+          }
+          el[1] = ex;
+          el[2] = ey;
+          el[3] = ez;
+        }
+        t1 = tg + kDs;
+      }
+      Hit h = solve_between<K, 0, true>(P, r, t1, t2, 0., 0., (A.assume & 1) != 0, &aux2);
+      const double hs = h.x, hphi = h.y, hr = h.z;
+      hit_done<K>(P, h);
+      int st = rays_good<K>(P, h.x, h.y);
+      if (h.lost) st = P.lost_num;
+      RayIn q;
+      q.path = in.path[i];
+      q.E = in.E[i];
+      double a = r.a, b = r.b, c = r.c, th = 0.;
+      if (st == 1) {
+        const Finished fin = finish_ray<K>(P, M, g, r, h, q, in, i, has_amp);
+        a = fin.a;
+        b = fin.b;
+        c = fin.c;
+        th = fin.theta;
+        q = fin.lo;                 // (path + t, E)
+        q.Jss = fin.vJss;           // lb is vlb: the matrix turned back is what stays
+        q.Jpp = fin.vJpp;           // (reflect.py:1106-1110)
+        q.Jsr = fin.vJsr;
+        q.Jsi = fin.vJsi;
+        q.Esr = fin.vEsr;
+        q.Esi = fin.vEsi;
+        q.Epr = fin.vEpr;
+        q.Epi = fin.vEpi;
+      } else {
+        load_fields(in, i, has_amp, q);
+      }
+      // back to the virgin local frame (reflect.py:1115-1132), every entering ray
+      double x = h.x + P.shift[0], y = h.y + P.shift[1], z = h.z + P.shift[2];
+      rotate3(P.to_virgin, x, y, z);
+      rotate3(P.to_virgin, a, b, c);
+      if (st == 3) {                // reflect.py:225-228
+        x = vx;
+        y = vy;
+        z = vz;
+      }
+      store_ray(out, i, x, y, z, a, b, c, q.path, q.E, q.Jss, q.Jpp, q.Jsr, q.Jsi, st, q.Esr,
+                q.Esi, q.Epr, q.Epi, has_amp);
+      const bool good = st == 1 || st == 2;
+      A.nrefl_out[i] = nr0 + (good ? 1 : 0);
+      A.theta[i] = th;
+      if (elevate)
+        for (int k = 0; k < 4; ++k) A.elev_out[k][i] = el[k];
+      if (A.spr[0]) {
+        A.spr[0][i] = hs;
+        A.spr[1][i] = hphi;
+        A.spr[2][i] = hr;
+      }
+      kept += good;
+      hit += st == 1;
+    }
+    // all lanes of the wave together again: the reports (the tangency search's, the hit search's)
+    if (P.is_multi) report_opt(slots1, aux1, viol);
+    report_opt(P.is_multi ? slots2 : slots1, aux2, P.is_multi ? 0 : viol);
+  }
+  auto faddu = [](unsigned long long u, unsigned long long v) { return u + v; };
+  kept = block_reduce(kept, faddu, lds_u);
+  hit = block_reduce(hit, faddu, lds_u);
+  if (threadIdx.x == 0) {
+    if (kept) (void)atomicAdd(&A.counts[0], kept);
+    if (hit) (void)atomicAdd(&A.counts[1], hit);
+  }
+}
+
 // The launch is preceded by reflect_init(g, 1) (decisions reset, barrier counter zeroed).
 template <class K>
 __global__ __launch_bounds__(REFLECT_MULTI_BLOCK, REFLECT_MULTI_PER_CU) void reflect_multi(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam out, MultiAux A) {
   GStat* g = A.g;
   unsigned phase = 0;
+  if (A.gate) {
+    // behind reflect_multi_opt: the verdict, folded by every block for itself (exact_gate's
+    // scheme); nothing contradicted -> nothing to do
+    __shared__ double lds_d[REFLECT_MAX_WAVES];
+    bool full = true;
+    if (g->optimistic) {
+      // (slots: the tangency search's reports and, behind them, the hit search's -- of a first
+      // bounce, which has no tangency search, the hit search's alone)
+      const OptStat* slots = reinterpret_cast<const OptStat*>(A.part);
+      double m1, m2, h1, h2;
+      if (P.is_multi) {
+        full = fold_opt(slots, lds_d, m1, m2, (A.assume & 2) != 0);
+        full = fold_opt(slots + MULTI_SLOTS2, lds_d, h1, h2, (A.assume & 1) != 0) || full;
+      } else {
+        full = fold_opt(slots, lds_d, h1, h2, (A.assume & 1) != 0);
+        m1 = m2 = 0.;
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.diag[9] = h2 > h1 * 20. ? 1. : 0.;       // what this batch asks for: hit search,
+        A.diag[10] = m2 > m1 * 20. ? 1. : 0.;      // tangency search
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      g->redo = full ? 1 : 0;
+      A.diag[11] = full ? 1. : 0.;
+      A.diag[12] = 1.;
+    }
+    if (!full) return;
+  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+    A.diag[11] = 0.;
+    A.diag[12] = 0.;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     A.counts[0] = 0;
     A.counts[1] = 0;
@@ -438,6 +660,7 @@ __global__ __launch_bounds__(REFLECT_MULTI_BLOCK, REFLECT_MULTI_PER_CU) void ref
       gl = load_gstat(g);
       if (blockIdx.x == 0 && threadIdx.x == 0) {
         A.diag[4] = gl.maxdz2 > gl.maxdz1 * 20. ? 1. : 0.;
+        A.diag[10] = A.diag[4];
         A.diag[5] = gl.t1min;
         A.diag[6] = gl.t2max;
       }
@@ -454,6 +677,8 @@ __global__ __launch_bounds__(REFLECT_MULTI_BLOCK, REFLECT_MULTI_PER_CU) void ref
     A.diag[0] = (double)gl.axis;
     A.diag[1] = (double)gl.positive;
     A.diag[2] = gl.maxdz2 > gl.maxdz1 * 20. ? 1. : 0.;
+    A.diag[9] = A.diag[2];
+    if (!P.is_multi) A.diag[10] = 0.;
     A.diag[3] = (double)gl.n_enter;
     A.diag[7] = gl.t1min;
     A.diag[8] = gl.t2max;
@@ -687,6 +912,7 @@ __global__ __launch_bounds__(REFLECT_MULTI_BLOCK) void reflect_multi_stats(
       gl = load_gstat(g);
       if (blockIdx.x == 0 && threadIdx.x == 0) {
         A.diag[4] = gl.maxdz2 > gl.maxdz1 * 20. ? 1. : 0.;
+        A.diag[10] = A.diag[4];
         A.diag[5] = gl.t1min;
         A.diag[6] = gl.t2max;
       }
@@ -705,6 +931,10 @@ __global__ __launch_bounds__(REFLECT_MULTI_BLOCK) void reflect_multi_stats(
       A.diag[1] = (double)ld_agent_i(&g->positive);
       const double d1 = ld_agent(&g->maxdz1), d2 = ld_agent(&g->maxdz2);
       A.diag[2] = d2 > d1 * 20. ? 1. : 0.;
+      A.diag[9] = A.diag[2];
+      if (!P.is_multi) A.diag[10] = 0.;
+      A.diag[11] = 0.;
+      A.diag[12] = 2.;
       A.diag[3] = (double)ld_agent_u(&g->n_enter);
       A.diag[7] = ld_agent(&g->t1min);
       A.diag[8] = ld_agent(&g->t2max);
@@ -1169,8 +1399,35 @@ inline int launch_multi_sparse_k(const MultiLaunch& L) {
 }
 
 template <class K>
+inline int launch_multi_opt_k(const MultiLaunch& L) {
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reflect_multi_opt<K>,
+                                                     REFLECT_MULTI_BLOCK, 0) != hipSuccess ||
+        nb < 1)
+      nb = 1;
+    per_cu = nb > REFLECT_MULTI_PER_CU ? REFLECT_MULTI_PER_CU : nb;
+  }
+  xrt_hip_pass head = *L.P;
+  head.method_hint = nullptr;
+  hipLaunchKernelGGL(multi_decide_opt<K>, dim3(1), dim3(REFLECT_BLOCK), 0, L.st, head, *L.M, *L.in,
+                     L.A);
+  int64_t blocks = (L.in->n + REFLECT_MULTI_BLOCK - 1) / REFLECT_MULTI_BLOCK;
+  const int64_t cap = (int64_t)L.cus * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(reflect_multi_opt<K>, dim3((unsigned)blocks), dim3(REFLECT_MULTI_BLOCK), 0,
+                     L.st, *L.P, *L.M, *L.in, *L.out, L.A);
+  return launch_multi_dense_k<K>(L);       // (A.gate set: returns at once unless contradicted)
+}
+
+// sparse: few rays still enter (exact, over an index); optimistic: a full bounce without its
+// statistics phases, verified per ray; else the exact dense kernel (A.gate = 0)
+template <class K>
 inline int launch_multi_k(const MultiLaunch& L) {
-  return L.sparse ? launch_multi_sparse_k<K>(L) : launch_multi_dense_k<K>(L);
+  if (L.sparse) return launch_multi_sparse_k<K>(L);
+  return L.A.gate ? launch_multi_opt_k<K>(L) : launch_multi_dense_k<K>(L);
 }
 
 }  // namespace xrt

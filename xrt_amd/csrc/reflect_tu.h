@@ -37,6 +37,7 @@ struct FusedLaunch {   // one launch of reflect_fused / reflect_fused_xtal
   const xrt_hip_beam* sb;      //   its image
   const xrt_hip_geosource* src;   // the source in its head (reflect_fused_gen_scr), or null
   const PlotTail* plot;        // a plot behind the screen (reflect_fused_scr_plot), or null
+  const TailApertures* ap;     // apertures right behind the element (n = 0: none)
 };
 struct ExactLaunch {   // reflect_exact
   dim3 grid, block;
@@ -79,6 +80,11 @@ struct MultiAux {
   int nseg;
   double *ht, *hx, *hy, *hz;
   int32_t* hlost;
+  // the optimistic form of a full bounce: reflect_multi is launched behind reflect_multi_opt
+  // and opens with its verdict (gate); assume: bit 0 the hit search takes Brent, bit 1 the
+  // tangency search does
+  int gate;
+  int assume;
 };
 struct MultiLaunch {   // one launch of reflect_multi
   hipStream_t st;
@@ -110,6 +116,7 @@ inline void launch_fused_scr_k(int mode, const FusedLaunch& L) {
   ScreenConsumer cons;
   cons.S = *L.scr;
   cons.out = *L.sb;
+  cons.ap = *L.ap;
   if (mode == 0)
     hipLaunchKernelGGL((reflect_fused_scr<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
                        *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt, cons);
@@ -122,6 +129,7 @@ inline void launch_fused_gen_scr_k(const FusedLaunch& L) {
   ScreenConsumer cons;
   cons.S = *L.scr;
   cons.out = *L.sb;
+  cons.ap = *L.ap;
   hipLaunchKernelGGL(reflect_fused_gen_scr<K>, L.grid, L.block, 0, L.st, *L.P, *L.M, *L.src, *L.in,
                      *L.lb, *L.vb, L.theta, L.g, L.opt, cons);
 }
@@ -130,6 +138,7 @@ inline void launch_fused_scr_plot_k(int mode, const FusedLaunch& L) {
   ScreenConsumer cons;
   cons.S = *L.scr;
   cons.out = *L.sb;
+  cons.ap = *L.ap;
   if (mode == 0)
     hipLaunchKernelGGL((reflect_fused_scr_plot<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
                        *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt, cons, *L.plot);
@@ -142,6 +151,7 @@ inline void launch_fused_gen_scr_plot_k(const FusedLaunch& L) {
   ScreenConsumer cons;
   cons.S = *L.scr;
   cons.out = *L.sb;
+  cons.ap = *L.ap;
   hipLaunchKernelGGL(reflect_fused_gen_scr_plot<K>, L.grid, L.block, 0, L.st, *L.P, *L.M, *L.src,
                      *L.in, *L.lb, *L.vb, L.theta, L.g, L.opt, cons, *L.plot);
 }
@@ -184,7 +194,8 @@ bool tu_figured_exact0(int spec, const ExactLaunch& L);             // reflect_f
 bool tu_figured_exact1(int spec, const ExactLaunch& L);             // reflect_figured_x1.hip
 bool tu_exact0(int spec, const ExactLaunch& L);                     // reflect_exact0.hip
 void tu_exact0_redo_scr(const ExactLaunch& L, const xrt_hip_screen& S, const xrt_hip_beam& sb,
-                        const xrt_hip_geosource* src, const PlotTail* plot);
+                        const xrt_hip_geosource* src, const PlotTail* plot,
+                        const TailApertures* ap);
 void tu_exact0_dcm(const DcmLaunch& L);
 bool tu_exact1(int spec, const ExactLaunch& L);                     // reflect_exact1.hip
 bool tu_exact2(int spec, const ExactLaunch& L);                     // reflect_exact2.hip

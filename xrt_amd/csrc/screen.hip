@@ -149,25 +149,15 @@ __global__ __launch_bounds__(256) void aperture_propagate_kernel(xrt_hip_apertur
   // stopped then was alive when it arrived, and is stopped again by the same test)
   const bool good = st > 0 || (A.own_marks && st == A.lost_num);
   if (good) {
-    const double gx = x - A.center[0], gy = y - A.center[1], gz = z - A.center[2];
-    const double ga = a, gb = b, gc = c;
-    x = (A.ex[0] * gx + A.ex[1] * gy) + A.ex[2] * gz;
-    y = (A.ey[0] * gx + A.ey[1] * gy) + A.ey[2] * gz;
-    z = (A.ez[0] * gx + A.ez[1] * gy) + A.ez[2] * gz;
-    a = (A.ex[0] * ga + A.ex[1] * gb) + A.ex[2] * gc;
-    b = (A.ey[0] * ga + A.ey[1] * gb) + A.ey[2] * gc;
-    c = (A.ez[0] * ga + A.ez[1] * gb) + A.ez[2] * gc;
-    const double dpath = -y / b;
-    x = x + a * dpath;
-    z = z + c * dpath;
+    const ApertureRay q = aperture_ray(A, x, y, z, a, b, c);
+    x = q.x;
+    z = q.z;
+    a = q.a;
+    b = q.b;
+    c = q.c;
+    const double dpath = q.dpath;
     path = path + dpath;
-    bool bad = false;
-    if (A.round) bad = sqrt(x * x + z * z) > A.radius;
-    if (A.blade_mask & 1) bad = bad || (x < A.blade[0]);
-    if (A.blade_mask & 2) bad = bad || (x > A.blade[1]);
-    if (A.blade_mask & 4) bad = bad || (z < A.blade[2]);
-    if (A.blade_mask & 8) bad = bad || (z > A.blade[3]);
-    if (A.has_shade) bad = bad || (z > A.shade[0] && z < A.shade[1]);
+    bool bad = q.bad;
     if (A.poly_n > 0) bad = !inside_polygon(A.poly_xz, A.poly_n, x, z);
     if (A.is_beam_stop) bad = !bad;
     if (bad) {

@@ -87,6 +87,62 @@ __device__ __forceinline__ void store_image(const xrt_hip_beam& out, int64_t i, 
   }
 }
 
+// RectangularAperture / RoundAperture / DoubleSlit / beam stops (apertures.py:334-413, 770-846,
+// 931-1021) on ONE ray that is alive, given in the global frame: the ray in the aperture's
+// frame on its plane, the path there, and whether the blades stop it. (No polygons: they need
+// their vertex array and also relabel dead rays -- screen.hip's kernel.) One code for the
+// stand-alone kernel and for an aperture in the tail of a ray pass (reflect_impl.h).
+struct ApertureRay {
+  double x, z, a, b, c, dpath;
+  bool bad;
+};
+__device__ __forceinline__ ApertureRay aperture_ray(const xrt_hip_aperture& A, double px,
+                                                    double py, double pz, double ga, double gb,
+                                                    double gc) {
+  ApertureRay r;
+  const double gx = px - A.center[0], gy = py - A.center[1], gz = pz - A.center[2];
+  double x = (A.ex[0] * gx + A.ex[1] * gy) + A.ex[2] * gz;
+  const double y = (A.ey[0] * gx + A.ey[1] * gy) + A.ey[2] * gz;
+  double z = (A.ez[0] * gx + A.ez[1] * gy) + A.ez[2] * gz;
+  r.a = (A.ex[0] * ga + A.ex[1] * gb) + A.ex[2] * gc;
+  r.b = (A.ey[0] * ga + A.ey[1] * gb) + A.ey[2] * gc;
+  r.c = (A.ez[0] * ga + A.ez[1] * gb) + A.ez[2] * gc;
+  r.dpath = -y / r.b;
+  x = x + r.a * r.dpath;
+  z = z + r.c * r.dpath;
+  bool bad = false;
+  if (A.round) bad = sqrt(x * x + z * z) > A.radius;
+  if (A.blade_mask & 1) bad = bad || (x < A.blade[0]);
+  if (A.blade_mask & 2) bad = bad || (x > A.blade[1]);
+  if (A.blade_mask & 4) bad = bad || (z < A.blade[2]);
+  if (A.blade_mask & 8) bad = bad || (z > A.blade[3]);
+  if (A.has_shade) bad = bad || (z > A.shade[0] && z < A.shade[1]);
+  r.x = x;
+  r.z = z;
+  r.bad = bad;
+  return r;
+}
+
+// up to two apertures right behind an element, in the order the beam meets them: the state of
+// the outgoing (global) record after them -- what aperture.propagate(gb) leaves in gb.state
+#define XRT_TAIL_APERTURES 2
+struct TailApertures {
+  int n;
+  xrt_hip_aperture a[XRT_TAIL_APERTURES];
+};
+__device__ __forceinline__ int apertures_mark(const TailApertures& T, double x, double y, double z,
+                                              double a, double b, double c, int st) {
+#pragma unroll
+  for (int k = 0; k < XRT_TAIL_APERTURES; ++k) {
+    if (k < T.n && st > 0) {
+      bool bad = aperture_ray(T.a[k], x, y, z, a, b, c).bad;
+      if (T.a[k].is_beam_stop) bad = !bad;
+      if (bad) st = T.a[k].lost_num;
+    }
+  }
+  return st;
+}
+
 __device__ __forceinline__ void expose_flat_store(
     const xrt_hip_screen& S, const xrt_hip_beam& out, int64_t i, double px, double py, double pz,
     double ga, double gb, double gc, double path0, double E, double Jss, double Jpp, double Jsr,
