@@ -933,6 +933,33 @@ XRT_HIP_API int xrt_hip_shine_reflect_screen_plot_f64_dev(
     xrt_hip_beam* out_screen, int keep_virgin, int keep_screen, const xrt_hip_plot_tail* tail,
     void* workspace, size_t workspace_bytes, void* stream, int* fused);
 
+/* ---- everything that may ride in the tail of a pass, in one record (round 6) ----------------
+ * Up to two apertures that follow the element directly (RectangularAperture, RoundAperture,
+ * DoubleSlit and their beam stops, apertures.py:334-413; no polygons) in the order the beam meets
+ * them, then optionally a screen, then optionally the plot of its image. An aperture in the
+ * tail is its states-only call (xrt_hip_aperture_propagate_f64_dev with out_local NULL) made on
+ * the outgoing record while it is in registers: the state written to out_virgin -- and seen by
+ * the screen -- is what aperture.propagate(gb) leaves in gb.state; the beam in the aperture's
+ * frame is made later, if anybody wants it, by the full call on out_virgin with own_marks = 1.
+ * The lean mirror / plate kernels carry the tail; any other pass is followed by the apertures'
+ * and the screen's own launches inside the call (*fused: bit 0 screen, 1 source, 2 plot,
+ * 3 apertures in the tail). source NULL: the rays are read from `in`; else they are made from
+ * the source's record and `in` is the scratch of xrt_hip_shine_reflect_screen_f64_dev. */
+typedef struct xrt_hip_tail {
+  int32_t n_apertures;
+  int32_t keep_screen;             /* 0: nobody else reads the image (with a plot only) */
+  xrt_hip_aperture aperture[2];
+  const struct xrt_hip_screen* screen;      /* or NULL */
+  xrt_hip_beam* out_screen;                 /* or NULL */
+  const xrt_hip_plot_tail* plot;            /* or NULL (needs the screen) */
+} xrt_hip_tail;
+XRT_HIP_API int xrt_hip_reflect_tail_f64_dev(
+    const struct xrt_hip_geosource* source, const xrt_hip_pass* pass,
+    const xrt_hip_material* material, xrt_hip_beam* in, const xrt_hip_beam* restore,
+    xrt_hip_beam* out_local, xrt_hip_beam* out_virgin, double* theta, const xrt_hip_tail* tail,
+    int keep_virgin, void* workspace, size_t workspace_bytes, void* stream, int* fused);
+
+
 
 /* ---- undulator field integral -------------------------
  * Replaces run_parallel('undulator' | 'undulator_taper' | 'undulator_nf', ...)

@@ -1008,3 +1008,229 @@ def test_the_fused_chain_against_the_oracle_directly():
     assert plot.nRaysGood == int((oimg.state == 1).sum())
     assert plot.nRaysOut == int((oimg.state == 2).sum())
     assert plot.nRaysDead == int((oimg.state < 0).sum())
+
+
+# ---- apertures in the tail of the pass -------------------------------------------------------
+def _eager_chain(oe, aps, scr, beam):
+    """element -> apertures -> screen, every step its own launch."""
+    old = roe.fuseConsumers
+    roe.fuseConsumers = False
+    try:
+        gb, lb = oe.reflect(beam)
+        locs = [a.propagate(gb) for a in aps]
+        img = scr.expose(gb) if scr is not None else None
+    finally:
+        roe.fuseConsumers = old
+    return gb, lb, locs, img
+
+
+def _forget(*objs):
+    for o in objs:
+        for key in ('_local_beam_wanted', '_global_beam_wanted', '_local_beams_wanted',
+                    '_image_wanted'):
+            o.__dict__.pop(key, None)
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+@pytest.mark.parametrize('pair', [(0, 1), (2, 3), (3,)])
+def test_apertures_ride_in_the_tail_of_the_pass(amplitudes, pair):
+    """aperture.propagate(gb) while the mirror's pass is pending (reference apertures.py:334-413
+    after oes/reflect.py): the marks are made on the ray in registers, between the element and
+    the screen; image, both beams of the element and -- on demand -- the apertures' local beams
+    have the bits of the separate launches."""
+    bl, oe, scr, beam = scene(n=80000, amplitudes=amplitudes)
+    kinds = _apertures(bl, eager(oe, scr, beam)[0])
+    aps = [kinds[k] for k in pair]
+    for k, a in enumerate(aps):          # (every aperture its own number, as in a beamline)
+        a.lostNum = -(40 + k)
+    gb0, lb0, locs0, img0 = _eager_chain(oe, aps, scr, beam)
+    assert 1000 < (gb0.state == aps[-1].lostNum).sum()
+    _forget(oe, scr, *aps)
+    gb, lb = oe.reflect(beam)
+    op = gb.__dict__['_op']
+    locs = [a.propagate(gb) for a in aps]
+    assert op.state == 'pending' and len(op.apertures) == len(aps)
+    assert all(type(b) is rs.LazyBeam and not b.__dict__['_filled'] for b in locs)
+    img = scr.expose(gb)
+    same(img, img0, 'image')
+    assert op.state == 'imaged' and not gb.__dict__['_filled']
+    same(lb, lb0, 'local', extra=('theta',))
+    same(gb, gb0, 'global')              # (made again, the marks in it)
+    for a, b, b0 in zip(aps, locs, locs0):
+        same(b, b0, 'beam at ' + a.name)
+        assert a.__dict__['_local_beam_wanted']
+    assert op.state == 'done' and op.beam is None
+    # an aperture whose beam has been looked at takes its own launch from then on
+    gb, lb = oe.reflect(beam)
+    again = aps[0].propagate(gb)
+    assert type(again.__dict__['_op']) is ra._DeferredLocal and gb.__dict__['_filled']
+    same(again, locs0[0], 'beam at the aperture, its own launch')
+
+
+def test_apertures_in_the_tail_without_a_screen():
+    """mirror -> slit -> next element: the marked global beam is all the pass writes."""
+    bl, oe, scr, beam = scene(n=50000)
+    kinds = _apertures(bl, eager(oe, scr, beam)[0])
+    aps = kinds[:2]
+    aps[1].lostNum = -41
+    gb0, lb0, locs0, _ = _eager_chain(oe, aps, None, beam)
+    _forget(oe, scr, *aps)
+    gb, lb = oe.reflect(beam)
+    op = gb.__dict__['_op']
+    locs = [a.propagate(gb) for a in aps]
+    del locs                              # (nobody looks at them: a beamline's slits)
+    assert op.state == 'pending'
+    assert np.array_equal(gb.state, gb0.state)
+    assert op.state == 'global' and not lb.__dict__['_filled']
+    same(gb, gb0, 'global')
+    same(lb, lb0, 'local', extra=('theta',))
+    assert op.state == 'done'
+    # the local beam first: still one launch with the marks
+    gb, lb = oe.reflect(beam)
+    op = gb.__dict__['_op']
+    aps[0].propagate(gb), aps[1].propagate(gb)
+    same(lb, lb0, 'local first', extra=('theta',))
+    assert op.state == 'done'
+    same(gb, gb0, 'global then')
+    # a third aperture, a polygon and an aperture after the screen take their own launches
+    gb, lb = oe.reflect(beam)
+    op = gb.__dict__['_op']
+    kinds[0].propagate(gb), kinds[1].propagate(gb)
+    assert op.state == 'pending'
+    kinds[2].propagate(gb)
+    assert op.state != 'pending' and len(op.apertures) == 2
+    gb, lb = oe.reflect(beam)
+    kinds[4].propagate(gb)
+    assert gb.__dict__['_op'].state != 'pending'
+    gb, lb = oe.reflect(beam)
+    img = scr.expose(gb)
+    kinds[0].propagate(gb)
+    assert not gb.__dict__['_op'].apertures
+    g1, _, _, i1 = _eager_chain(oe, [], scr, beam)
+    same(img, i1, 'the image from before the aperture')
+
+
+def test_apertures_in_the_tail_of_a_contradicted_pass_and_of_other_kernels():
+    import p1_cases
+    g = np.load(os.path.join(p1_cases.GOLDEN, 'g2_toroid_brent.npz'))
+    oe = p1_cases.product_oe('g2_toroid_brent', g)
+    beam = p1_cases.product_beam(g)
+    y0 = float(g['oe_center'][1])
+    scr = rsc.Screen(oe.bl, 'after', center=[0, y0 + 3000., 10.])
+    gb0 = eager(oe, scr, beam)[0]
+    ok = gb0.state == 1
+    mid = np.median(gb0.x[ok] + gb0.a[ok] / gb0.b[ok] * (y0 + 1000. - gb0.y[ok]))
+    slit = ra.RectangularAperture(oe.bl, 'slit', [0, y0 + 1000., 0], ('left',), [mid])
+    gb0, lb0, locs0, img0 = _eager_chain(oe, [slit], scr, beam)
+    assert 10 < (gb0.state == slit.lostNum).sum() < ok.sum()
+    _forget(oe, scr, slit)
+    gb, lb = oe.reflect(beam)
+    loc = slit.propagate(gb)
+    assert gb.__dict__['_op'].state == 'pending'
+    img = scr.expose(gb)
+    same(img, img0, 'image after the redo')
+    same(gb, gb0, 'global after the redo')
+    same(loc, locs0[0], 'beam at the slit')
+    same(lb, lb0, 'local', extra=('theta',))
+    # a Bragg crystal (no lean kernel): the same call, the apertures' own launches inside it
+    bl = raycing.BeamLine()
+    si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+    thB = float(np.ravel(si.get_Bragg_angle(9000.) - si.get_dtheta(9000.))[0])
+    xt = roe.OE(bl, 'xtal', center=[0, 20000., 0], pitch=thB, material=si, limPhysX=[-10, 10],
+                limPhysY=[-50, 50])
+    scr = rsc.Screen(bl, 'after', center=[0, 21000., 1000. * np.tan(2 * thB)])
+    pipe = ra.RoundAperture(bl, 'pipe', [0, 20500., 500. * np.tan(2 * thB)], r=2.)
+    beam = workloads.synthetic_rays(60000, 3, sa=1e-4, E=(8995., 9005.), amplitudes=True)
+    gb0, lb0, locs0, img0 = _eager_chain(xt, [pipe], scr, beam)
+    assert 1000 < (gb0.state == pipe.lostNum).sum() < 58000
+    _forget(xt, scr, pipe)
+    gb, lb = xt.reflect(beam)
+    loc = pipe.propagate(gb)
+    assert gb.__dict__['_op'].state == 'pending'
+    img = scr.expose(gb)
+    same(img, img0, 'image')
+    same(gb, gb0, 'global')
+    same(loc, locs0[0], 'beam in the pipe')
+    same(lb, lb0, 'local', extra=('theta',))
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+def test_source_mirror_slit_screen_in_one_pass(amplitudes):
+    bl, amplitudes = source_scene(amplitudes=amplitudes)
+    at = [0, 20000. + 5000. * np.cos(8e-3), 5000. * np.sin(8e-3)]
+    slit = ra.RectangularAperture(bl, 'slit', at, ('left', 'top'), [-0.2, 0.05])
+
+    def chain(fuse):
+        old = roe.fuseConsumers
+        roe.fuseConsumers = fuse
+        try:
+            bl.source._calls = 0
+            src = bl.source.shine(withAmplitudes=amplitudes)
+            gb, lb = bl.mirror.reflect(src)
+            loc = slit.propagate(gb)
+            img = bl.screen.expose(gb)
+            img.nrays
+        finally:
+            roe.fuseConsumers = old
+        return src, gb, lb, loc, img
+    s0, g0, l0, a0, i0 = chain(False)
+    assert 1000 < (g0.state == slit.lostNum).sum() < 0.9 * g0.nrays
+    _forget(bl.mirror, bl.screen, slit, bl.source)
+    s1, g1, l1, a1, i1 = chain(True)
+    assert not g1.__dict__['_filled'] and not s1.__dict__['_filled']
+    same(i1, i0, 'image')
+    same(g1, g0, 'global')
+    same(a1, a0, 'beam at the slit')
+    same(l1, l0, 'local', extra=('theta',))
+    same(s1, s0, 'source')
+
+
+def test_c_abi_tail_record():
+    """xrt_hip_reflect_tail_f64_dev directly: what rode where (*fused*), and what it refuses."""
+    import ctypes
+    from xrt_amd import _lib, _structs, hipcalls
+    bl, oe, scr, beam = scene(n=30000)
+    kinds = _apertures(bl, eager(oe, scr, beam)[0])
+    aps = kinds[:2]
+    aps[1].lostNum = -41
+    gb0, lb0, _, img0 = _eager_chain(oe, aps, scr, beam)
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    p = oe._make_pass(oe.pitch, oe.roll + oe.positionRoll, oe.yaw, oe.dx)
+    ms = oe._material_struct(oe.material, True, dev, beam)
+    theta = torch.empty(beam.nrays, dtype=torch.float64, device=dev)
+    ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(beam.nrays), 'reflect')
+    s_in = beam.to_struct(dev)
+    srec = scr._record(False)
+
+    def call(n_ap, screen, keep, polygon=False):
+        lb, gb, img = (rs.Beam.empty_like_on_device(beam, dev) for _ in range(3))
+        tail = _structs.Tail()
+        tail.n_apertures, tail.keep_screen = n_ap, 1
+        for k, a in enumerate(aps[:min(n_ap, 2)]):
+            tail.aperture[k] = a._record()
+        if polygon:
+            tail.aperture[0] = kinds[4]._record()
+        if screen:
+            tail.screen, tail.out_screen = ctypes.addressof(srec), \
+                ctypes.addressof(img.to_struct(dev))
+        fused = ctypes.c_int(-1)
+        rc = lib.xrt_hip_reflect_tail_f64_dev(
+            None, ctypes.byref(p), ctypes.byref(ms), ctypes.byref(s_in), ctypes.byref(s_in),
+            ctypes.byref(lb.to_struct(dev)), ctypes.byref(gb.to_struct(dev)),
+            ctypes.c_void_p(theta.data_ptr()), ctypes.byref(tail), keep,
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(fused))
+        return rc, fused.value, lb, gb, img
+    rc, fused, lb, gb, img = call(2, True, 1)
+    assert rc == 0 and fused == 9
+    same(img, img0, 'image')
+    same(gb, gb0, 'global')
+    same(lb, lb0, 'local')
+    rc, fused, lb, gb, img = call(2, False, 0)      # (no screen: the global beam is kept anyway)
+    assert rc == 0 and fused == 8
+    same(gb, gb0, 'global, no screen')
+    rc, fused, lb, gb, img = call(0, True, 1)
+    assert rc == 0 and fused == 1
+    assert call(3, True, 1)[0] != 0 and b'0 to 2' in lib.xrt_hip_last_error()
+    assert call(1, True, 1, polygon=True)[0] != 0 and b'polygon' in lib.xrt_hip_last_error()

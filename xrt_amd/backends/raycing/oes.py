@@ -885,6 +885,7 @@ class _DeferredReflect(rs.SharesStates, rs.FillsBeams):
         self.material = material
         self.n = self.src_op.n if self.src_op is not None else snap.nrays
         self.screen = self.screen_rec = None
+        self.apertures = []           # [(aperture, its record)]: marks_later
         self.state = 'pending'
         oe._adopt((self._make('gb'), self._make('lb')), beam)
         rs._PENDING.add(self)
@@ -910,6 +911,74 @@ class _DeferredReflect(rs.SharesStates, rs.FillsBeams):
         self.optional = True
         rs._PENDING.add(self)
 
+    def takes_aperture(self, aperture):
+        """Can ``aperture.propagate(gb)`` wait for the pass? Up to two apertures without an
+        outline of vertices right behind the element, before any screen has looked at the beam
+        (a screen sees the states as they are when it is exposed)."""
+        return self.state == 'pending' and self.screen_rec is None and self.out is None and \
+            len(self.apertures) < 2 and bool(self.p.out_to_global) and \
+            not hasattr(aperture, 'vertices') and \
+            not aperture.__dict__.get('_local_beam_wanted')
+
+    def marks_later(self, aperture):
+        """RectangularAperture.propagate of the global beam while the pass is still pending
+        (reference apertures.py:334-413 right after oes/reflect.py): the aperture's marks are
+        made in the tail of the pass, on the ray in registers (xrt_hip_reflect_tail_f64_dev) --
+        a slit between two mirrors costs no launch and no traffic of its own. -> the beam in the
+        aperture's frame, made when somebody first looks at it (the pass again + the aperture's
+        own kernel; the aperture remembers and takes its own launch from then on)."""
+        k = len(self.apertures)
+        self.apertures.append((aperture, aperture._record()))
+        gb = self.gb
+        gb.__dict__.setdefault('_stopped_by', set()).add(aperture.lostNum)
+        local = self._make('ap%d' % k)
+        rs.inherit_scalars(local, gb)
+        return self.hand_out()
+
+    def _aperture_locals_filled(self):
+        return all(rs.filled(self._beam('ap%d' % k)) for k in range(len(self.apertures)))
+
+    def _mark(self, gb):
+        """The apertures' marks in a global beam that a repeated pass has made."""
+        for _, rec in self.apertures:
+            _lib.check(_lib.load().xrt_hip_aperture_propagate_f64_dev(
+                ctypes.byref(rec), ctypes.byref(gb.to_struct(_device())), None, None, _stream()),
+                'xrt_hip_aperture_propagate_f64_dev')
+        gb._h.pop('state', None)
+
+    def _aperture_local(self, k):
+        """The beam in the frame of aperture *k* after all: the pass again (the global beam with
+        the states as the element leaves them), the marks of the apertures before this one,
+        then the aperture's full kernel."""
+        if self.state == 'pending':
+            self.materialize('gb')
+        target = self._beam('ap%d' % k)
+        if rs.filled(target):
+            return
+        aperture, rec = self.apertures[k]
+        aperture.__dict__['_local_beam_wanted'] = True
+        rays = self.beam
+        if type(rays) is rs.LazyBeam:      # (a source's, not made when the pass ran)
+            rays = self.src_op.rays_again()
+        _, gb, _ = self.oe._run_pass(self.p, self.material, True, rays, rays, local=False)
+        dev = _device()
+        lib = _lib.load()
+        for _, before in self.apertures[:k]:
+            _lib.check(lib.xrt_hip_aperture_propagate_f64_dev(
+                ctypes.byref(before), ctypes.byref(gb.to_struct(dev)), None, None, _stream()),
+                'xrt_hip_aperture_propagate_f64_dev')
+        local = rs.Beam.empty_like_on_device(gb, dev)
+        _lib.check(lib.xrt_hip_aperture_propagate_f64_dev(
+            ctypes.byref(rec), ctypes.byref(gb.to_struct(dev)),
+            ctypes.byref(local.to_struct(dev)), None, _stream()),
+            'xrt_hip_aperture_propagate_f64_dev')
+        rs.adopt_into(target, local)
+        if rs.filled(self.lb) and rs.filled(self.gb) and rs.filled(self.image) and \
+                self._aperture_locals_filled():
+            rs._PENDING.discard(self)
+            self.state = 'done'
+            self.beam, self.tensors = None, ()
+
     def expose_later(self, screen, rec):
         """Screen.expose of the global beam while the pass is still pending: the image is handed
         out before anything is launched as well, so that a plot of it may still join the pass
@@ -921,9 +990,12 @@ class _DeferredReflect(rs.SharesStates, rs.FillsBeams):
     def materialize(self, which=None):
         oe = self.oe
         filled = rs.filled
-        if self.state == 'pending' and self.screen_rec is not None:
-            # the pass with the screen in its tail; then the beam asked for, if it was left out
-            self._launch_with_screen()
+        if which is not None and which.startswith('ap'):
+            return self._aperture_local(int(which[2:]))
+        if self.state == 'pending' and (self.screen_rec is not None or self.apertures):
+            # the pass with the apertures and the screen in its tail; then the beam asked for,
+            # if it was left out
+            self._launch_with_screen(local=True if which == 'lb' else None)
             if which in (None, 'image') or filled(self.gb if which == 'gb' else self.lb):
                 return
         if self.state == 'pending':
@@ -953,7 +1025,7 @@ class _DeferredReflect(rs.SharesStates, rs.FillsBeams):
                 _, _, image, _ = oe._run_pass_screen(self.p, self.material, rays, self.screen_rec,
                                                      keep_global=False, local=False)
                 rs.adopt_into(self.image, image)
-            if filled(self.lb) and filled(self.gb):
+            if filled(self.lb) and filled(self.gb) and self._aperture_locals_filled():
                 rs._PENDING.discard(self)
                 self.state = 'done'
         elif self.state in ('global', 'imaged'):
@@ -973,28 +1045,34 @@ class _DeferredReflect(rs.SharesStates, rs.FillsBeams):
                 if want_lb:
                     rs.adopt_into(self.lb, lb)
                 if want_gb:
+                    self._mark(gb)
                     rs.adopt_into(self.gb, gb)
-            if filled(self.lb) and filled(self.gb) and filled(self.image):
+            if filled(self.lb) and filled(self.gb) and filled(self.image) and \
+                    self._aperture_locals_filled():
                 rs._PENDING.discard(self)
                 self.state = 'done'
         if self.state == 'done':
             self.beam, self.tensors = None, ()
 
-    def _launch_with_screen(self, plot=None):
-        """The pass with the screen in its tail (and *plot*, a _structs.PlotTail showing the
-        screen's image, behind it) -> True; False if *plot* cannot ride this pass (nothing
-        has been launched then)."""
+    def _launch_with_screen(self, plot=None, local=None):
+        """The pass with its tail: the apertures that wait (marks_later), the screen
+        (expose_later) and *plot*, a _structs.PlotTail showing the screen's image, behind it
+        -> True; False if *plot* cannot ride this pass (nothing has been launched then)."""
         oe = self.oe
         src = self.src_op
+        screened = self.screen_rec is not None
         tabulated = isinstance(getattr(self.material, 'refractiveIndex', None), list)
-        keep = bool(oe.__dict__.get('_global_beam_wanted'))
-        keep_image = plot is None or bool(self.screen.__dict__.get('_image_wanted'))
-        local = not _locals_on_demand(oe, self.material)
+        # (without a screen the marked global beam is what the pass is for)
+        keep = bool(oe.__dict__.get('_global_beam_wanted')) or not screened
+        keep_image = screened and (plot is None or bool(self.screen.__dict__.get('_image_wanted')))
+        if local is None:
+            local = not _locals_on_demand(oe, self.material)
         from_source = src is not None and src.state == 'pending' and not tabulated
         made = oe._run_pass_screen(self.p, self.material, None if from_source else self.beam,
                                    self.screen_rec, source=src if from_source else None,
                                    keep_global=keep, local=local, plot=plot,
-                                   keep_image=keep_image)
+                                   keep_image=keep_image,
+                                   apertures=[rec for _, rec in self.apertures])
         if made is None:
             return False
         rs._PENDING.discard(self)
@@ -1007,11 +1085,12 @@ class _DeferredReflect(rs.SharesStates, rs.FillsBeams):
             rs.adopt_into(self.gb, gb)
         if keep_image:
             rs.adopt_into(self.image, image)
-        if local and keep_image and not (fused and not keep):
+        if local and (keep_image or not screened) and not (fused and not keep) and \
+                self._aperture_locals_filled():
             self.state = 'done'
             self.beam, self.tensors = None, ()
         else:
-            self.state = 'imaged'
+            self.state = 'imaged' if screened else 'global'
             self._waits_with_its_own_states()
         return True
 
@@ -1058,7 +1137,7 @@ _SCRATCH_RAYS = 2_000_000
 
 
 def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, keep_global=False,
-                     local=True, plot=None, keep_image=True):
+                     local=True, plot=None, keep_image=True, apertures=()):
     """OE.reflect + Screen.expose in one C call (xrt_hip_reflect_screen_f64_dev) ->
     (lb, gb, image, fused): fused = the lean kernel carried the screen and gb holds nothing;
     *local* False: no local beam either (lb None).
@@ -1066,7 +1145,9 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
     source's record inside the same call (xrt_hip_shine_reflect_screen_f64_dev).
     *plot* (a _structs.PlotTail): the plot of the image behind the screen
     (xrt_hip_reflect_screen_plot_f64_dev); the image itself only with *keep_image*. -> None,
-    and nothing is launched, if this pass cannot carry the plot."""
+    and nothing is launched, if this pass cannot carry the plot.
+    *apertures* (up to two _structs.Aperture records): their marks between the element and the
+    screen (xrt_hip_reflect_tail_f64_dev); *screen_record* may then be None (no image)."""
     _lib.require_gpu()
     lib = _lib.load()
     dev = _device()
@@ -1084,6 +1165,7 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
         return None
     # (the global beam nobody keeps: the redo's scratch)
     gb = rs.Beam.empty_on_device(n, dev, amp) if keep_global else _scratch_beam('global', n, dev, amp)
+    keep_image = keep_image and screen_record is not None
     image = rs.Beam.empty_on_device(n, dev, amp) if keep_image else None
     image_ref = ctypes.byref(image.to_struct(dev)) if keep_image else None
     lb = rs.Beam.empty_on_device(n, dev, amp) if local else None
@@ -1092,7 +1174,25 @@ def _run_pass_screen(self, p, material, beam_in, screen_record, source=None, kee
     theta_ref = ctypes.c_void_p(theta.data_ptr()) if local else None
     ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(n), 'reflect')
     fused = ctypes.c_int(0)
-    if source is not None and plot is not None:
+    if apertures:
+        tail = _structs.Tail()
+        tail.n_apertures, tail.keep_screen = len(apertures), int(keep_image)
+        for k, rec in enumerate(apertures):
+            tail.aperture[k] = rec
+        if screen_record is not None:
+            tail.screen = ctypes.addressof(screen_record)
+        if keep_image:
+            tail.out_screen = ctypes.addressof(image.to_struct(dev))
+        if plot is not None:
+            tail.plot = ctypes.addressof(plot)
+        rays = scratch.to_struct(dev) if source is not None else s_in
+        _lib.check(lib.xrt_hip_reflect_tail_f64_dev(
+            ctypes.byref(source.g) if source is not None else None, ctypes.byref(p),
+            ctypes.byref(ms), ctypes.byref(rays), ctypes.byref(rays), lb_ref,
+            ctypes.byref(gb.to_struct(dev)), theta_ref, ctypes.byref(tail), int(keep_global),
+            ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(), ctypes.byref(fused)),
+            'xrt_hip_reflect_tail_f64_dev')
+    elif source is not None and plot is not None:
         _lib.check(lib.xrt_hip_shine_reflect_screen_plot_f64_dev(
             ctypes.byref(source.g), ctypes.byref(p), ctypes.byref(ms),
             ctypes.byref(scratch.to_struct(dev)), lb_ref,

@@ -257,6 +257,7 @@ int xrt_hip_sizeof(int which) {
     case 13: return (int)sizeof(xrt_hip_geosource);
     case 14: return (int)sizeof(xrt_hip_bounce);
     case 15: return (int)sizeof(xrt_hip_plot_tail);
+    case 16: return (int)sizeof(xrt_hip_tail);
     default: return fail(XRT_HIP_ERR_ARG, "xrt_hip_sizeof: unknown struct %d", which);
   }
 }
@@ -422,7 +423,8 @@ static int reflect_pass_impl(const xrt_hip_pass* pass, const xrt_hip_material* m
                              const xrt_hip_screen* screen, xrt_hip_beam* out_screen,
                              int keep_virgin, int* fused,
                              const xrt_hip_geosource* source = nullptr,
-                             const xrt_hip_plot_tail* tail = nullptr, int keep_screen = 1) {
+                             const xrt_hip_plot_tail* tail = nullptr, int keep_screen = 1,
+                             const xrt::TailApertures* ap = nullptr) {
   const ArmedEvents armed;
   int rc;
   if ((rc = check_pass(pass, material))) return rc;
@@ -503,7 +505,8 @@ static int reflect_pass_impl(const xrt_hip_pass* pass, const xrt_hip_material* m
   hipError_t e = xrt::reflect_pass_launch(*pass, *material, *in, *restore, *out_local,
                                           *out_virgin, theta, workspace, st, e0, e1, k0, k1,
                                           force_exact, screen, out_screen, keep_virgin != 0,
-                                          fused, source, tail ? &plan : nullptr, keep_screen != 0);
+                                          fused, source, tail ? &plan : nullptr, keep_screen != 0,
+                                          ap);
   if (e != hipSuccess) return fail(XRT_HIP_ERR_HIP, "reflect launch: %s", hipGetErrorString(e));
   if (kernel_ms) {
     HIP_TRY(hipEventSynchronize(e1));
@@ -635,6 +638,43 @@ int xrt_hip_shine_reflect_screen_plot_f64_dev(
   return reflect_pass_impl(pass, material, source_beam, source_beam, out_local, out_virgin, theta,
                            workspace, workspace_bytes, stream, nullptr, nullptr, screen,
                            out_screen, keep_virgin, fused, source, tail, keep_screen);
+}
+
+int xrt_hip_reflect_tail_f64_dev(const xrt_hip_geosource* source, const xrt_hip_pass* pass,
+                                 const xrt_hip_material* material, xrt_hip_beam* in,
+                                 const xrt_hip_beam* restore, xrt_hip_beam* out_local,
+                                 xrt_hip_beam* out_virgin, double* theta, const xrt_hip_tail* tail,
+                                 int keep_virgin, void* workspace, size_t workspace_bytes,
+                                 void* stream, int* fused) {
+  if (!tail) return fail(XRT_HIP_ERR_ARG, "NULL tail");
+  if (tail->n_apertures < 0 || tail->n_apertures > XRT_TAIL_APERTURES)
+    return fail(XRT_HIP_ERR_ARG, "a tail carries 0 to %d apertures", XRT_TAIL_APERTURES);
+  if (!pass || !pass->out_to_global)
+    return fail(XRT_HIP_ERR_ARG, "apertures and screens take the beam in the global frame "
+                                 "(out_to_global)");
+  xrt::TailApertures ap;
+  memset(&ap, 0, sizeof(ap));
+  ap.n = tail->n_apertures;
+  for (int k = 0; k < ap.n; ++k) {
+    if (tail->aperture[k].poly_n > 0)
+      return fail(XRT_HIP_ERR_ARG, "a polygonal aperture does not ride in a tail");
+    ap.a[k] = tail->aperture[k];
+  }
+  if (tail->plot && !tail->screen) return fail(XRT_HIP_ERR_ARG, "a plot shows a screen's image");
+  if (tail->screen && tail->screen->radius != 0. && !keep_virgin)
+    return fail(XRT_HIP_ERR_ARG, "a hemispheric screen takes the stored global beam "
+                                 "(keep_virgin = 1)");
+  int rc;
+  if (source) {
+    if ((rc = check_geosource(source))) return rc;
+    if (!pass->in_is_global || !source->to_global)
+      return fail(XRT_HIP_ERR_ARG, "source and element meet in the global frame");
+    restore = in;
+  }
+  return reflect_pass_impl(pass, material, in, restore, out_local, out_virgin, theta, workspace,
+                           workspace_bytes, stream, nullptr, nullptr, tail->screen,
+                           tail->out_screen, keep_virgin, fused, source, tail->plot,
+                           tail->keep_screen, &ap);
 }
 
 int xrt_hip_double_reflect_fusable(const xrt_hip_pass* pass1, const xrt_hip_material* material1,

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/xrt_hip.h"
+#include "screen.h"
 
 #define REFLECT_BLOCK 256
 // threads per block of the two big kernels (one ray per lane). Measured, three alternating
@@ -132,7 +133,7 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
                                int* fused = nullptr, const xrt_hip_geosource* src = nullptr,
                                const struct PlotTailPlan* plot = nullptr,
                                bool keep_screen = true,
-                               const struct TailApertures* ap = nullptr);
+                               const TailApertures* ap = nullptr);
 // would this pass carry a screen (and a plot) in its tail: one of the lean kernels, optimistic
 bool reflect_pass_carries_screen(const xrt_hip_pass& P, const xrt_hip_material& M,
                                  const xrt_hip_screen& S);

@@ -9,6 +9,7 @@
 
 #include "../../include/xrt_hip.h"
 #include "fp64_math.h"
+#include "screen.h"
 
 namespace xrt {
 
@@ -125,11 +126,6 @@ __device__ __forceinline__ ApertureRay aperture_ray(const xrt_hip_aperture& A, d
 
 // up to two apertures right behind an element, in the order the beam meets them: the state of
 // the outgoing (global) record after them -- what aperture.propagate(gb) leaves in gb.state
-#define XRT_TAIL_APERTURES 2
-struct TailApertures {
-  int n;
-  xrt_hip_aperture a[XRT_TAIL_APERTURES];
-};
 __device__ __forceinline__ int apertures_mark(const TailApertures& T, double x, double y, double z,
                                               double a, double b, double c, int st) {
 #pragma unroll
