@@ -1234,3 +1234,67 @@ def test_c_abi_tail_record():
     assert rc == 0 and fused == 1
     assert call(3, True, 1)[0] != 0 and b'0 to 2' in lib.xrt_hip_last_error()
     assert call(1, True, 1, polygon=True)[0] != 0 and b'polygon' in lib.xrt_hip_last_error()
+
+
+# ---- both faces of a plate in one pass -------------------------------------------------------
+@pytest.mark.parametrize('amplitudes', [False, True])
+@pytest.mark.parametrize('pitch', [1.1, np.pi / 2])
+def test_both_faces_of_a_plate_in_one_pass(amplitudes, pitch, monkeypatch):
+    """Plate.double_refract (refractive.py:171-235) as ONE kernel with the beam inside the
+    plate in registers (reflect_fused_plate2) against its two passes: the same bits in all
+    three beams, with rays dead on arrival, rays that miss the plate and rays lost in it; the
+    same when the exact sequence is forced."""
+    bl = raycing.BeamLine(azimuth=-0.1)
+    mat = rm.Material(('Si', 'O'), quantities=(1, 2), rho=2.2, kind='plate')
+    plate = roe.Plate(bl, 'w', center=[20000. * bl.sinAzimuth, 20000. * bl.cosAzimuth, 0.],
+                      pitch=pitch, material=mat, t=0.2, wedgeAngle=2e-3 if pitch < 1.5 else 0.,
+                      limPhysX=[-4., 5.], limPhysY=[-4., 4.])
+    rng = np.random.default_rng(5)
+    n = 100000
+    beam = rs.Beam(nrays=n, withAmplitudes=amplitudes)
+    beam.x[:], beam.z[:] = rng.normal(0, 2.5, n), rng.normal(0, 2.5, n)
+    beam.a[:], beam.c[:] = rng.normal(0, 1e-4, n), rng.normal(0, 1e-4, n)
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    for u, v in (('x', 'y'), ('a', 'b')):
+        pu, qv = raycing.rotate_z(getattr(beam, u).copy(), getattr(beam, v).copy(),
+                                  bl.cosAzimuth, -bl.sinAzimuth)
+        getattr(beam, u)[:], getattr(beam, v)[:] = pu, qv
+    beam.E[:] = rng.uniform(7000., 12000., n)
+    beam.state[::41] = -2
+    beam.state[7::43] = 2
+    if amplitudes:
+        ang = rng.uniform(0, np.pi, n)
+        beam.Es[:], beam.Ep[:] = np.cos(ang), np.sin(ang) * np.exp(1j * rng.uniform(-3, 3, n))
+        beam.Jss[:], beam.Jpp[:] = np.abs(beam.Es)**2, np.abs(beam.Ep)**2
+        beam.Jsp[:] = beam.Es * np.conj(beam.Ep)
+    roe.fuseConsumers = False
+    try:
+        monkeypatch.setenv('XRT_HIP_DCM_TWO_PASSES', '1')
+        g0, a0, b0 = plate.double_refract(rs.Beam(copyFrom=beam))
+        monkeypatch.delenv('XRT_HIP_DCM_TWO_PASSES')
+        # (the exit face asks for Brent's method: the first pass of a new plate learns that
+        # from being redone, the element remembers -- xrt_hip_pass.method_hint)
+        first, timing = {}, {}
+        g1, a1, b1 = plate.double_reflect(rs.Beam(copyFrom=beam), fromVacuum1=True,
+                                          fromVacuum2=False, _timing=first)
+        same(g1, g0, 'global, first call')
+        g1, a1, b1 = plate.double_reflect(rs.Beam(copyFrom=beam), fromVacuum1=True,
+                                          fromVacuum2=False, _timing=timing)
+        assert not timing['exact_sequence']
+        monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
+        g2, a2, b2 = plate.double_refract(rs.Beam(copyFrom=beam))
+        monkeypatch.delenv('XRT_HIP_REFLECT_EXACT')
+    finally:
+        roe.fuseConsumers = True
+    alive = int((g0.state == 1).sum())
+    assert 500 < alive < n - 500, alive
+    for tag, (g, a, b) in (('one pass', (g1, a1, b1)), ('exact', (g2, a2, b2))):
+        same(g, g0, 'global, ' + tag)
+        same(a, a0, 'front face, ' + tag, extra=('theta',))
+        same(b, b0, 'back face, ' + tag, extra=('theta',))
+    # without the local beams (the Balder chain's filter): the global beam alone
+    g3, a3, b3 = plate.double_refract(rs.Beam(copyFrom=beam))
+    assert type(a3) is rs.LazyBeam and not a3.__dict__['_filled']
+    same(g3, g0, 'global alone')
+    same(b3, b0, 'back face on demand', extra=('theta',))
+    same(a3, a0, 'front face on demand', extra=('theta',))

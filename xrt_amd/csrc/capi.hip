@@ -696,7 +696,8 @@ int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_mate
   if ((rc = check_pass(pass2, material2))) return rc;
   if (!xrt::reflect_dcm_fusable(*pass1, *material1, *pass2, *material2))
     return fail(XRT_HIP_ERR_ARG, "double_reflect: this pair of passes needs two "
-                                 "xrt_hip_reflect_pass_f64_dev calls (flat Bragg crystals only)");
+                                 "xrt_hip_reflect_pass_f64_dev calls (flat Bragg crystals or the faces of a "
+                                 "flat plate only)");
   if (!in) return fail(XRT_HIP_ERR_ARG, "NULL input beam");
   const int64_t n = in->n;
   if (n < 0) return fail(XRT_HIP_ERR_ARG, "negative ray count");

@@ -907,7 +907,13 @@ bool reflect_dcm_fusable(const xrt_hip_pass& P1, const xrt_hip_material& M1,
     return P.surf_kind == XRT_HIP_SURF_FLAT && !P.no_intersection_search && !P.grating;
   };
   if (P1.fe_c || P2.fe_c) return false;     // a figure error: two passes of the Figured kernels
-  return bragg(M1) && bragg(M2) && flat(P1) && flat(P2) && (M1.thick != 0) == (M2.thick != 0) &&
+  // the two faces of a flat plate (Plate.double_refract): what the lean plate kernel takes
+  auto face = [](const xrt_hip_pass& P, const xrt_hip_material& M) {
+    return M.kind == XRT_HIP_MAT_PLATE && M.n_fixed != 2 && !P.asymmetric && !P.g_ray_x;
+  };
+  const bool pair = (bragg(M1) && bragg(M2) && (M1.thick != 0) == (M2.thick != 0)) ||
+                    (face(P1, M1) && face(P2, M2));
+  return pair && flat(P1) && flat(P2) &&
          !P1.out_to_global && !P2.in_is_global && !P1.only_state1_out && !P2.only_state1_out;
 }
 
@@ -951,8 +957,10 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
     hipLaunchKernelGGL(reflect_decide_dcm, dim3(1), block, 0, st, P1, M1, P2, M2, in, L.part1,
                        L.part2, L.g1, L.g2);
     if (evk0) (void)hipEventRecord(evk0, st);
-    const int spec = M1.thick ? SP_THICK_FLAT : SP_FLAT_XTAL;
-    if (!(tu_hot_dcm(spec, DL) || tu_xtal_dcm(spec, DL))) return hipErrorInvalidDeviceFunction;
+    const int spec = M1.kind == XRT_HIP_MAT_PLATE ? SP_FLAT_PLATE
+                                                  : (M1.thick ? SP_THICK_FLAT : SP_FLAT_XTAL);
+    if (!(tu_hot_dcm(spec, DL) || tu_xtal_dcm(spec, DL) || tu_hot_plate2(spec, DL)))
+      return hipErrorInvalidDeviceFunction;
     if (evk1) (void)hipEventRecord(evk1, st);
   }
   DcmLaunch XD = DL;

@@ -176,6 +176,12 @@ inline void launch_dcm_k(const DcmLaunch& L) {
                      &L.g1->any_neg, &L.g2->any_neg, L.opt1, L.opt2);
 }
 
+template <class K>
+inline void launch_plate2_k(const DcmLaunch& L) {
+  hipLaunchKernelGGL(reflect_fused_plate2<K>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2, *L.M2,
+                     *L.in, *L.lo1, *L.lo2, *L.gb2, L.theta1, L.theta2, L.g1, L.g2, L.opt1, L.opt2);
+}
+
 // the units (each returns false for a spec it does not hold)
 bool tu_hot_fused(int spec, int mode, const FusedLaunch& L);        // reflect_hot.hip
 bool tu_hot_fused_scr(int spec, int mode, const FusedLaunch& L);    // reflect_hot_scr.hip
@@ -184,6 +190,7 @@ bool tu_hot_fused_scr_plot(int spec, int mode, const FusedLaunch& L);      // re
 bool tu_hot_fused_gen_scr_plot(int spec, const FusedLaunch& L);
 bool tu_hot_xtal(int spec, int mode, const FusedLaunch& L);
 bool tu_hot_dcm(int spec, const DcmLaunch& L);
+bool tu_hot_plate2(int spec, const DcmLaunch& L);                   // reflect_hot_plate2.hip
 bool tu_xtal_xtal(int spec, int mode, const FusedLaunch& L);        // reflect_xtal.hip
 bool tu_xtal_dcm(int spec, const DcmLaunch& L);
 bool tu_generic_fused(int spec, int mode, const FusedLaunch& L);    // reflect_generic.hip
