@@ -4447,6 +4447,21 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_plate2(
   v.c = r_in.c;
   v.f = req.q;
   v.st = st0;
+  // the refractive index at this ray's energy: one look-up for both faces (the same material
+  // on both sides of the same plate), in flight during the first root solve
+#ifdef XRT_PLATE2_NO_NPRE
+  const bool one_n = false;
+#else
+  bool one_n = M1.nelem == M2.nelem && M1.rho == M2.rho && M1.mass == M2.mass &&
+               M1.n_fixed == M2.n_fixed && M1.n_re == M2.n_re && M1.n_im == M2.n_im;
+  for (int e = 0; e < M1.nelem && one_n; ++e)
+    one_n = M2.tab_E[e] == M1.tab_E[e] && M2.tab_f1[e] == M1.tab_f1[e] &&
+            M2.tab_f2[e] == M1.tab_f2[e] && M2.tab_n[e] == M1.tab_n[e] &&
+            M2.Z[e] == M1.Z[e] && M2.quantity[e] == M1.quantity[e];
+#endif
+  cplx n_plate = C(1., 0.);
+  if (one_n && live) n_plate = refractive_index(M1, req.q.E, window_of(*g1p));
+  const cplx* npre = one_n ? &n_plate : nullptr;
   // ---- front face ----
   {
     const GStat g = *g1p;
@@ -4466,7 +4481,7 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_plate2(
       int st = rays_good<K>(P1, h.x, h.y);
       if (h.lost) st = P1.lost_num;
       const Completed c1 = complete_ray<K, true, true>(P1, M1, g, in, in, lo1, lo1, theta1, i, r,
-                                                       h, st, has_amp, 0, nullptr, req.q);
+                                                       h, st, has_amp, 0, nullptr, req.q, npre);
       if (c1.kept)
         v = c1.v;
       else
@@ -4505,7 +4520,7 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_plate2(
       int st = rays_good<K>(P2, h.x, h.y);
       if (h.lost) st = P2.lost_num;
       complete_ray<K, true>(P2, M2, g, in, in, lo2, gb2, theta2, i, r, h, st, has_amp, 0, nullptr,
-                            v.f);
+                            v.f, npre);
     } else if (live) {
       // (as the DCM: the local record of a ray that never reached the face is zeroed, the
       // global beam gets the ORIGINAL ray back)
