@@ -1090,6 +1090,25 @@ def bench_balder(nrays, runs=5, both=True):
     sec = (time.perf_counter() - t0) / runs
     arrived = float((image.state_count(1) if hasattr(image, 'state_count')
                      else (image.state == 1).sum()) / nrays)
+    # how many launches a pass of the chain is: the chain recorded into a HIP graph, its nodes
+    # counted (hipGraphGetNodes)
+    launches = None
+    try:
+        from xrt_amd import graphs
+        spare = rs.Beam(copyFrom=beam)
+        workloads.balder_trace(optics, rs.Beam(copyFrom=beam))
+        torch.cuda.synchronize()
+
+        def one_pass():
+            img = workloads.balder_trace(optics, spare)
+            rs.flush_pending()
+            return img
+        rec = graphs.IterationGraph(one_pass, keep_graph=True)
+        launches = rec.kernel_nodes()
+        rec.close()
+        del rec, spare
+    except Exception as e:      # noqa: BLE001  (the count is a report, not the measurement)
+        launches = 'not counted: %s' % e
     # ... and with every beam of every element written, looked at or not (rounds 1-4)
     from xrt_amd.backends.raycing import oes as roe
     roe.fuseConsumers = not both
@@ -1107,6 +1126,10 @@ def bench_balder(nrays, runs=5, both=True):
     del fresh
     return {'metric': 'Balder example beamline, mask -> sample, seconds per pass of the beam',
             'rays': nrays, 'seconds': sec, 'seconds_every_beam_written': sec_all,
+            'launches_per_pass': launches,
+            'in_one_pass': 'both faces of the filter are one kernel (reflect_fused_plate2), both '
+                           'crystals are one kernel, the two slits behind the focusing mirror and '
+                           'the sample screen ride in the tail of its pass (round 6)',
             'on_demand': 'the chain hands the global beam from element to element and shows the '
                          'two screens: the local beams of the mirrors and of the filter (308 -> '
                          '200 B per ray and surface), of the two crystals (416 -> 200 B per '

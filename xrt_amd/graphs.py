@@ -59,11 +59,13 @@ class IterationGraph(object):
     steady-state iteration looks like). The objects *fn* returned while recording are kept:
     their device arrays are what every replay overwrites."""
 
-    def __init__(self, fn):
+    def __init__(self, fn, keep_graph=False):
         self.after_replay = []
         self.before_end = []         # recorded after fn(): the last nodes of the graph
         self.pending_calls = {}      # source -> shine() calls recorded so far
-        self.graph = torch.cuda.CUDAGraph()
+        # (keep_graph: the hipGraph_t stays reachable -- kernel_nodes() counts its launches)
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else \
+            torch.cuda.CUDAGraph()
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         _tls.recording = self
@@ -87,6 +89,20 @@ class IterationGraph(object):
             if collects:
                 gc.enable()
         self.replays = 0
+
+    def kernel_nodes(self):
+        """How many launches one iteration is (hipGraphGetNodes on the recorded graph: kernel,
+        memcpy and memset nodes alike); needs ``keep_graph=True``."""
+        import ctypes
+        hip = ctypes.CDLL('libamdhip64.so')
+        hip.hipGraphGetNodes.argtypes = [ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.POINTER(ctypes.c_size_t)]
+        count = ctypes.c_size_t(0)
+        err = hip.hipGraphGetNodes(ctypes.c_void_p(self.graph.raw_cuda_graph()), None,
+                                   ctypes.byref(count))
+        if err:
+            raise RuntimeError('hipGraphGetNodes: error %d' % err)
+        return int(count.value)
 
     def close(self):
         """Drops the graph, the recorded beams and the hooks (which refer back to this object:
