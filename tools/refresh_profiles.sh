@@ -53,6 +53,11 @@ for env in "" "XRT_HIP_HIST_NO_SMALL=1" "XRT_HIP_NO_FUSE=1"; do echo "== [$env]"
 # the kernels of the Balder chain (bench.py balder leg) in launch order, one pass of the beam
 ( cd /tmp && rm -rf /tmp/pb && rocprofv3 --kernel-trace --stats -d /tmp/pb -o pb -- python $GRAFT_REPO_ROOT/tools/probe_balder.py > /tmp/pb.log 2>&1 )
 { grep '^{' /tmp/pb.log | cut -c1-400; python tools/prof_sequence.py /tmp/pb 30; } > profiles/r${RND}_balder_kernels.txt 2>&1
+# round 6: the Balder chain's fused pieces against their separate launches -- the focusing mirror
+# with its two slits and the sample screen in the tail of its pass; both faces of the filter in one kernel
+{ python tools/probe_tail_apertures.py; python tools/probe_plate2.py; \
+  XRT_HIP_DCM_TWO_PASSES=1 python tools/probe_plate2.py | sed 's/\[\]/[two passes]/'; } 2>&1 \
+  | grep -v amdgpu.ids > profiles/r${RND}_balder_tails.txt
 # round 6: the plot in the tail of the pass -- HBM bytes of an e2e iteration either way
 # (profiles/plot_tail_traffic.json, read by bench.py), ms per iteration with focused / wide plot limits
 bash tools/pmc_plot_tail.sh > profiles/r${RND}_plot_tail_pmc.txt 2>&1
