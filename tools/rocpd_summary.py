@@ -22,6 +22,8 @@ import sqlite3
 import sys
 
 OURS = ('reflect_fused_gen_scr_plot', 'reflect_fused_scr_plot', 'plot_tail_tiles',
+        'reflect_fused_plate2', 'reflect_redo_scr', 'reflect_multi_opt', 'multi_decide_opt',
+        'reflect_multi_stats', 'reflect_multi_solve', 'reflect_multi_finish',
         'reflect_fused_gen_scr', 'reflect_fused_scr', 'reflect_decide_opt_gen',
         'reflect_redo_verdict', 'geosource_shine_if_kernel', 'screen_expose_if_kernel',
         'reflect_multi', 'multi_to_global_kernel', 'plot_hist_small', 'reflect_fused_xtal', 'reflect_fused_dcm', 'reflect_dcm_exact', 'reflect_decide_dcm',
