@@ -1082,7 +1082,7 @@ def bench_balder(nrays, runs=5, both=True):
     optics = workloads.balder_optics()
     # three blocks of *runs* passes, the best block counts (one block of the round-6 profile run
     # held an 85-ms stall of the profiler's: all blocks are reported)
-    blocks = []
+    blocks, reserved = [], [torch.cuda.memory_reserved() / 1e9]
     for _ in range(3):
         fresh = [rs.Beam(copyFrom=beam) for _ in range(runs + 1)]    # the chain marks its input
         image = workloads.balder_trace(optics, fresh[0])
@@ -1092,6 +1092,7 @@ def bench_balder(nrays, runs=5, both=True):
             image = workloads.balder_trace(optics, fresh[k + 1])
         torch.cuda.synchronize()
         blocks.append((time.perf_counter() - t0) / runs)
+        reserved.append(torch.cuda.memory_reserved() / 1e9)
     sec = min(blocks)
     arrived = float((image.state_count(1) if hasattr(image, 'state_count')
                      else (image.state == 1).sum()) / nrays)
@@ -1131,7 +1132,8 @@ def bench_balder(nrays, runs=5, both=True):
     del fresh
     return {'metric': 'Balder example beamline, mask -> sample, seconds per pass of the beam',
             'rays': nrays, 'seconds': sec, 'seconds_every_beam_written': sec_all,
-            'seconds_by_block': blocks, 'launches_per_pass': launches,
+            'seconds_by_block': blocks, 'reserved_gb_before_and_after_each_block': reserved,
+            'launches_per_pass': launches,
             'in_one_pass': 'both faces of the filter are one kernel (reflect_fused_plate2), both '
                            'crystals are one kernel, the two slits behind the focusing mirror and '
                            'the sample screen ride in the tail of its pass (round 6)',

@@ -1,5 +1,9 @@
+"""Fills DESIGN.md section 0 / 0.1 (tools/design_section0.template.md) with the numbers of the committed
+round-6 profiles, so that the document cannot drift from them (tests/test_docs_match_profiles.py)."""
 import csv, json, re
-R='/root/repo/profiles/'
+import os
+HERE=os.path.dirname(os.path.abspath(__file__))
+R=os.path.join(HERE,'..','profiles')+'/'
 rows=list(csv.reader(open(R+'r06_kernel_stats.csv')))[1:]
 def find(pred):
     return [r for r in rows if pred(r)]
@@ -76,12 +80,12 @@ c5=u5.get('graph_choice') or {}; c6=u6.get('graph_choice') or {}
 v['SMALL_TEXT']=('Measured over 1000 / 500 iterations in the unprofiled run (the recording, ~6 ms, and the 44 iterations of the contest are then the small part they are in a real run): 1e5 rays eager %.3f ms (asked <= 0.125: %s), `graph=True` %.3f ms per iteration of the whole run, the replays themselves %.3f ms (asked <= 0.085: not met), speedup %.2f; 1e6 rays: the contest finds replay %.3f against eager %.3f ms, %s, and the `graph=True` run costs %.3f against %.3f ms eager = %.2f: what is left of "no size below 1.0" is the price of having tried.' % (
     u5['eager_ms_per_iteration'], 'met' if u5['eager_ms_per_iteration']<=0.125 else 'not met on this box', u5['graph_ms_per_iteration'], c5.get('replay_ms', float('nan')), u5['speedup'],
     c6.get('replay_ms', float('nan')), c6.get('eager_ms', float('nan')), 'replays' if c6.get('replaying') else 'keeps the eager loop (not 3 % better)', u6['graph_ms_per_iteration'], u6['eager_ms_per_iteration'], u6['speedup']))
-txt=open('/tmp/design_new0.md').read()
+txt=open(os.path.join(HERE,'design_section0.template.md')).read()
 for k,val in v.items():
     txt=txt.replace('{'+k+'}', str(val))
 left=re.findall(r'\{[A-Z0-9_]+\}', txt)
 print('unfilled', left)
-p='/root/repo/DESIGN.md'
+p=os.path.join(HERE,'..','DESIGN.md')
 s=open(p).read()
 a=s.index('## 0. Where it stands')
 bb=s.index('## 1. Scope (SURVEY §8 rows → where they live)')
