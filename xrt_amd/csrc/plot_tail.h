@@ -152,6 +152,9 @@ __device__ __forceinline__ PlotStash plot_tail_take(const PlotTail& Q, double x,
   s.word = 0;
   s.tile = Q.T;
   s.st = st;
+#ifdef TAIL_AB_NO_TAKE                 /* A/B: no weight, no bins (wrong plots) */
+  return s;
+#endif
   if (!ray_selected(st, Q.P.ray_flags)) return s;
   double w;
   if (Q.P.flux_kind == 1)
@@ -209,12 +212,19 @@ __device__ __forceinline__ unsigned wave_prefix_sum(unsigned v) {
 // All 64 lanes of the wave, converged; lane l holds the record of ray 64 * chunk + l (st 0: none).
 __device__ __forceinline__ void plot_tail_emit(const PlotTail& Q, int64_t chunk, const PlotStash& s) {
   if (chunk >= Q.chunks) return;       // (the last block's waves beyond the end of the beam)
+#ifdef TAIL_AB_NO_EMIT                 /* A/B (tools/ab_tail_pass.sh): what the wave's sort and stores cost */
+  return;
+#endif
   const int lane = (int)__lane_id();
   const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
   // rank of every ray within its bucket; lane t: how many rays bucket t has
   int rank = 0;
   unsigned here = 0;
   unsigned long long rem = ~0ull;
+#ifdef TAIL_AB_NO_SORT                 /* A/B: the records unsorted (wrong plots, the stores' cost alone) */
+  rem = 0;
+  rank = lane;
+#endif
   while (rem) {
     const int first = __builtin_ctzll(rem);
     const int t = __builtin_amdgcn_readlane(s.tile, first);
