@@ -959,6 +959,20 @@ XRT_HIP_API int xrt_hip_reflect_tail_f64_dev(
     xrt_hip_beam* out_local, xrt_hip_beam* out_virgin, double* theta, const xrt_hip_tail* tail,
     int keep_virgin, void* workspace, size_t workspace_bytes, void* stream, int* fused);
 
+/* ... and behind a DCM (round 6): xrt_hip_double_reflect_f64_dev with the apertures and the flat
+ * screen that follow the monochromator directly in the tail of its fused kernel (dcm.py:248-354 ->
+ * apertures.py:334-413 -> screens.py:226-302). tail->plot must be NULL. keep_global = 0 (with a
+ * screen): out_global is scratch, written only if the pass has to be redone. The pair of plate
+ * faces and a forced exact sequence are followed by the apertures' and the screen's own launches
+ * inside the call (*fused: bit 0 screen, bit 3 apertures in the tail). */
+XRT_HIP_API int xrt_hip_double_reflect_tail_f64_dev(
+    const xrt_hip_pass* pass1, const xrt_hip_material* material1, const xrt_hip_pass* pass2,
+    const xrt_hip_material* material2, const xrt_hip_beam* in, xrt_hip_beam* out_local1,
+    xrt_hip_beam* out_local2, xrt_hip_beam* out_global, double* theta1, double* theta2,
+    const xrt_hip_tail* tail, int keep_global, void* workspace, size_t workspace_bytes,
+    void* stream, int* fused);
+
+
 
 
 /* ---- undulator field integral -------------------------

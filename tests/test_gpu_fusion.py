@@ -1298,3 +1298,125 @@ def test_both_faces_of_a_plate_in_one_pass(amplitudes, pitch, monkeypatch):
     same(g3, g0, 'global alone')
     same(b3, b0, 'back face on demand', extra=('theta',))
     same(a3, a0, 'front face on demand', extra=('theta',))
+
+
+# ---- apertures and a screen in the tail of the DCM -------------------------------------------
+def _dcm_scene(n, amplitudes, odd_ray=False):
+    bl = raycing.BeamLine()
+    dcm = workloads.cfg3_dcm(bl)
+    beam = workloads.synthetic_rays(n, 11, sa=1e-4, E=(8995., 9005.), amplitudes=amplitudes)
+    beam.state[::37] = -2
+    beam.x[::29] *= 400.
+    if odd_ray:          # its largest direction cosine is not the head ray's: the pass is redone
+        beam.a[778] = 0.9
+        beam.b[778] = np.sqrt(1 - beam.a[778]**2 - beam.c[778]**2)
+    roe.fuseConsumers = False
+    try:
+        g0 = dcm.double_reflect(rs.Beam(copyFrom=beam))[0]
+    finally:
+        roe.fuseConsumers = True
+    ok = g0.state == 1
+    pos = np.array([g0.x[ok].mean(), g0.y[ok].mean(), g0.z[ok].mean()])
+    way = np.array([g0.a[ok].mean(), g0.b[ok].mean(), g0.c[ok].mean()])
+    slit = ra.RectangularAperture(bl, 'slit', list(pos + 1000. * way), ('left', 'top'), [0., 0.05])
+    scr = rsc.Screen(bl, 'after', center=list(pos + 2000. * way))
+    return dcm, beam, slit, scr
+
+
+def _eager_dcm_chain(dcm, aps, scr, beam):
+    old = roe.fuseConsumers
+    roe.fuseConsumers = False
+    try:
+        g, a, b = dcm.double_reflect(rs.Beam(copyFrom=beam))
+        locs = [s.propagate(g) for s in aps]
+        img = scr.expose(g) if scr is not None else None
+    finally:
+        roe.fuseConsumers = old
+    return g, a, b, locs, img
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+@pytest.mark.parametrize('what', ['screen', 'slit + screen', 'slit'])
+def test_apertures_and_a_screen_in_the_tail_of_the_dcm(amplitudes, what):
+    """DCM.double_reflect is handed out before it is launched too (oes._DeferredDouble): a slit and
+    a screen that take its global beam ride in the tail of the pair's kernel
+    (reflect_fused_dcm_scr; reference: dcm.py:248-354 -> apertures.py:334-413 ->
+    screens.py:226-302). Every beam has the bits of the separate launches."""
+    dcm, beam, slit, scr = _dcm_scene(80000, amplitudes)
+    aps = [slit] if 'slit' in what else []
+    scr = scr if 'screen' in what else None
+    g0, a0, b0, locs0, img0 = _eager_dcm_chain(dcm, aps, scr, beam)
+    if aps:
+        assert 1000 < (g0.state == slit.lostNum).sum() < 70000
+    _forget(dcm, slit, *([scr] if scr else []))
+    g, a, b = dcm.double_reflect(rs.Beam(copyFrom=beam))
+    op = g.__dict__['_op']
+    assert type(op) is roe._DeferredDouble and op.state == 'pending'
+    locs = [s.propagate(g) for s in aps]
+    assert op.state == 'pending' and len(op.apertures) == len(aps)
+    if scr is not None:
+        img = scr.expose(g)
+        assert op.state == 'pending'
+        same(img, img0, 'image')
+        assert op.state == 'imaged' and not g.__dict__['_filled']
+    same(g, g0, 'global')
+    same(b, b0, 'second crystal', extra=('theta',))
+    same(a, a0, 'first crystal', extra=('theta',))
+    for s, l, l0 in zip(aps, locs, locs0):
+        same(l, l0, 'beam at the slit')
+    assert op.state == 'done' and op.beam is None
+
+
+def test_a_contradicted_or_forced_dcm_pass_with_its_tail(monkeypatch):
+    dcm, beam, slit, scr = _dcm_scene(60000, True, odd_ray=True)
+    g0, a0, b0, locs0, img0 = _eager_dcm_chain(dcm, [slit], scr, beam)
+    t = {}
+    dcm.double_reflect(rs.Beam(copyFrom=beam), _timing=t)
+    assert t['exact_sequence']
+    for forced in (False, True):
+        _forget(dcm, slit, scr)
+        if forced:
+            monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
+        g, a, b = dcm.double_reflect(rs.Beam(copyFrom=beam))
+        loc = slit.propagate(g)
+        img = scr.expose(g)
+        same(img, img0, 'image %d' % forced)
+        same(g, g0, 'global %d' % forced)
+        same(loc, locs0[0], 'beam at the slit %d' % forced)
+        same(a, a0, 'first crystal %d' % forced, extra=('theta',))
+        same(b, b0, 'second crystal %d' % forced, extra=('theta',))
+
+
+def test_c_abi_double_reflect_tail():
+    import ctypes
+    from xrt_amd import _lib, _structs, hipcalls
+    dcm, beam, slit, scr = _dcm_scene(30000, False)
+    g0, a0, b0, locs0, img0 = _eager_dcm_chain(dcm, [slit], scr, beam)
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    first, second = dcm._own_angles(False), dcm._own_angles(True)
+    p1 = dcm._make_pass(*first[:4], fromVacuum=True, out_to_global=False)
+    p2 = dcm._make_pass(*second, fromVacuum=True, is2ndXtal=True, in_is_global=False, good_mode=1,
+                        out_to_global=True, zero_local_not_entering=True, force_lost_out=False)
+    m1 = dcm._material_struct(dcm.material, True, dev)
+    m2 = dcm._material_struct(dcm.material2, True, dev)
+    ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(beam.nrays), 'reflect')
+    s_in = beam.to_struct(dev)
+    srec, arec = scr._record(False), slit._record()
+    gb, img = (rs.Beam.empty_like_on_device(beam, dev) for _ in range(2))
+    tail = _structs.Tail()
+    tail.n_apertures, tail.keep_screen = 1, 1
+    tail.aperture[0] = arec
+    tail.screen, tail.out_screen = ctypes.addressof(srec), ctypes.addressof(img.to_struct(dev))
+    fused = ctypes.c_int(-1)
+    args = (ctypes.byref(p1), ctypes.byref(m1), ctypes.byref(p2), ctypes.byref(m2),
+            ctypes.byref(s_in), None, None, ctypes.byref(gb.to_struct(dev)), None, None)
+    rest = (1, ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(fused))
+    _lib.check(lib.xrt_hip_double_reflect_tail_f64_dev(*args, ctypes.byref(tail), *rest), 'tail')
+    assert fused.value == 9
+    same(img, img0, 'image')
+    same(gb, g0, 'global')
+    tail.plot = 1
+    assert lib.xrt_hip_double_reflect_tail_f64_dev(*args, ctypes.byref(tail), *rest) != 0
+    assert b'plot' in lib.xrt_hip_last_error()

@@ -53,6 +53,9 @@ SIGNATURES = {
         ctypes.c_size_t, vp, c_int_p]),
     'xrt_hip_reflect_tail_f64_dev': (ctypes.c_int, [
         vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_size_t, vp, c_int_p]),
+    'xrt_hip_double_reflect_tail_f64_dev': (ctypes.c_int, [
+        vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_size_t, vp,
+        c_int_p]),
     'xrt_hip_bounce_workspace_bytes': (ctypes.c_size_t, [i64]),
     'xrt_hip_reflect_bounce_f64_dev': (ctypes.c_int, [
         vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, ctypes.POINTER(ctypes.c_int64),

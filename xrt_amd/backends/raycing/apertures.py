@@ -137,7 +137,7 @@ class RectangularAperture(object):
         dev = torch.device('cuda', torch.cuda.current_device())
         from . import oes as roe
         op = beam.__dict__.get('_op') if type(beam) is rs.LazyBeam else None
-        if type(op) is roe._DeferredReflect and op.gb is beam and roe.fuseConsumers and \
+        if isinstance(op, roe._DeferredReflect) and op.gb is beam and roe.fuseConsumers and \
                 not needNewGlobal and op.takes_aperture(self):
             # the element's pass has not been launched: the marks are made in its tail
             return op.marks_later(self)

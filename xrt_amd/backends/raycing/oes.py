@@ -1111,6 +1111,128 @@ class _DeferredReflect(rs.SharesStates, rs.FillsBeams):
         return self._launch_with_screen(plot=tail)
 
 
+class _DeferredDouble(_DeferredReflect):
+    """DCM.double_reflect / Plate.double_refract not launched yet (pairs the fused kernels take,
+    local beams on demand): the global beam and the beams on the two surfaces are handed out
+    first; what the script does next decides the launch, as for OE.reflect -- apertures and a
+    flat screen that take the global beam ride in the tail of the pair's kernel
+    (xrt_hip_double_reflect_tail_f64_dev; reference: dcm.py:248-354 -> apertures.py:334-413 ->
+    screens.py:226-302). States: pending -> global / imaged (the local beams, and with a screen
+    the global beam, left out) -> done (on demand, by the pair's pass again)."""
+
+    def __init__(self, oe, p1, p2, from_vacuum, beam):
+        dev = _device()
+        beam.to_struct(dev)                          # everything up in HBM now
+        self.src_op = None
+        self.beam, self.tensors = _as_it_is(beam)
+        self.oe, self.p1, self.p2, self.from_vacuum = oe, p1, p2, from_vacuum
+        self.p, self.out = p2, None                  # (what a screen / an aperture looks at)
+        self.materials = (oe.material, oe.material2)
+        self.n = self.beam.nrays
+        self.screen = self.screen_rec = None
+        self.apertures = []
+        self.state = 'pending'
+        oe._adopt((self._make('gb'), self._make('lo1'), self._make('lo2')), beam)
+        rs._PENDING.add(self)
+
+    lo1 = property(lambda self: self._beam('lo1'))
+    lo2 = property(lambda self: self._beam('lo2'))
+
+    def plot_on(self, tail):
+        return False                 # (a plot of the image: its own launches)
+
+    def _all_filled(self):
+        f = rs.filled
+        return f(self.gb) and f(self.lo1) and f(self.lo2) and f(self.image) and \
+            self._aperture_locals_filled()
+
+    def _pair(self, rays, local, tail=False, keep=True):
+        """The pair's pass on *rays* -> (gb, lo1, lo2, image, fused); *tail*: with the apertures
+        and the screen that wait."""
+        oe = self.oe
+        return oe._run_double_tail(
+            self.p1, self.p2, self.materials, self.from_vacuum, rays, local,
+            self.screen_rec if tail else None,
+            [rec for _, rec in self.apertures] if tail else (), keep)
+
+    def _finish(self):
+        if self._all_filled():
+            rs._PENDING.discard(self)
+            self.state = 'done'
+            self.beam, self.tensors = None, ()
+
+    def materialize(self, which=None):
+        filled = rs.filled
+        if which is not None and which.startswith('ap'):
+            return self._aperture_local(int(which[2:]))
+        oe = self.oe
+        if self.state == 'pending':
+            rs._PENDING.discard(self)
+            screened = self.screen_rec is not None
+            keep = bool(oe.__dict__.get('_global_beam_wanted')) or not screened
+            local = which in ('lo1', 'lo2')
+            gb, lo1, lo2, image, fused = self._pair(self.beam, local, tail=True, keep=keep)
+            if local:
+                rs.adopt_into(self.lo1, lo1)
+                rs.adopt_into(self.lo2, lo2)
+            if fused and not keep:
+                self._scratch = gb            # (the redo's scratch: freed with this record)
+            else:
+                rs.adopt_into(self.gb, gb)
+            if screened:
+                rs.adopt_into(self.image, image)
+            if self._all_filled():
+                self.state = 'done'
+                self.beam, self.tensors = None, ()
+                return
+            self.state = 'imaged' if screened else 'global'
+            self._waits_with_its_own_states()
+            if which is None or which == 'image' or \
+                    filled({'gb': self.gb, 'lo1': self.lo1, 'lo2': self.lo2}.get(which)):
+                return
+        if self.state in ('global', 'imaged'):
+            # somebody wants a beam that was left out after all: the pair's pass again -- and the
+            # element remembers: next time it writes that beam at once
+            want_local = which in (None, 'lo1', 'lo2') and not (filled(self.lo1) and filled(self.lo2))
+            want_gb = which in (None, 'gb') and not filled(self.gb)
+            if which in ('lo1', 'lo2'):
+                oe.__dict__['_local_beams_wanted'] = True
+            if which == 'gb':
+                oe.__dict__['_global_beam_wanted'] = True
+            if which is not None and (want_local or want_gb):
+                gb, lo1, lo2, _, _ = self._pair(self.beam, want_local)
+                if want_local:
+                    rs.adopt_into(self.lo1, lo1)
+                    rs.adopt_into(self.lo2, lo2)
+                if not filled(self.gb):
+                    self._mark(gb)
+                    rs.adopt_into(self.gb, gb)
+            self._finish()
+
+    def _aperture_local(self, k):
+        if self.state == 'pending':
+            self.materialize('gb')
+        target = self._beam('ap%d' % k)
+        if rs.filled(target):
+            return
+        aperture, rec = self.apertures[k]
+        aperture.__dict__['_local_beam_wanted'] = True
+        gb = self._pair(self.beam, False)[0]
+        dev = _device()
+        lib = _lib.load()
+        for _, before in self.apertures[:k]:
+            _lib.check(lib.xrt_hip_aperture_propagate_f64_dev(
+                ctypes.byref(before), ctypes.byref(gb.to_struct(dev)), None, None, _stream()),
+                'xrt_hip_aperture_propagate_f64_dev')
+        local = rs.Beam.empty_like_on_device(gb, dev)
+        _lib.check(lib.xrt_hip_aperture_propagate_f64_dev(
+            ctypes.byref(rec), ctypes.byref(gb.to_struct(dev)),
+            ctypes.byref(local.to_struct(dev)), None, _stream()),
+            'xrt_hip_aperture_propagate_f64_dev')
+        rs.adopt_into(target, local)
+        self._finish()
+
+
 def _scratch_beam(role, n, dev, amplitudes):
     """A beam-sized scratch that a fused pass writes only if it has to be redone, kept from call
     to call per (thread, stream) for the beams of the size the host bounds (three allocations
@@ -2240,10 +2362,78 @@ class DCM(OE):
             return gb2, lo1, lo2
         if out is None and _timing is None and \
                 _locals_on_demand(self, self.material, self.material2):
+            if os.environ.get('XRT_HIP_DCM_TWO_PASSES', '') != '1' and \
+                    self._pair_is_fusable(p1, p2, fromVacuum1, fromVacuum2):
+                # nothing is launched yet: apertures and a screen that take the global beam
+                # ride in the tail of the pair's kernel (_DeferredDouble)
+                return _DeferredDouble(self, p1, p2, (fromVacuum1, fromVacuum2),
+                                       beam).hand_out(always_tuple=True)
             # the global beam now, the beams on the two surfaces when somebody looks at them
             later = _LocalsOnDemand(self, beam, 2, lambda was: both(was)[1:])
             return (both(beam, local=False)[0],) + later.hand_out(always_tuple=True)
         return both(beam)
+
+    def _pair_is_fusable(self, p1, p2, fromVacuum1, fromVacuum2):
+        _lib.require_gpu()
+        dev = _device()
+        m1 = self._material_struct(self.material, fromVacuum1, dev)
+        m2 = self._material_struct(self.material2, fromVacuum2, dev)
+        return bool(_lib.load().xrt_hip_double_reflect_fusable(
+            ctypes.byref(p1), ctypes.byref(m1), ctypes.byref(p2), ctypes.byref(m2)))
+
+    def _run_double_tail(self, p1, p2, materials, from_vacuum, beam, local, screen_rec, apertures,
+                         keep_global):
+        """The pair's fused pass, optionally with apertures and a screen in its tail
+        (xrt_hip_double_reflect_tail_f64_dev) -> (gb2, lo1, lo2, image, fused): fused = the
+        kernel carried the screen; with *keep_global* False gb2 then holds nothing."""
+        lib = _lib.load()
+        dev = _device()
+        m1 = self._material_struct(materials[0], from_vacuum[0], dev)
+        m2 = self._material_struct(materials[1], from_vacuum[1], dev)
+        n, amp = beam.nrays, beam.has_amplitudes()
+        screened = screen_rec is not None
+        keep_global = keep_global or not screened
+        gb2 = rs.Beam.empty_on_device(n, dev, amp) if keep_global else \
+            _scratch_beam('global', n, dev, amp)
+        image = rs.Beam.empty_on_device(n, dev, amp) if screened else None
+        lo1 = lo2 = None
+        angles = (None, None)
+        if local:
+            lo1, lo2 = (rs.Beam.empty_on_device(n, dev, amp) for _ in range(2))
+            angles = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
+        ws = hipcalls.workspace(dev, lib.xrt_hip_reflect_workspace_bytes(n), 'reflect')
+        common = (ctypes.byref(p1), ctypes.byref(m1), ctypes.byref(p2), ctypes.byref(m2),
+                  ctypes.byref(beam.to_struct(dev)),
+                  ctypes.byref(lo1.to_struct(dev)) if local else None,
+                  ctypes.byref(lo2.to_struct(dev)) if local else None,
+                  ctypes.byref(gb2.to_struct(dev)),
+                  ctypes.c_void_p(angles[0].data_ptr()) if local else None,
+                  ctypes.c_void_p(angles[1].data_ptr()) if local else None)
+        fused = ctypes.c_int(0)
+        if screened or apertures:
+            tail = _structs.Tail()
+            tail.n_apertures, tail.keep_screen = len(apertures), 1
+            for k, rec in enumerate(apertures):
+                tail.aperture[k] = rec
+            if screened:
+                tail.screen = ctypes.addressof(screen_rec)
+                tail.out_screen = ctypes.addressof(image.to_struct(dev))
+            _lib.check(lib.xrt_hip_double_reflect_tail_f64_dev(
+                *common, ctypes.byref(tail), int(keep_global), ctypes.c_void_p(ws.data_ptr()),
+                ws.numel(), _stream(), ctypes.byref(fused)),
+                'xrt_hip_double_reflect_tail_f64_dev')
+        else:
+            _lib.check(lib.xrt_hip_double_reflect_f64_dev(
+                *common, ctypes.c_void_p(ws.data_ptr()), ws.numel(), _stream(), None),
+                'xrt_hip_double_reflect_f64_dev')
+        if local:
+            lo1._d['theta'], lo2._d['theta'] = angles
+        if not (fused.value & 1) and not keep_global:
+            _scratch_beam.taken('global', gb2)      # (it holds the global beam after all)
+        self._adopt((lo1, lo2, gb2) if local else (gb2,), beam)
+        if image is not None:
+            rs.inherit_scalars(image, beam)
+        return gb2, lo1, lo2, image, bool(fused.value & 1)
 
     def _run_double(self, p1, p2, fromVacuum1, fromVacuum2, beam, timing=None, out=None,
                     local=True):

@@ -684,12 +684,14 @@ int xrt_hip_double_reflect_fusable(const xrt_hip_pass* pass1, const xrt_hip_mate
   return xrt::reflect_dcm_fusable(*pass1, *material1, *pass2, *material2) ? 1 : 0;
 }
 
-int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_material* material1,
-                                   const xrt_hip_pass* pass2, const xrt_hip_material* material2,
-                                   const xrt_hip_beam* in, xrt_hip_beam* out_local1,
-                                   xrt_hip_beam* out_local2, xrt_hip_beam* out_global,
-                                   double* theta1, double* theta2, void* workspace,
-                                   size_t workspace_bytes, void* stream, float* kernel_ms) {
+static int double_reflect_impl(const xrt_hip_pass* pass1, const xrt_hip_material* material1,
+                               const xrt_hip_pass* pass2, const xrt_hip_material* material2,
+                               const xrt_hip_beam* in, xrt_hip_beam* out_local1,
+                               xrt_hip_beam* out_local2, xrt_hip_beam* out_global,
+                               double* theta1, double* theta2, void* workspace,
+                               size_t workspace_bytes, void* stream, float* kernel_ms,
+                               const xrt_hip_screen* screen, xrt_hip_beam* out_screen,
+                               int keep_global, const xrt::TailApertures* ap, int* fused) {
   const ArmedEvents armed;
   int rc;
   if ((rc = check_pass(pass1, material1))) return rc;
@@ -718,6 +720,14 @@ int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_mate
     if ((rc = check_beam(out_local2, "out_local2", n, amp))) return rc;
   }
   if ((rc = check_beam(out_global, "out_global", n, amp))) return rc;
+  if (screen) {
+    if (!out_screen) return fail(XRT_HIP_ERR_ARG, "double_reflect: a screen without its image beam");
+    if ((rc = check_beam(out_screen, "out_screen", n, amp))) return rc;
+    if (screen->radius != 0. && !keep_global)
+      return fail(XRT_HIP_ERR_ARG, "a hemispheric screen takes the stored global beam "
+                                   "(keep_global = 1)");
+  }
+  if (fused) *fused = 0;
   if (n == 0) return XRT_HIP_OK;
   if (!workspace || workspace_bytes < xrt::reflect_workspace_bytes(n))
     return fail(XRT_HIP_ERR_NOMEM, "workspace %zu B < required %zu B", workspace_bytes,
@@ -744,7 +754,8 @@ int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_mate
   const bool force_exact = ex && ex[0] == '1';
   hipError_t e = xrt::reflect_dcm_launch(*pass1, *material1, *pass2, *material2, *in,
                                          *out_local1, *out_local2, *out_global, theta1, theta2,
-                                         workspace, st, e0, e1, k0, k1, force_exact);
+                                         workspace, st, e0, e1, k0, k1, force_exact, screen,
+                                         out_screen, keep_global != 0, ap, fused);
   if (e != hipSuccess)
     return fail(XRT_HIP_ERR_HIP, "double_reflect launch: %s", hipGetErrorString(e));
   if (kernel_ms) {
@@ -760,6 +771,43 @@ int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_mate
       return fail(XRT_HIP_ERR_HIP, "double_reflect: a grid barrier of the exact sequence timed out");
   }
   return XRT_HIP_OK;
+}
+
+int xrt_hip_double_reflect_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_material* material1,
+                                   const xrt_hip_pass* pass2, const xrt_hip_material* material2,
+                                   const xrt_hip_beam* in, xrt_hip_beam* out_local1,
+                                   xrt_hip_beam* out_local2, xrt_hip_beam* out_global,
+                                   double* theta1, double* theta2, void* workspace,
+                                   size_t workspace_bytes, void* stream, float* kernel_ms) {
+  return double_reflect_impl(pass1, material1, pass2, material2, in, out_local1, out_local2,
+                             out_global, theta1, theta2, workspace, workspace_bytes, stream,
+                             kernel_ms, nullptr, nullptr, 1, nullptr, nullptr);
+}
+
+int xrt_hip_double_reflect_tail_f64_dev(const xrt_hip_pass* pass1, const xrt_hip_material* material1,
+                                        const xrt_hip_pass* pass2, const xrt_hip_material* material2,
+                                        const xrt_hip_beam* in, xrt_hip_beam* out_local1,
+                                        xrt_hip_beam* out_local2, xrt_hip_beam* out_global,
+                                        double* theta1, double* theta2, const xrt_hip_tail* tail,
+                                        int keep_global, void* workspace, size_t workspace_bytes,
+                                        void* stream, int* fused) {
+  if (!tail) return fail(XRT_HIP_ERR_ARG, "NULL tail");
+  if (tail->n_apertures < 0 || tail->n_apertures > XRT_TAIL_APERTURES)
+    return fail(XRT_HIP_ERR_ARG, "a tail carries 0 to %d apertures", XRT_TAIL_APERTURES);
+  if (tail->plot)
+    return fail(XRT_HIP_ERR_ARG, "double_reflect: a plot does not ride behind the pair "
+                                 "(xrt_hip_plot_hist_ws_f64_dev on the image)");
+  xrt::TailApertures ap;
+  memset(&ap, 0, sizeof(ap));
+  ap.n = tail->n_apertures;
+  for (int k = 0; k < ap.n; ++k) {
+    if (tail->aperture[k].poly_n > 0)
+      return fail(XRT_HIP_ERR_ARG, "a polygonal aperture does not ride in a tail");
+    ap.a[k] = tail->aperture[k];
+  }
+  return double_reflect_impl(pass1, material1, pass2, material2, in, out_local1, out_local2,
+                             out_global, theta1, theta2, workspace, workspace_bytes, stream,
+                             nullptr, tail->screen, tail->out_screen, keep_global, &ap, fused);
 }
 
 int xrt_hip_surface_eval_f64_dev(const xrt_hip_pass* pass, int what, int64_t n, const double* u,

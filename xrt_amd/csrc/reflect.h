@@ -149,7 +149,10 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
                               const xrt_hip_beam& lo2, const xrt_hip_beam& gb2,
                               double* theta1, double* theta2, void* workspace,
                               hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                              hipEvent_t evk0, hipEvent_t evk1, bool force_exact);
+                              hipEvent_t evk0, hipEvent_t evk1, bool force_exact,
+                              const xrt_hip_screen* scr = nullptr, const xrt_hip_beam* sb = nullptr,
+                              bool keep_global = true, const TailApertures* ap = nullptr,
+                              int* fused = nullptr);
 
 // One bounce of OE.multiple_reflect (reflect_multi_impl.h); workspace: counts (16 B) | diag
 // (128 B) | GStat (256 B) | partial records | tang [n].

@@ -923,9 +923,25 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
                               const xrt_hip_beam& lo2, const xrt_hip_beam& gb2,
                               double* theta1, double* theta2, void* workspace,
                               hipStream_t st, hipEvent_t ev0, hipEvent_t ev1,
-                              hipEvent_t evk0, hipEvent_t evk1, bool force_exact) {
+                              hipEvent_t evk0, hipEvent_t evk1, bool force_exact,
+                              const xrt_hip_screen* scr, const xrt_hip_beam* sb, bool keep_global,
+                              const TailApertures* ap, int* fused) {
   const int64_t n = in.n;
+  if (fused) *fused = 0;
   if (n <= 0) return hipSuccess;
+  // apertures / a flat screen right behind the monochromator: in the tail of the fused kernel of
+  // the crystal pairs (the plate pair and a forced exact sequence: their own launches below)
+  if (ap && ap->n == 0) ap = nullptr;
+  const bool tail = (scr && sb) || ap;
+  const bool fuse_tail = tail && !force_exact && M1.kind != XRT_HIP_MAT_PLATE &&
+                         (!scr || scr->radius == 0.);
+  xrt_hip_screen no_screen;
+  xrt_hip_beam no_image;
+  memset(&no_screen, 0, sizeof(no_screen));
+  memset(&no_image, 0, sizeof(no_image));
+  no_image.n = n;
+  const TailApertures none{};
+  if (!scr || !sb) keep_global = true;      // (the marked global beam is what the caller wants)
   const WsLayout L = ws_layout(workspace, n);
   const dim3 grid((unsigned)((n + REFLECT_DCM_BLOCK - 1) / REFLECT_DCM_BLOCK)),
       block(REFLECT_BLOCK), fblock(REFLECT_DCM_BLOCK);
@@ -959,8 +975,20 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
     if (evk0) (void)hipEventRecord(evk0, st);
     const int spec = M1.kind == XRT_HIP_MAT_PLATE ? SP_FLAT_PLATE
                                                   : (M1.thick ? SP_THICK_FLAT : SP_FLAT_XTAL);
-    if (!(tu_hot_dcm(spec, DL) || tu_xtal_dcm(spec, DL) || tu_hot_plate2(spec, DL)))
+    if (fuse_tail) {
+      xrt_hip_beam gb_fused = gb2;
+      if (!keep_global) {
+        gb_fused.x = gb_fused.y = gb_fused.z = gb_fused.a = gb_fused.b = gb_fused.c = nullptr;
+        gb_fused.path = gb_fused.E = gb_fused.Jss = gb_fused.Jpp = gb_fused.Jsp_ri = nullptr;
+        gb_fused.state = nullptr;
+        gb_fused.Es_ri = gb_fused.Ep_ri = nullptr;
+      }
+      if (!tu_hot_dcm_scr(spec, DL, gb_fused, scr ? *scr : no_screen, scr && sb ? *sb : no_image,
+                          ap ? *ap : none))
+        return hipErrorInvalidDeviceFunction;
+    } else if (!(tu_hot_dcm(spec, DL) || tu_xtal_dcm(spec, DL) || tu_hot_plate2(spec, DL))) {
       return hipErrorInvalidDeviceFunction;
+    }
     if (evk1) (void)hipEventRecord(evk1, st);
   }
   DcmLaunch XD = DL;
@@ -968,8 +996,25 @@ hipError_t reflect_dcm_launch(const xrt_hip_pass& P1, const xrt_hip_material& M1
   XD.block = dim3(REFLECT_EXACT_BLOCK);
   {
     BarrierSerial one_at_a_time(st);
-    tu_exact0_dcm(XD);
+    if (fuse_tail)      // (the redo, if any, marks the real gb2 and makes the image from it)
+      tu_exact0_dcm_redo_scr(XD, scr ? *scr : no_screen, scr && sb ? *sb : no_image,
+                             ap ? *ap : none);
+    else
+      tu_exact0_dcm(XD);
   }
+  if (tail && !fuse_tail) {
+    if (ap) {
+      for (int k = 0; k < ap->n; ++k) {
+        const hipError_t ae = aperture_propagate_launch(ap->a[k], gb2, no_image, no_image, st);
+        if (ae != hipSuccess) return ae;
+      }
+    }
+    if (scr && sb) {
+      const hipError_t se = screen_expose_launch(*scr, gb2, *sb, st);
+      if (se != hipSuccess) return se;
+    }
+  }
+  if (fused) *fused = (fuse_tail && scr && sb ? 1 : 0) | (fuse_tail && ap ? 8 : 0);
   if (force_exact && evk1) (void)hipEventRecord(evk1, st);
   if (ev1) (void)hipEventRecord(ev1, st);
   return hipGetLastError();

@@ -29,4 +29,10 @@ void tu_exact0_dcm(const DcmLaunch& L) {
                      *L.M2, *L.in, *L.lo1, *L.lo2, *L.gb2, L.A1, L.A2);
 }
 
+void tu_exact0_dcm_redo_scr(const DcmLaunch& L, const xrt_hip_screen& S, const xrt_hip_beam& sb,
+                            const TailApertures& ap) {
+  hipLaunchKernelGGL(reflect_dcm_redo_scr<Generic0>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2,
+                     *L.M2, *L.in, *L.lo1, *L.lo2, *L.gb2, L.A1, L.A2, S, sb, ap);
+}
+
 }  // namespace xrt

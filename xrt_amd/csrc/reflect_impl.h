@@ -4291,13 +4291,16 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void reflect_decide_dcm(
 }
 #endif
 
-template <class K>
-__global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
-    xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2,
-    xrt_hip_beam in, xrt_hip_beam lo1, xrt_hip_beam lo2, xrt_hip_beam gb2, double* theta1,
-    double* theta2, const GStat* __restrict__ g1p, const GStat* __restrict__ g2p,
-    int* __restrict__ flags1, int* __restrict__ flags2, OptStat* __restrict__ opt1,
-    OptStat* __restrict__ opt2) {
+// (the body of the kernel: CONS = what rides behind the second crystal -- apertures and a screen,
+// reflect_fused_dcm_scr -- or nothing)
+template <class K, class CONS>
+__device__ __forceinline__ void fused_dcm_ray(
+    const xrt_hip_pass& P1, const xrt_hip_material& M1, const xrt_hip_pass& P2,
+    const xrt_hip_material& M2, const xrt_hip_beam& in, const xrt_hip_beam& lo1,
+    const xrt_hip_beam& lo2, const xrt_hip_beam& gb2, double* theta1, double* theta2,
+    const GStat* __restrict__ g1p, const GStat* __restrict__ g2p, int* __restrict__ flags1,
+    int* __restrict__ flags2, OptStat* __restrict__ opt1, OptStat* __restrict__ opt2,
+    const CONS& cons) {
   const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
   const bool has_amp = in.Es_ri != nullptr;
   const bool live = i < in.n;
@@ -4400,8 +4403,8 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
       int st = rays_good<K>(P2, h.x, h.y);
       if (h.lost) st = P2.lost_num;
       double bdn = 0.;
-      complete_ray<K, true>(P2, M2, g, in, in, lo2, gb2, theta2, i, r, h, st, has_amp, 1, &bdn,
-                            v.f, &anom2, nullptr, &xe, have_xe);
+      complete_ray<K, true, false, CONS>(P2, M2, g, in, in, lo2, gb2, theta2, i, r, h, st, has_amp,
+                                         1, &bdn, v.f, &anom2, nullptr, &xe, have_xe, nullptr, cons);
       neg2 |= st == 1 && bdn < 0.;
       pos2 |= st == 1 && !(bdn < 0.);
     } else if (live) {
@@ -4411,11 +4414,48 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
         store_rec(lo2, i, v, P2.zero_local_not_entering ? 0 : v.st, has_amp,
                   P2.zero_local_not_entering != 0);
       if (theta2) theta2[i] = 0.;
-      copy_ray(gb2, in, i, P2.force_lost_out ? P2.lost_num : v.st, has_amp, false);
+      const int vst = P2.force_lost_out ? P2.lost_num : v.st;
+      if constexpr (CONS::ON) {
+        // (the original record is still in registers: req)
+        const int mst = cons.mark(r_in.x, r_in.y, r_in.z, r_in.a, r_in.b, r_in.c, vst);
+        if (gb2.x)
+          store_ray(gb2, i, r_in.x, r_in.y, r_in.z, r_in.a, r_in.b, r_in.c, q0.path, q0.E, q0.Jss,
+                    q0.Jpp, q0.Jsr, q0.Jsi, mst, q0.Esr, q0.Esi, q0.Epr, q0.Epi, has_amp);
+        cons.take(i, r_in.x, r_in.y, r_in.z, r_in.a, r_in.b, r_in.c, q0.path, q0.E, q0.Jss, q0.Jpp,
+                  q0.Jsr, q0.Jsi, mst, q0.Esr, q0.Esi, q0.Epr, q0.Epi, has_amp);
+      } else {
+        copy_ray(gb2, in, i, vst, has_amp, false);
+      }
     }
   }
   raise_sign_flags(flags1, seen1n, seen1p, neg1, pos1);
   raise_sign_flags(flags2, seen2n, seen2p, neg2, pos2);
+}
+
+template <class K>
+__global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
+    xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2,
+    xrt_hip_beam in, xrt_hip_beam lo1, xrt_hip_beam lo2, xrt_hip_beam gb2, double* theta1,
+    double* theta2, const GStat* __restrict__ g1p, const GStat* __restrict__ g2p,
+    int* __restrict__ flags1, int* __restrict__ flags2, OptStat* __restrict__ opt1,
+    OptStat* __restrict__ opt2) {
+  fused_dcm_ray<K, NoConsumer>(P1, M1, P2, M2, in, lo1, lo2, gb2, theta1, theta2, g1p, g2p, flags1,
+                               flags2, opt1, opt2, NoConsumer());
+}
+
+// DCM.double_reflect with apertures and / or a screen right behind the monochromator in its tail
+// (dcm.py:248-354 -> apertures.py:334-413 -> screens.py:226-302): the marks and the image are made
+// from the outgoing record in registers; gb2 with null arrays = nobody else wants the global beam.
+// A contradicted pass is redone by reflect_dcm_redo_scr into the real gb2, marks and image from that.
+template <class K>
+__global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm_scr(
+    xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2,
+    xrt_hip_beam in, xrt_hip_beam lo1, xrt_hip_beam lo2, xrt_hip_beam gb2, double* theta1,
+    double* theta2, const GStat* __restrict__ g1p, const GStat* __restrict__ g2p,
+    int* __restrict__ flags1, int* __restrict__ flags2, OptStat* __restrict__ opt1,
+    OptStat* __restrict__ opt2, ScreenConsumer cons) {
+  fused_dcm_ray<K, ScreenConsumer>(P1, M1, P2, M2, in, lo1, lo2, gb2, theta1, theta2, g1p, g2p,
+                                   flags1, flags2, opt1, opt2, cons);
 }
 
 // Plate.double_refract (oes/refractive.py:171-235 = dcm.py:248-354 with the plate's two faces):
@@ -4561,6 +4601,59 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_dcm_exact(
   exact_pass<K>(P1, M1, in, in, lo1, gb2, A1, true, phase1);
   grid_barrier(g1, phase1);
   exact_pass<K>(P2, M2, gb2, in, lo2, gb2, A2, true, phase2);
+}
+
+// reflect_dcm_exact behind a pass with apertures / a screen in its tail: the same verdict and the
+// same exact passes, then the marks and the image from the real global beam (as reflect_redo_scr).
+template <class K>
+__global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_dcm_redo_scr(
+    xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2, xrt_hip_beam in,
+    xrt_hip_beam lo1, xrt_hip_beam lo2, xrt_hip_beam gb2, PassAux A1, PassAux A2, xrt_hip_screen S,
+    xrt_hip_beam sb, TailApertures ap) {
+  __shared__ double lds_d[REFLECT_MAX_WAVES];
+  GStat *g1 = A1.g, *g2 = A2.g;
+  const bool mixed = (g1->any_neg && g1->any_pos) || (g2->any_neg && g2->any_pos);
+  const bool forced = !g1->optimistic;
+  bool full = forced;
+  if (!forced) {
+    const bool f1 = exact_gate(g1, reinterpret_cast<const OptStat*>(A1.part), lds_d,
+                               P1.method_hint);
+    const bool f2 = exact_gate(g2, reinterpret_cast<const OptStat*>(A2.part), lds_d,
+                               P2.method_hint);
+    full = f1 || f2;
+  }
+  if (!full && !mixed) return;
+  unsigned phase1 = 0, phase2 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g1->redo = 1;
+    g2->redo = 1;
+    g2->any_neg = g2->any_pos = 0;
+  }
+  exact_pass<K>(P1, M1, in, in, lo1, gb2, A1, true, phase1);
+  grid_barrier(g1, phase1);
+  exact_pass<K>(P2, M2, gb2, in, lo2, gb2, A2, true, phase2);
+  grid_barrier(g2, phase2);
+  const bool has_amp = gb2.Es_ri != nullptr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < gb2.n; i += stride) {
+    int vst = gb2.state[i];
+    const double x = gb2.x[i], y = gb2.y[i], z = gb2.z[i], a = gb2.a[i], b = gb2.b[i], c = gb2.c[i];
+    if (ap.n) {
+      const int marked = apertures_mark(ap, x, y, z, a, b, c, vst);
+      if (marked != vst) gb2.state[i] = marked;
+      vst = marked;
+    }
+    if (sb.x) {
+      const double2 js = reinterpret_cast<const double2*>(gb2.Jsp_ri)[i];
+      double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+      if (has_amp) {
+        es = reinterpret_cast<const double2*>(gb2.Es_ri)[i];
+        ep = reinterpret_cast<const double2*>(gb2.Ep_ri)[i];
+      }
+      expose_flat_store(S, sb, i, x, y, z, a, b, c, gb2.path[i], gb2.E[i], gb2.Jss[i], gb2.Jpp[i],
+                        js.x, js.y, vst, es.x, es.y, ep.x, ep.y, has_amp);
+    }
+  }
 }
 
 }  // namespace xrt

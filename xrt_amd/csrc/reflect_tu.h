@@ -177,6 +177,17 @@ inline void launch_dcm_k(const DcmLaunch& L) {
 }
 
 template <class K>
+inline void launch_dcm_scr_k(const DcmLaunch& L, const xrt_hip_beam& gb2, const xrt_hip_screen& S,
+                             const xrt_hip_beam& sb, const TailApertures& ap) {
+  ScreenConsumer cons;
+  cons.S = S;
+  cons.out = sb;
+  cons.ap = ap;
+  hipLaunchKernelGGL(reflect_fused_dcm_scr<K>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2, *L.M2,
+                     *L.in, *L.lo1, *L.lo2, gb2, L.theta1, L.theta2, L.g1, L.g2, &L.g1->any_neg,
+                     &L.g2->any_neg, L.opt1, L.opt2, cons);
+}
+template <class K>
 inline void launch_plate2_k(const DcmLaunch& L) {
   hipLaunchKernelGGL(reflect_fused_plate2<K>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2, *L.M2,
                      *L.in, *L.lo1, *L.lo2, *L.gb2, L.theta1, L.theta2, L.g1, L.g2, L.opt1, L.opt2);
@@ -191,6 +202,9 @@ bool tu_hot_fused_gen_scr_plot(int spec, const FusedLaunch& L);
 bool tu_hot_xtal(int spec, int mode, const FusedLaunch& L);
 bool tu_hot_dcm(int spec, const DcmLaunch& L);
 bool tu_hot_plate2(int spec, const DcmLaunch& L);                   // reflect_hot_plate2.hip
+// (gb2: the global beam as the fused kernel sees it -- null arrays if nobody keeps it)
+bool tu_hot_dcm_scr(int spec, const DcmLaunch& L, const xrt_hip_beam& gb2, const xrt_hip_screen& S,
+                    const xrt_hip_beam& sb, const TailApertures& ap);   // reflect_hot_dcm_scr.hip
 bool tu_xtal_xtal(int spec, int mode, const FusedLaunch& L);        // reflect_xtal.hip
 bool tu_xtal_dcm(int spec, const DcmLaunch& L);
 bool tu_generic_fused(int spec, int mode, const FusedLaunch& L);    // reflect_generic.hip
@@ -204,6 +218,8 @@ void tu_exact0_redo_scr(const ExactLaunch& L, const xrt_hip_screen& S, const xrt
                         const xrt_hip_geosource* src, const PlotTail* plot,
                         const TailApertures* ap);
 void tu_exact0_dcm(const DcmLaunch& L);
+void tu_exact0_dcm_redo_scr(const DcmLaunch& L, const xrt_hip_screen& S, const xrt_hip_beam& sb,
+                            const TailApertures& ap);
 bool tu_exact1(int spec, const ExactLaunch& L);                     // reflect_exact1.hip
 bool tu_exact2(int spec, const ExactLaunch& L);                     // reflect_exact2.hip
 bool tu_exact3(int spec, const ExactLaunch& L);                     // reflect_exact3.hip
