@@ -27,7 +27,7 @@ def _one(table, *parts):
 
 def test_hot_kernels_keep_their_budget():
     table = kr.kernels()
-    lean = _one(table, 'reflect_fusedINS_4SpecILi0ELi1ELi1ELb1EEELi0')      # cfg2: toroid mirror
+    lean = _one(table, 'reflect_fused_lateINS_4SpecILi0ELi1ELi1ELb1EEELi0')      # cfg2: toroid mirror
     assert lean['scratch'] == 0 and lean['vgpr_spill'] == 0 and lean['vgpr'] <= 128
     dcm = _one(table, 'reflect_fused_dcmINS_9ThickXtalILi0')                # cfg3
     assert dcm['scratch'] == 0 and dcm['vgpr_spill'] == 0 and dcm['vgpr'] <= 128
@@ -84,3 +84,26 @@ def test_hot_kernels_keep_their_budget():
             # reflection in one pass per ray -- spills more than the phase-wise kernel)
             spill = 176 if 'reflect_multi_optINS_4SpecILi1E' in name else 112
             assert r['vgpr'] <= 256 and r['vgpr_spill'] <= spill and r['scratch'] <= 768, name
+
+
+def test_fused_kernels_do_not_park_their_arguments_in_vgpr_lanes():
+    """Round 6: the kernels with a tail (screen / apertures / plot), the pair kernels (DCM, plate)
+    and the lean plain pass take ONE record of arguments and read the tail's members where they are
+    used (reflect_impl.h: kernarg_at). Loaded in the entry block they were spilled to VGPR lanes
+    (v_writelane / v_readlane are VALU slots): 126-230 SGPRs in the kernels with a tail, 85 in the
+    DCM's, 404 in the optimistic bounce of multiple_reflect (profiles/r06_sgpr_late_ab.txt)."""
+    table = kr.kernels()
+    seen = 0
+    for name, r in table.items():
+        lean_spec = 'INS_4SpecILi0ELi' in name and 'ELb1EEE' in name
+        if lean_spec and ('reflect_fused_scr' in name or 'reflect_fused_gen_scr' in name or
+                          'reflect_fused_late' in name or 'reflect_fused_plate2' in name):
+            assert r.get('sgpr_spill', 0) <= 16, (name, r)
+            seen += 1
+        if 'ThickXtalILi0' in name and 'reflect_fused_dcm' in name:
+            assert r.get('sgpr_spill', 0) <= 16 and r['vgpr_spill'] == 0 and r['scratch'] == 0, \
+                (name, r)
+            seen += 1
+    assert seen >= 20, seen
+    opt = _one(table, 'reflect_multi_optINS_4SpecILi0ELin1ELin1ELb0')
+    assert opt.get('sgpr_spill', 0) <= 96 and opt['vgpr_spill'] <= 16, opt

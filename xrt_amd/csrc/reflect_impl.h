@@ -3225,7 +3225,7 @@ __device__ __forceinline__ Finished finish_ray(const xrt_hip_pass& P,
 // OPTIONAL: the record may be one nobody asked for (o.x null: OE.reflect(needLocal=False) makes
 // no local beam). Only the passes that can be called that way pay the test: with it in the
 // kernels of layered materials their spills went from 50 to 72 VGPRs.
-template <bool OPTIONAL = false>
+template <bool OPTIONAL = false, bool STATE = true>
 __device__ __forceinline__ void store_ray(const xrt_hip_beam& o, int64_t i, double x, double y,
                                           double z, double a, double b, double c, double path,
                                           double E, double Jss, double Jpp, double Jsr,
@@ -3248,7 +3248,7 @@ __device__ __forceinline__ void store_ray(const xrt_hip_beam& o, int64_t i, doub
   __builtin_nontemporal_store(Jss, &o.Jss[i]);
   __builtin_nontemporal_store(Jpp, &o.Jpp[i]);
   __builtin_nontemporal_store(v2d{Jsr, Jsi}, &reinterpret_cast<v2d*>(o.Jsp_ri)[i]);
-  __builtin_nontemporal_store(st, &o.state[i]);
+  if (STATE) __builtin_nontemporal_store(st, &o.state[i]);
   if (has_amp) {
     __builtin_nontemporal_store(v2d{Esr, Esi}, &reinterpret_cast<v2d*>(o.Es_ri)[i]);
     __builtin_nontemporal_store(v2d{Epr, Epi}, &reinterpret_cast<v2d*>(o.Ep_ri)[i]);
@@ -3282,22 +3282,64 @@ __device__ __forceinline__ void copy_ray(const xrt_hip_beam& o, const xrt_hip_be
 struct NoConsumer {
   static constexpr bool ON = false;
 };
-struct ScreenConsumer {        // [apertures ->] Screen.expose, flat screens (screen_impl.h)
-  static constexpr bool ON = true;
-  xrt_hip_screen S;
+// A record among the kernel's arguments, read from the argument segment WHERE IT IS USED.
+// The compiler loads by-value arguments in the entry block; what the tail of a ray pass needs
+// (screen, apertures, plot, the array pointers of the image and of the global beam: some 200
+// SGPRs) then waits through the whole pass in VGPR lanes -- v_writelane at the head, v_readlane
+// at the tail, ~400 VALU slots per wave of kernels that are bound by their VALU issue
+// (profiles/r06_sgpr_late_ab.txt). So the kernels with a tail take ONE record of arguments
+// (offset 0 of the segment), never name the tail's members, and the consumers read them through
+// the segment pointer + offsetof behind an empty asm: a new value to the compiler, scalar loads
+// issued at the point of use. (Taking the address of a by-value argument instead would make the
+// compiler keep a copy of the whole record in scratch memory.)
+template <class T>
+__device__ __forceinline__ const T& kernarg_at(unsigned off) {
+  typedef const T __attribute__((address_space(4))) * KernArgPtr;
+  const unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + off;
+  // (the same in every lane; said so explicitly: behind divergent control flow the compiler
+  // may hold it in a VGPR)
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return *(const T*)(KernArgPtr)(((unsigned long long)hi << 32) | lo);
+}
+
+struct ScreenConsumer {        // [apertures ->] Screen.expose, flat screens (screen_impl.h):
+  xrt_hip_screen S;            // the record as the host fills it
   xrt_hip_beam out;            // the image (x null: no screen, or nobody wants the image itself)
   TailApertures ap;
+};
+// where the tail's records lie in the kernel's argument record
+struct TailAt {
+  unsigned vb, S, out, ap, Q;
+};
+#define XRT_TAIL_AT(ARGS, VB)                                                            \
+  TailAt {                                                                               \
+    (unsigned)offsetof(ARGS, VB), (unsigned)offsetof(ARGS, scr.S),                        \
+        (unsigned)offsetof(ARGS, scr.out), (unsigned)offsetof(ARGS, scr.ap),              \
+        (unsigned)offsetof(ARGS, Q)                                                      \
+  }
+
+struct LateScreen {
+  static constexpr bool ON = true;
+  static constexpr bool TAKES = true;
+  TailAt at;
+  __device__ __forceinline__ const xrt_hip_beam& vb() const {
+    return kernarg_at<xrt_hip_beam>(at.vb);
+  }
   __device__ __forceinline__ int mark(double x, double y, double z, double a, double b, double c,
                                       int st) const {
-    return ap.n ? apertures_mark(ap, x, y, z, a, b, c, st) : st;
+    const TailApertures& A = kernarg_at<TailApertures>(at.ap);
+    return A.n ? apertures_mark(A, x, y, z, a, b, c, st) : st;
   }
   __device__ __forceinline__ void take(int64_t i, double x, double y, double z, double a,
                                        double b, double c, double path, double E, double Jss,
                                        double Jpp, double Jsr, double Jsi, int st, double Esr,
                                        double Esi, double Epr, double Epi, bool has_amp) const {
-    if (out.x)
-      expose_flat_store(S, out, i, x, y, z, a, b, c, path, E, Jss, Jpp, Jsr, Jsi, st, Esr, Esi,
-                        Epr, Epi, has_amp);
+    const xrt_hip_beam& o = kernarg_at<xrt_hip_beam>(at.out);
+    if (o.x)
+      expose_flat_store(kernarg_at<xrt_hip_screen>(at.S), o, i, x, y, z, a, b, c, path, E, Jss, Jpp,
+                        Jsr, Jsi, st, Esr, Esi, Epr, Epi, has_amp);
   }
 };
 
@@ -3305,29 +3347,110 @@ struct ScreenConsumer {        // [apertures ->] Screen.expose, flat screens (sc
 // plot_tail.h): the image is stored only if somebody else reads it (out.x), its ray's weight,
 // hue and bins are left in *stash* -- registers of the kernel -- for the wave to sort and write
 // when all its lanes are back together (plot_tail_emit at the end of the kernel: take() runs
-// inside divergent branches). References to the kernel's arguments and a pointer to a local: a
-// member written in an argument would send the whole record to scratch memory.
-struct ScreenPlotConsumer {
+// inside divergent branches).
+struct LateScreenPlot {
   static constexpr bool ON = true;
-  const xrt_hip_screen& S;
-  const xrt_hip_beam& out;
-  const PlotTail& Q;
+  static constexpr bool TAKES = true;
+  TailAt at;
   PlotStash* stash;
-  const TailApertures& ap;
+  __device__ __forceinline__ const xrt_hip_beam& vb() const {
+    return kernarg_at<xrt_hip_beam>(at.vb);
+  }
   __device__ __forceinline__ int mark(double x, double y, double z, double a, double b, double c,
                                       int st) const {
-    return ap.n ? apertures_mark(ap, x, y, z, a, b, c, st) : st;
+    const TailApertures& A = kernarg_at<TailApertures>(at.ap);
+    return A.n ? apertures_mark(A, x, y, z, a, b, c, st) : st;
   }
   __device__ __forceinline__ void take(int64_t i, double x, double y, double z, double a,
                                        double b, double c, double path, double E, double Jss,
                                        double Jpp, double Jsr, double Jsi, int st, double Esr,
                                        double Esi, double Epr, double Epi, bool has_amp) const {
-    const ImageRay r = expose_flat(S, x, y, z, a, b, c, st);
-    if (out.x) store_image(out, i, r, path, E, Jss, Jpp, Jsr, Jsi, Esr, Esi, Epr, Epi, has_amp);
-    *stash = plot_tail_take(Q, r.x, 0., r.z, r.a, r.b, r.c, path + r.path, E, Jss, Jpp, Jsr, Jsi,
-                            r.st);
+    const ImageRay r = expose_flat(kernarg_at<xrt_hip_screen>(at.S), x, y, z, a, b, c, st);
+    const xrt_hip_beam& o = kernarg_at<xrt_hip_beam>(at.out);
+    if (o.x) store_image(o, i, r, path, E, Jss, Jpp, Jsr, Jsi, Esr, Esi, Epr, Epi, has_amp);
+    *stash = plot_tail_take(kernarg_at<PlotTail>(at.Q), r.x, 0., r.z, r.a, r.b, r.c, path + r.path,
+                            E, Jss, Jpp, Jsr, Jsi, r.st);
   }
 };
+// Apertures alone (nothing exposes the beam behind them): the kernel whose registers are all
+// taken -- the DCM's, 119 of 128 -- stores the record first and forms the marks from position and
+// direction when everything else is on its way (emit_marked), and has no image arithmetic
+// compiled in.
+struct LateMarks {
+  static constexpr bool ON = true;
+  static constexpr bool TAKES = false;
+  TailAt at;
+  __device__ __forceinline__ const xrt_hip_beam& vb() const {
+    return kernarg_at<xrt_hip_beam>(at.vb);
+  }
+  __device__ __forceinline__ int mark(double x, double y, double z, double a, double b, double c,
+                                      int st) const {
+    const TailApertures& A = kernarg_at<TailApertures>(at.ap);
+    return A.n ? apertures_mark(A, x, y, z, a, b, c, st) : st;
+  }
+  __device__ __forceinline__ void take(int64_t, double, double, double, double, double, double,
+                                       double, double, double, double, double, double, int,
+                                       double, double, double, double, bool) const {}
+};
+
+// Nothing behind the element at all, but the global beam's array pointers read where the record
+// is stored (the DCM's plain kernel: 85 SGPRs waited in VGPR lanes through both crystals)
+struct LatePlain {
+  static constexpr bool ON = true;
+  static constexpr bool TAKES = false;
+  TailAt at;
+  __device__ __forceinline__ const xrt_hip_beam& vb() const {
+    return kernarg_at<xrt_hip_beam>(at.vb);
+  }
+  __device__ __forceinline__ int mark(double, double, double, double, double, double,
+                                      int st) const {
+    return st;
+  }
+  __device__ __forceinline__ void take(int64_t, double, double, double, double, double, double,
+                                       double, double, double, double, double, double, int,
+                                       double, double, double, double, bool) const {}
+};
+
+// the outgoing record of a ray with a consumer behind the element: marks, store, hand-over
+template <class CONS>
+__device__ __forceinline__ void emit_marked(const CONS& cons, int64_t i,
+                                            double x, double y, double z, double a, double b,
+                                            double c, double path, double E, double Jss,
+                                            double Jpp, double Jsr, double Jsi, int st, double Esr,
+                                            double Esi, double Epr, double Epi, bool has_amp) {
+  const xrt_hip_beam& vb = cons.vb();           // (the global beam's arrays: fetched here)
+  if constexpr (!CONS::TAKES) {
+    if (vb.x) {
+      store_ray<false, false>(vb, i, x, y, z, a, b, c, path, E, Jss, Jpp, Jsr, Jsi, st, Esr, Esi,
+                              Epr, Epi, has_amp);
+      __builtin_nontemporal_store(cons.mark(x, y, z, a, b, c, st), &vb.state[i]);
+    }
+  } else {
+    st = cons.mark(x, y, z, a, b, c, st);
+    if (vb.x)
+      store_ray(vb, i, x, y, z, a, b, c, path, E, Jss, Jpp, Jsr, Jsi, st, Esr, Esi, Epr, Epi,
+                has_amp);
+    cons.take(i, x, y, z, a, b, c, path, E, Jss, Jpp, Jsr, Jsi, st, Esr, Esi, Epr, Epi, has_amp);
+  }
+}
+
+// ... of a ray that goes through as it came (record `i` of `s`, read again here: a copy kept in
+// registers from the head of the kernel would live across both solves)
+template <class CONS>
+__device__ __forceinline__ void copy_marked(const CONS& cons, const xrt_hip_beam& s, int64_t i,
+                                            int st, bool has_amp) {
+  const double2 js = reinterpret_cast<const double2*>(s.Jsp_ri)[i];
+  double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
+  if (has_amp) {
+    es = reinterpret_cast<const double2*>(s.Es_ri)[i];
+    ep = reinterpret_cast<const double2*>(s.Ep_ri)[i];
+  }
+  const double x = s.x[i], y = s.y[i], z = s.z[i], a = s.a[i], b = s.b[i], c = s.c[i];
+  const double path = s.path[i], E = s.E[i], Jss = s.Jss[i], Jpp = s.Jpp[i];
+  emit_marked(cons, i, x, y, z, a, b, c, path, E, Jss, Jpp, js.x, js.y, st, es.x, es.y, ep.x, ep.y,
+              has_amp);
+}
+
 __device__ __forceinline__ PlotStash no_plot_ray(const PlotTail& Q) {
   PlotStash s;
   s.w = s.hue = 0.;
@@ -3493,13 +3616,12 @@ __device__ __forceinline__ Completed complete_ray(
     res.v.st = st;
     return res;
   }
-  if constexpr (CONS::ON) vst = cons.mark(x, y, z, la, lbb, lc, vst);    // apertures behind it
-  if (!CONS::ON || vb.x)
+  if constexpr (CONS::ON)      // apertures and / or a screen behind the element
+    emit_marked(cons, i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, vst, vEsr, vEsi,
+                vEpr, vEpi, has_amp);
+  else
     store_ray(vb, i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, vst, vEsr,
               vEsi, vEpr, vEpi, has_amp);
-  if constexpr (CONS::ON)
-    cons.take(i, x, y, z, la, lbb, lc, lo.path, lo.E, vJss, vJpp, vJsr, vJsi, vst, vEsr, vEsi,
-              vEpr, vEpi, has_amp);
   return res;
 }
 
@@ -3517,21 +3639,7 @@ __device__ __forceinline__ void pass_through(const xrt_hip_pass& P, const xrt_hi
     copy_ray<optional_local<K>()>(lb, in, i, st, has_amp, false);
   int vst = P.force_lost_out ? P.lost_num : st;
   if constexpr (CONS::ON) {
-    const xrt_hip_beam& s = restore;
-    const double2 js = reinterpret_cast<const double2*>(s.Jsp_ri)[i];
-    double2 es = make_double2(0., 0.), ep = make_double2(0., 0.);
-    if (has_amp) {
-      es = reinterpret_cast<const double2*>(s.Es_ri)[i];
-      ep = reinterpret_cast<const double2*>(s.Ep_ri)[i];
-    }
-    const double x = s.x[i], y = s.y[i], z = s.z[i], a = s.a[i], b = s.b[i], c = s.c[i];
-    const double path = s.path[i], E = s.E[i], Jss = s.Jss[i], Jpp = s.Jpp[i];
-    vst = cons.mark(x, y, z, a, b, c, vst);
-    if (vb.x)
-      store_ray(vb, i, x, y, z, a, b, c, path, E, Jss, Jpp, js.x, js.y, vst, es.x, es.y, ep.x,
-                ep.y, has_amp);
-    cons.take(i, x, y, z, a, b, c, path, E, Jss, Jpp, js.x, js.y, vst, es.x, es.y, ep.x, ep.y,
-              has_amp);
+    copy_marked(cons, restore, i, vst, has_amp);
   } else {
     copy_ray(vb, restore, i, vst, has_amp, false);
   }
@@ -3694,19 +3802,81 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
 // The same pass with a screen in its tail: OE.reflect whose global beam goes straight into
 // Screen.expose. `vb` with null arrays: the global beam itself is not wanted (nothing but the
 // screen reads it). The optimistic form only (mode 0 / 2): a contradicted pass is redone by
-// reflect_redo_scr into the real `vb`, which then makes the image from that.
+// reflect_redo_scr into the real `vb`, which then makes the image from that. ONE record of
+// arguments for the four kernels with a tail, so that the tail's members can be read late
+// (kernarg_at; `vb`, `scr` and `Q` are never named in the kernels).
+struct FusedTailArgs {
+  xrt_hip_pass P;
+  xrt_hip_material M;
+  xrt_hip_geosource G;         // (the kernels with the source in their head)
+  xrt_hip_beam in, restore, lb, vb;
+  double* theta;
+  const GStat* gp;
+  OptStat* opt;
+  ScreenConsumer scr;
+  PlotTail Q;                  // (the kernels with a plot behind the screen)
+};
+// (what fused_ray is given in vb's place: never looked at when a consumer rides)
+__device__ __forceinline__ xrt_hip_beam no_beam_here() {
+  xrt_hip_beam b = {};
+  return b;
+}
+
+// The lean kernels' plain pass on the same record (the headline kernels of reflect_hot.hip):
+// nothing behind the element, the global beam's array pointers read where the record is stored.
+template <class K, int mode>
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_late(
+    FusedTailArgs A) {
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
+#ifdef XRT_LATE_FIELDS
+  const RayRequest req = request_ray<false>(A.in, i, A.in.Es_ri != nullptr);
+#else
+  const RayRequest req = request_ray<early_fields<K>()>(A.in, i, A.in.Es_ri != nullptr);
+#endif
+  if (fused_skips(A.gp, mode)) return;
+  const GStat g = *A.gp;
+  int neg = 0, pos = 0;
+  const LatePlain cons{XRT_TAIL_AT(FusedTailArgs, vb)};
+  fused_ray<K, mode, false, LatePlain>(A.P, A.M, A.in, A.restore, A.lb, no_beam_here(), A.theta, g,
+                                       A.opt, i, req, neg, pos, cons);
+}
+
 template <class K, int mode>
 __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_scr(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
-    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
-    OptStat* __restrict__ opt, ScreenConsumer cons) {
+    FusedTailArgs A) {
   const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
-  const RayRequest req = request_ray<early_fields<K>()>(in, i, in.Es_ri != nullptr);
-  if (fused_skips(gp, mode)) return;
-  const GStat g = *gp;
+  const RayRequest req = request_ray<early_fields<K>()>(A.in, i, A.in.Es_ri != nullptr);
+  if (fused_skips(A.gp, mode)) return;
+  const GStat g = *A.gp;
   int neg = 0, pos = 0;
-  fused_ray<K, mode, false, ScreenConsumer>(P, M, in, restore, lb, vb, theta, g, opt, i, req,
-                                            neg, pos, cons);
+  const LateScreen cons{XRT_TAIL_AT(FusedTailArgs, vb)};
+  fused_ray<K, mode, false, LateScreen>(A.P, A.M, A.in, A.restore, A.lb, no_beam_here(), A.theta,
+                                        g, A.opt, i, req, neg, pos, cons);
+}
+
+// the source's ray of this lane as the pass's request (source_impl.h)
+__device__ __forceinline__ RayRequest made_request(const xrt_hip_geosource& G, int64_t i,
+                                                   int64_t n, bool has_amp) {
+  const gen::GenRay made = gen::make_ray(G, gen::call_of(G), i < n ? i : 0, has_amp);
+  RayRequest req;
+  req.st0 = i < n ? G.state : 0;
+  req.raw.x = made.x;
+  req.raw.y = made.y;
+  req.raw.z = made.z;
+  req.raw.a = made.a;
+  req.raw.b = made.b;
+  req.raw.c = made.c;
+  req.q.path = 0.;
+  req.q.E = made.E;
+  req.q.Jss = made.r.Jss;
+  req.q.Jpp = made.r.Jpp;
+  req.q.Jsr = made.r.Jre;
+  req.q.Jsi = made.r.Jim;
+  req.q.Esr = has_amp ? made.r.Esr : 0.;
+  req.q.Esi = has_amp ? made.r.Esi : 0.;
+  req.q.Epr = has_amp ? made.r.Epr : 0.;
+  req.q.Epi = has_amp ? made.r.Epi : 0.;
+  return req;
 }
 
 // ... and with the SOURCE in its head: GeometricSource.shine -> OE.reflect -> Screen.expose as one
@@ -3716,91 +3886,50 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_s
 // (geosource_shine_if_redo). Every ray of a source has the same state (> 0: all enter).
 template <class K>
 __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_gen_scr(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_geosource G, xrt_hip_beam in, xrt_hip_beam lb,
-    xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp, OptStat* __restrict__ opt,
-    ScreenConsumer cons) {
+    FusedTailArgs A) {
   const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
-  if (fused_skips(gp, 0)) return;
-  const bool has_amp = in.Es_ri != nullptr;
-  const gen::GenRay made = gen::make_ray(G, gen::call_of(G), i < in.n ? i : 0, has_amp);
-  RayRequest req;
-  req.st0 = i < in.n ? G.state : 0;
-  req.raw.x = made.x;
-  req.raw.y = made.y;
-  req.raw.z = made.z;
-  req.raw.a = made.a;
-  req.raw.b = made.b;
-  req.raw.c = made.c;
-  req.q.path = 0.;
-  req.q.E = made.E;
-  req.q.Jss = made.r.Jss;
-  req.q.Jpp = made.r.Jpp;
-  req.q.Jsr = made.r.Jre;
-  req.q.Jsi = made.r.Jim;
-  req.q.Esr = has_amp ? made.r.Esr : 0.;
-  req.q.Esi = has_amp ? made.r.Esi : 0.;
-  req.q.Epr = has_amp ? made.r.Epr : 0.;
-  req.q.Epi = has_amp ? made.r.Epi : 0.;
-  const GStat g = *gp;
+  if (fused_skips(A.gp, 0)) return;
+  const RayRequest req = made_request(A.G, i, A.in.n, A.in.Es_ri != nullptr);
+  const GStat g = *A.gp;
   int neg = 0, pos = 0;
-  fused_ray<K, 0, false, ScreenConsumer>(P, M, in, in, lb, vb, theta, g, opt, i, req, neg, pos,
-                                         cons);
+  const LateScreen cons{XRT_TAIL_AT(FusedTailArgs, vb)};
+  fused_ray<K, 0, false, LateScreen>(A.P, A.M, A.in, A.in, A.lb, no_beam_here(), A.theta, g, A.opt,
+                                     i, req, neg, pos, cons);
 }
 
-// ... and with the plot of that image behind the screen (ScreenPlotConsumer): OE.reflect ->
+// ... and with the plot of that image behind the screen (LateScreenPlot): OE.reflect ->
 // Screen.expose -> accumulate_plot as one pass; `scr.out` with null arrays: the image itself is
 // not wanted either. The wave writes its rays' plot records when the pass is through.
 template <class K, int mode>
 __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_scr_plot(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
-    xrt_hip_beam lb, xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp,
-    OptStat* __restrict__ opt, ScreenConsumer scr, PlotTail Q) {
+    FusedTailArgs A) {
   const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
-  const RayRequest req = request_ray<early_fields<K>()>(in, i, in.Es_ri != nullptr);
-  if (fused_skips(gp, mode)) return;
-  const GStat g = *gp;
+  const RayRequest req = request_ray<early_fields<K>()>(A.in, i, A.in.Es_ri != nullptr);
+  if (fused_skips(A.gp, mode)) return;
+  const GStat g = *A.gp;
   int neg = 0, pos = 0;
-  PlotStash stash = no_plot_ray(Q);
-  const ScreenPlotConsumer cons{scr.S, scr.out, Q, &stash, scr.ap};
-  fused_ray<K, mode, false, ScreenPlotConsumer>(P, M, in, restore, lb, vb, theta, g, opt, i, req,
-                                                neg, pos, cons);
-  plot_tail_emit(Q, i >> 6, stash);
+  const TailAt at = XRT_TAIL_AT(FusedTailArgs, vb);
+  PlotStash stash = no_plot_ray(kernarg_at<PlotTail>(at.Q));
+  const LateScreenPlot cons{at, &stash};
+  fused_ray<K, mode, false, LateScreenPlot>(A.P, A.M, A.in, A.restore, A.lb, no_beam_here(),
+                                            A.theta, g, A.opt, i, req, neg, pos, cons);
+  plot_tail_emit(kernarg_at<PlotTail>(at.Q), i >> 6, stash);
 }
 
 template <class K>
 __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_gen_scr_plot(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_geosource G, xrt_hip_beam in, xrt_hip_beam lb,
-    xrt_hip_beam vb, double* theta, const GStat* __restrict__ gp, OptStat* __restrict__ opt,
-    ScreenConsumer scr, PlotTail Q) {
+    FusedTailArgs A) {
   const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
-  if (fused_skips(gp, 0)) return;
-  const bool has_amp = in.Es_ri != nullptr;
-  const gen::GenRay made = gen::make_ray(G, gen::call_of(G), i < in.n ? i : 0, has_amp);
-  RayRequest req;
-  req.st0 = i < in.n ? G.state : 0;
-  req.raw.x = made.x;
-  req.raw.y = made.y;
-  req.raw.z = made.z;
-  req.raw.a = made.a;
-  req.raw.b = made.b;
-  req.raw.c = made.c;
-  req.q.path = 0.;
-  req.q.E = made.E;
-  req.q.Jss = made.r.Jss;
-  req.q.Jpp = made.r.Jpp;
-  req.q.Jsr = made.r.Jre;
-  req.q.Jsi = made.r.Jim;
-  req.q.Esr = has_amp ? made.r.Esr : 0.;
-  req.q.Esi = has_amp ? made.r.Esi : 0.;
-  req.q.Epr = has_amp ? made.r.Epr : 0.;
-  req.q.Epi = has_amp ? made.r.Epi : 0.;
-  const GStat g = *gp;
+  if (fused_skips(A.gp, 0)) return;
+  const RayRequest req = made_request(A.G, i, A.in.n, A.in.Es_ri != nullptr);
+  const GStat g = *A.gp;
   int neg = 0, pos = 0;
-  PlotStash stash = no_plot_ray(Q);
-  const ScreenPlotConsumer cons{scr.S, scr.out, Q, &stash, scr.ap};
-  fused_ray<K, 0, false, ScreenPlotConsumer>(P, M, in, in, lb, vb, theta, g, opt, i, req, neg,
-                                             pos, cons);
-  plot_tail_emit(Q, i >> 6, stash);
+  const TailAt at = XRT_TAIL_AT(FusedTailArgs, vb);
+  PlotStash stash = no_plot_ray(kernarg_at<PlotTail>(at.Q));
+  const LateScreenPlot cons{at, &stash};
+  fused_ray<K, 0, false, LateScreenPlot>(A.P, A.M, A.in, A.in, A.lb, no_beam_here(), A.theta, g,
+                                         A.opt, i, req, neg, pos, cons);
+  plot_tail_emit(kernarg_at<PlotTail>(at.Q), i >> 6, stash);
 }
 
 // ---------------------------------------------------------------------------
@@ -4416,13 +4545,7 @@ __device__ __forceinline__ void fused_dcm_ray(
       if (theta2) theta2[i] = 0.;
       const int vst = P2.force_lost_out ? P2.lost_num : v.st;
       if constexpr (CONS::ON) {
-        // (the original record is still in registers: req)
-        const int mst = cons.mark(r_in.x, r_in.y, r_in.z, r_in.a, r_in.b, r_in.c, vst);
-        if (gb2.x)
-          store_ray(gb2, i, r_in.x, r_in.y, r_in.z, r_in.a, r_in.b, r_in.c, q0.path, q0.E, q0.Jss,
-                    q0.Jpp, q0.Jsr, q0.Jsi, mst, q0.Esr, q0.Esi, q0.Epr, q0.Epi, has_amp);
-        cons.take(i, r_in.x, r_in.y, r_in.z, r_in.a, r_in.b, r_in.c, q0.path, q0.E, q0.Jss, q0.Jpp,
-                  q0.Jsr, q0.Jsi, mst, q0.Esr, q0.Esi, q0.Epr, q0.Epi, has_amp);
+        copy_marked(cons, in, i, vst, has_amp);
       } else {
         copy_ray(gb2, in, i, vst, has_amp, false);
       }
@@ -4432,6 +4555,7 @@ __device__ __forceinline__ void fused_dcm_ray(
   raise_sign_flags(flags2, seen2n, seen2p, neg2, pos2);
 }
 
+#ifdef XRT_DCM_EARLY_ARGS       // (A/B: the arguments one by one, all loaded in the entry block)
 template <class K>
 __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
     xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2,
@@ -4442,20 +4566,50 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(
   fused_dcm_ray<K, NoConsumer>(P1, M1, P2, M2, in, lo1, lo2, gb2, theta1, theta2, g1p, g2p, flags1,
                                flags2, opt1, opt2, NoConsumer());
 }
+#endif
 
 // DCM.double_reflect with apertures and / or a screen right behind the monochromator in its tail
 // (dcm.py:248-354 -> apertures.py:334-413 -> screens.py:226-302): the marks and the image are made
 // from the outgoing record in registers; gb2 with null arrays = nobody else wants the global beam.
 // A contradicted pass is redone by reflect_dcm_redo_scr into the real gb2, marks and image from that.
+// One record of arguments (see FusedTailArgs): `gb2` and `scr` are read where they are used.
+struct DcmTailArgs {
+  xrt_hip_pass P1;
+  xrt_hip_material M1;
+  xrt_hip_pass P2;
+  xrt_hip_material M2;
+  xrt_hip_beam in, lo1, lo2, gb2;
+  double *theta1, *theta2;
+  const GStat *g1p, *g2p;
+  int *flags1, *flags2;
+  OptStat *opt1, *opt2;
+  ScreenConsumer scr;
+  int Q;                       // (no plot behind a DCM's screen: XRT_TAIL_AT's last member)
+};
+#ifndef XRT_DCM_EARLY_ARGS
+// (the plain pass of the pair: the same record, nothing behind the second crystal)
 template <class K>
-__global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm_scr(
-    xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2,
-    xrt_hip_beam in, xrt_hip_beam lo1, xrt_hip_beam lo2, xrt_hip_beam gb2, double* theta1,
-    double* theta2, const GStat* __restrict__ g1p, const GStat* __restrict__ g2p,
-    int* __restrict__ flags1, int* __restrict__ flags2, OptStat* __restrict__ opt1,
-    OptStat* __restrict__ opt2, ScreenConsumer cons) {
-  fused_dcm_ray<K, ScreenConsumer>(P1, M1, P2, M2, in, lo1, lo2, gb2, theta1, theta2, g1p, g2p,
-                                   flags1, flags2, opt1, opt2, cons);
+__global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm(DcmTailArgs A) {
+  const LatePlain cons{XRT_TAIL_AT(DcmTailArgs, gb2)};
+  fused_dcm_ray<K, LatePlain>(A.P1, A.M1, A.P2, A.M2, A.in, A.lo1, A.lo2, no_beam_here(), A.theta1,
+                              A.theta2, A.g1p, A.g2p, A.flags1, A.flags2, A.opt1, A.opt2, cons);
+}
+#endif
+template <class K>
+__global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm_scr(DcmTailArgs A) {
+  const LateScreen cons{XRT_TAIL_AT(DcmTailArgs, gb2)};
+  fused_dcm_ray<K, LateScreen>(A.P1, A.M1, A.P2, A.M2, A.in, A.lo1, A.lo2, no_beam_here(),
+                               A.theta1, A.theta2, A.g1p, A.g2p, A.flags1, A.flags2, A.opt1, A.opt2,
+                               cons);
+}
+
+// ... with apertures alone behind it (the slit behind a monochromator whose beam goes on to the
+// next element): no image arithmetic in the kernel, the marks after the stores (LateMarks)
+template <class K>
+__global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm_marks(DcmTailArgs A) {
+  const LateMarks cons{XRT_TAIL_AT(DcmTailArgs, gb2)};
+  fused_dcm_ray<K, LateMarks>(A.P1, A.M1, A.P2, A.M2, A.in, A.lo1, A.lo2, no_beam_here(), A.theta1,
+                              A.theta2, A.g1p, A.g2p, A.flags1, A.flags2, A.opt1, A.opt2, cons);
 }
 
 // Plate.double_refract (oes/refractive.py:171-235 = dcm.py:248-354 with the plate's two faces):
@@ -4464,11 +4618,26 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_dcm_scr(
 // beams. The structure of reflect_fused_dcm without anything a crystal needs; decisions, reports
 // and the redo (reflect_dcm_exact) are the DCM's.
 template <class K>
+#ifdef XRT_DCM_EARLY_ARGS
 __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_plate2(
     xrt_hip_pass P1, xrt_hip_material M1, xrt_hip_pass P2, xrt_hip_material M2,
     xrt_hip_beam in, xrt_hip_beam lo1, xrt_hip_beam lo2, xrt_hip_beam gb2, double* theta1,
     double* theta2, const GStat* __restrict__ g1p, const GStat* __restrict__ g2p,
     OptStat* __restrict__ opt1, OptStat* __restrict__ opt2) {
+  const NoConsumer cons{};
+#else
+__global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_plate2(DcmTailArgs A) {
+  // (the pair's record; the global beam's array pointers are read where the record is stored)
+  const xrt_hip_pass &P1 = A.P1, &P2 = A.P2;
+  const xrt_hip_material &M1 = A.M1, &M2 = A.M2;
+  const xrt_hip_beam &in = A.in, &lo1 = A.lo1, &lo2 = A.lo2;
+  const xrt_hip_beam gb2 = no_beam_here();
+  double *theta1 = A.theta1, *theta2 = A.theta2;
+  const GStat *g1p = A.g1p, *g2p = A.g2p;
+  OptStat *opt1 = A.opt1, *opt2 = A.opt2;
+  const LatePlain cons{XRT_TAIL_AT(DcmTailArgs, gb2)};
+#endif
+  typedef typename std::remove_const<decltype(cons)>::type Cons;
   const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
   const bool has_amp = in.Es_ri != nullptr;
   const bool live = i < in.n;
@@ -4559,8 +4728,8 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_plate2(
     if (active) {
       int st = rays_good<K>(P2, h.x, h.y);
       if (h.lost) st = P2.lost_num;
-      complete_ray<K, true>(P2, M2, g, in, in, lo2, gb2, theta2, i, r, h, st, has_amp, 0, nullptr,
-                            v.f, npre);
+      complete_ray<K, true, false, Cons>(P2, M2, g, in, in, lo2, gb2, theta2, i, r, h, st, has_amp, 0,
+                                         nullptr, v.f, npre, nullptr, nullptr, false, nullptr, cons);
     } else if (live) {
       // (as the DCM: the local record of a ray that never reached the face is zeroed, the
       // global beam gets the ORIGINAL ray back)
@@ -4568,7 +4737,11 @@ __global__ __launch_bounds__(REFLECT_DCM_BLOCK, 4) void reflect_fused_plate2(
         store_rec(lo2, i, v, P2.zero_local_not_entering ? 0 : v.st, has_amp,
                   P2.zero_local_not_entering != 0);
       if (theta2) theta2[i] = 0.;
-      copy_ray(gb2, in, i, P2.force_lost_out ? P2.lost_num : v.st, has_amp, false);
+      const int vst = P2.force_lost_out ? P2.lost_num : v.st;
+      if constexpr (Cons::ON)
+        copy_marked(cons, in, i, vst, has_amp);
+      else
+        copy_ray(gb2, in, i, vst, has_amp, false);
     }
   }
 }

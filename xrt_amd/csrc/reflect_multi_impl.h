@@ -467,9 +467,197 @@ __global__ __launch_bounds__(REFLECT_BLOCK) void multi_decide_opt(
   decide_opt_body(P, M, in, slots, A.g, lds_u, ub_lo, ub_hi, dir0);
 }
 
+// The arguments as ONE record, read phase by phase where they are used (reflect_impl.h:
+// kernarg_at). Loaded in the entry block -- pass, material, two beams, the bounce's record: 570
+// dwords for 100 SGPRs -- they lived in VGPR lanes: 2744 v_writelane / v_readlane among the
+// kernel's 12074 VALU instructions, 600 of them inside the hit search's loop
+// (profiles/r06_sgpr_late_ab.txt).
+struct MultiArgs {
+  xrt_hip_pass P;
+  xrt_hip_material M;
+  xrt_hip_beam in, out;
+  MultiAux A;
+};
+#ifndef XRT_MULTI_EARLY_ARGS
 template <class K>
 __global__ __launch_bounds__(REFLECT_MULTI_BLOCK, REFLECT_MULTI_PER_CU) void reflect_multi_opt(
-    xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam out, MultiAux A) {
+    MultiArgs R) {
+  __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
+  constexpr unsigned oP = (unsigned)offsetof(MultiArgs, P), oM = (unsigned)offsetof(MultiArgs, M);
+  constexpr unsigned oIn = (unsigned)offsetof(MultiArgs, in);
+  constexpr unsigned oOut = (unsigned)offsetof(MultiArgs, out);
+  constexpr unsigned oA = (unsigned)offsetof(MultiArgs, A);
+  if (!R.A.g->optimistic) return;           // nothing could be assumed: reflect_multi does the bounce
+  const GStat g = *R.A.g;
+  const int64_t n = R.in.n;
+  const bool has_amp = R.in.Es_ri != nullptr;
+  const bool is_multi = R.P.is_multi != 0;
+  const bool elevate = R.A.elev_out[0] != nullptr;
+  const int assume = R.A.assume;
+  unsigned long long kept = 0, hit = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
+    const int64_t i = base + threadIdx.x;
+    const bool live = i < n;
+    const int64_t j = live ? i : n - 1;
+    LocalRay raw;
+    int st0;
+    bool active;
+    {
+      const xrt_hip_beam& in = kernarg_at<xrt_hip_beam>(oIn);
+      st0 = live ? in.state[j] : 0;
+      raw.x = in.x[j];
+      raw.y = in.y[j];
+      raw.z = in.z[j];
+      raw.a = in.a[j];
+      raw.b = in.b[j];
+      raw.c = in.c[j];
+      active = live && entering(kernarg_at<xrt_hip_pass>(oP), st0);
+    }
+    SolveAux aux1, aux2;
+    int viol = 0;
+    if (live && !active) {
+      const xrt_hip_beam& in = kernarg_at<xrt_hip_beam>(oIn);
+      const xrt_hip_beam& out = kernarg_at<xrt_hip_beam>(oOut);
+      const MultiAux& A = kernarg_at<MultiAux>(oA);
+      const int nr0 = A.nrefl_in ? A.nrefl_in[i] : 0;
+      copy_ray(out, in, i, st0, has_amp, false);
+      A.nrefl_out[i] = nr0;
+      A.theta[i] = 0.;
+      if (elevate) {
+        const double el0[4] = {-1., -kMaxHalfSize, -kMaxHalfSize, -kMaxHalfSize};
+        for (int k = 0; k < 4; ++k) A.elev_out[k][i] = A.elev_in[0] ? A.elev_in[k][i] : el0[k];
+      }
+      if (A.spr[0]) {   // reflect.py:1067-1069: copies of lb.x, y, z as they are
+        A.spr[0][i] = raw.x;
+        A.spr[1][i] = raw.y;
+        A.spr[2][i] = raw.z;
+      }
+    }
+    if (active) {
+      int nr0;
+      double el[4] = {-1., -kMaxHalfSize, -kMaxHalfSize, -kMaxHalfSize};   // reflect.py:214-218
+      {
+        const MultiAux& A = kernarg_at<MultiAux>(oA);
+        nr0 = A.nrefl_in ? A.nrefl_in[i] : 0;
+        if (elevate && A.elev_in[0])
+          for (int k = 0; k < 4; ++k) el[k] = A.elev_in[k][i];
+      }
+      double vx, vy, vz, t1, t2;
+      LocalRay r;
+      {
+        const xrt_hip_pass& P = kernarg_at<xrt_hip_pass>(oP);
+        r = multi_local(P, raw, vx, vy, vz);
+        // the axis stands only if its cosine dominates every state-1 ray's own (fused_ray)
+        viol = st0 == 1 && !dominates(g.axis, r);
+        bracket(P, g.axis, g.positive, r.x, r.y, r.z, r.a, r.b, r.c, t1, t2);
+      }
+      if (is_multi) {
+        const xrt_hip_pass& P = kernarg_at<xrt_hip_pass>(oP);
+        const Hit hp = solve_between<K, 1, true>(P, r, 0., t2, 0., 0., (assume & 2) != 0, &aux1);
+        const double tg = hp.t;
+        if (elevate) {   // base.py:1284-1286, reflect.py:651-659: find_dz at the tangency point
+          const xrt_hip_pass& Pe = kernarg_at<xrt_hip_pass>(oP);
+          double ex, ey, ez;
+          el[0] = multi_f<K, 0>(Pe, tg, r, ex, ey, ez);
+          if (surf_is_param<K>(Pe)) {
+            double cx, cy, cz;
+            ell_param_to_xyz(Pe, ex, ey, ez, cx, cy, cz);
+            ex = cx;
+            ey = cy;
+            ez = cz;
+          }
+          el[1] = ex;
+          el[2] = ey;
+          el[3] = ez;
+        }
+        t1 = tg + kDs;
+      }
+      Hit h;
+      {
+        const xrt_hip_pass& P = kernarg_at<xrt_hip_pass>(oP);
+        h = solve_between<K, 0, true>(P, r, t1, t2, 0., 0., (assume & 1) != 0, &aux2);
+      }
+      const double hs = h.x, hphi = h.y, hr = h.z;
+      const xrt_hip_pass& P = kernarg_at<xrt_hip_pass>(oP);
+      hit_done<K>(P, h);
+      int st = rays_good<K>(P, h.x, h.y);
+      if (h.lost) st = P.lost_num;
+      const xrt_hip_beam& in = kernarg_at<xrt_hip_beam>(oIn);
+      RayIn q;
+      q.path = in.path[i];
+      q.E = in.E[i];
+      double a = r.a, b = r.b, c = r.c, th = 0.;
+      if (st == 1) {
+        const Finished fin =
+            finish_ray<K>(P, kernarg_at<xrt_hip_material>(oM), g, r, h, q, in, i, has_amp);
+        a = fin.a;
+        b = fin.b;
+        c = fin.c;
+        th = fin.theta;
+        q = fin.lo;                 // (path + t, E)
+        q.Jss = fin.vJss;           // lb is vlb: the matrix turned back is what stays
+        q.Jpp = fin.vJpp;           // (reflect.py:1106-1110)
+        q.Jsr = fin.vJsr;
+        q.Jsi = fin.vJsi;
+        q.Esr = fin.vEsr;
+        q.Esi = fin.vEsi;
+        q.Epr = fin.vEpr;
+        q.Epi = fin.vEpi;
+      } else {
+        load_fields(in, i, has_amp, q);
+      }
+      // back to the virgin local frame (reflect.py:1115-1132), every entering ray
+      const xrt_hip_pass& Pv = kernarg_at<xrt_hip_pass>(oP);
+      double x = h.x + Pv.shift[0], y = h.y + Pv.shift[1], z = h.z + Pv.shift[2];
+      rotate3(Pv.to_virgin, x, y, z);
+      rotate3(Pv.to_virgin, a, b, c);
+      if (st == 3) {                // reflect.py:225-228
+        x = vx;
+        y = vy;
+        z = vz;
+      }
+      const xrt_hip_beam& out = kernarg_at<xrt_hip_beam>(oOut);
+      const MultiAux& A = kernarg_at<MultiAux>(oA);
+      store_ray(out, i, x, y, z, a, b, c, q.path, q.E, q.Jss, q.Jpp, q.Jsr, q.Jsi, st, q.Esr,
+                q.Esi, q.Epr, q.Epi, has_amp);
+      const bool good = st == 1 || st == 2;
+      A.nrefl_out[i] = nr0 + (good ? 1 : 0);
+      A.theta[i] = th;
+      if (elevate)
+        for (int k = 0; k < 4; ++k) A.elev_out[k][i] = el[k];
+      if (A.spr[0]) {
+        A.spr[0][i] = hs;
+        A.spr[1][i] = hphi;
+        A.spr[2][i] = hr;
+      }
+      kept += good;
+      hit += st == 1;
+    }
+    // all lanes of the wave together again: the reports (the tangency search's, the hit search's)
+    OptStat* slots1 = reinterpret_cast<OptStat*>(kernarg_at<MultiAux>(oA).part);
+    OptStat* slots2 = slots1 + MULTI_SLOTS2;
+    if (is_multi) report_opt(slots1, aux1, viol);
+    report_opt(is_multi ? slots2 : slots1, aux2, is_multi ? 0 : viol);
+  }
+  auto faddu = [](unsigned long long u, unsigned long long v) { return u + v; };
+  kept = block_reduce(kept, faddu, lds_u);
+  hit = block_reduce(hit, faddu, lds_u);
+  if (threadIdx.x == 0) {
+    unsigned long long* counts = kernarg_at<MultiAux>(oA).counts;
+    if (kept) (void)atomicAdd(&counts[0], kept);
+    if (hit) (void)atomicAdd(&counts[1], hit);
+  }
+}
+#else
+template <class K>
+__global__ __launch_bounds__(REFLECT_MULTI_BLOCK, REFLECT_MULTI_PER_CU) void reflect_multi_opt(
+    MultiArgs R) {
+  // (A/B: every argument named, all loaded in the entry block)
+  const xrt_hip_pass& P = R.P;
+  const xrt_hip_material& M = R.M;
+  const xrt_hip_beam &in = R.in, &out = R.out;
+  const MultiAux& A = R.A;
   __shared__ unsigned long long lds_u[REFLECT_MAX_WAVES];
   if (!A.g->optimistic) return;             // nothing could be assumed: reflect_multi does the bounce
   const GStat g = *A.g;
@@ -603,6 +791,7 @@ __global__ __launch_bounds__(REFLECT_MULTI_BLOCK, REFLECT_MULTI_PER_CU) void ref
     if (hit) (void)atomicAdd(&A.counts[1], hit);
   }
 }
+#endif
 
 // The launch is preceded by reflect_init(g, 1) (decisions reset, barrier counter zeroed).
 template <class K>
@@ -1417,8 +1606,15 @@ inline int launch_multi_opt_k(const MultiLaunch& L) {
   const int64_t cap = (int64_t)L.cus * per_cu;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
+  MultiArgs R;
+  memset(&R, 0, sizeof(R));
+  R.P = *L.P;
+  R.M = *L.M;
+  R.in = *L.in;
+  R.out = *L.out;
+  R.A = L.A;
   hipLaunchKernelGGL(reflect_multi_opt<K>, dim3((unsigned)blocks), dim3(REFLECT_MULTI_BLOCK), 0,
-                     L.st, *L.P, *L.M, *L.in, *L.out, L.A);
+                     L.st, R);
   return launch_multi_dense_k<K>(L);       // (A.gate set: returns at once unless contradicted)
 }
 

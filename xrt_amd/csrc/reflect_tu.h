@@ -3,6 +3,8 @@
 // change to the hot kernels recompiles one small file. Each unit exports plain launchers;
 // reflect.hip picks the unit by the spec id.
 #pragma once
+#include <string.h>
+
 #include "reflect_impl.h"
 
 namespace xrt {
@@ -111,49 +113,70 @@ inline void launch_fused_k(int mode, const FusedLaunch& L) {
     hipLaunchKernelGGL((reflect_fused<K, 2>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
                        *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt);
 }
+// the argument record of the kernels with a tail (reflect_impl.h: FusedTailArgs)
+inline FusedTailArgs fused_tail_args(const FusedLaunch& L) {
+  FusedTailArgs A;
+  memset(&A, 0, sizeof(A));
+  A.P = *L.P;
+  A.M = *L.M;
+  if (L.src) A.G = *L.src;
+  A.in = *L.in;
+  A.restore = *L.restore;
+  A.lb = *L.lb;
+  A.vb = *L.vb;
+  A.theta = L.theta;
+  A.gp = L.g;
+  A.opt = L.opt;
+  A.scr.S = *L.scr;
+  A.scr.out = *L.sb;
+  A.scr.ap = *L.ap;
+  if (L.plot) A.Q = *L.plot;
+  return A;
+}
+// (the plain pass of the lean kernels on the record: scr, G, Q left zero)
+template <class K>
+inline void launch_fused_late_k(int mode, const FusedLaunch& L) {
+  FusedTailArgs A;
+  memset(&A, 0, sizeof(A));
+  A.P = *L.P;
+  A.M = *L.M;
+  A.in = *L.in;
+  A.restore = *L.restore;
+  A.lb = *L.lb;
+  A.vb = *L.vb;
+  A.theta = L.theta;
+  A.gp = L.g;
+  A.opt = L.opt;
+  if (mode == 0)
+    hipLaunchKernelGGL((reflect_fused_late<K, 0>), L.grid, L.block, 0, L.st, A);
+  else
+    hipLaunchKernelGGL((reflect_fused_late<K, 2>), L.grid, L.block, 0, L.st, A);
+}
 template <class K>
 inline void launch_fused_scr_k(int mode, const FusedLaunch& L) {
-  ScreenConsumer cons;
-  cons.S = *L.scr;
-  cons.out = *L.sb;
-  cons.ap = *L.ap;
+  const FusedTailArgs A = fused_tail_args(L);
   if (mode == 0)
-    hipLaunchKernelGGL((reflect_fused_scr<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
-                       *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt, cons);
+    hipLaunchKernelGGL((reflect_fused_scr<K, 0>), L.grid, L.block, 0, L.st, A);
   else
-    hipLaunchKernelGGL((reflect_fused_scr<K, 2>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
-                       *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt, cons);
+    hipLaunchKernelGGL((reflect_fused_scr<K, 2>), L.grid, L.block, 0, L.st, A);
 }
 template <class K>
 inline void launch_fused_gen_scr_k(const FusedLaunch& L) {
-  ScreenConsumer cons;
-  cons.S = *L.scr;
-  cons.out = *L.sb;
-  cons.ap = *L.ap;
-  hipLaunchKernelGGL(reflect_fused_gen_scr<K>, L.grid, L.block, 0, L.st, *L.P, *L.M, *L.src, *L.in,
-                     *L.lb, *L.vb, L.theta, L.g, L.opt, cons);
+  const FusedTailArgs A = fused_tail_args(L);
+  hipLaunchKernelGGL(reflect_fused_gen_scr<K>, L.grid, L.block, 0, L.st, A);
 }
 template <class K>
 inline void launch_fused_scr_plot_k(int mode, const FusedLaunch& L) {
-  ScreenConsumer cons;
-  cons.S = *L.scr;
-  cons.out = *L.sb;
-  cons.ap = *L.ap;
+  const FusedTailArgs A = fused_tail_args(L);
   if (mode == 0)
-    hipLaunchKernelGGL((reflect_fused_scr_plot<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
-                       *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt, cons, *L.plot);
+    hipLaunchKernelGGL((reflect_fused_scr_plot<K, 0>), L.grid, L.block, 0, L.st, A);
   else
-    hipLaunchKernelGGL((reflect_fused_scr_plot<K, 2>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
-                       *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt, cons, *L.plot);
+    hipLaunchKernelGGL((reflect_fused_scr_plot<K, 2>), L.grid, L.block, 0, L.st, A);
 }
 template <class K>
 inline void launch_fused_gen_scr_plot_k(const FusedLaunch& L) {
-  ScreenConsumer cons;
-  cons.S = *L.scr;
-  cons.out = *L.sb;
-  cons.ap = *L.ap;
-  hipLaunchKernelGGL(reflect_fused_gen_scr_plot<K>, L.grid, L.block, 0, L.st, *L.P, *L.M, *L.src,
-                     *L.in, *L.lb, *L.vb, L.theta, L.g, L.opt, cons, *L.plot);
+  const FusedTailArgs A = fused_tail_args(L);
+  hipLaunchKernelGGL(reflect_fused_gen_scr_plot<K>, L.grid, L.block, 0, L.st, A);
 }
 template <class K>
 inline void launch_xtal_k(int mode, const FusedLaunch& L) {
@@ -169,28 +192,61 @@ inline void launch_exact_k(const ExactLaunch& L) {
   hipLaunchKernelGGL(reflect_exact<K>, L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in, *L.restore,
                      *L.lb, *L.vb, L.A);
 }
+// the argument record of the pair's kernels (reflect_impl.h: DcmTailArgs); scr left zero
+inline DcmTailArgs dcm_tail_args(const DcmLaunch& L, const xrt_hip_beam& gb2) {
+  DcmTailArgs A;
+  memset(&A, 0, sizeof(A));
+  A.P1 = *L.P1;
+  A.M1 = *L.M1;
+  A.P2 = *L.P2;
+  A.M2 = *L.M2;
+  A.in = *L.in;
+  A.lo1 = *L.lo1;
+  A.lo2 = *L.lo2;
+  A.gb2 = gb2;
+  A.theta1 = L.theta1;
+  A.theta2 = L.theta2;
+  A.g1p = L.g1;
+  A.g2p = L.g2;
+  A.flags1 = &L.g1->any_neg;
+  A.flags2 = &L.g2->any_neg;
+  A.opt1 = L.opt1;
+  A.opt2 = L.opt2;
+  return A;
+}
 template <class K>
 inline void launch_dcm_k(const DcmLaunch& L) {
+#ifdef XRT_DCM_EARLY_ARGS
   hipLaunchKernelGGL(reflect_fused_dcm<K>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2, *L.M2,
                      *L.in, *L.lo1, *L.lo2, *L.gb2, L.theta1, L.theta2, L.g1, L.g2,
                      &L.g1->any_neg, &L.g2->any_neg, L.opt1, L.opt2);
+#else
+  const DcmTailArgs A = dcm_tail_args(L, *L.gb2);
+  hipLaunchKernelGGL(reflect_fused_dcm<K>, L.grid, L.block, 0, L.st, A);
+#endif
 }
 
 template <class K>
 inline void launch_dcm_scr_k(const DcmLaunch& L, const xrt_hip_beam& gb2, const xrt_hip_screen& S,
                              const xrt_hip_beam& sb, const TailApertures& ap) {
-  ScreenConsumer cons;
-  cons.S = S;
-  cons.out = sb;
-  cons.ap = ap;
-  hipLaunchKernelGGL(reflect_fused_dcm_scr<K>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2, *L.M2,
-                     *L.in, *L.lo1, *L.lo2, gb2, L.theta1, L.theta2, L.g1, L.g2, &L.g1->any_neg,
-                     &L.g2->any_neg, L.opt1, L.opt2, cons);
+  DcmTailArgs A = dcm_tail_args(L, gb2);
+  A.scr.S = S;
+  A.scr.out = sb;
+  A.scr.ap = ap;
+  if (!sb.x)          // nothing exposes the beam: apertures alone
+    hipLaunchKernelGGL(reflect_fused_dcm_marks<K>, L.grid, L.block, 0, L.st, A);
+  else
+    hipLaunchKernelGGL(reflect_fused_dcm_scr<K>, L.grid, L.block, 0, L.st, A);
 }
 template <class K>
 inline void launch_plate2_k(const DcmLaunch& L) {
+#ifdef XRT_DCM_EARLY_ARGS
   hipLaunchKernelGGL(reflect_fused_plate2<K>, L.grid, L.block, 0, L.st, *L.P1, *L.M1, *L.P2, *L.M2,
                      *L.in, *L.lo1, *L.lo2, *L.gb2, L.theta1, L.theta2, L.g1, L.g2, L.opt1, L.opt2);
+#else
+  const DcmTailArgs A = dcm_tail_args(L, *L.gb2);
+  hipLaunchKernelGGL(reflect_fused_plate2<K>, L.grid, L.block, 0, L.st, A);
+#endif
 }
 
 // the units (each returns false for a spec it does not hold)
