@@ -27,7 +27,7 @@ def _one(table, *parts):
 
 def test_hot_kernels_keep_their_budget():
     table = kr.kernels()
-    lean = _one(table, 'reflect_fused_lateINS_4SpecILi0ELi1ELi1ELb1EEELi0')      # cfg2: toroid mirror
+    lean = _one(table, 'reflect_fusedINS_4SpecILi0ELi1ELi1ELb1EEELi0')      # cfg2: toroid mirror
     assert lean['scratch'] == 0 and lean['vgpr_spill'] == 0 and lean['vgpr'] <= 128
     dcm = _one(table, 'reflect_fused_dcmINS_9ThickXtalILi0')                # cfg3
     assert dcm['scratch'] == 0 and dcm['vgpr_spill'] == 0 and dcm['vgpr'] <= 128
@@ -97,7 +97,7 @@ def test_fused_kernels_do_not_park_their_arguments_in_vgpr_lanes():
     for name, r in table.items():
         lean_spec = 'INS_4SpecILi0ELi' in name and 'ELb1EEE' in name
         if lean_spec and ('reflect_fused_scr' in name or 'reflect_fused_gen_scr' in name or
-                          'reflect_fused_late' in name or 'reflect_fused_plate2' in name):
+                          'reflect_fusedINS' in name or 'reflect_fused_plate2' in name):
             assert r.get('sgpr_spill', 0) <= 16, (name, r)
             seen += 1
         if 'ThickXtalILi0' in name and 'reflect_fused_dcm' in name:

@@ -18,7 +18,7 @@ SOURCES = ['reflect_multi.hip', 'reflect_figured_x1.hip', 'reflect_figured_x0.hi
            'reflect_generic.hip', 'reflect_xtal.hip', 'reflect.hip', 'reflect_hot.hip',
            'reflect_hot_scr.hip', 'reflect_hot_gen.hip', 'reflect_hot_plot.hip', 'reflect_hot_plate2.hip', 'reflect_hot_dcm_scr.hip',
            'kirchhoff.hip', 'undulator.hip', 'capi.hip', 'screen.hip', 'hist.hip', 'source.hip']
-HEADERS = ['fp64_math.h', 'plot_tail.h', 'screen_impl.h', 'source_impl.h', 'kirchhoff.h', 'reflect.h', 'reflect_impl.h', 'reflect_tu.h',
+HEADERS = ['fp64_math.h', 'kernarg.h', 'plot_tail.h', 'screen_impl.h', 'source_impl.h', 'kirchhoff.h', 'reflect.h', 'reflect_impl.h', 'reflect_tu.h',
            'reflect_multi_impl.h',
            'screen.h', 'hist.h', 'undulator.h', 'source.h',
            os.path.join('..', '..', 'include', 'xrt_hip.h')]

@@ -10,6 +10,7 @@
 #include "../../include/xrt_hip.h"
 #include "fp64_math.h"
 #include "hist.h"
+#include "kernarg.h"
 #include "plot_tail.h"
 
 namespace xrt {
@@ -338,6 +339,15 @@ struct RayData {
   double x, y, c, jss, jpp, extra;
 };
 
+struct HistRaysArgs {       // plot_hist_rays' arguments as one record (kernarg.h)
+  xrt_hip_beam beam;
+  const double *x, *y, *cd;
+  xrt_hip_plot P;
+  PlotAxes A;
+  HistPlan H;
+  double *counters, *plane_copies, *line_copies;
+  HistRecords R;
+};
 // (only DIRECT needs the LDS of a whole CU: the others run as 256-lane blocks, several per CU)
 template <int MODE>
 #ifndef HIST_RAYS_PER_CU
@@ -348,10 +358,19 @@ template <int MODE>
 #endif
 __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256,
                              MODE == HIST_DIRECT ? 1 : HIST_RAYS_MIN_BLOCKS) void plot_hist_rays(
-    xrt_hip_beam beam, const double* __restrict__ x, const double* __restrict__ y,
-    const double* __restrict__ cd, xrt_hip_plot P, PlotAxes A, HistPlan H,
-    double* __restrict__ counters, double* __restrict__ plane_copies,
-    double* __restrict__ line_copies, HistRecords R) {
+    HistRaysArgs G) {
+  // One record of arguments, read chunk by chunk where they are used (kernarg.h): the beam's
+  // pointers for the loads, plot and axes for the bins, the records' pointers for the stores.
+  // Loaded in the entry block, 68 of them lived in VGPR lanes: 162 lane moves per chunk.
+#ifdef HIST_EARLY_ARGS
+#define HIST_ARG(T, m) G.m
+#else
+#define HIST_ARG(T, m) kernarg_at<T>((unsigned)offsetof(HistRaysArgs, m))
+#endif
+  const PlotAxes& A = G.A;          // (here: the bin counts, the LDS layout)
+  const HistPlan& H = G.H;
+  const int64_t nrays = G.beam.n;
+  const int flux_kind = G.P.flux_kind;
   constexpr int LANES = MODE == HIST_DIRECT ? HIST_BLOCK : 256;
   constexpr int U = HIST_CHUNK / LANES;     // rays per lane and step: 1 (DIRECT: depth comes from
                                             // the prefetch below) or 4
@@ -378,13 +397,17 @@ __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256,
   int cn[6] = {0, 0, 0, 0, 0, 0};      // selected, alive, good, out, over, dead
   double cw = 0., cw_in = 0.;          // flux of the selected rays, of those inside the 2-D range
   const double crange = A.c.hi - A.c.lo;
-  const int64_t nchunks = (beam.n + HIST_CHUNK - 1) / HIST_CHUNK;
+  const int64_t nchunks = (nrays + HIST_CHUNK - 1) / HIST_CHUNK;
 
   auto fetch = [&](int64_t chunk, RayData (&d)[U]) {
+    const xrt_hip_beam& beam = HIST_ARG(xrt_hip_beam, beam);
+    const double* x = HIST_ARG(const double*, x);
+    const double* y = HIST_ARG(const double*, y);
+    const double* cd = HIST_ARG(const double*, cd);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t i = chunk * HIST_CHUNK + u * LANES + threadIdx.x;
-      const int64_t j = i < beam.n ? i : beam.n - 1;
+      const int64_t j = i < nrays ? i : nrays - 1;
       d[u].st = __builtin_nontemporal_load(beam.state + j);
       d[u].x = __builtin_nontemporal_load(x + j);
       d[u].y = __builtin_nontemporal_load(y + j);
@@ -392,13 +415,13 @@ __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256,
       d[u].jss = __builtin_nontemporal_load(beam.Jss + j);
       d[u].jpp = __builtin_nontemporal_load(beam.Jpp + j);
       d[u].extra = 0.;
-      if (P.flux_kind == 3)
+      if (flux_kind == 3)
         d[u].extra = beam.Jsp_ri[2 * j];
-      else if (P.flux_kind == 4)
+      else if (flux_kind == 4)
         d[u].extra = beam.Jsp_ri[2 * j + 1];
-      else if (P.flux_kind == 5)
+      else if (flux_kind == 5)
         d[u].extra = beam.E[j];
-      if (i >= beam.n) d[u].st = 0;     // (state 0: counted nowhere, selected by no flag)
+      if (i >= nrays) d[u].st = 0;      // (state 0: counted nowhere, selected by no flag)
     }
   };
 
@@ -416,6 +439,9 @@ __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256,
       if (threadIdx.x < T + 1) bucket[threadIdx.x] = 0;
       __syncthreads();
     }
+    const xrt_hip_plot& P = HIST_ARG(xrt_hip_plot, P);
+    const PlotAxes& A = HIST_ARG(PlotAxes, A);
+    const HistPlan& H = HIST_ARG(HistPlan, H);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int st = d[u].st;
@@ -513,6 +539,7 @@ __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256,
         first[T + 1] = run;
       }
       __syncthreads();
+      const HistRecords& R = HIST_ARG(HistRecords, R);
       if (threadIdx.x < T + 2) R.start[chunk * (T + 2) + threadIdx.x] = first[threadIdx.x];
       if (threadIdx.x < T) tile_sum[threadIdx.x] += bucket[threadIdx.x];   // (its own thread's)
 #pragma unroll
@@ -535,16 +562,17 @@ __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256,
   }
   __syncthreads();
   if (MODE == HIST_RECORDS && threadIdx.x < T)
-    R.counts[(int64_t)blockIdx.x * T + threadIdx.x] = tile_sum[threadIdx.x];
+    HIST_ARG(HistRecords, R).counts[(int64_t)blockIdx.x * T + threadIdx.x] = tile_sum[threadIdx.x];
   // this block's copies, as they are (coalesced stores): the reduce kernel adds the blocks up
   if (MODE == HIST_DIRECT) {
-    double* out = plane_copies + (int64_t)blockIdx.x * n2;
+    double* out = G.plane_copies + (int64_t)blockIdx.x * n2;
     for (int k = threadIdx.x; k < n2; k += LANES) out[k] = cells[k];
   }
   if (lines) {
     const int nl = 4 * (nx + ny + nc);
-    double* out = line_copies + (int64_t)blockIdx.x * nl;
+    double* out = G.line_copies + (int64_t)blockIdx.x * nl;
     for (int k = threadIdx.x; k < nl; k += LANES) out[k] = lx[k];
+    double* counters = G.counters;
     if (counters) {
       double c[8] = {(double)cn[0], cw,           cw_in,         (double)cn[1],
                      (double)cn[2], (double)cn[3], (double)cn[4], (double)cn[5]};
@@ -1174,8 +1202,20 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
         if (own) (void)hipFreeAsync(scratch, st);
         return e;
       }
+      HistRaysArgs G;
+      G.beam = beam;
+      G.x = x;
+      G.y = y;
+      G.cd = c;
+      G.P = P;
+      G.A = A;
+      G.H = H;
+      G.counters = counters;
+      G.plane_copies = plane_copies;
+      G.line_copies = line_copies;
+      G.R = R;
       hipLaunchKernelGGL(rays, dim3((unsigned)nblk), dim3(mode == HIST_DIRECT ? HIST_BLOCK : 256),
-                         lds1, st, beam, x, y, c, P, A, H, counters, plane_copies, line_copies, R);
+                         lds1, st, G);
       if (mode == HIST_RECORDS) {
         auto tiles = H.nchan > 1 ? plot_hist_tiles<4> : plot_hist_tiles<1>;
         const size_t lds2 = sizeof(double) * (size_t)H.nchan * H.tx * H.ty;

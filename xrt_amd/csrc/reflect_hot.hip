@@ -5,7 +5,14 @@
 namespace xrt {
 
 bool tu_hot_fused(int spec, int mode, const FusedLaunch& L) {
-#ifndef XRT_FUSED_EARLY_ARGS      // (A/B: the arguments one by one, all loaded in the entry block)
+#ifdef XRT_FUSED_EARLY_ARGS       // (A/B: the arguments one by one, all loaded in the entry block)
+  switch (spec) {
+    case SP_TOROID_MIRROR: launch_fused_k<ToroidMirror>(mode, L); return true;
+    case SP_FLAT_MIRROR: launch_fused_k<FlatMirror>(mode, L); return true;
+    case SP_BENT_MIRROR: launch_fused_k<BentMirror>(mode, L); return true;
+    case SP_FLAT_PLATE: launch_fused_k<FlatPlate>(mode, L); return true;
+  }
+#else
   switch (spec) {
     case SP_TOROID_MIRROR: launch_fused_late_k<ToroidMirror>(mode, L); return true;
     case SP_FLAT_MIRROR: launch_fused_late_k<FlatMirror>(mode, L); return true;
@@ -13,12 +20,6 @@ bool tu_hot_fused(int spec, int mode, const FusedLaunch& L) {
     case SP_FLAT_PLATE: launch_fused_late_k<FlatPlate>(mode, L); return true;
   }
 #endif
-  switch (spec) {
-    case SP_TOROID_MIRROR: launch_fused_k<ToroidMirror>(mode, L); return true;
-    case SP_FLAT_MIRROR: launch_fused_k<FlatMirror>(mode, L); return true;
-    case SP_BENT_MIRROR: launch_fused_k<BentMirror>(mode, L); return true;
-    case SP_FLAT_PLATE: launch_fused_k<FlatPlate>(mode, L); return true;
-  }
   return false;
 }
 

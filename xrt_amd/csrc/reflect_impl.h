@@ -33,6 +33,7 @@
 
 #include "../../include/xrt_hip.h"
 #include "fp64_math.h"
+#include "kernarg.h"
 #include "reflect.h"
 #include "screen_impl.h"
 #include "plot_tail.h"
@@ -3282,28 +3283,7 @@ __device__ __forceinline__ void copy_ray(const xrt_hip_beam& o, const xrt_hip_be
 struct NoConsumer {
   static constexpr bool ON = false;
 };
-// A record among the kernel's arguments, read from the argument segment WHERE IT IS USED.
-// The compiler loads by-value arguments in the entry block; what the tail of a ray pass needs
-// (screen, apertures, plot, the array pointers of the image and of the global beam: some 200
-// SGPRs) then waits through the whole pass in VGPR lanes -- v_writelane at the head, v_readlane
-// at the tail, ~400 VALU slots per wave of kernels that are bound by their VALU issue
-// (profiles/r06_sgpr_late_ab.txt). So the kernels with a tail take ONE record of arguments
-// (offset 0 of the segment), never name the tail's members, and the consumers read them through
-// the segment pointer + offsetof behind an empty asm: a new value to the compiler, scalar loads
-// issued at the point of use. (Taking the address of a by-value argument instead would make the
-// compiler keep a copy of the whole record in scratch memory.)
-template <class T>
-__device__ __forceinline__ const T& kernarg_at(unsigned off) {
-  typedef const T __attribute__((address_space(4))) * KernArgPtr;
-  const unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + off;
-  // (the same in every lane; said so explicitly: behind divergent control flow the compiler
-  // may hold it in a VGPR)
-  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  asm volatile("" : "+s"(lo), "+s"(hi));
-  return *(const T*)(KernArgPtr)(((unsigned long long)hi << 32) | lo);
-}
-
+// (kernarg_at<T>(offset): csrc/kernarg.h -- the tail's records are read where they are used)
 struct ScreenConsumer {        // [apertures ->] Screen.expose, flat screens (screen_impl.h):
   xrt_hip_screen S;            // the record as the host fills it
   xrt_hip_beam out;            // the image (x null: no screen, or nobody wants the image itself)
@@ -3822,10 +3802,12 @@ __device__ __forceinline__ xrt_hip_beam no_beam_here() {
   return b;
 }
 
-// The lean kernels' plain pass on the same record (the headline kernels of reflect_hot.hip):
-// nothing behind the element, the global beam's array pointers read where the record is stored.
+// The lean kernels' plain pass on the same record (the headline kernels of reflect_hot.hip; an
+// overload of reflect_fused, so that profiles and tools know the kernel by the name it always
+// had): nothing behind the element, the global beam's array pointers read where the record is
+// stored.
 template <class K, int mode>
-__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_late(
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
     FusedTailArgs A) {
   const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
 #ifdef XRT_LATE_FIELDS

@@ -148,9 +148,9 @@ inline void launch_fused_late_k(int mode, const FusedLaunch& L) {
   A.gp = L.g;
   A.opt = L.opt;
   if (mode == 0)
-    hipLaunchKernelGGL((reflect_fused_late<K, 0>), L.grid, L.block, 0, L.st, A);
+    hipLaunchKernelGGL((reflect_fused<K, 0>), L.grid, L.block, 0, L.st, A);
   else
-    hipLaunchKernelGGL((reflect_fused_late<K, 2>), L.grid, L.block, 0, L.st, A);
+    hipLaunchKernelGGL((reflect_fused<K, 2>), L.grid, L.block, 0, L.st, A);
 }
 template <class K>
 inline void launch_fused_scr_k(int mode, const FusedLaunch& L) {
