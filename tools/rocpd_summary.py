@@ -21,7 +21,8 @@ import os
 import sqlite3
 import sys
 
-OURS = ('reflect_fused_gen_scr_plot', 'reflect_fused_scr_plot', 'plot_tail_tiles',
+OURS = ('reflect_fused_dcm_scr', 'reflect_fused_dcm_marks', 'reflect_dcm_redo_scr',
+        'reflect_fused_gen_scr_plot', 'reflect_fused_scr_plot', 'plot_tail_tiles',
         'reflect_fused_plate2', 'reflect_redo_scr', 'reflect_multi_opt', 'multi_decide_opt',
         'reflect_multi_stats', 'reflect_multi_solve', 'reflect_multi_finish',
         'reflect_fused_gen_scr', 'reflect_fused_scr', 'reflect_decide_opt_gen',

@@ -359,10 +359,11 @@ template <int MODE>
 __global__ __launch_bounds__(MODE == HIST_DIRECT ? HIST_BLOCK : 256,
                              MODE == HIST_DIRECT ? 1 : HIST_RAYS_MIN_BLOCKS) void plot_hist_rays(
     HistRaysArgs G) {
-  // One record of arguments, read chunk by chunk where they are used (kernarg.h): the beam's
-  // pointers for the loads, plot and axes for the bins, the records' pointers for the stores.
-  // Loaded in the entry block, 68 of them lived in VGPR lanes: 162 lane moves per chunk.
-#ifdef HIST_EARLY_ARGS
+  // One record of arguments. Reading them chunk by chunk where they are used (kernarg.h; -DHIST_LATE_ARGS)
+  // takes 68 -> 3 SGPRs out of the VGPR lanes and 263 -> 6 lane moves out of the code, and LOSES: 156-157
+  // against 148-150 us per 1e7 rays, same box (profiles/r06_sgpr_late_ab.txt) -- this kernel is bound by
+  // its block barriers and the LDS sort, not by VALU issue, and the scalar loads of every chunk wait.
+#ifndef HIST_LATE_ARGS
 #define HIST_ARG(T, m) G.m
 #else
 #define HIST_ARG(T, m) kernarg_at<T>((unsigned)offsetof(HistRaysArgs, m))
