@@ -119,12 +119,13 @@ def test_a_contradicted_pass_is_redone_and_imaged_from_the_real_beam():
 
 
 def test_elements_whose_kernels_do_not_carry_a_screen():
-    """A Bragg crystal (not a lean kernel): the same call, the screen's own launch inside it."""
+    """A bent Bragg crystal (surface family 2: neither a lean kernel nor the flat crystals'): the
+    same call, the screen's own launch inside it."""
     bl = raycing.BeamLine()
     si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
     thB = float(np.ravel(si.get_Bragg_angle(9000.) - si.get_dtheta(9000.))[0])
-    xt = roe.OE(bl, 'xtal', center=[0, 20000., 0], pitch=thB, material=si, limPhysX=[-10, 10],
-                limPhysY=[-50, 50])
+    xt = roe.JohannCylinder(bl, 'xtal', center=[0, 20000., 0], pitch=thB, material=si,
+                            Rm=1e9, limPhysX=[-10, 10], limPhysY=[-50, 50])
     scr = rsc.Screen(bl, 'after', center=[0, 21000., 1000. * np.tan(2 * thB)])
     beam = workloads.synthetic_rays(60000, 3, sa=1e-4, E=(8995., 9005.), amplitudes=True)
     gb0, lb0, img0 = eager(xt, scr, beam)
@@ -1420,3 +1421,103 @@ def test_c_abi_double_reflect_tail():
     tail.plot = 1
     assert lib.xrt_hip_double_reflect_tail_f64_dev(*args, ctypes.byref(tail), *rest) != 0
     assert b'plot' in lib.xrt_hip_last_error()
+
+
+# ---- apertures and a screen in the tail of a SINGLE flat Bragg crystal -------------------------
+def _xtal_scene(n, amplitudes, thin=False, alpha=None, odd_ray=False):
+    bl = raycing.BeamLine()
+    si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15, **({'t': 0.05} if thin else {}))
+    thB = float(np.ravel(si.get_Bragg_angle(9000.) - si.get_dtheta(9000.))[0])
+    xt = roe.OE(bl, 'xtal', center=[0, 20000., 0], pitch=thB, material=si, alpha=alpha,
+                limPhysX=[-10, 10], limPhysY=[-50, 50])
+    beam = workloads.synthetic_rays(n, 3, sa=1e-4, E=(8995., 9005.), amplitudes=amplitudes)
+    beam.state[::41] = -2
+    beam.x[::31] *= 300.
+    if odd_ray:          # its largest direction cosine is not the head ray's: the pass is redone
+        beam.a[778] = 0.9
+        beam.b[778] = np.sqrt(1 - beam.a[778]**2 - beam.c[778]**2)
+    scr = rsc.Screen(bl, 'after', center=[0, 21000., 1000. * np.tan(2 * thB)])
+    pipe = ra.RoundAperture(bl, 'pipe', [0, 20500., 500. * np.tan(2 * thB)], r=2.)
+    return xt, beam, pipe, scr
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+@pytest.mark.parametrize('thin', [False, True])
+@pytest.mark.parametrize('what', ['screen', 'pipe + screen', 'pipe'])
+def test_a_single_flat_crystal_carries_its_tail(amplitudes, thin, what):
+    """OE.reflect of a flat Bragg crystal (thick: ThickXtal kernels, thin: the general flat-crystal
+    ones) with the aperture and the screen that take its global beam in the tail of its pass
+    (reflect_fused_xtal_scr; reference oes/reflect.py -> apertures.py:334-413 ->
+    screens.py:226-302): every beam has the bits of the separate launches, and the global beam is
+    not written when only the screen reads it."""
+    xt, beam, pipe, scr = _xtal_scene(60000, amplitudes, thin=thin)
+    aps = [pipe] if 'pipe' in what else []
+    one = scr if 'screen' in what else None
+    gb0, lb0, locs0, img0 = _eager_chain(xt, aps, one, beam)
+    assert ((gb0.state == 1) | (gb0.state == pipe.lostNum)).sum() > 20000
+    if aps:
+        assert 1000 < (gb0.state == pipe.lostNum).sum() < 58000
+    _forget(xt, scr, pipe)
+    gb, lb = xt.reflect(rs.Beam(copyFrom=beam))
+    op = gb.__dict__['_op']
+    locs = [a.propagate(gb) for a in aps]
+    assert op.state == 'pending' and len(op.apertures) == len(aps)
+    if one is not None:
+        img = one.expose(gb)
+        assert op.state == 'pending'
+        same(img, img0, 'image')
+        assert op.state == 'imaged' and not gb.__dict__['_filled']     # (the kernel carried it)
+    same(gb, gb0, 'global')
+    same(lb, lb0, 'local', extra=('theta',))
+    for l, l0 in zip(locs, locs0):
+        same(l, l0, 'beam in the pipe')
+
+
+def test_a_contradicted_mixed_or_forced_crystal_pass_with_its_tail(monkeypatch):
+    """The redo behind a crystal pass with a tail (reflect_redo_scr): an assumption contradicted by
+    one ray, a batch with both signs of beamInDotNormal (asymmetric cut hit from both sides of the
+    cut angle: reflect.py:573-574), and the forced exact sequence -- marks and image are made from
+    the real global beam; the bits of the separate launches."""
+    for kind in ('odd ray', 'mixed', 'forced'):
+        if kind == 'mixed':
+            rng = np.random.default_rng(77)
+            bl = raycing.BeamLine()
+            si = rm.CrystalSi(hkl=(1, 1, 1), tK=297.15)
+            xt = roe.OE(bl, 'xtal', center=[0., 10000., 0.], pitch=np.radians(3.5), material=si,
+                        alpha=np.radians(3.), limPhysX=[-20, 20], limPhysY=[-300, 300])
+            n = 20000
+            beam = rs.Beam(nrays=n, withAmplitudes=True)
+            beam.x[:] = rng.normal(0, 1., n)
+            beam.z[:] = rng.normal(0, 0.5, n)
+            beam.a[:] = rng.normal(0, 1e-4, n)
+            beam.c[:] = rng.uniform(-np.radians(2.5), np.radians(2.0), n)
+            beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+            beam.y[:] = 9900.
+            beam.z[:] += -beam.c / beam.b * 100.
+            beam.E[:] = rng.uniform(8990., 9010., n)
+            beam.Jss[:], beam.Jpp[:], beam.Jsp[:] = 0.5, 0.5, 0.
+            beam.Es[:], beam.Ep[:] = np.sqrt(0.5), np.sqrt(0.5)
+            beam.state[:] = 1
+            scr = rsc.Screen(bl, 'after', center=[0, 10400., 50.])
+            pipe = ra.RectangularAperture(bl, 'slit', [0, 10200., 25.], ('bottom', 'top'),
+                                          [-10., 20.])
+            info = {}
+            xt.reflect(rs.Beam(copyFrom=beam), _info=info)
+            assert info['mixed_sign']
+        else:
+            xt, beam, pipe, scr = _xtal_scene(60000, True, odd_ray=kind == 'odd ray')
+            if kind == 'odd ray':
+                t = {}
+                xt.reflect(rs.Beam(copyFrom=beam), _timing=t)
+                assert t['exact_sequence']
+            else:
+                monkeypatch.setenv('XRT_HIP_REFLECT_EXACT', '1')
+        gb0, lb0, locs0, img0 = _eager_chain(xt, [pipe], scr, beam)
+        _forget(xt, scr, pipe)
+        gb, lb = xt.reflect(rs.Beam(copyFrom=beam))
+        loc = pipe.propagate(gb)
+        img = scr.expose(gb)
+        same(img, img0, 'image, ' + kind)
+        same(gb, gb0, 'global, ' + kind)
+        same(loc, locs0[0], 'beam at the aperture, ' + kind)
+        same(lb, lb0, 'local, ' + kind, extra=('theta',))

@@ -16,7 +16,7 @@ SOURCES = ['reflect_multi.hip', 'reflect_figured_x1.hip', 'reflect_figured_x0.hi
            'reflect_exact1.hip', 'reflect_exact3.hip', 'reflect_exact0.hip',
            'reflect_exact2.hip', 'reflect_layered_x.hip', 'reflect_layered_f.hip',
            'reflect_generic.hip', 'reflect_xtal.hip', 'reflect.hip', 'reflect_hot.hip',
-           'reflect_hot_scr.hip', 'reflect_hot_gen.hip', 'reflect_hot_plot.hip', 'reflect_hot_plate2.hip', 'reflect_hot_dcm_scr.hip',
+           'reflect_hot_scr.hip', 'reflect_hot_gen.hip', 'reflect_hot_plot.hip', 'reflect_hot_plate2.hip', 'reflect_hot_dcm_scr.hip', 'reflect_hot_xtal_scr.hip',
            'kirchhoff.hip', 'undulator.hip', 'capi.hip', 'screen.hip', 'hist.hip', 'source.hip']
 HEADERS = ['fp64_math.h', 'kernarg.h', 'plot_tail.h', 'screen_impl.h', 'source_impl.h', 'kirchhoff.h', 'reflect.h', 'reflect_impl.h', 'reflect_tu.h',
            'reflect_multi_impl.h',

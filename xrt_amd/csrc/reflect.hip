@@ -730,7 +730,12 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   // redo the pass: then the image is made from it afterwards).
   const bool lean = spec == SP_TOROID_MIRROR || spec == SP_FLAT_MIRROR ||
                     spec == SP_BENT_MIRROR || spec == SP_FLAT_PLATE;
-  const bool fuse_screen = scr && sb && optimistic && lean && scr->radius == 0.;
+  // ... and the fused kernels of a single flat Bragg crystal (apertures and screen; no plot, no source)
+  const bool xtal_tail = need_mean && !layers && !figured && M.kind == XRT_HIP_MAT_CRYSTAL &&
+                         (spec == SP_THICK_FLAT || spec == SP_FLAT_XTAL) &&
+                         family_spec == SP_GENERIC0 && !plot && !src &&
+                         P.surf_kind != XRT_HIP_SURF_USER;
+  const bool fuse_screen = scr && sb && optimistic && (lean || xtal_tail) && scr->radius == 0.;
   const TailApertures none{};
   // ... and the plot of the screen's image behind it (plot_tail.h): only in a tail
   if (plot && !fuse_screen) return hipErrorInvalidValue;   // (capi.hip asks ..._fusable first)
@@ -780,6 +785,8 @@ hipError_t reflect_pass_launch(const xrt_hip_pass& P, const xrt_hip_material& M,
   auto launch_fused = [&](int mode) {
     if (plot)
       launched &= tu_hot_fused_scr_plot(spec, mode, FL);
+    else if (fuse_screen && xtal_tail)
+      launched &= tu_hot_xtal_scr(spec, mode, FL);
     else if (fuse_screen)
       launched &= tu_hot_fused_scr(spec, mode, FL);
     else if (unit)      // (need_mean here: a multilayer deflecting as a crystal -- layered flavour)

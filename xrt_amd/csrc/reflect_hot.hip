@@ -5,21 +5,13 @@
 namespace xrt {
 
 bool tu_hot_fused(int spec, int mode, const FusedLaunch& L) {
-#ifdef XRT_FUSED_EARLY_ARGS       // (A/B: the arguments one by one, all loaded in the entry block)
+  // (launch_fused_k: the record of arguments; -DXRT_FUSED_EARLY_ARGS for the A/B: one by one)
   switch (spec) {
     case SP_TOROID_MIRROR: launch_fused_k<ToroidMirror>(mode, L); return true;
     case SP_FLAT_MIRROR: launch_fused_k<FlatMirror>(mode, L); return true;
     case SP_BENT_MIRROR: launch_fused_k<BentMirror>(mode, L); return true;
     case SP_FLAT_PLATE: launch_fused_k<FlatPlate>(mode, L); return true;
   }
-#else
-  switch (spec) {
-    case SP_TOROID_MIRROR: launch_fused_late_k<ToroidMirror>(mode, L); return true;
-    case SP_FLAT_MIRROR: launch_fused_late_k<FlatMirror>(mode, L); return true;
-    case SP_BENT_MIRROR: launch_fused_late_k<BentMirror>(mode, L); return true;
-    case SP_FLAT_PLATE: launch_fused_late_k<FlatPlate>(mode, L); return true;
-  }
-#endif
   return false;
 }
 

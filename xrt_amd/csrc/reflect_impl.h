@@ -3762,6 +3762,7 @@ __device__ __forceinline__ void fused_ray(const xrt_hip_pass& P, const xrt_hip_m
 #endif
 }
 
+#ifdef XRT_FUSED_EARLY_ARGS     // (A/B: the arguments one by one, all loaded in the entry block)
 template <class K, int mode>
 __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
@@ -3778,6 +3779,7 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused(
   int neg = 0, pos = 0;
   fused_ray<K, mode, false>(P, M, in, restore, lb, vb, theta, g, opt, i, req, neg, pos);
 }
+#endif
 
 // The same pass with a screen in its tail: OE.reflect whose global beam goes straight into
 // Screen.expose. `vb` with null arrays: the global beam itself is not wanted (nothing but the
@@ -3922,6 +3924,46 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_g
 // assumes so, and raises GStat::any_neg / any_pos for the sides it saw. Only if both
 // are up does reflect_exact run the two-pass tail.
 // ---------------------------------------------------------------------------
+#ifndef XRT_FUSED_EARLY_ARGS
+// (on the record of arguments, the outgoing beam's pointers read where the ray is stored; the
+// sign flags are GStat's any_neg / any_pos)
+template <class K, int mode>
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_xtal(
+    FusedTailArgs A) {
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
+  const RayRequest req = request_ray<false>(A.in, i, A.in.Es_ri != nullptr);
+  if (fused_skips(A.gp, mode)) return;
+  const GStat g = *A.gp;
+  int* any_neg_pos = const_cast<int*>(&A.gp->any_neg);
+  const int seen_neg = any_neg_pos[0], seen_pos = any_neg_pos[1];
+  int neg = 0, pos = 0;
+  const LatePlain cons{XRT_TAIL_AT(FusedTailArgs, vb)};
+  fused_ray<K, mode, true, LatePlain>(A.P, A.M, A.in, A.restore, A.lb, no_beam_here(), A.theta, g,
+                                      A.opt, i, req, neg, pos, cons);
+  raise_sign_flags(any_neg_pos, seen_neg, seen_pos, neg, pos);
+}
+#endif
+// A SINGLE crystal with apertures and / or a flat screen in its tail (round 6, last session:
+// monochromator crystal -> slit -> fluorescent screen; flat crystals of surface family 0): the
+// record of the lean kernels with a tail, the consumer in the crystal branch of fused_ray. A
+// contradicted pass -- or a batch with both signs of beamInDotNormal -- is redone by
+// reflect_redo_scr into the real global beam, marks and image from that.
+template <class K, int mode>
+__global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_xtal_scr(
+    FusedTailArgs A) {
+  const int64_t i = (int64_t)beam_block() * blockDim.x + threadIdx.x;
+  const RayRequest req = request_ray<false>(A.in, i, A.in.Es_ri != nullptr);
+  if (fused_skips(A.gp, mode)) return;
+  const GStat g = *A.gp;
+  int* any_neg_pos = const_cast<int*>(&A.gp->any_neg);
+  const int seen_neg = any_neg_pos[0], seen_pos = any_neg_pos[1];
+  int neg = 0, pos = 0;
+  const LateScreen cons{XRT_TAIL_AT(FusedTailArgs, vb)};
+  fused_ray<K, mode, true, LateScreen>(A.P, A.M, A.in, A.restore, A.lb, no_beam_here(), A.theta, g,
+                                       A.opt, i, req, neg, pos, cons);
+  raise_sign_flags(any_neg_pos, seen_neg, seen_pos, neg, pos);
+}
+#ifdef XRT_FUSED_EARLY_ARGS
 template <class K, int mode>
 __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_xtal(
     xrt_hip_pass P, xrt_hip_material M, xrt_hip_beam in, xrt_hip_beam restore,
@@ -3936,6 +3978,7 @@ __global__ __launch_bounds__(REFLECT_FUSED_BLOCK, K::WAVES) void reflect_fused_x
   fused_ray<K, mode, true>(P, M, in, restore, lb, vb, theta, g, opt, i, req, neg, pos);
   raise_sign_flags(any_neg_pos, seen_neg, seen_pos, neg, pos);
 }
+#endif
 
 // crystal path, first half: solve + state; stores t, local hit point and state,
 // accumulates sum(beamInDotNormal) over the rays that hit (reflect.py:573)
@@ -4251,9 +4294,13 @@ __global__ __launch_bounds__(REFLECT_EXACT_BLOCK, 1) void reflect_redo_scr(
     xrt_hip_beam lb, xrt_hip_beam vb, PassAux A, xrt_hip_screen S, xrt_hip_beam sb, PlotTail Q,
     TailApertures ap) {
   __shared__ double lds_d[REFLECT_MAX_WAVES];
+  // (a crystal pass that saw both signs of beamInDotNormal: the whole exact sequence as well --
+  // its fused form left no hit records behind for the two-pass tail alone; the lean kernels
+  // never raise the flags)
+  const bool mixed = A.g->any_neg && A.g->any_pos;
   const bool full = exact_gate(A.g, reinterpret_cast<const OptStat*>(A.part), lds_d,
                                P.method_hint);
-  if (!full) return;        // (the lean kernels: no crystal tail)
+  if (!full && !mixed) return;
   unsigned phase = 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -105,13 +105,19 @@ struct MultiLaunch {   // one launch of reflect_multi
          sizeof(xrt::MultiLaunch) * 11))
 
 template <class K>
+inline void launch_fused_late_k(int mode, const FusedLaunch& L);
+template <class K>
 inline void launch_fused_k(int mode, const FusedLaunch& L) {
+#ifndef XRT_FUSED_EARLY_ARGS
+  launch_fused_late_k<K>(mode, L);     // (every family: the record of arguments, kernarg.h)
+#else
   if (mode == 0)
     hipLaunchKernelGGL((reflect_fused<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
                        *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt);
   else
     hipLaunchKernelGGL((reflect_fused<K, 2>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
                        *L.restore, *L.lb, *L.vb, L.theta, L.g, L.opt);
+#endif
 }
 // the argument record of the kernels with a tail (reflect_impl.h: FusedTailArgs)
 inline FusedTailArgs fused_tail_args(const FusedLaunch& L) {
@@ -180,12 +186,39 @@ inline void launch_fused_gen_scr_plot_k(const FusedLaunch& L) {
 }
 template <class K>
 inline void launch_xtal_k(int mode, const FusedLaunch& L) {
+#ifndef XRT_FUSED_EARLY_ARGS
+  FusedTailArgs A;
+  memset(&A, 0, sizeof(A));
+  A.P = *L.P;
+  A.M = *L.M;
+  A.in = *L.in;
+  A.restore = *L.restore;
+  A.lb = *L.lb;
+  A.vb = *L.vb;
+  A.theta = L.theta;
+  A.gp = L.g;
+  A.opt = L.opt;
+  if (mode == 0)
+    hipLaunchKernelGGL((reflect_fused_xtal<K, 0>), L.grid, L.block, 0, L.st, A);
+  else
+    hipLaunchKernelGGL((reflect_fused_xtal<K, 2>), L.grid, L.block, 0, L.st, A);
+  return;
+#else
   if (mode == 0)
     hipLaunchKernelGGL((reflect_fused_xtal<K, 0>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
                        *L.restore, *L.lb, *L.vb, L.theta, L.g, &L.g->any_neg, L.opt);
   else
     hipLaunchKernelGGL((reflect_fused_xtal<K, 2>), L.grid, L.block, 0, L.st, *L.P, *L.M, *L.in,
                        *L.restore, *L.lb, *L.vb, L.theta, L.g, &L.g->any_neg, L.opt);
+#endif
+}
+template <class K>
+inline void launch_xtal_scr_k(int mode, const FusedLaunch& L) {
+  const FusedTailArgs A = fused_tail_args(L);
+  if (mode == 0)
+    hipLaunchKernelGGL((reflect_fused_xtal_scr<K, 0>), L.grid, L.block, 0, L.st, A);
+  else
+    hipLaunchKernelGGL((reflect_fused_xtal_scr<K, 2>), L.grid, L.block, 0, L.st, A);
 }
 template <class K>
 inline void launch_exact_k(const ExactLaunch& L) {
@@ -256,6 +289,7 @@ bool tu_hot_fused_gen_scr(int spec, const FusedLaunch& L);          // reflect_h
 bool tu_hot_fused_scr_plot(int spec, int mode, const FusedLaunch& L);      // reflect_hot_plot.hip
 bool tu_hot_fused_gen_scr_plot(int spec, const FusedLaunch& L);
 bool tu_hot_xtal(int spec, int mode, const FusedLaunch& L);
+bool tu_hot_xtal_scr(int spec, int mode, const FusedLaunch& L);    // reflect_hot_xtal_scr.hip
 bool tu_hot_dcm(int spec, const DcmLaunch& L);
 bool tu_hot_plate2(int spec, const DcmLaunch& L);                   // reflect_hot_plate2.hip
 // (gb2: the global beam as the fused kernel sees it -- null arrays if nobody keeps it)
