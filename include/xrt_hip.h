@@ -941,7 +941,8 @@ XRT_HIP_API int xrt_hip_shine_reflect_screen_plot_f64_dev(
  * the outgoing record while it is in registers: the state written to out_virgin -- and seen by
  * the screen -- is what aperture.propagate(gb) leaves in gb.state; the beam in the aperture's
  * frame is made later, if anybody wants it, by the full call on out_virgin with own_marks = 1.
- * The lean mirror / plate kernels carry the tail; any other pass is followed by the apertures'
+ * The lean mirror / plate kernels carry the tail, single flat Bragg crystals its apertures and
+ * screen; any other pass is followed by the apertures'
  * and the screen's own launches inside the call (*fused: bit 0 screen, 1 source, 2 plot,
  * 3 apertures in the tail). source NULL: the rays are read from `in`; else they are made from
  * the source's record and `in` is the scratch of xrt_hip_shine_reflect_screen_f64_dev. */
