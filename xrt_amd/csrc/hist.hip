@@ -951,6 +951,7 @@ __device__ __forceinline__ double sum_copies(const double* __restrict__ p, int64
     a3 += p[(int64_t)(sl + 3) * pitch];
   }
   for (; sl < s1; ++sl) a0 += p[(int64_t)sl * pitch];
+  // (sixteen sums instead of four: no difference, 24.9 against 23.6 us at 1e7 rays)
   return (a0 + a1) + (a2 + a3);
 }
 __global__ __launch_bounds__(256) void plot_hist_reduce(
@@ -958,16 +959,25 @@ __global__ __launch_bounds__(256) void plot_hist_reduce(
     const double* __restrict__ lines, int nline_copies, int nx, int ny, int nc,
     double* __restrict__ h2, double* __restrict__ h2rgb, double* __restrict__ hx,
     double* __restrict__ hy, double* __restrict__ hc, HistPlan H, int bins_x, int bins_y,
-    const int* __restrict__ tile_share, int plane_parts) {
+    const int* __restrict__ tile_share, int plane_parts, int nbl, int line_parts) {
   __shared__ int share[HIST_MAX_TILES + 1];
+  // a 1-D grid of the blocks that have work: nb2 * plane_parts for the planes, then nbl *
+  // line_parts for the lines (as (nb2 + nbl) x 16 blocks, 15 of 16 plane blocks of a 256 x 256
+  // plot -- plane_parts = 1 -- came and went: 16576 blocks for the work of 1216, ~10 us of every plot)
+  const int plane_blocks = nb2 * plane_parts;
+  const bool for_planes = (int)blockIdx.x < plane_blocks;
+  const int rest = (int)blockIdx.x - plane_blocks;
+  const int block_x = for_planes ? (int)blockIdx.x % (nb2 > 0 ? nb2 : 1)
+                                 : nb2 + rest % (nbl > 0 ? nbl : 1);
+  const int part = for_planes ? (int)blockIdx.x / (nb2 > 0 ? nb2 : 1) : rest / (nbl > 0 ? nbl : 1);
   const bool tiled = tile_share != nullptr;     // copies of plot_hist_tiles: [block][chan][ty][tx]
-  if (tiled) load_tile_shares(tile_share, H.ntx * H.nty, share);
-  if ((int)blockIdx.x < nb2) {
+  if (tiled && for_planes) load_tile_shares(tile_share, H.ntx * H.nty, share);
+  if (for_planes) {
     // block = (channel, 8 rows, 32 columns) of the plot: 256-B row segments of every copy, and
     // with H.derive the patch's column and row sums for the 1-D histograms of x and y
     __shared__ double scol[32], srow[8];
     const int nbx = (bins_x + 31) / 32, nby = (bins_y + 7) / 8;
-    int q = (int)blockIdx.x;
+    int q = block_x;
     const int ibx = q % nbx;
     q /= nbx;
     const int iby = q % nby, ch = q / nby;
@@ -979,7 +989,7 @@ __global__ __launch_bounds__(256) void plot_hist_reduce(
       __syncthreads();
     }
     double v = 0.;
-    if (bx < bins_x && by < bins_y && ch < nchan && (int)blockIdx.y < plane_parts) {
+    if (bx < bins_x && by < bins_y && ch < nchan) {
       const int b = by * bins_x + bx;
       int c0 = 0, cn = ncopies;
       int64_t pitch = (int64_t)nchan * plane;
@@ -996,7 +1006,7 @@ __global__ __launch_bounds__(256) void plot_hist_reduce(
       // has one thread and adds without an atomic -- at 2.4e10 global atomics per second the 16
       // groups of a 256 x 256 plot cost 44 us)
       const int per = (cn - c0 + plane_parts - 1) / plane_parts;
-      const int s0 = c0 + blockIdx.y * per, s1 = min(cn, s0 + per);
+      const int s0 = c0 + part * per, s1 = min(cn, s0 + per);
       if (s0 < s1) v = sum_copies(src, pitch, s0, s1);
       if (v != 0.) {
         double* dst = ch == 0 ? &h2[b] : &h2rgb[3 * (int64_t)b + ch - 1];
@@ -1022,10 +1032,10 @@ __global__ __launch_bounds__(256) void plot_hist_reduce(
     return;
   }
   const int nl = 4 * (nx + ny + nc);
-  const int j = ((int)blockIdx.x - nb2) * blockDim.x + threadIdx.x;
+  const int j = (block_x - nb2) * blockDim.x + threadIdx.x;
   if (j >= nl) return;
-  const int per = (nline_copies + (int)gridDim.y - 1) / (int)gridDim.y;
-  const int s0 = blockIdx.y * per, s1 = min(nline_copies, s0 + per);
+  const int per = (nline_copies + line_parts - 1) / line_parts;
+  const int s0 = part * per, s1 = min(nline_copies, s0 + per);
   const double v = sum_copies(lines + j, nl, s0, s1);
   if (v == 0.) return;
   if (j < 4 * nx) {
@@ -1234,13 +1244,15 @@ hipError_t plot_hist_launch(const xrt_hip_beam& beam, const double* x, const dou
         const int nb2 =
             total ? H.nchan * ((P.bins_x + 31) / 32) * ((P.bins_y + 7) / 8) : 0;   // 8 x 32 patches
         const int nbl = lines && (hx || hy || hc) ? (int)((nl + 255) / 256) : 0;
+        const int plane_parts = total >= 32768 ? 1 : HIST_REDUCE_PARTS;
         if (nb2 + nbl > 0)
-          hipLaunchKernelGGL(plot_hist_reduce, dim3((unsigned)(nb2 + nbl), HIST_REDUCE_PARTS),
+          hipLaunchKernelGGL(plot_hist_reduce,
+                             dim3((unsigned)(nb2 * plane_parts + nbl * HIST_REDUCE_PARTS)),
                              dim3(256), 0, st, plane_copies, ncopies, P.bins_x * P.bins_y, H.nchan,
                              nb2, line_copies, nblk, lines ? A.x.bins : 0, lines ? A.y.bins : 0,
                              lines ? A.c.bins : 0, h2, h2rgb, hx, hy, hc, H, P.bins_x, P.bins_y,
-                             mode == HIST_RECORDS ? R.share : nullptr,
-                             total >= 32768 ? 1 : HIST_REDUCE_PARTS);
+                             mode == HIST_RECORDS ? R.share : nullptr, plane_parts, nbl,
+                             HIST_REDUCE_PARTS);
       }
       if (own) (void)hipFreeAsync(scratch, st);
     } else {
@@ -1366,10 +1378,12 @@ hipError_t plot_tail_finish(const PlotTailPlan& L, hipStream_t st) {
   const int total = 4 * nx * ny;
   const int nb2 = 4 * ((nx + 31) / 32) * ((ny + 7) / 8);
   const int nbl = (int)((nl + 255) / 256);
-  hipLaunchKernelGGL(plot_hist_reduce, dim3((unsigned)(nb2 + nbl), HIST_REDUCE_PARTS), dim3(256),
+  const int plane_parts = total >= 32768 ? 1 : HIST_REDUCE_PARTS;
+  hipLaunchKernelGGL(plot_hist_reduce,
+                     dim3((unsigned)(nb2 * plane_parts + nbl * HIST_REDUCE_PARTS)), dim3(256),
                      0, st, L.plane_copies, L.ncopies, nx * ny, 4, nb2, L.line_copies, L.ncopies,
-                     nx, ny, nc, L.h2, L.h2rgb, L.hx, L.hy, L.hc, H, nx, ny, L.share,
-                     total >= 32768 ? 1 : HIST_REDUCE_PARTS);
+                     nx, ny, nc, L.h2, L.h2rgb, L.hx, L.hy, L.hc, H, nx, ny, L.share, plane_parts,
+                     nbl, HIST_REDUCE_PARTS);
   return hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 // The binning of an XYCPlot (multipro.py:316-361, raycing/__init__.py:170-300) per ray, shared by
 // the histogram kernels (hist.hip) and by the ray kernels that carry a PLOT in their tail
-// (reflect_impl.h: ScreenPlotConsumer) -- one code, the same bins either way.
+// (reflect_impl.h: LateScreenPlot) -- one code, the same bins either way.
 //
 // A plot in the tail of a pass (round 6): run_ray_tracing's accumulate_plot of a screen image
 // whose pass has not been launched joins that pass the way Screen.expose does. The tail takes

@@ -1,6 +1,6 @@
 // Screen.expose (screens.py:226-302) of ONE ray held in registers, flat screens: what the
 // stand-alone kernel (screen.hip) does per ray and what a ray pass does in its tail when the
-// script hands the beam it makes straight on to a screen (reflect_impl.h: ScreenConsumer) --
+// script hands the beam it makes straight on to a screen (reflect_impl.h: LateScreen) --
 // one code, the same bits either way.
 #pragma once
 #include <hip/hip_runtime.h>
