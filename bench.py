@@ -791,11 +791,16 @@ def bench_e2e(nrays, repeats=20):
     rr.run_process = run_process
     runner.run_ray_tracing([make_plot()], repeats=3, beamLine=bl)           # warm up
     torch.cuda.synchronize()
-    plot = make_plot()
-    t0 = time.perf_counter()
-    runner.run_ray_tracing([plot], repeats=repeats, beamLine=bl)
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / repeats
+    # three blocks of *repeats* iterations, as the Balder leg does: the first follows seconds of
+    # host-side preparation on an idle GPU; the steady state is the figure, all three are reported
+    walls = []
+    for _ in range(3):
+        plot = make_plot()
+        t0 = time.perf_counter()
+        runner.run_ray_tracing([plot], repeats=repeats, beamLine=bl)
+        torch.cuda.synchronize()
+        walls.append((time.perf_counter() - t0) / repeats)
+    wall = min(walls)
     t1 = time.perf_counter()
     flux = float(plot.total2D.sum())
     read_back = time.perf_counter() - t1
@@ -862,6 +867,10 @@ def bench_e2e(nrays, repeats=20):
     res = dict(
         metric='run_ray_tracing end to end: source -> toroid mirror -> screen -> XYCPlot, '
                'rays/s', rays=nrays, repeats=repeats, ms_per_iteration=wall * 1e3,
+        ms_per_iteration_by_block=[w * 1e3 for w in walls],
+        ms_per_iteration_first_block=walls[0] * 1e3,
+        ms_per_iteration_note='best of three blocks of %d iterations (all in '
+                              'ms_per_iteration_by_block; the first is what rounds 1-5 reported)' % repeats,
         value=nrays / wall, unit='rays/s', dtype='f64', source='device (Philox4x32-10)',
         gpu_ms_per_iteration=gpu_ms, gpu_ms_by_step=dev_ms, gpu_busy=gpu_ms / (wall * 1e3),
         gpu_busy_note='GPU time of one iteration (HIP events around its four steps, %d '
@@ -1514,6 +1523,7 @@ def compact_for_the_record(line, world):
         ('balder_every_beam_written_ms', ('balder', 'seconds_every_beam_written')),
         ('balder_launches', ('balder', 'launches_per_pass')),
         ('e2e_ms_per_iteration', ('e2e', 'ms_per_iteration')),
+        ('e2e_first_block_ms', ('e2e', 'ms_per_iteration_first_block')),
         ('e2e_plot_adds_ms', ('e2e', 'plot_adds_ms')),
         ('e2e_plot_as_own_launches_ms', ('e2e', 'ms_per_iteration_plot_as_own_launches')),
         ('e2e_traffic', ('e2e', 'roofline', 'traffic')),
@@ -1534,7 +1544,7 @@ def compact_for_the_record(line, world):
     in_summary = ('dcm_frac', 'dcm_ms_per_step', 'kirchhoff_general_frac',
                   'kirchhoff_general_relaxed_frac', 'und_imap_frac', 'hist_frac', 'hist_ms_per_plot',
                   'hist_traffic', 'nolocal_ms_per_step', 'softimax_seconds', 'balder_ms',
-                  'e2e_ms_per_iteration', 'e2e_plot_adds_ms', 'e2e_plot_as_own_launches_ms',
+                  'e2e_ms_per_iteration', 'e2e_first_block_ms', 'e2e_plot_adds_ms', 'e2e_plot_as_own_launches_ms',
                   'e2e_traffic', 'e2e_every_beam_written_ms', 'e2e_1e5_eager_ms',
                   'e2e_1e5_graph_ms', 'e2e_1e5_replay_ms', 'e2e_1e5_speedup', 'e2e_1e6_speedup',
                   'multiple_reflect_ms_per_bounce', 'multiple_reflect_intersections_per_s')
