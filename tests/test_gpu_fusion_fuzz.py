@@ -1,0 +1,172 @@
+"""GPU: randomised scripts over the Balder chain (reference examples/withRaycing/02_Balder_BL:
+front-end screen and mask, both faces of the filter, collimating mirror, DCM, focusing mirror,
+slits and screens between them) -- with the consumers fused into their producers
+(sources.LazyBeam: passes wait for the apertures, screens and elements that take their beams,
+beams nobody has asked for are not written, elements remember what was looked at) every beam,
+looked at in ANY order and over several iterations of the same script, has the bits of the
+run in which every call is an immediate launch (oes.fuseConsumers = False). The fixed-order
+tests are tests/test_gpu_fusion.py; this one draws which slits and screens are there and who
+looks at what first."""
+import numpy as np
+import pytest
+
+import xrt_amd.backends.raycing.apertures as ra
+import xrt_amd.backends.raycing.oes as roe
+import xrt_amd.backends.raycing.screens as rsc
+import xrt_amd.backends.raycing.sources as rs
+from xrt_amd import workloads
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp', 'Jsp', 'state')
+WANTS = ('_local_beam_wanted', '_global_beam_wanted', '_local_beams_wanted', '_image_wanted',
+         '_beam_wanted')
+
+
+def pencil(n, seed, amplitudes=False):
+    """The synthetic pencil of bench.py's Balder leg, some rays dead or astray on arrival."""
+    rng = np.random.default_rng(seed)
+    beam = rs.Beam(nrays=n, withAmplitudes=amplitudes)
+    beam.x, beam.z = rng.normal(0, 0.05, n), rng.normal(0, 0.01, n)
+    beam.y = np.zeros(n)
+    a, c = rng.uniform(-1.9e-4, 1.9e-4, n), rng.uniform(-4.5e-5, 4.5e-5, n)
+    beam.a, beam.c, beam.b = a, c, np.sqrt(1 - a**2 - c**2)
+    beam.E = rng.uniform(8999., 9001., n)
+    beam.state = np.ones(n, dtype=np.int32)
+    beam.state[::97] = -3
+    beam.state[5::101] = 2
+    beam.a[::53] *= 40.
+    beam.b = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.Jss, beam.Jpp, beam.Jsp = np.ones(n), np.zeros(n), np.zeros(n, complex)
+    if amplitudes:
+        beam.Es = np.exp(1j * rng.uniform(0, 6.28, n))
+        beam.Ep = 0.3 * np.exp(1j * rng.uniform(0, 6.28, n))
+    return beam
+
+
+def optics():
+    b = workloads.balder_optics()
+    # more consumers than the example has, so that every producer can get a tail:
+    # half-open slits (x is not touched by the vertical deflections) and screens
+    b.slitF = ra.RectangularAperture(b.bl, 'afterFilter', (0, 24000, 0), blades={'left': -0.8})
+    b.fsmF = rsc.Screen(b.bl, 'FSM-F', (0, 24500, 0))
+    b.slitVCM = ra.RectangularAperture(b.bl, 'afterVCM', (0, 26000, 0), blades={'right': 1.2})
+    b.slitVCM2 = ra.RectangularAperture(b.bl, 'afterVCM2', (0, 26100, 0), blades={'left': -1.5})
+    b.fsmVCM = rsc.Screen(b.bl, 'FSM-VCM', (0, 26300, 0))
+    b.fsmDCM = rsc.Screen(b.bl, 'FSM-DCM', (0, 29400, 0))
+    # a slit that a script closes on a beam AFTER the next element has taken it (marks in place)
+    b.slitLate = ra.RectangularAperture(b.bl, 'late', (0, 26200, 0), blades={'right': 0.6})
+    return b
+
+
+def script(b, beam, has, look=lambda out: None):
+    """One pass of the chain with the consumers *has* names -> {name: beam}, every beam kept;
+    *look(out)* is called between the steps (a script that prints or plots as it goes)."""
+    out = {}
+    if 'fsm0' in has:
+        out['fsm0'] = b.fsm0.expose(beam)
+    if 'mask' in has:
+        out['mask'] = b.mask.propagate(beam)
+    cur = beam
+    if 'filter' in has:
+        cur, out['filter.l1'], out['filter.l2'] = b.filter1.double_refract(cur)
+        out['filter.g'] = cur
+        if 'slitF' in has:
+            out['slitF'] = b.slitF.propagate(cur)
+        if 'fsmF' in has:
+            out['fsmF'] = b.fsmF.expose(cur)
+        look(out)
+    cur, out['vcm.l'] = b.vcm.reflect(cur)
+    out['vcm.g'] = cur
+    for name in ('slitVCM', 'slitVCM2'):
+        if name in has:
+            out[name] = getattr(b, name).propagate(cur)
+    if 'fsmVCM' in has:
+        out['fsmVCM'] = b.fsmVCM.expose(cur)
+    look(out)
+    if 'dcm' in has:
+        cur, out['dcm.l1'], out['dcm.l2'] = b.dcm.double_reflect(cur)
+        out['dcm.g'] = cur
+        if 'slitLate' in has:            # (the DCM has seen the beam as it was)
+            out['slitLate'] = b.slitLate.propagate(out['vcm.g'])
+        if 'slitDCM' in has:
+            out['slitDCM'] = b.slitDCM.propagate(cur)
+        if 'fsmDCM' in has:
+            out['fsmDCM'] = b.fsmDCM.expose(cur)
+    look(out)
+    cur, out['vfm.l'] = b.vfm.reflect(cur)
+    out['vfm.g'] = cur
+    for name in ('slitVFM', 'slitEH'):
+        if name in has:
+            out[name] = getattr(b, name).propagate(cur)
+    if 'sample' in has:
+        out['sample'] = b.sample.expose(cur)
+    return out
+
+
+def fields(beam):
+    return FIELDS + (('Es', 'Ep') if beam.has_amplitudes() else ())
+
+
+def snapshot(beams):
+    return {k: {f: np.array(v.peek(f)) for f in fields(v)} for k, v in beams.items()}
+
+
+def equal(beam, ref, what):
+    assert len(fields(beam)) == len(ref), what
+    for f in fields(beam):
+        u = beam.peek(f)
+        assert np.array_equal(u, ref[f], equal_nan=True), (what, f)
+
+
+OPTIONAL = ('fsm0', 'mask', 'filter', 'slitF', 'fsmF', 'slitVCM', 'slitVCM2', 'fsmVCM',
+            'slitLate', 'slitDCM', 'fsmDCM', 'slitVFM', 'slitEH', 'sample')
+
+
+@pytest.mark.parametrize('seed', range(96))
+def test_random_scripts_over_the_balder_chain(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([3000, 40000, 70001]))
+    beam = pencil(n, seed, amplitudes=bool(seed % 3 == 2))
+    b = optics()
+    has = set(k for k in OPTIONAL if rng.random() < 0.65) | {'dcm'}   # (the VFM sits behind it)
+    old = roe.fuseConsumers
+    roe.fuseConsumers = False
+    try:
+        # (a slit marks the beam it is given IN PLACE: a look on the way sees the states as they
+        # are at that point of the script, not as they are at its end)
+        on_the_way = []
+        ref = snapshot(script(b, rs.Beam(copyFrom=beam), has,
+                              lambda out: on_the_way.append(snapshot(out))))
+    finally:
+        roe.fuseConsumers = old
+    assert (ref['vfm.g']['state'] == 1).sum() > 0.05 * n, sorted(has)
+    for o in vars(b).values():
+        for key in WANTS:
+            getattr(o, '__dict__', {}).pop(key, None)
+    for iteration in range(4):
+        seen = []
+
+        def look(out, iteration=iteration, seen=seen):
+            # now and then the script looks at a beam it has got so far before it goes on
+            seen.append(None)
+            if out and rng.random() < (0.0, 0.3, 0.15, 0.3)[iteration]:
+                k = list(out)[int(rng.integers(len(out)))]
+                seen[-1] = k
+                equal(out[k], on_the_way[len(seen) - 1][k],
+                      (seed, iteration, k, sorted(has), 'on the way', seen))
+        got = script(b, rs.Beam(copyFrom=beam), has, look)
+        assert sorted(got) == sorted(ref)
+        names = list(got)
+        rng.shuffle(names)
+        # the first iterations look at little (what a beamline script does), the last at all
+        share = (0.15, 0.4, 0.0, 1.0)[iteration]
+        looked = [k for k in names if rng.random() < share]
+        for k in looked:
+            equal(got[k], ref[k], (seed, iteration, k, sorted(has), looked))
+        if rng.random() < 0.5:
+            rs.flush_pending()
+        for k in names:                 # what is looked at after the flush, or after the others
+            if k not in looked and rng.random() < share:
+                equal(got[k], ref[k], (seed, iteration, k, sorted(has), 'late'))
+        del got
