@@ -170,3 +170,126 @@ def test_random_scripts_over_the_balder_chain(seed):
             if k not in looked and rng.random() < share:
                 equal(got[k], ref[k], (seed, iteration, k, sorted(has), 'late'))
         del got
+
+
+# ---- whole run_ray_tracing jobs: which plots, of which beams, ride or not -----------------------
+def _job(n, has, seed):
+    """Device source -> cfg2 toroid -> [slits] -> screen at the focus -> [a slit behind it];
+    -> (beamLine, run_process)."""
+    import xrt_amd.backends.raycing as raycing
+    bl = raycing.BeamLine()
+    bl.source = rs.GeometricSource(bl, 'source', nrays=n, dx=0.1, dz=0.1, dxprime=2e-4,
+                                   dzprime=2e-5, distE='flat', energies=(8990., 9010.),
+                                   polarization='h', rng='device', seed=seed)
+    bl.mirror = workloads.cfg2_toroid(bl)
+    way = np.array([0., np.cos(8e-3), np.sin(8e-3)])
+    at = lambda d: list(np.array([0., 20000., 0.]) + d * way)      # noqa: E731
+    bl.slitA = ra.RectangularAperture(bl, 'A', at(3000.), blades={'left': -1.0})
+    bl.slitB = ra.RectangularAperture(bl, 'B', at(6000.), blades={'right': 0.8, 'top': 0.05})
+    bl.slitC = ra.RectangularAperture(bl, 'C', at(9000.), blades={'left': -0.1})
+    bl.screen = rsc.Screen(bl, 'focus', center=at(10000.))
+
+    def run_process(beamLine):
+        out = {}
+        src = out['source'] = beamLine.source.shine()
+        gb, lb = beamLine.mirror.reflect(src)
+        out['mirrorGlobal'], out['mirrorLocal'] = gb, lb
+        if 'slitA' in has:
+            out['slitA'] = beamLine.slitA.propagate(gb)
+        if 'slitB' in has:
+            out['slitB'] = beamLine.slitB.propagate(gb)
+        out['focus'] = beamLine.screen.expose(gb)
+        if 'slitC' in has:
+            out['slitC'] = beamLine.slitC.propagate(gb)
+        return out
+    return bl, run_process
+
+
+LIMITS = {          # beam -> axis label -> (unit, limits)
+    'focus': {'x': ('mm', [-0.4, 0.4]), 'z': ('mm', [-0.05, 0.05]), "x'": ('mrad', [-0.6, 0.6]),
+              "z'": ('mrad', [-0.1, 0.1]), 'path': ('mm', [29999., 30001.])},
+    'mirrorLocal': {'x': ('mm', [-12., 12.]), 'y': ('mm', [-350., 350.]),
+                    'z': ('mm', [-0.01, 0.06])},
+    'mirrorGlobal': {'x': ('mm', [-12., 12.]), 'z': ('mm', [-1.5, 1.5]),
+                     "z'": ('mrad', [7.8, 8.2])},
+    'source': {'x': ('mm', [-0.4, 0.4]), 'z': ('mm', [-0.4, 0.4]), "x'": ('mrad', [-0.8, 0.8])},
+    'slitA': {'x': ('mm', [-12., 12.]), 'z': ('mm', [-1., 1.])},
+}
+
+
+def _draw_plots(rng, has):
+    from xrt_amd import plotter as xrtp
+    beams = [k for k in LIMITS if k != 'slitA' or 'slitA' in has]
+    spec = []
+    for _ in range(int(rng.integers(1, 4))):
+        beam = beams[int(rng.integers(len(beams)))] if rng.random() < 0.5 else 'focus'
+        labels = list(LIMITS[beam])
+        rng.shuffle(labels)
+        spec.append((beam, labels[0], labels[1], int(rng.choice([64, 128, 256])),
+                     [(1,), (1, 2), (1, 2, 3, -1)][int(rng.integers(3))],
+                     int(rng.choice([32, 128]))))
+
+    def make():
+        plots = []
+        for beam, lx, ly, bins, flag, cbins in spec:
+            (ux, limx), (uy, limy) = LIMITS[beam][lx], LIMITS[beam][ly]
+            plots.append(xrtp.XYCPlot(
+                beam, flag, xaxis=xrtp.XYCAxis(lx, ux, limits=list(limx), bins=bins),
+                yaxis=xrtp.XYCAxis(ly, uy, limits=list(limy), bins=bins),
+                caxis=xrtp.XYCAxis('energy', 'eV', limits=[8989., 9011.], bins=cbins)))
+        return plots
+    return spec, make
+
+
+def _plots_agree(p, q, what):
+    for name in ('total2D', 'total2D_RGB'):
+        a, b = getattr(p, name), getattr(q, name)
+        assert np.array_equal(a != 0, b != 0), (what, name)
+        assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1e-300), (what, name)
+    for axis in ('xaxis', 'yaxis', 'caxis'):
+        a, b = getattr(p, axis).total1D4, getattr(q, axis).total1D4
+        assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1e-300), (what, axis)
+    for name in ('nRaysAll', 'nRaysSelected', 'nRaysAlive', 'nRaysGood', 'nRaysOut', 'nRaysOver',
+                 'nRaysDead', 'iteration'):
+        assert getattr(p, name) == getattr(q, name), (what, name)
+    for name in ('intensity', 'intensityInRange'):
+        assert abs(getattr(p, name) - getattr(q, name)) <= 1e-12 * abs(getattr(q, name)) + 1e-300, \
+            (what, name)
+
+
+@pytest.mark.parametrize('seed', range(100))
+def test_random_run_ray_tracing_jobs(seed):
+    """run_ray_tracing (reference xrt/runner.py:513-719) over drawn jobs: one to three plots of
+    drawn beams and axes, slits before and behind the screen, eager loop or HIP-graph replays --
+    the plots of the run with everything fused (a plot may ride in the tail of the pass, the
+    source in its head) equal those of the run of immediate launches."""
+    from xrt_amd import runner as xrtr
+    import xrt_amd.backends.raycing.run as rr
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.choice([2000, 50000, 120001]))
+    has = set(k for k in ('slitA', 'slitB', 'slitC') if rng.random() < 0.5)
+    repeats = int(rng.integers(2, 7))
+    graph = bool(rng.random() < 0.4)
+    bl, run_process = _job(n, has, seed)
+    spec, make = _draw_plots(rng, has)
+    what = (seed, n, sorted(has), repeats, graph, spec)
+    keep = rr.run_process
+    rr.run_process = run_process
+    old = roe.fuseConsumers
+    try:
+        roe.fuseConsumers = False
+        bl.source._calls = 0
+        ref = xrtr.run_ray_tracing(make(), repeats=repeats, beamLine=bl)
+        for q, (beam, lx, ly, _, _, _) in zip(ref, spec):
+            assert q.nRaysAll == n * repeats and q.iteration == repeats, what
+            if {lx, ly} <= {'x', 'y', 'z'}:       # (the limits hold the beam: something to compare)
+                assert q.total2D.sum() > 0 and (q.total2D != 0).sum() > 20, (what, beam)
+        roe.fuseConsumers = True
+        for again in range(2):        # (the second run: elements and screens remember)
+            bl.source._calls = 0
+            got = xrtr.run_ray_tracing(make(), repeats=repeats, beamLine=bl, graph=graph)
+            for k, (p, q) in enumerate(zip(got, ref)):
+                _plots_agree(p, q, what + (again, k))
+    finally:
+        roe.fuseConsumers = old
+        rr.run_process = keep
