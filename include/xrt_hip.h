@@ -771,6 +771,17 @@ XRT_HIP_API int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* apert
                                                    xrt_hip_beam* out_local,
                                                    xrt_hip_beam* out_global, void* stream);
 
+/* Screen.expose of a resident beam followed by aperture.propagate of the SAME beam (a front-end
+ * monitor and the mask behind it: screens.py:226-302, then apertures.py:334-413) as one pass
+ * over the rays: out_screen = what xrt_hip_screen_expose_f64_dev makes from the states as they
+ * are on entry, then the marks of xrt_hip_aperture_propagate_f64_dev (out_local NULL) in
+ * beam_inout. Flat screens (radius == 0) and apertures without vertices (poly_n == 0); refused
+ * (XRT_HIP_ERR_ARG) otherwise. Same bits as the two calls. */
+XRT_HIP_API int xrt_hip_screen_expose_mark_f64_dev(const xrt_hip_screen* screen,
+                                                   const xrt_hip_aperture* aperture,
+                                                   xrt_hip_beam* beam_inout,
+                                                   xrt_hip_beam* out_screen, void* stream);
+
 /* ---- GeometricSource.shine on the device ------------
  * Replaces the host sampling of GeometricSource.shine (sources/geoms.py:420-535) with one
  * kernel that writes the 13 (15) SoA arrays of the beam straight into HBM. The laws are the

@@ -1521,3 +1521,138 @@ def test_a_contradicted_mixed_or_forced_crystal_pass_with_its_tail(monkeypatch):
         same(gb, gb0, 'global, ' + kind)
         same(loc, locs0[0], 'beam at the aperture, ' + kind)
         same(lb, lb0, 'local, ' + kind, extra=('theta',))
+
+
+# ---- a screen and the mask behind it on a RESIDENT beam: one pass over the rays -----------------
+def _front_end(n, amplitudes):
+    """A source's beam, a monitor 15 m downstream and four kinds of mask behind it."""
+    bl = raycing.BeamLine()
+    beam = workloads.synthetic_rays(n, 23, amplitudes=amplitudes)
+    beam.state[::97] = -3
+    beam.state[5::101] = 2
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.b[3::211] *= -1.                      # (flies away: arrives with a negative path only)
+    fsm = rsc.Screen(bl, 'FSM0', [0, 15000., 0])
+    at = [0, 15750., 0]
+    masks = [ra.RectangularAperture(bl, 'mask', at, ('left', 'right', 'bottom', 'top'),
+                                    [-2., 2.5, -0.2, 0.25]),
+             ra.RectangularBeamStop(bl, 'stop', at, ('left', 'right', 'bottom', 'top'),
+                                    [-1., 1., -0.2, 0.2]),
+             ra.RoundAperture(bl, 'pipe', at, r=1.5),
+             ra.DoubleSlit(bl, 'two', at, ('bottom', 'top'), [-0.4, 0.4], shadeFraction=0.3),
+             ra.PolygonalAperture(bl, 'tri', at, opening=[(-2., -0.3), (2.5, -0.2), (0., 0.4)])]
+    return bl, beam, fsm, masks
+
+
+def _two_launches(fsm, mask, beam, **kw):
+    old = roe.fuseConsumers
+    roe.fuseConsumers = False
+    try:
+        b = rs.Beam(copyFrom=beam)
+        img = fsm.expose(b, **kw)
+        loc = mask.propagate(b)
+    finally:
+        roe.fuseConsumers = old
+    return b, img, loc
+
+
+@pytest.mark.parametrize('amplitudes', [False, True])
+@pytest.mark.parametrize('kind', [0, 1, 2, 3])
+def test_a_screen_and_the_mask_behind_it_are_one_pass(amplitudes, kind):
+    """Screen.expose(beam) then aperture.propagate(beam) of a resident beam (reference
+    screens.py:226-302, apertures.py:334-413: the front-end monitor and mask of every beamline)
+    = one launch (xrt_hip_screen_expose_mark_f64_dev): the image from the states as they were,
+    the marks in the beam, the beam in the mask's frame on demand -- the bits of the two calls."""
+    bl, beam, fsm, masks = _front_end(70001, amplitudes)
+    mask = masks[kind]
+    b0, img0, loc0 = _two_launches(fsm, mask, beam, onlyPositivePath=bool(kind % 2))
+    assert 3000 < (b0.state == mask.lostNum).sum() < 60000
+    assert ((img0.state == fsm.lostNum).sum() > 100) == bool(kind % 2)
+    b = rs.Beam(copyFrom=beam)
+    img = fsm.expose(b, onlyPositivePath=bool(kind % 2))
+    shot = img.__dict__['_op']
+    assert type(shot) is rsc._DeferredExpose and shot.state == 'pending'
+    loc = mask.propagate(b)
+    assert shot.state == 'done' and img.__dict__['_filled'] and shot.was is None
+    assert not loc.__dict__['_filled'] and loc.__dict__['_op'].shot is None
+    assert np.array_equal(b.state, b0.state)
+    same(img, img0, 'image')
+    same(loc, loc0, 'beam at the mask')
+    same(b, b0, 'the beam itself')
+
+
+def test_a_screen_on_a_resident_beam_in_any_other_order():
+    bl, beam, fsm, masks = _front_end(40000, False)
+    mask = masks[0]
+    b0, img0, loc0 = _two_launches(fsm, mask, beam)
+    # the image looked at first: the screen's own launch, then the mask's
+    b = rs.Beam(copyFrom=beam)
+    img = fsm.expose(b)
+    same(img, img0, 'image first')
+    loc = mask.propagate(b)
+    same(loc, loc0, 'mask after'), same(b, b0, 'beam')
+    # nobody keeps the image: written all the same (with the mask's marks in the same launch)
+    b = rs.Beam(copyFrom=beam)
+    fsm.expose(b)
+    assert len([op for op in rs._PENDING if type(op) is rsc._DeferredExpose]) == 1
+    mask.propagate(b)
+    assert not [op for op in rs._PENDING if type(op) is rsc._DeferredExpose]
+    assert np.array_equal(b.state, b0.state)
+    # an outline of vertices, two screens, a beam changed on the host in between: own launches
+    for case in ('polygon', 'two screens', 'host change', 'element'):
+        b = rs.Beam(copyFrom=beam)
+        img = fsm.expose(b)
+        shot = img.__dict__['_op']
+        if case == 'polygon':
+            m = masks[4]
+        else:
+            m = mask
+        ref_b, ref_img, ref_loc = _two_launches(fsm, m, beam)
+        if case == 'two screens':
+            img2 = rsc.Screen(bl, 'FSM1', [0, 15500., 0]).expose(b)
+        if case == 'host change':
+            b.state[::7] = -5          # (after the screen saw the beam)
+            ref_b = rs.Beam(copyFrom=beam)
+            roe.fuseConsumers = False
+            try:
+                ref_img = fsm.expose(ref_b)
+                ref_b.state[::7] = -5
+                ref_loc = m.propagate(ref_b)
+            finally:
+                roe.fuseConsumers = True
+        if case == 'element':        # every element's call launches what waits
+            bl2, oe, scr, _ = scene(n=10)
+            oe.reflect(workloads.synthetic_rays(1000, 1))[0].nrays
+            assert shot.state == 'done'
+        loc = m.propagate(b)
+        assert shot.state == 'done'
+        if case == 'two screens':
+            assert img2.__dict__['_op'].state == 'done'
+        same(img, ref_img, case + ': image')
+        same(loc, ref_loc, case + ': beam at the mask')
+        assert np.array_equal(b.state, ref_b.state), case
+
+
+def test_c_abi_screen_and_mask_refusals():
+    import ctypes
+    from xrt_amd import _lib
+    bl, beam, fsm, masks = _front_end(5000, False)
+    dev = torch.device('cuda', 0)
+    b = rs.Beam(copyFrom=beam)
+    out = rs.Beam.empty_like_on_device(b, dev)
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = lambda s, a: (ctypes.byref(s), ctypes.byref(a), ctypes.byref(b.to_struct(dev)),  # noqa: E731
+                         ctypes.byref(out.to_struct(dev)), stream)
+    rec = fsm._record(False)
+    rec.radius = 100.
+    assert lib.xrt_hip_screen_expose_mark_f64_dev(*args(rec, masks[0]._record())) != 0
+    assert b'hemispheric' in lib.xrt_hip_last_error()
+    assert lib.xrt_hip_screen_expose_mark_f64_dev(*args(fsm._record(False), masks[4]._record())) != 0
+    assert b'vertices' in lib.xrt_hip_last_error()
+    _lib.check(lib.xrt_hip_screen_expose_mark_f64_dev(*args(fsm._record(False), masks[2]._record())),
+               'screen + mask')
+    b._h.pop('state', None)
+    b0, img0, _ = _two_launches(fsm, masks[2], beam)
+    assert np.array_equal(b.state, b0.state)
+    same(out, img0, 'image through the C ABI')

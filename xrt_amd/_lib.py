@@ -81,6 +81,7 @@ SIGNATURES = {
         vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     'xrt_hip_screen_expose_f64_dev': (ctypes.c_int, [vp, vp, vp, vp]),
     'xrt_hip_aperture_propagate_f64_dev': (ctypes.c_int, [vp, vp, vp, vp, vp]),
+    'xrt_hip_screen_expose_mark_f64_dev': (ctypes.c_int, [vp, vp, vp, vp, vp]),
     'xrt_hip_user_unit_abi': (ctypes.c_int, []),
     'xrt_hip_user_surface_load': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
     'xrt_hip_user_surface_unload': (ctypes.c_int, [vp]),

@@ -142,10 +142,18 @@ class RectangularAperture(object):
             # the element's pass has not been launched: the marks are made in its tail
             return op.marks_later(self)
         beam.to_struct(dev)
-        rs.flush_pending(beam, only_state=True)    # (beam.state changes in place below)
+        shot = None
+        if roe.fuseConsumers and not needNewGlobal and type(beam) is rs.Beam and \
+                not hasattr(self, 'vertices'):
+            # a screen that was exposed to this very beam and has not been launched: its image
+            # and this aperture's marks are one pass over the rays (a front-end monitor and the
+            # mask behind it; screens._DeferredExpose)
+            from . import screens as rsc
+            shot = rsc.pending_expose_of(beam, dev)
+        rs.flush_pending(beam, keep=shot, only_state=True)   # (beam.state changes in place below)
         rs.before_states_change(beam)
         if not needNewGlobal and roe.fuseConsumers:
-            return _DeferredLocal(self, beam, dev).hand_out()
+            return _DeferredLocal(self, beam, dev, shot).hand_out()
         local = rs.Beam.empty_like_on_device(beam, dev)
         glo = rs.Beam.empty_like_on_device(beam, dev) if needNewGlobal else None
         rec = self._record()
@@ -197,8 +205,9 @@ class _DeferredLocal(rs.SharesStates, rs.FillsBeams):
     beam no plot shows)."""
     optional = True
 
-    def __init__(self, aperture, beam, dev):
+    def __init__(self, aperture, beam, dev, shot=None):
         self.aperture, self.device = aperture, dev
+        self.shot = shot                 # a screen's pending launch on the same rays
         self.record = aperture._record()
         # (the record points at the polygon's vertices in HBM: they live as long as it does,
         # whatever the script assigns to aperture.vertices in the meantime)
@@ -230,6 +239,9 @@ class _DeferredLocal(rs.SharesStates, rs.FillsBeams):
         rs._PENDING.add(self)
 
     def _launch(self, beam, local):
+        shot, self.shot = self.shot, None
+        if shot is not None and local is None:
+            return shot.with_marks(self.record, beam)
         with torch.cuda.device(self.device):
             _lib.check(_lib.load().xrt_hip_aperture_propagate_f64_dev(
                 ctypes.byref(self.record), ctypes.byref(beam.to_struct(self.device)),

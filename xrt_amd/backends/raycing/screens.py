@@ -68,6 +68,13 @@ class Screen(object):
             if op.screen_rec is None and type(self) is Screen:
                 return op.expose_later(self, rec)
             op.materialize('gb')
+        from . import oes as roe
+        if roe.fuseConsumers and type(self) is Screen and type(beam) is rs.Beam:
+            # a resident beam (a source's): the image is handed out before the launch, so that
+            # aperture.propagate of the same beam right behind this screen -- a front-end
+            # monitor and its mask -- can make image and marks in ONE pass over the rays
+            # (_DeferredExpose); launched at the latest by the next element's call
+            return _DeferredExpose(self, rec, beam, dev).hand_out()
         image = rs.Beam.empty_like_on_device(beam, dev)
         _lib.check(_lib.load().xrt_hip_screen_expose_f64_dev(
             ctypes.byref(rec), ctypes.byref(beam.to_struct(dev)),
@@ -103,6 +110,79 @@ class Screen(object):
         xg, yg, zg = self.local_to_global(x=gx, z=gz)
         return rw.receiving_wave(self, prevOE, (gx, gy, gz), (xg, yg + dy, zg), cell, area,
                                  prevOE.uuid)
+
+
+class _DeferredExpose(rs.FillsBeams):
+    """Screen.expose of a resident beam not launched yet (reference screens.py:226-302). The
+    record keeps the beam's arrays as they are now (whoever writes INTO them launches their
+    readers first, sources.flush_pending); ``aperture.propagate`` of the same beam finds the
+    record and makes the image and its own marks in one launch
+    (xrt_hip_screen_expose_mark_f64_dev: the image sees the states from before the marks, as
+    in the two calls); otherwise the next flush -- every element's call starts with one --
+    launches the screen's own kernel. Not optional: the image is written whether or not the
+    script keeps it, as the immediate launch does."""
+
+    def __init__(self, screen, rec, beam, dev):
+        self.rec, self.device = rec, dev
+        beam.to_struct(dev)                          # everything up in HBM now
+        was = rs.Beam.__new__(rs.Beam)
+        object.__setattr__(was, '_h', {})
+        object.__setattr__(was, '_d', dict(beam._d))
+        object.__setattr__(was, 'parentId', None)
+        self.was = was
+        self.tensors = {id(t) for t in was._d.values()}
+        self.state = 'pending'
+        rs.inherit_scalars(self._make('shot'), beam)
+        rs._PENDING.add(self)
+
+    def reads(self, beam):
+        d = beam.__dict__.get('_real_d', beam.__dict__.get('_d')) or {}
+        return any(id(t) in self.tensors for t in d.values())
+
+    def _done(self, picture):
+        rs._PENDING.discard(self)
+        self.state = 'done'
+        rs.adopt_into(self._beam('shot'), picture)
+        self.was, self.tensors = None, ()
+
+    def materialize(self, which=None):
+        if self.state == 'done':
+            return
+        picture = rs.Beam.empty_like_on_device(self.was, self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().xrt_hip_screen_expose_f64_dev(
+                ctypes.byref(self.rec), ctypes.byref(self.was.to_struct(self.device)),
+                ctypes.byref(picture.to_struct(self.device)), _hipcalls.stream_ptr()),
+                'xrt_hip_screen_expose_f64_dev')
+        self._done(picture)       # (a launch that raises is raised again by the next look)
+
+    def with_marks(self, aperture_record, beam):
+        """The image and the marks of *aperture_record* in *beam* (whose arrays are the ones
+        this record holds) in one launch."""
+        picture = rs.Beam.empty_like_on_device(self.was, self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().xrt_hip_screen_expose_mark_f64_dev(
+                ctypes.byref(self.rec), ctypes.byref(aperture_record),
+                ctypes.byref(beam.to_struct(self.device)),
+                ctypes.byref(picture.to_struct(self.device)), _hipcalls.stream_ptr()),
+                'xrt_hip_screen_expose_mark_f64_dev')
+        self._done(picture)
+
+
+def pending_expose_of(beam, dev):
+    """The screen that waits with its launch for *beam* as it is now (all of its arrays), if
+    there is exactly one and nothing else waits to read the beam -> its record, else None."""
+    found = None
+    for op in list(rs._PENDING) + rs._PENDING.optional():
+        if not op.reads(beam):
+            continue
+        if type(op) is _DeferredExpose and found is None and op.state == 'pending' and \
+                op.device == dev and \
+                op.tensors == {id(t) for t in beam._d.values()}:
+            found = op
+        elif type(op) is _DeferredExpose:
+            return None           # (two screens: each its own launch)
+    return found
 
 
 class HemisphericScreen(Screen):

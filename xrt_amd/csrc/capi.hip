@@ -1197,6 +1197,28 @@ int xrt_hip_aperture_propagate_f64_dev(const xrt_hip_aperture* aperture,
   return XRT_HIP_OK;
 }
 
+int xrt_hip_screen_expose_mark_f64_dev(const xrt_hip_screen* screen,
+                                       const xrt_hip_aperture* aperture,
+                                       xrt_hip_beam* beam_inout, xrt_hip_beam* out_screen,
+                                       void* stream) {
+  if (!screen || !aperture || !beam_inout)
+    return fail(XRT_HIP_ERR_ARG, "NULL screen / aperture / beam");
+  if (screen->radius != 0.)
+    return fail(XRT_HIP_ERR_ARG, "a hemispheric screen takes its own launch "
+                                 "(xrt_hip_screen_expose_f64_dev)");
+  if (aperture->poly_n > 0)
+    return fail(XRT_HIP_ERR_ARG, "an aperture with an outline of vertices takes its own launch "
+                                 "(xrt_hip_aperture_propagate_f64_dev)");
+  const int64_t n = beam_inout->n;
+  const bool amp = beam_inout->Es_ri != nullptr || beam_inout->Ep_ri != nullptr;
+  int rc;
+  if ((rc = check_beam(beam_inout, "beam", n, amp))) return rc;
+  if ((rc = check_beam(out_screen, "out_screen", n, amp))) return rc;
+  HIP_TRY(xrt::screen_expose_mark_launch(*screen, *aperture, *beam_inout, *out_screen,
+                                         reinterpret_cast<hipStream_t>(stream)));
+  return XRT_HIP_OK;
+}
+
 int xrt_hip_hist2d_f64_dev(const xrt_hip_beam* beam, const double* x, const double* y,
                            double x_factor, double y_factor, int ray_flags, int flux_kind,
                            double source_weight, int bins_x, double x_lo, double x_hi,

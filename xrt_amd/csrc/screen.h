@@ -11,6 +11,9 @@ struct TailApertures {
 };
 hipError_t screen_expose_launch(const xrt_hip_screen& S, const xrt_hip_beam& in,
                                 const xrt_hip_beam& out, hipStream_t st);
+hipError_t screen_expose_mark_launch(const xrt_hip_screen& S, const xrt_hip_aperture& A,
+                                     const xrt_hip_beam& in, const xrt_hip_beam& out,
+                                     hipStream_t st);
 hipError_t aperture_propagate_launch(const xrt_hip_aperture& A, const xrt_hip_beam& in,
                                      const xrt_hip_beam& lo, const xrt_hip_beam& glo,
                                      hipStream_t st);
