@@ -43,12 +43,12 @@ v['KG_FRAC']='%.3f'%b['kirchhoff_general']['roofline']['frac']; v['KGR_FRAC']='%
 v['UND_MS']='%.4f'%b['undulator']['ms']; v['UND_FRAC']='%.3f'%b['undulator']['roofline']['frac']
 v['HIST_MS']='%.3f'%b['hist']['ms_per_plot']; v['HIST_FRAC']='%.3f'%b['hist']['roofline']['frac']
 v['MULTI_MS']='%.2f'%b['multiple_reflect']['ms_per_bounce']
-sh=one('geosource_shine_kernel',10000128); sc=one('screen_expose_kernel',10000128); ap=one('aperture_propagate_kernel<false>',10000128)
+sh=one('geosource_shine_kernel',10000128); sc=one('screen_expose_kernel',10000128); ap=one('xrt::screen_expose_mark_kernel',10000128)
 v['SHINE_US']='%.0f'%(float(sh[4])/1e3); v['SCR_US']='%.0f'%(float(sc[4])/1e3); v['AP_US']='%.0f'%(float(ap[4])/1e3)
-v['SHINE_F']='%.2f'%(1e9/(float(sh[4])*1e-9)/8e12); v['SCR_F']='%.2f'%(2e9/(float(sc[4])*1e-9)/8e12); v['AP_F']='%.2f'%(0.52e9/(float(ap[4])*1e-9)/8e12)
+v['SHINE_F']='%.2f'%(1e9/(float(sh[4])*1e-9)/8e12); v['SCR_F']='%.2f'%(2e9/(float(sc[4])*1e-9)/8e12); v['AP_F']='%.2f'%(2.04e9/(float(ap[4])*1e-9)/8e12)
 v['CFG2_STEP']='%.3f'%b['ms_per_step']; v['CFG2_VALUE']='%.2e'%b['value']
 e=b['e2e']
-v['E2E_MS']='%.2f'%e['ms_per_iteration']; v['E2E_OWN']='%.2f'%e['ms_per_iteration_plot_as_own_launches']; v['E2E_ALL']='%.2f'%e['ms_per_iteration_every_beam_written']
+v['E2E_FIRST']='%.2f'%e['ms_per_iteration_first_block']; v['E2E_MS']='%.2f'%e['ms_per_iteration']; v['E2E_OWN']='%.2f'%e['ms_per_iteration_plot_as_own_launches']; v['E2E_ALL']='%.2f'%e['ms_per_iteration_every_beam_written']
 s5=e['small_beams']['100000_rays']; s6=e['small_beams']['1000000_rays']
 ub=json.load(open(R+'r06_bench.json'))['e2e']['small_beams']['100000_rays']
 v['E2E5_EAGER']='%.3f'%ub['eager_ms_per_iteration']; v['E2E5_GRAPH']='%.3f'%ub['graph_ms_per_iteration']

@@ -55,7 +55,7 @@ for env in "" "XRT_HIP_HIST_NO_SMALL=1" "XRT_HIP_NO_FUSE=1"; do echo "== [$env]"
 { grep '^{' /tmp/pb.log | cut -c1-400; python tools/prof_sequence.py /tmp/pb 30; } > profiles/r${RND}_balder_kernels.txt 2>&1
 # round 6: the Balder chain's fused pieces against their separate launches -- the focusing mirror
 # with its two slits and the sample screen in the tail of its pass; both faces of the filter in one kernel
-{ python tools/probe_tail_apertures.py; python tools/probe_xtal_tail.py; python tools/probe_plate2.py; \
+{ python tools/probe_front_end.py; python tools/probe_tail_apertures.py; python tools/probe_xtal_tail.py; python tools/probe_plate2.py; \
   XRT_HIP_DCM_TWO_PASSES=1 python tools/probe_plate2.py | sed 's/\[\]/[two passes]/'; } 2>&1 \
   | grep -v amdgpu.ids > profiles/r${RND}_balder_tails.txt
 # round 6: the plot in the tail of the pass -- HBM bytes of an e2e iteration either way
