@@ -1656,3 +1656,35 @@ def test_c_abi_screen_and_mask_refusals():
     b0, img0, _ = _two_launches(fsm, masks[2], beam)
     assert np.array_equal(b.state, b0.state)
     same(out, img0, 'image through the C ABI')
+
+
+@pytest.mark.parametrize('n', [0, 1, 63, 257, 20011])
+@pytest.mark.parametrize('kind', [0, 2, 3])
+def test_a_screen_and_the_mask_behind_it_against_the_oracle(n, kind):
+    """The one-launch form directly against the numpy restatement of screens.py:226-302 and
+    apertures.py:334-413 (oracle/elements_np.py, pinned by goldens G1 / G7), also for empty and
+    ragged beams: states bit for bit, geometry 1e-13, amplitudes 1e-12."""
+    from oracle import elements_np as en
+    from oracle.adapters import to_oracle_beam
+    bl, beam, fsm, masks = _front_end(n, True)
+    mask = masks[kind]
+    ob = to_oracle_beam(beam)
+    oimg = en.screen_expose(ob, (fsm.x, fsm.y, fsm.z), fsm.center, fsm.lostNum)
+    blades = dict(zip(mask.kind, mask.opening)) if kind != 2 else {}
+    oloc = en.aperture_propagate(ob, (mask.x, mask.y, mask.z), mask.center, blades, mask.lostNum,
+                                 radius=mask.r if kind == 2 else None,
+                                 shadeFraction=0.3 if kind == 3 else None)
+    b = rs.Beam(copyFrom=beam)
+    img = fsm.expose(b)
+    loc = mask.propagate(b)
+    assert img.__dict__['_op'].state == 'done' or n == 0
+    assert np.array_equal(b.state, ob.state) and len(b.state) == n
+    for got, ref, what in ((img, oimg, 'image'), (loc, oloc, 'beam at the mask')):
+        assert np.array_equal(got.state, ref.state), what
+        for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path', 'E', 'Jss', 'Jpp'):
+            r = getattr(ref, f)
+            assert np.abs(getattr(got, f) - r).max(initial=0.) <= \
+                1e-13 * max(np.abs(r).max(initial=0.), 1e-300), (what, f)
+        for f in ('Es', 'Ep'):
+            r = getattr(ref, f)
+            assert np.abs(getattr(got, f) - r).max(initial=0.) <= 1e-12, (what, f)
