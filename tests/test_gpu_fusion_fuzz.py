@@ -293,3 +293,93 @@ def test_random_run_ray_tracing_jobs(seed):
     finally:
         roe.fuseConsumers = old
         rr.run_process = keep
+
+
+# ---- drawn elements of every kernel family with drawn consumers behind them ---------------------
+def _consumers(oe, g0, rng):
+    """Up to two apertures and perhaps a screen along the beam that leaves *oe* (*g0*: its
+    global beam from the immediate launch), sized by the beam as a wide-open slit sees it."""
+    ok = g0.state == 1
+    pos = np.array([g0.x[ok].mean(), g0.y[ok].mean(), g0.z[ok].mean()])
+    way = np.array([g0.a[ok].mean(), g0.b[ok].mean(), g0.c[ok].mean()])
+    way /= np.sqrt((way**2).sum())
+    bl = oe.bl
+    aps = []
+    for k in range(int(rng.integers(0, 3))):
+        at = list(pos + 150. * (k + 1) * way)
+        seen = ra.RectangularAperture(bl, 'open', at, ('left',), [-1e9]).propagate(
+            rs.Beam(copyFrom=g0))
+        live = seen.state == 1
+        x, z = seen.x[live], seen.z[live]
+        what = str(rng.choice(['rect', 'round', 'stop']))
+        if what == 'rect':
+            aps.append(ra.RectangularAperture(bl, 'slit%d' % k, at, ('left', 'top'),
+                                              [float(np.quantile(x, 0.25)),
+                                               float(np.quantile(z, 0.8))]))
+        elif what == 'round':
+            aps.append(ra.RoundAperture(bl, 'pipe%d' % k, at,
+                                        r=float(np.median(np.hypot(x, z)))))
+        else:
+            aps.append(ra.RectangularBeamStop(
+                bl, 'stop%d' % k, at, ('left', 'right', 'bottom', 'top'),
+                [float(np.quantile(x, 0.4)), float(np.quantile(x, 0.6)),
+                 float(np.quantile(z, 0.3)), float(np.quantile(z, 0.7))]))
+    scr = rsc.Screen(bl, 'after', list(pos + 700. * way)) if rng.random() < 0.7 else None
+    return aps, scr
+
+
+def _element_script(oe, aps, scr, beam, need_local):
+    out = {}
+    g, l = oe.reflect(rs.Beam(copyFrom=beam), needLocal=need_local)
+    out['g'] = g
+    if need_local:
+        out['l'] = l
+    for k, a in enumerate(aps):
+        out['ap%d' % k] = a.propagate(g)
+    if scr is not None:
+        out['img'] = scr.expose(g)
+    return out
+
+
+@pytest.mark.parametrize('seed', range(5))
+@pytest.mark.parametrize('kind', ['flat', 'toroid', 'bentflat', 'ellipse', 'ellipse_cyl',
+                                  'parabola', 'hyperbola', 'blazed', 'grating'])
+def test_random_elements_with_random_consumers(kind, seed):
+    """OE.reflect of drawn elements (every surface family of tests/test_gpu_fuzz.py: lean,
+    generic, parametric, gratings; coatings, thin mirrors, no material) followed by drawn slits,
+    pipes, beam stops and a screen -- whether the kernel carries them in its tail or they take
+    their own launches inside the call, every beam has the bits of the immediate launches, over
+    three iterations in which the elements remember what was looked at."""
+    from test_gpu_fuzz import KINDS, aimed_beam, make_element
+    rng = np.random.default_rng(77000 + 100 * KINDS.index(kind) + seed)
+    oe, pitch = make_element(kind, rng)
+    beam = aimed_beam(oe, pitch, rng, n=int(rng.choice([400, 6000])))
+    need_local = bool(rng.random() < 0.75)
+    old = roe.fuseConsumers
+    roe.fuseConsumers = False
+    try:
+        try:
+            g0 = oe.reflect(rs.Beam(copyFrom=beam))[0]
+        except Exception as e:                 # (a blazed grating: "above both facets")
+            pytest.skip(str(e)[:80])
+        if (g0.state == 1).sum() < 100:
+            pytest.skip('the fan mostly misses')
+        aps, scr = _consumers(oe, g0, rng)
+        ref = snapshot(_element_script(oe, aps, scr, beam, need_local))
+    finally:
+        roe.fuseConsumers = old
+    what = (kind, seed, need_local, [type(a).__name__ for a in aps], scr is not None)
+    for iteration in range(3):
+        got = _element_script(oe, aps, scr, beam, need_local)
+        names = list(got)
+        rng.shuffle(names)
+        share = (0.3, 0.0, 1.0)[iteration]
+        for k in names:
+            if rng.random() < share:
+                equal(got[k], ref[k], what + (iteration, k))
+        if rng.random() < 0.5:
+            rs.flush_pending()
+        if iteration == 2:
+            for k in names:
+                equal(got[k], ref[k], what + (iteration, k, 'again'))
+        del got
