@@ -170,8 +170,10 @@ class _DeferredExpose(rs.FillsBeams):
 
 
 def pending_expose_of(beam, dev):
-    """The screen that waits with its launch for *beam* as it is now (all of its arrays), if
-    there is exactly one and nothing else waits to read the beam -> its record, else None."""
+    """-> the record of the ONE screen that waits with its launch for *beam* as it is now (the
+    very arrays the beam has at this moment, on this device), else None (no such screen, or
+    two of them: each then takes its own launch). Other records that read the beam are the
+    caller's to flush (sources.flush_pending(beam, keep=...))."""
     found = None
     for op in list(rs._PENDING) + rs._PENDING.optional():
         if not op.reads(beam):
