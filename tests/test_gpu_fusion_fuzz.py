@@ -383,3 +383,115 @@ def test_random_elements_with_random_consumers(kind, seed):
             for k in names:
                 equal(got[k], ref[k], what + (iteration, k, 'again'))
         del got
+
+
+# ---- drawn monochromators and single crystals with drawn consumers ------------------------------
+def _crystal_fan(bl, rng, E0, n):
+    """A fan converging on [0, 20000, 0] (turned by the beamline's azimuth), some rays dead or
+    over the edge on arrival."""
+    import xrt_amd.backends.raycing as raycing
+    beam = rs.Beam(nrays=n, withAmplitudes=bool(rng.random() < 0.5))
+    beam.x[:] = rng.normal(0, 2.5, n)
+    beam.z[:] = rng.normal(0, 0.6, n)
+    beam.a[:] = rng.normal(0, 1e-4, n)
+    beam.c[:] = rng.normal(0, 2e-5, n)
+    beam.b[:] = np.sqrt(1 - beam.a**2 - beam.c**2)
+    beam.y[:] = 9900.
+    beam.z[:] += -beam.c / beam.b * 100.
+    if bl.azimuth:
+        for u, v in (('x', 'y'), ('a', 'b')):
+            p, q = getattr(beam, u).copy(), getattr(beam, v).copy()
+            pu, qv = raycing.rotate_z(p, q, bl.cosAzimuth, -bl.sinAzimuth)
+            getattr(beam, u)[:] = pu
+            getattr(beam, v)[:] = qv
+    beam.E[:] = rng.uniform(E0 - 3., E0 + 3., n)
+    ang = rng.uniform(0, np.pi, n)
+    es, ep = np.cos(ang), np.sin(ang) * np.exp(1j * rng.uniform(-np.pi, np.pi, n))
+    beam.Jss[:], beam.Jpp[:], beam.Jsp[:] = es * es, (ep * np.conj(ep)).real, es * np.conj(ep)
+    if hasattr(beam, 'Es'):
+        beam.Es[:], beam.Ep[:] = es, ep
+    st = np.ones(n, dtype=np.int32)
+    st[rng.random(n) < 0.03] = 2
+    st[rng.random(n) < 0.02] = -1
+    beam.state[:] = st
+    return beam
+
+
+def _random_crystal_optic(rng, pair):
+    import xrt_amd.backends.raycing as raycing
+    import xrt_amd.backends.raycing.materials as rm
+    bl = raycing.BeamLine(azimuth=float(rng.choice([0., 0.15])))
+    hkl = [(1, 1, 1), (3, 1, 1), (3, 3, 3)][int(rng.integers(0, 3))]
+    E0 = float(rng.uniform(9500. if hkl == (3, 3, 3) else 7000., 16000.))
+    thin = dict(t=float(rng.uniform(0.02, 0.2))) if (not pair and rng.random() < 0.4) else {}
+    si1 = rm.CrystalSi(hkl=hkl, tK=297.15, **thin)
+    alpha = float(rng.choice([0., 0., np.radians(2.), np.radians(-3.)]))
+    thB = float(np.ravel(si1.get_Bragg_angle(E0))[0])
+    thB -= float(np.ravel(si1.get_dtheta(E0, alpha) if alpha else si1.get_dtheta(E0))[0]) \
+        if (alpha or not pair) else 0.
+    center = [20000. * bl.sinAzimuth, 20000. * bl.cosAzimuth, 0.]
+    if pair:
+        perp = float(rng.uniform(5., 25.))
+        optic = roe.DCM(
+            bl, 'dcm', center=center, bragg=thB, pitch=alpha, material=si1,
+            material2=rm.CrystalSi(hkl=hkl, tK=297.15), alpha=alpha if alpha else None,
+            cryst2perpTransl=perp,
+            cryst2longTransl=float(perp / np.tan(thB) * rng.uniform(0.8, 1.2)),
+            cryst2finePitch=float(rng.normal(0, 2e-6)), limPhysX=[-10, 10], limPhysY=[-40, 40],
+            limPhysX2=[-10, 10], limPhysY2=[-80, 80])
+    else:
+        optic = roe.OE(bl, 'xtal', center=center, pitch=thB + alpha, material=si1,
+                       alpha=alpha if alpha else None, limPhysX=[-10, 10], limPhysY=[-40, 40])
+    return optic, _crystal_fan(bl, rng, E0, int(rng.choice([500, 4000])))
+
+
+def _crystal_script(optic, pair, aps, scr, beam):
+    out = {}
+    made = optic.double_reflect(rs.Beam(copyFrom=beam)) if pair else \
+        optic.reflect(rs.Beam(copyFrom=beam))
+    g = out['g'] = made[0]
+    for k, lo in enumerate(made[1:]):
+        out['l%d' % k] = lo
+    for k, a in enumerate(aps):
+        out['ap%d' % k] = a.propagate(g)
+    if scr is not None:
+        out['img'] = scr.expose(g)
+    return out
+
+
+@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('pair', [True, False])
+def test_random_crystals_with_random_consumers(pair, seed):
+    """DCM.double_reflect (reference oes/dcm.py:248-354) and OE.reflect of a single flat Bragg
+    crystal, thick or thin, with drawn reflections, energies and asymmetric cuts, followed by
+    drawn slits, pipes, beam stops and a screen: in the tail of the crystal kernels or as their
+    own launches, every beam has the bits of the immediate launches over three iterations."""
+    rng = np.random.default_rng(91000 + 1000 * int(pair) + seed)
+    optic, beam = _random_crystal_optic(rng, pair)
+    old = roe.fuseConsumers
+    roe.fuseConsumers = False
+    try:
+        made = optic.double_reflect(rs.Beam(copyFrom=beam)) if pair else \
+            optic.reflect(rs.Beam(copyFrom=beam))
+        g0 = made[0]
+        if (g0.state == 1).sum() < 100:
+            pytest.skip('the fan mostly misses the rocking curve')
+        aps, scr = _consumers(optic, g0, rng)
+        ref = snapshot(_crystal_script(optic, pair, aps, scr, beam))
+    finally:
+        roe.fuseConsumers = old
+    what = (pair, seed, [type(a).__name__ for a in aps], scr is not None)
+    for iteration in range(3):
+        got = _crystal_script(optic, pair, aps, scr, beam)
+        names = list(got)
+        rng.shuffle(names)
+        share = (0.3, 0.0, 1.0)[iteration]
+        for k in names:
+            if rng.random() < share:
+                equal(got[k], ref[k], what + (iteration, k))
+        if rng.random() < 0.5:
+            rs.flush_pending()
+        if iteration == 2:
+            for k in names:
+                equal(got[k], ref[k], what + (iteration, k, 'again'))
+        del got
