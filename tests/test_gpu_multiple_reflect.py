@@ -213,3 +213,92 @@ def test_sparse_and_dense_bounces_are_the_same_bits():
     for form in ('dense', 'sparse', ''):
         for key, want in got['exact'].items():
             assert np.array_equal(got[form][key], want, equal_nan=True), (form or 'hinted', key)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_toroids_against_the_oracle(seed):
+    """Drawn whispering-gallery mirrors (radii, pitch, roll, length, optical limits, coating),
+    drawn fans, with and without the elevation map, the loop cut short or not: the whole
+    OE.multiple_reflect -- default forms of the bounce: optimistic, sparse where few rays are
+    left, exact where an assumption fails -- against the oracle (oracle/reflect_np.py:
+    oe_multiple_reflect, pinned by the reference's goldens): states and nRefl bit for bit."""
+    from oracle import reflect_np as rn
+    from oracle.adapters import oracle_params, to_oracle_beam
+    rng = np.random.default_rng(4400 + seed)
+    bl = raycing.BeamLine(azimuth=float(rng.choice([0., 0.25])), height=0)
+    for _ in range(int(rng.integers(0, 3))):
+        roe.OE(bl, 'before')
+    mat = [rm.Material('Au', rho=19.3, kind='mirror'), rm.Material('Pt', rho=21.45, kind='mirror'),
+           rm.Material('Rh', rho=12.41, kind='mirror')][int(rng.integers(3))]
+    length = float(rng.uniform(120., 260.))
+    x, y, z = 0., 1000., -float(rng.uniform(0.03, 0.07))
+    kw = dict(center=[bl.cosAzimuth * x + bl.sinAzimuth * y,
+                      -bl.sinAzimuth * x + bl.cosAzimuth * y, z],
+              pitch=float(rng.uniform(2.2e-3, 4e-3)), limPhysX=[-5, 5], limPhysY=[0, length],
+              R=float(rng.uniform(3000., 9000.)), r=float(rng.uniform(30., 90.)))
+    if rng.random() < 0.4:
+        kw.update(roll=float(rng.normal(0, 0.01)), yaw=float(rng.normal(0, 5e-4)))
+    if rng.random() < 0.4:
+        kw.update(limOptX=[-3, 3], limOptY=[5., 0.8 * length])
+    oe = roe.ToroidMirror(bl, 'gallery', material=mat, **kw)
+    n = int(rng.choice([700, 5000]))
+    src = case.point_source_rays(rs, n, 900 + seed, dxprime=float(rng.uniform(2e-4, 1e-3)),
+                                 dzprime=float(rng.uniform(5e-6, 3e-5)),
+                                 E=float(rng.uniform(2000., 12000.)), spread_E=5.,
+                                 amplitudes=bool(rng.random() < 0.5))
+    if bl.azimuth:
+        for u, v in (('x', 'y'), ('a', 'b')):
+            p, q = getattr(src, u).copy(), getattr(src, v).copy()
+            pu, qv = raycing.rotate_z(p, q, bl.cosAzimuth, -bl.sinAzimuth)
+            getattr(src, u)[:] = pu
+            getattr(src, v)[:] = qv
+    src.state[rng.random(n) < 0.02] = 2
+    src.state[rng.random(n) < 0.02] = -1
+    most = int(rng.choice([2, 4, 100]))
+    elevation = bool(rng.random() < 0.5)
+    ob = to_oracle_beam(src)
+    mgb, mlbN = rn.oe_multiple_reflect(oracle_params(oe), ob.copy(), most, elevation)
+    import types
+
+    def part(beam, idx):
+        """The rays *idx* of a beam, as compare() looks at one."""
+        view = types.SimpleNamespace()
+        for f in GEOM + ('E', 'state', 'nRefl') + FIELD + EXTRA:
+            if hasattr(beam, f):
+                setattr(view, f, np.asarray(getattr(beam, f))[idx])
+        return view
+    for run in range(2):          # (the second call: the element remembers the methods)
+        gb, lbN = oe.multiple_reflect(rs.Beam(copyFrom=src), maxReflections=most,
+                                      needElevationMap=elevation)
+        assert lbN.nrays == len(mlbN.x), (seed, run)
+        k = lbN.nrays // n
+        # A ray that lands OUTSIDE the optical limits (state 2) is not given a new direction
+        # (reflect.py:715: only state 1 is) and stays in the loop (:239): its next search starts
+        # ON the surface with the ray going through it, and whether that counts as one more
+        # hit at t = 0 hangs on the sign of a |dz| <= zEps = 1e-12 mm residual -- in the
+        # reference as here. Such rays are compared up to their first state-2 footprint and
+        # in where they end (nothing happens to them in between: no amplitude, no turn); all
+        # others bit for bit in states and nRefl throughout.
+        out2 = (np.asarray(lbN.state).reshape(k, n) == 2) | (mlbN.state.reshape(k, n) == 2)
+        through = out2.any(axis=0)
+        plain = np.nonzero(~through)[0]
+        every = np.concatenate([plain + b * n for b in range(k)])
+        compare(part(gb, plain), lambda f: None if getattr(mgb, f, None) is None
+                else getattr(mgb, f)[plain], 'gb %d/%d' % (seed, run), along_tol=2e-9)
+        compare(part(lbN, every), lambda f: None if getattr(mlbN, f, None) is None
+                else getattr(mlbN, f)[every], 'lbN %d/%d' % (seed, run), along_tol=2e-9)
+        odd = np.nonzero(through)[0]
+        if len(odd):
+            assert np.array_equal(gb.state[odd], mgb.state[odd]), (seed, run)
+            for f in ('x', 'y', 'z', 'a', 'b', 'c'):
+                assert np.abs(getattr(gb, f)[odd] - getattr(mgb, f)[odd]).max() <= 2e-9, (seed, f)
+            first = out2.argmax(axis=0)[odd]              # up to the first state-2 footprint
+            for b in range(k):
+                upto = odd[first >= b] + b * n
+                assert np.array_equal(np.asarray(lbN.state)[upto], mlbN.state[upto]), (seed, b)
+                assert np.array_equal(np.asarray(lbN.nRefl)[upto], mlbN.nRefl[upto]), (seed, b)
+                for f in ('x', 'y', 'z', 'a', 'b', 'c', 'path'):
+                    if len(upto):
+                        assert np.abs(np.asarray(getattr(lbN, f))[upto] -
+                                      getattr(mlbN, f)[upto]).max() <= 2e-9, (seed, b, f)
+    assert np.bincount(gb.nRefl).argmax() >= 1 and (gb.state == 1).sum() > n // 10
