@@ -301,4 +301,21 @@ def test_random_toroids_against_the_oracle(seed):
                     if len(upto):
                         assert np.abs(np.asarray(getattr(lbN, f))[upto] -
                                       getattr(mlbN, f)[upto]).max() <= 2e-9, (seed, b, f)
+    # ... and EVERY ray, bounce by bounce: the oracle's single bounce (reflect_local with
+    # isMulti) started from the footprints bounce b - 1 left HERE gives the states of bounce b
+    # made here, also for the rays outside the optical limits (tools/diag_multi_seed.py)
+    p = oracle_params(oe)
+    for b in range(1, k):
+        ob1 = rn.Beam(n, with_amplitudes=hasattr(lbN, 'Es'))
+        for f in ob1.fields():
+            setattr(ob1, f, np.array(getattr(lbN, f))[(b - 1) * n:b * n])
+        ob1.nRefl = np.array(lbN.nRefl)[(b - 1) * n:b * n]
+        if elevation:
+            for f in ('elevationD', 'elevationX', 'elevationY', 'elevationZ'):
+                setattr(ob1, f, np.array(getattr(lbN, f))[(b - 1) * n:b * n])
+        good = (ob1.state == 1) | (ob1.state == 2)
+        rn.reflect_local(p, good, ob1, ob1, p['pitch'], p['roll'] + p['positionRoll'], p['yaw'],
+                         p.get('dx', 0), material=p.get('material'), needElevationMap=elevation,
+                         isMulti=True)
+        assert np.array_equal(ob1.state, np.asarray(lbN.state)[b * n:(b + 1) * n]), (seed, b)
     assert np.bincount(gb.nRefl).argmax() >= 1 and (gb.state == 1).sum() > n // 10

@@ -50,14 +50,15 @@ most = int(rng.choice([2, 4, 100]))
 elevation = bool(rng.random() < 0.5)
 print('n', n, 'most', most, 'elevation', elevation)
 ob = to_oracle_beam(src)
-mgb, mlbN = rn.oe_multiple_reflect(oracle_params(oe), ob.copy(), most, elevation)
+oinfo = []
+mgb, mlbN = rn.oe_multiple_reflect(oracle_params(oe), ob.copy(), most, elevation, info=oinfo)
 info = []
 gb, lbN = oe.multiple_reflect(rs.Beam(copyFrom=src), maxReflections=most,
                               needElevationMap=elevation, _info=info)
 print('bounces', lbN.nrays // n, len(mlbN.x) // n)
 bad = np.nonzero(gb.nRefl != mgb.nRefl)[0]
 print('rays whose nRefl differs:', len(bad), bad[:10])
-for i in bad[:5]:
+for i in bad[:2]:
     print(i, 'nRefl', gb.nRefl[i], mgb.nRefl[i], 'state', gb.state[i], mgb.state[i],
           'dx', gb.x[i] - mgb.x[i], 'dy', gb.y[i] - mgb.y[i], 'dz', gb.z[i] - mgb.z[i])
     k = lbN.nrays // n
@@ -67,5 +68,30 @@ for i in bad[:5]:
 gb2, lbN2 = oe.multiple_reflect(rs.Beam(copyFrom=src), maxReflections=most, needElevationMap=elevation)
 print('second call differs from the oracle in', int((gb2.nRefl != mgb.nRefl).sum()), 'rays; from the first in',
       int((gb2.nRefl != gb.nRefl).sum()))
+print('oracle:')
+for one in oinfo:
+    print({k: one[k] for k in one if k in ('brent', 'left', 'entering', 'tangency')})
+print('here:')
 for one in info:
     print({k: one[k] for k in one if k in ('brent', 'left', 'entering')}, one.get('tangency'))
+
+# Is the bounce the oracle's, given THIS run's footprints of the bounce before? (the oracle's
+# single bounce -- reflect_local(isMulti=True) -- started from the footprints b - 1 made here)
+p = oracle_params(oe)
+k = lbN.nrays // n
+for b in range(1, k):
+    ob1 = rn.Beam(n, with_amplitudes=hasattr(lbN, 'Es'))
+    for f in ob1.fields():
+        setattr(ob1, f, np.array(getattr(lbN, f))[(b - 1) * n:b * n])
+    ob1.nRefl = np.array(lbN.nRefl)[(b - 1) * n:b * n]
+    if elevation:
+        for f in ('elevationD', 'elevationX', 'elevationY', 'elevationZ'):
+            setattr(ob1, f, np.array(getattr(lbN, f))[(b - 1) * n:b * n])
+    good = (ob1.state == 1) | (ob1.state == 2)
+    rn.reflect_local(p, good, ob1, ob1, p['pitch'], p['roll'] + p['positionRoll'], p['yaw'],
+                     p.get('dx', 0), material=p.get('material'), needElevationMap=elevation,
+                     isMulti=True)
+    mine = np.array(lbN.state)[b * n:(b + 1) * n]
+    diff = np.nonzero(ob1.state != mine)[0]
+    print('bounce %d from the footprints of bounce %d made here: the oracle\'s states differ in %d rays %s'
+          % (b, b - 1, len(diff), [(int(i), int(ob1.state[i]), int(mine[i])) for i in diff[:4]]))
