@@ -73,6 +73,9 @@ def test_hot_kernels_keep_their_budget():
         if 'geosource_shine' in name or 'plot_hist' in name and 'plot_hist_kernel' not in name \
                 and 'plot_hist_small' not in name:
             assert r['scratch'] == 0 and r['vgpr_spill'] == 0, name
+        # the streaming kernels of screens and apertures, incl. the one-pass screen + mask
+        if 'screen_expose' in name or 'aperture_propagate' in name:
+            assert r['scratch'] == 0 and r['vgpr_spill'] == 0 and r.get('sgpr_spill', 0) <= 16, name
         if 'plot_hist_small' in name or 'reflect_fused_scr' in name or \
                 'reflect_fused_gen_scr' in name:
             # (one plate variant with the plot and the apertures in its tail reserves 68 B -- an
