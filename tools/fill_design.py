@@ -43,7 +43,7 @@ v['KG_FRAC']='%.3f'%b['kirchhoff_general']['roofline']['frac']; v['KGR_FRAC']='%
 v['UND_MS']='%.4f'%b['undulator']['ms']; v['UND_FRAC']='%.3f'%b['undulator']['roofline']['frac']
 v['HIST_MS']='%.3f'%b['hist']['ms_per_plot']; v['HIST_FRAC']='%.3f'%b['hist']['roofline']['frac']
 v['MULTI_MS']='%.2f'%b['multiple_reflect']['ms_per_bounce']
-sh=one('geosource_shine_kernel',10000128); sc=one('screen_expose_kernel',10000128); ap=one('xrt::screen_expose_mark_kernel',10000128)
+sh=one('geosource_shine_kernel',10000128); sc=one('screen_expose_kernel',10000128); ap=([r for r in rows if 'screen_expose_mark_kernel' in r[0] and int(r[1])==10000128] or [None])[0]
 v['SHINE_US']='%.0f'%(float(sh[4])/1e3); v['SCR_US']='%.0f'%(float(sc[4])/1e3); v['AP_US']='%.0f'%(float(ap[4])/1e3)
 v['SHINE_F']='%.2f'%(1e9/(float(sh[4])*1e-9)/8e12); v['SCR_F']='%.2f'%(2e9/(float(sc[4])*1e-9)/8e12); v['AP_F']='%.2f'%(2.04e9/(float(ap[4])*1e-9)/8e12)
 v['CFG2_STEP']='%.3f'%b['ms_per_step']; v['CFG2_VALUE']='%.2e'%b['value']

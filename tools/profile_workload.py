@@ -32,9 +32,21 @@ if '--tight' in sys.argv:      # every ray hits (no divergent lost / over lanes 
     beam.c = beam.c * 0.2
 for f in beam.array_fields():
     beam.dev(f)
-scr = rsc.Screen(raycing.BeamLine(), 'scr', [0, 30000., 0])
+bl0 = raycing.BeamLine()
+scr = rsc.Screen(bl0, 'scr', [0, 30000., 0])
 for _ in range(reps):
-    scr.expose(beam)
+    scr.expose(beam).nrays          # (looked at: the screen's own launch)
+if '--nolocal' not in sys.argv:
+    # a screen and the mask behind it on a resident beam: one pass over the rays
+    # (screen_expose_mark_kernel: 100 B read, 100 B + the marks written per ray)
+    import xrt_amd.backends.raycing.apertures as ra  # noqa: E402
+    import xrt_amd.backends.raycing.sources as rs  # noqa: E402
+    mask = ra.RectangularAperture(bl0, 'mask', [0, 30500., 0], ('left', 'right', 'bottom', 'top'),
+                                  [-4., 5., -0.5, 0.6])
+    for _ in range(reps):
+        rays = rs.Beam(copyFrom=beam)
+        scr.expose(rays)
+        mask.propagate(rays)
 NOLOCAL = '--nolocal' in sys.argv
 dcm = workloads.cfg3_dcm()
 b3 = workloads.synthetic_rays(n, 43, sa=1e-4, E=(8995., 9005.))

@@ -29,7 +29,7 @@ OURS = ('reflect_fused_dcm_scr', 'reflect_fused_dcm_marks', 'reflect_dcm_redo_sc
         'reflect_redo_verdict', 'geosource_shine_if_kernel', 'screen_expose_if_kernel',
         'reflect_multi', 'multi_to_global_kernel', 'plot_hist_small', 'reflect_fused_xtal', 'reflect_fused_dcm', 'reflect_dcm_exact', 'reflect_decide_dcm',
         'reflect_decide_opt', 'reflect_exact', 'reflect_fused', 'reflect_init',
-        'screen_expose_kernel', 'kirchhoff_stream', 'kirchhoff_scan', 'kirchhoff_pack',
+        'screen_expose_mark_kernel', 'screen_expose_kernel', 'kirchhoff_stream', 'kirchhoff_scan', 'kirchhoff_pack',
         'kirchhoff_finalize', 'und_imap', 'und_sum', 'und_pack', 'aperture_propagate_kernel',
         'plot_hist_rays', 'plot_hist_tiles', 'plot_hist_reduce', 'geosource_shine_kernel',
         'plot_hist_kernel', 'surface_eval_kernel',
